@@ -1,0 +1,290 @@
+"""ctypes mirror of include/aardvark_amd.h plus the flat batch containers.
+
+Plumbing only: the structures here are bit-for-bit the C-ABI structs; `RegionBatch` packs
+Python-side regions into the structure-of-arrays layout the library takes and `ResultBatch`
+owns the caller-allocated output arrays.
+"""
+import ctypes as C
+
+import numpy as np
+
+# ---- enums (ordinals of the reference's Rust enums; include/aardvark_amd.h) -------------
+VARIANT_TYPES = [
+    "Snv", "Insertion", "Deletion", "Indel", "SvInsertion", "SvDeletion", "SvDuplication",
+    "SvInversion", "SvBreakend", "TrContraction", "TrExpansion", "Unknown",
+]
+VT = {n: i for i, n in enumerate(VARIANT_TYPES)}
+ZYGOSITIES = [
+    "Unknown", "HomozygousReference", "UnphasedHeterozygous", "PhasedHet01", "PhasedHet10",
+    "HomozygousAlternate",
+]
+ZYG = {n: i for i, n in enumerate(ZYGOSITIES)}
+CLASSES = ["UNK", "TP", "FN", "FP"]
+CLS = {n: i for i, n in enumerate(CLASSES)}
+ALLELE = {"UNK": 0, "REF": 1, "ALT": 2}
+
+N_GROUPS = 13
+N_FIELDS = 22
+TALLY_LEN = N_GROUPS * N_FIELDS + 2
+FIELDS = [
+    "GT_TRUTH_TP", "GT_TRUTH_FN", "GT_QUERY_TP", "GT_QUERY_FP", "GT_TRUTH_FN_GT", "GT_QUERY_FP_GT",
+    "HAP_TRUTH_TP", "HAP_TRUTH_FN", "HAP_QUERY_TP", "HAP_QUERY_FP",
+    "WHAP_TRUTH_TP", "WHAP_TRUTH_FN", "WHAP_QUERY_TP", "WHAP_QUERY_FP",
+    "BP_TRUTH_TP", "BP_TRUTH_FN", "BP_QUERY_TP", "BP_QUERY_FP",
+    "RBP_TRUTH_TP", "RBP_TRUTH_FN", "RBP_QUERY_TP", "RBP_QUERY_FP",
+]
+F = {n: i for i, n in enumerate(FIELDS)}
+
+ST_OK = 0
+ST_NAMES = {
+    0: "OK", 2: "BRANCH_FACTOR", 3: "NO_RESULTS", 4: "NO_GT_RESULT", 5: "UNKNOWN_ALLELE",
+    6: "BAD_ZYGOSITY", 7: "VARIANT_METRICS", 8: "TRUTH_FP", 9: "RECORD_BP", 10: "SEQ_MISMATCH",
+    11: "AUTOFAIL_OOB", 20: "INVALID_INPUT", 21: "CAPACITY",
+}
+
+_p = C.POINTER
+
+
+class AvkRegionBatch(C.Structure):
+    _fields_ = [
+        ("n_regions", C.c_uint64),
+        ("region_id", _p(C.c_uint64)),
+        ("contig_idx", _p(C.c_uint32)),
+        ("start", _p(C.c_uint64)),
+        ("end", _p(C.c_uint64)),
+        ("t_off", _p(C.c_uint64)),
+        ("t_cnt", _p(C.c_uint32)),
+        ("q_off", _p(C.c_uint64)),
+        ("q_cnt", _p(C.c_uint32)),
+        ("n_variants", C.c_uint64),
+        ("var_pos", _p(C.c_uint64)),
+        ("var_type", _p(C.c_uint8)),
+        ("var_zyg", _p(C.c_uint8)),
+        ("var_raw_space", _p(C.c_uint32)),
+        ("a0_off", _p(C.c_uint64)),
+        ("a0_len", _p(C.c_uint32)),
+        ("a1_off", _p(C.c_uint64)),
+        ("a1_len", _p(C.c_uint32)),
+        ("allele_bytes", _p(C.c_uint8)),
+        ("allele_bytes_len", C.c_uint64),
+    ]
+
+
+class AvkCompareConfig(C.Structure):
+    _fields_ = [
+        ("max_branch_factor", C.c_uint32),
+        ("enable_sequences", C.c_uint32),
+        ("enable_exact_shortcut", C.c_uint32),
+    ]
+
+
+class AvkResultBatch(C.Structure):
+    _fields_ = [
+        ("status", _p(C.c_int32)),
+        ("ed_h1", _p(C.c_uint32)),
+        ("ed_h2", _p(C.c_uint32)),
+        ("n_optima", _p(C.c_uint32)),
+        ("type_present", _p(C.c_uint16)),
+        ("group_metrics", _p(C.c_uint32)),
+        ("var_expected", _p(C.c_uint8)),
+        ("var_observed", _p(C.c_uint8)),
+        ("var_class", _p(C.c_uint8)),
+        ("var_zyg", _p(C.c_uint8)),
+        ("seq_bytes", _p(C.c_uint8)),
+        ("seq_off", _p(C.c_uint64)),
+        ("seq_stride", _p(C.c_uint32)),
+        ("seq_len", _p(C.c_uint32)),
+        ("tally", _p(C.c_uint64)),
+    ]
+
+
+def _ptr(arr, ctype):
+    return arr.ctypes.data_as(_p(ctype))
+
+
+def seq_stride(start, end, a0_len, a1_len):
+    """Upper bound of any haplotype length of a region (mirrors avk_seq_stride())."""
+    grow = int(np.maximum(a1_len.astype(np.int64) - a0_len.astype(np.int64), 0).sum()) if len(a0_len) else 0
+    return int(end - start) + grow
+
+
+class RegionBatch:
+    """Flat structure-of-arrays batch of CompareRegions (reference
+    src/data_types/compare_region.rs:13-26).  Build with `from_regions` (a list of dicts) or
+    directly from numpy arrays via the constructor."""
+
+    def __init__(self, region_id, contig_idx, start, end, t_off, t_cnt, q_off, q_cnt,
+                 var_pos, var_type, var_zyg, var_raw_space, a0_off, a0_len, a1_off, a1_len, allele_bytes):
+        g = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        self.region_id = g(region_id, np.uint64)
+        self.contig_idx = g(contig_idx, np.uint32)
+        self.start = g(start, np.uint64)
+        self.end = g(end, np.uint64)
+        self.t_off = g(t_off, np.uint64)
+        self.t_cnt = g(t_cnt, np.uint32)
+        self.q_off = g(q_off, np.uint64)
+        self.q_cnt = g(q_cnt, np.uint32)
+        self.var_pos = g(var_pos, np.uint64)
+        self.var_type = g(var_type, np.uint8)
+        self.var_zyg = g(var_zyg, np.uint8)
+        self.var_raw_space = g(var_raw_space, np.uint32)
+        self.a0_off = g(a0_off, np.uint64)
+        self.a0_len = g(a0_len, np.uint32)
+        self.a1_off = g(a1_off, np.uint64)
+        self.a1_len = g(a1_len, np.uint32)
+        self.allele_bytes = g(allele_bytes, np.uint8)
+        if self.allele_bytes.size == 0:
+            self.allele_bytes = np.zeros(1, np.uint8)
+        self.n_regions = int(self.start.size)
+        self.n_variants = int(self.var_pos.size)
+
+    @classmethod
+    def from_regions(cls, regions):
+        """regions: list of dicts {start, end, truth, query[, contig, region_id]}; a variant is
+        (pos, allele0, allele1, type, zygosity[, raw_allele_space]) with type/zygosity by name
+        or ordinal and alleles as str/bytes."""
+        rid, cidx, st, en, t_off, t_cnt, q_off, q_cnt = [], [], [], [], [], [], [], []
+        vpos, vtype, vzyg, vraw, a0o, a0l, a1o, a1l = [], [], [], [], [], [], [], []
+        blob = bytearray()
+
+        def add(v):
+            pos, a0, a1, ty = v[0], v[1], v[2], v[3]
+            zy = v[4] if len(v) > 4 else "Unknown"
+            a0 = a0.encode() if isinstance(a0, str) else bytes(a0)
+            a1 = a1.encode() if isinstance(a1, str) else bytes(a1)
+            vpos.append(pos)
+            vtype.append(VT[ty] if isinstance(ty, str) else int(ty))
+            vzyg.append(ZYG[zy] if isinstance(zy, str) else int(zy))
+            vraw.append(v[5] if len(v) > 5 else max(len(a0), len(a1)))
+            a0o.append(len(blob)); a0l.append(len(a0)); blob.extend(a0)
+            a1o.append(len(blob)); a1l.append(len(a1)); blob.extend(a1)
+
+        for i, r in enumerate(regions):
+            rid.append(r.get("region_id", i))
+            cidx.append(r.get("contig", 0))
+            st.append(r["start"]); en.append(r["end"])
+            t_off.append(len(vpos)); t_cnt.append(len(r["truth"]))
+            for v in r["truth"]:
+                add(v)
+            q_off.append(len(vpos)); q_cnt.append(len(r["query"]))
+            for v in r["query"]:
+                add(v)
+        return cls(rid, cidx, st, en, t_off, t_cnt, q_off, q_cnt, vpos, vtype, vzyg, vraw,
+                   a0o, a0l, a1o, a1l, np.frombuffer(bytes(blob), dtype=np.uint8))
+
+    def c_struct(self):
+        b = AvkRegionBatch()
+        b.n_regions = self.n_regions
+        b.region_id = _ptr(self.region_id, C.c_uint64)
+        b.contig_idx = _ptr(self.contig_idx, C.c_uint32)
+        b.start = _ptr(self.start, C.c_uint64)
+        b.end = _ptr(self.end, C.c_uint64)
+        b.t_off = _ptr(self.t_off, C.c_uint64)
+        b.t_cnt = _ptr(self.t_cnt, C.c_uint32)
+        b.q_off = _ptr(self.q_off, C.c_uint64)
+        b.q_cnt = _ptr(self.q_cnt, C.c_uint32)
+        b.n_variants = self.n_variants
+        b.var_pos = _ptr(self.var_pos, C.c_uint64)
+        b.var_type = _ptr(self.var_type, C.c_uint8)
+        b.var_zyg = _ptr(self.var_zyg, C.c_uint8)
+        b.var_raw_space = _ptr(self.var_raw_space, C.c_uint32)
+        b.a0_off = _ptr(self.a0_off, C.c_uint64)
+        b.a0_len = _ptr(self.a0_len, C.c_uint32)
+        b.a1_off = _ptr(self.a1_off, C.c_uint64)
+        b.a1_len = _ptr(self.a1_len, C.c_uint32)
+        b.allele_bytes = _ptr(self.allele_bytes, C.c_uint8)
+        b.allele_bytes_len = int(self.allele_bytes.size)
+        return b
+
+    def seq_strides(self):
+        out = np.zeros(self.n_regions, np.uint32)
+        for r in range(self.n_regions):
+            lo = int(self.t_off[r]); hi = lo + int(self.t_cnt[r])
+            g = seq_stride(int(self.start[r]), int(self.end[r]), self.a0_len[lo:hi], self.a1_len[lo:hi])
+            lo = int(self.q_off[r]); hi = lo + int(self.q_cnt[r])
+            g2 = seq_stride(int(self.start[r]), int(self.end[r]), self.a0_len[lo:hi], self.a1_len[lo:hi])
+            out[r] = max(g, g2, 1)
+        return out
+
+    def slice(self, lo, hi):
+        """Regions [lo, hi) as a new batch sharing the variant arrays."""
+        s = np.s_[lo:hi]
+        return RegionBatch(self.region_id[s], self.contig_idx[s], self.start[s], self.end[s],
+                           self.t_off[s], self.t_cnt[s], self.q_off[s], self.q_cnt[s],
+                           self.var_pos, self.var_type, self.var_zyg, self.var_raw_space,
+                           self.a0_off, self.a0_len, self.a1_off, self.a1_len, self.allele_bytes)
+
+
+class ResultBatch:
+    """Caller-allocated outputs of one avk_compare_batch / orc_compare_batch call."""
+
+    def __init__(self, batch, sequences=False, group_metrics=True):
+        n, v = batch.n_regions, batch.n_variants
+        self.status = np.full(n, -1, np.int32)
+        self.ed_h1 = np.zeros(n, np.uint32)
+        self.ed_h2 = np.zeros(n, np.uint32)
+        self.n_optima = np.zeros(n, np.uint32)
+        self.type_present = np.zeros(n, np.uint16)
+        self.group_metrics = np.zeros((n, N_GROUPS, N_FIELDS), np.uint32) if group_metrics else None
+        self.var_expected = np.zeros(max(v, 1), np.uint8)
+        self.var_observed = np.zeros(max(v, 1), np.uint8)
+        self.var_class = np.zeros(max(v, 1), np.uint8)
+        self.var_zyg = np.zeros(max(v, 1), np.uint8)
+        self.tally = np.zeros(TALLY_LEN, np.uint64)
+        self.sequences = sequences
+        if sequences:
+            self.seq_stride = batch.seq_strides()
+            self.seq_off = np.zeros(n, np.uint64)
+            if n:
+                self.seq_off[1:] = np.cumsum(self.seq_stride[:-1].astype(np.uint64) * 5)
+            total = int((self.seq_stride.astype(np.uint64) * 5).sum())
+            self.seq_bytes = np.zeros(max(total, 1), np.uint8)
+            self.seq_len = np.zeros((n, 5), np.uint32)
+
+    def c_struct(self):
+        o = AvkResultBatch()
+        o.status = _ptr(self.status, C.c_int32)
+        o.ed_h1 = _ptr(self.ed_h1, C.c_uint32)
+        o.ed_h2 = _ptr(self.ed_h2, C.c_uint32)
+        o.n_optima = _ptr(self.n_optima, C.c_uint32)
+        o.type_present = _ptr(self.type_present, C.c_uint16)
+        if self.group_metrics is not None:
+            o.group_metrics = _ptr(self.group_metrics, C.c_uint32)
+        o.var_expected = _ptr(self.var_expected, C.c_uint8)
+        o.var_observed = _ptr(self.var_observed, C.c_uint8)
+        o.var_class = _ptr(self.var_class, C.c_uint8)
+        o.var_zyg = _ptr(self.var_zyg, C.c_uint8)
+        o.tally = _ptr(self.tally, C.c_uint64)
+        if self.sequences:
+            o.seq_bytes = _ptr(self.seq_bytes, C.c_uint8)
+            o.seq_off = _ptr(self.seq_off, C.c_uint64)
+            o.seq_stride = _ptr(self.seq_stride, C.c_uint32)
+            o.seq_len = _ptr(self.seq_len, C.c_uint32)
+        return o
+
+    def sequence(self, r, k):
+        off = int(self.seq_off[r]) + k * int(self.seq_stride[r])
+        return bytes(self.seq_bytes[off:off + int(self.seq_len[r, k])])
+
+    FIELDS_CMP = ["status", "ed_h1", "ed_h2", "n_optima", "type_present", "group_metrics",
+                  "var_expected", "var_observed", "var_class", "var_zyg", "tally"]
+
+    def diff(self, other):
+        """Names of the output arrays that differ from `other` (bit-exact comparison)."""
+        bad = []
+        for f in self.FIELDS_CMP:
+            a, b = getattr(self, f), getattr(other, f)
+            if a is None or b is None:
+                continue
+            if not np.array_equal(a, b):
+                bad.append(f)
+        if self.sequences and other.sequences:
+            if not np.array_equal(self.seq_len, other.seq_len):
+                bad.append("seq_len")
+            else:
+                for r in range(self.seq_len.shape[0]):
+                    for k in range(5):
+                        if self.sequence(r, k) != other.sequence(r, k):
+                            bad.append("seq_bytes[%d,%d]" % (r, k))
+                            break
+        return bad

@@ -1,0 +1,219 @@
+/*
+ * aardvark_amd.h — C-ABI of the MI355X (gfx950) compare hot path.
+ *
+ * This is the drop-in boundary for the per-region solver of `aardvark compare`:
+ * one call replaces the reference's rayon loop
+ *     all_regions.into_par_iter().map(|r| solve_compare_region(&r, &genome, cfg, strat))
+ * (reference src/main.rs:251-268, src/waffle_solver.rs:122-124) with a batched launch
+ * of hand-written HIP kernels.  The reference has no FFI of its own; the flat
+ * structures below carry exactly the fields of `CompareRegion`
+ * (src/data_types/compare_region.rs:13-26), `Variant` (src/data_types/variants.rs:73-91),
+ * `CompareConfig` (src/waffle_solver.rs:94-103) and `CompareBenchmark`
+ * (src/data_types/compare_benchmark.rs:9-33).
+ *
+ * Conventions
+ *  - plain pointers + sizes, no C++/torch types; the caller owns every buffer;
+ *    nothing is retained after a call returns except what a context owns
+ *    (uploaded reference, uploaded batches).
+ *  - every function returns 0 on success or a negative AVK_E_* infrastructure code;
+ *    per-region solver outcomes are reported in `status[]` (AVK_ST_*), mirroring the
+ *    reference's `anyhow::Result` per region (src/main.rs:255-265): a failed region
+ *    produces no metrics and the batch continues.
+ *  - coordinates are 0-based half-open (src/data_types/coordinates.rs:6-13).
+ */
+#ifndef AARDVARK_AMD_H
+#define AARDVARK_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (ordinals identical to the reference's Rust enums) ------------------ */
+
+/* VariantType, src/data_types/variants.rs:6-31 */
+enum {
+    AVK_VT_SNV = 0, AVK_VT_INSERTION = 1, AVK_VT_DELETION = 2, AVK_VT_INDEL = 3,
+    AVK_VT_SV_INSERTION = 4, AVK_VT_SV_DELETION = 5, AVK_VT_SV_DUPLICATION = 6,
+    AVK_VT_SV_INVERSION = 7, AVK_VT_SV_BREAKEND = 8, AVK_VT_TR_CONTRACTION = 9,
+    AVK_VT_TR_EXPANSION = 10, AVK_VT_UNKNOWN = 11, AVK_N_VARIANT_TYPES = 12
+};
+
+/* PhasedZygosity, src/data_types/phase_enums.rs:33-46 */
+enum {
+    AVK_ZYG_UNKNOWN = 0, AVK_ZYG_HOM_REF = 1, AVK_ZYG_UNPHASED_HET = 2,
+    AVK_ZYG_PHASED_HET01 = 3, AVK_ZYG_PHASED_HET10 = 4, AVK_ZYG_HOM_ALT = 5
+};
+
+/* Classification, src/data_types/variant_metrics.rs:12-22 */
+enum { AVK_CLASS_UNKNOWN = 0, AVK_CLASS_TP = 1, AVK_CLASS_FN = 2, AVK_CLASS_FP = 3 };
+
+/* Metric block geometry.  A region's GroupTypeMetrics (src/data_types/grouped_metrics.rs:32-37)
+ * is 13 groups (group 0 = joint, group 1+t = VariantType t) of 22 counters
+ * (GroupMetrics, grouped_metrics.rs:150-161 + summary_metrics.rs:6-15,84-92). */
+#define AVK_N_GROUPS 13
+#define AVK_N_FIELDS 22
+enum {
+    AVK_F_GT_TRUTH_TP = 0, AVK_F_GT_TRUTH_FN, AVK_F_GT_QUERY_TP, AVK_F_GT_QUERY_FP,
+    AVK_F_GT_TRUTH_FN_GT, AVK_F_GT_QUERY_FP_GT,
+    AVK_F_HAP_TRUTH_TP, AVK_F_HAP_TRUTH_FN, AVK_F_HAP_QUERY_TP, AVK_F_HAP_QUERY_FP,
+    AVK_F_WHAP_TRUTH_TP, AVK_F_WHAP_TRUTH_FN, AVK_F_WHAP_QUERY_TP, AVK_F_WHAP_QUERY_FP,
+    AVK_F_BP_TRUTH_TP, AVK_F_BP_TRUTH_FN, AVK_F_BP_QUERY_TP, AVK_F_BP_QUERY_FP,
+    AVK_F_RBP_TRUTH_TP, AVK_F_RBP_TRUTH_FN, AVK_F_RBP_QUERY_TP, AVK_F_RBP_QUERY_FP
+};
+/* tally block = AVK_N_GROUPS*AVK_N_FIELDS sums, then solved_blocks, error_blocks
+ * (src/writers/summary.rs:146-163) */
+#define AVK_TALLY_LEN (AVK_N_GROUPS * AVK_N_FIELDS + 2)
+#define AVK_TALLY_SOLVED (AVK_N_GROUPS * AVK_N_FIELDS)
+#define AVK_TALLY_ERRORS (AVK_N_GROUPS * AVK_N_FIELDS + 1)
+
+/* per-region status: 0 = Ok(CompareBenchmark); >0 = the reference would return Err
+ * or panic for this region (class of the error) */
+enum {
+    AVK_ST_OK = 0,
+    AVK_ST_BRANCH_FACTOR = 2,   /* "max_branch_factor must be greater than 0", query_optimizer.rs:177 */
+    AVK_ST_NO_RESULTS = 3,      /* "no results found", query_optimizer.rs:331 */
+    AVK_ST_NO_GT_RESULT = 4,    /* "No result found for problem", exact_gt_optimizer.rs:347 */
+    AVK_ST_UNKNOWN_ALLELE = 5,  /* Allele::Unknown reached an optimizer, exact_gt_optimizer.rs:256 */
+    AVK_ST_BAD_ZYGOSITY = 6,    /* assert_eq!(zyg, HomozygousAlternate) panics, query_optimizer.rs:315 */
+    AVK_ST_VARIANT_METRICS = 7, /* VariantMetrics::new(.., 0, 0), variant_metrics.rs:57 */
+    AVK_ST_TRUTH_FP = 8,        /* assert!(exp >= obs), waffle_solver.rs:322 */
+    AVK_ST_RECORD_BP = 9,       /* "Truth/Query TP is less than basepair TP", waffle_solver.rs:492-493 */
+    AVK_ST_SEQ_MISMATCH = 10,   /* assert_eq!(regenerated, optimizer sequence), waffle_solver.rs:365-367 */
+    AVK_ST_AUTOFAIL_OOB = 11,   /* all_variant_order[auto_fail_index] out of bounds, exact_gt_optimizer.rs:312 */
+    AVK_ST_INVALID_INPUT = 20,  /* rejected by host validation (window outside contig, variant outside
+                                   window, unsorted variants, empty allele): the reference panics or is undefined */
+    AVK_ST_CAPACITY = 21        /* device workspace exhausted at the largest tier */
+};
+
+/* infrastructure errors (function return values) */
+enum {
+    AVK_E_OK = 0, AVK_E_ARG = -1, AVK_E_HIP = -2, AVK_E_OOM = -3, AVK_E_STATE = -4
+};
+
+/* ---- inputs ---------------------------------------------------------------------- */
+
+/* A batch of CompareRegions in structure-of-arrays form.  Region r owns truth variants
+ * [t_off[r], t_off[r]+t_cnt[r]) and query variants [q_off[r], q_off[r]+q_cnt[r]) of the
+ * variant arrays; variant v's alleles are allele_bytes[a0_off[v] .. +a0_len[v]) (allele0 =
+ * VCF REF after trimming) and [a1_off[v] .. +a1_len[v]) (allele1 = ALT). */
+typedef struct avk_region_batch {
+    uint64_t n_regions;
+    const uint64_t *region_id;   /* CompareRegion::region_id */
+    const uint32_t *contig_idx;  /* index into the uploaded reference (Coordinates::chrom) */
+    const uint64_t *start;       /* Coordinates::start */
+    const uint64_t *end;         /* Coordinates::end (exclusive) */
+    const uint64_t *t_off;
+    const uint32_t *t_cnt;
+    const uint64_t *q_off;
+    const uint32_t *q_cnt;
+
+    uint64_t n_variants;
+    const uint64_t *var_pos;       /* Variant::position (0-based, contig coordinates) */
+    const uint8_t  *var_type;      /* AVK_VT_* */
+    const uint8_t  *var_zyg;       /* AVK_ZYG_* (input zygosity of the call) */
+    const uint32_t *var_raw_space; /* Variant::raw_allele_space */
+    const uint64_t *a0_off;
+    const uint32_t *a0_len;
+    const uint64_t *a1_off;
+    const uint32_t *a1_len;
+
+    const uint8_t *allele_bytes;
+    uint64_t allele_bytes_len;
+} avk_region_batch;
+
+/* CompareConfig, src/waffle_solver.rs:94-115 */
+typedef struct avk_compare_config {
+    uint32_t max_branch_factor;     /* default 50 */
+    uint32_t enable_sequences;      /* fill seq_* outputs (debug region_sequences.tsv.gz) */
+    uint32_t enable_exact_shortcut; /* hidden --enable-exact-shortcut */
+} avk_compare_config;
+
+/* ---- outputs --------------------------------------------------------------------- */
+
+/* Caller-allocated result arrays, positionally aligned with the input batch.
+ * Any pointer except `status` may be NULL to skip that output. */
+typedef struct avk_result_batch {
+    int32_t  *status;        /* [n_regions] AVK_ST_* */
+    uint32_t *ed_h1;         /* [n_regions] CompareBenchmark::bm_edit_distance_h1 */
+    uint32_t *ed_h2;         /* [n_regions] */
+    uint32_t *n_optima;      /* [n_regions] tied optima returned by optimize_sequences */
+    uint16_t *type_present;  /* [n_regions] bit t: VariantType t has an entry in variant_metrics */
+    uint32_t *group_metrics; /* [n_regions][AVK_N_GROUPS][AVK_N_FIELDS] full GroupTypeMetrics */
+
+    /* per variant, same indexing as the input variant arrays; query entries are already
+     * toggled the way CompareBenchmark::add_swap_benchmark stores them
+     * (compare_benchmark.rs:109-123): these are the EA / OA / BD values of the output VCFs */
+    uint8_t  *var_expected;  /* [n_variants] */
+    uint8_t  *var_observed;  /* [n_variants] */
+    uint8_t  *var_class;     /* [n_variants] AVK_CLASS_* */
+    uint8_t  *var_zyg;       /* [n_variants] zygosity resolved by the phasing search (GT of output VCFs) */
+
+    /* SequenceBundle (compare_benchmark.rs:166-185) when cfg.enable_sequences:
+     * region r, sequence k (0 ref, 1 truth1, 2 truth2, 3 query1, 4 query2) is
+     * seq_bytes[seq_off[r] + k*seq_stride[r] .. + seq_len[5*r+k]).  seq_off/seq_stride are
+     * INPUTS sized with avk_seq_stride(). */
+    uint8_t  *seq_bytes;
+    const uint64_t *seq_off;    /* [n_regions] */
+    const uint32_t *seq_stride; /* [n_regions] */
+    uint32_t *seq_len;          /* [n_regions][5] */
+
+    uint64_t *tally;         /* [AVK_TALLY_LEN] sums over the Ok regions of this batch */
+} avk_result_batch;
+
+/* ---- context --------------------------------------------------------------------- */
+
+typedef struct avk_ctx avk_ctx;          /* one per GPU / per host thread */
+typedef struct avk_dev_batch avk_dev_batch; /* a region batch resident in HBM */
+
+int  avk_ctx_create(int device_id, avk_ctx **out);
+void avk_ctx_destroy(avk_ctx *ctx);
+/* last error text of this context (or of the failed create when ctx == NULL) */
+const char *avk_last_error(const avk_ctx *ctx);
+/* run every launch of this context on an existing hipStream_t (e.g. torch's current stream) */
+int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
+/* tuning knobs: name in {"lds_bytes_per_wave","waves_per_cu","ws_bytes_per_wave","big_ws_bytes","big_waves"} */
+int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
+
+/* Replaces ReferenceGenome::from_fasta + get_full_chromosome (src/main.rs:94,
+ * src/waffle_solver.rs:131): contigs are copied to HBM once (2-bit packed plus the raw
+ * bytes needed for windows holding non-ACGT symbols) and owned by the context. */
+int  avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs, const uint64_t *lens);
+
+/* One call = solve_compare_region for every region of the batch (H2D + kernels + D2H). */
+int  avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch,
+                       const avk_compare_config *cfg, avk_result_batch *out);
+
+/* The same in three steps, for callers that keep batches resident in HBM. */
+int  avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch **out);
+/* tally_dev: optional device pointer (uint64[AVK_TALLY_LEN]) that receives the batch tally,
+ * e.g. a tensor that is then reduced over RCCL; may be NULL. Asynchronous on the context stream. */
+int  avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev);
+int  avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out);
+void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db);
+int  avk_synchronize(avk_ctx *ctx);
+
+/* bytes needed per sequence slot of region r of `batch` (upper bound of any haplotype length) */
+uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
+
+/* measurement hooks: milliseconds of the solver kernels of the last avk_compare_resident /
+ * avk_compare_batch on this context, from hipEvents on the context stream; how many regions
+ * each workspace tier solved; algorithmic bytes of the batch (DESIGN.md "bytes per region") */
+int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);
+int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[4]);
+uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
+
+/* Merge path (src/merge_solver.rs:137-143): for pair p, optimize_sequences(set a, set b) and
+ * report all_opt_haps[0].is_exact_match().  Pair p compares variant ranges
+ * [t_off,t_cnt) vs [q_off,q_cnt) of region p of `batch` exactly like a CompareRegion. */
+int  avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32_t max_branch_factor,
+                              int32_t *status, uint8_t *is_exact_match);
+
+const char *avk_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AARDVARK_AMD_H */
