@@ -1,0 +1,73 @@
+/*
+ * avk_dev_types.h — layout of a region batch in HBM and of the kernel arguments.
+ * Shared by the host packer (avk_pack.h), the kernels (avk_solver.inl) and the lane emulator.
+ */
+#ifndef AVK_DEV_TYPES_H
+#define AVK_DEV_TYPES_H
+
+#include <stdint.h>
+#include "../../include/aardvark_amd.h"
+
+/* One region (CompareRegion, reference src/data_types/compare_region.rs:13-26).  Variants of
+ * the region are contiguous in the variant array: t_cnt truth records, then q_cnt query records. */
+struct AvkDevRegion {
+    uint64_t ref_off;    /* offset of the window start in the concatenated reference bytes */
+    uint32_t len;        /* window length L = end - start */
+    uint32_t v_off;      /* first variant record */
+    uint32_t t_cnt;
+    uint32_t q_cnt;
+    uint32_t pre_status; /* host validation: 0 or AVK_ST_INVALID_INPUT / AVK_ST_BAD_ZYGOSITY */
+    uint32_t seq_stride; /* bytes per output sequence slot (0 = no sequence output) */
+    uint64_t seq_off;    /* offset of the region's 5 slots in the sequence output */
+};
+
+/* One variant (reference src/data_types/variants.rs:73-91), window-relative */
+struct AvkDevVariant {
+    uint32_t rel_pos;   /* position - window start */
+    uint32_t a0_len;    /* ref_len() */
+    uint32_t a1_len;
+    uint32_t a_off;     /* allele0 bytes at a_off, allele1 bytes at a_off + a0_len of the allele arena */
+    uint32_t raw_space; /* raw_allele_space */
+    uint8_t type;       /* AVK_VT_* */
+    uint8_t zyg;        /* AVK_ZYG_* */
+    uint16_t pad;
+};
+
+/* capacities of one workspace tier */
+struct AvkTier {
+    uint64_t ws_bytes; /* bytes of workspace per wave in this tier */
+    uint32_t ed_cap;   /* 0 = exact worst case (wavefront can hold any edit distance) */
+    uint32_t pad;
+};
+
+struct AvkKernelArgs {
+    /* inputs */
+    const AvkDevRegion *regions;
+    const AvkDevVariant *variants;
+    const uint8_t *alleles;
+    const uint8_t *ref_bytes;
+    uint32_t n_regions;
+    uint32_t max_branch_factor;
+    uint32_t enable_exact_shortcut;
+    uint32_t first_tier; /* 0: LDS slice then HBM slice; 2: big HBM slice only (overflow pass) */
+    /* work distribution */
+    const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */
+    uint32_t *work_counter;    /* persistent waves pull the next region from here */
+    uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
+    uint32_t *overflow_count;
+    /* workspaces */
+    uint8_t *hbm_ws;           /* n_waves slices of tier[1] (or tier[2]) bytes */
+    AvkTier tier[3];
+    /* outputs */
+    int32_t *status;
+    uint32_t *ed_h1, *ed_h2, *n_optima;
+    uint16_t *type_present;
+    uint32_t *group_metrics; /* optional [n][13][22] */
+    uint8_t *var_expected, *var_observed, *var_class, *var_zyg;
+    uint8_t *seq_bytes;      /* optional */
+    uint32_t *seq_len;
+    uint64_t *tally;         /* [AVK_TALLY_LEN] */
+    uint64_t *tier_counts;   /* [4] regions solved per tier, capacity failures */
+};
+
+#endif

@@ -1,0 +1,1334 @@
+/*
+ * avk_solver.inl — the per-region compare solver as wave-cooperative device code.
+ *
+ * One 64-lane wavefront solves one region end to end (reference solve_compare_region,
+ * src/waffle_solver.rs:122-284):
+ *   phase A  phasing search        optimize_sequences   src/query_optimizer.rs:166-365
+ *   phase B  genotype assignment   optimize_gt_alleles  src/exact_gt_optimizer.rs:108-357 (x2 per tied optimum)
+ *   phase C  metrics               compare_expected_observed / add_basepair_stats /
+ *                                  add_record_basepair_stats  src/waffle_solver.rs:296-522
+ * on top of the dynamic wavefront aligner (src/dwfa/dynamic_wfa.rs:23-276) and the haplotype
+ * builders (src/dwfa/haplotype_dwfa.rs:17-245).
+ *
+ * MI355X mapping (not a translation of the reference's per-node heap objects):
+ *   - control flow is wave-uniform; all search bookkeeping (queue length, ids, quotas, best cost)
+ *     lives in scalar registers;
+ *   - the wavefront diagonals are extended by lane groups: 64/G diagonals at a time, G lanes
+ *     comparing G consecutive bases of one diagonal per step, one ballot + ctz per step;
+ *   - the best-first queues are flat (key, slot) arrays scanned 64 entries at a time and reduced
+ *     with a cross-lane min — exact pop order without a heap; keys are unique so order is total;
+ *   - nodes are fixed-stride records in a per-wave workspace: the LDS slice of the wave for the
+ *     common small regions, the wave's private HBM slice for larger ones, a big HBM slice in a
+ *     second pass for the long tail.  A tier that runs out of room reports overflow and the
+ *     region restarts on the next tier, so results never depend on the tier;
+ *   - haplotype sequences, wavefronts and allele bit-sets are copied lane-parallel as words.
+ *
+ * Every cross-lane exchange through memory is separated by wv_sync(); values that steer
+ * control flow are made uniform with wv_uni().
+ */
+#ifndef AVK_SOLVER_INL
+#define AVK_SOLVER_INL
+
+#include "avk_dev_types.h"
+#include "avk_wave.h"
+
+namespace avk {
+
+typedef uint8_t u8;
+typedef uint16_t u16;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+enum { AL_REF = 1, AL_ALT = 2 };
+enum { RS_OVERFLOW = -1 }; /* internal: this tier's workspace is too small, retry on the next */
+
+#define AVK_ALIGN8(x) (((x) + 7u) & ~(u64)7u)
+
+/* hap record: 10 header words, then alt bit-sets, wavefront, two sequences */
+enum { H_T_REFPOS = 0, H_Q_REFPOS, H_T_LEN, H_Q_LEN, H_T_SKIP, H_Q_SKIP, H_ED, H_T_NAL, H_Q_NAL, H_PAD, H_WORDS };
+
+struct HapHdr {
+    u32 t_refpos, q_refpos, t_len, q_len, t_skip, q_skip, ed, t_nal, q_nal;
+};
+
+/* local variant record in the workspace */
+struct LVar {
+    u32 rel_pos, a0_len, a1_len, a_off, raw_space, alt_ed;
+    u8 type, zyg, pad0, pad1;
+};
+
+struct Ctx {
+    /* region */
+    u32 L, T, Q, N;
+    const u8 *ref; /* window bytes (workspace copy) */
+    LVar *vars;    /* [N]: truth 0..T-1, query T..N-1 */
+    u8 *alle;
+    u32 *order;    /* [N] processing order (query_optimizer.rs:372-381) */
+    u32 *bucket;   /* [N+1] */
+    /* capacities */
+    u32 seqcap, wfcap, alw;
+    u32 hapA_bytes, nodeA_bytes, hapB_bytes, nodeB_bytes;
+    /* node pool + queue */
+    u8 *pool;
+    u64 pool_bytes;
+    u32 node_bytes; /* stride of the phase that is running */
+    u8 *pool_base;  /* first node of the running phase */
+    u32 pool_cap, pool_used, nfree;
+    u32 *freelist;
+    u64 *qkeys;
+    u32 *qslots;
+    u32 qn, qcap;
+    /* scratch */
+    u32 *wfs;
+    u32 wfs_cap;
+    u8 *seq_a, *seq_b;
+    u32 *gm, *gq; /* [13*22] metrics blocks */
+    u32 *optlist; /* tied optima (node indices) */
+    u32 optcap;
+    u64 *bres;    /* phase-B results: [2 cand][2 hap][2 side][alw] alt bit-sets */
+    u32 max_branch;
+};
+
+/* ------------------------------------------------------------------------------------------ */
+/* small lane-parallel helpers                                                                */
+/* ------------------------------------------------------------------------------------------ */
+AVK_DEV void copy_bytes(u8 *dst, const u8 *src, u32 n) {
+    for (u32 i = (u32)wv_lane(); i < n; i += 64) dst[i] = src[i];
+}
+AVK_DEV void copy_words(u32 *dst, const u32 *src, u32 n) {
+    for (u32 i = (u32)wv_lane(); i < n; i += 64) dst[i] = src[i];
+}
+AVK_DEV void zero_words(u32 *dst, u32 n) {
+    for (u32 i = (u32)wv_lane(); i < n; i += 64) dst[i] = 0;
+}
+AVK_DEV void st32(u32 *p, u32 v) {
+    if (wv_lane() == 0) *p = v;
+}
+AVK_DEV void st64(u64 *p, u64 v) {
+    if (wv_lane() == 0) *p = v;
+}
+AVK_DEV u32 ld32u(const u32 *p) { return wv_uni(*p); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* dynamic wavefront aligner — src/dwfa/dynamic_wfa.rs                                         */
+/* wf[i] = symbols of O consumed on diagonal i, baseline offset = wf[i] + ed - i (:114)        */
+/* ------------------------------------------------------------------------------------------ */
+
+/* extend (:94-130): every diagonal slides while the bases agree and both offsets are in range.
+ * 64/G diagonals are processed at once, G lanes per diagonal. */
+AVK_DEV void dw_extend(u32 *wf, u32 ed, const u8 *B, u32 bl, const u8 *O, u32 ol) {
+    const u32 nd = 2 * ed + 1;
+    const u32 lane = (u32)wv_lane();
+    u32 gs; /* log2(G) */
+    if (nd == 1) gs = 6;
+    else if (nd <= 4) gs = 4;
+    else if (nd <= 8) gs = 3;
+    else if (nd <= 16) gs = 2;
+    else if (nd <= 32) gs = 1;
+    else gs = 0;
+    const u32 G = 1u << gs, ngrp = 64u >> gs;
+    const u32 grp = lane >> gs, li = lane & (G - 1);
+    const u64 gmask = gs == 6 ? ~0ull : ((1ull << G) - 1);
+    for (u32 base = 0; base < nd; base += ngrp) {
+        const u32 i = base + grp;
+        const bool active = i < nd;
+        u32 d = active ? wf[i] : 0;
+        bool done = !active;
+        for (;;) {
+            bool match = false;
+            if (!done) {
+                const u32 oo = d + li, bo = d + ed - i + li;
+                match = bo < bl && oo < ol && B[bo] == O[oo];
+            }
+            const u64 m = wv_ballot(!match);
+            const u64 gm = (m >> (grp * G)) & gmask;
+            if (!done) {
+                d += gm ? (u32)avk_ctz64(gm) : G;
+                done = gm != 0;
+            }
+            if (wv_ballot(!done) == 0) break;
+        }
+        if (active && li == 0) wf[i] = d;
+    }
+    wv_sync();
+}
+
+/* increase_edit_distance (:140-173) without the re-extend: new[k] = max(old[k], old[k-1]+1, old[k-2]+1),
+ * no clipping to the sequence lengths.  In place, top chunk first. */
+AVK_DEV void dw_bump(u32 *wf, u32 old_ed) {
+    const u32 nd = 2 * old_ed + 1, nn = nd + 2;
+    const u32 lane = (u32)wv_lane();
+    for (int c = (int)(((nn - 1) >> 6) << 6); c >= 0; c -= 64) {
+        const u32 k = (u32)c + lane;
+        u32 v = 0;
+        if (k < nn) {
+            if (k < nd) v = wf[k];
+            if (k >= 1 && k - 1 < nd) {
+                const u32 t = wf[k - 1] + 1;
+                v = t > v ? t : v;
+            }
+            if (k >= 2 && k - 2 < nd) {
+                const u32 t = wf[k - 2] + 1;
+                v = t > v ? t : v;
+            }
+        }
+        wv_sync();
+        if (k < nn) wf[k] = v;
+        wv_sync();
+    }
+}
+
+/* maximum_baseline_distance / maximum_other_distance (:201-215) */
+AVK_DEV void dw_maxes(const u32 *wf, u32 ed, u32 &mb, u32 &mo) {
+    const u32 nd = 2 * ed + 1;
+    u32 lb = 0, lo = 0;
+    for (u32 i = (u32)wv_lane(); i < nd; i += 64) {
+        const u32 d = wf[i];
+        lo = d > lo ? d : lo;
+        const u32 b = d + ed - i;
+        lb = b > lb ? b : lb;
+    }
+    mb = wv_max_u32(lb);
+    mo = wv_max_u32(lo);
+}
+
+/* reached_full_diagonal (:237-245) */
+AVK_DEV bool dw_full_diagonal(const u32 *wf, u32 ed, u32 bl, u32 ol) {
+    const u32 nd = 2 * ed + 1;
+    bool any = false;
+    for (u32 i = (u32)wv_lane(); i < nd; i += 64) {
+        const u32 d = wf[i];
+        any = any || (d + ed - i >= bl && d >= ol);
+    }
+    return wv_ballot(any) != 0;
+}
+
+/* update (:68-84): extend, then raise the distance until EITHER end is touched.
+ * returns 0 or RS_OVERFLOW when the wavefront no longer fits `cap` entries. */
+AVK_DEV int dw_update(u32 *wf, u32 cap, u32 &ed, const u8 *B, u32 bl, const u8 *O, u32 ol) {
+    dw_extend(wf, ed, B, bl, O, ol);
+    for (;;) {
+        u32 mb, mo;
+        dw_maxes(wf, ed, mb, mo);
+        if (mb >= bl || mo >= ol) break;
+        if (2 * ed + 3 > cap) return RS_OVERFLOW;
+        dw_bump(wf, ed);
+        ed += 1;
+        dw_extend(wf, ed, B, bl, O, ol);
+    }
+    return 0;
+}
+
+/* finalize (:183-198) */
+AVK_DEV int dw_finalize(u32 *wf, u32 cap, u32 &ed, const u8 *B, u32 bl, const u8 *O, u32 ol) {
+    dw_extend(wf, ed, B, bl, O, ol);
+    while (!dw_full_diagonal(wf, ed, bl, ol)) {
+        if (2 * ed + 3 > cap) return RS_OVERFLOW;
+        dw_bump(wf, ed);
+        ed += 1;
+        dw_extend(wf, ed, B, bl, O, ol);
+    }
+    return 0;
+}
+
+/* wfa_ed (src/util/sequence_alignment.rs:9-13) on the scratch wavefront; < 0 = overflow */
+AVK_DEV int wfa_ed(const Ctx &c, const u8 *a, u32 al, const u8 *b, u32 bl) {
+    wv_sync();
+    st32(c.wfs, 0);
+    wv_sync();
+    u32 ed = 0;
+    if (dw_finalize(c.wfs, c.wfs_cap, ed, a, al, b, bl)) return RS_OVERFLOW;
+    return (int)ed;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* hap records                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+struct HapPtr {
+    u32 *w;
+    u64 *talt, *qalt;
+    u32 *wf;
+    u8 *tseq, *qseq;
+};
+AVK_DEV HapPtr hap_ptr(u8 *base, u32 alw, u32 wfcap, u32 seqcap) {
+    HapPtr p;
+    p.w = (u32 *)base;
+    p.talt = (u64 *)(base + H_WORDS * 4);
+    p.qalt = p.talt + alw;
+    p.wf = (u32 *)(p.qalt + alw);
+    p.tseq = (u8 *)(p.wf + wfcap);
+    p.qseq = p.tseq + seqcap;
+    return p;
+}
+AVK_DEV HapHdr hap_load(const u32 *w) {
+    HapHdr h;
+    h.t_refpos = ld32u(w + H_T_REFPOS);
+    h.q_refpos = ld32u(w + H_Q_REFPOS);
+    h.t_len = ld32u(w + H_T_LEN);
+    h.q_len = ld32u(w + H_Q_LEN);
+    h.t_skip = ld32u(w + H_T_SKIP);
+    h.q_skip = ld32u(w + H_Q_SKIP);
+    h.ed = ld32u(w + H_ED);
+    h.t_nal = ld32u(w + H_T_NAL);
+    h.q_nal = ld32u(w + H_Q_NAL);
+    return h;
+}
+AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
+    if (wv_lane() == 0) {
+        w[H_T_REFPOS] = h.t_refpos;
+        w[H_Q_REFPOS] = h.q_refpos;
+        w[H_T_LEN] = h.t_len;
+        w[H_Q_LEN] = h.q_len;
+        w[H_T_SKIP] = h.t_skip;
+        w[H_Q_SKIP] = h.q_skip;
+        w[H_ED] = h.ed;
+        w[H_T_NAL] = h.t_nal;
+        w[H_Q_NAL] = h.q_nal;
+    }
+}
+AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
+    if (wv_lane() == 0) {
+        for (int k = 0; k < H_WORDS; ++k) p.w[k] = 0;
+        for (u32 k = 0; k < alw; ++k) {
+            p.talt[k] = 0;
+            p.qalt[k] = 0;
+        }
+        p.wf[0] = 0;
+    }
+}
+
+/* HaplotypeTracker::copy_reference (haplotype_dwfa.rs:218-227) */
+AVK_DEV void trk_copy_reference(const Ctx &c, u8 *seq, u32 &len, u32 &refpos, u32 upto) {
+    if (refpos < upto) {
+        copy_bytes(seq + len, c.ref + refpos, upto - refpos);
+        len += upto - refpos;
+        refpos = upto;
+    }
+}
+
+/* HaplotypeTracker::extend_variant (haplotype_dwfa.rs:175-212); returns the `success` flag */
+AVK_DEV bool trk_extend_variant(const Ctx &c, const LVar &v, u32 allele, u32 sync, u8 *seq, u32 &len, u32 &refpos, u32 &skip,
+                                u64 *alt, u32 &nal) {
+    trk_copy_reference(c, seq, len, refpos, v.rel_pos);
+    bool ok = true;
+    if (allele == AL_ALT) {
+        if (refpos <= v.rel_pos) {
+            copy_bytes(seq + len, c.alle + v.a_off + v.a0_len, v.a1_len);
+            len += v.a1_len;
+            refpos = v.rel_pos + v.a0_len;
+            if (wv_lane() == 0) alt[nal >> 6] |= 1ull << (nal & 63);
+        } else {
+            skip += v.alt_ed; /* edit_distance(allele0, allele1), :199 — equal to the wavefront distance */
+            ok = false;
+            if (wv_lane() == 0) alt[nal >> 6] |= 1ull << (nal & 63); /* the allele pushed is still ALT (:204) */
+        }
+    } else {
+        if (wv_lane() == 0) alt[nal >> 6] &= ~(1ull << (nal & 63));
+    }
+    nal += 1;
+    trk_copy_reference(c, seq, len, refpos, sync);
+    return ok;
+}
+
+/* HaplotypeDWFA::extend_variant minus the DWFA update (haplotype_dwfa.rs:46-62) */
+AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, const LVar &v, u32 allele, u32 sync) {
+    bool ok;
+    if (is_truth) {
+        trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, sync);
+        ok = trk_extend_variant(c, v, allele, sync, p.tseq, h.t_len, h.t_refpos, h.t_skip, p.talt, h.t_nal);
+    } else {
+        trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, sync);
+        ok = trk_extend_variant(c, v, allele, sync, p.qseq, h.q_len, h.q_refpos, h.q_skip, p.qalt, h.q_nal);
+    }
+    wv_sync();
+    return ok;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* node pool + best-first queue                                                               */
+/* ------------------------------------------------------------------------------------------ */
+AVK_DEV u8 *node_at(const Ctx &c, u32 idx) { return c.pool_base + (u64)idx * c.node_bytes; }
+
+AVK_DEV int node_alloc(Ctx &c) {
+    if (c.nfree > 0) {
+        c.nfree -= 1;
+        return (int)ld32u(c.freelist + c.nfree);
+    }
+    if (c.pool_used < c.pool_cap) return (int)(c.pool_used++);
+    return RS_OVERFLOW;
+}
+AVK_DEV void node_free(Ctx &c, u32 idx) {
+    wv_sync();
+    st32(c.freelist + c.nfree, idx);
+    c.nfree += 1;
+    wv_sync();
+}
+AVK_DEV void node_copy(const Ctx &c, u32 dst, u32 src) {
+    wv_sync();
+    copy_words((u32 *)node_at(c, dst), (const u32 *)node_at(c, src), c.node_bytes >> 2);
+    wv_sync();
+}
+AVK_DEV int queue_push(Ctx &c, u64 key, u32 slot) {
+    if (c.qn >= c.qcap) return RS_OVERFLOW;
+    wv_sync();
+    if (wv_lane() == 0) {
+        c.qkeys[c.qn] = key;
+        c.qslots[c.qn] = slot;
+    }
+    c.qn += 1;
+    wv_sync();
+    return 0;
+}
+/* pop the entry with the smallest key (keys are unique: they end in the node id) */
+AVK_DEV u32 queue_pop(Ctx &c, u64 &key_out) {
+    const u32 lane = (u32)wv_lane();
+    u64 best = ~0ull;
+    u32 bpos = 0xFFFFFFFFu;
+    for (u32 j = lane; j < c.qn; j += 64) {
+        const u64 k = c.qkeys[j];
+        if (k < best) {
+            best = k;
+            bpos = j;
+        }
+    }
+    const u64 m = wv_min_u64(best);
+    const u32 pos = wv_min_u32(best == m ? bpos : 0xFFFFFFFFu);
+    const u32 slot = ld32u(c.qslots + pos);
+    const u32 last = c.qn - 1;
+    wv_sync();
+    if (lane == 0 && pos != last) {
+        c.qkeys[pos] = c.qkeys[last];
+        c.qslots[pos] = c.qslots[last];
+    }
+    c.qn = last;
+    wv_sync();
+    key_out = m;
+    return slot;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* phase A — optimize_sequences (src/query_optimizer.rs:166-365)                               */
+/* ------------------------------------------------------------------------------------------ */
+AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
+    const u32 *n = (const u32 *)node_at(c, idx);
+    const u32 *h0 = n + 2, *h1 = (const u32 *)((const u8 *)h0 + c.hapA_bytes);
+    return ld32u(h0 + H_ED) + ld32u(h0 + H_T_SKIP) + ld32u(h0 + H_Q_SKIP) + ld32u(h1 + H_ED) + ld32u(h1 + H_T_SKIP) + ld32u(h1 + H_Q_SKIP);
+}
+
+/* ComparisonNode::extend_variant (:443-451) = both haplotypes + their DWFA updates */
+AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const LVar &v, u32 a1, u32 a2, u32 sync) {
+    u8 *n = node_at(c, idx);
+    for (int hh = 0; hh < 2; ++hh) {
+        const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        HapHdr h = hap_load(p.w);
+        hap_extend_seq(c, p, h, is_truth, v, hh == 0 ? a1 : a2, sync);
+        if (dw_update(p.wf, c.wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len)) return RS_OVERFLOW;
+        wv_sync();
+        hap_store(p.w, h);
+        wv_sync();
+    }
+    return 0;
+}
+
+/* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
+AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
+    u8 *n = node_at(c, idx);
+    for (int hh = 0; hh < 2; ++hh) {
+        const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        HapHdr h = hap_load(p.w);
+        trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, c.L);
+        trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, c.L);
+        wv_sync();
+        if (dw_update(p.wf, c.wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len)) return RS_OVERFLOW;
+        if (dw_finalize(p.wf, c.wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len)) return RS_OVERFLOW;
+        wv_sync();
+        hap_store(p.w, h);
+        wv_sync();
+    }
+    return 0;
+}
+
+/* returns the number of tied optima (their node indices are in c.optlist), RS_OVERFLOW, or -status-100 */
+AVK_DEV int phaseA(Ctx &c) {
+    c.node_bytes = c.nodeA_bytes;
+    c.pool_base = c.pool;
+    c.pool_cap = (u32)(c.pool_bytes / c.nodeA_bytes);
+    if (c.pool_cap > c.qcap) c.pool_cap = c.qcap;
+    c.pool_used = 0;
+    c.nfree = 0;
+    c.qn = 0;
+    if (c.pool_cap < 3) return RS_OVERFLOW;
+    zero_words(c.bucket, c.N + 1);
+
+    int root = node_alloc(c);
+    {
+        u8 *n = node_at(c, (u32)root);
+        st32((u32 *)n, 0);
+        st32((u32 *)n + 1, 0);
+        hap_init(hap_ptr(n + 8, c.alw, c.wfcap, c.seqcap), c.alw);
+        hap_init(hap_ptr(n + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap), c.alw);
+    }
+    wv_sync();
+    queue_push(c, 0, (u32)root);
+    u32 next_id = 1;
+    u32 best_ed = 0xFFFFFFFFu;
+    u32 nbest = 0;
+
+    while (c.qn > 0) {
+        u64 key;
+        const u32 ni = queue_pop(c, key);
+        const u32 cost = (u32)(key >> 32);
+        if (cost > best_ed) { /* :204 */
+            node_free(c, ni);
+            continue;
+        }
+        const u32 *nw = (const u32 *)node_at(c, ni);
+        const u32 depth = ld32u(nw + 2 + H_T_NAL) + ld32u(nw + 2 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
+        const u32 cnt = ld32u(c.bucket + depth);
+        if (cnt >= c.max_branch) { /* :222 */
+            node_free(c, ni);
+            continue;
+        }
+        wv_sync();
+        st32(c.bucket + depth, cnt + 1);
+        wv_sync();
+
+        if (depth == c.N) { /* :227-247 */
+            if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
+            const u32 fc = nodeA_cost(c, ni);
+            if (fc < best_ed) {
+                for (u32 k = 0; k < nbest; ++k) node_free(c, ld32u(c.optlist + k));
+                best_ed = fc;
+                nbest = 0;
+            }
+            if (fc == best_ed) {
+                if (nbest >= c.optcap) return RS_OVERFLOW;
+                wv_sync();
+                st32(c.optlist + nbest, ni);
+                wv_sync();
+                nbest += 1;
+            } else {
+                node_free(c, ni);
+            }
+            continue;
+        }
+
+        const u32 vi = ld32u(c.order + depth);
+        const LVar v = c.vars[vi];
+        const bool is_truth = vi < c.T;
+        const u32 zyg = wv_uni(v.zyg);
+        u32 sync = c.L; /* :258-265 */
+        if (depth + 1 < c.N) sync = wv_uni(c.vars[ld32u(c.order + depth + 1)].rel_pos);
+        const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
+
+        if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
+            const int c1 = node_alloc(c);
+            if (c1 < 0) return RS_OVERFLOW;
+            node_copy(c, (u32)c1, ni);
+            st32((u32 *)node_at(c, (u32)c1), next_id);
+            wv_sync();
+            if (nodeA_extend(c, (u32)c1, is_truth, v, AL_REF, AL_ALT, sync)) return RS_OVERFLOW;
+            if (queue_push(c, ((u64)nodeA_cost(c, (u32)c1) << 32) | next_id, (u32)c1)) return RS_OVERFLOW;
+            next_id += 1;
+            /* the popped node itself becomes the second clone */
+            st32((u32 *)node_at(c, ni), next_id);
+            wv_sync();
+            if (nodeA_extend(c, ni, is_truth, v, AL_ALT, AL_REF, sync)) return RS_OVERFLOW;
+            if (queue_push(c, ((u64)nodeA_cost(c, ni) << 32) | next_id, ni)) return RS_OVERFLOW;
+            next_id += 1;
+        } else { /* :294-327: the node is moved, its id kept */
+            u32 a1 = AL_ALT, a2 = AL_ALT;
+            if (het) {
+                a1 = zyg == AVK_ZYG_PHASED_HET01 ? AL_REF : AL_ALT;
+                a2 = zyg == AVK_ZYG_PHASED_HET01 ? AL_ALT : AL_REF;
+            }
+            const u32 id = ld32u((const u32 *)node_at(c, ni));
+            if (nodeA_extend(c, ni, is_truth, v, a1, a2, sync)) return RS_OVERFLOW;
+            if (queue_push(c, ((u64)nodeA_cost(c, ni) << 32) | id, ni)) return RS_OVERFLOW;
+        }
+    }
+    if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
+    return (int)nbest;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* phase B — optimize_gt_alleles (src/exact_gt_optimizer.rs:108-357)                           */
+/* The DWFA of an ExactMatchNode has max_edit_distance 0 (:380): a live node's two sequences    */
+/* agree on their common prefix, so the whole wavefront is the single value d = matched length. */
+/* ------------------------------------------------------------------------------------------ */
+AVK_DEV bool exact_update(const HapPtr &p, HapHdr &h) {
+    /* update(): extend the main diagonal, then ed would have to rise unless one end is touched */
+    u32 d = ld32u(p.wf);
+    const u32 lane = (u32)wv_lane();
+    const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
+    while (d < lim) {
+        const u32 i = d + lane;
+        const bool match = i < lim && p.tseq[i] == p.qseq[i];
+        const u64 m = wv_ballot(!match);
+        if (m) {
+            d += (u32)avk_ctz64(m);
+            break;
+        }
+        d += 64;
+    }
+    wv_sync();
+    st32(p.wf, d);
+    wv_sync();
+    return d >= h.t_len || d >= h.q_len;
+}
+
+/* ExactMatchNode::extend_variant (:395-414): returns success && is_exact_match */
+AVK_DEV bool nodeB_extend(const Ctx &c, u32 idx, bool is_truth, const LVar &v, u32 allele, u32 sync, bool is_error) {
+    u8 *n = node_at(c, idx);
+    const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
+    HapHdr h = hap_load(p.w);
+    const bool ok = hap_extend_seq(c, p, h, is_truth, v, allele, sync);
+    const bool exact = exact_update(p, h);
+    if (is_error) {
+        const u32 e = ld32u((u32 *)n + 1);
+        wv_sync();
+        st32((u32 *)n + 1, e + 1);
+    }
+    wv_sync();
+    hap_store(p.w, h);
+    wv_sync();
+    return ok && exact;
+}
+
+AVK_DEV u64 keyB(u32 errors, u32 depth, u32 id) { /* (Reverse(errors), set - errors, Reverse(id)), :452-458 */
+    return ((u64)errors << 48) | ((u64)(0xFFFFu - (depth - errors)) << 32) | id;
+}
+
+/* runs one haplotype.  alleles come from optimum node `opt` (phase A pool), hap `hh`.
+ * result: errors (>= 0) and the final allele bit-sets in res[0..alw) truth, res[alw..2alw) query.
+ * returns errors, RS_OVERFLOW, or -status-100 */
+AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
+    c.qn = 0;
+    c.pool_used = 0;
+    c.nfree = 0;
+    if (c.pool_cap < 3) return RS_OVERFLOW;
+    int root = node_alloc(c);
+    {
+        u8 *n = node_at(c, (u32)root);
+        st32((u32 *)n, 0);
+        st32((u32 *)n + 1, 0);
+        hap_init(hap_ptr(n + 8, c.alw, 2, c.seqcap), c.alw);
+    }
+    wv_sync();
+    queue_push(c, keyB(0, 0, 0), (u32)root);
+    u32 next_id = 1;
+    u32 best_err = 0xFFFFFFFFu;
+    u32 min_sync = 0, af_index = 0, af_counts = 0;
+
+    while (c.qn > 0) {
+        u64 key;
+        const u32 ni = queue_pop(c, key);
+        u8 *n = node_at(c, ni);
+        const u32 errors = (u32)(key >> 48);
+        if (errors >= best_err) { /* :169 */
+            node_free(c, ni);
+            continue;
+        }
+        const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
+        HapHdr h = hap_load(p.w);
+        const u32 depth = h.t_nal + h.q_nal;
+        if (depth == c.N) { /* :180-192 finalize: both to the region end, exact iff identical */
+            trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, c.L);
+            trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, c.L);
+            wv_sync();
+            const bool touched = exact_update(p, h);
+            const u32 d = ld32u(p.wf);
+            const bool exact = touched && d >= h.t_len && d >= h.q_len;
+            if (exact) { /* errors < best_err already holds */
+                best_err = errors;
+                wv_sync();
+                for (u32 k = (u32)wv_lane(); k < c.alw; k += 64) {
+                    res[k] = p.talt[k];
+                    res[c.alw + k] = p.qalt[k];
+                }
+                wv_sync();
+            }
+            node_free(c, ni);
+            continue;
+        }
+        if (depth < min_sync) { /* :194-197 */
+            node_free(c, ni);
+            continue;
+        }
+        /* is_synchronized (haplotype_dwfa.rs:99-112); ed == 0 for every queued node */
+        if (h.t_len == h.q_len && h.t_refpos == h.q_refpos) { /* :206-217 */
+            min_sync = depth;
+            af_counts = 0;
+            af_index = min_sync;
+        }
+        const u32 vi = ld32u(c.order + depth);
+        const LVar v = c.vars[vi];
+        const bool is_truth = vi < c.T;
+        const u32 sub = is_truth ? vi : vi - c.T;
+        const u64 *in = is_truth ? in_talt : in_qalt;
+        const bool cur_alt = (wv_uni((u32)((in[sub >> 6] >> (sub & 63)) & 1))) != 0;
+        u32 sync = c.L;
+        if (depth + 1 < c.N) sync = wv_uni(c.vars[ld32u(c.order + depth + 1)].rel_pos);
+        const u32 id = ld32u((const u32 *)n);
+
+        if (!cur_alt) { /* :257-273 */
+            if (nodeB_extend(c, ni, is_truth, v, AL_REF, sync, false)) {
+                if (queue_push(c, keyB(errors, depth + 1, id), ni)) return RS_OVERFLOW;
+            } else node_free(c, ni);
+        } else { /* :274-306: (REF, error) first, then ALT unless auto-failed */
+            const bool do_alt = !(depth < af_index);
+            u32 ref_node = ni;
+            if (do_alt) { /* clone for the REF child, keep the popped node for the ALT child */
+                const int c1 = node_alloc(c);
+                if (c1 < 0) return RS_OVERFLOW;
+                node_copy(c, (u32)c1, ni);
+                ref_node = (u32)c1;
+            }
+            st32((u32 *)node_at(c, ref_node), next_id);
+            wv_sync();
+            if (nodeB_extend(c, ref_node, is_truth, v, AL_REF, sync, true)) {
+                if (queue_push(c, keyB(errors + 1, depth + 1, next_id), ref_node)) return RS_OVERFLOW;
+            } else node_free(c, ref_node);
+            next_id += 1;
+            if (do_alt) {
+                st32((u32 *)node_at(c, ni), next_id);
+                wv_sync();
+                if (nodeB_extend(c, ni, is_truth, v, AL_ALT, sync, false)) {
+                    if (queue_push(c, keyB(errors, depth + 1, next_id), ni)) return RS_OVERFLOW;
+                } else node_free(c, ni);
+                next_id += 1;
+            }
+        }
+
+        af_counts += 1; /* :309-339 */
+        if (af_counts >= 500) {
+            if (af_index >= c.N) return -100 - AVK_ST_AUTOFAIL_OOB;
+            const u32 fi = ld32u(c.order + af_index);
+            const bool f_truth = fi < c.T;
+            const u32 fsub = f_truth ? fi : fi - c.T;
+            const u32 lane = (u32)wv_lane();
+            u32 kept = 0;
+            const u32 qn0 = c.qn;
+            for (u32 base = 0; base < qn0; base += 64) {
+                const u32 j = base + lane;
+                bool keep = false, drop = false;
+                u64 k = 0;
+                u32 s = 0;
+                if (j < qn0) {
+                    k = c.qkeys[j];
+                    s = c.qslots[j];
+                    const u8 *nn = node_at(c, s);
+                    const HapPtr q = hap_ptr((u8 *)nn + 8, c.alw, 2, c.seqcap);
+                    const u32 nal = f_truth ? q.w[H_T_NAL] : q.w[H_Q_NAL];
+                    const u64 *bits = f_truth ? q.talt : q.qalt;
+                    const bool is_alt = fsub < nal && ((bits[fsub >> 6] >> (fsub & 63)) & 1);
+                    keep = !is_alt;
+                    drop = is_alt;
+                }
+                const u64 km = wv_ballot(keep), dm = wv_ballot(drop);
+                const u64 below = lane ? (~0ull >> (64 - lane)) : 0ull;
+                wv_sync();
+                if (keep) {
+                    const u32 dst = kept + (u32)avk_popc64(km & below);
+                    c.qkeys[dst] = k;
+                    c.qslots[dst] = s;
+                }
+                if (drop) c.freelist[c.nfree + (u32)avk_popc64(dm & below)] = s;
+                kept += (u32)avk_popc64(km);
+                c.nfree += (u32)avk_popc64(dm);
+                wv_sync();
+            }
+            c.qn = kept;
+            af_index += 1;
+            af_counts = 0;
+        }
+    }
+    if (best_err == 0xFFFFFFFFu) return -100 - AVK_ST_NO_GT_RESULT; /* :345-348 */
+    return (int)best_err;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* phase C — metrics (src/waffle_solver.rs:296-522, src/data_types/grouped_metrics.rs:183-277)  */
+/* ------------------------------------------------------------------------------------------ */
+AVK_DEV u32 *gfield(u32 *g, int group, int field) { return g + group * AVK_N_FIELDS + field; }
+
+/* GroupMetrics::add_truth_zygosity for one variant into joint + type group (lane-parallel caller) */
+AVK_DEV void gm_add_truth(u32 *g, u32 type, u32 w, u32 exp, u32 obs) {
+    for (int pass = 0; pass < 2; ++pass) {
+        const int grp = pass == 0 ? 0 : 1 + (int)type;
+        if (exp == obs) {
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_HAP_TRUTH_TP), exp);
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_WHAP_TRUTH_TP), exp * w);
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_GT_TRUTH_TP), 1);
+        } else {
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_HAP_TRUTH_TP), obs);
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_HAP_TRUTH_FN), exp - obs);
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_WHAP_TRUTH_TP), obs * w);
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_WHAP_TRUTH_FN), (exp - obs) * w);
+            avk_atomic_add_u32(gfield(g, grp, AVK_F_GT_TRUTH_FN), 1);
+            if (obs > 0) avk_atomic_add_u32(gfield(g, grp, AVK_F_GT_TRUTH_FN_GT), 1);
+        }
+    }
+}
+
+/* generate_allele_sequence (waffle_solver.rs:726-778) for the variants of one side that have
+ * type `ftype`, alleles taken from the optimum's bit-set.  returns the length; failed_ed out */
+AVK_DEV u32 gen_filtered(const Ctx &c, u32 v0, u32 cnt, const u64 *alt, u32 ftype, u8 *out, u32 &failed_ed) {
+    u32 cur = 0, len = 0, failed = 0;
+    for (u32 k = 0; k < cnt; ++k) {
+        const LVar v = c.vars[v0 + k];
+        if (wv_uni(v.type) != ftype) continue;
+        const bool is_alt = wv_uni((u32)((alt[k >> 6] >> (k & 63)) & 1)) != 0;
+        if (!is_alt) continue; /* :738-741 */
+        const u32 vpos = wv_uni(v.rel_pos);
+        if (vpos < cur) { /* :745-753 */
+            failed += wv_uni(v.alt_ed);
+            continue;
+        }
+        copy_bytes(out + len, c.ref + cur, vpos - cur);
+        len += vpos - cur;
+        const u32 a1 = wv_uni(v.a1_len);
+        copy_bytes(out + len, c.alle + wv_uni(v.a_off) + wv_uni(v.a0_len), a1);
+        len += a1;
+        cur = vpos + wv_uni(v.a0_len);
+    }
+    if (cur < c.L) {
+        copy_bytes(out + len, c.ref + cur, c.L - cur);
+        len += c.L - cur;
+    }
+    failed_ed = failed;
+    wv_sync();
+    return len;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* one region on one workspace tier                                                           */
+/* ------------------------------------------------------------------------------------------ */
+struct RegionOut {
+    u32 ed1, ed2, n_opt, present;
+};
+
+/* returns AVK_ST_* (>= 0) or RS_OVERFLOW */
+AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_bytes, u32 ed_cap, Ctx &c, RegionOut &out, u32 &winner_node) {
+    const AvkDevRegion reg = a.regions[r];
+    const u32 lane = (u32)wv_lane();
+    c.L = wv_uni(reg.len);
+    c.T = wv_uni(reg.t_cnt);
+    c.Q = wv_uni(reg.q_cnt);
+    c.N = c.T + c.Q;
+    c.max_branch = a.max_branch_factor;
+    const u32 v_off = wv_uni(reg.v_off);
+
+    /* sizes: sum of allele bytes and growth bound of each side */
+    u32 l_alle = 0, l_tg = 0, l_qg = 0;
+    for (u32 k = lane; k < c.N; k += 64) {
+        const AvkDevVariant dv = a.variants[v_off + k];
+        l_alle += dv.a0_len + dv.a1_len;
+        const u32 g = dv.a1_len > dv.a0_len ? dv.a1_len - dv.a0_len : 0;
+        if (k < c.T) l_tg += g;
+        else l_qg += g;
+    }
+    const u32 alle_bytes = wv_sum_u32(l_alle);
+    const u32 tg = wv_sum_u32(l_tg), qg = wv_sum_u32(l_qg);
+    c.seqcap = (c.L + (tg > qg ? tg : qg) + 7u) & ~7u;
+    if (c.seqcap == 0) c.seqcap = 8;
+    const u32 maxT = c.T > c.Q ? c.T : c.Q;
+    c.alw = maxT ? (maxT + 63) >> 6 : 1;
+    const u32 wf_full = 2 * c.seqcap + 4;
+    c.wfcap = ed_cap ? (2 * ed_cap + 2) : wf_full; /* even */
+    if (c.wfcap > wf_full) c.wfcap = wf_full;
+    c.wfs_cap = c.wfcap;
+    c.hapA_bytes = H_WORDS * 4 + 16 * c.alw + 4 * c.wfcap + 2 * c.seqcap;
+    c.nodeA_bytes = 8 + 2 * c.hapA_bytes;
+    c.hapB_bytes = H_WORDS * 4 + 16 * c.alw + 4 * 2 + 2 * c.seqcap;
+    c.nodeB_bytes = 8 + c.hapB_bytes;
+    c.optcap = c.max_branch < 4096 ? c.max_branch : 4096;
+
+    /* carve the workspace */
+    u64 off = 0;
+    u8 *refbuf = ws + off;
+    off = AVK_ALIGN8(off + c.L);
+    c.vars = (LVar *)(ws + off);
+    off = AVK_ALIGN8(off + (u64)c.N * sizeof(LVar));
+    c.alle = ws + off;
+    off = AVK_ALIGN8(off + alle_bytes);
+    c.order = (u32 *)(ws + off);
+    off = AVK_ALIGN8(off + 4ull * c.N);
+    c.bucket = (u32 *)(ws + off);
+    off = AVK_ALIGN8(off + 4ull * (c.N + 1));
+    c.gm = (u32 *)(ws + off);
+    off += 4ull * AVK_N_GROUPS * AVK_N_FIELDS;
+    c.gq = (u32 *)(ws + off);
+    off = AVK_ALIGN8(off + 4ull * AVK_N_GROUPS * AVK_N_FIELDS);
+    c.wfs = (u32 *)(ws + off);
+    off = AVK_ALIGN8(off + 4ull * c.wfs_cap);
+    c.seq_a = ws + off;
+    off += c.seqcap;
+    c.seq_b = ws + off;
+    off += c.seqcap;
+    c.optlist = (u32 *)(ws + off);
+    off = AVK_ALIGN8(off + 4ull * c.optcap);
+    c.bres = (u64 *)(ws + off);
+    off += 8ull * 2 * 2 * 2 * c.alw;
+    if (off + 64 > ws_bytes) return RS_OVERFLOW;
+    {
+        /* the rest: node pool + queue (key 8 + slot 4 + free 4 bytes per possible node) */
+        const u64 avail = ws_bytes - off;
+        u64 qcap = avail / ((u64)c.nodeB_bytes + 16);
+        if (qcap > 0x7FFFFFFFull) qcap = 0x7FFFFFFFull;
+        c.qcap = (u32)qcap;
+        c.qkeys = (u64 *)(ws + off);
+        off += 8ull * c.qcap;
+        c.qslots = (u32 *)(ws + off);
+        off += 4ull * c.qcap;
+        c.freelist = (u32 *)(ws + off);
+        off = AVK_ALIGN8(off + 4ull * c.qcap);
+        c.pool = ws + off;
+        c.pool_bytes = ws_bytes > off ? ws_bytes - off : 0;
+    }
+    if (c.qcap < 3) return RS_OVERFLOW;
+
+    /* stage the region: reference window, variants, alleles */
+    copy_bytes(refbuf, a.ref_bytes + reg.ref_off, c.L);
+    c.ref = refbuf;
+    {
+        u32 run = 0; /* allele arena offsets: sequential prefix over the variants */
+        for (u32 base = 0; base < c.N; base += 64) {
+            const u32 k = base + lane;
+            u32 mine = 0;
+            AvkDevVariant dv;
+            dv.rel_pos = dv.a0_len = dv.a1_len = dv.a_off = dv.raw_space = 0;
+            dv.type = dv.zyg = 0;
+            if (k < c.N) {
+                dv = a.variants[v_off + k];
+                mine = dv.a0_len + dv.a1_len;
+            }
+            /* exclusive prefix sum of `mine` over the lanes */
+            u32 pre = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const u32 t = wv_shfl(pre, (int)lane - o);
+                if ((int)lane >= o) pre += t;
+            }
+            const u32 excl = pre - mine;
+            const u32 total = wv_shfl(pre, 63);
+            if (k < c.N) {
+                LVar lv;
+                lv.rel_pos = dv.rel_pos;
+                lv.a0_len = dv.a0_len;
+                lv.a1_len = dv.a1_len;
+                lv.a_off = run + excl;
+                lv.raw_space = dv.raw_space;
+                lv.alt_ed = 0;
+                lv.type = dv.type;
+                lv.zyg = dv.zyg;
+                lv.pad0 = lv.pad1 = 0;
+                c.vars[k] = lv;
+                const u8 *src = a.alleles + dv.a_off;
+                for (u32 t = 0; t < mine; ++t) c.alle[run + excl + t] = src[t];
+            }
+            run += total;
+        }
+    }
+    wv_sync();
+
+    /* order_variants (query_optimizer.rs:372-381): stable sort by position of [truth.., query..] */
+    for (u32 k = lane; k < c.N; k += 64) {
+        const u32 pk = c.vars[k].rel_pos;
+        u32 rank = 0;
+        for (u32 j = 0; j < c.N; ++j) {
+            const u32 pj = c.vars[j].rel_pos;
+            rank += (pj < pk || (pj == pk && j < k)) ? 1u : 0u;
+        }
+        c.order[rank] = k;
+    }
+    wv_sync();
+
+    /* Variant::alt_ed for every variant (variants.rs:413-415) */
+    for (u32 k = 0; k < c.N; ++k) {
+        const LVar v = c.vars[k];
+        const u32 l0 = wv_uni(v.a0_len), l1 = wv_uni(v.a1_len), ao = wv_uni(v.a_off);
+        u32 e;
+        if (l0 == 1 && l1 == 1) e = wv_uni(c.alle[ao] != c.alle[ao + 1] ? 1u : 0u);
+        else {
+            const int ee = wfa_ed(c, c.alle + ao, l0, c.alle + ao + l0, l1);
+            if (ee < 0) return RS_OVERFLOW;
+            e = (u32)ee;
+        }
+        wv_sync();
+        st32(&c.vars[k].alt_ed, e);
+        wv_sync();
+    }
+
+    /* ---- phase A */
+    const int nopt = phaseA(c);
+    if (nopt == RS_OVERFLOW) return RS_OVERFLOW;
+    if (nopt < 0) return -nopt - 100;
+    out.n_opt = (u32)nopt;
+
+    /* keep the optima at the front of the pool: nodes [0, nopt) */
+    {
+        /* selection: repeatedly move optimum k to slot k (swap through a spare copy is not
+         * needed: optima that sit in slots < nopt but belong elsewhere are handled by cycling) */
+        for (u32 k = 0; k < (u32)nopt; ++k) {
+            const u32 src = ld32u(c.optlist + k);
+            if (src == k) continue;
+            /* is slot k occupied by another optimum?  then swap their places via the list */
+            int other = -1;
+            for (u32 j = k + 1; j < (u32)nopt; ++j)
+                if (ld32u(c.optlist + j) == k) other = (int)j;
+            if (other >= 0) {
+                /* swap contents of nodes src and k word by word */
+                u32 *pa = (u32 *)node_at(c, src), *pb = (u32 *)node_at(c, k);
+                wv_sync();
+                for (u32 i = lane; i < (c.nodeA_bytes >> 2); i += 64) {
+                    const u32 t = pa[i];
+                    pa[i] = pb[i];
+                    pb[i] = t;
+                }
+                wv_sync();
+                st32(c.optlist + (u32)other, src);
+            } else {
+                node_copy(c, k, src);
+            }
+            wv_sync();
+            st32(c.optlist + k, k);
+            wv_sync();
+        }
+    }
+
+    /* ---- phase B for every tied optimum (waffle_solver.rs:169-261) */
+    const u64 a_bytes = (u64)nopt * c.nodeA_bytes;
+    u8 *const poolA = c.pool;
+    const u32 nodeA_bytes = c.nodeA_bytes;
+    u32 best_total = 0xFFFFFFFFu, best_k = 0;
+    for (u32 k = 0; k < (u32)nopt; ++k) {
+        u32 errs[2];
+        for (int hh = 0; hh < 2; ++hh) {
+            c.node_bytes = c.nodeB_bytes;
+            c.pool_base = poolA + AVK_ALIGN8(a_bytes);
+            const u64 bbytes = c.pool_bytes > AVK_ALIGN8(a_bytes) ? c.pool_bytes - AVK_ALIGN8(a_bytes) : 0;
+            u64 cap = bbytes / c.nodeB_bytes;
+            if (cap > c.qcap) cap = c.qcap;
+            c.pool_cap = (u32)cap;
+            const HapPtr ap = hap_ptr(poolA + (u64)k * nodeA_bytes + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+            u64 *res = c.bres + (u64)(0 * 2 + hh) * 2 * c.alw; /* candidate slot 0 = current */
+            const int e = phaseB(c, ap.talt, ap.qalt, res);
+            if (e == RS_OVERFLOW) return RS_OVERFLOW;
+            if (e < 0) return -e - 100;
+            errs[hh] = (u32)e;
+        }
+        const u32 total = errs[0] + errs[1];
+        if (total < best_total) { /* min_by_key keeps the FIRST minimum, :264-265 */
+            best_total = total;
+            best_k = k;
+            wv_sync();
+            for (u32 i = lane; i < 4 * c.alw; i += 64) c.bres[4 * c.alw + i] = c.bres[i]; /* candidate slot 1 = best */
+            wv_sync();
+        }
+    }
+    winner_node = best_k;
+    const u64 *obs = c.bres + 4 * c.alw; /* [hap][side][alw] */
+
+    /* ---- phase C */
+    u8 *wn = poolA + (u64)best_k * nodeA_bytes;
+    const HapPtr w0 = hap_ptr(wn + 8, c.alw, c.wfcap, c.seqcap);
+    const HapPtr w1 = hap_ptr(wn + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+    const HapHdr h0 = hap_load(w0.w), h1 = hap_load(w1.w);
+    out.ed1 = h0.ed;
+    out.ed2 = h1.ed;
+
+    zero_words(c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
+    zero_words(c.gq, AVK_N_GROUPS * AVK_N_FIELDS);
+    wv_sync();
+    /* compare_expected_observed for truth and query (:296-327) + per-variant outputs */
+    u32 l_present = 0, l_bad = 0;
+    for (u32 k = lane; k < c.N; k += 64) {
+        const bool is_truth = k < c.T;
+        const u32 sub = is_truth ? k : k - c.T;
+        const u64 *e0 = is_truth ? w0.talt : w0.qalt, *e1 = is_truth ? w1.talt : w1.qalt;
+        const u64 *o0 = obs + (is_truth ? 0 : c.alw), *o1 = obs + 2 * c.alw + (is_truth ? 0 : c.alw);
+        const u32 b0 = (u32)((e0[sub >> 6] >> (sub & 63)) & 1), b1 = (u32)((e1[sub >> 6] >> (sub & 63)) & 1);
+        const u32 exp = b0 + b1;
+        const u32 ob = (u32)((o0[sub >> 6] >> (sub & 63)) & 1) + (u32)((o1[sub >> 6] >> (sub & 63)) & 1);
+        const LVar v = c.vars[k];
+        if (exp == 0) l_bad = AVK_ST_VARIANT_METRICS;
+        else if (exp < ob) l_bad = AVK_ST_TRUTH_FP;
+        else gm_add_truth(is_truth ? c.gm : c.gq, v.type, v.alt_ed, exp, ob);
+        l_present |= 1u << v.type;
+        /* VariantMetrics (variant_metrics.rs:43-101); query entries are toggled */
+        const u32 gv = v_off + k;
+        u32 cls = exp == ob ? AVK_CLASS_TP : AVK_CLASS_FN;
+        u32 ea = exp, oa = ob;
+        if (!is_truth) {
+            cls = cls == AVK_CLASS_FN ? AVK_CLASS_FP : cls;
+            ea = ob;
+            oa = exp;
+        }
+        a.var_expected[gv] = (u8)ea;
+        a.var_observed[gv] = (u8)oa;
+        a.var_class[gv] = (u8)cls;
+        a.var_zyg[gv] = (u8)(b0 && b1 ? AVK_ZYG_HOM_ALT : (b0 ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_PHASED_HET01));
+    }
+    const u32 bad = wv_max_u32(l_bad);
+    if (bad) return (int)bad;
+    u32 present = 0;
+    for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t)
+        if (wv_ballot((l_present >> t) & 1)) present |= 1u << t;
+    wv_sync();
+    /* add_swap_benchmark (:269, grouped_metrics.rs:268-277): query columns := query-run truth columns */
+    for (u32 g = lane; g < AVK_N_GROUPS; g += 64) {
+        u32 *d = c.gm + g * AVK_N_FIELDS;
+        const u32 *s = c.gq + g * AVK_N_FIELDS;
+        d[AVK_F_GT_QUERY_TP] = s[AVK_F_GT_TRUTH_TP];
+        d[AVK_F_GT_QUERY_FP] = s[AVK_F_GT_TRUTH_FN];
+        d[AVK_F_GT_QUERY_FP_GT] = s[AVK_F_GT_TRUTH_FN_GT];
+        d[AVK_F_HAP_QUERY_TP] = s[AVK_F_HAP_TRUTH_TP];
+        d[AVK_F_HAP_QUERY_FP] = s[AVK_F_HAP_TRUTH_FN];
+        d[AVK_F_WHAP_QUERY_TP] = s[AVK_F_WHAP_TRUTH_TP];
+        d[AVK_F_WHAP_QUERY_FP] = s[AVK_F_WHAP_TRUTH_FN];
+    }
+    wv_sync();
+
+    /* add_basepair_stats (:335-449).  The optimizer's own sequences are the regenerated ones
+     * (asserted equal at :364-367), ed(truth,query) is the node's finalized DWFA distance. */
+    const int SUP[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL, AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
+    u32 tcount[8], qcount[8];
+    for (int s = 0; s < 8; ++s) {
+        u32 lt = 0, lq = 0;
+        for (u32 k = lane; k < c.N; k += 64) {
+            if (c.vars[k].type == SUP[s]) {
+                if (k < c.T) lt++;
+                else lq++;
+            }
+        }
+        tcount[s] = wv_sum_u32(lt);
+        qcount[s] = wv_sum_u32(lq);
+        present |= 1u << SUP[s];
+    }
+    for (int hh = 0; hh < 2; ++hh) {
+        const HapPtr &wp = hh == 0 ? w0 : w1;
+        const HapHdr &hd = hh == 0 ? h0 : h1;
+        const int ert = wfa_ed(c, c.ref, c.L, wp.tseq, hd.t_len);
+        if (ert < 0) return RS_OVERFLOW;
+        const int erq = wfa_ed(c, c.ref, c.L, wp.qseq, hd.q_len);
+        if (erq < 0) return RS_OVERFLOW;
+        const u32 X = 2u * (u32)ert, Y = 2u * (u32)erq, Z = 2u * hd.ed;
+        const u32 tp = (X + Y - Z) / 2;
+        u32 add[4] = {tp, X - tp + 2 * hd.t_skip, tp, Y - tp + 2 * hd.q_skip}; /* + skip metrics :378-381 */
+        wv_sync();
+        if (lane < 4) c.gm[AVK_F_BP_TRUTH_TP + lane] += add[lane];
+        wv_sync();
+        for (int s = 0; s < 8; ++s) {
+            u32 q_tp = 0, q_fp = 0, t_tp = 0, t_fn = 0;
+            if (qcount[s]) {
+                if (qcount[s] == c.Q) { /* filtered query == the full query haplotype */
+                    q_tp = tp;
+                    q_fp = Y - tp + 2 * hd.q_skip;
+                } else {
+                    u32 failed;
+                    const u32 fl = gen_filtered(c, c.T, c.Q, wp.qalt, (u32)SUP[s], c.seq_a, failed);
+                    const int y2 = wfa_ed(c, c.ref, c.L, c.seq_a, fl);
+                    if (y2 < 0) return RS_OVERFLOW;
+                    const int z2 = wfa_ed(c, wp.tseq, hd.t_len, c.seq_a, fl);
+                    if (z2 < 0) return RS_OVERFLOW;
+                    const u32 Y2 = 2u * (u32)y2, Z2 = 2u * (u32)z2;
+                    const u32 tp2 = (X + Y2 - Z2) / 2;
+                    q_tp = tp2;
+                    q_fp = Y2 - tp2 + 2 * failed;
+                }
+            }
+            if (tcount[s]) {
+                if (tcount[s] == c.T) {
+                    t_tp = tp;
+                    t_fn = X - tp + 2 * hd.t_skip;
+                } else {
+                    u32 failed;
+                    const u32 fl = gen_filtered(c, 0, c.T, wp.talt, (u32)SUP[s], c.seq_a, failed);
+                    const int x2 = wfa_ed(c, c.ref, c.L, c.seq_a, fl);
+                    if (x2 < 0) return RS_OVERFLOW;
+                    const int z2 = wfa_ed(c, c.seq_a, fl, wp.qseq, hd.q_len);
+                    if (z2 < 0) return RS_OVERFLOW;
+                    const u32 X2 = 2u * (u32)x2, Z2 = 2u * (u32)z2;
+                    const u32 tp2 = (X2 + Y - Z2) / 2;
+                    t_tp = tp2;
+                    t_fn = X2 - tp2 + 2 * failed;
+                }
+            }
+            wv_sync();
+            if (lane == 0) {
+                u32 *g = c.gm + (1 + SUP[s]) * AVK_N_FIELDS;
+                g[AVK_F_BP_TRUTH_TP] += t_tp;
+                g[AVK_F_BP_TRUTH_FN] += t_fn;
+                g[AVK_F_BP_QUERY_TP] += q_tp;
+                g[AVK_F_BP_QUERY_FP] += q_fp;
+            }
+            wv_sync();
+        }
+    }
+
+    /* add_record_basepair_stats (:455-522): totals from the INPUT zygosities and raw allele space */
+    wv_sync();
+    {
+        u32 *tot = c.gq; /* reuse: tot[0..12] truth totals per group, tot[16..28] query totals */
+        zero_words(tot, 32);
+        wv_sync();
+        for (u32 k = lane; k < c.N; k += 64) {
+            const LVar v = c.vars[k];
+            const u32 z = v.zyg;
+            const u32 cntz = z == AVK_ZYG_HOM_ALT ? 2u : ((z == AVK_ZYG_UNPHASED_HET || z == AVK_ZYG_PHASED_HET01 || z == AVK_ZYG_PHASED_HET10) ? 1u : 0u);
+            const u32 val = cntz * v.raw_space;
+            const u32 basei = k < c.T ? 0 : 16;
+            avk_atomic_add_u32(tot + basei, val);
+            avk_atomic_add_u32(tot + basei + 1 + v.type, val);
+        }
+        wv_sync();
+        u32 l_err = 0;
+        for (u32 g = lane; g < AVK_N_GROUPS; g += 64) {
+            const bool on = g == 0 || ((present >> (g - 1)) & 1);
+            if (on) {
+                u32 *d = c.gm + g * AVK_N_FIELDS;
+                const u32 tfn = d[AVK_F_BP_TRUTH_FN], qfp = d[AVK_F_BP_QUERY_FP];
+                const u32 ttp = 2 * tot[g] - tfn, qtp = 2 * tot[16 + g] - qfp;
+                if (g == 0 && (ttp < d[AVK_F_BP_TRUTH_TP] || qtp < d[AVK_F_BP_QUERY_TP])) l_err = AVK_ST_RECORD_BP;
+                d[AVK_F_RBP_TRUTH_TP] += ttp;
+                d[AVK_F_RBP_TRUTH_FN] += tfn;
+                d[AVK_F_RBP_QUERY_TP] += qtp;
+                d[AVK_F_RBP_QUERY_FP] += qfp;
+            }
+        }
+        const u32 e = wv_max_u32(l_err);
+        if (e) return (int)e;
+    }
+    wv_sync();
+    out.present = present;
+    return AVK_ST_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* persistent wave: pulls regions, walks the tiers, writes results, keeps a private tally      */
+/* ------------------------------------------------------------------------------------------ */
+AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
+    const AvkDevRegion reg = a.regions[r];
+    const u32 lane = (u32)wv_lane();
+    if (lane == 0) {
+        a.status[r] = status;
+        a.ed_h1[r] = 0;
+        a.ed_h2[r] = 0;
+        a.n_optima[r] = 0;
+        a.type_present[r] = 0;
+    }
+    const u32 n = reg.t_cnt + reg.q_cnt;
+    for (u32 k = lane; k < n; k += 64) {
+        a.var_expected[reg.v_off + k] = 0;
+        a.var_observed[reg.v_off + k] = 0;
+        a.var_class[reg.v_off + k] = 0;
+        a.var_zyg[reg.v_off + k] = 0;
+    }
+    if (a.group_metrics) zero_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, AVK_N_GROUPS * AVK_N_FIELDS);
+    if (a.seq_bytes && a.seq_len && lane < 5) a.seq_len[5 * (u64)r + lane] = 0;
+}
+
+AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+    const u32 lane = (u32)wv_lane();
+    u64 tally[5] = {0, 0, 0, 0, 0};
+    u32 n_ok = 0, n_err = 0;
+    u32 tier_hits[4] = {0, 0, 0, 0};
+    u8 *hbm_slice = a.hbm_ws ? a.hbm_ws + (u64)wave_id * a.tier[a.first_tier == 2 ? 2 : 1].ws_bytes : (u8 *)0;
+
+    for (;;) {
+        u32 idx = 0;
+        if (lane == 0) idx = avk_atomic_add_u32_global(a.work_counter, 1);
+        idx = wv_shfl(idx, 0);
+        idx = wv_uni(idx);
+        if (idx >= a.n_regions) break;
+        const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : idx;
+        const AvkDevRegion reg = a.regions[r];
+        const u32 pre = wv_uni(reg.pre_status);
+        if (pre) {
+            write_failed_region(a, r, (int)pre);
+            n_err += 1;
+            continue;
+        }
+        Ctx c;
+        RegionOut out;
+        out.ed1 = out.ed2 = out.n_opt = out.present = 0;
+        u32 winner = 0;
+        int st = RS_OVERFLOW;
+        int used_tier = -1;
+        if (a.first_tier == 0) {
+            if (lds_slice && a.tier[0].ws_bytes) {
+                st = solve_region_tier(a, r, lds_slice, a.tier[0].ws_bytes, a.tier[0].ed_cap, c, out, winner);
+                used_tier = 0;
+            }
+            if (st == RS_OVERFLOW && hbm_slice) {
+                wv_sync();
+                st = solve_region_tier(a, r, hbm_slice, a.tier[1].ws_bytes, a.tier[1].ed_cap, c, out, winner);
+                used_tier = 1;
+            }
+            if (st == RS_OVERFLOW) { /* hand over to the overflow pass */
+                if (lane == 0) {
+                    const u32 slot = avk_atomic_add_u32_global(a.overflow_count, 1);
+                    a.overflow_list[slot] = r;
+                    a.status[r] = -1;
+                }
+                continue;
+            }
+        } else {
+            st = solve_region_tier(a, r, hbm_slice, a.tier[2].ws_bytes, a.tier[2].ed_cap, c, out, winner);
+            used_tier = 2;
+            if (st == RS_OVERFLOW) {
+                st = AVK_ST_CAPACITY;
+                used_tier = 3;
+            }
+        }
+        tier_hits[used_tier] += 1;
+        if (st != AVK_ST_OK) {
+            write_failed_region(a, r, st);
+            n_err += 1;
+            continue;
+        }
+        /* results of an Ok region */
+        if (lane == 0) {
+            a.status[r] = 0;
+            a.ed_h1[r] = out.ed1;
+            a.ed_h2[r] = out.ed2;
+            a.n_optima[r] = out.n_opt;
+            a.type_present[r] = (u16)out.present;
+        }
+        if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
+        for (int j = 0; j < 5; ++j) {
+            const u32 i = (u32)j * 64 + lane;
+            if (i < AVK_N_GROUPS * AVK_N_FIELDS) tally[j] += c.gm[i];
+        }
+        n_ok += 1;
+        if (a.seq_bytes && a.seq_len && reg.seq_stride) { /* SequenceBundle, waffle_solver.rs:237-246 */
+            u8 *wn = c.pool + (u64)winner * c.nodeA_bytes;
+            const HapPtr w0 = hap_ptr(wn + 8, c.alw, c.wfcap, c.seqcap);
+            const HapPtr w1 = hap_ptr(wn + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+            const HapHdr h0 = hap_load(w0.w), h1 = hap_load(w1.w);
+            const u8 *src[5] = {c.ref, w0.tseq, w1.tseq, w0.qseq, w1.qseq};
+            const u32 len[5] = {c.L, h0.t_len, h1.t_len, h0.q_len, h1.q_len};
+            for (int k = 0; k < 5; ++k) {
+                const u32 nbytes = len[k] < reg.seq_stride ? len[k] : reg.seq_stride;
+                copy_bytes(a.seq_bytes + reg.seq_off + (u64)k * reg.seq_stride, src[k], nbytes);
+                if (lane == 0) a.seq_len[5 * (u64)r + k] = nbytes;
+            }
+        }
+        wv_sync();
+    }
+
+    /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) */
+    for (int j = 0; j < 5; ++j) {
+        const u32 i = (u32)j * 64 + lane;
+        if (i < AVK_N_GROUPS * AVK_N_FIELDS && tally[j]) avk_atomic_add_u64_global(a.tally + i, tally[j]);
+    }
+    if (lane == 0) {
+        if (n_ok) avk_atomic_add_u64_global(a.tally + AVK_TALLY_SOLVED, n_ok);
+        if (n_err) avk_atomic_add_u64_global(a.tally + AVK_TALLY_ERRORS, n_err);
+        for (int t = 0; t < 4; ++t)
+            if (tier_hits[t]) avk_atomic_add_u64_global(a.tier_counts + t, tier_hits[t]);
+    }
+}
+
+} // namespace avk
+#endif

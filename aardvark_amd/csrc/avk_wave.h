@@ -1,0 +1,144 @@
+/*
+ * avk_wave.h — the wavefront-level primitives the solver kernels are written against.
+ *
+ * The solver (avk_solver.inl) maps ONE region to ONE 64-lane wavefront: control flow is
+ * wave-uniform, data-parallel work (byte compares along wavefront diagonals, sequence appends,
+ * node copies, priority-queue scans) is spread over the 64 lanes and combined with ballot /
+ * cross-lane reductions.  Everything cross-lane goes through the few functions below.
+ *
+ * Two bindings:
+ *   - hipcc (gfx950): the real thing — __ballot, ds_bpermute shuffles, DPP-free butterfly
+ *     reductions, readfirstlane for uniform values.
+ *   - AVK_EMU (g++, tests/emu/): a kernel-logic emulator that runs the 64 lanes of a wave as 64
+ *     cooperative fibers and rendezvouses at every primitive.  It exists so that the SAME kernel
+ *     source can be executed and fuzzed against the oracle in the GPU-less dev container
+ *     (`-m "not gpu"` tests).  It is test infrastructure: it is never compiled into
+ *     libaardvark_amd.so and is not a fallback.
+ */
+#ifndef AVK_WAVE_H
+#define AVK_WAVE_H
+
+#include <stdint.h>
+
+#ifdef AVK_EMU
+/* ------------------------------------------------------------------------------ emulator */
+#define AVK_DEV static inline
+#define AVK_DEV_NOINLINE static
+namespace avk_emu {
+/* deposits `v` for this lane, runs the other lanes up to the same call site, returns the 64
+ * deposited values.  `site` must be identical on all lanes (checked: catches divergent use). */
+const uint64_t *gather(uint64_t v, uint32_t site);
+int lane();
+} // namespace avk_emu
+#define AVK_SITE ((uint32_t)__LINE__)
+
+AVK_DEV int wv_lane() { return avk_emu::lane(); }
+AVK_DEV uint64_t wv_ballot_(bool p, uint32_t site) {
+    const uint64_t *g = avk_emu::gather(p ? 1 : 0, site);
+    uint64_t m = 0;
+    for (int i = 0; i < 64; ++i) m |= (g[i] & 1ull) << i;
+    return m;
+}
+AVK_DEV uint32_t wv_shfl_(uint32_t v, int src, uint32_t site) { return (uint32_t)avk_emu::gather(v, site)[src & 63]; }
+AVK_DEV uint32_t wv_uni_(uint32_t v, uint32_t site) { /* value must already be wave-uniform */
+    const uint64_t *g = avk_emu::gather(v, site | 0x80000000u);
+    return (uint32_t)g[0];
+}
+AVK_DEV uint32_t wv_max_u32_(uint32_t v, uint32_t site) {
+    const uint64_t *g = avk_emu::gather(v, site);
+    uint32_t m = 0;
+    for (int i = 0; i < 64; ++i) m = (uint32_t)g[i] > m ? (uint32_t)g[i] : m;
+    return m;
+}
+AVK_DEV uint32_t wv_min_u32_(uint32_t v, uint32_t site) {
+    const uint64_t *g = avk_emu::gather(v, site);
+    uint32_t m = 0xFFFFFFFFu;
+    for (int i = 0; i < 64; ++i) m = (uint32_t)g[i] < m ? (uint32_t)g[i] : m;
+    return m;
+}
+AVK_DEV uint32_t wv_sum_u32_(uint32_t v, uint32_t site) {
+    const uint64_t *g = avk_emu::gather(v, site);
+    uint32_t s = 0;
+    for (int i = 0; i < 64; ++i) s += (uint32_t)g[i];
+    return s;
+}
+AVK_DEV uint64_t wv_min_u64_(uint64_t v, uint32_t site) {
+    const uint64_t *g = avk_emu::gather(v, site);
+    uint64_t m = ~0ull;
+    for (int i = 0; i < 64; ++i) m = g[i] < m ? g[i] : m;
+    return m;
+}
+AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
+#define wv_ballot(p) wv_ballot_((p), AVK_SITE)
+#define wv_shfl(v, src) wv_shfl_((v), (src), AVK_SITE)
+#define wv_uni(v) wv_uni_((v), AVK_SITE)
+#define wv_max_u32(v) wv_max_u32_((v), AVK_SITE)
+#define wv_min_u32(v) wv_min_u32_((v), AVK_SITE)
+#define wv_sum_u32(v) wv_sum_u32_((v), AVK_SITE)
+#define wv_min_u64(v) wv_min_u64_((v), AVK_SITE)
+#define wv_sync() wv_sync_(AVK_SITE)
+
+AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+AVK_DEV int avk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
+AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
+
+#else
+/* -------------------------------------------------------------------------------- gfx950 */
+#include <hip/hip_runtime.h>
+#define AVK_DEV __device__ __forceinline__
+#define AVK_DEV_NOINLINE __device__ __noinline__
+
+AVK_DEV int wv_lane() { return (int)__lane_id(); }
+AVK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
+AVK_DEV uint32_t wv_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+/* a value that is identical on every lane: move it to an SGPR so branches on it are scalar */
+AVK_DEV uint32_t wv_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+AVK_DEV uint32_t wv_max_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = t > v ? t : v;
+    }
+    return wv_uni(v);
+}
+AVK_DEV uint32_t wv_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+        v = t < v ? t : v;
+    }
+    return wv_uni(v);
+}
+AVK_DEV uint32_t wv_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
+    return wv_uni(v);
+}
+AVK_DEV uint64_t wv_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
+        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
+        uint64_t t = ((uint64_t)hi << 32) | lo;
+        v = t < v ? t : v;
+    }
+    uint32_t lo = wv_uni((uint32_t)v), hi = wv_uni((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+/* orders this wave's own memory traffic: lanes of one wave communicate through LDS / their
+ * private HBM slice, the hardware keeps a wave's DS and VMEM operations in issue order, so only
+ * the compiler has to be stopped from moving or caching accesses across this point */
+AVK_DEV void wv_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
+AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+AVK_DEV int avk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
+AVK_DEV int avk_popc64(uint64_t x) { return __popcll(x); }
+#endif
+
+#endif /* AVK_WAVE_H */

@@ -35,7 +35,7 @@ enum { A_UNKNOWN = 0, A_REF = 1, A_ALT = 2 }; /* Allele, phase_enums.rs:20-24 */
 /* statistics (sizing aid for the kernels) */
 struct Stats {
     uint64_t max_pops_a = 0, max_queue_a = 0, max_pops_b = 0, max_queue_b = 0, max_ed = 0, max_optima = 0;
-    uint64_t total_pops_a = 0, total_pops_b = 0, total_wfa = 0;
+    uint64_t total_pops_a = 0, total_pops_b = 0, total_wfa = 0, incr_mismatch = 0;
     void merge(const Stats &o) {
         max_pops_a = std::max(max_pops_a, o.max_pops_a);
         max_queue_a = std::max(max_queue_a, o.max_queue_a);
@@ -46,6 +46,7 @@ struct Stats {
         total_pops_a += o.total_pops_a;
         total_pops_b += o.total_pops_b;
         total_wfa += o.total_wfa;
+        incr_mismatch += o.incr_mismatch;
     }
 };
 thread_local Stats t_stats;
@@ -903,6 +904,7 @@ int add_basepair_stats(const Region &problem, Span reference, CompareBenchmark *
         if (truth_seq != (hap == 0 ? oh.truth_seq1 : oh.truth_seq2)) return AVK_ST_SEQ_MISMATCH; /* :364-367 */
         if (query_seq != (hap == 0 ? oh.query_seq1 : oh.query_seq2)) return AVK_ST_SEQ_MISMATCH;
 
+        if (wfa_ed(truth_seq, query_seq) != (hap == 0 ? oh.ed1 : oh.ed2)) t_stats.incr_mismatch += 1; /* invariant the kernels rely on */
         bench->group_metrics.add_basepair(perform_basepair_compare(ref_window, truth_seq, query_seq), -1);
         SummaryMetrics skip; /* :378-381 */
         skip.truth_fn = 2 * (uint64_t)truth_ed;
@@ -1032,11 +1034,13 @@ int generate_exact_match(const Region &problem, Span ref_window, const Optimized
  * The host side of the product rejects the same regions with the same status. */
 int validate_region(const Region &p, size_t contig_len) {
     if (p.start > p.end || p.end > contig_len) return AVK_ST_INVALID_INPUT;
+    if (p.truth.size() + p.query.size() > 60000) return AVK_ST_INVALID_INPUT; /* batch format limit of the product */
     for (int side = 0; side < 2; ++side) {
         const std::vector<Var> &vs = side == 0 ? p.truth : p.query;
         uint64_t last = 0;
         for (const Var &v : vs) {
             if (v.allele0.n == 0 || v.allele1.n == 0) return AVK_ST_INVALID_INPUT;
+            if (v.raw_allele_space < std::max(v.allele0.n, v.allele1.n)) return AVK_ST_INVALID_INPUT; /* variants.rs:364-370 */
             if (v.variant_type >= AVK_N_VARIANT_TYPES || v.zyg > AVK_ZYG_HOM_ALT) return AVK_ST_INVALID_INPUT;
             if (v.position < p.start || v.position + v.allele0.n > p.end) return AVK_ST_INVALID_INPUT;
             if (v.position < last) return AVK_ST_INVALID_INPUT;
@@ -1473,6 +1477,7 @@ void orc_last_stats(uint64_t out[16]) {
     out[6] = g_stats.total_pops_a;
     out[7] = g_stats.total_pops_b;
     out[8] = g_stats.total_wfa;
+    out[9] = g_stats.incr_mismatch;
 }
 
 } /* extern "C" */

@@ -97,7 +97,8 @@ int      orc_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *
 /* search statistics of the last orc_compare_batch on this process (sizing aid for the kernels):
  * [0] max pops in optimize_sequences, [1] max live queue there, [2] max pops in optimize_gt_alleles,
  * [3] max live queue there, [4] max edit distance seen by any DWFA, [5] max tied optima,
- * [6] total pops A, [7] total pops B, [8] total wfa_ed calls */
+ * [6] total pops A, [7] total pops B, [8] total wfa_ed calls, [9] haplotypes whose incremental DWFA
+ * distance differed from a fresh wfa_ed of the final sequences (must stay 0) */
 void     orc_last_stats(uint64_t out[16]);
 
 #ifdef __cplusplus

@@ -1,0 +1,303 @@
+/*
+ * wave_emu.cpp — kernel-logic emulator for the GPU-less dev container.  TEST INFRASTRUCTURE.
+ *
+ * Compiles the SAME solver source the HIP library is built from (aardvark_amd/csrc/avk_solver.inl)
+ * with AVK_EMU and executes each 64-lane wavefront as 64 cooperative fibers on one OS thread.
+ * Every wave primitive (ballot, shuffle, reductions, wv_sync, wv_uni) is a rendezvous of the 64
+ * fibers; the call site of each rendezvous is compared across lanes, so divergent use of a wave
+ * primitive (which would hang or mis-ballot on the GPU) aborts the test.  Memory is plain host
+ * memory: the "LDS slice" and the HBM workspaces are heap buffers.
+ *
+ * Used by tests/test_emu_parity.py to fuzz the kernel logic against the oracle without a GPU.
+ * Never linked into libaardvark_amd.so; not a fallback path.
+ */
+#define AVK_EMU 1
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../aardvark_amd/csrc/avk_wave.h"
+
+/* ---- fibers ------------------------------------------------------------------------------ */
+extern "C" void avk_emu_switch(void **save_sp, void *load_sp);
+asm(R"(
+.text
+.globl avk_emu_switch
+.type avk_emu_switch,@function
+avk_emu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+.size avk_emu_switch,.-avk_emu_switch
+)");
+
+namespace avk_emu {
+
+struct Wave {
+    void *sp[64];
+    void *main_sp;
+    char *stacks;
+    size_t stack_bytes;
+    int cur;
+    uint32_t gen[64];
+    bool done[64];
+    uint64_t slots[2][64];
+    uint32_t sites[2][64];
+    void (*fn)(void *, int);
+    void *arg;
+};
+static thread_local Wave *t_wave = nullptr;
+
+int lane() { return t_wave->cur; }
+
+static void switch_to(Wave *w, int from, int to) {
+    w->cur = to;
+    avk_emu_switch(&w->sp[from], w->sp[to]);
+}
+
+const uint64_t *gather(uint64_t v, uint32_t site) {
+    Wave *w = t_wave;
+    const int me = w->cur;
+    const uint32_t g = w->gen[me]++;
+    w->slots[g & 1][me] = v;
+    w->sites[g & 1][me] = site;
+    switch_to(w, me, (me + 1) & 63);
+    /* back: every lane has deposited generation g */
+    const uint32_t *s = w->sites[g & 1];
+    for (int i = 0; i < 64; ++i) {
+        if (s[i] != site || w->gen[i] < g + 1) {
+            fprintf(stderr, "avk_emu: DIVERGENT wave primitive: lane %d at site %u, lane %d at site %u (gen %u/%u)\n", me, site & 0x7FFFFFFFu, i,
+                    s[i] & 0x7FFFFFFFu, g, w->gen[i]);
+            abort();
+        }
+    }
+    if (site & 0x80000000u) { /* wv_uni: the value must already be uniform */
+        const uint64_t *vals = w->slots[g & 1];
+        for (int i = 1; i < 64; ++i)
+            if (vals[i] != vals[0]) {
+                fprintf(stderr, "avk_emu: wv_uni on a NON-UNIFORM value at site %u: lane0=%llu lane%d=%llu\n", site & 0x7FFFFFFFu,
+                        (unsigned long long)vals[0], i, (unsigned long long)vals[i]);
+                abort();
+            }
+    }
+    return w->slots[g & 1];
+}
+
+static void fiber_entry() {
+    Wave *w = t_wave;
+    const int me = w->cur;
+    w->fn(w->arg, me);
+    w->done[me] = true;
+    /* all lanes must have passed the same number of rendezvous */
+    for (int i = 0; i < 64; ++i)
+        if (w->gen[i] != w->gen[me]) {
+            fprintf(stderr, "avk_emu: lane %d finished after %u rendezvous but lane %d is at %u\n", me, w->gen[me], i, w->gen[i]);
+            abort();
+        }
+    if (me == 63) {
+        w->cur = -1;
+        void *dummy;
+        avk_emu_switch(&dummy, w->main_sp);
+    } else {
+        void *dummy;
+        w->cur = me + 1;
+        avk_emu_switch(&dummy, w->sp[me + 1]);
+    }
+    abort(); /* unreachable */
+}
+
+/* runs fn(arg, lane) on 64 lanes as one wavefront */
+static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
+    w->fn = fn;
+    w->arg = arg;
+    for (int i = 0; i < 64; ++i) {
+        w->gen[i] = 0;
+        w->done[i] = false;
+        char *top = w->stacks + (size_t)(i + 1) * w->stack_bytes;
+        uintptr_t t = ((uintptr_t)top & ~(uintptr_t)15) - 8; /* rsp % 16 == 8 at function entry */
+        void **sp = (void **)t;
+        *--sp = (void *)&fiber_entry; /* return address popped by `ret` */
+        for (int k = 0; k < 6; ++k) *--sp = nullptr;
+        w->sp[i] = (void *)sp;
+    }
+    t_wave = w;
+    w->cur = 0;
+    avk_emu_switch(&w->main_sp, w->sp[0]);
+    t_wave = nullptr;
+}
+
+} // namespace avk_emu
+
+#include "../../aardvark_amd/csrc/avk_pack.h"
+#include "../../aardvark_amd/csrc/avk_solver.inl"
+
+namespace {
+
+struct WaveTask {
+    const AvkKernelArgs *args;
+    uint32_t wave_id;
+    uint8_t *lds;
+};
+
+void lane_main(void *p, int /*lane*/) {
+    WaveTask *t = (WaveTask *)p;
+    avk::region_worker(*t->args, t->wave_id, t->lds);
+}
+
+} // namespace
+
+extern "C" {
+
+/* Mirrors avk_compare_batch on emulated wavefronts.  lds_bytes / ws_bytes / big_ws_bytes are the
+ * per-wave workspace sizes of the three tiers (0 disables a tier), lds_ed_cap the wavefront cap
+ * of the LDS tier, n_waves the number of persistent waves, threads the OS threads running them.
+ * tier_counts[4] receives how many regions each tier solved (+ capacity failures). */
+int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
+                      const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t ws_bytes,
+                      uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
+    std::vector<uint64_t> base(n_contigs), lens(n_contigs);
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        base[c] = total;
+        lens[c] = ref_lens[c];
+        total += ref_lens[c];
+    }
+    std::vector<uint8_t> refcat(total + 1);
+    for (uint32_t c = 0; c < n_contigs; ++c) memcpy(refcat.data() + base[c], refs[c], ref_lens[c]);
+
+    avk::PackedBatch pb;
+    std::string err;
+    const bool want_seq = cfg->enable_sequences && out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride;
+    int rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err);
+    if (rc) {
+        fprintf(stderr, "emu pack error: %s\n", err.c_str());
+        return rc;
+    }
+    const uint64_t n = batch->n_regions, nv = pb.variants.size();
+    std::vector<int32_t> status(n, -1);
+    std::vector<uint32_t> ed1(n), ed2(n), nopt(n);
+    std::vector<uint16_t> present(n);
+    std::vector<uint32_t> gm(out->group_metrics ? n * AVK_N_GROUPS * AVK_N_FIELDS : 0);
+    std::vector<uint8_t> vexp(nv + 1), vobs(nv + 1), vcls(nv + 1), vzyg(nv + 1);
+    std::vector<uint64_t> tally(AVK_TALLY_LEN, 0), tiers(4, 0);
+    std::vector<uint32_t> overflow_list(n + 1);
+    uint32_t overflow_count = 0, work_counter = 0;
+
+    AvkKernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.regions = pb.regions.data();
+    a.variants = pb.variants.data();
+    a.alleles = pb.alleles.data();
+    a.ref_bytes = refcat.data();
+    a.n_regions = (uint32_t)n;
+    a.max_branch_factor = cfg->max_branch_factor;
+    a.enable_exact_shortcut = cfg->enable_exact_shortcut;
+    a.work_counter = &work_counter;
+    a.overflow_list = overflow_list.data();
+    a.overflow_count = &overflow_count;
+    a.tier[0].ws_bytes = lds_bytes;
+    a.tier[0].ed_cap = lds_ed_cap;
+    a.tier[1].ws_bytes = ws_bytes;
+    a.tier[1].ed_cap = 0;
+    a.tier[2].ws_bytes = big_ws_bytes;
+    a.tier[2].ed_cap = 0;
+    a.status = status.data();
+    a.ed_h1 = ed1.data();
+    a.ed_h2 = ed2.data();
+    a.n_optima = nopt.data();
+    a.type_present = present.data();
+    a.group_metrics = out->group_metrics ? gm.data() : nullptr;
+    a.var_expected = vexp.data();
+    a.var_observed = vobs.data();
+    a.var_class = vcls.data();
+    a.var_zyg = vzyg.data();
+    a.seq_bytes = want_seq ? out->seq_bytes : nullptr;
+    a.seq_len = want_seq ? out->seq_len : nullptr;
+    a.tally = tally.data();
+    a.tier_counts = tiers.data();
+
+    if (cfg->max_branch_factor == 0) { /* query_optimizer.rs:177 */
+        for (uint64_t r = 0; r < n; ++r)
+            if (!pb.regions[r].pre_status) pb.regions[r].pre_status = AVK_ST_BRANCH_FACTOR;
+    }
+
+    auto run_pass = [&](uint32_t waves, uint64_t slice_bytes, uint64_t lds) {
+        if (threads < 1) threads = 1;
+        std::vector<uint8_t> hbm(slice_bytes ? (size_t)waves * slice_bytes : 0);
+        a.hbm_ws = slice_bytes ? hbm.data() : nullptr;
+        std::atomic<uint32_t> next(0);
+        auto worker = [&]() {
+            avk_emu::Wave w;
+            w.stack_bytes = 256 * 1024;
+            std::vector<char> stacks(64 * w.stack_bytes + 64);
+            w.stacks = stacks.data();
+            std::vector<uint8_t> ldsbuf(lds ? lds : 8);
+            for (;;) {
+                uint32_t wid = next.fetch_add(1);
+                if (wid >= waves) break;
+                WaveTask t{&a, wid, lds ? ldsbuf.data() : nullptr};
+                avk_emu::run_wave(&w, lane_main, &t);
+            }
+        };
+        std::vector<std::thread> ts;
+        for (int i = 0; i < threads; ++i) ts.emplace_back(worker);
+        for (auto &t : ts) t.join();
+    };
+
+    a.first_tier = 0;
+    run_pass(n_waves ? n_waves : 1, ws_bytes, lds_bytes);
+    if (overflow_count) {
+        const uint32_t novf = overflow_count;
+        std::vector<uint32_t> list(overflow_list.begin(), overflow_list.begin() + novf);
+        a.work_list = list.data();
+        a.n_regions = novf;
+        work_counter = 0;
+        overflow_count = 0;
+        a.first_tier = 2;
+        if (big_ws_bytes) run_pass(novf < 4 ? novf : 4, big_ws_bytes, 0);
+        else {
+            for (uint32_t i = 0; i < novf; ++i) status[list[i]] = AVK_ST_CAPACITY;
+            tiers[3] += novf;
+            tally[AVK_TALLY_ERRORS] += novf;
+        }
+        a.work_list = nullptr;
+    }
+
+    /* copy back in caller order */
+    for (uint64_t r = 0; r < n; ++r) {
+        out->status[r] = status[r];
+        if (out->ed_h1) out->ed_h1[r] = ed1[r];
+        if (out->ed_h2) out->ed_h2[r] = ed2[r];
+        if (out->n_optima) out->n_optima[r] = nopt[r];
+        if (out->type_present) out->type_present[r] = present[r];
+    }
+    if (out->group_metrics) memcpy(out->group_metrics, gm.data(), gm.size() * sizeof(uint32_t));
+    for (uint64_t v = 0; v < nv; ++v) {
+        const uint64_t hv = pb.dev2host[v];
+        if (out->var_expected) out->var_expected[hv] = vexp[v];
+        if (out->var_observed) out->var_observed[hv] = vobs[v];
+        if (out->var_class) out->var_class[hv] = vcls[v];
+        if (out->var_zyg) out->var_zyg[hv] = vzyg[v];
+    }
+    if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
+    if (tier_counts) memcpy(tier_counts, tiers.data(), 4 * sizeof(uint64_t));
+    return 0;
+}
+
+} /* extern "C" */

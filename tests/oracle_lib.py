@@ -113,5 +113,5 @@ def compare_batch(lib, batch, contigs, max_branch_factor=50, sequences=False, ex
 def stats(lib):
     out = (C.c_uint64 * 16)()
     lib.orc_last_stats(out)
-    names = ["max_pops_a", "max_queue_a", "max_pops_b", "max_queue_b", "max_ed", "max_optima", "total_pops_a", "total_pops_b", "total_wfa"]
+    names = ["max_pops_a", "max_queue_a", "max_pops_b", "max_queue_b", "max_ed", "max_optima", "total_pops_a", "total_pops_b", "total_wfa", "incr_mismatch"]
     return {n: int(out[i]) for i, n in enumerate(names)}
