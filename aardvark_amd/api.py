@@ -1,0 +1,181 @@
+"""ctypes bindings of libaardvark_amd.so and the host-side mirror of the reference interface.
+
+`Context.solve_compare_regions(batch, config)` is the batched form of the reference's
+`solve_compare_region(problem, reference_genome, compare_config, stratifications)`
+(src/waffle_solver.rs:122-124): same inputs (CompareRegion fields, CompareConfig fields), same
+outputs (CompareBenchmark fields), same per-region error behaviour (a failed region yields a
+status instead of metrics and the batch continues, src/main.rs:255-265).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import (TALLY_LEN, AvkCompareConfig, AvkRegionBatch, AvkResultBatch, RegionBatch, ResultBatch)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_lib = None
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+
+
+class AardvarkAmdError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libaardvark_amd.so")
+
+
+def load_library():
+    """Loads libaardvark_amd.so (built in-tree by __graft_entry__.build() / csrc/Makefile).
+    Fails loudly when it is missing: there is no fallback implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise AardvarkAmdError("%s not found: build it with `make -C aardvark_amd/csrc` (hipcc, gfx950)" % path)
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.avk_version.restype = C.c_char_p
+    lib.avk_last_error.restype = C.c_char_p
+    lib.avk_last_error.argtypes = [vp]
+    lib.avk_ctx_create.argtypes = [C.c_int, C.POINTER(vp)]
+    lib.avk_ctx_destroy.argtypes = [vp]
+    lib.avk_ctx_destroy.restype = None
+    lib.avk_ctx_set_stream.argtypes = [vp, vp]
+    lib.avk_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    lib.avk_ref_upload.argtypes = [vp, C.c_uint32, C.POINTER(u8p), u64p]
+    lib.avk_compare_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
+    lib.avk_batch_upload.argtypes = [vp, C.POINTER(AvkRegionBatch), C.POINTER(vp)]
+    lib.avk_compare_resident.argtypes = [vp, vp, C.POINTER(AvkCompareConfig), vp]
+    lib.avk_results_download.argtypes = [vp, vp, C.POINTER(AvkResultBatch)]
+    lib.avk_batch_free.argtypes = [vp, vp]
+    lib.avk_batch_free.restype = None
+    lib.avk_synchronize.argtypes = [vp]
+    lib.avk_seq_stride.restype = C.c_uint32
+    lib.avk_seq_stride.argtypes = [C.POINTER(AvkRegionBatch), C.c_uint64]
+    lib.avk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.avk_last_tier_counts.argtypes = [vp, u64p]
+    lib.avk_algorithmic_bytes.restype = C.c_uint64
+    lib.avk_algorithmic_bytes.argtypes = [C.POINTER(AvkRegionBatch)]
+    lib.avk_optimize_pairs_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.c_uint32, C.POINTER(C.c_int32), u8p]
+    _lib = lib
+    return lib
+
+
+class CompareConfig:
+    """CompareConfig (reference src/waffle_solver.rs:94-115); defaults as the reference's."""
+
+    def __init__(self, enable_sequences=True, enable_exact_shortcut=False, max_branch_factor=50):
+        self.enable_sequences = enable_sequences
+        self.enable_exact_shortcut = enable_exact_shortcut
+        self.max_branch_factor = max_branch_factor
+
+    def c_struct(self):
+        return AvkCompareConfig(self.max_branch_factor, 1 if self.enable_sequences else 0, 1 if self.enable_exact_shortcut else 0)
+
+
+class ResidentBatch:
+    """A region batch living in HBM (avk_dev_batch)."""
+
+    def __init__(self, ctx, batch):
+        self.ctx, self.batch = ctx, batch
+        self.handle = C.c_void_p()
+        cb = batch.c_struct()
+        ctx._check(ctx.lib.avk_batch_upload(ctx.handle, C.byref(cb), C.byref(self.handle)))
+
+    def free(self):
+        if self.handle:
+            self.ctx.lib.avk_batch_free(self.ctx.handle, self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Context:
+    """One GPU context (avk_ctx): owns the uploaded reference genome and the workspaces."""
+
+    def __init__(self, device=0):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        rc = self.lib.avk_ctx_create(device, C.byref(self.handle))
+        if rc != 0:
+            raise AardvarkAmdError("avk_ctx_create(%d) failed (%d): %s" % (device, rc, self.lib.avk_last_error(None).decode()))
+        self._contigs = None
+
+    def close(self):
+        if self.handle:
+            self.lib.avk_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != 0:
+            raise AardvarkAmdError("libaardvark_amd error %d: %s" % (rc, self.lib.avk_last_error(self.handle).decode()))
+
+    def set_option(self, name, value):
+        self._check(self.lib.avk_ctx_set_option(self.handle, name.encode(), int(value)))
+
+    def set_stream(self, hip_stream):
+        self._check(self.lib.avk_ctx_set_stream(self.handle, C.c_void_p(hip_stream)))
+
+    def upload_reference(self, contigs):
+        """contigs: list of bytes / uint8 arrays (ReferenceGenome::from_fasta + get_full_chromosome,
+        reference src/main.rs:94, src/waffle_solver.rs:131)."""
+        arrs = [np.frombuffer(c, dtype=np.uint8) if isinstance(c, (bytes, bytearray)) else np.ascontiguousarray(c, dtype=np.uint8)
+                for c in contigs]
+        ptrs = (u8p * len(arrs))(*[a.ctypes.data_as(u8p) for a in arrs])
+        lens = (C.c_uint64 * len(arrs))(*[a.size for a in arrs])
+        self._check(self.lib.avk_ref_upload(self.handle, len(arrs), ptrs, lens))
+        self._contigs = arrs
+
+    def solve_compare_regions(self, batch, config=None, group_metrics=True):
+        """solve_compare_region for every region of `batch` -> ResultBatch."""
+        config = config or CompareConfig()
+        res = ResultBatch(batch, sequences=bool(config.enable_sequences), group_metrics=group_metrics)
+        cb, cfg, ro = batch.c_struct(), config.c_struct(), res.c_struct()
+        self._check(self.lib.avk_compare_batch(self.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
+        return res
+
+    # --- resident form (benchmarks, pipelines that keep batches in HBM)
+    def upload(self, batch):
+        return ResidentBatch(self, batch)
+
+    def compare_resident(self, rb, config=None, tally_dev_ptr=None):
+        config = config or CompareConfig(enable_sequences=False)
+        cfg = config.c_struct()
+        self._check(self.lib.avk_compare_resident(self.handle, rb.handle, C.byref(cfg), C.c_void_p(tally_dev_ptr or 0)))
+
+    def download(self, rb, sequences=False, group_metrics=True):
+        res = ResultBatch(rb.batch, sequences=sequences, group_metrics=group_metrics)
+        ro = res.c_struct()
+        self._check(self.lib.avk_results_download(self.handle, rb.handle, C.byref(ro)))
+        return res
+
+    def synchronize(self):
+        self._check(self.lib.avk_synchronize(self.handle))
+
+    def last_kernel_ms(self):
+        ms = C.c_float(0)
+        self._check(self.lib.avk_last_kernel_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def last_tier_counts(self):
+        out = (C.c_uint64 * 4)()
+        self._check(self.lib.avk_last_tier_counts(self.handle, out))
+        return [int(x) for x in out]
+
+    def algorithmic_bytes(self, batch):
+        cb = batch.c_struct()
+        return int(self.lib.avk_algorithmic_bytes(C.byref(cb)))

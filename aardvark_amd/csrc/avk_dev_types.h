@@ -52,6 +52,7 @@ struct AvkKernelArgs {
     uint32_t first_tier; /* 0: LDS slice then HBM slice; 2: big HBM slice only (overflow pass) */
     /* work distribution */
     const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */
+    const uint32_t *n_work_dev; /* when set, the number of work items is read from device memory (overflow pass) */
     uint32_t *work_counter;    /* persistent waves pull the next region from here */
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;

@@ -1,0 +1,565 @@
+/*
+ * avk_host.hip — libaardvark_amd.so: the C-ABI of include/aardvark_amd.h on top of the gfx950
+ * solver kernels.  Host code here owns device memory, streams and launches; the per-region
+ * algorithm lives in avk_solver.inl and runs only on the GPU (there is no CPU path in this
+ * library: without a HIP device every entry point fails with AVK_E_HIP).
+ *
+ * Launch shape: persistent 256-thread workgroups (4 independent wavefronts, each with a private
+ * slice of the block's dynamic LDS); every wavefront pulls region indices from a device counter
+ * until the batch is drained.  Pass 1 solves regions in the LDS slice or, if a region needs more
+ * room, in the wave's private HBM slice.  Regions that exhaust both are queued on the device and
+ * solved by pass 2 (few waves, very large HBM slices) — launched unconditionally and empty in
+ * the common case, so nothing has to be read back between the passes.
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/aardvark_amd.h"
+#include "avk_pack.h"
+#include "avk_solver.inl"
+
+/* ---------------------------------------------------------------------------------- kernels */
+__global__ void __launch_bounds__(256, 2) avk_region_kernel(AvkKernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    const unsigned wave_in_block = threadIdx.x >> 6;
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    unsigned char *slice = a.tier[0].ws_bytes && a.first_tier == 0 ? avk_smem + (size_t)wave_in_block * a.tier[0].ws_bytes : (unsigned char *)0;
+    avk::region_worker(a, wave_id, slice);
+}
+
+/* ---------------------------------------------------------------------------------- context */
+namespace {
+
+std::string g_create_error;
+std::mutex g_create_mutex;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+} // namespace
+
+struct avk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+    /* reference */
+    uint8_t *d_ref = nullptr;
+    std::vector<uint64_t> contig_base, contig_len;
+    /* options */
+    int64_t lds_bytes_per_wave = 16 * 1024;
+    int64_t lds_ed_cap = 8;
+    int64_t waves_per_cu = 8;
+    int64_t ws_bytes_per_wave = 1 << 20;
+    int64_t big_ws_bytes = 256ll << 20;
+    int64_t big_waves = 32;
+    int64_t emit_group_metrics = 1;
+    int n_cus = 0;
+    /* workspaces (grown on demand) */
+    uint8_t *d_ws = nullptr;
+    size_t ws_alloc = 0;
+    uint8_t *d_big = nullptr;
+    size_t big_alloc = 0;
+    /* measurement */
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool ev_valid = false;
+    uint64_t last_tiers[4] = {0, 0, 0, 0};
+};
+
+struct avk_dev_batch {
+    avk::PackedBatch host; /* regions/variants kept for the scatter maps */
+    uint64_t n_regions = 0, n_variants_dev = 0, n_variants_host = 0;
+    bool want_seq = false;
+    uint64_t seq_total = 0;
+    AvkDevRegion *d_regions = nullptr;
+    AvkDevVariant *d_variants = nullptr;
+    uint8_t *d_alleles = nullptr;
+    int32_t *d_status = nullptr;
+    uint32_t *d_ed1 = nullptr, *d_ed2 = nullptr, *d_nopt = nullptr;
+    uint16_t *d_present = nullptr;
+    uint32_t *d_gm = nullptr;
+    uint8_t *d_vexp = nullptr, *d_vobs = nullptr, *d_vcls = nullptr, *d_vzyg = nullptr;
+    uint8_t *d_seq = nullptr;
+    uint32_t *d_seqlen = nullptr;
+    uint64_t *d_tally = nullptr; /* AVK_TALLY_LEN + 4 tier counters */
+    uint32_t *d_counters = nullptr; /* [0] work pass1 [1] work pass2 [2] overflow count [3] overflow count of pass 2 */
+    uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr;
+    bool with_gm = true;
+};
+
+namespace {
+
+int fail(avk_ctx *ctx, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    else {
+        std::lock_guard<std::mutex> lk(g_create_mutex);
+        g_create_error = buf;
+    }
+    return code;
+}
+
+#define AVK_HIP(ctx, call)                                                                                  \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(ctx, e_ == hipErrorOutOfMemory ? AVK_E_OOM : AVK_E_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
+    *p = nullptr;
+    size_t bytes = count * sizeof(T);
+    if (bytes == 0) bytes = 16;
+    AVK_HIP(ctx, hipMalloc((void **)p, bytes));
+    return 0;
+}
+
+void free_batch_buffers(avk_dev_batch *db) {
+    void *ptrs[] = {db->d_regions, db->d_variants, db->d_alleles, db->d_status, db->d_ed1, db->d_ed2, db->d_nopt, db->d_present, db->d_gm,
+                    db->d_vexp, db->d_vobs, db->d_vcls, db->d_vzyg, db->d_seq, db->d_seqlen, db->d_tally, db->d_counters, db->d_overflow, db->d_overflow2};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+}
+
+} // namespace
+
+extern "C" {
+
+const char *avk_version(void) { return "aardvark_amd 0.1 (gfx950)"; }
+
+const char *avk_last_error(const avk_ctx *ctx) {
+    if (ctx) return ctx->err.c_str();
+    std::lock_guard<std::mutex> lk(g_create_mutex);
+    return g_create_error.c_str();
+}
+
+int avk_ctx_create(int device_id, avk_ctx **out) {
+    if (!out) return AVK_E_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(nullptr, AVK_E_HIP, "no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, AVK_E_ARG, "device %d out of range (have %d)", device_id, n);
+    avk_ctx *ctx = new avk_ctx();
+    ctx->device = device_id;
+    e = hipSetDevice(device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, AVK_E_HIP, "hipSetDevice failed: %s", hipGetErrorString(e));
+    }
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, AVK_E_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
+    }
+    ctx->n_cus = prop.multiProcessorCount;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess) {
+        delete ctx;
+        return fail(nullptr, AVK_E_HIP, "hipStreamCreate failed");
+    }
+    ctx->own_stream = true;
+    (void)hipEventCreate(&ctx->ev0);
+    (void)hipEventCreate(&ctx->ev1);
+    *out = ctx;
+    return 0;
+}
+
+void avk_ctx_destroy(avk_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+    if (ctx->d_big) (void)hipFree(ctx->d_big);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream) {
+    if (!ctx) return AVK_E_ARG;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->own_stream && ctx->stream) {
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamDestroy(ctx->stream);
+    }
+    ctx->stream = (hipStream_t)hip_stream;
+    ctx->own_stream = false;
+    return 0;
+}
+
+int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return AVK_E_ARG;
+    std::string n(name);
+    if (n == "lds_bytes_per_wave") {
+        if (value < 0 || value > 40 * 1024) return fail(ctx, AVK_E_ARG, "lds_bytes_per_wave must be in [0, 40960]");
+        ctx->lds_bytes_per_wave = value & ~15ll;
+    } else if (n == "lds_ed_cap") {
+        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "lds_ed_cap must be in [1, 4096]");
+        ctx->lds_ed_cap = value;
+    } else if (n == "waves_per_cu") {
+        if (value < 1 || value > 32) return fail(ctx, AVK_E_ARG, "waves_per_cu must be in [1, 32]");
+        ctx->waves_per_cu = value;
+    } else if (n == "ws_bytes_per_wave") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "ws_bytes_per_wave must be >= 0");
+        ctx->ws_bytes_per_wave = (value + 255) & ~255ll;
+    } else if (n == "big_ws_bytes") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "big_ws_bytes must be >= 0");
+        ctx->big_ws_bytes = (value + 255) & ~255ll;
+    } else if (n == "big_waves") {
+        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "big_waves must be in [1, 4096]");
+        ctx->big_waves = value;
+    } else if (n == "emit_group_metrics") {
+        ctx->emit_group_metrics = value ? 1 : 0;
+    } else
+        return fail(ctx, AVK_E_ARG, "unknown option '%s'", name);
+    return 0;
+}
+
+int avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs, const uint64_t *lens) {
+    if (!ctx || (n_contigs && (!seqs || !lens))) return AVK_E_ARG;
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->d_ref) {
+        AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipFree(ctx->d_ref);
+        ctx->d_ref = nullptr;
+    }
+    ctx->contig_base.assign(n_contigs, 0);
+    ctx->contig_len.assign(n_contigs, 0);
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        ctx->contig_base[c] = total;
+        ctx->contig_len[c] = lens[c];
+        total += lens[c];
+    }
+    AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ref, total + 64));
+    for (uint32_t c = 0; c < n_contigs; ++c)
+        if (lens[c]) AVK_HIP(ctx, hipMemcpyAsync(ctx->d_ref + ctx->contig_base[c], seqs[c], lens[c], hipMemcpyHostToDevice, ctx->stream));
+    AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r) {
+    if (!batch || r >= batch->n_regions) return 0;
+    return avk::seq_stride_of(batch, r);
+}
+
+uint64_t avk_algorithmic_bytes(const avk_region_batch *b) {
+    /* DESIGN.md "algorithmic bytes per region": 2-bit window + 12 B record and 2-bit alleles per
+     * variant + 16 B header in; 16 B + 2 B per variant + 16 B joint BASEPAIR and 16 B per variant
+     * type present out */
+    if (!b) return 0;
+    uint64_t total = 0;
+    for (uint64_t r = 0; r < b->n_regions; ++r) {
+        uint64_t L = b->end[r] > b->start[r] ? b->end[r] - b->start[r] : 0;
+        uint64_t bytes = (L + 3) / 4 + 16 + 16 + 16;
+        uint32_t types = 0;
+        for (int side = 0; side < 2; ++side) {
+            uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
+            uint32_t cnt = side == 0 ? b->t_cnt[r] : b->q_cnt[r];
+            for (uint32_t i = 0; i < cnt; ++i) {
+                uint64_t v = off + i;
+                bytes += 12 + (b->a0_len[v] + 3) / 4 + (b->a1_len[v] + 3) / 4 + 2;
+                types |= 1u << (b->var_type[v] & 15);
+            }
+        }
+        bytes += 16ull * (uint64_t)__builtin_popcount(types);
+        total += bytes;
+    }
+    return total;
+}
+
+int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch **out) {
+    if (!ctx || !batch || !out) return AVK_E_ARG;
+    *out = nullptr;
+    if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    avk_dev_batch *db = new avk_dev_batch();
+    db->n_regions = batch->n_regions;
+    db->n_variants_host = batch->n_variants;
+    /* sequence slots are laid out by the library: prefix of 5 * stride */
+    std::vector<uint64_t> seq_off(batch->n_regions);
+    std::vector<uint32_t> seq_stride(batch->n_regions);
+    uint64_t seq_total = 0;
+    for (uint64_t r = 0; r < batch->n_regions; ++r) {
+        seq_stride[r] = avk::seq_stride_of(batch, r);
+        seq_off[r] = seq_total;
+        seq_total += 5ull * seq_stride[r];
+    }
+    db->seq_total = seq_total;
+    std::string err;
+    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err);
+    if (rc) {
+        delete db;
+        return fail(ctx, rc, "%s", err.c_str());
+    }
+    const uint64_t n = db->n_regions, nv = db->host.variants.size();
+    db->n_variants_dev = nv;
+#define AVK_TRY(x)                \
+    do {                          \
+        int rc_ = (x);            \
+        if (rc_) {                \
+            free_batch_buffers(db); \
+            delete db;            \
+            return rc_;           \
+        }                         \
+    } while (0)
+    AVK_TRY(dev_alloc(ctx, &db->d_regions, n));
+    AVK_TRY(dev_alloc(ctx, &db->d_variants, nv));
+    AVK_TRY(dev_alloc(ctx, &db->d_alleles, db->host.alleles.size()));
+    AVK_TRY(dev_alloc(ctx, &db->d_status, n));
+    AVK_TRY(dev_alloc(ctx, &db->d_ed1, n));
+    AVK_TRY(dev_alloc(ctx, &db->d_ed2, n));
+    AVK_TRY(dev_alloc(ctx, &db->d_nopt, n));
+    AVK_TRY(dev_alloc(ctx, &db->d_present, n));
+    AVK_TRY(dev_alloc(ctx, &db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS));
+    AVK_TRY(dev_alloc(ctx, &db->d_vexp, nv));
+    AVK_TRY(dev_alloc(ctx, &db->d_vobs, nv));
+    AVK_TRY(dev_alloc(ctx, &db->d_vcls, nv));
+    AVK_TRY(dev_alloc(ctx, &db->d_vzyg, nv));
+    AVK_TRY(dev_alloc(ctx, &db->d_seqlen, n * 5));
+    AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_LEN + 4));
+    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)8));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
+#undef AVK_TRY
+    hipError_t e = hipSuccess;
+    if (n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && nv) e = hipMemcpyAsync(db->d_variants, db->host.variants.data(), nv * sizeof(AvkDevVariant), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_alleles, db->host.alleles.data(), db->host.alleles.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        free_batch_buffers(db);
+        delete db;
+        return fail(ctx, AVK_E_HIP, "batch upload failed: %s", hipGetErrorString(e));
+    }
+    *out = db;
+    return 0;
+}
+
+void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
+    if (!db) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    free_batch_buffers(db);
+    delete db;
+}
+
+int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev) {
+    if (!ctx || !db || !cfg) return AVK_E_ARG;
+    if (cfg->enable_exact_shortcut) return fail(ctx, AVK_E_ARG, "enable_exact_shortcut is not implemented on the device path yet");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = db->n_regions;
+    /* sequences: allocate the output arena on first use */
+    if (cfg->enable_sequences && !db->d_seq) {
+        int rc = dev_alloc(ctx, &db->d_seq, (size_t)db->seq_total + 16);
+        if (rc) return rc;
+    }
+    /* geometry */
+    const uint32_t waves_per_block = 4;
+    uint64_t want_waves = (uint64_t)ctx->n_cus * (uint64_t)ctx->waves_per_cu;
+    if (want_waves > n) want_waves = n;
+    uint32_t blocks = (uint32_t)((want_waves + waves_per_block - 1) / waves_per_block);
+    if (blocks == 0) blocks = 1;
+    const uint32_t n_waves = blocks * waves_per_block;
+    const size_t ws_need = (size_t)n_waves * (size_t)ctx->ws_bytes_per_wave;
+    if (ws_need > ctx->ws_alloc) {
+        if (ctx->d_ws) {
+            AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_ws);
+            ctx->d_ws = nullptr;
+            ctx->ws_alloc = 0;
+        }
+        AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ws, ws_need + 256));
+        ctx->ws_alloc = ws_need;
+    }
+    const uint32_t big_blocks = (uint32_t)((ctx->big_waves + waves_per_block - 1) / waves_per_block);
+    const size_t big_need = (size_t)big_blocks * waves_per_block * (size_t)ctx->big_ws_bytes;
+    if (big_need > ctx->big_alloc) {
+        if (ctx->d_big) {
+            AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            (void)hipFree(ctx->d_big);
+            ctx->d_big = nullptr;
+            ctx->big_alloc = 0;
+        }
+        AVK_HIP(ctx, hipMalloc((void **)&ctx->d_big, big_need + 256));
+        ctx->big_alloc = big_need;
+    }
+
+    AVK_HIP(ctx, hipMemsetAsync(db->d_tally, 0, ((size_t)AVK_TALLY_LEN + 4) * sizeof(uint64_t), ctx->stream));
+    AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
+
+    AvkKernelArgs a;
+    memset(&a, 0, sizeof(a));
+    a.regions = db->d_regions;
+    a.variants = db->d_variants;
+    a.alleles = db->d_alleles;
+    a.ref_bytes = ctx->d_ref;
+    a.n_regions = (uint32_t)n;
+    a.max_branch_factor = cfg->max_branch_factor;
+    a.enable_exact_shortcut = 0;
+    a.tier[0].ws_bytes = (uint64_t)ctx->lds_bytes_per_wave;
+    a.tier[0].ed_cap = (uint32_t)ctx->lds_ed_cap;
+    a.tier[1].ws_bytes = (uint64_t)ctx->ws_bytes_per_wave;
+    a.tier[1].ed_cap = 0;
+    a.tier[2].ws_bytes = (uint64_t)ctx->big_ws_bytes;
+    a.tier[2].ed_cap = 0;
+    a.status = db->d_status;
+    a.ed_h1 = db->d_ed1;
+    a.ed_h2 = db->d_ed2;
+    a.n_optima = db->d_nopt;
+    a.type_present = db->d_present;
+    a.group_metrics = ctx->emit_group_metrics ? db->d_gm : nullptr;
+    a.var_expected = db->d_vexp;
+    a.var_observed = db->d_vobs;
+    a.var_class = db->d_vcls;
+    a.var_zyg = db->d_vzyg;
+    a.seq_bytes = cfg->enable_sequences ? db->d_seq : nullptr;
+    a.seq_len = cfg->enable_sequences ? db->d_seqlen : nullptr;
+    a.tally = db->d_tally;
+    a.tier_counts = db->d_tally + AVK_TALLY_LEN;
+
+    if (cfg->max_branch_factor == 0) return fail(ctx, AVK_E_ARG, "max_branch_factor must be greater than 0 (query_optimizer.rs:177)");
+
+    AVK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    /* pass 1 */
+    a.first_tier = 0;
+    a.work_list = nullptr;
+    a.n_work_dev = nullptr;
+    a.work_counter = db->d_counters + 0;
+    a.overflow_list = db->d_overflow;
+    a.overflow_count = db->d_counters + 2;
+    a.hbm_ws = ctx->ws_bytes_per_wave ? ctx->d_ws : nullptr;
+    const size_t lds = (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave;
+    if (n) {
+        hipLaunchKernelGGL(avk_region_kernel, dim3(blocks), dim3(256), lds, ctx->stream, a);
+        AVK_HIP(ctx, hipGetLastError());
+    }
+    /* pass 2: whatever overflowed, big slices, work count read on the device */
+    if (n && ctx->big_ws_bytes) {
+        a.first_tier = 2;
+        a.work_list = db->d_overflow;
+        a.n_work_dev = db->d_counters + 2;
+        a.work_counter = db->d_counters + 1;
+        a.overflow_list = db->d_overflow2;
+        a.overflow_count = db->d_counters + 3;
+        a.hbm_ws = ctx->d_big;
+        hipLaunchKernelGGL(avk_region_kernel, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
+        AVK_HIP(ctx, hipGetLastError());
+    }
+    AVK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->ev_valid = true;
+    if (tally_dev) AVK_HIP(ctx, hipMemcpyAsync(tally_dev, db->d_tally, AVK_TALLY_LEN * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
+    return 0;
+}
+
+int avk_synchronize(avk_ctx *ctx) {
+    if (!ctx) return AVK_E_ARG;
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+int avk_last_kernel_ms(avk_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return AVK_E_ARG;
+    if (!ctx->ev_valid) return fail(ctx, AVK_E_STATE, "no launch has been timed yet");
+    AVK_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    AVK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return 0;
+}
+
+int avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[4]) {
+    if (!ctx || !counts) return AVK_E_ARG;
+    memcpy(counts, ctx->last_tiers, sizeof(ctx->last_tiers));
+    return 0;
+}
+
+int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out) {
+    if (!ctx || !db || !out || !out->status) return AVK_E_ARG;
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = db->n_regions, nv = db->n_variants_dev;
+    std::vector<uint8_t> vexp(nv + 1), vobs(nv + 1), vcls(nv + 1), vzyg(nv + 1);
+    std::vector<uint64_t> tally((size_t)AVK_TALLY_LEN + 4);
+    hipStream_t s = ctx->stream;
+#define D2H(dst, src, bytes) \
+    if ((bytes) > 0) AVK_HIP(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s))
+    D2H(out->status, db->d_status, n * sizeof(int32_t));
+    if (out->ed_h1) D2H(out->ed_h1, db->d_ed1, n * sizeof(uint32_t));
+    if (out->ed_h2) D2H(out->ed_h2, db->d_ed2, n * sizeof(uint32_t));
+    if (out->n_optima) D2H(out->n_optima, db->d_nopt, n * sizeof(uint32_t));
+    if (out->type_present) D2H(out->type_present, db->d_present, n * sizeof(uint16_t));
+    if (out->group_metrics && ctx->emit_group_metrics) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
+    if (out->var_expected) D2H(vexp.data(), db->d_vexp, nv);
+    if (out->var_observed) D2H(vobs.data(), db->d_vobs, nv);
+    if (out->var_class) D2H(vcls.data(), db->d_vcls, nv);
+    if (out->var_zyg) D2H(vzyg.data(), db->d_vzyg, nv);
+    D2H(tally.data(), db->d_tally, ((size_t)AVK_TALLY_LEN + 4) * sizeof(uint64_t));
+    std::vector<uint8_t> seq;
+    std::vector<uint32_t> seqlen;
+    const bool want_seq = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq;
+    if (want_seq) {
+        seq.resize(db->seq_total + 16);
+        seqlen.resize(n * 5 + 1);
+        D2H(seq.data(), db->d_seq, db->seq_total);
+        D2H(seqlen.data(), db->d_seqlen, n * 5 * sizeof(uint32_t));
+    }
+#undef D2H
+    AVK_HIP(ctx, hipStreamSynchronize(s));
+    for (uint64_t v = 0; v < nv; ++v) {
+        const uint64_t hv = db->host.dev2host[v];
+        if (out->var_expected) out->var_expected[hv] = vexp[v];
+        if (out->var_observed) out->var_observed[hv] = vobs[v];
+        if (out->var_class) out->var_class[hv] = vcls[v];
+        if (out->var_zyg) out->var_zyg[hv] = vzyg[v];
+    }
+    if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
+    memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 4 * sizeof(uint64_t));
+    if (want_seq) {
+        for (uint64_t r = 0; r < n; ++r) {
+            const AvkDevRegion &dr = db->host.regions[r];
+            for (int k = 0; k < 5; ++k) {
+                uint32_t len = seqlen[5 * r + k];
+                if (len > out->seq_stride[r]) len = out->seq_stride[r];
+                memcpy(out->seq_bytes + out->seq_off[r] + (uint64_t)k * out->seq_stride[r], seq.data() + dr.seq_off + (uint64_t)k * dr.seq_stride, len);
+                out->seq_len[5 * r + k] = len;
+            }
+        }
+    }
+    /* a region still marked -1 was queued for the overflow pass while that pass is disabled */
+    for (uint64_t r = 0; r < n; ++r)
+        if (out->status[r] < 0) out->status[r] = AVK_ST_CAPACITY;
+    return 0;
+}
+
+int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
+    if (!ctx || !batch || !cfg || !out) return AVK_E_ARG;
+    avk_dev_batch *db = nullptr;
+    int rc = avk_batch_upload(ctx, batch, &db);
+    if (rc) return rc;
+    rc = avk_compare_resident(ctx, db, cfg, nullptr);
+    if (!rc) rc = avk_results_download(ctx, db, out);
+    avk_batch_free(ctx, db);
+    return rc;
+}
+
+int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *, uint32_t, int32_t *, uint8_t *) {
+    return fail(ctx, AVK_E_STATE, "avk_optimize_pairs_batch (merge path) is not implemented yet");
+}
+
+} /* extern "C" */

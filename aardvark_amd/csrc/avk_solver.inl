@@ -1234,13 +1234,14 @@ AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     u32 n_ok = 0, n_err = 0;
     u32 tier_hits[4] = {0, 0, 0, 0};
     u8 *hbm_slice = a.hbm_ws ? a.hbm_ws + (u64)wave_id * a.tier[a.first_tier == 2 ? 2 : 1].ws_bytes : (u8 *)0;
+    const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_regions;
 
     for (;;) {
         u32 idx = 0;
         if (lane == 0) idx = avk_atomic_add_u32_global(a.work_counter, 1);
         idx = wv_shfl(idx, 0);
         idx = wv_uni(idx);
-        if (idx >= a.n_regions) break;
+        if (idx >= n_work) break;
         const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : idx;
         const AvkDevRegion reg = a.regions[r];
         const u32 pre = wv_uni(reg.pre_status);

@@ -174,7 +174,8 @@ void avk_ctx_destroy(avk_ctx *ctx);
 const char *avk_last_error(const avk_ctx *ctx);
 /* run every launch of this context on an existing hipStream_t (e.g. torch's current stream) */
 int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
-/* tuning knobs: name in {"lds_bytes_per_wave","waves_per_cu","ws_bytes_per_wave","big_ws_bytes","big_waves"} */
+/* knobs: "lds_bytes_per_wave", "lds_ed_cap", "waves_per_cu", "ws_bytes_per_wave", "big_ws_bytes", "big_waves",
+ * "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced) */
 int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
 
 /* Replaces ReferenceGenome::from_fasta + get_full_chromosome (src/main.rs:94,
