@@ -1060,7 +1060,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         u32 cls = exp == ob ? AVK_CLASS_TP : AVK_CLASS_FN;
         u32 ea = exp, oa = ob;
         if (!is_truth) {
-            cls = cls == AVK_CLASS_FN ? AVK_CLASS_FP : cls;
+            if (cls == AVK_CLASS_FN) cls = AVK_CLASS_FP;
             ea = ob;
             oa = exp;
         }

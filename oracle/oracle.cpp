@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cstdint>
 #include <cstring>
 #include <memory>
@@ -1422,6 +1423,54 @@ int orc_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
             out->tally[i] = s;
         }
     }
+    return 0;
+}
+
+/* Timed CPU baseline for bench.py: `reps` passes of solve_compare_region over the whole batch on
+ * `threads` workers (dynamic 64-region chunks, like the rayon loop of main.rs:251-268).  The clock
+ * starts when every worker is ready and stops when the last one finishes; results are discarded
+ * except for a checksum of the statuses + joint tallies so the work cannot be optimised away. */
+int orc_bench(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
+              const avk_compare_config *cfg, int threads, int reps, double *seconds, uint64_t *checksum) {
+    if (!batch || !cfg || !seconds) return AVK_E_ARG;
+    if (threads < 1) threads = 1;
+    if (reps < 1) reps = 1;
+    const uint64_t total = batch->n_regions * (uint64_t)reps;
+    std::atomic<uint64_t> next(0), sum(0);
+    std::atomic<int> ready(0);
+    std::atomic<bool> go(false);
+    auto worker = [&]() {
+        uint64_t local = 0;
+        ready.fetch_add(1);
+        while (!go.load(std::memory_order_acquire)) std::this_thread::yield();
+        const uint64_t chunk = 64;
+        for (;;) {
+            uint64_t i0 = next.fetch_add(chunk);
+            if (i0 >= total) break;
+            uint64_t i1 = std::min(total, i0 + chunk);
+            for (uint64_t i = i0; i < i1; ++i) {
+                const uint64_t r = i % batch->n_regions;
+                CompareBenchmark bm;
+                uint32_t c = batch->contig_idx ? batch->contig_idx[r] : 0;
+                int st = AVK_ST_INVALID_INPUT;
+                if (c < n_contigs) {
+                    Region reg = region_view(batch, r);
+                    st = solve_compare_region(reg, Span(refs[c], ref_lens[c]), *cfg, &bm);
+                }
+                local += (uint64_t)st * 1000003u + bm.group_metrics.m[0][AVK_F_GT_TRUTH_TP] + 3 * bm.group_metrics.m[0][AVK_F_BP_TRUTH_TP];
+            }
+        }
+        sum.fetch_add(local);
+    };
+    std::vector<std::thread> ts;
+    for (int t = 0; t < threads; ++t) ts.emplace_back(worker);
+    while (ready.load() < threads) std::this_thread::yield();
+    auto t0 = std::chrono::steady_clock::now();
+    go.store(true, std::memory_order_release);
+    for (std::thread &t : ts) t.join();
+    auto t1 = std::chrono::steady_clock::now();
+    *seconds = std::chrono::duration<double>(t1 - t0).count();
+    if (checksum) *checksum = sum.load();
     return 0;
 }
 

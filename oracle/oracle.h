@@ -76,6 +76,10 @@ int64_t  orc_optimize_gt_alleles(const avk_region_batch *batch, uint64_t r, cons
 int      orc_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens,
                            uint32_t n_contigs, const avk_compare_config *cfg, avk_result_batch *out, int threads);
 
+/* timed CPU baseline (bench.py cpu_baseline): reps passes over the batch on `threads` workers */
+int      orc_bench(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
+                   const avk_compare_config *cfg, int threads, int reps, double *seconds, uint64_t *checksum);
+
 /* perform_basepair_compare (waffle_solver.rs:611-658): out[4] = truth_tp, truth_fn, query_tp, query_fp */
 void     orc_basepair_compare(const uint8_t *ref, uint64_t rl, const uint8_t *t, uint64_t tl,
                               const uint8_t *q, uint64_t ql, uint64_t out[4]);

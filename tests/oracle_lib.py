@@ -77,6 +77,8 @@ def load():
     lib.orc_optimize_pairs_batch.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.c_uint32,
                                              C.POINTER(C.c_int32), u8p, C.c_int]
     lib.orc_last_stats.argtypes = [u64p]
+    lib.orc_bench.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.POINTER(AvkCompareConfig), C.c_int, C.c_int,
+                              C.POINTER(C.c_double), u64p]
     lib.orc_group_add_truth.argtypes = [u64p, C.c_uint64, C.c_uint8, C.c_uint8]
     lib.orc_group_add_query.argtypes = [u64p, C.c_uint64, C.c_uint8, C.c_uint8]
     lib.orc_group_swap.argtypes = [u64p, u64p]
@@ -115,3 +117,14 @@ def stats(lib):
     lib.orc_last_stats(out)
     names = ["max_pops_a", "max_queue_a", "max_pops_b", "max_queue_b", "max_ed", "max_optima", "total_pops_a", "total_pops_b", "total_wfa", "incr_mismatch"]
     return {n: int(out[i]) for i, n in enumerate(names)}
+
+
+def bench(lib, batch, contigs, threads, reps, max_branch_factor=50):
+    """Timed oracle passes (CPU baseline): returns (seconds, regions_per_second)."""
+    cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
+    cfg = AvkCompareConfig(max_branch_factor, 0, 0)
+    cb = batch.c_struct()
+    sec, chk = C.c_double(0), C.c_uint64(0)
+    rc = lib.orc_bench(C.byref(cb), cs.ptrs, cs.lens, cs.n, C.byref(cfg), threads, reps, C.byref(sec), C.byref(chk))
+    assert rc == 0
+    return sec.value, batch.n_regions * reps / sec.value

@@ -1,0 +1,95 @@
+"""Kernel-logic parity on CPU: the HIP solver source (aardvark_amd/csrc/avk_solver.inl) executed
+by the lane emulator (tests/emu) against the oracle, bit for bit, on every scenario.  These run
+in the GPU-less container; the same scenarios run on the real kernels in test_gpu_parity.py."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib
+import scenarios
+
+EMU_THREADS = 8
+
+
+def check(oracle, contigs, batch, **emu_kw):
+    want = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True, threads=4)
+    got = emu_lib.compare_batch(batch, contigs, sequences=True, threads=EMU_THREADS, **emu_kw)
+    assert got.diff(want) == []
+    return got, want
+
+
+def test_reference_known_answer_regions(oracle):
+    contigs, batch = scenarios.golden()
+    got, _ = check(oracle, contigs, batch, n_waves=2)
+    assert got.tier_counts[0] == batch.n_regions  # all of them fit the LDS tier
+
+
+def test_chr20_snv_regions(oracle):
+    contigs, batch = scenarios.chr20_small(3000)
+    check(oracle, contigs, batch, n_waves=16)
+
+
+def test_indel_mix_regions(oracle):
+    contigs, batch = scenarios.indel_small(1500)
+    check(oracle, contigs, batch, n_waves=16)
+
+
+@pytest.mark.parametrize("seed,kw", [(11, {}), (12, {"repeat_unit": b"CAG", "max_vars": 6}), (13, {"max_len": 20, "span": (30, 260)})])
+def test_fuzz_regions(oracle, seed, kw):
+    contigs, batch = scenarios.fuzz_regions(seed, 150, **kw)
+    check(oracle, contigs, batch, n_waves=16)
+
+
+def test_non_acgt_bytes(oracle):
+    contigs, batch = scenarios.non_acgt_regions()
+    check(oracle, contigs, batch, n_waves=8)
+
+
+def test_branch_quota_decides(oracle):
+    """more orientations than max_branch_factor: pop order under the quota must be the reference's"""
+    contigs, batch = scenarios.quota_regions(3, n=3, n_query=12)
+    got, want = check(oracle, contigs, batch, n_waves=4)
+    assert oracle_lib.stats(oracle)["max_optima"] >= 1
+    # a smaller quota changes the work but not the agreement
+    want5 = oracle_lib.compare_batch(oracle, batch, contigs, max_branch_factor=5, sequences=True)
+    got5 = emu_lib.compare_batch(batch, contigs, max_branch_factor=5, sequences=True, n_waves=4, threads=EMU_THREADS)
+    assert got5.diff(want5) == []
+
+
+def test_auto_fail_pruning(oracle):
+    contigs, batch = scenarios.autofail_regions()
+    check(oracle, contigs, batch, n_waves=4)
+    assert oracle_lib.stats(oracle)["max_pops_b"] > 500  # the scenario really reaches the 500-pop rule
+
+
+def test_invalid_and_degenerate_inputs(oracle):
+    contigs, batch = scenarios.invalid_regions()
+    got, want = check(oracle, contigs, batch, n_waves=2)
+    assert sorted(set(want.status.tolist())) == [0, 6, 20]
+    assert int(got.tally[-1]) == int((want.status != 0).sum())  # error_blocks
+    assert int(got.tally[-2]) == int((want.status == 0).sum())  # solved_blocks
+
+
+def test_results_do_not_depend_on_the_workspace_tier(oracle):
+    """the same regions solved in the LDS slice, in the per-wave HBM slice and in the overflow
+    pass give identical outputs; a workspace that is too small everywhere reports CAPACITY"""
+    contigs, batch = scenarios.fuzz_regions(21, 60)
+    want = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True)
+    lds_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=64 * 1024, lds_ed_cap=64, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    hbm_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    big_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    tiny_lds = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=4096, lds_ed_cap=2, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    for got in (lds_only, hbm_only, big_only, tiny_lds):
+        assert got.diff(want) == []
+    assert hbm_only.tier_counts[0] == 0 and big_only.tier_counts[2] == batch.n_regions and tiny_lds.tier_counts[1] > 0
+    starved = emu_lib.compare_batch(batch, contigs, lds_bytes=2048, lds_ed_cap=2, ws_bytes=0, big_ws_bytes=4096, threads=EMU_THREADS)
+    assert set(starved.status.tolist()) <= {0, 21} and (starved.status == 21).any()
+    ok = starved.status == 0
+    assert np.array_equal(starved.ed_h1[ok], want.ed_h1[ok]) and np.array_equal(starved.group_metrics[ok], want.group_metrics[ok])
+
+
+@pytest.mark.timeout(600)
+def test_long_alleles_and_large_edit_distance(oracle):
+    contigs, batch = scenarios.long_allele_regions()
+    sub = batch.slice(2, 4)  # the 600 bp SV pair and the TR pair (the 3 kbp pair runs on the GPU test)
+    check(oracle, contigs, sub, n_waves=2)
