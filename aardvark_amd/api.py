@@ -24,7 +24,8 @@ class AardvarkAmdError(RuntimeError):
 
 
 def library_path():
-    return os.path.join(_HERE, "libaardvark_amd.so")
+    """in-tree libaardvark_amd.so; AVK_LIB selects another in-tree build (kernel tuning experiments)"""
+    return os.path.join(_HERE, os.environ.get("AVK_LIB", "libaardvark_amd.so"))
 
 
 def load_library():
@@ -172,7 +173,7 @@ class Context:
         return float(ms.value)
 
     def last_tier_counts(self):
-        out = (C.c_uint64 * 4)()
+        out = (C.c_uint64 * 5)()
         self._check(self.lib.avk_last_tier_counts(self.handle, out))
         return [int(x) for x in out]
 

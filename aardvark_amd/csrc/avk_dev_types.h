@@ -49,7 +49,7 @@ struct AvkKernelArgs {
     uint32_t n_regions;
     uint32_t max_branch_factor;
     uint32_t enable_exact_shortcut;
-    uint32_t first_tier; /* 0: LDS slice then HBM slice; 2: big HBM slice only (overflow pass) */
+    uint32_t pass_tier;  /* workspace tier of this launch: 0 small LDS slice, 1 large LDS slice, 2 per-wave HBM slice, 3 big HBM slice */
     /* work distribution */
     const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */
     const uint32_t *n_work_dev; /* when set, the number of work items is read from device memory (overflow pass) */
@@ -57,18 +57,16 @@ struct AvkKernelArgs {
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;
     /* workspaces */
-    uint8_t *hbm_ws;           /* n_waves slices of tier[1] (or tier[2]) bytes */
-    AvkTier tier[3];
+    uint8_t *hbm_ws;           /* n_waves slices of tier[2] (or tier[3]) bytes */
+    AvkTier tier[4];
     /* outputs */
-    int32_t *status;
-    uint32_t *ed_h1, *ed_h2, *n_optima;
-    uint16_t *type_present;
+    uint32_t *region_out;    /* [n][4]: status, ed_h1, ed_h2, n_optima | type_present << 16 — one 16-byte store per region */
     uint32_t *group_metrics; /* optional [n][13][22] */
-    uint8_t *var_expected, *var_observed, *var_class, *var_zyg;
+    uint32_t *var_out;       /* [n_variants]: expected | observed << 8 | class << 16 | resolved zygosity << 24 */
     uint8_t *seq_bytes;      /* optional */
     uint32_t *seq_len;
     uint64_t *tally;         /* [AVK_TALLY_LEN] */
-    uint64_t *tier_counts;   /* [4] regions solved per tier, capacity failures */
+    uint64_t *tier_counts;   /* [5] regions finished per tier, then capacity failures */
 };
 
 #endif

@@ -25,12 +25,22 @@
 #include "avk_solver.inl"
 
 /* ---------------------------------------------------------------------------------- kernels */
-__global__ void __launch_bounds__(256, 2) avk_region_kernel(AvkKernelArgs a) {
+/* LDS passes: regions in the LDS slice of their wavefront (small slices at high occupancy first, then
+ * the overflow of that pass with large slices at one workgroup per CU) */
+#ifndef AVK_LDS_WAVES_PER_SIMD
+#define AVK_LDS_WAVES_PER_SIMD 4
+#endif
+__global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel_lds(AvkKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
     const unsigned wave_in_block = threadIdx.x >> 6;
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    unsigned char *slice = a.tier[0].ws_bytes && a.first_tier == 0 ? avk_smem + (size_t)wave_in_block * a.tier[0].ws_bytes : (unsigned char *)0;
-    avk::region_worker(a, wave_id, slice);
+    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
+}
+
+/* HBM passes: regions that outgrew the LDS tiers, in the wave's private HBM slice */
+__global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
 /* ---------------------------------------------------------------------------------- context */
@@ -55,9 +65,11 @@ struct avk_ctx {
     uint8_t *d_ref = nullptr;
     std::vector<uint64_t> contig_base, contig_len;
     /* options */
-    int64_t lds_bytes_per_wave = 16 * 1024;
+    int64_t lds_bytes_per_wave = 9 * 1024;
     int64_t lds_ed_cap = 8;
-    int64_t waves_per_cu = 8;
+    int64_t lds2_bytes_per_wave = 40 * 1024;
+    int64_t lds2_ed_cap = 48;
+    int64_t waves_per_cu = 16;
     int64_t ws_bytes_per_wave = 1 << 20;
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 32;
@@ -71,7 +83,7 @@ struct avk_ctx {
     /* measurement */
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
-    uint64_t last_tiers[4] = {0, 0, 0, 0};
+    uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
 };
 
 struct avk_dev_batch {
@@ -82,16 +94,14 @@ struct avk_dev_batch {
     AvkDevRegion *d_regions = nullptr;
     AvkDevVariant *d_variants = nullptr;
     uint8_t *d_alleles = nullptr;
-    int32_t *d_status = nullptr;
-    uint32_t *d_ed1 = nullptr, *d_ed2 = nullptr, *d_nopt = nullptr;
-    uint16_t *d_present = nullptr;
+    uint32_t *d_region_out = nullptr; /* [n][4] */
     uint32_t *d_gm = nullptr;
-    uint8_t *d_vexp = nullptr, *d_vobs = nullptr, *d_vcls = nullptr, *d_vzyg = nullptr;
+    uint32_t *d_var_out = nullptr;    /* [nv] */
     uint8_t *d_seq = nullptr;
     uint32_t *d_seqlen = nullptr;
     uint64_t *d_tally = nullptr; /* AVK_TALLY_LEN + 4 tier counters */
-    uint32_t *d_counters = nullptr; /* [0] work pass1 [1] work pass2 [2] overflow count [3] overflow count of pass 2 */
-    uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr;
+    uint32_t *d_counters = nullptr; /* [0..2] work counters of the three passes, [4] / [5] overflow counts of pass 1 / 2 */
+    uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
     bool with_gm = true;
 };
 
@@ -127,8 +137,8 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 }
 
 void free_batch_buffers(avk_dev_batch *db) {
-    void *ptrs[] = {db->d_regions, db->d_variants, db->d_alleles, db->d_status, db->d_ed1, db->d_ed2, db->d_nopt, db->d_present, db->d_gm,
-                    db->d_vexp, db->d_vobs, db->d_vcls, db->d_vzyg, db->d_seq, db->d_seqlen, db->d_tally, db->d_counters, db->d_overflow, db->d_overflow2};
+    void *ptrs[] = {db->d_regions, db->d_variants, db->d_alleles, db->d_region_out, db->d_gm, db->d_var_out,
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -208,6 +218,12 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     if (n == "lds_bytes_per_wave") {
         if (value < 0 || value > 40 * 1024) return fail(ctx, AVK_E_ARG, "lds_bytes_per_wave must be in [0, 40960]");
         ctx->lds_bytes_per_wave = value & ~15ll;
+    } else if (n == "lds2_bytes_per_wave") {
+        if (value < 0 || value > 40 * 1024) return fail(ctx, AVK_E_ARG, "lds2_bytes_per_wave must be in [0, 40960]");
+        ctx->lds2_bytes_per_wave = value & ~15ll;
+    } else if (n == "lds2_ed_cap") {
+        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "lds2_ed_cap must be in [1, 4096]");
+        ctx->lds2_ed_cap = value;
     } else if (n == "lds_ed_cap") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "lds_ed_cap must be in [1, 4096]");
         ctx->lds_ed_cap = value;
@@ -321,21 +337,14 @@ int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch 
     AVK_TRY(dev_alloc(ctx, &db->d_regions, n));
     AVK_TRY(dev_alloc(ctx, &db->d_variants, nv));
     AVK_TRY(dev_alloc(ctx, &db->d_alleles, db->host.alleles.size()));
-    AVK_TRY(dev_alloc(ctx, &db->d_status, n));
-    AVK_TRY(dev_alloc(ctx, &db->d_ed1, n));
-    AVK_TRY(dev_alloc(ctx, &db->d_ed2, n));
-    AVK_TRY(dev_alloc(ctx, &db->d_nopt, n));
-    AVK_TRY(dev_alloc(ctx, &db->d_present, n));
-    AVK_TRY(dev_alloc(ctx, &db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS));
-    AVK_TRY(dev_alloc(ctx, &db->d_vexp, nv));
-    AVK_TRY(dev_alloc(ctx, &db->d_vobs, nv));
-    AVK_TRY(dev_alloc(ctx, &db->d_vcls, nv));
-    AVK_TRY(dev_alloc(ctx, &db->d_vzyg, nv));
+    AVK_TRY(dev_alloc(ctx, &db->d_region_out, n * 4));
+    AVK_TRY(dev_alloc(ctx, &db->d_var_out, nv));
     AVK_TRY(dev_alloc(ctx, &db->d_seqlen, n * 5));
-    AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_LEN + 4));
-    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)8));
+    AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_LEN + 5));
+    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)16));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
 #undef AVK_TRY
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
@@ -366,6 +375,7 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
     if (cfg->enable_exact_shortcut) return fail(ctx, AVK_E_ARG, "enable_exact_shortcut is not implemented on the device path yet");
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions;
+    if (ctx->lds2_bytes_per_wave * 4 > 160 * 1024) return fail(ctx, AVK_E_ARG, "lds2_bytes_per_wave too large");
     /* sequences: allocate the output arena on first use */
     if (cfg->enable_sequences && !db->d_seq) {
         int rc = dev_alloc(ctx, &db->d_seq, (size_t)db->seq_total + 16);
@@ -402,8 +412,12 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
         ctx->big_alloc = big_need;
     }
 
-    AVK_HIP(ctx, hipMemsetAsync(db->d_tally, 0, ((size_t)AVK_TALLY_LEN + 4) * sizeof(uint64_t), ctx->stream));
-    AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 8 * sizeof(uint32_t), ctx->stream));
+    AVK_HIP(ctx, hipMemsetAsync(db->d_tally, 0, ((size_t)AVK_TALLY_LEN + 5) * sizeof(uint64_t), ctx->stream));
+    AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 16 * sizeof(uint32_t), ctx->stream));
+    if (ctx->emit_group_metrics && !db->d_gm) {
+        int rc = dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
+        if (rc) return rc;
+    }
 
     AvkKernelArgs a;
     memset(&a, 0, sizeof(a));
@@ -416,20 +430,15 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
     a.enable_exact_shortcut = 0;
     a.tier[0].ws_bytes = (uint64_t)ctx->lds_bytes_per_wave;
     a.tier[0].ed_cap = (uint32_t)ctx->lds_ed_cap;
-    a.tier[1].ws_bytes = (uint64_t)ctx->ws_bytes_per_wave;
-    a.tier[1].ed_cap = 0;
-    a.tier[2].ws_bytes = (uint64_t)ctx->big_ws_bytes;
+    a.tier[1].ws_bytes = (uint64_t)ctx->lds2_bytes_per_wave;
+    a.tier[1].ed_cap = (uint32_t)ctx->lds2_ed_cap;
+    a.tier[2].ws_bytes = (uint64_t)ctx->ws_bytes_per_wave;
     a.tier[2].ed_cap = 0;
-    a.status = db->d_status;
-    a.ed_h1 = db->d_ed1;
-    a.ed_h2 = db->d_ed2;
-    a.n_optima = db->d_nopt;
-    a.type_present = db->d_present;
+    a.tier[3].ws_bytes = (uint64_t)ctx->big_ws_bytes;
+    a.tier[3].ed_cap = 0;
+    a.region_out = db->d_region_out;
     a.group_metrics = ctx->emit_group_metrics ? db->d_gm : nullptr;
-    a.var_expected = db->d_vexp;
-    a.var_observed = db->d_vobs;
-    a.var_class = db->d_vcls;
-    a.var_zyg = db->d_vzyg;
+    a.var_out = db->d_var_out;
     a.seq_bytes = cfg->enable_sequences ? db->d_seq : nullptr;
     a.seq_len = cfg->enable_sequences ? db->d_seqlen : nullptr;
     a.tally = db->d_tally;
@@ -437,31 +446,51 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
 
     if (cfg->max_branch_factor == 0) return fail(ctx, AVK_E_ARG, "max_branch_factor must be greater than 0 (query_optimizer.rs:177)");
 
+    AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_region_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     AVK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    /* pass 1 */
-    a.first_tier = 0;
-    a.work_list = nullptr;
-    a.n_work_dev = nullptr;
-    a.work_counter = db->d_counters + 0;
-    a.overflow_list = db->d_overflow;
-    a.overflow_count = db->d_counters + 2;
-    a.hbm_ws = ctx->ws_bytes_per_wave ? ctx->d_ws : nullptr;
-    const size_t lds = (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave;
-    if (n) {
-        hipLaunchKernelGGL(avk_region_kernel, dim3(blocks), dim3(256), lds, ctx->stream, a);
+    /* up to four launches, one per workspace tier; each consumes the overflow list of the one
+     * before it (its length is read on the device, so nothing comes back to the host in between) */
+    const bool use[4] = {ctx->lds_bytes_per_wave > 0, ctx->lds2_bytes_per_wave > 0, ctx->ws_bytes_per_wave > 0, ctx->big_ws_bytes > 0};
+    int last = -1;
+    for (int t = 0; t < 4; ++t)
+        if (use[t]) last = t;
+    if (last < 0) return fail(ctx, AVK_E_ARG, "every workspace tier is disabled");
+    const uint32_t *list = nullptr, *count = nullptr;
+    uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
+    int nlist = 0;
+    for (int t = 0; t < 4 && n; ++t) {
+        if (!use[t]) continue;
+        a.pass_tier = (uint32_t)t;
+        a.work_list = list;
+        a.n_work_dev = count;
+        a.work_counter = db->d_counters + t;
+        if (t != last) {
+            a.overflow_list = lists[nlist];
+            a.overflow_count = db->d_counters + 8 + nlist;
+        } else {
+            a.overflow_list = nullptr;
+            a.overflow_count = nullptr;
+        }
+        if (t == 0) {
+            a.hbm_ws = nullptr;
+            hipLaunchKernelGGL(avk_region_kernel_lds, dim3(blocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
+        } else if (t == 1) { /* one workgroup per CU, four large slices */
+            a.hbm_ws = nullptr;
+            uint32_t b2 = (uint32_t)ctx->n_cus < blocks ? (uint32_t)ctx->n_cus : blocks;
+            hipLaunchKernelGGL(avk_region_kernel_lds, dim3(b2), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds2_bytes_per_wave, ctx->stream, a);
+        } else if (t == 2) {
+            a.hbm_ws = ctx->d_ws;
+            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(blocks), dim3(256), 0, ctx->stream, a);
+        } else {
+            a.hbm_ws = ctx->d_big;
+            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
+        }
         AVK_HIP(ctx, hipGetLastError());
-    }
-    /* pass 2: whatever overflowed, big slices, work count read on the device */
-    if (n && ctx->big_ws_bytes) {
-        a.first_tier = 2;
-        a.work_list = db->d_overflow;
-        a.n_work_dev = db->d_counters + 2;
-        a.work_counter = db->d_counters + 1;
-        a.overflow_list = db->d_overflow2;
-        a.overflow_count = db->d_counters + 3;
-        a.hbm_ws = ctx->d_big;
-        hipLaunchKernelGGL(avk_region_kernel, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
-        AVK_HIP(ctx, hipGetLastError());
+        if (t != last) {
+            list = lists[nlist];
+            count = db->d_counters + 8 + nlist;
+            nlist += 1;
+        }
     }
     AVK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
@@ -484,7 +513,7 @@ int avk_last_kernel_ms(avk_ctx *ctx, float *ms) {
     return 0;
 }
 
-int avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[4]) {
+int avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]) {
     if (!ctx || !counts) return AVK_E_ARG;
     memcpy(counts, ctx->last_tiers, sizeof(ctx->last_tiers));
     return 0;
@@ -494,22 +523,15 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     if (!ctx || !db || !out || !out->status) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions, nv = db->n_variants_dev;
-    std::vector<uint8_t> vexp(nv + 1), vobs(nv + 1), vcls(nv + 1), vzyg(nv + 1);
-    std::vector<uint64_t> tally((size_t)AVK_TALLY_LEN + 4);
+    std::vector<uint32_t> rout(n * 4 + 4), vout(nv + 1);
+    std::vector<uint64_t> tally((size_t)AVK_TALLY_LEN + 5);
     hipStream_t s = ctx->stream;
 #define D2H(dst, src, bytes) \
     if ((bytes) > 0) AVK_HIP(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s))
-    D2H(out->status, db->d_status, n * sizeof(int32_t));
-    if (out->ed_h1) D2H(out->ed_h1, db->d_ed1, n * sizeof(uint32_t));
-    if (out->ed_h2) D2H(out->ed_h2, db->d_ed2, n * sizeof(uint32_t));
-    if (out->n_optima) D2H(out->n_optima, db->d_nopt, n * sizeof(uint32_t));
-    if (out->type_present) D2H(out->type_present, db->d_present, n * sizeof(uint16_t));
-    if (out->group_metrics && ctx->emit_group_metrics) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
-    if (out->var_expected) D2H(vexp.data(), db->d_vexp, nv);
-    if (out->var_observed) D2H(vobs.data(), db->d_vobs, nv);
-    if (out->var_class) D2H(vcls.data(), db->d_vcls, nv);
-    if (out->var_zyg) D2H(vzyg.data(), db->d_vzyg, nv);
-    D2H(tally.data(), db->d_tally, ((size_t)AVK_TALLY_LEN + 4) * sizeof(uint64_t));
+    D2H(rout.data(), db->d_region_out, n * 4 * sizeof(uint32_t));
+    if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
+    if (out->var_expected || out->var_observed || out->var_class || out->var_zyg) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
+    D2H(tally.data(), db->d_tally, ((size_t)AVK_TALLY_LEN + 5) * sizeof(uint64_t));
     std::vector<uint8_t> seq;
     std::vector<uint32_t> seqlen;
     const bool want_seq = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq;
@@ -521,15 +543,24 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     }
 #undef D2H
     AVK_HIP(ctx, hipStreamSynchronize(s));
+    for (uint64_t r = 0; r < n; ++r) {
+        const uint32_t *w = rout.data() + 4 * r;
+        out->status[r] = (int32_t)w[0];
+        if (out->ed_h1) out->ed_h1[r] = w[1];
+        if (out->ed_h2) out->ed_h2[r] = w[2];
+        if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
+        if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
+    }
     for (uint64_t v = 0; v < nv; ++v) {
         const uint64_t hv = db->host.dev2host[v];
-        if (out->var_expected) out->var_expected[hv] = vexp[v];
-        if (out->var_observed) out->var_observed[hv] = vobs[v];
-        if (out->var_class) out->var_class[hv] = vcls[v];
-        if (out->var_zyg) out->var_zyg[hv] = vzyg[v];
+        const uint32_t w = vout[v];
+        if (out->var_expected) out->var_expected[hv] = (uint8_t)(w & 0xFF);
+        if (out->var_observed) out->var_observed[hv] = (uint8_t)((w >> 8) & 0xFF);
+        if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
+        if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
-    memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 4 * sizeof(uint64_t));
+    memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
     if (want_seq) {
         for (uint64_t r = 0; r < n; ++r) {
             const AvkDevRegion &dr = db->host.regions[r];
@@ -541,9 +572,6 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
             }
         }
     }
-    /* a region still marked -1 was queued for the overflow pass while that pass is disabled */
-    for (uint64_t r = 0; r < n; ++r)
-        if (out->status[r] < 0) out->status[r] = AVK_ST_CAPACITY;
     return 0;
 }
 

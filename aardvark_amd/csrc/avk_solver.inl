@@ -45,10 +45,11 @@ enum { RS_OVERFLOW = -1 }; /* internal: this tier's workspace is too small, retr
 #define AVK_ALIGN8(x) (((x) + 7u) & ~(u64)7u)
 
 /* hap record: 10 header words, then alt bit-sets, wavefront, two sequences */
-enum { H_T_REFPOS = 0, H_Q_REFPOS, H_T_LEN, H_Q_LEN, H_T_SKIP, H_Q_SKIP, H_ED, H_T_NAL, H_Q_NAL, H_PAD, H_WORDS };
+enum { H_T_REFPOS = 0, H_Q_REFPOS, H_T_LEN, H_Q_LEN, H_T_SKIP, H_Q_SKIP, H_ED, H_T_NAL, H_Q_NAL, H_NSKIP, H_WORDS };
 
 struct HapHdr {
     u32 t_refpos, q_refpos, t_len, q_len, t_skip, q_skip, ed, t_nal, q_nal;
+    u32 nskip; /* ALT alleles that could not be incorporated (either side); the skip DISTANCE can be 0 for REF == ALT */
 };
 
 /* local variant record in the workspace */
@@ -178,18 +179,16 @@ AVK_DEV void dw_bump(u32 *wf, u32 old_ed) {
     }
 }
 
-/* maximum_baseline_distance / maximum_other_distance (:201-215) */
-AVK_DEV void dw_maxes(const u32 *wf, u32 ed, u32 &mb, u32 &mo) {
+/* reached_baseline_end || reached_other_end (:220-231) as one ballot: some diagonal touches the end
+ * of either sequence (the two maxima of :201-215 are only ever compared with the lengths) */
+AVK_DEV bool dw_touches_end(const u32 *wf, u32 ed, u32 bl, u32 ol) {
     const u32 nd = 2 * ed + 1;
-    u32 lb = 0, lo = 0;
+    bool any = false;
     for (u32 i = (u32)wv_lane(); i < nd; i += 64) {
         const u32 d = wf[i];
-        lo = d > lo ? d : lo;
-        const u32 b = d + ed - i;
-        lb = b > lb ? b : lb;
+        any = any || d + ed - i >= bl || d >= ol;
     }
-    mb = wv_max_u32(lb);
-    mo = wv_max_u32(lo);
+    return wv_ballot(any) != 0;
 }
 
 /* reached_full_diagonal (:237-245) */
@@ -207,10 +206,7 @@ AVK_DEV bool dw_full_diagonal(const u32 *wf, u32 ed, u32 bl, u32 ol) {
  * returns 0 or RS_OVERFLOW when the wavefront no longer fits `cap` entries. */
 AVK_DEV int dw_update(u32 *wf, u32 cap, u32 &ed, const u8 *B, u32 bl, const u8 *O, u32 ol) {
     dw_extend(wf, ed, B, bl, O, ol);
-    for (;;) {
-        u32 mb, mo;
-        dw_maxes(wf, ed, mb, mo);
-        if (mb >= bl || mo >= ol) break;
+    while (!dw_touches_end(wf, ed, bl, ol)) {
         if (2 * ed + 3 > cap) return RS_OVERFLOW;
         dw_bump(wf, ed);
         ed += 1;
@@ -271,6 +267,7 @@ AVK_DEV HapHdr hap_load(const u32 *w) {
     h.ed = ld32u(w + H_ED);
     h.t_nal = ld32u(w + H_T_NAL);
     h.q_nal = ld32u(w + H_Q_NAL);
+    h.nskip = ld32u(w + H_NSKIP);
     return h;
 }
 AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
@@ -284,6 +281,7 @@ AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
         w[H_ED] = h.ed;
         w[H_T_NAL] = h.t_nal;
         w[H_Q_NAL] = h.q_nal;
+        w[H_NSKIP] = h.nskip;
     }
 }
 AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
@@ -308,7 +306,7 @@ AVK_DEV void trk_copy_reference(const Ctx &c, u8 *seq, u32 &len, u32 &refpos, u3
 
 /* HaplotypeTracker::extend_variant (haplotype_dwfa.rs:175-212); returns the `success` flag */
 AVK_DEV bool trk_extend_variant(const Ctx &c, const LVar &v, u32 allele, u32 sync, u8 *seq, u32 &len, u32 &refpos, u32 &skip,
-                                u64 *alt, u32 &nal) {
+                                u64 *alt, u32 &nal, u32 &nskip) {
     trk_copy_reference(c, seq, len, refpos, v.rel_pos);
     bool ok = true;
     if (allele == AL_ALT) {
@@ -319,6 +317,7 @@ AVK_DEV bool trk_extend_variant(const Ctx &c, const LVar &v, u32 allele, u32 syn
             if (wv_lane() == 0) alt[nal >> 6] |= 1ull << (nal & 63);
         } else {
             skip += v.alt_ed; /* edit_distance(allele0, allele1), :199 — equal to the wavefront distance */
+            nskip += 1;
             ok = false;
             if (wv_lane() == 0) alt[nal >> 6] |= 1ull << (nal & 63); /* the allele pushed is still ALT (:204) */
         }
@@ -335,10 +334,10 @@ AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_tr
     bool ok;
     if (is_truth) {
         trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, sync);
-        ok = trk_extend_variant(c, v, allele, sync, p.tseq, h.t_len, h.t_refpos, h.t_skip, p.talt, h.t_nal);
+        ok = trk_extend_variant(c, v, allele, sync, p.tseq, h.t_len, h.t_refpos, h.t_skip, p.talt, h.t_nal, h.nskip);
     } else {
         trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, sync);
-        ok = trk_extend_variant(c, v, allele, sync, p.qseq, h.q_len, h.q_refpos, h.q_skip, p.qalt, h.q_nal);
+        ok = trk_extend_variant(c, v, allele, sync, p.qseq, h.q_len, h.q_refpos, h.q_skip, p.qalt, h.q_nal, h.nskip);
     }
     wv_sync();
     return ok;
@@ -752,21 +751,28 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
 /* ------------------------------------------------------------------------------------------ */
 AVK_DEV u32 *gfield(u32 *g, int group, int field) { return g + group * AVK_N_FIELDS + field; }
 
-/* GroupMetrics::add_truth_zygosity for one variant into joint + type group (lane-parallel caller) */
-AVK_DEV void gm_add_truth(u32 *g, u32 type, u32 w, u32 exp, u32 obs) {
+/* GroupMetrics::add_truth_zygosity (grouped_metrics.rs:183-227) for one variant into joint + type
+ * group.  Query variants are scored "as truth" and then moved to the query columns by
+ * add_swap_benchmark (grouped_metrics.rs:268-277: query_tp <- truth_tp, query_fp <- truth_fn,
+ * query_fp_gt <- truth_fn_gt); `q` selects those columns directly. */
+AVK_DEV void gm_add(u32 *g, bool q, u32 type, u32 w, u32 exp, u32 obs) {
+    const int f_gt_tp = q ? AVK_F_GT_QUERY_TP : AVK_F_GT_TRUTH_TP, f_gt_fn = q ? AVK_F_GT_QUERY_FP : AVK_F_GT_TRUTH_FN;
+    const int f_gt_fn_gt = q ? AVK_F_GT_QUERY_FP_GT : AVK_F_GT_TRUTH_FN_GT;
+    const int f_hap_tp = q ? AVK_F_HAP_QUERY_TP : AVK_F_HAP_TRUTH_TP, f_hap_fn = q ? AVK_F_HAP_QUERY_FP : AVK_F_HAP_TRUTH_FN;
+    const int f_w_tp = q ? AVK_F_WHAP_QUERY_TP : AVK_F_WHAP_TRUTH_TP, f_w_fn = q ? AVK_F_WHAP_QUERY_FP : AVK_F_WHAP_TRUTH_FN;
     for (int pass = 0; pass < 2; ++pass) {
         const int grp = pass == 0 ? 0 : 1 + (int)type;
         if (exp == obs) {
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_HAP_TRUTH_TP), exp);
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_WHAP_TRUTH_TP), exp * w);
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_GT_TRUTH_TP), 1);
+            avk_atomic_add_u32(gfield(g, grp, f_hap_tp), exp);
+            avk_atomic_add_u32(gfield(g, grp, f_w_tp), exp * w);
+            avk_atomic_add_u32(gfield(g, grp, f_gt_tp), 1);
         } else {
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_HAP_TRUTH_TP), obs);
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_HAP_TRUTH_FN), exp - obs);
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_WHAP_TRUTH_TP), obs * w);
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_WHAP_TRUTH_FN), (exp - obs) * w);
-            avk_atomic_add_u32(gfield(g, grp, AVK_F_GT_TRUTH_FN), 1);
-            if (obs > 0) avk_atomic_add_u32(gfield(g, grp, AVK_F_GT_TRUTH_FN_GT), 1);
+            avk_atomic_add_u32(gfield(g, grp, f_hap_tp), obs);
+            avk_atomic_add_u32(gfield(g, grp, f_hap_fn), exp - obs);
+            avk_atomic_add_u32(gfield(g, grp, f_w_tp), obs * w);
+            avk_atomic_add_u32(gfield(g, grp, f_w_fn), (exp - obs) * w);
+            avk_atomic_add_u32(gfield(g, grp, f_gt_fn), 1);
+            if (obs > 0) avk_atomic_add_u32(gfield(g, grp, f_gt_fn_gt), 1);
         }
     }
 }
@@ -858,8 +864,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     off = AVK_ALIGN8(off + 4ull * (c.N + 1));
     c.gm = (u32 *)(ws + off);
     off += 4ull * AVK_N_GROUPS * AVK_N_FIELDS;
-    c.gq = (u32 *)(ws + off);
-    off = AVK_ALIGN8(off + 4ull * AVK_N_GROUPS * AVK_N_FIELDS);
+    c.gq = (u32 *)(ws + off); /* 32 words: RECORD_BP totals per group, truth then query */
+    off = AVK_ALIGN8(off + 4ull * 32);
     c.wfs = (u32 *)(ws + off);
     off = AVK_ALIGN8(off + 4ull * c.wfs_cap);
     c.seq_a = ws + off;
@@ -1012,6 +1018,22 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
             c.pool_cap = (u32)cap;
             const HapPtr ap = hap_ptr(poolA + (u64)k * nodeA_bytes + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
             u64 *res = c.bres + (u64)(0 * 2 + hh) * 2 * c.alw; /* candidate slot 0 = current */
+            const HapHdr ah = hap_load(ap.w);
+            if (ah.ed == 0 && ah.nskip == 0 && c.N < 500) {
+                /* The phasing search already proved truth == query on this haplotype with every ALT
+                 * incorporated.  The exact-match search then has exactly one zero-error path (keep every
+                 * allele); it is always the top of the queue, cannot be pruned before it finalises
+                 * (fewer than 500 expansions, :309-311) and wins with num_errors = 0 and the input
+                 * alleles (exact_gt_optimizer.rs:169-192).  Nothing to search. */
+                wv_sync();
+                for (u32 i = lane; i < c.alw; i += 64) {
+                    res[i] = ap.talt[i];
+                    res[c.alw + i] = ap.qalt[i];
+                }
+                wv_sync();
+                errs[hh] = 0;
+                continue;
+            }
             const int e = phaseB(c, ap.talt, ap.qalt, res);
             if (e == RS_OVERFLOW) return RS_OVERFLOW;
             if (e < 0) return -e - 100;
@@ -1024,6 +1046,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
             wv_sync();
             for (u32 i = lane; i < 4 * c.alw; i += 64) c.bres[4 * c.alw + i] = c.bres[i]; /* candidate slot 1 = best */
             wv_sync();
+            if (total == 0) break; /* no later optimum can be strictly better */
         }
     }
     winner_node = best_k;
@@ -1038,7 +1061,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     out.ed2 = h1.ed;
 
     zero_words(c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
-    zero_words(c.gq, AVK_N_GROUPS * AVK_N_FIELDS);
+    zero_words(c.gq, 32);
     wv_sync();
     /* compare_expected_observed for truth and query (:296-327) + per-variant outputs */
     u32 l_present = 0, l_bad = 0;
@@ -1053,7 +1076,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         const LVar v = c.vars[k];
         if (exp == 0) l_bad = AVK_ST_VARIANT_METRICS;
         else if (exp < ob) l_bad = AVK_ST_TRUTH_FP;
-        else gm_add_truth(is_truth ? c.gm : c.gq, v.type, v.alt_ed, exp, ob);
+        else gm_add(c.gm, !is_truth, v.type, v.alt_ed, exp, ob);
         l_present |= 1u << v.type;
         /* VariantMetrics (variant_metrics.rs:43-101); query entries are toggled */
         const u32 gv = v_off + k;
@@ -1064,10 +1087,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
             ea = ob;
             oa = exp;
         }
-        a.var_expected[gv] = (u8)ea;
-        a.var_observed[gv] = (u8)oa;
-        a.var_class[gv] = (u8)cls;
-        a.var_zyg[gv] = (u8)(b0 && b1 ? AVK_ZYG_HOM_ALT : (b0 ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_PHASED_HET01));
+        const u32 rz = b0 && b1 ? AVK_ZYG_HOM_ALT : (b0 ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_PHASED_HET01);
+        a.var_out[gv] = ea | (oa << 8) | (cls << 16) | (rz << 24);
     }
     const u32 bad = wv_max_u32(l_bad);
     if (bad) return (int)bad;
@@ -1075,43 +1096,44 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t)
         if (wv_ballot((l_present >> t) & 1)) present |= 1u << t;
     wv_sync();
-    /* add_swap_benchmark (:269, grouped_metrics.rs:268-277): query columns := query-run truth columns */
-    for (u32 g = lane; g < AVK_N_GROUPS; g += 64) {
-        u32 *d = c.gm + g * AVK_N_FIELDS;
-        const u32 *s = c.gq + g * AVK_N_FIELDS;
-        d[AVK_F_GT_QUERY_TP] = s[AVK_F_GT_TRUTH_TP];
-        d[AVK_F_GT_QUERY_FP] = s[AVK_F_GT_TRUTH_FN];
-        d[AVK_F_GT_QUERY_FP_GT] = s[AVK_F_GT_TRUTH_FN_GT];
-        d[AVK_F_HAP_QUERY_TP] = s[AVK_F_HAP_TRUTH_TP];
-        d[AVK_F_HAP_QUERY_FP] = s[AVK_F_HAP_TRUTH_FN];
-        d[AVK_F_WHAP_QUERY_TP] = s[AVK_F_WHAP_TRUTH_TP];
-        d[AVK_F_WHAP_QUERY_FP] = s[AVK_F_WHAP_TRUTH_FN];
-    }
-    wv_sync();
-
     /* add_basepair_stats (:335-449).  The optimizer's own sequences are the regenerated ones
      * (asserted equal at :364-367), ed(truth,query) is the node's finalized DWFA distance. */
     const int SUP[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL, AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
     u32 tcount[8], qcount[8];
     for (int s = 0; s < 8; ++s) {
-        u32 lt = 0, lq = 0;
-        for (u32 k = lane; k < c.N; k += 64) {
-            if (c.vars[k].type == SUP[s]) {
-                if (k < c.T) lt++;
-                else lq++;
-            }
+        u32 nt = 0, nq = 0;
+        for (u32 base = 0; base < c.N; base += 64) {
+            const u32 k = base + lane;
+            const bool hit = k < c.N && c.vars[k].type == SUP[s];
+            nt += (u32)avk_popc64(wv_ballot(hit && k < c.T));
+            nq += (u32)avk_popc64(wv_ballot(hit && k >= c.T));
         }
-        tcount[s] = wv_sum_u32(lt);
-        qcount[s] = wv_sum_u32(lq);
+        tcount[s] = nt;
+        qcount[s] = nq;
         present |= 1u << SUP[s];
     }
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr &wp = hh == 0 ? w0 : w1;
         const HapHdr &hd = hh == 0 ? h0 : h1;
-        const int ert = wfa_ed(c, c.ref, c.L, wp.tseq, hd.t_len);
-        if (ert < 0) return RS_OVERFLOW;
-        const int erq = wfa_ed(c, c.ref, c.L, wp.qseq, hd.q_len);
-        if (erq < 0) return RS_OVERFLOW;
+        /* a haplotype that carries no ALT allele IS the reference window: distance 0 without aligning */
+        bool l_t = false, l_q = false;
+        for (u32 i = lane; i < c.alw; i += 64) {
+            l_t = l_t || wp.talt[i] != 0;
+            l_q = l_q || wp.qalt[i] != 0;
+        }
+        const bool t_has_alt = wv_ballot(l_t) != 0, q_has_alt = wv_ballot(l_q) != 0;
+        int ert = 0, erq = 0;
+        if (t_has_alt) {
+            ert = wfa_ed(c, c.ref, c.L, wp.tseq, hd.t_len);
+            if (ert < 0) return RS_OVERFLOW;
+        }
+        if (q_has_alt) {
+            if (hd.ed == 0 && t_has_alt) erq = ert; /* distance 0 after finalize: the two sequences are identical */
+            else {
+                erq = wfa_ed(c, c.ref, c.L, wp.qseq, hd.q_len);
+                if (erq < 0) return RS_OVERFLOW;
+            }
+        } else if (hd.ed == 0) erq = ert;
         const u32 X = 2u * (u32)ert, Y = 2u * (u32)erq, Z = 2u * hd.ed;
         const u32 tp = (X + Y - Z) / 2;
         u32 add[4] = {tp, X - tp + 2 * hd.t_skip, tp, Y - tp + 2 * hd.q_skip}; /* + skip metrics :378-381 */
@@ -1119,6 +1141,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         if (lane < 4) c.gm[AVK_F_BP_TRUTH_TP + lane] += add[lane];
         wv_sync();
         for (int s = 0; s < 8; ++s) {
+            if (!qcount[s] && !tcount[s]) continue; /* contributes (0,0,0,0); the map entry exists via `present` */
             u32 q_tp = 0, q_fp = 0, t_tp = 0, t_fn = 0;
             if (qcount[s]) {
                 if (qcount[s] == c.Q) { /* filtered query == the full query haplotype */
@@ -1169,9 +1192,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     /* add_record_basepair_stats (:455-522): totals from the INPUT zygosities and raw allele space */
     wv_sync();
     {
-        u32 *tot = c.gq; /* reuse: tot[0..12] truth totals per group, tot[16..28] query totals */
-        zero_words(tot, 32);
-        wv_sync();
+        u32 *tot = c.gq; /* tot[0..12] truth totals per group, tot[16..28] query totals (zeroed above) */
         for (u32 k = lane; k < c.N; k += 64) {
             const LVar v = c.vars[k];
             const u32 z = v.zyg;
@@ -1207,33 +1228,35 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
 /* ------------------------------------------------------------------------------------------ */
 /* persistent wave: pulls regions, walks the tiers, writes results, keeps a private tally      */
 /* ------------------------------------------------------------------------------------------ */
+AVK_DEV void write_region_record(const AvkKernelArgs &a, u32 r, int status, u32 ed1, u32 ed2, u32 nopt, u32 present) {
+    const u32 lane = (u32)wv_lane();
+    if (lane < 4) {
+        const u32 w = lane == 0 ? (u32)status : lane == 1 ? ed1 : lane == 2 ? ed2 : (nopt | (present << 16));
+        a.region_out[4 * (u64)r + lane] = w; /* 4 lanes, one 16-byte segment */
+    }
+}
+
 AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
     const AvkDevRegion reg = a.regions[r];
     const u32 lane = (u32)wv_lane();
-    if (lane == 0) {
-        a.status[r] = status;
-        a.ed_h1[r] = 0;
-        a.ed_h2[r] = 0;
-        a.n_optima[r] = 0;
-        a.type_present[r] = 0;
-    }
+    write_region_record(a, r, status, 0, 0, 0, 0);
     const u32 n = reg.t_cnt + reg.q_cnt;
-    for (u32 k = lane; k < n; k += 64) {
-        a.var_expected[reg.v_off + k] = 0;
-        a.var_observed[reg.v_off + k] = 0;
-        a.var_class[reg.v_off + k] = 0;
-        a.var_zyg[reg.v_off + k] = 0;
-    }
+    for (u32 k = lane; k < n; k += 64) a.var_out[reg.v_off + k] = 0;
     if (a.group_metrics) zero_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, AVK_N_GROUPS * AVK_N_FIELDS);
     if (a.seq_bytes && a.seq_len && lane < 5) a.seq_len[5 * (u64)r + lane] = 0;
 }
 
-AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+/* PASS_LDS: this launch solves regions in the wave's LDS slice; otherwise in its HBM slice
+ * (a.pass_tier says which tier's capacities apply).  A region that does not fit is appended to the
+ * overflow list for the next launch; after the last tier it fails with AVK_ST_CAPACITY. */
+template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     const u32 lane = (u32)wv_lane();
     u64 tally[5] = {0, 0, 0, 0, 0};
-    u32 n_ok = 0, n_err = 0;
-    u32 tier_hits[4] = {0, 0, 0, 0};
-    u8 *hbm_slice = a.hbm_ws ? a.hbm_ws + (u64)wave_id * a.tier[a.first_tier == 2 ? 2 : 1].ws_bytes : (u8 *)0;
+    u32 n_ok = 0, n_err = 0, n_cap = 0;
+    const u32 tier = a.pass_tier;
+    u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
+    const u64 ws_bytes = a.tier[tier].ws_bytes;
+    const u32 ed_cap = a.tier[tier].ed_cap;
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_regions;
 
     for (;;) {
@@ -1254,48 +1277,25 @@ AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
         RegionOut out;
         out.ed1 = out.ed2 = out.n_opt = out.present = 0;
         u32 winner = 0;
-        int st = RS_OVERFLOW;
-        int used_tier = -1;
-        if (a.first_tier == 0) {
-            if (lds_slice && a.tier[0].ws_bytes) {
-                st = solve_region_tier(a, r, lds_slice, a.tier[0].ws_bytes, a.tier[0].ed_cap, c, out, winner);
-                used_tier = 0;
-            }
-            if (st == RS_OVERFLOW && hbm_slice) {
-                wv_sync();
-                st = solve_region_tier(a, r, hbm_slice, a.tier[1].ws_bytes, a.tier[1].ed_cap, c, out, winner);
-                used_tier = 1;
-            }
-            if (st == RS_OVERFLOW) { /* hand over to the overflow pass */
+        int st = solve_region_tier(a, r, ws, ws_bytes, ed_cap, c, out, winner);
+        if (st == RS_OVERFLOW) {
+            if (a.overflow_list) { /* hand over to the next tier's launch */
                 if (lane == 0) {
                     const u32 slot = avk_atomic_add_u32_global(a.overflow_count, 1);
                     a.overflow_list[slot] = r;
-                    a.status[r] = -1;
                 }
                 continue;
             }
-        } else {
-            st = solve_region_tier(a, r, hbm_slice, a.tier[2].ws_bytes, a.tier[2].ed_cap, c, out, winner);
-            used_tier = 2;
-            if (st == RS_OVERFLOW) {
-                st = AVK_ST_CAPACITY;
-                used_tier = 3;
-            }
+            st = AVK_ST_CAPACITY;
+            n_cap += 1;
         }
-        tier_hits[used_tier] += 1;
         if (st != AVK_ST_OK) {
             write_failed_region(a, r, st);
             n_err += 1;
             continue;
         }
         /* results of an Ok region */
-        if (lane == 0) {
-            a.status[r] = 0;
-            a.ed_h1[r] = out.ed1;
-            a.ed_h2[r] = out.ed2;
-            a.n_optima[r] = out.n_opt;
-            a.type_present[r] = (u16)out.present;
-        }
+        write_region_record(a, r, 0, out.ed1, out.ed2, out.n_opt, out.present);
         if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
         for (int j = 0; j < 5; ++j) {
             const u32 i = (u32)j * 64 + lane;
@@ -1326,8 +1326,8 @@ AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     if (lane == 0) {
         if (n_ok) avk_atomic_add_u64_global(a.tally + AVK_TALLY_SOLVED, n_ok);
         if (n_err) avk_atomic_add_u64_global(a.tally + AVK_TALLY_ERRORS, n_err);
-        for (int t = 0; t < 4; ++t)
-            if (tier_hits[t]) avk_atomic_add_u64_global(a.tier_counts + t, tier_hits[t]);
+        if (n_ok + n_err - n_cap) avk_atomic_add_u64_global(a.tier_counts + tier, n_ok + n_err - n_cap);
+        if (n_cap) avk_atomic_add_u64_global(a.tier_counts + 4, n_cap);
     }
 }
 

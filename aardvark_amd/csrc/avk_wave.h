@@ -7,8 +7,8 @@
  * cross-lane reductions.  Everything cross-lane goes through the few functions below.
  *
  * Two bindings:
- *   - hipcc (gfx950): the real thing — __ballot, ds_bpermute shuffles, DPP-free butterfly
- *     reductions, readfirstlane for uniform values.
+ *   - hipcc (gfx950): the real thing — __ballot, DPP row-shift/row-broadcast reductions,
+ *     readfirstlane for uniform values (ds_bpermute shuffles only where a true permute is needed).
  *   - AVK_EMU (g++, tests/emu/): a kernel-logic emulator that runs the 64 lanes of a wave as 64
  *     cooperative fibers and rendezvouses at every primitive.  It exists so that the SAME kernel
  *     source can be executed and fuzzed against the oracle in the GPU-less dev container
@@ -95,36 +95,42 @@ AVK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
 AVK_DEV uint32_t wv_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 /* a value that is identical on every lane: move it to an SGPR so branches on it are scalar */
 AVK_DEV uint32_t wv_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
-AVK_DEV uint32_t wv_max_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = t > v ? t : v;
+/* cross-lane reductions on the DPP network (row shifts inside 16 lanes, then row broadcasts):
+ * no LDS traffic, a handful of VALU cycles.  `ident` is the neutral element of the operation and
+ * fills lanes that have no source.  The result lands in lane 63 and is read back as a scalar. */
+#define AVK_DPP_STEP(op, ctrl, rmask)                                                             \
+    {                                                                                             \
+        const uint32_t t_ = (uint32_t)__builtin_amdgcn_update_dpp((int)ident, (int)v, ctrl, rmask, 0xf, false); \
+        v = op(v, t_);                                                                            \
     }
-    return wv_uni(v);
+#define AVK_OP_MAX(a, b) ((a) > (b) ? (a) : (b))
+#define AVK_OP_MIN(a, b) ((a) < (b) ? (a) : (b))
+#define AVK_OP_ADD(a, b) ((a) + (b))
+#define AVK_DPP_REDUCE(op)              \
+    AVK_DPP_STEP(op, 0x111, 0xf) /* row_shr:1 */  \
+    AVK_DPP_STEP(op, 0x112, 0xf) /* row_shr:2 */  \
+    AVK_DPP_STEP(op, 0x114, 0xf) /* row_shr:4 */  \
+    AVK_DPP_STEP(op, 0x118, 0xf) /* row_shr:8 */  \
+    AVK_DPP_STEP(op, 0x142, 0xa) /* row_bcast:15 */ \
+    AVK_DPP_STEP(op, 0x143, 0xc) /* row_bcast:31 */ \
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+
+AVK_DEV uint32_t wv_max_u32(uint32_t v) {
+    const uint32_t ident = 0u;
+    AVK_DPP_REDUCE(AVK_OP_MAX)
 }
 AVK_DEV uint32_t wv_min_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
-        v = t < v ? t : v;
-    }
-    return wv_uni(v);
+    const uint32_t ident = 0xFFFFFFFFu;
+    AVK_DPP_REDUCE(AVK_OP_MIN)
 }
 AVK_DEV uint32_t wv_sum_u32(uint32_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += (uint32_t)__shfl_xor((int)v, o, 64);
-    return wv_uni(v);
+    const uint32_t ident = 0u;
+    AVK_DPP_REDUCE(AVK_OP_ADD)
 }
+/* 64-bit minimum as two 32-bit reductions: high words first, then the low words of the ties */
 AVK_DEV uint64_t wv_min_u64(uint64_t v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, o, 64);
-        uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), o, 64);
-        uint64_t t = ((uint64_t)hi << 32) | lo;
-        v = t < v ? t : v;
-    }
-    uint32_t lo = wv_uni((uint32_t)v), hi = wv_uni((uint32_t)(v >> 32));
+    const uint32_t hi = wv_min_u32((uint32_t)(v >> 32));
+    const uint32_t lo = wv_min_u32((uint32_t)(v >> 32) == hi ? (uint32_t)v : 0xFFFFFFFFu);
     return ((uint64_t)hi << 32) | lo;
 }
 /* orders this wave's own memory traffic: lanes of one wave communicate through LDS / their

@@ -174,7 +174,8 @@ void avk_ctx_destroy(avk_ctx *ctx);
 const char *avk_last_error(const avk_ctx *ctx);
 /* run every launch of this context on an existing hipStream_t (e.g. torch's current stream) */
 int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
-/* knobs: "lds_bytes_per_wave", "lds_ed_cap", "waves_per_cu", "ws_bytes_per_wave", "big_ws_bytes", "big_waves",
+/* knobs: "lds_bytes_per_wave", "lds_ed_cap", "lds2_bytes_per_wave", "lds2_ed_cap", "waves_per_cu", "ws_bytes_per_wave",
+ * "big_ws_bytes", "big_waves" (workspace tiers: small LDS slice, large LDS slice, HBM slice, big HBM slice),
  * "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced) */
 int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
 
@@ -203,7 +204,7 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
  * avk_compare_batch on this context, from hipEvents on the context stream; how many regions
  * each workspace tier solved; algorithmic bytes of the batch (DESIGN.md "bytes per region") */
 int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);
-int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[4]);
+int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
 
 /* Merge path (src/merge_solver.rs:137-143): for pair p, optimize_sequences(set a, set b) and

@@ -157,20 +157,21 @@ struct WaveTask {
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
-    avk::region_worker(*t->args, t->wave_id, t->lds);
+    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds);
+    else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
 }
 
 } // namespace
 
 extern "C" {
 
-/* Mirrors avk_compare_batch on emulated wavefronts.  lds_bytes / ws_bytes / big_ws_bytes are the
- * per-wave workspace sizes of the three tiers (0 disables a tier), lds_ed_cap the wavefront cap
- * of the LDS tier, n_waves the number of persistent waves, threads the OS threads running them.
- * tier_counts[4] receives how many regions each tier solved (+ capacity failures). */
+/* Mirrors avk_compare_batch on emulated wavefronts.  lds_bytes / lds2_bytes / ws_bytes / big_ws_bytes
+ * are the per-wave workspace sizes of the four tiers (0 disables a tier), *_ed_cap the wavefront caps
+ * of the LDS tiers, n_waves the number of persistent waves, threads the OS threads running them.
+ * tier_counts[5] receives how many regions each tier finished, then the capacity failures. */
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
-                      const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t ws_bytes,
-                      uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
+                      const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
+                      uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
     std::vector<uint64_t> base(n_contigs), lens(n_contigs);
     uint64_t total = 0;
     for (uint32_t c = 0; c < n_contigs; ++c) {
@@ -190,14 +191,11 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
         return rc;
     }
     const uint64_t n = batch->n_regions, nv = pb.variants.size();
-    std::vector<int32_t> status(n, -1);
-    std::vector<uint32_t> ed1(n), ed2(n), nopt(n);
-    std::vector<uint16_t> present(n);
+    std::vector<uint32_t> rout(n * 4 + 4, 0), vout(nv + 1, 0);
     std::vector<uint32_t> gm(out->group_metrics ? n * AVK_N_GROUPS * AVK_N_FIELDS : 0);
-    std::vector<uint8_t> vexp(nv + 1), vobs(nv + 1), vcls(nv + 1), vzyg(nv + 1);
-    std::vector<uint64_t> tally(AVK_TALLY_LEN, 0), tiers(4, 0);
-    std::vector<uint32_t> overflow_list(n + 1);
-    uint32_t overflow_count = 0, work_counter = 0;
+    std::vector<uint64_t> tally(AVK_TALLY_LEN, 0), tiers(5, 0);
+    std::vector<uint32_t> lists[3] = {std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1)};
+    uint32_t counters[16] = {0};
 
     AvkKernelArgs a;
     memset(&a, 0, sizeof(a));
@@ -208,25 +206,17 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
     a.n_regions = (uint32_t)n;
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut;
-    a.work_counter = &work_counter;
-    a.overflow_list = overflow_list.data();
-    a.overflow_count = &overflow_count;
     a.tier[0].ws_bytes = lds_bytes;
     a.tier[0].ed_cap = lds_ed_cap;
-    a.tier[1].ws_bytes = ws_bytes;
-    a.tier[1].ed_cap = 0;
-    a.tier[2].ws_bytes = big_ws_bytes;
+    a.tier[1].ws_bytes = lds2_bytes;
+    a.tier[1].ed_cap = lds2_ed_cap;
+    a.tier[2].ws_bytes = ws_bytes;
     a.tier[2].ed_cap = 0;
-    a.status = status.data();
-    a.ed_h1 = ed1.data();
-    a.ed_h2 = ed2.data();
-    a.n_optima = nopt.data();
-    a.type_present = present.data();
+    a.tier[3].ws_bytes = big_ws_bytes;
+    a.tier[3].ed_cap = 0;
+    a.region_out = rout.data();
     a.group_metrics = out->group_metrics ? gm.data() : nullptr;
-    a.var_expected = vexp.data();
-    a.var_observed = vobs.data();
-    a.var_class = vcls.data();
-    a.var_zyg = vzyg.data();
+    a.var_out = vout.data();
     a.seq_bytes = want_seq ? out->seq_bytes : nullptr;
     a.seq_len = want_seq ? out->seq_len : nullptr;
     a.tally = tally.data();
@@ -260,43 +250,61 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
         for (auto &t : ts) t.join();
     };
 
-    a.first_tier = 0;
-    run_pass(n_waves ? n_waves : 1, ws_bytes, lds_bytes);
-    if (overflow_count) {
-        const uint32_t novf = overflow_count;
-        std::vector<uint32_t> list(overflow_list.begin(), overflow_list.begin() + novf);
-        a.work_list = list.data();
-        a.n_regions = novf;
-        work_counter = 0;
-        overflow_count = 0;
-        a.first_tier = 2;
-        if (big_ws_bytes) run_pass(novf < 4 ? novf : 4, big_ws_bytes, 0);
-        else {
-            for (uint32_t i = 0; i < novf; ++i) status[list[i]] = AVK_ST_CAPACITY;
-            tiers[3] += novf;
-            tally[AVK_TALLY_ERRORS] += novf;
+    /* the same four tier launches as avk_compare_resident (aardvark_amd/csrc/avk_host.hip) */
+    const bool use[4] = {lds_bytes > 0, lds2_bytes > 0, ws_bytes > 0, big_ws_bytes > 0};
+    int last = -1;
+    for (int t = 0; t < 4; ++t)
+        if (use[t]) last = t;
+    if (last < 0) return AVK_E_ARG;
+    const uint32_t *list = nullptr, *count = nullptr;
+    int nlist = 0;
+    for (int t = 0; t < 4 && n; ++t) {
+        if (!use[t]) continue;
+        a.pass_tier = (uint32_t)t;
+        a.work_list = list;
+        a.n_work_dev = count;
+        a.work_counter = counters + t;
+        if (t != last) {
+            a.overflow_list = lists[nlist].data();
+            a.overflow_count = counters + 8 + nlist;
+        } else {
+            a.overflow_list = nullptr;
+            a.overflow_count = nullptr;
         }
-        a.work_list = nullptr;
+        const uint32_t todo = count ? *count : (uint32_t)n;
+        if (todo) {
+            if (t == 0) run_pass(n_waves ? n_waves : 1, 0, lds_bytes);
+            else if (t == 1) run_pass(n_waves ? n_waves : 1, 0, lds2_bytes);
+            else if (t == 2) run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
+            else run_pass(todo < 4 ? todo : 4, big_ws_bytes, 0);
+        }
+        if (t != last) {
+            list = lists[nlist].data();
+            count = counters + 8 + nlist;
+            nlist += 1;
+        }
     }
 
     /* copy back in caller order */
     for (uint64_t r = 0; r < n; ++r) {
-        out->status[r] = status[r];
-        if (out->ed_h1) out->ed_h1[r] = ed1[r];
-        if (out->ed_h2) out->ed_h2[r] = ed2[r];
-        if (out->n_optima) out->n_optima[r] = nopt[r];
-        if (out->type_present) out->type_present[r] = present[r];
+        const uint32_t *w = rout.data() + 4 * r;
+        out->status[r] = (int32_t)w[0];
+        if (out->ed_h1) out->ed_h1[r] = w[1];
+        if (out->ed_h2) out->ed_h2[r] = w[2];
+        if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
+        if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
     }
     if (out->group_metrics) memcpy(out->group_metrics, gm.data(), gm.size() * sizeof(uint32_t));
     for (uint64_t v = 0; v < nv; ++v) {
         const uint64_t hv = pb.dev2host[v];
-        if (out->var_expected) out->var_expected[hv] = vexp[v];
-        if (out->var_observed) out->var_observed[hv] = vobs[v];
-        if (out->var_class) out->var_class[hv] = vcls[v];
-        if (out->var_zyg) out->var_zyg[hv] = vzyg[v];
+        const uint32_t w = vout[v];
+        if (out->var_expected) out->var_expected[hv] = (uint8_t)(w & 0xFF);
+        if (out->var_observed) out->var_observed[hv] = (uint8_t)((w >> 8) & 0xFF);
+        if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
+        if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
-    if (tier_counts) memcpy(tier_counts, tiers.data(), 4 * sizeof(uint64_t));
+    if (tier_counts) memcpy(tier_counts, tiers.data(), 5 * sizeof(uint64_t));
     return 0;
 }
 

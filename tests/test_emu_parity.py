@@ -75,15 +75,18 @@ def test_results_do_not_depend_on_the_workspace_tier(oracle):
     pass give identical outputs; a workspace that is too small everywhere reports CAPACITY"""
     contigs, batch = scenarios.fuzz_regions(21, 60)
     want = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True)
-    lds_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=64 * 1024, lds_ed_cap=64, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
-    hbm_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
-    big_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
-    tiny_lds = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=4096, lds_ed_cap=2, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
-    for got in (lds_only, hbm_only, big_only, tiny_lds):
+    lds_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=64 * 1024, lds_ed_cap=64, lds2_bytes=0, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    lds2_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, lds2_bytes=40 * 1024, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    hbm_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, lds2_bytes=0, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    big_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, lds2_bytes=0, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    tiny_lds = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=4096, lds_ed_cap=2, lds2_bytes=6144, lds2_ed_cap=4, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    for got in (lds_only, lds2_only, hbm_only, big_only, tiny_lds):
         assert got.diff(want) == []
-    assert hbm_only.tier_counts[0] == 0 and big_only.tier_counts[2] == batch.n_regions and tiny_lds.tier_counts[1] > 0
-    starved = emu_lib.compare_batch(batch, contigs, lds_bytes=2048, lds_ed_cap=2, ws_bytes=0, big_ws_bytes=4096, threads=EMU_THREADS)
+    assert hbm_only.tier_counts[0] == 0 and hbm_only.tier_counts[1] == 0 and big_only.tier_counts[3] == batch.n_regions
+    assert tiny_lds.tier_counts[1] > 0 and tiny_lds.tier_counts[2] > 0 and sum(tiny_lds.tier_counts) == batch.n_regions
+    starved = emu_lib.compare_batch(batch, contigs, lds_bytes=2048, lds_ed_cap=2, lds2_bytes=0, ws_bytes=0, big_ws_bytes=4096, threads=EMU_THREADS)
     assert set(starved.status.tolist()) <= {0, 21} and (starved.status == 21).any()
+    assert starved.tier_counts[4] == int((starved.status == 21).sum())
     ok = starved.status == 0
     assert np.array_equal(starved.ed_h1[ok], want.ed_h1[ok]) and np.array_equal(starved.group_metrics[ok], want.group_metrics[ok])
 

@@ -37,7 +37,7 @@ def test_native_library_is_the_one_running(ctx):
     import aardvark_amd
     assert os.path.exists(aardvark_amd.library_path())
     maps = open("/proc/self/maps").read()
-    assert "libaardvark_amd.so" in maps
+    assert os.path.basename(aardvark_amd.library_path()) in maps
 
 
 def test_reference_known_answer_regions(ctx, oracle):
@@ -114,14 +114,16 @@ def test_long_alleles_and_large_edit_distance(ctx, oracle):
     """3 kbp alleles, edit distances in the thousands: wavefronts live in the HBM tiers"""
     contigs, batch = scenarios.long_allele_regions()
     check(ctx, oracle, contigs, batch)
-    assert ctx.last_tier_counts()[0] == 0
+    assert ctx.last_tier_counts()[0] == 0 and sum(ctx.last_tier_counts()) == batch.n_regions
 
 
 def test_results_do_not_depend_on_the_workspace_tier(oracle):
     import aardvark_amd
     contigs, batch = scenarios.fuzz_regions(21, 800)
     want = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True, threads=8)
-    for opts in ({"lds_bytes_per_wave": 0}, {"lds_bytes_per_wave": 4096, "lds_ed_cap": 2}, {"lds_bytes_per_wave": 0, "ws_bytes_per_wave": 0},
+    for opts in ({"lds_bytes_per_wave": 0}, {"lds_bytes_per_wave": 0, "lds2_bytes_per_wave": 0},
+                 {"lds_bytes_per_wave": 4096, "lds_ed_cap": 2, "lds2_bytes_per_wave": 6144, "lds2_ed_cap": 4},
+                 {"lds_bytes_per_wave": 0, "lds2_bytes_per_wave": 0, "ws_bytes_per_wave": 0},
                  {"lds_bytes_per_wave": 32768, "lds_ed_cap": 64, "waves_per_cu": 4}):
         c = aardvark_amd.Context(0)
         for k, v in opts.items():
@@ -134,6 +136,7 @@ def test_results_do_not_depend_on_the_workspace_tier(oracle):
         c.close()
     c = aardvark_amd.Context(0)
     c.set_option("lds_bytes_per_wave", 2048)
+    c.set_option("lds2_bytes_per_wave", 0)
     c.set_option("ws_bytes_per_wave", 0)
     c.set_option("big_ws_bytes", 4096)
     starved = run(c, contigs, batch)

@@ -12,6 +12,10 @@ g = json.load(open(os.path.join(ROOT, "tests/golden/waffle_solver.json")))
 regions = [{"start": r["start"], "end": r["end"], "truth": r["truth"], "query": r["query"]} for r in g["regions"]]
 batch = RegionBatch.from_regions(regions)
 ctx = aardvark_amd.Context(0)
+for kv in os.environ.get("AVK_OPTS", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
 ctx.upload_reference([g["contig"].encode()])
 want = oracle_lib.compare_batch(lib, batch, [g["contig"].encode()], sequences=True)
 got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=True))
