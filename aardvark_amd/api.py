@@ -59,6 +59,7 @@ def load_library():
     lib.avk_seq_stride.argtypes = [C.POINTER(AvkRegionBatch), C.c_uint64]
     lib.avk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_tier_counts.argtypes = [vp, u64p]
+    lib.avk_debug_phase_cycles.argtypes = [vp, u64p]
     lib.avk_algorithmic_bytes.restype = C.c_uint64
     lib.avk_algorithmic_bytes.argtypes = [C.POINTER(AvkRegionBatch)]
     lib.avk_optimize_pairs_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.c_uint32, C.POINTER(C.c_int32), u8p]
@@ -175,6 +176,11 @@ class Context:
     def last_tier_counts(self):
         out = (C.c_uint64 * 5)()
         self._check(self.lib.avk_last_tier_counts(self.handle, out))
+        return [int(x) for x in out]
+
+    def debug_phase_cycles(self):
+        out = (C.c_uint64 * 8)()
+        self._check(self.lib.avk_debug_phase_cycles(self.handle, out))
         return [int(x) for x in out]
 
     def algorithmic_bytes(self, batch):

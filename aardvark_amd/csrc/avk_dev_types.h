@@ -40,6 +40,10 @@ struct AvkTier {
     uint32_t pad;
 };
 
+/* partial-tally geometry: AVK_TALLY_LEN sums + 5 tier counters + 8 profiling words, padded */
+#define AVK_TALLY_STRIDE 320
+#define AVK_TALLY_COPIES 64
+
 struct AvkKernelArgs {
     /* inputs */
     const AvkDevRegion *regions;
@@ -53,7 +57,9 @@ struct AvkKernelArgs {
     /* work distribution */
     const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */
     const uint32_t *n_work_dev; /* when set, the number of work items is read from device memory (overflow pass) */
-    uint32_t *work_counter;    /* persistent waves pull the next region from here */
+    uint32_t *work_counter;    /* 8 claim counters, 32 words (128 B) apart, one per shard of the dynamic part of the work list */
+    uint32_t n_waves;          /* persistent waves of this launch */
+    uint32_t pad_;
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;
     /* workspaces */
@@ -65,8 +71,8 @@ struct AvkKernelArgs {
     uint32_t *var_out;       /* [n_variants]: expected | observed << 8 | class << 16 | resolved zygosity << 24 */
     uint8_t *seq_bytes;      /* optional */
     uint32_t *seq_len;
-    uint64_t *tally;         /* [AVK_TALLY_LEN] */
-    uint64_t *tier_counts;   /* [5] regions finished per tier, then capacity failures */
+    uint64_t *tally;         /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] partial tallies; wave w adds into copy (w / 4) % AVK_TALLY_COPIES,
+                                a reduce kernel sums the copies: 4096 waves adding into ONE block serialise on its few cache lines */
 };
 
 #endif

@@ -43,6 +43,15 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a)
     avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
+/* sums the partial tallies into out[0 .. AVK_TALLY_STRIDE) */
+__global__ void avk_tally_reduce(const uint64_t *partials, uint64_t *out) {
+    const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= AVK_TALLY_STRIDE) return;
+    uint64_t s = 0;
+    for (int c = 0; c < AVK_TALLY_COPIES; ++c) s += partials[(size_t)c * AVK_TALLY_STRIDE + i];
+    out[i] = s;
+}
+
 /* ---------------------------------------------------------------------------------- context */
 namespace {
 
@@ -84,6 +93,7 @@ struct avk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
+    uint64_t last_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 struct avk_dev_batch {
@@ -99,8 +109,9 @@ struct avk_dev_batch {
     uint32_t *d_var_out = nullptr;    /* [nv] */
     uint8_t *d_seq = nullptr;
     uint32_t *d_seqlen = nullptr;
-    uint64_t *d_tally = nullptr; /* AVK_TALLY_LEN + 4 tier counters */
-    uint32_t *d_counters = nullptr; /* [0..2] work counters of the three passes, [4] / [5] overflow counts of pass 1 / 2 */
+    uint64_t *d_tally = nullptr;    /* [AVK_TALLY_STRIDE]: AVK_TALLY_LEN sums, 5 tier counters, 8 profiling words */
+    uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
+    uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
     bool with_gm = true;
 };
@@ -138,7 +149,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 
 void free_batch_buffers(avk_dev_batch *db) {
     void *ptrs[] = {db->d_regions, db->d_variants, db->d_alleles, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3};
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -340,8 +351,9 @@ int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch 
     AVK_TRY(dev_alloc(ctx, &db->d_region_out, n * 4));
     AVK_TRY(dev_alloc(ctx, &db->d_var_out, nv));
     AVK_TRY(dev_alloc(ctx, &db->d_seqlen, n * 5));
-    AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_LEN + 5));
-    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)16));
+    AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_STRIDE));
+    AVK_TRY(dev_alloc(ctx, &db->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES));
+    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)1088));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
@@ -412,8 +424,8 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
         ctx->big_alloc = big_need;
     }
 
-    AVK_HIP(ctx, hipMemsetAsync(db->d_tally, 0, ((size_t)AVK_TALLY_LEN + 5) * sizeof(uint64_t), ctx->stream));
-    AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 16 * sizeof(uint32_t), ctx->stream));
+    AVK_HIP(ctx, hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), ctx->stream));
+    AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 1088 * sizeof(uint32_t), ctx->stream));
     if (ctx->emit_group_metrics && !db->d_gm) {
         int rc = dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
         if (rc) return rc;
@@ -441,8 +453,7 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
     a.var_out = db->d_var_out;
     a.seq_bytes = cfg->enable_sequences ? db->d_seq : nullptr;
     a.seq_len = cfg->enable_sequences ? db->d_seqlen : nullptr;
-    a.tally = db->d_tally;
-    a.tier_counts = db->d_tally + AVK_TALLY_LEN;
+    a.tally = db->d_partials;
 
     if (cfg->max_branch_factor == 0) return fail(ctx, AVK_E_ARG, "max_branch_factor must be greater than 0 (query_optimizer.rs:177)");
 
@@ -463,35 +474,41 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
         a.pass_tier = (uint32_t)t;
         a.work_list = list;
         a.n_work_dev = count;
-        a.work_counter = db->d_counters + t;
+        a.work_counter = db->d_counters + 256 * t;
         if (t != last) {
             a.overflow_list = lists[nlist];
-            a.overflow_count = db->d_counters + 8 + nlist;
+            a.overflow_count = db->d_counters + 1024 + 16 * nlist;
         } else {
             a.overflow_list = nullptr;
             a.overflow_count = nullptr;
         }
         if (t == 0) {
             a.hbm_ws = nullptr;
+            a.n_waves = blocks * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(blocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;
             uint32_t b2 = (uint32_t)ctx->n_cus < blocks ? (uint32_t)ctx->n_cus : blocks;
+            a.n_waves = b2 * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(b2), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds2_bytes_per_wave, ctx->stream, a);
         } else if (t == 2) {
             a.hbm_ws = ctx->d_ws;
+            a.n_waves = blocks * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(blocks), dim3(256), 0, ctx->stream, a);
         } else {
             a.hbm_ws = ctx->d_big;
+            a.n_waves = big_blocks * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
         }
         AVK_HIP(ctx, hipGetLastError());
         if (t != last) {
             list = lists[nlist];
-            count = db->d_counters + 8 + nlist;
+            count = db->d_counters + 1024 + 16 * nlist;
             nlist += 1;
         }
     }
+    hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally);
+    AVK_HIP(ctx, hipGetLastError());
     AVK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
     if (tally_dev) AVK_HIP(ctx, hipMemcpyAsync(tally_dev, db->d_tally, AVK_TALLY_LEN * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
@@ -513,6 +530,13 @@ int avk_last_kernel_ms(avk_ctx *ctx, float *ms) {
     return 0;
 }
 
+/* profiling builds (-DAVK_PHASE_TIMING): summed s_memtime ticks per solver phase of the last download */
+int avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[8]) {
+    if (!ctx || !out) return AVK_E_ARG;
+    memcpy(out, ctx->last_phase, sizeof(ctx->last_phase));
+    return 0;
+}
+
 int avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]) {
     if (!ctx || !counts) return AVK_E_ARG;
     memcpy(counts, ctx->last_tiers, sizeof(ctx->last_tiers));
@@ -524,14 +548,14 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions, nv = db->n_variants_dev;
     std::vector<uint32_t> rout(n * 4 + 4), vout(nv + 1);
-    std::vector<uint64_t> tally((size_t)AVK_TALLY_LEN + 5);
+    std::vector<uint64_t> tally((size_t)AVK_TALLY_STRIDE);
     hipStream_t s = ctx->stream;
 #define D2H(dst, src, bytes) \
     if ((bytes) > 0) AVK_HIP(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s))
     D2H(rout.data(), db->d_region_out, n * 4 * sizeof(uint32_t));
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
     if (out->var_expected || out->var_observed || out->var_class || out->var_zyg) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
-    D2H(tally.data(), db->d_tally, ((size_t)AVK_TALLY_LEN + 5) * sizeof(uint64_t));
+    D2H(tally.data(), db->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t));
     std::vector<uint8_t> seq;
     std::vector<uint32_t> seqlen;
     const bool want_seq = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq;
@@ -561,6 +585,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
+    memcpy(ctx->last_phase, tally.data() + AVK_TALLY_LEN + 5, 8 * sizeof(uint64_t));
     if (want_seq) {
         for (uint64_t r = 0; r < n; ++r) {
             const AvkDevRegion &dr = db->host.regions[r];

@@ -41,8 +41,34 @@ typedef uint64_t u64;
 
 enum { AL_REF = 1, AL_ALT = 2 };
 enum { RS_OVERFLOW = -1 }; /* internal: this tier's workspace is too small, retry on the next */
+#ifndef AVK_STATIC_PCT
+#define AVK_STATIC_PCT 75
+#endif
+#ifndef AVK_CLAIM
+#define AVK_CLAIM 2u /* regions claimed per work-counter atomic */
+#endif
 
 #define AVK_ALIGN8(x) (((x) + 7u) & ~(u64)7u)
+
+/* optional per-phase cycle accounting (profiling builds: -DAVK_PHASE_TIMING) */
+#ifdef AVK_PHASE_TIMING
+#define AVK_T_DECL u64 t_phase_ = avk_clock();
+#define AVK_T_MARK(c, k)                    \
+    {                                       \
+        const u64 n_ = avk_clock();         \
+        (c).tphase[k] += n_ - t_phase_;     \
+        t_phase_ = n_;                      \
+    }
+#elif defined(AVK_STOP_AFTER)
+/* ablation builds: the region ends (as Ok, with whatever has been computed) after phase AVK_STOP_AFTER;
+ * timing experiments only, results are meaningless */
+#define AVK_T_DECL
+#define AVK_T_MARK(c, k) \
+    if ((k) == AVK_STOP_AFTER) return AVK_ST_OK;
+#else
+#define AVK_T_DECL
+#define AVK_T_MARK(c, k)
+#endif
 
 /* hap record: 10 header words, then alt bit-sets, wavefront, two sequences */
 enum { H_T_REFPOS = 0, H_Q_REFPOS, H_T_LEN, H_Q_LEN, H_T_SKIP, H_Q_SKIP, H_ED, H_T_NAL, H_Q_NAL, H_NSKIP, H_WORDS };
@@ -88,6 +114,9 @@ struct Ctx {
     u32 optcap;
     u64 *bres;    /* phase-B results: [2 cand][2 hap][2 side][alw] alt bit-sets */
     u32 max_branch;
+#ifdef AVK_PHASE_TIMING
+    u64 tphase[8];
+#endif
 };
 
 /* ------------------------------------------------------------------------------------------ */
@@ -816,6 +845,7 @@ struct RegionOut {
 
 /* returns AVK_ST_* (>= 0) or RS_OVERFLOW */
 AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_bytes, u32 ed_cap, Ctx &c, RegionOut &out, u32 &winner_node) {
+    AVK_T_DECL
     const AvkDevRegion reg = a.regions[r];
     const u32 lane = (u32)wv_lane();
     c.L = wv_uni(reg.len);
@@ -965,8 +995,10 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         wv_sync();
     }
 
+    AVK_T_MARK(c, 0)
     /* ---- phase A */
     const int nopt = phaseA(c);
+    AVK_T_MARK(c, 1)
     if (nopt == RS_OVERFLOW) return RS_OVERFLOW;
     if (nopt < 0) return -nopt - 100;
     out.n_opt = (u32)nopt;
@@ -1051,6 +1083,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     }
     winner_node = best_k;
     const u64 *obs = c.bres + 4 * c.alw; /* [hap][side][alw] */
+    AVK_T_MARK(c, 2)
 
     /* ---- phase C */
     u8 *wn = poolA + (u64)best_k * nodeA_bytes;
@@ -1099,6 +1132,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     /* add_basepair_stats (:335-449).  The optimizer's own sequences are the regenerated ones
      * (asserted equal at :364-367), ed(truth,query) is the node's finalized DWFA distance. */
     const int SUP[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL, AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
+    AVK_T_MARK(c, 3)
     u32 tcount[8], qcount[8];
     for (int s = 0; s < 8; ++s) {
         u32 nt = 0, nq = 0;
@@ -1189,6 +1223,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         }
     }
 
+    AVK_T_MARK(c, 4)
     /* add_record_basepair_stats (:455-522): totals from the INPUT zygosities and raw allele space */
     wv_sync();
     {
@@ -1221,6 +1256,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         if (e) return (int)e;
     }
     wv_sync();
+    AVK_T_MARK(c, 5)
     out.present = present;
     return AVK_ST_OK;
 }
@@ -1259,12 +1295,53 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     const u32 ed_cap = a.tier[tier].ed_cap;
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_regions;
 
+    /* Work distribution.  Returning atomics on one cache line saturate near 88 claims/us on this chip
+     * (MI355X_MICROARCH.md "dequeue"), far below what the solver needs, so claims are rationed:
+     *   - the first AVK_STATIC_PCT % of the work list is dealt statically, item k to wave k mod n_waves
+     *     (no atomics, neighbouring waves read neighbouring records);
+     *   - the rest is claimed dynamically in chunks of AVK_CLAIM from 8 shard counters that sit in
+     *     separate 128-byte lines; a wave starts on the shard of its workgroup's XCD and peeks at a
+     *     counter with a plain load before spending an atomic on it, so drained shards cost nothing.
+     * The dynamic tail evens out waves that drew expensive regions. */
+    const u32 n_static = a.n_waves ? (u32)(((u64)n_work * AVK_STATIC_PCT / 100) / a.n_waves) * a.n_waves : 0;
+    const u32 n_dyn = n_work - n_static;
+    const u32 shard_len = (n_dyn + 7u) >> 3;
+    const u32 home = (wave_id >> 2) & 7u;
+    u32 static_next = wave_id;
+    u32 shard_i = 0, claim_base = 0, claim_left = 0;
     for (;;) {
-        u32 idx = 0;
-        if (lane == 0) idx = avk_atomic_add_u32_global(a.work_counter, 1);
-        idx = wv_shfl(idx, 0);
-        idx = wv_uni(idx);
-        if (idx >= n_work) break;
+        u32 idx;
+        if (static_next < n_static) {
+            idx = static_next;
+            static_next += a.n_waves;
+        } else {
+            if (claim_left == 0) {
+                bool got = false;
+                while (!got && shard_i < 8) {
+                    const u32 sh = (home + shard_i) & 7u;
+                    const u32 lo = sh * shard_len < n_dyn ? sh * shard_len : n_dyn;
+                    const u32 hi = lo + shard_len < n_dyn ? lo + shard_len : n_dyn;
+                    u32 *ctr = a.work_counter + 32u * sh;
+                    u32 b = 0xFFFFFFFFu;
+                    if (lane == 0) {
+                        const u32 seen = *(volatile u32 *)ctr;
+                        if (lo + seen < hi) b = avk_atomic_add_u32_global(ctr, AVK_CLAIM);
+                    }
+                    b = wv_uni(wv_shfl(b, 0));
+                    if (b != 0xFFFFFFFFu && lo + b < hi) {
+                        claim_base = n_static + lo + b;
+                        claim_left = hi - (lo + b) < AVK_CLAIM ? hi - (lo + b) : AVK_CLAIM;
+                        got = true;
+                    } else {
+                        shard_i += 1;
+                    }
+                }
+                if (!got) break;
+            }
+            idx = claim_base;
+            claim_base += 1;
+            claim_left -= 1;
+        }
         const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : idx;
         const AvkDevRegion reg = a.regions[r];
         const u32 pre = wv_uni(reg.pre_status);
@@ -1274,6 +1351,10 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             continue;
         }
         Ctx c;
+#ifdef AVK_PHASE_TIMING
+        for (int k = 0; k < 8; ++k) c.tphase[k] = 0;
+        const u64 t_region0 = avk_clock();
+#endif
         RegionOut out;
         out.ed1 = out.ed2 = out.n_opt = out.present = 0;
         u32 winner = 0;
@@ -1316,18 +1397,28 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             }
         }
         wv_sync();
+#ifdef AVK_PHASE_TIMING
+        if (lane == 0) {
+            u64 *pc = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5;
+            for (int k = 0; k < 6; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
+            avk_atomic_add_u64_global(pc + 6, avk_clock() - t_region0);
+            avk_atomic_add_u64_global(pc + 7, 1);
+        }
+#endif
     }
 
-    /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) */
+    /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into
+     * one of the partial copies; avk_tally_reduce sums the copies */
+    u64 *part = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
     for (int j = 0; j < 5; ++j) {
         const u32 i = (u32)j * 64 + lane;
-        if (i < AVK_N_GROUPS * AVK_N_FIELDS && tally[j]) avk_atomic_add_u64_global(a.tally + i, tally[j]);
+        if (i < AVK_N_GROUPS * AVK_N_FIELDS && tally[j]) avk_atomic_add_u64_global(part + i, tally[j]);
     }
     if (lane == 0) {
-        if (n_ok) avk_atomic_add_u64_global(a.tally + AVK_TALLY_SOLVED, n_ok);
-        if (n_err) avk_atomic_add_u64_global(a.tally + AVK_TALLY_ERRORS, n_err);
-        if (n_ok + n_err - n_cap) avk_atomic_add_u64_global(a.tier_counts + tier, n_ok + n_err - n_cap);
-        if (n_cap) avk_atomic_add_u64_global(a.tier_counts + 4, n_cap);
+        if (n_ok) avk_atomic_add_u64_global(part + AVK_TALLY_SOLVED, n_ok);
+        if (n_err) avk_atomic_add_u64_global(part + AVK_TALLY_ERRORS, n_err);
+        if (n_ok + n_err - n_cap) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + tier, n_ok + n_err - n_cap);
+        if (n_cap) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 4, n_cap);
     }
 }
 

@@ -81,6 +81,7 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+AVK_DEV uint64_t avk_clock() { return 0; }
 AVK_DEV int avk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 
@@ -143,6 +144,7 @@ AVK_DEV void wv_sync() {
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+AVK_DEV uint64_t avk_clock() { return __builtin_amdgcn_s_memtime(); }
 AVK_DEV int avk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 AVK_DEV int avk_popc64(uint64_t x) { return __popcll(x); }
 #endif

@@ -206,6 +206,9 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
 int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
+/* profiling builds of the library only: summed clock ticks per solver phase (stage, search A, search B,
+ * metrics setup, base-pair metrics, record metrics, whole region, region count) of the last download */
+int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[8]);
 
 /* Merge path (src/merge_solver.rs:137-143): for pair p, optimize_sequences(set a, set b) and
  * report all_opt_haps[0].is_exact_match().  Pair p compares variant ranges

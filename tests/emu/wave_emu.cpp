@@ -193,9 +193,10 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
     const uint64_t n = batch->n_regions, nv = pb.variants.size();
     std::vector<uint32_t> rout(n * 4 + 4, 0), vout(nv + 1, 0);
     std::vector<uint32_t> gm(out->group_metrics ? n * AVK_N_GROUPS * AVK_N_FIELDS : 0);
-    std::vector<uint64_t> tally(AVK_TALLY_LEN, 0), tiers(5, 0);
+    std::vector<uint64_t> partials((size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES, 0), tally(AVK_TALLY_STRIDE, 0);
     std::vector<uint32_t> lists[3] = {std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1)};
-    uint32_t counters[16] = {0};
+    std::vector<uint32_t> counters_v(1088, 0);
+    uint32_t *counters = counters_v.data();
 
     AvkKernelArgs a;
     memset(&a, 0, sizeof(a));
@@ -219,8 +220,7 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
     a.var_out = vout.data();
     a.seq_bytes = want_seq ? out->seq_bytes : nullptr;
     a.seq_len = want_seq ? out->seq_len : nullptr;
-    a.tally = tally.data();
-    a.tier_counts = tiers.data();
+    a.tally = partials.data();
 
     if (cfg->max_branch_factor == 0) { /* query_optimizer.rs:177 */
         for (uint64_t r = 0; r < n; ++r)
@@ -229,6 +229,7 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
 
     auto run_pass = [&](uint32_t waves, uint64_t slice_bytes, uint64_t lds) {
         if (threads < 1) threads = 1;
+        a.n_waves = waves;
         std::vector<uint8_t> hbm(slice_bytes ? (size_t)waves * slice_bytes : 0);
         a.hbm_ws = slice_bytes ? hbm.data() : nullptr;
         std::atomic<uint32_t> next(0);
@@ -263,10 +264,10 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
         a.pass_tier = (uint32_t)t;
         a.work_list = list;
         a.n_work_dev = count;
-        a.work_counter = counters + t;
+        a.work_counter = counters + 256 * t;
         if (t != last) {
             a.overflow_list = lists[nlist].data();
-            a.overflow_count = counters + 8 + nlist;
+            a.overflow_count = counters + 1024 + 16 * nlist;
         } else {
             a.overflow_list = nullptr;
             a.overflow_count = nullptr;
@@ -280,11 +281,13 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
         }
         if (t != last) {
             list = lists[nlist].data();
-            count = counters + 8 + nlist;
+            count = counters + 1024 + 16 * nlist;
             nlist += 1;
         }
     }
 
+    for (int c = 0; c < AVK_TALLY_COPIES; ++c) /* avk_tally_reduce */
+        for (int i = 0; i < AVK_TALLY_STRIDE; ++i) tally[i] += partials[(size_t)c * AVK_TALLY_STRIDE + i];
     /* copy back in caller order */
     for (uint64_t r = 0; r < n; ++r) {
         const uint32_t *w = rout.data() + 4 * r;
@@ -304,7 +307,7 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
         if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
-    if (tier_counts) memcpy(tier_counts, tiers.data(), 5 * sizeof(uint64_t));
+    if (tier_counts) memcpy(tier_counts, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
     return 0;
 }
 

@@ -49,3 +49,7 @@ for it in range(5):
 res = ctx.download(rb)
 want2 = oracle_lib.compare_batch(lib, batch, [contig], sequences=False, threads=os.cpu_count())
 print("resident diff:", res.diff(want2))
+pc = ctx.debug_phase_cycles()
+if pc[7]:
+    names = ["stage", "searchA", "searchB", "metrics_setup", "basepair", "record", "region_total"]
+    print("phase ticks per region:", {n: round(pc[i] / pc[7], 1) for i, n in enumerate(names)}, "regions", pc[7])
