@@ -183,6 +183,16 @@ class Context:
         self._check(self.lib.avk_debug_phase_cycles(self.handle, out))
         return [int(x) for x in out]
 
+    def optimize_pairs(self, batch, max_branch_factor=50):
+        """merge path: optimize_sequences(truth range, query range)[0].is_exact_match() per region
+        (reference src/merge_solver.rs:135-147) -> (status int32[], is_exact uint8[])"""
+        status = np.full(batch.n_regions, -1, np.int32)
+        exact = np.zeros(max(batch.n_regions, 1), np.uint8)
+        cb = batch.c_struct()
+        self._check(self.lib.avk_optimize_pairs_batch(self.handle, C.byref(cb), max_branch_factor,
+                                                      status.ctypes.data_as(C.POINTER(C.c_int32)), exact.ctypes.data_as(u8p)))
+        return status, exact[:batch.n_regions]
+
     def algorithmic_bytes(self, batch):
         cb = batch.c_struct()
         return int(self.lib.avk_algorithmic_bytes(C.byref(cb)))

@@ -16,7 +16,8 @@ struct AvkDevRegion {
     uint32_t v_off;      /* first variant record */
     uint32_t t_cnt;
     uint32_t q_cnt;
-    uint32_t pre_status; /* host validation: 0 or AVK_ST_INVALID_INPUT / AVK_ST_BAD_ZYGOSITY */
+    uint32_t pre_status; /* host validation: 0, AVK_ST_INVALID_INPUT / AVK_ST_BAD_ZYGOSITY, or AVK_PRE_SKIP_OK (pairs mode:
+                            answered on the host, report status 0 / not exact) */
     uint32_t seq_stride; /* bytes per output sequence slot (0 = no sequence output) */
     uint64_t seq_off;    /* offset of the region's 5 slots in the sequence output */
 };
@@ -32,6 +33,8 @@ struct AvkDevVariant {
     uint8_t zyg;        /* AVK_ZYG_* */
     uint16_t pad;
 };
+
+#define AVK_PRE_SKIP_OK 0x1000u
 
 /* capacities of one workspace tier */
 struct AvkTier {
@@ -53,6 +56,8 @@ struct AvkKernelArgs {
     uint32_t n_regions;
     uint32_t max_branch_factor;
     uint32_t enable_exact_shortcut;
+    uint32_t mode; /* 0 solve_compare_region; 1 merge pairs: optimize_sequences only, report all_opt_haps[0].is_exact_match() */
+    uint32_t pad0_;
     uint32_t pass_tier;  /* workspace tier of this launch: 0 small LDS slice, 1 large LDS slice, 2 per-wave HBM slice, 3 big HBM slice */
     /* work distribution */
     const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */

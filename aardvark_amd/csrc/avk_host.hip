@@ -310,7 +310,7 @@ uint64_t avk_algorithmic_bytes(const avk_region_batch *b) {
     return total;
 }
 
-int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch **out) {
+static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pairs_mode, avk_dev_batch **out) {
     if (!ctx || !batch || !out) return AVK_E_ARG;
     *out = nullptr;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
@@ -336,6 +336,16 @@ int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch 
     }
     const uint64_t n = db->n_regions, nv = db->host.variants.size();
     db->n_variants_dev = nv;
+    if (pairs_mode) { /* solve_merge_region's pre-checks (merge_solver.rs:119-147, :211-223) */
+        for (uint64_t r = 0; r < n; ++r) {
+            AvkDevRegion &dr = db->host.regions[r];
+            if (dr.pre_status == AVK_ST_INVALID_INPUT) continue;
+            if (db->host.zyg_flags[r] & 1) dr.pre_status = AVK_ST_BAD_ZYGOSITY;                           /* Unknown: delta computation bails */
+            else if (db->host.delta_t[r] != db->host.delta_q[r]) dr.pre_status = AVK_PRE_SKIP_OK;        /* different net length: not exact, optimizer not run */
+            else if (db->host.zyg_flags[r] & 2) dr.pre_status = AVK_ST_BAD_ZYGOSITY;                      /* optimizer would hit assert_eq! */
+            else dr.pre_status = 0;
+        }
+    }
 #define AVK_TRY(x)                \
     do {                          \
         int rc_ = (x);            \
@@ -372,6 +382,8 @@ int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch 
     return 0;
 }
 
+int avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch **out) { return upload_internal(ctx, batch, false, out); }
+
 void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
     if (!db) return;
     if (ctx) {
@@ -382,9 +394,8 @@ void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
     delete db;
 }
 
-int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev) {
+static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev, uint32_t mode) {
     if (!ctx || !db || !cfg) return AVK_E_ARG;
-    if (cfg->enable_exact_shortcut) return fail(ctx, AVK_E_ARG, "enable_exact_shortcut is not implemented on the device path yet");
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions;
     if (ctx->lds2_bytes_per_wave * 4 > 160 * 1024) return fail(ctx, AVK_E_ARG, "lds2_bytes_per_wave too large");
@@ -439,7 +450,8 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
     a.ref_bytes = ctx->d_ref;
     a.n_regions = (uint32_t)n;
     a.max_branch_factor = cfg->max_branch_factor;
-    a.enable_exact_shortcut = 0;
+    a.enable_exact_shortcut = cfg->enable_exact_shortcut ? 1u : 0u;
+    a.mode = mode;
     a.tier[0].ws_bytes = (uint64_t)ctx->lds_bytes_per_wave;
     a.tier[0].ed_cap = (uint32_t)ctx->lds_ed_cap;
     a.tier[1].ws_bytes = (uint64_t)ctx->lds2_bytes_per_wave;
@@ -513,6 +525,10 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
     ctx->ev_valid = true;
     if (tally_dev) AVK_HIP(ctx, hipMemcpyAsync(tally_dev, db->d_tally, AVK_TALLY_LEN * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
+}
+
+int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev) {
+    return run_internal(ctx, db, cfg, tally_dev, 0);
 }
 
 int avk_synchronize(avk_ctx *ctx) {
@@ -611,8 +627,35 @@ int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_com
     return rc;
 }
 
-int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *, uint32_t, int32_t *, uint8_t *) {
-    return fail(ctx, AVK_E_STATE, "avk_optimize_pairs_batch (merge path) is not implemented yet");
+/* solve_merge_region's pairwise test (merge_solver.rs:128-147) for every region of the batch: the "truth"
+ * range is input i, the "query" range input j */
+int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32_t max_branch_factor, int32_t *status, uint8_t *is_exact_match) {
+    if (!ctx || !batch || !status || !is_exact_match) return AVK_E_ARG;
+    if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    avk_dev_batch *db = nullptr;
+    int rc = upload_internal(ctx, batch, true, &db);
+    if (rc) return rc;
+    avk_compare_config cfg;
+    cfg.max_branch_factor = max_branch_factor;
+    cfg.enable_sequences = 0;
+    cfg.enable_exact_shortcut = 0;
+    const int64_t keep = ctx->emit_group_metrics;
+    ctx->emit_group_metrics = 0;
+    rc = run_internal(ctx, db, &cfg, nullptr, 1);
+    ctx->emit_group_metrics = keep;
+    if (!rc) {
+        std::vector<uint32_t> rout(db->n_regions * 4 + 4);
+        hipError_t e = hipMemcpyAsync(rout.data(), db->d_region_out, db->n_regions * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "pairs download failed: %s", hipGetErrorString(e));
+        else
+            for (uint64_t r = 0; r < db->n_regions; ++r) {
+                status[r] = (int32_t)rout[4 * r];
+                is_exact_match[r] = status[r] == 0 && rout[4 * r + 1] ? 1 : 0;
+            }
+    }
+    avk_batch_free(ctx, db);
+    return rc;
 }
 
 } /* extern "C" */

@@ -24,6 +24,8 @@ struct PackedBatch {
     std::vector<AvkDevVariant> variants;
     std::vector<uint8_t> alleles;
     std::vector<uint64_t> dev2host; /* device variant index -> caller variant index */
+    std::vector<uint8_t> zyg_flags; /* per region: bit 0 an Unknown zygosity, bit 1 a HomozygousReference one */
+    std::vector<int64_t> delta_t, delta_q; /* variant_delta_length per side (merge_solver.rs:211-223) */
     uint64_t seq_total = 0;
 };
 
@@ -53,6 +55,9 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
         return AVK_E_ARG;
     }
     out->regions.resize(n);
+    out->zyg_flags.assign(n, 0);
+    out->delta_t.assign(n, 0);
+    out->delta_q.assign(n, 0);
     out->variants.clear();
     out->variants.reserve(b->n_variants);
     out->alleles.clear();
@@ -97,6 +102,12 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                 if (pos < start || pos + l0 > end || pos < last) pre = AVK_ST_INVALID_INPUT;
                 last = pos;
                 if (b->var_zyg[v] == AVK_ZYG_UNKNOWN || b->var_zyg[v] == AVK_ZYG_HOM_REF) bad_zyg = true;
+                if (b->var_zyg[v] == AVK_ZYG_UNKNOWN) out->zyg_flags[r] |= 1;
+                if (b->var_zyg[v] == AVK_ZYG_HOM_REF) out->zyg_flags[r] |= 2;
+                {
+                    const int64_t w = b->var_zyg[v] == AVK_ZYG_HOM_ALT ? 2 : ((b->var_zyg[v] >= AVK_ZYG_UNPHASED_HET && b->var_zyg[v] <= AVK_ZYG_PHASED_HET10) ? 1 : 0);
+                    (side == 0 ? out->delta_t[r] : out->delta_q[r]) += ((int64_t)l1 - (int64_t)l0) * w;
+                }
                 dv.rel_pos = pos >= start ? (uint32_t)(pos - start) : 0;
                 dv.a0_len = l0;
                 dv.a1_len = l1;

@@ -41,6 +41,7 @@ typedef uint64_t u64;
 
 enum { AL_REF = 1, AL_ALT = 2 };
 enum { RS_OVERFLOW = -1 }; /* internal: this tier's workspace is too small, retry on the next */
+enum { RS_CUT = -2 };      /* internal: phase B stopped because its answer can no longer matter */
 #ifndef AVK_STATIC_PCT
 #define AVK_STATIC_PCT 75
 #endif
@@ -79,9 +80,14 @@ struct HapHdr {
 };
 
 /* local variant record in the workspace */
-struct LVar {
-    u32 rel_pos, a0_len, a1_len, a_off, raw_space, alt_ed;
-    u8 type, zyg, pad0, pad1;
+struct LVar { /* 7 words; type_zyg = type | zyg << 8 */
+    u32 rel_pos, a0_len, a1_len, a_off, raw_space, alt_ed, type_zyg;
+};
+
+/* a variant record fetched for the whole wave: every field is made scalar, so the arithmetic and the
+ * branches that depend on it stay on the scalar unit */
+struct UVar {
+    u32 rel_pos, a0_len, a1_len, a_off, raw_space, alt_ed, type, zyg;
 };
 
 struct Ctx {
@@ -113,7 +119,11 @@ struct Ctx {
     u32 *optlist; /* tied optima (node indices) */
     u32 optcap;
     u64 *bres;    /* phase-B results: [2 cand][2 hap][2 side][alw] alt bit-sets */
+    u64 *memo;    /* phase-B memo: [memo_cap][4*alw] input and result bit-sets */
+    u32 *memo_err;
+    u32 memo_cap;
     u32 max_branch;
+    u32 best_cost; /* total cost shared by the tied optima of phase A */
 #ifdef AVK_PHASE_TIMING
     u64 tphase[8];
 #endif
@@ -138,6 +148,20 @@ AVK_DEV void st64(u64 *p, u64 v) {
     if (wv_lane() == 0) *p = v;
 }
 AVK_DEV u32 ld32u(const u32 *p) { return wv_uni(*p); }
+AVK_DEV UVar load_var(const LVar *vars, u32 i) {
+    const u32 *w = (const u32 *)(vars + i);
+    UVar v;
+    v.rel_pos = wv_uni(w[0]);
+    v.a0_len = wv_uni(w[1]);
+    v.a1_len = wv_uni(w[2]);
+    v.a_off = wv_uni(w[3]);
+    v.raw_space = wv_uni(w[4]);
+    v.alt_ed = wv_uni(w[5]);
+    const u32 tz = wv_uni(w[6]);
+    v.type = tz & 0xFF;
+    v.zyg = (tz >> 8) & 0xFF;
+    return v;
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* dynamic wavefront aligner — src/dwfa/dynamic_wfa.rs                                         */
@@ -334,7 +358,7 @@ AVK_DEV void trk_copy_reference(const Ctx &c, u8 *seq, u32 &len, u32 &refpos, u3
 }
 
 /* HaplotypeTracker::extend_variant (haplotype_dwfa.rs:175-212); returns the `success` flag */
-AVK_DEV bool trk_extend_variant(const Ctx &c, const LVar &v, u32 allele, u32 sync, u8 *seq, u32 &len, u32 &refpos, u32 &skip,
+AVK_DEV bool trk_extend_variant(const Ctx &c, const UVar &v, u32 allele, u32 sync, u8 *seq, u32 &len, u32 &refpos, u32 &skip,
                                 u64 *alt, u32 &nal, u32 &nskip) {
     trk_copy_reference(c, seq, len, refpos, v.rel_pos);
     bool ok = true;
@@ -359,7 +383,7 @@ AVK_DEV bool trk_extend_variant(const Ctx &c, const LVar &v, u32 allele, u32 syn
 }
 
 /* HaplotypeDWFA::extend_variant minus the DWFA update (haplotype_dwfa.rs:46-62) */
-AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, const LVar &v, u32 allele, u32 sync) {
+AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, const UVar &v, u32 allele, u32 sync) {
     bool ok;
     if (is_truth) {
         trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, sync);
@@ -444,7 +468,7 @@ AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
 }
 
 /* ComparisonNode::extend_variant (:443-451) = both haplotypes + their DWFA updates */
-AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const LVar &v, u32 a1, u32 a2, u32 sync) {
+AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
     u8 *n = node_at(c, idx);
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
@@ -506,10 +530,8 @@ AVK_DEV int phaseA(Ctx &c) {
         u64 key;
         const u32 ni = queue_pop(c, key);
         const u32 cost = (u32)(key >> 32);
-        if (cost > best_ed) { /* :204 */
-            node_free(c, ni);
-            continue;
-        }
+        if (cost > best_ed) break; /* :204 skips it — and, pops being in non-decreasing cost order (a child never
+                                      costs less than its parent), every node still queued would be skipped too */
         const u32 *nw = (const u32 *)node_at(c, ni);
         const u32 depth = ld32u(nw + 2 + H_T_NAL) + ld32u(nw + 2 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
         const u32 cnt = ld32u(c.bucket + depth);
@@ -542,9 +564,9 @@ AVK_DEV int phaseA(Ctx &c) {
         }
 
         const u32 vi = ld32u(c.order + depth);
-        const LVar v = c.vars[vi];
+        const UVar v = load_var(c.vars, vi);
         const bool is_truth = vi < c.T;
-        const u32 zyg = wv_uni(v.zyg);
+        const u32 zyg = v.zyg;
         u32 sync = c.L; /* :258-265 */
         if (depth + 1 < c.N) sync = wv_uni(c.vars[ld32u(c.order + depth + 1)].rel_pos);
         const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
@@ -576,6 +598,7 @@ AVK_DEV int phaseA(Ctx &c) {
         }
     }
     if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
+    c.best_cost = best_ed;
     return (int)nbest;
 }
 
@@ -606,7 +629,7 @@ AVK_DEV bool exact_update(const HapPtr &p, HapHdr &h) {
 }
 
 /* ExactMatchNode::extend_variant (:395-414): returns success && is_exact_match */
-AVK_DEV bool nodeB_extend(const Ctx &c, u32 idx, bool is_truth, const LVar &v, u32 allele, u32 sync, bool is_error) {
+AVK_DEV bool nodeB_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 allele, u32 sync, bool is_error) {
     u8 *n = node_at(c, idx);
     const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
     HapHdr h = hap_load(p.w);
@@ -627,10 +650,15 @@ AVK_DEV u64 keyB(u32 errors, u32 depth, u32 id) { /* (Reverse(errors), set - err
     return ((u64)errors << 48) | ((u64)(0xFFFFu - (depth - errors)) << 32) | id;
 }
 
-/* runs one haplotype.  alleles come from optimum node `opt` (phase A pool), hap `hh`.
+/* runs one haplotype with the input alleles in_talt / in_qalt.
  * result: errors (>= 0) and the final allele bit-sets in res[0..alw) truth, res[alw..2alw) query.
- * returns errors, RS_OVERFLOW, or -status-100 */
-AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
+ * Pops come in non-decreasing error order (a child never has fewer errors than its parent), so
+ *   - the first finalised exact node is the answer: everything popped after it is skipped by :169;
+ *   - once a popped node has `cutoff` errors the answer is >= cutoff and the caller no longer needs it
+ *     (only meaningful for N < 500, where the search cannot fail later on: the all-REF chain finishes
+ *     within N expansions of any auto-fail, :309-339).
+ * returns errors, RS_CUT, RS_OVERFLOW, or -status-100 */
+AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32 cutoff) {
     c.qn = 0;
     c.pool_used = 0;
     c.nfree = 0;
@@ -645,7 +673,6 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
     wv_sync();
     queue_push(c, keyB(0, 0, 0), (u32)root);
     u32 next_id = 1;
-    u32 best_err = 0xFFFFFFFFu;
     u32 min_sync = 0, af_index = 0, af_counts = 0;
 
     while (c.qn > 0) {
@@ -653,10 +680,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
         const u32 ni = queue_pop(c, key);
         u8 *n = node_at(c, ni);
         const u32 errors = (u32)(key >> 48);
-        if (errors >= best_err) { /* :169 */
-            node_free(c, ni);
-            continue;
-        }
+        if (errors >= cutoff) return RS_CUT;
         const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
         HapHdr h = hap_load(p.w);
         const u32 depth = h.t_nal + h.q_nal;
@@ -667,14 +691,14 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
             const bool touched = exact_update(p, h);
             const u32 d = ld32u(p.wf);
             const bool exact = touched && d >= h.t_len && d >= h.q_len;
-            if (exact) { /* errors < best_err already holds */
-                best_err = errors;
+            if (exact) { /* :187-190; later pops cannot improve on it */
                 wv_sync();
                 for (u32 k = (u32)wv_lane(); k < c.alw; k += 64) {
                     res[k] = p.talt[k];
                     res[c.alw + k] = p.qalt[k];
                 }
                 wv_sync();
+                return (int)errors;
             }
             node_free(c, ni);
             continue;
@@ -690,7 +714,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
             af_index = min_sync;
         }
         const u32 vi = ld32u(c.order + depth);
-        const LVar v = c.vars[vi];
+        const UVar v = load_var(c.vars, vi);
         const bool is_truth = vi < c.T;
         const u32 sub = is_truth ? vi : vi - c.T;
         const u64 *in = is_truth ? in_talt : in_qalt;
@@ -771,8 +795,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res) {
             af_counts = 0;
         }
     }
-    if (best_err == 0xFFFFFFFFu) return -100 - AVK_ST_NO_GT_RESULT; /* :345-348 */
-    return (int)best_err;
+    return -100 - AVK_ST_NO_GT_RESULT; /* :345-348 */
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -811,21 +834,20 @@ AVK_DEV void gm_add(u32 *g, bool q, u32 type, u32 w, u32 exp, u32 obs) {
 AVK_DEV u32 gen_filtered(const Ctx &c, u32 v0, u32 cnt, const u64 *alt, u32 ftype, u8 *out, u32 &failed_ed) {
     u32 cur = 0, len = 0, failed = 0;
     for (u32 k = 0; k < cnt; ++k) {
-        const LVar v = c.vars[v0 + k];
-        if (wv_uni(v.type) != ftype) continue;
+        const UVar v = load_var(c.vars, v0 + k);
+        if (v.type != ftype) continue;
         const bool is_alt = wv_uni((u32)((alt[k >> 6] >> (k & 63)) & 1)) != 0;
         if (!is_alt) continue; /* :738-741 */
-        const u32 vpos = wv_uni(v.rel_pos);
+        const u32 vpos = v.rel_pos;
         if (vpos < cur) { /* :745-753 */
-            failed += wv_uni(v.alt_ed);
+            failed += v.alt_ed;
             continue;
         }
         copy_bytes(out + len, c.ref + cur, vpos - cur);
         len += vpos - cur;
-        const u32 a1 = wv_uni(v.a1_len);
-        copy_bytes(out + len, c.alle + wv_uni(v.a_off) + wv_uni(v.a0_len), a1);
-        len += a1;
-        cur = vpos + wv_uni(v.a0_len);
+        copy_bytes(out + len, c.alle + v.a_off + v.a0_len, v.a1_len);
+        len += v.a1_len;
+        cur = vpos + v.a0_len;
     }
     if (cur < c.L) {
         copy_bytes(out + len, c.ref + cur, c.L - cur);
@@ -834,6 +856,54 @@ AVK_DEV u32 gen_filtered(const Ctx &c, u32 v0, u32 cnt, const u64 *alt, u32 ftyp
     failed_ed = failed;
     wv_sync();
     return len;
+}
+
+/* generate_exact_match (waffle_solver.rs:534-601), the hidden --enable-exact-shortcut: taken when the
+ * first optimum is an exact match (all tied optima share the total cost, so cost 0 decides).  Counts come
+ * from the INPUT zygosities, every variant is a TP, BASEPAIR is the distance of the (identical) haplotypes
+ * to the reference plus per-variant allele distances; no RECORD_BP, no entries for absent variant types. */
+AVK_DEV int exact_shortcut_metrics(const AvkKernelArgs &a, Ctx &c, u32 v_off, const HapPtr &w0, const HapHdr &h0, const HapPtr &w1,
+                                   const HapHdr &h1, u32 &present_out) {
+    const u32 lane = (u32)wv_lane();
+    zero_words(c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
+    wv_sync();
+    u32 l_present = 0, l_bad = 0;
+    for (u32 k = lane; k < c.N; k += 64) {
+        const bool is_truth = k < c.T;
+        const LVar v = c.vars[k];
+        const u32 vtype = v.type_zyg & 0xFF, z = (v.type_zyg >> 8) & 0xFF;
+        const u32 ev = z == AVK_ZYG_HOM_ALT ? 2u : 1u; /* Unknown / HomRef never get here (pre_status) */
+        for (int pass = 0; pass < 2; ++pass) {
+            u32 *g = c.gm + (pass == 0 ? 0 : 1 + vtype) * AVK_N_FIELDS;
+            avk_atomic_add_u32(g + (is_truth ? AVK_F_GT_TRUTH_TP : AVK_F_GT_QUERY_TP), 1);
+            avk_atomic_add_u32(g + (is_truth ? AVK_F_HAP_TRUTH_TP : AVK_F_HAP_QUERY_TP), ev);
+            avk_atomic_add_u32(g + (is_truth ? AVK_F_WHAP_TRUTH_TP : AVK_F_WHAP_QUERY_TP), ev * v.alt_ed);
+        }
+        avk_atomic_add_u32(c.gm + (1 + vtype) * AVK_N_FIELDS + (is_truth ? AVK_F_BP_TRUTH_TP : AVK_F_BP_QUERY_TP), ev * 2 * v.alt_ed);
+        l_present |= 1u << vtype;
+        const u32 b0 = (u32)(((is_truth ? w0.talt : w0.qalt)[(is_truth ? k : k - c.T) >> 6] >> ((is_truth ? k : k - c.T) & 63)) & 1);
+        const u32 b1 = (u32)(((is_truth ? w1.talt : w1.qalt)[(is_truth ? k : k - c.T) >> 6] >> ((is_truth ? k : k - c.T) & 63)) & 1);
+        if (b0 + b1 == 0) l_bad = AVK_ST_BAD_ZYGOSITY;
+        const u32 rz = b0 && b1 ? AVK_ZYG_HOM_ALT : (b0 ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_PHASED_HET01);
+        a.var_out[v_off + k] = ev | (ev << 8) | ((u32)AVK_CLASS_TP << 16) | (rz << 24);
+    }
+    if (wv_max_u32(l_bad)) return AVK_ST_BAD_ZYGOSITY;
+    u32 present = 0;
+    for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t)
+        if (wv_ballot((l_present >> t) & 1)) present |= 1u << t;
+    /* truth == query on both haplotypes (asserted at :561-562; cost 0 guarantees it) */
+    const int e1 = wfa_ed(c, c.ref, c.L, w0.tseq, h0.t_len);
+    if (e1 < 0) return RS_OVERFLOW;
+    const int e2 = wfa_ed(c, c.ref, c.L, w1.tseq, h1.t_len);
+    if (e2 < 0) return RS_OVERFLOW;
+    wv_sync();
+    if (lane == 0) {
+        c.gm[AVK_F_BP_TRUTH_TP] += 2u * (u32)(e1 + e2);
+        c.gm[AVK_F_BP_QUERY_TP] += 2u * (u32)(e1 + e2);
+    }
+    wv_sync();
+    present_out = present;
+    return AVK_ST_OK;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -906,6 +976,11 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     off = AVK_ALIGN8(off + 4ull * c.optcap);
     c.bres = (u64 *)(ws + off);
     off += 8ull * 2 * 2 * 2 * c.alw;
+    c.memo_cap = 8;
+    c.memo = (u64 *)(ws + off);
+    off += 8ull * 4 * c.alw * c.memo_cap;
+    c.memo_err = (u32 *)(ws + off);
+    off += 4ull * c.memo_cap;
     if (off + 64 > ws_bytes) return RS_OVERFLOW;
     {
         /* the rest: node pool + queue (key 8 + slot 4 + free 4 bytes per possible node) */
@@ -955,9 +1030,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
                 lv.a_off = run + excl;
                 lv.raw_space = dv.raw_space;
                 lv.alt_ed = 0;
-                lv.type = dv.type;
-                lv.zyg = dv.zyg;
-                lv.pad0 = lv.pad1 = 0;
+                lv.type_zyg = (u32)dv.type | ((u32)dv.zyg << 8);
                 c.vars[k] = lv;
                 const u8 *src = a.alleles + dv.a_off;
                 for (u32 t = 0; t < mine; ++t) c.alle[run + excl + t] = src[t];
@@ -981,8 +1054,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
 
     /* Variant::alt_ed for every variant (variants.rs:413-415) */
     for (u32 k = 0; k < c.N; ++k) {
-        const LVar v = c.vars[k];
-        const u32 l0 = wv_uni(v.a0_len), l1 = wv_uni(v.a1_len), ao = wv_uni(v.a_off);
+        const UVar v = load_var(c.vars, k);
+        const u32 l0 = v.a0_len, l1 = v.a1_len, ao = v.a_off;
         u32 e;
         if (l0 == 1 && l1 == 1) e = wv_uni(c.alle[ao] != c.alle[ao + 1] ? 1u : 0u);
         else {
@@ -1002,6 +1075,11 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     if (nopt == RS_OVERFLOW) return RS_OVERFLOW;
     if (nopt < 0) return -nopt - 100;
     out.n_opt = (u32)nopt;
+    if (a.mode == 1) { /* merge_solver.rs:137-143: only all_opt_haps[0].is_exact_match() is looked at, and every
+                          tied optimum has the same total cost = ed1 + ed2 + the four skip distances */
+        out.ed1 = c.best_cost == 0 ? 1u : 0u;
+        return AVK_ST_OK;
+    }
 
     /* keep the optima at the front of the pool: nodes [0, nopt) */
     {
@@ -1034,24 +1112,38 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         }
     }
 
-    /* ---- phase B for every tied optimum (waffle_solver.rs:169-261) */
+    if (a.enable_exact_shortcut && c.best_cost == 0) { /* waffle_solver.rs:171-199: returns on the first optimum */
+        const HapPtr s0 = hap_ptr(c.pool + 8, c.alw, c.wfcap, c.seqcap);
+        const HapPtr s1 = hap_ptr(c.pool + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        const HapHdr g0 = hap_load(s0.w), g1 = hap_load(s1.w);
+        winner_node = 0;
+        out.ed1 = 0;
+        out.ed2 = 0;
+        u32 present = 0;
+        const int st = exact_shortcut_metrics(a, c, v_off, s0, g0, s1, g1, present);
+        out.present = present;
+        return st;
+    }
+
+    /* ---- phase B for every tied optimum (waffle_solver.rs:169-261).
+     * optimize_gt_alleles is a pure function of the haplotype's input alleles, and tied optima share
+     * haplotypes (mirror images, independent orientation choices), so finished runs are memoised by
+     * their input bit-sets.  A candidate can only win with STRICTLY fewer flips than the best so far
+     * (min_by_key keeps the first minimum, :264-265), which gives every run its cutoff. */
     const u64 a_bytes = (u64)nopt * c.nodeA_bytes;
     u8 *const poolA = c.pool;
     const u32 nodeA_bytes = c.nodeA_bytes;
+    const bool small_n = c.N < 500;
     u32 best_total = 0xFFFFFFFFu, best_k = 0;
+    u32 n_memo = 0;
     for (u32 k = 0; k < (u32)nopt; ++k) {
-        u32 errs[2];
-        for (int hh = 0; hh < 2; ++hh) {
-            c.node_bytes = c.nodeB_bytes;
-            c.pool_base = poolA + AVK_ALIGN8(a_bytes);
-            const u64 bbytes = c.pool_bytes > AVK_ALIGN8(a_bytes) ? c.pool_bytes - AVK_ALIGN8(a_bytes) : 0;
-            u64 cap = bbytes / c.nodeB_bytes;
-            if (cap > c.qcap) cap = c.qcap;
-            c.pool_cap = (u32)cap;
+        u32 errs[2] = {0, 0};
+        bool cut = false;
+        for (int hh = 0; hh < 2 && !cut; ++hh) {
             const HapPtr ap = hap_ptr(poolA + (u64)k * nodeA_bytes + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
             u64 *res = c.bres + (u64)(0 * 2 + hh) * 2 * c.alw; /* candidate slot 0 = current */
             const HapHdr ah = hap_load(ap.w);
-            if (ah.ed == 0 && ah.nskip == 0 && c.N < 500) {
+            if (ah.ed == 0 && ah.nskip == 0 && small_n) {
                 /* The phasing search already proved truth == query on this haplotype with every ALT
                  * incorporated.  The exact-match search then has exactly one zero-error path (keep every
                  * allele); it is always the top of the queue, cannot be pruned before it finalises
@@ -1066,11 +1158,56 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
                 errs[hh] = 0;
                 continue;
             }
-            const int e = phaseB(c, ap.talt, ap.qalt, res);
+            /* memo lookup: entry m = [talt | qalt | res_t | res_q] (4*alw words) + errors */
+            int hit = -1;
+            for (u32 m = 0; m < n_memo && hit < 0; ++m) {
+                const u64 *e = c.memo + (u64)m * 4 * c.alw;
+                bool l_diff = false;
+                for (u32 i = lane; i < c.alw; i += 64) l_diff = l_diff || e[i] != ap.talt[i] || e[c.alw + i] != ap.qalt[i];
+                if (wv_ballot(l_diff) == 0) hit = (int)m;
+            }
+            if (hit >= 0) {
+                const u64 *e = c.memo + (u64)hit * 4 * c.alw;
+                wv_sync();
+                for (u32 i = lane; i < 2 * c.alw; i += 64) res[i] = e[2 * c.alw + i];
+                wv_sync();
+                errs[hh] = ld32u(c.memo_err + hit);
+                continue;
+            }
+            u32 cutoff = 0xFFFFFFFFu;
+            if (small_n && best_total != 0xFFFFFFFFu) cutoff = best_total > errs[0] ? best_total - (hh ? errs[0] : 0u) : 0u;
+            if (cutoff == 0) {
+                cut = true;
+                break;
+            }
+            c.node_bytes = c.nodeB_bytes;
+            c.pool_base = poolA + AVK_ALIGN8(a_bytes);
+            const u64 bbytes = c.pool_bytes > AVK_ALIGN8(a_bytes) ? c.pool_bytes - AVK_ALIGN8(a_bytes) : 0;
+            u64 cap = bbytes / c.nodeB_bytes;
+            if (cap > c.qcap) cap = c.qcap;
+            c.pool_cap = (u32)cap;
+            const int e = phaseB(c, ap.talt, ap.qalt, res, cutoff);
             if (e == RS_OVERFLOW) return RS_OVERFLOW;
+            if (e == RS_CUT) {
+                cut = true;
+                break;
+            }
             if (e < 0) return -e - 100;
             errs[hh] = (u32)e;
+            if (n_memo < c.memo_cap) {
+                u64 *me = c.memo + (u64)n_memo * 4 * c.alw;
+                wv_sync();
+                for (u32 i = lane; i < c.alw; i += 64) {
+                    me[i] = ap.talt[i];
+                    me[c.alw + i] = ap.qalt[i];
+                }
+                for (u32 i = lane; i < 2 * c.alw; i += 64) me[2 * c.alw + i] = res[i];
+                st32(c.memo_err + n_memo, (u32)e);
+                wv_sync();
+                n_memo += 1;
+            }
         }
+        if (cut) continue; /* this optimum needs at least as many flips as the best one */
         const u32 total = errs[0] + errs[1];
         if (total < best_total) { /* min_by_key keeps the FIRST minimum, :264-265 */
             best_total = total;
@@ -1106,11 +1243,12 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         const u32 b0 = (u32)((e0[sub >> 6] >> (sub & 63)) & 1), b1 = (u32)((e1[sub >> 6] >> (sub & 63)) & 1);
         const u32 exp = b0 + b1;
         const u32 ob = (u32)((o0[sub >> 6] >> (sub & 63)) & 1) + (u32)((o1[sub >> 6] >> (sub & 63)) & 1);
-        const LVar v = c.vars[k];
+        const LVar v = c.vars[k]; /* per-lane variant: lanes work on different variants here */
+        const u32 vtype = v.type_zyg & 0xFF;
         if (exp == 0) l_bad = AVK_ST_VARIANT_METRICS;
         else if (exp < ob) l_bad = AVK_ST_TRUTH_FP;
-        else gm_add(c.gm, !is_truth, v.type, v.alt_ed, exp, ob);
-        l_present |= 1u << v.type;
+        else gm_add(c.gm, !is_truth, vtype, v.alt_ed, exp, ob);
+        l_present |= 1u << vtype;
         /* VariantMetrics (variant_metrics.rs:43-101); query entries are toggled */
         const u32 gv = v_off + k;
         u32 cls = exp == ob ? AVK_CLASS_TP : AVK_CLASS_FN;
@@ -1138,7 +1276,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         u32 nt = 0, nq = 0;
         for (u32 base = 0; base < c.N; base += 64) {
             const u32 k = base + lane;
-            const bool hit = k < c.N && c.vars[k].type == SUP[s];
+            const bool hit = k < c.N && (c.vars[k].type_zyg & 0xFF) == (u32)SUP[s];
             nt += (u32)avk_popc64(wv_ballot(hit && k < c.T));
             nq += (u32)avk_popc64(wv_ballot(hit && k >= c.T));
         }
@@ -1230,12 +1368,12 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         u32 *tot = c.gq; /* tot[0..12] truth totals per group, tot[16..28] query totals (zeroed above) */
         for (u32 k = lane; k < c.N; k += 64) {
             const LVar v = c.vars[k];
-            const u32 z = v.zyg;
+            const u32 z = (v.type_zyg >> 8) & 0xFF;
             const u32 cntz = z == AVK_ZYG_HOM_ALT ? 2u : ((z == AVK_ZYG_UNPHASED_HET || z == AVK_ZYG_PHASED_HET01 || z == AVK_ZYG_PHASED_HET10) ? 1u : 0u);
             const u32 val = cntz * v.raw_space;
             const u32 basei = k < c.T ? 0 : 16;
             avk_atomic_add_u32(tot + basei, val);
-            avk_atomic_add_u32(tot + basei + 1 + v.type, val);
+            avk_atomic_add_u32(tot + basei + 1 + (v.type_zyg & 0xFF), val);
         }
         wv_sync();
         u32 l_err = 0;
@@ -1346,8 +1484,9 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         const AvkDevRegion reg = a.regions[r];
         const u32 pre = wv_uni(reg.pre_status);
         if (pre) {
-            write_failed_region(a, r, (int)pre);
-            n_err += 1;
+            write_failed_region(a, r, pre == AVK_PRE_SKIP_OK ? 0 : (int)pre);
+            n_err += pre == AVK_PRE_SKIP_OK ? 0u : 1u;
+            n_ok += pre == AVK_PRE_SKIP_OK ? 1u : 0u;
             continue;
         }
         Ctx c;
@@ -1377,12 +1516,13 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         }
         /* results of an Ok region */
         write_region_record(a, r, 0, out.ed1, out.ed2, out.n_opt, out.present);
+        n_ok += 1;
+        if (a.mode == 1) continue;
         if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
         for (int j = 0; j < 5; ++j) {
             const u32 i = (u32)j * 64 + lane;
             if (i < AVK_N_GROUPS * AVK_N_FIELDS) tally[j] += c.gm[i];
         }
-        n_ok += 1;
         if (a.seq_bytes && a.seq_len && reg.seq_stride) { /* SequenceBundle, waffle_solver.rs:237-246 */
             u8 *wn = c.pool + (u64)winner * c.nodeA_bytes;
             const HapPtr w0 = hap_ptr(wn + 8, c.alw, c.wfcap, c.seqcap);

@@ -1474,6 +1474,21 @@ int orc_bench(const avk_region_batch *batch, const uint8_t *const *refs, const u
     return 0;
 }
 
+/* per-region search statistics (sizing / tuning aid): out = pops A, max queue A, pops B (all runs), max queue B, optima, max ed */
+int orc_region_stats(const avk_region_batch *batch, uint64_t r, const uint8_t *ref, uint64_t ref_len, const avk_compare_config *cfg, uint64_t out[6]) {
+    t_stats = Stats();
+    Region reg = region_view(batch, r);
+    CompareBenchmark bm;
+    int st = solve_compare_region(reg, Span(ref, ref_len), *cfg, &bm);
+    out[0] = t_stats.total_pops_a;
+    out[1] = t_stats.max_queue_a;
+    out[2] = t_stats.total_pops_b;
+    out[3] = t_stats.max_queue_b;
+    out[4] = t_stats.max_optima;
+    out[5] = t_stats.max_ed;
+    return st;
+}
+
 int orc_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                              uint32_t max_branch_factor, int32_t *status, uint8_t *is_exact_match, int threads) {
     if (threads < 1) threads = 1;
@@ -1493,6 +1508,13 @@ int orc_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const
             int e = validate_region(reg, reference.n);
             if (e) {
                 status[r] = e;
+                continue;
+            }
+            bool unknown = false; /* variant_delta_length bails on an Unknown zygosity, merge_solver.rs:216 */
+            for (const Var &v : reg.truth) unknown = unknown || v.zyg == AVK_ZYG_UNKNOWN;
+            for (const Var &v : reg.query) unknown = unknown || v.zyg == AVK_ZYG_UNKNOWN;
+            if (unknown) {
+                status[r] = AVK_ST_BAD_ZYGOSITY;
                 continue;
             }
             if (variant_delta_length(reg.truth) != variant_delta_length(reg.query)) { /* merge_solver.rs:135,:147 */

@@ -98,6 +98,9 @@ int      orc_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *
                                   uint32_t n_contigs, uint32_t max_branch_factor, int32_t *status,
                                   uint8_t *is_exact_match, int threads);
 
+/* per-region search statistics: pops A, max queue A, pops B, max queue B, tied optima, max edit distance */
+int      orc_region_stats(const avk_region_batch *batch, uint64_t r, const uint8_t *ref, uint64_t ref_len, const avk_compare_config *cfg, uint64_t out[6]);
+
 /* search statistics of the last orc_compare_batch on this process (sizing aid for the kernels):
  * [0] max pops in optimize_sequences, [1] max live queue there, [2] max pops in optimize_gt_alleles,
  * [3] max live queue there, [4] max edit distance seen by any DWFA, [5] max tied optima,

@@ -169,7 +169,7 @@ extern "C" {
  * are the per-wave workspace sizes of the four tiers (0 disables a tier), *_ed_cap the wavefront caps
  * of the LDS tiers, n_waves the number of persistent waves, threads the OS threads running them.
  * tier_counts[5] receives how many regions each tier finished, then the capacity failures. */
-int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
+static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
                       uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
     std::vector<uint64_t> base(n_contigs), lens(n_contigs);
@@ -207,6 +207,17 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
     a.n_regions = (uint32_t)n;
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut;
+    a.mode = mode;
+    if (mode == 1) { /* the pre-checks of avk_optimize_pairs_batch (aardvark_amd/csrc/avk_host.hip) */
+        for (uint64_t r = 0; r < batch->n_regions; ++r) {
+            AvkDevRegion &dr = pb.regions[r];
+            if (dr.pre_status == AVK_ST_INVALID_INPUT) continue;
+            if (pb.zyg_flags[r] & 1) dr.pre_status = AVK_ST_BAD_ZYGOSITY;
+            else if (pb.delta_t[r] != pb.delta_q[r]) dr.pre_status = AVK_PRE_SKIP_OK;
+            else if (pb.zyg_flags[r] & 2) dr.pre_status = AVK_ST_BAD_ZYGOSITY;
+            else dr.pre_status = 0;
+        }
+    }
     a.tier[0].ws_bytes = lds_bytes;
     a.tier[0].ed_cap = lds_ed_cap;
     a.tier[1].ws_bytes = lds2_bytes;
@@ -308,6 +319,31 @@ int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs,
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     if (tier_counts) memcpy(tier_counts, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
+    return 0;
+}
+
+int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
+                      const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
+                      uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
+    return emu_run(0, batch, refs, ref_lens, n_contigs, cfg, out, lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, ws_bytes, big_ws_bytes, n_waves,
+                   threads, tier_counts);
+}
+
+/* avk_optimize_pairs_batch on emulated wavefronts (default tier sizes) */
+int emu_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
+                             uint32_t max_branch_factor, int32_t *status, uint8_t *is_exact_match, int threads) {
+    avk_compare_config cfg;
+    cfg.max_branch_factor = max_branch_factor;
+    cfg.enable_sequences = 0;
+    cfg.enable_exact_shortcut = 0;
+    std::vector<uint32_t> ed1(batch->n_regions + 1);
+    avk_result_batch out;
+    memset(&out, 0, sizeof(out));
+    out.status = status;
+    out.ed_h1 = ed1.data();
+    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 9 * 1024, 8, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr);
+    if (rc) return rc;
+    for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && ed1[r] ? 1 : 0;
     return 0;
 }
 

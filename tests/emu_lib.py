@@ -19,6 +19,8 @@ def load():
         lib.emu_compare_batch.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.POINTER(AvkCompareConfig),
                                           C.POINTER(AvkResultBatch), C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
                                           C.c_uint32, C.c_int, u64p]
+        lib.emu_optimize_pairs_batch.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.c_uint32,
+                                                 C.POINTER(C.c_int32), u8p, C.c_int]
         _lib = lib
     return _lib
 
@@ -37,3 +39,16 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     assert rc == 0
     res.tier_counts = [int(x) for x in tiers]
     return res
+
+
+def optimize_pairs(batch, contigs, max_branch_factor=50, threads=8):
+    import numpy as np
+    lib = load()
+    cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
+    status = np.full(batch.n_regions, -1, np.int32)
+    exact = np.zeros(max(batch.n_regions, 1), np.uint8)
+    cb = batch.c_struct()
+    rc = lib.emu_optimize_pairs_batch(C.byref(cb), cs.ptrs, cs.lens, cs.n, max_branch_factor, status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      exact.ctypes.data_as(u8p), threads)
+    assert rc == 0
+    return status, exact[:batch.n_regions]

@@ -128,3 +128,14 @@ def bench(lib, batch, contigs, threads, reps, max_branch_factor=50):
     rc = lib.orc_bench(C.byref(cb), cs.ptrs, cs.lens, cs.n, C.byref(cfg), threads, reps, C.byref(sec), C.byref(chk))
     assert rc == 0
     return sec.value, batch.n_regions * reps / sec.value
+
+
+def optimize_pairs(lib, batch, contigs, max_branch_factor=50, threads=1):
+    cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
+    status = np.full(batch.n_regions, -1, np.int32)
+    exact = np.zeros(max(batch.n_regions, 1), np.uint8)
+    cb = batch.c_struct()
+    rc = lib.orc_optimize_pairs_batch(C.byref(cb), cs.ptrs, cs.lens, cs.n, max_branch_factor, status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                      exact.ctypes.data_as(u8p), threads)
+    assert rc == 0
+    return status, exact[:batch.n_regions]

@@ -96,3 +96,14 @@ def test_long_alleles_and_large_edit_distance(oracle):
     contigs, batch = scenarios.long_allele_regions()
     sub = batch.slice(2, 4)  # the 600 bp SV pair and the TR pair (the 3 kbp pair runs on the GPU test)
     check(oracle, contigs, sub, n_waves=2)
+
+
+def test_hidden_exact_shortcut(oracle):
+    """--enable-exact-shortcut (waffle_solver.rs:171-199, :534-601): exact regions take the shortcut
+    metrics, the others the full path"""
+    for contigs, batch in (scenarios.golden(), scenarios.chr20_small(1200), scenarios.fuzz_regions(31, 120)):
+        want = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True, exact_shortcut=True, threads=4)
+        got = emu_lib.compare_batch(batch, contigs, sequences=True, exact_shortcut=True, threads=EMU_THREADS)
+        assert got.diff(want) == []
+        plain = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True, threads=4)
+        assert want.diff(plain) != []  # the shortcut really changes the metrics (no RECORD_BP, fewer type entries)

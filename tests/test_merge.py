@@ -1,0 +1,89 @@
+"""Merge path: the pairwise exact-match primitive (optimize_sequences behind
+avk_optimize_pairs_batch) and the host-side solve_merge_region classification, against the reference's
+known-answer tests (src/merge_solver.rs:243-370) and, for the device kernels, against the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib
+import scenarios
+from aardvark_amd import RegionBatch
+from aardvark_amd.merge import MergeConfig, pair_batch, solve_merge_regions
+
+GOLD = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "merge_solver.json")))
+
+
+def golden_regions():
+    return [{"start": r["start"], "end": r["end"], "inputs": r["inputs"]} for r in GOLD["regions"]]
+
+
+def classify(pairs_fn):
+    got = []
+    for r in GOLD["regions"]:
+        res = solve_merge_regions(pairs_fn, [{"start": r["start"], "end": r["end"], "inputs": r["inputs"]}], MergeConfig(**r["config"]))
+        got.append(res[0])
+    return got
+
+
+def expect():
+    return [(0, tuple(r["expect"]) if len(r["expect"]) == 1 else (r["expect"][0], r["expect"][1])) for r in GOLD["regions"]]
+
+
+def test_solve_merge_region_known_answers_oracle(oracle):
+    contig = [GOLD["contig"].encode()]
+    assert classify(lambda b, mbf: oracle_lib.optimize_pairs(oracle, b, contig, mbf)) == expect()
+
+
+def test_solve_merge_region_known_answers_kernel_logic():
+    contig = [GOLD["contig"].encode()]
+    assert classify(lambda b, mbf: emu_lib.optimize_pairs(b, contig, mbf, threads=2)) == expect()
+
+
+def test_variant_delta_length_rule(oracle):
+    """merge_solver.rs:351-370: pairs whose net inserted length differs are not exact (and never reach the optimizer)"""
+    g = GOLD["variant_delta_length"]
+    contig = [b"ACGT" * 20]
+    v = g["variants"]
+    fixed = [(10, "A", "C", "Snv", v[0][4]), (12, "ACGTACGT", "A", "Deletion", v[1][4]), (25, "C", "CCC", "Insertion", v[2][4])]
+    batch = RegionBatch.from_regions([{"start": 0, "end": 60, "truth": [fixed[1]], "query": [fixed[2]]},
+                                      {"start": 0, "end": 60, "truth": [fixed[0]], "query": [fixed[0]]}])
+    for fn in (lambda: oracle_lib.optimize_pairs(oracle, batch, contig), lambda: emu_lib.optimize_pairs(batch, contig, threads=2)):
+        st, ex = fn()
+        assert st.tolist() == [0, 0] and ex.tolist() == [0, 1]
+
+
+def test_pairs_kernel_logic_matches_oracle_on_fuzz(oracle):
+    for seed in (41, 42):
+        contigs, batch = scenarios.fuzz_regions(seed, 150, related=0.85)
+        st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs, threads=4)
+        st_e, ex_e = emu_lib.optimize_pairs(batch, contigs, threads=8)
+        assert np.array_equal(st_o, st_e) and np.array_equal(ex_o, ex_e)
+        assert ex_o.any() and not ex_o.all()
+    contigs, batch = scenarios.invalid_regions()
+    st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs)
+    st_e, ex_e = emu_lib.optimize_pairs(batch, contigs, threads=2)
+    assert np.array_equal(st_o, st_e) and np.array_equal(ex_o, ex_e)
+
+
+@pytest.mark.gpu
+def test_pairs_on_gpu_match_oracle(oracle):
+    import aardvark_amd
+    ctx = aardvark_amd.Context(0)
+    contig = [GOLD["contig"].encode()]
+    ctx.upload_reference(contig)
+    assert classify(lambda b, mbf: ctx.optimize_pairs(b, mbf)) == expect()
+    for seed in (41, 42, 43):
+        contigs, batch = scenarios.fuzz_regions(seed, 2000, related=0.85)
+        ctx.upload_reference(contigs)
+        st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs, threads=8)
+        st_g, ex_g = ctx.optimize_pairs(batch)
+        assert np.array_equal(st_o, st_g) and np.array_equal(ex_o, ex_g)
+    contigs, batch = scenarios.invalid_regions()
+    ctx.upload_reference(contigs)
+    st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs)
+    st_g, ex_g = ctx.optimize_pairs(batch)
+    assert np.array_equal(st_o, st_g) and np.array_equal(ex_o, ex_g)
+    ctx.close()
