@@ -52,7 +52,9 @@ struct AvkKernelArgs {
     const AvkDevRegion *regions;
     const AvkDevVariant *variants;
     const uint8_t *alleles;
-    const uint8_t *ref_bytes;
+    const uint8_t *ref_bytes;  /* concatenated contigs, one byte per base (used for windows that hold non-ACGT symbols) */
+    const uint32_t *ref_2bit;  /* the same, 16 bases per word, base i of a word in bits 2i..2i+1 (A 0, C 1, G 2, T 3); may be NULL */
+    const uint32_t *ref_exc;   /* bit w of this bitmap: packed word w holds a symbol other than upper-case A/C/G/T */
     uint32_t n_regions;
     uint32_t max_branch_factor;
     uint32_t enable_exact_shortcut;

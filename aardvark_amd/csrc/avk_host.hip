@@ -43,6 +43,36 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a)
     avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
+/* packs the uploaded reference: 16 bases per word, 2 bits each, plus one flag per word for anything that is
+ * not an upper-case A/C/G/T (those windows are read from the byte copy).  One thread per packed word. */
+__global__ void avk_pack_reference(const uint8_t *bytes, uint64_t n_bases, uint32_t *packed, uint32_t *exc) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t n_words = (n_bases + 15) >> 4;
+    uint32_t word = 0, bad = 0;
+    if (w < n_words) {
+        for (int j = 0; j < 16; ++j) {
+            const uint64_t p = w * 16 + j;
+            uint32_t code = 0;
+            if (p < n_bases) {
+                const uint8_t ch = bytes[p];
+                if (ch == 'A') code = 0;
+                else if (ch == 'C') code = 1;
+                else if (ch == 'G') code = 2;
+                else if (ch == 'T') code = 3;
+                else bad = 1;
+            }
+            word |= code << (2 * j);
+        }
+        packed[w] = word;
+    }
+    const unsigned long long m = __ballot(bad != 0);
+    const unsigned lane = threadIdx.x & 63u;
+    if (w < n_words + 64 && (lane & 31u) == 0) { /* 64 consecutive words = two 32-bit flag words */
+        const uint64_t fw = w >> 5;
+        if (fw <= ((n_words + 31) >> 5)) exc[fw] = lane == 0 ? (uint32_t)m : (uint32_t)(m >> 32);
+    }
+}
+
 /* sums the partial tallies into out[0 .. AVK_TALLY_STRIDE) */
 __global__ void avk_tally_reduce(const uint64_t *partials, uint64_t *out) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -72,6 +102,8 @@ struct avk_ctx {
     std::string err;
     /* reference */
     uint8_t *d_ref = nullptr;
+    uint32_t *d_ref2b = nullptr, *d_refexc = nullptr;
+    int64_t use_packed_reference = 1;
     std::vector<uint64_t> contig_base, contig_len;
     /* options */
     int64_t lds_bytes_per_wave = 9 * 1024;
@@ -203,6 +235,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
+    if (ctx->d_ref2b) (void)hipFree(ctx->d_ref2b);
+    if (ctx->d_refexc) (void)hipFree(ctx->d_refexc);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
@@ -250,6 +284,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "big_waves") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "big_waves must be in [1, 4096]");
         ctx->big_waves = value;
+    } else if (n == "use_packed_reference") {
+        ctx->use_packed_reference = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {
         ctx->emit_group_metrics = value ? 1 : 0;
     } else
@@ -264,6 +300,9 @@ int avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs,
         AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
         (void)hipFree(ctx->d_ref);
         ctx->d_ref = nullptr;
+        if (ctx->d_ref2b) (void)hipFree(ctx->d_ref2b);
+        if (ctx->d_refexc) (void)hipFree(ctx->d_refexc);
+        ctx->d_ref2b = ctx->d_refexc = nullptr;
     }
     ctx->contig_base.assign(n_contigs, 0);
     ctx->contig_len.assign(n_contigs, 0);
@@ -276,6 +315,16 @@ int avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs,
     AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ref, total + 64));
     for (uint32_t c = 0; c < n_contigs; ++c)
         if (lens[c]) AVK_HIP(ctx, hipMemcpyAsync(ctx->d_ref + ctx->contig_base[c], seqs[c], lens[c], hipMemcpyHostToDevice, ctx->stream));
+    {
+        const uint64_t n_words = (total + 15) >> 4;
+        AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ref2b, (n_words + 80) * sizeof(uint32_t)));
+        AVK_HIP(ctx, hipMalloc((void **)&ctx->d_refexc, ((n_words >> 5) + 8) * sizeof(uint32_t)));
+        AVK_HIP(ctx, hipMemsetAsync(ctx->d_ref2b, 0, (n_words + 80) * sizeof(uint32_t), ctx->stream));
+        AVK_HIP(ctx, hipMemsetAsync(ctx->d_refexc, 0, ((n_words >> 5) + 8) * sizeof(uint32_t), ctx->stream));
+        const uint64_t threads = ((n_words + 63) / 64 + 1) * 64;
+        hipLaunchKernelGGL(avk_pack_reference, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, ctx->d_ref, total, ctx->d_ref2b, ctx->d_refexc);
+        AVK_HIP(ctx, hipGetLastError());
+    }
     AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
@@ -448,6 +497,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.variants = db->d_variants;
     a.alleles = db->d_alleles;
     a.ref_bytes = ctx->d_ref;
+    a.ref_2bit = ctx->use_packed_reference ? ctx->d_ref2b : nullptr;
+    a.ref_exc = ctx->d_refexc;
     a.n_regions = (uint32_t)n;
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut ? 1u : 0u;

@@ -1000,7 +1000,35 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     if (c.qcap < 3) return RS_OVERFLOW;
 
     /* stage the region: reference window, variants, alleles */
-    copy_bytes(refbuf, a.ref_bytes + reg.ref_off, c.L);
+    {
+        /* reference window: read from the 2-bit packed genome (a quarter of the HBM bytes, one or two
+         * 32-byte sectors for the usual 101-base window) unless a word of the window is flagged as
+         * holding something else than A/C/G/T, in which case the raw bytes are read */
+        bool packed = a.ref_2bit != (const u32 *)0;
+        if (packed) {
+            const u64 w0 = reg.ref_off >> 4, w1 = (reg.ref_off + (c.L ? c.L - 1 : 0)) >> 4;
+            bool l_exc = false;
+            for (u64 w = w0 + lane; w <= w1; w += 64) l_exc = l_exc || ((a.ref_exc[w >> 5] >> (w & 31)) & 1u);
+            packed = wv_ballot(l_exc) == 0;
+        }
+        if (packed) {
+            for (u32 b = lane * 4; b < c.L; b += 256) { /* four bases = one aligned LDS word per lane */
+                const u64 p = reg.ref_off + b;
+                const u64 w = p >> 4;
+                const u32 sh = (u32)(p & 15) * 2;
+                u64 bits = a.ref_2bit[w];
+                if (sh > 24) bits |= (u64)a.ref_2bit[w + 1] << 32;
+                const u32 code = (u32)(bits >> sh) & 0xFFu;
+                u32 word = 0;
+                for (int j = 0; j < 4; ++j) word |= ((0x54474341u >> (8 * ((code >> (2 * j)) & 3u))) & 0xFFu) << (8 * j);
+                if (b + 4 <= c.L) *(u32 *)(refbuf + b) = word;
+                else
+                    for (u32 j = 0; b + j < c.L; ++j) refbuf[b + j] = (u8)(word >> (8 * j));
+            }
+        } else {
+            copy_bytes(refbuf, a.ref_bytes + reg.ref_off, c.L);
+        }
+    }
     c.ref = refbuf;
     {
         u32 run = 0; /* allele arena offsets: sequential prefix over the variants */

@@ -204,6 +204,21 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.variants = pb.variants.data();
     a.alleles = pb.alleles.data();
     a.ref_bytes = refcat.data();
+    /* packed copy, as avk_pack_reference builds it on the device */
+    const uint64_t n_words = (total + 15) >> 4;
+    std::vector<uint32_t> ref2b(n_words + 80, 0), refexc((n_words >> 5) + 8, 0);
+    for (uint64_t p = 0; p < total; ++p) {
+        const uint8_t ch = refcat[p];
+        uint32_t code = 0;
+        if (ch == 'A') code = 0;
+        else if (ch == 'C') code = 1;
+        else if (ch == 'G') code = 2;
+        else if (ch == 'T') code = 3;
+        else refexc[(p >> 4) >> 5] |= 1u << ((p >> 4) & 31);
+        ref2b[p >> 4] |= code << (2 * (p & 15));
+    }
+    a.ref_2bit = ref2b.data();
+    a.ref_exc = refexc.data();
     a.n_regions = (uint32_t)n;
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut;
