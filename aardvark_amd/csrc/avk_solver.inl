@@ -72,11 +72,12 @@ enum { RS_CUT = -2 };      /* internal: phase B stopped because its answer can n
 #endif
 
 /* hap record: 10 header words, then alt bit-sets, wavefront, two sequences */
-enum { H_T_REFPOS = 0, H_Q_REFPOS, H_T_LEN, H_Q_LEN, H_T_SKIP, H_Q_SKIP, H_ED, H_T_NAL, H_Q_NAL, H_NSKIP, H_WORDS };
+enum { H_T_REFPOS = 0, H_Q_REFPOS, H_T_LEN, H_Q_LEN, H_T_SKIP, H_Q_SKIP, H_ED, H_T_NAL, H_Q_NAL, H_NSKIP, H_D0, H_PAD, H_WORDS };
 
 struct HapHdr {
     u32 t_refpos, q_refpos, t_len, q_len, t_skip, q_skip, ed, t_nal, q_nal;
     u32 nskip; /* ALT alleles that could not be incorporated (either side); the skip DISTANCE can be 0 for REF == ALT */
+    u32 d0;    /* while ed == 0 the whole wavefront is this one offset and lives here, not in wf[] */
 };
 
 /* local variant record in the workspace */
@@ -93,6 +94,7 @@ struct UVar {
 struct Ctx {
     /* region */
     u32 L, T, Q, N;
+    u8 *ws;        /* base of this wave's workspace */
     const u8 *ref; /* window bytes (workspace copy) */
     LVar *vars;    /* [N]: truth 0..T-1, query T..N-1 */
     u8 *alle;
@@ -114,7 +116,8 @@ struct Ctx {
     /* scratch */
     u32 *wfs;
     u32 wfs_cap;
-    u8 *seq_a, *seq_b;
+    u8 *seq_a;
+    u64 cscratch_off, pool_off; /* byte offsets of the metrics scratch and of the pool in the workspace */
     u32 *gm, *gq; /* [13*22] metrics blocks */
     u32 *optlist; /* tied optima (node indices) */
     u32 optcap;
@@ -148,18 +151,27 @@ AVK_DEV void st64(u64 *p, u64 v) {
     if (wv_lane() == 0) *p = v;
 }
 AVK_DEV u32 ld32u(const u32 *p) { return wv_uni(*p); }
+/* loads n consecutive words first and makes them scalar afterwards: the loads go out back to back and
+ * complete under one wait instead of one LDS round trip per field */
+template <int N> AVK_DEV void ldvec_u(const u32 *p, u32 (&out)[N]) {
+    u32 t[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) t[k] = p[k];
+#pragma unroll
+    for (int k = 0; k < N; ++k) out[k] = wv_uni(t[k]);
+}
 AVK_DEV UVar load_var(const LVar *vars, u32 i) {
-    const u32 *w = (const u32 *)(vars + i);
+    u32 w[7];
+    ldvec_u<7>((const u32 *)(vars + i), w);
     UVar v;
-    v.rel_pos = wv_uni(w[0]);
-    v.a0_len = wv_uni(w[1]);
-    v.a1_len = wv_uni(w[2]);
-    v.a_off = wv_uni(w[3]);
-    v.raw_space = wv_uni(w[4]);
-    v.alt_ed = wv_uni(w[5]);
-    const u32 tz = wv_uni(w[6]);
-    v.type = tz & 0xFF;
-    v.zyg = (tz >> 8) & 0xFF;
+    v.rel_pos = w[0];
+    v.a0_len = w[1];
+    v.a1_len = w[2];
+    v.a_off = w[3];
+    v.raw_space = w[4];
+    v.alt_ed = w[5];
+    v.type = w[6] & 0xFF;
+    v.zyg = (w[6] >> 8) & 0xFF;
     return v;
 }
 
@@ -310,17 +322,20 @@ AVK_DEV HapPtr hap_ptr(u8 *base, u32 alw, u32 wfcap, u32 seqcap) {
     return p;
 }
 AVK_DEV HapHdr hap_load(const u32 *w) {
+    u32 t[H_WORDS];
+    ldvec_u<H_WORDS>(w, t);
     HapHdr h;
-    h.t_refpos = ld32u(w + H_T_REFPOS);
-    h.q_refpos = ld32u(w + H_Q_REFPOS);
-    h.t_len = ld32u(w + H_T_LEN);
-    h.q_len = ld32u(w + H_Q_LEN);
-    h.t_skip = ld32u(w + H_T_SKIP);
-    h.q_skip = ld32u(w + H_Q_SKIP);
-    h.ed = ld32u(w + H_ED);
-    h.t_nal = ld32u(w + H_T_NAL);
-    h.q_nal = ld32u(w + H_Q_NAL);
-    h.nskip = ld32u(w + H_NSKIP);
+    h.t_refpos = t[H_T_REFPOS];
+    h.q_refpos = t[H_Q_REFPOS];
+    h.t_len = t[H_T_LEN];
+    h.q_len = t[H_Q_LEN];
+    h.t_skip = t[H_T_SKIP];
+    h.q_skip = t[H_Q_SKIP];
+    h.ed = t[H_ED];
+    h.t_nal = t[H_T_NAL];
+    h.q_nal = t[H_Q_NAL];
+    h.nskip = t[H_NSKIP];
+    h.d0 = t[H_D0];
     return h;
 }
 AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
@@ -335,6 +350,7 @@ AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
         w[H_T_NAL] = h.t_nal;
         w[H_Q_NAL] = h.q_nal;
         w[H_NSKIP] = h.nskip;
+        w[H_D0] = h.d0;
     }
 }
 AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
@@ -348,52 +364,111 @@ AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
     }
 }
 
-/* HaplotypeTracker::copy_reference (haplotype_dwfa.rs:218-227) */
-AVK_DEV void trk_copy_reference(const Ctx &c, u8 *seq, u32 &len, u32 &refpos, u32 upto) {
-    if (refpos < upto) {
-        copy_bytes(seq + len, c.ref + refpos, upto - refpos);
-        len += upto - refpos;
-        refpos = upto;
-    }
-}
+/* One haplotype step = HaplotypeDWFA::extend_variant without the DWFA update (haplotype_dwfa.rs:46-62,
+ * :175-227), as ONE fused copy:
+ *   other side:  copy_reference(sync)                                   -> segment O
+ *   this side:   copy_reference(variant start)                          -> segment 1
+ *                ALT and compatible (ref_pos <= start): allele1         -> segment 2   (else skip penalty)
+ *                copy_reference(sync)                                   -> segment 3
+ * All lengths are scalar; each lane moves the bytes whose index it owns, picking the source by range.
+ * Returns the `success` flag of HaplotypeTracker::extend_variant.  `has_var` false = only the two
+ * copy_reference(upto) calls of finalize_dwfa (:84-88). */
+AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, bool has_var, const UVar &v, u32 allele, u32 sync) {
+    const u32 lane = (u32)wv_lane();
+    u32 &tl = is_truth ? h.t_len : h.q_len, &ol = is_truth ? h.q_len : h.t_len;
+    u32 &trp = is_truth ? h.t_refpos : h.q_refpos, &orp = is_truth ? h.q_refpos : h.t_refpos;
+    u32 &tskip = is_truth ? h.t_skip : h.q_skip, &tnal = is_truth ? h.t_nal : h.q_nal;
+    u8 *ts = is_truth ? p.tseq : p.qseq, *os = is_truth ? p.qseq : p.tseq;
+    u64 *talt = is_truth ? p.talt : p.qalt;
 
-/* HaplotypeTracker::extend_variant (haplotype_dwfa.rs:175-212); returns the `success` flag */
-AVK_DEV bool trk_extend_variant(const Ctx &c, const UVar &v, u32 allele, u32 sync, u8 *seq, u32 &len, u32 &refpos, u32 &skip,
-                                u64 *alt, u32 &nal, u32 &nskip) {
-    trk_copy_reference(c, seq, len, refpos, v.rel_pos);
+    const u32 n_o = orp < sync ? sync - orp : 0; /* other side up to the sync point */
+    const u32 s_o = orp;
+    u32 n1 = 0, n2 = 0, s1 = trp, rp = trp;
     bool ok = true;
-    if (allele == AL_ALT) {
-        if (refpos <= v.rel_pos) {
-            copy_bytes(seq + len, c.alle + v.a_off + v.a0_len, v.a1_len);
-            len += v.a1_len;
-            refpos = v.rel_pos + v.a0_len;
-            if (wv_lane() == 0) alt[nal >> 6] |= 1ull << (nal & 63);
-        } else {
-            skip += v.alt_ed; /* edit_distance(allele0, allele1), :199 — equal to the wavefront distance */
-            nskip += 1;
-            ok = false;
-            if (wv_lane() == 0) alt[nal >> 6] |= 1ull << (nal & 63); /* the allele pushed is still ALT (:204) */
+    if (has_var) {
+        if (rp < v.rel_pos) {
+            n1 = v.rel_pos - rp;
+            rp = v.rel_pos;
         }
-    } else {
-        if (wv_lane() == 0) alt[nal >> 6] &= ~(1ull << (nal & 63));
+        if (allele == AL_ALT) {
+            if (rp <= v.rel_pos) {
+                n2 = v.a1_len;
+                rp = v.rel_pos + v.a0_len;
+            } else {
+                tskip += v.alt_ed; /* edit_distance(allele0, allele1), :199 — equal to the wavefront distance */
+                h.nskip += 1;
+                ok = false;
+            }
+        }
+        if (lane == 0) { /* alleles.push(allele), :204 */
+            const u64 bit = 1ull << (tnal & 63);
+            if (allele == AL_ALT) talt[tnal >> 6] |= bit;
+            else talt[tnal >> 6] &= ~bit;
+        }
+        tnal += 1;
     }
-    nal += 1;
-    trk_copy_reference(c, seq, len, refpos, sync);
-    return ok;
-}
-
-/* HaplotypeDWFA::extend_variant minus the DWFA update (haplotype_dwfa.rs:46-62) */
-AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, const UVar &v, u32 allele, u32 sync) {
-    bool ok;
-    if (is_truth) {
-        trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, sync);
-        ok = trk_extend_variant(c, v, allele, sync, p.tseq, h.t_len, h.t_refpos, h.t_skip, p.talt, h.t_nal, h.nskip);
-    } else {
-        trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, sync);
-        ok = trk_extend_variant(c, v, allele, sync, p.qseq, h.q_len, h.q_refpos, h.q_skip, p.qalt, h.q_nal, h.nskip);
+    const u32 s3 = rp;
+    const u32 n3 = rp < sync ? sync - rp : 0;
+    if (rp < sync) rp = sync;
+    /* everything lives in the wave's workspace: sources and destinations are 32-bit offsets from its base */
+    const u32 ref_o = (u32)(c.ref - c.ws), alle_o = (u32)(c.alle - c.ws) + v.a_off + v.a0_len;
+    const u32 ts_o = (u32)(ts - c.ws) + tl, os_o = (u32)(os - c.ws) + ol;
+    const u32 total = n_o + n1 + n2 + n3;
+    for (u32 j = lane; j < total; j += 64) {
+        const bool other = j < n_o;
+        const u32 k = j - n_o; /* index on this side (meaningless when `other`) */
+        const u32 so = other ? ref_o + s_o + j : (k < n1 ? ref_o + s1 + k : (k < n1 + n2 ? alle_o + (k - n1) : ref_o + s3 + (k - n1 - n2)));
+        const u32 dof = other ? os_o + j : ts_o + k;
+        c.ws[dof] = c.ws[so];
     }
+    ol += n_o;
+    if (n_o) orp = sync;
+    tl += n1 + n2 + n3;
+    trp = rp;
     wv_sync();
     return ok;
+}
+
+/* DWFALite::update for a haplotype record (dynamic_wfa.rs:68-84).  While ed == 0 the wavefront is the single
+ * offset h.d0: extend = slide it over the common part of the two sequences, 64 bases per step; only a real
+ * mismatch (both sequences continue and differ) enters the general wavefront code. */
+AVK_DEV bool hap_slide_d0(const HapPtr &p, HapHdr &h) { /* returns true when either end is touched */
+    const u32 lane = (u32)wv_lane();
+    const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
+    u32 d = h.d0;
+    while (d < lim) {
+        const u32 i = d + lane;
+        const bool in = i < lim;
+        const u32 ii = in ? i : 0;
+        const bool match = in && p.tseq[ii] == p.qseq[ii];
+        const u64 m = wv_ballot(!match);
+        if (m) {
+            d += (u32)avk_ctz64(m);
+            break;
+        }
+        d += 64;
+    }
+    h.d0 = d;
+    return d >= lim;
+}
+AVK_DEV int hap_update(const HapPtr &p, u32 wfcap, HapHdr &h) {
+    if (h.ed == 0) {
+        if (hap_slide_d0(p, h)) return 0;
+        wv_sync();
+        st32(p.wf, h.d0);
+        wv_sync();
+    }
+    return dw_update(p.wf, wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len);
+}
+/* DWFALite::finalize (dynamic_wfa.rs:183-198) after an update */
+AVK_DEV int hap_finalize(const HapPtr &p, u32 wfcap, HapHdr &h) {
+    if (h.ed == 0) {
+        if (h.d0 >= h.t_len && h.d0 >= h.q_len) return 0; /* reached_full_diagonal with ed 0 */
+        wv_sync();
+        st32(p.wf, h.d0);
+        wv_sync();
+    }
+    return dw_finalize(p.wf, wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -464,7 +539,10 @@ AVK_DEV u32 queue_pop(Ctx &c, u64 &key_out) {
 AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
     const u32 *n = (const u32 *)node_at(c, idx);
     const u32 *h0 = n + 2, *h1 = (const u32 *)((const u8 *)h0 + c.hapA_bytes);
-    return ld32u(h0 + H_ED) + ld32u(h0 + H_T_SKIP) + ld32u(h0 + H_Q_SKIP) + ld32u(h1 + H_ED) + ld32u(h1 + H_T_SKIP) + ld32u(h1 + H_Q_SKIP);
+    u32 a[3], b[3];
+    ldvec_u<3>(h0 + H_T_SKIP, a); /* t_skip, q_skip, ed are consecutive header words */
+    ldvec_u<3>(h1 + H_T_SKIP, b);
+    return a[0] + a[1] + a[2] + b[0] + b[1] + b[2];
 }
 
 /* ComparisonNode::extend_variant (:443-451) = both haplotypes + their DWFA updates */
@@ -473,8 +551,8 @@ AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u3
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
-        hap_extend_seq(c, p, h, is_truth, v, hh == 0 ? a1 : a2, sync);
-        if (dw_update(p.wf, c.wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len)) return RS_OVERFLOW;
+        hap_extend_seq(c, p, h, is_truth, true, v, hh == 0 ? a1 : a2, sync);
+        if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
         wv_sync();
         hap_store(p.w, h);
         wv_sync();
@@ -485,14 +563,14 @@ AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u3
 /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
 AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
     u8 *n = node_at(c, idx);
+    UVar none;
+    none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
-        trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, c.L);
-        trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, c.L);
-        wv_sync();
-        if (dw_update(p.wf, c.wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len)) return RS_OVERFLOW;
-        if (dw_finalize(p.wf, c.wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len)) return RS_OVERFLOW;
+        hap_extend_seq(c, p, h, true, false, none, AL_REF, c.L); /* both sides to the region end */
+        if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
+        if (hap_finalize(p, c.wfcap, h)) return RS_OVERFLOW;
         wv_sync();
         hap_store(p.w, h);
         wv_sync();
@@ -607,34 +685,14 @@ AVK_DEV int phaseA(Ctx &c) {
 /* The DWFA of an ExactMatchNode has max_edit_distance 0 (:380): a live node's two sequences    */
 /* agree on their common prefix, so the whole wavefront is the single value d = matched length. */
 /* ------------------------------------------------------------------------------------------ */
-AVK_DEV bool exact_update(const HapPtr &p, HapHdr &h) {
-    /* update(): extend the main diagonal, then ed would have to rise unless one end is touched */
-    u32 d = ld32u(p.wf);
-    const u32 lane = (u32)wv_lane();
-    const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
-    while (d < lim) {
-        const u32 i = d + lane;
-        const bool match = i < lim && p.tseq[i] == p.qseq[i];
-        const u64 m = wv_ballot(!match);
-        if (m) {
-            d += (u32)avk_ctz64(m);
-            break;
-        }
-        d += 64;
-    }
-    wv_sync();
-    st32(p.wf, d);
-    wv_sync();
-    return d >= h.t_len || d >= h.q_len;
-}
-
-/* ExactMatchNode::extend_variant (:395-414): returns success && is_exact_match */
+/* ExactMatchNode::extend_variant (:395-414): returns success && is_exact_match.  With max_edit_distance 0 the
+ * update either slides d0 to an end (still exact) or would have to raise the distance (not exact). */
 AVK_DEV bool nodeB_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 allele, u32 sync, bool is_error) {
     u8 *n = node_at(c, idx);
     const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
     HapHdr h = hap_load(p.w);
-    const bool ok = hap_extend_seq(c, p, h, is_truth, v, allele, sync);
-    const bool exact = exact_update(p, h);
+    const bool ok = hap_extend_seq(c, p, h, is_truth, true, v, allele, sync);
+    const bool exact = hap_slide_d0(p, h);
     if (is_error) {
         const u32 e = ld32u((u32 *)n + 1);
         wv_sync();
@@ -685,12 +743,11 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
         HapHdr h = hap_load(p.w);
         const u32 depth = h.t_nal + h.q_nal;
         if (depth == c.N) { /* :180-192 finalize: both to the region end, exact iff identical */
-            trk_copy_reference(c, p.tseq, h.t_len, h.t_refpos, c.L);
-            trk_copy_reference(c, p.qseq, h.q_len, h.q_refpos, c.L);
-            wv_sync();
-            const bool touched = exact_update(p, h);
-            const u32 d = ld32u(p.wf);
-            const bool exact = touched && d >= h.t_len && d >= h.q_len;
+            UVar none;
+            none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
+            hap_extend_seq(c, p, h, true, false, none, AL_REF, c.L);
+            const bool touched = hap_slide_d0(p, h);
+            const bool exact = touched && h.d0 >= h.t_len && h.d0 >= h.q_len;
             if (exact) { /* :187-190; later pops cannot improve on it */
                 wv_sync();
                 for (u32 k = (u32)wv_lane(); k < c.alw; k += 64) {
@@ -951,6 +1008,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     c.optcap = c.max_branch < 4096 ? c.max_branch : 4096;
 
     /* carve the workspace */
+    c.ws = ws;
     u64 off = 0;
     u8 *refbuf = ws + off;
     off = AVK_ALIGN8(off + c.L);
@@ -962,16 +1020,6 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     off = AVK_ALIGN8(off + 4ull * c.N);
     c.bucket = (u32 *)(ws + off);
     off = AVK_ALIGN8(off + 4ull * (c.N + 1));
-    c.gm = (u32 *)(ws + off);
-    off += 4ull * AVK_N_GROUPS * AVK_N_FIELDS;
-    c.gq = (u32 *)(ws + off); /* 32 words: RECORD_BP totals per group, truth then query */
-    off = AVK_ALIGN8(off + 4ull * 32);
-    c.wfs = (u32 *)(ws + off);
-    off = AVK_ALIGN8(off + 4ull * c.wfs_cap);
-    c.seq_a = ws + off;
-    off += c.seqcap;
-    c.seq_b = ws + off;
-    off += c.seqcap;
     c.optlist = (u32 *)(ws + off);
     off = AVK_ALIGN8(off + 4ull * c.optcap);
     c.bres = (u64 *)(ws + off);
@@ -981,7 +1029,22 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     off += 8ull * 4 * c.alw * c.memo_cap;
     c.memo_err = (u32 *)(ws + off);
     off += 4ull * c.memo_cap;
-    if (off + 64 > ws_bytes) return RS_OVERFLOW;
+    /* metrics scratch (phase C only: metric block, RECORD_BP totals, the wfa_ed wavefront, one filtered
+     * sequence) sits at the TOP of the workspace and overlaps the tail of the node pool: the searches may
+     * grow into it, phase C only needs the optima at the front of the pool to stay clear of it */
+    const u64 csz = AVK_ALIGN8(4ull * AVK_N_GROUPS * AVK_N_FIELDS + 4ull * 32 + 4ull * c.wfs_cap + c.seqcap);
+    if (off + csz + 64 > ws_bytes) return RS_OVERFLOW;
+    {
+        u64 t = ws_bytes - csz;
+        c.cscratch_off = t;
+        c.gm = (u32 *)(ws + t);
+        t += 4ull * AVK_N_GROUPS * AVK_N_FIELDS;
+        c.gq = (u32 *)(ws + t); /* 32 words: RECORD_BP totals per group, truth then query */
+        t += 4ull * 32;
+        c.wfs = (u32 *)(ws + t);
+        t += 4ull * c.wfs_cap;
+        c.seq_a = ws + t;
+    }
     {
         /* the rest: node pool + queue (key 8 + slot 4 + free 4 bytes per possible node) */
         const u64 avail = ws_bytes - off;
@@ -996,6 +1059,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         off = AVK_ALIGN8(off + 4ull * c.qcap);
         c.pool = ws + off;
         c.pool_bytes = ws_bytes > off ? ws_bytes - off : 0;
+        c.pool_off = off;
     }
     if (c.qcap < 3) return RS_OVERFLOW;
 
@@ -1139,6 +1203,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
             wv_sync();
         }
     }
+
+    if (c.pool_off + (u64)nopt * c.nodeA_bytes > c.cscratch_off) return RS_OVERFLOW; /* optima would sit under the metrics scratch */
 
     if (a.enable_exact_shortcut && c.best_cost == 0) { /* waffle_solver.rs:171-199: returns on the first optimum */
         const HapPtr s0 = hap_ptr(c.pool + 8, c.alw, c.wfcap, c.seqcap);
@@ -1453,7 +1519,7 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
  * overflow list for the next launch; after the last tier it fails with AVK_ST_CAPACITY. */
 template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     const u32 lane = (u32)wv_lane();
-    u64 tally[5] = {0, 0, 0, 0, 0};
+    u32 tally[5] = {0, 0, 0, 0, 0}; /* a wave's share of a batch keeps every counter far below 2^32 */
     u32 n_ok = 0, n_err = 0, n_cap = 0;
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
