@@ -113,6 +113,13 @@ struct Ctx {
     u64 *qkeys;
     u32 *qslots;
     u32 qn, qcap;
+    /* register-resident form of the queue / free list / per-depth counters, used while the phase's pool has at
+     * most 64 nodes (and at most 64 depths): lane j holds queue entry j, lane d the counter of depth d, the free
+     * slots are a scalar bit mask — no LDS traffic for the search bookkeeping */
+    bool regq, regb;
+    u64 rq_key;
+    u32 rq_slot, rbucket;
+    u64 freemask;
     /* scratch */
     u32 *wfs;
     u32 wfs_cap;
@@ -292,10 +299,45 @@ AVK_DEV int dw_finalize(u32 *wf, u32 cap, u32 &ed, const u8 *B, u32 bl, const u8
     return 0;
 }
 
-/* wfa_ed (src/util/sequence_alignment.rs:9-13) on the scratch wavefront; < 0 = overflow */
+/* number of positions on which a[ia..] and b[ib..] agree before the first difference or either end */
+AVK_DEV u32 seq_match_run(const u8 *a, u32 al, u32 ia, const u8 *b, u32 bl, u32 ib) {
+    const u32 lane = (u32)wv_lane();
+    const u32 ra = al > ia ? al - ia : 0, rb = bl > ib ? bl - ib : 0;
+    const u32 lim = ra < rb ? ra : rb;
+    u32 n = 0;
+    while (n < lim) {
+        const u32 i = n + lane;
+        const bool in = i < lim;
+        const u32 ii = in ? i : 0;
+        const bool match = in && a[ia + ii] == b[ib + ii];
+        const u64 m = wv_ballot(!match);
+        if (m) {
+            n += (u32)avk_ctz64(m);
+            break;
+        }
+        n += 64;
+    }
+    return n;
+}
+
+/* wfa_ed (src/util/sequence_alignment.rs:9-13): a fresh DWFALite finalised on two complete strings, i.e. their
+ * unit-cost edit distance (the reference asserts wfa_ed == edit_distance, :58-116; the oracle's wavefront code and
+ * the full DP are fuzzed against each other).  Distances 0 and 1 — identical haplotypes, one substitution, one
+ * single-base indel: nearly every call — are decided by one or two lane-parallel comparisons; anything else runs
+ * the wavefront recurrence on the scratch front, starting from the common prefix.  < 0 = scratch overflow */
 AVK_DEV int wfa_ed(const Ctx &c, const u8 *a, u32 al, const u8 *b, u32 bl) {
     wv_sync();
-    st32(c.wfs, 0);
+    const u32 lim = al < bl ? al : bl;
+    const u32 d = seq_match_run(a, al, 0, b, bl, 0);
+    if (d == lim) return (int)((al > bl ? al : bl) - lim); /* one is a prefix of the other */
+    if (al == bl) {
+        if (d + 1 + seq_match_run(a, al, d + 1, b, bl, d + 1) == al) return 1;
+    } else if (al == bl + 1) {
+        if (d + seq_match_run(a, al, d + 1, b, bl, d) == bl) return 1;
+    } else if (bl == al + 1) {
+        if (d + seq_match_run(a, al, d, b, bl, d + 1) == al) return 1;
+    }
+    st32(c.wfs, d);
     wv_sync();
     u32 ed = 0;
     if (dw_finalize(c.wfs, c.wfs_cap, ed, a, al, b, bl)) return RS_OVERFLOW;
@@ -477,6 +519,15 @@ AVK_DEV int hap_finalize(const HapPtr &p, u32 wfcap, HapHdr &h) {
 AVK_DEV u8 *node_at(const Ctx &c, u32 idx) { return c.pool_base + (u64)idx * c.node_bytes; }
 
 AVK_DEV int node_alloc(Ctx &c) {
+    if (c.regq) {
+        if (c.freemask) {
+            const int idx = avk_ctz64(c.freemask);
+            c.freemask &= c.freemask - 1;
+            return idx;
+        }
+        if (c.pool_used < c.pool_cap) return (int)(c.pool_used++);
+        return RS_OVERFLOW;
+    }
     if (c.nfree > 0) {
         c.nfree -= 1;
         return (int)ld32u(c.freelist + c.nfree);
@@ -485,6 +536,10 @@ AVK_DEV int node_alloc(Ctx &c) {
     return RS_OVERFLOW;
 }
 AVK_DEV void node_free(Ctx &c, u32 idx) {
+    if (c.regq) {
+        c.freemask |= 1ull << idx;
+        return;
+    }
     wv_sync();
     st32(c.freelist + c.nfree, idx);
     c.nfree += 1;
@@ -497,6 +552,14 @@ AVK_DEV void node_copy(const Ctx &c, u32 dst, u32 src) {
 }
 AVK_DEV int queue_push(Ctx &c, u64 key, u32 slot) {
     if (c.qn >= c.qcap) return RS_OVERFLOW;
+    if (c.regq) {
+        if ((u32)wv_lane() == c.qn) {
+            c.rq_key = key;
+            c.rq_slot = slot;
+        }
+        c.qn += 1;
+        return 0;
+    }
     wv_sync();
     if (wv_lane() == 0) {
         c.qkeys[c.qn] = key;
@@ -509,6 +572,22 @@ AVK_DEV int queue_push(Ctx &c, u64 key, u32 slot) {
 /* pop the entry with the smallest key (keys are unique: they end in the node id) */
 AVK_DEV u32 queue_pop(Ctx &c, u64 &key_out) {
     const u32 lane = (u32)wv_lane();
+    if (c.regq) {
+        const u64 mine = lane < c.qn ? c.rq_key : ~0ull;
+        const u64 m = wv_min_u64(mine);
+        const u32 pos = (u32)avk_ctz64(wv_ballot(mine == m));
+        const u32 slot = wv_readlane(c.rq_slot, pos);
+        const u32 last = c.qn - 1;
+        const u32 lk_lo = wv_readlane((u32)c.rq_key, last), lk_hi = wv_readlane((u32)(c.rq_key >> 32), last);
+        const u32 ls = wv_readlane(c.rq_slot, last);
+        if (lane == pos) {
+            c.rq_key = ((u64)lk_hi << 32) | lk_lo;
+            c.rq_slot = ls;
+        }
+        c.qn = last;
+        key_out = m;
+        return slot;
+    }
     u64 best = ~0ull;
     u32 bpos = 0xFFFFFFFFu;
     for (u32 j = lane; j < c.qn; j += 64) {
@@ -531,6 +610,35 @@ AVK_DEV u32 queue_pop(Ctx &c, u64 &key_out) {
     wv_sync();
     key_out = m;
     return slot;
+}
+/* register form <-> memory form (only the auto-fail filter of phase B works on the memory form) */
+AVK_DEV void queue_spill(Ctx &c) {
+    const u32 lane = (u32)wv_lane();
+    wv_sync();
+    if (lane < c.qn) {
+        c.qkeys[lane] = c.rq_key;
+        c.qslots[lane] = c.rq_slot;
+    }
+    u32 nf = 0;
+    for (u64 m = c.freemask; m; m &= m - 1) {
+        st32(c.freelist + nf, (u32)avk_ctz64(m));
+        nf += 1;
+    }
+    c.nfree = nf;
+    wv_sync();
+}
+AVK_DEV void queue_reload(Ctx &c) {
+    const u32 lane = (u32)wv_lane();
+    wv_sync();
+    if (lane < c.qn) {
+        c.rq_key = c.qkeys[lane];
+        c.rq_slot = c.qslots[lane];
+    }
+    u64 m = 0;
+    for (u32 j = 0; j < c.nfree; ++j) m |= 1ull << ld32u(c.freelist + j);
+    c.freemask = m;
+    c.nfree = 0;
+    wv_sync();
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -588,7 +696,13 @@ AVK_DEV int phaseA(Ctx &c) {
     c.nfree = 0;
     c.qn = 0;
     if (c.pool_cap < 3) return RS_OVERFLOW;
-    zero_words(c.bucket, c.N + 1);
+    c.regq = c.pool_cap <= 64;
+    c.regb = c.N < 64;
+    c.freemask = 0;
+    c.rq_key = 0;
+    c.rq_slot = 0;
+    c.rbucket = 0;
+    if (!c.regb) zero_words(c.bucket, c.N + 1);
 
     int root = node_alloc(c);
     {
@@ -612,14 +726,18 @@ AVK_DEV int phaseA(Ctx &c) {
                                       costs less than its parent), every node still queued would be skipped too */
         const u32 *nw = (const u32 *)node_at(c, ni);
         const u32 depth = ld32u(nw + 2 + H_T_NAL) + ld32u(nw + 2 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
-        const u32 cnt = ld32u(c.bucket + depth);
+        const u32 cnt = c.regb ? wv_readlane(c.rbucket, depth) : ld32u(c.bucket + depth);
         if (cnt >= c.max_branch) { /* :222 */
             node_free(c, ni);
             continue;
         }
-        wv_sync();
-        st32(c.bucket + depth, cnt + 1);
-        wv_sync();
+        if (c.regb) {
+            if ((u32)wv_lane() == depth) c.rbucket += 1;
+        } else {
+            wv_sync();
+            st32(c.bucket + depth, cnt + 1);
+            wv_sync();
+        }
 
         if (depth == c.N) { /* :227-247 */
             if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
@@ -721,6 +839,10 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
     c.pool_used = 0;
     c.nfree = 0;
     if (c.pool_cap < 3) return RS_OVERFLOW;
+    c.regq = c.pool_cap <= 64;
+    c.freemask = 0;
+    c.rq_key = 0;
+    c.rq_slot = 0;
     int root = node_alloc(c);
     {
         u8 *n = node_at(c, (u32)root);
@@ -812,6 +934,11 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
         af_counts += 1; /* :309-339 */
         if (af_counts >= 500) {
             if (af_index >= c.N) return -100 - AVK_ST_AUTOFAIL_OOB;
+            const bool was_reg = c.regq;
+            if (was_reg) {
+                queue_spill(c);
+                c.regq = false;
+            }
             const u32 fi = ld32u(c.order + af_index);
             const bool f_truth = fi < c.T;
             const u32 fsub = f_truth ? fi : fi - c.T;
@@ -848,6 +975,10 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
                 wv_sync();
             }
             c.qn = kept;
+            if (was_reg) {
+                c.regq = true;
+                queue_reload(c);
+            }
             af_index += 1;
             af_counts = 0;
         }

@@ -68,6 +68,7 @@ AVK_DEV uint64_t wv_min_u64_(uint64_t v, uint32_t site) {
     for (int i = 0; i < 64; ++i) m = g[i] < m ? g[i] : m;
     return m;
 }
+AVK_DEV uint32_t wv_readlane_(uint32_t v, uint32_t src, uint32_t site) { return (uint32_t)avk_emu::gather(v, site)[src & 63]; }
 AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 #define wv_ballot(p) wv_ballot_((p), AVK_SITE)
 #define wv_shfl(v, src) wv_shfl_((v), (src), AVK_SITE)
@@ -76,6 +77,7 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 #define wv_min_u32(v) wv_min_u32_((v), AVK_SITE)
 #define wv_sum_u32(v) wv_sum_u32_((v), AVK_SITE)
 #define wv_min_u64(v) wv_min_u64_((v), AVK_SITE)
+#define wv_readlane(v, src) wv_readlane_((v), (src), AVK_SITE)
 #define wv_sync() wv_sync_(AVK_SITE)
 
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
@@ -94,6 +96,8 @@ AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 AVK_DEV int wv_lane() { return (int)__lane_id(); }
 AVK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
 AVK_DEV uint32_t wv_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
+/* value of lane `src` (src must be wave-uniform) as a scalar */
+AVK_DEV uint32_t wv_readlane(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
 /* a value that is identical on every lane: move it to an SGPR so branches on it are scalar */
 AVK_DEV uint32_t wv_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 /* cross-lane reductions on the DPP network (row shifts inside 16 lanes, then row broadcasts):
