@@ -35,6 +35,8 @@ struct AvkDevVariant {
 };
 
 #define AVK_PRE_SKIP_OK 0x1000u
+#define AVK_OVF_EMPTY 0xFFFFFFFFu
+#define AVK_OVF_DONE 0xFFFFFFFEu
 
 /* capacities of one workspace tier */
 struct AvkTier {
@@ -69,6 +71,17 @@ struct AvkKernelArgs {
     uint32_t pad_;
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;
+    /* in-launch overflow consumers (first LDS launch only): the first n_consumer_blocks workgroups run ONE wave
+     * each with the whole workgroup's LDS as its slice and solve overflowed regions while the launch is still
+     * running, so the large regions do not form a serial tail.  Entries of overflow_list are written once
+     * (0xFFFFFFFF = not yet), claimed through ovf_claimed, and marked AVK_OVF_DONE when a consumer solved
+     * them; whatever is not marked is picked up by the next launch. */
+    uint32_t n_consumer_blocks;
+    uint32_t consumer_pad_;
+    uint32_t *ovf_claimed;
+    uint32_t *producers_done;
+    uint32_t *overflow_list2; /* where a consumer puts a region that outgrows its slice too */
+    uint32_t *overflow_count2;
     /* workspaces */
     uint8_t *hbm_ws;           /* n_waves slices of tier[2] (or tier[3]) bytes */
     AvkTier tier[4];

@@ -33,14 +33,20 @@
 __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel_lds(AvkKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
     const unsigned wave_in_block = threadIdx.x >> 6;
-    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
+    if (blockIdx.x < a.n_consumer_blocks) {
+        /* overflow consumer: one wave owns the LDS of the whole workgroup */
+        if (wave_in_block != 0) return;
+        avk::region_worker<true>(a, blockIdx.x * 4u, avk_smem, true, 4ull * a.tier[0].ws_bytes);
+        return;
+    }
+    const unsigned wave_id = (blockIdx.x - a.n_consumer_blocks) * (blockDim.x >> 6) + wave_in_block;
+    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes, false, 0);
 }
 
 /* HBM passes: regions that outgrew the LDS tiers, in the wave's private HBM slice */
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    avk::region_worker<false>(a, wave_id, (unsigned char *)0);
+    avk::region_worker<false>(a, wave_id, (unsigned char *)0, false, 0);
 }
 
 /* packs the uploaded reference: 16 bases per word, 2 bits each, plus one flag per word for anything that is
@@ -114,6 +120,7 @@ struct avk_ctx {
     int64_t ws_bytes_per_wave = 1 << 20;
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 32;
+    int64_t consumer_blocks = 0; /* in-launch overflow consumers of the first LDS launch (experimental: measured slower, off by default) */
     int64_t emit_group_metrics = 1;
     int n_cus = 0;
     /* workspaces (grown on demand) */
@@ -145,6 +152,7 @@ struct avk_dev_batch {
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
+    uint32_t *d_order = nullptr; /* work order of the first launch: regions with many variants first */
     bool with_gm = true;
 };
 
@@ -181,7 +189,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 
 void free_batch_buffers(avk_dev_batch *db) {
     void *ptrs[] = {db->d_regions, db->d_variants, db->d_alleles, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3};
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -284,6 +292,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "big_waves") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "big_waves must be in [1, 4096]");
         ctx->big_waves = value;
+    } else if (n == "consumer_blocks") {
+        if (value < 0 || value > 512) return fail(ctx, AVK_E_ARG, "consumer_blocks must be in [0, 512]");
+        ctx->consumer_blocks = value;
     } else if (n == "use_packed_reference") {
         ctx->use_packed_reference = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {
@@ -413,12 +424,24 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_STRIDE));
     AVK_TRY(dev_alloc(ctx, &db->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES));
     AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)1088));
-    AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1024));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_order, n + 1));
 #undef AVK_TRY
+    /* longest-first order: the regions with the most variants (the expensive searches, and the ones that may outgrow
+     * the small LDS slice) are dealt first, so they overlap with the bulk instead of forming the tail */
+    std::vector<uint32_t> order(n);
+    {
+        std::vector<uint32_t> cnt(34, 0);
+        auto key = [&](uint64_t r) { const uint32_t k = db->host.regions[r].t_cnt + db->host.regions[r].q_cnt; return 32u - (k > 32u ? 32u : k); };
+        for (uint64_t r = 0; r < n; ++r) cnt[key(r) + 1] += 1;
+        for (int k = 1; k < 34; ++k) cnt[k] += cnt[k - 1];
+        for (uint64_t r = 0; r < n; ++r) order[cnt[key(r)]++] = (uint32_t)r;
+    }
     hipError_t e = hipSuccess;
-    if (n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
+    if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && nv) e = hipMemcpyAsync(db->d_variants, db->host.variants.data(), nv * sizeof(AvkDevVariant), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_alleles, db->host.alleles.data(), db->host.alleles.size(), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -486,6 +509,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
 
     AVK_HIP(ctx, hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), ctx->stream));
     AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 1088 * sizeof(uint32_t), ctx->stream));
+    AVK_HIP(ctx, hipMemsetAsync(db->d_overflow, 0xFF, (size_t)(n + 1024) * sizeof(uint32_t), ctx->stream));
     if (ctx->emit_group_metrics && !db->d_gm) {
         int rc = dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
         if (rc) return rc;
@@ -529,7 +553,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     for (int t = 0; t < 4; ++t)
         if (use[t]) last = t;
     if (last < 0) return fail(ctx, AVK_E_ARG, "every workspace tier is disabled");
-    const uint32_t *list = nullptr, *count = nullptr;
+    const uint32_t *list = db->d_order, *count = nullptr;
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
     int nlist = 0;
     for (int t = 0; t < 4 && n; ++t) {
@@ -545,9 +569,25 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.overflow_list = nullptr;
             a.overflow_count = nullptr;
         }
+        a.n_consumer_blocks = 0;
+        a.ovf_claimed = nullptr;
+        a.producers_done = nullptr;
+        a.overflow_list2 = nullptr;
+        a.overflow_count2 = nullptr;
         if (t == 0) {
             a.hbm_ws = nullptr;
-            a.n_waves = blocks * waves_per_block;
+            uint32_t cons = 0;
+            if (last >= 2 && use[1] && ctx->consumer_blocks > 0 && blocks > 8) { /* a later HBM launch reads what consumers pass on */
+                /* some workgroups of this launch become overflow consumers (one wave, whole-workgroup LDS, the large
+                 * LDS tier's edit-distance cap); what they cannot take goes to the list the HBM launch reads */
+                cons = (uint32_t)ctx->consumer_blocks < blocks / 8 ? (uint32_t)ctx->consumer_blocks : blocks / 8;
+                a.n_consumer_blocks = cons;
+                a.ovf_claimed = db->d_counters + 1072;
+                a.producers_done = db->d_counters + 1076;
+                a.overflow_list2 = lists[1];
+                a.overflow_count2 = db->d_counters + 1024 + 16 * 1;
+            }
+            a.n_waves = (blocks - cons) * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(blocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;

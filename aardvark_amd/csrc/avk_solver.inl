@@ -1648,15 +1648,18 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
 /* PASS_LDS: this launch solves regions in the wave's LDS slice; otherwise in its HBM slice
  * (a.pass_tier says which tier's capacities apply).  A region that does not fit is appended to the
  * overflow list for the next launch; after the last tier it fails with AVK_ST_CAPACITY. */
-template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice, bool consumer, u64 consumer_ws_bytes) {
     const u32 lane = (u32)wv_lane();
     u32 tally[5] = {0, 0, 0, 0, 0}; /* a wave's share of a batch keeps every counter far below 2^32 */
     u32 n_ok = 0, n_err = 0, n_cap = 0;
-    const u32 tier = a.pass_tier;
+    const u32 tier = consumer ? 1u : a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
-    const u64 ws_bytes = a.tier[tier].ws_bytes;
+    const u64 ws_bytes = consumer ? consumer_ws_bytes : a.tier[tier].ws_bytes;
     const u32 ed_cap = a.tier[tier].ed_cap;
-    const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_regions;
+    const u32 n_work = consumer ? 0u : (a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_regions);
+    u32 *const ovf_list = consumer ? a.overflow_list2 : a.overflow_list;
+    u32 *const ovf_count = consumer ? a.overflow_count2 : a.overflow_count;
+    u32 my_claim = 0;
 
     /* Work distribution.  Returning atomics on one cache line saturate near 88 claims/us on this chip
      * (MI355X_MICROARCH.md "dequeue"), far below what the solver needs, so claims are rationed:
@@ -1673,8 +1676,31 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     u32 static_next = wave_id;
     u32 shard_i = 0, claim_base = 0, claim_left = 0;
     for (;;) {
-        u32 idx;
-        if (static_next < n_static) {
+        u32 idx = 0;
+        u32 r_direct = 0xFFFFFFFFu;
+        if (consumer) {
+            /* claim one slot of the overflow queue, wait until its entry is written or every producer is done */
+            u32 got = AVK_OVF_EMPTY;
+            if (lane == 0) {
+                my_claim = avk_atomic_add_u32_global(a.ovf_claimed, 1);
+                if (my_claim < a.n_regions) {
+                    for (u32 spins = 0; spins < (1u << 20); ++spins) {
+                        got = avk_ld_agent_u32(a.overflow_list + my_claim);
+                        if (got != AVK_OVF_EMPTY) break;
+                        if (avk_ld_agent_u32(a.producers_done) >= a.n_waves) {
+                            avk_acquire_agent();
+                            got = avk_ld_agent_u32(a.overflow_list + my_claim);
+                            break;
+                        }
+                        avk_sleep();
+                    }
+                }
+            }
+            got = wv_uni(wv_shfl(got, 0));
+            my_claim = wv_uni(wv_shfl(my_claim, 0));
+            if (got >= 0xFFFFFFF0u) break;
+            r_direct = got;
+        } else if (static_next < n_static) {
             idx = static_next;
             static_next += a.n_waves;
         } else {
@@ -1705,7 +1731,8 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             claim_base += 1;
             claim_left -= 1;
         }
-        const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : idx;
+        const u32 r = consumer ? r_direct : (a.work_list ? wv_uni(a.work_list[idx]) : idx);
+        if (r >= 0xFFFFFFF0u) continue; /* entry already solved by an in-launch consumer */
         const AvkDevRegion reg = a.regions[r];
         const u32 pre = wv_uni(reg.pre_status);
         if (pre) {
@@ -1724,16 +1751,18 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         u32 winner = 0;
         int st = solve_region_tier(a, r, ws, ws_bytes, ed_cap, c, out, winner);
         if (st == RS_OVERFLOW) {
-            if (a.overflow_list) { /* hand over to the next tier's launch */
+            if (ovf_list) { /* hand over to the next tier (an in-launch consumer or the next launch) */
                 if (lane == 0) {
-                    const u32 slot = avk_atomic_add_u32_global(a.overflow_count, 1);
-                    a.overflow_list[slot] = r;
+                    const u32 slot = avk_atomic_add_u32_global(ovf_count, 1);
+                    avk_st_agent_u32(ovf_list + slot, r);
+                    if (consumer) avk_st_agent_u32(a.overflow_list + my_claim, AVK_OVF_DONE); /* it moved on to the next list */
                 }
                 continue;
             }
             st = AVK_ST_CAPACITY;
             n_cap += 1;
         }
+        if (consumer && st != RS_OVERFLOW && lane == 0) avk_st_agent_u32(a.overflow_list + my_claim, AVK_OVF_DONE);
         if (st != AVK_ST_OK) {
             write_failed_region(a, r, st);
             n_err += 1;
@@ -1770,6 +1799,11 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             avk_atomic_add_u64_global(pc + 7, 1);
         }
 #endif
+    }
+
+    if (!consumer && a.producers_done && lane == 0) { /* every overflow entry of this wave is visible before the count moves */
+        avk_release_agent();
+        avk_atomic_add_u32_global(a.producers_done, 1);
     }
 
     /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into

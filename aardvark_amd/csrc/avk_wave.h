@@ -84,6 +84,11 @@ AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; 
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV uint64_t avk_clock() { return 0; }
+AVK_DEV uint32_t avk_ld_agent_u32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+AVK_DEV void avk_st_agent_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+AVK_DEV void avk_release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
+AVK_DEV void avk_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
+AVK_DEV void avk_sleep() {}
 AVK_DEV int avk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 
@@ -149,6 +154,16 @@ AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 AVK_DEV uint64_t avk_clock() { return __builtin_amdgcn_s_memtime(); }
+/* device-scope (all XCDs) accesses for words that other workgroups poll: write-through / L1-bypassing forms
+ * (cdna_hip_programming.md §6 G16: granule = one aligned word that is its own flag) */
+AVK_DEV uint32_t avk_ld_agent_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+AVK_DEV void avk_st_agent_u32(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+AVK_DEV void avk_release_agent() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+AVK_DEV void avk_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
+AVK_DEV void avk_sleep() { __builtin_amdgcn_s_sleep(32); }
 AVK_DEV int avk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 AVK_DEV int avk_popc64(uint64_t x) { return __popcll(x); }
 #endif

@@ -157,8 +157,8 @@ struct WaveTask {
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
-    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds);
-    else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
+    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds, false, 0);
+    else avk::region_worker<false>(*t->args, t->wave_id, nullptr, false, 0);
 }
 
 } // namespace
