@@ -58,6 +58,7 @@ def load_library():
     lib.avk_seq_stride.restype = C.c_uint32
     lib.avk_seq_stride.argtypes = [C.POINTER(AvkRegionBatch), C.c_uint64]
     lib.avk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.avk_last_solver_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_tier_counts.argtypes = [vp, u64p]
     lib.avk_debug_phase_cycles.argtypes = [vp, u64p]
     lib.avk_algorithmic_bytes.restype = C.c_uint64
@@ -171,6 +172,11 @@ class Context:
     def last_kernel_ms(self):
         ms = C.c_float(0)
         self._check(self.lib.avk_last_kernel_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def last_solver_ms(self):
+        ms = C.c_float(0)
+        self._check(self.lib.avk_last_solver_ms(self.handle, C.byref(ms)))
         return float(ms.value)
 
     def last_tier_counts(self):

@@ -35,8 +35,6 @@ struct AvkDevVariant {
 };
 
 #define AVK_PRE_SKIP_OK 0x1000u
-#define AVK_OVF_EMPTY 0xFFFFFFFFu
-#define AVK_OVF_DONE 0xFFFFFFFEu
 
 /* capacities of one workspace tier */
 struct AvkTier {
@@ -67,21 +65,14 @@ struct AvkKernelArgs {
     const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */
     const uint32_t *n_work_dev; /* when set, the number of work items is read from device memory (overflow pass) */
     uint32_t *work_counter;    /* 8 claim counters, 32 words (128 B) apart, one per shard of the dynamic part of the work list */
-    uint32_t n_waves;          /* persistent waves of this launch */
-    uint32_t pad_;
+    uint32_t n_waves;          /* persistent waves of this launch (solo waves not counted) */
+    uint32_t n_work;           /* length of the work list when n_work_dev is NULL */
+    uint32_t static_pct;       /* share of the work list dealt statically (item k to wave k mod n_waves), the rest is claimed */
+    uint32_t n_shards;         /* claim counters in use (1..8) */
+    uint32_t claim;            /* regions per claim */
+    uint32_t high_priority;    /* raise the wave priority (the solo launch of the predicted-hard regions) */
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;
-    /* in-launch overflow consumers (first LDS launch only): the first n_consumer_blocks workgroups run ONE wave
-     * each with the whole workgroup's LDS as its slice and solve overflowed regions while the launch is still
-     * running, so the large regions do not form a serial tail.  Entries of overflow_list are written once
-     * (0xFFFFFFFF = not yet), claimed through ovf_claimed, and marked AVK_OVF_DONE when a consumer solved
-     * them; whatever is not marked is picked up by the next launch. */
-    uint32_t n_consumer_blocks;
-    uint32_t consumer_pad_;
-    uint32_t *ovf_claimed;
-    uint32_t *producers_done;
-    uint32_t *overflow_list2; /* where a consumer puts a region that outgrows its slice too */
-    uint32_t *overflow_count2;
     /* workspaces */
     uint8_t *hbm_ws;           /* n_waves slices of tier[2] (or tier[3]) bytes */
     AvkTier tier[4];

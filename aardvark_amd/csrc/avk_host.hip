@@ -33,20 +33,15 @@
 __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel_lds(AvkKernelArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
     const unsigned wave_in_block = threadIdx.x >> 6;
-    if (blockIdx.x < a.n_consumer_blocks) {
-        /* overflow consumer: one wave owns the LDS of the whole workgroup */
-        if (wave_in_block != 0) return;
-        avk::region_worker<true>(a, blockIdx.x * 4u, avk_smem, true, 4ull * a.tier[0].ws_bytes);
-        return;
-    }
-    const unsigned wave_id = (blockIdx.x - a.n_consumer_blocks) * (blockDim.x >> 6) + wave_in_block;
-    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes, false, 0);
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    if (a.high_priority) __builtin_amdgcn_s_setprio(3); /* solo launch: the long searches are the critical path */
+    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
 }
 
 /* HBM passes: regions that outgrew the LDS tiers, in the wave's private HBM slice */
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    avk::region_worker<false>(a, wave_id, (unsigned char *)0, false, 0);
+    avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
 /* packs the uploaded reference: 16 bases per word, 2 bits each, plus one flag per word for anything that is
@@ -112,15 +107,17 @@ struct avk_ctx {
     int64_t use_packed_reference = 1;
     std::vector<uint64_t> contig_base, contig_len;
     /* options */
-    int64_t lds_bytes_per_wave = 9 * 1024;
+    int64_t lds_bytes_per_wave = 10 * 1024;
     int64_t lds_ed_cap = 8;
     int64_t lds2_bytes_per_wave = 40 * 1024;
     int64_t lds2_ed_cap = 48;
     int64_t waves_per_cu = 16;
+    int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
+    int64_t solo_blocks_max = 128;
+    int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
     int64_t ws_bytes_per_wave = 1 << 20;
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 32;
-    int64_t consumer_blocks = 0; /* in-launch overflow consumers of the first LDS launch (experimental: measured slower, off by default) */
     int64_t emit_group_metrics = 1;
     int n_cus = 0;
     /* workspaces (grown on demand) */
@@ -129,7 +126,9 @@ struct avk_ctx {
     uint8_t *d_big = nullptr;
     size_t big_alloc = 0;
     /* measurement */
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk1 = nullptr; /* ev0..ev1 all solver launches, ev0..evk1 the first (dominant) one */
+    hipStream_t side_stream = nullptr; /* solo launch */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
     uint64_t last_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -150,9 +149,10 @@ struct avk_dev_batch {
     uint32_t *d_seqlen = nullptr;
     uint64_t *d_tally = nullptr;    /* [AVK_TALLY_STRIDE]: AVK_TALLY_LEN sums, 5 tier counters, 8 profiling words */
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
-    uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts */
+    uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
-    uint32_t *d_order = nullptr; /* work order of the first launch: regions with many variants first */
+    uint32_t *d_order = nullptr; /* work order of the first launch: [predicted-hard regions | the rest], most variants first */
+    uint32_t n_hard = 0;
     bool with_gm = true;
 };
 
@@ -234,6 +234,13 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     ctx->own_stream = true;
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
+    (void)hipEventCreate(&ctx->evk1);
+    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        avk_ctx_destroy(ctx);
+        return AVK_E_HIP;
+    }
     *out = ctx;
     return 0;
 }
@@ -249,6 +256,10 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->d_big) (void)hipFree(ctx->d_big);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -280,6 +291,14 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lds_ed_cap") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "lds_ed_cap must be in [1, 4096]");
         ctx->lds_ed_cap = value;
+    } else if (n == "solo_min_variants") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "solo_min_variants must not be negative");
+        ctx->solo_min_variants = value;
+    } else if (n == "bulk_full_grid") {
+        ctx->bulk_full_grid = value ? 1 : 0;
+    } else if (n == "solo_blocks_max") {
+        if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
+        ctx->solo_blocks_max = value;
     } else if (n == "waves_per_cu") {
         if (value < 1 || value > 32) return fail(ctx, AVK_E_ARG, "waves_per_cu must be in [1, 32]");
         ctx->waves_per_cu = value;
@@ -292,9 +311,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "big_waves") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "big_waves must be in [1, 4096]");
         ctx->big_waves = value;
-    } else if (n == "consumer_blocks") {
-        if (value < 0 || value > 512) return fail(ctx, AVK_E_ARG, "consumer_blocks must be in [0, 512]");
-        ctx->consumer_blocks = value;
     } else if (n == "use_packed_reference") {
         ctx->use_packed_reference = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {
@@ -429,16 +445,12 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_order, n + 1));
 #undef AVK_TRY
-    /* longest-first order: the regions with the most variants (the expensive searches, and the ones that may outgrow
-     * the small LDS slice) are dealt first, so they overlap with the bulk instead of forming the tail */
-    std::vector<uint32_t> order(n);
-    {
-        std::vector<uint32_t> cnt(34, 0);
-        auto key = [&](uint64_t r) { const uint32_t k = db->host.regions[r].t_cnt + db->host.regions[r].q_cnt; return 32u - (k > 32u ? 32u : k); };
-        for (uint64_t r = 0; r < n; ++r) cnt[key(r) + 1] += 1;
-        for (int k = 1; k < 34; ++k) cnt[k] += cnt[k - 1];
-        for (uint64_t r = 0; r < n; ++r) order[cnt[key(r)]++] = (uint32_t)r;
-    }
+    /* work order: the regions predicted to outgrow the small LDS slice first (solo waves take them), then the
+     * rest; within each part the regions with the most variants (the expensive searches) are dealt first, so
+     * they overlap with the bulk instead of forming the tail */
+    std::vector<uint32_t> order;
+    db->n_hard = avk::plan_work_order(db->host, (uint64_t)ctx->lds_bytes_per_wave, (uint32_t)ctx->lds_ed_cap,
+                                      pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order);
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
@@ -509,7 +521,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
 
     AVK_HIP(ctx, hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), ctx->stream));
     AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 1088 * sizeof(uint32_t), ctx->stream));
-    AVK_HIP(ctx, hipMemsetAsync(db->d_overflow, 0xFF, (size_t)(n + 1024) * sizeof(uint32_t), ctx->stream));
     if (ctx->emit_group_metrics && !db->d_gm) {
         int rc = dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
         if (rc) return rc;
@@ -556,6 +567,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = db->d_order, *count = nullptr;
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
     int nlist = 0;
+    bool solo_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
         if (!use[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -569,26 +581,51 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.overflow_list = nullptr;
             a.overflow_count = nullptr;
         }
-        a.n_consumer_blocks = 0;
-        a.ovf_claimed = nullptr;
-        a.producers_done = nullptr;
-        a.overflow_list2 = nullptr;
-        a.overflow_count2 = nullptr;
+        const bool first_launch = list == db->d_order; /* ev0 sits right before it */
+        a.n_work = (uint32_t)n;
+        a.high_priority = 0;
+        a.static_pct = AVK_STATIC_PCT;
+        a.n_shards = 8;
+        a.claim = AVK_CLAIM;
         if (t == 0) {
             a.hbm_ws = nullptr;
-            uint32_t cons = 0;
-            if (last >= 2 && use[1] && ctx->consumer_blocks > 0 && blocks > 8) { /* a later HBM launch reads what consumers pass on */
-                /* some workgroups of this launch become overflow consumers (one wave, whole-workgroup LDS, the large
-                 * LDS tier's edit-distance cap); what they cannot take goes to the list the HBM launch reads */
-                cons = (uint32_t)ctx->consumer_blocks < blocks / 8 ? (uint32_t)ctx->consumer_blocks : blocks / 8;
-                a.n_consumer_blocks = cons;
-                a.ovf_claimed = db->d_counters + 1072;
-                a.producers_done = db->d_counters + 1076;
-                a.overflow_list2 = lists[1];
-                a.overflow_count2 = db->d_counters + 1024 + 16 * 1;
+            /* Solo launch: the regions the host predicted to outgrow the small slice are solved AT THE SAME TIME by
+             * one-wave workgroups with a tier-1 slice each, launched on the side stream just before the bulk.  A solo
+             * workgroup's LDS displaces exactly one bulk workgroup, so the long searches overlap with the bulk instead
+             * of forming the tail of a second launch. */
+            uint32_t solo = 0;
+            if (use[1] && db->n_hard && ctx->solo_blocks_max && blocks >= 8 &&
+                (size_t)ctx->lds2_bytes_per_wave <= 2 * (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave) {
+                solo = db->n_hard < (uint32_t)ctx->solo_blocks_max ? db->n_hard : (uint32_t)ctx->solo_blocks_max;
+                if (solo > blocks / 4) solo = blocks / 4;
             }
-            a.n_waves = (blocks - cons) * waves_per_block;
-            hipLaunchKernelGGL(avk_region_kernel_lds, dim3(blocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
+            if (solo) {
+                AvkKernelArgs s = a;
+                s.pass_tier = 1;
+                s.work_list = db->d_order;
+                s.n_work = db->n_hard;
+                s.work_counter = db->d_counters + 1072;
+                s.static_pct = 0;
+                s.n_shards = 1;
+                s.claim = 1;
+                s.n_waves = solo;
+                s.high_priority = 1;
+                const bool t1_last = last == 1; /* what outgrows tier 1 joins the list the tier-1 launch appends to */
+                s.overflow_list = t1_last ? nullptr : lists[1];
+                s.overflow_count = t1_last ? nullptr : db->d_counters + 1024 + 16 * 1;
+                AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
+                AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
+                hipLaunchKernelGGL(avk_region_kernel_lds, dim3(solo), dim3(64), (size_t)ctx->lds2_bytes_per_wave, ctx->side_stream, s);
+                AVK_HIP(ctx, hipGetLastError());
+                AVK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
+                solo_pending = true;
+                a.work_list = db->d_order + db->n_hard;
+                a.n_work = (uint32_t)n - db->n_hard;
+            }
+            /* the bulk grid keeps its full size: the last `solo` workgroups find no room until solo workgroups retire;
+             * they take no static share (n_waves counts the others) and help with the dynamically claimed tail */
+            a.n_waves = (blocks - solo) * waves_per_block;
+            hipLaunchKernelGGL(avk_region_kernel_lds, dim3(ctx->bulk_full_grid ? blocks : blocks - solo), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;
             uint32_t b2 = (uint32_t)ctx->n_cus < blocks ? (uint32_t)ctx->n_cus : blocks;
@@ -604,6 +641,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
         }
         AVK_HIP(ctx, hipGetLastError());
+        if (first_launch) AVK_HIP(ctx, hipEventRecord(ctx->evk1, ctx->stream));
+        if (solo_pending) { /* everything later on the main stream also follows the solo launch */
+            AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            solo_pending = false;
+        }
         if (t != last) {
             list = lists[nlist];
             count = db->d_counters + 1024 + 16 * nlist;
@@ -630,6 +672,14 @@ int avk_synchronize(avk_ctx *ctx) {
 }
 
 int avk_last_kernel_ms(avk_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return AVK_E_ARG;
+    if (!ctx->ev_valid) return fail(ctx, AVK_E_STATE, "no launch has been timed yet");
+    AVK_HIP(ctx, hipEventSynchronize(ctx->evk1));
+    AVK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->evk1));
+    return 0;
+}
+
+int avk_last_solver_ms(avk_ctx *ctx, float *ms) {
     if (!ctx || !ms) return AVK_E_ARG;
     if (!ctx->ev_valid) return fail(ctx, AVK_E_STATE, "no launch has been timed yet");
     AVK_HIP(ctx, hipEventSynchronize(ctx->ev1));

@@ -1648,78 +1648,54 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
 /* PASS_LDS: this launch solves regions in the wave's LDS slice; otherwise in its HBM slice
  * (a.pass_tier says which tier's capacities apply).  A region that does not fit is appended to the
  * overflow list for the next launch; after the last tier it fails with AVK_ST_CAPACITY. */
-template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice, bool consumer, u64 consumer_ws_bytes) {
+template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     const u32 lane = (u32)wv_lane();
     u32 tally[5] = {0, 0, 0, 0, 0}; /* a wave's share of a batch keeps every counter far below 2^32 */
     u32 n_ok = 0, n_err = 0, n_cap = 0;
-    const u32 tier = consumer ? 1u : a.pass_tier;
+    const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
-    const u64 ws_bytes = consumer ? consumer_ws_bytes : a.tier[tier].ws_bytes;
+    const u64 ws_bytes = a.tier[tier].ws_bytes;
     const u32 ed_cap = a.tier[tier].ed_cap;
-    const u32 n_work = consumer ? 0u : (a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_regions);
-    u32 *const ovf_list = consumer ? a.overflow_list2 : a.overflow_list;
-    u32 *const ovf_count = consumer ? a.overflow_count2 : a.overflow_count;
-    u32 my_claim = 0;
+    const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_work;
 
     /* Work distribution.  Returning atomics on one cache line saturate near 88 claims/us on this chip
      * (MI355X_MICROARCH.md "dequeue"), far below what the solver needs, so claims are rationed:
-     *   - the first AVK_STATIC_PCT % of the work list is dealt statically, item k to wave k mod n_waves
+     *   - the first static_pct % (AVK_STATIC_PCT) of the work list is dealt statically, item k to wave k mod n_waves
      *     (no atomics, neighbouring waves read neighbouring records);
      *   - the rest is claimed dynamically in chunks of AVK_CLAIM from 8 shard counters that sit in
      *     separate 128-byte lines; a wave starts on the shard of its workgroup's XCD and peeks at a
      *     counter with a plain load before spending an atomic on it, so drained shards cost nothing.
      * The dynamic tail evens out waves that drew expensive regions. */
-    const u32 n_static = a.n_waves ? (u32)(((u64)n_work * AVK_STATIC_PCT / 100) / a.n_waves) * a.n_waves : 0;
+    const u32 n_static = a.n_waves ? (u32)(((u64)n_work * a.static_pct / 100) / a.n_waves) * a.n_waves : 0;
     const u32 n_dyn = n_work - n_static;
-    const u32 shard_len = (n_dyn + 7u) >> 3;
-    const u32 home = (wave_id >> 2) & 7u;
-    u32 static_next = wave_id;
+    const u32 n_shards = a.n_shards;
+    const u32 shard_len = (n_dyn + n_shards - 1) / n_shards;
+    const u32 home = (wave_id >> 2) % n_shards;
+    u32 static_next = wave_id < a.n_waves ? wave_id : 0xFFFFFFFFu; /* waves beyond n_waves (placed late) only claim */
     u32 shard_i = 0, claim_base = 0, claim_left = 0;
     for (;;) {
         u32 idx = 0;
-        u32 r_direct = 0xFFFFFFFFu;
-        if (consumer) {
-            /* claim one slot of the overflow queue, wait until its entry is written or every producer is done */
-            u32 got = AVK_OVF_EMPTY;
-            if (lane == 0) {
-                my_claim = avk_atomic_add_u32_global(a.ovf_claimed, 1);
-                if (my_claim < a.n_regions) {
-                    for (u32 spins = 0; spins < (1u << 20); ++spins) {
-                        got = avk_ld_agent_u32(a.overflow_list + my_claim);
-                        if (got != AVK_OVF_EMPTY) break;
-                        if (avk_ld_agent_u32(a.producers_done) >= a.n_waves) {
-                            avk_acquire_agent();
-                            got = avk_ld_agent_u32(a.overflow_list + my_claim);
-                            break;
-                        }
-                        avk_sleep();
-                    }
-                }
-            }
-            got = wv_uni(wv_shfl(got, 0));
-            my_claim = wv_uni(wv_shfl(my_claim, 0));
-            if (got >= 0xFFFFFFF0u) break;
-            r_direct = got;
-        } else if (static_next < n_static) {
+        if (static_next < n_static) {
             idx = static_next;
             static_next += a.n_waves;
         } else {
             if (claim_left == 0) {
                 bool got = false;
-                while (!got && shard_i < 8) {
-                    const u32 sh = (home + shard_i) & 7u;
+                while (!got && shard_i < n_shards) {
+                    u32 sh = home + shard_i;
+                    if (sh >= n_shards) sh -= n_shards;
                     const u32 lo = sh * shard_len < n_dyn ? sh * shard_len : n_dyn;
                     const u32 hi = lo + shard_len < n_dyn ? lo + shard_len : n_dyn;
                     u32 *ctr = a.work_counter + 32u * sh;
                     u32 b = 0xFFFFFFFFu;
                     if (lane == 0) {
                         const u32 seen = *(volatile u32 *)ctr;
-                        if (lo + seen < hi) b = avk_atomic_add_u32_global(ctr, AVK_CLAIM);
+                        if (lo + seen < hi) b = avk_atomic_add_u32_global(ctr, a.claim);
                     }
                     b = wv_uni(wv_shfl(b, 0));
                     if (b != 0xFFFFFFFFu && lo + b < hi) {
                         claim_base = n_static + lo + b;
-                        claim_left = hi - (lo + b) < AVK_CLAIM ? hi - (lo + b) : AVK_CLAIM;
+                        claim_left = hi - (lo + b) < a.claim ? hi - (lo + b) : a.claim;
                         got = true;
                     } else {
                         shard_i += 1;
@@ -1731,8 +1707,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             claim_base += 1;
             claim_left -= 1;
         }
-        const u32 r = consumer ? r_direct : (a.work_list ? wv_uni(a.work_list[idx]) : idx);
-        if (r >= 0xFFFFFFF0u) continue; /* entry already solved by an in-launch consumer */
+        const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : idx;
         const AvkDevRegion reg = a.regions[r];
         const u32 pre = wv_uni(reg.pre_status);
         if (pre) {
@@ -1751,18 +1726,16 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         u32 winner = 0;
         int st = solve_region_tier(a, r, ws, ws_bytes, ed_cap, c, out, winner);
         if (st == RS_OVERFLOW) {
-            if (ovf_list) { /* hand over to the next tier (an in-launch consumer or the next launch) */
+            if (a.overflow_list) { /* hand over to the next tier's launch */
                 if (lane == 0) {
-                    const u32 slot = avk_atomic_add_u32_global(ovf_count, 1);
-                    avk_st_agent_u32(ovf_list + slot, r);
-                    if (consumer) avk_st_agent_u32(a.overflow_list + my_claim, AVK_OVF_DONE); /* it moved on to the next list */
+                    const u32 slot = avk_atomic_add_u32_global(a.overflow_count, 1);
+                    a.overflow_list[slot] = r;
                 }
                 continue;
             }
             st = AVK_ST_CAPACITY;
             n_cap += 1;
         }
-        if (consumer && st != RS_OVERFLOW && lane == 0) avk_st_agent_u32(a.overflow_list + my_claim, AVK_OVF_DONE);
         if (st != AVK_ST_OK) {
             write_failed_region(a, r, st);
             n_err += 1;
@@ -1799,11 +1772,6 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             avk_atomic_add_u64_global(pc + 7, 1);
         }
 #endif
-    }
-
-    if (!consumer && a.producers_done && lane == 0) { /* every overflow entry of this wave is visible before the count moves */
-        avk_release_agent();
-        avk_atomic_add_u32_global(a.producers_done, 1);
     }
 
     /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into

@@ -203,7 +203,8 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
 /* measurement hooks: milliseconds of the solver kernels of the last avk_compare_resident /
  * avk_compare_batch on this context, from hipEvents on the context stream; how many regions
  * each workspace tier solved; algorithmic bytes of the batch (DESIGN.md "bytes per region") */
-int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);
+int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);  /* the dominant launch: first pass of avk_region_kernel_lds */
+int  avk_last_solver_ms(avk_ctx *ctx, float *ms);  /* all solver launches of the call (tier passes + tally reduce) */
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
 /* profiling builds of the library only: summed clock ticks per solver phase (stage, search A, search B,

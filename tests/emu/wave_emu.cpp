@@ -157,8 +157,8 @@ struct WaveTask {
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
-    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds, false, 0);
-    else avk::region_worker<false>(*t->args, t->wave_id, nullptr, false, 0);
+    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds);
+    else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
 }
 
 } // namespace
@@ -171,7 +171,8 @@ extern "C" {
  * tier_counts[5] receives how many regions each tier finished, then the capacity failures. */
 static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
-                      uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
+                      uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts,
+                      uint32_t solo_min_variants) {
     std::vector<uint64_t> base(n_contigs), lens(n_contigs);
     uint64_t total = 0;
     for (uint32_t c = 0; c < n_contigs; ++c) {
@@ -253,7 +254,9 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             if (!pb.regions[r].pre_status) pb.regions[r].pre_status = AVK_ST_BRANCH_FACTOR;
     }
 
-    auto run_pass = [&](uint32_t waves, uint64_t slice_bytes, uint64_t lds) {
+    /* solo_waves extra waves run before the others with the tier-1 slice size (the first solo_blocks workgroups of the launch) */
+    AvkKernelArgs a_solo;
+    auto run_pass = [&](uint32_t waves, uint64_t slice_bytes, uint64_t lds, uint32_t solo_waves = 0) {
         if (threads < 1) threads = 1;
         a.n_waves = waves;
         std::vector<uint8_t> hbm(slice_bytes ? (size_t)waves * slice_bytes : 0);
@@ -264,11 +267,12 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             w.stack_bytes = 256 * 1024;
             std::vector<char> stacks(64 * w.stack_bytes + 64);
             w.stacks = stacks.data();
-            std::vector<uint8_t> ldsbuf(lds ? lds : 8);
+            std::vector<uint8_t> ldsbuf(lds ? (solo_waves && lds2_bytes > lds ? lds2_bytes : lds) : 8);
             for (;;) {
                 uint32_t wid = next.fetch_add(1);
-                if (wid >= waves) break;
-                WaveTask t{&a, wid, lds ? ldsbuf.data() : nullptr};
+                if (wid >= waves + solo_waves) break;
+                const bool solo = wid < solo_waves;
+                WaveTask t{solo ? &a_solo : &a, solo ? wid : wid - solo_waves, lds ? ldsbuf.data() : nullptr};
                 avk_emu::run_wave(&w, lane_main, &t);
             }
         };
@@ -283,13 +287,21 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     for (int t = 0; t < 4; ++t)
         if (use[t]) last = t;
     if (last < 0) return AVK_E_ARG;
-    const uint32_t *list = nullptr, *count = nullptr;
+    /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
+    std::vector<uint32_t> order;
+    const uint32_t n_hard = avk::plan_work_order(pb, lds_bytes, lds_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
+    const uint32_t *list = order.data(), *count = nullptr;
     int nlist = 0;
     for (int t = 0; t < 4 && n; ++t) {
         if (!use[t]) continue;
         a.pass_tier = (uint32_t)t;
         a.work_list = list;
         a.n_work_dev = count;
+        a.n_work = (uint32_t)n;
+        a.high_priority = 0;
+        a.static_pct = AVK_STATIC_PCT;
+        a.n_shards = 8;
+        a.claim = AVK_CLAIM;
         a.work_counter = counters + 256 * t;
         if (t != last) {
             a.overflow_list = lists[nlist].data();
@@ -300,7 +312,28 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         }
         const uint32_t todo = count ? *count : (uint32_t)n;
         if (todo) {
-            if (t == 0) run_pass(n_waves ? n_waves : 1, 0, lds_bytes);
+            if (t == 0) {
+                uint32_t solo = 0;
+                if (use[1] && n_hard && lds2_bytes >= lds_bytes) {
+                    solo = n_waves / 4 ? n_waves / 4 : 1;
+                    if (solo > n_hard) solo = n_hard;
+                    a_solo = a;
+                    a_solo.pass_tier = 1;
+                    a_solo.work_list = order.data();
+                    a_solo.n_work = n_hard;
+                    a_solo.work_counter = counters + 1072;
+                    a_solo.static_pct = 0;
+                    a_solo.n_shards = 1;
+                    a_solo.claim = 1;
+                    a_solo.n_waves = solo;
+                    a_solo.high_priority = 1;
+                    a_solo.overflow_list = last == 1 ? nullptr : lists[1].data();
+                    a_solo.overflow_count = last == 1 ? nullptr : counters + 1024 + 16;
+                    a.work_list = order.data() + n_hard;
+                    a.n_work = (uint32_t)n - n_hard;
+                }
+                run_pass(n_waves ? n_waves : 1, 0, lds_bytes, solo);
+            }
             else if (t == 1) run_pass(n_waves ? n_waves : 1, 0, lds2_bytes);
             else if (t == 2) run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
             else run_pass(todo < 4 ? todo : 4, big_ws_bytes, 0);
@@ -339,9 +372,10 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
 
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
-                      uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts) {
+                      uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts,
+                      uint32_t solo_min_variants) {
     return emu_run(0, batch, refs, ref_lens, n_contigs, cfg, out, lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, ws_bytes, big_ws_bytes, n_waves,
-                   threads, tier_counts);
+                   threads, tier_counts, solo_min_variants);
 }
 
 /* avk_optimize_pairs_batch on emulated wavefronts (default tier sizes) */
@@ -356,7 +390,7 @@ int emu_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const
     memset(&out, 0, sizeof(out));
     out.status = status;
     out.ed_h1 = ed1.data();
-    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 9 * 1024, 8, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr);
+    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 9 * 1024, 8, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0);
     if (rc) return rc;
     for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && ed1[r] ? 1 : 0;
     return 0;

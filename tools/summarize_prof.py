@@ -22,9 +22,10 @@ lines.append("# per kernel (all dispatches): name, calls, total_us, avg_us, pct"
 for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
     lines.append("%-60s calls=%-6d total_us=%-12.1f avg_us=%-10.3f pct=%.2f" % (r[0][:60], r[1], r[2], r[3], r[4]))
 lines.append("")
-lines.append("# solver kernel dispatches grouped by launch geometry (pass 1 = full grid, pass 2 = overflow pass, normally empty)")
+lines.append("# solver kernel dispatches grouped by launch geometry: avk_region_kernel_lds full grid = dominant first pass (small LDS slices),")
+lines.append("# avk_region_kernel_lds with 160 KB LDS = overflow pass with large slices, avk_region_kernel_hbm = HBM tiers (normally empty)")
 q = ("select name, grid_x, workgroup_x, lds_size, vgpr_count, accum_vgpr_count, sgpr_count, count(*), avg(duration), min(duration), max(duration) "
-     "from kernels where name like 'avk_%' group by name, grid_x, lds_size order by avg(duration) desc")
+     "from kernels where name like 'avk_region%' group by name, grid_x, lds_size order by avg(duration) desc")
 main_avg_ns = None
 for r in cur.execute(q):
     lines.append("%s grid=%d wg=%d lds=%d vgpr=%d agpr=%d sgpr=%d calls=%d avg_us=%.3f min_us=%.3f max_us=%.3f" %
@@ -37,13 +38,13 @@ print("\n".join(lines))
 
 # PMC passes: average per main-pass dispatch of the solver kernel
 pm = ["# rocprofv3 --kernel-trace --pmc <set> -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity (one run per set)",
-      "# averages over the main-pass dispatches of the solver kernel (the largest grid)"]
+      "# averages over the dispatches of the dominant kernel: avk_region_kernel_lds, first pass (the largest grid)"]
 vals = {}
 for d in sorted(glob.glob(os.path.join(src, "pmc*", tag + "_results.db"))):
     c = sqlite3.connect(d).cursor()
     try:
-        g = c.execute("select max(grid_size) from counters_collection where kernel_name like 'avk_%'").fetchone()[0]
-        for name, avg, n in c.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like 'avk_%' and grid_size=? group by counter_name", (g,)):
+        g = c.execute("select max(grid_size) from counters_collection where kernel_name like 'avk_region_kernel_lds%'").fetchone()[0]
+        for name, avg, n in c.execute("select counter_name, avg(value), count(*) from counters_collection where kernel_name like 'avk_region_kernel_lds%' and grid_size=? group by counter_name", (g,)):
             vals[name] = avg
             pm.append("%-24s avg_per_launch=%-20.3f launches=%d" % (name, avg, n))
     except Exception as e:
