@@ -8,29 +8,53 @@
 #include <stdint.h>
 #include "../../include/aardvark_amd.h"
 
-/* One region (CompareRegion, reference src/data_types/compare_region.rs:13-26).  Variants of
- * the region are contiguous in the variant array: t_cnt truth records, then q_cnt query records. */
+/* One region (CompareRegion, reference src/data_types/compare_region.rs:13-26): one 64-byte record.
+ * Everything the solver needs about the region's variants is prepared by the host packer as ONE contiguous
+ * blob that the wave copies into its workspace as it is (see AvkBlobVar and pack_batch in avk_pack.h). */
 struct AvkDevRegion {
     uint64_t ref_off;    /* offset of the window start in the concatenated reference bytes */
     uint32_t len;        /* window length L = end - start */
-    uint32_t v_off;      /* first variant record */
+    uint32_t v_off;      /* first per-variant output word; the region owns t_cnt + q_cnt of them, truth first */
     uint32_t t_cnt;
     uint32_t q_cnt;
     uint32_t pre_status; /* host validation: 0, AVK_ST_INVALID_INPUT / AVK_ST_BAD_ZYGOSITY, or AVK_PRE_SKIP_OK (pairs mode:
                             answered on the host, report status 0 / not exact) */
     uint32_t seq_stride; /* bytes per output sequence slot (0 = no sequence output) */
     uint64_t seq_off;    /* offset of the region's 5 slots in the sequence output */
+    uint32_t blob_off;   /* the region's blob starts at 8 * blob_off bytes of the blob arena */
+    uint32_t blob_bytes; /* multiple of 8 */
+    uint32_t alle_bytes; /* bytes of the allele section of the blob (before padding) */
+    uint32_t grow;       /* max over the two sides of sum(max(0, a1_len - a0_len)): bound of a haplotype's growth */
+    uint32_t types;      /* bit t set: a variant of type t (AVK_VT_*) is present */
+    uint32_t pad;
 };
 
-/* One variant (reference src/data_types/variants.rs:73-91), window-relative */
-struct AvkDevVariant {
+/* One variant inside a region blob (reference src/data_types/variants.rs:73-91), window-relative.
+ * Blob layout (every section padded to 8 bytes):
+ *   AvkBlobVar[N]   truth records then query records
+ *   allele bytes    allele0 then allele1 of every variant, at a_off
+ *   u32 order[N]    order_variants (query_optimizer.rs:372-381): stable sort by position of [truth.., query..]
+ *   u32 counts[8]   for the 8 types add_basepair_stats filters by (waffle_solver.rs:383-440), in the order of
+ *                   AVK_SUP_TYPES: truth count | query count << 16 */
+struct AvkBlobVar {
     uint32_t rel_pos;   /* position - window start */
     uint32_t a0_len;    /* ref_len() */
     uint32_t a1_len;
-    uint32_t a_off;     /* allele0 bytes at a_off, allele1 bytes at a_off + a0_len of the allele arena */
+    uint32_t a_off;     /* allele0 bytes at a_off of the blob's allele section, allele1 at a_off + a0_len */
     uint32_t raw_space; /* raw_allele_space */
-    uint8_t type;       /* AVK_VT_* */
-    uint8_t zyg;        /* AVK_ZYG_* */
+    uint32_t alt_ed;    /* Variant::alt_ed = wfa_ed(allele0, allele1) (variants.rs:413-415) */
+    uint32_t type_zyg;  /* AVK_VT_* | AVK_ZYG_* << 8 */
+};
+
+/* host-side view of a variant (planning, scatter maps); not uploaded */
+struct AvkDevVariant {
+    uint32_t rel_pos;
+    uint32_t a0_len;
+    uint32_t a1_len;
+    uint32_t a_off;     /* into PackedBatch::alleles */
+    uint32_t raw_space;
+    uint8_t type;
+    uint8_t zyg;
     uint16_t pad;
 };
 
@@ -50,8 +74,7 @@ struct AvkTier {
 struct AvkKernelArgs {
     /* inputs */
     const AvkDevRegion *regions;
-    const AvkDevVariant *variants;
-    const uint8_t *alleles;
+    const uint32_t *blob;      /* region blobs, see AvkBlobVar */
     const uint8_t *ref_bytes;  /* concatenated contigs, one byte per base (used for windows that hold non-ACGT symbols) */
     const uint32_t *ref_2bit;  /* the same, 16 bases per word, base i of a word in bits 2i..2i+1 (A 0, C 1, G 2, T 3); may be NULL */
     const uint32_t *ref_exc;   /* bit w of this bitmap: packed word w holds a symbol other than upper-case A/C/G/T */

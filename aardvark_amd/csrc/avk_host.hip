@@ -140,8 +140,7 @@ struct avk_dev_batch {
     bool want_seq = false;
     uint64_t seq_total = 0;
     AvkDevRegion *d_regions = nullptr;
-    AvkDevVariant *d_variants = nullptr;
-    uint8_t *d_alleles = nullptr;
+    uint32_t *d_blob = nullptr; /* region blobs (AvkBlobVar in avk_dev_types.h) */
     uint32_t *d_region_out = nullptr; /* [n][4] */
     uint32_t *d_gm = nullptr;
     uint32_t *d_var_out = nullptr;    /* [nv] */
@@ -188,7 +187,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 }
 
 void free_batch_buffers(avk_dev_batch *db) {
-    void *ptrs[] = {db->d_regions, db->d_variants, db->d_alleles, db->d_region_out, db->d_gm, db->d_var_out,
+    void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
                     db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_order};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -199,6 +198,8 @@ void free_batch_buffers(avk_dev_batch *db) {
 extern "C" {
 
 const char *avk_version(void) { return "aardvark_amd 0.1 (gfx950)"; }
+
+uint64_t avk_edit_distance(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len) { return avk::host_edit_distance(a, a_len, b, b_len); }
 
 const char *avk_last_error(const avk_ctx *ctx) {
     if (ctx) return ctx->err.c_str();
@@ -432,8 +433,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
         }                         \
     } while (0)
     AVK_TRY(dev_alloc(ctx, &db->d_regions, n));
-    AVK_TRY(dev_alloc(ctx, &db->d_variants, nv));
-    AVK_TRY(dev_alloc(ctx, &db->d_alleles, db->host.alleles.size()));
+    AVK_TRY(dev_alloc(ctx, &db->d_blob, db->host.blob.size()));
     AVK_TRY(dev_alloc(ctx, &db->d_region_out, n * 4));
     AVK_TRY(dev_alloc(ctx, &db->d_var_out, nv));
     AVK_TRY(dev_alloc(ctx, &db->d_seqlen, n * 5));
@@ -454,8 +454,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && nv) e = hipMemcpyAsync(db->d_variants, db->host.variants.data(), nv * sizeof(AvkDevVariant), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(db->d_alleles, db->host.alleles.data(), db->host.alleles.size(), hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(db->d_blob, db->host.blob.data(), db->host.blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
         free_batch_buffers(db);
@@ -529,8 +528,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     AvkKernelArgs a;
     memset(&a, 0, sizeof(a));
     a.regions = db->d_regions;
-    a.variants = db->d_variants;
-    a.alleles = db->d_alleles;
+    a.blob = db->d_blob;
     a.ref_bytes = ctx->d_ref;
     a.ref_2bit = ctx->use_packed_reference ? ctx->d_ref2b : nullptr;
     a.ref_exc = ctx->d_refexc;

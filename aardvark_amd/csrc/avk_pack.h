@@ -19,10 +19,15 @@
 
 namespace avk {
 
+/* the 8 variant types add_basepair_stats filters by, in the reference's order (waffle_solver.rs:383) */
+static const uint8_t AVK_SUP_TYPES[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL,
+                                         AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
+
 struct PackedBatch {
     std::vector<AvkDevRegion> regions;
-    std::vector<AvkDevVariant> variants;
-    std::vector<uint8_t> alleles;
+    std::vector<uint32_t> blob;          /* what the device reads: one blob per region (AvkBlobVar in avk_dev_types.h) */
+    std::vector<AvkDevVariant> variants; /* host-side only */
+    std::vector<uint8_t> alleles;        /* host-side only */
     std::vector<uint64_t> dev2host; /* device variant index -> caller variant index */
     std::vector<uint8_t> zyg_flags; /* per region: bit 0 an Unknown zygosity, bit 1 a HomozygousReference one */
     std::vector<int64_t> delta_t, delta_q; /* variant_delta_length per side (merge_solver.rs:211-223) */
@@ -46,6 +51,54 @@ inline uint32_t seq_stride_of(const avk_region_batch *b, uint64_t r) {
     return (uint32_t)s;
 }
 
+/* Unit-cost edit distance of two byte strings = the reference's wfa_ed on complete strings
+ * (src/util/sequence_alignment.rs:9-13, asserted equal to the DP edit distance at :58-116).
+ * Common prefix and suffix are stripped first (every normalised SNV / insertion / deletion ends there);
+ * what is left runs the furthest-reaching wavefront recurrence, O((n + m) * d). */
+inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *b, uint64_t m) {
+    while (n && m && a[0] == b[0]) {
+        ++a;
+        ++b;
+        --n;
+        --m;
+    }
+    while (n && m && a[n - 1] == b[m - 1]) {
+        --n;
+        --m;
+    }
+    if (n == 0) return m;
+    if (m == 0) return n;
+    if (n == 1 && m == 1) return 1;
+    /* fr[k + d] = furthest x (symbols of a consumed) on diagonal k = x - y with cost d */
+    const int64_t N = (int64_t)n, M = (int64_t)m, target = N - M;
+    std::vector<int64_t> cur(1, 0), nxt;
+    auto slide = [&](int64_t x, int64_t k) {
+        int64_t y = x - k;
+        while (x < N && y < M && a[x] == b[y]) {
+            ++x;
+            ++y;
+        }
+        return x;
+    };
+    cur[0] = slide(0, 0);
+    for (int64_t d = 0;; ++d) {
+        if (target >= -d && target <= d && cur[(size_t)(target + d)] >= N) return (uint64_t)d;
+        nxt.assign((size_t)(2 * d + 3), -1);
+        for (int64_t k = -d - 1; k <= d + 1; ++k) {
+            int64_t best = -1;
+            if (k >= -d && k <= d && cur[(size_t)(k + d)] >= 0) best = cur[(size_t)(k + d)] + 1;                 /* substitution */
+            if (k - 1 >= -d && k - 1 <= d && cur[(size_t)(k - 1 + d)] >= 0 && cur[(size_t)(k - 1 + d)] + 1 > best) best = cur[(size_t)(k - 1 + d)] + 1; /* a[x] unmatched */
+            if (k + 1 >= -d && k + 1 <= d && cur[(size_t)(k + 1 + d)] > best) best = cur[(size_t)(k + 1 + d)]; /* b[y] unmatched */
+            if (best < 0) continue;
+            if (best > N) best = N;
+            if (best - k > M) best = M + k; /* y must stay within b */
+            if (best < 0 || best - k < 0) continue;
+            nxt[(size_t)(k + d + 1)] = slide(best, k);
+        }
+        cur.swap(nxt);
+    }
+}
+
 /* contig_base[c] = offset of contig c in the concatenated reference, contig_len[c] its length */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
                       const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err) {
@@ -58,6 +111,8 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
     out->zyg_flags.assign(n, 0);
     out->delta_t.assign(n, 0);
     out->delta_q.assign(n, 0);
+    out->blob.clear();
+    out->blob.reserve(b->n_variants * 10 + n * 10);
     out->variants.clear();
     out->variants.reserve(b->n_variants);
     out->alleles.clear();
@@ -127,12 +182,66 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
         }
         if (!pre && bad_zyg) pre = AVK_ST_BAD_ZYGOSITY;
         dr.pre_status = pre;
+        if (!pre) { /* the region's blob */
+            const uint32_t N = tc + qc;
+            const AvkDevVariant *hv = out->variants.data() + dr.v_off;
+            uint64_t alle = 0, g[2] = {0, 0};
+            uint32_t types = 0, counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (uint32_t k = 0; k < N; ++k) {
+                alle += (uint64_t)hv[k].a0_len + hv[k].a1_len;
+                if (hv[k].a1_len > hv[k].a0_len) g[k < tc ? 0 : 1] += hv[k].a1_len - hv[k].a0_len;
+                types |= 1u << hv[k].type;
+                for (int t = 0; t < 8; ++t)
+                    if (hv[k].type == AVK_SUP_TYPES[t]) counts[t] += k < tc ? 1u : 0x10000u;
+            }
+            const uint64_t vb = ((uint64_t)N * sizeof(AvkBlobVar) + 7) & ~7ull, ab = (alle + 7) & ~7ull, ob = (4ull * N + 7) & ~7ull;
+            const uint64_t bytes = vb + ab + ob + 32;
+            const uint64_t at = out->blob.size(); /* words; every blob is a multiple of 8 bytes */
+            if (bytes > 0x7FFFFFFFull || (at * 4 + bytes) / 8 > 0xFFFFFFFFull || (g[0] > g[1] ? g[0] : g[1]) > 0x7FFFFFFFull) {
+                *err = "region blob arena exceeds its limits; split the batch";
+                return AVK_E_ARG;
+            }
+            out->blob.resize(at + bytes / 4, 0);
+            uint8_t *base = (uint8_t *)(out->blob.data() + at);
+            AvkBlobVar *bv = (AvkBlobVar *)base;
+            uint8_t *ba = base + vb;
+            uint32_t *bo = (uint32_t *)(base + vb + ab), *bc = (uint32_t *)(base + vb + ab + ob);
+            uint32_t run = 0;
+            for (uint32_t k = 0; k < N; ++k) {
+                const uint8_t *a0 = out->alleles.data() + hv[k].a_off, *a1 = a0 + hv[k].a0_len;
+                bv[k].rel_pos = hv[k].rel_pos;
+                bv[k].a0_len = hv[k].a0_len;
+                bv[k].a1_len = hv[k].a1_len;
+                bv[k].a_off = run;
+                bv[k].raw_space = hv[k].raw_space;
+                const uint64_t ed = host_edit_distance(a0, hv[k].a0_len, a1, hv[k].a1_len);
+                bv[k].alt_ed = (uint32_t)ed;
+                bv[k].type_zyg = (uint32_t)hv[k].type | ((uint32_t)hv[k].zyg << 8);
+                memcpy(ba + run, a0, (size_t)hv[k].a0_len + hv[k].a1_len);
+                run += hv[k].a0_len + hv[k].a1_len;
+            }
+            /* order_variants: stable by position over [truth.., query..]; each side is already sorted (checked above) */
+            {
+                uint32_t i = 0, j = tc, o = 0;
+                while (i < tc || j < N) {
+                    if (j >= N || (i < tc && hv[i].rel_pos <= hv[j].rel_pos)) bo[o++] = i++;
+                    else bo[o++] = j++;
+                }
+            }
+            for (int t = 0; t < 8; ++t) bc[t] = counts[t];
+            dr.blob_off = (uint32_t)(at / 2);
+            dr.blob_bytes = (uint32_t)bytes;
+            dr.alle_bytes = (uint32_t)alle;
+            dr.grow = (uint32_t)(g[0] > g[1] ? g[0] : g[1]);
+            dr.types = types;
+        }
         if (seq_off && seq_stride) {
             dr.seq_off = seq_off[r];
             dr.seq_stride = seq_stride[r];
         }
     }
     if (out->alleles.empty()) out->alleles.push_back(0);
+    if (out->blob.empty()) out->blob.resize(2, 0);
     return 0;
 }
 

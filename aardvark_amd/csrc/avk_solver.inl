@@ -99,6 +99,7 @@ struct Ctx {
     LVar *vars;    /* [N]: truth 0..T-1, query T..N-1 */
     u8 *alle;
     u32 *order;    /* [N] processing order (query_optimizer.rs:372-381) */
+    u32 *counts;   /* [8] truth | query << 16 variants of each type of AVK_SUP_TYPES */
     u32 *bucket;   /* [N+1] */
     /* capacities */
     u32 seqcap, wfcap, alw;
@@ -1113,18 +1114,10 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     c.max_branch = a.max_branch_factor;
     const u32 v_off = wv_uni(reg.v_off);
 
-    /* sizes: sum of allele bytes and growth bound of each side */
-    u32 l_alle = 0, l_tg = 0, l_qg = 0;
-    for (u32 k = lane; k < c.N; k += 64) {
-        const AvkDevVariant dv = a.variants[v_off + k];
-        l_alle += dv.a0_len + dv.a1_len;
-        const u32 g = dv.a1_len > dv.a0_len ? dv.a1_len - dv.a0_len : 0;
-        if (k < c.T) l_tg += g;
-        else l_qg += g;
-    }
-    const u32 alle_bytes = wv_sum_u32(l_alle);
-    const u32 tg = wv_sum_u32(l_tg), qg = wv_sum_u32(l_qg);
-    c.seqcap = (c.L + (tg > qg ? tg : qg) + 7u) & ~7u;
+    /* sizes come with the region record (the host packer computed them) */
+    const u32 alle_bytes = wv_uni(reg.alle_bytes);
+    const u32 blob_bytes = wv_uni(reg.blob_bytes);
+    c.seqcap = (c.L + wv_uni(reg.grow) + 7u) & ~7u;
     if (c.seqcap == 0) c.seqcap = 8;
     const u32 maxT = c.T > c.Q ? c.T : c.Q;
     c.alw = maxT ? (maxT + 63) >> 6 : 1;
@@ -1143,12 +1136,17 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     u64 off = 0;
     u8 *refbuf = ws + off;
     off = AVK_ALIGN8(off + c.L);
+    /* the region blob lands here as it is: variant records | allele bytes | variant order | per-type counts
+     * (AvkBlobVar in avk_dev_types.h; every section padded to 8 bytes) */
+    u32 *const blob_dst = (u32 *)(ws + off);
     c.vars = (LVar *)(ws + off);
     off = AVK_ALIGN8(off + (u64)c.N * sizeof(LVar));
     c.alle = ws + off;
     off = AVK_ALIGN8(off + alle_bytes);
     c.order = (u32 *)(ws + off);
     off = AVK_ALIGN8(off + 4ull * c.N);
+    c.counts = (u32 *)(ws + off);
+    off += 32;
     c.bucket = (u32 *)(ws + off);
     off = AVK_ALIGN8(off + 4ull * (c.N + 1));
     c.optlist = (u32 *)(ws + off);
@@ -1225,71 +1223,12 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         }
     }
     c.ref = refbuf;
-    {
-        u32 run = 0; /* allele arena offsets: sequential prefix over the variants */
-        for (u32 base = 0; base < c.N; base += 64) {
-            const u32 k = base + lane;
-            u32 mine = 0;
-            AvkDevVariant dv;
-            dv.rel_pos = dv.a0_len = dv.a1_len = dv.a_off = dv.raw_space = 0;
-            dv.type = dv.zyg = 0;
-            if (k < c.N) {
-                dv = a.variants[v_off + k];
-                mine = dv.a0_len + dv.a1_len;
-            }
-            /* exclusive prefix sum of `mine` over the lanes */
-            u32 pre = mine;
-            for (int o = 1; o < 64; o <<= 1) {
-                const u32 t = wv_shfl(pre, (int)lane - o);
-                if ((int)lane >= o) pre += t;
-            }
-            const u32 excl = pre - mine;
-            const u32 total = wv_shfl(pre, 63);
-            if (k < c.N) {
-                LVar lv;
-                lv.rel_pos = dv.rel_pos;
-                lv.a0_len = dv.a0_len;
-                lv.a1_len = dv.a1_len;
-                lv.a_off = run + excl;
-                lv.raw_space = dv.raw_space;
-                lv.alt_ed = 0;
-                lv.type_zyg = (u32)dv.type | ((u32)dv.zyg << 8);
-                c.vars[k] = lv;
-                const u8 *src = a.alleles + dv.a_off;
-                for (u32 t = 0; t < mine; ++t) c.alle[run + excl + t] = src[t];
-            }
-            run += total;
-        }
+    { /* variants, alleles, order, counts: one coalesced copy of the prepared blob */
+        const u32 *src = a.blob + 2ull * wv_uni(reg.blob_off);
+        const u32 nw = blob_bytes >> 2;
+        for (u32 i = lane; i < nw; i += 64) blob_dst[i] = src[i];
     }
     wv_sync();
-
-    /* order_variants (query_optimizer.rs:372-381): stable sort by position of [truth.., query..] */
-    for (u32 k = lane; k < c.N; k += 64) {
-        const u32 pk = c.vars[k].rel_pos;
-        u32 rank = 0;
-        for (u32 j = 0; j < c.N; ++j) {
-            const u32 pj = c.vars[j].rel_pos;
-            rank += (pj < pk || (pj == pk && j < k)) ? 1u : 0u;
-        }
-        c.order[rank] = k;
-    }
-    wv_sync();
-
-    /* Variant::alt_ed for every variant (variants.rs:413-415) */
-    for (u32 k = 0; k < c.N; ++k) {
-        const UVar v = load_var(c.vars, k);
-        const u32 l0 = v.a0_len, l1 = v.a1_len, ao = v.a_off;
-        u32 e;
-        if (l0 == 1 && l1 == 1) e = wv_uni(c.alle[ao] != c.alle[ao + 1] ? 1u : 0u);
-        else {
-            const int ee = wfa_ed(c, c.alle + ao, l0, c.alle + ao + l0, l1);
-            if (ee < 0) return RS_OVERFLOW;
-            e = (u32)ee;
-        }
-        wv_sync();
-        st32(&c.vars[k].alt_ed, e);
-        wv_sync();
-    }
 
     AVK_T_MARK(c, 0)
     /* ---- phase A */
@@ -1459,7 +1398,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     zero_words(c.gq, 32);
     wv_sync();
     /* compare_expected_observed for truth and query (:296-327) + per-variant outputs */
-    u32 l_present = 0, l_bad = 0;
+    u32 l_bad = 0;
     for (u32 k = lane; k < c.N; k += 64) {
         const bool is_truth = k < c.T;
         const u32 sub = is_truth ? k : k - c.T;
@@ -1473,7 +1412,6 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         if (exp == 0) l_bad = AVK_ST_VARIANT_METRICS;
         else if (exp < ob) l_bad = AVK_ST_TRUTH_FP;
         else gm_add(c.gm, !is_truth, vtype, v.alt_ed, exp, ob);
-        l_present |= 1u << vtype;
         /* VariantMetrics (variant_metrics.rs:43-101); query entries are toggled */
         const u32 gv = v_off + k;
         u32 cls = exp == ob ? AVK_CLASS_TP : AVK_CLASS_FN;
@@ -1488,27 +1426,13 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     }
     const u32 bad = wv_max_u32(l_bad);
     if (bad) return (int)bad;
-    u32 present = 0;
-    for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t)
-        if (wv_ballot((l_present >> t) & 1)) present |= 1u << t;
     wv_sync();
     /* add_basepair_stats (:335-449).  The optimizer's own sequences are the regenerated ones
      * (asserted equal at :364-367), ed(truth,query) is the node's finalized DWFA distance. */
     const int SUP[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL, AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
+    u32 present = wv_uni(reg.types); /* types seen by compare_expected_observed, plus the 8 filtered types' map entries */
+    for (int s = 0; s < 8; ++s) present |= 1u << SUP[s];
     AVK_T_MARK(c, 3)
-    u32 tcount[8], qcount[8];
-    for (int s = 0; s < 8; ++s) {
-        u32 nt = 0, nq = 0;
-        for (u32 base = 0; base < c.N; base += 64) {
-            const u32 k = base + lane;
-            const bool hit = k < c.N && (c.vars[k].type_zyg & 0xFF) == (u32)SUP[s];
-            nt += (u32)avk_popc64(wv_ballot(hit && k < c.T));
-            nq += (u32)avk_popc64(wv_ballot(hit && k >= c.T));
-        }
-        tcount[s] = nt;
-        qcount[s] = nq;
-        present |= 1u << SUP[s];
-    }
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr &wp = hh == 0 ? w0 : w1;
         const HapHdr &hd = hh == 0 ? h0 : h1;
@@ -1538,10 +1462,11 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         if (lane < 4) c.gm[AVK_F_BP_TRUTH_TP + lane] += add[lane];
         wv_sync();
         for (int s = 0; s < 8; ++s) {
-            if (!qcount[s] && !tcount[s]) continue; /* contributes (0,0,0,0); the map entry exists via `present` */
+            const u32 tq = ld32u(c.counts + s), tcount_s = tq & 0xFFFFu, qcount_s = tq >> 16;
+            if (!tq) continue; /* contributes (0,0,0,0); the map entry exists via `present` */
             u32 q_tp = 0, q_fp = 0, t_tp = 0, t_fn = 0;
-            if (qcount[s]) {
-                if (qcount[s] == c.Q) { /* filtered query == the full query haplotype */
+            if (qcount_s) {
+                if (qcount_s == c.Q) { /* filtered query == the full query haplotype */
                     q_tp = tp;
                     q_fp = Y - tp + 2 * hd.q_skip;
                 } else {
@@ -1557,8 +1482,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
                     q_fp = Y2 - tp2 + 2 * failed;
                 }
             }
-            if (tcount[s]) {
-                if (tcount[s] == c.T) {
+            if (tcount_s) {
+                if (tcount_s == c.T) {
                     t_tp = tp;
                     t_fn = X - tp + 2 * hd.t_skip;
                 } else {

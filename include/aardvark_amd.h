@@ -217,6 +217,11 @@ int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[8]);
 int  avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32_t max_branch_factor,
                               int32_t *status, uint8_t *is_exact_match);
 
+/* Host utility (no GPU involved): unit-cost edit distance of two byte strings, the value of the reference's
+ * wfa_ed (src/util/sequence_alignment.rs:9-13).  The batch packer uses it for Variant::alt_ed
+ * (src/data_types/variants.rs:413-415), which travels to the device with the region records. */
+uint64_t avk_edit_distance(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len);
+
 const char *avk_version(void);
 
 #ifdef __cplusplus

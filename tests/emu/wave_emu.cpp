@@ -202,8 +202,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     AvkKernelArgs a;
     memset(&a, 0, sizeof(a));
     a.regions = pb.regions.data();
-    a.variants = pb.variants.data();
-    a.alleles = pb.alleles.data();
+    a.blob = pb.blob.data();
     a.ref_bytes = refcat.data();
     /* packed copy, as avk_pack_reference builds it on the device */
     const uint64_t n_words = (total + 15) >> 4;

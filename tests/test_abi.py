@@ -66,3 +66,37 @@ def test_product_library_does_not_link_the_oracle():
     assert "oracle" not in out and "avk_emu" not in out
     syms = subprocess.check_output(["nm", "-D", aardvark_amd.library_path()]).decode()
     assert "orc_" not in syms and "emu_compare_batch" not in syms
+
+
+def test_packer_edit_distance_matches_the_oracle():
+    """Variant::alt_ed is computed by the batch packer on the host (no GPU): fuzz it against the oracle's wfa_ed."""
+    import random
+    import oracle_lib
+    lib = aardvark_amd.load_library()
+    orc = oracle_lib.load()
+    rng = random.Random(7)
+    cases = [(b"A", b"A"), (b"A", b"C"), (b"A", b"ACGT"), (b"ACGT", b"A"), (b"ACGT", b"T"), (b"AAAA", b"AA"), (b"ACAC", b"CACA")]
+    for _ in range(3000):
+        n = rng.choice([1, 1, 2, 3, 5, 8, 20, 60])
+        a = bytes(rng.choice(b"ACGT") for _ in range(n))
+        kind = rng.random()
+        if kind < 0.3:
+            b = bytes(rng.choice(b"ACGT") for _ in range(rng.choice([1, 2, 3, 7, 30])))
+        else:  # a mutated copy
+            b = bytearray(a)
+            for _ in range(rng.randint(0, 4)):
+                op = rng.random()
+                pos = rng.randrange(len(b) + 1)
+                if op < 0.34 and len(b) > 1:
+                    del b[min(pos, len(b) - 1)]
+                elif op < 0.67:
+                    b.insert(pos, rng.choice(b"ACGT"))
+                elif len(b):
+                    b[min(pos, len(b) - 1)] = rng.choice(b"ACGT")
+            b = bytes(b) or b"A"
+        cases.append((a, b))
+    for a, b in cases:
+        pa, la = oracle_lib.b2p(a)
+        pb, lb = oracle_lib.b2p(b)
+        want = orc.orc_wfa_ed(pa, la, pb, lb)
+        assert lib.avk_edit_distance(a, len(a), b, len(b)) == want, (a, b)
