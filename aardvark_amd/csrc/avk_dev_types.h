@@ -26,7 +26,9 @@ struct AvkDevRegion {
     uint32_t alle_bytes; /* bytes of the allele section of the blob (before padding) */
     uint32_t grow;       /* max over the two sides of sum(max(0, a1_len - a0_len)): bound of a haplotype's growth */
     uint32_t types;      /* bit t set: a variant of type t (AVK_VT_*) is present */
-    uint32_t pad;
+    uint32_t ed_bound;   /* sum of alt_ed over the region's variants: no wavefront of the region can pass this distance
+                            (every haplotype is within its side's sum of the reference window), so the LDS tiers size
+                            their wavefronts by min(tier cap, ed_bound) */
 };
 
 /* One variant inside a region blob (reference src/data_types/variants.rs:73-91), window-relative.
@@ -98,6 +100,12 @@ struct AvkKernelArgs {
     uint32_t *overflow_count;
     /* workspaces */
     uint8_t *hbm_ws;           /* n_waves slices of tier[2] (or tier[3]) bytes */
+    /* in-place escalation of the HBM launch: a region that outgrows its wave's tier-2 slice is solved again at once in one of
+     * big_slots shared tier-3 slices (claimed through big_busy[slot], one word each), so the last tier needs no launch of its own */
+    uint8_t *big_ws;
+    uint32_t *big_busy;
+    uint32_t big_slots;
+    uint32_t pad1_;
     AvkTier tier[4];
     /* outputs */
     uint32_t *region_out;    /* [n][4]: status, ed_h1, ed_h2, n_optima | type_present << 16 — one 16-byte store per region */

@@ -74,13 +74,19 @@ __global__ void avk_pack_reference(const uint8_t *bytes, uint64_t n_bases, uint3
     }
 }
 
-/* sums the partial tallies into out[0 .. AVK_TALLY_STRIDE) */
-__global__ void avk_tally_reduce(const uint64_t *partials, uint64_t *out) {
+/* sums the partial tallies into out[0 .. AVK_TALLY_STRIDE) (and the caller's device tally, if any), then clears
+ * the partial tallies and the work / overflow counters for the next call on this batch */
+__global__ void avk_tally_reduce(uint64_t *partials, uint64_t *out, uint64_t *out_user, uint32_t *counters, unsigned n_counters) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (unsigned k = i; k < n_counters; k += gridDim.x * blockDim.x) counters[k] = 0;
     if (i >= AVK_TALLY_STRIDE) return;
     uint64_t s = 0;
-    for (int c = 0; c < AVK_TALLY_COPIES; ++c) s += partials[(size_t)c * AVK_TALLY_STRIDE + i];
+    for (int c = 0; c < AVK_TALLY_COPIES; ++c) {
+        s += partials[(size_t)c * AVK_TALLY_STRIDE + i];
+        partials[(size_t)c * AVK_TALLY_STRIDE + i] = 0;
+    }
     out[i] = s;
+    if (out_user && i < AVK_TALLY_LEN) out_user[i] = s;
 }
 
 /* ---------------------------------------------------------------------------------- context */
@@ -96,6 +102,8 @@ struct DevBuf {
 
 } // namespace
 
+#define AVK_N_COUNTERS 1280 /* words of avk_dev_batch::d_counters */
+
 struct avk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -108,12 +116,13 @@ struct avk_ctx {
     std::vector<uint64_t> contig_base, contig_len;
     /* options */
     int64_t lds_bytes_per_wave = 10 * 1024;
-    int64_t lds_ed_cap = 8;
+    int64_t lds_ed_cap = 48;
     int64_t lds2_bytes_per_wave = 40 * 1024;
     int64_t lds2_ed_cap = 48;
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
+    int64_t lds2_overflow_pass = 0; /* 1: a launch of its own with large LDS slices between the bulk and the HBM tier */
     int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
     int64_t ws_bytes_per_wave = 1 << 20;
     int64_t big_ws_bytes = 256ll << 20;
@@ -152,6 +161,7 @@ struct avk_dev_batch {
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
     uint32_t *d_order = nullptr; /* work order of the first launch: [predicted-hard regions | the rest], most variants first */
     uint32_t n_hard = 0;
+    bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
 };
 
@@ -295,6 +305,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "solo_min_variants") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "solo_min_variants must not be negative");
         ctx->solo_min_variants = value;
+    } else if (n == "lds2_overflow_pass") {
+        ctx->lds2_overflow_pass = value ? 1 : 0;
     } else if (n == "bulk_full_grid") {
         ctx->bulk_full_grid = value ? 1 : 0;
     } else if (n == "solo_blocks_max") {
@@ -439,7 +451,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_seqlen, n * 5));
     AVK_TRY(dev_alloc(ctx, &db->d_tally, (size_t)AVK_TALLY_STRIDE));
     AVK_TRY(dev_alloc(ctx, &db->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES));
-    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)1088));
+    AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)AVK_N_COUNTERS));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1024));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
@@ -518,8 +530,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         ctx->big_alloc = big_need;
     }
 
-    AVK_HIP(ctx, hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), ctx->stream));
-    AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, 1088 * sizeof(uint32_t), ctx->stream));
+    if (!db->scratch_clean) { /* normally left clean by avk_tally_reduce of the previous call */
+        AVK_HIP(ctx, hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), ctx->stream));
+        AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t), ctx->stream));
+    }
+    db->scratch_clean = false;
     if (ctx->emit_group_metrics && !db->d_gm) {
         int rc = dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
         if (rc) return rc;
@@ -558,16 +573,21 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     /* up to four launches, one per workspace tier; each consumes the overflow list of the one
      * before it (its length is read on the device, so nothing comes back to the host in between) */
     const bool use[4] = {ctx->lds_bytes_per_wave > 0, ctx->lds2_bytes_per_wave > 0, ctx->ws_bytes_per_wave > 0, ctx->big_ws_bytes > 0};
+    /* which tiers get a launch of their own: the large LDS slices normally only serve the solo launch (their
+     * overflow pass runs one workgroup per CU and measured slower than handing the overflow to the HBM tier,
+     * which runs twice the waves), and the big HBM slices are claimed in place by the tier-2 launch */
+    const bool launch[4] = {use[0], use[1] && (ctx->lds2_overflow_pass || !use[0]), use[2], use[3] && !use[2]};
     int last = -1;
     for (int t = 0; t < 4; ++t)
-        if (use[t]) last = t;
+        if (launch[t]) last = t;
     if (last < 0) return fail(ctx, AVK_E_ARG, "every workspace tier is disabled");
+    const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(ctx->big_waves < 128 ? ctx->big_waves : 128) : 0u;
     const uint32_t *list = db->d_order, *count = nullptr;
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
     int nlist = 0;
     bool solo_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
-        if (!use[t]) continue;
+        if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
         a.work_list = list;
         a.n_work_dev = count;
@@ -580,6 +600,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.overflow_count = nullptr;
         }
         const bool first_launch = list == db->d_order; /* ev0 sits right before it */
+        if (solo_pending && t >= 2) { /* the HBM launches read the list the solo launch appends to; the tier-1 launch does not */
+            AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            solo_pending = false;
+        }
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
         a.static_pct = AVK_STATIC_PCT;
@@ -601,24 +625,26 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AvkKernelArgs s = a;
                 s.pass_tier = 1;
                 s.work_list = db->d_order;
-                s.n_work = db->n_hard;
+                s.n_work = solo; /* one region each: the hardest ones; the other predicted-hard regions lead the bulk list */
                 s.work_counter = db->d_counters + 1072;
                 s.static_pct = 0;
                 s.n_shards = 1;
                 s.claim = 1;
                 s.n_waves = solo;
                 s.high_priority = 1;
-                const bool t1_last = last == 1; /* what outgrows tier 1 joins the list the tier-1 launch appends to */
-                s.overflow_list = t1_last ? nullptr : lists[1];
-                s.overflow_count = t1_last ? nullptr : db->d_counters + 1024 + 16 * 1;
+                /* what outgrows tier 1 joins the list the first HBM launch reads */
+                const int solo_list = launch[1] ? 1 : 0;
+                const bool later = last > (launch[1] ? 1 : 0);
+                s.overflow_list = later ? lists[solo_list] : nullptr;
+                s.overflow_count = later ? db->d_counters + 1024 + 16 * solo_list : nullptr;
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
                 hipLaunchKernelGGL(avk_region_kernel_lds, dim3(solo), dim3(64), (size_t)ctx->lds2_bytes_per_wave, ctx->side_stream, s);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
                 solo_pending = true;
-                a.work_list = db->d_order + db->n_hard;
-                a.n_work = (uint32_t)n - db->n_hard;
+                a.work_list = db->d_order + solo;
+                a.n_work = (uint32_t)n - solo;
             }
             /* the bulk grid keeps its full size: the last `solo` workgroups find no room until solo workgroups retire;
              * they take no static share (n_waves counts the others) and help with the dynamically claimed tail */
@@ -631,30 +657,33 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(b2), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds2_bytes_per_wave, ctx->stream, a);
         } else if (t == 2) {
             a.hbm_ws = ctx->d_ws;
+            a.big_ws = ctx->d_big;
+            a.big_busy = db->d_counters + 1088;
+            a.big_slots = big_slots;
             a.n_waves = blocks * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(blocks), dim3(256), 0, ctx->stream, a);
         } else {
             a.hbm_ws = ctx->d_big;
+            a.big_slots = 0;
             a.n_waves = big_blocks * waves_per_block;
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
         }
         AVK_HIP(ctx, hipGetLastError());
         if (first_launch) AVK_HIP(ctx, hipEventRecord(ctx->evk1, ctx->stream));
-        if (solo_pending) { /* everything later on the main stream also follows the solo launch */
-            AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            solo_pending = false;
-        }
+
         if (t != last) {
             list = lists[nlist];
             count = db->d_counters + 1024 + 16 * nlist;
             nlist += 1;
         }
     }
-    hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally);
+    if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally,
+                       (uint64_t *)tally_dev, db->d_counters, (unsigned)AVK_N_COUNTERS);
     AVK_HIP(ctx, hipGetLastError());
+    db->scratch_clean = true;
     AVK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = true;
-    if (tally_dev) AVK_HIP(ctx, hipMemcpyAsync(tally_dev, db->d_tally, AVK_TALLY_LEN * sizeof(uint64_t), hipMemcpyDeviceToDevice, ctx->stream));
     return 0;
 }
 

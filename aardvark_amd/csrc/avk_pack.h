@@ -207,6 +207,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             uint8_t *ba = base + vb;
             uint32_t *bo = (uint32_t *)(base + vb + ab), *bc = (uint32_t *)(base + vb + ab + ob);
             uint32_t run = 0;
+            uint64_t ed_sum = 0;
             for (uint32_t k = 0; k < N; ++k) {
                 const uint8_t *a0 = out->alleles.data() + hv[k].a_off, *a1 = a0 + hv[k].a0_len;
                 bv[k].rel_pos = hv[k].rel_pos;
@@ -216,6 +217,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                 bv[k].raw_space = hv[k].raw_space;
                 const uint64_t ed = host_edit_distance(a0, hv[k].a0_len, a1, hv[k].a1_len);
                 bv[k].alt_ed = (uint32_t)ed;
+                ed_sum += ed;
                 bv[k].type_zyg = (uint32_t)hv[k].type | ((uint32_t)hv[k].zyg << 8);
                 memcpy(ba + run, a0, (size_t)hv[k].a0_len + hv[k].a1_len);
                 run += hv[k].a0_len + hv[k].a1_len;
@@ -234,6 +236,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             dr.alle_bytes = (uint32_t)alle;
             dr.grow = (uint32_t)(g[0] > g[1] ? g[0] : g[1]);
             dr.types = types;
+            dr.ed_bound = (uint32_t)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
         }
         if (seq_off && seq_stride) {
             dr.seq_off = seq_off[r];
@@ -271,7 +274,9 @@ inline uint32_t plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         const uint64_t seqcap = ((uint64_t)dr.len + (g[0] > g[1] ? g[0] : g[1]) + 7) & ~7ull;
         const uint64_t maxT = dr.t_cnt > dr.q_cnt ? dr.t_cnt : dr.q_cnt;
         const uint64_t alw = maxT ? (maxT + 63) >> 6 : 1;
-        uint64_t wfcap = tier0_ed_cap ? 2ull * tier0_ed_cap + 2 : 2 * seqcap + 4;
+        uint64_t cap0 = tier0_ed_cap;
+        if (cap0 && dr.ed_bound < cap0) cap0 = dr.ed_bound ? dr.ed_bound : 1;
+        uint64_t wfcap = cap0 ? 2 * cap0 + 2 : 2 * seqcap + 4;
         if (wfcap > 2 * seqcap + 4) wfcap = 2 * seqcap + 4;
         const uint64_t hapA = 48 + 16 * alw + 4 * wfcap + 2 * seqcap, nodeA = 8 + 2 * hapA;
         const uint64_t optcap = max_branch < 4096 ? max_branch : 4096;

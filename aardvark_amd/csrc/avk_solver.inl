@@ -1122,7 +1122,12 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     const u32 maxT = c.T > c.Q ? c.T : c.Q;
     c.alw = maxT ? (maxT + 63) >> 6 : 1;
     const u32 wf_full = 2 * c.seqcap + 4;
-    c.wfcap = ed_cap ? (2 * ed_cap + 2) : wf_full; /* even */
+    u32 cap = ed_cap; /* LDS tiers: the region's own bound when it is lower than the tier's cap (AvkDevRegion::ed_bound) */
+    if (cap) {
+        const u32 b = wv_uni(reg.ed_bound);
+        if (b < cap) cap = b ? b : 1u;
+    }
+    c.wfcap = cap ? (2 * cap + 2) : wf_full; /* even */
     if (c.wfcap > wf_full) c.wfcap = wf_full;
     c.wfs_cap = c.wfcap;
     c.hapA_bytes = H_WORDS * 4 + 16 * c.alw + 4 * c.wfcap + 2 * c.seqcap;
@@ -1576,7 +1581,7 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
 template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     const u32 lane = (u32)wv_lane();
     u32 tally[5] = {0, 0, 0, 0, 0}; /* a wave's share of a batch keeps every counter far below 2^32 */
-    u32 n_ok = 0, n_err = 0, n_cap = 0;
+    u32 n_ok = 0, n_err = 0, n_cap = 0, n_big = 0; /* n_big: finished (either way) in a tier-3 slice */
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
     const u64 ws_bytes = a.tier[tier].ws_bytes;
@@ -1649,27 +1654,63 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         RegionOut out;
         out.ed1 = out.ed2 = out.n_opt = out.present = 0;
         u32 winner = 0;
-        int st = solve_region_tier(a, r, ws, ws_bytes, ed_cap, c, out, winner);
+        /* one call site: a wave of the HBM launch that finds its tier-2 slice too small claims one of the shared
+         * tier-3 slices and goes round again */
+        u8 *cur_ws = ws;
+        u64 cur_bytes = ws_bytes;
+        u32 cur_cap = ed_cap, cur_tier = tier, slot = 0xFFFFFFFFu;
+        int st;
+        for (;;) {
+            st = solve_region_tier(a, r, cur_ws, cur_bytes, cur_cap, c, out, winner);
+            if (PASS_LDS || st != RS_OVERFLOW || slot != 0xFFFFFFFFu || a.big_slots == 0) break;
+            u32 got = 0xFFFFFFFFu;
+            if (lane == 0) {
+                for (u32 probe = wave_id % a.big_slots;; probe = probe + 1 < a.big_slots ? probe + 1 : 0) { /* holders never wait: this ends */
+                    if (avk_ld_agent_u32(a.big_busy + probe) == 0 && avk_atomic_cas_u32_global(a.big_busy + probe, 0u, 1u) == 0u) {
+                        got = probe;
+                        break;
+                    }
+                    avk_sleep();
+                }
+            }
+            slot = wv_uni(wv_shfl(got, 0));
+            avk_acquire_agent(); /* the slice was last written through another XCD's L2 */
+            cur_ws = a.big_ws + (u64)slot * a.tier[3].ws_bytes;
+            cur_bytes = a.tier[3].ws_bytes;
+            cur_cap = a.tier[3].ed_cap;
+            cur_tier = 3;
+        }
+#define AVK_RELEASE_SLOT()                                        \
+    if (!PASS_LDS && slot != 0xFFFFFFFFu) {                       \
+        avk_release_agent();                                      \
+        if (lane == 0) avk_st_agent_u32(a.big_busy + slot, 0u);   \
+    }
         if (st == RS_OVERFLOW) {
             if (a.overflow_list) { /* hand over to the next tier's launch */
                 if (lane == 0) {
-                    const u32 slot = avk_atomic_add_u32_global(a.overflow_count, 1);
-                    a.overflow_list[slot] = r;
+                    const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1);
+                    a.overflow_list[slot_o] = r;
                 }
+                AVK_RELEASE_SLOT()
                 continue;
             }
             st = AVK_ST_CAPACITY;
             n_cap += 1;
         }
+        if (cur_tier != tier && st != AVK_ST_CAPACITY) n_big += 1;
         if (st != AVK_ST_OK) {
             write_failed_region(a, r, st);
             n_err += 1;
+            AVK_RELEASE_SLOT()
             continue;
         }
         /* results of an Ok region */
         write_region_record(a, r, 0, out.ed1, out.ed2, out.n_opt, out.present);
         n_ok += 1;
-        if (a.mode == 1) continue;
+        if (a.mode == 1) {
+            AVK_RELEASE_SLOT()
+            continue;
+        }
         if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
         for (int j = 0; j < 5; ++j) {
             const u32 i = (u32)j * 64 + lane;
@@ -1689,6 +1730,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             }
         }
         wv_sync();
+        AVK_RELEASE_SLOT()
 #ifdef AVK_PHASE_TIMING
         if (lane == 0) {
             u64 *pc = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5;
@@ -1709,7 +1751,8 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     if (lane == 0) {
         if (n_ok) avk_atomic_add_u64_global(part + AVK_TALLY_SOLVED, n_ok);
         if (n_err) avk_atomic_add_u64_global(part + AVK_TALLY_ERRORS, n_err);
-        if (n_ok + n_err - n_cap) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + tier, n_ok + n_err - n_cap);
+        if (n_ok + n_err - n_cap - n_big) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + tier, n_ok + n_err - n_cap - n_big);
+        if (n_big) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 3, n_big);
         if (n_cap) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 4, n_cap);
     }
 }

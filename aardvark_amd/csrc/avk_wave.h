@@ -83,6 +83,10 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) {
+    __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    return expect;
+}
 AVK_DEV uint64_t avk_clock() { return 0; }
 AVK_DEV uint32_t avk_ld_agent_u32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 AVK_DEV void avk_st_agent_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
@@ -153,6 +157,7 @@ AVK_DEV void wv_sync() {
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
 AVK_DEV uint64_t avk_clock() { return __builtin_amdgcn_s_memtime(); }
 /* device-scope (all XCDs) accesses for words that other workgroups poll: write-through / L1-bypassing forms
  * (cdna_hip_programming.md §6 G16: granule = one aligned word that is its own flag) */

@@ -172,7 +172,7 @@ extern "C" {
 static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
                       uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts,
-                      uint32_t solo_min_variants) {
+                      uint32_t solo_min_variants, uint32_t lds2_overflow_pass) {
     std::vector<uint64_t> base(n_contigs), lens(n_contigs);
     uint64_t total = 0;
     for (uint32_t c = 0; c < n_contigs; ++c) {
@@ -196,7 +196,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint32_t> gm(out->group_metrics ? n * AVK_N_GROUPS * AVK_N_FIELDS : 0);
     std::vector<uint64_t> partials((size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES, 0), tally(AVK_TALLY_STRIDE, 0);
     std::vector<uint32_t> lists[3] = {std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1)};
-    std::vector<uint32_t> counters_v(1088, 0);
+    std::vector<uint32_t> counters_v(1280, 0);
     uint32_t *counters = counters_v.data();
 
     AvkKernelArgs a;
@@ -282,18 +282,22 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
 
     /* the same four tier launches as avk_compare_resident (aardvark_amd/csrc/avk_host.hip) */
     const bool use[4] = {lds_bytes > 0, lds2_bytes > 0, ws_bytes > 0, big_ws_bytes > 0};
+    const bool launch[4] = {use[0], use[1] && (lds2_overflow_pass || !use[0]), use[2], use[3] && !use[2]};
     int last = -1;
     for (int t = 0; t < 4; ++t)
-        if (use[t]) last = t;
+        if (launch[t]) last = t;
     if (last < 0) return AVK_E_ARG;
+    const uint32_t big_slots = use[2] && use[3] ? 2u : 0u;
+    std::vector<uint8_t> big_slices(big_slots ? (size_t)big_slots * big_ws_bytes : 0);
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
     const uint32_t n_hard = avk::plan_work_order(pb, lds_bytes, lds_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
     const uint32_t *list = order.data(), *count = nullptr;
     int nlist = 0;
     for (int t = 0; t < 4 && n; ++t) {
-        if (!use[t]) continue;
+        if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
+        a.big_slots = 0;
         a.work_list = list;
         a.n_work_dev = count;
         a.n_work = (uint32_t)n;
@@ -319,22 +323,29 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     a_solo = a;
                     a_solo.pass_tier = 1;
                     a_solo.work_list = order.data();
-                    a_solo.n_work = n_hard;
+                    a_solo.n_work = solo;
                     a_solo.work_counter = counters + 1072;
                     a_solo.static_pct = 0;
                     a_solo.n_shards = 1;
                     a_solo.claim = 1;
                     a_solo.n_waves = solo;
                     a_solo.high_priority = 1;
-                    a_solo.overflow_list = last == 1 ? nullptr : lists[1].data();
-                    a_solo.overflow_count = last == 1 ? nullptr : counters + 1024 + 16;
-                    a.work_list = order.data() + n_hard;
-                    a.n_work = (uint32_t)n - n_hard;
+                    const int solo_list = launch[1] ? 1 : 0;
+                    const bool later = last > (launch[1] ? 1 : 0);
+                    a_solo.overflow_list = later ? lists[solo_list].data() : nullptr;
+                    a_solo.overflow_count = later ? counters + 1024 + 16 * solo_list : nullptr;
+                    a.work_list = order.data() + solo;
+                    a.n_work = (uint32_t)n - solo;
                 }
                 run_pass(n_waves ? n_waves : 1, 0, lds_bytes, solo);
             }
             else if (t == 1) run_pass(n_waves ? n_waves : 1, 0, lds2_bytes);
-            else if (t == 2) run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
+            else if (t == 2) {
+                a.big_ws = big_slots ? big_slices.data() : nullptr;
+                a.big_busy = counters + 1088;
+                a.big_slots = big_slots;
+                run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
+            }
             else run_pass(todo < 4 ? todo : 4, big_ws_bytes, 0);
         }
         if (t != last) {
@@ -372,9 +383,9 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
                       uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts,
-                      uint32_t solo_min_variants) {
+                      uint32_t solo_min_variants, uint32_t lds2_overflow_pass) {
     return emu_run(0, batch, refs, ref_lens, n_contigs, cfg, out, lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, ws_bytes, big_ws_bytes, n_waves,
-                   threads, tier_counts, solo_min_variants);
+                   threads, tier_counts, solo_min_variants, lds2_overflow_pass);
 }
 
 /* avk_optimize_pairs_batch on emulated wavefronts (default tier sizes) */
@@ -389,7 +400,7 @@ int emu_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const
     memset(&out, 0, sizeof(out));
     out.status = status;
     out.ed_h1 = ed1.data();
-    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 9 * 1024, 8, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0);
+    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 10 * 1024, 48, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0, 0);
     if (rc) return rc;
     for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && ed1[r] ? 1 : 0;
     return 0;

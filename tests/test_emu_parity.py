@@ -79,11 +79,17 @@ def test_results_do_not_depend_on_the_workspace_tier(oracle):
     lds2_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, lds2_bytes=40 * 1024, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
     hbm_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, lds2_bytes=0, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
     big_only = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=0, lds2_bytes=0, ws_bytes=0, big_ws_bytes=8 << 20, threads=EMU_THREADS)
-    tiny_lds = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=4096, lds_ed_cap=2, lds2_bytes=6144, lds2_ed_cap=4, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
-    for got in (lds_only, lds2_only, hbm_only, big_only, tiny_lds):
+    tiny = dict(sequences=True, lds_bytes=4096, lds_ed_cap=2, lds2_bytes=6144, lds2_ed_cap=4, ws_bytes=1 << 20, big_ws_bytes=8 << 20, threads=EMU_THREADS)
+    tiny_lds = emu_lib.compare_batch(batch, contigs, lds2_overflow_pass=1, solo_min_variants=0, **tiny)  # four-launch chain
+    tiny_solo = emu_lib.compare_batch(batch, contigs, solo_min_variants=3, **dict(tiny, lds2_bytes=40 * 1024, lds2_ed_cap=48))  # solo waves, overflow straight to the HBM tier
+    tiny.update(ws_bytes=12 * 1024)
+    tiny_hbm = emu_lib.compare_batch(batch, contigs, **tiny)  # tier-2 slices too small: big slices claimed in place
+    for got in (lds_only, lds2_only, hbm_only, big_only, tiny_lds, tiny_solo, tiny_hbm):
         assert got.diff(want) == []
     assert hbm_only.tier_counts[0] == 0 and hbm_only.tier_counts[1] == 0 and big_only.tier_counts[3] == batch.n_regions
     assert tiny_lds.tier_counts[1] > 0 and tiny_lds.tier_counts[2] > 0 and sum(tiny_lds.tier_counts) == batch.n_regions
+    assert tiny_solo.tier_counts[1] > 0 and tiny_solo.tier_counts[2] > 0 and sum(tiny_solo.tier_counts) == batch.n_regions
+    assert tiny_hbm.tier_counts[3] > 0 and tiny_hbm.tier_counts[4] == 0 and sum(tiny_hbm.tier_counts) == batch.n_regions
     starved = emu_lib.compare_batch(batch, contigs, lds_bytes=2048, lds_ed_cap=2, lds2_bytes=0, ws_bytes=0, big_ws_bytes=4096, threads=EMU_THREADS)
     assert set(starved.status.tolist()) <= {0, 21} and (starved.status == 21).any()
     assert starved.tier_counts[4] == int((starved.status == 21).sum())
