@@ -122,6 +122,7 @@ struct avk_ctx {
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
+    int64_t solo_regions_per_wave = 1; /* predicted-hard regions beyond solo waves x this lead the bulk list */
     int64_t lds2_overflow_pass = 0; /* 1: a launch of its own with large LDS slices between the bulk and the HBM tier */
     int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
     int64_t ws_bytes_per_wave = 1 << 20;
@@ -136,8 +137,8 @@ struct avk_ctx {
     size_t big_alloc = 0;
     /* measurement */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk1 = nullptr; /* ev0..ev1 all solver launches, ev0..evk1 the first (dominant) one */
-    hipStream_t side_stream = nullptr; /* solo launch */
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
     uint64_t last_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -160,7 +161,7 @@ struct avk_dev_batch {
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
     uint32_t *d_order = nullptr; /* work order of the first launch: [predicted-hard regions | the rest], most variants first */
-    uint32_t n_hard = 0;
+    avk::WorkPlan plan;
     bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
 };
@@ -247,6 +248,8 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     (void)hipEventCreate(&ctx->ev1);
     (void)hipEventCreate(&ctx->evk1);
     if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         avk_ctx_destroy(ctx);
@@ -270,7 +273,9 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
+    if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -309,6 +314,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->lds2_overflow_pass = value ? 1 : 0;
     } else if (n == "bulk_full_grid") {
         ctx->bulk_full_grid = value ? 1 : 0;
+    } else if (n == "solo_regions_per_wave") {
+        if (value < 1 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_regions_per_wave must be in [1, 1024]");
+        ctx->solo_regions_per_wave = value;
     } else if (n == "solo_blocks_max") {
         if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
         ctx->solo_blocks_max = value;
@@ -461,8 +469,8 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
      * rest; within each part the regions with the most variants (the expensive searches) are dealt first, so
      * they overlap with the bulk instead of forming the tail */
     std::vector<uint32_t> order;
-    db->n_hard = avk::plan_work_order(db->host, (uint64_t)ctx->lds_bytes_per_wave, (uint32_t)ctx->lds_ed_cap,
-                                      pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order);
+    db->plan = avk::plan_work_order(db->host, (uint64_t)ctx->lds_bytes_per_wave, (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
+                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order);
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
@@ -585,7 +593,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = db->d_order, *count = nullptr;
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
     int nlist = 0;
-    bool solo_pending = false;
+    bool solo_pending = false, hbm_solo_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -600,9 +608,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.overflow_count = nullptr;
         }
         const bool first_launch = list == db->d_order; /* ev0 sits right before it */
-        if (solo_pending && t >= 2) { /* the HBM launches read the list the solo launch appends to; the tier-1 launch does not */
-            AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            solo_pending = false;
+        if (t >= 2) { /* the HBM launches read the list the solo launches append to and share the HBM slices; the tier-1 launch does not */
+            if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
+            solo_pending = hbm_solo_pending = false;
         }
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
@@ -611,45 +620,89 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         a.claim = AVK_CLAIM;
         if (t == 0) {
             a.hbm_ws = nullptr;
-            /* Solo launch: the regions the host predicted to outgrow the small slice are solved AT THE SAME TIME by
-             * one-wave workgroups with a tier-1 slice each, launched on the side stream just before the bulk.  A solo
-             * workgroup's LDS displaces exactly one bulk workgroup, so the long searches overlap with the bulk instead
-             * of forming the tail of a second launch. */
-            uint32_t solo = 0;
-            if (use[1] && db->n_hard && ctx->solo_blocks_max && blocks >= 8 &&
+            /* Solo launches: the regions the host predicted to outgrow the small slice are solved AT THE SAME TIME, on the
+             * side stream, launched just before the bulk, so the long searches overlap with the bulk instead of forming
+             * the tail of a later launch:
+             *   class B (WorkPlan::n_hard): one-wave workgroups with a tier-1 LDS slice each; a solo workgroup's LDS
+             *           displaces exactly one bulk workgroup;
+             *   class C (WorkPlan::n_hbm):  predicted to outgrow tier 1 too: a small HBM-tier launch (its registers
+             *           displace about two bulk workgroups per workgroup).
+             * Both hand what they cannot hold to the list the first HBM launch of the main stream reads. */
+            const bool solo_ok = ctx->solo_blocks_max && blocks >= 8;
+            const bool hbm_solo_ok = solo_ok && launch[2] && db->plan.n_hbm;
+            const uint32_t n_c = hbm_solo_ok ? db->plan.n_hbm : 0u;          /* regions of the HBM solo launch */
+            const uint32_t n_front = db->plan.n_hbm + db->plan.n_hard - n_c; /* predicted-hard regions after them in d_order */
+            uint32_t solo = 0, solo_regions = 0, hbm_solo = 0;
+            if (solo_ok && use[1] && n_front &&
                 (size_t)ctx->lds2_bytes_per_wave <= 2 * (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave) {
-                solo = db->n_hard < (uint32_t)ctx->solo_blocks_max ? db->n_hard : (uint32_t)ctx->solo_blocks_max;
+                solo = n_front < (uint32_t)ctx->solo_blocks_max ? n_front : (uint32_t)ctx->solo_blocks_max;
                 if (solo > blocks / 4) solo = blocks / 4;
+                const uint64_t cap = (uint64_t)solo * (uint64_t)ctx->solo_regions_per_wave;
+                solo_regions = n_front < cap ? n_front : (uint32_t)cap; /* the others lead the bulk list */
+            }
+            if (n_c) {
+                hbm_solo = (n_c + 7) / 8;
+                if (hbm_solo > 64) hbm_solo = 64;
+                if (hbm_solo > blocks / 8) hbm_solo = blocks / 8;
+            }
+            const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
+            const bool later = last > solo_list;
+            if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
+            if (hbm_solo) {
+                AvkKernelArgs s = a;
+                s.pass_tier = 2;
+                s.work_list = db->d_order;
+                s.n_work = n_c;
+                s.work_counter = db->d_counters + 1076;
+                s.static_pct = 0;
+                s.n_shards = 1;
+                s.claim = 1;
+                s.n_waves = hbm_solo * waves_per_block;
+                s.high_priority = 1;
+                s.hbm_ws = ctx->d_ws; /* the later HBM launch of the main stream reuses these slices after the join */
+                s.big_ws = ctx->d_big;
+                s.big_busy = db->d_counters + 1088;
+                s.big_slots = big_slots;
+                s.overflow_list = nullptr; /* same capacities as the last tier: what does not fit fails with CAPACITY */
+                s.overflow_count = nullptr;
+                if (!big_slots && launch[3]) { /* the big tier has a launch of its own */
+                    s.overflow_list = lists[launch[1] ? 2 : 1];
+                    s.overflow_count = db->d_counters + 1024 + 16 * (launch[1] ? 2 : 1);
+                }
+                AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->ev_fork, 0));
+                hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_solo), dim3(256), 0, ctx->side_stream2, s);
+                AVK_HIP(ctx, hipGetLastError());
+                AVK_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side_stream2));
+                hbm_solo_pending = true;
             }
             if (solo) {
                 AvkKernelArgs s = a;
                 s.pass_tier = 1;
-                s.work_list = db->d_order;
-                s.n_work = solo; /* one region each: the hardest ones; the other predicted-hard regions lead the bulk list */
+                s.work_list = db->d_order + n_c;
+                s.n_work = solo_regions;
                 s.work_counter = db->d_counters + 1072;
                 s.static_pct = 0;
                 s.n_shards = 1;
                 s.claim = 1;
                 s.n_waves = solo;
                 s.high_priority = 1;
-                /* what outgrows tier 1 joins the list the first HBM launch reads */
-                const int solo_list = launch[1] ? 1 : 0;
-                const bool later = last > (launch[1] ? 1 : 0);
                 s.overflow_list = later ? lists[solo_list] : nullptr;
                 s.overflow_count = later ? db->d_counters + 1024 + 16 * solo_list : nullptr;
-                AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
                 hipLaunchKernelGGL(avk_region_kernel_lds, dim3(solo), dim3(64), (size_t)ctx->lds2_bytes_per_wave, ctx->side_stream, s);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
                 solo_pending = true;
-                a.work_list = db->d_order + solo;
-                a.n_work = (uint32_t)n - solo;
             }
-            /* the bulk grid keeps its full size: the last `solo` workgroups find no room until solo workgroups retire;
-             * they take no static share (n_waves counts the others) and help with the dynamically claimed tail */
-            a.n_waves = (blocks - solo) * waves_per_block;
-            hipLaunchKernelGGL(avk_region_kernel_lds, dim3(ctx->bulk_full_grid ? blocks : blocks - solo), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
+            if (solo || hbm_solo) {
+                a.work_list = db->d_order + n_c + solo_regions;
+                a.n_work = (uint32_t)n - n_c - solo_regions;
+            }
+            /* every workgroup of the three launches is resident at once */
+            uint32_t bulk = blocks - solo - 2 * hbm_solo;
+            if (ctx->bulk_full_grid) bulk = blocks;
+            a.n_waves = (blocks - solo - 2 * hbm_solo) * waves_per_block;
+            hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;
             uint32_t b2 = (uint32_t)ctx->n_cus < blocks ? (uint32_t)ctx->n_cus : blocks;
@@ -678,6 +731,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         }
     }
     if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+    if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
     hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally,
                        (uint64_t *)tally_dev, db->d_counters, (unsigned)AVK_N_COUNTERS);
     AVK_HIP(ctx, hipGetLastError());

@@ -249,54 +249,62 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
 }
 
 
-/* Work order of the first launch and the prediction of which regions outgrow the small LDS slice.
- * order = [hard regions, most variants first | the rest, most variants first]; returns the number of hard ones.
- * The prediction mirrors the workspace carve of solve_region_tier (avk_solver.inl): a phasing search over N
- * variants keeps about 2N+1 nodes alive; a region is "hard" when those do not fit tier0_bytes or when it has
- * at least solo_min_variants variants.  A wrong guess only costs time: a hard region solved by a solo wave has
- * more room than it needed, a missed one overflows into the tier-1 launch as before. */
-inline uint32_t plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint32_t solo_min_variants, uint32_t max_branch,
-                                std::vector<uint32_t> *order) {
+/* Work order of the first launch and the prediction of which regions outgrow the LDS slices.
+ * order = [class C | class B | the rest], each part with the most variants first:
+ *   class C  predicted to outgrow even a tier-1 slice (worst case, about 5.5 N nodes alive): solved by the HBM solo launch;
+ *   class B  predicted to outgrow the small slice (typical case, about 2N+1 nodes alive) or with at least
+ *            solo_min_variants variants: solved by the solo waves with a tier-1 slice each;
+ *   the rest goes to the bulk launch.
+ * The prediction mirrors the workspace carve of solve_region_tier (avk_solver.inl).  A wrong guess only costs
+ * time: a region solved in a larger class had more room than it needed, a missed one overflows into the next
+ * tier's launch as before. */
+struct WorkPlan {
+    uint32_t n_hbm = 0;  /* class C */
+    uint32_t n_hard = 0; /* class B */
+};
+
+inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
+                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
-    std::vector<uint8_t> hard(n, 0);
-    uint64_t n_hard = 0;
+    std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk */
+    WorkPlan plan;
+    auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
+        const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
+        const uint64_t maxT = dr.t_cnt > dr.q_cnt ? dr.t_cnt : dr.q_cnt;
+        const uint64_t alw = maxT ? (maxT + 63) >> 6 : 1;
+        uint64_t cap = tier_cap;
+        if (cap && dr.ed_bound < cap) cap = dr.ed_bound ? dr.ed_bound : 1;
+        uint64_t wfcap = cap ? 2 * cap + 2 : 2 * seqcap + 4;
+        if (wfcap > 2 * seqcap + 4) wfcap = 2 * seqcap + 4;
+        const uint64_t hapA = 48 + 16 * alw + 4 * wfcap + 2 * seqcap, nodeA = 8 + 2 * hapA;
+        const uint64_t optcap = max_branch < 4096 ? max_branch : 4096;
+        const uint64_t fixed = dr.len + 8 + 28 * N + alle + 8 + 8 * N + 16 + 32 + 4 * optcap + 8 * 8 * alw + 8 * 4 * alw * 8 + 32 + 64;
+        return fixed + nodes * (nodeA + 16);
+    };
     for (uint64_t r = 0; r < n; ++r) {
         const AvkDevRegion &dr = pb.regions[r];
         const uint64_t N = (uint64_t)dr.t_cnt + dr.q_cnt;
         if (dr.pre_status || N == 0 || solo_min_variants == 0) continue;
-        uint64_t alle = 0, g[2] = {0, 0};
-        for (uint64_t k = 0; k < N; ++k) {
-            const AvkDevVariant &v = pb.variants[dr.v_off + k];
-            alle += (uint64_t)v.a0_len + v.a1_len;
-            if (v.a1_len > v.a0_len) g[k < dr.t_cnt ? 0 : 1] += v.a1_len - v.a0_len;
-        }
-        const uint64_t seqcap = ((uint64_t)dr.len + (g[0] > g[1] ? g[0] : g[1]) + 7) & ~7ull;
-        const uint64_t maxT = dr.t_cnt > dr.q_cnt ? dr.t_cnt : dr.q_cnt;
-        const uint64_t alw = maxT ? (maxT + 63) >> 6 : 1;
-        uint64_t cap0 = tier0_ed_cap;
-        if (cap0 && dr.ed_bound < cap0) cap0 = dr.ed_bound ? dr.ed_bound : 1;
-        uint64_t wfcap = cap0 ? 2 * cap0 + 2 : 2 * seqcap + 4;
-        if (wfcap > 2 * seqcap + 4) wfcap = 2 * seqcap + 4;
-        const uint64_t hapA = 48 + 16 * alw + 4 * wfcap + 2 * seqcap, nodeA = 8 + 2 * hapA;
-        const uint64_t optcap = max_branch < 4096 ? max_branch : 4096;
-        const uint64_t fixed = dr.len + 8 + 28 * N + alle + 8 + 8 * N + 16 + 4 * optcap + 8 * 8 * alw + 8 * 4 * alw * 8 + 32 + 64;
-        const uint64_t nodes = 2 * N + 1;
-        if (N >= solo_min_variants || fixed + nodes * (nodeA + 16) > tier0_bytes) {
-            hard[r] = 1;
-            n_hard += 1;
+        const uint64_t alle = dr.alle_bytes, grow = dr.grow;
+        if (tier1_bytes && need(dr, N, alle, grow, tier1_ed_cap, (11 * N + 1) / 2) > tier1_bytes) {
+            cls[r] = 0;
+            plan.n_hbm += 1;
+        } else if (N >= solo_min_variants || need(dr, N, alle, grow, tier0_ed_cap, 2 * N + 1) > tier0_bytes) {
+            cls[r] = 1;
+            plan.n_hard += 1;
         }
     }
-    /* counting sort by variant count, descending, hard regions in front */
-    std::vector<uint64_t> cnt(2 * 33 + 1, 0);
+    /* counting sort by class, then by variant count, descending */
+    std::vector<uint64_t> cnt(3 * 33 + 1, 0);
     auto key = [&](uint64_t r) {
         const uint32_t k = pb.regions[r].t_cnt + pb.regions[r].q_cnt;
-        return (hard[r] ? 0u : 33u) + (32u - (k > 32u ? 32u : k));
+        return 33u * cls[r] + (32u - (k > 32u ? 32u : k));
     };
     for (uint64_t r = 0; r < n; ++r) cnt[key(r) + 1] += 1;
     for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
     for (uint64_t r = 0; r < n; ++r) (*order)[cnt[key(r)]++] = (uint32_t)r;
-    return (uint32_t)n_hard;
+    return plan;
 }
 
 } // namespace avk

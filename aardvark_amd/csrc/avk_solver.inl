@@ -1580,7 +1580,6 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
  * overflow list for the next launch; after the last tier it fails with AVK_ST_CAPACITY. */
 template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     const u32 lane = (u32)wv_lane();
-    u32 tally[5] = {0, 0, 0, 0, 0}; /* a wave's share of a batch keeps every counter far below 2^32 */
     u32 n_ok = 0, n_err = 0, n_cap = 0, n_big = 0; /* n_big: finished (either way) in a tier-3 slice */
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
@@ -1712,9 +1711,14 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             continue;
         }
         if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
-        for (int j = 0; j < 5; ++j) {
-            const u32 i = (u32)j * 64 + lane;
-            if (i < AVK_N_GROUPS * AVK_N_FIELDS) tally[j] += c.gm[i];
+        { /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters go
+           * straight into one of the partial tallies (fire-and-forget adds, a handful of lanes per region) */
+            u64 *part_r = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
+            for (int j = 0; j < 5; ++j) {
+                const u32 i = (u32)j * 64 + lane;
+                const u32 v = i < AVK_N_GROUPS * AVK_N_FIELDS ? c.gm[i] : 0u;
+                if (v) avk_atomic_add_u64_global(part_r + i, v);
+            }
         }
         if (a.seq_bytes && a.seq_len && reg.seq_stride) { /* SequenceBundle, waffle_solver.rs:237-246 */
             u8 *wn = c.pool + (u64)winner * c.nodeA_bytes;
@@ -1744,10 +1748,6 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into
      * one of the partial copies; avk_tally_reduce sums the copies */
     u64 *part = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
-    for (int j = 0; j < 5; ++j) {
-        const u32 i = (u32)j * 64 + lane;
-        if (i < AVK_N_GROUPS * AVK_N_FIELDS && tally[j]) avk_atomic_add_u64_global(part + i, tally[j]);
-    }
     if (lane == 0) {
         if (n_ok) avk_atomic_add_u64_global(part + AVK_TALLY_SOLVED, n_ok);
         if (n_err) avk_atomic_add_u64_global(part + AVK_TALLY_ERRORS, n_err);

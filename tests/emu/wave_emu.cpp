@@ -291,7 +291,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint8_t> big_slices(big_slots ? (size_t)big_slots * big_ws_bytes : 0);
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
-    const uint32_t n_hard = avk::plan_work_order(pb, lds_bytes, lds_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
+    const avk::WorkPlan plan = avk::plan_work_order(pb, lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
     const uint32_t *list = order.data(), *count = nullptr;
     int nlist = 0;
     for (int t = 0; t < 4 && n; ++t) {
@@ -316,13 +316,41 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         const uint32_t todo = count ? *count : (uint32_t)n;
         if (todo) {
             if (t == 0) {
+                /* the three concurrent launches of run_internal, one after the other: HBM solo (class C), LDS solo (class B), bulk */
+                const bool solo_ok = solo_min_variants != 0;
+                const uint32_t n_c = solo_ok && launch[2] ? plan.n_hbm : 0u;
+                const uint32_t n_front = plan.n_hbm + plan.n_hard - n_c;
+                const int solo_list = launch[1] ? 1 : 0;
+                const bool later = last > solo_list;
+                if (n_c) {
+                    AvkKernelArgs keep = a;
+                    a.pass_tier = 2;
+                    a.work_list = order.data();
+                    a.n_work = n_c;
+                    a.work_counter = counters + 1076;
+                    a.static_pct = 0;
+                    a.n_shards = 1;
+                    a.claim = 1;
+                    a.high_priority = 1;
+                    a.big_ws = big_slots ? big_slices.data() : nullptr;
+                    a.big_busy = counters + 1088;
+                    a.big_slots = big_slots;
+                    a.overflow_list = nullptr;
+                    a.overflow_count = nullptr;
+                    if (!big_slots && launch[3]) {
+                        a.overflow_list = lists[launch[1] ? 2 : 1].data();
+                        a.overflow_count = counters + 1024 + 16 * (launch[1] ? 2 : 1);
+                    }
+                    run_pass(n_waves / 2 ? n_waves / 2 : 1, ws_bytes, 0);
+                    a = keep;
+                }
                 uint32_t solo = 0;
-                if (use[1] && n_hard && lds2_bytes >= lds_bytes) {
+                if (solo_ok && use[1] && n_front && lds2_bytes >= lds_bytes) {
                     solo = n_waves / 4 ? n_waves / 4 : 1;
-                    if (solo > n_hard) solo = n_hard;
+                    if (solo > n_front) solo = n_front;
                     a_solo = a;
                     a_solo.pass_tier = 1;
-                    a_solo.work_list = order.data();
+                    a_solo.work_list = order.data() + n_c;
                     a_solo.n_work = solo;
                     a_solo.work_counter = counters + 1072;
                     a_solo.static_pct = 0;
@@ -330,13 +358,11 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     a_solo.claim = 1;
                     a_solo.n_waves = solo;
                     a_solo.high_priority = 1;
-                    const int solo_list = launch[1] ? 1 : 0;
-                    const bool later = last > (launch[1] ? 1 : 0);
                     a_solo.overflow_list = later ? lists[solo_list].data() : nullptr;
                     a_solo.overflow_count = later ? counters + 1024 + 16 * solo_list : nullptr;
-                    a.work_list = order.data() + solo;
-                    a.n_work = (uint32_t)n - solo;
                 }
+                a.work_list = order.data() + n_c + solo;
+                a.n_work = (uint32_t)n - n_c - solo;
                 run_pass(n_waves ? n_waves : 1, 0, lds_bytes, solo);
             }
             else if (t == 1) run_pass(n_waves ? n_waves : 1, 0, lds2_bytes);
