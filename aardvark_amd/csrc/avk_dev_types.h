@@ -95,6 +95,9 @@ struct AvkKernelArgs {
     uint32_t static_pct;       /* share of the work list dealt statically (item k to wave k mod n_waves), the rest is claimed */
     uint32_t n_shards;         /* claim counters in use (1..8) */
     uint32_t claim;            /* regions per claim */
+    uint32_t esc_bytes;        /* bulk launch: when a region outgrows its wave's slice, the wave takes the workgroup's whole LDS
+                                  (esc_bytes, the last 64 bytes of the allocation hold the control words) while its sibling waves
+                                  park between regions, and solves it again at once with tier 1's cap — no prediction, no later launch */
     uint32_t high_priority;    /* raise the wave priority (the solo launch of the predicted-hard regions) */
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;

@@ -35,13 +35,18 @@ __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel
     const unsigned wave_in_block = threadIdx.x >> 6;
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     if (a.high_priority) __builtin_amdgcn_s_setprio(3); /* solo launch: the long searches are the critical path */
-    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
+    if (a.esc_bytes) { /* control words of the in-workgroup escalation (AvkKernelArgs::esc_bytes) */
+        if (threadIdx.x < 8) ((unsigned *)(avk_smem + a.esc_bytes))[threadIdx.x] = 0;
+        __syncthreads();
+    }
+    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes, a.esc_bytes ? avk_smem : (unsigned char *)0,
+                             wave_in_block, blockDim.x >> 6);
 }
 
 /* HBM passes: regions that outgrew the LDS tiers, in the wave's private HBM slice */
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    avk::region_worker<false>(a, wave_id, (unsigned char *)0);
+    avk::region_worker<false>(a, wave_id, (unsigned char *)0, (unsigned char *)0, 0, 0);
 }
 
 /* packs the uploaded reference: 16 bases per word, 2 bits each, plus one flag per word for anything that is
@@ -122,7 +127,9 @@ struct avk_ctx {
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
-    int64_t solo_regions_per_wave = 1; /* predicted-hard regions beyond solo waves x this lead the bulk list */
+    int64_t class_c_nodes_x2 = 8; /* a region is sent to the HBM solo launch when 0.5 x this x N nodes outgrow a tier-1 slice */
+    int64_t solo_regions_per_wave = 4; /* predicted-hard regions beyond solo waves x this lead the bulk list */
+    int64_t lds_escalation = 1; /* in-workgroup escalation of the bulk launch (AvkKernelArgs::esc_bytes) */
     int64_t lds2_overflow_pass = 0; /* 1: a launch of its own with large LDS slices between the bulk and the HBM tier */
     int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
     int64_t ws_bytes_per_wave = 1 << 20;
@@ -310,6 +317,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "solo_min_variants") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "solo_min_variants must not be negative");
         ctx->solo_min_variants = value;
+    } else if (n == "lds_escalation") {
+        ctx->lds_escalation = value ? 1 : 0;
     } else if (n == "lds2_overflow_pass") {
         ctx->lds2_overflow_pass = value ? 1 : 0;
     } else if (n == "bulk_full_grid") {
@@ -317,6 +326,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "solo_regions_per_wave") {
         if (value < 1 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_regions_per_wave must be in [1, 1024]");
         ctx->solo_regions_per_wave = value;
+    } else if (n == "class_c_nodes_x2") {
+        if (value < 1 || value > 1000) return fail(ctx, AVK_E_ARG, "class_c_nodes_x2 must be in [1, 1000]");
+        ctx->class_c_nodes_x2 = value;
     } else if (n == "solo_blocks_max") {
         if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
         ctx->solo_blocks_max = value;
@@ -470,7 +482,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
      * they overlap with the bulk instead of forming the tail */
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, (uint64_t)ctx->lds_bytes_per_wave, (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
-                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order);
+                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2);
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
@@ -615,6 +627,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         }
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
+        a.esc_bytes = 0;
         a.static_pct = AVK_STATIC_PCT;
         a.n_shards = 8;
         a.claim = AVK_CLAIM;
@@ -702,6 +715,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             uint32_t bulk = blocks - solo - 2 * hbm_solo;
             if (ctx->bulk_full_grid) bulk = blocks;
             a.n_waves = (blocks - solo - 2 * hbm_solo) * waves_per_block;
+            if (ctx->lds_escalation && ctx->lds_bytes_per_wave >= 1024) a.esc_bytes = (uint32_t)(waves_per_block * ctx->lds_bytes_per_wave - 64);
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;

@@ -251,7 +251,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
 
 /* Work order of the first launch and the prediction of which regions outgrow the LDS slices.
  * order = [class C | class B | the rest], each part with the most variants first:
- *   class C  predicted to outgrow even a tier-1 slice (worst case, about 5.5 N nodes alive): solved by the HBM solo launch;
+ *   class C  predicted to outgrow even a tier-1 slice (upper range, about 4 N nodes alive): solved by the HBM solo launch;
  *   class B  predicted to outgrow the small slice (typical case, about 2N+1 nodes alive) or with at least
  *            solo_min_variants variants: solved by the solo waves with a tier-1 slice each;
  *   the rest goes to the bulk launch.
@@ -264,7 +264,7 @@ struct WorkPlan {
 };
 
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
-                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order) {
+                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 8) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk */
@@ -287,7 +287,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         const uint64_t N = (uint64_t)dr.t_cnt + dr.q_cnt;
         if (dr.pre_status || N == 0 || solo_min_variants == 0) continue;
         const uint64_t alle = dr.alle_bytes, grow = dr.grow;
-        if (tier1_bytes && need(dr, N, alle, grow, tier1_ed_cap, (11 * N + 1) / 2) > tier1_bytes) {
+        if (tier1_bytes && need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes) {
             cls[r] = 0;
             plan.n_hbm += 1;
         } else if (N >= solo_min_variants || need(dr, N, alle, grow, tier0_ed_cap, 2 * N + 1) > tier0_bytes) {

@@ -1578,12 +1578,60 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
 /* PASS_LDS: this launch solves regions in the wave's LDS slice; otherwise in its HBM slice
  * (a.pass_tier says which tier's capacities apply).  A region that does not fit is appended to the
  * overflow list for the next launch; after the last tier it fails with AVK_ST_CAPACITY. */
-template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+/* ---- in-workgroup escalation (LDS launches): control words at the end of the workgroup's LDS.
+ * ctl[0] lock = ticket of the wave that owns the whole LDS (0 = nobody), ctl[1] ticket counter,
+ * ctl[2 + w] state of wave w: 0 running, a ticket = parked for that ticket, 0xFFFFFFFF gone.
+ * A wave parks only between regions (nothing in its slice is live then); the owner waits until every sibling
+ * acknowledged ITS ticket, so a sibling that is just leaving an earlier park cannot slip back into its slice. */
+AVK_DEV u32 wg_word(u32 *p) {
+    u32 v = 0;
+    if (wv_lane() == 0) v = avk_wg_load(p);
+    return wv_uni(wv_shfl(v, 0));
+}
+AVK_DEV void wg_park(u32 *ctl, u32 w, u32 ticket) {
+    for (;;) {
+        if (wv_lane() == 0) avk_wg_store(ctl + 2 + w, ticket);
+        u32 cur;
+        do {
+            avk_sleep();
+            cur = wg_word(ctl);
+        } while (cur == ticket);
+        if (cur == 0) {
+            if (wv_lane() == 0) avk_wg_store(ctl + 2 + w, 0u);
+            return; /* the caller looks at the lock again before it touches its slice */
+        }
+        ticket = cur;
+    }
+}
+AVK_DEV void wg_acquire(u32 *ctl, u32 w, u32 n_wg_waves) {
+    u32 ticket;
+    for (;;) {
+        u32 t = 0, old = 0;
+        if (wv_lane() == 0) {
+            t = avk_wg_add(ctl + 1, 1u) + 1u;
+            old = avk_wg_cas(ctl, 0u, t);
+        }
+        ticket = wv_uni(wv_shfl(t, 0));
+        old = wv_uni(wv_shfl(old, 0));
+        if (old == 0) break;
+        wg_park(ctl, w, old); /* a sibling owns the LDS: it needs this wave's slice too */
+    }
+    for (u32 o = 0; o < n_wg_waves; ++o) {
+        if (o == w) continue;
+        for (;;) {
+            const u32 s = wg_word(ctl + 2 + o);
+            if (s == ticket || s == 0xFFFFFFFFu) break;
+            avk_sleep();
+        }
+    }
+}
+
+template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice, u8 *wg_lds, u32 wave_in_wg, u32 n_wg_waves) {
     const u32 lane = (u32)wv_lane();
     u32 n_ok = 0, n_err = 0, n_cap = 0, n_big = 0; /* n_big: finished (either way) in a tier-3 slice */
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
-    const u64 ws_bytes = a.tier[tier].ws_bytes;
+    const u64 ws_bytes = a.tier[tier].ws_bytes - (PASS_LDS && wg_lds ? 64u : 0u); /* the control words sit at the end of the last slice */
     const u32 ed_cap = a.tier[tier].ed_cap;
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_work;
 
@@ -1602,7 +1650,11 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     const u32 home = (wave_id >> 2) % n_shards;
     u32 static_next = wave_id < a.n_waves ? wave_id : 0xFFFFFFFFu; /* waves beyond n_waves (placed late) only claim */
     u32 shard_i = 0, claim_base = 0, claim_left = 0;
+    u32 *const wg_ctl = PASS_LDS && wg_lds ? (u32 *)(wg_lds + a.esc_bytes) : (u32 *)0;
     for (;;) {
+        if (PASS_LDS && wg_ctl) { /* a sibling wants the whole LDS: stay out of the slice until it is done */
+            for (u32 t = wg_word(wg_ctl); t != 0; t = wg_word(wg_ctl)) wg_park(wg_ctl, wave_in_wg, t);
+        }
         u32 idx = 0;
         if (static_next < n_static) {
             idx = static_next;
@@ -1661,7 +1713,18 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         int st;
         for (;;) {
             st = solve_region_tier(a, r, cur_ws, cur_bytes, cur_cap, c, out, winner);
-            if (PASS_LDS || st != RS_OVERFLOW || slot != 0xFFFFFFFFu || a.big_slots == 0) break;
+            if (st != RS_OVERFLOW || slot != 0xFFFFFFFFu) break;
+            if (PASS_LDS) {
+                if (!wg_ctl) break;
+                wg_acquire(wg_ctl, wave_in_wg, n_wg_waves);
+                slot = 0; /* owns the workgroup's LDS */
+                cur_ws = wg_lds;
+                cur_bytes = a.esc_bytes;
+                cur_cap = a.tier[1].ws_bytes ? a.tier[1].ed_cap : ed_cap;
+                cur_tier = 1;
+                continue;
+            }
+            if (a.big_slots == 0) break;
             u32 got = 0xFFFFFFFFu;
             if (lane == 0) {
                 for (u32 probe = wave_id % a.big_slots;; probe = probe + 1 < a.big_slots ? probe + 1 : 0) { /* holders never wait: this ends */
@@ -1680,9 +1743,14 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             cur_tier = 3;
         }
 #define AVK_RELEASE_SLOT()                                        \
-    if (!PASS_LDS && slot != 0xFFFFFFFFu) {                       \
-        avk_release_agent();                                      \
-        if (lane == 0) avk_st_agent_u32(a.big_busy + slot, 0u);   \
+    if (slot != 0xFFFFFFFFu) {                                    \
+        if (PASS_LDS) {                                           \
+            wv_sync();                                            \
+            if (lane == 0) avk_wg_store(wg_ctl, 0u);              \
+        } else {                                                  \
+            avk_release_agent();                                  \
+            if (lane == 0) avk_st_agent_u32(a.big_busy + slot, 0u); \
+        }                                                         \
     }
         if (st == RS_OVERFLOW) {
             if (a.overflow_list) { /* hand over to the next tier's launch */
@@ -1745,6 +1813,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
 #endif
     }
 
+    if (PASS_LDS && wg_ctl && lane == 0) avk_wg_store(wg_ctl + 2 + wave_in_wg, 0xFFFFFFFFu); /* never parks again */
     /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into
      * one of the partial copies; avk_tally_reduce sums the copies */
     u64 *part = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
@@ -1752,7 +1821,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         if (n_ok) avk_atomic_add_u64_global(part + AVK_TALLY_SOLVED, n_ok);
         if (n_err) avk_atomic_add_u64_global(part + AVK_TALLY_ERRORS, n_err);
         if (n_ok + n_err - n_cap - n_big) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + tier, n_ok + n_err - n_cap - n_big);
-        if (n_big) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 3, n_big);
+        if (n_big) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + (PASS_LDS ? 1 : 3), n_big);
         if (n_cap) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 4, n_cap);
     }
 }

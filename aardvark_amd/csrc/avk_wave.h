@@ -29,6 +29,7 @@ namespace avk_emu {
  * deposited values.  `site` must be identical on all lanes (checked: catches divergent use). */
 const uint64_t *gather(uint64_t v, uint32_t site);
 int lane();
+void yield(); /* lets the other emulated waves (OS threads) run */
 } // namespace avk_emu
 #define AVK_SITE ((uint32_t)__LINE__)
 
@@ -92,7 +93,15 @@ AVK_DEV uint32_t avk_ld_agent_u32(const uint32_t *p) { return __atomic_load_n(p,
 AVK_DEV void avk_st_agent_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 AVK_DEV void avk_release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
 AVK_DEV void avk_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
-AVK_DEV void avk_sleep() {}
+AVK_DEV void avk_sleep() { avk_emu::yield(); }
+/* words shared by the waves of one workgroup (LDS on the device) */
+AVK_DEV uint32_t avk_wg_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
+AVK_DEV void avk_wg_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
+AVK_DEV uint32_t avk_wg_add(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_ACQ_REL); }
+AVK_DEV uint32_t avk_wg_cas(uint32_t *p, uint32_t expect, uint32_t desired) {
+    __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
+    return expect;
+}
 AVK_DEV int avk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 
@@ -169,6 +178,14 @@ AVK_DEV void avk_release_agent() {
 }
 AVK_DEV void avk_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 AVK_DEV void avk_sleep() { __builtin_amdgcn_s_sleep(32); }
+/* words shared by the waves of one workgroup (they live in LDS) */
+AVK_DEV uint32_t avk_wg_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AVK_DEV void avk_wg_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AVK_DEV uint32_t avk_wg_add(uint32_t *p, uint32_t v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+AVK_DEV uint32_t avk_wg_cas(uint32_t *p, uint32_t expect, uint32_t desired) {
+    __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return expect;
+}
 AVK_DEV int avk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 AVK_DEV int avk_popc64(uint64_t x) { return __popcll(x); }
 #endif

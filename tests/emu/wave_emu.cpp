@@ -65,6 +65,7 @@ struct Wave {
 static thread_local Wave *t_wave = nullptr;
 
 int lane() { return t_wave->cur; }
+void yield() { std::this_thread::yield(); }
 
 static void switch_to(Wave *w, int from, int to) {
     w->cur = to;
@@ -153,12 +154,14 @@ struct WaveTask {
     const AvkKernelArgs *args;
     uint32_t wave_id;
     uint8_t *lds;
+    uint8_t *wg_lds = nullptr; /* the workgroup's whole LDS when the in-workgroup escalation is on */
+    uint32_t wave_in_wg = 0, n_wg_waves = 0;
 };
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
-    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds);
-    else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
+    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds, t->wg_lds, t->wave_in_wg, t->n_wg_waves);
+    else avk::region_worker<false>(*t->args, t->wave_id, nullptr, nullptr, 0, 0);
 }
 
 } // namespace
@@ -172,7 +175,7 @@ extern "C" {
 static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
                       uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts,
-                      uint32_t solo_min_variants, uint32_t lds2_overflow_pass) {
+                      uint32_t solo_min_variants, uint32_t lds2_overflow_pass, uint32_t lds_escalation) {
     std::vector<uint64_t> base(n_contigs), lens(n_contigs);
     uint64_t total = 0;
     for (uint32_t c = 0; c < n_contigs; ++c) {
@@ -269,15 +272,47 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             std::vector<uint8_t> ldsbuf(lds ? (solo_waves && lds2_bytes > lds ? lds2_bytes : lds) : 8);
             for (;;) {
                 uint32_t wid = next.fetch_add(1);
-                if (wid >= waves + solo_waves) break;
+                if (wid >= (a.esc_bytes ? 0u : waves) + solo_waves) break;
                 const bool solo = wid < solo_waves;
                 WaveTask t{solo ? &a_solo : &a, solo ? wid : wid - solo_waves, lds ? ldsbuf.data() : nullptr};
                 avk_emu::run_wave(&w, lane_main, &t);
             }
         };
+        /* in-workgroup escalation: the 4 waves of a workgroup run side by side (one OS thread each) on one LDS buffer */
+        std::atomic<uint32_t> next_wg(0);
+        auto wg_worker = [&]() {
+            const uint32_t n_wg = (waves + 3) / 4;
+            std::vector<uint8_t> wgbuf(4 * lds + 64);
+            for (;;) {
+                const uint32_t g = next_wg.fetch_add(1);
+                if (g >= n_wg) break;
+                const uint32_t alive = waves - 4 * g < 4 ? waves - 4 * g : 4;
+                uint32_t *ctl = (uint32_t *)(wgbuf.data() + a.esc_bytes);
+                for (int k = 0; k < 8; ++k) ctl[k] = 0;
+                std::vector<std::thread> wt;
+                for (uint32_t k = 0; k < alive; ++k)
+                    wt.emplace_back([&, k]() {
+                        avk_emu::Wave w;
+                        w.stack_bytes = 256 * 1024;
+                        std::vector<char> stacks(64 * w.stack_bytes + 64);
+                        w.stacks = stacks.data();
+                        WaveTask t{&a, 4 * g + k, wgbuf.data() + (size_t)k * lds};
+                        t.wg_lds = wgbuf.data();
+                        t.wave_in_wg = k;
+                        t.n_wg_waves = alive;
+                        avk_emu::run_wave(&w, lane_main, &t);
+                    });
+                for (auto &x : wt) x.join();
+            }
+        };
         std::vector<std::thread> ts;
         for (int i = 0; i < threads; ++i) ts.emplace_back(worker);
         for (auto &t : ts) t.join();
+        if (a.esc_bytes && lds) {
+            std::vector<std::thread> tg;
+            for (int i = 0; i < (threads + 3) / 4; ++i) tg.emplace_back(wg_worker);
+            for (auto &t : tg) t.join();
+        }
     };
 
     /* the same four tier launches as avk_compare_resident (aardvark_amd/csrc/avk_host.hip) */
@@ -302,6 +337,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         a.n_work_dev = count;
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
+        a.esc_bytes = 0;
         a.static_pct = AVK_STATIC_PCT;
         a.n_shards = 8;
         a.claim = AVK_CLAIM;
@@ -363,7 +399,9 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 }
                 a.work_list = order.data() + n_c + solo;
                 a.n_work = (uint32_t)n - n_c - solo;
+                if (lds_escalation && lds_bytes >= 1024) a.esc_bytes = (uint32_t)(4 * lds_bytes - 64);
                 run_pass(n_waves ? n_waves : 1, 0, lds_bytes, solo);
+                a.esc_bytes = 0;
             }
             else if (t == 1) run_pass(n_waves ? n_waves : 1, 0, lds2_bytes);
             else if (t == 2) {
@@ -409,9 +447,9 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,
                       uint32_t lds2_ed_cap, uint64_t ws_bytes, uint64_t big_ws_bytes, uint32_t n_waves, int threads, uint64_t *tier_counts,
-                      uint32_t solo_min_variants, uint32_t lds2_overflow_pass) {
+                      uint32_t solo_min_variants, uint32_t lds2_overflow_pass, uint32_t lds_escalation) {
     return emu_run(0, batch, refs, ref_lens, n_contigs, cfg, out, lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, ws_bytes, big_ws_bytes, n_waves,
-                   threads, tier_counts, solo_min_variants, lds2_overflow_pass);
+                   threads, tier_counts, solo_min_variants, lds2_overflow_pass, lds_escalation);
 }
 
 /* avk_optimize_pairs_batch on emulated wavefronts (default tier sizes) */
@@ -426,7 +464,7 @@ int emu_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const
     memset(&out, 0, sizeof(out));
     out.status = status;
     out.ed_h1 = ed1.data();
-    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 10 * 1024, 48, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0, 0);
+    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 10 * 1024, 48, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0, 0, 1);
     if (rc) return rc;
     for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && ed1[r] ? 1 : 0;
     return 0;

@@ -18,7 +18,7 @@ def load():
         lib = C.CDLL(os.path.join(EMU_DIR, "libavk_emu.so"))
         lib.emu_compare_batch.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.POINTER(AvkCompareConfig),
                                           C.POINTER(AvkResultBatch), C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,
-                                          C.c_uint32, C.c_int, u64p, C.c_uint32, C.c_uint32]
+                                          C.c_uint32, C.c_int, u64p, C.c_uint32, C.c_uint32, C.c_uint32]
         lib.emu_optimize_pairs_batch.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.c_uint32,
                                                  C.POINTER(C.c_int32), u8p, C.c_int]
         _lib = lib
@@ -27,7 +27,7 @@ def load():
 
 def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False,
                   lds_bytes=10 * 1024, lds_ed_cap=48, lds2_bytes=40 * 1024, lds2_ed_cap=48, ws_bytes=1 << 20, big_ws_bytes=64 << 20,
-                  n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0):
+                  n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1):
     lib = load()
     cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
     res = ResultBatch(batch, sequences=sequences)
@@ -35,7 +35,7 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     cb, ro = batch.c_struct(), res.c_struct()
     tiers = (C.c_uint64 * 5)()
     rc = lib.emu_compare_batch(C.byref(cb), cs.ptrs, cs.lens, cs.n, C.byref(cfg), C.byref(ro), lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap,
-                               ws_bytes, big_ws_bytes, n_waves, threads, tiers, solo_min_variants, lds2_overflow_pass)
+                               ws_bytes, big_ws_bytes, n_waves, threads, tiers, solo_min_variants, lds2_overflow_pass, lds_escalation)
     assert rc == 0
     res.tier_counts = [int(x) for x in tiers]
     return res

@@ -84,7 +84,11 @@ def test_results_do_not_depend_on_the_workspace_tier(oracle):
     tiny_solo = emu_lib.compare_batch(batch, contigs, solo_min_variants=3, **dict(tiny, lds2_bytes=40 * 1024, lds2_ed_cap=48))  # solo waves, overflow straight to the HBM tier
     tiny.update(ws_bytes=12 * 1024)
     tiny_hbm = emu_lib.compare_batch(batch, contigs, **tiny)  # tier-2 slices too small: big slices claimed in place
-    for got in (lds_only, lds2_only, hbm_only, big_only, tiny_lds, tiny_solo, tiny_hbm):
+    # in-workgroup escalation: a wave that outgrows its 4 KB slice takes its workgroup's 16 KB while the siblings park
+    tiny_esc = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=4096, lds_ed_cap=48, solo_min_variants=0, n_waves=8, threads=EMU_THREADS)
+    tiny_noesc = emu_lib.compare_batch(batch, contigs, sequences=True, lds_bytes=4096, lds_ed_cap=48, solo_min_variants=0, lds_escalation=0, threads=EMU_THREADS)
+    assert tiny_esc.tier_counts[1] > 0 and tiny_noesc.tier_counts[1] == 0
+    for got in (lds_only, lds2_only, hbm_only, big_only, tiny_lds, tiny_solo, tiny_hbm, tiny_esc, tiny_noesc):
         assert got.diff(want) == []
     assert hbm_only.tier_counts[0] == 0 and hbm_only.tier_counts[1] == 0 and big_only.tier_counts[3] == batch.n_regions
     assert tiny_lds.tier_counts[1] > 0 and tiny_lds.tier_counts[2] > 0 and sum(tiny_lds.tier_counts) == batch.n_regions
