@@ -39,14 +39,13 @@ __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel
         if (threadIdx.x < 8) ((unsigned *)(avk_smem + a.esc_bytes))[threadIdx.x] = 0;
         __syncthreads();
     }
-    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes, a.esc_bytes ? avk_smem : (unsigned char *)0,
-                             wave_in_block, blockDim.x >> 6);
+    avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
 }
 
 /* HBM passes: regions that outgrew the LDS tiers, in the wave's private HBM slice */
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    avk::region_worker<false>(a, wave_id, (unsigned char *)0, (unsigned char *)0, 0, 0);
+    avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
 /* packs the uploaded reference: 16 bases per word, 2 bits each, plus one flag per word for anything that is

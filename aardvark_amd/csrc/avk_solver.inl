@@ -1626,12 +1626,18 @@ AVK_DEV void wg_acquire(u32 *ctl, u32 w, u32 n_wg_waves) {
     }
 }
 
-template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice, u8 *wg_lds, u32 wave_in_wg, u32 n_wg_waves) {
+/* With esc_bytes set (bulk launch) the workgroups have exactly 4 waves: wave w of a workgroup has wave_id % 4 == w and
+ * its slice starts w slices into the workgroup's LDS. */
+template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+    const bool esc = PASS_LDS && a.esc_bytes != 0;
+    const u32 wave_in_wg = wave_id & 3u;
+    u8 *const wg_lds = lds_slice - (PASS_LDS ? (u32)wave_in_wg * (u32)a.tier[a.pass_tier].ws_bytes : 0u); /* meaningful when esc */
+    const u32 n_wg_waves = 4;
     const u32 lane = (u32)wv_lane();
     u32 n_ok = 0, n_err = 0, n_cap = 0, n_big = 0; /* n_big: finished (either way) in a tier-3 slice */
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
-    const u64 ws_bytes = a.tier[tier].ws_bytes - (PASS_LDS && wg_lds ? 64u : 0u); /* the control words sit at the end of the last slice */
+    const u64 ws_bytes = a.tier[tier].ws_bytes - (esc ? 64u : 0u); /* the control words sit at the end of the last slice */
     const u32 ed_cap = a.tier[tier].ed_cap;
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_work;
 
@@ -1650,9 +1656,9 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     const u32 home = (wave_id >> 2) % n_shards;
     u32 static_next = wave_id < a.n_waves ? wave_id : 0xFFFFFFFFu; /* waves beyond n_waves (placed late) only claim */
     u32 shard_i = 0, claim_base = 0, claim_left = 0;
-    u32 *const wg_ctl = PASS_LDS && wg_lds ? (u32 *)(wg_lds + a.esc_bytes) : (u32 *)0;
+    u32 *const wg_ctl = (u32 *)(wg_lds + a.esc_bytes); /* used when esc */
     for (;;) {
-        if (PASS_LDS && wg_ctl) { /* a sibling wants the whole LDS: stay out of the slice until it is done */
+        if (esc) { /* a sibling wants the whole LDS: stay out of the slice until it is done */
             for (u32 t = wg_word(wg_ctl); t != 0; t = wg_word(wg_ctl)) wg_park(wg_ctl, wave_in_wg, t);
         }
         u32 idx = 0;
@@ -1715,7 +1721,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             st = solve_region_tier(a, r, cur_ws, cur_bytes, cur_cap, c, out, winner);
             if (st != RS_OVERFLOW || slot != 0xFFFFFFFFu) break;
             if (PASS_LDS) {
-                if (!wg_ctl) break;
+                if (!esc) break;
                 wg_acquire(wg_ctl, wave_in_wg, n_wg_waves);
                 slot = 0; /* owns the workgroup's LDS */
                 cur_ws = wg_lds;
@@ -1813,7 +1819,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
 #endif
     }
 
-    if (PASS_LDS && wg_ctl && lane == 0) avk_wg_store(wg_ctl + 2 + wave_in_wg, 0xFFFFFFFFu); /* never parks again */
+    if (esc && lane == 0) avk_wg_store(wg_ctl + 2 + wave_in_wg, 0xFFFFFFFFu); /* never parks again */
     /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into
      * one of the partial copies; avk_tally_reduce sums the copies */
     u64 *part = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;

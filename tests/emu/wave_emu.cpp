@@ -160,8 +160,8 @@ struct WaveTask {
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
-    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds, t->wg_lds, t->wave_in_wg, t->n_wg_waves);
-    else avk::region_worker<false>(*t->args, t->wave_id, nullptr, nullptr, 0, 0);
+    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds);
+    else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
 }
 
 } // namespace
@@ -289,6 +289,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 const uint32_t alive = waves - 4 * g < 4 ? waves - 4 * g : 4;
                 uint32_t *ctl = (uint32_t *)(wgbuf.data() + a.esc_bytes);
                 for (int k = 0; k < 8; ++k) ctl[k] = 0;
+                for (uint32_t k = alive; k < 4; ++k) ctl[2 + k] = 0xFFFFFFFFu; /* a short last workgroup: the missing waves never park */
                 std::vector<std::thread> wt;
                 for (uint32_t k = 0; k < alive; ++k)
                     wt.emplace_back([&, k]() {
