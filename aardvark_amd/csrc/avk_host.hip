@@ -4,12 +4,12 @@
  * algorithm lives in avk_solver.inl and runs only on the GPU (there is no CPU path in this
  * library: without a HIP device every entry point fails with AVK_E_HIP).
  *
- * Launch shape: persistent 256-thread workgroups (4 independent wavefronts, each with a private
- * slice of the block's dynamic LDS); every wavefront pulls region indices from a device counter
- * until the batch is drained.  Pass 1 solves regions in the LDS slice or, if a region needs more
- * room, in the wave's private HBM slice.  Regions that exhaust both are queued on the device and
- * solved by pass 2 (few waves, very large HBM slices) — launched unconditionally and empty in
- * the common case, so nothing has to be read back between the passes.
+ * Launch shape: persistent workgroups of independent wavefronts, one wavefront solves one
+ * region end to end in its workspace slice.  A step starts up to three launches side by side — the bulk (small LDS
+ * slices, caller's stream) and, on two side streams, the solo launches of the regions the upload-time work plan
+ * predicted to need a large LDS slice or an HBM slice — followed by one HBM launch for whatever still overflowed
+ * (its list length is read on the device, so nothing returns to the host in between) and the tally reduce, which
+ * also clears the counters for the next step.
  */
 #include <hip/hip_runtime.h>
 

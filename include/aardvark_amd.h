@@ -174,9 +174,16 @@ void avk_ctx_destroy(avk_ctx *ctx);
 const char *avk_last_error(const avk_ctx *ctx);
 /* run every launch of this context on an existing hipStream_t (e.g. torch's current stream) */
 int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
-/* knobs: "lds_bytes_per_wave", "lds_ed_cap", "lds2_bytes_per_wave", "lds2_ed_cap", "waves_per_cu", "ws_bytes_per_wave",
- * "big_ws_bytes", "big_waves" (workspace tiers: small LDS slice, large LDS slice, HBM slice, big HBM slice),
- * "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced) */
+/* knobs (set them before avk_batch_upload: the work plan of a batch is made at upload):
+ *   workspace tiers  "lds_bytes_per_wave", "lds_ed_cap" (small LDS slice), "lds2_bytes_per_wave", "lds2_ed_cap" (large LDS
+ *                    slice), "ws_bytes_per_wave" (HBM slice), "big_ws_bytes", "big_waves" (big HBM slices), "waves_per_cu";
+ *                    0 bytes disables a tier
+ *   scheduling       "solo_min_variants" (regions with at least this many variants go to the solo launch, 0 = no solo
+ *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
+ *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid"
+ *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
+ *                    "use_packed_reference"
+ * None of them changes a result (tests/test_emu_parity.py, tests/test_gpu_parity.py). */
 int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
 
 /* Replaces ReferenceGenome::from_fasta + get_full_chromosome (src/main.rs:94,
