@@ -13,6 +13,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -423,6 +424,10 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     *out = nullptr;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     AVK_HIP(ctx, hipSetDevice(ctx->device));
+    const bool timing = getenv("AVK_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t_start = now();
     avk_dev_batch *db = new avk_dev_batch();
     db->n_regions = batch->n_regions;
     db->n_variants_host = batch->n_variants;
@@ -444,6 +449,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     }
     const uint64_t n = db->n_regions, nv = db->host.variants.size();
     db->n_variants_dev = nv;
+    const auto t_packed = now();
     if (pairs_mode) { /* solve_merge_region's pre-checks (merge_solver.rs:119-147, :211-223) */
         for (uint64_t r = 0; r < n; ++r) {
             AvkDevRegion &dr = db->host.regions[r];
@@ -479,9 +485,11 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     /* work order: the regions predicted to outgrow the small LDS slice first (solo waves take them), then the
      * rest; within each part the regions with the most variants (the expensive searches) are dealt first, so
      * they overlap with the bulk instead of forming the tail */
+    const auto t_alloc = now();
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, (uint64_t)ctx->lds_bytes_per_wave, (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2);
+    const auto t_plan = now();
     hipError_t e = hipSuccess;
     if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
@@ -492,6 +500,9 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
         delete db;
         return fail(ctx, AVK_E_HIP, "batch upload failed: %s", hipGetErrorString(e));
     }
+    if (timing)
+        fprintf(stderr, "avk upload: pack %.3f ms, alloc %.3f ms, plan %.3f ms, copy %.3f ms\n", ms(t_start, t_packed), ms(t_packed, t_alloc), ms(t_alloc, t_plan),
+                ms(t_plan, now()));
     *out = db;
     return 0;
 }

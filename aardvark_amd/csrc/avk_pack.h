@@ -13,6 +13,7 @@
 
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "avk_dev_types.h"
@@ -99,128 +100,165 @@ inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *
     }
 }
 
-/* contig_base[c] = offset of contig c in the concatenated reference, contig_len[c] its length */
+/* contig_base[c] = offset of contig c in the concatenated reference, contig_len[c] its length.
+ * Two passes: a serial one that checks the variant ranges and lays out the per-variant outputs and the blobs
+ * (prefix sums), then the regions are validated and their blobs written by `threads` workers (regions are
+ * independent once the offsets are known). */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
-                      const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err) {
+                      const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0) {
     const uint64_t n = b->n_regions;
     if (n > 0x7FFFFFFFull || b->n_variants > 0x7FFFFFFFull) {
         *err = "batch too large (more than 2^31 regions or variants); split it";
         return AVK_E_ARG;
     }
-    out->regions.resize(n);
+    out->regions.assign(n, AvkDevRegion());
     out->zyg_flags.assign(n, 0);
     out->delta_t.assign(n, 0);
     out->delta_q.assign(n, 0);
-    out->blob.clear();
-    out->blob.reserve(b->n_variants * 10 + n * 10);
-    out->variants.clear();
-    out->variants.reserve(b->n_variants);
-    out->alleles.clear();
-    out->dev2host.clear();
-    out->dev2host.reserve(b->n_variants);
+    /* pass 1: layout */
+    std::vector<uint64_t> blob_at(n + 1, 0); /* in words */
+    uint64_t nv = 0;
     for (uint64_t r = 0; r < n; ++r) {
         AvkDevRegion &dr = out->regions[r];
         memset(&dr, 0, sizeof(dr));
-        const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
-        const uint64_t start = b->start[r], end = b->end[r];
-        uint32_t pre = 0;
-        if (c >= contig_len.size() || start > end || end > contig_len[c] || end - start > 0x7FFFFFFFull) pre = AVK_ST_INVALID_INPUT;
         const uint32_t tc = b->t_cnt[r], qc = b->q_cnt[r];
-        if ((uint64_t)tc + qc > 60000) pre = AVK_ST_INVALID_INPUT;
-        dr.v_off = (uint32_t)out->variants.size();
-        dr.t_cnt = tc;
-        dr.q_cnt = qc;
-        dr.len = pre ? 0 : (uint32_t)(end - start);
-        dr.ref_off = pre ? 0 : contig_base[c] + start;
-        bool bad_zyg = false;
+        uint64_t alle = 0;
         for (int side = 0; side < 2; ++side) {
             const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
             const uint32_t cnt = side == 0 ? tc : qc;
-            uint64_t last = 0;
-            for (uint32_t i = 0; i < cnt; ++i) {
-                const uint64_t v = off + i;
-                if (v >= b->n_variants) {
-                    *err = "variant range of a region exceeds n_variants";
-                    return AVK_E_ARG;
-                }
-                AvkDevVariant dv;
-                memset(&dv, 0, sizeof(dv));
-                const uint64_t pos = b->var_pos[v];
-                const uint32_t l0 = b->a0_len[v], l1 = b->a1_len[v];
-                const uint32_t raw = b->var_raw_space ? b->var_raw_space[v] : (l0 > l1 ? l0 : l1);
-                if (b->a0_off[v] + l0 > b->allele_bytes_len || b->a1_off[v] + l1 > b->allele_bytes_len) {
-                    *err = "allele range exceeds allele_bytes_len";
-                    return AVK_E_ARG;
-                }
-                if (l0 == 0 || l1 == 0 || raw < (l0 > l1 ? l0 : l1)) pre = AVK_ST_INVALID_INPUT;
-                if (b->var_type[v] >= AVK_N_VARIANT_TYPES || b->var_zyg[v] > AVK_ZYG_HOM_ALT) pre = AVK_ST_INVALID_INPUT;
-                if (pos < start || pos + l0 > end || pos < last) pre = AVK_ST_INVALID_INPUT;
-                last = pos;
-                if (b->var_zyg[v] == AVK_ZYG_UNKNOWN || b->var_zyg[v] == AVK_ZYG_HOM_REF) bad_zyg = true;
-                if (b->var_zyg[v] == AVK_ZYG_UNKNOWN) out->zyg_flags[r] |= 1;
-                if (b->var_zyg[v] == AVK_ZYG_HOM_REF) out->zyg_flags[r] |= 2;
-                {
-                    const int64_t w = b->var_zyg[v] == AVK_ZYG_HOM_ALT ? 2 : ((b->var_zyg[v] >= AVK_ZYG_UNPHASED_HET && b->var_zyg[v] <= AVK_ZYG_PHASED_HET10) ? 1 : 0);
-                    (side == 0 ? out->delta_t[r] : out->delta_q[r]) += ((int64_t)l1 - (int64_t)l0) * w;
-                }
-                dv.rel_pos = pos >= start ? (uint32_t)(pos - start) : 0;
-                dv.a0_len = l0;
-                dv.a1_len = l1;
-                dv.a_off = (uint32_t)out->alleles.size();
-                dv.raw_space = raw;
-                dv.type = b->var_type[v];
-                dv.zyg = b->var_zyg[v];
-                if (out->alleles.size() + (uint64_t)l0 + l1 > 0xFFFFFFF0ull) {
-                    *err = "allele arena exceeds 4 GiB; split the batch";
-                    return AVK_E_ARG;
-                }
-                out->alleles.insert(out->alleles.end(), b->allele_bytes + b->a0_off[v], b->allele_bytes + b->a0_off[v] + l0);
-                out->alleles.insert(out->alleles.end(), b->allele_bytes + b->a1_off[v], b->allele_bytes + b->a1_off[v] + l1);
-                out->variants.push_back(dv);
-                out->dev2host.push_back(v);
-            }
-        }
-        if (!pre && bad_zyg) pre = AVK_ST_BAD_ZYGOSITY;
-        dr.pre_status = pre;
-        if (!pre) { /* the region's blob */
-            const uint32_t N = tc + qc;
-            const AvkDevVariant *hv = out->variants.data() + dr.v_off;
-            uint64_t alle = 0, g[2] = {0, 0};
-            uint32_t types = 0, counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            for (uint32_t k = 0; k < N; ++k) {
-                alle += (uint64_t)hv[k].a0_len + hv[k].a1_len;
-                if (hv[k].a1_len > hv[k].a0_len) g[k < tc ? 0 : 1] += hv[k].a1_len - hv[k].a0_len;
-                types |= 1u << hv[k].type;
-                for (int t = 0; t < 8; ++t)
-                    if (hv[k].type == AVK_SUP_TYPES[t]) counts[t] += k < tc ? 1u : 0x10000u;
-            }
-            const uint64_t vb = ((uint64_t)N * sizeof(AvkBlobVar) + 7) & ~7ull, ab = (alle + 7) & ~7ull, ob = (4ull * N + 7) & ~7ull;
-            const uint64_t bytes = vb + ab + ob + 32;
-            const uint64_t at = out->blob.size(); /* words; every blob is a multiple of 8 bytes */
-            if (bytes > 0x7FFFFFFFull || (at * 4 + bytes) / 8 > 0xFFFFFFFFull || (g[0] > g[1] ? g[0] : g[1]) > 0x7FFFFFFFull) {
-                *err = "region blob arena exceeds its limits; split the batch";
+            if (off > b->n_variants || (uint64_t)cnt > b->n_variants - off) {
+                *err = "variant range of a region exceeds n_variants";
                 return AVK_E_ARG;
             }
-            out->blob.resize(at + bytes / 4, 0);
-            uint8_t *base = (uint8_t *)(out->blob.data() + at);
+            for (uint32_t i = 0; i < cnt; ++i) alle += (uint64_t)b->a0_len[off + i] + b->a1_len[off + i];
+        }
+        const uint64_t N = (uint64_t)tc + qc;
+        dr.v_off = (uint32_t)nv;
+        dr.t_cnt = tc;
+        dr.q_cnt = qc;
+        nv += N;
+        if (nv > 0x7FFFFFFFull) {
+            *err = "more than 2^31 variant records; split the batch";
+            return AVK_E_ARG;
+        }
+        uint64_t bytes = 0;
+        if (N <= 60000) bytes = (((uint64_t)N * sizeof(AvkBlobVar) + 7) & ~7ull) + ((alle + 7) & ~7ull) + ((4ull * N + 7) & ~7ull) + 32;
+        if (bytes > 0x7FFFFFFFull) {
+            *err = "region blob exceeds 2 GiB; split the region's alleles";
+            return AVK_E_ARG;
+        }
+        dr.blob_bytes = (uint32_t)bytes;
+        dr.alle_bytes = (uint32_t)(alle < 0xFFFFFFFFull ? alle : 0xFFFFFFFFull);
+        blob_at[r + 1] = blob_at[r] + bytes / 4;
+        if (blob_at[r + 1] / 2 > 0xFFFFFFFFull) {
+            *err = "region blob arena exceeds its limits; split the batch";
+            return AVK_E_ARG;
+        }
+    }
+    out->variants.assign(nv, AvkDevVariant());
+    out->dev2host.assign(nv, 0);
+    out->alleles.assign(1, 0);
+    out->blob.assign(blob_at[n] ? blob_at[n] : 2, 0);
+
+    /* pass 2: validation and blobs, region by region */
+    auto pack_range = [&](uint64_t r0, uint64_t r1, std::string *werr) -> int {
+        for (uint64_t r = r0; r < r1; ++r) {
+            AvkDevRegion &dr = out->regions[r];
+            const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
+            const uint64_t start = b->start[r], end = b->end[r];
+            uint32_t pre = 0;
+            if (c >= contig_len.size() || start > end || end > contig_len[c] || end - start > 0x7FFFFFFFull) pre = AVK_ST_INVALID_INPUT;
+            const uint32_t tc = dr.t_cnt, qc = dr.q_cnt, N = tc + qc;
+            if ((uint64_t)tc + qc > 60000) pre = AVK_ST_INVALID_INPUT;
+            dr.len = pre ? 0 : (uint32_t)(end - start);
+            dr.ref_off = pre ? 0 : contig_base[c] + start;
+            AvkDevVariant *hv = out->variants.data() + dr.v_off;
+            bool bad_zyg = false;
+            uint64_t g[2] = {0, 0};
+            uint32_t types = 0, counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            uint32_t k = 0;
+            for (int side = 0; side < 2; ++side) {
+                const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
+                const uint32_t cnt = side == 0 ? tc : qc;
+                uint64_t last = 0;
+                for (uint32_t i = 0; i < cnt; ++i, ++k) {
+                    const uint64_t v = off + i;
+                    AvkDevVariant &dv = hv[k];
+                    const uint64_t pos = b->var_pos[v];
+                    const uint32_t l0 = b->a0_len[v], l1 = b->a1_len[v];
+                    const uint32_t raw = b->var_raw_space ? b->var_raw_space[v] : (l0 > l1 ? l0 : l1);
+                    if (b->a0_off[v] + l0 > b->allele_bytes_len || b->a1_off[v] + l1 > b->allele_bytes_len) {
+                        *werr = "allele range exceeds allele_bytes_len";
+                        return AVK_E_ARG;
+                    }
+                    const uint8_t vt = b->var_type[v], zy = b->var_zyg[v];
+                    if (l0 == 0 || l1 == 0 || raw < (l0 > l1 ? l0 : l1)) pre = AVK_ST_INVALID_INPUT;
+                    if (vt >= AVK_N_VARIANT_TYPES || zy > AVK_ZYG_HOM_ALT) pre = AVK_ST_INVALID_INPUT;
+                    if (pos < start || pos + l0 > end || pos < last) pre = AVK_ST_INVALID_INPUT;
+                    last = pos;
+                    if (zy == AVK_ZYG_UNKNOWN || zy == AVK_ZYG_HOM_REF) bad_zyg = true;
+                    if (zy == AVK_ZYG_UNKNOWN) out->zyg_flags[r] |= 1;
+                    if (zy == AVK_ZYG_HOM_REF) out->zyg_flags[r] |= 2;
+                    {
+                        const int64_t w = zy == AVK_ZYG_HOM_ALT ? 2 : ((zy >= AVK_ZYG_UNPHASED_HET && zy <= AVK_ZYG_PHASED_HET10) ? 1 : 0);
+                        (side == 0 ? out->delta_t[r] : out->delta_q[r]) += ((int64_t)l1 - (int64_t)l0) * w;
+                    }
+                    dv.rel_pos = pos >= start ? (uint32_t)(pos - start) : 0;
+                    dv.a0_len = l0;
+                    dv.a1_len = l1;
+                    dv.a_off = 0;
+                    dv.raw_space = raw;
+                    dv.type = vt;
+                    dv.zyg = zy;
+                    out->dev2host[dr.v_off + k] = v;
+                    if (l1 > l0) g[side] += l1 - l0;
+                    if (vt < AVK_N_VARIANT_TYPES) {
+                        types |= 1u << vt;
+                        for (int t = 0; t < 8; ++t)
+                            if (vt == AVK_SUP_TYPES[t]) counts[t] += side == 0 ? 1u : 0x10000u;
+                    }
+                }
+            }
+            if (!pre && bad_zyg) pre = AVK_ST_BAD_ZYGOSITY;
+            if (!pre && (g[0] > g[1] ? g[0] : g[1]) > 0x7FFFFFFFull) pre = AVK_ST_INVALID_INPUT;
+            dr.pre_status = pre;
+            if (seq_off && seq_stride) {
+                dr.seq_off = seq_off[r];
+                dr.seq_stride = seq_stride[r];
+            }
+            if (pre) {
+                dr.blob_bytes = 0;
+                continue;
+            }
+            /* the region's blob */
+            const uint64_t alle = dr.alle_bytes;
+            const uint64_t vb = ((uint64_t)N * sizeof(AvkBlobVar) + 7) & ~7ull, ab = (alle + 7) & ~7ull, ob = (4ull * N + 7) & ~7ull;
+            uint8_t *base = (uint8_t *)(out->blob.data() + blob_at[r]);
             AvkBlobVar *bv = (AvkBlobVar *)base;
             uint8_t *ba = base + vb;
             uint32_t *bo = (uint32_t *)(base + vb + ab), *bc = (uint32_t *)(base + vb + ab + ob);
             uint32_t run = 0;
             uint64_t ed_sum = 0;
-            for (uint32_t k = 0; k < N; ++k) {
-                const uint8_t *a0 = out->alleles.data() + hv[k].a_off, *a1 = a0 + hv[k].a0_len;
-                bv[k].rel_pos = hv[k].rel_pos;
-                bv[k].a0_len = hv[k].a0_len;
-                bv[k].a1_len = hv[k].a1_len;
-                bv[k].a_off = run;
-                bv[k].raw_space = hv[k].raw_space;
-                const uint64_t ed = host_edit_distance(a0, hv[k].a0_len, a1, hv[k].a1_len);
-                bv[k].alt_ed = (uint32_t)ed;
-                ed_sum += ed;
-                bv[k].type_zyg = (uint32_t)hv[k].type | ((uint32_t)hv[k].zyg << 8);
-                memcpy(ba + run, a0, (size_t)hv[k].a0_len + hv[k].a1_len);
-                run += hv[k].a0_len + hv[k].a1_len;
+            k = 0;
+            for (int side = 0; side < 2; ++side) {
+                const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
+                const uint32_t cnt = side == 0 ? tc : qc;
+                for (uint32_t i = 0; i < cnt; ++i, ++k) {
+                    const uint64_t v = off + i;
+                    const uint8_t *a0 = b->allele_bytes + b->a0_off[v], *a1 = b->allele_bytes + b->a1_off[v];
+                    bv[k].rel_pos = hv[k].rel_pos;
+                    bv[k].a0_len = hv[k].a0_len;
+                    bv[k].a1_len = hv[k].a1_len;
+                    bv[k].a_off = run;
+                    bv[k].raw_space = hv[k].raw_space;
+                    const uint64_t ed = host_edit_distance(a0, hv[k].a0_len, a1, hv[k].a1_len);
+                    bv[k].alt_ed = (uint32_t)ed;
+                    ed_sum += ed;
+                    bv[k].type_zyg = (uint32_t)hv[k].type | ((uint32_t)hv[k].zyg << 8);
+                    memcpy(ba + run, a0, hv[k].a0_len);
+                    memcpy(ba + run + hv[k].a0_len, a1, hv[k].a1_len);
+                    run += hv[k].a0_len + hv[k].a1_len;
+                }
             }
             /* order_variants: stable by position over [truth.., query..]; each side is already sorted (checked above) */
             {
@@ -231,20 +269,28 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                 }
             }
             for (int t = 0; t < 8; ++t) bc[t] = counts[t];
-            dr.blob_off = (uint32_t)(at / 2);
-            dr.blob_bytes = (uint32_t)bytes;
-            dr.alle_bytes = (uint32_t)alle;
+            dr.blob_off = (uint32_t)(blob_at[r] / 2);
             dr.grow = (uint32_t)(g[0] > g[1] ? g[0] : g[1]);
             dr.types = types;
             dr.ed_bound = (uint32_t)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
         }
-        if (seq_off && seq_stride) {
-            dr.seq_off = seq_off[r];
-            dr.seq_stride = seq_stride[r];
+        return 0;
+    };
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if ((uint64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
+    if (nt <= 1) return pack_range(0, n, err);
+    std::vector<std::thread> pool;
+    std::vector<int> rcs((size_t)nt, 0);
+    std::vector<std::string> errs((size_t)nt);
+    for (int t = 0; t < nt; ++t)
+        pool.emplace_back([&, t] { rcs[(size_t)t] = pack_range(n * (uint64_t)t / nt, n * (uint64_t)(t + 1) / nt, &errs[(size_t)t]); });
+    for (auto &th : pool) th.join();
+    for (int t = 0; t < nt; ++t)
+        if (rcs[(size_t)t]) {
+            *err = errs[(size_t)t];
+            return rcs[(size_t)t];
         }
-    }
-    if (out->alleles.empty()) out->alleles.push_back(0);
-    if (out->blob.empty()) out->blob.resize(2, 0);
     return 0;
 }
 
