@@ -1,0 +1,171 @@
+/*
+ * compare_main.cpp — `aardvark_amd_compare`: the reference's `aardvark compare` flow (src/main.rs:30-327) on top of the
+ * two C-ABIs: libaardvark_feeder.so turns FASTA + BED + truth/query VCFs into region batches, libaardvark_amd.so
+ * solves them on the GPU, the feeder library writes summary.tsv.  Option names are the reference's
+ * (src/cli/compare.rs).  Not implemented here: stratifications, the annotated truth/query VCFs and the debug
+ * TSVs (rest) — the flags are rejected rather than ignored.
+ */
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "../../../include/aardvark_amd.h"
+#include "../../../include/aardvark_feeder.h"
+
+namespace {
+
+double seconds_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
+[[noreturn]] void die(int code, const char *what, const char *detail) {
+    fprintf(stderr, "error: %s%s%s\n", what, detail && *detail ? ": " : "", detail ? detail : "");
+    exit(code);
+}
+
+void usage() {
+    fprintf(stderr,
+            "usage: aardvark_amd_compare -r REF.fa[.gz] -t TRUTH.vcf[.gz] -q QUERY.vcf[.gz] -b REGIONS.bed[.gz] -o OUT_DIR\n"
+            "  [--truth-sample S] [--query-sample S] [--compare-label L] [--min-variant-gap 50] [--disable-variant-trimming]\n"
+            "  [--max-branch-factor 50] [--enable-exact-shortcut] [--enable-haplotype-metrics] [--enable-weighted-haplotype-metrics]\n"
+            "  [--enable-record-basepair-metrics] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    const auto t_start = std::chrono::steady_clock::now();
+    std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare";
+    uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000;
+    bool trimming = true, shortcut = false, hap = false, whap = false, rbp = false;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) die(64, "missing value for", a.c_str());
+            return argv[++i];
+        };
+        if (a == "-r" || a == "--reference") ref = val();
+        else if (a == "-t" || a == "--truth-vcf") truth = val();
+        else if (a == "-q" || a == "--query-vcf") query = val();
+        else if (a == "-b" || a == "--regions") bed = val();
+        else if (a == "-o" || a == "--output-dir") out_dir = val();
+        else if (a == "--truth-sample") truth_sample = val();
+        else if (a == "--query-sample") query_sample = val();
+        else if (a == "--compare-label") label = val();
+        else if (a == "--min-variant-gap") gap = strtoull(val(), nullptr, 10);
+        else if (a == "--disable-variant-trimming") trimming = false;
+        else if (a == "--max-branch-factor") branch = strtoull(val(), nullptr, 10);
+        else if (a == "--enable-exact-shortcut") shortcut = true;
+        else if (a == "--enable-haplotype-metrics") hap = true;
+        else if (a == "--enable-weighted-haplotype-metrics") whap = true;
+        else if (a == "--enable-record-basepair-metrics") rbp = true;
+        else if (a == "--skip") skip = strtoull(val(), nullptr, 10);
+        else if (a == "--take") take = strtoull(val(), nullptr, 10);
+        else if (a == "--device") device = atoi(val());
+        else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
+        else if (a == "--threads" || a == "--max-edit-distance") (void)val(); /* accepted for command-line compatibility */
+        else if (a == "-s" || a == "--stratification" || a == "--output-debug") die(64, "not supported by this build", a.c_str());
+        else if (a == "-h" || a == "--help") {
+            usage();
+            return 0;
+        } else die(64, "unknown option", a.c_str());
+    }
+    if (ref.empty() || truth.empty() || query.empty() || out_dir.empty()) {
+        usage();
+        return 64;
+    }
+    if (gap == 0) die(78, "--min-variant-gap must be >0", "");
+    if (branch == 0 || branch > 0xFFFFFFFFull) die(78, "--max-branch-factor must be >0", "");
+    if (batch_regions == 0) batch_regions = 1;
+    if (mkdir(out_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create output folder", out_dir.c_str());
+
+    auto t0 = std::chrono::steady_clock::now();
+    avf_genome *genome = nullptr;
+    if (avf_genome_load(ref.c_str(), &genome)) die(74, "Error while loading reference genome", avf_last_error());
+    const double s_genome = seconds_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
+    avf_feed *feed = nullptr;
+    if (avf_feed_compare(truth.c_str(), truth_sample.c_str(), query.c_str(), query_sample.c_str(), bed.c_str(), genome, gap, trimming ? 1 : 0, &feed))
+        die(74, "Error while building regions", avf_last_error());
+    const avk_region_batch *all = avf_feed_batch(feed);
+    const double s_feed = seconds_since(t0);
+    fprintf(stderr, "Loaded %llu truth and %llu query variants; %llu regions.\n", (unsigned long long)avf_feed_loaded_variants(feed, 0),
+            (unsigned long long)avf_feed_loaded_variants(feed, 1), (unsigned long long)all->n_regions);
+
+    t0 = std::chrono::steady_clock::now();
+    avk_ctx *ctx = nullptr;
+    if (avk_ctx_create(device, &ctx)) die(70, "cannot create the GPU context", avk_last_error(nullptr));
+    const uint32_t n_contigs = avf_genome_n_contigs(genome);
+    std::vector<const uint8_t *> seqs(n_contigs);
+    std::vector<uint64_t> lens(n_contigs);
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        seqs[c] = avf_genome_seq(genome, c);
+        lens[c] = avf_genome_len(genome, c);
+    }
+    if (avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data())) die(70, "reference upload failed", avk_last_error(ctx));
+    const double s_ref = seconds_since(t0);
+
+    /* --skip / --take select regions by position in the iterator (src/main.rs:215-231) */
+    const uint64_t first = skip < all->n_regions ? skip : all->n_regions;
+    uint64_t count = all->n_regions - first;
+    if (take && take < count) count = take;
+
+    t0 = std::chrono::steady_clock::now();
+    std::vector<uint64_t> total(AVK_TALLY_LEN, 0), tally(AVK_TALLY_LEN);
+    avk_compare_config cfg;
+    cfg.max_branch_factor = (uint32_t)branch;
+    cfg.enable_sequences = 0;
+    cfg.enable_exact_shortcut = shortcut ? 1 : 0;
+    std::vector<int32_t> status;
+    (void)avk_ctx_set_option(ctx, "emit_group_metrics", 0); /* only the summed block is needed here */
+    for (uint64_t at = 0; at < count; at += batch_regions) {
+        const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
+        avk_region_batch b = *all; /* a window of the region arrays; variant arrays are shared */
+        b.n_regions = n;
+        b.region_id = all->region_id + first + at;
+        b.contig_idx = all->contig_idx + first + at;
+        b.start = all->start + first + at;
+        b.end = all->end + first + at;
+        b.t_off = all->t_off + first + at;
+        b.t_cnt = all->t_cnt + first + at;
+        b.q_off = all->q_off + first + at;
+        b.q_cnt = all->q_cnt + first + at;
+        status.assign(n, 0);
+        avk_result_batch out;
+        memset(&out, 0, sizeof(out));
+        out.status = status.data();
+        out.tally = tally.data();
+        if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
+        for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += tally[k];
+        for (uint64_t r = 0; r < n; ++r)
+            if (status[r] != 0)
+                fprintf(stderr, "Error while solving compare region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)b.region_id[r], b.contig_idx[r],
+                        (unsigned long long)b.start[r], (unsigned long long)b.end[r], status[r]);
+    }
+    const double s_solve = seconds_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
+    uint32_t mask = AVF_METRIC_GT | AVF_METRIC_BASEPAIR;
+    if (hap) mask |= AVF_METRIC_HAP;
+    if (whap) mask |= AVF_METRIC_WEIGHTED_HAP;
+    if (rbp) mask |= AVF_METRIC_RECORD_BP;
+    const std::string summary = out_dir + "/summary.tsv";
+    if (avf_write_summary(summary.c_str(), label.c_str(), total.data(), mask)) die(74, "Error while saving summary file", avf_last_error());
+    const double s_write = seconds_since(t0);
+
+    fprintf(stderr, "Solved:error blocks: %llu : %llu\n", (unsigned long long)total[AVK_TALLY_LEN - 2], (unsigned long long)total[AVK_TALLY_LEN - 1]);
+    fprintf(stderr, "stages [s]: reference %.3f, feeder %.3f, gpu context + reference upload %.3f, solve (pack + H2D + kernels + D2H) %.3f, summary %.3f\n",
+            s_genome, s_feed, s_ref, s_solve, s_write);
+    fprintf(stderr, "Comparisons completed in %.3f seconds (%.2f M regions/s in the solve stage).\n", seconds_since(t_start),
+            s_solve > 0 ? (double)count / s_solve / 1e6 : 0.0);
+    avk_ctx_destroy(ctx);
+    avf_feed_free(feed);
+    avf_genome_free(genome);
+    return 0;
+}

@@ -1,0 +1,125 @@
+"""ctypes plumbing for libaardvark_feeder.so (include/aardvark_feeder.h): FASTA / BED / VCF -> RegionBatch with the
+reference's region ids and windows (src/parsing/region_generation.rs), and the summary.tsv writer
+(src/writers/summary.rs).  Host code only; the solver stays in libaardvark_amd.so."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from ._abi import AvkRegionBatch, RegionBatch
+
+METRIC_GT, METRIC_HAP, METRIC_WEIGHTED_HAP, METRIC_BASEPAIR, METRIC_RECORD_BP = 1, 2, 4, 8, 16
+_lib = None
+
+
+class FeederError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.environ.get("AVF_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libaardvark_feeder.so")
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise FeederError("%s is missing: build it with `python __graft_entry__.py` (make -C aardvark_amd/csrc/feeder)" % path)
+    lib = C.CDLL(path)
+    vp = C.c_void_p
+    lib.avf_last_error.restype = C.c_char_p
+    lib.avf_genome_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.avf_genome_n_contigs.restype = C.c_uint32
+    lib.avf_genome_n_contigs.argtypes = [vp]
+    lib.avf_genome_name.restype = C.c_char_p
+    lib.avf_genome_name.argtypes = [vp, C.c_uint32]
+    lib.avf_genome_seq.restype = C.POINTER(C.c_uint8)
+    lib.avf_genome_seq.argtypes = [vp, C.c_uint32]
+    lib.avf_genome_len.restype = C.c_uint64
+    lib.avf_genome_len.argtypes = [vp, C.c_uint32]
+    lib.avf_genome_free.argtypes = [vp]
+    lib.avf_feed_compare.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    lib.avf_feed_batch.restype = C.POINTER(AvkRegionBatch)
+    lib.avf_feed_batch.argtypes = [vp]
+    lib.avf_feed_var_record.restype = C.POINTER(C.c_uint64)
+    lib.avf_feed_var_record.argtypes = [vp]
+    lib.avf_feed_var_alt_index.restype = C.POINTER(C.c_uint32)
+    lib.avf_feed_var_alt_index.argtypes = [vp]
+    lib.avf_feed_loaded_variants.restype = C.c_uint64
+    lib.avf_feed_loaded_variants.argtypes = [vp, C.c_int]
+    lib.avf_feed_free.argtypes = [vp]
+    lib.avf_write_summary.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32]
+    _lib = lib
+    return lib
+
+
+def _check(lib, rc):
+    if rc:
+        raise FeederError((lib.avf_last_error() or b"").decode(errors="replace"))
+
+
+def _arr(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype)
+    return np.ctypeslib.as_array(ptr, shape=(n,)).astype(dtype, copy=True)
+
+
+class Genome:
+    """ReferenceGenome::from_fasta: contigs in file order."""
+
+    def __init__(self, fasta_path):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.avf_genome_load(os.fsencode(fasta_path), C.byref(h)))
+        self.handle = h
+        n = self.lib.avf_genome_n_contigs(h)
+        self.names = [self.lib.avf_genome_name(h, i).decode() for i in range(n)]
+
+    def contigs(self):
+        """list of numpy uint8 arrays (copies), in file order: what avk_ref_upload takes"""
+        return [_arr(self.lib.avf_genome_seq(self.handle, i), int(self.lib.avf_genome_len(self.handle, i)), np.uint8) for i in range(len(self.names))]
+
+    def close(self):
+        if self.handle:
+            self.lib.avf_genome_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Feed:
+    """The result of RegionIterator over a truth/query VCF pair: a RegionBatch plus provenance."""
+
+    def __init__(self, batch, var_record, var_alt_index, loaded):
+        self.batch, self.var_record, self.var_alt_index, self.loaded = batch, var_record, var_alt_index, loaded
+
+
+def feed_compare(truth_vcf, query_vcf, regions_bed, genome, truth_sample="", query_sample="", min_variant_gap=50, enable_trimming=True):
+    lib = load_library()
+    h = C.c_void_p()
+    _check(lib, lib.avf_feed_compare(os.fsencode(truth_vcf), truth_sample.encode(), os.fsencode(query_vcf), query_sample.encode(),
+                                     os.fsencode(regions_bed) if regions_bed else None, genome.handle, min_variant_gap, 1 if enable_trimming else 0, C.byref(h)))
+    try:
+        b = lib.avf_feed_batch(h).contents
+        n, nv = int(b.n_regions), int(b.n_variants)
+        batch = RegionBatch(_arr(b.region_id, n, np.uint64), _arr(b.contig_idx, n, np.uint32), _arr(b.start, n, np.uint64), _arr(b.end, n, np.uint64),
+                            _arr(b.t_off, n, np.uint64), _arr(b.t_cnt, n, np.uint32), _arr(b.q_off, n, np.uint64), _arr(b.q_cnt, n, np.uint32),
+                            _arr(b.var_pos, nv, np.uint64), _arr(b.var_type, nv, np.uint8), _arr(b.var_zyg, nv, np.uint8), _arr(b.var_raw_space, nv, np.uint32),
+                            _arr(b.a0_off, nv, np.uint64), _arr(b.a0_len, nv, np.uint32), _arr(b.a1_off, nv, np.uint64), _arr(b.a1_len, nv, np.uint32),
+                            _arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
+        return Feed(batch, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
+                    (int(lib.avf_feed_loaded_variants(h, 0)), int(lib.avf_feed_loaded_variants(h, 1))))
+    finally:
+        lib.avf_feed_free(h)
+
+
+def write_summary(path, tally, compare_label="compare", metrics=METRIC_GT | METRIC_BASEPAIR):
+    lib = load_library()
+    t = np.ascontiguousarray(tally, dtype=np.uint64)
+    _check(lib, lib.avf_write_summary(os.fsencode(path), compare_label.encode(), t.ctypes.data_as(C.POINTER(C.c_uint64)), metrics))

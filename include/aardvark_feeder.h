@@ -1,0 +1,69 @@
+/*
+ * aardvark_feeder.h — C-ABI of libaardvark_feeder.so: the host-side feeder and summary writer around the
+ * compare hot path.  Plain host C++ behind it, no GPU involved.
+ *
+ * What it replaces in the reference (PacificBiosciences/aardvark v0.10.5):
+ *   avf_genome_load     ReferenceGenome::from_fasta                           (src/main.rs:94)
+ *   avf_feed_compare    RegionIterator::new_compare_iterator + the iterator   (src/parsing/region_generation.rs:61-122, :281-478)
+ *                       with load_variants_in_region / parse_variant /
+ *                       parse_genotype / get_variant_type                     (:489-758)
+ *                       and LoadedBed::preload_bed_file                       (src/parsing/noodles_helper.rs:48-86)
+ *   avf_write_summary   SummaryWriter::write_summary                          (src/writers/summary.rs:163-395)
+ *
+ * The feed hands out an avk_region_batch (include/aardvark_amd.h) whose regions carry the reference's region ids
+ * and windows, ready for avk_compare_batch.
+ */
+#ifndef AARDVARK_FEEDER_H
+#define AARDVARK_FEEDER_H
+
+#include <stdint.h>
+#include "aardvark_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct avf_genome avf_genome;
+typedef struct avf_feed avf_feed;
+
+/* error text of the last failed call on this thread */
+const char *avf_last_error(void);
+
+/* FASTA (plain or gzip/BGZF): contig name = header up to the first white space, sequence bytes as they are in
+ * the file (no case folding). */
+int avf_genome_load(const char *fasta_path, avf_genome **out);
+uint32_t avf_genome_n_contigs(const avf_genome *g);
+const char *avf_genome_name(const avf_genome *g, uint32_t i);
+const uint8_t *avf_genome_seq(const avf_genome *g, uint32_t i);
+uint64_t avf_genome_len(const avf_genome *g, uint32_t i);
+void avf_genome_free(avf_genome *g);
+
+/* Region generation for `compare`.  truth_sample / query_sample: NULL or "" = the first sample of the file
+ * (src/cli/compare.rs:186-194).  regions_bed is required (region_generation.rs:93-97).  min_variant_gap > 0
+ * (default of the reference: 50); enable_trimming = !--disable-variant-trimming.
+ * The batch's contig_idx refers to the contigs of `g` in file order. */
+int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char *query_vcf, const char *query_sample,
+                     const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int enable_trimming, avf_feed **out);
+const avk_region_batch *avf_feed_batch(const avf_feed *f);
+/* provenance of batch variant v, for the VCF writers: 0-based index of its record among the data lines of its
+ * file, and the 1-based ALT index it came from */
+const uint64_t *avf_feed_var_record(const avf_feed *f);
+const uint32_t *avf_feed_var_alt_index(const avf_feed *f);
+/* variants loaded per input after parsing and the chromosome-span filter (the "Loaded N truth variants" log lines) */
+uint64_t avf_feed_loaded_variants(const avf_feed *f, int input);
+void avf_feed_free(avf_feed *f);
+
+/* metrics_mask: bit i set = write MetricsType i of {GT, HAP, WEIGHTED_HAP, BASEPAIR, RECORD_BP} (the reference always
+ * writes GT and BASEPAIR, the others on request, in the order GT, BASEPAIR, HAP, WEIGHTED_HAP, RECORD_BP: src/main.rs:134-147).
+ * tally = the ALL block of avk_result_batch::tally summed over all batches.  A path ending in .csv is comma separated. */
+#define AVF_METRIC_GT 1u
+#define AVF_METRIC_HAP 2u
+#define AVF_METRIC_WEIGHTED_HAP 4u
+#define AVF_METRIC_BASEPAIR 8u
+#define AVF_METRIC_RECORD_BP 16u
+int avf_write_summary(const char *path, const char *compare_label, const uint64_t *tally, uint32_t metrics_mask);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AARDVARK_FEEDER_H */

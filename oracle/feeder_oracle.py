@@ -1,0 +1,272 @@
+"""CPU restatement of the reference's feeder and summary writer in plain Python.  TEST INFRASTRUCTURE: only tests/
+may import it; the product is aardvark_amd/csrc/feeder/avf_feeder.cpp.
+
+Parity unpinned: the reference holds no tests or fixtures for src/parsing/ and src/writers/ (0 #[test] functions,
+"TODO: we likely need to add tests" at region_generation.rs:814-821), so this restatement is anchored on the source
+only; the end-to-end check that IS pinned is the 8 solve_compare_region known-answer regions run through
+VCF -> feeder -> solver (tests/test_feeder.py).
+
+file:line citations are into PacificBiosciences/aardvark v0.10.5.
+"""
+import gzip
+from decimal import Decimal
+
+VT = {n: i for i, n in enumerate(["Snv", "Insertion", "Deletion", "Indel", "SvInsertion", "SvDeletion", "SvDuplication",
+                                  "SvInversion", "SvBreakend", "TrContraction", "TrExpansion", "Unknown"])}
+ZYG = {n: i for i, n in enumerate(["Unknown", "HomozygousReference", "UnphasedHeterozygous", "PhasedHet01", "PhasedHet10", "HomozygousAlternate"])}
+
+
+def _open(path):
+    with open(path, "rb") as f:
+        magic = f.read(2)
+    return gzip.open(path, "rt") if magic == b"\x1f\x8b" else open(path, "rt")
+
+
+def read_fasta(path):
+    """ReferenceGenome::from_fasta (src/main.rs:94): [(name, sequence)] in file order."""
+    out = []
+    with _open(path) as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            if line.startswith(">"):
+                out.append([line[1:].split()[0] if line[1:].split() else "", []])
+            else:
+                out[-1][1].append(line)
+    return [(n, "".join(s)) for n, s in out]
+
+
+def read_bed(path):
+    """LoadedBed::preload_bed_file (noodles_helper.rs:48-86): {chrom: [(start1, end1)]} in order of first appearance,
+    intervals 1-based inclusive, sorted by (start, end)."""
+    bed = {}
+    with _open(path) as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if not line or line.startswith(("#", "track", "browser")):
+                continue
+            c, s, e = line.split("\t")[:3]
+            bed.setdefault(c, []).append((int(s) + 1, int(e)))
+    for c in bed:
+        bed[c].sort()
+    return bed
+
+
+def parse_genotype(gt):
+    """parse_genotype (region_generation.rs:660-712) -> [(alt_index, zygosity name)]"""
+    phased = "|" in gt
+    alleles = gt.replace("|", "/").split("/")
+    if len(alleles) == 1:
+        alleles = alleles * 2  # hemizygous is treated as homozygous
+    if len(alleles) != 2:
+        raise ValueError("allele.len() != [1, 2]: %s" % gt)
+    i1, i2 = [0 if a == "." else int(a) for a in alleles]
+    if i1 == i2:
+        return [(i1, "HomozygousAlternate")] if i1 else []
+    out = []
+    if i1:
+        out.append((i1, "PhasedHet10" if phased else "UnphasedHeterozygous"))
+    if i2:
+        out.append((i2, "PhasedHet01" if phased else "UnphasedHeterozygous"))
+    return out
+
+
+def variant_type(info, ref, alt):
+    """get_variant_type (:715-758) + the constructors' checks (variants.rs:104-383); None = skipped kind"""
+    if "SVTYPE" in info and info["SVTYPE"] is not None:
+        sv = info["SVTYPE"]
+        if sv in ("BND", "DUP"):
+            return None
+        if sv == "DEL":
+            if len(ref) <= 1 or len(alt) > len(ref):
+                raise ValueError("bad SV deletion")
+            return "SvDeletion"
+        if sv == "INS":
+            if len(alt) < len(ref) or not ref:
+                raise ValueError("bad SV insertion")
+            return "SvInsertion"
+        raise ValueError("Unsupported SVTYPE detected: %s" % sv)
+    if info.get("TRID"):
+        return "TrContraction" if len(alt) < len(ref) else "TrExpansion"
+    if not ref or not alt:
+        raise ValueError("cannot have alleles with 0 length")
+    if len(ref) == 1 and len(alt) == 1:
+        return "Snv"
+    if len(ref) == 1:
+        return "Insertion"
+    if len(alt) == 1:
+        return "Deletion"
+    return "Indel"
+
+
+def load_calls(path, sample, enable_trimming=True):
+    """parse_variant over every record (:563-654) -> {chrom: [call dict]} in file order"""
+    calls, col, rec = {}, None, 0
+    with _open(path) as f:
+        for line in f:
+            line = line.rstrip("\r\n")
+            if not line:
+                continue
+            if line.startswith("#"):
+                if line.startswith("#CHROM"):
+                    hdr = line.split("\t")
+                    col = 9 if not sample else hdr.index(sample)
+                continue
+            fld = line.split("\t")
+            this_rec, rec = rec, rec + 1
+            chrom, pos1, ref, alts_s, info_s, fmt = fld[0], int(fld[1]), fld[3], fld[4], fld[7], fld[8].split(":")
+            if "GT" not in fmt:
+                raise ValueError("Missing GT")
+            sv = fld[col].split(":")
+            gi = fmt.index("GT")
+            if gi >= len(sv) or sv[gi] in (".", ""):
+                continue
+            alts = [] if alts_s in (".", "") else alts_s.split(",")
+            info = {}
+            if info_s not in (".", ""):
+                for kv in info_s.split(";"):
+                    k, _, v = kv.partition("=")
+                    info[k] = v if "=" in kv else None
+            for alt_index, zyg in parse_genotype(sv[gi]):
+                alt = alts[alt_index - 1]
+                if alt == "*" or alt.startswith("<"):
+                    continue
+                r, a = ref, alt
+                raw = max(len(r), len(a))
+                while enable_trimming and len(r) > 1 and len(a) > 1 and r[-1] == a[-1]:
+                    r, a = r[:-1], a[:-1]
+                if len(r) > 10000 or len(a) > 10000:
+                    continue
+                vt = variant_type(info, r, a)
+                if vt is None:
+                    continue
+                calls.setdefault(chrom, []).append(dict(pos=pos1 - 1, a0=r, a1=a, raw=raw, type=vt, zyg=zyg, record=this_rec, alt_index=alt_index))
+    return calls
+
+
+def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
+    """RegionIterator::next (:281-478) -> list of region dicts (region_id, contig index, chrom, start, end, truth, query)."""
+    names = [n for n, _ in contigs]
+    regions, next_id, loaded = [], 0, [0, 0]
+    for chrom, intervals in bed.items():
+        if chrom not in names:
+            raise ValueError("Chromosome %s was not found in reference genome" % chrom)
+        ci = names.index(chrom)
+        chrom_length = len(contigs[ci][1])
+        zb_start, zb_end = intervals[0][0] - 1, intervals[-1][1]
+        joint = []
+        for inp, calls in enumerate((truth_calls, query_calls)):
+            for c in calls.get(chrom, []):
+                last = c["pos"] + len(c["a0"]) - 1
+                if zb_start <= c["pos"] < zb_end and zb_start <= last < zb_end:  # is_variant_contained (:764-778)
+                    joint.append((inp, c))
+                    loaded[inp] += 1
+        joint.sort(key=lambda t: t[1]["pos"])  # stable
+        head = 0
+        for (s1, e1) in intervals:
+            ib, ie = s1 - 1, e1
+            variants = [[], []]
+            ws = we = None
+            while head < len(joint):
+                inp, c = joint[head]
+                vs, ve = c["pos"], c["pos"] + len(c["a0"])
+                if vs < ib:
+                    head += 1
+                    continue
+                if vs >= ie:
+                    break
+                head += 1
+                if ve > ie:
+                    continue
+                if we is not None and vs >= we:
+                    regions.append(dict(region_id=next_id, contig=ci, chrom=chrom, start=ws, end=we, truth=variants[0], query=variants[1]))
+                    next_id += 1
+                    variants = [[], []]
+                    ws = None
+                if ws is None:
+                    ws = max(vs - gap, 0)
+                flank_end = min(vs + len(c["a0"]) + gap, chrom_length)
+                we = flank_end if we is None else max(we, flank_end)
+                variants[inp].append(c)
+            if ws is not None and we is not None:
+                regions.append(dict(region_id=next_id, contig=ci, chrom=chrom, start=ws, end=we, truth=variants[0], query=variants[1]))
+                next_id += 1
+    return regions, loaded
+
+
+def ryu(x):
+    """Text of an f64 as Rust's ryu (the csv crate) writes it."""
+    if x != x:
+        return "NaN"
+    if x in (float("inf"), float("-inf")):
+        return "inf" if x > 0 else "-inf"
+    if x == 0:
+        return "0.0"
+    sign, digits, exp = Decimal(repr(x)).as_tuple()
+    digits = list(digits)
+    while len(digits) > 1 and digits[-1] == 0:
+        digits.pop()
+        exp += 1
+    ds = "".join(map(str, digits))
+    k, kk = exp, len(ds) + exp
+    if 0 <= k and kk <= 16:
+        body = ds + "0" * k + ".0"
+    elif 0 < kk <= 16:
+        body = ds[:kk] + "." + ds[kk:]
+    elif -5 < kk <= 0:
+        body = "0." + "0" * (-kk) + ds
+    else:
+        body = ds[0] + ("." + ds[1:] if len(ds) > 1 else "") + "e" + str(kk - 1)
+    return ("-" if sign else "") + body
+
+
+FIELDS = ["GT_TRUTH_TP", "GT_TRUTH_FN", "GT_QUERY_TP", "GT_QUERY_FP", "GT_TRUTH_FN_GT", "GT_QUERY_FP_GT", "HAP_TRUTH_TP", "HAP_TRUTH_FN", "HAP_QUERY_TP",
+          "HAP_QUERY_FP", "WHAP_TRUTH_TP", "WHAP_TRUTH_FN", "WHAP_QUERY_TP", "WHAP_QUERY_FP", "BP_TRUTH_TP", "BP_TRUTH_FN", "BP_QUERY_TP", "BP_QUERY_FP",
+          "RBP_TRUTH_TP", "RBP_TRUTH_FN", "RBP_QUERY_TP", "RBP_QUERY_FP"]
+
+
+def summary_text(tally, compare_label="compare", metrics=("GT", "BASEPAIR"), delim="\t"):
+    """SummaryWriter::write_summary (src/writers/summary.rs:163-395) over the ALL block."""
+    types = list(VT)
+    base = {"GT": 0, "HAP": 6, "WEIGHTED_HAP": 10, "BASEPAIR": 14, "RECORD_BP": 18}
+    joints = [("JointIndel", ["Insertion", "Deletion", "Indel"]),
+              ("JointStructuralVariant", ["SvInsertion", "SvDeletion", "SvDuplication", "SvInversion", "SvBreakend"]),
+              ("JointTandemRepeat", ["TrExpansion", "TrContraction"])]
+    lines = [delim.join(["compare_label", "comparison", "region_label", "filter", "variant_type", "truth_total", "truth_tp", "truth_fn", "query_total",
+                         "query_tp", "query_fp", "metric_recall", "metric_precision", "metric_f1", "truth_fn_gt", "query_fp_gt"])]
+
+    def group(g):
+        return [int(x) for x in tally[g * 22:(g + 1) * 22]]
+
+    def row(kind, vtype, m, extra):
+        ttot, qtot = m[0] + m[1], m[2] + m[3]
+        rec = m[0] / ttot if ttot else None
+        pre = m[2] / qtot if qtot else None
+        if rec is not None and pre is not None:
+            f1 = 2.0 * rec * pre / (rec + pre) if rec + pre != 0 else float("nan")
+        else:
+            f1 = None
+        cells = [compare_label, kind, "ALL", "ALL", vtype, ttot, m[0], m[1], qtot, m[2], m[3], "" if rec is None else ryu(rec), "" if pre is None else ryu(pre),
+                 "" if f1 is None else ryu(f1)] + (list(extra) if kind == "GT" else ["", ""])
+        lines.append(delim.join(str(c) for c in cells))
+
+    for kind in metrics:
+        b = base[kind]
+        g0 = group(0)
+        row(kind, "ALL", g0[b:b + 4], g0[4:6])
+        for t, name in enumerate(types):
+            g = group(1 + t)
+            if sum(g[b:b + 4]) == 0:
+                continue
+            row(kind, name, g[b:b + 4], g[4:6])
+        for label, members in joints:
+            s, sx = [0, 0, 0, 0], [0, 0]
+            for name in members:
+                g = group(1 + VT[name])
+                s = [a + c for a, c in zip(s, g[b:b + 4])]
+                sx = [a + c for a, c in zip(sx, g[4:6])]
+            if sum(s) == 0:
+                continue
+            row(kind, label, s, sx)
+    return "\n".join(lines) + "\n"

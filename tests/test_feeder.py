@@ -1,0 +1,292 @@
+"""The C++ feeder (FASTA / BED / VCF -> region batch) and summary writer of libaardvark_feeder.so against the plain-Python
+restatement of the reference (oracle/feeder_oracle.py), the synthetic generator's clustering, and — pinned by the
+reference's own known answers — the 8 solve_compare_region test regions sent through VCF files."""
+import gzip
+import json
+import os
+import re
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import feeder_oracle as fo  # noqa: E402
+import oracle_lib  # noqa: E402
+import scenarios  # noqa: E402
+from aardvark_amd import feeder, synth  # noqa: E402
+from aardvark_amd._abi import F, VT, ZYG, RegionBatch  # noqa: E402
+from test_oracle_golden import check_region_expectations  # noqa: E402
+
+GT_OF = {"HomozygousAlternate": "1/1", "UnphasedHeterozygous": "0/1", "PhasedHet01": "0|1", "PhasedHet10": "1|0"}
+ZNAME = {v: k for k, v in ZYG.items()}
+HEADER = "##fileformat=VCFv4.2\n##contig=<ID={c}>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t{s}\n"
+
+
+@pytest.fixture(scope="module")
+def oracle():
+    return oracle_lib.load()
+
+
+def write_text(path, text, mode="plain"):
+    data = text.encode()
+    if mode == "plain":
+        open(path, "wb").write(data)
+    elif mode == "gz":
+        open(path, "wb").write(gzip.compress(data))
+    else:  # several gzip members back to back, like BGZF blocks
+        cut = [0, len(data) // 3, 2 * len(data) // 3, len(data)]
+        open(path, "wb").write(b"".join(gzip.compress(data[a:b]) for a, b in zip(cut[:-1], cut[1:])))
+
+
+def vcf_text(chrom, calls, sample="S1"):
+    """calls: [(pos0, ref, alt, zygosity name)]"""
+    lines = [HEADER.format(c=chrom, s=sample)]
+    for pos, ref, alt, zyg in calls:
+        lines.append("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (chrom, pos + 1, ref, alt, GT_OF[zyg]))
+    return "".join(lines)
+
+
+def batch_of(regions):
+    """feeder_oracle regions -> RegionBatch"""
+    conv = lambda c: (c["pos"], c["a0"], c["a1"], c["type"], c["zyg"], c["raw"])
+    return RegionBatch.from_regions([dict(region_id=r["region_id"], contig=r["contig"], start=r["start"], end=r["end"],
+                                          truth=[conv(c) for c in r["truth"]], query=[conv(c) for c in r["query"]]) for r in regions])
+
+
+def assert_same_batch(a, b):
+    assert a.n_regions == b.n_regions and a.n_variants == b.n_variants
+    for f in ("region_id", "contig_idx", "start", "end", "t_cnt", "q_cnt", "t_off", "q_off", "var_pos", "var_type", "var_zyg", "var_raw_space", "a0_len", "a1_len"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    for v in range(a.n_variants):
+        for off, ln in (("a0_off", "a0_len"), ("a1_off", "a1_len")):
+            sa = a.allele_bytes[int(getattr(a, off)[v]):int(getattr(a, off)[v]) + int(getattr(a, ln)[v])]
+            sb = b.allele_bytes[int(getattr(b, off)[v]):int(getattr(b, off)[v]) + int(getattr(b, ln)[v])]
+            assert bytes(sa) == bytes(sb)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = feeder.load_library()
+    src = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "aardvark_feeder.h")).read(), flags=re.S)
+    names = sorted(set(re.findall(r"\b(avf_[a-z0-9_]+)\s*\(", src)))
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), n
+
+
+EDGE_FASTA = ">chrA first contig\n" + "ACGTTGCAAC" * 40 + "\n>chrB\n" + "GATTACA" * 30 + "\n>chrUnused\nACGT\n"
+EDGE_BED = "chrB\t5\t150\nchrA\t200\t390\nchrA\t10\t120\nchrA\t130\t180\n#comment\nchrB\t160\t205\n"  # chrB first, chrA unsorted
+EDGE_VCF_T = HEADER.format(c="chrA", s="OTHER\tS1") + "".join([
+    "chrA\t5\t.\tT\tG\t.\t.\t.\tGT\t0/1\t1/1\n",                      # before the first interval: dropped
+    "chrA\t12\t.\tT\tG,C\t.\t.\t.\tGT:DP\t0/0:3\t1|2:9\n",            # multi-allelic, phased: two calls
+    "chrA\t15\t.\tTGC\tT\t.\t.\t.\tGT\t./.\t1\n",                     # hemizygous -> homozygous
+    "chrA\t40\t.\tCA\tCAA,*\t.\t.\t.\tGT\t0/1\t2/1\n",                 # '*' allele skipped, insertion kept; no suffix left after trimming? CA/CAA -> C/CA
+    "chrA\t60\t.\tA\t<DEL>\t.\t.\tSVTYPE=DEL\tGT\t0/1\t0/1\n",         # symbolic: skipped
+    "chrA\t70\t.\tAC\tGC\t.\t.\t.\tGT\t0/1\t0|1\n",                    # trims to A>G (SNV), raw space 2
+    "chrA\t80\t.\tG\tT\t.\t.\t.\tGT\t0/1\t.\n",                       # missing GT: no-op
+    "chrA\t90\t.\tG\tT\t.\t.\t.\tGT\t0/1\t0/0\n",                      # hom ref: nothing
+    "chrA\t118\t.\tGCAACA\tG\t.\t.\t.\tGT\t0/1\t0/1\n",                # runs past the interval end (120): overlapping, dropped
+    "chrA\t125\t.\tG\tT\t.\t.\t.\tGT\t0/1\t1/1\n",                     # between intervals: dropped
+    "chrA\t135\t.\tACGTTGCAACACG\tA\t.\t.\tSVTYPE=DEL\tGT\t0/1\t1/0\n",  # sequence-resolved SV deletion
+    "chrA\t150\t.\tC\tCGGGG\t.\t.\tTRID=tr1\tGT\t0/1\t0/1\n",          # tandem-repeat expansion
+    "chrA\t160\t.\tCAAC\tC\t.\t.\tTRID=tr2\tGT\t0/1\t1|0\n",           # tandem-repeat contraction
+    "chrA\t170\t.\tA\tAT\t.\t.\tSVTYPE=DUP\tGT\t0/1\t0/1\n",           # unsupported SV kind: skipped
+    "chrA\t210\t.\tC\tA\t.\t.\t.\tGT\t0/1\t0/1\n",
+    "chrA\t262\t.\tC\tA\t.\t.\t.\tGT\t0/1\t0/1\n",                     # 52 bp later: its own window... (210+1+50 = 260 <= 261)
+    "chrA\t300\t.\tC\tCTT\t.\t.\t.\tGT\t0/1\t1/1\n",
+    "chrA\t395\t.\tC\tA\t.\t.\t.\tGT\t0/1\t1/1\n",                     # after the last interval
+    "chrB\t3\t.\tT\tA\t.\t.\t.\tGT\t0/1\t1/1\n",                       # before chrB's span
+    "chrB\t10\t.\tA\tC\t.\t.\t.\tGT\t0/1\t1/1\n",
+    "chrB\t200\t.\tC\tA\t.\t.\t.\tGT\t0/1\t0/1\n",
+    "chrC\t10\t.\tA\tC\t.\t.\t.\tGT\t0/1\t1/1\n",                      # chromosome without BED intervals
+])
+EDGE_VCF_Q = HEADER.format(c="chrA", s="Q") + "".join([
+    "chrA\t12\t.\tT\tG\t.\t.\t.\tGT\t0/1\n",
+    "chrA\t12\t.\tT\tC\t.\t.\t.\tGT\t1/0\n",
+    "chrA\t16\t.\tGC\tG\t.\t.\t.\tGT\t1/1\n",
+    "chrA\t41\t.\tA\tAA\t.\t.\t.\tGT\t0/1\n",
+    "chrA\t70\t.\tA\tG\t.\t.\t.\tGT\t1|0\n",
+    "chrA\t300\t.\tC\tCT\t.\t.\t.\tGT\t1/1\n",
+    "chrB\t10\t.\tA\tC\t.\t.\t.\tGT\t0/1\n",
+    "chrB\t204\t.\tAC\tA\t.\t.\t.\tGT\t0/1\n",                          # ends exactly at the span end (205): contained
+])
+
+
+@pytest.mark.parametrize("mode", ["plain", "gz", "members"])
+def test_edge_case_files_match_the_restatement(tmp_path, mode):
+    paths = {}
+    for name, text in (("ref.fa", EDGE_FASTA), ("hc.bed", EDGE_BED), ("truth.vcf", EDGE_VCF_T), ("query.vcf", EDGE_VCF_Q)):
+        paths[name] = str(tmp_path / (name + ("" if mode == "plain" else ".gz")))
+        write_text(paths[name], text, mode)
+    genome = feeder.Genome(paths["ref.fa"])
+    contigs = fo.read_fasta(paths["ref.fa"])
+    assert genome.names == [n for n, _ in contigs] == ["chrA", "chrB", "chrUnused"]
+    assert [bytes(c).decode() for c in genome.contigs()] == [s for _, s in contigs]
+    for trim in (True, False):
+        feed = feeder.feed_compare(paths["truth.vcf"], paths["query.vcf"], paths["hc.bed"], genome, truth_sample="S1", enable_trimming=trim)
+        regions, loaded = fo.generate_regions(fo.load_calls(paths["truth.vcf"], "S1", trim), fo.load_calls(paths["query.vcf"], "", trim),
+                                              fo.read_bed(paths["hc.bed"]), contigs)
+        assert_same_batch(feed.batch, batch_of(regions))
+        assert list(feed.loaded) == loaded
+        flat = [c for r in regions for c in r["truth"] + r["query"]]
+        assert [int(x) for x in feed.var_record] == [c["record"] for c in flat]
+        assert [int(x) for x in feed.var_alt_index] == [c["alt_index"] for c in flat]
+        if trim:  # spot checks of the rules themselves, independent of the restatement
+            b = feed.batch
+            assert [int(x) for x in b.contig_idx[:2]] == [1, 1]          # chrB comes first in the BED
+            names = {(int(b.contig_idx[r]), int(b.start[r]), int(b.end[r])) for r in range(b.n_regions)}
+            assert (0, 159, 260) in names and (0, 211, 350) in names     # 210 and 262 (1-based) do not share a window; 262 and 300 do
+            t_types = [int(x) for x in b.var_type[:]]
+            assert VT["SvDeletion"] in t_types and VT["TrExpansion"] in t_types and VT["TrContraction"] in t_types
+            i = list(b.var_pos).index(69)                                # AC>GC trimmed to A>G, raw allele space kept
+            assert int(b.a0_len[i]) == 1 and int(b.var_raw_space[i]) == 2 and int(b.var_zyg[i]) == ZYG["PhasedHet01"]
+
+
+def test_errors_are_reported(tmp_path):
+    fa, bed = str(tmp_path / "r.fa"), str(tmp_path / "r.bed")
+    write_text(fa, EDGE_FASTA)
+    write_text(bed, "chrZ\t1\t50\n")
+    t = str(tmp_path / "t.vcf")
+    write_text(t, vcf_text("chrA", [(11, "T", "G", "HomozygousAlternate")]))
+    g = feeder.Genome(fa)
+    with pytest.raises(feeder.FeederError, match="not found in reference genome"):
+        feeder.feed_compare(t, t, bed, g)
+    with pytest.raises(feeder.FeederError, match="was not found in"):
+        feeder.feed_compare(t, t, bed, g, truth_sample="nobody")
+    with pytest.raises(feeder.FeederError, match="required"):
+        feeder.feed_compare(t, t, "", g)
+    bad = str(tmp_path / "bad.vcf")
+    write_text(bad, HEADER.format(c="chrA", s="S1") + "chrA\t12\t.\tT\tG\t.\t.\t.\tGT\t0/1/1\n")
+    write_text(bed, "chrA\t1\t50\n")
+    with pytest.raises(feeder.FeederError, match="allele.len"):
+        feeder.feed_compare(bad, t, bed, g)
+
+
+def test_synthetic_call_sets_round_trip_through_vcf(tmp_path):
+    """the generator's own clustering (a numpy mirror of RegionIterator) and the feeder agree on a chr20-like call set"""
+    length = 400_000
+    contig = synth.make_contig(length, 5)
+    rng = np.random.default_rng(6)
+    bed = synth.make_bed(length, 12, 0.9, rng)
+    truth = synth.indel_truth(contig, bed, 1500, 7)
+    query = synth.perturb_query(contig, bed, truth, 8, 20)
+    want = synth.cluster_regions(length, bed, truth, query, 50)
+    fa, bd, tv, qv = (str(tmp_path / n) for n in ("c.fa.gz", "c.bed", "t.vcf.gz", "q.vcf"))
+    seq = bytes(contig).decode()
+    write_text(fa, ">chr20 synthetic\n" + "\n".join(seq[i:i + 60] for i in range(0, length, 60)) + "\n", "members")
+    write_text(bd, "".join("chr20\t%d\t%d\n" % (a, b) for a, b in bed))
+    for path, cs, mode in ((tv, truth, "gz"), (qv, query, "plain")):
+        write_text(path, vcf_text("chr20", [(int(cs.pos[i]), cs.ref[i].decode(), cs.alt[i].decode(), ZNAME[int(cs.zyg[i])]) for i in range(len(cs))]), mode)
+    genome = feeder.Genome(fa)
+    feed = feeder.feed_compare(tv, qv, bd, genome, enable_trimming=False)
+    assert_same_batch(feed.batch, want)
+    assert np.array_equal(genome.contigs()[0], contig)
+
+
+def test_reference_known_answers_through_vcf_files(tmp_path, oracle):
+    """the 8 solve_compare_region test regions as truth/query VCFs + BED on mock_chr1; the metrics the
+    reference asserts come out of feeder -> solver (the window is the generated one, so sequences are not compared)."""
+    g = json.load(open(os.path.join(ROOT, "tests", "golden", "waffle_solver.json")))
+    fa, bd = str(tmp_path / "mock.fa"), str(tmp_path / "mock.bed")
+    write_text(fa, ">mock_chr1\n" + g["contig"] + "\n")
+    write_text(bd, "mock_chr1\t0\t%d\n" % len(g["contig"]))
+    genome = feeder.Genome(fa)
+    tallies = []
+    for k, reg in enumerate(g["regions"]):
+        tv, qv = str(tmp_path / ("t%d.vcf" % k)), str(tmp_path / ("q%d.vcf" % k))
+        write_text(tv, vcf_text("mock_chr1", [(p, a0, a1, z) for p, a0, a1, _t, z in reg["truth"]]))
+        write_text(qv, vcf_text("mock_chr1", [(p, a0, a1, z) for p, a0, a1, _t, z in reg["query"]]))
+        feed = feeder.feed_compare(tv, qv, bd, genome)
+        b = feed.batch
+        assert b.n_regions == 1 and int(b.start[0]) == 0 and int(b.end[0]) == len(g["contig"])
+        assert [int(x) for x in b.var_type] == [VT[v[3]] for v in reg["truth"] + reg["query"]]
+        assert [int(x) for x in b.var_zyg] == [ZYG[v[4]] for v in reg["truth"] + reg["query"]]
+        res = oracle_lib.compare_batch(oracle, b, [c for c in genome.contigs()])
+        check_region_expectations(res, 0, reg, b)
+        tallies.append(res.tally.copy())
+    # and the summary of all of them, written by the library, against the restatement
+    total = np.sum(tallies, axis=0).astype(np.uint64)
+    out = str(tmp_path / "summary.tsv")
+    feeder.write_summary(out, total, "golden", feeder.METRIC_GT | feeder.METRIC_BASEPAIR | feeder.METRIC_HAP)
+    text = open(out).read()
+    assert text == fo.summary_text(total, "golden", ("GT", "BASEPAIR", "HAP"))
+    rows = [l.split("\t") for l in text.splitlines()]
+    assert rows[0][:5] == ["compare_label", "comparison", "region_label", "filter", "variant_type"] and len(rows[0]) == 16
+    gt_all = rows[1]
+    assert gt_all[:5] == ["golden", "GT", "ALL", "ALL", "ALL"]
+    want_tp = sum(r["expect"]["gt"][0] for r in g["regions"])
+    want_fn = sum(r["expect"]["gt"][1] for r in g["regions"])
+    assert int(gt_all[6]) == want_tp and int(gt_all[7]) == want_fn and int(gt_all[5]) == want_tp + want_fn
+    assert float(gt_all[11]) == want_tp / (want_tp + want_fn)
+
+
+def test_summary_float_text_and_csv(tmp_path):
+    """ryu's shortest round-trip float text as the csv crate writes it; empty categories are left out; .csv is comma separated"""
+    assert [fo.ryu(x) for x in (1.0, 0.5, 1 / 3, 2 / 3, 0.1, 1e-5, 9.5e-6, 123456.0, 1e16, 1.5e-7, float("nan"))] == \
+        ["1.0", "0.5", "0.3333333333333333", "0.6666666666666666", "0.1", "0.00001", "9.5e-6", "123456.0", "1e16", "1.5e-7", "NaN"]
+    rng = np.random.default_rng(3)
+    for trial in range(6):
+        tally = np.zeros(288, np.uint64)
+        for g in rng.choice(13, size=int(rng.integers(1, 8)), replace=False):
+            tally[g * 22:(g + 1) * 22] = rng.integers(0, 10 ** int(rng.integers(1, 9)), size=22)
+        if trial == 0:  # a block whose recall and precision are both 0: F1 is 0/0
+            tally[:22] = 0
+            tally[F["GT_TRUTH_FN"]] = 3
+            tally[F["GT_QUERY_FP"]] = 2
+        for ext, delim in ((".tsv", "\t"), (".csv", ",")):
+            out = str(tmp_path / ("s%d%s" % (trial, ext)))
+            feeder.write_summary(out, tally, "lab,el" if ext == ".csv" else "label", 31)
+            want = fo.summary_text(tally, '"lab,el"' if ext == ".csv" else "label", ("GT", "BASEPAIR", "HAP", "WEIGHTED_HAP", "RECORD_BP"), delim)
+            assert open(out).read() == want
+        if trial == 0:
+            assert "NaN" in open(out).read()
+
+
+def write_case_files(tmp_path, n_truth=3000, length=1_500_000):
+    """a small chr20-shaped SNV+indel call set as FASTA(.gz) + BED + two VCFs; returns (paths, contig, batch the generator clusters)"""
+    contig = synth.make_contig(length, 15)
+    rng = np.random.default_rng(16)
+    bed = synth.make_bed(length, 20, 0.9, rng)
+    truth = synth.indel_truth(contig, bed, n_truth, 17)
+    query = synth.perturb_query(contig, bed, truth, 18, 30)
+    want = synth.cluster_regions(length, bed, truth, query, 50)
+    p = {k: str(tmp_path / v) for k, v in dict(fa="c.fa.gz", bed="c.bed", t="t.vcf.gz", q="q.vcf.gz", out="out").items()}
+    seq = bytes(contig).decode()
+    write_text(p["fa"], ">chr20\n" + "\n".join(seq[i:i + 80] for i in range(0, length, 80)) + "\n", "gz")
+    write_text(p["bed"], "".join("chr20\t%d\t%d\n" % (a, b) for a, b in bed))
+    for path, cs in ((p["t"], truth), (p["q"], query)):
+        write_text(path, vcf_text("chr20", [(int(cs.pos[i]), cs.ref[i].decode(), cs.alt[i].decode(), ZNAME[int(cs.zyg[i])]) for i in range(len(cs))]), "members")
+    return p, contig, want
+
+
+def cli_path():
+    return os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare")
+
+
+def test_command_line_tool_fails_loudly_without_a_gpu(tmp_path):
+    """there is no CPU path behind the tool either: without a HIP device it stops at context creation"""
+    import subprocess
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    p, _, _ = write_case_files(tmp_path, 50, 60_000)
+    r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"]], capture_output=True, text=True)
+    assert r.returncode == 70 and "cannot create the GPU context" in r.stderr
+    assert not os.path.exists(os.path.join(p["out"], "summary.tsv"))
+
+
+@pytest.mark.gpu
+def test_command_line_tool_end_to_end(tmp_path, oracle):
+    """FASTA + BED + VCFs -> aardvark_amd_compare on the GPU -> summary.tsv, against generator clustering + oracle + restated writer"""
+    import subprocess
+    p, contig, want_batch = write_case_files(tmp_path)
+    r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"], "--disable-variant-trimming",
+                        "--compare-label", "e2e", "--enable-haplotype-metrics", "--enable-weighted-haplotype-metrics", "--enable-record-basepair-metrics",
+                        "--batch-regions", "700"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    res = oracle_lib.compare_batch(oracle, want_batch, [contig], threads=8)
+    assert (res.status == 0).all()
+    want = fo.summary_text(res.tally, "e2e", ("GT", "BASEPAIR", "HAP", "WEIGHTED_HAP", "RECORD_BP"))
+    assert open(os.path.join(p["out"], "summary.tsv")).read() == want
+    assert "Solved:error blocks: %d : 0" % want_batch.n_regions in r.stderr

@@ -124,7 +124,14 @@ def test_results_do_not_depend_on_the_workspace_tier(oracle):
     for opts in ({"lds_bytes_per_wave": 0}, {"lds_bytes_per_wave": 0, "lds2_bytes_per_wave": 0},
                  {"lds_bytes_per_wave": 4096, "lds_ed_cap": 2, "lds2_bytes_per_wave": 6144, "lds2_ed_cap": 4},
                  {"lds_bytes_per_wave": 0, "lds2_bytes_per_wave": 0, "ws_bytes_per_wave": 0},
-                 {"lds_bytes_per_wave": 32768, "lds_ed_cap": 64, "waves_per_cu": 4}):
+                 {"lds_bytes_per_wave": 32768, "lds_ed_cap": 64, "waves_per_cu": 4},
+                 # scheduling variants: no solo launches, no in-workgroup escalation, the four-launch chain, solo waves with
+                 # several regions each, tiny tier-0 slices (every other region escalates inside its workgroup), tier-2
+                 # slices too small (big slices claimed in place)
+                 {"solo_min_variants": 0}, {"lds_escalation": 0}, {"lds_escalation": 0, "lds2_overflow_pass": 1, "solo_min_variants": 0},
+                 {"solo_min_variants": 3, "solo_regions_per_wave": 16, "solo_blocks_max": 16, "class_c_nodes_x2": 3},
+                 {"lds_bytes_per_wave": 4096, "solo_min_variants": 0},
+                 {"lds_bytes_per_wave": 4096, "lds2_bytes_per_wave": 8192, "ws_bytes_per_wave": 12288, "big_waves": 4}):
         c = aardvark_amd.Context(0)
         for k, v in opts.items():
             c.set_option(k, v)
