@@ -2,8 +2,8 @@
  * compare_main.cpp — `aardvark_amd_compare`: the reference's `aardvark compare` flow (src/main.rs:30-327) on top of the
  * two C-ABIs: libaardvark_feeder.so turns FASTA + BED + truth/query VCFs into region batches, libaardvark_amd.so
  * solves them on the GPU, the feeder library writes summary.tsv.  Option names are the reference's
- * (src/cli/compare.rs).  Not implemented here: stratifications, the annotated truth/query VCFs and the debug
- * TSVs (rest) — the flags are rejected rather than ignored.
+ * (src/cli/compare.rs).  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).  Not implemented here: stratifications
+ * and the debug TSVs — the flags are rejected rather than ignored.
  */
 #include <cerrno>
 #include <chrono>
@@ -122,7 +122,8 @@ int main(int argc, char **argv) {
     cfg.max_branch_factor = (uint32_t)branch;
     cfg.enable_sequences = 0;
     cfg.enable_exact_shortcut = shortcut ? 1 : 0;
-    std::vector<int32_t> status;
+    std::vector<int32_t> status(all->n_regions, -1); /* regions outside --skip/--take stay unsolved and unwritten */
+    std::vector<uint8_t> var_expected(all->n_variants + 1), var_observed(all->n_variants + 1), var_class(all->n_variants + 1);
     (void)avk_ctx_set_option(ctx, "emit_group_metrics", 0); /* only the summed block is needed here */
     for (uint64_t at = 0; at < count; at += batch_regions) {
         const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
@@ -136,17 +137,19 @@ int main(int argc, char **argv) {
         b.t_cnt = all->t_cnt + first + at;
         b.q_off = all->q_off + first + at;
         b.q_cnt = all->q_cnt + first + at;
-        status.assign(n, 0);
         avk_result_batch out;
         memset(&out, 0, sizeof(out));
-        out.status = status.data();
+        out.status = status.data() + first + at;
         out.tally = tally.data();
+        out.var_expected = var_expected.data(); /* indexed by the (shared) variant arrays */
+        out.var_observed = var_observed.data();
+        out.var_class = var_class.data();
         if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
         for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += tally[k];
         for (uint64_t r = 0; r < n; ++r)
-            if (status[r] != 0)
+            if (out.status[r] != 0)
                 fprintf(stderr, "Error while solving compare region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)b.region_id[r], b.contig_idx[r],
-                        (unsigned long long)b.start[r], (unsigned long long)b.end[r], status[r]);
+                        (unsigned long long)b.start[r], (unsigned long long)b.end[r], out.status[r]);
     }
     const double s_solve = seconds_since(t0);
 
@@ -157,10 +160,18 @@ int main(int argc, char **argv) {
     if (rbp) mask |= AVF_METRIC_RECORD_BP;
     const std::string summary = out_dir + "/summary.tsv";
     if (avf_write_summary(summary.c_str(), label.c_str(), total.data(), mask)) die(74, "Error while saving summary file", avf_last_error());
+    /* the annotated VCFs (VariantCategorizer): truth.vcf.gz and query.vcf.gz with their .tbi */
+    std::string command;
+    for (int i = 0; i < argc; ++i) command += (i ? " " : "") + std::string(argv[i]);
+    const char *in_vcf[2] = {truth.c_str(), query.c_str()}, *samples[2] = {truth_sample.c_str(), query_sample.c_str()}, *names[2] = {"/truth.vcf.gz", "/query.vcf.gz"};
+    for (int src = 0; src < 2; ++src)
+        if (avf_write_annotated_vcf((out_dir + names[src]).c_str(), in_vcf[src], samples[src], avk_version(), command.c_str(), genome, all, src, status.data(),
+                                    var_expected.data(), var_observed.data(), var_class.data()))
+            die(74, "Error while saving output files", avf_last_error());
     const double s_write = seconds_since(t0);
 
     fprintf(stderr, "Solved:error blocks: %llu : %llu\n", (unsigned long long)total[AVK_TALLY_LEN - 2], (unsigned long long)total[AVK_TALLY_LEN - 1]);
-    fprintf(stderr, "stages [s]: reference %.3f, feeder %.3f, gpu context + reference upload %.3f, solve (pack + H2D + kernels + D2H) %.3f, summary %.3f\n",
+    fprintf(stderr, "stages [s]: reference %.3f, feeder %.3f, gpu context + reference upload %.3f, solve (pack + H2D + kernels + D2H) %.3f, summary + annotated VCFs %.3f\n",
             s_genome, s_feed, s_ref, s_solve, s_write);
     fprintf(stderr, "Comparisons completed in %.3f seconds (%.2f M regions/s in the solve stage).\n", seconds_since(t_start),
             s_solve > 0 ? (double)count / s_solve / 1e6 : 0.0);

@@ -33,6 +33,21 @@ int fail(int code, const char *fmt, ...) {
     return code;
 }
 
+} // namespace
+
+/* for the other translation units of the library */
+int avf_fail_(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_error = buf;
+    return code;
+}
+
+namespace {
+
 /* line reader over plain, gzip and BGZF files (zlib reads all three; BGZF is a series of gzip members) */
 class LineReader {
   public:

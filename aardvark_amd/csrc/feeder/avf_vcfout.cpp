@@ -1,0 +1,251 @@
+/*
+ * avf_vcfout.cpp — the annotated truth.vcf.gz / query.vcf.gz of `aardvark compare`
+ * (src/writers/variant_categorizer.rs:41-230, src/writers/noodles_idx.rs:7-20), written as BGZF with a tabix index.
+ * Part of libaardvark_feeder.so; host code only.
+ */
+#include "../../../include/aardvark_feeder.h"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+int avf_fail_(int code, const char *fmt, ...); /* avf_feeder.cpp: sets the text avf_last_error returns */
+
+namespace {
+
+/* ---- BGZF (SAM spec section 4.1): gzip members of at most 64 KiB with a BC extra field ---- */
+class BgzfWriter {
+  public:
+    explicit BgzfWriter(FILE *fp) : fp_(fp) { buf_.reserve(kBlock); }
+    /* virtual offset of the next byte written */
+    uint64_t tell() const { return (file_off_ << 16) | (uint64_t)buf_.size(); }
+    bool write(const char *p, size_t n) {
+        while (n) {
+            const size_t room = kBlock - buf_.size();
+            const size_t take = n < room ? n : room;
+            buf_.insert(buf_.end(), p, p + take);
+            p += take;
+            n -= take;
+            if (buf_.size() == kBlock && !flush_block()) return false;
+        }
+        return true;
+    }
+    bool finish() {
+        if (!buf_.empty() && !flush_block()) return false;
+        static const unsigned char eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
+        return fwrite(eof, 1, sizeof(eof), fp_) == sizeof(eof);
+    }
+
+  private:
+    static constexpr size_t kBlock = 0xff00;
+    bool flush_block() {
+        std::vector<unsigned char> out(kBlock + 1024);
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        zs.next_in = (Bytef *)buf_.data();
+        zs.avail_in = (uInt)buf_.size();
+        zs.next_out = out.data() + 18;
+        zs.avail_out = (uInt)(out.size() - 18 - 8);
+        const int rc = deflate(&zs, Z_FINISH);
+        const size_t clen = zs.total_out;
+        deflateEnd(&zs);
+        if (rc != Z_STREAM_END) return false;
+        const size_t total = 18 + clen + 8;
+        static const unsigned char head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};
+        memcpy(out.data(), head, 16);
+        out[16] = (unsigned char)((total - 1) & 0xff);
+        out[17] = (unsigned char)((total - 1) >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)buf_.data(), (uInt)buf_.size());
+        const uint32_t isize = (uint32_t)buf_.size();
+        for (int k = 0; k < 4; ++k) {
+            out[18 + clen + k] = (unsigned char)(crc >> (8 * k));
+            out[18 + clen + 4 + k] = (unsigned char)(isize >> (8 * k));
+        }
+        if (fwrite(out.data(), 1, total, fp_) != total) return false;
+        file_off_ += total;
+        buf_.clear();
+        return true;
+    }
+    FILE *fp_;
+    std::vector<char> buf_;
+    uint64_t file_off_ = 0;
+};
+
+/* ---- tabix index (tabix spec): binning index + 16 kb linear index per contig ---- */
+int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+};
+
+template <typename T> void put(std::string &s, T v) {
+    for (size_t k = 0; k < sizeof(T); ++k) s.push_back((char)((uint64_t)v >> (8 * k)));
+}
+
+} // namespace
+
+extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_vcf, const char *sample_name, const char *version, const char *command_line,
+                                       const avf_genome *g, const avk_region_batch *b, int source, const int32_t *status, const uint8_t *var_expected,
+                                       const uint8_t *var_observed, const uint8_t *var_class) {
+    if (!out_path || !input_vcf || !g || !b || !status || !var_expected || !var_observed || !var_class || (source != 0 && source != 1))
+        return avf_fail_(AVK_E_ARG, "null or invalid argument");
+    /* header of the input file, up to the column line */
+    std::vector<std::string> meta;
+    std::string first_sample;
+    {
+        gzFile in = gzopen(input_vcf, "rb");
+        if (!in) return avf_fail_(AVK_E_ARG, "Error while opening %s", input_vcf);
+        std::string line;
+        char chunk[1 << 16];
+        bool done = false;
+        while (!done && gzgets(in, chunk, sizeof(chunk))) {
+            line += chunk;
+            if (line.empty() || line.back() != '\n') continue; /* a longer line: keep reading */
+            while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+            if (line.compare(0, 2, "##") == 0) meta.push_back(line);
+            else {
+                if (line.compare(0, 6, "#CHROM") == 0) {
+                    size_t tabs = 0, at = 0;
+                    while (tabs < 9 && (at = line.find('\t', at)) != std::string::npos) {
+                        ++tabs;
+                        ++at;
+                    }
+                    if (tabs == 9) first_sample = line.substr(at, line.find('\t', at) == std::string::npos ? std::string::npos : line.find('\t', at) - at);
+                }
+                done = true;
+            }
+            line.clear();
+        }
+        gzclose(in);
+    }
+    const std::string sample = sample_name && *sample_name ? sample_name : first_sample;
+    FILE *fp = fopen(out_path, "wb");
+    if (!fp) return avf_fail_(AVK_E_ARG, "cannot create %s", out_path);
+    BgzfWriter w(fp);
+    bool ok = true;
+    auto emit = [&](const std::string &s) { ok = ok && w.write(s.data(), s.size()); };
+    for (const std::string &m : meta) emit(m + "\n");
+    /* what the reference adds (variant_categorizer.rs:41-87) */
+    emit(std::string("##aardvark_version=\"") + (version ? version : "") + "\"\n");
+    emit(std::string("##aardvark_command=\"") + (command_line ? command_line : "") + "\"\n");
+    emit("##FORMAT=<ID=BD,Number=1,Type=String,Description=\"Benchmark Decision for call (TP/FP/FN)\">\n");
+    emit("##FORMAT=<ID=EA,Number=1,Type=Integer,Description=\"Expected Allele count for this genotype\">\n");
+    emit("##FORMAT=<ID=OA,Number=1,Type=Integer,Description=\"Observed Allele count for this genotype\">\n");
+    emit("##FORMAT=<ID=RI,Number=1,Type=Integer,Description=\"Region ID for the comparison\">\n");
+    emit("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n");
+
+    static const char *const gts[6] = {".", "0/0", "0/1", "0|1", "1|0", "1/1"};
+    static const char *const classes[4] = {"UNK", "TP", "FN", "FP"};
+    const uint32_t n_contigs = avf_genome_n_contigs(g);
+    std::vector<RefIndex> index(n_contigs);
+    std::vector<uint32_t> contig_order; /* contigs in order of first record */
+    std::vector<char> seen(n_contigs, 0);
+    std::string rec;
+    for (uint64_t r = 0; r < b->n_regions && ok; ++r) {
+        if (status[r] != 0) continue; /* failed regions are not written (compare_parallel.rs:229-262) */
+        const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
+        if (c >= n_contigs) {
+            fclose(fp);
+            return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
+        }
+        const uint64_t off = source == 0 ? b->t_off[r] : b->q_off[r];
+        const uint32_t cnt = source == 0 ? b->t_cnt[r] : b->q_cnt[r];
+        for (uint32_t i = 0; i < cnt && ok; ++i) {
+            const uint64_t v = off + i;
+            rec.assign(avf_genome_name(g, c));
+            rec += '\t';
+            rec += std::to_string(b->var_pos[v] + 1);
+            rec += "\t.\t";
+            rec.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
+            rec += '\t';
+            rec.append((const char *)b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+            rec += "\t.\t.\t.\tGT:BD:EA:OA:RI\t";
+            rec += gts[b->var_zyg[v] < 6 ? b->var_zyg[v] : 0];
+            rec += ':';
+            rec += classes[var_class[v] < 4 ? var_class[v] : 0];
+            rec += ':';
+            rec += std::to_string((int)var_expected[v]);
+            rec += ':';
+            rec += std::to_string((int)var_observed[v]);
+            rec += ':';
+            rec += std::to_string((int32_t)b->region_id[r]); /* `region_id as i32` (:205) */
+            rec += '\n';
+            const uint64_t vbeg = w.tell();
+            emit(rec);
+            const uint64_t vend = w.tell();
+            /* index entry: [beg, end) = POS-1 .. POS-1 + len(REF) */
+            if (!seen[c]) {
+                seen[c] = 1;
+                contig_order.push_back(c);
+            }
+            const int64_t beg = (int64_t)b->var_pos[v], end = beg + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1);
+            RefIndex &ri = index[c];
+            auto &chunks = ri.bins[(uint32_t)reg2bin(beg, end)];
+            if (!chunks.empty() && chunks.back().second == vbeg) chunks.back().second = vend;
+            else chunks.emplace_back(vbeg, vend);
+            const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+            if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+            for (size_t k = w0; k <= w1; ++k)
+                if (ri.linear[k] == 0) ri.linear[k] = vbeg;
+        }
+    }
+    ok = ok && w.finish();
+    if (fclose(fp) != 0 || !ok) return avf_fail_(AVK_E_ARG, "write error on %s", out_path);
+
+    /* the .tbi next to it */
+    std::string tbi;
+    tbi.append("TBI\1", 4);
+    put<int32_t>(tbi, (int32_t)contig_order.size());
+    put<int32_t>(tbi, 2);   /* format: VCF */
+    put<int32_t>(tbi, 1);   /* col_seq */
+    put<int32_t>(tbi, 2);   /* col_beg */
+    put<int32_t>(tbi, 0);   /* col_end */
+    put<int32_t>(tbi, '#'); /* meta */
+    put<int32_t>(tbi, 0);   /* skip */
+    std::string names;
+    for (uint32_t c : contig_order) {
+        names += avf_genome_name(g, c);
+        names.push_back('\0');
+    }
+    put<int32_t>(tbi, (int32_t)names.size());
+    tbi += names;
+    for (uint32_t c : contig_order) {
+        RefIndex &ri = index[c];
+        put<int32_t>(tbi, (int32_t)ri.bins.size());
+        for (auto &kv : ri.bins) {
+            put<uint32_t>(tbi, kv.first);
+            put<int32_t>(tbi, (int32_t)kv.second.size());
+            for (auto &ch : kv.second) {
+                put<uint64_t>(tbi, ch.first);
+                put<uint64_t>(tbi, ch.second);
+            }
+        }
+        /* windows without a record inherit the offset of the next one before them (htslib convention) */
+        for (size_t k = 1; k < ri.linear.size(); ++k)
+            if (ri.linear[k] == 0) ri.linear[k] = ri.linear[k - 1];
+        put<int32_t>(tbi, (int32_t)ri.linear.size());
+        for (uint64_t o : ri.linear) put<uint64_t>(tbi, o);
+    }
+    const std::string tbi_path = std::string(out_path) + ".tbi";
+    FILE *tf = fopen(tbi_path.c_str(), "wb");
+    if (!tf) return avf_fail_(AVK_E_ARG, "cannot create %s", tbi_path.c_str());
+    BgzfWriter tw(tf);
+    const bool tok = tw.write(tbi.data(), tbi.size()) && tw.finish();
+    if (fclose(tf) != 0 || !tok) return avf_fail_(AVK_E_ARG, "write error on %s", tbi_path.c_str());
+    return 0;
+}

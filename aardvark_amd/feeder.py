@@ -51,6 +51,9 @@ def load_library():
     lib.avf_feed_loaded_variants.argtypes = [vp, C.c_int]
     lib.avf_feed_free.argtypes = [vp]
     lib.avf_write_summary.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), C.c_uint32]
+    u8p = C.POINTER(C.c_uint8)
+    lib.avf_write_annotated_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(AvkRegionBatch), C.c_int,
+                                            C.POINTER(C.c_int32), u8p, u8p, u8p]
     _lib = lib
     return lib
 
@@ -123,3 +126,14 @@ def write_summary(path, tally, compare_label="compare", metrics=METRIC_GT | METR
     lib = load_library()
     t = np.ascontiguousarray(tally, dtype=np.uint64)
     _check(lib, lib.avf_write_summary(os.fsencode(path), compare_label.encode(), t.ctypes.data_as(C.POINTER(C.c_uint64)), metrics))
+
+
+def write_annotated_vcf(out_path, input_vcf, genome, batch, result, source, sample_name="", version="aardvark_amd", command_line=""):
+    """truth.vcf.gz (source 0) or query.vcf.gz (source 1) of `compare` + its .tbi; `result` is the ResultBatch of `batch`."""
+    lib = load_library()
+    cb = batch.c_struct()
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8).ctypes.data_as(C.POINTER(C.c_uint8))
+    st = np.ascontiguousarray(result.status, np.int32)
+    keep = [np.ascontiguousarray(x, np.uint8) for x in (result.var_expected, result.var_observed, result.var_class)]
+    _check(lib, lib.avf_write_annotated_vcf(os.fsencode(out_path), os.fsencode(input_vcf), sample_name.encode(), version.encode(), command_line.encode(),
+                                            genome.handle, C.byref(cb), source, st.ctypes.data_as(C.POINTER(C.c_int32)), u8(keep[0]), u8(keep[1]), u8(keep[2])))

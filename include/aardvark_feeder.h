@@ -63,6 +63,17 @@ void avf_feed_free(avf_feed *f);
 #define AVF_METRIC_RECORD_BP 16u
 int avf_write_summary(const char *path, const char *compare_label, const uint64_t *tally, uint32_t metrics_mask);
 
+/* One of the two annotated VCFs of `compare` (VariantCategorizer, src/writers/variant_categorizer.rs:41-230; source 0 =
+ * truth.vcf.gz, 1 = query.vcf.gz): the meta lines of input_vcf, the aardvark_version / aardvark_command lines and the
+ * BD / EA / OA / RI FORMAT definitions, one sample column (sample_name, or the input's first sample when empty), then one
+ * record per variant of every solved region (status 0) in region order:
+ *   CHROM POS . REF ALT . . . GT:BD:EA:OA:RI  gt:TP|FN|FP:expected:observed:region_id
+ * with REF/ALT as the solver saw them (after trimming).  Written as BGZF; a tabix index goes to out_path + ".tbi"
+ * (src/writers/noodles_idx.rs:7-20).  status / var_* are the arrays of the avk_result_batch of `batch`. */
+int avf_write_annotated_vcf(const char *out_path, const char *input_vcf, const char *sample_name, const char *version, const char *command_line,
+                            const avf_genome *g, const avk_region_batch *batch, int source, const int32_t *status, const uint8_t *var_expected,
+                            const uint8_t *var_observed, const uint8_t *var_class);
+
 #ifdef __cplusplus
 }
 #endif

@@ -270,3 +270,19 @@ def summary_text(tally, compare_label="compare", metrics=("GT", "BASEPAIR"), del
                 continue
             row(kind, label, s, sx)
     return "\n".join(lines) + "\n"
+
+
+def annotated_vcf_records(regions, source, status, var_expected, var_observed, var_class):
+    """The record lines of VariantCategorizer::write_variants (src/writers/variant_categorizer.rs:160-226) for regions as
+    generate_regions returns them; the per-variant arrays are indexed like the flattened batch (truth then query per region)."""
+    gt = {"Unknown": ".", "HomozygousReference": "0/0", "UnphasedHeterozygous": "0/1", "PhasedHet01": "0|1", "PhasedHet10": "1|0", "HomozygousAlternate": "1/1"}
+    cls = ["UNK", "TP", "FN", "FP"]
+    lines, v = [], 0
+    for r, reg in enumerate(regions):
+        for side, key in enumerate(("truth", "query")):
+            for c in reg[key]:
+                if side == source and status[r] == 0:
+                    lines.append("%s\t%d\t.\t%s\t%s\t.\t.\t.\tGT:BD:EA:OA:RI\t%s:%s:%d:%d:%d" % (
+                        reg["chrom"], c["pos"] + 1, c["a0"], c["a1"], gt[c["zyg"]], cls[int(var_class[v])], int(var_expected[v]), int(var_observed[v]), reg["region_id"]))
+                v += 1
+    return lines

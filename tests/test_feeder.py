@@ -243,6 +243,150 @@ def test_summary_float_text_and_csv(tmp_path):
             assert "NaN" in open(out).read()
 
 
+# ------------------------------------------------------------------ annotated VCFs: BGZF + tabix, read back with plain Python
+def bgzf_blocks(path):
+    """[(file offset, decompressed bytes)] of every BGZF block; checks the BC extra field and the EOF marker"""
+    import struct
+    import zlib
+    data = open(path, "rb").read()
+    out, at = [], 0
+    while at < len(data):
+        assert data[at:at + 4] == b"\x1f\x8b\x08\x04" and data[at + 12:at + 16] == b"BC\x02\x00"
+        bsize = struct.unpack_from("<H", data, at + 16)[0] + 1
+        raw = zlib.decompress(data[at + 18:at + bsize - 8], -15)
+        crc, isize = struct.unpack_from("<II", data, at + bsize - 8)
+        assert isize == len(raw) and crc == (zlib.crc32(raw) & 0xFFFFFFFF) and len(raw) <= 0xff00
+        out.append((at, raw))
+        at += bsize
+    assert out[-1][1] == b"" and len(data) - out[-1][0] == 28  # the BGZF end-of-file block
+    return out
+
+
+def reg2bins(beg, end):
+    end -= 1
+    bins = [0]
+    for shift, base in ((26, 1), (23, 9), (20, 73), (17, 585), (14, 4681)):
+        bins += list(range(base + (beg >> shift), base + (end >> shift) + 1))
+    return bins
+
+
+def tabix_fetch(vcf_path, chrom, beg, end):
+    """records of vcf_path overlapping [beg, end) of chrom, found THROUGH the .tbi (bins, chunks, linear index, virtual offsets)"""
+    import struct
+    blocks = bgzf_blocks(vcf_path)
+    by_off = {o: raw for o, raw in blocks}
+    tbi = b"".join(raw for _, raw in bgzf_blocks(vcf_path + ".tbi"))
+    assert tbi[:4] == b"TBI\x01"
+    n_ref, fmt, col_seq, col_beg, col_end, meta, skip, l_nm = struct.unpack_from("<8i", tbi, 4)
+    assert (fmt, col_seq, col_beg, col_end, meta, skip) == (2, 1, 2, 0, ord("#"), 0)
+    names = tbi[36:36 + l_nm].split(b"\0")[:-1]
+    assert len(names) == n_ref
+    at = 36 + l_nm
+    found = None
+    for name in names:
+        n_bin = struct.unpack_from("<i", tbi, at)[0]
+        at += 4
+        bins = {}
+        for _ in range(n_bin):
+            b, n_chunk = struct.unpack_from("<Ii", tbi, at)
+            at += 8
+            bins[b] = [struct.unpack_from("<QQ", tbi, at + 16 * k) for k in range(n_chunk)]
+            at += 16 * n_chunk
+        n_intv = struct.unpack_from("<i", tbi, at)[0]
+        at += 4
+        linear = list(struct.unpack_from("<%dQ" % n_intv, tbi, at))
+        at += 8 * n_intv
+        if name.decode() == chrom:
+            found = (bins, linear)
+    if found is None:
+        return []
+    bins, linear = found
+    min_off = linear[min(beg >> 14, len(linear) - 1)] if linear else 0
+    # flat text addressed by virtual offset
+    offs = sorted(by_off)
+    recs = []
+    for b in reg2bins(beg, end):
+        for cb, ce in bins.get(b, []):
+            if ce <= min_off:
+                continue
+            o, within = cb >> 16, cb & 0xFFFF
+            text = b""
+            k = offs.index(o)
+            pos = within
+            while (offs[k] << 16 | pos) < ce:  # walk block by block up to the chunk end
+                raw = by_off[offs[k]]
+                stop = (ce & 0xFFFF) if offs[k] == ce >> 16 else len(raw)
+                text += raw[pos:stop]
+                if offs[k] == ce >> 16:
+                    break
+                k, pos = k + 1, 0
+            for line in text.decode().splitlines():
+                f = line.split("\t")
+                p0 = int(f[1]) - 1
+                if f[0] == chrom and p0 < end and p0 + len(f[3]) > beg:
+                    recs.append(line)
+    return sorted(set(recs), key=lambda l: (int(l.split("\t")[1]), l))
+
+
+def test_annotated_vcfs_bgzf_and_tabix(tmp_path, oracle):
+    """truth.vcf.gz / query.vcf.gz as the reference's VariantCategorizer writes them: header additions, one record per variant of
+    every solved region, BGZF blocks, and a tabix index through which every record can be fetched"""
+    paths = {}
+    for name, text in (("ref.fa", EDGE_FASTA), ("hc.bed", EDGE_BED), ("truth.vcf", EDGE_VCF_T), ("query.vcf", EDGE_VCF_Q)):
+        paths[name] = str(tmp_path / name)
+        write_text(paths[name], text)
+    genome = feeder.Genome(paths["ref.fa"])
+    feed = feeder.feed_compare(paths["truth.vcf"], paths["query.vcf"], paths["hc.bed"], genome, truth_sample="S1")
+    res = oracle_lib.compare_batch(oracle, feed.batch, genome.contigs())
+    res.status = res.status.copy()
+    res.status[1] = 3  # pretend one region failed: its variants are left out
+    regions, _ = fo.generate_regions(fo.load_calls(paths["truth.vcf"], "S1"), fo.load_calls(paths["query.vcf"], ""), fo.read_bed(paths["hc.bed"]),
+                                     fo.read_fasta(paths["ref.fa"]))
+    for source, name, inp, sample in ((0, "truth.vcf.gz", "truth.vcf", "S1"), (1, "query.vcf.gz", "query.vcf", "")):
+        out = str(tmp_path / name)
+        feeder.write_annotated_vcf(out, paths[inp], genome, feed.batch, res, source, sample_name=sample, version="v-test", command_line="cmd --x 1")
+        text = b"".join(raw for _, raw in bgzf_blocks(out)).decode()
+        assert gzip.open(out, "rt").read() == text  # an ordinary gzip reader sees the same
+        lines = text.splitlines()
+        meta = [l for l in lines if l.startswith("##")]
+        src_meta = [l for l in open(paths[inp]).read().splitlines() if l.startswith("##")]
+        assert meta[:len(src_meta)] == src_meta
+        assert meta[len(src_meta):] == ['##aardvark_version="v-test"', '##aardvark_command="cmd --x 1"',
+                                        '##FORMAT=<ID=BD,Number=1,Type=String,Description="Benchmark Decision for call (TP/FP/FN)">',
+                                        '##FORMAT=<ID=EA,Number=1,Type=Integer,Description="Expected Allele count for this genotype">',
+                                        '##FORMAT=<ID=OA,Number=1,Type=Integer,Description="Observed Allele count for this genotype">',
+                                        '##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">']
+        assert lines[len(meta)] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + ("S1" if source == 0 else "Q")
+        records = lines[len(meta) + 1:]
+        want = fo.annotated_vcf_records(regions, source, res.status, res.var_expected, res.var_observed, res.var_class)
+        assert records == want and len(records) > 3
+        assert not any(r.split(":")[-1] == str(regions[1]["region_id"]) for r in records)
+        # every record comes back through the index, and region queries return exactly the overlapping ones
+        for chrom in ("chrA", "chrB", "chrUnused"):
+            mine = [r for r in records if r.split("\t")[0] == chrom]
+            assert tabix_fetch(out, chrom, 0, 1 << 29) == sorted(set(mine), key=lambda l: (int(l.split("\t")[1]), l))
+            for beg, end in ((0, 20), (11, 12), (60, 160), (140, 141), (299, 300), (300, 400)):
+                hit = [r for r in mine if int(r.split("\t")[1]) - 1 < end and int(r.split("\t")[1]) - 1 + len(r.split("\t")[3]) > beg]
+                assert tabix_fetch(out, chrom, beg, end) == sorted(set(hit), key=lambda l: (int(l.split("\t")[1]), l))
+
+
+def test_bgzf_writer_splits_large_outputs(tmp_path, oracle):
+    """more than one 64 KiB block: virtual offsets in the index point into later blocks"""
+    p, contig, want_batch = write_case_files(tmp_path, 4000, 2_000_000)
+    genome = feeder.Genome(p["fa"])
+    feed = feeder.feed_compare(p["t"], p["q"], p["bed"], genome, enable_trimming=False)
+    res = oracle_lib.compare_batch(oracle, feed.batch, genome.contigs(), threads=8)
+    out = str(tmp_path / "truth.vcf.gz")
+    feeder.write_annotated_vcf(out, p["t"], genome, feed.batch, res, 0)
+    blocks = bgzf_blocks(out)
+    assert len(blocks) > 3
+    records = [l for l in b"".join(raw for _, raw in blocks).decode().splitlines() if not l.startswith("#")]
+    assert len(records) == int(feed.batch.t_cnt.sum())
+    for beg, end in ((0, 2_000_000), (500_000, 500_500), (1_234_000, 1_300_000), (1_999_000, 2_000_000)):
+        hit = [r for r in records if int(r.split("\t")[1]) - 1 < end and int(r.split("\t")[1]) - 1 + len(r.split("\t")[3]) > beg]
+        assert tabix_fetch(out, "chr20", beg, end) == sorted(set(hit), key=lambda l: (int(l.split("\t")[1]), l))
+
+
 def write_case_files(tmp_path, n_truth=3000, length=1_500_000):
     """a small chr20-shaped SNV+indel call set as FASTA(.gz) + BED + two VCFs; returns (paths, contig, batch the generator clusters)"""
     contig = synth.make_contig(length, 15)
@@ -290,3 +434,10 @@ def test_command_line_tool_end_to_end(tmp_path, oracle):
     want = fo.summary_text(res.tally, "e2e", ("GT", "BASEPAIR", "HAP", "WEIGHTED_HAP", "RECORD_BP"))
     assert open(os.path.join(p["out"], "summary.tsv")).read() == want
     assert "Solved:error blocks: %d : 0" % want_batch.n_regions in r.stderr
+    # the annotated VCFs: one record per variant, decisions as the oracle made them
+    regions, _ = fo.generate_regions(fo.load_calls(p["t"], "", False), fo.load_calls(p["q"], "", False), fo.read_bed(p["bed"]), fo.read_fasta(p["fa"]))
+    for source, name in ((0, "truth.vcf.gz"), (1, "query.vcf.gz")):
+        out = os.path.join(p["out"], name)
+        records = [l for l in gzip.open(out, "rt").read().splitlines() if not l.startswith("#")]
+        assert records == fo.annotated_vcf_records(regions, source, res.status, res.var_expected, res.var_observed, res.var_class)
+        assert tabix_fetch(out, "chr20", 700_000, 800_000) == [r for r in records if 700_000 < int(r.split("\t")[1]) + len(r.split("\t")[3]) - 1 and int(r.split("\t")[1]) - 1 < 800_000]
