@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
@@ -164,10 +165,20 @@ int main(int argc, char **argv) {
     std::string command;
     for (int i = 0; i < argc; ++i) command += (i ? " " : "") + std::string(argv[i]);
     const char *in_vcf[2] = {truth.c_str(), query.c_str()}, *samples[2] = {truth_sample.c_str(), query_sample.c_str()}, *names[2] = {"/truth.vcf.gz", "/query.vcf.gz"};
-    for (int src = 0; src < 2; ++src)
-        if (avf_write_annotated_vcf((out_dir + names[src]).c_str(), in_vcf[src], samples[src], avk_version(), command.c_str(), genome, all, src, status.data(),
-                                    var_expected.data(), var_observed.data(), var_class.data()))
-            die(74, "Error while saving output files", avf_last_error());
+    {
+        int rcs[2] = {0, 0};
+        std::string errs[2];
+        auto write_one = [&](int src) {
+            rcs[src] = avf_write_annotated_vcf((out_dir + names[src]).c_str(), in_vcf[src], samples[src], avk_version(), command.c_str(), genome, all, src,
+                                               status.data(), var_expected.data(), var_observed.data(), var_class.data());
+            if (rcs[src]) errs[src] = avf_last_error(); /* the error text is per thread */
+        };
+        std::thread other(write_one, 1);
+        write_one(0);
+        other.join();
+        for (int src = 0; src < 2; ++src)
+            if (rcs[src]) die(74, "Error while saving output files", errs[src].c_str());
+    }
     const double s_write = seconds_since(t0);
 
     fprintf(stderr, "Solved:error blocks: %llu : %llu\n", (unsigned long long)total[AVK_TALLY_LEN - 2], (unsigned long long)total[AVK_TALLY_LEN - 1]);

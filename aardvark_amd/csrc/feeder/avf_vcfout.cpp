@@ -12,69 +12,96 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <vector>
 
 int avf_fail_(int code, const char *fmt, ...); /* avf_feeder.cpp: sets the text avf_last_error returns */
 
 namespace {
 
-/* ---- BGZF (SAM spec section 4.1): gzip members of at most 64 KiB with a BC extra field ---- */
+/* ---- BGZF (SAM spec section 4.1): gzip members of at most 64 KiB with a BC extra field ----
+ * The text is cut into blocks as it is written; the blocks are compressed by a few threads at the end (like the
+ * reference's MultithreadedWriter, variant_categorizer.rs:108-110).  tell() therefore returns a LOGICAL virtual offset
+ * (block index << 16 | offset in block); real() turns it into the file's virtual offset once the block sizes are known. */
 class BgzfWriter {
   public:
-    explicit BgzfWriter(FILE *fp) : fp_(fp) { buf_.reserve(kBlock); }
-    /* virtual offset of the next byte written */
-    uint64_t tell() const { return (file_off_ << 16) | (uint64_t)buf_.size(); }
-    bool write(const char *p, size_t n) {
+    BgzfWriter() { blocks_.emplace_back(); }
+    uint64_t tell() const { return ((uint64_t)(blocks_.size() - 1) << 16) | (uint64_t)blocks_.back().size(); }
+    void write(const char *p, size_t n) {
         while (n) {
-            const size_t room = kBlock - buf_.size();
+            std::string &cur = blocks_.back();
+            const size_t room = kBlock - cur.size();
             const size_t take = n < room ? n : room;
-            buf_.insert(buf_.end(), p, p + take);
+            cur.append(p, take);
             p += take;
             n -= take;
-            if (buf_.size() == kBlock && !flush_block()) return false;
+            if (blocks_.back().size() == kBlock) blocks_.emplace_back();
         }
-        return true;
     }
-    bool finish() {
-        if (!buf_.empty() && !flush_block()) return false;
+    /* compresses and writes everything plus the end-of-file block */
+    bool finish(FILE *fp, int threads) {
+        if (blocks_.back().empty()) blocks_.pop_back();
+        const size_t nb = blocks_.size();
+        std::vector<std::string> packed(nb);
+        std::vector<char> bad(nb, 0);
+        int nt = threads < 1 ? 1 : threads;
+        if ((size_t)nt > nb) nt = nb ? (int)nb : 1;
+        auto work = [&](size_t t) {
+            for (size_t k = t; k < nb; k += (size_t)nt)
+                if (!compress_block(blocks_[k], packed[k])) bad[k] = 1;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, (size_t)t);
+        work(0);
+        for (auto &th : pool) th.join();
+        file_off_.assign(nb + 1, 0);
+        for (size_t k = 0; k < nb; ++k) {
+            if (bad[k]) return false;
+            file_off_[k + 1] = file_off_[k] + packed[k].size();
+            if (fwrite(packed[k].data(), 1, packed[k].size(), fp) != packed[k].size()) return false;
+        }
         static const unsigned char eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
-        return fwrite(eof, 1, sizeof(eof), fp_) == sizeof(eof);
+        return fwrite(eof, 1, sizeof(eof), fp) == sizeof(eof);
+    }
+    /* after finish(): the file's virtual offset of a logical one (an offset at the very end of a block is the start of the next) */
+    uint64_t real(uint64_t logical) const {
+        size_t blk = (size_t)(logical >> 16);
+        uint64_t off = logical & 0xFFFF;
+        if (blk >= file_off_.size() - 1) return file_off_.back() << 16;
+        return (file_off_[blk] << 16) | off;
     }
 
   private:
     static constexpr size_t kBlock = 0xff00;
-    bool flush_block() {
-        std::vector<unsigned char> out(kBlock + 1024);
+    static bool compress_block(const std::string &in, std::string &out) {
+        std::vector<unsigned char> buf(kBlock + 1024);
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
         if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        zs.next_in = (Bytef *)buf_.data();
-        zs.avail_in = (uInt)buf_.size();
-        zs.next_out = out.data() + 18;
-        zs.avail_out = (uInt)(out.size() - 18 - 8);
+        zs.next_in = (Bytef *)in.data();
+        zs.avail_in = (uInt)in.size();
+        zs.next_out = buf.data() + 18;
+        zs.avail_out = (uInt)(buf.size() - 18 - 8);
         const int rc = deflate(&zs, Z_FINISH);
         const size_t clen = zs.total_out;
         deflateEnd(&zs);
         if (rc != Z_STREAM_END) return false;
         const size_t total = 18 + clen + 8;
         static const unsigned char head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};
-        memcpy(out.data(), head, 16);
-        out[16] = (unsigned char)((total - 1) & 0xff);
-        out[17] = (unsigned char)((total - 1) >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)buf_.data(), (uInt)buf_.size());
-        const uint32_t isize = (uint32_t)buf_.size();
+        memcpy(buf.data(), head, 16);
+        buf[16] = (unsigned char)((total - 1) & 0xff);
+        buf[17] = (unsigned char)((total - 1) >> 8);
+        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)in.data(), (uInt)in.size());
+        const uint32_t isize = (uint32_t)in.size();
         for (int k = 0; k < 4; ++k) {
-            out[18 + clen + k] = (unsigned char)(crc >> (8 * k));
-            out[18 + clen + 4 + k] = (unsigned char)(isize >> (8 * k));
+            buf[18 + clen + k] = (unsigned char)(crc >> (8 * k));
+            buf[18 + clen + 4 + k] = (unsigned char)(isize >> (8 * k));
         }
-        if (fwrite(out.data(), 1, total, fp_) != total) return false;
-        file_off_ += total;
-        buf_.clear();
+        out.assign((const char *)buf.data(), total);
         return true;
     }
-    FILE *fp_;
-    std::vector<char> buf_;
-    uint64_t file_off_ = 0;
+    std::vector<std::string> blocks_;
+    std::vector<uint64_t> file_off_;
 };
 
 /* ---- tabix index (tabix spec): binning index + 16 kb linear index per contig ---- */
@@ -87,6 +114,8 @@ int reg2bin(int64_t beg, int64_t end) {
     if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
     return 0;
 }
+
+const uint64_t kNone = ~0ull;
 
 struct RefIndex {
     std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
@@ -136,9 +165,9 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
     const std::string sample = sample_name && *sample_name ? sample_name : first_sample;
     FILE *fp = fopen(out_path, "wb");
     if (!fp) return avf_fail_(AVK_E_ARG, "cannot create %s", out_path);
-    BgzfWriter w(fp);
+    BgzfWriter w;
     bool ok = true;
-    auto emit = [&](const std::string &s) { ok = ok && w.write(s.data(), s.size()); };
+    auto emit = [&](const std::string &s) { w.write(s.data(), s.size()); };
     for (const std::string &m : meta) emit(m + "\n");
     /* what the reference adds (variant_categorizer.rs:41-87) */
     emit(std::string("##aardvark_version=\"") + (version ? version : "") + "\"\n");
@@ -199,13 +228,25 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
             if (!chunks.empty() && chunks.back().second == vbeg) chunks.back().second = vend;
             else chunks.emplace_back(vbeg, vend);
             const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
-            if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, 0);
+            if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, kNone);
             for (size_t k = w0; k <= w1; ++k)
-                if (ri.linear[k] == 0) ri.linear[k] = vbeg;
+                if (ri.linear[k] == kNone) ri.linear[k] = vbeg;
         }
     }
-    ok = ok && w.finish();
+    int threads = (int)std::thread::hardware_concurrency();
+    if (threads > 8) threads = 8;
+    ok = ok && w.finish(fp, threads);
     if (fclose(fp) != 0 || !ok) return avf_fail_(AVK_E_ARG, "write error on %s", out_path);
+    /* logical virtual offsets -> the file's */
+    for (RefIndex &ri : index) {
+        for (auto &kv : ri.bins)
+            for (auto &ch : kv.second) {
+                ch.first = w.real(ch.first);
+                ch.second = w.real(ch.second);
+            }
+        for (uint64_t &o : ri.linear)
+            if (o != kNone) o = w.real(o);
+    }
 
     /* the .tbi next to it */
     std::string tbi;
@@ -236,16 +277,17 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
             }
         }
         /* windows without a record inherit the offset of the next one before them (htslib convention) */
-        for (size_t k = 1; k < ri.linear.size(); ++k)
-            if (ri.linear[k] == 0) ri.linear[k] = ri.linear[k - 1];
+        for (size_t k = 0; k < ri.linear.size(); ++k)
+            if (ri.linear[k] == kNone) ri.linear[k] = k ? ri.linear[k - 1] : 0;
         put<int32_t>(tbi, (int32_t)ri.linear.size());
         for (uint64_t o : ri.linear) put<uint64_t>(tbi, o);
     }
     const std::string tbi_path = std::string(out_path) + ".tbi";
     FILE *tf = fopen(tbi_path.c_str(), "wb");
     if (!tf) return avf_fail_(AVK_E_ARG, "cannot create %s", tbi_path.c_str());
-    BgzfWriter tw(tf);
-    const bool tok = tw.write(tbi.data(), tbi.size()) && tw.finish();
+    BgzfWriter tw;
+    tw.write(tbi.data(), tbi.size());
+    const bool tok = tw.finish(tf, 1);
     if (fclose(tf) != 0 || !tok) return avf_fail_(AVK_E_ARG, "write error on %s", tbi_path.c_str());
     return 0;
 }

@@ -1,0 +1,54 @@
+"""Whole-genome-shaped end-to-end run (the stand-in for BASELINE configs[2]): 24 contigs with GRCh38
+primary lengths (scaled by SCALE), SNV+indel truth/query call sets at HG002 density, written as FASTA + BED + VCF.gz, then
+aardvark_amd_compare on the GPU.  Prints the tool's stage breakdown.  SCALE=1 needs about 12 GB of host memory and 8 GB of disk."""
+import gzip, os, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from aardvark_amd import synth
+from aardvark_amd._abi import ZYG
+
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622, 133275309,
+          114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+GT = {ZYG["HomozygousAlternate"]: "1/1", ZYG["UnphasedHeterozygous"]: "0/1", ZYG["PhasedHet01"]: "0|1", ZYG["PhasedHet10"]: "1|0"}
+scale = float(os.environ.get("SCALE", "0.1"))
+density = 3.9e6 / sum(GRCH38)  # truth variants per base
+d = tempfile.mkdtemp(prefix="avk_genome_", dir=os.environ.get("TMPDIR", "/tmp"))
+t0 = time.time()
+hdr = "##fileformat=VCFv4.2\n" + "".join("##contig=<ID=%s>\n" % n for n in NAMES) + \
+      "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tHG002\n"
+fa = open(os.path.join(d, "genome.fa"), "wb")
+bedf = open(os.path.join(d, "hc.bed"), "w")
+vt = gzip.open(os.path.join(d, "truth.vcf.gz"), "wt", compresslevel=1)
+vq = gzip.open(os.path.join(d, "query.vcf.gz"), "wt", compresslevel=1)
+vt.write(hdr); vq.write(hdr)
+n_regions = n_truth = 0
+for ci, (name, full) in enumerate(zip(NAMES, GRCH38)):
+    length = max(int(full * scale), 200_000)
+    contig = synth.make_contig(length, 20250103 + ci)
+    rng = np.random.default_rng(20250103 + 100 + ci)
+    bed = synth.make_bed(length, max(4, int(1000 * length / 64_444_167)), 0.9, rng)
+    truth = synth.indel_truth(contig, bed, int(length * density), 20250103 + 200 + ci)
+    query = synth.perturb_query(contig, bed, truth, 20250104 + ci, max(1, len(truth) // 100))
+    n_truth += len(truth)
+    fa.write(b">" + name.encode() + b"\n")
+    pad = (-length) % 80
+    rows = np.concatenate([contig, np.full(pad, ord("N"), np.uint8)]).reshape(-1, 80)
+    body = np.concatenate([rows, np.full((rows.shape[0], 1), 10, np.uint8)], axis=1).tobytes()
+    fa.write(body[:len(body) - pad - 1] + b"\n" if pad else body)
+    bedf.write("".join("%s\t%d\t%d\n" % (name, a, b) for a, b in bed))
+    for f, cs in ((vt, truth), (vq, query)):
+        f.write("".join("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (name, int(cs.pos[i]) + 1, cs.ref[i].decode(), cs.alt[i].decode(), GT[int(cs.zyg[i])]) for i in range(len(cs))))
+    del contig, truth, query, rows, body
+for f in (fa, bedf, vt, vq):
+    f.close()
+print("fixtures: %d truth variants over %d contigs (scale %.2f) written to %s in %.0f s" % (n_truth, len(NAMES), scale, d, time.time() - t0), flush=True)
+cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", os.path.join(d, "genome.fa"), "-t", os.path.join(d, "truth.vcf.gz"),
+       "-q", os.path.join(d, "query.vcf.gz"), "-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "out"), "--disable-variant-trimming"]
+t0 = time.time()
+r = subprocess.run(cmd, capture_output=True, text=True)
+print("exit %d, wall %.2f s" % (r.returncode, time.time() - t0))
+print("\n".join(l for l in r.stderr.strip().splitlines() if not l.startswith("Error while solving")))
+print(open(os.path.join(d, "out", "summary.tsv")).read())
+subprocess.run(["rm", "-rf", d])
