@@ -72,6 +72,8 @@ struct AvkTier {
 /* partial-tally geometry: AVK_TALLY_LEN sums + 5 tier counters + 8 profiling words, padded */
 #define AVK_TALLY_STRIDE 320
 #define AVK_TALLY_COPIES 64
+/* tail of a bulk workgroup's LDS: 16 control words + AVK_TALLY_LEN (rounded up) tally words */
+#define AVK_WG_TAIL_BYTES (64 + 4 * 288)
 
 struct AvkKernelArgs {
     /* inputs */
@@ -95,9 +97,14 @@ struct AvkKernelArgs {
     uint32_t static_pct;       /* share of the work list dealt statically (item k to wave k mod n_waves), the rest is claimed */
     uint32_t n_shards;         /* claim counters in use (1..8) */
     uint32_t claim;            /* regions per claim */
-    uint32_t esc_bytes;        /* bulk launch: when a region outgrows its wave's slice, the wave takes the workgroup's whole LDS
-                                  (esc_bytes, the last 64 bytes of the allocation hold the control words) while its sibling waves
-                                  park between regions, and solves it again at once with tier 1's cap — no prediction, no later launch */
+    uint32_t esc_bytes;        /* bulk launch (workgroups of exactly 4 waves): offset of the workgroup's TAIL in its LDS = 4 slices of
+                                  tier[0].ws_bytes.  The tail holds 16 control words and the workgroup's tally (AVK_WG_TAIL_BYTES):
+                                  - the waves add a region's nonzero counters to the LDS tally; the last wave to leave flushes it to
+                                    a partial tally in HBM (a global atomic per counter and region was 16 MB of HBM writes per launch);
+                                  - with esc_enabled, a wave whose region outgrows its slice takes the workgroup's whole LDS
+                                    ([0, esc_bytes)) while its sibling waves park between regions, and solves it again at once with
+                                    tier 1's cap — no prediction, no later launch.  0 = no tail (solo and HBM launches). */
+    uint32_t esc_enabled;
     uint32_t high_priority;    /* raise the wave priority (the solo launch of the predicted-hard regions) */
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;

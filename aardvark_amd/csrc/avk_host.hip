@@ -36,8 +36,8 @@ __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel
     const unsigned wave_in_block = threadIdx.x >> 6;
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
     if (a.high_priority) __builtin_amdgcn_s_setprio(3); /* solo launch: the long searches are the critical path */
-    if (a.esc_bytes) { /* control words of the in-workgroup escalation (AvkKernelArgs::esc_bytes) */
-        if (threadIdx.x < 8) ((unsigned *)(avk_smem + a.esc_bytes))[threadIdx.x] = 0;
+    if (a.esc_bytes) { /* the workgroup's tail: control words and tally (AvkKernelArgs::esc_bytes) */
+        for (unsigned k = threadIdx.x; k < AVK_WG_TAIL_BYTES / 4; k += blockDim.x) ((unsigned *)(avk_smem + a.esc_bytes))[k] = 0;
         __syncthreads();
     }
     avk::region_worker<true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
@@ -487,7 +487,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
      * they overlap with the bulk instead of forming the tail */
     const auto t_alloc = now();
     std::vector<uint32_t> order;
-    db->plan = avk::plan_work_order(db->host, (uint64_t)ctx->lds_bytes_per_wave, (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
+    db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
@@ -638,6 +638,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
         a.esc_bytes = 0;
+        a.esc_enabled = 0;
         a.static_pct = AVK_STATIC_PCT;
         a.n_shards = 8;
         a.claim = AVK_CLAIM;
@@ -725,8 +726,14 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             uint32_t bulk = blocks - solo - 2 * hbm_solo;
             if (ctx->bulk_full_grid) bulk = blocks;
             a.n_waves = (blocks - solo - 2 * hbm_solo) * waves_per_block;
-            if (ctx->lds_escalation && ctx->lds_bytes_per_wave >= 1024) a.esc_bytes = (uint32_t)(waves_per_block * ctx->lds_bytes_per_wave - 64);
+            const uint64_t slice0 = a.tier[0].ws_bytes;
+            if (ctx->lds_bytes_per_wave >= 1024) { /* slices shrink to make room for the workgroup's tail */
+                a.tier[0].ws_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave);
+                a.esc_bytes = (uint32_t)(waves_per_block * a.tier[0].ws_bytes);
+                a.esc_enabled = ctx->lds_escalation ? 1u : 0u;
+            }
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
+            a.tier[0].ws_bytes = slice0;
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;
             uint32_t b2 = (uint32_t)ctx->n_cus < blocks ? (uint32_t)ctx->n_cus : blocks;

@@ -304,6 +304,12 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
  * The prediction mirrors the workspace carve of solve_region_tier (avk_solver.inl).  A wrong guess only costs
  * time: a region solved in a larger class had more room than it needed, a missed one overflows into the next
  * tier's launch as before. */
+/* bytes of a wave's slice in the bulk launch: the workgroup's LDS (4 x lds_bytes_per_wave) minus its tail, in 4 equal parts */
+inline uint64_t bulk_slice_bytes(uint64_t lds_bytes_per_wave) {
+    if (lds_bytes_per_wave < 1024) return lds_bytes_per_wave;
+    return ((4 * lds_bytes_per_wave - AVK_WG_TAIL_BYTES) / 4) & ~15ull;
+}
+
 struct WorkPlan {
     uint32_t n_hbm = 0;  /* class C */
     uint32_t n_hard = 0; /* class B */

@@ -1629,7 +1629,8 @@ AVK_DEV void wg_acquire(u32 *ctl, u32 w, u32 n_wg_waves) {
 /* With esc_bytes set (bulk launch) the workgroups have exactly 4 waves: wave w of a workgroup has wave_id % 4 == w and
  * its slice starts w slices into the workgroup's LDS. */
 template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
-    const bool esc = PASS_LDS && a.esc_bytes != 0;
+    const bool wgt = PASS_LDS && a.esc_bytes != 0; /* this workgroup has a tail: shared tally, and the lock of the escalation */
+    const bool esc = wgt && a.esc_enabled != 0;
     const u32 wave_in_wg = wave_id & 3u;
     u8 *const wg_lds = lds_slice - (PASS_LDS ? (u32)wave_in_wg * (u32)a.tier[a.pass_tier].ws_bytes : 0u); /* meaningful when esc */
     const u32 n_wg_waves = 4;
@@ -1637,7 +1638,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     u32 n_ok = 0, n_err = 0, n_cap = 0, n_big = 0; /* n_big: finished (either way) in a tier-3 slice */
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
-    const u64 ws_bytes = a.tier[tier].ws_bytes - (esc ? 64u : 0u); /* the control words sit at the end of the last slice */
+    const u64 ws_bytes = a.tier[tier].ws_bytes;
     const u32 ed_cap = a.tier[tier].ed_cap;
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_work;
 
@@ -1656,7 +1657,8 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
     const u32 home = (wave_id >> 2) % n_shards;
     u32 static_next = wave_id < a.n_waves ? wave_id : 0xFFFFFFFFu; /* waves beyond n_waves (placed late) only claim */
     u32 shard_i = 0, claim_base = 0, claim_left = 0;
-    u32 *const wg_ctl = (u32 *)(wg_lds + a.esc_bytes); /* used when esc */
+    u32 *const wg_ctl = (u32 *)(wg_lds + a.esc_bytes); /* used when wgt: [0] lock, [1] ticket counter, [2..5] wave states, [6] waves gone */
+    u32 *const wg_tally = wg_ctl + 16;
     for (;;) {
         if (esc) { /* a sibling wants the whole LDS: stay out of the slice until it is done */
             for (u32 t = wg_word(wg_ctl); t != 0; t = wg_word(wg_ctl)) wg_park(wg_ctl, wave_in_wg, t);
@@ -1785,13 +1787,16 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             continue;
         }
         if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
-        { /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters go
-           * straight into one of the partial tallies (fire-and-forget adds, a handful of lanes per region) */
+        { /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters (a handful of
+           * the 286) are added to the workgroup's tally in LDS, or — launches without a tail — straight to a partial tally */
             u64 *part_r = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
             for (int j = 0; j < 5; ++j) {
-                const u32 i = (u32)j * 64 + lane;
+                const u32 i = avk_opaque_u32((u32)j * 64 + lane);
                 const u32 v = i < AVK_N_GROUPS * AVK_N_FIELDS ? c.gm[i] : 0u;
-                if (v) avk_atomic_add_u64_global(part_r + i, v);
+                if (v) {
+                    if (wgt) avk_atomic_add_u32(wg_tally + i, v);
+                    else avk_atomic_add_u64_global(part_r + i, v);
+                }
             }
         }
         if (a.seq_bytes && a.seq_len && reg.seq_stride) { /* SequenceBundle, waffle_solver.rs:237-246 */
@@ -1819,7 +1824,22 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
 #endif
     }
 
-    if (esc && lane == 0) avk_wg_store(wg_ctl + 2 + wave_in_wg, 0xFFFFFFFFu); /* never parks again */
+    if (wgt) {
+        wv_sync();
+        u32 gone = 0;
+        if (lane == 0) {
+            avk_wg_store(wg_ctl + 2 + wave_in_wg, 0xFFFFFFFFu); /* never parks again */
+            gone = avk_wg_add(wg_ctl + 6, 1u) + 1u;
+        }
+        gone = wv_uni(wv_shfl(gone, 0));
+        if (gone == n_wg_waves) { /* the last wave of the workgroup: its LDS adds and everybody else's are done */
+            u64 *part_w = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
+            for (u32 i = lane; i < AVK_N_GROUPS * AVK_N_FIELDS; i += 64) {
+                const u32 v = wg_tally[i];
+                if (v) avk_atomic_add_u64_global(part_w + i, v);
+            }
+        }
+    }
     /* flush the private tally (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163) into
      * one of the partial copies; avk_tally_reduce sums the copies */
     u64 *part = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;

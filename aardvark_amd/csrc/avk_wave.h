@@ -81,7 +81,7 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 #define wv_readlane(v, src) wv_readlane_((v), (src), AVK_SITE)
 #define wv_sync() wv_sync_(AVK_SITE)
 
-AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { uint32_t o = *p; *p = o + v; return o; }
+AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); } /* waves of a workgroup are OS threads */
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) {
@@ -89,6 +89,8 @@ AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_
     return expect;
 }
 AVK_DEV uint64_t avk_clock() { return 0; }
+/* identity the optimiser cannot see through: keeps per-lane address arithmetic inside the loop it belongs to */
+AVK_DEV uint32_t avk_opaque_u32(uint32_t v) { return v; }
 AVK_DEV uint32_t avk_ld_agent_u32(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 AVK_DEV void avk_st_agent_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
 AVK_DEV void avk_release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
@@ -111,7 +113,14 @@ AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 #define AVK_DEV __device__ __forceinline__
 #define AVK_DEV_NOINLINE __device__ __noinline__
 
-AVK_DEV int wv_lane() { return (int)__lane_id(); }
+/* The lane index is deliberately opaque to the optimiser (a volatile asm, two VALU instructions per use): as a pure
+ * function it and everything derived from it (lane * 28 + 16, lane < 32, ...) is hoisted out of the persistent region loop,
+ * where dozens of such invariants outgrow the register file, are spilled in the prologue and reloaded for every region. */
+AVK_DEV int wv_lane() {
+    unsigned l;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+    return (int)l;
+}
 AVK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
 AVK_DEV uint32_t wv_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 /* value of lane `src` (src must be wave-uniform) as a scalar */
@@ -168,6 +177,12 @@ AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return ato
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
 AVK_DEV uint64_t avk_clock() { return __builtin_amdgcn_s_memtime(); }
+/* identity the optimiser cannot see through: keeps per-lane address arithmetic inside the loop it belongs to (hoisted
+ * out of the persistent region loop it is spilled to scratch in the prologue and reloaded for every region) */
+AVK_DEV uint32_t avk_opaque_u32(uint32_t v) {
+    asm volatile("" : "+v"(v));
+    return v;
+}
 /* device-scope (all XCDs) accesses for words that other workgroups poll: write-through / L1-bypassing forms
  * (cdna_hip_programming.md §6 G16: granule = one aligned word that is its own flag) */
 AVK_DEV uint32_t avk_ld_agent_u32(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }

@@ -288,8 +288,9 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 if (g >= n_wg) break;
                 const uint32_t alive = waves - 4 * g < 4 ? waves - 4 * g : 4;
                 uint32_t *ctl = (uint32_t *)(wgbuf.data() + a.esc_bytes);
-                for (int k = 0; k < 8; ++k) ctl[k] = 0;
+                for (int k = 0; k < AVK_WG_TAIL_BYTES / 4; ++k) ctl[k] = 0;
                 for (uint32_t k = alive; k < 4; ++k) ctl[2 + k] = 0xFFFFFFFFu; /* a short last workgroup: the missing waves never park */
+                ctl[6] = 4 - alive;                                            /* ... and count as gone */
                 std::vector<std::thread> wt;
                 for (uint32_t k = 0; k < alive; ++k)
                     wt.emplace_back([&, k]() {
@@ -297,7 +298,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                         w.stack_bytes = 256 * 1024;
                         std::vector<char> stacks(64 * w.stack_bytes + 64);
                         w.stacks = stacks.data();
-                        WaveTask t{&a, 4 * g + k, wgbuf.data() + (size_t)k * lds};
+                        WaveTask t{&a, 4 * g + k, wgbuf.data() + (size_t)k * a.tier[0].ws_bytes};
                         t.wg_lds = wgbuf.data();
                         t.wave_in_wg = k;
                         t.n_wg_waves = alive;
@@ -327,7 +328,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint8_t> big_slices(big_slots ? (size_t)big_slots * big_ws_bytes : 0);
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
-    const avk::WorkPlan plan = avk::plan_work_order(pb, lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
+    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
     const uint32_t *list = order.data(), *count = nullptr;
     int nlist = 0;
     for (int t = 0; t < 4 && n; ++t) {
@@ -339,6 +340,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
         a.esc_bytes = 0;
+        a.esc_enabled = 0;
         a.static_pct = AVK_STATIC_PCT;
         a.n_shards = 8;
         a.claim = AVK_CLAIM;
@@ -400,9 +402,15 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 }
                 a.work_list = order.data() + n_c + solo;
                 a.n_work = (uint32_t)n - n_c - solo;
-                if (lds_escalation && lds_bytes >= 1024) a.esc_bytes = (uint32_t)(4 * lds_bytes - 64);
+                if (lds_bytes >= 1024) {
+                    a.tier[0].ws_bytes = avk::bulk_slice_bytes(lds_bytes);
+                    a.esc_bytes = (uint32_t)(4 * a.tier[0].ws_bytes);
+                    a.esc_enabled = lds_escalation ? 1u : 0u;
+                }
                 run_pass(n_waves ? n_waves : 1, 0, lds_bytes, solo);
+                a.tier[0].ws_bytes = lds_bytes;
                 a.esc_bytes = 0;
+                a.esc_enabled = 0;
             }
             else if (t == 1) run_pass(n_waves ? n_waves : 1, 0, lds2_bytes);
             else if (t == 2) {
