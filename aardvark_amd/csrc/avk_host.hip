@@ -81,7 +81,7 @@ __global__ void avk_pack_reference(const uint8_t *bytes, uint64_t n_bases, uint3
 
 /* sums the partial tallies into out[0 .. AVK_TALLY_STRIDE) (and the caller's device tally, if any), then clears
  * the partial tallies and the work / overflow counters for the next call on this batch */
-__global__ void avk_tally_reduce(uint64_t *partials, uint64_t *out, uint64_t *out_user, uint32_t *counters, unsigned n_counters) {
+__global__ void avk_tally_reduce(uint64_t *partials, uint64_t *out, uint64_t *out_user, uint32_t *counters, unsigned n_counters, unsigned accumulate) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     for (unsigned k = i; k < n_counters; k += gridDim.x * blockDim.x) counters[k] = 0;
     if (i >= AVK_TALLY_STRIDE) return;
@@ -91,7 +91,7 @@ __global__ void avk_tally_reduce(uint64_t *partials, uint64_t *out, uint64_t *ou
         partials[(size_t)c * AVK_TALLY_STRIDE + i] = 0;
     }
     out[i] = s;
-    if (out_user && i < AVK_TALLY_LEN) out_user[i] = s;
+    if (out_user && i < AVK_TALLY_LEN) out_user[i] = accumulate ? out_user[i] + s : s; /* accumulate: a job's running total over its batches */
 }
 
 /* ---------------------------------------------------------------------------------- context */
@@ -129,6 +129,7 @@ struct avk_ctx {
     int64_t solo_blocks_max = 128;
     int64_t class_c_nodes_x2 = 8; /* a region is sent to the HBM solo launch when 0.5 x this x N nodes outgrow a tier-1 slice */
     int64_t solo_regions_per_wave = 4; /* predicted-hard regions beyond solo waves x this lead the bulk list */
+    int64_t accumulate_tally = 0; /* avk_compare_resident adds to the caller's device tally instead of overwriting it */
     int64_t lds_escalation = 1; /* in-workgroup escalation of the bulk launch (AvkKernelArgs::esc_bytes) */
     int64_t lds2_overflow_pass = 0; /* 1: a launch of its own with large LDS slices between the bulk and the HBM tier */
     int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
@@ -254,8 +255,13 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     (void)hipEventCreate(&ctx->evk1);
-    if (hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->side_stream2, hipStreamNonBlocking) != hipSuccess ||
+    /* the solo launches get streams of the highest priority: they are the critical path, and HIP never folds streams of
+     * different priorities onto one hardware queue (with a communicator library in the process the default-priority streams
+     * of a process share queues, and a shared queue would serialise the solo launches with the bulk) */
+    int prio_low = 0, prio_high = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -317,6 +323,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "solo_min_variants") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "solo_min_variants must not be negative");
         ctx->solo_min_variants = value;
+    } else if (n == "accumulate_tally") {
+        ctx->accumulate_tally = value ? 1 : 0;
     } else if (n == "lds_escalation") {
         ctx->lds_escalation = value ? 1 : 0;
     } else if (n == "lds2_overflow_pass") {
@@ -764,7 +772,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
     hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally,
-                       (uint64_t *)tally_dev, db->d_counters, (unsigned)AVK_N_COUNTERS);
+                       (uint64_t *)tally_dev, db->d_counters, (unsigned)AVK_N_COUNTERS, ctx->accumulate_tally ? 1u : 0u);
     AVK_HIP(ctx, hipGetLastError());
     db->scratch_clean = true;
     AVK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));

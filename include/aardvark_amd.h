@@ -182,7 +182,8 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
  *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid"
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
- *                    "use_packed_reference"
+ *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
+ *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
  * None of them changes a result (tests/test_emu_parity.py, tests/test_gpu_parity.py). */
 int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
 

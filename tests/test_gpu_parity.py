@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module")
 def ctx():
     import aardvark_amd
+    import torch
+    torch.cuda.init()  # torch ships its own HIP runtime: it must come up before the library's (one test hands the library a torch tensor)
     c = aardvark_amd.Context(0)
     yield c
     c.close()
