@@ -187,7 +187,7 @@ class Context:
         return [int(x) for x in out]
 
     def debug_phase_cycles(self):
-        out = (C.c_uint64 * 8)()
+        out = (C.c_uint64 * 16)()
         self._check(self.lib.avk_debug_phase_cycles(self.handle, out))
         return [int(x) for x in out]
 

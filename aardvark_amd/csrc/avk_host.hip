@@ -149,7 +149,7 @@ struct avk_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
-    uint64_t last_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t last_phase[16] = {0};
 };
 
 struct avk_dev_batch {
@@ -808,7 +808,7 @@ int avk_last_solver_ms(avk_ctx *ctx, float *ms) {
 }
 
 /* profiling builds (-DAVK_PHASE_TIMING): summed s_memtime ticks per solver phase of the last download */
-int avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[8]) {
+int avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]) {
     if (!ctx || !out) return AVK_E_ARG;
     memcpy(out, ctx->last_phase, sizeof(ctx->last_phase));
     return 0;
@@ -862,7 +862,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
-    memcpy(ctx->last_phase, tally.data() + AVK_TALLY_LEN + 5, 8 * sizeof(uint64_t));
+    memcpy(ctx->last_phase, tally.data() + AVK_TALLY_LEN + 5, 16 * sizeof(uint64_t));
     if (want_seq) {
         for (uint64_t r = 0; r < n; ++r) {
             const AvkDevRegion &dr = db->host.regions[r];

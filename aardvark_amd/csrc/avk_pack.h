@@ -329,7 +329,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         if (cap && dr.ed_bound < cap) cap = dr.ed_bound ? dr.ed_bound : 1;
         uint64_t wfcap = cap ? 2 * cap + 2 : 2 * seqcap + 4;
         if (wfcap > 2 * seqcap + 4) wfcap = 2 * seqcap + 4;
-        const uint64_t hapA = 48 + 16 * alw + 4 * wfcap + 2 * seqcap, nodeA = 8 + 2 * hapA;
+        const uint64_t hapA = (48 + 16 * alw + 4 * wfcap + 2 * seqcap + 15) & ~15ull, nodeA = 16 + 2 * hapA;
         const uint64_t optcap = max_branch < 4096 ? max_branch : 4096;
         const uint64_t fixed = dr.len + 8 + 28 * N + alle + 8 + 8 * N + 16 + 32 + 4 * optcap + 8 * 8 * alw + 8 * 4 * alw * 8 + 32 + 64;
         return fixed + nodes * (nodeA + 16);

@@ -50,6 +50,10 @@ enum { RS_CUT = -2 };      /* internal: phase B stopped because its answer can n
 #endif
 
 #define AVK_ALIGN8(x) (((x) + 7u) & ~(u64)7u)
+#define AVK_ALIGN16(x) (((x) + 15u) & ~(u64)15u)
+/* a node = NODE_HDR bytes (id, auxiliary word) + its haplotype record(s); records start on 16-byte boundaries so their
+ * 12 header words move as three 16-byte LDS accesses */
+#define NODE_HDR 16u
 
 /* optional per-phase cycle accounting (profiling builds: -DAVK_PHASE_TIMING) */
 #ifdef AVK_PHASE_TIMING
@@ -69,6 +73,13 @@ enum { RS_CUT = -2 };      /* internal: phase B stopped because its answer can n
 #else
 #define AVK_T_DECL
 #define AVK_T_MARK(c, k)
+#endif
+#ifndef AVK_PHASE_TIMING
+#define AVK_TA_DECL
+#define AVK_TA_MARK(c, k)
+#else
+#define AVK_TA_DECL AVK_T_DECL
+#define AVK_TA_MARK(c, k) AVK_T_MARK(c, k)
 #endif
 
 /* hap record: 10 header words, then alt bit-sets, wavefront, two sequences */
@@ -136,7 +147,7 @@ struct Ctx {
     u32 max_branch;
     u32 best_cost; /* total cost shared by the tied optima of phase A */
 #ifdef AVK_PHASE_TIMING
-    u64 tphase[8];
+    u64 tphase[16];
 #endif
 };
 
@@ -364,36 +375,44 @@ AVK_DEV HapPtr hap_ptr(u8 *base, u32 alw, u32 wfcap, u32 seqcap) {
     p.qseq = p.tseq + seqcap;
     return p;
 }
+/* the 12 header words of a haplotype record sit on a 16-byte boundary (NODE_HDR, AVK_ALIGN16 record sizes): three
+ * 16-byte accesses instead of twelve 4-byte ones */
 AVK_DEV HapHdr hap_load(const u32 *w) {
-    u32 t[H_WORDS];
-    ldvec_u<H_WORDS>(w, t);
+    const avk_u4 *q = (const avk_u4 *)w;
+    const avk_u4 a = q[0], b = q[1], d = q[2];
     HapHdr h;
-    h.t_refpos = t[H_T_REFPOS];
-    h.q_refpos = t[H_Q_REFPOS];
-    h.t_len = t[H_T_LEN];
-    h.q_len = t[H_Q_LEN];
-    h.t_skip = t[H_T_SKIP];
-    h.q_skip = t[H_Q_SKIP];
-    h.ed = t[H_ED];
-    h.t_nal = t[H_T_NAL];
-    h.q_nal = t[H_Q_NAL];
-    h.nskip = t[H_NSKIP];
-    h.d0 = t[H_D0];
+    h.t_refpos = wv_uni(a.x);
+    h.q_refpos = wv_uni(a.y);
+    h.t_len = wv_uni(a.z);
+    h.q_len = wv_uni(a.w);
+    h.t_skip = wv_uni(b.x);
+    h.q_skip = wv_uni(b.y);
+    h.ed = wv_uni(b.z);
+    h.t_nal = wv_uni(b.w);
+    h.q_nal = wv_uni(d.x);
+    h.nskip = wv_uni(d.y);
+    h.d0 = wv_uni(d.z);
     return h;
 }
 AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
     if (wv_lane() == 0) {
-        w[H_T_REFPOS] = h.t_refpos;
-        w[H_Q_REFPOS] = h.q_refpos;
-        w[H_T_LEN] = h.t_len;
-        w[H_Q_LEN] = h.q_len;
-        w[H_T_SKIP] = h.t_skip;
-        w[H_Q_SKIP] = h.q_skip;
-        w[H_ED] = h.ed;
-        w[H_T_NAL] = h.t_nal;
-        w[H_Q_NAL] = h.q_nal;
-        w[H_NSKIP] = h.nskip;
-        w[H_D0] = h.d0;
+        avk_u4 *q = (avk_u4 *)w;
+        avk_u4 a, b, d;
+        a.x = h.t_refpos;
+        a.y = h.q_refpos;
+        a.z = h.t_len;
+        a.w = h.q_len;
+        b.x = h.t_skip;
+        b.y = h.q_skip;
+        b.z = h.ed;
+        b.w = h.t_nal;
+        d.x = h.q_nal;
+        d.y = h.nskip;
+        d.z = h.d0;
+        d.w = 0;
+        q[0] = a;
+        q[1] = b;
+        q[2] = d;
     }
 }
 AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
@@ -416,7 +435,8 @@ AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
  * All lengths are scalar; each lane moves the bytes whose index it owns, picking the source by range.
  * Returns the `success` flag of HaplotypeTracker::extend_variant.  `has_var` false = only the two
  * copy_reference(upto) calls of finalize_dwfa (:84-88). */
-AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, bool has_var, const UVar &v, u32 allele, u32 sync) {
+/* IS_TRUTH is a template parameter: as a run-time flag every header field it selects costs scalar selects on the way in and out */
+template <bool is_truth> AVK_DEV bool hap_extend_seq_t(const Ctx &c, const HapPtr &p, HapHdr &h, bool has_var, const UVar &v, u32 allele, u32 sync) {
     const u32 lane = (u32)wv_lane();
     u32 &tl = is_truth ? h.t_len : h.q_len, &ol = is_truth ? h.q_len : h.t_len;
     u32 &trp = is_truth ? h.t_refpos : h.q_refpos, &orp = is_truth ? h.q_refpos : h.t_refpos;
@@ -470,6 +490,9 @@ AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_tr
     trp = rp;
     wv_sync();
     return ok;
+}
+AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_truth, bool has_var, const UVar &v, u32 allele, u32 sync) {
+    return is_truth ? hap_extend_seq_t<true>(c, p, h, has_var, v, allele, sync) : hap_extend_seq_t<false>(c, p, h, has_var, v, allele, sync);
 }
 
 /* DWFALite::update for a haplotype record (dynamic_wfa.rs:68-84).  While ed == 0 the wavefront is the single
@@ -647,7 +670,7 @@ AVK_DEV void queue_reload(Ctx &c) {
 /* ------------------------------------------------------------------------------------------ */
 AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
     const u32 *n = (const u32 *)node_at(c, idx);
-    const u32 *h0 = n + 2, *h1 = (const u32 *)((const u8 *)h0 + c.hapA_bytes);
+    const u32 *h0 = n + NODE_HDR / 4, *h1 = (const u32 *)((const u8 *)h0 + c.hapA_bytes);
     u32 a[3], b[3];
     ldvec_u<3>(h0 + H_T_SKIP, a); /* t_skip, q_skip, ed are consecutive header words */
     ldvec_u<3>(h1 + H_T_SKIP, b);
@@ -658,7 +681,7 @@ AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
 AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
     u8 *n = node_at(c, idx);
     for (int hh = 0; hh < 2; ++hh) {
-        const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        const HapPtr p = hap_ptr(n + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
         hap_extend_seq(c, p, h, is_truth, true, v, hh == 0 ? a1 : a2, sync);
         if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
@@ -675,7 +698,7 @@ AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
     UVar none;
     none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
     for (int hh = 0; hh < 2; ++hh) {
-        const HapPtr p = hap_ptr(n + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        const HapPtr p = hap_ptr(n + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
         hap_extend_seq(c, p, h, true, false, none, AL_REF, c.L); /* both sides to the region end */
         if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
@@ -689,6 +712,7 @@ AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
 
 /* returns the number of tied optima (their node indices are in c.optlist), RS_OVERFLOW, or -status-100 */
 AVK_DEV int phaseA(Ctx &c) {
+    AVK_TA_DECL
     c.node_bytes = c.nodeA_bytes;
     c.pool_base = c.pool;
     c.pool_cap = (u32)(c.pool_bytes / c.nodeA_bytes);
@@ -710,14 +734,15 @@ AVK_DEV int phaseA(Ctx &c) {
         u8 *n = node_at(c, (u32)root);
         st32((u32 *)n, 0);
         st32((u32 *)n + 1, 0);
-        hap_init(hap_ptr(n + 8, c.alw, c.wfcap, c.seqcap), c.alw);
-        hap_init(hap_ptr(n + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap), c.alw);
+        hap_init(hap_ptr(n + NODE_HDR, c.alw, c.wfcap, c.seqcap), c.alw);
+        hap_init(hap_ptr(n + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap), c.alw);
     }
     wv_sync();
     queue_push(c, 0, (u32)root);
     u32 next_id = 1;
     u32 best_ed = 0xFFFFFFFFu;
     u32 nbest = 0;
+    AVK_TA_MARK(c, 8)
 
     while (c.qn > 0) {
         u64 key;
@@ -726,7 +751,7 @@ AVK_DEV int phaseA(Ctx &c) {
         if (cost > best_ed) break; /* :204 skips it — and, pops being in non-decreasing cost order (a child never
                                       costs less than its parent), every node still queued would be skipped too */
         const u32 *nw = (const u32 *)node_at(c, ni);
-        const u32 depth = ld32u(nw + 2 + H_T_NAL) + ld32u(nw + 2 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
+        const u32 depth = ld32u(nw + NODE_HDR / 4 + H_T_NAL) + ld32u(nw + NODE_HDR / 4 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
         const u32 cnt = c.regb ? wv_readlane(c.rbucket, depth) : ld32u(c.bucket + depth);
         if (cnt >= c.max_branch) { /* :222 */
             node_free(c, ni);
@@ -740,6 +765,7 @@ AVK_DEV int phaseA(Ctx &c) {
             wv_sync();
         }
 
+        AVK_TA_MARK(c, 9)
         if (depth == c.N) { /* :227-247 */
             if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
             const u32 fc = nodeA_cost(c, ni);
@@ -757,6 +783,7 @@ AVK_DEV int phaseA(Ctx &c) {
             } else {
                 node_free(c, ni);
             }
+            AVK_TA_MARK(c, 10)
             continue;
         }
 
@@ -774,15 +801,20 @@ AVK_DEV int phaseA(Ctx &c) {
             node_copy(c, (u32)c1, ni);
             st32((u32 *)node_at(c, (u32)c1), next_id);
             wv_sync();
+            AVK_TA_MARK(c, 11)
             if (nodeA_extend(c, (u32)c1, is_truth, v, AL_REF, AL_ALT, sync)) return RS_OVERFLOW;
+            AVK_TA_MARK(c, 12)
             if (queue_push(c, ((u64)nodeA_cost(c, (u32)c1) << 32) | next_id, (u32)c1)) return RS_OVERFLOW;
             next_id += 1;
             /* the popped node itself becomes the second clone */
             st32((u32 *)node_at(c, ni), next_id);
             wv_sync();
+            AVK_TA_MARK(c, 13)
             if (nodeA_extend(c, ni, is_truth, v, AL_ALT, AL_REF, sync)) return RS_OVERFLOW;
+            AVK_TA_MARK(c, 12)
             if (queue_push(c, ((u64)nodeA_cost(c, ni) << 32) | next_id, ni)) return RS_OVERFLOW;
             next_id += 1;
+            AVK_TA_MARK(c, 13)
         } else { /* :294-327: the node is moved, its id kept */
             u32 a1 = AL_ALT, a2 = AL_ALT;
             if (het) {
@@ -790,8 +822,11 @@ AVK_DEV int phaseA(Ctx &c) {
                 a2 = zyg == AVK_ZYG_PHASED_HET01 ? AL_ALT : AL_REF;
             }
             const u32 id = ld32u((const u32 *)node_at(c, ni));
+            AVK_TA_MARK(c, 11)
             if (nodeA_extend(c, ni, is_truth, v, a1, a2, sync)) return RS_OVERFLOW;
+            AVK_TA_MARK(c, 12)
             if (queue_push(c, ((u64)nodeA_cost(c, ni) << 32) | id, ni)) return RS_OVERFLOW;
+            AVK_TA_MARK(c, 13)
         }
     }
     if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
@@ -808,7 +843,7 @@ AVK_DEV int phaseA(Ctx &c) {
  * update either slides d0 to an end (still exact) or would have to raise the distance (not exact). */
 AVK_DEV bool nodeB_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 allele, u32 sync, bool is_error) {
     u8 *n = node_at(c, idx);
-    const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
+    const HapPtr p = hap_ptr(n + NODE_HDR, c.alw, 2, c.seqcap);
     HapHdr h = hap_load(p.w);
     const bool ok = hap_extend_seq(c, p, h, is_truth, true, v, allele, sync);
     const bool exact = hap_slide_d0(p, h);
@@ -849,7 +884,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
         u8 *n = node_at(c, (u32)root);
         st32((u32 *)n, 0);
         st32((u32 *)n + 1, 0);
-        hap_init(hap_ptr(n + 8, c.alw, 2, c.seqcap), c.alw);
+        hap_init(hap_ptr(n + NODE_HDR, c.alw, 2, c.seqcap), c.alw);
     }
     wv_sync();
     queue_push(c, keyB(0, 0, 0), (u32)root);
@@ -862,7 +897,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
         u8 *n = node_at(c, ni);
         const u32 errors = (u32)(key >> 48);
         if (errors >= cutoff) return RS_CUT;
-        const HapPtr p = hap_ptr(n + 8, c.alw, 2, c.seqcap);
+        const HapPtr p = hap_ptr(n + NODE_HDR, c.alw, 2, c.seqcap);
         HapHdr h = hap_load(p.w);
         const u32 depth = h.t_nal + h.q_nal;
         if (depth == c.N) { /* :180-192 finalize: both to the region end, exact iff identical */
@@ -955,7 +990,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
                     k = c.qkeys[j];
                     s = c.qslots[j];
                     const u8 *nn = node_at(c, s);
-                    const HapPtr q = hap_ptr((u8 *)nn + 8, c.alw, 2, c.seqcap);
+                    const HapPtr q = hap_ptr((u8 *)nn + NODE_HDR, c.alw, 2, c.seqcap);
                     const u32 nal = f_truth ? q.w[H_T_NAL] : q.w[H_Q_NAL];
                     const u64 *bits = f_truth ? q.talt : q.qalt;
                     const bool is_alt = fsub < nal && ((bits[fsub >> 6] >> (fsub & 63)) & 1);
@@ -1130,10 +1165,10 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     c.wfcap = cap ? (2 * cap + 2) : wf_full; /* even */
     if (c.wfcap > wf_full) c.wfcap = wf_full;
     c.wfs_cap = c.wfcap;
-    c.hapA_bytes = H_WORDS * 4 + 16 * c.alw + 4 * c.wfcap + 2 * c.seqcap;
-    c.nodeA_bytes = 8 + 2 * c.hapA_bytes;
-    c.hapB_bytes = H_WORDS * 4 + 16 * c.alw + 4 * 2 + 2 * c.seqcap;
-    c.nodeB_bytes = 8 + c.hapB_bytes;
+    c.hapA_bytes = (u32)AVK_ALIGN16(H_WORDS * 4 + 16 * c.alw + 4 * c.wfcap + 2 * c.seqcap);
+    c.nodeA_bytes = NODE_HDR + 2 * c.hapA_bytes;
+    c.hapB_bytes = (u32)AVK_ALIGN16(H_WORDS * 4 + 16 * c.alw + 4 * 2 + 2 * c.seqcap);
+    c.nodeB_bytes = NODE_HDR + c.hapB_bytes;
     c.optcap = c.max_branch < 4096 ? c.max_branch : 4096;
 
     /* carve the workspace */
@@ -1190,7 +1225,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         c.qslots = (u32 *)(ws + off);
         off += 4ull * c.qcap;
         c.freelist = (u32 *)(ws + off);
-        off = AVK_ALIGN8(off + 4ull * c.qcap);
+        off = AVK_ALIGN16(off + 4ull * c.qcap);
         c.pool = ws + off;
         c.pool_bytes = ws_bytes > off ? ws_bytes - off : 0;
         c.pool_off = off;
@@ -1282,8 +1317,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     if (c.pool_off + (u64)nopt * c.nodeA_bytes > c.cscratch_off) return RS_OVERFLOW; /* optima would sit under the metrics scratch */
 
     if (a.enable_exact_shortcut && c.best_cost == 0) { /* waffle_solver.rs:171-199: returns on the first optimum */
-        const HapPtr s0 = hap_ptr(c.pool + 8, c.alw, c.wfcap, c.seqcap);
-        const HapPtr s1 = hap_ptr(c.pool + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        const HapPtr s0 = hap_ptr(c.pool + NODE_HDR, c.alw, c.wfcap, c.seqcap);
+        const HapPtr s1 = hap_ptr(c.pool + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         const HapHdr g0 = hap_load(s0.w), g1 = hap_load(s1.w);
         winner_node = 0;
         out.ed1 = 0;
@@ -1309,7 +1344,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         u32 errs[2] = {0, 0};
         bool cut = false;
         for (int hh = 0; hh < 2 && !cut; ++hh) {
-            const HapPtr ap = hap_ptr(poolA + (u64)k * nodeA_bytes + 8 + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+            const HapPtr ap = hap_ptr(poolA + (u64)k * nodeA_bytes + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
             u64 *res = c.bres + (u64)(0 * 2 + hh) * 2 * c.alw; /* candidate slot 0 = current */
             const HapHdr ah = hap_load(ap.w);
             if (ah.ed == 0 && ah.nskip == 0 && small_n) {
@@ -1350,8 +1385,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
                 break;
             }
             c.node_bytes = c.nodeB_bytes;
-            c.pool_base = poolA + AVK_ALIGN8(a_bytes);
-            const u64 bbytes = c.pool_bytes > AVK_ALIGN8(a_bytes) ? c.pool_bytes - AVK_ALIGN8(a_bytes) : 0;
+            c.pool_base = poolA + AVK_ALIGN16(a_bytes);
+            const u64 bbytes = c.pool_bytes > AVK_ALIGN16(a_bytes) ? c.pool_bytes - AVK_ALIGN16(a_bytes) : 0;
             u64 cap = bbytes / c.nodeB_bytes;
             if (cap > c.qcap) cap = c.qcap;
             c.pool_cap = (u32)cap;
@@ -1393,8 +1428,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
 
     /* ---- phase C */
     u8 *wn = poolA + (u64)best_k * nodeA_bytes;
-    const HapPtr w0 = hap_ptr(wn + 8, c.alw, c.wfcap, c.seqcap);
-    const HapPtr w1 = hap_ptr(wn + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+    const HapPtr w0 = hap_ptr(wn + NODE_HDR, c.alw, c.wfcap, c.seqcap);
+    const HapPtr w1 = hap_ptr(wn + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
     const HapHdr h0 = hap_load(w0.w), h1 = hap_load(w1.w);
     out.ed1 = h0.ed;
     out.ed2 = h1.ed;
@@ -1707,7 +1742,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         }
         Ctx c;
 #ifdef AVK_PHASE_TIMING
-        for (int k = 0; k < 8; ++k) c.tphase[k] = 0;
+        for (int k = 0; k < 16; ++k) c.tphase[k] = 0;
         const u64 t_region0 = avk_clock();
 #endif
         RegionOut out;
@@ -1801,8 +1836,8 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         }
         if (a.seq_bytes && a.seq_len && reg.seq_stride) { /* SequenceBundle, waffle_solver.rs:237-246 */
             u8 *wn = c.pool + (u64)winner * c.nodeA_bytes;
-            const HapPtr w0 = hap_ptr(wn + 8, c.alw, c.wfcap, c.seqcap);
-            const HapPtr w1 = hap_ptr(wn + 8 + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+            const HapPtr w0 = hap_ptr(wn + NODE_HDR, c.alw, c.wfcap, c.seqcap);
+            const HapPtr w1 = hap_ptr(wn + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
             const HapHdr h0 = hap_load(w0.w), h1 = hap_load(w1.w);
             const u8 *src[5] = {c.ref, w0.tseq, w1.tseq, w0.qseq, w1.qseq};
             const u32 len[5] = {c.L, h0.t_len, h1.t_len, h0.q_len, h1.q_len};
@@ -1820,6 +1855,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             for (int k = 0; k < 6; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
             avk_atomic_add_u64_global(pc + 6, avk_clock() - t_region0);
             avk_atomic_add_u64_global(pc + 7, 1);
+            for (int k = 8; k < 14; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
         }
 #endif
     }

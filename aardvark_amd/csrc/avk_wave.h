@@ -33,6 +33,9 @@ void yield(); /* lets the other emulated waves (OS threads) run */
 } // namespace avk_emu
 #define AVK_SITE ((uint32_t)__LINE__)
 
+struct alignas(16) avk_u4 {
+    uint32_t x, y, z, w;
+};
 AVK_DEV int wv_lane() { return avk_emu::lane(); }
 AVK_DEV uint64_t wv_ballot_(bool p, uint32_t site) {
     const uint64_t *g = avk_emu::gather(p ? 1 : 0, site);
@@ -112,6 +115,7 @@ AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 #include <hip/hip_runtime.h>
 #define AVK_DEV __device__ __forceinline__
 #define AVK_DEV_NOINLINE __device__ __noinline__
+typedef uint4 avk_u4; /* one 16-byte LDS / global access */
 
 /* The lane index is deliberately opaque to the optimiser (a volatile asm, two VALU instructions per use): as a pure
  * function it and everything derived from it (lane * 28 + 16, lane < 32, ...) is hoisted out of the persistent region loop,

@@ -215,9 +215,10 @@ int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);  /* the dominant launch: first
 int  avk_last_solver_ms(avk_ctx *ctx, float *ms);  /* all solver launches of the call (tier passes + tally reduce) */
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
-/* profiling builds of the library only: summed clock ticks per solver phase (stage, search A, search B,
- * metrics setup, base-pair metrics, record metrics, whole region, region count) of the last download */
-int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[8]);
+/* profiling builds of the library only (-DAVK_PHASE_TIMING): summed clock ticks per solver phase of the last download:
+ * [0] stage, [1] search A, [2] search B, [3] metrics setup, [4] base-pair metrics, [5] record metrics, [6] whole region,
+ * [7] region count, [8..13] inside search A: setup, pop + quota, finalise, clone, extend, push */
+int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]);
 
 /* Merge path (src/merge_solver.rs:137-143): for pair p, optimize_sequences(set a, set b) and
  * report all_opt_haps[0].is_exact_match().  Pair p compares variant ranges
