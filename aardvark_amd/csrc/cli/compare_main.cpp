@@ -2,8 +2,8 @@
  * compare_main.cpp — `aardvark_amd_compare`: the reference's `aardvark compare` flow (src/main.rs:30-327) on top of the
  * two C-ABIs: libaardvark_feeder.so turns FASTA + BED + truth/query VCFs into region batches, libaardvark_amd.so
  * solves them on the GPU, the feeder library writes summary.tsv.  Option names are the reference's
- * (src/cli/compare.rs).  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).  Not implemented here: stratifications
- * and the debug TSVs — the flags are rejected rather than ignored.
+ * (src/cli/compare.rs), --stratification included.  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).
+ * Not implemented here: the debug TSVs (--output-debug is rejected rather than ignored).
  */
 #include <cerrno>
 #include <chrono>
@@ -33,14 +33,14 @@ void usage() {
             "usage: aardvark_amd_compare -r REF.fa[.gz] -t TRUTH.vcf[.gz] -q QUERY.vcf[.gz] -b REGIONS.bed[.gz] -o OUT_DIR\n"
             "  [--truth-sample S] [--query-sample S] [--compare-label L] [--min-variant-gap 50] [--disable-variant-trimming]\n"
             "  [--max-branch-factor 50] [--enable-exact-shortcut] [--enable-haplotype-metrics] [--enable-weighted-haplotype-metrics]\n"
-            "  [--enable-record-basepair-metrics] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
+            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
 }
 
 } // namespace
 
 int main(int argc, char **argv) {
     const auto t_start = std::chrono::steady_clock::now();
-    std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare";
+    std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare", strat_tsv;
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000;
     bool trimming = true, shortcut = false, hap = false, whap = false, rbp = false;
     int device = 0;
@@ -70,7 +70,8 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
         else if (a == "--threads" || a == "--max-edit-distance") (void)val(); /* accepted for command-line compatibility */
-        else if (a == "-s" || a == "--stratification" || a == "--output-debug") die(64, "not supported by this build", a.c_str());
+        else if (a == "-s" || a == "--stratification") strat_tsv = val();
+        else if (a == "--output-debug") die(64, "not supported by this build", a.c_str());
         else if (a == "-h" || a == "--help") {
             usage();
             return 0;
@@ -89,6 +90,10 @@ int main(int argc, char **argv) {
     avf_genome *genome = nullptr;
     if (avf_genome_load(ref.c_str(), &genome)) die(74, "Error while loading reference genome", avf_last_error());
     const double s_genome = seconds_since(t0);
+
+    avf_strat *strat = nullptr;
+    if (!strat_tsv.empty() && avf_strat_load(strat_tsv.c_str(), &strat)) die(74, "Error while loading stratifications", avf_last_error());
+    const uint32_t n_labels = avf_strat_n_labels(strat);
 
     t0 = std::chrono::steady_clock::now();
     avf_feed *feed = nullptr;
@@ -125,7 +130,12 @@ int main(int argc, char **argv) {
     cfg.enable_exact_shortcut = shortcut ? 1 : 0;
     std::vector<int32_t> status(all->n_regions, -1); /* regions outside --skip/--take stay unsolved and unwritten */
     std::vector<uint8_t> var_expected(all->n_variants + 1), var_observed(all->n_variants + 1), var_class(all->n_variants + 1);
-    (void)avk_ctx_set_option(ctx, "emit_group_metrics", 0); /* only the summed block is needed here */
+    /* stratified tallies (SummaryWriter::add_comparison_benchmark, summary.rs:146-163): label l sums the metric blocks of the
+     * regions it contains, so the per-region blocks come back from the GPU, in batches that keep them at a few hundred MB */
+    (void)avk_ctx_set_option(ctx, "emit_group_metrics", n_labels ? 1 : 0);
+    if (n_labels && batch_regions > 262144) batch_regions = 262144;
+    std::vector<uint64_t> strat_total((size_t)n_labels * AVK_TALLY_LEN, 0);
+    std::vector<uint32_t> gm, labels(n_labels ? n_labels : 1);
     for (uint64_t at = 0; at < count; at += batch_regions) {
         const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
         avk_region_batch b = *all; /* a window of the region arrays; variant arrays are shared */
@@ -145,8 +155,21 @@ int main(int argc, char **argv) {
         out.var_expected = var_expected.data(); /* indexed by the (shared) variant arrays */
         out.var_observed = var_observed.data();
         out.var_class = var_class.data();
+        if (n_labels) {
+            gm.resize((size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
+            out.group_metrics = gm.data();
+        }
         if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
         for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += tally[k];
+        for (uint64_t r = 0; n_labels && r < n; ++r) {
+            if (out.status[r] != 0) continue;
+            const uint32_t hit = avf_strat_region_labels(strat, genome, all, first + at + r, labels.data(), n_labels);
+            const uint32_t *block = gm.data() + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS;
+            for (uint32_t h = 0; h < hit; ++h) {
+                uint64_t *dst = strat_total.data() + (size_t)labels[h] * AVK_TALLY_LEN;
+                for (int k = 0; k < AVK_N_GROUPS * AVK_N_FIELDS; ++k) dst[k] += block[k];
+            }
+        }
         for (uint64_t r = 0; r < n; ++r)
             if (out.status[r] != 0)
                 fprintf(stderr, "Error while solving compare region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)b.region_id[r], b.contig_idx[r],
@@ -160,7 +183,8 @@ int main(int argc, char **argv) {
     if (whap) mask |= AVF_METRIC_WEIGHTED_HAP;
     if (rbp) mask |= AVF_METRIC_RECORD_BP;
     const std::string summary = out_dir + "/summary.tsv";
-    if (avf_write_summary(summary.c_str(), label.c_str(), total.data(), mask)) die(74, "Error while saving summary file", avf_last_error());
+    if (avf_write_summary_stratified(summary.c_str(), label.c_str(), total.data(), strat, strat_total.data(), mask))
+        die(74, "Error while saving summary file", avf_last_error());
     /* the annotated VCFs (VariantCategorizer): truth.vcf.gz and query.vcf.gz with their .tbi */
     std::string command;
     for (int i = 0; i < argc; ++i) command += (i ? " " : "") + std::string(argv[i]);
@@ -188,6 +212,7 @@ int main(int argc, char **argv) {
             s_solve > 0 ? (double)count / s_solve / 1e6 : 0.0);
     avk_ctx_destroy(ctx);
     avf_feed_free(feed);
+    avf_strat_free(strat);
     avf_genome_free(genome);
     return 0;
 }

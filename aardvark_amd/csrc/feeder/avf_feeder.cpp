@@ -604,8 +604,9 @@ const uint32_t *avf_feed_var_alt_index(const avf_feed *f) { return f ? f->var_al
 uint64_t avf_feed_loaded_variants(const avf_feed *f, int input) { return f && (input == 0 || input == 1) ? f->loaded[input] : 0; }
 void avf_feed_free(avf_feed *f) { delete f; }
 
-int avf_write_summary(const char *path, const char *compare_label, const uint64_t *tally, uint32_t metrics_mask) {
-    if (!path || !tally) return fail(AVK_E_ARG, "null argument");
+int avf_write_summary_stratified(const char *path, const char *compare_label, const uint64_t *tally, const avf_strat *strat, const uint64_t *strat_tallies,
+                                 uint32_t metrics_mask) {
+    if (!path || !tally || (strat && !strat_tallies)) return fail(AVK_E_ARG, "null argument");
     const std::string p(path);
     const char delim = p.size() >= 4 && p.compare(p.size() - 4, 4, ".csv") == 0 ? ',' : '\t';
     FILE *fp = fopen(path, "w");
@@ -636,6 +637,7 @@ int avf_write_summary(const char *path, const char *compare_label, const uint64_
                            {AVF_METRIC_HAP, "HAP", AVK_F_HAP_TRUTH_TP, false},
                            {AVF_METRIC_WEIGHTED_HAP, "WEIGHTED_HAP", AVK_F_WHAP_TRUTH_TP, false},
                            {AVF_METRIC_RECORD_BP, "RECORD_BP", AVK_F_RBP_TRUTH_TP, false}};
+    std::string region_label = "ALL";
     auto row = [&](const Kind &kd, const char *vtype, const uint64_t m[4], const uint64_t gt_extra[2]) {
         const uint64_t ttot = m[0] + m[1], qtot = m[2] + m[3];
         std::string recall, precision, f1;
@@ -645,43 +647,56 @@ int avf_write_summary(const char *path, const char *compare_label, const uint64_
             const double r = (double)m[0] / (double)ttot, pr = (double)m[2] / (double)qtot;
             f1 = fmt_f64(2.0 * r * pr / (r + pr));
         }
-        fprintf(fp, "%s%c%s%cALL%cALL%c%s%c%llu%c%llu%c%llu%c%llu%c%llu%c%llu%c%s%c%s%c%s%c", label.c_str(), delim, kd.name, delim, delim, delim, vtype, delim,
+        fprintf(fp, "%s%c%s%c%s%cALL%c%s%c%llu%c%llu%c%llu%c%llu%c%llu%c%llu%c%s%c%s%c%s%c", label.c_str(), delim, kd.name, delim, region_label.c_str(), delim, delim, vtype, delim,
                 (unsigned long long)ttot, delim, (unsigned long long)m[0], delim, (unsigned long long)m[1], delim, (unsigned long long)qtot, delim,
                 (unsigned long long)m[2], delim, (unsigned long long)m[3], delim, recall.c_str(), delim, precision.c_str(), delim, f1.c_str(), delim);
         if (kd.gt) fprintf(fp, "%llu%c%llu\n", (unsigned long long)gt_extra[0], delim, (unsigned long long)gt_extra[1]);
         else fprintf(fp, "%c\n", delim);
     };
-    for (const Kind &kd : kinds) {
-        if (!(metrics_mask & kd.bit)) continue;
-        auto fields = [&](int group, uint64_t m[4], uint64_t ex[2]) {
-            const uint64_t *gp = tally + (size_t)group * AVK_N_FIELDS;
-            for (int k = 0; k < 4; ++k) m[k] = gp[kd.base + k];
-            ex[0] = gp[AVK_F_GT_TRUTH_FN_GT];
-            ex[1] = gp[AVK_F_GT_QUERY_FP_GT];
-        };
-        uint64_t m[4], ex[2];
-        fields(0, m, ex);
-        row(kd, "ALL", m, ex);
-        for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t) {
-            fields(1 + t, m, ex);
-            if (m[0] + m[1] + m[2] + m[3] == 0) continue; /* is_empty: no row */
-            row(kd, type_name[t], m, ex);
-        }
-        for (const Joint &jt : joints) {
-            uint64_t s[4] = {0, 0, 0, 0}, sx[2] = {0, 0};
-            for (int t : jt.types) {
+    auto write_group = [&](const uint64_t *tally) {
+        for (const Kind &kd : kinds) {
+            if (!(metrics_mask & kd.bit)) continue;
+            auto fields = [&](int group, uint64_t m[4], uint64_t ex[2]) {
+                const uint64_t *gp = tally + (size_t)group * AVK_N_FIELDS;
+                for (int k = 0; k < 4; ++k) m[k] = gp[kd.base + k];
+                ex[0] = gp[AVK_F_GT_TRUTH_FN_GT];
+                ex[1] = gp[AVK_F_GT_QUERY_FP_GT];
+            };
+            uint64_t m[4], ex[2];
+            fields(0, m, ex);
+            row(kd, "ALL", m, ex);
+            for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t) {
                 fields(1 + t, m, ex);
-                for (int k = 0; k < 4; ++k) s[k] += m[k];
-                sx[0] += ex[0];
-                sx[1] += ex[1];
+                if (m[0] + m[1] + m[2] + m[3] == 0) continue; /* is_empty: no row */
+                row(kd, type_name[t], m, ex);
             }
-            if (s[0] + s[1] + s[2] + s[3] == 0) continue;
-            row(kd, jt.label, s, sx);
+            for (const Joint &jt : joints) {
+                uint64_t s[4] = {0, 0, 0, 0}, sx[2] = {0, 0};
+                for (int t : jt.types) {
+                    fields(1 + t, m, ex);
+                    for (int k = 0; k < 4; ++k) s[k] += m[k];
+                    sx[0] += ex[0];
+                    sx[1] += ex[1];
+                }
+                if (s[0] + s[1] + s[2] + s[3] == 0) continue;
+                row(kd, jt.label, s, sx);
+            }
         }
-    }
+    };
+    write_group(tally); /* the ALL group first (summary.rs:196-201) */
+    if (strat)
+        for (uint32_t l = 0; l < avf_strat_n_labels(strat); ++l) {
+            region_label = csv_field(avf_strat_label(strat, l), delim);
+            write_group(strat_tallies + (size_t)l * AVK_TALLY_LEN);
+        }
     const bool bad = ferror(fp) != 0;
     if (fclose(fp) != 0 || bad) return fail(AVK_E_ARG, "write error on %s", path);
     return 0;
+}
+
+
+int avf_write_summary(const char *path, const char *compare_label, const uint64_t *tally, uint32_t metrics_mask) {
+    return avf_write_summary_stratified(path, compare_label, tally, nullptr, nullptr, metrics_mask);
 }
 
 } /* extern "C" */

@@ -54,6 +54,21 @@ def load_library():
     u8p = C.POINTER(C.c_uint8)
     lib.avf_write_annotated_vcf.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(AvkRegionBatch), C.c_int,
                                             C.POINTER(C.c_int32), u8p, u8p, u8p]
+    lib.avf_strat_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.avf_strat_n_labels.restype = C.c_uint32
+    lib.avf_strat_n_labels.argtypes = [vp]
+    lib.avf_strat_label.restype = C.c_char_p
+    lib.avf_strat_label.argtypes = [vp, C.c_uint32]
+    lib.avf_strat_n_intervals.restype = C.c_uint64
+    lib.avf_strat_n_intervals.argtypes = [vp, C.c_uint32, C.c_char_p]
+    u32p = C.POINTER(C.c_uint32)
+    for f in (lib.avf_strat_containments, lib.avf_strat_overlaps):
+        f.restype = C.c_uint32
+        f.argtypes = [vp, C.c_char_p, C.c_int64, C.c_int64, u32p, C.c_uint32]
+    lib.avf_strat_region_labels.restype = C.c_uint32
+    lib.avf_strat_region_labels.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, u32p, C.c_uint32]
+    lib.avf_strat_free.argtypes = [vp]
+    lib.avf_write_summary_stratified.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_uint64), C.c_uint32]
     _lib = lib
     return lib
 
@@ -137,3 +152,47 @@ def write_annotated_vcf(out_path, input_vcf, genome, batch, result, source, samp
     keep = [np.ascontiguousarray(x, np.uint8) for x in (result.var_expected, result.var_observed, result.var_class)]
     _check(lib, lib.avf_write_annotated_vcf(os.fsencode(out_path), os.fsencode(input_vcf), sample_name.encode(), version.encode(), command_line.encode(),
                                             genome.handle, C.byref(cb), source, st.ctypes.data_as(C.POINTER(C.c_int32)), u8(keep[0]), u8(keep[1]), u8(keep[2])))
+
+
+class Stratifications:
+    """Stratifications::from_tsv_batch (src/parsing/stratifications.rs): labelled BED sets, labels in sorted order."""
+
+    def __init__(self, tsv_path):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.avf_strat_load(os.fsencode(tsv_path), C.byref(h)))
+        self.handle = h
+        self.labels = [self.lib.avf_strat_label(h, i).decode() for i in range(self.lib.avf_strat_n_labels(h))]
+
+    def _query(self, fn, chrom, first, last):
+        out = (C.c_uint32 * max(len(self.labels), 1))()
+        n = fn(self.handle, chrom.encode(), first, last, out, len(self.labels))
+        return [int(out[i]) for i in range(n)]
+
+    def containments(self, chrom, first, last):
+        return self._query(self.lib.avf_strat_containments, chrom, first, last)
+
+    def overlaps(self, chrom, first, last):
+        return self._query(self.lib.avf_strat_overlaps, chrom, first, last)
+
+    def n_intervals(self, label, chrom):
+        return int(self.lib.avf_strat_n_intervals(self.handle, label, chrom.encode()))
+
+    def region_labels(self, genome, batch, r):
+        cb = batch.c_struct()
+        out = (C.c_uint32 * max(len(self.labels), 1))()
+        n = self.lib.avf_strat_region_labels(self.handle, genome.handle, C.byref(cb), r, out, len(self.labels))
+        return [int(out[i]) for i in range(n)]
+
+    def close(self):
+        if self.handle:
+            self.lib.avf_strat_free(self.handle)
+            self.handle = None
+
+
+def write_summary_stratified(path, tally, strat, strat_tallies, compare_label="compare", metrics=METRIC_GT | METRIC_BASEPAIR):
+    lib = load_library()
+    t = np.ascontiguousarray(tally, dtype=np.uint64)
+    st = np.ascontiguousarray(strat_tallies, dtype=np.uint64).reshape(-1)
+    _check(lib, lib.avf_write_summary_stratified(os.fsencode(path), compare_label.encode(), t.ctypes.data_as(C.POINTER(C.c_uint64)), strat.handle,
+                                                 st.ctypes.data_as(C.POINTER(C.c_uint64)), metrics))

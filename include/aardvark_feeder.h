@@ -63,6 +63,29 @@ void avf_feed_free(avf_feed *f);
 #define AVF_METRIC_RECORD_BP 16u
 int avf_write_summary(const char *path, const char *compare_label, const uint64_t *tally, uint32_t metrics_mask);
 
+/* ---- stratifications (src/parsing/stratifications.rs) ------------------------------------------------------------------
+ * avf_strat_load = Stratifications::from_tsv_batch (:30-86): a TSV of `label <TAB> BED path` rows (paths relative to the
+ * TSV's folder), duplicate labels rejected; labels end up in sorted order (the reference collects them in a BTreeMap).
+ * Intervals are kept 0-based inclusive per label and chromosome (:147-176). */
+typedef struct avf_strat avf_strat;
+int avf_strat_load(const char *tsv_path, avf_strat **out);
+uint32_t avf_strat_n_labels(const avf_strat *s);
+const char *avf_strat_label(const avf_strat *s, uint32_t label);
+uint64_t avf_strat_n_intervals(const avf_strat *s, uint32_t label, const char *chrom); /* COITree::len of that chromosome */
+/* Stratifications::containments / overlaps (:88-113) of the 0-based inclusive range [first, last] on chrom: the indices of
+ * the labels with an interval that contains / overlaps it, ascending, written to out (at most cap); returns how many */
+uint32_t avf_strat_containments(const avf_strat *s, const char *chrom, int64_t first, int64_t last, uint32_t *out, uint32_t cap);
+uint32_t avf_strat_overlaps(const avf_strat *s, const char *chrom, int64_t first, int64_t last, uint32_t *out, uint32_t cap);
+/* The labels containing region r of `batch` the way solve_compare_region asks (src/waffle_solver.rs:151-166):
+ * [min first position, max over the two LAST variants of pos + ref_len) of CompareRegion::var_coordinates
+ * (compare_region.rs:54-66), queried as first..last-1. */
+uint32_t avf_strat_region_labels(const avf_strat *s, const avf_genome *g, const avk_region_batch *batch, uint64_t r, uint32_t *out, uint32_t cap);
+void avf_strat_free(avf_strat *s);
+/* avf_write_summary with the stratified blocks after the ALL block (summary.rs:203-222): strat_tallies holds
+ * avf_strat_n_labels(s) blocks of AVK_TALLY_LEN words, block l = the sum over the regions label l contains */
+int avf_write_summary_stratified(const char *path, const char *compare_label, const uint64_t *tally, const avf_strat *s, const uint64_t *strat_tallies,
+                                 uint32_t metrics_mask);
+
 /* One of the two annotated VCFs of `compare` (VariantCategorizer, src/writers/variant_categorizer.rs:41-230; source 0 =
  * truth.vcf.gz, 1 = query.vcf.gz): the meta lines of input_vcf, the aardvark_version / aardvark_command lines and the
  * BD / EA / OA / RI FORMAT definitions, one sample column (sample_name, or the input's first sample when empty), then one

@@ -226,8 +226,42 @@ FIELDS = ["GT_TRUTH_TP", "GT_TRUTH_FN", "GT_QUERY_TP", "GT_QUERY_FP", "GT_TRUTH_
           "RBP_TRUTH_TP", "RBP_TRUTH_FN", "RBP_QUERY_TP", "RBP_QUERY_FP"]
 
 
-def summary_text(tally, compare_label="compare", metrics=("GT", "BASEPAIR"), delim="\t"):
-    """SummaryWriter::write_summary (src/writers/summary.rs:163-395) over the ALL block."""
+def load_stratifications(tsv_path):
+    """Stratifications::from_tsv_batch (src/parsing/stratifications.rs:30-86): [(label, {chrom: [(first, last)]})], labels sorted,
+    intervals 0-based inclusive"""
+    import os
+    folder = os.path.dirname(tsv_path)
+    files = {}
+    for row in open(tsv_path).read().splitlines():
+        if not row:
+            continue
+        label, fn = row.split("\t")[:2]
+        if label in files:
+            raise ValueError("Duplicate label found: %s" % label)
+        files[label] = fn if os.path.isabs(fn) else os.path.join(folder, fn)
+    return [(label, {c: [(s - 1, e - 1) for s, e in iv] for c, iv in read_bed(files[label]).items()}) for label in sorted(files)]
+
+
+def containments(strat, chrom, first, last):
+    """:101-113 + :189-199: labels with an interval i.first <= first && i.last >= last"""
+    return [k for k, (_l, trees) in enumerate(strat) if any(a <= first and b >= last for a, b in trees.get(chrom, []))]
+
+
+def overlaps(strat, chrom, first, last):
+    return [k for k, (_l, trees) in enumerate(strat) if any(a <= last and b >= first for a, b in trees.get(chrom, []))]
+
+
+def region_labels(strat, region):
+    """solve_compare_region's query (waffle_solver.rs:151-166) with CompareRegion::var_coordinates (compare_region.rs:54-66)"""
+    t, q = region["truth"], region["query"]
+    start = min([v[0]["pos"] for v in (t, q) if v])
+    end = max([v[-1]["pos"] + len(v[-1]["a0"]) for v in (t, q) if v])
+    return containments(strat, region["chrom"], start, end - 1)
+
+
+def summary_text(tally, compare_label="compare", metrics=("GT", "BASEPAIR"), delim="\t", strat_blocks=()):
+    """SummaryWriter::write_summary (src/writers/summary.rs:163-395): the ALL block, then one block per stratification label
+    (strat_blocks = [(label, tally)])."""
     types = list(VT)
     base = {"GT": 0, "HAP": 6, "WEIGHTED_HAP": 10, "BASEPAIR": 14, "RECORD_BP": 18}
     joints = [("JointIndel", ["Insertion", "Deletion", "Indel"]),
@@ -236,8 +270,10 @@ def summary_text(tally, compare_label="compare", metrics=("GT", "BASEPAIR"), del
     lines = [delim.join(["compare_label", "comparison", "region_label", "filter", "variant_type", "truth_total", "truth_tp", "truth_fn", "query_total",
                          "query_tp", "query_fp", "metric_recall", "metric_precision", "metric_f1", "truth_fn_gt", "query_fp_gt"])]
 
+    state = {"tally": tally, "region": "ALL"}
+
     def group(g):
-        return [int(x) for x in tally[g * 22:(g + 1) * 22]]
+        return [int(x) for x in state["tally"][g * 22:(g + 1) * 22]]
 
     def row(kind, vtype, m, extra):
         ttot, qtot = m[0] + m[1], m[2] + m[3]
@@ -247,28 +283,31 @@ def summary_text(tally, compare_label="compare", metrics=("GT", "BASEPAIR"), del
             f1 = 2.0 * rec * pre / (rec + pre) if rec + pre != 0 else float("nan")
         else:
             f1 = None
-        cells = [compare_label, kind, "ALL", "ALL", vtype, ttot, m[0], m[1], qtot, m[2], m[3], "" if rec is None else ryu(rec), "" if pre is None else ryu(pre),
+        cells = [compare_label, kind, state["region"], "ALL", vtype, ttot, m[0], m[1], qtot, m[2], m[3], "" if rec is None else ryu(rec), "" if pre is None else ryu(pre),
                  "" if f1 is None else ryu(f1)] + (list(extra) if kind == "GT" else ["", ""])
         lines.append(delim.join(str(c) for c in cells))
 
-    for kind in metrics:
-        b = base[kind]
-        g0 = group(0)
-        row(kind, "ALL", g0[b:b + 4], g0[4:6])
-        for t, name in enumerate(types):
-            g = group(1 + t)
-            if sum(g[b:b + 4]) == 0:
-                continue
-            row(kind, name, g[b:b + 4], g[4:6])
-        for label, members in joints:
-            s, sx = [0, 0, 0, 0], [0, 0]
-            for name in members:
-                g = group(1 + VT[name])
-                s = [a + c for a, c in zip(s, g[b:b + 4])]
-                sx = [a + c for a, c in zip(sx, g[4:6])]
-            if sum(s) == 0:
-                continue
-            row(kind, label, s, sx)
+    blocks = [("ALL", tally)] + list(strat_blocks)
+    for region, block in blocks:
+        state["tally"], state["region"] = block, region
+        for kind in metrics:
+            b = base[kind]
+            g0 = group(0)
+            row(kind, "ALL", g0[b:b + 4], g0[4:6])
+            for t, name in enumerate(types):
+                g = group(1 + t)
+                if sum(g[b:b + 4]) == 0:
+                    continue
+                row(kind, name, g[b:b + 4], g[4:6])
+            for label, members in joints:
+                s, sx = [0, 0, 0, 0], [0, 0]
+                for name in members:
+                    g = group(1 + VT[name])
+                    s = [a + c for a, c in zip(s, g[b:b + 4])]
+                    sx = [a + c for a, c in zip(sx, g[4:6])]
+                if sum(s) == 0:
+                    continue
+                row(kind, label, s, sx)
     return "\n".join(lines) + "\n"
 
 

@@ -441,3 +441,93 @@ def test_command_line_tool_end_to_end(tmp_path, oracle):
         records = [l for l in gzip.open(out, "rt").read().splitlines() if not l.startswith("#")]
         assert records == fo.annotated_vcf_records(regions, source, res.status, res.var_expected, res.var_observed, res.var_class)
         assert tabix_fetch(out, "chr20", 700_000, 800_000) == [r for r in records if 700_000 < int(r.split("\t")[1]) + len(r.split("\t")[3]) - 1 and int(r.split("\t")[1]) - 1 < 800_000]
+
+
+# ------------------------------------------------------------------ stratifications: pinned by the reference's own test + fixture
+STRAT_TSV = os.path.join(ROOT, "tests", "golden", "example_stratification", "strat.tsv")
+
+
+def test_example_stratification_known_answers():
+    """src/parsing/stratifications.rs:214-243 (test_example_stratification) on the reference's fixture files
+    (test_data/example_stratification, copied to tests/golden/): the C++ library and the Python restatement"""
+    strat = feeder.Stratifications(STRAT_TSV)
+    ostrat = fo.load_stratifications(STRAT_TSV)
+    assert len(strat.labels) == 2 and strat.labels == [l for l, _ in ostrat] == ["example1", "example2"]
+    assert [strat.n_intervals(0, "mock"), strat.n_intervals(0, "mock2"), strat.n_intervals(1, "mock"), strat.n_intervals(1, "mock2")] == [2, 1, 2, 2]
+    for impl in (strat.containments, lambda c, a, b: fo.containments(ostrat, c, a, b)):
+        assert impl("mock", 9, 9) == []
+        assert impl("mock", 10, 10) == [0]
+        assert impl("mock", 14, 14) == [0]
+        assert impl("mock", 15, 15) == [0, 1]
+        assert impl("mock", 20, 20) == [1]
+        assert impl("mock", 25, 25) == [0]
+        assert impl("mock", 10, 19) == [0]
+        assert impl("mock", 15, 24) == [1]
+    for impl in (strat.overlaps, lambda c, a, b: fo.overlaps(ostrat, c, a, b)):
+        assert impl("mock", 10, 19) == [0, 1]
+        assert impl("mock", 15, 24) == [0, 1]
+    # every single-base and short range of the fixture: library == restatement
+    for chrom in ("mock", "mock2", "absent"):
+        for a in range(0, 40):
+            for b in range(a, min(a + 12, 40)):
+                assert strat.containments(chrom, a, b) == fo.containments(ostrat, chrom, a, b)
+                assert strat.overlaps(chrom, a, b) == fo.overlaps(ostrat, chrom, a, b)
+    strat.close()
+
+
+def test_stratified_summary_and_region_labels(tmp_path, oracle):
+    """per-label tallies = sums over the regions a label contains (summary.rs:146-163), written after the ALL block"""
+    p, contig, _ = write_case_files(tmp_path, 600, 300_000)
+    # three stratification BEDs over chr20: two overlapping halves and scattered small windows; labels sort as a, b, c
+    rng = np.random.default_rng(4)
+    beds = {"b_right": [(140_000, 300_000)], "a_left": [(0, 160_000)],
+            "c_windows": sorted((int(s), int(s) + int(w)) for s, w in zip(rng.integers(0, 299_000, 400), rng.integers(1, 900, 400)))}
+    for name, iv in beds.items():
+        write_text(str(tmp_path / (name + ".bed")), "".join("chr20\t%d\t%d\n" % x for x in iv))
+    write_text(str(tmp_path / "strat.tsv"), "".join("%s\t%s.bed\n" % (n, n) for n in beds))
+    strat = feeder.Stratifications(str(tmp_path / "strat.tsv"))
+    ostrat = fo.load_stratifications(str(tmp_path / "strat.tsv"))
+    assert strat.labels == ["a_left", "b_right", "c_windows"]
+    genome = feeder.Genome(p["fa"])
+    feed = feeder.feed_compare(p["t"], p["q"], p["bed"], genome, enable_trimming=False)
+    regions, _ = fo.generate_regions(fo.load_calls(p["t"], "", False), fo.load_calls(p["q"], "", False), fo.read_bed(p["bed"]), fo.read_fasta(p["fa"]))
+    res = oracle_lib.compare_batch(oracle, feed.batch, genome.contigs(), threads=4)
+    blocks = np.zeros((3, 288), np.uint64)
+    seen = set()
+    for r, reg in enumerate(regions):
+        labels = strat.region_labels(genome, feed.batch, r)
+        assert labels == fo.region_labels(ostrat, reg)
+        seen.update(labels)
+        for l in labels:
+            blocks[l, :286] += res.group_metrics[r].reshape(-1).astype(np.uint64)
+    assert seen == {0, 1, 2}
+    out = str(tmp_path / "summary.tsv")
+    feeder.write_summary_stratified(out, res.tally, strat, blocks, "strat", 31)
+    want = fo.summary_text(res.tally, "strat", ("GT", "BASEPAIR", "HAP", "WEIGHTED_HAP", "RECORD_BP"), strat_blocks=[(l, blocks[k]) for k, l in enumerate(strat.labels)])
+    text = open(out).read()
+    assert text == want
+    assert [l.split("\t")[2] for l in text.splitlines()[1:] if l.split("\t")[1] == "GT" and l.split("\t")[4] == "ALL"] == ["ALL", "a_left", "b_right", "c_windows"]
+
+
+@pytest.mark.gpu
+def test_command_line_tool_with_stratifications(tmp_path, oracle):
+    """--stratification: per-label blocks summed from the per-region metric blocks the GPU returns"""
+    import subprocess
+    p, contig, want_batch = write_case_files(tmp_path, 2500, 1_200_000)
+    beds = {"lowhalf": [(0, 600_000)], "highhalf": [(500_000, 1_200_000)], "tiles": [(k * 10_000, k * 10_000 + 4_000) for k in range(120)]}
+    for name, iv in beds.items():
+        write_text(str(tmp_path / (name + ".bed")), "".join("chr20\t%d\t%d\n" % x for x in iv))
+    write_text(str(tmp_path / "strat.tsv"), "".join("%s\t%s.bed\n" % (n, n) for n in beds))
+    r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"], "--disable-variant-trimming",
+                        "-s", str(tmp_path / "strat.tsv"), "--batch-regions", "900"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    ostrat = fo.load_stratifications(str(tmp_path / "strat.tsv"))
+    regions, _ = fo.generate_regions(fo.load_calls(p["t"], "", False), fo.load_calls(p["q"], "", False), fo.read_bed(p["bed"]), fo.read_fasta(p["fa"]))
+    res = oracle_lib.compare_batch(oracle, want_batch, [contig], threads=8)
+    blocks = np.zeros((3, 288), np.uint64)
+    for k, reg in enumerate(regions):
+        for l in fo.region_labels(ostrat, reg):
+            blocks[l, :286] += res.group_metrics[k].reshape(-1).astype(np.uint64)
+    want = fo.summary_text(res.tally, "compare", ("GT", "BASEPAIR"), strat_blocks=[(l, blocks[i]) for i, (l, _) in enumerate(ostrat)])
+    assert open(os.path.join(p["out"], "summary.tsv")).read() == want
+    assert blocks.sum() > 0
