@@ -1473,6 +1473,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     u32 present = wv_uni(reg.types); /* types seen by compare_expected_observed, plus the 8 filtered types' map entries */
     for (int s = 0; s < 8; ++s) present |= 1u << SUP[s];
     AVK_T_MARK(c, 3)
+    /* which of the 8 filtered types occur at all: one LDS read by 8 lanes instead of 8 dependent round trips per haplotype */
+    const u32 type_mask = (u32)wv_ballot(lane < 8 && c.counts[lane < 8 ? lane : 0] != 0) & 0xFFu;
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr &wp = hh == 0 ? w0 : w1;
         const HapHdr &hd = hh == 0 ? h0 : h1;
@@ -1501,9 +1503,9 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         wv_sync();
         if (lane < 4) c.gm[AVK_F_BP_TRUTH_TP + lane] += add[lane];
         wv_sync();
-        for (int s = 0; s < 8; ++s) {
+        for (u32 left = type_mask; left; left &= left - 1) { /* absent types contribute (0,0,0,0); their map entries exist via `present` */
+            const int s = avk_ctz64(left);
             const u32 tq = ld32u(c.counts + s), tcount_s = tq & 0xFFFFu, qcount_s = tq >> 16;
-            if (!tq) continue; /* contributes (0,0,0,0); the map entry exists via `present` */
             u32 q_tp = 0, q_fp = 0, t_tp = 0, t_fn = 0;
             if (qcount_s) {
                 if (qcount_s == c.Q) { /* filtered query == the full query haplotype */
