@@ -32,10 +32,12 @@ struct AvkDevRegion {
 };
 
 /* One variant inside a region blob (reference src/data_types/variants.rs:73-91), window-relative.
- * Blob layout (every section padded to 8 bytes):
+ * Blob layout (every section padded to 16 bytes):
  *   AvkBlobVar[N]   truth records then query records
  *   allele bytes    allele0 then allele1 of every variant, at a_off
- *   u32 order[N]    order_variants (query_optimizer.rs:372-381): stable sort by position of [truth.., query..]
+ *   AvkOrdVar[N]    the variants again in the order the searches walk them — order_variants (query_optimizer.rs:372-381):
+ *                   stable sort by position of [truth.., query..] — each with the position of the NEXT one (the sync
+ *                   point of the step): a pop reads one 32-byte record instead of chasing order -> variant -> next variant
  *   u32 counts[8]   for the 8 types add_basepair_stats filters by (waffle_solver.rs:383-440), in the order of
  *                   AVK_SUP_TYPES: truth count | query count << 16 */
 struct AvkBlobVar {
@@ -46,6 +48,12 @@ struct AvkBlobVar {
     uint32_t raw_space; /* raw_allele_space */
     uint32_t alt_ed;    /* Variant::alt_ed = wfa_ed(allele0, allele1) (variants.rs:413-415) */
     uint32_t type_zyg;  /* AVK_VT_* | AVK_ZYG_* << 8 */
+};
+
+struct AvkOrdVar {
+    uint32_t rel_pos, a0_len, a1_len, a_off, alt_ed, type_zyg;
+    uint32_t sync; /* rel_pos of the next variant in this order, or the window length for the last one */
+    uint32_t vi;   /* index into AvkBlobVar[] (vi < t_cnt: a truth variant) */
 };
 
 /* host-side view of a variant (planning, scatter maps); not uploaded */

@@ -142,7 +142,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             return AVK_E_ARG;
         }
         uint64_t bytes = 0;
-        if (N <= 60000) bytes = (((uint64_t)N * sizeof(AvkBlobVar) + 7) & ~7ull) + ((alle + 7) & ~7ull) + ((4ull * N + 7) & ~7ull) + 32;
+        if (N <= 60000) bytes = (((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull) + ((alle + 15) & ~15ull) + (uint64_t)N * sizeof(AvkOrdVar) + 32;
         if (bytes > 0x7FFFFFFFull) {
             *err = "region blob exceeds 2 GiB; split the region's alleles";
             return AVK_E_ARG;
@@ -232,11 +232,12 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             }
             /* the region's blob */
             const uint64_t alle = dr.alle_bytes;
-            const uint64_t vb = ((uint64_t)N * sizeof(AvkBlobVar) + 7) & ~7ull, ab = (alle + 7) & ~7ull, ob = (4ull * N + 7) & ~7ull;
+            const uint64_t vb = ((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull, ab = (alle + 15) & ~15ull, ob = (uint64_t)N * sizeof(AvkOrdVar);
             uint8_t *base = (uint8_t *)(out->blob.data() + blob_at[r]);
             AvkBlobVar *bv = (AvkBlobVar *)base;
             uint8_t *ba = base + vb;
-            uint32_t *bo = (uint32_t *)(base + vb + ab), *bc = (uint32_t *)(base + vb + ab + ob);
+            AvkOrdVar *bo = (AvkOrdVar *)(base + vb + ab);
+            uint32_t *bc = (uint32_t *)(base + vb + ab + ob);
             uint32_t run = 0;
             uint64_t ed_sum = 0;
             k = 0;
@@ -264,9 +265,18 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             {
                 uint32_t i = 0, j = tc, o = 0;
                 while (i < tc || j < N) {
-                    if (j >= N || (i < tc && hv[i].rel_pos <= hv[j].rel_pos)) bo[o++] = i++;
-                    else bo[o++] = j++;
+                    const uint32_t k2 = (j >= N || (i < tc && hv[i].rel_pos <= hv[j].rel_pos)) ? i++ : j++;
+                    AvkOrdVar &ov = bo[o++];
+                    ov.rel_pos = bv[k2].rel_pos;
+                    ov.a0_len = bv[k2].a0_len;
+                    ov.a1_len = bv[k2].a1_len;
+                    ov.a_off = bv[k2].a_off;
+                    ov.alt_ed = bv[k2].alt_ed;
+                    ov.type_zyg = bv[k2].type_zyg;
+                    ov.sync = dr.len;
+                    ov.vi = k2;
                 }
+                for (uint32_t o2 = 0; o2 + 1 < N; ++o2) bo[o2].sync = bo[o2 + 1].rel_pos;
             }
             for (int t = 0; t < 8; ++t) bc[t] = counts[t];
             dr.blob_off = (uint32_t)(blob_at[r] / 2);
@@ -331,7 +341,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         if (wfcap > 2 * seqcap + 4) wfcap = 2 * seqcap + 4;
         const uint64_t hapA = (48 + 16 * alw + 4 * wfcap + 2 * seqcap + 15) & ~15ull, nodeA = 16 + 2 * hapA;
         const uint64_t optcap = max_branch < 4096 ? max_branch : 4096;
-        const uint64_t fixed = dr.len + 8 + 28 * N + alle + 8 + 8 * N + 16 + 32 + 4 * optcap + 8 * 8 * alw + 8 * 4 * alw * 8 + 32 + 64;
+        const uint64_t fixed = dr.len + 8 + 28 * N + alle + 32 + 32 * N + 4 * N + 16 + 32 + 4 * optcap + 8 * 8 * alw + 8 * 4 * alw * 8 + 32 + 64;
         return fixed + nodes * (nodeA + 16);
     };
     for (uint64_t r = 0; r < n; ++r) {

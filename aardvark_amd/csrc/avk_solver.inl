@@ -109,7 +109,7 @@ struct Ctx {
     const u8 *ref; /* window bytes (workspace copy) */
     LVar *vars;    /* [N]: truth 0..T-1, query T..N-1 */
     u8 *alle;
-    u32 *order;    /* [N] processing order (query_optimizer.rs:372-381) */
+    const AvkOrdVar *ovars; /* [N] the variants in processing order (query_optimizer.rs:372-381), each with its sync point */
     u32 *counts;   /* [8] truth | query << 16 variants of each type of AVK_SUP_TYPES */
     u32 *bucket;   /* [N+1] */
     /* capacities */
@@ -178,6 +178,24 @@ template <int N> AVK_DEV void ldvec_u(const u32 *p, u32 (&out)[N]) {
     for (int k = 0; k < N; ++k) t[k] = p[k];
 #pragma unroll
     for (int k = 0; k < N; ++k) out[k] = wv_uni(t[k]);
+}
+/* one AvkOrdVar: two 16-byte LDS reads under one wait; also returns the step's sync point and the variant's index */
+AVK_DEV UVar load_ovar(const AvkOrdVar *ov, u32 depth, u32 &sync, u32 &vi) {
+    const avk_u4 *q = (const avk_u4 *)(ov + depth);
+    const avk_u4 a = q[0], b = q[1];
+    UVar v;
+    v.rel_pos = wv_uni(a.x);
+    v.a0_len = wv_uni(a.y);
+    v.a1_len = wv_uni(a.z);
+    v.a_off = wv_uni(a.w);
+    v.raw_space = 0;
+    v.alt_ed = wv_uni(b.x);
+    const u32 tz = wv_uni(b.y);
+    v.type = tz & 0xFF;
+    v.zyg = (tz >> 8) & 0xFF;
+    sync = wv_uni(b.z);
+    vi = wv_uni(b.w);
+    return v;
 }
 AVK_DEV UVar load_var(const LVar *vars, u32 i) {
     u32 w[7];
@@ -787,12 +805,10 @@ AVK_DEV int phaseA(Ctx &c) {
             continue;
         }
 
-        const u32 vi = ld32u(c.order + depth);
-        const UVar v = load_var(c.vars, vi);
+        u32 sync, vi; /* sync: position of the next variant, or the window end (:258-265) */
+        const UVar v = load_ovar(c.ovars, depth, sync, vi);
         const bool is_truth = vi < c.T;
         const u32 zyg = v.zyg;
-        u32 sync = c.L; /* :258-265 */
-        if (depth + 1 < c.N) sync = wv_uni(c.vars[ld32u(c.order + depth + 1)].rel_pos);
         const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
 
         if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
@@ -928,14 +944,12 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
             af_counts = 0;
             af_index = min_sync;
         }
-        const u32 vi = ld32u(c.order + depth);
-        const UVar v = load_var(c.vars, vi);
+        u32 sync, vi;
+        const UVar v = load_ovar(c.ovars, depth, sync, vi);
         const bool is_truth = vi < c.T;
         const u32 sub = is_truth ? vi : vi - c.T;
         const u64 *in = is_truth ? in_talt : in_qalt;
         const bool cur_alt = (wv_uni((u32)((in[sub >> 6] >> (sub & 63)) & 1))) != 0;
-        u32 sync = c.L;
-        if (depth + 1 < c.N) sync = wv_uni(c.vars[ld32u(c.order + depth + 1)].rel_pos);
         const u32 id = ld32u((const u32 *)n);
 
         if (!cur_alt) { /* :257-273 */
@@ -975,7 +989,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
                 queue_spill(c);
                 c.regq = false;
             }
-            const u32 fi = ld32u(c.order + af_index);
+            const u32 fi = ld32u(&c.ovars[af_index].vi);
             const bool f_truth = fi < c.T;
             const u32 fsub = f_truth ? fi : fi - c.T;
             const u32 lane = (u32)wv_lane();
@@ -1175,16 +1189,16 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     c.ws = ws;
     u64 off = 0;
     u8 *refbuf = ws + off;
-    off = AVK_ALIGN8(off + c.L);
-    /* the region blob lands here as it is: variant records | allele bytes | variant order | per-type counts
-     * (AvkBlobVar in avk_dev_types.h; every section padded to 8 bytes) */
+    off = AVK_ALIGN16(off + c.L);
+    /* the region blob lands here as it is: variant records | allele bytes | variants in search order | per-type counts
+     * (AvkBlobVar in avk_dev_types.h; every section padded to 16 bytes) */
     u32 *const blob_dst = (u32 *)(ws + off);
     c.vars = (LVar *)(ws + off);
-    off = AVK_ALIGN8(off + (u64)c.N * sizeof(LVar));
+    off = AVK_ALIGN16(off + (u64)c.N * sizeof(LVar));
     c.alle = ws + off;
-    off = AVK_ALIGN8(off + alle_bytes);
-    c.order = (u32 *)(ws + off);
-    off = AVK_ALIGN8(off + 4ull * c.N);
+    off = AVK_ALIGN16(off + alle_bytes);
+    c.ovars = (const AvkOrdVar *)(ws + off);
+    off += (u64)c.N * sizeof(AvkOrdVar);
     c.counts = (u32 *)(ws + off);
     off += 32;
     c.bucket = (u32 *)(ws + off);
