@@ -535,12 +535,33 @@ AVK_DEV bool hap_slide_d0(const HapPtr &p, HapHdr &h) { /* returns true when eit
     h.d0 = d;
     return d >= lim;
 }
+/* The step from distance 0 to distance 1, in registers.  The zero-distance front stopped at offset d with both sequences
+ * continuing; increase_edit_distance turns [d] into [d, d+1, d+1] (no clipping), i.e. the three diagonals start at
+ *   i = 0: O offset d,   B offset d+1      i = 1: O d+1, B d+1 (the substitution)      i = 2: O d+1, B d
+ * and each slides while the bases agree, 64 bases per step (the general lane-group code takes 16 per step for three
+ * diagonals and keeps the front in LDS).  Leaves the front in
+ * wf[0..2] and returns whether an end is touched (update's stopping rule, dynamic_wfa.rs:68-84). */
+AVK_DEV bool hap_raise_to_one(const HapPtr &p, const HapHdr &h) {
+    const u32 lane = (u32)wv_lane();
+    const u32 d = h.d0, bl = h.t_len, ol = h.q_len;
+    /* seq_match_run stops at the first difference or at either end; starts past an end give 0 */
+    const u32 n0 = seq_match_run(p.tseq, bl, d + 1, p.qseq, ol, d);
+    const u32 n1 = seq_match_run(p.tseq, bl, d + 1, p.qseq, ol, d + 1);
+    const u32 n2 = seq_match_run(p.tseq, bl, d, p.qseq, ol, d + 1);
+    const u32 o0 = d + n0, o1 = d + 1 + n1, o2 = d + 1 + n2;
+    wv_sync();
+    if (lane < 3) p.wf[lane] = lane == 0 ? o0 : (lane == 1 ? o1 : o2);
+    wv_sync();
+    /* reached_baseline_end || reached_other_end at distance 1: the offset in B is wf[i] + 1 - i */
+    return o0 + 1 >= bl || o0 >= ol || o1 >= bl || o1 >= ol || o2 - 1 >= bl || o2 >= ol;
+}
 AVK_DEV int hap_update(const HapPtr &p, u32 wfcap, HapHdr &h) {
     if (h.ed == 0) {
         if (hap_slide_d0(p, h)) return 0;
-        wv_sync();
-        st32(p.wf, h.d0);
-        wv_sync();
+        if (wfcap < 3) return RS_OVERFLOW; /* 2 * ed + 3 > cap at ed 0 */
+        const bool touched = hap_raise_to_one(p, h);
+        h.ed = 1;
+        if (touched) return 0;
     }
     return dw_update(p.wf, wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len);
 }
@@ -697,12 +718,16 @@ AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
 
 /* ComparisonNode::extend_variant (:443-451) = both haplotypes + their DWFA updates */
 AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
+    AVK_TA_DECL
     u8 *n = node_at(c, idx);
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr p = hap_ptr(n + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
+        AVK_TA_MARK(const_cast<Ctx &>(c), 12)
         hap_extend_seq(c, p, h, is_truth, true, v, hh == 0 ? a1 : a2, sync);
+        AVK_TA_MARK(const_cast<Ctx &>(c), 14)
         if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
+        AVK_TA_MARK(const_cast<Ctx &>(c), 15)
         wv_sync();
         hap_store(p.w, h);
         wv_sync();
@@ -1871,7 +1896,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             for (int k = 0; k < 6; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
             avk_atomic_add_u64_global(pc + 6, avk_clock() - t_region0);
             avk_atomic_add_u64_global(pc + 7, 1);
-            for (int k = 8; k < 14; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
+            for (int k = 8; k < 16; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
         }
 #endif
     }

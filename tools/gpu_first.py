@@ -53,5 +53,5 @@ pc = ctx.debug_phase_cycles()
 if pc[7]:
     names = ["stage", "searchA", "searchB", "metrics_setup", "basepair", "record", "region_total"]
     print("phase ticks per region:", {n: round(pc[i] / pc[7], 1) for i, n in enumerate(names)}, "regions", pc[7])
-    sub = ["A_setup", "A_pop", "A_finalise", "A_clone", "A_extend", "A_push"]
+    sub = ["A_setup", "A_pop", "A_finalise", "A_clone", "A_extend(load+store)", "A_push", "ext_copy", "ext_update"]
     print("inside search A:", {n: round(pc[8 + i] / pc[7], 1) for i, n in enumerate(sub)})
