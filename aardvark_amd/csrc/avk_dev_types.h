@@ -17,15 +17,17 @@ struct AvkDevRegion {
     uint32_t v_off;      /* first per-variant output word; the region owns t_cnt + q_cnt of them, truth first */
     uint32_t t_cnt;
     uint32_t q_cnt;
-    uint32_t pre_status; /* host validation: 0, AVK_ST_INVALID_INPUT / AVK_ST_BAD_ZYGOSITY, or AVK_PRE_SKIP_OK (pairs mode:
-                            answered on the host, report status 0 / not exact) */
+    uint32_t pre_status; /* low 16 bits: host validation: 0, AVK_ST_INVALID_INPUT / AVK_ST_BAD_ZYGOSITY, or AVK_PRE_SKIP_OK (pairs
+                            mode: answered on the host, report status 0 / not exact); high 16 bits: bit t set = a variant of
+                            type t (AVK_VT_*) is present */
     uint32_t seq_stride; /* bytes per output sequence slot (0 = no sequence output) */
     uint64_t seq_off;    /* offset of the region's 5 slots in the sequence output */
     uint32_t blob_off;   /* the region's blob starts at 8 * blob_off bytes of the blob arena */
     uint32_t blob_bytes; /* multiple of 8 */
     uint32_t alle_bytes; /* bytes of the allele section of the blob (before padding) */
     uint32_t grow;       /* max over the two sides of sum(max(0, a1_len - a0_len)): bound of a haplotype's growth */
-    uint32_t types;      /* bit t set: a variant of type t (AVK_VT_*) is present */
+    uint32_t orig;       /* the region's index in the caller's batch: the records are uploaded in WORK ORDER (plan_work_order),
+                            so a wave gets its record straight from its work index; outputs are written at `orig` */
     uint32_t ed_bound;   /* sum of alt_ed over the region's variants: no wavefront of the region can pass this distance
                             (every haplotype is within its side's sum of the reference window), so the LDS tiers size
                             their wavefronts by min(tier cap, ed_bound) */
@@ -97,7 +99,9 @@ struct AvkKernelArgs {
     uint32_t pad0_;
     uint32_t pass_tier;  /* workspace tier of this launch: 0 small LDS slice, 1 large LDS slice, 2 per-wave HBM slice, 3 big HBM slice */
     /* work distribution */
-    const uint32_t *work_list; /* NULL = regions 0..n_regions-1; else indices (overflow pass) */
+    const uint32_t *work_list; /* NULL = records work_base .. work_base + n_work - 1; else record indices (overflow pass) */
+    uint32_t work_base;
+    uint32_t pad2_;
     const uint32_t *n_work_dev; /* when set, the number of work items is read from device memory (overflow pass) */
     uint32_t *work_counter;    /* 8 claim counters, 32 words (128 B) apart, one per shard of the dynamic part of the work list */
     uint32_t n_waves;          /* persistent waves of this launch (solo waves not counted) */

@@ -168,7 +168,6 @@ struct avk_dev_batch {
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
-    uint32_t *d_order = nullptr; /* work order of the first launch: [predicted-hard regions | the rest], most variants first */
     avk::WorkPlan plan;
     bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
@@ -207,7 +206,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 
 void free_batch_buffers(avk_dev_batch *db) {
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_order};
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -461,7 +460,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     if (pairs_mode) { /* solve_merge_region's pre-checks (merge_solver.rs:119-147, :211-223) */
         for (uint64_t r = 0; r < n; ++r) {
             AvkDevRegion &dr = db->host.regions[r];
-            if (dr.pre_status == AVK_ST_INVALID_INPUT) continue;
+            if ((dr.pre_status & 0xFFFFu) == AVK_ST_INVALID_INPUT) continue;
             if (db->host.zyg_flags[r] & 1) dr.pre_status = AVK_ST_BAD_ZYGOSITY;                           /* Unknown: delta computation bails */
             else if (db->host.delta_t[r] != db->host.delta_q[r]) dr.pre_status = AVK_PRE_SKIP_OK;        /* different net length: not exact, optimizer not run */
             else if (db->host.zyg_flags[r] & 2) dr.pre_status = AVK_ST_BAD_ZYGOSITY;                      /* optimizer would hit assert_eq! */
@@ -488,7 +487,6 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1024));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
-    AVK_TRY(dev_alloc(ctx, &db->d_order, n + 1));
 #undef AVK_TRY
     /* work order: the regions predicted to outgrow the small LDS slice first (solo waves take them), then the
      * rest; within each part the regions with the most variants (the expensive searches) are dealt first, so
@@ -499,8 +497,9 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
-    if (n) e = hipMemcpyAsync(db->d_order, order.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess && n) e = hipMemcpyAsync(db->d_regions, db->host.regions.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
+    /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
+    const std::vector<AvkDevRegion> sorted = avk::regions_in_work_order(db->host, order);
+    if (n) e = hipMemcpyAsync(db->d_regions, sorted.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_blob, db->host.blob.data(), db->host.blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -620,7 +619,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         if (launch[t]) last = t;
     if (last < 0) return fail(ctx, AVK_E_ARG, "every workspace tier is disabled");
     const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(ctx->big_waves < 128 ? ctx->big_waves : 128) : 0u;
-    const uint32_t *list = db->d_order, *count = nullptr;
+    const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
     int nlist = 0;
     bool solo_pending = false, hbm_solo_pending = false;
@@ -628,6 +627,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
         a.work_list = list;
+        a.work_base = 0;
         a.n_work_dev = count;
         a.work_counter = db->d_counters + 256 * t;
         if (t != last) {
@@ -637,7 +637,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.overflow_list = nullptr;
             a.overflow_count = nullptr;
         }
-        const bool first_launch = list == db->d_order; /* ev0 sits right before it */
+        const bool first_launch = list == nullptr; /* ev0 sits right before it */
         if (t >= 2) { /* the HBM launches read the list the solo launches append to and share the HBM slices; the tier-1 launch does not */
             if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
@@ -663,7 +663,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             const bool solo_ok = ctx->solo_blocks_max && blocks >= 8;
             const bool hbm_solo_ok = solo_ok && launch[2] && db->plan.n_hbm;
             const uint32_t n_c = hbm_solo_ok ? db->plan.n_hbm : 0u;          /* regions of the HBM solo launch */
-            const uint32_t n_front = db->plan.n_hbm + db->plan.n_hard - n_c; /* predicted-hard regions after them in d_order */
+            const uint32_t n_front = db->plan.n_hbm + db->plan.n_hard - n_c; /* predicted-hard records after them */
             uint32_t solo = 0, solo_regions = 0, hbm_solo = 0;
             if (solo_ok && use[1] && n_front &&
                 (size_t)ctx->lds2_bytes_per_wave <= 2 * (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave) {
@@ -683,7 +683,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (hbm_solo) {
                 AvkKernelArgs s = a;
                 s.pass_tier = 2;
-                s.work_list = db->d_order;
+                s.work_base = 0;
                 s.n_work = n_c;
                 s.work_counter = db->d_counters + 1076;
                 s.static_pct = 0;
@@ -710,7 +710,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (solo) {
                 AvkKernelArgs s = a;
                 s.pass_tier = 1;
-                s.work_list = db->d_order + n_c;
+                s.work_base = n_c;
                 s.n_work = solo_regions;
                 s.work_counter = db->d_counters + 1072;
                 s.static_pct = 0;
@@ -727,7 +727,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 solo_pending = true;
             }
             if (solo || hbm_solo) {
-                a.work_list = db->d_order + n_c + solo_regions;
+                a.work_base = n_c + solo_regions;
                 a.n_work = (uint32_t)n - n_c - solo_regions;
             }
             /* every workgroup of the three launches is resident at once */

@@ -281,7 +281,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             for (int t = 0; t < 8; ++t) bc[t] = counts[t];
             dr.blob_off = (uint32_t)(blob_at[r] / 2);
             dr.grow = (uint32_t)(g[0] > g[1] ? g[0] : g[1]);
-            dr.types = types;
+            dr.pre_status |= types << 16;
             dr.ed_bound = (uint32_t)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
         }
         return 0;
@@ -320,6 +320,16 @@ inline uint64_t bulk_slice_bytes(uint64_t lds_bytes_per_wave) {
     return ((4 * lds_bytes_per_wave - AVK_WG_TAIL_BYTES) / 4) & ~15ull;
 }
 
+/* the region records in work order, each remembering where it came from */
+inline std::vector<AvkDevRegion> regions_in_work_order(const PackedBatch &pb, const std::vector<uint32_t> &order) {
+    std::vector<AvkDevRegion> out(order.size());
+    for (size_t k = 0; k < order.size(); ++k) {
+        out[k] = pb.regions[order[k]];
+        out[k].orig = order[k];
+    }
+    return out;
+}
+
 struct WorkPlan {
     uint32_t n_hbm = 0;  /* class C */
     uint32_t n_hard = 0; /* class B */
@@ -347,7 +357,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
     for (uint64_t r = 0; r < n; ++r) {
         const AvkDevRegion &dr = pb.regions[r];
         const uint64_t N = (uint64_t)dr.t_cnt + dr.q_cnt;
-        if (dr.pre_status || N == 0 || solo_min_variants == 0) continue;
+        if ((dr.pre_status & 0xFFFFu) || N == 0 || solo_min_variants == 0) continue;
         const uint64_t alle = dr.alle_bytes, grow = dr.grow;
         if (tier1_bytes && need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes) {
             cls[r] = 0;

@@ -1509,7 +1509,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     /* add_basepair_stats (:335-449).  The optimizer's own sequences are the regenerated ones
      * (asserted equal at :364-367), ed(truth,query) is the node's finalized DWFA distance. */
     const int SUP[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL, AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
-    u32 present = wv_uni(reg.types); /* types seen by compare_expected_observed, plus the 8 filtered types' map entries */
+    u32 present = wv_uni(reg.pre_status) >> 16; /* types seen by compare_expected_observed, plus the 8 filtered types' map entries */
     for (int s = 0; s < 8; ++s) present |= 1u << SUP[s];
     AVK_T_MARK(c, 3)
     /* which of the 8 filtered types occur at all: one LDS read by 8 lanes instead of 8 dependent round trips per haplotype */
@@ -1641,9 +1641,11 @@ AVK_DEV void write_region_record(const AvkKernelArgs &a, u32 r, int status, u32 
     }
 }
 
-AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 r, int status) {
-    const AvkDevRegion reg = a.regions[r];
+/* rec = index of the region's record (work order); the outputs sit at the region's place in the caller's batch */
+AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 rec, int status) {
+    const AvkDevRegion reg = a.regions[rec];
     const u32 lane = (u32)wv_lane();
+    const u32 r = wv_uni(reg.orig);
     write_region_record(a, r, status, 0, 0, 0, 0);
     const u32 n = reg.t_cnt + reg.q_cnt;
     for (u32 k = lane; k < n; k += 64) a.var_out[reg.v_off + k] = 0;
@@ -1772,9 +1774,10 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             claim_base += 1;
             claim_left -= 1;
         }
-        const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : idx;
+        const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : a.work_base + idx; /* index of the RECORD (work order) */
         const AvkDevRegion reg = a.regions[r];
-        const u32 pre = wv_uni(reg.pre_status);
+        const u32 orig = wv_uni(reg.orig); /* where the caller's batch has this region: outputs go there */
+        const u32 pre = wv_uni(reg.pre_status) & 0xFFFFu;
         if (pre) {
             write_failed_region(a, r, pre == AVK_PRE_SKIP_OK ? 0 : (int)pre);
             n_err += pre == AVK_PRE_SKIP_OK ? 0u : 1u;
@@ -1856,13 +1859,13 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             continue;
         }
         /* results of an Ok region */
-        write_region_record(a, r, 0, out.ed1, out.ed2, out.n_opt, out.present);
+        write_region_record(a, orig, 0, out.ed1, out.ed2, out.n_opt, out.present);
         n_ok += 1;
         if (a.mode == 1) {
             AVK_RELEASE_SLOT()
             continue;
         }
-        if (a.group_metrics) copy_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
+        if (a.group_metrics) copy_words(a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
         { /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters (a handful of
            * the 286) are added to the workgroup's tally in LDS, or — launches without a tail — straight to a partial tally */
             u64 *part_r = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
@@ -1885,7 +1888,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             for (int k = 0; k < 5; ++k) {
                 const u32 nbytes = len[k] < reg.seq_stride ? len[k] : reg.seq_stride;
                 copy_bytes(a.seq_bytes + reg.seq_off + (u64)k * reg.seq_stride, src[k], nbytes);
-                if (lane == 0) a.seq_len[5 * (u64)r + k] = nbytes;
+                if (lane == 0) a.seq_len[5 * (u64)orig + k] = nbytes;
             }
         }
         wv_sync();

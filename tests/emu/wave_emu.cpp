@@ -229,7 +229,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     if (mode == 1) { /* the pre-checks of avk_optimize_pairs_batch (aardvark_amd/csrc/avk_host.hip) */
         for (uint64_t r = 0; r < batch->n_regions; ++r) {
             AvkDevRegion &dr = pb.regions[r];
-            if (dr.pre_status == AVK_ST_INVALID_INPUT) continue;
+            if ((dr.pre_status & 0xFFFFu) == AVK_ST_INVALID_INPUT) continue;
             if (pb.zyg_flags[r] & 1) dr.pre_status = AVK_ST_BAD_ZYGOSITY;
             else if (pb.delta_t[r] != pb.delta_q[r]) dr.pre_status = AVK_PRE_SKIP_OK;
             else if (pb.zyg_flags[r] & 2) dr.pre_status = AVK_ST_BAD_ZYGOSITY;
@@ -253,7 +253,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
 
     if (cfg->max_branch_factor == 0) { /* query_optimizer.rs:177 */
         for (uint64_t r = 0; r < n; ++r)
-            if (!pb.regions[r].pre_status) pb.regions[r].pre_status = AVK_ST_BRANCH_FACTOR;
+            if (!(pb.regions[r].pre_status & 0xFFFFu)) pb.regions[r].pre_status = AVK_ST_BRANCH_FACTOR;
     }
 
     /* solo_waves extra waves run before the others with the tier-1 slice size (the first solo_blocks workgroups of the launch) */
@@ -329,13 +329,16 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
     const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
-    const uint32_t *list = order.data(), *count = nullptr;
+    const std::vector<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
+    a.regions = sorted.data();
+    const uint32_t *list = nullptr, *count = nullptr;
     int nlist = 0;
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
         a.big_slots = 0;
         a.work_list = list;
+        a.work_base = 0;
         a.n_work_dev = count;
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
@@ -364,7 +367,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 if (n_c) {
                     AvkKernelArgs keep = a;
                     a.pass_tier = 2;
-                    a.work_list = order.data();
+                    a.work_base = 0;
                     a.n_work = n_c;
                     a.work_counter = counters + 1076;
                     a.static_pct = 0;
@@ -389,7 +392,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     if (solo > n_front) solo = n_front;
                     a_solo = a;
                     a_solo.pass_tier = 1;
-                    a_solo.work_list = order.data() + n_c;
+                    a_solo.work_base = n_c;
                     a_solo.n_work = solo;
                     a_solo.work_counter = counters + 1072;
                     a_solo.static_pct = 0;
@@ -400,7 +403,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     a_solo.overflow_list = later ? lists[solo_list].data() : nullptr;
                     a_solo.overflow_count = later ? counters + 1024 + 16 * solo_list : nullptr;
                 }
-                a.work_list = order.data() + n_c + solo;
+                a.work_base = n_c + solo;
                 a.n_work = (uint32_t)n - n_c - solo;
                 if (lds_bytes >= 1024) {
                     a.tier[0].ws_bytes = avk::bulk_slice_bytes(lds_bytes);
