@@ -717,10 +717,21 @@ AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
 }
 
 /* ComparisonNode::extend_variant (:443-451) = both haplotypes + their DWFA updates */
+/* Node word 1 of a phasing-search node: 1 while its two haplotype records are identical (the root, and every node reached from
+ * it by giving both haplotypes the same allele).  Extending identical records with the same allele gives identical records, so
+ * the second one is copied instead of computed; and the (ALT|REF) clone of a symmetric parent is the (REF|ALT) clone with its
+ * records swapped.  Pure reuse of results: ids, costs and pop order are untouched. */
+AVK_DEV void hap_record_copy(const Ctx &c, u8 *dst, const u8 *src) {
+    wv_sync();
+    copy_words((u32 *)dst, (const u32 *)src, c.hapA_bytes >> 2);
+    wv_sync();
+}
 AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
     AVK_TA_DECL
     u8 *n = node_at(c, idx);
-    for (int hh = 0; hh < 2; ++hh) {
+    const bool sym = ld32u((const u32 *)n + 1) != 0;
+    const bool twin = sym && a1 == a2; /* the second record will equal the first */
+    for (int hh = 0; hh < (twin ? 1 : 2); ++hh) {
         const HapPtr p = hap_ptr(n + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
         AVK_TA_MARK(const_cast<Ctx &>(c), 12)
@@ -732,7 +743,21 @@ AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u3
         hap_store(p.w, h);
         wv_sync();
     }
+    if (twin) hap_record_copy(c, n + NODE_HDR + c.hapA_bytes, n + NODE_HDR);
+    else if (sym) {
+        st32((u32 *)n + 1, 0);
+        wv_sync();
+    }
     return 0;
+}
+/* node `idx` := node `from` with its two haplotype records swapped (and no longer symmetric) */
+AVK_DEV void nodeA_mirror(const Ctx &c, u32 idx, u32 from) {
+    u8 *n = node_at(c, idx);
+    const u8 *f = node_at(c, from);
+    hap_record_copy(c, n + NODE_HDR, f + NODE_HDR + c.hapA_bytes);
+    hap_record_copy(c, n + NODE_HDR + c.hapA_bytes, f + NODE_HDR);
+    st32((u32 *)n + 1, 0);
+    wv_sync();
 }
 
 /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
@@ -740,7 +765,8 @@ AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
     u8 *n = node_at(c, idx);
     UVar none;
     none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
-    for (int hh = 0; hh < 2; ++hh) {
+    const bool twin = ld32u((const u32 *)n + 1) != 0; /* identical haplotype records: finalise one, copy it (nodeA_extend) */
+    for (int hh = 0; hh < (twin ? 1 : 2); ++hh) {
         const HapPtr p = hap_ptr(n + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
         hap_extend_seq(c, p, h, true, false, none, AL_REF, c.L); /* both sides to the region end */
@@ -750,6 +776,7 @@ AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
         hap_store(p.w, h);
         wv_sync();
     }
+    if (twin) hap_record_copy(c, n + NODE_HDR + c.hapA_bytes, n + NODE_HDR);
     return 0;
 }
 
@@ -776,7 +803,7 @@ AVK_DEV int phaseA(Ctx &c) {
     {
         u8 *n = node_at(c, (u32)root);
         st32((u32 *)n, 0);
-        st32((u32 *)n + 1, 0);
+        st32((u32 *)n + 1, 1); /* the two haplotypes of the root are identical (nodeA_extend) */
         hap_init(hap_ptr(n + NODE_HDR, c.alw, c.wfcap, c.seqcap), c.alw);
         hap_init(hap_ptr(n + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap), c.alw);
     }
@@ -848,10 +875,12 @@ AVK_DEV int phaseA(Ctx &c) {
             if (queue_push(c, ((u64)nodeA_cost(c, (u32)c1) << 32) | next_id, (u32)c1)) return RS_OVERFLOW;
             next_id += 1;
             /* the popped node itself becomes the second clone */
+            const bool parent_sym = ld32u((const u32 *)node_at(c, ni) + 1) != 0;
             st32((u32 *)node_at(c, ni), next_id);
             wv_sync();
             AVK_TA_MARK(c, 13)
-            if (nodeA_extend(c, ni, is_truth, v, AL_ALT, AL_REF, sync)) return RS_OVERFLOW;
+            if (parent_sym) nodeA_mirror(c, ni, (u32)c1); /* (ALT|REF) of identical haplotypes = (REF|ALT) swapped */
+            else if (nodeA_extend(c, ni, is_truth, v, AL_ALT, AL_REF, sync)) return RS_OVERFLOW;
             AVK_TA_MARK(c, 12)
             if (queue_push(c, ((u64)nodeA_cost(c, ni) << 32) | next_id, ni)) return RS_OVERFLOW;
             next_id += 1;
