@@ -40,6 +40,8 @@ def load_library():
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.avk_version.restype = C.c_char_p
+    lib.avk_merge_classify.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                       vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
     lib.avk_edit_distance.restype = C.c_uint64
     lib.avk_edit_distance.argtypes = [C.c_char_p, C.c_uint64, C.c_char_p, C.c_uint64]
     lib.avk_last_error.restype = C.c_char_p

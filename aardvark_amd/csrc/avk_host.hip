@@ -919,4 +919,123 @@ int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32
     return rc;
 }
 
+/* solve_merge_region's classification (merge_solver.rs:149-199) on top of the pair matrix */
+int avk_merge_classify(uint64_t n_regions, uint32_t k, const uint32_t *in_cnt, const uint8_t *has_unknown_zyg, const int32_t *pair_status,
+                       const uint8_t *pair_exact, const avk_merge_config *cfg, int32_t *status, uint8_t *classification, uint64_t *members) {
+    if (!in_cnt || !cfg || !status || !classification || !members || (n_regions && (!pair_status || !pair_exact))) return AVK_E_ARG;
+    if (k < 1 || k > 64) return AVK_E_ARG;
+    const uint64_t ppr = (uint64_t)k * (k - 1) / 2;
+    for (uint64_t m = 0; m < n_regions; ++m) {
+        status[m] = 0;
+        classification[m] = AVK_MERGE_DIFFERENT;
+        members[m] = 0;
+        if (has_unknown_zyg && has_unknown_zyg[m]) { /* variant_delta_length bails on an Unknown zygosity before anything else */
+            status[m] = AVK_ST_BAD_ZYGOSITY;
+            continue;
+        }
+        const uint32_t *cnt = in_cnt + m * k;
+        bool all_identical = true, no_conflict = true;
+        uint64_t match[64];
+        for (uint32_t i = 0; i < k; ++i) match[i] = 1ull << i;
+        uint64_t p = m * ppr;
+        int32_t err = 0;
+        for (uint32_t i = 0; i < k && !err; ++i)
+            for (uint32_t j = i + 1; j < k; ++j, ++p) {
+                if (pair_status[p] != 0) {
+                    err = pair_status[p];
+                    break;
+                }
+                const bool ex = pair_exact[p] != 0;
+                all_identical = all_identical && ex;
+                no_conflict = no_conflict && (cnt[i] == 0 || cnt[j] == 0 || ex); /* :160-164 */
+                if (ex) {
+                    match[i] |= 1ull << j;
+                    match[j] |= 1ull << i;
+                }
+            }
+        if (err) {
+            status[m] = err;
+            continue;
+        }
+        const uint32_t majority = k / 2 + 1;
+        uint64_t first_majority = 0;
+        for (uint32_t i = 0; i < k && !first_majority; ++i)
+            if ((uint32_t)__builtin_popcountll(match[i]) >= majority) first_majority = match[i];
+        if (all_identical) classification[m] = AVK_MERGE_IDENTICAL;
+        else if (cfg->no_conflict_enabled && no_conflict) {
+            classification[m] = AVK_MERGE_NO_CONFLICT;
+            for (uint32_t i = 0; i < k; ++i)
+                if (cnt[i]) members[m] |= 1ull << i;
+        } else if (cfg->majority_voting_enabled && first_majority) {
+            classification[m] = AVK_MERGE_MAJORITY_AGREE;
+            members[m] = first_majority;
+        } else if (cfg->conflict_selection >= 0) {
+            classification[m] = AVK_MERGE_CONFLICT_SELECTION;
+            members[m] = (uint64_t)cfg->conflict_selection;
+        }
+    }
+    return 0;
+}
+
+int avk_merge_batch(avk_ctx *ctx, const avk_multi_batch *mb, const avk_merge_config *cfg, int32_t *status, uint8_t *classification, uint64_t *members) {
+    if (!ctx || !mb || !cfg || !status || !classification || !members) return AVK_E_ARG;
+    const uint32_t k = mb->n_inputs;
+    if (k < 1 || k > 64) return fail(ctx, AVK_E_ARG, "n_inputs must be in [1, 64]");
+    const uint64_t n = mb->n_regions, ppr = (uint64_t)k * (k - 1) / 2, np = n * ppr;
+    /* one CompareRegion-shaped item per (i < j) pair: input i plays the truth side, input j the query side */
+    std::vector<uint64_t> rid(np), st(np), en(np), t_off(np), q_off(np);
+    std::vector<uint32_t> cidx(np), t_cnt(np), q_cnt(np);
+    std::vector<uint8_t> unknown(n, 0);
+    uint64_t p = 0;
+    for (uint64_t m = 0; m < n; ++m) {
+        for (uint32_t i = 0; i < k; ++i) {
+            const uint64_t off = mb->in_off[m * k + i];
+            const uint32_t cnt = mb->in_cnt[m * k + i];
+            if (off > mb->n_variants || cnt > mb->n_variants - off) return fail(ctx, AVK_E_ARG, "variant range of a region exceeds n_variants");
+            for (uint32_t v = 0; v < cnt; ++v)
+                if (mb->var_zyg[off + v] == AVK_ZYG_UNKNOWN) unknown[m] = 1;
+        }
+        for (uint32_t i = 0; i < k; ++i)
+            for (uint32_t j = i + 1; j < k; ++j, ++p) {
+                rid[p] = mb->region_id ? mb->region_id[m] : m;
+                cidx[p] = mb->contig_idx ? mb->contig_idx[m] : 0;
+                st[p] = mb->start[m];
+                en[p] = mb->end[m];
+                t_off[p] = mb->in_off[m * k + i];
+                t_cnt[p] = mb->in_cnt[m * k + i];
+                q_off[p] = mb->in_off[m * k + j];
+                q_cnt[p] = mb->in_cnt[m * k + j];
+            }
+    }
+    avk_region_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_regions = np;
+    b.region_id = rid.data();
+    b.contig_idx = cidx.data();
+    b.start = st.data();
+    b.end = en.data();
+    b.t_off = t_off.data();
+    b.t_cnt = t_cnt.data();
+    b.q_off = q_off.data();
+    b.q_cnt = q_cnt.data();
+    b.n_variants = mb->n_variants;
+    b.var_pos = mb->var_pos;
+    b.var_type = mb->var_type;
+    b.var_zyg = mb->var_zyg;
+    b.var_raw_space = mb->var_raw_space;
+    b.a0_off = mb->a0_off;
+    b.a0_len = mb->a0_len;
+    b.a1_off = mb->a1_off;
+    b.a1_len = mb->a1_len;
+    b.allele_bytes = mb->allele_bytes;
+    b.allele_bytes_len = mb->allele_bytes_len;
+    std::vector<int32_t> pst(np ? np : 1, 0);
+    std::vector<uint8_t> pex(np ? np : 1, 0);
+    if (np) {
+        const int rc = avk_optimize_pairs_batch(ctx, &b, cfg->max_branch_factor, pst.data(), pex.data());
+        if (rc) return rc;
+    }
+    return avk_merge_classify(n, k, mb->in_cnt, unknown.data(), pst.data(), pex.data(), cfg, status, classification, members);
+}
+
 } /* extern "C" */

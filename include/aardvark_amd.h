@@ -226,6 +226,48 @@ int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]);
 int  avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32_t max_branch_factor,
                               int32_t *status, uint8_t *is_exact_match);
 
+/* solve_merge_region (src/merge_solver.rs:110-200) for regions with k inputs each.  The expensive part is the all-pairs
+ * exact-match test above; the classification on top of the pair matrix is host logic:
+ *   MergeClassification (src/data_types/merge_benchmark.rs:5-14) -> AVK_MERGE_*; `members` = bit i set for the input indices
+ *   of NoConflict / MajorityAgree, or the selected index itself for ConflictSelection. */
+enum {
+    AVK_MERGE_DIFFERENT = 0, AVK_MERGE_IDENTICAL = 1, AVK_MERGE_NO_CONFLICT = 2, AVK_MERGE_MAJORITY_AGREE = 3,
+    AVK_MERGE_CONFLICT_SELECTION = 4
+};
+typedef struct avk_merge_config { /* MergeConfig (src/merge_solver.rs:62-84) */
+    uint32_t max_branch_factor;      /* default 50 */
+    uint32_t no_conflict_enabled;
+    uint32_t majority_voting_enabled;
+    int32_t  conflict_selection;     /* -1 = None */
+} avk_merge_config;
+/* A batch of MultiRegions (src/data_types/multi_region.rs): region m, input i owns variants
+ * [in_off[m*k + i], +in_cnt[m*k + i]) of the variant arrays (same meaning as in avk_region_batch). */
+typedef struct avk_multi_batch {
+    uint64_t n_regions;
+    uint32_t n_inputs;               /* k, 2..64 */
+    const uint64_t *region_id;
+    const uint32_t *contig_idx;
+    const uint64_t *start, *end;
+    const uint64_t *in_off;          /* [n_regions * k] */
+    const uint32_t *in_cnt;          /* [n_regions * k] */
+    uint64_t n_variants;
+    const uint64_t *var_pos;
+    const uint8_t  *var_type, *var_zyg;
+    const uint32_t *var_raw_space;
+    const uint64_t *a0_off; const uint32_t *a0_len;
+    const uint64_t *a1_off; const uint32_t *a1_len;
+    const uint8_t  *allele_bytes; uint64_t allele_bytes_len;
+} avk_multi_batch;
+/* Host only (no GPU): classification from the pair results.  The pairs of region m are the k(k-1)/2 pairs (i < j) in
+ * lexicographic order starting at m * k(k-1)/2; has_unknown_zyg[m] != 0 = some variant of the region has an Unknown zygosity
+ * (variant_delta_length bails first, :119-124 -> status AVK_ST_BAD_ZYGOSITY). */
+int avk_merge_classify(uint64_t n_regions, uint32_t n_inputs, const uint32_t *in_cnt, const uint8_t *has_unknown_zyg,
+                       const int32_t *pair_status, const uint8_t *pair_exact, const avk_merge_config *cfg,
+                       int32_t *status, uint8_t *classification, uint64_t *members);
+/* All of solve_merge_region for a batch: pairs on the GPU, classification on the host. */
+int avk_merge_batch(avk_ctx *ctx, const avk_multi_batch *batch, const avk_merge_config *cfg,
+                    int32_t *status, uint8_t *classification, uint64_t *members);
+
 /* Host utility (no GPU involved): unit-cost edit distance of two byte strings, the value of the reference's
  * wfa_ed (src/util/sequence_alignment.rs:9-13).  The batch packer uses it for Variant::alt_ed
  * (src/data_types/variants.rs:413-415), which travels to the device with the region records. */

@@ -86,4 +86,25 @@ def test_pairs_on_gpu_match_oracle(oracle):
     st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs)
     st_g, ex_g = ctx.optimize_pairs(batch)
     assert np.array_equal(st_o, st_g) and np.array_equal(ex_o, ex_g)
+    # avk_merge_batch: the whole of solve_merge_region in one library call, per configuration of the known-answer tests
+    from aardvark_amd.merge import merge_batch
+    ctx.upload_reference(contig)
+    for r, want in zip(GOLD["regions"], expect()):
+        got = merge_batch(ctx, [{"start": r["start"], "end": r["end"], "inputs": r["inputs"]}], MergeConfig(**r["config"]))
+        assert got[0] == want, r
+    # and on three-input regions built from fuzzed call sets, against oracle pairs + the same classification
+    contigs, batch = scenarios.fuzz_regions(44, 300, related=0.9)
+    ctx.upload_reference(contigs)
+    def variants(b, off, cnt):
+        return [(int(b.var_pos[v]), bytes(b.allele_bytes[int(b.a0_off[v]):int(b.a0_off[v]) + int(b.a0_len[v])]),
+                 bytes(b.allele_bytes[int(b.a1_off[v]):int(b.a1_off[v]) + int(b.a1_len[v])]), int(b.var_type[v]), int(b.var_zyg[v]),
+                 int(b.var_raw_space[v])) for v in range(off, off + cnt)]
+    multi = []
+    for q in range(batch.n_regions):
+        t = variants(batch, int(batch.t_off[q]), int(batch.t_cnt[q]))
+        qv = variants(batch, int(batch.q_off[q]), int(batch.q_cnt[q]))
+        multi.append({"start": int(batch.start[q]), "end": int(batch.end[q]), "inputs": [t, qv, t if q % 2 else qv]})
+    for cfg in (MergeConfig(), MergeConfig(majority_voting_enabled=True), MergeConfig(no_conflict_enabled=True, conflict_selection=1)):
+        want = solve_merge_regions(lambda b, mbf: oracle_lib.optimize_pairs(oracle, b, contigs, max_branch_factor=mbf, threads=8), multi, cfg)
+        assert merge_batch(ctx, multi, cfg) == want
     ctx.close()
