@@ -1408,7 +1408,16 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     const bool small_n = c.N < 500;
     u32 best_total = 0xFFFFFFFFu, best_k = 0;
     u32 n_memo = 0;
-    for (u32 k = 0; k < (u32)nopt; ++k) {
+    /* The common case in one look: the first optimum costs 0 and skipped no ALT on either haplotype.  Both of its genotype
+     * searches are then the trivial ones (see below), their result is the node's own allele sets with 0 flips, and total == 0
+     * ends the loop at k = 0: the observed alleles ARE the expected ones, nothing is searched or copied. */
+    bool obs_same = false;
+    if (small_n && c.best_cost == 0) {
+        const u32 *w = (const u32 *)(poolA + NODE_HDR);
+        const u32 ns0 = ld32u(w + H_NSKIP), ns1 = ld32u((const u32 *)((const u8 *)w + c.hapA_bytes) + H_NSKIP);
+        obs_same = ns0 == 0 && ns1 == 0;
+    }
+    for (u32 k = 0; k < (obs_same ? 0u : (u32)nopt); ++k) {
         u32 errs[2] = {0, 0};
         bool cut = false;
         for (int hh = 0; hh < 2 && !cut; ++hh) {
@@ -1511,7 +1520,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         const bool is_truth = k < c.T;
         const u32 sub = is_truth ? k : k - c.T;
         const u64 *e0 = is_truth ? w0.talt : w0.qalt, *e1 = is_truth ? w1.talt : w1.qalt;
-        const u64 *o0 = obs + (is_truth ? 0 : c.alw), *o1 = obs + 2 * c.alw + (is_truth ? 0 : c.alw);
+        const u64 *o0 = obs_same ? e0 : obs + (is_truth ? 0 : c.alw), *o1 = obs_same ? e1 : obs + 2 * c.alw + (is_truth ? 0 : c.alw);
         const u32 b0 = (u32)((e0[sub >> 6] >> (sub & 63)) & 1), b1 = (u32)((e1[sub >> 6] >> (sub & 63)) & 1);
         const u32 exp = b0 + b1;
         const u32 ob = (u32)((o0[sub >> 6] >> (sub & 63)) & 1) + (u32)((o1[sub >> 6] >> (sub & 63)) & 1);
