@@ -1099,6 +1099,27 @@ AVK_DEV u32 *gfield(u32 *g, int group, int field) { return g + group * AVK_N_FIE
  * group.  Query variants are scored "as truth" and then moved to the query columns by
  * add_swap_benchmark (grouped_metrics.rs:268-277: query_tp <- truth_tp, query_fp <- truth_fn,
  * query_fp_gt <- truth_fn_gt); `q` selects those columns directly. */
+/* Only the joint group and the groups of the variant types that occur in the region can hold anything: `gmask` has bit 0
+ * and bit 1 + t for every such type.  Two groups per step: lanes 0..21 take one, lanes 32..53 the next.  Returns through
+ * `idx` the metric-block index this lane handles in the current step, or AVK_N_GROUPS * AVK_N_FIELDS when it has none. */
+AVK_DEV u32 gm_step(u32 &left, u32 lane) {
+    const u32 ga = (u32)avk_ctz64(left);
+    left &= left - 1;
+    u32 gb = 0xFFu;
+    if (left) {
+        gb = (u32)avk_ctz64(left);
+        left &= left - 1;
+    }
+    const u32 g = (lane >> 5) ? gb : ga, f = lane & 31u;
+    return (g != 0xFFu && f < AVK_N_FIELDS) ? g * AVK_N_FIELDS + f : (u32)(AVK_N_GROUPS * AVK_N_FIELDS);
+}
+AVK_DEV void gm_zero(u32 *gm, u32 gmask) {
+    const u32 lane = (u32)wv_lane();
+    for (u32 left = gmask; left;) {
+        const u32 i = gm_step(left, lane);
+        if (i < AVK_N_GROUPS * AVK_N_FIELDS) gm[i] = 0;
+    }
+}
 AVK_DEV void gm_add(u32 *g, bool q, u32 type, u32 w, u32 exp, u32 obs) {
     const int f_gt_tp = q ? AVK_F_GT_QUERY_TP : AVK_F_GT_TRUTH_TP, f_gt_fn = q ? AVK_F_GT_QUERY_FP : AVK_F_GT_TRUTH_FN;
     const int f_gt_fn_gt = q ? AVK_F_GT_QUERY_FP_GT : AVK_F_GT_TRUTH_FN_GT;
@@ -1511,7 +1532,8 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     out.ed1 = h0.ed;
     out.ed2 = h1.ed;
 
-    zero_words(c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
+    if (a.group_metrics) zero_words(c.gm, AVK_N_GROUPS * AVK_N_FIELDS); /* the whole block goes out */
+    else gm_zero(c.gm, 1u | ((wv_uni(reg.pre_status) >> 16) << 1));
     zero_words(c.gq, 32);
     wv_sync();
     /* compare_expected_observed for truth and query (:296-327) + per-variant outputs */
@@ -1907,8 +1929,8 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
         { /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters (a handful of
            * the 286) are added to the workgroup's tally in LDS, or — launches without a tail — straight to a partial tally */
             u64 *part_r = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
-            for (int j = 0; j < 5; ++j) {
-                const u32 i = avk_opaque_u32((u32)j * 64 + lane);
+            for (u32 left = 1u | ((wv_uni(reg.pre_status) >> 16) << 1); left;) { /* only groups that can be nonzero (gm_step) */
+                const u32 i = avk_opaque_u32(gm_step(left, lane));
                 const u32 v = i < AVK_N_GROUPS * AVK_N_FIELDS ? c.gm[i] : 0u;
                 if (v) {
                     if (wgt) avk_atomic_add_u32(wg_tally + i, v);

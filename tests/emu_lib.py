@@ -27,10 +27,10 @@ def load():
 
 def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False,
                   lds_bytes=10 * 1024, lds_ed_cap=48, lds2_bytes=40 * 1024, lds2_ed_cap=48, ws_bytes=1 << 20, big_ws_bytes=64 << 20,
-                  n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1):
+                  n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1, group_metrics=True):
     lib = load()
     cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
-    res = ResultBatch(batch, sequences=sequences)
+    res = ResultBatch(batch, sequences=sequences, group_metrics=group_metrics)
     cfg = AvkCompareConfig(max_branch_factor, 1 if sequences else 0, 1 if exact_shortcut else 0)
     cb, ro = batch.c_struct(), res.c_struct()
     tiers = (C.c_uint64 * 5)()

@@ -18,6 +18,17 @@ def check(oracle, contigs, batch, **emu_kw):
     return got, want
 
 
+def test_tally_without_per_region_blocks(oracle):
+    """emit_group_metrics = 0 (what the benchmark runs): only the metric groups of the types that occur are cleared and
+    flushed per region; the batch tally and the per-variant decisions must not change"""
+    for contigs, batch in (scenarios.golden(), scenarios.fuzz_regions(17, 150), scenarios.indel_small(1500), scenarios.chr20_small(800)):
+        want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
+        got = emu_lib.compare_batch(batch, contigs, threads=EMU_THREADS, group_metrics=False)
+        want.group_metrics = None
+        assert got.diff(want) == []
+        assert np.array_equal(got.tally, want.tally)
+
+
 def test_reference_known_answer_regions(oracle):
     contigs, batch = scenarios.golden()
     got, _ = check(oracle, contigs, batch, n_waves=2)
