@@ -3,7 +3,7 @@
  * two C-ABIs: libaardvark_feeder.so turns FASTA + BED + truth/query VCFs into region batches, libaardvark_amd.so
  * solves them on the GPU, the feeder library writes summary.tsv.  Option names are the reference's
  * (src/cli/compare.rs), --stratification included.  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).
- * Not implemented here: the debug TSVs (--output-debug is rejected rather than ignored).
+ * --output-debug writes region_summary.tsv.gz and region_sequences.tsv.gz (not cli_settings.json).
  */
 #include <cerrno>
 #include <chrono>
@@ -33,14 +33,14 @@ void usage() {
             "usage: aardvark_amd_compare -r REF.fa[.gz] -t TRUTH.vcf[.gz] -q QUERY.vcf[.gz] -b REGIONS.bed[.gz] -o OUT_DIR\n"
             "  [--truth-sample S] [--query-sample S] [--compare-label L] [--min-variant-gap 50] [--disable-variant-trimming]\n"
             "  [--max-branch-factor 50] [--enable-exact-shortcut] [--enable-haplotype-metrics] [--enable-weighted-haplotype-metrics]\n"
-            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
+            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
 }
 
 } // namespace
 
 int main(int argc, char **argv) {
     const auto t_start = std::chrono::steady_clock::now();
-    std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare", strat_tsv;
+    std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare", strat_tsv, debug_dir;
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000;
     bool trimming = true, shortcut = false, hap = false, whap = false, rbp = false;
     int device = 0;
@@ -71,7 +71,7 @@ int main(int argc, char **argv) {
         else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
         else if (a == "--threads" || a == "--max-edit-distance") (void)val(); /* accepted for command-line compatibility */
         else if (a == "-s" || a == "--stratification") strat_tsv = val();
-        else if (a == "--output-debug") die(64, "not supported by this build", a.c_str());
+        else if (a == "--output-debug") debug_dir = val();
         else if (a == "-h" || a == "--help") {
             usage();
             return 0;
@@ -85,6 +85,7 @@ int main(int argc, char **argv) {
     if (branch == 0 || branch > 0xFFFFFFFFull) die(78, "--max-branch-factor must be >0", "");
     if (batch_regions == 0) batch_regions = 1;
     if (mkdir(out_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create output folder", out_dir.c_str());
+    if (!debug_dir.empty() && mkdir(debug_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create debug folder", debug_dir.c_str());
 
     auto t0 = std::chrono::steady_clock::now();
     avf_genome *genome = nullptr;
@@ -132,8 +133,23 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> var_expected(all->n_variants + 1), var_observed(all->n_variants + 1), var_class(all->n_variants + 1);
     /* stratified tallies (SummaryWriter::add_comparison_benchmark, summary.rs:146-163): label l sums the metric blocks of the
      * regions it contains, so the per-region blocks come back from the GPU, in batches that keep them at a few hundred MB */
-    (void)avk_ctx_set_option(ctx, "emit_group_metrics", n_labels ? 1 : 0);
-    if (n_labels && batch_regions > 262144) batch_regions = 262144;
+    const bool debug = !debug_dir.empty();
+    (void)avk_ctx_set_option(ctx, "emit_group_metrics", n_labels || debug ? 1 : 0);
+    if ((n_labels || debug) && batch_regions > 262144) batch_regions = 262144;
+    cfg.enable_sequences = debug ? 1 : 0; /* enable_sequences(region_seq_writer.is_some()), src/main.rs:236 */
+    uint32_t mask = AVF_METRIC_GT | AVF_METRIC_BASEPAIR;
+    if (hap) mask |= AVF_METRIC_HAP;
+    if (whap) mask |= AVF_METRIC_WEIGHTED_HAP;
+    if (rbp) mask |= AVF_METRIC_RECORD_BP;
+    avf_table *region_table = nullptr, *sequence_table = nullptr;
+    if (debug) { /* the debug tables (src/main.rs:163-188) */
+        if (avf_region_summary_open((debug_dir + "/region_summary.tsv.gz").c_str(), mask, &region_table) ||
+            avf_region_sequences_open((debug_dir + "/region_sequences.tsv.gz").c_str(), &sequence_table))
+            die(74, "Error while building debug writers", avf_last_error());
+    }
+    std::vector<uint8_t> seq_bytes;
+    std::vector<uint64_t> seq_off;
+    std::vector<uint32_t> seq_stride, seq_len;
     std::vector<uint64_t> strat_total((size_t)n_labels * AVK_TALLY_LEN, 0);
     std::vector<uint32_t> gm, labels(n_labels ? n_labels : 1);
     for (uint64_t at = 0; at < count; at += batch_regions) {
@@ -155,12 +171,32 @@ int main(int argc, char **argv) {
         out.var_expected = var_expected.data(); /* indexed by the (shared) variant arrays */
         out.var_observed = var_observed.data();
         out.var_class = var_class.data();
-        if (n_labels) {
+        if (n_labels || debug) {
             gm.resize((size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
             out.group_metrics = gm.data();
         }
+        if (debug) {
+            seq_off.resize(n);
+            seq_stride.resize(n);
+            seq_len.assign(5 * n, 0);
+            uint64_t total_seq = 0;
+            for (uint64_t r = 0; r < n; ++r) {
+                seq_stride[r] = avk_seq_stride(&b, r);
+                seq_off[r] = total_seq;
+                total_seq += 5ull * seq_stride[r];
+            }
+            seq_bytes.resize(total_seq + 16);
+            out.seq_bytes = seq_bytes.data();
+            out.seq_off = seq_off.data();
+            out.seq_stride = seq_stride.data();
+            out.seq_len = seq_len.data();
+        }
         if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
         for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += tally[k];
+        if (debug && (avf_region_summary_rows(region_table, genome, all, first + at, n, out.status, gm.data()) ||
+                      avf_region_sequences_rows(sequence_table, genome, all, first + at, n, out.status, seq_bytes.data(), seq_len.data(), seq_off.data(),
+                                                seq_stride.data())))
+            die(74, "Error while writing the debug tables", avf_last_error());
         for (uint64_t r = 0; n_labels && r < n; ++r) {
             if (out.status[r] != 0) continue;
             const uint32_t hit = avf_strat_region_labels(strat, genome, all, first + at + r, labels.data(), n_labels);
@@ -178,10 +214,7 @@ int main(int argc, char **argv) {
     const double s_solve = seconds_since(t0);
 
     t0 = std::chrono::steady_clock::now();
-    uint32_t mask = AVF_METRIC_GT | AVF_METRIC_BASEPAIR;
-    if (hap) mask |= AVF_METRIC_HAP;
-    if (whap) mask |= AVF_METRIC_WEIGHTED_HAP;
-    if (rbp) mask |= AVF_METRIC_RECORD_BP;
+    if (avf_table_close(region_table) || avf_table_close(sequence_table)) die(74, "Error while saving the debug tables", avf_last_error());
     const std::string summary = out_dir + "/summary.tsv";
     if (avf_write_summary_stratified(summary.c_str(), label.c_str(), total.data(), strat, strat_total.data(), mask))
         die(74, "Error while saving summary file", avf_last_error());

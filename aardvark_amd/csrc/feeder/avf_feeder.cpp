@@ -410,6 +410,8 @@ std::string csv_field(const std::string &s, char delim) {
 
 } // namespace
 
+std::string avf_fmt_f64_(double v) { return fmt_f64(v); } /* for the other translation units */
+
 extern "C" {
 
 const char *avf_last_error(void) { return t_error.c_str(); }

@@ -5,7 +5,7 @@
  */
 #include "../../../include/aardvark_feeder.h"
 
-#include <zlib.h>
+#include "avf_bgzf.h"
 
 #include <algorithm>
 #include <cstdio>
@@ -60,8 +60,7 @@ class BgzfWriter {
             file_off_[k + 1] = file_off_[k] + packed[k].size();
             if (fwrite(packed[k].data(), 1, packed[k].size(), fp) != packed[k].size()) return false;
         }
-        static const unsigned char eof[28] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00, 0x1b, 0x00, 0x03, 0x00, 0, 0, 0, 0, 0, 0, 0, 0};
-        return fwrite(eof, 1, sizeof(eof), fp) == sizeof(eof);
+        return avf_bgzf::write_eof(fp);
     }
     /* after finish(): the file's virtual offset of a logical one (an offset at the very end of a block is the start of the next) */
     uint64_t real(uint64_t logical) const {
@@ -72,34 +71,8 @@ class BgzfWriter {
     }
 
   private:
-    static constexpr size_t kBlock = 0xff00;
-    static bool compress_block(const std::string &in, std::string &out) {
-        std::vector<unsigned char> buf(kBlock + 1024);
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-        zs.next_in = (Bytef *)in.data();
-        zs.avail_in = (uInt)in.size();
-        zs.next_out = buf.data() + 18;
-        zs.avail_out = (uInt)(buf.size() - 18 - 8);
-        const int rc = deflate(&zs, Z_FINISH);
-        const size_t clen = zs.total_out;
-        deflateEnd(&zs);
-        if (rc != Z_STREAM_END) return false;
-        const size_t total = 18 + clen + 8;
-        static const unsigned char head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};
-        memcpy(buf.data(), head, 16);
-        buf[16] = (unsigned char)((total - 1) & 0xff);
-        buf[17] = (unsigned char)((total - 1) >> 8);
-        const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)in.data(), (uInt)in.size());
-        const uint32_t isize = (uint32_t)in.size();
-        for (int k = 0; k < 4; ++k) {
-            buf[18 + clen + k] = (unsigned char)(crc >> (8 * k));
-            buf[18 + clen + 4 + k] = (unsigned char)(isize >> (8 * k));
-        }
-        out.assign((const char *)buf.data(), total);
-        return true;
-    }
+    static constexpr size_t kBlock = avf_bgzf::kBlock;
+    static bool compress_block(const std::string &in, std::string &out) { return avf_bgzf::compress_block(in.data(), in.size(), out); }
     std::vector<std::string> blocks_;
     std::vector<uint64_t> file_off_;
 };

@@ -69,6 +69,12 @@ def load_library():
     lib.avf_strat_region_labels.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, u32p, C.c_uint32]
     lib.avf_strat_free.argtypes = [vp]
     lib.avf_write_summary_stratified.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_uint64), C.c_uint32]
+    lib.avf_region_summary_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(vp)]
+    lib.avf_region_summary_rows.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
+    lib.avf_region_sequences_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    lib.avf_region_sequences_rows.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
+                                              C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    lib.avf_table_close.argtypes = [vp]
     _lib = lib
     return lib
 
@@ -196,3 +202,25 @@ def write_summary_stratified(path, tally, strat, strat_tallies, compare_label="c
     st = np.ascontiguousarray(strat_tallies, dtype=np.uint64).reshape(-1)
     _check(lib, lib.avf_write_summary_stratified(os.fsencode(path), compare_label.encode(), t.ctypes.data_as(C.POINTER(C.c_uint64)), strat.handle,
                                                  st.ctypes.data_as(C.POINTER(C.c_uint64)), metrics))
+
+
+def write_debug_tables(summary_path, sequences_path, genome, batch, result, metrics=METRIC_GT | METRIC_BASEPAIR):
+    """region_summary.tsv.gz and region_sequences.tsv.gz of --output-debug for one batch and its ResultBatch (with sequences)."""
+    lib = load_library()
+    cb = batch.c_struct()
+    st = np.ascontiguousarray(result.status, np.int32)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    for path, is_seq in ((summary_path, False), (sequences_path, True)):
+        if not path:
+            continue
+        h = C.c_void_p()
+        if is_seq:
+            _check(lib, lib.avf_region_sequences_open(os.fsencode(path), C.byref(h)))
+            rc = lib.avf_region_sequences_rows(h, genome.handle, C.byref(cb), 0, batch.n_regions, P(st, C.c_int32), P(result.seq_bytes, C.c_uint8),
+                                               P(np.ascontiguousarray(result.seq_len, np.uint32), C.c_uint32), P(result.seq_off, C.c_uint64), P(result.seq_stride, C.c_uint32))
+        else:
+            _check(lib, lib.avf_region_summary_open(os.fsencode(path), metrics, C.byref(h)))
+            gm = np.ascontiguousarray(result.group_metrics, np.uint32)
+            rc = lib.avf_region_summary_rows(h, genome.handle, C.byref(cb), 0, batch.n_regions, P(st, C.c_int32), P(gm, C.c_uint32))
+        rc2 = lib.avf_table_close(h)
+        _check(lib, rc or rc2)

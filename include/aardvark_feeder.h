@@ -97,6 +97,23 @@ int avf_write_annotated_vcf(const char *out_path, const char *input_vcf, const c
                             const avf_genome *g, const avk_region_batch *batch, int source, const int32_t *status, const uint8_t *var_expected,
                             const uint8_t *var_observed, const uint8_t *var_class);
 
+/* ---- the debug tables of --output-debug, both BGZF-compressed tab-separated text, rows appended batch by batch ----------------
+ * region_summary.tsv.gz   (RegionSummaryWriter, src/writers/region_summary.rs): one row per metric kind of metrics_mask and solved
+ *                         region with the region's JOINT metrics; columns region_id, coordinates ("chrom:start+1-end"),
+ *                         comparison, the six counts, recall / precision / F1, truth_fn_gt, query_fp_gt
+ * region_sequences.tsv.gz (RegionSequenceWriter, src/writers/region_sequence.rs): region_id, coordinates, reference window and
+ *                         the four haplotype sequences (needs avk_compare_config::enable_sequences)
+ * first / n select the regions of `batch` the arrays belong to: status[k], group_metrics block k, sequence slots k describe
+ * region first + k. */
+typedef struct avf_table avf_table;
+int avf_region_summary_open(const char *path, uint32_t metrics_mask, avf_table **out);
+int avf_region_summary_rows(avf_table *t, const avf_genome *g, const avk_region_batch *batch, uint64_t first, uint64_t n, const int32_t *status,
+                            const uint32_t *group_metrics);
+int avf_region_sequences_open(const char *path, avf_table **out);
+int avf_region_sequences_rows(avf_table *t, const avf_genome *g, const avk_region_batch *batch, uint64_t first, uint64_t n, const int32_t *status,
+                              const uint8_t *seq_bytes, const uint32_t *seq_len, const uint64_t *seq_off, const uint32_t *seq_stride);
+int avf_table_close(avf_table *t);
+
 #ifdef __cplusplus
 }
 #endif

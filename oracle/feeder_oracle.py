@@ -325,3 +325,34 @@ def annotated_vcf_records(regions, source, status, var_expected, var_observed, v
                         reg["chrom"], c["pos"] + 1, c["a0"], c["a1"], gt[c["zyg"]], cls[int(var_class[v])], int(var_expected[v]), int(var_observed[v]), reg["region_id"]))
                 v += 1
     return lines
+
+
+def region_summary_text(regions, status, group_metrics, metrics=("GT", "BASEPAIR")):
+    """RegionSummaryWriter (src/writers/region_summary.rs:11-139): the joint metrics of every solved region"""
+    base = {"GT": 0, "HAP": 6, "WEIGHTED_HAP": 10, "BASEPAIR": 14, "RECORD_BP": 18}
+    lines = ["\t".join(["region_id", "coordinates", "comparison", "truth_total", "truth_tp", "truth_fn", "query_total", "query_tp", "query_fp", "metric_recall",
+                        "metric_precision", "metric_f1", "truth_fn_gt", "query_fp_gt"])]
+    for r, reg in enumerate(regions):
+        if status[r] != 0:
+            continue
+        joint = [int(x) for x in group_metrics[r][0]]
+        coords = "%s:%d-%d" % (reg["chrom"], reg["start"] + 1, reg["end"])
+        for kind in metrics:
+            m = joint[base[kind]:base[kind] + 4]
+            ttot, qtot = m[0] + m[1], m[2] + m[3]
+            rec = m[0] / ttot if ttot else None
+            pre = m[2] / qtot if qtot else None
+            f1 = None if rec is None or pre is None else (2.0 * rec * pre / (rec + pre) if rec + pre != 0 else float("nan"))
+            cells = [reg["region_id"], coords, kind, ttot, m[0], m[1], qtot, m[2], m[3], "" if rec is None else ryu(rec), "" if pre is None else ryu(pre),
+                     "" if f1 is None else ryu(f1)] + ([joint[4], joint[5]] if kind == "GT" else ["", ""])
+            lines.append("\t".join(str(c) for c in cells))
+    return "\n".join(lines) + "\n"
+
+
+def region_sequences_text(regions, status, sequences):
+    """RegionSequenceWriter (src/writers/region_sequence.rs:9-77); sequences[r] = the 5 strings of region r"""
+    lines = ["\t".join(["region_id", "coordinates", "ref_seq", "truth_seq1", "truth_seq2", "query_seq1", "query_seq2"])]
+    for r, reg in enumerate(regions):
+        if status[r] == 0:
+            lines.append("\t".join([str(reg["region_id"]), "%s:%d-%d" % (reg["chrom"], reg["start"] + 1, reg["end"])] + list(sequences[r])))
+    return "\n".join(lines) + "\n"

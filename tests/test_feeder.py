@@ -519,7 +519,7 @@ def test_command_line_tool_with_stratifications(tmp_path, oracle):
         write_text(str(tmp_path / (name + ".bed")), "".join("chr20\t%d\t%d\n" % x for x in iv))
     write_text(str(tmp_path / "strat.tsv"), "".join("%s\t%s.bed\n" % (n, n) for n in beds))
     r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"], "--disable-variant-trimming",
-                        "-s", str(tmp_path / "strat.tsv"), "--batch-regions", "900"], capture_output=True, text=True)
+                        "-s", str(tmp_path / "strat.tsv"), "--batch-regions", "900", "--output-debug", str(tmp_path / "dbg")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     ostrat = fo.load_stratifications(str(tmp_path / "strat.tsv"))
     regions, _ = fo.generate_regions(fo.load_calls(p["t"], "", False), fo.load_calls(p["q"], "", False), fo.read_bed(p["bed"]), fo.read_fasta(p["fa"]))
@@ -531,3 +531,27 @@ def test_command_line_tool_with_stratifications(tmp_path, oracle):
     want = fo.summary_text(res.tally, "compare", ("GT", "BASEPAIR"), strat_blocks=[(l, blocks[i]) for i, (l, _) in enumerate(ostrat)])
     assert open(os.path.join(p["out"], "summary.tsv")).read() == want
     assert blocks.sum() > 0
+    # --output-debug: the per-region tables, written batch by batch
+    full = oracle_lib.compare_batch(oracle, want_batch, [contig], sequences=True, threads=8)
+    assert gzip.open(str(tmp_path / "dbg" / "region_summary.tsv.gz"), "rt").read() == fo.region_summary_text(regions, full.status, full.group_metrics)
+    seqs = [[full.sequence(k, j).decode() for j in range(5)] for k in range(want_batch.n_regions)]
+    assert gzip.open(str(tmp_path / "dbg" / "region_sequences.tsv.gz"), "rt").read() == fo.region_sequences_text(regions, full.status, seqs)
+
+
+def test_debug_tables(tmp_path, oracle):
+    """region_summary.tsv.gz / region_sequences.tsv.gz (--output-debug): BGZF text equal to the restated writers"""
+    p, contig, _ = write_case_files(tmp_path, 500, 250_000)
+    genome = feeder.Genome(p["fa"])
+    feed = feeder.feed_compare(p["t"], p["q"], p["bed"], genome, enable_trimming=False)
+    regions, _ = fo.generate_regions(fo.load_calls(p["t"], "", False), fo.load_calls(p["q"], "", False), fo.read_bed(p["bed"]), fo.read_fasta(p["fa"]))
+    res = oracle_lib.compare_batch(oracle, feed.batch, genome.contigs(), sequences=True, threads=4)
+    res.status = res.status.copy()
+    res.status[3] = 7  # a failed region is left out of both tables
+    rs, sq = str(tmp_path / "region_summary.tsv.gz"), str(tmp_path / "region_sequences.tsv.gz")
+    feeder.write_debug_tables(rs, sq, genome, feed.batch, res, 31)
+    for path in (rs, sq):
+        assert b"".join(raw for _, raw in bgzf_blocks(path)).decode() == gzip.open(path, "rt").read()
+    assert gzip.open(rs, "rt").read() == fo.region_summary_text(regions, res.status, res.group_metrics, ("GT", "BASEPAIR", "HAP", "WEIGHTED_HAP", "RECORD_BP"))
+    seqs = [[res.sequence(r, k).decode() for k in range(5)] for r in range(feed.batch.n_regions)]
+    assert gzip.open(sq, "rt").read() == fo.region_sequences_text(regions, res.status, seqs)
+    assert len(gzip.open(sq, "rt").read().splitlines()) == feed.batch.n_regions  # header + all but one
