@@ -1,0 +1,188 @@
+/* avf_tbx.h — a BGZF text file with a tabix index next to it (VCF or BED records), for the writers of libaardvark_feeder.so */
+#ifndef AVF_TBX_H
+#define AVF_TBX_H
+#include "avf_bgzf.h"
+
+#include <map>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace avf_tbx {
+
+/* ---- BGZF (SAM spec section 4.1): gzip members of at most 64 KiB with a BC extra field ----
+ * The text is cut into blocks as it is written; the blocks are compressed by a few threads at the end (like the
+ * reference's MultithreadedWriter, variant_categorizer.rs:108-110).  tell() therefore returns a LOGICAL virtual offset
+ * (block index << 16 | offset in block); real() turns it into the file's virtual offset once the block sizes are known. */
+class BgzfWriter {
+  public:
+    BgzfWriter() { blocks_.emplace_back(); }
+    uint64_t tell() const { return ((uint64_t)(blocks_.size() - 1) << 16) | (uint64_t)blocks_.back().size(); }
+    void write(const char *p, size_t n) {
+        while (n) {
+            std::string &cur = blocks_.back();
+            const size_t room = kBlock - cur.size();
+            const size_t take = n < room ? n : room;
+            cur.append(p, take);
+            p += take;
+            n -= take;
+            if (blocks_.back().size() == kBlock) blocks_.emplace_back();
+        }
+    }
+    /* compresses and writes everything plus the end-of-file block */
+    bool finish(FILE *fp, int threads) {
+        if (blocks_.back().empty()) blocks_.pop_back();
+        const size_t nb = blocks_.size();
+        std::vector<std::string> packed(nb);
+        std::vector<char> bad(nb, 0);
+        int nt = threads < 1 ? 1 : threads;
+        if ((size_t)nt > nb) nt = nb ? (int)nb : 1;
+        auto work = [&](size_t t) {
+            for (size_t k = t; k < nb; k += (size_t)nt)
+                if (!compress_block(blocks_[k], packed[k])) bad[k] = 1;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; ++t) pool.emplace_back(work, (size_t)t);
+        work(0);
+        for (auto &th : pool) th.join();
+        file_off_.assign(nb + 1, 0);
+        for (size_t k = 0; k < nb; ++k) {
+            if (bad[k]) return false;
+            file_off_[k + 1] = file_off_[k] + packed[k].size();
+            if (fwrite(packed[k].data(), 1, packed[k].size(), fp) != packed[k].size()) return false;
+        }
+        return avf_bgzf::write_eof(fp);
+    }
+    /* after finish(): the file's virtual offset of a logical one (an offset at the very end of a block is the start of the next) */
+    uint64_t real(uint64_t logical) const {
+        size_t blk = (size_t)(logical >> 16);
+        uint64_t off = logical & 0xFFFF;
+        if (blk >= file_off_.size() - 1) return file_off_.back() << 16;
+        return (file_off_[blk] << 16) | off;
+    }
+
+  private:
+    static constexpr size_t kBlock = avf_bgzf::kBlock;
+    static bool compress_block(const std::string &in, std::string &out) { return avf_bgzf::compress_block(in.data(), in.size(), out); }
+    std::vector<std::string> blocks_;
+    std::vector<uint64_t> file_off_;
+};
+
+/* ---- tabix index (tabix spec): binning index + 16 kb linear index per contig ---- */
+inline int reg2bin(int64_t beg, int64_t end) {
+    --end;
+    if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+    if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+    if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+    if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+    if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+    return 0;
+}
+
+constexpr uint64_t kNone = ~0ull;
+
+struct RefIndex {
+    std::map<uint32_t, std::vector<std::pair<uint64_t, uint64_t>>> bins;
+    std::vector<uint64_t> linear;
+};
+
+template <typename T> inline void put(std::string &s, T v) {
+    for (size_t k = 0; k < sizeof(T); ++k) s.push_back((char)((uint64_t)v >> (8 * k)));
+}
+
+
+/* Collects the text and the index entries of one output file; finish() compresses, writes path and path + ".tbi".
+ * Records must arrive sorted by position within a sequence; sequences are indexed in order of first appearance. */
+class IndexedText {
+  public:
+    void header(const std::string &s) { w_.write(s.data(), s.size()); }
+    /* one record line covering [beg, end) (0-based) of sequence `name` */
+    void record(const std::string &name, int64_t beg, int64_t end, const std::string &line) {
+        auto it = seq_of_.find(name);
+        size_t k;
+        if (it == seq_of_.end()) {
+            k = names_.size();
+            seq_of_.emplace(name, k);
+            names_.push_back(name);
+            index_.emplace_back();
+        } else k = it->second;
+        const uint64_t vbeg = w_.tell();
+        w_.write(line.data(), line.size());
+        const uint64_t vend = w_.tell();
+        if (end <= beg) end = beg + 1;
+        RefIndex &ri = index_[k];
+        auto &chunks = ri.bins[(uint32_t)reg2bin(beg, end)];
+        if (!chunks.empty() && chunks.back().second == vbeg) chunks.back().second = vend;
+        else chunks.emplace_back(vbeg, vend);
+        const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
+        if (ri.linear.size() <= w1) ri.linear.resize(w1 + 1, kNone);
+        for (size_t q = w0; q <= w1; ++q)
+            if (ri.linear[q] == kNone) ri.linear[q] = vbeg;
+    }
+    /* format: 2 = VCF (col_seq 1, col_beg 2, col_end 0), 0x10000 = zero-based BED (1, 2, 3) */
+    bool finish(const std::string &path, int format) {
+        FILE *fp = fopen(path.c_str(), "wb");
+        if (!fp) return false;
+        int threads = (int)std::thread::hardware_concurrency();
+        if (threads > 8) threads = 8;
+        bool ok = w_.finish(fp, threads);
+        ok = (fclose(fp) == 0) && ok;
+        if (!ok) return false;
+        for (RefIndex &ri : index_) { /* logical virtual offsets -> the file's */
+            for (auto &kv : ri.bins)
+                for (auto &ch : kv.second) {
+                    ch.first = w_.real(ch.first);
+                    ch.second = w_.real(ch.second);
+                }
+            for (uint64_t &o : ri.linear)
+                if (o != kNone) o = w_.real(o);
+        }
+        std::string tbi;
+        tbi.append("TBI\1", 4);
+        put<int32_t>(tbi, (int32_t)names_.size());
+        put<int32_t>(tbi, format);
+        put<int32_t>(tbi, 1);
+        put<int32_t>(tbi, 2);
+        put<int32_t>(tbi, format == 2 ? 0 : 3);
+        put<int32_t>(tbi, '#');
+        put<int32_t>(tbi, 0);
+        std::string names;
+        for (const std::string &n : names_) {
+            names += n;
+            names.push_back('\0');
+        }
+        put<int32_t>(tbi, (int32_t)names.size());
+        tbi += names;
+        for (RefIndex &ri : index_) {
+            put<int32_t>(tbi, (int32_t)ri.bins.size());
+            for (auto &kv : ri.bins) {
+                put<uint32_t>(tbi, kv.first);
+                put<int32_t>(tbi, (int32_t)kv.second.size());
+                for (auto &ch : kv.second) {
+                    put<uint64_t>(tbi, ch.first);
+                    put<uint64_t>(tbi, ch.second);
+                }
+            }
+            /* windows without a record inherit the offset of the one before them (htslib convention) */
+            for (size_t q = 0; q < ri.linear.size(); ++q)
+                if (ri.linear[q] == kNone) ri.linear[q] = q ? ri.linear[q - 1] : 0;
+            put<int32_t>(tbi, (int32_t)ri.linear.size());
+            for (uint64_t o : ri.linear) put<uint64_t>(tbi, o);
+        }
+        FILE *tf = fopen((path + ".tbi").c_str(), "wb");
+        if (!tf) return false;
+        BgzfWriter tw;
+        tw.write(tbi.data(), tbi.size());
+        const bool tok = tw.finish(tf, 1);
+        return (fclose(tf) == 0) && tok;
+    }
+
+  private:
+    BgzfWriter w_;
+    std::vector<std::string> names_;
+    std::map<std::string, size_t> seq_of_;
+    std::vector<RefIndex> index_;
+};
+
+} // namespace avf_tbx
+#endif
