@@ -1,0 +1,257 @@
+/*
+ * merge_main.cpp — `aardvark_amd_merge`: the reference's `aardvark merge` flow (src/main.rs:329-546) on top of the two C-ABIs:
+ * libaardvark_feeder.so turns FASTA + BED + k VCFs into MultiRegion batches, libaardvark_amd.so runs the all-pairs exact-match
+ * test on the GPU and classifies the regions, the feeder library writes passing.vcf.gz, regions.bed.gz, failed_regions.bed.gz
+ * (+ .tbi each) and the summary table.  Option names are the reference's (src/cli/merge.rs).
+ */
+#include <cerrno>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include <sys/stat.h>
+
+#include "../../../include/aardvark_amd.h"
+#include "../../../include/aardvark_feeder.h"
+
+namespace {
+
+double seconds_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+
+[[noreturn]] void die(int code, const char *what, const char *detail) {
+    fprintf(stderr, "error: %s%s%s\n", what, detail && *detail ? ": " : "", detail ? detail : "");
+    exit(code);
+}
+
+void usage() {
+    fprintf(stderr,
+            "usage: aardvark_amd_merge -r REF.fa[.gz] -i VCF [-i VCF ...] -b REGIONS.bed[.gz] -o OUT_VCF_DIR\n"
+            "  [-s SAMPLE ...] [-t TAG ...] [--output-summary SUMMARY.tsv|.csv] [--output-debug DIR]\n"
+            "  [--min-variant-gap 50] [--disable-variant-trimming] [--merge-strategy exact|no_conflict|majority|all]\n"
+            "  [--enable-no-conflict] [--enable-voting] [--conflict-select INDEX] [--max-branch-factor 50]\n"
+            "  [--skip N] [--take N] [--device 0] [--batch-regions 1000000]\n");
+}
+
+std::string json_string(const std::string &s) {
+    std::string out = "\"";
+    for (unsigned char c : s) {
+        if (c == '"') out += "\\\"";
+        else if (c == '\\') out += "\\\\";
+        else if (c == '\n') out += "\\n";
+        else if (c == '\t') out += "\\t";
+        else if (c == '\r') out += "\\r";
+        else if (c < 0x20) {
+            char buf[8];
+            snprintf(buf, sizeof(buf), "\\u%04x", c);
+            out += buf;
+        } else out.push_back((char)c);
+    }
+    return out + "\"";
+}
+
+std::string json_list(const std::vector<std::string> &items) {
+    if (items.empty()) return "[]";
+    std::string out = "[\n";
+    for (size_t i = 0; i < items.size(); ++i) out += "    " + json_string(items[i]) + (i + 1 < items.size() ? ",\n" : "\n");
+    return out + "  ]";
+}
+
+} // namespace
+
+int main(int argc, char **argv) {
+    const auto t_start = std::chrono::steady_clock::now();
+    std::string ref, bed, out_dir, summary_path, debug_dir, strategy;
+    std::vector<std::string> vcfs, samples, tags;
+    uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 1000000, threads = 1, verbosity = 0;
+    bool trimming = true, no_conflict = false, voting = false;
+    long long conflict_select = -1;
+    int device = 0;
+    for (int i = 1; i < argc; ++i) {
+        const std::string a = argv[i];
+        auto val = [&]() -> const char * {
+            if (i + 1 >= argc) die(64, "missing value for", a.c_str());
+            return argv[++i];
+        };
+        if (a == "-r" || a == "--reference") ref = val();
+        else if (a == "-i" || a == "--input-vcf") vcfs.push_back(val());
+        else if (a == "-s" || a == "--vcf-sample") samples.push_back(val());
+        else if (a == "-t" || a == "--vcf-tag") tags.push_back(val());
+        else if (a == "-b" || a == "--regions") bed = val();
+        else if (a == "-o" || a == "--output-vcfs") out_dir = val();
+        else if (a == "--output-summary") summary_path = val();
+        else if (a == "--output-debug") debug_dir = val();
+        else if (a == "--min-variant-gap") gap = strtoull(val(), nullptr, 10);
+        else if (a == "--disable-variant-trimming") trimming = false;
+        else if (a == "--merge-strategy") strategy = val();
+        else if (a == "--enable-no-conflict") no_conflict = true;
+        else if (a == "--enable-voting") voting = true;
+        else if (a == "--conflict-select") conflict_select = strtoll(val(), nullptr, 10);
+        else if (a == "--max-branch-factor") branch = strtoull(val(), nullptr, 10);
+        else if (a == "--skip") skip = strtoull(val(), nullptr, 10);
+        else if (a == "--take") take = strtoull(val(), nullptr, 10);
+        else if (a == "--device") device = atoi(val());
+        else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
+        else if (a == "--threads") threads = strtoull(val(), nullptr, 10);
+        else if (a == "-v" || a == "--verbose") verbosity += 1;
+        else if (a == "-h" || a == "--help") {
+            usage();
+            return 0;
+        } else die(64, "unknown option", a.c_str());
+    }
+    if (ref.empty() || vcfs.empty() || out_dir.empty()) {
+        usage();
+        return 64;
+    }
+    /* check_merge_settings (src/cli/merge.rs:178-266) */
+    if (vcfs.size() > 64) die(78, "Error while verifying settings", "at most 64 input VCFs are supported");
+    if (gap == 0) die(78, "Error while verifying settings", "--min-variant-gap must be >0");
+    if (branch == 0 || branch > 0xFFFFFFFFull) die(78, "Error while verifying settings", "--max-branch-factor must be >0");
+    std::string strategy_name; /* serde name of MergeStrategy for cli_settings.json */
+    if (!strategy.empty()) {
+        std::string s = strategy;
+        for (char &c : s) c = (char)tolower((unsigned char)c);
+        if (s == "exact") strategy_name = "Exact";
+        else if (s == "no_conflict") {
+            no_conflict = true;
+            strategy_name = "NoConflict";
+        } else if (s == "majority") {
+            voting = true;
+            strategy_name = "MajorityVote";
+        } else if (s == "all") {
+            no_conflict = voting = true;
+            strategy_name = "AllOptions";
+        } else die(64, "invalid value for --merge-strategy (exact, no_conflict, majority, all)", strategy.c_str());
+    }
+    if (conflict_select >= (long long)vcfs.size()) die(78, "Error while verifying settings", "--conflict-selection index is greater than number of provided VCFs");
+    if (conflict_select < -1) die(64, "invalid value for --conflict-select", "");
+    for (size_t i = tags.size(); i < vcfs.size(); ++i) tags.push_back("vcf_" + std::to_string(i));
+    if (samples.size() > vcfs.size()) samples.resize(vcfs.size());
+    if (batch_regions == 0) batch_regions = 1;
+    if (threads == 0) threads = 1;
+
+    auto t0 = std::chrono::steady_clock::now();
+    avf_genome *genome = nullptr;
+    if (avf_genome_load(ref.c_str(), &genome)) die(74, "Error while loading reference genome", avf_last_error());
+    const double s_genome = seconds_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
+    const uint32_t k = (uint32_t)vcfs.size();
+    std::vector<const char *> vcf_ptrs(k), sample_ptrs(k), tag_ptrs(k);
+    for (uint32_t i = 0; i < k; ++i) {
+        vcf_ptrs[i] = vcfs[i].c_str();
+        sample_ptrs[i] = i < samples.size() ? samples[i].c_str() : "";
+        tag_ptrs[i] = tags[i].c_str();
+    }
+    avf_feed *feed = nullptr;
+    if (avf_feed_merge(k, vcf_ptrs.data(), sample_ptrs.data(), bed.c_str(), genome, gap, trimming ? 1 : 0, &feed))
+        die(74, "Error while building region iterator", avf_last_error());
+    const avk_multi_batch *all = avf_feed_multi_batch(feed);
+    const double s_feed = seconds_since(t0);
+    for (uint32_t i = 0; i < k; ++i)
+        fprintf(stderr, "Loaded %llu variants from input #%u.\n", (unsigned long long)avf_feed_loaded_variants(feed, (int)i), i);
+    fprintf(stderr, "Found %llu segments.\n", (unsigned long long)all->n_regions);
+
+    if (!debug_dir.empty()) { /* the CLI options as the reference saves them (src/main.rs:363-381) */
+        if (mkdir(debug_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "Error while creating debug folder", debug_dir.c_str());
+        std::string js = "{\n";
+        js += "  \"aardvark_version\": " + json_string(avk_version()) + ",\n";
+        js += "  \"reference_fn\": " + json_string(ref) + ",\n";
+        js += "  \"vcf_filenames\": " + json_list(vcfs) + ",\n";
+        std::vector<std::string> sample_names(k);
+        for (uint32_t i = 0; i < k; ++i) sample_names[i] = sample_ptrs[i]; /* "" = the file's first sample */
+        js += "  \"vcf_samples\": " + json_list(sample_names) + ",\n";
+        js += "  \"vcf_tags\": " + json_list(tags) + ",\n";
+        js += "  \"merge_regions\": " + (bed.empty() ? std::string("null") : json_string(bed)) + ",\n";
+        js += "  \"output_vcf_folder\": " + json_string(out_dir) + ",\n";
+        js += "  \"output_summary_filename\": " + (summary_path.empty() ? std::string("null") : json_string(summary_path)) + ",\n";
+        js += "  \"debug_folder\": " + json_string(debug_dir) + ",\n";
+        js += "  \"min_variant_gap\": " + std::to_string(gap) + ",\n";
+        js += std::string("  \"disable_variant_trimming\": ") + (trimming ? "false" : "true") + ",\n";
+        js += "  \"merge_strategy\": " + (strategy_name.empty() ? std::string("null") : json_string(strategy_name)) + ",\n";
+        js += std::string("  \"enable_no_conflict\": ") + (no_conflict ? "true" : "false") + ",\n";
+        js += std::string("  \"enable_voting\": ") + (voting ? "true" : "false") + ",\n";
+        js += "  \"conflict_selection\": " + (conflict_select < 0 ? std::string("null") : std::to_string(conflict_select)) + ",\n";
+        js += "  \"max_branch_factor\": " + std::to_string(branch) + ",\n";
+        js += "  \"threads\": " + std::to_string(threads) + ",\n";
+        js += "  \"verbosity\": " + std::to_string(verbosity) + ",\n";
+        js += "  \"skip_blocks\": " + std::to_string(skip) + ",\n";
+        js += "  \"take_blocks\": " + (take ? std::to_string(take) : std::string("18446744073709551615")) + "\n}";
+        FILE *fp = fopen((debug_dir + "/cli_settings.json").c_str(), "wb");
+        if (!fp || fwrite(js.data(), 1, js.size(), fp) != js.size() || fclose(fp) != 0) die(74, "Error while saving CLI options", debug_dir.c_str());
+    }
+
+    t0 = std::chrono::steady_clock::now();
+    avk_ctx *ctx = nullptr;
+    if (avk_ctx_create(device, &ctx)) die(70, "cannot create the GPU context", avk_last_error(nullptr));
+    const uint32_t n_contigs = avf_genome_n_contigs(genome);
+    std::vector<const uint8_t *> seqs(n_contigs);
+    std::vector<uint64_t> lens(n_contigs);
+    for (uint32_t c = 0; c < n_contigs; ++c) {
+        seqs[c] = avf_genome_seq(genome, c);
+        lens[c] = avf_genome_len(genome, c);
+    }
+    if (avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data())) die(70, "reference upload failed", avk_last_error(ctx));
+    const double s_ref = seconds_since(t0);
+
+    /* --skip / --take select regions by position in the iterator (src/main.rs:409-443) */
+    const uint64_t first = skip < all->n_regions ? skip : all->n_regions;
+    uint64_t count = all->n_regions - first;
+    if (take && take < count) count = take;
+
+    t0 = std::chrono::steady_clock::now();
+    avk_merge_config cfg;
+    cfg.max_branch_factor = (uint32_t)branch;
+    cfg.no_conflict_enabled = no_conflict ? 1 : 0;
+    cfg.majority_voting_enabled = voting ? 1 : 0;
+    cfg.conflict_selection = (int32_t)conflict_select;
+    std::vector<int32_t> status(all->n_regions + 1, -1); /* regions outside --skip/--take stay unsolved and unwritten */
+    std::vector<uint8_t> classification(all->n_regions + 1, 0);
+    std::vector<uint64_t> members(all->n_regions + 1, 0);
+    uint64_t solved = 0, errors = 0;
+    for (uint64_t at = 0; at < count; at += batch_regions) {
+        const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
+        avk_multi_batch b = *all; /* a window of the region arrays; variant arrays are shared */
+        b.n_regions = n;
+        b.region_id = all->region_id + first + at;
+        b.contig_idx = all->contig_idx + first + at;
+        b.start = all->start + first + at;
+        b.end = all->end + first + at;
+        b.in_off = all->in_off + (first + at) * k;
+        b.in_cnt = all->in_cnt + (first + at) * k;
+        if (avk_merge_batch(ctx, &b, &cfg, status.data() + first + at, classification.data() + first + at, members.data() + first + at))
+            die(70, "merge failed", avk_last_error(ctx));
+        for (uint64_t r = 0; r < n; ++r) {
+            if (status[first + at + r] == 0) {
+                solved += 1;
+                continue;
+            }
+            errors += 1;
+            fprintf(stderr, "Error while solving merge region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)b.region_id[r], b.contig_idx[r],
+                    (unsigned long long)b.start[r], (unsigned long long)b.end[r], status[first + at + r]);
+        }
+    }
+    const double s_solve = seconds_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
+    std::string command;
+    for (int i = 0; i < argc; ++i) command += (i ? " " : "") + std::string(argv[i]);
+    if (avf_write_merge_outputs(out_dir.c_str(), vcfs[0].c_str(), sample_ptrs[0], avk_version(), command.c_str(), genome, all, tag_ptrs.data(), status.data(),
+                                classification.data(), members.data()))
+        die(74, "Error while writing merged VCF results", avf_last_error());
+    fprintf(stderr, "Solved:error blocks: %llu : %llu\n", (unsigned long long)solved, (unsigned long long)errors);
+    if (!summary_path.empty() &&
+        avf_write_merge_summary(summary_path.c_str(), all, tag_ptrs.data(), status.data(), classification.data(), members.data()))
+        die(74, "Error while saving summary file", avf_last_error());
+    const double s_write = seconds_since(t0);
+
+    fprintf(stderr, "stages [s]: reference %.3f, feeder %.3f, gpu context + reference upload %.3f, solve (pack + H2D + kernels + D2H + classify) %.3f, outputs %.3f\n",
+            s_genome, s_feed, s_ref, s_solve, s_write);
+    fprintf(stderr, "Merge completed in %.3f seconds.\n", seconds_since(t_start));
+    avk_ctx_destroy(ctx);
+    avf_feed_free(feed);
+    avf_genome_free(genome);
+    return 0;
+}

@@ -8,6 +8,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdarg>
@@ -129,11 +130,14 @@ struct avf_genome {
 
 /* ------------------------------------------------------------------------------------------ feed */
 struct avf_feed {
-    avk_region_batch batch;
-    std::vector<uint64_t> region_id, start, end, t_off, q_off, var_pos, a0_off, a1_off, var_record;
-    std::vector<uint32_t> contig_idx, t_cnt, q_cnt, var_raw, a0_len, a1_len, var_alt;
+    uint32_t k = 2;              /* inputs: 2 for compare (truth, query), the number of VCFs for merge */
+    bool is_merge = false;
+    avk_region_batch batch;      /* compare feeds */
+    avk_multi_batch multi;       /* merge feeds */
+    std::vector<uint64_t> region_id, start, end, in_off, t_off, q_off, var_pos, a0_off, a1_off, var_record;
+    std::vector<uint32_t> contig_idx, in_cnt, t_cnt, q_cnt, var_raw, a0_len, a1_len, var_alt;
     std::vector<uint8_t> var_type, var_zyg, alleles;
-    uint64_t loaded[2] = {0, 0};
+    std::vector<uint64_t> loaded;
 };
 
 namespace {
@@ -411,6 +415,7 @@ std::string csv_field(const std::string &s, char delim) {
 } // namespace
 
 std::string avf_fmt_f64_(double v) { return fmt_f64(v); } /* for the other translation units */
+std::string avf_csv_field_(const std::string &s, char delim) { return csv_field(s, delim); }
 
 extern "C" {
 
@@ -452,56 +457,59 @@ const uint8_t *avf_genome_seq(const avf_genome *g, uint32_t i) { return g && i <
 uint64_t avf_genome_len(const avf_genome *g, uint32_t i) { return g && i < g->seqs.size() ? g->seqs[i].size() : 0; }
 void avf_genome_free(avf_genome *g) { delete g; }
 
-int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char *query_vcf, const char *query_sample,
-                     const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
-    if (!truth_vcf || !query_vcf || !g || !out) return fail(AVK_E_ARG, "null argument");
-    *out = nullptr;
+/* RegionIterator::next (region_generation.rs:281-478) over k inputs; input i's variants of region m end up at
+ * [in_off[m*k + i], +in_cnt[m*k + i]).  Both the compare and the merge iterator are this loop. */
+static int build_regions(uint32_t k, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
+                         uint64_t min_variant_gap, int enable_trimming, avf_feed *f) {
     if (!regions_bed || !*regions_bed) return fail(AVK_E_ARG, "High confidence regions are currently required.");
     if (min_variant_gap == 0) return fail(AVK_E_ARG, "--min-variant-gap must be >0");
     LoadedBed bed;
     int rc = load_bed(regions_bed, bed);
     if (rc) return rc;
-    /* the two files are read side by side, like the reference's per-file parallel load (:324-347) */
-    std::unordered_map<std::string, std::vector<Call>> calls[2];
-    int rcs[2] = {0, 0};
-    std::string errs[2];
+    /* the files are read side by side, like the reference's per-file parallel load (:324-347) */
+    std::vector<std::unordered_map<std::string, std::vector<Call>>> calls(k);
+    std::vector<int> rcs(k, 0);
+    std::vector<std::string> errs(k);
     {
-        const char *paths[2] = {truth_vcf, query_vcf}, *samples[2] = {truth_sample, query_sample};
-        std::thread other([&] {
-            rcs[1] = load_vcf(paths[1], samples[1], enable_trimming != 0, calls[1]);
-            if (rcs[1]) errs[1] = t_error;
-        });
-        rcs[0] = load_vcf(paths[0], samples[0], enable_trimming != 0, calls[0]);
-        if (rcs[0]) errs[0] = t_error;
-        other.join();
+        const uint32_t n_threads = std::min<uint32_t>(k, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+        std::atomic<uint32_t> next{0};
+        auto work = [&] {
+            for (uint32_t i = next.fetch_add(1); i < k; i = next.fetch_add(1)) {
+                rcs[i] = load_vcf(vcfs[i], samples ? samples[i] : nullptr, enable_trimming != 0, calls[i]);
+                if (rcs[i]) errs[i] = t_error;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (uint32_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
     }
-    for (int i = 0; i < 2; ++i)
+    for (uint32_t i = 0; i < k; ++i)
         if (rcs[i]) {
             t_error = errs[i];
             return rcs[i];
         }
 
-    avf_feed *f = new avf_feed();
+    f->k = k;
+    f->loaded.assign(k, 0);
     struct Joint {
-        int input;
+        uint32_t input;
         const Call *c;
     };
     std::vector<Joint> joint;
     uint64_t next_region_id = 0;
+    std::vector<std::vector<const Call *>> vars(k);
     for (size_t ci = 0; ci < bed.chroms.size(); ++ci) {
         const std::string &chrom = bed.chroms[ci];
         const std::vector<Interval1> &intervals = bed.intervals[ci];
         const auto git = g->index.find(chrom);
-        if (git == g->index.end()) {
-            delete f;
-            return fail(AVK_E_ARG, "Chromosome %s was not found in reference genome", chrom.c_str());
-        }
+        if (git == g->index.end()) return fail(AVK_E_ARG, "Chromosome %s was not found in reference genome", chrom.c_str());
         const uint32_t contig = git->second;
         const uint64_t chrom_length = g->seqs[contig].size();
         /* the span the reference queries through tabix: first interval's start to the LAST interval's end (:289-296) */
         const uint64_t zb_start = intervals.front().start - 1, zb_end = intervals.back().end;
         joint.clear();
-        for (int input = 0; input < 2; ++input) {
+        for (uint32_t input = 0; input < k; ++input) {
             const auto it = calls[input].find(chrom);
             if (it == calls[input].end()) continue;
             for (const Call &c : it->second) {
@@ -515,15 +523,14 @@ int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char
         }
         std::stable_sort(joint.begin(), joint.end(), [](const Joint &a, const Joint &b) { return a.c->pos < b.c->pos; }); /* sort_by_key(position) */
         size_t head = 0; /* the deque's front */
-        std::vector<const Call *> vars[2];
         auto flush = [&](uint64_t ws, uint64_t we) {
             f->region_id.push_back(next_region_id++);
             f->contig_idx.push_back(contig);
             f->start.push_back(ws);
             f->end.push_back(we);
-            for (int input = 0; input < 2; ++input) {
-                (input == 0 ? f->t_off : f->q_off).push_back(f->var_pos.size());
-                (input == 0 ? f->t_cnt : f->q_cnt).push_back((uint32_t)vars[input].size());
+            for (uint32_t input = 0; input < k; ++input) {
+                f->in_off.push_back(f->var_pos.size());
+                f->in_cnt.push_back((uint32_t)vars[input].size());
                 for (const Call *c : vars[input]) {
                     f->var_pos.push_back(c->pos);
                     f->var_type.push_back(c->type);
@@ -574,6 +581,32 @@ int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char
         }
     }
     if (f->alleles.empty()) f->alleles.push_back(0);
+    return 0;
+}
+
+int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char *query_vcf, const char *query_sample,
+                     const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
+    if (!truth_vcf || !query_vcf || !g || !out) return fail(AVK_E_ARG, "null argument");
+    *out = nullptr;
+    avf_feed *f = new avf_feed();
+    const char *paths[2] = {truth_vcf, query_vcf}, *samples[2] = {truth_sample, query_sample};
+    const int rc = build_regions(2, paths, samples, regions_bed, g, min_variant_gap, enable_trimming, f);
+    if (rc) {
+        delete f;
+        return rc;
+    }
+    const size_t n = f->region_id.size();
+    f->t_off.resize(n);
+    f->q_off.resize(n);
+    f->t_cnt.resize(n);
+    f->q_cnt.resize(n);
+    for (size_t r = 0; r < n; ++r) {
+        f->t_off[r] = f->in_off[2 * r];
+        f->q_off[r] = f->in_off[2 * r + 1];
+        f->t_cnt[r] = f->in_cnt[2 * r];
+        f->q_cnt[r] = f->in_cnt[2 * r + 1];
+    }
+    memset(&f->multi, 0, sizeof(f->multi));
     avk_region_batch &b = f->batch;
     memset(&b, 0, sizeof(b));
     b.n_regions = f->region_id.size();
@@ -600,10 +633,52 @@ int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char
     return 0;
 }
 
-const avk_region_batch *avf_feed_batch(const avf_feed *f) { return f ? &f->batch : nullptr; }
+int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
+                   uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
+    if (!vcfs || !g || !out) return fail(AVK_E_ARG, "null argument");
+    *out = nullptr;
+    if (n_inputs == 0) return fail(AVK_E_ARG, "Must provide at least 1 VCF to iterate on");
+    if (n_inputs > 64) return fail(AVK_E_ARG, "at most 64 input VCFs are supported, got %u", n_inputs);
+    for (uint32_t i = 0; i < n_inputs; ++i)
+        if (!vcfs[i]) return fail(AVK_E_ARG, "null argument");
+    avf_feed *f = new avf_feed();
+    f->is_merge = true;
+    const int rc = build_regions(n_inputs, vcfs, samples, regions_bed, g, min_variant_gap, enable_trimming, f);
+    if (rc) {
+        delete f;
+        return rc;
+    }
+    memset(&f->batch, 0, sizeof(f->batch));
+    avk_multi_batch &b = f->multi;
+    memset(&b, 0, sizeof(b));
+    b.n_regions = f->region_id.size();
+    b.n_inputs = n_inputs;
+    b.region_id = f->region_id.data();
+    b.contig_idx = f->contig_idx.data();
+    b.start = f->start.data();
+    b.end = f->end.data();
+    b.in_off = f->in_off.data();
+    b.in_cnt = f->in_cnt.data();
+    b.n_variants = f->var_pos.size();
+    b.var_pos = f->var_pos.data();
+    b.var_type = f->var_type.data();
+    b.var_zyg = f->var_zyg.data();
+    b.var_raw_space = f->var_raw.data();
+    b.a0_off = f->a0_off.data();
+    b.a0_len = f->a0_len.data();
+    b.a1_off = f->a1_off.data();
+    b.a1_len = f->a1_len.data();
+    b.allele_bytes = f->alleles.data();
+    b.allele_bytes_len = f->alleles.size();
+    *out = f;
+    return 0;
+}
+
+const avk_region_batch *avf_feed_batch(const avf_feed *f) { return f && !f->is_merge ? &f->batch : nullptr; }
+const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f) { return f && f->is_merge ? &f->multi : nullptr; }
 const uint64_t *avf_feed_var_record(const avf_feed *f) { return f ? f->var_record.data() : nullptr; }
 const uint32_t *avf_feed_var_alt_index(const avf_feed *f) { return f ? f->var_alt.data() : nullptr; }
-uint64_t avf_feed_loaded_variants(const avf_feed *f, int input) { return f && (input == 0 || input == 1) ? f->loaded[input] : 0; }
+uint64_t avf_feed_loaded_variants(const avf_feed *f, int input) { return f && input >= 0 && (size_t)input < f->loaded.size() ? f->loaded[input] : 0; }
 void avf_feed_free(avf_feed *f) { delete f; }
 
 int avf_write_summary_stratified(const char *path, const char *compare_label, const uint64_t *tally, const avf_strat *strat, const uint64_t *strat_tallies,

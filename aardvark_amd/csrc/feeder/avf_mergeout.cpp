@@ -1,0 +1,251 @@
+/*
+ * avf_mergeout.cpp — the outputs of `aardvark merge`: passing.vcf.gz, regions.bed.gz, failed_regions.bed.gz with their tabix
+ * indexes (src/writers/variant_merger.rs:47-349) and the merge summary table (src/writers/merge_summary.rs).
+ * Part of libaardvark_feeder.so; host code only.
+ */
+#include "../../../include/aardvark_feeder.h"
+
+#include "avf_tbx.h"
+
+#include <sys/stat.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <tuple>
+#include <vector>
+
+int avf_fail_(int code, const char *fmt, ...); /* avf_feeder.cpp */
+std::string avf_csv_field_(const std::string &s, char delim);
+
+namespace {
+
+/* MergeClassification::simplify (src/data_types/merge_benchmark.rs:44-53) */
+const char *simplify(uint8_t classification) {
+    switch (classification) {
+    case AVK_MERGE_DIFFERENT: return "different";
+    case AVK_MERGE_NO_CONFLICT: return "no_conflict";
+    case AVK_MERGE_MAJORITY_AGREE: return "majority";
+    case AVK_MERGE_CONFLICT_SELECTION: return "conflict_select";
+    case AVK_MERGE_IDENTICAL: return "identical";
+    }
+    return nullptr;
+}
+
+/* the input indices the classification names: the set bits for no_conflict / majority, the index itself for a selection */
+std::vector<uint32_t> member_indices(uint8_t classification, uint64_t members) {
+    std::vector<uint32_t> idx;
+    if (classification == AVK_MERGE_NO_CONFLICT || classification == AVK_MERGE_MAJORITY_AGREE) {
+        for (uint32_t i = 0; i < 64; ++i)
+            if (members >> i & 1) idx.push_back(i);
+    } else if (classification == AVK_MERGE_CONFLICT_SELECTION) idx.push_back((uint32_t)members);
+    return idx;
+}
+
+bool make_dirs(const std::string &path) { /* create_dir_all */
+    for (size_t at = 1; at <= path.size(); ++at) {
+        if (at != path.size() && path[at] != '/') continue;
+        const std::string part = path.substr(0, at);
+        if (mkdir(part.c_str(), 0777) != 0 && errno != EEXIST) return false;
+    }
+    struct stat st;
+    return stat(path.c_str(), &st) == 0 && S_ISDIR(st.st_mode);
+}
+
+/* meta lines and first sample name of a VCF header */
+bool read_header(const char *path, std::vector<std::string> &meta, std::string &first_sample) {
+    gzFile in = gzopen(path, "rb");
+    if (!in) return false;
+    std::string line;
+    char chunk[1 << 16];
+    bool done = false;
+    while (!done && gzgets(in, chunk, sizeof(chunk))) {
+        line += chunk;
+        if (line.empty() || line.back() != '\n') continue; /* a longer line: keep reading */
+        while (!line.empty() && (line.back() == '\n' || line.back() == '\r')) line.pop_back();
+        if (line.compare(0, 2, "##") == 0) meta.push_back(line);
+        else {
+            if (line.compare(0, 6, "#CHROM") == 0) {
+                size_t tabs = 0, at = 0;
+                while (tabs < 9 && (at = line.find('\t', at)) != std::string::npos) {
+                    ++tabs;
+                    ++at;
+                }
+                if (tabs == 9) {
+                    const size_t e = line.find('\t', at);
+                    first_sample = line.substr(at, e == std::string::npos ? std::string::npos : e - at);
+                }
+            }
+            done = true;
+        }
+        line.clear();
+    }
+    gzclose(in);
+    return true;
+}
+
+int check_results(const avk_multi_batch *b, const uint8_t *classification, const uint64_t *members, const int32_t *status) {
+    if (b->n_inputs == 0 || b->n_inputs > 64) return avf_fail_(AVK_E_ARG, "n_inputs must be 1..64, got %u", b->n_inputs);
+    for (uint64_t r = 0; r < b->n_regions; ++r) {
+        if (status[r] != 0) continue;
+        if (!simplify(classification[r])) return avf_fail_(AVK_E_ARG, "region %llu has the unknown classification %u", (unsigned long long)r, classification[r]);
+        const std::vector<uint32_t> idx = member_indices(classification[r], members[r]);
+        if (classification[r] != AVK_MERGE_DIFFERENT && classification[r] != AVK_MERGE_IDENTICAL && idx.empty())
+            return avf_fail_(AVK_E_ARG, "region %llu: classification %s without member inputs", (unsigned long long)r, simplify(classification[r]));
+        for (uint32_t i : idx)
+            if (i >= b->n_inputs) return avf_fail_(AVK_E_ARG, "region %llu names input %u of %u", (unsigned long long)r, i, b->n_inputs);
+    }
+    return 0;
+}
+
+} // namespace
+
+extern "C" int avf_write_merge_outputs(const char *out_folder, const char *primary_vcf, const char *sample_name, const char *version,
+                                       const char *command_line, const avf_genome *g, const avk_multi_batch *b, const char *const *tags,
+                                       const int32_t *status, const uint8_t *classification, const uint64_t *members) {
+    if (!out_folder || !primary_vcf || !g || !b || !tags || !status || !classification || !members) return avf_fail_(AVK_E_ARG, "null argument");
+    int rc = check_results(b, classification, members, status);
+    if (rc) return rc;
+    for (uint32_t i = 0; i < b->n_inputs; ++i)
+        if (!tags[i]) return avf_fail_(AVK_E_ARG, "null tag for input %u", i);
+    std::vector<std::string> meta;
+    std::string first_sample;
+    if (!read_header(primary_vcf, meta, first_sample)) return avf_fail_(AVK_E_ARG, "Error while opening %s", primary_vcf);
+    if (!make_dirs(out_folder)) return avf_fail_(AVK_E_ARG, "Error while creating output VCF folder %s", out_folder);
+    const std::string sample = sample_name && *sample_name ? sample_name : first_sample;
+
+    avf_tbx::IndexedText vcf, passing_bed, failed_bed;
+    for (const std::string &m : meta) vcf.header(m + "\n");
+    /* what the reference adds (variant_merger.rs:85-121) */
+    vcf.header(std::string("##aardvark_version=\"") + (version ? version : "") + "\"\n");
+    vcf.header(std::string("##aardvark_command=\"") + (command_line ? command_line : "") + "\"\n");
+    vcf.header("##INFO=<ID=SOURCES,Number=.,Type=String,Description=\"List of tools or technologies that called the same record\">\n");
+    vcf.header("##INFO=<ID=MR,Number=1,Type=String,Description=\"The reason this record was allowed in the merge\">\n");
+    vcf.header("##FORMAT=<ID=RI,Number=1,Type=Integer,Description=\"Region ID for the comparison\">\n");
+    vcf.header("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n");
+
+    static const char *const gts[6] = {".", "0/0", "0/1", "0|1", "1|0", "1/1"};
+    const uint32_t n_contigs = avf_genome_n_contigs(g), k = b->n_inputs;
+    std::string all_tags; /* identical: every input is a source (:135-143) */
+    for (uint32_t i = 0; i < k; ++i) {
+        if (i) all_tags += ',';
+        all_tags += tags[i];
+    }
+    std::string rec, info;
+    for (uint64_t r = 0; r < b->n_regions; ++r) {
+        if (status[r] != 0) continue;
+        const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
+        if (c >= n_contigs) return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
+        const std::string chrom = avf_genome_name(g, c);
+        const uint8_t cls = classification[r];
+        const std::string reason = simplify(cls);
+        /* write_region (:293-311): 0-based start, end, "<reason>_<region id>" */
+        rec = chrom + '\t' + std::to_string(b->start[r]) + '\t' + std::to_string(b->end[r]) + '\t' + reason + '_' + std::to_string(b->region_id[r]) + '\n';
+        (cls == AVK_MERGE_DIFFERENT ? failed_bed : passing_bed).record(chrom, (int64_t)b->start[r], (int64_t)b->end[r], rec);
+        if (cls == AVK_MERGE_DIFFERENT) continue;
+        const std::vector<uint32_t> idx = member_indices(cls, members[r]);
+        const uint32_t source = cls == AVK_MERGE_IDENTICAL ? 0 : idx[0];
+        info = "SOURCES=";
+        if (cls == AVK_MERGE_IDENTICAL) info += all_tags;
+        else
+            for (size_t i = 0; i < idx.size(); ++i) {
+                if (i) info += ',';
+                info += tags[idx[i]];
+            }
+        info += ";MR=" + reason;
+        const uint64_t off = b->in_off[r * k + source];
+        const uint32_t cnt = b->in_cnt[r * k + source];
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint64_t v = off + i;
+            rec = chrom;
+            rec += '\t';
+            rec += std::to_string(b->var_pos[v] + 1);
+            rec += "\t.\t";
+            rec.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
+            rec += '\t';
+            rec.append((const char *)b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+            rec += "\t.\t.\t";
+            rec += info;
+            rec += "\tGT:RI\t";
+            rec += gts[b->var_zyg[v] < 6 ? b->var_zyg[v] : 0];
+            rec += ':';
+            rec += std::to_string((int32_t)b->region_id[r]); /* `region_id as i32` (:263) */
+            rec += '\n';
+            vcf.record(chrom, (int64_t)b->var_pos[v], (int64_t)b->var_pos[v] + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1), rec);
+        }
+    }
+    const std::string folder = out_folder;
+    if (!vcf.finish(folder + "/passing.vcf.gz", 2)) return avf_fail_(AVK_E_ARG, "write error on %s/passing.vcf.gz (or its .tbi)", out_folder);
+    if (!passing_bed.finish(folder + "/regions.bed.gz", 0x10000)) return avf_fail_(AVK_E_ARG, "write error on %s/regions.bed.gz (or its .tbi)", out_folder);
+    if (!failed_bed.finish(folder + "/failed_regions.bed.gz", 0x10000))
+        return avf_fail_(AVK_E_ARG, "write error on %s/failed_regions.bed.gz (or its .tbi)", out_folder);
+    return 0;
+}
+
+extern "C" int avf_write_merge_summary(const char *path, const avk_multi_batch *b, const char *const *tags, const int32_t *status,
+                                       const uint8_t *classification, const uint64_t *members) {
+    if (!path || !b || !tags || !status || !classification || !members) return avf_fail_(AVK_E_ARG, "null argument");
+    int rc = check_results(b, classification, members, status);
+    if (rc) return rc;
+    /* derive(Ord) of MergeClassification: Different < NoConflict{indices} < MajorityAgree{indices} < ConflictSelection{index} <
+     * BasepairIdentical, index lists compared lexicographically; then VariantType in declaration order; then the input */
+    static const int rank_of[5] = {0, 4, 1, 2, 3}; /* AVK_MERGE_* -> position in the enum */
+    static const char *const type_names[AVK_N_VARIANT_TYPES] = {"Snv", "Insertion", "Deletion", "Indel", "SvInsertion", "SvDeletion", "SvDuplication",
+                                                                 "SvInversion", "SvBreakend", "TrContraction", "TrExpansion", "Unknown"};
+    typedef std::tuple<int, std::vector<uint32_t>, uint8_t, uint32_t> Key;
+    std::map<Key, std::pair<uint64_t, uint64_t>> counts;
+    const uint32_t k = b->n_inputs;
+    for (uint64_t r = 0; r < b->n_regions; ++r) {
+        if (status[r] != 0) continue;
+        const uint8_t cls = classification[r];
+        const std::vector<uint32_t> idx = member_indices(cls, members[r]);
+        for (uint32_t i = 0; i < k; ++i) {
+            const bool passing = cls == AVK_MERGE_IDENTICAL || std::find(idx.begin(), idx.end(), i) != idx.end();
+            const uint64_t off = b->in_off[r * k + i];
+            for (uint32_t j = 0; j < b->in_cnt[r * k + i]; ++j) {
+                const uint8_t vt = b->var_type[off + j];
+                if (vt >= AVK_N_VARIANT_TYPES) return avf_fail_(AVK_E_ARG, "variant %llu has the unknown type %u", (unsigned long long)(off + j), vt);
+                std::pair<uint64_t, uint64_t> &e = counts[Key(rank_of[cls], idx, vt, i)];
+                (passing ? e.first : e.second) += 1;
+            }
+        }
+    }
+    const std::string p = path;
+    const char delim = p.size() >= 4 && p.compare(p.size() - 4, 4, ".csv") == 0 ? ',' : '\t';
+    std::string text;
+    const char *const columns[6] = {"merge_reason", "variant_type", "vcf_index", "vcf_label", "pass_variants", "fail_variants"};
+    for (int i = 0; i < 6; ++i) {
+        if (i) text += delim;
+        text += columns[i];
+    }
+    text += '\n';
+    static const uint8_t cls_of_rank[5] = {AVK_MERGE_DIFFERENT, AVK_MERGE_NO_CONFLICT, AVK_MERGE_MAJORITY_AGREE, AVK_MERGE_CONFLICT_SELECTION,
+                                           AVK_MERGE_IDENTICAL};
+    if (counts.empty()) text.clear(); /* the csv writer emits its header with the first row: no rows, empty file */
+    for (const auto &kv : counts) {
+        /* Display of MergeClassification (:18-39): the reason, then "_<i>" per index */
+        std::string reason = simplify(cls_of_rank[std::get<0>(kv.first)]);
+        for (uint32_t i : std::get<1>(kv.first)) reason += '_' + std::to_string(i);
+        const uint32_t input = std::get<3>(kv.first);
+        text += reason;
+        text += delim;
+        text += type_names[std::get<2>(kv.first)];
+        text += delim;
+        text += std::to_string(input);
+        text += delim;
+        text += avf_csv_field_(tags[input] ? tags[input] : "", delim);
+        text += delim;
+        text += std::to_string(kv.second.first);
+        text += delim;
+        text += std::to_string(kv.second.second);
+        text += '\n';
+    }
+    FILE *fp = fopen(path, "wb");
+    if (!fp) return avf_fail_(AVK_E_ARG, "cannot create %s", path);
+    const bool ok = fwrite(text.data(), 1, text.size(), fp) == text.size();
+    if (fclose(fp) != 0 || !ok) return avf_fail_(AVK_E_ARG, "write error on %s", path);
+    return 0;
+}

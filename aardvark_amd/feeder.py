@@ -75,6 +75,14 @@ def load_library():
     lib.avf_region_sequences_rows.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
                                               C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     lib.avf_table_close.argtypes = [vp]
+    from .merge import AvkMultiBatch
+    cpp = C.POINTER(C.c_char_p)
+    lib.avf_feed_merge.argtypes = [C.c_uint32, cpp, cpp, C.c_char_p, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    lib.avf_feed_multi_batch.restype = C.POINTER(AvkMultiBatch)
+    lib.avf_feed_multi_batch.argtypes = [vp]
+    lib.avf_write_merge_outputs.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(AvkMultiBatch), cpp,
+                                            C.POINTER(C.c_int32), u8p, C.POINTER(C.c_uint64)]
+    lib.avf_write_merge_summary.argtypes = [C.c_char_p, C.POINTER(AvkMultiBatch), cpp, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_uint64)]
     _lib = lib
     return lib
 
@@ -224,3 +232,62 @@ def write_debug_tables(summary_path, sequences_path, genome, batch, result, metr
             rc = lib.avf_region_summary_rows(h, genome.handle, C.byref(cb), 0, batch.n_regions, P(st, C.c_int32), P(gm, C.c_uint32))
         rc2 = lib.avf_table_close(h)
         _check(lib, rc or rc2)
+
+
+# ---- merge (src/main.rs run_merge: region generation over k VCFs, VariantMerger, MergeSummaryWriter) -----------------------------------
+def _strs(items):
+    arr = (C.c_char_p * len(items))(*[os.fsencode(x) if x is not None else None for x in items])
+    return arr
+
+
+def feed_merge(vcfs, regions_bed, genome, samples=None, min_variant_gap=50, enable_trimming=True):
+    """RegionIterator::new_merge_iterator + the iterator: a merge.MultiBatch plus provenance (Feed.batch is the MultiBatch)."""
+    from .merge import MultiBatch
+    lib = load_library()
+    h = C.c_void_p()
+    k = len(vcfs)
+    samples = list(samples or []) + [""] * (k - len(samples or []))
+    _check(lib, lib.avf_feed_merge(k, _strs(vcfs), _strs(samples), os.fsencode(regions_bed) if regions_bed else None, genome.handle, min_variant_gap,
+                                   1 if enable_trimming else 0, C.byref(h)))
+    try:
+        b = lib.avf_feed_multi_batch(h).contents
+        n, nv = int(b.n_regions), int(b.n_variants)
+        mb = MultiBatch(k, region_id=_arr(b.region_id, n, np.uint64), contig_idx=_arr(b.contig_idx, n, np.uint32), start=_arr(b.start, n, np.uint64),
+                        end=_arr(b.end, n, np.uint64), in_off=_arr(b.in_off, n * k, np.uint64), in_cnt=_arr(b.in_cnt, n * k, np.uint32),
+                        var_pos=_arr(b.var_pos, nv, np.uint64), var_type=_arr(b.var_type, nv, np.uint8), var_zyg=_arr(b.var_zyg, nv, np.uint8),
+                        var_raw_space=_arr(b.var_raw_space, nv, np.uint32), a0_off=_arr(b.a0_off, nv, np.uint64), a0_len=_arr(b.a0_len, nv, np.uint32),
+                        a1_off=_arr(b.a1_off, nv, np.uint64), a1_len=_arr(b.a1_len, nv, np.uint32),
+                        allele_bytes=_arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
+        return Feed(mb, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
+                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)))
+    finally:
+        lib.avf_feed_free(h)
+
+
+def _merge_args(mb, result):
+    st = np.ascontiguousarray(result.status, np.int32)
+    cls = np.ascontiguousarray(result.classification, np.uint8)
+    mem = np.ascontiguousarray(result.members, np.uint64)
+    if st.size == 0:
+        st, cls, mem = np.zeros(1, np.int32), np.zeros(1, np.uint8), np.zeros(1, np.uint64)
+    return st, cls, mem
+
+
+def write_merge_outputs(out_folder, primary_vcf, genome, mb, result, tags=None, sample_name="", version="aardvark_amd", command_line=""):
+    """passing.vcf.gz, regions.bed.gz, failed_regions.bed.gz (+ .tbi each) of `merge`; result = merge.MergeResult of `mb`"""
+    lib = load_library()
+    tags = list(tags) if tags else ["vcf_%d" % i for i in range(mb.n_inputs)]
+    st, cls, mem = _merge_args(mb, result)
+    cb = mb.c_struct()
+    _check(lib, lib.avf_write_merge_outputs(os.fsencode(out_folder), os.fsencode(primary_vcf), sample_name.encode(), version.encode(), command_line.encode(),
+                                            genome.handle, C.byref(cb), _strs(tags), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            cls.ctypes.data_as(C.POINTER(C.c_uint8)), mem.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+
+def write_merge_summary(path, mb, result, tags=None):
+    lib = load_library()
+    tags = list(tags) if tags else ["vcf_%d" % i for i in range(mb.n_inputs)]
+    st, cls, mem = _merge_args(mb, result)
+    cb = mb.c_struct()
+    _check(lib, lib.avf_write_merge_summary(os.fsencode(path), C.byref(cb), _strs(tags), st.ctypes.data_as(C.POINTER(C.c_int32)),
+                                            cls.ctypes.data_as(C.POINTER(C.c_uint8)), mem.ctypes.data_as(C.POINTER(C.c_uint64))))

@@ -98,43 +98,107 @@ class AvkMultiBatch(C.Structure):
                 ("a1_len", _p(C.c_uint32)), ("allele_bytes", _p(C.c_uint8)), ("allele_bytes_len", C.c_uint64)]
 
 
-def merge_batch(ctx, multi_regions, config=None):
-    """avk_merge_batch: all of solve_merge_region for a list of MultiRegion dicts (same number of inputs each) in one library
-    call — pairs on the GPU, classification on the host.  Same return shape as solve_merge_regions."""
+class MultiBatch:
+    """A batch of MultiRegions as flat numpy arrays (avk_multi_batch): input i of region m owns variants
+    [in_off[m*k + i], +in_cnt[m*k + i])."""
+
+    FIELDS = ("region_id", "contig_idx", "start", "end", "in_off", "in_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space",
+              "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes")
+    DTYPES = (np.uint64, np.uint32, np.uint64, np.uint64, np.uint64, np.uint32, np.uint64, np.uint8, np.uint8, np.uint32,
+              np.uint64, np.uint32, np.uint64, np.uint32, np.uint8)
+
+    def __init__(self, n_inputs, **arrays):
+        self.n_inputs = int(n_inputs)
+        for name, dt in zip(self.FIELDS, self.DTYPES):
+            setattr(self, name, np.ascontiguousarray(arrays[name], dtype=dt))
+        if self.allele_bytes.size == 0:
+            self.allele_bytes = np.zeros(1, np.uint8)
+        self.n_regions = int(self.region_id.size)
+        self.n_variants = int(self.var_pos.size)
+        assert self.in_off.size == self.n_regions * self.n_inputs and self.in_cnt.size == self.in_off.size
+
+    @classmethod
+    def from_regions(cls, multi_regions, n_inputs=None):
+        """MultiRegion dicts {start, end, inputs:[variants...][, contig, region_id]}, the same number of inputs each"""
+        n = len(multi_regions)
+        k = len(multi_regions[0]["inputs"]) if n else (n_inputs or 2)
+        assert all(len(mr["inputs"]) == k for mr in multi_regions), "regions of one batch must have the same number of inputs"
+        # flatten through RegionBatch: region m contributes one pseudo-region per input (its variants as "truth")
+        flat = RegionBatch.from_regions([{"start": mr["start"], "end": mr["end"], "contig": mr.get("contig", 0), "truth": inp, "query": []}
+                                         for mr in multi_regions for inp in mr["inputs"]])
+        return cls(k, region_id=[mr.get("region_id", m) for m, mr in enumerate(multi_regions)], contig_idx=[mr.get("contig", 0) for mr in multi_regions],
+                   start=[mr["start"] for mr in multi_regions], end=[mr["end"] for mr in multi_regions], in_off=flat.t_off, in_cnt=flat.t_cnt,
+                   var_pos=flat.var_pos, var_type=flat.var_type, var_zyg=flat.var_zyg, var_raw_space=flat.var_raw_space, a0_off=flat.a0_off,
+                   a0_len=flat.a0_len, a1_off=flat.a1_off, a1_len=flat.a1_len, allele_bytes=flat.allele_bytes)
+
+    def c_struct(self):
+        P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+        return AvkMultiBatch(self.n_regions, self.n_inputs, P(self.region_id, C.c_uint64), P(self.contig_idx, C.c_uint32), P(self.start, C.c_uint64),
+                             P(self.end, C.c_uint64), P(self.in_off, C.c_uint64), P(self.in_cnt, C.c_uint32), self.n_variants, P(self.var_pos, C.c_uint64),
+                             P(self.var_type, C.c_uint8), P(self.var_zyg, C.c_uint8), P(self.var_raw_space, C.c_uint32), P(self.a0_off, C.c_uint64),
+                             P(self.a0_len, C.c_uint32), P(self.a1_off, C.c_uint64), P(self.a1_len, C.c_uint32), P(self.allele_bytes, C.c_uint8),
+                             self.allele_bytes.size)
+
+    def regions(self):
+        """back to MultiRegion dicts (variants as (pos, ref, alt, type code, zygosity code, raw_space) tuples)"""
+        ab = self.allele_bytes.tobytes()
+        out = []
+        k = self.n_inputs
+        for m in range(self.n_regions):
+            inputs = []
+            for i in range(k):
+                o, c = int(self.in_off[m * k + i]), int(self.in_cnt[m * k + i])
+                inputs.append([(int(self.var_pos[v]), ab[int(self.a0_off[v]):int(self.a0_off[v]) + int(self.a0_len[v])],
+                                ab[int(self.a1_off[v]):int(self.a1_off[v]) + int(self.a1_len[v])], int(self.var_type[v]), int(self.var_zyg[v]),
+                                int(self.var_raw_space[v]))
+                               for v in range(o, o + c)])
+            out.append({"region_id": int(self.region_id[m]), "contig": int(self.contig_idx[m]), "start": int(self.start[m]), "end": int(self.end[m]),
+                        "inputs": inputs})
+        return out
+
+
+class MergeResult:
+    """status / classification (AVK_MERGE_*) / members per region, the outputs of avk_merge_batch"""
+
+    def __init__(self, status, classification, members, n_inputs):
+        self.status, self.classification, self.members, self.n_inputs = status, classification, members, n_inputs
+
+    def decoded(self):
+        """[(status, None) | (0, ("identical",) / ("no_conflict", indices) / ("majority", indices) / ("conflict_select", index) / ("different",))]"""
+        out = []
+        for m in range(len(self.status)):
+            if self.status[m] != 0:
+                out.append((int(self.status[m]), None))
+                continue
+            name = CLASSES[int(self.classification[m])]
+            if name in ("no_conflict", "majority"):
+                out.append((0, (name, [i for i in range(self.n_inputs) if (int(self.members[m]) >> i) & 1])))
+            elif name == "conflict_select":
+                out.append((0, (name, int(self.members[m]))))
+            else:
+                out.append((0, (name,)))
+        return out
+
+
+def merge_multi_batch(ctx, mb, config=None):
+    """avk_merge_batch on a MultiBatch: pairs on the GPU, classification on the host -> MergeResult"""
     config = config or MergeConfig()
-    n = len(multi_regions)
-    k = len(multi_regions[0]["inputs"]) if n else 2
-    # flatten through RegionBatch: region m contributes one pseudo-region per input (its variants as "truth")
-    flat = RegionBatch.from_regions([{"start": mr["start"], "end": mr["end"], "contig": mr.get("contig", 0), "truth": inp, "query": []}
-                                     for mr in multi_regions for inp in mr["inputs"]])
-    g = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
-    start = g([mr["start"] for mr in multi_regions], np.uint64)
-    end = g([mr["end"] for mr in multi_regions], np.uint64)
-    rid = g(range(n), np.uint64)
-    cidx = g([mr.get("contig", 0) for mr in multi_regions], np.uint32)
-    in_off, in_cnt = g(flat.t_off, np.uint64), g(flat.t_cnt, np.uint32)
-    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
-    mb = AvkMultiBatch(n, k, P(rid, C.c_uint64), P(cidx, C.c_uint32), P(start, C.c_uint64), P(end, C.c_uint64), P(in_off, C.c_uint64), P(in_cnt, C.c_uint32),
-                       flat.n_variants, P(flat.var_pos, C.c_uint64), P(flat.var_type, C.c_uint8), P(flat.var_zyg, C.c_uint8), P(flat.var_raw_space, C.c_uint32),
-                       P(flat.a0_off, C.c_uint64), P(flat.a0_len, C.c_uint32), P(flat.a1_off, C.c_uint64), P(flat.a1_len, C.c_uint32),
-                       P(flat.allele_bytes, C.c_uint8), flat.allele_bytes.size)
+    n = mb.n_regions
     cfg = AvkMergeConfig(config.max_branch_factor, int(config.no_conflict_enabled), int(config.majority_voting_enabled),
                          -1 if config.conflict_selection is None else int(config.conflict_selection))
     st = np.zeros(max(n, 1), np.int32)
     cls = np.zeros(max(n, 1), np.uint8)
     members = np.zeros(max(n, 1), np.uint64)
+    P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
+    cb = mb.c_struct()
     ctx.lib.avk_merge_batch.argtypes = [C.c_void_p, C.POINTER(AvkMultiBatch), C.POINTER(AvkMergeConfig), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
-    ctx._check(ctx.lib.avk_merge_batch(ctx.handle, C.byref(mb), C.byref(cfg), P(st, C.c_int32), P(cls, C.c_uint8), P(members, C.c_uint64)))
-    out = []
-    for m in range(n):
-        if st[m] != 0:
-            out.append((int(st[m]), None))
-            continue
-        name = CLASSES[int(cls[m])]
-        if name in ("no_conflict", "majority"):
-            out.append((0, (name, [i for i in range(k) if (int(members[m]) >> i) & 1])))
-        elif name == "conflict_select":
-            out.append((0, (name, int(members[m]))))
-        else:
-            out.append((0, (name,)))
-    return out
+    ctx._check(ctx.lib.avk_merge_batch(ctx.handle, C.byref(cb), C.byref(cfg), P(st, C.c_int32), P(cls, C.c_uint8), P(members, C.c_uint64)))
+    return MergeResult(st[:n], cls[:n], members[:n], mb.n_inputs)
+
+
+def merge_batch(ctx, multi_regions, config=None):
+    """avk_merge_batch: all of solve_merge_region for a list of MultiRegion dicts (same number of inputs each) in one library
+    call — pairs on the GPU, classification on the host.  Same return shape as solve_merge_regions."""
+    if not multi_regions:
+        return []
+    return merge_multi_batch(ctx, MultiBatch.from_regions(multi_regions), config).decoded()

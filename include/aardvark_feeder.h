@@ -9,6 +9,8 @@
  *                       parse_genotype / get_variant_type                     (:489-758)
  *                       and LoadedBed::preload_bed_file                       (src/parsing/noodles_helper.rs:48-86)
  *   avf_write_summary   SummaryWriter::write_summary                          (src/writers/summary.rs:163-395)
+ *   avf_feed_merge      RegionIterator::new_merge_iterator + the iterator     (src/parsing/region_generation.rs:129-192, :281-478)
+ *   avf_write_merge_*   VariantMerger, MergeSummaryWriter                     (src/writers/variant_merger.rs, merge_summary.rs)
  *
  * The feed hands out an avk_region_batch (include/aardvark_amd.h) whose regions carry the reference's region ids
  * and windows, ready for avk_compare_batch.
@@ -49,6 +51,13 @@ const avk_region_batch *avf_feed_batch(const avf_feed *f);
  * file, and the 1-based ALT index it came from */
 const uint64_t *avf_feed_var_record(const avf_feed *f);
 const uint32_t *avf_feed_var_alt_index(const avf_feed *f);
+/* Region generation for `merge` (RegionIterator::new_merge_iterator, region_generation.rs:129-192): the same walk over
+ * n_inputs VCFs (1..64), in priority order.  samples: NULL, or per input NULL / "" = that file's first sample
+ * (src/cli/merge.rs:196-198).  The feed hands out an avk_multi_batch for avk_merge_batch; avf_feed_batch is NULL for it
+ * (and avf_feed_multi_batch is NULL for a compare feed). */
+int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
+                   uint64_t min_variant_gap, int enable_trimming, avf_feed **out);
+const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f);
 /* variants loaded per input after parsing and the chromosome-span filter (the "Loaded N truth variants" log lines) */
 uint64_t avf_feed_loaded_variants(const avf_feed *f, int input);
 void avf_feed_free(avf_feed *f);
@@ -96,6 +105,27 @@ int avf_write_summary_stratified(const char *path, const char *compare_label, co
 int avf_write_annotated_vcf(const char *out_path, const char *input_vcf, const char *sample_name, const char *version, const char *command_line,
                             const avf_genome *g, const avk_region_batch *batch, int source, const int32_t *status, const uint8_t *var_expected,
                             const uint8_t *var_observed, const uint8_t *var_class);
+
+/* ---- outputs of `merge` ---------------------------------------------------------------------------------------------------
+ * avf_write_merge_outputs = VariantMerger (src/writers/variant_merger.rs:47-349) over a whole job: creates out_folder and in it
+ *   passing.vcf.gz          header of primary_vcf (input 0) + aardvark_version / aardvark_command + INFO SOURCES, MR + FORMAT RI,
+ *                           one sample column (sample_name, or the first sample of primary_vcf when empty); for every solved
+ *                           region that is not `different`, the variants of its source input (lowest member index of
+ *                           no_conflict / majority, the selected index, input 0 for identical; :167-173) as
+ *                             CHROM POS . REF ALT . . SOURCES=<tags of the members>;MR=<reason>  GT:RI  gt:region_id
+ *   regions.bed.gz          CHROM start end <reason>_<region_id> of those regions
+ *   failed_regions.bed.gz   the same for the `different` regions
+ * each with a tabix index next to it (index_merger, :316-349).  Regions whose status is not 0 are written nowhere (main.rs:517-519).
+ * tags[i] = the annotation tag of input i (--vcf-tag, default "vcf_<i>"); status / classification / members are the outputs of
+ * avk_merge_batch for `batch`. */
+int avf_write_merge_outputs(const char *out_folder, const char *primary_vcf, const char *sample_name, const char *version, const char *command_line,
+                            const avf_genome *g, const avk_multi_batch *batch, const char *const *tags, const int32_t *status,
+                            const uint8_t *classification, const uint64_t *members);
+/* MergeSummaryWriter (src/writers/merge_summary.rs): pass / fail variant counts per (merge reason with its indices, variant type,
+ * input), rows in the reference's key order (BTreeMap over (MergeClassification, VariantType, vcf_index)); columns merge_reason,
+ * variant_type, vcf_index, vcf_label, pass_variants, fail_variants.  A path ending in .csv is comma separated. */
+int avf_write_merge_summary(const char *path, const avk_multi_batch *batch, const char *const *tags, const int32_t *status,
+                            const uint8_t *classification, const uint64_t *members);
 
 /* ---- the debug tables of --output-debug, both BGZF-compressed tab-separated text, rows appended batch by batch ----------------
  * region_summary.tsv.gz   (RegionSummaryWriter, src/writers/region_summary.rs): one row per metric kind of metrics_mask and solved

@@ -145,10 +145,12 @@ def load_calls(path, sample, enable_trimming=True):
     return calls
 
 
-def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
-    """RegionIterator::next (:281-478) -> list of region dicts (region_id, contig index, chrom, start, end, truth, query)."""
+def generate_multi_regions(calls_list, bed, contigs, gap=50):
+    """RegionIterator::next (:281-478) over k inputs -> list of region dicts (region_id, contig index, chrom, start, end,
+    inputs = one call list per input) and the per-input loaded counts."""
+    k = len(calls_list)
     names = [n for n, _ in contigs]
-    regions, next_id, loaded = [], 0, [0, 0]
+    regions, next_id, loaded = [], 0, [0] * k
     for chrom, intervals in bed.items():
         if chrom not in names:
             raise ValueError("Chromosome %s was not found in reference genome" % chrom)
@@ -156,7 +158,7 @@ def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
         chrom_length = len(contigs[ci][1])
         zb_start, zb_end = intervals[0][0] - 1, intervals[-1][1]
         joint = []
-        for inp, calls in enumerate((truth_calls, query_calls)):
+        for inp, calls in enumerate(calls_list):
             for c in calls.get(chrom, []):
                 last = c["pos"] + len(c["a0"]) - 1
                 if zb_start <= c["pos"] < zb_end and zb_start <= last < zb_end:  # is_variant_contained (:764-778)
@@ -166,7 +168,7 @@ def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
         head = 0
         for (s1, e1) in intervals:
             ib, ie = s1 - 1, e1
-            variants = [[], []]
+            variants = [[] for _ in range(k)]
             ws = we = None
             while head < len(joint):
                 inp, c = joint[head]
@@ -180,9 +182,9 @@ def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
                 if ve > ie:
                     continue
                 if we is not None and vs >= we:
-                    regions.append(dict(region_id=next_id, contig=ci, chrom=chrom, start=ws, end=we, truth=variants[0], query=variants[1]))
+                    regions.append(dict(region_id=next_id, contig=ci, chrom=chrom, start=ws, end=we, inputs=variants))
                     next_id += 1
-                    variants = [[], []]
+                    variants = [[] for _ in range(k)]
                     ws = None
                 if ws is None:
                     ws = max(vs - gap, 0)
@@ -190,9 +192,16 @@ def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
                 we = flank_end if we is None else max(we, flank_end)
                 variants[inp].append(c)
             if ws is not None and we is not None:
-                regions.append(dict(region_id=next_id, contig=ci, chrom=chrom, start=ws, end=we, truth=variants[0], query=variants[1]))
+                regions.append(dict(region_id=next_id, contig=ci, chrom=chrom, start=ws, end=we, inputs=variants))
                 next_id += 1
     return regions, loaded
+
+
+def generate_regions(truth_calls, query_calls, bed, contigs, gap=50):
+    """The compare iterator (:61-122): the same walk over (truth, query) -> region dicts with truth / query lists."""
+    multi, loaded = generate_multi_regions([truth_calls, query_calls], bed, contigs, gap)
+    return [dict(region_id=m["region_id"], contig=m["contig"], chrom=m["chrom"], start=m["start"], end=m["end"], truth=m["inputs"][0], query=m["inputs"][1])
+            for m in multi], loaded
 
 
 def ryu(x):
