@@ -1,0 +1,73 @@
+"""Large parity sweep on the GPU box: many seeds x generator settings, every output array of the GPU path (through the C-ABI)
+against the oracle.  Prints one line per case and a total; exits non-zero on the first difference (the failing case's seed and
+settings are in the line).  BUDGET_S bounds the wall time."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import aardvark_amd
+from aardvark_amd import synth, CompareConfig
+import oracle_lib
+import scenarios
+
+budget = float(os.environ.get("BUDGET_S", "600"))
+lib = oracle_lib.load()
+ctx = aardvark_amd.Context(0)
+for kv in os.environ.get("AVK_OPTS", "").split(","):
+    if "=" in kv:
+        k, v = kv.split("=")
+        ctx.set_option(k, int(v))
+t_start = time.time()
+total = 0
+cases = 0
+
+
+def check(name, contigs, batch, sequences=True, mbf=50):
+    global total, cases
+    t0 = time.time()
+    want = oracle_lib.compare_batch(lib, batch, contigs, sequences=sequences, threads=os.cpu_count(), max_branch_factor=mbf)
+    t1 = time.time()
+    ctx.upload_reference(contigs)
+    got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=sequences, max_branch_factor=mbf))
+    t2 = time.time()
+    d = got.diff(want)
+    total += batch.n_regions
+    cases += 1
+    print("%-70s %8d regions  oracle %.2fs gpu %.2fs  tiers %s  status!=0: %d  %s" % (name, batch.n_regions, t1 - t0, t2 - t1, ctx.last_tier_counts(),
+                                                                                  int((want.status != 0).sum()), "OK" if not d else "DIFF " + str(d)), flush=True)
+    if d:
+        n = batch.n_regions
+        bad = np.nonzero((got.status != want.status) | (got.ed_h1 != want.ed_h1) | (got.ed_h2 != want.ed_h2) |
+                         (got.group_metrics.reshape(n, -1) != want.group_metrics.reshape(n, -1)).any(axis=1))[0]
+        print("bad regions:", bad[:20].tolist(), len(bad))
+        sys.exit(1)
+
+
+FUZZ = [dict(), dict(repeat_unit=b"CAG", max_vars=6), dict(max_len=20, span=(30, 260)), dict(max_vars=9, span=(40, 200)), dict(related=0.95, max_vars=7),
+        dict(repeat_unit=b"A", max_vars=5, max_len=12), dict(repeat_unit=b"AT", max_vars=8, span=(20, 120)), dict(alphabet=b"AC", max_vars=6),
+        dict(max_vars=12, span=(60, 300), related=0.9), dict(max_len=40, span=(100, 400), max_vars=4), dict(alphabet=b"ACGTNacgt", max_vars=5),
+        dict(max_vars=3, span=(12, 40)), dict(repeat_unit=b"GGC", max_vars=10, span=(50, 250), related=0.9)]
+rnd = 0
+while time.time() - t_start < budget:
+    for i, kw in enumerate(FUZZ):
+        if time.time() - t_start > budget:
+            break
+        seed = 1000 + 100 * rnd + i
+        contigs, batch = scenarios.fuzz_regions(seed, int(os.environ.get("FUZZ_N", "20000")), **kw)
+        check("fuzz seed %d %s" % (seed, kw), contigs, batch, mbf=(50, 50, 7, 2)[rnd % 4])
+    # call-set shaped cases: SNV + indel truth, queries perturbed at several error levels
+    for j, (drop, flip, change, extra) in enumerate(((0.01, 0.005, 0.005, 2000), (0.1, 0.05, 0.05, 20000), (0.3, 0.2, 0.2, 60000))):
+        if time.time() - t_start > budget:
+            break
+        seed = 5000 + 10 * rnd + j
+        length = 20_000_000
+        contig = synth.make_contig(length, seed)
+        rng = np.random.default_rng(seed + 1)
+        bed = synth.make_bed(length, 300, 0.9, rng)
+        truth = synth.indel_truth(contig, bed, 150_000, seed + 2, snv_frac=(0.82, 0.6, 0.4)[j], close_frac=(0.03, 0.1, 0.2)[j], str_frac=(0.05, 0.1, 0.15)[j])
+        query = synth.perturb_query(contig, bed, truth, seed + 3, extra, drop, flip, change)
+        batch = synth.cluster_regions(length, bed, truth, query, (50, 20, 120)[rnd % 3])
+        check("callset seed %d drop %.2f flip %.2f change %.2f extra %d gap %d" % (seed, drop, flip, change, extra, (50, 20, 120)[rnd % 3]), [contig], batch,
+              sequences=(rnd % 2 == 0))
+    rnd += 1
+print("ALL OK: %d cases, %d regions in %.0f s" % (cases, total, time.time() - t_start))
