@@ -120,6 +120,13 @@ struct AvkKernelArgs {
     uint32_t high_priority;    /* raise the wave priority (the solo launch of the predicted-hard regions) */
     uint32_t *overflow_list;   /* regions that exhausted this pass's tiers */
     uint32_t *overflow_count;
+    /* A second work source, taken one record at a time once the launch's own list is exhausted: records extra_base ..
+     * extra_base + extra_n - 1, ticket counter extra_counter.  The HBM launch of the main stream shares the class C list
+     * (and its counter) with the HBM solo launch this way: whatever the solo launch has not started when the bulk is done
+     * is spread over the whole chip. */
+    uint32_t *extra_counter;
+    uint32_t extra_base;
+    uint32_t extra_n;
     /* workspaces */
     uint8_t *hbm_ws;           /* n_waves slices of tier[2] (or tier[3]) bytes */
     /* in-place escalation of the HBM launch: a region that outgrows its wave's tier-2 slice is solved again at once in one of

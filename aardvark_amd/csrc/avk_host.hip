@@ -127,7 +127,7 @@ struct avk_ctx {
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
-    int64_t class_c_nodes_x2 = 8; /* a region is sent to the HBM solo launch when 0.5 x this x N nodes outgrow a tier-1 slice */
+    int64_t class_c_nodes_x2 = 12; /* a region is sent to the HBM solo launch when 0.5 x this x N nodes outgrow a tier-1 slice */
     int64_t solo_regions_per_wave = 4; /* predicted-hard regions beyond solo waves x this lead the bulk list */
     int64_t accumulate_tally = 0; /* avk_compare_resident adds to the caller's device tally instead of overwriting it */
     int64_t lds_escalation = 1; /* in-workgroup escalation of the bulk launch (AvkKernelArgs::esc_bytes) */
@@ -543,7 +543,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     uint32_t blocks = (uint32_t)((want_waves + waves_per_block - 1) / waves_per_block);
     if (blocks == 0) blocks = 1;
     const uint32_t n_waves = blocks * waves_per_block;
-    const size_t ws_need = (size_t)n_waves * (size_t)ctx->ws_bytes_per_wave;
+    /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
+    const uint32_t hbm_solo_max = 64;
+    const size_t ws_need = (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
     if (ws_need > ctx->ws_alloc) {
         if (ctx->d_ws) {
             AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -638,10 +640,14 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.overflow_count = nullptr;
         }
         const bool first_launch = list == nullptr; /* ev0 sits right before it */
-        if (t >= 2) { /* the HBM launches read the list the solo launches append to and share the HBM slices; the tier-1 launch does not */
+        if (t >= 2) { /* the HBM launches read the list the LDS solo launch appends to; the tier-1 launch does not */
             if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
-            if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
-            solo_pending = hbm_solo_pending = false;
+            solo_pending = false;
+            /* the tier-3 launch of its own (big_slots == 0) reads the list the HBM solo launch appends to */
+            if (t == 3 && hbm_solo_pending) {
+                AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
+                hbm_solo_pending = false;
+            }
         }
         a.n_work = (uint32_t)n;
         a.high_priority = 0;
@@ -674,7 +680,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             }
             if (n_c) {
                 hbm_solo = (n_c + 7) / 8;
-                if (hbm_solo > 64) hbm_solo = 64;
+                if (hbm_solo > hbm_solo_max) hbm_solo = hbm_solo_max;
                 if (hbm_solo > blocks / 8) hbm_solo = blocks / 8;
             }
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
@@ -691,7 +697,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 s.claim = 1;
                 s.n_waves = hbm_solo * waves_per_block;
                 s.high_priority = 1;
-                s.hbm_ws = ctx->d_ws; /* the later HBM launch of the main stream reuses these slices after the join */
+                s.hbm_ws = ctx->d_ws + (size_t)n_waves * (size_t)ctx->ws_bytes_per_wave; /* its own slices: the main stream's HBM launch may run beside it */
                 s.big_ws = ctx->d_big;
                 s.big_busy = db->d_counters + 1088;
                 s.big_slots = big_slots;
@@ -753,6 +759,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.big_busy = db->d_counters + 1088;
             a.big_slots = big_slots;
             a.n_waves = blocks * waves_per_block;
+            if (hbm_solo_pending) { /* class C records the solo launch has not started yet: every wave of this launch helps (same ticket counter) */
+                a.extra_counter = db->d_counters + 1076;
+                a.extra_base = 0;
+                a.extra_n = db->plan.n_hbm;
+            }
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(blocks), dim3(256), 0, ctx->stream, a);
         } else {
             a.hbm_ws = ctx->d_big;
@@ -761,6 +772,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
         }
         AVK_HIP(ctx, hipGetLastError());
+        a.extra_counter = nullptr;
+        a.extra_n = 0;
         if (first_launch) AVK_HIP(ctx, hipEventRecord(ctx->evk1, ctx->stream));
 
         if (t != last) {

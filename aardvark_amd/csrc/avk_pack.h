@@ -336,7 +336,7 @@ struct WorkPlan {
 };
 
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
-                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 8) {
+                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk */

@@ -1802,6 +1802,7 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             for (u32 t = wg_word(wg_ctl); t != 0; t = wg_word(wg_ctl)) wg_park(wg_ctl, wave_in_wg, t);
         }
         u32 idx = 0;
+        bool have = true;
         if (static_next < n_static) {
             idx = static_next;
             static_next += a.n_waves;
@@ -1828,13 +1829,28 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
                         shard_i += 1;
                     }
                 }
-                if (!got) break;
+                have = got;
             }
-            idx = claim_base;
-            claim_base += 1;
-            claim_left -= 1;
+            if (have) {
+                idx = claim_base;
+                claim_base += 1;
+                claim_left -= 1;
+            }
         }
-        const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : a.work_base + idx; /* index of the RECORD (work order) */
+        u32 r; /* index of the RECORD (work order) */
+        if (have) {
+            r = a.work_list ? wv_uni(a.work_list[idx]) : a.work_base + idx;
+        } else { /* the launch's own list is done: the shared list (AvkKernelArgs::extra_counter), one record per ticket */
+            if (a.extra_n == 0) break;
+            u32 b = 0xFFFFFFFFu;
+            if (lane == 0) {
+                const u32 seen = avk_ld_agent_u32(a.extra_counter);
+                if (seen < a.extra_n) b = avk_atomic_add_u32_global(a.extra_counter, 1u);
+            }
+            b = wv_uni(wv_shfl(b, 0));
+            if (b == 0xFFFFFFFFu || b >= a.extra_n) break;
+            r = a.extra_base + b;
+        }
         const AvkDevRegion reg = a.regions[r];
         const u32 orig = wv_uni(reg.orig); /* where the caller's batch has this region: outputs go there */
         const u32 pre = wv_uni(reg.pre_status) & 0xFFFFu;

@@ -328,11 +328,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint8_t> big_slices(big_slots ? (size_t)big_slots * big_ws_bytes : 0);
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
-    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order);
+    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
+                                                    getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u);
     const std::vector<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     a.regions = sorted.data();
     const uint32_t *list = nullptr, *count = nullptr;
     int nlist = 0;
+    uint32_t hbm_shared = 0; /* length of the class C list the HBM launches share */
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -356,7 +358,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             a.overflow_count = nullptr;
         }
         const uint32_t todo = count ? *count : (uint32_t)n;
-        if (todo) {
+        if (todo || (t == 2 && hbm_shared)) {
             if (t == 0) {
                 /* the three concurrent launches of run_internal, one after the other: HBM solo (class C), LDS solo (class B), bulk */
                 const bool solo_ok = solo_min_variants != 0;
@@ -364,7 +366,11 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 const uint32_t n_front = plan.n_hbm + plan.n_hard - n_c;
                 const int solo_list = launch[1] ? 1 : 0;
                 const bool later = last > solo_list;
-                if (n_c) {
+                /* AVK_EMU_SKIP_HBM_SOLO=1 (tests): the solo launch starts nothing, so the whole class C list is left to the shared
+                 * ticket counter of the main HBM pass — the state of a GPU run whose bulk finished before the solo launch got going */
+                const bool skip_hbm_solo = getenv("AVK_EMU_SKIP_HBM_SOLO") != nullptr;
+                hbm_shared = n_c;
+                if (n_c && !skip_hbm_solo) {
                     AvkKernelArgs keep = a;
                     a.pass_tier = 2;
                     a.work_base = 0;
@@ -420,7 +426,14 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 a.big_ws = big_slots ? big_slices.data() : nullptr;
                 a.big_busy = counters + 1088;
                 a.big_slots = big_slots;
+                if (hbm_shared) { /* run_internal: the class C list is shared with the HBM solo launch through its ticket counter */
+                    a.extra_counter = counters + 1076;
+                    a.extra_base = 0;
+                    a.extra_n = hbm_shared;
+                }
                 run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
+                a.extra_counter = nullptr;
+                a.extra_n = 0;
             }
             else run_pass(todo < 4 ? todo : 4, big_ws_bytes, 0);
         }

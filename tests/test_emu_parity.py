@@ -128,3 +128,21 @@ def test_hidden_exact_shortcut(oracle):
         assert got.diff(want) == []
         plain = oracle_lib.compare_batch(oracle, batch, contigs, sequences=True, threads=4)
         assert want.diff(plain) != []  # the shortcut really changes the metrics (no RECORD_BP, fewer type entries)
+
+
+def test_class_c_list_shared_between_the_hbm_launches(oracle, monkeypatch):
+    """the records predicted to outgrow tier 1 are taken ticket by ticket from one counter by the HBM solo launch and by the main
+    stream's HBM launch: every split of the list between the two gives the same results (here: all to one, all to the other),
+    at thresholds that put almost nothing / a fifth of the batch into the list"""
+    contigs, batch = scenarios.indel_small(4000)
+    want = oracle_lib.compare_batch(oracle, batch, contigs, threads=8)
+    seen = set()
+    for skip in (False, True):
+        for c in ("6", "12", "40"):
+            monkeypatch.setenv("AVK_EMU_CLASS_C", c)
+            if skip:
+                monkeypatch.setenv("AVK_EMU_SKIP_HBM_SOLO", "1")
+            got = emu_lib.compare_batch(batch, contigs, threads=8)
+            assert got.diff(want) == []
+            seen.add(got.tier_counts[2])
+    assert max(seen) > 500 and min(seen) < 50
