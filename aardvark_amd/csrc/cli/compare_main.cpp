@@ -87,10 +87,38 @@ int main(int argc, char **argv) {
     if (mkdir(out_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create output folder", out_dir.c_str());
     if (!debug_dir.empty() && mkdir(debug_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create debug folder", debug_dir.c_str());
 
+    /* the reference genome, the two call sets and the GPU context come up side by side */
     auto t0 = std::chrono::steady_clock::now();
     avf_genome *genome = nullptr;
-    if (avf_genome_load(ref.c_str(), &genome)) die(74, "Error while loading reference genome", avf_last_error());
+    avf_calls *calls[2] = {nullptr, nullptr};
+    avk_ctx *ctx = nullptr;
+    int rc_calls[2] = {0, 0}, rc_ctx = 0;
+    std::string err_calls[2], err_ctx;
+    double s_calls[2] = {0, 0}, s_ctx = 0;
+    std::thread th_calls[2], th_ctx;
+    for (int i = 0; i < 2; ++i)
+        th_calls[i] = std::thread([&, i] {
+            const auto t = std::chrono::steady_clock::now();
+            rc_calls[i] = avf_calls_load(i == 0 ? truth.c_str() : query.c_str(), i == 0 ? truth_sample.c_str() : query_sample.c_str(), trimming ? 1 : 0, &calls[i]);
+            if (rc_calls[i]) err_calls[i] = avf_last_error(); /* the error text is per thread */
+            s_calls[i] = seconds_since(t);
+        });
+    th_ctx = std::thread([&] {
+        const auto t = std::chrono::steady_clock::now();
+        rc_ctx = avk_ctx_create(device, &ctx);
+        if (rc_ctx) err_ctx = avk_last_error(nullptr);
+        s_ctx = seconds_since(t);
+    });
+    const int rc_genome = avf_genome_load(ref.c_str(), &genome);
+    const std::string err_genome = rc_genome ? avf_last_error() : "";
     const double s_genome = seconds_since(t0);
+    for (std::thread &t : th_calls) t.join();
+    th_ctx.join();
+    if (rc_genome) die(74, "Error while loading reference genome", err_genome.c_str());
+    for (int i = 0; i < 2; ++i)
+        if (rc_calls[i]) die(74, "Error while building regions", err_calls[i].c_str());
+    if (rc_ctx) die(70, "cannot create the GPU context", err_ctx.c_str());
+    const double s_load = seconds_since(t0);
 
     avf_strat *strat = nullptr;
     if (!strat_tsv.empty() && avf_strat_load(strat_tsv.c_str(), &strat)) die(74, "Error while loading stratifications", avf_last_error());
@@ -98,16 +126,15 @@ int main(int argc, char **argv) {
 
     t0 = std::chrono::steady_clock::now();
     avf_feed *feed = nullptr;
-    if (avf_feed_compare(truth.c_str(), truth_sample.c_str(), query.c_str(), query_sample.c_str(), bed.c_str(), genome, gap, trimming ? 1 : 0, &feed))
-        die(74, "Error while building regions", avf_last_error());
+    if (avf_feed_from_calls(2, calls, bed.c_str(), genome, gap, 0, &feed)) die(74, "Error while building regions", avf_last_error());
+    avf_calls_free(calls[0]);
+    avf_calls_free(calls[1]);
     const avk_region_batch *all = avf_feed_batch(feed);
     const double s_feed = seconds_since(t0);
     fprintf(stderr, "Loaded %llu truth and %llu query variants; %llu regions.\n", (unsigned long long)avf_feed_loaded_variants(feed, 0),
             (unsigned long long)avf_feed_loaded_variants(feed, 1), (unsigned long long)all->n_regions);
 
     t0 = std::chrono::steady_clock::now();
-    avk_ctx *ctx = nullptr;
-    if (avk_ctx_create(device, &ctx)) die(70, "cannot create the GPU context", avk_last_error(nullptr));
     const uint32_t n_contigs = avf_genome_n_contigs(genome);
     std::vector<const uint8_t *> seqs(n_contigs);
     std::vector<uint64_t> lens(n_contigs);
@@ -239,8 +266,9 @@ int main(int argc, char **argv) {
     const double s_write = seconds_since(t0);
 
     fprintf(stderr, "Solved:error blocks: %llu : %llu\n", (unsigned long long)total[AVK_TALLY_LEN - 2], (unsigned long long)total[AVK_TALLY_LEN - 1]);
-    fprintf(stderr, "stages [s]: reference %.3f, feeder %.3f, gpu context + reference upload %.3f, solve (pack + H2D + kernels + D2H) %.3f, summary + annotated VCFs %.3f\n",
-            s_genome, s_feed, s_ref, s_solve, s_write);
+    fprintf(stderr, "stages [s]: load %.3f (side by side: reference %.3f, truth calls %.3f, query calls %.3f, gpu context %.3f), regions %.3f, reference upload %.3f, "
+                    "solve (pack + H2D + kernels + D2H) %.3f, summary + annotated VCFs %.3f\n",
+            s_load, s_genome, s_calls[0], s_calls[1], s_ctx, s_feed, s_ref, s_solve, s_write);
     fprintf(stderr, "Comparisons completed in %.3f seconds (%.2f M regions/s in the solve stage).\n", seconds_since(t_start),
             s_solve > 0 ? (double)count / s_solve / 1e6 : 0.0);
     avk_ctx_destroy(ctx);

@@ -5,11 +5,13 @@
  * (+ .tbi each) and the summary table.  Option names are the reference's (src/cli/merge.rs).
  */
 #include <cerrno>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <sys/stat.h>
@@ -132,22 +134,48 @@ int main(int argc, char **argv) {
     if (batch_regions == 0) batch_regions = 1;
     if (threads == 0) threads = 1;
 
+    /* the reference genome, the call sets and the GPU context come up side by side */
     auto t0 = std::chrono::steady_clock::now();
-    avf_genome *genome = nullptr;
-    if (avf_genome_load(ref.c_str(), &genome)) die(74, "Error while loading reference genome", avf_last_error());
-    const double s_genome = seconds_since(t0);
-
-    t0 = std::chrono::steady_clock::now();
     const uint32_t k = (uint32_t)vcfs.size();
-    std::vector<const char *> vcf_ptrs(k), sample_ptrs(k), tag_ptrs(k);
+    std::vector<const char *> sample_ptrs(k), tag_ptrs(k);
     for (uint32_t i = 0; i < k; ++i) {
-        vcf_ptrs[i] = vcfs[i].c_str();
         sample_ptrs[i] = i < samples.size() ? samples[i].c_str() : "";
         tag_ptrs[i] = tags[i].c_str();
     }
+    avf_genome *genome = nullptr;
+    std::vector<avf_calls *> calls(k, nullptr);
+    std::vector<int> rc_calls(k, 0);
+    std::vector<std::string> err_calls(k);
+    avk_ctx *ctx = nullptr;
+    int rc_ctx = 0;
+    std::string err_ctx;
+    std::atomic<uint32_t> next_vcf{0};
+    auto load_calls = [&] {
+        for (uint32_t i = next_vcf.fetch_add(1); i < k; i = next_vcf.fetch_add(1)) {
+            rc_calls[i] = avf_calls_load(vcfs[i].c_str(), sample_ptrs[i], trimming ? 1 : 0, &calls[i]);
+            if (rc_calls[i]) err_calls[i] = avf_last_error(); /* the error text is per thread */
+        }
+    };
+    std::vector<std::thread> pool;
+    for (uint32_t t = 0; t < (k < 8 ? k : 8u); ++t) pool.emplace_back(load_calls);
+    pool.emplace_back([&] {
+        rc_ctx = avk_ctx_create(device, &ctx);
+        if (rc_ctx) err_ctx = avk_last_error(nullptr);
+    });
+    const int rc_genome = avf_genome_load(ref.c_str(), &genome);
+    const std::string err_genome = rc_genome ? avf_last_error() : "";
+    const double s_genome = seconds_since(t0);
+    for (std::thread &t : pool) t.join();
+    if (rc_genome) die(74, "Error while loading reference genome", err_genome.c_str());
+    for (uint32_t i = 0; i < k; ++i)
+        if (rc_calls[i]) die(74, "Error while building region iterator", err_calls[i].c_str());
+    if (rc_ctx) die(70, "cannot create the GPU context", err_ctx.c_str());
+    const double s_load = seconds_since(t0);
+
+    t0 = std::chrono::steady_clock::now();
     avf_feed *feed = nullptr;
-    if (avf_feed_merge(k, vcf_ptrs.data(), sample_ptrs.data(), bed.c_str(), genome, gap, trimming ? 1 : 0, &feed))
-        die(74, "Error while building region iterator", avf_last_error());
+    if (avf_feed_from_calls(k, calls.data(), bed.c_str(), genome, gap, 1, &feed)) die(74, "Error while building region iterator", avf_last_error());
+    for (avf_calls *c : calls) avf_calls_free(c);
     const avk_multi_batch *all = avf_feed_multi_batch(feed);
     const double s_feed = seconds_since(t0);
     for (uint32_t i = 0; i < k; ++i)
@@ -184,8 +212,6 @@ int main(int argc, char **argv) {
     }
 
     t0 = std::chrono::steady_clock::now();
-    avk_ctx *ctx = nullptr;
-    if (avk_ctx_create(device, &ctx)) die(70, "cannot create the GPU context", avk_last_error(nullptr));
     const uint32_t n_contigs = avf_genome_n_contigs(genome);
     std::vector<const uint8_t *> seqs(n_contigs);
     std::vector<uint64_t> lens(n_contigs);
@@ -247,8 +273,9 @@ int main(int argc, char **argv) {
         die(74, "Error while saving summary file", avf_last_error());
     const double s_write = seconds_since(t0);
 
-    fprintf(stderr, "stages [s]: reference %.3f, feeder %.3f, gpu context + reference upload %.3f, solve (pack + H2D + kernels + D2H + classify) %.3f, outputs %.3f\n",
-            s_genome, s_feed, s_ref, s_solve, s_write);
+    fprintf(stderr, "stages [s]: load %.3f (reference %.3f beside the call sets and the gpu context), regions %.3f, reference upload %.3f, "
+                    "solve (pack + H2D + kernels + D2H + classify) %.3f, outputs %.3f\n",
+            s_load, s_genome, s_feed, s_ref, s_solve, s_write);
     fprintf(stderr, "Merge completed in %.3f seconds.\n", seconds_since(t_start));
     avk_ctx_destroy(ctx);
     avf_feed_free(feed);

@@ -5,16 +5,25 @@
  */
 #include "../../../include/aardvark_feeder.h"
 
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <atomic>
 #include <charconv>
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -122,9 +131,21 @@ bool parse_u64(const std::string &s, uint64_t &v) {
 } // namespace
 
 /* ------------------------------------------------------------------------------------------ genome */
+/* a byte vector whose resize() leaves the new bytes uninitialised (the parallel FASTA loader fills them from several threads) */
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+typedef std::vector<uint8_t, NoInitAlloc<uint8_t>> SeqBytes;
+
 struct avf_genome {
     std::vector<std::string> names;
-    std::vector<std::vector<uint8_t>> seqs;
+    std::vector<SeqBytes> seqs;
     std::unordered_map<std::string, uint32_t> index;
 };
 
@@ -134,9 +155,10 @@ struct avf_feed {
     bool is_merge = false;
     avk_region_batch batch;      /* compare feeds */
     avk_multi_batch multi;       /* merge feeds */
-    std::vector<uint64_t> region_id, start, end, in_off, t_off, q_off, var_pos, a0_off, a1_off, var_record;
-    std::vector<uint32_t> contig_idx, in_cnt, t_cnt, q_cnt, var_raw, a0_len, a1_len, var_alt;
-    std::vector<uint8_t> var_type, var_zyg, alleles;
+    /* resize() of these leaves new elements uninitialised: the chromosomes' parts are copied in by several threads */
+    std::vector<uint64_t, NoInitAlloc<uint64_t>> region_id, start, end, in_off, t_off, q_off, var_pos, a0_off, a1_off, var_record;
+    std::vector<uint32_t, NoInitAlloc<uint32_t>> contig_idx, in_cnt, t_cnt, q_cnt, var_raw, a0_len, a1_len, var_alt;
+    std::vector<uint8_t, NoInitAlloc<uint8_t>> var_type, var_zyg, alleles;
     std::vector<uint64_t> loaded;
 };
 
@@ -230,11 +252,128 @@ int variant_type_of(const std::string &svtype, bool has_svtype, bool has_trid, s
 
 /* All calls of one sample on every chromosome: parse_variant + parse_genotype (region_generation.rs:563-712).
  * calls[chrom] keeps file order. */
-int load_vcf(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls) {
+/* per-thread scratch of the record parser */
+struct VcfScratch {
+    std::vector<std::string> f, alts, fmt, sv, info;
+};
+
+/* the #CHROM line: which column holds the sample */
+int vcf_sample_column(const char *path, const std::string &line, const char *sample, VcfScratch &w, long &sample_col) {
+    split(line, '\t', w.f);
+    if (w.f.size() < 10) return fail(AVK_E_ARG, "%s has no sample columns", path);
+    sample_col = -1;
+    if (!sample || !*sample) sample_col = 9; /* get_vcf_sample_name(.., 0) */
+    else {
+        for (size_t k = 9; k < w.f.size(); ++k)
+            if (w.f[k] == sample) {
+                sample_col = (long)k;
+                break;
+            }
+        if (sample_col < 0) return fail(AVK_E_ARG, "Sample name \"%s\" was not found in %s", sample, path);
+    }
+    return 0;
+}
+
+/* One data line -> zero, one or two calls (load_variants_in_region / parse_variant / parse_genotype, region_generation.rs:489-758),
+ * handed to emit(chrom, call).  rec = index of the line among the data lines (for messages and provenance). */
+template <class Emit> int vcf_parse_record(const char *path, const std::string &line, long sample_col, bool enable_trimming, uint64_t rec, VcfScratch &w, Emit &&emit) {
+    std::vector<std::string> &f = w.f, &alts = w.alts, &fmt = w.fmt, &sv = w.sv, &info = w.info;
+    split(line, '\t', f);
+    if ((long)f.size() <= sample_col) return fail(AVK_E_ARG, "%s: record %llu has too few columns", path, (unsigned long long)rec);
+    uint64_t pos1 = 0;
+    if (!parse_u64(f[1], pos1) || pos1 == 0) return fail(AVK_E_ARG, "%s: record %llu: Missing POS", path, (unsigned long long)rec);
+    const std::string &ref_seq = f[3];
+    /* sample GT */
+    split(f[8], ':', fmt);
+    long gt_at = -1;
+    for (size_t k = 0; k < fmt.size(); ++k)
+        if (fmt[k] == "GT") {
+            gt_at = (long)k;
+            break;
+        }
+    if (gt_at < 0) return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): Missing GT", path, (unsigned long long)rec, f[0].c_str(), (unsigned long long)pos1);
+    split(f[(size_t)sample_col], ':', sv);
+    if ((long)sv.size() <= gt_at || sv[(size_t)gt_at] == "." || sv[(size_t)gt_at].empty()) return 0; /* GT = '.': a no-op (:583-586) */
+    const std::string &gt = sv[(size_t)gt_at];
+    /* parse_genotype (:660-712) */
+    uint64_t idx[2] = {0, 0};
+    bool phased = false;
+    {
+        size_t n_alleles = 0, b = 0;
+        for (size_t k = 0; k <= gt.size(); ++k) {
+            if (k == gt.size() || gt[k] == '/' || gt[k] == '|') {
+                if (k < gt.size() && gt[k] == '|') phased = true;
+                if (n_alleles >= 2) return fail(AVK_E_ARG, "%s: record %llu: allele.len() != [1, 2]: %s", path, (unsigned long long)rec, gt.c_str());
+                const std::string a(gt, b, k - b);
+                uint64_t v = 0;
+                if (a != "." && !parse_u64(a, v)) return fail(AVK_E_ARG, "%s: record %llu: malformed GT %s", path, (unsigned long long)rec, gt.c_str());
+                idx[n_alleles++] = v; /* '.' is treated as a reference call */
+                b = k + 1;
+            }
+        }
+        if (n_alleles == 1) idx[1] = idx[0]; /* hemizygous is treated as homozygous */
+    }
+    std::pair<uint64_t, uint8_t> picks[2];
+    int n_picks = 0;
+    if (idx[0] == idx[1]) {
+        if (idx[0] != 0) picks[n_picks++] = {idx[0], (uint8_t)AVK_ZYG_HOM_ALT};
+    } else {
+        const uint8_t ap1 = phased ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_UNPHASED_HET, ap2 = phased ? AVK_ZYG_PHASED_HET01 : AVK_ZYG_UNPHASED_HET;
+        if (idx[0] != 0) picks[n_picks++] = {idx[0], ap1};
+        if (idx[1] != 0) picks[n_picks++] = {idx[1], ap2};
+    }
+    if (n_picks == 0) return 0;
+    if (f[4] == "." || f[4].empty()) alts.clear();
+    else split(f[4], ',', alts);
+    /* INFO: SVTYPE and TRID */
+    bool has_svtype = false, has_trid = false;
+    std::string svtype;
+    if (f[7] != "." && !f[7].empty()) {
+        split(f[7], ';', info);
+        for (const std::string &kv : info) {
+            if (kv.compare(0, 7, "SVTYPE=") == 0) {
+                has_svtype = true;
+                svtype.assign(kv, 7);
+            } else if (kv.compare(0, 5, "TRID=") == 0 && kv.size() > 5) has_trid = true;
+        }
+    }
+    for (int p = 0; p < n_picks; ++p) {
+        const uint64_t alt_index = picks[p].first;
+        if (alt_index > alts.size()) return fail(AVK_E_ARG, "%s: record %llu: GT refers to ALT %llu of %zu", path, (unsigned long long)rec, (unsigned long long)alt_index, alts.size());
+        const std::string &alt = alts[alt_index - 1];
+        if (alt == "*") continue;            /* effectively a reference allele (:597-600) */
+        if (!alt.empty() && alt[0] == '<') continue; /* symbolic: needs sequence-resolved (:604-607) */
+        std::string r = ref_seq, a = alt;
+        const size_t raw_space = std::max(r.size(), a.size()); /* before trimming (:612) */
+        while (enable_trimming && r.size() > 1 && a.size() > 1 && r.back() == a.back()) {
+            r.pop_back();
+            a.pop_back();
+        }
+        if (r.size() > 10000 || a.size() > 10000) continue; /* allele_size_limit (:621-626) */
+        uint8_t type = 0;
+        const int rc = variant_type_of(svtype, has_svtype, has_trid, r.size(), a.size(), type);
+        if (rc == 1) continue;
+        if (rc < 0) return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): %s", path, (unsigned long long)rec, f[0].c_str(), (unsigned long long)pos1, std::string(t_error).c_str());
+        Call c;
+        c.pos = pos1 - 1;
+        c.a0.swap(r);
+        c.a1.swap(a);
+        c.raw_space = (uint32_t)raw_space;
+        c.type = type;
+        c.zyg = picks[p].second;
+        c.record = rec;
+        c.alt_index = (uint32_t)alt_index;
+        emit(f[0], std::move(c));
+    }
+    return 0;
+}
+
+/* the whole file line by line on the calling thread: the reference behaviour, and the source of every error message */
+int load_vcf_sequential(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls) {
     LineReader in(path);
     if (!in.ok()) return fail(AVK_E_ARG, "Error while opening %s", path);
     std::string line;
-    std::vector<std::string> f, alts, fmt, sv, info;
+    VcfScratch w;
     long sample_col = -1;
     uint64_t record = 0;
     bool have_header = false;
@@ -242,113 +381,191 @@ int load_vcf(const char *path, const char *sample, bool enable_trimming, std::un
         if (line.empty()) continue;
         if (line[0] == '#') {
             if (line.compare(0, 6, "#CHROM") == 0) {
-                split(line, '\t', f);
+                const int rc = vcf_sample_column(path, line, sample, w, sample_col);
+                if (rc) return rc;
                 have_header = true;
-                if (f.size() < 10) return fail(AVK_E_ARG, "%s has no sample columns", path);
-                if (!sample || !*sample) sample_col = 9; /* get_vcf_sample_name(.., 0) */
-                else {
-                    for (size_t k = 9; k < f.size(); ++k)
-                        if (f[k] == sample) {
-                            sample_col = (long)k;
-                            break;
-                        }
-                    if (sample_col < 0) return fail(AVK_E_ARG, "Sample name \"%s\" was not found in %s", sample, path);
-                }
             }
             continue;
         }
         if (!have_header) return fail(AVK_E_ARG, "%s: data line before the #CHROM header", path);
-        const uint64_t rec = record++;
-        split(line, '\t', f);
-        if ((long)f.size() <= sample_col) return fail(AVK_E_ARG, "%s: record %llu has too few columns", path, (unsigned long long)rec);
-        uint64_t pos1 = 0;
-        if (!parse_u64(f[1], pos1) || pos1 == 0) return fail(AVK_E_ARG, "%s: record %llu: Missing POS", path, (unsigned long long)rec);
-        const std::string &ref_seq = f[3];
-        /* sample GT */
-        split(f[8], ':', fmt);
-        long gt_at = -1;
-        for (size_t k = 0; k < fmt.size(); ++k)
-            if (fmt[k] == "GT") {
-                gt_at = (long)k;
-                break;
-            }
-        if (gt_at < 0) return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): Missing GT", path, (unsigned long long)rec, f[0].c_str(), (unsigned long long)pos1);
-        split(f[(size_t)sample_col], ':', sv);
-        if ((long)sv.size() <= gt_at || sv[(size_t)gt_at] == "." || sv[(size_t)gt_at].empty()) continue; /* GT = '.': a no-op (:583-586) */
-        const std::string &gt = sv[(size_t)gt_at];
-        /* parse_genotype (:660-712) */
-        uint64_t idx[2] = {0, 0};
-        bool phased = false;
-        {
-            size_t n_alleles = 0, b = 0;
-            for (size_t k = 0; k <= gt.size(); ++k) {
-                if (k == gt.size() || gt[k] == '/' || gt[k] == '|') {
-                    if (k < gt.size() && gt[k] == '|') phased = true;
-                    if (n_alleles >= 2) return fail(AVK_E_ARG, "%s: record %llu: allele.len() != [1, 2]: %s", path, (unsigned long long)rec, gt.c_str());
-                    const std::string a(gt, b, k - b);
-                    uint64_t v = 0;
-                    if (a != "." && !parse_u64(a, v)) return fail(AVK_E_ARG, "%s: record %llu: malformed GT %s", path, (unsigned long long)rec, gt.c_str());
-                    idx[n_alleles++] = v; /* '.' is treated as a reference call */
-                    b = k + 1;
-                }
-            }
-            if (n_alleles == 1) idx[1] = idx[0]; /* hemizygous is treated as homozygous */
-        }
-        std::pair<uint64_t, uint8_t> picks[2];
-        int n_picks = 0;
-        if (idx[0] == idx[1]) {
-            if (idx[0] != 0) picks[n_picks++] = {idx[0], (uint8_t)AVK_ZYG_HOM_ALT};
-        } else {
-            const uint8_t ap1 = phased ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_UNPHASED_HET, ap2 = phased ? AVK_ZYG_PHASED_HET01 : AVK_ZYG_UNPHASED_HET;
-            if (idx[0] != 0) picks[n_picks++] = {idx[0], ap1};
-            if (idx[1] != 0) picks[n_picks++] = {idx[1], ap2};
-        }
-        if (n_picks == 0) continue;
-        if (f[4] == "." || f[4].empty()) alts.clear();
-        else split(f[4], ',', alts);
-        /* INFO: SVTYPE and TRID */
-        bool has_svtype = false, has_trid = false;
-        std::string svtype;
-        if (f[7] != "." && !f[7].empty()) {
-            split(f[7], ';', info);
-            for (const std::string &kv : info) {
-                if (kv.compare(0, 7, "SVTYPE=") == 0) {
-                    has_svtype = true;
-                    svtype.assign(kv, 7);
-                } else if (kv.compare(0, 5, "TRID=") == 0 && kv.size() > 5) has_trid = true;
-            }
-        }
-        for (int p = 0; p < n_picks; ++p) {
-            const uint64_t alt_index = picks[p].first;
-            if (alt_index > alts.size()) return fail(AVK_E_ARG, "%s: record %llu: GT refers to ALT %llu of %zu", path, (unsigned long long)rec, (unsigned long long)alt_index, alts.size());
-            const std::string &alt = alts[alt_index - 1];
-            if (alt == "*") continue;            /* effectively a reference allele (:597-600) */
-            if (!alt.empty() && alt[0] == '<') continue; /* symbolic: needs sequence-resolved (:604-607) */
-            std::string r = ref_seq, a = alt;
-            const size_t raw_space = std::max(r.size(), a.size()); /* before trimming (:612) */
-            while (enable_trimming && r.size() > 1 && a.size() > 1 && r.back() == a.back()) {
-                r.pop_back();
-                a.pop_back();
-            }
-            if (r.size() > 10000 || a.size() > 10000) continue; /* allele_size_limit (:621-626) */
-            uint8_t type = 0;
-            const int rc = variant_type_of(svtype, has_svtype, has_trid, r.size(), a.size(), type);
-            if (rc == 1) continue;
-            if (rc < 0) return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): %s", path, (unsigned long long)rec, f[0].c_str(), (unsigned long long)pos1, std::string(t_error).c_str());
-            Call c;
-            c.pos = pos1 - 1;
-            c.a0.swap(r);
-            c.a1.swap(a);
-            c.raw_space = (uint32_t)raw_space;
-            c.type = type;
-            c.zyg = picks[p].second;
-            c.record = rec;
-            c.alt_index = (uint32_t)alt_index;
-            calls[f[0]].push_back(std::move(c));
-        }
+        const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, record++, w, [&](const std::string &chrom, Call &&c) { calls[chrom].push_back(std::move(c)); });
+        if (rc) return rc;
     }
     if (in.failed()) return fail(AVK_E_ARG, "read error in %s", path);
     if (!have_header) return fail(AVK_E_ARG, "%s has no #CHROM header line", path);
+    return 0;
+}
+
+/* The file is decompressed on the calling thread and cut into blocks of whole lines; worker threads parse the blocks, and the calls
+ * are put together in file order.  Anything irregular (an error, a #CHROM line after the first data line) is left to the sequential
+ * reader above, which then reports it the usual way. */
+int load_vcf(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_workers = std::min<size_t>(hw > 1 ? hw - 1 : 0, 8);
+    if (n_workers < 2 || getenv("AVF_SEQUENTIAL_VCF")) return load_vcf_sequential(path, sample, enable_trimming, calls);
+    gzFile gz = gzopen(path, "rb");
+    if (!gz) return fail(AVK_E_ARG, "Error while opening %s", path);
+    gzbuffer(gz, 1 << 20);
+    size_t block_bytes = 4u << 20;
+    if (const char *e = getenv("AVF_VCF_BLOCK")) block_bytes = std::max<size_t>(16, (size_t)strtoull(e, nullptr, 10)); /* tests: force block boundaries */
+
+    struct BlockOut {
+        std::vector<std::string> chroms;
+        std::vector<std::vector<Call>> lists;
+        uint64_t n_records = 0;
+    };
+    std::vector<std::unique_ptr<std::string>> blocks; /* block k's text, released once parsed */
+    std::vector<std::unique_ptr<BlockOut>> outs;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_room;
+    size_t next_block = 0, in_flight = 0;
+    bool done_reading = false;
+    std::atomic<bool> irregular{false};
+    long sample_col = -1;
+
+    auto worker = [&] {
+        VcfScratch w;
+        std::string line;
+        for (;;) {
+            size_t k;
+            std::string *text;
+            BlockOut *out;
+            {
+                std::unique_lock<std::mutex> lock(mu);
+                cv_work.wait(lock, [&] { return next_block < blocks.size() || done_reading; });
+                if (next_block >= blocks.size()) return;
+                k = next_block++;
+                text = blocks[k].get();
+                out = outs[k].get();
+            }
+            if (!irregular.load(std::memory_order_relaxed)) {
+                size_t last = (size_t)-1;
+                const char *p = text->data(), *end = p + text->size();
+                while (p < end) {
+                    const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                    const char *le = nl ? nl : end;
+                    size_t len = (size_t)(le - p);
+                    if (len && p[len - 1] == '\r') len -= 1;
+                    if (len) {
+                        if (p[0] == '#') {
+                            if (len >= 6 && memcmp(p, "#CHROM", 6) == 0) irregular.store(true);
+                        } else {
+                            line.assign(p, len);
+                            const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, out->n_records, w, [&](const std::string &chrom, Call &&c) {
+                                if (last == (size_t)-1 || out->chroms[last] != chrom) {
+                                    last = (size_t)-1;
+                                    for (size_t q = 0; q < out->chroms.size(); ++q)
+                                        if (out->chroms[q] == chrom) last = q;
+                                    if (last == (size_t)-1) {
+                                        out->chroms.push_back(chrom);
+                                        out->lists.emplace_back();
+                                        last = out->chroms.size() - 1;
+                                    }
+                                }
+                                out->lists[last].push_back(std::move(c));
+                            });
+                            out->n_records += 1;
+                            if (rc) {
+                                irregular.store(true);
+                                break;
+                            }
+                        }
+                    }
+                    p = nl ? nl + 1 : end;
+                }
+            }
+            {
+                std::lock_guard<std::mutex> lock(mu);
+                blocks[k].reset(); /* the text is no longer needed */
+                in_flight -= 1;
+            }
+            cv_room.notify_one();
+        }
+    };
+    std::vector<std::thread> pool;
+
+    /* the reader: header lines first (they fix the sample column), then blocks of whole lines */
+    std::string pending; /* bytes read but not yet handed out */
+    std::vector<char> buf(1 << 20);
+    bool have_header = false, in_header = true, read_failed = false;
+    VcfScratch hw_scratch;
+    int rc_header = 0;
+    auto hand_out = [&](std::string &&text) {
+        std::unique_lock<std::mutex> lock(mu);
+        cv_room.wait(lock, [&] { return in_flight < 4 * n_workers; }); /* bounds the decompressed text held in memory */
+        blocks.emplace_back(new std::string(std::move(text)));
+        outs.emplace_back(new BlockOut());
+        in_flight += 1;
+        lock.unlock();
+        cv_work.notify_one();
+    };
+    for (;;) {
+        const int n = gzread(gz, buf.data(), (unsigned)buf.size());
+        if (n < 0) {
+            read_failed = true;
+            break;
+        }
+        if (n == 0) break;
+        pending.append(buf.data(), (size_t)n);
+        if (in_header) { /* consume whole header / empty lines from the front */
+            size_t at = 0;
+            while (in_header) {
+                const size_t nl = pending.find('\n', at);
+                if (nl == std::string::npos) break;
+                size_t len = nl - at;
+                if (len && pending[at + len - 1] == '\r') len -= 1;
+                if (len == 0 || pending[at] == '#') {
+                    if (len >= 6 && pending.compare(at, 6, "#CHROM") == 0) {
+                        rc_header = vcf_sample_column(path, pending.substr(at, len), sample, hw_scratch, sample_col);
+                        if (rc_header) break;
+                        have_header = true;
+                    }
+                    at = nl + 1;
+                } else in_header = false; /* first data line */
+            }
+            pending.erase(0, at);
+            if (rc_header) break;
+            if (!in_header) {
+                if (!have_header) break; /* data before #CHROM: the sequential reader words the error */
+                for (size_t t = 0; t < n_workers; ++t) pool.emplace_back(worker);
+            }
+        }
+        if (!in_header && pending.size() >= block_bytes) {
+            const size_t cut = pending.rfind('\n');
+            if (cut != std::string::npos) {
+                std::string text(pending, 0, cut + 1);
+                pending.erase(0, cut + 1);
+                hand_out(std::move(text));
+            }
+        }
+        if (irregular.load(std::memory_order_relaxed)) break;
+    }
+    gzclose(gz);
+    if (rc_header) return rc_header;
+    if (!in_header && have_header && !pending.empty() && !read_failed) hand_out(std::move(pending));
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        done_reading = true;
+    }
+    cv_work.notify_all();
+    for (std::thread &t : pool) t.join();
+    if (read_failed || irregular.load() || in_header || !have_header) {
+        calls.clear();
+        return load_vcf_sequential(path, sample, enable_trimming, calls);
+    }
+    /* in file order: block after block; record indices become file-wide */
+    uint64_t base = 0;
+    for (std::unique_ptr<BlockOut> &o : outs) {
+        for (size_t q = 0; q < o->chroms.size(); ++q) {
+            std::vector<Call> &dst = calls[o->chroms[q]];
+            for (Call &c : o->lists[q]) {
+                c.record += base;
+                dst.push_back(std::move(c));
+            }
+        }
+        base += o->n_records;
+        o.reset();
+    }
     return 0;
 }
 
@@ -421,12 +638,150 @@ extern "C" {
 
 const char *avf_last_error(void) { return t_error.c_str(); }
 
+/* Uncompressed FASTA files are mapped and parsed by several threads: header lines are found first ('>' at a line start), then
+ * every sequence body is cut into pieces whose kept bytes (everything but line terminators) are counted and copied side by side.
+ * Same result as the line-by-line reader below, which still serves gzip / BGZF files. */
+static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n, avf_genome *g) {
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, 32));
+    auto parallel = [&](size_t items, const std::function<void(size_t)> &fn) {
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t i = next.fetch_add(1); i < items; i = next.fetch_add(1)) fn(i);
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < std::min(n_threads, items); ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    };
+    const bool timing = getenv("AVF_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char *what) {
+        if (!timing) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[avf] fasta %s: %.3f s\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
+    /* 1. header positions */
+    size_t piece = 8u << 20;
+    if (const char *e = getenv("AVF_FASTA_PIECE")) piece = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10)); /* tests: force piece boundaries */
+    const size_t n_pieces = (n + piece - 1) / piece;
+    std::vector<std::vector<size_t>> found(n_pieces);
+    parallel(n_pieces, [&](size_t k) {
+        const size_t lo = k * piece, hi = std::min(n, lo + piece);
+        for (size_t at = lo; at < hi;) {
+            const uint8_t *q = (const uint8_t *)memchr(d + at, '>', hi - at);
+            if (!q) break;
+            const size_t pos = (size_t)(q - d);
+            if (pos == 0 || d[pos - 1] == '\n') found[k].push_back(pos);
+            at = pos + 1;
+        }
+    });
+    lap("header scan");
+    std::vector<size_t> headers;
+    for (const auto &f : found) headers.insert(headers.end(), f.begin(), f.end());
+    /* anything but empty lines before the first header is an error */
+    const size_t first = headers.empty() ? n : headers[0];
+    for (size_t at = 0; at < first; ++at)
+        if (d[at] != '\n' && !(d[at] == '\r' && (at + 1 == n || d[at + 1] == '\n'))) return fail(AVK_E_ARG, "%s: sequence before the first header", fasta_path);
+    /* 2. names and bodies */
+    struct Piece {
+        size_t contig, lo, hi, kept, out;
+    };
+    std::vector<Piece> pieces;
+    g->names.reserve(headers.size());
+    for (size_t i = 0; i < headers.size(); ++i) {
+        const size_t h = headers[i], end = i + 1 < headers.size() ? headers[i + 1] : n;
+        const uint8_t *nl = (const uint8_t *)memchr(d + h, '\n', end - h);
+        size_t eol = nl ? (size_t)(nl - d) : end, line_end = eol;
+        if (line_end > h && d[line_end - 1] == '\r') line_end -= 1;
+        size_t e = h + 1;
+        while (e < line_end && d[e] != ' ' && d[e] != '\t') ++e;
+        g->names.emplace_back((const char *)d + h + 1, e - h - 1);
+        const size_t body = nl ? eol + 1 : end;
+        for (size_t lo = body; lo < end; lo += piece) pieces.push_back(Piece{i, lo, std::min(end, lo + piece), 0, 0});
+    }
+    g->seqs.resize(headers.size());
+    /* a byte is dropped when it is a line feed, or a carriage return right before a line feed or the end of the file */
+    auto dropped = [&](size_t at) { return d[at] == '\n' || (d[at] == '\r' && (at + 1 == n || d[at + 1] == '\n')); };
+    parallel(pieces.size(), [&](size_t k) {
+        Piece &pc = pieces[k];
+        size_t drop = 0;
+        for (size_t at = pc.lo; at < pc.hi;) {
+            const uint8_t *q = (const uint8_t *)memchr(d + at, '\n', pc.hi - at);
+            if (!q) break;
+            const size_t pos = (size_t)(q - d);
+            drop += 1 + (pos > pc.lo && d[pos - 1] == '\r' ? 1 : 0);
+            at = pos + 1;
+        }
+        if (d[pc.hi - 1] == '\r' && dropped(pc.hi - 1)) drop += 1; /* its line feed is the first byte of the next piece, or the file ends here */
+        pc.kept = (pc.hi - pc.lo) - drop;
+    });
+    lap("count");
+    std::vector<size_t> total(headers.size(), 0);
+    for (Piece &pc : pieces) {
+        pc.out = total[pc.contig];
+        total[pc.contig] += pc.kept;
+    }
+    for (size_t i = 0; i < headers.size(); ++i) {
+        g->seqs[i].resize(total[i]);
+    }
+    lap("allocate");
+    parallel(pieces.size(), [&](size_t k) {
+        const Piece &pc = pieces[k];
+        uint8_t *out = g->seqs[pc.contig].data() + pc.out;
+        size_t at = pc.lo;
+        while (at < pc.hi) {
+            const uint8_t *q = (const uint8_t *)memchr(d + at, '\n', pc.hi - at);
+            size_t stop = q ? (size_t)(q - d) : pc.hi; /* end of this line's bytes inside the piece */
+            size_t keep_to = stop;
+            if (keep_to > at && d[keep_to - 1] == '\r' && dropped(keep_to - 1)) keep_to -= 1;
+            memcpy(out, d + at, keep_to - at);
+            out += keep_to - at;
+            at = q ? stop + 1 : pc.hi;
+        }
+    });
+    lap("copy");
+    return 0;
+}
+
 int avf_genome_load(const char *fasta_path, avf_genome **out) {
     if (!fasta_path || !out) return fail(AVK_E_ARG, "null argument");
     *out = nullptr;
-    LineReader in(fasta_path);
-    if (!in.ok()) return fail(AVK_E_ARG, "cannot open FASTA file %s", fasta_path);
     avf_genome *g = new avf_genome();
+    /* plain text (no gzip magic): map it */
+    {
+        const int fd = open(fasta_path, O_RDONLY);
+        if (fd < 0) {
+            delete g;
+            return fail(AVK_E_ARG, "cannot open FASTA file %s", fasta_path);
+        }
+        struct stat st;
+        uint8_t magic[2] = {0, 0};
+        const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
+        const bool gz = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (regular && !gz) {
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                const int rc = genome_load_mapped(fasta_path, (const uint8_t *)m, (size_t)st.st_size, g);
+                munmap(m, (size_t)st.st_size);
+                close(fd);
+                if (rc) {
+                    delete g;
+                    return rc;
+                }
+                for (uint32_t i = 0; i < g->names.size(); ++i) g->index.emplace(g->names[i], i);
+                *out = g;
+                return 0;
+            }
+        }
+        close(fd);
+    }
+    LineReader in(fasta_path);
+    if (!in.ok()) {
+        delete g;
+        return fail(AVK_E_ARG, "cannot open FASTA file %s", fasta_path);
+    }
     std::string line;
     while (in.next(line)) {
         if (line.empty()) continue;
@@ -459,15 +814,14 @@ void avf_genome_free(avf_genome *g) { delete g; }
 
 /* RegionIterator::next (region_generation.rs:281-478) over k inputs; input i's variants of region m end up at
  * [in_off[m*k + i], +in_cnt[m*k + i]).  Both the compare and the merge iterator are this loop. */
-static int build_regions(uint32_t k, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
-                         uint64_t min_variant_gap, int enable_trimming, avf_feed *f) {
-    if (!regions_bed || !*regions_bed) return fail(AVK_E_ARG, "High confidence regions are currently required.");
-    if (min_variant_gap == 0) return fail(AVK_E_ARG, "--min-variant-gap must be >0");
-    LoadedBed bed;
-    int rc = load_bed(regions_bed, bed);
-    if (rc) return rc;
-    /* the files are read side by side, like the reference's per-file parallel load (:324-347) */
-    std::vector<std::unordered_map<std::string, std::vector<Call>>> calls(k);
+typedef std::unordered_map<std::string, std::vector<Call>> CallMap;
+struct avf_calls {
+    CallMap by_chrom;
+};
+
+/* the VCFs are read side by side, like the reference's per-file parallel load (:324-347) */
+static int load_call_sets(uint32_t k, const char *const *vcfs, const char *const *samples, int enable_trimming, std::vector<CallMap> &calls) {
+    calls.assign(k, CallMap());
     std::vector<int> rcs(k, 0);
     std::vector<std::string> errs(k);
     {
@@ -489,6 +843,15 @@ static int build_regions(uint32_t k, const char *const *vcfs, const char *const 
             t_error = errs[i];
             return rcs[i];
         }
+    return 0;
+}
+
+static int build_regions(uint32_t k, const CallMap *const *calls, const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, avf_feed *f) {
+    if (!regions_bed || !*regions_bed) return fail(AVK_E_ARG, "High confidence regions are currently required.");
+    if (min_variant_gap == 0) return fail(AVK_E_ARG, "--min-variant-gap must be >0");
+    LoadedBed bed;
+    int rc = load_bed(regions_bed, bed);
+    if (rc) return rc;
 
     f->k = k;
     f->loaded.assign(k, 0);
@@ -496,54 +859,60 @@ static int build_regions(uint32_t k, const char *const *vcfs, const char *const 
         uint32_t input;
         const Call *c;
     };
-    std::vector<Joint> joint;
-    uint64_t next_region_id = 0;
-    std::vector<std::vector<const Call *>> vars(k);
-    for (size_t ci = 0; ci < bed.chroms.size(); ++ci) {
+    const size_t n_chroms = bed.chroms.size();
+    std::vector<uint32_t> contig_of(n_chroms);
+    for (size_t ci = 0; ci < n_chroms; ++ci) {
+        const auto git = g->index.find(bed.chroms[ci]);
+        if (git == g->index.end()) return fail(AVK_E_ARG, "Chromosome %s was not found in reference genome", bed.chroms[ci].c_str());
+        contig_of[ci] = git->second;
+    }
+    /* every chromosome on its own (a part has the feed's arrays, offsets relative to the part), several at a time */
+    std::vector<std::unique_ptr<avf_feed>> parts(n_chroms);
+    auto walk = [&](size_t ci) {
+        avf_feed *part = parts[ci].get();
+        part->loaded.assign(k, 0);
         const std::string &chrom = bed.chroms[ci];
         const std::vector<Interval1> &intervals = bed.intervals[ci];
-        const auto git = g->index.find(chrom);
-        if (git == g->index.end()) return fail(AVK_E_ARG, "Chromosome %s was not found in reference genome", chrom.c_str());
-        const uint32_t contig = git->second;
+        const uint32_t contig = contig_of[ci];
         const uint64_t chrom_length = g->seqs[contig].size();
         /* the span the reference queries through tabix: first interval's start to the LAST interval's end (:289-296) */
         const uint64_t zb_start = intervals.front().start - 1, zb_end = intervals.back().end;
-        joint.clear();
+        std::vector<Joint> joint;
+        std::vector<std::vector<const Call *>> vars(k);
         for (uint32_t input = 0; input < k; ++input) {
-            const auto it = calls[input].find(chrom);
-            if (it == calls[input].end()) continue;
+            const auto it = calls[input]->find(chrom);
+            if (it == calls[input]->end()) continue;
             for (const Call &c : it->second) {
                 /* is_variant_contained (:764-778): first and last reference base inside the span */
                 const uint64_t last = c.pos + c.a0.size() - 1;
                 if (c.pos >= zb_start && c.pos < zb_end && last >= zb_start && last < zb_end) {
                     joint.push_back(Joint{input, &c});
-                    f->loaded[input] += 1;
+                    part->loaded[input] += 1;
                 }
             }
         }
         std::stable_sort(joint.begin(), joint.end(), [](const Joint &a, const Joint &b) { return a.c->pos < b.c->pos; }); /* sort_by_key(position) */
         size_t head = 0; /* the deque's front */
         auto flush = [&](uint64_t ws, uint64_t we) {
-            f->region_id.push_back(next_region_id++);
-            f->contig_idx.push_back(contig);
-            f->start.push_back(ws);
-            f->end.push_back(we);
+            part->contig_idx.push_back(contig);
+            part->start.push_back(ws);
+            part->end.push_back(we);
             for (uint32_t input = 0; input < k; ++input) {
-                f->in_off.push_back(f->var_pos.size());
-                f->in_cnt.push_back((uint32_t)vars[input].size());
+                part->in_off.push_back(part->var_pos.size());
+                part->in_cnt.push_back((uint32_t)vars[input].size());
                 for (const Call *c : vars[input]) {
-                    f->var_pos.push_back(c->pos);
-                    f->var_type.push_back(c->type);
-                    f->var_zyg.push_back(c->zyg);
-                    f->var_raw.push_back(c->raw_space);
-                    f->a0_off.push_back(f->alleles.size());
-                    f->a0_len.push_back((uint32_t)c->a0.size());
-                    f->alleles.insert(f->alleles.end(), c->a0.begin(), c->a0.end());
-                    f->a1_off.push_back(f->alleles.size());
-                    f->a1_len.push_back((uint32_t)c->a1.size());
-                    f->alleles.insert(f->alleles.end(), c->a1.begin(), c->a1.end());
-                    f->var_record.push_back(c->record);
-                    f->var_alt.push_back(c->alt_index);
+                    part->var_pos.push_back(c->pos);
+                    part->var_type.push_back(c->type);
+                    part->var_zyg.push_back(c->zyg);
+                    part->var_raw.push_back(c->raw_space);
+                    part->a0_off.push_back(part->alleles.size());
+                    part->a0_len.push_back((uint32_t)c->a0.size());
+                    part->alleles.insert(part->alleles.end(), c->a0.begin(), c->a0.end());
+                    part->a1_off.push_back(part->alleles.size());
+                    part->a1_len.push_back((uint32_t)c->a1.size());
+                    part->alleles.insert(part->alleles.end(), c->a1.begin(), c->a1.end());
+                    part->var_record.push_back(c->record);
+                    part->var_alt.push_back(c->alt_index);
                 }
                 vars[input].clear();
             }
@@ -579,22 +948,79 @@ static int build_regions(uint32_t k, const char *const *vcfs, const char *const 
             }
             if (have_window && have_end) flush(window_start, window_end);
         }
+    };
+    const unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, n_chroms}));
+    auto parallel = [&](const std::function<void(size_t)> &fn) {
+        std::atomic<size_t> next{0};
+        auto work = [&] {
+            for (size_t ci = next.fetch_add(1); ci < n_chroms; ci = next.fetch_add(1)) fn(ci);
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < n_threads; ++t) pool.emplace_back(work);
+        work();
+        for (std::thread &t : pool) t.join();
+    };
+    for (size_t ci = 0; ci < n_chroms; ++ci) parts[ci].reset(new avf_feed());
+    parallel(walk);
+    /* region ids run over the chromosomes in BED order (next_region_id); offsets become batch-wide */
+    std::vector<uint64_t> r0(n_chroms + 1, 0), v0(n_chroms + 1, 0), a0(n_chroms + 1, 0);
+    for (size_t ci = 0; ci < n_chroms; ++ci) {
+        r0[ci + 1] = r0[ci] + parts[ci]->start.size();
+        v0[ci + 1] = v0[ci] + parts[ci]->var_pos.size();
+        a0[ci + 1] = a0[ci] + parts[ci]->alleles.size();
+        for (uint32_t input = 0; input < k; ++input) f->loaded[input] += parts[ci]->loaded[input];
     }
+    const uint64_t nr = r0[n_chroms], nv = v0[n_chroms], na = a0[n_chroms];
+    f->region_id.resize(nr);
+    f->contig_idx.resize(nr);
+    f->start.resize(nr);
+    f->end.resize(nr);
+    f->in_off.resize(nr * k);
+    f->in_cnt.resize(nr * k);
+    f->var_pos.resize(nv);
+    f->var_type.resize(nv);
+    f->var_zyg.resize(nv);
+    f->var_raw.resize(nv);
+    f->a0_off.resize(nv);
+    f->a0_len.resize(nv);
+    f->a1_off.resize(nv);
+    f->a1_len.resize(nv);
+    f->var_record.resize(nv);
+    f->var_alt.resize(nv);
+    f->alleles.resize(na);
+    parallel([&](size_t ci) {
+        avf_feed *part = parts[ci].get();
+        const uint64_t rb = r0[ci], vb = v0[ci], ab = a0[ci], n = part->start.size(), m = part->var_pos.size();
+        auto copy = [](auto &dst, uint64_t at, const auto &src) {
+            if (!src.empty()) memcpy(dst.data() + at, src.data(), src.size() * sizeof(src[0]));
+        };
+        for (uint64_t r = 0; r < n; ++r) f->region_id[rb + r] = rb + r;
+        copy(f->contig_idx, rb, part->contig_idx);
+        copy(f->start, rb, part->start);
+        copy(f->end, rb, part->end);
+        for (uint64_t q = 0; q < n * k; ++q) f->in_off[rb * k + q] = part->in_off[q] + vb;
+        copy(f->in_cnt, rb * k, part->in_cnt);
+        copy(f->var_pos, vb, part->var_pos);
+        copy(f->var_type, vb, part->var_type);
+        copy(f->var_zyg, vb, part->var_zyg);
+        copy(f->var_raw, vb, part->var_raw);
+        for (uint64_t q = 0; q < m; ++q) {
+            f->a0_off[vb + q] = part->a0_off[q] + ab;
+            f->a1_off[vb + q] = part->a1_off[q] + ab;
+        }
+        copy(f->a0_len, vb, part->a0_len);
+        copy(f->a1_len, vb, part->a1_len);
+        copy(f->var_record, vb, part->var_record);
+        copy(f->var_alt, vb, part->var_alt);
+        copy(f->alleles, ab, part->alleles);
+        parts[ci].reset();
+    });
     if (f->alleles.empty()) f->alleles.push_back(0);
     return 0;
 }
 
-int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char *query_vcf, const char *query_sample,
-                     const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
-    if (!truth_vcf || !query_vcf || !g || !out) return fail(AVK_E_ARG, "null argument");
-    *out = nullptr;
-    avf_feed *f = new avf_feed();
-    const char *paths[2] = {truth_vcf, query_vcf}, *samples[2] = {truth_sample, query_sample};
-    const int rc = build_regions(2, paths, samples, regions_bed, g, min_variant_gap, enable_trimming, f);
-    if (rc) {
-        delete f;
-        return rc;
-    }
+static void fill_compare_batch(avf_feed *f) {
     const size_t n = f->region_id.size();
     f->t_off.resize(n);
     f->q_off.resize(n);
@@ -629,25 +1055,10 @@ int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char
     b.a1_len = f->a1_len.data();
     b.allele_bytes = f->alleles.data();
     b.allele_bytes_len = f->alleles.size();
-    *out = f;
-    return 0;
 }
 
-int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
-                   uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
-    if (!vcfs || !g || !out) return fail(AVK_E_ARG, "null argument");
-    *out = nullptr;
-    if (n_inputs == 0) return fail(AVK_E_ARG, "Must provide at least 1 VCF to iterate on");
-    if (n_inputs > 64) return fail(AVK_E_ARG, "at most 64 input VCFs are supported, got %u", n_inputs);
-    for (uint32_t i = 0; i < n_inputs; ++i)
-        if (!vcfs[i]) return fail(AVK_E_ARG, "null argument");
-    avf_feed *f = new avf_feed();
+static void fill_multi_batch(avf_feed *f, uint32_t n_inputs) {
     f->is_merge = true;
-    const int rc = build_regions(n_inputs, vcfs, samples, regions_bed, g, min_variant_gap, enable_trimming, f);
-    if (rc) {
-        delete f;
-        return rc;
-    }
     memset(&f->batch, 0, sizeof(f->batch));
     avk_multi_batch &b = f->multi;
     memset(&b, 0, sizeof(b));
@@ -670,8 +1081,85 @@ int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const
     b.a1_len = f->a1_len.data();
     b.allele_bytes = f->alleles.data();
     b.allele_bytes_len = f->alleles.size();
+}
+
+int avf_calls_load(const char *vcf, const char *sample, int enable_trimming, avf_calls **out) {
+    if (!vcf || !out) return fail(AVK_E_ARG, "null argument");
+    *out = nullptr;
+    avf_calls *c = new avf_calls();
+    const int rc = load_vcf(vcf, sample, enable_trimming != 0, c->by_chrom);
+    if (rc) {
+        delete c;
+        return rc;
+    }
+    *out = c;
+    return 0;
+}
+void avf_calls_free(avf_calls *c) { delete c; }
+
+int avf_feed_from_calls(uint32_t n_inputs, const avf_calls *const *calls, const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int merge,
+                        avf_feed **out) {
+    if (!calls || !g || !out) return fail(AVK_E_ARG, "null argument");
+    *out = nullptr;
+    if (n_inputs == 0) return fail(AVK_E_ARG, "Must provide at least 1 VCF to iterate on");
+    if (n_inputs > 64) return fail(AVK_E_ARG, "at most 64 input VCFs are supported, got %u", n_inputs);
+    if (!merge && n_inputs != 2) return fail(AVK_E_ARG, "a compare feed has exactly two inputs (truth, query), got %u", n_inputs);
+    std::vector<const CallMap *> maps(n_inputs);
+    for (uint32_t i = 0; i < n_inputs; ++i) {
+        if (!calls[i]) return fail(AVK_E_ARG, "null argument");
+        maps[i] = &calls[i]->by_chrom;
+    }
+    avf_feed *f = new avf_feed();
+    const int rc = build_regions(n_inputs, maps.data(), regions_bed, g, min_variant_gap, f);
+    if (rc) {
+        delete f;
+        return rc;
+    }
+    if (merge) fill_multi_batch(f, n_inputs);
+    else fill_compare_batch(f);
     *out = f;
     return 0;
+}
+
+static int feed_from_files(uint32_t k, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap,
+                           int enable_trimming, int merge, avf_feed **out) {
+    /* argument checks that come before any file is read */
+    if (!regions_bed || !*regions_bed) return fail(AVK_E_ARG, "High confidence regions are currently required.");
+    if (min_variant_gap == 0) return fail(AVK_E_ARG, "--min-variant-gap must be >0");
+    std::vector<CallMap> calls;
+    int rc = load_call_sets(k, vcfs, samples, enable_trimming, calls);
+    if (rc) return rc;
+    std::vector<const CallMap *> maps(k);
+    for (uint32_t i = 0; i < k; ++i) maps[i] = &calls[i];
+    avf_feed *f = new avf_feed();
+    rc = build_regions(k, maps.data(), regions_bed, g, min_variant_gap, f);
+    if (rc) {
+        delete f;
+        return rc;
+    }
+    if (merge) fill_multi_batch(f, k);
+    else fill_compare_batch(f);
+    *out = f;
+    return 0;
+}
+
+int avf_feed_compare(const char *truth_vcf, const char *truth_sample, const char *query_vcf, const char *query_sample,
+                     const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
+    if (!truth_vcf || !query_vcf || !g || !out) return fail(AVK_E_ARG, "null argument");
+    *out = nullptr;
+    const char *paths[2] = {truth_vcf, query_vcf}, *samples[2] = {truth_sample, query_sample};
+    return feed_from_files(2, paths, samples, regions_bed, g, min_variant_gap, enable_trimming, 0, out);
+}
+
+int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
+                   uint64_t min_variant_gap, int enable_trimming, avf_feed **out) {
+    if (!vcfs || !g || !out) return fail(AVK_E_ARG, "null argument");
+    *out = nullptr;
+    if (n_inputs == 0) return fail(AVK_E_ARG, "Must provide at least 1 VCF to iterate on");
+    if (n_inputs > 64) return fail(AVK_E_ARG, "at most 64 input VCFs are supported, got %u", n_inputs);
+    for (uint32_t i = 0; i < n_inputs; ++i)
+        if (!vcfs[i]) return fail(AVK_E_ARG, "null argument");
+    return feed_from_files(n_inputs, vcfs, samples, regions_bed, g, min_variant_gap, enable_trimming, 1, out);
 }
 
 const avk_region_batch *avf_feed_batch(const avf_feed *f) { return f && !f->is_merge ? &f->batch : nullptr; }

@@ -134,49 +134,78 @@ extern "C" int avf_write_merge_outputs(const char *out_folder, const char *prima
         if (i) all_tags += ',';
         all_tags += tags[i];
     }
-    std::string rec, info;
     for (uint64_t r = 0; r < b->n_regions; ++r) {
-        if (status[r] != 0) continue;
         const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
-        if (c >= n_contigs) return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
-        const std::string chrom = avf_genome_name(g, c);
-        const uint8_t cls = classification[r];
-        const std::string reason = simplify(cls);
-        /* write_region (:293-311): 0-based start, end, "<reason>_<region id>" */
-        rec = chrom + '\t' + std::to_string(b->start[r]) + '\t' + std::to_string(b->end[r]) + '\t' + reason + '_' + std::to_string(b->region_id[r]) + '\n';
-        (cls == AVK_MERGE_DIFFERENT ? failed_bed : passing_bed).record(chrom, (int64_t)b->start[r], (int64_t)b->end[r], rec);
-        if (cls == AVK_MERGE_DIFFERENT) continue;
-        const std::vector<uint32_t> idx = member_indices(cls, members[r]);
-        const uint32_t source = cls == AVK_MERGE_IDENTICAL ? 0 : idx[0];
-        info = "SOURCES=";
-        if (cls == AVK_MERGE_IDENTICAL) info += all_tags;
-        else
-            for (size_t i = 0; i < idx.size(); ++i) {
-                if (i) info += ',';
-                info += tags[idx[i]];
-            }
-        info += ";MR=" + reason;
-        const uint64_t off = b->in_off[r * k + source];
-        const uint32_t cnt = b->in_cnt[r * k + source];
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint64_t v = off + i;
-            rec = chrom;
-            rec += '\t';
-            rec += std::to_string(b->var_pos[v] + 1);
-            rec += "\t.\t";
-            rec.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
-            rec += '\t';
-            rec.append((const char *)b->allele_bytes + b->a1_off[v], b->a1_len[v]);
-            rec += "\t.\t.\t";
-            rec += info;
-            rec += "\tGT:RI\t";
-            rec += gts[b->var_zyg[v] < 6 ? b->var_zyg[v] : 0];
-            rec += ':';
-            rec += std::to_string((int32_t)b->region_id[r]); /* `region_id as i32` (:263) */
-            rec += '\n';
-            vcf.record(chrom, (int64_t)b->var_pos[v], (int64_t)b->var_pos[v] + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1), rec);
-        }
+        if (status[r] == 0 && c >= n_contigs) return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
     }
+    auto name_of = [&](uint32_t c) { return std::string(avf_genome_name(g, c)); };
+    /* write_region (:293-311): 0-based start, end, "<reason>_<region id>"; passing or failed file */
+    for (int failed = 0; failed < 2; ++failed) {
+        auto format = [&](uint64_t first, uint64_t last, std::string &text, std::vector<avf_tbx::LineMeta> &lines) {
+            for (uint64_t r = first; r < last; ++r) {
+                if (status[r] != 0 || (classification[r] == AVK_MERGE_DIFFERENT) != (failed == 1)) continue;
+                const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
+                const size_t at = text.size();
+                text += avf_genome_name(g, c);
+                text += '\t';
+                text += std::to_string(b->start[r]);
+                text += '\t';
+                text += std::to_string(b->end[r]);
+                text += '\t';
+                text += simplify(classification[r]);
+                text += '_';
+                text += std::to_string(b->region_id[r]);
+                text += '\n';
+                lines.push_back(avf_tbx::LineMeta{c, (uint32_t)(text.size() - at), (int64_t)b->start[r], (int64_t)b->end[r]});
+            }
+            return true;
+        };
+        if (!avf_tbx::format_parallel(b->n_regions, format, name_of, failed ? failed_bed : passing_bed)) return avf_fail_(AVK_E_ARG, "cannot format the region records");
+    }
+    auto format_vcf = [&](uint64_t first, uint64_t last, std::string &text, std::vector<avf_tbx::LineMeta> &lines) {
+        std::string info;
+        for (uint64_t r = first; r < last; ++r) {
+            if (status[r] != 0 || classification[r] == AVK_MERGE_DIFFERENT) continue;
+            const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
+            const char *chrom = avf_genome_name(g, c);
+            const uint8_t cls = classification[r];
+            const std::vector<uint32_t> idx = member_indices(cls, members[r]);
+            const uint32_t source = cls == AVK_MERGE_IDENTICAL ? 0 : idx[0];
+            info = "SOURCES=";
+            if (cls == AVK_MERGE_IDENTICAL) info += all_tags;
+            else
+                for (size_t i = 0; i < idx.size(); ++i) {
+                    if (i) info += ',';
+                    info += tags[idx[i]];
+                }
+            info += ";MR=";
+            info += simplify(cls);
+            const std::string ri = std::to_string((int32_t)b->region_id[r]); /* `region_id as i32` (:263) */
+            const uint64_t off = b->in_off[r * k + source];
+            const uint32_t cnt = b->in_cnt[r * k + source];
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t v = off + i;
+                const size_t at = text.size();
+                text += chrom;
+                text += '\t';
+                text += std::to_string(b->var_pos[v] + 1);
+                text += "\t.\t";
+                text.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
+                text += '\t';
+                text.append((const char *)b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+                text += "\t.\t.\t";
+                text += info;
+                text += "\tGT:RI\t";
+                text += gts[b->var_zyg[v] < 6 ? b->var_zyg[v] : 0];
+                text += ':';
+                text += ri;
+                text += '\n';
+                lines.push_back(avf_tbx::LineMeta{c, (uint32_t)(text.size() - at), (int64_t)b->var_pos[v], (int64_t)b->var_pos[v] + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1)});
+            }
+        }
+        return true;
+    };
+    if (!avf_tbx::format_parallel(b->n_regions, format_vcf, name_of, vcf)) return avf_fail_(AVK_E_ARG, "cannot format the records of passing.vcf.gz");
     const std::string folder = out_folder;
     if (!vcf.finish(folder + "/passing.vcf.gz", 2)) return avf_fail_(AVK_E_ARG, "write error on %s/passing.vcf.gz (or its .tbi)", out_folder);
     if (!passing_bed.finish(folder + "/regions.bed.gz", 0x10000)) return avf_fail_(AVK_E_ARG, "write error on %s/regions.bed.gz (or its .tbi)", out_folder);

@@ -3,6 +3,8 @@
 #define AVF_TBX_H
 #include "avf_bgzf.h"
 
+#include <algorithm>
+#include <atomic>
 #include <map>
 #include <string>
 #include <thread>
@@ -18,7 +20,11 @@ class BgzfWriter {
   public:
     BgzfWriter() { blocks_.emplace_back(); }
     uint64_t tell() const { return ((uint64_t)(blocks_.size() - 1) << 16) | (uint64_t)blocks_.back().size(); }
+    /* bytes written so far, and the logical virtual offset of byte `abs` of the text (every block but the last one is full) */
+    uint64_t size() const { return total_; }
+    static uint64_t logical_at(uint64_t abs) { return ((abs / kBlock) << 16) | (abs % kBlock); }
     void write(const char *p, size_t n) {
+        total_ += n;
         while (n) {
             std::string &cur = blocks_.back();
             const size_t room = kBlock - cur.size();
@@ -66,6 +72,7 @@ class BgzfWriter {
     static bool compress_block(const std::string &in, std::string &out) { return avf_bgzf::compress_block(in.data(), in.size(), out); }
     std::vector<std::string> blocks_;
     std::vector<uint64_t> file_off_;
+    uint64_t total_ = 0;
 };
 
 /* ---- tabix index (tabix spec): binning index + 16 kb linear index per contig ---- */
@@ -98,20 +105,38 @@ class IndexedText {
     void header(const std::string &s) { w_.write(s.data(), s.size()); }
     /* one record line covering [beg, end) (0-based) of sequence `name` */
     void record(const std::string &name, int64_t beg, int64_t end, const std::string &line) {
+        const size_t k = seq_id(name);
+        const uint64_t at = w_.size();
+        w_.write(line.data(), line.size());
+        index_record(k, beg, end, at, at + line.size());
+    }
+    /* the same in two steps, for text formatted elsewhere (by several threads): the sequence's id, then append() the text and
+     * index_record() every line of it with its byte range in the whole text */
+    size_t seq_id(const std::string &name) {
+        if (last_seq_ < names_.size() && names_[last_seq_] == name) return last_seq_;
         auto it = seq_of_.find(name);
-        size_t k;
         if (it == seq_of_.end()) {
-            k = names_.size();
-            seq_of_.emplace(name, k);
+            last_seq_ = names_.size();
+            seq_of_.emplace(name, last_seq_);
             names_.push_back(name);
             index_.emplace_back();
-        } else k = it->second;
-        const uint64_t vbeg = w_.tell();
-        w_.write(line.data(), line.size());
-        const uint64_t vend = w_.tell();
+            last_chunks_ = nullptr;
+        } else last_seq_ = it->second;
+        return last_seq_;
+    }
+    uint64_t text_size() const { return w_.size(); }
+    void append(const char *p, size_t n) { w_.write(p, n); }
+    void index_record(size_t k, int64_t beg, int64_t end, uint64_t abs_beg, uint64_t abs_end) {
+        const uint64_t vbeg = BgzfWriter::logical_at(abs_beg), vend = BgzfWriter::logical_at(abs_end);
         if (end <= beg) end = beg + 1;
         RefIndex &ri = index_[k];
-        auto &chunks = ri.bins[(uint32_t)reg2bin(beg, end)];
+        const uint32_t bin = (uint32_t)reg2bin(beg, end);
+        if (!last_chunks_ || last_bin_seq_ != k || last_bin_ != bin) { /* neighbours mostly share a bin */
+            last_chunks_ = &ri.bins[bin];
+            last_bin_seq_ = k;
+            last_bin_ = bin;
+        }
+        auto &chunks = *last_chunks_;
         if (!chunks.empty() && chunks.back().second == vbeg) chunks.back().second = vend;
         else chunks.emplace_back(vbeg, vend);
         const size_t w0 = (size_t)(beg >> 14), w1 = (size_t)((end - 1) >> 14);
@@ -182,7 +207,57 @@ class IndexedText {
     std::vector<std::string> names_;
     std::map<std::string, size_t> seq_of_;
     std::vector<RefIndex> index_;
+    size_t last_seq_ = (size_t)-1, last_bin_seq_ = (size_t)-1;
+    uint32_t last_bin_ = 0;
+    std::vector<std::pair<uint64_t, uint64_t>> *last_chunks_ = nullptr; /* std::map nodes do not move */
 };
+
+/* Record lines formatted by several threads: fn(first, last, text, lines) appends the lines of items [first, last) to `text` and one
+ * LineMeta per line to `lines` (false = error); the pieces are then appended to `out` and indexed in item order.
+ * name_of(contig) gives the sequence name of LineMeta::contig. */
+struct LineMeta {
+    uint32_t contig;
+    uint32_t len; /* bytes of the line, terminator included */
+    int64_t beg, end;
+};
+template <class Fn, class NameOf> bool format_parallel(uint64_t n_items, Fn &&fn, NameOf &&name_of, IndexedText &out) {
+    unsigned hw = std::thread::hardware_concurrency();
+    const size_t n_threads = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+    const size_t n_pieces = n_items < 512 ? 1 : std::min<size_t>(4 * n_threads, (size_t)(n_items / 128));
+    std::vector<std::string> texts(n_pieces);
+    std::vector<std::vector<LineMeta>> metas(n_pieces);
+    std::vector<char> bad(n_pieces, 0);
+    std::atomic<size_t> next{0};
+    auto work = [&] {
+        for (size_t k = next.fetch_add(1); k < n_pieces; k = next.fetch_add(1)) {
+            const uint64_t first = n_items * k / n_pieces, last = n_items * (k + 1) / n_pieces;
+            if (!fn(first, last, texts[k], metas[k])) bad[k] = 1;
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < std::min(n_threads, n_pieces); ++t) pool.emplace_back(work);
+    work();
+    for (std::thread &t : pool) t.join();
+    for (size_t k = 0; k < n_pieces; ++k)
+        if (bad[k]) return false;
+    for (size_t k = 0; k < n_pieces; ++k) {
+        uint64_t at = out.text_size();
+        out.append(texts[k].data(), texts[k].size());
+        uint32_t last_contig = 0xFFFFFFFFu;
+        size_t seq = 0;
+        for (const LineMeta &m : metas[k]) {
+            if (m.contig != last_contig) {
+                seq = out.seq_id(name_of(m.contig));
+                last_contig = m.contig;
+            }
+            out.index_record(seq, m.beg, m.end, at, at + m.len);
+            at += m.len;
+        }
+        std::string().swap(texts[k]);
+        std::vector<LineMeta>().swap(metas[k]);
+    }
+    return true;
+}
 
 } // namespace avf_tbx
 #endif

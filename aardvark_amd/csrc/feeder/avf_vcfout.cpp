@@ -66,38 +66,50 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
     static const char *const gts[6] = {".", "0/0", "0/1", "0|1", "1|0", "1/1"};
     static const char *const classes[4] = {"UNK", "TP", "FN", "FP"};
     const uint32_t n_contigs = avf_genome_n_contigs(g);
-    std::string rec;
     for (uint64_t r = 0; r < b->n_regions; ++r) {
-        if (status[r] != 0) continue; /* failed regions are not written (compare_parallel.rs:229-262) */
         const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
-        if (c >= n_contigs) return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
-        const std::string chrom = avf_genome_name(g, c);
-        const uint64_t off = source == 0 ? b->t_off[r] : b->q_off[r];
-        const uint32_t cnt = source == 0 ? b->t_cnt[r] : b->q_cnt[r];
-        for (uint32_t i = 0; i < cnt; ++i) {
-            const uint64_t v = off + i;
-            rec = chrom;
-            rec += '\t';
-            rec += std::to_string(b->var_pos[v] + 1);
-            rec += "\t.\t";
-            rec.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
-            rec += '\t';
-            rec.append((const char *)b->allele_bytes + b->a1_off[v], b->a1_len[v]);
-            rec += "\t.\t.\t.\tGT:BD:EA:OA:RI\t";
-            rec += gts[b->var_zyg[v] < 6 ? b->var_zyg[v] : 0];
-            rec += ':';
-            rec += classes[var_class[v] < 4 ? var_class[v] : 0];
-            rec += ':';
-            rec += std::to_string((int)var_expected[v]);
-            rec += ':';
-            rec += std::to_string((int)var_observed[v]);
-            rec += ':';
-            rec += std::to_string((int32_t)b->region_id[r]); /* `region_id as i32` (:205) */
-            rec += '\n';
-            /* index entry: [beg, end) = POS-1 .. POS-1 + len(REF) */
-            out.record(chrom, (int64_t)b->var_pos[v], (int64_t)b->var_pos[v] + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1), rec);
-        }
+        if (status[r] == 0 && c >= n_contigs) return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
     }
+    auto format = [&](uint64_t first, uint64_t last, std::string &text, std::vector<avf_tbx::LineMeta> &lines) {
+        char num[24];
+        for (uint64_t r = first; r < last; ++r) {
+            if (status[r] != 0) continue; /* failed regions are not written (compare_parallel.rs:229-262) */
+            const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
+            const char *chrom = avf_genome_name(g, c);
+            const size_t chrom_len = strlen(chrom);
+            const uint64_t off = source == 0 ? b->t_off[r] : b->q_off[r];
+            const uint32_t cnt = source == 0 ? b->t_cnt[r] : b->q_cnt[r];
+            const int ri_len = snprintf(num, sizeof(num), "%d", (int32_t)b->region_id[r]); /* `region_id as i32` (:205) */
+            const std::string ri(num, (size_t)ri_len);
+            for (uint32_t i = 0; i < cnt; ++i) {
+                const uint64_t v = off + i;
+                const size_t at = text.size();
+                text.append(chrom, chrom_len);
+                text += '\t';
+                text.append(num, (size_t)snprintf(num, sizeof(num), "%llu", (unsigned long long)(b->var_pos[v] + 1)));
+                text += "\t.\t";
+                text.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
+                text += '\t';
+                text.append((const char *)b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+                text += "\t.\t.\t.\tGT:BD:EA:OA:RI\t";
+                text += gts[b->var_zyg[v] < 6 ? b->var_zyg[v] : 0];
+                text += ':';
+                text += classes[var_class[v] < 4 ? var_class[v] : 0];
+                text += ':';
+                text.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)var_expected[v]));
+                text += ':';
+                text.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)var_observed[v]));
+                text += ':';
+                text += ri;
+                text += '\n';
+                /* index entry: [beg, end) = POS-1 .. POS-1 + len(REF) */
+                lines.push_back(avf_tbx::LineMeta{c, (uint32_t)(text.size() - at), (int64_t)b->var_pos[v], (int64_t)b->var_pos[v] + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1)});
+            }
+        }
+        return true;
+    };
+    if (!avf_tbx::format_parallel(b->n_regions, format, [&](uint32_t c) { return std::string(avf_genome_name(g, c)); }, out))
+        return avf_fail_(AVK_E_ARG, "cannot format the records of %s", out_path);
     if (!out.finish(out_path, 2)) return avf_fail_(AVK_E_ARG, "write error on %s (or its .tbi)", out_path);
     return 0;
 }

@@ -58,6 +58,15 @@ const uint32_t *avf_feed_var_alt_index(const avf_feed *f);
 int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
                    uint64_t min_variant_gap, int enable_trimming, avf_feed **out);
 const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f);
+/* The two halves of a feed on their own, so that a caller can read the VCFs while the reference genome is still loading (the reference
+ * preloads its variants the same way, RegionIterator::preload_all_variants, region_generation.rs:199-279):
+ * avf_calls_load parses one VCF (every chromosome), avf_feed_from_calls walks the regions over already loaded call sets.
+ * merge = 0: a compare feed (exactly two inputs: truth, query), merge != 0: a merge feed. */
+typedef struct avf_calls avf_calls;
+int avf_calls_load(const char *vcf, const char *sample, int enable_trimming, avf_calls **out);
+void avf_calls_free(avf_calls *c);
+int avf_feed_from_calls(uint32_t n_inputs, const avf_calls *const *calls, const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int merge,
+                        avf_feed **out);
 /* variants loaded per input after parsing and the chromosome-span filter (the "Loaded N truth variants" log lines) */
 uint64_t avf_feed_loaded_variants(const avf_feed *f, int input);
 void avf_feed_free(avf_feed *f);

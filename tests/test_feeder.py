@@ -143,6 +143,70 @@ def test_edge_case_files_match_the_restatement(tmp_path, mode):
             assert int(b.a0_len[i]) == 1 and int(b.var_raw_space[i]) == 2 and int(b.var_zyg[i]) == ZYG["PhasedHet01"]
 
 
+def test_mapped_fasta_loader_matches_the_line_reader(tmp_path, monkeypatch):
+    """plain FASTA files are parsed from a mapping by several threads, gzip ones line by line: same contigs either way, with CRLF
+    line ends, empty lines, '>' inside header text, no final newline, and piece boundaries at every possible offset"""
+    rng = np.random.default_rng(5)
+    def seq(n):
+        return "".join(rng.choice(list("ACGTNacgt"), size=n))
+    texts = [">c1 desc > more\n" + seq(70) + "\n" + seq(70) + "\n\n" + seq(13) + "\n>c2\tx\n" + seq(5) + "\n>empty\n>c3\n" + seq(200),
+             "\n\r\n>a\r\n" + seq(60) + "\r\n" + seq(60) + "\r\n\r\n" + seq(7) + "\r\n>b x\r\n" + seq(31) + "\r",
+             ">only\n" + seq(1000) + "\n"]
+    for ti, text in enumerate(texts):
+        plain, gz = str(tmp_path / ("f%d.fa" % ti)), str(tmp_path / ("f%d.fa.gz" % ti))
+        write_text(plain, text)
+        write_text(gz, text, "gz")
+        want = feeder.Genome(gz)
+        ref = dict(fo.read_fasta(gz))
+        for piece in ("1", "2", "3", "7", "64", "1000000"):
+            monkeypatch.setenv("AVF_FASTA_PIECE", piece)
+            got = feeder.Genome(plain)
+            assert got.names == want.names
+            for a, b, name in zip(got.contigs(), want.contigs(), got.names):
+                assert bytes(a) == bytes(b) == ref[name].encode()
+    bad = str(tmp_path / "bad.fa")
+    write_text(bad, "\nACGT\n>c\nAC\n")
+    with pytest.raises(feeder.FeederError, match="sequence before the first header"):
+        feeder.Genome(bad)
+
+
+def test_block_parallel_vcf_reader_matches_the_sequential_one(tmp_path, monkeypatch):
+    """VCFs are decompressed on one thread and parsed in blocks of whole lines by others: same calls, same record numbers, same errors
+    as the line-by-line reader, whatever the block size"""
+    paths = {}
+    for name, text in (("ref.fa", EDGE_FASTA), ("hc.bed", EDGE_BED), ("truth.vcf", EDGE_VCF_T), ("query.vcf", EDGE_VCF_Q)):
+        paths[name] = str(tmp_path / name)
+        write_text(paths[name], text, "members" if name.endswith("vcf") else "plain")
+    p, contig, want_batch = write_case_files(tmp_path, 800, 400_000)
+    cases = [(paths["ref.fa"], paths["truth.vcf"], paths["query.vcf"], paths["hc.bed"], "S1", True), (p["fa"], p["t"], p["q"], p["bed"], "", False)]
+    for fa, t, q, bed, sample, trimming in cases:
+        genome = feeder.Genome(fa)
+        monkeypatch.setenv("AVF_SEQUENTIAL_VCF", "1")
+        want = feeder.feed_compare(t, q, bed, genome, truth_sample=sample, enable_trimming=trimming)
+        monkeypatch.delenv("AVF_SEQUENTIAL_VCF")
+        for block in ("16", "100", "5000", "4194304"):
+            monkeypatch.setenv("AVF_VCF_BLOCK", block)
+            got = feeder.feed_compare(t, q, bed, genome, truth_sample=sample, enable_trimming=trimming)
+            assert_same_batch(got.batch, want.batch)
+            assert np.array_equal(got.var_record, want.var_record) and np.array_equal(got.var_alt_index, want.var_alt_index) and got.loaded == want.loaded
+    # an error deep in the file is reported exactly like the sequential reader reports it
+    genome = feeder.Genome(p["fa"])
+    lines = gzip.open(p["t"], "rt").read().splitlines()
+    lines[len(lines) // 2] = lines[len(lines) // 2].replace("\tGT\t", "\tDP\t")
+    bad = str(tmp_path / "bad_mid.vcf")
+    write_text(bad, "\n".join(lines) + "\n")
+    msgs = []
+    for env in ({"AVF_SEQUENTIAL_VCF": "1"}, {"AVF_VCF_BLOCK": "200"}, {}):
+        for k in ("AVF_SEQUENTIAL_VCF", "AVF_VCF_BLOCK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with pytest.raises(feeder.FeederError) as e:
+            feeder.feed_compare(bad, p["q"], p["bed"], genome)
+        msgs.append(str(e.value))
+    assert "Missing GT" in msgs[0] and msgs[0] == msgs[1] == msgs[2]
+
+
 def test_errors_are_reported(tmp_path):
     fa, bed = str(tmp_path / "r.fa"), str(tmp_path / "r.bed")
     write_text(fa, EDGE_FASTA)

@@ -23,6 +23,10 @@ bedf = open(os.path.join(d, "hc.bed"), "w")
 vt = gzip.open(os.path.join(d, "truth.vcf.gz"), "wt", compresslevel=1)
 vq = gzip.open(os.path.join(d, "query.vcf.gz"), "wt", compresslevel=1)
 vt.write(hdr); vq.write(hdr)
+n_merge = int(os.environ.get("MERGE_INPUTS", "0"))  # also run `merge` with truth + query + (n_merge - 2) more callers of the same sample
+vm = [gzip.open(os.path.join(d, "caller%d.vcf.gz" % i), "wt", compresslevel=1) for i in range(2, n_merge)]
+for f in vm:
+    f.write(hdr)
 n_regions = n_truth = 0
 for ci, (name, full) in enumerate(zip(NAMES, GRCH38)):
     length = max(int(full * scale), 200_000)
@@ -40,8 +44,11 @@ for ci, (name, full) in enumerate(zip(NAMES, GRCH38)):
     bedf.write("".join("%s\t%d\t%d\n" % (name, a, b) for a, b in bed))
     for f, cs in ((vt, truth), (vq, query)):
         f.write("".join("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (name, int(cs.pos[i]) + 1, cs.ref[i].decode(), cs.alt[i].decode(), GT[int(cs.zyg[i])]) for i in range(len(cs))))
+    for i, f in enumerate(vm):
+        cs = synth.perturb_query(contig, bed, truth, 20250105 + 1000 * i + ci, max(1, len(truth) // 100))
+        f.write("".join("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (name, int(cs.pos[j]) + 1, cs.ref[j].decode(), cs.alt[j].decode(), GT[int(cs.zyg[j])]) for j in range(len(cs))))
     del contig, truth, query, rows, body
-for f in (fa, bedf, vt, vq):
+for f in [fa, bedf, vt, vq] + vm:
     f.close()
 print("fixtures: %d truth variants over %d contigs (scale %.2f) written to %s in %.0f s" % (n_truth, len(NAMES), scale, d, time.time() - t0), flush=True)
 cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", os.path.join(d, "genome.fa"), "-t", os.path.join(d, "truth.vcf.gz"),
@@ -51,4 +58,14 @@ r = subprocess.run(cmd, capture_output=True, text=True)
 print("exit %d, wall %.2f s" % (r.returncode, time.time() - t0))
 print("\n".join(l for l in r.stderr.strip().splitlines() if not l.startswith("Error while solving")))
 print(open(os.path.join(d, "out", "summary.tsv")).read())
+if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote over the callers
+    vcfs = [os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz")] + [os.path.join(d, "caller%d.vcf.gz" % i) for i in range(2, n_merge)]
+    cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, "genome.fa")] + [x for v in vcfs for x in ("-i", v)] + \
+          ["-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "merged"), "--output-summary", os.path.join(d, "merge_summary.tsv"), "--merge-strategy", "majority",
+           "--disable-variant-trimming"]
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    print("merge of %d inputs: exit %d, wall %.2f s" % (n_merge, r.returncode, time.time() - t0))
+    print("\n".join(l for l in r.stderr.strip().splitlines() if not l.startswith("Error while solving")))
+    print(open(os.path.join(d, "merge_summary.tsv")).read())
 subprocess.run(["rm", "-rf", d])
