@@ -5,6 +5,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <thread>
@@ -146,13 +149,16 @@ class IndexedText {
     }
     /* format: 2 = VCF (col_seq 1, col_beg 2, col_end 0), 0x10000 = zero-based BED (1, 2, 3) */
     bool finish(const std::string &path, int format) {
+        const bool timing = getenv("AVF_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         FILE *fp = fopen(path.c_str(), "wb");
         if (!fp) return false;
         int threads = (int)std::thread::hardware_concurrency();
-        if (threads > 8) threads = 8;
+        if (threads > 16) threads = 16;
         bool ok = w_.finish(fp, threads);
         ok = (fclose(fp) == 0) && ok;
         if (!ok) return false;
+        if (timing) fprintf(stderr, "[avf] compress + write %s: %.3f s\n", path.c_str(), std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         for (RefIndex &ri : index_) { /* logical virtual offsets -> the file's */
             for (auto &kv : ri.bins)
                 for (auto &ch : kv.second) {
@@ -234,10 +240,13 @@ template <class Fn, class NameOf> bool format_parallel(uint64_t n_items, Fn &&fn
             if (!fn(first, last, texts[k], metas[k])) bad[k] = 1;
         }
     };
+    const bool timing = getenv("AVF_TIMING") != nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     std::vector<std::thread> pool;
     for (size_t t = 1; t < std::min(n_threads, n_pieces); ++t) pool.emplace_back(work);
     work();
     for (std::thread &t : pool) t.join();
+    if (timing) fprintf(stderr, "[avf] format %zu pieces: %.3f s\n", n_pieces, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     for (size_t k = 0; k < n_pieces; ++k)
         if (bad[k]) return false;
     for (size_t k = 0; k < n_pieces; ++k) {
@@ -256,6 +265,7 @@ template <class Fn, class NameOf> bool format_parallel(uint64_t n_items, Fn &&fn
         std::string().swap(texts[k]);
         std::vector<LineMeta>().swap(metas[k]);
     }
+    if (timing) fprintf(stderr, "[avf] format + append + index: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     return true;
 }
 

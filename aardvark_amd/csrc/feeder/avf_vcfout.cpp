@@ -8,6 +8,7 @@
 #include "avf_tbx.h"
 
 #include <algorithm>
+#include <charconv>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -72,6 +73,20 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
     }
     auto format = [&](uint64_t first, uint64_t last, std::string &text, std::vector<avf_tbx::LineMeta> &lines) {
         char num[24];
+        auto put_u64 = [&](uint64_t v) { text.append(num, (size_t)(std::to_chars(num, num + sizeof(num), v).ptr - num)); };
+        auto put_i32 = [&](int32_t v) { text.append(num, (size_t)(std::to_chars(num, num + sizeof(num), v).ptr - num)); };
+        {
+            uint64_t n_lines = 0, n_allele = 0;
+            for (uint64_t r = first; r < last; ++r) {
+                if (status[r] != 0) continue;
+                const uint64_t off = source == 0 ? b->t_off[r] : b->q_off[r];
+                const uint32_t cnt = source == 0 ? b->t_cnt[r] : b->q_cnt[r];
+                n_lines += cnt;
+                for (uint32_t i = 0; i < cnt; ++i) n_allele += (uint64_t)b->a0_len[off + i] + b->a1_len[off + i];
+            }
+            text.reserve(text.size() + n_lines * 64 + n_allele);
+            lines.reserve(lines.size() + n_lines);
+        }
         for (uint64_t r = first; r < last; ++r) {
             if (status[r] != 0) continue; /* failed regions are not written (compare_parallel.rs:229-262) */
             const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
@@ -79,14 +94,14 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
             const size_t chrom_len = strlen(chrom);
             const uint64_t off = source == 0 ? b->t_off[r] : b->q_off[r];
             const uint32_t cnt = source == 0 ? b->t_cnt[r] : b->q_cnt[r];
-            const int ri_len = snprintf(num, sizeof(num), "%d", (int32_t)b->region_id[r]); /* `region_id as i32` (:205) */
-            const std::string ri(num, (size_t)ri_len);
+            char ri[16];
+            const size_t ri_len = (size_t)(std::to_chars(ri, ri + sizeof(ri), (int32_t)b->region_id[r]).ptr - ri); /* `region_id as i32` (:205) */
             for (uint32_t i = 0; i < cnt; ++i) {
                 const uint64_t v = off + i;
                 const size_t at = text.size();
                 text.append(chrom, chrom_len);
                 text += '\t';
-                text.append(num, (size_t)snprintf(num, sizeof(num), "%llu", (unsigned long long)(b->var_pos[v] + 1)));
+                put_u64(b->var_pos[v] + 1);
                 text += "\t.\t";
                 text.append((const char *)b->allele_bytes + b->a0_off[v], b->a0_len[v]);
                 text += '\t';
@@ -96,11 +111,11 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
                 text += ':';
                 text += classes[var_class[v] < 4 ? var_class[v] : 0];
                 text += ':';
-                text.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)var_expected[v]));
+                put_i32((int32_t)var_expected[v]);
                 text += ':';
-                text.append(num, (size_t)snprintf(num, sizeof(num), "%d", (int)var_observed[v]));
+                put_i32((int32_t)var_observed[v]);
                 text += ':';
-                text += ri;
+                text.append(ri, ri_len);
                 text += '\n';
                 /* index entry: [beg, end) = POS-1 .. POS-1 + len(REF) */
                 lines.push_back(avf_tbx::LineMeta{c, (uint32_t)(text.size() - at), (int64_t)b->var_pos[v], (int64_t)b->var_pos[v] + (int64_t)(b->a0_len[v] ? b->a0_len[v] : 1)});
