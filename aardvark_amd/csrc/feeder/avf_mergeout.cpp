@@ -15,6 +15,7 @@
 #include <cstring>
 #include <map>
 #include <string>
+#include <thread>
 #include <tuple>
 #include <vector>
 
@@ -139,8 +140,12 @@ extern "C" int avf_write_merge_outputs(const char *out_folder, const char *prima
         if (status[r] == 0 && c >= n_contigs) return avf_fail_(AVK_E_ARG, "region %llu refers to contig %u of %u", (unsigned long long)r, c, n_contigs);
     }
     auto name_of = [&](uint32_t c) { return std::string(avf_genome_name(g, c)); };
-    /* write_region (:293-311): 0-based start, end, "<reason>_<region id>"; passing or failed file */
-    for (int failed = 0; failed < 2; ++failed) {
+    /* the three files are formatted, compressed and indexed side by side */
+    const std::string folder = out_folder;
+    bool ok_file[3] = {true, true, true};
+    auto bed_file = [&](int failed) {
+        avf_tbx::IndexedText &dst = failed ? failed_bed : passing_bed;
+        /* write_region (:293-311): 0-based start, end, "<reason>_<region id>"; passing or failed file */
         auto format = [&](uint64_t first, uint64_t last, std::string &text, std::vector<avf_tbx::LineMeta> &lines) {
             for (uint64_t r = first; r < last; ++r) {
                 if (status[r] != 0 || (classification[r] == AVK_MERGE_DIFFERENT) != (failed == 1)) continue;
@@ -160,8 +165,10 @@ extern "C" int avf_write_merge_outputs(const char *out_folder, const char *prima
             }
             return true;
         };
-        if (!avf_tbx::format_parallel(b->n_regions, format, name_of, failed ? failed_bed : passing_bed)) return avf_fail_(AVK_E_ARG, "cannot format the region records");
-    }
+        ok_file[1 + failed] = avf_tbx::format_parallel(b->n_regions, format, name_of, dst) &&
+                              dst.finish(folder + (failed ? "/failed_regions.bed.gz" : "/regions.bed.gz"), 0x10000);
+    };
+    std::thread th_pass(bed_file, 0), th_fail(bed_file, 1);
     auto format_vcf = [&](uint64_t first, uint64_t last, std::string &text, std::vector<avf_tbx::LineMeta> &lines) {
         std::string info;
         for (uint64_t r = first; r < last; ++r) {
@@ -205,12 +212,12 @@ extern "C" int avf_write_merge_outputs(const char *out_folder, const char *prima
         }
         return true;
     };
-    if (!avf_tbx::format_parallel(b->n_regions, format_vcf, name_of, vcf)) return avf_fail_(AVK_E_ARG, "cannot format the records of passing.vcf.gz");
-    const std::string folder = out_folder;
-    if (!vcf.finish(folder + "/passing.vcf.gz", 2)) return avf_fail_(AVK_E_ARG, "write error on %s/passing.vcf.gz (or its .tbi)", out_folder);
-    if (!passing_bed.finish(folder + "/regions.bed.gz", 0x10000)) return avf_fail_(AVK_E_ARG, "write error on %s/regions.bed.gz (or its .tbi)", out_folder);
-    if (!failed_bed.finish(folder + "/failed_regions.bed.gz", 0x10000))
-        return avf_fail_(AVK_E_ARG, "write error on %s/failed_regions.bed.gz (or its .tbi)", out_folder);
+    ok_file[0] = avf_tbx::format_parallel(b->n_regions, format_vcf, name_of, vcf) && vcf.finish(folder + "/passing.vcf.gz", 2);
+    th_pass.join();
+    th_fail.join();
+    if (!ok_file[0]) return avf_fail_(AVK_E_ARG, "write error on %s/passing.vcf.gz (or its .tbi)", out_folder);
+    if (!ok_file[1]) return avf_fail_(AVK_E_ARG, "write error on %s/regions.bed.gz (or its .tbi)", out_folder);
+    if (!ok_file[2]) return avf_fail_(AVK_E_ARG, "write error on %s/failed_regions.bed.gz (or its .tbi)", out_folder);
     return 0;
 }
 
