@@ -442,8 +442,20 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     std::vector<uint64_t> seq_off(batch->n_regions);
     std::vector<uint32_t> seq_stride(batch->n_regions);
     uint64_t seq_total = 0;
+    {
+        const uint64_t nr = batch->n_regions;
+        size_t nt = std::thread::hardware_concurrency();
+        if (nt > 16) nt = 16;
+        if (nt > nr / 65536 + 1) nt = (size_t)(nr / 65536 + 1);
+        auto part = [&](size_t t) {
+            for (uint64_t r = nr * t / nt; r < nr * (t + 1) / nt; ++r) seq_stride[r] = avk::seq_stride_of(batch, r);
+        };
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; ++t) pool.emplace_back(part, t);
+        part(0);
+        for (auto &th : pool) th.join();
+    }
     for (uint64_t r = 0; r < batch->n_regions; ++r) {
-        seq_stride[r] = avk::seq_stride_of(batch, r);
         seq_off[r] = seq_total;
         seq_total += 5ull * seq_stride[r];
     }
@@ -498,7 +510,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
-    const std::vector<AvkDevRegion> sorted = avk::regions_in_work_order(db->host, order);
+    const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(db->host, order);
     if (n) e = hipMemcpyAsync(db->d_regions, sorted.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_blob, db->host.blob.data(), db->host.blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -13,6 +13,7 @@
 
 #include <cstring>
 #include <string>
+#include <functional>
 #include <thread>
 #include <vector>
 
@@ -24,12 +25,24 @@ namespace avk {
 static const uint8_t AVK_SUP_TYPES[8] = {AVK_VT_SNV, AVK_VT_INSERTION, AVK_VT_DELETION, AVK_VT_INDEL,
                                          AVK_VT_TR_CONTRACTION, AVK_VT_TR_EXPANSION, AVK_VT_SV_DELETION, AVK_VT_SV_INSERTION};
 
+/* vectors of plain records whose resize() leaves new elements uninitialised: the packer's threads write every byte that is read */
+template <class T> struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    template <class U, class... A> void construct(U *p, A &&...a) {
+        if constexpr (sizeof...(A) == 0) ::new ((void *)p) U;
+        else ::new ((void *)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T> using PodVec = std::vector<T, NoInitAlloc<T>>;
+
 struct PackedBatch {
-    std::vector<AvkDevRegion> regions;
-    std::vector<uint32_t> blob;          /* what the device reads: one blob per region (AvkBlobVar in avk_dev_types.h) */
-    std::vector<AvkDevVariant> variants; /* host-side only */
+    PodVec<AvkDevRegion> regions;
+    PodVec<uint32_t> blob;          /* what the device reads: one blob per region (AvkBlobVar in avk_dev_types.h) */
+    PodVec<AvkDevVariant> variants; /* host-side only */
     std::vector<uint8_t> alleles;        /* host-side only */
-    std::vector<uint64_t> dev2host; /* device variant index -> caller variant index */
+    PodVec<uint64_t> dev2host; /* device variant index -> caller variant index */
     std::vector<uint8_t> zyg_flags; /* per region: bit 0 an Unknown zygosity, bit 1 a HomozygousReference one */
     std::vector<int64_t> delta_t, delta_q; /* variant_delta_length per side (merge_solver.rs:211-223) */
     uint64_t seq_total = 0;
@@ -41,6 +54,7 @@ inline uint32_t seq_stride_of(const avk_region_batch *b, uint64_t r) {
     for (int side = 0; side < 2; ++side) {
         uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
         uint32_t cnt = side == 0 ? b->t_cnt[r] : b->q_cnt[r];
+        if (off > b->n_variants || (uint64_t)cnt > b->n_variants - off) return 1; /* the packer rejects the batch */
         for (uint32_t i = 0; i < cnt; ++i) {
             uint64_t v = off + i;
             if (b->a1_len[v] > b->a0_len[v]) g[side] += b->a1_len[v] - b->a0_len[v];
@@ -111,59 +125,98 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
         *err = "batch too large (more than 2^31 regions or variants); split it";
         return AVK_E_ARG;
     }
-    out->regions.assign(n, AvkDevRegion());
+    out->regions.resize(n);
     out->zyg_flags.assign(n, 0);
     out->delta_t.assign(n, 0);
     out->delta_q.assign(n, 0);
-    /* pass 1: layout */
-    std::vector<uint64_t> blob_at(n + 1, 0); /* in words */
-    uint64_t nv = 0;
-    for (uint64_t r = 0; r < n; ++r) {
-        AvkDevRegion &dr = out->regions[r];
-        memset(&dr, 0, sizeof(dr));
-        const uint32_t tc = b->t_cnt[r], qc = b->q_cnt[r];
-        uint64_t alle = 0;
-        for (int side = 0; side < 2; ++side) {
-            const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
-            const uint32_t cnt = side == 0 ? tc : qc;
-            if (off > b->n_variants || (uint64_t)cnt > b->n_variants - off) {
-                *err = "variant range of a region exceeds n_variants";
+    /* the same cut of the regions into ranges for both passes */
+    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if ((uint64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
+    if (nt < 1) nt = 1;
+    auto range_lo = [&](int t) { return n * (uint64_t)t / (uint64_t)nt; };
+    auto run_ranges = [&](const std::function<int(int, std::string *)> &fn) -> int {
+        std::vector<int> rcs((size_t)nt, 0);
+        std::vector<std::string> errs((size_t)nt);
+        if (nt == 1) rcs[0] = fn(0, &errs[0]);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t) pool.emplace_back([&, t] { rcs[(size_t)t] = fn(t, &errs[(size_t)t]); });
+            for (auto &th : pool) th.join();
+        }
+        for (int t = 0; t < nt; ++t)
+            if (rcs[(size_t)t]) {
+                *err = errs[(size_t)t];
+                return rcs[(size_t)t];
+            }
+        return 0;
+    };
+    /* pass 1: sizes — variant records and blob words per region (kept in the record), summed per range */
+    std::vector<uint64_t> nv_at((size_t)nt + 1, 0), words_at((size_t)nt + 1, 0);
+    int rc1 = run_ranges([&](int t, std::string *werr) -> int {
+        uint64_t nv_t = 0, words_t = 0;
+        for (uint64_t r = range_lo(t); r < range_lo(t + 1); ++r) {
+            AvkDevRegion &dr = out->regions[r];
+            memset(&dr, 0, sizeof(dr));
+            const uint32_t tc = b->t_cnt[r], qc = b->q_cnt[r];
+            uint64_t alle = 0;
+            for (int side = 0; side < 2; ++side) {
+                const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
+                const uint32_t cnt = side == 0 ? tc : qc;
+                if (off > b->n_variants || (uint64_t)cnt > b->n_variants - off) {
+                    *werr = "variant range of a region exceeds n_variants";
+                    return AVK_E_ARG;
+                }
+                for (uint32_t i = 0; i < cnt; ++i) alle += (uint64_t)b->a0_len[off + i] + b->a1_len[off + i];
+            }
+            const uint64_t N = (uint64_t)tc + qc;
+            dr.t_cnt = tc;
+            dr.q_cnt = qc;
+            nv_t += N;
+            uint64_t bytes = 0;
+            if (N <= 60000) bytes = (((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull) + ((alle + 15) & ~15ull) + (uint64_t)N * sizeof(AvkOrdVar) + 32;
+            if (bytes > 0x7FFFFFFFull) {
+                *werr = "region blob exceeds 2 GiB; split the region's alleles";
                 return AVK_E_ARG;
             }
-            for (uint32_t i = 0; i < cnt; ++i) alle += (uint64_t)b->a0_len[off + i] + b->a1_len[off + i];
+            dr.blob_bytes = (uint32_t)bytes;
+            dr.alle_bytes = (uint32_t)(alle < 0xFFFFFFFFull ? alle : 0xFFFFFFFFull);
+            words_t += bytes / 4;
         }
-        const uint64_t N = (uint64_t)tc + qc;
-        dr.v_off = (uint32_t)nv;
-        dr.t_cnt = tc;
-        dr.q_cnt = qc;
-        nv += N;
-        if (nv > 0x7FFFFFFFull) {
-            *err = "more than 2^31 variant records; split the batch";
-            return AVK_E_ARG;
-        }
-        uint64_t bytes = 0;
-        if (N <= 60000) bytes = (((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull) + ((alle + 15) & ~15ull) + (uint64_t)N * sizeof(AvkOrdVar) + 32;
-        if (bytes > 0x7FFFFFFFull) {
-            *err = "region blob exceeds 2 GiB; split the region's alleles";
-            return AVK_E_ARG;
-        }
-        dr.blob_bytes = (uint32_t)bytes;
-        dr.alle_bytes = (uint32_t)(alle < 0xFFFFFFFFull ? alle : 0xFFFFFFFFull);
-        blob_at[r + 1] = blob_at[r] + bytes / 4;
-        if (blob_at[r + 1] / 2 > 0xFFFFFFFFull) {
-            *err = "region blob arena exceeds its limits; split the batch";
-            return AVK_E_ARG;
-        }
+        nv_at[(size_t)t + 1] = nv_t;
+        words_at[(size_t)t + 1] = words_t;
+        return 0;
+    });
+    if (rc1) return rc1;
+    for (int t = 0; t < nt; ++t) {
+        nv_at[(size_t)t + 1] += nv_at[(size_t)t];
+        words_at[(size_t)t + 1] += words_at[(size_t)t];
     }
-    out->variants.assign(nv, AvkDevVariant());
-    out->dev2host.assign(nv, 0);
+    const uint64_t nv = nv_at[(size_t)nt], n_words = words_at[(size_t)nt];
+    if (nv > 0x7FFFFFFFull) {
+        *err = "more than 2^31 variant records; split the batch";
+        return AVK_E_ARG;
+    }
+    if (n_words / 2 > 0xFFFFFFFFull) {
+        *err = "region blob arena exceeds its limits; split the batch";
+        return AVK_E_ARG;
+    }
+    out->variants.resize(nv);
+    out->dev2host.resize(nv);
     out->alleles.assign(1, 0);
-    out->blob.assign(blob_at[n] ? blob_at[n] : 2, 0);
+    out->blob.resize(n_words ? n_words : 2);
+    if (!n_words) out->blob[0] = out->blob[1] = 0;
 
     /* pass 2: validation and blobs, region by region */
-    auto pack_range = [&](uint64_t r0, uint64_t r1, std::string *werr) -> int {
-        for (uint64_t r = r0; r < r1; ++r) {
+    auto pack_range = [&](int t, std::string *werr) -> int {
+        uint64_t v_at = nv_at[(size_t)t], w_at = words_at[(size_t)t]; /* running offsets of this range */
+        for (uint64_t r = range_lo(t); r < range_lo(t + 1); ++r) {
             AvkDevRegion &dr = out->regions[r];
+            const uint64_t blob_word = w_at;
+            dr.v_off = (uint32_t)v_at;
+            v_at += (uint64_t)dr.t_cnt + dr.q_cnt;
+            w_at += dr.blob_bytes / 4;
+            if (dr.blob_bytes) memset(out->blob.data() + blob_word, 0, dr.blob_bytes); /* padding between the parts stays zero */
             const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
             const uint64_t start = b->start[r], end = b->end[r];
             uint32_t pre = 0;
@@ -233,7 +286,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             /* the region's blob */
             const uint64_t alle = dr.alle_bytes;
             const uint64_t vb = ((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull, ab = (alle + 15) & ~15ull, ob = (uint64_t)N * sizeof(AvkOrdVar);
-            uint8_t *base = (uint8_t *)(out->blob.data() + blob_at[r]);
+            uint8_t *base = (uint8_t *)(out->blob.data() + blob_word);
             AvkBlobVar *bv = (AvkBlobVar *)base;
             uint8_t *ba = base + vb;
             AvkOrdVar *bo = (AvkOrdVar *)(base + vb + ab);
@@ -279,29 +332,14 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                 for (uint32_t o2 = 0; o2 + 1 < N; ++o2) bo[o2].sync = bo[o2 + 1].rel_pos;
             }
             for (int t = 0; t < 8; ++t) bc[t] = counts[t];
-            dr.blob_off = (uint32_t)(blob_at[r] / 2);
+            dr.blob_off = (uint32_t)(blob_word / 2);
             dr.grow = (uint32_t)(g[0] > g[1] ? g[0] : g[1]);
             dr.pre_status |= types << 16;
             dr.ed_bound = (uint32_t)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
         }
         return 0;
     };
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
-    if (nt > 16) nt = 16;
-    if ((uint64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
-    if (nt <= 1) return pack_range(0, n, err);
-    std::vector<std::thread> pool;
-    std::vector<int> rcs((size_t)nt, 0);
-    std::vector<std::string> errs((size_t)nt);
-    for (int t = 0; t < nt; ++t)
-        pool.emplace_back([&, t] { rcs[(size_t)t] = pack_range(n * (uint64_t)t / nt, n * (uint64_t)(t + 1) / nt, &errs[(size_t)t]); });
-    for (auto &th : pool) th.join();
-    for (int t = 0; t < nt; ++t)
-        if (rcs[(size_t)t]) {
-            *err = errs[(size_t)t];
-            return rcs[(size_t)t];
-        }
-    return 0;
+    return run_ranges(pack_range);
 }
 
 
@@ -321,12 +359,24 @@ inline uint64_t bulk_slice_bytes(uint64_t lds_bytes_per_wave) {
 }
 
 /* the region records in work order, each remembering where it came from */
-inline std::vector<AvkDevRegion> regions_in_work_order(const PackedBatch &pb, const std::vector<uint32_t> &order) {
-    std::vector<AvkDevRegion> out(order.size());
-    for (size_t k = 0; k < order.size(); ++k) {
-        out[k] = pb.regions[order[k]];
-        out[k].orig = order[k];
-    }
+inline PodVec<AvkDevRegion> regions_in_work_order(const PackedBatch &pb, const std::vector<uint32_t> &order) {
+    PodVec<AvkDevRegion> out;
+    out.resize(order.size());
+    const size_t n = order.size();
+    size_t nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt > n / 65536 + 1) nt = n / 65536 + 1;
+    if (nt < 1) nt = 1;
+    auto part = [&](size_t t) {
+        for (size_t k = n * t / nt; k < n * (t + 1) / nt; ++k) {
+            out[k] = pb.regions[order[k]];
+            out[k].orig = order[k];
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (auto &th : pool) th.join();
     return out;
 }
 

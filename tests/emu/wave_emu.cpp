@@ -330,7 +330,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint32_t> order;
     const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
                                                     getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u);
-    const std::vector<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
+    const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     a.regions = sorted.data();
     const uint32_t *list = nullptr, *count = nullptr;
     int nlist = 0;
