@@ -3,7 +3,7 @@
  * two C-ABIs: libaardvark_feeder.so turns FASTA + BED + truth/query VCFs into region batches, libaardvark_amd.so
  * solves them on the GPU, the feeder library writes summary.tsv.  Option names are the reference's
  * (src/cli/compare.rs), --stratification included.  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).
- * --output-debug writes region_summary.tsv.gz and region_sequences.tsv.gz (not cli_settings.json).
+ * --output-debug writes cli_settings.json, region_summary.tsv.gz and region_sequences.tsv.gz.
  */
 #include <cerrno>
 #include <chrono>
@@ -36,12 +36,29 @@ void usage() {
             "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
 }
 
+std::string json_string(const std::string &s) {
+    std::string out = "\"";
+    for (unsigned char c : s) {
+        if (c == '"') out += "\\\"";
+        else if (c == '\\') out += "\\\\";
+        else if (c == '\n') out += "\\n";
+        else if (c == '\t') out += "\\t";
+        else if (c == '\r') out += "\\r";
+        else if (c < 0x20) {
+            char buf[8];
+            snprintf(buf, sizeof(buf), "\\u%04x", c);
+            out += buf;
+        } else out.push_back((char)c);
+    }
+    return out + "\"";
+}
+
 } // namespace
 
 int main(int argc, char **argv) {
     const auto t_start = std::chrono::steady_clock::now();
     std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare", strat_tsv, debug_dir;
-    uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000;
+    uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000, threads = 1, max_ed = 5000, verbosity = 0;
     bool trimming = true, shortcut = false, hap = false, whap = false, rbp = false;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
@@ -69,7 +86,9 @@ int main(int argc, char **argv) {
         else if (a == "--take") take = strtoull(val(), nullptr, 10);
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
-        else if (a == "--threads" || a == "--max-edit-distance") (void)val(); /* accepted for command-line compatibility */
+        else if (a == "--threads") threads = strtoull(val(), nullptr, 10);          /* accepted for command-line compatibility */
+        else if (a == "--max-edit-distance") max_ed = strtoull(val(), nullptr, 10); /* hidden in the reference as well, unused by it */
+        else if (a == "-v" || a == "--verbose") verbosity += 1;
         else if (a == "-s" || a == "--stratification") strat_tsv = val();
         else if (a == "--output-debug") debug_dir = val();
         else if (a == "-h" || a == "--help") {
@@ -86,6 +105,42 @@ int main(int argc, char **argv) {
     if (batch_regions == 0) batch_regions = 1;
     if (mkdir(out_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create output folder", out_dir.c_str());
     if (!debug_dir.empty() && mkdir(debug_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create debug folder", debug_dir.c_str());
+    if (!debug_dir.empty()) { /* the CLI options as the reference saves them (src/main.rs:64-82; serde field order of CompareSettings) */
+        auto opt = [&](const std::string &v) { return v.empty() ? std::string("null") : json_string(v); };
+        auto flag = [](bool v) { return std::string(v ? "true" : "false"); };
+        std::string samples[2] = {truth_sample, query_sample};
+        const std::string *files[2] = {&truth, &query};
+        for (int i = 0; i < 2; ++i) { /* the first sample of the file when none was named (src/cli/compare.rs:186-194) */
+            char first[4096];
+            if (samples[i].empty() && avf_vcf_sample_name(files[i]->c_str(), 0, first, sizeof(first)) == 0) samples[i] = first;
+        }
+        std::string js = "{\n";
+        js += "  \"aardvark_version\": " + json_string(avk_version()) + ",\n";
+        js += "  \"reference_fn\": " + json_string(ref) + ",\n";
+        js += "  \"truth_vcf_filename\": " + json_string(truth) + ",\n";
+        js += "  \"query_vcf_filename\": " + json_string(query) + ",\n";
+        js += "  \"regions\": " + opt(bed) + ",\n";
+        js += "  \"stratifications\": " + opt(strat_tsv) + ",\n";
+        js += "  \"output_folder\": " + json_string(out_dir) + ",\n";
+        js += "  \"debug_folder\": " + json_string(debug_dir) + ",\n";
+        js += "  \"compare_label\": " + json_string(label) + ",\n";
+        js += "  \"truth_sample\": " + json_string(samples[0]) + ",\n";
+        js += "  \"query_sample\": " + json_string(samples[1]) + ",\n";
+        js += "  \"min_variant_gap\": " + std::to_string(gap) + ",\n";
+        js += "  \"disable_variant_trimming\": " + flag(!trimming) + ",\n";
+        js += "  \"max_edit_distance\": " + std::to_string(max_ed) + ",\n";
+        js += "  \"max_branch_factor\": " + std::to_string(branch) + ",\n";
+        js += "  \"enable_exact_shortcut\": " + flag(shortcut) + ",\n";
+        js += "  \"enable_haplotype_scoring\": " + flag(hap) + ",\n";
+        js += "  \"enable_weighted_haplotype_scoring\": " + flag(whap) + ",\n";
+        js += "  \"enable_record_basepair_scoring\": " + flag(rbp) + ",\n";
+        js += "  \"threads\": " + std::to_string(threads ? threads : 1) + ",\n";
+        js += "  \"verbosity\": " + std::to_string(verbosity) + ",\n";
+        js += "  \"skip_blocks\": " + std::to_string(skip) + ",\n";
+        js += "  \"take_blocks\": " + (take ? std::to_string(take) : std::string("18446744073709551615")) + "\n}";
+        FILE *fp = fopen((debug_dir + "/cli_settings.json").c_str(), "wb");
+        if (!fp || fwrite(js.data(), 1, js.size(), fp) != js.size() || fclose(fp) != 0) die(74, "Error while saving CLI options", debug_dir.c_str());
+    }
 
     /* the reference genome, the two call sets and the GPU context come up side by side */
     auto t0 = std::chrono::steady_clock::now();

@@ -189,7 +189,11 @@ int main(int argc, char **argv) {
         js += "  \"reference_fn\": " + json_string(ref) + ",\n";
         js += "  \"vcf_filenames\": " + json_list(vcfs) + ",\n";
         std::vector<std::string> sample_names(k);
-        for (uint32_t i = 0; i < k; ++i) sample_names[i] = sample_ptrs[i]; /* "" = the file's first sample */
+        for (uint32_t i = 0; i < k; ++i) { /* the first sample of the file when none was named (src/cli/merge.rs:196-198) */
+            sample_names[i] = sample_ptrs[i];
+            char first[4096];
+            if (sample_names[i].empty() && avf_vcf_sample_name(vcfs[i].c_str(), 0, first, sizeof(first)) == 0) sample_names[i] = first;
+        }
         js += "  \"vcf_samples\": " + json_list(sample_names) + ",\n";
         js += "  \"vcf_tags\": " + json_list(tags) + ",\n";
         js += "  \"merge_regions\": " + (bed.empty() ? std::string("null") : json_string(bed)) + ",\n";

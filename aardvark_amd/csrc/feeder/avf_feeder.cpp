@@ -1083,6 +1083,26 @@ static void fill_multi_batch(avf_feed *f, uint32_t n_inputs) {
     b.allele_bytes_len = f->alleles.size();
 }
 
+int avf_vcf_sample_name(const char *vcf, uint32_t index, char *out, uint64_t cap) {
+    if (!vcf || !out || cap == 0) return fail(AVK_E_ARG, "null argument");
+    out[0] = 0;
+    LineReader in(vcf);
+    if (!in.ok()) return fail(AVK_E_ARG, "Error while opening %s", vcf);
+    std::string line;
+    std::vector<std::string> f;
+    while (in.next(line)) {
+        if (line.empty() || line[0] != '#') break;
+        if (line.compare(0, 6, "#CHROM") != 0) continue;
+        split(line, '\t', f);
+        if (f.size() <= 9 + (size_t)index) return fail(AVK_E_ARG, "Sample index %u does not exist.", index);
+        const std::string &name = f[9 + index];
+        if (name.size() + 1 > cap) return fail(AVK_E_ARG, "sample name of %s does not fit %llu bytes", vcf, (unsigned long long)cap);
+        memcpy(out, name.c_str(), name.size() + 1);
+        return 0;
+    }
+    return fail(AVK_E_ARG, "%s has no #CHROM header line", vcf);
+}
+
 int avf_calls_load(const char *vcf, const char *sample, int enable_trimming, avf_calls **out) {
     if (!vcf || !out) return fail(AVK_E_ARG, "null argument");
     *out = nullptr;

@@ -40,6 +40,10 @@ const uint8_t *avf_genome_seq(const avf_genome *g, uint32_t i);
 uint64_t avf_genome_len(const avf_genome *g, uint32_t i);
 void avf_genome_free(avf_genome *g);
 
+/* Name of sample `index` of a VCF's #CHROM line (get_vcf_sample_name, src/parsing/noodles_helper.rs:103-120), copied into out (cap
+ * bytes, always terminated). */
+int avf_vcf_sample_name(const char *vcf, uint32_t index, char *out, uint64_t cap);
+
 /* Region generation for `compare`.  truth_sample / query_sample: NULL or "" = the first sample of the file
  * (src/cli/compare.rs:186-194).  regions_bed is required (region_generation.rs:93-97).  min_variant_gap > 0
  * (default of the reference: 50); enable_trimming = !--disable-variant-trimming.

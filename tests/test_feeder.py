@@ -482,6 +482,16 @@ def test_command_line_tool_fails_loudly_without_a_gpu(tmp_path):
     r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"]], capture_output=True, text=True)
     assert r.returncode == 70 and "cannot create the GPU context" in r.stderr
     assert not os.path.exists(os.path.join(p["out"], "summary.tsv"))
+    # the options are saved to the debug folder before anything is computed (src/main.rs:64-82), samples resolved to names
+    dbg = str(tmp_path / "dbg")
+    r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"], "--output-debug", dbg, "--take", "7",
+                        "--enable-haplotype-metrics", "--compare-label", 'a "quoted" label'], capture_output=True, text=True)
+    assert r.returncode == 70
+    js = json.load(open(os.path.join(dbg, "cli_settings.json")))
+    assert list(js)[:4] == ["aardvark_version", "reference_fn", "truth_vcf_filename", "query_vcf_filename"] and len(js) == 23
+    assert js["truth_sample"] == "S1" and js["query_sample"] == "S1" and js["compare_label"] == 'a "quoted" label' and js["take_blocks"] == 7
+    assert js["enable_haplotype_scoring"] is True and js["enable_record_basepair_scoring"] is False and js["stratifications"] is None
+    assert js["min_variant_gap"] == 50 and js["max_edit_distance"] == 5000 and js["skip_blocks"] == 0 and js["regions"] == p["bed"]
 
 
 @pytest.mark.gpu
