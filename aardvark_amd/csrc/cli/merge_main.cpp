@@ -172,9 +172,30 @@ int main(int argc, char **argv) {
     if (rc_ctx) die(70, "cannot create the GPU context", err_ctx.c_str());
     const double s_load = seconds_since(t0);
 
+    /* the reference goes to the GPU (upload + 2-bit packing) while the regions are walked */
     t0 = std::chrono::steady_clock::now();
+    int rc_ref = 0;
+    std::string err_ref;
+    double s_ref = 0;
+    std::thread th_ref([&] {
+        const auto t = std::chrono::steady_clock::now();
+        const uint32_t n_contigs = avf_genome_n_contigs(genome);
+        std::vector<const uint8_t *> seqs(n_contigs);
+        std::vector<uint64_t> lens(n_contigs);
+        for (uint32_t c = 0; c < n_contigs; ++c) {
+            seqs[c] = avf_genome_seq(genome, c);
+            lens[c] = avf_genome_len(genome, c);
+        }
+        rc_ref = avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data());
+        if (rc_ref) err_ref = avk_last_error(ctx);
+        s_ref = seconds_since(t);
+    });
     avf_feed *feed = nullptr;
-    if (avf_feed_from_calls(k, calls.data(), bed.c_str(), genome, gap, 1, &feed)) die(74, "Error while building region iterator", avf_last_error());
+    const int rc_feed = avf_feed_from_calls(k, calls.data(), bed.c_str(), genome, gap, 1, &feed);
+    const std::string err_feed = rc_feed ? avf_last_error() : "";
+    th_ref.join();
+    if (rc_feed) die(74, "Error while building region iterator", err_feed.c_str());
+    if (rc_ref) die(70, "reference upload failed", err_ref.c_str());
     for (avf_calls *c : calls) avf_calls_free(c);
     const avk_multi_batch *all = avf_feed_multi_batch(feed);
     const double s_feed = seconds_since(t0);
@@ -214,17 +235,6 @@ int main(int argc, char **argv) {
         FILE *fp = fopen((debug_dir + "/cli_settings.json").c_str(), "wb");
         if (!fp || fwrite(js.data(), 1, js.size(), fp) != js.size() || fclose(fp) != 0) die(74, "Error while saving CLI options", debug_dir.c_str());
     }
-
-    t0 = std::chrono::steady_clock::now();
-    const uint32_t n_contigs = avf_genome_n_contigs(genome);
-    std::vector<const uint8_t *> seqs(n_contigs);
-    std::vector<uint64_t> lens(n_contigs);
-    for (uint32_t c = 0; c < n_contigs; ++c) {
-        seqs[c] = avf_genome_seq(genome, c);
-        lens[c] = avf_genome_len(genome, c);
-    }
-    if (avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data())) die(70, "reference upload failed", avk_last_error(ctx));
-    const double s_ref = seconds_since(t0);
 
     /* --skip / --take select regions by position in the iterator (src/main.rs:409-443) */
     const uint64_t first = skip < all->n_regions ? skip : all->n_regions;
@@ -277,7 +287,7 @@ int main(int argc, char **argv) {
         die(74, "Error while saving summary file", avf_last_error());
     const double s_write = seconds_since(t0);
 
-    fprintf(stderr, "stages [s]: load %.3f (reference %.3f beside the call sets and the gpu context), regions %.3f, reference upload %.3f, "
+    fprintf(stderr, "stages [s]: load %.3f (reference %.3f beside the call sets and the gpu context), regions %.3f (beside it: reference upload %.3f), "
                     "solve (pack + H2D + kernels + D2H + classify) %.3f, outputs %.3f\n",
             s_load, s_genome, s_feed, s_ref, s_solve, s_write);
     fprintf(stderr, "Merge completed in %.3f seconds.\n", seconds_since(t_start));

@@ -83,6 +83,10 @@ def load_library():
     lib.avf_write_merge_outputs.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(AvkMultiBatch), cpp,
                                             C.POINTER(C.c_int32), u8p, C.POINTER(C.c_uint64)]
     lib.avf_write_merge_summary.argtypes = [C.c_char_p, C.POINTER(AvkMultiBatch), cpp, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_uint64)]
+    lib.avf_calls_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
+    lib.avf_calls_free.argtypes = [vp]
+    lib.avf_feed_from_calls.argtypes = [C.c_uint32, C.POINTER(vp), C.c_char_p, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
+    lib.avf_vcf_sample_name.argtypes = [C.c_char_p, C.c_uint32, C.c_char_p, C.c_uint64]
     _lib = lib
     return lib
 
@@ -130,6 +134,70 @@ class Feed:
 
     def __init__(self, batch, var_record, var_alt_index, loaded):
         self.batch, self.var_record, self.var_alt_index, self.loaded = batch, var_record, var_alt_index, loaded
+
+
+def vcf_sample_name(vcf, index=0):
+    """get_vcf_sample_name: the name of sample `index` of the file's #CHROM line"""
+    lib = load_library()
+    buf = C.create_string_buffer(4096)
+    _check(lib, lib.avf_vcf_sample_name(os.fsencode(vcf), index, buf, len(buf)))
+    return buf.value.decode()
+
+
+class Calls:
+    """One VCF's calls, every chromosome (avf_calls_load): the first half of a feed, loadable while the genome is still loading."""
+
+    def __init__(self, vcf, sample="", enable_trimming=True):
+        self.lib = load_library()
+        h = C.c_void_p()
+        _check(self.lib, self.lib.avf_calls_load(os.fsencode(vcf), sample.encode(), 1 if enable_trimming else 0, C.byref(h)))
+        self.handle = h
+
+    def close(self):
+        if self.handle:
+            self.lib.avf_calls_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def feed_from_calls(calls, regions_bed, genome, min_variant_gap=50, merge=False):
+    """avf_feed_from_calls: the region walk over loaded call sets -> the Feed of feed_compare (two inputs) or feed_merge"""
+    lib = load_library()
+    h = C.c_void_p()
+    arr = (C.c_void_p * len(calls))(*[c.handle for c in calls])
+    _check(lib, lib.avf_feed_from_calls(len(calls), arr, os.fsencode(regions_bed) if regions_bed else None, genome.handle, min_variant_gap, 1 if merge else 0, C.byref(h)))
+    return _take_feed(lib, h, len(calls), merge)
+
+
+def _take_feed(lib, h, k, merge):
+    try:
+        if merge:
+            from .merge import MultiBatch
+            b = lib.avf_feed_multi_batch(h).contents
+            n, nv = int(b.n_regions), int(b.n_variants)
+            batch = MultiBatch(k, region_id=_arr(b.region_id, n, np.uint64), contig_idx=_arr(b.contig_idx, n, np.uint32), start=_arr(b.start, n, np.uint64),
+                               end=_arr(b.end, n, np.uint64), in_off=_arr(b.in_off, n * k, np.uint64), in_cnt=_arr(b.in_cnt, n * k, np.uint32),
+                               var_pos=_arr(b.var_pos, nv, np.uint64), var_type=_arr(b.var_type, nv, np.uint8), var_zyg=_arr(b.var_zyg, nv, np.uint8),
+                               var_raw_space=_arr(b.var_raw_space, nv, np.uint32), a0_off=_arr(b.a0_off, nv, np.uint64), a0_len=_arr(b.a0_len, nv, np.uint32),
+                               a1_off=_arr(b.a1_off, nv, np.uint64), a1_len=_arr(b.a1_len, nv, np.uint32),
+                               allele_bytes=_arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
+        else:
+            b = lib.avf_feed_batch(h).contents
+            n, nv = int(b.n_regions), int(b.n_variants)
+            batch = RegionBatch(_arr(b.region_id, n, np.uint64), _arr(b.contig_idx, n, np.uint32), _arr(b.start, n, np.uint64), _arr(b.end, n, np.uint64),
+                                _arr(b.t_off, n, np.uint64), _arr(b.t_cnt, n, np.uint32), _arr(b.q_off, n, np.uint64), _arr(b.q_cnt, n, np.uint32),
+                                _arr(b.var_pos, nv, np.uint64), _arr(b.var_type, nv, np.uint8), _arr(b.var_zyg, nv, np.uint8), _arr(b.var_raw_space, nv, np.uint32),
+                                _arr(b.a0_off, nv, np.uint64), _arr(b.a0_len, nv, np.uint32), _arr(b.a1_off, nv, np.uint64), _arr(b.a1_len, nv, np.uint32),
+                                _arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
+        return Feed(batch, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
+                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)))
+    finally:
+        lib.avf_feed_free(h)
 
 
 def feed_compare(truth_vcf, query_vcf, regions_bed, genome, truth_sample="", query_sample="", min_variant_gap=50, enable_trimming=True):

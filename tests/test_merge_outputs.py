@@ -207,6 +207,33 @@ def test_merge_feed_matches_the_restatement(tmp_path):
     assert_same_multi(feed.batch, regions)
 
 
+def test_feed_in_two_halves(tmp_path):
+    """avf_calls_load + avf_feed_from_calls (the tools load the call sets while the genome is still loading) give the feeds of the
+    one-call forms, for compare and for merge; avf_vcf_sample_name names the samples"""
+    from test_feeder import assert_same_batch
+    p, contig = write_case(tmp_path, 200, 80_000, 3)
+    genome = feeder.Genome(p["fa"])
+    assert [feeder.vcf_sample_name(v) for v in p["vcfs"]] == ["S0", "S1", "S2"]
+    with pytest.raises(feeder.FeederError, match="Sample index 1 does not exist"):
+        feeder.vcf_sample_name(p["vcfs"][0], 1)
+    calls = [feeder.Calls(v, sample="S%d" % i) for i, v in enumerate(p["vcfs"])]
+    whole = feeder.feed_merge(p["vcfs"], p["bed"], genome)
+    halves = feeder.feed_from_calls(calls, p["bed"], genome, merge=True)
+    regions, loaded = restated_regions(p)
+    assert_same_multi(halves.batch, regions)
+    assert halves.loaded == whole.loaded == tuple(loaded) and np.array_equal(halves.var_record, whole.var_record)
+    pair = feeder.feed_from_calls(calls[:2], p["bed"], genome, min_variant_gap=30)
+    want = feeder.feed_compare(p["vcfs"][0], p["vcfs"][1], p["bed"], genome, min_variant_gap=30)
+    assert_same_batch(pair.batch, want.batch)
+    assert np.array_equal(pair.var_record, want.var_record) and np.array_equal(pair.var_alt_index, want.var_alt_index)
+    with pytest.raises(feeder.FeederError, match="exactly two inputs"):
+        feeder.feed_from_calls(calls, p["bed"], genome)
+    with pytest.raises(feeder.FeederError, match="High confidence regions are currently required"):
+        feeder.feed_from_calls(calls[:2], None, genome)
+    with pytest.raises(feeder.FeederError, match="NOPE"):
+        feeder.Calls(p["vcfs"][0], sample="NOPE")
+
+
 def test_merge_feed_errors(tmp_path):
     p, _ = write_case(tmp_path, 30, 20_000, 2)
     genome = feeder.Genome(p["fa"])
