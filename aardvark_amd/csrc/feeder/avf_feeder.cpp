@@ -396,6 +396,255 @@ int load_vcf_sequential(const char *path, const char *sample, bool enable_trimmi
     return 0;
 }
 
+/* BGZF files (what bgzip / htslib write, and what the reference requires for its tabix queries): the blocks are independent gzip
+ * members, so GROUPS of blocks are inflated AND parsed by the worker threads.  A group's text starts and ends in the middle of a line:
+ * the workers parse the whole lines inside, the fragments at both ends are put together afterwards (one line per group boundary).
+ * Returns 1 when the file is not BGZF or anything is irregular — the caller then reads it the ordinary way. */
+int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls, size_t n_workers) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return 1;
+    struct stat st;
+    if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 28) {
+        close(fd);
+        return 1;
+    }
+    const size_t n = (size_t)st.st_size;
+    const uint8_t *d = (const uint8_t *)mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (d == (const uint8_t *)MAP_FAILED) return 1;
+    struct Unmap {
+        const uint8_t *p;
+        size_t n;
+        ~Unmap() { munmap((void *)p, n); }
+    } unmap{d, n};
+    /* the block table: offset of the deflate payload, its length, the uncompressed size */
+    struct Blk {
+        size_t data, len;
+        uint32_t isize, crc;
+    };
+    std::vector<Blk> blks;
+    for (size_t at = 0; at < n;) {
+        if (n - at < 18 || d[at] != 0x1f || d[at + 1] != 0x8b || d[at + 2] != 8 || !(d[at + 3] & 4)) return 1;
+        const size_t xlen = d[at + 10] | ((size_t)d[at + 11] << 8);
+        if (n - at < 12 + xlen + 8) return 1;
+        size_t bsize = 0;
+        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) { /* extra subfields: SI1 SI2 SLEN data */
+            const size_t slen = d[x + 2] | ((size_t)d[x + 3] << 8);
+            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= at + 12 + xlen) bsize = (d[x + 4] | ((size_t)d[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > n - at) return 1;
+        if (d[at + 3] & ~4) return 1; /* name / comment / header crc fields: not what bgzip writes */
+        Blk b;
+        b.data = at + 12 + xlen;
+        b.len = bsize - (12 + xlen) - 8;
+        b.crc = d[at + bsize - 8] | ((uint32_t)d[at + bsize - 7] << 8) | ((uint32_t)d[at + bsize - 6] << 16) | ((uint32_t)d[at + bsize - 5] << 24);
+        b.isize = d[at + bsize - 4] | ((uint32_t)d[at + bsize - 3] << 8) | ((uint32_t)d[at + bsize - 2] << 16) | ((uint32_t)d[at + bsize - 1] << 24);
+        if (b.isize > 65536) return 1;
+        if (b.isize) blks.push_back(b); /* empty blocks (the end-of-file marker) carry nothing */
+        at += bsize;
+    }
+    auto inflate_block = [&](const Blk &b, z_stream &zs, std::string &out) -> bool {
+        const size_t at = out.size();
+        out.resize(at + b.isize);
+        if (inflateReset(&zs) != Z_OK) return false;
+        zs.next_in = (Bytef *)(d + b.data);
+        zs.avail_in = (uInt)b.len;
+        zs.next_out = (Bytef *)&out[at];
+        zs.avail_out = b.isize;
+        if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) return false;
+        return (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)&out[at], b.isize) == b.crc;
+    };
+    /* the header: inflate from the start until the #CHROM line is complete */
+    long sample_col = -1;
+    {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) return 1;
+        std::string head;
+        bool found = false, bad = false;
+        size_t scanned = 0;
+        VcfScratch w;
+        for (size_t k = 0; k < blks.size() && !found && !bad; ++k) {
+            if (!inflate_block(blks[k], zs, head)) {
+                bad = true;
+                break;
+            }
+            for (;;) {
+                const size_t nl = head.find('\n', scanned);
+                if (nl == std::string::npos) break;
+                size_t len = nl - scanned;
+                if (len && head[scanned + len - 1] == '\r') len -= 1;
+                if (len) {
+                    if (head[scanned] != '#') { /* a data line before #CHROM: the ordinary reader words the error */
+                        bad = true;
+                        break;
+                    }
+                    if (len >= 6 && head.compare(scanned, 6, "#CHROM") == 0) {
+                        const int rc = vcf_sample_column(path, head.substr(scanned, len), sample, w, sample_col);
+                        inflateEnd(&zs);
+                        if (rc) return rc;
+                        found = true;
+                        break;
+                    }
+                }
+                scanned = nl + 1;
+            }
+        }
+        if (!found) {
+            inflateEnd(&zs);
+            return 1;
+        }
+        inflateEnd(&zs);
+    }
+    size_t group_blocks = 64;
+    if (const char *e = getenv("AVF_VCF_GROUP")) group_blocks = std::max<size_t>(1, (size_t)strtoull(e, nullptr, 10)); /* tests: force group boundaries */
+    const size_t n_groups = (blks.size() + group_blocks - 1) / group_blocks;
+    struct GroupOut {
+        std::vector<std::string> chroms;
+        std::vector<std::vector<Call>> lists;
+        uint64_t n_records = 0;
+        std::string head, tail; /* the fragments before the first and after the last line feed; head = everything when there is none */
+        bool has_newline = false, has_chrom = false, has_data = false, chrom_after_data = false;
+    };
+    std::vector<GroupOut> outs(n_groups);
+    std::atomic<size_t> next{0};
+    std::atomic<bool> irregular{false};
+    auto emit_into = [](GroupOut &out, size_t &last, const std::string &chrom, Call &&c) {
+        if (last == (size_t)-1 || out.chroms[last] != chrom) {
+            last = (size_t)-1;
+            for (size_t q = 0; q < out.chroms.size(); ++q)
+                if (out.chroms[q] == chrom) last = q;
+            if (last == (size_t)-1) {
+                out.chroms.push_back(chrom);
+                out.lists.emplace_back();
+                last = out.chroms.size() - 1;
+            }
+        }
+        out.lists[last].push_back(std::move(c));
+    };
+    auto worker = [&] {
+        z_stream zs;
+        memset(&zs, 0, sizeof(zs));
+        if (inflateInit2(&zs, -15) != Z_OK) {
+            irregular.store(true);
+            return;
+        }
+        VcfScratch w;
+        std::string text, line;
+        for (size_t g = next.fetch_add(1); g < n_groups && !irregular.load(std::memory_order_relaxed); g = next.fetch_add(1)) {
+            GroupOut &out = outs[g];
+            text.clear();
+            bool ok = true;
+            for (size_t k = g * group_blocks; k < std::min(blks.size(), (g + 1) * group_blocks) && ok; ++k) ok = inflate_block(blks[k], zs, text);
+            if (!ok) {
+                irregular.store(true);
+                break;
+            }
+            const size_t first_nl = text.find('\n');
+            if (first_nl == std::string::npos) {
+                out.head = text;
+                continue;
+            }
+            out.has_newline = true;
+            const size_t last_nl = text.rfind('\n');
+            out.head.assign(text, 0, first_nl);
+            out.tail.assign(text, last_nl + 1, std::string::npos);
+            size_t last = (size_t)-1;
+            const char *p = text.data() + first_nl + 1, *end = text.data() + last_nl + 1;
+            while (p < end) {
+                const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+                size_t len = (size_t)(nl - p);
+                if (len && p[len - 1] == '\r') len -= 1;
+                if (len) {
+                    if (p[0] == '#') {
+                        if (len >= 6 && memcmp(p, "#CHROM", 6) == 0) {
+                            out.has_chrom = true;
+                            if (out.has_data) out.chrom_after_data = true;
+                        }
+                    } else {
+                        out.has_data = true;
+                        line.assign(p, len);
+                        const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, out.n_records, w,
+                                                        [&](const std::string &chrom, Call &&c) { emit_into(out, last, chrom, std::move(c)); });
+                        out.n_records += 1;
+                        if (rc) {
+                            irregular.store(true);
+                            break;
+                        }
+                    }
+                }
+                p = nl + 1;
+            }
+        }
+        inflateEnd(&zs);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < std::min(n_workers, std::max<size_t>(n_groups, 1)); ++t) pool.emplace_back(worker);
+        worker();
+        for (std::thread &t : pool) t.join();
+    }
+    if (irregular.load()) return 1;
+    /* in file order: the line put together at a group's front, then the group's own lines; record indices become file-wide */
+    uint64_t base = 0;
+    bool data_seen = false;
+    std::string carry;
+    VcfScratch w;
+    GroupOut joint;
+    auto boundary_line = [&](std::string &text) -> int { /* one complete line made of fragments */
+        if (!text.empty() && text.back() == '\r') text.pop_back();
+        if (text.empty()) return 0;
+        if (text[0] == '#') {
+            if (text.compare(0, 6, "#CHROM") == 0 && data_seen) return 1;
+            return 0;
+        }
+        data_seen = true;
+        size_t last = (size_t)-1;
+        const int rc = vcf_parse_record(path, text, sample_col, enable_trimming, base, w, [&](const std::string &chrom, Call &&c) { emit_into(joint, last, chrom, std::move(c)); });
+        base += 1;
+        if (rc) return 1;
+        for (size_t q = 0; q < joint.chroms.size(); ++q) {
+            std::vector<Call> &dst = calls[joint.chroms[q]];
+            for (Call &c : joint.lists[q]) dst.push_back(std::move(c));
+        }
+        joint.chroms.clear();
+        joint.lists.clear();
+        return 0;
+    };
+    for (size_t g = 0; g < n_groups; ++g) {
+        GroupOut &o = outs[g];
+        carry += o.head;
+        if (!o.has_newline) continue;
+        if (boundary_line(carry)) {
+            calls.clear();
+            return 1;
+        }
+        carry = o.tail;
+        if ((o.has_chrom && data_seen) || o.chrom_after_data) {
+            calls.clear();
+            return 1;
+        }
+        data_seen = data_seen || o.has_data;
+        for (size_t q = 0; q < o.chroms.size(); ++q) {
+            std::vector<Call> &dst = calls[o.chroms[q]];
+            for (Call &c : o.lists[q]) {
+                c.record += base;
+                dst.push_back(std::move(c));
+            }
+        }
+        base += o.n_records;
+        GroupOut().chroms.swap(o.chroms);
+        std::vector<std::vector<Call>>().swap(o.lists);
+    }
+    if (boundary_line(carry)) { /* a last line without a line feed */
+        calls.clear();
+        return 1;
+    }
+    if (getenv("AVF_TIMING")) fprintf(stderr, "[avf] vcf %s: %zu BGZF blocks in %zu groups, %llu records\n", path, blks.size(), n_groups, (unsigned long long)base);
+    return 0;
+}
+
 /* The file is decompressed on the calling thread and cut into blocks of whole lines; worker threads parse the blocks, and the calls
  * are put together in file order.  Anything irregular (an error, a #CHROM line after the first data line) is left to the sequential
  * reader above, which then reports it the usual way. */
@@ -403,6 +652,11 @@ int load_vcf(const char *path, const char *sample, bool enable_trimming, std::un
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t n_workers = std::min<size_t>(hw > 1 ? hw - 1 : 0, 8);
     if (n_workers < 2 || getenv("AVF_SEQUENTIAL_VCF")) return load_vcf_sequential(path, sample, enable_trimming, calls);
+    if (!getenv("AVF_NO_BGZF_GROUPS")) {
+        const int rc = load_vcf_bgzf(path, sample, enable_trimming, calls, std::min<size_t>(hw, 16));
+        if (rc != 1) return rc; /* done, or a header error worded the usual way */
+        calls.clear();
+    }
     gzFile gz = gzopen(path, "rb");
     if (!gz) return fail(AVK_E_ARG, "Error while opening %s", path);
     gzbuffer(gz, 1 << 20);

@@ -40,6 +40,20 @@ def write_text(path, text, mode="plain"):
         open(path, "wb").write(b"".join(gzip.compress(data[a:b]) for a, b in zip(cut[:-1], cut[1:])))
 
 
+def bgzf_bytes(data, block=0xff00, level=6):
+    """BGZF as bgzip writes it: independent gzip members of at most 64 KiB with the BC extra field, then the empty end-of-file block"""
+    import struct
+    import zlib
+    out = []
+    for at in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if at is None else data[at:at + block]
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        payload = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(payload) + 25) + payload +
+                   struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
 def vcf_text(chrom, calls, sample="S1"):
     """calls: [(pos0, ref, alt, zygosity name)]"""
     lines = [HEADER.format(c=chrom, s=sample)]
@@ -205,6 +219,52 @@ def test_block_parallel_vcf_reader_matches_the_sequential_one(tmp_path, monkeypa
             feeder.feed_compare(bad, p["q"], p["bed"], genome)
         msgs.append(str(e.value))
     assert "Missing GT" in msgs[0] and msgs[0] == msgs[1] == msgs[2]
+
+
+def test_bgzf_vcfs_are_inflated_and_parsed_in_groups(tmp_path, monkeypatch, capfd):
+    """BGZF inputs: groups of blocks are inflated and parsed by the worker threads, the lines cut by group boundaries are put together
+    afterwards — same calls and record numbers as the line-by-line reader for every block and group size, CRLF and a missing final
+    line feed included; a damaged block or a plain gzip file goes the ordinary way"""
+    p, contig, want_batch = write_case_files(tmp_path, 600, 300_000)
+    genome = feeder.Genome(p["fa"])
+    texts = {k: gzip.open(p[k], "rb").read() for k in ("t", "q")}
+    monkeypatch.setenv("AVF_SEQUENTIAL_VCF", "1")
+    want = feeder.feed_compare(p["t"], p["q"], p["bed"], genome, enable_trimming=False)
+    monkeypatch.delenv("AVF_SEQUENTIAL_VCF")
+    variants = [("lf", lambda b: b), ("crlf", lambda b: b.replace(b"\n", b"\r\n")), ("no_final_lf", lambda b: b.rstrip(b"\n"))]
+    for name, change in variants:
+        for block in (97, 1000, 0xff00):
+            paths = {}
+            for k in ("t", "q"):
+                paths[k] = str(tmp_path / ("%s_%s_%d.vcf.gz" % (k, name, block)))
+                open(paths[k], "wb").write(bgzf_bytes(change(texts[k]), block))
+            assert gzip.open(paths["t"], "rb").read() == change(texts["t"])  # an ordinary gzip reader sees the text
+            for group in ("1", "2", "7", "64"):
+                monkeypatch.setenv("AVF_VCF_GROUP", group)
+                monkeypatch.setenv("AVF_TIMING", "1")
+                capfd.readouterr()
+                got = feeder.feed_compare(paths["t"], paths["q"], p["bed"], genome, enable_trimming=False)
+                monkeypatch.delenv("AVF_TIMING")
+                assert capfd.readouterr().err.count("BGZF blocks in") == 2  # both files went through the group reader
+                assert_same_batch(got.batch, want.batch)
+                assert np.array_equal(got.var_record, want.var_record) and got.loaded == want.loaded
+    # a damaged payload: the group reader steps aside and the ordinary reader reports the read error
+    raw = bytearray(bgzf_bytes(texts["t"], 1000))
+    raw[len(raw) // 2] ^= 0x55
+    bad = str(tmp_path / "damaged.vcf.gz")
+    open(bad, "wb").write(bytes(raw))
+    with pytest.raises(feeder.FeederError):
+        feeder.feed_compare(bad, p["q"], p["bed"], genome)
+    # an error inside a record is worded by the ordinary reader
+    lines = texts["t"].decode().splitlines()
+    lines[len(lines) // 2] = lines[len(lines) // 2].replace("\tGT\t", "\tDP\t")
+    broken = str(tmp_path / "broken.vcf.gz")
+    open(broken, "wb").write(bgzf_bytes(("\n".join(lines) + "\n").encode(), 500))
+    monkeypatch.setenv("AVF_VCF_GROUP", "3")
+    with pytest.raises(feeder.FeederError, match="Missing GT"):
+        feeder.feed_compare(broken, p["q"], p["bed"], genome)
+    with pytest.raises(feeder.FeederError, match="NOPE"):
+        feeder.feed_compare(paths["t"], paths["q"], p["bed"], genome, truth_sample="NOPE")
 
 
 def test_errors_are_reported(tmp_path):

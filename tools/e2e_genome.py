@@ -13,6 +13,38 @@ GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 1593
 NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
 GT = {ZYG["HomozygousAlternate"]: "1/1", ZYG["UnphasedHeterozygous"]: "0/1", ZYG["PhasedHet01"]: "0|1", ZYG["PhasedHet10"]: "1|0"}
 scale = float(os.environ.get("SCALE", "0.1"))
+BGZF = os.environ.get("PLAIN_GZIP", "0") != "1"  # inputs as bgzip writes them (what the reference needs for its tabix queries); PLAIN_GZIP=1: one gzip stream
+
+
+class BgzfText:
+    """text writer producing BGZF: independent gzip members of at most 0xff00 input bytes with the BC extra field, then the end-of-file block"""
+
+    def __init__(self, path):
+        import zlib
+        self.f, self.buf, self.z = open(path, "wb"), bytearray(), zlib
+
+    def write(self, text):
+        self.buf += text.encode()
+        while len(self.buf) >= 0xff00:
+            self._block(bytes(self.buf[:0xff00]))
+            del self.buf[:0xff00]
+
+    def _block(self, chunk):
+        import struct
+        co = self.z.compressobj(1, self.z.DEFLATED, -15)
+        payload = co.compress(chunk) + co.flush()
+        self.f.write(b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00" + struct.pack("<H", len(payload) + 25) + payload +
+                     struct.pack("<II", self.z.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+
+    def close(self):
+        if self.buf:
+            self._block(bytes(self.buf))
+        self._block(b"")
+        self.f.close()
+
+
+def open_vcf(path):
+    return BgzfText(path) if BGZF else gzip.open(path, "wt", compresslevel=1)
 density = 3.9e6 / sum(GRCH38)  # truth variants per base
 d = tempfile.mkdtemp(prefix="avk_genome_", dir=os.environ.get("TMPDIR", "/tmp"))
 t0 = time.time()
@@ -20,11 +52,11 @@ hdr = "##fileformat=VCFv4.2\n" + "".join("##contig=<ID=%s>\n" % n for n in NAMES
       "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tHG002\n"
 fa = open(os.path.join(d, "genome.fa"), "wb")
 bedf = open(os.path.join(d, "hc.bed"), "w")
-vt = gzip.open(os.path.join(d, "truth.vcf.gz"), "wt", compresslevel=1)
-vq = gzip.open(os.path.join(d, "query.vcf.gz"), "wt", compresslevel=1)
+vt = open_vcf(os.path.join(d, "truth.vcf.gz"))
+vq = open_vcf(os.path.join(d, "query.vcf.gz"))
 vt.write(hdr); vq.write(hdr)
 n_merge = int(os.environ.get("MERGE_INPUTS", "0"))  # also run `merge` with truth + query + (n_merge - 2) more callers of the same sample
-vm = [gzip.open(os.path.join(d, "caller%d.vcf.gz" % i), "wt", compresslevel=1) for i in range(2, n_merge)]
+vm = [open_vcf(os.path.join(d, "caller%d.vcf.gz" % i)) for i in range(2, n_merge)]
 for f in vm:
     f.write(hdr)
 n_regions = n_truth = 0
