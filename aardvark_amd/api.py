@@ -170,6 +170,19 @@ class Context:
         self._check(self.lib.avk_results_download(self.handle, rb.handle, C.byref(ro)))
         return res
 
+    def label_tallies(self, rb, n_labels, label_off, label_idx, out=None):
+        """avk_label_tallies: per-label sums of the resident batch's per-region metric blocks (needs emit_group_metrics during
+        compare_resident); returns / adds to a [n_labels, TALLY_LEN] uint64 array"""
+        out = np.zeros((n_labels, TALLY_LEN), np.uint64) if out is None else out
+        off = np.ascontiguousarray(label_off, np.uint64)
+        idx = np.ascontiguousarray(label_idx, np.uint32)
+        if idx.size == 0:
+            idx = np.zeros(1, np.uint32)
+        self.lib.avk_label_tallies.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        self._check(self.lib.avk_label_tallies(self.handle, rb.handle, n_labels, off.ctypes.data_as(C.POINTER(C.c_uint64)), idx.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                               out.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return out
+
     def synchronize(self):
         self._check(self.lib.avk_synchronize(self.handle))
 

@@ -49,6 +49,52 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a)
     avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
+/* Stratified tallies (SummaryWriter::add_comparison_benchmark with containment regions, writers/summary.rs:146-163): label l sums the
+ * metric blocks of the solved regions whose label list names it.  One wave per region at a time; a workgroup keeps the tallies of the
+ * AVK_LABEL_BLOCK labels of this launch in LDS (64-bit adds) and flushes them once — HBM traffic is the 1144-byte metric block of
+ * every region that has a label in the block, read once. */
+#define AVK_LABEL_BLOCK 16
+#define AVK_GM_WORDS (AVK_N_GROUPS * AVK_N_FIELDS)
+__global__ void __launch_bounds__(256) avk_label_tally_kernel(const uint32_t *gm, const uint32_t *region_out, const unsigned long long *label_off,
+                                                             const uint32_t *label_idx, uint32_t n_regions, uint32_t label_lo, uint32_t label_hi,
+                                                             unsigned long long *out) {
+    __shared__ unsigned long long acc[AVK_LABEL_BLOCK * AVK_GM_WORDS];
+    for (unsigned k = threadIdx.x; k < AVK_LABEL_BLOCK * AVK_GM_WORDS; k += blockDim.x) acc[k] = 0;
+    __syncthreads();
+    const unsigned lane = threadIdx.x & 63u;
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), n_waves = gridDim.x * (blockDim.x >> 6);
+    for (unsigned r = wave; r < n_regions; r += n_waves) {
+        if (region_out[4u * r] != 0) continue; /* only solved regions count */
+        const unsigned long long lo = label_off[r], hi = label_off[r + 1];
+        bool any = false;
+        for (unsigned long long q = lo; q < hi; ++q) {
+            const uint32_t l = label_idx[q];
+            any = any || (l >= label_lo && l < label_hi);
+        }
+        if (!any) continue;
+        uint32_t v[5];
+        const uint32_t *block = gm + (size_t)r * AVK_GM_WORDS;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const unsigned i = lane + 64u * (unsigned)j;
+            v[j] = i < AVK_GM_WORDS ? block[i] : 0u;
+        }
+        for (unsigned long long q = lo; q < hi; ++q) {
+            const uint32_t l = label_idx[q];
+            if (l < label_lo || l >= label_hi) continue;
+            unsigned long long *dst = acc + (size_t)(l - label_lo) * AVK_GM_WORDS;
+#pragma unroll
+            for (int j = 0; j < 5; ++j)
+                if (v[j]) atomicAdd(dst + lane + 64u * (unsigned)j, (unsigned long long)v[j]);
+        }
+    }
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < (label_hi - label_lo) * AVK_GM_WORDS; k += blockDim.x) {
+        const unsigned long long x = acc[k];
+        if (x) atomicAdd(out + (size_t)(label_lo + k / AVK_GM_WORDS) * AVK_TALLY_LEN + k % AVK_GM_WORDS, x);
+    }
+}
+
 /* packs the uploaded reference: 16 bases per word, 2 bits each, plus one flag per word for anything that is
  * not an upper-case A/C/G/T (those windows are read from the byte copy).  One thread per packed word. */
 __global__ void avk_pack_reference(const uint8_t *bytes, uint64_t n_bases, uint32_t *packed, uint32_t *exc) {
@@ -911,6 +957,46 @@ int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_com
     if (!rc) rc = avk_results_download(ctx, db, out);
     avk_batch_free(ctx, db);
     return rc;
+}
+
+int avk_label_tallies(avk_ctx *ctx, avk_dev_batch *db, uint32_t n_labels, const uint64_t *label_off, const uint32_t *label_idx, uint64_t *out) {
+    if (!ctx || !db || !label_off || !out || (label_off[db->n_regions] && !label_idx)) return AVK_E_ARG;
+    if (n_labels == 0) return 0;
+    if (!db->d_gm) return fail(ctx, AVK_E_STATE, "the batch has no per-region metric blocks on the device: set emit_group_metrics before avk_compare_resident");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = db->n_regions, n_idx = label_off[n];
+    for (uint64_t r = 0; r < n; ++r)
+        if (label_off[r + 1] < label_off[r]) return fail(ctx, AVK_E_ARG, "label_off must not decrease");
+    for (uint64_t q = 0; q < n_idx; ++q)
+        if (label_idx[q] >= n_labels) return fail(ctx, AVK_E_ARG, "label index %u of %u", label_idx[q], n_labels);
+    unsigned long long *d_off = nullptr, *d_out = nullptr;
+    uint32_t *d_idx = nullptr;
+    int rc = dev_alloc(ctx, &d_off, (size_t)n + 1);
+    if (!rc) rc = dev_alloc(ctx, &d_idx, (size_t)n_idx);
+    if (!rc) rc = dev_alloc(ctx, &d_out, (size_t)n_labels * AVK_TALLY_LEN);
+    std::vector<uint64_t> host((size_t)n_labels * AVK_TALLY_LEN, 0);
+    hipError_t e = hipSuccess;
+    if (!rc) {
+        e = hipMemcpyAsync(d_off, label_off, (n + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess && n_idx) e = hipMemcpyAsync(d_idx, label_idx, n_idx * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, host.size() * sizeof(uint64_t), ctx->stream);
+        uint32_t blocks = (uint32_t)ctx->n_cus * 4u;
+        if ((uint64_t)blocks * 4 > n) blocks = (uint32_t)((n + 3) / 4);
+        for (uint32_t lo = 0; lo < n_labels && e == hipSuccess && n; lo += AVK_LABEL_BLOCK) {
+            const uint32_t hi = lo + AVK_LABEL_BLOCK < n_labels ? lo + AVK_LABEL_BLOCK : n_labels;
+            hipLaunchKernelGGL(avk_label_tally_kernel, dim3(blocks), dim3(256), 0, ctx->stream, db->d_gm, db->d_region_out, d_off, d_idx, (uint32_t)n, lo, hi, d_out);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (d_off) (void)hipFree(d_off);
+    if (d_idx) (void)hipFree(d_idx);
+    if (d_out) (void)hipFree(d_out);
+    if (rc) return rc;
+    if (e != hipSuccess) return fail(ctx, AVK_E_HIP, "label tallies failed: %s", hipGetErrorString(e));
+    for (size_t k = 0; k < host.size(); ++k) out[k] += host[k];
+    return 0;
 }
 
 /* solve_merge_region's pairwise test (merge_solver.rs:128-147) for every region of the batch: the "truth"

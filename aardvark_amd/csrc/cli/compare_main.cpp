@@ -227,7 +227,10 @@ int main(int argc, char **argv) {
      * regions it contains, so the per-region blocks come back from the GPU, in batches that keep them at a few hundred MB */
     const bool debug = !debug_dir.empty();
     (void)avk_ctx_set_option(ctx, "emit_group_metrics", n_labels || debug ? 1 : 0);
-    if ((n_labels || debug) && batch_regions > 262144) batch_regions = 262144;
+    /* the per-region blocks only come back to the host for the debug tables; the stratified tallies are summed on the GPU
+     * (avk_label_tallies) from the region labels the feeder library lists (avf_strat_batch_labels) */
+    const bool device_labels = n_labels && !debug;
+    if (debug && batch_regions > 262144) batch_regions = 262144;
     cfg.enable_sequences = debug ? 1 : 0; /* enable_sequences(region_seq_writer.is_some()), src/main.rs:236 */
     uint32_t mask = AVF_METRIC_GT | AVF_METRIC_BASEPAIR;
     if (hap) mask |= AVF_METRIC_HAP;
@@ -263,7 +266,7 @@ int main(int argc, char **argv) {
         out.var_expected = var_expected.data(); /* indexed by the (shared) variant arrays */
         out.var_observed = var_observed.data();
         out.var_class = var_class.data();
-        if (n_labels || debug) {
+        if (debug) {
             gm.resize((size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
             out.group_metrics = gm.data();
         }
@@ -283,13 +286,33 @@ int main(int argc, char **argv) {
             out.seq_stride = seq_stride.data();
             out.seq_len = seq_len.data();
         }
-        if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
+        if (device_labels) {
+            std::vector<uint64_t> label_off(n + 1, 0);
+            std::vector<uint32_t> label_idx;
+            int rc_labels = 0;
+            std::thread th_labels([&] { /* beside the upload and the kernels */
+                rc_labels = avf_strat_batch_labels(strat, genome, all, first + at, n, label_off.data(), nullptr);
+                if (!rc_labels) {
+                    label_idx.resize(label_off[n] + 1);
+                    rc_labels = avf_strat_batch_labels(strat, genome, all, first + at, n, label_off.data(), label_idx.data());
+                }
+            });
+            avk_dev_batch *db = nullptr;
+            int rc = avk_batch_upload(ctx, &b, &db);
+            if (!rc) rc = avk_compare_resident(ctx, db, &cfg, nullptr);
+            if (!rc) rc = avk_results_download(ctx, db, &out);
+            th_labels.join();
+            if (rc) die(70, "compare failed", avk_last_error(ctx));
+            if (rc_labels) die(70, "cannot list the region labels", avf_last_error());
+            if (avk_label_tallies(ctx, db, n_labels, label_off.data(), label_idx.data(), strat_total.data())) die(70, "stratified tallies failed", avk_last_error(ctx));
+            avk_batch_free(ctx, db);
+        } else if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
         for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += tally[k];
         if (debug && (avf_region_summary_rows(region_table, genome, all, first + at, n, out.status, gm.data()) ||
                       avf_region_sequences_rows(sequence_table, genome, all, first + at, n, out.status, seq_bytes.data(), seq_len.data(), seq_off.data(),
                                                 seq_stride.data())))
             die(74, "Error while writing the debug tables", avf_last_error());
-        for (uint64_t r = 0; n_labels && r < n; ++r) {
+        for (uint64_t r = 0; n_labels && !device_labels && r < n; ++r) { /* debug runs: the blocks are on the host anyway */
             if (out.status[r] != 0) continue;
             const uint32_t hit = avf_strat_region_labels(strat, genome, all, first + at + r, labels.data(), n_labels);
             const uint32_t *block = gm.data() + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS;

@@ -11,6 +11,8 @@
 
 #include <algorithm>
 #include <map>
+#include <functional>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -162,6 +164,36 @@ uint32_t avf_strat_region_labels(const avf_strat *s, const avf_genome *g, const 
     if (start >= end) return 0;
     const char *chrom = avf_genome_name(g, b->contig_idx ? b->contig_idx[r] : 0);
     return query(s, chrom, (int64_t)start, (int64_t)end - 1, true, out, cap);
+}
+/* the same for regions first .. first + n - 1 at once, by several threads: label_off[k] .. label_off[k + 1] delimits the labels of
+ * region first + k in label_idx.  Call with label_idx = NULL to get the offsets (label_off[n] = entries needed), then again with room. */
+int avf_strat_batch_labels(const avf_strat *s, const avf_genome *g, const avk_region_batch *b, uint64_t first, uint64_t n, uint64_t *label_off,
+                           uint32_t *label_idx) {
+    if (!s || !g || !b || !label_off || first > b->n_regions || n > b->n_regions - first) return AVK_E_ARG;
+    const uint32_t n_labels = avf_strat_n_labels(s);
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+    if (nt > n / 4096 + 1) nt = (size_t)(n / 4096 + 1);
+    auto run = [&](const std::function<void(uint64_t, uint64_t)> &fn) {
+        std::vector<std::thread> pool;
+        for (size_t t = 1; t < nt; ++t) pool.emplace_back(fn, n * t / nt, n * (t + 1) / nt);
+        fn(0, n / nt);
+        for (std::thread &t : pool) t.join();
+    };
+    if (!label_idx) {
+        run([&](uint64_t lo, uint64_t hi) {
+            std::vector<uint32_t> tmp(n_labels ? n_labels : 1);
+            for (uint64_t k = lo; k < hi; ++k) label_off[k + 1] = avf_strat_region_labels(s, g, b, first + k, tmp.data(), n_labels);
+        });
+        label_off[0] = 0;
+        for (uint64_t k = 0; k < n; ++k) label_off[k + 1] += label_off[k];
+        return 0;
+    }
+    run([&](uint64_t lo, uint64_t hi) {
+        for (uint64_t k = lo; k < hi; ++k)
+            (void)avf_strat_region_labels(s, g, b, first + k, label_idx + label_off[k], (uint32_t)(label_off[k + 1] - label_off[k]));
+    });
+    return 0;
 }
 void avf_strat_free(avf_strat *s) { delete s; }
 

@@ -68,6 +68,7 @@ def load_library():
     lib.avf_strat_region_labels.restype = C.c_uint32
     lib.avf_strat_region_labels.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, u32p, C.c_uint32]
     lib.avf_strat_free.argtypes = [vp]
+    lib.avf_strat_batch_labels.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64), u32p]
     lib.avf_write_summary_stratified.argtypes = [C.c_char_p, C.c_char_p, C.POINTER(C.c_uint64), vp, C.POINTER(C.c_uint64), C.c_uint32]
     lib.avf_region_summary_open.argtypes = [C.c_char_p, C.c_uint32, C.POINTER(vp)]
     lib.avf_region_summary_rows.argtypes = [vp, vp, C.POINTER(AvkRegionBatch), C.c_uint64, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_uint32)]
@@ -265,6 +266,17 @@ class Stratifications:
         out = (C.c_uint32 * max(len(self.labels), 1))()
         n = self.lib.avf_strat_region_labels(self.handle, genome.handle, C.byref(cb), r, out, len(self.labels))
         return [int(out[i]) for i in range(n)]
+
+    def batch_labels(self, genome, batch, first=0, n=None):
+        """avf_strat_batch_labels: (label_off[n + 1], label_idx) — the labels of region first + k are label_idx[label_off[k]:label_off[k + 1]]"""
+        n = batch.n_regions - first if n is None else n
+        cb = batch.c_struct()
+        off = np.zeros(n + 1, np.uint64)
+        u64p, u32p = C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)
+        _check(self.lib, self.lib.avf_strat_batch_labels(self.handle, genome.handle, C.byref(cb), first, n, off.ctypes.data_as(u64p), None))
+        idx = np.zeros(int(off[n]) + 1, np.uint32)
+        _check(self.lib, self.lib.avf_strat_batch_labels(self.handle, genome.handle, C.byref(cb), first, n, off.ctypes.data_as(u64p), idx.ctypes.data_as(u32p)))
+        return off, idx[:int(off[n])]
 
     def close(self):
         if self.handle:

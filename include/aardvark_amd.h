@@ -220,6 +220,13 @@ uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
  * [7] region count, [8..13] inside search A: setup, pop + quota, finalise, clone, extend, push */
 int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]);
 
+/* Stratified tallies on the device (SummaryWriter::add_comparison_benchmark with the region's containment labels,
+ * src/writers/summary.rs:146-163): after avk_compare_resident with the option emit_group_metrics set, label l's block of
+ * AVK_TALLY_LEN words gets the sum of the metric blocks of the solved regions whose label list names l.  The labels of region r (caller
+ * order) are label_idx[label_off[r] .. label_off[r + 1]) — what avf_strat_batch_labels of the feeder library produces.  The sums are
+ * ADDED to out[n_labels * AVK_TALLY_LEN] (a job sums over its batches); the per-region blocks never leave the GPU. */
+int  avk_label_tallies(avk_ctx *ctx, avk_dev_batch *db, uint32_t n_labels, const uint64_t *label_off, const uint32_t *label_idx, uint64_t *out);
+
 /* Merge path (src/merge_solver.rs:137-143): for pair p, optimize_sequences(set a, set b) and
  * report all_opt_haps[0].is_exact_match().  Pair p compares variant ranges
  * [t_off,t_cnt) vs [q_off,q_cnt) of region p of `batch` exactly like a CompareRegion. */

@@ -102,6 +102,11 @@ uint32_t avf_strat_overlaps(const avf_strat *s, const char *chrom, int64_t first
  * [min first position, max over the two LAST variants of pos + ref_len) of CompareRegion::var_coordinates
  * (compare_region.rs:54-66), queried as first..last-1. */
 uint32_t avf_strat_region_labels(const avf_strat *s, const avf_genome *g, const avk_region_batch *batch, uint64_t r, uint32_t *out, uint32_t cap);
+/* avf_strat_region_labels for regions first .. first + n - 1 at once (several threads), as a compressed list: the labels of region
+ * first + k are label_idx[label_off[k] .. label_off[k + 1]).  Two calls: with label_idx = NULL label_off[0..n] is filled
+ * (label_off[n] = entries needed), with room for that many entries the list itself.  This is what avk_label_tallies takes. */
+int avf_strat_batch_labels(const avf_strat *s, const avf_genome *g, const avk_region_batch *batch, uint64_t first, uint64_t n, uint64_t *label_off,
+                           uint32_t *label_idx);
 void avf_strat_free(avf_strat *s);
 /* avf_write_summary with the stratified blocks after the ALL block (summary.rs:203-222): strat_tallies holds
  * avf_strat_n_labels(s) blocks of AVK_TALLY_LEN words, block l = the sum over the regions label l contains */

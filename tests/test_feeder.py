@@ -635,6 +635,11 @@ def test_stratified_summary_and_region_labels(tmp_path, oracle):
         for l in labels:
             blocks[l, :286] += res.group_metrics[r].reshape(-1).astype(np.uint64)
     assert seen == {0, 1, 2}
+    # the whole batch at once (what avk_label_tallies takes), and a window of it
+    off, idx = strat.batch_labels(genome, feed.batch)
+    assert [idx[int(off[r]):int(off[r + 1])].tolist() for r in range(len(regions))] == [fo.region_labels(ostrat, reg) for reg in regions]
+    off2, idx2 = strat.batch_labels(genome, feed.batch, 50, 100)
+    assert off2.size == 101 and np.array_equal(idx2, idx[int(off[50]):int(off[150])]) and np.array_equal(off2, off[50:151] - off[50])
     out = str(tmp_path / "summary.tsv")
     feeder.write_summary_stratified(out, res.tally, strat, blocks, "strat", 31)
     want = fo.summary_text(res.tally, "strat", ("GT", "BASEPAIR", "HAP", "WEIGHTED_HAP", "RECORD_BP"), strat_blocks=[(l, blocks[k]) for k, l in enumerate(strat.labels)])
@@ -670,6 +675,57 @@ def test_command_line_tool_with_stratifications(tmp_path, oracle):
     assert gzip.open(str(tmp_path / "dbg" / "region_summary.tsv.gz"), "rt").read() == fo.region_summary_text(regions, full.status, full.group_metrics)
     seqs = [[full.sequence(k, j).decode() for j in range(5)] for k in range(want_batch.n_regions)]
     assert gzip.open(str(tmp_path / "dbg" / "region_sequences.tsv.gz"), "rt").read() == fo.region_sequences_text(regions, full.status, seqs)
+
+
+@pytest.mark.gpu
+def test_label_tallies_on_the_device(tmp_path, oracle):
+    """avk_label_tallies: 20 labels (two launches of 16), per-label sums from the metric blocks that stay on the GPU, against sums of the
+    oracle's blocks; then the tool without --output-debug (the path that uses it), batches of 900 regions"""
+    import subprocess
+    import torch
+    torch.cuda.init()
+    import aardvark_amd
+    p, contig, want_batch = write_case_files(tmp_path, 2500, 1_200_000)
+    rng = np.random.default_rng(8)
+    names = ["s%02d" % i for i in range(20)]
+    for i, name in enumerate(names):
+        iv = sorted((int(s), int(s) + int(w)) for s, w in zip(rng.integers(0, 1_190_000, 30 + 10 * i), rng.integers(200, 40_000, 30 + 10 * i)))
+        write_text(str(tmp_path / (name + ".bed")), "".join("chr20\t%d\t%d\n" % x for x in iv))
+    write_text(str(tmp_path / "strat.tsv"), "".join("%s\t%s.bed\n" % (n, n) for n in names))
+    strat = feeder.Stratifications(str(tmp_path / "strat.tsv"))
+    genome = feeder.Genome(p["fa"])
+    feed = feeder.feed_compare(p["t"], p["q"], p["bed"], genome, enable_trimming=False)
+    res = oracle_lib.compare_batch(oracle, feed.batch, genome.contigs(), threads=8)
+    res.status = res.status.copy()
+    off, idx = strat.batch_labels(genome, feed.batch)
+    blocks = np.zeros((20, 288), np.uint64)
+    for r in range(feed.batch.n_regions):
+        for l in idx[int(off[r]):int(off[r + 1])]:
+            blocks[int(l), :286] += res.group_metrics[r].reshape(-1).astype(np.uint64)
+    assert (blocks.sum(axis=1) > 0).all()
+    ctx = aardvark_amd.Context(0)
+    ctx.upload_reference(genome.contigs())
+    rb = ctx.upload(feed.batch)
+    with pytest.raises(aardvark_amd.AardvarkAmdError, match="emit_group_metrics"):
+        ctx.set_option("emit_group_metrics", 0)
+        ctx.compare_resident(rb)
+        ctx.label_tallies(rb, 20, off, idx)
+    rb.free()
+    ctx.set_option("emit_group_metrics", 1)
+    rb = ctx.upload(feed.batch)
+    ctx.compare_resident(rb)
+    got = ctx.label_tallies(rb, 20, off, idx)
+    assert np.array_equal(got, blocks)
+    assert np.array_equal(ctx.label_tallies(rb, 20, off, idx, out=got), 2 * blocks)  # sums are added to `out`
+    with pytest.raises(aardvark_amd.AardvarkAmdError, match="label index"):
+        ctx.label_tallies(rb, 3, off, idx)
+    rb.free()
+    ctx.close()
+    r = subprocess.run([cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "-o", p["out"], "--disable-variant-trimming",
+                        "-s", str(tmp_path / "strat.tsv"), "--batch-regions", "900"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    want = fo.summary_text(res.tally, "compare", ("GT", "BASEPAIR"), strat_blocks=[(l, blocks[i]) for i, l in enumerate(strat.labels)])
+    assert open(os.path.join(p["out"], "summary.tsv")).read() == want
 
 
 def test_debug_tables(tmp_path, oracle):

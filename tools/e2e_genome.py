@@ -82,14 +82,30 @@ for ci, (name, full) in enumerate(zip(NAMES, GRCH38)):
     del contig, truth, query, rows, body
 for f in [fa, bedf, vt, vq] + vm:
     f.close()
+n_strat = int(os.environ.get("STRAT", "0"))  # labelled BED sets for --stratification: label i covers about (i + 1) / (n + 1) of every contig, in 200 intervals per contig
+if n_strat:
+    with open(os.path.join(d, "strat.tsv"), "w") as ts:
+        for i in range(n_strat):
+            ts.write("label_%02d\tstrat_%02d.bed\n" % (i, i))
+            rng = np.random.default_rng(777 + i)
+            with open(os.path.join(d, "strat_%02d.bed" % i), "w") as bf:
+                for name, full in zip(NAMES, GRCH38):
+                    length = max(int(full * scale), 200_000)
+                    for a, b in synth.make_bed(length, 200, (i + 1) / (n_strat + 1), rng):
+                        bf.write("%s\t%d\t%d\n" % (name, a, b))
 print("fixtures: %d truth variants over %d contigs (scale %.2f) written to %s in %.0f s" % (n_truth, len(NAMES), scale, d, time.time() - t0), flush=True)
 cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", os.path.join(d, "genome.fa"), "-t", os.path.join(d, "truth.vcf.gz"),
        "-q", os.path.join(d, "query.vcf.gz"), "-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "out"), "--disable-variant-trimming"]
+if n_strat:
+    cmd += ["-s", os.path.join(d, "strat.tsv")]
 t0 = time.time()
 r = subprocess.run(cmd, capture_output=True, text=True)
 print("exit %d, wall %.2f s" % (r.returncode, time.time() - t0))
 print("\n".join(l for l in r.stderr.strip().splitlines() if not l.startswith("Error while solving")))
-print(open(os.path.join(d, "out", "summary.tsv")).read())
+summary_text = open(os.path.join(d, "out", "summary.tsv")).read()
+print("\n".join(l for l in summary_text.splitlines() if "\tALL\tALL\tALL\t" in l or l.startswith("compare_label")))
+if os.environ.get("KEEP_SUMMARY"):
+    open(os.environ["KEEP_SUMMARY"], "w").write(summary_text)
 if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote over the callers
     vcfs = [os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz")] + [os.path.join(d, "caller%d.vcf.gz" % i) for i in range(2, n_merge)]
     cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, "genome.fa")] + [x for v in vcfs for x in ("-i", v)] + \
