@@ -982,10 +982,21 @@ int avk_label_tallies(avk_ctx *ctx, avk_dev_batch *db, uint32_t n_labels, const 
         if (e == hipSuccess) e = hipMemsetAsync(d_out, 0, host.size() * sizeof(uint64_t), ctx->stream);
         uint32_t blocks = (uint32_t)ctx->n_cus * 4u;
         if ((uint64_t)blocks * 4 > n) blocks = (uint32_t)((n + 3) / 4);
+        const bool timing = getenv("AVK_TIMING") != nullptr;
+        if (timing && e == hipSuccess) e = hipEventRecord(ctx->ev0, ctx->stream);
         for (uint32_t lo = 0; lo < n_labels && e == hipSuccess && n; lo += AVK_LABEL_BLOCK) {
             const uint32_t hi = lo + AVK_LABEL_BLOCK < n_labels ? lo + AVK_LABEL_BLOCK : n_labels;
             hipLaunchKernelGGL(avk_label_tally_kernel, dim3(blocks), dim3(256), 0, ctx->stream, db->d_gm, db->d_region_out, d_off, d_idx, (uint32_t)n, lo, hi, d_out);
             e = hipGetLastError();
+        }
+        if (timing && e == hipSuccess) {
+            e = hipEventRecord(ctx->ev1, ctx->stream);
+            if (e == hipSuccess) e = hipEventSynchronize(ctx->ev1);
+            float ms = 0;
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+            fprintf(stderr, "avk label tallies: %u labels, %llu regions, %llu list entries: kernels %.3f ms (%.1f GB/s of per-region blocks per launch)\n", n_labels,
+                    (unsigned long long)n, (unsigned long long)n_idx, ms,
+                    ms > 0 ? (double)n * AVK_GM_WORDS * 4 * ((n_labels + AVK_LABEL_BLOCK - 1) / AVK_LABEL_BLOCK) / (ms * 1e6) : 0.0);
         }
         if (e == hipSuccess) e = hipMemcpyAsync(host.data(), d_out, host.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
