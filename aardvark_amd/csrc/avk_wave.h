@@ -122,7 +122,12 @@ typedef uint4 avk_u4; /* one 16-byte LDS / global access */
  * where dozens of such invariants outgrow the register file, are spilled in the prologue and reloaded for every region. */
 AVK_DEV int wv_lane() {
     unsigned l;
+#ifdef AVK_LANE_MBCNT
     asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+#else
+    /* one instruction: the workgroups are one-dimensional and the lanes of a wave are 64 consecutive work-items */
+    asm volatile("v_and_b32 %0, 63, %1" : "=v"(l) : "v"(__builtin_amdgcn_workitem_id_x()));
+#endif
     return (int)l;
 }
 AVK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
