@@ -173,6 +173,8 @@ struct avk_ctx {
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
+    int64_t static_pct = AVK_STATIC_PCT; /* share of a launch's work list dealt statically; the rest is claimed */
+    int64_t claim = AVK_CLAIM;           /* regions per claim */
     int64_t class_c_nodes_x2 = 12; /* a region is sent to the HBM solo launch when 0.5 x this x N nodes outgrow a tier-1 slice */
     int64_t solo_regions_per_wave = 4; /* predicted-hard regions beyond solo waves x this lead the bulk list */
     int64_t accumulate_tally = 0; /* avk_compare_resident adds to the caller's device tally instead of overwriting it */
@@ -382,6 +384,12 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "class_c_nodes_x2") {
         if (value < 1 || value > 1000) return fail(ctx, AVK_E_ARG, "class_c_nodes_x2 must be in [1, 1000]");
         ctx->class_c_nodes_x2 = value;
+    } else if (n == "static_pct") {
+        if (value < 0 || value > 100) return fail(ctx, AVK_E_ARG, "static_pct must be in [0, 100]");
+        ctx->static_pct = value;
+    } else if (n == "claim") {
+        if (value < 1 || value > 64) return fail(ctx, AVK_E_ARG, "claim must be in [1, 64]");
+        ctx->claim = value;
     } else if (n == "solo_blocks_max") {
         if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
         ctx->solo_blocks_max = value;
@@ -711,9 +719,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         a.high_priority = 0;
         a.esc_bytes = 0;
         a.esc_enabled = 0;
-        a.static_pct = AVK_STATIC_PCT;
+        a.static_pct = (uint32_t)ctx->static_pct;
         a.n_shards = 8;
-        a.claim = AVK_CLAIM;
+        a.claim = (uint32_t)ctx->claim;
         if (t == 0) {
             a.hbm_ws = nullptr;
             /* Solo launches: the regions the host predicted to outgrow the small slice are solved AT THE SAME TIME, on the

@@ -25,6 +25,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <string_view>
 #include <thread>
 #include <unordered_map>
 #include <vector>
@@ -120,6 +121,26 @@ void split(const std::string &s, char sep, std::vector<std::string> &out) {
         out.emplace_back(s, b, e - b);
         b = e + 1;
     }
+}
+
+void split_sv(std::string_view s, char sep, std::vector<std::string_view> &out) {
+    out.clear();
+    size_t b = 0;
+    for (;;) {
+        const size_t e = s.find(sep, b);
+        if (e == std::string_view::npos) {
+            out.push_back(s.substr(b));
+            return;
+        }
+        out.push_back(s.substr(b, e - b));
+        b = e + 1;
+    }
+}
+
+bool parse_u64_sv(std::string_view s, uint64_t &v) {
+    if (s.empty()) return false;
+    const auto r = std::from_chars(s.data(), s.data() + s.size(), v);
+    return r.ec == std::errc() && r.ptr == s.data() + s.size();
 }
 
 bool parse_u64(const std::string &s, uint64_t &v) {
@@ -252,9 +273,11 @@ int variant_type_of(const std::string &svtype, bool has_svtype, bool has_trid, s
 
 /* All calls of one sample on every chromosome: parse_variant + parse_genotype (region_generation.rs:563-712).
  * calls[chrom] keeps file order. */
-/* per-thread scratch of the record parser */
+/* per-thread scratch of the record parser: the fields are views into the line, nothing is copied until a call is made */
 struct VcfScratch {
-    std::vector<std::string> f, alts, fmt, sv, info;
+    std::vector<std::string> f; /* the #CHROM line */
+    std::vector<std::string_view> v, alts, fmt, sv, info;
+    std::string chrom;
 };
 
 /* the #CHROM line: which column holds the sample */
@@ -276,25 +299,26 @@ int vcf_sample_column(const char *path, const std::string &line, const char *sam
 
 /* One data line -> zero, one or two calls (load_variants_in_region / parse_variant / parse_genotype, region_generation.rs:489-758),
  * handed to emit(chrom, call).  rec = index of the line among the data lines (for messages and provenance). */
-template <class Emit> int vcf_parse_record(const char *path, const std::string &line, long sample_col, bool enable_trimming, uint64_t rec, VcfScratch &w, Emit &&emit) {
-    std::vector<std::string> &f = w.f, &alts = w.alts, &fmt = w.fmt, &sv = w.sv, &info = w.info;
-    split(line, '\t', f);
+template <class Emit> int vcf_parse_record(const char *path, std::string_view line, long sample_col, bool enable_trimming, uint64_t rec, VcfScratch &w, Emit &&emit) {
+    std::vector<std::string_view> &f = w.v, &alts = w.alts, &fmt = w.fmt, &sv = w.sv, &info = w.info;
+    split_sv(line, '\t', f);
     if ((long)f.size() <= sample_col) return fail(AVK_E_ARG, "%s: record %llu has too few columns", path, (unsigned long long)rec);
     uint64_t pos1 = 0;
-    if (!parse_u64(f[1], pos1) || pos1 == 0) return fail(AVK_E_ARG, "%s: record %llu: Missing POS", path, (unsigned long long)rec);
-    const std::string &ref_seq = f[3];
+    if (!parse_u64_sv(f[1], pos1) || pos1 == 0) return fail(AVK_E_ARG, "%s: record %llu: Missing POS", path, (unsigned long long)rec);
+    const std::string_view ref_seq = f[3];
     /* sample GT */
-    split(f[8], ':', fmt);
+    split_sv(f[8], ':', fmt);
     long gt_at = -1;
     for (size_t k = 0; k < fmt.size(); ++k)
         if (fmt[k] == "GT") {
             gt_at = (long)k;
             break;
         }
-    if (gt_at < 0) return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): Missing GT", path, (unsigned long long)rec, f[0].c_str(), (unsigned long long)pos1);
-    split(f[(size_t)sample_col], ':', sv);
+    if (gt_at < 0)
+        return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): Missing GT", path, (unsigned long long)rec, std::string(f[0]).c_str(), (unsigned long long)pos1);
+    split_sv(f[(size_t)sample_col], ':', sv);
     if ((long)sv.size() <= gt_at || sv[(size_t)gt_at] == "." || sv[(size_t)gt_at].empty()) return 0; /* GT = '.': a no-op (:583-586) */
-    const std::string &gt = sv[(size_t)gt_at];
+    const std::string_view gt = sv[(size_t)gt_at];
     /* parse_genotype (:660-712) */
     uint64_t idx[2] = {0, 0};
     bool phased = false;
@@ -303,10 +327,10 @@ template <class Emit> int vcf_parse_record(const char *path, const std::string &
         for (size_t k = 0; k <= gt.size(); ++k) {
             if (k == gt.size() || gt[k] == '/' || gt[k] == '|') {
                 if (k < gt.size() && gt[k] == '|') phased = true;
-                if (n_alleles >= 2) return fail(AVK_E_ARG, "%s: record %llu: allele.len() != [1, 2]: %s", path, (unsigned long long)rec, gt.c_str());
-                const std::string a(gt, b, k - b);
+                if (n_alleles >= 2) return fail(AVK_E_ARG, "%s: record %llu: allele.len() != [1, 2]: %s", path, (unsigned long long)rec, std::string(gt).c_str());
+                const std::string_view a = gt.substr(b, k - b);
                 uint64_t v = 0;
-                if (a != "." && !parse_u64(a, v)) return fail(AVK_E_ARG, "%s: record %llu: malformed GT %s", path, (unsigned long long)rec, gt.c_str());
+                if (a != "." && !parse_u64_sv(a, v)) return fail(AVK_E_ARG, "%s: record %llu: malformed GT %s", path, (unsigned long long)rec, std::string(gt).c_str());
                 idx[n_alleles++] = v; /* '.' is treated as a reference call */
                 b = k + 1;
             }
@@ -324,46 +348,48 @@ template <class Emit> int vcf_parse_record(const char *path, const std::string &
     }
     if (n_picks == 0) return 0;
     if (f[4] == "." || f[4].empty()) alts.clear();
-    else split(f[4], ',', alts);
+    else split_sv(f[4], ',', alts);
     /* INFO: SVTYPE and TRID */
     bool has_svtype = false, has_trid = false;
     std::string svtype;
     if (f[7] != "." && !f[7].empty()) {
-        split(f[7], ';', info);
-        for (const std::string &kv : info) {
+        split_sv(f[7], ';', info);
+        for (const std::string_view kv : info) {
             if (kv.compare(0, 7, "SVTYPE=") == 0) {
                 has_svtype = true;
-                svtype.assign(kv, 7);
+                svtype.assign(kv.substr(7));
             } else if (kv.compare(0, 5, "TRID=") == 0 && kv.size() > 5) has_trid = true;
         }
     }
     for (int p = 0; p < n_picks; ++p) {
         const uint64_t alt_index = picks[p].first;
         if (alt_index > alts.size()) return fail(AVK_E_ARG, "%s: record %llu: GT refers to ALT %llu of %zu", path, (unsigned long long)rec, (unsigned long long)alt_index, alts.size());
-        const std::string &alt = alts[alt_index - 1];
+        const std::string_view alt = alts[alt_index - 1];
         if (alt == "*") continue;            /* effectively a reference allele (:597-600) */
         if (!alt.empty() && alt[0] == '<') continue; /* symbolic: needs sequence-resolved (:604-607) */
-        std::string r = ref_seq, a = alt;
-        const size_t raw_space = std::max(r.size(), a.size()); /* before trimming (:612) */
-        while (enable_trimming && r.size() > 1 && a.size() > 1 && r.back() == a.back()) {
-            r.pop_back();
-            a.pop_back();
+        size_t rl = ref_seq.size(), al = alt.size();
+        const size_t raw_space = std::max(rl, al); /* before trimming (:612) */
+        while (enable_trimming && rl > 1 && al > 1 && ref_seq[rl - 1] == alt[al - 1]) {
+            rl -= 1;
+            al -= 1;
         }
-        if (r.size() > 10000 || a.size() > 10000) continue; /* allele_size_limit (:621-626) */
+        if (rl > 10000 || al > 10000) continue; /* allele_size_limit (:621-626) */
         uint8_t type = 0;
-        const int rc = variant_type_of(svtype, has_svtype, has_trid, r.size(), a.size(), type);
+        const int rc = variant_type_of(svtype, has_svtype, has_trid, rl, al, type);
         if (rc == 1) continue;
-        if (rc < 0) return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): %s", path, (unsigned long long)rec, f[0].c_str(), (unsigned long long)pos1, std::string(t_error).c_str());
+        if (rc < 0)
+            return fail(AVK_E_ARG, "%s: record %llu (%s:%llu): %s", path, (unsigned long long)rec, std::string(f[0]).c_str(), (unsigned long long)pos1, std::string(t_error).c_str());
         Call c;
         c.pos = pos1 - 1;
-        c.a0.swap(r);
-        c.a1.swap(a);
+        c.a0.assign(ref_seq.data(), rl);
+        c.a1.assign(alt.data(), al);
         c.raw_space = (uint32_t)raw_space;
         c.type = type;
         c.zyg = picks[p].second;
         c.record = rec;
         c.alt_index = (uint32_t)alt_index;
-        emit(f[0], std::move(c));
+        if (w.chrom.size() != f[0].size() || memcmp(w.chrom.data(), f[0].data(), f[0].size()) != 0) w.chrom.assign(f[0]);
+        emit(w.chrom, std::move(c));
     }
     return 0;
 }
@@ -565,8 +591,7 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, st
                         }
                     } else {
                         out.has_data = true;
-                        line.assign(p, len);
-                        const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, out.n_records, w,
+                        const int rc = vcf_parse_record(path, std::string_view(p, len), sample_col, enable_trimming, out.n_records, w,
                                                         [&](const std::string &chrom, Call &&c) { emit_into(out, last, chrom, std::move(c)); });
                         out.n_records += 1;
                         if (rc) {
@@ -716,8 +741,7 @@ int load_vcf(const char *path, const char *sample, bool enable_trimming, std::un
                         if (p[0] == '#') {
                             if (len >= 6 && memcmp(p, "#CHROM", 6) == 0) irregular.store(true);
                         } else {
-                            line.assign(p, len);
-                            const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, out->n_records, w, [&](const std::string &chrom, Call &&c) {
+                            const int rc = vcf_parse_record(path, std::string_view(p, len), sample_col, enable_trimming, out->n_records, w, [&](const std::string &chrom, Call &&c) {
                                 if (last == (size_t)-1 || out->chroms[last] != chrom) {
                                     last = (size_t)-1;
                                     for (size_t q = 0; q < out->chroms.size(); ++q)
