@@ -3,8 +3,9 @@ may import it; the product is aardvark_amd/csrc/feeder/avf_feeder.cpp.
 
 Parity unpinned: the reference holds no tests or fixtures for src/parsing/ and src/writers/ (0 #[test] functions,
 "TODO: we likely need to add tests" at region_generation.rs:814-821), so this restatement is anchored on the source
-only; the end-to-end check that IS pinned is the 8 solve_compare_region known-answer regions run through
-VCF -> feeder -> solver (tests/test_feeder.py).
+only; the end-to-end checks that ARE pinned: the 8 solve_compare_region known-answer regions run through
+VCF -> feeder -> solver (tests/test_feeder.py), and the worked examples of the reference's documentation (labeled VCF,
+summary rows, the two debug tables; tests/test_docs_examples.py), which the C++ writers reproduce byte for byte.
 
 file:line citations are into PacificBiosciences/aardvark v0.10.5.
 """

@@ -8,7 +8,8 @@
   merge_summary_text    MergeSummaryWriter                                          (src/writers/merge_summary.rs)
 
 Pinned by the reference's own known answers for solve_merge_region (tests/golden/merge_solver.json, from
-src/merge_solver.rs:243-370).  The writers' text layout has no fixture in the reference: parity unpinned for them.
+src/merge_solver.rs:243-370).  The writers' text layout has no fixture in the reference's source tree; the record layout of the merged VCF and the BED names are
+pinned by the documentation's example (docs/merge.md, tests/test_docs_examples.py), the summary table is not: parity unpinned for it.
 """
 
 SIMPLE = {"different": "different", "no_conflict": "no_conflict", "majority": "majority", "conflict_select": "conflict_select", "identical": "identical"}
