@@ -9,7 +9,8 @@
 
 Pinned by the reference's own known answers for solve_merge_region (tests/golden/merge_solver.json, from
 src/merge_solver.rs:243-370).  The writers' text layout has no fixture in the reference's source tree; the record layout of the merged VCF and the BED names are
-pinned by the documentation's example (docs/merge.md, tests/test_docs_examples.py), the summary table is not: parity unpinned for it.
+and the summary table (row order, reason names with their index lists, columns) are pinned by the documentation's examples
+(docs/merge.md, tests/test_docs_examples.py).
 """
 
 SIMPLE = {"different": "different", "no_conflict": "no_conflict", "majority": "majority", "conflict_select": "conflict_select", "identical": "identical"}

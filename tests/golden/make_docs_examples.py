@@ -39,6 +39,7 @@ out = {
     "region_sequences": block_starting(compare, "region_id\tcoordinates\tref_seq"),
     "region_summary": block_starting(compare, "region_id\tcoordinates\tcomparison"),
     "merged_vcf": block_starting(merge, "#CHROM\tPOS"),
+    "merge_summary": block_starting(merge, "merge_reason\tvariant_type"),
 }
 json.dump(out, open(OUT, "w"), indent=1)
 print({k: len(v) for k, v in out.items() if isinstance(v, list)})

@@ -145,3 +145,41 @@ def test_merged_vcf_documentation_example(tmp_path):
     assert [l for l in lines if not l.startswith("##")] == DOC["merged_vcf"]
     bed = gzip.open(os.path.join(out, "regions.bed.gz"), "rt").read().splitlines()
     assert [l.split("\t")[3] for l in bed] == ["no_conflict_0", "identical_1", "no_conflict_2", "no_conflict_3", "identical_4", "majority_5", "identical_6", "identical_7"]
+
+
+def test_merge_summary_documentation_example(tmp_path):
+    """the printed merge summary (Snv rows of a three-caller run): one region per merge reason carrying the printed pass / fail counts —
+    row order (derive(Ord) of the classification with its index lists), reason names and columns must come out as printed"""
+    from aardvark_amd.merge import MultiBatch
+    rows = [l.split("\t") for l in DOC["merge_summary"][1:]]
+    tags = ["pb", "ilmn", "ont"]
+    assert all(r[1] == "Snv" and tags[int(r[2])] == r[3] for r in rows)
+    reasons = []
+    for r in rows:
+        if r[0] not in reasons:
+            reasons.append(r[0])
+    code = {"different": 0, "identical": 1, "no_conflict": 2, "majority": 3}
+    n = len(reasons)
+    in_cnt = np.zeros((n, 3), np.uint32)
+    cls, mem = np.zeros(n, np.uint8), np.zeros(n, np.uint64)
+    for m, reason in enumerate(reasons):
+        name = reason.rstrip("_0123456789")
+        idx = [int(x) for x in reason[len(name):].split("_") if x]
+        cls[m] = code[name]
+        mem[m] = sum(1 << i for i in idx)
+        for r in rows:
+            if r[0] == reason:
+                passing, failing = int(r[4]), int(r[5])
+                assert (passing == 0) != (failing == 0) and (passing > 0) == (name == "identical" or int(r[2]) in idx)
+                in_cnt[m, int(r[2])] = passing + failing
+    total = int(in_cnt.sum())
+    in_off = np.concatenate([[0], np.cumsum(in_cnt.reshape(-1))[:-1]]).astype(np.uint64)
+    zeros = lambda dt: np.zeros(total, dt)
+    mb = MultiBatch(3, region_id=np.arange(n), contig_idx=np.zeros(n), start=np.zeros(n), end=np.ones(n), in_off=in_off, in_cnt=in_cnt.reshape(-1),
+                    var_pos=zeros(np.uint64), var_type=zeros(np.uint8), var_zyg=np.full(total, 5, np.uint8), var_raw_space=np.ones(total, np.uint32),
+                    a0_off=zeros(np.uint64), a0_len=np.ones(total, np.uint32), a1_off=np.ones(total, np.uint64), a1_len=np.ones(total, np.uint32),
+                    allele_bytes=np.frombuffer(b"AC", np.uint8))
+    res = MergeResult(np.zeros(n, np.int32), cls, mem, 3)
+    out = str(tmp_path / "merge_summary.tsv")
+    feeder.write_merge_summary(out, mb, res, tags=tags)
+    assert open(out).read().splitlines() == DOC["merge_summary"]
