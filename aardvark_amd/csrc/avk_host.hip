@@ -612,6 +612,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
     const uint32_t hbm_solo_max = 64;
     const size_t ws_need = (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
+    const auto t_ws = std::chrono::steady_clock::now();
+    const bool ws_grows = ws_need > ctx->ws_alloc;
     if (ws_need > ctx->ws_alloc) {
         if (ctx->d_ws) {
             AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -635,6 +637,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         ctx->big_alloc = big_need;
     }
 
+    if (getenv("AVK_TIMING") && (ws_grows || big_need > 0))
+        fprintf(stderr, "avk run: workspaces (%.1f GB per-wave slices%s, %.1f GB shared slices) %.3f ms\n", (double)ws_need / 1e9, ws_grows ? ", allocated now" : "",
+                (double)big_need / 1e9, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ws).count());
     if (!db->scratch_clean) { /* normally left clean by avk_tally_reduce of the previous call */
         AVK_HIP(ctx, hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), ctx->stream));
         AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t), ctx->stream));
@@ -903,6 +908,8 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     if (!ctx || !db || !out || !out->status) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions, nv = db->n_variants_dev;
+    const bool timing = getenv("AVK_TIMING") != nullptr;
+    const auto t_begin = std::chrono::steady_clock::now();
     std::vector<uint32_t> rout(n * 4 + 4), vout(nv + 1);
     std::vector<uint64_t> tally((size_t)AVK_TALLY_STRIDE);
     hipStream_t s = ctx->stream;
@@ -923,6 +930,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     }
 #undef D2H
     AVK_HIP(ctx, hipStreamSynchronize(s));
+    const auto t_copied = std::chrono::steady_clock::now();
     for (uint64_t r = 0; r < n; ++r) {
         const uint32_t *w = rout.data() + 4 * r;
         out->status[r] = (int32_t)w[0];
@@ -939,6 +947,9 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
         if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
     }
+    if (timing)
+        fprintf(stderr, "avk download: kernels + copies %.3f ms, unpack %.3f ms\n", std::chrono::duration<double, std::milli>(t_copied - t_begin).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copied).count());
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
     memcpy(ctx->last_phase, tally.data() + AVK_TALLY_LEN + 5, 16 * sizeof(uint64_t));
