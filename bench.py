@@ -76,6 +76,9 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx.set_stream(stream.cuda_stream)  # launches go on torch's current stream
     ctx.set_option("emit_group_metrics", 0)  # per-variant decisions + batch tally only
+    for kv in os.environ.get("AVK_OPTS", "").split(","):  # tuning experiments: context options by name
+        if "=" in kv:
+            ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ctx.upload_reference([contig])
     rb = ctx.upload(batch)
     cfg = CompareConfig(enable_sequences=False)

@@ -181,7 +181,10 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *   scheduling       "solo_min_variants" (regions with at least this many variants go to the solo launch, 0 = no solo
  *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
  *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid",
- *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2)
+ *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2),
+ *                    "order_guard" (1 for callers that queue avk_compare_resident calls back to back without synchronising: the bulk
+ *                    launch then waits for the side streams to reach their launches), "timing_events" (0 = no event records for
+ *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
