@@ -345,7 +345,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
 
 /* Work order of the first launch and the prediction of which regions outgrow the LDS slices.
  * order = [class C | class B | the rest], each part with the most variants first:
- *   class C  predicted to outgrow even a tier-1 slice (upper range, about 4 N nodes alive): solved by the HBM solo launch;
+ *   class C  predicted to outgrow even a tier-1 slice (upper range, about 6 N nodes alive = class_c_nodes_x2 / 2): solved by the HBM solo launch, which shares its list with the main stream's HBM launch;
  *   class B  predicted to outgrow the small slice (typical case, about 2N+1 nodes alive) or with at least
  *            solo_min_variants variants: solved by the solo waves with a tier-1 slice each;
  *   the rest goes to the bulk launch.
