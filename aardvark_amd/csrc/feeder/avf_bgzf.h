@@ -13,18 +13,31 @@ namespace avf_bgzf {
 
 constexpr size_t kBlock = 0xff00; /* uncompressed bytes per block */
 
-inline bool compress_block(const char *in, size_t n, std::string &out) {
-    std::vector<unsigned char> buf(kBlock + 1024);
+/* every thread keeps one deflate state and one output buffer for all the blocks it compresses: a fresh deflateInit2 per 64 KiB block
+ * is two large allocations (memory maps) per block, which many compressing threads serialise on */
+struct Deflater {
     z_stream zs;
-    memset(&zs, 0, sizeof(zs));
-    if (deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    bool ok = false;
+    std::vector<unsigned char> buf;
+    Deflater() : buf(kBlock + 1024) {
+        memset(&zs, 0, sizeof(zs));
+        ok = deflateInit2(&zs, 6, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) == Z_OK;
+    }
+    ~Deflater() {
+        if (ok) deflateEnd(&zs);
+    }
+};
+inline bool compress_block(const char *in, size_t n, std::string &out) {
+    static thread_local Deflater d;
+    if (!d.ok || deflateReset(&d.zs) != Z_OK) return false;
+    std::vector<unsigned char> &buf = d.buf;
+    z_stream &zs = d.zs;
     zs.next_in = (Bytef *)in;
     zs.avail_in = (uInt)n;
     zs.next_out = buf.data() + 18;
     zs.avail_out = (uInt)(buf.size() - 18 - 8);
     const int rc = deflate(&zs, Z_FINISH);
     const size_t clen = zs.total_out;
-    deflateEnd(&zs);
     if (rc != Z_STREAM_END) return false;
     const size_t total = 18 + clen + 8;
     static const unsigned char head[16] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0, 0xff, 0x06, 0x00, 0x42, 0x43, 0x02, 0x00};

@@ -50,10 +50,13 @@ class BgzfWriter {
             for (size_t k = t; k < nb; k += (size_t)nt)
                 if (!compress_block(blocks_[k], packed[k])) bad[k] = 1;
         };
+        const auto t0 = std::chrono::steady_clock::now();
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; ++t) pool.emplace_back(work, (size_t)t);
         work(0);
         for (auto &th : pool) th.join();
+        if (getenv("AVF_TIMING"))
+            fprintf(stderr, "[avf] bgzf: %zu blocks compressed by %d threads in %.3f s\n", nb, nt, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         file_off_.assign(nb + 1, 0);
         for (size_t k = 0; k < nb; ++k) {
             if (bad[k]) return false;
@@ -154,7 +157,7 @@ class IndexedText {
         FILE *fp = fopen(path.c_str(), "wb");
         if (!fp) return false;
         int threads = (int)std::thread::hardware_concurrency();
-        if (threads > 16) threads = 16;
+        if (threads > 64) threads = 64;
         bool ok = w_.finish(fp, threads);
         ok = (fclose(fp) == 0) && ok;
         if (!ok) return false;
@@ -204,7 +207,7 @@ class IndexedText {
         if (!tf) return false;
         BgzfWriter tw;
         tw.write(tbi.data(), tbi.size());
-        const bool tok = tw.finish(tf, 1);
+        const bool tok = tw.finish(tf, threads); /* a whole-genome index is several megabytes */
         return (fclose(tf) == 0) && tok;
     }
 
@@ -228,7 +231,7 @@ struct LineMeta {
 };
 template <class Fn, class NameOf> bool format_parallel(uint64_t n_items, Fn &&fn, NameOf &&name_of, IndexedText &out) {
     unsigned hw = std::thread::hardware_concurrency();
-    const size_t n_threads = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
+    const size_t n_threads = hw < 1 ? 1 : (hw > 32 ? 32 : hw);
     const size_t n_pieces = n_items < 512 ? 1 : std::min<size_t>(4 * n_threads, (size_t)(n_items / 128));
     std::vector<std::string> texts(n_pieces);
     std::vector<std::vector<LineMeta>> metas(n_pieces);
