@@ -19,6 +19,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/aardvark_amd.h"
@@ -197,6 +198,8 @@ struct avk_ctx {
     /* measurement */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk1 = nullptr; /* ev0..ev1 all solver launches, ev0..evk1 the first (dominant) one */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
+    std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
+    std::mutex reaper_mutex;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ready = nullptr, ev_ready2 = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
@@ -326,6 +329,10 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
 
 void avk_ctx_destroy(avk_ctx *ctx) {
     if (!ctx) return;
+    {
+        std::lock_guard<std::mutex> lock(ctx->reaper_mutex);
+        if (ctx->reaper.joinable()) ctx->reaper.join();
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
@@ -598,6 +605,19 @@ void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+    }
+    /* a large batch holds a dozen device buffers and about a gigabyte of host records: releasing them takes 0.1 s, which a tool that
+     * works through its batches one after the other should not wait for.  One release runs behind the caller at a time. */
+    if (ctx && db->n_regions >= 65536) {
+        std::lock_guard<std::mutex> lock(ctx->reaper_mutex);
+        if (ctx->reaper.joinable()) ctx->reaper.join();
+        const int device = ctx->device;
+        ctx->reaper = std::thread([db, device] {
+            (void)hipSetDevice(device);
+            free_batch_buffers(db);
+            delete db;
+        });
+        return;
     }
     free_batch_buffers(db);
     delete db;
@@ -996,11 +1016,20 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
 int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
     if (!ctx || !batch || !cfg || !out) return AVK_E_ARG;
     avk_dev_batch *db = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = avk_batch_upload(ctx, batch, &db);
     if (rc) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     rc = avk_compare_resident(ctx, db, cfg, nullptr);
+    const auto t2 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_results_download(ctx, db, out);
+    const auto t3 = std::chrono::steady_clock::now();
     avk_batch_free(ctx, db);
+    if (getenv("AVK_TIMING")) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "avk compare batch: upload %.3f ms, launches %.3f ms, download %.3f ms, free %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
+                ms(t3, std::chrono::steady_clock::now()));
+    }
     return rc;
 }
 

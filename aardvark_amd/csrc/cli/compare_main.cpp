@@ -203,8 +203,10 @@ int main(int argc, char **argv) {
     th_ref.join();
     if (rc_feed) die(74, "Error while building regions", err_feed.c_str());
     if (rc_ref) die(70, "reference upload failed", err_ref.c_str());
-    avf_calls_free(calls[0]);
-    avf_calls_free(calls[1]);
+    std::thread th_free([&calls] { /* millions of small records: released beside the solve stage */
+        avf_calls_free(calls[0]);
+        avf_calls_free(calls[1]);
+    });
     const avk_region_batch *all = avf_feed_batch(feed);
     const double s_feed = seconds_since(t0);
     fprintf(stderr, "Loaded %llu truth and %llu query variants; %llu regions.\n", (unsigned long long)avf_feed_loaded_variants(feed, 0),
@@ -359,6 +361,7 @@ int main(int argc, char **argv) {
             s_load, s_genome, s_calls[0], s_calls[1], s_ctx, s_feed, s_ref, s_solve, s_write);
     fprintf(stderr, "Comparisons completed in %.3f seconds (%.2f M regions/s in the solve stage).\n", seconds_since(t_start),
             s_solve > 0 ? (double)count / s_solve / 1e6 : 0.0);
+    th_free.join();
     avk_ctx_destroy(ctx);
     avf_feed_free(feed);
     avf_strat_free(strat);

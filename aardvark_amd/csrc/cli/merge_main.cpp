@@ -196,7 +196,9 @@ int main(int argc, char **argv) {
     th_ref.join();
     if (rc_feed) die(74, "Error while building region iterator", err_feed.c_str());
     if (rc_ref) die(70, "reference upload failed", err_ref.c_str());
-    for (avf_calls *c : calls) avf_calls_free(c);
+    std::thread th_free([&calls] { /* millions of small records: released beside the solve stage */
+        for (avf_calls *c : calls) avf_calls_free(c);
+    });
     const avk_multi_batch *all = avf_feed_multi_batch(feed);
     const double s_feed = seconds_since(t0);
     for (uint32_t i = 0; i < k; ++i)
@@ -291,6 +293,7 @@ int main(int argc, char **argv) {
                     "solve (pack + H2D + kernels + D2H + classify) %.3f, outputs %.3f\n",
             s_load, s_genome, s_feed, s_ref, s_solve, s_write);
     fprintf(stderr, "Merge completed in %.3f seconds.\n", seconds_since(t_start));
+    th_free.join();
     avk_ctx_destroy(ctx);
     avf_feed_free(feed);
     avf_genome_free(genome);
