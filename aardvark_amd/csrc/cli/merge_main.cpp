@@ -34,7 +34,7 @@ void usage() {
             "  [-s SAMPLE ...] [-t TAG ...] [--output-summary SUMMARY.tsv|.csv] [--output-debug DIR]\n"
             "  [--min-variant-gap 50] [--disable-variant-trimming] [--merge-strategy exact|no_conflict|majority|all]\n"
             "  [--enable-no-conflict] [--enable-voting] [--conflict-select INDEX] [--max-branch-factor 50]\n"
-            "  [--skip N] [--take N] [--device 0] [--batch-regions 1000000]\n");
+            "  [--skip N] [--take N] [--device 0] [--batch-regions 1000000] [--contexts 2]\n");
 }
 
 std::string json_string(const std::string &s) {
@@ -67,7 +67,7 @@ int main(int argc, char **argv) {
     const auto t_start = std::chrono::steady_clock::now();
     std::string ref, bed, out_dir, summary_path, debug_dir, strategy;
     std::vector<std::string> vcfs, samples, tags;
-    uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 1000000, threads = 1, verbosity = 0;
+    uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 1000000, threads = 1, verbosity = 0, contexts = 2;
     bool trimming = true, no_conflict = false, voting = false;
     long long conflict_select = -1;
     int device = 0;
@@ -96,6 +96,7 @@ int main(int argc, char **argv) {
         else if (a == "--take") take = strtoull(val(), nullptr, 10);
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
+        else if (a == "--contexts") contexts = strtoull(val(), nullptr, 10);
         else if (a == "--threads") threads = strtoull(val(), nullptr, 10);
         else if (a == "-v" || a == "--verbose") verbosity += 1;
         else if (a == "-h" || a == "--help") {
@@ -253,27 +254,67 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> classification(all->n_regions + 1, 0);
     std::vector<uint64_t> members(all->n_regions + 1, 0);
     uint64_t solved = 0, errors = 0;
-    for (uint64_t at = 0; at < count; at += batch_regions) {
-        const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
-        avk_multi_batch b = *all; /* a window of the region arrays; variant arrays are shared */
-        b.n_regions = n;
-        b.region_id = all->region_id + first + at;
-        b.contig_idx = all->contig_idx + first + at;
-        b.start = all->start + first + at;
-        b.end = all->end + first + at;
-        b.in_off = all->in_off + (first + at) * k;
-        b.in_cnt = all->in_cnt + (first + at) * k;
-        if (avk_merge_batch(ctx, &b, &cfg, status.data() + first + at, classification.data() + first + at, members.data() + first + at))
-            die(70, "merge failed", avk_last_error(ctx));
-        for (uint64_t r = 0; r < n; ++r) {
-            if (status[first + at + r] == 0) {
-                solved += 1;
-                continue;
+    /* Two contexts on the same GPU work through the batches: the host side of one batch (pair records, packing, upload, classification)
+     * runs beside the kernels of the other.  The second context is made by its own thread, reference upload included. */
+    const uint64_t n_batches = (count + batch_regions - 1) / batch_regions;
+    const int n_workers = n_batches >= 2 && contexts >= 2 ? 2 : 1;
+    std::atomic<uint64_t> next_batch{0};
+    std::string worker_err[2];
+    auto solve_batches = [&](int w) {
+        avk_ctx *my = ctx;
+        if (w > 0) {
+            my = nullptr;
+            if (avk_ctx_create(device, &my)) {
+                worker_err[w] = std::string("cannot create the GPU context: ") + avk_last_error(nullptr);
+                return;
             }
-            errors += 1;
-            fprintf(stderr, "Error while solving merge region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)b.region_id[r], b.contig_idx[r],
-                    (unsigned long long)b.start[r], (unsigned long long)b.end[r], status[first + at + r]);
+            const uint32_t n_contigs = avf_genome_n_contigs(genome);
+            std::vector<const uint8_t *> seqs(n_contigs);
+            std::vector<uint64_t> lens(n_contigs);
+            for (uint32_t c = 0; c < n_contigs; ++c) {
+                seqs[c] = avf_genome_seq(genome, c);
+                lens[c] = avf_genome_len(genome, c);
+            }
+            if (avk_ref_upload(my, n_contigs, seqs.data(), lens.data())) {
+                worker_err[w] = std::string("reference upload failed: ") + avk_last_error(my);
+                avk_ctx_destroy(my);
+                return;
+            }
         }
+        for (uint64_t bi = next_batch.fetch_add(1); bi < n_batches; bi = next_batch.fetch_add(1)) {
+            const uint64_t at = bi * batch_regions;
+            const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
+            avk_multi_batch b = *all; /* a window of the region arrays; variant arrays are shared */
+            b.n_regions = n;
+            b.region_id = all->region_id + first + at;
+            b.contig_idx = all->contig_idx + first + at;
+            b.start = all->start + first + at;
+            b.end = all->end + first + at;
+            b.in_off = all->in_off + (first + at) * k;
+            b.in_cnt = all->in_cnt + (first + at) * k;
+            if (avk_merge_batch(my, &b, &cfg, status.data() + first + at, classification.data() + first + at, members.data() + first + at)) {
+                worker_err[w] = std::string("merge failed: ") + avk_last_error(my);
+                break;
+            }
+        }
+        if (w > 0) avk_ctx_destroy(my);
+    };
+    {
+        std::thread other;
+        if (n_workers == 2) other = std::thread(solve_batches, 1);
+        solve_batches(0);
+        if (other.joinable()) other.join();
+        for (int w = 0; w < 2; ++w)
+            if (!worker_err[w].empty()) die(70, worker_err[w].c_str(), "");
+    }
+    for (uint64_t r = first; r < first + count; ++r) {
+        if (status[r] == 0) {
+            solved += 1;
+            continue;
+        }
+        errors += 1;
+        fprintf(stderr, "Error while solving merge region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)all->region_id[r], all->contig_idx[r],
+                (unsigned long long)all->start[r], (unsigned long long)all->end[r], status[r]);
     }
     const double s_solve = seconds_since(t0);
 
