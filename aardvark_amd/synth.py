@@ -167,6 +167,32 @@ def indel_truth(contig, bed, n, seed, snv_frac=0.82, close_frac=0.03, str_frac=0
     return CallSet(base, ref, alt, vt, _random_zyg(n, rng))
 
 
+def add_multiallelic(calls, frac, seed):
+    """a share of the sites is multi-allelic (`1/2`): the site's call becomes a heterozygous one and a second
+    heterozygous call with another ALT is added at the same position (what the feeder's multi-ALT split makes of a `1/2` record;
+    phased sites get the complementary phase)."""
+    rng = np.random.default_rng(seed)
+    n = len(calls)
+    pick = np.nonzero(rng.random(n) < frac)[0]
+    pos, ref, alt, vt, zyg = list(calls.pos), list(calls.ref), list(calls.alt), list(calls.vtype), list(calls.zyg)
+    for i in pick:
+        r, a = ref[i], alt[i]
+        if len(r) == 1 and len(a) == 1:  # SNV: another base
+            b = bytes(_snv_alt(np.frombuffer(a, np.uint8), rng))
+            if b == r:
+                continue
+            a2, t2 = b, VT["Snv"]
+        elif len(r) == 1:  # insertion: the inserted bases once more
+            a2, t2 = a + a[1:], VT["Insertion"]
+        else:  # deletion: one base less deleted, or an SNV at the anchor when nothing is left
+            a2, t2 = (r[:2], VT["Deletion"]) if len(r) > 2 else (bytes(_snv_alt(np.frombuffer(r[:1], np.uint8), rng)) + r[1:], VT["Indel"])
+        phased = rng.random() < 0.5
+        zyg[i] = ZYG["PhasedHet01"] if phased else ZYG["UnphasedHeterozygous"]
+        pos.append(pos[i]); ref.append(r); alt.append(a2); vt.append(t2)
+        zyg.append(ZYG["PhasedHet10"] if phased else ZYG["UnphasedHeterozygous"])
+    return CallSet(np.array(pos), ref, alt, np.array(vt, np.uint8), np.array(zyg, np.uint8))
+
+
 def cluster_regions(contig_len, bed, truth, query, gap=50, contig_idx=0, region_id_base=0):
     """RegionIterator::next for one contig (region_generation.rs:373-470) -> RegionBatch."""
     nt, nq = len(truth), len(query)

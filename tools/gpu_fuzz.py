@@ -65,9 +65,12 @@ while time.time() - t_start < budget:
         rng = np.random.default_rng(seed + 1)
         bed = synth.make_bed(length, 300, 0.9, rng)
         truth = synth.indel_truth(contig, bed, 150_000, seed + 2, snv_frac=(0.82, 0.6, 0.4)[j], close_frac=(0.03, 0.1, 0.2)[j], str_frac=(0.05, 0.1, 0.15)[j])
+        if rnd % 2 == 1:  # multi-allelic sites (two calls at one position), in the truth set and — perturbed like the rest — in the query
+            truth = synth.add_multiallelic(truth, 0.02 * (j + 1), seed + 5)
         query = synth.perturb_query(contig, bed, truth, seed + 3, extra, drop, flip, change)
         batch = synth.cluster_regions(length, bed, truth, query, (50, 20, 120)[rnd % 3])
-        check("callset seed %d drop %.2f flip %.2f change %.2f extra %d gap %d" % (seed, drop, flip, change, extra, (50, 20, 120)[rnd % 3]), [contig], batch,
+        check("callset seed %d drop %.2f flip %.2f change %.2f extra %d gap %d%s" % (seed, drop, flip, change, extra, (50, 20, 120)[rnd % 3],
+                                                                                 " multiallelic" if rnd % 2 == 1 else ""), [contig], batch,
               sequences=(rnd % 2 == 0))
     rnd += 1
 print("ALL OK: %d cases, %d regions in %.0f s" % (cases, total, time.time() - t_start))
