@@ -18,6 +18,8 @@ contig = synth.make_contig(synth.CHR20_LEN, 20250101)
 rng = np.random.default_rng(20250101 + 7)
 bed = synth.make_bed(synth.CHR20_LEN, 1000, 0.9, rng)
 truth = synth.snv_truth(contig, bed, n_truth, 20250101 + 11)
+if os.environ.get("MULTIALLELIC", "1") == "1":  # 2 % of the sites carry two ALT alleles, written as one `1/2` record (the feeder splits it again)
+    truth = synth.add_multiallelic(truth, 0.02, 20250101 + 13)
 query = synth.perturb_query(contig, bed, truth, 20250102, 500)
 batch = synth.cluster_regions(synth.CHR20_LEN, bed, truth, query, 50)
 seq = contig.tobytes()
@@ -29,8 +31,19 @@ hdr = "##fileformat=VCFv4.2\n##contig=<ID=chr20>\n##FORMAT=<ID=GT,Number=1,Type=
 for name, cs in (("truth.vcf.gz", truth), ("query.vcf.gz", query)):
     with gzip.open(os.path.join(d, name), "wt", compresslevel=1) as f:
         f.write(hdr)
-        for i in range(len(cs)):
+        i, merged = 0, 0
+        while i < len(cs):
+            two = i + 1 < len(cs) and cs.pos[i + 1] == cs.pos[i] and cs.ref[i + 1] == cs.ref[i] and cs.alt[i + 1] != cs.alt[i]
+            z = (int(cs.zyg[i]), int(cs.zyg[i + 1])) if two else None
+            if two and z in ((ZYG["UnphasedHeterozygous"],) * 2, (ZYG["PhasedHet01"], ZYG["PhasedHet10"]), (ZYG["PhasedHet10"], ZYG["PhasedHet01"])):
+                gt = "1/2" if z[0] == ZYG["UnphasedHeterozygous"] else ("2|1" if z[0] == ZYG["PhasedHet01"] else "1|2")
+                f.write("chr20\t%d\t.\t%s\t%s,%s\t.\tPASS\t.\tGT\t%s\n" % (int(cs.pos[i]) + 1, cs.ref[i].decode(), cs.alt[i].decode(), cs.alt[i + 1].decode(), gt))
+                i += 2
+                merged += 1
+                continue
             f.write("chr20\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (int(cs.pos[i]) + 1, cs.ref[i].decode(), cs.alt[i].decode(), GT[int(cs.zyg[i])]))
+            i += 1
+        print("%s: %d records, %d of them multi-allelic" % (name, len(cs) - merged, merged))
 print("fixtures written to %s in %.1f s (%d regions expected)" % (d, time.time() - t0, batch.n_regions), flush=True)
 cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", os.path.join(d, "chr20.fa.gz"), "-t", os.path.join(d, "truth.vcf.gz"),
        "-q", os.path.join(d, "query.vcf.gz"), "-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "out")]
