@@ -187,7 +187,7 @@ struct avk_ctx {
     int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
     int64_t ws_bytes_per_wave = 1 << 20;
     int64_t big_ws_bytes = 256ll << 20;
-    int64_t big_waves = 32;
+    int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
     int n_cus = 0;
     /* workspaces (grown on demand) */
@@ -639,7 +639,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (want_waves > n) want_waves = n;
     uint32_t blocks = (uint32_t)((want_waves + waves_per_block - 1) / waves_per_block);
     if (blocks == 0) blocks = 1;
-    const uint32_t n_waves = blocks * waves_per_block;
+    /* the HBM launches: no more workgroups than can be resident (three per CU at the kernel's register count) — later ones would find
+     * the work list empty anyway, and every wave of the grid needs a slice of HBM (fresh device memory is scrubbed when it is handed
+     * out: 13 GB of workspaces cost 0.25 s at the first call of a process, 4 GB a third of that) */
+    uint32_t hbm_blocks = (uint32_t)ctx->n_cus * 3u;
+    if (hbm_blocks > blocks) hbm_blocks = blocks;
+    const uint32_t n_waves = hbm_blocks * waves_per_block;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
     const uint32_t hbm_solo_max = 64;
     const size_t ws_need = (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
@@ -875,13 +880,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.big_ws = ctx->d_big;
             a.big_busy = db->d_counters + 1088;
             a.big_slots = big_slots;
-            a.n_waves = blocks * waves_per_block;
+            a.n_waves = hbm_blocks * waves_per_block;
             if (hbm_solo_pending) { /* class C records the solo launch has not started yet: every wave of this launch helps (same ticket counter) */
                 a.extra_counter = db->d_counters + 1076;
                 a.extra_base = 0;
                 a.extra_n = db->plan.n_hbm;
             }
-            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(blocks), dim3(256), 0, ctx->stream, a);
+            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_blocks), dim3(256), 0, ctx->stream, a);
         } else {
             a.hbm_ws = ctx->d_big;
             a.big_slots = 0;
