@@ -195,6 +195,29 @@ struct Call {
     uint32_t alt_index;
 };
 
+/* the calls of one chromosome in file order, as the chunks the reader's threads produced them (no copy into one list);
+ * base[k] is added to Call::record of the calls of chunk k */
+struct CallList {
+    std::vector<std::vector<Call>> chunks;
+    std::vector<uint64_t> base;
+    bool open = false; /* the last chunk takes single calls */
+    void push(Call &&c) {
+        if (!open) {
+            chunks.emplace_back();
+            base.push_back(0);
+            open = true;
+        }
+        chunks.back().push_back(std::move(c));
+    }
+    void add_chunk(std::vector<Call> &&calls, uint64_t record_base) {
+        if (calls.empty()) return;
+        chunks.push_back(std::move(calls));
+        base.push_back(record_base);
+        open = false;
+    }
+};
+typedef std::unordered_map<std::string, CallList> CallMap;
+
 struct Interval1 { /* noodles Interval: 1-based, inclusive */
     uint64_t start, end;
 };
@@ -395,7 +418,7 @@ template <class Emit> int vcf_parse_record(const char *path, std::string_view li
 }
 
 /* the whole file line by line on the calling thread: the reference behaviour, and the source of every error message */
-int load_vcf_sequential(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls) {
+int load_vcf_sequential(const char *path, const char *sample, bool enable_trimming, CallMap &calls) {
     LineReader in(path);
     if (!in.ok()) return fail(AVK_E_ARG, "Error while opening %s", path);
     std::string line;
@@ -414,7 +437,7 @@ int load_vcf_sequential(const char *path, const char *sample, bool enable_trimmi
             continue;
         }
         if (!have_header) return fail(AVK_E_ARG, "%s: data line before the #CHROM header", path);
-        const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, record++, w, [&](const std::string &chrom, Call &&c) { calls[chrom].push_back(std::move(c)); });
+        const int rc = vcf_parse_record(path, line, sample_col, enable_trimming, record++, w, [&](const std::string &chrom, Call &&c) { calls[chrom].push(std::move(c)); });
         if (rc) return rc;
     }
     if (in.failed()) return fail(AVK_E_ARG, "read error in %s", path);
@@ -426,7 +449,7 @@ int load_vcf_sequential(const char *path, const char *sample, bool enable_trimmi
  * members, so GROUPS of blocks are inflated AND parsed by the worker threads.  A group's text starts and ends in the middle of a line:
  * the workers parse the whole lines inside, the fragments at both ends are put together afterwards (one line per group boundary).
  * Returns 1 when the file is not BGZF or anything is irregular — the caller then reads it the ordinary way. */
-int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls, size_t n_workers) {
+int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, CallMap &calls, size_t n_workers) {
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return 1;
     struct stat st;
@@ -613,13 +636,6 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, st
     }
     if (irregular.load()) return 1;
     const auto t_parsed = std::chrono::steady_clock::now();
-    /* every chromosome's list gets its final size at once */
-    {
-        std::unordered_map<std::string, size_t> total;
-        for (const GroupOut &o : outs)
-            for (size_t q = 0; q < o.chroms.size(); ++q) total[o.chroms[q]] += o.lists[q].size();
-        for (const auto &kv : total) calls[kv.first].reserve(kv.second + n_groups + 1);
-    }
     /* in file order: the line put together at a group's front, then the group's own lines; record indices become file-wide */
     uint64_t base = 0;
     bool data_seen = false;
@@ -638,10 +654,8 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, st
         const int rc = vcf_parse_record(path, text, sample_col, enable_trimming, base, w, [&](const std::string &chrom, Call &&c) { emit_into(joint, last, chrom, std::move(c)); });
         base += 1;
         if (rc) return 1;
-        for (size_t q = 0; q < joint.chroms.size(); ++q) {
-            std::vector<Call> &dst = calls[joint.chroms[q]];
-            for (Call &c : joint.lists[q]) dst.push_back(std::move(c));
-        }
+        for (size_t q = 0; q < joint.chroms.size(); ++q)
+            for (Call &c : joint.lists[q]) calls[joint.chroms[q]].push(std::move(c));
         joint.chroms.clear();
         joint.lists.clear();
         return 0;
@@ -660,13 +674,7 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, st
             return 1;
         }
         data_seen = data_seen || o.has_data;
-        for (size_t q = 0; q < o.chroms.size(); ++q) {
-            std::vector<Call> &dst = calls[o.chroms[q]];
-            for (Call &c : o.lists[q]) {
-                c.record += base;
-                dst.push_back(std::move(c));
-            }
-        }
+        for (size_t q = 0; q < o.chroms.size(); ++q) calls[o.chroms[q]].add_chunk(std::move(o.lists[q]), base); /* the list is handed over as it is */
         base += o.n_records;
         GroupOut().chroms.swap(o.chroms);
         std::vector<std::vector<Call>>().swap(o.lists);
@@ -685,7 +693,7 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, st
 /* The file is decompressed on the calling thread and cut into blocks of whole lines; worker threads parse the blocks, and the calls
  * are put together in file order.  Anything irregular (an error, a #CHROM line after the first data line) is left to the sequential
  * reader above, which then reports it the usual way. */
-int load_vcf(const char *path, const char *sample, bool enable_trimming, std::unordered_map<std::string, std::vector<Call>> &calls) {
+int load_vcf(const char *path, const char *sample, bool enable_trimming, CallMap &calls) {
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t n_workers = std::min<size_t>(hw > 1 ? hw - 1 : 0, 8);
     if (n_workers < 2 || getenv("AVF_SEQUENTIAL_VCF")) return load_vcf_sequential(path, sample, enable_trimming, calls);
@@ -846,13 +854,7 @@ int load_vcf(const char *path, const char *sample, bool enable_trimming, std::un
     /* in file order: block after block; record indices become file-wide */
     uint64_t base = 0;
     for (std::unique_ptr<BlockOut> &o : outs) {
-        for (size_t q = 0; q < o->chroms.size(); ++q) {
-            std::vector<Call> &dst = calls[o->chroms[q]];
-            for (Call &c : o->lists[q]) {
-                c.record += base;
-                dst.push_back(std::move(c));
-            }
-        }
+        for (size_t q = 0; q < o->chroms.size(); ++q) calls[o->chroms[q]].add_chunk(std::move(o->lists[q]), base);
         base += o->n_records;
         o.reset();
     }
@@ -1104,7 +1106,6 @@ void avf_genome_free(avf_genome *g) { delete g; }
 
 /* RegionIterator::next (region_generation.rs:281-478) over k inputs; input i's variants of region m end up at
  * [in_off[m*k + i], +in_cnt[m*k + i]).  Both the compare and the merge iterator are this loop. */
-typedef std::unordered_map<std::string, std::vector<Call>> CallMap;
 struct avf_calls {
     CallMap by_chrom;
 };
@@ -1148,6 +1149,7 @@ static int build_regions(uint32_t k, const CallMap *const *calls, const char *re
     struct Joint {
         uint32_t input;
         const Call *c;
+        uint64_t record; /* index of the call's line among the data lines of its file */
     };
     const size_t n_chroms = bed.chroms.size();
     std::vector<uint32_t> contig_of(n_chroms);
@@ -1168,18 +1170,19 @@ static int build_regions(uint32_t k, const CallMap *const *calls, const char *re
         /* the span the reference queries through tabix: first interval's start to the LAST interval's end (:289-296) */
         const uint64_t zb_start = intervals.front().start - 1, zb_end = intervals.back().end;
         std::vector<Joint> joint;
-        std::vector<std::vector<const Call *>> vars(k);
+        std::vector<std::vector<Joint>> vars(k);
         for (uint32_t input = 0; input < k; ++input) {
             const auto it = calls[input]->find(chrom);
             if (it == calls[input]->end()) continue;
-            for (const Call &c : it->second) {
-                /* is_variant_contained (:764-778): first and last reference base inside the span */
-                const uint64_t last = c.pos + c.a0.size() - 1;
-                if (c.pos >= zb_start && c.pos < zb_end && last >= zb_start && last < zb_end) {
-                    joint.push_back(Joint{input, &c});
-                    part->loaded[input] += 1;
+            for (size_t ch = 0; ch < it->second.chunks.size(); ++ch)
+                for (const Call &c : it->second.chunks[ch]) {
+                    /* is_variant_contained (:764-778): first and last reference base inside the span */
+                    const uint64_t last = c.pos + c.a0.size() - 1;
+                    if (c.pos >= zb_start && c.pos < zb_end && last >= zb_start && last < zb_end) {
+                        joint.push_back(Joint{input, &c, c.record + it->second.base[ch]});
+                        part->loaded[input] += 1;
+                    }
                 }
-            }
         }
         std::stable_sort(joint.begin(), joint.end(), [](const Joint &a, const Joint &b) { return a.c->pos < b.c->pos; }); /* sort_by_key(position) */
         size_t head = 0; /* the deque's front */
@@ -1190,7 +1193,8 @@ static int build_regions(uint32_t k, const CallMap *const *calls, const char *re
             for (uint32_t input = 0; input < k; ++input) {
                 part->in_off.push_back(part->var_pos.size());
                 part->in_cnt.push_back((uint32_t)vars[input].size());
-                for (const Call *c : vars[input]) {
+                for (const Joint &jv : vars[input]) {
+                    const Call *c = jv.c;
                     part->var_pos.push_back(c->pos);
                     part->var_type.push_back(c->type);
                     part->var_zyg.push_back(c->zyg);
@@ -1201,7 +1205,7 @@ static int build_regions(uint32_t k, const CallMap *const *calls, const char *re
                     part->a1_off.push_back(part->alleles.size());
                     part->a1_len.push_back((uint32_t)c->a1.size());
                     part->alleles.insert(part->alleles.end(), c->a1.begin(), c->a1.end());
-                    part->var_record.push_back(c->record);
+                    part->var_record.push_back(jv.record);
                     part->var_alt.push_back(c->alt_index);
                 }
                 vars[input].clear();
@@ -1234,7 +1238,7 @@ static int build_regions(uint32_t k, const CallMap *const *calls, const char *re
                 const uint64_t var_flank_end = std::min(vs + j.c->a0.size() + min_variant_gap, chrom_length);
                 window_end = have_end ? std::max(window_end, var_flank_end) : var_flank_end;
                 have_end = true;
-                vars[j.input].push_back(j.c);
+                vars[j.input].push_back(j);
             }
             if (have_window && have_end) flush(window_start, window_end);
         }
