@@ -106,6 +106,18 @@ summary_text = open(os.path.join(d, "out", "summary.tsv")).read()
 print("\n".join(l for l in summary_text.splitlines() if "\tALL\tALL\tALL\t" in l or l.startswith("compare_label")))
 if os.environ.get("KEEP_SUMMARY"):
     open(os.environ["KEEP_SUMMARY"], "w").write(summary_text)
+if os.environ.get("VERIFY", "0") == "1":  # the whole run again on the CPU: feeder -> oracle (all host threads) -> restated summary writer
+    sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import feeder_oracle as fo
+    import oracle_lib
+    from aardvark_amd import feeder
+    t0 = time.time()
+    genome = feeder.Genome(os.path.join(d, "genome.fa"))
+    feed = feeder.feed_compare(os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz"), os.path.join(d, "hc.bed"), genome, enable_trimming=False)
+    res = oracle_lib.compare_batch(oracle_lib.load(), feed.batch, genome.contigs(), threads=os.cpu_count())
+    want = fo.summary_text(res.tally, "compare", ("GT", "BASEPAIR"))
+    print("oracle on %d regions in %.1f s (feeder + %d threads); summary.tsv identical to oracle + restated writer: %s; error regions %d" % (
+        feed.batch.n_regions, time.time() - t0, os.cpu_count(), summary_text == want if not n_strat else "n/a (stratified)", int((res.status != 0).sum())))
 if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote over the callers
     vcfs = [os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz")] + [os.path.join(d, "caller%d.vcf.gz" % i) for i in range(2, n_merge)]
     cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, "genome.fa")] + [x for v in vcfs for x in ("-i", v)] + \
