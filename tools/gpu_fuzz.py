@@ -11,6 +11,7 @@ import oracle_lib
 import scenarios
 
 budget = float(os.environ.get("BUDGET_S", "600"))
+seed_base = int(os.environ.get("SEED_BASE", "0"))  # other seeds than the committed reports used
 lib = oracle_lib.load()
 ctx = aardvark_amd.Context(0)
 for kv in os.environ.get("AVK_OPTS", "").split(","):
@@ -52,14 +53,14 @@ while time.time() - t_start < budget:
     for i, kw in enumerate(FUZZ):
         if time.time() - t_start > budget:
             break
-        seed = 1000 + 100 * rnd + i
+        seed = seed_base + 1000 + 100 * rnd + i
         contigs, batch = scenarios.fuzz_regions(seed, int(os.environ.get("FUZZ_N", "20000")), **kw)
         check("fuzz seed %d %s" % (seed, kw), contigs, batch, mbf=(50, 50, 7, 2)[rnd % 4])
     # call-set shaped cases: SNV + indel truth, queries perturbed at several error levels
     for j, (drop, flip, change, extra) in enumerate(((0.01, 0.005, 0.005, 2000), (0.1, 0.05, 0.05, 20000), (0.3, 0.2, 0.2, 60000))):
         if time.time() - t_start > budget:
             break
-        seed = 5000 + 10 * rnd + j
+        seed = seed_base + 5000 + 10 * rnd + j
         length = 20_000_000
         contig = synth.make_contig(length, seed)
         rng = np.random.default_rng(seed + 1)
