@@ -119,13 +119,14 @@ extern "C" int avf_write_merge_outputs(const char *out_folder, const char *prima
     const std::string sample = sample_name && *sample_name ? sample_name : first_sample;
 
     avf_tbx::IndexedText vcf, passing_bed, failed_bed;
-    for (const std::string &m : meta) vcf.header(m + "\n");
-    /* what the reference adds (variant_merger.rs:85-121) */
-    vcf.header(std::string("##aardvark_version=\"") + (version ? version : "") + "\"\n");
-    vcf.header(std::string("##aardvark_command=\"") + (command_line ? command_line : "") + "\"\n");
-    vcf.header("##INFO=<ID=SOURCES,Number=.,Type=String,Description=\"List of tools or technologies that called the same record\">\n");
-    vcf.header("##INFO=<ID=MR,Number=1,Type=String,Description=\"The reason this record was allowed in the merge\">\n");
-    vcf.header("##FORMAT=<ID=RI,Number=1,Type=Integer,Description=\"Region ID for the comparison\">\n");
+    /* what the reference adds (variant_merger.rs:85-121), in the layout its VCF library writes a header in */
+    const std::vector<avf_tbx::HeaderDef> defs = {
+        {"INFO", "SOURCES", "##INFO=<ID=SOURCES,Number=.,Type=String,Description=\"List of tools or technologies that called the same record\">"},
+        {"INFO", "MR", "##INFO=<ID=MR,Number=1,Type=String,Description=\"The reason this record was allowed in the merge\">"},
+        {"FORMAT", "RI", "##FORMAT=<ID=RI,Number=1,Type=Integer,Description=\"Region ID for the comparison\">"}};
+    const std::vector<std::pair<std::string, std::string>> others = {{"aardvark_version", std::string("\"") + (version ? version : "") + "\""},
+                                                                      {"aardvark_command", std::string("\"") + (command_line ? command_line : "") + "\""}};
+    for (const std::string &m : avf_tbx::vcf_header_lines(meta, defs, others)) vcf.header(m + "\n");
     vcf.header("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n");
 
     static const char *const gts[6] = {".", "0/0", "0/1", "0|1", "1|0", "1/1"};

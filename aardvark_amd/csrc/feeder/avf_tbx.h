@@ -8,6 +8,7 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <string>
 #include <thread>
@@ -220,6 +221,72 @@ class IndexedText {
     uint32_t last_bin_ = 0;
     std::vector<std::pair<uint64_t, uint64_t>> *last_chunks_ = nullptr; /* std::map nodes do not move */
 };
+
+/* The header of an output VCF the way the reference's VCF library serialises a header it has parsed and extended (noodles: the
+ * file format line, then the INFO, FILTER, FORMAT, ALT and contig definitions as groups, then every other line grouped by its key in
+ * order of first appearance): the input's meta lines regrouped — their text is kept as it is —, `defs` added to (or replacing the
+ * same ID in) the INFO / FORMAT groups, `others` (key, value) appended under their keys. */
+struct HeaderDef {
+    const char *group; /* "INFO" or "FORMAT" */
+    const char *id;
+    const char *line;  /* the whole meta line */
+};
+inline std::vector<std::string> vcf_header_lines(const std::vector<std::string> &meta, const std::vector<HeaderDef> &defs,
+                                                 const std::vector<std::pair<std::string, std::string>> &others) {
+    static const char *const kGroups[5] = {"INFO", "FILTER", "FORMAT", "ALT", "contig"};
+    std::string fileformat;
+    std::vector<std::pair<std::string, std::string>> grouped[5]; /* (ID, line) */
+    std::vector<std::pair<std::string, std::vector<std::string>>> rest; /* key -> lines */
+    auto id_of = [](const std::string &line) {
+        const size_t lt = line.find('<');
+        size_t at = lt == std::string::npos ? std::string::npos : line.find("ID=", lt);
+        if (at == std::string::npos) return std::string();
+        at += 3;
+        size_t e = at;
+        while (e < line.size() && line[e] != ',' && line[e] != '>') ++e;
+        return line.substr(at, e - at);
+    };
+    auto add_other = [&](const std::string &key, const std::string &line) {
+        for (auto &kv : rest)
+            if (kv.first == key) {
+                kv.second.push_back(line);
+                return;
+            }
+        rest.emplace_back(key, std::vector<std::string>(1, line));
+    };
+    for (const std::string &m : meta) {
+        if (m.compare(0, 2, "##") != 0) continue;
+        const size_t eq = m.find('=');
+        const std::string key = m.substr(2, eq == std::string::npos ? std::string::npos : eq - 2);
+        if (key == "fileformat") {
+            if (fileformat.empty()) fileformat = m;
+            continue;
+        }
+        int g = -1;
+        for (int k = 0; k < 5; ++k)
+            if (key == kGroups[k] && eq != std::string::npos && eq + 1 < m.size() && m[eq + 1] == '<') g = k;
+        if (g >= 0) grouped[g].emplace_back(id_of(m), m);
+        else add_other(key, m);
+    }
+    for (const HeaderDef &d : defs) {
+        const int g = strcmp(d.group, "INFO") == 0 ? 0 : 2;
+        bool replaced = false;
+        for (auto &kv : grouped[g])
+            if (kv.first == d.id) {
+                kv.second = d.line;
+                replaced = true;
+            }
+        if (!replaced) grouped[g].emplace_back(d.id, d.line);
+    }
+    for (const auto &kv : others) add_other(kv.first, "##" + kv.first + "=" + kv.second);
+    std::vector<std::string> out;
+    if (!fileformat.empty()) out.push_back(fileformat);
+    for (int k = 0; k < 5; ++k)
+        for (const auto &kv : grouped[k]) out.push_back(kv.second);
+    for (const auto &kv : rest)
+        for (const std::string &l : kv.second) out.push_back(l);
+    return out;
+}
 
 /* Record lines formatted by several threads: fn(first, last, text, lines) appends the lines of items [first, last) to `text` and one
  * LineMeta per line to `lines` (false = error); the pieces are then appended to `out` and indexed in item order.

@@ -54,14 +54,15 @@ extern "C" int avf_write_annotated_vcf(const char *out_path, const char *input_v
     }
     const std::string sample = sample_name && *sample_name ? sample_name : first_sample;
     avf_tbx::IndexedText out;
-    for (const std::string &m : meta) out.header(m + "\n");
-    /* what the reference adds (variant_categorizer.rs:41-87) */
-    out.header(std::string("##aardvark_version=\"") + (version ? version : "") + "\"\n");
-    out.header(std::string("##aardvark_command=\"") + (command_line ? command_line : "") + "\"\n");
-    out.header("##FORMAT=<ID=BD,Number=1,Type=String,Description=\"Benchmark Decision for call (TP/FP/FN)\">\n");
-    out.header("##FORMAT=<ID=EA,Number=1,Type=Integer,Description=\"Expected Allele count for this genotype\">\n");
-    out.header("##FORMAT=<ID=OA,Number=1,Type=Integer,Description=\"Observed Allele count for this genotype\">\n");
-    out.header("##FORMAT=<ID=RI,Number=1,Type=Integer,Description=\"Region ID for the comparison\">\n");
+    /* what the reference adds (variant_categorizer.rs:41-87), in the layout its VCF library writes a header in */
+    const std::vector<avf_tbx::HeaderDef> defs = {
+        {"FORMAT", "BD", "##FORMAT=<ID=BD,Number=1,Type=String,Description=\"Benchmark Decision for call (TP/FP/FN)\">"},
+        {"FORMAT", "EA", "##FORMAT=<ID=EA,Number=1,Type=Integer,Description=\"Expected Allele count for this genotype\">"},
+        {"FORMAT", "OA", "##FORMAT=<ID=OA,Number=1,Type=Integer,Description=\"Observed Allele count for this genotype\">"},
+        {"FORMAT", "RI", "##FORMAT=<ID=RI,Number=1,Type=Integer,Description=\"Region ID for the comparison\">"}};
+    const std::vector<std::pair<std::string, std::string>> others = {{"aardvark_version", std::string("\"") + (version ? version : "") + "\""},
+                                                                      {"aardvark_command", std::string("\"") + (command_line ? command_line : "") + "\""}};
+    for (const std::string &m : avf_tbx::vcf_header_lines(meta, defs, others)) out.header(m + "\n");
     out.header("#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample + "\n");
 
     static const char *const gts[6] = {".", "0/0", "0/1", "0|1", "1|0", "1/1"};

@@ -474,12 +474,16 @@ def test_annotated_vcfs_bgzf_and_tabix(tmp_path, oracle):
         lines = text.splitlines()
         meta = [l for l in lines if l.startswith("##")]
         src_meta = [l for l in open(paths[inp]).read().splitlines() if l.startswith("##")]
-        assert meta[:len(src_meta)] == src_meta
-        assert meta[len(src_meta):] == ['##aardvark_version="v-test"', '##aardvark_command="cmd --x 1"',
-                                        '##FORMAT=<ID=BD,Number=1,Type=String,Description="Benchmark Decision for call (TP/FP/FN)">',
-                                        '##FORMAT=<ID=EA,Number=1,Type=Integer,Description="Expected Allele count for this genotype">',
-                                        '##FORMAT=<ID=OA,Number=1,Type=Integer,Description="Observed Allele count for this genotype">',
-                                        '##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">']
+        # the layout the reference's VCF library gives a header: file format, INFO, FILTER, FORMAT, ALT, contig groups, then the other
+        # lines grouped by key; the input's lines keep their text, the additions join their groups
+        added = ['##FORMAT=<ID=BD,Number=1,Type=String,Description="Benchmark Decision for call (TP/FP/FN)">',
+                 '##FORMAT=<ID=EA,Number=1,Type=Integer,Description="Expected Allele count for this genotype">',
+                 '##FORMAT=<ID=OA,Number=1,Type=Integer,Description="Observed Allele count for this genotype">',
+                 '##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">']
+        group = lambda key: [l for l in src_meta if l.startswith("##%s=<" % key)]
+        other = [l for l in src_meta if not l.startswith("##fileformat=") and not any(l.startswith("##%s=<" % k) for k in ("INFO", "FILTER", "FORMAT", "ALT", "contig"))]
+        assert meta == [l for l in src_meta if l.startswith("##fileformat=")] + group("INFO") + group("FILTER") + group("FORMAT") + added + group("ALT") + \
+            group("contig") + other + ['##aardvark_version="v-test"', '##aardvark_command="cmd --x 1"']
         assert lines[len(meta)] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + ("S1" if source == 0 else "Q")
         records = lines[len(meta) + 1:]
         want = fo.annotated_vcf_records(regions, source, res.status, res.var_expected, res.var_observed, res.var_class)
@@ -492,6 +496,35 @@ def test_annotated_vcfs_bgzf_and_tabix(tmp_path, oracle):
             for beg, end in ((0, 20), (11, 12), (60, 160), (140, 141), (299, 300), (300, 400)):
                 hit = [r for r in mine if int(r.split("\t")[1]) - 1 < end and int(r.split("\t")[1]) - 1 + len(r.split("\t")[3]) > beg]
                 assert tabix_fetch(out, chrom, beg, end) == sorted(set(hit), key=lambda l: (int(l.split("\t")[1]), l))
+
+
+def test_output_header_is_regrouped_like_the_reference_library_writes_it(tmp_path, oracle):
+    """a header in an arbitrary order comes out as: file format, INFO, FILTER, FORMAT, ALT, contig definitions, then the other lines
+    grouped by key in order of first appearance; a FORMAT definition with the ID of an added one is replaced in place"""
+    paths = {}
+    for name, text in (("ref.fa", EDGE_FASTA), ("hc.bed", EDGE_BED), ("truth.vcf", EDGE_VCF_T), ("query.vcf", EDGE_VCF_Q)):
+        paths[name] = str(tmp_path / name)
+        write_text(paths[name], text)
+    body = [l for l in EDGE_VCF_T.splitlines() if not l.startswith("##")]
+    messy = ['##source=callerA', '##contig=<ID=chrA,length=300>', '##FORMAT=<ID=RI,Number=1,Type=String,Description="an older definition">',
+             '##fileformat=VCFv4.2', '##FILTER=<ID=LowQual,Description="low">', '##cmdline=first', '##INFO=<ID=DP,Number=1,Type=Integer,Description="depth">',
+             '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">', '##source=callerB', '##ALT=<ID=DEL,Description="deletion">',
+             '##contig=<ID=chrB,length=300>', '##cmdline=second']
+    src = str(tmp_path / "messy.vcf")
+    write_text(src, "\n".join(messy + body) + "\n")
+    genome = feeder.Genome(paths["ref.fa"])
+    feed = feeder.feed_compare(src, paths["query.vcf"], paths["hc.bed"], genome, truth_sample="S1")
+    res = oracle_lib.compare_batch(oracle, feed.batch, genome.contigs())
+    out = str(tmp_path / "truth.vcf.gz")
+    feeder.write_annotated_vcf(out, src, genome, feed.batch, res, 0, sample_name="S1", version="v", command_line="c")
+    meta = [l for l in gzip.open(out, "rt").read().splitlines() if l.startswith("##")]
+    assert meta == ['##fileformat=VCFv4.2', '##INFO=<ID=DP,Number=1,Type=Integer,Description="depth">', '##FILTER=<ID=LowQual,Description="low">',
+                    '##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">', '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+                    '##FORMAT=<ID=BD,Number=1,Type=String,Description="Benchmark Decision for call (TP/FP/FN)">',
+                    '##FORMAT=<ID=EA,Number=1,Type=Integer,Description="Expected Allele count for this genotype">',
+                    '##FORMAT=<ID=OA,Number=1,Type=Integer,Description="Observed Allele count for this genotype">',
+                    '##ALT=<ID=DEL,Description="deletion">', '##contig=<ID=chrA,length=300>', '##contig=<ID=chrB,length=300>',
+                    '##source=callerA', '##source=callerB', '##cmdline=first', '##cmdline=second', '##aardvark_version="v"', '##aardvark_command="c"']
 
 
 def test_bgzf_writer_splits_large_outputs(tmp_path, oracle):

@@ -158,14 +158,18 @@ def check_outputs(out_dir, primary_vcf, regions, results, tags, sample, version=
     lines = text.splitlines()
     meta = [l for l in lines if l.startswith("##")]
     src_meta = [l for l in gzip.open(primary_vcf, "rt").read().splitlines() if l.startswith("##")]
-    assert meta[:len(src_meta)] == src_meta
-    extra = meta[len(src_meta):]
+    # header layout of the reference's VCF library: file format, INFO, FILTER, FORMAT, ALT, contig groups, then the other lines
+    group = lambda key: [l for l in src_meta if l.startswith("##%s=<" % key)]
+    other = [l for l in src_meta if not l.startswith("##fileformat=") and not any(l.startswith("##%s=<" % k) for k in ("INFO", "FILTER", "FORMAT", "ALT", "contig"))]
+    want = [l for l in src_meta if l.startswith("##fileformat=")] + group("INFO") + \
+        ['##INFO=<ID=SOURCES,Number=.,Type=String,Description="List of tools or technologies that called the same record">',
+         '##INFO=<ID=MR,Number=1,Type=String,Description="The reason this record was allowed in the merge">'] + group("FILTER") + group("FORMAT") + \
+        ['##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">'] + group("ALT") + group("contig") + other
+    assert meta[:len(want)] == want and len(meta) == len(want) + 2
+    extra = meta[len(want):]
     assert extra[0].startswith('##aardvark_version="') and extra[1].startswith('##aardvark_command="')
     if version is not None:
         assert extra[0] == '##aardvark_version="%s"' % version and extra[1] == '##aardvark_command="%s"' % command
-    assert extra[2:] == ['##INFO=<ID=SOURCES,Number=.,Type=String,Description="List of tools or technologies that called the same record">',
-                         '##INFO=<ID=MR,Number=1,Type=String,Description="The reason this record was allowed in the merge">',
-                         '##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">']
     assert lines[len(meta)] == "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\t" + sample
     records = lines[len(meta) + 1:]
     assert records == mo.passing_vcf_records(regions, results, tags)
