@@ -445,6 +445,37 @@ int load_vcf_sequential(const char *path, const char *sample, bool enable_trimmi
     return 0;
 }
 
+/* the block table of a BGZF file (gzip members with the BC extra subfield): offset of the deflate payload, its length, the
+ * uncompressed size and checksum; false when the file is anything else */
+struct BgzfBlk {
+    size_t data, len;
+    uint32_t isize, crc;
+};
+bool scan_bgzf_blocks(const uint8_t *d, size_t n, std::vector<BgzfBlk> &blks) {
+    for (size_t at = 0; at < n;) {
+        if (n - at < 18 || d[at] != 0x1f || d[at + 1] != 0x8b || d[at + 2] != 8 || !(d[at + 3] & 4)) return false;
+        const size_t xlen = d[at + 10] | ((size_t)d[at + 11] << 8);
+        if (n - at < 12 + xlen + 8) return false;
+        size_t bsize = 0;
+        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) { /* extra subfields: SI1 SI2 SLEN data */
+            const size_t slen = d[x + 2] | ((size_t)d[x + 3] << 8);
+            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= at + 12 + xlen) bsize = (d[x + 4] | ((size_t)d[x + 5] << 8)) + 1;
+            x += 4 + slen;
+        }
+        if (bsize < 12 + xlen + 8 || bsize > n - at) return false;
+        if (d[at + 3] & ~4) return false; /* name / comment / header crc fields: not what bgzip writes */
+        BgzfBlk b;
+        b.data = at + 12 + xlen;
+        b.len = bsize - (12 + xlen) - 8;
+        b.crc = d[at + bsize - 8] | ((uint32_t)d[at + bsize - 7] << 8) | ((uint32_t)d[at + bsize - 6] << 16) | ((uint32_t)d[at + bsize - 5] << 24);
+        b.isize = d[at + bsize - 4] | ((uint32_t)d[at + bsize - 3] << 8) | ((uint32_t)d[at + bsize - 2] << 16) | ((uint32_t)d[at + bsize - 1] << 24);
+        if (b.isize > 65536) return false;
+        if (b.isize) blks.push_back(b); /* empty blocks (the end-of-file marker) carry nothing */
+        at += bsize;
+    }
+    return true;
+}
+
 /* BGZF files (what bgzip / htslib write, and what the reference requires for its tabix queries): the blocks are independent gzip
  * members, so GROUPS of blocks are inflated AND parsed by the worker threads.  A group's text starts and ends in the middle of a line:
  * the workers parse the whole lines inside, the fragments at both ends are put together afterwards (one line per group boundary).
@@ -466,33 +497,9 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, Ca
         size_t n;
         ~Unmap() { munmap((void *)p, n); }
     } unmap{d, n};
-    /* the block table: offset of the deflate payload, its length, the uncompressed size */
-    struct Blk {
-        size_t data, len;
-        uint32_t isize, crc;
-    };
-    std::vector<Blk> blks;
-    for (size_t at = 0; at < n;) {
-        if (n - at < 18 || d[at] != 0x1f || d[at + 1] != 0x8b || d[at + 2] != 8 || !(d[at + 3] & 4)) return 1;
-        const size_t xlen = d[at + 10] | ((size_t)d[at + 11] << 8);
-        if (n - at < 12 + xlen + 8) return 1;
-        size_t bsize = 0;
-        for (size_t x = at + 12; x + 4 <= at + 12 + xlen;) { /* extra subfields: SI1 SI2 SLEN data */
-            const size_t slen = d[x + 2] | ((size_t)d[x + 3] << 8);
-            if (d[x] == 'B' && d[x + 1] == 'C' && slen == 2 && x + 6 <= at + 12 + xlen) bsize = (d[x + 4] | ((size_t)d[x + 5] << 8)) + 1;
-            x += 4 + slen;
-        }
-        if (bsize < 12 + xlen + 8 || bsize > n - at) return 1;
-        if (d[at + 3] & ~4) return 1; /* name / comment / header crc fields: not what bgzip writes */
-        Blk b;
-        b.data = at + 12 + xlen;
-        b.len = bsize - (12 + xlen) - 8;
-        b.crc = d[at + bsize - 8] | ((uint32_t)d[at + bsize - 7] << 8) | ((uint32_t)d[at + bsize - 6] << 16) | ((uint32_t)d[at + bsize - 5] << 24);
-        b.isize = d[at + bsize - 4] | ((uint32_t)d[at + bsize - 3] << 8) | ((uint32_t)d[at + bsize - 2] << 16) | ((uint32_t)d[at + bsize - 1] << 24);
-        if (b.isize > 65536) return 1;
-        if (b.isize) blks.push_back(b); /* empty blocks (the end-of-file marker) carry nothing */
-        at += bsize;
-    }
+    std::vector<BgzfBlk> blks;
+    if (!scan_bgzf_blocks(d, n, blks)) return 1;
+    typedef BgzfBlk Blk;
     auto inflate_block = [&](const Blk &b, z_stream &zs, std::string &out) -> bool {
         const size_t at = out.size();
         out.resize(at + b.isize);
@@ -1052,6 +1059,63 @@ int avf_genome_load(const char *fasta_path, avf_genome **out) {
         uint8_t magic[2] = {0, 0};
         const bool regular = fstat(fd, &st) == 0 && S_ISREG(st.st_mode) && st.st_size > 0;
         const bool gz = regular && pread(fd, magic, 2, 0) == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (regular && gz) { /* bgzip-compressed (what faidx wants): the blocks are inflated by several threads, then parsed like a plain file */
+            void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+            if (m != MAP_FAILED) {
+                const uint8_t *d = (const uint8_t *)m;
+                std::vector<BgzfBlk> blks;
+                SeqBytes raw;
+                bool ok = scan_bgzf_blocks(d, (size_t)st.st_size, blks) && !blks.empty();
+                if (ok) {
+                    std::vector<size_t> at(blks.size() + 1, 0);
+                    for (size_t k = 0; k < blks.size(); ++k) at[k + 1] = at[k] + blks[k].isize;
+                    raw.resize(at.back());
+                    const unsigned hw = std::thread::hardware_concurrency();
+                    const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, blks.size()}));
+                    std::atomic<size_t> next{0};
+                    std::atomic<bool> bad{false};
+                    auto work = [&] {
+                        z_stream zs;
+                        memset(&zs, 0, sizeof(zs));
+                        if (inflateInit2(&zs, -15) != Z_OK) {
+                            bad.store(true);
+                            return;
+                        }
+                        for (size_t k0 = next.fetch_add(64); k0 < blks.size() && !bad.load(std::memory_order_relaxed); k0 = next.fetch_add(64))
+                            for (size_t k = k0; k < std::min(blks.size(), k0 + 64); ++k) {
+                                const BgzfBlk &b = blks[k];
+                                if (inflateReset(&zs) != Z_OK) bad.store(true);
+                                zs.next_in = (Bytef *)(d + b.data);
+                                zs.avail_in = (uInt)b.len;
+                                zs.next_out = (Bytef *)(raw.data() + at[k]);
+                                zs.avail_out = b.isize;
+                                if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0 ||
+                                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(raw.data() + at[k]), b.isize) != b.crc)
+                                    bad.store(true);
+                            }
+                        inflateEnd(&zs);
+                    };
+                    std::vector<std::thread> pool;
+                    for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+                    work();
+                    for (std::thread &t : pool) t.join();
+                    ok = !bad.load();
+                }
+                munmap(m, (size_t)st.st_size);
+                if (ok) {
+                    close(fd);
+                    const int rc = genome_load_mapped(fasta_path, raw.data(), raw.size(), g);
+                    if (rc) {
+                        delete g;
+                        return rc;
+                    }
+                    for (uint32_t i = 0; i < g->names.size(); ++i) g->index.emplace(g->names[i], i);
+                    *out = g;
+                    return 0;
+                }
+                /* a plain gzip stream, or a damaged file: the line reader below reads it (and reports it) */
+            }
+        }
         if (regular && !gz) {
             void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) {

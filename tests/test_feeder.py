@@ -178,6 +178,19 @@ def test_mapped_fasta_loader_matches_the_line_reader(tmp_path, monkeypatch):
             assert got.names == want.names
             for a, b, name in zip(got.contigs(), want.contigs(), got.names):
                 assert bytes(a) == bytes(b) == ref[name].encode()
+        # bgzip-compressed FASTA: blocks inflated by several threads, then the same parser
+        for block in (50, 4096):
+            bg = str(tmp_path / ("f%d_%d.fa.bgz" % (ti, block)))
+            open(bg, "wb").write(bgzf_bytes(text.encode(), block))
+            monkeypatch.setenv("AVF_FASTA_PIECE", "33")
+            got = feeder.Genome(bg)
+            assert got.names == want.names and all(bytes(a) == bytes(b) for a, b in zip(got.contigs(), want.contigs()))
+    damaged = bytearray(bgzf_bytes(texts[2].encode(), 200))
+    damaged[len(damaged) // 2] ^= 0x11
+    dpath = str(tmp_path / "damaged.fa.gz")
+    open(dpath, "wb").write(bytes(damaged))
+    with pytest.raises(feeder.FeederError):
+        feeder.Genome(dpath)
     bad = str(tmp_path / "bad.fa")
     write_text(bad, "\nACGT\n>c\nAC\n")
     with pytest.raises(feeder.FeederError, match="sequence before the first header"):

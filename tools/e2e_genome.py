@@ -50,7 +50,25 @@ d = tempfile.mkdtemp(prefix="avk_genome_", dir=os.environ.get("TMPDIR", "/tmp"))
 t0 = time.time()
 hdr = "##fileformat=VCFv4.2\n" + "".join("##contig=<ID=%s>\n" % n for n in NAMES) + \
       "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tHG002\n"
-fa = open(os.path.join(d, "genome.fa"), "wb")
+FASTA_BGZF = os.environ.get("FASTA_BGZF", "0") == "1"  # the reference as bgzip writes it (genome.fa.gz) instead of plain text
+
+
+class BgzfBytes:
+    def __init__(self, path):
+        self.t = BgzfText(path)
+
+    def write(self, b):
+        self.t.buf += b
+        while len(self.t.buf) >= 0xff00:
+            self.t._block(bytes(self.t.buf[:0xff00]))
+            del self.t.buf[:0xff00]
+
+    def close(self):
+        self.t.close()
+
+
+FASTA_NAME = "genome.fa.gz" if FASTA_BGZF else "genome.fa"
+fa = BgzfBytes(os.path.join(d, FASTA_NAME)) if FASTA_BGZF else open(os.path.join(d, FASTA_NAME), "wb")
 bedf = open(os.path.join(d, "hc.bed"), "w")
 vt = open_vcf(os.path.join(d, "truth.vcf.gz"))
 vq = open_vcf(os.path.join(d, "query.vcf.gz"))
@@ -94,7 +112,7 @@ if n_strat:
                     for a, b in synth.make_bed(length, 200, (i + 1) / (n_strat + 1), rng):
                         bf.write("%s\t%d\t%d\n" % (name, a, b))
 print("fixtures: %d truth variants over %d contigs (scale %.2f) written to %s in %.0f s" % (n_truth, len(NAMES), scale, d, time.time() - t0), flush=True)
-cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", os.path.join(d, "genome.fa"), "-t", os.path.join(d, "truth.vcf.gz"),
+cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", os.path.join(d, FASTA_NAME), "-t", os.path.join(d, "truth.vcf.gz"),
        "-q", os.path.join(d, "query.vcf.gz"), "-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "out"), "--disable-variant-trimming"]
 if n_strat:
     cmd += ["-s", os.path.join(d, "strat.tsv")]
@@ -112,7 +130,7 @@ if os.environ.get("VERIFY", "0") == "1":  # the whole run again on the CPU: feed
     import oracle_lib
     from aardvark_amd import feeder
     t0 = time.time()
-    genome = feeder.Genome(os.path.join(d, "genome.fa"))
+    genome = feeder.Genome(os.path.join(d, FASTA_NAME))
     feed = feeder.feed_compare(os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz"), os.path.join(d, "hc.bed"), genome, enable_trimming=False)
     res = oracle_lib.compare_batch(oracle_lib.load(), feed.batch, genome.contigs(), threads=os.cpu_count())
     want = fo.summary_text(res.tally, "compare", ("GT", "BASEPAIR"))
@@ -120,7 +138,7 @@ if os.environ.get("VERIFY", "0") == "1":  # the whole run again on the CPU: feed
         feed.batch.n_regions, time.time() - t0, os.cpu_count(), summary_text == want if not n_strat else "n/a (stratified)", int((res.status != 0).sum())))
 if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote over the callers
     vcfs = [os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz")] + [os.path.join(d, "caller%d.vcf.gz" % i) for i in range(2, n_merge)]
-    cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, "genome.fa")] + [x for v in vcfs for x in ("-i", v)] + \
+    cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, FASTA_NAME)] + [x for v in vcfs for x in ("-i", v)] + \
           ["-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "merged"), "--output-summary", os.path.join(d, "merge_summary.tsv"), "--merge-strategy", "majority",
            "--disable-variant-trimming"]
     t0 = time.time()
