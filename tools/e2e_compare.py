@@ -23,9 +23,13 @@ if os.environ.get("MULTIALLELIC", "1") == "1":  # 2 % of the sites carry two ALT
 query = synth.perturb_query(contig, bed, truth, 20250102, 500)
 batch = synth.cluster_regions(synth.CHR20_LEN, bed, truth, query, 50)
 seq = contig.tobytes()
-with gzip.open(os.path.join(d, "chr20.fa.gz"), "wb", compresslevel=1) as f:
-    f.write(b">chr20\n")
-    f.write(b"\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + b"\n")
+fasta_text = b">chr20\n" + b"\n".join(seq[i:i + 60] for i in range(0, len(seq), 60)) + b"\n"
+if os.environ.get("PLAIN_GZIP", "0") == "1":  # one gzip stream: inflated by one thread
+    with gzip.open(os.path.join(d, "chr20.fa.gz"), "wb", compresslevel=1) as f:
+        f.write(fasta_text)
+else:  # as bgzip writes it (what samtools faidx wants): inflated block-parallel
+    from test_feeder import bgzf_bytes
+    open(os.path.join(d, "chr20.fa.gz"), "wb").write(bgzf_bytes(fasta_text, 0xff00, 1))
 open(os.path.join(d, "hc.bed"), "w").write("".join("chr20\t%d\t%d\n" % (a, b) for a, b in bed))
 hdr = "##fileformat=VCFv4.2\n##contig=<ID=chr20>\n##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tSAMPLE\n"
 for name, cs in (("truth.vcf.gz", truth), ("query.vcf.gz", query)):
