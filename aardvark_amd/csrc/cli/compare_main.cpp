@@ -5,6 +5,8 @@
  * (src/cli/compare.rs), --stratification included.  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).
  * --output-debug writes cli_settings.json, region_summary.tsv.gz and region_sequences.tsv.gz.
  */
+#include <atomic>
+#include <mutex>
 #include <cerrno>
 #include <chrono>
 #include <cstdio>
@@ -33,7 +35,7 @@ void usage() {
             "usage: aardvark_amd_compare -r REF.fa[.gz] -t TRUTH.vcf[.gz] -q QUERY.vcf[.gz] -b REGIONS.bed[.gz] -o OUT_DIR\n"
             "  [--truth-sample S] [--query-sample S] [--compare-label L] [--min-variant-gap 50] [--disable-variant-trimming]\n"
             "  [--max-branch-factor 50] [--enable-exact-shortcut] [--enable-haplotype-metrics] [--enable-weighted-haplotype-metrics]\n"
-            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0] [--batch-regions 4000000]\n");
+            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0 | --devices 0,1,..] [--batch-regions 4000000]\n");
 }
 
 std::string json_string(const std::string &s) {
@@ -61,6 +63,8 @@ int main(int argc, char **argv) {
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000, threads = 1, max_ed = 5000, verbosity = 0;
     bool trimming = true, shortcut = false, hap = false, whap = false, rbp = false;
     int device = 0;
+    std::vector<int> devices; /* --devices: the contexts that share the region batches (the first one is `device`) */
+    bool batch_given = false;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * {
@@ -85,7 +89,21 @@ int main(int argc, char **argv) {
         else if (a == "--skip") skip = strtoull(val(), nullptr, 10);
         else if (a == "--take") take = strtoull(val(), nullptr, 10);
         else if (a == "--device") device = atoi(val());
-        else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
+        else if (a == "--batch-regions") {
+            batch_regions = strtoull(val(), nullptr, 10);
+            batch_given = true;
+        } else if (a == "--devices") { /* one solver context per entry, e.g. 0,1,2,3 — or 0,0 for two contexts on one GPU */
+            std::string list = val();
+            devices.clear();
+            for (size_t b = 0; b <= list.size();) {
+                const size_t e = list.find(',', b);
+                const std::string item = list.substr(b, e == std::string::npos ? std::string::npos : e - b);
+                if (item.empty()) die(64, "invalid value for --devices", list.c_str());
+                devices.push_back(atoi(item.c_str()));
+                if (e == std::string::npos) break;
+                b = e + 1;
+            }
+        }
         else if (a == "--threads") threads = strtoull(val(), nullptr, 10);          /* accepted for command-line compatibility */
         else if (a == "--max-edit-distance") max_ed = strtoull(val(), nullptr, 10); /* hidden in the reference as well, unused by it */
         else if (a == "-v" || a == "--verbose") verbosity += 1;
@@ -103,6 +121,7 @@ int main(int argc, char **argv) {
     if (gap == 0) die(78, "--min-variant-gap must be >0", "");
     if (branch == 0 || branch > 0xFFFFFFFFull) die(78, "--max-branch-factor must be >0", "");
     if (batch_regions == 0) batch_regions = 1;
+    if (!devices.empty()) device = devices[0];
     if (mkdir(out_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create output folder", out_dir.c_str());
     if (!debug_dir.empty() && mkdir(debug_dir.c_str(), 0777) != 0 && errno != EEXIST) die(74, "cannot create debug folder", debug_dir.c_str());
     if (!debug_dir.empty()) { /* the CLI options as the reference saves them (src/main.rs:64-82; serde field order of CompareSettings) */
@@ -249,7 +268,110 @@ int main(int argc, char **argv) {
     std::vector<uint32_t> seq_stride, seq_len;
     std::vector<uint64_t> strat_total((size_t)n_labels * AVK_TALLY_LEN, 0);
     std::vector<uint32_t> gm, labels(n_labels ? n_labels : 1);
-    for (uint64_t at = 0; at < count; at += batch_regions) {
+    /* Several contexts (--devices: one per entry, GPUs may repeat) share the region batches: regions are independent, every context
+     * solves the batches it draws, the tallies are summed on the host (the sum the benchmark does with one RCCL all-reduce across
+     * processes).  The debug tables are written in region order by one context. */
+    const size_t n_workers = debug || devices.size() < 2 ? 1 : devices.size();
+    if (n_workers > 1) {
+        if (!batch_given) { /* about two batches per context */
+            batch_regions = (count + 2 * n_workers - 1) / (2 * n_workers);
+            if (batch_regions < 100000) batch_regions = 100000;
+        }
+        const uint64_t n_batches = (count + batch_regions - 1) / batch_regions;
+        std::atomic<uint64_t> next_batch{0};
+        std::vector<std::string> worker_err(n_workers);
+        std::vector<std::vector<uint64_t>> w_total(n_workers, std::vector<uint64_t>(AVK_TALLY_LEN, 0)),
+            w_strat(n_workers, std::vector<uint64_t>((size_t)n_labels * AVK_TALLY_LEN, 0));
+        std::mutex log_mutex;
+        auto worker = [&](size_t w) {
+            avk_ctx *my = ctx;
+            if (w > 0) {
+                my = nullptr;
+                if (avk_ctx_create(devices[w], &my)) {
+                    worker_err[w] = std::string("cannot create the GPU context: ") + avk_last_error(nullptr);
+                    return;
+                }
+                const uint32_t n_contigs = avf_genome_n_contigs(genome);
+                std::vector<const uint8_t *> seqs(n_contigs);
+                std::vector<uint64_t> lens(n_contigs);
+                for (uint32_t c = 0; c < n_contigs; ++c) {
+                    seqs[c] = avf_genome_seq(genome, c);
+                    lens[c] = avf_genome_len(genome, c);
+                }
+                if (avk_ref_upload(my, n_contigs, seqs.data(), lens.data())) {
+                    worker_err[w] = std::string("reference upload failed: ") + avk_last_error(my);
+                    avk_ctx_destroy(my);
+                    return;
+                }
+                (void)avk_ctx_set_option(my, "emit_group_metrics", n_labels ? 1 : 0);
+            }
+            std::vector<uint64_t> w_tally(AVK_TALLY_LEN);
+            for (uint64_t bi = next_batch.fetch_add(1); bi < n_batches; bi = next_batch.fetch_add(1)) {
+                const uint64_t at = bi * batch_regions;
+                const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
+                avk_region_batch b = *all;
+                b.n_regions = n;
+                b.region_id = all->region_id + first + at;
+                b.contig_idx = all->contig_idx + first + at;
+                b.start = all->start + first + at;
+                b.end = all->end + first + at;
+                b.t_off = all->t_off + first + at;
+                b.t_cnt = all->t_cnt + first + at;
+                b.q_off = all->q_off + first + at;
+                b.q_cnt = all->q_cnt + first + at;
+                avk_result_batch out;
+                memset(&out, 0, sizeof(out));
+                out.status = status.data() + first + at;
+                out.tally = w_tally.data();
+                out.var_expected = var_expected.data();
+                out.var_observed = var_observed.data();
+                out.var_class = var_class.data();
+                int rc = 0;
+                if (n_labels) {
+                    std::vector<uint64_t> label_off(n + 1, 0);
+                    std::vector<uint32_t> label_idx;
+                    rc = avf_strat_batch_labels(strat, genome, all, first + at, n, label_off.data(), nullptr);
+                    if (!rc) {
+                        label_idx.resize(label_off[n] + 1);
+                        rc = avf_strat_batch_labels(strat, genome, all, first + at, n, label_off.data(), label_idx.data());
+                    }
+                    if (rc) {
+                        worker_err[w] = std::string("cannot list the region labels: ") + avf_last_error();
+                        break;
+                    }
+                    avk_dev_batch *db = nullptr;
+                    rc = avk_batch_upload(my, &b, &db);
+                    if (!rc) rc = avk_compare_resident(my, db, &cfg, nullptr);
+                    if (!rc) rc = avk_results_download(my, db, &out);
+                    if (!rc) rc = avk_label_tallies(my, db, n_labels, label_off.data(), label_idx.data(), w_strat[w].data());
+                    if (db) avk_batch_free(my, db);
+                } else rc = avk_compare_batch(my, &b, &cfg, &out);
+                if (rc) {
+                    worker_err[w] = std::string("compare failed: ") + avk_last_error(my);
+                    break;
+                }
+                for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) w_total[w][k] += w_tally[k];
+                for (uint64_t r = 0; r < n; ++r)
+                    if (out.status[r] != 0) {
+                        std::lock_guard<std::mutex> lock(log_mutex);
+                        fprintf(stderr, "Error while solving compare region #%llu (contig %u:%llu-%llu): status %d\n", (unsigned long long)b.region_id[r], b.contig_idx[r],
+                                (unsigned long long)b.start[r], (unsigned long long)b.end[r], out.status[r]);
+                    }
+            }
+            if (w > 0) avk_ctx_destroy(my);
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < n_workers; ++w) pool.emplace_back(worker, w);
+        worker(0);
+        for (std::thread &t : pool) t.join();
+        for (size_t w = 0; w < n_workers; ++w)
+            if (!worker_err[w].empty()) die(70, worker_err[w].c_str(), "");
+        for (size_t w = 0; w < n_workers; ++w) {
+            for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += w_total[w][k];
+            for (size_t k = 0; k < strat_total.size(); ++k) strat_total[k] += w_strat[w][k];
+        }
+    }
+    for (uint64_t at = 0; n_workers == 1 && at < count; at += batch_regions) {
         const uint64_t n = count - at < batch_regions ? count - at : batch_regions;
         avk_region_batch b = *all; /* a window of the region arrays; variant arrays are shared */
         b.n_regions = n;

@@ -623,6 +623,33 @@ def test_command_line_tool_end_to_end(tmp_path, oracle):
         assert tabix_fetch(out, "chr20", 700_000, 800_000) == [r for r in records if 700_000 < int(r.split("\t")[1]) + len(r.split("\t")[3]) - 1 and int(r.split("\t")[1]) - 1 < 800_000]
 
 
+@pytest.mark.gpu
+def test_command_line_tool_with_several_contexts(tmp_path):
+    """--devices 0,0: two contexts (here on the one GPU of the box) draw the region batches; every output file is byte-identical to the
+    single-context run, with and without stratification labels"""
+    import subprocess
+    p, contig, want_batch = write_case_files(tmp_path)
+    beds = {"lo": [(0, 700_000)], "hi": [(600_000, 1_500_000)]}
+    for name, iv in beds.items():
+        write_text(str(tmp_path / (name + ".bed")), "".join("chr20\t%d\t%d\n" % x for x in iv))
+    write_text(str(tmp_path / "strat.tsv"), "".join("%s\t%s.bed\n" % (n, n) for n in beds))
+    base = [cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "--disable-variant-trimming"]
+    for extra in ([], ["-s", str(tmp_path / "strat.tsv")]):
+        outs = []
+        for k, dev in enumerate((["--device", "0"], ["--devices", "0,0", "--batch-regions", "400"], ["--devices", "0,0,0"])):
+            out = str(tmp_path / ("out_%d_%d" % (len(extra), k)))
+            r = subprocess.run(base + ["-o", out] + extra + dev, capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr
+            assert "Solved:error blocks: %d : 0" % want_batch.n_regions in r.stderr
+            outs.append(out)
+        for name in ("summary.tsv", "truth.vcf.gz", "query.vcf.gz"):
+            ref = gzip.open(os.path.join(outs[0], name), "rb").read() if name.endswith(".gz") else open(os.path.join(outs[0], name), "rb").read()
+            ref = b"\n".join(l for l in ref.split(b"\n") if not l.startswith(b"##aardvark_command"))
+            for o in outs[1:]:
+                got = gzip.open(os.path.join(o, name), "rb").read() if name.endswith(".gz") else open(os.path.join(o, name), "rb").read()
+                assert b"\n".join(l for l in got.split(b"\n") if not l.startswith(b"##aardvark_command")) == ref, (name, o)
+
+
 # ------------------------------------------------------------------ stratifications: pinned by the reference's own test + fixture
 STRAT_TSV = os.path.join(ROOT, "tests", "golden", "example_stratification", "strat.tsv")
 

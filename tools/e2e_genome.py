@@ -116,6 +116,8 @@ cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare"), "-r", 
        "-q", os.path.join(d, "query.vcf.gz"), "-b", os.path.join(d, "hc.bed"), "-o", os.path.join(d, "out"), "--disable-variant-trimming"]
 if n_strat:
     cmd += ["-s", os.path.join(d, "strat.tsv")]
+if os.environ.get("DEVICES"):  # several solver contexts, e.g. DEVICES=0,0 or 0,1,2,3
+    cmd += ["--devices", os.environ["DEVICES"]]
 t0 = time.time()
 r = subprocess.run(cmd, capture_output=True, text=True)
 print("exit %d, wall %.2f s" % (r.returncode, time.time() - t0))
