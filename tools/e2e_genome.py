@@ -148,4 +148,35 @@ if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote o
     print("merge of %d inputs: exit %d, wall %.2f s" % (n_merge, r.returncode, time.time() - t0))
     print("\n".join(l for l in r.stderr.strip().splitlines() if not l.startswith("Error while solving")))
     print(open(os.path.join(d, "merge_summary.tsv")).read())
+    if os.environ.get("VERIFY", "0") == "1" and n_merge == 3:
+        # every region's merge reason again on the CPU: k-input feed, the three input pairs through the oracle, the majority rule of
+        # solve_merge_region (merge_solver.rs:149-199) with numpy; compared with the names in the two BED files of the tool
+        sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle_lib
+        from aardvark_amd import feeder
+        from aardvark_amd._abi import RegionBatch
+        t0 = time.time()
+        genome = feeder.Genome(os.path.join(d, FASTA_NAME))
+        mb = feeder.feed_merge(vcfs, os.path.join(d, "hc.bed"), genome, enable_trimming=False).batch
+        n = mb.n_regions
+        off, cnt = mb.in_off.reshape(n, 3), mb.in_cnt.reshape(n, 3)
+        ex = {}
+        for i, j in ((0, 1), (0, 2), (1, 2)):
+            pb = RegionBatch(mb.region_id, mb.contig_idx, mb.start, mb.end, off[:, i], cnt[:, i], off[:, j], cnt[:, j], mb.var_pos, mb.var_type, mb.var_zyg,
+                             mb.var_raw_space, mb.a0_off, mb.a0_len, mb.a1_off, mb.a1_len, mb.allele_bytes)
+            st, e = oracle_lib.optimize_pairs(oracle_lib.load(), pb, genome.contigs(), 50, threads=os.cpu_count())
+            assert (st == 0).all()
+            ex[(i, j)] = e.astype(bool)
+        identical = ex[(0, 1)] & ex[(0, 2)] & ex[(1, 2)]
+        # first input whose match set (itself + the inputs it matches) reaches 2 of 3
+        maj = np.where(ex[(0, 1)], 1, np.where(ex[(0, 2)], 2, np.where(ex[(1, 2)], 3, 0)))  # 1: {0,1}  2: {0,2}  3: {1,2}  0: none
+        want = np.where(identical, "identical", np.where(maj > 0, "majority", "different"))
+        got = {}
+        for name in ("regions.bed.gz", "failed_regions.bed.gz"):
+            for line in gzip.open(os.path.join(d, "merged", name), "rt"):
+                reason, rid = line.rstrip("\n").split("\t")[3].rsplit("_", 1)
+                got[int(rid)] = reason
+        same = len(got) == n and all(got[int(r)] == w for r, w in zip(mb.region_id, want))
+        print("merge reasons of %d regions identical to oracle pairs + majority rule: %s (%.1f s; identical %d, majority %d, different %d)" % (
+            n, same, time.time() - t0, int(identical.sum()), int(((maj > 0) & ~identical).sum()), int((want == "different").sum())))
 subprocess.run(["rm", "-rf", d])
