@@ -50,6 +50,12 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    # stdout carries exactly ONE line, the JSON of rank 0: everything else that writes to file descriptor 1 — RCCL prints a version
+    # banner there when a communicator comes up — is sent to stderr; the JSON goes to the original descriptor at the end
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -192,7 +198,8 @@ def main():
             out["cpu_baseline"] = {"value": rate, "unit": "regions/s", "cores": cores, "kind": "port",
                                    "sample": "%d passes over the same %d-region batch (%.2f s wall on %d threads); 1 thread: %.0f regions/s"
                                              % (reps, n_regions, sec, cores, rate1)}
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
