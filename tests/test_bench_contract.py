@@ -1,0 +1,34 @@
+"""bench.py's output contract: exactly one line on stdout, a JSON object with the agreed keys — also when a RCCL communicator is up
+(RCCL writes a version banner to file descriptor 1)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+        "roofline", "cpu_baseline"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("force_dist", ["0", "1"])
+def test_one_json_line_on_stdout(force_dist):
+    env = dict(os.environ, AVK_BENCH_FORCE_DIST=force_dist, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--n-truth", "6000"], capture_output=True, text=True, env=env,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[:500]
+    out = json.loads(lines[0])
+    assert [k for k in KEYS if k not in out] == []
+    assert out["metric"] == "compared regions/sec (whole node)" and out["unit"] == "regions/s" and out["n_gpus"] == 1 and out["steps"] == 4 and out["warmup"] == 2
+    assert out["higher_is_better"] is True and out["scaling"] == "weak" and out["vs_baseline"] is None and out["dtype"] == "u8" and out["data"] == "synthetic"
+    assert out["config"]["parity"] == "bit-identical" and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["unit"] == "regions/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert out["value"] > 0 and out["ms_per_step"] > 0
