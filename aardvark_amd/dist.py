@@ -30,6 +30,14 @@ def take_regions(batch, idx):
                        batch.a0_off, batch.a0_len, batch.a1_off, batch.a1_len, batch.allele_bytes)
 
 
+def shard_batch(batch, rank, world):
+    """the regions of `batch` this rank owns: hash(region_id) % world == rank (reference loop src/main.rs:251-268 maps over
+    independent regions).  bench.py --scaling strong and the tools use this one function."""
+    if world <= 1:
+        return batch
+    return take_regions(batch, shard_indices(batch.region_id, rank, world))
+
+
 def allreduce_tally(tally):
     """in-place SUM all-reduce of an int64 tally tensor over the default process group"""
     import torch.distributed as dist

@@ -269,3 +269,331 @@ def config_indel_mix(n_truth=200_000, contig_len=CHR20_LEN, n_intervals=1000, se
     query = perturb_query(contig, bed, truth, seed_query, max(1, n_truth // 100))
     batch = cluster_regions(contig_len, bed, truth, query, gap)
     return contig, batch
+
+
+# ------------------------------------------------------------------------------------------------
+# Whole-genome-shaped workload (BASELINE.json configs[2]), vectorised:
+# 24 contigs with GRCh38 primary lengths, 3.9 M truth calls (82 % SNV, 9 % insertion, 9 % deletion,
+# lengths geometric with mean 3 and cap 50), 3 % of the sites within 30 bp of another site, 2 % of the
+# sites multi-allelic (`1/2`, split into two heterozygous calls the way the feeder splits them), 5 % of
+# the indels placed in an injected homopolymer / short-tandem-repeat run where the truth call is written
+# at the start of the run and the query call shifted by whole repeat units (same haplotype, different
+# record: the case optimize_gt_alleles exists for), query error model of config 2.
+# ------------------------------------------------------------------------------------------------
+GRCH38 = [248956422, 242193529, 198295559, 190214555, 181538259, 170805979, 159345973, 145138636, 138394717, 133797422, 135086622,
+          133275309, 114364328, 107043718, 101991189, 90338345, 83257441, 80373285, 58617616, 64444167, 46709983, 50818468, 156040895, 57227415]
+GRCH38_NAMES = ["chr%d" % i for i in range(1, 23)] + ["chrX", "chrY"]
+HG002_TRUTH_CALLS = 3_900_000
+
+
+def make_contig_fast(length, seed):
+    """i.i.d. uniform A/C/G/T like make_contig, from the raw 64-bit stream of the generator (20x faster: 3.1 Gbp in seconds)"""
+    raw = np.random.PCG64(seed).random_raw((length + 7) // 8)
+    b = raw.view(np.uint8)[:length]
+    b &= 3
+    return ACGT[b]
+
+
+def _ragged(starts, lens):
+    """indices of the concatenated ranges [starts[i], starts[i] + lens[i])"""
+    lens = np.asarray(lens, np.int64)
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64)
+    first = np.cumsum(lens) - lens
+    within = np.arange(total, dtype=np.int64) - np.repeat(first, lens)
+    return np.repeat(np.asarray(starts, np.int64), lens) + within, within
+
+
+def _other_base(b, k):
+    """the k-th (1..3) base after b in ACGT order"""
+    return ACGT[(np.searchsorted(ACGT, b) + k) % 4]
+
+
+class VCalls:
+    """Vectorised call set of one contig.  allele0 of call i = contig[pos : pos + ref_len]; allele1 = contig[pos] (if anchor) followed by
+    pool[alt_off : alt_off + alt_len]."""
+
+    def __init__(self, pos, ref_len, anchor, alt_off, alt_len, pool, vtype, zyg):
+        order = np.argsort(pos, kind="stable")
+        self.pos = np.asarray(pos, np.int64)[order]
+        self.ref_len = np.asarray(ref_len, np.int64)[order]
+        self.anchor = np.asarray(anchor, np.int64)[order]
+        self.alt_off = np.asarray(alt_off, np.int64)[order]
+        self.alt_len = np.asarray(alt_len, np.int64)[order]
+        self.vtype = np.asarray(vtype, np.uint8)[order]
+        self.zyg = np.asarray(zyg, np.uint8)[order]
+        self.pool = pool
+        self.order = order  # position of the sorted calls in the constructor's input
+
+    def __len__(self):
+        return self.pos.size
+
+    def alleles(self, contig, i):
+        """(allele0, allele1) of call i as bytes (tests, VCF writers)"""
+        p = int(self.pos[i])
+        a1 = (bytes(contig[p:p + 1]) if self.anchor[i] else b"") + bytes(self.pool[int(self.alt_off[i]):int(self.alt_off[i] + self.alt_len[i])])
+        return bytes(contig[p:p + int(self.ref_len[i])]), a1
+
+
+def genome_truth(contig, bed, n, seed, snv_frac=0.82, close_frac=0.03, str_frac=0.05, multi_frac=0.02):
+    """Truth calls of one contig.  WRITES the injected repeat runs into `contig`.  Returns (VCalls, str_info) where str_info holds, per
+    call (in the VCalls order), the repeat unit length and the number of units the query representation may be shifted by (0 = none)."""
+    rng = np.random.default_rng(seed)
+    base = positions_in_bed(bed, n, rng)
+    nclose = int(n * close_frac)
+    if nclose:
+        src = rng.choice(n, size=nclose, replace=False)
+        base[src] = np.clip(base[(src + 1) % n] + rng.integers(1, 30, size=nclose), 1, contig.size - 64)
+    base = np.unique(base)
+    n = base.size
+    u = rng.random(n)
+    kinds = np.where(u < snv_frac, 0, np.where(u < snv_frac + (1 - snv_frac) / 2, 1, 2))
+    lens = np.minimum(rng.geometric(1.0 / 3.0, size=n), 50).astype(np.int64)
+    # ---- repeat runs: unit of 1..3 bases, 4..10 copies, written right after the anchor base
+    unit = rng.integers(1, 4, size=n)
+    copies = rng.integers(4, 11, size=n)
+    m_units = rng.integers(1, 3, size=n)
+    run = unit * copies
+    k_iv = np.clip(np.searchsorted(bed[:, 0], base, side="right") - 1, 0, None)
+    gap_next = np.append(np.diff(base), 1 << 40)
+    gap_prev = np.insert(np.diff(base), 0, 1 << 40)
+    is_str = (kinds != 0) & (rng.random(n) < str_frac) & (gap_prev > 8) & (gap_next > run + 8) & (base + run + 8 < bed[k_iv, 1])
+    s_idx = np.nonzero(is_str)[0]
+    if s_idx.size:
+        ub = rng.integers(0, 4, size=(s_idx.size, 3))
+        dst, within = _ragged(base[s_idx] + 1, run[s_idx])
+        rep_unit = np.repeat(unit[s_idx], run[s_idx])
+        row = np.repeat(np.arange(s_idx.size), run[s_idx])
+        contig[dst] = ACGT[ub[row, within % rep_unit]]
+        lens[s_idx] = unit[s_idx] * m_units[s_idx]
+    # ---- alleles
+    ref_len = np.where(kinds == 2, 1 + lens, 1)
+    anchor = (kinds != 0).astype(np.int64)
+    alt_len = np.where(kinds == 0, 1, np.where(kinds == 1, lens, 0))
+    alt_off = np.cumsum(alt_len) - alt_len
+    pool = np.zeros(int(alt_len.sum()), np.uint8)
+    snv = np.nonzero(kinds == 0)[0]
+    pool[alt_off[snv]] = _other_base(contig[base[snv]], rng.integers(1, 4, size=snv.size))
+    ins = np.nonzero((kinds == 1) & ~is_str)[0]
+    d, _ = _ragged(alt_off[ins], alt_len[ins])
+    pool[d] = ACGT[rng.integers(0, 4, size=d.size)]
+    sins = np.nonzero((kinds == 1) & is_str)[0]
+    d, _ = _ragged(alt_off[sins], alt_len[sins])
+    s, _ = _ragged(base[sins] + 1, alt_len[sins])
+    pool[d] = contig[s]
+    vtype = np.where(kinds == 0, VT["Snv"], np.where(kinds == 1, VT["Insertion"], VT["Deletion"])).astype(np.uint8)
+    zyg = _random_zyg(n, rng)
+    shift_unit = np.where(is_str, unit, 0)
+    shift_max = np.where(is_str, np.where(kinds == 2, copies - m_units, copies), 0)  # deletion: the deleted units must stay inside the run
+    # ---- multi-allelic sites: a second heterozygous call with another ALT at the same position
+    pick = np.nonzero((rng.random(n) < multi_frac) & ~is_str)[0]
+    if pick.size:
+        kp = kinds[pick]
+        phased = rng.random(pick.size) < 0.5
+        zyg[pick] = np.where(phased, ZYG["PhasedHet01"], ZYG["UnphasedHeterozygous"])
+        z2 = np.where(phased, ZYG["PhasedHet10"], ZYG["UnphasedHeterozygous"]).astype(np.uint8)
+        short_del = (kp == 2) & (lens[pick] == 1)
+        a2_len = np.where(kp == 0, 1, np.where(kp == 1, 2 * lens[pick], np.where(short_del, 2, 1)))
+        a2_anchor = np.where((kp == 0) | short_del, 0, 1)
+        a2_off = pool.size + np.cumsum(a2_len) - a2_len
+        pool2 = np.zeros(int(a2_len.sum()), np.uint8)
+        rel = a2_off - pool.size
+        # SNV: a third base (neither REF nor the first ALT)
+        sp = np.nonzero(kp == 0)[0]
+        refb, alt1 = contig[base[pick[sp]]], pool[alt_off[pick[sp]]]
+        cand = _other_base(alt1, 1)
+        cand = np.where(cand == refb, _other_base(alt1, 2), cand)
+        pool2[rel[sp]] = cand
+        # insertion: the inserted bases twice
+        ip = np.nonzero(kp == 1)[0]
+        for rep in range(2):
+            d, _ = _ragged(rel[ip] + rep * lens[pick[ip]], lens[pick[ip]])
+            s, _ = _ragged(alt_off[pick[ip]], lens[pick[ip]])
+            pool2[d] = pool[s]
+        # deletion of 2+ bases: one base less deleted (ALT = first two REF bases); of 1 base: substitution at the anchor (Indel)
+        dp = np.nonzero((kp == 2) & ~short_del)[0]
+        pool2[rel[dp]] = contig[base[pick[dp]] + 1]
+        xp = np.nonzero(short_del)[0]
+        pool2[rel[xp]] = _other_base(contig[base[pick[xp]]], rng.integers(1, 4, size=xp.size))
+        pool2[rel[xp] + 1] = contig[base[pick[xp]] + 1]
+        t2 = np.where(kp == 0, VT["Snv"], np.where(kp == 1, VT["Insertion"], np.where(short_del, VT["Indel"], VT["Deletion"]))).astype(np.uint8)
+        base = np.concatenate([base, base[pick]])
+        ref_len = np.concatenate([ref_len, ref_len[pick]])
+        anchor = np.concatenate([anchor, a2_anchor])
+        alt_off = np.concatenate([alt_off, a2_off])
+        alt_len = np.concatenate([alt_len, a2_len])
+        vtype = np.concatenate([vtype, t2])
+        zyg = np.concatenate([zyg, z2])
+        pool = np.concatenate([pool, pool2])
+        shift_unit = np.concatenate([shift_unit, np.zeros(pick.size, np.int64)])
+        shift_max = np.concatenate([shift_max, np.zeros(pick.size, np.int64)])
+    calls = VCalls(base, ref_len, anchor, alt_off, alt_len, pool, vtype, zyg)
+    return calls, (shift_unit[calls.order], shift_max[calls.order])
+
+
+def genome_query(contig, bed, truth, str_info, seed, n_extra, drop=0.01, flip=0.005, change=0.005):
+    """query = truth with per-call drop / zygosity flip / ALT change, all genotypes unphased, repeat-run indels written at a position
+    shifted by whole units, plus n_extra random SNVs (false positives)."""
+    rng = np.random.default_rng(seed)
+    n = len(truth)
+    keep = np.nonzero(rng.random(n) >= drop)[0]
+    pos, ref_len, anchor = truth.pos[keep].copy(), truth.ref_len[keep].copy(), truth.anchor[keep].copy()
+    alt_off, alt_len = truth.alt_off[keep].copy(), truth.alt_len[keep].copy()
+    vt, zyg = truth.vtype[keep].copy(), truth.zyg[keep].copy()
+    het = zyg != ZYG["HomozygousAlternate"]
+    zyg[het] = ZYG["UnphasedHeterozygous"]
+    m = pos.size
+    fl = rng.random(m) < flip
+    zyg[fl] = np.where(zyg[fl] == ZYG["HomozygousAlternate"], ZYG["UnphasedHeterozygous"], ZYG["HomozygousAlternate"])
+    pool = truth.pool
+    # ALT change: SNV -> one of the two bases that are neither REF nor the old ALT; others -> last base of the ALT changed
+    ch = np.nonzero(rng.random(m) < change)[0]
+    if ch.size:
+        is_snv = vt[ch] == VT["Snv"]
+        new_len = np.where(is_snv | (alt_len[ch] == 0), 1, alt_len[ch])
+        new_off = pool.size + np.cumsum(new_len) - new_len
+        extra = np.zeros(int(new_len.sum()), np.uint8)
+        rel = new_off - pool.size
+        d, _ = _ragged(rel, np.where(alt_len[ch] > 0, alt_len[ch], 0))
+        s, _ = _ragged(alt_off[ch], alt_len[ch])
+        extra[d] = pool[s]
+        last = rel + new_len - 1
+        pick = rng.integers(0, 2, size=ch.size)
+        sc = np.nonzero(is_snv)[0]
+        refb, oldb = contig[pos[ch[sc]]], pool[alt_off[ch[sc]]]
+        c1 = _other_base(oldb, 1)
+        c1 = np.where(c1 == refb, _other_base(oldb, 2), c1)
+        c2 = _other_base(c1, 1)
+        c2 = np.where((c2 == refb) | (c2 == oldb), _other_base(c2, 1), c2)
+        c2 = np.where((c2 == refb) | (c2 == oldb), _other_base(c2, 1), c2)
+        extra[last[sc]] = np.where(pick[sc] == 0, c1, c2)
+        oc = np.nonzero(~is_snv)[0]
+        old_last = np.where(alt_len[ch[oc]] > 0, extra[last[oc]], contig[pos[ch[oc]]])
+        extra[last[oc]] = _other_base(old_last, rng.integers(1, 4, size=oc.size))
+        anchor[ch] = np.where(is_snv | (alt_len[ch] == 0), 0, anchor[ch])
+        alt_off[ch], alt_len[ch] = new_off, new_len
+        pool = np.concatenate([pool, extra])
+    # representation shift inside the repeat runs
+    s_unit, s_max = str_info[0][keep], str_info[1][keep]
+    sh = np.nonzero(s_max > 0)[0]
+    if sh.size:
+        j = 1 + (rng.integers(0, 1 << 30, size=sh.size) % s_max[sh])
+        pos[sh] += s_unit[sh] * j
+    if n_extra:
+        epos = positions_in_bed(bed, n_extra, rng)
+        eoff = pool.size + np.arange(n_extra)
+        pool = np.concatenate([pool, _other_base(contig[epos], rng.integers(1, 4, size=n_extra))])
+        pos = np.concatenate([pos, epos])
+        ref_len = np.concatenate([ref_len, np.ones(n_extra, np.int64)])
+        anchor = np.concatenate([anchor, np.zeros(n_extra, np.int64)])
+        alt_off = np.concatenate([alt_off, eoff])
+        alt_len = np.concatenate([alt_len, np.ones(n_extra, np.int64)])
+        vt = np.concatenate([vt, np.full(n_extra, VT["Snv"], np.uint8)])
+        ez = _random_zyg(n_extra, rng)
+        ez[ez != ZYG["HomozygousAlternate"]] = ZYG["UnphasedHeterozygous"]
+        zyg = np.concatenate([zyg, ez])
+    return VCalls(pos, ref_len, anchor, alt_off, alt_len, pool, vt, zyg)
+
+
+def cluster_regions_v(contig, bed, truth, query, gap=50, contig_idx=0, region_id_base=0):
+    """cluster_regions for vectorised call sets: RegionIterator::next (region_generation.rs:373-470) -> RegionBatch"""
+    contig_len = contig.size
+    nt, nq = len(truth), len(query)
+    pos = np.concatenate([truth.pos, query.pos])
+    rlen = np.concatenate([truth.ref_len, query.ref_len])
+    side = np.concatenate([np.zeros(nt, np.int8), np.ones(nq, np.int8)])
+    local = np.concatenate([np.arange(nt), np.arange(nq)])
+    order = np.argsort(pos, kind="stable")
+    pos, rlen, side, local = pos[order], rlen[order], side[order], local[order]
+    k = np.searchsorted(bed[:, 0], pos, side="right") - 1
+    ok = k >= 0
+    kk = np.clip(k, 0, None)
+    ok &= (pos < bed[kk, 1]) & (pos + rlen <= bed[kk, 1])
+    pos, rlen, side, local, k = pos[ok], rlen[ok], side[ok], local[ok], k[ok]
+    n = pos.size
+    if n == 0:
+        z = np.zeros(0, np.int64)
+        return RegionBatch(z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, z, np.zeros(1, np.uint8))
+    flank_end = np.minimum(pos + rlen + gap, contig_len)
+    big = np.int64(1) << 40
+    seg_max = np.maximum.accumulate(flank_end + k * big) - k * big
+    brk = np.ones(n, bool)
+    brk[1:] = (k[1:] != k[:-1]) | (pos[1:] >= seg_max[:-1])
+    win = np.cumsum(brk) - 1
+    nwin = int(win[-1]) + 1
+    first = np.nonzero(brk)[0]
+    w_start = np.maximum(pos[first] - gap, 0)
+    w_end = np.maximum.reduceat(flank_end, first)
+    vorder = np.lexsort((np.arange(n), side, win))
+    side_s, local_s, win_s = side[vorder], local[vorder], win[vorder]
+    t_cnt = np.bincount(win_s[side_s == 0], minlength=nwin)
+    q_cnt = np.bincount(win_s[side_s == 1], minlength=nwin)
+    woff = np.concatenate([[0], np.cumsum(t_cnt + q_cnt)[:-1]])
+    is_t = side_s == 0
+    lt, lq = np.where(is_t, local_s, 0), np.where(is_t, 0, local_s)
+    pick = lambda f: np.where(is_t, getattr(truth, f)[lt], getattr(query, f)[lq]) if nq and nt else (getattr(truth, f)[lt] if nt else getattr(query, f)[lq])
+    vpos, vref, vanchor, valt_len = pick("pos"), pick("ref_len"), pick("anchor"), pick("alt_len")
+    valt_off = np.where(is_t, truth.alt_off[lt], query.alt_off[lq] + truth.pool.size) if nq and nt else (truth.alt_off[lt] if nt else query.alt_off[lq])
+    pool = np.concatenate([truth.pool, query.pool]) if nq and nt else (truth.pool if nt else query.pool)
+    a0_len, a1_len = vref, vanchor + valt_len
+    a0_off = np.cumsum(a0_len + a1_len) - (a0_len + a1_len)
+    a1_off = a0_off + a0_len
+    arena = np.zeros(int((a0_len + a1_len).sum()), np.uint8)
+    d, _ = _ragged(a0_off, a0_len)
+    s, _ = _ragged(vpos, a0_len)
+    arena[d] = contig[s]
+    has = vanchor > 0
+    arena[a1_off[has]] = contig[vpos[has]]
+    d, _ = _ragged(a1_off + vanchor, valt_len)
+    s, _ = _ragged(valt_off, valt_len)
+    arena[d] = pool[s]
+    return RegionBatch(np.arange(nwin) + region_id_base, np.full(nwin, contig_idx), w_start, w_end, woff, t_cnt, woff + t_cnt, q_cnt,
+                       vpos, pick("vtype"), pick("zyg"), np.maximum(a0_len, a1_len), a0_off, a0_len, a1_off, a1_len, arena)
+
+
+def concat_batches(batches):
+    """several RegionBatches (one per contig) as one: variant and allele offsets are shifted"""
+    voff = np.cumsum([0] + [b.n_variants for b in batches])
+    aoff = np.cumsum([0] + [int(b.allele_bytes.size) for b in batches])
+    cat = lambda f, sh=None: np.concatenate([getattr(b, f) + (np.uint64(sh[i]) if sh is not None else 0) for i, b in enumerate(batches)])
+    return RegionBatch(cat("region_id"), cat("contig_idx"), cat("start"), cat("end"), cat("t_off", voff), cat("t_cnt"), cat("q_off", voff), cat("q_cnt"),
+                       cat("var_pos"), cat("var_type"), cat("var_zyg"), cat("var_raw_space"), cat("a0_off", aoff), cat("a0_len"), cat("a1_off", aoff),
+                       cat("a1_len"), cat("allele_bytes"))
+
+
+def contig_calls(ci, length, density, seed_ref=20250103, seed_query=20250104, keep_calls=False, **kw):
+    """one contig of the whole-genome workload: (contig bytes, bed, truth, query)"""
+    contig = make_contig_fast(length, seed_ref + ci)
+    rng = np.random.default_rng(seed_ref + 100 + ci)
+    bed = make_bed(length, max(4, int(1000 * length / CHR20_LEN)), 0.9, rng)
+    truth, info = genome_truth(contig, bed, max(1, int(length * density)), seed_ref + 200 + ci, **kw)
+    query = genome_query(contig, bed, truth, info, seed_query + ci, max(1, len(truth) // 100))
+    return contig, bed, truth, query
+
+
+def config_genome(scale=1.0, seed_ref=20250103, seed_query=20250104, gap=50, threads=8, n_truth=HG002_TRUTH_CALLS, **kw):
+    """BASELINE.json configs[2] stand-in: (list of 24 contigs, RegionBatch); `scale` shrinks the contigs (and the
+    call counts with them) for tests.  Contigs are generated side by side on `threads` threads (numpy releases the interpreter lock)."""
+    from concurrent.futures import ThreadPoolExecutor
+    density = n_truth / sum(GRCH38)
+    lengths = [max(int(l * scale), 200_000) for l in GRCH38]
+
+    def one(ci):
+        contig, bed, truth, query = contig_calls(ci, lengths[ci], density, seed_ref, seed_query, **kw)
+        return contig, cluster_regions_v(contig, bed, truth, query, gap, contig_idx=ci)
+
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        parts = list(ex.map(one, range(len(lengths))))
+    batches = [p[1] for p in parts]
+    base = 0
+    for b in batches:  # region ids in genome order (region_generation.rs:403-409)
+        b.region_id = (np.arange(b.n_regions) + base).astype(np.uint64)
+        base += b.n_regions
+    return [p[0] for p in parts], concat_batches(batches)
+
+
+def config_indel_mix_v2(n_truth=20_000, contig_len=8_000_000, seed_ref=20250103, seed_query=20250104, gap=50, **kw):
+    """one contig at the density and with every feature of the whole-genome workload (multi-allelic sites, shifted repeat-run indels)"""
+    contig, bed, truth, query = contig_calls(19, contig_len, n_truth / contig_len, seed_ref, seed_query, **kw)
+    return contig, cluster_regions_v(contig, bed, truth, query, gap)

@@ -37,6 +37,7 @@ enum { A_UNKNOWN = 0, A_REF = 1, A_ALT = 2 }; /* Allele, phase_enums.rs:20-24 */
 struct Stats {
     uint64_t max_pops_a = 0, max_queue_a = 0, max_pops_b = 0, max_queue_b = 0, max_ed = 0, max_optima = 0;
     uint64_t total_pops_a = 0, total_pops_b = 0, total_wfa = 0, incr_mismatch = 0;
+    uint64_t byte_compares = 0; /* base comparisons made by DWFALite::extend (the compute-side figure of SURVEY.md 8d) */
     void merge(const Stats &o) {
         max_pops_a = std::max(max_pops_a, o.max_pops_a);
         max_queue_a = std::max(max_queue_a, o.max_queue_a);
@@ -48,6 +49,7 @@ struct Stats {
         total_pops_b += o.total_pops_b;
         total_wfa += o.total_wfa;
         incr_mismatch += o.incr_mismatch;
+        byte_compares += o.byte_compares;
     }
 };
 thread_local Stats t_stats;
@@ -72,15 +74,19 @@ struct DWFALite {
 
     /* :94-130 */
     void extend(Span b, Span o) {
+        uint64_t compares = 0;
         for (size_t i = 0; i < wavefront.size(); ++i) {
             size_t &d = wavefront[i];
             for (;;) {
                 size_t baseline_offset = d + edit_distance - i;
                 size_t other_offset = d;
-                if (baseline_offset >= b.n || other_offset >= o.n || b.p[baseline_offset] != o.p[other_offset]) break;
+                if (baseline_offset >= b.n || other_offset >= o.n) break;
+                compares += 1;
+                if (b.p[baseline_offset] != o.p[other_offset]) break;
                 d += 1;
             }
         }
+        t_stats.byte_compares += compares;
     }
 
     /* :140-173 — the distance is incremented BEFORE the max check (:146-149); offsets are not
@@ -1549,6 +1555,7 @@ void orc_last_stats(uint64_t out[16]) {
     out[7] = g_stats.total_pops_b;
     out[8] = g_stats.total_wfa;
     out[9] = g_stats.incr_mismatch;
+    out[10] = g_stats.byte_compares;
 }
 
 } /* extern "C" */

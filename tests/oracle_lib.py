@@ -101,10 +101,11 @@ class ContigSet:
         self.n = len(self.arrs)
 
 
-def compare_batch(lib, batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False, threads=1):
-    """Runs the oracle's solve_compare_region over a RegionBatch; returns a ResultBatch."""
+def compare_batch(lib, batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False, threads=1, group_metrics=True):
+    """Runs the oracle's solve_compare_region over a RegionBatch; returns a ResultBatch (group_metrics=False: no per-region 13x22
+    blocks, 1144 bytes per region — the whole-genome batches of bench.py)."""
     cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
-    res = ResultBatch(batch, sequences=sequences)
+    res = ResultBatch(batch, sequences=sequences, group_metrics=group_metrics)
     cfg = AvkCompareConfig(max_branch_factor, 1 if sequences else 0, 1 if exact_shortcut else 0)
     cb, ro = batch.c_struct(), res.c_struct()
     rc = lib.orc_compare_batch(C.byref(cb), cs.ptrs, cs.lens, cs.n, C.byref(cfg), C.byref(ro), threads)
@@ -115,7 +116,7 @@ def compare_batch(lib, batch, contigs, max_branch_factor=50, sequences=False, ex
 def stats(lib):
     out = (C.c_uint64 * 16)()
     lib.orc_last_stats(out)
-    names = ["max_pops_a", "max_queue_a", "max_pops_b", "max_queue_b", "max_ed", "max_optima", "total_pops_a", "total_pops_b", "total_wfa", "incr_mismatch"]
+    names = ["max_pops_a", "max_queue_a", "max_pops_b", "max_queue_b", "max_ed", "max_optima", "total_pops_a", "total_pops_b", "total_wfa", "incr_mismatch", "byte_compares"]
     return {n: int(out[i]) for i, n in enumerate(names)}
 
 

@@ -10,14 +10,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-        "roofline", "cpu_baseline"]
+        "roofline", "cpu_baseline", "host_boundary", "dwfa_byte_compares_per_s", "secondary"]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("force_dist", ["0", "1"])
 def test_one_json_line_on_stdout(force_dist):
     env = dict(os.environ, AVK_BENCH_FORCE_DIST=force_dist, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--n-truth", "6000"], capture_output=True, text=True, env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--scale", "0.01", "--boundary-calls", "1"], capture_output=True, text=True, env=env,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()
@@ -31,4 +31,7 @@ def test_one_json_line_on_stdout(force_dist):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["achieved"] > 0
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "regions/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert 0 < cb["parallel_efficiency"] < 1.5 and cb["one_thread_value"] > 0
+    hb = out["host_boundary"]
+    assert hb["value"] > 0 and hb["identical_to_resident_path"] is True
     assert out["value"] > 0 and out["ms_per_step"] > 0

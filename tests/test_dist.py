@@ -30,7 +30,8 @@ def _worker(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     contigs, batch = scenarios.chr20_small(1200)
     mine = avk_dist.shard_indices(batch.region_id, rank, world)
-    shard = avk_dist.take_regions(batch, mine)
+    shard = avk_dist.shard_batch(batch, rank, world)  # what bench.py --scaling strong hands to each rank
+    assert np.array_equal(shard.region_id, batch.region_id[mine])
     res = emu_lib.compare_batch(shard, contigs, n_waves=4, threads=2)
     tally = torch.from_numpy(res.tally.astype(np.int64))
     avk_dist.allreduce_tally(tally)
