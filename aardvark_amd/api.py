@@ -64,6 +64,8 @@ def load_library():
     lib.avk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_solver_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_tier_counts.argtypes = [vp, u64p]
+    lib.avk_last_lane_ms.argtypes = [vp, C.POINTER(C.c_float)]
+    lib.avk_last_lane_solved.argtypes = [vp, u64p]
     lib.avk_debug_phase_cycles.argtypes = [vp, u64p]
     lib.avk_algorithmic_bytes.restype = C.c_uint64
     lib.avk_algorithmic_bytes.argtypes = [C.POINTER(AvkRegionBatch)]
@@ -195,6 +197,18 @@ class Context:
         ms = C.c_float(0)
         self._check(self.lib.avk_last_solver_ms(self.handle, C.byref(ms)))
         return float(ms.value)
+
+    def last_lane_ms(self):
+        """HIP-event time from the start of the last step to the end of its lane-per-region launches (0 when it had none)"""
+        ms = C.c_float(0)
+        self._check(self.lib.avk_last_lane_ms(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    def last_lane_solved(self):
+        """regions the lane-per-region kernel finished in the step whose results were downloaded last"""
+        out = C.c_uint64(0)
+        self._check(self.lib.avk_last_lane_solved(self.handle, C.byref(out)))
+        return int(out.value)
 
     def last_tier_counts(self):
         out = (C.c_uint64 * 5)()

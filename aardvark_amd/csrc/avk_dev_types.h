@@ -72,6 +72,37 @@ struct AvkDevVariant {
 
 #define AVK_PRE_SKIP_OK 0x1000u
 
+/* ---- fast records: the input of the lane-per-region kernel (avk_lane.inl) ------------------------------------------------
+ * Regions of the small classes (at most 2 calls per side, short window, small edit-distance bound, ACGT-only ALT alleles) get,
+ * besides their AvkDevRegion, a fixed-size record of AVK_FAST_WORDS words.  Records are stored in TILES of 64: word w of the
+ * record of lane l of tile t sits at [(t * AVK_FAST_WORDS + w) * 64 + l], so the 64 lanes of a wave read their records with
+ * fully coalesced loads.
+ *   word 0   index of the packed reference word that holds the window's first base (ref_off >> 4)
+ *   word 1   ref_off & 15 | L << 4 | T << 12 | Q << 14 | order << 16   (order: 2 bits per search depth = slot of the call
+ *            handled there, order_variants query_optimizer.rs:372-381); 0xFFFFFFFF = no region in this lane
+ *   word 2   first per-variant output word (AvkDevRegion::v_off)
+ *   word 3   the region's index in the caller's batch (AvkDevRegion::orig)
+ *   then 4 call slots of 4 words (slots 0,1 truth, 2,3 query):
+ *            rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28;  alt_ed | raw_space << 8;  allele1, 2 bits per
+ *            base, 16 bases per word (2 words) */
+#define AVK_FAST_HDR 4
+#define AVK_FAST_WORDS 20
+#define AVK_FAST_CLASSES 4
+/* capacities of the launch classes: sequence words (16 bases each), calls per side, wavefront cap, queue entries.
+ * ed_max caps the edit distance a lane follows, not what the region may contain: with the lazily evaluated search (avk_lane.inl,
+ * phaseA) the alignments of wrongly phased branches stop at their first edit, so a region of matching 40-base deletions never needs
+ * a wavefront; a lane that does need more — a missed call of 7+ bases on the best path — hands its region to the wave-per-region
+ * kernels, whose lanes work on the diagonals of one wavefront in parallel. */
+struct AvkFastClass {
+    uint32_t W, maxv, ed_max, qcap;
+};
+static const AvkFastClass AVK_FAST_CLASS[AVK_FAST_CLASSES] = {
+    {7, 1, 6, 4},    /* one call per side, window + growth <= 112 bases (84 % of a genome) */
+    {12, 1, 6, 4},   /* one call per side, <= 192 bases */
+    {10, 2, 6, 16},  /* two calls per side, <= 160 bases */
+    {12, 2, 6, 16},  /* two calls per side, <= 192 bases */
+};
+
 /* capacities of one workspace tier */
 struct AvkTier {
     uint64_t ws_bytes; /* bytes of workspace per wave in this tier */
@@ -81,6 +112,7 @@ struct AvkTier {
 
 /* partial-tally geometry: AVK_TALLY_LEN sums + 5 tier counters + 8 profiling words, padded */
 #define AVK_TALLY_STRIDE 320
+#define AVK_TALLY_LANE_SOLVED 310 /* word of a partial tally: regions finished (either way) by the lane-per-region kernel */
 #define AVK_TALLY_COPIES 64
 /* tail of a bulk workgroup's LDS: 16 control words + AVK_TALLY_LEN (rounded up) tally words */
 #define AVK_WG_TAIL_BYTES (64 + 4 * 288)

@@ -25,6 +25,7 @@
 #include "../../include/aardvark_amd.h"
 #include "avk_pack.h"
 #include "avk_solver.inl"
+#include "avk_lane.inl"
 
 /* ---------------------------------------------------------------------------------- kernels */
 /* LDS passes: regions in the LDS slice of their wavefront (small slices at high occupancy first, then
@@ -48,6 +49,39 @@ __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     avk::region_worker<false>(a, wave_id, (unsigned char *)0);
+}
+
+/* Small regions, one per LANE (avk_lane.inl): a workgroup is four independent waves, each claims tiles of 64 fast records; the
+ * workgroup's LDS holds the four waves' per-lane arrays and one shared tally that is flushed once */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) avk_lane_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    uint32_t *smem = (uint32_t *)avk_smem;
+    const unsigned wave_in_block = threadIdx.x >> 6;
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, 16);
+    uint32_t *wg_tally = smem + (size_t)(blockDim.x >> 6) * rows * 64u;
+    for (unsigned k = threadIdx.x; k < 288; k += blockDim.x) wg_tally[k] = 0;
+    __syncthreads();
+    uint32_t n_ok = 0, n_err = 0;
+    avk::lane::lane_worker(a, la, wave_id, smem + (size_t)wave_in_block * rows * 64u, wg_tally, n_ok, n_err);
+    n_ok = wv_sum_u32(n_ok);
+    n_err = wv_sum_u32(n_err);
+    uint64_t *part = a.tally + (uint64_t)(blockIdx.x % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_ok) {
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_SOLVED), (unsigned long long)n_ok);
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_LANE_SOLVED), (unsigned long long)n_ok);
+        }
+        if (n_err) {
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_ERRORS), (unsigned long long)n_err);
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_LANE_SOLVED), (unsigned long long)n_err);
+        }
+    }
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < AVK_N_GROUPS * AVK_N_FIELDS; k += blockDim.x) {
+        const uint32_t v = wg_tally[k];
+        if (v) atomicAdd((unsigned long long *)(part + k), (unsigned long long)v);
+    }
 }
 
 /* Stratified tallies (SummaryWriter::add_comparison_benchmark with containment regions, writers/summary.rs:146-163): label l sums the
@@ -189,6 +223,9 @@ struct avk_ctx {
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
+    int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
+    bool lane_attr_set = false;
+    uint64_t last_lane_solved = 0;
     int n_cus = 0;
     /* workspaces (grown on demand) */
     uint8_t *d_ws = nullptr;
@@ -197,6 +234,10 @@ struct avk_ctx {
     size_t big_alloc = 0;
     /* measurement */
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk1 = nullptr; /* ev0..ev1 all solver launches, ev0..evk1 the first (dominant) one */
+    hipEvent_t ev_lane = nullptr; /* after the lane-kernel launches of a step */
+    bool ev_lane_valid = false;
+    hipStream_t lane_stream = nullptr; /* the lane-kernel launches of the two-calls-per-side classes run beside everything else */
+    hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -223,6 +264,8 @@ struct avk_dev_batch {
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
     avk::WorkPlan plan;
+    uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
+    uint32_t fast_tile_base[AVK_FAST_CLASSES] = {0}, fast_tiles[AVK_FAST_CLASSES] = {0};
     bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
 };
@@ -260,7 +303,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 
 void free_batch_buffers(avk_dev_batch *db) {
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3};
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_fast};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -308,6 +351,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     (void)hipEventCreate(&ctx->ev0);
     (void)hipEventCreate(&ctx->ev1);
     (void)hipEventCreate(&ctx->evk1);
+    (void)hipEventCreate(&ctx->ev_lane);
     /* the solo launches get streams of the highest priority: they are the critical path, and HIP never folds streams of
      * different priorities onto one hardware queue (with a communicator library in the process the default-priority streams
      * of a process share queues, and a shared queue would serialise the solo launches with the bulk) */
@@ -319,6 +363,9 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready2, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
         avk_ctx_destroy(ctx);
         return AVK_E_HIP;
@@ -343,11 +390,15 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
+    if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->ev_ready2) (void)hipEventDestroy(ctx->ev_ready2);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+    if (ctx->ev_lane_fork) (void)hipEventDestroy(ctx->ev_lane_fork);
+    if (ctx->ev_lane_join) (void)hipEventDestroy(ctx->ev_lane_join);
+    if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -427,6 +478,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->use_packed_reference = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {
         ctx->emit_group_metrics = value ? 1 : 0;
+    } else if (n == "lane_kernel") {
+        ctx->lane_kernel = value ? 1 : 0;
     } else
         return fail(ctx, AVK_E_ARG, "unknown option '%s'", name);
     return 0;
@@ -583,7 +636,13 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
     const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(db->host, order);
-    if (n) e = hipMemcpyAsync(db->d_regions, sorted.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
+    avk::PodVec<uint32_t> fast;
+    if (db->plan.n_fast_total) {
+        fast = avk::build_fast_records(db->host, order, db->plan, db->fast_tile_base, db->fast_tiles);
+        e = hipMalloc((void **)&db->d_fast, fast.size() * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMemcpyAsync(db->d_fast, fast.data(), fast.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
+    }
+    if (n && e == hipSuccess) e = hipMemcpyAsync(db->d_regions, sorted.data(), n * sizeof(AvkDevRegion), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(db->d_blob, db->host.blob.data(), db->host.blob.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e != hipSuccess) {
@@ -633,10 +692,28 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         int rc = dev_alloc(ctx, &db->d_seq, (size_t)db->seq_total + 16);
         if (rc) return rc;
     }
+    /* up to four launches, one per workspace tier; each consumes the overflow list of the one
+     * before it (its length is read on the device, so nothing comes back to the host in between) */
+    const bool use[4] = {ctx->lds_bytes_per_wave > 0, ctx->lds2_bytes_per_wave > 0, ctx->ws_bytes_per_wave > 0, ctx->big_ws_bytes > 0};
+    /* which tiers get a launch of their own: the large LDS slices normally only serve the solo launch (their
+     * overflow pass runs one workgroup per CU and measured slower than handing the overflow to the HBM tier,
+     * which runs twice the waves), and the big HBM slices are claimed in place by the tier-2 launch */
+    const bool launch[4] = {use[0], use[1] && (ctx->lds2_overflow_pass || !use[0]), use[2], use[3] && !use[2]};
+    int last = -1;
+    for (int t = 0; t < 4; ++t)
+        if (launch[t]) last = t;
+    if (last < 0) return fail(ctx, AVK_E_ARG, "every workspace tier is disabled");
+    /* The lane-per-region kernel takes the fast segments at the end of the work order (WorkPlan::fast_base); what it cannot finish it
+     * appends to the list the first HBM launch reads.  Without such a launch, with sequence output (the haplotype bytes are never
+     * materialised there) or with the exact-match shortcut the wave-per-region bulk launch covers those records itself. */
+    const int fast_list = launch[1] ? 1 : 0;
+    const bool use_fast = ctx->lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && db->d_fast && db->plan.n_fast_total && !cfg->enable_sequences &&
+                          !cfg->enable_exact_shortcut && n;
+    const uint32_t n_fast = use_fast ? db->plan.n_fast_total : 0u;
     /* geometry */
     const uint32_t waves_per_block = 4;
     uint64_t want_waves = (uint64_t)ctx->n_cus * (uint64_t)ctx->waves_per_cu;
-    if (want_waves > n) want_waves = n;
+    if (want_waves > n - n_fast) want_waves = n - n_fast;
     uint32_t blocks = (uint32_t)((want_waves + waves_per_block - 1) / waves_per_block);
     if (blocks == 0) blocks = 1;
     /* the HBM launches: no more workgroups than can be resident (three per CU at the kernel's register count) — later ones would find
@@ -646,7 +723,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (hbm_blocks > blocks) hbm_blocks = blocks;
     const uint32_t n_waves = hbm_blocks * waves_per_block;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
-    const uint32_t hbm_solo_max = 64;
+    const uint32_t hbm_solo_max = 128;
     const size_t ws_need = (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
     const auto t_ws = std::chrono::steady_clock::now();
     const bool ws_grows = ws_need > ctx->ws_alloc;
@@ -720,17 +797,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     }
     const bool timed = ctx->timing_events != 0;
     if (timed) AVK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    /* up to four launches, one per workspace tier; each consumes the overflow list of the one
-     * before it (its length is read on the device, so nothing comes back to the host in between) */
-    const bool use[4] = {ctx->lds_bytes_per_wave > 0, ctx->lds2_bytes_per_wave > 0, ctx->ws_bytes_per_wave > 0, ctx->big_ws_bytes > 0};
-    /* which tiers get a launch of their own: the large LDS slices normally only serve the solo launch (their
-     * overflow pass runs one workgroup per CU and measured slower than handing the overflow to the HBM tier,
-     * which runs twice the waves), and the big HBM slices are claimed in place by the tier-2 launch */
-    const bool launch[4] = {use[0], use[1] && (ctx->lds2_overflow_pass || !use[0]), use[2], use[3] && !use[2]};
-    int last = -1;
-    for (int t = 0; t < 4; ++t)
-        if (launch[t]) last = t;
-    if (last < 0) return fail(ctx, AVK_E_ARG, "every workspace tier is disabled");
+    ctx->ev_lane_valid = false;
     const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(ctx->big_waves < 128 ? ctx->big_waves : 128) : 0u;
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
@@ -760,7 +827,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 hbm_solo_pending = false;
             }
         }
-        a.n_work = (uint32_t)n;
+        a.n_work = (uint32_t)n - (t == 0 ? n_fast : 0u);
         a.high_priority = 0;
         a.esc_bytes = 0;
         a.esc_enabled = 0;
@@ -790,7 +857,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 solo_regions = n_front < cap ? n_front : (uint32_t)cap; /* the others lead the bulk list */
             }
             if (n_c) {
-                hbm_solo = (n_c + 7) / 8;
+                hbm_solo = (n_c + 3) / 4;
                 if (hbm_solo > hbm_solo_max) hbm_solo = hbm_solo_max;
                 if (hbm_solo > blocks / 8) hbm_solo = blocks / 8;
             }
@@ -847,7 +914,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             }
             if (solo || hbm_solo) {
                 a.work_base = n_c + solo_regions;
-                a.n_work = (uint32_t)n - n_c - solo_regions;
+                a.n_work = (uint32_t)n - n_fast - n_c - solo_regions;
             }
             /* With calls queued back to back (no host synchronisation in between) the bulk is dispatched the moment the previous call
              * ends, ahead of the solo launches whose streams still have to see the fork event, and takes every LDS allocation before
@@ -857,6 +924,54 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (ctx->order_guard) {
                 if (hbm_solo) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ready2, 0));
                 if (solo) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ready, 0));
+            }
+            /* ---- the lane-per-region launches (avk_lane.inl): the classes with two calls per side (long, latency-bound tiles at low
+             * occupancy) on a stream of their own, the one-call classes on the caller's stream ahead of the bulk.  What a lane cannot
+             * finish goes to the DEFERRED list, solved after the bulk by an LDS launch of the wave-per-region kernel. */
+            bool lane_side = false;
+            if (use_fast) {
+                if (!ctx->lane_attr_set) {
+                    AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+                    ctx->lane_attr_set = true;
+                }
+                AvkKernelArgs f = a;
+                f.overflow_list = lists[2];
+                f.overflow_count = db->d_counters + 1024 + 32;
+                AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_fork, ctx->stream));
+                for (int fc = AVK_FAST_CLASSES - 1; fc >= 0; --fc) {
+                    if (!db->fast_tiles[fc]) continue;
+                    const AvkFastClass &cl = AVK_FAST_CLASS[fc];
+                    avk::lane::LaneArgs la;
+                    la.recs = db->d_fast;
+                    la.tile_base = db->fast_tile_base[fc];
+                    la.n_tiles = db->fast_tiles[fc];
+                    la.tile_counter = db->d_counters + 1220 + fc;
+                    la.W = cl.W;
+                    la.nm = 1u << cl.maxv;
+                    la.ed_max = cl.ed_max;
+                    la.qcap = cl.qcap;
+                    la.gen_base = db->plan.fast_base[fc];
+                    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + 3 * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + 4;
+                    /* one-wave workgroups: the per-lane arrays of a wave plus a tally of its own; as many as the LDS and the registers hold */
+                    const size_t lds = (size_t)rows * 256 + 288 * 4;
+                    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+                    if (per_cu < 1) return fail(ctx, AVK_E_ARG, "lane kernel class %d does not fit the LDS", fc);
+                    if (per_cu > 12) per_cu = 12;
+                    uint32_t grid = (uint32_t)ctx->n_cus * per_cu;
+                    if (grid > la.n_tiles) grid = la.n_tiles;
+                    const bool side = cl.maxv > 1;
+                    if (side && !lane_side) {
+                        AVK_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream, ctx->ev_lane_fork, 0));
+                        lane_side = true;
+                    }
+                    hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, side ? ctx->lane_stream : ctx->stream, f, la);
+                    AVK_HIP(ctx, hipGetLastError());
+                }
+                if (lane_side) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join, ctx->lane_stream));
+                if (timed) {
+                    AVK_HIP(ctx, hipEventRecord(ctx->ev_lane, ctx->stream));
+                    ctx->ev_lane_valid = true;
+                }
             }
             /* every workgroup of the three launches is resident at once */
             uint32_t bulk = blocks - solo - 2 * hbm_solo;
@@ -869,6 +984,18 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 a.esc_enabled = ctx->lds_escalation ? 1u : 0u;
             }
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
+            if (use_fast) { /* the regions the lanes handed over: small ones, so the LDS tier with its in-workgroup escalation; its own overflow joins the bulk's */
+                AVK_HIP(ctx, hipGetLastError());
+                if (lane_side) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join, 0));
+                AvkKernelArgs d = a;
+                d.work_list = lists[2];
+                d.n_work_dev = db->d_counters + 1024 + 32;
+                d.work_base = 0;
+                d.n_work = 0;
+                d.work_counter = db->d_counters + 768;
+                d.n_waves = bulk * waves_per_block;
+                hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, d);
+            }
             a.tier[0].ws_bytes = slice0;
         } else if (t == 1) { /* one workgroup per CU, four large slices */
             a.hbm_ws = nullptr;
@@ -931,6 +1058,22 @@ int avk_last_kernel_ms(avk_ctx *ctx, float *ms) {
     if (!ctx->ev_valid) return fail(ctx, AVK_E_STATE, "no launch has been timed yet");
     AVK_HIP(ctx, hipEventSynchronize(ctx->evk1));
     AVK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->evk1));
+    return 0;
+}
+
+int avk_last_lane_ms(avk_ctx *ctx, float *ms) {
+    if (!ctx || !ms) return AVK_E_ARG;
+    *ms = 0;
+    if (!ctx->ev_valid) return fail(ctx, AVK_E_STATE, "no launch has been timed yet");
+    if (!ctx->ev_lane_valid) return 0; /* the last call had no lane-kernel launches */
+    AVK_HIP(ctx, hipEventSynchronize(ctx->ev_lane));
+    AVK_HIP(ctx, hipEventElapsedTime(ms, ctx->ev0, ctx->ev_lane));
+    return 0;
+}
+
+int avk_last_lane_solved(avk_ctx *ctx, uint64_t *count) {
+    if (!ctx || !count) return AVK_E_ARG;
+    *count = ctx->last_lane_solved;
     return 0;
 }
 
@@ -1003,6 +1146,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copied).count());
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
+    ctx->last_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
     memcpy(ctx->last_phase, tally.data() + AVK_TALLY_LEN + 5, 16 * sizeof(uint64_t));
     if (want_seq) {
         for (uint64_t r = 0; r < n; ++r) {

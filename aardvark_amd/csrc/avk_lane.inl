@@ -1,0 +1,994 @@
+/*
+ * avk_lane.inl — the compare solver for SMALL regions, one region per LANE (64 regions per wavefront).
+ *
+ * avk_solver.inl gives a whole 64-lane wavefront to one region; for the modal region of a call-set comparison (one or two
+ * calls per side on a ~100-base window: 97 % of a whole-genome run) that leaves most lanes idle and spends ~30 bookkeeping
+ * instructions per base compared.  Here every lane runs the SAME algorithm (reference solve_compare_region,
+ * src/waffle_solver.rs:122-284, with optimize_sequences src/query_optimizer.rs:166-365, optimize_gt_alleles
+ * src/exact_gt_optimizer.rs:108-357 and the dynamic wavefront aligner src/dwfa/dynamic_wfa.rs:23-276) on its own region:
+ *
+ *   - sequences are 2 bits per base, 16 bases per word; comparing two sequences is XOR + count-trailing-zeros on words;
+ *   - a haplotype under construction is never copied: with at most MAXV calls per side there are at most 2^MAXV distinct
+ *     full-length haplotype sequences per side; they are built once per region (FULL(side, mask), the rule of
+ *     generate_allele_sequence, waffle_solver.rs:726-778, which is also the rule of HaplotypeTracker::extend_variant,
+ *     haplotype_dwfa.rs:175-212, because a side's calls are sorted and sync points never pass a later call) and a search node's
+ *     sequence is the PREFIX of FULL(side, alleles chosen so far) of the node's current length;
+ *   - a search node is not stored either: a queue entry is ONE word (cost | node id | allele choices | depth) and the node's
+ *     aligner state is rebuilt by replaying its at most 4 extension steps from the root when it is popped.  Pop order, node
+ *     ids, the per-depth quota and the order of tied optima are exactly the reference's;
+ *   - per-lane arrays (sequence table, wavefronts, queue) live in LDS as [word][lane]: bank = lane, conflict-free for any
+ *     per-lane index.
+ *
+ * A lane that meets something outside this kernel's class (a non-ACGT base in its window, a wavefront or queue that would
+ * outgrow the launch's capacities) appends its region to the overflow list of the wave-per-region kernels: results never
+ * depend on which kernel solved a region (tests/test_emu_parity.py, tests/test_gpu_parity.py compare both against the oracle).
+ */
+#ifndef AVK_LANE_INL
+#define AVK_LANE_INL
+
+#include "avk_dev_types.h"
+#include "avk_wave.h"
+
+namespace avk {
+namespace lane {
+
+typedef uint8_t u8;
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+/* work counters of instrumented emulator builds (-DAVK_LANE_STATS): [0] match_run words, [1] diagonals extended, [2] extension steps,
+ * [3] pops, [4] partial re-pops, [5] regions, [6] phase-C alignments, [7] replayed steps */
+#ifdef AVK_LANE_STATS
+extern uint64_t g_lane_stats[16];
+#define AVK_LSTAT(k, n) g_lane_stats[k] += (n)
+#else
+#define AVK_LSTAT(k, n)
+#endif
+
+enum { L_REF = 1, L_ALT = 2 };
+enum { LS_DEFER = -1 }; /* internal: not this kernel's class after all, hand the region to the wave-per-region kernels */
+
+/* per-lane view of the wave's LDS: word (row, lane) sits at p[row * 64] */
+struct LCtx {
+    u32 *p;
+    u32 W1;      /* words per sequence (W + 1: the word after the last one is read by unaligned extracts) */
+    u32 nm1;     /* masks per side minus one (1 or 3): sequence id = 0 reference, 1 + m - 1 truth mask m, 1 + nm1 + m - 1 query mask m */
+    u32 off_wf;  /* first row of the wavefront byte arrays: hap 0, hap 1, scratch */
+    u32 wfr;     /* rows per wavefront array */
+    u32 wfcap;   /* entries per wavefront array */
+    u32 off_q, qcap;
+    u32 off_opt, optcap;
+    /* the region */
+    u32 L, T, Q, N, ord;
+    u32 vw0[4], vw1[4]; /* slots 0,1 truth, 2,3 query: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 ; alt_ed | raw_space << 8 */
+    u64 seq_len;   /* 8 bits per sequence id */
+    u64 seq_fail;  /* failed_ed per sequence id (generate_allele_sequence, :745-753) */
+    u32 max_branch;
+};
+
+AVK_DEV u32 v_pos(const LCtx &c, u32 s) { return c.vw0[s] & 0xFFu; }
+AVK_DEV u32 v_a0(const LCtx &c, u32 s) { return (c.vw0[s] >> 8) & 0xFFu; }
+AVK_DEV u32 v_a1(const LCtx &c, u32 s) { return (c.vw0[s] >> 16) & 0xFFu; }
+AVK_DEV u32 v_type(const LCtx &c, u32 s) { return (c.vw0[s] >> 24) & 0xFu; }
+AVK_DEV u32 v_zyg(const LCtx &c, u32 s) { return (c.vw0[s] >> 28) & 0x7u; }
+AVK_DEV u32 v_alt_ed(const LCtx &c, u32 s) { return c.vw1[s] & 0xFFu; }
+AVK_DEV u32 v_raw(const LCtx &c, u32 s) { return (c.vw1[s] >> 8) & 0xFFFFu; }
+/* dynamic slot index: a select chain over the four register-resident records */
+AVK_DEV u32 sel4(const u32 (&a)[4], u32 i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+
+AVK_DEV u32 seq_id(const LCtx &c, u32 side, u32 mask) { return mask == 0 ? 0u : 1u + side * c.nm1 + (mask - 1u); }
+AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return (u32)(c.seq_len >> (8 * s)) & 0xFFu; }
+AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return (u32)(c.seq_fail >> (8 * s)) & 0xFFu; }
+
+/* 16 bases of sequence s starting at base `off` (bits beyond the sequence's end are whatever the table holds) */
+AVK_DEV u32 extract16(const LCtx &c, u32 s, u32 off) {
+    const u32 k = off >> 4, sh = (off & 15u) * 2u;
+    const u32 *w = c.p + (s * c.W1 + k) * 64u;
+    const u32 lo = w[0], hi = w[64];
+    return (u32)((((u64)hi << 32) | lo) >> sh);
+}
+
+/* number of positions on which a[ia..la) and b[ib..lb) agree before the first difference or either end */
+AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32 lb) {
+    const u32 ra = la > ia ? la - ia : 0u, rb = lb > ib ? lb - ib : 0u;
+    const u32 lim = ra < rb ? ra : rb;
+    u32 n = 0;
+    while (n < lim) {
+        AVK_LSTAT(0, 1);
+        const u32 x = extract16(c, sa, ia + n) ^ extract16(c, sb, ib + n);
+        if (x) {
+            n += (u32)__builtin_ctz(x) >> 1;
+            break;
+        }
+        n += 16;
+    }
+    return n < lim ? n : lim;
+}
+
+/* ---- wavefront byte arrays ---------------------------------------------------------------- */
+AVK_DEV u8 *wf_ptr(const LCtx &c, u32 arr, u32 i) { return (u8 *)(c.p + (c.off_wf + arr * c.wfr + (i >> 2)) * 64u) + (i & 3u); }
+AVK_DEV u32 wf_get(const LCtx &c, u32 arr, u32 i) { return *wf_ptr(c, arr, i); }
+AVK_DEV void wf_set(const LCtx &c, u32 arr, u32 i, u32 v) { *wf_ptr(c, arr, i) = (u8)v; }
+
+/* DWFALite on (B = sequence sb of length bl, O = sequence so of length ol); wf[i] = symbols of O consumed on diagonal i,
+ * baseline offset = wf[i] + ed - i (dynamic_wfa.rs:114) */
+AVK_DEV void dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) { /* :94-130 */
+    for (u32 i = 0; i <= 2 * ed; ++i) {
+        AVK_LSTAT(1, 1);
+        const u32 d = wf_get(c, arr, i);
+        const u32 bo = d + ed - i;
+        wf_set(c, arr, i, d + match_run(c, sb, bo, bl, so, d, ol));
+    }
+}
+AVK_DEV void dw_bump(const LCtx &c, u32 arr, u32 old_ed) { /* :140-173 without the re-extend; no clipping */
+    const u32 nd = 2 * old_ed + 1;
+    for (int k = (int)nd + 1; k >= 0; --k) {
+        u32 v = 0;
+        if ((u32)k < nd) v = wf_get(c, arr, (u32)k);
+        if (k >= 1 && (u32)(k - 1) < nd) {
+            const u32 t = wf_get(c, arr, (u32)(k - 1)) + 1;
+            v = t > v ? t : v;
+        }
+        if (k >= 2 && (u32)(k - 2) < nd) {
+            const u32 t = wf_get(c, arr, (u32)(k - 2)) + 1;
+            v = t > v ? t : v;
+        }
+        wf_set(c, arr, (u32)k, v);
+    }
+}
+AVK_DEV bool dw_touches_end(const LCtx &c, u32 arr, u32 ed, u32 bl, u32 ol) { /* :220-231 */
+    bool any = false;
+    for (u32 i = 0; i <= 2 * ed; ++i) {
+        const u32 d = wf_get(c, arr, i);
+        any = any || d + ed - i >= bl || d >= ol;
+    }
+    return any;
+}
+AVK_DEV bool dw_full_diagonal(const LCtx &c, u32 arr, u32 ed, u32 bl, u32 ol) { /* :237-245 */
+    bool any = false;
+    for (u32 i = 0; i <= 2 * ed; ++i) {
+        const u32 d = wf_get(c, arr, i);
+        any = any || (d + ed - i >= bl && d >= ol);
+    }
+    return any;
+}
+enum { LS_PARTIAL = 1 }; /* a capped alignment stopped: the distance is MORE than the budget (how much more is not known) */
+/* update (:68-84): extend, then raise the distance until EITHER end is touched; LS_DEFER when the array is too small.
+ * `budget` = the largest distance the caller cares about: LS_PARTIAL as soon as the distance is known to exceed it. */
+AVK_DEV int dw_update(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget) {
+    dw_extend(c, arr, ed, sb, bl, so, ol);
+    while (!dw_touches_end(c, arr, ed, bl, ol)) {
+        if (ed + 1 > budget) return LS_PARTIAL;
+        if (2 * ed + 3 > c.wfcap) return LS_DEFER;
+        dw_bump(c, arr, ed);
+        ed += 1;
+        dw_extend(c, arr, ed, sb, bl, so, ol);
+    }
+    return 0;
+}
+AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget) { /* :183-198 */
+    dw_extend(c, arr, ed, sb, bl, so, ol);
+    while (!dw_full_diagonal(c, arr, ed, bl, ol)) {
+        if (ed + 1 > budget) return LS_PARTIAL;
+        if (2 * ed + 3 > c.wfcap) return LS_DEFER;
+        dw_bump(c, arr, ed);
+        ed += 1;
+        dw_extend(c, arr, ed, sb, bl, so, ol);
+    }
+    return 0;
+}
+/* wfa_ed (src/util/sequence_alignment.rs:9-13) = unit-cost edit distance of two complete sequences, on the scratch array */
+AVK_DEV int wfa_ed(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
+    AVK_LSTAT(6, 1);
+    const u32 lim = la < lb ? la : lb;
+    const u32 d = match_run(c, sa, 0, la, sb, 0, lb);
+    if (d == lim) return (int)((la > lb ? la : lb) - lim);
+    wf_set(c, 2, 0, d);
+    u32 ed = 0;
+    if (dw_finalize(c, 2, ed, sa, la, sb, lb, 0xFFFFu)) return LS_DEFER;
+    return (int)ed;
+}
+
+/* ---- one haplotype of a search node (HaplotypeDWFA, haplotype_dwfa.rs:17-24) ----------------------------------------- */
+struct Hap {
+    u32 t_refpos, q_refpos, t_len, q_len, t_skip, q_skip, nskip;
+    u32 t_alt, q_alt; /* alleles chosen so far: bit j = ALT for the side's call j */
+    u32 t_nal, q_nal;
+    u32 ed, d0;       /* while ed == 0 the wavefront is the single offset d0 */
+};
+AVK_DEV void hap_init(Hap &h) {
+    h.t_refpos = h.q_refpos = h.t_len = h.q_len = h.t_skip = h.q_skip = h.nskip = 0;
+    h.t_alt = h.q_alt = h.t_nal = h.q_nal = h.ed = h.d0 = 0;
+}
+/* HaplotypeDWFA::extend_variant without the aligner update (haplotype_dwfa.rs:46-62, :175-227): lengths and positions only,
+ * the bases are implied by FULL(side, chosen alleles).  has_var false = the two copy_reference(region end) of finalize_dwfa. */
+AVK_DEV bool hap_step(const LCtx &c, Hap &h, bool is_truth, bool has_var, u32 slot, u32 allele, u32 sync) {
+    /* "this" side and the "other" side by value (selects), written back at the end: no addresses into the record are taken */
+    u32 tl = is_truth ? h.t_len : h.q_len, ol = is_truth ? h.q_len : h.t_len;
+    u32 trp = is_truth ? h.t_refpos : h.q_refpos, orp = is_truth ? h.q_refpos : h.t_refpos;
+    u32 tskip = is_truth ? h.t_skip : h.q_skip, tnal = is_truth ? h.t_nal : h.q_nal, talt = is_truth ? h.t_alt : h.q_alt;
+    const u32 n_o = orp < sync ? sync - orp : 0u;
+    u32 n1 = 0, n2 = 0, rp = trp;
+    bool ok = true;
+    if (has_var) {
+        const u32 w0 = sel4(c.vw0, slot);
+        const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+        if (rp < pos) {
+            n1 = pos - rp;
+            rp = pos;
+        }
+        if (allele == L_ALT) {
+            if (rp <= pos) {
+                n2 = a1;
+                rp = pos + a0;
+            } else {
+                tskip += sel4(c.vw1, slot) & 0xFFu; /* edit_distance(allele0, allele1), :199 */
+                h.nskip += 1;
+                ok = false;
+            }
+            talt |= 1u << tnal;
+        }
+        tnal += 1;
+    }
+    const u32 n3 = rp < sync ? sync - rp : 0u;
+    if (rp < sync) rp = sync;
+    ol += n_o;
+    if (n_o) orp = sync;
+    tl += n1 + n2 + n3;
+    trp = rp;
+    h.t_len = is_truth ? tl : ol;
+    h.q_len = is_truth ? ol : tl;
+    h.t_refpos = is_truth ? trp : orp;
+    h.q_refpos = is_truth ? orp : trp;
+    h.t_skip = is_truth ? tskip : h.t_skip;
+    h.q_skip = is_truth ? h.q_skip : tskip;
+    h.t_nal = is_truth ? tnal : h.t_nal;
+    h.q_nal = is_truth ? h.q_nal : tnal;
+    h.t_alt = is_truth ? talt : h.t_alt;
+    h.q_alt = is_truth ? h.q_alt : talt;
+    return ok;
+}
+/* DWFALite::update on the haplotype's two sequences (hap_update of avk_solver.inl) */
+AVK_DEV int hap_update(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
+    const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+    if (h.ed == 0) {
+        h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
+        const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
+        if (h.d0 >= lim) return 0;
+        if (budget == 0) return LS_PARTIAL;
+        if (c.wfcap < 3) return LS_DEFER;
+        wf_set(c, arr, 0, h.d0);
+    }
+    return dw_update(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget);
+}
+AVK_DEV int hap_finalize(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
+    const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+    if (h.ed == 0) {
+        if (h.d0 >= h.t_len && h.d0 >= h.q_len) return 0;
+        if (budget == 0) return LS_PARTIAL;
+        wf_set(c, arr, 0, h.d0);
+    }
+    return dw_finalize(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget);
+}
+/* the search order (order_variants, query_optimizer.rs:372-381): slot of the call at depth d, and the step's sync point */
+AVK_DEV u32 ord_slot(const LCtx &c, u32 d) { return (c.ord >> (2 * d)) & 3u; }
+AVK_DEV u32 sync_after(const LCtx &c, u32 d) { return d + 1 < c.N ? (sel4(c.vw0, ord_slot(c, d + 1)) & 0xFFu) : c.L; }
+
+/* ---- phase A: optimize_sequences ------------------------------------------------------------------------------------- */
+/* a node = two haplotypes; code: 2 bits per depth, bit 0 = ALT on haplotype 1, bit 1 = ALT on haplotype 2 */
+struct NodeA {
+    Hap h[2];
+};
+AVK_DEV u32 nodeA_cost(const NodeA &n) { return n.h[0].t_skip + n.h[0].q_skip + n.h[0].ed + n.h[1].t_skip + n.h[1].q_skip + n.h[1].ed; }
+/* One extension step of both haplotypes.  `cap` = the largest total node cost the caller cares about: the search only needs a
+ * node's exact cost when the node can still be the next pop, and most wrongly phased branches never are — their alignments stop at
+ * the first edit that proves cost > cap instead of running to a distance of tens (returns LS_PARTIAL and a lower bound > cap). */
+AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice, u32 cap, u32 &lb) {
+    const u32 slot = ord_slot(c, d);
+    const bool is_truth = slot < 2;
+    const u32 sync = sync_after(c, d);
+    AVK_LSTAT(2, 1);
+    hap_step(c, n.h[0], is_truth, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
+    hap_step(c, n.h[1], is_truth, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
+    const u32 base = n.h[0].t_skip + n.h[0].q_skip + n.h[1].t_skip + n.h[1].q_skip;
+    lb = base + n.h[0].ed + n.h[1].ed; /* distances never decrease */
+    if (lb > cap) return LS_PARTIAL;
+    const u32 b0 = cap - base - n.h[1].ed;
+    int r = hap_update(c, n.h[0], 0, b0);
+    if (r == LS_PARTIAL) lb = cap + 1;
+    if (r) return r;
+    const u32 b1 = cap - base - n.h[0].ed;
+    r = hap_update(c, n.h[1], 1, b1);
+    if (r == LS_PARTIAL) lb = cap + 1;
+    return r;
+}
+AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice) {
+    u32 lb;
+    return nodeA_step(c, n, d, choice, 0xFFFFu, lb);
+}
+AVK_DEV int nodeA_replay(const LCtx &c, NodeA &n, u32 code, u32 depth) {
+    hap_init(n.h[0]);
+    hap_init(n.h[1]);
+    AVK_LSTAT(7, depth);
+    for (u32 d = 0; d < depth; ++d)
+        if (nodeA_step(c, n, d, (code >> (2 * d)) & 3u)) return LS_DEFER;
+    return 0;
+}
+/* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95); LS_PARTIAL: the final cost is more than `cap` */
+AVK_DEV int nodeA_finalize(const LCtx &c, NodeA &n, u32 cap = 0xFFFFu) {
+    hap_step(c, n.h[0], true, false, 0, L_REF, c.L);
+    hap_step(c, n.h[1], true, false, 0, L_REF, c.L);
+    const u32 base = n.h[0].t_skip + n.h[0].q_skip + n.h[1].t_skip + n.h[1].q_skip;
+    if (base + n.h[0].ed + n.h[1].ed > cap) return LS_PARTIAL;
+    int r = hap_update(c, n.h[0], 0, cap - base - n.h[1].ed);
+    if (r) return r;
+    r = hap_finalize(c, n.h[0], 0, cap - base - n.h[1].ed);
+    if (r) return r;
+    r = hap_update(c, n.h[1], 1, cap - base - n.h[0].ed);
+    if (r) return r;
+    return hap_finalize(c, n.h[1], 1, cap - base - n.h[0].ed);
+}
+/* pops the smallest queue word (the entries of both searches are built so that this is the reference's next pop) */
+AVK_DEV u32 q_pop_min(const LCtx &c, u32 &qn) {
+    u32 best = 0xFFFFFFFFu, bi = 0;
+    for (u32 i = 0; i < qn; ++i) {
+        const u32 e = c.p[(c.off_q + i) * 64u];
+        if (e < best) {
+            best = e;
+            bi = i;
+        }
+    }
+    qn -= 1;
+    c.p[(c.off_q + bi) * 64u] = c.p[(c.off_q + qn) * 64u];
+    return best;
+}
+AVK_DEV int q_push(const LCtx &c, u32 &qn, u32 e) {
+    if (qn >= c.qcap) return LS_DEFER;
+    c.p[(c.off_q + qn) * 64u] = e;
+    qn += 1;
+    return 0;
+}
+AVK_DEV u32 opt_get(const LCtx &c, u32 k) { return *((u8 *)(c.p + (c.off_opt + (k >> 2)) * 64u) + (k & 3u)); }
+AVK_DEV void opt_set(const LCtx &c, u32 k, u32 v) { *((u8 *)(c.p + (c.off_opt + (k >> 2)) * 64u) + (k & 3u)) = (u8)v; }
+
+/* Queue words of phase A: cost << 20 | id << 12 | code << 4 | partial << 3 | depth.  A `partial` entry carries a LOWER BOUND of the
+ * node's cost (its last step was stopped early, nodeA_step).  The reference pops the minimum of (cost, id); here the minimum word is
+ * popped, and when it is partial its cost is worked out further — up to the next entry's cost, which is as far as it can matter —
+ * and it goes back into the queue unless it turns out to cost exactly what it was popped for.  Lower bounds never exceed the true
+ * cost, ids are unique, so the sequence of REAL pops (and with it ids, quota counts and the order of tied optima) is the reference's. */
+AVK_DEV u32 q_min_cost(const LCtx &c, u32 qn) {
+    u32 best = 0xFFFFFFFFu;
+    for (u32 i = 0; i < qn; ++i) {
+        const u32 e = c.p[(c.off_q + i) * 64u];
+        best = e < best ? e : best;
+    }
+    return qn ? best >> 20 : 0xFFFFu;
+}
+AVK_DEV u32 keyA(u32 cost, u32 id, u32 code, u32 partial, u32 depth) { return (cost << 20) | (id << 12) | (code << 4) | (partial << 3) | depth; }
+
+/* returns the number of tied optima (codes in the opt array, in the order the reference finds them), LS_DEFER, or -100 - status */
+AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
+    u32 qn = 0;
+    q_push(c, qn, 0);
+    u32 next_id = 1, best = 0xFFFFu, nbest = 0;
+    u32 bucket = 0; /* 6 bits per depth: a depth sees at most 2^4 pops */
+    while (qn > 0) {
+        const u32 e = q_pop_min(c, qn);
+        const u32 cost = e >> 20;
+        if (cost > best) break; /* :204; pops come in non-decreasing cost order */
+        AVK_LSTAT(3, 1);
+        AVK_LSTAT(4, (e >> 3) & 1u);
+        const u32 depth = e & 7u, code = (e >> 4) & 0xFFu, id = (e >> 12) & 0xFFu;
+        NodeA n;
+        if (e & 8u) { /* partial: ancestors are exact (they were popped), the last step is taken further */
+            /* as far as it can matter for the order (the next entry's cost), and at least doubling, so that a node that really is
+             * expensive is taken up a logarithmic number of times; never beyond the best finished cost (:204 drops it there) */
+            u32 cap = q_min_cost(c, qn);
+            cap = cap > 2 * cost + 2 ? cap : 2 * cost + 2;
+            cap = cap < best ? cap : best;
+            cap = cap > cost ? cap : cost;
+            if (nodeA_replay(c, n, code, depth - 1)) return LS_DEFER;
+            u32 lb = 0;
+            const int r = nodeA_step(c, n, depth - 1, (code >> (2 * (depth - 1))) & 3u, cap, lb);
+            if (r == LS_DEFER) return LS_DEFER;
+            if (r == LS_PARTIAL) {
+                if (q_push(c, qn, keyA(lb, id, code, 1, depth))) return LS_DEFER;
+                continue;
+            }
+            const u32 full = nodeA_cost(n);
+            if (full != cost) {
+                if (q_push(c, qn, keyA(full, id, code, 0, depth))) return LS_DEFER;
+                continue;
+            }
+        }
+        const u32 cnt = (bucket >> (6 * depth)) & 0x3Fu;
+        if (cnt >= c.max_branch) continue; /* :222 */
+        bucket += 1u << (6 * depth);
+        if (!(e & 8u) && nodeA_replay(c, n, code, depth)) return LS_DEFER;
+        if (depth == c.N) { /* :227-247 */
+            const int r = nodeA_finalize(c, n, best);
+            if (r == LS_DEFER) return LS_DEFER;
+            if (r == LS_PARTIAL) continue; /* costs more than the best: neither kept nor tied */
+            const u32 fc = nodeA_cost(n);
+            if (fc < best) {
+                best = fc;
+                nbest = 0;
+            }
+            if (fc == best) {
+                if (nbest >= c.optcap) return LS_DEFER;
+                opt_set(c, nbest, code);
+                nbest += 1;
+            }
+            continue;
+        }
+        const u32 slot = ord_slot(c, depth);
+        const bool is_truth = slot < 2;
+        const u32 zyg = (sel4(c.vw0, slot) >> 28) & 7u;
+        const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
+        u32 lb = 0;
+        if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
+            NodeA m = n;
+            /* the first child works on the arrays of `n`; the second is replayed from the root (the arrays hold child 1 by then) */
+            int r = nodeA_step(c, n, depth, 2u, cost, lb);
+            if (r == LS_DEFER) return LS_DEFER;
+            if (q_push(c, qn, keyA(r ? lb : nodeA_cost(n), next_id, code | (2u << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
+            next_id += 1;
+            if (m.h[0].ed | m.h[1].ed) { /* parent wavefronts were overwritten */
+                if (nodeA_replay(c, m, code, depth)) return LS_DEFER;
+            }
+            r = nodeA_step(c, m, depth, 1u, cost, lb);
+            if (r == LS_DEFER) return LS_DEFER;
+            if (q_push(c, qn, keyA(r ? lb : nodeA_cost(m), next_id, code | (1u << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
+            next_id += 1;
+        } else { /* :294-327: the node is moved, its id kept */
+            u32 choice = 3u;
+            if (het) choice = zyg == AVK_ZYG_PHASED_HET01 ? 2u : 1u; /* 0|1: REF on haplotype 1, ALT on haplotype 2 */
+            const int r = nodeA_step(c, n, depth, choice, cost, lb);
+            if (r == LS_DEFER) return LS_DEFER;
+            if (q_push(c, qn, keyA(r ? lb : nodeA_cost(n), id, code | (choice << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
+        }
+        if (next_id > 250) return LS_DEFER;
+    }
+    if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
+    best_out = best;
+    return (int)nbest;
+}
+
+/* ---- phase B: optimize_gt_alleles for one haplotype ------------------------------------------------------------------ */
+/* The aligner of an ExactMatchNode has max_edit_distance 0 (:380): a live node is `exact`, its wavefront the single offset d0.
+ * code: bit d = the allele assigned at depth d is ALT.  Entry: errors << 28 | (15 - (depth - errors)) << 24 | id << 12 | code << 4 | depth
+ * (Reverse(errors), set - errors, Reverse(id); :452-458). */
+AVK_DEV bool hapB_step(const LCtx &c, Hap &h, u32 d, bool alt) {
+    const u32 slot = ord_slot(c, d);
+    const bool ok = hap_step(c, h, slot < 2, true, slot, alt ? L_ALT : L_REF, sync_after(c, d));
+    const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+    h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
+    const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
+    return ok && h.d0 >= lim;
+}
+AVK_DEV u32 keyB(u32 errors, u32 depth, u32 id, u32 code) { return (errors << 28) | ((15u - (depth - errors)) << 24) | (id << 12) | (code << 4) | depth; }
+/* in_t / in_q: the haplotype's input alleles (bit j = ALT for the side's call j).  Returns the number of flips and the final
+ * alleles, LS_DEFER, or -100 - status. */
+AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
+    u32 qn = 0;
+    q_push(c, qn, keyB(0, 0, 0, 0));
+    u32 next_id = 1, min_sync = 0;
+    while (qn > 0) {
+        const u32 e = q_pop_min(c, qn);
+        const u32 errors = e >> 28, depth = e & 0xFu, code = (e >> 4) & 0xFFu, id = (e >> 12) & 0xFFFu;
+        Hap h;
+        hap_init(h);
+        for (u32 d = 0; d < depth; ++d) hapB_step(c, h, d, (code >> d) & 1u);
+        if (depth == c.N) { /* :180-192 */
+            hap_step(c, h, true, false, 0, L_REF, c.L);
+            const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+            h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
+            if (h.d0 >= h.t_len && h.d0 >= h.q_len) {
+                res_t = h.t_alt;
+                res_q = h.q_alt;
+                return (int)errors;
+            }
+            continue;
+        }
+        if (depth < min_sync) continue;                                   /* :194-197 */
+        if (h.t_len == h.q_len && h.t_refpos == h.q_refpos) min_sync = depth; /* :206-217 (fewer than 500 expansions: no auto-fail) */
+        const u32 slot = ord_slot(c, depth);
+        const bool is_truth = slot < 2;
+        const bool cur_alt = (((is_truth ? in_t : in_q) >> (is_truth ? slot : slot - 2u)) & 1u) != 0;
+        if (!cur_alt) { /* :257-273 */
+            if (hapB_step(c, h, depth, false)) {
+                if (q_push(c, qn, keyB(errors, depth + 1, id, code))) return LS_DEFER;
+            }
+        } else { /* :274-306: (REF, error) first, then ALT */
+            Hap r = h;
+            if (hapB_step(c, r, depth, false)) {
+                if (q_push(c, qn, keyB(errors + 1, depth + 1, next_id, code))) return LS_DEFER;
+            }
+            next_id += 1;
+            if (hapB_step(c, h, depth, true)) {
+                if (q_push(c, qn, keyB(errors, depth + 1, next_id, code | (1u << depth)))) return LS_DEFER;
+            }
+            next_id += 1;
+        }
+        if (next_id > 4000) return LS_DEFER;
+    }
+    return -100 - AVK_ST_NO_GT_RESULT; /* :345-348 */
+}
+
+/* wfa_ed(reference window, FULL(side, mask)).  No alleles: 0.  One call whose alt_ed is 1 (the haplotype differs from the window
+ * and one edit makes them equal) or equals the length difference of its alleles (any alignment needs at least that many edits, and
+ * alt_ed edits suffice): alt_ed, without aligning.  Anything else is aligned. */
+AVK_DEV int ed_to_ref(const LCtx &c, u32 side, u32 mask, u32 len) {
+    if (mask == 0) return 0;
+    if ((mask & (mask - 1)) == 0) {
+        const u32 slot = 2 * side + (mask == 1 ? 0u : 1u);
+        const u32 w0 = sel4(c.vw0, slot), e = sel4(c.vw1, slot) & 0xFFu;
+        const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+        const u32 diff = a0 > a1 ? a0 - a1 : a1 - a0;
+        if (e == 1 || (e && e == diff)) return (int)e;
+    }
+    return wfa_ed(c, 0, c.L, seq_id(c, side, mask), len);
+}
+
+/* the genotype assignment of one haplotype of an optimum: flips, observed alleles */
+AVK_DEV int gt_for_hap(const LCtx &c, const Hap &h, u32 &rt, u32 &rq) {
+    if (h.ed == 0 && h.nskip == 0) { /* truth == query with every ALT incorporated: the zero-flip path wins (exact_gt_optimizer.rs:169-192) */
+        rt = h.t_alt;
+        rq = h.q_alt;
+        return 0;
+    }
+    rt = rq = 0;
+    return phaseB(c, h.t_alt, h.q_alt, rt, rq);
+}
+
+/* ---- region staging -------------------------------------------------------------------------------------------------- */
+struct SeqWriter {
+    u64 acc;
+    u32 nb, row, k;
+};
+AVK_DEV void sw_push(const LCtx &c, SeqWriter &w, u32 bits, u32 nbases) {
+    if (nbases == 0) return;
+    const u64 m = nbases >= 16 ? 0xFFFFFFFFull : ((1ull << (2 * nbases)) - 1ull);
+    w.acc |= ((u64)bits & m) << w.nb;
+    w.nb += 2 * nbases;
+    if (w.nb >= 32) {
+        c.p[(w.row * c.W1 + w.k) * 64u] = (u32)w.acc;
+        w.k += 1;
+        w.acc >>= 32;
+        w.nb -= 32;
+    }
+}
+AVK_DEV void sw_ref(const LCtx &c, SeqWriter &w, u32 from, u32 to) {
+    for (u32 p = from; p < to; p += 16) sw_push(c, w, extract16(c, 0, p), to - p < 16 ? to - p : 16u);
+}
+/* FULL(side, mask): the calls of the mask applied in the side's order, a call that starts before the end of the previous applied one
+ * is dropped and its alt_ed counted (generate_allele_sequence, waffle_solver.rs:726-778) */
+template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)[4], const u32 (&a1hi)[4]) {
+    const u32 s = seq_id(c, side, mask), cnt = side == 0 ? c.T : c.Q;
+    SeqWriter w;
+    w.acc = 0;
+    w.nb = 0;
+    w.row = s;
+    w.k = 0;
+    u32 cur = 0, len = 0, failed = 0;
+#pragma unroll
+    for (u32 j = 0; j < 2; ++j) { /* static slot indices: the records stay in registers */
+        if (j >= cnt || !((mask >> j) & 1u)) continue;
+        const u32 slot = 2 * side + j;
+        const u32 w0 = c.vw0[slot];
+        const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+        if (pos < cur) {
+            failed += c.vw1[slot] & 0xFFu;
+            continue;
+        }
+        sw_ref(c, w, cur, pos);
+        sw_push(c, w, a1lo[slot], a1 < 16 ? a1 : 16u);
+        if (a1 > 16) sw_push(c, w, a1hi[slot], a1 - 16);
+        len += pos - cur + a1;
+        cur = pos + a0;
+    }
+    if (cur < c.L) {
+        sw_ref(c, w, cur, c.L);
+        len += c.L - cur;
+    }
+    if (w.nb) c.p[(w.row * c.W1 + w.k) * 64u] = (u32)w.acc;
+    c.seq_len |= (u64)len << (8 * s);
+    c.seq_fail |= (u64)failed << (8 * s);
+}
+
+/* ---- one region ------------------------------------------------------------------------------------------------------ */
+struct LaneOut {
+    u32 ed1, ed2, n_opt, present;
+};
+/* 22 counters of one metric group, in the field order of include/aardvark_amd.h */
+struct Group22 {
+    u32 f[AVK_N_FIELDS];
+};
+/* GroupMetrics::add_truth_zygosity (grouped_metrics.rs:183-227); query calls are scored as truth and land in the query columns
+ * (add_swap_benchmark, grouped_metrics.rs:268-277) */
+template <bool q> AVK_DEV void g_add(Group22 &g, u32 w, u32 exp, u32 obs) {
+    const int f_gt_tp = q ? AVK_F_GT_QUERY_TP : AVK_F_GT_TRUTH_TP, f_gt_fn = q ? AVK_F_GT_QUERY_FP : AVK_F_GT_TRUTH_FN;
+    const int f_gt_fn_gt = q ? AVK_F_GT_QUERY_FP_GT : AVK_F_GT_TRUTH_FN_GT;
+    const int f_hap_tp = q ? AVK_F_HAP_QUERY_TP : AVK_F_HAP_TRUTH_TP, f_hap_fn = q ? AVK_F_HAP_QUERY_FP : AVK_F_HAP_TRUTH_FN;
+    const int f_w_tp = q ? AVK_F_WHAP_QUERY_TP : AVK_F_WHAP_TRUTH_TP, f_w_fn = q ? AVK_F_WHAP_QUERY_FP : AVK_F_WHAP_TRUTH_FN;
+    /* branch-free form of the two cases (equal: everything expected was observed; fewer: the difference is missed) */
+    const u32 eq = exp == obs ? 1u : 0u;
+    g.f[f_hap_tp] += obs;
+    g.f[f_hap_fn] += exp - obs;
+    g.f[f_w_tp] += obs * w;
+    g.f[f_w_fn] += (exp - obs) * w;
+    g.f[f_gt_tp] += eq;
+    g.f[f_gt_fn] += 1u - eq;
+    g.f[f_gt_fn_gt] += (1u - eq) & (obs > 0 ? 1u : 0u);
+}
+
+struct LaneArgs { /* what a launch of the lane kernel needs besides AvkKernelArgs' outputs */
+    const u32 *recs;     /* fast records, tile-major: word w of lane l of tile t at recs[(t * AVK_FAST_WORDS + w) * 64 + l] */
+    u32 tile_base, n_tiles;
+    u32 *tile_counter;
+    u32 W, nm, ed_max, qcap; /* the class of this launch */
+    u32 gen_base;        /* record index (work order of the wave-per-region kernels) of fast record 0 */
+};
+
+/* returns AVK_ST_* (>= 0) or LS_DEFER.  `tally` = the workgroup's LDS tally (u32 counters). */
+AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane_stride, LaneOut &out, u32 *tally) {
+    const u32 h0 = rec[0], h1 = rec[1 * lane_stride], v_off = rec[2 * lane_stride], orig = rec[3 * lane_stride];
+    const u32 shift = h1 & 15u;
+    c.L = (h1 >> 4) & 0xFFu;
+    c.T = (h1 >> 12) & 3u;
+    c.Q = (h1 >> 14) & 3u;
+    c.N = c.T + c.Q;
+    c.ord = (h1 >> 16) & 0xFFu;
+    c.max_branch = a.max_branch_factor;
+    c.seq_len = c.L;
+    c.seq_fail = 0;
+    u32 a1lo[4], a1hi[4];
+    u32 types = 0;
+#pragma unroll
+    for (u32 s = 0; s < 4; ++s) {
+        const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
+        c.vw0[s] = c.vw1[s] = a1lo[s] = a1hi[s] = 0;
+        if (on) {
+            const u32 *v = rec + (AVK_FAST_HDR + 4 * s) * lane_stride;
+            c.vw0[s] = v[0];
+            c.vw1[s] = v[1 * lane_stride];
+            a1lo[s] = v[2 * lane_stride];
+            a1hi[s] = v[3 * lane_stride];
+            types |= 1u << ((c.vw0[s] >> 24) & 0xFu);
+        }
+    }
+    /* reference window: 2 bits per base from the packed genome; a flagged word (anything but upper-case ACGT) is not for this kernel */
+    {
+        const u32 nw = (c.L + shift + 15u) >> 4; /* packed words the window touches */
+        bool exc = false;
+        for (u32 k = 0; k < nw; ++k) {
+            const u64 w = (u64)h0 + k;
+            exc = exc || ((a.ref_exc[w >> 5] >> (w & 31)) & 1u);
+        }
+        if (exc) return LS_DEFER;
+        u32 prev = a.ref_2bit[h0];
+        for (u32 k = 0; k < c.W1; ++k) {
+            u32 word = 0;
+            if (k * 16 < c.L) {
+                const u32 next = a.ref_2bit[(u64)h0 + k + 1];
+                word = (u32)((((u64)next << 32) | prev) >> (2 * shift));
+                prev = next;
+            }
+            c.p[k * 64u] = word;
+        }
+    }
+    for (u32 m = 1; m <= c.nm1; ++m) {
+        if (m < (1u << c.T)) build_full<0>(c, m, a1lo, a1hi);
+        if (m < (1u << c.Q)) build_full<1>(c, m, a1lo, a1hi);
+    }
+
+    /* ---- phase A */
+    AVK_LSTAT(5, 1);
+    u32 best_cost = 0;
+    const int nopt = phaseA(c, best_cost);
+    if (nopt == LS_DEFER) return LS_DEFER;
+    if (nopt < 0) return -nopt - 100;
+    out.n_opt = (u32)nopt;
+    if (a.mode == 1) { /* merge_solver.rs:137-143 */
+        out.ed1 = best_cost == 0 ? 1u : 0u;
+        return AVK_ST_OK;
+    }
+
+    /* ---- phase B for every tied optimum (waffle_solver.rs:169-261); the first optimum with the fewest flips wins (:264-265) */
+    u32 best_total = 0xFFFFFFFFu;
+    u32 o_t0 = 0, o_q0 = 0, o_t1 = 0, o_q1 = 0; /* observed alleles of the winner, per haplotype and side */
+    NodeA wn;
+    for (u32 k = 0; k < (u32)nopt; ++k) {
+        const u32 code = opt_get(c, k);
+        NodeA n;
+        if (nodeA_replay(c, n, code, c.N)) return LS_DEFER;
+        if (nodeA_finalize(c, n)) return LS_DEFER;
+        u32 rt0, rq0, rt1, rq1;
+        const int e0 = gt_for_hap(c, n.h[0], rt0, rq0);
+        if (e0 == LS_DEFER) return LS_DEFER;
+        if (e0 < 0) return -e0 - 100;
+        const int e1 = gt_for_hap(c, n.h[1], rt1, rq1);
+        if (e1 == LS_DEFER) return LS_DEFER;
+        if (e1 < 0) return -e1 - 100;
+        const u32 total = (u32)e0 + (u32)e1;
+        if (total < best_total) {
+            best_total = total;
+            wn = n;
+            o_t0 = rt0;
+            o_q0 = rq0;
+            o_t1 = rt1;
+            o_q1 = rq1;
+            if (total == 0) break;
+        }
+    }
+    out.ed1 = wn.h[0].ed;
+    out.ed2 = wn.h[1].ed;
+
+    /* ---- phase C: compare_expected_observed (:296-327) + per-call outputs */
+    u32 exp_pack = 0, obs_pack = 0; /* 2 bits per call slot */
+    int bad = 0;
+#pragma unroll
+    for (u32 s = 0; s < 4; ++s) {
+        const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
+        const u32 side = s >> 1, j = s & 1u;
+        const u32 b0 = ((side ? wn.h[0].q_alt : wn.h[0].t_alt) >> j) & 1u, b1 = ((side ? wn.h[1].q_alt : wn.h[1].t_alt) >> j) & 1u;
+        const u32 o0 = ((side ? o_q0 : o_t0) >> j) & 1u, o1 = ((side ? o_q1 : o_t1) >> j) & 1u;
+        const u32 ex = on ? b0 + b1 : 0u, ob = on ? o0 + o1 : 0u;
+        exp_pack |= ex << (2 * s);
+        obs_pack |= ob << (2 * s);
+        if (!on) continue;
+        if (ex == 0) bad = AVK_ST_VARIANT_METRICS;
+        else if (ex < ob) bad = AVK_ST_TRUTH_FP;
+        u32 cls = ex == ob ? AVK_CLASS_TP : AVK_CLASS_FN;
+        u32 ea = ex, oa = ob;
+        if (side) {
+            if (cls == AVK_CLASS_FN) cls = AVK_CLASS_FP;
+            ea = ob;
+            oa = ex;
+        }
+        const u32 rz = b0 && b1 ? AVK_ZYG_HOM_ALT : (b0 ? AVK_ZYG_PHASED_HET10 : AVK_ZYG_PHASED_HET01);
+        a.var_out[v_off + (side ? c.T + j : j)] = ea | (oa << 8) | (cls << 16) | (rz << 24);
+    }
+    if (bad) return bad;
+
+    /* add_basepair_stats (:335-449): per haplotype X = 2 ed(ref, truth), Y = 2 ed(ref, query), Z = 2 ed(truth, query) */
+    const u32 SUPMASK = (1u << AVK_VT_SNV) | (1u << AVK_VT_INSERTION) | (1u << AVK_VT_DELETION) | (1u << AVK_VT_INDEL) | (1u << AVK_VT_TR_CONTRACTION) |
+                        (1u << AVK_VT_TR_EXPANSION) | (1u << AVK_VT_SV_DELETION) | (1u << AVK_VT_SV_INSERTION);
+    out.present = types | SUPMASK;
+    u32 X0 = 0, Y0 = 0, tp0 = 0, X1 = 0, Y1 = 0, tp1 = 0;
+    for (u32 hh = 0; hh < 2; ++hh) {
+        const Hap &h = hh ? wn.h[1] : wn.h[0];
+        int ert = 0, erq = 0;
+        if (h.t_alt) {
+            ert = ed_to_ref(c, 0, h.t_alt, h.t_len);
+            if (ert < 0) return LS_DEFER;
+        }
+        if (h.q_alt) {
+            if (h.ed == 0 && h.t_alt) erq = ert;
+            else {
+                erq = ed_to_ref(c, 1, h.q_alt, h.q_len);
+                if (erq < 0) return LS_DEFER;
+            }
+        } else if (h.ed == 0) erq = ert;
+        const u32 Xh = 2u * (u32)ert, Yh = 2u * (u32)erq, tph = (Xh + Yh - 2u * h.ed) / 2u;
+        if (hh) {
+            X1 = Xh;
+            Y1 = Yh;
+            tp1 = tph;
+        } else {
+            X0 = Xh;
+            Y0 = Yh;
+            tp0 = tph;
+        }
+    }
+    /* Alignments of the per-type groups (:383-445), done BEFORE anything is added to the tally (they can still hand the region over):
+     * a side with two calls of different types is compared once with only its first and once with only its second call, per haplotype.
+     * 8 bits each: x = ed(ref, filtered side), z = ed(filtered side, other side as it is); entry (hap, j) at bits 16 * (2 * hap + j). */
+    u64 tfilt = 0, qfilt = 0;
+    const bool t_split = c.T == 2 && ((c.vw0[0] ^ c.vw0[1]) >> 24 & 0xFu) != 0, q_split = c.Q == 2 && ((c.vw0[2] ^ c.vw0[3]) >> 24 & 0xFu) != 0;
+    if (t_split || q_split) {
+        for (u32 hh = 0; hh < 2; ++hh) {
+            const Hap &h = hh ? wn.h[1] : wn.h[0];
+            const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+            const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
+            for (u32 j = 0; j < 2; ++j) {
+                if (t_split) {
+                    const u32 m = h.t_alt & (1u << j);
+                    u32 x2 = 0, z2 = Yh / 2; /* nothing left of the truth side: it is the reference window */
+                    if (m) {
+                        const u32 sf = seq_id(c, 0, m), fl = seq_len_of(c, sf);
+                        const int x = ed_to_ref(c, 0, m, fl);
+                        const int z = wfa_ed(c, sf, fl, sq, h.q_len);
+                        if (x < 0 || z < 0) return LS_DEFER;
+                        x2 = (u32)x;
+                        z2 = (u32)z;
+                    }
+                    tfilt |= (u64)(x2 | (z2 << 8)) << (16 * (2 * hh + j));
+                }
+                if (q_split) {
+                    const u32 m = h.q_alt & (1u << j);
+                    u32 y2 = 0, z2 = Xh / 2;
+                    if (m) {
+                        const u32 sf = seq_id(c, 1, m), fl = seq_len_of(c, sf);
+                        const int y = ed_to_ref(c, 1, m, fl);
+                        const int z = wfa_ed(c, st, h.t_len, sf, fl);
+                        if (y < 0 || z < 0) return LS_DEFER;
+                        y2 = (u32)y;
+                        z2 = (u32)z;
+                    }
+                    qfilt |= (u64)(y2 | (z2 << 8)) << (16 * (2 * hh + j));
+                }
+            }
+        }
+    }
+    /* groups that can hold anything: the joint one and one per call type of the region */
+    u32 *gm_out = a.group_metrics ? a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS : (u32 *)0;
+    if (gm_out)
+        for (u32 i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) gm_out[i] = 0;
+    /* The joint group comes first (bit 0): its RECORD_BP check is the only way the region can still fail, so nothing has been added to
+     * the tally when it does; every alignment has been made above. */
+    for (u32 left = 1u | (types << 1); left; left &= left - 1) {
+        const u32 g = (u32)__builtin_ctz(left);
+        Group22 G;
+#pragma unroll
+        for (int i = 0; i < AVK_N_FIELDS; ++i) G.f[i] = 0;
+        u32 tot_t = 0, tot_q = 0, tcount = 0, qcount = 0;
+        u32 tmask_g = 0, qmask_g = 0; /* the side's calls of this group's type */
+#pragma unroll
+        for (u32 s = 0; s < 4; ++s) {
+            const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
+            const u32 w0 = c.vw0[s], w1 = c.vw1[s];
+            const u32 vt = (w0 >> 24) & 0xFu, z = (w0 >> 28) & 7u;
+            if (!on || (g != 0 && vt != g - 1)) continue;
+            if (s >= 2) g_add<true>(G, w1 & 0xFFu, (exp_pack >> (2 * s)) & 3u, (obs_pack >> (2 * s)) & 3u); /* static field indices */
+            else g_add<false>(G, w1 & 0xFFu, (exp_pack >> (2 * s)) & 3u, (obs_pack >> (2 * s)) & 3u);
+            const u32 cntz = z == AVK_ZYG_HOM_ALT ? 2u : ((z == AVK_ZYG_UNPHASED_HET || z == AVK_ZYG_PHASED_HET01 || z == AVK_ZYG_PHASED_HET10) ? 1u : 0u);
+            const u32 val = cntz * ((w1 >> 8) & 0xFFFFu);
+            if (s < 2) {
+                tot_t += val;
+                tcount += 1;
+                tmask_g |= 1u << s;
+            } else {
+                tot_q += val;
+                qcount += 1;
+                qmask_g |= 1u << (s - 2);
+            }
+        }
+        if (g == 0) {
+            G.f[AVK_F_BP_TRUTH_TP] += tp0 + tp1;
+            G.f[AVK_F_BP_TRUTH_FN] += X0 - tp0 + 2 * wn.h[0].t_skip + X1 - tp1 + 2 * wn.h[1].t_skip; /* + skip metrics :378-381 */
+            G.f[AVK_F_BP_QUERY_TP] += tp0 + tp1;
+            G.f[AVK_F_BP_QUERY_FP] += Y0 - tp0 + 2 * wn.h[0].q_skip + Y1 - tp1 + 2 * wn.h[1].q_skip;
+        } else if ((SUPMASK >> (g - 1)) & 1u) { /* :383-445: one side filtered to the type against the other side as it is */
+            for (u32 hh = 0; hh < 2; ++hh) {
+                const Hap &h = hh ? wn.h[1] : wn.h[0];
+                const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0, tph = hh ? tp1 : tp0;
+                u32 q_tp = 0, q_fp = 0, t_tp = 0, t_fn = 0;
+                if (qcount) {
+                    if (qcount == c.Q) {
+                        q_tp = tph;
+                        q_fp = Yh - tph + 2 * h.q_skip;
+                    } else { /* one of two calls: the alignments were made above */
+                        const u32 sf = seq_id(c, 1, h.q_alt & qmask_g);
+                        const u32 e = (u32)(qfilt >> (16 * (2 * hh + (qmask_g == 1 ? 0u : 1u)))) & 0xFFFFu;
+                        const u32 y2 = e & 0xFFu, z2 = e >> 8;
+                        const u32 tp2 = (Xh + 2u * y2 - 2u * z2) / 2u;
+                        q_tp = tp2;
+                        q_fp = 2u * y2 - tp2 + 2 * seq_fail_of(c, sf);
+                    }
+                }
+                if (tcount) {
+                    if (tcount == c.T) {
+                        t_tp = tph;
+                        t_fn = Xh - tph + 2 * h.t_skip;
+                    } else {
+                        const u32 sf = seq_id(c, 0, h.t_alt & tmask_g);
+                        const u32 e = (u32)(tfilt >> (16 * (2 * hh + (tmask_g == 1 ? 0u : 1u)))) & 0xFFFFu;
+                        const u32 x2 = e & 0xFFu, z2 = e >> 8;
+                        const u32 tp2 = (2u * x2 + Yh - 2u * z2) / 2u;
+                        t_tp = tp2;
+                        t_fn = 2u * x2 - tp2 + 2 * seq_fail_of(c, sf);
+                    }
+                }
+                G.f[AVK_F_BP_TRUTH_TP] += t_tp;
+                G.f[AVK_F_BP_TRUTH_FN] += t_fn;
+                G.f[AVK_F_BP_QUERY_TP] += q_tp;
+                G.f[AVK_F_BP_QUERY_FP] += q_fp;
+            }
+        }
+        /* add_record_basepair_stats (:455-522) */
+        {
+            const u32 tfn = G.f[AVK_F_BP_TRUTH_FN], qfp = G.f[AVK_F_BP_QUERY_FP];
+            const u32 ttp = 2 * tot_t - tfn, qtp = 2 * tot_q - qfp;
+            if (g == 0 && (ttp < G.f[AVK_F_BP_TRUTH_TP] || qtp < G.f[AVK_F_BP_QUERY_TP])) return AVK_ST_RECORD_BP;
+            G.f[AVK_F_RBP_TRUTH_TP] += ttp;
+            G.f[AVK_F_RBP_TRUTH_FN] += tfn;
+            G.f[AVK_F_RBP_QUERY_TP] += qtp;
+            G.f[AVK_F_RBP_QUERY_FP] += qfp;
+        }
+#pragma unroll
+        for (int i = 0; i < AVK_N_FIELDS; ++i) {
+            const u32 v = G.f[i];
+            if (!v) continue;
+            avk_atomic_add_u32(tally + g * AVK_N_FIELDS + i, v);
+            if (gm_out) gm_out[g * AVK_N_FIELDS + i] = v;
+        }
+    }
+    return AVK_ST_OK;
+}
+
+/* LDS words per wave for a launch class */
+AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap, u32 optcap) {
+    const u32 ns = 1 + 2 * (nm - 1);
+    const u32 wfr = (2 * ed_max + 2 + 3) / 4;
+    return ns * (W + 1) + 3 * wfr + qcap + (optcap + 3) / 4;
+}
+
+/* One persistent wave: claims tiles of 64 fast records, every lane solves its record.  wave_lds = this wave's rows, wg_tally =
+ * the workgroup's 288 tally words in LDS (zeroed by the caller, flushed by the caller). */
+AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id, u32 *wave_lds, u32 *wg_tally, u32 &n_ok_out, u32 &n_err_out) {
+    const u32 lane = (u32)wv_lane();
+    LCtx c;
+    c.p = wave_lds + lane;
+    c.W1 = la.W + 1;
+    c.nm1 = la.nm - 1;
+    c.off_wf = (1 + 2 * c.nm1) * c.W1;
+    c.wfr = (2 * la.ed_max + 2 + 3) / 4;
+    c.wfcap = 2 * la.ed_max + 2;
+    c.off_q = c.off_wf + 3 * c.wfr;
+    c.qcap = la.qcap;
+    c.off_opt = c.off_q + la.qcap;
+    c.optcap = 16;
+    u32 n_ok = 0, n_err = 0;
+    for (;;) {
+        u32 t = 0;
+        if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
+        t = wv_uni(wv_shfl(t, 0));
+        if (t >= la.n_tiles) break;
+        const u32 tile = la.tile_base + t;
+        const u32 *rec = la.recs + (u64)tile * AVK_FAST_WORDS * 64u + lane;
+        const u32 h1 = rec[64];
+        if (h1 != 0xFFFFFFFFu) { /* a lane of the class's last tile may have no region */
+            const u32 orig = rec[3 * 64];
+            const u32 v_off = rec[2 * 64];
+            LaneOut out;
+            out.ed1 = out.ed2 = out.n_opt = out.present = 0;
+            const int st = solve_lane(a, c, rec, 64u, out, wg_tally);
+            if (st == LS_DEFER) { /* hand over to the wave-per-region kernels */
+                const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1u);
+                a.overflow_list[slot_o] = la.gen_base + (t * 64u + lane);
+            } else {
+                uint32_t w4[4];
+                if (st == AVK_ST_OK) {
+                    w4[0] = 0;
+                    w4[1] = out.ed1;
+                    w4[2] = out.ed2;
+                    w4[3] = out.n_opt | (out.present << 16);
+                    n_ok += 1;
+                } else {
+                    w4[0] = (u32)st;
+                    w4[1] = w4[2] = w4[3] = 0;
+                    n_err += 1;
+                    const u32 h1b = h1;
+                    const u32 nvar = ((h1b >> 12) & 3u) + ((h1b >> 14) & 3u);
+                    for (u32 k = 0; k < nvar; ++k) a.var_out[v_off + k] = 0;
+                    if (a.group_metrics)
+                        for (u32 i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) a.group_metrics[(u64)orig * AVK_N_GROUPS * AVK_N_FIELDS + i] = 0;
+                }
+                avk_u4 *dst = (avk_u4 *)(a.region_out + 4 * (u64)orig);
+                avk_u4 v;
+                v.x = w4[0];
+                v.y = w4[1];
+                v.z = w4[2];
+                v.w = w4[3];
+                *dst = v;
+            }
+        }
+    }
+    n_ok_out = n_ok;
+    n_err_out = n_err;
+}
+
+} // namespace lane
+} // namespace avk
+#endif

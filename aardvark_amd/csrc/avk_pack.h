@@ -45,6 +45,7 @@ struct PackedBatch {
     PodVec<uint64_t> dev2host; /* device variant index -> caller variant index */
     std::vector<uint8_t> zyg_flags; /* per region: bit 0 an Unknown zygosity, bit 1 a HomozygousReference one */
     std::vector<int64_t> delta_t, delta_q; /* variant_delta_length per side (merge_solver.rs:211-223) */
+    std::vector<uint8_t> fast_class;       /* per region: 0, or 1 + index into AVK_FAST_CLASS (eligible for the lane-per-region kernel) */
     uint64_t seq_total = 0;
 };
 
@@ -129,6 +130,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
     out->zyg_flags.assign(n, 0);
     out->delta_t.assign(n, 0);
     out->delta_q.assign(n, 0);
+    out->fast_class.assign(n, 0);
     /* the same cut of the regions into ranges for both passes */
     int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
@@ -336,6 +338,22 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             dr.grow = (uint32_t)(g[0] > g[1] ? g[0] : g[1]);
             dr.pre_status |= types << 16;
             dr.ed_bound = (uint32_t)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
+            /* small enough for the lane-per-region kernel?  (capacities of AvkFastClass; everything must fit the record's bit fields) */
+            if (tc <= 2 && qc <= 2 && N >= 1 && dr.len <= 255 && ed_sum <= 255) {
+                bool ok = true;
+                for (uint32_t i = 0; i < N && ok; ++i) {
+                    ok = bv[i].rel_pos <= 255 && bv[i].a0_len <= 255 && bv[i].a1_len <= 32 && bv[i].alt_ed <= 255 && bv[i].raw_space <= 0xFFFF;
+                    const uint8_t *a1 = ba + bv[i].a_off + bv[i].a0_len;
+                    for (uint32_t j = 0; j < bv[i].a1_len && ok; ++j) ok = a1[j] == 'A' || a1[j] == 'C' || a1[j] == 'G' || a1[j] == 'T';
+                }
+                for (int cl = 0; cl < AVK_FAST_CLASSES && ok; ++cl) {
+                    const AvkFastClass &fc = AVK_FAST_CLASS[cl];
+                    if (tc <= fc.maxv && qc <= fc.maxv && (uint64_t)dr.len + dr.grow <= 16ull * fc.W) {
+                        out->fast_class[r] = (uint8_t)(cl + 1);
+                        break;
+                    }
+                }
+            }
         }
         return 0;
     };
@@ -383,13 +401,18 @@ inline PodVec<AvkDevRegion> regions_in_work_order(const PackedBatch &pb, const s
 struct WorkPlan {
     uint32_t n_hbm = 0;  /* class C */
     uint32_t n_hard = 0; /* class B */
+    /* the regions of the lane-per-region kernel's classes close the work order, largest class first:
+     * [class C | class B | bulk | fast class AVK_FAST_CLASSES - 1 | .. | fast class 0] */
+    uint32_t n_fast[AVK_FAST_CLASSES] = {0};
+    uint32_t fast_base[AVK_FAST_CLASSES] = {0}; /* first record of the class in the work order */
+    uint32_t n_fast_total = 0;
 };
 
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
                                 uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
-    std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk */
+    std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
     WorkPlan plan;
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
@@ -407,6 +430,12 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
     for (uint64_t r = 0; r < n; ++r) {
         const AvkDevRegion &dr = pb.regions[r];
         const uint64_t N = (uint64_t)dr.t_cnt + dr.q_cnt;
+        if (!pb.fast_class.empty() && pb.fast_class[r] && !(dr.pre_status & 0xFFFFu)) {
+            const uint32_t fc = pb.fast_class[r] - 1u;
+            cls[r] = (uint8_t)(3 + (AVK_FAST_CLASSES - 1 - fc));
+            plan.n_fast[fc] += 1;
+            continue;
+        }
         if ((dr.pre_status & 0xFFFFu) || N == 0 || solo_min_variants == 0) continue;
         const uint64_t alle = dr.alle_bytes, grow = dr.grow;
         if (tier1_bytes && need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes) {
@@ -418,15 +447,99 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         }
     }
     /* counting sort by class, then by variant count, descending */
-    std::vector<uint64_t> cnt(3 * 33 + 1, 0);
+    std::vector<uint64_t> cnt((3 + AVK_FAST_CLASSES) * 33 + 1, 0);
     auto key = [&](uint64_t r) {
-        const uint32_t k = pb.regions[r].t_cnt + pb.regions[r].q_cnt;
+        uint32_t k = pb.regions[r].t_cnt + pb.regions[r].q_cnt;
+        if (cls[r] >= 3) { /* a tile of 64 lanes should hold regions of one cost: calls, then edit-distance bound */
+            const uint32_t e = pb.regions[r].ed_bound;
+            k = k * 6 + (e > 5 ? 5 : e);
+        }
         return 33u * cls[r] + (32u - (k > 32u ? 32u : k));
     };
     for (uint64_t r = 0; r < n; ++r) cnt[key(r) + 1] += 1;
     for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];
     for (uint64_t r = 0; r < n; ++r) (*order)[cnt[key(r)]++] = (uint32_t)r;
+    {
+        uint32_t at = (uint32_t)n;
+        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) { /* class 0 is the last segment */
+            at -= plan.n_fast[fc];
+            plan.fast_base[fc] = at;
+            plan.n_fast_total += plan.n_fast[fc];
+        }
+    }
     return plan;
+}
+
+/* 2 bits per base, 16 bases per word (A 0, C 1, G 2, T 3), the layout of the packed reference */
+inline uint32_t pack_bases_2bit(const uint8_t *s, uint32_t n) {
+    uint32_t w = 0;
+    for (uint32_t i = 0; i < n && i < 16; ++i) {
+        const uint8_t ch = s[i];
+        const uint32_t code = ch == 'C' ? 1u : (ch == 'G' ? 2u : (ch == 'T' ? 3u : 0u));
+        w |= code << (2 * i);
+    }
+    return w;
+}
+
+/* The fast records (avk_dev_types.h) of the plan's fast segments, class AVK_FAST_CLASSES - 1 first (the order of the segments): every
+ * class starts on a tile boundary.  tile_base[c] / n_tiles[c] receive the class's tile range. */
+inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vector<uint32_t> &order, const WorkPlan &plan, uint32_t *tile_base,
+                                           uint32_t *n_tiles) {
+    uint32_t tiles = 0;
+    for (int fc = AVK_FAST_CLASSES - 1; fc >= 0; --fc) {
+        tile_base[fc] = tiles;
+        n_tiles[fc] = (plan.n_fast[fc] + 63u) / 64u;
+        tiles += n_tiles[fc];
+    }
+    PodVec<uint32_t> recs;
+    recs.resize((size_t)tiles * AVK_FAST_WORDS * 64u + 1);
+    size_t nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt > tiles / 256 + 1) nt = tiles / 256 + 1;
+    if (nt < 1) nt = 1;
+    auto part = [&](size_t t) {
+        for (uint32_t tile = (uint32_t)((uint64_t)tiles * t / nt); tile < (uint32_t)((uint64_t)tiles * (t + 1) / nt); ++tile) {
+            int fc = 0;
+            for (int c = 0; c < AVK_FAST_CLASSES; ++c)
+                if (tile >= tile_base[c] && tile < tile_base[c] + n_tiles[c]) fc = c;
+            uint32_t *T = recs.data() + (size_t)tile * AVK_FAST_WORDS * 64u;
+            for (uint32_t lane = 0; lane < 64; ++lane) {
+                const uint32_t k = (tile - tile_base[fc]) * 64u + lane;
+                for (int w = 0; w < AVK_FAST_WORDS; ++w) T[w * 64 + lane] = w == 1 ? 0xFFFFFFFFu : 0u;
+                if (k >= plan.n_fast[fc]) continue;
+                const uint32_t r = order[plan.fast_base[fc] + k];
+                const AvkDevRegion &dr = pb.regions[r];
+                const uint32_t tc = dr.t_cnt, qc = dr.q_cnt, N = tc + qc;
+                const uint8_t *base = (const uint8_t *)(pb.blob.data() + 2ull * dr.blob_off);
+                const AvkBlobVar *bv = (const AvkBlobVar *)base;
+                const uint8_t *ba = base + (((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull);
+                const AvkOrdVar *bo = (const AvkOrdVar *)(ba + (((uint64_t)dr.alle_bytes + 15) & ~15ull));
+                uint32_t ord = 0;
+                for (uint32_t d = 0; d < N; ++d) {
+                    const uint32_t vi = bo[d].vi;
+                    ord |= (vi < tc ? vi : 2u + (vi - tc)) << (2 * d);
+                }
+                T[0 * 64 + lane] = (uint32_t)(dr.ref_off >> 4);
+                T[1 * 64 + lane] = (uint32_t)(dr.ref_off & 15u) | (dr.len << 4) | (tc << 12) | (qc << 14) | (ord << 16);
+                T[2 * 64 + lane] = dr.v_off;
+                T[3 * 64 + lane] = r;
+                for (uint32_t i = 0; i < N; ++i) {
+                    const uint32_t slot = i < tc ? i : 2u + (i - tc);
+                    uint32_t *V = T + (AVK_FAST_HDR + 4 * slot) * 64 + lane;
+                    const uint8_t *a1 = ba + bv[i].a_off + bv[i].a0_len;
+                    V[0] = bv[i].rel_pos | (bv[i].a0_len << 8) | (bv[i].a1_len << 16) | ((bv[i].type_zyg & 0xFu) << 24) | (((bv[i].type_zyg >> 8) & 7u) << 28);
+                    V[64] = bv[i].alt_ed | (bv[i].raw_space << 8);
+                    V[128] = pack_bases_2bit(a1, bv[i].a1_len);
+                    V[192] = bv[i].a1_len > 16 ? pack_bases_2bit(a1 + 16, bv[i].a1_len - 16) : 0u;
+                }
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (size_t t = 1; t < nt; ++t) pool.emplace_back(part, t);
+    part(0);
+    for (auto &th : pool) th.join();
+    return recs;
 }
 
 } // namespace avk

@@ -185,6 +185,9 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    "order_guard" (1 for callers that queue avk_compare_resident calls back to back without synchronising: the bulk
  *                    launch then waits for the side streams to reach their launches), "timing_events" (0 = no event records for
  *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
+ *                    "lane_kernel" (1, default: regions with at most two calls per side, a short window and a small edit-distance
+ *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
+ *                    are identical either way)
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
@@ -218,6 +221,9 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
 int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);  /* the dominant launch: first pass of avk_region_kernel_lds */
 int  avk_last_solver_ms(avk_ctx *ctx, float *ms);  /* all solver launches of the call (tier passes + tally reduce) */
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
+int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */
+int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
+                                                             they are not counted in any workspace tier */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
 /* profiling builds of the library only (-DAVK_PHASE_TIMING): summed clock ticks per solver phase of the last download:
  * [0] stage, [1] search A, [2] search B, [3] metrics setup, [4] base-pair metrics, [5] record metrics, [6] whole region,

@@ -147,8 +147,30 @@ static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
 
 #include "../../aardvark_amd/csrc/avk_pack.h"
 #include "../../aardvark_amd/csrc/avk_solver.inl"
+#ifdef AVK_LANE_STATS
+namespace avk { namespace lane { uint64_t g_lane_stats[16]; } }
+#endif
+#include "../../aardvark_amd/csrc/avk_lane.inl"
 
 namespace {
+
+int g_lane_kernel = 1; /* emu_set_lane_kernel: small regions through the lane-per-region code (avk_lane.inl), as run_internal does */
+uint64_t g_lane_solved = 0;
+
+struct LaneTask {
+    const AvkKernelArgs *args;
+    const avk::lane::LaneArgs *la;
+    uint32_t wave_id;
+    uint32_t *lds, *tally;
+    uint32_t n_ok[64], n_err[64];
+};
+void lane_kernel_main(void *p, int lane) {
+    LaneTask *t = (LaneTask *)p;
+    uint32_t ok = 0, err = 0;
+    avk::lane::lane_worker(*t->args, *t->la, t->wave_id, t->lds, t->tally, ok, err);
+    t->n_ok[lane] = ok;
+    t->n_err[lane] = err;
+}
 
 struct WaveTask {
     const AvkKernelArgs *args;
@@ -332,6 +354,69 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                                                     getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u);
     const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     a.regions = sorted.data();
+    /* the lane-per-region launches of run_internal (aardvark_amd/csrc/avk_host.hip): fast segments first, leftovers to the list the
+     * first HBM pass reads */
+    const int fast_list = launch[1] ? 1 : 0;
+    const bool use_fast = g_lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && plan.n_fast_total && !cfg->enable_sequences && !cfg->enable_exact_shortcut && n;
+    (void)fast_list;
+    const uint32_t n_fast = use_fast ? plan.n_fast_total : 0u;
+    g_lane_solved = 0;
+    if (use_fast) {
+        uint32_t tile_base[AVK_FAST_CLASSES], n_tiles[AVK_FAST_CLASSES];
+        const avk::PodVec<uint32_t> fast = avk::build_fast_records(pb, order, plan, tile_base, n_tiles);
+        AvkKernelArgs f = a;
+        f.overflow_list = lists[2].data(); /* the DEFERRED list: an LDS pass of the wave-per-region code after the bulk */
+        f.overflow_count = counters + 1024 + 32;
+        for (int fc = AVK_FAST_CLASSES - 1; fc >= 0; --fc) {
+            if (!n_tiles[fc]) continue;
+            const AvkFastClass &cl = AVK_FAST_CLASS[fc];
+            avk::lane::LaneArgs la;
+            la.recs = fast.data();
+            la.tile_base = tile_base[fc];
+            la.n_tiles = n_tiles[fc];
+            la.tile_counter = counters + 1220 + fc;
+            la.W = cl.W;
+            la.nm = 1u << cl.maxv;
+            la.ed_max = cl.ed_max;
+            la.qcap = cl.qcap;
+            la.gen_base = plan.fast_base[fc];
+            const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, 16);
+            std::atomic<uint32_t> next(0);
+            const uint32_t waves = n_waves ? n_waves : 1;
+            const int nthr = threads < 1 ? 1 : threads;
+            std::vector<uint64_t> sums((size_t)nthr * AVK_TALLY_STRIDE, 0);
+            auto worker = [&](int tid) {
+                avk_emu::Wave w;
+                w.stack_bytes = 256 * 1024;
+                std::vector<char> stacks(64 * w.stack_bytes + 64);
+                w.stacks = stacks.data();
+                std::vector<uint32_t> lds((size_t)rows * 64 + 64, 0xA5A5A5A5u), tl(288, 0);
+                uint64_t *sm = sums.data() + (size_t)tid * AVK_TALLY_STRIDE;
+                for (;;) {
+                    const uint32_t wid = next.fetch_add(1);
+                    if (wid >= waves) break;
+                    LaneTask t;
+                    t.args = &f;
+                    t.la = &la;
+                    t.wave_id = wid;
+                    t.lds = lds.data();
+                    t.tally = tl.data();
+                    avk_emu::run_wave(&w, lane_kernel_main, &t);
+                    for (int l = 0; l < 64; ++l) {
+                        sm[AVK_TALLY_SOLVED] += t.n_ok[l];
+                        sm[AVK_TALLY_ERRORS] += t.n_err[l];
+                        sm[AVK_TALLY_LANE_SOLVED] += t.n_ok[l] + t.n_err[l];
+                    }
+                }
+                for (int i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) sm[i] += tl[i];
+            };
+            std::vector<std::thread> ts;
+            for (int i = 0; i < nthr; ++i) ts.emplace_back(worker, i);
+            for (auto &t : ts) t.join();
+            for (int i = 0; i < nthr; ++i)
+                for (int k = 0; k < AVK_TALLY_STRIDE; ++k) partials[k] += sums[(size_t)i * AVK_TALLY_STRIDE + k];
+        }
+    }
     const uint32_t *list = nullptr, *count = nullptr;
     int nlist = 0;
     uint32_t hbm_shared = 0; /* length of the class C list the HBM launches share */
@@ -342,7 +427,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         a.work_list = list;
         a.work_base = 0;
         a.n_work_dev = count;
-        a.n_work = (uint32_t)n;
+        a.n_work = (uint32_t)n - (t == 0 ? n_fast : 0u);
         a.high_priority = 0;
         a.esc_bytes = 0;
         a.esc_enabled = 0;
@@ -410,13 +495,23 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     a_solo.overflow_count = later ? counters + 1024 + 16 * solo_list : nullptr;
                 }
                 a.work_base = n_c + solo;
-                a.n_work = (uint32_t)n - n_c - solo;
+                a.n_work = (uint32_t)n - n_fast - n_c - solo;
                 if (lds_bytes >= 1024) {
                     a.tier[0].ws_bytes = avk::bulk_slice_bytes(lds_bytes);
                     a.esc_bytes = (uint32_t)(4 * a.tier[0].ws_bytes);
                     a.esc_enabled = lds_escalation ? 1u : 0u;
                 }
                 run_pass(n_waves ? n_waves : 1, 0, lds_bytes, solo);
+                if (use_fast && counters[1024 + 32]) { /* what the lanes handed over (run_internal: the deferred LDS launch) */
+                    AvkKernelArgs keep = a;
+                    a.work_list = lists[2].data();
+                    a.n_work_dev = counters + 1024 + 32;
+                    a.work_base = 0;
+                    a.n_work = 0;
+                    a.work_counter = counters + 768;
+                    run_pass(n_waves ? n_waves : 1, 0, lds_bytes, 0);
+                    a = keep;
+                }
                 a.tier[0].ws_bytes = lds_bytes;
                 a.esc_bytes = 0;
                 a.esc_enabled = 0;
@@ -466,8 +561,20 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     if (tier_counts) memcpy(tier_counts, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
+    g_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
     return 0;
 }
+
+void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
+#ifdef AVK_LANE_STATS
+void emu_lane_stats(uint64_t *out, int reset) {
+    for (int i = 0; i < 16; ++i) {
+        out[i] = avk::lane::g_lane_stats[i];
+        if (reset) avk::lane::g_lane_stats[i] = 0;
+    }
+}
+#endif
+uint64_t emu_last_lane_solved(void) { return g_lane_solved; }
 
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,

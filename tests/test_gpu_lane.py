@@ -1,0 +1,94 @@
+"""The lane-per-region kernel (aardvark_amd/csrc/avk_lane.inl) on a real MI355X through the C-ABI, against the oracle, bit for bit; every
+case also with the kernel switched off (context option lane_kernel = 0: all regions through the wave-per-region kernels)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenarios
+from aardvark_amd import synth
+
+pytestmark = pytest.mark.gpu
+CPUS = min(os.cpu_count() or 1, 16)
+
+
+@pytest.fixture(scope="module")
+def ctxs():
+    import aardvark_amd
+    on, off = aardvark_amd.Context(0), aardvark_amd.Context(0)
+    off.set_option("lane_kernel", 0)
+    yield on, off
+    on.close()
+    off.close()
+
+
+def both_ways(ctxs, oracle, contigs, batch, min_lane_share=0.0, max_branch_factor=50, group_metrics=True):
+    from aardvark_amd import CompareConfig
+    want = oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS, max_branch_factor=max_branch_factor, group_metrics=group_metrics)
+    out = []
+    for c in ctxs:
+        c.set_option("emit_group_metrics", 1 if group_metrics else 0)
+        c.upload_reference(contigs)
+        got = c.solve_compare_regions(batch, CompareConfig(enable_sequences=False, max_branch_factor=max_branch_factor), group_metrics=group_metrics)
+        assert got.diff(want) == []
+        out.append(c.last_lane_solved())
+    assert out[1] == 0 and out[0] >= min_lane_share * batch.n_regions
+    return out[0], want
+
+
+def test_reference_known_answer_regions_on_lanes(ctxs, oracle):
+    contigs, batch = scenarios.golden()
+    n, _ = both_ways(ctxs, oracle, contigs, batch)
+    assert n >= batch.n_regions - 1
+
+
+@pytest.mark.parametrize("seed,kw", [(101, {}), (102, {"repeat_unit": b"CA"}), (103, {"repeat_unit": b"A", "max_len": 4}), (104, {"max_len": 16, "span": (20, 190)}),
+                                     (105, {"repeat_unit": b"CAG", "related": 0.9}), (106, {"span": (4, 40), "max_len": 3})])
+def test_small_region_fuzz(ctxs, oracle, seed, kw):
+    contigs, batch = scenarios.fuzz_regions(seed, 6000, max_vars=2, **kw)
+    both_ways(ctxs, oracle, contigs, batch, min_lane_share=0.1)
+
+
+def test_whole_genome_mix_one_contig_full_density(ctxs, oracle):
+    """one contig of the benchmark workload at full density (chr20-sized: about 75 k regions): per-variant decisions, per-region blocks,
+    tally; multi-allelic sites and repeat-run indels at shifted positions included"""
+    contig, batch = synth.config_indel_mix_v2(n_truth=int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38)), contig_len=synth.CHR20_LEN)
+    n, want = both_ways(ctxs, oracle, [contig], batch, min_lane_share=0.9)
+    assert int(want.tally[-2]) == batch.n_regions
+    t1 = (batch.t_cnt == 1) & (batch.q_cnt == 1)
+    shifted = t1 & (batch.var_pos[batch.t_off.astype(np.int64) * t1] != batch.var_pos[batch.q_off.astype(np.int64) * t1])
+    assert (shifted & (want.ed_h1 == 0) & (want.ed_h2 == 0)).sum() > 100
+
+
+@pytest.mark.parametrize("quota", [1, 2, 3, 7])
+def test_branch_quota_on_lanes(ctxs, oracle, quota):
+    contigs, batch = scenarios.fuzz_regions(111, 3000, max_vars=2, related=0.8)
+    both_ways(ctxs, oracle, contigs, batch, min_lane_share=0.1, max_branch_factor=quota)
+
+
+def test_windows_with_other_symbols_are_handed_over(ctxs, oracle):
+    contigs, batch = scenarios.fuzz_regions(9, 3000, max_vars=2, contig_len=2500, alphabet=b"ACGT" * 50 + b"Nc")
+    n, _ = both_ways(ctxs, oracle, contigs, batch)
+    assert 0 < n < batch.n_regions
+
+
+def test_capacities_are_class_limits_not_errors(ctxs, oracle):
+    contigs, batch = scenarios.fuzz_regions(121, 3000, max_vars=3, max_len=24, span=(30, 260))
+    n, _ = both_ways(ctxs, oracle, contigs, batch)
+    assert 0 < n < batch.n_regions
+
+
+def test_tally_only_outputs(ctxs, oracle):
+    """what the benchmark runs: no per-region metric blocks"""
+    contigs, batch = scenarios.fuzz_regions(141, 5000, max_vars=2, related=0.8)
+    both_ways(ctxs, oracle, contigs, batch, min_lane_share=0.1, group_metrics=False)
+
+
+def test_merge_pairs_on_lanes(ctxs, oracle):
+    contigs, batch = scenarios.fuzz_regions(131, 4000, max_vars=2, related=0.9)
+    st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs, threads=CPUS)
+    for c in ctxs:
+        c.upload_reference(contigs)
+        st, ex = c.optimize_pairs(batch)
+        assert np.array_equal(st_o, st) and np.array_equal(ex_o, ex)
