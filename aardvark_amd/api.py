@@ -64,6 +64,7 @@ def load_library():
     lib.avk_last_kernel_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_solver_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_tier_counts.argtypes = [vp, u64p]
+    lib.avk_last_compare_was_one_shot.argtypes = [vp]
     lib.avk_last_lane_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_lane_solved.argtypes = [vp, u64p]
     lib.avk_debug_phase_cycles.argtypes = [vp, u64p]
@@ -197,6 +198,9 @@ class Context:
         ms = C.c_float(0)
         self._check(self.lib.avk_last_solver_ms(self.handle, C.byref(ms)))
         return float(ms.value)
+
+    def last_compare_was_one_shot(self):
+        return bool(self.lib.avk_last_compare_was_one_shot(self.handle))
 
     def last_lane_ms(self):
         """HIP-event time from the start of the last step to the end of its lane-per-region launches (0 when it had none)"""

@@ -82,11 +82,14 @@ struct AvkDevVariant {
  *            handled there, order_variants query_optimizer.rs:372-381); 0xFFFFFFFF = no region in this lane
  *   word 2   first per-variant output word (AvkDevRegion::v_off)
  *   word 3   the region's index in the caller's batch (AvkDevRegion::orig)
- *   then 4 call slots of 4 words (slots 0,1 truth, 2,3 query):
+ *   then 2 * maxv call slots of 4 words (maxv = calls per side of the record's class; truth slots first, then query slots):
  *            rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28;  alt_ed | raw_space << 8;  allele1, 2 bits per
  *            base, 16 bases per word (2 words) */
 #define AVK_FAST_HDR 4
-#define AVK_FAST_WORDS 20
+#define AVK_FAST_WORDS 20 /* largest record: 4 call slots */
+/* words of a record of a class with `maxv` calls per side: header + 2 * maxv call slots (truth slots first); the tiles of a class are
+ * contiguous, tile t of the class at [t * words * 64, (t + 1) * words * 64) of the class's part of the record array */
+#define AVK_FAST_WORDS_OF(maxv) (AVK_FAST_HDR + 8u * (maxv))
 #define AVK_FAST_CLASSES 4
 /* capacities of the launch classes: sequence words (16 bases each), calls per side, wavefront cap, queue entries.
  * ed_max caps the edit distance a lane follows, not what the region may contain: with the lazily evaluated search (avk_lane.inl,

@@ -13,6 +13,8 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
@@ -186,6 +188,9 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
+struct StreamBufs; /* staging buffers of the one-shot path (avk_stream.inl) */
+void stream_bufs_free(StreamBufs *b);
+
 } // namespace
 
 #define AVK_N_COUNTERS 1280 /* words of avk_dev_batch::d_counters */
@@ -224,8 +229,12 @@ struct avk_ctx {
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
     int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
+    int64_t lane_min_regions = 8192; /* a lane class is launched when it holds at least this many regions (x16 for the two-call
+                                        classes): a launch lasts at least as long as its slowest tile, which a small class cannot amortise */
     bool lane_attr_set = false;
     uint64_t last_lane_solved = 0;
+    StreamBufs *sbufs = nullptr;
+    int last_one_shot = 0; /* the last avk_compare_batch took the one-shot path of avk_stream.inl */
     int n_cus = 0;
     /* workspaces (grown on demand) */
     uint8_t *d_ws = nullptr;
@@ -265,7 +274,8 @@ struct avk_dev_batch {
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
     avk::WorkPlan plan;
     uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
-    uint32_t fast_tile_base[AVK_FAST_CLASSES] = {0}, fast_tiles[AVK_FAST_CLASSES] = {0};
+    uint64_t fast_word_base[AVK_FAST_CLASSES] = {0}; /* first word of the class's tiles in d_fast */
+    uint32_t fast_tiles[AVK_FAST_CLASSES] = {0};
     bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
 };
@@ -382,6 +392,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    stream_bufs_free(ctx->sbufs);
+    ctx->sbufs = nullptr;
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->d_ref2b) (void)hipFree(ctx->d_ref2b);
     if (ctx->d_refexc) (void)hipFree(ctx->d_refexc);
@@ -480,6 +492,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->emit_group_metrics = value ? 1 : 0;
     } else if (n == "lane_kernel") {
         ctx->lane_kernel = value ? 1 : 0;
+    } else if (n == "lane_min_regions") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_regions must not be negative");
+        ctx->lane_min_regions = value;
     } else
         return fail(ctx, AVK_E_ARG, "unknown option '%s'", name);
     return 0;
@@ -631,14 +646,15 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     const auto t_alloc = now();
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
-                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2);
+                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
+                                    ctx->lane_kernel ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
     const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(db->host, order);
     avk::PodVec<uint32_t> fast;
     if (db->plan.n_fast_total) {
-        fast = avk::build_fast_records(db->host, order, db->plan, db->fast_tile_base, db->fast_tiles);
+        fast = avk::build_fast_records(db->host, order, db->plan, db->fast_word_base, db->fast_tiles);
         e = hipMalloc((void **)&db->d_fast, fast.size() * sizeof(uint32_t));
         if (e == hipSuccess) e = hipMemcpyAsync(db->d_fast, fast.data(), fast.size() * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream);
     }
@@ -706,10 +722,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     /* The lane-per-region kernel takes the fast segments at the end of the work order (WorkPlan::fast_base); what it cannot finish it
      * appends to the list the first HBM launch reads.  Without such a launch, with sequence output (the haplotype bytes are never
      * materialised there) or with the exact-match shortcut the wave-per-region bulk launch covers those records itself. */
-    const int fast_list = launch[1] ? 1 : 0;
-    const bool use_fast = ctx->lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && db->d_fast && db->plan.n_fast_total && !cfg->enable_sequences &&
+
+    /* which classes go to the lanes was decided with the work order (plan_work_order, option lane_min_regions at upload time) */
+    const int lane_k = AVK_FAST_CLASSES;
+    const uint32_t n_lane_regions = db->plan.n_fast_total;
+    const bool use_fast = ctx->lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && db->d_fast && n_lane_regions && !cfg->enable_sequences &&
                           !cfg->enable_exact_shortcut && n;
-    const uint32_t n_fast = use_fast ? db->plan.n_fast_total : 0u;
+    const uint32_t n_fast = use_fast ? n_lane_regions : 0u;
     /* geometry */
     const uint32_t waves_per_block = 4;
     uint64_t want_waves = (uint64_t)ctx->n_cus * (uint64_t)ctx->waves_per_cu;
@@ -938,12 +957,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 f.overflow_list = lists[2];
                 f.overflow_count = db->d_counters + 1024 + 32;
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_fork, ctx->stream));
-                for (int fc = AVK_FAST_CLASSES - 1; fc >= 0; --fc) {
+                for (int fc = lane_k - 1; fc >= 0; --fc) {
                     if (!db->fast_tiles[fc]) continue;
                     const AvkFastClass &cl = AVK_FAST_CLASS[fc];
                     avk::lane::LaneArgs la;
-                    la.recs = db->d_fast;
-                    la.tile_base = db->fast_tile_base[fc];
+                    la.recs = db->d_fast + db->fast_word_base[fc];
+                    la.rec_words = AVK_FAST_WORDS_OF(cl.maxv);
                     la.n_tiles = db->fast_tiles[fc];
                     la.tile_counter = db->d_counters + 1220 + fc;
                     la.W = cl.W;
@@ -1162,8 +1181,26 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     return 0;
 }
 
+} /* extern "C" */
+
+#include "avk_stream.inl"
+
+extern "C" {
+
+int avk_last_compare_was_one_shot(avk_ctx *ctx) { return ctx ? ctx->last_one_shot : 0; }
+
 int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
-    if (!ctx || !batch || !cfg || !out) return AVK_E_ARG;
+    if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
+    if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    /* large batches without per-region blocks or sequences: written straight into pinned fast records, copied while they are written */
+    ctx->last_one_shot = 0;
+    {
+        const int rs = compare_batch_stream(ctx, batch, cfg, out);
+        if (rs != 100) {
+            ctx->last_one_shot = rs == 0;
+            return rs;
+        }
+    }
     avk_dev_batch *db = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = avk_batch_upload(ctx, batch, &db);

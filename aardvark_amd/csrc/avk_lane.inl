@@ -623,8 +623,9 @@ template <bool q> AVK_DEV void g_add(Group22 &g, u32 w, u32 exp, u32 obs) {
 }
 
 struct LaneArgs { /* what a launch of the lane kernel needs besides AvkKernelArgs' outputs */
-    const u32 *recs;     /* fast records, tile-major: word w of lane l of tile t at recs[(t * AVK_FAST_WORDS + w) * 64 + l] */
-    u32 tile_base, n_tiles;
+    const u32 *recs;     /* the class's fast records, tile-major: word w of lane l of tile t at recs[(t * rec_words + w) * 64 + l] */
+    u32 rec_words;       /* AVK_FAST_WORDS_OF(calls per side of the class) */
+    u32 n_tiles;
     u32 *tile_counter;
     u32 W, nm, ed_max, qcap; /* the class of this launch */
     u32 gen_base;        /* record index (work order of the wave-per-region kernels) of fast record 0 */
@@ -649,7 +650,8 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
         const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
         c.vw0[s] = c.vw1[s] = a1lo[s] = a1hi[s] = 0;
         if (on) {
-            const u32 *v = rec + (AVK_FAST_HDR + 4 * s) * lane_stride;
+            const u32 maxv = c.nm1 == 1 ? 1u : 2u; /* record slots: truth [0, maxv), query [maxv, 2 maxv) */
+            const u32 *v = rec + (AVK_FAST_HDR + 4 * (s < 2 ? s : maxv + (s - 2))) * lane_stride;
             c.vw0[s] = v[0];
             c.vw1[s] = v[1 * lane_stride];
             a1lo[s] = v[2 * lane_stride];
@@ -945,8 +947,7 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
         if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
         t = wv_uni(wv_shfl(t, 0));
         if (t >= la.n_tiles) break;
-        const u32 tile = la.tile_base + t;
-        const u32 *rec = la.recs + (u64)tile * AVK_FAST_WORDS * 64u + lane;
+        const u32 *rec = la.recs + (u64)t * la.rec_words * 64u + lane;
         const u32 h1 = rec[64];
         if (h1 != 0xFFFFFFFFu) { /* a lane of the class's last tile may have no region */
             const u32 orig = rec[3 * 64];

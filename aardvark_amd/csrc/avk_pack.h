@@ -408,12 +408,25 @@ struct WorkPlan {
     uint32_t n_fast_total = 0;
 };
 
+/* lane_min_regions: a class of the lane-per-region kernel is used when the batch holds at least lane_min_regions x {1, 1, 16, 16} of its
+ * regions (a launch lasts as long as its slowest tile: a small class is better off with the wave-per-region kernels); the regions of
+ * an unused class are planned like any other region.  0xFFFFFFFF = no lane classes at all. */
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
-                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12) {
+                                uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12,
+                                uint64_t lane_min_regions = 0) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
     WorkPlan plan;
+    bool lane_on[AVK_FAST_CLASSES];
+    {
+        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16};
+        uint64_t have[AVK_FAST_CLASSES] = {0};
+        if (!pb.fast_class.empty())
+            for (uint64_t r = 0; r < n; ++r)
+                if (pb.fast_class[r] && !(pb.regions[r].pre_status & 0xFFFFu)) have[pb.fast_class[r] - 1u] += 1;
+        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lane_on[fc] = lane_min_regions != 0xFFFFFFFFull && have[fc] > 0 && have[fc] >= lane_min_regions * scale[fc];
+    }
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
         const uint64_t maxT = dr.t_cnt > dr.q_cnt ? dr.t_cnt : dr.q_cnt;
@@ -430,7 +443,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
     for (uint64_t r = 0; r < n; ++r) {
         const AvkDevRegion &dr = pb.regions[r];
         const uint64_t N = (uint64_t)dr.t_cnt + dr.q_cnt;
-        if (!pb.fast_class.empty() && pb.fast_class[r] && !(dr.pre_status & 0xFFFFu)) {
+        if (!pb.fast_class.empty() && pb.fast_class[r] && !(dr.pre_status & 0xFFFFu) && lane_on[pb.fast_class[r] - 1u]) {
             const uint32_t fc = pb.fast_class[r] - 1u;
             cls[r] = (uint8_t)(3 + (AVK_FAST_CLASSES - 1 - fc));
             plan.n_fast[fc] += 1;
@@ -481,18 +494,21 @@ inline uint32_t pack_bases_2bit(const uint8_t *s, uint32_t n) {
     return w;
 }
 
-/* The fast records (avk_dev_types.h) of the plan's fast segments, class AVK_FAST_CLASSES - 1 first (the order of the segments): every
- * class starts on a tile boundary.  tile_base[c] / n_tiles[c] receive the class's tile range. */
-inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vector<uint32_t> &order, const WorkPlan &plan, uint32_t *tile_base,
+/* The fast records (avk_dev_types.h) of the plan's fast segments, class AVK_FAST_CLASSES - 1 first (the order of the segments).
+ * word_base[c] = first word of class c's tiles in the returned array, n_tiles[c] = its tiles (AVK_FAST_WORDS_OF(maxv) * 64 words each). */
+inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vector<uint32_t> &order, const WorkPlan &plan, uint64_t *word_base,
                                            uint32_t *n_tiles) {
-    uint32_t tiles = 0;
+    uint64_t words = 0;
+    uint32_t tiles = 0, tile_first[AVK_FAST_CLASSES];
     for (int fc = AVK_FAST_CLASSES - 1; fc >= 0; --fc) {
-        tile_base[fc] = tiles;
+        word_base[fc] = words;
+        tile_first[fc] = tiles;
         n_tiles[fc] = (plan.n_fast[fc] + 63u) / 64u;
         tiles += n_tiles[fc];
+        words += (uint64_t)n_tiles[fc] * AVK_FAST_WORDS_OF(AVK_FAST_CLASS[fc].maxv) * 64u;
     }
     PodVec<uint32_t> recs;
-    recs.resize((size_t)tiles * AVK_FAST_WORDS * 64u + 1);
+    recs.resize((size_t)words + 1);
     size_t nt = std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
     if (nt > tiles / 256 + 1) nt = tiles / 256 + 1;
@@ -501,11 +517,12 @@ inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vec
         for (uint32_t tile = (uint32_t)((uint64_t)tiles * t / nt); tile < (uint32_t)((uint64_t)tiles * (t + 1) / nt); ++tile) {
             int fc = 0;
             for (int c = 0; c < AVK_FAST_CLASSES; ++c)
-                if (tile >= tile_base[c] && tile < tile_base[c] + n_tiles[c]) fc = c;
-            uint32_t *T = recs.data() + (size_t)tile * AVK_FAST_WORDS * 64u;
+                if (tile >= tile_first[c] && tile < tile_first[c] + n_tiles[c]) fc = c;
+            const uint32_t maxv = AVK_FAST_CLASS[fc].maxv, rw = AVK_FAST_WORDS_OF(maxv);
+            uint32_t *T = recs.data() + word_base[fc] + (size_t)(tile - tile_first[fc]) * rw * 64u;
             for (uint32_t lane = 0; lane < 64; ++lane) {
-                const uint32_t k = (tile - tile_base[fc]) * 64u + lane;
-                for (int w = 0; w < AVK_FAST_WORDS; ++w) T[w * 64 + lane] = w == 1 ? 0xFFFFFFFFu : 0u;
+                const uint32_t k = (tile - tile_first[fc]) * 64u + lane;
+                for (uint32_t w = 0; w < rw; ++w) T[w * 64 + lane] = w == 1 ? 0xFFFFFFFFu : 0u;
                 if (k >= plan.n_fast[fc]) continue;
                 const uint32_t r = order[plan.fast_base[fc] + k];
                 const AvkDevRegion &dr = pb.regions[r];
@@ -524,7 +541,7 @@ inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vec
                 T[2 * 64 + lane] = dr.v_off;
                 T[3 * 64 + lane] = r;
                 for (uint32_t i = 0; i < N; ++i) {
-                    const uint32_t slot = i < tc ? i : 2u + (i - tc);
+                    const uint32_t slot = i < tc ? i : maxv + (i - tc);
                     uint32_t *V = T + (AVK_FAST_HDR + 4 * slot) * 64 + lane;
                     const uint8_t *a1 = ba + bv[i].a_off + bv[i].a0_len;
                     V[0] = bv[i].rel_pos | (bv[i].a0_len << 8) | (bv[i].a1_len << 16) | ((bv[i].type_zyg & 0xFu) << 24) | (((bv[i].type_zyg >> 8) & 7u) << 28);

@@ -187,7 +187,9 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
  *                    "lane_kernel" (1, default: regions with at most two calls per side, a short window and a small edit-distance
  *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
- *                    are identical either way)
+ *                    are identical either way), "lane_min_regions" (8192: a class of the lane kernel gets a launch of its own only
+ *                    when the batch holds that many of its regions — x16 for the two-call classes —, smaller classes stay with
+ *                    the wave-per-region kernels; 0 = always)
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
@@ -221,6 +223,8 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
 int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);  /* the dominant launch: first pass of avk_region_kernel_lds */
 int  avk_last_solver_ms(avk_ctx *ctx, float *ms);  /* all solver launches of the call (tier passes + tally reduce) */
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
+int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the last avk_compare_batch took the one-shot path (large batch, no per-region
+                                                      blocks, no sequences): pinned fast records written and copied tile range by tile range */
 int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */
 int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
                                                              they are not counted in any workspace tier */

@@ -362,8 +362,9 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     const uint32_t n_fast = use_fast ? plan.n_fast_total : 0u;
     g_lane_solved = 0;
     if (use_fast) {
-        uint32_t tile_base[AVK_FAST_CLASSES], n_tiles[AVK_FAST_CLASSES];
-        const avk::PodVec<uint32_t> fast = avk::build_fast_records(pb, order, plan, tile_base, n_tiles);
+        uint64_t word_base[AVK_FAST_CLASSES];
+        uint32_t n_tiles[AVK_FAST_CLASSES];
+        const avk::PodVec<uint32_t> fast = avk::build_fast_records(pb, order, plan, word_base, n_tiles);
         AvkKernelArgs f = a;
         f.overflow_list = lists[2].data(); /* the DEFERRED list: an LDS pass of the wave-per-region code after the bulk */
         f.overflow_count = counters + 1024 + 32;
@@ -371,8 +372,8 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             if (!n_tiles[fc]) continue;
             const AvkFastClass &cl = AVK_FAST_CLASS[fc];
             avk::lane::LaneArgs la;
-            la.recs = fast.data();
-            la.tile_base = tile_base[fc];
+            la.recs = fast.data() + word_base[fc];
+            la.rec_words = AVK_FAST_WORDS_OF(cl.maxv);
             la.n_tiles = n_tiles[fc];
             la.tile_counter = counters + 1220 + fc;
             la.W = cl.W;

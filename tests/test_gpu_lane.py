@@ -17,6 +17,7 @@ CPUS = min(os.cpu_count() or 1, 16)
 def ctxs():
     import aardvark_amd
     on, off = aardvark_amd.Context(0), aardvark_amd.Context(0)
+    on.set_option("lane_min_regions", 0)  # every class of the lane kernel, however small the batch
     off.set_option("lane_kernel", 0)
     yield on, off
     on.close()
@@ -92,3 +93,30 @@ def test_merge_pairs_on_lanes(ctxs, oracle):
         c.upload_reference(contigs)
         st, ex = c.optimize_pairs(batch)
         assert np.array_equal(st_o, st) and np.array_equal(ex_o, ex)
+
+
+def test_one_shot_path_equals_resident_path(ctxs, oracle):
+    """avk_compare_batch on a large batch without per-region blocks takes the one-shot path (avk_stream.inl: fast records written straight
+    into pinned memory, general and handed-back regions through gathered sub-batches): every output equals the oracle's and the resident
+    path's; windows with other symbols and regions beyond the lane classes are in the batch"""
+    from aardvark_amd import CompareConfig
+    contig, batch = synth.config_indel_mix_v2(n_truth=int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38)), contig_len=synth.CHR20_LEN)
+    contig = contig.copy()
+    rng = np.random.default_rng(5)
+    contig[rng.integers(0, contig.size, size=contig.size // 5000)] = ord("N")  # some windows are not for the lanes
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=False)
+    on, off = ctxs
+    for c in ctxs:
+        c.set_option("emit_group_metrics", 0)
+        c.upload_reference([contig])
+    got = on.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False)
+    assert on.last_compare_was_one_shot()
+    assert got.diff(want) == []
+    assert 0.8 * batch.n_regions < on.last_lane_solved() < batch.n_regions
+    res = off.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False)
+    assert not off.last_compare_was_one_shot()
+    assert res.diff(want) == []
+    rb = on.upload(batch)
+    on.compare_resident(rb, CompareConfig(enable_sequences=False))
+    assert on.download(rb, group_metrics=False).diff(want) == []
+    rb.free()
