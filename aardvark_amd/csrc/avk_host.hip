@@ -28,6 +28,7 @@
 #include "avk_pack.h"
 #include "avk_solver.inl"
 #include "avk_lane.inl"
+#include "avk_dwfa_script.inl"
 
 /* ---------------------------------------------------------------------------------- kernels */
 /* LDS passes: regions in the LDS slice of their wavefront (small slices at high occupancy first, then
@@ -84,6 +85,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) av
         const uint32_t v = wg_tally[k];
         if (v) atomicAdd((unsigned long long *)(part + k), (unsigned long long)v);
     }
+}
+
+/* DWFALite scripts (avk_dwfa_script.inl): engine 0 one script per wavefront, engine 1 one script per lane */
+__global__ void __launch_bounds__(256) avk_dwfa_wave_kernel(AvkDwfaArgs a) {
+    const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (wave < a.n_scripts) avk::dwfa_script_wave(a, wave);
+}
+__global__ void __launch_bounds__(64) avk_dwfa_lane_kernel(AvkDwfaArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    const unsigned s = blockIdx.x * 64u + threadIdx.x;
+    if (s < a.n_scripts) avk::lane::dwfa_script_lane(a, s, (uint32_t *)avk_smem);
 }
 
 /* Stratified tallies (SummaryWriter::add_comparison_benchmark with containment regions, writers/summary.rs:146-163): label l sums the
@@ -228,6 +240,7 @@ struct avk_ctx {
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
+    int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
     int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
     int64_t lane_min_regions = 8192; /* a lane class is launched when it holds at least this many regions (x16 for the two-call
                                         classes): a launch lasts at least as long as its slowest tile, which a small class cannot amortise */
@@ -245,8 +258,8 @@ struct avk_ctx {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk1 = nullptr; /* ev0..ev1 all solver launches, ev0..evk1 the first (dominant) one */
     hipEvent_t ev_lane = nullptr; /* after the lane-kernel launches of a step */
     bool ev_lane_valid = false;
-    hipStream_t lane_stream = nullptr; /* the lane-kernel launches of the two-calls-per-side classes run beside everything else */
-    hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr;
+    hipStream_t lane_stream = nullptr, lane_stream2 = nullptr; /* the lane-kernel launches run beside the wave-per-region launches: two-call classes / one-call classes */
+    hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_lane_join2 = nullptr, ev_lane_ready = nullptr, ev_lane_ready2 = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -276,6 +289,9 @@ struct avk_dev_batch {
     uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
     uint64_t fast_word_base[AVK_FAST_CLASSES] = {0}; /* first word of the class's tiles in d_fast */
     uint32_t fast_tiles[AVK_FAST_CLASSES] = {0};
+    avk_compare_config last_cfg = {50, 0, 0}; /* the configuration of the last run (the capacity retry of avk_results_download repeats it) */
+    uint32_t last_mode = 0;
+    bool has_run = false;
     bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
 };
@@ -374,6 +390,10 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready2, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
@@ -410,7 +430,11 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->ev_lane_fork) (void)hipEventDestroy(ctx->ev_lane_fork);
     if (ctx->ev_lane_join) (void)hipEventDestroy(ctx->ev_lane_join);
+    if (ctx->ev_lane_join2) (void)hipEventDestroy(ctx->ev_lane_join2);
+    if (ctx->ev_lane_ready) (void)hipEventDestroy(ctx->ev_lane_ready);
+    if (ctx->ev_lane_ready2) (void)hipEventDestroy(ctx->ev_lane_ready2);
     if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
+    if (ctx->lane_stream2) (void)hipStreamDestroy(ctx->lane_stream2);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -490,6 +514,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->use_packed_reference = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {
         ctx->emit_group_metrics = value ? 1 : 0;
+    } else if (n == "capacity_retry") {
+        ctx->capacity_retry = value ? 1 : 0;
     } else if (n == "lane_kernel") {
         ctx->lane_kernel = value ? 1 : 0;
     } else if (n == "lane_min_regions") {
@@ -947,7 +973,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             /* ---- the lane-per-region launches (avk_lane.inl): the classes with two calls per side (long, latency-bound tiles at low
              * occupancy) on a stream of their own, the one-call classes on the caller's stream ahead of the bulk.  What a lane cannot
              * finish goes to the DEFERRED list, solved after the bulk by an LDS launch of the wave-per-region kernel. */
-            bool lane_side = false;
+            bool lane_side = false, lane_side2 = false;
             if (use_fast) {
                 if (!ctx->lane_attr_set) {
                     AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -981,15 +1007,28 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     const bool side = cl.maxv > 1;
                     if (side && !lane_side) {
                         AVK_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream, ctx->ev_lane_fork, 0));
+                        if (ctx->order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_ready, ctx->lane_stream));
                         lane_side = true;
                     }
-                    hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, side ? ctx->lane_stream : ctx->stream, f, la);
+                    if (!side && !lane_side2) {
+                        AVK_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream2, ctx->ev_lane_fork, 0));
+                        if (ctx->order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_ready2, ctx->lane_stream2));
+                        lane_side2 = true;
+                    }
+                    hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, side ? ctx->lane_stream : ctx->lane_stream2, f, la);
                     AVK_HIP(ctx, hipGetLastError());
                 }
+                if (ctx->order_guard) { /* the bulk must not take the machine before the lane launches are in their queues */
+                    if (lane_side) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_ready, 0));
+                    if (lane_side2) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_ready2, 0));
+                }
                 if (lane_side) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join, ctx->lane_stream));
-                if (timed) {
-                    AVK_HIP(ctx, hipEventRecord(ctx->ev_lane, ctx->stream));
-                    ctx->ev_lane_valid = true;
+                if (lane_side2) {
+                    AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join2, ctx->lane_stream2));
+                    if (timed) { /* end of the one-call classes' launches */
+                        AVK_HIP(ctx, hipEventRecord(ctx->ev_lane, ctx->lane_stream2));
+                        ctx->ev_lane_valid = true;
+                    }
                 }
             }
             /* every workgroup of the three launches is resident at once */
@@ -1006,6 +1045,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (use_fast) { /* the regions the lanes handed over: small ones, so the LDS tier with its in-workgroup escalation; its own overflow joins the bulk's */
                 AVK_HIP(ctx, hipGetLastError());
                 if (lane_side) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join, 0));
+                if (lane_side2) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join2, 0));
                 AvkKernelArgs d = a;
                 d.work_list = lists[2];
                 d.n_work_dev = db->d_counters + 1024 + 32;
@@ -1056,6 +1096,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                        (uint64_t *)tally_dev, db->d_counters, (unsigned)AVK_N_COUNTERS, ctx->accumulate_tally ? 1u : 0u);
     AVK_HIP(ctx, hipGetLastError());
     db->scratch_clean = true;
+    db->last_cfg = *cfg;
+    db->last_mode = mode;
+    db->has_run = true;
     if (timed) AVK_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->ev_valid = timed;
     return 0;
@@ -1115,6 +1158,108 @@ int avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]) {
     if (!ctx || !counts) return AVK_E_ARG;
     memcpy(counts, ctx->last_tiers, sizeof(ctx->last_tiers));
     return 0;
+}
+
+
+/* Regions that exhausted the last workspace tier (AVK_ST_CAPACITY) are solved again by the library itself, in slices of 1, 4 and 16 GB
+ * (the reference grows its vectors without bound, dynamic_wfa.rs:152; an MI355X has 288 GB): the regions are rebuilt from the packed
+ * batch the context keeps, sent through the big-slice tier alone, and their results are written over the failed ones.  `fixed`
+ * receives, per level, the sub-batch results. */
+namespace {
+struct CapacityFix {
+    std::vector<uint32_t> idx; /* caller region index of the sub-batch's regions */
+    std::vector<int32_t> status;
+    std::vector<uint32_t> ed1, ed2, nopt, seq_len, gm;
+    std::vector<uint16_t> present;
+    std::vector<uint8_t> ve, vo, vc, vz, seq;
+    std::vector<uint64_t> seq_off, v_first; /* first sub-batch variant of a region (truth first, then query) */
+    std::vector<uint32_t> seq_stride;
+    std::vector<uint64_t> tally;
+};
+} // namespace
+
+static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::vector<uint32_t> &cap, bool want_gm, bool want_seq, uint64_t slice_bytes, CapacityFix *fx) {
+    const uint64_t m = cap.size();
+    std::vector<uint64_t> rid(m), st(m), en(m), toff(m), qoff(m), vpos, a0off, a1off;
+    std::vector<uint32_t> cidx(m), tcnt(m), qcnt(m), vraw, a0len, a1len;
+    std::vector<uint8_t> vtype, vzyg, arena;
+    fx->idx = cap;
+    fx->v_first.assign(m, 0);
+    for (uint64_t k = 0; k < m; ++k) {
+        const AvkDevRegion &dr = db->host.regions[cap[k]];
+        uint32_t c = 0;
+        while (c + 1 < ctx->contig_base.size() && ctx->contig_base[c + 1] <= dr.ref_off) c += 1;
+        rid[k] = cap[k];
+        cidx[k] = c;
+        st[k] = dr.ref_off - ctx->contig_base[c];
+        en[k] = st[k] + dr.len;
+        const uint32_t N = dr.t_cnt + dr.q_cnt;
+        const uint8_t *base = (const uint8_t *)(db->host.blob.data() + 2ull * dr.blob_off);
+        const AvkBlobVar *bv = (const AvkBlobVar *)base;
+        const uint8_t *ba = base + (((uint64_t)N * sizeof(AvkBlobVar) + 15) & ~15ull);
+        toff[k] = vpos.size();
+        tcnt[k] = dr.t_cnt;
+        qoff[k] = vpos.size() + dr.t_cnt;
+        qcnt[k] = dr.q_cnt;
+        fx->v_first[k] = vpos.size();
+        for (uint32_t i = 0; i < N; ++i) {
+            vpos.push_back(st[k] + bv[i].rel_pos);
+            vtype.push_back((uint8_t)(bv[i].type_zyg & 0xFF));
+            vzyg.push_back((uint8_t)((bv[i].type_zyg >> 8) & 0xFF));
+            vraw.push_back(bv[i].raw_space);
+            a0off.push_back(arena.size());
+            a0len.push_back(bv[i].a0_len);
+            arena.insert(arena.end(), ba + bv[i].a_off, ba + bv[i].a_off + bv[i].a0_len);
+            a1off.push_back(arena.size());
+            a1len.push_back(bv[i].a1_len);
+            arena.insert(arena.end(), ba + bv[i].a_off + bv[i].a0_len, ba + bv[i].a_off + bv[i].a0_len + bv[i].a1_len);
+        }
+    }
+    arena.push_back(0);
+    avk_region_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_regions = m;
+    b.region_id = rid.data(), b.contig_idx = cidx.data(), b.start = st.data(), b.end = en.data(), b.t_off = toff.data(), b.t_cnt = tcnt.data(), b.q_off = qoff.data(),
+    b.q_cnt = qcnt.data();
+    b.n_variants = vpos.size();
+    b.var_pos = vpos.data(), b.var_type = vtype.data(), b.var_zyg = vzyg.data(), b.var_raw_space = vraw.data(), b.a0_off = a0off.data(), b.a0_len = a0len.data(),
+    b.a1_off = a1off.data(), b.a1_len = a1len.data(), b.allele_bytes = arena.data(), b.allele_bytes_len = arena.size();
+    const uint64_t nvs = vpos.size();
+    fx->status.assign(m, 0), fx->ed1.assign(m, 0), fx->ed2.assign(m, 0), fx->nopt.assign(m, 0), fx->present.assign(m, 0);
+    fx->ve.assign(nvs + 1, 0), fx->vo.assign(nvs + 1, 0), fx->vc.assign(nvs + 1, 0), fx->vz.assign(nvs + 1, 0);
+    fx->tally.assign(AVK_TALLY_LEN, 0);
+    avk_result_batch o;
+    memset(&o, 0, sizeof(o));
+    o.status = fx->status.data(), o.ed_h1 = fx->ed1.data(), o.ed_h2 = fx->ed2.data(), o.n_optima = fx->nopt.data(), o.type_present = fx->present.data();
+    o.var_expected = fx->ve.data(), o.var_observed = fx->vo.data(), o.var_class = fx->vc.data(), o.var_zyg = fx->vz.data(), o.tally = fx->tally.data();
+    if (want_gm) {
+        fx->gm.assign(m * AVK_N_GROUPS * AVK_N_FIELDS, 0);
+        o.group_metrics = fx->gm.data();
+    }
+    if (want_seq) {
+        fx->seq_off.assign(m, 0), fx->seq_stride.assign(m, 0), fx->seq_len.assign(m * 5, 0);
+        uint64_t total = 0;
+        for (uint64_t k = 0; k < m; ++k) {
+            fx->seq_stride[k] = avk::seq_stride_of(&b, k);
+            fx->seq_off[k] = total;
+            total += 5ull * fx->seq_stride[k];
+        }
+        fx->seq.assign(total + 16, 0);
+        o.seq_bytes = fx->seq.data(), o.seq_off = fx->seq_off.data(), o.seq_stride = fx->seq_stride.data(), o.seq_len = fx->seq_len.data();
+    }
+    /* the big-slice tier alone */
+    const int64_t keep[] = {ctx->lds_bytes_per_wave, ctx->lds2_bytes_per_wave, ctx->ws_bytes_per_wave, ctx->big_ws_bytes, ctx->big_waves, ctx->lane_kernel, ctx->capacity_retry,
+                            ctx->emit_group_metrics};
+    ctx->lds_bytes_per_wave = 0, ctx->lds2_bytes_per_wave = 0, ctx->ws_bytes_per_wave = 0, ctx->big_ws_bytes = (int64_t)slice_bytes, ctx->big_waves = m < 4 ? (int64_t)m : 4,
+    ctx->lane_kernel = 0, ctx->capacity_retry = 0, ctx->emit_group_metrics = want_gm ? 1 : 0;
+    avk_dev_batch *sub = nullptr;
+    int rc = upload_internal(ctx, &b, false, &sub);
+    if (!rc) rc = run_internal(ctx, sub, &db->last_cfg, nullptr, 0);
+    if (!rc) rc = avk_results_download(ctx, sub, &o);
+    if (sub) avk_batch_free(ctx, sub);
+    ctx->lds_bytes_per_wave = keep[0], ctx->lds2_bytes_per_wave = keep[1], ctx->ws_bytes_per_wave = keep[2], ctx->big_ws_bytes = keep[3], ctx->big_waves = keep[4],
+    ctx->lane_kernel = keep[5], ctx->capacity_retry = keep[6], ctx->emit_group_metrics = keep[7];
+    return rc;
 }
 
 int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out) {
@@ -1178,6 +1323,69 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
             }
         }
     }
+    /* no solvable region stays a capacity failure: larger slices, level by level (an overflow status is only allowed when
+     * the library itself solves the region again) */
+    if (ctx->capacity_retry && db->has_run && db->last_mode == 0) {
+        std::vector<uint32_t> cap;
+        for (uint64_t r = 0; r < n; ++r)
+            if (out->status[r] == AVK_ST_CAPACITY) cap.push_back((uint32_t)r);
+        const bool big_grown = !cap.empty();
+        const size_t big_before = ctx->big_alloc;
+        uint64_t keep_tiers[5];
+        memcpy(keep_tiers, ctx->last_tiers, sizeof(keep_tiers));
+        const uint64_t keep_lane_solved = ctx->last_lane_solved;
+        for (uint64_t slice = 1ull << 30; !cap.empty() && slice <= (16ull << 30); slice <<= 2) {
+            if ((int64_t)slice <= ctx->big_ws_bytes) continue;
+            CapacityFix fx;
+            const bool want_gm = out->group_metrics && ctx->emit_group_metrics && db->d_gm;
+            const int rc = rerun_capacity_regions(ctx, db, cap, want_gm, want_seq, slice, &fx);
+            if (rc == AVK_E_OOM) break; /* the device cannot hold slices of this size: the regions keep their status */
+            if (rc) return rc;
+            std::vector<uint32_t> still;
+            for (uint64_t k = 0; k < fx.idx.size(); ++k) {
+                const uint32_t r = fx.idx[k];
+                if (fx.status[k] == AVK_ST_CAPACITY) {
+                    still.push_back(r);
+                    continue;
+                }
+                out->status[r] = fx.status[k];
+                if (out->ed_h1) out->ed_h1[r] = fx.ed1[k];
+                if (out->ed_h2) out->ed_h2[r] = fx.ed2[k];
+                if (out->n_optima) out->n_optima[r] = fx.nopt[k];
+                if (out->type_present) out->type_present[r] = fx.present[k];
+                const AvkDevRegion &dr = db->host.regions[r];
+                for (uint32_t i = 0; i < dr.t_cnt + dr.q_cnt; ++i) {
+                    const uint64_t hv = db->host.dev2host[dr.v_off + i], sv = fx.v_first[k] + i;
+                    if (out->var_expected) out->var_expected[hv] = fx.ve[sv];
+                    if (out->var_observed) out->var_observed[hv] = fx.vo[sv];
+                    if (out->var_class) out->var_class[hv] = fx.vc[sv];
+                    if (out->var_zyg) out->var_zyg[hv] = fx.vz[sv];
+                }
+                if (want_gm) memcpy(out->group_metrics + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
+                if (want_seq)
+                    for (int q = 0; q < 5; ++q) {
+                        uint32_t len = fx.seq_len[5 * k + q];
+                        if (len > out->seq_stride[r]) len = out->seq_stride[r];
+                        memcpy(out->seq_bytes + out->seq_off[r] + (uint64_t)q * out->seq_stride[r], fx.seq.data() + fx.seq_off[k] + (uint64_t)q * fx.seq_stride[k], len);
+                        out->seq_len[5 * r + q] = len;
+                    }
+            }
+            if (out->tally) { /* the sub-batch's sums come from its solved regions only */
+                for (int i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) out->tally[i] += fx.tally[i];
+                out->tally[AVK_TALLY_SOLVED] += fx.tally[AVK_TALLY_SOLVED];
+                out->tally[AVK_TALLY_ERRORS] -= fx.tally[AVK_TALLY_SOLVED];
+            }
+            cap.swap(still);
+        }
+        memcpy(ctx->last_tiers, keep_tiers, sizeof(keep_tiers)); /* the statistics of the caller's batch, not of the retries */
+        ctx->last_lane_solved = keep_lane_solved;
+        if (big_grown && ctx->big_alloc > big_before && ctx->d_big) { /* give the large slices back */
+            (void)hipStreamSynchronize(ctx->stream);
+            (void)hipFree(ctx->d_big);
+            ctx->d_big = nullptr;
+            ctx->big_alloc = 0;
+        }
+    }
     return 0;
 }
 
@@ -1217,6 +1425,59 @@ int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_com
                 ms(t3, std::chrono::steady_clock::now()));
     }
     return rc;
+}
+
+int avk_dwfa_script_batch(avk_ctx *ctx, int engine, uint32_t n_scripts, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *base_off, const uint64_t *other_off,
+                          const uint64_t *step_off, const uint8_t *step_op, const uint32_t *step_blen, const uint32_t *step_olen, uint32_t *step_ed,
+                          int32_t *step_status, uint32_t wf_cap, uint32_t *final_wf, uint32_t *final_wf_len) {
+    if (!ctx || !bytes || !base_off || !other_off || !step_off || !step_op || !step_blen || !step_olen || !step_ed || !step_status) return AVK_E_ARG;
+    if (engine != 0 && engine != 1) return fail(ctx, AVK_E_ARG, "engine must be 0 (wave per script) or 1 (lane per script)");
+    if (n_scripts == 0) return 0;
+    if (wf_cap < 3) return fail(ctx, AVK_E_ARG, "wf_cap must be at least 3");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n_steps = step_off[n_scripts];
+    for (uint32_t s = 0; s < n_scripts; ++s) {
+        if (step_off[s + 1] < step_off[s] || base_off[s] > n_bytes || other_off[s] > n_bytes) return fail(ctx, AVK_E_ARG, "script %u: offsets out of range", s);
+        for (uint64_t k = step_off[s]; k < step_off[s + 1]; ++k)
+            if (step_op[k] > 1 || base_off[s] + step_blen[k] > n_bytes || other_off[s] + step_olen[k] > n_bytes)
+                return fail(ctx, AVK_E_ARG, "script %u: a step reads past the byte arena", s);
+    }
+    AvkDwfaArgs a;
+    memset(&a, 0, sizeof(a));
+    a.wf_cap = wf_cap;
+    a.n_scripts = n_scripts;
+    std::vector<void *> allocs;
+    auto up = [&](const void *src, size_t nbytes, void **dst) -> hipError_t {
+        hipError_t e = hipMalloc(dst, nbytes ? nbytes : 16);
+        if (e != hipSuccess) return e;
+        allocs.push_back(*dst);
+        return nbytes && src ? hipMemcpyAsync(*dst, src, nbytes, hipMemcpyHostToDevice, ctx->stream) : hipSuccess;
+    };
+    hipError_t e = up(bytes, n_bytes, (void **)&a.bytes);
+    if (e == hipSuccess) e = up(base_off, n_scripts * sizeof(uint64_t), (void **)&a.base_off);
+    if (e == hipSuccess) e = up(other_off, n_scripts * sizeof(uint64_t), (void **)&a.other_off);
+    if (e == hipSuccess) e = up(step_off, (n_scripts + 1) * sizeof(uint64_t), (void **)&a.step_off);
+    if (e == hipSuccess) e = up(step_op, n_steps, (void **)&a.step_op);
+    if (e == hipSuccess) e = up(step_blen, n_steps * sizeof(uint32_t), (void **)&a.step_blen);
+    if (e == hipSuccess) e = up(step_olen, n_steps * sizeof(uint32_t), (void **)&a.step_olen);
+    if (e == hipSuccess) e = up(nullptr, n_steps * sizeof(uint32_t), (void **)&a.step_ed);
+    if (e == hipSuccess) e = up(nullptr, n_steps * sizeof(int32_t), (void **)&a.step_status);
+    if (e == hipSuccess && final_wf) e = up(nullptr, (size_t)n_scripts * wf_cap * sizeof(uint32_t), (void **)&a.final_wf);
+    if (e == hipSuccess && final_wf_len) e = up(nullptr, (size_t)n_scripts * sizeof(uint32_t), (void **)&a.final_wf_len);
+    if (e == hipSuccess && engine == 0) e = up(nullptr, (size_t)n_scripts * wf_cap * sizeof(uint32_t), (void **)&a.ws);
+    if (e == hipSuccess) {
+        if (engine == 0) hipLaunchKernelGGL(avk_dwfa_wave_kernel, dim3((n_scripts + 3) / 4), dim3(256), 0, ctx->stream, a);
+        else hipLaunchKernelGGL(avk_dwfa_lane_kernel, dim3((n_scripts + 63) / 64), dim3(64), (size_t)(3 * (AVK_DWFA_LANE_W + 1) + 3 * ((2 * AVK_DWFA_LANE_ED + 2 + 3) / 4)) * 256, ctx->stream, a);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(step_ed, a.step_ed, n_steps * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(step_status, a.step_status, n_steps * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && final_wf) e = hipMemcpyAsync(final_wf, a.final_wf, (size_t)n_scripts * wf_cap * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess && final_wf_len) e = hipMemcpyAsync(final_wf_len, a.final_wf_len, (size_t)n_scripts * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    for (void *p : allocs) (void)hipFree(p);
+    if (e != hipSuccess) return fail(ctx, AVK_E_HIP, "avk_dwfa_script_batch failed: %s", hipGetErrorString(e));
+    return 0;
 }
 
 int avk_label_tallies(avk_ctx *ctx, avk_dev_batch *db, uint32_t n_labels, const uint64_t *label_off, const uint32_t *label_idx, uint64_t *out) {

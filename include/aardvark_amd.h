@@ -85,7 +85,8 @@ enum {
     AVK_ST_AUTOFAIL_OOB = 11,   /* all_variant_order[auto_fail_index] out of bounds, exact_gt_optimizer.rs:312 */
     AVK_ST_INVALID_INPUT = 20,  /* rejected by host validation (window outside contig, variant outside
                                    window, unsorted variants, empty allele): the reference panics or is undefined */
-    AVK_ST_CAPACITY = 21        /* device workspace exhausted at the largest tier */
+    AVK_ST_CAPACITY = 21        /* device workspace exhausted at the largest tier AND in the library's own retries with slices of
+                                   1, 4 and 16 GB (avk_results_download, context option "capacity_retry", default 1) */
 };
 
 /* infrastructure errors (function return values) */
@@ -229,6 +230,19 @@ int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the e
 int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
                                                              they are not counted in any workspace tier */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
+
+/* The device aligner by itself: a batch of DWFALite SCRIPTS (reference src/dwfa/dynamic_wfa.rs:23-276).  Script s works on the two
+ * byte strings bytes[base_off[s]..] ("baseline") and bytes[other_off[s]..] ("other") and makes the calls step_off[s] .. step_off[s+1]:
+ * step_op 0 = update(baseline[..step_blen], other[..step_olen]) (:68-84), 1 = finalize(..) (:183-198) on ONE aligner state, as the
+ * reference's tests do (dynamic_wfa.rs:283-468).  Outputs per step: edit_distance() after the call and a status (0; 2 = the aligner was
+ * already finalized, :69-71; AVK_ST_CAPACITY = more than wf_cap wavefront entries; engine 1 only: AVK_ST_INVALID_INPUT for symbols other
+ * than ACGT or strings over 192 bases); optionally the final wavefront (final_wf [n][wf_cap], final_wf_len [n]).
+ * engine 0: one wavefront per script, the lane-group aligner of the wave-per-region kernels; engine 1: one lane per script, the 2-bit
+ * aligner of the lane-per-region kernel. */
+int  avk_dwfa_script_batch(avk_ctx *ctx, int engine, uint32_t n_scripts, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *base_off,
+                           const uint64_t *other_off, const uint64_t *step_off, const uint8_t *step_op, const uint32_t *step_blen,
+                           const uint32_t *step_olen, uint32_t *step_ed, int32_t *step_status, uint32_t wf_cap, uint32_t *final_wf,
+                           uint32_t *final_wf_len);
 /* profiling builds of the library only (-DAVK_PHASE_TIMING): summed clock ticks per solver phase of the last download:
  * [0] stage, [1] search A, [2] search B, [3] metrics setup, [4] base-pair metrics, [5] record metrics, [6] whole region,
  * [7] region count, [8..13] inside search A: setup, pop + quota, finalise, clone, extend, push */

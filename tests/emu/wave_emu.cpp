@@ -151,6 +151,7 @@ static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
 namespace avk { namespace lane { uint64_t g_lane_stats[16]; } }
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
+#include "../../aardvark_amd/csrc/avk_dwfa_script.inl"
 
 namespace {
 
@@ -563,6 +564,41 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     if (tier_counts) memcpy(tier_counts, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
     g_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
+    return 0;
+}
+
+/* avk_dwfa_script_batch on emulated wavefronts / lanes (same device functions, avk_dwfa_script.inl) */
+struct DwfaTask {
+    AvkDwfaArgs a;
+    uint32_t first; /* engine 0: the script; engine 1: the first script of the wave's 64 */
+    int engine;
+    uint32_t *lds;
+};
+static void dwfa_task_main(void *p, int lane) {
+    DwfaTask *t = (DwfaTask *)p;
+    if (t->engine == 0) avk::dwfa_script_wave(t->a, t->first);
+    else if (t->first + (uint32_t)lane < t->a.n_scripts) avk::lane::dwfa_script_lane(t->a, t->first + (uint32_t)lane, t->lds);
+}
+int emu_dwfa_script_batch(int engine, uint32_t n_scripts, const uint8_t *bytes, uint64_t n_bytes, const uint64_t *base_off, const uint64_t *other_off,
+                          const uint64_t *step_off, const uint8_t *step_op, const uint32_t *step_blen, const uint32_t *step_olen, uint32_t *step_ed,
+                          int32_t *step_status, uint32_t wf_cap, uint32_t *final_wf, uint32_t *final_wf_len) {
+    (void)n_bytes;
+    std::vector<uint32_t> ws((size_t)n_scripts * wf_cap + 64), lds((size_t)avk::lane::dwfa_lane_rows() * 64 + 64, 0x5A5A5A5Au);
+    DwfaTask t;
+    memset(&t.a, 0, sizeof(t.a));
+    t.a.bytes = bytes, t.a.base_off = base_off, t.a.other_off = other_off, t.a.step_off = step_off, t.a.step_op = step_op, t.a.step_blen = step_blen,
+    t.a.step_olen = step_olen, t.a.step_ed = step_ed, t.a.step_status = step_status, t.a.final_wf = final_wf, t.a.final_wf_len = final_wf_len, t.a.ws = ws.data(),
+    t.a.wf_cap = wf_cap, t.a.n_scripts = n_scripts;
+    t.engine = engine;
+    t.lds = lds.data();
+    avk_emu::Wave w;
+    w.stack_bytes = 256 * 1024;
+    std::vector<char> stacks(64 * w.stack_bytes + 64);
+    w.stacks = stacks.data();
+    for (uint32_t s = 0; s < n_scripts; s += engine == 0 ? 1u : 64u) {
+        t.first = s;
+        avk_emu::run_wave(&w, dwfa_task_main, &t);
+    }
     return 0;
 }
 

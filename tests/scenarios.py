@@ -174,3 +174,34 @@ def chr20_small(n_truth=3000):
 def indel_small(n_truth=2500):
     contig, batch = synth.config_indel_mix(n_truth=n_truth, contig_len=1_500_000, n_intervals=40)
     return [contig], batch
+
+
+def optimizer_golden_regions():
+    """the regions of the reference's optimize_sequences tests (src/query_optimizer.rs:533-665) as compare regions, with their expectations"""
+    q = json.load(open(os.path.join(GOLD, "query_optimizer.json")))
+    regions = [{"start": r["start"], "end": r["end"], "truth": [tuple(v) for v in r["truth"]], "query": [tuple(v) for v in r["query"]]} for r in q["regions"]]
+    return [q["contig"].encode()], RegionBatch.from_regions(regions), [r["expect"] for r in q["regions"]]
+
+
+def max_allele_regions(seed=15):
+    """alleles at the reference's size limit (variants over 10 kbp are dropped by its feeder, region_generation.rs:621-626): a 10,000-base
+    insertion pair that differs in a hundred places, a 10,000-base deletion against a 9,000-base deletion, and the reference's 5,278-edit
+    DWFA vector (dynamic_wfa.rs:453-468) as a region: the window is its 651-base string, the query call replaces it by its 5,929-base string"""
+    rng = np.random.default_rng(seed)
+    big = json.load(open(os.path.join(GOLD, "dwfa_big.json")))
+    base, other = big["baseline"].encode(), big["other"].encode()
+    contig = np.concatenate([synth.ACGT[rng.integers(0, 4, size=40000, dtype=np.uint8)], np.frombuffer(base, np.uint8), synth.ACGT[rng.integers(0, 4, size=500, dtype=np.uint8)]])
+    ins = bytes(synth.ACGT[rng.integers(0, 4, size=9999, dtype=np.uint8)])
+    ins2 = bytearray(ins)
+    for i in range(0, 9999, 101):
+        ins2[i] = ord("A") if ins2[i] != ord("A") else ord("C")
+    a = lambda lo, hi: contig[lo:hi].tobytes()
+    regions = [
+        {"start": 100, "end": 400, "truth": [(200, a(200, 201), a(200, 201) + ins, "Insertion", "HomozygousAlternate")],
+         "query": [(200, a(200, 201), a(200, 201) + bytes(ins2), "Insertion", "UnphasedHeterozygous")]},
+        {"start": 1000, "end": 11200, "truth": [(1100, a(1100, 11100), a(1100, 1101), "Deletion", "PhasedHet10")],
+         "query": [(1100, a(1100, 10100), a(1100, 1101), "Deletion", "UnphasedHeterozygous"),
+                   (11150, a(11150, 11151), b"T" if contig[11150] != ord("T") else b"G", "Snv", "HomozygousAlternate")]},
+        {"start": 40000, "end": 40000 + len(base), "truth": [], "query": [(40000, base, other, "Indel", "HomozygousAlternate")]},
+    ]
+    return [contig.tobytes()], RegionBatch.from_regions(regions), big["ed_after_finalize"]
