@@ -34,6 +34,7 @@ void usage() {
     fprintf(stderr,
             "usage: aardvark_amd_compare -r REF.fa[.gz] -t TRUTH.vcf[.gz] -q QUERY.vcf[.gz] -b REGIONS.bed[.gz] -o OUT_DIR\n"
             "  [--truth-sample S] [--query-sample S] [--compare-label L] [--min-variant-gap 50] [--disable-variant-trimming]\n"
+            "  [--reference-case upper|raw]  (default upper: soft-masked reference bases are compared as upper case)\n"
             "  [--max-branch-factor 50] [--enable-exact-shortcut] [--enable-haplotype-metrics] [--enable-weighted-haplotype-metrics]\n"
             "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0 | --devices 0,1,..] [--batch-regions 4000000]\n");
 }
@@ -62,6 +63,7 @@ int main(int argc, char **argv) {
     std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare", strat_tsv, debug_dir;
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000, threads = 1, max_ed = 5000, verbosity = 0;
     bool trimming = true, shortcut = false, hap = false, whap = false, rbp = false;
+    bool ref_upper = true; /* --reference-case upper|raw (include/aardvark_feeder.h, avf_genome_load_case) */
     int device = 0;
     std::vector<int> devices; /* --devices: the contexts that share the region batches (the first one is `device`) */
     bool batch_given = false;
@@ -81,6 +83,11 @@ int main(int argc, char **argv) {
         else if (a == "--compare-label") label = val();
         else if (a == "--min-variant-gap") gap = strtoull(val(), nullptr, 10);
         else if (a == "--disable-variant-trimming") trimming = false;
+        else if (a == "--reference-case") {
+            const std::string v = val();
+            if (v != "upper" && v != "raw") die(78, "--reference-case must be 'upper' or 'raw'", "");
+            ref_upper = v == "upper";
+        }
         else if (a == "--max-branch-factor") branch = strtoull(val(), nullptr, 10);
         else if (a == "--enable-exact-shortcut") shortcut = true;
         else if (a == "--enable-haplotype-metrics") hap = true;
@@ -183,7 +190,7 @@ int main(int argc, char **argv) {
         if (rc_ctx) err_ctx = avk_last_error(nullptr);
         s_ctx = seconds_since(t);
     });
-    const int rc_genome = avf_genome_load(ref.c_str(), &genome);
+    const int rc_genome = avf_genome_load_case(ref.c_str(), ref_upper ? 1 : 0, &genome);
     const std::string err_genome = rc_genome ? avf_last_error() : "";
     const double s_genome = seconds_since(t0);
     for (std::thread &t : th_calls) t.join();

@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
     std::vector<std::string> vcfs, samples, tags;
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 1000000, threads = 1, verbosity = 0, contexts = 2;
     bool trimming = true, no_conflict = false, voting = false;
+    bool ref_upper = true; /* --reference-case upper|raw (include/aardvark_feeder.h, avf_genome_load_case) */
     long long conflict_select = -1;
     int device = 0;
     for (int i = 1; i < argc; ++i) {
@@ -87,6 +88,11 @@ int main(int argc, char **argv) {
         else if (a == "--output-debug") debug_dir = val();
         else if (a == "--min-variant-gap") gap = strtoull(val(), nullptr, 10);
         else if (a == "--disable-variant-trimming") trimming = false;
+        else if (a == "--reference-case") {
+            const std::string v = val();
+            if (v != "upper" && v != "raw") die(78, "--reference-case must be 'upper' or 'raw'", "");
+            ref_upper = v == "upper";
+        }
         else if (a == "--merge-strategy") strategy = val();
         else if (a == "--enable-no-conflict") no_conflict = true;
         else if (a == "--enable-voting") voting = true;
@@ -163,7 +169,7 @@ int main(int argc, char **argv) {
         rc_ctx = avk_ctx_create(device, &ctx);
         if (rc_ctx) err_ctx = avk_last_error(nullptr);
     });
-    const int rc_genome = avf_genome_load(ref.c_str(), &genome);
+    const int rc_genome = avf_genome_load_case(ref.c_str(), ref_upper ? 1 : 0, &genome);
     const std::string err_genome = rc_genome ? avf_last_error() : "";
     const double s_genome = seconds_since(t0);
     for (std::thread &t : pool) t.join();

@@ -940,7 +940,7 @@ const char *avf_last_error(void) { return t_error.c_str(); }
 /* Uncompressed FASTA files are mapped and parsed by several threads: header lines are found first ('>' at a line start), then
  * every sequence body is cut into pieces whose kept bytes (everything but line terminators) are counted and copied side by side.
  * Same result as the line-by-line reader below, which still serves gzip / BGZF files. */
-static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n, avf_genome *g) {
+static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n, avf_genome *g, bool upper) {
     const unsigned hw = std::thread::hardware_concurrency();
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, 32));
     auto parallel = [&](size_t items, const std::function<void(size_t)> &fn) {
@@ -1036,6 +1036,8 @@ static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n
             size_t keep_to = stop;
             if (keep_to > at && d[keep_to - 1] == '\r' && dropped(keep_to - 1)) keep_to -= 1;
             memcpy(out, d + at, keep_to - at);
+            if (upper) /* soft-masked (lower-case) bases become upper case: see avf_genome_load_case */
+                for (size_t j = 0; j < keep_to - at; ++j) out[j] = (uint8_t)(out[j] >= 'a' && out[j] <= 'z' ? out[j] - 32 : out[j]);
             out += keep_to - at;
             at = q ? stop + 1 : pc.hi;
         }
@@ -1044,8 +1046,11 @@ static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n
     return 0;
 }
 
-int avf_genome_load(const char *fasta_path, avf_genome **out) {
+int avf_genome_load(const char *fasta_path, avf_genome **out) { return avf_genome_load_case(fasta_path, 1, out); }
+
+int avf_genome_load_case(const char *fasta_path, int upper_case, avf_genome **out) {
     if (!fasta_path || !out) return fail(AVK_E_ARG, "null argument");
+    const bool upper = upper_case != 0;
     *out = nullptr;
     avf_genome *g = new avf_genome();
     /* plain text (no gzip magic): map it */
@@ -1104,7 +1109,7 @@ int avf_genome_load(const char *fasta_path, avf_genome **out) {
                 munmap(m, (size_t)st.st_size);
                 if (ok) {
                     close(fd);
-                    const int rc = genome_load_mapped(fasta_path, raw.data(), raw.size(), g);
+                    const int rc = genome_load_mapped(fasta_path, raw.data(), raw.size(), g, upper);
                     if (rc) {
                         delete g;
                         return rc;
@@ -1119,7 +1124,7 @@ int avf_genome_load(const char *fasta_path, avf_genome **out) {
         if (regular && !gz) {
             void *m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
             if (m != MAP_FAILED) {
-                const int rc = genome_load_mapped(fasta_path, (const uint8_t *)m, (size_t)st.st_size, g);
+                const int rc = genome_load_mapped(fasta_path, (const uint8_t *)m, (size_t)st.st_size, g, upper);
                 munmap(m, (size_t)st.st_size);
                 close(fd);
                 if (rc) {
@@ -1152,6 +1157,8 @@ int avf_genome_load(const char *fasta_path, avf_genome **out) {
             delete g;
             return fail(AVK_E_ARG, "%s: sequence before the first header", fasta_path);
         }
+        if (upper)
+            for (char &ch : line) ch = (char)(ch >= 'a' && ch <= 'z' ? ch - 32 : ch);
         g->seqs.back().insert(g->seqs.back().end(), line.begin(), line.end());
     }
     if (in.failed()) {

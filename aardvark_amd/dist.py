@@ -38,6 +38,32 @@ def shard_batch(batch, rank, world):
     return take_regions(batch, shard_indices(batch.region_id, rank, world))
 
 
+def result_checksum(batch, res):
+    """An order-independent 64-bit checksum of every per-region and per-variant output of `res` for the regions of `batch`: the sum, modulo
+    2^64, of a hash per region (region_id, status, ed_h1, ed_h2, optima, types) and a hash per variant (region_id, index in the region,
+    expected, observed, class, resolved zygosity).  The checksums of the shards of a job add up to the checksum of the whole job, so a
+    sharded run can be compared with a single-process one by one integer (bench.py --scaling strong)."""
+    with np.errstate(over="ignore"):
+        rid = np.asarray(batch.region_id, np.uint64)
+        w = (res.status.astype(np.int64).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + res.ed_h1.astype(np.uint64) * np.uint64(1000003) +
+             res.ed_h2.astype(np.uint64) * np.uint64(998244353) + res.n_optima.astype(np.uint64) * np.uint64(7919) + res.type_present.astype(np.uint64) * np.uint64(104729))
+        total = region_hash(rid * np.uint64(3) + np.uint64(1) + w * np.uint64(0xD6E8FEB86659FD93)).sum(dtype=np.uint64)
+        for side, off, cnt in ((np.uint64(1), batch.t_off, batch.t_cnt), (np.uint64(2), batch.q_off, batch.q_cnt)):
+            cnt64 = np.asarray(cnt, np.int64)
+            n = int(cnt64.sum())
+            if n == 0:
+                continue
+            first = np.cumsum(cnt64) - cnt64
+            reg = np.repeat(np.arange(batch.n_regions), cnt64)
+            k = np.arange(n, dtype=np.int64) - np.repeat(first, cnt64)
+            v = (np.repeat(np.asarray(off, np.int64), cnt64) + k)
+            word = (res.var_expected[v].astype(np.uint64) | (res.var_observed[v].astype(np.uint64) << np.uint64(8)) |
+                    (res.var_class[v].astype(np.uint64) << np.uint64(16)) | (res.var_zyg[v].astype(np.uint64) << np.uint64(24)))
+            total = total + region_hash(rid[reg] * np.uint64(1315423911) + k.astype(np.uint64) * np.uint64(2654435761) + side * np.uint64(0x51ED27) +
+                                        word * np.uint64(0x9E3779B97F4A7C15)).sum(dtype=np.uint64)
+    return int(total)
+
+
 def allreduce_tally(tally):
     """in-place SUM all-reduce of an int64 tally tensor over the default process group"""
     import torch.distributed as dist

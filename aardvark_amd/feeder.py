@@ -104,12 +104,16 @@ def _arr(ptr, n, dtype):
 
 
 class Genome:
-    """ReferenceGenome::from_fasta: contigs in file order."""
+    """ReferenceGenome::from_fasta: contigs in file order.  case: "upper" (default: soft-masked bases are loaded as upper case, like
+    the tools' --reference-case upper) or "raw" (the file's bytes); see avf_genome_load_case in include/aardvark_feeder.h."""
 
-    def __init__(self, fasta_path):
+    def __init__(self, fasta_path, case="upper"):
+        if case not in ("upper", "raw"):
+            raise ValueError("case must be 'upper' or 'raw'")
         self.lib = load_library()
         h = C.c_void_p()
-        _check(self.lib, self.lib.avf_genome_load(os.fsencode(fasta_path), C.byref(h)))
+        self.lib.avf_genome_load_case.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+        _check(self.lib, self.lib.avf_genome_load_case(os.fsencode(fasta_path), 1 if case == "upper" else 0, C.byref(h)))
         self.handle = h
         n = self.lib.avf_genome_n_contigs(h)
         self.names = [self.lib.avf_genome_name(h, i).decode() for i in range(n)]

@@ -33,7 +33,15 @@ const char *avf_last_error(void);
 
 /* FASTA (plain or gzip/BGZF): contig name = header up to the first white space, sequence bytes as they are in
  * the file (no case folding). */
-int avf_genome_load(const char *fasta_path, avf_genome **out);
+int avf_genome_load(const char *fasta_path, avf_genome **out); /* = avf_genome_load_case(path, 1, out) */
+/* Case of the reference bases.  ReferenceGenome::from_fasta lives in a crate that is not vendored with the reference
+ * (rust-lib-reference-genome 0.2.1; its dependencies are bio, flate2, log, rustc-hash, simple-error — Cargo.lock:1344-1353), so whether it
+ * folds case cannot be read there; every test of the reference uses upper-case contigs.  GRCh38 is about half soft-masked (lower case)
+ * while VCF alleles are upper case; compared as raw bytes, wfa_ed(reference window, haplotype) (waffle_solver.rs:639-656) would count a
+ * case difference for every ALT base that re-states a lower-case reference base.  upper_case = 1 (the default of this build and of the
+ * tools, --reference-case upper) maps a-z to A-Z while loading: IUPAC codes and N stay as they are; 0 (--reference-case raw) keeps the
+ * file's bytes. */
+int avf_genome_load_case(const char *fasta_path, int upper_case, avf_genome **out);
 uint32_t avf_genome_n_contigs(const avf_genome *g);
 const char *avf_genome_name(const avf_genome *g, uint32_t i);
 const uint8_t *avf_genome_seq(const avf_genome *g, uint32_t i);

@@ -39,6 +39,10 @@ def _worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, "idx_%d.npy" % rank), mine)
     np.save(os.path.join(out_dir, "status_%d.npy" % rank), res.status)
     np.save(os.path.join(out_dir, "gm_%d.npy" % rank), res.group_metrics)
+    # what bench.py --scaling strong does: per-shard checksums summed over the ranks (int64 wrap-around = sum modulo 2^64)
+    chk = torch.from_numpy(np.array([avk_dist.result_checksum(shard, res)], np.uint64).view(np.int64).copy())
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    np.save(os.path.join(out_dir, "chk_%d.npy" % rank), chk.numpy().view(np.uint64))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -61,5 +65,10 @@ def test_two_rank_sharding_and_tally_allreduce(tmp_path, oracle):
         assert np.array_equal(np.load(tmp_path / ("status_%d.npy" % r)), want.status[idx])
         assert np.array_equal(np.load(tmp_path / ("gm_%d.npy" % r)), want.group_metrics[idx])
     assert seen.all()
+    whole = avk_dist.result_checksum(batch, want)
+    assert int(np.load(tmp_path / "chk_0.npy")[0]) == whole == int(np.load(tmp_path / "chk_1.npy")[0])
+    broken = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
+    broken.var_observed[3] ^= 1
+    assert avk_dist.result_checksum(batch, broken) != whole  # one flipped decision changes the checksum
     sizes = [len(np.load(tmp_path / ("idx_%d.npy" % r))) for r in range(world)]
     assert abs(sizes[0] - sizes[1]) < 0.1 * batch.n_regions  # the hash balances the shards

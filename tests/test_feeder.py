@@ -170,11 +170,11 @@ def test_mapped_fasta_loader_matches_the_line_reader(tmp_path, monkeypatch):
         plain, gz = str(tmp_path / ("f%d.fa" % ti)), str(tmp_path / ("f%d.fa.gz" % ti))
         write_text(plain, text)
         write_text(gz, text, "gz")
-        want = feeder.Genome(gz)
+        want = feeder.Genome(gz, case="raw")
         ref = dict(fo.read_fasta(gz))
         for piece in ("1", "2", "3", "7", "64", "1000000"):
             monkeypatch.setenv("AVF_FASTA_PIECE", piece)
-            got = feeder.Genome(plain)
+            got = feeder.Genome(plain, case="raw")
             assert got.names == want.names
             for a, b, name in zip(got.contigs(), want.contigs(), got.names):
                 assert bytes(a) == bytes(b) == ref[name].encode()
@@ -183,8 +183,12 @@ def test_mapped_fasta_loader_matches_the_line_reader(tmp_path, monkeypatch):
             bg = str(tmp_path / ("f%d_%d.fa.bgz" % (ti, block)))
             open(bg, "wb").write(bgzf_bytes(text.encode(), block))
             monkeypatch.setenv("AVF_FASTA_PIECE", "33")
-            got = feeder.Genome(bg)
+            got = feeder.Genome(bg, case="raw")
             assert got.names == want.names and all(bytes(a) == bytes(b) for a, b in zip(got.contigs(), want.contigs()))
+            up = feeder.Genome(bg)  # the default folds soft-masked bases to upper case, whatever the loader
+            assert all(bytes(a) == bytes(b).upper() for a, b in zip(up.contigs(), want.contigs()))
+        for path in (plain, gz):
+            assert all(bytes(a) == bytes(b).upper() for a, b in zip(feeder.Genome(path).contigs(), want.contigs()))
     damaged = bytearray(bgzf_bytes(texts[2].encode(), 200))
     damaged[len(damaged) // 2] ^= 0x11
     dpath = str(tmp_path / "damaged.fa.gz")
@@ -195,6 +199,30 @@ def test_mapped_fasta_loader_matches_the_line_reader(tmp_path, monkeypatch):
     write_text(bad, "\nACGT\n>c\nAC\n")
     with pytest.raises(feeder.FeederError, match="sequence before the first header"):
         feeder.Genome(bad)
+
+
+def test_soft_masked_reference_is_compared_as_upper_case(tmp_path, oracle):
+    """GRCh38-style soft masking: the same calls against an upper-case contig and against its soft-masked twin give the same results with
+    the default --reference-case upper; with raw bytes an ALT that re-states masked reference bases is charged for the case difference"""
+    rng = np.random.default_rng(11)
+    contig = "".join(rng.choice(list("ACGT"), size=600))
+    masked = contig[:200] + contig[200:420].lower() + contig[420:]
+    # MNV at 0-based 300 (inside the masked stretch): REF = 3 reference bases, ALT keeps the first two (upper case in the VCF) and changes the third
+    ref3 = contig[300:303]
+    alt3 = ref3[:2] + ("A" if ref3[2] != "A" else "C")
+    calls = [(300, ref3, alt3, "HomozygousAlternate"), (449, contig[449], "A" if contig[449] != "A" else "C", "UnphasedHeterozygous")]  # 0-based
+    write_text(str(tmp_path / "truth.vcf"), vcf_text("c", calls))
+    write_text(str(tmp_path / "query.vcf"), vcf_text("c", calls))
+    write_text(str(tmp_path / "r.bed"), "c\t0\t600\n")
+    res = {}
+    for name, seq, case in (("upper_file", contig, "upper"), ("masked_default", masked, "upper"), ("masked_raw", masked, "raw")):
+        write_text(str(tmp_path / (name + ".fa")), ">c\n" + seq + "\n")
+        g = feeder.Genome(str(tmp_path / (name + ".fa")), case=case)
+        feed = feeder.feed_compare(str(tmp_path / "truth.vcf"), str(tmp_path / "query.vcf"), str(tmp_path / "r.bed"), g, enable_trimming=False)
+        res[name] = oracle_lib.compare_batch(oracle, feed.batch, g.contigs())
+    assert res["masked_default"].diff(res["upper_file"]) == []
+    bp = lambda r: int(r.tally[F["BP_TRUTH_TP"]])
+    assert bp(res["masked_raw"]) > bp(res["upper_file"])  # raw bytes: "ac" vs "AC" counts as two more edits on each haplotype
 
 
 def test_block_parallel_vcf_reader_matches_the_sequential_one(tmp_path, monkeypatch):

@@ -80,11 +80,9 @@ for f in vm:
 n_regions = n_truth = 0
 for ci, (name, full) in enumerate(zip(NAMES, GRCH38)):
     length = max(int(full * scale), 200_000)
-    contig = synth.make_contig(length, 20250103 + ci)
-    rng = np.random.default_rng(20250103 + 100 + ci)
-    bed = synth.make_bed(length, max(4, int(1000 * length / 64_444_167)), 0.9, rng)
-    truth = synth.indel_truth(contig, bed, int(length * density), 20250103 + 200 + ci)
-    query = synth.perturb_query(contig, bed, truth, 20250104 + ci, max(1, len(truth) // 100))
+    # the call sets of bench.py's workload (synth.contig_calls: multi-allelic sites as two records at one position, repeat-run indels with
+    # the query record shifted by whole units)
+    contig, bed, truth, query = synth.contig_calls(ci, length, density)
     n_truth += len(truth)
     fa.write(b">" + name.encode() + b"\n")
     pad = (-length) % 80
@@ -92,11 +90,16 @@ for ci, (name, full) in enumerate(zip(NAMES, GRCH38)):
     body = np.concatenate([rows, np.full((rows.shape[0], 1), 10, np.uint8)], axis=1).tobytes()
     fa.write(body[:len(body) - pad - 1] + b"\n" if pad else body)
     bedf.write("".join("%s\t%d\t%d\n" % (name, a, b) for a, b in bed))
+    def records(cs):
+        out = []
+        for i in range(len(cs)):
+            a0, a1 = cs.alleles(contig, i)
+            out.append("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (name, int(cs.pos[i]) + 1, a0.decode(), a1.decode(), GT[int(cs.zyg[i])]))
+        return "".join(out)
     for f, cs in ((vt, truth), (vq, query)):
-        f.write("".join("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (name, int(cs.pos[i]) + 1, cs.ref[i].decode(), cs.alt[i].decode(), GT[int(cs.zyg[i])]) for i in range(len(cs))))
+        f.write(records(cs))
     for i, f in enumerate(vm):
-        cs = synth.perturb_query(contig, bed, truth, 20250105 + 1000 * i + ci, max(1, len(truth) // 100))
-        f.write("".join("%s\t%d\t.\t%s\t%s\t.\tPASS\t.\tGT\t%s\n" % (name, int(cs.pos[j]) + 1, cs.ref[j].decode(), cs.alt[j].decode(), GT[int(cs.zyg[j])]) for j in range(len(cs))))
+        f.write(records(synth.genome_query(contig, bed, truth, (np.zeros(len(truth), np.int64), np.zeros(len(truth), np.int64)), 20250105 + 1000 * i + ci, max(1, len(truth) // 100))))
     del contig, truth, query, rows, body
 for f in [fa, bedf, vt, vq] + vm:
     f.close()
@@ -138,6 +141,32 @@ if os.environ.get("VERIFY", "0") == "1":  # the whole run again on the CPU: feed
     want = fo.summary_text(res.tally, "compare", ("GT", "BASEPAIR"))
     print("oracle on %d regions in %.1f s (feeder + %d threads); summary.tsv identical to oracle + restated writer: %s; error regions %d" % (
         feed.batch.n_regions, time.time() - t0, os.cpu_count(), summary_text == want if not n_strat else "n/a (stratified)", int((res.status != 0).sum())))
+    # per-variant decisions: every record of the two annotated VCFs (position and the GT:BD:EA:OA:RI column) against the oracle's
+    # per-variant arrays (VariantCategorizer::write_variants, src/writers/variant_categorizer.rs:160-226: one record per variant of every
+    # solved region, regions in order, the side's variants in order)
+    t0 = time.time()
+    b = feed.batch
+    gt_txt = np.array([".", "0/0", "0/1", "0|1", "1|0", "1/1"])
+    cls_txt = np.array(["UNK", "TP", "FN", "FP"])
+    ok_all = True
+    for side, name, off, cnt in ((0, "truth.vcf.gz", b.t_off, b.t_cnt), (1, "query.vcf.gz", b.q_off, b.q_cnt)):
+        cnt64 = np.where(res.status == 0, cnt, 0).astype(np.int64)
+        first = np.cumsum(cnt64) - cnt64
+        reg = np.repeat(np.arange(b.n_regions), cnt64)
+        v = np.repeat(off.astype(np.int64), cnt64) + (np.arange(int(cnt64.sum())) - np.repeat(first, cnt64))
+        want_pos = b.var_pos[v].astype(np.int64) + 1
+        col = np.char.add(np.char.add(np.char.add(np.char.add(gt_txt[b.var_zyg[v]], ":"), cls_txt[res.var_class[v]]), ":"),
+                          np.char.add(np.char.add(res.var_expected[v].astype(str), ":"), np.char.add(np.char.add(res.var_observed[v].astype(str), ":"), b.region_id[reg].astype(str))))
+        got_pos, got_col = [], []
+        for line in gzip.open(os.path.join(d, "out", name), "rt"):
+            if line[0] == "#":
+                continue
+            f = line.rstrip("\n").split("\t")
+            got_pos.append(int(f[1])); got_col.append(f[9])
+        same = len(got_pos) == len(want_pos) and np.array_equal(np.array(got_pos), want_pos) and np.array_equal(np.array(got_col), col)
+        ok_all = ok_all and same
+        print("%s: %d records, positions and GT:BD:EA:OA:RI identical to the oracle's per-variant decisions: %s" % (name, len(got_pos), same))
+    print("per-variant verification %s in %.0f s" % ("PASSED" if ok_all else "FAILED", time.time() - t0))
 if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote over the callers
     vcfs = [os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz")] + [os.path.join(d, "caller%d.vcf.gz" % i) for i in range(2, n_merge)]
     cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, FASTA_NAME)] + [x for v in vcfs for x in ("-i", v)] + \
