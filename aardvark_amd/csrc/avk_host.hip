@@ -847,7 +847,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
     int nlist = 0;
-    bool solo_pending = false, hbm_solo_pending = false;
+    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -1042,18 +1042,27 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 a.esc_enabled = ctx->lds_escalation ? 1u : 0u;
             }
             hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, a);
-            if (use_fast) { /* the regions the lanes handed over: small ones, so the LDS tier with its in-workgroup escalation; its own overflow joins the bulk's */
+            if (use_fast) {
+                /* The regions the lanes handed over: small ones, so the LDS tier with its in-workgroup escalation — on the one-call lane
+                 * stream, behind the lane launches, BESIDE the bulk and the HBM launch of this stream.  What overflows there (rare) goes to a
+                 * list of its own, read by one more HBM launch at the very end (normally empty: 10 us). */
                 AVK_HIP(ctx, hipGetLastError());
-                if (lane_side) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join, 0));
-                if (lane_side2) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join2, 0));
+                hipStream_t ds = lane_side2 ? ctx->lane_stream2 : ctx->lane_stream;
+                if (lane_side && lane_side2) AVK_HIP(ctx, hipStreamWaitEvent(ds, ctx->ev_lane_join, 0));
                 AvkKernelArgs d = a;
                 d.work_list = lists[2];
                 d.n_work_dev = db->d_counters + 1024 + 32;
                 d.work_base = 0;
                 d.n_work = 0;
                 d.work_counter = db->d_counters + 768;
-                d.n_waves = bulk * waves_per_block;
-                hipLaunchKernelGGL(avk_region_kernel_lds, dim3(bulk), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, d);
+                uint32_t dblocks = bulk < (uint32_t)ctx->n_cus ? bulk : (uint32_t)ctx->n_cus; /* one workgroup per CU: the list is short */
+                d.n_waves = dblocks * waves_per_block;
+                d.overflow_list = lists[1];
+                d.overflow_count = db->d_counters + 1024 + 16;
+                hipLaunchKernelGGL(avk_region_kernel_lds, dim3(dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ds, d);
+                AVK_HIP(ctx, hipGetLastError());
+                AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join2, ds)); /* everything of the lane streams is behind this record */
+                deferred_pending = true;
             }
             a.tier[0].ws_bytes = slice0;
         } else if (t == 1) { /* one workgroup per CU, four large slices */
@@ -1092,6 +1101,34 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     }
     if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
+    if (deferred_pending) { /* the lane streams (lane launches, then the handed-back regions) join here; what even the escalation could not hold */
+        AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join2, 0));
+        AvkKernelArgs h = a;
+        h.pass_tier = 2;
+        h.work_list = lists[1];
+        h.n_work_dev = db->d_counters + 1024 + 16;
+        h.work_base = 0;
+        h.n_work = 0;
+        h.work_counter = db->d_counters + 256; /* the claim counters of the (unused) tier-1 launch */
+        h.static_pct = 0;
+        h.n_shards = 1;
+        h.claim = 1;
+        h.esc_bytes = 0;
+        h.esc_enabled = 0;
+        h.high_priority = 0;
+        h.extra_counter = nullptr;
+        h.extra_n = 0;
+        h.overflow_list = nullptr;
+        h.overflow_count = nullptr;
+        h.hbm_ws = ctx->d_ws;
+        h.big_ws = ctx->d_big;
+        h.big_busy = db->d_counters + 1088;
+        h.big_slots = big_slots;
+        const uint32_t hb = hbm_blocks < 64 ? hbm_blocks : 64;
+        h.n_waves = hb * waves_per_block;
+        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hb), dim3(256), 0, ctx->stream, h);
+        AVK_HIP(ctx, hipGetLastError());
+    }
     hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally,
                        (uint64_t *)tally_dev, db->d_counters, (unsigned)AVK_N_COUNTERS, ctx->accumulate_tally ? 1u : 0u);
     AVK_HIP(ctx, hipGetLastError());

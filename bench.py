@@ -67,6 +67,7 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--boundary-calls", type=int, default=3, help="timed avk_compare_batch calls of the host-boundary leg (0 = skip)")
+    ap.add_argument("--watchdog-seconds", type=int, default=900, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the bit-identity gate against the oracle")
@@ -85,6 +86,10 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+
+    if args.watchdog_seconds > 0:  # a stuck run must end with evidence instead of holding the machine
+        import faulthandler
+        faulthandler.dump_traceback_later(args.watchdog_seconds, exit=True)
 
     # stdout carries exactly ONE line, the JSON of rank 0: everything else that writes to file descriptor 1 — RCCL prints a version
     # banner there when a communicator comes up — is sent to stderr; the JSON goes to the original descriptor at the end

@@ -511,6 +511,8 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     a.work_base = 0;
                     a.n_work = 0;
                     a.work_counter = counters + 768;
+                    a.overflow_list = lists[1].data(); /* its own overflow list: one more HBM pass at the very end */
+                    a.overflow_count = counters + 1024 + 16;
                     run_pass(n_waves ? n_waves : 1, 0, lds_bytes, 0);
                     a = keep;
                 }
@@ -541,6 +543,28 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         }
     }
 
+    if (use_fast && counters[1024 + 16]) { /* run_internal: what the handed-back regions' LDS pass could not hold */
+        a.pass_tier = 2;
+        a.work_list = lists[1].data();
+        a.n_work_dev = counters + 1024 + 16;
+        a.work_base = 0;
+        a.n_work = 0;
+        a.work_counter = counters + 256;
+        a.static_pct = 0;
+        a.n_shards = 1;
+        a.claim = 1;
+        a.esc_bytes = 0;
+        a.esc_enabled = 0;
+        a.high_priority = 0;
+        a.extra_counter = nullptr;
+        a.extra_n = 0;
+        a.overflow_list = nullptr;
+        a.overflow_count = nullptr;
+        a.big_ws = big_slots ? big_slices.data() : nullptr;
+        a.big_busy = counters + 1088;
+        a.big_slots = big_slots;
+        run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
+    }
     for (int c = 0; c < AVK_TALLY_COPIES; ++c) /* avk_tally_reduce */
         for (int i = 0; i < AVK_TALLY_STRIDE; ++i) tally[i] += partials[(size_t)c * AVK_TALLY_STRIDE + i];
     /* copy back in caller order */
