@@ -928,7 +928,7 @@ AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap, u32 optcap) {
 
 /* One persistent wave: claims tiles of 64 fast records, every lane solves its record.  wave_lds = this wave's rows, wg_tally =
  * the workgroup's 288 tally words in LDS (zeroed by the caller, flushed by the caller). */
-AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id, u32 *wave_lds, u32 *wg_tally, u32 &n_ok_out, u32 &n_err_out) {
+AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id, u32 *wave_lds, u32 *wg_tally, u32 &n_ok_out, u32 &n_err_out, u64 *part = (u64 *)0) {
     const u32 lane = (u32)wv_lane();
     LCtx c;
     c.p = wave_lds + lane;
@@ -941,12 +941,21 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     c.qcap = la.qcap;
     c.off_opt = c.off_q + la.qcap;
     c.optcap = 16;
-    u32 n_ok = 0, n_err = 0;
+    u32 n_ok = 0, n_err = 0, n_tiles_done = 0;
     for (;;) {
         u32 t = 0;
         if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
         t = wv_uni(wv_shfl(t, 0));
         if (t >= la.n_tiles) break;
+        n_tiles_done += 1;
+        if (part && (n_tiles_done & 15u) == 0) { /* the 32-bit LDS tally moves on to the 64-bit partial tally every 16 tiles (1024 regions) */
+            wv_sync();
+            for (u32 i = lane; i < AVK_N_GROUPS * AVK_N_FIELDS; i += 64) {
+                const u32 v = avk_wg_xchg(wg_tally + i, 0u);
+                if (v) avk_atomic_add_u64_global(part + i, v);
+            }
+            wv_sync();
+        }
         const u32 *rec = la.recs + (u64)t * la.rec_words * 64u + lane;
         const u32 h1 = rec[64];
         if (h1 != 0xFFFFFFFFu) { /* a lane of the class's last tile may have no region */

@@ -1953,6 +1953,14 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
                     else avk_atomic_add_u64_global(part_r + i, v);
                 }
             }
+            /* the workgroup's LDS tally is 32 bits wide and a region can add 10^5 to a counter (BASEPAIR / RECORD_BP of 10 kbp alleles):
+             * every wave moves the tally on to the 64-bit partial tally after 256 of its regions, long before a counter can wrap */
+            if (wgt && (n_ok & 255u) == 0) {
+                for (u32 i = lane; i < AVK_N_GROUPS * AVK_N_FIELDS; i += 64) {
+                    const u32 v = avk_wg_xchg(wg_tally + i, 0u);
+                    if (v) avk_atomic_add_u64_global(part_r + i, v);
+                }
+            }
         }
         if (a.seq_bytes && a.seq_len && reg.seq_stride) { /* SequenceBundle, waffle_solver.rs:237-246 */
             u8 *wn = c.pool + (u64)winner * c.nodeA_bytes;

@@ -96,6 +96,35 @@ struct StreamClass {
 
 } // namespace
 
+static int stream_bufs_init(avk_ctx *ctx) {
+    if (ctx->sbufs) return 0;
+    ctx->sbufs = new StreamBufs();
+    AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->sbufs->copy_stream, hipStreamNonBlocking));
+    AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_copied, hipEventDisableTiming));
+    AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done, hipEventDisableTiming));
+    AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t)));
+    AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t)));
+    AVK_HIP(ctx, hipHostMalloc((void **)&ctx->sbufs->h_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t), hipHostMallocDefault));
+    AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_counters, AVK_N_COUNTERS * sizeof(uint32_t)));
+    AVK_HIP(ctx, hipMemset(ctx->sbufs->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t)));
+    AVK_HIP(ctx, hipMemset(ctx->sbufs->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t)));
+    return 0;
+}
+
+/* avk_ctx_reserve: pins and allocates what avk_compare_batch needs for a batch of up to n_regions / n_variants, so that a tool can pay for
+ * it while it is still reading its inputs (pinning 300 MB and the first device allocations cost 60-100 ms) */
+static int stream_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants) {
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = stream_bufs_init(ctx);
+    if (rc) return rc;
+    StreamBufs &sb = *ctx->sbufs;
+    rc = grow_pair(ctx, &sb.h_fast, &sb.d_fast, &sb.fast_words, (size_t)(n_regions + 64 * AVK_FAST_CLASSES) * AVK_FAST_WORDS);
+    if (!rc) rc = grow_pair(ctx, &sb.h_rout, &sb.d_rout, &sb.rout_words, (size_t)n_regions * 4);
+    if (!rc) rc = grow_pair(ctx, &sb.h_vout, &sb.d_vout, &sb.vout_words, (size_t)n_variants + 1);
+    if (!rc) rc = grow_pair(ctx, &sb.h_defer, &sb.d_defer, &sb.defer_words, (size_t)n_regions + 64);
+    return rc;
+}
+
 /* the one-shot path proper; returns AVK_E_STATE + 100 when the batch is not for it (the caller then takes the resident path) */
 static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const avk_compare_config *cfg, avk_result_batch *out) {
     const uint64_t n = b->n_regions, nv = b->n_variants;
@@ -109,17 +138,9 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point c) { return std::chrono::duration<double, std::milli>(c - a).count(); };
     const auto t_begin = now();
     const unsigned nt = avk_host_threads();
-    if (!ctx->sbufs) {
-        ctx->sbufs = new StreamBufs();
-        AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->sbufs->copy_stream, hipStreamNonBlocking));
-        AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_copied, hipEventDisableTiming));
-        AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done, hipEventDisableTiming));
-        AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t)));
-        AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t)));
-        AVK_HIP(ctx, hipHostMalloc((void **)&ctx->sbufs->h_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t), hipHostMallocDefault));
-        AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_counters, AVK_N_COUNTERS * sizeof(uint32_t)));
-        AVK_HIP(ctx, hipMemset(ctx->sbufs->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t)));
-        AVK_HIP(ctx, hipMemset(ctx->sbufs->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t)));
+    {
+        const int rc0 = stream_bufs_init(ctx);
+        if (rc0) return rc0;
     }
     StreamBufs &sb = *ctx->sbufs;
 

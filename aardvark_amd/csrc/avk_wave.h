@@ -107,6 +107,7 @@ AVK_DEV uint32_t avk_wg_cas(uint32_t *p, uint32_t expect, uint32_t desired) {
     __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     return expect;
 }
+AVK_DEV uint32_t avk_wg_xchg(uint32_t *p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_ACQ_REL); }
 AVK_DEV int avk_ctz64(uint64_t x) { return __builtin_ctzll(x); }
 AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 
@@ -210,6 +211,7 @@ AVK_DEV uint32_t avk_wg_cas(uint32_t *p, uint32_t expect, uint32_t desired) {
     __hip_atomic_compare_exchange_strong(p, &expect, desired, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return expect;
 }
+AVK_DEV uint32_t avk_wg_xchg(uint32_t *p, uint32_t v) { return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 AVK_DEV int avk_ctz64(uint64_t x) { return __ffsll((unsigned long long)x) - 1; }
 AVK_DEV int avk_popc64(uint64_t x) { return __popcll(x); }
 #endif

@@ -221,6 +221,10 @@ int main(int argc, char **argv) {
         }
         rc_ref = avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data());
         if (rc_ref) err_ref = avk_last_error(ctx);
+        else { /* the staging buffers of the solve stage, while the regions are still being walked (every call is in at most one region) */
+            const uint64_t n_calls = avf_calls_count(calls[0]) + avf_calls_count(calls[1]);
+            (void)avk_ctx_reserve(ctx, n_calls, n_calls);
+        }
         s_ref = seconds_since(t);
     });
     avf_feed *feed = nullptr;

@@ -1481,6 +1481,13 @@ int avf_calls_load(const char *vcf, const char *sample, int enable_trimming, avf
     return 0;
 }
 void avf_calls_free(avf_calls *c) { delete c; }
+uint64_t avf_calls_count(const avf_calls *c) {
+    uint64_t n = 0;
+    if (c)
+        for (const auto &kv : c->by_chrom)
+            for (const auto &ch : kv.second.chunks) n += ch.size();
+    return n;
+}
 
 int avf_feed_from_calls(uint32_t n_inputs, const avf_calls *const *calls, const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int merge,
                         avf_feed **out) {

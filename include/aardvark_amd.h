@@ -183,8 +183,9 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
  *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid",
  *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2),
- *                    "order_guard" (1 for callers that queue avk_compare_resident calls back to back without synchronising: the bulk
- *                    launch then waits for the side streams to reach their launches), "timing_events" (0 = no event records for
+ *                    "order_guard" (the bulk launch waits for the side streams to reach their launches, for callers that queue
+ *                    avk_compare_resident calls back to back without synchronising: 1 always, 0 never, 2 = default: for batches of
+ *                    262,144 regions or more), "timing_events" (0 = no event records for
  *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
  *                    "lane_kernel" (1, default: regions with at most two calls per side, a short window and a small edit-distance
  *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
@@ -224,6 +225,9 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
 int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);  /* the dominant launch: first pass of avk_region_kernel_lds */
 int  avk_last_solver_ms(avk_ctx *ctx, float *ms);  /* all solver launches of the call (tier passes + tally reduce) */
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
+/* optional: pins and allocates the staging buffers avk_compare_batch will need for batches of up to n_regions / n_variants (they are kept
+ * by the context and only grow), e.g. while a tool is still reading its inputs; without it the first large call pays for them */
+int  avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants);
 int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the last avk_compare_batch took the one-shot path (large batch, no per-region
                                                       blocks, no sequences): pinned fast records written and copied tile range by tile range */
 int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */

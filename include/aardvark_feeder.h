@@ -77,6 +77,7 @@ const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f);
 typedef struct avf_calls avf_calls;
 int avf_calls_load(const char *vcf, const char *sample, int enable_trimming, avf_calls **out);
 void avf_calls_free(avf_calls *c);
+uint64_t avf_calls_count(const avf_calls *c); /* loaded calls (every chromosome) */
 int avf_feed_from_calls(uint32_t n_inputs, const avf_calls *const *calls, const char *regions_bed, const avf_genome *g, uint64_t min_variant_gap, int merge,
                         avf_feed **out);
 /* variants loaded per input after parsing and the chromosome-span filter (the "Loaded N truth variants" log lines) */
