@@ -188,6 +188,15 @@ int main(int argc, char **argv) {
         const auto t = std::chrono::steady_clock::now();
         rc_ctx = avk_ctx_create(device, &ctx);
         if (rc_ctx) err_ctx = avk_last_error(nullptr);
+        else { /* the staging buffers of the solve stage while the inputs are still being read: a first guess from the size of the reference
+                  file (a region per 750 bases is twice the density of a human call set); the exact sizes follow when the calls are loaded */
+            struct stat st;
+            if (stat(ref.c_str(), &st) == 0 && st.st_size > (256ll << 20)) {
+                const bool gz = ref.size() > 3 && ref.compare(ref.size() - 3, 3, ".gz") == 0;
+                const uint64_t guess = (uint64_t)st.st_size * (gz ? 4u : 1u) / 750u;
+                (void)avk_ctx_reserve(ctx, guess, 2 * guess);
+            }
+        }
         s_ctx = seconds_since(t);
     });
     const int rc_genome = avf_genome_load_case(ref.c_str(), ref_upper ? 1 : 0, &genome);
@@ -222,8 +231,8 @@ int main(int argc, char **argv) {
         rc_ref = avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data());
         if (rc_ref) err_ref = avk_last_error(ctx);
         else { /* the staging buffers of the solve stage, while the regions are still being walked (every call is in at most one region) */
-            const uint64_t n_calls = avf_calls_count(calls[0]) + avf_calls_count(calls[1]);
-            (void)avk_ctx_reserve(ctx, n_calls, n_calls);
+            const uint64_t ct = avf_calls_count(calls[0]), cq = avf_calls_count(calls[1]);
+            (void)avk_ctx_reserve(ctx, ct > cq ? ct : cq, ct + cq); /* a region holds at least one call: normally a no-op after the first guess */
         }
         s_ref = seconds_since(t);
     });
