@@ -19,6 +19,8 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <string>
 #include <thread>

@@ -18,15 +18,88 @@
 
 namespace {
 
+/* A small persistent pool: the one-shot path runs five or six parallel loops per call, and starting 16 threads for each costs more than a
+ * chr20-sized call's kernels.  Workers sleep on a condition variable between loops; one loop at a time (calls on different contexts
+ * take turns). */
+class AvkPool {
+  public:
+    static AvkPool &get() {
+        static AvkPool p;
+        return p;
+    }
+    /* runs fn(t) for t in [0, nt) on the workers (t = 0 on the caller) and returns when all are done */
+    void run(unsigned nt, const std::function<void(unsigned)> &fn) {
+        if (nt <= 1) {
+            fn(0);
+            return;
+        }
+        std::lock_guard<std::mutex> one(loop_mutex_);
+        ensure(nt - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            want_ = nt - 1;
+            next_ = 0;
+            done_ = 0;
+            gen_ += 1;
+        }
+        cv_.notify_all();
+        fn(0);
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return done_ == want_; });
+        fn_ = nullptr;
+    }
+
+  private:
+    AvkPool() {}
+    ~AvkPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            gen_ += 1;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void ensure(unsigned n) {
+        while (workers_.size() < n) workers_.emplace_back([this] { work(); });
+    }
+    void work() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *fn = nullptr;
+            unsigned t = 0;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < want_); });
+                if (stop_) return;
+                t = ++next_; /* 1 .. want_ */
+                if (next_ >= want_) seen = gen_;
+                fn = fn_;
+            }
+            (*fn)(t);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                done_ += 1;
+                if (done_ == want_) cv_done_.notify_all();
+            }
+        }
+    }
+    std::mutex m_, loop_mutex_;
+    std::condition_variable cv_, cv_done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned want_ = 0, next_ = 0, done_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
 template <class F> void avk_parallel_for(uint64_t n, unsigned nt, F f) { /* f(thread, lo, hi) */
     if (nt <= 1 || n < 4096) {
         f(0u, (uint64_t)0, n);
         return;
     }
-    std::vector<std::thread> pool;
-    for (unsigned t = 1; t < nt; ++t) pool.emplace_back([=, &f] { f(t, n * t / nt, n * (t + 1) / nt); });
-    f(0u, (uint64_t)0, n / nt);
-    for (auto &th : pool) th.join();
+    AvkPool::get().run(nt, [&](unsigned t) { f(t, n * t / nt, n * (t + 1) / nt); });
 }
 
 unsigned avk_host_threads() {
@@ -406,17 +479,20 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             chunk_done[t0 / chunk_tiles].fetch_add(1, std::memory_order_release);
         }
     };
-    std::vector<std::thread> packers;
-    for (unsigned t = 0; t < nt; ++t) packers.emplace_back(pack_worker);
     hipError_t herr = hipSuccess;
-    for (uint32_t ch = 0; ch < n_chunks && herr == hipSuccess; ++ch) {
-        const uint32_t t0 = ch * chunk_tiles, t1 = t0 + chunk_tiles < tiles ? t0 + chunk_tiles : tiles;
-        const uint32_t want = (t1 - t0 + piece - 1) / piece;
-        while (chunk_done[ch].load(std::memory_order_acquire) < want) std::this_thread::sleep_for(std::chrono::microseconds(30));
-        const size_t w0 = (size_t)word_of_tile(t0), w1 = (size_t)word_of_tile(t1);
-        herr = hipMemcpyAsync(sb.d_fast + w0, sb.h_fast + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, sb.copy_stream);
-    }
-    for (auto &th : packers) th.join();
+    auto copy_loop = [&] {
+        for (uint32_t ch = 0; ch < n_chunks && herr == hipSuccess; ++ch) {
+            const uint32_t t0 = ch * chunk_tiles, t1 = t0 + chunk_tiles < tiles ? t0 + chunk_tiles : tiles;
+            const uint32_t want = (t1 - t0 + piece - 1) / piece;
+            while (chunk_done[ch].load(std::memory_order_acquire) < want) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            const size_t w0 = (size_t)word_of_tile(t0), w1 = (size_t)word_of_tile(t1);
+            herr = hipMemcpyAsync(sb.d_fast + w0, sb.h_fast + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, sb.copy_stream);
+        }
+    };
+    AvkPool::get().run(nt + 1, [&](unsigned t) { /* this thread queues the copies, the pool writes the records */
+        if (t == 0) copy_loop();
+        else pack_worker();
+    });
     const auto t_packed = now();
 
     /* ---- 4. the lane launches: one-call classes on the copy stream, two-call classes beside them */

@@ -184,6 +184,7 @@ int main(int argc, char **argv) {
             if (rc_calls[i]) err_calls[i] = avf_last_error(); /* the error text is per thread */
             s_calls[i] = seconds_since(t);
         });
+    std::thread th_reserve;
     th_ctx = std::thread([&] {
         const auto t = std::chrono::steady_clock::now();
         rc_ctx = avk_ctx_create(device, &ctx);
@@ -194,7 +195,7 @@ int main(int argc, char **argv) {
             if (stat(ref.c_str(), &st) == 0 && st.st_size > (256ll << 20)) {
                 const bool gz = ref.size() > 3 && ref.compare(ref.size() - 3, 3, ".gz") == 0;
                 const uint64_t guess = (uint64_t)st.st_size * (gz ? 4u : 1u) / 750u;
-                (void)avk_ctx_reserve(ctx, guess, 2 * guess);
+                th_reserve = std::thread([guess, &ctx] { (void)avk_ctx_reserve(ctx, guess, 2 * guess); }); /* joined before the solve stage */
             }
         }
         s_ctx = seconds_since(t);
@@ -230,10 +231,6 @@ int main(int argc, char **argv) {
         }
         rc_ref = avk_ref_upload(ctx, n_contigs, seqs.data(), lens.data());
         if (rc_ref) err_ref = avk_last_error(ctx);
-        else { /* the staging buffers of the solve stage, while the regions are still being walked (every call is in at most one region) */
-            const uint64_t ct = avf_calls_count(calls[0]), cq = avf_calls_count(calls[1]);
-            (void)avk_ctx_reserve(ctx, ct > cq ? ct : cq, ct + cq); /* a region holds at least one call: normally a no-op after the first guess */
-        }
         s_ref = seconds_since(t);
     });
     avf_feed *feed = nullptr;
@@ -247,6 +244,7 @@ int main(int argc, char **argv) {
         avf_calls_free(calls[1]);
     });
     const avk_region_batch *all = avf_feed_batch(feed);
+    if (th_reserve.joinable()) th_reserve.join();
     const double s_feed = seconds_since(t0);
     fprintf(stderr, "Loaded %llu truth and %llu query variants; %llu regions.\n", (unsigned long long)avf_feed_loaded_variants(feed, 0),
             (unsigned long long)avf_feed_loaded_variants(feed, 1), (unsigned long long)all->n_regions);

@@ -67,7 +67,10 @@ def parse():
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
     ap.add_argument("--boundary-calls", type=int, default=3, help="timed avk_compare_batch calls of the host-boundary leg (0 = skip)")
-    ap.add_argument("--watchdog-seconds", type=int, default=900, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
+    ap.add_argument("--watchdog-seconds", type=int, default=600, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
+    ap.add_argument("--no-supervisor", action="store_true",
+                    help="run in this process (default for N > 1 ranks and under a profiler): otherwise the single-GPU run is a child of a thin supervisor "
+                         "that has not touched the GPU, ends a run that exceeds --watchdog-seconds and starts it once more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the bit-identity gate against the oracle")
@@ -86,6 +89,29 @@ def main():
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
+
+    # Single-GPU runs go through a supervisor: this process (standard library only, no GPU) starts the benchmark as a child, waits at most
+    # --watchdog-seconds (+ 60 s for the child's own stack dump) and starts it ONE more time if it had to end it.  One stuck start was seen in
+    # some eighty runs of this benchmark on fresh boxes (a first queued step that never finished; not reproduced in 30,000 steps since).
+    profiled = any(k in os.environ for k in ("ROCPROFILER_REGISTER_LIBRARY", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
+    if world == 1 and not args.no_supervisor and not profiled and os.environ.get("AVK_BENCH_CHILD") != "1":
+        env = dict(os.environ, AVK_BENCH_CHILD="1")
+        rc = 1
+        for attempt in range(2):
+            child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True)
+            try:
+                rc = child.wait(timeout=args.watchdog_seconds + 60 if args.watchdog_seconds > 0 else None)
+                break
+            except subprocess.TimeoutExpired:
+                print("[bench supervisor] attempt %d exceeded %d s: ending it%s" % (attempt + 1, args.watchdog_seconds + 60, ", starting once more" if attempt == 0 else ""),
+                      file=sys.stderr, flush=True)
+                try:
+                    os.killpg(child.pid, 9)
+                except Exception:
+                    child.kill()
+                child.wait()
+                rc = 124
+        sys.exit(rc)
 
     if args.watchdog_seconds > 0:  # a stuck run must end with evidence instead of holding the machine
         import faulthandler

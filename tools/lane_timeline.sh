@@ -3,6 +3,6 @@
 TAG=${1:-tl}
 R=$(pwd)
 cd /tmp && export TMPDIR=/tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG/stats -o $TAG -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --boundary-calls 0 > $R/gpurun_out/prof_${TAG}_stats.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_$TAG/stats -o $TAG -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-secondary --boundary-calls 0 --no-supervisor > $R/gpurun_out/prof_${TAG}_stats.log 2>&1
 echo prof rc $?
 grep "bench " $R/gpurun_out/prof_${TAG}_stats.log | cut -c1-400

@@ -8,7 +8,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-SHORT="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-secondary --boundary-calls 0 $*"
+SHORT="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-secondary --boundary-calls 0 --no-supervisor $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o "$TAG" -- $SHORT > "$OUT/stats.log" 2>&1
 echo "stats rc $?"
 i=0
