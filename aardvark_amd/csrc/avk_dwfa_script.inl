@@ -104,7 +104,7 @@ AVK_DEV void dwfa_script_lane(const AvkDwfaArgs &a, u32 s, u32 *lds) {
         else if (finalized) status = 2;
         else {
             const int rc = a.step_op[k] == 0 ? dw_update(c, 0, ed, 1, a.step_blen[k], 2, a.step_olen[k], 0xFFFFu)
-                                             : dw_finalize(c, 0, ed, 1, a.step_blen[k], 2, a.step_olen[k], 0xFFFFu);
+                                             : dw_finalize(c, 0, ed, 1, a.step_blen[k], 2, a.step_olen[k], 0xFFFFu, c.wfcap);
             if (rc) status = AVK_ST_CAPACITY;
             else if (a.step_op[k] == 1) finalized = true;
         }

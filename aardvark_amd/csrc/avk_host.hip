@@ -1210,6 +1210,22 @@ int avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]) {
     return 0;
 }
 
+/* diagnostic: which of the context's streams still have work queued (caller's, two solo streams, two lane streams) and the batch's
+ * device counters as they are NOW (copied on a stream of its own, beside whatever is running) */
+int avk_debug_snapshot(avk_ctx *ctx, avk_dev_batch *db, uint32_t *counters, uint32_t n_counters, int32_t busy[5]) {
+    if (!ctx || !db || !counters || !busy) return AVK_E_ARG;
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    static hipStream_t probe = nullptr;
+    if (!probe) AVK_HIP(ctx, hipStreamCreateWithFlags(&probe, hipStreamNonBlocking));
+    hipStream_t ss[5] = {ctx->stream, ctx->side_stream, ctx->side_stream2, ctx->lane_stream, ctx->lane_stream2};
+    for (int i = 0; i < 5; ++i) busy[i] = ss[i] ? (hipStreamQuery(ss[i]) == hipErrorNotReady ? 1 : 0) : -1;
+    (void)hipGetLastError();
+    if (n_counters > AVK_N_COUNTERS) n_counters = AVK_N_COUNTERS;
+    AVK_HIP(ctx, hipMemcpyAsync(counters, db->d_counters, (size_t)n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, probe));
+    AVK_HIP(ctx, hipStreamSynchronize(probe));
+    return 0;
+}
+
 int avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]) {
     if (!ctx || !counts) return AVK_E_ARG;
     memcpy(counts, ctx->last_tiers, sizeof(ctx->last_tiers));

@@ -39,10 +39,30 @@ typedef uint64_t u64;
 /* work counters of instrumented emulator builds (-DAVK_LANE_STATS): [0] match_run words, [1] diagonals extended, [2] extension steps,
  * [3] pops, [4] partial re-pops, [5] regions, [6] phase-C alignments, [7] replayed steps */
 #ifdef AVK_LANE_STATS
-extern uint64_t g_lane_stats[16];
+extern uint64_t g_lane_stats[32];
+extern int g_lane_phase;
 #define AVK_LSTAT(k, n) g_lane_stats[k] += (n)
+#define AVK_LPHASE(k) g_lane_phase = (k)
+#define AVK_LDEFER(k) (g_lane_stats[8 + (k)] += 1, g_lane_stats[16 + g_lane_phase] += ((k) == 0), (int)LS_DEFER)
 #else
 #define AVK_LSTAT(k, n)
+#define AVK_LPHASE(k)
+#define AVK_LDEFER(k) ((int)LS_DEFER)
+#endif
+
+/* profiling builds (-DAVK_LANE_PHASE_TIMING, make lane-timing): clock ticks per phase of solve_lane, summed per lane and added to the
+ * spare words of the partial tally at the end of the launch (avk_debug_phase_cycles reads them after a download):
+ * [0] record + reference window + sequence tables, [1] search A, [2] optimum replay + genotype search, [3] per-call outputs + edit
+ * distances to the reference, [4] per-type alignments, [5] metric groups + tally, [6] whole tiles (claim to result), [7] lanes */
+#ifdef AVK_LANE_PHASE_TIMING
+#define AVK_LT_MARK(c, k)                     \
+    {                                         \
+        const u64 n_ = avk_clock();           \
+        (c).tph[k] += n_ - (c).tlast;         \
+        (c).tlast = n_;                       \
+    }
+#else
+#define AVK_LT_MARK(c, k)
 #endif
 
 enum { L_REF = 1, L_ALT = 2 };
@@ -55,6 +75,10 @@ struct LCtx {
     u32 nm1;     /* masks per side minus one (1 or 3): sequence id = 0 reference, 1 + m - 1 truth mask m, 1 + nm1 + m - 1 query mask m */
     u32 off_wf;  /* first row of the wavefront byte arrays: hap 0, hap 1, scratch */
     u32 wfr;     /* rows per wavefront array */
+    u32 wfcap_c; /* bytes of the metrics phase's one array (wfa_ed) */
+#ifdef AVK_LANE_PHASE_TIMING
+    u64 tph[8], tlast;
+#endif
     u32 wfcap;   /* entries per wavefront array */
     u32 off_q, qcap;
     u32 off_opt, optcap;
@@ -95,6 +119,7 @@ AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32
     u32 n = 0;
     while (n < lim) {
         AVK_LSTAT(0, 1);
+        AVK_LSTAT(24 + g_lane_phase, 1);
         const u32 x = extract16(c, sa, ia + n) ^ extract16(c, sb, ib + n);
         if (x) {
             n += (u32)__builtin_ctz(x) >> 1;
@@ -159,33 +184,34 @@ AVK_DEV int dw_update(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u
     dw_extend(c, arr, ed, sb, bl, so, ol);
     while (!dw_touches_end(c, arr, ed, bl, ol)) {
         if (ed + 1 > budget) return LS_PARTIAL;
-        if (2 * ed + 3 > c.wfcap) return LS_DEFER;
+        if (2 * ed + 3 > c.wfcap) return AVK_LDEFER(0);
         dw_bump(c, arr, ed);
         ed += 1;
         dw_extend(c, arr, ed, sb, bl, so, ol);
     }
     return 0;
 }
-AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget) { /* :183-198 */
+AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget, u32 cap) { /* :183-198 */
     dw_extend(c, arr, ed, sb, bl, so, ol);
     while (!dw_full_diagonal(c, arr, ed, bl, ol)) {
         if (ed + 1 > budget) return LS_PARTIAL;
-        if (2 * ed + 3 > c.wfcap) return LS_DEFER;
+        if (2 * ed + 3 > cap) return AVK_LDEFER(0);
         dw_bump(c, arr, ed);
         ed += 1;
         dw_extend(c, arr, ed, sb, bl, so, ol);
     }
     return 0;
 }
-/* wfa_ed (src/util/sequence_alignment.rs:9-13) = unit-cost edit distance of two complete sequences, on the scratch array */
+/* wfa_ed (src/util/sequence_alignment.rs:9-13) = unit-cost edit distance of two complete sequences.  Only the metrics phase aligns this
+ * way, when the search is over: the rows of the three wavefront arrays and of the queue are one long array for it (wfcap_c bytes). */
 AVK_DEV int wfa_ed(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
     AVK_LSTAT(6, 1);
     const u32 lim = la < lb ? la : lb;
     const u32 d = match_run(c, sa, 0, la, sb, 0, lb);
     if (d == lim) return (int)((la > lb ? la : lb) - lim);
-    wf_set(c, 2, 0, d);
+    wf_set(c, 0, 0, d);
     u32 ed = 0;
-    if (dw_finalize(c, 2, ed, sa, la, sb, lb, 0xFFFFu)) return LS_DEFER;
+    if (dw_finalize(c, 0, ed, sa, la, sb, lb, 0xFFFFu, c.wfcap_c)) return LS_DEFER;
     return (int)ed;
 }
 
@@ -256,7 +282,7 @@ AVK_DEV int hap_update(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
         const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
         if (h.d0 >= lim) return 0;
         if (budget == 0) return LS_PARTIAL;
-        if (c.wfcap < 3) return LS_DEFER;
+        if (c.wfcap < 3) return AVK_LDEFER(0);
         wf_set(c, arr, 0, h.d0);
     }
     return dw_update(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget);
@@ -268,7 +294,7 @@ AVK_DEV int hap_finalize(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
         if (budget == 0) return LS_PARTIAL;
         wf_set(c, arr, 0, h.d0);
     }
-    return dw_finalize(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget);
+    return dw_finalize(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget, c.wfcap);
 }
 /* the search order (order_variants, query_optimizer.rs:372-381): slot of the call at depth d, and the step's sync point */
 AVK_DEV u32 ord_slot(const LCtx &c, u32 d) { return (c.ord >> (2 * d)) & 3u; }
@@ -314,6 +340,20 @@ AVK_DEV int nodeA_replay(const LCtx &c, NodeA &n, u32 code, u32 depth) {
         if (nodeA_step(c, n, d, (code >> (2 * d)) & 3u)) return LS_DEFER;
     return 0;
 }
+/* The same for a node whose exact cost is known to be 0: no call was skipped and neither haplotype has an edit, on the node and (costs
+ * never decrease along a path) on all its ancestors.  Every update stopped at the end of the shorter sequence without a mismatch, so
+ * the wavefront is that offset and nothing needs to be compared again. */
+AVK_DEV void nodeA_replay_zero(const LCtx &c, NodeA &n, u32 code, u32 depth) {
+    hap_init(n.h[0]);
+    hap_init(n.h[1]);
+    for (u32 d = 0; d < depth; ++d) {
+        const u32 slot = ord_slot(c, d), choice = (code >> (2 * d)) & 3u, sync = sync_after(c, d);
+        hap_step(c, n.h[0], slot < 2, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
+        hap_step(c, n.h[1], slot < 2, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
+    }
+    n.h[0].d0 = n.h[0].t_len < n.h[0].q_len ? n.h[0].t_len : n.h[0].q_len;
+    n.h[1].d0 = n.h[1].t_len < n.h[1].q_len ? n.h[1].t_len : n.h[1].q_len;
+}
 /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95); LS_PARTIAL: the final cost is more than `cap` */
 AVK_DEV int nodeA_finalize(const LCtx &c, NodeA &n, u32 cap = 0xFFFFu) {
     hap_step(c, n.h[0], true, false, 0, L_REF, c.L);
@@ -343,7 +383,7 @@ AVK_DEV u32 q_pop_min(const LCtx &c, u32 &qn) {
     return best;
 }
 AVK_DEV int q_push(const LCtx &c, u32 &qn, u32 e) {
-    if (qn >= c.qcap) return LS_DEFER;
+    if (qn >= c.qcap) return AVK_LDEFER(1);
     c.p[(c.off_q + qn) * 64u] = e;
     qn += 1;
     return 0;
@@ -404,7 +444,10 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
         const u32 cnt = (bucket >> (6 * depth)) & 0x3Fu;
         if (cnt >= c.max_branch) continue; /* :222 */
         bucket += 1u << (6 * depth);
-        if (!(e & 8u) && nodeA_replay(c, n, code, depth)) return LS_DEFER;
+        if (!(e & 8u)) {
+            if (cost == 0) nodeA_replay_zero(c, n, code, depth);
+            else if (nodeA_replay(c, n, code, depth)) return LS_DEFER;
+        }
         if (depth == c.N) { /* :227-247 */
             const int r = nodeA_finalize(c, n, best);
             if (r == LS_DEFER) return LS_DEFER;
@@ -415,7 +458,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
                 nbest = 0;
             }
             if (fc == best) {
-                if (nbest >= c.optcap) return LS_DEFER;
+                if (nbest >= c.optcap) return AVK_LDEFER(2);
                 opt_set(c, nbest, code);
                 nbest += 1;
             }
@@ -447,7 +490,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
             if (r == LS_DEFER) return LS_DEFER;
             if (q_push(c, qn, keyA(r ? lb : nodeA_cost(n), id, code | (choice << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
         }
-        if (next_id > 250) return LS_DEFER;
+        if (next_id > 250) return AVK_LDEFER(3);
     }
     if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
     best_out = best;
@@ -478,7 +521,12 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
         const u32 errors = e >> 28, depth = e & 0xFu, code = (e >> 4) & 0xFFu, id = (e >> 12) & 0xFFFu;
         Hap h;
         hap_init(h);
-        for (u32 d = 0; d < depth; ++d) hapB_step(c, h, d, (code >> d) & 1u);
+        /* every queued node is exact (that is what let it in): its wavefront is the end of its shorter sequence, no comparing again */
+        for (u32 d = 0; d < depth; ++d) {
+            const u32 slot = ord_slot(c, d);
+            hap_step(c, h, slot < 2, true, slot, ((code >> d) & 1u) ? L_ALT : L_REF, sync_after(c, d));
+        }
+        h.d0 = h.t_len < h.q_len ? h.t_len : h.q_len;
         if (depth == c.N) { /* :180-192 */
             hap_step(c, h, true, false, 0, L_REF, c.L);
             const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
@@ -510,7 +558,7 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
             }
             next_id += 1;
         }
-        if (next_id > 4000) return LS_DEFER;
+        if (next_id > 4000) return AVK_LDEFER(3);
     }
     return -100 - AVK_ST_NO_GT_RESULT; /* :345-348 */
 }
@@ -526,8 +574,28 @@ AVK_DEV int ed_to_ref(const LCtx &c, u32 side, u32 mask, u32 len) {
         const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
         const u32 diff = a0 > a1 ? a0 - a1 : a1 - a0;
         if (e == 1 || (e && e == diff)) return (int)e;
+    } else if (seq_fail_of(c, seq_id(c, side, mask)) == 0) {
+        /* both calls of the side, both applied.  Two substitutions at different positions: the strings have one length and differ in
+         * two places, no single edit does that.  Two pure insertions (or two pure deletions): the length changes by the sum of their
+         * edits, which is also enough. */
+        const u32 wa = sel4(c.vw0, 2 * side), wb = sel4(c.vw0, 2 * side + 1);
+        const u32 ea = sel4(c.vw1, 2 * side) & 0xFFu, eb = sel4(c.vw1, 2 * side + 1) & 0xFFu;
+        const u32 a0a = (wa >> 8) & 0xFFu, a1a = (wa >> 16) & 0xFFu, a0b = (wb >> 8) & 0xFFu, a1b = (wb >> 16) & 0xFFu;
+        if (a0a == 1 && a1a == 1 && a0b == 1 && a1b == 1 && ea == 1 && eb == 1 && ((wa ^ wb) & 0xFFu) != 0) return 2;
+        if (ea && eb && ((a1a > a0a && a1b > a0b && ea == a1a - a0a && eb == a1b - a0b) || (a0a > a1a && a0b > a1b && ea == a0a - a1a && eb == a0b - a1b)))
+            return (int)(ea + eb);
     }
     return wfa_ed(c, 0, c.L, seq_id(c, side, mask), len);
+}
+
+/* Distance between a haplotype string and the same string without ONE of its calls (slot), when the call's own distance decides it:
+ * alt_ed 1 (the strings differ, one edit makes them equal) or a pure insertion / deletion (the length difference needs that many).
+ * -1: not decided this way. */
+AVK_DEV int one_call_distance(const LCtx &c, u32 slot) {
+    const u32 w0 = sel4(c.vw0, slot), e = sel4(c.vw1, slot) & 0xFFu;
+    const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+    const u32 diff = a0 > a1 ? a0 - a1 : a1 - a0;
+    return (e == 1 || (e && e == diff)) ? (int)e : -1;
 }
 
 /* the genotype assignment of one haplotype of an optimum: flips, observed alleles */
@@ -667,7 +735,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
             const u64 w = (u64)h0 + k;
             exc = exc || ((a.ref_exc[w >> 5] >> (w & 31)) & 1u);
         }
-        if (exc) return LS_DEFER;
+        if (exc) return AVK_LDEFER(4);
         u32 prev = a.ref_2bit[h0];
         for (u32 k = 0; k < c.W1; ++k) {
             u32 word = 0;
@@ -683,11 +751,14 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
         if (m < (1u << c.T)) build_full<0>(c, m, a1lo, a1hi);
         if (m < (1u << c.Q)) build_full<1>(c, m, a1lo, a1hi);
     }
+    AVK_LT_MARK(c, 0)
 
     /* ---- phase A */
     AVK_LSTAT(5, 1);
+    AVK_LPHASE(0);
     u32 best_cost = 0;
     const int nopt = phaseA(c, best_cost);
+    AVK_LT_MARK(c, 1)
     if (nopt == LS_DEFER) return LS_DEFER;
     if (nopt < 0) return -nopt - 100;
     out.n_opt = (u32)nopt;
@@ -697,14 +768,23 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     }
 
     /* ---- phase B for every tied optimum (waffle_solver.rs:169-261); the first optimum with the fewest flips wins (:264-265) */
+    AVK_LPHASE(1);
     u32 best_total = 0xFFFFFFFFu;
     u32 o_t0 = 0, o_q0 = 0, o_t1 = 0, o_q1 = 0; /* observed alleles of the winner, per haplotype and side */
     NodeA wn;
     for (u32 k = 0; k < (u32)nopt; ++k) {
         const u32 code = opt_get(c, k);
         NodeA n;
-        if (nodeA_replay(c, n, code, c.N)) return LS_DEFER;
-        if (nodeA_finalize(c, n)) return LS_DEFER;
+        if (best_cost == 0) { /* nothing skipped, no edits: the finished haplotypes are equal sequences */
+            nodeA_replay_zero(c, n, code, c.N);
+            hap_step(c, n.h[0], true, false, 0, L_REF, c.L);
+            hap_step(c, n.h[1], true, false, 0, L_REF, c.L);
+            n.h[0].d0 = n.h[0].t_len;
+            n.h[1].d0 = n.h[1].t_len;
+        } else {
+            if (nodeA_replay(c, n, code, c.N)) return LS_DEFER;
+            if (nodeA_finalize(c, n)) return LS_DEFER;
+        }
         u32 rt0, rq0, rt1, rq1;
         const int e0 = gt_for_hap(c, n.h[0], rt0, rq0);
         if (e0 == LS_DEFER) return LS_DEFER;
@@ -725,6 +805,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     }
     out.ed1 = wn.h[0].ed;
     out.ed2 = wn.h[1].ed;
+    AVK_LT_MARK(c, 2)
 
     /* ---- phase C: compare_expected_observed (:296-327) + per-call outputs */
     u32 exp_pack = 0, obs_pack = 0; /* 2 bits per call slot */
@@ -758,8 +839,17 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
                         (1u << AVK_VT_TR_EXPANSION) | (1u << AVK_VT_SV_DELETION) | (1u << AVK_VT_SV_INSERTION);
     out.present = types | SUPMASK;
     u32 X0 = 0, Y0 = 0, tp0 = 0, X1 = 0, Y1 = 0, tp1 = 0;
+    AVK_LPHASE(2);
+    /* a second haplotype with the alleles of the first is the same pair of sequences: same distances */
+    const bool same_haps = wn.h[0].t_alt == wn.h[1].t_alt && wn.h[0].q_alt == wn.h[1].q_alt;
     for (u32 hh = 0; hh < 2; ++hh) {
         const Hap &h = hh ? wn.h[1] : wn.h[0];
+        if (hh && same_haps) {
+            X1 = X0;
+            Y1 = Y0;
+            tp1 = tp0;
+            break;
+        }
         int ert = 0, erq = 0;
         if (h.t_alt) {
             ert = ed_to_ref(c, 0, h.t_alt, h.t_len);
@@ -786,21 +876,33 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     /* Alignments of the per-type groups (:383-445), done BEFORE anything is added to the tally (they can still hand the region over):
      * a side with two calls of different types is compared once with only its first and once with only its second call, per haplotype.
      * 8 bits each: x = ed(ref, filtered side), z = ed(filtered side, other side as it is); entry (hap, j) at bits 16 * (2 * hap + j). */
+    AVK_LT_MARK(c, 3)
     u64 tfilt = 0, qfilt = 0;
     const bool t_split = c.T == 2 && ((c.vw0[0] ^ c.vw0[1]) >> 24 & 0xFu) != 0, q_split = c.Q == 2 && ((c.vw0[2] ^ c.vw0[3]) >> 24 & 0xFu) != 0;
+    AVK_LPHASE(3);
     if (t_split || q_split) {
         for (u32 hh = 0; hh < 2; ++hh) {
             const Hap &h = hh ? wn.h[1] : wn.h[0];
+            if (hh && same_haps) {
+                tfilt |= tfilt << 32;
+                qfilt |= qfilt << 32;
+                break;
+            }
             const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
             const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
             for (u32 j = 0; j < 2; ++j) {
                 if (t_split) {
                     const u32 m = h.t_alt & (1u << j);
                     u32 x2 = 0, z2 = Yh / 2; /* nothing left of the truth side: it is the reference window */
-                    if (m) {
+                    if (m && m == h.t_alt) { /* the call is the haplotype's only one: the filtered side is the side as it is */
+                        x2 = Xh / 2;
+                        z2 = h.ed;
+                    } else if (m) {
                         const u32 sf = seq_id(c, 0, m), fl = seq_len_of(c, sf);
                         const int x = ed_to_ref(c, 0, m, fl);
-                        const int z = wfa_ed(c, sf, fl, sq, h.q_len);
+                        /* equal haplotypes with everything applied: the query string is the filtered truth string plus the other call */
+                        int z = (h.ed == 0 && h.nskip == 0 && seq_fail_of(c, st) == 0 && seq_fail_of(c, sf) == 0) ? one_call_distance(c, 1u - j) : -1;
+                        if (z < 0) z = wfa_ed(c, sf, fl, sq, h.q_len);
                         if (x < 0 || z < 0) return LS_DEFER;
                         x2 = (u32)x;
                         z2 = (u32)z;
@@ -810,10 +912,14 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
                 if (q_split) {
                     const u32 m = h.q_alt & (1u << j);
                     u32 y2 = 0, z2 = Xh / 2;
-                    if (m) {
+                    if (m && m == h.q_alt) {
+                        y2 = Yh / 2;
+                        z2 = h.ed;
+                    } else if (m) {
                         const u32 sf = seq_id(c, 1, m), fl = seq_len_of(c, sf);
                         const int y = ed_to_ref(c, 1, m, fl);
-                        const int z = wfa_ed(c, st, h.t_len, sf, fl);
+                        int z = (h.ed == 0 && h.nskip == 0 && seq_fail_of(c, sq) == 0 && seq_fail_of(c, sf) == 0) ? one_call_distance(c, 2u + (1u - j)) : -1;
+                        if (z < 0) z = wfa_ed(c, st, h.t_len, sf, fl);
                         if (y < 0 || z < 0) return LS_DEFER;
                         y2 = (u32)y;
                         z2 = (u32)z;
@@ -823,6 +929,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
             }
         }
     }
+    AVK_LT_MARK(c, 4)
     /* groups that can hold anything: the joint one and one per call type of the region */
     u32 *gm_out = a.group_metrics ? a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS : (u32 *)0;
     if (gm_out)
@@ -938,12 +1045,19 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     c.wfr = (2 * la.ed_max + 2 + 3) / 4;
     c.wfcap = 2 * la.ed_max + 2;
     c.off_q = c.off_wf + 3 * c.wfr;
+    c.wfcap_c = 4 * (3 * c.wfr + la.qcap);
     c.qcap = la.qcap;
     c.off_opt = c.off_q + la.qcap;
     c.optcap = 16;
     u32 n_ok = 0, n_err = 0, n_tiles_done = 0;
+#ifdef AVK_LANE_PHASE_TIMING
+    for (int k = 0; k < 8; ++k) c.tph[k] = 0;
+#endif
     for (;;) {
         u32 t = 0;
+#ifdef AVK_LANE_PHASE_TIMING
+        const u64 t_tile0 = avk_clock();
+#endif
         if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
         t = wv_uni(wv_shfl(t, 0));
         if (t >= la.n_tiles) break;
@@ -963,7 +1077,13 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
             const u32 v_off = rec[2 * 64];
             LaneOut out;
             out.ed1 = out.ed2 = out.n_opt = out.present = 0;
+#ifdef AVK_LANE_PHASE_TIMING
+            c.tlast = avk_clock();
+#endif
             const int st = solve_lane(a, c, rec, 64u, out, wg_tally);
+            if (st == AVK_ST_OK) {
+                AVK_LT_MARK(c, 5)
+            }
             if (st == LS_DEFER) { /* hand over to the wave-per-region kernels */
                 const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1u);
                 a.overflow_list[slot_o] = la.gen_base + (t * 64u + lane);
@@ -994,7 +1114,17 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
                 *dst = v;
             }
         }
+#ifdef AVK_LANE_PHASE_TIMING
+        c.tph[6] += avk_clock() - t_tile0;
+#endif
     }
+#ifdef AVK_LANE_PHASE_TIMING
+    {
+        u64 *pc = a.tally + (u64)(wave_id % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5 + (la.nm > 2 ? 8 : 0); /* one-call classes, two-call classes */
+        for (int k = 0; k < 7; ++k) avk_atomic_add_u64_global(pc + k, c.tph[k]);
+        avk_atomic_add_u64_global(pc + 7, 1);
+    }
+#endif
     n_ok_out = n_ok;
     n_err_out = n_err;
 }

@@ -45,6 +45,7 @@ class AvkPool {
         }
         cv_.notify_all();
         fn(0);
+        for (int spin = 0; spin < 4000 && done_.load(std::memory_order_acquire) != want_; ++spin) __builtin_ia32_pause();
         std::unique_lock<std::mutex> lk(m_);
         cv_done_.wait(lk, [&] { return done_ == want_; });
         fn_ = nullptr;
@@ -69,12 +70,14 @@ class AvkPool {
         for (;;) {
             const std::function<void(unsigned)> *fn = nullptr;
             unsigned t = 0;
+            /* the loops of one call follow each other within microseconds: look for the next one for a while before sleeping */
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
             {
                 std::unique_lock<std::mutex> lk(m_);
                 cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < want_); });
                 if (stop_) return;
                 t = ++next_; /* 1 .. want_ */
-                if (next_ >= want_) seen = gen_;
+                seen = gen_; /* one index per loop and worker */
                 fn = fn_;
             }
             (*fn)(t);
@@ -89,8 +92,9 @@ class AvkPool {
     std::condition_variable cv_, cv_done_;
     std::vector<std::thread> workers_;
     const std::function<void(unsigned)> *fn_ = nullptr;
-    unsigned want_ = 0, next_ = 0, done_ = 0;
-    uint64_t gen_ = 0;
+    unsigned want_ = 0, next_ = 0;
+    std::atomic<unsigned> done_{0};
+    std::atomic<uint64_t> gen_{0};
     bool stop_ = false;
 };
 
@@ -224,7 +228,9 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     sc.alt_ed.assign(nv ? nv : 1, 0);
     sc.v_off.assign(n + 1, 0);
     const size_t n_contigs = ctx->contig_len.size();
-    avk_parallel_for(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
+    std::vector<uint64_t> have((size_t)nt * 8 * AVK_FAST_CLASSES, 0); /* regions per class found by every thread (a cache line apart) */
+    avk_parallel_for(n, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+        uint64_t *mine = have.data() + (size_t)t * 8 * AVK_FAST_CLASSES;
         for (uint64_t r = lo; r < hi; ++r) {
             const uint32_t tc = b->t_cnt[r], qc = b->q_cnt[r];
             sc.v_off[r + 1] = tc + qc; /* turned into the prefix sum below */
@@ -266,6 +272,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
                 const AvkFastClass &fc = AVK_FAST_CLASS[cl];
                 if (tc <= fc.maxv && qc <= fc.maxv && L + g <= 16ull * fc.W) {
                     sc.cls[r] = (uint8_t)(cl + 1);
+                    mine[cl] += 1;
                     const uint32_t k = (tc + qc) * 6 + (uint32_t)(ed_sum > 5 ? 5 : ed_sum);
                     sc.key[r] = (uint8_t)(32u - (k > 32u ? 32u : k));
                     break;
@@ -277,15 +284,10 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     if (sc.v_off[n] > 0x7FFFFFFFull) return 100;
     { /* a class too small for a launch of its own (plan_work_order's rule, option lane_min_regions) joins the general part */
         static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16};
-        std::vector<uint64_t> have((size_t)nt * AVK_FAST_CLASSES, 0);
-        avk_parallel_for(n, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
-            for (uint64_t r = lo; r < hi; ++r)
-                if (sc.cls[r]) have[(size_t)t * AVK_FAST_CLASSES + sc.cls[r] - 1] += 1;
-        });
         bool drop[AVK_FAST_CLASSES], any = false;
         for (int cl = 0; cl < AVK_FAST_CLASSES; ++cl) {
             uint64_t c = 0;
-            for (unsigned t = 0; t < nt; ++t) c += have[(size_t)t * AVK_FAST_CLASSES + cl];
+            for (unsigned t = 0; t < nt; ++t) c += have[(size_t)t * 8 * AVK_FAST_CLASSES + cl];
             drop[cl] = c > 0 && c < (uint64_t)ctx->lane_min_regions * scale[cl];
             any = any || drop[cl];
         }
@@ -298,7 +300,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     const uint64_t nv_dev = sc.v_off[n];
     /* counting sort, stable, on the host threads: per class, by key (most expensive first); every thread owns a contiguous range of regions */
     enum { NB = (AVK_FAST_CLASSES + 1) * 33 };
-    const unsigned st = nt > 1 && n >= 65536 ? nt : 1;
+    const unsigned st = nt > 1 && n >= 16384 ? nt : 1;
     std::vector<uint64_t> hist((size_t)st * NB, 0);
     avk_parallel_for(n, st, [&](unsigned t, uint64_t lo, uint64_t hi) {
         uint64_t *h = hist.data() + (size_t)t * NB;
@@ -363,34 +365,37 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         G.region_id = g_rid.data(), G.contig_idx = g_cidx.data(), G.start = g_start.data(), G.end = g_end.data();
         G.t_off = g_toff.data(), G.t_cnt = g_tcnt.data(), G.q_off = g_qoff.data(), G.q_cnt = g_qcnt.data();
     };
-    /* results of a gathered batch, scattered into the caller's arrays */
-    auto finish_gathered = [&](avk_dev_batch *db, const uint32_t *idx, uint64_t m, uint64_t *tally_sum) -> int {
-        std::vector<int32_t> st(m + 1);
-        std::vector<uint32_t> e1(m + 1), e2(m + 1), no(m + 1);
-        std::vector<uint16_t> tp(m + 1);
-        std::vector<uint64_t> tl(AVK_TALLY_LEN);
-        std::vector<uint8_t> ve, vo, vc, vz;
+    /* results of a gathered batch: fetched into temporaries (the per-variant outputs go straight to the caller's arrays, which the gathered
+     * batch shares), then scattered into the caller's per-region arrays */
+    struct Gathered {
+        std::vector<int32_t> st;
+        std::vector<uint32_t> e1, e2, no;
+        std::vector<uint16_t> tp;
+        std::vector<uint64_t> tl;
+    };
+    auto fetch_gathered = [&](avk_dev_batch *db, uint64_t m, Gathered &g) -> int {
+        g.st.resize(m + 1), g.e1.resize(m + 1), g.e2.resize(m + 1), g.no.resize(m + 1), g.tp.resize(m + 1), g.tl.assign(AVK_TALLY_LEN, 0);
         avk_result_batch o;
         memset(&o, 0, sizeof(o));
-        o.status = st.data(), o.ed_h1 = e1.data(), o.ed_h2 = e2.data(), o.n_optima = no.data(), o.type_present = tp.data(), o.tally = tl.data();
-        /* per-variant outputs are indexed like the input variant arrays, which the gathered batch shares with the caller's */
+        o.status = g.st.data(), o.ed_h1 = g.e1.data(), o.ed_h2 = g.e2.data(), o.n_optima = g.no.data(), o.type_present = g.tp.data(), o.tally = g.tl.data();
         o.var_expected = out->var_expected, o.var_observed = out->var_observed, o.var_class = out->var_class, o.var_zyg = out->var_zyg;
-        const int rc = avk_results_download(ctx, db, &o);
-        if (rc) return rc;
+        return avk_results_download(ctx, db, &o);
+    };
+    auto scatter_gathered = [&](const Gathered &g, const uint32_t *idx, uint64_t m, uint64_t *tally_sum) {
         for (uint64_t k = 0; k < m; ++k) {
             const uint32_t r = idx[k];
-            out->status[r] = st[k];
-            if (out->ed_h1) out->ed_h1[r] = e1[k];
-            if (out->ed_h2) out->ed_h2[r] = e2[k];
-            if (out->n_optima) out->n_optima[r] = no[k];
-            if (out->type_present) out->type_present[r] = tp[k];
+            out->status[r] = g.st[k];
+            if (out->ed_h1) out->ed_h1[r] = g.e1[k];
+            if (out->ed_h2) out->ed_h2[r] = g.e2[k];
+            if (out->n_optima) out->n_optima[r] = g.no[k];
+            if (out->type_present) out->type_present[r] = g.tp[k];
         }
-        for (int i = 0; i < AVK_TALLY_LEN; ++i) tally_sum[i] += tl[i];
-        return 0;
+        for (int i = 0; i < AVK_TALLY_LEN; ++i) tally_sum[i] += g.tl[i];
     };
     const int64_t keep_gm = ctx->emit_group_metrics;
     ctx->emit_group_metrics = 0;
     int rc = 0, rc_general = 0;
+    Gathered resG, resD;
     std::thread general_thread; /* packs, uploads and launches the general part while this thread writes the fast records */
     if (n_general) {
         gather(order.data(), n_general);
@@ -398,6 +403,9 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             (void)hipSetDevice(ctx->device);
             rc_general = upload_internal(ctx, &G, false, &dbG);
             if (!rc_general) rc_general = run_internal(ctx, dbG, cfg, nullptr, 0);
+            if (!rc_general) rc_general = fetch_gathered(dbG, n_general, resG); /* waits for the general kernels on this thread */
+            if (dbG) avk_batch_free(ctx, dbG);
+            dbG = nullptr;
         });
     }
     const auto t_general = now();
@@ -547,13 +555,37 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         herr = hipEventRecord(sb.ev_lane_done, ctx->lane_stream);
         if (herr == hipSuccess) herr = hipStreamWaitEvent(sb.copy_stream, sb.ev_lane_done, 0);
     }
-    if (herr == hipSuccess) {
-        /* the handed-back list first (it decides the second call), then tally and results */
-        herr = hipMemcpyAsync(sb.h_defer, sb.d_counters + 1024, sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
-    }
+    /* the handed-back list first (it decides the second call, which starts beside the download of the lane results) */
+    if (herr == hipSuccess) herr = hipMemcpyAsync(sb.h_defer, sb.d_counters + 1024, sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(sb.copy_stream);
-    uint32_t n_defer = herr == hipSuccess ? sb.h_defer[0] : 0;
-    if (herr == hipSuccess && n_defer) herr = hipMemcpyAsync(sb.h_defer, sb.d_defer, (size_t)n_defer * sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
+    const uint32_t n_defer = herr == hipSuccess ? sb.h_defer[0] : 0;
+    if (herr == hipSuccess && n_defer) {
+        herr = hipMemcpyAsync(sb.h_defer, sb.d_defer, (size_t)n_defer * sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
+        if (herr == hipSuccess) herr = hipStreamSynchronize(sb.copy_stream);
+    }
+    if (general_thread.joinable()) general_thread.join();
+    if (!rc) rc = rc_general;
+    std::vector<uint32_t> defer_idx(herr == hipSuccess ? n_defer : 0);
+    for (size_t k = 0; k < defer_idx.size(); ++k) {
+        defer_idx[k] = fast_order[sb.h_defer[k]];
+        sc.cls[defer_idx[k]] = 0; /* not a lane result after all */
+    }
+    int rc_tail = 0;
+    std::thread tail_thread;
+    if (!rc && !defer_idx.empty())
+        tail_thread = std::thread([&] { /* wave-per-region kernels only: the lanes gave these back */
+            (void)hipSetDevice(ctx->device);
+            std::sort(defer_idx.begin(), defer_idx.end());
+            gather(defer_idx.data(), n_defer);
+            avk_dev_batch *dbD = nullptr;
+            const int64_t keep_lane = ctx->lane_kernel;
+            ctx->lane_kernel = 0;
+            rc_tail = upload_internal(ctx, &G, false, &dbD);
+            if (!rc_tail) rc_tail = run_internal(ctx, dbD, cfg, nullptr, 0);
+            ctx->lane_kernel = keep_lane;
+            if (!rc_tail) rc_tail = fetch_gathered(dbD, n_defer, resD);
+            if (dbD) avk_batch_free(ctx, dbD);
+        });
     if (herr == hipSuccess) {
         hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, sb.copy_stream, sb.d_partials, sb.d_tally, (uint64_t *)nullptr, sb.d_counters,
                            (unsigned)AVK_N_COUNTERS, 0u);
@@ -564,43 +596,16 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     if (herr == hipSuccess && nv_dev) herr = hipMemcpyAsync(sb.h_vout, sb.d_vout, (size_t)nv_dev * sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(sb.copy_stream);
     const auto t_lanes = now();
-    if (general_thread.joinable()) general_thread.join();
-    if (!rc) rc = rc_general;
     if (herr != hipSuccess) {
-        if (dbG) avk_batch_free(ctx, dbG);
+        if (tail_thread.joinable()) tail_thread.join();
         ctx->emit_group_metrics = keep_gm;
         return fail(ctx, AVK_E_HIP, "one-shot compare failed: %s", hipGetErrorString(herr));
     }
 
-    /* ---- 5. results: general part, handed-back part (a second small call), fast part */
+    /* ---- 5. results: lane part unpacked on the host threads beside the second call; general and handed-back parts scattered after */
     std::vector<uint64_t> tally_sum(AVK_TALLY_LEN, 0);
     for (int i = 0; i < AVK_TALLY_LEN; ++i) tally_sum[i] = sb.h_tally[i];
-    std::vector<uint32_t> defer_idx(n_defer);
-    for (uint32_t k = 0; k < n_defer; ++k) {
-        defer_idx[k] = fast_order[sb.h_defer[k]];
-        sc.cls[defer_idx[k]] = 0; /* not a lane result after all */
-    }
-    /* the results of the general part and the second call for the handed-back regions on a thread of their own, beside the unpacking
-     * of the lane results (disjoint regions of the caller's arrays) */
-    int rc_tail = 0;
-    std::thread tail_thread([&] {
-        (void)hipSetDevice(ctx->device);
-        if (n_general && !rc) rc_tail = finish_gathered(dbG, order.data(), n_general, tally_sum.data());
-        if (dbG) avk_batch_free(ctx, dbG);
-        dbG = nullptr;
-        if (!rc && !rc_tail && n_defer) {
-            std::sort(defer_idx.begin(), defer_idx.end());
-            gather(defer_idx.data(), n_defer);
-            avk_dev_batch *dbD = nullptr;
-            const int64_t keep_lane = ctx->lane_kernel;
-            ctx->lane_kernel = 0; /* the lanes gave these back: wave-per-region kernels only */
-            rc_tail = upload_internal(ctx, &G, false, &dbD);
-            if (!rc_tail) rc_tail = run_internal(ctx, dbD, cfg, nullptr, 0);
-            ctx->lane_kernel = keep_lane;
-            if (!rc_tail) rc_tail = finish_gathered(dbD, defer_idx.data(), n_defer, tally_sum.data());
-            if (dbD) avk_batch_free(ctx, dbD);
-        }
-    });
+    if (n_general && !rc) scatter_gathered(resG, order.data(), n_general, tally_sum.data());
     const auto t_defer_done = now();
     avk_parallel_for(n, nt, [&](unsigned, uint64_t lo, uint64_t hi) {
         for (uint64_t r = lo; r < hi; ++r) {
@@ -624,7 +629,8 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         }
     });
     const auto t_unpacked = now();
-    tail_thread.join();
+    if (tail_thread.joinable()) tail_thread.join();
+    if (!rc && !rc_tail && n_defer) scatter_gathered(resD, defer_idx.data(), n_defer, tally_sum.data());
     ctx->emit_group_metrics = keep_gm;
     if (rc || rc_tail) return rc ? rc : rc_tail;
     if (out->tally) memcpy(out->tally, tally_sum.data(), AVK_TALLY_LEN * sizeof(uint64_t));

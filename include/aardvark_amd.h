@@ -252,6 +252,11 @@ int  avk_dwfa_script_batch(avk_ctx *ctx, int engine, uint32_t n_scripts, const u
  * [7] region count, [8..13] inside search A: setup, pop + quota, finalise, clone, extend, push */
 int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]);
 
+/* diagnostic (tools/gpu_hang_probe.py): busy[i] = 1 while stream i of the context still has queued work (0 the caller's stream, 1-2 the
+ * solo launches' streams, 3-4 the lane launches' streams; -1 = no such stream), and the first n_counters words of the batch's device
+ * counters (work-list claims, list lengths, tile claims) as they are at the time of the call, while the launches may still be running */
+int  avk_debug_snapshot(avk_ctx *ctx, avk_dev_batch *db, uint32_t *counters, uint32_t n_counters, int32_t busy[5]);
+
 /* Stratified tallies on the device (SummaryWriter::add_comparison_benchmark with the region's containment labels,
  * src/writers/summary.rs:146-163): after avk_compare_resident with the option emit_group_metrics set, label l's block of
  * AVK_TALLY_LEN words gets the sum of the metric blocks of the solved regions whose label list names l.  The labels of region r (caller
