@@ -6,6 +6,14 @@ a host-side mirror of the reference's `solve_compare_region` interface, and the 
 workload generator used by the benchmark.  There is no CPU path: if the shared library is
 missing or no HIP device is present, loading / context creation raises.
 """
+import os as _os
+
+# The solver launches on six HIP streams side by side (wave-per-region launches, three lane classes, two solo launches).  The HIP runtime
+# maps streams onto 4 hardware queues unless told otherwise, and streams that share a queue run one after the other: with 8 queues a
+# whole-genome step takes 7.3 ms instead of 10.2 (profiles/r02).  The runtime reads the variable when it initialises, so this only
+# helps when nothing in the process has used HIP yet; the caller's own setting wins.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from ._abi import (CLASSES, FIELDS, N_FIELDS, N_GROUPS, ST_NAMES, TALLY_LEN, VARIANT_TYPES, ZYGOSITIES, RegionBatch,
                    ResultBatch)
 from .api import AardvarkAmdError, CompareConfig, Context, library_path, load_library

@@ -73,24 +73,25 @@ struct AvkDevVariant {
 #define AVK_PRE_SKIP_OK 0x1000u
 
 /* ---- fast records: the input of the lane-per-region kernel (avk_lane.inl) ------------------------------------------------
- * Regions of the small classes (at most 2 calls per side, short window, small edit-distance bound, ACGT-only ALT alleles) get,
+ * Regions of the small classes (at most 3 calls per side, short window, small edit-distance bound, ACGT-only ALT alleles) get,
  * besides their AvkDevRegion, a fixed-size record of AVK_FAST_WORDS words.  Records are stored in TILES of 64: word w of the
  * record of lane l of tile t sits at [(t * AVK_FAST_WORDS + w) * 64 + l], so the 64 lanes of a wave read their records with
  * fully coalesced loads.
  *   word 0   index of the packed reference word that holds the window's first base (ref_off >> 4)
- *   word 1   ref_off & 15 | L << 4 | T << 12 | Q << 14 | order << 16   (order: 2 bits per search depth = slot of the call
- *            handled there, order_variants query_optimizer.rs:372-381); 0xFFFFFFFF = no region in this lane
+ *   word 1   ref_off & 15 | L << 4 | T << 12 | Q << 14 | order << 16   (order: bit d set = search depth d handles the next QUERY call,
+ *            clear = the next truth call; order_variants query_optimizer.rs:372-381); 0xFFFFFFFF = no region in this lane
  *   word 2   first per-variant output word (AvkDevRegion::v_off)
  *   word 3   the region's index in the caller's batch (AvkDevRegion::orig)
  *   then 2 * maxv call slots of 4 words (maxv = calls per side of the record's class; truth slots first, then query slots):
  *            rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28;  alt_ed | raw_space << 8;  allele1, 2 bits per
  *            base, 16 bases per word (2 words) */
 #define AVK_FAST_HDR 4
-#define AVK_FAST_WORDS 20 /* largest record: 4 call slots */
+#define AVK_FAST_WORDS 28 /* largest record: 6 call slots */
+#define AVK_FAST_MAXV 3   /* most calls per side a lane takes */
 /* words of a record of a class with `maxv` calls per side: header + 2 * maxv call slots (truth slots first); the tiles of a class are
  * contiguous, tile t of the class at [t * words * 64, (t + 1) * words * 64) of the class's part of the record array */
 #define AVK_FAST_WORDS_OF(maxv) (AVK_FAST_HDR + 8u * (maxv))
-#define AVK_FAST_CLASSES 4
+#define AVK_FAST_CLASSES 5
 /* capacities of the launch classes: sequence words (16 bases each), calls per side, wavefront cap, queue entries.
  * ed_max caps the edit distance a lane follows, not what the region may contain: with the lazily evaluated search (avk_lane.inl,
  * phaseA) the alignments of wrongly phased branches stop at their first edit, so a region of matching 40-base deletions never needs
@@ -104,6 +105,7 @@ static const AvkFastClass AVK_FAST_CLASS[AVK_FAST_CLASSES] = {
     {12, 1, 6, 4},   /* one call per side, <= 192 bases */
     {10, 2, 6, 16},  /* two calls per side, <= 160 bases */
     {12, 2, 6, 16},  /* two calls per side, <= 192 bases */
+    {12, 3, 6, 32},  /* three calls per side, <= 192 bases (nine in ten of the regions that are left) */
 };
 
 /* capacities of one workspace tier */

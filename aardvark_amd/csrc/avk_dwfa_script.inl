@@ -68,6 +68,8 @@ AVK_DEV void dwfa_script_lane(const AvkDwfaArgs &a, u32 s, u32 *lds) {
     LCtx c;
     c.p = lds + (u32)wv_lane();
     c.W1 = AVK_DWFA_LANE_W + 1;
+    c.ls = 6;
+    c.max_nodes = 250;
     c.nm1 = 1;
     c.off_wf = 3 * c.W1;
     c.wfr = (2 * AVK_DWFA_LANE_ED + 2 + 3) / 4;

@@ -63,13 +63,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) av
     uint32_t *smem = (uint32_t *)avk_smem;
     const unsigned wave_in_block = threadIdx.x >> 6;
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, 16);
-    uint32_t *wg_tally = smem + (size_t)(blockDim.x >> 6) * rows * 64u;
+    const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap);
+    const uint32_t wave_words = rows << la.lanes_log2;
+    uint32_t *wg_tally = smem + (size_t)(blockDim.x >> 6) * wave_words;
     for (unsigned k = threadIdx.x; k < 288; k += blockDim.x) wg_tally[k] = 0;
     __syncthreads();
     uint32_t n_ok = 0, n_err = 0;
     uint64_t *part = a.tally + (uint64_t)(blockIdx.x % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
-    avk::lane::lane_worker(a, la, wave_id, smem + (size_t)wave_in_block * rows * 64u, wg_tally, n_ok, n_err, blockDim.x == 64 ? part : (uint64_t *)0);
+    avk::lane::lane_worker(a, la, wave_id, smem + (size_t)wave_in_block * wave_words, wg_tally, n_ok, n_err, blockDim.x == 64 ? part : (uint64_t *)0);
     n_ok = wv_sum_u32(n_ok);
     n_err = wv_sum_u32(n_err);
     if ((threadIdx.x & 63u) == 0) {
@@ -227,9 +228,10 @@ struct avk_ctx {
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
-    int64_t order_guard = 2; /* 1: the bulk launch waits until the side streams have reached their launches (for callers that queue calls back to back);
-                                2 (default): only for batches of 262,144 regions or more (measured: whole genome queued 10.5 -> 9.4 ms per step, but
-                                +0.06 ms on a synchronised chr20 step); 0: never */
+    int64_t order_guard = 0; /* 1: the bulk launch waits until the side streams have reached their launches; 2: only for batches of 262,144 regions
+                                or more; 0 (default): never.  With the bulk of a genome on the lanes the wave-per-region bulk launch is short and
+                                better off early: 7.25 ms per whole-genome step without the guard, 7.5 with it (it paid off while the bulk launch
+                                held 52,000 regions: 10.5 -> 9.4 ms) */
     int64_t timing_events = 1; /* record the events avk_last_kernel_ms / avk_last_solver_ms read (three per call) */
     bool lds_attr_set = false;
     int64_t static_pct = AVK_STATIC_PCT; /* share of a launch's work list dealt statically; the rest is claimed */
@@ -248,6 +250,10 @@ struct avk_ctx {
     int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
     int64_t lane_min_regions = 8192; /* a lane class is launched when it holds at least this many regions (x16 for the two-call
                                         classes): a launch lasts at least as long as its slowest tile, which a small class cannot amortise */
+    int64_t lane_width_one = 64, lane_width_two = 64, lane_width_three = 16; /* records a wave takes at a time (64, 32, 16) in the one- / two- / three-call classes */
+    int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
+    int64_t lane_node_cap = 64;                       /* search nodes the three-call lane class makes before it hands a region over */
+    int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
     uint64_t last_lane_solved = 0;
     StreamBufs *sbufs = nullptr;
@@ -264,6 +270,8 @@ struct avk_ctx {
     bool ev_lane_valid = false;
     hipStream_t lane_stream = nullptr, lane_stream2 = nullptr; /* the lane-kernel launches run beside the wave-per-region launches: two-call classes / one-call classes */
     hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_lane_join2 = nullptr, ev_lane_ready = nullptr, ev_lane_ready2 = nullptr;
+    hipStream_t lane_stream3 = nullptr; /* the three-call class: long tiles, few of them, beside everything else */
+    hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -288,7 +296,7 @@ struct avk_dev_batch {
     uint64_t *d_tally = nullptr;    /* [AVK_TALLY_STRIDE]: AVK_TALLY_LEN sums, 5 tier counters, 8 profiling words */
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
-    uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr;
+    uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr, *d_overflow4 = nullptr;
     avk::WorkPlan plan;
     uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
     uint64_t fast_word_base[AVK_FAST_CLASSES] = {0}; /* first word of the class's tiles in d_fast */
@@ -333,7 +341,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 
 void free_batch_buffers(avk_dev_batch *db) {
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_fast};
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_fast};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -355,6 +363,9 @@ const char *avk_last_error(const avk_ctx *ctx) {
 int avk_ctx_create(int device_id, avk_ctx **out) {
     if (!out) return AVK_E_ARG;
     *out = nullptr;
+    /* six streams side by side need hardware queues of their own (the runtime's default is 4 and streams that share one run in turn);
+     * read by the runtime when it initialises, so this helps when this is the process's first HIP call; the caller's setting wins */
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(nullptr, AVK_E_HIP, "no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -397,6 +408,10 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join2, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->lane_stream3, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_ready3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
@@ -440,6 +455,10 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_ready2) (void)hipEventDestroy(ctx->ev_lane_ready2);
     if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     if (ctx->lane_stream2) (void)hipStreamDestroy(ctx->lane_stream2);
+    if (ctx->ev_lane_join3) (void)hipEventDestroy(ctx->ev_lane_join3);
+    if (ctx->ev_lane_ready3) (void)hipEventDestroy(ctx->ev_lane_ready3);
+    if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
+    if (ctx->lane_stream3) (void)hipStreamDestroy(ctx->lane_stream3);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -527,6 +546,18 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_min_regions") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_regions must not be negative");
         ctx->lane_min_regions = value;
+    } else if (n == "lane_width_one" || n == "lane_width_two" || n == "lane_width_three") {
+        if (value != 64 && value != 32 && value != 16) return fail(ctx, AVK_E_ARG, "%s must be 64, 32 or 16", name);
+        (n == "lane_width_one" ? ctx->lane_width_one : (n == "lane_width_two" ? ctx->lane_width_two : ctx->lane_width_three)) = value;
+    } else if (n == "lane_max_calls") {
+        if (value < 1 || value > AVK_FAST_MAXV) return fail(ctx, AVK_E_ARG, "lane_max_calls must be 1..%d", AVK_FAST_MAXV);
+        ctx->lane_max_calls = value;
+    } else if (n == "lane_node_cap") {
+        if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
+        ctx->lane_node_cap = value;
+    } else if (n == "lane_waves_per_cu") {
+        if (value < 1 || value > 32) return fail(ctx, AVK_E_ARG, "lane_waves_per_cu must be 1..32");
+        ctx->lane_waves_per_cu = value;
     } else
         return fail(ctx, AVK_E_ARG, "unknown option '%s'", name);
     return 0;
@@ -683,6 +714,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1024));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow4, n + 1));
 #undef AVK_TRY
     /* work order: the regions predicted to outgrow the small LDS slice first (solo waves take them), then the
      * rest; within each part the regions with the most variants (the expensive searches) are dealt first, so
@@ -691,7 +723,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
-                                    ctx->lane_kernel ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull);
+                                    ctx->lane_kernel ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
@@ -742,6 +774,27 @@ void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
     delete db;
 }
 
+/* tile width of a lane launch (options lane_width_one / lane_width_two: 64, 32 or 16 records per wave at a time) */
+static uint32_t lane_width_log2(const avk_ctx *ctx, uint32_t maxv) {
+    const int64_t w = maxv > 2 ? ctx->lane_width_three : (maxv > 1 ? ctx->lane_width_two : ctx->lane_width_one);
+    return w <= 16 ? 4u : (w <= 32 ? 5u : 6u);
+}
+/* LDS bytes of a one-wave workgroup of the lane kernel (0: does not fit) and the grid that fills the machine: the per-lane arrays of
+ * `width` lanes plus a tally of its own; as many workgroups per CU as the LDS and the wave slots hold */
+static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs &la, uint32_t *grid) {
+    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + 3 * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + (la.nm == 2 ? 4 : 8); /* lane_rows */
+    const size_t lds = (size_t)rows * (4u << la.lanes_log2) + 288 * 4;
+    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
+    if (per_cu < 1) return 0;
+    const uint32_t cap = (uint32_t)(ctx->lane_waves_per_cu > 0 ? ctx->lane_waves_per_cu : 12);
+    if (per_cu > cap) per_cu = cap;
+    const uint32_t claims = la.n_tiles * (64u >> la.lanes_log2);
+    uint32_t g = (uint32_t)ctx->n_cus * per_cu;
+    if (g > claims) g = claims;
+    *grid = g;
+    return lds;
+}
+
 static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev, uint32_t mode) {
     if (!ctx || !db || !cfg) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
@@ -787,7 +840,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t n_waves = hbm_blocks * waves_per_block;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
     const uint32_t hbm_solo_max = 128;
-    const size_t ws_need = (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
+    const uint32_t hbm_early_max = 64; /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
+    const size_t ws_need = (size_t)(n_waves + (hbm_solo_max + hbm_early_max) * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
     const auto t_ws = std::chrono::steady_clock::now();
     const bool ws_grows = ws_need > ctx->ws_alloc;
     if (ws_need > ctx->ws_alloc) {
@@ -864,7 +918,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     ctx->ev_lane_valid = false;
     const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(ctx->big_waves < 128 ? ctx->big_waves : 128) : 0u;
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
-    uint32_t *lists[3] = {db->d_overflow, db->d_overflow2, db->d_overflow3};
+    uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
     bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
@@ -992,7 +1046,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             /* ---- the lane-per-region launches (avk_lane.inl): the classes with two calls per side (long, latency-bound tiles at low
              * occupancy) on a stream of their own, the one-call classes on the caller's stream ahead of the bulk.  What a lane cannot
              * finish goes to the DEFERRED list, solved after the bulk by an LDS launch of the wave-per-region kernel. */
-            bool lane_side = false, lane_side2 = false;
+            /* lane streams: 0 the two-call classes, 1 the one-call classes, 2 the three-call class */
+            hipStream_t lstream[3] = {ctx->lane_stream, ctx->lane_stream2, ctx->lane_stream3};
+            hipEvent_t lready[3] = {ctx->ev_lane_ready, ctx->ev_lane_ready2, ctx->ev_lane_ready3};
+            hipEvent_t ljoin[3] = {ctx->ev_lane_join, ctx->ev_lane_join2, ctx->ev_lane_join3};
+            bool lused[3] = {false, false, false};
             if (use_fast) {
                 if (!ctx->lane_attr_set) {
                     AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1015,39 +1073,64 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     la.ed_max = cl.ed_max;
                     la.qcap = cl.qcap;
                     la.gen_base = db->plan.fast_base[fc];
-                    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + 3 * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + 4;
-                    /* one-wave workgroups: the per-lane arrays of a wave plus a tally of its own; as many as the LDS and the registers hold */
-                    const size_t lds = (size_t)rows * 256 + 288 * 4;
-                    uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
-                    if (per_cu < 1) return fail(ctx, AVK_E_ARG, "lane kernel class %d does not fit the LDS", fc);
-                    if (per_cu > 12) per_cu = 12;
-                    uint32_t grid = (uint32_t)ctx->n_cus * per_cu;
-                    if (grid > la.n_tiles) grid = la.n_tiles;
-                    const bool side = cl.maxv > 1;
-                    if (side && !lane_side) {
-                        AVK_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream, ctx->ev_lane_fork, 0));
-                        if (order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_ready, ctx->lane_stream));
-                        lane_side = true;
+                    la.lanes_log2 = lane_width_log2(ctx, cl.maxv);
+                    la.max_nodes = cl.maxv > 2 ? (uint32_t)ctx->lane_node_cap : 250u;
+                    uint32_t grid = 0;
+                    const size_t lds = lane_launch_geometry(ctx, la, &grid);
+                    if (!lds) return fail(ctx, AVK_E_ARG, "lane kernel class %d does not fit the LDS", fc);
+                    const int li = cl.maxv == 2 ? 0 : (cl.maxv == 1 ? 1 : 2);
+                    if (!lused[li]) {
+                        AVK_HIP(ctx, hipStreamWaitEvent(lstream[li], ctx->ev_lane_fork, 0));
+                        if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[li], lstream[li]));
+                        lused[li] = true;
                     }
-                    if (!side && !lane_side2) {
-                        AVK_HIP(ctx, hipStreamWaitEvent(ctx->lane_stream2, ctx->ev_lane_fork, 0));
-                        if (order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_ready2, ctx->lane_stream2));
-                        lane_side2 = true;
+                    if (cl.maxv > 2) {
+                        /* The three-call class gives up early on large searches (la.max_nodes): those regions are for whole wavefronts.
+                         * They get a list of their own and an HBM-tier launch right behind the class on its stream, so that they are
+                         * being solved while the other lane classes still run, not after them. */
+                        AvkKernelArgs f3 = f;
+                        f3.overflow_list = lists[3];
+                        f3.overflow_count = db->d_counters + 1104;
+                        hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f3, la);
+                        AVK_HIP(ctx, hipGetLastError());
+                        AvkKernelArgs e = a;
+                        e.pass_tier = 2;
+                        e.work_list = lists[3];
+                        e.n_work_dev = db->d_counters + 1104;
+                        e.work_base = 0;
+                        e.n_work = 0;
+                        e.work_counter = db->d_counters + 1120;
+                        e.static_pct = 0;
+                        e.n_shards = 1;
+                        e.claim = 1;
+                        e.esc_bytes = 0;
+                        e.esc_enabled = 0;
+                        e.high_priority = 0;
+                        e.extra_counter = nullptr;
+                        e.extra_n = 0;
+                        e.overflow_list = nullptr;
+                        e.overflow_count = nullptr;
+                        e.hbm_ws = ctx->d_ws + (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
+                        e.big_ws = ctx->d_big;
+                        e.big_busy = db->d_counters + 1088;
+                        e.big_slots = big_slots;
+                        const uint32_t eb = hbm_blocks < hbm_early_max ? hbm_blocks : hbm_early_max;
+                        e.n_waves = eb * waves_per_block;
+                        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(eb), dim3(256), 0, lstream[li], e);
+                        AVK_HIP(ctx, hipGetLastError());
+                        continue;
                     }
-                    hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, side ? ctx->lane_stream : ctx->lane_stream2, f, la);
+                    hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f, la);
                     AVK_HIP(ctx, hipGetLastError());
                 }
-                if (order_guard) { /* the bulk must not take the machine before the lane launches are in their queues */
-                    if (lane_side) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_ready, 0));
-                    if (lane_side2) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_ready2, 0));
+                for (int li = 0; li < 3; ++li) {
+                    if (!lused[li]) continue;
+                    if (order_guard) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, lready[li], 0)); /* the bulk must not take the machine before the lane launches are in their queues */
+                    AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
                 }
-                if (lane_side) AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join, ctx->lane_stream));
-                if (lane_side2) {
-                    AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join2, ctx->lane_stream2));
-                    if (timed) { /* end of the one-call classes' launches */
-                        AVK_HIP(ctx, hipEventRecord(ctx->ev_lane, ctx->lane_stream2));
-                        ctx->ev_lane_valid = true;
-                    }
+                if (lused[1] && timed) { /* end of the one-call classes' launches */
+                    AVK_HIP(ctx, hipEventRecord(ctx->ev_lane, ctx->lane_stream2));
+                    ctx->ev_lane_valid = true;
                 }
             }
             /* every workgroup of the three launches is resident at once */
@@ -1066,8 +1149,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                  * stream, behind the lane launches, BESIDE the bulk and the HBM launch of this stream.  What overflows there (rare) goes to a
                  * list of its own, read by one more HBM launch at the very end (normally empty: 10 us). */
                 AVK_HIP(ctx, hipGetLastError());
-                hipStream_t ds = lane_side2 ? ctx->lane_stream2 : ctx->lane_stream;
-                if (lane_side && lane_side2) AVK_HIP(ctx, hipStreamWaitEvent(ds, ctx->ev_lane_join, 0));
+                const int di = lused[1] ? 1 : (lused[0] ? 0 : 2);
+                hipStream_t ds = lstream[di];
+                for (int li = 0; li < 3; ++li)
+                    if (li != di && lused[li]) AVK_HIP(ctx, hipStreamWaitEvent(ds, ljoin[li], 0));
                 AvkKernelArgs d = a;
                 d.work_list = lists[2];
                 d.n_work_dev = db->d_counters + 1024 + 32;
@@ -1080,7 +1165,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 d.overflow_count = db->d_counters + 1024 + 16;
                 hipLaunchKernelGGL(avk_region_kernel_lds, dim3(dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ds, d);
                 AVK_HIP(ctx, hipGetLastError());
-                AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_join2, ds)); /* everything of the lane streams is behind this record */
+                AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_done, ds)); /* everything of the lane streams is behind this record */
                 deferred_pending = true;
             }
             a.tier[0].ws_bytes = slice0;
@@ -1121,7 +1206,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
     if (deferred_pending) { /* the lane streams (lane launches, then the handed-back regions) join here; what even the escalation could not hold */
-        AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_join2, 0));
+        AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_done, 0));
         AvkKernelArgs h = a;
         h.pass_tier = 2;
         h.work_list = lists[1];
@@ -1217,7 +1302,7 @@ int avk_debug_snapshot(avk_ctx *ctx, avk_dev_batch *db, uint32_t *counters, uint
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     static hipStream_t probe = nullptr;
     if (!probe) AVK_HIP(ctx, hipStreamCreateWithFlags(&probe, hipStreamNonBlocking));
-    hipStream_t ss[5] = {ctx->stream, ctx->side_stream, ctx->side_stream2, ctx->lane_stream, ctx->lane_stream2};
+    hipStream_t ss[5] = {ctx->stream, ctx->side_stream, ctx->side_stream2, ctx->lane_stream, ctx->lane_stream2}; /* (lane_stream3 joins lane_stream2 or lane_stream) */
     for (int i = 0; i < 5; ++i) busy[i] = ss[i] ? (hipStreamQuery(ss[i]) == hipErrorNotReady ? 1 : 0) : -1;
     (void)hipGetLastError();
     if (n_counters > AVK_N_COUNTERS) n_counters = AVK_N_COUNTERS;

@@ -68,12 +68,15 @@ extern int g_lane_phase;
 enum { L_REF = 1, L_ALT = 2 };
 enum { LS_DEFER = -1 }; /* internal: not this kernel's class after all, hand the region to the wave-per-region kernels */
 
-/* per-lane view of the wave's LDS: word (row, lane) sits at p[row * 64] */
+enum { MV = AVK_FAST_MAXV, NS = 2 * AVK_FAST_MAXV }; /* call slots per side, call slots of a region */
+
+/* per-lane view of the wave's LDS: word (row, lane) sits at p[row << ls], ls = log2 of the lanes that work (the tile width of the launch) */
 struct LCtx {
     u32 *p;
     u32 W1;      /* words per sequence (W + 1: the word after the last one is read by unaligned extracts) */
     u32 nm1;     /* masks per side minus one (1 or 3): sequence id = 0 reference, 1 + m - 1 truth mask m, 1 + nm1 + m - 1 query mask m */
     u32 off_wf;  /* first row of the wavefront byte arrays: hap 0, hap 1, scratch */
+    u32 ls;      /* log2 of the LDS row stride in words (= lanes per tile) */
     u32 wfr;     /* rows per wavefront array */
     u32 wfcap_c; /* bytes of the metrics phase's one array (wfa_ed) */
 #ifdef AVK_LANE_PHASE_TIMING
@@ -83,11 +86,12 @@ struct LCtx {
     u32 off_q, qcap;
     u32 off_opt, optcap;
     /* the region */
-    u32 L, T, Q, N, ord;
-    u32 vw0[4], vw1[4]; /* slots 0,1 truth, 2,3 query: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 ; alt_ed | raw_space << 8 */
-    u64 seq_len;   /* 8 bits per sequence id */
-    u64 seq_fail;  /* failed_ed per sequence id (generate_allele_sequence, :745-753) */
+    u32 L, T, Q, N, ord; /* ord: 3 bits per search depth = slot of the call handled there */
+    u32 vw0[NS], vw1[NS]; /* slots [0, MV) truth, [MV, 2 MV) query: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 ; alt_ed | raw_space << 8 */
+    u64 seq_len_lo, seq_len_hi;   /* 8 bits per sequence id (ids 0-7, 8-15) */
+    u64 seq_fail_lo, seq_fail_hi; /* failed_ed per sequence id (generate_allele_sequence, :745-753) */
     u32 max_branch;
+    u32 max_nodes; /* a search that makes more nodes than this is handed over (LaneArgs::max_nodes) */
 };
 
 AVK_DEV u32 v_pos(const LCtx &c, u32 s) { return c.vw0[s] & 0xFFu; }
@@ -97,18 +101,27 @@ AVK_DEV u32 v_type(const LCtx &c, u32 s) { return (c.vw0[s] >> 24) & 0xFu; }
 AVK_DEV u32 v_zyg(const LCtx &c, u32 s) { return (c.vw0[s] >> 28) & 0x7u; }
 AVK_DEV u32 v_alt_ed(const LCtx &c, u32 s) { return c.vw1[s] & 0xFFu; }
 AVK_DEV u32 v_raw(const LCtx &c, u32 s) { return (c.vw1[s] >> 8) & 0xFFFFu; }
-/* dynamic slot index: a select chain over the four register-resident records */
-AVK_DEV u32 sel4(const u32 (&a)[4], u32 i) { return i == 0 ? a[0] : (i == 1 ? a[1] : (i == 2 ? a[2] : a[3])); }
+/* dynamic slot index: a select chain over the register-resident records */
+AVK_DEV u32 sel4(const u32 (&a)[NS], u32 i) {
+    const u32 v0 = a[0], v1 = a[1], v2 = a[2], v3 = a[3], v4 = a[4], v5 = a[5]; /* every element read, selects on the values */
+    u32 r = v0;
+    r = i == 1 ? v1 : r;
+    r = i == 2 ? v2 : r;
+    r = i == 3 ? v3 : r;
+    r = i == 4 ? v4 : r;
+    r = i == 5 ? v5 : r;
+    return r;
+}
 
 AVK_DEV u32 seq_id(const LCtx &c, u32 side, u32 mask) { return mask == 0 ? 0u : 1u + side * c.nm1 + (mask - 1u); }
-AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return (u32)(c.seq_len >> (8 * s)) & 0xFFu; }
-AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return (u32)(c.seq_fail >> (8 * s)) & 0xFFu; }
+AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return (u32)((s < 8 ? c.seq_len_lo : c.seq_len_hi) >> (8 * (s & 7u))) & 0xFFu; }
+AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return (u32)((s < 8 ? c.seq_fail_lo : c.seq_fail_hi) >> (8 * (s & 7u))) & 0xFFu; }
 
 /* 16 bases of sequence s starting at base `off` (bits beyond the sequence's end are whatever the table holds) */
 AVK_DEV u32 extract16(const LCtx &c, u32 s, u32 off) {
     const u32 k = off >> 4, sh = (off & 15u) * 2u;
-    const u32 *w = c.p + (s * c.W1 + k) * 64u;
-    const u32 lo = w[0], hi = w[64];
+    const u32 *w = c.p + ((s * c.W1 + k) << c.ls);
+    const u32 lo = w[0], hi = w[1u << c.ls];
     return (u32)((((u64)hi << 32) | lo) >> sh);
 }
 
@@ -131,7 +144,7 @@ AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32
 }
 
 /* ---- wavefront byte arrays ---------------------------------------------------------------- */
-AVK_DEV u8 *wf_ptr(const LCtx &c, u32 arr, u32 i) { return (u8 *)(c.p + (c.off_wf + arr * c.wfr + (i >> 2)) * 64u) + (i & 3u); }
+AVK_DEV u8 *wf_ptr(const LCtx &c, u32 arr, u32 i) { return (u8 *)(c.p + ((c.off_wf + arr * c.wfr + (i >> 2)) << c.ls)) + (i & 3u); }
 AVK_DEV u32 wf_get(const LCtx &c, u32 arr, u32 i) { return *wf_ptr(c, arr, i); }
 AVK_DEV void wf_set(const LCtx &c, u32 arr, u32 i, u32 v) { *wf_ptr(c, arr, i) = (u8)v; }
 
@@ -297,7 +310,7 @@ AVK_DEV int hap_finalize(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
     return dw_finalize(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget, c.wfcap);
 }
 /* the search order (order_variants, query_optimizer.rs:372-381): slot of the call at depth d, and the step's sync point */
-AVK_DEV u32 ord_slot(const LCtx &c, u32 d) { return (c.ord >> (2 * d)) & 3u; }
+AVK_DEV u32 ord_slot(const LCtx &c, u32 d) { return (c.ord >> (3 * d)) & 7u; }
 AVK_DEV u32 sync_after(const LCtx &c, u32 d) { return d + 1 < c.N ? (sel4(c.vw0, ord_slot(c, d + 1)) & 0xFFu) : c.L; }
 
 /* ---- phase A: optimize_sequences ------------------------------------------------------------------------------------- */
@@ -311,7 +324,7 @@ AVK_DEV u32 nodeA_cost(const NodeA &n) { return n.h[0].t_skip + n.h[0].q_skip + 
  * the first edit that proves cost > cap instead of running to a distance of tens (returns LS_PARTIAL and a lower bound > cap). */
 AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice, u32 cap, u32 &lb) {
     const u32 slot = ord_slot(c, d);
-    const bool is_truth = slot < 2;
+    const bool is_truth = slot < MV;
     const u32 sync = sync_after(c, d);
     AVK_LSTAT(2, 1);
     hap_step(c, n.h[0], is_truth, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
@@ -348,8 +361,8 @@ AVK_DEV void nodeA_replay_zero(const LCtx &c, NodeA &n, u32 code, u32 depth) {
     hap_init(n.h[1]);
     for (u32 d = 0; d < depth; ++d) {
         const u32 slot = ord_slot(c, d), choice = (code >> (2 * d)) & 3u, sync = sync_after(c, d);
-        hap_step(c, n.h[0], slot < 2, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
-        hap_step(c, n.h[1], slot < 2, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
+        hap_step(c, n.h[0], slot < MV, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
+        hap_step(c, n.h[1], slot < MV, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
     }
     n.h[0].d0 = n.h[0].t_len < n.h[0].q_len ? n.h[0].t_len : n.h[0].q_len;
     n.h[1].d0 = n.h[1].t_len < n.h[1].q_len ? n.h[1].t_len : n.h[1].q_len;
@@ -372,26 +385,30 @@ AVK_DEV int nodeA_finalize(const LCtx &c, NodeA &n, u32 cap = 0xFFFFu) {
 AVK_DEV u32 q_pop_min(const LCtx &c, u32 &qn) {
     u32 best = 0xFFFFFFFFu, bi = 0;
     for (u32 i = 0; i < qn; ++i) {
-        const u32 e = c.p[(c.off_q + i) * 64u];
+        const u32 e = c.p[(c.off_q + i) << c.ls];
         if (e < best) {
             best = e;
             bi = i;
         }
     }
     qn -= 1;
-    c.p[(c.off_q + bi) * 64u] = c.p[(c.off_q + qn) * 64u];
+    c.p[(c.off_q + bi) << c.ls] = c.p[(c.off_q + qn) << c.ls];
     return best;
 }
 AVK_DEV int q_push(const LCtx &c, u32 &qn, u32 e) {
     if (qn >= c.qcap) return AVK_LDEFER(1);
-    c.p[(c.off_q + qn) * 64u] = e;
+    c.p[(c.off_q + qn) << c.ls] = e;
     qn += 1;
     return 0;
 }
-AVK_DEV u32 opt_get(const LCtx &c, u32 k) { return *((u8 *)(c.p + (c.off_opt + (k >> 2)) * 64u) + (k & 3u)); }
-AVK_DEV void opt_set(const LCtx &c, u32 k, u32 v) { *((u8 *)(c.p + (c.off_opt + (k >> 2)) * 64u) + (k & 3u)) = (u8)v; }
+/* after the searches the same rows hold the (x, z) pairs of the per-type alignments, 16 bits each */
+AVK_DEV u32 filt_get(const LCtx &c, u32 k) { return *((uint16_t *)(c.p + ((c.off_opt + (k >> 1)) << c.ls)) + (k & 1u)); }
+AVK_DEV void filt_set(const LCtx &c, u32 k, u32 v) { *((uint16_t *)(c.p + ((c.off_opt + (k >> 1)) << c.ls)) + (k & 1u)) = (uint16_t)v; }
+AVK_DEV u32 opt_get(const LCtx &c, u32 k) { return *((uint16_t *)(c.p + ((c.off_opt + (k >> 1)) << c.ls)) + (k & 1u)); }
+AVK_DEV void opt_set(const LCtx &c, u32 k, u32 v) { *((uint16_t *)(c.p + ((c.off_opt + (k >> 1)) << c.ls)) + (k & 1u)) = (uint16_t)v; }
 
-/* Queue words of phase A: cost << 20 | id << 12 | code << 4 | partial << 3 | depth.  A `partial` entry carries a LOWER BOUND of the
+/* Queue words of phase A: cost << 24 | id << 16 | code << 4 | partial << 3 | depth (code: 2 bits per depth, up to 6 depths; a cost
+ * beyond 255 hands the region over).  A `partial` entry carries a LOWER BOUND of the
  * node's cost (its last step was stopped early, nodeA_step).  The reference pops the minimum of (cost, id); here the minimum word is
  * popped, and when it is partial its cost is worked out further — up to the next entry's cost, which is as far as it can matter —
  * and it goes back into the queue unless it turns out to cost exactly what it was popped for.  Lower bounds never exceed the true
@@ -399,26 +416,30 @@ AVK_DEV void opt_set(const LCtx &c, u32 k, u32 v) { *((u8 *)(c.p + (c.off_opt + 
 AVK_DEV u32 q_min_cost(const LCtx &c, u32 qn) {
     u32 best = 0xFFFFFFFFu;
     for (u32 i = 0; i < qn; ++i) {
-        const u32 e = c.p[(c.off_q + i) * 64u];
+        const u32 e = c.p[(c.off_q + i) << c.ls];
         best = e < best ? e : best;
     }
-    return qn ? best >> 20 : 0xFFFFu;
+    return qn ? best >> 24 : 0xFFFFu;
 }
-AVK_DEV u32 keyA(u32 cost, u32 id, u32 code, u32 partial, u32 depth) { return (cost << 20) | (id << 12) | (code << 4) | (partial << 3) | depth; }
+AVK_DEV u32 keyA(u32 cost, u32 id, u32 code, u32 partial, u32 depth) { return (cost << 24) | (id << 16) | (code << 4) | (partial << 3) | depth; }
+AVK_DEV int pushA(const LCtx &c, u32 &qn, u32 cost, u32 id, u32 code, u32 partial, u32 depth) {
+    if (cost > 255u) return AVK_LDEFER(5);
+    return q_push(c, qn, keyA(cost, id, code, partial, depth));
+}
 
 /* returns the number of tied optima (codes in the opt array, in the order the reference finds them), LS_DEFER, or -100 - status */
 AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
     u32 qn = 0;
     q_push(c, qn, 0);
     u32 next_id = 1, best = 0xFFFFu, nbest = 0;
-    u32 bucket = 0; /* 6 bits per depth: a depth sees at most 2^4 pops */
+    u64 bucket = 0; /* 8 bits per depth (fewer than 250 nodes are ever made) */
     while (qn > 0) {
         const u32 e = q_pop_min(c, qn);
-        const u32 cost = e >> 20;
+        const u32 cost = e >> 24;
         if (cost > best) break; /* :204; pops come in non-decreasing cost order */
         AVK_LSTAT(3, 1);
         AVK_LSTAT(4, (e >> 3) & 1u);
-        const u32 depth = e & 7u, code = (e >> 4) & 0xFFu, id = (e >> 12) & 0xFFu;
+        const u32 depth = e & 7u, code = (e >> 4) & 0xFFFu, id = (e >> 16) & 0xFFu;
         NodeA n;
         if (e & 8u) { /* partial: ancestors are exact (they were popped), the last step is taken further */
             /* as far as it can matter for the order (the next entry's cost), and at least doubling, so that a node that really is
@@ -432,18 +453,18 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
             const int r = nodeA_step(c, n, depth - 1, (code >> (2 * (depth - 1))) & 3u, cap, lb);
             if (r == LS_DEFER) return LS_DEFER;
             if (r == LS_PARTIAL) {
-                if (q_push(c, qn, keyA(lb, id, code, 1, depth))) return LS_DEFER;
+                if (pushA(c, qn, lb, id, code, 1, depth)) return LS_DEFER;
                 continue;
             }
             const u32 full = nodeA_cost(n);
             if (full != cost) {
-                if (q_push(c, qn, keyA(full, id, code, 0, depth))) return LS_DEFER;
+                if (pushA(c, qn, full, id, code, 0, depth)) return LS_DEFER;
                 continue;
             }
         }
-        const u32 cnt = (bucket >> (6 * depth)) & 0x3Fu;
+        const u32 cnt = (u32)(bucket >> (8 * depth)) & 0xFFu;
         if (cnt >= c.max_branch) continue; /* :222 */
-        bucket += 1u << (6 * depth);
+        bucket += 1ull << (8 * depth);
         if (!(e & 8u)) {
             if (cost == 0) nodeA_replay_zero(c, n, code, depth);
             else if (nodeA_replay(c, n, code, depth)) return LS_DEFER;
@@ -465,7 +486,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
             continue;
         }
         const u32 slot = ord_slot(c, depth);
-        const bool is_truth = slot < 2;
+        const bool is_truth = slot < MV;
         const u32 zyg = (sel4(c.vw0, slot) >> 28) & 7u;
         const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
         u32 lb = 0;
@@ -474,23 +495,23 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
             /* the first child works on the arrays of `n`; the second is replayed from the root (the arrays hold child 1 by then) */
             int r = nodeA_step(c, n, depth, 2u, cost, lb);
             if (r == LS_DEFER) return LS_DEFER;
-            if (q_push(c, qn, keyA(r ? lb : nodeA_cost(n), next_id, code | (2u << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
+            if (pushA(c, qn, r ? lb : nodeA_cost(n), next_id, code | (2u << (2 * depth)), r ? 1u : 0u, depth + 1)) return LS_DEFER;
             next_id += 1;
             if (m.h[0].ed | m.h[1].ed) { /* parent wavefronts were overwritten */
                 if (nodeA_replay(c, m, code, depth)) return LS_DEFER;
             }
             r = nodeA_step(c, m, depth, 1u, cost, lb);
             if (r == LS_DEFER) return LS_DEFER;
-            if (q_push(c, qn, keyA(r ? lb : nodeA_cost(m), next_id, code | (1u << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
+            if (pushA(c, qn, r ? lb : nodeA_cost(m), next_id, code | (1u << (2 * depth)), r ? 1u : 0u, depth + 1)) return LS_DEFER;
             next_id += 1;
         } else { /* :294-327: the node is moved, its id kept */
             u32 choice = 3u;
             if (het) choice = zyg == AVK_ZYG_PHASED_HET01 ? 2u : 1u; /* 0|1: REF on haplotype 1, ALT on haplotype 2 */
             const int r = nodeA_step(c, n, depth, choice, cost, lb);
             if (r == LS_DEFER) return LS_DEFER;
-            if (q_push(c, qn, keyA(r ? lb : nodeA_cost(n), id, code | (choice << (2 * depth)), r ? 1u : 0u, depth + 1))) return LS_DEFER;
+            if (pushA(c, qn, r ? lb : nodeA_cost(n), id, code | (choice << (2 * depth)), r ? 1u : 0u, depth + 1)) return LS_DEFER;
         }
-        if (next_id > 250) return AVK_LDEFER(3);
+        if (next_id > c.max_nodes) return AVK_LDEFER(3);
     }
     if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
     best_out = best;
@@ -503,7 +524,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
  * (Reverse(errors), set - errors, Reverse(id); :452-458). */
 AVK_DEV bool hapB_step(const LCtx &c, Hap &h, u32 d, bool alt) {
     const u32 slot = ord_slot(c, d);
-    const bool ok = hap_step(c, h, slot < 2, true, slot, alt ? L_ALT : L_REF, sync_after(c, d));
+    const bool ok = hap_step(c, h, slot < MV, true, slot, alt ? L_ALT : L_REF, sync_after(c, d));
     const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
     h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
     const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
@@ -524,7 +545,7 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
         /* every queued node is exact (that is what let it in): its wavefront is the end of its shorter sequence, no comparing again */
         for (u32 d = 0; d < depth; ++d) {
             const u32 slot = ord_slot(c, d);
-            hap_step(c, h, slot < 2, true, slot, ((code >> d) & 1u) ? L_ALT : L_REF, sync_after(c, d));
+            hap_step(c, h, slot < MV, true, slot, ((code >> d) & 1u) ? L_ALT : L_REF, sync_after(c, d));
         }
         h.d0 = h.t_len < h.q_len ? h.t_len : h.q_len;
         if (depth == c.N) { /* :180-192 */
@@ -541,8 +562,8 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
         if (depth < min_sync) continue;                                   /* :194-197 */
         if (h.t_len == h.q_len && h.t_refpos == h.q_refpos) min_sync = depth; /* :206-217 (fewer than 500 expansions: no auto-fail) */
         const u32 slot = ord_slot(c, depth);
-        const bool is_truth = slot < 2;
-        const bool cur_alt = (((is_truth ? in_t : in_q) >> (is_truth ? slot : slot - 2u)) & 1u) != 0;
+        const bool is_truth = slot < MV;
+        const bool cur_alt = (((is_truth ? in_t : in_q) >> (is_truth ? slot : slot - MV)) & 1u) != 0;
         if (!cur_alt) { /* :257-273 */
             if (hapB_step(c, h, depth, false)) {
                 if (q_push(c, qn, keyB(errors, depth + 1, id, code))) return LS_DEFER;
@@ -569,21 +590,30 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
 AVK_DEV int ed_to_ref(const LCtx &c, u32 side, u32 mask, u32 len) {
     if (mask == 0) return 0;
     if ((mask & (mask - 1)) == 0) {
-        const u32 slot = 2 * side + (mask == 1 ? 0u : 1u);
+        const u32 slot = MV * side + (u32)__builtin_ctz(mask);
         const u32 w0 = sel4(c.vw0, slot), e = sel4(c.vw1, slot) & 0xFFu;
         const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
         const u32 diff = a0 > a1 ? a0 - a1 : a1 - a0;
         if (e == 1 || (e && e == diff)) return (int)e;
     } else if (seq_fail_of(c, seq_id(c, side, mask)) == 0) {
-        /* both calls of the side, both applied.  Two substitutions at different positions: the strings have one length and differ in
-         * two places, no single edit does that.  Two pure insertions (or two pure deletions): the length changes by the sum of their
-         * edits, which is also enough. */
-        const u32 wa = sel4(c.vw0, 2 * side), wb = sel4(c.vw0, 2 * side + 1);
-        const u32 ea = sel4(c.vw1, 2 * side) & 0xFFu, eb = sel4(c.vw1, 2 * side + 1) & 0xFFu;
-        const u32 a0a = (wa >> 8) & 0xFFu, a1a = (wa >> 16) & 0xFFu, a0b = (wb >> 8) & 0xFFu, a1b = (wb >> 16) & 0xFFu;
-        if (a0a == 1 && a1a == 1 && a0b == 1 && a1b == 1 && ea == 1 && eb == 1 && ((wa ^ wb) & 0xFFu) != 0) return 2;
-        if (ea && eb && ((a1a > a0a && a1b > a0b && ea == a1a - a0a && eb == a1b - a0b) || (a0a > a1a && a0b > a1b && ea == a0a - a1a && eb == a0b - a1b)))
-            return (int)(ea + eb);
+        /* several calls of the side, all applied.  Two substitutions at different positions: the strings have one length and differ
+         * in two places, no single edit does that.  Pure insertions only (or pure deletions only): the length changes by the sum of
+         * their edits, which is also enough. */
+        u32 n = 0, n_snv = 0, n_ins = 0, n_del = 0, sum = 0, pos_x = 0;
+#pragma unroll
+        for (u32 j = 0; j < MV; ++j) {
+            if (!((mask >> j) & 1u)) continue;
+            const u32 w0 = side ? c.vw0[MV + j] : c.vw0[j], e = (side ? c.vw1[MV + j] : c.vw1[j]) & 0xFFu;
+            const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+            n += 1;
+            sum += e;
+            n_snv += (a0 == 1 && a1 == 1 && e == 1) ? 1u : 0u;
+            n_ins += (a1 > a0 && e == a1 - a0) ? 1u : 0u;
+            n_del += (a0 > a1 && e == a0 - a1) ? 1u : 0u;
+            pos_x ^= w0 & 0xFFu;
+        }
+        if (n == 2 && n_snv == 2 && pos_x != 0) return 2;
+        if (n_ins == n || n_del == n) return (int)sum;
     }
     return wfa_ed(c, 0, c.L, seq_id(c, side, mask), len);
 }
@@ -620,7 +650,7 @@ AVK_DEV void sw_push(const LCtx &c, SeqWriter &w, u32 bits, u32 nbases) {
     w.acc |= ((u64)bits & m) << w.nb;
     w.nb += 2 * nbases;
     if (w.nb >= 32) {
-        c.p[(w.row * c.W1 + w.k) * 64u] = (u32)w.acc;
+        c.p[(w.row * c.W1 + w.k) << c.ls] = (u32)w.acc;
         w.k += 1;
         w.acc >>= 32;
         w.nb -= 32;
@@ -631,7 +661,7 @@ AVK_DEV void sw_ref(const LCtx &c, SeqWriter &w, u32 from, u32 to) {
 }
 /* FULL(side, mask): the calls of the mask applied in the side's order, a call that starts before the end of the previous applied one
  * is dropped and its alt_ed counted (generate_allele_sequence, waffle_solver.rs:726-778) */
-template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)[4], const u32 (&a1hi)[4]) {
+template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)[NS], const u32 (&a1hi)[NS]) {
     const u32 s = seq_id(c, side, mask), cnt = side == 0 ? c.T : c.Q;
     SeqWriter w;
     w.acc = 0;
@@ -640,9 +670,9 @@ template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)
     w.k = 0;
     u32 cur = 0, len = 0, failed = 0;
 #pragma unroll
-    for (u32 j = 0; j < 2; ++j) { /* static slot indices: the records stay in registers */
+    for (u32 j = 0; j < MV; ++j) { /* static slot indices: the records stay in registers */
         if (j >= cnt || !((mask >> j) & 1u)) continue;
-        const u32 slot = 2 * side + j;
+        const u32 slot = MV * side + j;
         const u32 w0 = c.vw0[slot];
         const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
         if (pos < cur) {
@@ -659,9 +689,12 @@ template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)
         sw_ref(c, w, cur, c.L);
         len += c.L - cur;
     }
-    if (w.nb) c.p[(w.row * c.W1 + w.k) * 64u] = (u32)w.acc;
-    c.seq_len |= (u64)len << (8 * s);
-    c.seq_fail |= (u64)failed << (8 * s);
+    if (w.nb) c.p[(w.row * c.W1 + w.k) << c.ls] = (u32)w.acc;
+    const u64 len_s = (u64)len << (8 * (s & 7u)), fail_s = (u64)failed << (8 * (s & 7u));
+    c.seq_len_lo |= s < 8 ? len_s : 0ull;
+    c.seq_len_hi |= s < 8 ? 0ull : len_s;
+    c.seq_fail_lo |= s < 8 ? fail_s : 0ull;
+    c.seq_fail_hi |= s < 8 ? 0ull : fail_s;
 }
 
 /* ---- one region ------------------------------------------------------------------------------------------------------ */
@@ -697,6 +730,9 @@ struct LaneArgs { /* what a launch of the lane kernel needs besides AvkKernelArg
     u32 *tile_counter;
     u32 W, nm, ed_max, qcap; /* the class of this launch */
     u32 gen_base;        /* record index (work order of the wave-per-region kernels) of fast record 0 */
+    u32 max_nodes;       /* phase A gives up (hands the region over) beyond this many search nodes: at most 250 (ids are 8 bits) */
+    u32 lanes_log2;      /* 6, 5 or 4: a wave takes 64, 32 or 16 records of a tile at a time on its first lanes (smaller LDS slice per wave, more
+                            waves per CU, less waiting for the slowest record) */
 };
 
 /* returns AVK_ST_* (>= 0) or LS_DEFER.  `tally` = the workgroup's LDS tally (u32 counters). */
@@ -707,19 +743,30 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     c.T = (h1 >> 12) & 3u;
     c.Q = (h1 >> 14) & 3u;
     c.N = c.T + c.Q;
-    c.ord = (h1 >> 16) & 0xFFu;
+    { /* the record says which side each search depth takes its call from; the sides' calls come in their own order */
+        const u32 takeq = h1 >> 16;
+        u32 ord = 0, it = 0, iq = 0;
+        for (u32 d = 0; d < c.N; ++d) {
+            const u32 q = (takeq >> d) & 1u;
+            ord |= (q ? MV + iq : it) << (3 * d);
+            iq += q;
+            it += 1u - q;
+        }
+        c.ord = ord;
+    }
     c.max_branch = a.max_branch_factor;
-    c.seq_len = c.L;
-    c.seq_fail = 0;
-    u32 a1lo[4], a1hi[4];
+    c.seq_len_lo = c.L;
+    c.seq_len_hi = c.seq_fail_lo = c.seq_fail_hi = 0;
+    u32 a1lo[NS], a1hi[NS];
     u32 types = 0;
+    const u32 maxv = c.nm1 == 1 ? 1u : (c.nm1 == 3 ? 2u : 3u); /* record slots: truth [0, maxv), query [maxv, 2 maxv) */
 #pragma unroll
-    for (u32 s = 0; s < 4; ++s) {
-        const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
+    for (u32 s = 0; s < NS; ++s) {
+        const u32 side = s / MV, j = s % MV;
+        const bool on = j < (side ? c.Q : c.T);
         c.vw0[s] = c.vw1[s] = a1lo[s] = a1hi[s] = 0;
         if (on) {
-            const u32 maxv = c.nm1 == 1 ? 1u : 2u; /* record slots: truth [0, maxv), query [maxv, 2 maxv) */
-            const u32 *v = rec + (AVK_FAST_HDR + 4 * (s < 2 ? s : maxv + (s - 2))) * lane_stride;
+            const u32 *v = rec + (AVK_FAST_HDR + 4 * (side * maxv + j)) * lane_stride;
             c.vw0[s] = v[0];
             c.vw1[s] = v[1 * lane_stride];
             a1lo[s] = v[2 * lane_stride];
@@ -744,7 +791,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
                 word = (u32)((((u64)next << 32) | prev) >> (2 * shift));
                 prev = next;
             }
-            c.p[k * 64u] = word;
+            c.p[k << c.ls] = word;
         }
     }
     for (u32 m = 1; m <= c.nm1; ++m) {
@@ -811,9 +858,9 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     u32 exp_pack = 0, obs_pack = 0; /* 2 bits per call slot */
     int bad = 0;
 #pragma unroll
-    for (u32 s = 0; s < 4; ++s) {
-        const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
-        const u32 side = s >> 1, j = s & 1u;
+    for (u32 s = 0; s < NS; ++s) {
+        const u32 side = s / MV, j = s % MV;
+        const bool on = j < (side ? c.Q : c.T);
         const u32 b0 = ((side ? wn.h[0].q_alt : wn.h[0].t_alt) >> j) & 1u, b1 = ((side ? wn.h[1].q_alt : wn.h[1].t_alt) >> j) & 1u;
         const u32 o0 = ((side ? o_q0 : o_t0) >> j) & 1u, o1 = ((side ? o_q1 : o_t1) >> j) & 1u;
         const u32 ex = on ? b0 + b1 : 0u, ob = on ? o0 + o1 : 0u;
@@ -873,59 +920,54 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
             tp0 = tph;
         }
     }
-    /* Alignments of the per-type groups (:383-445), done BEFORE anything is added to the tally (they can still hand the region over):
-     * a side with two calls of different types is compared once with only its first and once with only its second call, per haplotype.
-     * 8 bits each: x = ed(ref, filtered side), z = ed(filtered side, other side as it is); entry (hap, j) at bits 16 * (2 * hap + j). */
     AVK_LT_MARK(c, 3)
-    u64 tfilt = 0, qfilt = 0;
-    const bool t_split = c.T == 2 && ((c.vw0[0] ^ c.vw0[1]) >> 24 & 0xFu) != 0, q_split = c.Q == 2 && ((c.vw0[2] ^ c.vw0[3]) >> 24 & 0xFu) != 0;
+    /* Alignments of the per-type groups (:383-445), done BEFORE anything is added to the tally (they can still hand the region over).
+     * One pass over the call types of the region: a side that has calls of the type AND calls of other types is compared with only the
+     * type's calls applied, per haplotype: x = ed(ref, filtered side), z = ed(filtered side, other side as it is), 8 bits each.  The
+     * pair goes to the rows of the optima list (read and done with), entry (hap, side, first call of the type on the side), for the
+     * pass below that adds the groups up. */
     AVK_LPHASE(3);
-    if (t_split || q_split) {
-        for (u32 hh = 0; hh < 2; ++hh) {
-            const Hap &h = hh ? wn.h[1] : wn.h[0];
-            if (hh && same_haps) {
-                tfilt |= tfilt << 32;
-                qfilt |= qfilt << 32;
-                break;
-            }
-            const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
-            const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
-            for (u32 j = 0; j < 2; ++j) {
-                if (t_split) {
-                    const u32 m = h.t_alt & (1u << j);
-                    u32 x2 = 0, z2 = Yh / 2; /* nothing left of the truth side: it is the reference window */
-                    if (m && m == h.t_alt) { /* the call is the haplotype's only one: the filtered side is the side as it is */
-                        x2 = Xh / 2;
-                        z2 = h.ed;
-                    } else if (m) {
-                        const u32 sf = seq_id(c, 0, m), fl = seq_len_of(c, sf);
-                        const int x = ed_to_ref(c, 0, m, fl);
-                        /* equal haplotypes with everything applied: the query string is the filtered truth string plus the other call */
-                        int z = (h.ed == 0 && h.nskip == 0 && seq_fail_of(c, st) == 0 && seq_fail_of(c, sf) == 0) ? one_call_distance(c, 1u - j) : -1;
-                        if (z < 0) z = wfa_ed(c, sf, fl, sq, h.q_len);
-                        if (x < 0 || z < 0) return LS_DEFER;
-                        x2 = (u32)x;
-                        z2 = (u32)z;
-                    }
-                    tfilt |= (u64)(x2 | (z2 << 8)) << (16 * (2 * hh + j));
+    for (u32 left = types; left; left &= left - 1) {
+        const u32 vt = (u32)__builtin_ctz(left);
+        if (!((SUPMASK >> vt) & 1u)) continue;
+        u32 tmask_g = 0, qmask_g = 0;
+#pragma unroll
+        for (u32 s = 0; s < NS; ++s) {
+            const u32 side = s / MV, j = s % MV;
+            if (j < (side ? c.Q : c.T) && ((c.vw0[s] >> 24) & 0xFu) == vt) (side ? qmask_g : tmask_g) |= 1u << j;
+        }
+        const u32 t_all = (1u << c.T) - 1u, q_all = (1u << c.Q) - 1u;
+        for (u32 side = 0; side < 2; ++side) {
+            const u32 mask_g = side ? qmask_g : tmask_g;
+            if (mask_g == 0 || mask_g == (side ? q_all : t_all)) continue; /* none of the type, or nothing but the type: no filtering */
+            for (u32 hh = 0; hh < 2; ++hh) {
+                const Hap &h = hh ? wn.h[1] : wn.h[0];
+                const u32 e_idx = (hh * 2 + side) * MV + (u32)__builtin_ctz(mask_g);
+                if (hh && same_haps) {
+                    filt_set(c, e_idx, filt_get(c, e_idx - 2 * MV));
+                    continue;
                 }
-                if (q_split) {
-                    const u32 m = h.q_alt & (1u << j);
-                    u32 y2 = 0, z2 = Xh / 2;
-                    if (m && m == h.q_alt) {
-                        y2 = Yh / 2;
-                        z2 = h.ed;
-                    } else if (m) {
-                        const u32 sf = seq_id(c, 1, m), fl = seq_len_of(c, sf);
-                        const int y = ed_to_ref(c, 1, m, fl);
-                        int z = (h.ed == 0 && h.nskip == 0 && seq_fail_of(c, sq) == 0 && seq_fail_of(c, sf) == 0) ? one_call_distance(c, 2u + (1u - j)) : -1;
-                        if (z < 0) z = wfa_ed(c, st, h.t_len, sf, fl);
-                        if (y < 0 || z < 0) return LS_DEFER;
-                        y2 = (u32)y;
-                        z2 = (u32)z;
-                    }
-                    qfilt |= (u64)(y2 | (z2 << 8)) << (16 * (2 * hh + j));
+                const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+                const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
+                const u32 alt = side ? h.q_alt : h.t_alt, m = alt & mask_g;
+                u32 x2 = 0, z2 = (side ? Xh : Yh) / 2; /* nothing left of the side: it is the reference window */
+                if (m && m == alt) { /* nothing filtered away on this haplotype: the side as it is */
+                    x2 = (side ? Yh : Xh) / 2;
+                    z2 = h.ed;
+                } else if (m) {
+                    const u32 sf = seq_id(c, side, m), fl = seq_len_of(c, sf);
+                    const int x = ed_to_ref(c, side, m, fl);
+                    /* equal haplotypes with everything applied, one call filtered away: the other side's string is the filtered string plus that call */
+                    const u32 gone = alt ^ m;
+                    int z = -1;
+                    if (h.ed == 0 && h.nskip == 0 && (gone & (gone - 1)) == 0 && seq_fail_of(c, side ? sq : st) == 0 && seq_fail_of(c, sf) == 0)
+                        z = one_call_distance(c, MV * side + (u32)__builtin_ctz(gone));
+                    if (z < 0) z = side ? wfa_ed(c, st, h.t_len, sf, fl) : wfa_ed(c, sf, fl, sq, h.q_len);
+                    if (x < 0 || z < 0) return LS_DEFER;
+                    x2 = (u32)x;
+                    z2 = (u32)z;
                 }
+                filt_set(c, e_idx, x2 | (z2 << 8));
             }
         }
     }
@@ -944,23 +986,23 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
         u32 tot_t = 0, tot_q = 0, tcount = 0, qcount = 0;
         u32 tmask_g = 0, qmask_g = 0; /* the side's calls of this group's type */
 #pragma unroll
-        for (u32 s = 0; s < 4; ++s) {
-            const bool on = (s < 2) ? (s < c.T) : (s - 2 < c.Q);
+        for (u32 s = 0; s < NS; ++s) {
+            const bool on = (s % MV) < (s < MV ? c.T : c.Q);
             const u32 w0 = c.vw0[s], w1 = c.vw1[s];
             const u32 vt = (w0 >> 24) & 0xFu, z = (w0 >> 28) & 7u;
             if (!on || (g != 0 && vt != g - 1)) continue;
-            if (s >= 2) g_add<true>(G, w1 & 0xFFu, (exp_pack >> (2 * s)) & 3u, (obs_pack >> (2 * s)) & 3u); /* static field indices */
+            if (s >= MV) g_add<true>(G, w1 & 0xFFu, (exp_pack >> (2 * s)) & 3u, (obs_pack >> (2 * s)) & 3u); /* static field indices */
             else g_add<false>(G, w1 & 0xFFu, (exp_pack >> (2 * s)) & 3u, (obs_pack >> (2 * s)) & 3u);
             const u32 cntz = z == AVK_ZYG_HOM_ALT ? 2u : ((z == AVK_ZYG_UNPHASED_HET || z == AVK_ZYG_PHASED_HET01 || z == AVK_ZYG_PHASED_HET10) ? 1u : 0u);
             const u32 val = cntz * ((w1 >> 8) & 0xFFFFu);
-            if (s < 2) {
+            if (s < MV) {
                 tot_t += val;
                 tcount += 1;
                 tmask_g |= 1u << s;
             } else {
                 tot_q += val;
                 qcount += 1;
-                qmask_g |= 1u << (s - 2);
+                qmask_g |= 1u << (s - MV);
             }
         }
         if (g == 0) {
@@ -977,9 +1019,9 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
                     if (qcount == c.Q) {
                         q_tp = tph;
                         q_fp = Yh - tph + 2 * h.q_skip;
-                    } else { /* one of two calls: the alignments were made above */
+                    } else { /* some of the side's calls: the alignments were made above */
                         const u32 sf = seq_id(c, 1, h.q_alt & qmask_g);
-                        const u32 e = (u32)(qfilt >> (16 * (2 * hh + (qmask_g == 1 ? 0u : 1u)))) & 0xFFFFu;
+                        const u32 e = filt_get(c, (hh * 2 + 1u) * MV + (u32)__builtin_ctz(qmask_g));
                         const u32 y2 = e & 0xFFu, z2 = e >> 8;
                         const u32 tp2 = (Xh + 2u * y2 - 2u * z2) / 2u;
                         q_tp = tp2;
@@ -992,7 +1034,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
                         t_fn = Xh - tph + 2 * h.t_skip;
                     } else {
                         const u32 sf = seq_id(c, 0, h.t_alt & tmask_g);
-                        const u32 e = (u32)(tfilt >> (16 * (2 * hh + (tmask_g == 1 ? 0u : 1u)))) & 0xFFFFu;
+                        const u32 e = filt_get(c, (hh * 2) * MV + (u32)__builtin_ctz(tmask_g));
                         const u32 x2 = e & 0xFFu, z2 = e >> 8;
                         const u32 tp2 = (2u * x2 + Yh - 2u * z2) / 2u;
                         t_tp = tp2;
@@ -1027,10 +1069,11 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
 }
 
 /* LDS words per wave for a launch class */
-AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap, u32 optcap) {
+AVK_DEV u32 lane_optcap(u32 nm) { return nm == 2 ? 8u : 16u; } /* tied optima a lane keeps (16 bits each); more: handed over */
+AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap) {
     const u32 ns = 1 + 2 * (nm - 1);
     const u32 wfr = (2 * ed_max + 2 + 3) / 4;
-    return ns * (W + 1) + 3 * wfr + qcap + (optcap + 3) / 4;
+    return ns * (W + 1) + 3 * wfr + qcap + lane_optcap(nm) / 2;
 }
 
 /* One persistent wave: claims tiles of 64 fast records, every lane solves its record.  wave_lds = this wave's rows, wg_tally =
@@ -1038,7 +1081,8 @@ AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap, u32 optcap) {
 AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id, u32 *wave_lds, u32 *wg_tally, u32 &n_ok_out, u32 &n_err_out, u64 *part = (u64 *)0) {
     const u32 lane = (u32)wv_lane();
     LCtx c;
-    c.p = wave_lds + lane;
+    c.ls = la.lanes_log2;
+    c.p = wave_lds + (lane & ((1u << la.lanes_log2) - 1u));
     c.W1 = la.W + 1;
     c.nm1 = la.nm - 1;
     c.off_wf = (1 + 2 * c.nm1) * c.W1;
@@ -1048,11 +1092,14 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     c.wfcap_c = 4 * (3 * c.wfr + la.qcap);
     c.qcap = la.qcap;
     c.off_opt = c.off_q + la.qcap;
-    c.optcap = 16;
+    c.optcap = lane_optcap(la.nm);
+    c.max_nodes = la.max_nodes < 250u ? la.max_nodes : 250u;
     u32 n_ok = 0, n_err = 0, n_tiles_done = 0;
 #ifdef AVK_LANE_PHASE_TIMING
     for (int k = 0; k < 8; ++k) c.tph[k] = 0;
 #endif
+    const u32 width = 1u << la.lanes_log2, parts = 64u >> la.lanes_log2; /* records per claim, claims per tile */
+    const u32 n_claims = la.n_tiles * parts;
     for (;;) {
         u32 t = 0;
 #ifdef AVK_LANE_PHASE_TIMING
@@ -1060,9 +1107,9 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #endif
         if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
         t = wv_uni(wv_shfl(t, 0));
-        if (t >= la.n_tiles) break;
+        if (t >= n_claims) break;
         n_tiles_done += 1;
-        if (part && (n_tiles_done & 15u) == 0) { /* the 32-bit LDS tally moves on to the 64-bit partial tally every 16 tiles (1024 regions) */
+        if (part && (n_tiles_done & 15u) == 0) { /* the 32-bit LDS tally moves on to the 64-bit partial tally every 16 claims (at most 1024 regions) */
             wv_sync();
             for (u32 i = lane; i < AVK_N_GROUPS * AVK_N_FIELDS; i += 64) {
                 const u32 v = avk_wg_xchg(wg_tally + i, 0u);
@@ -1070,7 +1117,10 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
             }
             wv_sync();
         }
-        const u32 *rec = la.recs + (u64)t * la.rec_words * 64u + lane;
+        const u32 rl = (t & (parts - 1u)) * width + lane; /* this lane's record in the tile */
+        t >>= 6u - la.lanes_log2;
+        if (lane >= width) continue; /* the other lanes only take part in the wave's claims and flushes */
+        const u32 *rec = la.recs + (u64)t * la.rec_words * 64u + rl;
         const u32 h1 = rec[64];
         if (h1 != 0xFFFFFFFFu) { /* a lane of the class's last tile may have no region */
             const u32 orig = rec[3 * 64];
@@ -1086,7 +1136,7 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
             }
             if (st == LS_DEFER) { /* hand over to the wave-per-region kernels */
                 const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1u);
-                a.overflow_list[slot_o] = la.gen_base + (t * 64u + lane);
+                a.overflow_list[slot_o] = la.gen_base + (t * 64u + rl);
             } else {
                 uint32_t w4[4];
                 if (st == AVK_ST_OK) {
@@ -1119,7 +1169,7 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #endif
     }
 #ifdef AVK_LANE_PHASE_TIMING
-    {
+    if (lane < width) {
         u64 *pc = a.tally + (u64)(wave_id % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5 + (la.nm > 2 ? 8 : 0); /* one-call classes, two-call classes */
         for (int k = 0; k < 7; ++k) avk_atomic_add_u64_global(pc + k, c.tph[k]);
         avk_atomic_add_u64_global(pc + 7, 1);

@@ -339,7 +339,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
             dr.pre_status |= types << 16;
             dr.ed_bound = (uint32_t)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
             /* small enough for the lane-per-region kernel?  (capacities of AvkFastClass; everything must fit the record's bit fields) */
-            if (tc <= 2 && qc <= 2 && N >= 1 && dr.len <= 255 && ed_sum <= 255) {
+            if (tc <= AVK_FAST_MAXV && qc <= AVK_FAST_MAXV && N >= 1 && dr.len <= 255 && ed_sum <= 255) {
                 bool ok = true;
                 for (uint32_t i = 0; i < N && ok; ++i) {
                     ok = bv[i].rel_pos <= 255 && bv[i].a0_len <= 255 && bv[i].a1_len <= 32 && bv[i].alt_ed <= 255 && bv[i].raw_space <= 0xFFFF;
@@ -413,19 +413,20 @@ struct WorkPlan {
  * an unused class are planned like any other region.  0xFFFFFFFF = no lane classes at all. */
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
                                 uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12,
-                                uint64_t lane_min_regions = 0) {
+                                uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
     WorkPlan plan;
     bool lane_on[AVK_FAST_CLASSES];
     {
-        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16};
+        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2};
         uint64_t have[AVK_FAST_CLASSES] = {0};
         if (!pb.fast_class.empty())
             for (uint64_t r = 0; r < n; ++r)
                 if (pb.fast_class[r] && !(pb.regions[r].pre_status & 0xFFFFu)) have[pb.fast_class[r] - 1u] += 1;
-        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lane_on[fc] = lane_min_regions != 0xFFFFFFFFull && have[fc] > 0 && have[fc] >= lane_min_regions * scale[fc];
+        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc)
+            lane_on[fc] = lane_min_regions != 0xFFFFFFFFull && have[fc] > 0 && have[fc] >= lane_min_regions * scale[fc] && AVK_FAST_CLASS[fc].maxv <= lane_max_calls;
     }
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
@@ -534,7 +535,7 @@ inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vec
                 uint32_t ord = 0;
                 for (uint32_t d = 0; d < N; ++d) {
                     const uint32_t vi = bo[d].vi;
-                    ord |= (vi < tc ? vi : 2u + (vi - tc)) << (2 * d);
+                    ord |= (vi < tc ? 0u : 1u) << d; /* each side's calls come in their own order */
                 }
                 T[0 * 64 + lane] = (uint32_t)(dr.ref_off >> 4);
                 T[1 * 64 + lane] = (uint32_t)(dr.ref_off & 15u) | (dr.len << 4) | (tc << 12) | (qc << 14) | (ord << 16);

@@ -130,7 +130,7 @@ struct StreamBufs {
     uint64_t *d_partials = nullptr, *d_tally = nullptr, *h_tally = nullptr;
     uint32_t *d_counters = nullptr;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied = nullptr, ev_lane_done = nullptr;
+    hipEvent_t ev_copied = nullptr, ev_lane_done = nullptr, ev_lane_done3 = nullptr;
 };
 
 void stream_bufs_free(StreamBufs *b) {
@@ -145,6 +145,7 @@ void stream_bufs_free(StreamBufs *b) {
         if (p) (void)hipFree(p);
     if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
     if (b->ev_lane_done) (void)hipEventDestroy(b->ev_lane_done);
+    if (b->ev_lane_done3) (void)hipEventDestroy(b->ev_lane_done3);
     if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
     delete b;
 }
@@ -179,6 +180,7 @@ static int stream_bufs_init(avk_ctx *ctx) {
     AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->sbufs->copy_stream, hipStreamNonBlocking));
     AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_copied, hipEventDisableTiming));
     AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done, hipEventDisableTiming));
+    AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done3, hipEventDisableTiming));
     AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t)));
     AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t)));
     AVK_HIP(ctx, hipHostMalloc((void **)&ctx->sbufs->h_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t), hipHostMallocDefault));
@@ -195,7 +197,7 @@ static int stream_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants)
     int rc = stream_bufs_init(ctx);
     if (rc) return rc;
     StreamBufs &sb = *ctx->sbufs;
-    rc = grow_pair(ctx, &sb.h_fast, &sb.d_fast, &sb.fast_words, (size_t)(n_regions + 64 * AVK_FAST_CLASSES) * AVK_FAST_WORDS);
+    rc = grow_pair(ctx, &sb.h_fast, &sb.d_fast, &sb.fast_words, (size_t)(n_regions + 64 * AVK_FAST_CLASSES) * 20); /* a genome's mix needs about 14 words per region; grows when a batch needs more */
     if (!rc) rc = grow_pair(ctx, &sb.h_rout, &sb.d_rout, &sb.rout_words, (size_t)n_regions * 4);
     if (!rc) rc = grow_pair(ctx, &sb.h_vout, &sb.d_vout, &sb.vout_words, (size_t)n_variants + 1);
     if (!rc) rc = grow_pair(ctx, &sb.h_defer, &sb.d_defer, &sb.defer_words, (size_t)n_regions + 64);
@@ -236,7 +238,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             sc.v_off[r + 1] = tc + qc; /* turned into the prefix sum below */
             const uint32_t c = b->contig_idx ? b->contig_idx[r] : 0;
             const uint64_t start = b->start[r], end = b->end[r];
-            if (tc > 2 || qc > 2 || tc + qc == 0 || c >= n_contigs || start > end || end > ctx->contig_len[c] || end - start > 255) continue;
+            if (tc > AVK_FAST_MAXV || qc > AVK_FAST_MAXV || tc + qc == 0 || c >= n_contigs || start > end || end > ctx->contig_len[c] || end - start > 255) continue;
             bool ok = true;
             uint64_t ed_sum = 0, grow[2] = {0, 0};
             for (int side = 0; side < 2 && ok; ++side) {
@@ -283,12 +285,12 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     for (uint64_t r = 0; r < n; ++r) sc.v_off[r + 1] += sc.v_off[r];
     if (sc.v_off[n] > 0x7FFFFFFFull) return 100;
     { /* a class too small for a launch of its own (plan_work_order's rule, option lane_min_regions) joins the general part */
-        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16};
+        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2};
         bool drop[AVK_FAST_CLASSES], any = false;
         for (int cl = 0; cl < AVK_FAST_CLASSES; ++cl) {
             uint64_t c = 0;
             for (unsigned t = 0; t < nt; ++t) c += have[(size_t)t * 8 * AVK_FAST_CLASSES + cl];
-            drop[cl] = c > 0 && c < (uint64_t)ctx->lane_min_regions * scale[cl];
+            drop[cl] = c > 0 && (c < (uint64_t)ctx->lane_min_regions * scale[cl] || (int64_t)AVK_FAST_CLASS[cl].maxv > ctx->lane_max_calls);
             any = any || drop[cl];
         }
         if (any)
@@ -454,16 +456,17 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
                 const uint32_t tc = b->t_cnt[r], qc = b->q_cnt[r];
                 const uint64_t start = b->start[r];
                 const uint64_t ref_off = ctx->contig_base[b->contig_idx ? b->contig_idx[r] : 0] + start;
-                uint32_t slot_pos[4] = {0, 0, 0, 0};
-                for (int s = 0; s < 4; ++s) {
-                    const bool on = s < 2 ? (uint32_t)s < tc : (uint32_t)(s - 2) < qc;
-                    if ((uint32_t)(s & 1) >= maxv) continue; /* the class's records have no such slot */
-                    uint32_t *V = T + (AVK_FAST_HDR + 4 * (s < 2 ? (uint32_t)s : maxv + (uint32_t)(s - 2))) * 64;
+                uint32_t slot_pos[2 * AVK_FAST_MAXV] = {0};
+                for (uint32_t s = 0; s < 2 * AVK_FAST_MAXV; ++s) { /* s = side * AVK_FAST_MAXV + the call's index on its side */
+                    const uint32_t side = s / AVK_FAST_MAXV, j = s % AVK_FAST_MAXV;
+                    if (j >= maxv) continue; /* the class's records have no such slot */
+                    const bool on = j < (side ? qc : tc);
+                    uint32_t *V = T + (AVK_FAST_HDR + 4 * (side * maxv + j)) * 64;
                     if (!on) {
                         V[0] = V[64] = V[128] = V[192] = 0;
                         continue;
                     }
-                    const uint64_t v = (s < 2 ? b->t_off[r] + s : b->q_off[r] + (s - 2));
+                    const uint64_t v = (side ? b->q_off[r] : b->t_off[r]) + j;
                     const uint32_t l0 = b->a0_len[v], l1 = b->a1_len[v];
                     const uint32_t raw = b->var_raw_space ? b->var_raw_space[v] : (l0 > l1 ? l0 : l1);
                     const uint8_t *a1 = b->allele_bytes + b->a1_off[v];
@@ -473,11 +476,13 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
                     V[128] = avk::pack_bases_2bit(a1, l1);
                     V[192] = l1 > 16 ? avk::pack_bases_2bit(a1 + 16, l1 - 16) : 0u;
                 }
-                /* order_variants (query_optimizer.rs:372-381): stable merge by position, truth first on ties */
+                /* order_variants (query_optimizer.rs:372-381): stable merge by position, truth first on ties; bit d = depth d takes a query call */
                 uint32_t ord = 0, i = 0, j = 0, d = 0;
                 while (i < tc || j < qc) {
-                    const bool take_t = j >= qc || (i < tc && slot_pos[i] <= slot_pos[2 + j]);
-                    ord |= (take_t ? i++ : 2u + j++) << (2 * d++);
+                    const bool take_t = j >= qc || (i < tc && slot_pos[i] <= slot_pos[AVK_FAST_MAXV + j]);
+                    if (take_t) i++;
+                    else j++, ord |= 1u << d;
+                    d++;
                 }
                 T[0] = (uint32_t)(ref_off >> 4);
                 T[64] = (uint32_t)(ref_off & 15u) | ((uint32_t)(b->end[r] - start) << 4) | (tc << 12) | (qc << 14) | (ord << 16);
@@ -521,7 +526,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     f.tally = sb.d_partials;
     f.overflow_list = sb.d_defer;
     f.overflow_count = sb.d_counters + 1024;
-    bool side_used = false;
+    bool side_used = false, side3_used = false;
     for (int cl = AVK_FAST_CLASSES - 1; cl >= 0 && herr == hipSuccess; --cl) {
         if (!n_tiles[cl]) continue;
         const AvkFastClass &fcl = AVK_FAST_CLASS[cl];
@@ -535,25 +540,35 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         la.ed_max = fcl.ed_max;
         la.qcap = fcl.qcap;
         la.gen_base = (uint32_t)(class_lo[cl] - n_general);
-        const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + 3 * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + 4;
-        const size_t lds = (size_t)rows * 256 + 288 * 4;
-        uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
-        if (per_cu > 12) per_cu = 12;
-        uint32_t grid = (uint32_t)ctx->n_cus * per_cu;
-        if (grid > la.n_tiles) grid = la.n_tiles;
-        const bool side = fcl.maxv > 1;
-        if (side && !side_used) {
-            herr = hipStreamWaitEvent(ctx->lane_stream, sb.ev_copied, 0);
+        la.lanes_log2 = lane_width_log2(ctx, fcl.maxv);
+        la.max_nodes = fcl.maxv > 2 ? (uint32_t)ctx->lane_node_cap : 250u;
+        uint32_t grid = 0;
+        const size_t lds = lane_launch_geometry(ctx, la, &grid);
+        if (!lds) {
+            herr = hipErrorInvalidValue;
+            break;
+        }
+        hipStream_t ls = fcl.maxv == 1 ? sb.copy_stream : (fcl.maxv == 2 ? ctx->lane_stream : ctx->lane_stream3); /* side by side, as in run_internal */
+        if (fcl.maxv == 2 && !side_used) {
+            herr = hipStreamWaitEvent(ls, sb.ev_copied, 0);
             side_used = true;
         }
+        if (fcl.maxv == 3 && !side3_used) {
+            herr = hipStreamWaitEvent(ls, sb.ev_copied, 0);
+            side3_used = true;
+        }
         if (herr == hipSuccess) {
-            hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, side ? ctx->lane_stream : sb.copy_stream, f, la);
+            hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, ls, f, la);
             herr = hipGetLastError();
         }
     }
     if (herr == hipSuccess && side_used) {
         herr = hipEventRecord(sb.ev_lane_done, ctx->lane_stream);
         if (herr == hipSuccess) herr = hipStreamWaitEvent(sb.copy_stream, sb.ev_lane_done, 0);
+    }
+    if (herr == hipSuccess && side3_used) {
+        herr = hipEventRecord(sb.ev_lane_done3, ctx->lane_stream3);
+        if (herr == hipSuccess) herr = hipStreamWaitEvent(sb.copy_stream, sb.ev_lane_done3, 0);
     }
     /* the handed-back list first (it decides the second call, which starts beside the download of the lane results) */
     if (herr == hipSuccess) herr = hipMemcpyAsync(sb.h_defer, sb.d_counters + 1024, sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);

@@ -183,15 +183,23 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
  *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid",
  *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2),
- *                    "order_guard" (the bulk launch waits for the side streams to reach their launches, for callers that queue
- *                    avk_compare_resident calls back to back without synchronising: 1 always, 0 never, 2 = default: for batches of
- *                    262,144 regions or more), "timing_events" (0 = no event records for
+ *                    "order_guard" (the bulk launch waits for the side streams to reach their launches: 1 always, 2 for batches of
+ *                    262,144 regions or more, 0 = default: never), "timing_events" (0 = no event records for
  *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
- *                    "lane_kernel" (1, default: regions with at most two calls per side, a short window and a small edit-distance
+ *   lane kernel      "lane_kernel" (1, default: regions with at most three calls per side, a short window and a small edit-distance
  *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
  *                    are identical either way), "lane_min_regions" (8192: a class of the lane kernel gets a launch of its own only
- *                    when the batch holds that many of its regions — x16 for the two-call classes —, smaller classes stay with
- *                    the wave-per-region kernels; 0 = always)
+ *                    when the batch holds that many of its regions — x16 for the two-call classes, x2 for the three-call class —,
+ *                    smaller classes stay with the wave-per-region kernels; 0 = always), "lane_max_calls" (3: classes with more
+ *                    calls per side than this stay with the wave-per-region kernels), "lane_node_cap" (64: search nodes the
+ *                    three-call class makes before it hands a region to a wave-per-region launch that runs right behind it),
+ *                    "lane_width_one" / "lane_width_two" / "lane_width_three" (64, 64, 16: records a wave takes at a time in the
+ *                    one- / two- / three-call classes; fewer = smaller LDS slice per wave and less waiting for the slowest record),
+ *                    "lane_waves_per_cu" (12: cap on the one-wave workgroups of a lane launch per CU)
+ *                    The launches of one call run on six HIP streams side by side; the HIP runtime gives a process 4 hardware queues
+ *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=8 unless the
+ *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
+ *                    earlier should export the variable itself (whole-genome step: 7.3 ms with 8 queues, 10.2 ms with 4).
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"

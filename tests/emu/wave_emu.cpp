@@ -157,6 +157,8 @@ namespace {
 
 int g_lane_kernel = 1; /* emu_set_lane_kernel: small regions through the lane-per-region code (avk_lane.inl), as run_internal does */
 uint64_t g_lane_solved = 0;
+uint32_t g_lane_width_log2[3] = {6, 6, 4};
+uint32_t g_lane_node_cap = 64; /* emu_set_lane_width: records a wave takes at a time in the one-call / two-call classes */
 
 struct LaneTask {
     const AvkKernelArgs *args;
@@ -221,7 +223,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint32_t> rout(n * 4 + 4, 0), vout(nv + 1, 0);
     std::vector<uint32_t> gm(out->group_metrics ? n * AVK_N_GROUPS * AVK_N_FIELDS : 0);
     std::vector<uint64_t> partials((size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES, 0), tally(AVK_TALLY_STRIDE, 0);
-    std::vector<uint32_t> lists[3] = {std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1)};
+    std::vector<uint32_t> lists[4] = {std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1), std::vector<uint32_t>(n + 1)};
     std::vector<uint32_t> counters_v(1280, 0);
     uint32_t *counters = counters_v.data();
 
@@ -352,7 +354,8 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
     const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
-                                                    getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u);
+                                                    getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
+                                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */);
     const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     a.regions = sorted.data();
     /* the lane-per-region launches of run_internal (aardvark_amd/csrc/avk_host.hip): fast segments first, leftovers to the list the
@@ -382,7 +385,12 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             la.ed_max = cl.ed_max;
             la.qcap = cl.qcap;
             la.gen_base = plan.fast_base[fc];
-            const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, 16);
+            la.lanes_log2 = g_lane_width_log2[cl.maxv - 1];
+            la.max_nodes = cl.maxv > 2 ? g_lane_node_cap : 250u;
+            AvkKernelArgs f3 = f; /* run_internal: the three-call class hands back to a list of its own, solved by an HBM-tier launch right behind it */
+            f3.overflow_list = lists[3].data();
+            f3.overflow_count = counters + 1104;
+            const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap);
             std::atomic<uint32_t> next(0);
             const uint32_t waves = n_waves ? n_waves : 1;
             const int nthr = threads < 1 ? 1 : threads;
@@ -392,13 +400,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 w.stack_bytes = 256 * 1024;
                 std::vector<char> stacks(64 * w.stack_bytes + 64);
                 w.stacks = stacks.data();
-                std::vector<uint32_t> lds((size_t)rows * 64 + 64, 0xA5A5A5A5u), tl(288, 0);
+                std::vector<uint32_t> lds(((size_t)rows << la.lanes_log2) + 64, 0xA5A5A5A5u), tl(288, 0);
                 uint64_t *sm = sums.data() + (size_t)tid * AVK_TALLY_STRIDE;
                 for (;;) {
                     const uint32_t wid = next.fetch_add(1);
                     if (wid >= waves) break;
                     LaneTask t;
-                    t.args = &f;
+                    t.args = cl.maxv > 2 ? &f3 : &f;
                     t.la = &la;
                     t.wave_id = wid;
                     t.lds = lds.data();
@@ -417,6 +425,30 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             for (auto &t : ts) t.join();
             for (int i = 0; i < nthr; ++i)
                 for (int k = 0; k < AVK_TALLY_STRIDE; ++k) partials[k] += sums[(size_t)i * AVK_TALLY_STRIDE + k];
+            if (cl.maxv > 2 && counters[1104]) { /* run_internal: the HBM-tier launch behind the three-call class */
+                AvkKernelArgs keep = a;
+                a.pass_tier = 2;
+                a.work_list = lists[3].data();
+                a.n_work_dev = counters + 1104;
+                a.work_base = 0;
+                a.n_work = 0;
+                a.work_counter = counters + 1120;
+                a.static_pct = 0;
+                a.n_shards = 1;
+                a.claim = 1;
+                a.esc_bytes = 0;
+                a.esc_enabled = 0;
+                a.high_priority = 0;
+                a.extra_counter = nullptr;
+                a.extra_n = 0;
+                a.overflow_list = nullptr;
+                a.overflow_count = nullptr;
+                a.big_ws = big_slots ? big_slices.data() : nullptr;
+                a.big_busy = counters + 1088;
+                a.big_slots = big_slots;
+                run_pass(n_waves ? n_waves : 1, ws_bytes, 0);
+                a = keep;
+            }
         }
     }
     const uint32_t *list = nullptr, *count = nullptr;
@@ -636,6 +668,11 @@ void emu_lane_stats(uint64_t *out, int reset) {
 }
 #endif
 uint64_t emu_last_lane_solved(void) { return g_lane_solved; }
+void emu_set_lane_node_cap(int cap) { g_lane_node_cap = (uint32_t)cap; }
+void emu_set_lane_width(int one, int two) {
+    g_lane_width_log2[0] = one <= 16 ? 4 : (one <= 32 ? 5 : 6);
+    g_lane_width_log2[1] = two <= 16 ? 4 : (two <= 32 ? 5 : 6);
+}
 
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,

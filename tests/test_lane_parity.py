@@ -77,3 +77,19 @@ def test_merge_pairs_on_lanes(oracle):
     st_e, ex_e = emu_lib.optimize_pairs(batch, contigs, threads=THREADS)
     assert np.array_equal(st_o, st_e) and np.array_equal(ex_o, ex_e)
     assert ex_o.sum() > 20
+
+
+@pytest.mark.parametrize("one,two", [(32, 32), (16, 16), (64, 16)])
+def test_narrow_tiles(oracle, one, two):
+    """a wave that takes 32 or 16 records of a tile at a time (options lane_width_one / lane_width_two) gives what 64-wide tiles give"""
+    lib = emu_lib.load()
+    lib.emu_set_lane_width(one, two)
+    try:
+        for seed, kw in ((201, {}), (202, {"repeat_unit": b"CA", "related": 0.9}), (203, {"max_len": 16, "span": (20, 190)})):
+            contigs, batch = scenarios.fuzz_regions(seed, 700, max_vars=2, **kw)
+            want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
+            got = emu_lib.compare_batch(batch, contigs, threads=THREADS, lane_kernel=True, n_waves=8)
+            assert got.diff(want) == []
+            assert got.lane_solved >= 0.1 * batch.n_regions
+    finally:
+        lib.emu_set_lane_width(64, 64)
