@@ -252,6 +252,7 @@ struct avk_ctx {
                                         classes): a launch lasts at least as long as its slowest tile, which a small class cannot amortise */
     int64_t lane_width_one = 64, lane_width_two = 64, lane_width_three = 16; /* records a wave takes at a time (64, 32, 16) in the one- / two- / three-call classes */
     int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
+    int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_node_cap = 64;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
@@ -552,6 +553,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_max_calls") {
         if (value < 1 || value > AVK_FAST_MAXV) return fail(ctx, AVK_E_ARG, "lane_max_calls must be 1..%d", AVK_FAST_MAXV);
         ctx->lane_max_calls = value;
+    } else if (n == "lane_max_est") {
+        if (value < 0 || value > 15) return fail(ctx, AVK_E_ARG, "lane_max_est must be 0..15");
+        ctx->lane_max_est = value;
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
@@ -676,7 +680,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     }
     db->seq_total = seq_total;
     std::string err;
-    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err);
+    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est);
     if (rc) {
         delete db;
         return fail(ctx, rc, "%s", err.c_str());

@@ -41,6 +41,8 @@ typedef uint64_t u64;
 #ifdef AVK_LANE_STATS
 extern uint64_t g_lane_stats[32];
 extern int g_lane_phase;
+extern uint32_t *g_lane_work; /* per region (caller order): a weighted count of what its lane did (tools/lane_stats.py) */
+static inline uint64_t lane_work_now() { return 30 * g_lane_stats[0] + 60 * g_lane_stats[1] + 150 * g_lane_stats[2] + 100 * g_lane_stats[3] + 300 * g_lane_stats[6] + 600 * g_lane_stats[5]; }
 #define AVK_LSTAT(k, n) g_lane_stats[k] += (n)
 #define AVK_LPHASE(k) g_lane_phase = (k)
 #define AVK_LDEFER(k) (g_lane_stats[8 + (k)] += 1, g_lane_stats[16 + g_lane_phase] += ((k) == 0), (int)LS_DEFER)
@@ -1130,7 +1132,13 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #ifdef AVK_LANE_PHASE_TIMING
             c.tlast = avk_clock();
 #endif
+#ifdef AVK_LANE_STATS
+            const uint64_t work0 = lane_work_now();
+#endif
             const int st = solve_lane(a, c, rec, 64u, out, wg_tally);
+#ifdef AVK_LANE_STATS
+            if (g_lane_work) g_lane_work[orig] = (uint32_t)(lane_work_now() - work0);
+#endif
             if (st == AVK_ST_OK) {
                 AVK_LT_MARK(c, 5)
             }

@@ -37,6 +37,54 @@ template <class T> struct NoInitAlloc : std::allocator<T> {
 };
 template <class T> using PodVec = std::vector<T, NoInitAlloc<T>>;
 
+/* What a lane will spend on a region, as far as the host can tell without solving it: a tile of 64 lanes takes as long as its slowest
+ * region, so the records of a lane class are sorted by this key and a tile holds regions of one cost.  Almost all of the time beyond
+ * the common case goes into edits (a wavefront alignment costs the square of its distance): calls without an identical call on the other
+ * side (the edits of a missed or extra call, twice for a homozygous one), identical calls with different genotypes, and — the metrics
+ * phase — a side whose calls have different types (its per-type alignments see the side's longest allele difference).  Measured on the
+ * whole-genome workload with the emulator's work counters: sum over tiles of the slowest lane / mean lane = 2.9 (one call per side),
+ * 5.4 (two), 8.2 (three) when sorted by call count only, 1.2 / 2.8 / 4.1 with this key.
+ * Layout: estimated edits (capped at 15) << 4 | calls above the class's minimum (capped at 3) << 2 | calls that are not homozygous (capped at 3);
+ * larger = more expensive. */
+struct FastCall {
+    uint32_t pos, a0, a1, alt_ed, type, zyg;
+    const uint8_t *alt;
+};
+inline uint8_t fast_cost_key(const FastCall *t, uint32_t tc, const FastCall *q, uint32_t qc) {
+    uint32_t est = 0, used = 0, nhet = 0;
+    auto copies = [](uint32_t z) { return z == AVK_ZYG_HOM_ALT ? 2u : 1u; };
+    for (uint32_t i = 0; i < tc; ++i) {
+        int m = -1;
+        for (uint32_t j = 0; j < qc && m < 0; ++j)
+            if (!((used >> j) & 1u) && t[i].pos == q[j].pos && t[i].a0 == q[j].a0 && t[i].a1 == q[j].a1 && memcmp(t[i].alt, q[j].alt, t[i].a1) == 0) m = (int)j;
+        if (m < 0) est += t[i].alt_ed * copies(t[i].zyg);
+        else {
+            used |= 1u << m;
+            const uint32_t a = copies(t[i].zyg), b = copies(q[m].zyg);
+            est += t[i].alt_ed * (a > b ? a - b : b - a);
+        }
+        nhet += t[i].zyg != AVK_ZYG_HOM_ALT;
+    }
+    for (uint32_t j = 0; j < qc; ++j) {
+        if (!((used >> j) & 1u)) est += q[j].alt_ed * copies(q[j].zyg);
+        nhet += q[j].zyg != AVK_ZYG_HOM_ALT;
+    }
+    for (int side = 0; side < 2; ++side) {
+        const FastCall *c = side ? q : t;
+        const uint32_t n = side ? qc : tc;
+        bool mixed = false;
+        uint32_t longest = 0;
+        for (uint32_t i = 0; i < n; ++i) {
+            mixed = mixed || c[i].type != c[0].type;
+            longest = c[i].alt_ed > longest ? c[i].alt_ed : longest;
+        }
+        if (mixed && longest > 2) est += longest - 2;
+    }
+    const uint32_t n_all = tc + qc, lo = tc > qc ? tc : qc; /* the class's fewest calls: one side full */
+    const uint32_t extra = n_all - lo;
+    return (uint8_t)(((est > 15 ? 15u : est) << 4) | ((extra > 3 ? 3u : extra) << 2) | (nhet > 3 ? 3u : nhet));
+}
+
 struct PackedBatch {
     PodVec<AvkDevRegion> regions;
     PodVec<uint32_t> blob;          /* what the device reads: one blob per region (AvkBlobVar in avk_dev_types.h) */
@@ -46,6 +94,7 @@ struct PackedBatch {
     std::vector<uint8_t> zyg_flags; /* per region: bit 0 an Unknown zygosity, bit 1 a HomozygousReference one */
     std::vector<int64_t> delta_t, delta_q; /* variant_delta_length per side (merge_solver.rs:211-223) */
     std::vector<uint8_t> fast_class;       /* per region: 0, or 1 + index into AVK_FAST_CLASS (eligible for the lane-per-region kernel) */
+    std::vector<uint8_t> fast_key;         /* per region of a fast class: fast_cost_key (tiles hold regions of one cost) */
     uint64_t seq_total = 0;
 };
 
@@ -120,7 +169,7 @@ inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *
  * (prefix sums), then the regions are validated and their blobs written by `threads` workers (regions are
  * independent once the offsets are known). */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
-                      const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0) {
+                      const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0, uint32_t lane_max_est = 15) {
     const uint64_t n = b->n_regions;
     if (n > 0x7FFFFFFFull || b->n_variants > 0x7FFFFFFFull) {
         *err = "batch too large (more than 2^31 regions or variants); split it";
@@ -131,6 +180,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
     out->delta_t.assign(n, 0);
     out->delta_q.assign(n, 0);
     out->fast_class.assign(n, 0);
+    out->fast_key.assign(n, 0);
     /* the same cut of the regions into ranges for both passes */
     int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
     if (nt > 16) nt = 16;
@@ -350,6 +400,15 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                     const AvkFastClass &fc = AVK_FAST_CLASS[cl];
                     if (tc <= fc.maxv && qc <= fc.maxv && (uint64_t)dr.len + dr.grow <= 16ull * fc.W) {
                         out->fast_class[r] = (uint8_t)(cl + 1);
+                        FastCall fcv[2 * AVK_FAST_MAXV];
+                        for (uint32_t i = 0; i < N; ++i)
+                            fcv[i] = FastCall{bv[i].rel_pos, bv[i].a0_len, bv[i].a1_len, bv[i].alt_ed, bv[i].type_zyg & 0xFFu, (bv[i].type_zyg >> 8) & 0xFFu, ba + bv[i].a_off + bv[i].a0_len};
+                        out->fast_key[r] = fast_cost_key(fcv, tc, fcv + tc, qc);
+                        if ((uint32_t)(out->fast_key[r] >> 4) > lane_max_est) out->fast_class[r] = 0; /* many edits: a whole wavefront's work (option lane_max_est) */
+                        /* The three-call class keeps the caller's order: its expensive regions are large searches, which the key does not
+                         * see, and lanes that diverge do not run side by side — 16 expensive regions in one tile take 16 times as long as
+                         * one, and the launch lasts as long as that tile (measured: 3.1 ms in caller order, 6.2 ms sorted). */
+                        if (fc.maxv > 2) out->fast_key[r] = 0;
                         break;
                     }
                 }
@@ -460,15 +519,13 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
             plan.n_hard += 1;
         }
     }
-    /* counting sort by class, then by variant count, descending */
-    std::vector<uint64_t> cnt((3 + AVK_FAST_CLASSES) * 33 + 1, 0);
+    /* counting sort by class, then by variant count (lane classes: by fast_cost_key), descending */
+    std::vector<uint64_t> cnt((3 + AVK_FAST_CLASSES) * 256 + 1, 0);
     auto key = [&](uint64_t r) {
         uint32_t k = pb.regions[r].t_cnt + pb.regions[r].q_cnt;
-        if (cls[r] >= 3) { /* a tile of 64 lanes should hold regions of one cost: calls, then edit-distance bound */
-            const uint32_t e = pb.regions[r].ed_bound;
-            k = k * 6 + (e > 5 ? 5 : e);
-        }
-        return 33u * cls[r] + (32u - (k > 32u ? 32u : k));
+        k = k > 255u ? 255u : k;
+        if (cls[r] >= 3) k = pb.fast_key[r]; /* a tile of 64 lanes should hold regions of one cost */
+        return 256u * cls[r] + (255u - k);
     };
     for (uint64_t r = 0; r < n; ++r) cnt[key(r) + 1] += 1;
     for (size_t k = 1; k < cnt.size(); ++k) cnt[k] += cnt[k - 1];

@@ -241,6 +241,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             if (tc > AVK_FAST_MAXV || qc > AVK_FAST_MAXV || tc + qc == 0 || c >= n_contigs || start > end || end > ctx->contig_len[c] || end - start > 255) continue;
             bool ok = true;
             uint64_t ed_sum = 0, grow[2] = {0, 0};
+            avk::FastCall calls[2][AVK_FAST_MAXV];
             for (int side = 0; side < 2 && ok; ++side) {
                 const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
                 const uint32_t cnt = side == 0 ? tc : qc;
@@ -264,6 +265,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
                     const uint64_t ed = avk::host_edit_distance(a0, l0, a1, l1);
                     ok = ok && ed <= 255;
                     sc.alt_ed[v] = (uint8_t)ed;
+                    calls[side][i] = avk::FastCall{(uint32_t)(pos - start), l0, l1, (uint32_t)ed, b->var_type[v], zy, a1};
                     ed_sum += ed;
                     if (l1 > l0) grow[side] += l1 - l0;
                 }
@@ -275,8 +277,13 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
                 if (tc <= fc.maxv && qc <= fc.maxv && L + g <= 16ull * fc.W) {
                     sc.cls[r] = (uint8_t)(cl + 1);
                     mine[cl] += 1;
-                    const uint32_t k = (tc + qc) * 6 + (uint32_t)(ed_sum > 5 ? 5 : ed_sum);
-                    sc.key[r] = (uint8_t)(32u - (k > 32u ? 32u : k));
+                    const uint8_t ck = avk::fast_cost_key(calls[0], tc, calls[1], qc);
+                    if ((int64_t)(ck >> 4) > ctx->lane_max_est) {
+                        sc.cls[r] = 0; /* many edits: a whole wavefront's work */
+                        mine[cl] -= 1;
+                        break;
+                    }
+                    sc.key[r] = fc.maxv > 2 ? (uint8_t)255 : (uint8_t)(255u - ck); /* ascending = most expensive first; the three-call class keeps the caller's order (avk_pack.h) */
                     break;
                 }
             }
@@ -301,12 +308,12 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     }
     const uint64_t nv_dev = sc.v_off[n];
     /* counting sort, stable, on the host threads: per class, by key (most expensive first); every thread owns a contiguous range of regions */
-    enum { NB = (AVK_FAST_CLASSES + 1) * 33 };
+    enum { KEYS = 256, NB = (AVK_FAST_CLASSES + 1) * KEYS };
     const unsigned st = nt > 1 && n >= 16384 ? nt : 1;
     std::vector<uint64_t> hist((size_t)st * NB, 0);
     avk_parallel_for(n, st, [&](unsigned t, uint64_t lo, uint64_t hi) {
         uint64_t *h = hist.data() + (size_t)t * NB;
-        for (uint64_t r = lo; r < hi; ++r) h[(uint32_t)sc.cls[r] * 33 + sc.key[r]] += 1;
+        for (uint64_t r = lo; r < hi; ++r) h[(uint32_t)sc.cls[r] * KEYS + sc.key[r]] += 1;
     });
     uint64_t cnt[NB + 1];
     {
@@ -321,13 +328,13 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         }
         cnt[NB] = run;
     }
-    const uint64_t n_general = cnt[33];
+    const uint64_t n_general = cnt[KEYS];
     uint64_t class_lo[AVK_FAST_CLASSES + 1];
-    for (int cl = 0; cl <= AVK_FAST_CLASSES; ++cl) class_lo[cl] = cnt[(uint32_t)(cl + 1) * 33]; /* start of cls == cl + 1 */
+    for (int cl = 0; cl <= AVK_FAST_CLASSES; ++cl) class_lo[cl] = cnt[(uint32_t)(cl + 1) * KEYS]; /* start of cls == cl + 1 */
     std::vector<uint32_t> order(n); /* [general | class 0 | class 1 | ..] */
     avk_parallel_for(n, st, [&](unsigned t, uint64_t lo, uint64_t hi) {
         uint64_t *at = hist.data() + (size_t)t * NB;
-        for (uint64_t r = lo; r < hi; ++r) order[at[(uint32_t)sc.cls[r] * 33 + sc.key[r]]++] = (uint32_t)r;
+        for (uint64_t r = lo; r < hi; ++r) order[at[(uint32_t)sc.cls[r] * KEYS + sc.key[r]]++] = (uint32_t)r;
     });
     const uint64_t n_fast = n - n_general;
     if (n_fast < 16384) return 100;

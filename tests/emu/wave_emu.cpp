@@ -148,7 +148,7 @@ static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
 #include "../../aardvark_amd/csrc/avk_pack.h"
 #include "../../aardvark_amd/csrc/avk_solver.inl"
 #ifdef AVK_LANE_STATS
-namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; } }
+namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; uint32_t *g_lane_work; } }
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
 #include "../../aardvark_amd/csrc/avk_dwfa_script.inl"
@@ -660,6 +660,7 @@ int emu_dwfa_script_batch(int engine, uint32_t n_scripts, const uint8_t *bytes, 
 
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 #ifdef AVK_LANE_STATS
+void emu_lane_work(uint32_t *per_region) { avk::lane::g_lane_work = per_region; }
 void emu_lane_stats(uint64_t *out, int reset) {
     for (int i = 0; i < 32; ++i) {
         out[i] = avk::lane::g_lane_stats[i];
