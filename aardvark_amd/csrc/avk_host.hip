@@ -253,6 +253,7 @@ struct avk_ctx {
     int64_t lane_width_one = 64, lane_width_two = 64, lane_width_three = 16; /* records a wave takes at a time (64, 32, 16) in the one- / two- / three-call classes */
     int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
+    int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_node_cap = 64;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
@@ -556,6 +557,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_max_est") {
         if (value < 0 || value > 15) return fail(ctx, AVK_E_ARG, "lane_max_est must be 0..15");
         ctx->lane_max_est = value;
+    } else if (n == "lane_head_width") {
+        if (value != 0 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4) return fail(ctx, AVK_E_ARG, "lane_head_width must be 0, 64, 32, 16, 8 or 4");
+        ctx->lane_head_width = value;
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
@@ -785,12 +789,16 @@ static uint32_t lane_width_log2(const avk_ctx *ctx, uint32_t maxv) {
 }
 /* LDS bytes of a one-wave workgroup of the lane kernel (0: does not fit) and the grid that fills the machine: the per-lane arrays of
  * `width` lanes plus a tally of its own; as many workgroups per CU as the LDS and the wave slots hold */
+static uint32_t head_width_log2(const avk_ctx *ctx) {
+    const int64_t w = ctx->lane_head_width;
+    return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
+}
 static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs &la, uint32_t *grid) {
     const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + 3 * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + (la.nm == 2 ? 4 : 8); /* lane_rows */
     const size_t lds = (size_t)rows * (4u << la.lanes_log2) + 288 * 4;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     if (per_cu < 1) return 0;
-    const uint32_t cap = (uint32_t)(ctx->lane_waves_per_cu > 0 ? ctx->lane_waves_per_cu : 12);
+    const uint32_t cap = la.lanes_log2 < 4 ? 32u : (uint32_t)(ctx->lane_waves_per_cu > 0 ? ctx->lane_waves_per_cu : 12); /* very narrow tiles: every wave slot */
     if (per_cu > cap) per_cu = cap;
     const uint32_t claims = la.n_tiles * (64u >> la.lanes_log2);
     uint32_t g = (uint32_t)ctx->n_cus * per_cu;
@@ -1123,6 +1131,24 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(eb), dim3(256), 0, lstream[li], e);
                         AVK_HIP(ctx, hipGetLastError());
                         continue;
+                    }
+                    /* The head of the class — the tiles of regions with estimated edits, which the cost key puts first — in narrow tiles
+                     * of its own: lanes that diverge take turns, so 64 expensive regions in one wave take 64 turns; 16 per wave, four times as
+                     * many waves.  Same records, same stream, a launch ahead of the rest of the class. */
+                    const uint32_t head_tiles = ctx->lane_head_width ? (db->plan.n_fast_heavy[fc] + 63u) / 64u : 0u;
+                    if (head_tiles > 0 && head_tiles < la.n_tiles && (uint32_t)ctx->lane_head_width < (1u << la.lanes_log2)) {
+                        avk::lane::LaneArgs hd = la;
+                        hd.n_tiles = head_tiles;
+                        hd.tile_counter = db->d_counters + 1230 + fc;
+                        hd.lanes_log2 = head_width_log2(ctx);
+                        uint32_t hgrid = 0;
+                        const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
+                        hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, lstream[li], f, hd);
+                        AVK_HIP(ctx, hipGetLastError());
+                        la.recs += (size_t)head_tiles * la.rec_words * 64u;
+                        la.n_tiles -= head_tiles;
+                        la.gen_base += head_tiles * 64u;
+                        if (grid > la.n_tiles) grid = la.n_tiles;
                     }
                     hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f, la);
                     AVK_HIP(ctx, hipGetLastError());

@@ -463,6 +463,7 @@ struct WorkPlan {
     /* the regions of the lane-per-region kernel's classes close the work order, largest class first:
      * [class C | class B | bulk | fast class AVK_FAST_CLASSES - 1 | .. | fast class 0] */
     uint32_t n_fast[AVK_FAST_CLASSES] = {0};
+    uint32_t n_fast_heavy[AVK_FAST_CLASSES] = {0}; /* of those, regions with estimated edits (fast_cost_key >> 4 != 0): they lead the class's records */
     uint32_t fast_base[AVK_FAST_CLASSES] = {0}; /* first record of the class in the work order */
     uint32_t n_fast_total = 0;
 };
@@ -507,6 +508,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
             const uint32_t fc = pb.fast_class[r] - 1u;
             cls[r] = (uint8_t)(3 + (AVK_FAST_CLASSES - 1 - fc));
             plan.n_fast[fc] += 1;
+            plan.n_fast_heavy[fc] += (pb.fast_key[r] >> 4) != 0;
             continue;
         }
         if ((dr.pre_status & 0xFFFFu) || N == 0 || solo_min_variants == 0) continue;

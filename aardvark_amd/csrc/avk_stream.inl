@@ -331,6 +331,8 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     const uint64_t n_general = cnt[KEYS];
     uint64_t class_lo[AVK_FAST_CLASSES + 1];
     for (int cl = 0; cl <= AVK_FAST_CLASSES; ++cl) class_lo[cl] = cnt[(uint32_t)(cl + 1) * KEYS]; /* start of cls == cl + 1 */
+    uint64_t n_heavy[AVK_FAST_CLASSES]; /* regions with estimated edits (cost key >> 4 != 0, i.e. sort key below 240): the head of the class */
+    for (int cl = 0; cl < AVK_FAST_CLASSES; ++cl) n_heavy[cl] = cnt[(uint32_t)(cl + 1) * KEYS + 240] - cnt[(uint32_t)(cl + 1) * KEYS];
     std::vector<uint32_t> order(n); /* [general | class 0 | class 1 | ..] */
     avk_parallel_for(n, st, [&](unsigned t, uint64_t lo, uint64_t hi) {
         uint64_t *at = hist.data() + (size_t)t * NB;
@@ -563,6 +565,21 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         if (fcl.maxv == 3 && !side3_used) {
             herr = hipStreamWaitEvent(ls, sb.ev_copied, 0);
             side3_used = true;
+        }
+        const uint32_t head_tiles = ctx->lane_head_width ? (uint32_t)((n_heavy[cl] + 63u) / 64u) : 0u; /* as in run_internal */
+        if (herr == hipSuccess && head_tiles > 0 && head_tiles < la.n_tiles && (uint32_t)ctx->lane_head_width < (1u << la.lanes_log2)) {
+            avk::lane::LaneArgs hd = la;
+            hd.n_tiles = head_tiles;
+            hd.tile_counter = sb.d_counters + 1230 + cl;
+            hd.lanes_log2 = head_width_log2(ctx);
+            uint32_t hgrid = 0;
+            const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
+            hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, ls, f, hd);
+            herr = hipGetLastError();
+            la.recs += (size_t)head_tiles * la.rec_words * 64u;
+            la.n_tiles -= head_tiles;
+            la.gen_base += head_tiles * 64u;
+            if (grid > la.n_tiles) grid = la.n_tiles;
         }
         if (herr == hipSuccess) {
             hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, ls, f, la);

@@ -195,7 +195,11 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    three-call class makes before it hands a region to a wave-per-region launch that runs right behind it),
  *                    "lane_width_one" / "lane_width_two" / "lane_width_three" (64, 64, 16: records a wave takes at a time in the
  *                    one- / two- / three-call classes; fewer = smaller LDS slice per wave and less waiting for the slowest record),
- *                    "lane_waves_per_cu" (12: cap on the one-wave workgroups of a lane launch per CU)
+ *                    "lane_waves_per_cu" (12: cap on the one-wave workgroups of a lane launch per CU), "lane_head_width" (16: the
+ *                    records of a class are sorted by a host-side cost estimate, avk_pack.h fast_cost_key; the tiles of regions with
+ *                    estimated edits — the head of the class — get a launch of their own with this many records per wave, because
+ *                    lanes that diverge take turns; 0 = no head launch), "lane_max_est" (15: regions whose estimated edits exceed
+ *                    this stay with the wave-per-region kernels)
  *                    The launches of one call run on six HIP streams side by side; the HIP runtime gives a process 4 hardware queues
  *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=8 unless the
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP

@@ -158,7 +158,8 @@ namespace {
 int g_lane_kernel = 1; /* emu_set_lane_kernel: small regions through the lane-per-region code (avk_lane.inl), as run_internal does */
 uint64_t g_lane_solved = 0;
 uint32_t g_lane_width_log2[3] = {6, 6, 4};
-uint32_t g_lane_node_cap = 64; /* emu_set_lane_width: records a wave takes at a time in the one-call / two-call classes */
+uint32_t g_lane_node_cap = 64;
+uint32_t g_lane_head_width = 16; /* run_internal's option lane_head_width */ /* emu_set_lane_width: records a wave takes at a time in the one-call / two-call classes */
 
 struct LaneTask {
     const AvkKernelArgs *args;
@@ -390,41 +391,56 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             AvkKernelArgs f3 = f; /* run_internal: the three-call class hands back to a list of its own, solved by an HBM-tier launch right behind it */
             f3.overflow_list = lists[3].data();
             f3.overflow_count = counters + 1104;
-            const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap);
-            std::atomic<uint32_t> next(0);
-            const uint32_t waves = n_waves ? n_waves : 1;
-            const int nthr = threads < 1 ? 1 : threads;
-            std::vector<uint64_t> sums((size_t)nthr * AVK_TALLY_STRIDE, 0);
-            auto worker = [&](int tid) {
-                avk_emu::Wave w;
-                w.stack_bytes = 256 * 1024;
-                std::vector<char> stacks(64 * w.stack_bytes + 64);
-                w.stacks = stacks.data();
-                std::vector<uint32_t> lds(((size_t)rows << la.lanes_log2) + 64, 0xA5A5A5A5u), tl(288, 0);
-                uint64_t *sm = sums.data() + (size_t)tid * AVK_TALLY_STRIDE;
-                for (;;) {
-                    const uint32_t wid = next.fetch_add(1);
-                    if (wid >= waves) break;
-                    LaneTask t;
-                    t.args = cl.maxv > 2 ? &f3 : &f;
-                    t.la = &la;
-                    t.wave_id = wid;
-                    t.lds = lds.data();
-                    t.tally = tl.data();
-                    avk_emu::run_wave(&w, lane_kernel_main, &t);
-                    for (int l = 0; l < 64; ++l) {
-                        sm[AVK_TALLY_SOLVED] += t.n_ok[l];
-                        sm[AVK_TALLY_ERRORS] += t.n_err[l];
-                        sm[AVK_TALLY_LANE_SOLVED] += t.n_ok[l] + t.n_err[l];
+            auto launch = [&](const avk::lane::LaneArgs &la) {
+                const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap);
+                std::atomic<uint32_t> next(0);
+                const uint32_t waves = n_waves ? n_waves : 1;
+                const int nthr = threads < 1 ? 1 : threads;
+                std::vector<uint64_t> sums((size_t)nthr * AVK_TALLY_STRIDE, 0);
+                auto worker = [&](int tid) {
+                    avk_emu::Wave w;
+                    w.stack_bytes = 256 * 1024;
+                    std::vector<char> stacks(64 * w.stack_bytes + 64);
+                    w.stacks = stacks.data();
+                    std::vector<uint32_t> lds(((size_t)rows << la.lanes_log2) + 64, 0xA5A5A5A5u), tl(288, 0);
+                    uint64_t *sm = sums.data() + (size_t)tid * AVK_TALLY_STRIDE;
+                    for (;;) {
+                        const uint32_t wid = next.fetch_add(1);
+                        if (wid >= waves) break;
+                        LaneTask t;
+                        t.args = cl.maxv > 2 ? &f3 : &f;
+                        t.la = &la;
+                        t.wave_id = wid;
+                        t.lds = lds.data();
+                        t.tally = tl.data();
+                        avk_emu::run_wave(&w, lane_kernel_main, &t);
+                        for (int l = 0; l < 64; ++l) {
+                            sm[AVK_TALLY_SOLVED] += t.n_ok[l];
+                            sm[AVK_TALLY_ERRORS] += t.n_err[l];
+                            sm[AVK_TALLY_LANE_SOLVED] += t.n_ok[l] + t.n_err[l];
+                        }
                     }
-                }
-                for (int i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) sm[i] += tl[i];
+                    for (int i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) sm[i] += tl[i];
+                };
+                std::vector<std::thread> ts;
+                for (int i = 0; i < nthr; ++i) ts.emplace_back(worker, i);
+                for (auto &t : ts) t.join();
+                for (int i = 0; i < nthr; ++i)
+                    for (int k = 0; k < AVK_TALLY_STRIDE; ++k) partials[k] += sums[(size_t)i * AVK_TALLY_STRIDE + k];
             };
-            std::vector<std::thread> ts;
-            for (int i = 0; i < nthr; ++i) ts.emplace_back(worker, i);
-            for (auto &t : ts) t.join();
-            for (int i = 0; i < nthr; ++i)
-                for (int k = 0; k < AVK_TALLY_STRIDE; ++k) partials[k] += sums[(size_t)i * AVK_TALLY_STRIDE + k];
+            /* run_internal: the head of the class (regions with estimated edits) in narrow tiles of its own, ahead of the rest */
+            const uint32_t head_tiles = g_lane_head_width ? (plan.n_fast_heavy[fc] + 63u) / 64u : 0u;
+            if (head_tiles > 0 && head_tiles < la.n_tiles && g_lane_head_width < (1u << la.lanes_log2)) {
+                avk::lane::LaneArgs hd = la;
+                hd.n_tiles = head_tiles;
+                hd.tile_counter = counters + 1230 + fc;
+                hd.lanes_log2 = g_lane_head_width <= 4 ? 2u : (g_lane_head_width <= 8 ? 3u : (g_lane_head_width <= 16 ? 4u : 5u));
+                launch(hd);
+                la.recs += (size_t)head_tiles * la.rec_words * 64u;
+                la.n_tiles -= head_tiles;
+                la.gen_base += head_tiles * 64u;
+            }
+            launch(la);
             if (cl.maxv > 2 && counters[1104]) { /* run_internal: the HBM-tier launch behind the three-call class */
                 AvkKernelArgs keep = a;
                 a.pass_tier = 2;
@@ -670,6 +686,7 @@ void emu_lane_stats(uint64_t *out, int reset) {
 #endif
 uint64_t emu_last_lane_solved(void) { return g_lane_solved; }
 void emu_set_lane_node_cap(int cap) { g_lane_node_cap = (uint32_t)cap; }
+void emu_set_lane_head_width(int w) { g_lane_head_width = (uint32_t)w; }
 void emu_set_lane_width(int one, int two) {
     g_lane_width_log2[0] = one <= 16 ? 4 : (one <= 32 ? 5 : 6);
     g_lane_width_log2[1] = two <= 16 ? 4 : (two <= 32 ? 5 : 6);
