@@ -254,6 +254,9 @@ struct avk_ctx {
     int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
+    int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
+    int64_t lane_head_stream = 0;                     /* 1: the heads of the two-call classes on a stream of their own (a synchronised step: 5.4 -> 5.1 ms;
+                                                         steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_node_cap = 64;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
@@ -274,6 +277,8 @@ struct avk_ctx {
     hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_lane_join2 = nullptr, ev_lane_ready = nullptr, ev_lane_ready2 = nullptr;
     hipStream_t lane_stream3 = nullptr; /* the three-call class: long tiles, few of them, beside everything else */
     hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
+    hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
+    hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -414,6 +419,9 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_lane_join3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_ready4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
@@ -460,6 +468,9 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_join3) (void)hipEventDestroy(ctx->ev_lane_join3);
     if (ctx->ev_lane_ready3) (void)hipEventDestroy(ctx->ev_lane_ready3);
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
+    if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
+    if (ctx->ev_lane_ready4) (void)hipEventDestroy(ctx->ev_lane_ready4);
+    if (ctx->lane_stream4) (void)hipStreamDestroy(ctx->lane_stream4);
     if (ctx->lane_stream3) (void)hipStreamDestroy(ctx->lane_stream3);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
@@ -560,6 +571,11 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_head_width") {
         if (value != 0 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4) return fail(ctx, AVK_E_ARG, "lane_head_width must be 0, 64, 32, 16, 8 or 4");
         ctx->lane_head_width = value;
+    } else if (n == "lane_metrics_ed_cap") {
+        if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
+        ctx->lane_metrics_ed_cap = value;
+    } else if (n == "lane_head_stream") {
+        ctx->lane_head_stream = value ? 1 : 0;
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
@@ -1058,11 +1074,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             /* ---- the lane-per-region launches (avk_lane.inl): the classes with two calls per side (long, latency-bound tiles at low
              * occupancy) on a stream of their own, the one-call classes on the caller's stream ahead of the bulk.  What a lane cannot
              * finish goes to the DEFERRED list, solved after the bulk by an LDS launch of the wave-per-region kernel. */
-            /* lane streams: 0 the two-call classes, 1 the one-call classes, 2 the three-call class */
-            hipStream_t lstream[3] = {ctx->lane_stream, ctx->lane_stream2, ctx->lane_stream3};
-            hipEvent_t lready[3] = {ctx->ev_lane_ready, ctx->ev_lane_ready2, ctx->ev_lane_ready3};
-            hipEvent_t ljoin[3] = {ctx->ev_lane_join, ctx->ev_lane_join2, ctx->ev_lane_join3};
-            bool lused[3] = {false, false, false};
+            /* lane streams: 0 the two-call classes, 1 the one-call classes, 2 the three-call class, 3 the heads of the two-call classes */
+            enum { N_LS = 4 };
+            hipStream_t lstream[N_LS] = {ctx->lane_stream, ctx->lane_stream2, ctx->lane_stream3, ctx->lane_stream4};
+            hipEvent_t lready[N_LS] = {ctx->ev_lane_ready, ctx->ev_lane_ready2, ctx->ev_lane_ready3, ctx->ev_lane_ready4};
+            hipEvent_t ljoin[N_LS] = {ctx->ev_lane_join, ctx->ev_lane_join2, ctx->ev_lane_join3, ctx->ev_lane_join4};
+            bool lused[N_LS] = {false, false, false, false};
             if (use_fast) {
                 if (!ctx->lane_attr_set) {
                     AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1087,6 +1104,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     la.gen_base = db->plan.fast_base[fc];
                     la.lanes_log2 = lane_width_log2(ctx, cl.maxv);
                     la.max_nodes = cl.maxv > 2 ? (uint32_t)ctx->lane_node_cap : 250u;
+                    la.max_ed_c = (uint32_t)ctx->lane_metrics_ed_cap;
                     uint32_t grid = 0;
                     const size_t lds = lane_launch_geometry(ctx, la, &grid);
                     if (!lds) return fail(ctx, AVK_E_ARG, "lane kernel class %d does not fit the LDS", fc);
@@ -1143,7 +1161,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         hd.lanes_log2 = head_width_log2(ctx);
                         uint32_t hgrid = 0;
                         const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
-                        hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, lstream[li], f, hd);
+                        const int hi = (cl.maxv == 2 && ctx->lane_head_stream) ? 3 : li; /* a long head runs beside the rest of its class */
+                        if (!lused[hi]) {
+                            AVK_HIP(ctx, hipStreamWaitEvent(lstream[hi], ctx->ev_lane_fork, 0));
+                            if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[hi], lstream[hi]));
+                            lused[hi] = true;
+                        }
+                        hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, lstream[hi], f, hd);
                         AVK_HIP(ctx, hipGetLastError());
                         la.recs += (size_t)head_tiles * la.rec_words * 64u;
                         la.n_tiles -= head_tiles;
@@ -1153,7 +1177,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f, la);
                     AVK_HIP(ctx, hipGetLastError());
                 }
-                for (int li = 0; li < 3; ++li) {
+                for (int li = 0; li < N_LS; ++li) {
                     if (!lused[li]) continue;
                     if (order_guard) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, lready[li], 0)); /* the bulk must not take the machine before the lane launches are in their queues */
                     AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
@@ -1181,7 +1205,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AVK_HIP(ctx, hipGetLastError());
                 const int di = lused[1] ? 1 : (lused[0] ? 0 : 2);
                 hipStream_t ds = lstream[di];
-                for (int li = 0; li < 3; ++li)
+                for (int li = 0; li < N_LS; ++li)
                     if (li != di && lused[li]) AVK_HIP(ctx, hipStreamWaitEvent(ds, ljoin[li], 0));
                 AvkKernelArgs d = a;
                 d.work_list = lists[2];

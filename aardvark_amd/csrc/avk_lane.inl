@@ -732,6 +732,7 @@ struct LaneArgs { /* what a launch of the lane kernel needs besides AvkKernelArg
     u32 *tile_counter;
     u32 W, nm, ed_max, qcap; /* the class of this launch */
     u32 gen_base;        /* record index (work order of the wave-per-region kernels) of fast record 0 */
+    u32 max_ed_c;        /* largest distance a lane follows in the alignments of the metrics phase (beyond: handed over); 0 = what the rows hold */
     u32 max_nodes;       /* phase A gives up (hands the region over) beyond this many search nodes: at most 250 (ids are 8 bits) */
     u32 lanes_log2;      /* 6, 5 or 4: a wave takes 64, 32 or 16 records of a tile at a time on its first lanes (smaller LDS slice per wave, more
                             waves per CU, less waiting for the slowest record) */
@@ -1092,6 +1093,7 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     c.wfcap = 2 * la.ed_max + 2;
     c.off_q = c.off_wf + 3 * c.wfr;
     c.wfcap_c = 4 * (3 * c.wfr + la.qcap);
+    if (la.max_ed_c && 2 * la.max_ed_c + 3 < c.wfcap_c) c.wfcap_c = 2 * la.max_ed_c + 3;
     c.qcap = la.qcap;
     c.off_opt = c.off_q + la.qcap;
     c.optcap = lane_optcap(la.nm);

@@ -551,6 +551,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         la.gen_base = (uint32_t)(class_lo[cl] - n_general);
         la.lanes_log2 = lane_width_log2(ctx, fcl.maxv);
         la.max_nodes = fcl.maxv > 2 ? (uint32_t)ctx->lane_node_cap : 250u;
+        la.max_ed_c = (uint32_t)ctx->lane_metrics_ed_cap;
         uint32_t grid = 0;
         const size_t lds = lane_launch_geometry(ctx, la, &grid);
         if (!lds) {

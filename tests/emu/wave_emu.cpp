@@ -388,6 +388,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             la.gen_base = plan.fast_base[fc];
             la.lanes_log2 = g_lane_width_log2[cl.maxv - 1];
             la.max_nodes = cl.maxv > 2 ? g_lane_node_cap : 250u;
+            la.max_ed_c = 0;
             AvkKernelArgs f3 = f; /* run_internal: the three-call class hands back to a list of its own, solved by an HBM-tier launch right behind it */
             f3.overflow_list = lists[3].data();
             f3.overflow_count = counters + 1104;
