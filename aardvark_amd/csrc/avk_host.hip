@@ -278,7 +278,7 @@ struct avk_ctx {
     hipStream_t lane_stream3 = nullptr; /* the three-call class: long tiles, few of them, beside everything else */
     hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
-    hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr;
+    hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -422,6 +422,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_early, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
@@ -470,6 +471,7 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
     if (ctx->ev_lane_ready4) (void)hipEventDestroy(ctx->ev_lane_ready4);
+    if (ctx->ev_lane_early) (void)hipEventDestroy(ctx->ev_lane_early);
     if (ctx->lane_stream4) (void)hipStreamDestroy(ctx->lane_stream4);
     if (ctx->lane_stream3) (void)hipStreamDestroy(ctx->lane_stream3);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -948,7 +950,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
-    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false;
+    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -1079,7 +1081,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             hipStream_t lstream[N_LS] = {ctx->lane_stream, ctx->lane_stream2, ctx->lane_stream3, ctx->lane_stream4};
             hipEvent_t lready[N_LS] = {ctx->ev_lane_ready, ctx->ev_lane_ready2, ctx->ev_lane_ready3, ctx->ev_lane_ready4};
             hipEvent_t ljoin[N_LS] = {ctx->ev_lane_join, ctx->ev_lane_join2, ctx->ev_lane_join3, ctx->ev_lane_join4};
-            bool lused[N_LS] = {false, false, false, false};
+            bool lused[N_LS] = {false, false, false, false}, ljoined[N_LS] = {false, false, false, false}, early_used = false;
             if (use_fast) {
                 if (!ctx->lane_attr_set) {
                     AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
@@ -1123,6 +1125,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         f3.overflow_count = db->d_counters + 1104;
                         hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f3, la);
                         AVK_HIP(ctx, hipGetLastError());
+                        /* the launch for what ALL lanes hand back waits for the lane launches only, not for the launch behind this class */
+                        AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
+                        ljoined[li] = true;
                         AvkKernelArgs e = a;
                         e.pass_tier = 2;
                         e.work_list = lists[3];
@@ -1148,6 +1153,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         e.n_waves = eb * waves_per_block;
                         hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(eb), dim3(256), 0, lstream[li], e);
                         AVK_HIP(ctx, hipGetLastError());
+                        AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, lstream[li])); /* the caller's stream waits for this one at the end */
+                        early_used = true;
                         continue;
                     }
                     /* The head of the class — the tiles of regions with estimated edits, which the cost key puts first — in narrow tiles
@@ -1180,7 +1187,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 for (int li = 0; li < N_LS; ++li) {
                     if (!lused[li]) continue;
                     if (order_guard) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, lready[li], 0)); /* the bulk must not take the machine before the lane launches are in their queues */
-                    AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
+                    if (!ljoined[li]) AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
                 }
                 if (lused[1] && timed) { /* end of the one-call classes' launches */
                     AVK_HIP(ctx, hipEventRecord(ctx->ev_lane, ctx->lane_stream2));
@@ -1221,6 +1228,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_done, ds)); /* everything of the lane streams is behind this record */
                 deferred_pending = true;
+                early_pending = early_used;
             }
             a.tier[0].ws_bytes = slice0;
         } else if (t == 1) { /* one workgroup per CU, four large slices */
@@ -1261,6 +1269,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
     if (deferred_pending) { /* the lane streams (lane launches, then the handed-back regions) join here; what even the escalation could not hold */
         AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_done, 0));
+        if (early_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_early, 0));
         AvkKernelArgs h = a;
         h.pass_tier = 2;
         h.work_list = lists[1];
