@@ -562,7 +562,7 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_regions must not be negative");
         ctx->lane_min_regions = value;
     } else if (n == "lane_width_one" || n == "lane_width_two" || n == "lane_width_three") {
-        if (value != 64 && value != 32 && value != 16) return fail(ctx, AVK_E_ARG, "%s must be 64, 32 or 16", name);
+        if (value != 64 && value != 32 && value != 16 && value != 8 && value != 4) return fail(ctx, AVK_E_ARG, "%s must be 64, 32, 16, 8 or 4", name);
         (n == "lane_width_one" ? ctx->lane_width_one : (n == "lane_width_two" ? ctx->lane_width_two : ctx->lane_width_three)) = value;
     } else if (n == "lane_max_calls") {
         if (value < 1 || value > AVK_FAST_MAXV) return fail(ctx, AVK_E_ARG, "lane_max_calls must be 1..%d", AVK_FAST_MAXV);
@@ -803,7 +803,7 @@ void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
 /* tile width of a lane launch (options lane_width_one / lane_width_two: 64, 32 or 16 records per wave at a time) */
 static uint32_t lane_width_log2(const avk_ctx *ctx, uint32_t maxv) {
     const int64_t w = maxv > 2 ? ctx->lane_width_three : (maxv > 1 ? ctx->lane_width_two : ctx->lane_width_one);
-    return w <= 16 ? 4u : (w <= 32 ? 5u : 6u);
+    return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
 }
 /* LDS bytes of a one-wave workgroup of the lane kernel (0: does not fit) and the grid that fills the machine: the per-lane arrays of
  * `width` lanes plus a tally of its own; as many workgroups per CU as the LDS and the wave slots hold */
