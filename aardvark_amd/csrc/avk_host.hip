@@ -257,6 +257,7 @@ struct avk_ctx {
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
     int64_t lane_head_stream = 0;                     /* 1: the heads of the two-call classes on a stream of their own (a synchronised step: 5.4 -> 5.1 ms;
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
+    int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
     int64_t lane_node_cap = 64;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
@@ -578,6 +579,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->lane_metrics_ed_cap = value;
     } else if (n == "lane_head_stream") {
         ctx->lane_head_stream = value ? 1 : 0;
+    } else if (n == "lane_min_batch") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_batch must not be negative");
+        ctx->lane_min_batch = value;
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
@@ -749,7 +753,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
-                                    ctx->lane_kernel ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls);
+                                    ctx->lane_kernel ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls, (uint64_t)ctx->lane_min_batch);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */

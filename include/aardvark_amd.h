@@ -190,7 +190,10 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
  *                    are identical either way), "lane_min_regions" (8192: a class of the lane kernel gets a launch of its own only
  *                    when the batch holds that many of its regions — x16 for the two-call classes, x2 for the three-call class —,
- *                    smaller classes stay with the wave-per-region kernels; 0 = always), "lane_max_calls" (3: classes with more
+ *                    smaller classes stay with the wave-per-region kernels; 0 = always), "lane_min_batch" (65536: a resident batch with fewer
+ *                    lane regions in all is solved by the wave-per-region kernels alone — a chr20-sized step is 0.37 ms that way, 0.41
+ *                    with lane launches; the one-shot path of avk_compare_batch, whose packing is the cheaper one, keeps its lanes),
+ *                    "lane_max_calls" (3: classes with more
  *                    calls per side than this stay with the wave-per-region kernels), "lane_node_cap" (64: search nodes the
  *                    three-call class makes before it hands a region to a wave-per-region launch that runs right behind it),
  *                    "lane_width_one" / "lane_width_two" / "lane_width_three" (64, 64, 16: records a wave takes at a time in the
