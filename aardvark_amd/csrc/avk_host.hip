@@ -258,7 +258,9 @@ struct avk_ctx {
     int64_t lane_head_stream = 0;                     /* 1: the heads of the two-call classes on a stream of their own (a synchronised step: 5.4 -> 5.1 ms;
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
-    int64_t lane_node_cap = 64;                       /* search nodes the three-call lane class makes before it hands a region over */
+    int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
+    int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
+    int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
     uint64_t last_lane_solved = 0;
@@ -582,6 +584,12 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_min_batch") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_batch must not be negative");
         ctx->lane_min_batch = value;
+    } else if (n == "hbm_early_blocks") {
+        if (value < 1 || value > 768) return fail(ctx, AVK_E_ARG, "hbm_early_blocks must be 1..768");
+        ctx->hbm_early_blocks = value;
+    } else if (n == "hbm_solo_blocks") {
+        if (value < 1 || value > 768) return fail(ctx, AVK_E_ARG, "hbm_solo_blocks must be 1..768");
+        ctx->hbm_solo_blocks = value;
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
@@ -873,8 +881,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (hbm_blocks > blocks) hbm_blocks = blocks;
     const uint32_t n_waves = hbm_blocks * waves_per_block;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
-    const uint32_t hbm_solo_max = 128;
-    const uint32_t hbm_early_max = 64; /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
+    const uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128);
+    const uint32_t hbm_early_max = (uint32_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64); /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
     const size_t ws_need = (size_t)(n_waves + (hbm_solo_max + hbm_early_max) * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
     const auto t_ws = std::chrono::steady_clock::now();
     const bool ws_grows = ws_need > ctx->ws_alloc;

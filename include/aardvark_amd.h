@@ -194,10 +194,11 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    lane regions in all is solved by the wave-per-region kernels alone — a chr20-sized step is 0.37 ms that way, 0.41
  *                    with lane launches; the one-shot path of avk_compare_batch, whose packing is the cheaper one, keeps its lanes),
  *                    "lane_max_calls" (3: classes with more
- *                    calls per side than this stay with the wave-per-region kernels), "lane_node_cap" (64: search nodes the
+ *                    calls per side than this stay with the wave-per-region kernels), "lane_node_cap" (32: search nodes the
  *                    three-call class makes before it hands a region to a wave-per-region launch that runs right behind it),
  *                    "lane_width_one" / "lane_width_two" / "lane_width_three" (64, 64, 16: records a wave takes at a time in the
  *                    one- / two- / three-call classes; fewer = smaller LDS slice per wave and less waiting for the slowest record),
+ *                    "hbm_early_blocks" (256: workgroups of that launch), "hbm_solo_blocks" (128: most workgroups of the HBM solo launch),
  *                    "lane_waves_per_cu" (12: cap on the one-wave workgroups of a lane launch per CU), "lane_head_width" (16: the
  *                    records of a class are sorted by a host-side cost estimate, avk_pack.h fast_cost_key; the tiles of regions with
  *                    estimated edits — the head of the class — get a launch of their own with this many records per wave, because

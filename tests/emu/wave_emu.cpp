@@ -158,7 +158,7 @@ namespace {
 int g_lane_kernel = 1; /* emu_set_lane_kernel: small regions through the lane-per-region code (avk_lane.inl), as run_internal does */
 uint64_t g_lane_solved = 0;
 uint32_t g_lane_width_log2[3] = {6, 6, 4};
-uint32_t g_lane_node_cap = 64;
+uint32_t g_lane_node_cap = 32;
 uint32_t g_lane_head_width = 16; /* run_internal's option lane_head_width */ /* emu_set_lane_width: records a wave takes at a time in the one-call / two-call classes */
 
 struct LaneTask {
