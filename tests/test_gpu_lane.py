@@ -120,3 +120,33 @@ def test_one_shot_path_equals_resident_path(ctxs, oracle):
     on.compare_resident(rb, CompareConfig(enable_sequences=False))
     assert on.download(rb, group_metrics=False).diff(want) == []
     rb.free()
+
+
+@pytest.mark.parametrize("opts", [
+    dict(lane_width_one=32, lane_width_two=16, lane_width_three=8, lane_head_width=4, lane_waves_per_cu=24),
+    dict(lane_head_width=0, lane_node_cap=8, lane_max_est=3, hbm_early_blocks=8),
+    dict(lane_max_calls=2, lane_metrics_ed_cap=8, lane_head_stream=1, lane_head_width=32, order_guard=1),
+    dict(lane_max_calls=1, lane_node_cap=250, lane_max_est=0, hbm_solo_blocks=16),
+])
+def test_scheduling_options_do_not_change_results(oracle, opts):
+    """tile widths, head launches, node budget, edit estimates, stream layout: every combination gives the oracle's outputs, in the
+    resident form (per-region blocks on) and through avk_compare_batch's one-shot path (blocks off)"""
+    import aardvark_amd
+    from aardvark_amd import CompareConfig
+    ctx = aardvark_amd.Context(0)
+    try:
+        ctx.set_option("lane_min_regions", 0)
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        contig, bed, truth, query = synth.contig_calls(0, 24_000_000, 70_000 / 24_000_000, seed_ref=77, seed_query=78, str_frac=0.15, multi_frac=0.05)
+        batch = synth.cluster_regions_v(contig, bed, truth, query, 50)
+        for gm in (True, False):
+            want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=gm)
+            ctx.set_option("emit_group_metrics", 1 if gm else 0)
+            ctx.upload_reference([contig])
+            got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=gm)
+            assert got.diff(want) == []
+            assert ctx.last_lane_solved() > 0.5 * batch.n_regions
+        assert ctx.last_compare_was_one_shot()
+    finally:
+        ctx.close()

@@ -93,3 +93,22 @@ def test_narrow_tiles(oracle, one, two):
             assert got.lane_solved >= 0.1 * batch.n_regions
     finally:
         lib.emu_set_lane_width(64, 64)
+
+
+@pytest.mark.parametrize("head,cap", [(0, 250), (4, 8), (32, 16), (16, 250)])
+def test_head_launch_and_node_budget_do_not_change_results(oracle, head, cap):
+    """the head launch of a class (regions with estimated edits, narrow tiles: option lane_head_width) and the node budget of the
+    three-call class (lane_node_cap: larger searches are handed to an HBM-tier launch behind the class) are scheduling only"""
+    lib = emu_lib.load()
+    lib.emu_set_lane_head_width(head)
+    lib.emu_set_lane_node_cap(cap)
+    try:
+        for seed, kw in ((301, {"max_vars": 3}), (302, {"max_vars": 3, "repeat_unit": b"CA", "related": 0.9}), (303, {"max_vars": 2, "max_len": 16, "span": (20, 190)})):
+            contigs, batch = scenarios.fuzz_regions(seed, 900, **kw)
+            want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
+            got = emu_lib.compare_batch(batch, contigs, threads=THREADS, lane_kernel=True, n_waves=8)
+            assert got.diff(want) == []
+            assert got.lane_solved >= 0.1 * batch.n_regions
+    finally:
+        lib.emu_set_lane_head_width(16)
+        lib.emu_set_lane_node_cap(32)
