@@ -130,7 +130,7 @@ struct StreamBufs {
     uint64_t *d_partials = nullptr, *d_tally = nullptr, *h_tally = nullptr;
     uint32_t *d_counters = nullptr;
     hipStream_t copy_stream = nullptr;
-    hipEvent_t ev_copied = nullptr, ev_lane_done = nullptr, ev_lane_done3 = nullptr;
+    hipEvent_t ev_copied = nullptr, ev_lane_done = nullptr, ev_lane_done2 = nullptr, ev_lane_done3 = nullptr;
 };
 
 void stream_bufs_free(StreamBufs *b) {
@@ -146,6 +146,7 @@ void stream_bufs_free(StreamBufs *b) {
     if (b->ev_copied) (void)hipEventDestroy(b->ev_copied);
     if (b->ev_lane_done) (void)hipEventDestroy(b->ev_lane_done);
     if (b->ev_lane_done3) (void)hipEventDestroy(b->ev_lane_done3);
+    if (b->ev_lane_done2) (void)hipEventDestroy(b->ev_lane_done2);
     if (b->copy_stream) (void)hipStreamDestroy(b->copy_stream);
     delete b;
 }
@@ -181,6 +182,7 @@ static int stream_bufs_init(avk_ctx *ctx) {
     AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_copied, hipEventDisableTiming));
     AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done, hipEventDisableTiming));
     AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done3, hipEventDisableTiming));
+    AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->sbufs->ev_lane_done2, hipEventDisableTiming));
     AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_partials, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t)));
     AVK_HIP(ctx, hipMalloc((void **)&ctx->sbufs->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t)));
     AVK_HIP(ctx, hipHostMalloc((void **)&ctx->sbufs->h_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t), hipHostMallocDefault));
@@ -345,7 +347,9 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     if (n_fast < 16384) return 100;
     uint32_t tile_base[AVK_FAST_CLASSES], n_tiles[AVK_FAST_CLASSES], tiles = 0;
     uint64_t n_class[AVK_FAST_CLASSES], word_base[AVK_FAST_CLASSES + 1], words = 0;
-    for (int cl = 0; cl < AVK_FAST_CLASSES; ++cl) {
+    /* the classes with the most calls per side come first in the record array: they are written and copied first, and their launches — the
+     * long ones — start while the one-call classes are still being written */
+    for (int cl = AVK_FAST_CLASSES - 1; cl >= 0; --cl) {
         n_class[cl] = class_lo[cl + 1] - class_lo[cl];
         tile_base[cl] = tiles;
         word_base[cl] = words;
@@ -505,24 +509,9 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         }
     };
     hipError_t herr = hipSuccess;
-    auto copy_loop = [&] {
-        for (uint32_t ch = 0; ch < n_chunks && herr == hipSuccess; ++ch) {
-            const uint32_t t0 = ch * chunk_tiles, t1 = t0 + chunk_tiles < tiles ? t0 + chunk_tiles : tiles;
-            const uint32_t want = (t1 - t0 + piece - 1) / piece;
-            while (chunk_done[ch].load(std::memory_order_acquire) < want) std::this_thread::sleep_for(std::chrono::microseconds(20));
-            const size_t w0 = (size_t)word_of_tile(t0), w1 = (size_t)word_of_tile(t1);
-            herr = hipMemcpyAsync(sb.d_fast + w0, sb.h_fast + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, sb.copy_stream);
-        }
-    };
-    AvkPool::get().run(nt + 1, [&](unsigned t) { /* this thread queues the copies, the pool writes the records */
-        if (t == 0) copy_loop();
-        else pack_worker();
-    });
-    const auto t_packed = now();
-
-    /* ---- 4. the lane launches: one-call classes on the copy stream, two-call classes beside them */
-    if (herr == hipSuccess) herr = hipEventRecord(sb.ev_copied, sb.copy_stream);
-    if (herr == hipSuccess && !ctx->lane_attr_set) {
+    /* ---- 4. the lane launches, class by class as soon as a class's records are on their way: two-call classes, three-call class and
+     * one-call classes on a lane stream each (as in run_internal), behind an event on the copy stream */
+    if (!ctx->lane_attr_set) {
         herr = hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         ctx->lane_attr_set = herr == hipSuccess;
     }
@@ -538,9 +527,9 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     f.tally = sb.d_partials;
     f.overflow_list = sb.d_defer;
     f.overflow_count = sb.d_counters + 1024;
-    bool side_used = false, side3_used = false;
-    for (int cl = AVK_FAST_CLASSES - 1; cl >= 0 && herr == hipSuccess; --cl) {
-        if (!n_tiles[cl]) continue;
+    bool stream_used[3] = {false, false, false}; /* lane_stream (two calls), lane_stream2 (one call), lane_stream3 (three calls) */
+    auto launch_class = [&](int cl) { /* on the thread that queues the copies; everything of the class has been queued for copying */
+        if (!n_tiles[cl] || herr != hipSuccess) return;
         const AvkFastClass &fcl = AVK_FAST_CLASS[cl];
         avk::lane::LaneArgs la;
         la.recs = sb.d_fast + word_base[cl];
@@ -559,16 +548,15 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         const size_t lds = lane_launch_geometry(ctx, la, &grid);
         if (!lds) {
             herr = hipErrorInvalidValue;
-            break;
+            return;
         }
-        hipStream_t ls = fcl.maxv == 1 ? sb.copy_stream : (fcl.maxv == 2 ? ctx->lane_stream : ctx->lane_stream3); /* side by side, as in run_internal */
-        if (fcl.maxv == 2 && !side_used) {
-            herr = hipStreamWaitEvent(ls, sb.ev_copied, 0);
-            side_used = true;
-        }
-        if (fcl.maxv == 3 && !side3_used) {
-            herr = hipStreamWaitEvent(ls, sb.ev_copied, 0);
-            side3_used = true;
+        const int si = fcl.maxv == 2 ? 0 : (fcl.maxv == 1 ? 1 : 2);
+        hipStream_t ls = si == 0 ? ctx->lane_stream : (si == 1 ? ctx->lane_stream2 : ctx->lane_stream3);
+        if (si == 1 && n_chunks <= 1) ls = sb.copy_stream; /* a small batch: behind its one copy, no event hop (a chr20-sized call is 1.3 ms in all) */
+        else {
+            herr = hipEventRecord(sb.ev_copied, sb.copy_stream); /* the class's last copy is ahead of this record */
+            if (herr == hipSuccess) herr = hipStreamWaitEvent(ls, sb.ev_copied, 0);
+            stream_used[si] = true;
         }
         const uint32_t head_tiles = ctx->lane_head_width ? (uint32_t)((n_heavy[cl] + 63u) / 64u) : 0u; /* as in run_internal */
         if (herr == hipSuccess && head_tiles > 0 && head_tiles < la.n_tiles && (uint32_t)ctx->lane_head_width < (1u << la.lanes_log2)) {
@@ -589,14 +577,32 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, ls, f, la);
             herr = hipGetLastError();
         }
-    }
-    if (herr == hipSuccess && side_used) {
-        herr = hipEventRecord(sb.ev_lane_done, ctx->lane_stream);
-        if (herr == hipSuccess) herr = hipStreamWaitEvent(sb.copy_stream, sb.ev_lane_done, 0);
-    }
-    if (herr == hipSuccess && side3_used) {
-        herr = hipEventRecord(sb.ev_lane_done3, ctx->lane_stream3);
-        if (herr == hipSuccess) herr = hipStreamWaitEvent(sb.copy_stream, sb.ev_lane_done3, 0);
+    };
+    int next_class = AVK_FAST_CLASSES - 1; /* classes are complete in the order of the record array */
+    auto copy_loop = [&] {
+        for (uint32_t ch = 0; ch < n_chunks && herr == hipSuccess; ++ch) {
+            const uint32_t t0 = ch * chunk_tiles, t1 = t0 + chunk_tiles < tiles ? t0 + chunk_tiles : tiles;
+            const uint32_t want = (t1 - t0 + piece - 1) / piece;
+            while (chunk_done[ch].load(std::memory_order_acquire) < want) std::this_thread::sleep_for(std::chrono::microseconds(20));
+            const size_t w0 = (size_t)word_of_tile(t0), w1 = (size_t)word_of_tile(t1);
+            herr = hipMemcpyAsync(sb.d_fast + w0, sb.h_fast + w0, (w1 - w0) * sizeof(uint32_t), hipMemcpyHostToDevice, sb.copy_stream);
+            while (herr == hipSuccess && next_class >= 0 && tile_base[next_class] + n_tiles[next_class] <= t1) launch_class(next_class--);
+        }
+    };
+    AvkPool::get().run(nt + 1, [&](unsigned t) { /* this thread queues the copies and the launches, the pool writes the records */
+        if (t == 0) copy_loop();
+        else pack_worker();
+    });
+    while (herr == hipSuccess && next_class >= 0) launch_class(next_class--);
+    const auto t_packed = now();
+    {
+        hipStream_t lss[3] = {ctx->lane_stream, ctx->lane_stream2, ctx->lane_stream3};
+        hipEvent_t evs[3] = {sb.ev_lane_done, sb.ev_lane_done2, sb.ev_lane_done3};
+        for (int si = 0; si < 3 && herr == hipSuccess; ++si) {
+            if (!stream_used[si]) continue;
+            herr = hipEventRecord(evs[si], lss[si]);
+            if (herr == hipSuccess) herr = hipStreamWaitEvent(sb.copy_stream, evs[si], 0);
+        }
     }
     /* the handed-back list first (it decides the second call, which starts beside the download of the lane results) */
     if (herr == hipSuccess) herr = hipMemcpyAsync(sb.h_defer, sb.d_counters + 1024, sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
