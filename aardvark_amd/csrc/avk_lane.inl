@@ -84,6 +84,12 @@ struct LCtx {
 #ifdef AVK_LANE_PHASE_TIMING
     u64 tph[8], tlast;
 #endif
+#ifdef AVK_LANE_SLOW_TILES
+    mutable u32 n_pops, n_diag, n_words; /* this lane's own loop turns in the current record (lanes share time, not turns) */
+#define AVK_LCOUNT(c, f) (c).f += 1
+#else
+#define AVK_LCOUNT(c, f)
+#endif
     u32 wfcap;   /* entries per wavefront array */
     u32 off_q, qcap;
     u32 off_opt, optcap;
@@ -133,6 +139,7 @@ AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32
     const u32 lim = ra < rb ? ra : rb;
     u32 n = 0;
     while (n < lim) {
+        AVK_LCOUNT(c, n_words);
         AVK_LSTAT(0, 1);
         AVK_LSTAT(24 + g_lane_phase, 1);
         const u32 x = extract16(c, sa, ia + n) ^ extract16(c, sb, ib + n);
@@ -152,9 +159,13 @@ AVK_DEV void wf_set(const LCtx &c, u32 arr, u32 i, u32 v) { *wf_ptr(c, arr, i) =
 
 /* DWFALite on (B = sequence sb of length bl, O = sequence so of length ol); wf[i] = symbols of O consumed on diagonal i,
  * baseline offset = wf[i] + ed - i (dynamic_wfa.rs:114) */
-AVK_DEV void dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) { /* :94-130 */
+/* extend (:94-130): every diagonal as far as it matches.  (A flat loop over (diagonal, word) instead of this nest — lanes that diverge
+ * take turns, a nest costs the slowest lane of every inner loop — was measured: no change on the benchmark genome, whose extensions are
+ * one word long; tools/gpu_slow_tiles.py shows that a slow tile is the sum of sixteen different lanes, not one long one.) */
+AVK_DEV void dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) {
     for (u32 i = 0; i <= 2 * ed; ++i) {
         AVK_LSTAT(1, 1);
+        AVK_LCOUNT(c, n_diag);
         const u32 d = wf_get(c, arr, i);
         const u32 bo = d + ed - i;
         wf_set(c, arr, i, d + match_run(c, sb, bo, bl, so, d, ol));
@@ -440,6 +451,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
         const u32 cost = e >> 24;
         if (cost > best) break; /* :204; pops come in non-decreasing cost order */
         AVK_LSTAT(3, 1);
+        AVK_LCOUNT(c, n_pops);
         AVK_LSTAT(4, (e >> 3) & 1u);
         const u32 depth = e & 7u, code = (e >> 4) & 0xFFFu, id = (e >> 16) & 0xFFu;
         NodeA n;
@@ -1124,6 +1136,9 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
         const u32 rl = (t & (parts - 1u)) * width + lane; /* this lane's record in the tile */
         t >>= 6u - la.lanes_log2;
         if (lane >= width) continue; /* the other lanes only take part in the wave's claims and flushes */
+#ifdef AVK_LANE_SLOW_TILES
+        c.n_pops = c.n_diag = c.n_words = 0;
+#endif
         const u32 *rec = la.recs + (u64)t * la.rec_words * 64u + rl;
         const u32 h1 = rec[64];
         if (h1 != 0xFFFFFFFFu) { /* a lane of the class's last tile may have no region */
@@ -1175,7 +1190,18 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
             }
         }
 #ifdef AVK_LANE_PHASE_TIMING
-        c.tph[6] += avk_clock() - t_tile0;
+        {
+            const u64 dt_tile = avk_clock() - t_tile0;
+            c.tph[6] += dt_tile;
+#ifdef AVK_LANE_SLOW_TILES
+            if (la.lanes_log2 < 6) { /* profiling: how long every narrow tile took (its first lane says), and which lanes did the most turns */
+                if (lane == 0) printf("tile nm %u claim %u ticks %llu\n", la.nm, t * parts + (rl >> la.lanes_log2), (unsigned long long)dt_tile);
+                if (c.n_diag > (u32)AVK_LANE_SLOW_TILES || c.n_pops > 60)
+                    printf("busylane nm %u claim %u lane %u orig %u pops %u diagonals %u words %u\n", la.nm, t * parts + (rl >> la.lanes_log2), lane,
+                           la.recs[((u64)t * la.rec_words + 3) * 64u + rl], c.n_pops, c.n_diag, c.n_words);
+            }
+#endif
+        }
 #endif
     }
 #ifdef AVK_LANE_PHASE_TIMING
