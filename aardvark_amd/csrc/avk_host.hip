@@ -1774,13 +1774,27 @@ int avk_label_tallies(avk_ctx *ctx, avk_dev_batch *db, uint32_t n_labels, const 
 int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32_t max_branch_factor, int32_t *status, uint8_t *is_exact_match) {
     if (!ctx || !batch || !status || !is_exact_match) return AVK_E_ARG;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
-    avk_dev_batch *db = nullptr;
-    int rc = upload_internal(ctx, batch, true, &db);
-    if (rc) return rc;
     avk_compare_config cfg;
     cfg.max_branch_factor = max_branch_factor;
     cfg.enable_sequences = 0;
     cfg.enable_exact_shortcut = 0;
+    { /* a large batch: the one-shot path of avk_stream.inl, as avk_compare_batch (a whole-genome merge asks for one such batch per pair of inputs) */
+        std::vector<uint32_t> exact(batch->n_regions + 1);
+        avk_result_batch ro;
+        memset(&ro, 0, sizeof(ro));
+        ro.status = status;
+        ro.ed_h1 = exact.data();
+        const int rs = compare_batch_stream(ctx, batch, &cfg, &ro, 1);
+        ctx->last_one_shot = rs == 0;
+        if (rs == 0) {
+            for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && exact[r] ? 1 : 0;
+            return 0;
+        }
+        if (rs != 100) return rs;
+    }
+    avk_dev_batch *db = nullptr;
+    int rc = upload_internal(ctx, batch, true, &db);
+    if (rc) return rc;
     const int64_t keep = ctx->emit_group_metrics;
     ctx->emit_group_metrics = 0;
     rc = run_internal(ctx, db, &cfg, nullptr, 1);

@@ -207,7 +207,8 @@ static int stream_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants)
 }
 
 /* the one-shot path proper; returns AVK_E_STATE + 100 when the batch is not for it (the caller then takes the resident path) */
-static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const avk_compare_config *cfg, avk_result_batch *out) {
+/* mode 1 = the merge form (avk_optimize_pairs_batch: search A only; out->status and out->ed_h1, which carries `the pair is an exact match`) */
+static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const avk_compare_config *cfg, avk_result_batch *out, uint32_t mode = 0) {
     const uint64_t n = b->n_regions, nv = b->n_variants;
     if (!ctx->lane_kernel || cfg->enable_sequences || cfg->enable_exact_shortcut || cfg->max_branch_factor == 0 || (out->group_metrics && ctx->emit_group_metrics) ||
         n < 32768 || n > 0x7FFFFFFFull || nv > 0x7FFFFFFFull || !ctx->d_ref2b || !ctx->use_packed_reference || ctx->lds_bytes_per_wave == 0 ||
@@ -393,6 +394,14 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     };
     auto fetch_gathered = [&](avk_dev_batch *db, uint64_t m, Gathered &g) -> int {
         g.st.resize(m + 1), g.e1.resize(m + 1), g.e2.resize(m + 1), g.no.resize(m + 1), g.tp.resize(m + 1), g.tl.assign(AVK_TALLY_LEN, 0);
+        if (mode == 1) { /* the pair form has per-region records only (as avk_optimize_pairs_batch reads them) */
+            std::vector<uint32_t> rout(m * 4 + 4);
+            hipError_t e = hipMemcpyAsync(rout.data(), db->d_region_out, m * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e != hipSuccess) return fail(ctx, AVK_E_HIP, "pairs download failed: %s", hipGetErrorString(e));
+            for (uint64_t k = 0; k < m; ++k) g.st[k] = (int32_t)rout[4 * k], g.e1[k] = rout[4 * k + 1], g.e2[k] = 0, g.no[k] = 0, g.tp[k] = 0;
+            return 0;
+        }
         avk_result_batch o;
         memset(&o, 0, sizeof(o));
         o.status = g.st.data(), o.ed_h1 = g.e1.data(), o.ed_h2 = g.e2.data(), o.n_optima = g.no.data(), o.type_present = g.tp.data(), o.tally = g.tl.data();
@@ -419,8 +428,8 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
         gather(order.data(), n_general);
         general_thread = std::thread([&] {
             (void)hipSetDevice(ctx->device);
-            rc_general = upload_internal(ctx, &G, false, &dbG);
-            if (!rc_general) rc_general = run_internal(ctx, dbG, cfg, nullptr, 0);
+            rc_general = upload_internal(ctx, &G, mode == 1, &dbG);
+            if (!rc_general) rc_general = run_internal(ctx, dbG, cfg, nullptr, mode);
             if (!rc_general) rc_general = fetch_gathered(dbG, n_general, resG); /* waits for the general kernels on this thread */
             if (dbG) avk_batch_free(ctx, dbG);
             dbG = nullptr;
@@ -522,6 +531,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     f.ref_exc = ctx->d_refexc;
     f.n_regions = (uint32_t)n;
     f.max_branch_factor = cfg->max_branch_factor;
+    f.mode = mode;
     f.region_out = sb.d_rout;
     f.var_out = sb.d_vout;
     f.tally = sb.d_partials;
@@ -629,8 +639,8 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             avk_dev_batch *dbD = nullptr;
             const int64_t keep_lane = ctx->lane_kernel;
             ctx->lane_kernel = 0;
-            rc_tail = upload_internal(ctx, &G, false, &dbD);
-            if (!rc_tail) rc_tail = run_internal(ctx, dbD, cfg, nullptr, 0);
+            rc_tail = upload_internal(ctx, &G, mode == 1, &dbD);
+            if (!rc_tail) rc_tail = run_internal(ctx, dbD, cfg, nullptr, mode);
             ctx->lane_kernel = keep_lane;
             if (!rc_tail) rc_tail = fetch_gathered(dbD, n_defer, resD);
             if (dbD) avk_batch_free(ctx, dbD);
@@ -642,7 +652,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
     }
     if (herr == hipSuccess) herr = hipMemcpyAsync(sb.h_tally, sb.d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t), hipMemcpyDeviceToHost, sb.copy_stream);
     if (herr == hipSuccess) herr = hipMemcpyAsync(sb.h_rout, sb.d_rout, (size_t)n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
-    if (herr == hipSuccess && nv_dev) herr = hipMemcpyAsync(sb.h_vout, sb.d_vout, (size_t)nv_dev * sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
+    if (herr == hipSuccess && nv_dev && mode == 0) herr = hipMemcpyAsync(sb.h_vout, sb.d_vout, (size_t)nv_dev * sizeof(uint32_t), hipMemcpyDeviceToHost, sb.copy_stream);
     if (herr == hipSuccess) herr = hipStreamSynchronize(sb.copy_stream);
     const auto t_lanes = now();
     if (herr != hipSuccess) {
@@ -665,6 +675,7 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             if (out->ed_h2) out->ed_h2[r] = w[2];
             if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
             if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
+            if (mode != 0) continue; /* the pair form has no per-call outputs */
             const uint32_t tc = b->t_cnt[r], qc = b->q_cnt[r];
             const uint32_t *vw = sb.h_vout + sc.v_off[r];
             for (uint32_t k = 0; k < tc + qc; ++k) {

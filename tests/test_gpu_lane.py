@@ -150,3 +150,22 @@ def test_scheduling_options_do_not_change_results(oracle, opts):
         assert ctx.last_compare_was_one_shot()
     finally:
         ctx.close()
+
+
+def test_merge_pairs_one_shot_path(ctxs, oracle):
+    """avk_optimize_pairs_batch on a large batch takes the one-shot path too (mode 1 of avk_stream.inl): status and exact-match flag of every
+    pair equal the oracle's and the resident path's (lane kernel off)"""
+    contig, batch = synth.config_indel_mix_v2(n_truth=int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38)), contig_len=synth.CHR20_LEN)
+    contig = contig.copy()
+    rng = np.random.default_rng(6)
+    contig[rng.integers(0, contig.size, size=contig.size // 5000)] = ord("N")
+    st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, [contig], threads=CPUS)
+    on, off = ctxs
+    for c in ctxs:
+        c.upload_reference([contig])
+        st, ex = c.optimize_pairs(batch)
+        assert np.array_equal(st_o, st) and np.array_equal(ex_o, ex)
+    on.upload_reference([contig])
+    on.optimize_pairs(batch)
+    assert on.last_compare_was_one_shot()
+    assert on.last_lane_solved() > 0.8 * batch.n_regions
