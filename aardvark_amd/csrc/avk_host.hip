@@ -409,6 +409,12 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
      * of a process share queues, and a shared queue would serialise the solo launches with the bulk) */
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    { /* the side and lane streams run at the default priority: with hardware queues of their own (GPU_MAX_HW_QUEUES=8) a high priority changes
+       * nothing (4.94 / 4.98 ms per whole-genome step), with the runtime's default of 4 queues it costs 0.9 ms (7.0 / 7.9 ms);
+       * AVK_STREAM_PRIORITY=high brings it back for experiments */
+        const char *pe = getenv("AVK_STREAM_PRIORITY");
+        if (!pe || strcmp(pe, "high") != 0) prio_high = 0;
+    }
     if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess ||

@@ -207,7 +207,7 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    The launches of one call run on six HIP streams side by side; the HIP runtime gives a process 4 hardware queues
  *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=8 unless the
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
- *                    earlier should export the variable itself (whole-genome step of the final build: 5.0 ms with 8 queues, 7.9 ms with 4).
+ *                    earlier should export the variable itself (whole-genome step of the final build: 5.0 ms with 8 queues, 7.0 ms with 4).
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
