@@ -168,7 +168,7 @@ template <class T> int grow_pair(avk_ctx *ctx, T **h, T **d, size_t *cap, size_t
 /* what the classification pass finds out about a region */
 struct StreamClass {
     std::vector<uint8_t> cls;     /* 0 = general path, 1 + k = fast class k */
-    std::vector<uint8_t> key;     /* cost key inside the class (calls, edit-distance bound): tiles hold regions of one cost */
+    std::vector<uint8_t> key;     /* cost key inside the class (fast_cost_key): tiles hold regions of one cost */
     std::vector<uint8_t> alt_ed;  /* per caller variant: Variant::alt_ed (fast regions only) */
     std::vector<uint32_t> v_off;  /* first per-variant output word of a region (prefix sum of t_cnt + q_cnt) */
 };
@@ -292,7 +292,22 @@ static int compare_batch_stream(avk_ctx *ctx, const avk_region_batch *b, const a
             }
         }
     });
-    for (uint64_t r = 0; r < n; ++r) sc.v_off[r + 1] += sc.v_off[r];
+    { /* prefix sum of the per-region call counts, in two passes over the threads' ranges (3.5 M additions in a row cost 3 ms of a 40 ms call) */
+        std::vector<uint64_t> part((size_t)nt + 1, 0);
+        avk_parallel_for(n, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+            uint64_t sum = 0;
+            for (uint64_t r = lo; r < hi; ++r) sum += sc.v_off[r + 1];
+            part[t + 1] = sum;
+        });
+        for (unsigned t = 0; t < nt; ++t) part[t + 1] += part[t];
+        avk_parallel_for(n, nt, [&](unsigned t, uint64_t lo, uint64_t hi) {
+            uint32_t run = (uint32_t)part[t];
+            for (uint64_t r = lo; r < hi; ++r) {
+                run += sc.v_off[r + 1];
+                sc.v_off[r + 1] = run;
+            }
+        });
+    }
     if (sc.v_off[n] > 0x7FFFFFFFull) return 100;
     { /* a class too small for a launch of its own (plan_work_order's rule, option lane_min_regions) joins the general part */
         static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2};
