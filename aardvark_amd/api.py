@@ -71,6 +71,10 @@ def load_library():
     lib.avk_algorithmic_bytes.restype = C.c_uint64
     lib.avk_algorithmic_bytes.argtypes = [C.POINTER(AvkRegionBatch)]
     lib.avk_optimize_pairs_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.c_uint32, C.POINTER(C.c_int32), u8p]
+    lib.avk_host_alloc.restype = vp
+    lib.avk_host_alloc.argtypes = [vp, C.c_size_t]
+    lib.avk_host_free.restype = None
+    lib.avk_host_free.argtypes = [vp, vp]
     _lib = lib
     return lib
 
@@ -118,11 +122,46 @@ class Context:
         if rc != 0:
             raise AardvarkAmdError("avk_ctx_create(%d) failed (%d): %s" % (device, rc, self.lib.avk_last_error(None).decode()))
         self._contigs = None
+        self._pinned = []
 
     def close(self):
         if self.handle:
+            for p in self._pinned:
+                self.lib.avk_host_free(self.handle, p)
+            self._pinned = []
             self.lib.avk_ctx_destroy(self.handle)
             self.handle = C.c_void_p()
+
+    def host_array(self, shape, dtype):
+        """a numpy array in pinned host memory (avk_host_alloc): batch and result arrays that live there are copied by DMA without a host pass;
+        freed when the context is closed"""
+        count = int(np.prod(shape))
+        nbytes = max(16, count * np.dtype(dtype).itemsize)
+        p = self.lib.avk_host_alloc(self.handle, nbytes)
+        if not p:
+            raise AardvarkAmdError("avk_host_alloc(%d) failed: %s" % (nbytes, self.lib.avk_last_error(self.handle).decode()))
+        self._pinned.append(p)
+        buf = (C.c_uint8 * nbytes).from_address(p)
+        return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
+
+    def pinned_batch(self, batch):
+        """a copy of `batch` whose arrays live in pinned memory"""
+        def pin(a):
+            out = self.host_array(a.shape, a.dtype)
+            out[...] = a
+            return out
+        return RegionBatch(*[pin(getattr(batch, f)) for f in ("region_id", "contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg",
+                                                              "var_raw_space", "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes")])
+
+    def pinned_results(self, batch, group_metrics=False):
+        """a ResultBatch whose arrays live in pinned memory"""
+        res = ResultBatch(batch, sequences=False, group_metrics=group_metrics)
+        for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg") + (("group_metrics",) if group_metrics else ()):
+            a = getattr(res, f)
+            b = self.host_array(a.shape, a.dtype)
+            b[...] = a
+            setattr(res, f, b)
+        return res
 
     def __del__(self):
         try:

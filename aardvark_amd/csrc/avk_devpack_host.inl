@@ -1,0 +1,797 @@
+/*
+ * avk_devpack_host.inl — the kernels around avk_devpack.inl and the host side of a device-packed batch.  Included by avk_host.hip.
+ *
+ * The host's part of avk_batch_upload / avk_compare_batch is now: queue the copies of the caller's arrays (straight from the caller's memory
+ * when it is pinned — avk_host_alloc —, through a pinned bounce buffer filled by the host threads when it is not), queue a dozen
+ * kernels, read ONE small state block back (sizes of the variable-length outputs, batch-level errors), queue the writers.  Device
+ * buffers come from a pool the context keeps, so a call allocates nothing after the first one of its size.
+ */
+
+/* ---------------------------------------------------------------------------------- kernels */
+namespace dpk = avk::dp;
+
+__global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dpk::dp_variant(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+
+/* dp_region for 256 regions; the workgroup's sums of the three scanned quantities go to block_sums[3 * block] */
+__global__ void __launch_bounds__(256) avk_dp_region_kernel(dpk::DpArgs a, uint64_t *block_sums) {
+    __shared__ unsigned long long sums[3];
+    if (threadIdx.x < 3) sums[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t nc = 0, bw = 0, fc = 0;
+    uint64_t sq = 0;
+    dpk::dp_region(a, (uint64_t)blockIdx.x * 256u + threadIdx.x, nc, bw, sq, fc);
+    for (uint32_t c = 1; c <= AVK_FAST_CLASSES; ++c) { /* one atomic per wave and class */
+        const unsigned long long m = __ballot(fc == c);
+        if (m && (threadIdx.x & 63u) == 0) atomicAdd((unsigned long long *)&a.st->have[c - 1], (unsigned long long)__popcll(m));
+    }
+    const uint32_t nc_w = wv_sum_u32(nc); /* at most 64 x 60000 */
+    if ((threadIdx.x & 63u) == 0 && nc_w) atomicAdd(&sums[0], (unsigned long long)nc_w);
+    if (bw) atomicAdd(&sums[1], (unsigned long long)bw);
+    if (sq) atomicAdd(&sums[2], (unsigned long long)sq);
+    __syncthreads();
+    if (threadIdx.x < 3) block_sums[3u * blockIdx.x + threadIdx.x] = sums[threadIdx.x];
+}
+
+/* exclusive scan of the block sums, in place (one workgroup), and the totals */
+__global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *block_sums, uint32_t n_blocks, dpk::DpState *st) {
+    __shared__ unsigned long long part[3][1024];
+    const uint32_t t = threadIdx.x, per = (n_blocks + 1023u) / 1024u;
+    const uint32_t lo = t * per < n_blocks ? t * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
+    unsigned long long s[3] = {0, 0, 0};
+    for (uint32_t b = lo; b < hi; ++b)
+        for (int q = 0; q < 3; ++q) s[q] += block_sums[3u * b + q];
+    for (int q = 0; q < 3; ++q) part[q][t] = s[q];
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        unsigned long long x[3];
+        for (int q = 0; q < 3; ++q) x[q] = t >= d ? part[q][t - d] : 0ull;
+        __syncthreads();
+        for (int q = 0; q < 3; ++q) part[q][t] += x[q];
+        __syncthreads();
+    }
+    unsigned long long run[3];
+    for (int q = 0; q < 3; ++q) run[q] = part[q][t] - s[q];
+    for (uint32_t b = lo; b < hi; ++b)
+        for (int q = 0; q < 3; ++q) {
+            const unsigned long long v = block_sums[3u * b + q];
+            block_sums[3u * b + q] = run[q];
+            run[q] += v;
+        }
+    if (t == 1023) {
+        st->total_v = part[0][1023];
+        st->total_blob_words = part[1][1023];
+        st->total_seq = part[2][1023];
+    }
+}
+
+/* per-region offsets: the block's base + the exclusive scan inside the block */
+__global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, const uint64_t *block_sums) {
+    __shared__ unsigned long long sh[3][256];
+    const uint32_t t = threadIdx.x;
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + t;
+    unsigned long long v[3] = {0, 0, 0};
+    if (r < a.in.n_regions) {
+        const uint32_t tc = a.in.t_cnt[r], qc = a.in.q_cnt[r];
+        const uint64_t toff = a.in.t_off[r], qoff = a.in.q_off[r], nv = a.in.n_variants;
+        if (!(toff > nv || (uint64_t)tc > nv - toff || qoff > nv || (uint64_t)qc > nv - qoff)) { /* as dp_region counted it */
+            v[0] = (unsigned long long)tc + qc;
+            v[1] = a.rinfo[r].blob_bytes / 4u;
+            v[2] = 5ull * a.rinfo[r].seq_stride;
+        }
+    }
+    for (int q = 0; q < 3; ++q) sh[q][t] = v[q];
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        unsigned long long x[3];
+        for (int q = 0; q < 3; ++q) x[q] = t >= d ? sh[q][t - d] : 0ull;
+        __syncthreads();
+        for (int q = 0; q < 3; ++q) sh[q][t] += x[q];
+        __syncthreads();
+    }
+    if (r < a.in.n_regions) {
+        a.v_off[r] = (uint32_t)(block_sums[3u * blockIdx.x + 0] + sh[0][t] - v[0]);
+        a.blob_off8[r] = (uint32_t)((block_sums[3u * blockIdx.x + 1] + sh[1][t] - v[1]) / 2ull);
+        a.seq_off[r] = block_sums[3u * blockIdx.x + 2] + sh[2][t] - v[2];
+    }
+}
+
+__global__ void avk_dp_lane_switch_kernel(dpk::DpArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) dpk::dp_lane_switch(a);
+}
+
+/* counting sort, pass 1: the histogram of the buckets (in LDS per workgroup, one global atomic per bucket the workgroup met) */
+__global__ void __launch_bounds__(1024) avk_dp_hist_kernel(dpk::DpArgs a) {
+    __shared__ uint32_t h[dpk::DP_NB];
+    for (uint32_t k = threadIdx.x; k < dpk::DP_NB; k += 1024u) h[k] = 0;
+    __syncthreads();
+    const uint64_t r = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
+    if (r < a.in.n_regions) {
+        const uint32_t b = dpk::dp_bucket_of(a, r);
+        a.rinfo[r].bucket = b;
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < dpk::DP_NB; k += 1024u)
+        if (h[k]) atomicAdd(&a.st->hist[k], h[k]);
+}
+
+__global__ void avk_dp_bucket_bases_kernel(dpk::DpArgs a) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) dpk::dp_bucket_bases(a);
+}
+
+/* pass 2: a workgroup reserves its share of every bucket with one atomic and ranks its regions inside the share in LDS.  The order inside a
+ * bucket is the caller's at the granularity of a workgroup (1024 regions) — a bucket holds regions of one cost, so nothing depends on it. */
+__global__ void __launch_bounds__(1024) avk_dp_scatter_kernel(dpk::DpArgs a) {
+    __shared__ uint32_t h[dpk::DP_NB];
+    for (uint32_t k = threadIdx.x; k < dpk::DP_NB; k += 1024u) h[k] = 0;
+    __syncthreads();
+    const uint64_t r = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
+    uint32_t b = 0;
+    if (r < a.in.n_regions) {
+        b = a.rinfo[r].bucket;
+        atomicAdd(&h[b], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = threadIdx.x; k < dpk::DP_NB; k += 1024u)
+        if (h[k]) h[k] = atomicAdd(&a.st->cursor[k], h[k]);
+    __syncthreads();
+    if (r < a.in.n_regions) a.order[atomicAdd(&h[b], 1u)] = (uint32_t)r;
+}
+
+__global__ void __launch_bounds__(256) avk_dp_fast_records_kernel(dpk::DpArgs a, uint32_t n_tiles_total) {
+    const uint32_t tile = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    if (tile >= n_tiles_total) return;
+    uint32_t fc = 0;
+    for (uint32_t c = 0; c < AVK_FAST_CLASSES; ++c)
+        if (tile >= a.st->tile_first[c] && tile < a.st->tile_first[c] + a.st->fast_tiles[c]) fc = c;
+    dpk::dp_fast_record(a, fc, tile - a.st->tile_first[fc], lane);
+}
+
+__global__ void __launch_bounds__(256) avk_dp_region_records_kernel(dpk::DpArgs a) { dpk::dp_region_record(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+
+__global__ void __launch_bounds__(256) avk_dp_region_records_wave_kernel(dpk::DpArgs a) {
+    const uint32_t n_big = a.st->n_big, n_waves = gridDim.x * 4u;
+    for (uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6); item < n_big; item += n_waves) dpk::dp_region_record_wave(a, item);
+}
+
+/* alt_ed of the calls dp_variant left to the host */
+__global__ void avk_dp_patch_ed_kernel(dpk::DpVarInfo *vinfo, const uint32_t *idx, const uint32_t *ed, uint32_t n) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) {
+        vinfo[idx[k]].alt_ed = ed[k];
+        vinfo[idx[k]].flags &= ~(uint32_t)dpk::DP_VF_PENDING;
+    }
+}
+
+__global__ void __launch_bounds__(256) avk_dp_unpack_kernel(dpk::DpOut o, uint8_t *pair_exact) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    dpk::dp_unpack(o, r);
+    if (pair_exact && r < o.n_regions) pair_exact[r] = (o.region_out[4 * r] == 0 && o.region_out[4 * r + 1] != 0) ? 1 : 0; /* all_opt_haps[0].is_exact_match() */
+}
+
+/* ---------------------------------------------------------------------------------- host threads */
+namespace {
+
+/* A small persistent pool for the loops that are left on the host (copies between pageable and pinned memory): workers sleep on a condition
+ * variable between loops; one loop at a time (calls on different contexts take turns). */
+class AvkPool {
+  public:
+    static AvkPool &get() {
+        static AvkPool p;
+        return p;
+    }
+    /* runs fn(t) for t in [0, nt) on the workers (t = 0 on the caller) and returns when all are done */
+    void run(unsigned nt, const std::function<void(unsigned)> &fn) {
+        if (nt <= 1) {
+            fn(0);
+            return;
+        }
+        std::lock_guard<std::mutex> one(loop_mutex_);
+        ensure(nt - 1);
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            fn_ = &fn;
+            want_ = nt - 1;
+            next_ = 0;
+            done_ = 0;
+            gen_ += 1;
+        }
+        cv_.notify_all();
+        fn(0);
+        for (int spin = 0; spin < 4000 && done_.load(std::memory_order_acquire) != want_; ++spin) __builtin_ia32_pause();
+        std::unique_lock<std::mutex> lk(m_);
+        cv_done_.wait(lk, [&] { return done_ == want_; });
+        fn_ = nullptr;
+    }
+
+  private:
+    AvkPool() {}
+    ~AvkPool() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+            gen_ += 1;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void ensure(unsigned n) {
+        while (workers_.size() < n) workers_.emplace_back([this] { work(); });
+    }
+    void work() {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(unsigned)> *fn = nullptr;
+            unsigned t = 0;
+            for (int spin = 0; spin < 20000 && gen_.load(std::memory_order_acquire) == seen; ++spin) __builtin_ia32_pause();
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || (gen_ != seen && next_ < want_); });
+                if (stop_) return;
+                t = ++next_; /* 1 .. want_ */
+                seen = gen_; /* one index per loop and worker */
+                fn = fn_;
+            }
+            (*fn)(t);
+            {
+                std::lock_guard<std::mutex> lk(m_);
+                done_ += 1;
+                if (done_ == want_) cv_done_.notify_all();
+            }
+        }
+    }
+    std::mutex m_, loop_mutex_;
+    std::condition_variable cv_, cv_done_;
+    std::vector<std::thread> workers_;
+    const std::function<void(unsigned)> *fn_ = nullptr;
+    unsigned want_ = 0, next_ = 0;
+    std::atomic<unsigned> done_{0};
+    std::atomic<uint64_t> gen_{0};
+    bool stop_ = false;
+};
+
+template <class F> void avk_parallel_for(uint64_t n, unsigned nt, F f) { /* f(thread, lo, hi) */
+    if (nt <= 1 || n < 4096) {
+        f(0u, (uint64_t)0, n);
+        return;
+    }
+    AvkPool::get().run(nt, [&](unsigned t) { f(t, n * t / nt, n * (t + 1) / nt); });
+}
+
+unsigned avk_host_threads() {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt > 16) nt = 16;
+    if (nt < 1) nt = 1;
+    if (const char *e = getenv("AVK_HOST_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 256) nt = (unsigned)v;
+    }
+    return nt;
+}
+
+/* ---- pinned memory handed to the caller (avk_host_alloc): arrays that live there are copied by DMA without a host pass */
+struct PinnedRange {
+    const uint8_t *lo, *hi;
+};
+std::mutex g_pinned_mutex;
+std::vector<PinnedRange> g_pinned;
+
+bool is_pinned(const void *p, size_t bytes) {
+    if (!p) return true;
+    const uint8_t *lo = (const uint8_t *)p;
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mutex);
+        for (const PinnedRange &r : g_pinned)
+            if (lo >= r.lo && lo + bytes <= r.hi) return true;
+    }
+    if (bytes < (1u << 20)) return false; /* small arrays: the bounce buffer costs less than asking the runtime */
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return attr.type == hipMemoryTypeHost;
+}
+
+} // namespace
+
+/* ---- the context's pool of device buffers: every buffer is used in the order of the context's stream (side streams are forked from and joined
+ * into it), so a released buffer may be handed out again at once — whatever is still queued on it runs before the next user's work */
+static int pool_alloc(avk_ctx *ctx, void **p, size_t bytes) {
+    *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    bytes = (bytes + 255) & ~(size_t)255;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mutex);
+        int best = -1;
+        for (size_t i = 0; i < ctx->pool.size(); ++i) {
+            const auto &b = ctx->pool[i];
+            if (b.used || b.bytes < bytes || b.bytes > 2 * bytes + (1u << 20)) continue;
+            if (best < 0 || b.bytes < ctx->pool[(size_t)best].bytes) best = (int)i;
+        }
+        if (best >= 0) {
+            ctx->pool[(size_t)best].used = true;
+            ctx->pool_free_bytes -= ctx->pool[(size_t)best].bytes;
+            *p = ctx->pool[(size_t)best].p;
+            return 0;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e == hipErrorOutOfMemory) { /* give the cached buffers back and try again */
+        (void)hipGetLastError();
+        std::vector<void *> drop;
+        {
+            std::lock_guard<std::mutex> lk(ctx->pool_mutex);
+            for (size_t i = 0; i < ctx->pool.size();) {
+                if (!ctx->pool[i].used) {
+                    drop.push_back(ctx->pool[i].p);
+                    ctx->pool_free_bytes -= ctx->pool[i].bytes;
+                    ctx->pool.erase(ctx->pool.begin() + (long)i);
+                } else
+                    ++i;
+            }
+        }
+        for (void *q : drop) (void)hipFree(q);
+        e = hipMalloc(p, bytes);
+    }
+    if (e != hipSuccess) {
+        *p = nullptr;
+        return fail(ctx, e == hipErrorOutOfMemory ? AVK_E_OOM : AVK_E_HIP, "device allocation of %zu bytes failed: %s", bytes, hipGetErrorString(e));
+    }
+    std::lock_guard<std::mutex> lk(ctx->pool_mutex);
+    ctx->pool.push_back({*p, bytes, true});
+    return 0;
+}
+
+static void pool_release(avk_ctx *ctx, void *p) {
+    if (!p) return;
+    bool drop = false;
+    {
+        std::lock_guard<std::mutex> lk(ctx->pool_mutex);
+        for (size_t i = 0; i < ctx->pool.size(); ++i)
+            if (ctx->pool[i].p == p) {
+                if (ctx->pool_free_bytes + ctx->pool[i].bytes > (size_t)ctx->pool_cache_bytes) { /* beyond the cache limit: back to the runtime */
+                    ctx->pool.erase(ctx->pool.begin() + (long)i);
+                    drop = true;
+                } else {
+                    ctx->pool[i].used = false;
+                    ctx->pool_free_bytes += ctx->pool[i].bytes;
+                }
+                break;
+            }
+    }
+    if (drop) (void)hipFree(p);
+}
+
+static void pool_destroy(avk_ctx *ctx) {
+    for (auto &b : ctx->pool) (void)hipFree(b.p);
+    ctx->pool.clear();
+    ctx->pool_free_bytes = 0;
+    if (ctx->h_bounce) (void)hipHostFree(ctx->h_bounce);
+    ctx->h_bounce = nullptr;
+    ctx->bounce_bytes = 0;
+    if (ctx->h_dpstate) (void)hipHostFree(ctx->h_dpstate);
+    ctx->h_dpstate = nullptr;
+}
+
+template <typename T> static int pool_alloc_t(avk_ctx *ctx, avk_dev_batch *db, T **p, size_t count) {
+    void *q = nullptr;
+    const int rc = pool_alloc(ctx, &q, count * sizeof(T));
+    *p = (T *)q;
+    if (!rc && db) db->pooled.push_back(q);
+    return rc;
+}
+
+static int bounce_reserve(avk_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->bounce_bytes) return 0;
+    bytes += bytes / 8 + (1u << 20);
+    if (ctx->h_bounce) {
+        AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        (void)hipHostFree(ctx->h_bounce);
+        ctx->h_bounce = nullptr;
+        ctx->bounce_bytes = 0;
+    }
+    AVK_HIP(ctx, hipHostMalloc((void **)&ctx->h_bounce, bytes, hipHostMallocDefault));
+    ctx->bounce_bytes = bytes;
+    return 0;
+}
+
+/* ---- copies between the caller's arrays and the device ---------------------------------------------------------------------- */
+struct CopySeg {
+    const void *host; /* caller's array (source of an upload, destination of a download) */
+    void *dev;
+    size_t bytes;
+};
+
+/* host -> device on the context's stream: straight from pinned arrays; pageable ones through the bounce buffer, piece by piece — the host threads
+ * fill pieces while this thread queues the copy of every piece that is ready */
+static int copy_in(avk_ctx *ctx, const std::vector<CopySeg> &segs) {
+    struct Piece {
+        const uint8_t *src;
+        uint8_t *dev;
+        size_t off, bytes;
+    };
+    std::vector<Piece> pieces;
+    size_t staged = 0;
+    const size_t piece_bytes = 4u << 20;
+    for (const CopySeg &s : segs) {
+        if (!s.bytes || !s.host) continue;
+        if (is_pinned(s.host, s.bytes)) {
+            AVK_HIP(ctx, hipMemcpyAsync(s.dev, s.host, s.bytes, hipMemcpyHostToDevice, ctx->stream));
+            continue;
+        }
+        for (size_t o = 0; o < s.bytes; o += piece_bytes) {
+            const size_t nb = s.bytes - o < piece_bytes ? s.bytes - o : piece_bytes;
+            pieces.push_back({(const uint8_t *)s.host + o, (uint8_t *)s.dev + o, staged, nb});
+            staged += (nb + 63) & ~(size_t)63;
+        }
+    }
+    if (pieces.empty()) return 0;
+    const int rc = bounce_reserve(ctx, staged);
+    if (rc) return rc;
+    const unsigned nt = avk_host_threads();
+    std::atomic<size_t> next(0);
+    std::vector<std::atomic<uint8_t>> ready(pieces.size());
+    for (auto &x : ready) x.store(0);
+    hipError_t herr = hipSuccess;
+    AvkPool::get().run(nt > 1 ? nt + 1 : 1, [&](unsigned t) {
+        const bool copier = t == 0;
+        if (copier && nt > 1) { /* this thread queues, the others fill */
+            for (size_t k = 0; k < pieces.size() && herr == hipSuccess; ++k) {
+                while (!ready[k].load(std::memory_order_acquire)) std::this_thread::yield();
+                herr = hipMemcpyAsync(pieces[k].dev, ctx->h_bounce + pieces[k].off, pieces[k].bytes, hipMemcpyHostToDevice, ctx->stream);
+            }
+            return;
+        }
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= pieces.size()) break;
+            memcpy(ctx->h_bounce + pieces[k].off, pieces[k].src, pieces[k].bytes);
+            ready[k].store(1, std::memory_order_release);
+            if (nt <= 1 && herr == hipSuccess)
+                herr = hipMemcpyAsync(pieces[k].dev, ctx->h_bounce + pieces[k].off, pieces[k].bytes, hipMemcpyHostToDevice, ctx->stream);
+        }
+    });
+    if (herr != hipSuccess) return fail(ctx, AVK_E_HIP, "host to device copy failed: %s", hipGetErrorString(herr));
+    return 0;
+}
+
+/* device -> host: queues the copies (pinned destinations directly, the others into the bounce buffer); finish_copy_out waits for the stream and
+ * moves the bounced parts into the caller's arrays on the host threads */
+struct CopyOut {
+    struct Part {
+        void *host;
+        size_t off, bytes;
+    };
+    std::vector<Part> parts;
+};
+static int copy_out(avk_ctx *ctx, const std::vector<CopySeg> &segs, CopyOut *co) {
+    size_t staged = 0;
+    for (const CopySeg &s : segs)
+        if (s.bytes && s.host && !is_pinned(s.host, s.bytes)) staged += (s.bytes + 63) & ~(size_t)63;
+    if (staged) {
+        const int rc = bounce_reserve(ctx, staged);
+        if (rc) return rc;
+    }
+    size_t off = 0;
+    for (const CopySeg &s : segs) {
+        if (!s.bytes || !s.host) continue;
+        if (is_pinned(s.host, s.bytes)) {
+            AVK_HIP(ctx, hipMemcpyAsync((void *)s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
+            continue;
+        }
+        AVK_HIP(ctx, hipMemcpyAsync(ctx->h_bounce + off, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
+        co->parts.push_back({(void *)s.host, off, s.bytes});
+        off += (s.bytes + 63) & ~(size_t)63;
+    }
+    return 0;
+}
+static int finish_copy_out(avk_ctx *ctx, const CopyOut &co) {
+    AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (co.parts.empty()) return 0;
+    struct Piece {
+        uint8_t *dst;
+        const uint8_t *src;
+        size_t bytes;
+    };
+    std::vector<Piece> pieces;
+    const size_t piece_bytes = 4u << 20;
+    for (const auto &p : co.parts)
+        for (size_t o = 0; o < p.bytes; o += piece_bytes) pieces.push_back({(uint8_t *)p.host + o, ctx->h_bounce + p.off + o, p.bytes - o < piece_bytes ? p.bytes - o : piece_bytes});
+    std::atomic<size_t> next(0);
+    const unsigned nt = pieces.size() > 1 ? avk_host_threads() : 1;
+    AvkPool::get().run(nt, [&](unsigned) {
+        for (;;) {
+            const size_t k = next.fetch_add(1);
+            if (k >= pieces.size()) break;
+            memcpy(pieces[k].dst, pieces[k].src, pieces[k].bytes);
+        }
+    });
+    return 0;
+}
+
+/* ---- upload ---------------------------------------------------------------------------------------------------------------- */
+static void release_pooled(avk_ctx *ctx, avk_dev_batch *db) {
+    for (void *p : db->pooled) pool_release(ctx, p);
+    db->pooled.clear();
+}
+
+static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pairs_mode, avk_dev_batch **out) {
+    const uint64_t n = b->n_regions, nv = b->n_variants, alen = b->allele_bytes_len;
+    if (n > 0x7FFFFFFFull || nv > 0x7FFFFFFFull) return fail(ctx, AVK_E_ARG, "batch too large (more than 2^31 regions or variants); split it");
+    if (n && (!b->start || !b->end || !b->t_off || !b->t_cnt || !b->q_off || !b->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (nv && (!b->var_pos || !b->var_type || !b->var_zyg || !b->a0_off || !b->a0_len || !b->a1_off || !b->a1_len || !b->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    const bool timing = getenv("AVK_TIMING") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
+    const auto t_start = now();
+    hipStream_t s = ctx->stream;
+    avk_dev_batch *db = new avk_dev_batch();
+    db->dev_packed = true;
+    db->n_regions = n;
+    db->n_variants_host = nv;
+    std::vector<void *> temps; /* released (to the pool) at the end of the upload */
+    int rc = 0;
+    auto tmp = [&](size_t bytes) -> void * {
+        void *p = nullptr;
+        if (!rc) rc = pool_alloc(ctx, &p, bytes);
+        if (p) temps.push_back(p);
+        return p;
+    };
+    auto kept = [&](size_t bytes) -> void * {
+        void *p = nullptr;
+        if (!rc) rc = pool_alloc(ctx, &p, bytes);
+        if (p) db->pooled.push_back(p);
+        return p;
+    };
+    auto bail = [&](int code) {
+        (void)hipStreamSynchronize(s);
+        for (void *p : temps) pool_release(ctx, p);
+        release_pooled(ctx, db);
+        delete db;
+        return code;
+    };
+    /* the caller's arrays in HBM; the four that dp_unpack reads after the solve stay with the batch */
+    dpk::DpArgs a;
+    memset(&a, 0, sizeof(a));
+    uint64_t *d_start = (uint64_t *)tmp((n + 1) * 8), *d_end = (uint64_t *)tmp((n + 1) * 8);
+    db->d_in_t_off = (uint64_t *)kept((n + 1) * 8), db->d_in_q_off = (uint64_t *)kept((n + 1) * 8);
+    db->d_in_t_cnt = (uint32_t *)kept((n + 1) * 4), db->d_in_q_cnt = (uint32_t *)kept((n + 1) * 4);
+    uint32_t *d_contig = b->contig_idx ? (uint32_t *)tmp((n + 1) * 4) : nullptr;
+    uint64_t *d_pos = (uint64_t *)tmp((nv + 1) * 8), *d_a0o = (uint64_t *)tmp((nv + 1) * 8), *d_a1o = (uint64_t *)tmp((nv + 1) * 8);
+    uint32_t *d_a0l = (uint32_t *)tmp((nv + 1) * 4), *d_a1l = (uint32_t *)tmp((nv + 1) * 4);
+    uint32_t *d_raw = b->var_raw_space ? (uint32_t *)tmp((nv + 1) * 4) : nullptr;
+    uint8_t *d_type = (uint8_t *)tmp(nv + 16), *d_zyg = (uint8_t *)tmp(nv + 16), *d_alleles = (uint8_t *)tmp(alen + 16);
+    /* intermediates */
+    const uint32_t n_blocks = (uint32_t)((n + 255) / 256);
+    a.vinfo = (dpk::DpVarInfo *)tmp((nv + 1) * sizeof(dpk::DpVarInfo));
+    a.rinfo = (dpk::DpRegionInfo *)tmp((n + 1) * sizeof(dpk::DpRegionInfo));
+    a.st = (dpk::DpState *)tmp(sizeof(dpk::DpState));
+    a.pending = (uint32_t *)tmp((nv + 1) * 4);
+    db->d_voff = (uint32_t *)kept((n + 1) * 4);
+    a.v_off = db->d_voff;
+    a.blob_off8 = (uint32_t *)tmp((n + 1) * 4);
+    a.seq_off = (uint64_t *)tmp((n + 1) * 8);
+    a.order = (uint32_t *)tmp((n + 1) * 4);
+    a.big_list = (uint32_t *)tmp((n + 1) * 4);
+    uint64_t *d_block_sums = (uint64_t *)tmp(((size_t)n_blocks + 1) * 3 * 8);
+    if (!ctx->h_dpstate && !rc) {
+        hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState), hipHostMallocDefault);
+        if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "pinned state block: %s", hipGetErrorString(e));
+    }
+    if (!ctx->d_contig_tab && !rc) rc = fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    if (rc) return bail(rc);
+    const auto t_alloc = now();
+    {
+        std::vector<CopySeg> segs = {
+            {b->start, d_start, n * 8}, {b->end, d_end, n * 8}, {b->t_off, db->d_in_t_off, n * 8}, {b->q_off, db->d_in_q_off, n * 8},
+            {b->t_cnt, db->d_in_t_cnt, n * 4}, {b->q_cnt, db->d_in_q_cnt, n * 4}, {b->contig_idx, d_contig, b->contig_idx ? n * 4 : 0},
+            {b->var_pos, d_pos, nv * 8}, {b->a0_off, d_a0o, nv * 8}, {b->a1_off, d_a1o, nv * 8}, {b->a0_len, d_a0l, nv * 4}, {b->a1_len, d_a1l, nv * 4},
+            {b->var_raw_space, d_raw, b->var_raw_space ? nv * 4 : 0}, {b->var_type, d_type, nv}, {b->var_zyg, d_zyg, nv}, {b->allele_bytes, d_alleles, alen}};
+        rc = copy_in(ctx, segs);
+        if (rc) return bail(rc);
+    }
+    const auto t_copy = now();
+    a.in.contig_idx = d_contig, a.in.start = d_start, a.in.end = d_end, a.in.t_off = db->d_in_t_off, a.in.q_off = db->d_in_q_off, a.in.t_cnt = db->d_in_t_cnt,
+    a.in.q_cnt = db->d_in_q_cnt, a.in.var_pos = d_pos, a.in.var_type = d_type, a.in.var_zyg = d_zyg, a.in.var_raw = d_raw, a.in.a0_off = d_a0o, a.in.a1_off = d_a1o,
+    a.in.a0_len = d_a0l, a.in.a1_len = d_a1l, a.in.alleles = d_alleles, a.in.n_regions = n, a.in.n_variants = nv, a.in.alleles_len = alen,
+    a.in.contig_base = ctx->d_contig_tab, a.in.contig_len = ctx->d_contig_tab + ctx->contig_len.size(), a.in.n_contigs = (uint32_t)ctx->contig_len.size(),
+    a.in.pairs_mode = pairs_mode ? 1u : 0u;
+    const bool lanes = ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b;
+    a.opt.tier0_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), a.opt.tier0_ed_cap = (uint32_t)ctx->lds_ed_cap, a.opt.tier1_bytes = (uint64_t)ctx->lds2_bytes_per_wave,
+    a.opt.tier1_ed_cap = (uint32_t)ctx->lds2_ed_cap, a.opt.solo_min_variants = pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, a.opt.max_branch = 50,
+    a.opt.class_c_nodes_x2 = (uint32_t)ctx->class_c_nodes_x2, a.opt.lane_min_regions = lanes ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull,
+    a.opt.lane_max_calls = (uint32_t)ctx->lane_max_calls, a.opt.lane_min_batch = (uint64_t)ctx->lane_min_batch, a.opt.lane_max_est = (uint32_t)ctx->lane_max_est;
+    hipError_t e = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
+    if (e == hipSuccess && nv) {
+        hipLaunchKernelGGL(avk_dp_variant_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, a);
+        e = hipGetLastError();
+    }
+    dpk::DpState *hs = (dpk::DpState *)ctx->h_dpstate;
+    auto region_passes = [&]() -> hipError_t { /* everything that depends on alt_ed, up to the state block on the host */
+        hipError_t x = hipSuccess;
+        if (n) {
+            hipLaunchKernelGGL(avk_dp_region_kernel, dim3(n_blocks), dim3(256), 0, s, a, d_block_sums);
+            hipLaunchKernelGGL(avk_dp_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, d_block_sums, n_blocks, a.st);
+            hipLaunchKernelGGL(avk_dp_scan_apply_kernel, dim3(n_blocks), dim3(256), 0, s, a, (const uint64_t *)d_block_sums);
+            hipLaunchKernelGGL(avk_dp_lane_switch_kernel, dim3(1), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(avk_dp_hist_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
+            hipLaunchKernelGGL(avk_dp_bucket_bases_kernel, dim3(1), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(avk_dp_scatter_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
+            x = hipGetLastError();
+        }
+        if (x == hipSuccess) x = hipMemcpyAsync(hs, a.st, sizeof(dpk::DpState), hipMemcpyDeviceToHost, s);
+        if (x == hipSuccess) x = hipStreamSynchronize(s);
+        return x;
+    };
+    if (e == hipSuccess) e = region_passes();
+    if (e == hipSuccess && hs->n_pending) {
+        /* calls whose two alleles are both long after the common prefix and suffix are gone: their alt_ed comes from the host
+         * (avk_edit_distance, the routine the host-side packer uses for every call), and the region passes run again */
+        const uint32_t np = hs->n_pending;
+        std::vector<uint32_t> idx(np), ed(np);
+        e = hipMemcpy(idx.data(), a.pending, (size_t)np * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess) {
+            avk_parallel_for(np, avk_host_threads(), [&](unsigned, uint64_t lo, uint64_t hi) {
+                for (uint64_t k = lo; k < hi; ++k) {
+                    const uint64_t v = idx[k];
+                    ed[k] = (uint32_t)avk::host_edit_distance(b->allele_bytes + b->a0_off[v], b->a0_len[v], b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+                }
+            });
+            uint32_t *d_idx = (uint32_t *)tmp((size_t)np * 4), *d_ed = (uint32_t *)tmp((size_t)np * 4);
+            if (rc) return bail(rc);
+            e = hipMemcpy(d_idx, idx.data(), (size_t)np * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) e = hipMemcpy(d_ed, ed.data(), (size_t)np * 4, hipMemcpyHostToDevice);
+            if (e == hipSuccess) {
+                hipLaunchKernelGGL(avk_dp_patch_ed_kernel, dim3((np + 255) / 256), dim3(256), 0, s, a.vinfo, (const uint32_t *)d_idx, (const uint32_t *)d_ed, np);
+                e = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
+            }
+            if (e == hipSuccess) e = region_passes();
+        }
+    }
+    if (e != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
+    const auto t_plan = now();
+    if (hs->err & dpk::DP_ERR_RANGE) return bail(fail(ctx, AVK_E_ARG, "variant range of a region exceeds n_variants"));
+    if (hs->err & dpk::DP_ERR_ALLELE) return bail(fail(ctx, AVK_E_ARG, "allele range exceeds allele_bytes_len"));
+    if (hs->err & dpk::DP_ERR_BLOB) return bail(fail(ctx, AVK_E_ARG, "region blob exceeds 2 GiB; split the region's alleles"));
+    if (hs->total_v > 0x7FFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "more than 2^31 variant records; split the batch"));
+    if (hs->total_blob_words / 2 > 0xFFFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "region blob arena exceeds its limits; split the batch"));
+    db->n_variants_dev = hs->total_v;
+    db->seq_total = hs->total_seq;
+    db->plan.n_hbm = hs->n_hbm, db->plan.n_hard = hs->n_hard, db->plan.n_fast_total = hs->n_fast_total;
+    uint32_t tiles_total = 0;
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) {
+        db->plan.n_fast[fc] = hs->n_fast[fc], db->plan.n_fast_heavy[fc] = hs->n_fast_heavy[fc], db->plan.fast_base[fc] = hs->fast_base[fc];
+        db->fast_word_base[fc] = hs->fast_word_base[fc], db->fast_tiles[fc] = hs->fast_tiles[fc];
+        tiles_total += hs->fast_tiles[fc];
+    }
+    /* the batch's own buffers */
+    const uint64_t nvd = hs->total_v;
+    db->d_regions = (AvkDevRegion *)kept((n + 1) * sizeof(AvkDevRegion));
+    db->d_blob = (uint32_t *)kept(((size_t)hs->total_blob_words + 4) * 4);
+    db->d_region_out = (uint32_t *)kept((n * 4 + 4) * 4);
+    db->d_var_out = (uint32_t *)kept((nvd + 1) * 4);
+    db->d_seqlen = (uint32_t *)kept((n * 5 + 1) * 4);
+    db->d_tally = (uint64_t *)kept((size_t)AVK_TALLY_STRIDE * 8);
+    db->d_partials = (uint64_t *)kept((size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * 8);
+    db->d_counters = (uint32_t *)kept((size_t)AVK_N_COUNTERS * 4);
+    db->d_overflow = (uint32_t *)kept((n + 1024) * 4);
+    db->d_overflow2 = (uint32_t *)kept((n + 1) * 4);
+    db->d_overflow3 = (uint32_t *)kept((n + 1) * 4);
+    db->d_overflow4 = (uint32_t *)kept((n + 1) * 4);
+    if (hs->n_fast_total) db->d_fast = (uint32_t *)kept(((size_t)hs->fast_words + 64) * 4);
+    if (rc) return bail(rc);
+    a.regions = db->d_regions, a.blob = db->d_blob, a.fast = db->d_fast;
+    if (tiles_total) hipLaunchKernelGGL(avk_dp_fast_records_kernel, dim3((tiles_total + 3) / 4), dim3(256), 0, s, a, tiles_total);
+    if (n) {
+        hipLaunchKernelGGL(avk_dp_region_records_kernel, dim3(n_blocks), dim3(256), 0, s, a);
+        hipLaunchKernelGGL(avk_dp_region_records_wave_kernel, dim3(256), dim3(256), 0, s, a);
+    }
+    e = hipGetLastError();
+    if (e != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
+    for (void *p : temps) pool_release(ctx, p); /* in stream order: the writers above run before anything that is handed these buffers next */
+    if (timing)
+        fprintf(stderr, "avk upload (device-packed): %llu regions, %llu calls: buffers %.3f ms, copies queued %.3f ms, packing kernels + plan %.3f ms, writers queued %.3f ms; lanes %u regions in %u tiles, class C %u, class B %u\n",
+                (unsigned long long)n, (unsigned long long)nv, ms(t_start, t_alloc), ms(t_alloc, t_copy), ms(t_copy, t_plan), ms(t_plan, now()), hs->n_fast_total, tiles_total,
+                hs->n_hbm, hs->n_hard);
+    *out = db;
+    return 0;
+}
+
+/* ---- download of a device-packed batch: dp_unpack on the device, then plain copies into the caller's arrays ------------------------- */
+static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out, uint8_t *pair_exact, uint64_t *tally_words /* [AVK_TALLY_STRIDE] */) {
+    const uint64_t n = db->n_regions, nv = db->n_variants_host;
+    hipStream_t s = ctx->stream;
+    std::vector<void *> temps;
+    int rc = 0;
+    auto tmp = [&](size_t bytes) -> void * {
+        void *p = nullptr;
+        if (!rc) rc = pool_alloc(ctx, &p, bytes);
+        if (p) temps.push_back(p);
+        return p;
+    };
+    auto done = [&](int code) {
+        for (void *p : temps) pool_release(ctx, p);
+        return code;
+    };
+    dpk::DpOut o;
+    memset(&o, 0, sizeof(o));
+    o.region_out = db->d_region_out, o.var_out = db->d_var_out, o.v_off = db->d_voff, o.t_off = db->d_in_t_off, o.q_off = db->d_in_q_off, o.t_cnt = db->d_in_t_cnt,
+    o.q_cnt = db->d_in_q_cnt, o.n_regions = n, o.n_variants = nv, o.mode = db->last_mode;
+    o.status = (int32_t *)tmp((n + 1) * 4);
+    if (out->ed_h1) o.ed_h1 = (uint32_t *)tmp((n + 1) * 4);
+    if (out->ed_h2) o.ed_h2 = (uint32_t *)tmp((n + 1) * 4);
+    if (out->n_optima) o.n_optima = (uint32_t *)tmp((n + 1) * 4);
+    if (out->type_present) o.type_present = (uint16_t *)tmp((n + 1) * 2);
+    const bool want_var = db->last_mode == 0 && (out->var_expected || out->var_observed || out->var_class || out->var_zyg);
+    if (want_var) {
+        if (out->var_expected) o.var_expected = (uint8_t *)tmp(nv + 16);
+        if (out->var_observed) o.var_observed = (uint8_t *)tmp(nv + 16);
+        if (out->var_class) o.var_class = (uint8_t *)tmp(nv + 16);
+        if (out->var_zyg) o.var_zyg = (uint8_t *)tmp(nv + 16);
+    }
+    uint8_t *d_exact = pair_exact ? (uint8_t *)tmp(n + 16) : nullptr;
+    if (rc) return done(rc);
+    if (!ctx->h_dpstate) {
+        hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState), hipHostMallocDefault);
+        if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "pinned state block: %s", hipGetErrorString(e)));
+    }
+    static_assert(sizeof(dpk::DpState) >= AVK_TALLY_STRIDE * 8, "the pinned state block also receives the tally");
+    hipError_t e = hipSuccess;
+    if (want_var) { /* calls no region owns read as zero */
+        uint8_t *arrs[4] = {o.var_expected, o.var_observed, o.var_class, o.var_zyg};
+        for (uint8_t *p : arrs)
+            if (p && e == hipSuccess) e = hipMemsetAsync(p, 0, nv + 16, s);
+    }
+    if (e == hipSuccess && n) {
+        hipLaunchKernelGGL(avk_dp_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o, d_exact);
+        e = hipGetLastError();
+    }
+    if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(e)));
+    std::vector<CopySeg> segs = {{out->status, o.status, n * 4}, {out->ed_h1, o.ed_h1, n * 4}, {out->ed_h2, o.ed_h2, n * 4}, {out->n_optima, o.n_optima, n * 4},
+                                 {out->type_present, o.type_present, n * 2}, {pair_exact, d_exact, pair_exact ? n : 0}};
+    if (want_var) {
+        segs.push_back({out->var_expected, o.var_expected, nv});
+        segs.push_back({out->var_observed, o.var_observed, nv});
+        segs.push_back({out->var_class, o.var_class, nv});
+        segs.push_back({out->var_zyg, o.var_zyg, nv});
+    }
+    if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
+    CopyOut co;
+    rc = copy_out(ctx, segs, &co);
+    if (rc) return done(rc);
+    e = hipMemcpyAsync(ctx->h_dpstate, db->d_tally, (size_t)AVK_TALLY_STRIDE * 8, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "tally download failed: %s", hipGetErrorString(e)));
+    rc = finish_copy_out(ctx, co);
+    if (rc) return done(rc);
+    memcpy(tally_words, ctx->h_dpstate, (size_t)AVK_TALLY_STRIDE * 8);
+    return done(0);
+}
+
+/* The host-side view of a device-packed batch (region records, blobs, the map from per-call output words to the caller's calls), fetched only when
+ * something needs it: the capacity retry and the sequence outputs of avk_results_download. */
+static int materialize_host_view(avk_ctx *ctx, avk_dev_batch *db) {
+    if (!db->dev_packed || !db->host.regions.empty() || !db->n_regions) return 0;
+    const uint64_t n = db->n_regions;
+    avk::PodVec<AvkDevRegion> recs;
+    recs.resize(n);
+    AVK_HIP(ctx, hipMemcpy(recs.data(), db->d_regions, n * sizeof(AvkDevRegion), hipMemcpyDeviceToHost));
+    db->host.regions.resize(n);
+    uint64_t blob_words = 2;
+    for (uint64_t k = 0; k < n; ++k) {
+        db->host.regions[recs[k].orig] = recs[k];
+        const uint64_t end = 2ull * recs[k].blob_off + recs[k].blob_bytes / 4;
+        if (recs[k].blob_bytes && end > blob_words) blob_words = end;
+    }
+    db->host.blob.resize(blob_words);
+    AVK_HIP(ctx, hipMemcpy(db->host.blob.data(), db->d_blob, blob_words * 4, hipMemcpyDeviceToHost));
+    std::vector<uint64_t> toff(n), qoff(n);
+    AVK_HIP(ctx, hipMemcpy(toff.data(), db->d_in_t_off, n * 8, hipMemcpyDeviceToHost));
+    AVK_HIP(ctx, hipMemcpy(qoff.data(), db->d_in_q_off, n * 8, hipMemcpyDeviceToHost));
+    db->host.dev2host.resize(db->n_variants_dev);
+    for (uint64_t r = 0; r < n; ++r) {
+        const AvkDevRegion &dr = db->host.regions[r];
+        for (uint32_t k = 0; k < dr.t_cnt + dr.q_cnt; ++k) db->host.dev2host[dr.v_off + k] = k < dr.t_cnt ? toff[r] + k : qoff[r] + (k - dr.t_cnt);
+    }
+    return 0;
+}

@@ -31,6 +31,7 @@
 #include "avk_solver.inl"
 #include "avk_lane.inl"
 #include "avk_dwfa_script.inl"
+#include "avk_devpack.inl"
 
 /* ---------------------------------------------------------------------------------- kernels */
 /* LDS passes: regions in the LDS slice of their wavefront (small slices at high occupancy first, then
@@ -203,8 +204,11 @@ struct DevBuf {
     size_t bytes = 0;
 };
 
-struct StreamBufs; /* staging buffers of the one-shot path (avk_stream.inl) */
-void stream_bufs_free(StreamBufs *b);
+struct PoolBlk { /* a device buffer of the context's pool (avk_devpack_host.inl) */
+    void *p;
+    size_t bytes;
+    bool used;
+};
 
 } // namespace
 
@@ -220,6 +224,16 @@ struct avk_ctx {
     uint32_t *d_ref2b = nullptr, *d_refexc = nullptr;
     int64_t use_packed_reference = 1;
     std::vector<uint64_t> contig_base, contig_len;
+    uint64_t *d_contig_tab = nullptr; /* contig_base[n_contigs] then contig_len[n_contigs], for the device-side packer */
+    /* device-side packing (avk_devpack_host.inl) */
+    int64_t device_pack = 1;               /* batches are validated, classified, ordered and written ON THE DEVICE from the caller's arrays (0: avk_pack.h on the host threads) */
+    int64_t pool_cache_bytes = 12ll << 30; /* released device buffers the context keeps for the next batch (beyond: back to the runtime) */
+    std::vector<PoolBlk> pool;
+    std::mutex pool_mutex;
+    size_t pool_free_bytes = 0;
+    uint8_t *h_bounce = nullptr; /* pinned staging for caller arrays that are not pinned (grow-only) */
+    size_t bounce_bytes = 0;
+    void *h_dpstate = nullptr;   /* pinned: the packer's state block / the tally of a download */
     /* options */
     int64_t lds_bytes_per_wave = 10 * 1024;
     int64_t lds_ed_cap = 48;
@@ -264,8 +278,7 @@ struct avk_ctx {
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
     uint64_t last_lane_solved = 0;
-    StreamBufs *sbufs = nullptr;
-    int last_one_shot = 0; /* the last avk_compare_batch took the one-shot path of avk_stream.inl */
+    int last_one_shot = 0; /* the last avk_compare_batch / avk_optimize_pairs_batch packed its batch on the device */
     int n_cus = 0;
     /* workspaces (grown on demand) */
     uint8_t *d_ws = nullptr;
@@ -316,6 +329,12 @@ struct avk_dev_batch {
     bool has_run = false;
     bool scratch_clean = false; /* partial tallies and counters are zero */
     bool with_gm = true;
+    /* device-packed batches (avk_devpack_host.inl): every buffer comes from the context's pool; `host` stays empty unless the capacity retry or
+     * the sequence outputs ask for it (materialize_host_view) */
+    bool dev_packed = false;
+    std::vector<void *> pooled;
+    uint64_t *d_in_t_off = nullptr, *d_in_q_off = nullptr; /* the caller's t_off / q_off / t_cnt / q_cnt: dp_unpack scatters the per-call outputs with them */
+    uint32_t *d_in_t_cnt = nullptr, *d_in_q_cnt = nullptr, *d_voff = nullptr;
 };
 
 namespace {
@@ -350,6 +369,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 }
 
 void free_batch_buffers(avk_dev_batch *db) {
+    if (db->dev_packed) return; /* pooled buffers: release_pooled */
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
                     db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_fast};
     for (void *p : ptrs)
@@ -357,6 +377,8 @@ void free_batch_buffers(avk_dev_batch *db) {
 }
 
 } // namespace
+
+#include "avk_devpack_host.inl"
 
 extern "C" {
 
@@ -452,8 +474,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
-    stream_bufs_free(ctx->sbufs);
-    ctx->sbufs = nullptr;
+    pool_destroy(ctx);
+    if (ctx->d_contig_tab) (void)hipFree(ctx->d_contig_tab);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
     if (ctx->d_ref2b) (void)hipFree(ctx->d_ref2b);
     if (ctx->d_refexc) (void)hipFree(ctx->d_refexc);
@@ -561,6 +583,11 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->big_waves = value;
     } else if (n == "use_packed_reference") {
         ctx->use_packed_reference = value ? 1 : 0;
+    } else if (n == "device_pack") {
+        ctx->device_pack = value ? 1 : 0;
+    } else if (n == "pool_cache_bytes") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "pool_cache_bytes must not be negative");
+        ctx->pool_cache_bytes = value;
     } else if (n == "emit_group_metrics") {
         ctx->emit_group_metrics = value ? 1 : 0;
     } else if (n == "capacity_retry") {
@@ -631,6 +658,11 @@ int avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs,
     for (uint32_t c = 0; c < n_contigs && e == hipSuccess; ++c)
         if (lens[c]) e = hipMemcpyAsync(ctx->d_ref + ctx->contig_base[c], seqs[c], lens[c], hipMemcpyHostToDevice, ctx->stream);
     const uint64_t n_words = (total + 15) >> 4;
+    if (ctx->d_contig_tab) (void)hipFree(ctx->d_contig_tab);
+    ctx->d_contig_tab = nullptr;
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_contig_tab, ((size_t)2 * n_contigs + 2) * sizeof(uint64_t));
+    if (e == hipSuccess && n_contigs) e = hipMemcpyAsync(ctx->d_contig_tab, ctx->contig_base.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && n_contigs) e = hipMemcpyAsync(ctx->d_contig_tab + n_contigs, ctx->contig_len.data(), (size_t)n_contigs * 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_ref2b, (n_words + 80) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_refexc, ((n_words >> 5) + 8) * sizeof(uint32_t));
     if (e == hipSuccess) e = hipMemsetAsync(ctx->d_ref2b, 0, (n_words + 80) * sizeof(uint32_t), ctx->stream);
@@ -646,6 +678,8 @@ int avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs,
         if (ctx->d_ref) (void)hipFree(ctx->d_ref);
         if (ctx->d_ref2b) (void)hipFree(ctx->d_ref2b);
         if (ctx->d_refexc) (void)hipFree(ctx->d_refexc);
+        if (ctx->d_contig_tab) (void)hipFree(ctx->d_contig_tab);
+        ctx->d_contig_tab = nullptr;
         ctx->d_ref = nullptr;
         ctx->d_ref2b = ctx->d_refexc = nullptr;
         ctx->contig_base.clear();
@@ -690,6 +724,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     *out = nullptr;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     AVK_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->device_pack) return upload_device_packed(ctx, batch, pairs_mode, out);
     const bool timing = getenv("AVK_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -767,7 +802,8 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
-                                    ctx->lane_kernel ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls, (uint64_t)ctx->lane_min_batch);
+                                    ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls,
+                                    (uint64_t)ctx->lane_min_batch);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
@@ -800,6 +836,11 @@ void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
     if (ctx) {
         (void)hipSetDevice(ctx->device);
         (void)hipStreamSynchronize(ctx->stream);
+    }
+    if (ctx && db->dev_packed) { /* back to the context's pool: nothing to wait for */
+        release_pooled(ctx, db);
+        delete db;
+        return;
     }
     /* a large batch holds a dozen device buffers and about a gigabyte of host records: releasing them takes 0.1 s, which a tool that
      * works through its batches one after the other should not wait for.  One release runs behind the caller at a time. */
@@ -850,7 +891,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (ctx->lds2_bytes_per_wave * 4 > 160 * 1024) return fail(ctx, AVK_E_ARG, "lds2_bytes_per_wave too large");
     /* sequences: allocate the output arena on first use */
     if (cfg->enable_sequences && !db->d_seq) {
-        int rc = dev_alloc(ctx, &db->d_seq, (size_t)db->seq_total + 16);
+        int rc = db->dev_packed ? pool_alloc_t(ctx, db, &db->d_seq, (size_t)db->seq_total + 16) : dev_alloc(ctx, &db->d_seq, (size_t)db->seq_total + 16);
         if (rc) return rc;
     }
     /* up to four launches, one per workspace tier; each consumes the overflow list of the one
@@ -871,8 +912,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     /* which classes go to the lanes was decided with the work order (plan_work_order, option lane_min_regions at upload time) */
     const int lane_k = AVK_FAST_CLASSES;
     const uint32_t n_lane_regions = db->plan.n_fast_total;
+    /* the lanes read the 2-bit reference only: with use_packed_reference off (a.ref_2bit == NULL) the wave-per-region kernels take every record */
     const bool use_fast = ctx->lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && db->d_fast && n_lane_regions && !cfg->enable_sequences &&
-                          !cfg->enable_exact_shortcut && n;
+                          !cfg->enable_exact_shortcut && n && ctx->use_packed_reference && ctx->d_ref2b;
     const uint32_t n_fast = use_fast ? n_lane_regions : 0u;
     /* geometry */
     const uint32_t waves_per_block = 4;
@@ -924,7 +966,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     }
     db->scratch_clean = false;
     if (ctx->emit_group_metrics && !db->d_gm) {
-        int rc = dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
+        int rc = db->dev_packed ? pool_alloc_t(ctx, db, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS + 4) : dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
         if (rc) return rc;
     }
 
@@ -1506,45 +1548,56 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     const uint64_t n = db->n_regions, nv = db->n_variants_dev;
     const bool timing = getenv("AVK_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
-    std::vector<uint32_t> rout(n * 4 + 4), vout(nv + 1);
     std::vector<uint64_t> tally((size_t)AVK_TALLY_STRIDE);
     hipStream_t s = ctx->stream;
-#define D2H(dst, src, bytes) \
-    if ((bytes) > 0) AVK_HIP(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s))
-    D2H(rout.data(), db->d_region_out, n * 4 * sizeof(uint32_t));
-    if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
-    if (out->var_expected || out->var_observed || out->var_class || out->var_zyg) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
-    D2H(tally.data(), db->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t));
+    const bool want_seq = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq;
     std::vector<uint8_t> seq;
     std::vector<uint32_t> seqlen;
-    const bool want_seq = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq;
+#define D2H(dst, src, bytes) \
+    if ((bytes) > 0) AVK_HIP(ctx, hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, s))
     if (want_seq) {
         seq.resize(db->seq_total + 16);
         seqlen.resize(n * 5 + 1);
         D2H(seq.data(), db->d_seq, db->seq_total);
         D2H(seqlen.data(), db->d_seqlen, n * 5 * sizeof(uint32_t));
     }
+    std::chrono::steady_clock::time_point t_copied;
+    if (db->dev_packed) { /* the caller's layout is made on the device (dp_unpack); the copies land in the caller's arrays */
+        const int rc = download_device_packed(ctx, db, out, nullptr, tally.data());
+        if (rc) return rc;
+        t_copied = std::chrono::steady_clock::now();
+        if (want_seq) {
+            const int rv = materialize_host_view(ctx, db);
+            if (rv) return rv;
+        }
+    } else {
+        std::vector<uint32_t> rout(n * 4 + 4), vout(nv + 1);
+        D2H(rout.data(), db->d_region_out, n * 4 * sizeof(uint32_t));
+        if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
+        if (out->var_expected || out->var_observed || out->var_class || out->var_zyg) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
+        D2H(tally.data(), db->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t));
+        AVK_HIP(ctx, hipStreamSynchronize(s));
+        t_copied = std::chrono::steady_clock::now();
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint32_t *w = rout.data() + 4 * r;
+            out->status[r] = (int32_t)w[0];
+            if (out->ed_h1) out->ed_h1[r] = w[1];
+            if (out->ed_h2) out->ed_h2[r] = w[2];
+            if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
+            if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
+        }
+        for (uint64_t v = 0; v < nv; ++v) {
+            const uint64_t hv = db->host.dev2host[v];
+            const uint32_t w = vout[v];
+            if (out->var_expected) out->var_expected[hv] = (uint8_t)(w & 0xFF);
+            if (out->var_observed) out->var_observed[hv] = (uint8_t)((w >> 8) & 0xFF);
+            if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
+            if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
+        }
+    }
 #undef D2H
-    AVK_HIP(ctx, hipStreamSynchronize(s));
-    const auto t_copied = std::chrono::steady_clock::now();
-    for (uint64_t r = 0; r < n; ++r) {
-        const uint32_t *w = rout.data() + 4 * r;
-        out->status[r] = (int32_t)w[0];
-        if (out->ed_h1) out->ed_h1[r] = w[1];
-        if (out->ed_h2) out->ed_h2[r] = w[2];
-        if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
-        if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
-    }
-    for (uint64_t v = 0; v < nv; ++v) {
-        const uint64_t hv = db->host.dev2host[v];
-        const uint32_t w = vout[v];
-        if (out->var_expected) out->var_expected[hv] = (uint8_t)(w & 0xFF);
-        if (out->var_observed) out->var_observed[hv] = (uint8_t)((w >> 8) & 0xFF);
-        if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
-        if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
-    }
     if (timing)
-        fprintf(stderr, "avk download: kernels + copies %.3f ms, unpack %.3f ms\n", std::chrono::duration<double, std::milli>(t_copied - t_begin).count(),
+        fprintf(stderr, "avk download%s: kernels + copies %.3f ms, unpack %.3f ms\n", db->dev_packed ? " (device-packed)" : "", std::chrono::duration<double, std::milli>(t_copied - t_begin).count(),
                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_copied).count());
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
@@ -1567,8 +1620,13 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         std::vector<uint32_t> cap;
         for (uint64_t r = 0; r < n; ++r)
             if (out->status[r] == AVK_ST_CAPACITY) cap.push_back((uint32_t)r);
+        if (!cap.empty()) { /* the retry rebuilds the regions from the packed records: a device-packed batch fetches them now */
+            const int rv = materialize_host_view(ctx, db);
+            if (rv) return rv;
+        }
         const bool big_grown = !cap.empty();
         const size_t big_before = ctx->big_alloc;
+        int retry_rc = 0;
         uint64_t keep_tiers[5];
         memcpy(keep_tiers, ctx->last_tiers, sizeof(keep_tiers));
         const uint64_t keep_lane_solved = ctx->last_lane_solved;
@@ -1578,7 +1636,10 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
             const bool want_gm = out->group_metrics && ctx->emit_group_metrics && db->d_gm;
             const int rc = rerun_capacity_regions(ctx, db, cap, want_gm, want_seq, slice, &fx);
             if (rc == AVK_E_OOM) break; /* the device cannot hold slices of this size: the regions keep their status */
-            if (rc) return rc;
+            if (rc) { /* reported after the statistics and the shared slices are back as they were (below) */
+                retry_rc = rc;
+                break;
+            }
             std::vector<uint32_t> still;
             for (uint64_t k = 0; k < fx.idx.size(); ++k) {
                 const uint32_t r = fx.idx[k];
@@ -1623,46 +1684,79 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
             ctx->d_big = nullptr;
             ctx->big_alloc = 0;
         }
+        if (retry_rc) return retry_rc;
     }
     return 0;
 }
 
 } /* extern "C" */
 
-#include "avk_stream.inl"
-
 extern "C" {
 
 int avk_last_compare_was_one_shot(avk_ctx *ctx) { return ctx ? ctx->last_one_shot : 0; }
 
+/* pinned host memory for the caller's batch and result arrays: arrays that live there are copied by DMA, no host pass (pageable arrays go through
+ * a pinned bounce buffer that the host threads fill) */
+void *avk_host_alloc(avk_ctx *ctx, size_t bytes) {
+    if (ctx) (void)hipSetDevice(ctx->device);
+    void *p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ctx) fail(ctx, AVK_E_OOM, "cannot pin %zu bytes of host memory", bytes);
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_pinned_mutex);
+    g_pinned.push_back({(const uint8_t *)p, (const uint8_t *)p + bytes});
+    return p;
+}
+
+void avk_host_free(avk_ctx *ctx, void *p) {
+    if (!p) return;
+    if (ctx) {
+        (void)hipSetDevice(ctx->device);
+        (void)hipStreamSynchronize(ctx->stream);
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_pinned_mutex);
+        for (size_t i = 0; i < g_pinned.size(); ++i)
+            if (g_pinned[i].lo == (const uint8_t *)p) {
+                g_pinned.erase(g_pinned.begin() + (long)i);
+                break;
+            }
+    }
+    (void)hipHostFree(p);
+}
+
+/* what a batch of this size will need, ahead of the first call: the pinned bounce buffer for pageable arrays (callers whose arrays come from
+ * avk_host_alloc need none) and the device buffers of the pool */
 int avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants) {
     if (!ctx) return AVK_E_ARG;
-    if (n_regions < 32768 || n_regions > 0x7FFFFFFFull || n_variants > 0x7FFFFFFFull) return 0; /* such batches take the resident path */
-    return stream_reserve(ctx, n_regions, n_variants);
+    if (n_regions > 0x7FFFFFFFull || n_variants > 0x7FFFFFFFull) return 0;
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    return bounce_reserve(ctx, (size_t)n_regions * 52 + (size_t)n_variants * 48 + (1u << 20));
 }
 
 int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
     if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
-    /* large batches without per-region blocks or sequences: written straight into pinned fast records, copied while they are written */
     ctx->last_one_shot = 0;
-    {
-        const int rs = compare_batch_stream(ctx, batch, cfg, out);
-        if (rs != 100) {
-            ctx->last_one_shot = rs == 0;
-            return rs;
-        }
-    }
     avk_dev_batch *db = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
+    /* per-region metric blocks only when the caller has an array for them */
+    const int64_t keep_gm = ctx->emit_group_metrics;
+    if (!out->group_metrics) ctx->emit_group_metrics = 0;
     int rc = avk_batch_upload(ctx, batch, &db);
-    if (rc) return rc;
     const auto t1 = std::chrono::steady_clock::now();
-    rc = avk_compare_resident(ctx, db, cfg, nullptr);
+    if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
     const auto t2 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_results_download(ctx, db, out);
     const auto t3 = std::chrono::steady_clock::now();
-    avk_batch_free(ctx, db);
+    ctx->emit_group_metrics = keep_gm;
+    if (db) {
+        ctx->last_one_shot = db->dev_packed ? 1 : 0;
+        avk_batch_free(ctx, db);
+    }
     if (getenv("AVK_TIMING")) {
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "avk compare batch: upload %.3f ms, launches %.3f ms, download %.3f ms, free %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
@@ -1784,20 +1878,6 @@ int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32
     cfg.max_branch_factor = max_branch_factor;
     cfg.enable_sequences = 0;
     cfg.enable_exact_shortcut = 0;
-    { /* a large batch: the one-shot path of avk_stream.inl, as avk_compare_batch (a whole-genome merge asks for one such batch per pair of inputs) */
-        std::vector<uint32_t> exact(batch->n_regions + 1);
-        avk_result_batch ro;
-        memset(&ro, 0, sizeof(ro));
-        ro.status = status;
-        ro.ed_h1 = exact.data();
-        const int rs = compare_batch_stream(ctx, batch, &cfg, &ro, 1);
-        ctx->last_one_shot = rs == 0;
-        if (rs == 0) {
-            for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && exact[r] ? 1 : 0;
-            return 0;
-        }
-        if (rs != 100) return rs;
-    }
     avk_dev_batch *db = nullptr;
     int rc = upload_internal(ctx, batch, true, &db);
     if (rc) return rc;
@@ -1805,7 +1885,16 @@ int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32
     ctx->emit_group_metrics = 0;
     rc = run_internal(ctx, db, &cfg, nullptr, 1);
     ctx->emit_group_metrics = keep;
-    if (!rc) {
+    if (!rc && db->dev_packed) { /* status and the exact-match flag in the caller's layout come from dp_unpack */
+        avk_result_batch ro;
+        memset(&ro, 0, sizeof(ro));
+        ro.status = status;
+        std::vector<uint64_t> tally((size_t)AVK_TALLY_STRIDE);
+        rc = download_device_packed(ctx, db, &ro, is_exact_match, tally.data());
+        ctx->last_one_shot = rc == 0;
+        memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
+        ctx->last_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
+    } else if (!rc) {
         std::vector<uint32_t> rout(db->n_regions * 4 + 4);
         hipError_t e = hipMemcpyAsync(rout.data(), db->d_region_out, db->n_regions * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -87,6 +87,7 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); } /* waves of a workgroup are OS threads */
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+AVK_DEV void avk_atomic_or_u32_global(uint32_t *p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) {
     __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     return expect;
@@ -185,6 +186,7 @@ AVK_DEV void wv_sync() {
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
+AVK_DEV void avk_atomic_or_u32_global(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
 AVK_DEV uint64_t avk_clock() { return __builtin_amdgcn_s_memtime(); }
 /* identity the optimiser cannot see through: keeps per-lane address arithmetic inside the loop it belongs to (hoisted

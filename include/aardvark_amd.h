@@ -86,7 +86,10 @@ enum {
     AVK_ST_INVALID_INPUT = 20,  /* rejected by host validation (window outside contig, variant outside
                                    window, unsorted variants, empty allele): the reference panics or is undefined */
     AVK_ST_CAPACITY = 21        /* device workspace exhausted at the largest tier AND in the library's own retries with slices of
-                                   1, 4 and 16 GB (avk_results_download, context option "capacity_retry", default 1) */
+                                   1, 4 and 16 GB (avk_results_download, context option "capacity_retry", default 1).  The retries repair
+                                   what avk_results_download hands to the caller (per-region and per-call arrays, out->tally); the
+                                   DEVICE-side totals of the same step — tally_dev of avk_compare_resident, what avk_label_tallies reads —
+                                   still count a retried region as failed */
 };
 
 /* infrastructure errors (function return values) */
@@ -211,6 +214,10 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
+ *   packing          "device_pack" (1, default: a batch is validated, classified, ordered and written in the kernels' layout ON THE DEVICE, from
+ *                    the caller's arrays copied to HBM as they are — csrc/avk_devpack.inl; 0: by the host threads, csrc/avk_pack.h; same
+ *                    records either way, tests/test_devpack.py), "pool_cache_bytes" (12 GiB: released device buffers the context keeps for
+ *                    the next batch)
  * None of them changes a result (tests/test_emu_parity.py, tests/test_gpu_parity.py). */
 int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
 
@@ -219,7 +226,8 @@ int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
  * bytes needed for windows holding non-ACGT symbols) and owned by the context. */
 int  avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs, const uint64_t *lens);
 
-/* One call = solve_compare_region for every region of the batch (H2D + kernels + D2H). */
+/* One call = solve_compare_region for every region of the batch: the caller's arrays go to HBM as they are, packing kernels, solver
+ * kernels, unpacking kernel, results into the caller's arrays (no per-region work on the host). */
 int  avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch,
                        const avk_compare_config *cfg, avk_result_batch *out);
 
@@ -241,11 +249,17 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r);
 int  avk_last_kernel_ms(avk_ctx *ctx, float *ms);  /* the dominant launch: first pass of avk_region_kernel_lds */
 int  avk_last_solver_ms(avk_ctx *ctx, float *ms);  /* all solver launches of the call (tier passes + tally reduce) */
 int  avk_last_tier_counts(avk_ctx *ctx, uint64_t counts[5]); /* regions finished per tier, then capacity failures */
-/* optional: pins and allocates the staging buffers avk_compare_batch will need for batches of up to n_regions / n_variants (they are kept
- * by the context and only grow), e.g. while a tool is still reading its inputs; without it the first large call pays for them */
+/* Pinned host memory for batch and result arrays (hipHostMalloc behind it; avk_host_free gives it back).  avk_compare_batch / avk_batch_upload /
+ * avk_results_download copy arrays that live in such memory by DMA straight from / into them; arrays anywhere else go through a pinned bounce
+ * buffer that the library's host threads fill or drain (a whole-genome batch: about 0.5 GB in, 0.1 GB out).  The Rust side would back its
+ * FlatBatch vectors with this allocator. */
+void *avk_host_alloc(avk_ctx *ctx, size_t bytes);
+void  avk_host_free(avk_ctx *ctx, void *p);
+/* optional: pins the bounce buffer avk_compare_batch needs for PAGEABLE arrays of a batch of up to n_regions / n_variants (kept by the context, only
+ * grows), e.g. while a tool is still reading its inputs; without it the first large call pays for it */
 int  avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants);
-int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the last avk_compare_batch took the one-shot path (large batch, no per-region
-                                                      blocks, no sequences): pinned fast records written and copied tile range by tile range */
+int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the batch of the last avk_compare_batch / avk_optimize_pairs_batch was packed on the device
+                                                      (context option device_pack) */
 int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */
 int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
                                                              they are not counted in any workspace tier */

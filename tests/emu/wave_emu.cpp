@@ -152,6 +152,7 @@ namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; ui
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
 #include "../../aardvark_amd/csrc/avk_dwfa_script.inl"
+#include "../../aardvark_amd/csrc/avk_devpack.inl"
 
 namespace {
 
@@ -190,6 +191,110 @@ void lane_main(void *p, int /*lane*/) {
     else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
 }
 
+/* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
+ * device functions, the workgroup-level plumbing (histogram, scans, scatter) as plain loops */
+int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
+namespace dpk = avk::dp;
+struct DpResult {
+    std::vector<AvkDevRegion> regions; /* work order */
+    std::vector<uint32_t> blob, fast, order, v_off, blob_off8;
+    std::vector<uint64_t> seq_off;
+    std::vector<dpk::DpVarInfo> vinfo;
+    std::vector<dpk::DpRegionInfo> rinfo;
+    dpk::DpState st;
+    std::string err;
+};
+struct DpWaveTask {
+    const dpk::DpArgs *a;
+    uint32_t item;
+};
+void dp_wave_main(void *p, int /*lane*/) {
+    DpWaveTask *t = (DpWaveTask *)p;
+    dpk::dp_region_record_wave(*t->a, t->item);
+}
+int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const std::vector<uint64_t> &lens, const dpk::DpOpts &opt, bool pairs_mode, DpResult *R) {
+    const uint64_t n = b->n_regions, nv = b->n_variants;
+    dpk::DpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in.contig_idx = b->contig_idx, a.in.start = b->start, a.in.end = b->end, a.in.t_off = b->t_off, a.in.q_off = b->q_off, a.in.t_cnt = b->t_cnt, a.in.q_cnt = b->q_cnt,
+    a.in.var_pos = b->var_pos, a.in.var_type = b->var_type, a.in.var_zyg = b->var_zyg, a.in.var_raw = b->var_raw_space, a.in.a0_off = b->a0_off, a.in.a1_off = b->a1_off,
+    a.in.a0_len = b->a0_len, a.in.a1_len = b->a1_len, a.in.alleles = b->allele_bytes, a.in.n_regions = n, a.in.n_variants = nv, a.in.alleles_len = b->allele_bytes_len,
+    a.in.contig_base = base.data(), a.in.contig_len = lens.data(), a.in.n_contigs = (uint32_t)lens.size(), a.in.pairs_mode = pairs_mode ? 1u : 0u;
+    a.opt = opt;
+    R->vinfo.assign(nv + 1, dpk::DpVarInfo());
+    R->rinfo.assign(n + 1, dpk::DpRegionInfo());
+    std::vector<uint32_t> pending(nv + 1), big_list(n + 1);
+    R->v_off.assign(n + 1, 0), R->blob_off8.assign(n + 1, 0), R->seq_off.assign(n + 1, 0), R->order.assign(n + 1, 0);
+    memset(&R->st, 0, sizeof(R->st));
+    a.vinfo = R->vinfo.data(), a.rinfo = R->rinfo.data(), a.st = &R->st, a.pending = pending.data(), a.v_off = R->v_off.data(), a.blob_off8 = R->blob_off8.data(),
+    a.seq_off = R->seq_off.data(), a.order = R->order.data(), a.big_list = big_list.data();
+    for (uint64_t v = 0; v < nv; ++v) dpk::dp_variant(a, v);
+    auto region_passes = [&] {
+        uint64_t run_v = 0, run_b = 0, run_s = 0;
+        for (uint64_t r = 0; r < n; ++r) {
+            uint32_t nc, bw, fc;
+            uint64_t sq;
+            dpk::dp_region(a, r, nc, bw, sq, fc);
+            if (fc) R->st.have[fc - 1] += 1;
+            R->v_off[r] = (uint32_t)run_v, R->blob_off8[r] = (uint32_t)(run_b / 2), R->seq_off[r] = run_s;
+            run_v += nc, run_b += bw, run_s += sq;
+        }
+        R->st.total_v = run_v, R->st.total_blob_words = run_b, R->st.total_seq = run_s;
+        dpk::dp_lane_switch(a);
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint32_t bk = dpk::dp_bucket_of(a, r);
+            R->rinfo[r].bucket = bk;
+            R->st.hist[bk] += 1;
+        }
+        dpk::dp_bucket_bases(a);
+        for (uint64_t r = 0; r < n; ++r) R->order[R->st.cursor[R->rinfo[r].bucket]++] = (uint32_t)r;
+    };
+    region_passes();
+    if (R->st.n_pending) { /* upload_device_packed: the host's edit distance for the calls dp_variant left, then the region passes again */
+        for (uint32_t k = 0; k < R->st.n_pending; ++k) {
+            const uint64_t v = pending[k];
+            R->vinfo[v].alt_ed = (uint32_t)avk::host_edit_distance(b->allele_bytes + b->a0_off[v], b->a0_len[v], b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+            R->vinfo[v].flags &= ~(uint32_t)dpk::DP_VF_PENDING;
+        }
+        memset(&R->st, 0, sizeof(R->st));
+        region_passes();
+    }
+    if (R->st.err & dpk::DP_ERR_RANGE) R->err = "variant range of a region exceeds n_variants";
+    else if (R->st.err & dpk::DP_ERR_ALLELE) R->err = "allele range exceeds allele_bytes_len";
+    else if (R->st.err & dpk::DP_ERR_BLOB) R->err = "region blob exceeds 2 GiB; split the region's alleles";
+    else if (R->st.total_v > 0x7FFFFFFFull) R->err = "more than 2^31 variant records; split the batch";
+    if (!R->err.empty()) return AVK_E_ARG;
+    R->regions.resize(n + 1);
+    R->blob.assign((size_t)R->st.total_blob_words + 4, 0xA5A5A5A5u); /* device memory is not zeroed: the writers must write every byte that is read */
+    R->fast.assign((size_t)R->st.fast_words + 64, 0xA5A5A5A5u);
+    a.regions = R->regions.data(), a.blob = R->blob.data(), a.fast = R->fast.data();
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc)
+        for (uint32_t t = 0; t < R->st.fast_tiles[fc]; ++t)
+            for (uint32_t lane = 0; lane < 64; ++lane) dpk::dp_fast_record(a, (uint32_t)fc, t, lane);
+    for (uint64_t k = 0; k < n; ++k) dpk::dp_region_record(a, k);
+    if (R->st.n_big) {
+        avk_emu::Wave w;
+        w.stack_bytes = 256 * 1024;
+        std::vector<char> stacks(64 * w.stack_bytes + 64);
+        w.stacks = stacks.data();
+        for (uint32_t item = 0; item < R->st.n_big; ++item) {
+            DpWaveTask t{&a, item};
+            avk_emu::run_wave(&w, dp_wave_main, &t);
+        }
+    }
+    return 0;
+}
+dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes, uint32_t lds2_ed_cap, uint32_t solo_min_variants, bool pairs, uint64_t lane_min_regions,
+                       uint64_t lane_min_batch = 0, uint32_t lane_max_est = 15) {
+    dpk::DpOpts o;
+    memset(&o, 0, sizeof(o));
+    o.tier0_bytes = avk::bulk_slice_bytes(lds_bytes), o.tier0_ed_cap = lds_ed_cap, o.tier1_bytes = lds2_bytes, o.tier1_ed_cap = lds2_ed_cap;
+    o.solo_min_variants = pairs ? 0u : solo_min_variants, o.max_branch = 50;
+    o.class_c_nodes_x2 = getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u;
+    o.lane_min_regions = lane_min_regions, o.lane_max_calls = AVK_FAST_MAXV, o.lane_min_batch = lane_min_batch, o.lane_max_est = lane_max_est;
+    return o;
+}
+
 } // namespace
 
 extern "C" {
@@ -215,12 +320,19 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     avk::PackedBatch pb;
     std::string err;
     const bool want_seq = cfg->enable_sequences && out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride;
-    int rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err);
+    const bool devpack = g_device_pack != 0 && !want_seq; /* (the library lays the sequence slots out itself; this harness writes them straight to the caller's) */
+    DpResult dpr;
+    int rc = 0;
+    if (devpack) {
+        rc = dp_run(batch, base, lens, dp_opts_of(lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, solo_min_variants, mode == 1, g_lane_kernel ? 0ull : 0xFFFFFFFFull), mode == 1, &dpr);
+        err = dpr.err;
+    } else
+        rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err);
     if (rc) {
         fprintf(stderr, "emu pack error: %s\n", err.c_str());
         return rc;
     }
-    const uint64_t n = batch->n_regions, nv = pb.variants.size();
+    const uint64_t n = batch->n_regions, nv = devpack ? dpr.st.total_v : pb.variants.size();
     std::vector<uint32_t> rout(n * 4 + 4, 0), vout(nv + 1, 0);
     std::vector<uint32_t> gm(out->group_metrics ? n * AVK_N_GROUPS * AVK_N_FIELDS : 0);
     std::vector<uint64_t> partials((size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES, 0), tally(AVK_TALLY_STRIDE, 0);
@@ -231,7 +343,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     AvkKernelArgs a;
     memset(&a, 0, sizeof(a));
     a.regions = pb.regions.data();
-    a.blob = pb.blob.data();
+    a.blob = devpack ? dpr.blob.data() : pb.blob.data();
     a.ref_bytes = refcat.data();
     /* packed copy, as avk_pack_reference builds it on the device */
     const uint64_t n_words = (total + 15) >> 4;
@@ -252,7 +364,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut;
     a.mode = mode;
-    if (mode == 1) { /* the pre-checks of avk_optimize_pairs_batch (aardvark_amd/csrc/avk_host.hip) */
+    if (mode == 1 && !devpack) { /* the pre-checks of avk_optimize_pairs_batch (aardvark_amd/csrc/avk_host.hip); dp_region applies them itself */
         for (uint64_t r = 0; r < batch->n_regions; ++r) {
             AvkDevRegion &dr = pb.regions[r];
             if ((dr.pre_status & 0xFFFFu) == AVK_ST_INVALID_INPUT) continue;
@@ -278,8 +390,10 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.tally = partials.data();
 
     if (cfg->max_branch_factor == 0) { /* query_optimizer.rs:177 */
-        for (uint64_t r = 0; r < n; ++r)
-            if (!(pb.regions[r].pre_status & 0xFFFFu)) pb.regions[r].pre_status = AVK_ST_BRANCH_FACTOR;
+        for (uint64_t r = 0; r < n; ++r) {
+            AvkDevRegion &dr = devpack ? dpr.regions[r] : pb.regions[r];
+            if (!(dr.pre_status & 0xFFFFu)) dr.pre_status = AVK_ST_BRANCH_FACTOR;
+        }
     }
 
     /* solo_waves extra waves run before the others with the tier-1 slice size (the first solo_blocks workgroups of the launch) */
@@ -354,10 +468,19 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     std::vector<uint8_t> big_slices(big_slots ? (size_t)big_slots * big_ws_bytes : 0);
     /* work order and solo waves as in upload_internal / run_internal (aardvark_amd/csrc/avk_host.hip) */
     std::vector<uint32_t> order;
-    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
-                                                    getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
-                                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */);
-    const avk::PodVec<AvkDevRegion> sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
+    avk::WorkPlan plan;
+    avk::PodVec<AvkDevRegion> sorted;
+    if (devpack) { /* the packer wrote the records in work order and made the plan */
+        plan.n_hbm = dpr.st.n_hbm, plan.n_hard = dpr.st.n_hard, plan.n_fast_total = dpr.st.n_fast_total;
+        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) plan.n_fast[fc] = dpr.st.n_fast[fc], plan.n_fast_heavy[fc] = dpr.st.n_fast_heavy[fc], plan.fast_base[fc] = dpr.st.fast_base[fc];
+        sorted.resize(n);
+        for (uint64_t k = 0; k < n; ++k) sorted[k] = dpr.regions[k];
+    } else {
+        plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
+                                    getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
+                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */);
+        sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
+    }
     a.regions = sorted.data();
     /* the lane-per-region launches of run_internal (aardvark_amd/csrc/avk_host.hip): fast segments first, leftovers to the list the
      * first HBM pass reads */
@@ -369,7 +492,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     if (use_fast) {
         uint64_t word_base[AVK_FAST_CLASSES];
         uint32_t n_tiles[AVK_FAST_CLASSES];
-        const avk::PodVec<uint32_t> fast = avk::build_fast_records(pb, order, plan, word_base, n_tiles);
+        avk::PodVec<uint32_t> fast;
+        if (devpack) {
+            fast.resize(dpr.fast.size());
+            memcpy(fast.data(), dpr.fast.data(), dpr.fast.size() * sizeof(uint32_t));
+            for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) word_base[fc] = dpr.st.fast_word_base[fc], n_tiles[fc] = dpr.st.fast_tiles[fc];
+        } else
+            fast = avk::build_fast_records(pb, order, plan, word_base, n_tiles);
         AvkKernelArgs f = a;
         f.overflow_list = lists[2].data(); /* the DEFERRED list: an LDS pass of the wave-per-region code after the bulk */
         f.overflow_count = counters + 1024 + 32;
@@ -616,8 +745,17 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     }
     for (int c = 0; c < AVK_TALLY_COPIES; ++c) /* avk_tally_reduce */
         for (int i = 0; i < AVK_TALLY_STRIDE; ++i) tally[i] += partials[(size_t)c * AVK_TALLY_STRIDE + i];
+    if (devpack) { /* download_device_packed: dp_unpack writes the caller's layout */
+        dpk::DpOut o;
+        memset(&o, 0, sizeof(o));
+        o.region_out = rout.data(), o.var_out = vout.data(), o.v_off = dpr.v_off.data(), o.t_off = batch->t_off, o.q_off = batch->q_off, o.t_cnt = batch->t_cnt, o.q_cnt = batch->q_cnt;
+        o.n_regions = n, o.n_variants = batch->n_variants, o.mode = mode;
+        o.status = out->status, o.ed_h1 = out->ed_h1, o.ed_h2 = out->ed_h2, o.n_optima = out->n_optima, o.type_present = out->type_present;
+        o.var_expected = out->var_expected, o.var_observed = out->var_observed, o.var_class = out->var_class, o.var_zyg = out->var_zyg;
+        for (uint64_t r = 0; r < n; ++r) dpk::dp_unpack(o, r);
+    }
     /* copy back in caller order */
-    for (uint64_t r = 0; r < n; ++r) {
+    for (uint64_t r = 0; r < n && !devpack; ++r) {
         const uint32_t *w = rout.data() + 4 * r;
         out->status[r] = (int32_t)w[0];
         if (out->ed_h1) out->ed_h1[r] = w[1];
@@ -626,7 +764,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
     }
     if (out->group_metrics) memcpy(out->group_metrics, gm.data(), gm.size() * sizeof(uint32_t));
-    for (uint64_t v = 0; v < nv; ++v) {
+    for (uint64_t v = 0; v < nv && !devpack; ++v) {
         const uint64_t hv = pb.dev2host[v];
         const uint32_t w = vout[v];
         if (out->var_expected) out->var_expected[hv] = (uint8_t)(w & 0xFF);
@@ -676,6 +814,110 @@ int emu_dwfa_script_batch(int engine, uint32_t n_scripts, const uint8_t *bytes, 
 }
 
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
+void emu_set_device_pack(int on) { g_device_pack = on; }
+
+/* The device-side packer against the host-side one on the same batch: every region record, every blob, the plan, the work order and the fast
+ * records must be identical (the blob arena may be laid out differently: blobs are compared by content).  Returns 0, or 1 with the first
+ * difference in `msg`.  lane_min_regions / lane_min_batch / lane_max_est as the context options of the same names. */
+int emu_devpack_compare(const avk_region_batch *batch, const uint64_t *ref_lens, uint32_t n_contigs, int pairs_mode, uint64_t lane_min_regions, uint64_t lane_min_batch,
+                        uint32_t lane_max_est, uint32_t solo_min_variants, char *msg, size_t msg_len) {
+    std::vector<uint64_t> base(n_contigs), lens(n_contigs);
+    uint64_t total = 0;
+    for (uint32_t c = 0; c < n_contigs; ++c) base[c] = total, lens[c] = ref_lens[c], total += ref_lens[c];
+    auto say = [&](const char *fmt, auto... args) {
+        snprintf(msg, msg_len, fmt, args...);
+        return 1;
+    };
+    const uint64_t n = batch->n_regions;
+    /* host side, as upload_internal does it */
+    std::vector<uint64_t> seq_off(n);
+    std::vector<uint32_t> seq_stride(n);
+    uint64_t seq_total = 0;
+    for (uint64_t r = 0; r < n; ++r) seq_stride[r] = avk::seq_stride_of(batch, r);
+    for (uint64_t r = 0; r < n; ++r) seq_off[r] = seq_total, seq_total += 5ull * seq_stride[r];
+    avk::PackedBatch pb;
+    std::string err;
+    const int rc_h = avk::pack_batch(batch, base, lens, seq_off.data(), seq_stride.data(), &pb, &err, 0, lane_max_est);
+    const uint64_t lds_bytes = 10 * 1024, lds2_bytes = 40 * 1024;
+    DpResult R;
+    const int rc_d = dp_run(batch, base, lens, dp_opts_of(lds_bytes, 48, lds2_bytes, 48, solo_min_variants, pairs_mode != 0, lane_min_regions, lane_min_batch, lane_max_est), pairs_mode != 0, &R);
+    if (rc_h != rc_d) return say("return codes differ: host %d (%s), device %d (%s)", rc_h, err.c_str(), rc_d, R.err.c_str());
+    if (rc_h) return err == R.err ? 0 : say("error texts differ: host '%s', device '%s'", err.c_str(), R.err.c_str());
+    if (pairs_mode)
+        for (uint64_t r = 0; r < n; ++r) {
+            AvkDevRegion &dr = pb.regions[r];
+            if ((dr.pre_status & 0xFFFFu) == AVK_ST_INVALID_INPUT) continue;
+            if (pb.zyg_flags[r] & 1) dr.pre_status = AVK_ST_BAD_ZYGOSITY;
+            else if (pb.delta_t[r] != pb.delta_q[r]) dr.pre_status = AVK_PRE_SKIP_OK;
+            else if (pb.zyg_flags[r] & 2) dr.pre_status = AVK_ST_BAD_ZYGOSITY;
+            else dr.pre_status = 0;
+        }
+    std::vector<uint32_t> order;
+    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), 48, lds2_bytes, 48, pairs_mode ? 0u : solo_min_variants, 50, &order, 12, lane_min_regions,
+                                                    AVK_FAST_MAXV, lane_min_batch);
+    if (pb.variants.size() != R.st.total_v) return say("per-call output words: host %zu, device %llu", pb.variants.size(), (unsigned long long)R.st.total_v);
+    if (seq_total != R.st.total_seq) return say("sequence bytes: host %llu, device %llu", (unsigned long long)seq_total, (unsigned long long)R.st.total_seq);
+    if (plan.n_hbm != R.st.n_hbm || plan.n_hard != R.st.n_hard || plan.n_fast_total != R.st.n_fast_total)
+        return say("plan: host C %u B %u lanes %u, device C %u B %u lanes %u", plan.n_hbm, plan.n_hard, plan.n_fast_total, R.st.n_hbm, R.st.n_hard, R.st.n_fast_total);
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc)
+        if (plan.n_fast[fc] != R.st.n_fast[fc] || plan.n_fast_heavy[fc] != R.st.n_fast_heavy[fc] || (plan.n_fast[fc] && plan.fast_base[fc] != R.st.fast_base[fc]))
+            return say("lane class %d: host n %u heavy %u base %u, device n %u heavy %u base %u", fc, plan.n_fast[fc], plan.n_fast_heavy[fc], plan.fast_base[fc], R.st.n_fast[fc],
+                       R.st.n_fast_heavy[fc], R.st.fast_base[fc]);
+    for (uint64_t k = 0; k < n; ++k)
+        if (order[k] != R.order[k]) return say("work order differs at %llu: host region %u, device region %u", (unsigned long long)k, order[k], R.order[k]);
+    for (uint64_t k = 0; k < n; ++k) {
+        const uint32_t r = order[k];
+        AvkDevRegion h = pb.regions[r];
+        h.orig = r;
+        const AvkDevRegion &d = R.regions[k];
+        if (h.ref_off != d.ref_off || h.len != d.len || h.v_off != d.v_off || h.t_cnt != d.t_cnt || h.q_cnt != d.q_cnt || h.pre_status != d.pre_status || h.seq_stride != d.seq_stride ||
+            h.seq_off != d.seq_off || h.blob_bytes != d.blob_bytes || h.alle_bytes != d.alle_bytes || h.grow != d.grow || h.orig != d.orig || h.ed_bound != d.ed_bound)
+            return say("record of region %u differs: host ref %llu len %u v_off %u t %u q %u pre %x stride %u seq_off %llu blob %u alle %u grow %u ed %u | device ref %llu len %u v_off %u t %u q %u pre %x "
+                       "stride %u seq_off %llu blob %u alle %u grow %u ed %u",
+                       r, (unsigned long long)h.ref_off, h.len, h.v_off, h.t_cnt, h.q_cnt, h.pre_status, h.seq_stride, (unsigned long long)h.seq_off, h.blob_bytes, h.alle_bytes, h.grow, h.ed_bound,
+                       (unsigned long long)d.ref_off, d.len, d.v_off, d.t_cnt, d.q_cnt, d.pre_status, d.seq_stride, (unsigned long long)d.seq_off, d.blob_bytes, d.alle_bytes, d.grow, d.ed_bound);
+        if (h.blob_bytes && memcmp(pb.blob.data() + 2ull * h.blob_off, R.blob.data() + 2ull * d.blob_off, h.blob_bytes) != 0) {
+            const uint8_t *x = (const uint8_t *)(pb.blob.data() + 2ull * h.blob_off), *y = (const uint8_t *)(R.blob.data() + 2ull * d.blob_off);
+            uint32_t at = 0;
+            while (x[at] == y[at]) ++at;
+            return say("blob of region %u (%u + %u calls, %u bytes) differs at byte %u: host %02x, device %02x", r, h.t_cnt, h.q_cnt, h.blob_bytes, at, x[at], y[at]);
+        }
+    }
+    if (plan.n_fast_total) {
+        uint64_t word_base[AVK_FAST_CLASSES];
+        uint32_t n_tiles[AVK_FAST_CLASSES];
+        const avk::PodVec<uint32_t> fast = avk::build_fast_records(pb, order, plan, word_base, n_tiles);
+        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) {
+            if (n_tiles[fc] != R.st.fast_tiles[fc] || (n_tiles[fc] && word_base[fc] != R.st.fast_word_base[fc]))
+                return say("fast records of class %d: host %u tiles at word %llu, device %u tiles at word %llu", fc, n_tiles[fc], (unsigned long long)word_base[fc], R.st.fast_tiles[fc],
+                           (unsigned long long)R.st.fast_word_base[fc]);
+            const uint64_t words = (uint64_t)n_tiles[fc] * AVK_FAST_WORDS_OF(AVK_FAST_CLASS[fc].maxv) * 64u;
+            for (uint64_t w = 0; w < words; ++w)
+                if (fast[word_base[fc] + w] != R.fast[word_base[fc] + w])
+                    return say("fast record word %llu of class %d differs: host %08x, device %08x", (unsigned long long)w, fc, fast[word_base[fc] + w], R.fast[word_base[fc] + w]);
+        }
+    }
+    return 0;
+}
+
+/* dp_myers64 / dp_variant's alt_ed against the host's edit distance */
+uint32_t emu_devpack_alt_ed(const uint8_t *a0, uint32_t l0, const uint8_t *a1, uint32_t l1, int *pending) {
+    std::vector<uint8_t> bytes(l0 + l1 + 1);
+    memcpy(bytes.data(), a0, l0);
+    memcpy(bytes.data() + l0, a1, l1);
+    const uint64_t o0 = 0, o1 = l0;
+    dpk::DpArgs a;
+    memset(&a, 0, sizeof(a));
+    a.in.a0_off = &o0, a.in.a1_off = &o1, a.in.a0_len = &l0, a.in.a1_len = &l1, a.in.alleles = bytes.data(), a.in.alleles_len = l0 + l1, a.in.n_variants = 1;
+    dpk::DpVarInfo vi;
+    dpk::DpState st;
+    memset(&st, 0, sizeof(st));
+    uint32_t pend[2];
+    a.vinfo = &vi, a.st = &st, a.pending = pend;
+    dpk::dp_variant(a, 0);
+    *pending = (vi.flags & dpk::DP_VF_PENDING) ? 1 : 0;
+    return vi.alt_ed;
+}
 #ifdef AVK_LANE_STATS
 void emu_lane_work(uint32_t *per_region) { avk::lane::g_lane_work = per_region; }
 void emu_lane_stats(uint64_t *out, int reset) {

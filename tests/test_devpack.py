@@ -1,0 +1,205 @@
+"""The device-side batch packer (aardvark_amd/csrc/avk_devpack.inl: validation, Variant::alt_ed, lane classes and cost keys, work plan, work order, fast
+records, region records and blobs — all as kernels on the caller's arrays) against the host-side packer it replaces (avk_pack.h), record by record, and
+end to end against the oracle.  The device functions run here through the kernel-logic emulator (tests/emu: the same source, the workgroup plumbing as
+plain loops); the GPU runs of the same code are in test_gpu_devpack.py."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib
+import scenarios
+from aardvark_amd import RegionBatch, synth
+from aardvark_amd._abi import AvkRegionBatch
+from oracle_lib import u8p, u64p
+
+
+def _lib():
+    lib = emu_lib.load()
+    lib.emu_devpack_compare.argtypes = [C.POINTER(AvkRegionBatch), u64p, C.c_uint32, C.c_int, C.c_uint64, C.c_uint64, C.c_uint32, C.c_uint32, C.c_char_p, C.c_size_t]
+    lib.emu_devpack_alt_ed.argtypes = [u8p, C.c_uint32, u8p, C.c_uint32, C.POINTER(C.c_int)]
+    lib.emu_devpack_alt_ed.restype = C.c_uint32
+    lib.emu_set_device_pack.argtypes = [C.c_int]
+    return lib
+
+
+def same_as_host_packer(batch, contig_lens, pairs=False, lane_min_regions=0, lane_min_batch=0, lane_max_est=15, solo_min_variants=5):
+    lib = _lib()
+    lens = np.asarray(contig_lens, np.uint64)
+    msg = C.create_string_buffer(2048)
+    cb = batch.c_struct()
+    rc = lib.emu_devpack_compare(C.byref(cb), lens.ctypes.data_as(u64p), len(lens), 1 if pairs else 0, lane_min_regions, lane_min_batch, lane_max_est, solo_min_variants, msg, 2048)
+    assert rc == 0, msg.value.decode()
+
+
+def lens_of(contigs):
+    return [len(c) for c in contigs]
+
+
+def test_alt_ed_equals_host_edit_distance():
+    """dp_variant's alt_ed (prefix / suffix strip + the 64-bit bit-vector recurrence) == avk_edit_distance (the host packer's, == oracle wfa_ed)"""
+    import aardvark_amd
+    lib = _lib()
+    host = aardvark_amd.load_library()
+    rng = np.random.default_rng(7)
+    pend = C.c_int(0)
+    n_checked = 0
+    for it in range(4000):
+        kind = it % 5
+        if kind == 0:  # unrelated strings, lengths 1..70
+            a = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 70))).astype(np.uint8))
+            b = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 70))).astype(np.uint8))
+        elif kind == 1:  # a mutated copy (few edits), up to 300 symbols
+            a = bytearray(rng.choice(list(b"ACGT"), size=int(rng.integers(2, 300))).astype(np.uint8))
+            b = bytearray(a)
+            for _ in range(int(rng.integers(0, 6))):
+                p = int(rng.integers(0, len(b)))
+                op = int(rng.integers(0, 3))
+                if op == 0:
+                    b[p] = b"ACGT"[int(rng.integers(0, 4))]
+                elif op == 1 and len(b) > 1:
+                    del b[p]
+                else:
+                    b.insert(p, b"ACGT"[int(rng.integers(0, 4))])
+            a, b = bytes(a), bytes(b)
+        elif kind == 2:  # two-letter alphabet: many equally good alignments
+            a = bytes(rng.choice(list(b"AC"), size=int(rng.integers(1, 64))).astype(np.uint8))
+            b = bytes(rng.choice(list(b"AC"), size=int(rng.integers(1, 200))).astype(np.uint8))
+        elif kind == 3:  # exactly 64 / 65 symbols on the short side (the width of the bit vector)
+            a = bytes(rng.choice(list(b"ACGTN"), size=int(rng.choice([63, 64, 65]))).astype(np.uint8))
+            b = bytes(rng.choice(list(b"ACGTN"), size=int(rng.integers(60, 120))).astype(np.uint8))
+        else:  # normalised indels
+            a = bytes(rng.choice(list(b"ACGT"), size=1).astype(np.uint8))
+            b = a + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 40))).astype(np.uint8))
+            if it % 2:
+                a, b = b, a
+        a0 = np.frombuffer(a, np.uint8)
+        a1 = np.frombuffer(b, np.uint8)
+        got = lib.emu_devpack_alt_ed(a0.ctypes.data_as(u8p), len(a), a1.ctypes.data_as(u8p), len(b), C.byref(pend))
+        if pend.value:
+            continue  # both stripped alleles longer than 64: left to the host by design
+        want = host.avk_edit_distance(a, len(a), b, len(b))
+        assert got == want, (a, b, got, want)
+        n_checked += 1
+    assert n_checked > 3500
+
+
+def test_reference_known_answer_regions():
+    contigs, batch = scenarios.golden()
+    same_as_host_packer(batch, lens_of(contigs))
+    same_as_host_packer(batch, lens_of(contigs), lane_min_regions=0xFFFFFFFF)
+    same_as_host_packer(batch, lens_of(contigs), pairs=True)
+
+
+@pytest.mark.parametrize("seed,kw", [(201, {}), (202, {"repeat_unit": b"CA", "max_vars": 3}), (203, {"max_vars": 9, "max_len": 12}), (204, {"max_len": 40, "span": (20, 250)}),
+                                     (205, {"alphabet": b"ACGTN", "max_vars": 3})])
+def test_fuzz_regions_pack_identically(seed, kw):
+    contigs, batch = scenarios.fuzz_regions(seed, 1500, **kw)
+    same_as_host_packer(batch, lens_of(contigs))
+    same_as_host_packer(batch, lens_of(contigs), lane_max_est=3, solo_min_variants=3)
+    same_as_host_packer(batch, lens_of(contigs), pairs=True)
+
+
+def test_benchmark_mix_packs_identically():
+    """the features of the benchmark genome; with the production thresholds for the lane classes (some classes too small for a launch) and without"""
+    contig, batch = synth.config_indel_mix_v2(n_truth=30_000, contig_len=12_000_000)
+    same_as_host_packer(batch, [len(contig)])
+    same_as_host_packer(batch, [len(contig)], lane_min_regions=512, lane_min_batch=1000)
+    same_as_host_packer(batch, [len(contig)], lane_min_regions=8192, lane_min_batch=65536)
+
+
+def test_invalid_long_and_odd_inputs_pack_identically():
+    for sc in (scenarios.invalid_regions(), scenarios.long_allele_regions(), scenarios.non_acgt_regions(), scenarios.autofail_regions(), scenarios.quota_regions(3),
+               scenarios.max_allele_regions(), scenarios.optimizer_golden_regions()):
+        contigs, batch = sc[0], sc[1]
+        same_as_host_packer(batch, lens_of(contigs))
+        same_as_host_packer(batch, lens_of(contigs), pairs=True)
+
+
+def test_large_regions_go_through_the_wave_writer():
+    """more than 48 calls in a region: the blob is written by a whole wave (prefix sums over lanes, ranks by binary search)"""
+    rng = np.random.default_rng(11)
+    contig = bytes(rng.choice(list(b"ACGT"), size=60_000).astype(np.uint8))
+    regions = []
+    for k in range(6):
+        start, end = 1000 + 9000 * k, 1000 + 9000 * k + 8000
+        def calls(n):
+            pos = np.sort(rng.choice(np.arange(start + 5, end - 40), size=n, replace=k % 2 == 0))
+            out = []
+            for p in pos:
+                p = int(p)
+                kind = int(rng.integers(0, 3))
+                if kind == 0:
+                    out.append((p, contig[p:p + 1], bytes([b"ACGT"[(b"ACGT".index(contig[p]) + 1) % 4]]), "Snv", scenarios.ZY[int(rng.integers(0, 4))]))
+                elif kind == 1:
+                    out.append((p, contig[p:p + 1], contig[p:p + 1] + bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 30))).astype(np.uint8)), "Insertion", scenarios.ZY[int(rng.integers(0, 4))]))
+                else:
+                    d = int(rng.integers(2, 20))
+                    out.append((p, contig[p:p + d], contig[p:p + 1], "Deletion", scenarios.ZY[int(rng.integers(0, 4))]))
+            return out
+        regions.append({"start": start, "end": end, "truth": calls(int(rng.integers(49, 300))), "query": calls(int(rng.integers(1, 300)))})
+    batch = RegionBatch.from_regions(regions)
+    same_as_host_packer(batch, [len(contig)])
+
+
+def test_batch_level_errors_match():
+    contigs, batch = scenarios.fuzz_regions(31, 50)
+    bad = RegionBatch(batch.region_id, batch.contig_idx, batch.start, batch.end, batch.t_off, batch.t_cnt.copy(), batch.q_off, batch.q_cnt, batch.var_pos, batch.var_type,
+                      batch.var_zyg, batch.var_raw_space, batch.a0_off, batch.a0_len, batch.a1_off, batch.a1_len, batch.allele_bytes)
+    bad.t_cnt[7] = 0x80000000
+    same_as_host_packer(bad, lens_of(contigs))
+    bad2 = RegionBatch(batch.region_id, batch.contig_idx, batch.start, batch.end, batch.t_off, batch.t_cnt, batch.q_off, batch.q_cnt, batch.var_pos, batch.var_type,
+                       batch.var_zyg, batch.var_raw_space, batch.a0_off, batch.a0_len, batch.a1_off.copy(), batch.a1_len, batch.allele_bytes)
+    used = int(batch.t_off[3]) if batch.t_cnt[3] else int(batch.q_off[3])
+    bad2.a1_off[used] = batch.allele_bytes.size + 5
+    same_as_host_packer(bad2, lens_of(contigs))
+
+
+@pytest.mark.parametrize("lane_kernel", [True, False])
+def test_end_to_end_through_the_emulator_equals_oracle(oracle, lane_kernel):
+    """device-packed batch -> solver kernels -> dp_unpack: every output array equals the oracle's"""
+    lib = _lib()
+    lib.emu_set_device_pack(1)
+    try:
+        contigs, batch = scenarios.golden()
+        got = emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel, n_waves=2)
+        assert got.diff(oracle_lib.compare_batch(oracle, batch, contigs)) == []
+        contig, batch = synth.config_indel_mix_v2(n_truth=3000, contig_len=1_500_000)
+        got = emu_lib.compare_batch(batch, [contig], lane_kernel=lane_kernel, n_waves=16)
+        assert got.diff(oracle_lib.compare_batch(oracle, batch, [contig], threads=4)) == []
+        if lane_kernel:
+            assert got.lane_solved > 0.9 * batch.n_regions
+        for contigs, batch in (scenarios.fuzz_regions(41, 300, max_vars=6), scenarios.invalid_regions(), scenarios.non_acgt_regions()):
+            got = emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel)
+            assert got.diff(oracle_lib.compare_batch(oracle, batch, contigs, threads=4)) == []
+        contigs, batch = scenarios.fuzz_regions(43, 300, max_vars=3, related=0.9)
+        st, ex = emu_lib.optimize_pairs(batch, contigs)
+        lib.emu_set_device_pack(0)
+        st0, ex0 = emu_lib.optimize_pairs(batch, contigs)
+        assert np.array_equal(st, st0) and np.array_equal(ex, ex0)
+    finally:
+        lib.emu_set_device_pack(0)
+
+
+def test_long_unrelated_alleles_take_the_host_edit_distance():
+    """both alleles longer than 64 symbols after the common prefix and suffix are gone: alt_ed comes from the host and the region passes run again"""
+    rng = np.random.default_rng(5)
+    contig = bytes(rng.choice(list(b"ACGT"), size=5000).astype(np.uint8))
+    regions = []
+    for k in range(5):
+        start = 200 + 900 * k
+        p = start + 50
+        ref = contig[p:p + 150 + 10 * k]
+        alt = bytes(rng.choice(list(b"ACGT"), size=120 + 7 * k).astype(np.uint8))
+        v = (p, ref, alt, "Indel", "HomozygousAlternate")
+        regions.append({"start": start, "end": start + 600, "truth": [v, (p + 300, contig[p + 300:p + 301], b"T" if contig[p + 300] != ord("T") else b"G", "Snv", "UnphasedHeterozygous")],
+                        "query": [v] if k % 2 else []})
+    batch = RegionBatch.from_regions(regions)
+    lib = _lib()
+    a0 = np.frombuffer(regions[0]["truth"][0][1], np.uint8)
+    a1 = np.frombuffer(regions[0]["truth"][0][2], np.uint8)
+    pend = C.c_int(0)
+    lib.emu_devpack_alt_ed(a0.ctypes.data_as(u8p), len(a0), a1.ctypes.data_as(u8p), len(a1), C.byref(pend))
+    assert pend.value == 1
+    same_as_host_packer(batch, [len(contig)])

@@ -1,0 +1,150 @@
+"""The device-side packer on the GPU (aardvark_amd/csrc/avk_devpack.inl behind avk_batch_upload / avk_compare_batch): the same batches through
+device_pack = 1 (default) and device_pack = 0 (host packer, avk_pack.h) against the oracle; pinned and pageable caller arrays; the pair form; the
+capacity retry and the sequence outputs of a device-packed batch (they fetch the packed records back).  tests/test_devpack.py runs the packer's
+device functions on the CPU against the host packer record by record."""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scenarios
+from aardvark_amd import CompareConfig, RegionBatch, synth
+
+pytestmark = pytest.mark.gpu
+CPUS = 8
+
+
+@pytest.fixture(scope="module")
+def ctx_pair():
+    import aardvark_amd
+    dev, host = aardvark_amd.Context(0), aardvark_amd.Context(0)
+    host.set_option("device_pack", 0)
+    yield dev, host
+    dev.close()
+    host.close()
+
+
+def check(ctx_pair, oracle, contigs, batch, sequences=False, group_metrics=True, **okw):
+    want = oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS, sequences=sequences, group_metrics=group_metrics, **okw)
+    for c in ctx_pair:
+        c.upload_reference(contigs)
+        got = c.solve_compare_regions(batch, CompareConfig(enable_sequences=sequences, **okw), group_metrics=group_metrics)
+        assert got.diff(want) == []
+    assert ctx_pair[0].last_compare_was_one_shot() and not ctx_pair[1].last_compare_was_one_shot()
+    return want
+
+
+def test_known_answer_regions_with_sequences(ctx_pair, oracle):
+    contigs, batch = scenarios.golden()
+    check(ctx_pair, oracle, contigs, batch, sequences=True)
+    check(ctx_pair, oracle, contigs, batch, sequences=False, group_metrics=False)
+
+
+@pytest.mark.parametrize("seed,kw", [(301, {}), (302, {"repeat_unit": b"CA", "max_vars": 3}), (303, {"max_vars": 9, "max_len": 12}), (304, {"alphabet": b"ACGTN", "max_vars": 3})])
+def test_fuzz_regions(ctx_pair, oracle, seed, kw):
+    contigs, batch = scenarios.fuzz_regions(seed, 3000, **kw)
+    check(ctx_pair, oracle, contigs, batch)
+
+
+def test_invalid_long_and_odd_inputs(ctx_pair, oracle):
+    for sc in (scenarios.invalid_regions(), scenarios.long_allele_regions(), scenarios.non_acgt_regions(), scenarios.max_allele_regions()):
+        check(ctx_pair, oracle, sc[0], sc[1], sequences=True)
+
+
+def test_quota_and_autofail(ctx_pair, oracle):
+    contigs, batch = scenarios.autofail_regions()
+    check(ctx_pair, oracle, contigs, batch)
+    contigs, batch, _ = scenarios.quota_regions(3)
+    check(ctx_pair, oracle, contigs, batch, max_branch_factor=3)
+
+
+def test_benchmark_contig_pinned_and_pageable(ctx_pair, oracle):
+    """one chr20-sized contig of the benchmark workload at full density, N-sprinkled: pageable arrays (bounce buffer) and pinned arrays (avk_host_alloc,
+    direct DMA) give the same outputs; resident form too"""
+    contig, batch = synth.config_indel_mix_v2(n_truth=int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38)), contig_len=synth.CHR20_LEN)
+    contig = contig.copy()
+    rng = np.random.default_rng(5)
+    contig[rng.integers(0, contig.size, size=contig.size // 5000)] = ord("N")
+    want = check(ctx_pair, oracle, [contig], batch, group_metrics=False)
+    dev = ctx_pair[0]
+    assert 0.8 * batch.n_regions < dev.last_lane_solved() < batch.n_regions
+    import ctypes as C
+    pb = dev.pinned_batch(batch)
+    res = dev.pinned_results(pb)
+    cb, cfg, ro = pb.c_struct(), CompareConfig(enable_sequences=False).c_struct(), res.c_struct()
+    dev.set_option("emit_group_metrics", 0)
+    for _ in range(2):
+        res.status[:] = -7
+        dev._check(dev.lib.avk_compare_batch(dev.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
+        assert res.diff(want) == []
+    dev.set_option("emit_group_metrics", 1)
+    rb = dev.upload(batch)
+    for _ in range(2):
+        dev.compare_resident(rb, CompareConfig(enable_sequences=False))
+    assert dev.download(rb, group_metrics=True).diff(oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS)) == []
+    rb.free()
+
+
+def test_pair_form(ctx_pair, oracle):
+    for contigs, batch in (scenarios.fuzz_regions(331, 4000, max_vars=3, related=0.9), scenarios.invalid_regions(), scenarios.fuzz_regions(332, 2000, max_vars=7, related=0.95)):
+        st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs, threads=CPUS)
+        for c in ctx_pair:
+            c.upload_reference(contigs)
+            st, ex = c.optimize_pairs(batch)
+            assert np.array_equal(st_o, st) and np.array_equal(ex_o, ex)
+
+
+def test_capacity_retry_of_a_device_packed_batch(oracle):
+    """tiny workspaces: regions fail with CAPACITY on the device and are solved again by avk_results_download, which fetches the packed records of
+    a device-packed batch for that"""
+    import aardvark_amd
+    ctx = aardvark_amd.Context(0)
+    try:
+        for k, v in dict(lds_bytes_per_wave=2048, lds2_bytes_per_wave=0, ws_bytes_per_wave=0, big_ws_bytes=4096).items():
+            ctx.set_option(k, v)
+        contigs, batch = scenarios.fuzz_regions(341, 400, max_vars=9, max_len=12)
+        ctx.upload_reference(contigs)
+        got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False))
+        want = oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS)
+        assert got.diff(want) == []
+        ctx.set_option("capacity_retry", 0)
+        starved = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False))
+        assert (starved.status == 21).any()  # some regions do exhaust the last tier on the first try
+    finally:
+        ctx.close()
+
+
+def test_batch_level_errors(ctx_pair):
+    from aardvark_amd.api import AardvarkAmdError
+    contigs, batch = scenarios.fuzz_regions(351, 50)
+    bad = RegionBatch(batch.region_id, batch.contig_idx, batch.start, batch.end, batch.t_off, batch.t_cnt.copy(), batch.q_off, batch.q_cnt, batch.var_pos, batch.var_type,
+                      batch.var_zyg, batch.var_raw_space, batch.a0_off, batch.a0_len, batch.a1_off, batch.a1_len, batch.allele_bytes)
+    bad.t_cnt[7] = 0x80000000
+    for c in ctx_pair:
+        c.upload_reference(contigs)
+        with pytest.raises(AardvarkAmdError, match="variant range"):
+            c.solve_compare_regions(bad, CompareConfig(enable_sequences=False))
+        assert c.solve_compare_regions(batch, CompareConfig(enable_sequences=False)).status.min() >= 0  # the context is fine afterwards
+
+
+def test_packed_reference_off_with_lane_sized_batch(oracle):
+    """use_packed_reference = 0 on a batch large enough for lane launches: the lanes (which read the 2-bit reference only) are not used"""
+    import aardvark_amd
+    contig, batch = synth.config_indel_mix_v2(n_truth=60_000, contig_len=24_000_000)
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=False)
+    for dp in (1, 0):
+        ctx = aardvark_amd.Context(0)
+        try:
+            ctx.set_option("device_pack", dp)
+            ctx.set_option("lane_min_batch", 0)
+            ctx.set_option("lane_min_regions", 0)
+            ctx.set_option("emit_group_metrics", 0)
+            ctx.upload_reference([contig])
+            rb = ctx.upload(batch)  # planned with the lanes on
+            ctx.set_option("use_packed_reference", 0)
+            ctx.compare_resident(rb, CompareConfig(enable_sequences=False))
+            got = ctx.download(rb, group_metrics=False)
+            assert got.diff(want) == []
+            assert ctx.last_lane_solved() == 0
+            rb.free()
+        finally:
+            ctx.close()

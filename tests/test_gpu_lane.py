@@ -96,9 +96,9 @@ def test_merge_pairs_on_lanes(ctxs, oracle):
 
 
 def test_one_shot_path_equals_resident_path(ctxs, oracle):
-    """avk_compare_batch on a large batch without per-region blocks takes the one-shot path (avk_stream.inl: fast records written straight
-    into pinned memory, general and handed-back regions through gathered sub-batches): every output equals the oracle's and the resident
-    path's; windows with other symbols and regions beyond the lane classes are in the batch"""
+    """avk_compare_batch (host arrays in, host arrays out; the batch is packed on the device, avk_devpack.inl) on a chr20-sized contig of the
+    benchmark workload: every output equals the oracle's and the resident path's, with the lane kernel and without; windows with other symbols
+    and regions beyond the lane classes are in the batch"""
     from aardvark_amd import CompareConfig
     contig, batch = synth.config_indel_mix_v2(n_truth=int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38)), contig_len=synth.CHR20_LEN)
     contig = contig.copy()
@@ -114,7 +114,8 @@ def test_one_shot_path_equals_resident_path(ctxs, oracle):
     assert got.diff(want) == []
     assert 0.8 * batch.n_regions < on.last_lane_solved() < batch.n_regions
     res = off.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False)
-    assert not off.last_compare_was_one_shot()
+    assert off.last_compare_was_one_shot()
+    assert off.last_lane_solved() == 0
     assert res.diff(want) == []
     rb = on.upload(batch)
     on.compare_resident(rb, CompareConfig(enable_sequences=False))
@@ -153,8 +154,8 @@ def test_scheduling_options_do_not_change_results(oracle, opts):
 
 
 def test_merge_pairs_one_shot_path(ctxs, oracle):
-    """avk_optimize_pairs_batch on a large batch takes the one-shot path too (mode 1 of avk_stream.inl): status and exact-match flag of every
-    pair equal the oracle's and the resident path's (lane kernel off)"""
+    """avk_optimize_pairs_batch on a chr20-sized batch (packed on the device in the pair form, results unpacked on the device): status and
+    exact-match flag of every pair equal the oracle's, with the lane kernel and without"""
     contig, batch = synth.config_indel_mix_v2(n_truth=int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38)), contig_len=synth.CHR20_LEN)
     contig = contig.copy()
     rng = np.random.default_rng(6)
