@@ -70,6 +70,8 @@ def load_library():
     lib.avk_debug_phase_cycles.argtypes = [vp, u64p]
     lib.avk_algorithmic_bytes.restype = C.c_uint64
     lib.avk_algorithmic_bytes.argtypes = [C.POINTER(AvkRegionBatch)]
+    lib.avk_algorithmic_bytes_ex.restype = C.c_uint64
+    lib.avk_algorithmic_bytes_ex.argtypes = [C.POINTER(AvkRegionBatch), C.c_int]
     lib.avk_optimize_pairs_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.c_uint32, C.POINTER(C.c_int32), u8p]
     lib.avk_host_alloc.restype = vp
     lib.avk_host_alloc.argtypes = [vp, C.c_size_t]
@@ -273,6 +275,6 @@ class Context:
                                                       status.ctypes.data_as(C.POINTER(C.c_int32)), exact.ctypes.data_as(u8p)))
         return status, exact[:batch.n_regions]
 
-    def algorithmic_bytes(self, batch):
+    def algorithmic_bytes(self, batch, with_groups=True):
         cb = batch.c_struct()
-        return int(self.lib.avk_algorithmic_bytes(C.byref(cb)))
+        return int(self.lib.avk_algorithmic_bytes_ex(C.byref(cb), 1 if with_groups else 0))

@@ -694,30 +694,31 @@ uint32_t avk_seq_stride(const avk_region_batch *batch, uint64_t r) {
     return avk::seq_stride_of(batch, r);
 }
 
-uint64_t avk_algorithmic_bytes(const avk_region_batch *b) {
-    /* DESIGN.md "algorithmic bytes per region": 2-bit window + 12 B record and 2-bit alleles per
-     * variant + 16 B header in; 16 B + 2 B per variant + 16 B joint BASEPAIR and 16 B per variant
-     * type present out */
+/* DESIGN.md "algorithmic bytes per region" (SURVEY.md 8d): in — 2-bit window, 12 B record and 2-bit alleles per call, 16 B header; out — 16 B
+ * record, 2 B per call and, when the run writes per-region BASEPAIR groups (with_groups), 16 B for the joint group and 16 B per call type present */
+uint64_t avk_algorithmic_bytes_ex(const avk_region_batch *b, int with_groups) {
     if (!b) return 0;
     uint64_t total = 0;
     for (uint64_t r = 0; r < b->n_regions; ++r) {
         uint64_t L = b->end[r] > b->start[r] ? b->end[r] - b->start[r] : 0;
-        uint64_t bytes = (L + 3) / 4 + 16 + 16 + 16;
+        uint64_t bytes = (L + 3) / 4 + 16 + 16 + (with_groups ? 16 : 0);
         uint32_t types = 0;
         for (int side = 0; side < 2; ++side) {
             uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
             uint32_t cnt = side == 0 ? b->t_cnt[r] : b->q_cnt[r];
+            if (off > b->n_variants || cnt > b->n_variants - off) continue;
             for (uint32_t i = 0; i < cnt; ++i) {
                 uint64_t v = off + i;
                 bytes += 12 + (b->a0_len[v] + 3) / 4 + (b->a1_len[v] + 3) / 4 + 2;
                 types |= 1u << (b->var_type[v] & 15);
             }
         }
-        bytes += 16ull * (uint64_t)__builtin_popcount(types);
+        if (with_groups) bytes += 16ull * (uint64_t)__builtin_popcount(types);
         total += bytes;
     }
     return total;
 }
+uint64_t avk_algorithmic_bytes(const avk_region_batch *b) { return avk_algorithmic_bytes_ex(b, 1); }
 
 static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pairs_mode, avk_dev_batch **out) {
     if (!ctx || !batch || !out) return AVK_E_ARG;

@@ -597,3 +597,91 @@ def config_indel_mix_v2(n_truth=20_000, contig_len=8_000_000, seed_ref=20250103,
     """one contig at the density and with every feature of the whole-genome workload (multi-allelic sites, shifted repeat-run indels)"""
     contig, bed, truth, query = contig_calls(19, contig_len, n_truth / contig_len, seed_ref, seed_query, **kw)
     return contig, cluster_regions_v(contig, bed, truth, query, gap)
+
+
+def cluster_multi_v(contig, bed, sets, gap=50, contig_idx=0, region_id_base=0):
+    """cluster_regions_v for k call sets of one contig: RegionIterator::next (region_generation.rs:281-478) over k inputs -> the arrays of an
+    avk_multi_batch (aardvark_amd/merge.py::MultiBatch) as a dict; input i of region m owns variants [in_off[m*k+i], +in_cnt[m*k+i])"""
+    k = len(sets)
+    contig_len = contig.size
+    pos = np.concatenate([s.pos for s in sets])
+    rlen = np.concatenate([s.ref_len for s in sets])
+    side = np.concatenate([np.full(len(s), i, np.int8) for i, s in enumerate(sets)])
+    local = np.concatenate([np.arange(len(s)) for s in sets])
+    order = np.argsort(pos, kind="stable")
+    pos, rlen, side, local = pos[order], rlen[order], side[order], local[order]
+    kb = np.searchsorted(bed[:, 0], pos, side="right") - 1
+    ok = kb >= 0
+    kk = np.clip(kb, 0, None)
+    ok &= (pos < bed[kk, 1]) & (pos + rlen <= bed[kk, 1])
+    pos, rlen, side, local, kb = pos[ok], rlen[ok], side[ok], local[ok], kb[ok]
+    n = pos.size
+    flank_end = np.minimum(pos + rlen + gap, contig_len)
+    big = np.int64(1) << 40
+    seg_max = np.maximum.accumulate(flank_end + kb * big) - kb * big
+    brk = np.ones(n, bool)
+    brk[1:] = (kb[1:] != kb[:-1]) | (pos[1:] >= seg_max[:-1])
+    win = np.cumsum(brk) - 1
+    nwin = int(win[-1]) + 1 if n else 0
+    first = np.nonzero(brk)[0]
+    w_start = np.maximum(pos[first] - gap, 0)
+    w_end = np.maximum.reduceat(flank_end, first) if n else np.zeros(0, np.int64)
+    vorder = np.lexsort((np.arange(n), side, win))
+    side_s, local_s, win_s = side[vorder].astype(np.int64), local[vorder], win[vorder]
+    in_cnt = np.bincount(win_s * k + side_s, minlength=nwin * k)
+    in_off = np.cumsum(in_cnt) - in_cnt
+    pool_base = np.cumsum([0] + [s.pool.size for s in sets])
+    pool = np.concatenate([s.pool for s in sets])
+
+    def pick(f):
+        out = np.zeros(n, getattr(sets[0], f).dtype)
+        for i, s in enumerate(sets):
+            m = side_s == i
+            out[m] = getattr(s, f)[local_s[m]]
+        return out
+
+    vpos, vref, vanchor, valt_len = pick("pos"), pick("ref_len"), pick("anchor"), pick("alt_len")
+    valt_off = pick("alt_off") + pool_base[side_s]
+    a0_len, a1_len = vref, vanchor + valt_len
+    a0_off = np.cumsum(a0_len + a1_len) - (a0_len + a1_len)
+    a1_off = a0_off + a0_len
+    arena = np.zeros(int((a0_len + a1_len).sum()), np.uint8)
+    d, _ = _ragged(a0_off, a0_len)
+    s_, _ = _ragged(vpos, a0_len)
+    arena[d] = contig[s_]
+    has = vanchor > 0
+    arena[a1_off[has]] = contig[vpos[has]]
+    d, _ = _ragged(a1_off + vanchor, valt_len)
+    s_, _ = _ragged(valt_off, valt_len)
+    arena[d] = pool[s_]
+    return dict(region_id=np.arange(nwin) + region_id_base, contig_idx=np.full(nwin, contig_idx), start=w_start, end=w_end, in_off=in_off, in_cnt=in_cnt, var_pos=vpos,
+                var_type=pick("vtype"), var_zyg=pick("zyg"), var_raw_space=np.maximum(a0_len, a1_len), a0_off=a0_off, a0_len=a0_len, a1_off=a1_off, a1_len=a1_len,
+                allele_bytes=arena)
+
+
+def config_genome_merge(scale=1.0, k=3, seed_ref=20250103, seeds=(20250105, 20250106, 20250107), gap=50, threads=8, n_truth=HG002_TRUTH_CALLS):
+    """BASELINE.json configs[4] stand-in: k perturbed call sets of one hidden truth set on the 24 contigs of the compare
+    workload (seeds 20250105-7) -> (contigs, MultiBatch)"""
+    from concurrent.futures import ThreadPoolExecutor
+    from .merge import MultiBatch
+    density = n_truth / sum(GRCH38)
+    lengths = [max(int(l * scale), 200_000) for l in GRCH38]
+
+    def one(ci):
+        contig = make_contig_fast(lengths[ci], seed_ref + ci)
+        rng = np.random.default_rng(seed_ref + 100 + ci)
+        bed = make_bed(lengths[ci], max(4, int(1000 * lengths[ci] / CHR20_LEN)), 0.9, rng)
+        truth, info = genome_truth(contig, bed, max(1, int(lengths[ci] * density)), seed_ref + 200 + ci)
+        sets = [genome_query(contig, bed, truth, info, seeds[i % len(seeds)] + 1000 * (i // len(seeds)) + ci, max(1, len(truth) // 100)) for i in range(k)]
+        return contig, cluster_multi_v(contig, bed, sets, gap, contig_idx=ci)
+
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        parts = list(ex.map(one, range(len(lengths))))
+    ds = [p[1] for p in parts]
+    voff = np.cumsum([0] + [d["var_pos"].size for d in ds])
+    aoff = np.cumsum([0] + [d["allele_bytes"].size for d in ds])
+    roff = np.cumsum([0] + [d["start"].size for d in ds])
+    cat = lambda f, sh=None: np.concatenate([d[f] + (sh[i] if sh is not None else 0) for i, d in enumerate(ds)])
+    return [p[0] for p in parts], MultiBatch(k, region_id=cat("region_id", roff), contig_idx=cat("contig_idx"), start=cat("start"), end=cat("end"), in_off=cat("in_off", voff),
+                                             in_cnt=cat("in_cnt"), var_pos=cat("var_pos"), var_type=cat("var_type"), var_zyg=cat("var_zyg"), var_raw_space=cat("var_raw_space"),
+                                             a0_off=cat("a0_off", aoff), a0_len=cat("a0_len"), a1_off=cat("a1_off", aoff), a1_len=cat("a1_len"), allele_bytes=cat("allele_bytes"))

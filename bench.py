@@ -1,29 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the compare hot path on MI355X.
 
-Workload (default): the stand-in for BASELINE.json configs[2] "HG002 GIAB v4.2.1 truth vs DeepVariant query, GRCh38, SNV+indel,
-1xMI355X" — the configuration the metric is quoted on; the real GIAB files are not available offline, so the call sets are synthetic
-(aardvark_amd/synth.py::config_genome): 24 contigs with GRCh38 primary lengths (3.1 Gbp), 3.9 M truth calls
-(82 % SNV, 9 % insertion, 9 % deletion, 3 % of the sites within 30 bp of another, 2 % multi-allelic, 5 % of the indels in a repeat run with
-the query record shifted by whole units), query = truth with 1 % dropped / 0.5 % zygosity flips / 0.5 % ALT changes / 1 % extra calls,
-seeds 20250103/4: about 3.57 M regions.
+Workload (default): the stand-in for BASELINE.json configs[2] "HG002 GIAB v4.2.1 truth vs DeepVariant query, GRCh38, SNV+indel, 1xMI355X" — the
+configuration the metric is quoted on; the real GIAB files are not available offline, so the call sets are synthetic (SURVEY.md 8d config 3,
+aardvark_amd/synth.py::config_genome): 24 contigs with GRCh38 primary lengths (3.1 Gbp), 3.9 M truth calls (82 % SNV, 9 % insertion, 9 % deletion, 3 %
+of the sites within 30 bp of another, 2 % multi-allelic, 5 % of the indels in a repeat run with the query record shifted by whole units), query = truth
+with 1 % dropped / 0.5 % zygosity flips / 0.5 % ALT changes / 1 % extra calls, seeds 20250103/4: about 3.57 M regions.
 
-One step = one pass of the per-region solver (phasing search + genotype assignment + metrics, reference solve_compare_region,
-src/waffle_solver.rs:122; the rayon loop of src/main.rs:251-268) over the whole resident batch; every step adds its per-category tallies
-to the job total on the device.  `value` = regions/s of the timed steps with the inputs (reference genome, region batch) resident in HBM.
-Beside it, in the same JSON line:
-  host_boundary   the rate of avk_compare_batch on the same batch: region batch in host memory -> packing -> H2D -> kernels -> D2H ->
-                  per-region records, per-variant decisions and tally in the caller's host arrays (the boundary of the reference's loop,
-                  SURVEY.md 8d);
+One step = ONE CALL of avk_compare_batch: the reference's rayon loop over solve_compare_region (src/main.rs:251-268, src/waffle_solver.rs:122) on the
+boundary SURVEY.md 8d and BASELINE.md section 2 define — the region batch in HOST memory (pinned arrays from avk_host_alloc, which is where the Rust side
+would build its FlatBatch) -> H2D of the caller's arrays as they are -> packing kernels -> solver kernels -> unpacking kernel -> D2H -> per-region
+records, per-variant decisions and the 288-counter tally in the caller's HOST arrays.  `value` = regions/s of the timed steps on that boundary.
+In the same JSON line:
+  resident_value  regions/s of avk_compare_resident on the same batch already packed in HBM (no copies in the timed region): the kernels by themselves;
   roofline        algorithmic bytes of the batch / duration of all solver launches of a step (HIP events on the launch stream);
-  cpu_baseline    the CPU restatement of the reference algorithm (oracle/) on the usable host cores, same outputs, >= 5 s of wall time;
-  dwfa_byte_compares_per_s   base comparisons the reference algorithm makes on this batch (counted by the oracle) x steps / time;
-  secondary       the resident rate on configs[1] (synthetic chr20, 50 k SNV calls).
+  cpu_baseline    the CPU restatement of the reference algorithm (oracle/) on the usable host cores, same outputs, >= 6 s of wall time;
+  secondary       configs[1] (synthetic chr20 SNV), two robustness mixes (dense calls; --min-variant-gap 1000) and configs[4] (merge of three call sets,
+                  majority strategy, avk_merge_batch host -> host) on one GPU.
 
-N > 1 ranks (launched by torch.distributed.run, one rank per GPU): regions are independent, so there is no data-path collective; the job
-tally is summed over the ranks by ONE RCCL all-reduce inside the timed region.  `--scaling weak` (default): every rank owns a whole-genome
-call set of its own (seeds offset by the rank).  `--scaling strong`: ONE call set, rank r solves the regions with
-hash(region_id) % N == r (aardvark_amd/dist.py), the reference is replicated.
+N > 1 ranks (launched by torch.distributed.run, one rank per GPU): `--scaling strong` (the default for N > 1, the shape north_star describes): ONE call
+set, rank r solves the regions with hash(region_id) % N == r (aardvark_amd/dist.py), the reference is replicated, no data-path collective; the job
+tally is summed over the ranks by ONE RCCL all-reduce inside the timed region and the shards' per-variant decisions are checked against the
+single-process solution through an order-independent checksum.  `--scaling weak`: every rank owns a whole-genome call set of its own.
 
 Prints ONE JSON line on rank 0.
 """
@@ -31,6 +29,7 @@ import argparse
 import json
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before anything loads the HIP runtime: the solver's six streams need queues of their own (aardvark_amd/__init__.py)
+import signal
 import subprocess
 import sys
 import time
@@ -38,6 +37,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (MI355X_MICROARCH.md: 8.0 TB/s spec)
 
@@ -63,21 +63,71 @@ def usable_cpus():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=50, help="timed avk_compare_batch calls (host arrays -> host arrays)")
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--resident-steps", type=int, default=200, help="timed avk_compare_resident steps of the resident leg (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
-    ap.add_argument("--boundary-calls", type=int, default=3, help="timed avk_compare_batch calls of the host-boundary leg (0 = skip)")
-    ap.add_argument("--watchdog-seconds", type=int, default=600, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
+    ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto", help="auto = strong for N > 1 (one call set sharded over the ranks)")
+    ap.add_argument("--pageable", action="store_true", help="caller arrays in ordinary memory (the library stages them through a pinned bounce buffer) instead of avk_host_alloc memory")
+    ap.add_argument("--watchdog-seconds", type=int, default=900, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
     ap.add_argument("--no-supervisor", action="store_true",
                     help="run in this process (default for N > 1 ranks and under a profiler): otherwise the single-GPU run is a child of a thin supervisor "
                          "that has not touched the GPU, ends a run that exceeds --watchdog-seconds and starts it once more")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-merge", action="store_true", help="skip the configs[4] merge leg of `secondary`")
+    ap.add_argument("--merge-scale", type=float, default=1.0)
+    ap.add_argument("--secondary-scale", type=float, default=0.25, help="genome scale of the two robustness mixes of `secondary`")
     ap.add_argument("--no-parity", action="store_true", help="skip the bit-identity gate against the oracle")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r02_pmc_traffic.json"),
-                    help="PMC-derived HBM bytes per step collected with rocprofv3 --pmc (optional)")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r03_pmc_traffic.json"),
+                    help="PMC-derived HBM bytes per step collected with rocprofv3 --pmc in a builder-side run (optional; reported with its source)")
     return ap.parse_args()
+
+
+def supervise(args):
+    """A thin parent that has not touched the GPU: runs the benchmark as a child, forwards SIGTERM / SIGINT to the child's process group, ends a child
+    that exceeds the watchdog and starts it once more (belt: 1,012 fresh-process first steps of the library ran without a stall in round 3,
+    profiles/r03_first_steps_1012.log; the one stuck start of round 2 was never reproduced)."""
+    env = dict(os.environ, AVK_BENCH_CHILD="1")
+    state = {"child": None}
+
+    def forward(signum, _frame):
+        c = state["child"]
+        if c is not None and c.poll() is None:
+            try:
+                os.killpg(c.pid, signal.SIGKILL)
+            except Exception:
+                c.kill()
+        sys.exit(128 + signum)
+
+    signal.signal(signal.SIGTERM, forward)
+    signal.signal(signal.SIGINT, forward)
+
+    def child_setup():
+        os.setsid()
+        try:  # the child dies with the supervisor even if the supervisor is killed outright
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)  # PR_SET_PDEATHSIG
+        except Exception:
+            pass
+
+    rc = 1
+    limit = args.watchdog_seconds + 60 if args.watchdog_seconds > 0 else None
+    for attempt in range(2):
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, preexec_fn=child_setup)
+        state["child"] = child
+        try:
+            rc = child.wait(timeout=limit)
+            break
+        except subprocess.TimeoutExpired:
+            print("[bench supervisor] attempt %d exceeded %d s: ending it%s" % (attempt + 1, limit, ", starting once more" if attempt == 0 else ""), file=sys.stderr, flush=True)
+            try:
+                os.killpg(child.pid, signal.SIGKILL)
+            except Exception:
+                child.kill()
+            child.wait()
+            rc = 124
+    sys.exit(rc)
 
 
 def main():
@@ -91,28 +141,9 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29511"), os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
-    # Single-GPU runs go through a supervisor: this process (standard library only, no GPU) starts the benchmark as a child, waits at most
-    # --watchdog-seconds (+ 60 s for the child's own stack dump) and starts it ONE more time if it had to end it.  One stuck start was seen in
-    # some eighty runs of this benchmark on fresh boxes (a first queued step that never finished; not reproduced in 30,000 steps since).
     profiled = any(k in os.environ for k in ("ROCPROFILER_REGISTER_LIBRARY", "ROCP_TOOL_LIBRARIES", "ROCPROF_OUTPUT_PATH")) or "rocprof" in os.environ.get("LD_PRELOAD", "")
     if world == 1 and not args.no_supervisor and not profiled and os.environ.get("AVK_BENCH_CHILD") != "1":
-        env = dict(os.environ, AVK_BENCH_CHILD="1")
-        rc = 1
-        for attempt in range(2):
-            child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, start_new_session=True)
-            try:
-                rc = child.wait(timeout=args.watchdog_seconds + 60 if args.watchdog_seconds > 0 else None)
-                break
-            except subprocess.TimeoutExpired:
-                print("[bench supervisor] attempt %d exceeded %d s: ending it%s" % (attempt + 1, args.watchdog_seconds + 60, ", starting once more" if attempt == 0 else ""),
-                      file=sys.stderr, flush=True)
-                try:
-                    os.killpg(child.pid, 9)
-                except Exception:
-                    child.kill()
-                child.wait()
-                rc = 124
-        sys.exit(rc)
+        supervise(args)
 
     if args.watchdog_seconds > 0:  # a stuck run must end with evidence instead of holding the machine
         import faulthandler
@@ -124,6 +155,7 @@ def main():
     json_fd = os.dup(1)
     os.dup2(2, 1)
 
+    import ctypes as C
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -132,7 +164,6 @@ def main():
     from aardvark_amd import CompareConfig, synth
     from aardvark_amd import dist as avk_dist
     from aardvark_amd._abi import ResultBatch
-    import ctypes as C
 
     def log(msg):
         if rank == 0:
@@ -149,15 +180,16 @@ def main():
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
+    scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
 
     # ---- workload
     cpus = usable_cpus()
-    seed_shift = 1000 * rank if args.scaling == "weak" else 0
+    seed_shift = 1000 * rank if scaling == "weak" else 0
     contigs, batch = synth.config_genome(scale=args.scale, seed_ref=20250103 + seed_shift, seed_query=20250104 + seed_shift,
                                          threads=max(1, min(8, cpus // max(1, world))))
     n_job_regions = batch.n_regions
     job_batch = batch  # strong scaling: every rank holds the job's call set and solves its hash shard of it
-    if args.scaling == "strong" and world > 1:
+    if scaling == "strong" and world > 1:
         batch = avk_dist.shard_batch(batch, rank, world)
     n_regions = batch.n_regions
     log("workload: %d contigs, %d bases, %d regions on this rank, %d calls" % (len(contigs), sum(c.size for c in contigs), n_regions, batch.n_variants))
@@ -170,17 +202,9 @@ def main():
         if "=" in kv:
             ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
     ctx.upload_reference(contigs)
-    rb = ctx.upload(batch)
     cfg = CompareConfig(enable_sequences=False)
-    # The job's tally: every step (= one batch of the job) adds its tally block to a running total on the device
-    # (SummaryWriter::add_comparison_benchmark, writers/summary.rs:146-163); the total is summed over the ranks with ONE
-    # RCCL all-reduce when the job's batches are done — inside the timed region.  There is no data-path collective.
-    ctx.set_option("accumulate_tally", 1)
-    tally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
-    log("reference and batch resident")
-
-    def step():
-        ctx.compare_resident(rb, cfg, tally.data_ptr())
+    ccfg = cfg.c_struct()
+    log("reference resident")
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -188,18 +212,28 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # ---- the timed steps: avk_compare_batch, host arrays -> host arrays
+    hb = batch if args.pageable else ctx.pinned_batch(batch)
+    res = ResultBatch(hb, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(hb)
+    cb, ro = hb.c_struct(), res.c_struct()
+
+    def step():
+        ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
+
+    job_tally_host = np.zeros(aardvark_amd.TALLY_LEN, np.uint64)
+    tally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
     for _ in range(args.warmup):
         step()
     if use_dist:
         dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # warm the communicator up as well
     fence()
-    tally.zero_()
-    fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        job_tally_host += res.tally  # SummaryWriter::add_comparison_benchmark over the job's batches (writers/summary.rs:146-163)
+    tally.copy_(torch.from_numpy(job_tally_host.astype(np.int64)))
     if use_dist:
-        dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 288 x int64
+        dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 288 x int64, the job's only collective
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -211,14 +245,40 @@ def main():
         total_regions = int(cnt.item())
     else:
         total_regions = n_regions
-    log("timed region: %d steps in %.3f s" % (args.steps, elapsed))
+    log("timed region: %d avk_compare_batch calls in %.3f s (%.2f ms per call)" % (args.steps, elapsed, elapsed / max(args.steps, 1) * 1e3))
     job_tally = tally.clone()
+    got_boundary = res  # the outputs of the last timed call, in the caller's arrays
 
-    # kernel durations for the roofline: HIP events the library records on the launch stream, read on steps OUTSIDE the timed region
-    # (reading them synchronises the host with the step)
-    ctx.set_option("accumulate_tally", 0)
+    # ---- resident leg: the same batch packed once in HBM, avk_compare_resident steps queued back to back (the kernels by themselves)
+    resident = None
+    rb = ctx.upload(batch)
     kernel_ms, solver_ms = [], []
-    for _ in range(min(5, max(2, args.steps))):
+    if args.resident_steps > 0:
+        ctx.set_option("accumulate_tally", 1)
+        rtally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
+        for _ in range(args.warmup):
+            ctx.compare_resident(rb, cfg, rtally.data_ptr())
+        fence()
+        rtally.zero_()
+        fence()
+        tr = time.perf_counter()
+        for _ in range(args.resident_steps):
+            ctx.compare_resident(rb, cfg, rtally.data_ptr())
+        if use_dist:
+            dist.all_reduce(rtally, op=dist.ReduceOp.SUM)
+        fence()
+        r_elapsed = time.perf_counter() - tr
+        if world > 1:
+            t = torch.tensor([r_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            r_elapsed = float(t.item())
+        resident = {"value": total_regions * args.resident_steps / r_elapsed, "unit": "regions/s", "ms_per_step": r_elapsed / args.resident_steps * 1e3,
+                    "steps": args.resident_steps, "what": "avk_compare_resident on the batch packed once in HBM, steps queued back to back, tally added on the device; no copies in the timed region"}
+        resident_tally = rtally.clone()
+        ctx.set_option("accumulate_tally", 0)
+        log("resident leg: %.3f ms per step" % resident["ms_per_step"])
+    # kernel durations for the roofline: HIP events the library records on the launch stream, read on steps outside the timed regions
+    for _ in range(5):
         ctx.compare_resident(rb, cfg, None)
         kernel_ms.append(ctx.last_kernel_ms())
         solver_ms.append(ctx.last_solver_ms())
@@ -229,27 +289,9 @@ def main():
         lane_regions = ctx.last_lane_solved()  # regions finished by the lane-per-region kernel
     except Exception:
         pass
+    rb.free()
 
-    # ---- host-boundary leg: avk_compare_batch on the same batch, host arrays in, host arrays out
-    boundary = None
-    if args.boundary_calls > 0:
-        res = ResultBatch(batch, sequences=False, group_metrics=False)
-        cb, ccfg, ro = batch.c_struct(), cfg.c_struct(), res.c_struct()
-        ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))  # untimed first call
-        ctx.synchronize()
-        tb = time.perf_counter()
-        for _ in range(args.boundary_calls):
-            ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
-        ctx.synchronize()
-        b_elapsed = time.perf_counter() - tb
-        same = res.diff(got) == []
-        boundary = {"value": n_regions * args.boundary_calls / b_elapsed, "unit": "regions/s (this rank)", "ms_per_call": b_elapsed / args.boundary_calls * 1e3,
-                    "calls": args.boundary_calls, "identical_to_resident_path": same,
-                    "what": "avk_compare_batch: region batch in host memory -> validation + packing (host threads) -> H2D -> solver launches -> D2H -> "
-                            "per-region records, per-variant decisions and tally in caller-owned host arrays (reference loop src/main.rs:251-268)"}
-        log("host boundary: %.1f ms per call" % boundary["ms_per_call"])
-
-    # ---- bit-identity gate (same-run rule): this rank's outputs against the oracle
+    # ---- bit-identity gate (same-run rule): this rank's outputs — of the host boundary AND of the resident path — against the oracle
     parity = None
     byte_compares = None
     cpu_rate_parity = None
@@ -261,17 +303,19 @@ def main():
         want = oracle_lib.compare_batch(lib, batch, cs, threads=cpus, group_metrics=False)
         cpu_rate_parity = (time.perf_counter() - tp, n_regions)
         byte_compares = oracle_lib.stats(lib).get("byte_compares")
-        bad = got.diff(want)
+        bad = ["boundary:" + x for x in got_boundary.diff(want)] + ["resident:" + x for x in got.diff(want)]
         # the job total must be steps x this rank's tally, summed over the ranks
-        mine = torch.from_numpy(want.tally.astype(np.int64)).to(dev) * args.steps
+        mine = torch.from_numpy(want.tally.astype(np.int64)).to(dev)
         if use_dist:
             dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-        if not torch.equal(mine, job_tally):
+        if not torch.equal(mine * args.steps, job_tally):
             bad.append("job_tally")
-        if args.scaling == "strong" and world > 1:
+        if resident is not None and not torch.equal(mine * args.resident_steps, resident_tally):
+            bad.append("resident_job_tally")
+        if scaling == "strong" and world > 1:
             # the shards' per-variant decisions, gathered as ONE integer: the sum of the ranks' checksums must be the checksum of the
             # single-process solution of the whole job (the oracle on rank 0)
-            chk = torch.from_numpy(np.array([avk_dist.result_checksum(batch, got)], np.uint64).view(np.int64).copy()).to(dev)
+            chk = torch.from_numpy(np.array([avk_dist.result_checksum(batch, got_boundary)], np.uint64).view(np.int64).copy()).to(dev)
             dist.all_reduce(chk, op=dist.ReduceOp.SUM)
             if rank == 0:
                 whole = oracle_lib.compare_batch(lib, job_batch, cs, threads=cpus, group_metrics=False)
@@ -289,16 +333,20 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_regions * args.steps / elapsed
-        alg_bytes = ctx.algorithmic_bytes(batch)
+        alg_bytes = ctx.algorithmic_bytes(batch, with_groups=False)  # this run writes per-region records, per-call decisions and the tally: no per-region groups
         s_ms = float(np.mean(solver_ms))
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (s_ms * 1e-3) / 1e9
-        traffic = None
+        traffic = traffic_src = None
         if os.path.exists(args.traffic_json):
             try:
                 traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
+                traffic_src = "NOT measured in this process: FETCH_SIZE + WRITE_SIZE of a builder-side `rocprofv3 --pmc` run of the resident step, " + os.path.relpath(args.traffic_json, ROOT)
             except Exception:
                 traffic = None
+        in_bytes = sum(getattr(hb, f).nbytes for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space",
+                                                        "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"))
+        out_bytes = sum(getattr(res, f).nbytes for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg"))
         out = {
             "metric": "compared regions/sec (whole node)",
             "value": value,
@@ -308,34 +356,42 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "higher_is_better": True,
-            "scaling": args.scaling,
+            "scaling": scaling,
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] stand-in: HG002-scale SNV+indel compare, 24 contigs of GRCh38 primary lengths x %.3g (%d bases), "
-                                   "%d regions in the job (%d on rank 0), %d calls on rank 0; seeds 20250103/4; inputs resident in HBM"
-                                   % (args.scale, sum(c.size for c in contigs), n_job_regions if args.scaling == "strong" else total_regions, n_regions, batch.n_variants),
+                                   "%d regions in the job (%d on rank 0), %d calls on rank 0; seeds 20250103/4; one step = one avk_compare_batch call, region batch and results in "
+                                   "%s host memory (the reference loop's boundary, src/main.rs:251-268), H2D and D2H inside the timed region"
+                                   % (args.scale, sum(c.size for c in contigs), n_job_regions if scaling == "strong" else total_regions, n_regions, batch.n_variants,
+                                      "pageable" if args.pageable else "pinned (avk_host_alloc)"),
                        "regions_per_gpu": n_regions, "max_branch_factor": cfg.max_branch_factor, "min_variant_gap": 50,
-                       "outputs_per_step": "per-region record (status, ed_h1, ed_h2, optima, types), per-variant decision word, 288-counter tally",
-                       "parallelism": ("regions of ONE call set sharded by hash(region_id) over %d GPU(s)" % world if args.scaling == "strong" else
+                       "host_bytes_in_per_step": in_bytes, "host_bytes_out_per_step": out_bytes,
+                       "outputs_per_step": "per-region record (status, ed_h1, ed_h2, optima, types), per-variant decision (EA, OA, class, resolved zygosity), 288-counter tally",
+                       "parallelism": ("regions of ONE call set sharded by hash(region_id) over %d GPU(s)" % world if scaling == "strong" else
                                        "one call set per GPU on %d GPU(s)" % world) +
                                       ", no data-path collective; one RCCL all-reduce of the job tally (288 x int64) inside the timed region",
                        "parity": parity, "workspace_tiers": tiers, "lane_kernel_regions": lane_regions},
+            "resident_value": resident["value"] if resident else None,
+            "resident": resident,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "all solver launches of a step (bulk + solo + overflow; HIP events ev0..ev1 on the launch stream)",
+                         "traffic": traffic, "traffic_source": traffic_src,
+                         "kernel": "all solver launches of a step (lane classes + bulk + solo + overflow; HIP events ev0..ev1 on the launch stream)",
                          "kernel_ms": s_ms, "first_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "bytes_per_region": alg_bytes / max(n_regions, 1)},
+                         "bytes_per_region": alg_bytes / max(n_regions, 1),
+                         "pcie": {"bytes_per_step": in_bytes + out_bytes, "achieved_GBs": (in_bytes + out_bytes) * (total_regions / max(n_regions, 1)) / world / (ms_per_step * 1e-3) / 1e9,
+                                  "note": "the host boundary moves the caller's arrays over PCIe (57 GB/s each way measured on this pool, profiles/r03_pcie_probe.txt): its floor per step is bytes / 57 GB/s"}},
         }
-        if boundary:
-            out["host_boundary"] = boundary
-        if byte_compares:
-            out["dwfa_byte_compares_per_s"] = byte_compares * args.steps / elapsed * (total_regions / max(n_regions, 1))
+        if byte_compares:  # base comparisons the reference algorithm makes on this batch (counted by the oracle), at the rates above
             out["dwfa_byte_compares_per_region"] = byte_compares / max(n_regions, 1)
+            out["dwfa_byte_compares_per_s"] = out["dwfa_byte_compares_per_region"] * value
+            if resident:
+                out["dwfa_byte_compares_per_s_resident"] = out["dwfa_byte_compares_per_region"] * resident["value"]
         if world == 1 and not args.no_cpu_baseline:
             import oracle_lib
             lib = oracle_lib.load()
             cs = oracle_lib.ContigSet(contigs)
-            # all usable cores, >= 5 s of wall time: whole passes over the batch (same outputs as the GPU step: per-region records,
+            # all usable cores, >= 6 s of wall time: whole passes over the batch (same outputs as the GPU step: per-region records,
             # per-variant decisions, tally; every thread has solved regions before the clock of a pass matters: a pass takes seconds)
             est = cpu_rate_parity[1] / cpu_rate_parity[0] if cpu_rate_parity else 1e6
             reps = max(1, int(np.ceil(6.0 * est / max(n_regions, 1))))
@@ -354,37 +410,159 @@ def main():
             out["cpu_baseline"] = {"value": rate, "unit": "regions/s", "cores": cpus, "kind": "port",
                                    "one_thread_value": rate1, "parallel_efficiency": rate / (rate1 * cpus),
                                    "host": "%d logical CPUs visible, %d usable (affinity / cgroup quota)" % (os.cpu_count() or 0, cpus),
-                                   "sample": "%d pass(es) over the same %d-region batch on %d threads, %.2f s wall, same outputs as the GPU step; "
+                                   "sample": "%d pass(es) over the same %d-region batch on %d threads, %.2f s wall, same outputs as the GPU step, host arrays in and out; "
                                              "1 thread: first %d regions" % (reps, n_regions, cpus, sec, n1)}
             log("cpu baseline: %.0f regions/s on %d threads (%.2f s), 1 thread %.0f" % (rate, cpus, sec, rate1))
         if world == 1 and not args.no_secondary:
-            contig2, batch2 = synth.config_chr20_snv()
-            ctx.upload_reference([contig2])
-            rb2 = ctx.upload(batch2)
-            ctx.set_option("accumulate_tally", 0)
-            for _ in range(10):
-                ctx.compare_resident(rb2, cfg, None)
-            ctx.synchronize()
-            n2 = 200
-            t2 = time.perf_counter()
-            for _ in range(n2):  # every step synchronised: a step of this size is a launch chain over five streams, and queued back to
-                ctx.compare_resident(rb2, cfg, None)  # back the cross-stream event waits of consecutive steps cost more than they hide
-                ctx.synchronize()
-            e2 = time.perf_counter() - t2
-            t3 = time.perf_counter()
-            for _ in range(n2):
-                ctx.compare_resident(rb2, cfg, None)
-            ctx.synchronize()
-            e3 = time.perf_counter() - t3
-            out["secondary"] = {"workload": "BASELINE configs[1]: synthetic chr20, 50000 SNV-only truth vs query calls, %d regions, resident" % batch2.n_regions,
-                                "value": batch2.n_regions * n2 / e2, "unit": "regions/s", "ms_per_step": e2 / n2 * 1e3, "steps": n2,
-                                "mode": "one host synchronisation per step", "queued_value": batch2.n_regions * n2 / e3, "queued_ms_per_step": e3 / n2 * 1e3}
-            rb2.free()
+            out["secondary"] = secondary_legs(ctx, cfg, args, cpus, log)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def secondary_legs(ctx, cfg, args, cpus, log):
+    """configs[1], the two robustness mixes and configs[4] on one GPU: each with the host-boundary rate (pinned arrays), the resident step and — where it
+    says so — a parity check against the oracle"""
+    import ctypes as C
+    import numpy as np
+    import oracle_lib
+    from aardvark_amd import synth
+    lib = oracle_lib.load()
+    ccfg = cfg.c_struct()
+    sec = {}
+
+    def compare_leg(name, contigs, batch, what, parity=True, resident_sync=False):
+        ctx.upload_reference(contigs)
+        hb = ctx.pinned_batch(batch)
+        res = ctx.pinned_results(hb)
+        cb, ro = hb.c_struct(), res.c_struct()
+        call = lambda: ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
+        call()
+        t1 = time.perf_counter()
+        call()
+        one = time.perf_counter() - t1
+        nb = max(3, min(200, int(0.5 / max(one, 1e-4))))
+        t0 = time.perf_counter()
+        for _ in range(nb):
+            call()
+        be = time.perf_counter() - t0
+        rb = ctx.upload(batch)
+        for _ in range(3):
+            ctx.compare_resident(rb, cfg, None)
+        ctx.synchronize()
+        nr = max(5, min(400, int(0.5 / max(one, 1e-4)) * 2))
+        t0 = time.perf_counter()
+        for _ in range(nr):
+            ctx.compare_resident(rb, cfg, None)
+        ctx.synchronize()
+        re_ = time.perf_counter() - t0
+        got = ctx.download(rb, group_metrics=False)
+        entry = {"workload": what, "regions": batch.n_regions, "value": batch.n_regions * nb / be, "unit": "regions/s", "ms_per_step": be / nb * 1e3, "steps": nb,
+                 "resident_value": batch.n_regions * nr / re_, "resident_ms_per_step": re_ / nr * 1e3, "lane_kernel_regions": ctx.last_lane_solved(),
+                 "lane_share": ctx.last_lane_solved() / max(batch.n_regions, 1), "workspace_tiers": ctx.last_tier_counts()}
+        if resident_sync:  # every step synchronised: a step of this size is a launch chain over several streams
+            t0 = time.perf_counter()
+            for _ in range(nr):
+                ctx.compare_resident(rb, cfg, None)
+                ctx.synchronize()
+            entry["resident_sync_ms_per_step"] = (time.perf_counter() - t0) / nr * 1e3
+        rb.free()
+        if parity:
+            want = oracle_lib.compare_batch(lib, batch, oracle_lib.ContigSet(contigs), threads=cpus, group_metrics=False)
+            bad = ["boundary:" + x for x in res.diff(want)] + ["resident:" + x for x in got.diff(want)]
+            entry["parity"] = "bit-identical" if not bad else "MISMATCH:" + ",".join(bad)
+            if bad:
+                print("PARITY FAILURE in secondary leg %s: %s" % (name, entry["parity"]), file=sys.stderr)
+                sys.exit(3)
+        sec[name] = entry
+        log("secondary %s: boundary %.3f ms, resident %.3f ms per step, lane share %.4f" % (name, entry["ms_per_step"], entry["resident_ms_per_step"], entry["lane_share"]))
+
+    contig2, batch2 = synth.config_chr20_snv()
+    compare_leg("chr20_snv", [contig2], batch2, "BASELINE configs[1]: synthetic chr20, 50000 SNV-only truth vs query calls, %d regions" % batch2.n_regions, resident_sync=True)
+    # robustness: a denser, messier mix and the reference's recommended SV / TR setting (docs/recommended_settings.md:16-37)
+    contigs3, batch3 = synth.config_genome(scale=args.secondary_scale, threads=min(8, cpus), close_frac=0.10, str_frac=0.15, multi_frac=0.05)
+    compare_leg("dense_mix", contigs3, batch3, "genome x %.3g, 10 %% of the sites within 30 bp of another, 15 %% of the indels in repeat runs, 5 %% multi-allelic, %d regions" % (args.secondary_scale, batch3.n_regions))
+    contigs4, batch4 = synth.config_genome(scale=args.secondary_scale, threads=min(8, cpus), gap=1000)
+    compare_leg("min_variant_gap_1000", contigs4, batch4, "genome x %.3g clustered with --min-variant-gap 1000, %d regions" % (args.secondary_scale, batch4.n_regions))
+    if not args.no_merge:
+        from aardvark_amd.merge import MergeConfig, merge_multi_batch
+        import merge_oracle as mo
+        contigs5, mb = synth.config_genome_merge(scale=args.merge_scale, k=3, threads=min(8, cpus))
+        ctx.upload_reference(contigs5)
+        mcfg = MergeConfig(majority_voting_enabled=True)
+        merge_multi_batch(ctx, mb, mcfg)
+        t0 = time.perf_counter()
+        nm = 3
+        for _ in range(nm):
+            mres = merge_multi_batch(ctx, mb, mcfg)
+        me = time.perf_counter() - t0
+        entry = {"workload": "BASELINE configs[4] stand-in on ONE GPU: merge of 3 call sets (seeds 20250105-7) x %.3g genome, majority strategy, %d regions, %d input pairs"
+                             % (args.merge_scale, mb.n_regions, 3 * mb.n_regions),
+                 "value": mb.n_regions * nm / me, "unit": "merge regions/s", "ms_per_step": me / nm * 1e3, "steps": nm,
+                 "what": "avk_merge_batch (solve_merge_region, src/merge_solver.rs:110-200): multi-region batch in host memory -> pairs + classification on the GPU -> status, "
+                         "classification and members in host arrays"}
+        # parity: oracle pairs + the restated classification (oracle/merge_oracle.py) on a sample, and the pair results of every region
+        k = 3
+        st_o, ex_o = oracle_lib.optimize_pairs(lib, pair_batch_of(mb), oracle_lib.ContigSet(contigs5), 50, threads=cpus)
+        st_o, ex_o = st_o.reshape(-1, 3), ex_o.reshape(-1, 3)
+        bad = []
+        # vectorised restatement of merge_solver.rs:149-199 for k = 3, majority voting on, the other strategies off
+        err = (st_o != 0).any(axis=1)
+        first_err = np.where(st_o[:, 0] != 0, st_o[:, 0], np.where(st_o[:, 1] != 0, st_o[:, 1], st_o[:, 2]))
+        ident = ex_o.all(axis=1) & ~err
+        e01, e02, e12 = ex_o[:, 0] != 0, ex_o[:, 1] != 0, ex_o[:, 2] != 0
+        m0 = 1 | (e01 << 1) | (e02 << 2)
+        m1 = (e01 << 0) | 2 | (e12 << 2)
+        m2 = (e02 << 0) | (e12 << 1) | 4
+        pc = lambda m: (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1)
+        maj = np.where(pc(m0) >= 2, m0, np.where(pc(m1) >= 2, m1, np.where(pc(m2) >= 2, m2, 0)))
+        want_cls = np.where(err, 0, np.where(ident, 1, np.where(maj != 0, 3, 0)))
+        want_members = np.where(err | ident | (maj == 0), 0, maj)
+        want_status = np.where(err, first_err, 0)
+        if not np.array_equal(mres.status, want_status):
+            bad.append("status")
+        if not np.array_equal(mres.classification, want_cls.astype(np.uint8)):
+            bad.append("classification")
+        if not np.array_equal(mres.members, want_members.astype(np.uint64)):
+            bad.append("members")
+        sample = mb.regions()[:2000] if mb.n_regions <= 200_000 else None  # the dict form is slow: small runs only
+        if sample is not None:
+            dec = mres.decoded()[:len(sample)]
+            for m, reg in enumerate(sample):
+                if (st_o[m] != 0).any():
+                    continue
+                w = mo.classify([len(v) for v in reg["inputs"]], lambda i, j: int(ex_o[m][{(0, 1): 0, (0, 2): 1, (1, 2): 2}[(i, j)]]), False, True, None)
+                if dec[m][1] is None or dec[m][1][0] != w[0]:
+                    bad.append("restated_rule[%d]" % m)
+                    break
+        entry["parity"] = "bit-identical (pairs: oracle; classification: restated rule)" if not bad else "MISMATCH:" + ",".join(bad)
+        entry["classification_counts"] = {name: int((mres.classification == code).sum()) for name, code in (("different", 0), ("identical", 1), ("majority", 3))}
+        if bad:
+            print("PARITY FAILURE in the merge leg: %s" % entry["parity"], file=sys.stderr)
+            sys.exit(3)
+        sec["merge_3_callers"] = entry
+        log("secondary merge: %.2f ms per call" % entry["ms_per_step"])
+    return sec
+
+
+def pair_batch_of(mb):
+    """the CompareRegion-shaped pair batch of a MultiBatch (avk_merge_batch builds the same on its side): pair (i < j) of region m in lexicographic order"""
+    import numpy as np
+    from aardvark_amd import RegionBatch
+    k, n = mb.n_inputs, mb.n_regions
+    pairs = [(i, j) for i in range(k) for j in range(i + 1, k)]
+    ppr = len(pairs)
+    rep = lambda a: np.repeat(a, ppr)
+    off = mb.in_off.reshape(n, k)
+    cnt = mb.in_cnt.reshape(n, k)
+    t_off = np.stack([off[:, i] for i, _ in pairs], axis=1).reshape(-1)
+    t_cnt = np.stack([cnt[:, i] for i, _ in pairs], axis=1).reshape(-1)
+    q_off = np.stack([off[:, j] for _, j in pairs], axis=1).reshape(-1)
+    q_cnt = np.stack([cnt[:, j] for _, j in pairs], axis=1).reshape(-1)
+    return RegionBatch(rep(mb.region_id), rep(mb.contig_idx), rep(mb.start), rep(mb.end), t_off, t_cnt, q_off, q_cnt, mb.var_pos, mb.var_type, mb.var_zyg,
+                       mb.var_raw_space, mb.a0_off, mb.a0_len, mb.a1_off, mb.a1_len, mb.allele_bytes)
 
 
 if __name__ == "__main__":

@@ -264,6 +264,9 @@ int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the e
 int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
                                                              they are not counted in any workspace tier */
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
+/* the same with (1) or without (0) the per-region BASEPAIR groups among the outputs: a run that produces per-region records, per-call decisions and
+ * the batch tally only (emit_group_metrics 0) writes no per-region groups */
+uint64_t avk_algorithmic_bytes_ex(const avk_region_batch *batch, int with_groups);
 
 /* The device aligner by itself: a batch of DWFALite SCRIPTS (reference src/dwfa/dynamic_wfa.rs:23-276).  Script s works on the two
  * byte strings bytes[base_off[s]..] ("baseline") and bytes[other_off[s]..] ("other") and makes the calls step_off[s] .. step_off[s+1]:

@@ -10,14 +10,14 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-        "roofline", "cpu_baseline", "host_boundary", "dwfa_byte_compares_per_s", "secondary"]
+        "roofline", "cpu_baseline", "resident_value", "resident", "dwfa_byte_compares_per_s", "secondary"]
 
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("force_dist", ["0", "1"])
 def test_one_json_line_on_stdout(force_dist):
     env = dict(os.environ, AVK_BENCH_FORCE_DIST=force_dist, MASTER_ADDR="127.0.0.1", MASTER_PORT="29577")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--scale", "0.01", "--boundary-calls", "1"], capture_output=True, text=True, env=env,
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--scale", "0.01", "--resident-steps", "4", "--merge-scale", "0.01", "--secondary-scale", "0.01"], capture_output=True, text=True, env=env,
                        timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = r.stdout.splitlines()
@@ -32,6 +32,8 @@ def test_one_json_line_on_stdout(force_dist):
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["unit"] == "regions/s" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert 0 < cb["parallel_efficiency"] < 1.5 and cb["one_thread_value"] > 0
-    hb = out["host_boundary"]
-    assert hb["value"] > 0 and hb["identical_to_resident_path"] is True
+    assert out["resident_value"] > 0 and out["resident"]["steps"] == 4
     assert out["value"] > 0 and out["ms_per_step"] > 0
+    sec = out["secondary"]
+    assert set(sec) == {"chr20_snv", "dense_mix", "min_variant_gap_1000", "merge_3_callers"}
+    assert all(sec[k]["parity"].startswith("bit-identical") for k in ("dense_mix", "min_variant_gap_1000", "merge_3_callers", "chr20_snv"))

@@ -53,7 +53,7 @@ def test_invalid_long_and_odd_inputs(ctx_pair, oracle):
 def test_quota_and_autofail(ctx_pair, oracle):
     contigs, batch = scenarios.autofail_regions()
     check(ctx_pair, oracle, contigs, batch)
-    contigs, batch, _ = scenarios.quota_regions(3)
+    contigs, batch = scenarios.quota_regions(3)
     check(ctx_pair, oracle, contigs, batch, max_branch_factor=3)
 
 
