@@ -181,6 +181,12 @@ struct AvkKernelArgs {
     uint32_t *seq_len;
     uint64_t *tally;         /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] partial tallies; wave w adds into copy (w / 4) % AVK_TALLY_COPIES,
                                 a reduce kernel sums the copies: 4096 waves adding into ONE block serialise on its few cache lines */
+    /* Device-packed batches (avk_devpack.inl) write the AvkDevRegion + blob of a lane-class region only when a wave-per-region launch takes
+     * the region (0.15 % of a genome: what the lanes hand back): records from index lazy_from on are written by the wave that is about to
+     * solve them, with the packer's arguments at lazy_dp (device memory).  NULL = every record exists. */
+    const void *lazy_dp;
+    uint32_t lazy_from;
+    uint32_t pad3_;
 };
 
 #endif

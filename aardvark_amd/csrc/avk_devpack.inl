@@ -35,8 +35,10 @@ typedef uint64_t u64;
 typedef int64_t i64;
 
 enum { DP_NB = (3 + AVK_FAST_CLASSES) * 256 }; /* buckets of the work order: class C, class B, bulk, lane classes 4..0, 256 keys each */
-enum { DP_ERR_RANGE = 1, DP_ERR_BLOB = 2, DP_ERR_ALLELE = 4 }; /* batch-level errors (pack_batch returns AVK_E_ARG) */
+enum { DP_ERR_RANGE = 1, DP_ERR_BLOB = 2, DP_ERR_ALLELE = 4, /* batch-level errors (pack_batch returns AVK_E_ARG) */
+       DP_NOTE_OUTSIDE = 256 };                              /* not an error: a region owns calls outside [v_lo, v_hi), the range the host guessed from the first and last region */
 enum { DP_VF_BAD_RANGE = 1, DP_VF_ACGT32 = 2, DP_VF_PENDING = 4 };
+enum { DP_NEED_BUCKETS = 9 };
 
 /* the caller's arrays, as they are, in HBM (names of avk_region_batch) */
 struct DpIn {
@@ -53,6 +55,7 @@ struct DpIn {
     const u64 *contig_base, *contig_len;
     u32 n_contigs;
     u32 pairs_mode;
+    u64 v_lo, v_hi; /* the calls the batch's regions are expected to own (results are copied back for this range only: batches may share call arrays) */
 };
 
 /* context options the plan depends on (plan_work_order's arguments) */
@@ -89,6 +92,7 @@ struct DpState {
     u32 pad0_;
     u64 have[AVK_FAST_CLASSES]; /* regions eligible per lane class */
     u64 total_v, total_blob_words, total_seq; /* totals of the three scans */
+    u64 need_hist[DP_NEED_BUCKETS];           /* class C regions by predicted HBM workspace: bucket b = at most 1 MB << b (the last one: more) */
     u32 hist[DP_NB];
     u32 base[DP_NB + 1];
     u32 cursor[DP_NB];
@@ -193,33 +197,45 @@ struct DpCall { /* FastCall of avk_pack.h */
     u32 pos, a0, a1, alt_ed, type, zyg, lo, hi;
 };
 AVK_DEV u32 dp_copies(u32 z) { return z == AVK_ZYG_HOM_ALT ? 2u : 1u; }
-/* fast_cost_key (avk_pack.h), the same arithmetic on the packed ALT words */
-AVK_DEV u32 dp_cost_key(const DpCall *t, u32 tc, const DpCall *q, u32 qc) {
+/* fast_cost_key (avk_pack.h), the same arithmetic on the packed ALT words.  c[0..2] = the truth calls, c[3..5] = the query calls; every index is a
+ * compile-time constant (the loops are unrolled over the three slots of a side), so the six records stay in registers */
+AVK_DEV u32 dp_cost_key(const DpCall (&c)[2 * AVK_FAST_MAXV], u32 tc, u32 qc) {
     u32 est = 0, used = 0, nhet = 0;
-    for (u32 i = 0; i < tc; ++i) {
+#pragma unroll
+    for (u32 i = 0; i < AVK_FAST_MAXV; ++i) {
+        if (i >= tc) continue;
         int m = -1;
-        for (u32 j = 0; j < qc && m < 0; ++j)
-            if (!((used >> j) & 1u) && t[i].pos == q[j].pos && t[i].a0 == q[j].a0 && t[i].a1 == q[j].a1 && t[i].lo == q[j].lo && t[i].hi == q[j].hi) m = (int)j;
-        if (m < 0) est += t[i].alt_ed * dp_copies(t[i].zyg);
+#pragma unroll
+        for (u32 j = 0; j < AVK_FAST_MAXV; ++j) {
+            const DpCall &q = c[AVK_FAST_MAXV + j];
+            if (j < qc && m < 0 && !((used >> j) & 1u) && c[i].pos == q.pos && c[i].a0 == q.a0 && c[i].a1 == q.a1 && c[i].lo == q.lo && c[i].hi == q.hi) m = (int)j;
+        }
+        if (m < 0) est += c[i].alt_ed * dp_copies(c[i].zyg);
         else {
             used |= 1u << m;
-            const u32 x = dp_copies(t[i].zyg), y = dp_copies(q[m].zyg);
-            est += t[i].alt_ed * (x > y ? x - y : y - x);
+            const u32 qz = m == 0 ? c[AVK_FAST_MAXV].zyg : (m == 1 ? c[AVK_FAST_MAXV + 1].zyg : c[AVK_FAST_MAXV + 2].zyg);
+            const u32 x = dp_copies(c[i].zyg), y = dp_copies(qz);
+            est += c[i].alt_ed * (x > y ? x - y : y - x);
         }
-        nhet += t[i].zyg != AVK_ZYG_HOM_ALT;
+        nhet += c[i].zyg != AVK_ZYG_HOM_ALT;
     }
-    for (u32 j = 0; j < qc; ++j) {
-        if (!((used >> j) & 1u)) est += q[j].alt_ed * dp_copies(q[j].zyg);
-        nhet += q[j].zyg != AVK_ZYG_HOM_ALT;
+#pragma unroll
+    for (u32 j = 0; j < AVK_FAST_MAXV; ++j) {
+        if (j >= qc) continue;
+        const DpCall &q = c[AVK_FAST_MAXV + j];
+        if (!((used >> j) & 1u)) est += q.alt_ed * dp_copies(q.zyg);
+        nhet += q.zyg != AVK_ZYG_HOM_ALT;
     }
-    for (int side = 0; side < 2; ++side) {
-        const DpCall *c = side ? q : t;
+#pragma unroll
+    for (u32 side = 0; side < 2; ++side) {
         const u32 n = side ? qc : tc;
         bool mixed = false;
         u32 longest = 0;
-        for (u32 i = 0; i < n; ++i) {
-            mixed = mixed || c[i].type != c[0].type;
-            longest = c[i].alt_ed > longest ? c[i].alt_ed : longest;
+#pragma unroll
+        for (u32 i = 0; i < AVK_FAST_MAXV; ++i) {
+            if (i >= n) continue;
+            mixed = mixed || c[side * AVK_FAST_MAXV + i].type != c[side * AVK_FAST_MAXV].type;
+            longest = c[side * AVK_FAST_MAXV + i].alt_ed > longest ? c[side * AVK_FAST_MAXV + i].alt_ed : longest;
         }
         if (mixed && longest > 2) est += longest - 2;
     }
@@ -244,8 +260,8 @@ AVK_DEV u64 dp_need(u32 len, u32 t_cnt, u32 q_cnt, u32 ed_bound, u64 N, u64 alle
 
 /* returns the three quantities the scans add up (per-call words, blob words, sequence bytes) and the lane class the region is eligible for
  * (0 = none; the caller counts them into DpState::have — one atomic per wave, not per region) through the references */
-AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u64 &seq_bytes, u32 &lane_class) {
-    n_calls = 0, blob_words = 0, seq_bytes = 0, lane_class = 0;
+AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u64 &seq_bytes, u32 &lane_class, u32 &need_bucket) {
+    n_calls = 0, blob_words = 0, seq_bytes = 0, lane_class = 0, need_bucket = 0xFFu;
     if (r >= a.in.n_regions) return;
     const DpIn &in = a.in;
     DpRegionInfo ri;
@@ -258,6 +274,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
         return;
     }
     const u64 N = (u64)tc + qc;
+    if ((tc && (toff < in.v_lo || toff + tc > in.v_hi)) || (qc && (qoff < in.v_lo || qoff + qc > in.v_hi))) avk_atomic_or_u32_global(&a.st->err, DP_NOTE_OUTSIDE);
     const u32 c = in.contig_idx ? in.contig_idx[r] : 0u;
     const u64 start = in.start[r], end = in.end[r];
     u32 pre = 0;
@@ -269,9 +286,6 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     i64 delta_t = 0, delta_q = 0;
     u32 types = 0, zflags = 0;
     bool bad_zyg = false, bad_allele = false;
-    /* the lane classes' per-call limits, checked on the way (pack_batch does it on the blob afterwards) */
-    bool lane_ok = tc <= AVK_FAST_MAXV && qc <= AVK_FAST_MAXV && N >= 1;
-    DpCall calls[2 * AVK_FAST_MAXV];
     for (int side = 0; side < 2; ++side) {
         const u64 off = side == 0 ? toff : qoff;
         const u32 cnt = side == 0 ? tc : qc;
@@ -299,12 +313,6 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
             if (l1 > l0) (side == 0 ? g0 : g1) += l1 - l0;
             if (vt < AVK_N_VARIANT_TYPES) types |= 1u << vt;
             ed_sum += vi.alt_ed;
-            if (lane_ok) {
-                const u32 rel = pos >= start ? (u32)((pos - start) > 0xFFFFFFFFull ? 0xFFFFFFFFull : (pos - start)) : 0u;
-                lane_ok = rel <= 255 && l0 <= 255 && l1 <= 32 && vi.alt_ed <= 255 && raw <= 0xFFFF && (vi.flags & DP_VF_ACGT32);
-                DpCall &k = calls[side * AVK_FAST_MAXV + i];
-                k.pos = rel, k.a0 = l0, k.a1 = l1, k.alt_ed = vi.alt_ed, k.type = vt, k.zyg = zy, k.lo = vi.a1lo, k.hi = vi.a1hi;
-            }
         }
     }
     if (bad_allele) avk_atomic_or_u32_global(&a.st->err, DP_ERR_ALLELE);
@@ -331,12 +339,30 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
         ri.grow = (u32)grow;
         ri.pre_status |= types << 16;
         ri.ed_bound = (u32)(ed_sum < 0x7FFFFFFFull ? ed_sum : 0x7FFFFFFFull);
-        if (lane_ok && ri.len <= 255 && ed_sum <= 255) {
-            for (int cl = 0; cl < AVK_FAST_CLASSES; ++cl) {
+        if (tc <= AVK_FAST_MAXV && qc <= AVK_FAST_MAXV && N >= 1 && ri.len <= 255 && ed_sum <= 255) {
+            /* a candidate for the lanes: its (at most six) calls once more, into registers (the loop is unrolled over the slots: static indices), with
+             * the classes' per-call limits (pack_batch checks them on the blob) */
+            DpCall calls[2 * AVK_FAST_MAXV];
+            bool lane_ok = true;
+#pragma unroll
+            for (u32 sidx = 0; sidx < 2 * AVK_FAST_MAXV; ++sidx) {
+                const u32 side = sidx / AVK_FAST_MAXV, j = sidx % AVK_FAST_MAXV;
+                DpCall &k = calls[sidx];
+                k.pos = k.a0 = k.a1 = k.alt_ed = k.type = k.zyg = k.lo = k.hi = 0;
+                if (j >= (side ? qc : tc)) continue;
+                const u64 v = (side ? qoff : toff) + j;
+                const u32 l0 = in.a0_len[v], l1 = in.a1_len[v];
+                const u32 raw = in.var_raw ? in.var_raw[v] : (l0 > l1 ? l0 : l1);
+                const DpVarInfo vi = a.vinfo[v];
+                const u64 rel = in.var_pos[v] - start;
+                lane_ok = lane_ok && rel <= 255 && l0 <= 255 && l1 <= 32 && vi.alt_ed <= 255 && raw <= 0xFFFF && (vi.flags & DP_VF_ACGT32);
+                k.pos = (u32)rel, k.a0 = l0, k.a1 = l1, k.alt_ed = vi.alt_ed, k.type = in.var_type[v], k.zyg = in.var_zyg[v], k.lo = vi.a1lo, k.hi = vi.a1hi;
+            }
+            for (int cl = 0; cl < AVK_FAST_CLASSES && lane_ok; ++cl) {
                 const u32 W = AVK_FAST_CLASS[cl].W, maxv = AVK_FAST_CLASS[cl].maxv;
                 if (tc <= maxv && qc <= maxv && (u64)ri.len + ri.grow <= 16ull * W) {
                     fast_class = (u32)cl + 1u;
-                    fast_key = dp_cost_key(calls, tc, calls + AVK_FAST_MAXV, qc);
+                    fast_key = dp_cost_key(calls, tc, qc);
                     if ((fast_key >> 4) > a.opt.lane_max_est) fast_class = 0;
                     if (maxv > 2) fast_key = 0; /* the three-call class keeps the caller's order (avk_pack.h) */
                     break;
@@ -357,8 +383,16 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     const bool failed = (ri.pre_status & 0xFFFFu) != 0;
     if (!failed && N != 0 && a.opt.solo_min_variants != 0) {
         if (a.opt.tier1_bytes && dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier1_ed_cap, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch) > a.opt.tier1_bytes)
+        {
             cls = 0;
-        else if (N >= a.opt.solo_min_variants || dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier0_ed_cap, 2 * N + 1, a.opt.max_branch) > a.opt.tier0_bytes)
+            /* how large an HBM slice the region is predicted to want (no edit-distance cap there): the host sizes the per-wave slices of the batch's
+             * launches by the distribution — large windows (--min-variant-gap 1000) outgrow the default 1 MB by the thousand, and the shared big
+             * slices serialise whatever overflows */
+            const u64 need2 = dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, 0u, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch);
+            u32 b = 0;
+            while (b + 1 < DP_NEED_BUCKETS && need2 > (1ull << (20 + b))) ++b;
+            need_bucket = b;
+        } else if (N >= a.opt.solo_min_variants || dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier0_ed_cap, 2 * N + 1, a.opt.max_branch) > a.opt.tier0_bytes)
             cls = 1;
     }
     if (failed) fast_class = 0; /* `have` and the work order only count regions that will be solved */
@@ -660,6 +694,7 @@ struct DpOut {
     const u64 *t_off, *q_off;
     const u32 *t_cnt, *q_cnt;
     u64 n_regions, n_variants;
+    u64 v_lo; /* the per-call arrays below start at call v_lo of the caller's arrays */
     int32_t *status;
     u32 *ed_h1, *ed_h2, *n_optima;
     uint16_t *type_present;
@@ -680,7 +715,7 @@ AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
     if (toff > o.n_variants || (u64)tc > o.n_variants - toff || qoff > o.n_variants || (u64)qc > o.n_variants - qoff) return;
     const u32 *vw = o.var_out + o.v_off[r];
     for (u32 k = 0; k < tc + qc; ++k) {
-        const u64 hv = k < tc ? toff + k : qoff + (k - tc);
+        const u64 hv = (k < tc ? toff + k : qoff + (k - tc)) - o.v_lo;
         const u32 x = vw[k];
         if (o.var_expected) o.var_expected[hv] = (u8)(x & 0xFF);
         if (o.var_observed) o.var_observed[hv] = (u8)((x >> 8) & 0xFF);

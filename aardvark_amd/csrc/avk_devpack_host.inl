@@ -12,36 +12,57 @@ namespace dpk = avk::dp;
 
 __global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dpk::dp_variant(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 
-/* dp_region for 256 regions; the workgroup's sums of the three scanned quantities go to block_sums[3 * block] */
+/* dp_region for 256 regions; the workgroup's sums of the three scanned quantities and its count of regions per lane class go to
+ * block_sums[AVK_DP_BS * block ..]: no global atomics (56,000 waves adding to the one counter of the modal class took 1.3 ms of this kernel's 1.6) */
+#define AVK_DP_BS (3 + AVK_FAST_CLASSES + avk::dp::DP_NEED_BUCKETS)
 __global__ void __launch_bounds__(256) avk_dp_region_kernel(dpk::DpArgs a, uint64_t *block_sums) {
-    __shared__ unsigned long long sums[3];
-    if (threadIdx.x < 3) sums[threadIdx.x] = 0;
+    __shared__ unsigned long long sums[AVK_DP_BS];
+    if (threadIdx.x < AVK_DP_BS) sums[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t nc = 0, bw = 0, fc = 0;
+    uint32_t nc = 0, bw = 0, fc = 0, nb = 0xFFu;
     uint64_t sq = 0;
-    dpk::dp_region(a, (uint64_t)blockIdx.x * 256u + threadIdx.x, nc, bw, sq, fc);
-    for (uint32_t c = 1; c <= AVK_FAST_CLASSES; ++c) { /* one atomic per wave and class */
+    dpk::dp_region(a, (uint64_t)blockIdx.x * 256u + threadIdx.x, nc, bw, sq, fc, nb);
+    if (__ballot(nb != 0xFFu)) /* class C regions: rare on a small-window genome */
+        for (uint32_t c = 0; c < dpk::DP_NEED_BUCKETS; ++c) {
+            const unsigned long long m = __ballot(nb == c);
+            if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sums[3 + AVK_FAST_CLASSES + c], (unsigned long long)__popcll(m));
+        }
+    for (uint32_t c = 1; c <= AVK_FAST_CLASSES; ++c) { /* one LDS atomic per wave and class */
         const unsigned long long m = __ballot(fc == c);
-        if (m && (threadIdx.x & 63u) == 0) atomicAdd((unsigned long long *)&a.st->have[c - 1], (unsigned long long)__popcll(m));
+        if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sums[2 + c], (unsigned long long)__popcll(m));
     }
+    /* per-wave sums on the DPP network, 16 bits at a time so that 64 lanes cannot overflow a word; one LDS atomic per wave and quantity */
     const uint32_t nc_w = wv_sum_u32(nc); /* at most 64 x 60000 */
-    if ((threadIdx.x & 63u) == 0 && nc_w) atomicAdd(&sums[0], (unsigned long long)nc_w);
-    if (bw) atomicAdd(&sums[1], (unsigned long long)bw);
-    if (sq) atomicAdd(&sums[2], (unsigned long long)sq);
+    const unsigned long long bw_w = (unsigned long long)wv_sum_u32(bw & 0xFFFFu) + ((unsigned long long)wv_sum_u32(bw >> 16) << 16);
+    const unsigned long long sq_w = (unsigned long long)wv_sum_u32((uint32_t)sq & 0xFFFFu) + ((unsigned long long)wv_sum_u32((uint32_t)(sq >> 16) & 0xFFFFu) << 16) +
+                                    ((unsigned long long)wv_sum_u32((uint32_t)(sq >> 32)) << 32);
+    if ((threadIdx.x & 63u) == 0) {
+        if (nc_w) atomicAdd(&sums[0], (unsigned long long)nc_w);
+        if (bw_w) atomicAdd(&sums[1], bw_w);
+        if (sq_w) atomicAdd(&sums[2], sq_w);
+    }
     __syncthreads();
-    if (threadIdx.x < 3) block_sums[3u * blockIdx.x + threadIdx.x] = sums[threadIdx.x];
+    if (threadIdx.x < AVK_DP_BS) block_sums[(size_t)AVK_DP_BS * blockIdx.x + threadIdx.x] = sums[threadIdx.x];
 }
 
-/* exclusive scan of the block sums, in place (one workgroup), and the totals */
+/* exclusive scan of the block sums, in place (one workgroup), the totals, and the regions per lane class */
 __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *block_sums, uint32_t n_blocks, dpk::DpState *st) {
     __shared__ unsigned long long part[3][1024];
+    __shared__ unsigned long long have[AVK_FAST_CLASSES + dpk::DP_NEED_BUCKETS];
     const uint32_t t = threadIdx.x, per = (n_blocks + 1023u) / 1024u;
     const uint32_t lo = t * per < n_blocks ? t * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
-    unsigned long long s[3] = {0, 0, 0};
-    for (uint32_t b = lo; b < hi; ++b)
-        for (int q = 0; q < 3; ++q) s[q] += block_sums[3u * b + q];
+    enum { NH = AVK_FAST_CLASSES + dpk::DP_NEED_BUCKETS };
+    if (t < NH) have[t] = 0;
+    unsigned long long s[3] = {0, 0, 0}, h[NH];
+    for (int c = 0; c < NH; ++c) h[c] = 0;
+    for (uint32_t b = lo; b < hi; ++b) {
+        for (int q = 0; q < 3; ++q) s[q] += block_sums[(size_t)AVK_DP_BS * b + q];
+        for (int c = 0; c < NH; ++c) h[c] += block_sums[(size_t)AVK_DP_BS * b + 3 + c];
+    }
     for (int q = 0; q < 3; ++q) part[q][t] = s[q];
     __syncthreads();
+    for (int c = 0; c < NH; ++c)
+        if (h[c]) atomicAdd(&have[c], h[c]);
     for (uint32_t d = 1; d < 1024; d <<= 1) {
         unsigned long long x[3];
         for (int q = 0; q < 3; ++q) x[q] = t >= d ? part[q][t - d] : 0ull;
@@ -53,8 +74,8 @@ __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *bloc
     for (int q = 0; q < 3; ++q) run[q] = part[q][t] - s[q];
     for (uint32_t b = lo; b < hi; ++b)
         for (int q = 0; q < 3; ++q) {
-            const unsigned long long v = block_sums[3u * b + q];
-            block_sums[3u * b + q] = run[q];
+            const unsigned long long v = block_sums[(size_t)AVK_DP_BS * b + q];
+            block_sums[(size_t)AVK_DP_BS * b + q] = run[q];
             run[q] += v;
         }
     if (t == 1023) {
@@ -62,6 +83,8 @@ __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *bloc
         st->total_blob_words = part[1][1023];
         st->total_seq = part[2][1023];
     }
+    if (t < AVK_FAST_CLASSES) st->have[t] = have[t];
+    else if (t < NH) st->need_hist[t - AVK_FAST_CLASSES] = have[t];
 }
 
 /* per-region offsets: the block's base + the exclusive scan inside the block */
@@ -89,9 +112,10 @@ __global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, c
         __syncthreads();
     }
     if (r < a.in.n_regions) {
-        a.v_off[r] = (uint32_t)(block_sums[3u * blockIdx.x + 0] + sh[0][t] - v[0]);
-        a.blob_off8[r] = (uint32_t)((block_sums[3u * blockIdx.x + 1] + sh[1][t] - v[1]) / 2ull);
-        a.seq_off[r] = block_sums[3u * blockIdx.x + 2] + sh[2][t] - v[2];
+        const uint64_t *bs = block_sums + (size_t)AVK_DP_BS * blockIdx.x;
+        a.v_off[r] = (uint32_t)(bs[0] + sh[0][t] - v[0]);
+        a.blob_off8[r] = (uint32_t)((bs[1] + sh[1][t] - v[1]) / 2ull);
+        a.seq_off[r] = bs[2] + sh[2][t] - v[2];
     }
 }
 
@@ -147,8 +171,12 @@ __global__ void __launch_bounds__(256) avk_dp_fast_records_kernel(dpk::DpArgs a,
     dpk::dp_fast_record(a, fc, tile - a.st->tile_first[fc], lane);
 }
 
-__global__ void __launch_bounds__(256) avk_dp_region_records_kernel(dpk::DpArgs a) { dpk::dp_region_record(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
-
+/* region records + blobs of the work-order positions [0, n_items): the regions the wave-per-region launches read from the start (classes C, B, bulk) — or
+ * every region, when a run has no lane launches */
+__global__ void __launch_bounds__(256) avk_dp_region_records_kernel(dpk::DpArgs a, uint32_t n_items) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k < n_items) dpk::dp_region_record(a, k);
+}
 __global__ void __launch_bounds__(256) avk_dp_region_records_wave_kernel(dpk::DpArgs a) {
     const uint32_t n_big = a.st->n_big, n_waves = gridDim.x * 4u;
     for (uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6); item < n_big; item += n_waves) dpk::dp_region_record_wave(a, item);
@@ -554,27 +582,29 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     /* the caller's arrays in HBM; the four that dp_unpack reads after the solve stay with the batch */
     dpk::DpArgs a;
     memset(&a, 0, sizeof(a));
-    uint64_t *d_start = (uint64_t *)tmp((n + 1) * 8), *d_end = (uint64_t *)tmp((n + 1) * 8);
+    /* (the inputs and the packer's intermediates stay with the batch: region records of lane regions are written when a launch needs them) */
+    auto tmp_or_kept = [&](size_t bytes) -> void * { return kept(bytes); };
+    uint64_t *d_start = (uint64_t *)tmp_or_kept((n + 1) * 8), *d_end = (uint64_t *)tmp_or_kept((n + 1) * 8);
     db->d_in_t_off = (uint64_t *)kept((n + 1) * 8), db->d_in_q_off = (uint64_t *)kept((n + 1) * 8);
     db->d_in_t_cnt = (uint32_t *)kept((n + 1) * 4), db->d_in_q_cnt = (uint32_t *)kept((n + 1) * 4);
-    uint32_t *d_contig = b->contig_idx ? (uint32_t *)tmp((n + 1) * 4) : nullptr;
-    uint64_t *d_pos = (uint64_t *)tmp((nv + 1) * 8), *d_a0o = (uint64_t *)tmp((nv + 1) * 8), *d_a1o = (uint64_t *)tmp((nv + 1) * 8);
-    uint32_t *d_a0l = (uint32_t *)tmp((nv + 1) * 4), *d_a1l = (uint32_t *)tmp((nv + 1) * 4);
-    uint32_t *d_raw = b->var_raw_space ? (uint32_t *)tmp((nv + 1) * 4) : nullptr;
-    uint8_t *d_type = (uint8_t *)tmp(nv + 16), *d_zyg = (uint8_t *)tmp(nv + 16), *d_alleles = (uint8_t *)tmp(alen + 16);
+    uint32_t *d_contig = b->contig_idx ? (uint32_t *)tmp_or_kept((n + 1) * 4) : nullptr;
+    uint64_t *d_pos = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a0o = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a1o = (uint64_t *)tmp_or_kept((nv + 1) * 8);
+    uint32_t *d_a0l = (uint32_t *)tmp_or_kept((nv + 1) * 4), *d_a1l = (uint32_t *)tmp_or_kept((nv + 1) * 4);
+    uint32_t *d_raw = b->var_raw_space ? (uint32_t *)tmp_or_kept((nv + 1) * 4) : nullptr;
+    uint8_t *d_type = (uint8_t *)tmp_or_kept(nv + 16), *d_zyg = (uint8_t *)tmp_or_kept(nv + 16), *d_alleles = (uint8_t *)tmp_or_kept(alen + 16);
     /* intermediates */
     const uint32_t n_blocks = (uint32_t)((n + 255) / 256);
-    a.vinfo = (dpk::DpVarInfo *)tmp((nv + 1) * sizeof(dpk::DpVarInfo));
-    a.rinfo = (dpk::DpRegionInfo *)tmp((n + 1) * sizeof(dpk::DpRegionInfo));
-    a.st = (dpk::DpState *)tmp(sizeof(dpk::DpState));
+    a.vinfo = (dpk::DpVarInfo *)kept((nv + 1) * sizeof(dpk::DpVarInfo));
+    a.rinfo = (dpk::DpRegionInfo *)kept((n + 1) * sizeof(dpk::DpRegionInfo));
+    a.st = (dpk::DpState *)kept(sizeof(dpk::DpState));
     a.pending = (uint32_t *)tmp((nv + 1) * 4);
     db->d_voff = (uint32_t *)kept((n + 1) * 4);
     a.v_off = db->d_voff;
-    a.blob_off8 = (uint32_t *)tmp((n + 1) * 4);
-    a.seq_off = (uint64_t *)tmp((n + 1) * 8);
-    a.order = (uint32_t *)tmp((n + 1) * 4);
-    a.big_list = (uint32_t *)tmp((n + 1) * 4);
-    uint64_t *d_block_sums = (uint64_t *)tmp(((size_t)n_blocks + 1) * 3 * 8);
+    a.blob_off8 = (uint32_t *)kept((n + 1) * 4);
+    a.seq_off = (uint64_t *)kept((n + 1) * 8);
+    a.order = (uint32_t *)kept((n + 1) * 4);
+    a.big_list = (uint32_t *)kept((n + 1) * 4);
+    uint64_t *d_block_sums = (uint64_t *)tmp(((size_t)n_blocks + 1) * AVK_DP_BS * 8);
     if (!ctx->h_dpstate && !rc) {
         hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState), hipHostMallocDefault);
         if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "pinned state block: %s", hipGetErrorString(e));
@@ -597,6 +627,19 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     a.in.a0_len = d_a0l, a.in.a1_len = d_a1l, a.in.alleles = d_alleles, a.in.n_regions = n, a.in.n_variants = nv, a.in.alleles_len = alen,
     a.in.contig_base = ctx->d_contig_tab, a.in.contig_len = ctx->d_contig_tab + ctx->contig_len.size(), a.in.n_contigs = (uint32_t)ctx->contig_len.size(),
     a.in.pairs_mode = pairs_mode ? 1u : 0u;
+    { /* the calls this batch owns, guessed from its first and last region (batches of one job may share the call arrays: compare_main.cpp);
+       * dp_region notes any region outside the guess */
+        uint64_t lo = 0, hi = 0;
+        if (n) {
+            const uint64_t a0 = b->t_cnt[0] ? b->t_off[0] : b->q_off[0], a1 = b->q_cnt[0] ? b->q_off[0] : b->t_off[0];
+            lo = a0 < a1 ? a0 : a1;
+            const uint64_t e0 = b->t_off[n - 1] + b->t_cnt[n - 1], e1 = b->q_off[n - 1] + b->q_cnt[n - 1];
+            hi = e0 > e1 ? e0 : e1;
+            if (hi > nv) hi = nv;
+            if (lo > hi) lo = hi;
+        }
+        a.in.v_lo = lo, a.in.v_hi = hi;
+    }
     const bool lanes = ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b;
     a.opt.tier0_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), a.opt.tier0_ed_cap = (uint32_t)ctx->lds_ed_cap, a.opt.tier1_bytes = (uint64_t)ctx->lds2_bytes_per_wave,
     a.opt.tier1_ed_cap = (uint32_t)ctx->lds2_ed_cap, a.opt.solo_min_variants = pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, a.opt.max_branch = 50,
@@ -655,9 +698,25 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     if (hs->err & dpk::DP_ERR_ALLELE) return bail(fail(ctx, AVK_E_ARG, "allele range exceeds allele_bytes_len"));
     if (hs->err & dpk::DP_ERR_BLOB) return bail(fail(ctx, AVK_E_ARG, "region blob exceeds 2 GiB; split the region's alleles"));
     if (hs->total_v > 0x7FFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "more than 2^31 variant records; split the batch"));
+    db->v_lo = a.in.v_lo, db->v_hi = a.in.v_hi;
+    if (hs->err & dpk::DP_NOTE_OUTSIDE) db->v_lo = 0, db->v_hi = nv;
+    db->var_dense = !(hs->err & dpk::DP_NOTE_OUTSIDE) && hs->total_v == db->v_hi - db->v_lo; /* every call of the range is owned (once): nothing to preserve */
     if (hs->total_blob_words / 2 > 0xFFFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "region blob arena exceeds its limits; split the batch"));
     db->n_variants_dev = hs->total_v;
     db->seq_total = hs->total_seq;
+    { /* per-wave HBM slices of this batch's launches: large enough for 98 % of the regions predicted to need the tier (64 MB at most) */
+        uint64_t n_c = 0, run = 0;
+        for (int k = 0; k < dpk::DP_NEED_BUCKETS; ++k) n_c += hs->need_hist[k];
+        int pick = 0;
+        for (int k = 0; k < dpk::DP_NEED_BUCKETS && n_c >= 64; ++k) {
+            run += hs->need_hist[k];
+            pick = k;
+            if (run * 100 >= n_c * 98) break;
+        }
+        if (pick > 6) pick = 6;
+        const int64_t want = 1ll << (20 + pick);
+        db->ws_bytes_eff = want > ctx->ws_bytes_per_wave && ctx->ws_bytes_per_wave > 0 && ctx->adaptive_ws ? want : 0;
+    }
     db->plan.n_hbm = hs->n_hbm, db->plan.n_hard = hs->n_hard, db->plan.n_fast_total = hs->n_fast_total;
     uint32_t tiles_total = 0;
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) {
@@ -683,9 +742,20 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     if (rc) return bail(rc);
     a.regions = db->d_regions, a.blob = db->d_blob, a.fast = db->d_fast;
     if (tiles_total) hipLaunchKernelGGL(avk_dp_fast_records_kernel, dim3((tiles_total + 3) / 4), dim3(256), 0, s, a, tiles_total);
-    if (n) {
-        hipLaunchKernelGGL(avk_dp_region_records_kernel, dim3(n_blocks), dim3(256), 0, s, a);
+    /* records and blobs: now for the regions the wave-per-region launches start with; for the lanes' regions when (and if) a launch asks for them */
+    const uint32_t n_eager = (uint32_t)n - hs->n_fast_total;
+    if (n_eager) {
+        hipLaunchKernelGGL(avk_dp_region_records_kernel, dim3((n_eager + 255) / 256), dim3(256), 0, s, a, n_eager);
         hipLaunchKernelGGL(avk_dp_region_records_wave_kernel, dim3(256), dim3(256), 0, s, a);
+    }
+    db->dp_args = a;
+    db->records_full = hs->n_fast_total == 0;
+    db->lazy_from = n_eager;
+    if (!db->records_full) { /* the packer's arguments in device memory: the waves that solve handed-back regions write their records themselves */
+        db->d_dp_args = (dpk::DpArgs *)kept(sizeof(dpk::DpArgs));
+        if (rc) return bail(rc);
+        hipError_t ec = hipMemcpyAsync(db->d_dp_args, &db->dp_args, sizeof(dpk::DpArgs), hipMemcpyHostToDevice, s);
+        if (ec != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ec)));
     }
     e = hipGetLastError();
     if (e != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
@@ -723,12 +793,14 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     if (out->ed_h2) o.ed_h2 = (uint32_t *)tmp((n + 1) * 4);
     if (out->n_optima) o.n_optima = (uint32_t *)tmp((n + 1) * 4);
     if (out->type_present) o.type_present = (uint16_t *)tmp((n + 1) * 2);
-    const bool want_var = db->last_mode == 0 && (out->var_expected || out->var_observed || out->var_class || out->var_zyg);
+    const bool want_var = db->last_mode == 0 && (out->var_expected || out->var_observed || out->var_class || out->var_zyg) && db->v_hi > db->v_lo;
+    const uint64_t nvr = db->v_hi - db->v_lo; /* the calls this batch owns: only they are copied back */
+    o.v_lo = db->v_lo;
     if (want_var) {
-        if (out->var_expected) o.var_expected = (uint8_t *)tmp(nv + 16);
-        if (out->var_observed) o.var_observed = (uint8_t *)tmp(nv + 16);
-        if (out->var_class) o.var_class = (uint8_t *)tmp(nv + 16);
-        if (out->var_zyg) o.var_zyg = (uint8_t *)tmp(nv + 16);
+        if (out->var_expected) o.var_expected = (uint8_t *)tmp(nvr + 16);
+        if (out->var_observed) o.var_observed = (uint8_t *)tmp(nvr + 16);
+        if (out->var_class) o.var_class = (uint8_t *)tmp(nvr + 16);
+        if (out->var_zyg) o.var_zyg = (uint8_t *)tmp(nvr + 16);
     }
     uint8_t *d_exact = pair_exact ? (uint8_t *)tmp(n + 16) : nullptr;
     if (rc) return done(rc);
@@ -738,10 +810,13 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     }
     static_assert(sizeof(dpk::DpState) >= AVK_TALLY_STRIDE * 8, "the pinned state block also receives the tally");
     hipError_t e = hipSuccess;
-    if (want_var) { /* calls no region owns read as zero */
-        uint8_t *arrs[4] = {o.var_expected, o.var_observed, o.var_class, o.var_zyg};
-        for (uint8_t *p : arrs)
-            if (p && e == hipSuccess) e = hipMemsetAsync(p, 0, nv + 16, s);
+    if (want_var && !db->var_dense) { /* calls of the range that no region of this batch owns keep what the caller's arrays hold (another batch of the job may own them) */
+        std::vector<CopySeg> pre = {{out->var_expected ? out->var_expected + db->v_lo : nullptr, o.var_expected, out->var_expected ? nvr : 0},
+                                    {out->var_observed ? out->var_observed + db->v_lo : nullptr, o.var_observed, out->var_observed ? nvr : 0},
+                                    {out->var_class ? out->var_class + db->v_lo : nullptr, o.var_class, out->var_class ? nvr : 0},
+                                    {out->var_zyg ? out->var_zyg + db->v_lo : nullptr, o.var_zyg, out->var_zyg ? nvr : 0}};
+        rc = copy_in(ctx, pre);
+        if (rc) return done(rc);
     }
     if (e == hipSuccess && n) {
         hipLaunchKernelGGL(avk_dp_unpack_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, o, d_exact);
@@ -751,10 +826,10 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     std::vector<CopySeg> segs = {{out->status, o.status, n * 4}, {out->ed_h1, o.ed_h1, n * 4}, {out->ed_h2, o.ed_h2, n * 4}, {out->n_optima, o.n_optima, n * 4},
                                  {out->type_present, o.type_present, n * 2}, {pair_exact, d_exact, pair_exact ? n : 0}};
     if (want_var) {
-        segs.push_back({out->var_expected, o.var_expected, nv});
-        segs.push_back({out->var_observed, o.var_observed, nv});
-        segs.push_back({out->var_class, o.var_class, nv});
-        segs.push_back({out->var_zyg, o.var_zyg, nv});
+        segs.push_back({out->var_expected ? out->var_expected + db->v_lo : nullptr, o.var_expected, out->var_expected ? nvr : 0});
+        segs.push_back({out->var_observed ? out->var_observed + db->v_lo : nullptr, o.var_observed, out->var_observed ? nvr : 0});
+        segs.push_back({out->var_class ? out->var_class + db->v_lo : nullptr, o.var_class, out->var_class ? nvr : 0});
+        segs.push_back({out->var_zyg ? out->var_zyg + db->v_lo : nullptr, o.var_zyg, out->var_zyg ? nvr : 0});
     }
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
     CopyOut co;
@@ -768,11 +843,29 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     return done(0);
 }
 
+/* every region record and blob of a device-packed batch (a run without lane launches, the host-side view) */
+static int ensure_all_records(avk_ctx *ctx, avk_dev_batch *db, hipStream_t s) {
+    if (!db->dev_packed || db->records_full || !db->n_regions) return 0;
+    const uint32_t n = (uint32_t)db->n_regions;
+    /* n_big restarts: the wave-level writer takes the large regions of this pass */
+    AVK_HIP(ctx, hipMemsetAsync(&db->dp_args.st->n_big, 0, sizeof(uint32_t), s));
+    hipLaunchKernelGGL(avk_dp_region_records_kernel, dim3((n + 255) / 256), dim3(256), 0, s, db->dp_args, n);
+    hipLaunchKernelGGL(avk_dp_region_records_wave_kernel, dim3(256), dim3(256), 0, s, db->dp_args);
+    AVK_HIP(ctx, hipGetLastError());
+    db->records_full = true;
+    return 0;
+}
+
 /* The host-side view of a device-packed batch (region records, blobs, the map from per-call output words to the caller's calls), fetched only when
  * something needs it: the capacity retry and the sequence outputs of avk_results_download. */
 static int materialize_host_view(avk_ctx *ctx, avk_dev_batch *db) {
     if (!db->dev_packed || !db->host.regions.empty() || !db->n_regions) return 0;
     const uint64_t n = db->n_regions;
+    {
+        const int rf = ensure_all_records(ctx, db, ctx->stream);
+        if (rf) return rf;
+        AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
     avk::PodVec<AvkDevRegion> recs;
     recs.resize(n);
     AVK_HIP(ctx, hipMemcpy(recs.data(), db->d_regions, n * sizeof(AvkDevRegion), hipMemcpyDeviceToHost));

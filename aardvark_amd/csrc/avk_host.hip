@@ -57,6 +57,23 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a)
     avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
+/* the same two for the regions the lanes handed back: device-packed batches (avk_devpack.inl) write the region record and blob of such a region
+ * on demand, in the wave that is about to solve it (AvkKernelArgs::lazy_dp) */
+__global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel_lds_lazy(AvkKernelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    const unsigned wave_in_block = threadIdx.x >> 6;
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
+    if (a.esc_bytes) {
+        for (unsigned k = threadIdx.x; k < AVK_WG_TAIL_BYTES / 4; k += blockDim.x) ((unsigned *)(avk_smem + a.esc_bytes))[k] = 0;
+        __syncthreads();
+    }
+    avk::region_worker<true, true>(a, wave_id, avk_smem + (size_t)wave_in_block * a.tier[a.pass_tier].ws_bytes);
+}
+__global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm_lazy(AvkKernelArgs a) {
+    const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    avk::region_worker<false, true>(a, wave_id, (unsigned char *)0);
+}
+
 /* Small regions, one per LANE (avk_lane.inl): a workgroup is four independent waves, each claims tiles of 64 fast records; the
  * workgroup's LDS holds the four waves' per-lane arrays and one shared tally that is flushed once */
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) avk_lane_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) {
@@ -226,6 +243,8 @@ struct avk_ctx {
     std::vector<uint64_t> contig_base, contig_len;
     uint64_t *d_contig_tab = nullptr; /* contig_base[n_contigs] then contig_len[n_contigs], for the device-side packer */
     /* device-side packing (avk_devpack_host.inl) */
+    int64_t adaptive_ws = 1;               /* device-packed batches size their per-wave HBM slices by the predicted need of their class C regions (option ws_bytes_per_wave is the minimum) */
+    int64_t ws_budget_bytes = 96ll << 30;  /* at most this much HBM for those slices: fewer waves per launch when the slices are large */
     int64_t device_pack = 1;               /* batches are validated, classified, ordered and written ON THE DEVICE from the caller's arrays (0: avk_pack.h on the host threads) */
     int64_t pool_cache_bytes = 12ll << 30; /* released device buffers the context keeps for the next batch (beyond: back to the runtime) */
     std::vector<PoolBlk> pool;
@@ -335,6 +354,13 @@ struct avk_dev_batch {
     std::vector<void *> pooled;
     uint64_t *d_in_t_off = nullptr, *d_in_q_off = nullptr; /* the caller's t_off / q_off / t_cnt / q_cnt: dp_unpack scatters the per-call outputs with them */
     uint32_t *d_in_t_cnt = nullptr, *d_in_q_cnt = nullptr, *d_voff = nullptr;
+    avk::dp::DpArgs dp_args; /* the packer's arguments: the writers of region records run again for the regions a launch turns out to need */
+    avk::dp::DpArgs *d_dp_args = nullptr; /* the same in device memory (AvkKernelArgs::lazy_dp) */
+    uint32_t lazy_from = 0;               /* first work-order index without a record (the lane classes' segment) */
+    uint64_t v_lo = 0, v_hi = 0;          /* the calls the batch's regions own: results are copied back for this range of the caller's arrays only */
+    bool var_dense = false;               /* every call of the range is owned by a region of the batch */
+    int64_t ws_bytes_eff = 0;             /* per-wave HBM slice of this batch's launches when the packer's prediction asks for more than the option ws_bytes_per_wave (0: the option) */
+    bool records_full = false; /* every region has its AvkDevRegion + blob (false: only the regions outside the lane classes, until a launch asks for more) */
 };
 
 namespace {
@@ -583,6 +609,11 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->big_waves = value;
     } else if (n == "use_packed_reference") {
         ctx->use_packed_reference = value ? 1 : 0;
+    } else if (n == "adaptive_ws") {
+        ctx->adaptive_ws = value ? 1 : 0;
+    } else if (n == "ws_budget_bytes") {
+        if (value < (1ll << 30)) return fail(ctx, AVK_E_ARG, "ws_budget_bytes must be at least 1 GiB");
+        ctx->ws_budget_bytes = value;
     } else if (n == "device_pack") {
         ctx->device_pack = value ? 1 : 0;
     } else if (n == "pool_cache_bytes") {
@@ -917,6 +948,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const bool use_fast = ctx->lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && db->d_fast && n_lane_regions && !cfg->enable_sequences &&
                           !cfg->enable_exact_shortcut && n && ctx->use_packed_reference && ctx->d_ref2b;
     const uint32_t n_fast = use_fast ? n_lane_regions : 0u;
+    if (db->dev_packed && !use_fast) { /* the wave-per-region launches take every record: write the ones the packer left for later */
+        const int rf = ensure_all_records(ctx, db, ctx->stream);
+        if (rf) return rf;
+    }
     /* geometry */
     const uint32_t waves_per_block = 4;
     uint64_t want_waves = (uint64_t)ctx->n_cus * (uint64_t)ctx->waves_per_cu;
@@ -928,11 +963,23 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
      * out: 13 GB of workspaces cost 0.25 s at the first call of a process, 4 GB a third of that) */
     uint32_t hbm_blocks = (uint32_t)ctx->n_cus * 3u;
     if (hbm_blocks > blocks) hbm_blocks = blocks;
-    const uint32_t n_waves = hbm_blocks * waves_per_block;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
-    const uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128);
-    const uint32_t hbm_early_max = (uint32_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64); /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
-    const size_t ws_need = (size_t)(n_waves + (hbm_solo_max + hbm_early_max) * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
+    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128);
+    uint32_t hbm_early_max = (uint32_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64); /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
+    /* the per-wave slice: the option, or what the packer's prediction asks for (device-packed batches of large windows: upload_device_packed); large
+     * slices mean fewer waves per launch (option ws_budget_bytes) and more of the shared big slices for what still overflows */
+    const int64_t ws_bytes = db->ws_bytes_eff > ctx->ws_bytes_per_wave ? db->ws_bytes_eff : ctx->ws_bytes_per_wave;
+    const int64_t big_waves = ws_bytes > ctx->ws_bytes_per_wave && ctx->big_waves < 64 ? 64 : ctx->big_waves;
+    {
+        const double total = (double)(hbm_blocks + hbm_solo_max + hbm_early_max) * waves_per_block * (double)ws_bytes;
+        if (total > (double)ctx->ws_budget_bytes) {
+            const double f = (double)ctx->ws_budget_bytes / total;
+            auto shrink = [&](uint32_t b) { const uint32_t x = (uint32_t)(b * f); return x < 8 ? (b < 8 ? b : 8u) : x; };
+            hbm_blocks = shrink(hbm_blocks), hbm_solo_max = shrink(hbm_solo_max), hbm_early_max = shrink(hbm_early_max);
+        }
+    }
+    const uint32_t n_waves = hbm_blocks * waves_per_block;
+    const size_t ws_need = (size_t)(n_waves + (hbm_solo_max + hbm_early_max) * waves_per_block) * (size_t)ws_bytes;
     const auto t_ws = std::chrono::steady_clock::now();
     const bool ws_grows = ws_need > ctx->ws_alloc;
     if (ws_need > ctx->ws_alloc) {
@@ -945,7 +992,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ws, ws_need + 256));
         ctx->ws_alloc = ws_need;
     }
-    const uint32_t big_blocks = (uint32_t)((ctx->big_waves + waves_per_block - 1) / waves_per_block);
+    const uint32_t big_blocks = (uint32_t)((big_waves + waves_per_block - 1) / waves_per_block);
     const size_t big_need = (size_t)big_blocks * waves_per_block * (size_t)ctx->big_ws_bytes;
     if (big_need > ctx->big_alloc) {
         if (ctx->d_big) {
@@ -986,7 +1033,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.tier[0].ed_cap = (uint32_t)ctx->lds_ed_cap;
     a.tier[1].ws_bytes = (uint64_t)ctx->lds2_bytes_per_wave;
     a.tier[1].ed_cap = (uint32_t)ctx->lds2_ed_cap;
-    a.tier[2].ws_bytes = (uint64_t)ctx->ws_bytes_per_wave;
+    a.tier[2].ws_bytes = (uint64_t)ws_bytes;
     a.tier[2].ed_cap = 0;
     a.tier[3].ws_bytes = (uint64_t)ctx->big_ws_bytes;
     a.tier[3].ed_cap = 0;
@@ -996,18 +1043,23 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.seq_bytes = cfg->enable_sequences ? db->d_seq : nullptr;
     a.seq_len = cfg->enable_sequences ? db->d_seqlen : nullptr;
     a.tally = db->d_partials;
+    if (db->dev_packed && !db->records_full) { /* (only the launches for handed-back regions ever meet an index >= lazy_from) */
+        a.lazy_dp = db->d_dp_args;
+        a.lazy_from = db->lazy_from;
+    }
 
     if (cfg->max_branch_factor == 0) return fail(ctx, AVK_E_ARG, "max_branch_factor must be greater than 0 (query_optimizer.rs:177)");
 
     if (!ctx->lds_attr_set) {
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_region_kernel_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_region_kernel_lds_lazy, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->lds_attr_set = true;
     }
     const bool timed = ctx->timing_events != 0;
     const bool order_guard = ctx->order_guard == 1 || (ctx->order_guard == 2 && n >= 262144);
     if (timed) AVK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     ctx->ev_lane_valid = false;
-    const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(ctx->big_waves < 128 ? ctx->big_waves : 128) : 0u;
+    const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(big_waves < 128 ? big_waves : 128) : 0u;
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
@@ -1084,7 +1136,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 s.claim = 1;
                 s.n_waves = hbm_solo * waves_per_block;
                 s.high_priority = 1;
-                s.hbm_ws = ctx->d_ws + (size_t)n_waves * (size_t)ctx->ws_bytes_per_wave; /* its own slices: the main stream's HBM launch may run beside it */
+                s.hbm_ws = ctx->d_ws + (size_t)n_waves * (size_t)ws_bytes; /* its own slices: the main stream's HBM launch may run beside it */
                 s.big_ws = ctx->d_big;
                 s.big_busy = db->d_counters + 1088;
                 s.big_slots = big_slots;
@@ -1206,13 +1258,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         e.extra_n = 0;
                         e.overflow_list = nullptr;
                         e.overflow_count = nullptr;
-                        e.hbm_ws = ctx->d_ws + (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ctx->ws_bytes_per_wave;
+                        e.hbm_ws = ctx->d_ws + (size_t)(n_waves + hbm_solo_max * waves_per_block) * (size_t)ws_bytes;
                         e.big_ws = ctx->d_big;
                         e.big_busy = db->d_counters + 1088;
                         e.big_slots = big_slots;
                         const uint32_t eb = hbm_blocks < hbm_early_max ? hbm_blocks : hbm_early_max;
                         e.n_waves = eb * waves_per_block;
-                        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(eb), dim3(256), 0, lstream[li], e);
+                        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), 0, lstream[li], e);
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, lstream[li])); /* the caller's stream waits for this one at the end */
                         early_used = true;
@@ -1285,7 +1337,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 d.n_waves = dblocks * waves_per_block;
                 d.overflow_list = lists[1];
                 d.overflow_count = db->d_counters + 1024 + 16;
-                hipLaunchKernelGGL(avk_region_kernel_lds, dim3(dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ds, d);
+                hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ds, d);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_done, ds)); /* everything of the lane streams is behind this record */
                 deferred_pending = true;
@@ -1354,7 +1406,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         h.big_slots = big_slots;
         const uint32_t hb = hbm_blocks < 64 ? hbm_blocks : 64;
         h.n_waves = hb * waves_per_block;
-        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hb), dim3(256), 0, ctx->stream, h);
+        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(hb), dim3(256), 0, ctx->stream, h);
         AVK_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally,

@@ -31,6 +31,7 @@
 
 #include "avk_dev_types.h"
 #include "avk_wave.h"
+#include "avk_devpack.inl" /* dp_region_record: region records of device-packed batches are written on demand */
 
 namespace avk {
 
@@ -1766,7 +1767,9 @@ AVK_DEV void wg_acquire(u32 *ctl, u32 w, u32 n_wg_waves) {
 
 /* With esc_bytes set (bulk launch) the workgroups have exactly 4 waves: wave w of a workgroup has wave_id % 4 == w and
  * its slice starts w slices into the workgroup's LDS. */
-template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+/* LAZY: a launch for regions the lanes handed back (device-packed batches write those regions' records on demand, below) — a separate instantiation, so that
+ * the launches that solve a genome's bulk keep their register allocation */
+template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
     const bool wgt = PASS_LDS && a.esc_bytes != 0; /* this workgroup has a tail: shared tally, and the lock of the escalation */
     const bool esc = wgt && a.esc_enabled != 0;
     const u32 wave_in_wg = wave_id & 3u;
@@ -1850,6 +1853,10 @@ template <bool PASS_LDS> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 
             b = wv_uni(wv_shfl(b, 0));
             if (b == 0xFFFFFFFFu || b >= a.extra_n) break;
             r = a.extra_base + b;
+        }
+        if (LAZY && a.lazy_dp && r >= a.lazy_from) { /* a lane-class region of a device-packed batch: its record and blob are written now, by this wave */
+            if (lane == 0) dp::dp_region_record(*(const dp::DpArgs *)a.lazy_dp, r);
+            wv_sync();
         }
         const AvkDevRegion reg = a.regions[r];
         const u32 orig = wv_uni(reg.orig); /* where the caller's batch has this region: outputs go there */

@@ -187,8 +187,8 @@ struct WaveTask {
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
-    if (t->lds) avk::region_worker<true>(*t->args, t->wave_id, t->lds);
-    else avk::region_worker<false>(*t->args, t->wave_id, nullptr);
+    if (t->lds) avk::region_worker<true, true>(*t->args, t->wave_id, t->lds); /* (the lazy instantiations: they differ from the others only when lazy_dp is set) */
+    else avk::region_worker<false, true>(*t->args, t->wave_id, nullptr);
 }
 
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
@@ -201,7 +201,10 @@ struct DpResult {
     std::vector<uint64_t> seq_off;
     std::vector<dpk::DpVarInfo> vinfo;
     std::vector<dpk::DpRegionInfo> rinfo;
+    std::vector<uint32_t> pending, big_list;
     dpk::DpState st;
+    dpk::DpArgs args; /* for the writers that run later (records of the regions the lanes hand back) */
+    bool lazy = false;
     std::string err;
 };
 struct DpWaveTask {
@@ -212,7 +215,7 @@ void dp_wave_main(void *p, int /*lane*/) {
     DpWaveTask *t = (DpWaveTask *)p;
     dpk::dp_region_record_wave(*t->a, t->item);
 }
-int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const std::vector<uint64_t> &lens, const dpk::DpOpts &opt, bool pairs_mode, DpResult *R) {
+int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const std::vector<uint64_t> &lens, const dpk::DpOpts &opt, bool pairs_mode, DpResult *R, bool lazy = false) {
     const uint64_t n = b->n_regions, nv = b->n_variants;
     dpk::DpArgs a;
     memset(&a, 0, sizeof(a));
@@ -220,10 +223,12 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     a.in.var_pos = b->var_pos, a.in.var_type = b->var_type, a.in.var_zyg = b->var_zyg, a.in.var_raw = b->var_raw_space, a.in.a0_off = b->a0_off, a.in.a1_off = b->a1_off,
     a.in.a0_len = b->a0_len, a.in.a1_len = b->a1_len, a.in.alleles = b->allele_bytes, a.in.n_regions = n, a.in.n_variants = nv, a.in.alleles_len = b->allele_bytes_len,
     a.in.contig_base = base.data(), a.in.contig_len = lens.data(), a.in.n_contigs = (uint32_t)lens.size(), a.in.pairs_mode = pairs_mode ? 1u : 0u;
+    a.in.v_lo = 0, a.in.v_hi = nv;
     a.opt = opt;
     R->vinfo.assign(nv + 1, dpk::DpVarInfo());
     R->rinfo.assign(n + 1, dpk::DpRegionInfo());
-    std::vector<uint32_t> pending(nv + 1), big_list(n + 1);
+    std::vector<uint32_t> &pending = R->pending, &big_list = R->big_list;
+    pending.assign(nv + 1, 0), big_list.assign(n + 1, 0);
     R->v_off.assign(n + 1, 0), R->blob_off8.assign(n + 1, 0), R->seq_off.assign(n + 1, 0), R->order.assign(n + 1, 0);
     memset(&R->st, 0, sizeof(R->st));
     a.vinfo = R->vinfo.data(), a.rinfo = R->rinfo.data(), a.st = &R->st, a.pending = pending.data(), a.v_off = R->v_off.data(), a.blob_off8 = R->blob_off8.data(),
@@ -232,10 +237,11 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     auto region_passes = [&] {
         uint64_t run_v = 0, run_b = 0, run_s = 0;
         for (uint64_t r = 0; r < n; ++r) {
-            uint32_t nc, bw, fc;
+            uint32_t nc, bw, fc, nb;
             uint64_t sq;
-            dpk::dp_region(a, r, nc, bw, sq, fc);
+            dpk::dp_region(a, r, nc, bw, sq, fc, nb);
             if (fc) R->st.have[fc - 1] += 1;
+            if (nb != 0xFFu) R->st.need_hist[nb] += 1;
             R->v_off[r] = (uint32_t)run_v, R->blob_off8[r] = (uint32_t)(run_b / 2), R->seq_off[r] = run_s;
             run_v += nc, run_b += bw, run_s += sq;
         }
@@ -271,7 +277,10 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc)
         for (uint32_t t = 0; t < R->st.fast_tiles[fc]; ++t)
             for (uint32_t lane = 0; lane < 64; ++lane) dpk::dp_fast_record(a, (uint32_t)fc, t, lane);
-    for (uint64_t k = 0; k < n; ++k) dpk::dp_region_record(a, k);
+    /* upload_device_packed: records and blobs of the regions outside the lane classes now, of the others when a launch asks for them */
+    for (uint64_t k = 0; k < (lazy ? n - R->st.n_fast_total : n); ++k) dpk::dp_region_record(a, k);
+    R->args = a;
+    R->lazy = lazy;
     if (R->st.n_big) {
         avk_emu::Wave w;
         w.stack_bytes = 256 * 1024;
@@ -324,7 +333,10 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     DpResult dpr;
     int rc = 0;
     if (devpack) {
-        rc = dp_run(batch, base, lens, dp_opts_of(lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, solo_min_variants, mode == 1, g_lane_kernel ? 0ull : 0xFFFFFFFFull), mode == 1, &dpr);
+        rc = dp_run(batch, base, lens, dp_opts_of(lds_bytes, lds_ed_cap, lds2_bytes, lds2_ed_cap, solo_min_variants, mode == 1, g_lane_kernel ? 0ull : 0xFFFFFFFFull), mode == 1, &dpr,
+                    /* lazily, exactly when run_internal's lane launches will run (use_fast below) */
+                    g_device_pack == 2 && cfg->max_branch_factor != 0 && g_lane_kernel && !cfg->enable_exact_shortcut && !cfg->enable_sequences && lds_bytes > 0 &&
+                        !(lds2_bytes > 0 && lds2_overflow_pass) && ws_bytes > 0);
         err = dpr.err;
     } else
         rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err);
@@ -473,15 +485,17 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     if (devpack) { /* the packer wrote the records in work order and made the plan */
         plan.n_hbm = dpr.st.n_hbm, plan.n_hard = dpr.st.n_hard, plan.n_fast_total = dpr.st.n_fast_total;
         for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) plan.n_fast[fc] = dpr.st.n_fast[fc], plan.n_fast_heavy[fc] = dpr.st.n_fast_heavy[fc], plan.fast_base[fc] = dpr.st.fast_base[fc];
-        sorted.resize(n);
-        for (uint64_t k = 0; k < n; ++k) sorted[k] = dpr.regions[k];
     } else {
         plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
                                     getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
                                     g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */);
         sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     }
-    a.regions = sorted.data();
+    a.regions = devpack ? dpr.regions.data() : sorted.data();
+    if (devpack && dpr.lazy) { /* run_internal: the waves that take handed-back regions write their records themselves */
+        a.lazy_dp = &dpr.args;
+        a.lazy_from = (uint32_t)n - dpr.st.n_fast_total;
+    }
     /* the lane-per-region launches of run_internal (aardvark_amd/csrc/avk_host.hip): fast segments first, leftovers to the list the
      * first HBM pass reads */
     const int fast_list = launch[1] ? 1 : 0;

@@ -148,3 +148,35 @@ def test_packed_reference_off_with_lane_sized_batch(oracle):
             rb.free()
         finally:
             ctx.close()
+
+
+def test_batches_that_share_the_call_arrays(ctx_pair, oracle):
+    """a job cut into batches of regions over ONE set of call arrays, results into ONE set of per-call output arrays (what compare_main.cpp does):
+    a batch only writes the calls its regions own — in region order and, for the last case, with the batches' calls interleaved"""
+    import ctypes as C
+    from aardvark_amd._abi import ResultBatch
+    contig, batch = synth.config_indel_mix_v2(n_truth=20_000, contig_len=8_000_000)
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=False)
+    n = batch.n_regions
+    cfg = CompareConfig(enable_sequences=False).c_struct()
+    for c in ctx_pair:
+        c.upload_reference([contig])
+        c.set_option("emit_group_metrics", 0)
+        for parts in ([(0, n // 3), (n // 3, n // 2), (n // 2, n)], "interleaved"):
+            whole = ResultBatch(batch, sequences=False, group_metrics=False)
+            if parts == "interleaved":  # even regions, then odd regions: each batch's calls lie between the other's
+                idx = [np.arange(0, n, 2), np.arange(1, n, 2)]
+                subs = [RegionBatch(batch.region_id[i], batch.contig_idx[i], batch.start[i], batch.end[i], batch.t_off[i], batch.t_cnt[i], batch.q_off[i], batch.q_cnt[i], batch.var_pos,
+                                    batch.var_type, batch.var_zyg, batch.var_raw_space, batch.a0_off, batch.a0_len, batch.a1_off, batch.a1_len, batch.allele_bytes) for i in idx]
+            else:
+                idx = [np.arange(lo, hi) for lo, hi in parts]
+                subs = [batch.slice(lo, hi) for lo, hi in parts]
+            for i, sub in zip(idx, subs):
+                res = ResultBatch(sub, sequences=False, group_metrics=False)
+                res.var_expected, res.var_observed, res.var_class, res.var_zyg = whole.var_expected, whole.var_observed, whole.var_class, whole.var_zyg
+                cb, ro = sub.c_struct(), res.c_struct()
+                c._check(c.lib.avk_compare_batch(c.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
+                whole.status[i], whole.ed_h1[i], whole.ed_h2[i], whole.n_optima[i], whole.type_present[i] = res.status, res.ed_h1, res.ed_h2, res.n_optima, res.type_present
+                whole.tally += res.tally
+            assert whole.diff(want) == []
+        c.set_option("emit_group_metrics", 1)

@@ -8,11 +8,9 @@ tables = [r[0] for r in cur.execute("select name from sqlite_master where type i
 ev = []
 for r in cur.execute("select name, grid_x, workgroup_x, lds_size, start, end from kernels where name like 'avk_%'"):
     ev.append((r[4], r[5], "kernel %-36s grid=%-8d wg=%-4d lds=%-6d" % (r[0].split("(")[0], r[1], r[2], r[3])))
-mc = [t for t in tables if "memory_cop" in t]
-for t in mc[:1]:
-    cols = [c[1] for c in cur.execute("pragma table_info(%s)" % t)]
-    sel = "name, size, start, end" if "size" in cols else "name, 0, start, end"
-    for r in cur.execute("select %s from %s" % (sel, t)):
+mc = ["memory_copies"] if "memory_copies" in tables else []
+for t in mc:
+    for r in cur.execute("select name, size, start, end from %s" % t):
         ev.append((r[2], r[3], "copy   %-36s bytes=%d" % (r[0], r[1])))
 ev.sort()
 # the last call starts at the last run of large host-to-device copies that follows a device-to-host copy
