@@ -11,7 +11,7 @@ import os
 
 import numpy as np
 
-from ._abi import (TALLY_LEN, AvkCompareConfig, AvkRegionBatch, AvkResultBatch, RegionBatch, ResultBatch)
+from ._abi import (TALLY_LEN, AvkCompactBatch, AvkCompareConfig, AvkRegionBatch, AvkResultBatch, CompactBatch, RegionBatch, ResultBatch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
@@ -54,6 +54,8 @@ def load_library():
     lib.avk_ref_upload.argtypes = [vp, C.c_uint32, C.POINTER(u8p), u64p]
     lib.avk_compare_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
     lib.avk_batch_upload.argtypes = [vp, C.POINTER(AvkRegionBatch), C.POINTER(vp)]
+    lib.avk_compare_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
+    lib.avk_batch_upload_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(vp)]
     lib.avk_compare_resident.argtypes = [vp, vp, C.POINTER(AvkCompareConfig), vp]
     lib.avk_results_download.argtypes = [vp, vp, C.POINTER(AvkResultBatch)]
     lib.avk_batch_free.argtypes = [vp, vp]
@@ -154,6 +156,24 @@ class Context:
             return out
         return RegionBatch(*[pin(getattr(batch, f)) for f in ("region_id", "contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg",
                                                               "var_raw_space", "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes")])
+
+    def pinned_compact(self, cbatch):
+        """a copy of a CompactBatch whose arrays live in pinned memory"""
+        def pin(a):
+            if a is None:
+                return None
+            out = self.host_array(a.shape, a.dtype)
+            out[...] = a
+            return out
+        return CompactBatch(**{f: pin(getattr(cbatch, f)) for f in CompactBatch.FIELDS})
+
+    def solve_compact(self, cbatch, config=None, res=None):
+        """avk_compare_compact: solve_compare_region for every region of a batch in the compact form -> ResultBatch (indexed like the compact arrays)"""
+        config = config or CompareConfig(enable_sequences=False)
+        res = res if res is not None else ResultBatch(cbatch, sequences=False, group_metrics=False)
+        cb, cfg, ro = cbatch.c_struct(), config.c_struct(), res.c_struct()
+        self._check(self.lib.avk_compare_compact(self.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
+        return res
 
     def pinned_results(self, batch, group_metrics=False):
         """a ResultBatch whose arrays live in pinned memory"""

@@ -124,6 +124,44 @@ struct DpArgs {
 
 #define DP_SMALL_N 48u /* regions with at most this many calls are written by one lane; larger ones by a whole wave */
 
+/* ---- dp_widen: a batch in the compact form (avk_compact_batch, include/aardvark_amd.h) into the arrays of DpIn, in HBM ------------------------------ */
+struct DpCompact {
+    const u32 *contig_idx, *start, *len, *v_off;
+    const uint16_t *t_cnt, *q_cnt;
+    const u32 *var_pos, *a_off, *a0_len, *a1_len, *var_raw;
+    const u8 *var_type_zyg;
+    u64 n_regions, n_variants;
+    /* the wide arrays (device), written here */
+    u32 *w_contig, *w_t_cnt, *w_q_cnt, *w_a0_len, *w_a1_len, *w_raw;
+    u64 *w_start, *w_end, *w_t_off, *w_q_off, *w_pos, *w_a0_off, *w_a1_off;
+    u8 *w_type, *w_zyg;
+};
+AVK_DEV void dp_widen(const DpCompact &c, u64 i) { /* one lane: region i and call i */
+    if (i < c.n_regions) {
+        const u64 st = c.start[i], vo = c.v_off[i];
+        const u32 tc = c.t_cnt[i], qc = c.q_cnt[i];
+        if (c.w_contig) c.w_contig[i] = c.contig_idx[i];
+        c.w_start[i] = st;
+        c.w_end[i] = st + c.len[i];
+        c.w_t_off[i] = vo;
+        c.w_q_off[i] = vo + tc;
+        c.w_t_cnt[i] = tc;
+        c.w_q_cnt[i] = qc;
+    }
+    if (i < c.n_variants) {
+        const u64 ao = c.a_off[i];
+        const u32 l0 = c.a0_len[i], tz = c.var_type_zyg[i];
+        c.w_pos[i] = c.var_pos[i];
+        c.w_a0_off[i] = ao;
+        c.w_a1_off[i] = ao + l0;
+        c.w_a0_len[i] = l0;
+        c.w_a1_len[i] = c.a1_len[i];
+        if (c.w_raw) c.w_raw[i] = c.var_raw[i];
+        c.w_type[i] = (u8)(tz & 15u);
+        c.w_zyg[i] = (u8)(tz >> 4);
+    }
+}
+
 /* ---- dp_variant: Variant::alt_ed (variants.rs:413-415 = wfa_ed(allele0, allele1), sequence_alignment.rs:9-13) ------------------------ */
 /* Unit-cost edit distance of a pattern of at most 64 symbols against a text of any length: the bit-vector recurrence of Myers
  * (J. ACM 46, 1999) in Hyyrö's global-distance form (the horizontal delta of row 0 is +1 in every column).  Symbols are bytes, so

@@ -10,6 +10,8 @@
 /* ---------------------------------------------------------------------------------- kernels */
 namespace dpk = avk::dp;
 
+__global__ void __launch_bounds__(256) avk_dp_widen_kernel(dpk::DpCompact c) { dpk::dp_widen(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+
 __global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dpk::dp_variant(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 
 /* dp_region for 256 regions; the workgroup's sums of the three scanned quantities and its count of regions per lane class go to
@@ -544,11 +546,17 @@ static void release_pooled(avk_ctx *ctx, avk_dev_batch *db) {
     db->pooled.clear();
 }
 
-static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pairs_mode, avk_dev_batch **out) {
-    const uint64_t n = b->n_regions, nv = b->n_variants, alen = b->allele_bytes_len;
+/* b: the batch in the wide form, or NULL and cb: the batch in the compact form (avk_compact_batch: half the bytes over PCIe, widened on the device) */
+static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out) {
+    const uint64_t n = b ? b->n_regions : cb->n_regions, nv = b ? b->n_variants : cb->n_variants, alen = b ? b->allele_bytes_len : cb->allele_bytes_len;
     if (n > 0x7FFFFFFFull || nv > 0x7FFFFFFFull) return fail(ctx, AVK_E_ARG, "batch too large (more than 2^31 regions or variants); split it");
-    if (n && (!b->start || !b->end || !b->t_off || !b->t_cnt || !b->q_off || !b->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
-    if (nv && (!b->var_pos || !b->var_type || !b->var_zyg || !b->a0_off || !b->a0_len || !b->a1_off || !b->a1_len || !b->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    if (b && n && (!b->start || !b->end || !b->t_off || !b->t_cnt || !b->q_off || !b->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (b && nv && (!b->var_pos || !b->var_type || !b->var_zyg || !b->a0_off || !b->a0_len || !b->a1_off || !b->a1_len || !b->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    if (cb && n && (!cb->start || !cb->len || !cb->v_off || !cb->t_cnt || !cb->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (cb && nv && (!cb->var_pos || !cb->var_type_zyg || !cb->a_off || !cb->a0_len || !cb->a1_len || !cb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    if (cb && alen > 0xFFFFFFFFull) return fail(ctx, AVK_E_ARG, "the compact form holds at most 2^32 allele bytes");
+    const bool has_contig = b ? b->contig_idx != nullptr : cb->contig_idx != nullptr, has_raw = b ? b->var_raw_space != nullptr : cb->var_raw_space != nullptr;
+    const uint8_t *host_alleles = b ? b->allele_bytes : cb->allele_bytes;
     const bool timing = getenv("AVK_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
@@ -587,10 +595,10 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     uint64_t *d_start = (uint64_t *)tmp_or_kept((n + 1) * 8), *d_end = (uint64_t *)tmp_or_kept((n + 1) * 8);
     db->d_in_t_off = (uint64_t *)kept((n + 1) * 8), db->d_in_q_off = (uint64_t *)kept((n + 1) * 8);
     db->d_in_t_cnt = (uint32_t *)kept((n + 1) * 4), db->d_in_q_cnt = (uint32_t *)kept((n + 1) * 4);
-    uint32_t *d_contig = b->contig_idx ? (uint32_t *)tmp_or_kept((n + 1) * 4) : nullptr;
+    uint32_t *d_contig = has_contig ? (uint32_t *)tmp_or_kept((n + 1) * 4) : nullptr;
     uint64_t *d_pos = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a0o = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a1o = (uint64_t *)tmp_or_kept((nv + 1) * 8);
     uint32_t *d_a0l = (uint32_t *)tmp_or_kept((nv + 1) * 4), *d_a1l = (uint32_t *)tmp_or_kept((nv + 1) * 4);
-    uint32_t *d_raw = b->var_raw_space ? (uint32_t *)tmp_or_kept((nv + 1) * 4) : nullptr;
+    uint32_t *d_raw = has_raw ? (uint32_t *)tmp_or_kept((nv + 1) * 4) : nullptr;
     uint8_t *d_type = (uint8_t *)tmp_or_kept(nv + 16), *d_zyg = (uint8_t *)tmp_or_kept(nv + 16), *d_alleles = (uint8_t *)tmp_or_kept(alen + 16);
     /* intermediates */
     const uint32_t n_blocks = (uint32_t)((n + 255) / 256);
@@ -612,7 +620,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     if (!ctx->d_contig_tab && !rc) rc = fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     if (rc) return bail(rc);
     const auto t_alloc = now();
-    {
+    if (b) {
         std::vector<CopySeg> segs = {
             {b->start, d_start, n * 8}, {b->end, d_end, n * 8}, {b->t_off, db->d_in_t_off, n * 8}, {b->q_off, db->d_in_q_off, n * 8},
             {b->t_cnt, db->d_in_t_cnt, n * 4}, {b->q_cnt, db->d_in_q_cnt, n * 4}, {b->contig_idx, d_contig, b->contig_idx ? n * 4 : 0},
@@ -620,6 +628,30 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
             {b->var_raw_space, d_raw, b->var_raw_space ? nv * 4 : 0}, {b->var_type, d_type, nv}, {b->var_zyg, d_zyg, nv}, {b->allele_bytes, d_alleles, alen}};
         rc = copy_in(ctx, segs);
         if (rc) return bail(rc);
+    } else { /* the compact arrays as they are, then one kernel that writes the wide ones */
+        dpk::DpCompact c;
+        memset(&c, 0, sizeof(c));
+        uint32_t *c_contig = has_contig ? (uint32_t *)tmp((n + 1) * 4) : nullptr, *c_start = (uint32_t *)tmp((n + 1) * 4), *c_len = (uint32_t *)tmp((n + 1) * 4),
+                 *c_voff = (uint32_t *)tmp((n + 1) * 4), *c_pos = (uint32_t *)tmp((nv + 1) * 4), *c_aoff = (uint32_t *)tmp((nv + 1) * 4);
+        uint16_t *c_tc = (uint16_t *)tmp((n + 1) * 2), *c_qc = (uint16_t *)tmp((n + 1) * 2);
+        uint8_t *c_tz = (uint8_t *)tmp(nv + 16);
+        if (rc) return bail(rc);
+        /* a0_len / a1_len / raw_space have the wide arrays' type: they are copied straight into them */
+        std::vector<CopySeg> segs = {{cb->start, c_start, n * 4}, {cb->len, c_len, n * 4}, {cb->v_off, c_voff, n * 4}, {cb->t_cnt, c_tc, n * 2}, {cb->q_cnt, c_qc, n * 2},
+                                     {cb->contig_idx, c_contig, has_contig ? n * 4 : 0}, {cb->var_pos, c_pos, nv * 4}, {cb->a_off, c_aoff, nv * 4}, {cb->var_type_zyg, c_tz, nv},
+                                     {cb->a0_len, d_a0l, nv * 4}, {cb->a1_len, d_a1l, nv * 4}, {cb->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {cb->allele_bytes, d_alleles, alen}};
+        rc = copy_in(ctx, segs);
+        if (rc) return bail(rc);
+        c.contig_idx = c_contig, c.start = c_start, c.len = c_len, c.v_off = c_voff, c.t_cnt = c_tc, c.q_cnt = c_qc, c.var_pos = c_pos, c.a_off = c_aoff, c.a0_len = d_a0l, c.a1_len = d_a1l,
+        c.var_raw = nullptr, c.var_type_zyg = c_tz, c.n_regions = n, c.n_variants = nv;
+        c.w_contig = d_contig, c.w_t_cnt = db->d_in_t_cnt, c.w_q_cnt = db->d_in_q_cnt, c.w_a0_len = d_a0l, c.w_a1_len = d_a1l, c.w_raw = nullptr, c.w_start = d_start, c.w_end = d_end,
+        c.w_t_off = db->d_in_t_off, c.w_q_off = db->d_in_q_off, c.w_pos = d_pos, c.w_a0_off = d_a0o, c.w_a1_off = d_a1o, c.w_type = d_type, c.w_zyg = d_zyg;
+        const uint64_t m = n > nv ? n : nv;
+        if (m) {
+            hipLaunchKernelGGL(avk_dp_widen_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, c);
+            hipError_t ew = hipGetLastError();
+            if (ew != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ew)));
+        }
     }
     const auto t_copy = now();
     a.in.contig_idx = d_contig, a.in.start = d_start, a.in.end = d_end, a.in.t_off = db->d_in_t_off, a.in.q_off = db->d_in_q_off, a.in.t_cnt = db->d_in_t_cnt,
@@ -630,14 +662,17 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
     { /* the calls this batch owns, guessed from its first and last region (batches of one job may share the call arrays: compare_main.cpp);
        * dp_region notes any region outside the guess */
         uint64_t lo = 0, hi = 0;
-        if (n) {
+        if (n && b) {
             const uint64_t a0 = b->t_cnt[0] ? b->t_off[0] : b->q_off[0], a1 = b->q_cnt[0] ? b->q_off[0] : b->t_off[0];
             lo = a0 < a1 ? a0 : a1;
             const uint64_t e0 = b->t_off[n - 1] + b->t_cnt[n - 1], e1 = b->q_off[n - 1] + b->q_cnt[n - 1];
             hi = e0 > e1 ? e0 : e1;
-            if (hi > nv) hi = nv;
-            if (lo > hi) lo = hi;
+        } else if (n) {
+            lo = cb->v_off[0];
+            hi = (uint64_t)cb->v_off[n - 1] + cb->t_cnt[n - 1] + cb->q_cnt[n - 1];
         }
+        if (hi > nv) hi = nv;
+        if (lo > hi) lo = hi;
         a.in.v_lo = lo, a.in.v_hi = hi;
     }
     const bool lanes = ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b;
@@ -678,7 +713,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, bool pa
             avk_parallel_for(np, avk_host_threads(), [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t k = lo; k < hi; ++k) {
                     const uint64_t v = idx[k];
-                    ed[k] = (uint32_t)avk::host_edit_distance(b->allele_bytes + b->a0_off[v], b->a0_len[v], b->allele_bytes + b->a1_off[v], b->a1_len[v]);
+                    const uint64_t o0 = b ? b->a0_off[v] : cb->a_off[v], l0 = b ? b->a0_len[v] : cb->a0_len[v], o1 = b ? b->a1_off[v] : o0 + l0, l1 = b ? b->a1_len[v] : cb->a1_len[v];
+                    ed[k] = (uint32_t)avk::host_edit_distance(host_alleles + o0, l0, host_alleles + o1, l1);
                 }
             });
             uint32_t *d_idx = (uint32_t *)tmp((size_t)np * 4), *d_ed = (uint32_t *)tmp((size_t)np * 4);

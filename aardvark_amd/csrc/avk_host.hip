@@ -756,7 +756,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     *out = nullptr;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     AVK_HIP(ctx, hipSetDevice(ctx->device));
-    if (ctx->device_pack) return upload_device_packed(ctx, batch, pairs_mode, out);
+    if (ctx->device_pack) return upload_device_packed(ctx, batch, nullptr, pairs_mode, out);
     const bool timing = getenv("AVK_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1788,6 +1788,31 @@ int avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants) {
     if (n_regions > 0x7FFFFFFFull || n_variants > 0x7FFFFFFFull) return 0;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     return bounce_reserve(ctx, (size_t)n_regions * 52 + (size_t)n_variants * 48 + (1u << 20));
+}
+
+int avk_batch_upload_compact(avk_ctx *ctx, const avk_compact_batch *batch, avk_dev_batch **out) {
+    if (!ctx || !batch || !out) return AVK_E_ARG;
+    *out = nullptr;
+    if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    return upload_device_packed(ctx, nullptr, batch, false, out);
+}
+
+int avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
+    if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
+    ctx->last_one_shot = 0;
+    avk_dev_batch *db = nullptr;
+    const int64_t keep_gm = ctx->emit_group_metrics;
+    if (!out->group_metrics) ctx->emit_group_metrics = 0;
+    int rc = avk_batch_upload_compact(ctx, batch, &db);
+    if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
+    if (!rc) rc = avk_results_download(ctx, db, out);
+    ctx->emit_group_metrics = keep_gm;
+    if (db) {
+        ctx->last_one_shot = 1;
+        avk_batch_free(ctx, db);
+    }
+    return rc;
 }
 
 int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {

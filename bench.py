@@ -213,12 +213,18 @@ def main():
         torch.cuda.synchronize(dev)
 
     # ---- the timed steps: avk_compare_batch, host arrays -> host arrays
-    hb = batch if args.pageable else ctx.pinned_batch(batch)
+    # the caller's flat batch in the library's compact form (avk_compact_batch: 20 B per region + 17 B per call; the library widens it on the device),
+    # the results in the arrays of avk_result_batch; both in pinned memory unless --pageable
+    from aardvark_amd import CompactBatch
+    hb = CompactBatch.from_region_batch(batch)
+    wide = batch
+    if not args.pageable:
+        hb, wide = ctx.pinned_compact(hb), ctx.pinned_batch(batch)
     res = ResultBatch(hb, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(hb)
     cb, ro = hb.c_struct(), res.c_struct()
 
     def step():
-        ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
+        ctx._check(ctx.lib.avk_compare_compact(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
 
     job_tally_host = np.zeros(aardvark_amd.TALLY_LEN, np.uint64)
     tally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
@@ -248,6 +254,21 @@ def main():
     log("timed region: %d avk_compare_batch calls in %.3f s (%.2f ms per call)" % (args.steps, elapsed, elapsed / max(args.steps, 1) * 1e3))
     job_tally = tally.clone()
     got_boundary = res  # the outputs of the last timed call, in the caller's arrays
+    # the same boundary with the batch in the WIDE structure-of-arrays form (avk_region_batch: 52 B per region + 38 B per call over PCIe)
+    wres = ResultBatch(wide, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(wide)
+    wcb, wro = wide.c_struct(), wres.c_struct()
+    ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(wcb), C.byref(ccfg), C.byref(wro)))
+    n_wide = max(3, min(args.steps, 20))
+    fence()
+    tw = time.perf_counter()
+    for _ in range(n_wide):
+        ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(wcb), C.byref(ccfg), C.byref(wro)))
+    fence()
+    wide_elapsed = time.perf_counter() - tw
+    if world > 1:
+        t = torch.tensor([wide_elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wide_elapsed = float(t.item())
 
     # ---- resident leg: the same batch packed once in HBM, avk_compare_resident steps queued back to back (the kernels by themselves)
     resident = None
@@ -303,7 +324,7 @@ def main():
         want = oracle_lib.compare_batch(lib, batch, cs, threads=cpus, group_metrics=False)
         cpu_rate_parity = (time.perf_counter() - tp, n_regions)
         byte_compares = oracle_lib.stats(lib).get("byte_compares")
-        bad = ["boundary:" + x for x in got_boundary.diff(want)] + ["resident:" + x for x in got.diff(want)]
+        bad = ["boundary:" + x for x in got_boundary.diff(want)] + ["wide_boundary:" + x for x in wres.diff(want)] + ["resident:" + x for x in got.diff(want)]
         # the job total must be steps x this rank's tally, summed over the ranks
         mine = torch.from_numpy(want.tally.astype(np.int64)).to(dev)
         if use_dist:
@@ -344,8 +365,9 @@ def main():
                 traffic_src = "NOT measured in this process: FETCH_SIZE + WRITE_SIZE of a builder-side `rocprofv3 --pmc` run of the resident step, " + os.path.relpath(args.traffic_json, ROOT)
             except Exception:
                 traffic = None
-        in_bytes = sum(getattr(hb, f).nbytes for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space",
-                                                        "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"))
+        in_bytes = hb.nbytes()
+        wide_bytes = sum(getattr(wide, f).nbytes for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space",
+                                                            "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"))
         out_bytes = sum(getattr(res, f).nbytes for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg"))
         out = {
             "metric": "compared regions/sec (whole node)",
@@ -361,8 +383,8 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] stand-in: HG002-scale SNV+indel compare, 24 contigs of GRCh38 primary lengths x %.3g (%d bases), "
-                                   "%d regions in the job (%d on rank 0), %d calls on rank 0; seeds 20250103/4; one step = one avk_compare_batch call, region batch and results in "
-                                   "%s host memory (the reference loop's boundary, src/main.rs:251-268), H2D and D2H inside the timed region"
+                                   "%d regions in the job (%d on rank 0), %d calls on rank 0; seeds 20250103/4; one step = one avk_compare_compact call, region batch (compact flat form) and "
+                                   "results in %s host memory (the reference loop's boundary, src/main.rs:251-268), H2D and D2H inside the timed region"
                                    % (args.scale, sum(c.size for c in contigs), n_job_regions if scaling == "strong" else total_regions, n_regions, batch.n_variants,
                                       "pageable" if args.pageable else "pinned (avk_host_alloc)"),
                        "regions_per_gpu": n_regions, "max_branch_factor": cfg.max_branch_factor, "min_variant_gap": 50,
@@ -374,6 +396,8 @@ def main():
                        "parity": parity, "workspace_tiers": tiers, "lane_kernel_regions": lane_regions},
             "resident_value": resident["value"] if resident else None,
             "resident": resident,
+            "wide_soa": {"value": total_regions * n_wide / wide_elapsed, "unit": "regions/s", "ms_per_step": wide_elapsed / n_wide * 1e3, "steps": n_wide, "host_bytes_in_per_step": wide_bytes,
+                         "what": "the same boundary with the batch in the wide structure-of-arrays form (avk_region_batch through avk_compare_batch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "all solver launches of a step (lane classes + bulk + solo + overflow; HIP events ev0..ev1 on the launch stream)",
@@ -433,7 +457,7 @@ def secondary_legs(ctx, cfg, args, cpus, log):
     ccfg = cfg.c_struct()
     sec = {}
 
-    def compare_leg(name, contigs, batch, what, parity=True, resident_sync=False):
+    def compare_leg(name, contigs, batch, what, parity=True, resident_sync=False, few=False):
         ctx.upload_reference(contigs)
         hb = ctx.pinned_batch(batch)
         res = ctx.pinned_results(hb)
@@ -443,16 +467,16 @@ def secondary_legs(ctx, cfg, args, cpus, log):
         t1 = time.perf_counter()
         call()
         one = time.perf_counter() - t1
-        nb = max(3, min(200, int(0.5 / max(one, 1e-4))))
+        nb = 2 if few else max(3, min(200, int(0.5 / max(one, 1e-4))))
         t0 = time.perf_counter()
         for _ in range(nb):
             call()
         be = time.perf_counter() - t0
         rb = ctx.upload(batch)
-        for _ in range(3):
+        for _ in range(1 if few else 3):
             ctx.compare_resident(rb, cfg, None)
         ctx.synchronize()
-        nr = max(5, min(400, int(0.5 / max(one, 1e-4)) * 2))
+        nr = 2 if few else max(5, min(400, int(0.5 / max(one, 1e-4)) * 2))
         t0 = time.perf_counter()
         for _ in range(nr):
             ctx.compare_resident(rb, cfg, None)
@@ -484,8 +508,9 @@ def secondary_legs(ctx, cfg, args, cpus, log):
     # robustness: a denser, messier mix and the reference's recommended SV / TR setting (docs/recommended_settings.md:16-37)
     contigs3, batch3 = synth.config_genome(scale=args.secondary_scale, threads=min(8, cpus), close_frac=0.10, str_frac=0.15, multi_frac=0.05)
     compare_leg("dense_mix", contigs3, batch3, "genome x %.3g, 10 %% of the sites within 30 bp of another, 15 %% of the indels in repeat runs, 5 %% multi-allelic, %d regions" % (args.secondary_scale, batch3.n_regions))
-    contigs4, batch4 = synth.config_genome(scale=args.secondary_scale, threads=min(8, cpus), gap=1000)
-    compare_leg("min_variant_gap_1000", contigs4, batch4, "genome x %.3g clustered with --min-variant-gap 1000, %d regions" % (args.secondary_scale, batch4.n_regions))
+    # (windows of kilobases: every region goes to the wave-per-region kernels and costs some fifty times a small one — on the CPU as well; a fifth of the other leg's scale)
+    contigs4, batch4 = synth.config_genome(scale=args.secondary_scale / 5, threads=min(8, cpus), gap=1000)
+    compare_leg("min_variant_gap_1000", contigs4, batch4, "genome x %.3g clustered with --min-variant-gap 1000, %d regions" % (args.secondary_scale / 5, batch4.n_regions), few=True)
     if not args.no_merge:
         from aardvark_amd.merge import MergeConfig, merge_multi_batch
         import merge_oracle as mo

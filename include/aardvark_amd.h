@@ -128,6 +128,28 @@ typedef struct avk_region_batch {
     uint64_t allele_bytes_len;
 } avk_region_batch;
 
+/* The same batch in the library's COMPACT form: 20 bytes per region and 17 (21 with raw_allele_space) per call instead of 52 and 38 — the form to
+ * build when the batch crosses PCIe once per call (a whole genome: 0.23 GB instead of 0.48 GB; the host boundary is bound by that copy).  Constraints
+ * that make the narrow fields possible: contigs shorter than 4 Gbp, the calls of a region adjacent in the call arrays (truth calls at
+ * [v_off, v_off + t_cnt), query calls right behind them), allele1 of a call right behind its allele0 in allele_bytes, fewer than 2^32 calls and
+ * allele bytes, at most 65535 calls per region and side.  The library widens it on the device (one kernel); results are indexed like the arrays here. */
+typedef struct avk_compact_batch {
+    uint64_t n_regions;
+    const uint32_t *contig_idx;    /* [n_regions] may be NULL (contig 0) */
+    const uint32_t *start;         /* [n_regions] Coordinates::start */
+    const uint32_t *len;           /* [n_regions] end - start */
+    const uint32_t *v_off;         /* [n_regions] first call of the region */
+    const uint16_t *t_cnt, *q_cnt; /* [n_regions] */
+    uint64_t n_variants;
+    const uint32_t *var_pos;       /* [n_variants] Variant::position */
+    const uint8_t  *var_type_zyg;  /* [n_variants] AVK_VT_* | AVK_ZYG_* << 4 */
+    const uint32_t *a_off;         /* [n_variants] allele0 at allele_bytes[a_off ..), allele1 right behind it */
+    const uint32_t *a0_len, *a1_len;
+    const uint32_t *var_raw_space; /* [n_variants] may be NULL (= the longer allele) */
+    const uint8_t  *allele_bytes;
+    uint64_t allele_bytes_len;
+} avk_compact_batch;
+
 /* CompareConfig, src/waffle_solver.rs:94-115 */
 typedef struct avk_compare_config {
     uint32_t max_branch_factor;     /* default 50 */
@@ -230,6 +252,10 @@ int  avk_ref_upload(avk_ctx *ctx, uint32_t n_contigs, const uint8_t *const *seqs
  * kernels, unpacking kernel, results into the caller's arrays (no per-region work on the host). */
 int  avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch,
                        const avk_compare_config *cfg, avk_result_batch *out);
+
+/* the same for a batch in the compact form */
+int  avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_compare_config *cfg, avk_result_batch *out);
+int  avk_batch_upload_compact(avk_ctx *ctx, const avk_compact_batch *batch, avk_dev_batch **out);
 
 /* The same in three steps, for callers that keep batches resident in HBM. */
 int  avk_batch_upload(avk_ctx *ctx, const avk_region_batch *batch, avk_dev_batch **out);

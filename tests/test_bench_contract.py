@@ -10,7 +10,7 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 KEYS = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
-        "roofline", "cpu_baseline", "resident_value", "resident", "dwfa_byte_compares_per_s", "secondary"]
+        "roofline", "cpu_baseline", "resident_value", "resident", "wide_soa", "dwfa_byte_compares_per_s", "secondary"]
 
 
 @pytest.mark.gpu

@@ -204,3 +204,18 @@ def test_long_unrelated_alleles_take_the_host_edit_distance():
     lib.emu_devpack_alt_ed(a0.ctypes.data_as(u8p), len(a0), a1.ctypes.data_as(u8p), len(a1), C.byref(pend))
     assert pend.value == 1
     same_as_host_packer(batch, [len(contig)])
+
+
+def test_compact_form_round_trip():
+    """CompactBatch.from_region_batch / widen (the numpy statement of the library's dp_widen kernel): the wide arrays come back as they were"""
+    from aardvark_amd import CompactBatch
+    contig, batch = synth.config_indel_mix_v2(n_truth=5000, contig_len=2_000_000)
+    cb = CompactBatch.from_region_batch(batch)
+    w = cb.widen()
+    for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space", "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"):
+        assert np.array_equal(getattr(w, f), getattr(batch, f)), f
+    assert cb.nbytes() < 0.55 * 90 * batch.n_variants + 60 * batch.n_regions
+    contigs, bad = scenarios.invalid_regions()
+    with pytest.raises(ValueError):
+        CompactBatch.from_region_batch(RegionBatch(bad.region_id, bad.contig_idx, bad.start, bad.end, bad.t_off, bad.t_cnt, bad.q_off + 1, bad.q_cnt, bad.var_pos, bad.var_type, bad.var_zyg,
+                                                   bad.var_raw_space, bad.a0_off, bad.a0_len, bad.a1_off, bad.a1_len, bad.allele_bytes))

@@ -180,3 +180,34 @@ def test_batches_that_share_the_call_arrays(ctx_pair, oracle):
                 whole.tally += res.tally
             assert whole.diff(want) == []
         c.set_option("emit_group_metrics", 1)
+
+
+def test_compact_form(ctx_pair, oracle):
+    """avk_compare_compact (the batch in 20 + 17 bytes per region / call, widened on the device) == avk_compare_batch == oracle; pageable and pinned; with and
+    without raw_allele_space; the resident form from a compact upload"""
+    import ctypes as C
+    from aardvark_amd import CompactBatch
+    dev = ctx_pair[0]
+    contig, batch = synth.config_indel_mix_v2(n_truth=40_000, contig_len=16_000_000)
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=False)
+    dev.upload_reference([contig])
+    cb = CompactBatch.from_region_batch(batch)
+    assert cb.var_raw_space is None and cb.nbytes() < 0.55 * sum(getattr(batch, f).nbytes for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type",
+                                                                                                     "var_zyg", "var_raw_space", "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"))
+    assert dev.solve_compact(cb).diff(want) == []
+    pc = dev.pinned_compact(cb)
+    res = dev.pinned_results(pc)
+    for _ in range(2):
+        res.status[:] = -3
+        assert dev.solve_compact(pc, res=res).diff(want) == []
+    cb_raw = CompactBatch.from_region_batch(batch, keep_raw_space=True)
+    assert dev.solve_compact(cb_raw).diff(want) == []
+    # odd inputs in the compact form: invalid regions, other symbols, long alleles
+    for sc in (scenarios.invalid_regions(), scenarios.non_acgt_regions(), scenarios.long_allele_regions(), scenarios.fuzz_regions(361, 1500, max_vars=7)):
+        contigs, b = sc[0], sc[1]
+        try:
+            c2 = CompactBatch.from_region_batch(b)
+        except ValueError:
+            continue  # (a window that ends before it starts has no compact form)
+        dev.upload_reference(contigs)
+        assert dev.solve_compact(c2, res=None).diff(oracle_lib.compare_batch(oracle, b, contigs, threads=CPUS, group_metrics=False)) == []

@@ -28,6 +28,21 @@ ctx.synchronize()
 print("resident: %d regions, %.3f ms per step, lanes %d, tiers %s" % (batch.n_regions, (time.perf_counter() - t0) / 10 * 1e3, ctx.last_lane_solved(), ctx.last_tier_counts()), flush=True)
 rb.free()
 ccfg = cfg.c_struct()
+from aardvark_amd import CompactBatch
+for name in ("pageable", "pinned"):
+    cbt = CompactBatch.from_region_batch(batch)
+    if name == "pinned":
+        cbt = ctx.pinned_compact(cbt)
+    res = ResultBatch(cbt, sequences=False, group_metrics=False) if name == "pageable" else ctx.pinned_results(cbt)
+    cc, ro = cbt.c_struct(), res.c_struct()
+    ctx._check(ctx.lib.avk_compare_compact(ctx.handle, C.byref(cc), C.byref(ccfg), C.byref(ro)))
+    ts = []
+    for _ in range(calls):
+        t = time.perf_counter()
+        ctx._check(ctx.lib.avk_compare_compact(ctx.handle, C.byref(cc), C.byref(ccfg), C.byref(ro)))
+        ts.append((time.perf_counter() - t) * 1e3)
+    print("%s compact arrays (%.0f MB in): avk_compare_compact %s ms -> best %.1f M regions/s, mean %.1f; identical to the resident path: %s" %
+          (name, cbt.nbytes() / 1e6, " ".join("%.2f" % x for x in ts), batch.n_regions / min(ts) / 1e3, batch.n_regions / np.mean(ts) / 1e3, res.diff(want) == []), flush=True)
 for name in ("pageable", "pinned"):
     b = batch if name == "pageable" else ctx.pinned_batch(batch)
     res = ResultBatch(b, sequences=False, group_metrics=False) if name == "pageable" else ctx.pinned_results(b)
