@@ -162,6 +162,119 @@ AVK_DEV void dp_widen(const DpCompact &c, u64 i) { /* one lane: region i and cal
     }
 }
 
+/* ---- the merge path on the device (solve_merge_region, src/merge_solver.rs:110-200) ------------------------------------------------------------------- */
+/* a batch of MultiRegions (avk_multi_batch) as one CompareRegion-shaped item per input pair (i < j, lexicographic): input i plays the truth side */
+struct DpPairs {
+    const u32 *contig_idx; /* may be NULL */
+    const u64 *start, *end, *in_off;
+    const u32 *in_cnt;
+    u64 n_multi;
+    u32 k, ppr; /* inputs per region, pairs per region */
+    u32 *w_contig, *w_t_cnt, *w_q_cnt;
+    u64 *w_start, *w_end, *w_t_off, *w_q_off;
+};
+AVK_DEV void dp_expand_pairs(const DpPairs &c, u64 p) {
+    if (p >= c.n_multi * c.ppr) return;
+    const u64 m = p / c.ppr;
+    u32 rest = (u32)(p % c.ppr), i = 0;
+    while (rest >= c.k - 1 - i) rest -= c.k - 1 - i, ++i;
+    const u32 j = i + 1 + rest;
+    if (c.w_contig) c.w_contig[p] = c.contig_idx[m];
+    c.w_start[p] = c.start[m];
+    c.w_end[p] = c.end[m];
+    c.w_t_off[p] = c.in_off[m * c.k + i];
+    c.w_t_cnt[p] = c.in_cnt[m * c.k + i];
+    c.w_q_off[p] = c.in_off[m * c.k + j];
+    c.w_q_cnt[p] = c.in_cnt[m * c.k + j];
+}
+/* solve_merge_region's decision on top of the pair matrix (merge_solver.rs:149-199) for ONE region with at most KMAX inputs: pair(p, st, ex) hands out status
+ * and exact-match flag of the region's pair p (lexicographic order).  The library's host function avk_merge_classify (KMAX 64) and the kernel behind
+ * avk_merge_batch (KMAX 8) both call this. */
+template <int KMAX, class PairFn>
+AVK_HD void merge_classify_one(u32 k, const u32 *cnt, bool has_unknown, PairFn pair, u32 no_conflict_enabled, u32 majority_voting_enabled, int32_t conflict_selection,
+                               int32_t *status, u8 *classification, u64 *members) {
+    *status = 0;
+    *classification = AVK_MERGE_DIFFERENT;
+    *members = 0;
+    if (has_unknown) { /* variant_delta_length bails on an Unknown zygosity before anything else */
+        *status = AVK_ST_BAD_ZYGOSITY;
+        return;
+    }
+    bool all_identical = true, no_conflict = true;
+    u64 match[KMAX];
+    for (u32 i = 0; i < k && i < (u32)KMAX; ++i) match[i] = 1ull << i;
+    u64 p = 0;
+    for (u32 i = 0; i < k; ++i)
+        for (u32 j = i + 1; j < k; ++j, ++p) {
+            int32_t pst;
+            bool ex;
+            pair(p, pst, ex);
+            if (pst != 0) {
+                *status = pst;
+                return;
+            }
+            all_identical = all_identical && ex;
+            no_conflict = no_conflict && (cnt[i] == 0 || cnt[j] == 0 || ex); /* :160-164 */
+            if (ex) {
+                match[i] |= 1ull << j;
+                match[j] |= 1ull << i;
+            }
+        }
+    const u32 majority = k / 2 + 1;
+    u64 first_majority = 0;
+    for (u32 i = 0; i < k && !first_majority; ++i) {
+        u32 pc = 0;
+        for (u64 x = match[i]; x; x &= x - 1) ++pc;
+        if (pc >= majority) first_majority = match[i];
+    }
+    if (all_identical) *classification = AVK_MERGE_IDENTICAL;
+    else if (no_conflict_enabled && no_conflict) {
+        *classification = AVK_MERGE_NO_CONFLICT;
+        for (u32 i = 0; i < k; ++i)
+            if (cnt[i]) *members |= 1ull << i;
+    } else if (majority_voting_enabled && first_majority) {
+        *classification = AVK_MERGE_MAJORITY_AGREE;
+        *members = first_majority;
+    } else if (conflict_selection >= 0) {
+        *classification = AVK_MERGE_CONFLICT_SELECTION;
+        *members = (u64)conflict_selection;
+    }
+}
+enum { DP_MERGE_KMAX = 8 }; /* regions with more inputs are classified by the host function */
+struct DpMerge {
+    const u32 *region_out; /* [n_multi * ppr][4] of the pair solve: status, exact */
+    const u64 *in_off;
+    const u32 *in_cnt;
+    const u8 *var_zyg;
+    u64 n_multi, n_variants;
+    u32 k, ppr;
+    u32 no_conflict_enabled, majority_voting_enabled;
+    int32_t conflict_selection;
+    int32_t *status;
+    u8 *classification;
+    u64 *members;
+};
+AVK_DEV void dp_merge_classify(const DpMerge &c, u64 m) {
+    if (m >= c.n_multi) return;
+    bool unknown = false;
+    for (u32 i = 0; i < c.k; ++i) {
+        const u64 off = c.in_off[m * c.k + i];
+        const u32 cnt = c.in_cnt[m * c.k + i];
+        for (u32 v = 0; v < cnt && off + v < c.n_variants; ++v) unknown = unknown || c.var_zyg[off + v] == AVK_ZYG_UNKNOWN;
+    }
+    const u32 *ro = c.region_out + 4 * (m * c.ppr);
+    int32_t st;
+    u8 cl;
+    u64 mem;
+    merge_classify_one<DP_MERGE_KMAX>(c.k, c.in_cnt + m * c.k, unknown, [ro](u64 p, int32_t &pst, bool &ex) {
+        pst = (int32_t)ro[4 * p];
+        ex = pst == 0 && ro[4 * p + 1] != 0;
+    }, c.no_conflict_enabled, c.majority_voting_enabled, c.conflict_selection, &st, &cl, &mem);
+    c.status[m] = st;
+    c.classification[m] = cl;
+    c.members[m] = mem;
+}
+
 /* ---- dp_variant: Variant::alt_ed (variants.rs:413-415 = wfa_ed(allele0, allele1), sequence_alignment.rs:9-13) ------------------------ */
 /* Unit-cost edit distance of a pattern of at most 64 symbols against a text of any length: the bit-vector recurrence of Myers
  * (J. ACM 46, 1999) in Hyyrö's global-distance form (the horizontal delta of row 0 is +1 in every column).  Symbols are bytes, so

@@ -10,6 +10,9 @@
 /* ---------------------------------------------------------------------------------- kernels */
 namespace dpk = avk::dp;
 
+__global__ void __launch_bounds__(256) avk_dp_expand_pairs_kernel(dpk::DpPairs c) { dpk::dp_expand_pairs(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) avk_dp_merge_classify_kernel(dpk::DpMerge c) { dpk::dp_merge_classify(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+
 __global__ void __launch_bounds__(256) avk_dp_widen_kernel(dpk::DpCompact c) { dpk::dp_widen(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 
 __global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dpk::dp_variant(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
@@ -547,16 +550,22 @@ static void release_pooled(avk_ctx *ctx, avk_dev_batch *db) {
 }
 
 /* b: the batch in the wide form, or NULL and cb: the batch in the compact form (avk_compact_batch: half the bytes over PCIe, widened on the device) */
-static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out) {
-    const uint64_t n = b ? b->n_regions : cb->n_regions, nv = b ? b->n_variants : cb->n_variants, alen = b ? b->allele_bytes_len : cb->allele_bytes_len;
+/* mb: a batch of MultiRegions (the merge path): one region per input pair is made on the device (dp_expand_pairs) */
+static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out, const avk_multi_batch *mb = nullptr) {
+    const uint32_t mk = mb ? mb->n_inputs : 0, mppr = mk * (mk - (mk ? 1u : 0u)) / 2;
+    const uint64_t n = b ? b->n_regions : (cb ? cb->n_regions : mb->n_regions * mppr), nv = b ? b->n_variants : (cb ? cb->n_variants : mb->n_variants),
+                   alen = b ? b->allele_bytes_len : (cb ? cb->allele_bytes_len : mb->allele_bytes_len);
+    if (mb && mb->n_regions && (!mb->start || !mb->end || !mb->in_off || !mb->in_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (mb && nv && (!mb->var_pos || !mb->var_type || !mb->var_zyg || !mb->a0_off || !mb->a0_len || !mb->a1_off || !mb->a1_len || !mb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (n > 0x7FFFFFFFull || nv > 0x7FFFFFFFull) return fail(ctx, AVK_E_ARG, "batch too large (more than 2^31 regions or variants); split it");
     if (b && n && (!b->start || !b->end || !b->t_off || !b->t_cnt || !b->q_off || !b->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (b && nv && (!b->var_pos || !b->var_type || !b->var_zyg || !b->a0_off || !b->a0_len || !b->a1_off || !b->a1_len || !b->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (cb && n && (!cb->start || !cb->len || !cb->v_off || !cb->t_cnt || !cb->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (cb && nv && (!cb->var_pos || !cb->var_type_zyg || !cb->a_off || !cb->a0_len || !cb->a1_len || !cb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (cb && alen > 0xFFFFFFFFull) return fail(ctx, AVK_E_ARG, "the compact form holds at most 2^32 allele bytes");
-    const bool has_contig = b ? b->contig_idx != nullptr : cb->contig_idx != nullptr, has_raw = b ? b->var_raw_space != nullptr : cb->var_raw_space != nullptr;
-    const uint8_t *host_alleles = b ? b->allele_bytes : cb->allele_bytes;
+    const bool has_contig = b ? b->contig_idx != nullptr : (cb ? cb->contig_idx != nullptr : mb->contig_idx != nullptr),
+               has_raw = b ? b->var_raw_space != nullptr : (cb ? cb->var_raw_space != nullptr : mb->var_raw_space != nullptr);
+    const uint8_t *host_alleles = b ? b->allele_bytes : (cb ? cb->allele_bytes : mb->allele_bytes);
     const bool timing = getenv("AVK_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
@@ -628,6 +637,30 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             {b->var_raw_space, d_raw, b->var_raw_space ? nv * 4 : 0}, {b->var_type, d_type, nv}, {b->var_zyg, d_zyg, nv}, {b->allele_bytes, d_alleles, alen}};
         rc = copy_in(ctx, segs);
         if (rc) return bail(rc);
+    } else if (mb) { /* the MultiRegions as they are, one kernel that writes a region per input pair; the call arrays are shared by all pairs */
+        const uint64_t nm = mb->n_regions;
+        uint32_t *m_contig = has_contig ? (uint32_t *)tmp((nm + 1) * 4) : nullptr;
+        uint64_t *m_start = (uint64_t *)tmp((nm + 1) * 8), *m_end = (uint64_t *)tmp((nm + 1) * 8);
+        db->d_m_in_off = (uint64_t *)kept((nm * mk + 1) * 8);
+        db->d_m_in_cnt = (uint32_t *)kept((nm * mk + 1) * 4);
+        db->d_in_zyg = d_zyg;
+        db->n_multi = nm, db->m_inputs = mk;
+        if (rc) return bail(rc);
+        std::vector<CopySeg> segs = {{mb->start, m_start, nm * 8}, {mb->end, m_end, nm * 8}, {mb->in_off, db->d_m_in_off, nm * mk * 8}, {mb->in_cnt, db->d_m_in_cnt, nm * mk * 4},
+                                     {mb->contig_idx, m_contig, has_contig ? nm * 4 : 0}, {mb->var_pos, d_pos, nv * 8}, {mb->a0_off, d_a0o, nv * 8}, {mb->a1_off, d_a1o, nv * 8},
+                                     {mb->a0_len, d_a0l, nv * 4}, {mb->a1_len, d_a1l, nv * 4}, {mb->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {mb->var_type, d_type, nv},
+                                     {mb->var_zyg, d_zyg, nv}, {mb->allele_bytes, d_alleles, alen}};
+        rc = copy_in(ctx, segs);
+        if (rc) return bail(rc);
+        dpk::DpPairs c;
+        memset(&c, 0, sizeof(c));
+        c.contig_idx = m_contig, c.start = m_start, c.end = m_end, c.in_off = db->d_m_in_off, c.in_cnt = db->d_m_in_cnt, c.n_multi = nm, c.k = mk, c.ppr = mppr;
+        c.w_contig = d_contig, c.w_t_cnt = db->d_in_t_cnt, c.w_q_cnt = db->d_in_q_cnt, c.w_start = d_start, c.w_end = d_end, c.w_t_off = db->d_in_t_off, c.w_q_off = db->d_in_q_off;
+        if (n) {
+            hipLaunchKernelGGL(avk_dp_expand_pairs_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, c);
+            hipError_t ew = hipGetLastError();
+            if (ew != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ew)));
+        }
     } else { /* the compact arrays as they are, then one kernel that writes the wide ones */
         dpk::DpCompact c;
         memset(&c, 0, sizeof(c));
@@ -667,10 +700,11 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             lo = a0 < a1 ? a0 : a1;
             const uint64_t e0 = b->t_off[n - 1] + b->t_cnt[n - 1], e1 = b->q_off[n - 1] + b->q_cnt[n - 1];
             hi = e0 > e1 ? e0 : e1;
-        } else if (n) {
+        } else if (n && cb) {
             lo = cb->v_off[0];
             hi = (uint64_t)cb->v_off[n - 1] + cb->t_cnt[n - 1] + cb->q_cnt[n - 1];
-        }
+        } else
+            hi = nv; /* (the pair form has no per-call outputs) */
         if (hi > nv) hi = nv;
         if (lo > hi) lo = hi;
         a.in.v_lo = lo, a.in.v_hi = hi;
@@ -713,7 +747,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             avk_parallel_for(np, avk_host_threads(), [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t k = lo; k < hi; ++k) {
                     const uint64_t v = idx[k];
-                    const uint64_t o0 = b ? b->a0_off[v] : cb->a_off[v], l0 = b ? b->a0_len[v] : cb->a0_len[v], o1 = b ? b->a1_off[v] : o0 + l0, l1 = b ? b->a1_len[v] : cb->a1_len[v];
+                    const uint64_t o0 = b ? b->a0_off[v] : (cb ? cb->a_off[v] : mb->a0_off[v]), l0 = b ? b->a0_len[v] : (cb ? cb->a0_len[v] : mb->a0_len[v]),
+                                   o1 = b ? b->a1_off[v] : (cb ? o0 + l0 : mb->a1_off[v]), l1 = b ? b->a1_len[v] : (cb ? cb->a1_len[v] : mb->a1_len[v]);
                     ed[k] = (uint32_t)avk::host_edit_distance(host_alleles + o0, l0, host_alleles + o1, l1);
                 }
             });

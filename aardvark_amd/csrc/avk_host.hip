@@ -357,6 +357,11 @@ struct avk_dev_batch {
     avk::dp::DpArgs dp_args; /* the packer's arguments: the writers of region records run again for the regions a launch turns out to need */
     avk::dp::DpArgs *d_dp_args = nullptr; /* the same in device memory (AvkKernelArgs::lazy_dp) */
     uint32_t lazy_from = 0;               /* first work-order index without a record (the lane classes' segment) */
+    uint64_t *d_m_in_off = nullptr;       /* merge batches (avk_merge_batch): the MultiRegions' in_off / in_cnt and the calls' zygosities, for the classification kernel */
+    uint32_t *d_m_in_cnt = nullptr;
+    uint8_t *d_in_zyg = nullptr;
+    uint64_t n_multi = 0;
+    uint32_t m_inputs = 0;
     uint64_t v_lo = 0, v_hi = 0;          /* the calls the batch's regions own: results are copied back for this range of the caller's arrays only */
     bool var_dense = false;               /* every call of the range is owned by a region of the batch */
     int64_t ws_bytes_eff = 0;             /* per-wave HBM slice of this batch's launches when the packer's prediction asks for more than the option ws_bytes_per_wave (0: the option) */
@@ -1994,53 +1999,12 @@ int avk_merge_classify(uint64_t n_regions, uint32_t k, const uint32_t *in_cnt, c
     if (k < 1 || k > 64) return AVK_E_ARG;
     const uint64_t ppr = (uint64_t)k * (k - 1) / 2;
     for (uint64_t m = 0; m < n_regions; ++m) {
-        status[m] = 0;
-        classification[m] = AVK_MERGE_DIFFERENT;
-        members[m] = 0;
-        if (has_unknown_zyg && has_unknown_zyg[m]) { /* variant_delta_length bails on an Unknown zygosity before anything else */
-            status[m] = AVK_ST_BAD_ZYGOSITY;
-            continue;
-        }
-        const uint32_t *cnt = in_cnt + m * k;
-        bool all_identical = true, no_conflict = true;
-        uint64_t match[64];
-        for (uint32_t i = 0; i < k; ++i) match[i] = 1ull << i;
-        uint64_t p = m * ppr;
-        int32_t err = 0;
-        for (uint32_t i = 0; i < k && !err; ++i)
-            for (uint32_t j = i + 1; j < k; ++j, ++p) {
-                if (pair_status[p] != 0) {
-                    err = pair_status[p];
-                    break;
-                }
-                const bool ex = pair_exact[p] != 0;
-                all_identical = all_identical && ex;
-                no_conflict = no_conflict && (cnt[i] == 0 || cnt[j] == 0 || ex); /* :160-164 */
-                if (ex) {
-                    match[i] |= 1ull << j;
-                    match[j] |= 1ull << i;
-                }
-            }
-        if (err) {
-            status[m] = err;
-            continue;
-        }
-        const uint32_t majority = k / 2 + 1;
-        uint64_t first_majority = 0;
-        for (uint32_t i = 0; i < k && !first_majority; ++i)
-            if ((uint32_t)__builtin_popcountll(match[i]) >= majority) first_majority = match[i];
-        if (all_identical) classification[m] = AVK_MERGE_IDENTICAL;
-        else if (cfg->no_conflict_enabled && no_conflict) {
-            classification[m] = AVK_MERGE_NO_CONFLICT;
-            for (uint32_t i = 0; i < k; ++i)
-                if (cnt[i]) members[m] |= 1ull << i;
-        } else if (cfg->majority_voting_enabled && first_majority) {
-            classification[m] = AVK_MERGE_MAJORITY_AGREE;
-            members[m] = first_majority;
-        } else if (cfg->conflict_selection >= 0) {
-            classification[m] = AVK_MERGE_CONFLICT_SELECTION;
-            members[m] = (uint64_t)cfg->conflict_selection;
-        }
+        const int32_t *pst = pair_status + m * ppr;
+        const uint8_t *pex = pair_exact + m * ppr;
+        avk::dp::merge_classify_one<64>(k, in_cnt + m * k, has_unknown_zyg && has_unknown_zyg[m], [pst, pex](uint64_t p, int32_t &st, bool &ex) {
+            st = pst[p];
+            ex = pex[p] != 0;
+        }, cfg->no_conflict_enabled, cfg->majority_voting_enabled, cfg->conflict_selection, status + m, classification + m, members + m);
     }
     return 0;
 }
@@ -2049,6 +2013,47 @@ int avk_merge_batch(avk_ctx *ctx, const avk_multi_batch *mb, const avk_merge_con
     if (!ctx || !mb || !cfg || !status || !classification || !members) return AVK_E_ARG;
     const uint32_t k = mb->n_inputs;
     if (k < 1 || k > 64) return fail(ctx, AVK_E_ARG, "n_inputs must be in [1, 64]");
+    if (ctx->device_pack && k >= 2 && k <= (uint32_t)avk::dp::DP_MERGE_KMAX && mb->n_regions && mb->n_regions * (uint64_t)(k * (k - 1) / 2) <= 0x7FFFFFFFull) {
+        /* all of solve_merge_region on the device: the MultiRegions as they are over PCIe, one region per input pair made by a kernel, the pair solve (mode 1),
+         * the decision on top of the pair matrix by a kernel; status / classification / members come back */
+        if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+        AVK_HIP(ctx, hipSetDevice(ctx->device));
+        avk_dev_batch *db = nullptr;
+        int rc = upload_device_packed(ctx, nullptr, nullptr, true, &db, mb);
+        if (rc) return rc;
+        avk_compare_config pcfg;
+        pcfg.max_branch_factor = cfg->max_branch_factor, pcfg.enable_sequences = 0, pcfg.enable_exact_shortcut = 0;
+        const int64_t keep = ctx->emit_group_metrics;
+        ctx->emit_group_metrics = 0;
+        rc = run_internal(ctx, db, &pcfg, nullptr, 1);
+        ctx->emit_group_metrics = keep;
+        const uint64_t nm = mb->n_regions;
+        void *d_st = nullptr, *d_cl = nullptr, *d_mem = nullptr;
+        if (!rc) rc = pool_alloc(ctx, &d_st, (nm + 1) * 4);
+        if (!rc) rc = pool_alloc(ctx, &d_cl, nm + 16);
+        if (!rc) rc = pool_alloc(ctx, &d_mem, (nm + 1) * 8);
+        if (!rc) {
+            avk::dp::DpMerge c;
+            memset(&c, 0, sizeof(c));
+            c.region_out = db->d_region_out, c.in_off = db->d_m_in_off, c.in_cnt = db->d_m_in_cnt, c.var_zyg = db->d_in_zyg, c.n_multi = nm, c.n_variants = mb->n_variants, c.k = k,
+            c.ppr = k * (k - 1) / 2, c.no_conflict_enabled = cfg->no_conflict_enabled, c.majority_voting_enabled = cfg->majority_voting_enabled, c.conflict_selection = cfg->conflict_selection;
+            c.status = (int32_t *)d_st, c.classification = (uint8_t *)d_cl, c.members = (uint64_t *)d_mem;
+            hipLaunchKernelGGL(avk_dp_merge_classify_kernel, dim3((unsigned)((nm + 255) / 256)), dim3(256), 0, ctx->stream, c);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "merge classification failed: %s", hipGetErrorString(e));
+        }
+        if (!rc) {
+            std::vector<CopySeg> segs = {{status, d_st, nm * 4}, {classification, d_cl, nm}, {members, d_mem, nm * 8}};
+            CopyOut co;
+            rc = copy_out(ctx, segs, &co);
+            if (!rc) rc = finish_copy_out(ctx, co);
+        }
+        (void)hipStreamSynchronize(ctx->stream);
+        pool_release(ctx, d_st), pool_release(ctx, d_cl), pool_release(ctx, d_mem);
+        ctx->last_one_shot = rc == 0;
+        avk_batch_free(ctx, db);
+        return rc;
+    }
     const uint64_t n = mb->n_regions, ppr = (uint64_t)k * (k - 1) / 2, np = n * ppr;
     /* one CompareRegion-shaped item per (i < j) pair: input i plays the truth side, input j the query side */
     std::vector<uint64_t> rid(np), st(np), en(np), t_off(np), q_off(np);

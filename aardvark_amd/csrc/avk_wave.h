@@ -24,6 +24,7 @@
 /* ------------------------------------------------------------------------------ emulator */
 #define AVK_DEV static inline
 #define AVK_DEV_NOINLINE static
+#define AVK_HD static inline /* plain functions the host code calls as well */
 namespace avk_emu {
 /* deposits `v` for this lane, runs the other lanes up to the same call site, returns the 64
  * deposited values.  `site` must be identical on all lanes (checked: catches divergent use). */
@@ -117,6 +118,7 @@ AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 #include <hip/hip_runtime.h>
 #define AVK_DEV __device__ __forceinline__
 #define AVK_DEV_NOINLINE __device__ __noinline__
+#define AVK_HD __host__ __device__ inline /* plain functions the host code calls as well */
 typedef uint4 avk_u4; /* one 16-byte LDS / global access */
 
 /* The lane index is deliberately opaque to the optimiser (a volatile asm, two VALU instructions per use): as a pure

@@ -30,6 +30,30 @@ def take_regions(batch, idx):
                        batch.a0_off, batch.a0_len, batch.a1_off, batch.a1_len, batch.allele_bytes)
 
 
+def gather_calls(batch):
+    """the same regions with call and allele arrays that hold only THEIR calls, region by region (truth calls, then query calls): what a rank copies to its GPU is
+    its shard, not the job; also the layout the compact form (CompactBatch) asks for"""
+    from .synth import _ragged
+    n = batch.n_regions
+    tc, qc = batch.t_cnt.astype(np.int64), batch.q_cnt.astype(np.int64)
+    starts = np.stack([batch.t_off.astype(np.int64), batch.q_off.astype(np.int64)], axis=1).reshape(-1)
+    lens = np.stack([tc, qc], axis=1).reshape(-1)
+    src, _ = _ragged(starts, lens)
+    new_t = np.cumsum(tc + qc) - (tc + qc)
+    a0_len, a1_len = batch.a0_len[src].astype(np.int64), batch.a1_len[src].astype(np.int64)
+    a0_off = np.cumsum(a0_len + a1_len) - (a0_len + a1_len)
+    a1_off = a0_off + a0_len
+    arena = np.zeros(int((a0_len + a1_len).sum()) + 1, np.uint8)
+    d, _ = _ragged(a0_off, a0_len)
+    sidx, _ = _ragged(batch.a0_off[src].astype(np.int64), a0_len)
+    arena[d] = batch.allele_bytes[sidx]
+    d, _ = _ragged(a1_off, a1_len)
+    sidx, _ = _ragged(batch.a1_off[src].astype(np.int64), a1_len)
+    arena[d] = batch.allele_bytes[sidx]
+    return RegionBatch(batch.region_id, batch.contig_idx, batch.start, batch.end, new_t, batch.t_cnt, new_t + tc, batch.q_cnt, batch.var_pos[src], batch.var_type[src], batch.var_zyg[src],
+                       batch.var_raw_space[src], a0_off, a0_len, a1_off, a1_len, arena[:max(int((a0_len + a1_len).sum()), 1)])
+
+
 def shard_batch(batch, rank, world):
     """the regions of `batch` this rank owns: hash(region_id) % world == rank (reference loop src/main.rs:251-268 maps over
     independent regions).  bench.py --scaling strong and the tools use this one function."""

@@ -190,7 +190,7 @@ def main():
     n_job_regions = batch.n_regions
     job_batch = batch  # strong scaling: every rank holds the job's call set and solves its hash shard of it
     if scaling == "strong" and world > 1:
-        batch = avk_dist.shard_batch(batch, rank, world)
+        batch = avk_dist.gather_calls(avk_dist.shard_batch(batch, rank, world))  # the rank's regions with their own calls only: a rank copies its shard, not the job
     n_regions = batch.n_regions
     log("workload: %d contigs, %d bases, %d regions on this rank, %d calls" % (len(contigs), sum(c.size for c in contigs), n_regions, batch.n_variants))
 
@@ -251,7 +251,7 @@ def main():
         total_regions = int(cnt.item())
     else:
         total_regions = n_regions
-    log("timed region: %d avk_compare_batch calls in %.3f s (%.2f ms per call)" % (args.steps, elapsed, elapsed / max(args.steps, 1) * 1e3))
+    log("timed region: %d avk_compare_compact calls in %.3f s (%.2f ms per call)" % (args.steps, elapsed, elapsed / max(args.steps, 1) * 1e3))
     job_tally = tally.clone()
     got_boundary = res  # the outputs of the last timed call, in the caller's arrays
     # the same boundary with the batch in the WIDE structure-of-arrays form (avk_region_batch: 52 B per region + 38 B per call over PCIe)
@@ -533,24 +533,12 @@ def secondary_legs(ctx, cfg, args, cpus, log):
         st_o, ex_o = oracle_lib.optimize_pairs(lib, pair_batch_of(mb), oracle_lib.ContigSet(contigs5), 50, threads=cpus)
         st_o, ex_o = st_o.reshape(-1, 3), ex_o.reshape(-1, 3)
         bad = []
-        # vectorised restatement of merge_solver.rs:149-199 for k = 3, majority voting on, the other strategies off
-        err = (st_o != 0).any(axis=1)
-        first_err = np.where(st_o[:, 0] != 0, st_o[:, 0], np.where(st_o[:, 1] != 0, st_o[:, 1], st_o[:, 2]))
-        ident = ex_o.all(axis=1) & ~err
-        e01, e02, e12 = ex_o[:, 0] != 0, ex_o[:, 1] != 0, ex_o[:, 2] != 0
-        m0 = 1 | (e01 << 1) | (e02 << 2)
-        m1 = (e01 << 0) | 2 | (e12 << 2)
-        m2 = (e02 << 0) | (e12 << 1) | 4
-        pc = lambda m: (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1)
-        maj = np.where(pc(m0) >= 2, m0, np.where(pc(m1) >= 2, m1, np.where(pc(m2) >= 2, m2, 0)))
-        want_cls = np.where(err, 0, np.where(ident, 1, np.where(maj != 0, 3, 0)))
-        want_members = np.where(err | ident | (maj == 0), 0, maj)
-        want_status = np.where(err, first_err, 0)
+        want_status, want_cls, want_members = mo.classify_k3_majority(st_o, ex_o)  # the restated rule, vectorised (oracle/merge_oracle.py)
         if not np.array_equal(mres.status, want_status):
             bad.append("status")
-        if not np.array_equal(mres.classification, want_cls.astype(np.uint8)):
+        if not np.array_equal(mres.classification, want_cls):
             bad.append("classification")
-        if not np.array_equal(mres.members, want_members.astype(np.uint64)):
+        if not np.array_equal(mres.members, want_members):
             bad.append("members")
         sample = mb.regions()[:2000] if mb.n_regions <= 200_000 else None  # the dict form is slow: small runs only
         if sample is not None:

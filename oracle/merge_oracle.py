@@ -105,3 +105,23 @@ def merge_summary_text(regions, results, tags, type_index, delim="\t"):
         reason = SIMPLE[name] + "".join("_%d" % i for i in key[1])
         out.append(delim.join([reason, TYPE_NAMES[key[2]], str(key[3]), tags[key[3]], str(p), str(f)]))
     return "\n".join(out) + "\n"
+
+
+def classify_k3_majority(pair_status, pair_exact):
+    """solve_merge_region's decision (src/merge_solver.rs:149-199) for MANY regions of three inputs at once, majority voting on and the other strategies off, in
+    numpy: pair_status / pair_exact [n][3] for the pairs (0,1), (0,2), (1,2) -> (status[n], classification code[n], members bitmask[n]) with the codes of
+    include/aardvark_amd.h (0 different, 1 identical, 3 majority).  The whole-genome checks of bench.py and tests/test_gpu_devpack.py use it; `classify` above is
+    the general per-region form."""
+    import numpy as np
+    st = np.asarray(pair_status).reshape(-1, 3)
+    ex = np.asarray(pair_exact).reshape(-1, 3) != 0
+    err = (st != 0).any(axis=1)
+    first_err = np.where(st[:, 0] != 0, st[:, 0], np.where(st[:, 1] != 0, st[:, 1], st[:, 2]))
+    ident = ex.all(axis=1) & ~err
+    e01, e02, e12 = ex[:, 0].astype(np.int64), ex[:, 1].astype(np.int64), ex[:, 2].astype(np.int64)
+    m0, m1, m2 = 1 | (e01 << 1) | (e02 << 2), e01 | 2 | (e12 << 2), e02 | (e12 << 1) | 4
+    pc = lambda m: (m & 1) + ((m >> 1) & 1) + ((m >> 2) & 1)
+    maj = np.where(pc(m0) >= 2, m0, np.where(pc(m1) >= 2, m1, np.where(pc(m2) >= 2, m2, 0)))
+    cls = np.where(err, 0, np.where(ident, 1, np.where(maj != 0, 3, 0))).astype(np.uint8)
+    members = np.where(err | ident | (maj == 0), 0, maj).astype(np.uint64)
+    return np.where(err, first_err, 0).astype(np.int32), cls, members

@@ -827,6 +827,44 @@ int emu_dwfa_script_batch(int engine, uint32_t n_scripts, const uint8_t *bytes, 
     return 0;
 }
 
+/* avk_merge_batch's device path on emulated wavefronts: dp_expand_pairs, the pair solve (mode 1), dp_merge_classify */
+int emu_merge_batch(const avk_multi_batch *mb, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs, const avk_merge_config *cfg, int32_t *status,
+                    uint8_t *classification, uint64_t *members, int threads) {
+    const uint32_t k = mb->n_inputs, ppr = k * (k - 1) / 2;
+    const uint64_t nm = mb->n_regions, np = nm * ppr;
+    std::vector<uint64_t> st(np + 1), en(np + 1), toff(np + 1), qoff(np + 1);
+    std::vector<uint32_t> cidx(np + 1), tcnt(np + 1), qcnt(np + 1);
+    dpk::DpPairs c;
+    memset(&c, 0, sizeof(c));
+    c.contig_idx = mb->contig_idx, c.start = mb->start, c.end = mb->end, c.in_off = mb->in_off, c.in_cnt = mb->in_cnt, c.n_multi = nm, c.k = k, c.ppr = ppr;
+    c.w_contig = mb->contig_idx ? cidx.data() : nullptr, c.w_t_cnt = tcnt.data(), c.w_q_cnt = qcnt.data(), c.w_start = st.data(), c.w_end = en.data(), c.w_t_off = toff.data(), c.w_q_off = qoff.data();
+    for (uint64_t p = 0; p < np; ++p) dpk::dp_expand_pairs(c, p);
+    avk_region_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_regions = np, b.contig_idx = mb->contig_idx ? cidx.data() : nullptr, b.start = st.data(), b.end = en.data(), b.t_off = toff.data(), b.t_cnt = tcnt.data(), b.q_off = qoff.data(),
+    b.q_cnt = qcnt.data(), b.n_variants = mb->n_variants, b.var_pos = mb->var_pos, b.var_type = mb->var_type, b.var_zyg = mb->var_zyg, b.var_raw_space = mb->var_raw_space, b.a0_off = mb->a0_off,
+    b.a0_len = mb->a0_len, b.a1_off = mb->a1_off, b.a1_len = mb->a1_len, b.allele_bytes = mb->allele_bytes, b.allele_bytes_len = mb->allele_bytes_len;
+    std::vector<int32_t> pst(np + 1);
+    std::vector<uint32_t> pex(np + 1);
+    avk_compare_config pc;
+    pc.max_branch_factor = cfg->max_branch_factor, pc.enable_sequences = 0, pc.enable_exact_shortcut = 0;
+    avk_result_batch out;
+    memset(&out, 0, sizeof(out));
+    out.status = pst.data();
+    out.ed_h1 = pex.data();
+    const int rc = emu_run(1, &b, refs, ref_lens, n_contigs, &pc, &out, 10 * 1024, 48, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0, 0, 1);
+    if (rc) return rc;
+    std::vector<uint32_t> rout(4 * np + 4, 0); /* what the pair solve leaves in region_out: status, exact */
+    for (uint64_t p = 0; p < np; ++p) rout[4 * p] = (uint32_t)pst[p], rout[4 * p + 1] = pex[p];
+    dpk::DpMerge m;
+    memset(&m, 0, sizeof(m));
+    m.region_out = rout.data(), m.in_off = mb->in_off, m.in_cnt = mb->in_cnt, m.var_zyg = mb->var_zyg, m.n_multi = nm, m.n_variants = mb->n_variants, m.k = k, m.ppr = ppr;
+    m.no_conflict_enabled = cfg->no_conflict_enabled, m.majority_voting_enabled = cfg->majority_voting_enabled, m.conflict_selection = cfg->conflict_selection;
+    m.status = status, m.classification = classification, m.members = members;
+    for (uint64_t r = 0; r < nm; ++r) dpk::dp_merge_classify(m, r);
+    return 0;
+}
+
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 

@@ -211,3 +211,50 @@ def test_compact_form(ctx_pair, oracle):
             continue  # (a window that ends before it starts has no compact form)
         dev.upload_reference(contigs)
         assert dev.solve_compact(c2, res=None).diff(oracle_lib.compare_batch(oracle, b, contigs, threads=CPUS, group_metrics=False)) == []
+
+
+def test_merge_of_three_call_sets_at_genome_density(oracle):
+    """configs[4] at the size of one contig: three perturbed call sets of one chr20-sized contig at the benchmark's density through avk_merge_batch (pair
+    expansion, pair solve and classification on the device) against oracle pairs + the restated rule; every strategy on a slice"""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import merge_oracle as mo
+    import aardvark_amd
+    from aardvark_amd.merge import MergeConfig, MultiBatch, merge_multi_batch, pair_batch
+    n_truth = int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38))
+    contig = synth.make_contig_fast(synth.CHR20_LEN, 20250103 + 19)
+    rng = np.random.default_rng(20250103 + 119)
+    bed = synth.make_bed(synth.CHR20_LEN, 1000, 0.9, rng)
+    truth, info = synth.genome_truth(contig, bed, n_truth, 20250103 + 219)
+    sets = [synth.genome_query(contig, bed, truth, info, seed, max(1, len(truth) // 100)) for seed in (20250105, 20250106, 20250107)]
+    mb = MultiBatch(3, **synth.cluster_multi_v(contig, bed, sets, 50))
+    ctx = aardvark_amd.Context(0)
+    try:
+        ctx.upload_reference([contig])
+        got = merge_multi_batch(ctx, mb, MergeConfig(majority_voting_enabled=True))
+        assert ctx.last_compare_was_one_shot()
+        k, n = 3, mb.n_regions
+        off, cnt = mb.in_off.reshape(n, k), mb.in_cnt.reshape(n, k)
+        pairs = [(0, 1), (0, 2), (1, 2)]
+        rep = lambda a: np.repeat(a, 3)
+        pb = RegionBatch(rep(mb.region_id), rep(mb.contig_idx), rep(mb.start), rep(mb.end), np.stack([off[:, i] for i, _ in pairs], 1).reshape(-1),
+                         np.stack([cnt[:, i] for i, _ in pairs], 1).reshape(-1), np.stack([off[:, j] for _, j in pairs], 1).reshape(-1), np.stack([cnt[:, j] for _, j in pairs], 1).reshape(-1),
+                         mb.var_pos, mb.var_type, mb.var_zyg, mb.var_raw_space, mb.a0_off, mb.a0_len, mb.a1_off, mb.a1_len, mb.allele_bytes)
+        st_o, ex_o = oracle_lib.optimize_pairs(oracle, pb, [contig], 50, threads=CPUS)
+        ws, wc, wm = mo.classify_k3_majority(st_o, ex_o)
+        assert np.array_equal(got.status, ws) and np.array_equal(got.classification, wc) and np.array_equal(got.members, wm)
+        assert (wc == 1).sum() > 0.8 * n and (wc == 3).sum() > 0.01 * n
+        # the general rule, region by region, for every strategy on a slice of the contig
+        sub = MultiBatch(3, region_id=mb.region_id[:3000], contig_idx=mb.contig_idx[:3000], start=mb.start[:3000], end=mb.end[:3000], in_off=mb.in_off[:9000], in_cnt=mb.in_cnt[:9000],
+                         var_pos=mb.var_pos, var_type=mb.var_type, var_zyg=mb.var_zyg, var_raw_space=mb.var_raw_space, a0_off=mb.a0_off, a0_len=mb.a0_len, a1_off=mb.a1_off, a1_len=mb.a1_len,
+                         allele_bytes=mb.allele_bytes)
+        for cfg in (MergeConfig(), MergeConfig(no_conflict_enabled=True), MergeConfig(no_conflict_enabled=True, majority_voting_enabled=True, conflict_selection=2)):
+            dec = merge_multi_batch(ctx, sub, cfg).decoded()
+            for m in range(sub.n_regions):
+                if (st_o.reshape(-1, 3)[m] != 0).any():
+                    continue
+                w = mo.classify([int(x) for x in cnt[m]], lambda i, j: int(ex_o.reshape(-1, 3)[m][{(0, 1): 0, (0, 2): 1, (1, 2): 2}[(i, j)]]), cfg.no_conflict_enabled,
+                                cfg.majority_voting_enabled, cfg.conflict_selection)
+                assert dec[m][1] == tuple(w) or dec[m][1] == w, (m, dec[m], w)
+    finally:
+        ctx.close()

@@ -108,3 +108,41 @@ def test_pairs_on_gpu_match_oracle(oracle):
         want = solve_merge_regions(lambda b, mbf: oracle_lib.optimize_pairs(oracle, b, contigs, max_branch_factor=mbf, threads=8), multi, cfg)
         assert merge_batch(ctx, multi, cfg) == want
     ctx.close()
+
+
+def test_device_merge_path_kernel_logic(oracle):
+    """avk_merge_batch's device path (dp_expand_pairs -> pair solve -> dp_merge_classify, aardvark_amd/csrc/avk_devpack.inl) through the emulator: the reference's
+    known-answer regions, and three-input regions from fuzzed call sets against oracle pairs + the library's host classification"""
+    import ctypes as C
+    from aardvark_amd.merge import AvkMergeConfig, AvkMultiBatch, MergeResult, MultiBatch
+    from oracle_lib import ContigSet
+    lib = emu_lib.load()
+    lib.emu_merge_batch.argtypes = [C.POINTER(AvkMultiBatch), C.POINTER(oracle_lib.u8p), oracle_lib.u64p, C.c_uint32, C.POINTER(AvkMergeConfig), C.POINTER(C.c_int32), oracle_lib.u8p,
+                                    oracle_lib.u64p, C.c_int]
+
+    def device_merge(multi, contigs, config):
+        mb = MultiBatch.from_regions(multi)
+        cs = ContigSet(contigs)
+        cfg = AvkMergeConfig(config.max_branch_factor, int(config.no_conflict_enabled), int(config.majority_voting_enabled), -1 if config.conflict_selection is None else int(config.conflict_selection))
+        st, cl, mem = np.zeros(mb.n_regions, np.int32), np.zeros(mb.n_regions, np.uint8), np.zeros(mb.n_regions, np.uint64)
+        cb = mb.c_struct()
+        assert lib.emu_merge_batch(C.byref(cb), cs.ptrs, cs.lens, cs.n, C.byref(cfg), st.ctypes.data_as(C.POINTER(C.c_int32)), cl.ctypes.data_as(oracle_lib.u8p),
+                                   mem.ctypes.data_as(oracle_lib.u64p), 4) == 0
+        return MergeResult(st, cl, mem, mb.n_inputs).decoded()
+
+    contig = [GOLD["contig"].encode()]
+    for r, want in zip(GOLD["regions"], expect()):
+        assert device_merge([{"start": r["start"], "end": r["end"], "inputs": r["inputs"]}], contig, MergeConfig(**r["config"]))[0] == want, r
+    contigs, batch = scenarios.fuzz_regions(44, 120, related=0.9)
+
+    def variants(b, off, cnt):
+        return [(int(b.var_pos[v]), bytes(b.allele_bytes[int(b.a0_off[v]):int(b.a0_off[v]) + int(b.a0_len[v])]), bytes(b.allele_bytes[int(b.a1_off[v]):int(b.a1_off[v]) + int(b.a1_len[v])]),
+                 int(b.var_type[v]), int(b.var_zyg[v]), int(b.var_raw_space[v])) for v in range(off, off + cnt)]
+    multi = []
+    for q in range(batch.n_regions):
+        t = variants(batch, int(batch.t_off[q]), int(batch.t_cnt[q]))
+        qv = variants(batch, int(batch.q_off[q]), int(batch.q_cnt[q]))
+        multi.append({"start": int(batch.start[q]), "end": int(batch.end[q]), "inputs": [t, qv, t if q % 2 else qv, qv if q % 3 else []]})
+    for cfg in (MergeConfig(), MergeConfig(majority_voting_enabled=True), MergeConfig(no_conflict_enabled=True, conflict_selection=1)):
+        want = solve_merge_regions(lambda b, mbf: oracle_lib.optimize_pairs(oracle, b, contigs, max_branch_factor=mbf, threads=8), multi, cfg)
+        assert device_merge(multi, contigs, cfg) == want
