@@ -1076,7 +1076,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
         for (int i = 0; i < AVK_N_FIELDS; ++i) {
             const u32 v = G.f[i];
             if (!v) continue;
-            avk_atomic_add_u32(tally + g * AVK_N_FIELDS + i, v);
+            avk_tally_add_u32(tally, g * AVK_N_FIELDS + i, v); /* lanes with the same (counter, value) share one LDS atomic */
             if (gm_out) gm_out[g * AVK_N_FIELDS + i] = v;
         }
     }

@@ -93,6 +93,8 @@ AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_
     __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     return expect;
 }
+/* many lanes adding to the counters of one table (the emulated lanes are fibers of one thread: a plain add each) */
+AVK_DEV void avk_tally_add_u32(uint32_t *table, uint32_t off, uint32_t v) { __atomic_fetch_add(table + off, v, __ATOMIC_RELAXED); }
 AVK_DEV uint64_t avk_clock() { return 0; }
 /* identity the optimiser cannot see through: keeps per-lane address arithmetic inside the loop it belongs to */
 AVK_DEV uint32_t avk_opaque_u32(uint32_t v) { return v; }
@@ -190,6 +192,21 @@ AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return ato
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 AVK_DEV void avk_atomic_or_u32_global(uint32_t *p, uint32_t v) { atomicOr(p, v); }
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
+/* Many lanes adding to the counters of one LDS table, called from DIVERGENT code by whichever lanes have something to add: lanes that add the SAME value
+ * to the SAME counter are combined into one atomic (the first remaining lane's pair is broadcast, the lanes that match it leave together) — a tile of the
+ * modal class adds the same ones and twos to the same dozen counters from all 64 lanes, which as 64 separate ds_add on one address serialise
+ * (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE was 0.70 on that launch). */
+AVK_DEV void avk_tally_add_u32(uint32_t *table, uint32_t off, uint32_t v) {
+    for (;;) {
+        const uint32_t off0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)off), v0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+        const bool same = off == off0 && v == v0;
+        const unsigned long long m = __ballot(same);
+        if (same) {
+            if ((unsigned)wv_lane() == (unsigned)(__ffsll((unsigned long long)m) - 1)) atomicAdd(table + off0, v0 * (uint32_t)__popcll(m));
+            break;
+        }
+    }
+}
 AVK_DEV uint64_t avk_clock() { return __builtin_amdgcn_s_memtime(); }
 /* identity the optimiser cannot see through: keeps per-lane address arithmetic inside the loop it belongs to (hoisted
  * out of the persistent region loop it is spilled to scratch in the prologue and reloaded for every region) */
