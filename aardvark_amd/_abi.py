@@ -116,6 +116,8 @@ class AvkResultBatch(C.Structure):
         ("seq_stride", _p(C.c_uint32)),
         ("seq_len", _p(C.c_uint32)),
         ("tally", _p(C.c_uint64)),
+        ("bp_off", _p(C.c_uint32)),
+        ("bp_groups", _p(C.c_uint32)),
     ]
 
 
@@ -290,8 +292,10 @@ class CompactBatch:
 class ResultBatch:
     """Caller-allocated outputs of one avk_compare_batch / orc_compare_batch call."""
 
-    def __init__(self, batch, sequences=False, group_metrics=True):
+    def __init__(self, batch, sequences=False, group_metrics=True, bp_groups=False):
         n, v = batch.n_regions, batch.n_variants
+        self.bp_off = np.zeros(n + 1, np.uint32) if bp_groups else None       # compact per-region BASEPAIR groups (avk_result_batch::bp_off / bp_groups)
+        self.bp_groups = np.zeros((n + v + 1, 4), np.uint32) if bp_groups else None
         self.status = np.full(n, -1, np.int32)
         self.ed_h1 = np.zeros(n, np.uint32)
         self.ed_h2 = np.zeros(n, np.uint32)
@@ -327,6 +331,9 @@ class ResultBatch:
         o.var_class = _ptr(self.var_class, C.c_uint8)
         o.var_zyg = _ptr(self.var_zyg, C.c_uint8)
         o.tally = _ptr(self.tally, C.c_uint64)
+        if self.bp_off is not None:
+            o.bp_off = _ptr(self.bp_off, C.c_uint32)
+            o.bp_groups = _ptr(self.bp_groups, C.c_uint32)
         if self.sequences:
             o.seq_bytes = _ptr(self.seq_bytes, C.c_uint8)
             o.seq_off = _ptr(self.seq_off, C.c_uint64)

@@ -75,6 +75,7 @@ def load_library():
     lib.avk_algorithmic_bytes_ex.restype = C.c_uint64
     lib.avk_algorithmic_bytes_ex.argtypes = [C.POINTER(AvkRegionBatch), C.c_int]
     lib.avk_optimize_pairs_batch.argtypes = [vp, C.POINTER(AvkRegionBatch), C.c_uint32, C.POINTER(C.c_int32), u8p]
+    lib.avk_group_metrics_from_compact.argtypes = [C.POINTER(AvkRegionBatch), C.c_uint64, C.POINTER(AvkResultBatch), C.POINTER(C.c_uint32)]
     lib.avk_host_alloc.restype = vp
     lib.avk_host_alloc.argtypes = [vp, C.c_size_t]
     lib.avk_host_free.restype = None
@@ -175,10 +176,11 @@ class Context:
         self._check(self.lib.avk_compare_compact(self.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
         return res
 
-    def pinned_results(self, batch, group_metrics=False):
+    def pinned_results(self, batch, group_metrics=False, bp_groups=False):
         """a ResultBatch whose arrays live in pinned memory"""
-        res = ResultBatch(batch, sequences=False, group_metrics=group_metrics)
-        for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg") + (("group_metrics",) if group_metrics else ()):
+        res = ResultBatch(batch, sequences=False, group_metrics=group_metrics, bp_groups=bp_groups)
+        for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg") + (("group_metrics",) if group_metrics else ()) + \
+                (("bp_off", "bp_groups") if bp_groups else ()):
             a = getattr(res, f)
             b = self.host_array(a.shape, a.dtype)
             b[...] = a
@@ -211,10 +213,10 @@ class Context:
         self._check(self.lib.avk_ref_upload(self.handle, len(arrs), ptrs, lens))
         self._contigs = arrs
 
-    def solve_compare_regions(self, batch, config=None, group_metrics=True):
+    def solve_compare_regions(self, batch, config=None, group_metrics=True, bp_groups=False):
         """solve_compare_region for every region of `batch` -> ResultBatch."""
         config = config or CompareConfig()
-        res = ResultBatch(batch, sequences=bool(config.enable_sequences), group_metrics=group_metrics)
+        res = ResultBatch(batch, sequences=bool(config.enable_sequences), group_metrics=group_metrics, bp_groups=bp_groups)
         cb, cfg, ro = batch.c_struct(), config.c_struct(), res.c_struct()
         self._check(self.lib.avk_compare_batch(self.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
         return res
@@ -298,3 +300,18 @@ class Context:
     def algorithmic_bytes(self, batch, with_groups=True):
         cb = batch.c_struct()
         return int(self.lib.avk_algorithmic_bytes_ex(C.byref(cb), 1 if with_groups else 0))
+
+
+def group_metrics_from_compact(batch, res):
+    """avk_group_metrics_from_compact for every solved region: the full [n][13][22] blocks rebuilt on the host from the per-call outputs and the compact per-region
+    BASEPAIR groups of `res` (regions with a non-zero status stay zero)"""
+    lib = load_library()
+    out = np.zeros((batch.n_regions, 13, 22), np.uint32)
+    cb, ro = batch.c_struct(), res.c_struct()
+    for r in range(batch.n_regions):
+        if res.status[r] != 0:
+            continue
+        rc = lib.avk_group_metrics_from_compact(C.byref(cb), r, C.byref(ro), out[r].ctypes.data_as(C.POINTER(C.c_uint32)))
+        if rc != 0:
+            raise AardvarkAmdError("avk_group_metrics_from_compact failed for region %d" % r)
+    return out

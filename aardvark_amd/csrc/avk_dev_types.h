@@ -187,6 +187,11 @@ struct AvkKernelArgs {
     const void *lazy_dp;
     uint32_t lazy_from;
     uint32_t pad3_;
+    /* compact per-region BASEPAIR groups (optional): region r (caller order) owns groups [bp_off[r], bp_off[r + 1]) of bp_out — the joint group, then one per
+     * call type present among its calls, in type order — 4 counters each (AVK_F_BP_TRUTH_TP .. AVK_F_BP_QUERY_FP).  The other 18 counters of a group follow
+     * from the per-call decisions (avk_group_metrics_from_compact). */
+    const uint32_t *bp_off;
+    uint32_t *bp_out;
 };
 
 #endif

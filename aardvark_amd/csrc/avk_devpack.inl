@@ -91,7 +91,7 @@ struct DpState {
     u32 lane_on[AVK_FAST_CLASSES];
     u32 pad0_;
     u64 have[AVK_FAST_CLASSES]; /* regions eligible per lane class */
-    u64 total_v, total_blob_words, total_seq; /* totals of the three scans */
+    u64 total_v, total_blob_words, total_seq, total_groups; /* totals of the four scans */
     u64 need_hist[DP_NEED_BUCKETS];           /* class C regions by predicted HBM workspace: bucket b = at most 1 MB << b (the last one: more) */
     u32 hist[DP_NB];
     u32 base[DP_NB + 1];
@@ -114,6 +114,7 @@ struct DpArgs {
     u32 *v_off;         /* [n_regions] first per-call output word */
     u32 *blob_off8;     /* [n_regions] blob offset in units of 8 bytes */
     u64 *seq_off;       /* [n_regions] */
+    u32 *bp_off;        /* [n_regions + 1] first compact BASEPAIR group of a region (1 + its call types groups each; none for regions that fail validation) */
     u32 *order;         /* [n_regions] work order: record k holds region order[k] */
     u32 *big_list;      /* [n_regions] work-order indices of regions with more than DP_SMALL_N calls */
     /* outputs */
@@ -411,8 +412,8 @@ AVK_DEV u64 dp_need(u32 len, u32 t_cnt, u32 q_cnt, u32 ed_bound, u64 N, u64 alle
 
 /* returns the three quantities the scans add up (per-call words, blob words, sequence bytes) and the lane class the region is eligible for
  * (0 = none; the caller counts them into DpState::have — one atomic per wave, not per region) through the references */
-AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u64 &seq_bytes, u32 &lane_class, u32 &need_bucket) {
-    n_calls = 0, blob_words = 0, seq_bytes = 0, lane_class = 0, need_bucket = 0xFFu;
+AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u64 &seq_bytes, u32 &lane_class, u32 &need_bucket, u32 &n_groups) {
+    n_calls = 0, blob_words = 0, seq_bytes = 0, lane_class = 0, need_bucket = 0xFFu, n_groups = 0;
     if (r >= a.in.n_regions) return;
     const DpIn &in = a.in;
     DpRegionInfo ri;
@@ -550,6 +551,10 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     ri.keys = fast_class | (fast_key << 8) | (cls << 16) | ((u32)(N > 255 ? 255 : N) << 24);
     a.rinfo[r] = ri;
     lane_class = fast_class;
+    if (!failed) { /* compact BASEPAIR groups: the joint one and one per call type of the region */
+        n_groups = 1;
+        for (u32 x = ri.pre_status >> 16; x; x &= x - 1) n_groups += 1;
+    }
     n_calls = (u32)N;
     blob_words = ri.blob_bytes / 4;
     seq_bytes = 5ull * ri.seq_stride;

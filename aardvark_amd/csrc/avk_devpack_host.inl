@@ -19,29 +19,32 @@ __global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dp
 
 /* dp_region for 256 regions; the workgroup's sums of the three scanned quantities and its count of regions per lane class go to
  * block_sums[AVK_DP_BS * block ..]: no global atomics (56,000 waves adding to the one counter of the modal class took 1.3 ms of this kernel's 1.6) */
-#define AVK_DP_BS (3 + AVK_FAST_CLASSES + avk::dp::DP_NEED_BUCKETS)
+#define AVK_DP_NS 4 /* scanned quantities: per-call output words, blob words, sequence bytes, compact BASEPAIR groups */
+#define AVK_DP_BS (AVK_DP_NS + AVK_FAST_CLASSES + avk::dp::DP_NEED_BUCKETS)
 __global__ void __launch_bounds__(256) avk_dp_region_kernel(dpk::DpArgs a, uint64_t *block_sums) {
     __shared__ unsigned long long sums[AVK_DP_BS];
     if (threadIdx.x < AVK_DP_BS) sums[threadIdx.x] = 0;
     __syncthreads();
-    uint32_t nc = 0, bw = 0, fc = 0, nb = 0xFFu;
+    uint32_t nc = 0, bw = 0, fc = 0, nb = 0xFFu, ng = 0;
     uint64_t sq = 0;
-    dpk::dp_region(a, (uint64_t)blockIdx.x * 256u + threadIdx.x, nc, bw, sq, fc, nb);
+    dpk::dp_region(a, (uint64_t)blockIdx.x * 256u + threadIdx.x, nc, bw, sq, fc, nb, ng);
     if (__ballot(nb != 0xFFu)) /* class C regions: rare on a small-window genome */
         for (uint32_t c = 0; c < dpk::DP_NEED_BUCKETS; ++c) {
             const unsigned long long m = __ballot(nb == c);
-            if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sums[3 + AVK_FAST_CLASSES + c], (unsigned long long)__popcll(m));
+            if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sums[AVK_DP_NS + AVK_FAST_CLASSES + c], (unsigned long long)__popcll(m));
         }
     for (uint32_t c = 1; c <= AVK_FAST_CLASSES; ++c) { /* one LDS atomic per wave and class */
         const unsigned long long m = __ballot(fc == c);
-        if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sums[2 + c], (unsigned long long)__popcll(m));
+        if (m && (threadIdx.x & 63u) == 0) atomicAdd(&sums[AVK_DP_NS - 1 + c], (unsigned long long)__popcll(m));
     }
     /* per-wave sums on the DPP network, 16 bits at a time so that 64 lanes cannot overflow a word; one LDS atomic per wave and quantity */
     const uint32_t nc_w = wv_sum_u32(nc); /* at most 64 x 60000 */
     const unsigned long long bw_w = (unsigned long long)wv_sum_u32(bw & 0xFFFFu) + ((unsigned long long)wv_sum_u32(bw >> 16) << 16);
     const unsigned long long sq_w = (unsigned long long)wv_sum_u32((uint32_t)sq & 0xFFFFu) + ((unsigned long long)wv_sum_u32((uint32_t)(sq >> 16) & 0xFFFFu) << 16) +
                                     ((unsigned long long)wv_sum_u32((uint32_t)(sq >> 32)) << 32);
+    const uint32_t ng_w = wv_sum_u32(ng); /* at most 64 x 13 */
     if ((threadIdx.x & 63u) == 0) {
+        if (ng_w) atomicAdd(&sums[3], (unsigned long long)ng_w);
         if (nc_w) atomicAdd(&sums[0], (unsigned long long)nc_w);
         if (bw_w) atomicAdd(&sums[1], bw_w);
         if (sq_w) atomicAdd(&sums[2], sq_w);
@@ -52,33 +55,33 @@ __global__ void __launch_bounds__(256) avk_dp_region_kernel(dpk::DpArgs a, uint6
 
 /* exclusive scan of the block sums, in place (one workgroup), the totals, and the regions per lane class */
 __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *block_sums, uint32_t n_blocks, dpk::DpState *st) {
-    __shared__ unsigned long long part[3][1024];
+    __shared__ unsigned long long part[AVK_DP_NS][1024];
     __shared__ unsigned long long have[AVK_FAST_CLASSES + dpk::DP_NEED_BUCKETS];
     const uint32_t t = threadIdx.x, per = (n_blocks + 1023u) / 1024u;
     const uint32_t lo = t * per < n_blocks ? t * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
     enum { NH = AVK_FAST_CLASSES + dpk::DP_NEED_BUCKETS };
     if (t < NH) have[t] = 0;
-    unsigned long long s[3] = {0, 0, 0}, h[NH];
+    unsigned long long s[AVK_DP_NS] = {0, 0, 0, 0}, h[NH];
     for (int c = 0; c < NH; ++c) h[c] = 0;
     for (uint32_t b = lo; b < hi; ++b) {
-        for (int q = 0; q < 3; ++q) s[q] += block_sums[(size_t)AVK_DP_BS * b + q];
-        for (int c = 0; c < NH; ++c) h[c] += block_sums[(size_t)AVK_DP_BS * b + 3 + c];
+        for (int q = 0; q < AVK_DP_NS; ++q) s[q] += block_sums[(size_t)AVK_DP_BS * b + q];
+        for (int c = 0; c < NH; ++c) h[c] += block_sums[(size_t)AVK_DP_BS * b + AVK_DP_NS + c];
     }
-    for (int q = 0; q < 3; ++q) part[q][t] = s[q];
+    for (int q = 0; q < AVK_DP_NS; ++q) part[q][t] = s[q];
     __syncthreads();
     for (int c = 0; c < NH; ++c)
         if (h[c]) atomicAdd(&have[c], h[c]);
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        unsigned long long x[3];
-        for (int q = 0; q < 3; ++q) x[q] = t >= d ? part[q][t - d] : 0ull;
+        unsigned long long x[AVK_DP_NS];
+        for (int q = 0; q < AVK_DP_NS; ++q) x[q] = t >= d ? part[q][t - d] : 0ull;
         __syncthreads();
-        for (int q = 0; q < 3; ++q) part[q][t] += x[q];
+        for (int q = 0; q < AVK_DP_NS; ++q) part[q][t] += x[q];
         __syncthreads();
     }
-    unsigned long long run[3];
-    for (int q = 0; q < 3; ++q) run[q] = part[q][t] - s[q];
+    unsigned long long run[AVK_DP_NS];
+    for (int q = 0; q < AVK_DP_NS; ++q) run[q] = part[q][t] - s[q];
     for (uint32_t b = lo; b < hi; ++b)
-        for (int q = 0; q < 3; ++q) {
+        for (int q = 0; q < AVK_DP_NS; ++q) {
             const unsigned long long v = block_sums[(size_t)AVK_DP_BS * b + q];
             block_sums[(size_t)AVK_DP_BS * b + q] = run[q];
             run[q] += v;
@@ -87,6 +90,7 @@ __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *bloc
         st->total_v = part[0][1023];
         st->total_blob_words = part[1][1023];
         st->total_seq = part[2][1023];
+        st->total_groups = part[3][1023];
     }
     if (t < AVK_FAST_CLASSES) st->have[t] = have[t];
     else if (t < NH) st->need_hist[t - AVK_FAST_CLASSES] = have[t];
@@ -94,10 +98,10 @@ __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *bloc
 
 /* per-region offsets: the block's base + the exclusive scan inside the block */
 __global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, const uint64_t *block_sums) {
-    __shared__ unsigned long long sh[3][256];
+    __shared__ unsigned long long sh[AVK_DP_NS][256];
     const uint32_t t = threadIdx.x;
     const uint64_t r = (uint64_t)blockIdx.x * 256u + t;
-    unsigned long long v[3] = {0, 0, 0};
+    unsigned long long v[AVK_DP_NS] = {0, 0, 0, 0};
     if (r < a.in.n_regions) {
         const uint32_t tc = a.in.t_cnt[r], qc = a.in.q_cnt[r];
         const uint64_t toff = a.in.t_off[r], qoff = a.in.q_off[r], nv = a.in.n_variants;
@@ -105,15 +109,17 @@ __global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, c
             v[0] = (unsigned long long)tc + qc;
             v[1] = a.rinfo[r].blob_bytes / 4u;
             v[2] = 5ull * a.rinfo[r].seq_stride;
+            const uint32_t ps = a.rinfo[r].pre_status;
+            v[3] = (ps & 0xFFFFu) ? 0u : 1u + (unsigned)__popc(ps >> 16); /* as dp_region counted the compact BASEPAIR groups */
         }
     }
-    for (int q = 0; q < 3; ++q) sh[q][t] = v[q];
+    for (int q = 0; q < AVK_DP_NS; ++q) sh[q][t] = v[q];
     __syncthreads();
     for (uint32_t d = 1; d < 256; d <<= 1) {
-        unsigned long long x[3];
-        for (int q = 0; q < 3; ++q) x[q] = t >= d ? sh[q][t - d] : 0ull;
+        unsigned long long x[AVK_DP_NS];
+        for (int q = 0; q < AVK_DP_NS; ++q) x[q] = t >= d ? sh[q][t - d] : 0ull;
         __syncthreads();
-        for (int q = 0; q < 3; ++q) sh[q][t] += x[q];
+        for (int q = 0; q < AVK_DP_NS; ++q) sh[q][t] += x[q];
         __syncthreads();
     }
     if (r < a.in.n_regions) {
@@ -121,6 +127,8 @@ __global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, c
         a.v_off[r] = (uint32_t)(bs[0] + sh[0][t] - v[0]);
         a.blob_off8[r] = (uint32_t)((bs[1] + sh[1][t] - v[1]) / 2ull);
         a.seq_off[r] = bs[2] + sh[2][t] - v[2];
+        a.bp_off[r] = (uint32_t)(bs[3] + sh[3][t] - v[3]);
+        if (r + 1 == a.in.n_regions) a.bp_off[r + 1] = (uint32_t)(bs[3] + sh[3][t]);
     }
 }
 
@@ -619,6 +627,9 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.v_off = db->d_voff;
     a.blob_off8 = (uint32_t *)kept((n + 1) * 4);
     a.seq_off = (uint64_t *)kept((n + 1) * 8);
+    db->d_bp_off = (uint32_t *)kept((n + 2) * 4);
+    a.bp_off = db->d_bp_off;
+    if (db->d_bp_off) (void)hipMemsetAsync(db->d_bp_off, 0, 8, s); /* (an empty batch: bp_off[0] = 0) */
     a.order = (uint32_t *)kept((n + 1) * 4);
     a.big_list = (uint32_t *)kept((n + 1) * 4);
     uint64_t *d_block_sums = (uint64_t *)tmp(((size_t)n_blocks + 1) * AVK_DP_BS * 8);
@@ -775,6 +786,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     if (hs->total_blob_words / 2 > 0xFFFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "region blob arena exceeds its limits; split the batch"));
     db->n_variants_dev = hs->total_v;
     db->seq_total = hs->total_seq;
+    db->n_bp_groups = hs->total_groups;
     { /* per-wave HBM slices of this batch's launches: large enough for 98 % of the regions predicted to need the tier (64 MB at most) */
         uint64_t n_c = 0, run = 0;
         for (int k = 0; k < dpk::DP_NEED_BUCKETS; ++k) n_c += hs->need_hist[k];
@@ -903,6 +915,10 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         segs.push_back({out->var_zyg ? out->var_zyg + db->v_lo : nullptr, o.var_zyg, out->var_zyg ? nvr : 0});
     }
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
+    if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {
+        segs.push_back({out->bp_off, db->d_bp_off, (n + 1) * sizeof(uint32_t)});
+        segs.push_back({out->bp_groups, db->d_bp, (size_t)db->n_bp_groups * 4 * sizeof(uint32_t)});
+    }
     CopyOut co;
     rc = copy_out(ctx, segs, &co);
     if (rc) return done(rc);

@@ -279,6 +279,7 @@ struct avk_ctx {
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
+    int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
     int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
     int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
     int64_t lane_min_regions = 8192; /* a lane class is launched when it holds at least this many regions (x16 for the two-call
@@ -357,6 +358,8 @@ struct avk_dev_batch {
     avk::dp::DpArgs dp_args; /* the packer's arguments: the writers of region records run again for the regions a launch turns out to need */
     avk::dp::DpArgs *d_dp_args = nullptr; /* the same in device memory (AvkKernelArgs::lazy_dp) */
     uint32_t lazy_from = 0;               /* first work-order index without a record (the lane classes' segment) */
+    uint32_t *d_bp_off = nullptr, *d_bp = nullptr; /* compact per-region BASEPAIR groups: first group of a region (caller order), the groups (allocated when a run asks for them) */
+    uint64_t n_bp_groups = 0;
     uint64_t *d_m_in_off = nullptr;       /* merge batches (avk_merge_batch): the MultiRegions' in_off / in_cnt and the calls' zygosities, for the classification kernel */
     uint32_t *d_m_in_cnt = nullptr;
     uint8_t *d_in_zyg = nullptr;
@@ -402,7 +405,8 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 void free_batch_buffers(avk_dev_batch *db) {
     if (db->dev_packed) return; /* pooled buffers: release_pooled */
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_fast};
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_fast,
+                    db->d_bp_off, db->d_bp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
 }
@@ -624,6 +628,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "pool_cache_bytes") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "pool_cache_bytes must not be negative");
         ctx->pool_cache_bytes = value;
+    } else if (n == "emit_bp_groups") {
+        ctx->emit_bp_groups = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {
         ctx->emit_group_metrics = value ? 1 : 0;
     } else if (n == "capacity_retry") {
@@ -756,6 +762,64 @@ uint64_t avk_algorithmic_bytes_ex(const avk_region_batch *b, int with_groups) {
 }
 uint64_t avk_algorithmic_bytes(const avk_region_batch *b) { return avk_algorithmic_bytes_ex(b, 1); }
 
+/* GroupTypeMetrics of one region from its compact BASEPAIR groups and the per-call outputs (include/aardvark_amd.h) */
+int avk_group_metrics_from_compact(const avk_region_batch *b, uint64_t r, const avk_result_batch *res, uint32_t *out) {
+    if (!b || !res || !out || r >= b->n_regions || !res->var_expected || !res->var_observed || !res->bp_off || !res->bp_groups) return AVK_E_ARG;
+    memset(out, 0, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
+    uint32_t types = 0;
+    uint64_t tot[2][1 + AVK_N_VARIANT_TYPES];
+    memset(tot, 0, sizeof(tot));
+    for (int side = 0; side < 2; ++side) {
+        const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
+        const uint32_t cnt = side == 0 ? b->t_cnt[r] : b->q_cnt[r];
+        if (off > b->n_variants || cnt > b->n_variants - off) return AVK_E_ARG;
+        for (uint32_t i = 0; i < cnt; ++i) {
+            const uint64_t v = off + i;
+            const uint32_t vt = b->var_type[v];
+            if (vt >= AVK_N_VARIANT_TYPES) return AVK_E_ARG;
+            types |= 1u << vt;
+            const uint64_t w = avk::host_edit_distance(b->allele_bytes + b->a0_off[v], b->a0_len[v], b->allele_bytes + b->a1_off[v], b->a1_len[v]); /* Variant::alt_ed */
+            /* the query entries are stored toggled (compare_benchmark.rs:109-123): scored as truth they expected var_observed and observed var_expected */
+            const uint32_t exp = side == 0 ? res->var_expected[v] : res->var_observed[v], obs = side == 0 ? res->var_observed[v] : res->var_expected[v];
+            const int f_gt_tp = side ? AVK_F_GT_QUERY_TP : AVK_F_GT_TRUTH_TP, f_gt_fn = side ? AVK_F_GT_QUERY_FP : AVK_F_GT_TRUTH_FN, f_gt_fn_gt = side ? AVK_F_GT_QUERY_FP_GT : AVK_F_GT_TRUTH_FN_GT;
+            const int f_hap_tp = side ? AVK_F_HAP_QUERY_TP : AVK_F_HAP_TRUTH_TP, f_hap_fn = side ? AVK_F_HAP_QUERY_FP : AVK_F_HAP_TRUTH_FN;
+            const int f_w_tp = side ? AVK_F_WHAP_QUERY_TP : AVK_F_WHAP_TRUTH_TP, f_w_fn = side ? AVK_F_WHAP_QUERY_FP : AVK_F_WHAP_TRUTH_FN;
+            for (uint32_t g : {0u, 1u + vt}) { /* GroupMetrics::add_truth_zygosity (grouped_metrics.rs:183-227) on the joint group and the type's */
+                uint32_t *G = out + g * AVK_N_FIELDS;
+                G[f_hap_tp] += obs;
+                G[f_hap_fn] += exp - obs;
+                G[f_w_tp] += (uint32_t)(obs * w);
+                G[f_w_fn] += (uint32_t)((exp - obs) * w);
+                if (exp == obs) G[f_gt_tp] += 1;
+                else {
+                    G[f_gt_fn] += 1;
+                    if (obs > 0) G[f_gt_fn_gt] += 1;
+                }
+            }
+            const uint32_t z = b->var_zyg[v];
+            const uint64_t cz = z == AVK_ZYG_HOM_ALT ? 2 : ((z >= AVK_ZYG_UNPHASED_HET && z <= AVK_ZYG_PHASED_HET10) ? 1 : 0);
+            const uint64_t raw = b->var_raw_space ? b->var_raw_space[v] : (b->a0_len[v] > b->a1_len[v] ? b->a0_len[v] : b->a1_len[v]);
+            tot[side][0] += cz * raw;
+            tot[side][1 + vt] += cz * raw;
+        }
+    }
+    /* BASEPAIR from the compact groups (joint, then the region's call types in type order); RECORD_BP from them and the totals (waffle_solver.rs:455-522) */
+    const uint32_t lo = res->bp_off[r], hi = res->bp_off[r + 1];
+    uint32_t k = lo;
+    for (uint32_t left = 1u | (types << 1); left; left &= left - 1, ++k) {
+        if (k >= hi) return AVK_E_ARG; /* the region owns no groups (it failed validation) or fewer than its call types */
+        const uint32_t g = (uint32_t)__builtin_ctz(left);
+        uint32_t *G = out + g * AVK_N_FIELDS;
+        const uint32_t *bp = res->bp_groups + 4 * (size_t)k;
+        for (int i = 0; i < 4; ++i) G[AVK_F_BP_TRUTH_TP + i] = bp[i];
+        G[AVK_F_RBP_TRUTH_TP] = (uint32_t)(2 * tot[0][g] - bp[1]);
+        G[AVK_F_RBP_TRUTH_FN] = bp[1];
+        G[AVK_F_RBP_QUERY_TP] = (uint32_t)(2 * tot[1][g] - bp[3]);
+        G[AVK_F_RBP_QUERY_FP] = bp[3];
+    }
+    return k == hi ? 0 : AVK_E_ARG;
+}
+
 static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pairs_mode, avk_dev_batch **out) {
     if (!ctx || !batch || !out) return AVK_E_ARG;
     *out = nullptr;
@@ -832,6 +896,21 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow4, n + 1));
 #undef AVK_TRY
+    { /* compact BASEPAIR groups: 1 + the region's call types each (none for regions that fail validation), as the device packer counts them */
+        std::vector<uint32_t> bp_off(n + 1, 0);
+        for (uint64_t r = 0; r < n; ++r) {
+            const uint32_t ps = db->host.regions[r].pre_status;
+            bp_off[r + 1] = bp_off[r] + ((ps & 0xFFFFu) ? 0u : 1u + (uint32_t)__builtin_popcount(ps >> 16));
+        }
+        db->n_bp_groups = bp_off[n];
+        hipError_t eb = hipMalloc((void **)&db->d_bp_off, (n + 2) * sizeof(uint32_t));
+        if (eb == hipSuccess) eb = hipMemcpy(db->d_bp_off, bp_off.data(), (n + 1) * sizeof(uint32_t), hipMemcpyHostToDevice);
+        if (eb != hipSuccess) {
+            free_batch_buffers(db);
+            delete db;
+            return fail(ctx, AVK_E_HIP, "batch upload failed: %s", hipGetErrorString(eb));
+        }
+    }
     /* work order: the regions predicted to outgrow the small LDS slice first (solo waves take them), then the
      * rest; within each part the regions with the most variants (the expensive searches) are dealt first, so
      * they overlap with the bulk instead of forming the tail */
@@ -1018,6 +1097,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         AVK_HIP(ctx, hipMemsetAsync(db->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t), ctx->stream));
     }
     db->scratch_clean = false;
+    if (ctx->emit_bp_groups && mode == 0 && !db->d_bp && db->d_bp_off) {
+        int rc = db->dev_packed ? pool_alloc_t(ctx, db, &db->d_bp, (size_t)db->n_bp_groups * 4 + 4) : dev_alloc(ctx, &db->d_bp, (size_t)db->n_bp_groups * 4 + 4);
+        if (rc) return rc;
+    }
     if (ctx->emit_group_metrics && !db->d_gm) {
         int rc = db->dev_packed ? pool_alloc_t(ctx, db, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS + 4) : dev_alloc(ctx, &db->d_gm, (size_t)n * AVK_N_GROUPS * AVK_N_FIELDS);
         if (rc) return rc;
@@ -1048,6 +1131,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.seq_bytes = cfg->enable_sequences ? db->d_seq : nullptr;
     a.seq_len = cfg->enable_sequences ? db->d_seqlen : nullptr;
     a.tally = db->d_partials;
+    if (ctx->emit_bp_groups && mode == 0 && db->d_bp) {
+        a.bp_off = db->d_bp_off;
+        a.bp_out = db->d_bp;
+    }
     if (db->dev_packed && !db->records_full) { /* (only the launches for handed-back regions ever meet an index >= lazy_from) */
         a.lazy_dp = db->d_dp_args;
         a.lazy_from = db->lazy_from;
@@ -1507,7 +1594,7 @@ namespace {
 struct CapacityFix {
     std::vector<uint32_t> idx; /* caller region index of the sub-batch's regions */
     std::vector<int32_t> status;
-    std::vector<uint32_t> ed1, ed2, nopt, seq_len, gm;
+    std::vector<uint32_t> ed1, ed2, nopt, seq_len, gm, bp_off, bp;
     std::vector<uint16_t> present;
     std::vector<uint8_t> ve, vo, vc, vz, seq;
     std::vector<uint64_t> seq_off, v_first; /* first sub-batch variant of a region (truth first, then query) */
@@ -1516,7 +1603,7 @@ struct CapacityFix {
 };
 } // namespace
 
-static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::vector<uint32_t> &cap, bool want_gm, bool want_seq, uint64_t slice_bytes, CapacityFix *fx) {
+static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::vector<uint32_t> &cap, bool want_gm, bool want_seq, bool want_bp, uint64_t slice_bytes, CapacityFix *fx) {
     const uint64_t m = cap.size();
     std::vector<uint64_t> rid(m), st(m), en(m), toff(m), qoff(m), vpos, a0off, a1off;
     std::vector<uint32_t> cidx(m), tcnt(m), qcnt(m), vraw, a0len, a1len;
@@ -1574,6 +1661,13 @@ static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::ve
         fx->gm.assign(m * AVK_N_GROUPS * AVK_N_FIELDS, 0);
         o.group_metrics = fx->gm.data();
     }
+    const int64_t keep_bp = ctx->emit_bp_groups;
+    if (want_bp) {
+        fx->bp_off.assign(m + 1, 0);
+        fx->bp.assign((m + nvs + 1) * 4, 0);
+        o.bp_off = fx->bp_off.data(), o.bp_groups = fx->bp.data();
+    }
+    ctx->emit_bp_groups = want_bp ? 1 : 0;
     if (want_seq) {
         fx->seq_off.assign(m, 0), fx->seq_stride.assign(m, 0), fx->seq_len.assign(m * 5, 0);
         uint64_t total = 0;
@@ -1597,6 +1691,7 @@ static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::ve
     if (sub) avk_batch_free(ctx, sub);
     ctx->lds_bytes_per_wave = keep[0], ctx->lds2_bytes_per_wave = keep[1], ctx->ws_bytes_per_wave = keep[2], ctx->big_ws_bytes = keep[3], ctx->big_waves = keep[4],
     ctx->lane_kernel = keep[5], ctx->capacity_retry = keep[6], ctx->emit_group_metrics = keep[7];
+    ctx->emit_bp_groups = keep_bp;
     return rc;
 }
 
@@ -1632,6 +1727,10 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         std::vector<uint32_t> rout(n * 4 + 4), vout(nv + 1);
         D2H(rout.data(), db->d_region_out, n * 4 * sizeof(uint32_t));
         if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) D2H(out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t));
+        if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off) {
+            D2H(out->bp_off, db->d_bp_off, (n + 1) * sizeof(uint32_t));
+            D2H(out->bp_groups, db->d_bp, (size_t)db->n_bp_groups * 4 * sizeof(uint32_t));
+        }
         if (out->var_expected || out->var_observed || out->var_class || out->var_zyg) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
         D2H(tally.data(), db->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t));
         AVK_HIP(ctx, hipStreamSynchronize(s));
@@ -1692,7 +1791,8 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
             if ((int64_t)slice <= ctx->big_ws_bytes) continue;
             CapacityFix fx;
             const bool want_gm = out->group_metrics && ctx->emit_group_metrics && db->d_gm;
-            const int rc = rerun_capacity_regions(ctx, db, cap, want_gm, want_seq, slice, &fx);
+            const bool want_bp = out->bp_off && out->bp_groups && db->d_bp;
+            const int rc = rerun_capacity_regions(ctx, db, cap, want_gm, want_seq, want_bp, slice, &fx);
             if (rc == AVK_E_OOM) break; /* the device cannot hold slices of this size: the regions keep their status */
             if (rc) { /* reported after the statistics and the shared slices are back as they were (below) */
                 retry_rc = rc;
@@ -1719,6 +1819,8 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
                     if (out->var_zyg) out->var_zyg[hv] = fx.vz[sv];
                 }
                 if (want_gm) memcpy(out->group_metrics + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
+                if (want_bp && out->bp_off[r + 1] - out->bp_off[r] == fx.bp_off[k + 1] - fx.bp_off[k]) /* the same calls, so the same groups */
+                    memcpy(out->bp_groups + 4 * (size_t)out->bp_off[r], fx.bp.data() + 4 * (size_t)fx.bp_off[k], 16 * (size_t)(fx.bp_off[k + 1] - fx.bp_off[k]));
                 if (want_seq)
                     for (int q = 0; q < 5; ++q) {
                         uint32_t len = fx.seq_len[5 * k + q];
@@ -1807,12 +1909,13 @@ int avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_
     if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
     ctx->last_one_shot = 0;
     avk_dev_batch *db = nullptr;
-    const int64_t keep_gm = ctx->emit_group_metrics;
+    const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
+    if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
     int rc = avk_batch_upload_compact(ctx, batch, &db);
     if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
     if (!rc) rc = avk_results_download(ctx, db, out);
-    ctx->emit_group_metrics = keep_gm;
+    ctx->emit_group_metrics = keep_gm, ctx->emit_bp_groups = keep_bp;
     if (db) {
         ctx->last_one_shot = 1;
         avk_batch_free(ctx, db);
@@ -1827,15 +1930,16 @@ int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_com
     avk_dev_batch *db = nullptr;
     const auto t0 = std::chrono::steady_clock::now();
     /* per-region metric blocks only when the caller has an array for them */
-    const int64_t keep_gm = ctx->emit_group_metrics;
+    const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
+    if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
     int rc = avk_batch_upload(ctx, batch, &db);
     const auto t1 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
     const auto t2 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_results_download(ctx, db, out);
     const auto t3 = std::chrono::steady_clock::now();
-    ctx->emit_group_metrics = keep_gm;
+    ctx->emit_group_metrics = keep_gm, ctx->emit_bp_groups = keep_bp;
     if (db) {
         ctx->last_one_shot = db->dev_packed ? 1 : 0;
         avk_batch_free(ctx, db);

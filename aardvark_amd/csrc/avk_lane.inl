@@ -991,6 +991,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     u32 *gm_out = a.group_metrics ? a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS : (u32 *)0;
     if (gm_out)
         for (u32 i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) gm_out[i] = 0;
+    u32 *bp_dst = a.bp_out ? a.bp_out + 4 * (u64)a.bp_off[orig] : (u32 *)0; /* compact BASEPAIR groups: the loop below visits them in their order */
     /* The joint group comes first (bit 0): its RECORD_BP check is the only way the region can still fail, so nothing has been added to
      * the tally when it does; every alignment has been made above. */
     for (u32 left = 1u | (types << 1); left; left &= left - 1) {
@@ -1078,6 +1079,12 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
             if (!v) continue;
             avk_tally_add_u32(tally, g * AVK_N_FIELDS + i, v); /* lanes with the same (counter, value) share one LDS atomic */
             if (gm_out) gm_out[g * AVK_N_FIELDS + i] = v;
+        }
+        if (bp_dst) {
+            avk_u4 w;
+            w.x = G.f[AVK_F_BP_TRUTH_TP], w.y = G.f[AVK_F_BP_TRUTH_FN], w.z = G.f[AVK_F_BP_QUERY_TP], w.w = G.f[AVK_F_BP_QUERY_FP];
+            *(avk_u4 *)bp_dst = w;
+            bp_dst += 4;
         }
     }
     return AVK_ST_OK;
@@ -1179,6 +1186,8 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
                     for (u32 k = 0; k < nvar; ++k) a.var_out[v_off + k] = 0;
                     if (a.group_metrics)
                         for (u32 i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) a.group_metrics[(u64)orig * AVK_N_GROUPS * AVK_N_FIELDS + i] = 0;
+                    if (a.bp_out)
+                        for (u32 i = 4 * a.bp_off[orig]; i < 4 * a.bp_off[orig + 1]; ++i) a.bp_out[i] = 0;
                 }
                 avk_u4 *dst = (avk_u4 *)(a.region_out + 4 * (u64)orig);
                 avk_u4 v;

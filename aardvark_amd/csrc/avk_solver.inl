@@ -1711,6 +1711,7 @@ AVK_DEV void write_failed_region(const AvkKernelArgs &a, u32 rec, int status) {
     const u32 n = reg.t_cnt + reg.q_cnt;
     for (u32 k = lane; k < n; k += 64) a.var_out[reg.v_off + k] = 0;
     if (a.group_metrics) zero_words(a.group_metrics + (u64)r * AVK_N_GROUPS * AVK_N_FIELDS, AVK_N_GROUPS * AVK_N_FIELDS);
+    if (a.bp_out) zero_words(a.bp_out + 4 * (u64)a.bp_off[r], 4 * (a.bp_off[r + 1] - a.bp_off[r]));
     if (a.seq_bytes && a.seq_len && lane < 5) a.seq_len[5 * (u64)r + lane] = 0;
 }
 
@@ -1949,6 +1950,11 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
             continue;
         }
         if (a.group_metrics) copy_words(a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS, c.gm, AVK_N_GROUPS * AVK_N_FIELDS);
+        if (a.bp_out) { /* the BASEPAIR counters of the groups that can hold anything: the joint one, then the call types of the region in type order */
+            u32 *dst = a.bp_out + 4 * (u64)wv_uni(a.bp_off[orig]);
+            for (u32 left = 1u | ((wv_uni(reg.pre_status) >> 16) << 1); left; left &= left - 1, dst += 4)
+                if (lane < 4) dst[lane] = c.gm[(u32)__builtin_ctz(left) * AVK_N_FIELDS + AVK_F_BP_TRUTH_TP + lane];
+        }
         { /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters (a handful of
            * the 286) are added to the workgroup's tally in LDS, or — launches without a tail — straight to a partial tally */
             u64 *part_r = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;

@@ -187,6 +187,15 @@ typedef struct avk_result_batch {
     uint32_t *seq_len;          /* [n_regions][5] */
 
     uint64_t *tally;         /* [AVK_TALLY_LEN] sums over the Ok regions of this batch */
+
+    /* Compact per-region BASEPAIR groups (optional; both or neither): what is left of a region's GroupTypeMetrics once the per-call decisions above are known.
+     * Region r owns groups [bp_off[r], bp_off[r + 1]) of bp_groups: the joint group first, then one per VariantType that occurs among the region's
+     * calls, in type order; a group is 4 counters: BASEPAIR truth_tp, truth_fn, query_tp, query_fp (summary_metrics.rs:6-15; the doubled values of
+     * waffle_solver.rs:335-449).  16 bytes x (1 + call types) per region instead of the 1144-byte block of group_metrics; regions that fail validation own no
+     * group, regions that fail in the solver own zeros.  avk_group_metrics_from_compact rebuilds the full 13 x 22 block of a region from these and the
+     * per-call outputs. */
+    uint32_t *bp_off;        /* [n_regions + 1] */
+    uint32_t *bp_groups;     /* [capacity][4] with capacity >= n_regions + n_variants (a region has at most 1 + its number of calls groups) */
 } avk_result_batch;
 
 /* ---- context --------------------------------------------------------------------- */
@@ -234,6 +243,8 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
  *                    earlier should export the variable itself (whole-genome step of the final build: 5.0 ms with 8 queues, 7.0 ms with 4).
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
+ *                    "emit_bp_groups" (1 = kernels write the compact per-region BASEPAIR groups, avk_result_batch::bp_groups; avk_compare_batch /
+ *                    avk_compare_compact switch it on by themselves when the caller hands the two arrays in),
  *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
  *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
  *   packing          "device_pack" (1, default: a batch is validated, classified, ordered and written in the kernels' layout ON THE DEVICE, from
@@ -289,6 +300,11 @@ int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the batch of the last a
 int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */
 int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
                                                              they are not counted in any workspace tier */
+/* Host utility (no GPU involved): the full GroupTypeMetrics block of region r (13 groups x 22 counters, the layout of group_metrics) from the batch, the
+ * per-call outputs var_expected / var_observed of `res` and the region's compact BASEPAIR groups: the GT / HAP / WEIGHTED_HAP counters follow from
+ * (expected, observed) per call (grouped_metrics.rs:183-227 and the swap of :268-277), RECORD_BP from the calls' zygosities and raw_allele_space
+ * (waffle_solver.rs:455-522).  Only meaningful for regions with status 0.  Returns 0, or AVK_E_ARG. */
+int avk_group_metrics_from_compact(const avk_region_batch *batch, uint64_t r, const avk_result_batch *res, uint32_t *out /* [AVK_N_GROUPS * AVK_N_FIELDS] */);
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
 /* the same with (1) or without (0) the per-region BASEPAIR groups among the outputs: a run that produces per-region records, per-call decisions and
  * the batch tally only (emit_group_metrics 0) writes no per-region groups */

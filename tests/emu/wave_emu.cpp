@@ -197,7 +197,7 @@ int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the 
 namespace dpk = avk::dp;
 struct DpResult {
     std::vector<AvkDevRegion> regions; /* work order */
-    std::vector<uint32_t> blob, fast, order, v_off, blob_off8;
+    std::vector<uint32_t> blob, fast, order, v_off, blob_off8, bp_off;
     std::vector<uint64_t> seq_off;
     std::vector<dpk::DpVarInfo> vinfo;
     std::vector<dpk::DpRegionInfo> rinfo;
@@ -229,23 +229,26 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     R->rinfo.assign(n + 1, dpk::DpRegionInfo());
     std::vector<uint32_t> &pending = R->pending, &big_list = R->big_list;
     pending.assign(nv + 1, 0), big_list.assign(n + 1, 0);
-    R->v_off.assign(n + 1, 0), R->blob_off8.assign(n + 1, 0), R->seq_off.assign(n + 1, 0), R->order.assign(n + 1, 0);
+    R->v_off.assign(n + 1, 0), R->blob_off8.assign(n + 1, 0), R->seq_off.assign(n + 1, 0), R->order.assign(n + 1, 0), R->bp_off.assign(n + 2, 0);
     memset(&R->st, 0, sizeof(R->st));
     a.vinfo = R->vinfo.data(), a.rinfo = R->rinfo.data(), a.st = &R->st, a.pending = pending.data(), a.v_off = R->v_off.data(), a.blob_off8 = R->blob_off8.data(),
-    a.seq_off = R->seq_off.data(), a.order = R->order.data(), a.big_list = big_list.data();
+    a.seq_off = R->seq_off.data(), a.order = R->order.data(), a.big_list = big_list.data(), a.bp_off = R->bp_off.data();
     for (uint64_t v = 0; v < nv; ++v) dpk::dp_variant(a, v);
     auto region_passes = [&] {
-        uint64_t run_v = 0, run_b = 0, run_s = 0;
+        uint64_t run_v = 0, run_b = 0, run_s = 0, run_g = 0;
         for (uint64_t r = 0; r < n; ++r) {
-            uint32_t nc, bw, fc, nb;
+            uint32_t nc, bw, fc, nb, ng;
             uint64_t sq;
-            dpk::dp_region(a, r, nc, bw, sq, fc, nb);
+            dpk::dp_region(a, r, nc, bw, sq, fc, nb, ng);
+            R->bp_off[r] = (uint32_t)run_g;
+            run_g += ng;
+            R->bp_off[r + 1] = (uint32_t)run_g;
             if (fc) R->st.have[fc - 1] += 1;
             if (nb != 0xFFu) R->st.need_hist[nb] += 1;
             R->v_off[r] = (uint32_t)run_v, R->blob_off8[r] = (uint32_t)(run_b / 2), R->seq_off[r] = run_s;
             run_v += nc, run_b += bw, run_s += sq;
         }
-        R->st.total_v = run_v, R->st.total_blob_words = run_b, R->st.total_seq = run_s;
+        R->st.total_v = run_v, R->st.total_blob_words = run_b, R->st.total_seq = run_s, R->st.total_groups = run_g;
         dpk::dp_lane_switch(a);
         for (uint64_t r = 0; r < n; ++r) {
             const uint32_t bk = dpk::dp_bucket_of(a, r);
@@ -400,6 +403,19 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.seq_bytes = want_seq ? out->seq_bytes : nullptr;
     a.seq_len = want_seq ? out->seq_len : nullptr;
     a.tally = partials.data();
+    std::vector<uint32_t> bp_off_host; /* compact BASEPAIR groups (avk_result_batch::bp_groups): offsets as the packers count them, written straight to the caller's array */
+    if (out->bp_off && out->bp_groups && mode == 0) {
+        if (devpack) memcpy(out->bp_off, dpr.bp_off.data(), (n + 1) * sizeof(uint32_t));
+        else {
+            out->bp_off[0] = 0;
+            for (uint64_t r = 0; r < n; ++r) {
+                const uint32_t ps = pb.regions[r].pre_status;
+                out->bp_off[r + 1] = out->bp_off[r] + ((ps & 0xFFFFu) ? 0u : 1u + (uint32_t)__builtin_popcount(ps >> 16));
+            }
+        }
+        a.bp_off = out->bp_off;
+        a.bp_out = out->bp_groups;
+    }
 
     if (cfg->max_branch_factor == 0) { /* query_optimizer.rs:177 */
         for (uint64_t r = 0; r < n; ++r) {

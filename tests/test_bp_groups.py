@@ -1,0 +1,78 @@
+"""Compact per-region BASEPAIR groups (avk_result_batch::bp_off / bp_groups: 16 bytes per group instead of the 1144-byte block): the kernels' groups, expanded with
+the per-call outputs by the library's host function avk_group_metrics_from_compact, must give the oracle's full GroupTypeMetrics block for every solved region."""
+import numpy as np
+import pytest
+
+import emu_lib
+import oracle_lib
+import scenarios
+from aardvark_amd import CompareConfig, synth
+from aardvark_amd.api import group_metrics_from_compact
+
+
+def check(batch, got, want):
+    assert np.array_equal(got.status, want.status)
+    full = group_metrics_from_compact(batch, got)
+    ok = want.status == 0
+    assert np.array_equal(full[ok], want.group_metrics[ok])
+    # regions that fail validation own no group; the others 1 + their call types
+    n_groups = np.diff(got.bp_off.astype(np.int64))
+    for r in range(batch.n_regions):
+        types = set(int(batch.var_type[v]) for off, cnt in ((batch.t_off[r], batch.t_cnt[r]), (batch.q_off[r], batch.q_cnt[r])) for v in range(int(off), int(off) + int(cnt)))
+        assert n_groups[r] in (0, 1 + len(types)), r
+        if want.status[r] == 0:
+            assert n_groups[r] == 1 + len(types)
+
+
+def cases():
+    yield scenarios.golden()
+    yield scenarios.fuzz_regions(71, 400, max_vars=6, max_len=10)
+    yield scenarios.fuzz_regions(72, 300, max_vars=3, repeat_unit=b"CA")
+    c = scenarios.long_allele_regions()
+    yield c[0], c[1]
+    yield scenarios.invalid_regions()
+    contig, batch = synth.config_indel_mix_v2(n_truth=2500, contig_len=1_200_000)
+    yield [contig], batch
+
+
+@pytest.mark.parametrize("lane_kernel", [True, False])
+def test_compact_groups_rebuild_the_full_block_kernel_logic(oracle, lane_kernel):
+    lib = emu_lib.load()
+    lib.emu_set_device_pack.argtypes = [__import__("ctypes").c_int]
+    for devpack in (0, 2):
+        lib.emu_set_device_pack(devpack)
+        try:
+            for contigs, batch in cases():
+                want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
+                got = emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel, group_metrics=False, bp_groups=True, threads=8)
+                check(batch, got, want)
+        finally:
+            lib.emu_set_device_pack(0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("device_pack", [1, 0])
+def test_compact_groups_on_the_gpu(oracle, device_pack):
+    import aardvark_amd
+    ctx = aardvark_amd.Context(0)
+    try:
+        ctx.set_option("device_pack", device_pack)
+        ctx.set_option("lane_min_regions", 0)
+        ctx.set_option("lane_min_batch", 0)
+        for lane in (1, 0):
+            ctx.set_option("lane_kernel", lane)
+            for contigs, batch in cases():
+                want = oracle_lib.compare_batch(oracle, batch, contigs, threads=8)
+                ctx.upload_reference(contigs)
+                got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False, bp_groups=True)
+                check(batch, got, want)
+        # a contig at the benchmark's density: the compact groups cost 16 B x (1 + types) per region
+        contig, batch = synth.config_indel_mix_v2(n_truth=60_000, contig_len=24_000_000)
+        ctx.set_option("lane_kernel", 1)
+        ctx.upload_reference([contig])
+        want = oracle_lib.compare_batch(oracle, batch, [contig], threads=8)
+        got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False, bp_groups=True)
+        check(batch, got, want)
+        assert got.bp_off[-1] * 16 < 0.04 * want.group_metrics.nbytes
+    finally:
+        ctx.close()
