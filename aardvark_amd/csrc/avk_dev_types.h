@@ -108,6 +108,26 @@ static const AvkFastClass AVK_FAST_CLASS[AVK_FAST_CLASSES] = {
     {12, 3, 6, 32},  /* three calls per side, <= 192 bases (nine in ten of the regions that are left) */
 };
 
+#if defined(__HIPCC__) && !defined(AVK_EMU)
+#define AVK_TYPES_HD __host__ __device__ static inline
+#else
+#define AVK_TYPES_HD static inline
+#endif
+/* The HEAD of a lane class (the tiles of regions with estimated edits, sorted most expensive first) is dealt out over its claims of `w`
+ * records: sorted position p -> slot (p mod claims) * w + p / claims, so that every claim holds one of the `claims` most expensive
+ * regions, one of the next `claims`, ... instead of the first claim holding the w most expensive ones.  Lanes that diverge take
+ * turns: a claim lasts as long as the SUM of its lanes, and the launch as long as its slowest claim. */
+AVK_TYPES_HD uint32_t avk_stripe_slot(uint32_t p, uint32_t head_slots, uint32_t w) {
+    if (p >= head_slots || w == 0 || head_slots < w) return p;
+    const uint32_t claims = head_slots / w;
+    return (p % claims) * w + p / claims;
+}
+/* slots of a class's striped head (0: none): whole tiles of 64 that hold the n_heavy leading regions, when records are left behind them */
+AVK_TYPES_HD uint32_t avk_head_slots(uint32_t maxv, uint32_t n_fast, uint32_t n_heavy, uint32_t w) {
+    const uint32_t head_tiles = (n_heavy + 63u) / 64u, tiles = (n_fast + 63u) / 64u;
+    return (w && w < 64u && maxv <= 2u && head_tiles > 0 && head_tiles < tiles) ? head_tiles * 64u : 0u;
+}
+
 /* capacities of one workspace tier */
 struct AvkTier {
     uint64_t ws_bytes; /* bytes of workspace per wave in this tier */

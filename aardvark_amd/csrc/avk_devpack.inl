@@ -63,7 +63,7 @@ struct DpOpts {
     u64 tier0_bytes, tier1_bytes;
     u32 tier0_ed_cap, tier1_ed_cap;
     u32 solo_min_variants, max_branch, class_c_nodes_x2, lane_max_calls, lane_max_est;
-    u32 pad_;
+    u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
     u64 lane_min_batch;
 };
@@ -100,6 +100,7 @@ struct DpState {
     u32 n_hbm, n_hard, n_fast_total, pad1_;
     u32 n_fast[AVK_FAST_CLASSES], n_fast_heavy[AVK_FAST_CLASSES], fast_base[AVK_FAST_CLASSES], fast_tiles[AVK_FAST_CLASSES], tile_first[AVK_FAST_CLASSES];
     u32 pad2_;
+    u32 head_slots[AVK_FAST_CLASSES], pad4_; /* striped head of each lane class (avk_head_slots) */
     u64 fast_word_base[AVK_FAST_CLASSES], fast_words;
     u32 n_big, pad3_; /* regions left to the wave-per-region record writer */
 };
@@ -583,6 +584,14 @@ AVK_DEV u32 dp_bucket_of(const DpArgs &a, u64 r) {
     return 256u * ((k >> 16) & 0xFFu) + (255u - (k >> 24));
 }
 
+/* where the region that came `pos`-th in the sort goes in the work order: the heads of the lane classes are striped (avk_stripe_slot) */
+AVK_DEV u32 dp_order_slot(const DpArgs &a, u32 bucket, u32 pos) {
+    if (bucket < 256u * 3u) return pos;
+    const u32 fc = (u32)AVK_FAST_CLASSES - 1u - (bucket / 256u - 3u);
+    const DpState &s = *a.st;
+    return s.fast_base[fc] + avk_stripe_slot(pos - s.fast_base[fc], s.head_slots[fc], a.opt.stripe_w);
+}
+
 /* ---- dp_bucket_bases: exclusive scan of the histogram, the plan, the geometry of the fast records; one thread ---------------------- */
 AVK_DEV void dp_bucket_bases(const DpArgs &a) {
     DpState &s = *a.st;
@@ -603,6 +612,7 @@ AVK_DEV void dp_bucket_bases(const DpArgs &a) {
         s.fast_base[fc] = s.base[256 * seg];
         s.n_fast[fc] = s.base[256 * (seg + 1)] - s.base[256 * seg];
         s.n_fast_heavy[fc] = s.base[256 * seg + 240] - s.base[256 * seg]; /* cost key >> 4 != 0 <=> sort key below 240 */
+        s.head_slots[fc] = avk_head_slots(AVK_FAST_CLASS[fc].maxv, s.n_fast[fc], s.n_fast_heavy[fc], a.opt.stripe_w);
         s.n_fast_total += s.n_fast[fc];
         s.tile_first[fc] = tiles;
         s.fast_word_base[fc] = words;

@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(1024) avk_dp_scatter_kernel(dpk::DpArgs a) {
     for (uint32_t k = threadIdx.x; k < dpk::DP_NB; k += 1024u)
         if (h[k]) h[k] = atomicAdd(&a.st->cursor[k], h[k]);
     __syncthreads();
-    if (r < a.in.n_regions) a.order[atomicAdd(&h[b], 1u)] = (uint32_t)r;
+    if (r < a.in.n_regions) a.order[dpk::dp_order_slot(a, b, atomicAdd(&h[b], 1u))] = (uint32_t)r;
 }
 
 __global__ void __launch_bounds__(256) avk_dp_fast_records_kernel(dpk::DpArgs a, uint32_t n_tiles_total) {
@@ -725,6 +725,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.opt.tier1_ed_cap = (uint32_t)ctx->lds2_ed_cap, a.opt.solo_min_variants = pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, a.opt.max_branch = 50,
     a.opt.class_c_nodes_x2 = (uint32_t)ctx->class_c_nodes_x2, a.opt.lane_min_regions = lanes ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull,
     a.opt.lane_max_calls = (uint32_t)ctx->lane_max_calls, a.opt.lane_min_batch = (uint64_t)ctx->lane_min_batch, a.opt.lane_max_est = (uint32_t)ctx->lane_max_est;
+    a.opt.stripe_w = ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u;
     hipError_t e = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
     if (e == hipSuccess && nv) {
         hipLaunchKernelGGL(avk_dp_variant_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, a);

@@ -76,7 +76,10 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm_lazy(AvkKernelAr
 
 /* Small regions, one per LANE (avk_lane.inl): a workgroup is four independent waves, each claims tiles of 64 fast records; the
  * workgroup's LDS holds the four waves' per-lane arrays and one shared tally that is flushed once */
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(3))) avk_lane_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) {
+#ifndef AVK_LANE_WPE
+#define AVK_LANE_WPE 3
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_LANE_WPE))) avk_lane_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) {
     extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
     uint32_t *smem = (uint32_t *)avk_smem;
     const unsigned wave_in_block = threadIdx.x >> 6;
@@ -289,6 +292,9 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
+    int64_t lane_stripe = 0;                          /* 1: the heads' records dealt out over their claims (avk_stripe_slot, avk_dev_types.h) instead of most expensive first.  Measured
+                                                         WORSE (whole genome 4.84 -> 5.40 ms per step): regions of one cost key take the same path through the search, a claim of equals
+                                                         runs in lockstep, a claim of unequals takes turns */
     int64_t lane_head_stream = 0;                     /* 1: the heads of the two-call classes on a stream of their own (a synchronised step: 5.4 -> 5.1 ms;
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
@@ -654,6 +660,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
+    } else if (n == "lane_stripe") {
+        ctx->lane_stripe = value ? 1 : 0;
     } else if (n == "lane_head_stream") {
         ctx->lane_head_stream = value ? 1 : 0;
     } else if (n == "lane_min_batch") {
@@ -919,7 +927,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
                                     ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls,
-                                    (uint64_t)ctx->lane_min_batch);
+                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */

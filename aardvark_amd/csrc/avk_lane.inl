@@ -42,6 +42,7 @@ typedef uint64_t u64;
 extern uint64_t g_lane_stats[32];
 extern int g_lane_phase;
 extern uint32_t *g_lane_work; /* per region (caller order): a weighted count of what its lane did (tools/lane_stats.py) */
+extern uint32_t *g_lane_comp; /* per region: the first 8 counters above, as counted for that region alone */
 static inline uint64_t lane_work_now() { return 30 * g_lane_stats[0] + 60 * g_lane_stats[1] + 150 * g_lane_stats[2] + 100 * g_lane_stats[3] + 300 * g_lane_stats[6] + 600 * g_lane_stats[5]; }
 #define AVK_LSTAT(k, n) g_lane_stats[k] += (n)
 #define AVK_LPHASE(k) g_lane_phase = (k)
@@ -151,80 +152,175 @@ AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32
     }
     return n < lim ? n : lim;
 }
+/* The same for two sequences read from the SAME offset i (the zero-distance front of a haplotype, whose two strings are compared
+ * position by position): whole table words, no unaligned extracts, and four words of each sequence per LDS round trip — a lane is a
+ * chain of dependent LDS accesses, and this slide over the common part is most of what a cheap region does. */
+AVK_DEV u32 match_run_same(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb, u32 i) {
+#ifdef AVK_NO_MRS
+    return match_run(c, sa, i, la, sb, i, lb);
+#endif
+    const u32 lmin = la < lb ? la : lb;
+    if (i >= lmin) return 0;
+    const u32 lim = lmin - i;
+    const u32 *pa = c.p + ((sa * c.W1) << c.ls), *pb = c.p + ((sb * c.W1) << c.ls);
+    u32 k = i >> 4;
+    const u32 kend = (lmin + 15u) >> 4; /* words that hold bases below lmin */
+    const u32 sh = (i & 15u) * 2u;
+    u32 n = 0;
+    { /* the word the run starts in */
+        AVK_LSTAT(0, 1);
+        AVK_LSTAT(24 + g_lane_phase, 1);
+        const u32 x = (pa[k << c.ls] ^ pb[k << c.ls]) >> sh;
+        if (x) {
+            n = (u32)__builtin_ctz(x) >> 1;
+            return n < lim ? n : lim;
+        }
+        n = 16u - (i & 15u);
+        k += 1;
+    }
+    while (k < kend) { /* (words past kend are read from k: rows past the table's end are never touched) */
+        const u32 k1 = k + 1 < kend ? k + 1 : k, k2 = k + 2 < kend ? k + 2 : k, k3 = k + 3 < kend ? k + 3 : k;
+        const u32 a0 = pa[k << c.ls], b0 = pb[k << c.ls], a1 = pa[k1 << c.ls], b1 = pb[k1 << c.ls];
+        const u32 a2 = pa[k2 << c.ls], b2 = pb[k2 << c.ls], a3 = pa[k3 << c.ls], b3 = pb[k3 << c.ls];
+        AVK_LSTAT(0, 1);
+        AVK_LSTAT(24 + g_lane_phase, 1);
+        const u32 x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
+        const u32 have = kend - k; /* words left, this one included */
+        /* the first word that differs or ends the run */
+        u32 adv = 64u;
+        if (x3 || have <= 3u) adv = 48u + (x3 && have > 3u ? ((u32)__builtin_ctz(x3) >> 1) : 0u);
+        if (x2 || have <= 2u) adv = 32u + (x2 && have > 2u ? ((u32)__builtin_ctz(x2) >> 1) : 0u);
+        if (x1 || have <= 1u) adv = 16u + (x1 && have > 1u ? ((u32)__builtin_ctz(x1) >> 1) : 0u);
+        if (x0) adv = (u32)__builtin_ctz(x0) >> 1;
+        n += adv;
+        if (adv < 64u) break;
+        k += 4;
+    }
+    return n < lim ? n : lim;
+}
 
 /* ---- wavefront byte arrays ---------------------------------------------------------------- */
 AVK_DEV u8 *wf_ptr(const LCtx &c, u32 arr, u32 i) { return (u8 *)(c.p + ((c.off_wf + arr * c.wfr + (i >> 2)) << c.ls)) + (i & 3u); }
 AVK_DEV u32 wf_get(const LCtx &c, u32 arr, u32 i) { return *wf_ptr(c, arr, i); }
 AVK_DEV void wf_set(const LCtx &c, u32 arr, u32 i, u32 v) { *wf_ptr(c, arr, i) = (u8)v; }
+AVK_DEV u32 *wf_row(const LCtx &c, u32 arr, u32 row) { return c.p + ((c.off_wf + arr * c.wfr + row) << c.ls); } /* entries 4 row .. 4 row + 3 */
 
 /* DWFALite on (B = sequence sb of length bl, O = sequence so of length ol); wf[i] = symbols of O consumed on diagonal i,
- * baseline offset = wf[i] + ed - i (dynamic_wfa.rs:114) */
-/* extend (:94-130): every diagonal as far as it matches.  (A flat loop over (diagonal, word) instead of this nest — lanes that diverge
- * take turns, a nest costs the slowest lane of every inner loop — was measured: no change on the benchmark genome, whose extensions are
- * one word long; tools/gpu_slow_tiles.py shows that a slow tile is the sum of sixteen different lanes, not one long one.) */
-AVK_DEV void dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) {
-    for (u32 i = 0; i <= 2 * ed; ++i) {
-        AVK_LSTAT(1, 1);
-        AVK_LCOUNT(c, n_diag);
-        const u32 d = wf_get(c, arr, i);
-        const u32 bo = d + ed - i;
-        wf_set(c, arr, i, d + match_run(c, sb, bo, bl, so, d, ol));
-    }
-}
-AVK_DEV void dw_bump(const LCtx &c, u32 arr, u32 old_ed) { /* :140-173 without the re-extend; no clipping */
-    const u32 nd = 2 * old_ed + 1;
-    for (int k = (int)nd + 1; k >= 0; --k) {
-        u32 v = 0;
-        if ((u32)k < nd) v = wf_get(c, arr, (u32)k);
-        if (k >= 1 && (u32)(k - 1) < nd) {
-            const u32 t = wf_get(c, arr, (u32)(k - 1)) + 1;
-            v = t > v ? t : v;
+ * baseline offset = wf[i] + ed - i (dynamic_wfa.rs:114).
+ * A lane's time is a chain of dependent LDS round trips, so the front is handled a ROW (four diagonals, one LDS word) at a time: one
+ * read for the four offsets, the sixteen table reads of their first 16-base comparisons issued together, one write — instead of
+ * a read, two dependent pairs of reads and a write per diagonal.  Diagonals that agree beyond 16 bases carry on one by one (rare
+ * behind the first edit).  Each pass also says whether the front touches an end (update's stopping rule, :220-231: bit 0) or
+ * holds a full diagonal (finalize's, :237-245: bit 1), so nothing is read again to decide how to go on. */
+enum { DW_TOUCH = 1, DW_FULL = 2 };
+#ifndef AVK_DW_BATCH
+#define AVK_DW_BATCH 2u
+#endif
+/* the four diagonals 4 row .. 4 row + 3 of a front of `nd` diagonals at distance `ed`, offsets in `w` (one byte each): extended, flags added */
+AVK_DEV u32 dw_extend_row(const LCtx &c, u32 w, u32 row, u32 nd, u32 ed, u32 sb, u32 bl, u32 so, u32 ol, u32 &flags) {
+    u32 out = 0;
+#pragma unroll
+    for (u32 half = 0; half < 4; half += AVK_DW_BATCH) { /* AVK_DW_BATCH diagonals' reads in flight at a time (registers) */
+        u32 d[AVK_DW_BATCH], bo[AVK_DW_BATCH], lim[AVK_DW_BATCH], xa[AVK_DW_BATCH], xb[AVK_DW_BATCH];
+#pragma unroll
+        for (u32 k = 0; k < AVK_DW_BATCH; ++k) {
+            const u32 i = 4 * row + half + k;
+            d[k] = (w >> (8 * (half + k))) & 0xFFu;
+            bo[k] = d[k] + ed - i;
+            const u32 ra = bl > bo[k] ? bl - bo[k] : 0u, rb = ol > d[k] ? ol - d[k] : 0u;
+            lim[k] = i < nd ? (ra < rb ? ra : rb) : 0u;
         }
-        if (k >= 2 && (u32)(k - 2) < nd) {
-            const u32 t = wf_get(c, arr, (u32)(k - 2)) + 1;
-            v = t > v ? t : v;
+#pragma unroll
+        for (u32 k = 0; k < AVK_DW_BATCH; ++k) { /* nothing to compare: read word 0 (offsets past an end may lie outside the table) */
+            xa[k] = extract16(c, sb, lim[k] ? bo[k] : 0u);
+            xb[k] = extract16(c, so, lim[k] ? d[k] : 0u);
         }
-        wf_set(c, arr, (u32)k, v);
+#pragma unroll
+        for (u32 k = 0; k < AVK_DW_BATCH; ++k) {
+            const u32 i = 4 * row + half + k;
+            const u32 x = xa[k] ^ xb[k];
+            u32 n = x ? (u32)__builtin_ctz(x) >> 1 : 16u;
+            if (i < nd) {
+                AVK_LSTAT(1, 1);
+                AVK_LCOUNT(c, n_diag);
+                AVK_LSTAT(0, lim[k] ? 1 : 0);
+                AVK_LSTAT(24 + g_lane_phase, lim[k] ? 1 : 0);
+            }
+            if (n >= 16u && lim[k] > 16u) n = 16u + match_run(c, sb, bo[k] + 16u, bl, so, d[k] + 16u, ol);
+            n = n < lim[k] ? n : lim[k];
+            const u32 dn = d[k] + n;
+            if (i < nd) {
+                const bool eb = dn + ed - i >= bl, eo = dn >= ol;
+                flags |= (eb || eo) ? (u32)DW_TOUCH : 0u;
+                flags |= (eb && eo) ? (u32)DW_FULL : 0u;
+            }
+            out |= dn << (8 * (half + k));
+        }
     }
+    return out;
 }
-AVK_DEV bool dw_touches_end(const LCtx &c, u32 arr, u32 ed, u32 bl, u32 ol) { /* :220-231 */
-    bool any = false;
-    for (u32 i = 0; i <= 2 * ed; ++i) {
-        const u32 d = wf_get(c, arr, i);
-        any = any || d + ed - i >= bl || d >= ol;
+/* extend (:94-130): every diagonal as far as it matches */
+AVK_DEV u32 dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) {
+    const u32 nd = 2 * ed + 1;
+    u32 flags = 0;
+    for (u32 row = 0; 4 * row < nd; ++row) {
+        u32 *pw = wf_row(c, arr, row);
+        *pw = dw_extend_row(c, *pw, row, nd, ed, sb, bl, so, ol, flags);
     }
-    return any;
+    return flags;
 }
-AVK_DEV bool dw_full_diagonal(const LCtx &c, u32 arr, u32 ed, u32 bl, u32 ol) { /* :237-245 */
-    bool any = false;
-    for (u32 i = 0; i <= 2 * ed; ++i) {
-        const u32 d = wf_get(c, arr, i);
-        any = any || (d + ed - i >= bl && d >= ol);
+/* increase_edit_distance (:140-173: new[k] = max(old[k], old[k-1] + 1, old[k-2] + 1), no clipping) and the extend that always follows it,
+ * in one pass over the rows, top row first (row r of the new front needs rows r and r - 1 of the old one) */
+AVK_DEV u32 dw_bump_extend(const LCtx &c, u32 arr, u32 old_ed, u32 sb, u32 bl, u32 so, u32 ol) {
+    const u32 nd = 2 * old_ed + 1, nn = nd + 2, ed = old_ed + 1;
+    u32 flags = 0;
+    int row = (int)((nn - 1) >> 2);
+    auto old_row = [&](int r) -> u32 { /* entries >= nd of the old front do not exist */
+        if (r < 0 || 4u * (u32)r >= nd) return 0u;
+        const u32 w = *wf_row(c, arr, (u32)r);
+        const u32 have = nd - 4u * (u32)r;
+        return have >= 4u ? w : (w & ((1u << (8u * have)) - 1u));
+    };
+    u32 cur = old_row(row);
+    for (; row >= 0; --row) {
+        const u32 prev = old_row(row - 1);
+        const u64 both = ((u64)cur << 32) | prev;
+        const u32 b1 = (u32)(both >> 24), b2 = (u32)(both >> 16); /* entries k - 1 and k - 2 of the old front, byte k */
+        u32 w = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            const u32 g = 4u * (u32)row + k;
+            u32 v = (cur >> (8 * k)) & 0xFFu; /* 0 where the old front has no entry */
+            const u32 t1 = ((b1 >> (8 * k)) & 0xFFu) + 1u, t2 = ((b2 >> (8 * k)) & 0xFFu) + 1u;
+            if (g >= 1u && g - 1u < nd) v = t1 > v ? t1 : v;
+            if (g >= 2u && g - 2u < nd) v = t2 > v ? t2 : v;
+            w |= (g < nn ? v : 0u) << (8 * k);
+        }
+        *wf_row(c, arr, (u32)row) = dw_extend_row(c, w, (u32)row, nn, ed, sb, bl, so, ol, flags);
+        cur = prev;
     }
-    return any;
+    return flags;
 }
 enum { LS_PARTIAL = 1 }; /* a capped alignment stopped: the distance is MORE than the budget (how much more is not known) */
 /* update (:68-84): extend, then raise the distance until EITHER end is touched; LS_DEFER when the array is too small.
  * `budget` = the largest distance the caller cares about: LS_PARTIAL as soon as the distance is known to exceed it. */
 AVK_DEV int dw_update(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget) {
-    dw_extend(c, arr, ed, sb, bl, so, ol);
-    while (!dw_touches_end(c, arr, ed, bl, ol)) {
+    u32 fl = dw_extend(c, arr, ed, sb, bl, so, ol);
+    while (!(fl & DW_TOUCH)) {
         if (ed + 1 > budget) return LS_PARTIAL;
         if (2 * ed + 3 > c.wfcap) return AVK_LDEFER(0);
-        dw_bump(c, arr, ed);
+        fl = dw_bump_extend(c, arr, ed, sb, bl, so, ol);
         ed += 1;
-        dw_extend(c, arr, ed, sb, bl, so, ol);
     }
     return 0;
 }
 AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget, u32 cap) { /* :183-198 */
-    dw_extend(c, arr, ed, sb, bl, so, ol);
-    while (!dw_full_diagonal(c, arr, ed, bl, ol)) {
+    u32 fl = dw_extend(c, arr, ed, sb, bl, so, ol);
+    while (!(fl & DW_FULL)) {
         if (ed + 1 > budget) return LS_PARTIAL;
         if (2 * ed + 3 > cap) return AVK_LDEFER(0);
-        dw_bump(c, arr, ed);
+        fl = dw_bump_extend(c, arr, ed, sb, bl, so, ol);
         ed += 1;
-        dw_extend(c, arr, ed, sb, bl, so, ol);
     }
     return 0;
 }
@@ -233,7 +329,7 @@ AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so,
 AVK_DEV int wfa_ed(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
     AVK_LSTAT(6, 1);
     const u32 lim = la < lb ? la : lb;
-    const u32 d = match_run(c, sa, 0, la, sb, 0, lb);
+    const u32 d = match_run_same(c, sa, la, sb, lb, 0);
     if (d == lim) return (int)((la > lb ? la : lb) - lim);
     wf_set(c, 0, 0, d);
     u32 ed = 0;
@@ -304,7 +400,7 @@ AVK_DEV bool hap_step(const LCtx &c, Hap &h, bool is_truth, bool has_var, u32 sl
 AVK_DEV int hap_update(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
     const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
     if (h.ed == 0) {
-        h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
+        h.d0 += match_run_same(c, st, h.t_len, sq, h.q_len, h.d0);
         const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
         if (h.d0 >= lim) return 0;
         if (budget == 0) return LS_PARTIAL;
@@ -540,7 +636,7 @@ AVK_DEV bool hapB_step(const LCtx &c, Hap &h, u32 d, bool alt) {
     const u32 slot = ord_slot(c, d);
     const bool ok = hap_step(c, h, slot < MV, true, slot, alt ? L_ALT : L_REF, sync_after(c, d));
     const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
-    h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
+    h.d0 += match_run_same(c, st, h.t_len, sq, h.q_len, h.d0);
     const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
     return ok && h.d0 >= lim;
 }
@@ -565,7 +661,7 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
         if (depth == c.N) { /* :180-192 */
             hap_step(c, h, true, false, 0, L_REF, c.L);
             const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
-            h.d0 += match_run(c, st, h.d0, h.t_len, sq, h.d0, h.q_len);
+            h.d0 += match_run_same(c, st, h.t_len, sq, h.q_len, h.d0);
             if (h.d0 >= h.t_len && h.d0 >= h.q_len) {
                 res_t = h.t_alt;
                 res_q = h.q_alt;
@@ -1158,10 +1254,14 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #endif
 #ifdef AVK_LANE_STATS
             const uint64_t work0 = lane_work_now();
+            uint64_t comp0[8];
+            for (int k = 0; k < 8; ++k) comp0[k] = g_lane_stats[k];
 #endif
             const int st = solve_lane(a, c, rec, 64u, out, wg_tally);
 #ifdef AVK_LANE_STATS
             if (g_lane_work) g_lane_work[orig] = (uint32_t)(lane_work_now() - work0);
+            if (g_lane_comp)
+                for (int k = 0; k < 8; ++k) g_lane_comp[8 * (size_t)orig + k] = (uint32_t)(g_lane_stats[k] - comp0[k]);
 #endif
             if (st == AVK_ST_OK) {
                 AVK_LT_MARK(c, 5)

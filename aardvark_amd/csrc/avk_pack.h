@@ -473,7 +473,7 @@ struct WorkPlan {
  * an unused class are planned like any other region.  0xFFFFFFFF = no lane classes at all. */
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
                                 uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12,
-                                uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV, uint64_t lane_min_batch = 0) {
+                                uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV, uint64_t lane_min_batch = 0, uint32_t stripe_w = 0) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
@@ -546,6 +546,13 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
             plan.fast_base[fc] = at;
             plan.n_fast_total += plan.n_fast[fc];
         }
+    }
+    /* the heads of the lane classes are dealt out over their claims (avk_stripe_slot, avk_dev_types.h) */
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) {
+        const uint32_t hs = avk_head_slots(AVK_FAST_CLASS[fc].maxv, plan.n_fast[fc], plan.n_fast_heavy[fc], stripe_w);
+        if (!hs) continue;
+        std::vector<uint32_t> head(order->begin() + plan.fast_base[fc], order->begin() + plan.fast_base[fc] + hs);
+        for (uint32_t p = 0; p < hs; ++p) (*order)[plan.fast_base[fc] + avk_stripe_slot(p, hs, stripe_w)] = head[p];
     }
     return plan;
 }

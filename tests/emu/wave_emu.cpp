@@ -148,7 +148,7 @@ static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
 #include "../../aardvark_amd/csrc/avk_pack.h"
 #include "../../aardvark_amd/csrc/avk_solver.inl"
 #ifdef AVK_LANE_STATS
-namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; uint32_t *g_lane_work; } }
+namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; uint32_t *g_lane_work; uint32_t *g_lane_comp; } }
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
 #include "../../aardvark_amd/csrc/avk_dwfa_script.inl"
@@ -193,6 +193,7 @@ void lane_main(void *p, int /*lane*/) {
 
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
  * device functions, the workgroup-level plumbing (histogram, scans, scatter) as plain loops */
+uint32_t g_stripe_w = 0; /* emu_set_stripe: claim width the heads of the lane classes are dealt out over (context option lane_stripe; 0 = sorted order) */
 int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
 namespace dpk = avk::dp;
 struct DpResult {
@@ -256,7 +257,7 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
             R->st.hist[bk] += 1;
         }
         dpk::dp_bucket_bases(a);
-        for (uint64_t r = 0; r < n; ++r) R->order[R->st.cursor[R->rinfo[r].bucket]++] = (uint32_t)r;
+        for (uint64_t r = 0; r < n; ++r) R->order[dpk::dp_order_slot(a, R->rinfo[r].bucket, R->st.cursor[R->rinfo[r].bucket]++)] = (uint32_t)r;
     };
     region_passes();
     if (R->st.n_pending) { /* upload_device_packed: the host's edit distance for the calls dp_variant left, then the region passes again */
@@ -304,6 +305,7 @@ dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_by
     o.solo_min_variants = pairs ? 0u : solo_min_variants, o.max_branch = 50;
     o.class_c_nodes_x2 = getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u;
     o.lane_min_regions = lane_min_regions, o.lane_max_calls = AVK_FAST_MAXV, o.lane_min_batch = lane_min_batch, o.lane_max_est = lane_max_est;
+    o.stripe_w = g_stripe_w;
     return o;
 }
 
@@ -504,7 +506,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     } else {
         plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
                                     getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
-                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */);
+                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */, AVK_FAST_MAXV, 0, g_stripe_w);
         sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     }
     a.regions = devpack ? dpr.regions.data() : sorted.data();
@@ -883,6 +885,7 @@ int emu_merge_batch(const avk_multi_batch *mb, const uint8_t *const *refs, const
 
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
+void emu_set_stripe(uint32_t w) { g_stripe_w = w; }
 
 /* The device-side packer against the host-side one on the same batch: every region record, every blob, the plan, the work order and the fast
  * records must be identical (the blob arena may be laid out differently: blobs are compared by content).  Returns 0, or 1 with the first
@@ -922,7 +925,7 @@ int emu_devpack_compare(const avk_region_batch *batch, const uint64_t *ref_lens,
         }
     std::vector<uint32_t> order;
     const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), 48, lds2_bytes, 48, pairs_mode ? 0u : solo_min_variants, 50, &order, 12, lane_min_regions,
-                                                    AVK_FAST_MAXV, lane_min_batch);
+                                                    AVK_FAST_MAXV, lane_min_batch, g_stripe_w);
     if (pb.variants.size() != R.st.total_v) return say("per-call output words: host %zu, device %llu", pb.variants.size(), (unsigned long long)R.st.total_v);
     if (seq_total != R.st.total_seq) return say("sequence bytes: host %llu, device %llu", (unsigned long long)seq_total, (unsigned long long)R.st.total_seq);
     if (plan.n_hbm != R.st.n_hbm || plan.n_hard != R.st.n_hard || plan.n_fast_total != R.st.n_fast_total)
@@ -988,6 +991,7 @@ uint32_t emu_devpack_alt_ed(const uint8_t *a0, uint32_t l0, const uint8_t *a1, u
 }
 #ifdef AVK_LANE_STATS
 void emu_lane_work(uint32_t *per_region) { avk::lane::g_lane_work = per_region; }
+void emu_lane_comp(uint32_t *per_region_x8) { avk::lane::g_lane_comp = per_region_x8; }
 void emu_lane_stats(uint64_t *out, int reset) {
     for (int i = 0; i < 32; ++i) {
         out[i] = avk::lane::g_lane_stats[i];
