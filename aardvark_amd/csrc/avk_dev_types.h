@@ -91,7 +91,9 @@ struct AvkDevVariant {
 /* words of a record of a class with `maxv` calls per side: header + 2 * maxv call slots (truth slots first); the tiles of a class are
  * contiguous, tile t of the class at [t * words * 64, (t + 1) * words * 64) of the class's part of the record array */
 #define AVK_FAST_WORDS_OF(maxv) (AVK_FAST_HDR + 8u * (maxv))
-#define AVK_FAST_CLASSES 5
+#define AVK_FAST_CLASSES 6
+#define AVK_FAST_GENERIC 5 /* classes 0 .. 4: solved by the search of avk_lane.inl; the class behind them is looked up (avk_pairs.inl) */
+#define AVK_FAST_PAIR 5
 /* capacities of the launch classes: sequence words (16 bases each), calls per side, wavefront cap, queue entries.
  * ed_max caps the edit distance a lane follows, not what the region may contain: with the lazily evaluated search (avk_lane.inl,
  * phaseA) the alignments of wrongly phased branches stop at their first edit, so a region of matching 40-base deletions never needs
@@ -106,6 +108,7 @@ static const AvkFastClass AVK_FAST_CLASS[AVK_FAST_CLASSES] = {
     {10, 2, 6, 16},  /* two calls per side, <= 160 bases */
     {12, 2, 6, 16},  /* two calls per side, <= 192 bases */
     {12, 3, 6, 32},  /* three calls per side, <= 192 bases (nine in ten of the regions that are left) */
+    {12, 1, 0, 0},   /* AVK_FAST_PAIR: one SNV per side, the same one (seven in ten regions of a genome): no search, avk_pairs.inl */
 };
 
 #if defined(__HIPCC__) && !defined(AVK_EMU)

@@ -25,6 +25,7 @@
 
 #include "avk_dev_types.h"
 #include "avk_wave.h"
+#include "avk_pairs.inl"
 
 namespace avk {
 namespace dp {
@@ -63,6 +64,7 @@ struct DpOpts {
     u64 tier0_bytes, tier1_bytes;
     u32 tier0_ed_cap, tier1_ed_cap;
     u32 solo_min_variants, max_branch, class_c_nodes_x2, lane_max_calls, lane_max_est;
+    u32 lane_pairs, pad_; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
     u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
     u64 lane_min_batch;
@@ -347,7 +349,7 @@ AVK_DEV void dp_variant(const DpArgs &a, u64 v) {
 
 /* ---- dp_region: pack_batch's validation and sizes, the lane class and its cost key, the predicted workspace class ------------------- */
 struct DpCall { /* FastCall of avk_pack.h */
-    u32 pos, a0, a1, alt_ed, type, zyg, lo, hi;
+    u32 pos, a0, a1, alt_ed, type, zyg, lo, hi, raw;
 };
 AVK_DEV u32 dp_copies(u32 z) { return z == AVK_ZYG_HOM_ALT ? 2u : 1u; }
 /* fast_cost_key (avk_pack.h), the same arithmetic on the packed ALT words.  c[0..2] = the truth calls, c[3..5] = the query calls; every index is a
@@ -501,7 +503,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
             for (u32 sidx = 0; sidx < 2 * AVK_FAST_MAXV; ++sidx) {
                 const u32 side = sidx / AVK_FAST_MAXV, j = sidx % AVK_FAST_MAXV;
                 DpCall &k = calls[sidx];
-                k.pos = k.a0 = k.a1 = k.alt_ed = k.type = k.zyg = k.lo = k.hi = 0;
+                k.pos = k.a0 = k.a1 = k.alt_ed = k.type = k.zyg = k.lo = k.hi = k.raw = 0;
                 if (j >= (side ? qc : tc)) continue;
                 const u64 v = (side ? qoff : toff) + j;
                 const u32 l0 = in.a0_len[v], l1 = in.a1_len[v];
@@ -509,9 +511,9 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                 const DpVarInfo vi = a.vinfo[v];
                 const u64 rel = in.var_pos[v] - start;
                 lane_ok = lane_ok && rel <= 255 && l0 <= 255 && l1 <= 32 && vi.alt_ed <= 255 && raw <= 0xFFFF && (vi.flags & DP_VF_ACGT32);
-                k.pos = (u32)rel, k.a0 = l0, k.a1 = l1, k.alt_ed = vi.alt_ed, k.type = in.var_type[v], k.zyg = in.var_zyg[v], k.lo = vi.a1lo, k.hi = vi.a1hi;
+                k.pos = (u32)rel, k.a0 = l0, k.a1 = l1, k.alt_ed = vi.alt_ed, k.type = in.var_type[v], k.zyg = in.var_zyg[v], k.lo = vi.a1lo, k.hi = vi.a1hi, k.raw = raw;
             }
-            for (int cl = 0; cl < AVK_FAST_CLASSES && lane_ok; ++cl) {
+            for (int cl = 0; cl < AVK_FAST_GENERIC && lane_ok; ++cl) {
                 const u32 W = AVK_FAST_CLASS[cl].W, maxv = AVK_FAST_CLASS[cl].maxv;
                 if (tc <= maxv && qc <= maxv && (u64)ri.len + ri.grow <= 16ull * W) {
                     fast_class = (u32)cl + 1u;
@@ -520,6 +522,14 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                     if (maxv > 2) fast_key = 0; /* the three-call class keeps the caller's order (avk_pack.h) */
                     break;
                 }
+            }
+            /* the same SNV on both sides: looked up, not searched (avk_pairs.inl) */
+            if (fast_class && a.opt.lane_pairs &&
+                pairs::pair_is_candidate(tc, qc, calls[0].pos, calls[AVK_FAST_MAXV].pos, calls[0].a0, calls[0].a1, calls[AVK_FAST_MAXV].a0, calls[AVK_FAST_MAXV].a1, calls[0].type,
+                                         calls[AVK_FAST_MAXV].type, calls[0].zyg, calls[AVK_FAST_MAXV].zyg, calls[0].alt_ed, calls[AVK_FAST_MAXV].alt_ed, calls[0].raw,
+                                         calls[AVK_FAST_MAXV].raw, calls[0].lo, calls[AVK_FAST_MAXV].lo)) {
+                fast_class = (u32)AVK_FAST_PAIR + 1u;
+                fast_key = 0;
             }
         }
     }
@@ -563,7 +573,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
 
 /* ---- dp_lane_switch: which lane classes get launches (plan_work_order), one thread ------------------------------------------------ */
 AVK_DEV void dp_lane_switch(const DpArgs &a) {
-    const u64 scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2};
+    const u64 scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2, 1};
     u64 have_all = 0;
     u32 on[AVK_FAST_CLASSES];
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) {
@@ -572,7 +582,7 @@ AVK_DEV void dp_lane_switch(const DpArgs &a) {
         have_all += on[fc] ? h : 0;
     }
     if (a.opt.lane_min_regions != 0 && have_all < a.opt.lane_min_batch)
-        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) on[fc] = 0;
+        for (int fc = 0; fc < AVK_FAST_GENERIC; ++fc) on[fc] = 0; /* (the looked-up class has no long tiles: it stays) */
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) a.st->lane_on[fc] = on[fc];
 }
 

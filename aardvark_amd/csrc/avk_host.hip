@@ -111,6 +111,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_LAN
     }
 }
 
+/* regions with the same SNV on both sides (avk_pairs.inl): table rows copied out, 64 regions per wave at a time */
+__global__ void __launch_bounds__(256) avk_pair_kernel(AvkKernelArgs a, avk::pairs::PairArgs pa) {
+    avk::pairs::pair_worker(a, pa, a.tally + (uint64_t)(blockIdx.x % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE);
+}
+
 /* DWFALite scripts (avk_dwfa_script.inl): engine 0 one script per wavefront, engine 1 one script per lane */
 __global__ void __launch_bounds__(256) avk_dwfa_wave_kernel(AvkDwfaArgs a) {
     const unsigned wave = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -292,6 +297,11 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
+    int64_t lane_pairs = 1;                           /* regions with the same SNV on both sides are looked up in a table the solver fills (avk_pairs.inl); 0: they stay in the one-call classes */
+    avk::pairs::PairTable *d_pair_tab = nullptr;      /* the table, made for max_branch_factor pair_tab_mbf */
+    uint32_t *d_pair_aux = nullptr;                   /* probe records, probe reference and the scratch outputs of the probe launch */
+    int64_t pair_tab_mbf = -1;
+    int64_t pair_blocks_per_cu = 4;                   /* workgroups (4 waves) of the lookup launch per CU */
     int64_t lane_stripe = 0;                          /* 1: the heads' records dealt out over their claims (avk_stripe_slot, avk_dev_types.h) instead of most expensive first.  Measured
                                                          WORSE (whole genome 4.84 -> 5.40 ms per step): regions of one cost key take the same path through the search, a claim of equals
                                                          runs in lockstep, a claim of unequals takes turns */
@@ -531,6 +541,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_ready2) (void)hipEventDestroy(ctx->ev_ready2);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
+    if (ctx->d_pair_tab) (void)hipFree(ctx->d_pair_tab);
+    if (ctx->d_pair_aux) (void)hipFree(ctx->d_pair_aux);
     if (ctx->ev_lane_fork) (void)hipEventDestroy(ctx->ev_lane_fork);
     if (ctx->ev_lane_join) (void)hipEventDestroy(ctx->ev_lane_join);
     if (ctx->ev_lane_join2) (void)hipEventDestroy(ctx->ev_lane_join2);
@@ -660,6 +672,11 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
+    } else if (n == "lane_pairs") {
+        ctx->lane_pairs = value ? 1 : 0;
+    } else if (n == "pair_blocks_per_cu") {
+        if (value < 1 || value > 8) return fail(ctx, AVK_E_ARG, "pair_blocks_per_cu must be 1..8");
+        ctx->pair_blocks_per_cu = value;
     } else if (n == "lane_stripe") {
         ctx->lane_stripe = value ? 1 : 0;
     } else if (n == "lane_head_stream") {
@@ -864,7 +881,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     }
     db->seq_total = seq_total;
     std::string err;
-    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est);
+    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0);
     if (rc) {
         delete db;
         return fail(ctx, rc, "%s", err.c_str());
@@ -1006,6 +1023,59 @@ static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs
     if (g > claims) g = claims;
     *grid = g;
     return lds;
+}
+
+/* The table of avk_pairs.inl for this max_branch_factor, on `s`: sixteen probe regions through the lane kernel, outputs redirected into the table.
+ * Words of d_pair_aux: [0, 768) probe records, [768, 784) probe reference, [784, 792) its exception bitmap (zeros), [792, 812) BASEPAIR offsets 0, 2, .. 32,
+ * [812] tile counter, [813] overflow count, [816, 880) overflow list, [896, 896 + 2 * AVK_TALLY_STRIDE) a partial tally nobody reads. */
+static int ensure_pair_table(avk_ctx *ctx, uint32_t max_branch_factor, hipStream_t s) {
+    enum { AUX_WORDS = 896 + 2 * AVK_TALLY_STRIDE };
+    if (!ctx->d_pair_tab) {
+        AVK_HIP(ctx, hipMalloc((void **)&ctx->d_pair_tab, sizeof(avk::pairs::PairTable)));
+        AVK_HIP(ctx, hipMalloc((void **)&ctx->d_pair_aux, (size_t)AUX_WORDS * 4));
+        std::vector<uint32_t> aux(AUX_WORDS, 0);
+        avk::pairs::pair_probe_records(aux.data(), aux.data() + 768);
+        for (uint32_t k = 0; k <= avk::pairs::N_SIG; ++k) aux[792 + k] = 2 * k;
+        AVK_HIP(ctx, hipMemcpy(ctx->d_pair_aux, aux.data(), (size_t)AUX_WORDS * 4, hipMemcpyHostToDevice));
+        ctx->pair_tab_mbf = -1;
+    }
+    if (ctx->pair_tab_mbf == (int64_t)max_branch_factor) return AVK_E_OK;
+    AVK_HIP(ctx, hipMemsetAsync(ctx->d_pair_tab, 0xFF, sizeof(avk::pairs::PairTable), s));
+    AVK_HIP(ctx, hipMemsetAsync(ctx->d_pair_aux + 812, 0, (size_t)(AUX_WORDS - 812) * 4, s));
+    AvkKernelArgs f;
+    memset(&f, 0, sizeof(f));
+    f.ref_2bit = ctx->d_pair_aux + 768;
+    f.ref_exc = ctx->d_pair_aux + 784;
+    f.n_regions = avk::pairs::N_SIG;
+    f.max_branch_factor = max_branch_factor;
+    f.region_out = &ctx->d_pair_tab->region[0][0];
+    f.var_out = &ctx->d_pair_tab->var[0][0];
+    f.group_metrics = &ctx->d_pair_tab->gm[0][0];
+    f.bp_off = ctx->d_pair_aux + 792;
+    f.bp_out = &ctx->d_pair_tab->bp[0][0];
+    f.tally = (uint64_t *)(ctx->d_pair_aux + 896);
+    f.overflow_list = ctx->d_pair_aux + 816;
+    f.overflow_count = ctx->d_pair_aux + 813;
+    avk::lane::LaneArgs la;
+    memset(&la, 0, sizeof(la));
+    const AvkFastClass &cl = AVK_FAST_CLASS[0];
+    la.recs = ctx->d_pair_aux;
+    la.rec_words = AVK_FAST_WORDS_OF(1);
+    la.n_tiles = 1;
+    la.tile_counter = ctx->d_pair_aux + 812;
+    la.W = cl.W, la.nm = 2, la.ed_max = cl.ed_max, la.qcap = cl.qcap;
+    la.lanes_log2 = 6;
+    la.max_nodes = 250;
+    uint32_t grid = 0;
+    const size_t lds = lane_launch_geometry(ctx, la, &grid);
+    if (!ctx->lane_attr_set) {
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->lane_attr_set = true;
+    }
+    hipLaunchKernelGGL(avk_lane_kernel, dim3(1), dim3(64), lds, s, f, la);
+    AVK_HIP(ctx, hipGetLastError());
+    ctx->pair_tab_mbf = (int64_t)max_branch_factor;
+    return AVK_E_OK;
 }
 
 static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev, uint32_t mode) {
@@ -1306,7 +1376,33 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_fork, ctx->stream));
                 for (int fc = lane_k - 1; fc >= 0; --fc) {
                     if (!db->fast_tiles[fc]) continue;
-                    const AvkFastClass &cl = AVK_FAST_CLASS[fc];
+                    if (fc == AVK_FAST_PAIR && mode == 0 && ctx->lane_pairs) {
+                        /* looked up, not searched (avk_pairs.inl): first on the stream of the one-call classes, BESIDE everything else.  (Alone it needs 0.18 ms;
+                         * beside the persistent waves of the other launches its workgroups wait for wave slots and it lasts 1.1 ms — in their shadow, which
+                         * measured better than 0.18 ms ahead of them: 3.95 against 4.2 ms per whole-genome step.) */
+                        const int li = 1;
+                        if (!lused[li]) {
+                            AVK_HIP(ctx, hipStreamWaitEvent(lstream[li], ctx->ev_lane_fork, 0));
+                            if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[li], lstream[li]));
+                            lused[li] = true;
+                        }
+                        const int rt = ensure_pair_table(ctx, cfg->max_branch_factor, lstream[li]);
+                        if (rt) return rt;
+                        avk::pairs::PairArgs pa;
+                        pa.recs = db->d_fast + db->fast_word_base[fc];
+                        pa.n_tiles = db->fast_tiles[fc];
+                        pa.gen_base = db->plan.fast_base[fc];
+                        pa.tab = ctx->d_pair_tab;
+                        pa.tile_counter = db->d_counters + 1220 + fc;
+                        uint32_t pg = (uint32_t)ctx->n_cus * (uint32_t)(ctx->pair_blocks_per_cu > 0 ? ctx->pair_blocks_per_cu : 1);
+                        const uint32_t claims = (pa.n_tiles + avk::pairs::PAIR_CLAIM - 1) / avk::pairs::PAIR_CLAIM;
+                        if (pg > (claims + 3u) / 4u) pg = (claims + 3u) / 4u;
+                        hipLaunchKernelGGL(avk_pair_kernel, dim3(pg), dim3(256), 0, lstream[li], f, pa);
+                        AVK_HIP(ctx, hipGetLastError());
+                        continue;
+                    }
+                    /* (the looked-up class in merge mode or with the option off: its records are those of a one-call class) */
+                    const AvkFastClass &cl = fc == AVK_FAST_PAIR ? AVK_FAST_CLASS[1] : AVK_FAST_CLASS[fc];
                     avk::lane::LaneArgs la;
                     la.recs = db->d_fast + db->fast_word_base[fc];
                     la.rec_words = AVK_FAST_WORDS_OF(cl.maxv);

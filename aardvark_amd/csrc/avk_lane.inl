@@ -694,49 +694,58 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
     return -100 - AVK_ST_NO_GT_RESULT; /* :345-348 */
 }
 
-/* wfa_ed(reference window, FULL(side, mask)).  No alleles: 0.  One call whose alt_ed is 1 (the haplotype differs from the window
- * and one edit makes them equal) or equals the length difference of its alleles (any alignment needs at least that many edits, and
- * alt_ed edits suffice): alt_ed, without aligning.  Anything else is aligned. */
+/* What ONE call does to a string that has the window's bases over the call's REF span, decided from the window itself — never from the
+ * caller's REF allele or its alt_ed, which may disagree with the genome (a record whose REF is not what the reference has there: the solver
+ * splices the ALT into the WINDOW, generate_allele_sequence waffle_solver.rs:726-778, so that is what counts):
+ *   one base for one base: 0 when the ALT base is the window's base, else 1 (equal lengths, one position);
+ *   one side of the call is a single base and it is the window's base there (the anchor is kept): the call only inserts or only deletes the
+ *   rest, the lengths differ by that much and that many edits suffice;
+ *   anything else: -1, to be aligned. */
+AVK_DEV int call_effect(const LCtx &c, u32 side, u32 j) {
+    const u32 slot = MV * side + j;
+    const u32 w0 = sel4(c.vw0, slot);
+    const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+    if (a1 == 0 || a0 == 0) return -1;
+    /* FULL(side, this call alone) has the ALT allele at `pos` (a single call is never dropped) */
+    const bool anchored = ((extract16(c, 0, pos) ^ extract16(c, seq_id(c, side, 1u << j), pos)) & 3u) == 0;
+    if (a0 == 1 && a1 == 1) return anchored ? 0 : 1;
+    if ((a0 == 1 || a1 == 1) && anchored) return (int)(a0 > a1 ? a0 - a1 : a1 - a0);
+    return -1;
+}
+
+/* wfa_ed(reference window, FULL(side, mask)).  No alleles: 0.  One call: call_effect.  Several calls, all applied: substitutions at two
+ * different positions add up (equal lengths, the positions where the strings differ; no single edit gives two), pure insertions only (or pure
+ * deletions only) add up as well (the length changes by their sum, which is also enough).  Anything else is aligned. */
 AVK_DEV int ed_to_ref(const LCtx &c, u32 side, u32 mask, u32 len) {
     if (mask == 0) return 0;
     if ((mask & (mask - 1)) == 0) {
-        const u32 slot = MV * side + (u32)__builtin_ctz(mask);
-        const u32 w0 = sel4(c.vw0, slot), e = sel4(c.vw1, slot) & 0xFFu;
-        const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
-        const u32 diff = a0 > a1 ? a0 - a1 : a1 - a0;
-        if (e == 1 || (e && e == diff)) return (int)e;
+        const int e = call_effect(c, side, (u32)__builtin_ctz(mask));
+        if (e >= 0) return e;
     } else if (seq_fail_of(c, seq_id(c, side, mask)) == 0) {
-        /* several calls of the side, all applied.  Two substitutions at different positions: the strings have one length and differ
-         * in two places, no single edit does that.  Pure insertions only (or pure deletions only): the length changes by the sum of
-         * their edits, which is also enough. */
         u32 n = 0, n_snv = 0, n_ins = 0, n_del = 0, sum = 0, pos_x = 0;
+        bool all = true;
 #pragma unroll
         for (u32 j = 0; j < MV; ++j) {
             if (!((mask >> j) & 1u)) continue;
-            const u32 w0 = side ? c.vw0[MV + j] : c.vw0[j], e = (side ? c.vw1[MV + j] : c.vw1[j]) & 0xFFu;
+            const u32 w0 = side ? c.vw0[MV + j] : c.vw0[j];
             const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
+            const int e = call_effect(c, side, j);
+            all = all && e >= 0;
             n += 1;
-            sum += e;
-            n_snv += (a0 == 1 && a1 == 1 && e == 1) ? 1u : 0u;
-            n_ins += (a1 > a0 && e == a1 - a0) ? 1u : 0u;
-            n_del += (a0 > a1 && e == a0 - a1) ? 1u : 0u;
+            sum += e >= 0 ? (u32)e : 0u;
+            n_snv += (a0 == 1 && a1 == 1) ? 1u : 0u;
+            n_ins += (a0 == 1 && a1 > 1) ? 1u : 0u;
+            n_del += (a1 == 1 && a0 > 1) ? 1u : 0u;
             pos_x ^= w0 & 0xFFu;
         }
-        if (n == 2 && n_snv == 2 && pos_x != 0) return 2;
-        if (n_ins == n || n_del == n) return (int)sum;
+        if (all && n == 2 && n_snv == 2 && pos_x != 0) return (int)sum;
+        if (all && (n_ins == n || n_del == n)) return (int)sum;
     }
     return wfa_ed(c, 0, c.L, seq_id(c, side, mask), len);
 }
 
-/* Distance between a haplotype string and the same string without ONE of its calls (slot), when the call's own distance decides it:
- * alt_ed 1 (the strings differ, one edit makes them equal) or a pure insertion / deletion (the length difference needs that many).
- * -1: not decided this way. */
-AVK_DEV int one_call_distance(const LCtx &c, u32 slot) {
-    const u32 w0 = sel4(c.vw0, slot), e = sel4(c.vw1, slot) & 0xFFu;
-    const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
-    const u32 diff = a0 > a1 ? a0 - a1 : a1 - a0;
-    return (e == 1 || (e && e == diff)) ? (int)e : -1;
-}
+/* Distance between a haplotype string and the same string without ONE of its calls (slot), when call_effect decides it.  -1: not decided this way. */
+AVK_DEV int one_call_distance(const LCtx &c, u32 slot) { return call_effect(c, slot / MV, slot % MV); }
 
 /* the genotype assignment of one haplotype of an optimum: flips, observed alleles */
 AVK_DEV int gt_for_hap(const LCtx &c, const Hap &h, u32 &rt, u32 &rq) {

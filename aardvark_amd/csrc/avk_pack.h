@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "avk_dev_types.h"
+#include "avk_pairs.inl"
 
 namespace avk {
 
@@ -169,7 +170,8 @@ inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *
  * (prefix sums), then the regions are validated and their blobs written by `threads` workers (regions are
  * independent once the offsets are known). */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
-                      const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0, uint32_t lane_max_est = 15) {
+                      const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0, uint32_t lane_max_est = 15,
+                      bool lane_pairs = true) {
     const uint64_t n = b->n_regions;
     if (n > 0x7FFFFFFFull || b->n_variants > 0x7FFFFFFFull) {
         *err = "batch too large (more than 2^31 regions or variants); split it";
@@ -396,7 +398,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                     const uint8_t *a1 = ba + bv[i].a_off + bv[i].a0_len;
                     for (uint32_t j = 0; j < bv[i].a1_len && ok; ++j) ok = a1[j] == 'A' || a1[j] == 'C' || a1[j] == 'G' || a1[j] == 'T';
                 }
-                for (int cl = 0; cl < AVK_FAST_CLASSES && ok; ++cl) {
+                for (int cl = 0; cl < AVK_FAST_GENERIC && ok; ++cl) {
                     const AvkFastClass &fc = AVK_FAST_CLASS[cl];
                     if (tc <= fc.maxv && qc <= fc.maxv && (uint64_t)dr.len + dr.grow <= 16ull * fc.W) {
                         out->fast_class[r] = (uint8_t)(cl + 1);
@@ -410,6 +412,16 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                          * one, and the launch lasts as long as that tile (measured: 3.1 ms in caller order, 6.2 ms sorted). */
                         if (fc.maxv > 2) out->fast_key[r] = 0;
                         break;
+                    }
+                }
+                /* the same SNV on both sides: looked up, not searched (avk_pairs.inl) */
+                if (ok && out->fast_class[r] && lane_pairs && tc == 1 && qc == 1) {
+                    auto code = [&](const AvkBlobVar &x) { const uint8_t ch = ba[x.a_off + x.a0_len]; return ch == 'C' ? 1u : (ch == 'G' ? 2u : (ch == 'T' ? 3u : 0u)); };
+                    if (pairs::pair_is_candidate(tc, qc, bv[0].rel_pos, bv[1].rel_pos, bv[0].a0_len, bv[0].a1_len, bv[1].a0_len, bv[1].a1_len, bv[0].type_zyg & 0xFFu, bv[1].type_zyg & 0xFFu,
+                                                 (bv[0].type_zyg >> 8) & 0xFFu, (bv[1].type_zyg >> 8) & 0xFFu, bv[0].alt_ed, bv[1].alt_ed, bv[0].raw_space, bv[1].raw_space,
+                                                 bv[0].a1_len ? code(bv[0]) : 0u, bv[1].a1_len ? code(bv[1]) : 0u)) {
+                        out->fast_class[r] = (uint8_t)(AVK_FAST_PAIR + 1);
+                        out->fast_key[r] = 0;
                     }
                 }
             }
@@ -480,7 +492,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
     WorkPlan plan;
     bool lane_on[AVK_FAST_CLASSES];
     {
-        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2};
+        static const uint64_t scale[AVK_FAST_CLASSES] = {1, 1, 16, 16, 2, 1};
         uint64_t have[AVK_FAST_CLASSES] = {0};
         if (!pb.fast_class.empty())
             for (uint64_t r = 0; r < n; ++r)
@@ -493,7 +505,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         uint64_t have_all = 0;
         for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) have_all += lane_on[fc] ? have[fc] : 0;
         if (lane_min_regions != 0 && have_all < lane_min_batch)
-            for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lane_on[fc] = false;
+            for (int fc = 0; fc < AVK_FAST_GENERIC; ++fc) lane_on[fc] = false; /* (the looked-up class has no long tiles: it stays) */
     }
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;

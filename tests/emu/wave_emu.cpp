@@ -169,6 +169,15 @@ struct LaneTask {
     uint32_t *lds, *tally;
     uint32_t n_ok[64], n_err[64];
 };
+struct PairTask {
+    const AvkKernelArgs *args;
+    const avk::pairs::PairArgs *pa;
+    uint64_t *part;
+};
+void pair_kernel_main(void *p, int) {
+    PairTask *t = (PairTask *)p;
+    avk::pairs::pair_worker(*t->args, *t->pa, t->part);
+}
 void lane_kernel_main(void *p, int lane) {
     LaneTask *t = (LaneTask *)p;
     uint32_t ok = 0, err = 0;
@@ -193,6 +202,8 @@ void lane_main(void *p, int /*lane*/) {
 
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
  * device functions, the workgroup-level plumbing (histogram, scans, scatter) as plain loops */
+uint64_t g_last_pair_regions = 0; /* emu_last_pair_regions: regions of the last emulated call that went through the lookup of avk_pairs.inl */
+int g_lane_pairs = 1; /* emu_set_lane_pairs: context option lane_pairs (regions with the same SNV on both sides are looked up, avk_pairs.inl) */
 uint32_t g_stripe_w = 0; /* emu_set_stripe: claim width the heads of the lane classes are dealt out over (context option lane_stripe; 0 = sorted order) */
 int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
 namespace dpk = avk::dp;
@@ -306,6 +317,7 @@ dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_by
     o.class_c_nodes_x2 = getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u;
     o.lane_min_regions = lane_min_regions, o.lane_max_calls = AVK_FAST_MAXV, o.lane_min_batch = lane_min_batch, o.lane_max_est = lane_max_est;
     o.stripe_w = g_stripe_w;
+    o.lane_pairs = g_lane_pairs ? 1u : 0u, o.pad_ = 0;
     return o;
 }
 
@@ -344,7 +356,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                         !(lds2_bytes > 0 && lds2_overflow_pass) && ws_bytes > 0);
         err = dpr.err;
     } else
-        rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err);
+        rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err, 0, 15, g_lane_pairs != 0);
     if (rc) {
         fprintf(stderr, "emu pack error: %s\n", err.c_str());
         return rc;
@@ -521,6 +533,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     (void)fast_list;
     const uint32_t n_fast = use_fast ? plan.n_fast_total : 0u;
     g_lane_solved = 0;
+    g_last_pair_regions = 0;
     if (use_fast) {
         uint64_t word_base[AVK_FAST_CLASSES];
         uint32_t n_tiles[AVK_FAST_CLASSES];
@@ -536,7 +549,58 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         f.overflow_count = counters + 1024 + 32;
         for (int fc = AVK_FAST_CLASSES - 1; fc >= 0; --fc) {
             if (!n_tiles[fc]) continue;
-            const AvkFastClass &cl = AVK_FAST_CLASS[fc];
+            if (fc == AVK_FAST_PAIR && mode == 0 && g_lane_pairs) { /* run_internal: the table (ensure_pair_table), then the lookups */
+                namespace pr = avk::pairs;
+                g_last_pair_regions = plan.n_fast[fc];
+                static pr::PairTable tab; /* (one emulated call at a time fills and reads it) */
+                memset(&tab, 0xFF, sizeof(tab));
+                std::vector<uint32_t> aux(896 + 2 * AVK_TALLY_STRIDE, 0);
+                pr::pair_probe_records(aux.data(), aux.data() + 768);
+                for (uint32_t k = 0; k <= pr::N_SIG; ++k) aux[792 + k] = 2 * k;
+                AvkKernelArgs pf;
+                memset(&pf, 0, sizeof(pf));
+                pf.ref_2bit = aux.data() + 768, pf.ref_exc = aux.data() + 784;
+                pf.n_regions = pr::N_SIG, pf.max_branch_factor = cfg->max_branch_factor;
+                pf.region_out = &tab.region[0][0], pf.var_out = &tab.var[0][0], pf.group_metrics = &tab.gm[0][0];
+                pf.bp_off = aux.data() + 792, pf.bp_out = &tab.bp[0][0];
+                pf.tally = (uint64_t *)(aux.data() + 896);
+                pf.overflow_list = aux.data() + 816, pf.overflow_count = aux.data() + 813;
+                avk::lane::LaneArgs pla;
+                memset(&pla, 0, sizeof(pla));
+                pla.recs = aux.data(), pla.rec_words = AVK_FAST_WORDS_OF(1), pla.n_tiles = 1, pla.tile_counter = aux.data() + 812;
+                pla.W = AVK_FAST_CLASS[0].W, pla.nm = 2, pla.ed_max = AVK_FAST_CLASS[0].ed_max, pla.qcap = AVK_FAST_CLASS[0].qcap, pla.lanes_log2 = 6, pla.max_nodes = 250;
+                {
+                    avk_emu::Wave w;
+                    w.stack_bytes = 256 * 1024;
+                    std::vector<char> stacks(64 * w.stack_bytes + 64);
+                    w.stacks = stacks.data();
+                    std::vector<uint32_t> lds(((size_t)avk::lane::lane_rows(pla.W, pla.nm, pla.ed_max, pla.qcap) << 6) + 64, 0xA5A5A5A5u), tl(288, 0);
+                    LaneTask t;
+                    t.args = &pf, t.la = &pla, t.wave_id = 0, t.lds = lds.data(), t.tally = tl.data();
+                    avk_emu::run_wave(&w, lane_kernel_main, &t);
+                }
+                pr::PairArgs pa;
+                pa.recs = fast.data() + word_base[fc], pa.n_tiles = n_tiles[fc], pa.gen_base = plan.fast_base[fc], pa.tab = &tab, pa.tile_counter = counters + 1220 + fc;
+                const int nthr = threads < 1 ? 1 : threads;
+                std::vector<uint64_t> sums((size_t)nthr * AVK_TALLY_STRIDE, 0);
+                auto worker = [&](int tid) {
+                    avk_emu::Wave w;
+                    w.stack_bytes = 256 * 1024;
+                    std::vector<char> stacks(64 * w.stack_bytes + 64);
+                    w.stacks = stacks.data();
+                    PairTask t;
+                    t.args = &f, t.pa = &pa, t.part = sums.data() + (size_t)tid * AVK_TALLY_STRIDE;
+                    avk_emu::run_wave(&w, pair_kernel_main, &t);
+                };
+                std::vector<std::thread> ts;
+                for (int i = 0; i < nthr; ++i) ts.emplace_back(worker, i);
+                for (auto &t : ts) t.join();
+                for (int i = 0; i < nthr; ++i)
+                    for (int k = 0; k < AVK_TALLY_STRIDE; ++k) partials[k] += sums[(size_t)i * AVK_TALLY_STRIDE + k];
+                continue;
+            }
+            /* (the looked-up class in merge mode or with the option off: its records are those of a one-call class) */
+            const AvkFastClass &cl = fc == AVK_FAST_PAIR ? AVK_FAST_CLASS[1] : AVK_FAST_CLASS[fc];
             avk::lane::LaneArgs la;
             la.recs = fast.data() + word_base[fc];
             la.rec_words = AVK_FAST_WORDS_OF(cl.maxv);
@@ -886,6 +950,8 @@ int emu_merge_batch(const avk_multi_batch *mb, const uint8_t *const *refs, const
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_stripe(uint32_t w) { g_stripe_w = w; }
+void emu_set_lane_pairs(int on) { g_lane_pairs = on; }
+uint64_t emu_last_pair_regions() { return g_last_pair_regions; }
 
 /* The device-side packer against the host-side one on the same batch: every region record, every blob, the plan, the work order and the fast
  * records must be identical (the blob arena may be laid out differently: blobs are compared by content).  Returns 0, or 1 with the first
@@ -908,7 +974,7 @@ int emu_devpack_compare(const avk_region_batch *batch, const uint64_t *ref_lens,
     for (uint64_t r = 0; r < n; ++r) seq_off[r] = seq_total, seq_total += 5ull * seq_stride[r];
     avk::PackedBatch pb;
     std::string err;
-    const int rc_h = avk::pack_batch(batch, base, lens, seq_off.data(), seq_stride.data(), &pb, &err, 0, lane_max_est);
+    const int rc_h = avk::pack_batch(batch, base, lens, seq_off.data(), seq_stride.data(), &pb, &err, 0, lane_max_est, g_lane_pairs != 0);
     const uint64_t lds_bytes = 10 * 1024, lds2_bytes = 40 * 1024;
     DpResult R;
     const int rc_d = dp_run(batch, base, lens, dp_opts_of(lds_bytes, 48, lds2_bytes, 48, solo_min_variants, pairs_mode != 0, lane_min_regions, lane_min_batch, lane_max_est), pairs_mode != 0, &R);
