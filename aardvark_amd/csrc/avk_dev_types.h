@@ -131,6 +131,15 @@ AVK_TYPES_HD uint32_t avk_head_slots(uint32_t maxv, uint32_t n_fast, uint32_t n_
     return (w && w < 64u && maxv <= 2u && head_tiles > 0 && head_tiles < tiles) ? head_tiles * 64u : 0u;
 }
 
+/* Regions with this many unphased heterozygous calls (both sides counted) are big phasing searches whatever their size: every such call doubles the
+ * orientations the search keeps alive (query_optimizer.rs:269-293), six of them already mean more nodes than a lane's queue ids or a 40 KB LDS slice
+ * hold.  Both packers put them into class C (solved from the start of the step on a wave and an HBM slice of their own) and keep them out of the lanes'
+ * three-call class — they used to be tried there or in an LDS slice first and started over late in the step, on its critical path. */
+#define AVK_HET_SEARCH_MIN 6
+/* three-call lane class: regions with at least this many unphased heterozygous calls lead the class (cost key 0x10) — nearly every region the class hands
+ * back for its node cap is one of them, and the launch for handed-back regions starts behind that head, beside the rest of the class */
+#define AVK_HET_HEAD_MIN 4
+
 /* capacities of one workspace tier */
 struct AvkTier {
     uint64_t ws_bytes; /* bytes of workspace per wave in this tier */

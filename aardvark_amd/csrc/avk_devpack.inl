@@ -64,7 +64,7 @@ struct DpOpts {
     u64 tier0_bytes, tier1_bytes;
     u32 tier0_ed_cap, tier1_ed_cap;
     u32 solo_min_variants, max_branch, class_c_nodes_x2, lane_max_calls, lane_max_est;
-    u32 lane_pairs, pad_; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
+    u32 lane_pairs, split_three; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
     u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
     u64 lane_min_batch;
@@ -439,7 +439,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     ri.ref_off = pre ? 0ull : in.contig_base[c] + start;
     u64 alle = 0, g0 = 0, g1 = 0, ed_sum = 0;
     i64 delta_t = 0, delta_q = 0;
-    u32 types = 0, zflags = 0;
+    u32 types = 0, zflags = 0, nhet_u = 0;
     bool bad_zyg = false, bad_allele = false;
     for (int side = 0; side < 2; ++side) {
         const u64 off = side == 0 ? toff : qoff;
@@ -461,6 +461,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
             if (zy == AVK_ZYG_UNKNOWN || zy == AVK_ZYG_HOM_REF) bad_zyg = true;
             if (zy == AVK_ZYG_UNKNOWN) zflags |= 1u;
             if (zy == AVK_ZYG_HOM_REF) zflags |= 2u;
+            nhet_u += zy == AVK_ZYG_UNPHASED_HET ? 1u : 0u;
             {
                 const i64 w = zy == AVK_ZYG_HOM_ALT ? 2 : ((zy >= AVK_ZYG_UNPHASED_HET && zy <= AVK_ZYG_PHASED_HET10) ? 1 : 0);
                 (side == 0 ? delta_t : delta_q) += ((i64)l1 - (i64)l0) * w;
@@ -519,12 +520,13 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                     fast_class = (u32)cl + 1u;
                     fast_key = dp_cost_key(calls, tc, qc);
                     if ((fast_key >> 4) > a.opt.lane_max_est) fast_class = 0;
-                    if (maxv > 2) fast_key = 0; /* the three-call class keeps the caller's order (avk_pack.h) */
+                    if (maxv > 2) fast_key = a.opt.split_three && nhet_u >= AVK_HET_HEAD_MIN ? 0x10u : 0u; /* the three-call class keeps the caller's order (avk_pack.h); option lane_split_three: likely hand-backs first */
+                    if (nhet_u >= AVK_HET_SEARCH_MIN) fast_class = 0; /* a big phasing search (avk_dev_types.h) */
                     break;
                 }
             }
             /* the same SNV on both sides: looked up, not searched (avk_pairs.inl) */
-            if (fast_class && a.opt.lane_pairs &&
+            if (fast_class && a.opt.lane_pairs && !in.pairs_mode && /* (merge batches are solved in mode 1: nothing to look up) */
                 pairs::pair_is_candidate(tc, qc, calls[0].pos, calls[AVK_FAST_MAXV].pos, calls[0].a0, calls[0].a1, calls[AVK_FAST_MAXV].a0, calls[AVK_FAST_MAXV].a1, calls[0].type,
                                          calls[AVK_FAST_MAXV].type, calls[0].zyg, calls[AVK_FAST_MAXV].zyg, calls[0].alt_ed, calls[AVK_FAST_MAXV].alt_ed, calls[0].raw,
                                          calls[AVK_FAST_MAXV].raw, calls[0].lo, calls[AVK_FAST_MAXV].lo)) {
@@ -545,7 +547,8 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     u32 cls = 2;
     const bool failed = (ri.pre_status & 0xFFFFu) != 0;
     if (!failed && N != 0 && a.opt.solo_min_variants != 0) {
-        if (a.opt.tier1_bytes && dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier1_ed_cap, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch) > a.opt.tier1_bytes)
+        if (a.opt.tier1_bytes && (nhet_u >= AVK_HET_SEARCH_MIN ||
+                                  dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier1_ed_cap, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch) > a.opt.tier1_bytes))
         {
             cls = 0;
             /* how large an HBM slice the region is predicted to want (no edit-distance cap there): the host sizes the per-wave slices of the batch's
@@ -582,7 +585,7 @@ AVK_DEV void dp_lane_switch(const DpArgs &a) {
         have_all += on[fc] ? h : 0;
     }
     if (a.opt.lane_min_regions != 0 && have_all < a.opt.lane_min_batch)
-        for (int fc = 0; fc < AVK_FAST_GENERIC; ++fc) on[fc] = 0; /* (the looked-up class has no long tiles: it stays) */
+        for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) on[fc] = 0;
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) a.st->lane_on[fc] = on[fc];
 }
 

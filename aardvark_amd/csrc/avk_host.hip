@@ -297,6 +297,8 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
+    int64_t lane_split_three = 0;                     /* 1: the three-call class as two launches: likely hand-backs (AVK_HET_HEAD_MIN) first, their launch beside the rest.  Measured WORSE (3.95 ->
+                                                         4.9 ms per whole-genome step): the class lasts as long as its slowest claims, and the head is all of them — 2.3 ms for a third of the class */
     int64_t lane_pairs = 1;                           /* regions with the same SNV on both sides are looked up in a table the solver fills (avk_pairs.inl); 0: they stay in the one-call classes */
     avk::pairs::PairTable *d_pair_tab = nullptr;      /* the table, made for max_branch_factor pair_tab_mbf */
     uint32_t *d_pair_aux = nullptr;                   /* probe records, probe reference and the scratch outputs of the probe launch */
@@ -309,7 +311,7 @@ struct avk_ctx {
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
     int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
-    int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
+    int64_t hbm_solo_blocks = 512;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
@@ -330,7 +332,7 @@ struct avk_ctx {
     hipStream_t lane_stream3 = nullptr; /* the three-call class: long tiles, few of them, beside everything else */
     hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
-    hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr;
+    hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr, ev_lane_head3 = nullptr;
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -505,6 +507,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_lane_join4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_early, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_head3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
@@ -556,6 +559,7 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
     if (ctx->ev_lane_ready4) (void)hipEventDestroy(ctx->ev_lane_ready4);
     if (ctx->ev_lane_early) (void)hipEventDestroy(ctx->ev_lane_early);
+    if (ctx->ev_lane_head3) (void)hipEventDestroy(ctx->ev_lane_head3);
     if (ctx->lane_stream4) (void)hipStreamDestroy(ctx->lane_stream4);
     if (ctx->lane_stream3) (void)hipStreamDestroy(ctx->lane_stream3);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
@@ -672,6 +676,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
+    } else if (n == "lane_split_three") {
+        ctx->lane_split_three = value ? 1 : 0;
     } else if (n == "lane_pairs") {
         ctx->lane_pairs = value ? 1 : 0;
     } else if (n == "pair_blocks_per_cu") {
@@ -881,7 +887,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     }
     db->seq_total = seq_total;
     std::string err;
-    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0);
+    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0 && !pairs_mode, ctx->lane_split_three != 0);
     if (rc) {
         delete db;
         return fail(ctx, rc, "%s", err.c_str());
@@ -1126,7 +1132,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     uint32_t hbm_blocks = (uint32_t)ctx->n_cus * 3u;
     if (hbm_blocks > blocks) hbm_blocks = blocks;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
-    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128);
+    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 512);
     uint32_t hbm_early_max = (uint32_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64); /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
     /* the per-wave slice: the option, or what the packer's prediction asks for (device-packed batches of large windows: upload_device_packed); large
      * slices mean fewer waves per launch (option ws_budget_bytes) and more of the shared big slices for what still overflows */
@@ -1290,7 +1296,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (n_c) {
                 hbm_solo = (n_c + 3) / 4;
                 if (hbm_solo > hbm_solo_max) hbm_solo = hbm_solo_max;
-                if (hbm_solo > blocks / 8) hbm_solo = blocks / 8;
             }
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
@@ -1432,7 +1437,30 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         AvkKernelArgs f3 = f;
                         f3.overflow_list = lists[3];
                         f3.overflow_count = db->d_counters + 1104;
-                        hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f3, la);
+                        /* The regions that are likely to come back (AVK_HET_HEAD_MIN: the packers put them first) are a launch of their own; the launch
+                         * for what they hand back starts behind it on another stream, BESIDE the rest of the class — it used to follow the whole class,
+                         * 1.1 ms at the very end of the step.  What the rest hands back (rare) joins the other classes' list. */
+                        const uint32_t head3 = (db->plan.n_fast_heavy[fc] + 63u) / 64u;
+                        const bool split3 = ctx->lane_split_three && head3 > 0 && head3 < la.n_tiles;
+                        hipStream_t es = lstream[li]; /* where the launch for the handed-back regions goes */
+                        if (split3) {
+                            avk::lane::LaneArgs hd = la;
+                            hd.n_tiles = head3;
+                            hd.tile_counter = db->d_counters + 1230 + fc;
+                            uint32_t hgrid = 0;
+                            const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
+                            hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, lstream[li], f3, hd);
+                            AVK_HIP(ctx, hipGetLastError());
+                            AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_head3, lstream[li]));
+                            es = lstream[3];
+                            AVK_HIP(ctx, hipStreamWaitEvent(es, ctx->ev_lane_head3, 0));
+                            la.recs += (size_t)head3 * la.rec_words * 64u;
+                            la.n_tiles -= head3;
+                            la.gen_base += head3 * 64u;
+                            if (grid > la.n_tiles * (64u >> la.lanes_log2)) grid = la.n_tiles * (64u >> la.lanes_log2);
+                            hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f, la);
+                        } else
+                            hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f3, la);
                         AVK_HIP(ctx, hipGetLastError());
                         /* the launch for what ALL lanes hand back waits for the lane launches only, not for the launch behind this class */
                         AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
@@ -1460,9 +1488,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         e.big_slots = big_slots;
                         const uint32_t eb = hbm_blocks < hbm_early_max ? hbm_blocks : hbm_early_max;
                         e.n_waves = eb * waves_per_block;
-                        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), 0, lstream[li], e);
+                        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), 0, es, e);
                         AVK_HIP(ctx, hipGetLastError());
-                        AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, lstream[li])); /* the caller's stream waits for this one at the end */
+                        AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, es)); /* the caller's stream waits for this one at the end */
                         early_used = true;
                         continue;
                     }
@@ -1504,9 +1532,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 }
             }
             /* every workgroup of the three launches is resident at once */
-            uint32_t bulk = blocks - solo - 2 * hbm_solo;
+            uint32_t bulk = blocks > solo + 2 * hbm_solo + blocks / 4 ? blocks - solo - 2 * hbm_solo : blocks / 4; /* (a large class C launch: the bulk keeps a quarter of its workgroups) */
+            if (bulk < 1) bulk = 1;
+            if (bulk > blocks) bulk = blocks;
             if (ctx->bulk_full_grid) bulk = blocks;
-            a.n_waves = (blocks - solo - 2 * hbm_solo) * waves_per_block;
+            a.n_waves = bulk * waves_per_block;
             const uint64_t slice0 = a.tier[0].ws_bytes;
             if (ctx->lds_bytes_per_wave >= 1024) { /* slices shrink to make room for the workgroup's tail */
                 a.tier[0].ws_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave);

@@ -93,6 +93,7 @@ struct PackedBatch {
     std::vector<uint8_t> alleles;        /* host-side only */
     PodVec<uint64_t> dev2host; /* device variant index -> caller variant index */
     std::vector<uint8_t> zyg_flags; /* per region: bit 0 an Unknown zygosity, bit 1 a HomozygousReference one */
+    std::vector<uint8_t> nhet_u;    /* per region: unphased heterozygous calls, both sides (AVK_HET_SEARCH_MIN) */
     std::vector<int64_t> delta_t, delta_q; /* variant_delta_length per side (merge_solver.rs:211-223) */
     std::vector<uint8_t> fast_class;       /* per region: 0, or 1 + index into AVK_FAST_CLASS (eligible for the lane-per-region kernel) */
     std::vector<uint8_t> fast_key;         /* per region of a fast class: fast_cost_key (tiles hold regions of one cost) */
@@ -171,7 +172,7 @@ inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *
  * independent once the offsets are known). */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
                       const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0, uint32_t lane_max_est = 15,
-                      bool lane_pairs = true) {
+                      bool lane_pairs = true, bool split_three = false) {
     const uint64_t n = b->n_regions;
     if (n > 0x7FFFFFFFull || b->n_variants > 0x7FFFFFFFull) {
         *err = "batch too large (more than 2^31 regions or variants); split it";
@@ -179,6 +180,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
     }
     out->regions.resize(n);
     out->zyg_flags.assign(n, 0);
+    out->nhet_u.assign(n, 0);
     out->delta_t.assign(n, 0);
     out->delta_q.assign(n, 0);
     out->fast_class.assign(n, 0);
@@ -306,6 +308,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                     if (zy == AVK_ZYG_UNKNOWN || zy == AVK_ZYG_HOM_REF) bad_zyg = true;
                     if (zy == AVK_ZYG_UNKNOWN) out->zyg_flags[r] |= 1;
                     if (zy == AVK_ZYG_HOM_REF) out->zyg_flags[r] |= 2;
+                    if (zy == AVK_ZYG_UNPHASED_HET && out->nhet_u[r] < 255) out->nhet_u[r] += 1;
                     {
                         const int64_t w = zy == AVK_ZYG_HOM_ALT ? 2 : ((zy >= AVK_ZYG_UNPHASED_HET && zy <= AVK_ZYG_PHASED_HET10) ? 1 : 0);
                         (side == 0 ? out->delta_t[r] : out->delta_q[r]) += ((int64_t)l1 - (int64_t)l0) * w;
@@ -410,7 +413,8 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                         /* The three-call class keeps the caller's order: its expensive regions are large searches, which the key does not
                          * see, and lanes that diverge do not run side by side — 16 expensive regions in one tile take 16 times as long as
                          * one, and the launch lasts as long as that tile (measured: 3.1 ms in caller order, 6.2 ms sorted). */
-                        if (fc.maxv > 2) out->fast_key[r] = 0;
+                        if (fc.maxv > 2) out->fast_key[r] = split_three && out->nhet_u[r] >= AVK_HET_HEAD_MIN ? 0x10 : 0; /* (option lane_split_three: the likely hand-backs first, AVK_HET_HEAD_MIN) */
+                        if (out->nhet_u[r] >= AVK_HET_SEARCH_MIN) out->fast_class[r] = 0; /* a big phasing search (avk_dev_types.h) */
                         break;
                     }
                 }
@@ -505,7 +509,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         uint64_t have_all = 0;
         for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) have_all += lane_on[fc] ? have[fc] : 0;
         if (lane_min_regions != 0 && have_all < lane_min_batch)
-            for (int fc = 0; fc < AVK_FAST_GENERIC; ++fc) lane_on[fc] = false; /* (the looked-up class has no long tiles: it stays) */
+            for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lane_on[fc] = false;
     }
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
@@ -532,7 +536,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         }
         if ((dr.pre_status & 0xFFFFu) || N == 0 || solo_min_variants == 0) continue;
         const uint64_t alle = dr.alle_bytes, grow = dr.grow;
-        if (tier1_bytes && need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes) {
+        if (tier1_bytes && ((!pb.nhet_u.empty() && pb.nhet_u[r] >= AVK_HET_SEARCH_MIN) || need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes)) {
             cls[r] = 0;
             plan.n_hbm += 1;
         } else if (N >= solo_min_variants || need(dr, N, alle, grow, tier0_ed_cap, 2 * N + 1) > tier0_bytes) {

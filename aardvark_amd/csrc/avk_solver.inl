@@ -1995,6 +1995,12 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
             u64 *pc = a.tally + (u64)((wave_id >> 2) % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5;
             for (int k = 0; k < 6; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
             avk_atomic_add_u64_global(pc + 6, avk_clock() - t_region0);
+            if (a.group_metrics) /* profiling builds: searchA, searchB, metrics_setup, basepair ticks / 16 of this region in words -3 .. -6 (c.tphase is reset per region below) */
+                for (int k = 1; k <= 4; ++k) a.group_metrics[(u64)orig * AVK_N_GROUPS * AVK_N_FIELDS + AVK_N_GROUPS * AVK_N_FIELDS - 2 - k] = (u32)(c.tphase[k] >> 4);
+            if (a.group_metrics) { /* profiling builds: the region's own ticks and the tier that finished it in the last two words of its metric block (group 12 is never used) */
+                a.group_metrics[(u64)orig * AVK_N_GROUPS * AVK_N_FIELDS + AVK_N_GROUPS * AVK_N_FIELDS - 1] = (u32)((avk_clock() - t_region0) >> 4);
+                a.group_metrics[(u64)orig * AVK_N_GROUPS * AVK_N_FIELDS + AVK_N_GROUPS * AVK_N_FIELDS - 2] = (1u + a.pass_tier) | (a.high_priority ? 0x10u : 0u) | (a.work_list ? 0x20u : 0u) | (LAZY ? 0x40u : 0u) | (a.extra_n ? 0x80u : 0u);
+            }
             avk_atomic_add_u64_global(pc + 7, 1);
             for (int k = 8; k < 16; ++k) avk_atomic_add_u64_global(pc + k, c.tphase[k]);
         }

@@ -317,7 +317,7 @@ dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_by
     o.class_c_nodes_x2 = getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u;
     o.lane_min_regions = lane_min_regions, o.lane_max_calls = AVK_FAST_MAXV, o.lane_min_batch = lane_min_batch, o.lane_max_est = lane_max_est;
     o.stripe_w = g_stripe_w;
-    o.lane_pairs = g_lane_pairs ? 1u : 0u, o.pad_ = 0;
+    o.lane_pairs = g_lane_pairs ? 1u : 0u, o.split_three = 0;
     return o;
 }
 
@@ -356,7 +356,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                         !(lds2_bytes > 0 && lds2_overflow_pass) && ws_bytes > 0);
         err = dpr.err;
     } else
-        rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err, 0, 15, g_lane_pairs != 0);
+        rc = avk::pack_batch(batch, base, lens, want_seq ? out->seq_off : nullptr, want_seq ? out->seq_stride : nullptr, &pb, &err, 0, 15, g_lane_pairs != 0 && mode == 0);
     if (rc) {
         fprintf(stderr, "emu pack error: %s\n", err.c_str());
         return rc;
