@@ -974,7 +974,7 @@ int emu_devpack_compare(const avk_region_batch *batch, const uint64_t *ref_lens,
     for (uint64_t r = 0; r < n; ++r) seq_off[r] = seq_total, seq_total += 5ull * seq_stride[r];
     avk::PackedBatch pb;
     std::string err;
-    const int rc_h = avk::pack_batch(batch, base, lens, seq_off.data(), seq_stride.data(), &pb, &err, 0, lane_max_est, g_lane_pairs != 0);
+    const int rc_h = avk::pack_batch(batch, base, lens, seq_off.data(), seq_stride.data(), &pb, &err, 0, lane_max_est, g_lane_pairs != 0 && !pairs_mode);
     const uint64_t lds_bytes = 10 * 1024, lds2_bytes = 40 * 1024;
     DpResult R;
     const int rc_d = dp_run(batch, base, lens, dp_opts_of(lds_bytes, 48, lds2_bytes, 48, solo_min_variants, pairs_mode != 0, lane_min_regions, lane_min_batch, lane_max_est), pairs_mode != 0, &R);
