@@ -64,6 +64,7 @@ struct DpOpts {
     u64 tier0_bytes, tier1_bytes;
     u32 tier0_ed_cap, tier1_ed_cap;
     u32 solo_min_variants, max_branch, class_c_nodes_x2, lane_max_calls, lane_max_est;
+    u32 head_est, pad1_; /* regions with at least this many estimated edits form the head of their lane class (1..15) */
     u32 lane_pairs, split_three; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
     u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
@@ -624,7 +625,7 @@ AVK_DEV void dp_bucket_bases(const DpArgs &a) {
         const u32 seg = 3u + (AVK_FAST_CLASSES - 1 - fc);
         s.fast_base[fc] = s.base[256 * seg];
         s.n_fast[fc] = s.base[256 * (seg + 1)] - s.base[256 * seg];
-        s.n_fast_heavy[fc] = s.base[256 * seg + 240] - s.base[256 * seg]; /* cost key >> 4 != 0 <=> sort key below 240 */
+        s.n_fast_heavy[fc] = s.base[256 * seg + 256 - 16 * (a.opt.head_est ? a.opt.head_est : 1u)] - s.base[256 * seg]; /* estimated edits (cost key >> 4) >= head_est <=> sort key below 256 - 16 head_est */
         s.head_slots[fc] = avk_head_slots(AVK_FAST_CLASS[fc].maxv, s.n_fast[fc], s.n_fast_heavy[fc], a.opt.stripe_w);
         s.n_fast_total += s.n_fast[fc];
         s.tile_first[fc] = tiles;

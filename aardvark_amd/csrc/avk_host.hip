@@ -297,6 +297,8 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
+    int64_t early_lds = 0;                            /* 1: what the three-call lane class hands back goes through the LDS tier first (run_internal) */
+    int64_t lane_head_est = 1;                        /* regions with at least this many estimated edits (fast_cost_key) form the narrow-tiled head of their lane class */
     int64_t lane_split_three = 0;                     /* 1: the three-call class as two launches: likely hand-backs (AVK_HET_HEAD_MIN) first, their launch beside the rest.  Measured WORSE (3.95 ->
                                                          4.9 ms per whole-genome step): the class lasts as long as its slowest claims, and the head is all of them — 2.3 ms for a third of the class */
     int64_t lane_pairs = 1;                           /* regions with the same SNV on both sides are looked up in a table the solver fills (avk_pairs.inl); 0: they stay in the one-call classes */
@@ -311,7 +313,7 @@ struct avk_ctx {
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
     int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
-    int64_t hbm_solo_blocks = 512;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
+    int64_t hbm_solo_blocks = 256;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
@@ -676,6 +678,11 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
+    } else if (n == "early_lds") {
+        ctx->early_lds = value ? 1 : 0;
+    } else if (n == "lane_head_est") {
+        if (value < 1 || value > 15) return fail(ctx, AVK_E_ARG, "lane_head_est must be 1..15");
+        ctx->lane_head_est = value;
     } else if (n == "lane_split_three") {
         ctx->lane_split_three = value ? 1 : 0;
     } else if (n == "lane_pairs") {
@@ -950,7 +957,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
                                     ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls,
-                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u);
+                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u, (uint32_t)ctx->lane_head_est);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
@@ -1132,7 +1139,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     uint32_t hbm_blocks = (uint32_t)ctx->n_cus * 3u;
     if (hbm_blocks > blocks) hbm_blocks = blocks;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
-    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 512);
+    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 256);
     uint32_t hbm_early_max = (uint32_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64); /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
     /* the per-wave slice: the option, or what the packer's prediction asks for (device-packed batches of large windows: upload_device_packed); large
      * slices mean fewer waves per launch (option ws_budget_bytes) and more of the shared big slices for what still overflows */
@@ -1486,9 +1493,24 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         e.big_ws = ctx->d_big;
                         e.big_busy = db->d_counters + 1088;
                         e.big_slots = big_slots;
-                        const uint32_t eb = hbm_blocks < hbm_early_max ? hbm_blocks : hbm_early_max;
+                        uint32_t eb = hbm_blocks < hbm_early_max ? hbm_blocks : hbm_early_max;
+                        if (ctx->early_lds && ctx->lds_bytes_per_wave >= 1024) {
+                            /* option early_lds: the regions the three-call class hands back are small windows with large searches — the LDS tier with its
+                             * in-workgroup escalation first (as the launch for the other classes' hand-backs), the HBM launch at the end for what overflows */
+                            e.pass_tier = 0;
+                            e.hbm_ws = nullptr;
+                            e.tier[0].ws_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave);
+                            e.esc_bytes = (uint32_t)(waves_per_block * e.tier[0].ws_bytes);
+                            e.esc_enabled = ctx->lds_escalation ? 1u : 0u;
+                            e.overflow_list = lists[1];
+                            e.overflow_count = db->d_counters + 1024 + 16;
+                            if (eb > (uint32_t)ctx->n_cus * 2u) eb = (uint32_t)ctx->n_cus * 2u;
+                            e.n_waves = eb * waves_per_block;
+                            hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(eb), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, es, e);
+                        } else {
                         e.n_waves = eb * waves_per_block;
                         hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), 0, es, e);
+                        }
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, es)); /* the caller's stream waits for this one at the end */
                         early_used = true;

@@ -489,7 +489,8 @@ struct WorkPlan {
  * an unused class are planned like any other region.  0xFFFFFFFF = no lane classes at all. */
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
                                 uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12,
-                                uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV, uint64_t lane_min_batch = 0, uint32_t stripe_w = 0) {
+                                uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV, uint64_t lane_min_batch = 0, uint32_t stripe_w = 0,
+                                uint32_t head_est = 1) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
@@ -531,7 +532,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
             const uint32_t fc = pb.fast_class[r] - 1u;
             cls[r] = (uint8_t)(3 + (AVK_FAST_CLASSES - 1 - fc));
             plan.n_fast[fc] += 1;
-            plan.n_fast_heavy[fc] += (pb.fast_key[r] >> 4) != 0;
+            plan.n_fast_heavy[fc] += (uint32_t)(pb.fast_key[r] >> 4) >= (head_est ? head_est : 1u);
             continue;
         }
         if ((dr.pre_status & 0xFFFFu) || N == 0 || solo_min_variants == 0) continue;
