@@ -319,8 +319,9 @@ struct avk_ctx {
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
     int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
-    int64_t hbm_solo_blocks = 256;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
+    int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
+    int64_t lane_waves_three = 0;                     /* > 0: at most this many one-wave workgroups of the three-call class per CU (its waves take 17 KB of LDS each) */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     bool lane_attr_set = false;
     uint64_t last_lane_solved = 0;
@@ -716,6 +717,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
+    } else if (n == "lane_waves_three") {
+        if (value < 0 || value > 32) return fail(ctx, AVK_E_ARG, "lane_waves_three must be 0..32");
+        ctx->lane_waves_three = value;
     } else if (n == "lane_waves_per_cu") {
         if (value < 1 || value > 32) return fail(ctx, AVK_E_ARG, "lane_waves_per_cu must be 1..32");
         ctx->lane_waves_per_cu = value;
@@ -1039,7 +1043,8 @@ static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs
     const size_t lds = (size_t)rows * (4u << la.lanes_log2) + 288 * 4;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     if (per_cu < 1) return 0;
-    const uint32_t cap = la.lanes_log2 < 4 ? 32u : (uint32_t)(ctx->lane_waves_per_cu > 0 ? ctx->lane_waves_per_cu : 12); /* very narrow tiles: every wave slot */
+    uint32_t cap = la.lanes_log2 < 4 ? 32u : (uint32_t)(ctx->lane_waves_per_cu > 0 ? ctx->lane_waves_per_cu : 12); /* very narrow tiles: every wave slot */
+    if (la.nm > 4 && ctx->lane_waves_three > 0) cap = (uint32_t)ctx->lane_waves_three; /* the three-call class: 17 KB per wave */
     if (per_cu > cap) per_cu = cap;
     const uint32_t claims = la.n_tiles * (64u >> la.lanes_log2);
     uint32_t g = (uint32_t)ctx->n_cus * per_cu;
@@ -1149,7 +1154,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     uint32_t hbm_blocks = (uint32_t)ctx->n_cus * 3u;
     if (hbm_blocks > blocks) hbm_blocks = blocks;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
-    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 256);
+    uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128);
     uint32_t hbm_early_max = (uint32_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64); /* workgroups of the launch behind the three-call lane class (its hand-backs), slices of their own too */
     /* the per-wave slice: the option, or what the packer's prediction asks for (device-packed batches of large windows: upload_device_packed); large
      * slices mean fewer waves per launch (option ws_budget_bytes) and more of the shared big slices for what still overflows */

@@ -1,0 +1,14 @@
+cd /root/repo
+[ -f /tmp/w100.bin ] || python tools/dump_workload.py 1.0 /tmp/w100.bin > /dev/null
+run() { printf "%-52s " "$1"; for k in 1 2 3; do timeout 120 .scratch/first_step_probe /tmp/w100.bin 50 1 25 "$1" 2>&1 | tail -1 | sed 's/.*finished \([0-9.]*\) ms later.*/\1/' | tr '\n' ' '; done; echo; }
+run "lane_kernel=1"
+run "hbm_solo_blocks=64"
+run "hbm_solo_blocks=96"
+run "hbm_solo_blocks=192"
+run "hbm_early_blocks=128"
+run "hbm_early_blocks=192"
+run "lane_node_cap=24"
+run "lane_node_cap=48"
+run "waves_per_cu=12"
+run "waves_per_cu=24"
+run "lane_kernel=1"
