@@ -170,7 +170,7 @@ struct AvkKernelArgs {
     /* work distribution */
     const uint32_t *work_list; /* NULL = records work_base .. work_base + n_work - 1; else record indices (overflow pass) */
     uint32_t work_base;
-    uint32_t hbm_stage; /* HBM launches: 1 = the launch has AVK_STAGE_BYTES of LDS per wave for the node being extended (avk_solver.inl: the stage) */
+    uint32_t pad2_;
     const uint32_t *n_work_dev; /* when set, the number of work items is read from device memory (overflow pass) */
     uint32_t *work_counter;    /* 8 claim counters, 32 words (128 B) apart, one per shard of the dynamic part of the work list */
     uint32_t n_waves;          /* persistent waves of this launch (solo waves not counted) */

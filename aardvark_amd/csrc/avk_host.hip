@@ -54,8 +54,7 @@ __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel
 /* HBM passes: regions that outgrew the LDS tiers, in the wave's private HBM slice */
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
-    avk::region_worker<false>(a, wave_id, a.hbm_stage ? avk_smem + (size_t)(threadIdx.x >> 6) * AVK_STAGE_BYTES : (unsigned char *)0);
+    avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
 /* the same two for the regions the lanes handed back: device-packed batches (avk_devpack.inl) write the region record and blob of such a region
@@ -72,8 +71,7 @@ __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel
 }
 __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm_lazy(AvkKernelArgs a) {
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
-    avk::region_worker<false, true>(a, wave_id, a.hbm_stage ? avk_smem + (size_t)(threadIdx.x >> 6) * AVK_STAGE_BYTES : (unsigned char *)0);
+    avk::region_worker<false, true>(a, wave_id, (unsigned char *)0);
 }
 
 /* Small regions, one per LANE (avk_lane.inl): a workgroup is four independent waves, each claims tiles of 64 fast records; the
@@ -299,7 +297,6 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
-    int64_t hbm_stage = 1;                            /* with implied_sequences: the HBM launches extend the popped node in 2 KB of LDS per wave (avk_solver.inl: the stage) */
     int64_t implied_sequences = 0;                    /* 1: wave-per-region kernels: regions of at most six calls per side keep no haplotype bytes in their search nodes (Ctx::implied,
                                                          avk_solver.inl): nodes a third of the size, no sequence copies.  Measured: no change of the whole-genome step (the class C launch 3.23
                                                          against 3.27 ms) — a node extension is a chain of header, front and queue round trips, not its byte copies; off by default */
@@ -685,8 +682,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
-    } else if (n == "hbm_stage") {
-        ctx->hbm_stage = value ? 1 : 0;
     } else if (n == "implied_sequences") {
         ctx->implied_sequences = value ? 1 : 0;
     } else if (n == "early_lds") {
@@ -1224,8 +1219,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.enable_exact_shortcut = cfg->enable_exact_shortcut ? 1u : 0u;
     a.mode = mode;
     a.implied_seqs = ctx->implied_sequences ? 1u : 0u;
-    a.hbm_stage = ctx->implied_sequences && ctx->hbm_stage ? 1u : 0u; /* (the stage holds nodes without haplotype bytes only) */
-    const size_t hbm_lds = a.hbm_stage ? (size_t)4 * AVK_STAGE_BYTES : 0;
     a.tier[0].ws_bytes = (uint64_t)ctx->lds_bytes_per_wave;
     a.tier[0].ed_cap = (uint32_t)ctx->lds_ed_cap;
     a.tier[1].ws_bytes = (uint64_t)ctx->lds2_bytes_per_wave;
@@ -1348,7 +1341,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 }
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->ev_fork, 0));
                 if (order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_ready2, ctx->side_stream2));
-                hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_solo), dim3(256), hbm_lds, ctx->side_stream2, s);
+                hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_solo), dim3(256), 0, ctx->side_stream2, s);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side_stream2));
                 hbm_solo_pending = true;
@@ -1527,7 +1520,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(eb), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, es, e);
                         } else {
                         e.n_waves = eb * waves_per_block;
-                        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), hbm_lds, es, e);
+                        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), 0, es, e);
                         }
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, es)); /* the caller's stream waits for this one at the end */
@@ -1626,12 +1619,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 a.extra_base = 0;
                 a.extra_n = db->plan.n_hbm;
             }
-            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_blocks), dim3(256), hbm_lds, ctx->stream, a);
+            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_blocks), dim3(256), 0, ctx->stream, a);
         } else {
             a.hbm_ws = ctx->d_big;
             a.big_slots = 0;
             a.n_waves = big_blocks * waves_per_block;
-            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), hbm_lds, ctx->stream, a);
+            hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(big_blocks), dim3(256), 0, ctx->stream, a);
         }
         AVK_HIP(ctx, hipGetLastError());
         a.extra_counter = nullptr;
@@ -1672,7 +1665,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         h.big_slots = big_slots;
         const uint32_t hb = hbm_blocks < 64 ? hbm_blocks : 64;
         h.n_waves = hb * waves_per_block;
-        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(hb), dim3(256), hbm_lds, ctx->stream, h);
+        hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(hb), dim3(256), 0, ctx->stream, h);
         AVK_HIP(ctx, hipGetLastError());
     }
     hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, db->d_partials, db->d_tally,

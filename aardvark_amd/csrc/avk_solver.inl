@@ -156,8 +156,6 @@ struct Ctx {
      * node chooses that set; a node keeps the two sets in HapHdr::masks and its lengths as before.  Nodes shrink by two sequence capacities per
      * haplotype (three quarters of a node in a window of SNVs), cloning a node copies a few hundred bytes, extending one writes no sequence. */
     bool implied;
-    u8 *stage;       /* HBM tiers: this wave's LDS area for the node being extended (AVK_STAGE_BYTES), or NULL */
-    u32 stage_bytes;
     u8 *full[2];
     u32 fstride;
     mutable u64 fvalid[2]; /* which sets have been built */
@@ -780,15 +778,14 @@ AVK_DEV void queue_reload(Ctx &c) {
 /* ------------------------------------------------------------------------------------------ */
 /* phase A — optimize_sequences (src/query_optimizer.rs:166-365)                               */
 /* ------------------------------------------------------------------------------------------ */
-AVK_DEV u32 nodeA_cost_at(const Ctx &c, const u8 *nb) {
-    const u32 *n = (const u32 *)nb;
+AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
+    const u32 *n = (const u32 *)node_at(c, idx);
     const u32 *h0 = n + NODE_HDR / 4, *h1 = (const u32 *)((const u8 *)h0 + c.hapA_bytes);
     u32 a[3], b[3];
     ldvec_u<3>(h0 + H_T_SKIP, a); /* t_skip, q_skip, ed are consecutive header words */
     ldvec_u<3>(h1 + H_T_SKIP, b);
     return a[0] + a[1] + a[2] + b[0] + b[1] + b[2];
 }
-AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) { return nodeA_cost_at(c, node_at(c, idx)); }
 
 /* ComparisonNode::extend_variant (:443-451) = both haplotypes + their DWFA updates */
 /* Node word 1 of a phasing-search node: 1 while its two haplotype records are identical (the root, and every node reached from
@@ -800,8 +797,9 @@ AVK_DEV void hap_record_copy(const Ctx &c, u8 *dst, const u8 *src) {
     copy_words((u32 *)dst, (const u32 *)src, c.hapA_bytes >> 2);
     wv_sync();
 }
-AVK_DEV int nodeA_extend_at(const Ctx &c, u8 *n, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
+AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
     AVK_TA_DECL
+    u8 *n = node_at(c, idx);
     const bool sym = ld32u((const u32 *)n + 1) != 0;
     const bool twin = sym && a1 == a2; /* the second record will equal the first */
     for (int hh = 0; hh < (twin ? 1 : 2); ++hh) {
@@ -823,20 +821,19 @@ AVK_DEV int nodeA_extend_at(const Ctx &c, u8 *n, bool is_truth, const UVar &v, u
     }
     return 0;
 }
-AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
-    return nodeA_extend_at(c, node_at(c, idx), is_truth, v, a1, a2, sync);
-}
 /* node `idx` := node `from` with its two haplotype records swapped (and no longer symmetric) */
-AVK_DEV void nodeA_mirror_at(const Ctx &c, u8 *n, const u8 *f) {
+AVK_DEV void nodeA_mirror(const Ctx &c, u32 idx, u32 from) {
+    u8 *n = node_at(c, idx);
+    const u8 *f = node_at(c, from);
     hap_record_copy(c, n + NODE_HDR, f + NODE_HDR + c.hapA_bytes);
     hap_record_copy(c, n + NODE_HDR + c.hapA_bytes, f + NODE_HDR);
     st32((u32 *)n + 1, 0);
     wv_sync();
 }
-AVK_DEV void nodeA_mirror(const Ctx &c, u32 idx, u32 from) { nodeA_mirror_at(c, node_at(c, idx), node_at(c, from)); }
 
 /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
-AVK_DEV int nodeA_finalize_at(const Ctx &c, u8 *n) {
+AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
+    u8 *n = node_at(c, idx);
     UVar none;
     none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
     const bool twin = ld32u((const u32 *)n + 1) != 0; /* identical haplotype records: finalise one, copy it (nodeA_extend) */
@@ -852,26 +849,6 @@ AVK_DEV int nodeA_finalize_at(const Ctx &c, u8 *n) {
     }
     if (twin) hap_record_copy(c, n + NODE_HDR + c.hapA_bytes, n + NODE_HDR);
     return 0;
-}
-AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) { return nodeA_finalize_at(c, node_at(c, idx)); }
-
-/* THE STAGE (HBM tiers, implied sequences).  A node extension is a chain of dependent accesses to the node's header words and wavefront — a dozen round
- * trips of a microsecond each when the node sits in HBM.  A node without haplotype bytes is a few hundred bytes, so the popped node is brought into the
- * wave's LDS area with one coalesced copy, extended there (the same code, on an LDS address), and written back with one copy; its depth travels in the
- * top byte of the queue's slot word, so nothing of the node is read before the copy.  Two areas: the parent stays in one while its first clone is made
- * in the other.  Pop order, ids, costs: untouched — only where the bytes are while they are worked on. */
-#ifndef AVK_STAGE_BYTES
-#define AVK_STAGE_BYTES 2048u
-#endif
-AVK_DEV void stage_load(const Ctx &c, u8 *dst, u32 idx) {
-    wv_sync();
-    copy_words((u32 *)dst, (const u32 *)node_at(c, idx), c.node_bytes >> 2);
-    wv_sync();
-}
-AVK_DEV void stage_store(const Ctx &c, u32 idx, const u8 *src) {
-    wv_sync();
-    copy_words((u32 *)node_at(c, idx), (const u32 *)src, c.node_bytes >> 2);
-    wv_sync();
 }
 
 /* returns the number of tied optima (their node indices are in c.optlist), RS_OVERFLOW, or -status-100 */
@@ -908,19 +885,14 @@ AVK_DEV int phaseA(Ctx &c) {
     u32 nbest = 0;
     AVK_TA_MARK(c, 8)
 
-    /* the stage (above): nodes small enough for two of them in this wave's LDS area; slot words then carry the node's depth in their top byte */
-    const bool staged = c.stage != (u8 *)0 && c.implied && 2u * c.nodeA_bytes <= c.stage_bytes && c.pool_cap < (1u << 24) && c.N < 255u;
-    u8 *const S = c.stage, *const S2 = c.stage + c.nodeA_bytes;
-
     while (c.qn > 0) {
         u64 key;
-        const u32 nslot = queue_pop(c, key);
-        const u32 ni = staged ? (nslot & 0xFFFFFFu) : nslot;
+        const u32 ni = queue_pop(c, key);
         const u32 cost = (u32)(key >> 32);
         if (cost > best_ed) break; /* :204 skips it — and, pops being in non-decreasing cost order (a child never
                                       costs less than its parent), every node still queued would be skipped too */
         const u32 *nw = (const u32 *)node_at(c, ni);
-        const u32 depth = staged ? (nslot >> 24) : ld32u(nw + NODE_HDR / 4 + H_T_NAL) + ld32u(nw + NODE_HDR / 4 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
+        const u32 depth = ld32u(nw + NODE_HDR / 4 + H_T_NAL) + ld32u(nw + NODE_HDR / 4 + H_Q_NAL); /* set_alleles of hap 1, :478-481 */
         const u32 cnt = c.regb ? wv_readlane(c.rbucket, depth) : ld32u(c.bucket + depth);
         if (cnt >= c.max_branch) { /* :222 */
             node_free(c, ni);
@@ -936,16 +908,8 @@ AVK_DEV int phaseA(Ctx &c) {
 
         AVK_TA_MARK(c, 9)
         if (depth == c.N) { /* :227-247 */
-            u32 fc;
-            if (staged) {
-                stage_load(c, S, ni);
-                if (nodeA_finalize_at(c, S)) return RS_OVERFLOW;
-                fc = nodeA_cost_at(c, S);
-                stage_store(c, ni, S);
-            } else {
-                if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
-                fc = nodeA_cost(c, ni);
-            }
+            if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
+            const u32 fc = nodeA_cost(c, ni);
             if (fc < best_ed) {
                 for (u32 k = 0; k < nbest; ++k) node_free(c, ld32u(c.optlist + k));
                 best_ed = fc;
@@ -970,45 +934,6 @@ AVK_DEV int phaseA(Ctx &c) {
         const u32 zyg = v.zyg;
         const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
 
-        if (staged) {
-            const u32 dnext = (depth + 1u) << 24;
-            stage_load(c, S, ni);
-            if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
-                const int c1 = node_alloc(c);
-                if (c1 < 0) return RS_OVERFLOW;
-                copy_words((u32 *)S2, (const u32 *)S, c.nodeA_bytes >> 2);
-                wv_sync();
-                st32((u32 *)S2, next_id);
-                wv_sync();
-                if (nodeA_extend_at(c, S2, is_truth, v, AL_REF, AL_ALT, sync)) return RS_OVERFLOW;
-                const u32 cost1 = nodeA_cost_at(c, S2);
-                stage_store(c, (u32)c1, S2);
-                if (queue_push(c, ((u64)cost1 << 32) | next_id, (u32)c1 | dnext)) return RS_OVERFLOW;
-                next_id += 1;
-                /* the popped node itself becomes the second clone */
-                const bool parent_sym = ld32u((const u32 *)S + 1) != 0;
-                st32((u32 *)S, next_id);
-                wv_sync();
-                if (parent_sym) nodeA_mirror_at(c, S, S2); /* (ALT|REF) of identical haplotypes = (REF|ALT) swapped */
-                else if (nodeA_extend_at(c, S, is_truth, v, AL_ALT, AL_REF, sync)) return RS_OVERFLOW;
-                const u32 cost2 = nodeA_cost_at(c, S);
-                stage_store(c, ni, S);
-                if (queue_push(c, ((u64)cost2 << 32) | next_id, ni | dnext)) return RS_OVERFLOW;
-                next_id += 1;
-            } else { /* :294-327: the node is moved, its id kept */
-                u32 a1 = AL_ALT, a2 = AL_ALT;
-                if (het) {
-                    a1 = zyg == AVK_ZYG_PHASED_HET01 ? AL_REF : AL_ALT;
-                    a2 = zyg == AVK_ZYG_PHASED_HET01 ? AL_ALT : AL_REF;
-                }
-                const u32 id = ld32u((const u32 *)S);
-                if (nodeA_extend_at(c, S, is_truth, v, a1, a2, sync)) return RS_OVERFLOW;
-                const u32 cost1 = nodeA_cost_at(c, S);
-                stage_store(c, ni, S);
-                if (queue_push(c, ((u64)cost1 << 32) | id, ni | dnext)) return RS_OVERFLOW;
-            }
-            continue;
-        }
         if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
             const int c1 = node_alloc(c);
             if (c1 < 0) return RS_OVERFLOW;
@@ -1943,7 +1868,6 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
     u32 n_ok = 0, n_err = 0, n_cap = 0, n_big = 0; /* n_big: finished (either way) in a tier-3 slice */
     const u32 tier = a.pass_tier;
     u8 *ws = PASS_LDS ? lds_slice : a.hbm_ws + (u64)wave_id * a.tier[tier].ws_bytes;
-    u8 *const stage_area = PASS_LDS ? (u8 *)0 : lds_slice; /* HBM launches: AVK_STAGE_BYTES of LDS per wave for the node being extended, or NULL */
     const u64 ws_bytes = a.tier[tier].ws_bytes;
     const u32 ed_cap = a.tier[tier].ed_cap;
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_work;
@@ -2033,8 +1957,6 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
             continue;
         }
         Ctx c;
-        c.stage = a.hbm_stage ? stage_area : (u8 *)0;
-        c.stage_bytes = c.stage ? (u32)AVK_STAGE_BYTES : 0u;
 #ifdef AVK_PHASE_TIMING
         for (int k = 0; k < 16; ++k) c.tphase[k] = 0;
         const u64 t_region0 = avk_clock();

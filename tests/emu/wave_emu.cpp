@@ -192,13 +192,12 @@ struct WaveTask {
     uint8_t *lds;
     uint8_t *wg_lds = nullptr; /* the workgroup's whole LDS when the in-workgroup escalation is on */
     uint32_t wave_in_wg = 0, n_wg_waves = 0;
-    uint8_t *stage = nullptr; /* HBM passes: the wave's LDS area for the node being extended (AvkKernelArgs::hbm_stage) */
 };
 
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
     if (t->lds) avk::region_worker<true, true>(*t->args, t->wave_id, t->lds); /* (the lazy instantiations: they differ from the others only when lazy_dp is set) */
-    else avk::region_worker<false, true>(*t->args, t->wave_id, t->args->hbm_stage ? t->stage : nullptr);
+    else avk::region_worker<false, true>(*t->args, t->wave_id, nullptr);
 }
 
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
@@ -397,7 +396,6 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.enable_exact_shortcut = cfg->enable_exact_shortcut;
     a.mode = mode;
     a.implied_seqs = g_implied ? 1u : 0u;
-    a.hbm_stage = g_implied ? 1u : 0u;
     if (mode == 1 && !devpack) { /* the pre-checks of avk_optimize_pairs_batch (aardvark_amd/csrc/avk_host.hip); dp_region applies them itself */
         for (uint64_t r = 0; r < batch->n_regions; ++r) {
             AvkDevRegion &dr = pb.regions[r];
@@ -457,13 +455,11 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             std::vector<char> stacks(64 * w.stack_bytes + 64);
             w.stacks = stacks.data();
             std::vector<uint8_t> ldsbuf(lds ? (solo_waves && lds2_bytes > lds ? lds2_bytes : lds) : 8);
-            std::vector<uint8_t> stagebuf(AVK_STAGE_BYTES + 64, 0xA5);
             for (;;) {
                 uint32_t wid = next.fetch_add(1);
                 if (wid >= (a.esc_bytes ? 0u : waves) + solo_waves) break;
                 const bool solo = wid < solo_waves;
                 WaveTask t{solo ? &a_solo : &a, solo ? wid : wid - solo_waves, lds ? ldsbuf.data() : nullptr};
-                t.stage = stagebuf.data();
                 avk_emu::run_wave(&w, lane_main, &t);
             }
         };
