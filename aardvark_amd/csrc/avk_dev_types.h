@@ -165,7 +165,7 @@ struct AvkKernelArgs {
     uint32_t max_branch_factor;
     uint32_t enable_exact_shortcut;
     uint32_t mode; /* 0 solve_compare_region; 1 merge pairs: optimize_sequences only, report all_opt_haps[0].is_exact_match() */
-    uint32_t implied_seqs; /* 1: regions of few calls per side keep no haplotype bytes in their search nodes (Ctx::implied, avk_solver.inl) */
+    uint32_t pad0_;
     uint32_t pass_tier;  /* workspace tier of this launch: 0 small LDS slice, 1 large LDS slice, 2 per-wave HBM slice, 3 big HBM slice */
     /* work distribution */
     const uint32_t *work_list; /* NULL = records work_base .. work_base + n_work - 1; else record indices (overflow pass) */

@@ -297,9 +297,6 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
-    int64_t implied_sequences = 0;                    /* 1: wave-per-region kernels: regions of at most six calls per side keep no haplotype bytes in their search nodes (Ctx::implied,
-                                                         avk_solver.inl): nodes a third of the size, no sequence copies.  Measured: no change of the whole-genome step (the class C launch 3.23
-                                                         against 3.27 ms) — a node extension is a chain of header, front and queue round trips, not its byte copies; off by default */
     int64_t early_lds = 0;                            /* 1: what the three-call lane class hands back goes through the LDS tier first (run_internal) */
     int64_t lane_head_est = 1;                        /* regions with at least this many estimated edits (fast_cost_key) form the narrow-tiled head of their lane class */
     int64_t lane_split_three = 0;                     /* 1: the three-call class as two launches: likely hand-backs (AVK_HET_HEAD_MIN) first, their launch beside the rest.  Measured WORSE (3.95 ->
@@ -682,8 +679,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
-    } else if (n == "implied_sequences") {
-        ctx->implied_sequences = value ? 1 : 0;
     } else if (n == "early_lds") {
         ctx->early_lds = value ? 1 : 0;
     } else if (n == "lane_head_est") {
@@ -1218,7 +1213,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut ? 1u : 0u;
     a.mode = mode;
-    a.implied_seqs = ctx->implied_sequences ? 1u : 0u;
     a.tier[0].ws_bytes = (uint64_t)ctx->lds_bytes_per_wave;
     a.tier[0].ed_cap = (uint32_t)ctx->lds_ed_cap;
     a.tier[1].ws_bytes = (uint64_t)ctx->lds2_bytes_per_wave;

@@ -90,7 +90,6 @@ struct HapHdr {
     u32 t_refpos, q_refpos, t_len, q_len, t_skip, q_skip, ed, t_nal, q_nal;
     u32 nskip; /* ALT alleles that could not be incorporated (either side); the skip DISTANCE can be 0 for REF == ALT */
     u32 d0;    /* while ed == 0 the whole wavefront is this one offset and lives here, not in wf[] */
-    u32 masks; /* implied sequences (Ctx::implied): ALT choices so far, truth side in bits 0-15, query side in bits 16-31 (bit j = the side's call j) */
 };
 
 /* local variant record in the workspace */
@@ -148,17 +147,6 @@ struct Ctx {
     u32 memo_cap;
     u32 max_branch;
     u32 best_cost; /* total cost shared by the tied optima of phase A */
-    /* IMPLIED SEQUENCES (regions of at most AVK_IMPLIED_MAXV calls per side whose tables fit the workspace): a node carries no haplotype bytes.  With the
-     * calls of a side sorted and sync points that never pass a later call, the sequence of a node's haplotype side is a PREFIX of FULL(side, ALT choices so
-     * far) — the side's calls of that set spliced into the whole window by generate_allele_sequence's rule (waffle_solver.rs:726-778), which is also
-     * HaplotypeTracker::extend_variant's (haplotype_dwfa.rs:175-212): a call that starts before the end of the previous applied one is dropped.  (The lane
-     * kernel rests on the same fact, avk_lane.inl.)  full[side] holds the 2^calls sequences of a side, `fstride` bytes apart, each built the first time a
-     * node chooses that set; a node keeps the two sets in HapHdr::masks and its lengths as before.  Nodes shrink by two sequence capacities per
-     * haplotype (three quarters of a node in a window of SNVs), cloning a node copies a few hundred bytes, extending one writes no sequence. */
-    bool implied;
-    u8 *full[2];
-    u32 fstride;
-    mutable u64 fvalid[2]; /* which sets have been built */
 #ifdef AVK_PHASE_TIMING
     u64 tphase[16];
 #endif
@@ -423,7 +411,6 @@ AVK_DEV HapHdr hap_load(const u32 *w) {
     h.q_nal = wv_uni(d.x);
     h.nskip = wv_uni(d.y);
     h.d0 = wv_uni(d.z);
-    h.masks = wv_uni(d.w);
     return h;
 }
 AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
@@ -441,7 +428,7 @@ AVK_DEV void hap_store(u32 *w, const HapHdr &h) {
         d.x = h.q_nal;
         d.y = h.nskip;
         d.z = h.d0;
-        d.w = h.masks;
+        d.w = 0;
         q[0] = a;
         q[1] = b;
         q[2] = d;
@@ -458,42 +445,6 @@ AVK_DEV void hap_init(const HapPtr &p, u32 alw) {
     }
 }
 
-#ifndef AVK_IMPLIED_MAXV
-#define AVK_IMPLIED_MAXV 6u
-#endif
-/* FULL(side, set): generate_allele_sequence (waffle_solver.rs:726-778) over the whole window for the side's calls whose bit is in `set` */
-AVK_DEV void build_full(const Ctx &c, u32 side, u32 set) {
-    u8 *out = c.full[side] + (u64)set * c.fstride;
-    const u32 v0 = side ? c.T : 0u, cnt = side ? c.Q : c.T;
-    u32 cur = 0, len = 0;
-    for (u32 k = 0; k < cnt; ++k) {
-        if (!((set >> k) & 1u)) continue;
-        const UVar v = load_var(c.vars, v0 + k);
-        if (v.rel_pos < cur) continue; /* :745-753: dropped (the node that chose it paid the skip penalty) */
-        copy_bytes(out + len, c.ref + cur, v.rel_pos - cur);
-        len += v.rel_pos - cur;
-        copy_bytes(out + len, c.alle + v.a_off + v.a0_len, v.a1_len);
-        len += v.a1_len;
-        cur = v.rel_pos + v.a0_len;
-    }
-    if (cur < c.L) copy_bytes(out + len, c.ref + cur, c.L - cur);
-    wv_sync();
-    c.fvalid[side] |= 1ull << set;
-}
-AVK_DEV void ensure_full(const Ctx &c, u32 side, u32 set) {
-    if (set != 0 && !((c.fvalid[side] >> set) & 1ull)) build_full(c, side, set);
-}
-/* the two sequences of a haplotype record: its own bytes, or (implied) the tables' entries for its two sets — set 0 is the window itself */
-AVK_DEV void hap_seqs(const Ctx &c, const HapPtr &p, const HapHdr &h, const u8 *&ts, const u8 *&qs) {
-    if (!c.implied) {
-        ts = p.tseq;
-        qs = p.qseq;
-        return;
-    }
-    const u32 mt = h.masks & 0xFFFFu, mq = h.masks >> 16;
-    ts = mt ? c.full[0] + (u64)mt * c.fstride : c.ref;
-    qs = mq ? c.full[1] + (u64)mq * c.fstride : c.ref;
-}
 /* One haplotype step = HaplotypeDWFA::extend_variant without the DWFA update (haplotype_dwfa.rs:46-62,
  * :175-227), as ONE fused copy:
  *   other side:  copy_reference(sync)                                   -> segment O
@@ -541,19 +492,6 @@ template <bool is_truth> AVK_DEV bool hap_extend_seq_t(const Ctx &c, const HapPt
     const u32 s3 = rp;
     const u32 n3 = rp < sync ? sync - rp : 0;
     if (rp < sync) rp = sync;
-    if (c.implied) { /* no bytes move: the side's set grows by this call when ALT was chosen (skipped or not, as talt does), and the table gets the set's sequence */
-        if (has_var && allele == AL_ALT) {
-            const u32 bit = (tnal - 1u) + (is_truth ? 0u : 16u);
-            h.masks |= 1u << bit;
-            ensure_full(c, is_truth ? 0u : 1u, is_truth ? (h.masks & 0xFFFFu) : (h.masks >> 16));
-        }
-        ol += n_o;
-        if (n_o) orp = sync;
-        tl += n1 + n2 + n3;
-        trp = rp;
-        if (has_var) wv_sync(); /* (the allele bit-set) */
-        return ok;
-    }
     /* everything lives in the wave's workspace: sources and destinations are 32-bit offsets from its base */
     const u32 ref_o = (u32)(c.ref - c.ws), alle_o = (u32)(c.alle - c.ws) + v.a_off + v.a0_len;
     const u32 ts_o = (u32)(ts - c.ws) + tl, os_o = (u32)(os - c.ws) + ol;
@@ -579,17 +517,15 @@ AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_tr
 /* DWFALite::update for a haplotype record (dynamic_wfa.rs:68-84).  While ed == 0 the wavefront is the single
  * offset h.d0: extend = slide it over the common part of the two sequences, 64 bases per step; only a real
  * mismatch (both sequences continue and differ) enters the general wavefront code. */
-AVK_DEV bool hap_slide_d0(const Ctx &c, const HapPtr &p, HapHdr &h) { /* returns true when either end is touched */
+AVK_DEV bool hap_slide_d0(const HapPtr &p, HapHdr &h) { /* returns true when either end is touched */
     const u32 lane = (u32)wv_lane();
-    const u8 *tseq, *qseq;
-    hap_seqs(c, p, h, tseq, qseq);
     const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
     u32 d = h.d0;
     while (d < lim) {
         const u32 i = d + lane;
         const bool in = i < lim;
         const u32 ii = in ? i : 0;
-        const bool match = in && tseq[ii] == qseq[ii];
+        const bool match = in && p.tseq[ii] == p.qseq[ii];
         const u64 m = wv_ballot(!match);
         if (m) {
             d += (u32)avk_ctz64(m);
@@ -606,15 +542,13 @@ AVK_DEV bool hap_slide_d0(const Ctx &c, const HapPtr &p, HapHdr &h) { /* returns
  * and each slides while the bases agree, 64 bases per step (the general lane-group code takes 16 per step for three
  * diagonals and keeps the front in LDS).  Leaves the front in
  * wf[0..2] and returns whether an end is touched (update's stopping rule, dynamic_wfa.rs:68-84). */
-AVK_DEV bool hap_raise_to_one(const Ctx &c, const HapPtr &p, const HapHdr &h) {
+AVK_DEV bool hap_raise_to_one(const HapPtr &p, const HapHdr &h) {
     const u32 lane = (u32)wv_lane();
-    const u8 *tseq, *qseq;
-    hap_seqs(c, p, h, tseq, qseq);
     const u32 d = h.d0, bl = h.t_len, ol = h.q_len;
     /* seq_match_run stops at the first difference or at either end; starts past an end give 0 */
-    const u32 n0 = seq_match_run(tseq, bl, d + 1, qseq, ol, d);
-    const u32 n1 = seq_match_run(tseq, bl, d + 1, qseq, ol, d + 1);
-    const u32 n2 = seq_match_run(tseq, bl, d, qseq, ol, d + 1);
+    const u32 n0 = seq_match_run(p.tseq, bl, d + 1, p.qseq, ol, d);
+    const u32 n1 = seq_match_run(p.tseq, bl, d + 1, p.qseq, ol, d + 1);
+    const u32 n2 = seq_match_run(p.tseq, bl, d, p.qseq, ol, d + 1);
     const u32 o0 = d + n0, o1 = d + 1 + n1, o2 = d + 1 + n2;
     wv_sync();
     if (lane < 3) p.wf[lane] = lane == 0 ? o0 : (lane == 1 ? o1 : o2);
@@ -622,29 +556,25 @@ AVK_DEV bool hap_raise_to_one(const Ctx &c, const HapPtr &p, const HapHdr &h) {
     /* reached_baseline_end || reached_other_end at distance 1: the offset in B is wf[i] + 1 - i */
     return o0 + 1 >= bl || o0 >= ol || o1 >= bl || o1 >= ol || o2 - 1 >= bl || o2 >= ol;
 }
-AVK_DEV int hap_update(const Ctx &c, const HapPtr &p, u32 wfcap, HapHdr &h) {
+AVK_DEV int hap_update(const HapPtr &p, u32 wfcap, HapHdr &h) {
     if (h.ed == 0) {
-        if (hap_slide_d0(c, p, h)) return 0;
+        if (hap_slide_d0(p, h)) return 0;
         if (wfcap < 3) return RS_OVERFLOW; /* 2 * ed + 3 > cap at ed 0 */
-        const bool touched = hap_raise_to_one(c, p, h);
+        const bool touched = hap_raise_to_one(p, h);
         h.ed = 1;
         if (touched) return 0;
     }
-    const u8 *tseq, *qseq;
-    hap_seqs(c, p, h, tseq, qseq);
-    return dw_update(p.wf, wfcap, h.ed, tseq, h.t_len, qseq, h.q_len);
+    return dw_update(p.wf, wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len);
 }
 /* DWFALite::finalize (dynamic_wfa.rs:183-198) after an update */
-AVK_DEV int hap_finalize(const Ctx &c, const HapPtr &p, u32 wfcap, HapHdr &h) {
+AVK_DEV int hap_finalize(const HapPtr &p, u32 wfcap, HapHdr &h) {
     if (h.ed == 0) {
         if (h.d0 >= h.t_len && h.d0 >= h.q_len) return 0; /* reached_full_diagonal with ed 0 */
         wv_sync();
         st32(p.wf, h.d0);
         wv_sync();
     }
-    const u8 *tseq, *qseq;
-    hap_seqs(c, p, h, tseq, qseq);
-    return dw_finalize(p.wf, wfcap, h.ed, tseq, h.t_len, qseq, h.q_len);
+    return dw_finalize(p.wf, wfcap, h.ed, p.tseq, h.t_len, p.qseq, h.q_len);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -808,7 +738,7 @@ AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u3
         AVK_TA_MARK(const_cast<Ctx &>(c), 12)
         hap_extend_seq(c, p, h, is_truth, true, v, hh == 0 ? a1 : a2, sync);
         AVK_TA_MARK(const_cast<Ctx &>(c), 14)
-        if (hap_update(c, p, c.wfcap, h)) return RS_OVERFLOW;
+        if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
         AVK_TA_MARK(const_cast<Ctx &>(c), 15)
         wv_sync();
         hap_store(p.w, h);
@@ -841,8 +771,8 @@ AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
         const HapPtr p = hap_ptr(n + NODE_HDR + (u64)hh * c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
         HapHdr h = hap_load(p.w);
         hap_extend_seq(c, p, h, true, false, none, AL_REF, c.L); /* both sides to the region end */
-        if (hap_update(c, p, c.wfcap, h)) return RS_OVERFLOW;
-        if (hap_finalize(c, p, c.wfcap, h)) return RS_OVERFLOW;
+        if (hap_update(p, c.wfcap, h)) return RS_OVERFLOW;
+        if (hap_finalize(p, c.wfcap, h)) return RS_OVERFLOW;
         wv_sync();
         hap_store(p.w, h);
         wv_sync();
@@ -987,7 +917,7 @@ AVK_DEV bool nodeB_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u
     const HapPtr p = hap_ptr(n + NODE_HDR, c.alw, 2, c.seqcap);
     HapHdr h = hap_load(p.w);
     const bool ok = hap_extend_seq(c, p, h, is_truth, true, v, allele, sync);
-    const bool exact = hap_slide_d0(c, p, h);
+    const bool exact = hap_slide_d0(p, h);
     if (is_error) {
         const u32 e = ld32u((u32 *)n + 1);
         wv_sync();
@@ -1045,7 +975,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
             UVar none;
             none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
             hap_extend_seq(c, p, h, true, false, none, AL_REF, c.L);
-            const bool touched = hap_slide_d0(c, p, h);
+            const bool touched = hap_slide_d0(p, h);
             const bool exact = touched && h.d0 >= h.t_len && h.d0 >= h.q_len;
             if (exact) { /* :187-190; later pops cannot improve on it */
                 wv_sync();
@@ -1276,12 +1206,9 @@ AVK_DEV int exact_shortcut_metrics(const AvkKernelArgs &a, Ctx &c, u32 v_off, co
     for (int t = 0; t < AVK_N_VARIANT_TYPES; ++t)
         if (wv_ballot((l_present >> t) & 1)) present |= 1u << t;
     /* truth == query on both haplotypes (asserted at :561-562; cost 0 guarantees it) */
-    const u8 *s0t, *s0q, *s1t, *s1q;
-    hap_seqs(c, w0, h0, s0t, s0q);
-    hap_seqs(c, w1, h1, s1t, s1q);
-    const int e1 = wfa_ed(c, c.ref, c.L, s0t, h0.t_len);
+    const int e1 = wfa_ed(c, c.ref, c.L, w0.tseq, h0.t_len);
     if (e1 < 0) return RS_OVERFLOW;
-    const int e2 = wfa_ed(c, c.ref, c.L, s1t, h1.t_len);
+    const int e2 = wfa_ed(c, c.ref, c.L, w1.tseq, h1.t_len);
     if (e2 < 0) return RS_OVERFLOW;
     wv_sync();
     if (lane == 0) {
@@ -1328,16 +1255,9 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     c.wfcap = cap ? (2 * cap + 2) : wf_full; /* even */
     if (c.wfcap > wf_full) c.wfcap = wf_full;
     c.wfs_cap = c.wfcap;
-    /* implied sequences (Ctx::implied): few enough calls per side, and the two tables take at most a third of this tier's workspace */
-    c.implied = a.implied_seqs && c.T <= AVK_IMPLIED_MAXV && c.Q <= AVK_IMPLIED_MAXV && c.N >= 1 &&
-                3ull * (((u64)1 << c.T) + ((u64)1 << c.Q)) * c.seqcap <= ws_bytes;
-    c.fstride = c.seqcap;
-    c.fvalid[0] = c.fvalid[1] = 0;
-    c.full[0] = c.full[1] = (u8 *)0;
-    const u32 node_seq = c.implied ? 0u : 2 * c.seqcap;
-    c.hapA_bytes = (u32)AVK_ALIGN16(H_WORDS * 4 + 16 * c.alw + 4 * c.wfcap + node_seq);
+    c.hapA_bytes = (u32)AVK_ALIGN16(H_WORDS * 4 + 16 * c.alw + 4 * c.wfcap + 2 * c.seqcap);
     c.nodeA_bytes = NODE_HDR + 2 * c.hapA_bytes;
-    c.hapB_bytes = (u32)AVK_ALIGN16(H_WORDS * 4 + 16 * c.alw + 4 * 2 + node_seq);
+    c.hapB_bytes = (u32)AVK_ALIGN16(H_WORDS * 4 + 16 * c.alw + 4 * 2 + 2 * c.seqcap);
     c.nodeB_bytes = NODE_HDR + c.hapB_bytes;
     c.optcap = c.max_branch < 4096 ? c.max_branch : 4096;
 
@@ -1346,12 +1266,6 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     u64 off = 0;
     u8 *refbuf = ws + off;
     off = AVK_ALIGN16(off + c.L);
-    if (c.implied) {
-        c.full[0] = ws + off;
-        off += ((u64)1 << c.T) * c.seqcap;
-        c.full[1] = ws + off;
-        off = AVK_ALIGN16(off + ((u64)1 << c.Q) * c.seqcap);
-    }
     /* the region blob lands here as it is: variant records | allele bytes | variants in search order | per-type counts
      * (AvkBlobVar in avk_dev_types.h; every section padded to 16 bytes) */
     u32 *const blob_dst = (u32 *)(ws + off);
@@ -1664,8 +1578,6 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     for (int hh = 0; hh < 2; ++hh) {
         const HapPtr &wp = hh == 0 ? w0 : w1;
         const HapHdr &hd = hh == 0 ? h0 : h1;
-        const u8 *wp_t, *wp_q;
-        hap_seqs(c, wp, hd, wp_t, wp_q);
         /* a haplotype that carries no ALT allele IS the reference window: distance 0 without aligning */
         bool l_t = false, l_q = false;
         for (u32 i = lane; i < c.alw; i += 64) {
@@ -1675,13 +1587,13 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
         const bool t_has_alt = wv_ballot(l_t) != 0, q_has_alt = wv_ballot(l_q) != 0;
         int ert = 0, erq = 0;
         if (t_has_alt) {
-            ert = wfa_ed(c, c.ref, c.L, wp_t, hd.t_len);
+            ert = wfa_ed(c, c.ref, c.L, wp.tseq, hd.t_len);
             if (ert < 0) return RS_OVERFLOW;
         }
         if (q_has_alt) {
             if (hd.ed == 0 && t_has_alt) erq = ert; /* distance 0 after finalize: the two sequences are identical */
             else {
-                erq = wfa_ed(c, c.ref, c.L, wp_q, hd.q_len);
+                erq = wfa_ed(c, c.ref, c.L, wp.qseq, hd.q_len);
                 if (erq < 0) return RS_OVERFLOW;
             }
         } else if (hd.ed == 0) erq = ert;
@@ -1704,7 +1616,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
                     const u32 fl = gen_filtered(c, c.T, c.Q, wp.qalt, (u32)SUP[s], c.seq_a, failed);
                     const int y2 = wfa_ed(c, c.ref, c.L, c.seq_a, fl);
                     if (y2 < 0) return RS_OVERFLOW;
-                    const int z2 = wfa_ed(c, wp_t, hd.t_len, c.seq_a, fl);
+                    const int z2 = wfa_ed(c, wp.tseq, hd.t_len, c.seq_a, fl);
                     if (z2 < 0) return RS_OVERFLOW;
                     const u32 Y2 = 2u * (u32)y2, Z2 = 2u * (u32)z2;
                     const u32 tp2 = (X + Y2 - Z2) / 2;
@@ -1721,7 +1633,7 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
                     const u32 fl = gen_filtered(c, 0, c.T, wp.talt, (u32)SUP[s], c.seq_a, failed);
                     const int x2 = wfa_ed(c, c.ref, c.L, c.seq_a, fl);
                     if (x2 < 0) return RS_OVERFLOW;
-                    const int z2 = wfa_ed(c, c.seq_a, fl, wp_q, hd.q_len);
+                    const int z2 = wfa_ed(c, c.seq_a, fl, wp.qseq, hd.q_len);
                     if (z2 < 0) return RS_OVERFLOW;
                     const u32 X2 = 2u * (u32)x2, Z2 = 2u * (u32)z2;
                     const u32 tp2 = (X2 + Y - Z2) / 2;
@@ -2068,10 +1980,7 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
             const HapPtr w0 = hap_ptr(wn + NODE_HDR, c.alw, c.wfcap, c.seqcap);
             const HapPtr w1 = hap_ptr(wn + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
             const HapHdr h0 = hap_load(w0.w), h1 = hap_load(w1.w);
-            const u8 *o0t, *o0q, *o1t, *o1q;
-            hap_seqs(c, w0, h0, o0t, o0q);
-            hap_seqs(c, w1, h1, o1t, o1q);
-            const u8 *src[5] = {c.ref, o0t, o1t, o0q, o1q};
+            const u8 *src[5] = {c.ref, w0.tseq, w1.tseq, w0.qseq, w1.qseq};
             const u32 len[5] = {c.L, h0.t_len, h1.t_len, h0.q_len, h1.q_len};
             for (int k = 0; k < 5; ++k) {
                 const u32 nbytes = len[k] < reg.seq_stride ? len[k] : reg.seq_stride;

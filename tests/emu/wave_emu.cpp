@@ -203,7 +203,6 @@ void lane_main(void *p, int /*lane*/) {
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
  * device functions, the workgroup-level plumbing (histogram, scans, scatter) as plain loops */
 uint64_t g_last_pair_regions = 0; /* emu_last_pair_regions: regions of the last emulated call that went through the lookup of avk_pairs.inl */
-int g_implied = 0; /* emu_set_implied: context option implied_sequences */
 int g_lane_pairs = 1; /* emu_set_lane_pairs: context option lane_pairs (regions with the same SNV on both sides are looked up, avk_pairs.inl) */
 uint32_t g_stripe_w = 0; /* emu_set_stripe: claim width the heads of the lane classes are dealt out over (context option lane_stripe; 0 = sorted order) */
 int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
@@ -395,7 +394,6 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.max_branch_factor = cfg->max_branch_factor;
     a.enable_exact_shortcut = cfg->enable_exact_shortcut;
     a.mode = mode;
-    a.implied_seqs = g_implied ? 1u : 0u;
     if (mode == 1 && !devpack) { /* the pre-checks of avk_optimize_pairs_batch (aardvark_amd/csrc/avk_host.hip); dp_region applies them itself */
         for (uint64_t r = 0; r < batch->n_regions; ++r) {
             AvkDevRegion &dr = pb.regions[r];
@@ -954,7 +952,6 @@ void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_stripe(uint32_t w) { g_stripe_w = w; }
 void emu_set_lane_pairs(int on) { g_lane_pairs = on; }
-void emu_set_implied(int on) { g_implied = on; }
 uint64_t emu_last_pair_regions() { return g_last_pair_regions; }
 
 /* The device-side packer against the host-side one on the same batch: every region record, every blob, the plan, the work order and the fast

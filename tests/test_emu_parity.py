@@ -146,28 +146,3 @@ def test_class_c_list_shared_between_the_hbm_launches(oracle, monkeypatch):
             assert got.diff(want) == []
             seen.add(got.tier_counts[2])
     assert max(seen) >= 50 and min(seen) < 20  # (regions of the lane-per-region classes are never predicted into the HBM list)
-
-
-def test_implied_sequences(oracle):
-    """context option implied_sequences: search nodes without haplotype bytes (the sequences are prefixes of per-side tables, Ctx::implied in avk_solver.inl) —
-    sequences out, every tier, quotas, overlapping and same-position calls, the wave-per-region code alone and beside the lanes"""
-    import ctypes as C
-    lib = emu_lib.load()
-    lib.emu_set_implied.argtypes = [C.c_int]
-    lib.emu_set_implied(1)
-    try:
-        for contigs, batch in (scenarios.golden(), scenarios.fuzz_regions(31, 300, max_vars=6), scenarios.fuzz_regions(32, 200, max_vars=4, repeat_unit=b"CA"),
-                               scenarios.fuzz_regions(33, 200, max_vars=3, repeat_unit=b"A", max_len=4), scenarios.indel_small(1200)):
-            check(oracle, contigs, batch, lane_kernel=False, n_waves=4)
-            check(oracle, contigs, batch, lane_kernel=False, lds_bytes=0, lds2_bytes=0, n_waves=4)  # the HBM tier alone
-        contigs, batch = scenarios.quota_regions(5)
-        for quota in (1, 3, 50):
-            want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4, max_branch_factor=quota)
-            got = emu_lib.compare_batch(batch, contigs, threads=EMU_THREADS, max_branch_factor=quota, lane_kernel=False)
-            assert got.diff(want) == []
-        contigs, batch = scenarios.fuzz_regions(34, 400, max_vars=3)
-        want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
-        got = emu_lib.compare_batch(batch, contigs, threads=EMU_THREADS, lane_kernel=True)
-        assert got.diff(want) == []
-    finally:
-        lib.emu_set_implied(0)
