@@ -150,7 +150,7 @@ def test_scheduling_options_do_not_change_results(oracle, opts):
             got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=gm)
             assert got.diff(want) == []
             assert ctx.last_lane_solved() > 0.5 * batch.n_regions
-        assert ctx.last_compare_was_one_shot()
+        assert ctx.last_compare_was_one_shot() or opts.get("device_pack", 1) == 0
     finally:
         ctx.close()
 
