@@ -64,7 +64,8 @@ struct DpOpts {
     u64 tier0_bytes, tier1_bytes;
     u32 tier0_ed_cap, tier1_ed_cap;
     u32 solo_min_variants, max_branch, class_c_nodes_x2, lane_max_calls, lane_max_est;
-    u32 head_est, pad1_; /* regions with at least this many estimated edits form the head of their lane class (1..15) */
+    u32 head_est, het_min; /* het_min: regions with at least this many unphased heterozygous calls are big phasing searches (AVK_HET_SEARCH_MIN; 0 = no such rule) */
+/* regions with at least this many estimated edits form the head of their lane class (1..15) */
     u32 lane_pairs, split_three; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
     u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
@@ -92,7 +93,7 @@ struct DpState {
     u32 err;        /* DP_ERR_* */
     u32 n_pending;  /* calls whose alt_ed is left to the host (both stripped alleles longer than 64 symbols) */
     u32 lane_on[AVK_FAST_CLASSES];
-    u32 pad0_;
+    u32 lanes_any; /* some lane class has launches */
     u64 have[AVK_FAST_CLASSES]; /* regions eligible per lane class */
     u64 total_v, total_blob_words, total_seq, total_groups; /* totals of the four scans */
     u64 need_hist[DP_NEED_BUCKETS];           /* class C regions by predicted HBM workspace: bucket b = at most 1 MB << b (the last one: more) */
@@ -522,7 +523,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                     fast_key = dp_cost_key(calls, tc, qc);
                     if ((fast_key >> 4) > a.opt.lane_max_est) fast_class = 0;
                     if (maxv > 2) fast_key = a.opt.split_three && nhet_u >= AVK_HET_HEAD_MIN ? 0x10u : 0u; /* the three-call class keeps the caller's order (avk_pack.h); option lane_split_three: likely hand-backs first */
-                    if (nhet_u >= AVK_HET_SEARCH_MIN) fast_class = 0; /* a big phasing search (avk_dev_types.h) */
+                    if (maxv > 2 && a.opt.het_min && nhet_u >= a.opt.het_min) fast_class = 0; /* a big phasing search (avk_dev_types.h): not for a lane */
                     break;
                 }
             }
@@ -547,11 +548,12 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     /* plan_work_order: the class of a region the lanes do not take */
     u32 cls = 2;
     const bool failed = (ri.pre_status & 0xFFFFu) != 0;
+    /* a big phasing search (AVK_HET_SEARCH_MIN): class C — in batches that have lane launches, which is decided after this kernel (dp_bucket_of reads the flag) */
+    const bool het_search = !failed && N != 0 && a.opt.solo_min_variants != 0 && a.opt.tier1_bytes && a.opt.het_min && nhet_u >= a.opt.het_min;
     if (!failed && N != 0 && a.opt.solo_min_variants != 0) {
-        if (a.opt.tier1_bytes && (nhet_u >= AVK_HET_SEARCH_MIN ||
-                                  dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier1_ed_cap, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch) > a.opt.tier1_bytes))
-        {
-            cls = 0;
+        const bool c_by_size = a.opt.tier1_bytes && dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier1_ed_cap, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch) > a.opt.tier1_bytes;
+        if (c_by_size || het_search) {
+            if (c_by_size) cls = 0;
             /* how large an HBM slice the region is predicted to want (no edit-distance cap there): the host sizes the per-wave slices of the batch's
              * launches by the distribution — large windows (--min-variant-gap 1000) outgrow the default 1 MB by the thousand, and the shared big
              * slices serialise whatever overflows */
@@ -559,9 +561,11 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
             u32 b = 0;
             while (b + 1 < DP_NEED_BUCKETS && need2 > (1ull << (20 + b))) ++b;
             need_bucket = b;
-        } else if (N >= a.opt.solo_min_variants || dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier0_ed_cap, 2 * N + 1, a.opt.max_branch) > a.opt.tier0_bytes)
+        }
+        if (cls != 0 && (N >= a.opt.solo_min_variants || dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier0_ed_cap, 2 * N + 1, a.opt.max_branch) > a.opt.tier0_bytes))
             cls = 1;
     }
+    if (het_search) cls |= 0x80u;
     if (failed) fast_class = 0; /* `have` and the work order only count regions that will be solved */
     ri.keys = fast_class | (fast_key << 8) | (cls << 16) | ((u32)(N > 255 ? 255 : N) << 24);
     a.rinfo[r] = ri;
@@ -587,7 +591,9 @@ AVK_DEV void dp_lane_switch(const DpArgs &a) {
     }
     if (a.opt.lane_min_regions != 0 && have_all < a.opt.lane_min_batch)
         for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) on[fc] = 0;
-    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) a.st->lane_on[fc] = on[fc];
+    u32 any = 0;
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) a.st->lane_on[fc] = on[fc], any |= on[fc];
+    a.st->lanes_any = any;
 }
 
 /* the bucket of a region in the work order: [class C | class B | bulk | lane class 4 | .. | lane class 0], most expensive key first */
@@ -595,7 +601,9 @@ AVK_DEV u32 dp_bucket_of(const DpArgs &a, u64 r) {
     const u32 k = a.rinfo[r].keys;
     const u32 fc = k & 0xFFu;
     if (fc && a.st->lane_on[fc - 1]) return 256u * (3u + (AVK_FAST_CLASSES - fc)) + (255u - ((k >> 8) & 0xFFu));
-    return 256u * ((k >> 16) & 0xFFu) + (255u - (k >> 24));
+    u32 cls = (k >> 16) & 0x7Fu;
+    if (((k >> 16) & 0x80u) && a.st->lanes_any) cls = 0; /* a big phasing search, in a batch with lane launches: class C */
+    return 256u * cls + (255u - (k >> 24));
 }
 
 /* where the region that came `pos`-th in the sort goes in the work order: the heads of the lane classes are striped (avk_stripe_slot) */

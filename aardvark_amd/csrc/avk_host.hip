@@ -298,6 +298,7 @@ struct avk_ctx {
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
     int64_t early_lds = 0;                            /* 1: what the three-call lane class hands back goes through the LDS tier first (run_internal) */
+    int64_t het_search_min = AVK_HET_SEARCH_MIN;      /* regions with at least this many unphased heterozygous calls go to class C and stay out of the three-call lane class (0 = no such rule) */
     int64_t lane_head_est = 1;                        /* regions with at least this many estimated edits (fast_cost_key) form the narrow-tiled head of their lane class */
     int64_t lane_split_three = 0;                     /* 1: the three-call class as two launches: likely hand-backs (AVK_HET_HEAD_MIN) first, their launch beside the rest.  Measured WORSE (3.95 ->
                                                          4.9 ms per whole-genome step): the class lasts as long as its slowest claims, and the head is all of them — 2.3 ms for a third of the class */
@@ -681,6 +682,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->lane_metrics_ed_cap = value;
     } else if (n == "early_lds") {
         ctx->early_lds = value ? 1 : 0;
+    } else if (n == "het_search_min") {
+        if (value < 0 || value > 255) return fail(ctx, AVK_E_ARG, "het_search_min must be 0..255");
+        ctx->het_search_min = value;
     } else if (n == "lane_head_est") {
         if (value < 1 || value > 15) return fail(ctx, AVK_E_ARG, "lane_head_est must be 1..15");
         ctx->lane_head_est = value;
@@ -898,7 +902,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     }
     db->seq_total = seq_total;
     std::string err;
-    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0 && !pairs_mode, ctx->lane_split_three != 0);
+    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0 && !pairs_mode, ctx->lane_split_three != 0, (uint32_t)ctx->het_search_min);
     if (rc) {
         delete db;
         return fail(ctx, rc, "%s", err.c_str());
@@ -961,7 +965,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
                                     ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls,
-                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u, (uint32_t)ctx->lane_head_est);
+                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u, (uint32_t)ctx->lane_head_est, (uint32_t)ctx->het_search_min);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */

@@ -172,7 +172,7 @@ inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *
  * independent once the offsets are known). */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
                       const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0, uint32_t lane_max_est = 15,
-                      bool lane_pairs = true, bool split_three = false) {
+                      bool lane_pairs = true, bool split_three = false, uint32_t het_min = AVK_HET_SEARCH_MIN) {
     const uint64_t n = b->n_regions;
     if (n > 0x7FFFFFFFull || b->n_variants > 0x7FFFFFFFull) {
         *err = "batch too large (more than 2^31 regions or variants); split it";
@@ -414,7 +414,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                          * see, and lanes that diverge do not run side by side — 16 expensive regions in one tile take 16 times as long as
                          * one, and the launch lasts as long as that tile (measured: 3.1 ms in caller order, 6.2 ms sorted). */
                         if (fc.maxv > 2) out->fast_key[r] = split_three && out->nhet_u[r] >= AVK_HET_HEAD_MIN ? 0x10 : 0; /* (option lane_split_three: the likely hand-backs first, AVK_HET_HEAD_MIN) */
-                        if (out->nhet_u[r] >= AVK_HET_SEARCH_MIN) out->fast_class[r] = 0; /* a big phasing search (avk_dev_types.h) */
+                        if (fc.maxv > 2 && het_min && out->nhet_u[r] >= het_min) out->fast_class[r] = 0; /* a big phasing search (avk_dev_types.h): not for a lane */
                         break;
                     }
                 }
@@ -490,7 +490,7 @@ struct WorkPlan {
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
                                 uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12,
                                 uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV, uint64_t lane_min_batch = 0, uint32_t stripe_w = 0,
-                                uint32_t head_est = 1) {
+                                uint32_t head_est = 1, uint32_t het_min = AVK_HET_SEARCH_MIN) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
@@ -512,6 +512,8 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         if (lane_min_regions != 0 && have_all < lane_min_batch)
             for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lane_on[fc] = false;
     }
+    bool lanes_any = false;
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lanes_any = lanes_any || lane_on[fc];
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
         const uint64_t maxT = dr.t_cnt > dr.q_cnt ? dr.t_cnt : dr.q_cnt;
@@ -537,7 +539,7 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         }
         if ((dr.pre_status & 0xFFFFu) || N == 0 || solo_min_variants == 0) continue;
         const uint64_t alle = dr.alle_bytes, grow = dr.grow;
-        if (tier1_bytes && ((!pb.nhet_u.empty() && pb.nhet_u[r] >= AVK_HET_SEARCH_MIN) || need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes)) {
+        if (tier1_bytes && ((lanes_any && het_min && !pb.nhet_u.empty() && pb.nhet_u[r] >= het_min) || /* (a big phasing search, in a batch with lane launches) */ need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes)) {
             cls[r] = 0;
             plan.n_hbm += 1;
         } else if (N >= solo_min_variants || need(dr, N, alle, grow, tier0_ed_cap, 2 * N + 1) > tier0_bytes) {
