@@ -14,9 +14,9 @@ import os as _os
 # helps when nothing in the process has used HIP yet; the caller's own setting wins.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from ._abi import (CLASSES, FIELDS, N_FIELDS, N_GROUPS, ST_NAMES, TALLY_LEN, VARIANT_TYPES, ZYGOSITIES, CompactBatch, RegionBatch,
+from ._abi import (CLASSES, FIELDS, N_FIELDS, N_GROUPS, ST_NAMES, TALLY_LEN, VARIANT_TYPES, ZYGOSITIES, CompactBatch, PackedBatch, RegionBatch,
                    ResultBatch)
 from .api import AardvarkAmdError, CompareConfig, Context, library_path, load_library
 
-__all__ = ["Context", "CompareConfig", "RegionBatch", "CompactBatch", "ResultBatch", "AardvarkAmdError", "load_library", "library_path",
+__all__ = ["Context", "CompareConfig", "RegionBatch", "CompactBatch", "PackedBatch", "ResultBatch", "AardvarkAmdError", "load_library", "library_path",
            "VARIANT_TYPES", "ZYGOSITIES", "CLASSES", "FIELDS", "N_GROUPS", "N_FIELDS", "TALLY_LEN", "ST_NAMES"]

@@ -91,6 +91,25 @@ class AvkCompactBatch(C.Structure):
     ]
 
 
+class AvkPackedBatch(C.Structure):
+    _fields_ = [
+        ("n_regions", C.c_uint64),
+        ("contig_idx", _p(C.c_uint16)),
+        ("start", _p(C.c_uint32)),
+        ("len", _p(C.c_uint16)),
+        ("t_cnt", _p(C.c_uint8)),
+        ("q_cnt", _p(C.c_uint8)),
+        ("n_variants", C.c_uint64),
+        ("var_rel_pos", _p(C.c_uint16)),
+        ("var_type_zyg", _p(C.c_uint8)),
+        ("a0_len", _p(C.c_uint8)),
+        ("a1_len", _p(C.c_uint8)),
+        ("var_raw_space", _p(C.c_uint32)),
+        ("allele_bytes", _p(C.c_uint8)),
+        ("allele_bytes_len", C.c_uint64),
+    ]
+
+
 class AvkCompareConfig(C.Structure):
     _fields_ = [
         ("max_branch_factor", C.c_uint32),
@@ -282,6 +301,55 @@ class CompactBatch:
         b.n_regions, b.n_variants = self.n_regions, self.n_variants
         for name, ct in (("contig_idx", C.c_uint32), ("start", C.c_uint32), ("len", C.c_uint32), ("v_off", C.c_uint32), ("t_cnt", C.c_uint16), ("q_cnt", C.c_uint16), ("var_pos", C.c_uint32),
                          ("var_type_zyg", C.c_uint8), ("a_off", C.c_uint32), ("a0_len", C.c_uint32), ("a1_len", C.c_uint32), ("var_raw_space", C.c_uint32), ("allele_bytes", C.c_uint8)):
+            a = getattr(self, name)
+            if a is not None:
+                setattr(b, name, _ptr(a, ct))
+        b.allele_bytes_len = int(self.allele_bytes.size)
+        return b
+
+
+class PackedBatch:
+    """The same batch in the library's packed form (avk_packed_batch): 10 bytes per region, 5 per call plus the allele bytes; every offset is implied by
+    order.  `from_compact` checks the constraints (calls and alleles back to back in region / call order, narrow fields wide enough)."""
+
+    FIELDS = ("contig_idx", "start", "len", "t_cnt", "q_cnt", "var_rel_pos", "var_type_zyg", "a0_len", "a1_len", "var_raw_space", "allele_bytes")
+    DTYPES = (np.uint16, np.uint32, np.uint16, np.uint8, np.uint8, np.uint16, np.uint8, np.uint8, np.uint8, np.uint32, np.uint8)
+
+    def __init__(self, **arrays):
+        for name, dt in zip(self.FIELDS, self.DTYPES):
+            a = arrays.get(name)
+            setattr(self, name, None if a is None else np.ascontiguousarray(a, dtype=dt))
+        self.n_regions = int(self.start.size)
+        self.n_variants = int(self.var_rel_pos.size)
+
+    @classmethod
+    def from_compact(cls, cb):
+        n, nv = cb.n_regions, cb.n_variants
+        cnt = cb.t_cnt.astype(np.int64) + cb.q_cnt
+        voff = np.concatenate([[0], np.cumsum(cnt)])
+        alen = cb.a0_len.astype(np.int64) + cb.a1_len
+        aoff = np.concatenate([[0], np.cumsum(alen)])
+        ok = (np.array_equal(cb.v_off, voff[:-1]) and int(voff[-1]) == nv and np.array_equal(cb.a_off, aoff[:-1]) and int(aoff[-1]) == cb.allele_bytes.size and
+              (n == 0 or (int(cb.len.max()) < 65536 and int(cb.t_cnt.max()) < 256 and int(cb.q_cnt.max()) < 256)) and
+              (nv == 0 or (int(cb.a0_len.max()) < 256 and int(cb.a1_len.max()) < 256)) and (cb.contig_idx is None or n == 0 or int(cb.contig_idx.max()) < 65536))
+        rel = None
+        if ok:
+            region_of = np.repeat(np.arange(n), cnt)
+            rel = cb.var_pos.astype(np.int64) - cb.start.astype(np.int64)[region_of]
+            ok = nv == 0 or (int(rel.min()) >= 0 and int(rel.max()) < 65536)
+        if not ok:
+            raise ValueError("the batch does not satisfy the constraints of the packed form (include/aardvark_amd.h: avk_packed_batch)")
+        return cls(contig_idx=cb.contig_idx, start=cb.start, len=cb.len, t_cnt=cb.t_cnt, q_cnt=cb.q_cnt, var_rel_pos=rel, var_type_zyg=cb.var_type_zyg, a0_len=cb.a0_len,
+                   a1_len=cb.a1_len, var_raw_space=cb.var_raw_space, allele_bytes=cb.allele_bytes)
+
+    def nbytes(self):
+        return sum(getattr(self, f).nbytes for f in self.FIELDS if getattr(self, f) is not None)
+
+    def c_struct(self):
+        b = AvkPackedBatch()
+        b.n_regions, b.n_variants = self.n_regions, self.n_variants
+        for name, ct in (("contig_idx", C.c_uint16), ("start", C.c_uint32), ("len", C.c_uint16), ("t_cnt", C.c_uint8), ("q_cnt", C.c_uint8), ("var_rel_pos", C.c_uint16),
+                         ("var_type_zyg", C.c_uint8), ("a0_len", C.c_uint8), ("a1_len", C.c_uint8), ("var_raw_space", C.c_uint32), ("allele_bytes", C.c_uint8)):
             a = getattr(self, name)
             if a is not None:
                 setattr(b, name, _ptr(a, ct))

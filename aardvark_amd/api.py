@@ -11,7 +11,8 @@ import os
 
 import numpy as np
 
-from ._abi import (TALLY_LEN, AvkCompactBatch, AvkCompareConfig, AvkRegionBatch, AvkResultBatch, CompactBatch, RegionBatch, ResultBatch)
+from ._abi import (TALLY_LEN, AvkCompactBatch, AvkCompareConfig, AvkPackedBatch, AvkRegionBatch, AvkResultBatch, CompactBatch, PackedBatch, RegionBatch,
+                   ResultBatch)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _lib = None
@@ -56,6 +57,8 @@ def load_library():
     lib.avk_batch_upload.argtypes = [vp, C.POINTER(AvkRegionBatch), C.POINTER(vp)]
     lib.avk_compare_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
     lib.avk_batch_upload_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(vp)]
+    lib.avk_compare_packed.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
+    lib.avk_batch_upload_packed.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(vp)]
     lib.avk_compare_resident.argtypes = [vp, vp, C.POINTER(AvkCompareConfig), vp]
     lib.avk_results_download.argtypes = [vp, vp, C.POINTER(AvkResultBatch)]
     lib.avk_batch_free.argtypes = [vp, vp]
@@ -167,6 +170,24 @@ class Context:
             out[...] = a
             return out
         return CompactBatch(**{f: pin(getattr(cbatch, f)) for f in CompactBatch.FIELDS})
+
+    def pinned_packed(self, pbatch):
+        """a copy of a PackedBatch whose arrays live in pinned memory"""
+        def pin(a):
+            if a is None:
+                return None
+            out = self.host_array(a.shape, a.dtype)
+            out[...] = a
+            return out
+        return PackedBatch(**{f: pin(getattr(pbatch, f)) for f in PackedBatch.FIELDS})
+
+    def solve_packed(self, pbatch, config=None, res=None):
+        """avk_compare_packed: solve_compare_region for every region of a batch in the packed form -> ResultBatch (indexed like the packed arrays)"""
+        config = config or CompareConfig(enable_sequences=False)
+        res = res if res is not None else ResultBatch(pbatch, sequences=False, group_metrics=False)
+        pb, cfg, ro = pbatch.c_struct(), config.c_struct(), res.c_struct()
+        self._check(self.lib.avk_compare_packed(self.handle, C.byref(pb), C.byref(cfg), C.byref(ro)))
+        return res
 
     def solve_compact(self, cbatch, config=None, res=None):
         """avk_compare_compact: solve_compare_region for every region of a batch in the compact form -> ResultBatch (indexed like the compact arrays)"""

@@ -168,6 +168,43 @@ AVK_DEV void dp_widen(const DpCompact &c, u64 i) { /* one lane: region i and cal
     }
 }
 
+/* ---- the packed form (avk_packed_batch): every offset implied by order; v_off / a_off come from two prefix sums on the device ------------------------- */
+struct DpPacked {
+    const uint16_t *contig_idx, *len, *rel_pos;
+    const u32 *start, *var_raw;
+    const u8 *t_cnt, *q_cnt, *var_type_zyg, *a0_len, *a1_len;
+    const u64 *v_off, *a_off; /* exclusive prefix sums: calls before region r, allele bytes before call v */
+    u64 n_regions, n_variants;
+    u32 *w_contig, *w_t_cnt, *w_q_cnt, *w_a0_len, *w_a1_len, *w_raw;
+    u64 *w_start, *w_end, *w_t_off, *w_q_off, *w_pos, *w_a0_off, *w_a1_off;
+    u8 *w_type, *w_zyg;
+};
+AVK_DEV void dp_widen_packed(const DpPacked &c, u64 i) { /* one lane: region i (and the positions of its calls) and call i */
+    if (i < c.n_regions) {
+        const u64 st = c.start[i], vo = c.v_off[i];
+        const u32 tc = c.t_cnt[i], qc = c.q_cnt[i];
+        if (c.w_contig) c.w_contig[i] = c.contig_idx[i];
+        c.w_start[i] = st;
+        c.w_end[i] = st + c.len[i];
+        c.w_t_off[i] = vo;
+        c.w_q_off[i] = vo + tc;
+        c.w_t_cnt[i] = tc;
+        c.w_q_cnt[i] = qc;
+        for (u32 k = 0; k < tc + qc && vo + k < c.n_variants; ++k) c.w_pos[vo + k] = st + c.rel_pos[vo + k];
+    }
+    if (i < c.n_variants) {
+        const u64 ao = c.a_off[i];
+        const u32 l0 = c.a0_len[i], l1 = c.a1_len[i], tz = c.var_type_zyg[i];
+        c.w_a0_off[i] = ao;
+        c.w_a1_off[i] = ao + l0;
+        c.w_a0_len[i] = l0;
+        c.w_a1_len[i] = l1;
+        if (c.w_raw) c.w_raw[i] = c.var_raw ? c.var_raw[i] : (l0 > l1 ? l0 : l1);
+        c.w_type[i] = (u8)(tz & 15u);
+        c.w_zyg[i] = (u8)(tz >> 4);
+    }
+}
+
 /* ---- the merge path on the device (solve_merge_region, src/merge_solver.rs:110-200) ------------------------------------------------------------------- */
 /* a batch of MultiRegions (avk_multi_batch) as one CompareRegion-shaped item per input pair (i < j, lexicographic): input i plays the truth side */
 struct DpPairs {

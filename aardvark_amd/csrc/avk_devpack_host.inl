@@ -14,6 +14,75 @@ __global__ void __launch_bounds__(256) avk_dp_expand_pairs_kernel(dpk::DpPairs c
 __global__ void __launch_bounds__(256) avk_dp_merge_classify_kernel(dpk::DpMerge c) { dpk::dp_merge_classify(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 
 __global__ void __launch_bounds__(256) avk_dp_widen_kernel(dpk::DpCompact c) { dpk::dp_widen(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) avk_dp_widen_packed_kernel(dpk::DpPacked c) { dpk::dp_widen_packed(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+/* Exclusive prefix sum of a[i] + b[i] over n byte pairs (the packed form's offsets: calls per region, allele bytes per call): per-workgroup sums of 4096
+ * elements, a one-workgroup scan of those sums, then every workgroup scans its own 4096 again from its base.  16 elements per thread, waves and workgroup
+ * combined through LDS. */
+#define AVK_PS_BLOCK 4096u
+__device__ inline uint32_t avk_ps_thread_sum(const uint8_t *a, const uint8_t *b, uint64_t n, uint64_t i0, uint32_t (&v)[16]) {
+    uint32_t s = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        const uint64_t i = i0 + k;
+        v[k] = i < n ? (uint32_t)a[i] + (uint32_t)b[i] : 0u;
+        s += v[k];
+    }
+    return s;
+}
+__global__ void __launch_bounds__(256) avk_ps_block_sums_kernel(const uint8_t *a, const uint8_t *b, uint64_t n, uint64_t *block_sums) {
+    __shared__ uint32_t part[256];
+    uint32_t v[16];
+    part[threadIdx.x] = avk_ps_thread_sum(a, b, n, (uint64_t)blockIdx.x * AVK_PS_BLOCK + threadIdx.x * 16u, v);
+    __syncthreads();
+    for (uint32_t st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) part[threadIdx.x] += part[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) block_sums[blockIdx.x] = part[0];
+}
+__global__ void __launch_bounds__(1024) avk_ps_scan_sums_kernel(uint64_t *block_sums, uint32_t n_blocks, uint64_t *total) { /* one workgroup: in-place exclusive scan */
+    __shared__ uint64_t part[1024];
+    __shared__ uint64_t carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (uint32_t base = 0; base < n_blocks; base += 1024u) {
+        const uint32_t i = base + threadIdx.x;
+        const uint64_t x = i < n_blocks ? block_sums[i] : 0ull;
+        part[threadIdx.x] = x;
+        __syncthreads();
+        for (uint32_t st = 1; st < 1024u; st <<= 1) { /* Hillis-Steele inclusive scan */
+            const uint64_t y = threadIdx.x >= st ? part[threadIdx.x - st] : 0ull;
+            __syncthreads();
+            part[threadIdx.x] += y;
+            __syncthreads();
+        }
+        if (i < n_blocks) block_sums[i] = carry + part[threadIdx.x] - x;
+        __syncthreads();
+        if (threadIdx.x == 1023u) carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0 && total) *total = carry;
+}
+__global__ void __launch_bounds__(256) avk_ps_apply_kernel(const uint8_t *a, const uint8_t *b, uint64_t n, const uint64_t *block_base, uint64_t *out) {
+    __shared__ uint32_t part[256];
+    uint32_t v[16];
+    const uint64_t i0 = (uint64_t)blockIdx.x * AVK_PS_BLOCK + threadIdx.x * 16u;
+    const uint32_t mine = avk_ps_thread_sum(a, b, n, i0, v);
+    part[threadIdx.x] = mine;
+    __syncthreads();
+    for (uint32_t st = 1; st < 256u; st <<= 1) {
+        const uint32_t y = threadIdx.x >= st ? part[threadIdx.x - st] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += y;
+        __syncthreads();
+    }
+    uint64_t run = block_base[blockIdx.x] + (part[threadIdx.x] - mine);
+#pragma unroll
+    for (uint32_t k = 0; k < 16; ++k) {
+        if (i0 + k < n) out[i0 + k] = run;
+        run += v[k];
+    }
+}
 
 __global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dpk::dp_variant(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 
@@ -559,10 +628,13 @@ static void release_pooled(avk_ctx *ctx, avk_dev_batch *db) {
 
 /* b: the batch in the wide form, or NULL and cb: the batch in the compact form (avk_compact_batch: half the bytes over PCIe, widened on the device) */
 /* mb: a batch of MultiRegions (the merge path): one region per input pair is made on the device (dp_expand_pairs) */
-static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out, const avk_multi_batch *mb = nullptr) {
+static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out, const avk_multi_batch *mb = nullptr,
+                                const avk_packed_batch *pk = nullptr) {
     const uint32_t mk = mb ? mb->n_inputs : 0, mppr = mk * (mk - (mk ? 1u : 0u)) / 2;
-    const uint64_t n = b ? b->n_regions : (cb ? cb->n_regions : mb->n_regions * mppr), nv = b ? b->n_variants : (cb ? cb->n_variants : mb->n_variants),
-                   alen = b ? b->allele_bytes_len : (cb ? cb->allele_bytes_len : mb->allele_bytes_len);
+    const uint64_t n = pk ? pk->n_regions : (b ? b->n_regions : (cb ? cb->n_regions : mb->n_regions * mppr)), nv = pk ? pk->n_variants : (b ? b->n_variants : (cb ? cb->n_variants : mb->n_variants)),
+                   alen = pk ? pk->allele_bytes_len : (b ? b->allele_bytes_len : (cb ? cb->allele_bytes_len : mb->allele_bytes_len));
+    if (pk && n && (!pk->start || !pk->len || !pk->t_cnt || !pk->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (pk && nv && (!pk->var_rel_pos || !pk->var_type_zyg || !pk->a0_len || !pk->a1_len || !pk->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (mb && mb->n_regions && (!mb->start || !mb->end || !mb->in_off || !mb->in_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (mb && nv && (!mb->var_pos || !mb->var_type || !mb->var_zyg || !mb->a0_off || !mb->a0_len || !mb->a1_off || !mb->a1_len || !mb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (n > 0x7FFFFFFFull || nv > 0x7FFFFFFFull) return fail(ctx, AVK_E_ARG, "batch too large (more than 2^31 regions or variants); split it");
@@ -571,14 +643,15 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     if (cb && n && (!cb->start || !cb->len || !cb->v_off || !cb->t_cnt || !cb->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (cb && nv && (!cb->var_pos || !cb->var_type_zyg || !cb->a_off || !cb->a0_len || !cb->a1_len || !cb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (cb && alen > 0xFFFFFFFFull) return fail(ctx, AVK_E_ARG, "the compact form holds at most 2^32 allele bytes");
-    const bool has_contig = b ? b->contig_idx != nullptr : (cb ? cb->contig_idx != nullptr : mb->contig_idx != nullptr),
-               has_raw = b ? b->var_raw_space != nullptr : (cb ? cb->var_raw_space != nullptr : mb->var_raw_space != nullptr);
-    const uint8_t *host_alleles = b ? b->allele_bytes : (cb ? cb->allele_bytes : mb->allele_bytes);
+    const bool has_contig = pk ? pk->contig_idx != nullptr : (b ? b->contig_idx != nullptr : (cb ? cb->contig_idx != nullptr : mb->contig_idx != nullptr)),
+               has_raw = pk ? pk->var_raw_space != nullptr : (b ? b->var_raw_space != nullptr : (cb ? cb->var_raw_space != nullptr : mb->var_raw_space != nullptr));
+    const uint8_t *host_alleles = pk ? pk->allele_bytes : (b ? b->allele_bytes : (cb ? cb->allele_bytes : mb->allele_bytes));
     const bool timing = getenv("AVK_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
     const auto t_start = now();
     hipStream_t s = ctx->stream;
+    uint64_t *pk_totals = nullptr; /* packed form: device words {sum of the call counts, sum of the allele lengths} */
     avk_dev_batch *db = new avk_dev_batch();
     db->dev_packed = true;
     db->n_regions = n;
@@ -640,7 +713,43 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     if (!ctx->d_contig_tab && !rc) rc = fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     if (rc) return bail(rc);
     const auto t_alloc = now();
-    if (b) {
+    if (pk) { /* the packed arrays as they are, two prefix sums for the offsets they leave out, one kernel that writes the wide arrays */
+        uint16_t *p_contig = has_contig ? (uint16_t *)tmp((n + 1) * 2) : nullptr, *p_len = (uint16_t *)tmp((n + 1) * 2), *p_rel = (uint16_t *)tmp((nv + 1) * 2);
+        uint32_t *p_start = (uint32_t *)tmp((n + 1) * 4);
+        uint8_t *p_tc = (uint8_t *)tmp(n + 16), *p_qc = (uint8_t *)tmp(n + 16), *p_tz = (uint8_t *)tmp(nv + 16), *p_a0 = (uint8_t *)tmp(nv + 16), *p_a1 = (uint8_t *)tmp(nv + 16);
+        const uint32_t nb_r = (uint32_t)((n + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK), nb_v = (uint32_t)((nv + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK);
+        uint64_t *p_voff = (uint64_t *)tmp((n + 1) * 8), *p_aoff = (uint64_t *)tmp((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
+        if (rc) return bail(rc);
+        std::vector<CopySeg> segs = {{pk->start, p_start, n * 4}, {pk->len, p_len, n * 2}, {pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->contig_idx, p_contig, has_contig ? n * 2 : 0},
+                                     {pk->var_rel_pos, p_rel, nv * 2}, {pk->var_type_zyg, p_tz, nv}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv},
+                                     {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {pk->allele_bytes, d_alleles, alen}};
+        rc = copy_in(ctx, segs);
+        if (rc) return bail(rc);
+        if (n) {
+            hipLaunchKernelGGL(avk_ps_block_sums_kernel, dim3(nb_r), dim3(256), 0, s, (const uint8_t *)p_tc, (const uint8_t *)p_qc, n, p_sums);
+            hipLaunchKernelGGL(avk_ps_scan_sums_kernel, dim3(1), dim3(1024), 0, s, p_sums, nb_r, p_sums + nb_r + nb_v);
+            hipLaunchKernelGGL(avk_ps_apply_kernel, dim3(nb_r), dim3(256), 0, s, (const uint8_t *)p_tc, (const uint8_t *)p_qc, n, (const uint64_t *)p_sums, p_voff);
+        }
+        if (nv) {
+            hipLaunchKernelGGL(avk_ps_block_sums_kernel, dim3(nb_v), dim3(256), 0, s, (const uint8_t *)p_a0, (const uint8_t *)p_a1, nv, p_sums + nb_r);
+            hipLaunchKernelGGL(avk_ps_scan_sums_kernel, dim3(1), dim3(1024), 0, s, p_sums + nb_r, nb_v, p_sums + nb_r + nb_v + 1);
+            hipLaunchKernelGGL(avk_ps_apply_kernel, dim3(nb_v), dim3(256), 0, s, (const uint8_t *)p_a0, (const uint8_t *)p_a1, nv, (const uint64_t *)(p_sums + nb_r), p_aoff);
+        }
+        /* the totals must be what the caller said: n_variants calls, allele_bytes_len bytes (two words back, with the packer's state block) */
+        pk_totals = p_sums + nb_r + nb_v;
+        dpk::DpPacked c;
+        memset(&c, 0, sizeof(c));
+        c.contig_idx = p_contig, c.len = p_len, c.rel_pos = p_rel, c.start = p_start, c.var_raw = d_raw, c.t_cnt = p_tc, c.q_cnt = p_qc, c.var_type_zyg = p_tz, c.a0_len = p_a0, c.a1_len = p_a1,
+        c.v_off = p_voff, c.a_off = p_aoff, c.n_regions = n, c.n_variants = nv;
+        c.w_contig = d_contig, c.w_t_cnt = db->d_in_t_cnt, c.w_q_cnt = db->d_in_q_cnt, c.w_a0_len = d_a0l, c.w_a1_len = d_a1l, c.w_raw = nullptr, c.w_start = d_start, c.w_end = d_end,
+        c.w_t_off = db->d_in_t_off, c.w_q_off = db->d_in_q_off, c.w_pos = d_pos, c.w_a0_off = d_a0o, c.w_a1_off = d_a1o, c.w_type = d_type, c.w_zyg = d_zyg;
+        const uint64_t m = n > nv ? n : nv;
+        if (m) {
+            hipLaunchKernelGGL(avk_dp_widen_packed_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, c);
+            hipError_t ew = hipGetLastError();
+            if (ew != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ew)));
+        }
+    } else if (b) {
         std::vector<CopySeg> segs = {
             {b->start, d_start, n * 8}, {b->end, d_end, n * 8}, {b->t_off, db->d_in_t_off, n * 8}, {b->q_off, db->d_in_q_off, n * 8},
             {b->t_cnt, db->d_in_t_cnt, n * 4}, {b->q_cnt, db->d_in_q_cnt, n * 4}, {b->contig_idx, d_contig, b->contig_idx ? n * 4 : 0},
@@ -706,7 +815,9 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     { /* the calls this batch owns, guessed from its first and last region (batches of one job may share the call arrays: compare_main.cpp);
        * dp_region notes any region outside the guess */
         uint64_t lo = 0, hi = 0;
-        if (n && b) {
+        if (pk) {
+            hi = nv; /* the packed form owns its calls by construction */
+        } else if (n && b) {
             const uint64_t a0 = b->t_cnt[0] ? b->t_off[0] : b->q_off[0], a1 = b->q_cnt[0] ? b->q_off[0] : b->t_off[0];
             lo = a0 < a1 ? a0 : a1;
             const uint64_t e0 = b->t_off[n - 1] + b->t_cnt[n - 1], e1 = b->q_off[n - 1] + b->q_cnt[n - 1];
@@ -751,6 +862,19 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         return x;
     };
     if (e == hipSuccess) e = region_passes();
+    if (e == hipSuccess && pk) { /* the two sums the packed form implies must be what the caller says they are */
+        uint64_t tot[2] = {0, 0};
+        e = hipMemcpy(tot, pk_totals, sizeof(tot), hipMemcpyDeviceToHost);
+        if (e == hipSuccess && ((n && tot[0] != nv) || (nv && tot[1] != alen)))
+            return bail(fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to %llu (n_variants %llu), the allele lengths to %llu (allele_bytes_len %llu)",
+                             (unsigned long long)tot[0], (unsigned long long)nv, (unsigned long long)tot[1], (unsigned long long)alen));
+    }
+    std::vector<uint64_t> pk_aoff; /* packed form: allele offsets on the host, made only when a call needs the host's edit distance */
+    if (e == hipSuccess && hs->n_pending && pk) {
+        pk_aoff.resize(nv + 1);
+        uint64_t run = 0;
+        for (uint64_t v = 0; v < nv; ++v) pk_aoff[v] = run, run += (uint64_t)pk->a0_len[v] + pk->a1_len[v];
+    }
     if (e == hipSuccess && hs->n_pending) {
         /* calls whose two alleles are both long after the common prefix and suffix are gone: their alt_ed comes from the host
          * (avk_edit_distance, the routine the host-side packer uses for every call), and the region passes run again */
@@ -761,8 +885,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             avk_parallel_for(np, avk_host_threads(), [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t k = lo; k < hi; ++k) {
                     const uint64_t v = idx[k];
-                    const uint64_t o0 = b ? b->a0_off[v] : (cb ? cb->a_off[v] : mb->a0_off[v]), l0 = b ? b->a0_len[v] : (cb ? cb->a0_len[v] : mb->a0_len[v]),
-                                   o1 = b ? b->a1_off[v] : (cb ? o0 + l0 : mb->a1_off[v]), l1 = b ? b->a1_len[v] : (cb ? cb->a1_len[v] : mb->a1_len[v]);
+                    const uint64_t o0 = pk ? pk_aoff[v] : (b ? b->a0_off[v] : (cb ? cb->a_off[v] : mb->a0_off[v])), l0 = pk ? pk->a0_len[v] : (b ? b->a0_len[v] : (cb ? cb->a0_len[v] : mb->a0_len[v])),
+                                   o1 = pk ? o0 + l0 : (b ? b->a1_off[v] : (cb ? o0 + l0 : mb->a1_off[v])), l1 = pk ? pk->a1_len[v] : (b ? b->a1_len[v] : (cb ? cb->a1_len[v] : mb->a1_len[v]));
                     ed[k] = (uint32_t)avk::host_edit_distance(host_alleles + o0, l0, host_alleles + o1, l1);
                 }
             });

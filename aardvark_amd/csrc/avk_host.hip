@@ -2070,6 +2070,32 @@ int avk_batch_upload_compact(avk_ctx *ctx, const avk_compact_batch *batch, avk_d
     return upload_device_packed(ctx, nullptr, batch, false, out);
 }
 
+int avk_batch_upload_packed(avk_ctx *ctx, const avk_packed_batch *batch, avk_dev_batch **out) {
+    if (!ctx || !batch || !out) return AVK_E_ARG;
+    *out = nullptr;
+    if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    return upload_device_packed(ctx, nullptr, nullptr, false, out, nullptr, batch);
+}
+
+int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
+    if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
+    ctx->last_one_shot = 0;
+    avk_dev_batch *db = nullptr;
+    const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
+    if (!out->group_metrics) ctx->emit_group_metrics = 0;
+    if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
+    int rc = avk_batch_upload_packed(ctx, batch, &db);
+    if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
+    if (!rc) rc = avk_results_download(ctx, db, out);
+    ctx->emit_group_metrics = keep_gm, ctx->emit_bp_groups = keep_bp;
+    if (db) {
+        ctx->last_one_shot = 1;
+        avk_batch_free(ctx, db);
+    }
+    return rc;
+}
+
 int avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
     if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
     ctx->last_one_shot = 0;

@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--resident-steps", type=int, default=200, help="timed avk_compare_resident steps of the resident leg (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto", help="auto = strong for N > 1 (one call set sharded over the ranks)")
+    ap.add_argument("--form", choices=("packed", "compact"), default="packed", help="flat form of the region batch the timed calls hand over: packed (avk_packed_batch, 94 MB per genome) or compact (avk_compact_batch, 227 MB)")
     ap.add_argument("--pageable", action="store_true", help="caller arrays in ordinary memory (the library stages them through a pinned bounce buffer) instead of avk_host_alloc memory")
     ap.add_argument("--watchdog-seconds", type=int, default=900, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
     ap.add_argument("--no-supervisor", action="store_true",
@@ -215,16 +216,29 @@ def main():
     # ---- the timed steps: avk_compare_batch, host arrays -> host arrays
     # the caller's flat batch in the library's compact form (avk_compact_batch: 20 B per region + 17 B per call; the library widens it on the device),
     # the results in the arrays of avk_result_batch; both in pinned memory unless --pageable
-    from aardvark_amd import CompactBatch
-    hb = CompactBatch.from_region_batch(batch)
+    from aardvark_amd import CompactBatch, PackedBatch
+    cmp_b = CompactBatch.from_region_batch(batch)
+    # the form `value` is measured on: the packed one (avk_packed_batch: 10 B per region + 5 B per call + the allele bytes, offsets computed on the device) when
+    # the batch fits its narrow fields, else the compact one
+    form = args.form
+    if form == "packed":
+        try:
+            hb = PackedBatch.from_compact(cmp_b)
+        except ValueError:
+            form, hb = "compact", cmp_b
+    else:
+        hb = cmp_b
     wide = batch
     if not args.pageable:
-        hb, wide = ctx.pinned_compact(hb), ctx.pinned_batch(batch)
+        hb, wide = (ctx.pinned_packed(hb) if form == "packed" else ctx.pinned_compact(hb)), ctx.pinned_batch(batch)
+        cmp_b = ctx.pinned_compact(cmp_b) if form == "packed" else hb
     res = ResultBatch(hb, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(hb)
     cb, ro = hb.c_struct(), res.c_struct()
+    entry_point = ctx.lib.avk_compare_packed if form == "packed" else ctx.lib.avk_compare_compact
+    entry_name = "avk_compare_packed" if form == "packed" else "avk_compare_compact"
 
     def step():
-        ctx._check(ctx.lib.avk_compare_compact(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
+        ctx._check(entry_point(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
 
     job_tally_host = np.zeros(aardvark_amd.TALLY_LEN, np.uint64)
     tally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
@@ -251,9 +265,30 @@ def main():
         total_regions = int(cnt.item())
     else:
         total_regions = n_regions
-    log("timed region: %d avk_compare_compact calls in %.3f s (%.2f ms per call)" % (args.steps, elapsed, elapsed / max(args.steps, 1) * 1e3))
+    log("timed region: %d %s calls in %.3f s (%.2f ms per call)" % (args.steps, entry_name, elapsed, elapsed / max(args.steps, 1) * 1e3))
     job_tally = tally.clone()
     got_boundary = res  # the outputs of the last timed call, in the caller's arrays
+    # the same boundary with the batch in the compact form (avk_compact_batch: 20 B per region + 17 B per call, explicit offsets), when `value` is on the packed one
+    compact_entry = None
+    if form == "packed":
+        cres = ResultBatch(cmp_b, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(cmp_b)
+        ccb, cro = cmp_b.c_struct(), cres.c_struct()
+        ctx._check(ctx.lib.avk_compare_compact(ctx.handle, C.byref(ccb), C.byref(ccfg), C.byref(cro)))
+        n_c = max(3, min(args.steps, 20))
+        fence()
+        tc0 = time.perf_counter()
+        for _ in range(n_c):
+            ctx._check(ctx.lib.avk_compare_compact(ctx.handle, C.byref(ccb), C.byref(ccfg), C.byref(cro)))
+        fence()
+        c_elapsed = time.perf_counter() - tc0
+        if world > 1:
+            t = torch.tensor([c_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            c_elapsed = float(t.item())
+        same = cres.diff(res) == []
+        compact_entry = {"value": total_regions * n_c / c_elapsed, "unit": "regions/s", "ms_per_step": c_elapsed / n_c * 1e3, "steps": n_c, "host_bytes_in_per_step": cmp_b.nbytes(),
+                         "same_outputs_as_value_leg": same, "what": "the same boundary with the batch in the compact form (avk_compact_batch through avk_compare_compact)"}
+        del cres
     # the same boundary with the batch in the WIDE structure-of-arrays form (avk_region_batch: 52 B per region + 38 B per call over PCIe)
     wres = ResultBatch(wide, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(wide)
     wcb, wro = wide.c_struct(), wres.c_struct()
@@ -383,9 +418,9 @@ def main():
             "dtype": "u8",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2] stand-in: HG002-scale SNV+indel compare, 24 contigs of GRCh38 primary lengths x %.3g (%d bases), "
-                                   "%d regions in the job (%d on rank 0), %d calls on rank 0; seeds 20250103/4; one step = one avk_compare_compact call, region batch (compact flat form) and "
+                                   "%d regions in the job (%d on rank 0), %d calls on rank 0; seeds 20250103/4; one step = one %s call, region batch (%s flat form) and "
                                    "results in %s host memory (the reference loop's boundary, src/main.rs:251-268), H2D and D2H inside the timed region"
-                                   % (args.scale, sum(c.size for c in contigs), n_job_regions if scaling == "strong" else total_regions, n_regions, batch.n_variants,
+                                   % (args.scale, sum(c.size for c in contigs), n_job_regions if scaling == "strong" else total_regions, n_regions, batch.n_variants, entry_name, form,
                                       "pageable" if args.pageable else "pinned (avk_host_alloc)"),
                        "regions_per_gpu": n_regions, "max_branch_factor": cfg.max_branch_factor, "min_variant_gap": 50,
                        "host_bytes_in_per_step": in_bytes, "host_bytes_out_per_step": out_bytes,
@@ -396,6 +431,7 @@ def main():
                        "parity": parity, "workspace_tiers": tiers, "lane_kernel_regions": lane_regions},
             "resident_value": resident["value"] if resident else None,
             "resident": resident,
+            "compact_soa": compact_entry,
             "wide_soa": {"value": total_regions * n_wide / wide_elapsed, "unit": "regions/s", "ms_per_step": wide_elapsed / n_wide * 1e3, "steps": n_wide, "host_bytes_in_per_step": wide_bytes,
                          "what": "the same boundary with the batch in the wide structure-of-arrays form (avk_region_batch through avk_compare_batch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

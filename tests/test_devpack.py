@@ -219,3 +219,31 @@ def test_compact_form_round_trip():
     with pytest.raises(ValueError):
         CompactBatch.from_region_batch(RegionBatch(bad.region_id, bad.contig_idx, bad.start, bad.end, bad.t_off, bad.t_cnt, bad.q_off + 1, bad.q_cnt, bad.var_pos, bad.var_type, bad.var_zyg,
                                                    bad.var_raw_space, bad.a0_off, bad.a0_len, bad.a1_off, bad.a1_len, bad.allele_bytes))
+
+
+def test_packed_form_round_trip_and_constraints():
+    """PackedBatch.from_compact: the offsets the packed form leaves out are exactly the running sums of its counts and lengths; batches that break a constraint
+    (calls out of region order, an allele of 256 bases, a window of 65,536) have no packed form"""
+    from aardvark_amd import CompactBatch, PackedBatch, synth
+    contig, batch = synth.config_indel_mix_v2(n_truth=3000, contig_len=1_500_000)
+    cb = CompactBatch.from_region_batch(batch)
+    pk = PackedBatch.from_compact(cb)
+    assert pk.n_regions == cb.n_regions and pk.n_variants == cb.n_variants and pk.nbytes() < 0.5 * cb.nbytes()
+    cnt = pk.t_cnt.astype(np.int64) + pk.q_cnt
+    assert np.array_equal(np.concatenate([[0], np.cumsum(cnt)])[:-1], cb.v_off)
+    assert np.array_equal(np.repeat(pk.start.astype(np.int64), cnt) + pk.var_rel_pos, cb.var_pos)
+    assert np.array_equal(np.concatenate([[0], np.cumsum(pk.a0_len.astype(np.int64) + pk.a1_len)])[:-1], cb.a_off)
+    import copy
+    for breaker in ("v_off", "a0_len", "len"):
+        c2 = copy.deepcopy(cb)
+        if breaker == "v_off":
+            c2.v_off = c2.v_off.copy()
+            c2.v_off[3], c2.v_off[4] = c2.v_off[4], c2.v_off[3]
+        elif breaker == "a0_len":
+            c2.a0_len = c2.a0_len.copy()
+            c2.a0_len[7] = 256
+        else:
+            c2.len = c2.len.copy()
+            c2.len[2] = 65536
+        with pytest.raises(ValueError):
+            PackedBatch.from_compact(c2)

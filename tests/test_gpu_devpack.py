@@ -213,6 +213,54 @@ def test_compact_form(ctx_pair, oracle):
         assert dev.solve_compact(c2, res=None).diff(oracle_lib.compare_batch(oracle, b, contigs, threads=CPUS, group_metrics=False)) == []
 
 
+def test_packed_form(ctx_pair, oracle):
+    """avk_compare_packed (10 + 5 bytes per region / call and the allele bytes; offsets from two prefix sums on the device) == avk_compare_compact == oracle;
+    pageable and pinned, with and without raw_allele_space and contig indices, BASEPAIR groups, several contigs, odd inputs, totals that do not add up"""
+    import aardvark_amd
+    from aardvark_amd import CompactBatch, PackedBatch
+    dev = ctx_pair[0]
+    contig, batch = synth.config_indel_mix_v2(n_truth=40_000, contig_len=16_000_000)
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=False)
+    dev.upload_reference([contig])
+    cb = CompactBatch.from_region_batch(batch)
+    pk = PackedBatch.from_compact(cb)
+    assert pk.nbytes() < 0.5 * cb.nbytes()
+    got = dev.solve_packed(pk)
+    assert got.diff(want) == [] and np.array_equal(got.tally, want.tally)
+    pp = dev.pinned_packed(pk)
+    res = dev.pinned_results(pp, bp_groups=True)
+    ref = dev.solve_compact(cb, res=aardvark_amd._abi.ResultBatch(cb, sequences=False, group_metrics=False, bp_groups=True))
+    for _ in range(2):
+        res.status[:] = -3
+        assert dev.solve_packed(pp, res=res).diff(want) == []
+        assert np.array_equal(res.bp_off, ref.bp_off) and np.array_equal(res.bp_groups[:res.bp_off[-1]], ref.bp_groups[:ref.bp_off[-1]])
+    assert dev.solve_packed(PackedBatch.from_compact(CompactBatch.from_region_batch(batch, keep_raw_space=True))).diff(want) == []
+    # several contigs and more prefix-sum workgroups than one scan round (a quarter of a genome: 0.9 M regions, 2 M calls)
+    contigs, b = synth.config_genome(scale=0.25)
+    dev.upload_reference(contigs)
+    c4 = CompactBatch.from_region_batch(b)
+    assert dev.solve_packed(PackedBatch.from_compact(c4)).diff(dev.solve_compact(c4)) == []
+    # odd inputs: invalid regions, other symbols, long alleles (over 255 bases: no packed form)
+    n_packed = 0
+    for sc in (scenarios.invalid_regions(), scenarios.non_acgt_regions(), scenarios.long_allele_regions(), scenarios.fuzz_regions(362, 1500, max_vars=7)):
+        contigs, b = sc[0], sc[1]
+        try:
+            p2 = PackedBatch.from_compact(CompactBatch.from_region_batch(b))
+        except ValueError:
+            continue
+        n_packed += 1
+        dev.upload_reference(contigs)
+        assert dev.solve_packed(p2).diff(oracle_lib.compare_batch(oracle, b, contigs, threads=CPUS, group_metrics=False)) == []
+    assert n_packed >= 1
+    # a batch whose counts do not add up to n_variants is refused, not read out of bounds
+    bad = PackedBatch.from_compact(cb)
+    bad.t_cnt = bad.t_cnt.copy()
+    bad.t_cnt[5] += 1
+    with pytest.raises(aardvark_amd.AardvarkAmdError):
+        dev.upload_reference([contig])
+        dev.solve_packed(bad)
+
+
 def test_merge_of_three_call_sets_at_genome_density(oracle):
     """configs[4] at the size of one contig: three perturbed call sets of one chr20-sized contig at the benchmark's density through avk_merge_batch (pair
     expansion, pair solve and classification on the device) against oracle pairs + the restated rule; every strategy on a slice"""
