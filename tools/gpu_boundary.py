@@ -43,6 +43,23 @@ for name in ("pageable", "pinned"):
         ts.append((time.perf_counter() - t) * 1e3)
     print("%s compact arrays (%.0f MB in): avk_compare_compact %s ms -> best %.1f M regions/s, mean %.1f; identical to the resident path: %s" %
           (name, cbt.nbytes() / 1e6, " ".join("%.2f" % x for x in ts), batch.n_regions / min(ts) / 1e3, batch.n_regions / np.mean(ts) / 1e3, res.diff(want) == []), flush=True)
+# the packed form (avk_packed_batch): offsets implied by order, computed on the device
+from aardvark_amd import PackedBatch
+for name in ("pageable", "pinned"):
+    pk = PackedBatch.from_compact(CompactBatch.from_region_batch(batch))
+    if name == "pinned":
+        pk = ctx.pinned_packed(pk)
+    res = ResultBatch(pk, sequences=False, group_metrics=False) if name == "pageable" else ctx.pinned_results(pk)
+    pc, ro = pk.c_struct(), res.c_struct()
+    ctx._check(ctx.lib.avk_compare_packed(ctx.handle, C.byref(pc), C.byref(ccfg), C.byref(ro)))
+    ts = []
+    for _ in range(calls):
+        t = time.perf_counter()
+        ctx._check(ctx.lib.avk_compare_packed(ctx.handle, C.byref(pc), C.byref(ccfg), C.byref(ro)))
+        ts.append((time.perf_counter() - t) * 1e3)
+    print("%s packed arrays (%.0f MB in): avk_compare_packed %s ms -> best %.1f M regions/s, mean %.1f; identical to the resident path: %s" %
+          (name, pk.nbytes() / 1e6, " ".join("%.2f" % x for x in ts), batch.n_regions / min(ts) / 1e3, batch.n_regions / np.mean(ts) / 1e3, res.diff(want) == []), flush=True)
+    del pk, res
 # the same call with the compact per-region BASEPAIR groups written too (16 B x (1 + call types) per region)
 cbt = ctx.pinned_compact(CompactBatch.from_region_batch(batch))
 res = ctx.pinned_results(cbt, bp_groups=True)
