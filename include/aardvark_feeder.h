@@ -31,8 +31,8 @@ typedef struct avf_feed avf_feed;
 /* error text of the last failed call on this thread */
 const char *avf_last_error(void);
 
-/* FASTA (plain or gzip/BGZF): contig name = header up to the first white space, sequence bytes as they are in
- * the file (no case folding). */
+/* FASTA (plain or gzip/BGZF): contig name = header up to the first white space; the sequence bytes with a-z folded to A-Z (the default of this
+ * build, see avf_genome_load_case below — NOT the file's raw bytes: that is avf_genome_load_case(path, 0, out)). */
 int avf_genome_load(const char *fasta_path, avf_genome **out); /* = avf_genome_load_case(path, 1, out) */
 /* Case of the reference bases.  ReferenceGenome::from_fasta lives in a crate that is not vendored with the reference
  * (rust-lib-reference-genome 0.2.1; its dependencies are bio, flate2, log, rustc-hash, simple-error — Cargo.lock:1344-1353), so whether it
