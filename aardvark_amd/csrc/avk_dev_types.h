@@ -140,6 +140,7 @@ AVK_TYPES_HD uint32_t avk_head_slots(uint32_t maxv, uint32_t n_fast, uint32_t n_
  * back for its node cap is one of them, and the launch for handed-back regions starts behind that head, beside the rest of the class */
 #define AVK_HET_HEAD_MIN 4
 
+#define AVK_CAP_BOUND_ONLY 0x80000000u /* flag in AvkTier::ed_cap: the cap is only taken by regions whose own bound is below it (avk_solver.inl) */
 /* capacities of one workspace tier */
 struct AvkTier {
     uint64_t ws_bytes; /* bytes of workspace per wave in this tier */

@@ -594,6 +594,9 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
             /* how large an HBM slice the region is predicted to want (no edit-distance cap there): the host sizes the per-wave slices of the batch's
              * launches by the distribution — large windows (--min-variant-gap 1000) outgrow the default 1 MB by the thousand, and the shared big
              * slices serialise whatever overflows */
+            /* (priced with two wavefront entries per base although the tier sizes the fronts by the region's bound since round 3 — hbm_ed_cap: the search of a
+             * large window keeps many more nodes alive than the 6 N counted here, and the generous slice is what holds them; priced by the real fronts, 417 instead
+             * of 10 of 49 k large-window regions went on to the shared big slices and the step took 1.6 instead of 1.2 s) */
             const u64 need2 = dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, 0u, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch);
             u32 b = 0;
             while (b + 1 < DP_NEED_BUCKETS && need2 > (1ull << (20 + b))) ++b;

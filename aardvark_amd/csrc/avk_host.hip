@@ -297,6 +297,8 @@ struct avk_ctx {
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
+    int64_t hbm_ed_cap = 1024;                        /* the per-wave HBM slices size a region's wavefronts by the region's own bound (the sum of its calls' edit distances) when that is at most this;
+                                                         0: two entries per base of the window for every region (rounds 1-2).  Large windows: 1.64 -> 1.21 s per 49 k-region step, whole genome -3 % */
     int64_t early_lds = 0;                            /* 1: what the three-call lane class hands back goes through the LDS tier first (run_internal) */
     int64_t het_search_min = AVK_HET_SEARCH_MIN;      /* regions with at least this many unphased heterozygous calls go to class C and stay out of the three-call lane class (0 = no such rule) */
     int64_t lane_head_est = 1;                        /* regions with at least this many estimated edits (fast_cost_key) form the narrow-tiled head of their lane class */
@@ -680,6 +682,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_metrics_ed_cap") {
         if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
         ctx->lane_metrics_ed_cap = value;
+    } else if (n == "hbm_ed_cap") {
+        if (value < 0 || value > 1000000) return fail(ctx, AVK_E_ARG, "hbm_ed_cap must be 0..1000000");
+        ctx->hbm_ed_cap = value;
     } else if (n == "early_lds") {
         ctx->early_lds = value ? 1 : 0;
     } else if (n == "het_search_min") {
@@ -1222,7 +1227,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.tier[1].ws_bytes = (uint64_t)ctx->lds2_bytes_per_wave;
     a.tier[1].ed_cap = (uint32_t)ctx->lds2_ed_cap;
     a.tier[2].ws_bytes = (uint64_t)ws_bytes;
-    a.tier[2].ed_cap = 0;
+    a.tier[2].ed_cap = ctx->hbm_ed_cap > 0 ? ((uint32_t)ctx->hbm_ed_cap | AVK_CAP_BOUND_ONLY) : 0u;
     a.tier[3].ws_bytes = (uint64_t)ctx->big_ws_bytes;
     a.tier[3].ed_cap = 0;
     a.region_out = db->d_region_out;

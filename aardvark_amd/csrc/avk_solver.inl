@@ -1247,10 +1247,15 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     const u32 maxT = c.T > c.Q ? c.T : c.Q;
     c.alw = maxT ? (maxT + 63) >> 6 : 1;
     const u32 wf_full = 2 * c.seqcap + 4;
-    u32 cap = ed_cap; /* LDS tiers: the region's own bound when it is lower than the tier's cap (AvkDevRegion::ed_bound) */
+    /* LDS tiers: the region's own bound when it is lower than the tier's cap (AvkDevRegion::ed_bound: the sum of its calls' edit distances — no haplotype
+     * pair of the region can be further apart), else the tier's cap, beyond which the region goes on to the next tier.  HBM per-wave slices
+     * (AVK_CAP_BOUND_ONLY): the region's own bound when the tier's cap covers it, otherwise NO cap — a region is never sent on to the few shared big slices
+     * for its wavefronts.  Either way the front gets 2 cap + 2 entries instead of two per base of the window: a node of a 3 kbp window is 20 KB instead of 100. */
+    u32 cap = ed_cap & ~(u32)AVK_CAP_BOUND_ONLY;
     if (cap) {
         const u32 b = wv_uni(reg.ed_bound);
         if (b < cap) cap = b ? b : 1u;
+        else if (ed_cap & (u32)AVK_CAP_BOUND_ONLY) cap = 0;
     }
     c.wfcap = cap ? (2 * cap + 2) : wf_full; /* even */
     if (c.wfcap > wf_full) c.wfcap = wf_full;

@@ -203,6 +203,7 @@ void lane_main(void *p, int /*lane*/) {
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
  * device functions, the workgroup-level plumbing (histogram, scans, scatter) as plain loops */
 uint64_t g_last_pair_regions = 0; /* emu_last_pair_regions: regions of the last emulated call that went through the lookup of avk_pairs.inl */
+uint32_t g_hbm_ed_cap = 1024; /* emu_set_hbm_ed_cap: context option hbm_ed_cap */
 int g_lane_pairs = 1; /* emu_set_lane_pairs: context option lane_pairs (regions with the same SNV on both sides are looked up, avk_pairs.inl) */
 uint32_t g_stripe_w = 0; /* emu_set_stripe: claim width the heads of the lane classes are dealt out over (context option lane_stripe; 0 = sorted order) */
 int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
@@ -409,7 +410,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.tier[1].ws_bytes = lds2_bytes;
     a.tier[1].ed_cap = lds2_ed_cap;
     a.tier[2].ws_bytes = ws_bytes;
-    a.tier[2].ed_cap = 0;
+    a.tier[2].ed_cap = g_hbm_ed_cap ? (g_hbm_ed_cap | AVK_CAP_BOUND_ONLY) : 0u;
     a.tier[3].ws_bytes = big_ws_bytes;
     a.tier[3].ed_cap = 0;
     a.region_out = rout.data();
@@ -952,6 +953,7 @@ void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_stripe(uint32_t w) { g_stripe_w = w; }
 void emu_set_lane_pairs(int on) { g_lane_pairs = on; }
+void emu_set_hbm_ed_cap(uint32_t cap) { g_hbm_ed_cap = cap; }
 uint64_t emu_last_pair_regions() { return g_last_pair_regions; }
 
 /* The device-side packer against the host-side one on the same batch: every region record, every blob, the plan, the work order and the fast
