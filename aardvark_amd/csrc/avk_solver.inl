@@ -609,9 +609,37 @@ AVK_DEV void node_free(Ctx &c, u32 idx) {
     c.nfree += 1;
     wv_sync();
 }
-AVK_DEV void node_copy(const Ctx &c, u32 dst, u32 src) {
+/* A haplotype record's bytes that mean something: header and allele sets, the front's 2 ed + 1 entries, the two sequences up to their lengths.  A record is laid
+ * out for the window's worst case (two sequence capacities, a front of the tier's cap); in a window of kilobases that is 10-20 KB of which a node early in the
+ * search uses a few hundred bytes.  Records over AVK_COPY_USED_MIN bytes are copied this way (one more round trip for the three header words, far fewer bytes). */
+#ifndef AVK_COPY_USED_MIN
+#define AVK_COPY_USED_MIN 2048u
+#endif
+AVK_DEV void hap_copy_used(const Ctx &c, u8 *dst, const u8 *src, u32 wfcap) {
+    u32 w[5];
+    ldvec_u<5>((const u32 *)src + H_T_LEN, w); /* t_len, q_len, t_skip, q_skip, ed: consecutive header words */
+    const u32 t_len = w[0], q_len = w[1], ed = w[4];
+    const u32 front = H_WORDS + 4u * c.alw; /* words: header, two allele sets */
+    u32 nwf = 2u * ed + 1u;
+    if (nwf > wfcap) nwf = wfcap;
+    const u32 *s32 = (const u32 *)src;
+    u32 *d32 = (u32 *)dst;
+    copy_words(d32, s32, front + nwf);
+    const u32 seq_w = front + wfcap; /* first word of tseq */
+    copy_words(d32 + seq_w, s32 + seq_w, (t_len + 3u) >> 2);
+    copy_words(d32 + seq_w + (c.seqcap >> 2), s32 + seq_w + (c.seqcap >> 2), (q_len + 3u) >> 2);
+}
+AVK_DEV void node_copy(const Ctx &c, u32 dst, u32 src, bool phase_a = true) {
     wv_sync();
-    copy_words((u32 *)node_at(c, dst), (const u32 *)node_at(c, src), c.node_bytes >> 2);
+    const u32 rec = phase_a ? c.hapA_bytes : c.hapB_bytes;
+    if (rec < (u32)AVK_COPY_USED_MIN) copy_words((u32 *)node_at(c, dst), (const u32 *)node_at(c, src), c.node_bytes >> 2);
+    else {
+        u8 *d = node_at(c, dst);
+        const u8 *s = node_at(c, src);
+        copy_words((u32 *)d, (const u32 *)s, NODE_HDR >> 2);
+        hap_copy_used(c, d + NODE_HDR, s + NODE_HDR, phase_a ? c.wfcap : 2u);
+        if (phase_a) hap_copy_used(c, d + NODE_HDR + rec, s + NODE_HDR + rec, c.wfcap);
+    }
     wv_sync();
 }
 AVK_DEV int queue_push(Ctx &c, u64 key, u32 slot) {
@@ -724,7 +752,8 @@ AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
  * records swapped.  Pure reuse of results: ids, costs and pop order are untouched. */
 AVK_DEV void hap_record_copy(const Ctx &c, u8 *dst, const u8 *src) {
     wv_sync();
-    copy_words((u32 *)dst, (const u32 *)src, c.hapA_bytes >> 2);
+    if (c.hapA_bytes < (u32)AVK_COPY_USED_MIN) copy_words((u32 *)dst, (const u32 *)src, c.hapA_bytes >> 2);
+    else hap_copy_used(c, dst, src, c.wfcap);
     wv_sync();
 }
 AVK_DEV int nodeA_extend(const Ctx &c, u32 idx, bool is_truth, const UVar &v, u32 a1, u32 a2, u32 sync) {
@@ -1017,7 +1046,7 @@ AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32
             if (do_alt) { /* clone for the REF child, keep the popped node for the ALT child */
                 const int c1 = node_alloc(c);
                 if (c1 < 0) return RS_OVERFLOW;
-                node_copy(c, (u32)c1, ni);
+                node_copy(c, (u32)c1, ni, false);
                 ref_node = (u32)c1;
             }
             st32((u32 *)node_at(c, ref_node), next_id);

@@ -146,3 +146,23 @@ def test_class_c_list_shared_between_the_hbm_launches(oracle, monkeypatch):
             assert got.diff(want) == []
             seen.add(got.tier_counts[2])
     assert max(seen) >= 50 and min(seen) < 20  # (regions of the lane-per-region classes are never predicted into the HBM list)
+
+
+def test_large_windows_with_many_calls(oracle):
+    """--min-variant-gap 1000 (windows of kilobases, a dozen and more calls per region): the searches run in the HBM tier, whose node records are large enough
+    for the copies of their used part only (hap_copy_used) and whose wavefronts are sized by the region's own bound (hbm_ed_cap)"""
+    import ctypes as C
+    from aardvark_amd import synth
+    contigs, batch = synth.config_genome(scale=0.0002, threads=2, gap=1000)
+    assert batch.n_regions >= 20 and int((batch.end - batch.start).max()) > 2000 and int((batch.t_cnt + batch.q_cnt).max()) >= 12
+    want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
+    lib = emu_lib.load()
+    lib.emu_set_hbm_ed_cap.argtypes = [C.c_uint32]
+    try:
+        for cap in (1024, 8):  # (8: most regions' bounds are above it — those keep two entries per base, as with 0)
+            lib.emu_set_hbm_ed_cap(cap)
+            got = emu_lib.compare_batch(batch, contigs, threads=EMU_THREADS, lane_kernel=False, big_ws_bytes=512 << 20)  # (one region of 52 calls in 11 kbp wants 300 MB)
+            assert got.diff(want) == [], cap
+            assert got.tier_counts[2] + got.tier_counts[3] > 0.5 * batch.n_regions
+    finally:
+        lib.emu_set_hbm_ed_cap(1024)
