@@ -7,7 +7,8 @@ assert "phasetiming" in os.environ.get("AVK_LIB", "")
 import aardvark_amd
 from aardvark_amd import synth, CompareConfig
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
-contigs, batch = synth.config_genome(scale=scale)
+gap = int(os.environ.get("GAP", "50"))  # GAP=1000: the large-window workload of bench.py's secondary leg (use scale 0.05)
+contigs, batch = synth.config_genome(scale=scale, gap=gap) if gap != 50 else synth.config_genome(scale=scale)
 ctx = aardvark_amd.Context(0)
 ctx.set_option("emit_group_metrics", 0)
 for kv in (sys.argv[2] if len(sys.argv) > 2 else "").split(","):
