@@ -72,3 +72,18 @@ def test_two_rank_sharding_and_tally_allreduce(tmp_path, oracle):
     assert avk_dist.result_checksum(batch, broken) != whole  # one flipped decision changes the checksum
     sizes = [len(np.load(tmp_path / ("idx_%d.npy" % r))) for r in range(world)]
     assert abs(sizes[0] - sizes[1]) < 0.1 * batch.n_regions  # the hash balances the shards
+
+
+def test_shards_have_the_packed_form():
+    """bench.py --scaling strong hands every rank's shard over in the packed form (avk_packed_batch): gather_calls leaves a shard's calls and alleles back to back in
+    region order, which is all that form asks for"""
+    from aardvark_amd import CompactBatch, PackedBatch, synth
+    from aardvark_amd import dist as avk_dist
+    contigs, batch = synth.config_genome(scale=0.004)
+    seen = 0
+    for rank in range(3):
+        shard = avk_dist.gather_calls(avk_dist.shard_batch(batch, rank, 3))
+        pk = PackedBatch.from_compact(CompactBatch.from_region_batch(shard))
+        assert pk.n_regions == shard.n_regions and pk.n_variants == shard.n_variants
+        seen += pk.n_regions
+    assert seen == batch.n_regions
