@@ -63,9 +63,9 @@ def usable_cpus():
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50, help="timed avk_compare_batch calls (host arrays -> host arrays)")
+    ap.add_argument("--steps", type=int, default=100, help="timed avk_compare_batch calls (host arrays -> host arrays)")
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--resident-steps", type=int, default=200, help="timed avk_compare_resident steps of the resident leg (0 = skip)")
+    ap.add_argument("--resident-steps", type=int, default=300, help="timed avk_compare_resident steps of the resident leg (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto", help="auto = strong for N > 1 (one call set sharded over the ranks)")
     ap.add_argument("--form", choices=("packed", "compact"), default="packed", help="flat form of the region batch the timed calls hand over: packed (avk_packed_batch, 94 MB per genome) or compact (avk_compact_batch, 227 MB)")
