@@ -36,7 +36,7 @@ void usage() {
             "  [--truth-sample S] [--query-sample S] [--compare-label L] [--min-variant-gap 50] [--disable-variant-trimming]\n"
             "  [--reference-case upper|raw]  (default upper: soft-masked reference bases are compared as upper case)\n"
             "  [--max-branch-factor 50] [--enable-exact-shortcut] [--enable-haplotype-metrics] [--enable-weighted-haplotype-metrics]\n"
-            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0 | --devices 0,1,..] [--batch-regions 4000000]\n");
+            "  [--enable-record-basepair-metrics] [-s STRAT.tsv] [--output-debug DIR] [--skip N] [--take N] [--device 0 | --devices 0,1,..] [--batch-regions 4000000] [--batch-form packed|wide]\n");
 }
 
 std::string json_string(const std::string &s) {
@@ -80,7 +80,7 @@ int main(int argc, char **argv) {
     bool ref_upper = true; /* --reference-case upper|raw (include/aardvark_feeder.h, avf_genome_load_case) */
     int device = 0;
     std::vector<int> devices; /* --devices: the contexts that share the region batches (the first one is `device`) */
-    bool batch_given = false;
+    bool batch_given = false, want_packed = true;
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * {
@@ -124,6 +124,11 @@ int main(int argc, char **argv) {
                 if (e == std::string::npos) break;
                 b = e + 1;
             }
+        }
+        else if (a == "--batch-form") { /* packed (default; wide when the call set does not fit the form, or with --output-debug) | wide */
+            const std::string v = val();
+            if (v != "packed" && v != "wide") die(78, "--batch-form must be 'packed' or 'wide'", "");
+            want_packed = v == "packed";
         }
         else if (a == "--threads") threads = strtoull(val(), nullptr, 10);          /* accepted for command-line compatibility */
         else if (a == "--max-edit-distance") max_ed = strtoull(val(), nullptr, 10); /* hidden in the reference as well, unused by it */
@@ -263,6 +268,40 @@ int main(int argc, char **argv) {
     fprintf(stderr, "Loaded %llu truth and %llu query variants; %llu regions.\n", (unsigned long long)avf_feed_loaded_variants(feed, 0),
             (unsigned long long)avf_feed_loaded_variants(feed, 1), (unsigned long long)all->n_regions);
 
+    /* the feed in the library's packed form (10 bytes per region, 5 per call + allele bytes over PCIe instead of 479 MB per whole genome); the wide arrays
+     * stay for the writers.  Ordinary memory: pinning it would cost more than the one pass through the library's bounce buffer it saves. */
+    avk_packed_batch packed_all;
+    bool packed = false;
+    if (want_packed && debug_dir.empty()) {
+        const int rc_pack = avf_feed_pack(feed, [](void *, size_t bytes) { return malloc(bytes); }, nullptr, &packed_all);
+        if (rc_pack < 0) die(70, "cannot pack the region batch", avf_last_error());
+        packed = rc_pack == 0;
+        if (!packed && verbosity) fprintf(stderr, "The call set does not fit the packed batch form (window, call count or allele length limits): using the wide form.\n");
+    }
+    /* regions [first + at, +n): as a batch in the chosen form; `out` is indexed by the feed's call arrays either way */
+    auto out_for = [](avk_result_batch out, uint64_t v_first) { /* a packed part's results are indexed from its first call */
+        if (out.var_expected) out.var_expected += v_first;
+        if (out.var_observed) out.var_observed += v_first;
+        if (out.var_class) out.var_class += v_first;
+        if (out.var_zyg) out.var_zyg += v_first;
+        return out;
+    };
+    auto compare_part = [&](avk_ctx *c, const avk_region_batch &b, uint64_t at_abs, uint64_t n, const avk_compare_config &cfg, const avk_result_batch &out) -> int {
+        if (!packed) return avk_compare_batch(c, &b, &cfg, const_cast<avk_result_batch *>(&out));
+        avk_packed_batch part;
+        uint64_t v_first = 0;
+        if (avf_packed_slice(feed, &packed_all, at_abs, n, &part, &v_first)) return AVK_E_ARG;
+        avk_result_batch shifted = out_for(out, v_first);
+        return avk_compare_packed(c, &part, &cfg, &shifted);
+    };
+    auto upload_part = [&](avk_ctx *c, const avk_region_batch &b, uint64_t at_abs, uint64_t n, avk_dev_batch **db, uint64_t *v_first) -> int {
+        *v_first = 0;
+        if (!packed) return avk_batch_upload(c, &b, db);
+        avk_packed_batch part;
+        if (avf_packed_slice(feed, &packed_all, at_abs, n, &part, v_first)) return AVK_E_ARG;
+        return avk_batch_upload_packed(c, &part, db);
+    };
+
     /* --skip / --take select regions by position in the iterator (src/main.rs:215-231) */
     const uint64_t first = skip < all->n_regions ? skip : all->n_regions;
     uint64_t count = all->n_regions - first;
@@ -372,12 +411,14 @@ int main(int argc, char **argv) {
                         break;
                     }
                     avk_dev_batch *db = nullptr;
-                    rc = avk_batch_upload(my, &b, &db);
+                    uint64_t v_first = 0;
+                    rc = upload_part(my, b, first + at, n, &db, &v_first);
                     if (!rc) rc = avk_compare_resident(my, db, &cfg, nullptr);
-                    if (!rc) rc = avk_results_download(my, db, &out);
+                    avk_result_batch shifted = out_for(out, v_first);
+                    if (!rc) rc = avk_results_download(my, db, &shifted);
                     if (!rc) rc = avk_label_tallies(my, db, n_labels, label_off.data(), label_idx.data(), w_strat[w].data());
                     if (db) avk_batch_free(my, db);
-                } else rc = avk_compare_batch(my, &b, &cfg, &out);
+                } else rc = compare_part(my, b, first + at, n, cfg, out);
                 if (rc) {
                     worker_err[w] = std::string("compare failed: ") + avk_last_error(my);
                     break;
@@ -453,15 +494,17 @@ int main(int argc, char **argv) {
                 }
             });
             avk_dev_batch *db = nullptr;
-            int rc = avk_batch_upload(ctx, &b, &db);
+            uint64_t v_first = 0;
+            int rc = upload_part(ctx, b, first + at, n, &db, &v_first);
             if (!rc) rc = avk_compare_resident(ctx, db, &cfg, nullptr);
-            if (!rc) rc = avk_results_download(ctx, db, &out);
+            avk_result_batch shifted = out_for(out, v_first);
+            if (!rc) rc = avk_results_download(ctx, db, &shifted);
             th_labels.join();
             if (rc) die(70, "compare failed", avk_last_error(ctx));
             if (rc_labels) die(70, "cannot list the region labels", avf_last_error());
             if (avk_label_tallies(ctx, db, n_labels, label_off.data(), label_idx.data(), strat_total.data())) die(70, "stratified tallies failed", avk_last_error(ctx));
             avk_batch_free(ctx, db);
-        } else if (avk_compare_batch(ctx, &b, &cfg, &out)) die(70, "compare failed", avk_last_error(ctx));
+        } else if (compare_part(ctx, b, first + at, n, cfg, out)) die(70, "compare failed", avk_last_error(ctx));
         for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += tally[k];
         if (debug && (avf_region_summary_rows(region_table, genome, all, first + at, n, out.status, gm.data()) ||
                       avf_region_sequences_rows(sequence_table, genome, all, first + at, n, out.status, seq_bytes.data(), seq_len.data(), seq_off.data(),

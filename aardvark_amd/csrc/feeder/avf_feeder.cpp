@@ -1555,6 +1555,101 @@ int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const
 }
 
 const avk_region_batch *avf_feed_batch(const avf_feed *f) { return f && !f->is_merge ? &f->batch : nullptr; }
+
+int avf_feed_pack(const avf_feed *f, void *(*alloc)(void *, size_t), void *user, avk_packed_batch *out) {
+    if (!f || f->is_merge || !alloc || !out) return fail(AVK_E_ARG, "null argument, or a merge feed");
+    const avk_region_batch &b = f->batch;
+    const uint64_t n = b.n_regions, nv = b.n_variants, na = nv ? b.allele_bytes_len : 0;
+    memset(out, 0, sizeof(*out));
+    /* the form's constraints (aardvark_amd.h); the layout ones hold by construction (flush() above) and are checked all the same */
+    if (nv >= (1ull << 32) || na >= (1ull << 32)) return 1;
+    std::atomic<int> bad{0}, raw_differs{0};
+    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned n_threads = std::max(1u, std::min(hw ? hw : 1u, 16u));
+    auto parallel = [&](uint64_t count, const std::function<void(uint64_t, uint64_t)> &fn) {
+        std::vector<std::thread> pool;
+        const uint64_t per = (count + n_threads - 1) / n_threads;
+        for (unsigned t = 0; t < n_threads; ++t) {
+            const uint64_t lo = std::min(count, t * per), hi = std::min(count, lo + per);
+            if (lo < hi) pool.emplace_back(fn, lo, hi);
+        }
+        for (std::thread &t : pool) t.join();
+    };
+    parallel(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; ++r) {
+            const uint64_t len = b.end[r] - b.start[r];
+            const uint64_t next = r + 1 < n ? b.t_off[r + 1] : nv;
+            if (b.end[r] < b.start[r] || len > 0xFFFF || b.start[r] > 0xFFFFFFFFull || b.contig_idx[r] > 0xFFFF || b.t_cnt[r] > 255 || b.q_cnt[r] > 255 ||
+                b.q_off[r] != b.t_off[r] + b.t_cnt[r] || next != b.q_off[r] + b.q_cnt[r] || (r == 0 && b.t_off[0] != 0)) {
+                bad = 1;
+                return;
+            }
+            for (uint64_t v = b.t_off[r]; v < next; ++v)
+                if (b.var_pos[v] < b.start[r] || b.var_pos[v] - b.start[r] > 0xFFFF) {
+                    bad = 1;
+                    return;
+                }
+        }
+    });
+    parallel(nv, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t v = lo; v < hi; ++v) {
+            const uint64_t next = v + 1 < nv ? b.a0_off[v + 1] : na;
+            if (b.a0_len[v] > 255 || b.a1_len[v] > 255 || b.var_type[v] > 15 || b.var_zyg[v] > 15 || b.a1_off[v] != b.a0_off[v] + b.a0_len[v] ||
+                next != b.a1_off[v] + b.a1_len[v] || (v == 0 && b.a0_off[0] != 0)) {
+                bad = 1;
+                return;
+            }
+            if (b.var_raw_space[v] != std::max(b.a0_len[v], b.a1_len[v])) raw_differs = 1;
+        }
+    });
+    if (bad) return 1;
+    bool oom = false;
+    auto get = [&](size_t bytes) {
+        void *p = alloc(user, bytes ? bytes : 1);
+        if (!p) oom = true;
+        return p;
+    };
+    uint16_t *contig = (uint16_t *)get(n * 2), *len = (uint16_t *)get(n * 2), *rel = (uint16_t *)get(nv * 2);
+    uint32_t *start = (uint32_t *)get(n * 4), *raw = raw_differs ? (uint32_t *)get(nv * 4) : nullptr;
+    uint8_t *tc = (uint8_t *)get(n), *qc = (uint8_t *)get(n), *tz = (uint8_t *)get(nv), *l0 = (uint8_t *)get(nv), *l1 = (uint8_t *)get(nv), *bytes = (uint8_t *)get(na);
+    if (oom) return fail(AVK_E_OOM, "the allocator returned NULL for an array of the packed form");
+    parallel(n, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t r = lo; r < hi; ++r) {
+            contig[r] = (uint16_t)b.contig_idx[r], start[r] = (uint32_t)b.start[r], len[r] = (uint16_t)(b.end[r] - b.start[r]);
+            tc[r] = (uint8_t)b.t_cnt[r], qc[r] = (uint8_t)b.q_cnt[r];
+            const uint64_t next = b.q_off[r] + b.q_cnt[r];
+            for (uint64_t v = b.t_off[r]; v < next; ++v) rel[v] = (uint16_t)(b.var_pos[v] - b.start[r]);
+        }
+    });
+    parallel(nv, [&](uint64_t lo, uint64_t hi) {
+        for (uint64_t v = lo; v < hi; ++v) {
+            tz[v] = (uint8_t)(b.var_type[v] | b.var_zyg[v] << 4), l0[v] = (uint8_t)b.a0_len[v], l1[v] = (uint8_t)b.a1_len[v];
+            if (raw) raw[v] = b.var_raw_space[v];
+        }
+    });
+    if (na) memcpy(bytes, b.allele_bytes, na);
+    out->n_regions = n, out->contig_idx = contig, out->start = start, out->len = len, out->t_cnt = tc, out->q_cnt = qc;
+    out->n_variants = nv, out->var_rel_pos = rel, out->var_type_zyg = tz, out->a0_len = l0, out->a1_len = l1, out->var_raw_space = raw;
+    out->allele_bytes = bytes, out->allele_bytes_len = na;
+    return 0;
+}
+
+int avf_packed_slice(const avf_feed *f, const avk_packed_batch *all, uint64_t first, uint64_t n, avk_packed_batch *part, uint64_t *v_first) {
+    if (!f || f->is_merge || !all || !part || !v_first) return fail(AVK_E_ARG, "null argument, or a merge feed");
+    const avk_region_batch &b = f->batch;
+    if (all->n_regions != b.n_regions || all->n_variants != b.n_variants) return fail(AVK_E_ARG, "the packed batch is not this feed's");
+    if (first > b.n_regions || n > b.n_regions - first) return fail(AVK_E_ARG, "regions [%llu, +%llu) of %llu", (unsigned long long)first, (unsigned long long)n, (unsigned long long)b.n_regions);
+    const uint64_t v0 = first < b.n_regions ? b.t_off[first] : b.n_variants, v1 = first + n < b.n_regions ? b.t_off[first + n] : b.n_variants;
+    const uint64_t a0 = v0 < b.n_variants ? b.a0_off[v0] : all->allele_bytes_len, a1 = v1 < b.n_variants ? b.a0_off[v1] : all->allele_bytes_len;
+    *part = *all;
+    part->n_regions = n, part->contig_idx = all->contig_idx + first, part->start = all->start + first, part->len = all->len + first;
+    part->t_cnt = all->t_cnt + first, part->q_cnt = all->q_cnt + first;
+    part->n_variants = v1 - v0, part->var_rel_pos = all->var_rel_pos + v0, part->var_type_zyg = all->var_type_zyg + v0;
+    part->a0_len = all->a0_len + v0, part->a1_len = all->a1_len + v0, part->var_raw_space = all->var_raw_space ? all->var_raw_space + v0 : nullptr;
+    part->allele_bytes = all->allele_bytes + a0, part->allele_bytes_len = a1 - a0;
+    *v_first = v0;
+    return 0;
+}
 const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f) { return f && f->is_merge ? &f->multi : nullptr; }
 const uint64_t *avf_feed_var_record(const avf_feed *f) { return f ? f->var_record.data() : nullptr; }
 const uint32_t *avf_feed_var_alt_index(const avf_feed *f) { return f ? f->var_alt.data() : nullptr; }

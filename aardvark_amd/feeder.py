@@ -135,10 +135,45 @@ class Genome:
 
 
 class Feed:
-    """The result of RegionIterator over a truth/query VCF pair: a RegionBatch plus provenance."""
+    """The result of RegionIterator over a truth/query VCF pair: a RegionBatch plus provenance; `packed` = the same batch in the packed form
+    (avf_feed_pack -> PackedBatch), None when the call set does not fit that form or for merge feeds."""
 
-    def __init__(self, batch, var_record, var_alt_index, loaded):
-        self.batch, self.var_record, self.var_alt_index, self.loaded = batch, var_record, var_alt_index, loaded
+    def __init__(self, batch, var_record, var_alt_index, loaded, packed=None):
+        self.batch, self.var_record, self.var_alt_index, self.loaded, self.packed = batch, var_record, var_alt_index, loaded, packed
+
+
+_ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def _take_packed(lib, h):
+    """avf_feed_pack into numpy-owned buffers -> PackedBatch, or None when the feed does not fit the form"""
+    from ._abi import AvkPackedBatch, PackedBatch
+    bufs = {}
+
+    def alloc(_user, nbytes):
+        a = np.empty(max(int(nbytes), 1), np.uint8)
+        bufs[a.ctypes.data] = a
+        return a.ctypes.data
+
+    cb = _ALLOC(alloc)
+    out = AvkPackedBatch()
+    lib.avf_feed_pack.argtypes = [C.c_void_p, _ALLOC, C.c_void_p, C.POINTER(AvkPackedBatch)]
+    rc = lib.avf_feed_pack(h, cb, None, C.byref(out))
+    if rc == 1:
+        return None
+    _check(lib, rc)
+    n, nv, na = int(out.n_regions), int(out.n_variants), int(out.allele_bytes_len)
+
+    def view(ptr, count, dtype):
+        addr = C.cast(ptr, C.c_void_p).value
+        if addr is None:
+            return None
+        return bufs[addr][:count * np.dtype(dtype).itemsize].view(dtype)
+
+    return PackedBatch(contig_idx=view(out.contig_idx, n, np.uint16), start=view(out.start, n, np.uint32), len=view(out.len, n, np.uint16),
+                       t_cnt=view(out.t_cnt, n, np.uint8), q_cnt=view(out.q_cnt, n, np.uint8), var_rel_pos=view(out.var_rel_pos, nv, np.uint16),
+                       var_type_zyg=view(out.var_type_zyg, nv, np.uint8), a0_len=view(out.a0_len, nv, np.uint8), a1_len=view(out.a1_len, nv, np.uint8),
+                       var_raw_space=view(out.var_raw_space, nv, np.uint32), allele_bytes=view(out.allele_bytes, na, np.uint8))
 
 
 def vcf_sample_name(vcf, index=0):
@@ -200,7 +235,7 @@ def _take_feed(lib, h, k, merge):
                                 _arr(b.a0_off, nv, np.uint64), _arr(b.a0_len, nv, np.uint32), _arr(b.a1_off, nv, np.uint64), _arr(b.a1_len, nv, np.uint32),
                                 _arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
         return Feed(batch, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
-                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)))
+                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)), None if merge else _take_packed(lib, h))
     finally:
         lib.avf_feed_free(h)
 
@@ -219,7 +254,7 @@ def feed_compare(truth_vcf, query_vcf, regions_bed, genome, truth_sample="", que
                             _arr(b.a0_off, nv, np.uint64), _arr(b.a0_len, nv, np.uint32), _arr(b.a1_off, nv, np.uint64), _arr(b.a1_len, nv, np.uint32),
                             _arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
         return Feed(batch, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
-                    (int(lib.avf_feed_loaded_variants(h, 0)), int(lib.avf_feed_loaded_variants(h, 1))))
+                    (int(lib.avf_feed_loaded_variants(h, 0)), int(lib.avf_feed_loaded_variants(h, 1))), _take_packed(lib, h))
     finally:
         lib.avf_feed_free(h)
 

@@ -180,6 +180,17 @@ class MergeResult:
         return out
 
 
+def pinned_multi_batch(ctx, mb):
+    """a copy of a MultiBatch whose arrays live in pinned memory (avk_host_alloc): avk_merge_batch then copies them by DMA instead of through the bounce buffer"""
+    arrays = {}
+    for name in MultiBatch.FIELDS:
+        a = getattr(mb, name)
+        out = ctx.host_array(a.shape, a.dtype)
+        out[...] = a
+        arrays[name] = out
+    return MultiBatch(mb.n_inputs, **arrays)
+
+
 def merge_multi_batch(ctx, mb, config=None):
     """avk_merge_batch on a MultiBatch: pairs on the GPU, classification on the host -> MergeResult"""
     config = config or MergeConfig()

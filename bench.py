@@ -548,22 +548,24 @@ def secondary_legs(ctx, cfg, args, cpus, log):
     contigs4, batch4 = synth.config_genome(scale=args.secondary_scale / 5, threads=min(8, cpus), gap=1000)
     compare_leg("min_variant_gap_1000", contigs4, batch4, "genome x %.3g clustered with --min-variant-gap 1000, %d regions" % (args.secondary_scale / 5, batch4.n_regions), few=True)
     if not args.no_merge:
-        from aardvark_amd.merge import MergeConfig, merge_multi_batch
+        from aardvark_amd.merge import MergeConfig, merge_multi_batch, pinned_multi_batch
         import merge_oracle as mo
         contigs5, mb = synth.config_genome_merge(scale=args.merge_scale, k=3, threads=min(8, cpus))
         ctx.upload_reference(contigs5)
+        if not args.pageable:
+            mb = pinned_multi_batch(ctx, mb)
         mcfg = MergeConfig(majority_voting_enabled=True)
         merge_multi_batch(ctx, mb, mcfg)
         t0 = time.perf_counter()
-        nm = 3
+        nm = 6
         for _ in range(nm):
             mres = merge_multi_batch(ctx, mb, mcfg)
         me = time.perf_counter() - t0
         entry = {"workload": "BASELINE configs[4] stand-in on ONE GPU: merge of 3 call sets (seeds 20250105-7) x %.3g genome, majority strategy, %d regions, %d input pairs"
                              % (args.merge_scale, mb.n_regions, 3 * mb.n_regions),
                  "value": mb.n_regions * nm / me, "unit": "merge regions/s", "ms_per_step": me / nm * 1e3, "steps": nm,
-                 "what": "avk_merge_batch (solve_merge_region, src/merge_solver.rs:110-200): multi-region batch in host memory -> pairs + classification on the GPU -> status, "
-                         "classification and members in host arrays"}
+                 "what": ("avk_merge_batch (solve_merge_region, src/merge_solver.rs:110-200): multi-region batch in %s host memory -> pairs + classification on the GPU -> status, "
+                         "classification and members in host arrays") % ("pageable" if args.pageable else "pinned")}
         # parity: oracle pairs + the restated classification (oracle/merge_oracle.py) on a sample, and the pair results of every region
         k = 3
         st_o, ex_o = oracle_lib.optimize_pairs(lib, pair_batch_of(mb), oracle_lib.ContigSet(contigs5), 50, threads=cpus)

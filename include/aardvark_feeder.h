@@ -63,6 +63,16 @@ const avk_region_batch *avf_feed_batch(const avf_feed *f);
  * file, and the 1-based ALT index it came from */
 const uint64_t *avf_feed_var_record(const avf_feed *f);
 const uint32_t *avf_feed_var_alt_index(const avf_feed *f);
+/* The compare feed in the library's PACKED form (avk_packed_batch, aardvark_amd.h: 10 bytes per region, 5 per call, the allele bytes) — what
+ * avk_compare_packed / avk_batch_upload_packed take.  The feed's calls already lie in the order the form implies (region by region, truth calls then query
+ * calls, allele0 then allele1).  The arrays come from alloc(user, bytes) — pass avk_host_alloc and the context for pinned memory that is copied by DMA — and
+ * belong to the caller; var_raw_space stays NULL when every call's raw space is its longer allele.  Returns 0; 1 when the feed does not meet the form's
+ * constraints (a window of 65,536 bases or more, more than 255 calls on a side, an allele longer than 255 bases, ...: nothing is allocated, use
+ * avf_feed_batch); a negative AVK_E_* code on errors. */
+int avf_feed_pack(const avf_feed *f, void *(*alloc)(void *user, size_t bytes), void *user, avk_packed_batch *out);
+/* Regions [first, first + n) of a packed feed as a batch of their own (its arrays point into `all`'s); *v_first = index of the part's first call in the
+ * feed's call arrays: the part's per-call results are indexed from there. */
+int avf_packed_slice(const avf_feed *f, const avk_packed_batch *all, uint64_t first, uint64_t n, avk_packed_batch *part, uint64_t *v_first);
 /* Region generation for `merge` (RegionIterator::new_merge_iterator, region_generation.rs:129-192): the same walk over
  * n_inputs VCFs (1..64), in priority order.  samples: NULL, or per input NULL / "" = that file's first sample
  * (src/cli/merge.rs:196-198).  The feed hands out an avk_multi_batch for avk_merge_batch; avf_feed_batch is NULL for it

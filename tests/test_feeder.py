@@ -347,6 +347,68 @@ def test_synthetic_call_sets_round_trip_through_vcf(tmp_path):
     feed = feeder.feed_compare(tv, qv, bd, genome, enable_trimming=False)
     assert_same_batch(feed.batch, want)
     assert np.array_equal(genome.contigs()[0], contig)
+    # the feeder's own packed form (avf_feed_pack) = the wide batch narrowed by the Python classes
+    from aardvark_amd._abi import AvkPackedBatch, CompactBatch, PackedBatch
+    ref = PackedBatch.from_compact(CompactBatch.from_region_batch(feed.batch))
+    assert feed.packed is not None and feed.packed.n_regions == ref.n_regions and feed.packed.n_variants == ref.n_variants
+    for name in PackedBatch.FIELDS:
+        a, b = getattr(feed.packed, name), getattr(ref, name)
+        assert (a is None and b is None) or np.array_equal(a, b), name
+    assert feed.packed.var_raw_space is None  # untrimmed calls: the raw space is the longer allele
+    # parts of it (avf_packed_slice): the arrays of regions [first, first + n) and of their calls, inside the whole
+    import ctypes as C
+    lib = feeder.load_library()
+    h = C.c_void_p()
+    assert lib.avf_feed_compare(os.fsencode(tv), b"", os.fsencode(qv), b"", os.fsencode(bd), genome.handle, 50, 0, C.byref(h)) == 0
+    libc = C.CDLL(None)
+    libc.malloc.restype, libc.malloc.argtypes = C.c_void_p, [C.c_size_t]
+    alloc = feeder._ALLOC(lambda _u, nbytes: libc.malloc(nbytes))
+    whole, part, v_first = AvkPackedBatch(), AvkPackedBatch(), C.c_uint64()
+    lib.avf_feed_pack.argtypes = [C.c_void_p, feeder._ALLOC, C.c_void_p, C.POINTER(AvkPackedBatch)]
+    lib.avf_packed_slice.argtypes = [C.c_void_p, C.POINTER(AvkPackedBatch), C.c_uint64, C.c_uint64, C.POINTER(AvkPackedBatch), C.POINTER(C.c_uint64)]
+    assert lib.avf_feed_pack(h, alloc, None, C.byref(whole)) == 0
+    addr = lambda ptr: C.cast(ptr, C.c_void_p).value
+    b, n = feed.batch, feed.batch.n_regions
+    for first, cnt in ((0, n), (0, 0), (n, 0), (n // 3, n // 2), (n - 1, 1), (5, 1)):
+        assert lib.avf_packed_slice(h, C.byref(whole), first, cnt, C.byref(part), C.byref(v_first)) == 0
+        v0 = int(b.t_off[first]) if first < n else b.n_variants
+        v1 = int(b.t_off[first + cnt]) if first + cnt < n else b.n_variants
+        a0 = int(b.a0_off[v0]) if v0 < b.n_variants else int(whole.allele_bytes_len)
+        a1 = int(b.a0_off[v1]) if v1 < b.n_variants else int(whole.allele_bytes_len)
+        assert (part.n_regions, part.n_variants, part.allele_bytes_len, v_first.value) == (cnt, v1 - v0, a1 - a0, v0)
+        assert addr(part.start) - addr(whole.start) == 4 * first and addr(part.len) - addr(whole.len) == 2 * first and addr(part.contig_idx) - addr(whole.contig_idx) == 2 * first
+        assert addr(part.t_cnt) - addr(whole.t_cnt) == first and addr(part.q_cnt) - addr(whole.q_cnt) == first
+        assert addr(part.var_rel_pos) - addr(whole.var_rel_pos) == 2 * v0 and addr(part.var_type_zyg) - addr(whole.var_type_zyg) == v0
+        assert addr(part.a0_len) - addr(whole.a0_len) == v0 and addr(part.a1_len) - addr(whole.a1_len) == v0 and addr(part.allele_bytes) - addr(whole.allele_bytes) == a0
+        assert addr(part.var_raw_space) is None
+    assert lib.avf_packed_slice(h, C.byref(whole), n, 1, C.byref(part), C.byref(v_first)) < 0
+    lib.avf_feed_free(h)
+
+
+def test_call_sets_outside_the_packed_form_are_reported(tmp_path):
+    """an allele of more than 255 bases, or a window of 65,536 bases or more: avf_feed_pack returns 1 and the wide batch is what there is; trimmed calls keep
+    their raw space in the packed form"""
+    length = 200_000
+    contig = synth.make_contig(length, 11)
+    seq = bytes(contig).decode()
+    fa, bd = str(tmp_path / "c.fa"), str(tmp_path / "c.bed")
+    write_text(fa, ">chr20\n" + "\n".join(seq[i:i + 60] for i in range(0, length, 60)) + "\n")
+    write_text(bd, "chr20\t0\t%d\n" % length)
+    genome = feeder.Genome(fa)
+    snv = lambda pos: (pos, seq[pos], "A" if seq[pos] != "A" else "C", "UnphasedHeterozygous")
+    long_del = (5000, seq[5000:5000 + 300], seq[5000], "HomozygousAlternate")
+    padded = (9000, seq[9000:9003], ("A" if seq[9000] != "A" else "C") + seq[9001:9003], "HomozygousAlternate")  # trimmed to one base, raw space 3
+    cases = {"fits": ([snv(1000), padded], True), "long_allele": ([snv(1000), long_del], False)}
+    for name, (calls, fits) in cases.items():
+        tv = str(tmp_path / (name + ".vcf"))
+        write_text(tv, vcf_text("chr20", calls))
+        feed = feeder.feed_compare(tv, tv, bd, genome)
+        assert (feed.packed is not None) == fits, name
+        if fits:
+            assert feed.packed.var_raw_space is not None and np.array_equal(feed.packed.var_raw_space, feed.batch.var_raw_space)
+    tv = str(tmp_path / "fits.vcf")
+    feed = feeder.feed_compare(tv, tv, bd, genome, min_variant_gap=60_000)  # one window of 69,003 bases
+    assert feed.packed is None and feed.batch.n_regions == 1
 
 
 def test_reference_known_answers_through_vcf_files(tmp_path, oracle):
@@ -664,7 +726,8 @@ def test_command_line_tool_with_several_contexts(tmp_path):
     base = [cli_path(), "-r", p["fa"], "-t", p["t"], "-q", p["q"], "-b", p["bed"], "--disable-variant-trimming"]
     for extra in ([], ["-s", str(tmp_path / "strat.tsv")]):
         outs = []
-        for k, dev in enumerate((["--device", "0"], ["--devices", "0,0", "--batch-regions", "400"], ["--devices", "0,0,0"])):
+        for k, dev in enumerate((["--device", "0"], ["--devices", "0,0", "--batch-regions", "400"], ["--devices", "0,0,0"], ["--device", "0", "--batch-form", "wide"],
+                                 ["--device", "0", "--batch-regions", "333"])):
             out = str(tmp_path / ("out_%d_%d" % (len(extra), k)))
             r = subprocess.run(base + ["-o", out] + extra + dev, capture_output=True, text=True)
             assert r.returncode == 0, r.stderr

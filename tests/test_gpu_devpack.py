@@ -268,7 +268,7 @@ def test_merge_of_three_call_sets_at_genome_density(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import merge_oracle as mo
     import aardvark_amd
-    from aardvark_amd.merge import MergeConfig, MultiBatch, merge_multi_batch, pair_batch
+    from aardvark_amd.merge import MergeConfig, MultiBatch, merge_multi_batch, pair_batch, pinned_multi_batch
     n_truth = int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38))
     contig = synth.make_contig_fast(synth.CHR20_LEN, 20250103 + 19)
     rng = np.random.default_rng(20250103 + 119)
@@ -291,6 +291,9 @@ def test_merge_of_three_call_sets_at_genome_density(oracle):
         st_o, ex_o = oracle_lib.optimize_pairs(oracle, pb, [contig], 50, threads=CPUS)
         ws, wc, wm = mo.classify_k3_majority(st_o, ex_o)
         assert np.array_equal(got.status, ws) and np.array_equal(got.classification, wc) and np.array_equal(got.members, wm)
+        # the same batch from pinned arrays (DMA instead of the bounce buffer)
+        got_p = merge_multi_batch(ctx, pinned_multi_batch(ctx, mb), MergeConfig(majority_voting_enabled=True))
+        assert np.array_equal(got_p.status, ws) and np.array_equal(got_p.classification, wc) and np.array_equal(got_p.members, wm)
         assert (wc == 1).sum() > 0.8 * n and (wc == 3).sum() > 0.01 * n
         # the general rule, region by region, for every strategy on a slice of the contig
         sub = MultiBatch(3, region_id=mb.region_id[:3000], contig_idx=mb.contig_idx[:3000], start=mb.start[:3000], end=mb.end[:3000], in_off=mb.in_off[:9000], in_cnt=mb.in_cnt[:9000],

@@ -121,6 +121,12 @@ if n_strat:
     cmd += ["-s", os.path.join(d, "strat.tsv")]
 if os.environ.get("DEVICES"):  # several solver contexts, e.g. DEVICES=0,0 or 0,1,2,3
     cmd += ["--devices", os.environ["DEVICES"]]
+if os.environ.get("CLI_ARGS"):  # further options of the tool, e.g. CLI_ARGS="--batch-form wide"
+    cmd += os.environ["CLI_ARGS"].split()
+for _ in range(int(os.environ.get("RUNS", "1")) - 1):  # RUNS=n: the same command n times, the last one is the one checked below
+    t0 = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    print("exit %d, wall %.2f s; %s" % (r.returncode, time.time() - t0, " | ".join(l for l in r.stderr.strip().splitlines() if l.startswith("stages") or l.startswith("Comparisons"))), flush=True)
 t0 = time.time()
 r = subprocess.run(cmd, capture_output=True, text=True)
 print("exit %d, wall %.2f s" % (r.returncode, time.time() - t0))

@@ -36,3 +36,12 @@ if "--merge" in sys.argv:
         merge_multi_batch(ctx, mb, mcfg)
         ts.append((time.perf_counter() - t) * 1e3)
     print("%-40s merge of 3 call sets: %s ms per call" % (",".join(opts) or "defaults", " ".join("%.2f" % x for x in ts)), flush=True)
+    from aardvark_amd.merge import pinned_multi_batch
+    pm = pinned_multi_batch(ctx, mb)
+    merge_multi_batch(ctx, pm, mcfg)
+    ts = []
+    for _ in range(8):
+        t = time.perf_counter()
+        merge_multi_batch(ctx, pm, mcfg)
+        ts.append((time.perf_counter() - t) * 1e3)
+    print("%-40s merge, pinned arrays:   %s ms per call" % (",".join(opts) or "defaults", " ".join("%.2f" % x for x in ts)), flush=True)
