@@ -655,6 +655,7 @@ AVK_DEV u32 dp_order_slot(const DpArgs &a, u32 bucket, u32 pos) {
 }
 
 /* ---- dp_bucket_bases: exclusive scan of the histogram, the plan, the geometry of the fast records; one thread ---------------------- */
+AVK_DEV void dp_bucket_plan(const DpArgs &a);
 AVK_DEV void dp_bucket_bases(const DpArgs &a) {
     DpState &s = *a.st;
     u32 run = 0;
@@ -664,6 +665,11 @@ AVK_DEV void dp_bucket_bases(const DpArgs &a) {
         run += s.hist[b];
     }
     s.base[DP_NB] = run;
+    dp_bucket_plan(a);
+}
+/* what follows from the bucket bases (the GPU makes the bases with a workgroup, avk_dp_bucket_bases_kernel, and calls this from one thread) */
+AVK_DEV void dp_bucket_plan(const DpArgs &a) {
+    DpState &s = *a.st;
     s.n_hbm = s.base[256] - s.base[0];
     s.n_hard = s.base[512] - s.base[256];
     s.n_fast_total = 0;

@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(256) avk_ps_apply_kernel(const uint8_t *a, con
 __global__ void __launch_bounds__(256) avk_dp_variant_kernel(dpk::DpArgs a) { dpk::dp_variant(a, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 
 /* dp_region for 256 regions; the workgroup's sums of the three scanned quantities and its count of regions per lane class go to
- * block_sums[AVK_DP_BS * block ..]: no global atomics (56,000 waves adding to the one counter of the modal class took 1.3 ms of this kernel's 1.6) */
+ * column-major block_sums[quantity][block]: no global atomics (56,000 waves adding to the one counter of the modal class took 1.3 ms of this kernel's 1.6) */
 #define AVK_DP_NS 4 /* scanned quantities: per-call output words, blob words, sequence bytes, compact BASEPAIR groups */
 #define AVK_DP_BS (AVK_DP_NS + AVK_FAST_CLASSES + avk::dp::DP_NEED_BUCKETS)
 __global__ void __launch_bounds__(256) avk_dp_region_kernel(dpk::DpArgs a, uint64_t *block_sums) {
@@ -119,50 +119,43 @@ __global__ void __launch_bounds__(256) avk_dp_region_kernel(dpk::DpArgs a, uint6
         if (sq_w) atomicAdd(&sums[2], sq_w);
     }
     __syncthreads();
-    if (threadIdx.x < AVK_DP_BS) block_sums[(size_t)AVK_DP_BS * blockIdx.x + threadIdx.x] = sums[threadIdx.x];
+    if (threadIdx.x < AVK_DP_BS) block_sums[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = sums[threadIdx.x]; /* one column per quantity */
 }
 
-/* exclusive scan of the block sums, in place (one workgroup), the totals, and the regions per lane class */
+/* one workgroup per column of the block sums: the scanned quantities get their exclusive scan in place and their total, the class and
+ * workspace-bucket columns their sum (one workgroup walking all AVK_DP_BS columns of 14,000 rows took 0.2 ms of a 10 ms call) */
 __global__ void __launch_bounds__(1024) avk_dp_scan_blocks_kernel(uint64_t *block_sums, uint32_t n_blocks, dpk::DpState *st) {
-    __shared__ unsigned long long part[AVK_DP_NS][1024];
-    __shared__ unsigned long long have[AVK_FAST_CLASSES + dpk::DP_NEED_BUCKETS];
-    const uint32_t t = threadIdx.x, per = (n_blocks + 1023u) / 1024u;
+    __shared__ unsigned long long part[1024];
+    const uint32_t q = blockIdx.x, t = threadIdx.x, per = (n_blocks + 1023u) / 1024u;
+    uint64_t *col = block_sums + (size_t)q * n_blocks;
     const uint32_t lo = t * per < n_blocks ? t * per : n_blocks, hi = lo + per < n_blocks ? lo + per : n_blocks;
-    enum { NH = AVK_FAST_CLASSES + dpk::DP_NEED_BUCKETS };
-    if (t < NH) have[t] = 0;
-    unsigned long long s[AVK_DP_NS] = {0, 0, 0, 0}, h[NH];
-    for (int c = 0; c < NH; ++c) h[c] = 0;
-    for (uint32_t b = lo; b < hi; ++b) {
-        for (int q = 0; q < AVK_DP_NS; ++q) s[q] += block_sums[(size_t)AVK_DP_BS * b + q];
-        for (int c = 0; c < NH; ++c) h[c] += block_sums[(size_t)AVK_DP_BS * b + AVK_DP_NS + c];
-    }
-    for (int q = 0; q < AVK_DP_NS; ++q) part[q][t] = s[q];
+    unsigned long long s = 0;
+    for (uint32_t b = lo; b < hi; ++b) s += col[b];
+    part[t] = s;
     __syncthreads();
-    for (int c = 0; c < NH; ++c)
-        if (h[c]) atomicAdd(&have[c], h[c]);
     for (uint32_t d = 1; d < 1024; d <<= 1) {
-        unsigned long long x[AVK_DP_NS];
-        for (int q = 0; q < AVK_DP_NS; ++q) x[q] = t >= d ? part[q][t - d] : 0ull;
+        const unsigned long long x = t >= d ? part[t - d] : 0ull;
         __syncthreads();
-        for (int q = 0; q < AVK_DP_NS; ++q) part[q][t] += x[q];
+        part[t] += x;
         __syncthreads();
     }
-    unsigned long long run[AVK_DP_NS];
-    for (int q = 0; q < AVK_DP_NS; ++q) run[q] = part[q][t] - s[q];
-    for (uint32_t b = lo; b < hi; ++b)
-        for (int q = 0; q < AVK_DP_NS; ++q) {
-            const unsigned long long v = block_sums[(size_t)AVK_DP_BS * b + q];
-            block_sums[(size_t)AVK_DP_BS * b + q] = run[q];
-            run[q] += v;
+    if (q < AVK_DP_NS) {
+        unsigned long long run = part[t] - s;
+        for (uint32_t b = lo; b < hi; ++b) {
+            const unsigned long long v = col[b];
+            col[b] = run;
+            run += v;
         }
-    if (t == 1023) {
-        st->total_v = part[0][1023];
-        st->total_blob_words = part[1][1023];
-        st->total_seq = part[2][1023];
-        st->total_groups = part[3][1023];
     }
-    if (t < AVK_FAST_CLASSES) st->have[t] = have[t];
-    else if (t < NH) st->need_hist[t - AVK_FAST_CLASSES] = have[t];
+    if (t == 1023) {
+        const unsigned long long total = part[1023];
+        if (q == 0) st->total_v = total;
+        else if (q == 1) st->total_blob_words = total;
+        else if (q == 2) st->total_seq = total;
+        else if (q == 3) st->total_groups = total;
+        else if (q < AVK_DP_NS + AVK_FAST_CLASSES) st->have[q - AVK_DP_NS] = total;
+        else st->need_hist[q - AVK_DP_NS - AVK_FAST_CLASSES] = total;
+    }
 }
 
 /* per-region offsets: the block's base + the exclusive scan inside the block */
@@ -192,12 +185,13 @@ __global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, c
         __syncthreads();
     }
     if (r < a.in.n_regions) {
-        const uint64_t *bs = block_sums + (size_t)AVK_DP_BS * blockIdx.x;
+        const uint64_t *bs = block_sums + blockIdx.x; /* column q of this workgroup: bs[q * gridDim.x] */
+        const size_t col = gridDim.x;
         a.v_off[r] = (uint32_t)(bs[0] + sh[0][t] - v[0]);
-        a.blob_off8[r] = (uint32_t)((bs[1] + sh[1][t] - v[1]) / 2ull);
-        a.seq_off[r] = bs[2] + sh[2][t] - v[2];
-        a.bp_off[r] = (uint32_t)(bs[3] + sh[3][t] - v[3]);
-        if (r + 1 == a.in.n_regions) a.bp_off[r + 1] = (uint32_t)(bs[3] + sh[3][t]);
+        a.blob_off8[r] = (uint32_t)((bs[col] + sh[1][t] - v[1]) / 2ull);
+        a.seq_off[r] = bs[2 * col] + sh[2][t] - v[2];
+        a.bp_off[r] = (uint32_t)(bs[3 * col] + sh[3][t] - v[3]);
+        if (r + 1 == a.in.n_regions) a.bp_off[r + 1] = (uint32_t)(bs[3 * col] + sh[3][t]);
     }
 }
 
@@ -221,8 +215,34 @@ __global__ void __launch_bounds__(1024) avk_dp_hist_kernel(dpk::DpArgs a) {
         if (h[k]) atomicAdd(&a.st->hist[k], h[k]);
 }
 
-__global__ void avk_dp_bucket_bases_kernel(dpk::DpArgs a) {
-    if (blockIdx.x == 0 && threadIdx.x == 0) dpk::dp_bucket_bases(a);
+/* dp_bucket_bases by one workgroup: thread t scans its 9 consecutive buckets, the 256 partial sums are scanned in LDS (one thread walking the 2,304
+ * buckets in global memory took 50 us) */
+__global__ void __launch_bounds__(256) avk_dp_bucket_bases_kernel(dpk::DpArgs a) {
+    static_assert(dpk::DP_NB % 256 == 0, "buckets per thread");
+    enum { PER = dpk::DP_NB / 256 };
+    __shared__ uint32_t part[256];
+    dpk::DpState &s = *a.st;
+    const uint32_t t = threadIdx.x;
+    uint32_t h[PER], sum = 0;
+    for (int k = 0; k < PER; ++k) h[k] = s.hist[t * PER + k], sum += h[k];
+    part[t] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 256; d <<= 1) {
+        const uint32_t x = t >= d ? part[t - d] : 0u;
+        __syncthreads();
+        part[t] += x;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (int k = 0; k < PER; ++k) {
+        s.base[t * PER + k] = run;
+        s.cursor[t * PER + k] = run;
+        run += h[k];
+    }
+    if (t == 255) s.base[dpk::DP_NB] = run;
+    __threadfence();
+    __syncthreads();
+    if (t == 0) dpk::dp_bucket_plan(a);
 }
 
 /* pass 2: a workgroup reserves its share of every bucket with one atomic and ranks its regions inside the share in LDS.  The order inside a
@@ -849,11 +869,11 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         hipError_t x = hipSuccess;
         if (n) {
             hipLaunchKernelGGL(avk_dp_region_kernel, dim3(n_blocks), dim3(256), 0, s, a, d_block_sums);
-            hipLaunchKernelGGL(avk_dp_scan_blocks_kernel, dim3(1), dim3(1024), 0, s, d_block_sums, n_blocks, a.st);
+            hipLaunchKernelGGL(avk_dp_scan_blocks_kernel, dim3(AVK_DP_BS), dim3(1024), 0, s, d_block_sums, n_blocks, a.st);
             hipLaunchKernelGGL(avk_dp_scan_apply_kernel, dim3(n_blocks), dim3(256), 0, s, a, (const uint64_t *)d_block_sums);
             hipLaunchKernelGGL(avk_dp_lane_switch_kernel, dim3(1), dim3(64), 0, s, a);
             hipLaunchKernelGGL(avk_dp_hist_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
-            hipLaunchKernelGGL(avk_dp_bucket_bases_kernel, dim3(1), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(avk_dp_bucket_bases_kernel, dim3(1), dim3(256), 0, s, a);
             hipLaunchKernelGGL(avk_dp_scatter_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
             x = hipGetLastError();
         }
