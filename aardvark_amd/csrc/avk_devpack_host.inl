@@ -531,57 +531,78 @@ struct CopySeg {
     const void *host; /* caller's array (source of an upload, destination of a download) */
     void *dev;
     size_t bytes;
+    hipStream_t stream = nullptr;     /* uploads: a stream other than the context's for this array */
+    hipEvent_t then_record = nullptr; /* uploads: recorded on that stream behind this array's copy */
 };
 
-/* host -> device on the context's stream: straight from pinned arrays; pageable ones through the bounce buffer, piece by piece — the host threads
+/* host -> device on the context's stream (or the segment's): straight from pinned arrays; pageable ones through the bounce buffer, piece by piece — the host threads
  * fill pieces while this thread queues the copy of every piece that is ready */
 static int copy_in(avk_ctx *ctx, const std::vector<CopySeg> &segs) {
     struct Piece {
         const uint8_t *src;
         uint8_t *dev;
         size_t off, bytes;
+        hipStream_t stream;
+        hipEvent_t then_record; /* after this piece (the last of its segment) */
+        bool direct;            /* pinned source: no staging */
     };
     std::vector<Piece> pieces;
     size_t staged = 0;
     const size_t piece_bytes = 4u << 20;
     for (const CopySeg &s : segs) {
-        if (!s.bytes || !s.host) continue;
+        hipStream_t stream = s.stream ? s.stream : ctx->stream;
+        if (!s.bytes || !s.host) {
+            if (s.then_record) pieces.push_back({nullptr, nullptr, 0, 0, stream, s.then_record, true});
+            continue;
+        }
         if (is_pinned(s.host, s.bytes)) {
-            AVK_HIP(ctx, hipMemcpyAsync(s.dev, s.host, s.bytes, hipMemcpyHostToDevice, ctx->stream));
+            pieces.push_back({(const uint8_t *)s.host, (uint8_t *)s.dev, 0, s.bytes, stream, s.then_record, true});
             continue;
         }
         for (size_t o = 0; o < s.bytes; o += piece_bytes) {
             const size_t nb = s.bytes - o < piece_bytes ? s.bytes - o : piece_bytes;
-            pieces.push_back({(const uint8_t *)s.host + o, (uint8_t *)s.dev + o, staged, nb});
+            pieces.push_back({(const uint8_t *)s.host + o, (uint8_t *)s.dev + o, staged, nb, stream, o + nb == s.bytes ? s.then_record : (hipEvent_t) nullptr, false});
             staged += (nb + 63) & ~(size_t)63;
         }
     }
     if (pieces.empty()) return 0;
-    const int rc = bounce_reserve(ctx, staged);
-    if (rc) return rc;
-    const unsigned nt = avk_host_threads();
-    std::atomic<size_t> next(0);
-    std::vector<std::atomic<uint8_t>> ready(pieces.size());
-    for (auto &x : ready) x.store(0);
+    if (staged) {
+        const int rc = bounce_reserve(ctx, staged);
+        if (rc) return rc;
+    }
+    auto issue = [&](const Piece &p) -> hipError_t { /* pieces are queued in segment order, whatever their source */
+        hipError_t e = p.bytes ? hipMemcpyAsync(p.dev, p.direct ? p.src : ctx->h_bounce + p.off, p.bytes, hipMemcpyHostToDevice, p.stream) : hipSuccess;
+        if (e == hipSuccess && p.then_record) e = hipEventRecord(p.then_record, p.stream);
+        return e;
+    };
     hipError_t herr = hipSuccess;
-    AvkPool::get().run(nt > 1 ? nt + 1 : 1, [&](unsigned t) {
-        const bool copier = t == 0;
-        if (copier && nt > 1) { /* this thread queues, the others fill */
-            for (size_t k = 0; k < pieces.size() && herr == hipSuccess; ++k) {
-                while (!ready[k].load(std::memory_order_acquire)) std::this_thread::yield();
-                herr = hipMemcpyAsync(pieces[k].dev, ctx->h_bounce + pieces[k].off, pieces[k].bytes, hipMemcpyHostToDevice, ctx->stream);
+    const unsigned nt = avk_host_threads();
+    if (!staged || nt <= 1) {
+        for (size_t k = 0; k < pieces.size() && herr == hipSuccess; ++k) {
+            if (!pieces[k].direct) memcpy(ctx->h_bounce + pieces[k].off, pieces[k].src, pieces[k].bytes);
+            herr = issue(pieces[k]);
+        }
+    } else {
+        std::atomic<size_t> next(0);
+        std::vector<std::atomic<uint8_t>> ready(pieces.size());
+        for (size_t k = 0; k < pieces.size(); ++k) ready[k].store(pieces[k].direct ? 1 : 0);
+        AvkPool::get().run(nt + 1, [&](unsigned t) {
+            if (t == 0) { /* this thread queues, the others fill */
+                for (size_t k = 0; k < pieces.size() && herr == hipSuccess; ++k) {
+                    while (!ready[k].load(std::memory_order_acquire)) std::this_thread::yield();
+                    herr = issue(pieces[k]);
+                }
+                return;
             }
-            return;
-        }
-        for (;;) {
-            const size_t k = next.fetch_add(1);
-            if (k >= pieces.size()) break;
-            memcpy(ctx->h_bounce + pieces[k].off, pieces[k].src, pieces[k].bytes);
-            ready[k].store(1, std::memory_order_release);
-            if (nt <= 1 && herr == hipSuccess)
-                herr = hipMemcpyAsync(pieces[k].dev, ctx->h_bounce + pieces[k].off, pieces[k].bytes, hipMemcpyHostToDevice, ctx->stream);
-        }
-    });
+            for (;;) {
+                const size_t k = next.fetch_add(1);
+                if (k >= pieces.size()) break;
+                if (pieces[k].direct) continue;
+                memcpy(ctx->h_bounce + pieces[k].off, pieces[k].src, pieces[k].bytes);
+                ready[k].store(1, std::memory_order_release);
+            }
+        });
+    }
     if (herr != hipSuccess) return fail(ctx, AVK_E_HIP, "host to device copy failed: %s", hipGetErrorString(herr));
     return 0;
 }
@@ -740,11 +761,20 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         const uint32_t nb_r = (uint32_t)((n + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK), nb_v = (uint32_t)((nv + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK);
         uint64_t *p_voff = (uint64_t *)tmp((n + 1) * 8), *p_aoff = (uint64_t *)tmp((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
         if (rc) return bail(rc);
-        std::vector<CopySeg> segs = {{pk->start, p_start, n * 4}, {pk->len, p_len, n * 2}, {pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->contig_idx, p_contig, has_contig ? n * 2 : 0},
-                                     {pk->var_rel_pos, p_rel, nv * 2}, {pk->var_type_zyg, p_tz, nv}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv},
-                                     {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {pk->allele_bytes, d_alleles, alen}};
-        rc = copy_in(ctx, segs);
-        if (rc) return bail(rc);
+        /* The counts and lengths on the context's stream: the two prefix sums need nothing else.  Everything else crosses on a stream of its own beside them —
+         * first what the widening kernel reads, then the allele bytes (a fifth of the form), which dp_variant is the first to read. */
+        hipStream_t side = ctx->lane_stream4;
+        hipError_t ec = hipEventRecord(ctx->ev_copy_fork, s);
+        if (ec == hipSuccess) ec = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0);
+        if (ec != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "packed upload: %s", hipGetErrorString(ec)));
+        auto side_fail = [&](int code) { /* nothing of this call may still be in flight on the side stream when its buffers go back */
+            (void)hipStreamSynchronize(side);
+            return bail(code);
+        };
+        rc = copy_in(ctx, {{pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv}, {pk->start, p_start, n * 4, side}, {pk->len, p_len, n * 2, side},
+                           {pk->contig_idx, p_contig, has_contig ? n * 2 : 0, side}, {pk->var_rel_pos, p_rel, nv * 2, side}, {pk->var_type_zyg, p_tz, nv, side, ctx->ev_copy_mid},
+                           {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0, side}, {pk->allele_bytes, d_alleles, alen, side, ctx->ev_copy_join}});
+        if (rc) return side_fail(rc);
         if (n) {
             hipLaunchKernelGGL(avk_ps_block_sums_kernel, dim3(nb_r), dim3(256), 0, s, (const uint8_t *)p_tc, (const uint8_t *)p_qc, n, p_sums);
             hipLaunchKernelGGL(avk_ps_scan_sums_kernel, dim3(1), dim3(1024), 0, s, p_sums, nb_r, p_sums + nb_r + nb_v);
@@ -764,11 +794,13 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         c.w_contig = d_contig, c.w_t_cnt = db->d_in_t_cnt, c.w_q_cnt = db->d_in_q_cnt, c.w_a0_len = d_a0l, c.w_a1_len = d_a1l, c.w_raw = nullptr, c.w_start = d_start, c.w_end = d_end,
         c.w_t_off = db->d_in_t_off, c.w_q_off = db->d_in_q_off, c.w_pos = d_pos, c.w_a0_off = d_a0o, c.w_a1_off = d_a1o, c.w_type = d_type, c.w_zyg = d_zyg;
         const uint64_t m = n > nv ? n : nv;
-        if (m) {
+        hipError_t ew = hipStreamWaitEvent(s, ctx->ev_copy_mid, 0);
+        if (m && ew == hipSuccess) {
             hipLaunchKernelGGL(avk_dp_widen_packed_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, s, c);
-            hipError_t ew = hipGetLastError();
-            if (ew != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ew)));
+            ew = hipGetLastError();
         }
+        const hipError_t ej = hipStreamWaitEvent(s, ctx->ev_copy_join, 0); /* from here on the stream has the allele bytes */
+        if (ew != hipSuccess || ej != hipSuccess) return side_fail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ew != hipSuccess ? ew : ej)));
     } else if (b) {
         std::vector<CopySeg> segs = {
             {b->start, d_start, n * 8}, {b->end, d_end, n * 8}, {b->t_off, db->d_in_t_off, n * 8}, {b->q_off, db->d_in_q_off, n * 8},

@@ -339,6 +339,7 @@ struct avk_ctx {
     hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
     hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr, ev_lane_head3 = nullptr;
+    hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -511,6 +512,9 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_copy_mid, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_copy_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_early, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_head3, hipEventDisableTiming) != hipSuccess ||
@@ -563,6 +567,9 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_ready3) (void)hipEventDestroy(ctx->ev_lane_ready3);
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
+    if (ctx->ev_copy_fork) (void)hipEventDestroy(ctx->ev_copy_fork);
+    if (ctx->ev_copy_mid) (void)hipEventDestroy(ctx->ev_copy_mid);
+    if (ctx->ev_copy_join) (void)hipEventDestroy(ctx->ev_copy_join);
     if (ctx->ev_lane_ready4) (void)hipEventDestroy(ctx->ev_lane_ready4);
     if (ctx->ev_lane_early) (void)hipEventDestroy(ctx->ev_lane_early);
     if (ctx->ev_lane_head3) (void)hipEventDestroy(ctx->ev_lane_head3);

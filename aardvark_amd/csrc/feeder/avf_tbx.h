@@ -222,10 +222,112 @@ class IndexedText {
     std::vector<std::pair<uint64_t, uint64_t>> *last_chunks_ = nullptr; /* std::map nodes do not move */
 };
 
+/* One structured meta line, `##KEY=<k=v,...>`, written again field by field the way the reference's VCF library (noodles-vcf 0.80, a Cargo dependency
+ * that is not vendored: restated from its published writer, not pinned by a reference run) writes a definition it has parsed:
+ *   INFO / FORMAT   ID, Number, Type, Description, then the other fields, then IDX
+ *   FILTER / ALT    ID, Description, the other fields, IDX
+ *   contig          ID, length, md5, URL, the other fields, IDX
+ *   any other key   the first field (its "ID tag"), then the other fields
+ * ID, Number, Type, length, md5, URL and IDX bare; Description and every "other" field in double quotes with `\` and `"` escaped, whether or not the input
+ * quoted them (`Source=x,Version=3` comes out as `Source="x",Version="3"`).  A line that does not parse (no closing `>`, a field without `=`, a definition
+ * without the fields its kind requires — the reference's reader would refuse the file) is returned as it is. */
+inline std::string vcf_reserialise_definition(const std::string &line) {
+    const size_t eq = line.find('=');
+    if (line.compare(0, 2, "##") != 0 || eq == std::string::npos || eq + 1 >= line.size() || line[eq + 1] != '<' || line.back() != '>') return line;
+    const std::string key = line.substr(2, eq - 2);
+    struct Field {
+        std::string k, v;
+    };
+    std::vector<Field> fields;
+    size_t at = eq + 2;
+    const size_t end = line.size() - 1;
+    while (at < end) {
+        const size_t ke = line.find('=', at);
+        if (ke == std::string::npos || ke >= end) return line;
+        Field f;
+        f.k = line.substr(at, ke - at);
+        if (f.k.empty() || f.k.find(',') != std::string::npos) return line;
+        at = ke + 1;
+        if (at < end && line[at] == '"') {
+            ++at;
+            bool closed = false;
+            while (at < end) {
+                const char ch = line[at++];
+                if (ch == '\\' && at < end && (line[at] == '"' || line[at] == '\\')) f.v.push_back(line[at++]);
+                else if (ch == '"') {
+                    closed = true;
+                    break;
+                } else f.v.push_back(ch);
+            }
+            if (!closed) return line;
+            if (at < end && line[at] != ',') return line;
+        } else {
+            const size_t ve = std::min(line.find(',', at), end);
+            f.v = line.substr(at, ve - at);
+            at = ve;
+        }
+        if (at < end) ++at; /* the comma */
+        fields.push_back(std::move(f));
+    }
+    if (fields.empty()) return line;
+    auto quoted = [](const std::string &v) {
+        std::string q = "\"";
+        for (const char ch : v) {
+            if (ch == '"' || ch == '\\') q.push_back('\\');
+            q.push_back(ch);
+        }
+        return q + "\"";
+    };
+    std::vector<bool> used(fields.size(), false);
+    std::string out = "##" + key + "=<";
+    bool first = true;
+    auto take = [&](const char *name, bool quote, bool required) {
+        for (size_t i = 0; i < fields.size(); ++i)
+            if (!used[i] && fields[i].k == name) {
+                used[i] = true;
+                if (!first) out += ',';
+                first = false;
+                out += fields[i].k + "=" + (quote ? quoted(fields[i].v) : fields[i].v);
+                return true;
+            }
+        return !required;
+    };
+    auto rest = [&](bool with_idx) {
+        for (size_t i = 0; i < fields.size(); ++i)
+            if (!used[i] && !(with_idx && fields[i].k == "IDX")) {
+                used[i] = true;
+                out += (first ? "" : ",") + fields[i].k + "=" + quoted(fields[i].v);
+                first = false;
+            }
+        if (with_idx) take("IDX", false, false);
+    };
+    bool ok = true;
+    if (key == "INFO" || key == "FORMAT") {
+        ok = take("ID", false, true) && take("Number", false, true) && take("Type", false, true) && take("Description", true, true);
+        rest(true);
+    } else if (key == "FILTER" || key == "ALT") {
+        ok = take("ID", false, true) && take("Description", true, true);
+        rest(key == "FILTER");
+    } else if (key == "contig") {
+        ok = take("ID", false, true);
+        take("length", false, false);
+        take("md5", false, false);
+        take("URL", false, false);
+        rest(true);
+    } else {
+        used[0] = true;
+        out += fields[0].k + "=" + fields[0].v;
+        first = false;
+        rest(false);
+    }
+    return ok ? out + ">" : line;
+}
+
 /* The header of an output VCF the way the reference's VCF library serialises a header it has parsed and extended (noodles: the
  * file format line, then the INFO, FILTER, FORMAT, ALT and contig definitions as groups, then every other line grouped by its key in
- * order of first appearance): the input's meta lines regrouped — their text is kept as it is —, `defs` added to (or replacing the
- * same ID in) the INFO / FORMAT groups, `others` (key, value) appended under their keys. */
+ * order of first appearance): the input's meta lines regrouped and its structured lines written again field by field
+ * (vcf_reserialise_definition), `defs` added to (or replacing the same ID in) the INFO / FORMAT groups, `others` (key, value) appended
+ * under their keys. */
 struct HeaderDef {
     const char *group; /* "INFO" or "FORMAT" */
     const char *id;
@@ -265,8 +367,8 @@ inline std::vector<std::string> vcf_header_lines(const std::vector<std::string> 
         int g = -1;
         for (int k = 0; k < 5; ++k)
             if (key == kGroups[k] && eq != std::string::npos && eq + 1 < m.size() && m[eq + 1] == '<') g = k;
-        if (g >= 0) grouped[g].emplace_back(id_of(m), m);
-        else add_other(key, m);
+        if (g >= 0) grouped[g].emplace_back(id_of(m), vcf_reserialise_definition(m));
+        else add_other(key, vcf_reserialise_definition(m)); /* (unstructured lines come back as they are) */
     }
     for (const HeaderDef &d : defs) {
         const int g = strcmp(d.group, "INFO") == 0 ? 0 : 2;

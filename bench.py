@@ -247,10 +247,12 @@ def main():
     if use_dist:
         dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # warm the communicator up as well
     fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
+    call_end = np.zeros(args.steps + 1)  # the calls are synchronous: a timestamp behind each gives the spread of the calls inside the timed region
+    t0 = call_end[0] = time.perf_counter()
+    for k in range(args.steps):
         step()
         job_tally_host += res.tally  # SummaryWriter::add_comparison_benchmark over the job's batches (writers/summary.rs:146-163)
+        call_end[k + 1] = time.perf_counter()
     tally.copy_(torch.from_numpy(job_tally_host.astype(np.int64)))
     if use_dist:
         dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 288 x int64, the job's only collective
@@ -265,7 +267,10 @@ def main():
         total_regions = int(cnt.item())
     else:
         total_regions = n_regions
-    log("timed region: %d %s calls in %.3f s (%.2f ms per call)" % (args.steps, entry_name, elapsed, elapsed / max(args.steps, 1) * 1e3))
+    call_ms = np.diff(call_end) * 1e3
+    call_stats = {"min": round(float(call_ms.min()), 3), "median": round(float(np.median(call_ms)), 3), "p95": round(float(np.percentile(call_ms, 95)), 3),
+                  "max": round(float(call_ms.max()), 3)} if args.steps else None
+    log("timed region: %d %s calls in %.3f s (%.2f ms per call; single calls %s)" % (args.steps, entry_name, elapsed, elapsed / max(args.steps, 1) * 1e3, call_stats))
     job_tally = tally.clone()
     got_boundary = res  # the outputs of the last timed call, in the caller's arrays
     # the same boundary with the batch in the compact form (avk_compact_batch: 20 B per region + 17 B per call, explicit offsets), when `value` is on the packed one
@@ -429,6 +434,7 @@ def main():
                                        "one call set per GPU on %d GPU(s)" % world) +
                                       ", no data-path collective; one RCCL all-reduce of the job tally (288 x int64) inside the timed region",
                        "parity": parity, "workspace_tiers": tiers, "lane_kernel_regions": lane_regions},
+            "call_ms": call_stats,  # this rank's single calls inside the timed region (value = all of them, barrier to barrier)
             "resident_value": resident["value"] if resident else None,
             "resident": resident,
             "compact_soa": compact_entry,

@@ -603,7 +603,8 @@ def test_annotated_vcfs_bgzf_and_tabix(tmp_path, oracle):
 
 def test_output_header_is_regrouped_like_the_reference_library_writes_it(tmp_path, oracle):
     """a header in an arbitrary order comes out as: file format, INFO, FILTER, FORMAT, ALT, contig definitions, then the other lines
-    grouped by key in order of first appearance; a FORMAT definition with the ID of an added one is replaced in place"""
+    grouped by key in order of first appearance; a FORMAT definition with the ID of an added one is replaced in place; structured lines are written
+    again field by field (fixed field order per kind, "other" fields quoted, IDX last), lines that do not parse are kept as they are"""
     paths = {}
     for name, text in (("ref.fa", EDGE_FASTA), ("hc.bed", EDGE_BED), ("truth.vcf", EDGE_VCF_T), ("query.vcf", EDGE_VCF_Q)):
         paths[name] = str(tmp_path / name)
@@ -612,7 +613,12 @@ def test_output_header_is_regrouped_like_the_reference_library_writes_it(tmp_pat
     messy = ['##source=callerA', '##contig=<ID=chrA,length=300>', '##FORMAT=<ID=RI,Number=1,Type=String,Description="an older definition">',
              '##fileformat=VCFv4.2', '##FILTER=<ID=LowQual,Description="low">', '##cmdline=first', '##INFO=<ID=DP,Number=1,Type=Integer,Description="depth">',
              '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">', '##source=callerB', '##ALT=<ID=DEL,Description="deletion">',
-             '##contig=<ID=chrB,length=300>', '##cmdline=second']
+             '##contig=<ID=chrB,length=300>', '##cmdline=second',
+             # definitions the library writes differently from how they came in: fields out of order, bare "other" fields, IDX, escapes
+             '##INFO=<ID=AF,Type=Float,Description="allele \\"frequency\\", a\\\\b",Number=A,Source=callerA,Version=3>',
+             '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read depth",IDX=7,Note="kept, quoted">',
+             '##contig=<ID=chrC,assembly=toy,md5=0123abcd,length=300,URL=http://x/y>', '##FILTER=<Description="q<10",ID=q10>',
+             '##SAMPLE=<ID=S1,Assay=WGS,Description="the sample">', '##PEDIGREE=<Name_0=child,Name_1=mother>', '##META=<broken']
     src = str(tmp_path / "messy.vcf")
     write_text(src, "\n".join(messy + body) + "\n")
     genome = feeder.Genome(paths["ref.fa"])
@@ -621,13 +627,19 @@ def test_output_header_is_regrouped_like_the_reference_library_writes_it(tmp_pat
     out = str(tmp_path / "truth.vcf.gz")
     feeder.write_annotated_vcf(out, src, genome, feed.batch, res, 0, sample_name="S1", version="v", command_line="c")
     meta = [l for l in gzip.open(out, "rt").read().splitlines() if l.startswith("##")]
-    assert meta == ['##fileformat=VCFv4.2', '##INFO=<ID=DP,Number=1,Type=Integer,Description="depth">', '##FILTER=<ID=LowQual,Description="low">',
+    assert meta == ['##fileformat=VCFv4.2', '##INFO=<ID=DP,Number=1,Type=Integer,Description="depth">',
+                    '##INFO=<ID=AF,Number=A,Type=Float,Description="allele \\"frequency\\", a\\\\b",Source="callerA",Version="3">',
+                    '##FILTER=<ID=LowQual,Description="low">', '##FILTER=<ID=q10,Description="q<10">',
                     '##FORMAT=<ID=RI,Number=1,Type=Integer,Description="Region ID for the comparison">', '##FORMAT=<ID=GT,Number=1,Type=String,Description="Genotype">',
+                    '##FORMAT=<ID=DP,Number=1,Type=Integer,Description="Read depth",Note="kept, quoted",IDX=7>',
                     '##FORMAT=<ID=BD,Number=1,Type=String,Description="Benchmark Decision for call (TP/FP/FN)">',
                     '##FORMAT=<ID=EA,Number=1,Type=Integer,Description="Expected Allele count for this genotype">',
                     '##FORMAT=<ID=OA,Number=1,Type=Integer,Description="Observed Allele count for this genotype">',
                     '##ALT=<ID=DEL,Description="deletion">', '##contig=<ID=chrA,length=300>', '##contig=<ID=chrB,length=300>',
-                    '##source=callerA', '##source=callerB', '##cmdline=first', '##cmdline=second', '##aardvark_version="v"', '##aardvark_command="c"']
+                    '##contig=<ID=chrC,length=300,md5=0123abcd,URL=http://x/y,assembly="toy">',
+                    '##source=callerA', '##source=callerB', '##cmdline=first', '##cmdline=second',
+                    '##SAMPLE=<ID=S1,Assay="WGS",Description="the sample">', '##PEDIGREE=<Name_0=child,Name_1="mother">', '##META=<broken',
+                    '##aardvark_version="v"', '##aardvark_command="c"']
 
 
 def test_bgzf_writer_splits_large_outputs(tmp_path, oracle):
