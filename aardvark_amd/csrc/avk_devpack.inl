@@ -205,6 +205,45 @@ AVK_DEV void dp_widen_packed(const DpPacked &c, u64 i) { /* one lane: region i (
     }
 }
 
+/* the packed MultiRegions (avk_packed_multi_batch): in_off = exclusive prefix sum of in_cnt over (region, input) */
+struct DpPackedMulti {
+    const uint16_t *contig_idx, *len, *rel_pos;
+    const u32 *start, *var_raw;
+    const u8 *in_cnt, *var_type_zyg, *a0_len, *a1_len;
+    const u64 *in_off, *a_off;
+    u64 n_multi, n_variants;
+    u32 k;
+    u32 *w_contig, *w_in_cnt, *w_a0_len, *w_a1_len, *w_raw;
+    u64 *w_start, *w_end, *w_pos, *w_a0_off, *w_a1_off;
+    u8 *w_type, *w_zyg;
+};
+AVK_DEV void dp_widen_packed_multi(const DpPackedMulti &c, u64 i) { /* one lane: MultiRegion i (and the positions of its calls) and call i */
+    if (i < c.n_multi) {
+        const u64 st = c.start[i], vo = c.in_off[i * c.k];
+        if (c.w_contig) c.w_contig[i] = c.contig_idx[i];
+        c.w_start[i] = st;
+        c.w_end[i] = st + c.len[i];
+        u32 calls = 0;
+        for (u32 j = 0; j < c.k; ++j) {
+            const u32 cnt = c.in_cnt[i * c.k + j];
+            c.w_in_cnt[i * c.k + j] = cnt;
+            calls += cnt;
+        }
+        for (u32 q = 0; q < calls && vo + q < c.n_variants; ++q) c.w_pos[vo + q] = st + c.rel_pos[vo + q];
+    }
+    if (i < c.n_variants) {
+        const u64 ao = c.a_off[i];
+        const u32 l0 = c.a0_len[i], l1 = c.a1_len[i], tz = c.var_type_zyg[i];
+        c.w_a0_off[i] = ao;
+        c.w_a1_off[i] = ao + l0;
+        c.w_a0_len[i] = l0;
+        c.w_a1_len[i] = l1;
+        if (c.w_raw) c.w_raw[i] = c.var_raw ? c.var_raw[i] : (l0 > l1 ? l0 : l1);
+        c.w_type[i] = (u8)(tz & 15u);
+        c.w_zyg[i] = (u8)(tz >> 4);
+    }
+}
+
 /* ---- the merge path on the device (solve_merge_region, src/merge_solver.rs:110-200) ------------------------------------------------------------------- */
 /* a batch of MultiRegions (avk_multi_batch) as one CompareRegion-shaped item per input pair (i < j, lexicographic): input i plays the truth side */
 struct DpPairs {

@@ -15,6 +15,7 @@ __global__ void __launch_bounds__(256) avk_dp_merge_classify_kernel(dpk::DpMerge
 
 __global__ void __launch_bounds__(256) avk_dp_widen_kernel(dpk::DpCompact c) { dpk::dp_widen(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 __global__ void __launch_bounds__(256) avk_dp_widen_packed_kernel(dpk::DpPacked c) { dpk::dp_widen_packed(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
+__global__ void __launch_bounds__(256) avk_dp_widen_packed_multi_kernel(dpk::DpPackedMulti c) { dpk::dp_widen_packed_multi(c, (uint64_t)blockIdx.x * 256u + threadIdx.x); }
 /* Exclusive prefix sum of a[i] + b[i] over n byte pairs (the packed form's offsets: calls per region, allele bytes per call): per-workgroup sums of 4096
  * elements, a one-workgroup scan of those sums, then every workgroup scans its own 4096 again from its base.  16 elements per thread, waves and workgroup
  * combined through LDS. */
@@ -24,7 +25,7 @@ __device__ inline uint32_t avk_ps_thread_sum(const uint8_t *a, const uint8_t *b,
 #pragma unroll
     for (uint32_t k = 0; k < 16; ++k) {
         const uint64_t i = i0 + k;
-        v[k] = i < n ? (uint32_t)a[i] + (uint32_t)b[i] : 0u;
+        v[k] = i < n ? (uint32_t)a[i] + (b ? (uint32_t)b[i] : 0u) : 0u; /* b == NULL: the sum of one array */
         s += v[k];
     }
     return s;
@@ -446,7 +447,10 @@ static int pool_alloc(avk_ctx *ctx, void **p, size_t bytes) {
             return 0;
         }
     }
+    const bool timing = getenv("AVK_TIMING") != nullptr;
+    const auto t_malloc = std::chrono::steady_clock::now();
     hipError_t e = hipMalloc(p, bytes);
+    if (timing) fprintf(stderr, "avk pool: no cached buffer of %zu bytes, hipMalloc %.3f ms\n", bytes, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_malloc).count());
     if (e == hipErrorOutOfMemory) { /* give the cached buffers back and try again */
         (void)hipGetLastError();
         std::vector<void *> drop;
@@ -490,7 +494,11 @@ static void pool_release(avk_ctx *ctx, void *p) {
                 break;
             }
     }
-    if (drop) (void)hipFree(p);
+    if (drop) {
+        const auto t_free = std::chrono::steady_clock::now();
+        (void)hipFree(p);
+        if (getenv("AVK_TIMING")) fprintf(stderr, "avk pool: cache limit reached, hipFree %.3f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_free).count());
+    }
 }
 
 static void pool_destroy(avk_ctx *ctx) {
@@ -669,23 +677,26 @@ static void release_pooled(avk_ctx *ctx, avk_dev_batch *db) {
 
 /* b: the batch in the wide form, or NULL and cb: the batch in the compact form (avk_compact_batch: half the bytes over PCIe, widened on the device) */
 /* mb: a batch of MultiRegions (the merge path): one region per input pair is made on the device (dp_expand_pairs) */
+/* (pm: the packed form of a multi batch; `mb` then only carries n_regions, n_inputs, n_variants, allele_bytes and allele_bytes_len) */
 static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out, const avk_multi_batch *mb = nullptr,
-                                const avk_packed_batch *pk = nullptr) {
+                                const avk_packed_batch *pk = nullptr, const avk_packed_multi_batch *pm = nullptr) {
     const uint32_t mk = mb ? mb->n_inputs : 0, mppr = mk * (mk - (mk ? 1u : 0u)) / 2;
     const uint64_t n = pk ? pk->n_regions : (b ? b->n_regions : (cb ? cb->n_regions : mb->n_regions * mppr)), nv = pk ? pk->n_variants : (b ? b->n_variants : (cb ? cb->n_variants : mb->n_variants)),
                    alen = pk ? pk->allele_bytes_len : (b ? b->allele_bytes_len : (cb ? cb->allele_bytes_len : mb->allele_bytes_len));
     if (pk && n && (!pk->start || !pk->len || !pk->t_cnt || !pk->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (pk && nv && (!pk->var_rel_pos || !pk->var_type_zyg || !pk->a0_len || !pk->a1_len || !pk->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
-    if (mb && mb->n_regions && (!mb->start || !mb->end || !mb->in_off || !mb->in_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
-    if (mb && nv && (!mb->var_pos || !mb->var_type || !mb->var_zyg || !mb->a0_off || !mb->a0_len || !mb->a1_off || !mb->a1_len || !mb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    if (pm && pm->n_regions && (!pm->start || !pm->len || !pm->in_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (pm && nv && (!pm->var_rel_pos || !pm->var_type_zyg || !pm->a0_len || !pm->a1_len || !pm->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    if (mb && !pm && mb->n_regions && (!mb->start || !mb->end || !mb->in_off || !mb->in_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (mb && !pm && nv && (!mb->var_pos || !mb->var_type || !mb->var_zyg || !mb->a0_off || !mb->a0_len || !mb->a1_off || !mb->a1_len || !mb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (n > 0x7FFFFFFFull || nv > 0x7FFFFFFFull) return fail(ctx, AVK_E_ARG, "batch too large (more than 2^31 regions or variants); split it");
     if (b && n && (!b->start || !b->end || !b->t_off || !b->t_cnt || !b->q_off || !b->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (b && nv && (!b->var_pos || !b->var_type || !b->var_zyg || !b->a0_off || !b->a0_len || !b->a1_off || !b->a1_len || !b->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (cb && n && (!cb->start || !cb->len || !cb->v_off || !cb->t_cnt || !cb->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
     if (cb && nv && (!cb->var_pos || !cb->var_type_zyg || !cb->a_off || !cb->a0_len || !cb->a1_len || !cb->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
     if (cb && alen > 0xFFFFFFFFull) return fail(ctx, AVK_E_ARG, "the compact form holds at most 2^32 allele bytes");
-    const bool has_contig = pk ? pk->contig_idx != nullptr : (b ? b->contig_idx != nullptr : (cb ? cb->contig_idx != nullptr : mb->contig_idx != nullptr)),
-               has_raw = pk ? pk->var_raw_space != nullptr : (b ? b->var_raw_space != nullptr : (cb ? cb->var_raw_space != nullptr : mb->var_raw_space != nullptr));
+    const bool has_contig = pm ? pm->contig_idx != nullptr : (pk ? pk->contig_idx != nullptr : (b ? b->contig_idx != nullptr : (cb ? cb->contig_idx != nullptr : mb->contig_idx != nullptr))),
+               has_raw = pm ? pm->var_raw_space != nullptr : (pk ? pk->var_raw_space != nullptr : (b ? b->var_raw_space != nullptr : (cb ? cb->var_raw_space != nullptr : mb->var_raw_space != nullptr)));
     const uint8_t *host_alleles = pk ? pk->allele_bytes : (b ? b->allele_bytes : (cb ? cb->allele_bytes : mb->allele_bytes));
     const bool timing = getenv("AVK_TIMING") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -818,12 +829,59 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         db->d_in_zyg = d_zyg;
         db->n_multi = nm, db->m_inputs = mk;
         if (rc) return bail(rc);
+        if (pm) { /* the packed arrays as they are; in_off and a_off by prefix sums; one kernel writes the wide MultiRegion arrays the pair expansion reads */
+            const uint64_t ni = nm * mk;
+            uint16_t *p_contig = has_contig ? (uint16_t *)tmp((nm + 1) * 2) : nullptr, *p_len = (uint16_t *)tmp((nm + 1) * 2), *p_rel = (uint16_t *)tmp((nv + 1) * 2);
+            uint32_t *p_start = (uint32_t *)tmp((nm + 1) * 4);
+            uint8_t *p_ic = (uint8_t *)tmp(ni + 16), *p_tz = (uint8_t *)tmp(nv + 16), *p_a0 = (uint8_t *)tmp(nv + 16), *p_a1 = (uint8_t *)tmp(nv + 16);
+            const uint32_t nb_r = (uint32_t)((ni + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK), nb_v = (uint32_t)((nv + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK);
+            uint64_t *p_aoff = (uint64_t *)tmp((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
+            if (rc) return bail(rc);
+            hipStream_t side = ctx->lane_stream4; /* as for avk_packed_batch: the counts on this stream, the rest beside the prefix sums */
+            hipError_t ec = hipEventRecord(ctx->ev_copy_fork, s);
+            if (ec == hipSuccess) ec = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0);
+            if (ec != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "packed upload: %s", hipGetErrorString(ec)));
+            auto side_fail = [&](int code) {
+                (void)hipStreamSynchronize(side);
+                return bail(code);
+            };
+            rc = copy_in(ctx, {{pm->in_cnt, p_ic, ni}, {pm->a0_len, p_a0, nv}, {pm->a1_len, p_a1, nv}, {pm->start, p_start, nm * 4, side}, {pm->len, p_len, nm * 2, side},
+                               {pm->contig_idx, p_contig, has_contig ? nm * 2 : 0, side}, {pm->var_rel_pos, p_rel, nv * 2, side}, {pm->var_type_zyg, p_tz, nv, side, ctx->ev_copy_mid},
+                               {pm->var_raw_space, d_raw, has_raw ? nv * 4 : 0, side}, {pm->allele_bytes, d_alleles, alen, side, ctx->ev_copy_join}});
+            if (rc) return side_fail(rc);
+            if (ni) {
+                hipLaunchKernelGGL(avk_ps_block_sums_kernel, dim3(nb_r), dim3(256), 0, s, (const uint8_t *)p_ic, (const uint8_t *)nullptr, ni, p_sums);
+                hipLaunchKernelGGL(avk_ps_scan_sums_kernel, dim3(1), dim3(1024), 0, s, p_sums, nb_r, p_sums + nb_r + nb_v);
+                hipLaunchKernelGGL(avk_ps_apply_kernel, dim3(nb_r), dim3(256), 0, s, (const uint8_t *)p_ic, (const uint8_t *)nullptr, ni, (const uint64_t *)p_sums, db->d_m_in_off);
+            }
+            if (nv) {
+                hipLaunchKernelGGL(avk_ps_block_sums_kernel, dim3(nb_v), dim3(256), 0, s, (const uint8_t *)p_a0, (const uint8_t *)p_a1, nv, p_sums + nb_r);
+                hipLaunchKernelGGL(avk_ps_scan_sums_kernel, dim3(1), dim3(1024), 0, s, p_sums + nb_r, nb_v, p_sums + nb_r + nb_v + 1);
+                hipLaunchKernelGGL(avk_ps_apply_kernel, dim3(nb_v), dim3(256), 0, s, (const uint8_t *)p_a0, (const uint8_t *)p_a1, nv, (const uint64_t *)(p_sums + nb_r), p_aoff);
+            }
+            pk_totals = p_sums + nb_r + nb_v;
+            dpk::DpPackedMulti w;
+            memset(&w, 0, sizeof(w));
+            w.contig_idx = p_contig, w.len = p_len, w.rel_pos = p_rel, w.start = p_start, w.var_raw = d_raw, w.in_cnt = p_ic, w.var_type_zyg = p_tz, w.a0_len = p_a0, w.a1_len = p_a1,
+            w.in_off = db->d_m_in_off, w.a_off = p_aoff, w.n_multi = nm, w.n_variants = nv, w.k = mk;
+            w.w_contig = m_contig, w.w_in_cnt = db->d_m_in_cnt, w.w_a0_len = d_a0l, w.w_a1_len = d_a1l, w.w_raw = nullptr, w.w_start = m_start, w.w_end = m_end, w.w_pos = d_pos,
+            w.w_a0_off = d_a0o, w.w_a1_off = d_a1o, w.w_type = d_type, w.w_zyg = d_zyg;
+            const uint64_t mx = nm > nv ? nm : nv;
+            hipError_t ew = hipStreamWaitEvent(s, ctx->ev_copy_mid, 0);
+            if (mx && ew == hipSuccess) {
+                hipLaunchKernelGGL(avk_dp_widen_packed_multi_kernel, dim3((unsigned)((mx + 255) / 256)), dim3(256), 0, s, w);
+                ew = hipGetLastError();
+            }
+            const hipError_t ej = hipStreamWaitEvent(s, ctx->ev_copy_join, 0);
+            if (ew != hipSuccess || ej != hipSuccess) return side_fail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ew != hipSuccess ? ew : ej)));
+        } else {
         std::vector<CopySeg> segs = {{mb->start, m_start, nm * 8}, {mb->end, m_end, nm * 8}, {mb->in_off, db->d_m_in_off, nm * mk * 8}, {mb->in_cnt, db->d_m_in_cnt, nm * mk * 4},
                                      {mb->contig_idx, m_contig, has_contig ? nm * 4 : 0}, {mb->var_pos, d_pos, nv * 8}, {mb->a0_off, d_a0o, nv * 8}, {mb->a1_off, d_a1o, nv * 8},
                                      {mb->a0_len, d_a0l, nv * 4}, {mb->a1_len, d_a1l, nv * 4}, {mb->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {mb->var_type, d_type, nv},
                                      {mb->var_zyg, d_zyg, nv}, {mb->allele_bytes, d_alleles, alen}};
         rc = copy_in(ctx, segs);
         if (rc) return bail(rc);
+        }
         dpk::DpPairs c;
         memset(&c, 0, sizeof(c));
         c.contig_idx = m_contig, c.start = m_start, c.end = m_end, c.in_off = db->d_m_in_off, c.in_cnt = db->d_m_in_cnt, c.n_multi = nm, c.k = mk, c.ppr = mppr;
@@ -914,18 +972,19 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         return x;
     };
     if (e == hipSuccess) e = region_passes();
-    if (e == hipSuccess && pk) { /* the two sums the packed form implies must be what the caller says they are */
+    if (e == hipSuccess && (pk || pm)) { /* the two sums the packed form implies must be what the caller says they are */
         uint64_t tot[2] = {0, 0};
         e = hipMemcpy(tot, pk_totals, sizeof(tot), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && ((n && tot[0] != nv) || (nv && tot[1] != alen)))
+        if (e == hipSuccess && (((pm ? pm->n_regions : n) && tot[0] != nv) || (nv && tot[1] != alen)))
             return bail(fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to %llu (n_variants %llu), the allele lengths to %llu (allele_bytes_len %llu)",
                              (unsigned long long)tot[0], (unsigned long long)nv, (unsigned long long)tot[1], (unsigned long long)alen));
     }
     std::vector<uint64_t> pk_aoff; /* packed form: allele offsets on the host, made only when a call needs the host's edit distance */
-    if (e == hipSuccess && hs->n_pending && pk) {
+    const uint8_t *pk_l0 = pk ? pk->a0_len : (pm ? pm->a0_len : nullptr), *pk_l1 = pk ? pk->a1_len : (pm ? pm->a1_len : nullptr);
+    if (e == hipSuccess && hs->n_pending && pk_l0) {
         pk_aoff.resize(nv + 1);
         uint64_t run = 0;
-        for (uint64_t v = 0; v < nv; ++v) pk_aoff[v] = run, run += (uint64_t)pk->a0_len[v] + pk->a1_len[v];
+        for (uint64_t v = 0; v < nv; ++v) pk_aoff[v] = run, run += (uint64_t)pk_l0[v] + pk_l1[v];
     }
     if (e == hipSuccess && hs->n_pending) {
         /* calls whose two alleles are both long after the common prefix and suffix are gone: their alt_ed comes from the host
@@ -937,8 +996,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             avk_parallel_for(np, avk_host_threads(), [&](unsigned, uint64_t lo, uint64_t hi) {
                 for (uint64_t k = lo; k < hi; ++k) {
                     const uint64_t v = idx[k];
-                    const uint64_t o0 = pk ? pk_aoff[v] : (b ? b->a0_off[v] : (cb ? cb->a_off[v] : mb->a0_off[v])), l0 = pk ? pk->a0_len[v] : (b ? b->a0_len[v] : (cb ? cb->a0_len[v] : mb->a0_len[v])),
-                                   o1 = pk ? o0 + l0 : (b ? b->a1_off[v] : (cb ? o0 + l0 : mb->a1_off[v])), l1 = pk ? pk->a1_len[v] : (b ? b->a1_len[v] : (cb ? cb->a1_len[v] : mb->a1_len[v]));
+                    const uint64_t o0 = pk_l0 ? pk_aoff[v] : (b ? b->a0_off[v] : (cb ? cb->a_off[v] : mb->a0_off[v])), l0 = pk_l0 ? pk_l0[v] : (b ? b->a0_len[v] : (cb ? cb->a0_len[v] : mb->a0_len[v])),
+                                   o1 = pk_l0 ? o0 + l0 : (b ? b->a1_off[v] : (cb ? o0 + l0 : mb->a1_off[v])), l1 = pk_l0 ? pk_l1[v] : (b ? b->a1_len[v] : (cb ? cb->a1_len[v] : mb->a1_len[v]));
                     ed[k] = (uint32_t)avk::host_edit_distance(host_alleles + o0, l0, host_alleles + o1, l1);
                 }
             });

@@ -1296,7 +1296,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         a.high_priority = 0;
         a.esc_bytes = 0;
         a.esc_enabled = 0;
-        a.static_pct = (uint32_t)ctx->static_pct;
+        /* pairs of a merge batch: the bulk launch is long (200,000 regions beside 10 M in the lanes) and its 40 KB workgroups do not all become resident while the
+         * lane launches keep taking the LDS that comes free; a statically dealt share would wait for workgroups that start when the lanes are done
+         * (12 or 22 ms per whole-genome merge, from call to call) — everything is claimed there */
+        a.static_pct = mode == 1 ? 0u : (uint32_t)ctx->static_pct;
         a.n_shards = 8;
         a.claim = (uint32_t)ctx->claim;
         if (t == 0) {
@@ -2316,17 +2319,66 @@ int avk_merge_classify(uint64_t n_regions, uint32_t k, const uint32_t *in_cnt, c
     return 0;
 }
 
+static bool merge_on_device(const avk_ctx *ctx, uint64_t n_regions, uint32_t k) {
+    return ctx->device_pack && k >= 2 && k <= (uint32_t)avk::dp::DP_MERGE_KMAX && n_regions && n_regions * (uint64_t)(k * (k - 1) / 2) <= 0x7FFFFFFFull;
+}
+static int merge_batch_internal(avk_ctx *ctx, const avk_multi_batch *mb, const avk_packed_multi_batch *pm, const avk_merge_config *cfg, int32_t *status, uint8_t *classification,
+                                uint64_t *members);
+
+int avk_merge_packed(avk_ctx *ctx, const avk_packed_multi_batch *pm, const avk_merge_config *cfg, int32_t *status, uint8_t *classification, uint64_t *members) {
+    if (!ctx || !pm || !cfg || !status || !classification || !members) return AVK_E_ARG;
+    const uint32_t k = pm->n_inputs;
+    if (k < 1 || k > 64) return fail(ctx, AVK_E_ARG, "n_inputs must be in [1, 64]");
+    const uint64_t n = pm->n_regions, nv = pm->n_variants;
+    if (n && (!pm->start || !pm->len || !pm->in_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (nv && (!pm->var_rel_pos || !pm->var_type_zyg || !pm->a0_len || !pm->a1_len || !pm->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    avk_multi_batch mb;
+    memset(&mb, 0, sizeof(mb));
+    mb.n_regions = n, mb.n_inputs = k, mb.n_variants = nv, mb.allele_bytes = pm->allele_bytes, mb.allele_bytes_len = pm->allele_bytes_len;
+    if (merge_on_device(ctx, n, k)) return merge_batch_internal(ctx, &mb, pm, cfg, status, classification, members);
+    /* no device path for this batch (more than DP_MERGE_KMAX inputs, an empty batch, device_pack = 0): the wide form, made here, through avk_merge_batch */
+    std::vector<uint64_t> start(n), end(n), in_off(n * k), pos(nv), a0_off(nv), a1_off(nv);
+    std::vector<uint32_t> contig(n), in_cnt(n * k), a0_len(nv), a1_len(nv), raw(nv);
+    std::vector<uint8_t> type(nv + 1), zyg(nv + 1);
+    uint64_t v = 0, ab = 0;
+    for (uint64_t m = 0; m < n; ++m) {
+        contig[m] = pm->contig_idx ? pm->contig_idx[m] : 0u, start[m] = pm->start[m], end[m] = (uint64_t)pm->start[m] + pm->len[m];
+        for (uint32_t i = 0; i < k; ++i) {
+            in_off[m * k + i] = v, in_cnt[m * k + i] = pm->in_cnt[m * k + i];
+            for (uint32_t q = 0; q < pm->in_cnt[m * k + i]; ++q, ++v) {
+                if (v >= nv) return fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to more than n_variants %llu", (unsigned long long)nv);
+                pos[v] = start[m] + pm->var_rel_pos[v];
+            }
+        }
+    }
+    if (v != nv) return fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to %llu (n_variants %llu)", (unsigned long long)v, (unsigned long long)nv);
+    for (v = 0; v < nv; ++v) {
+        a0_off[v] = ab, a0_len[v] = pm->a0_len[v], a1_off[v] = ab + a0_len[v], a1_len[v] = pm->a1_len[v], ab += (uint64_t)a0_len[v] + a1_len[v];
+        raw[v] = pm->var_raw_space ? pm->var_raw_space[v] : (a0_len[v] > a1_len[v] ? a0_len[v] : a1_len[v]);
+        type[v] = pm->var_type_zyg[v] & 15u, zyg[v] = pm->var_type_zyg[v] >> 4;
+    }
+    if (ab != pm->allele_bytes_len && nv) return fail(ctx, AVK_E_ARG, "packed batch: the allele lengths sum to %llu (allele_bytes_len %llu)", (unsigned long long)ab, (unsigned long long)pm->allele_bytes_len);
+    mb.contig_idx = contig.data(), mb.start = start.data(), mb.end = end.data(), mb.in_off = in_off.data(), mb.in_cnt = in_cnt.data(), mb.var_pos = pos.data(), mb.var_type = type.data(),
+    mb.var_zyg = zyg.data(), mb.var_raw_space = raw.data(), mb.a0_off = a0_off.data(), mb.a0_len = a0_len.data(), mb.a1_off = a1_off.data(), mb.a1_len = a1_len.data();
+    return avk_merge_batch(ctx, &mb, cfg, status, classification, members);
+}
+
 int avk_merge_batch(avk_ctx *ctx, const avk_multi_batch *mb, const avk_merge_config *cfg, int32_t *status, uint8_t *classification, uint64_t *members) {
+    return merge_batch_internal(ctx, mb, nullptr, cfg, status, classification, members);
+}
+
+static int merge_batch_internal(avk_ctx *ctx, const avk_multi_batch *mb, const avk_packed_multi_batch *pm, const avk_merge_config *cfg, int32_t *status, uint8_t *classification,
+                                uint64_t *members) {
     if (!ctx || !mb || !cfg || !status || !classification || !members) return AVK_E_ARG;
     const uint32_t k = mb->n_inputs;
     if (k < 1 || k > 64) return fail(ctx, AVK_E_ARG, "n_inputs must be in [1, 64]");
-    if (ctx->device_pack && k >= 2 && k <= (uint32_t)avk::dp::DP_MERGE_KMAX && mb->n_regions && mb->n_regions * (uint64_t)(k * (k - 1) / 2) <= 0x7FFFFFFFull) {
+    if (merge_on_device(ctx, mb->n_regions, k)) {
         /* all of solve_merge_region on the device: the MultiRegions as they are over PCIe, one region per input pair made by a kernel, the pair solve (mode 1),
          * the decision on top of the pair matrix by a kernel; status / classification / members come back */
         if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
         AVK_HIP(ctx, hipSetDevice(ctx->device));
         avk_dev_batch *db = nullptr;
-        int rc = upload_device_packed(ctx, nullptr, nullptr, true, &db, mb);
+        int rc = upload_device_packed(ctx, nullptr, nullptr, true, &db, mb, nullptr, pm);
         if (rc) return rc;
         avk_compare_config pcfg;
         pcfg.max_branch_factor = cfg->max_branch_factor, pcfg.enable_sequences = 0, pcfg.enable_exact_shortcut = 0;

@@ -157,6 +157,83 @@ class MultiBatch:
         return out
 
 
+class AvkPackedMultiBatch(C.Structure):
+    _p = C.POINTER
+    _fields_ = [("n_regions", C.c_uint64), ("n_inputs", C.c_uint32), ("contig_idx", _p(C.c_uint16)), ("start", _p(C.c_uint32)), ("len", _p(C.c_uint16)),
+                ("in_cnt", _p(C.c_uint8)), ("n_variants", C.c_uint64), ("var_rel_pos", _p(C.c_uint16)), ("var_type_zyg", _p(C.c_uint8)),
+                ("a0_len", _p(C.c_uint8)), ("a1_len", _p(C.c_uint8)), ("var_raw_space", _p(C.c_uint32)), ("allele_bytes", _p(C.c_uint8)),
+                ("allele_bytes_len", C.c_uint64)]
+
+
+class PackedMultiBatch:
+    """The same batch in the library's packed form (avk_packed_multi_batch): 8 + k bytes per region, 5 per call plus the allele bytes; every offset is implied
+    by order.  `from_multi` checks the constraints (calls back to back in region / input order, alleles back to back in call order, narrow fields wide enough)."""
+
+    FIELDS = ("contig_idx", "start", "len", "in_cnt", "var_rel_pos", "var_type_zyg", "a0_len", "a1_len", "var_raw_space", "allele_bytes")
+    DTYPES = (np.uint16, np.uint32, np.uint16, np.uint8, np.uint16, np.uint8, np.uint8, np.uint8, np.uint32, np.uint8)
+
+    def __init__(self, n_inputs, **arrays):
+        self.n_inputs = int(n_inputs)
+        for name, dt in zip(self.FIELDS, self.DTYPES):
+            a = arrays.get(name)
+            setattr(self, name, None if a is None else np.ascontiguousarray(a, dtype=dt))
+        self.n_regions = int(self.start.size)
+        self.n_variants = int(self.var_rel_pos.size)
+        assert self.in_cnt.size == self.n_regions * self.n_inputs
+
+    @classmethod
+    def from_multi(cls, mb, keep_raw_space=None):
+        n, nv, k = mb.n_regions, mb.n_variants, mb.n_inputs
+        cnt = mb.in_cnt.astype(np.int64)
+        ioff = np.concatenate([[0], np.cumsum(cnt)])
+        alen = mb.a0_len.astype(np.int64) + mb.a1_len
+        aoff = np.concatenate([[0], np.cumsum(alen)])
+        nbytes = int(aoff[-1])
+        ok = (np.array_equal(mb.in_off, ioff[:-1]) and int(ioff[-1]) == nv and np.array_equal(mb.a0_off, aoff[:-1]) and np.array_equal(mb.a1_off, aoff[:-1] + mb.a0_len) and
+              (nv == 0 or nbytes == mb.allele_bytes.size) and bool(np.all(mb.end >= mb.start)) and
+              (n == 0 or (int((mb.end - mb.start).max()) < 65536 and int(mb.start.max()) < 2 ** 32 and int(cnt.max()) < 256 and int(mb.contig_idx.max()) < 65536)) and
+              (nv == 0 or (int(mb.a0_len.max()) < 256 and int(mb.a1_len.max()) < 256 and int(mb.var_type.max()) < 16 and int(mb.var_zyg.max()) < 16)))
+        rel = None
+        if ok:
+            per_region = cnt.reshape(n, k).sum(axis=1) if n else np.zeros(0, np.int64)
+            rel = mb.var_pos.astype(np.int64) - np.repeat(mb.start.astype(np.int64), per_region)
+            ok = nv == 0 or (int(rel.min()) >= 0 and int(rel.max()) < 65536)
+        if not ok:
+            raise ValueError("the batch does not satisfy the constraints of the packed form (include/aardvark_amd.h: avk_packed_multi_batch)")
+        if keep_raw_space is None:
+            keep_raw_space = not np.array_equal(mb.var_raw_space, np.maximum(mb.a0_len, mb.a1_len))
+        return cls(k, contig_idx=mb.contig_idx, start=mb.start, len=mb.end - mb.start, in_cnt=mb.in_cnt, var_rel_pos=rel, var_type_zyg=mb.var_type | (mb.var_zyg << 4),
+                   a0_len=mb.a0_len, a1_len=mb.a1_len, var_raw_space=mb.var_raw_space if keep_raw_space else None,
+                   allele_bytes=mb.allele_bytes[:nbytes] if nv else np.zeros(1, np.uint8))
+
+    def widen(self):
+        """back to the wide form (what the library's dp_widen_packed_multi kernel writes on the device)"""
+        n, k = self.n_regions, self.n_inputs
+        cnt = self.in_cnt.astype(np.int64)
+        ioff = np.concatenate([[0], np.cumsum(cnt)])[:-1]
+        aoff = np.concatenate([[0], np.cumsum(self.a0_len.astype(np.int64) + self.a1_len)])[:-1]
+        per_region = cnt.reshape(n, k).sum(axis=1) if n else np.zeros(0, np.int64)
+        raw = self.var_raw_space if self.var_raw_space is not None else np.maximum(self.a0_len, self.a1_len)
+        return MultiBatch(k, region_id=np.arange(n), contig_idx=self.contig_idx if self.contig_idx is not None else np.zeros(n), start=self.start,
+                          end=self.start.astype(np.uint64) + self.len, in_off=ioff, in_cnt=self.in_cnt, var_pos=np.repeat(self.start.astype(np.int64), per_region) + self.var_rel_pos,
+                          var_type=self.var_type_zyg & 15, var_zyg=self.var_type_zyg >> 4, var_raw_space=raw, a0_off=aoff, a0_len=self.a0_len, a1_off=aoff + self.a0_len,
+                          a1_len=self.a1_len, allele_bytes=self.allele_bytes)
+
+    def nbytes(self):
+        return sum(getattr(self, f).nbytes for f in self.FIELDS if getattr(self, f) is not None)
+
+    def c_struct(self):
+        b = AvkPackedMultiBatch()
+        b.n_regions, b.n_inputs, b.n_variants = self.n_regions, self.n_inputs, self.n_variants
+        for name, ct in (("contig_idx", C.c_uint16), ("start", C.c_uint32), ("len", C.c_uint16), ("in_cnt", C.c_uint8), ("var_rel_pos", C.c_uint16), ("var_type_zyg", C.c_uint8),
+                         ("a0_len", C.c_uint8), ("a1_len", C.c_uint8), ("var_raw_space", C.c_uint32), ("allele_bytes", C.c_uint8)):
+            a = getattr(self, name)
+            if a is not None:
+                setattr(b, name, a.ctypes.data_as(C.POINTER(ct)))
+        b.allele_bytes_len = int(self.allele_bytes.size) if self.n_variants else 0
+        return b
+
+
 class MergeResult:
     """status / classification (AVK_MERGE_*) / members per region, the outputs of avk_merge_batch"""
 
@@ -181,18 +258,21 @@ class MergeResult:
 
 
 def pinned_multi_batch(ctx, mb):
-    """a copy of a MultiBatch whose arrays live in pinned memory (avk_host_alloc): avk_merge_batch then copies them by DMA instead of through the bounce buffer"""
+    """a copy of a MultiBatch / PackedMultiBatch whose arrays live in pinned memory (avk_host_alloc): avk_merge_batch / avk_merge_packed then copy them by DMA
+    instead of through the bounce buffer"""
     arrays = {}
-    for name in MultiBatch.FIELDS:
+    for name in type(mb).FIELDS:
         a = getattr(mb, name)
+        if a is None:
+            continue
         out = ctx.host_array(a.shape, a.dtype)
         out[...] = a
         arrays[name] = out
-    return MultiBatch(mb.n_inputs, **arrays)
+    return type(mb)(mb.n_inputs, **arrays)
 
 
 def merge_multi_batch(ctx, mb, config=None):
-    """avk_merge_batch on a MultiBatch: pairs on the GPU, classification on the host -> MergeResult"""
+    """avk_merge_batch on a MultiBatch, avk_merge_packed on a PackedMultiBatch: all of solve_merge_region on the GPU -> MergeResult"""
     config = config or MergeConfig()
     n = mb.n_regions
     cfg = AvkMergeConfig(config.max_branch_factor, int(config.no_conflict_enabled), int(config.majority_voting_enabled),
@@ -202,8 +282,10 @@ def merge_multi_batch(ctx, mb, config=None):
     members = np.zeros(max(n, 1), np.uint64)
     P = lambda a, t: a.ctypes.data_as(C.POINTER(t))
     cb = mb.c_struct()
-    ctx.lib.avk_merge_batch.argtypes = [C.c_void_p, C.POINTER(AvkMultiBatch), C.POINTER(AvkMergeConfig), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
-    ctx._check(ctx.lib.avk_merge_batch(ctx.handle, C.byref(cb), C.byref(cfg), P(st, C.c_int32), P(cls, C.c_uint8), P(members, C.c_uint64)))
+    packed = isinstance(mb, PackedMultiBatch)
+    entry = ctx.lib.avk_merge_packed if packed else ctx.lib.avk_merge_batch
+    entry.argtypes = [C.c_void_p, C.POINTER(AvkPackedMultiBatch if packed else AvkMultiBatch), C.POINTER(AvkMergeConfig), C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
+    ctx._check(entry(ctx.handle, C.byref(cb), C.byref(cfg), P(st, C.c_int32), P(cls, C.c_uint8), P(members, C.c_uint64)))
     return MergeResult(st[:n], cls[:n], members[:n], mb.n_inputs)
 
 

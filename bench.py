@@ -554,24 +554,44 @@ def secondary_legs(ctx, cfg, args, cpus, log):
     contigs4, batch4 = synth.config_genome(scale=args.secondary_scale / 5, threads=min(8, cpus), gap=1000)
     compare_leg("min_variant_gap_1000", contigs4, batch4, "genome x %.3g clustered with --min-variant-gap 1000, %d regions" % (args.secondary_scale / 5, batch4.n_regions), few=True)
     if not args.no_merge:
-        from aardvark_amd.merge import MergeConfig, merge_multi_batch, pinned_multi_batch
+        from aardvark_amd.merge import MergeConfig, MultiBatch, PackedMultiBatch, merge_multi_batch, pinned_multi_batch
         import merge_oracle as mo
         contigs5, mb = synth.config_genome_merge(scale=args.merge_scale, k=3, threads=min(8, cpus))
         ctx.upload_reference(contigs5)
+        wide_mb = mb
+        try:  # the packed form (avk_merge_packed) when the batch fits it, as the compare legs do
+            timed_mb = PackedMultiBatch.from_multi(mb) if args.form == "packed" else mb
+        except ValueError:
+            timed_mb = mb
+        merge_packed = isinstance(timed_mb, PackedMultiBatch)
         if not args.pageable:
-            mb = pinned_multi_batch(ctx, mb)
+            timed_mb, wide_mb = pinned_multi_batch(ctx, timed_mb), (pinned_multi_batch(ctx, mb) if merge_packed else None)
+            if wide_mb is None:
+                wide_mb = timed_mb
         mcfg = MergeConfig(majority_voting_enabled=True)
-        merge_multi_batch(ctx, mb, mcfg)
+        merge_multi_batch(ctx, timed_mb, mcfg)
         t0 = time.perf_counter()
         nm = 6
         for _ in range(nm):
-            mres = merge_multi_batch(ctx, mb, mcfg)
+            mres = merge_multi_batch(ctx, timed_mb, mcfg)
         me = time.perf_counter() - t0
+        where = "pageable" if args.pageable else "pinned"
         entry = {"workload": "BASELINE configs[4] stand-in on ONE GPU: merge of 3 call sets (seeds 20250105-7) x %.3g genome, majority strategy, %d regions, %d input pairs"
                              % (args.merge_scale, mb.n_regions, 3 * mb.n_regions),
                  "value": mb.n_regions * nm / me, "unit": "merge regions/s", "ms_per_step": me / nm * 1e3, "steps": nm,
-                 "what": ("avk_merge_batch (solve_merge_region, src/merge_solver.rs:110-200): multi-region batch in %s host memory -> pairs + classification on the GPU -> status, "
-                         "classification and members in host arrays") % ("pageable" if args.pageable else "pinned")}
+                 "bytes_in": int(timed_mb.nbytes()) if merge_packed else int(sum(getattr(mb, f).nbytes for f in MultiBatch.FIELDS)),
+                 "what": ("%s (solve_merge_region, src/merge_solver.rs:110-200): multi-region batch (%s form) in %s host memory -> pairs + classification on the GPU -> status, "
+                          "classification and members in host arrays") % ("avk_merge_packed" if merge_packed else "avk_merge_batch", "packed" if merge_packed else "wide", where)}
+        if merge_packed:  # the same call with the wide arrays (avk_merge_batch), same outputs
+            merge_multi_batch(ctx, wide_mb, mcfg)
+            t0 = time.perf_counter()
+            for _ in range(nm):
+                wres = merge_multi_batch(ctx, wide_mb, mcfg)
+            we = time.perf_counter() - t0
+            entry["wide_soa"] = {"value": mb.n_regions * nm / we, "ms_per_step": we / nm * 1e3, "bytes_in": int(sum(getattr(mb, f).nbytes for f in MultiBatch.FIELDS)),
+                                 "same_outputs": bool(np.array_equal(wres.status, mres.status) and np.array_equal(wres.classification, mres.classification) and
+                                                      np.array_equal(wres.members, mres.members)),
+                                 "what": "the same through avk_merge_batch (avk_multi_batch arrays in %s host memory)" % where}
         # parity: oracle pairs + the restated classification (oracle/merge_oracle.py) on a sample, and the pair results of every region
         k = 3
         st_o, ex_o = oracle_lib.optimize_pairs(lib, pair_batch_of(mb), oracle_lib.ContigSet(contigs5), 50, threads=cpus)

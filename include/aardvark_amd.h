@@ -401,6 +401,25 @@ typedef struct avk_multi_batch {
     const uint64_t *a1_off; const uint32_t *a1_len;
     const uint8_t  *allele_bytes; uint64_t allele_bytes_len;
 } avk_multi_batch;
+/* The same batch in the PACKED form (round 3; avk_packed_batch's rules): every offset implied by order — the calls of region m follow those of region
+ * m - 1, input by input; the alleles of call v follow those of call v - 1 (allele0, then allele1); call positions are relative to their region's start.
+ * 8 + k bytes per region and 5 per call plus the allele bytes: a three-caller whole genome crosses PCIe as 0.13 GB instead of 0.72.  Constraints: windows
+ * shorter than 65,536 bases, at most 255 calls per region and input, alleles of at most 255 bases, fewer than 2^32 calls and allele bytes, contigs shorter
+ * than 4 Gbp, at most 65,535 contigs. */
+typedef struct avk_packed_multi_batch {
+    uint64_t n_regions;
+    uint32_t n_inputs;               /* k, 2..64 */
+    const uint16_t *contig_idx;      /* [n_regions] may be NULL (contig 0) */
+    const uint32_t *start;           /* [n_regions] */
+    const uint16_t *len;             /* [n_regions] end - start */
+    const uint8_t  *in_cnt;          /* [n_regions * k] */
+    uint64_t n_variants;             /* = sum of in_cnt */
+    const uint16_t *var_rel_pos;     /* [n_variants] position - the region's start */
+    const uint8_t  *var_type_zyg;    /* [n_variants] AVK_VT_* | AVK_ZYG_* << 4 */
+    const uint8_t  *a0_len, *a1_len; /* [n_variants] */
+    const uint32_t *var_raw_space;   /* [n_variants] may be NULL (= the longer allele) */
+    const uint8_t  *allele_bytes; uint64_t allele_bytes_len; /* = sum of a0_len + a1_len */
+} avk_packed_multi_batch;
 /* Host only (no GPU): classification from the pair results.  The pairs of region m are the k(k-1)/2 pairs (i < j) in
  * lexicographic order starting at m * k(k-1)/2; has_unknown_zyg[m] != 0 = some variant of the region has an Unknown zygosity
  * (variant_delta_length bails first, :119-124 -> status AVK_ST_BAD_ZYGOSITY). */
@@ -410,6 +429,9 @@ int avk_merge_classify(uint64_t n_regions, uint32_t n_inputs, const uint32_t *in
 /* All of solve_merge_region for a batch: pairs on the GPU, classification on the host. */
 int avk_merge_batch(avk_ctx *ctx, const avk_multi_batch *batch, const avk_merge_config *cfg,
                     int32_t *status, uint8_t *classification, uint64_t *members);
+/* the same for a batch in the packed form (offsets by two prefix sums on the device, one kernel that writes the wide arrays there) */
+int avk_merge_packed(avk_ctx *ctx, const avk_packed_multi_batch *batch, const avk_merge_config *cfg,
+                     int32_t *status, uint8_t *classification, uint64_t *members);
 
 /* Host utility (no GPU involved): unit-cost edit distance of two byte strings, the value of the reference's
  * wfa_ed (src/util/sequence_alignment.rs:9-13).  The batch packer uses it for Variant::alt_ed

@@ -40,6 +40,8 @@ def test_struct_layouts_match_the_header():
       printf("%zu %zu %zu\n", offsetof(avk_region_batch, n_variants), offsetof(avk_region_batch, allele_bytes_len), offsetof(avk_result_batch, tally));
       printf("%d %d %d\n", AVK_N_GROUPS, AVK_N_FIELDS, AVK_TALLY_LEN);
       printf("%zu %zu %zu %zu\n", sizeof(avk_compact_batch), sizeof(avk_packed_batch), offsetof(avk_packed_batch, n_variants), offsetof(avk_packed_batch, allele_bytes_len));
+      printf("%zu %zu %zu %zu %zu\n", sizeof(avk_multi_batch), sizeof(avk_packed_multi_batch), offsetof(avk_packed_multi_batch, in_cnt), offsetof(avk_packed_multi_batch, n_variants),
+             offsetof(avk_packed_multi_batch, allele_bytes_len));
       return 0; }
     '''
     with tempfile.TemporaryDirectory() as d:
@@ -52,6 +54,9 @@ def test_struct_layouts_match_the_header():
     assert offs == [_abi.AvkRegionBatch.n_variants.offset, _abi.AvkRegionBatch.allele_bytes_len.offset, _abi.AvkResultBatch.tally.offset]
     assert [int(x) for x in out[2].split()] == [_abi.N_GROUPS, _abi.N_FIELDS, _abi.TALLY_LEN]
     assert [int(x) for x in out[3].split()] == [C.sizeof(_abi.AvkCompactBatch), C.sizeof(_abi.AvkPackedBatch), _abi.AvkPackedBatch.n_variants.offset, _abi.AvkPackedBatch.allele_bytes_len.offset]
+    from aardvark_amd import merge
+    assert [int(x) for x in out[4].split()] == [C.sizeof(merge.AvkMultiBatch), C.sizeof(merge.AvkPackedMultiBatch), merge.AvkPackedMultiBatch.in_cnt.offset,
+                                                merge.AvkPackedMultiBatch.n_variants.offset, merge.AvkPackedMultiBatch.allele_bytes_len.offset]
 
 
 def test_context_creation_fails_loudly_without_a_gpu():

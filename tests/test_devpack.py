@@ -247,3 +247,37 @@ def test_packed_form_round_trip_and_constraints():
             c2.len[2] = 65536
         with pytest.raises(ValueError):
             PackedBatch.from_compact(c2)
+
+
+def test_packed_multi_form_round_trip_and_constraints():
+    """PackedMultiBatch.from_multi / widen: the offsets the packed form leaves out are the running sums of its counts and lengths, the wide batch comes back field
+    by field; batches that break a constraint have no packed form"""
+    import copy
+    from aardvark_amd import synth
+    from aardvark_amd.merge import MultiBatch, PackedMultiBatch
+    contigs, mb = synth.config_genome_merge(scale=0.004, k=3, threads=4)
+    pm = PackedMultiBatch.from_multi(mb)
+    assert pm.n_regions == mb.n_regions and pm.n_variants == mb.n_variants and pm.n_inputs == 3
+    assert pm.nbytes() < 0.25 * sum(getattr(mb, f).nbytes for f in MultiBatch.FIELDS)
+    wide = pm.widen()
+    for f in MultiBatch.FIELDS:
+        if f != "region_id":
+            assert np.array_equal(getattr(wide, f)[:getattr(mb, f).size], getattr(mb, f)), f
+    kept = PackedMultiBatch.from_multi(mb, keep_raw_space=True)
+    assert pm.var_raw_space is None and np.array_equal(kept.var_raw_space, mb.var_raw_space)
+    for breaker in ("in_off", "a0_len", "end", "in_cnt"):
+        m2 = copy.deepcopy(mb)
+        if breaker == "in_off":
+            m2.in_off = m2.in_off.copy()
+            m2.in_off[3], m2.in_off[4] = m2.in_off[4] + 1, m2.in_off[3]
+        elif breaker == "a0_len":
+            m2.a0_len = m2.a0_len.copy()
+            m2.a0_len[7] = 256
+        elif breaker == "end":
+            m2.end = m2.end.copy()
+            m2.end[2] = m2.start[2] + 65536
+        else:
+            m2.in_cnt = m2.in_cnt.copy()
+            m2.in_cnt[5] += 1
+        with pytest.raises(ValueError):
+            PackedMultiBatch.from_multi(m2)

@@ -268,7 +268,7 @@ def test_merge_of_three_call_sets_at_genome_density(oracle):
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
     import merge_oracle as mo
     import aardvark_amd
-    from aardvark_amd.merge import MergeConfig, MultiBatch, merge_multi_batch, pair_batch, pinned_multi_batch
+    from aardvark_amd.merge import MergeConfig, MultiBatch, PackedMultiBatch, merge_multi_batch, pair_batch, pinned_multi_batch
     n_truth = int(synth.HG002_TRUTH_CALLS * synth.CHR20_LEN / sum(synth.GRCH38))
     contig = synth.make_contig_fast(synth.CHR20_LEN, 20250103 + 19)
     rng = np.random.default_rng(20250103 + 119)
@@ -276,6 +276,14 @@ def test_merge_of_three_call_sets_at_genome_density(oracle):
     truth, info = synth.genome_truth(contig, bed, n_truth, 20250103 + 219)
     sets = [synth.genome_query(contig, bed, truth, info, seed, max(1, len(truth) // 100)) for seed in (20250105, 20250106, 20250107)]
     mb = MultiBatch(3, **synth.cluster_multi_v(contig, bed, sets, 50))
+
+    def sub_of(b, nr):  # the first nr regions with their calls (the calls lie in region order)
+        nvv = int(b.in_off[3 * nr]) if nr < b.n_regions else b.n_variants
+        na = int(b.a0_off[nvv]) if nvv < b.n_variants else b.allele_bytes.size
+        return MultiBatch(3, region_id=b.region_id[:nr], contig_idx=b.contig_idx[:nr], start=b.start[:nr], end=b.end[:nr], in_off=b.in_off[:3 * nr], in_cnt=b.in_cnt[:3 * nr],
+                          var_pos=b.var_pos[:nvv], var_type=b.var_type[:nvv], var_zyg=b.var_zyg[:nvv], var_raw_space=b.var_raw_space[:nvv], a0_off=b.a0_off[:nvv], a0_len=b.a0_len[:nvv],
+                          a1_off=b.a1_off[:nvv], a1_len=b.a1_len[:nvv], allele_bytes=b.allele_bytes[:na])
+
     ctx = aardvark_amd.Context(0)
     try:
         ctx.upload_reference([contig])
@@ -291,6 +299,22 @@ def test_merge_of_three_call_sets_at_genome_density(oracle):
         st_o, ex_o = oracle_lib.optimize_pairs(oracle, pb, [contig], 50, threads=CPUS)
         ws, wc, wm = mo.classify_k3_majority(st_o, ex_o)
         assert np.array_equal(got.status, ws) and np.array_equal(got.classification, wc) and np.array_equal(got.members, wm)
+        # the packed form of the same batch (avk_merge_packed: offsets by prefix sums on the device), from pageable and from pinned arrays
+        pm = PackedMultiBatch.from_multi(mb)
+        for form in (pm, pinned_multi_batch(ctx, pm), PackedMultiBatch.from_multi(mb, keep_raw_space=True)):
+            got_k = merge_multi_batch(ctx, form, MergeConfig(majority_voting_enabled=True))
+            assert ctx.last_compare_was_one_shot()
+            assert np.array_equal(got_k.status, ws) and np.array_equal(got_k.classification, wc) and np.array_equal(got_k.members, wm)
+        bad = PackedMultiBatch.from_multi(mb)
+        bad.in_cnt = bad.in_cnt.copy()
+        bad.in_cnt[11] += 1  # the counts no longer sum to n_variants: refused, not computed
+        with pytest.raises(aardvark_amd.AardvarkAmdError):
+            merge_multi_batch(ctx, bad, MergeConfig())
+        # without the device packer the packed form is widened on the host and takes the wide path
+        ctx.set_option("device_pack", 0)
+        got_h = merge_multi_batch(ctx, PackedMultiBatch.from_multi(sub_of(mb, 2000)), MergeConfig(majority_voting_enabled=True))
+        ctx.set_option("device_pack", 1)
+        assert np.array_equal(got_h.status, ws[:2000]) and np.array_equal(got_h.classification, wc[:2000]) and np.array_equal(got_h.members, wm[:2000])
         # the same batch from pinned arrays (DMA instead of the bounce buffer)
         got_p = merge_multi_batch(ctx, pinned_multi_batch(ctx, mb), MergeConfig(majority_voting_enabled=True))
         assert np.array_equal(got_p.status, ws) and np.array_equal(got_p.classification, wc) and np.array_equal(got_p.members, wm)
