@@ -6,7 +6,7 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
-lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-secondary --resident-steps 5   (%s): 6 avk_compare_compact calls, 6 avk_compare_batch calls and 11 resident steps, each with one set of solver launches" % tag]
+lines = ["# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-secondary --resident-steps 5   (%s): the calls of the three boundary forms (avk_compare_packed timed, avk_compare_compact and avk_compare_batch beside it) and the resident steps, each with one set of solver launches" % tag]
 cur = sqlite3.connect(os.path.join(src, "stats", tag + "_results.db")).cursor()
 lines.append("# per kernel (all dispatches): name, calls, total_us, avg_us, pct")
 for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
