@@ -24,14 +24,16 @@ def check(batch, got, want):
             assert n_groups[r] == 1 + len(types)
 
 
-def cases():
+def cases(light=False):
+    """light: without the four long-allele regions and with fewer fuzz regions (the emulator needs seconds for each of the former)"""
     yield scenarios.golden()
-    yield scenarios.fuzz_regions(71, 400, max_vars=6, max_len=10)
+    yield scenarios.fuzz_regions(71, 120 if light else 400, max_vars=6, max_len=10)
     yield scenarios.fuzz_regions(72, 300, max_vars=3, repeat_unit=b"CA")
-    c = scenarios.long_allele_regions()
-    yield c[0], c[1]
+    if not light:
+        c = scenarios.long_allele_regions()
+        yield c[0], c[1]
     yield scenarios.invalid_regions()
-    contig, batch = synth.config_indel_mix_v2(n_truth=2500, contig_len=1_200_000)
+    contig, batch = synth.config_indel_mix_v2(n_truth=700, contig_len=400_000)
     yield [contig], batch
 
 
@@ -42,7 +44,7 @@ def test_compact_groups_rebuild_the_full_block_kernel_logic(oracle, lane_kernel)
     for devpack in (0, 2):
         lib.emu_set_device_pack(devpack)
         try:
-            for contigs, batch in cases():
+            for contigs, batch in cases(light=not (devpack == 2 and lane_kernel)):  # the full set once, through the device packer and the lane code
                 want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
                 got = emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel, group_metrics=False, bp_groups=True, threads=8)
                 check(batch, got, want)
