@@ -329,7 +329,7 @@ class PackedBatch:
         voff = np.concatenate([[0], np.cumsum(cnt)])
         alen = cb.a0_len.astype(np.int64) + cb.a1_len
         aoff = np.concatenate([[0], np.cumsum(alen)])
-        ok = (np.array_equal(cb.v_off, voff[:-1]) and int(voff[-1]) == nv and np.array_equal(cb.a_off, aoff[:-1]) and int(aoff[-1]) == cb.allele_bytes.size and
+        ok = (np.array_equal(cb.v_off, voff[:-1]) and int(voff[-1]) == nv and np.array_equal(cb.a_off, aoff[:-1]) and (nv == 0 or int(aoff[-1]) == cb.allele_bytes.size) and
               (n == 0 or (int(cb.len.max()) < 65536 and int(cb.t_cnt.max()) < 256 and int(cb.q_cnt.max()) < 256)) and
               (nv == 0 or (int(cb.a0_len.max()) < 256 and int(cb.a1_len.max()) < 256)) and (cb.contig_idx is None or n == 0 or int(cb.contig_idx.max()) < 65536))
         rel = None

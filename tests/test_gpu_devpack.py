@@ -252,6 +252,16 @@ def test_packed_form(ctx_pair, oracle):
         dev.upload_reference(contigs)
         assert dev.solve_packed(p2).diff(oracle_lib.compare_batch(oracle, b, contigs, threads=CPUS, group_metrics=False)) == []
     assert n_packed >= 1
+    # batches of no region, of one region, of a few regions (fewer pieces than streams and events of the upload)
+    from aardvark_amd.dist import gather_calls
+    dev.upload_reference([contig])
+    for lo, hi in ((0, 0), (0, 1), (7, 10), (100, 164)):
+        small = gather_calls(batch.slice(lo, hi))
+        p3 = PackedBatch.from_compact(CompactBatch.from_region_batch(small))
+        got3 = dev.solve_packed(p3)
+        assert np.array_equal(got3.status, want.status[lo:hi]) and np.array_equal(got3.ed_h1, want.ed_h1[lo:hi]) and np.array_equal(got3.n_optima, want.n_optima[lo:hi]), (lo, hi)
+        if hi > lo:
+            assert got3.diff(oracle_lib.compare_batch(oracle, small, [contig], threads=CPUS, group_metrics=False)) == [], (lo, hi)
     # a batch whose counts do not add up to n_variants is refused, not read out of bounds
     bad = PackedBatch.from_compact(cb)
     bad.t_cnt = bad.t_cnt.copy()
