@@ -33,10 +33,29 @@ def check(name, contigs, batch, sequences=True, mbf=50):
     got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=sequences, max_branch_factor=mbf))
     t2 = time.time()
     d = got.diff(want)
+    one_shot = " one-shot" if ctx.last_compare_was_one_shot() else ""
+    if not d and os.environ.get("FORMS", "1") != "0":  # the same batch through the compact and the packed form (avk_compare_compact / avk_compare_packed), where it fits them
+        from aardvark_amd import CompactBatch, PackedBatch
+        from aardvark_amd.dist import gather_calls
+        try:
+            own = gather_calls(batch)  # calls region by region: the layout the narrow forms imply
+            cb = CompactBatch.from_region_batch(own)
+            want_own = oracle_lib.compare_batch(lib, own, contigs, sequences=False, threads=min(16, os.cpu_count() or 1), max_branch_factor=mbf, group_metrics=False)
+            cfg = CompareConfig(enable_sequences=False, max_branch_factor=mbf)
+            d = ["compact:" + x for x in ctx.solve_compact(cb, cfg).diff(want_own)]
+            one_shot += " +compact"
+            try:
+                pk = PackedBatch.from_compact(cb)
+                d += ["packed:" + x for x in ctx.solve_packed(pk, cfg).diff(want_own)]
+                one_shot += "+packed"
+            except ValueError:
+                pass
+        except ValueError:
+            pass
     total += batch.n_regions
     cases += 1
     print("%-70s %8d regions  oracle %.2fs gpu %.2fs  tiers %s lanes %d%s  status!=0: %d  %s" % (
-        name, batch.n_regions, t1 - t0, t2 - t1, ctx.last_tier_counts(), ctx.last_lane_solved(), " one-shot" if ctx.last_compare_was_one_shot() else "",
+        name, batch.n_regions, t1 - t0, t2 - t1, ctx.last_tier_counts(), ctx.last_lane_solved(), one_shot,
         int((want.status != 0).sum()), "OK" if not d else "DIFF " + str(d)), flush=True)
     if d:
         n = batch.n_regions
