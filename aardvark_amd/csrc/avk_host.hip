@@ -1577,7 +1577,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     ctx->ev_lane_valid = true;
                 }
             }
-            /* every workgroup of the three launches is resident at once */
+            /* the three launches are sized so that all their workgroups CAN be resident at once; with lane launches beside them they are not (a 40 KB LDS
+             * allocation waits for a contiguous hole) — nothing waits for a workgroup to start, late ones find the claimed part of the list empty */
             uint32_t bulk = blocks > solo + 2 * hbm_solo + blocks / 4 ? blocks - solo - 2 * hbm_solo : blocks / 4; /* (a large class C launch: the bulk keeps a quarter of its workgroups) */
             if (bulk < 1) bulk = 1;
             if (bulk > blocks) bulk = blocks;
