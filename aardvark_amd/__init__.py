@@ -10,9 +10,10 @@ import os as _os
 
 # The solver launches on six HIP streams side by side (wave-per-region launches, three lane classes, two solo launches).  The HIP runtime
 # maps streams onto 4 hardware queues unless told otherwise, and streams that share a queue run one after the other: with 8 queues a
-# whole-genome step takes 5.0 ms instead of 7.0.  The runtime reads the variable when it initialises, so this only
+# whole-genome step takes 5.0 ms instead of 7.0 (round 2), and with a communicator (RCCL) in the process 8 are not enough either (round 3: 6.0 ms
+# against 3.8 with 16 or 24: profiles/r03_rccl_queues.txt).  The runtime reads the variable when it initialises, so this only
 # helps when nothing in the process has used HIP yet; the caller's own setting wins.
-_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 
 from ._abi import (CLASSES, FIELDS, N_FIELDS, N_GROUPS, ST_NAMES, TALLY_LEN, VARIANT_TYPES, ZYGOSITIES, CompactBatch, PackedBatch, RegionBatch,
                    ResultBatch)

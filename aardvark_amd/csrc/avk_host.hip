@@ -457,7 +457,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     *out = nullptr;
     /* six streams side by side need hardware queues of their own (the runtime's default is 4 and streams that share one run in turn);
      * read by the runtime when it initialises, so this helps when this is the process's first HIP call; the caller's setting wins */
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    setenv("GPU_MAX_HW_QUEUES", "24", 0); /* 8 are enough for this library alone; with a communicator (RCCL) in the process 8 make the step 6.0 ms instead of 3.8 */
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) return fail(nullptr, AVK_E_HIP, "no HIP device available (%s)", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
@@ -491,7 +491,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
      * of a process share queues, and a shared queue would serialise the solo launches with the bulk) */
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    { /* the side and lane streams run at the default priority: with hardware queues of their own (GPU_MAX_HW_QUEUES=8) a high priority changes
+    { /* the side and lane streams run at the default priority: with hardware queues of their own (GPU_MAX_HW_QUEUES >= 8) a high priority changes
        * nothing (4.94 / 4.98 ms per whole-genome step), with the runtime's default of 4 queues it costs 0.9 ms (7.0 / 7.9 ms);
        * AVK_STREAM_PRIORITY=high brings it back for experiments */
         const char *pe = getenv("AVK_STREAM_PRIORITY");

@@ -72,7 +72,7 @@ static void report_unsolved(const avk_region_batch &b, uint64_t r, int32_t statu
 }
 
 int main(int argc, char **argv) {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0); /* before the first HIP call: the solver's six streams need hardware queues of their own (include/aardvark_amd.h, avk_ctx_create) */
+    setenv("GPU_MAX_HW_QUEUES", "24", 0); /* before the first HIP call: the solver's six streams need hardware queues of their own (include/aardvark_amd.h, avk_ctx_create) */
     const auto t_start = std::chrono::steady_clock::now();
     std::string ref, truth, query, bed, out_dir, truth_sample, query_sample, label = "compare", strat_tsv, debug_dir;
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 4000000, threads = 1, max_ed = 5000, verbosity = 0;

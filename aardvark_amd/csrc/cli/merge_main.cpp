@@ -64,7 +64,7 @@ std::string json_list(const std::vector<std::string> &items) {
 } // namespace
 
 int main(int argc, char **argv) {
-    setenv("GPU_MAX_HW_QUEUES", "8", 0); /* before the first HIP call (see compare_main.cpp) */
+    setenv("GPU_MAX_HW_QUEUES", "24", 0); /* before the first HIP call (see compare_main.cpp) */
     const auto t_start = std::chrono::steady_clock::now();
     std::string ref, bed, out_dir, summary_path, debug_dir, strategy;
     std::vector<std::string> vcfs, samples, tags;

@@ -28,7 +28,7 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # before anything loads the HIP runtime: the solver's six streams need queues of their own (aardvark_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # before anything loads the HIP runtime: the solver's streams need queues of their own, also beside a communicator's (aardvark_amd/__init__.py)
 import signal
 import subprocess
 import sys

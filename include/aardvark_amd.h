@@ -260,9 +260,10 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    lanes that diverge take turns; 0 = no head launch), "lane_max_est" (15: regions whose estimated edits exceed
  *                    this stay with the wave-per-region kernels)
  *                    The launches of one call run on six HIP streams side by side; the HIP runtime gives a process 4 hardware queues
- *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=8 unless the
+ *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=24 unless the
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
- *                    earlier should export the variable itself (whole-genome step of the final build: 5.0 ms with 8 queues, 7.0 ms with 4).
+ *                    earlier should export the variable itself (whole-genome step: 7.0 ms with 4 queues, 5.0 with 8 in round 2; with a
+ *                    communicator library in the process 6.0 ms with 8 queues, 3.8 with 16 or 24 in round 3).
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "emit_bp_groups" (1 = kernels write the compact per-region BASEPAIR groups, avk_result_batch::bp_groups; avk_compare_batch /
  *                    avk_compare_compact switch it on by themselves when the caller hands the two arrays in),

@@ -3,7 +3,7 @@ usage: python tools/boundary_once.py [scale] [calls] [opt=value,...] [form: pack
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")
 import numpy as np
 import aardvark_amd
 from aardvark_amd import synth, CompareConfig
