@@ -1299,7 +1299,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         /* pairs of a merge batch: the bulk launch is long (200,000 regions beside 10 M in the lanes) and its 40 KB workgroups do not all become resident while the
          * lane launches keep taking the LDS that comes free; a statically dealt share would wait for workgroups that start when the lanes are done
          * (12 or 22 ms per whole-genome merge, from call to call) — everything is claimed there */
-        a.static_pct = mode == 1 ? 0u : (uint32_t)ctx->static_pct;
+        /* the same for every short list — the bulk beside the lane classes (a few thousand regions) and the overflow lists of the later tiers: same step,
+         * fewer slow calls (tools/gpu_static_ab.py); a static share is for the first launch of a batch that goes through the wave-per-region kernels as a whole */
+        a.static_pct = mode == 0 && t == 0 && a.n_work >= 16384u ? (uint32_t)ctx->static_pct : 0u; /* (50,000 single-call regions through the bulk: 0.40 ms with the static share, 0.43 without) */
         a.n_shards = 8;
         a.claim = (uint32_t)ctx->claim;
         if (t == 0) {
