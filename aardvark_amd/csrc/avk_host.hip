@@ -2103,13 +2103,22 @@ int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_co
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
     if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
+    const auto t0 = std::chrono::steady_clock::now();
     int rc = avk_batch_upload_packed(ctx, batch, &db);
+    const auto t1 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
+    const auto t2 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_results_download(ctx, db, out);
+    const auto t3 = std::chrono::steady_clock::now();
     ctx->emit_group_metrics = keep_gm, ctx->emit_bp_groups = keep_bp;
     if (db) {
         ctx->last_one_shot = 1;
         avk_batch_free(ctx, db);
+    }
+    if (getenv("AVK_TIMING")) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        fprintf(stderr, "avk compare packed: upload %.3f ms, launches %.3f ms, download %.3f ms, free %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
+                ms(t3, std::chrono::steady_clock::now()));
     }
     return rc;
 }
