@@ -34,7 +34,7 @@ void usage() {
             "  [-s SAMPLE ...] [-t TAG ...] [--output-summary SUMMARY.tsv|.csv] [--output-debug DIR]\n"
             "  [--min-variant-gap 50] [--disable-variant-trimming] [--merge-strategy exact|no_conflict|majority|all]\n"
             "  [--enable-no-conflict] [--enable-voting] [--conflict-select INDEX] [--max-branch-factor 50]\n"
-            "  [--skip N] [--take N] [--device 0] [--batch-regions 1000000] [--contexts 2]\n");
+            "  [--skip N] [--take N] [--device 0] [--batch-regions 1000000] [--contexts 2] [--batch-form packed|wide]\n");
 }
 
 std::string json_string(const std::string &s) {
@@ -69,6 +69,7 @@ int main(int argc, char **argv) {
     std::string ref, bed, out_dir, summary_path, debug_dir, strategy;
     std::vector<std::string> vcfs, samples, tags;
     uint64_t gap = 50, branch = 50, skip = 0, take = 0, batch_regions = 1000000, threads = 1, verbosity = 0, contexts = 2;
+    bool want_packed = true;
     bool trimming = true, no_conflict = false, voting = false;
     bool ref_upper = true; /* --reference-case upper|raw (include/aardvark_feeder.h, avf_genome_load_case) */
     long long conflict_select = -1;
@@ -104,6 +105,11 @@ int main(int argc, char **argv) {
         else if (a == "--device") device = atoi(val());
         else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
         else if (a == "--contexts") contexts = strtoull(val(), nullptr, 10);
+        else if (a == "--batch-form") { /* packed (default; wide when the call sets do not fit the form) | wide */
+            const std::string v = val();
+            if (v != "packed" && v != "wide") die(78, "--batch-form must be 'packed' or 'wide'", "");
+            want_packed = v == "packed";
+        }
         else if (a == "--threads") threads = strtoull(val(), nullptr, 10);
         else if (a == "-v" || a == "--verbose") verbosity += 1;
         else if (a == "-h" || a == "--help") {
@@ -257,6 +263,15 @@ int main(int argc, char **argv) {
     cfg.no_conflict_enabled = no_conflict ? 1 : 0;
     cfg.majority_voting_enabled = voting ? 1 : 0;
     cfg.conflict_selection = (int32_t)conflict_select;
+    /* the feed in the library's packed form (8 + k bytes per region, 5 per call + allele bytes over PCIe instead of the wide arrays); the wide ones stay for the writers */
+    avk_packed_multi_batch packed_all;
+    bool packed = false;
+    if (want_packed) {
+        const int rc_pack = avf_feed_pack_multi(feed, [](void *, size_t bytes) { return malloc(bytes); }, nullptr, &packed_all);
+        if (rc_pack < 0) die(70, "cannot pack the region batch", avf_last_error());
+        packed = rc_pack == 0;
+        if (!packed && verbosity) fprintf(stderr, "The call sets do not fit the packed batch form (window, call count or allele length limits): using the wide form.\n");
+    }
     std::vector<int32_t> status(all->n_regions + 1, -1); /* regions outside --skip/--take stay unsolved and unwritten */
     std::vector<uint8_t> classification(all->n_regions + 1, 0);
     std::vector<uint64_t> members(all->n_regions + 1, 0);
@@ -299,7 +314,14 @@ int main(int argc, char **argv) {
             b.end = all->end + first + at;
             b.in_off = all->in_off + (first + at) * k;
             b.in_cnt = all->in_cnt + (first + at) * k;
-            if (avk_merge_batch(my, &b, &cfg, status.data() + first + at, classification.data() + first + at, members.data() + first + at)) {
+            int rc_merge = 0;
+            if (packed) {
+                avk_packed_multi_batch part;
+                rc_merge = avf_packed_multi_slice(feed, &packed_all, first + at, n, &part);
+                if (!rc_merge) rc_merge = avk_merge_packed(my, &part, &cfg, status.data() + first + at, classification.data() + first + at, members.data() + first + at);
+            } else
+                rc_merge = avk_merge_batch(my, &b, &cfg, status.data() + first + at, classification.data() + first + at, members.data() + first + at);
+            if (rc_merge) {
                 worker_err[w] = std::string("merge failed: ") + avk_last_error(my);
                 break;
             }

@@ -1651,6 +1651,75 @@ int avf_packed_slice(const avf_feed *f, const avk_packed_batch *all, uint64_t fi
     return 0;
 }
 const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f) { return f && f->is_merge ? &f->multi : nullptr; }
+
+int avf_feed_pack_multi(const avf_feed *f, void *(*alloc)(void *, size_t), void *user, avk_packed_multi_batch *out) {
+    if (!f || !f->is_merge || !alloc || !out) return fail(AVK_E_ARG, "null argument, or a compare feed");
+    const avk_multi_batch &b = f->multi;
+    const uint64_t n = b.n_regions, k = b.n_inputs, nv = b.n_variants, na = nv ? b.allele_bytes_len : 0;
+    memset(out, 0, sizeof(*out));
+    if (nv >= (1ull << 32) || na >= (1ull << 32)) return 1;
+    bool raw_differs = false;
+    for (uint64_t r = 0; r < n; ++r) { /* the form's constraints; the layout ones hold by construction (flush() above) and are checked all the same */
+        const uint64_t next = r + 1 < n ? b.in_off[(r + 1) * k] : nv;
+        if (b.end[r] < b.start[r] || b.end[r] - b.start[r] > 0xFFFF || b.start[r] > 0xFFFFFFFFull || b.contig_idx[r] > 0xFFFF || (r == 0 && n && b.in_off[0] != 0)) return 1;
+        uint64_t at = b.in_off[r * k];
+        for (uint64_t i = 0; i < k; ++i) {
+            if (b.in_off[r * k + i] != at || b.in_cnt[r * k + i] > 255) return 1;
+            at += b.in_cnt[r * k + i];
+        }
+        if (at != next) return 1;
+        for (uint64_t v = b.in_off[r * k]; v < next; ++v)
+            if (b.var_pos[v] < b.start[r] || b.var_pos[v] - b.start[r] > 0xFFFF) return 1;
+    }
+    for (uint64_t v = 0; v < nv; ++v) {
+        const uint64_t next = v + 1 < nv ? b.a0_off[v + 1] : na;
+        if (b.a0_len[v] > 255 || b.a1_len[v] > 255 || b.var_type[v] > 15 || b.var_zyg[v] > 15 || b.a1_off[v] != b.a0_off[v] + b.a0_len[v] || next != b.a1_off[v] + b.a1_len[v] ||
+            (v == 0 && b.a0_off[0] != 0))
+            return 1;
+        if (b.var_raw_space[v] != std::max(b.a0_len[v], b.a1_len[v])) raw_differs = true;
+    }
+    bool oom = false;
+    auto get = [&](size_t bytes) {
+        void *p = alloc(user, bytes ? bytes : 1);
+        if (!p) oom = true;
+        return p;
+    };
+    uint16_t *contig = (uint16_t *)get(n * 2), *len = (uint16_t *)get(n * 2), *rel = (uint16_t *)get(nv * 2);
+    uint32_t *start = (uint32_t *)get(n * 4), *raw = raw_differs ? (uint32_t *)get(nv * 4) : nullptr;
+    uint8_t *ic = (uint8_t *)get(n * k), *tz = (uint8_t *)get(nv), *l0 = (uint8_t *)get(nv), *l1 = (uint8_t *)get(nv), *bytes = (uint8_t *)get(na);
+    if (oom) return fail(AVK_E_OOM, "the allocator returned NULL for an array of the packed form");
+    for (uint64_t r = 0; r < n; ++r) {
+        contig[r] = (uint16_t)b.contig_idx[r], start[r] = (uint32_t)b.start[r], len[r] = (uint16_t)(b.end[r] - b.start[r]);
+        for (uint64_t i = 0; i < k; ++i) ic[r * k + i] = (uint8_t)b.in_cnt[r * k + i];
+        const uint64_t next = r + 1 < n ? b.in_off[(r + 1) * k] : nv;
+        for (uint64_t v = b.in_off[r * k]; v < next; ++v) rel[v] = (uint16_t)(b.var_pos[v] - b.start[r]);
+    }
+    for (uint64_t v = 0; v < nv; ++v) {
+        tz[v] = (uint8_t)(b.var_type[v] | b.var_zyg[v] << 4), l0[v] = (uint8_t)b.a0_len[v], l1[v] = (uint8_t)b.a1_len[v];
+        if (raw) raw[v] = b.var_raw_space[v];
+    }
+    if (na) memcpy(bytes, b.allele_bytes, na);
+    out->n_regions = n, out->n_inputs = (uint32_t)k, out->contig_idx = contig, out->start = start, out->len = len, out->in_cnt = ic;
+    out->n_variants = nv, out->var_rel_pos = rel, out->var_type_zyg = tz, out->a0_len = l0, out->a1_len = l1, out->var_raw_space = raw;
+    out->allele_bytes = bytes, out->allele_bytes_len = na;
+    return 0;
+}
+
+int avf_packed_multi_slice(const avf_feed *f, const avk_packed_multi_batch *all, uint64_t first, uint64_t n, avk_packed_multi_batch *part) {
+    if (!f || !f->is_merge || !all || !part) return fail(AVK_E_ARG, "null argument, or a compare feed");
+    const avk_multi_batch &b = f->multi;
+    const uint64_t k = b.n_inputs;
+    if (all->n_regions != b.n_regions || all->n_variants != b.n_variants || all->n_inputs != b.n_inputs) return fail(AVK_E_ARG, "the packed batch is not this feed's");
+    if (first > b.n_regions || n > b.n_regions - first) return fail(AVK_E_ARG, "regions [%llu, +%llu) of %llu", (unsigned long long)first, (unsigned long long)n, (unsigned long long)b.n_regions);
+    const uint64_t v0 = first < b.n_regions ? b.in_off[first * k] : b.n_variants, v1 = first + n < b.n_regions ? b.in_off[(first + n) * k] : b.n_variants;
+    const uint64_t a0 = v0 < b.n_variants ? b.a0_off[v0] : all->allele_bytes_len, a1 = v1 < b.n_variants ? b.a0_off[v1] : all->allele_bytes_len;
+    *part = *all;
+    part->n_regions = n, part->contig_idx = all->contig_idx + first, part->start = all->start + first, part->len = all->len + first, part->in_cnt = all->in_cnt + first * k;
+    part->n_variants = v1 - v0, part->var_rel_pos = all->var_rel_pos + v0, part->var_type_zyg = all->var_type_zyg + v0;
+    part->a0_len = all->a0_len + v0, part->a1_len = all->a1_len + v0, part->var_raw_space = all->var_raw_space ? all->var_raw_space + v0 : nullptr;
+    part->allele_bytes = all->allele_bytes + a0, part->allele_bytes_len = a1 - a0;
+    return 0;
+}
 const uint64_t *avf_feed_var_record(const avf_feed *f) { return f ? f->var_record.data() : nullptr; }
 const uint32_t *avf_feed_var_alt_index(const avf_feed *f) { return f ? f->var_alt.data() : nullptr; }
 uint64_t avf_feed_loaded_variants(const avf_feed *f, int input) { return f && input >= 0 && (size_t)input < f->loaded.size() ? f->loaded[input] : 0; }

@@ -136,13 +136,44 @@ class Genome:
 
 class Feed:
     """The result of RegionIterator over a truth/query VCF pair: a RegionBatch plus provenance; `packed` = the same batch in the packed form
-    (avf_feed_pack -> PackedBatch), None when the call set does not fit that form or for merge feeds."""
+    (avf_feed_pack -> PackedBatch; merge feeds: avf_feed_pack_multi -> merge.PackedMultiBatch), None when the call sets do not fit that form."""
 
     def __init__(self, batch, var_record, var_alt_index, loaded, packed=None):
         self.batch, self.var_record, self.var_alt_index, self.loaded, self.packed = batch, var_record, var_alt_index, loaded, packed
 
 
 _ALLOC = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+def _take_packed_multi(lib, h):
+    """avf_feed_pack_multi into numpy-owned buffers -> merge.PackedMultiBatch, or None when the feed does not fit the form"""
+    from .merge import AvkPackedMultiBatch, PackedMultiBatch
+    bufs = {}
+
+    def alloc(_user, nbytes):
+        a = np.empty(max(int(nbytes), 1), np.uint8)
+        bufs[a.ctypes.data] = a
+        return a.ctypes.data
+
+    cb = _ALLOC(alloc)
+    out = AvkPackedMultiBatch()
+    lib.avf_feed_pack_multi.argtypes = [C.c_void_p, _ALLOC, C.c_void_p, C.POINTER(AvkPackedMultiBatch)]
+    rc = lib.avf_feed_pack_multi(h, cb, None, C.byref(out))
+    if rc == 1:
+        return None
+    _check(lib, rc)
+    n, nv, na, k = int(out.n_regions), int(out.n_variants), int(out.allele_bytes_len), int(out.n_inputs)
+
+    def view(ptr, count, dtype):
+        addr = C.cast(ptr, C.c_void_p).value
+        if addr is None:
+            return None
+        return bufs[addr][:count * np.dtype(dtype).itemsize].view(dtype)
+
+    return PackedMultiBatch(k, contig_idx=view(out.contig_idx, n, np.uint16), start=view(out.start, n, np.uint32), len=view(out.len, n, np.uint16),
+                            in_cnt=view(out.in_cnt, n * k, np.uint8), var_rel_pos=view(out.var_rel_pos, nv, np.uint16), var_type_zyg=view(out.var_type_zyg, nv, np.uint8),
+                            a0_len=view(out.a0_len, nv, np.uint8), a1_len=view(out.a1_len, nv, np.uint8), var_raw_space=view(out.var_raw_space, nv, np.uint32),
+                            allele_bytes=view(out.allele_bytes, max(na, 1), np.uint8))
 
 
 def _take_packed(lib, h):
@@ -235,7 +266,7 @@ def _take_feed(lib, h, k, merge):
                                 _arr(b.a0_off, nv, np.uint64), _arr(b.a0_len, nv, np.uint32), _arr(b.a1_off, nv, np.uint64), _arr(b.a1_len, nv, np.uint32),
                                 _arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
         return Feed(batch, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
-                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)), None if merge else _take_packed(lib, h))
+                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)), _take_packed_multi(lib, h) if merge else _take_packed(lib, h))
     finally:
         lib.avf_feed_free(h)
 
@@ -378,7 +409,7 @@ def feed_merge(vcfs, regions_bed, genome, samples=None, min_variant_gap=50, enab
                         a1_off=_arr(b.a1_off, nv, np.uint64), a1_len=_arr(b.a1_len, nv, np.uint32),
                         allele_bytes=_arr(b.allele_bytes, int(b.allele_bytes_len), np.uint8))
         return Feed(mb, _arr(lib.avf_feed_var_record(h), nv, np.uint64), _arr(lib.avf_feed_var_alt_index(h), nv, np.uint32),
-                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)))
+                    tuple(int(lib.avf_feed_loaded_variants(h, i)) for i in range(k)), _take_packed_multi(lib, h))
     finally:
         lib.avf_feed_free(h)
 

@@ -80,6 +80,10 @@ int avf_packed_slice(const avf_feed *f, const avk_packed_batch *all, uint64_t fi
 int avf_feed_merge(uint32_t n_inputs, const char *const *vcfs, const char *const *samples, const char *regions_bed, const avf_genome *g,
                    uint64_t min_variant_gap, int enable_trimming, avf_feed **out);
 const avk_multi_batch *avf_feed_multi_batch(const avf_feed *f);
+/* The merge feed in the packed form (avk_packed_multi_batch) for avk_merge_packed, and a range of its regions as a batch of its own: as avf_feed_pack /
+ * avf_packed_slice for compare feeds (returns 1 when the feed does not meet the form's constraints: use avf_feed_multi_batch). */
+int avf_feed_pack_multi(const avf_feed *f, void *(*alloc)(void *user, size_t bytes), void *user, avk_packed_multi_batch *out);
+int avf_packed_multi_slice(const avf_feed *f, const avk_packed_multi_batch *all, uint64_t first, uint64_t n, avk_packed_multi_batch *part);
 /* The two halves of a feed on their own, so that a caller can read the VCFs while the reference genome is still loading (the reference
  * preloads its variants the same way, RegionIterator::preload_all_variants, region_generation.rs:199-279):
  * avf_calls_load parses one VCF (every chromosome), avf_feed_from_calls walks the regions over already loaded call sets.

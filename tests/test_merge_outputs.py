@@ -202,6 +202,13 @@ def test_merge_feed_matches_the_restatement(tmp_path):
         regions, loaded = restated_regions(p, trimming)
         assert_same_multi(feed.batch, regions)
         assert list(feed.loaded) == loaded and len(regions) > 100
+        # the feeder's own packed form (avf_feed_pack_multi) = the wide batch narrowed by the Python class
+        from aardvark_amd.merge import PackedMultiBatch
+        ref = PackedMultiBatch.from_multi(feed.batch)
+        assert feed.packed is not None and (feed.packed.n_regions, feed.packed.n_variants, feed.packed.n_inputs) == (ref.n_regions, ref.n_variants, ref.n_inputs)
+        for name in PackedMultiBatch.FIELDS:
+            a, b = getattr(feed.packed, name), getattr(ref, name)
+            assert (a is None and b is None) or np.array_equal(a, b), name
     # one input is the compare feed's truth side: the same windows when the second input is the same file
     one = feeder.feed_merge(p["vcfs"][:1], p["bed"], genome)
     assert one.batch.n_inputs == 1 and one.batch.n_regions > 0
@@ -387,3 +394,10 @@ def test_merge_tool_end_to_end(tmp_path, oracle):
     want2 = oracle_results(oracle, feed.batch, genome.contigs(), MergeConfig())
     want2 = [w if 5 <= m < 45 else None for m, w in enumerate(want2)]
     check_outputs(p["out"] + "2", p["vcfs"][0], regions, want2, ["vcf_%d" % i for i in range(4)], "S0")
+    # the tool hands the packed form to avk_merge_packed by default (here in batches of 300 regions: avf_packed_multi_slice); --batch-form wide gives the same files
+    r = subprocess.run(cmd[:cmd.index("-o")] + ["-o", p["out"] + "3"] + cmd[cmd.index("-o") + 2:] + ["--batch-form", "wide"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    for name in ("passing.vcf.gz", "regions.bed.gz", "failed_regions.bed.gz"):
+        a, b = (gzip.open(os.path.join(d, name), "rb").read() for d in (p["out"], p["out"] + "3"))
+        strip = lambda x: b"\n".join(l for l in x.split(b"\n") if not l.startswith(b"##aardvark_command"))
+        assert strip(a) == strip(b), name
