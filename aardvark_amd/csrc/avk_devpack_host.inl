@@ -733,6 +733,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     };
     auto bail = [&](int code) {
         (void)hipStreamSynchronize(s);
+        (void)hipStreamSynchronize(ctx->lane_stream4); /* (the side stream of the upload: prefix sums, widening, the cleared scratch) */
         for (void *p : temps) pool_release(ctx, p);
         release_pooled(ctx, db);
         delete db;
@@ -1072,6 +1073,19 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     db->d_overflow4 = (uint32_t *)kept((n + 1) * 4);
     if (hs->n_fast_total) db->d_fast = (uint32_t *)kept(((size_t)hs->fast_words + 64) * 4);
     if (rc) return bail(rc);
+    { /* the batch's partial tallies and counters are cleared beside the writers, on a side stream (in front of the solver launches the two fills took 55 us) */
+        hipStream_t side = ctx->lane_stream4;
+        hipError_t ez = hipEventRecord(ctx->ev_copy_fork, s); /* the buffers may have been another batch's until here */
+        if (ez == hipSuccess) ez = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0);
+        if (ez == hipSuccess) ez = hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), side);
+        if (ez == hipSuccess) ez = hipMemsetAsync(db->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t), side);
+        if (ez == hipSuccess) ez = hipEventRecord(ctx->ev_copy_join, side);
+        if (ez != hipSuccess) {
+            (void)hipStreamSynchronize(side);
+            return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ez)));
+        }
+        db->scratch_clean = true;
+    }
     a.regions = db->d_regions, a.blob = db->d_blob, a.fast = db->d_fast;
     if (tiles_total) hipLaunchKernelGGL(avk_dp_fast_records_kernel, dim3((tiles_total + 3) / 4), dim3(256), 0, s, a, tiles_total);
     /* records and blobs: now for the regions the wave-per-region launches start with; for the lanes' regions when (and if) a launch asks for them */
@@ -1090,7 +1104,11 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         if (ec != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ec)));
     }
     e = hipGetLastError();
-    if (e != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
+    if (e == hipSuccess) e = hipStreamWaitEvent(s, ctx->ev_copy_join, 0); /* the cleared scratch, before anything that follows on this stream */
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->lane_stream4);
+        return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
+    }
     for (void *p : temps) pool_release(ctx, p); /* in stream order: the writers above run before anything that is handed these buffers next */
     if (timing)
         fprintf(stderr, "avk upload (device-packed): %llu regions, %llu calls: buffers %.3f ms, copies queued %.3f ms, packing kernels + plan %.3f ms, writers queued %.3f ms; lanes %u regions in %u tiles, class C %u, class B %u\n",
