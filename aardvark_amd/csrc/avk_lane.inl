@@ -101,6 +101,20 @@ struct LCtx {
     u64 seq_fail_lo, seq_fail_hi; /* failed_ed per sequence id (generate_allele_sequence, :745-753) */
     u32 max_branch;
     u32 max_nodes; /* a search that makes more nodes than this is handed over (LaneArgs::max_nodes) */
+    /* The primitives below (sequence compares, the wavefront aligner, haplotype steps, the distances of the metrics phase) are written against these
+     * accessors, so that another kernel can run them on a different layout: avk_wide.inl keeps one region's tables in a wave's LDS and lets every lane
+     * work on a piece of that region. */
+    enum { MV = AVK_FAST_MAXV };
+    AVK_DEV const u32 *seq_word(u32 s, u32 k) const { return p + ((s * W1 + k) << ls); } /* word k of sequence s */
+    AVK_DEV u32 seq_stride() const { return 1u << ls; }                                   /* distance to the sequence's next word */
+    AVK_DEV u32 seq_at(u32 k) const { return k << ls; }                                   /* word k of a sequence, from the sequence's word 0 */
+    AVK_DEV u32 *wf_row(u32 arr, u32 row) const { return p + ((off_wf + arr * wfr + row) << ls); } /* entries 4 row .. 4 row + 3 of wavefront array arr */
+    AVK_DEV u32 vw0_at(u32 slot) const;
+    AVK_DEV u32 vw1_at(u32 slot) const;
+    AVK_DEV u32 vw0_side(u32 side, u32 j) const { return side ? vw0[AVK_FAST_MAXV + j] : vw0[j]; } /* j static: the records stay in registers */
+    AVK_DEV u32 seq_id(u32 side, u32 mask) const { return mask == 0 ? 0u : 1u + side * nm1 + (mask - 1u); }
+    AVK_DEV u32 seq_len(u32 s) const { return (u32)((s < 8 ? seq_len_lo : seq_len_hi) >> (8 * (s & 7u))) & 0xFFu; }
+    AVK_DEV u32 seq_fail(u32 s) const { return (u32)((s < 8 ? seq_fail_lo : seq_fail_hi) >> (8 * (s & 7u))) & 0xFFu; }
 };
 
 AVK_DEV u32 v_pos(const LCtx &c, u32 s) { return c.vw0[s] & 0xFFu; }
@@ -122,20 +136,22 @@ AVK_DEV u32 sel4(const u32 (&a)[NS], u32 i) {
     return r;
 }
 
-AVK_DEV u32 seq_id(const LCtx &c, u32 side, u32 mask) { return mask == 0 ? 0u : 1u + side * c.nm1 + (mask - 1u); }
-AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return (u32)((s < 8 ? c.seq_len_lo : c.seq_len_hi) >> (8 * (s & 7u))) & 0xFFu; }
-AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return (u32)((s < 8 ? c.seq_fail_lo : c.seq_fail_hi) >> (8 * (s & 7u))) & 0xFFu; }
+AVK_DEV u32 LCtx::vw0_at(u32 slot) const { return sel4(vw0, slot); }
+AVK_DEV u32 LCtx::vw1_at(u32 slot) const { return sel4(vw1, slot); }
+AVK_DEV u32 seq_id(const LCtx &c, u32 side, u32 mask) { return c.seq_id(side, mask); }
+AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return c.seq_len(s); }
+AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return c.seq_fail(s); }
 
 /* 16 bases of sequence s starting at base `off` (bits beyond the sequence's end are whatever the table holds) */
-AVK_DEV u32 extract16(const LCtx &c, u32 s, u32 off) {
+template <class C> AVK_DEV u32 extract16(const C &c, u32 s, u32 off) {
     const u32 k = off >> 4, sh = (off & 15u) * 2u;
-    const u32 *w = c.p + ((s * c.W1 + k) << c.ls);
-    const u32 lo = w[0], hi = w[1u << c.ls];
+    const u32 *w = c.seq_word(s, k);
+    const u32 lo = w[0], hi = w[c.seq_stride()];
     return (u32)((((u64)hi << 32) | lo) >> sh);
 }
 
 /* number of positions on which a[ia..la) and b[ib..lb) agree before the first difference or either end */
-AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32 lb) {
+template <class C> AVK_DEV u32 match_run(const C &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32 lb) {
     const u32 ra = la > ia ? la - ia : 0u, rb = lb > ib ? lb - ib : 0u;
     const u32 lim = ra < rb ? ra : rb;
     u32 n = 0;
@@ -155,14 +171,14 @@ AVK_DEV u32 match_run(const LCtx &c, u32 sa, u32 ia, u32 la, u32 sb, u32 ib, u32
 /* The same for two sequences read from the SAME offset i (the zero-distance front of a haplotype, whose two strings are compared
  * position by position): whole table words, no unaligned extracts, and four words of each sequence per LDS round trip — a lane is a
  * chain of dependent LDS accesses, and this slide over the common part is most of what a cheap region does. */
-AVK_DEV u32 match_run_same(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb, u32 i) {
+template <class C> AVK_DEV u32 match_run_same(const C &c, u32 sa, u32 la, u32 sb, u32 lb, u32 i) {
 #ifdef AVK_NO_MRS
     return match_run(c, sa, i, la, sb, i, lb);
 #endif
     const u32 lmin = la < lb ? la : lb;
     if (i >= lmin) return 0;
     const u32 lim = lmin - i;
-    const u32 *pa = c.p + ((sa * c.W1) << c.ls), *pb = c.p + ((sb * c.W1) << c.ls);
+    const u32 *pa = c.seq_word(sa, 0), *pb = c.seq_word(sb, 0);
     u32 k = i >> 4;
     const u32 kend = (lmin + 15u) >> 4; /* words that hold bases below lmin */
     const u32 sh = (i & 15u) * 2u;
@@ -170,7 +186,7 @@ AVK_DEV u32 match_run_same(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb, u32 i)
     { /* the word the run starts in */
         AVK_LSTAT(0, 1);
         AVK_LSTAT(24 + g_lane_phase, 1);
-        const u32 x = (pa[k << c.ls] ^ pb[k << c.ls]) >> sh;
+        const u32 x = (pa[c.seq_at(k)] ^ pb[c.seq_at(k)]) >> sh;
         if (x) {
             n = (u32)__builtin_ctz(x) >> 1;
             return n < lim ? n : lim;
@@ -180,8 +196,8 @@ AVK_DEV u32 match_run_same(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb, u32 i)
     }
     while (k < kend) { /* (words past kend are read from k: rows past the table's end are never touched) */
         const u32 k1 = k + 1 < kend ? k + 1 : k, k2 = k + 2 < kend ? k + 2 : k, k3 = k + 3 < kend ? k + 3 : k;
-        const u32 a0 = pa[k << c.ls], b0 = pb[k << c.ls], a1 = pa[k1 << c.ls], b1 = pb[k1 << c.ls];
-        const u32 a2 = pa[k2 << c.ls], b2 = pb[k2 << c.ls], a3 = pa[k3 << c.ls], b3 = pb[k3 << c.ls];
+        const u32 a0 = pa[c.seq_at(k)], b0 = pb[c.seq_at(k)], a1 = pa[c.seq_at(k1)], b1 = pb[c.seq_at(k1)];
+        const u32 a2 = pa[c.seq_at(k2)], b2 = pb[c.seq_at(k2)], a3 = pa[c.seq_at(k3)], b3 = pb[c.seq_at(k3)];
         AVK_LSTAT(0, 1);
         AVK_LSTAT(24 + g_lane_phase, 1);
         const u32 x0 = a0 ^ b0, x1 = a1 ^ b1, x2 = a2 ^ b2, x3 = a3 ^ b3;
@@ -200,10 +216,10 @@ AVK_DEV u32 match_run_same(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb, u32 i)
 }
 
 /* ---- wavefront byte arrays ---------------------------------------------------------------- */
-AVK_DEV u8 *wf_ptr(const LCtx &c, u32 arr, u32 i) { return (u8 *)(c.p + ((c.off_wf + arr * c.wfr + (i >> 2)) << c.ls)) + (i & 3u); }
-AVK_DEV u32 wf_get(const LCtx &c, u32 arr, u32 i) { return *wf_ptr(c, arr, i); }
-AVK_DEV void wf_set(const LCtx &c, u32 arr, u32 i, u32 v) { *wf_ptr(c, arr, i) = (u8)v; }
-AVK_DEV u32 *wf_row(const LCtx &c, u32 arr, u32 row) { return c.p + ((c.off_wf + arr * c.wfr + row) << c.ls); } /* entries 4 row .. 4 row + 3 */
+template <class C> AVK_DEV u8 *wf_ptr(const C &c, u32 arr, u32 i) { return (u8 *)c.wf_row(arr, i >> 2) + (i & 3u); }
+template <class C> AVK_DEV u32 wf_get(const C &c, u32 arr, u32 i) { return *wf_ptr(c, arr, i); }
+template <class C> AVK_DEV void wf_set(const C &c, u32 arr, u32 i, u32 v) { *wf_ptr(c, arr, i) = (u8)v; }
+template <class C> AVK_DEV u32 *wf_row(const C &c, u32 arr, u32 row) { return c.wf_row(arr, row); } /* entries 4 row .. 4 row + 3 */
 
 /* DWFALite on (B = sequence sb of length bl, O = sequence so of length ol); wf[i] = symbols of O consumed on diagonal i,
  * baseline offset = wf[i] + ed - i (dynamic_wfa.rs:114).
@@ -217,7 +233,7 @@ enum { DW_TOUCH = 1, DW_FULL = 2 };
 #define AVK_DW_BATCH 2u
 #endif
 /* the four diagonals 4 row .. 4 row + 3 of a front of `nd` diagonals at distance `ed`, offsets in `w` (one byte each): extended, flags added */
-AVK_DEV u32 dw_extend_row(const LCtx &c, u32 w, u32 row, u32 nd, u32 ed, u32 sb, u32 bl, u32 so, u32 ol, u32 &flags) {
+template <class C> AVK_DEV u32 dw_extend_row(const C &c, u32 w, u32 row, u32 nd, u32 ed, u32 sb, u32 bl, u32 so, u32 ol, u32 &flags) {
     u32 out = 0;
 #pragma unroll
     for (u32 half = 0; half < 4; half += AVK_DW_BATCH) { /* AVK_DW_BATCH diagonals' reads in flight at a time (registers) */
@@ -260,7 +276,7 @@ AVK_DEV u32 dw_extend_row(const LCtx &c, u32 w, u32 row, u32 nd, u32 ed, u32 sb,
     return out;
 }
 /* extend (:94-130): every diagonal as far as it matches */
-AVK_DEV u32 dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) {
+template <class C> AVK_DEV u32 dw_extend(const C &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u32 ol) {
     const u32 nd = 2 * ed + 1;
     u32 flags = 0;
     for (u32 row = 0; 4 * row < nd; ++row) {
@@ -271,7 +287,7 @@ AVK_DEV u32 dw_extend(const LCtx &c, u32 arr, u32 ed, u32 sb, u32 bl, u32 so, u3
 }
 /* increase_edit_distance (:140-173: new[k] = max(old[k], old[k-1] + 1, old[k-2] + 1), no clipping) and the extend that always follows it,
  * in one pass over the rows, top row first (row r of the new front needs rows r and r - 1 of the old one) */
-AVK_DEV u32 dw_bump_extend(const LCtx &c, u32 arr, u32 old_ed, u32 sb, u32 bl, u32 so, u32 ol) {
+template <class C> AVK_DEV u32 dw_bump_extend(const C &c, u32 arr, u32 old_ed, u32 sb, u32 bl, u32 so, u32 ol) {
     const u32 nd = 2 * old_ed + 1, nn = nd + 2, ed = old_ed + 1;
     u32 flags = 0;
     int row = (int)((nn - 1) >> 2);
@@ -304,7 +320,7 @@ AVK_DEV u32 dw_bump_extend(const LCtx &c, u32 arr, u32 old_ed, u32 sb, u32 bl, u
 enum { LS_PARTIAL = 1 }; /* a capped alignment stopped: the distance is MORE than the budget (how much more is not known) */
 /* update (:68-84): extend, then raise the distance until EITHER end is touched; LS_DEFER when the array is too small.
  * `budget` = the largest distance the caller cares about: LS_PARTIAL as soon as the distance is known to exceed it. */
-AVK_DEV int dw_update(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget) {
+template <class C> AVK_DEV int dw_update(const C &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget) {
     u32 fl = dw_extend(c, arr, ed, sb, bl, so, ol);
     while (!(fl & DW_TOUCH)) {
         if (ed + 1 > budget) return LS_PARTIAL;
@@ -314,7 +330,7 @@ AVK_DEV int dw_update(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u
     }
     return 0;
 }
-AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget, u32 cap) { /* :183-198 */
+template <class C> AVK_DEV int dw_finalize(const C &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so, u32 ol, u32 budget, u32 cap) { /* :183-198 */
     u32 fl = dw_extend(c, arr, ed, sb, bl, so, ol);
     while (!(fl & DW_FULL)) {
         if (ed + 1 > budget) return LS_PARTIAL;
@@ -326,7 +342,7 @@ AVK_DEV int dw_finalize(const LCtx &c, u32 arr, u32 &ed, u32 sb, u32 bl, u32 so,
 }
 /* wfa_ed (src/util/sequence_alignment.rs:9-13) = unit-cost edit distance of two complete sequences.  Only the metrics phase aligns this
  * way, when the search is over: the rows of the three wavefront arrays and of the queue are one long array for it (wfcap_c bytes). */
-AVK_DEV int wfa_ed(const LCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
+template <class C> AVK_DEV int wfa_ed(const C &c, u32 sa, u32 la, u32 sb, u32 lb) {
     AVK_LSTAT(6, 1);
     const u32 lim = la < lb ? la : lb;
     const u32 d = match_run_same(c, sa, la, sb, lb, 0);
@@ -350,7 +366,7 @@ AVK_DEV void hap_init(Hap &h) {
 }
 /* HaplotypeDWFA::extend_variant without the aligner update (haplotype_dwfa.rs:46-62, :175-227): lengths and positions only,
  * the bases are implied by FULL(side, chosen alleles).  has_var false = the two copy_reference(region end) of finalize_dwfa. */
-AVK_DEV bool hap_step(const LCtx &c, Hap &h, bool is_truth, bool has_var, u32 slot, u32 allele, u32 sync) {
+template <class C> AVK_DEV bool hap_step(const C &c, Hap &h, bool is_truth, bool has_var, u32 slot, u32 allele, u32 sync) {
     /* "this" side and the "other" side by value (selects), written back at the end: no addresses into the record are taken */
     u32 tl = is_truth ? h.t_len : h.q_len, ol = is_truth ? h.q_len : h.t_len;
     u32 trp = is_truth ? h.t_refpos : h.q_refpos, orp = is_truth ? h.q_refpos : h.t_refpos;
@@ -359,7 +375,7 @@ AVK_DEV bool hap_step(const LCtx &c, Hap &h, bool is_truth, bool has_var, u32 sl
     u32 n1 = 0, n2 = 0, rp = trp;
     bool ok = true;
     if (has_var) {
-        const u32 w0 = sel4(c.vw0, slot);
+        const u32 w0 = c.vw0_at(slot);
         const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
         if (rp < pos) {
             n1 = pos - rp;
@@ -370,7 +386,7 @@ AVK_DEV bool hap_step(const LCtx &c, Hap &h, bool is_truth, bool has_var, u32 sl
                 n2 = a1;
                 rp = pos + a0;
             } else {
-                tskip += sel4(c.vw1, slot) & 0xFFu; /* edit_distance(allele0, allele1), :199 */
+                tskip += c.vw1_at(slot) & 0xFFu; /* edit_distance(allele0, allele1), :199 */
                 h.nskip += 1;
                 ok = false;
             }
@@ -397,8 +413,8 @@ AVK_DEV bool hap_step(const LCtx &c, Hap &h, bool is_truth, bool has_var, u32 sl
     return ok;
 }
 /* DWFALite::update on the haplotype's two sequences (hap_update of avk_solver.inl) */
-AVK_DEV int hap_update(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
-    const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+template <class C> AVK_DEV int hap_update(const C &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
+    const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
     if (h.ed == 0) {
         h.d0 += match_run_same(c, st, h.t_len, sq, h.q_len, h.d0);
         const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
@@ -409,8 +425,8 @@ AVK_DEV int hap_update(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
     }
     return dw_update(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget);
 }
-AVK_DEV int hap_finalize(const LCtx &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
-    const u32 st = seq_id(c, 0, h.t_alt), sq = seq_id(c, 1, h.q_alt);
+template <class C> AVK_DEV int hap_finalize(const C &c, Hap &h, u32 arr, u32 budget = 0xFFFFu) {
+    const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
     if (h.ed == 0) {
         if (h.d0 >= h.t_len && h.d0 >= h.q_len) return 0;
         if (budget == 0) return LS_PARTIAL;
@@ -701,13 +717,13 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
  *   one side of the call is a single base and it is the window's base there (the anchor is kept): the call only inserts or only deletes the
  *   rest, the lengths differ by that much and that many edits suffice;
  *   anything else: -1, to be aligned. */
-AVK_DEV int call_effect(const LCtx &c, u32 side, u32 j) {
-    const u32 slot = MV * side + j;
-    const u32 w0 = sel4(c.vw0, slot);
+template <class C> AVK_DEV int call_effect(const C &c, u32 side, u32 j) {
+    const u32 slot = (u32)C::MV * side + j;
+    const u32 w0 = c.vw0_at(slot);
     const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
     if (a1 == 0 || a0 == 0) return -1;
     /* FULL(side, this call alone) has the ALT allele at `pos` (a single call is never dropped) */
-    const bool anchored = ((extract16(c, 0, pos) ^ extract16(c, seq_id(c, side, 1u << j), pos)) & 3u) == 0;
+    const bool anchored = ((extract16(c, 0, pos) ^ extract16(c, c.seq_id(side, 1u << j), pos)) & 3u) == 0;
     if (a0 == 1 && a1 == 1) return anchored ? 0 : 1;
     if ((a0 == 1 || a1 == 1) && anchored) return (int)(a0 > a1 ? a0 - a1 : a1 - a0);
     return -1;
@@ -716,18 +732,18 @@ AVK_DEV int call_effect(const LCtx &c, u32 side, u32 j) {
 /* wfa_ed(reference window, FULL(side, mask)).  No alleles: 0.  One call: call_effect.  Several calls, all applied: substitutions at two
  * different positions add up (equal lengths, the positions where the strings differ; no single edit gives two), pure insertions only (or pure
  * deletions only) add up as well (the length changes by their sum, which is also enough).  Anything else is aligned. */
-AVK_DEV int ed_to_ref(const LCtx &c, u32 side, u32 mask, u32 len) {
+template <class C> AVK_DEV int ed_to_ref(const C &c, u32 side, u32 mask, u32 len) {
     if (mask == 0) return 0;
     if ((mask & (mask - 1)) == 0) {
         const int e = call_effect(c, side, (u32)__builtin_ctz(mask));
         if (e >= 0) return e;
-    } else if (seq_fail_of(c, seq_id(c, side, mask)) == 0) {
+    } else if (c.seq_fail(c.seq_id(side, mask)) == 0) {
         u32 n = 0, n_snv = 0, n_ins = 0, n_del = 0, sum = 0, pos_x = 0;
         bool all = true;
 #pragma unroll
-        for (u32 j = 0; j < MV; ++j) {
+        for (u32 j = 0; j < (u32)C::MV; ++j) {
             if (!((mask >> j) & 1u)) continue;
-            const u32 w0 = side ? c.vw0[MV + j] : c.vw0[j];
+            const u32 w0 = c.vw0_side(side, j);
             const u32 a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
             const int e = call_effect(c, side, j);
             all = all && e >= 0;
@@ -741,11 +757,11 @@ AVK_DEV int ed_to_ref(const LCtx &c, u32 side, u32 mask, u32 len) {
         if (all && n == 2 && n_snv == 2 && pos_x != 0) return (int)sum;
         if (all && (n_ins == n || n_del == n)) return (int)sum;
     }
-    return wfa_ed(c, 0, c.L, seq_id(c, side, mask), len);
+    return wfa_ed(c, 0, c.L, c.seq_id(side, mask), len);
 }
 
 /* Distance between a haplotype string and the same string without ONE of its calls (slot), when call_effect decides it.  -1: not decided this way. */
-AVK_DEV int one_call_distance(const LCtx &c, u32 slot) { return call_effect(c, slot / MV, slot % MV); }
+template <class C> AVK_DEV int one_call_distance(const C &c, u32 slot) { return call_effect(c, slot / (u32)C::MV, slot % (u32)C::MV); }
 
 /* the genotype assignment of one haplotype of an optimum: flips, observed alleles */
 AVK_DEV int gt_for_hap(const LCtx &c, const Hap &h, u32 &rt, u32 &rq) {
