@@ -105,16 +105,16 @@ struct LCtx {
      * accessors, so that another kernel can run them on a different layout: avk_wide.inl keeps one region's tables in a wave's LDS and lets every lane
      * work on a piece of that region. */
     enum { MV = AVK_FAST_MAXV };
-    AVK_DEV const u32 *seq_word(u32 s, u32 k) const { return p + ((s * W1 + k) << ls); } /* word k of sequence s */
-    AVK_DEV u32 seq_stride() const { return 1u << ls; }                                   /* distance to the sequence's next word */
-    AVK_DEV u32 seq_at(u32 k) const { return k << ls; }                                   /* word k of a sequence, from the sequence's word 0 */
-    AVK_DEV u32 *wf_row(u32 arr, u32 row) const { return p + ((off_wf + arr * wfr + row) << ls); } /* entries 4 row .. 4 row + 3 of wavefront array arr */
-    AVK_DEV u32 vw0_at(u32 slot) const;
-    AVK_DEV u32 vw1_at(u32 slot) const;
-    AVK_DEV u32 vw0_side(u32 side, u32 j) const { return side ? vw0[AVK_FAST_MAXV + j] : vw0[j]; } /* j static: the records stay in registers */
-    AVK_DEV u32 seq_id(u32 side, u32 mask) const { return mask == 0 ? 0u : 1u + side * nm1 + (mask - 1u); }
-    AVK_DEV u32 seq_len(u32 s) const { return (u32)((s < 8 ? seq_len_lo : seq_len_hi) >> (8 * (s & 7u))) & 0xFFu; }
-    AVK_DEV u32 seq_fail(u32 s) const { return (u32)((s < 8 ? seq_fail_lo : seq_fail_hi) >> (8 * (s & 7u))) & 0xFFu; }
+    AVK_DEV_M const u32 *seq_word(u32 s, u32 k) const { return p + ((s * W1 + k) << ls); } /* word k of sequence s */
+    AVK_DEV_M u32 seq_stride() const { return 1u << ls; }                                   /* distance to the sequence's next word */
+    AVK_DEV_M u32 seq_at(u32 k) const { return k << ls; }                                   /* word k of a sequence, from the sequence's word 0 */
+    AVK_DEV_M u32 *wf_row(u32 arr, u32 row) const { return p + ((off_wf + arr * wfr + row) << ls); } /* entries 4 row .. 4 row + 3 of wavefront array arr */
+    AVK_DEV_M u32 vw0_at(u32 slot) const;
+    AVK_DEV_M u32 vw1_at(u32 slot) const;
+    AVK_DEV_M u32 vw0_side(u32 side, u32 j) const { return side ? vw0[AVK_FAST_MAXV + j] : vw0[j]; } /* j static: the records stay in registers */
+    AVK_DEV_M u32 seq_id(u32 side, u32 mask) const { return mask == 0 ? 0u : 1u + side * nm1 + (mask - 1u); }
+    AVK_DEV_M u32 seq_len(u32 s) const { return (u32)((s < 8 ? seq_len_lo : seq_len_hi) >> (8 * (s & 7u))) & 0xFFu; }
+    AVK_DEV_M u32 seq_fail(u32 s) const { return (u32)((s < 8 ? seq_fail_lo : seq_fail_hi) >> (8 * (s & 7u))) & 0xFFu; }
 };
 
 AVK_DEV u32 v_pos(const LCtx &c, u32 s) { return c.vw0[s] & 0xFFu; }
@@ -136,8 +136,8 @@ AVK_DEV u32 sel4(const u32 (&a)[NS], u32 i) {
     return r;
 }
 
-AVK_DEV u32 LCtx::vw0_at(u32 slot) const { return sel4(vw0, slot); }
-AVK_DEV u32 LCtx::vw1_at(u32 slot) const { return sel4(vw1, slot); }
+AVK_DEV_M u32 LCtx::vw0_at(u32 slot) const { return sel4(vw0, slot); }
+AVK_DEV_M u32 LCtx::vw1_at(u32 slot) const { return sel4(vw1, slot); }
 AVK_DEV u32 seq_id(const LCtx &c, u32 side, u32 mask) { return c.seq_id(side, mask); }
 AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return c.seq_len(s); }
 AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return c.seq_fail(s); }
