@@ -151,6 +151,7 @@ struct AvkTier {
 /* partial-tally geometry: AVK_TALLY_LEN sums + 5 tier counters + 8 profiling words, padded */
 #define AVK_TALLY_STRIDE 320
 #define AVK_TALLY_LANE_SOLVED 310 /* word of a partial tally: regions finished (either way) by the lane-per-region kernel */
+#define AVK_TALLY_WIDE_SOLVED 311 /* regions finished (either way) by the wave-cooperative kernel of avk_wide.inl */
 #define AVK_TALLY_COPIES 64
 /* tail of a bulk workgroup's LDS: 16 control words + AVK_TALLY_LEN (rounded up) tally words */
 #define AVK_WG_TAIL_BYTES (64 + 4 * 288)

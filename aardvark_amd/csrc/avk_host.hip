@@ -30,6 +30,7 @@
 #include "avk_pack.h"
 #include "avk_solver.inl"
 #include "avk_lane.inl"
+#include "avk_wide.inl"
 #include "avk_dwfa_script.inl"
 #include "avk_devpack.inl"
 
@@ -109,6 +110,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_LAN
         const uint32_t v = wg_tally[k];
         if (v) atomicAdd((unsigned long long *)(part + k), (unsigned long long)v);
     }
+}
+
+/* Regions with large searches on small windows, one per wave, every lane a piece of the search (avk_wide.inl): one-wave workgroups, the region's tables in
+ * the workgroup's LDS */
+__global__ void __launch_bounds__(64) avk_wide_kernel(AvkKernelArgs a, avk::wide::WideArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    avk::wide::wide_worker<false>(a, wa, blockIdx.x, (uint32_t *)avk_smem);
+}
+/* the same for regions the lanes handed back (device-packed batches write their records on demand, AvkKernelArgs::lazy_dp) */
+__global__ void __launch_bounds__(64) avk_wide_kernel_lazy(AvkKernelArgs a, avk::wide::WideArgs wa) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    avk::wide::wide_worker<true>(a, wa, blockIdx.x, (uint32_t *)avk_smem);
 }
 
 /* regions with the same SNV on both sides (avk_pairs.inl): table rows copied out, 64 regions per wave at a time */
@@ -320,6 +333,11 @@ struct avk_ctx {
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_waves_three = 0;                     /* > 0: at most this many one-wave workgroups of the three-call class per CU (its waves take 17 KB of LDS each) */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
+    int64_t wide_kernel = 1;                          /* regions with large searches on small windows (class C, what the three-call lane class hands back) go to the wave-cooperative kernel of avk_wide.inl first */
+    int64_t wide_lds_bytes = 40 * 1024;               /* LDS of one of its waves: 4 KB of tables, the region's 2^T + 2^Q full-length sequences, the rest search nodes (29 words each, at most 240) */
+    int64_t wide_blocks = 512;                        /* most one-wave workgroups of one of its launches */
+    bool wide_attr_set = false;
+    uint64_t last_wide_solved = 0;
     bool lane_attr_set = false;
     uint64_t last_lane_solved = 0;
     int last_one_shot = 0; /* the last avk_compare_batch / avk_optimize_pairs_batch packed its batch on the device */
@@ -343,7 +361,7 @@ struct avk_ctx {
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ready = nullptr, ev_ready2 = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ready = nullptr, ev_ready2 = nullptr, ev_wide = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
     uint64_t last_phase[16] = {0};
@@ -365,6 +383,7 @@ struct avk_dev_batch {
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr, *d_overflow4 = nullptr;
+    uint32_t *d_overflow5 = nullptr, *d_overflow6 = nullptr; /* what the launches of avk_wide.inl could not take: of class C, of the three-call lane class's hand-backs */
     avk::WorkPlan plan;
     uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
     uint64_t fast_word_base[AVK_FAST_CLASSES] = {0}; /* first word of the class's tiles in d_fast */
@@ -430,7 +449,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 void free_batch_buffers(avk_dev_batch *db) {
     if (db->dev_packed) return; /* pooled buffers: release_pooled */
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_fast,
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_fast,
                     db->d_bp_off, db->d_bp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -503,6 +522,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_wide, hipEventDisableTiming) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join2, hipEventDisableTiming) != hipSuccess ||
@@ -552,6 +572,7 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
     if (ctx->ev_ready2) (void)hipEventDestroy(ctx->ev_ready2);
+    if (ctx->ev_wide) (void)hipEventDestroy(ctx->ev_wide);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
     if (ctx->d_pair_tab) (void)hipFree(ctx->d_pair_tab);
@@ -636,6 +657,14 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "claim") {
         if (value < 1 || value > 64) return fail(ctx, AVK_E_ARG, "claim must be in [1, 64]");
         ctx->claim = value;
+    } else if (n == "wide_kernel") {
+        ctx->wide_kernel = value ? 1 : 0;
+    } else if (n == "wide_lds_bytes") {
+        if (value < 24 * 1024 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_lds_bytes must be in [24576, 65536]");
+        ctx->wide_lds_bytes = value & ~15ll;
+    } else if (n == "wide_blocks") {
+        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_blocks must be in [1, 4096]");
+        ctx->wide_blocks = value;
     } else if (n == "solo_blocks_max") {
         if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
         ctx->solo_blocks_max = value;
@@ -953,6 +982,8 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow4, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow5, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow6, n + 1));
 #undef AVK_TRY
     { /* compact BASEPAIR groups: 1 + the region's call types each (none for regions that fail validation), as the device packer counts them */
         std::vector<uint32_t> bp_off(n + 1, 0);
@@ -1144,6 +1175,18 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const bool use_fast = ctx->lane_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && db->d_fast && n_lane_regions && !cfg->enable_sequences &&
                           !cfg->enable_exact_shortcut && n && ctx->use_packed_reference && ctx->d_ref2b;
     const uint32_t n_fast = use_fast ? n_lane_regions : 0u;
+    /* the wave-cooperative kernel of avk_wide.inl takes class C and what the three-call lane class hands back ahead of the HBM-tier launches (which get what it
+     * cannot take); like the lanes it reads the 2-bit reference and writes no sequences */
+    const bool use_wide = ctx->wide_kernel && launch[0] && !launch[1] && launch[2] && !launch[3] && !cfg->enable_sequences && !cfg->enable_exact_shortcut && n &&
+                          ctx->use_packed_reference && ctx->d_ref2b;
+    avk::wide::WideArgs wa;
+    wa.lds_words = (uint32_t)(ctx->wide_lds_bytes / 4);
+    wa.pad = 0;
+    if (use_wide && !ctx->wide_attr_set) {
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_wide_kernel_lazy, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        ctx->wide_attr_set = true;
+    }
     if (db->dev_packed && !use_fast) { /* the wave-per-region launches take every record: write the ones the packer left for later */
         const int rf = ensure_all_records(ctx, db, ctx->stream);
         if (rf) return rf;
@@ -1267,7 +1310,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
-    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false;
+    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false, hbm_shared = false;
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -1333,8 +1376,26 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
             if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
+            bool wide_c = false;
             if (hbm_solo) {
                 AvkKernelArgs s = a;
+                AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->ev_fork, 0));
+                if (use_wide) { /* class C through avk_wide.inl first; the HBM launch behind it on this stream takes the list of what that could not take */
+                    AvkKernelArgs w = a;
+                    w.work_list = nullptr;
+                    w.n_work_dev = nullptr;
+                    w.work_base = 0;
+                    w.n_work = n_c;
+                    w.work_counter = db->d_counters + 1240;
+                    w.overflow_list = db->d_overflow5;
+                    w.overflow_count = db->d_counters + 1244;
+                    uint32_t wg = n_c < (uint32_t)ctx->wide_blocks ? n_c : (uint32_t)ctx->wide_blocks;
+                    hipLaunchKernelGGL(avk_wide_kernel, dim3(wg), dim3(64), (size_t)ctx->wide_lds_bytes, ctx->side_stream2, w, wa);
+                    AVK_HIP(ctx, hipGetLastError());
+                    wide_c = true;
+                    s.work_list = db->d_overflow5;
+                    s.n_work_dev = db->d_counters + 1244;
+                }
                 s.pass_tier = 2;
                 s.work_base = 0;
                 s.n_work = n_c;
@@ -1354,12 +1415,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     s.overflow_list = lists[launch[1] ? 2 : 1];
                     s.overflow_count = db->d_counters + 1024 + 16 * (launch[1] ? 2 : 1);
                 }
-                AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->ev_fork, 0));
                 if (order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_ready2, ctx->side_stream2));
                 hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_solo), dim3(256), 0, ctx->side_stream2, s);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side_stream2));
                 hbm_solo_pending = true;
+                hbm_shared = !wide_c; /* (the records of class C are the wide launch's: the main stream's HBM launch has nothing to share) */
             }
             if (solo) {
                 AvkKernelArgs s = a;
@@ -1520,6 +1581,16 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         e.big_busy = db->d_counters + 1088;
                         e.big_slots = big_slots;
                         uint32_t eb = hbm_blocks < hbm_early_max ? hbm_blocks : hbm_early_max;
+                        if (use_wide) { /* large searches on small windows: avk_wide.inl first, the HBM-tier launch takes what is left */
+                            AvkKernelArgs w = e;
+                            w.work_counter = db->d_counters + 1248;
+                            w.overflow_list = db->d_overflow6;
+                            w.overflow_count = db->d_counters + 1252;
+                            hipLaunchKernelGGL(avk_wide_kernel_lazy, dim3((uint32_t)ctx->wide_blocks), dim3(64), (size_t)ctx->wide_lds_bytes, es, w, wa);
+                            AVK_HIP(ctx, hipGetLastError());
+                            e.work_list = db->d_overflow6;
+                            e.n_work_dev = db->d_counters + 1252;
+                        }
                         if (ctx->early_lds && ctx->lds_bytes_per_wave >= 1024) {
                             /* option early_lds: the regions the three-call class hands back are small windows with large searches — the LDS tier with its
                              * in-workgroup escalation first (as the launch for the other classes' hand-backs), the HBM launch at the end for what overflows */
@@ -1630,7 +1701,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.big_busy = db->d_counters + 1088;
             a.big_slots = big_slots;
             a.n_waves = hbm_blocks * waves_per_block;
-            if (hbm_solo_pending) { /* class C records the solo launch has not started yet: every wave of this launch helps (same ticket counter) */
+            if (hbm_solo_pending && hbm_shared) { /* class C records the solo launch has not started yet: every wave of this launch helps (same ticket counter) */
                 a.extra_counter = db->d_counters + 1076;
                 a.extra_base = 0;
                 a.extra_n = db->plan.n_hbm;
@@ -1728,6 +1799,12 @@ int avk_last_lane_ms(avk_ctx *ctx, float *ms) {
 int avk_last_lane_solved(avk_ctx *ctx, uint64_t *count) {
     if (!ctx || !count) return AVK_E_ARG;
     *count = ctx->last_lane_solved;
+    return 0;
+}
+
+int avk_last_wide_solved(avk_ctx *ctx, uint64_t *count) {
+    if (!ctx || !count) return AVK_E_ARG;
+    *count = ctx->last_wide_solved;
     return 0;
 }
 
@@ -1942,6 +2019,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
     ctx->last_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
+    ctx->last_wide_solved = tally[AVK_TALLY_WIDE_SOLVED];
     memcpy(ctx->last_phase, tally.data() + AVK_TALLY_LEN + 5, 16 * sizeof(uint64_t));
     if (want_seq) {
         for (uint64_t r = 0; r < n; ++r) {
@@ -1969,7 +2047,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         int retry_rc = 0;
         uint64_t keep_tiers[5];
         memcpy(keep_tiers, ctx->last_tiers, sizeof(keep_tiers));
-        const uint64_t keep_lane_solved = ctx->last_lane_solved;
+        const uint64_t keep_lane_solved = ctx->last_lane_solved, keep_wide_solved = ctx->last_wide_solved;
         for (uint64_t slice = 1ull << 30; !cap.empty() && slice <= (16ull << 30); slice <<= 2) {
             if ((int64_t)slice <= ctx->big_ws_bytes) continue;
             CapacityFix fx;
@@ -2021,6 +2099,7 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         }
         memcpy(ctx->last_tiers, keep_tiers, sizeof(keep_tiers)); /* the statistics of the caller's batch, not of the retries */
         ctx->last_lane_solved = keep_lane_solved;
+        ctx->last_wide_solved = keep_wide_solved;
         if (big_grown && ctx->big_alloc > big_before && ctx->d_big) { /* give the large slices back */
             (void)hipStreamSynchronize(ctx->stream);
             (void)hipFree(ctx->d_big);
@@ -2299,6 +2378,7 @@ int avk_optimize_pairs_batch(avk_ctx *ctx, const avk_region_batch *batch, uint32
         ctx->last_one_shot = rc == 0;
         memcpy(ctx->last_tiers, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
         ctx->last_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
+        ctx->last_wide_solved = tally[AVK_TALLY_WIDE_SOLVED];
     } else if (!rc) {
         std::vector<uint32_t> rout(db->n_regions * 4 + 4);
         hipError_t e = hipMemcpyAsync(rout.data(), db->d_region_out, db->n_regions * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream);

@@ -105,7 +105,7 @@ struct LCtx {
      * accessors, so that another kernel can run them on a different layout: avk_wide.inl keeps one region's tables in a wave's LDS and lets every lane
      * work on a piece of that region. */
     enum { MV = AVK_FAST_MAXV };
-    AVK_DEV_M const u32 *seq_word(u32 s, u32 k) const { return p + ((s * W1 + k) << ls); } /* word k of sequence s */
+    AVK_DEV_M u32 *seq_word(u32 s, u32 k) const { return p + ((s * W1 + k) << ls); } /* word k of sequence s */
     AVK_DEV_M u32 seq_stride() const { return 1u << ls; }                                   /* distance to the sequence's next word */
     AVK_DEV_M u32 seq_at(u32 k) const { return k << ls; }                                   /* word k of a sequence, from the sequence's word 0 */
     AVK_DEV_M u32 *wf_row(u32 arr, u32 row) const { return p + ((off_wf + arr * wfr + row) << ls); } /* entries 4 row .. 4 row + 3 of wavefront array arr */
@@ -779,19 +779,19 @@ struct SeqWriter {
     u64 acc;
     u32 nb, row, k;
 };
-AVK_DEV void sw_push(const LCtx &c, SeqWriter &w, u32 bits, u32 nbases) {
+template <class C> AVK_DEV void sw_push(const C &c, SeqWriter &w, u32 bits, u32 nbases) {
     if (nbases == 0) return;
     const u64 m = nbases >= 16 ? 0xFFFFFFFFull : ((1ull << (2 * nbases)) - 1ull);
     w.acc |= ((u64)bits & m) << w.nb;
     w.nb += 2 * nbases;
     if (w.nb >= 32) {
-        c.p[(w.row * c.W1 + w.k) << c.ls] = (u32)w.acc;
+        *c.seq_word(w.row, w.k) = (u32)w.acc;
         w.k += 1;
         w.acc >>= 32;
         w.nb -= 32;
     }
 }
-AVK_DEV void sw_ref(const LCtx &c, SeqWriter &w, u32 from, u32 to) {
+template <class C> AVK_DEV void sw_ref(const C &c, SeqWriter &w, u32 from, u32 to) {
     for (u32 p = from; p < to; p += 16) sw_push(c, w, extract16(c, 0, p), to - p < 16 ? to - p : 16u);
 }
 /* FULL(side, mask): the calls of the mask applied in the side's order, a call that starts before the end of the previous applied one
@@ -824,7 +824,7 @@ template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)
         sw_ref(c, w, cur, c.L);
         len += c.L - cur;
     }
-    if (w.nb) c.p[(w.row * c.W1 + w.k) << c.ls] = (u32)w.acc;
+    if (w.nb) *c.seq_word(w.row, w.k) = (u32)w.acc;
     const u64 len_s = (u64)len << (8 * (s & 7u)), fail_s = (u64)failed << (8 * (s & 7u));
     c.seq_len_lo |= s < 8 ? len_s : 0ull;
     c.seq_len_hi |= s < 8 ? 0ull : len_s;

@@ -84,6 +84,17 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 #define wv_sum_u32(v) wv_sum_u32_((v), AVK_SITE)
 #define wv_min_u64(v) wv_min_u64_((v), AVK_SITE)
 #define wv_readlane(v, src) wv_readlane_((v), (src), AVK_SITE)
+/* the value of the lane below / above (lane 0 / lane 63 keep their own) */
+AVK_DEV uint32_t wv_from_below_(uint32_t v, uint32_t site) {
+    const int l = avk_emu::lane();
+    return (uint32_t)avk_emu::gather(v, site)[l ? l - 1 : 0];
+}
+AVK_DEV uint32_t wv_from_above_(uint32_t v, uint32_t site) {
+    const int l = avk_emu::lane();
+    return (uint32_t)avk_emu::gather(v, site)[l < 63 ? l + 1 : 63];
+}
+#define wv_from_below(v) wv_from_below_((v), AVK_SITE)
+#define wv_from_above(v) wv_from_above_((v), AVK_SITE)
 #define wv_sync() wv_sync_(AVK_SITE)
 
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); } /* waves of a workgroup are OS threads */
@@ -142,6 +153,9 @@ AVK_DEV uint64_t wv_ballot(bool p) { return __ballot(p); }
 AVK_DEV uint32_t wv_shfl(uint32_t v, int src) { return (uint32_t)__shfl((int)v, src, 64); }
 /* value of lane `src` (src must be wave-uniform) as a scalar */
 AVK_DEV uint32_t wv_readlane(uint32_t v, uint32_t src) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)src); }
+/* the value of the lane below / above (lane 0 / lane 63 keep their own): one DPP move over the whole wave (wave_shr:1 / wave_shl:1) */
+AVK_DEV uint32_t wv_from_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x138, 0xf, 0xf, false); }
+AVK_DEV uint32_t wv_from_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
 /* a value that is identical on every lane: move it to an SGPR so branches on it are scalar */
 AVK_DEV uint32_t wv_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
 /* cross-lane reductions on the DPP network (row shifts inside 16 lanes, then row broadcasts):

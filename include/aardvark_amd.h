@@ -325,6 +325,7 @@ int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the batch of the last a
 int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */
 int  avk_last_lane_solved(avk_ctx *ctx, uint64_t *count); /* regions the lane-per-region kernel finished (last downloaded step);
                                                              they are not counted in any workspace tier */
+int  avk_last_wide_solved(avk_ctx *ctx, uint64_t *count); /* the same for the wave-cooperative kernel of the large searches on small windows (option wide_kernel) */
 /* Host utility (no GPU involved): the full GroupTypeMetrics block of region r (13 groups x 22 counters, the layout of group_metrics) from the batch, the
  * per-call outputs var_expected / var_observed of `res` and the region's compact BASEPAIR groups: the GT / HAP / WEIGHTED_HAP counters follow from
  * (expected, observed) per call (grouped_metrics.rs:183-227 and the swap of :268-277), RECORD_BP from the calls' zygosities and raw_allele_space

@@ -151,6 +151,10 @@ static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
 namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; uint32_t *g_lane_work; uint32_t *g_lane_comp; } }
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
+#ifdef AVK_WIDE_STATS
+namespace avk { namespace wide { uint64_t g_wide_defer[64]; } }
+#endif
+#include "../../aardvark_amd/csrc/avk_wide.inl"
 #include "../../aardvark_amd/csrc/avk_dwfa_script.inl"
 #include "../../aardvark_amd/csrc/avk_devpack.inl"
 
@@ -184,6 +188,20 @@ void lane_kernel_main(void *p, int lane) {
     avk::lane::lane_worker(*t->args, *t->la, t->wave_id, t->lds, t->tally, ok, err);
     t->n_ok[lane] = ok;
     t->n_err[lane] = err;
+}
+
+int g_wide_kernel = 1;                 /* emu_set_wide_kernel: context option wide_kernel (avk_wide.inl ahead of the HBM-tier launches of class C and of the three-call class's hand-backs) */
+uint32_t g_wide_lds_bytes = 40 * 1024; /* context option wide_lds_bytes */
+uint64_t g_wide_solved = 0;
+struct WideTask {
+    const AvkKernelArgs *args;
+    avk::wide::WideArgs wa;
+    uint32_t wave_id;
+    uint32_t *lds;
+};
+void wide_kernel_main(void *p, int) {
+    WideTask *t = (WideTask *)p;
+    avk::wide::wide_worker<true>(*t->args, t->wa, t->wave_id, t->lds); /* (the lazy instantiation: it differs from the other only when lazy_dp is set) */
 }
 
 struct WaveTask {
@@ -501,6 +519,31 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         }
     };
 
+    /* a launch of avk_wide.inl (run_internal: avk_wide_kernel / avk_wide_kernel_lazy): `waves` one-wave workgroups on the list of `w` */
+    auto run_wide = [&](const AvkKernelArgs &w, uint32_t waves) {
+        std::atomic<uint32_t> next(0);
+        auto worker = [&]() {
+            avk_emu::Wave wv;
+            wv.stack_bytes = 256 * 1024;
+            std::vector<char> stacks(64 * wv.stack_bytes + 64);
+            wv.stacks = stacks.data();
+            std::vector<uint32_t> ldsbuf(g_wide_lds_bytes / 4 + 64);
+            for (;;) {
+                const uint32_t wid = next.fetch_add(1);
+                if (wid >= waves) break;
+                for (auto &x : ldsbuf) x = 0xA5A5A5A5u; /* LDS is not zeroed */
+                WideTask t;
+                t.args = &w, t.wa.lds_words = g_wide_lds_bytes / 4, t.wa.pad = 0, t.wave_id = wid, t.lds = ldsbuf.data();
+                avk_emu::run_wave(&wv, wide_kernel_main, &t);
+            }
+        };
+        std::vector<std::thread> ts;
+        for (int i = 0; i < (threads < 1 ? 1 : threads); ++i) ts.emplace_back(worker);
+        for (auto &t : ts) t.join();
+    };
+    std::vector<uint32_t> wide_left_c(n + 1), wide_left_3(n + 1); /* what the wide launches could not take (run_internal: d_overflow5 / d_overflow6) */
+    const bool use_wide = g_wide_kernel && lds_bytes > 0 && !(lds2_bytes > 0 && lds2_overflow_pass) && ws_bytes > 0 && !cfg->enable_sequences && !cfg->enable_exact_shortcut && n;
+
     /* the same four tier launches as avk_compare_resident (aardvark_amd/csrc/avk_host.hip) */
     const bool use[4] = {lds_bytes > 0, lds2_bytes > 0, ws_bytes > 0, big_ws_bytes > 0};
     const bool launch[4] = {use[0], use[1] && (lds2_overflow_pass || !use[0]), use[2], use[3] && !use[2]};
@@ -674,6 +717,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 a.pass_tier = 2;
                 a.work_list = lists[3].data();
                 a.n_work_dev = counters + 1104;
+                if (use_wide) { /* ... and the launch of avk_wide.inl ahead of it */
+                    AvkKernelArgs w = a;
+                    w.work_base = 0, w.n_work = 0, w.work_counter = counters + 1248, w.overflow_list = wide_left_3.data(), w.overflow_count = counters + 1252;
+                    run_wide(w, n_waves ? n_waves : 1);
+                    a.work_list = wide_left_3.data();
+                    a.n_work_dev = counters + 1252;
+                }
                 a.work_base = 0;
                 a.n_work = 0;
                 a.work_counter = counters + 1120;
@@ -735,6 +785,15 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 hbm_shared = n_c;
                 if (n_c && !skip_hbm_solo) {
                     AvkKernelArgs keep = a;
+                    if (use_wide) { /* run_internal: class C through avk_wide.inl first, the HBM solo launch takes what is left */
+                        AvkKernelArgs w = a;
+                        w.work_list = nullptr, w.n_work_dev = nullptr, w.work_base = 0, w.n_work = n_c, w.work_counter = counters + 1240;
+                        w.overflow_list = wide_left_c.data(), w.overflow_count = counters + 1244;
+                        run_wide(w, n_waves ? n_waves : 1);
+                        a.work_list = wide_left_c.data();
+                        a.n_work_dev = counters + 1244;
+                        hbm_shared = 0;
+                    }
                     a.pass_tier = 2;
                     a.work_base = 0;
                     a.n_work = n_c;
@@ -873,6 +932,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     if (tier_counts) memcpy(tier_counts, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));
     g_lane_solved = tally[AVK_TALLY_LANE_SOLVED];
+    g_wide_solved = tally[AVK_TALLY_WIDE_SOLVED];
     return 0;
 }
 
@@ -1069,6 +1129,17 @@ void emu_lane_stats(uint64_t *out, int reset) {
 }
 #endif
 uint64_t emu_last_lane_solved(void) { return g_lane_solved; }
+uint64_t emu_last_wide_solved(void) { return g_wide_solved; }
+void emu_set_wide_kernel(int on) { g_wide_kernel = on; }
+#ifdef AVK_WIDE_STATS
+void emu_wide_defer_stats(uint64_t *out, int reset) {
+    for (int i = 0; i < 64; ++i) {
+        out[i] = avk::wide::g_wide_defer[i];
+        if (reset) avk::wide::g_wide_defer[i] = 0;
+    }
+}
+#endif
+void emu_set_wide_lds_bytes(uint32_t bytes) { g_wide_lds_bytes = bytes; }
 void emu_set_lane_node_cap(int cap) { g_lane_node_cap = (uint32_t)cap; }
 void emu_set_lane_head_width(int w) { g_lane_head_width = (uint32_t)w; }
 void emu_set_lane_width(int one, int two) {

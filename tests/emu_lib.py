@@ -23,17 +23,29 @@ def load():
                                                  C.POINTER(C.c_int32), u8p, C.c_int]
         lib.emu_set_lane_kernel.argtypes = [C.c_int]
         lib.emu_last_lane_solved.restype = C.c_uint64
+        lib.emu_last_wide_solved.restype = C.c_uint64
+        lib.emu_set_wide_kernel.argtypes = [C.c_int]
+        lib.emu_set_wide_lds_bytes.argtypes = [C.c_uint32]
         _lib = lib
     return _lib
 
 
 def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False,
                   lds_bytes=10 * 1024, lds_ed_cap=48, lds2_bytes=40 * 1024, lds2_ed_cap=48, ws_bytes=1 << 20, big_ws_bytes=64 << 20,
-                  n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1, group_metrics=True, lane_kernel=True, bp_groups=False):
+                  n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1, group_metrics=True, lane_kernel=True, bp_groups=False,
+                  wide_kernel=True, wide_lds_bytes=40 * 1024, class_c_all=False):
     """lane_kernel: small regions go through the lane-per-region code (avk_lane.inl), the rest through the wave-per-region code, as
-    avk_compare_resident does; False = everything through the wave-per-region code.  res.lane_solved = regions the lane code finished."""
+    avk_compare_resident does; False = everything through the wave-per-region code.  res.lane_solved = regions the lane code finished.
+    wide_kernel: class C and what the three-call lane class hands back go through the wave-cooperative code of avk_wide.inl first
+    (res.wide_solved = regions it finished); class_c_all = every region outside the lane classes is planned as class C."""
     lib = load()
     lib.emu_set_lane_kernel(1 if lane_kernel else 0)
+    lib.emu_set_wide_kernel(1 if wide_kernel else 0)
+    lib.emu_set_wide_lds_bytes(wide_lds_bytes)
+    if class_c_all:
+        os.environ["AVK_EMU_CLASS_C"] = "100000"
+    else:
+        os.environ.pop("AVK_EMU_CLASS_C", None)
     cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
     res = ResultBatch(batch, sequences=sequences, group_metrics=group_metrics, bp_groups=bp_groups)
     cfg = AvkCompareConfig(max_branch_factor, 1 if sequences else 0, 1 if exact_shortcut else 0)
@@ -44,6 +56,8 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     assert rc == 0
     res.tier_counts = [int(x) for x in tiers]
     res.lane_solved = int(lib.emu_last_lane_solved())
+    res.wide_solved = int(lib.emu_last_wide_solved())
+    os.environ.pop("AVK_EMU_CLASS_C", None)
     return res
 
 
