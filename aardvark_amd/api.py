@@ -72,6 +72,7 @@ def load_library():
     lib.avk_last_compare_was_one_shot.argtypes = [vp]
     lib.avk_last_lane_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.avk_last_lane_solved.argtypes = [vp, u64p]
+    lib.avk_last_wide_solved.argtypes = [vp, u64p]
     lib.avk_debug_phase_cycles.argtypes = [vp, u64p]
     lib.avk_algorithmic_bytes.restype = C.c_uint64
     lib.avk_algorithmic_bytes.argtypes = [C.POINTER(AvkRegionBatch)]
@@ -296,6 +297,12 @@ class Context:
         """regions the lane-per-region kernel finished in the step whose results were downloaded last"""
         out = C.c_uint64(0)
         self._check(self.lib.avk_last_lane_solved(self.handle, C.byref(out)))
+        return int(out.value)
+
+    def last_wide_solved(self):
+        """regions the wave-cooperative kernel of the large searches on small windows (avk_wide.inl) finished in the step whose results were downloaded last"""
+        out = C.c_uint64(0)
+        self._check(self.lib.avk_last_wide_solved(self.handle, C.byref(out)))
         return int(out.value)
 
     def last_tier_counts(self):

@@ -334,7 +334,7 @@ struct avk_ctx {
     int64_t lane_waves_three = 0;                     /* > 0: at most this many one-wave workgroups of the three-call class per CU (its waves take 17 KB of LDS each) */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     int64_t wide_kernel = 1;                          /* regions with large searches on small windows (class C, what the three-call lane class hands back) go to the wave-cooperative kernel of avk_wide.inl first */
-    int64_t wide_lds_bytes = 40 * 1024;               /* LDS of one of its waves: 4 KB of tables, the region's 2^T + 2^Q full-length sequences, the rest search nodes (29 words each, at most 240) */
+    int64_t wide_lds_bytes = 16 * 1024;               /* LDS of one of its waves: 1.2 KB of tables, the region's 2^T + 2^Q full-length sequences, the rest search nodes (10 words each, at most 240) and 32 wavefront blocks */
     int64_t wide_blocks = 512;                        /* most one-wave workgroups of one of its launches */
     bool wide_attr_set = false;
     uint64_t last_wide_solved = 0;
@@ -660,7 +660,7 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "wide_kernel") {
         ctx->wide_kernel = value ? 1 : 0;
     } else if (n == "wide_lds_bytes") {
-        if (value < 24 * 1024 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_lds_bytes must be in [24576, 65536]");
+        if (value < 8 * 1024 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_lds_bytes must be in [8192, 65536]");
         ctx->wide_lds_bytes = value & ~15ll;
     } else if (n == "wide_blocks") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_blocks must be in [1, 4096]");

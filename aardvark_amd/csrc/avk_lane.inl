@@ -111,6 +111,7 @@ struct LCtx {
     AVK_DEV_M u32 *wf_row(u32 arr, u32 row) const { return p + ((off_wf + arr * wfr + row) << ls); } /* entries 4 row .. 4 row + 3 of wavefront array arr */
     AVK_DEV_M u32 vw0_at(u32 slot) const;
     AVK_DEV_M u32 vw1_at(u32 slot) const;
+    AVK_DEV_M u32 step_w0(u32 slot) const; /* vw0_at for the call a haplotype step applies (avk_wide.inl has that word at hand before it knows the slot) */
     AVK_DEV_M u32 vw0_side(u32 side, u32 j) const { return side ? vw0[AVK_FAST_MAXV + j] : vw0[j]; } /* j static: the records stay in registers */
     AVK_DEV_M u32 seq_id(u32 side, u32 mask) const { return mask == 0 ? 0u : 1u + side * nm1 + (mask - 1u); }
     AVK_DEV_M u32 seq_len(u32 s) const { return (u32)((s < 8 ? seq_len_lo : seq_len_hi) >> (8 * (s & 7u))) & 0xFFu; }
@@ -138,6 +139,7 @@ AVK_DEV u32 sel4(const u32 (&a)[NS], u32 i) {
 
 AVK_DEV_M u32 LCtx::vw0_at(u32 slot) const { return sel4(vw0, slot); }
 AVK_DEV_M u32 LCtx::vw1_at(u32 slot) const { return sel4(vw1, slot); }
+AVK_DEV_M u32 LCtx::step_w0(u32 slot) const { return sel4(vw0, slot); }
 AVK_DEV u32 seq_id(const LCtx &c, u32 side, u32 mask) { return c.seq_id(side, mask); }
 AVK_DEV u32 seq_len_of(const LCtx &c, u32 s) { return c.seq_len(s); }
 AVK_DEV u32 seq_fail_of(const LCtx &c, u32 s) { return c.seq_fail(s); }
@@ -375,7 +377,7 @@ template <class C> AVK_DEV bool hap_step(const C &c, Hap &h, bool is_truth, bool
     u32 n1 = 0, n2 = 0, rp = trp;
     bool ok = true;
     if (has_var) {
-        const u32 w0 = c.vw0_at(slot);
+        const u32 w0 = c.step_w0(slot);
         const u32 pos = w0 & 0xFFu, a0 = (w0 >> 8) & 0xFFu, a1 = (w0 >> 16) & 0xFFu;
         if (rp < pos) {
             n1 = pos - rp;

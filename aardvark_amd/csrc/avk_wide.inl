@@ -46,39 +46,70 @@ using lane::L_REF;
 
 enum { WMV = 8, WNS = 16 };  /* call slots per side, per region: slot = WMV * side + index on the side */
 enum { W_ED_MAX = 16 };      /* largest distance a search node's wavefront holds (2 ed + 1 offsets, one byte each) */
-enum { W_WFW = 9, W_HAP_W = 4 + W_WFW, W_NODE_W = 2 * W_HAP_W + 3 }; /* words: wavefront rows, one haplotype state, one node (odd: spreads the banks) */
+enum { W_BLK_W = 9 };        /* words of a wavefront block: the offsets of one haplotype state with distance > 0 (most states have none) */
+enum { W_NBLK_MAX = 254, W_NBLK_MIN = 16 }; /* wavefront blocks of a region (a state names its block in 8 bits) */
+enum { W_NODE_W = 9 };       /* words of a search node: two haplotype states of 4 words (odd stride: spreads the banks) */
 enum { W_K = 16 };           /* queue entries expanded per round (x up to 2 children x 2 haplotypes = the 64 lanes) */
 enum { W_QR = 4 };           /* rows of the sorted queue: 64 entries each, entry 64 r + j in lane j of row r */
-enum { W_POOL_MAX = 240 };   /* most search nodes alive (a node's slot is 8 bits; the free list has this many words) */
+enum { W_POOL_MAX = 240 };   /* most search nodes alive (a node's slot is 8 bits) */
+enum { W_POOL_MIN = 24 };
 enum { W_OPTCAP = 64 };      /* tied optima kept */
-enum { W_QB = 16 };          /* queue entries of one genotype search (4 words each, a row of 64 lanes per word) */
-enum { W_SCR = 65 };         /* words of a lane's alignment scratch in the metrics phase (odd: spreads the banks) */
+enum { W_QB = 16 };          /* queue entries of one genotype search (4 words each) */
+enum { W_QB_W = 4 * W_QB + 1 }; /* words of one genotype search's queue (odd: spreads the banks) */
 enum { WD_DEFER = -1 };      /* internal: not this kernel's region after all */
 /* instrumented emulator builds (-DAVK_WIDE_STATS): how often each hand-over site of solve_wide fired (tools/wide_defer_stats.py) */
 #ifdef AVK_WIDE_STATS
 extern uint64_t g_wide_defer[64];
 #define AVK_WDEFER(k) ((wv_lane() == 0 ? (void)(g_wide_defer[k] += 1) : (void)0), (int)WD_DEFER)
+#elif defined(AVK_WIDE_TIMING)
+/* (profiling builds: the sites in four groups — class limits 1-5, inexact nodes 6-7, capacities 8-12, later phases 13-16 — in the last four profiling words) */
+#define AVK_WDEFER(k) (wt.t[12 + ((k) <= 5 ? 0 : (k) <= 7 ? 1 : (k) <= 12 ? 2 : 3)] += 1, (int)WD_DEFER)
 #else
 #define AVK_WDEFER(k) ((int)WD_DEFER)
 #endif
 
-/* the wave's LDS, in words: a fixed head, then the sequence table of the region, then the phase's working area */
-enum {
-    WO_VW0 = 0,     /* [16] call slot: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 */
-    WO_VW1 = 16,    /* [16] alt_ed | raw_space << 8 */
-    WO_A1LO = 32,   /* [16] allele1, 2 bits per base: bases 0-15 */
-    WO_A1HI = 48,   /* [16] bases 16-31 */
-    WO_ORD = 64,    /* [16] search depth d: slot of its call | sync point << 8 (order_variants, query_optimizer.rs:372-381) */
-    WO_SEL = 80,    /* [16] the round's entries: node | depth << 8 */
-    WO_RES = 96,    /* [16][4] the round's results: child 0, child 1 (node | cost << 8 | inexact << 31), kind */
-    WO_OPT = 160,   /* [64] nodes of the tied optima, in the order the reference finds them */
-    WO_FILT = 224,  /* [12][2][2] per-type alignments of the metrics phase: x | z << 16 */
-    WO_TALLY = 272, /* [288] the wave's tally (flushed every 256 regions) */
-    WO_OPTH = 560,  /* [64][8] the optima's haplotype states (4 words each, wavefronts dropped) */
-    WO_FREE = 1072, /* [<= 240] free node slots (a stack) */
-    WO_META = 1312, /* [NSEQ] sequence s: length | failed_ed << 16; then the sequences, W1 words each; then the working area (what is left of the launch's LDS) */
+/* profiling builds (-DAVK_WIDE_TIMING, make wide-timing): clock ticks per phase of solve_wide, summed per wave and added to the spare words of the partial
+ * tally at the end of the launch (avk_debug_phase_cycles reads them after a download; tools/gpu_wide_phases.py):
+ * [0] record + tables, [1] rounds (the expansions), [2] commits, [3] genotype searches, [4] per-call outputs + alignments, [5] groups + outputs,
+ * [6] whole regions, [7] regions, [8] rounds, [9] committed pops, [10] entries expanded, [11] handed over */
+#ifdef AVK_WIDE_TIMING
+struct WTime {
+    u64 t[16], last;
 };
-enum { W_DYN_MIN = 4096 }; /* least working area: the genotype searches' rows (64 lanes x 16 entries x 4 words); the phasing search's node pool takes what the launch's LDS leaves */
+#define AVK_WT_MARK(k)                      \
+    {                                       \
+        const u64 n_ = avk_clock();         \
+        wt.t[k] += n_ - wt.last;            \
+        wt.last = n_;                       \
+    }
+#define AVK_WT_COUNT(k, n) wt.t[k] += (n)
+#define AVK_WT_ARG , WTime &wt
+#define AVK_WT_PASS , wt
+#else
+#define AVK_WT_MARK(k)
+#define AVK_WT_COUNT(k, n)
+#define AVK_WT_ARG
+#define AVK_WT_PASS
+#endif
+
+/* The wave's LDS, in words: a fixed head, then the region's sequence table, then the working area — what is left of the launch's LDS:
+ *   phasing search:    free node slots [pool] | free wavefront blocks [blocks] | nodes [pool][W_NODE_W] | wavefront blocks [blocks][W_BLK_W]
+ *   genotype searches: the optima's haplotype states [optima][8] | one queue of W_QB_W words per search
+ *   metrics:           one alignment scratch per lane that aligns */
+enum {
+    WO_VW0 = 0,    /* [16] call slot: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 */
+    WO_VW1 = 16,   /* [16] alt_ed | raw_space << 8 */
+    WO_A1LO = 32,  /* [16] allele1, 2 bits per base: bases 0-15 */
+    WO_A1HI = 48,  /* [16] bases 16-31 */
+    WO_ORD = 64,   /* [16] search depth d: slot of its call | sync point << 8 (order_variants, query_optimizer.rs:372-381) */
+    WO_ORDV = 80,  /* [16] search depth d: the call's slot word (as WO_VW0) */
+    WO_SEL = 96,   /* [16] the round's entries: node | depth << 8 */
+    WO_RES = 112,  /* [16][4] the round's results: child 0, child 1 (node | cost << 8 | has wavefront << 24 | inexact << 25), kind */
+    WO_OPT = 176,  /* [64] nodes of the tied optima (| has wavefront << 8), in the order the reference finds them */
+    WO_FILT = 240, /* [12][2][2] per-type alignments of the metrics phase: x | z << 16 */
+    WO_CNT = 288,  /* [0] free wavefront blocks */
+    WO_META = 296, /* [NSEQ] sequence s: length | failed_ed << 16; then the sequences, W1 words each; then the working area */
+};
 
 struct WideArgs {
     u32 lds_words; /* LDS words per wave of this launch */
@@ -93,6 +124,7 @@ struct WCtx {
     u32 *wfp;  /* this lane's wavefront rows */
     u32 W1, L, T, Q, N, qbase;
     u32 wfcap, wfcap_c;
+    u32 jw0;   /* the slot word of the call this lane's haplotype step applies */
 #ifdef AVK_LANE_SLOW_TILES
     mutable u32 n_pops, n_diag, n_words;
 #endif
@@ -103,13 +135,16 @@ struct WCtx {
     AVK_DEV_M u32 *wf_row(u32, u32 row) const { return wfp + row; }
     AVK_DEV_M u32 vw0_at(u32 slot) const { return lds[WO_VW0 + slot]; }
     AVK_DEV_M u32 vw1_at(u32 slot) const { return lds[WO_VW1 + slot]; }
+    AVK_DEV_M u32 step_w0(u32) const { return jw0; }
     AVK_DEV_M u32 vw0_side(u32 side, u32 j) const { return lds[WO_VW0 + WMV * side + j]; }
     AVK_DEV_M u32 seq_id(u32 side, u32 mask) const { return mask == 0 ? 0u : (side ? qbase + mask : mask); } /* truth masks 1 .. 2^T - 1, then query masks */
     AVK_DEV_M u32 seq_len(u32 s) const { return meta[s] & 0xFFFFu; }
     AVK_DEV_M u32 seq_fail(u32 s) const { return meta[s] >> 16; }
 };
 
-/* a haplotype state in 4 words (every field fits: positions and lengths <= 255, skip penalties <= the region's edit bound <= 255) */
+/* A haplotype state in 4 words (every field fits: positions and lengths <= 255, skip penalties <= the region's edit bound <= 255).  Word 3 is the
+ * wavefront of a state at distance 0 (the one offset d0) AND of a state at distance 1 (its three offsets, one byte each: the usual distance of a node
+ * that is not exact); from distance 2 on the offsets are in a wavefront block, bits 24-31 of word 2 = 1 + the block. */
 AVK_DEV void hap_unpack(Hap &h, const u32 *w) {
     const u32 w0 = w[0], w1 = w[1], w2 = w[2];
     h.t_refpos = w0 & 0xFFu, h.q_refpos = (w0 >> 8) & 0xFFu, h.t_len = (w0 >> 16) & 0xFFu, h.q_len = w0 >> 24;
@@ -117,11 +152,11 @@ AVK_DEV void hap_unpack(Hap &h, const u32 *w) {
     h.t_alt = w2 & 0xFFu, h.q_alt = (w2 >> 8) & 0xFFu, h.t_nal = (w2 >> 16) & 0xFu, h.q_nal = (w2 >> 20) & 0xFu;
     h.d0 = w[3];
 }
-AVK_DEV void hap_pack(u32 *w, const Hap &h) {
+AVK_DEV void hap_pack(u32 *w, const Hap &h, u32 blk1 = 0) {
     w[0] = h.t_refpos | (h.q_refpos << 8) | (h.t_len << 16) | (h.q_len << 24);
     w[1] = h.t_skip | (h.q_skip << 8) | (h.nskip << 16) | (h.ed << 24);
-    w[2] = h.t_alt | (h.q_alt << 8) | (h.t_nal << 16) | (h.q_nal << 20);
-    w[3] = h.d0;
+    w[2] = h.t_alt | (h.q_alt << 8) | (h.t_nal << 16) | (h.q_nal << 20) | (blk1 << 24);
+    if (h.ed == 0) w[3] = h.d0; /* (distance 1: the aligner wrote its front there) */
 }
 
 /* FULL(side, mask): the calls of the mask applied in the side's order; a call that starts before the end of the previous applied one is dropped and
@@ -169,7 +204,10 @@ enum {
     QF_INEXACT = 1u << 17, /* the node's own cost is a lower bound (a wavefront past W_ED_MAX): it cannot be expanded here */
     QF_C0X = 1u << 18,     /* child 0 / the final cost is inexact */
     QF_C1X = 1u << 19,
+    QF_WF = 1u << 20,      /* a haplotype state of the node has a wavefront block */
 };
+/* c0 / c1 and the round's result words: node | cost << 8 | has wavefront << 24 | inexact << 25 */
+enum { CH_WF = 1u << 24, CH_X = 1u << 25 };
 /* entry i + 1 becomes entry i (rows that hold nothing are left alone: qn is wave-uniform) */
 AVK_DEV void q_pop_front(WQ &q, u32 &qn) {
     const u32 lane = (u32)wv_lane();
@@ -211,11 +249,11 @@ AVK_DEV void q_insert(WQ &q, u32 &qn, u32 key, u32 info) {
 
 /* ---- optimize_gt_alleles for one haplotype, one search per lane (exact_gt_optimizer.rs:108-357; phaseB of avk_lane.inl with the nodes' states stored
  * instead of replayed).  The aligner of an ExactMatchNode has max_edit_distance 0 (:380): a live node is exact, its wavefront the end of its
- * shorter sequence.  Entry i of the lane's queue = words (4 i .. 4 i + 3) x 64 + lane of `qb`: key, then the state's first three words.
+ * shorter sequence.  Entry i of the search's queue = words 4 i .. 4 i + 3 of `qb`: key, then the state's first three words.
  * key = errors << 26 | (31 - (depth - errors)) << 21 | id  (Reverse(errors), set - errors, Reverse(id); :452-458). */
 AVK_DEV u32 keyB(u32 errors, u32 depth, u32 id) { return (errors << 26) | ((31u - (depth - errors)) << 21) | id; }
 AVK_DEV bool hapB_step(const WCtx &c, Hap &h, u32 slot, u32 sync, bool alt) {
-    const bool ok = lane::hap_step(c, h, slot < WMV, true, slot, alt ? L_ALT : L_REF, sync);
+    const bool ok = lane::hap_step(c, h, slot < WMV, true, slot, alt ? L_ALT : L_REF, sync); /* (c.jw0 is the call's slot word) */
     const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
     h.d0 += lane::match_run_same(c, st, h.t_len, sq, h.q_len, h.d0);
     const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
@@ -225,13 +263,13 @@ AVK_DEV int pushB(u32 *qb, u32 &qn, u32 key, const Hap &h) {
     if (qn >= (u32)W_QB) return WD_DEFER;
     u32 w[4];
     hap_pack(w, h);
-    u32 *e = qb + 4u * qn * 64u;
-    e[0] = key, e[64] = w[0], e[128] = w[1], e[192] = w[2];
+    u32 *e = qb + 4u * qn;
+    e[0] = key, e[1] = w[0], e[2] = w[1], e[3] = w[2];
     qn += 1;
     return 0;
 }
 /* returns the number of flips and the final alleles, WD_DEFER, or -100 - status */
-AVK_DEV int phaseB(const WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
+AVK_DEV int phaseB(WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
     u32 qn = 0;
     {
         Hap root;
@@ -242,15 +280,15 @@ AVK_DEV int phaseB(const WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &
     while (qn > 0) {
         u32 best = 0xFFFFFFFFu, bi = 0;
         for (u32 i = 0; i < qn; ++i) {
-            const u32 k = qb[4u * i * 64u];
+            const u32 k = qb[4u * i];
             if (k < best) best = k, bi = i;
         }
         Hap h;
         {
-            u32 *e = qb + 4u * bi * 64u, *l = qb + 4u * (qn - 1) * 64u;
-            const u32 w[4] = {e[64], e[128], e[192], 0u};
+            u32 *e = qb + 4u * bi, *l = qb + 4u * (qn - 1);
+            const u32 w[4] = {e[1], e[2], e[3], 0u};
             hap_unpack(h, w);
-            e[0] = l[0], e[64] = l[64], e[128] = l[128], e[192] = l[192];
+            e[0] = l[0], e[1] = l[1], e[2] = l[2], e[3] = l[3];
             qn -= 1;
         }
         const u32 errors = best >> 26, id = best & 0x1FFFFFu;
@@ -273,6 +311,7 @@ AVK_DEV int phaseB(const WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &
             af_counts = 0;
         }
         const u32 o = c.lds[WO_ORD + depth], slot = o & 0xFFu, sync = o >> 8;
+        c.jw0 = c.lds[WO_ORDV + depth];
         const bool cur_alt = (((slot < WMV ? in_t : in_q) >> (slot & 7u)) & 1u) != 0;
         if (!cur_alt) { /* :257-273 */
             if (hapB_step(c, h, slot, sync, false)) {
@@ -296,8 +335,56 @@ AVK_DEV int phaseB(const WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &
 }
 
 /* ---- one region ---------------------------------------------------------------------------------------------------------------------------- */
+/* DWFALite::update (and finalize, `fin`) of the haplotype state H, read from srcp and about to be written to dstp (the same place when a finished node is
+ * finalised).  Where the wavefront lives depends on the distance: at 0 it is H.d0 and the state is first advanced without memory (most stay at 0); at 1
+ * its three offsets are the state's fourth word, the aligner works on dstp[3]; from 2 on it takes a block of the pool (the parent's is copied; a state
+ * updated in place keeps its own).  db1 = 1 + the block of the result (0: none).  Returns 0, or nonzero when the state could not be brought up to date
+ * (front of W_ED_MAX full, or no block left): the distance is then at least H.ed + more (more: 0 or 1). */
+AVK_DEV int hap_advance(const WCtx &c, u32 *blocks, u32 *wfree, Hap &H, const u32 *srcp, u32 *dstp, bool fin, u32 &db1, u32 &more) {
+    WCtx cj = c;
+    int rr = 0;
+    db1 = 0;
+    more = 0;
+    const u32 sb1 = H.ed >= 2 ? (srcp[2] >> 24) : 0u;
+    if (H.ed == 0) {
+        rr = lane::hap_update(cj, H, 0, 0u); /* 0, or LS_PARTIAL: a mismatch with both sequences going on */
+        if (rr == 0 && fin) rr = lane::hap_finalize(cj, H, 0, 0u);
+        if (rr == 0) return 0;
+    }
+    if (H.ed <= 1) { /* the front fits the state's fourth word */
+        if (H.ed == 1 && dstp != srcp) dstp[3] = srcp[3];
+        cj.wfp = dstp + 3;
+        cj.wfcap = 4;
+        rr = lane::hap_update(cj, H, 0);
+        if (!rr && fin) rr = lane::hap_finalize(cj, H, 0);
+        if (rr == 0) return 0;
+        /* the front of distance 1 is extended as far as it goes and touches no end: distance 2 and more */
+    }
+    if (dstp == srcp && sb1) db1 = sb1;
+    else {
+        const u32 old = avk_wg_add(c.lds + WO_CNT, 0xFFFFFFFFu);
+        if ((int)old <= 0) { /* no block left */
+            avk_wg_add(c.lds + WO_CNT, 1u);
+            more = H.ed <= 1 ? 1u : 0u;
+            return 1;
+        }
+        db1 = wfree[old - 1u] + 1u;
+        u32 *dp = blocks + (db1 - 1u) * W_BLK_W;
+        if (sb1) {
+            const u32 *sp = blocks + (sb1 - 1u) * W_BLK_W;
+            for (u32 k = 0; k < (2 * H.ed + 1 + 3) >> 2; ++k) dp[k] = sp[k];
+        } else dp[0] = dstp[3];
+    }
+    cj.wfp = blocks + (db1 - 1u) * W_BLK_W;
+    cj.wfcap = c.wfcap;
+    rr = lane::hap_update(cj, H, 0);
+    if (!rr && fin) rr = lane::hap_finalize(cj, H, 0);
+    more = rr ? 1u : 0u; /* the front at H.ed is full and touches no end: the distance is more */
+    return rr;
+}
+
 /* returns AVK_ST_* (>= 0) or WD_DEFER */
-AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *lds, lane::LaneOut &out) {
+AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *lds, u64 *part, lane::LaneOut &out AVK_WT_ARG) {
     const u32 lane = (u32)wv_lane();
     const u64 below = lane ? (~0ull >> (64u - lane)) : 0ull;
     const AvkDevRegion reg = a.regions[r];
@@ -312,14 +399,17 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
     c.L = L, c.T = T, c.Q = Q, c.N = N;
     c.W1 = ((L + grow + 15u) >> 4) + 1u;
     c.qbase = (1u << T) - 1u;
+    c.jw0 = 0;
     const u32 nseq = (1u << T) + (1u << Q) - 1u;
     c.meta = lds + WO_META;
     c.seq = c.meta + nseq;
     u32 *const dyn = c.seq + nseq * c.W1;
-    if ((u64)WO_META + (u64)nseq * (c.W1 + 1u) + (u64)W_DYN_MIN > (u64)wa.lds_words) return AVK_WDEFER(3);
-    const u32 dyn_words = wa.lds_words - ((u32)WO_META + nseq * (c.W1 + 1u));
+    const u64 fixed_words = (u64)WO_META + (u64)nseq * (c.W1 + 1u);
+    if (fixed_words + (u64)W_NBLK_MIN * (W_BLK_W + 1u) + (u64)W_POOL_MIN * (W_NODE_W + 1u) > (u64)wa.lds_words) return AVK_WDEFER(3);
+    const u32 dyn_words = wa.lds_words - (u32)fixed_words;
     c.wfcap = 2 * W_ED_MAX + 2;
-    c.wfcap_c = 4 * (W_SCR - 1);
+    const u32 scr_w = (2 * ed_bound + 3 + 3) >> 2; /* words of an alignment scratch of the metrics phase: no two strings of the region are further apart than the bound */
+    c.wfcap_c = 4 * scr_w;
     c.wfp = dyn;
 
     /* ---- the region's tables */
@@ -371,6 +461,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
             if (lane < N) {
                 const AvkOrdVar o = bo[lane];
                 lds[WO_ORD + lane] = (o.vi < T ? o.vi : (u32)WMV + o.vi - T) | (o.sync << 8);
+                lds[WO_ORDV + lane] = (o.rel_pos & 0xFFu) | ((o.a0_len & 0xFFu) << 8) | ((o.a1_len & 0xFFu) << 16) | ((o.type_zyg & 0xFu) << 24) | (((o.type_zyg >> 8) & 7u) << 28);
             }
         }
         if (wv_ballot(bad) != 0) return AVK_WDEFER(5);
@@ -380,20 +471,41 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         const u32 side = s > c.qbase ? 1u : 0u;
         build_full(c, side, side ? s - c.qbase : s);
     }
-    wv_sync();
 
+    AVK_WT_MARK(0)
     /* ---- phase A: optimize_sequences */
-    const u32 pool_n = dyn_words / (u32)W_NODE_W < (u32)W_POOL_MAX ? dyn_words / (u32)W_NODE_W : (u32)W_POOL_MAX;
-    u32 *const nodes = dyn;
+    /* seven tenths of the working area for nodes (at most W_POOL_MAX), the rest for wavefront blocks */
+    const u32 pool_want = (dyn_words * 7u / 10u) / (W_NODE_W + 1u);
+    const u32 pool_n = pool_want < (u32)W_POOL_MAX ? pool_want : (u32)W_POOL_MAX;
+    const u32 blk_room = (dyn_words - pool_n * (W_NODE_W + 1u)) / (W_BLK_W + 1u);
+    const u32 n_blk = blk_room < (u32)W_NBLK_MAX ? blk_room : (u32)W_NBLK_MAX;
+    u32 *const nfree_list = dyn, *const wfree = dyn + pool_n, *const nodes = wfree + n_blk, *const blocks = nodes + pool_n * W_NODE_W;
     u32 nfree = pool_n - 1; /* node 0 is the root */
-    for (u32 k = lane; k < nfree; k += 64) lds[WO_FREE + k] = pool_n - 1 - k; /* (the stack's top is the lowest slot) */
-    for (u32 k = lane; k < (u32)W_NODE_W; k += 64) nodes[k] = 0; /* the root: two empty haplotypes */
+    for (u32 k = lane; k < nfree; k += 64) nfree_list[k] = pool_n - 1 - k; /* (the stack's top is the lowest slot) */
+    for (u32 k = lane; k < n_blk; k += 64) wfree[k] = k;
+    if (lane < (u32)W_NODE_W) nodes[lane] = 0; /* the root: two empty haplotypes */
+    if (lane == 0) lds[WO_CNT] = n_blk;
     WQ q;
 #pragma unroll
     for (int rr = 0; rr < W_QR; ++rr) q.key[rr] = 0, q.info[rr] = 0, q.c0[rr] = 0, q.c1[rr] = 0; /* entry 0: the root (cost 0, id 0, node 0, depth 0) */
     u32 qn = 1, next_id = 1, best = 0xFFFFFFFFu, nbest = 0;
     u32 rbucket = 0; /* lane d: nodes of depth d looked at (the per-depth quota, :222-225) */
     const u32 max_branch = a.max_branch_factor;
+    /* a node goes back to the pool — with the wavefront blocks of its states, when it has any (rare: the flag spares the look) */
+    auto free_node = [&](u32 slot_wf) {
+        if (lane == 0) {
+            const u32 slot = slot_wf & 0xFFu;
+            nfree_list[nfree] = slot;
+            if (slot_wf & CH_WF) {
+                u32 cnt = lds[WO_CNT];
+                const u32 b0 = nodes[slot * W_NODE_W + 2] >> 24, b1 = nodes[slot * W_NODE_W + 6] >> 24;
+                if (b0) wfree[cnt++] = b0 - 1u;
+                if (b1) wfree[cnt++] = b1 - 1u;
+                lds[WO_CNT] = cnt;
+            }
+        }
+        nfree += 1;
+    };
     for (;;) {
         bool need_round = false;
         while (qn > 0) {
@@ -403,17 +515,13 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
                 qn = 0;
                 break;
             }
-            const u32 depth = (info0 >> 8) & 31u, node0 = info0 & 0xFFu;
+            const u32 depth = (info0 >> 8) & 31u, node0 = (info0 & 0xFFu) | ((info0 & QF_WF) ? (u32)CH_WF : 0u);
             if (wv_readlane(rbucket, depth) >= max_branch) { /* :222: dropped — with what was made of it ahead of its turn */
-                if (lane == 0) {
-                    u32 nf = nfree;
-                    lds[WO_FREE + nf++] = node0;
-                    if ((info0 & QF_EXP) && !(info0 & QF_FINAL)) {
-                        lds[WO_FREE + nf++] = c0 & 0xFFu;
-                        if (info0 & QF_TWO) lds[WO_FREE + nf++] = c1 & 0xFFu;
-                    }
+                if ((info0 & QF_EXP) && !(info0 & QF_FINAL)) {
+                    free_node(c0);
+                    if (info0 & QF_TWO) free_node(c1);
                 }
-                nfree += 1 + (((info0 & QF_EXP) && !(info0 & QF_FINAL)) ? ((info0 & QF_TWO) ? 2u : 1u) : 0u);
+                free_node((info0 & QF_FINAL) && (info0 & QF_EXP) ? (c0 & (0xFFu | CH_WF)) : node0);
                 q_pop_front(q, qn);
                 continue;
             }
@@ -423,25 +531,24 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
                 break;
             }
             if (lane == depth) rbucket += 1;
+            AVK_WT_COUNT(9, 1);
             q_pop_front(q, qn);
             if (info0 & QF_FINAL) { /* :227-247 */
-                if (info0 & QF_C0X) return AVK_WDEFER(7);
-                const u32 fc = c0 >> 8;
+                if (c0 & CH_X) return AVK_WDEFER(7);
+                const u32 fc = (c0 >> 8) & 0xFFFFu;
                 if (fc < best) {
-                    if (lane == 0)
-                        for (u32 k = 0; k < nbest; ++k) lds[WO_FREE + nfree + k] = lds[WO_OPT + k];
-                    nfree += nbest;
+                    for (u32 k = 0; k < nbest; ++k) {
+                        const u32 o = wv_uni(lds[WO_OPT + k]);
+                        free_node((o & 0xFFu) | ((o >> 8) ? (u32)CH_WF : 0u));
+                    }
                     best = fc;
                     nbest = 0;
                 }
                 if (fc == best) {
                     if (nbest >= (u32)W_OPTCAP) return AVK_WDEFER(8);
-                    if (lane == 0) lds[WO_OPT + nbest] = node0;
+                    if (lane == 0) lds[WO_OPT + nbest] = (c0 & 0xFFu) | ((c0 & CH_WF) ? 0x100u : 0u);
                     nbest += 1;
-                } else {
-                    if (lane == 0) lds[WO_FREE + nfree] = node0;
-                    nfree += 1;
-                }
+                } else free_node(c0);
                 continue;
             }
             /* the children, in the reference's order: (REF|ALT) then (ALT|REF) with new ids, or the moved node with its own */
@@ -450,14 +557,12 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
             for (u32 k = 0; k < n_child; ++k) {
                 const u32 ch = k ? c1 : c0;
                 const u32 id = (info0 & QF_TWO) ? next_id++ : (key0 & 0xFFFFu);
-                const u32 ccost = ch >> 8;
-                if (ccost > 0xFFFFu) return AVK_WDEFER(10);
-                q_insert(q, qn, (ccost << 16) | id, (ch & 0xFFu) | ((depth + 1u) << 8) | ((info0 & (k ? QF_C1X : QF_C0X)) ? (u32)QF_INEXACT : 0u));
+                q_insert(q, qn, (((ch >> 8) & 0xFFFFu) << 16) | id, (ch & 0xFFu) | ((depth + 1u) << 8) | ((ch & CH_X) ? (u32)QF_INEXACT : 0u) | ((ch & CH_WF) ? (u32)QF_WF : 0u));
             }
-            if (lane == 0) lds[WO_FREE + nfree] = node0;
-            nfree += 1;
+            free_node(node0);
             if (next_id > 60000u) return AVK_WDEFER(11);
         }
+        AVK_WT_MARK(2)
         if (!need_round) break;
 
         /* ---- a round: the first entries that have no expansion yet, all at once */
@@ -470,21 +575,24 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         K = K < (u32)W_K ? K : (u32)W_K;
         K = K < nfree / 2 ? K : nfree / 2;
         if (K == 0) return AVK_WDEFER(12); /* the pool is exhausted */
+        AVK_WT_COUNT(8, 1);
+        AVK_WT_COUNT(10, K);
         const u32 rank = (u32)avk_popc64(cm & below);
         const bool sel = cand && rank < K;
-        if (sel) lds[WO_SEL + rank] = q.info[0] & 0x1FFFu;
+        if (sel) lds[WO_SEL + rank] = q.info[0] & (0x1FFFu | QF_WF);
         wv_sync();
         const u32 e = lane >> 2, cc = (lane >> 1) & 1u, hh = lane & 1u;
         const bool act = e < K;
         const u32 sinfo = act ? lds[WO_SEL + e] : 0u;
-        const u32 ns = sinfo & 0xFFu, d = sinfo >> 8;
+        const u32 ns = sinfo & 0xFFu, d = (sinfo >> 8) & 31u;
         const bool fin = act && d == N;
-        u32 slot = 0, sync = 0, zyg = 0;
+        u32 slot = 0, sync = 0, zyg = 0, jw0 = 0;
         if (act && !fin) {
             const u32 o = lds[WO_ORD + d];
+            jw0 = lds[WO_ORDV + d];
             slot = o & 0xFFu;
             sync = o >> 8;
-            zyg = lds[WO_VW0 + slot] >> 28;
+            zyg = jw0 >> 28;
         }
         const bool is_truth = slot < (u32)WMV;
         const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
@@ -495,43 +603,40 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         else if (het) allele = ((zyg == AVK_ZYG_PHASED_HET01) == (hh == 1)) ? L_ALT : L_REF; /* 0|1: REF on haplotype 1, ALT on haplotype 2 */
         const bool wants = job && !fin && hh == 0;
         const u64 am = wv_ballot(wants);
-        u32 cnode = wants ? lds[WO_FREE + nfree - 1u - (u32)avk_popc64(am & below)] : 0u;
+        u32 cnode = wants ? nfree_list[nfree - 1u - (u32)avk_popc64(am & below)] : 0u;
         cnode = wv_shfl(cnode, (int)(lane & ~1u));
         nfree -= (u32)avk_popc64(am);
         const u32 dnode = fin ? ns : cnode;
-        u32 mycost = 0, myx = 0;
+        u32 mycost = 0, myflags = 0;
         if (job) {
-            const u32 *srcp = nodes + ns * W_NODE_W + hh * W_HAP_W;
-            u32 *dstp = nodes + dnode * W_NODE_W + hh * W_HAP_W;
+            const u32 *srcp = nodes + ns * W_NODE_W + 4 * hh;
+            u32 *dstp = nodes + dnode * W_NODE_W + 4 * hh;
             Hap H;
             hap_unpack(H, srcp);
-            if (!fin && H.ed)
-                for (u32 k = 0; k < (2 * H.ed + 1 + 3) >> 2; ++k) dstp[4 + k] = srcp[4 + k];
             WCtx cj = c;
-            cj.wfp = dstp + 4;
-            int rr;
-            if (fin) { /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
-                lane::hap_step(cj, H, true, false, 0, L_REF, L);
-                rr = lane::hap_update(cj, H, 0);
-                if (!rr) rr = lane::hap_finalize(cj, H, 0);
-            } else {
-                lane::hap_step(cj, H, is_truth, true, slot, allele, sync);
-                rr = lane::hap_update(cj, H, 0);
-            }
-            myx = rr ? 1u : 0u; /* the wavefront is full: the distance is more than it says */
-            mycost = H.t_skip + H.q_skip + H.ed + myx;
-            hap_pack(dstp, H);
+            cj.jw0 = jw0;
+            if (fin) lane::hap_step(cj, H, true, false, 0, L_REF, L); /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
+            else lane::hap_step(cj, H, is_truth, true, slot, allele, sync);
+            u32 db1 = 0, more = 0;
+            const int rr = hap_advance(cj, blocks, wfree, H, srcp, dstp, fin, db1, more);
+            mycost = H.t_skip + H.q_skip + H.ed + more; /* (rr: a lower bound) */
+            myflags = (rr ? (u32)CH_X : 0u) | (db1 ? (u32)CH_WF : 0u);
+            hap_pack(dstp, H, db1);
         }
-        const u32 ocost = wv_shfl(mycost, (int)(lane ^ 1u)), ox = wv_shfl(myx, (int)(lane ^ 1u));
-        if (job && hh == 0) lds[WO_RES + 4 * e + cc] = dnode | ((mycost + ocost) << 8) | ((myx | ox) ? 0x80000000u : 0u);
+        const u32 ocost = wv_shfl(mycost, (int)(lane ^ 1u)), oflags = wv_shfl(myflags, (int)(lane ^ 1u));
+        if (job && hh == 0) {
+            const u32 cst = mycost + ocost;
+            lds[WO_RES + 4 * e + cc] = dnode | ((cst < 0xFFFFu ? cst : 0xFFFFu) << 8) | myflags | oflags | (cst >= 0xFFFFu ? (u32)CH_X : 0u);
+        }
         if (act && cc == 0 && hh == 0) lds[WO_RES + 4 * e + 2] = (fin ? (u32)QF_FINAL : 0u) | (two ? (u32)QF_TWO : 0u);
         wv_sync();
         if (sel) {
             const u32 r0 = lds[WO_RES + 4 * rank], r1 = lds[WO_RES + 4 * rank + 1], kind = lds[WO_RES + 4 * rank + 2];
-            q.c0[0] = r0 & 0x7FFFFFFFu;
-            q.c1[0] = (kind & QF_TWO) ? (r1 & 0x7FFFFFFFu) : 0u;
-            q.info[0] |= (u32)QF_EXP | kind | ((r0 >> 31) ? (u32)QF_C0X : 0u) | (((kind & QF_TWO) && (r1 >> 31)) ? (u32)QF_C1X : 0u);
+            q.c0[0] = r0;
+            q.c1[0] = (kind & QF_TWO) ? r1 : 0u;
+            q.info[0] |= (u32)QF_EXP | kind;
         }
+        AVK_WT_MARK(1)
     }
     if (nbest == 0) return AVK_ST_NO_RESULTS; /* :331 */
     out.n_opt = nbest;
@@ -540,26 +645,44 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         return AVK_ST_OK;
     }
 
-    /* ---- phase B for every tied optimum (waffle_solver.rs:169-261), all searches at once; the first optimum with the fewest flips wins (:264-265) */
+    /* ---- phase B for every tied optimum (waffle_solver.rs:169-261), as many searches at once as the working area holds queues; the first optimum with
+     * the fewest flips wins (:264-265) */
     wv_sync();
-    for (u32 k = lane; k < nbest * 8u; k += 64) { /* the optima's states leave the pool: the searches' rows take its place */
-        const u32 o = k >> 3, w = k & 7u;
-        lds[WO_OPTH + k] = nodes[lds[WO_OPT + o] * W_NODE_W + (w >> 2) * W_HAP_W + (w & 3u)];
+    u32 *const opth = dyn; /* the optima's haplotype states leave the pool (through registers: source and destination overlap) */
+    {
+        u32 keep[8];
+#pragma unroll
+        for (u32 i = 0; i < 8; ++i) {
+            const u32 k = lane + 64u * i;
+            keep[i] = k < nbest * 8u ? nodes[(lds[WO_OPT + (k >> 3)] & 0xFFu) * W_NODE_W + (k & 7u)] : 0u;
+        }
+        wv_sync();
+#pragma unroll
+        for (u32 i = 0; i < 8; ++i) {
+            const u32 k = lane + 64u * i;
+            if (k < nbest * 8u) opth[k] = keep[i];
+        }
     }
     wv_sync();
-    /* 32 optima (64 searches) at a time: the reference goes through the optima in order and stops at the first one without flips */
+    u32 *const qrows = dyn + nbest * 8u;
+    const u32 q_room = (dyn_words - nbest * 8u) / (2u * (u32)W_QB_W);
+    const u32 chunk = q_room < 32u ? q_room : 32u; /* optima per pass */
+    if (chunk == 0) return AVK_WDEFER(13);
     u32 win = 0, best_total = 0xFFFFFFFFu, o_t0 = 0, o_q0 = 0, o_t1 = 0, o_q1 = 0;
-    for (u32 kb = 0; kb < nbest && best_total != 0; kb += 32) {
-        const u32 nk = nbest - kb < 32u ? nbest - kb : 32u;
+    for (u32 kb = 0; kb < nbest && best_total != 0; kb += chunk) { /* the reference goes through the optima in order and stops at the first one without flips */
+        const u32 nk = nbest - kb < chunk ? nbest - kb : chunk;
         int eB = 0;
         u32 rt = 0, rq = 0;
         if (lane < 2 * nk) {
             Hap h;
-            hap_unpack(h, lds + WO_OPTH + 8 * kb + 4 * lane);
+            hap_unpack(h, opth + 8 * kb + 4 * lane);
             if (h.ed == 0 && h.nskip == 0) { /* truth == query with every ALT incorporated: the zero-flip path wins (exact_gt_optimizer.rs:169-192) */
                 rt = h.t_alt;
                 rq = h.q_alt;
-            } else eB = phaseB(c, dyn + lane, h.t_alt, h.q_alt, rt, rq);
+            } else {
+                WCtx cb = c;
+                eB = phaseB(cb, qrows + lane * (u32)W_QB_W, h.t_alt, h.q_alt, rt, rq);
+            }
         }
         for (u32 k = 0; k < nk; ++k) {
             const int e0 = (int)wv_readlane((u32)eB, 2 * k), e1 = (int)wv_readlane((u32)eB, 2 * k + 1);
@@ -577,9 +700,10 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         }
         wv_sync();
     }
+    AVK_WT_MARK(3)
     Hap wn[2];
-    hap_unpack(wn[0], lds + WO_OPTH + 8 * win);
-    hap_unpack(wn[1], lds + WO_OPTH + 8 * win + 4);
+    hap_unpack(wn[0], opth + 8 * win);
+    hap_unpack(wn[1], opth + 8 * win + 4);
     out.ed1 = wn[0].ed;
     out.ed2 = wn[1].ed;
 
@@ -609,13 +733,16 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
     if (bad) return (int)bad;
     const u32 ex_lo = (u32)wv_ballot(ex & 1u), ex_hi = (u32)wv_ballot(ex & 2u), ob_lo = (u32)wv_ballot(ob & 1u), ob_hi = (u32)wv_ballot(ob & 2u);
 
-    /* add_basepair_stats (:335-449): per haplotype X = 2 ed(ref, truth), Y = 2 ed(ref, query), Z = 2 ed(truth, query); lane (haplotype, side) */
+    /* add_basepair_stats (:335-449): per haplotype X = 2 ed(ref, truth), Y = 2 ed(ref, query), Z = 2 ed(truth, query); lane (haplotype, side).
+     * Every lane that aligns gets a scratch of its own in the working area, by its rank among the lanes that do. */
     const u32 SUPMASK = (1u << AVK_VT_SNV) | (1u << AVK_VT_INSERTION) | (1u << AVK_VT_DELETION) | (1u << AVK_VT_INDEL) | (1u << AVK_VT_TR_CONTRACTION) |
                         (1u << AVK_VT_TR_EXPANSION) | (1u << AVK_VT_SV_DELETION) | (1u << AVK_VT_SV_INSERTION);
     out.present = types | SUPMASK;
     wv_sync();
+    const u32 scr_stride = scr_w | 1u, scr_slots = dyn_words / scr_stride;
+    if (scr_slots < 4) return AVK_WDEFER(15);
     WCtx cs = c;
-    cs.wfp = dyn + lane * (u32)W_SCR;
+    cs.wfp = dyn + (lane & 3u) * scr_stride;
     int e_ref = 0;
     if (lane < 4) {
         const Hap &h = (lane >> 1) ? wn[1] : wn[0];
@@ -632,31 +759,35 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         const u32 vt = lane >> 2, side = (lane >> 1) & 1u, hh = lane & 1u;
         int x = 0, z = 0;
         bool store = false;
+        u32 mask_g = 0;
+        const u32 cnt = side ? Q : T;
         if (vt < (u32)AVK_N_VARIANT_TYPES && ((types & SUPMASK) >> vt) & 1u) {
-            u32 mask_g = 0;
-            const u32 cnt = side ? Q : T;
             for (u32 j = 0; j < cnt; ++j)
                 if (((lds[WO_VW0 + WMV * side + j] >> 24) & 0xFu) == vt) mask_g |= 1u << j;
-            if (mask_g != 0 && mask_g != (1u << cnt) - 1u) { /* else: none of the type, or nothing but the type: no filtering */
-                store = true;
-                const Hap &h = hh ? wn[1] : wn[0];
-                const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
-                const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
-                const u32 alt = side ? h.q_alt : h.t_alt, m = alt & mask_g;
-                x = 0, z = (int)((side ? Xh : Yh) / 2); /* nothing left of the side: it is the reference window */
-                if (m && m == alt) {                    /* nothing filtered away on this haplotype: the side as it is */
-                    x = (int)((side ? Yh : Xh) / 2);
-                    z = (int)h.ed;
-                } else if (m) {
-                    const u32 sf = c.seq_id(side, m), fl = c.seq_len(sf);
-                    x = lane::ed_to_ref(cs, side, m, fl);
-                    /* equal haplotypes with everything applied, one call filtered away: the other side's string is the filtered string plus that call */
-                    const u32 gone = alt ^ m;
-                    z = -1;
-                    if (h.ed == 0 && h.nskip == 0 && (gone & (gone - 1)) == 0 && c.seq_fail(side ? sq : st) == 0 && c.seq_fail(sf) == 0)
-                        z = lane::one_call_distance(cs, WMV * side + (u32)__builtin_ctz(gone));
-                    if (z < 0) z = side ? lane::wfa_ed(cs, st, h.t_len, sf, fl) : lane::wfa_ed(cs, sf, fl, sq, h.q_len);
-                }
+            store = mask_g != 0 && mask_g != (1u << cnt) - 1u; /* else: none of the type, or nothing but the type: no filtering */
+        }
+        const u64 sm = wv_ballot(store);
+        if ((u32)avk_popc64(sm) > scr_slots) return AVK_WDEFER(16);
+        wv_sync();
+        if (store) {
+            cs.wfp = dyn + (u32)avk_popc64(sm & below) * scr_stride;
+            const Hap &h = hh ? wn[1] : wn[0];
+            const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
+            const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
+            const u32 alt = side ? h.q_alt : h.t_alt, m = alt & mask_g;
+            x = 0, z = (int)((side ? Xh : Yh) / 2); /* nothing left of the side: it is the reference window */
+            if (m && m == alt) {                    /* nothing filtered away on this haplotype: the side as it is */
+                x = (int)((side ? Yh : Xh) / 2);
+                z = (int)h.ed;
+            } else if (m) {
+                const u32 sf = c.seq_id(side, m), fl = c.seq_len(sf);
+                x = lane::ed_to_ref(cs, side, m, fl);
+                /* equal haplotypes with everything applied, one call filtered away: the other side's string is the filtered string plus that call */
+                const u32 gone = alt ^ m;
+                z = -1;
+                if (h.ed == 0 && h.nskip == 0 && (gone & (gone - 1)) == 0 && c.seq_fail(side ? sq : st) == 0 && c.seq_fail(sf) == 0)
+                    z = lane::one_call_distance(cs, WMV * side + (u32)__builtin_ctz(gone));
+                if (z < 0) z = side ? lane::wfa_ed(cs, st, h.t_len, sf, fl) : lane::wfa_ed(cs, sf, fl, sq, h.q_len);
             }
         }
         if (wv_ballot(store && (x < 0 || z < 0)) != 0) return AVK_WDEFER(16);
@@ -664,6 +795,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
     }
     wv_sync();
 
+    AVK_WT_MARK(4)
     /* ---- the metric groups, lane g = group g: the joint one and one per call type of the region */
     const u32 gmask = 1u | (types << 1);
     const bool g_on = lane < (u32)AVK_N_GROUPS && ((gmask >> lane) & 1u);
@@ -748,7 +880,8 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
     }
     const u32 rerr = wv_max_u32(l_err);
     if (rerr) return (int)rerr;
-    /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the wave's tally; the optional per-region outputs */
+    /* SummaryWriter::add_comparison_benchmark (writers/summary.rs:146-163): the region's nonzero counters (a handful of the 286) go to a partial tally, lane g
+     * its group's; the optional per-region outputs */
     u32 *gm_out = a.group_metrics ? a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS : (u32 *)0;
     if (gm_out) {
         for (u32 i = lane; i < (u32)(AVK_N_GROUPS * AVK_N_FIELDS); i += 64) gm_out[i] = 0;
@@ -760,7 +893,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         for (int i = 0; i < AVK_N_FIELDS; ++i) {
             const u32 v = G.f[i];
             if (!v) continue;
-            lds[WO_TALLY + g * AVK_N_FIELDS + i] += v;
+            avk_atomic_add_u64_global(part + g * AVK_N_FIELDS + i, v);
             if (gm_out) gm_out[g * AVK_N_FIELDS + i] = v;
         }
         if (a.bp_out) { /* compact BASEPAIR groups: the joint group, then the call types of the region in type order */
@@ -769,6 +902,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
             *(avk_u4 *)(a.bp_out + 4 * ((u64)a.bp_off[orig] + (u32)__builtin_popcount(gmask & ((1u << g) - 1u)))) = w;
         }
     }
+    AVK_WT_MARK(5)
     return AVK_ST_OK;
 }
 
@@ -779,8 +913,10 @@ template <bool LAZY> AVK_DEV void wide_worker(const AvkKernelArgs &a, const Wide
     const u32 n_work = a.n_work_dev ? wv_uni(*a.n_work_dev) : a.n_work;
     u32 n_ok = 0, n_err = 0;
     u64 *part = a.tally + (u64)(wave_id % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
-    for (u32 i = lane; i < 288u; i += 64) lds[WO_TALLY + i] = 0;
-    wv_sync();
+#ifdef AVK_WIDE_TIMING
+    WTime wt;
+    for (int k = 0; k < 16; ++k) wt.t[k] = 0;
+#endif
     for (;;) {
         u32 idx = 0xFFFFFFFFu;
         if (lane == 0) {
@@ -796,8 +932,17 @@ template <bool LAZY> AVK_DEV void wide_worker(const AvkKernelArgs &a, const Wide
         }
         lane::LaneOut out;
         out.ed1 = out.ed2 = out.n_opt = out.present = 0;
-        const int st = solve_wide(a, wa, r, lds, out);
+#ifdef AVK_WIDE_TIMING
+        const u64 t_region0 = avk_clock();
+        wt.last = t_region0;
+#endif
+        const int st = solve_wide(a, wa, r, lds, part, out AVK_WT_PASS);
         wv_sync();
+#ifdef AVK_WIDE_TIMING
+        wt.t[6] += avk_clock() - t_region0;
+        wt.t[7] += 1;
+        wt.t[11] += st == WD_DEFER ? 1u : 0u;
+#endif
         if (st == WD_DEFER) {
             if (lane == 0) {
                 const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1u);
@@ -812,24 +957,14 @@ template <bool LAZY> AVK_DEV void wide_worker(const AvkKernelArgs &a, const Wide
         }
         write_region_record(a, wv_uni(a.regions[r].orig), 0, out.ed1, out.ed2, out.n_opt, out.present);
         n_ok += 1;
-        if ((n_ok & 255u) == 0) { /* the 32-bit LDS tally moves on to the 64-bit partial tally long before a counter can wrap */
-            for (u32 i = lane; i < (u32)(AVK_N_GROUPS * AVK_N_FIELDS); i += 64) {
-                const u32 v = lds[WO_TALLY + i];
-                lds[WO_TALLY + i] = 0;
-                if (v) avk_atomic_add_u64_global(part + i, v);
-            }
-            wv_sync();
-        }
-    }
-    wv_sync();
-    for (u32 i = lane; i < (u32)(AVK_N_GROUPS * AVK_N_FIELDS); i += 64) {
-        const u32 v = lds[WO_TALLY + i];
-        if (v) avk_atomic_add_u64_global(part + i, v);
     }
     if (lane == 0) {
         if (n_ok) avk_atomic_add_u64_global(part + AVK_TALLY_SOLVED, n_ok);
         if (n_err) avk_atomic_add_u64_global(part + AVK_TALLY_ERRORS, n_err);
         if (n_ok + n_err) avk_atomic_add_u64_global(part + AVK_TALLY_WIDE_SOLVED, n_ok + n_err);
+#ifdef AVK_WIDE_TIMING
+        for (int k = 0; k < 16; ++k) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 5 + k, wt.t[k]);
+#endif
     }
 }
 

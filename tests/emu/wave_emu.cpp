@@ -191,7 +191,7 @@ void lane_kernel_main(void *p, int lane) {
 }
 
 int g_wide_kernel = 1;                 /* emu_set_wide_kernel: context option wide_kernel (avk_wide.inl ahead of the HBM-tier launches of class C and of the three-call class's hand-backs) */
-uint32_t g_wide_lds_bytes = 40 * 1024; /* context option wide_lds_bytes */
+uint32_t g_wide_lds_bytes = 16 * 1024; /* context option wide_lds_bytes */
 uint64_t g_wide_solved = 0;
 struct WideTask {
     const AvkKernelArgs *args;
