@@ -140,6 +140,14 @@ AVK_TYPES_HD uint32_t avk_head_slots(uint32_t maxv, uint32_t n_fast, uint32_t n_
  * back for its node cap is one of them, and the launch for handed-back regions starts behind that head, beside the rest of the class */
 #define AVK_HET_HEAD_MIN 4
 
+#define AVK_WIDE_ED_MAX 62u /* largest distance a search node's wavefront holds there (one byte per offset, a state names at most 2 x 62 + 2 of them) */
+/* What a region record says about whether the wave-cooperative kernel of avk_wide.inl can take the region (it looks at the alleles and the reference window
+ * itself): at most 8 calls on a side, window + growth + edit bound within a byte — every offset of its wavefronts is one — and an edit bound its search nodes hold.  A launch of the wave-per-region
+ * kernel with AvkKernelArgs::only_not_wide takes the records that fail this from the list the wide launch walks at the same time (it skips them). */
+AVK_TYPES_HD bool avk_wide_static_ok(uint32_t len, uint32_t grow, uint32_t ed_bound, uint32_t t_cnt, uint32_t q_cnt, uint32_t pre_status) {
+    return !(pre_status & 0xFFFFu) && t_cnt + q_cnt != 0 && t_cnt <= 8u && q_cnt <= 8u && (uint64_t)len + grow + ed_bound <= 255ull && ed_bound <= AVK_WIDE_ED_MAX;
+}
+
 #define AVK_CAP_BOUND_ONLY 0x80000000u /* flag in AvkTier::ed_cap: the cap is only taken by regions whose own bound is below it (avk_solver.inl) */
 /* capacities of one workspace tier */
 struct AvkTier {
@@ -226,6 +234,8 @@ struct AvkKernelArgs {
      * from the per-call decisions (avk_group_metrics_from_compact). */
     const uint32_t *bp_off;
     uint32_t *bp_out;
+    uint32_t only_not_wide; /* this launch takes only the records avk_wide_static_ok() turns down (a launch of avk_wide.inl has the others) */
+    uint32_t pad4_;
 };
 
 #endif

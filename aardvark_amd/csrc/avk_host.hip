@@ -335,7 +335,9 @@ struct avk_ctx {
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     int64_t wide_kernel = 1;                          /* regions with large searches on small windows (class C, what the three-call lane class hands back) go to the wave-cooperative kernel of avk_wide.inl first */
     int64_t wide_lds_bytes = 16 * 1024;               /* LDS of one of its waves: 1.2 KB of tables, the region's 2^T + 2^Q full-length sequences, the rest search nodes (10 words each, at most 240) and 32 wavefront blocks */
-    int64_t wide_blocks = 512;                        /* most one-wave workgroups of one of its launches */
+    int64_t wide_blocks = 512;                        /* most one-wave workgroups of its class C launch */
+    int64_t wide_lane_handbacks = 1;                  /* what the one- and two-call lane classes hand back goes through avk_wide.inl too, ahead of the LDS launch */
+    int64_t wide_lazy_blocks = 128;                   /* one-wave workgroups of its launch for what the three-call lane class hands back (a short list, its length known on the device only) */
     bool wide_attr_set = false;
     uint64_t last_wide_solved = 0;
     bool lane_attr_set = false;
@@ -359,6 +361,10 @@ struct avk_ctx {
     hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr, ev_lane_head3 = nullptr;
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
+    hipStream_t wide_stream = nullptr; /* the class C records that are not for the wide kernel (run_internal) */
+    hipStream_t tail_stream = nullptr, tail_stream2 = nullptr; /* HIGH priority: the launches for what the lanes handed back start when the chip is full of the other lane classes' waiting
+                                                                  workgroups; at the default priority theirs wait their turn among thousands (a 0.2 ms launch took 0.9) */
+    int64_t tail_priority = 1;         /* 0: those launches go behind the lane launches on the lane streams, as in round 3 */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ready = nullptr, ev_ready2 = nullptr, ev_wide = nullptr;
@@ -383,7 +389,7 @@ struct avk_dev_batch {
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr, *d_overflow4 = nullptr;
-    uint32_t *d_overflow5 = nullptr, *d_overflow6 = nullptr; /* what the launches of avk_wide.inl could not take: of class C, of the three-call lane class's hand-backs */
+    uint32_t *d_overflow5 = nullptr, *d_overflow6 = nullptr, *d_overflow7 = nullptr; /* what the launches of avk_wide.inl could not take: of class C, of the three-call lane class's hand-backs, of the other lane classes' */
     avk::WorkPlan plan;
     uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
     uint64_t fast_word_base[AVK_FAST_CLASSES] = {0}; /* first word of the class's tiles in d_fast */
@@ -449,7 +455,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 void free_batch_buffers(avk_dev_batch *db) {
     if (db->dev_packed) return; /* pooled buffers: release_pooled */
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_fast,
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_overflow7, db->d_fast,
                     db->d_bp_off, db->d_bp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -510,6 +516,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
      * of a process share queues, and a shared queue would serialise the solo launches with the bulk) */
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
+    const int prio_tail = prio_high; /* the streams of the launches that END a step (what the lanes handed back) */
     { /* the side and lane streams run at the default priority: with hardware queues of their own (GPU_MAX_HW_QUEUES >= 8) a high priority changes
        * nothing (4.94 / 4.98 ms per whole-genome step), with the runtime's default of 4 queues it costs 0.9 ms (7.0 / 7.9 ms);
        * AVK_STREAM_PRIORITY=high brings it back for experiments */
@@ -518,6 +525,9 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     }
     if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->wide_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, prio_tail) != hipSuccess ||
+        hipStreamCreateWithPriority(&ctx->tail_stream2, hipStreamNonBlocking, prio_tail) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess ||
@@ -598,6 +608,9 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->lane_stream3) (void)hipStreamDestroy(ctx->lane_stream3);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
+    if (ctx->wide_stream) (void)hipStreamDestroy(ctx->wide_stream);
+    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
+    if (ctx->tail_stream2) (void)hipStreamDestroy(ctx->tail_stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -665,6 +678,13 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "wide_blocks") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_blocks must be in [1, 4096]");
         ctx->wide_blocks = value;
+    } else if (n == "tail_priority") {
+        ctx->tail_priority = value ? 1 : 0;
+    } else if (n == "wide_lane_handbacks") {
+        ctx->wide_lane_handbacks = value ? 1 : 0;
+    } else if (n == "wide_lazy_blocks") {
+        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_lazy_blocks must be in [1, 4096]");
+        ctx->wide_lazy_blocks = value;
     } else if (n == "solo_blocks_max") {
         if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
         ctx->solo_blocks_max = value;
@@ -984,6 +1004,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow4, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow5, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow6, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow7, n + 1));
 #undef AVK_TRY
     { /* compact BASEPAIR groups: 1 + the region's call types each (none for regions that fail validation), as the device packer counts them */
         std::vector<uint32_t> bp_off(n + 1, 0);
@@ -1181,7 +1202,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                           ctx->use_packed_reference && ctx->d_ref2b;
     avk::wide::WideArgs wa;
     wa.lds_words = (uint32_t)(ctx->wide_lds_bytes / 4);
-    wa.pad = 0;
+    wa.skip_static = 0;
     if (use_wide && !ctx->wide_attr_set) {
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_wide_kernel_lazy, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -1310,7 +1331,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
-    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false, hbm_shared = false;
+    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false, hbm_shared = false, wide_x_pending = false;
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -1376,7 +1397,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
             if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
-            bool wide_c = false;
+            bool wide_c = false, wide_x = false;
             if (hbm_solo) {
                 AvkKernelArgs s = a;
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->ev_fork, 0));
@@ -1390,8 +1411,39 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     w.overflow_list = db->d_overflow5;
                     w.overflow_count = db->d_counters + 1244;
                     uint32_t wg = n_c < (uint32_t)ctx->wide_blocks ? n_c : (uint32_t)ctx->wide_blocks;
-                    hipLaunchKernelGGL(avk_wide_kernel, dim3(wg), dim3(64), (size_t)ctx->wide_lds_bytes, ctx->side_stream2, w, wa);
+                    avk::wide::WideArgs wc = wa;
+                    wc.skip_static = 1;
+                    hipLaunchKernelGGL(avk_wide_kernel, dim3(wg), dim3(64), (size_t)ctx->wide_lds_bytes, ctx->side_stream2, w, wc);
                     AVK_HIP(ctx, hipGetLastError());
+                    { /* the records of class C that are not for the wide kernel by what they say themselves (avk_wide_static_ok: a long window, many calls on a
+                       * side) start at the same time, on the HBM-tier kernel and a stream of their own: they are few and each of them is long */
+                        AvkKernelArgs x = s;
+                        x.pass_tier = 2;
+                        x.only_not_wide = 1;
+                        x.work_list = nullptr;
+                        x.n_work_dev = nullptr;
+                        x.work_base = 0;
+                        x.n_work = n_c;
+                        x.work_counter = db->d_counters + 1256;
+                        x.static_pct = 0;
+                        x.n_shards = 1;
+                        x.claim = 4;
+                        x.high_priority = 1;
+                        const uint32_t xb = hbm_solo < 32u ? hbm_solo : 32u;
+                        x.n_waves = xb * waves_per_block;
+                        x.hbm_ws = ctx->d_ws + (size_t)(n_waves + (hbm_solo_max - xb) * waves_per_block) * (size_t)ws_bytes; /* the last slices of the solo launch's share (that launch gets the others) */
+                        x.big_ws = ctx->d_big;
+                        x.big_busy = db->d_counters + 1088;
+                        x.big_slots = big_slots;
+                        x.overflow_list = nullptr;
+                        x.overflow_count = nullptr;
+                        AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
+                        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
+                        AVK_HIP(ctx, hipGetLastError());
+                        AVK_HIP(ctx, hipEventRecord(ctx->ev_wide, ctx->wide_stream));
+                        wide_x = true;
+                        if (hbm_solo > hbm_solo_max - xb) hbm_solo = hbm_solo_max - xb > 0 ? hbm_solo_max - xb : 1;
+                    }
                     wide_c = true;
                     s.work_list = db->d_overflow5;
                     s.n_work_dev = db->d_counters + 1244;
@@ -1421,6 +1473,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side_stream2));
                 hbm_solo_pending = true;
                 hbm_shared = !wide_c; /* (the records of class C are the wide launch's: the main stream's HBM launch has nothing to share) */
+                wide_x_pending = wide_x;
             }
             if (solo) {
                 AvkKernelArgs s = a;
@@ -1537,6 +1590,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         const uint32_t head3 = (db->plan.n_fast_heavy[fc] + 63u) / 64u;
                         const bool split3 = ctx->lane_split_three && head3 > 0 && head3 < la.n_tiles;
                         hipStream_t es = lstream[li]; /* where the launch for the handed-back regions goes */
+                        bool es_tail = false;
                         if (split3) {
                             avk::lane::LaneArgs hd = la;
                             hd.n_tiles = head3;
@@ -1559,6 +1613,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         /* the launch for what ALL lanes hand back waits for the lane launches only, not for the launch behind this class */
                         AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
                         ljoined[li] = true;
+                        if (ctx->tail_priority && !split3) { /* the hand-backs' launches on the high-priority stream, behind the class */
+                            es = ctx->tail_stream;
+                            es_tail = true;
+                            AVK_HIP(ctx, hipStreamWaitEvent(es, ljoin[li], 0));
+                        }
+                        (void)es_tail;
                         AvkKernelArgs e = a;
                         e.pass_tier = 2;
                         e.work_list = lists[3];
@@ -1586,7 +1646,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             w.work_counter = db->d_counters + 1248;
                             w.overflow_list = db->d_overflow6;
                             w.overflow_count = db->d_counters + 1252;
-                            hipLaunchKernelGGL(avk_wide_kernel_lazy, dim3((uint32_t)ctx->wide_blocks), dim3(64), (size_t)ctx->wide_lds_bytes, es, w, wa);
+                            hipLaunchKernelGGL(avk_wide_kernel_lazy, dim3((uint32_t)ctx->wide_lazy_blocks), dim3(64), (size_t)ctx->wide_lds_bytes, es, w, wa);
                             AVK_HIP(ctx, hipGetLastError());
                             e.work_list = db->d_overflow6;
                             e.n_work_dev = db->d_counters + 1252;
@@ -1669,8 +1729,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                  * stream, behind the lane launches, BESIDE the bulk and the HBM launch of this stream.  What overflows there (rare) goes to a
                  * list of its own, read by one more HBM launch at the very end (normally empty: 10 us). */
                 AVK_HIP(ctx, hipGetLastError());
-                const int di = lused[1] ? 1 : (lused[0] ? 0 : 2);
-                hipStream_t ds = lstream[di];
+                const int di = ctx->tail_priority ? -1 : (lused[1] ? 1 : (lused[0] ? 0 : 2));
+                hipStream_t ds = di < 0 ? ctx->tail_stream2 : lstream[di];
                 for (int li = 0; li < N_LS; ++li)
                     if (li != di && lused[li]) AVK_HIP(ctx, hipStreamWaitEvent(ds, ljoin[li], 0));
                 AvkKernelArgs d = a;
@@ -1679,6 +1739,16 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 d.work_base = 0;
                 d.n_work = 0;
                 d.work_counter = db->d_counters + 768;
+                if (use_wide && ctx->wide_lane_handbacks) { /* small windows, whatever made the lanes give up: avk_wide.inl first, the LDS launch takes what is left */
+                    AvkKernelArgs w = d;
+                    w.work_counter = db->d_counters + 1260;
+                    w.overflow_list = db->d_overflow7;
+                    w.overflow_count = db->d_counters + 1264;
+                    hipLaunchKernelGGL(avk_wide_kernel_lazy, dim3((uint32_t)ctx->wide_lazy_blocks), dim3(64), (size_t)ctx->wide_lds_bytes, ds, w, wa);
+                    AVK_HIP(ctx, hipGetLastError());
+                    d.work_list = db->d_overflow7;
+                    d.n_work_dev = db->d_counters + 1264;
+                }
                 uint32_t dblocks = bulk < (uint32_t)ctx->n_cus ? bulk : (uint32_t)ctx->n_cus; /* one workgroup per CU: the list is short */
                 d.n_waves = dblocks * waves_per_block;
                 d.overflow_list = lists[1];
@@ -1726,6 +1796,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     }
     if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
     if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
+    if (wide_x_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wide, 0));
     if (deferred_pending) { /* the lane streams (lane launches, then the handed-back regions) join here; what even the escalation could not hold */
         AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_done, 0));
         if (early_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_early, 0));

@@ -1894,6 +1894,7 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
             wv_sync();
         }
         const AvkDevRegion reg = a.regions[r];
+        if (a.only_not_wide && avk_wide_static_ok(wv_uni(reg.len), wv_uni(reg.grow), wv_uni(reg.ed_bound), wv_uni(reg.t_cnt), wv_uni(reg.q_cnt), wv_uni(reg.pre_status))) continue;
         const u32 orig = wv_uni(reg.orig); /* where the caller's batch has this region: outputs go there */
         const u32 pre = wv_uni(reg.pre_status) & 0xFFFFu;
         if (pre) {

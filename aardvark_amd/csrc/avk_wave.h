@@ -101,6 +101,10 @@ AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return __atomic_f
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_or_u32_global(uint32_t *p, uint32_t v) { __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+AVK_DEV void avk_atomic_max_u64_global(uint64_t *p, uint64_t v) {
+    uint64_t cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (cur < v && !__atomic_compare_exchange_n(p, &cur, v, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+}
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) {
     __atomic_compare_exchange_n(p, &expect, desired, false, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE);
     return expect;
@@ -207,6 +211,7 @@ AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return atomicAdd(
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return atomicAdd(p, v); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { atomicAdd((unsigned long long *)p, (unsigned long long)v); }
 AVK_DEV void avk_atomic_or_u32_global(uint32_t *p, uint32_t v) { atomicOr(p, v); }
+AVK_DEV void avk_atomic_max_u64_global(uint64_t *p, uint64_t v) { atomicMax((unsigned long long *)p, (unsigned long long)v); }
 AVK_DEV uint32_t avk_atomic_cas_u32_global(uint32_t *p, uint32_t expect, uint32_t desired) { return atomicCAS(p, expect, desired); }
 /* Many lanes adding to the counters of one LDS table, called from DIVERGENT code by whichever lanes have something to add: lanes that add the SAME value
  * to the SAME counter are combined into one atomic (the first remaining lane's pair is broadcast, the lanes that match it leave together) — a tile of the

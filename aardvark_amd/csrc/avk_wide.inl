@@ -45,9 +45,9 @@ using lane::L_ALT;
 using lane::L_REF;
 
 enum { WMV = 8, WNS = 16 };  /* call slots per side, per region: slot = WMV * side + index on the side */
-enum { W_ED_MAX = 16 };      /* largest distance a search node's wavefront holds (2 ed + 1 offsets, one byte each) */
-enum { W_BLK_W = 9 };        /* words of a wavefront block: the offsets of one haplotype state with distance > 0 (most states have none) */
-enum { W_NBLK_MAX = 254, W_NBLK_MIN = 16 }; /* wavefront blocks of a region (a state names its block in 8 bits) */
+enum { W_ED_MAX = AVK_WIDE_ED_MAX };      /* largest distance a search node's wavefront holds (2 ed + 1 offsets, one byte each); a region's wavefront blocks are sized by its own
+                                edit bound (AvkDevRegion::ed_bound: no two strings of the region are further apart), which is what the wave-per-region kernel trusts too */
+enum { W_NBLK_MAX = 254, W_NBLK_MIN = 8 }; /* wavefront blocks of a region (a state names its block in 8 bits) */
 enum { W_NODE_W = 9 };       /* words of a search node: two haplotype states of 4 words (odd stride: spreads the banks) */
 enum { W_K = 16 };           /* queue entries expanded per round (x up to 2 children x 2 haplotypes = the 64 lanes) */
 enum { W_QR = 4 };           /* rows of the sorted queue: 64 entries each, entry 64 r + j in lane j of row r */
@@ -56,7 +56,9 @@ enum { W_POOL_MIN = 24 };
 enum { W_OPTCAP = 64 };      /* tied optima kept */
 enum { W_QB = 16 };          /* queue entries of one genotype search (4 words each) */
 enum { W_QB_W = 4 * W_QB + 1 }; /* words of one genotype search's queue (odd: spreads the banks) */
+enum { W_COOP_MIN = 12 };    /* regions with a larger edit bound align their metrics one pair at a time, the wave on one pair (wfa_ed_wave) */
 enum { WD_DEFER = -1 };      /* internal: not this kernel's region after all */
+enum { WD_SKIP = -2 };       /* internal: not this kernel's region by its record (avk_wide_static_ok): another launch is taking it (WideArgs::skip_static) */
 /* instrumented emulator builds (-DAVK_WIDE_STATS): how often each hand-over site of solve_wide fired (tools/wide_defer_stats.py) */
 #ifdef AVK_WIDE_STATS
 extern uint64_t g_wide_defer[64];
@@ -93,7 +95,7 @@ struct WTime {
 #endif
 
 /* The wave's LDS, in words: a fixed head, then the region's sequence table, then the working area — what is left of the launch's LDS:
- *   phasing search:    free node slots [pool] | free wavefront blocks [blocks] | nodes [pool][W_NODE_W] | wavefront blocks [blocks][W_BLK_W]
+ *   phasing search:    free node slots [pool] | free wavefront blocks [blocks] | nodes [pool][W_NODE_W] | wavefront blocks [blocks][block words]
  *   genotype searches: the optima's haplotype states [optima][8] | one queue of W_QB_W words per search
  *   metrics:           one alignment scratch per lane that aligns */
 enum {
@@ -112,8 +114,8 @@ enum {
 };
 
 struct WideArgs {
-    u32 lds_words; /* LDS words per wave of this launch */
-    u32 pad;
+    u32 lds_words;   /* LDS words per wave of this launch */
+    u32 skip_static; /* records that fail avk_wide_static_ok() are left alone (a launch with AvkKernelArgs::only_not_wide takes them) instead of handed over */
 };
 
 /* the context avk_lane.inl's primitives run on: tables shared by the wave, the wavefront rows private to the lane */
@@ -125,6 +127,8 @@ struct WCtx {
     u32 W1, L, T, Q, N, qbase;
     u32 wfcap, wfcap_c;
     u32 jw0;   /* the slot word of the call this lane's haplotype step applies */
+    u32 coop;  /* metrics phase of a region with a large edit bound: wfa_ed does not align, it leaves a request for the whole wave (resolve_alignments) */
+    mutable u32 req0, req1, pending;
 #ifdef AVK_LANE_SLOW_TILES
     mutable u32 n_pops, n_diag, n_words;
 #endif
@@ -157,6 +161,77 @@ AVK_DEV void hap_pack(u32 *w, const Hap &h, u32 blk1 = 0) {
     w[1] = h.t_skip | (h.q_skip << 8) | (h.nskip << 16) | (h.ed << 24);
     w[2] = h.t_alt | (h.q_alt << 8) | (h.t_nal << 16) | (h.q_nal << 20) | (blk1 << 24);
     if (h.ed == 0) w[3] = h.d0; /* (distance 1: the aligner wrote its front there) */
+}
+
+/* wfa_ed (src/util/sequence_alignment.rs:9-13) of sequences sa (baseline) and sb by the WHOLE WAVE: diagonal i of the front in lane i & 63, register i >> 6
+ * (distances up to 63), every lane slides its diagonals (dynamic_wfa.rs:94-130), one ballot says whether a diagonal is full (:237-245), the next front
+ * (:140-173, no clipping) is two moves along the lanes.  A lane on its own walks the 2 ed + 1 diagonals of every front one after the other — 25 ed^2
+ * instructions, half a millisecond at distance 50; this is 50 ed.  Returns the distance, or -1 beyond 63. */
+AVK_DEV int wfa_ed_wave(const WCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
+    const u32 lane = (u32)wv_lane();
+    u32 w0 = 0, w1 = 0, ed = 0;
+    for (;;) {
+        const u32 nd = 2 * ed + 1;
+        bool full = false;
+        if (lane < nd) {
+            w0 += lane::match_run(c, sa, w0 + ed - lane, la, sb, w0, lb);
+            full = w0 + ed - lane >= la && w0 >= lb;
+        }
+        if (nd > 64u && 64u + lane < nd) {
+            w1 += lane::match_run(c, sa, w1 + ed - (64u + lane), la, sb, w1, lb);
+            full = full || (w1 + ed - (64u + lane) >= la && w1 >= lb);
+        }
+        if (wv_ballot(full) != 0) return (int)ed;
+        if (ed >= 63u) return -1;
+        /* new[k] = max(old[k], old[k - 1] + 1, old[k - 2] + 1) over the entries that exist (old: k < nd) */
+        const u32 a0 = wv_from_below(w0), top0 = wv_readlane(w0, 63);
+        u32 a1 = wv_from_below(w1);
+        a1 = lane == 0 ? top0 : a1; /* old[k - 1]: entry 64 takes entry 63 */
+        const u32 b0 = wv_from_below(a0), top1 = wv_readlane(a0, 63);
+        u32 b1 = wv_from_below(a1);
+        b1 = lane == 0 ? top1 : b1; /* old[k - 2] */
+        {
+            const u32 k = lane;
+            u32 v = k < nd ? w0 : 0u;
+            if (k >= 1 && k - 1 < nd) v = a0 + 1 > v ? a0 + 1 : v;
+            if (k >= 2 && k - 2 < nd) v = b0 + 1 > v ? b0 + 1 : v;
+            w0 = v;
+        }
+        {
+            const u32 k = 64u + lane;
+            u32 v = k < nd ? w1 : 0u;
+            if (k - 1 < nd) v = a1 + 1 > v ? a1 + 1 : v;
+            if (k - 2 < nd) v = b1 + 1 > v ? b1 + 1 : v;
+            w1 = v;
+        }
+        ed += 1;
+    }
+}
+/* What avk_lane.inl's distance functions call when they have to align (found by argument-dependent lookup: this context is of this namespace).  Small
+ * edit bounds: the lane aligns by itself, side by side with the others.  Large ones (WCtx::coop): the lane leaves its request, the wave takes the requests
+ * one after the other (resolve_alignments). */
+AVK_DEV int wfa_ed(const WCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
+    if (c.coop) {
+        c.req0 = sa | (la << 16);
+        c.req1 = sb | (lb << 16);
+        c.pending = 1;
+        return 0;
+    }
+    return lane::wfa_ed<WCtx>(c, sa, la, sb, lb);
+}
+/* the requests the lanes left in wfa_ed: each is aligned by the whole wave, its lane gets the distance in `val`; false: a distance beyond wfa_ed_wave's reach */
+AVK_DEV bool resolve_alignments(const WCtx &c, int &val) {
+    const u32 lane = (u32)wv_lane();
+    bool ok = true;
+    for (u64 m = wv_ballot(c.pending != 0); m; m &= m - 1) {
+        const u32 src = (u32)avk_ctz64(m);
+        const u32 r0 = wv_readlane(c.req0, src), r1 = wv_readlane(c.req1, src);
+        const int e = wfa_ed_wave(c, r0 & 0xFFFFu, r0 >> 16, r1 & 0xFFFFu, r1 >> 16);
+        ok = ok && e >= 0;
+        if (lane == src) val = e;
+    }
+    c.pending = 0;
+    return ok;
 }
 
 /* FULL(side, mask): the calls of the mask applied in the side's order; a call that starts before the end of the previous applied one is dropped and
@@ -340,7 +415,7 @@ AVK_DEV int phaseB(WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q)
  * its three offsets are the state's fourth word, the aligner works on dstp[3]; from 2 on it takes a block of the pool (the parent's is copied; a state
  * updated in place keeps its own).  db1 = 1 + the block of the result (0: none).  Returns 0, or nonzero when the state could not be brought up to date
  * (front of W_ED_MAX full, or no block left): the distance is then at least H.ed + more (more: 0 or 1). */
-AVK_DEV int hap_advance(const WCtx &c, u32 *blocks, u32 *wfree, Hap &H, const u32 *srcp, u32 *dstp, bool fin, u32 &db1, u32 &more) {
+AVK_DEV int hap_advance(const WCtx &c, u32 *blocks, u32 blk_w, u32 *wfree, Hap &H, const u32 *srcp, u32 *dstp, bool fin, u32 &db1, u32 &more) {
     WCtx cj = c;
     int rr = 0;
     db1 = 0;
@@ -369,13 +444,13 @@ AVK_DEV int hap_advance(const WCtx &c, u32 *blocks, u32 *wfree, Hap &H, const u3
             return 1;
         }
         db1 = wfree[old - 1u] + 1u;
-        u32 *dp = blocks + (db1 - 1u) * W_BLK_W;
+        u32 *dp = blocks + (db1 - 1u) * blk_w;
         if (sb1) {
-            const u32 *sp = blocks + (sb1 - 1u) * W_BLK_W;
+            const u32 *sp = blocks + (sb1 - 1u) * blk_w;
             for (u32 k = 0; k < (2 * H.ed + 1 + 3) >> 2; ++k) dp[k] = sp[k];
         } else dp[0] = dstp[3];
     }
-    cj.wfp = blocks + (db1 - 1u) * W_BLK_W;
+    cj.wfp = blocks + (db1 - 1u) * blk_w;
     cj.wfcap = c.wfcap;
     rr = lane::hap_update(cj, H, 0);
     if (!rr && fin) rr = lane::hap_finalize(cj, H, 0);
@@ -391,23 +466,26 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
     const u32 L = wv_uni(reg.len), T = wv_uni(reg.t_cnt), Q = wv_uni(reg.q_cnt), N = T + Q;
     const u32 grow = wv_uni(reg.grow), ed_bound = wv_uni(reg.ed_bound);
     const u32 orig = wv_uni(reg.orig), v_off = wv_uni(reg.v_off), pre = wv_uni(reg.pre_status);
-    if ((pre & 0xFFFFu) || N == 0 || T > (u32)WMV || Q > (u32)WMV) return AVK_WDEFER(1);
-    /* every offset of every wavefront is a byte: an offset can pass its sequence's end by the distance (increase_edit_distance does not clip) */
-    if ((u64)L + grow + ed_bound > 255ull) return AVK_WDEFER(2);
+    /* at most WMV calls on a side; every offset of every wavefront is a byte, and an offset can pass its sequence's end by the distance
+     * (increase_edit_distance does not clip) */
+    if (!avk_wide_static_ok(L, grow, ed_bound, T, Q, pre)) return wa.skip_static ? (int)WD_SKIP : AVK_WDEFER(1);
     WCtx c;
     c.lds = lds;
     c.L = L, c.T = T, c.Q = Q, c.N = N;
     c.W1 = ((L + grow + 15u) >> 4) + 1u;
     c.qbase = (1u << T) - 1u;
     c.jw0 = 0;
+    c.coop = 0, c.req0 = 0, c.req1 = 0, c.pending = 0;
     const u32 nseq = (1u << T) + (1u << Q) - 1u;
     c.meta = lds + WO_META;
     c.seq = c.meta + nseq;
     u32 *const dyn = c.seq + nseq * c.W1;
     const u64 fixed_words = (u64)WO_META + (u64)nseq * (c.W1 + 1u);
-    if (fixed_words + (u64)W_NBLK_MIN * (W_BLK_W + 1u) + (u64)W_POOL_MIN * (W_NODE_W + 1u) > (u64)wa.lds_words) return AVK_WDEFER(3);
+    const u32 ed_node = ed_bound < 1u ? 1u : (ed_bound < (u32)W_ED_MAX ? ed_bound : (u32)W_ED_MAX);
+    const u32 blk_w = ((2 * ed_node + 2 + 3) >> 2) | 1u; /* words of a wavefront block (odd: spreads the banks) */
+    if (fixed_words + (u64)W_NBLK_MIN * (blk_w + 1u) + (u64)W_POOL_MIN * (W_NODE_W + 1u) > (u64)wa.lds_words) return AVK_WDEFER(3);
     const u32 dyn_words = wa.lds_words - (u32)fixed_words;
-    c.wfcap = 2 * W_ED_MAX + 2;
+    c.wfcap = 2 * ed_node + 2;
     const u32 scr_w = (2 * ed_bound + 3 + 3) >> 2; /* words of an alignment scratch of the metrics phase: no two strings of the region are further apart than the bound */
     c.wfcap_c = 4 * scr_w;
     c.wfp = dyn;
@@ -477,7 +555,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
     /* seven tenths of the working area for nodes (at most W_POOL_MAX), the rest for wavefront blocks */
     const u32 pool_want = (dyn_words * 7u / 10u) / (W_NODE_W + 1u);
     const u32 pool_n = pool_want < (u32)W_POOL_MAX ? pool_want : (u32)W_POOL_MAX;
-    const u32 blk_room = (dyn_words - pool_n * (W_NODE_W + 1u)) / (W_BLK_W + 1u);
+    const u32 blk_room = (dyn_words - pool_n * (W_NODE_W + 1u)) / (blk_w + 1u);
     const u32 n_blk = blk_room < (u32)W_NBLK_MAX ? blk_room : (u32)W_NBLK_MAX;
     u32 *const nfree_list = dyn, *const wfree = dyn + pool_n, *const nodes = wfree + n_blk, *const blocks = nodes + pool_n * W_NODE_W;
     u32 nfree = pool_n - 1; /* node 0 is the root */
@@ -618,7 +696,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
             if (fin) lane::hap_step(cj, H, true, false, 0, L_REF, L); /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
             else lane::hap_step(cj, H, is_truth, true, slot, allele, sync);
             u32 db1 = 0, more = 0;
-            const int rr = hap_advance(cj, blocks, wfree, H, srcp, dstp, fin, db1, more);
+            const int rr = hap_advance(cj, blocks, blk_w, wfree, H, srcp, dstp, fin, db1, more);
             mycost = H.t_skip + H.q_skip + H.ed + more; /* (rr: a lower bound) */
             myflags = (rr ? (u32)CH_X : 0u) | (db1 ? (u32)CH_WF : 0u);
             hap_pack(dstp, H, db1);
@@ -739,9 +817,11 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
                         (1u << AVK_VT_TR_EXPANSION) | (1u << AVK_VT_SV_DELETION) | (1u << AVK_VT_SV_INSERTION);
     out.present = types | SUPMASK;
     wv_sync();
+    const bool coop = ed_bound > (u32)W_COOP_MIN;
     const u32 scr_stride = scr_w | 1u, scr_slots = dyn_words / scr_stride;
-    if (scr_slots < 4) return AVK_WDEFER(15);
+    if (!coop && scr_slots < 4) return AVK_WDEFER(15);
     WCtx cs = c;
+    cs.coop = coop ? 1u : 0u;
     cs.wfp = dyn + (lane & 3u) * scr_stride;
     int e_ref = 0;
     if (lane < 4) {
@@ -749,6 +829,7 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         const u32 side = lane & 1u, alt = side ? h.q_alt : h.t_alt;
         if (alt) e_ref = lane::ed_to_ref(cs, side, alt, side ? h.q_len : h.t_len);
     }
+    if (coop && !resolve_alignments(cs, e_ref)) return AVK_WDEFER(15);
     if (wv_ballot(e_ref < 0) != 0) return AVK_WDEFER(15);
     const u32 X0 = 2u * wv_readlane((u32)e_ref, 0), Y0 = 2u * wv_readlane((u32)e_ref, 1), X1 = 2u * wv_readlane((u32)e_ref, 2), Y1 = 2u * wv_readlane((u32)e_ref, 3);
     const u32 tp0 = (X0 + Y0 - 2u * wn[0].ed) / 2u, tp1 = (X1 + Y1 - 2u * wn[1].ed) / 2u;
@@ -767,29 +848,33 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
             store = mask_g != 0 && mask_g != (1u << cnt) - 1u; /* else: none of the type, or nothing but the type: no filtering */
         }
         const u64 sm = wv_ballot(store);
-        if ((u32)avk_popc64(sm) > scr_slots) return AVK_WDEFER(16);
+        if (!coop && (u32)avk_popc64(sm) > scr_slots) return AVK_WDEFER(16);
         wv_sync();
+        cs.wfp = dyn + (coop ? 0u : (u32)avk_popc64(sm & below) * scr_stride);
+        const Hap &h = hh ? wn[1] : wn[0];
+        const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
+        const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
+        const u32 alt = side ? h.q_alt : h.t_alt, m = alt & mask_g;
+        const bool part = store && m && m != alt; /* some of the side's calls are filtered away on this haplotype: two alignments */
+        const u32 sf = part ? c.seq_id(side, m) : 0u, fl = part ? c.seq_len(sf) : 0u;
         if (store) {
-            cs.wfp = dyn + (u32)avk_popc64(sm & below) * scr_stride;
-            const Hap &h = hh ? wn[1] : wn[0];
-            const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
-            const u32 Xh = hh ? X1 : X0, Yh = hh ? Y1 : Y0;
-            const u32 alt = side ? h.q_alt : h.t_alt, m = alt & mask_g;
             x = 0, z = (int)((side ? Xh : Yh) / 2); /* nothing left of the side: it is the reference window */
             if (m && m == alt) {                    /* nothing filtered away on this haplotype: the side as it is */
                 x = (int)((side ? Yh : Xh) / 2);
                 z = (int)h.ed;
-            } else if (m) {
-                const u32 sf = c.seq_id(side, m), fl = c.seq_len(sf);
-                x = lane::ed_to_ref(cs, side, m, fl);
-                /* equal haplotypes with everything applied, one call filtered away: the other side's string is the filtered string plus that call */
-                const u32 gone = alt ^ m;
-                z = -1;
-                if (h.ed == 0 && h.nskip == 0 && (gone & (gone - 1)) == 0 && c.seq_fail(side ? sq : st) == 0 && c.seq_fail(sf) == 0)
-                    z = lane::one_call_distance(cs, WMV * side + (u32)__builtin_ctz(gone));
-                if (z < 0) z = side ? lane::wfa_ed(cs, st, h.t_len, sf, fl) : lane::wfa_ed(cs, sf, fl, sq, h.q_len);
             }
         }
+        if (part) x = lane::ed_to_ref(cs, side, m, fl);
+        if (coop && !resolve_alignments(cs, x)) return AVK_WDEFER(16);
+        if (part) {
+            /* equal haplotypes with everything applied, one call filtered away: the other side's string is the filtered string plus that call */
+            const u32 gone = alt ^ m;
+            z = -1;
+            if (h.ed == 0 && h.nskip == 0 && (gone & (gone - 1)) == 0 && c.seq_fail(side ? sq : st) == 0 && c.seq_fail(sf) == 0)
+                z = lane::one_call_distance(cs, WMV * side + (u32)__builtin_ctz(gone));
+            if (z < 0) z = side ? wfa_ed(cs, st, h.t_len, sf, fl) : wfa_ed(cs, sf, fl, sq, h.q_len);
+        }
+        if (coop && !resolve_alignments(cs, z)) return AVK_WDEFER(16);
         if (wv_ballot(store && (x < 0 || z < 0)) != 0) return AVK_WDEFER(16);
         if (store) lds[WO_FILT + lane] = (u32)x | ((u32)z << 16);
     }
@@ -916,6 +1001,9 @@ template <bool LAZY> AVK_DEV void wide_worker(const AvkKernelArgs &a, const Wide
 #ifdef AVK_WIDE_TIMING
     WTime wt;
     for (int k = 0; k < 16; ++k) wt.t[k] = 0;
+    const u64 t_wave0 = avk_clock();
+    u64 t_lazy = 0, t_max = 0;
+    (void)t_wave0, (void)t_lazy, (void)t_max;
 #endif
     for (;;) {
         u32 idx = 0xFFFFFFFFu;
@@ -927,22 +1015,34 @@ template <bool LAZY> AVK_DEV void wide_worker(const AvkKernelArgs &a, const Wide
         if (idx == 0xFFFFFFFFu || idx >= n_work) break;
         const u32 r = a.work_list ? wv_uni(a.work_list[idx]) : a.work_base + idx;
         if (LAZY && a.lazy_dp && r >= a.lazy_from) { /* a lane-class region of a device-packed batch: its record and blob are written now, by this wave */
+#ifdef AVK_WIDE_TIMING
+            const u64 t_l0 = avk_clock();
+#endif
             if (lane == 0) dp::dp_region_record(*(const dp::DpArgs *)a.lazy_dp, r);
             wv_sync();
+#ifdef AVK_WIDE_TIMING
+            t_lazy += avk_clock() - t_l0;
+#endif
         }
         lane::LaneOut out;
         out.ed1 = out.ed2 = out.n_opt = out.present = 0;
 #ifdef AVK_WIDE_TIMING
-        const u64 t_region0 = avk_clock();
+        const u64 t_region0 = avk_clock(), r8 = wt.t[8], r9 = wt.t[9];
         wt.last = t_region0;
 #endif
         const int st = solve_wide(a, wa, r, lds, part, out AVK_WT_PASS);
         wv_sync();
 #ifdef AVK_WIDE_TIMING
         wt.t[6] += avk_clock() - t_region0;
+        { /* the longest region of the wave: ticks / 16 << 32 | rounds << 20 | pops << 8 | calls */
+            const u64 dt = (avk_clock() - t_region0) >> 4;
+            const u64 rec = (dt << 32) | (((wt.t[8] - r8) & 0xFFFu) << 20) | (((wt.t[9] - r9) & 0xFFFu) << 8) | ((a.regions[r].t_cnt + a.regions[r].q_cnt) & 0xFFu);
+            if (rec > t_max) t_max = rec;
+        }
         wt.t[7] += 1;
         wt.t[11] += st == WD_DEFER ? 1u : 0u;
 #endif
+        if (st == WD_SKIP) continue;
         if (st == WD_DEFER) {
             if (lane == 0) {
                 const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1u);
@@ -963,7 +1063,15 @@ template <bool LAZY> AVK_DEV void wide_worker(const AvkKernelArgs &a, const Wide
         if (n_err) avk_atomic_add_u64_global(part + AVK_TALLY_ERRORS, n_err);
         if (n_ok + n_err) avk_atomic_add_u64_global(part + AVK_TALLY_WIDE_SOLVED, n_ok + n_err);
 #ifdef AVK_WIDE_TIMING
+#ifdef AVK_WIDE_TRACE /* this build reports the hand-back launch alone; [12] the waves that took a region, [13] their lifetimes, [14] the time spent writing records on demand, [15] the longest region */
+        if (LAZY && wt.t[7]) {
+            wt.t[12] = 1, wt.t[13] = avk_clock() - t_wave0, wt.t[14] = t_lazy;
+            for (int k = 0; k < 15; ++k) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 5 + k, wt.t[k]);
+            avk_atomic_max_u64_global(a.tally + AVK_TALLY_LEN + 5 + 15, t_max); /* (one copy: the reduce sums the copies) */
+        }
+#else
         for (int k = 0; k < 16; ++k) avk_atomic_add_u64_global(part + AVK_TALLY_LEN + 5 + k, wt.t[k]);
+#endif
 #endif
     }
 }

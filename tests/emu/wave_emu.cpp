@@ -520,7 +520,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     };
 
     /* a launch of avk_wide.inl (run_internal: avk_wide_kernel / avk_wide_kernel_lazy): `waves` one-wave workgroups on the list of `w` */
-    auto run_wide = [&](const AvkKernelArgs &w, uint32_t waves) {
+    auto run_wide = [&](const AvkKernelArgs &w, uint32_t waves, uint32_t skip_static = 0) {
         std::atomic<uint32_t> next(0);
         auto worker = [&]() {
             avk_emu::Wave wv;
@@ -533,7 +533,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 if (wid >= waves) break;
                 for (auto &x : ldsbuf) x = 0xA5A5A5A5u; /* LDS is not zeroed */
                 WideTask t;
-                t.args = &w, t.wa.lds_words = g_wide_lds_bytes / 4, t.wa.pad = 0, t.wave_id = wid, t.lds = ldsbuf.data();
+                t.args = &w, t.wa.lds_words = g_wide_lds_bytes / 4, t.wa.skip_static = skip_static, t.wave_id = wid, t.lds = ldsbuf.data();
                 avk_emu::run_wave(&wv, wide_kernel_main, &t);
             }
         };
@@ -541,7 +541,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         for (int i = 0; i < (threads < 1 ? 1 : threads); ++i) ts.emplace_back(worker);
         for (auto &t : ts) t.join();
     };
-    std::vector<uint32_t> wide_left_c(n + 1), wide_left_3(n + 1); /* what the wide launches could not take (run_internal: d_overflow5 / d_overflow6) */
+    std::vector<uint32_t> wide_left_c(n + 1), wide_left_3(n + 1), wide_left_l(n + 1); /* what the wide launches could not take (run_internal: d_overflow5 / d_overflow6) */
     const bool use_wide = g_wide_kernel && lds_bytes > 0 && !(lds2_bytes > 0 && lds2_overflow_pass) && ws_bytes > 0 && !cfg->enable_sequences && !cfg->enable_exact_shortcut && n;
 
     /* the same four tier launches as avk_compare_resident (aardvark_amd/csrc/avk_host.hip) */
@@ -789,7 +789,15 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                         AvkKernelArgs w = a;
                         w.work_list = nullptr, w.n_work_dev = nullptr, w.work_base = 0, w.n_work = n_c, w.work_counter = counters + 1240;
                         w.overflow_list = wide_left_c.data(), w.overflow_count = counters + 1244;
-                        run_wide(w, n_waves ? n_waves : 1);
+                        run_wide(w, n_waves ? n_waves : 1, 1);
+                        { /* ... beside the HBM-tier launch for the records that are not the wide kernel's by what they say themselves (AvkKernelArgs::only_not_wide) */
+                            AvkKernelArgs keep2 = a;
+                            a.pass_tier = 2, a.only_not_wide = 1, a.work_list = nullptr, a.n_work_dev = nullptr, a.work_base = 0, a.n_work = n_c, a.work_counter = counters + 1256;
+                            a.static_pct = 0, a.n_shards = 1, a.claim = 4, a.high_priority = 1, a.overflow_list = nullptr, a.overflow_count = nullptr;
+                            a.big_ws = big_slots ? big_slices.data() : nullptr, a.big_busy = counters + 1088, a.big_slots = big_slots;
+                            run_pass(n_waves / 4 ? n_waves / 4 : 1, ws_bytes, 0);
+                            a = keep2;
+                        }
                         a.work_list = wide_left_c.data();
                         a.n_work_dev = counters + 1244;
                         hbm_shared = 0;
@@ -845,6 +853,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     a.n_work_dev = counters + 1024 + 32;
                     a.work_base = 0;
                     a.n_work = 0;
+                    if (use_wide) { /* run_internal: avk_wide.inl first */
+                        AvkKernelArgs w = a;
+                        w.work_counter = counters + 1260, w.overflow_list = wide_left_l.data(), w.overflow_count = counters + 1264;
+                        run_wide(w, n_waves ? n_waves : 1);
+                        a.work_list = wide_left_l.data();
+                        a.n_work_dev = counters + 1264;
+                    }
                     a.work_counter = counters + 768;
                     a.overflow_list = lists[1].data(); /* its own overflow list: one more HBM pass at the very end */
                     a.overflow_count = counters + 1024 + 16;

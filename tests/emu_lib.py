@@ -42,10 +42,9 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     lib.emu_set_lane_kernel(1 if lane_kernel else 0)
     lib.emu_set_wide_kernel(1 if wide_kernel else 0)
     lib.emu_set_wide_lds_bytes(wide_lds_bytes)
+    before = os.environ.get("AVK_EMU_CLASS_C")
     if class_c_all:
         os.environ["AVK_EMU_CLASS_C"] = "100000"
-    else:
-        os.environ.pop("AVK_EMU_CLASS_C", None)
     cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
     res = ResultBatch(batch, sequences=sequences, group_metrics=group_metrics, bp_groups=bp_groups)
     cfg = AvkCompareConfig(max_branch_factor, 1 if sequences else 0, 1 if exact_shortcut else 0)
@@ -57,7 +56,11 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     res.tier_counts = [int(x) for x in tiers]
     res.lane_solved = int(lib.emu_last_lane_solved())
     res.wide_solved = int(lib.emu_last_wide_solved())
-    os.environ.pop("AVK_EMU_CLASS_C", None)
+    if class_c_all:
+        if before is None:
+            os.environ.pop("AVK_EMU_CLASS_C", None)
+        else:
+            os.environ["AVK_EMU_CLASS_C"] = before
     return res
 
 

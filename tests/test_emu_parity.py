@@ -142,7 +142,7 @@ def test_class_c_list_shared_between_the_hbm_launches(oracle, monkeypatch):
             monkeypatch.setenv("AVK_EMU_CLASS_C", c)
             if skip:
                 monkeypatch.setenv("AVK_EMU_SKIP_HBM_SOLO", "1")
-            got = emu_lib.compare_batch(batch, contigs, threads=8, lane_kernel=False)  # every region through the wave-per-region launches
+            got = emu_lib.compare_batch(batch, contigs, threads=8, lane_kernel=False, wide_kernel=False)  # every region through the wave-per-region launches
             assert got.diff(want) == []
             seen.add(got.tier_counts[2])
     assert max(seen) >= 50 and min(seen) < 20  # (regions of the lane-per-region classes are never predicted into the HBM list)

@@ -119,6 +119,15 @@ def test_windows_with_other_symbols_and_long_alleles_are_handed_over(oracle):
     assert wide.wide_solved == 0
 
 
+@pytest.mark.parametrize("seed,kw", [(81, {"max_vars": 2, "max_len": 30, "span": (60, 150)}), (82, {"max_vars": 3, "max_len": 24, "span": (40, 120), "related": 0.3}),
+                                     (83, {"max_vars": 4, "max_len": 20, "span": (80, 160), "repeat_unit": b"CAG"})])
+def test_large_edit_bounds_align_by_the_whole_wave(oracle, seed, kw):
+    """edit bounds over 12: the alignments of the metrics phase are made one pair at a time by the whole wave (wfa_ed_wave), distances of tens"""
+    contigs, batch = scenarios.fuzz_regions(seed, 300, **kw)
+    wide, want = through_wide(oracle, contigs, batch, min_share=0.3, n_waves=8)
+    assert int(np.maximum(want.ed_h1, want.ed_h2).max()) >= 20
+
+
 @pytest.mark.parametrize("lds", [8 * 1024, 24 * 1024, 64 * 1024])
 def test_lds_budget_is_a_class_limit(oracle, lds):
     """a region whose 2^T + 2^Q sequences do not fit the launch's LDS goes to the wave-per-region code"""

@@ -3,7 +3,7 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-assert "widetiming" in os.environ.get("AVK_LIB", "")
+assert "widetiming" in os.environ.get("AVK_LIB", "") or "widetrace" in os.environ.get("AVK_LIB", "")
 import aardvark_amd
 from aardvark_amd import synth, CompareConfig
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
@@ -28,3 +28,5 @@ print("wide-kernel regions %d (handed over %d), ticks per region %.0f, rounds pe
 for i, name in enumerate(["record + tables", "rounds", "commits", "genotype searches", "outputs + alignments", "groups"]):
     print("   %-22s %6.2f %%   %8.0f ticks per region" % (name, 100.0 * pc[i] / tot, pc[i] / n))
 print("handed over by: class limits %d, inexact nodes %d, capacities (optima / queue / ids / pool) %d, genotype searches + alignments %d" % tuple(pc[12:16]))
+if "widetrace" in os.environ.get("AVK_LIB", ""):
+    print("(trace build: the numbers above are the hand-back launch's) waves that took a region %d, mean lifetime %.0f ticks, records written on demand %.0f ticks per region, longest region %d ticks, %d rounds, %d pops, %d calls" % (pc[12], pc[13] / max(pc[12], 1), pc[14] / n, (pc[15] >> 32) << 4, (pc[15] >> 20) & 0xFFF, (pc[15] >> 8) & 0xFFF, pc[15] & 0xFF))
