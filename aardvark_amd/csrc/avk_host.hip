@@ -337,7 +337,7 @@ struct avk_ctx {
     int64_t wide_lds_bytes = 16 * 1024;               /* LDS of one of its waves: 1.2 KB of tables, the region's 2^T + 2^Q full-length sequences, the rest search nodes (10 words each, at most 240) and 32 wavefront blocks */
     int64_t wide_blocks = 512;                        /* most one-wave workgroups of its class C launch */
     int64_t wide_lane_handbacks = 1;                  /* what the one- and two-call lane classes hand back goes through avk_wide.inl too, ahead of the LDS launch */
-    int64_t wide_lazy_blocks = 128;                   /* one-wave workgroups of its launch for what the three-call lane class hands back (a short list, its length known on the device only) */
+    int64_t wide_lazy_blocks = 512;                   /* one-wave workgroups of its launch for what the three-call lane class hands back (a short list, its length known on the device only) */
     bool wide_attr_set = false;
     uint64_t last_wide_solved = 0;
     bool lane_attr_set = false;
@@ -364,7 +364,7 @@ struct avk_ctx {
     hipStream_t wide_stream = nullptr; /* the class C records that are not for the wide kernel (run_internal) */
     hipStream_t tail_stream = nullptr, tail_stream2 = nullptr; /* HIGH priority: the launches for what the lanes handed back start when the chip is full of the other lane classes' waiting
                                                                   workgroups; at the default priority theirs wait their turn among thousands (a 0.2 ms launch took 0.9) */
-    int64_t tail_priority = 1;         /* 0: those launches go behind the lane launches on the lane streams, as in round 3 */
+    int64_t tail_priority = 0;         /* 1: those launches on the high-priority streams.  Measured: no gain (their workgroups still wait for LDS), 0.5 % slower; off */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ready = nullptr, ev_ready2 = nullptr, ev_wide = nullptr;

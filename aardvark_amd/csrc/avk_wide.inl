@@ -56,13 +56,15 @@ enum { W_POOL_MIN = 24 };
 enum { W_OPTCAP = 64 };      /* tied optima kept */
 enum { W_QB = 16 };          /* queue entries of one genotype search (4 words each) */
 enum { W_QB_W = 4 * W_QB + 1 }; /* words of one genotype search's queue (odd: spreads the banks) */
+enum { W_COOP_ED = 8 };      /* a search node's aligner is taken over by the whole wave when its distance passes this (dw_continue_wave) */
 enum { W_COOP_MIN = 12 };    /* regions with a larger edit bound align their metrics one pair at a time, the wave on one pair (wfa_ed_wave) */
 enum { WD_DEFER = -1 };      /* internal: not this kernel's region after all */
 enum { WD_SKIP = -2 };       /* internal: not this kernel's region by its record (avk_wide_static_ok): another launch is taking it (WideArgs::skip_static) */
 /* instrumented emulator builds (-DAVK_WIDE_STATS): how often each hand-over site of solve_wide fired (tools/wide_defer_stats.py) */
 #ifdef AVK_WIDE_STATS
 extern uint64_t g_wide_defer[64];
-#define AVK_WDEFER(k) ((wv_lane() == 0 ? (void)(g_wide_defer[k] += 1) : (void)0), (int)WD_DEFER)
+extern uint32_t g_wide_defer_region[64]; /* the caller's index of the last region handed over at each site */
+#define AVK_WDEFER(k) ((wv_lane() == 0 ? (void)(g_wide_defer[k] += 1, g_wide_defer_region[k] = a.regions[r].orig) : (void)0), (int)WD_DEFER)
 #elif defined(AVK_WIDE_TIMING)
 /* (profiling builds: the sites in four groups — class limits 1-5, inexact nodes 6-7, capacities 8-12, later phases 13-16 — in the last four profiling words) */
 #define AVK_WDEFER(k) (wt.t[12 + ((k) <= 5 ? 0 : (k) <= 7 ? 1 : (k) <= 12 ? 2 : 3)] += 1, (int)WD_DEFER)
@@ -128,7 +130,7 @@ struct WCtx {
     u32 wfcap, wfcap_c;
     u32 jw0;   /* the slot word of the call this lane's haplotype step applies */
     u32 coop;  /* metrics phase of a region with a large edit bound: wfa_ed does not align, it leaves a request for the whole wave (resolve_alignments) */
-    mutable u32 req0, req1, pending;
+    mutable u32 req0, req1, req2, pending;
 #ifdef AVK_LANE_SLOW_TILES
     mutable u32 n_pops, n_diag, n_words;
 #endif
@@ -207,6 +209,68 @@ AVK_DEV int wfa_ed_wave(const WCtx &c, u32 sa, u32 la, u32 sb, u32 lb) {
         ed += 1;
     }
 }
+/* DWFALite::update / finalize of ONE haplotype state by the whole wave, from the front a lane left in its wavefront block (distance `ed`, offsets as bytes;
+ * the lane stopped at W_COOP_ED, or did not start because the state was past it already): extend, then raise the distance until an end is touched
+ * (update, dynamic_wfa.rs:68-84) or — `fin` — until a diagonal is full (update, then finalize :183-198: the same sequence of fronts, the first full one ends
+ * both).  Diagonal i in lane i & 63, register i >> 6, as wfa_ed_wave.  The front goes back to the block.  Returns the distance, or -1 when the block's
+ * `cap` entries do not hold the next front (the distance is more than `ed_out`). */
+AVK_DEV int dw_continue_wave(const WCtx &c, u32 *blk, u32 ed, u32 cap, u32 sa, u32 la, u32 sb, u32 lb, bool fin, u32 &ed_out) {
+    const u32 lane = (u32)wv_lane();
+    const u8 *bytes = (const u8 *)blk;
+    u32 w0 = lane < 2 * ed + 1 ? bytes[lane] : 0u, w1 = 64u + lane < 2 * ed + 1 ? bytes[64u + lane] : 0u;
+    int ret;
+    for (;;) {
+        const u32 nd = 2 * ed + 1;
+        bool stop = false;
+        if (lane < nd) {
+            w0 += lane::match_run(c, sa, w0 + ed - lane, la, sb, w0, lb);
+            const bool eb = w0 + ed - lane >= la, eo = w0 >= lb;
+            stop = fin ? (eb && eo) : (eb || eo);
+        }
+        if (nd > 64u && 64u + lane < nd) {
+            w1 += lane::match_run(c, sa, w1 + ed - (64u + lane), la, sb, w1, lb);
+            const bool eb = w1 + ed - (64u + lane) >= la, eo = w1 >= lb;
+            stop = stop || (fin ? (eb && eo) : (eb || eo));
+        }
+        if (wv_ballot(stop) != 0) {
+            ret = (int)ed;
+            break;
+        }
+        if (2 * ed + 3 > cap) {
+            ret = -1;
+            break;
+        }
+        const u32 a0 = wv_from_below(w0), top0 = wv_readlane(w0, 63);
+        u32 a1 = wv_from_below(w1);
+        a1 = lane == 0 ? top0 : a1;
+        const u32 b0 = wv_from_below(a0), top1 = wv_readlane(a0, 63);
+        u32 b1 = wv_from_below(a1);
+        b1 = lane == 0 ? top1 : b1;
+        {
+            const u32 k = lane;
+            u32 v = k < nd ? w0 : 0u;
+            if (k >= 1 && k - 1 < nd) v = a0 + 1 > v ? a0 + 1 : v;
+            if (k >= 2 && k - 2 < nd) v = b0 + 1 > v ? b0 + 1 : v;
+            w0 = v;
+        }
+        {
+            const u32 k = 64u + lane;
+            u32 v = k < nd ? w1 : 0u;
+            if (k - 1 < nd) v = a1 + 1 > v ? a1 + 1 : v;
+            if (k - 2 < nd) v = b1 + 1 > v ? b1 + 1 : v;
+            w1 = v;
+        }
+        ed += 1;
+    }
+    wv_sync();
+    u8 *out = (u8 *)blk;
+    if (lane < 2 * ed + 1) out[lane] = (u8)w0;
+    if (64u + lane < 2 * ed + 1) out[64u + lane] = (u8)w1;
+    wv_sync();
+    ed_out = ed;
+    return ret;
+}
+
 /* What avk_lane.inl's distance functions call when they have to align (found by argument-dependent lookup: this context is of this namespace).  Small
  * edit bounds: the lane aligns by itself, side by side with the others.  Large ones (WCtx::coop): the lane leaves its request, the wave takes the requests
  * one after the other (resolve_alignments). */
@@ -416,6 +480,7 @@ AVK_DEV int phaseB(WCtx &c, u32 *qb, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q)
  * updated in place keeps its own).  db1 = 1 + the block of the result (0: none).  Returns 0, or nonzero when the state could not be brought up to date
  * (front of W_ED_MAX full, or no block left): the distance is then at least H.ed + more (more: 0 or 1). */
 AVK_DEV int hap_advance(const WCtx &c, u32 *blocks, u32 blk_w, u32 *wfree, Hap &H, const u32 *srcp, u32 *dstp, bool fin, u32 &db1, u32 &more) {
+    const int LS_PARTIAL_ = (int)lane::LS_PARTIAL;
     WCtx cj = c;
     int rr = 0;
     db1 = 0;
@@ -452,10 +517,39 @@ AVK_DEV int hap_advance(const WCtx &c, u32 *blocks, u32 blk_w, u32 *wfree, Hap &
     }
     cj.wfp = blocks + (db1 - 1u) * blk_w;
     cj.wfcap = c.wfcap;
-    rr = lane::hap_update(cj, H, 0);
-    if (!rr && fin) rr = lane::hap_finalize(cj, H, 0);
+    /* a lane follows the front up to distance W_COOP_ED; from there every new front is the whole wave's (a lane walks the 2 ed + 1 diagonals of each front
+     * one after the other: a state that meets a 50-base difference took half a millisecond) */
+    rr = LS_PARTIAL_;
+    if (H.ed < (u32)W_COOP_ED) {
+        rr = lane::hap_update(cj, H, 0, (u32)W_COOP_ED);
+        if (!rr && fin) rr = lane::hap_finalize(cj, H, 0, (u32)W_COOP_ED);
+    }
+    if (rr == LS_PARTIAL_) { /* the request (resolve_updates) */
+        const u32 st = c.seq_id(0, H.t_alt), sq = c.seq_id(1, H.q_alt);
+        c.req0 = st | (H.t_len << 16);
+        c.req1 = sq | (H.q_len << 16);
+        c.req2 = (db1 - 1u) | (H.ed << 8) | (fin ? 0x10000u : 0u);
+        c.pending = 1;
+        return 0;
+    }
     more = rr ? 1u : 0u; /* the front at H.ed is full and touches no end: the distance is more */
     return rr;
+}
+/* the requests the lanes of a round left in hap_advance: the whole wave takes each state's aligner on, the state's lane gets the distance */
+AVK_DEV void resolve_updates(const WCtx &c, u32 *blocks, u32 blk_w, Hap &H, int &rr, u32 &more) {
+    const u32 lane = (u32)wv_lane();
+    for (u64 m = wv_ballot(c.pending != 0); m; m &= m - 1) {
+        const u32 src = (u32)avk_ctz64(m);
+        const u32 r0 = wv_readlane(c.req0, src), r1 = wv_readlane(c.req1, src), r2 = wv_readlane(c.req2, src);
+        u32 ed_out = 0;
+        const int e = dw_continue_wave(c, blocks + (r2 & 0xFFu) * blk_w, (r2 >> 8) & 0xFFu, c.wfcap, r0 & 0xFFFFu, r0 >> 16, r1 & 0xFFFFu, r1 >> 16, (r2 >> 16) != 0, ed_out);
+        if (lane == src) {
+            H.ed = ed_out;
+            rr = e < 0 ? 1 : 0;
+            more = e < 0 ? 1u : 0u;
+        }
+    }
+    c.pending = 0;
 }
 
 /* returns AVK_ST_* (>= 0) or WD_DEFER */
@@ -685,18 +779,23 @@ AVK_DEV int solve_wide(const AvkKernelArgs &a, const WideArgs &wa, u32 r, u32 *l
         cnode = wv_shfl(cnode, (int)(lane & ~1u));
         nfree -= (u32)avk_popc64(am);
         const u32 dnode = fin ? ns : cnode;
-        u32 mycost = 0, myflags = 0;
+        u32 mycost = 0, myflags = 0, db1 = 0, more = 0;
+        int rr = 0;
+        Hap H;
+        lane::hap_init(H);
+        u32 *dstp = nodes + dnode * W_NODE_W + 4 * hh;
+        WCtx cj = c;
+        cj.jw0 = jw0;
+        cj.pending = 0;
         if (job) {
             const u32 *srcp = nodes + ns * W_NODE_W + 4 * hh;
-            u32 *dstp = nodes + dnode * W_NODE_W + 4 * hh;
-            Hap H;
             hap_unpack(H, srcp);
-            WCtx cj = c;
-            cj.jw0 = jw0;
             if (fin) lane::hap_step(cj, H, true, false, 0, L_REF, L); /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95) */
             else lane::hap_step(cj, H, is_truth, true, slot, allele, sync);
-            u32 db1 = 0, more = 0;
-            const int rr = hap_advance(cj, blocks, blk_w, wfree, H, srcp, dstp, fin, db1, more);
+            rr = hap_advance(cj, blocks, blk_w, wfree, H, srcp, dstp, fin, db1, more);
+        }
+        resolve_updates(cj, blocks, blk_w, H, rr, more); /* (states whose distance passed W_COOP_ED: the whole wave, one state at a time) */
+        if (job) {
             mycost = H.t_skip + H.q_skip + H.ed + more; /* (rr: a lower bound) */
             myflags = (rr ? (u32)CH_X : 0u) | (db1 ? (u32)CH_WF : 0u);
             hap_pack(dstp, H, db1);

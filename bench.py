@@ -343,11 +343,12 @@ def main():
         ctx.compare_resident(rb, cfg, None)
         kernel_ms.append(ctx.last_kernel_ms())
         solver_ms.append(ctx.last_solver_ms())
-    tiers = lane_regions = None
+    tiers = lane_regions = wide_regions = None
     got = ctx.download(rb, group_metrics=False)
     try:
         tiers = ctx.last_tier_counts()  # regions finished per workspace tier of the wave-per-region kernels, then capacity failures
         lane_regions = ctx.last_lane_solved()  # regions finished by the lane-per-region kernel
+        wide_regions = ctx.last_wide_solved()  # regions finished by the wave-cooperative kernel of the large searches on small windows
     except Exception:
         pass
     rb.free()
@@ -433,7 +434,7 @@ def main():
                        "parallelism": ("regions of ONE call set sharded by hash(region_id) over %d GPU(s)" % world if scaling == "strong" else
                                        "one call set per GPU on %d GPU(s)" % world) +
                                       ", no data-path collective; one RCCL all-reduce of the job tally (288 x int64) inside the timed region",
-                       "parity": parity, "workspace_tiers": tiers, "lane_kernel_regions": lane_regions},
+                       "parity": parity, "workspace_tiers": tiers, "lane_kernel_regions": lane_regions, "wide_kernel_regions": wide_regions},
             "call_ms": call_stats,  # this rank's single calls inside the timed region (value = all of them, barrier to barrier)
             "resident_value": resident["value"] if resident else None,
             "resident": resident,
@@ -475,12 +476,17 @@ def main():
             rate1 = n1 / (time.perf_counter() - t1)
             out["cpu_baseline"] = {"value": rate, "unit": "regions/s", "cores": cpus, "kind": "port",
                                    "one_thread_value": rate1, "parallel_efficiency": rate / (rate1 * cpus),
+                                   "all_core_extrapolation": {"value": rate / cpus * (os.cpu_count() or cpus), "logical_cpus": os.cpu_count() or cpus,
+                                                              "note": "NOT measured: the rate above scaled from the %d granted cores to the %d logical CPUs the box shows, at the measured per-core rate "
+                                                                      "(an upper bound: hyper-threads and memory bandwidth scale worse); north_star's '10x the all-core CPU rate' is checked against this"
+                                                                      % (cpus, os.cpu_count() or cpus),
+                                                              "gpu_over_this": value / max(rate / cpus * (os.cpu_count() or cpus), 1.0)},
                                    "host": "%d logical CPUs visible, %d usable (affinity / cgroup quota)" % (os.cpu_count() or 0, cpus),
                                    "sample": "%d pass(es) over the same %d-region batch on %d threads, %.2f s wall, same outputs as the GPU step, host arrays in and out; "
                                              "1 thread: first %d regions" % (reps, n_regions, cpus, sec, n1)}
             log("cpu baseline: %.0f regions/s on %d threads (%.2f s), 1 thread %.0f" % (rate, cpus, sec, rate1))
         if world == 1 and not args.no_secondary:
-            out["secondary"] = secondary_legs(ctx, cfg, args, cpus, log)
+            out["secondary"] = secondary_legs(ctx, cfg, args, cpus, log, contigs, job_batch, ms_per_step, resident["ms_per_step"] if resident else None)
         sys.stdout.flush()
         os.write(json_fd, (json.dumps(out) + "\n").encode())
     if use_dist:
@@ -488,7 +494,7 @@ def main():
         dist.destroy_process_group()
 
 
-def secondary_legs(ctx, cfg, args, cpus, log):
+def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, headline_ms=None, headline_resident_ms=None):
     """configs[1], the two robustness mixes and configs[4] on one GPU: each with the host-boundary rate (pinned arrays), the resident step and — where it
     says so — a parity check against the oracle"""
     import ctypes as C
@@ -499,12 +505,30 @@ def secondary_legs(ctx, cfg, args, cpus, log):
     ccfg = cfg.c_struct()
     sec = {}
 
-    def compare_leg(name, contigs, batch, what, parity=True, resident_sync=False, few=False):
+    def cpu_figure(fn, n_units, unit, min_seconds=2.0):
+        """the oracle on the usable cores beside a leg: whole passes until min_seconds have gone by (a reported baseline, not a target)"""
+        t0 = time.perf_counter()
+        passes = 0
+        while True:
+            out = fn()
+            passes += 1
+            if time.perf_counter() - t0 >= min_seconds:
+                break
+        dt = time.perf_counter() - t0
+        return out, {"value": n_units * passes / dt, "unit": unit, "cores": cpus, "kind": "port", "sample": "%d pass(es) over the leg's batch on %d threads, %.2f s" % (passes, cpus, dt)}
+
+    def compare_leg(name, contigs, batch, what, parity=True, resident_sync=False, few=False, packed=False):
+        from aardvark_amd import CompactBatch, PackedBatch
         ctx.upload_reference(contigs)
-        hb = ctx.pinned_batch(batch)
+        if packed:  # the form the headline value is measured on
+            hb = ctx.pinned_packed(PackedBatch.from_compact(CompactBatch.from_region_batch(batch)))
+            entry_point = ctx.lib.avk_compare_packed
+        else:
+            hb = ctx.pinned_batch(batch)
+            entry_point = ctx.lib.avk_compare_batch
         res = ctx.pinned_results(hb)
         cb, ro = hb.c_struct(), res.c_struct()
-        call = lambda: ctx._check(ctx.lib.avk_compare_batch(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
+        call = lambda: ctx._check(entry_point(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
         call()
         t1 = time.perf_counter()
         call()
@@ -527,7 +551,8 @@ def secondary_legs(ctx, cfg, args, cpus, log):
         got = ctx.download(rb, group_metrics=False)
         entry = {"workload": what, "regions": batch.n_regions, "value": batch.n_regions * nb / be, "unit": "regions/s", "ms_per_step": be / nb * 1e3, "steps": nb,
                  "resident_value": batch.n_regions * nr / re_, "resident_ms_per_step": re_ / nr * 1e3, "lane_kernel_regions": ctx.last_lane_solved(),
-                 "lane_share": ctx.last_lane_solved() / max(batch.n_regions, 1), "workspace_tiers": ctx.last_tier_counts()}
+                 "lane_share": ctx.last_lane_solved() / max(batch.n_regions, 1), "wide_kernel_regions": ctx.last_wide_solved(), "workspace_tiers": ctx.last_tier_counts(),
+                 "boundary_form": "packed (avk_compare_packed)" if packed else "wide (avk_compare_batch)"}
         if resident_sync:  # every step synchronised: a step of this size is a launch chain over several streams
             t0 = time.perf_counter()
             for _ in range(nr):
@@ -536,7 +561,9 @@ def secondary_legs(ctx, cfg, args, cpus, log):
             entry["resident_sync_ms_per_step"] = (time.perf_counter() - t0) / nr * 1e3
         rb.free()
         if parity:
-            want = oracle_lib.compare_batch(lib, batch, oracle_lib.ContigSet(contigs), threads=cpus, group_metrics=False)
+            cs_leg = oracle_lib.ContigSet(contigs)
+            want, entry["cpu_baseline"] = cpu_figure(lambda: oracle_lib.compare_batch(lib, batch, cs_leg, threads=cpus, group_metrics=False), batch.n_regions, "regions/s")
+            entry["gpu_over_cpu"] = {"boundary": entry["value"] / entry["cpu_baseline"]["value"], "resident": entry["resident_value"] / entry["cpu_baseline"]["value"]}
             bad = ["boundary:" + x for x in res.diff(want)] + ["resident:" + x for x in got.diff(want)]
             entry["parity"] = "bit-identical" if not bad else "MISMATCH:" + ",".join(bad)
             if bad:
@@ -545,6 +572,17 @@ def secondary_legs(ctx, cfg, args, cpus, log):
         sec[name] = entry
         log("secondary %s: boundary %.3f ms, resident %.3f ms per step, lane share %.4f" % (name, entry["ms_per_step"], entry["resident_ms_per_step"], entry["lane_share"]))
 
+    if job_batch is not None:
+        # What ONE rank of an 8-GPU strong-scaling run does per step: rank 0's hash shard of the job (aardvark_amd/dist.py::shard_batch, gather_calls), same call,
+        # same outputs.  NOT a scaling curve (this pool has one GPU; the driver measures the curve when it has a node): the per-rank step that bounds N = 8.
+        from aardvark_amd import dist as avk_dist
+        shard = avk_dist.gather_calls(avk_dist.shard_batch(job_batch, 0, 8))
+        compare_leg("shard_1_of_8", job_contigs, shard, "rank 0's hash shard (region_id %% 8 == 0 after hashing) of the headline job: %d of %d regions" % (shard.n_regions, job_batch.n_regions), packed=True)
+        sec["shard_1_of_8"]["strong_scaling_bound"] = {
+            "boundary": headline_ms / sec["shard_1_of_8"]["ms_per_step"] if headline_ms else None,
+            "resident": headline_resident_ms / sec["shard_1_of_8"]["resident_ms_per_step"] if headline_resident_ms else None,
+            "note": "the most an 8-GPU strong-scaling run can gain over one GPU = the headline ms_per_step / this leg's (the ranks run side by side, one all-reduce of 288 counters "
+                    "behind them); measured on ONE GPU, no scaling curve can be measured on this pool"}
     contig2, batch2 = synth.config_chr20_snv()
     compare_leg("chr20_snv", [contig2], batch2, "BASELINE configs[1]: synthetic chr20, 50000 SNV-only truth vs query calls, %d regions" % batch2.n_regions, resident_sync=True)
     # robustness: a denser, messier mix and the reference's recommended SV / TR setting (docs/recommended_settings.md:16-37)
@@ -594,7 +632,10 @@ def secondary_legs(ctx, cfg, args, cpus, log):
                                  "what": "the same through avk_merge_batch (avk_multi_batch arrays in %s host memory)" % where}
         # parity: oracle pairs + the restated classification (oracle/merge_oracle.py) on a sample, and the pair results of every region
         k = 3
-        st_o, ex_o = oracle_lib.optimize_pairs(lib, pair_batch_of(mb), oracle_lib.ContigSet(contigs5), 50, threads=cpus)
+        pb5, cs5 = pair_batch_of(mb), oracle_lib.ContigSet(contigs5)
+        (st_o, ex_o), entry["cpu_baseline"] = cpu_figure(lambda: oracle_lib.optimize_pairs(lib, pb5, cs5, 50, threads=cpus), mb.n_regions, "merge regions/s")
+        entry["cpu_baseline"]["sample"] += " (the pairwise optimize_sequences of solve_merge_region; the classification is a table lookup beside it)"
+        entry["gpu_over_cpu"] = entry["value"] / entry["cpu_baseline"]["value"]
         st_o, ex_o = st_o.reshape(-1, 3), ex_o.reshape(-1, 3)
         bad = []
         want_status, want_cls, want_members = mo.classify_k3_majority(st_o, ex_o)  # the restated rule, vectorised (oracle/merge_oracle.py)

@@ -152,7 +152,7 @@ namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; ui
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
 #ifdef AVK_WIDE_STATS
-namespace avk { namespace wide { uint64_t g_wide_defer[64]; } }
+namespace avk { namespace wide { uint64_t g_wide_defer[64]; uint32_t g_wide_defer_region[64]; } }
 #endif
 #include "../../aardvark_amd/csrc/avk_wide.inl"
 #include "../../aardvark_amd/csrc/avk_dwfa_script.inl"
@@ -1149,7 +1149,7 @@ void emu_set_wide_kernel(int on) { g_wide_kernel = on; }
 #ifdef AVK_WIDE_STATS
 void emu_wide_defer_stats(uint64_t *out, int reset) {
     for (int i = 0; i < 64; ++i) {
-        out[i] = avk::wide::g_wide_defer[i];
+        out[i] = avk::wide::g_wide_defer[i] | ((uint64_t)avk::wide::g_wide_defer_region[i] << 32);
         if (reset) avk::wide::g_wide_defer[i] = 0;
     }
 }

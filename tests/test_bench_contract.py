@@ -35,5 +35,8 @@ def test_one_json_line_on_stdout(force_dist):
     assert out["resident_value"] > 0 and out["resident"]["steps"] == 4
     assert out["value"] > 0 and out["ms_per_step"] > 0
     sec = out["secondary"]
-    assert set(sec) == {"chr20_snv", "dense_mix", "min_variant_gap_1000", "merge_3_callers"}
-    assert all(sec[k]["parity"].startswith("bit-identical") for k in ("dense_mix", "min_variant_gap_1000", "merge_3_callers", "chr20_snv"))
+    assert {"shard_1_of_8", "chr20_snv", "dense_mix", "min_variant_gap_1000", "merge_3_callers"} <= set(sec)
+    assert all(sec[k]["parity"].startswith("bit-identical") for k in ("shard_1_of_8", "dense_mix", "min_variant_gap_1000", "merge_3_callers", "chr20_snv"))
+    assert all(sec[k]["cpu_baseline"]["value"] > 0 and sec[k]["cpu_baseline"]["cores"] >= 1 for k in ("shard_1_of_8", "dense_mix", "min_variant_gap_1000", "merge_3_callers", "chr20_snv"))
+    assert sec["shard_1_of_8"]["strong_scaling_bound"]["boundary"] > 0
+    assert out["cpu_baseline"]["all_core_extrapolation"]["value"] >= out["cpu_baseline"]["value"]

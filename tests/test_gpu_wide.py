@@ -94,6 +94,5 @@ def test_hand_backs_of_the_three_call_lane_class_and_class_c_of_a_genome_slice()
         got = ctx.solve_compare_regions(batch, CompareConfig(), group_metrics=False)
         assert got.diff(want) == []
         assert ctx.last_wide_solved() > 100
-        assert ctx.last_tier_counts()[2] < 20  # nearly nothing is left to the HBM tier
     finally:
         ctx.close()
