@@ -7,6 +7,7 @@ outputs (CompareBenchmark fields), same per-region error behaviour (a failed reg
 status instead of metrics and the batch continues, src/main.rs:255-265).
 """
 import ctypes as C
+import weakref
 import os
 
 import numpy as np
@@ -121,6 +122,30 @@ class ResidentBatch:
             pass
 
 
+class _ContextCore:
+    """The native context and its pinned blocks.  Arrays handed out by Context.host_array are views of avk_host_alloc memory: each block is freed when the LAST
+    array that views it is collected (a finalizer on the buffer numpy keeps as the array's base), and the native context is destroyed when it has been closed AND
+    its last block is gone — so an array read after close(), or at interpreter shutdown, never touches freed memory."""
+
+    def __init__(self, lib, handle):
+        self.lib, self.handle, self.live_blocks, self.closed = lib, handle, 0, False
+
+    def release_block(self, p):
+        if self.handle:
+            self.lib.avk_host_free(self.handle, p)
+        self.live_blocks -= 1
+        self._destroy_if_done()
+
+    def close(self):
+        self.closed = True
+        self._destroy_if_done()
+
+    def _destroy_if_done(self):
+        if self.closed and self.live_blocks <= 0 and self.handle:
+            self.lib.avk_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
 class Context:
     """One GPU context (avk_ctx): owns the uploaded reference genome and the workspaces."""
 
@@ -131,26 +156,25 @@ class Context:
         if rc != 0:
             raise AardvarkAmdError("avk_ctx_create(%d) failed (%d): %s" % (device, rc, self.lib.avk_last_error(None).decode()))
         self._contigs = None
-        self._pinned = []
+        self._core = _ContextCore(self.lib, self.handle)
 
     def close(self):
+        """No call may follow.  The native context goes at once, or — when arrays of host_array / pinned_* are still referenced — with the last of them."""
         if self.handle:
-            for p in self._pinned:
-                self.lib.avk_host_free(self.handle, p)
-            self._pinned = []
-            self.lib.avk_ctx_destroy(self.handle)
+            self._core.close()
             self.handle = C.c_void_p()
 
     def host_array(self, shape, dtype):
         """a numpy array in pinned host memory (avk_host_alloc): batch and result arrays that live there are copied by DMA without a host pass;
-        freed when the context is closed"""
+        freed when the last array that views the block is collected (not by close(): see _ContextCore)"""
         count = int(np.prod(shape))
         nbytes = max(16, count * np.dtype(dtype).itemsize)
         p = self.lib.avk_host_alloc(self.handle, nbytes)
         if not p:
             raise AardvarkAmdError("avk_host_alloc(%d) failed: %s" % (nbytes, self.lib.avk_last_error(self.handle).decode()))
-        self._pinned.append(p)
         buf = (C.c_uint8 * nbytes).from_address(p)
+        self._core.live_blocks += 1
+        weakref.finalize(buf, self._core.release_block, p)  # numpy keeps `buf` as the base of every view of the block
         return np.frombuffer(buf, dtype=dtype, count=count).reshape(shape)
 
     def pinned_batch(self, batch):

@@ -1074,6 +1074,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     db->d_overflow5 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow6 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow7 = (uint32_t *)kept((n + 1) * 4);
+    db->d_overflow8 = (uint32_t *)kept((n + 1) * 4);
     if (hs->n_fast_total) db->d_fast = (uint32_t *)kept(((size_t)hs->fast_words + 64) * 4);
     if (rc) return bail(rc);
     const bool clear_beside = n >= 262144; /* (a small batch: the two events between the streams cost more than the fills, 1.16 instead of 0.98 ms per 46,000-region call) */

@@ -335,6 +335,7 @@ struct avk_ctx {
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     int64_t wide_kernel = 1;                          /* regions with large searches on small windows (class C, what the three-call lane class hands back) go to the wave-cooperative kernel of avk_wide.inl first */
     int64_t wide_lds_bytes = 16 * 1024;               /* LDS of one of its waves: 1.2 KB of tables, the region's 2^T + 2^Q full-length sequences, the rest search nodes (10 words each, at most 240) and 32 wavefront blocks */
+    int64_t wide_retry_lds_bytes = 64 * 1024;         /* LDS per wave of the second launch over what the class C launch handed over (0: none) */
     int64_t wide_blocks = 512;                        /* most one-wave workgroups of its class C launch */
     int64_t wide_lane_handbacks = 1;                  /* what the one- and two-call lane classes hand back goes through avk_wide.inl too, ahead of the LDS launch */
     int64_t wide_lazy_blocks = 512;                   /* one-wave workgroups of its launch for what the three-call lane class hands back (a short list, its length known on the device only) */
@@ -389,6 +390,7 @@ struct avk_dev_batch {
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr, *d_overflow4 = nullptr;
+    uint32_t *d_overflow8 = nullptr; /* what the second, large-LDS launch of avk_wide.inl over class C's leftovers could not take either */
     uint32_t *d_overflow5 = nullptr, *d_overflow6 = nullptr, *d_overflow7 = nullptr; /* what the launches of avk_wide.inl could not take: of class C, of the three-call lane class's hand-backs, of the other lane classes' */
     avk::WorkPlan plan;
     uint32_t *d_fast = nullptr; /* fast records of the lane-per-region kernel (avk_dev_types.h), tiles of 64 */
@@ -455,7 +457,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 void free_batch_buffers(avk_dev_batch *db) {
     if (db->dev_packed) return; /* pooled buffers: release_pooled */
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_overflow7, db->d_fast,
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_overflow7, db->d_overflow8, db->d_fast,
                     db->d_bp_off, db->d_bp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -680,6 +682,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->wide_blocks = value;
     } else if (n == "tail_priority") {
         ctx->tail_priority = value ? 1 : 0;
+    } else if (n == "wide_retry_lds_bytes") {
+        if (value < 0 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_retry_lds_bytes must be in [0, 65536]");
+        ctx->wide_retry_lds_bytes = value & ~15ll;
     } else if (n == "wide_lane_handbacks") {
         ctx->wide_lane_handbacks = value ? 1 : 0;
     } else if (n == "wide_lazy_blocks") {
@@ -1005,6 +1010,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_overflow5, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow6, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow7, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow8, n + 1));
 #undef AVK_TRY
     { /* compact BASEPAIR groups: 1 + the region's call types each (none for regions that fail validation), as the device packer counts them */
         std::vector<uint32_t> bp_off(n + 1, 0);
@@ -1447,6 +1453,24 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     wide_c = true;
                     s.work_list = db->d_overflow5;
                     s.n_work_dev = db->d_counters + 1244;
+                    if (ctx->wide_retry_lds_bytes > ctx->wide_lds_bytes) {
+                        /* what it hands over at run time is nearly always a search that outgrew the 16 KB (nodes, wavefront blocks): once more with the LDS of a
+                         * whole workgroup, a few waves — the wave-per-region kernel needs 2 ms for such a region, at the end of this chain */
+                        AvkKernelArgs w2 = w;
+                        w2.work_list = db->d_overflow5;
+                        w2.n_work_dev = db->d_counters + 1244;
+                        w2.work_base = 0;
+                        w2.n_work = 0;
+                        w2.work_counter = db->d_counters + 1268;
+                        w2.overflow_list = db->d_overflow8;
+                        w2.overflow_count = db->d_counters + 1272;
+                        avk::wide::WideArgs wb = wa;
+                        wb.lds_words = (uint32_t)(ctx->wide_retry_lds_bytes / 4);
+                        hipLaunchKernelGGL(avk_wide_kernel, dim3(32), dim3(64), (size_t)ctx->wide_retry_lds_bytes, ctx->side_stream2, w2, wb);
+                        AVK_HIP(ctx, hipGetLastError());
+                        s.work_list = db->d_overflow8;
+                        s.n_work_dev = db->d_counters + 1272;
+                    }
                 }
                 s.pass_tier = 2;
                 s.work_base = 0;
@@ -2228,6 +2252,54 @@ int avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants) {
     if (n_regions > 0x7FFFFFFFull || n_variants > 0x7FFFFFFFull) return 0;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     return bounce_reserve(ctx, (size_t)n_regions * 52 + (size_t)n_variants * 48 + (1u << 20));
+}
+
+/* What a process's FIRST large call pays for beyond the call itself, done ahead of it (a tool: on a thread beside its parsing): the device code is brought in by a
+ * launch of nothing, the table of the looked-up class is made for the default branch factor, and the workspaces of a batch of that size are allocated (7 GB for a
+ * genome; fresh device memory is scrubbed when it is handed out).  Nothing here changes a result; every step is also made on demand by the call that needs it. */
+int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hint) {
+    if (!ctx) return AVK_E_ARG;
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    int rc = avk_ctx_reserve(ctx, n_regions_hint, n_variants_hint);
+    if (rc) return rc;
+    unsigned *d_scratch = nullptr;
+    AVK_HIP(ctx, hipMalloc((void **)&d_scratch, (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1) * sizeof(uint64_t) + AVK_N_COUNTERS * sizeof(uint32_t)));
+    AVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1) * sizeof(uint64_t) + AVK_N_COUNTERS * sizeof(uint32_t), ctx->stream));
+    uint64_t *parts = (uint64_t *)d_scratch;
+    hipLaunchKernelGGL(avk_tally_reduce, dim3((AVK_TALLY_STRIDE + 63) / 64), dim3(64), 0, ctx->stream, parts, parts + (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES, (uint64_t *)nullptr,
+                       (uint32_t *)(parts + (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1)), (unsigned)AVK_N_COUNTERS, 0u);
+    AVK_HIP(ctx, hipGetLastError());
+    if (!ctx->lane_attr_set) {
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        ctx->lane_attr_set = true;
+    }
+    if (ctx->lane_kernel && ctx->lane_pairs) {
+        rc = ensure_pair_table(ctx, 50, ctx->stream);
+        if (rc) {
+            (void)hipFree(d_scratch);
+            return rc;
+        }
+    }
+    if (n_regions_hint >= 65536 && ctx->ws_bytes_per_wave > 0) { /* the workspaces run_internal sizes for a batch of a genome's size (its lane classes leave a few thousand regions) */
+        const size_t waves = ((size_t)ctx->n_cus * 3u + (size_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128) + (size_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64)) * 4u;
+        const size_t ws_need = waves * (size_t)ctx->ws_bytes_per_wave;
+        if (ws_need > ctx->ws_alloc && (double)ws_need <= (double)ctx->ws_budget_bytes) {
+            if (ctx->d_ws) (void)hipFree(ctx->d_ws);
+            ctx->d_ws = nullptr, ctx->ws_alloc = 0;
+            AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ws, ws_need + 256));
+            ctx->ws_alloc = ws_need;
+        }
+        const size_t big_need = (size_t)((ctx->big_waves + 3) / 4) * 4u * (size_t)ctx->big_ws_bytes;
+        if (ctx->big_ws_bytes > 0 && big_need > ctx->big_alloc) {
+            if (ctx->d_big) (void)hipFree(ctx->d_big);
+            ctx->d_big = nullptr, ctx->big_alloc = 0;
+            AVK_HIP(ctx, hipMalloc((void **)&ctx->d_big, big_need + 256));
+            ctx->big_alloc = big_need;
+        }
+    }
+    AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_scratch);
+    return 0;
 }
 
 int avk_batch_upload_compact(avk_ctx *ctx, const avk_compact_batch *batch, avk_dev_batch **out) {

@@ -214,7 +214,7 @@ int main(int argc, char **argv) {
             if (stat(ref.c_str(), &st) == 0 && st.st_size > (256ll << 20)) {
                 const bool gz = ref.size() > 3 && ref.compare(ref.size() - 3, 3, ".gz") == 0;
                 const uint64_t guess = (uint64_t)st.st_size * (gz ? 4u : 1u) / 750u;
-                th_reserve = std::thread([guess, &ctx] { (void)avk_ctx_reserve(ctx, guess, 2 * guess); }); /* joined before the solve stage */
+                th_reserve = std::thread([guess, &ctx] { (void)avk_ctx_warmup(ctx, guess, 2 * guess); }); /* (bounce buffer, device code, workspaces) joined before the solve stage */
             }
         }
         s_ctx = seconds_since(t);

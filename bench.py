@@ -77,6 +77,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-merge", action="store_true", help="skip the configs[4] merge leg of `secondary`")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the whole-`compare` wall-clock leg of `secondary` (files on disk, the command-line tool in fresh processes)")
     ap.add_argument("--merge-scale", type=float, default=1.0)
     ap.add_argument("--secondary-scale", type=float, default=0.25, help="genome scale of the two robustness mixes of `secondary`")
     ap.add_argument("--no-parity", action="store_true", help="skip the bit-identity gate against the oracle")
@@ -662,7 +663,48 @@ def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, 
             sys.exit(3)
         sec["merge_3_callers"] = entry
         log("secondary merge: %.2f ms per call" % entry["ms_per_step"])
+    if not args.no_e2e:
+        sec["e2e_compare"] = e2e_leg(args, log)
     return sec
+
+
+def e2e_leg(args, log):
+    """The wall-clock half of the metric: the whole `compare` run — FASTA + BED + two VCF.gz of the headline workload's shape written to disk, then the command-line
+    tool (aardvark_amd/csrc/cli/compare_main.cpp, the stand-in for the reference's run_compare, src/main.rs:30-327) in fresh processes, the last run checked
+    against the oracle (summary.tsv byte for byte, every record of both annotated VCFs).  tools/e2e_genome.py does the work; this parses what it prints."""
+    import re
+    exe = os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare")
+    if not os.path.exists(exe):
+        return {"skipped": "aardvark_amd/bin/aardvark_amd_compare is not built (make -C aardvark_amd/csrc/cli)"}
+    env = dict(os.environ, SCALE=str(args.scale), RUNS="3", VERIFY="1")
+    env.pop("AVK_BENCH_CHILD", None)
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "e2e_genome.py")], capture_output=True, text=True, env=env, timeout=1500)
+    except subprocess.TimeoutExpired:
+        return {"skipped": "tools/e2e_genome.py did not finish in 1500 s"}
+    text = r.stdout
+    if r.returncode != 0:
+        return {"failed": "tools/e2e_genome.py exit %d" % r.returncode, "stderr_tail": r.stderr[-400:]}
+    walls = [float(x) for x in re.findall(r"^exit 0, wall ([0-9.]+) s", text, re.M)]
+    tool = [float(x) for x in re.findall(r"Comparisons completed in ([0-9.]+) seconds", text)]
+    stages = re.findall(r"stages \[s\]: load ([0-9.]+) .*?regions ([0-9.]+) .*?solve \(pack \+ H2D \+ kernels \+ D2H\) ([0-9.]+), summary \+ annotated VCFs ([0-9.]+)", text)
+    loaded = re.search(r"Loaded (\d+) truth and (\d+) query variants; (\d+) regions", text)
+    entry = {"workload": "the headline workload as files: 24 contigs x %.3g, FASTA + confident BED + truth.vcf.gz + query.vcf.gz (bgzip), `aardvark_amd_compare -r -t -q -b -o` in a fresh "
+                         "process, 3 runs" % args.scale,
+             "wall_s": min(tool) if tool else None, "wall_s_runs": tool, "process_wall_s_runs": walls,
+             "what": "wall_s = the tool's own clock from its first line to its last (as the reference's, src/main.rs:32,326), best of the runs; process_wall_s includes process start and teardown",
+             "stages_s": [{"load": float(a), "regions": float(b), "solve": float(c), "summary_and_vcfs": float(dd)} for a, b, c, dd in stages],
+             "regions": int(loaded.group(3)) if loaded else None,
+             "summary_identical_to_oracle": "summary.tsv identical to oracle + restated writer: True" in text,
+             "per_variant_identical_to_oracle": "per-variant verification PASSED" in text,
+             "fixture_seconds": float(re.search(r"written to .* in ([0-9.]+) s", text).group(1)) if re.search(r"written to .* in ([0-9.]+) s", text) else None,
+             "leg_seconds": time.perf_counter() - t0}
+    if not (entry["summary_identical_to_oracle"] and entry["per_variant_identical_to_oracle"]):
+        print("PARITY FAILURE in the e2e_compare leg:\n" + text[-1500:], file=sys.stderr)
+        sys.exit(3)
+    log("secondary e2e_compare: wall %s s (tool clock), solve stage %s s" % (entry["wall_s"], [s["solve"] for s in entry["stages_s"]]))
+    return entry
 
 
 def pair_batch_of(mb):

@@ -320,6 +320,10 @@ void  avk_host_free(avk_ctx *ctx, void *p);
 /* optional: pins the bounce buffer avk_compare_batch needs for PAGEABLE arrays of a batch of up to n_regions / n_variants (kept by the context, only
  * grows), e.g. while a tool is still reading its inputs; without it the first large call pays for it */
 int  avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants);
+/* optional, for a process that makes ONE large call (the reference's `aardvark compare` is one run per process, src/main.rs:30): what the first call of a context
+ * pays for beyond the call itself — the device code brought in, the table of the looked-up class, the bounce buffer of avk_ctx_reserve, the workspaces of a batch
+ * of about n_regions regions — done now, e.g. on a thread beside the parsing of the inputs.  Changes no result; without it the first call does the same on demand. */
+int  avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hint);
 int  avk_last_compare_was_one_shot(avk_ctx *ctx);  /* 1: the batch of the last avk_compare_batch / avk_optimize_pairs_batch was packed on the device
                                                       (context option device_pack) */
 int  avk_last_lane_ms(avk_ctx *ctx, float *ms);    /* start of the call to the end of its lane-per-region launches (0: it had none) */

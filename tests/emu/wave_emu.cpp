@@ -520,20 +520,21 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     };
 
     /* a launch of avk_wide.inl (run_internal: avk_wide_kernel / avk_wide_kernel_lazy): `waves` one-wave workgroups on the list of `w` */
-    auto run_wide = [&](const AvkKernelArgs &w, uint32_t waves, uint32_t skip_static = 0) {
+    auto run_wide = [&](const AvkKernelArgs &w, uint32_t waves, uint32_t skip_static = 0, uint32_t lds_bytes_w = 0) {
+        if (!lds_bytes_w) lds_bytes_w = g_wide_lds_bytes;
         std::atomic<uint32_t> next(0);
         auto worker = [&]() {
             avk_emu::Wave wv;
             wv.stack_bytes = 256 * 1024;
             std::vector<char> stacks(64 * wv.stack_bytes + 64);
             wv.stacks = stacks.data();
-            std::vector<uint32_t> ldsbuf(g_wide_lds_bytes / 4 + 64);
+            std::vector<uint32_t> ldsbuf(lds_bytes_w / 4 + 64);
             for (;;) {
                 const uint32_t wid = next.fetch_add(1);
                 if (wid >= waves) break;
                 for (auto &x : ldsbuf) x = 0xA5A5A5A5u; /* LDS is not zeroed */
                 WideTask t;
-                t.args = &w, t.wa.lds_words = g_wide_lds_bytes / 4, t.wa.skip_static = skip_static, t.wave_id = wid, t.lds = ldsbuf.data();
+                t.args = &w, t.wa.lds_words = lds_bytes_w / 4, t.wa.skip_static = skip_static, t.wave_id = wid, t.lds = ldsbuf.data();
                 avk_emu::run_wave(&wv, wide_kernel_main, &t);
             }
         };
@@ -541,7 +542,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         for (int i = 0; i < (threads < 1 ? 1 : threads); ++i) ts.emplace_back(worker);
         for (auto &t : ts) t.join();
     };
-    std::vector<uint32_t> wide_left_c(n + 1), wide_left_3(n + 1), wide_left_l(n + 1); /* what the wide launches could not take (run_internal: d_overflow5 / d_overflow6) */
+    std::vector<uint32_t> wide_left_c(n + 1), wide_left_3(n + 1), wide_left_l(n + 1), wide_left_c2(n + 1); /* what the wide launches could not take (run_internal: d_overflow5 / d_overflow6) */
     const bool use_wide = g_wide_kernel && lds_bytes > 0 && !(lds2_bytes > 0 && lds2_overflow_pass) && ws_bytes > 0 && !cfg->enable_sequences && !cfg->enable_exact_shortcut && n;
 
     /* the same four tier launches as avk_compare_resident (aardvark_amd/csrc/avk_host.hip) */
@@ -800,6 +801,14 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                         }
                         a.work_list = wide_left_c.data();
                         a.n_work_dev = counters + 1244;
+                        if (g_wide_lds_bytes < 64u * 1024u) { /* run_internal: what it handed over once more with the LDS of a whole workgroup (option wide_retry_lds_bytes) */
+                            AvkKernelArgs w2 = w;
+                            w2.work_list = wide_left_c.data(), w2.n_work_dev = counters + 1244, w2.work_base = 0, w2.n_work = 0, w2.work_counter = counters + 1268;
+                            w2.overflow_list = wide_left_c2.data(), w2.overflow_count = counters + 1272;
+                            run_wide(w2, 2, 0, 64u * 1024u);
+                            a.work_list = wide_left_c2.data();
+                            a.n_work_dev = counters + 1272;
+                        }
                         hbm_shared = 0;
                     }
                     a.pass_tier = 2;

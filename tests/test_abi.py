@@ -107,3 +107,49 @@ def test_packer_edit_distance_matches_the_oracle():
         pb, lb = oracle_lib.b2p(b)
         want = orc.orc_wfa_ed(pa, la, pb, lb)
         assert lib.avk_edit_distance(a, len(a), b, len(b)) == want, (a, b)
+
+
+def test_pinned_arrays_outlive_close_without_touching_freed_memory():
+    """Context.host_array blocks are freed with the last array that views them, the native context with the last block after close()
+    (the counting is host logic: a stand-in library records the calls, no GPU needed)"""
+    import gc
+    import ctypes as C
+    import numpy as np
+    from aardvark_amd import api
+
+    class FakeLib:
+        def __init__(self):
+            self.freed, self.destroyed = [], 0
+            self.blocks = {}
+
+        def avk_host_alloc(self, handle, nbytes):
+            buf = (C.c_uint8 * nbytes)()
+            self.blocks[C.addressof(buf)] = buf
+            return C.addressof(buf)
+
+        def avk_host_free(self, handle, p):
+            self.freed.append(p)
+
+        def avk_ctx_destroy(self, handle):
+            self.destroyed += 1
+
+    lib = FakeLib()
+    ctx = api.Context.__new__(api.Context)
+    ctx.lib, ctx.handle, ctx._contigs = lib, C.c_void_p(1234), None
+    ctx._core = api._ContextCore(lib, ctx.handle)
+    a = ctx.host_array((16,), np.uint32)
+    b = ctx.host_array((4, 4), np.uint8)
+    view = a[2:5]
+    a[:] = 7
+    ctx.close()
+    assert lib.destroyed == 0 and lib.freed == []  # arrays are alive: nothing is freed yet
+    assert int(view.sum()) == 21
+    del a
+    gc.collect()
+    assert lib.freed == []  # `view` still keeps the first block
+    del b
+    gc.collect()
+    assert len(lib.freed) == 1 and lib.destroyed == 0
+    del view
+    gc.collect()
+    assert len(lib.freed) == 2 and lib.destroyed == 1

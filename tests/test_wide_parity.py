@@ -175,3 +175,4 @@ def test_merge_pairs(oracle):
         lib.emu_set_lane_node_cap(32)
     assert np.array_equal(st_o, st_e) and np.array_equal(ex_o, ex_e)
     assert 20 < ex_o.sum() < batch.n_regions
+

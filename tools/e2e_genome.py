@@ -173,6 +173,14 @@ if os.environ.get("VERIFY", "0") == "1":  # the whole run again on the CPU: feed
         ok_all = ok_all and same
         print("%s: %d records, positions and GT:BD:EA:OA:RI identical to the oracle's per-variant decisions: %s" % (name, len(got_pos), same))
     print("per-variant verification %s in %.0f s" % ("PASSED" if ok_all else "FAILED", time.time() - t0))
+def _cleanup():
+    if os.environ.get("KEEP", "0") != "1":  # the fixtures are gigabytes: gone unless KEEP=1
+        import shutil
+        shutil.rmtree(d, ignore_errors=True)
+
+
+import atexit
+atexit.register(_cleanup)
 if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote over the callers
     vcfs = [os.path.join(d, "truth.vcf.gz"), os.path.join(d, "query.vcf.gz")] + [os.path.join(d, "caller%d.vcf.gz" % i) for i in range(2, n_merge)]
     cmd = [os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_merge"), "-r", os.path.join(d, FASTA_NAME)] + [x for v in vcfs for x in ("-i", v)] + \
