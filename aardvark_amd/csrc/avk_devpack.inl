@@ -101,7 +101,8 @@ struct DpState {
     u32 base[DP_NB + 1];
     u32 cursor[DP_NB];
     /* the plan (WorkPlan of avk_pack.h) and the geometry of the fast records */
-    u32 n_hbm, n_hard, n_fast_total, pad1_;
+    u32 n_hbm, n_hard, n_fast_total;
+    u32 n_hbm_notwide; /* class C regions (by size) that are not for avk_wide.inl by their record (avk_wide_static_ok): how the class's launches share the waves */
     u32 n_fast[AVK_FAST_CLASSES], n_fast_heavy[AVK_FAST_CLASSES], fast_base[AVK_FAST_CLASSES], fast_tiles[AVK_FAST_CLASSES], tile_first[AVK_FAST_CLASSES];
     u32 pad2_;
     u32 head_slots[AVK_FAST_CLASSES], pad4_; /* striped head of each lane class (avk_head_slots) */
@@ -630,6 +631,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
         const bool c_by_size = a.opt.tier1_bytes && dp_need(ri.len, tc, qc, ri.ed_bound, N, ri.alle_bytes, ri.grow, a.opt.tier1_ed_cap, ((u64)a.opt.class_c_nodes_x2 * N + 1) / 2, a.opt.max_branch) > a.opt.tier1_bytes;
         if (c_by_size || het_search) {
             if (c_by_size) cls = 0;
+            if (c_by_size && !avk_wide_static_ok(ri.len, ri.grow, ri.ed_bound, tc, qc, 0u)) avk_atomic_add_u32_global(&a.st->n_hbm_notwide, 1u); /* (rare, or the whole batch: a batch of large windows) */
             /* how large an HBM slice the region is predicted to want (no edit-distance cap there): the host sizes the per-wave slices of the batch's
              * launches by the distribution — large windows (--min-variant-gap 1000) outgrow the default 1 MB by the thousand, and the shared big
              * slices serialise whatever overflows */

@@ -1050,7 +1050,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         const int64_t want = 1ll << (20 + pick);
         db->ws_bytes_eff = want > ctx->ws_bytes_per_wave && ctx->ws_bytes_per_wave > 0 && ctx->adaptive_ws ? want : 0;
     }
-    db->plan.n_hbm = hs->n_hbm, db->plan.n_hard = hs->n_hard, db->plan.n_fast_total = hs->n_fast_total;
+    db->plan.n_hbm = hs->n_hbm, db->plan.n_hard = hs->n_hard, db->plan.n_fast_total = hs->n_fast_total, db->plan.n_hbm_notwide = hs->n_hbm_notwide;
     uint32_t tiles_total = 0;
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) {
         db->plan.n_fast[fc] = hs->n_fast[fc], db->plan.n_fast_heavy[fc] = hs->n_fast_heavy[fc], db->plan.fast_base[fc] = hs->fast_base[fc];

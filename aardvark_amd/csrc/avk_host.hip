@@ -1407,7 +1407,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (hbm_solo) {
                 AvkKernelArgs s = a;
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream2, ctx->ev_fork, 0));
-                if (use_wide) { /* class C through avk_wide.inl first; the HBM launch behind it on this stream takes the list of what that could not take */
+                /* how many of them are not the wide kernel's by their own record (a long window, many calls on a side): none or few in a genome, all of them in a
+                 * batch of large windows (--min-variant-gap 1000) — which then keeps the launches of round 3: every HBM wave on the whole list */
+                const uint32_t n_nw = db->plan.n_hbm_notwide < n_c ? db->plan.n_hbm_notwide : n_c;
+                if (use_wide && 2u * n_nw <= n_c) { /* class C through avk_wide.inl first; the HBM launch behind it on this stream takes the list of what that could not take */
                     AvkKernelArgs w = a;
                     w.work_list = nullptr;
                     w.n_work_dev = nullptr;
@@ -1418,10 +1421,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     w.overflow_count = db->d_counters + 1244;
                     uint32_t wg = n_c < (uint32_t)ctx->wide_blocks ? n_c : (uint32_t)ctx->wide_blocks;
                     avk::wide::WideArgs wc = wa;
-                    wc.skip_static = 1;
+                    wc.skip_static = n_nw ? 1u : 0u; /* (without the launch below such a record is handed over like any other) */
                     hipLaunchKernelGGL(avk_wide_kernel, dim3(wg), dim3(64), (size_t)ctx->wide_lds_bytes, ctx->side_stream2, w, wc);
                     AVK_HIP(ctx, hipGetLastError());
-                    { /* the records of class C that are not for the wide kernel by what they say themselves (avk_wide_static_ok: a long window, many calls on a
+                    if (n_nw) { /* the records of class C that are not for the wide kernel by what they say themselves (avk_wide_static_ok: a long window, many calls on a
                        * side) start at the same time, on the HBM-tier kernel and a stream of their own: they are few and each of them is long */
                         AvkKernelArgs x = s;
                         x.pass_tier = 2;
@@ -1435,7 +1438,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.n_shards = 1;
                         x.claim = 4;
                         x.high_priority = 1;
-                        const uint32_t xb = hbm_solo < 32u ? hbm_solo : 32u;
+                        uint32_t xb = (n_nw + 3u) / 4u;
+                        xb = xb < hbm_solo ? xb : hbm_solo;
+                        xb = xb < 64u ? xb : 64u;
                         x.n_waves = xb * waves_per_block;
                         x.hbm_ws = ctx->d_ws + (size_t)(n_waves + (hbm_solo_max - xb) * waves_per_block) * (size_t)ws_bytes; /* the last slices of the solo launch's share (that launch gets the others) */
                         x.big_ws = ctx->d_big;

@@ -475,6 +475,7 @@ inline PodVec<AvkDevRegion> regions_in_work_order(const PackedBatch &pb, const s
 
 struct WorkPlan {
     uint32_t n_hbm = 0;  /* class C */
+    uint32_t n_hbm_notwide = 0; /* of those (by size): not for avk_wide.inl by their record (avk_wide_static_ok) */
     uint32_t n_hard = 0; /* class B */
     /* the regions of the lane-per-region kernel's classes close the work order, largest class first:
      * [class C | class B | bulk | fast class AVK_FAST_CLASSES - 1 | .. | fast class 0] */
@@ -542,6 +543,8 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
         if (tier1_bytes && ((lanes_any && het_min && !pb.nhet_u.empty() && pb.nhet_u[r] >= het_min) || /* (a big phasing search, in a batch with lane launches) */ need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes)) {
             cls[r] = 0;
             plan.n_hbm += 1;
+            if (need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes && !avk_wide_static_ok(dr.len, dr.grow, dr.ed_bound, dr.t_cnt, dr.q_cnt, 0u))
+                plan.n_hbm_notwide += 1;
         } else if (N >= solo_min_variants || need(dr, N, alle, grow, tier0_ed_cap, 2 * N + 1) > tier0_bytes) {
             cls[r] = 1;
             plan.n_hard += 1;

@@ -688,7 +688,178 @@ def scenarios():
             continue
         regions.append(dict(start=start, end=end, truth=truth, query=query))
     out.append(dict(name="random_small", contig=contig4, regions=regions, max_branch_factor=50))
+
+    # 5. (round 4) clusters of unphased heterozygous call pairs on short windows: symmetric phasing searches with up to dozens of tied optima, whose ORDER decides the
+    # winner (waffle_solver.rs:264-265) — what the wave-cooperative kernel expands sixteen queue entries at a time and commits in the reference's order
+    r5 = random.Random(20251003)
+    contig5 = rand_seq(r5, 2400)
+    regions5 = []
+    for k in range(14):
+        L = r5.randrange(90, 200)
+        start = 20 + 165 * k
+        end = start + L
+        n_sites = 3 + k % 4
+        pos = sorted(r5.sample(range(start + 3, end - 8), n_sites))
+        truth, query = [], []
+        for p in pos:
+            kind = r5.random()
+            if kind < 0.75:
+                a0, a1, vt = contig5[p:p + 1], bytes([other_base(contig5[p], r5)]), "Snv"
+            elif kind < 0.88:
+                a0, a1, vt = contig5[p:p + 1], contig5[p:p + 1] + rand_seq(r5, r5.randrange(1, 5)), "Insertion"
+            else:
+                a0, a1, vt = contig5[p:p + r5.randrange(2, 6)], contig5[p:p + 1], "Deletion"
+            zt = "UnphasedHeterozygous" if r5.random() < 0.8 else r5.choice(ZY)
+            zq = "UnphasedHeterozygous" if r5.random() < 0.85 else r5.choice(ZY)
+            if r5.random() > 0.08:
+                truth.append(V(p, a0, a1, vt, zt))
+            if r5.random() > 0.08:
+                qa1 = bytes([other_base(contig5[p], r5)]) if vt == "Snv" and r5.random() < 0.12 else a1  # sometimes another ALT base on the query side
+                query.append(V(p, a0, qa1, vt, zq))
+        if k % 5 == 4 and truth:  # a multi-allelic site: two records at one position on each side (the second is skipped on the haplotype that took the first)
+            v = truth[0]
+            if v["type"] == "Snv":
+                third = bytes([c for c in b"ACGT" if c != v["a0"][0] and c != v["a1"][0]][:1])
+                truth.insert(1, V(v["pos"], v["a0"], third, "Snv", "UnphasedHeterozygous"))
+                query.insert(0, V(v["pos"], v["a0"], third, "Snv", "UnphasedHeterozygous"))
+                query.sort(key=lambda x: x["pos"])
+        regions5.append(dict(start=start, end=end, truth=truth, query=query))
+    for mb in (50, 3):
+        out.append(dict(name="het_clusters_mbf%d" % mb, contig=contig5, regions=regions5, max_branch_factor=mb))
+
+    # 6. (round 4) one SNV per side, the same one — the class that is looked up, not searched (avk_pairs.inl): every pair of zygosities, with the window cut by the
+    # contig's start and end and the call on the window's first and last base; branch factors 1, 2, 3 (the quota reaches a two-call search at 1 and 2)
+    r6 = random.Random(616)
+    contig6 = rand_seq(r6, 260)
+    regions6 = []
+    spots = [(0, 40, 0), (0, 40, 39), (0, 51, 25), (len(contig6) - 45, len(contig6), len(contig6) - 1), (len(contig6) - 45, len(contig6), len(contig6) - 45), (100, 201, 150)]
+    for i, (start, end, p) in enumerate(spots):
+        for j, (zt, zq) in enumerate([(a, b) for a in ZY for b in ZY]):
+            if (i + j) % 3 and i not in (0, 3):
+                continue  # all sixteen pairs at the two clipped spots, a third of them elsewhere
+            alt = bytes([other_base(contig6[p], r6)])
+            regions6.append(dict(start=start, end=end, truth=[V(p, contig6[p:p + 1], alt, "Snv", zt)], query=[V(p, contig6[p:p + 1], alt, "Snv", zq)]))
+    for mb in (1, 2, 3):
+        out.append(dict(name="same_snv_edges_mbf%d" % mb, contig=contig6, regions=regions6, max_branch_factor=mb))
+
+    # 7. (round 4) records whose REF allele is not what the genome has at their position (the solver splices the ALT into the WINDOW, waffle_solver.rs:726-778, while
+    # Variant::alt_ed and the skip penalty come from the record's own alleles): an SNV whose ALT is the genome's base, an SNV with a foreign REF, indels written with
+    # another anchor base, against plain calls at the same place
+    r7 = random.Random(717)
+    contig7 = rand_seq(r7, 1600)
+    regions7 = []
+    for k in range(16):
+        start = 30 + 95 * k
+        end = start + r7.randrange(60, 90)
+        p = r7.randrange(start + 5, end - 12)
+        g = contig7[p:p + 1]
+        wrong = bytes([other_base(contig7[p], r7)])
+        wrong2 = bytes([c for c in b"ACGT" if c != contig7[p] and c != wrong[0]][:1])
+        ins = rand_seq(r7, r7.randrange(1, 4))
+        dl = r7.randrange(2, 5)
+        shapes = [
+            V(p, wrong, g, "Snv", r7.choice(ZY)),                                  # "ALT" is the genome's base: the haplotype IS the window
+            V(p, wrong, wrong2, "Snv", r7.choice(ZY)),                             # foreign REF, foreign ALT
+            V(p, wrong, wrong + ins, "Insertion", r7.choice(ZY)),                  # insertion behind an anchor the genome does not have
+            V(p, wrong + contig7[p + 1:p + dl], wrong, "Deletion", r7.choice(ZY)),  # deletion with a foreign anchor
+            V(p, g + contig7[p + 1:p + dl], wrong, "Deletion", r7.choice(ZY)),      # deletion that also changes the anchor
+        ]
+        plain = [V(p, g, wrong, "Snv", r7.choice(ZY)), V(p, g, g + ins, "Insertion", r7.choice(ZY)), V(p, contig7[p:p + dl], g, "Deletion", r7.choice(ZY))]
+        t = [shapes[k % 5]]
+        q = [r7.choice(plain)] if k % 3 else [dict(shapes[k % 5], zyg=r7.choice(ZY))]
+        if k % 4 == 0:  # a second, ordinary call further on
+            p2 = p + dl + r7.randrange(3, 8)
+            if p2 < end - 2:
+                extra = V(p2, contig7[p2:p2 + 1], bytes([other_base(contig7[p2], r7)]), "Snv", r7.choice(ZY))
+                t.append(extra)
+                q.append(dict(extra, zyg=r7.choice(ZY)))
+        regions7.append(dict(start=start, end=end, truth=t, query=q))
+    out.append(dict(name="ref_allele_disagrees", contig=contig7, regions=regions7, max_branch_factor=50))
     return out
+
+
+# ---------------------------------------------------------------- merge_solver.rs:110-223 (round 4: four and five inputs)
+def variant_delta_length(variants):  # :211-223
+    total = 0
+    for v in variants:
+        if v["zyg"] == "Unknown":
+            raise SolverError("BAD_ZYGOSITY")
+        total += (len(v["a1"]) - len(v["a0"])) * zyg_count(v["zyg"])
+    return total
+
+
+def solve_merge_region(reference, region, no_conflict_enabled, majority_voting_enabled, conflict_selection, max_branch=50):
+    inputs = region["inputs"]
+    k = len(inputs)
+    delta = [variant_delta_length(v) for v in inputs]
+    all_identical, no_conflict = True, True
+    match_sets = [set([i]) for i in range(k)]
+    for i in range(k):
+        for j in range(i + 1, k):
+            if delta[i] == delta[j]:
+                best = optimize_sequences(reference, region["start"], region["end"], inputs[i], [v["zyg"] for v in inputs[i]], inputs[j], [v["zyg"] for v in inputs[j]], max_branch)[0]
+                exact = best["ed1"] == 0 and best["ed2"] == 0 and best["tvs1"] == 0 and best["tvs2"] == 0 and best["qvs1"] == 0 and best["qvs2"] == 0  # is_exact_match, query_optimizer.rs:96-98
+            else:
+                exact = False
+            all_identical = all_identical and exact
+            no_conflict = no_conflict and (not inputs[i] or not inputs[j] or exact)
+            if exact:
+                match_sets[i].add(j)
+                match_sets[j].add(i)
+    maj_count = k // 2 + 1
+    first_maj = next((sorted(m) for m in match_sets if len(m) >= maj_count), [])
+    if all_identical:
+        return ["BasepairIdentical"]
+    if no_conflict_enabled and no_conflict:
+        return ["NoConflict", [i for i, v in enumerate(inputs) if v]]
+    if majority_voting_enabled and first_maj:
+        return ["MajorityAgree", first_maj]
+    if conflict_selection is not None:
+        return ["ConflictSelection", conflict_selection]
+    return ["Different"]
+
+
+def merge_scenarios():
+    r = random.Random(20251004)
+    contig = rand_seq(r, 3000)
+    ZY = ["UnphasedHeterozygous", "PhasedHet01", "PhasedHet10", "HomozygousAlternate"]
+    regions = []
+    for n in range(36):
+        k = 4 + n % 2
+        L = r.randrange(50, 140)
+        start = 10 + 80 * n
+        end = start + L
+
+        def rv():
+            kind = r.randrange(3)
+            p = r.randrange(start + 2, end - 8)
+            if kind == 0:
+                return V(p, contig[p:p + 1], bytes([other_base(contig[p], r)]), "Snv", r.choice(ZY))
+            if kind == 1:
+                return V(p, contig[p:p + 1], contig[p:p + 1] + rand_seq(r, r.randrange(1, 4)), "Insertion", r.choice(ZY))
+            return V(p, contig[p:p + r.randrange(2, 5)], contig[p:p + 1], "Deletion", r.choice(ZY))
+        base = sorted([rv() for _ in range(r.randrange(1, 4))], key=lambda v: v["pos"])
+
+        def unphase(vs):  # the same calls written by another caller: phase dropped (still an exact match: the search finds the orientation)
+            return [dict(v, zyg="UnphasedHeterozygous" if v["zyg"].startswith("PhasedHet") and r.random() < 0.7 else v["zyg"]) for v in vs]
+        inputs = []
+        for i in range(k):
+            u = r.random() if n % 6 else 0.0  # (every sixth region: all callers agree)
+            if u < 0.45:
+                inputs.append(unphase(base))
+            elif u < 0.6:
+                inputs.append([])                                   # a caller without calls here
+            elif u < 0.8:
+                other = [dict(v) for v in base]
+                w = r.randrange(len(other))
+                other[w] = dict(other[w], zyg=r.choice([z for z in ZY if zyg_count(z) != zyg_count(other[w]["zyg"])] or ZY))  # another genotype
+                inputs.append(other)
+            else:
+                inputs.append(sorted([rv() for _ in range(r.randrange(1, 3))], key=lambda v: v["pos"]))  # unrelated calls
+        regions.append(dict(start=start, end=end, inputs=inputs))
+    configs = [dict(no_conflict_enabled=False, majority_voting_enabled=False, conflict_selection=None), dict(no_conflict_enabled=False, majority_voting_enabled=True, conflict_selection=None),
+               dict(no_conflict_enabled=True, majority_voting_enabled=True, conflict_selection=None), dict(no_conflict_enabled=True, majority_voting_enabled=False, conflict_selection=2)]
+    return contig, regions, configs
 
 
 def main():
@@ -714,6 +885,17 @@ def main():
     json.dump(dict(source="tests/golden/make_crosscheck.py: an independent Python restatement of the reference solver (see its header for the lines it follows)", scenarios=fixtures),
               open(os.path.join(here, "crosscheck.json"), "w"), indent=None, separators=(",", ":"))
     print("wrote crosscheck.json")
+    contig, regions, configs = merge_scenarios()
+    out = []
+    for cfg in configs:
+        out.append(dict(config=cfg, expect=[solve_merge_region(contig, reg, **cfg) for reg in regions]))
+    kinds = sorted(set(e[0] for c in out for e in c["expect"]))
+    print("merge: %d regions of 4 / 5 inputs x %d configurations: classifications %s" % (len(regions), len(configs), kinds))
+    json.dump(dict(source="tests/golden/make_crosscheck.py: solve_merge_region (merge_solver.rs:110-223) restated on top of the same script's optimize_sequences", contig=contig.decode("latin1"),
+                   regions=[dict(start=reg["start"], end=reg["end"], inputs=[[[v["pos"], v["a0"].decode("latin1"), v["a1"].decode("latin1"), v["type"], v["zyg"], v["raw"]] for v in inp]
+                                                                             for inp in reg["inputs"]]) for reg in regions], cases=out),
+              open(os.path.join(here, "merge_crosscheck.json"), "w"), indent=None, separators=(",", ":"))
+    print("wrote merge_crosscheck.json")
 
 
 if __name__ == "__main__":

@@ -146,3 +146,54 @@ def test_device_merge_path_kernel_logic(oracle):
     for cfg in (MergeConfig(), MergeConfig(majority_voting_enabled=True), MergeConfig(no_conflict_enabled=True, conflict_selection=1)):
         want = solve_merge_regions(lambda b, mbf: oracle_lib.optimize_pairs(oracle, b, contigs, max_branch_factor=mbf, threads=8), multi, cfg)
         assert device_merge(multi, contigs, cfg) == want
+
+
+XMERGE = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "merge_crosscheck.json")))
+
+
+def xmerge_regions():
+    conv = lambda vs: [(v[0], v[1].encode("latin1"), v[2].encode("latin1"), v[3], v[4], v[5]) for v in vs]
+    return [{"start": r["start"], "end": r["end"], "inputs": [conv(i) for i in r["inputs"]]} for r in XMERGE["regions"]]
+
+
+XNAMES = {"BasepairIdentical": "identical", "NoConflict": "no_conflict", "MajorityAgree": "majority", "ConflictSelection": "conflict_select", "Different": "different"}
+
+
+def xmerge_expect(case):
+    """the restatement names the reference's MergeClassification variants (merge_benchmark.rs:5-14); the library's decoded form uses its own short names"""
+    return [(0, (XNAMES[e[0]],) if len(e) == 1 else (XNAMES[e[0]], e[1])) for e in case["expect"]]
+
+
+def test_four_and_five_input_regions_against_the_independent_restatement(oracle):
+    """solve_merge_region (merge_solver.rs:110-223) on regions of four and five call sets, four strategy settings: the answers of the second, independently written
+    restatement (tests/golden/make_crosscheck.py) from the oracle's pairs + the library's classification, and from the device path's kernel logic"""
+    contig = [XMERGE["contig"].encode("latin1")]
+    multi = xmerge_regions()
+    kinds = set()
+    for case in XMERGE["cases"]:
+        cfg = MergeConfig(**case["config"])
+        want = xmerge_expect(case)
+        kinds |= {w[1][0] for w in want}
+        for n_inputs in (4, 5):  # (the regions of one call have one input count)
+            idx = [i for i, r in enumerate(multi) if len(r["inputs"]) == n_inputs]
+            sub, sub_want = [multi[i] for i in idx], [want[i] for i in idx]
+            assert solve_merge_regions(lambda b, mbf: oracle_lib.optimize_pairs(oracle, b, contig, max_branch_factor=mbf, threads=4), sub, cfg) == sub_want
+            assert solve_merge_regions(lambda b, mbf: emu_lib.optimize_pairs(b, contig, mbf, threads=8), sub, cfg) == sub_want
+    assert {"identical", "no_conflict", "majority", "conflict_select", "different"} <= kinds
+
+
+@pytest.mark.gpu
+def test_four_and_five_input_regions_on_the_gpu():
+    import aardvark_amd
+    from aardvark_amd.merge import merge_batch
+    ctx = aardvark_amd.Context(0)
+    try:
+        ctx.upload_reference([XMERGE["contig"].encode("latin1")])
+        multi = xmerge_regions()
+        for n_inputs in (4, 5):  # (a batch has one input count)
+            idx = [i for i, r in enumerate(multi) if len(r["inputs"]) == n_inputs]
+            for case in XMERGE["cases"]:
+                want = xmerge_expect(case)
+                assert merge_batch(ctx, [multi[i] for i in idx], MergeConfig(**case["config"])) == [want[i] for i in idx]
+    finally:
+        ctx.close()

@@ -78,6 +78,8 @@ def test_fixture_reaches_the_unpinned_behaviours(oracle):
     types = {v[3] for r in names["sv_tr_types"]["regions"] for v in r["truth"] + r["query"]}
     assert {"SvInsertion", "SvDeletion", "TrExpansion", "TrContraction", "SvDuplication", "Indel"} <= types
     assert sum(s["generator_stats"]["quota_drops"] for s in FIX["scenarios"] if s["name"].startswith("quota")) > 800
+    assert max(e["n_optima"] for e in names["het_clusters_mbf50"]["expect"]) >= 8  # tied optima: their order decides the winner
+    assert names["het_clusters_mbf3"]["generator_stats"]["quota_drops"] > 100
     assert names["autofail_homopolymer"]["generator_stats"]["autofail_prunings"] >= 5
     small, large = names["quota_repeats_mbf1"]["expect"], names["quota_repeats_mbf50"]["expect"]
     assert sum(a["ed1"] + a["ed2"] != b["ed1"] + b["ed2"] or a["groups"] != b["groups"] for a, b in zip(small, large)) >= 3  # the quota changes answers
@@ -89,6 +91,17 @@ def test_kernel_logic_reproduces_the_independent_restatement(lane_kernel):
         batch = batch_of(sc)
         got = emu_lib.compare_batch(batch, [sc["contig"].encode("latin1")], max_branch_factor=sc["max_branch_factor"], sequences=True, lane_kernel=lane_kernel, threads=8)
         check(sc, got, batch)
+
+
+def test_wide_kernel_logic_reproduces_the_independent_restatement():
+    """the wave-cooperative kernel (avk_wide.inl) on the same answers: every region planned as class C, no sequence output (it writes none)"""
+    solved = 0
+    for sc in FIX["scenarios"]:
+        batch = batch_of(sc)
+        got = emu_lib.compare_batch(batch, [sc["contig"].encode("latin1")], max_branch_factor=sc["max_branch_factor"], lane_kernel=False, class_c_all=True, wide_lds_bytes=40 * 1024, threads=8)
+        check(sc, got, batch, sequences=False)
+        solved += got.wide_solved
+    assert solved >= 200  # (long alleles, more than eight calls on a side, SV types with 40-base alleles: the wave-per-region code's)
 
 
 @pytest.mark.gpu
@@ -109,5 +122,16 @@ def test_gpu_reproduces_the_independent_restatement(lane_kernel):
             check(sc, got, batch)
             got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False, max_branch_factor=sc["max_branch_factor"]))
             check(sc, got, batch, sequences=False)
+        if not lane_kernel:  # once more with every region planned as class C: the wave-cooperative kernel sees it first
+            ctx.set_option("class_c_nodes_x2", 1000)
+            ctx.set_option("wide_lds_bytes", 40 * 1024)
+            solved = 0
+            for sc in FIX["scenarios"]:
+                batch = batch_of(sc)
+                ctx.upload_reference([sc["contig"].encode("latin1")])
+                got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False, max_branch_factor=sc["max_branch_factor"]))
+                check(sc, got, batch, sequences=False)
+                solved += ctx.last_wide_solved()
+            assert solved >= 100
     finally:
         ctx.close()
