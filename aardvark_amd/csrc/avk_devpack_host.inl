@@ -501,6 +501,42 @@ static void pool_release(avk_ctx *ctx, void *p) {
     }
 }
 
+/* avk_ctx_warmup: the buffers a device-packed batch of about n regions / nv calls takes from the pool, allocated, written once (fresh device memory is scrubbed
+ * when it is first touched: 2.5 GB of them made the packing kernels of a process's first whole-genome call take 16 ms instead of 1.5) and put back.  A later
+ * request takes a cached buffer that is at least as large and at most twice as large (pool_alloc): the sizes only have to be about right. */
+static int pool_prewarm(avk_ctx *ctx, uint64_t n, uint64_t nv) {
+    std::vector<size_t> sizes;
+    auto add = [&](size_t bytes, int count) {
+        for (int i = 0; i < count; ++i) sizes.push_back(bytes);
+    };
+    add((size_t)(n + 1) * 8, 5);   /* start, end, t_off, q_off, seq_off */
+    add((size_t)(n + 1) * 4, 16);  /* counts, contig, per-region offsets, work order, the eight hand-over lists */
+    add((size_t)(n + 1) * sizeof(dpk::DpRegionInfo), 1);
+    add((size_t)(n + 1) * sizeof(AvkDevRegion), 1);
+    add((size_t)n * 16 + 16, 2);   /* region records out, their caller-order form */
+    add((size_t)n * 20 + 4, 1);
+    add((size_t)(nv + 1) * 8, 3);  /* positions, allele offsets */
+    add((size_t)(nv + 1) * 4, 5);  /* allele lengths, raw space, per-call words out and their caller-order form */
+    add((size_t)nv + 16, 3);
+    add((size_t)(nv + 1) * sizeof(dpk::DpVarInfo), 1);
+    add((size_t)n * 190, 1);       /* region blobs: 2.2 calls per region */
+    add((size_t)n * 52, 1);        /* fast records */
+    add((size_t)nv * 3 + 16, 1);   /* allele bytes */
+    add((size_t)n * 10 + 16, 1);   /* the packed form's region and call records */
+    add((size_t)nv * 5 + 16, 1);
+    std::vector<void *> got;
+    int rc = 0;
+    for (size_t s : sizes) {
+        void *p = nullptr;
+        rc = pool_alloc(ctx, &p, s);
+        if (rc) break;
+        got.push_back(p);
+        if (hipMemsetAsync(p, 0, s, ctx->stream) != hipSuccess) (void)hipGetLastError();
+    }
+    for (void *p : got) pool_release(ctx, p);
+    return rc;
+}
+
 static void pool_destroy(avk_ctx *ctx) {
     for (auto &b : ctx->pool) (void)hipFree(b.p);
     ctx->pool.clear();

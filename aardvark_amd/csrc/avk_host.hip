@@ -2262,11 +2262,66 @@ int avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants) {
 /* What a process's FIRST large call pays for beyond the call itself, done ahead of it (a tool: on a thread beside its parsing): the device code is brought in by a
  * launch of nothing, the table of the looked-up class is made for the default branch factor, and the workspaces of a batch of that size are allocated (7 GB for a
  * genome; fresh device memory is scrubbed when it is handed out).  Nothing here changes a result; every step is also made on demand by the call that needs it. */
+/* a small call through every kind of launch on a context of its own (the caller's may be taking its reference at this moment): a kernel's FIRST launch in a
+ * process costs about a millisecond — the dozen packing kernels of a first whole-genome call took 16 ms instead of 1.5 */
+static void warm_kernels(int device) {
+    avk_ctx *t = nullptr;
+    if (avk_ctx_create(device, &t) || !t) return;
+    const char *opts[] = {"lane_min_regions", "lane_min_batch", "emit_group_metrics"};
+    for (const char *o : opts) (void)avk_ctx_set_option(t, o, 0);
+    (void)avk_ctx_set_option(t, "class_c_nodes_x2", 1000); /* every region the lanes do not take is planned as class C: the wide kernel, the HBM launches */
+    (void)avk_ctx_set_option(t, "lane_node_cap", 4);       /* ... and the three-call class hands back */
+    const uint32_t L = 120, n_contig = 1u << 16;
+    std::vector<uint8_t> contig(n_contig);
+    uint32_t x = 12345u;
+    for (uint32_t i = 0; i < n_contig; ++i) {
+        x = x * 1664525u + 1013904223u;
+        contig[i] = "ACGT"[x >> 30];
+    }
+    std::vector<uint32_t> start;
+    std::vector<uint16_t> len, rel;
+    std::vector<uint8_t> tc, qc, tz, a0l, a1l, alle;
+    auto other = [](uint8_t b) { return (uint8_t)(b == 'A' ? 'C' : 'A'); };
+    for (uint32_t r = 0; r < 448; ++r) { /* calls per side: 1 (the looked-up class and its neighbours), 2, 3, 5 */
+        const uint32_t per = r < 256 ? 1u : (r < 320 ? 2u : (r < 384 ? 3u : 5u)), s0 = 100u + r * 140u;
+        start.push_back(s0), len.push_back((uint16_t)L), tc.push_back((uint8_t)per), qc.push_back((uint8_t)per);
+        for (uint32_t side = 0; side < 2; ++side)
+            for (uint32_t k = 0; k < per; ++k) {
+                const uint32_t p = 10u + 20u * k;
+                rel.push_back((uint16_t)p);
+                tz.push_back((uint8_t)(AVK_VT_SNV | ((r & 1u ? AVK_ZYG_UNPHASED_HET : AVK_ZYG_HOM_ALT) << 4)));
+                a0l.push_back(1), a1l.push_back(1);
+                alle.push_back(contig[s0 + p]);
+                alle.push_back(side && (r & 2u) && k == 0 ? (uint8_t)(other(contig[s0 + p]) == 'C' ? 'G' : 'T') : other(contig[s0 + p]));
+            }
+    }
+    avk_packed_batch b;
+    memset(&b, 0, sizeof(b));
+    b.n_regions = start.size(), b.start = start.data(), b.len = len.data(), b.t_cnt = tc.data(), b.q_cnt = qc.data();
+    b.n_variants = rel.size(), b.var_rel_pos = rel.data(), b.var_type_zyg = tz.data(), b.a0_len = a0l.data(), b.a1_len = a1l.data();
+    b.allele_bytes = alle.data(), b.allele_bytes_len = alle.size();
+    std::vector<int32_t> status(b.n_regions);
+    std::vector<uint32_t> e1(b.n_regions), e2(b.n_regions), no(b.n_regions);
+    std::vector<uint16_t> tp(b.n_regions);
+    std::vector<uint8_t> ve(b.n_variants), vo(b.n_variants), vc(b.n_variants), vz(b.n_variants);
+    std::vector<uint64_t> tally(AVK_TALLY_LEN);
+    avk_result_batch out;
+    memset(&out, 0, sizeof(out));
+    out.status = status.data(), out.ed_h1 = e1.data(), out.ed_h2 = e2.data(), out.n_optima = no.data(), out.type_present = tp.data();
+    out.var_expected = ve.data(), out.var_observed = vo.data(), out.var_class = vc.data(), out.var_zyg = vz.data(), out.tally = tally.data();
+    const uint8_t *seqs[1] = {contig.data()};
+    const uint64_t lens[1] = {n_contig};
+    avk_compare_config cfg = {50, 0, 0};
+    if (avk_ref_upload(t, 1, seqs, lens) == 0) (void)avk_compare_packed(t, &b, &cfg, &out);
+    avk_ctx_destroy(t);
+}
+
 int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hint) {
     if (!ctx) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     int rc = avk_ctx_reserve(ctx, n_regions_hint, n_variants_hint);
     if (rc) return rc;
+    warm_kernels(ctx->device);
     unsigned *d_scratch = nullptr;
     AVK_HIP(ctx, hipMalloc((void **)&d_scratch, (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1) * sizeof(uint64_t) + AVK_N_COUNTERS * sizeof(uint32_t)));
     AVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1) * sizeof(uint64_t) + AVK_N_COUNTERS * sizeof(uint32_t), ctx->stream));
@@ -2285,7 +2340,15 @@ int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hi
             return rc;
         }
     }
-    if (n_regions_hint >= 65536 && ctx->ws_bytes_per_wave > 0) { /* the workspaces run_internal sizes for a batch of a genome's size (its lane classes leave a few thousand regions) */
+    if (ctx->device_pack && n_regions_hint >= 65536 && getenv("AVK_WARM_POOL")) { /* (measured in the tool: the 2.5 GB of buffers and the 7 GB of workspaces below take longer
+                                                                                        than the parsing they run beside — the solve stage waited for them; off unless asked for) */
+        rc = pool_prewarm(ctx, n_regions_hint, n_variants_hint);
+        if (rc) {
+            (void)hipFree(d_scratch);
+            return rc;
+        }
+    }
+    if (n_regions_hint >= 65536 && ctx->ws_bytes_per_wave > 0 && getenv("AVK_WARM_POOL")) { /* the workspaces run_internal sizes for a batch of a genome's size (its lane classes leave a few thousand regions) */
         const size_t waves = ((size_t)ctx->n_cus * 3u + (size_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128) + (size_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64)) * 4u;
         const size_t ws_need = waves * (size_t)ctx->ws_bytes_per_wave;
         if (ws_need > ctx->ws_alloc && (double)ws_need <= (double)ctx->ws_budget_bytes) {

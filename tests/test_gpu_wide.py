@@ -91,7 +91,7 @@ def test_hand_backs_of_the_three_call_lane_class_and_class_c_of_a_genome_slice()
     try:
         ctx.set_option("emit_group_metrics", 0)
         ctx.upload_reference(contigs)
-        got = ctx.solve_compare_regions(batch, CompareConfig(), group_metrics=False)
+        got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False)
         assert got.diff(want) == []
         assert ctx.last_wide_solved() > 100
     finally:

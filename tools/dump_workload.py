@@ -1,5 +1,5 @@
 """Writes the benchmark workload (aardvark_amd/synth.py::config_genome) as one flat file for the C++ harnesses (tools/first_step_probe.cpp).
-usage: python tools/dump_workload.py <scale> <out file> [gap=50] [dense=0]
+usage: python tools/dump_workload.py <scale> <out file> [gap=50] [dense=0] [shards=1]   (shards = K: rank 0's hash shard of K, aardvark_amd/dist.py)
 layout (little endian): u64 magic 'AVKWORK1', u64 n_contigs, u64 len[n_contigs], contig bytes (each padded to 16), u64 n_regions, u64 n_variants,
 u64 allele_bytes_len, then the arrays of avk_region_batch in declaration order, each padded to 16 bytes"""
 import os, sys
@@ -13,6 +13,9 @@ out = sys.argv[2]
 gap = int(sys.argv[3]) if len(sys.argv) > 3 else 50
 kw = dict(close_frac=0.10, str_frac=0.15, multi_frac=0.05) if len(sys.argv) > 4 and sys.argv[4] == "1" else {}
 contigs, b = synth.config_genome(scale=scale, threads=8, gap=gap, **kw)
+if len(sys.argv) > 5 and int(sys.argv[5]) > 1:
+    from aardvark_amd import dist as avk_dist
+    b = avk_dist.gather_calls(avk_dist.shard_batch(b, 0, int(sys.argv[5])))
 
 
 def pad(f):
