@@ -137,6 +137,8 @@ class AvkResultBatch(C.Structure):
         ("tally", _p(C.c_uint64)),
         ("bp_off", _p(C.c_uint32)),
         ("bp_groups", _p(C.c_uint32)),
+        ("region_packed", _p(C.c_uint64)),
+        ("var_packed", _p(C.c_uint8)),
     ]
 
 
@@ -360,20 +362,27 @@ class PackedBatch:
 class ResultBatch:
     """Caller-allocated outputs of one avk_compare_batch / orc_compare_batch call."""
 
-    def __init__(self, batch, sequences=False, group_metrics=True, bp_groups=False):
+    WIDE_REGION = (("status", np.int32), ("ed_h1", np.uint32), ("ed_h2", np.uint32), ("n_optima", np.uint32), ("type_present", np.uint16))
+    WIDE_CALL = ("var_expected", "var_observed", "var_class", "var_zyg")
+
+    def __init__(self, batch, sequences=False, group_metrics=True, bp_groups=False, packed=False):
+        """packed: False = the wide arrays; True = the wide arrays and the packed form (avk_result_batch::region_packed / var_packed); "only" = the packed form
+        alone — 8 bytes per region and 1 per call cross PCIe, the wide arrays are None until expand()"""
         n, v = batch.n_regions, batch.n_variants
+        self.n_regions, self.n_variants = n, v
         self.bp_off = np.zeros(n + 1, np.uint32) if bp_groups else None       # compact per-region BASEPAIR groups (avk_result_batch::bp_off / bp_groups)
         self.bp_groups = np.zeros((n + v + 1, 4), np.uint32) if bp_groups else None
-        self.status = np.full(n, -1, np.int32)
-        self.ed_h1 = np.zeros(n, np.uint32)
-        self.ed_h2 = np.zeros(n, np.uint32)
-        self.n_optima = np.zeros(n, np.uint32)
-        self.type_present = np.zeros(n, np.uint16)
+        wide = packed != "only"
+        self.status = np.full(n, -1, np.int32) if wide else None
+        self.ed_h1 = np.zeros(n, np.uint32) if wide else None
+        self.ed_h2 = np.zeros(n, np.uint32) if wide else None
+        self.n_optima = np.zeros(n, np.uint32) if wide else None
+        self.type_present = np.zeros(n, np.uint16) if wide else None
         self.group_metrics = np.zeros((n, N_GROUPS, N_FIELDS), np.uint32) if group_metrics else None
-        self.var_expected = np.zeros(max(v, 1), np.uint8)
-        self.var_observed = np.zeros(max(v, 1), np.uint8)
-        self.var_class = np.zeros(max(v, 1), np.uint8)
-        self.var_zyg = np.zeros(max(v, 1), np.uint8)
+        for f in self.WIDE_CALL:
+            setattr(self, f, np.zeros(max(v, 1), np.uint8) if wide else None)
+        self.region_packed = np.full(max(n, 1), 0x7F, np.uint64) if packed else None
+        self.var_packed = np.zeros(max(v, 1), np.uint8) if packed else None
         self.tally = np.zeros(TALLY_LEN, np.uint64)
         self.sequences = sequences
         if sequences:
@@ -387,17 +396,22 @@ class ResultBatch:
 
     def c_struct(self):
         o = AvkResultBatch()
-        o.status = _ptr(self.status, C.c_int32)
-        o.ed_h1 = _ptr(self.ed_h1, C.c_uint32)
-        o.ed_h2 = _ptr(self.ed_h2, C.c_uint32)
-        o.n_optima = _ptr(self.n_optima, C.c_uint32)
-        o.type_present = _ptr(self.type_present, C.c_uint16)
+        if self.status is not None:
+            o.status = _ptr(self.status, C.c_int32)
+            o.ed_h1 = _ptr(self.ed_h1, C.c_uint32)
+            o.ed_h2 = _ptr(self.ed_h2, C.c_uint32)
+            o.n_optima = _ptr(self.n_optima, C.c_uint32)
+            o.type_present = _ptr(self.type_present, C.c_uint16)
         if self.group_metrics is not None:
             o.group_metrics = _ptr(self.group_metrics, C.c_uint32)
-        o.var_expected = _ptr(self.var_expected, C.c_uint8)
-        o.var_observed = _ptr(self.var_observed, C.c_uint8)
-        o.var_class = _ptr(self.var_class, C.c_uint8)
-        o.var_zyg = _ptr(self.var_zyg, C.c_uint8)
+        if self.var_expected is not None:
+            o.var_expected = _ptr(self.var_expected, C.c_uint8)
+            o.var_observed = _ptr(self.var_observed, C.c_uint8)
+            o.var_class = _ptr(self.var_class, C.c_uint8)
+            o.var_zyg = _ptr(self.var_zyg, C.c_uint8)
+        if self.region_packed is not None:
+            o.region_packed = _ptr(self.region_packed, C.c_uint64)
+            o.var_packed = _ptr(self.var_packed, C.c_uint8)
         o.tally = _ptr(self.tally, C.c_uint64)
         if self.bp_off is not None:
             o.bp_off = _ptr(self.bp_off, C.c_uint32)
@@ -408,6 +422,23 @@ class ResultBatch:
             o.seq_stride = _ptr(self.seq_stride, C.c_uint32)
             o.seq_len = _ptr(self.seq_len, C.c_uint32)
         return o
+
+    def expanded(self, lib, batch):
+        """avk_results_expand: a ResultBatch with the wide arrays rebuilt from this one's packed form (host work, no GPU involved); group_metrics,
+        bp_groups, tally and sequences are shared with this one"""
+        import copy
+        out = copy.copy(self)
+        n, v = self.n_regions, self.n_variants
+        for f, dt in self.WIDE_REGION:
+            setattr(out, f, np.full(n, -1, dt) if f == "status" else np.zeros(n, dt))
+        for f in self.WIDE_CALL:
+            setattr(out, f, np.zeros(max(v, 1), np.uint8))
+        cb, src, dst = batch.c_struct(), self.c_struct(), out.c_struct()
+        lib.avk_results_expand.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(AvkResultBatch), C.POINTER(AvkResultBatch)]
+        rc = lib.avk_results_expand(C.byref(cb), C.byref(src), C.byref(dst))
+        if rc != 0:
+            raise ValueError("avk_results_expand: %d" % rc)
+        return out
 
     def sequence(self, r, k):
         off = int(self.seq_off[r]) + k * int(self.seq_stride[r])

@@ -222,16 +222,22 @@ class Context:
         self._check(self.lib.avk_compare_compact(self.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
         return res
 
-    def pinned_results(self, batch, group_metrics=False, bp_groups=False):
-        """a ResultBatch whose arrays live in pinned memory"""
-        res = ResultBatch(batch, sequences=False, group_metrics=group_metrics, bp_groups=bp_groups)
-        for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg") + (("group_metrics",) if group_metrics else ()) + \
-                (("bp_off", "bp_groups") if bp_groups else ()):
+    def pinned_results(self, batch, group_metrics=False, bp_groups=False, packed=False):
+        """a ResultBatch whose arrays live in pinned memory (packed: as ResultBatch)"""
+        res = ResultBatch(batch, sequences=False, group_metrics=group_metrics, bp_groups=bp_groups, packed=packed)
+        for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg", "region_packed", "var_packed",
+                  "group_metrics", "bp_off", "bp_groups"):
             a = getattr(res, f)
+            if a is None:
+                continue
             b = self.host_array(a.shape, a.dtype)
             b[...] = a
             setattr(res, f, b)
         return res
+
+    def expand_results(self, res, batch):
+        """the wide arrays of a ResultBatch that holds the packed form (avk_results_expand)"""
+        return res.expanded(self.lib, batch)
 
     def __del__(self):
         try:
@@ -259,10 +265,10 @@ class Context:
         self._check(self.lib.avk_ref_upload(self.handle, len(arrs), ptrs, lens))
         self._contigs = arrs
 
-    def solve_compare_regions(self, batch, config=None, group_metrics=True, bp_groups=False):
+    def solve_compare_regions(self, batch, config=None, group_metrics=True, bp_groups=False, packed=False):
         """solve_compare_region for every region of `batch` -> ResultBatch."""
         config = config or CompareConfig()
-        res = ResultBatch(batch, sequences=bool(config.enable_sequences), group_metrics=group_metrics, bp_groups=bp_groups)
+        res = ResultBatch(batch, sequences=bool(config.enable_sequences), group_metrics=group_metrics, bp_groups=bp_groups, packed=packed)
         cb, cfg, ro = batch.c_struct(), config.c_struct(), res.c_struct()
         self._check(self.lib.avk_compare_batch(self.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
         return res
@@ -276,8 +282,8 @@ class Context:
         cfg = config.c_struct()
         self._check(self.lib.avk_compare_resident(self.handle, rb.handle, C.byref(cfg), C.c_void_p(tally_dev_ptr or 0)))
 
-    def download(self, rb, sequences=False, group_metrics=True):
-        res = ResultBatch(rb.batch, sequences=sequences, group_metrics=group_metrics)
+    def download(self, rb, sequences=False, group_metrics=True, packed=False):
+        res = ResultBatch(rb.batch, sequences=sequences, group_metrics=group_metrics, packed=packed)
         ro = res.c_struct()
         self._check(self.lib.avk_results_download(self.handle, rb.handle, C.byref(ro)))
         return res
@@ -360,8 +366,9 @@ def group_metrics_from_compact(batch, res):
     lib = load_library()
     out = np.zeros((batch.n_regions, 13, 22), np.uint32)
     cb, ro = batch.c_struct(), res.c_struct()
+    status = res.status if res.status is not None else (res.region_packed & np.uint64(0x7F))
     for r in range(batch.n_regions):
-        if res.status[r] != 0:
+        if status[r] != 0:
             continue
         rc = lib.avk_group_metrics_from_compact(C.byref(cb), r, C.byref(ro), out[r].ctypes.data_as(C.POINTER(C.c_uint32)))
         if rc != 0:

@@ -77,7 +77,7 @@ struct DpVarInfo {
     u32 alt_ed, flags, a1lo, a1hi;
 };
 
-/* per region, written by dp_region (16-byte aligned, 48 bytes) */
+/* per region, written by dp_region (64 bytes: two sectors, read whole by the record writers) */
 struct DpRegionInfo {
     u32 pre_status; /* as AvkDevRegion::pre_status */
     u32 len;
@@ -85,7 +85,14 @@ struct DpRegionInfo {
     u32 keys; /* fast_class | fast_key << 8 | plan class (0 C, 1 B, 2 bulk) << 16 | min(N, 255) << 24 */
     u64 ref_off;
     u32 bucket; /* final bucket of the work order (dp_hist) */
-    u32 pad_;
+    u32 counts; /* candidates of the lane classes: truth calls | query calls << 8 (what dp_fast_record needs of the caller's region arrays, ... */
+    u32 t_first, q_first; /* ... with the index of the side's first call) */
+    u32 pad_[2];
+};
+/* per call of a candidate of the lane classes, written by dp_region: the call slot of its fast record as it will be stored (avk_dev_types.h) — dp_fast_record, which
+ * visits the regions in work order, then reads 16 bytes per call instead of eight arrays of the caller's */
+struct DpSlot {
+    u32 w[4];
 };
 
 /* small shared state of one packing run */
@@ -123,6 +130,7 @@ struct DpArgs {
     u32 *bp_off;        /* [n_regions + 1] first compact BASEPAIR group of a region (1 + its call types groups each; none for regions that fail validation) */
     u32 *order;         /* [n_regions] work order: record k holds region order[k] */
     u32 *big_list;      /* [n_regions] work-order indices of regions with more than DP_SMALL_N calls */
+    DpSlot *slots;      /* [n_variants] */
     /* outputs */
     AvkDevRegion *regions;
     u32 *blob;
@@ -499,7 +507,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     if (r >= a.in.n_regions) return;
     const DpIn &in = a.in;
     DpRegionInfo ri;
-    ri.pre_status = 0, ri.len = 0, ri.alle_bytes = 0, ri.blob_bytes = 0, ri.grow = 0, ri.ed_bound = 0, ri.seq_stride = 1, ri.keys = 2u << 16, ri.ref_off = 0, ri.bucket = 0, ri.pad_ = 0;
+    ri.pre_status = 0, ri.len = 0, ri.alle_bytes = 0, ri.blob_bytes = 0, ri.grow = 0, ri.ed_bound = 0, ri.seq_stride = 1, ri.keys = 2u << 16, ri.ref_off = 0, ri.bucket = 0, ri.counts = 0, ri.t_first = 0, ri.q_first = 0, ri.pad_[0] = ri.pad_[1] = 0;
     const u32 tc = in.t_cnt[r], qc = in.q_cnt[r];
     const u64 toff = in.t_off[r], qoff = in.q_off[r], nv = in.n_variants;
     if (toff > nv || (u64)tc > nv - toff || qoff > nv || (u64)qc > nv - qoff) { /* pass 1 of pack_batch: the batch is rejected */
@@ -611,6 +619,20 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                                          calls[AVK_FAST_MAXV].raw, calls[0].lo, calls[AVK_FAST_MAXV].lo)) {
                 fast_class = (u32)AVK_FAST_PAIR + 1u;
                 fast_key = 0;
+            }
+            if (fast_class) { /* the call slots of its fast record */
+                ri.counts = tc | (qc << 8), ri.t_first = (u32)toff, ri.q_first = (u32)qoff;
+#pragma unroll
+                for (u32 sidx = 0; sidx < 2 * AVK_FAST_MAXV; ++sidx) {
+                    const u32 side = sidx / AVK_FAST_MAXV, j = sidx % AVK_FAST_MAXV;
+                    if (j >= (side ? qc : tc)) continue;
+                    const DpCall &k = calls[sidx];
+                    DpSlot sl;
+                    sl.w[0] = k.pos | (k.a0 << 8) | (k.a1 << 16) | ((k.type & 0xFu) << 24) | ((k.zyg & 7u) << 28);
+                    sl.w[1] = k.alt_ed | (k.raw << 8);
+                    sl.w[2] = k.lo, sl.w[3] = k.hi;
+                    *(avk_u4 *)&a.slots[(side ? qoff : toff) + j] = *(const avk_u4 *)&sl;
+                }
             }
         }
     }
@@ -735,7 +757,6 @@ AVK_DEV void dp_bucket_plan(const DpArgs &a) {
 /* ---- dp_fast_record: one record slot (class fc, tile, lane), build_fast_records of avk_pack.h ------------------------------------- */
 AVK_DEV void dp_fast_record(const DpArgs &a, u32 fc, u32 tile_in_class, u32 lane) {
     const DpState &s = *a.st;
-    const DpIn &in = a.in;
     const u32 maxv = AVK_FAST_CLASS[fc].maxv, rw = AVK_FAST_WORDS_OF(maxv);
     u32 *T = a.fast + s.fast_word_base[fc] + (u64)tile_in_class * rw * 64u + lane;
     const u32 k = tile_in_class * 64u + lane;
@@ -745,8 +766,7 @@ AVK_DEV void dp_fast_record(const DpArgs &a, u32 fc, u32 tile_in_class, u32 lane
     }
     const u32 r = a.order[s.fast_base[fc] + k];
     const DpRegionInfo ri = a.rinfo[r];
-    const u32 tc = in.t_cnt[r], qc = in.q_cnt[r];
-    const u64 start = in.start[r];
+    const u32 tc = ri.counts & 0xFFu, qc = ri.counts >> 8;
     u32 slot_pos[2 * AVK_FAST_MAXV];
     for (u32 q = 0; q < 2 * AVK_FAST_MAXV; ++q) slot_pos[q] = 0;
     for (u32 sidx = 0; sidx < 2 * AVK_FAST_MAXV; ++sidx) {
@@ -757,15 +777,9 @@ AVK_DEV void dp_fast_record(const DpArgs &a, u32 fc, u32 tile_in_class, u32 lane
             V[0] = V[64] = V[128] = V[192] = 0;
             continue;
         }
-        const u64 v = (side ? in.q_off[r] : in.t_off[r]) + j;
-        const u32 l0 = in.a0_len[v], l1 = in.a1_len[v];
-        const u32 raw = in.var_raw ? in.var_raw[v] : (l0 > l1 ? l0 : l1);
-        const DpVarInfo vi = a.vinfo[v];
-        slot_pos[sidx] = (u32)(in.var_pos[v] - start);
-        V[0] = slot_pos[sidx] | (l0 << 8) | (l1 << 16) | ((u32)(in.var_type[v] & 0xFu) << 24) | ((u32)(in.var_zyg[v] & 7u) << 28);
-        V[64] = vi.alt_ed | (raw << 8);
-        V[128] = vi.a1lo;
-        V[192] = vi.a1hi;
+        const avk_u4 sl = *(const avk_u4 *)&a.slots[(u64)(side ? ri.q_first : ri.t_first) + j]; /* written by dp_region */
+        slot_pos[sidx] = sl.x & 0xFFu;
+        V[0] = sl.x, V[64] = sl.y, V[128] = sl.z, V[192] = sl.w;
     }
     /* order_variants (query_optimizer.rs:372-381): stable merge by position, truth first on ties; bit d = depth d takes a query call */
     u32 ord = 0, i = 0, j = 0, d = 0;
@@ -975,16 +989,23 @@ struct DpOut {
     uint16_t *type_present;
     u8 *var_expected, *var_observed, *var_class, *var_zyg; /* any of them may be NULL */
     u32 mode; /* 1: the pair form — no per-call outputs */
+    u64 *region_packed; /* the packed form (avk_result_batch::region_packed / var_packed), or NULL; then status may be NULL too */
+    u8 *var_packed;
 };
 AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
     if (r >= o.n_regions) return;
     const avk_u4 w = *(const avk_u4 *)(o.region_out + 4 * r);
-    o.status[r] = (int32_t)w.x;
+    if (o.status) o.status[r] = (int32_t)w.x;
     if (o.ed_h1) o.ed_h1[r] = w.y;
     if (o.ed_h2) o.ed_h2[r] = w.z;
     if (o.n_optima) o.n_optima[r] = w.w & 0xFFFFu;
     if (o.type_present) o.type_present[r] = (uint16_t)(w.w >> 16);
-    if (o.mode != 0 || !(o.var_expected || o.var_observed || o.var_class || o.var_zyg)) return;
+    if (o.region_packed) { /* avk_rp_make of the public header */
+        const u64 e1 = w.y < AVK_RP_ED_MAX ? w.y : AVK_RP_ED_MAX, e2 = w.z < AVK_RP_ED_MAX ? w.z : AVK_RP_ED_MAX;
+        const u64 filtered = ((w.w >> 16) & AVK_FILTERED_TYPE_MASK) == AVK_FILTERED_TYPE_MASK ? 1u : 0u;
+        o.region_packed[r] = (u64)(w.x & 0x7Fu) | filtered << 7 | (u64)(w.w & 0xFFFFu) << 8 | e1 << 24 | e2 << 44;
+    }
+    if (o.mode != 0 || !(o.var_expected || o.var_observed || o.var_class || o.var_zyg || o.var_packed)) return;
     const u32 tc = o.t_cnt[r], qc = o.q_cnt[r];
     const u64 toff = o.t_off[r], qoff = o.q_off[r];
     if (toff > o.n_variants || (u64)tc > o.n_variants - toff || qoff > o.n_variants || (u64)qc > o.n_variants - qoff) return;
@@ -996,6 +1017,7 @@ AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
         if (o.var_observed) o.var_observed[hv] = (u8)((x >> 8) & 0xFF);
         if (o.var_class) o.var_class[hv] = (u8)((x >> 16) & 0xFF);
         if (o.var_zyg) o.var_zyg[hv] = (u8)(x >> 24);
+        if (o.var_packed) o.var_packed[hv] = (u8)((x & 3u) | ((x >> 8) & 3u) << 2 | ((x >> 24) & 7u) << 4);
     }
 }
 

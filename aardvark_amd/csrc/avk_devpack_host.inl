@@ -518,7 +518,7 @@ static int pool_prewarm(avk_ctx *ctx, uint64_t n, uint64_t nv) {
     add((size_t)(nv + 1) * 8, 3);  /* positions, allele offsets */
     add((size_t)(nv + 1) * 4, 5);  /* allele lengths, raw space, per-call words out and their caller-order form */
     add((size_t)nv + 16, 3);
-    add((size_t)(nv + 1) * sizeof(dpk::DpVarInfo), 1);
+    add((size_t)(nv + 1) * sizeof(dpk::DpVarInfo), 2); /* (and the call slots of the lane candidates) */
     add((size_t)n * 190, 1);       /* region blobs: 2.2 calls per region */
     add((size_t)n * 52, 1);        /* fast records */
     add((size_t)nv * 3 + 16, 1);   /* allele bytes */
@@ -794,6 +794,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.rinfo = (dpk::DpRegionInfo *)kept((n + 1) * sizeof(dpk::DpRegionInfo));
     a.st = (dpk::DpState *)kept(sizeof(dpk::DpState));
     a.pending = (uint32_t *)tmp((nv + 1) * 4);
+    a.slots = (dpk::DpSlot *)tmp((nv + 1) * sizeof(dpk::DpSlot));
     db->d_voff = (uint32_t *)kept((n + 1) * 4);
     a.v_off = db->d_voff;
     a.blob_off8 = (uint32_t *)kept((n + 1) * 4);
@@ -1112,12 +1113,18 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     db->d_overflow7 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow8 = (uint32_t *)kept((n + 1) * 4);
     if (hs->n_fast_total) db->d_fast = (uint32_t *)kept(((size_t)hs->fast_words + 64) * 4);
+    /* the packer's arguments in device memory: the waves that solve handed-back regions write their records themselves */
+    if (hs->n_fast_total) db->d_dp_args = (dpk::DpArgs *)kept(sizeof(dpk::DpArgs));
     if (rc) return bail(rc);
+    a.regions = db->d_regions, a.blob = db->d_blob, a.fast = db->d_fast;
+    db->dp_args = a;
     const bool clear_beside = n >= 262144; /* (a small batch: the two events between the streams cost more than the fills, 1.16 instead of 0.98 ms per 46,000-region call) */
     if (clear_beside) { /* the batch's partial tallies and counters are cleared beside the writers, on a side stream (in front of the solver launches the two fills took 55 us) */
         hipStream_t side = ctx->lane_stream4;
         hipError_t ez = hipEventRecord(ctx->ev_copy_fork, s); /* the buffers may have been another batch's until here */
         if (ez == hipSuccess) ez = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0);
+        if (ez == hipSuccess && db->d_dp_args) ez = hipMemcpyAsync(db->d_dp_args, &db->dp_args, sizeof(dpk::DpArgs), hipMemcpyHostToDevice, side); /* (behind the writers it was
+                                                                                                     most of a 130 us gap in front of the solver launches) */
         if (ez == hipSuccess) ez = hipMemsetAsync(db->d_partials, 0, (size_t)AVK_TALLY_STRIDE * AVK_TALLY_COPIES * sizeof(uint64_t), side);
         if (ez == hipSuccess) ez = hipMemsetAsync(db->d_counters, 0, AVK_N_COUNTERS * sizeof(uint32_t), side);
         if (ez == hipSuccess) ez = hipEventRecord(ctx->ev_copy_join, side);
@@ -1127,7 +1134,6 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         }
         db->scratch_clean = true;
     }
-    a.regions = db->d_regions, a.blob = db->d_blob, a.fast = db->d_fast;
     if (tiles_total) hipLaunchKernelGGL(avk_dp_fast_records_kernel, dim3((tiles_total + 3) / 4), dim3(256), 0, s, a, tiles_total);
     /* records and blobs: now for the regions the wave-per-region launches start with; for the lanes' regions when (and if) a launch asks for them */
     const uint32_t n_eager = (uint32_t)n - hs->n_fast_total;
@@ -1135,12 +1141,9 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         hipLaunchKernelGGL(avk_dp_region_records_kernel, dim3((n_eager + 255) / 256), dim3(256), 0, s, a, n_eager);
         hipLaunchKernelGGL(avk_dp_region_records_wave_kernel, dim3(256), dim3(256), 0, s, a);
     }
-    db->dp_args = a;
     db->records_full = hs->n_fast_total == 0;
     db->lazy_from = n_eager;
-    if (!db->records_full) { /* the packer's arguments in device memory: the waves that solve handed-back regions write their records themselves */
-        db->d_dp_args = (dpk::DpArgs *)kept(sizeof(dpk::DpArgs));
-        if (rc) return bail(rc);
+    if (db->d_dp_args && !clear_beside) {
         hipError_t ec = hipMemcpyAsync(db->d_dp_args, &db->dp_args, sizeof(dpk::DpArgs), hipMemcpyHostToDevice, s);
         if (ec != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(ec)));
     }
@@ -1179,12 +1182,13 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     memset(&o, 0, sizeof(o));
     o.region_out = db->d_region_out, o.var_out = db->d_var_out, o.v_off = db->d_voff, o.t_off = db->d_in_t_off, o.q_off = db->d_in_q_off, o.t_cnt = db->d_in_t_cnt,
     o.q_cnt = db->d_in_q_cnt, o.n_regions = n, o.n_variants = nv, o.mode = db->last_mode;
-    o.status = (int32_t *)tmp((n + 1) * 4);
+    if (out->status || !out->region_packed) o.status = (int32_t *)tmp((n + 1) * 4);
+    if (out->region_packed) o.region_packed = (uint64_t *)tmp((n + 1) * 8);
     if (out->ed_h1) o.ed_h1 = (uint32_t *)tmp((n + 1) * 4);
     if (out->ed_h2) o.ed_h2 = (uint32_t *)tmp((n + 1) * 4);
     if (out->n_optima) o.n_optima = (uint32_t *)tmp((n + 1) * 4);
     if (out->type_present) o.type_present = (uint16_t *)tmp((n + 1) * 2);
-    const bool want_var = db->last_mode == 0 && (out->var_expected || out->var_observed || out->var_class || out->var_zyg) && db->v_hi > db->v_lo;
+    const bool want_var = db->last_mode == 0 && (out->var_expected || out->var_observed || out->var_class || out->var_zyg || out->var_packed) && db->v_hi > db->v_lo;
     const uint64_t nvr = db->v_hi - db->v_lo; /* the calls this batch owns: only they are copied back */
     o.v_lo = db->v_lo;
     if (want_var) {
@@ -1192,6 +1196,7 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         if (out->var_observed) o.var_observed = (uint8_t *)tmp(nvr + 16);
         if (out->var_class) o.var_class = (uint8_t *)tmp(nvr + 16);
         if (out->var_zyg) o.var_zyg = (uint8_t *)tmp(nvr + 16);
+        if (out->var_packed) o.var_packed = (uint8_t *)tmp(nvr + 16);
     }
     uint8_t *d_exact = pair_exact ? (uint8_t *)tmp(n + 16) : nullptr;
     if (rc) return done(rc);
@@ -1205,7 +1210,8 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         std::vector<CopySeg> pre = {{out->var_expected ? out->var_expected + db->v_lo : nullptr, o.var_expected, out->var_expected ? nvr : 0},
                                     {out->var_observed ? out->var_observed + db->v_lo : nullptr, o.var_observed, out->var_observed ? nvr : 0},
                                     {out->var_class ? out->var_class + db->v_lo : nullptr, o.var_class, out->var_class ? nvr : 0},
-                                    {out->var_zyg ? out->var_zyg + db->v_lo : nullptr, o.var_zyg, out->var_zyg ? nvr : 0}};
+                                    {out->var_zyg ? out->var_zyg + db->v_lo : nullptr, o.var_zyg, out->var_zyg ? nvr : 0},
+                                    {out->var_packed ? out->var_packed + db->v_lo : nullptr, o.var_packed, out->var_packed ? nvr : 0}};
         rc = copy_in(ctx, pre);
         if (rc) return done(rc);
     }
@@ -1214,13 +1220,15 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         e = hipGetLastError();
     }
     if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(e)));
-    std::vector<CopySeg> segs = {{out->status, o.status, n * 4}, {out->ed_h1, o.ed_h1, n * 4}, {out->ed_h2, o.ed_h2, n * 4}, {out->n_optima, o.n_optima, n * 4},
+    std::vector<CopySeg> segs = {{out->status, o.status, out->status ? n * 4 : 0}, {out->region_packed, o.region_packed, out->region_packed ? n * 8 : 0},
+                                 {out->ed_h1, o.ed_h1, n * 4}, {out->ed_h2, o.ed_h2, n * 4}, {out->n_optima, o.n_optima, n * 4},
                                  {out->type_present, o.type_present, n * 2}, {pair_exact, d_exact, pair_exact ? n : 0}};
     if (want_var) {
         segs.push_back({out->var_expected ? out->var_expected + db->v_lo : nullptr, o.var_expected, out->var_expected ? nvr : 0});
         segs.push_back({out->var_observed ? out->var_observed + db->v_lo : nullptr, o.var_observed, out->var_observed ? nvr : 0});
         segs.push_back({out->var_class ? out->var_class + db->v_lo : nullptr, o.var_class, out->var_class ? nvr : 0});
         segs.push_back({out->var_zyg ? out->var_zyg + db->v_lo : nullptr, o.var_zyg, out->var_zyg ? nvr : 0});
+        segs.push_back({out->var_packed ? out->var_packed + db->v_lo : nullptr, o.var_packed, out->var_packed ? nvr : 0});
     }
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
     if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {

@@ -874,9 +874,57 @@ uint64_t avk_algorithmic_bytes_ex(const avk_region_batch *b, int with_groups) {
 }
 uint64_t avk_algorithmic_bytes(const avk_region_batch *b) { return avk_algorithmic_bytes_ex(b, 1); }
 
+/* the wide result arrays from the packed form (include/aardvark_amd.h) */
+int avk_results_expand(const avk_region_batch *b, const avk_result_batch *packed, avk_result_batch *wide) {
+    if (!b || !packed || !wide) return AVK_E_ARG;
+    const bool want_region = wide->status || wide->ed_h1 || wide->ed_h2 || wide->n_optima || wide->type_present;
+    const bool want_calls = wide->var_expected || wide->var_observed || wide->var_class || wide->var_zyg;
+    if ((want_region && !packed->region_packed) || (want_calls && !packed->var_packed)) return AVK_E_ARG;
+    if (!want_region && !want_calls) return 0;
+    std::atomic<int> bad(0);
+    const uint64_t n = b->n_regions, piece = 1u << 16, pieces = (n + piece - 1) / piece;
+    std::atomic<uint64_t> next(0);
+    AvkPool::get().run(pieces > 1 ? avk_host_threads() : 1, [&](unsigned) {
+        for (;;) {
+            const uint64_t p = next.fetch_add(1);
+            if (p >= pieces) break;
+            for (uint64_t r = p * piece; r < n && r < (p + 1) * piece; ++r) {
+                uint32_t types = 0;
+                for (int side = 0; side < 2; ++side) {
+                    const uint64_t off = side == 0 ? b->t_off[r] : b->q_off[r];
+                    const uint32_t cnt = side == 0 ? b->t_cnt[r] : b->q_cnt[r];
+                    if (off > b->n_variants || cnt > b->n_variants - off) {
+                        bad.store(1);
+                        continue;
+                    }
+                    for (uint32_t i = 0; i < cnt; ++i) {
+                        const uint64_t v = off + i;
+                        if (b->var_type && b->var_type[v] < AVK_N_VARIANT_TYPES) types |= 1u << b->var_type[v];
+                        if (!want_calls) continue;
+                        const uint8_t x = packed->var_packed[v];
+                        if (wide->var_expected) wide->var_expected[v] = avk_vp_expected(x);
+                        if (wide->var_observed) wide->var_observed[v] = avk_vp_observed(x);
+                        if (wide->var_class) wide->var_class[v] = avk_vp_class(x, side);
+                        if (wide->var_zyg) wide->var_zyg[v] = avk_vp_zyg(x);
+                    }
+                }
+                if (!want_region) continue;
+                const uint64_t w = packed->region_packed[r];
+                if (wide->status) wide->status[r] = avk_rp_status(w);
+                if (wide->ed_h1) wide->ed_h1[r] = avk_rp_ed_h1(w);
+                if (wide->ed_h2) wide->ed_h2[r] = avk_rp_ed_h2(w);
+                if (wide->n_optima) wide->n_optima[r] = avk_rp_n_optima(w);
+                if (wide->type_present) wide->type_present[r] = avk_rp_type_present(w, types);
+            }
+        }
+    });
+    return bad.load() ? AVK_E_ARG : 0;
+}
+
 /* GroupTypeMetrics of one region from its compact BASEPAIR groups and the per-call outputs (include/aardvark_amd.h) */
 int avk_group_metrics_from_compact(const avk_region_batch *b, uint64_t r, const avk_result_batch *res, uint32_t *out) {
-    if (!b || !res || !out || r >= b->n_regions || !res->var_expected || !res->var_observed || !res->bp_off || !res->bp_groups) return AVK_E_ARG;
+    if (!b || !res || !out || r >= b->n_regions || !((res->var_expected && res->var_observed) || res->var_packed) || !res->bp_off || !res->bp_groups) return AVK_E_ARG;
+    const bool wide_calls = res->var_expected && res->var_observed; /* otherwise the packed bytes */
     memset(out, 0, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
     uint32_t types = 0;
     uint64_t tot[2][1 + AVK_N_VARIANT_TYPES];
@@ -892,7 +940,8 @@ int avk_group_metrics_from_compact(const avk_region_batch *b, uint64_t r, const 
             types |= 1u << vt;
             const uint64_t w = avk::host_edit_distance(b->allele_bytes + b->a0_off[v], b->a0_len[v], b->allele_bytes + b->a1_off[v], b->a1_len[v]); /* Variant::alt_ed */
             /* the query entries are stored toggled (compare_benchmark.rs:109-123): scored as truth they expected var_observed and observed var_expected */
-            const uint32_t exp = side == 0 ? res->var_expected[v] : res->var_observed[v], obs = side == 0 ? res->var_observed[v] : res->var_expected[v];
+            const uint32_t ea = wide_calls ? res->var_expected[v] : avk_vp_expected(res->var_packed[v]), oa = wide_calls ? res->var_observed[v] : avk_vp_observed(res->var_packed[v]);
+            const uint32_t exp = side == 0 ? ea : oa, obs = side == 0 ? oa : ea;
             const int f_gt_tp = side ? AVK_F_GT_QUERY_TP : AVK_F_GT_TRUTH_TP, f_gt_fn = side ? AVK_F_GT_QUERY_FP : AVK_F_GT_TRUTH_FN, f_gt_fn_gt = side ? AVK_F_GT_QUERY_FP_GT : AVK_F_GT_TRUTH_FN_GT;
             const int f_hap_tp = side ? AVK_F_HAP_QUERY_TP : AVK_F_HAP_TRUTH_TP, f_hap_fn = side ? AVK_F_HAP_QUERY_FP : AVK_F_HAP_TRUTH_FN;
             const int f_w_tp = side ? AVK_F_WHAP_QUERY_TP : AVK_F_WHAP_TRUTH_TP, f_w_fn = side ? AVK_F_WHAP_QUERY_FP : AVK_F_WHAP_TRUTH_FN;
@@ -2056,7 +2105,7 @@ static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::ve
 }
 
 int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out) {
-    if (!ctx || !db || !out || !out->status) return AVK_E_ARG;
+    if (!ctx || !db || !out || !(out->status || out->region_packed)) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions, nv = db->n_variants_dev;
     const bool timing = getenv("AVK_TIMING") != nullptr;
@@ -2075,6 +2124,23 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         D2H(seqlen.data(), db->d_seqlen, n * 5 * sizeof(uint32_t));
     }
     std::chrono::steady_clock::time_point t_copied;
+    /* the host-side writers of a region's and a call's results: whichever of the wide arrays and of the packed form the caller handed in */
+    auto put_region = [&](uint64_t r, uint32_t st, uint32_t e1, uint32_t e2, uint32_t nopt, uint32_t present) {
+        if (out->status) out->status[r] = (int32_t)st;
+        if (out->ed_h1) out->ed_h1[r] = e1;
+        if (out->ed_h2) out->ed_h2[r] = e2;
+        if (out->n_optima) out->n_optima[r] = nopt;
+        if (out->type_present) out->type_present[r] = (uint16_t)present;
+        if (out->region_packed) out->region_packed[r] = avk_rp_make(st, e1, e2, nopt, present);
+    };
+    auto put_call = [&](uint64_t hv, uint32_t ea, uint32_t oa, uint32_t cls, uint32_t zyg) {
+        if (out->var_expected) out->var_expected[hv] = (uint8_t)ea;
+        if (out->var_observed) out->var_observed[hv] = (uint8_t)oa;
+        if (out->var_class) out->var_class[hv] = (uint8_t)cls;
+        if (out->var_zyg) out->var_zyg[hv] = (uint8_t)zyg;
+        if (out->var_packed) out->var_packed[hv] = avk_vp_make(ea, oa, zyg);
+    };
+    auto status_of = [&](uint64_t r) -> int32_t { return out->status ? out->status[r] : avk_rp_status(out->region_packed[r]); };
     if (db->dev_packed) { /* the caller's layout is made on the device (dp_unpack); the copies land in the caller's arrays */
         const int rc = download_device_packed(ctx, db, out, nullptr, tally.data());
         if (rc) return rc;
@@ -2091,25 +2157,18 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
             D2H(out->bp_off, db->d_bp_off, (n + 1) * sizeof(uint32_t));
             D2H(out->bp_groups, db->d_bp, (size_t)db->n_bp_groups * 4 * sizeof(uint32_t));
         }
-        if (out->var_expected || out->var_observed || out->var_class || out->var_zyg) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
+        const bool want_calls = out->var_expected || out->var_observed || out->var_class || out->var_zyg || out->var_packed;
+        if (want_calls) D2H(vout.data(), db->d_var_out, nv * sizeof(uint32_t));
         D2H(tally.data(), db->d_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t));
         AVK_HIP(ctx, hipStreamSynchronize(s));
         t_copied = std::chrono::steady_clock::now();
         for (uint64_t r = 0; r < n; ++r) {
             const uint32_t *w = rout.data() + 4 * r;
-            out->status[r] = (int32_t)w[0];
-            if (out->ed_h1) out->ed_h1[r] = w[1];
-            if (out->ed_h2) out->ed_h2[r] = w[2];
-            if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
-            if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
+            put_region(r, w[0], w[1], w[2], w[3] & 0xFFFFu, w[3] >> 16);
         }
-        for (uint64_t v = 0; v < nv; ++v) {
-            const uint64_t hv = db->host.dev2host[v];
+        for (uint64_t v = 0; want_calls && v < nv; ++v) {
             const uint32_t w = vout[v];
-            if (out->var_expected) out->var_expected[hv] = (uint8_t)(w & 0xFF);
-            if (out->var_observed) out->var_observed[hv] = (uint8_t)((w >> 8) & 0xFF);
-            if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
-            if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
+            put_call(db->host.dev2host[v], w & 0xFF, (w >> 8) & 0xFF, (w >> 16) & 0xFF, w >> 24);
         }
     }
 #undef D2H
@@ -2134,10 +2193,12 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     }
     /* no solvable region stays a capacity failure: larger slices, level by level (an overflow status is only allowed when
      * the library itself solves the region again) */
-    if (ctx->capacity_retry && db->has_run && db->last_mode == 0) {
+    if (ctx->capacity_retry && db->has_run && db->last_mode == 0 && ctx->last_tiers[4] > 0) { /* (the kernels count the regions they give up on: a step without
+                                                                                                  any — every step of a genome — does not walk over its 3.6 million
+                                                                                                  statuses, 1.4 ms of one host thread) */
         std::vector<uint32_t> cap;
         for (uint64_t r = 0; r < n; ++r)
-            if (out->status[r] == AVK_ST_CAPACITY) cap.push_back((uint32_t)r);
+            if (status_of(r) == AVK_ST_CAPACITY) cap.push_back((uint32_t)r);
         if (!cap.empty()) { /* the retry rebuilds the regions from the packed records: a device-packed batch fetches them now */
             const int rv = materialize_host_view(ctx, db);
             if (rv) return rv;
@@ -2166,18 +2227,11 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
                     still.push_back(r);
                     continue;
                 }
-                out->status[r] = fx.status[k];
-                if (out->ed_h1) out->ed_h1[r] = fx.ed1[k];
-                if (out->ed_h2) out->ed_h2[r] = fx.ed2[k];
-                if (out->n_optima) out->n_optima[r] = fx.nopt[k];
-                if (out->type_present) out->type_present[r] = fx.present[k];
+                put_region(r, (uint32_t)fx.status[k], fx.ed1[k], fx.ed2[k], fx.nopt[k], fx.present[k]);
                 const AvkDevRegion &dr = db->host.regions[r];
                 for (uint32_t i = 0; i < dr.t_cnt + dr.q_cnt; ++i) {
-                    const uint64_t hv = db->host.dev2host[dr.v_off + i], sv = fx.v_first[k] + i;
-                    if (out->var_expected) out->var_expected[hv] = fx.ve[sv];
-                    if (out->var_observed) out->var_observed[hv] = fx.vo[sv];
-                    if (out->var_class) out->var_class[hv] = fx.vc[sv];
-                    if (out->var_zyg) out->var_zyg[hv] = fx.vz[sv];
+                    const uint64_t sv = fx.v_first[k] + i;
+                    put_call(db->host.dev2host[dr.v_off + i], fx.ve[sv], fx.vo[sv], fx.vc[sv], fx.vz[sv]);
                 }
                 if (want_gm) memcpy(out->group_metrics + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
                 if (want_bp && out->bp_off[r + 1] - out->bp_off[r] == fx.bp_off[k + 1] - fx.bp_off[k]) /* the same calls, so the same groups */
@@ -2387,7 +2441,7 @@ int avk_batch_upload_packed(avk_ctx *ctx, const avk_packed_batch *batch, avk_dev
 }
 
 int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
-    if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
+    if (!ctx || !batch || !cfg || !out || !(out->status || out->region_packed)) return AVK_E_ARG;
     ctx->last_one_shot = 0;
     avk_dev_batch *db = nullptr;
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
@@ -2414,7 +2468,7 @@ int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_co
 }
 
 int avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
-    if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
+    if (!ctx || !batch || !cfg || !out || !(out->status || out->region_packed)) return AVK_E_ARG;
     ctx->last_one_shot = 0;
     avk_dev_batch *db = nullptr;
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
@@ -2432,7 +2486,7 @@ int avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_
 }
 
 int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
-    if (!ctx || !batch || !cfg || !out || !out->status) return AVK_E_ARG;
+    if (!ctx || !batch || !cfg || !out || !(out->status || out->region_packed)) return AVK_E_ARG;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     ctx->last_one_shot = 0;
     avk_dev_batch *db = nullptr;

@@ -68,6 +68,7 @@ def parse():
     ap.add_argument("--resident-steps", type=int, default=300, help="timed avk_compare_resident steps of the resident leg (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto", help="auto = strong for N > 1 (one call set sharded over the ranks)")
+    ap.add_argument("--wide-results", action="store_true", help="the timed calls fill the wide result arrays instead of the packed form")
     ap.add_argument("--form", choices=("packed", "compact"), default="packed", help="flat form of the region batch the timed calls hand over: packed (avk_packed_batch, 94 MB per genome) or compact (avk_compact_batch, 227 MB)")
     ap.add_argument("--pageable", action="store_true", help="caller arrays in ordinary memory (the library stages them through a pinned bounce buffer) instead of avk_host_alloc memory")
     ap.add_argument("--watchdog-seconds", type=int, default=900, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
@@ -233,7 +234,9 @@ def main():
     if not args.pageable:
         hb, wide = (ctx.pinned_packed(hb) if form == "packed" else ctx.pinned_compact(hb)), ctx.pinned_batch(batch)
         cmp_b = ctx.pinned_compact(cmp_b) if form == "packed" else hb
-    res = ResultBatch(hb, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(hb)
+    # the results in the packed form (avk_result_batch::region_packed / var_packed: 8 B per region + 1 B per call, everything the wide arrays say) unless --wide-results
+    res_form = False if args.wide_results else "only"
+    res = ResultBatch(hb, sequences=False, group_metrics=False, packed=res_form) if args.pageable else ctx.pinned_results(hb, packed=res_form)
     cb, ro = hb.c_struct(), res.c_struct()
     entry_point = ctx.lib.avk_compare_packed if form == "packed" else ctx.lib.avk_compare_compact
     entry_name = "avk_compare_packed" if form == "packed" else "avk_compare_compact"
@@ -273,7 +276,30 @@ def main():
                   "max": round(float(call_ms.max()), 3)} if args.steps else None
     log("timed region: %d %s calls in %.3f s (%.2f ms per call; single calls %s)" % (args.steps, entry_name, elapsed, elapsed / max(args.steps, 1) * 1e3, call_stats))
     job_tally = tally.clone()
-    got_boundary = res  # the outputs of the last timed call, in the caller's arrays
+    got_boundary = res if args.wide_results else res.expanded(ctx.lib, batch)  # the outputs of the last timed call (the packed form: expanded on the host, outside the timed region)
+    # the same call with the results in the wide arrays (18 B per region + 4 B per call over PCIe)
+    wide_results_entry = None
+    if not args.wide_results:
+        r2 = ResultBatch(hb, sequences=False, group_metrics=False) if args.pageable else ctx.pinned_results(hb)
+        ro2 = r2.c_struct()
+        ctx._check(entry_point(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro2)))
+        n_w = max(3, min(args.steps, 20))
+        fence()
+        tw0 = time.perf_counter()
+        for _ in range(n_w):
+            ctx._check(entry_point(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro2)))
+        fence()
+        w_elapsed = time.perf_counter() - tw0
+        if world > 1:
+            t = torch.tensor([w_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            w_elapsed = float(t.item())
+        wide_results_entry = {"value": total_regions * n_w / w_elapsed, "unit": "regions/s", "ms_per_step": w_elapsed / n_w * 1e3, "steps": n_w,
+                              "host_bytes_out_per_step": int(sum(getattr(r2, f).nbytes for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed",
+                                                                                                  "var_class", "var_zyg"))),
+                              "same_outputs_as_value_leg": r2.diff(got_boundary) == [],
+                              "what": "the value leg's call with the results in the wide arrays of avk_result_batch instead of the packed form"}
+        del r2
     # the same boundary with the batch in the compact form (avk_compact_batch: 20 B per region + 17 B per call, explicit offsets), when `value` is on the packed one
     compact_entry = None
     if form == "packed":
@@ -410,7 +436,8 @@ def main():
         in_bytes = hb.nbytes()
         wide_bytes = sum(getattr(wide, f).nbytes for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space",
                                                             "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"))
-        out_bytes = sum(getattr(res, f).nbytes for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg"))
+        out_bytes = int(sum(getattr(res, f).nbytes for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg",
+                                                             "region_packed", "var_packed") if getattr(res, f) is not None))
         out = {
             "metric": "compared regions/sec (whole node)",
             "value": value,
@@ -431,7 +458,8 @@ def main():
                                       "pageable" if args.pageable else "pinned (avk_host_alloc)"),
                        "regions_per_gpu": n_regions, "max_branch_factor": cfg.max_branch_factor, "min_variant_gap": 50,
                        "host_bytes_in_per_step": in_bytes, "host_bytes_out_per_step": out_bytes,
-                       "outputs_per_step": "per-region record (status, ed_h1, ed_h2, optima, types), per-variant decision (EA, OA, class, resolved zygosity), 288-counter tally",
+                       "outputs_per_step": "per-region record (status, ed_h1, ed_h2, optima, types), per-variant decision (EA, OA, class, resolved zygosity), 288-counter tally" +
+                                           ("" if args.wide_results else "; regions and calls in the packed form of avk_result_batch (8 B + 1 B; avk_results_expand gives the wide arrays)"),
                        "parallelism": ("regions of ONE call set sharded by hash(region_id) over %d GPU(s)" % world if scaling == "strong" else
                                        "one call set per GPU on %d GPU(s)" % world) +
                                       ", no data-path collective; one RCCL all-reduce of the job tally (288 x int64) inside the timed region",
@@ -439,6 +467,7 @@ def main():
             "call_ms": call_stats,  # this rank's single calls inside the timed region (value = all of them, barrier to barrier)
             "resident_value": resident["value"] if resident else None,
             "resident": resident,
+            "wide_results": wide_results_entry,
             "compact_soa": compact_entry,
             "wide_soa": {"value": total_regions * n_wide / wide_elapsed, "unit": "regions/s", "ms_per_step": wide_elapsed / n_wide * 1e3, "steps": n_wide, "host_bytes_in_per_step": wide_bytes,
                          "what": "the same boundary with the batch in the wide structure-of-arrays form (avk_region_batch through avk_compare_batch)"},
@@ -527,7 +556,7 @@ def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, 
         else:
             hb = ctx.pinned_batch(batch)
             entry_point = ctx.lib.avk_compare_batch
-        res = ctx.pinned_results(hb)
+        res = ctx.pinned_results(hb, packed="only" if packed else False)  # (the packed batch form goes with the packed result form, as on the value leg)
         cb, ro = hb.c_struct(), res.c_struct()
         call = lambda: ctx._check(entry_point(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
         call()
@@ -553,7 +582,7 @@ def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, 
         entry = {"workload": what, "regions": batch.n_regions, "value": batch.n_regions * nb / be, "unit": "regions/s", "ms_per_step": be / nb * 1e3, "steps": nb,
                  "resident_value": batch.n_regions * nr / re_, "resident_ms_per_step": re_ / nr * 1e3, "lane_kernel_regions": ctx.last_lane_solved(),
                  "lane_share": ctx.last_lane_solved() / max(batch.n_regions, 1), "wide_kernel_regions": ctx.last_wide_solved(), "workspace_tiers": ctx.last_tier_counts(),
-                 "boundary_form": "packed (avk_compare_packed)" if packed else "wide (avk_compare_batch)"}
+                 "boundary_form": "packed batch and packed results (avk_compare_packed)" if packed else "wide (avk_compare_batch)"}
         if resident_sync:  # every step synchronised: a step of this size is a launch chain over several streams
             t0 = time.perf_counter()
             for _ in range(nr):
@@ -565,7 +594,7 @@ def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, 
             cs_leg = oracle_lib.ContigSet(contigs)
             want, entry["cpu_baseline"] = cpu_figure(lambda: oracle_lib.compare_batch(lib, batch, cs_leg, threads=cpus, group_metrics=False), batch.n_regions, "regions/s")
             entry["gpu_over_cpu"] = {"boundary": entry["value"] / entry["cpu_baseline"]["value"], "resident": entry["resident_value"] / entry["cpu_baseline"]["value"]}
-            bad = ["boundary:" + x for x in res.diff(want)] + ["resident:" + x for x in got.diff(want)]
+            bad = ["boundary:" + x for x in (res.expanded(ctx.lib, batch) if packed else res).diff(want)] + ["resident:" + x for x in got.diff(want)]
             entry["parity"] = "bit-identical" if not bad else "MISMATCH:" + ",".join(bad)
             if bad:
                 print("PARITY FAILURE in secondary leg %s: %s" % (name, entry["parity"]), file=sys.stderr)

@@ -181,7 +181,7 @@ typedef struct avk_compare_config {
 /* ---- outputs --------------------------------------------------------------------- */
 
 /* Caller-allocated result arrays, positionally aligned with the input batch.
- * Any pointer except `status` may be NULL to skip that output. */
+ * Any pointer except `status` may be NULL to skip that output (and `status` too when region_packed is given). */
 typedef struct avk_result_batch {
     int32_t  *status;        /* [n_regions] AVK_ST_* */
     uint32_t *ed_h1;         /* [n_regions] CompareBenchmark::bm_edit_distance_h1 */
@@ -217,7 +217,47 @@ typedef struct avk_result_batch {
      * per-call outputs. */
     uint32_t *bp_off;        /* [n_regions + 1] */
     uint32_t *bp_groups;     /* [capacity][4] with capacity >= n_regions + n_variants (a region has at most 1 + its number of calls groups) */
+
+    /* The packed result form (optional, each on its own): everything the arrays above say per region in 8 bytes and per call in 1 byte — a whole-genome
+     * job's results cross PCIe as 37 MB instead of 96.  A caller that hands in region_packed may leave `status` NULL; one that hands in var_packed needs none
+     * of var_expected / var_observed / var_class / var_zyg.  Read them with the avk_rp_* / avk_vp_* accessors below (what the FFI side would do while it
+     * builds its CompareBenchmark values) or expand them into the arrays above with avk_results_expand.
+     *   region_packed[r] = status (bits 0-6) | "the 8 filtered types have map entries" (bit 7) | n_optima (bits 8-23) | ed_h1 (bits 24-43) | ed_h2 (bits 44-63);
+     *                      an edit distance of 2^20 - 1 or more reads as AVK_RP_ED_MAX: ask for ed_h1 / ed_h2 as well if regions can be that far from the
+     *                      reference (none of a genome's is: the search gives up on such windows long before, AVK_ST_CAPACITY)
+     *   var_packed[v]    = expected (bits 0-1) | observed (bits 2-3) | resolved zygosity AVK_ZYG_* (bits 4-6); the class follows from the two counts and the
+     *                      side the call is on (variant_metrics.rs:43-101): avk_vp_class */
+    uint64_t *region_packed; /* [n_regions] */
+    uint8_t  *var_packed;    /* [n_variants] */
 } avk_result_batch;
+
+#define AVK_RP_ED_MAX 0xFFFFFu
+/* the 8 variant types add_basepair_stats filters by (waffle_solver.rs:383-445): a solved region has map entries for them whether they occur or not */
+#define AVK_FILTERED_TYPE_MASK ((1u << AVK_VT_SNV) | (1u << AVK_VT_INSERTION) | (1u << AVK_VT_DELETION) | (1u << AVK_VT_INDEL) | (1u << AVK_VT_TR_CONTRACTION) | \
+                                (1u << AVK_VT_TR_EXPANSION) | (1u << AVK_VT_SV_DELETION) | (1u << AVK_VT_SV_INSERTION))
+static inline uint64_t avk_rp_make(uint32_t status, uint32_t ed_h1, uint32_t ed_h2, uint32_t n_optima, uint32_t type_present) {
+    const uint64_t e1 = ed_h1 < AVK_RP_ED_MAX ? ed_h1 : AVK_RP_ED_MAX, e2 = ed_h2 < AVK_RP_ED_MAX ? ed_h2 : AVK_RP_ED_MAX;
+    const uint64_t filtered = (type_present & AVK_FILTERED_TYPE_MASK) == AVK_FILTERED_TYPE_MASK ? 1u : 0u;
+    return (uint64_t)(status & 0x7Fu) | filtered << 7 | (uint64_t)(n_optima & 0xFFFFu) << 8 | e1 << 24 | e2 << 44;
+}
+static inline int32_t  avk_rp_status(uint64_t w) { return (int32_t)(w & 0x7Fu); }
+static inline uint32_t avk_rp_filtered_types(uint64_t w) { return (uint32_t)(w >> 7) & 1u; }
+static inline uint32_t avk_rp_n_optima(uint64_t w) { return (uint32_t)(w >> 8) & 0xFFFFu; }
+static inline uint32_t avk_rp_ed_h1(uint64_t w) { return (uint32_t)(w >> 24) & AVK_RP_ED_MAX; }
+static inline uint32_t avk_rp_ed_h2(uint64_t w) { return (uint32_t)(w >> 44) & AVK_RP_ED_MAX; }
+/* type_present of a region from its packed word and the OR of (1 << type) over its calls */
+static inline uint16_t avk_rp_type_present(uint64_t w, uint32_t call_types) {
+    return avk_rp_status(w) != 0 ? (uint16_t)0 : (uint16_t)(call_types | (avk_rp_filtered_types(w) ? AVK_FILTERED_TYPE_MASK : 0u));
+}
+static inline uint8_t avk_vp_make(uint32_t expected, uint32_t observed, uint32_t zyg) { return (uint8_t)((expected & 3u) | (observed & 3u) << 2 | (zyg & 7u) << 4); }
+static inline uint8_t avk_vp_expected(uint8_t b) { return (uint8_t)(b & 3u); }
+static inline uint8_t avk_vp_observed(uint8_t b) { return (uint8_t)((b >> 2) & 3u); }
+static inline uint8_t avk_vp_zyg(uint8_t b) { return (uint8_t)((b >> 4) & 7u); }
+/* TP when the counts agree; otherwise a truth call is a FN and a query call (stored toggled) a FP; a call of a failed region has no class */
+static inline uint8_t avk_vp_class(uint8_t b, int is_query) {
+    if ((b & 15u) == 0) return AVK_CLASS_UNKNOWN;
+    return avk_vp_expected(b) == avk_vp_observed(b) ? AVK_CLASS_TP : (is_query ? AVK_CLASS_FP : AVK_CLASS_FN);
+}
 
 /* ---- context --------------------------------------------------------------------- */
 
@@ -335,6 +375,11 @@ int  avk_last_wide_solved(avk_ctx *ctx, uint64_t *count); /* the same for the wa
  * (expected, observed) per call (grouped_metrics.rs:183-227 and the swap of :268-277), RECORD_BP from the calls' zygosities and raw_allele_space
  * (waffle_solver.rs:455-522).  Only meaningful for regions with status 0.  Returns 0, or AVK_E_ARG. */
 int avk_group_metrics_from_compact(const avk_region_batch *batch, uint64_t r, const avk_result_batch *res, uint32_t *out /* [AVK_N_GROUPS * AVK_N_FIELDS] */);
+/* Host utility (no GPU involved): the wide arrays of `wide` (whichever of status, ed_h1, ed_h2, n_optima, type_present, var_expected, var_observed, var_class,
+ * var_zyg are not NULL) from packed->region_packed / packed->var_packed and the batch.  Calls that no region of the batch owns are left as they are.
+ * Returns 0, or AVK_E_ARG (a wide per-region array is wanted without region_packed, a per-call one without var_packed, or a region's call range is outside the
+ * batch). */
+int avk_results_expand(const avk_region_batch *batch, const avk_result_batch *packed, avk_result_batch *wide);
 uint64_t avk_algorithmic_bytes(const avk_region_batch *batch);
 /* the same with (1) or without (0) the per-region BASEPAIR groups among the outputs: a run that produces per-region records, per-call decisions and
  * the batch tally only (emit_group_metrics 0) writes no per-region groups */

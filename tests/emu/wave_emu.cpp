@@ -232,6 +232,7 @@ struct DpResult {
     std::vector<uint64_t> seq_off;
     std::vector<dpk::DpVarInfo> vinfo;
     std::vector<dpk::DpRegionInfo> rinfo;
+    std::vector<dpk::DpSlot> slots;
     std::vector<uint32_t> pending, big_list;
     dpk::DpState st;
     dpk::DpArgs args; /* for the writers that run later (records of the regions the lanes hand back) */
@@ -258,12 +259,13 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     a.opt = opt;
     R->vinfo.assign(nv + 1, dpk::DpVarInfo());
     R->rinfo.assign(n + 1, dpk::DpRegionInfo());
+    R->slots.assign(nv + 1, dpk::DpSlot());
     std::vector<uint32_t> &pending = R->pending, &big_list = R->big_list;
     pending.assign(nv + 1, 0), big_list.assign(n + 1, 0);
     R->v_off.assign(n + 1, 0), R->blob_off8.assign(n + 1, 0), R->seq_off.assign(n + 1, 0), R->order.assign(n + 1, 0), R->bp_off.assign(n + 2, 0);
     memset(&R->st, 0, sizeof(R->st));
     a.vinfo = R->vinfo.data(), a.rinfo = R->rinfo.data(), a.st = &R->st, a.pending = pending.data(), a.v_off = R->v_off.data(), a.blob_off8 = R->blob_off8.data(),
-    a.seq_off = R->seq_off.data(), a.order = R->order.data(), a.big_list = big_list.data(), a.bp_off = R->bp_off.data();
+    a.seq_off = R->seq_off.data(), a.order = R->order.data(), a.big_list = big_list.data(), a.bp_off = R->bp_off.data(), a.slots = R->slots.data();
     for (uint64_t v = 0; v < nv; ++v) dpk::dp_variant(a, v);
     auto region_passes = [&] {
         uint64_t run_v = 0, run_b = 0, run_s = 0, run_g = 0;
@@ -933,16 +935,18 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         o.n_regions = n, o.n_variants = batch->n_variants, o.mode = mode;
         o.status = out->status, o.ed_h1 = out->ed_h1, o.ed_h2 = out->ed_h2, o.n_optima = out->n_optima, o.type_present = out->type_present;
         o.var_expected = out->var_expected, o.var_observed = out->var_observed, o.var_class = out->var_class, o.var_zyg = out->var_zyg;
+        o.region_packed = out->region_packed, o.var_packed = out->var_packed;
         for (uint64_t r = 0; r < n; ++r) dpk::dp_unpack(o, r);
     }
     /* copy back in caller order */
     for (uint64_t r = 0; r < n && !devpack; ++r) {
         const uint32_t *w = rout.data() + 4 * r;
-        out->status[r] = (int32_t)w[0];
+        if (out->status) out->status[r] = (int32_t)w[0];
         if (out->ed_h1) out->ed_h1[r] = w[1];
         if (out->ed_h2) out->ed_h2[r] = w[2];
         if (out->n_optima) out->n_optima[r] = w[3] & 0xFFFFu;
         if (out->type_present) out->type_present[r] = (uint16_t)(w[3] >> 16);
+        if (out->region_packed) out->region_packed[r] = avk_rp_make(w[0], w[1], w[2], w[3] & 0xFFFFu, w[3] >> 16);
     }
     if (out->group_metrics) memcpy(out->group_metrics, gm.data(), gm.size() * sizeof(uint32_t));
     for (uint64_t v = 0; v < nv && !devpack; ++v) {
@@ -952,6 +956,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         if (out->var_observed) out->var_observed[hv] = (uint8_t)((w >> 8) & 0xFF);
         if (out->var_class) out->var_class[hv] = (uint8_t)((w >> 16) & 0xFF);
         if (out->var_zyg) out->var_zyg[hv] = (uint8_t)(w >> 24);
+        if (out->var_packed) out->var_packed[hv] = avk_vp_make(w & 0xFF, (w >> 8) & 0xFF, w >> 24);
     }
     if (out->tally) memcpy(out->tally, tally.data(), AVK_TALLY_LEN * sizeof(uint64_t));
     if (tier_counts) memcpy(tier_counts, tally.data() + AVK_TALLY_LEN, 5 * sizeof(uint64_t));

@@ -33,7 +33,7 @@ def load():
 def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False,
                   lds_bytes=10 * 1024, lds_ed_cap=48, lds2_bytes=40 * 1024, lds2_ed_cap=48, ws_bytes=1 << 20, big_ws_bytes=64 << 20,
                   n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1, group_metrics=True, lane_kernel=True, bp_groups=False,
-                  wide_kernel=True, wide_lds_bytes=16 * 1024, class_c_all=False):
+                  wide_kernel=True, wide_lds_bytes=16 * 1024, class_c_all=False, packed=False):
     """lane_kernel: small regions go through the lane-per-region code (avk_lane.inl), the rest through the wave-per-region code, as
     avk_compare_resident does; False = everything through the wave-per-region code.  res.lane_solved = regions the lane code finished.
     wide_kernel: class C and what the three-call lane class hands back go through the wave-cooperative code of avk_wide.inl first
@@ -46,7 +46,7 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     if class_c_all:
         os.environ["AVK_EMU_CLASS_C"] = "100000"
     cs = contigs if isinstance(contigs, ContigSet) else ContigSet(contigs)
-    res = ResultBatch(batch, sequences=sequences, group_metrics=group_metrics, bp_groups=bp_groups)
+    res = ResultBatch(batch, sequences=sequences, group_metrics=group_metrics, bp_groups=bp_groups, packed=packed)
     cfg = AvkCompareConfig(max_branch_factor, 1 if sequences else 0, 1 if exact_shortcut else 0)
     cb, ro = batch.c_struct(), res.c_struct()
     tiers = (C.c_uint64 * 5)()

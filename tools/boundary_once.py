@@ -1,5 +1,5 @@
 """One process, a few host-boundary calls on the benchmark genome with pinned caller arrays: the command rocprofv3 traces for profiles/r03_boundary_*.
-usage: python tools/boundary_once.py [scale] [calls] [opt=value,...] [form: packed (default) | compact | wide]"""
+usage: python tools/boundary_once.py [scale] [calls] [opt=value,...] [form: packed (default) | compact | wide] [results: packed (default) | wide]"""
 import ctypes as C, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -25,7 +25,7 @@ elif form == "compact":
     pb, fn = ctx.pinned_compact(CompactBatch.from_region_batch(batch)), ctx.lib.avk_compare_compact
 else:
     pb, fn = ctx.pinned_packed(PackedBatch.from_compact(CompactBatch.from_region_batch(batch))), ctx.lib.avk_compare_packed
-res = ctx.pinned_results(pb)
+res = ctx.pinned_results(pb, packed=False if (sys.argv[5] if len(sys.argv) > 5 else "packed") == "wide" else "only")
 cb, ccfg, ro = pb.c_struct(), CompareConfig(enable_sequences=False).c_struct(), res.c_struct()
 print("form %s: %.0f MB of caller arrays in" % (form, (pb.nbytes() if hasattr(pb, "nbytes") else 0) / 1e6), flush=True)
 for k in range(calls + 1):

@@ -18,7 +18,7 @@ starts = [i for i, e in enumerate(ev) if "HOST_TO_DEVICE" in e[2].upper() and "b
           (i == 0 or "DEVICE_TO_HOST" in ev[i - 1][2].upper() or "avk_tally" in ev[i - 1][2] or "unpack" in ev[i - 1][2])]
 i0 = starts[-1] if starts else 0
 t0 = ev[i0][0]
-lines = ["# last avk_compare_batch of: rocprofv3 --kernel-trace --memory-copy-trace --stats -- python3 tools/boundary_once.py 1.0 3   (pinned caller arrays)",
+lines = ["# last boundary call of: rocprofv3 --kernel-trace --memory-copy-trace --stats -- python3 tools/boundary_once.py 1.0 3   (whole genome; packed batch form through avk_compare_packed, packed result form, pinned caller arrays)",
          "# start_us and dur_us relative to the call's first host-to-device copy; tables in the database: " + " ".join(mc)]
 for s, e, txt in ev[i0:]:
     lines.append("%10.1f %10.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, txt))
