@@ -85,7 +85,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_LAN
     uint32_t *smem = (uint32_t *)avk_smem;
     const unsigned wave_in_block = threadIdx.x >> 6;
     const unsigned wave_id = blockIdx.x * (blockDim.x >> 6) + wave_in_block;
-    const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap);
+    const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool);
     const uint32_t wave_words = rows << la.lanes_log2;
     uint32_t *wg_tally = smem + (size_t)(blockDim.x >> 6) * wave_words;
     for (unsigned k = threadIdx.x; k < 288; k += blockDim.x) wg_tally[k] = 0;
@@ -331,6 +331,7 @@ struct avk_ctx {
     int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
     int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
+    int64_t lane_pool = -1;                           /* node states a lane keeps during its search (avk_lane.inl NodePool): -1 = by class (2 / 4 / 6 for one / two / three calls per side), 0 = none */
     int64_t lane_waves_three = 0;                     /* > 0: at most this many one-wave workgroups of the three-call class per CU (its waves take 17 KB of LDS each) */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
     int64_t wide_kernel = 1;                          /* regions with large searches on small windows (class C, what the three-call lane class hands back) go to the wave-cooperative kernel of avk_wide.inl first */
@@ -777,6 +778,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
+    } else if (n == "lane_pool") {
+        if (value < -1 || value > 8) return fail(ctx, AVK_E_ARG, "lane_pool must be -1..8");
+        ctx->lane_pool = value;
     } else if (n == "lane_waves_three") {
         if (value < 0 || value > 32) return fail(ctx, AVK_E_ARG, "lane_waves_three must be 0..32");
         ctx->lane_waves_three = value;
@@ -1152,7 +1156,7 @@ static uint32_t head_width_log2(const avk_ctx *ctx) {
     return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
 }
 static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs &la, uint32_t *grid) {
-    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + 3 * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + (la.nm == 2 ? 4 : 8); /* lane_rows */
+    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + (3 + 2 * la.pool) * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + (la.nm == 2 ? 4 : 8); /* lane_rows */
     const size_t lds = (size_t)rows * (4u << la.lanes_log2) + 288 * 4;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     if (per_cu < 1) return 0;
@@ -1644,6 +1648,10 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     la.qcap = cl.qcap;
                     la.gen_base = db->plan.fast_base[fc];
                     la.lanes_log2 = lane_width_log2(ctx, cl.maxv);
+                    /* kept node states: where the expensive searches are — the three-call class and the heads of the others (16 records per wave: half a KB of LDS per
+                     * slot; in the 64-wide launches of the regions without estimated edits a slot would be 2 KB) */
+                    const uint32_t pool_heavy = ctx->lane_pool < 0 ? (la.nm == 2 ? 2u : (la.nm == 4 ? 4u : 6u)) /* lane_pool_default */ : (uint32_t)ctx->lane_pool;
+                    la.pool = ctx->lane_pool < 0 ? (cl.maxv > 2 ? pool_heavy : 0u) : (uint32_t)ctx->lane_pool;
                     la.max_nodes = cl.maxv > 2 ? (uint32_t)ctx->lane_node_cap : 250u;
                     la.max_ed_c = (uint32_t)ctx->lane_metrics_ed_cap;
                     uint32_t grid = 0;
@@ -1760,6 +1768,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         hd.n_tiles = head_tiles;
                         hd.tile_counter = db->d_counters + 1230 + fc;
                         hd.lanes_log2 = head_width_log2(ctx);
+                        hd.pool = pool_heavy;
                         uint32_t hgrid = 0;
                         const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
                         const int hi = (cl.maxv == 2 && ctx->lane_head_stream) ? 3 : li; /* a long head runs beside the rest of its class */

@@ -42,7 +42,8 @@ typedef uint64_t u64;
 extern uint64_t g_lane_stats[32];
 extern int g_lane_phase;
 extern uint32_t *g_lane_work; /* per region (caller order): a weighted count of what its lane did (tools/lane_stats.py) */
-extern uint32_t *g_lane_comp; /* per region: the first 8 counters above, as counted for that region alone */
+extern uint32_t *g_lane_comp; /* per region: the first 16 counters above, as counted for that region alone ([13] steps of zero-cost replays, [14] pops of
+                                 the genotype searches, [15] their replayed steps) */
 static inline uint64_t lane_work_now() { return 30 * g_lane_stats[0] + 60 * g_lane_stats[1] + 150 * g_lane_stats[2] + 100 * g_lane_stats[3] + 300 * g_lane_stats[6] + 600 * g_lane_stats[5]; }
 #define AVK_LSTAT(k, n) g_lane_stats[k] += (n)
 #define AVK_LPHASE(k) g_lane_phase = (k)
@@ -94,6 +95,7 @@ struct LCtx {
     u32 wfcap;   /* entries per wavefront array */
     u32 off_q, qcap;
     u32 off_opt, optcap;
+    u32 off_pool, pool; /* kept node states of the search (NodePool): first row, slots */
     /* the region */
     u32 L, T, Q, N, ord; /* ord: 3 bits per search depth = slot of the call handled there */
     u32 vw0[NS], vw1[NS]; /* slots [0, MV) truth, [MV, 2 MV) query: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 ; alt_ed | raw_space << 8 */
@@ -449,13 +451,8 @@ AVK_DEV u32 nodeA_cost(const NodeA &n) { return n.h[0].t_skip + n.h[0].q_skip + 
 /* One extension step of both haplotypes.  `cap` = the largest total node cost the caller cares about: the search only needs a
  * node's exact cost when the node can still be the next pop, and most wrongly phased branches never are — their alignments stop at
  * the first edit that proves cost > cap instead of running to a distance of tens (returns LS_PARTIAL and a lower bound > cap). */
-AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice, u32 cap, u32 &lb) {
-    const u32 slot = ord_slot(c, d);
-    const bool is_truth = slot < MV;
-    const u32 sync = sync_after(c, d);
-    AVK_LSTAT(2, 1);
-    hap_step(c, n.h[0], is_truth, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
-    hap_step(c, n.h[1], is_truth, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
+/* the alignments of a step whose haplotype steps are made (also: of a kept node whose last step was stopped early, taken further) */
+AVK_DEV int nodeA_settle(const LCtx &c, NodeA &n, u32 cap, u32 &lb) {
     const u32 base = n.h[0].t_skip + n.h[0].q_skip + n.h[1].t_skip + n.h[1].q_skip;
     lb = base + n.h[0].ed + n.h[1].ed; /* distances never decrease */
     if (lb > cap) return LS_PARTIAL;
@@ -467,6 +464,15 @@ AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice, u32 cap, u32 
     r = hap_update(c, n.h[1], 1, b1);
     if (r == LS_PARTIAL) lb = cap + 1;
     return r;
+}
+AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice, u32 cap, u32 &lb) {
+    const u32 slot = ord_slot(c, d);
+    const bool is_truth = slot < MV;
+    const u32 sync = sync_after(c, d);
+    AVK_LSTAT(2, 1);
+    hap_step(c, n.h[0], is_truth, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
+    hap_step(c, n.h[1], is_truth, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
+    return nodeA_settle(c, n, cap, lb);
 }
 AVK_DEV int nodeA_step(const LCtx &c, NodeA &n, u32 d, u32 choice) {
     u32 lb;
@@ -483,16 +489,75 @@ AVK_DEV int nodeA_replay(const LCtx &c, NodeA &n, u32 code, u32 depth) {
 /* The same for a node whose exact cost is known to be 0: no call was skipped and neither haplotype has an edit, on the node and (costs
  * never decrease along a path) on all its ancestors.  Every update stopped at the end of the shorter sequence without a mismatch, so
  * the wavefront is that offset and nothing needs to be compared again. */
-AVK_DEV void nodeA_replay_zero(const LCtx &c, NodeA &n, u32 code, u32 depth) {
+AVK_DEV void nodeA_replay_steps(const LCtx &c, NodeA &n, u32 code, u32 depth) { /* lengths, positions, skipped calls: everything but the alignments */
     hap_init(n.h[0]);
     hap_init(n.h[1]);
+    AVK_LSTAT(13, depth);
     for (u32 d = 0; d < depth; ++d) {
         const u32 slot = ord_slot(c, d), choice = (code >> (2 * d)) & 3u, sync = sync_after(c, d);
         hap_step(c, n.h[0], slot < MV, true, slot, (choice & 1u) ? L_ALT : L_REF, sync);
         hap_step(c, n.h[1], slot < MV, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
     }
+}
+AVK_DEV void nodeA_replay_zero(const LCtx &c, NodeA &n, u32 code, u32 depth) {
+    nodeA_replay_steps(c, n, code, depth);
     n.h[0].d0 = n.h[0].t_len < n.h[0].q_len ? n.h[0].t_len : n.h[0].q_len;
     n.h[1].d0 = n.h[1].t_len < n.h[1].q_len ? n.h[1].t_len : n.h[1].q_len;
+}
+/* ---- kept node states.  A node is queued as its path (code, depth); what the path does not say is where its two alignments stand: the distance and the
+ * front of each haplotype (while the distance is 0: the single offset d0).  Replaying the path to get them back is an alignment of the whole prefix per
+ * pop — for the regions that make a launch long, most of the work.  So the fronts of queued nodes that HAVE a distance (or whose last step was stopped
+ * early) are kept in a small pool of slots in the lane's rows, found again by the node's id; a node that finds no free slot is replayed as before.
+ * Slot: 2 x wfr rows (the two haplotypes' front arrays as they are); ids and distances of the slots in two registers (a byte per slot). */
+struct NodePool {
+    u64 ids; /* byte s: id of the node in slot s, 0xFF = free (ids stay below 251) */
+    u64 eds; /* byte s: ed of haplotype 0 | ed of haplotype 1 << 4 */
+};
+AVK_DEV u32 pool_find(const LCtx &c, const NodePool &pl, u32 id) {
+    u32 hit = c.pool;
+    for (u32 s = 0; s < c.pool; ++s)
+        if (((u32)(pl.ids >> (8 * s)) & 0xFFu) == id) hit = s;
+    return hit;
+}
+AVK_DEV void pool_free(NodePool &pl, u32 s) { pl.ids |= 0xFFull << (8 * s); }
+AVK_DEV void pool_save(const LCtx &c, NodePool &pl, u32 s, u32 id, const NodeA &n) {
+    pl.ids = (pl.ids & ~(0xFFull << (8 * s))) | ((u64)id << (8 * s));
+    pl.eds = (pl.eds & ~(0xFFull << (8 * s))) | ((u64)(n.h[0].ed | (n.h[1].ed << 4)) << (8 * s));
+    for (u32 k = 0; k < 2; ++k) {
+        u32 *dst = c.p + ((c.off_pool + (2 * s + k) * c.wfr) << c.ls);
+        if (n.h[k].ed == 0) {
+            dst[0] = n.h[k].d0;
+            continue;
+        }
+        const u32 rows = (2 * n.h[k].ed + 1 + 3) >> 2;
+        for (u32 r = 0; r < rows; ++r) dst[r << c.ls] = *c.wf_row(k, r);
+    }
+}
+AVK_DEV void pool_load(const LCtx &c, NodePool &pl, u32 s, NodeA &n) { /* the haplotype steps of n are made (nodeA_replay_steps); frees the slot */
+    const u32 e = (u32)(pl.eds >> (8 * s)) & 0xFFu;
+    n.h[0].ed = e & 15u, n.h[1].ed = e >> 4;
+    for (u32 k = 0; k < 2; ++k) {
+        const u32 *src = c.p + ((c.off_pool + (2 * s + k) * c.wfr) << c.ls);
+        if (n.h[k].ed == 0) {
+            n.h[k].d0 = src[0] & 0xFFu;
+            continue;
+        }
+        const u32 rows = (2 * n.h[k].ed + 1 + 3) >> 2;
+        for (u32 r = 0; r < rows; ++r) *c.wf_row(k, r) = src[r << c.ls];
+    }
+    pool_free(pl, s);
+}
+/* a queued node's state goes into a free slot, if there is one and the path alone does not say it all */
+AVK_DEV void pool_keep(const LCtx &c, NodePool &pl, u32 id, const NodeA &n, bool partial) {
+    if (!c.pool || !(partial || (n.h[0].ed | n.h[1].ed))) return;
+    u32 s = c.pool;
+    for (u32 k = 0; k < c.pool; ++k)
+        if (((u32)(pl.ids >> (8 * k)) & 0xFFu) == 0xFFu) s = k;
+    if (s >= c.pool) {
+        AVK_LSTAT(22, 1);
+        return;
+    }
+    pool_save(c, pl, s, id, n);
 }
 /* ComparisonNode::finalize_dwfas (:457-462, haplotype_dwfa.rs:84-95); LS_PARTIAL: the final cost is more than `cap` */
 AVK_DEV int nodeA_finalize(const LCtx &c, NodeA &n, u32 cap = 0xFFFFu) {
@@ -560,6 +625,8 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
     q_push(c, qn, 0);
     u32 next_id = 1, best = 0xFFFFu, nbest = 0;
     u64 bucket = 0; /* 8 bits per depth (fewer than 250 nodes are ever made) */
+    NodePool pl;
+    pl.ids = ~0ull, pl.eds = 0;
     while (qn > 0) {
         const u32 e = q_pop_min(c, qn);
         const u32 cost = e >> 24;
@@ -569,6 +636,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
         AVK_LSTAT(4, (e >> 3) & 1u);
         const u32 depth = e & 7u, code = (e >> 4) & 0xFFFu, id = (e >> 16) & 0xFFu;
         NodeA n;
+        bool have = false; /* n holds the node's state */
         if (e & 8u) { /* partial: ancestors are exact (they were popped), the last step is taken further */
             /* as far as it can matter for the order (the next entry's cost), and at least doubling, so that a node that really is
              * expensive is taken up a logarithmic number of times; never beyond the best finished cost (:204 drops it there) */
@@ -576,26 +644,59 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
             cap = cap > 2 * cost + 2 ? cap : 2 * cost + 2;
             cap = cap < best ? cap : best;
             cap = cap > cost ? cap : cost;
-            if (nodeA_replay(c, n, code, depth - 1)) return LS_DEFER;
             u32 lb = 0;
-            const int r = nodeA_step(c, n, depth - 1, (code >> (2 * (depth - 1))) & 3u, cap, lb);
+            int r;
+            const u32 slot = pool_find(c, pl, id);
+            if (slot < c.pool) { /* where the step stopped was kept: on from there */
+                AVK_LSTAT(20, 1);
+                nodeA_replay_steps(c, n, code, depth);
+                pool_load(c, pl, slot, n);
+                r = nodeA_settle(c, n, cap, lb);
+            } else {
+                AVK_LSTAT(21, 1);
+                if (nodeA_replay(c, n, code, depth - 1)) return LS_DEFER;
+                r = nodeA_step(c, n, depth - 1, (code >> (2 * (depth - 1))) & 3u, cap, lb);
+            }
             if (r == LS_DEFER) return LS_DEFER;
             if (r == LS_PARTIAL) {
                 if (pushA(c, qn, lb, id, code, 1, depth)) return LS_DEFER;
+                pool_keep(c, pl, id, n, true);
                 continue;
             }
             const u32 full = nodeA_cost(n);
             if (full != cost) {
                 if (pushA(c, qn, full, id, code, 0, depth)) return LS_DEFER;
+                pool_keep(c, pl, id, n, false);
                 continue;
             }
+            have = true;
         }
         const u32 cnt = (u32)(bucket >> (8 * depth)) & 0xFFu;
-        if (cnt >= c.max_branch) continue; /* :222 */
+        if (cnt >= c.max_branch) { /* :222 */
+            if (!have && cost) {
+                const u32 slot = pool_find(c, pl, id);
+                if (slot < c.pool) pool_free(pl, slot);
+            }
+            continue;
+        }
         bucket += 1ull << (8 * depth);
-        if (!(e & 8u)) {
+        if (!have) {
             if (cost == 0) nodeA_replay_zero(c, n, code, depth);
-            else if (nodeA_replay(c, n, code, depth)) return LS_DEFER;
+            else {
+                /* the path says what was skipped; a cost that is all skipped calls leaves no distance: the fronts are the ends of the shorter sequences */
+                nodeA_replay_steps(c, n, code, depth);
+                const u32 slot = n.h[0].t_skip + n.h[0].q_skip + n.h[1].t_skip + n.h[1].q_skip == cost ? c.pool + 1u : pool_find(c, pl, id);
+                if (slot > c.pool) {
+                    n.h[0].d0 = n.h[0].t_len < n.h[0].q_len ? n.h[0].t_len : n.h[0].q_len;
+                    n.h[1].d0 = n.h[1].t_len < n.h[1].q_len ? n.h[1].t_len : n.h[1].q_len;
+                } else if (slot < c.pool) {
+                    AVK_LSTAT(20, 1);
+                    pool_load(c, pl, slot, n);
+                } else {
+                    AVK_LSTAT(21, 1);
+                    if (nodeA_replay(c, n, code, depth)) return LS_DEFER;
+                }
+            }
         }
         if (depth == c.N) { /* :227-247 */
             const int r = nodeA_finalize(c, n, best);
@@ -620,17 +721,28 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
         u32 lb = 0;
         if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
             NodeA m = n;
-            /* the first child works on the arrays of `n`; the second is replayed from the root (the arrays hold child 1 by then) */
+            /* the first child works on the arrays of `n`; for the second the parent's fronts come back from a slot that held them meanwhile (or, without
+             * a free slot, by a replay from the root) */
+            const bool fronts = (m.h[0].ed | m.h[1].ed) != 0;
+            u32 held = c.pool;
+            if (fronts && c.pool) {
+                for (u32 k = 0; k < c.pool; ++k)
+                    if (((u32)(pl.ids >> (8 * k)) & 0xFFu) == 0xFFu) held = k;
+                if (held < c.pool) pool_save(c, pl, held, 0xFEu, m); /* (an id no node has) */
+            }
             int r = nodeA_step(c, n, depth, 2u, cost, lb);
             if (r == LS_DEFER) return LS_DEFER;
             if (pushA(c, qn, r ? lb : nodeA_cost(n), next_id, code | (2u << (2 * depth)), r ? 1u : 0u, depth + 1)) return LS_DEFER;
+            pool_keep(c, pl, next_id, n, r != 0);
             next_id += 1;
-            if (m.h[0].ed | m.h[1].ed) { /* parent wavefronts were overwritten */
-                if (nodeA_replay(c, m, code, depth)) return LS_DEFER;
+            if (fronts) { /* parent wavefronts were overwritten */
+                if (held < c.pool) pool_load(c, pl, held, m);
+                else if (nodeA_replay(c, m, code, depth)) return LS_DEFER;
             }
             r = nodeA_step(c, m, depth, 1u, cost, lb);
             if (r == LS_DEFER) return LS_DEFER;
             if (pushA(c, qn, r ? lb : nodeA_cost(m), next_id, code | (1u << (2 * depth)), r ? 1u : 0u, depth + 1)) return LS_DEFER;
+            pool_keep(c, pl, next_id, m, r != 0);
             next_id += 1;
         } else { /* :294-327: the node is moved, its id kept */
             u32 choice = 3u;
@@ -638,6 +750,7 @@ AVK_DEV int phaseA(const LCtx &c, u32 &best_out) {
             const int r = nodeA_step(c, n, depth, choice, cost, lb);
             if (r == LS_DEFER) return LS_DEFER;
             if (pushA(c, qn, r ? lb : nodeA_cost(n), id, code | (choice << (2 * depth)), r ? 1u : 0u, depth + 1)) return LS_DEFER;
+            pool_keep(c, pl, id, n, r != 0);
         }
         if (next_id > c.max_nodes) return AVK_LDEFER(3);
     }
@@ -670,6 +783,8 @@ AVK_DEV int phaseB(const LCtx &c, u32 in_t, u32 in_q, u32 &res_t, u32 &res_q) {
         const u32 errors = e >> 28, depth = e & 0xFu, code = (e >> 4) & 0xFFu, id = (e >> 12) & 0xFFFu;
         Hap h;
         hap_init(h);
+        AVK_LSTAT(14, 1);
+        AVK_LSTAT(15, depth);
         /* every queued node is exact (that is what let it in): its wavefront is the end of its shorter sequence, no comparing again */
         for (u32 d = 0; d < depth; ++d) {
             const u32 slot = ord_slot(c, d);
@@ -869,6 +984,7 @@ struct LaneArgs { /* what a launch of the lane kernel needs besides AvkKernelArg
     u32 gen_base;        /* record index (work order of the wave-per-region kernels) of fast record 0 */
     u32 max_ed_c;        /* largest distance a lane follows in the alignments of the metrics phase (beyond: handed over); 0 = what the rows hold */
     u32 max_nodes;       /* phase A gives up (hands the region over) beyond this many search nodes: at most 250 (ids are 8 bits) */
+    u32 pool;            /* node states a lane keeps during its search (NodePool; at most 8, 0 = every pop replays its path) */
     u32 lanes_log2;      /* 6, 5 or 4: a wave takes 64, 32 or 16 records of a tile at a time on its first lanes (smaller LDS slice per wave, more
                             waves per CU, less waiting for the slowest record) */
 };
@@ -1215,10 +1331,11 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
 
 /* LDS words per wave for a launch class */
 AVK_DEV u32 lane_optcap(u32 nm) { return nm == 2 ? 8u : 16u; } /* tied optima a lane keeps (16 bits each); more: handed over */
-AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap) {
+AVK_DEV u32 lane_pool_default(u32 nm) { return nm == 2 ? 2u : (nm == 4 ? 4u : 6u); } /* kept node states per lane (NodePool), by calls per side */
+AVK_DEV u32 lane_rows(u32 W, u32 nm, u32 ed_max, u32 qcap, u32 pool) {
     const u32 ns = 1 + 2 * (nm - 1);
     const u32 wfr = (2 * ed_max + 2 + 3) / 4;
-    return ns * (W + 1) + 3 * wfr + qcap + lane_optcap(nm) / 2;
+    return ns * (W + 1) + 3 * wfr + qcap + lane_optcap(nm) / 2 + pool * 2 * wfr;
 }
 
 /* One persistent wave: claims tiles of 64 fast records, every lane solves its record.  wave_lds = this wave's rows, wg_tally =
@@ -1239,6 +1356,8 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     c.qcap = la.qcap;
     c.off_opt = c.off_q + la.qcap;
     c.optcap = lane_optcap(la.nm);
+    c.off_pool = c.off_opt + c.optcap / 2;
+    c.pool = la.pool < 8u ? la.pool : 8u;
     c.max_nodes = la.max_nodes < 250u ? la.max_nodes : 250u;
     u32 n_ok = 0, n_err = 0, n_tiles_done = 0;
 #ifdef AVK_LANE_PHASE_TIMING
@@ -1281,14 +1400,14 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #endif
 #ifdef AVK_LANE_STATS
             const uint64_t work0 = lane_work_now();
-            uint64_t comp0[8];
-            for (int k = 0; k < 8; ++k) comp0[k] = g_lane_stats[k];
+            uint64_t comp0[16];
+            for (int k = 0; k < 16; ++k) comp0[k] = g_lane_stats[k];
 #endif
             const int st = solve_lane(a, c, rec, 64u, out, wg_tally);
 #ifdef AVK_LANE_STATS
             if (g_lane_work) g_lane_work[orig] = (uint32_t)(lane_work_now() - work0);
             if (g_lane_comp)
-                for (int k = 0; k < 8; ++k) g_lane_comp[8 * (size_t)orig + k] = (uint32_t)(g_lane_stats[k] - comp0[k]);
+                for (int k = 0; k < 16; ++k) g_lane_comp[16 * (size_t)orig + k] = (uint32_t)(g_lane_stats[k] - comp0[k]);
 #endif
             if (st == AVK_ST_OK) {
                 AVK_LT_MARK(c, 5)

@@ -164,6 +164,7 @@ int g_lane_kernel = 1; /* emu_set_lane_kernel: small regions through the lane-pe
 uint64_t g_lane_solved = 0;
 uint32_t g_lane_width_log2[3] = {6, 6, 4};
 uint32_t g_lane_node_cap = 32;
+int g_lane_pool = -1; /* context option lane_pool */
 uint32_t g_lane_head_width = 16; /* run_internal's option lane_head_width */ /* emu_set_lane_width: records a wave takes at a time in the one-call / two-call classes */
 
 struct LaneTask {
@@ -622,7 +623,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                     w.stack_bytes = 256 * 1024;
                     std::vector<char> stacks(64 * w.stack_bytes + 64);
                     w.stacks = stacks.data();
-                    std::vector<uint32_t> lds(((size_t)avk::lane::lane_rows(pla.W, pla.nm, pla.ed_max, pla.qcap) << 6) + 64, 0xA5A5A5A5u), tl(288, 0);
+                    std::vector<uint32_t> lds(((size_t)avk::lane::lane_rows(pla.W, pla.nm, pla.ed_max, pla.qcap, pla.pool) << 6) + 64, 0xA5A5A5A5u), tl(288, 0);
                     LaneTask t;
                     t.args = &pf, t.la = &pla, t.wave_id = 0, t.lds = lds.data(), t.tally = tl.data();
                     avk_emu::run_wave(&w, lane_kernel_main, &t);
@@ -662,11 +663,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             la.lanes_log2 = g_lane_width_log2[cl.maxv - 1];
             la.max_nodes = cl.maxv > 2 ? g_lane_node_cap : 250u;
             la.max_ed_c = 0;
+            const uint32_t pool_heavy = g_lane_pool < 0 ? avk::lane::lane_pool_default(la.nm) : (uint32_t)g_lane_pool; /* run_internal's rule */
+            la.pool = g_lane_pool < 0 ? (cl.maxv > 2 ? pool_heavy : 0u) : (uint32_t)g_lane_pool;
             AvkKernelArgs f3 = f; /* run_internal: the three-call class hands back to a list of its own, solved by an HBM-tier launch right behind it */
             f3.overflow_list = lists[3].data();
             f3.overflow_count = counters + 1104;
             auto launch = [&](const avk::lane::LaneArgs &la) {
-                const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap);
+                const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool);
                 std::atomic<uint32_t> next(0);
                 const uint32_t waves = n_waves ? n_waves : 1;
                 const int nthr = threads < 1 ? 1 : threads;
@@ -709,6 +712,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                 hd.n_tiles = head_tiles;
                 hd.tile_counter = counters + 1230 + fc;
                 hd.lanes_log2 = g_lane_head_width <= 4 ? 2u : (g_lane_head_width <= 8 ? 3u : (g_lane_head_width <= 16 ? 4u : 5u));
+                hd.pool = pool_heavy;
                 launch(hd);
                 la.recs += (size_t)head_tiles * la.rec_words * 64u;
                 la.n_tiles -= head_tiles;
@@ -1170,6 +1174,7 @@ void emu_wide_defer_stats(uint64_t *out, int reset) {
 #endif
 void emu_set_wide_lds_bytes(uint32_t bytes) { g_wide_lds_bytes = bytes; }
 void emu_set_lane_node_cap(int cap) { g_lane_node_cap = (uint32_t)cap; }
+void emu_set_lane_pool(int slots) { g_lane_pool = slots; }
 void emu_set_lane_head_width(int w) { g_lane_head_width = (uint32_t)w; }
 void emu_set_lane_width(int one, int two) {
     g_lane_width_log2[0] = one <= 16 ? 4 : (one <= 32 ? 5 : 6);
