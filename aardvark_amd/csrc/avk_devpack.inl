@@ -57,6 +57,8 @@ struct DpIn {
     u32 n_contigs;
     u32 pairs_mode;
     u64 v_lo, v_hi; /* the calls the batch's regions are expected to own (results are copied back for this range only: batches may share call arrays) */
+    u8 *owned;      /* [v_hi - v_lo] or NULL: forms with explicit call offsets — dp_region marks the calls its region owns, so that "every call of the range is owned
+                       exactly once" is counted, not assumed from the sum of the counts (two regions may share a call while another call belongs to nobody) */
 };
 
 /* context options the plan depends on (plan_work_order's arguments) */
@@ -114,7 +116,7 @@ struct DpState {
     u32 pad2_;
     u32 head_slots[AVK_FAST_CLASSES], pad4_; /* striped head of each lane class (avk_head_slots) */
     u64 fast_word_base[AVK_FAST_CLASSES], fast_words;
-    u32 n_big, pad3_; /* regions left to the wave-per-region record writer */
+    u32 n_big, n_owned; /* regions left to the wave-per-region record writer; marked calls of DpIn::owned */
 };
 
 struct DpArgs {
@@ -517,6 +519,12 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     }
     const u64 N = (u64)tc + qc;
     if ((tc && (toff < in.v_lo || toff + tc > in.v_hi)) || (qc && (qoff < in.v_lo || qoff + qc > in.v_hi))) avk_atomic_or_u32_global(&a.st->err, DP_NOTE_OUTSIDE);
+    if (in.owned) {
+        for (u32 i = 0; i < tc; ++i)
+            if (toff + i >= in.v_lo && toff + i < in.v_hi) in.owned[toff + i - in.v_lo] = 1;
+        for (u32 i = 0; i < qc; ++i)
+            if (qoff + i >= in.v_lo && qoff + i < in.v_hi) in.owned[qoff + i - in.v_lo] = 1;
+    }
     const u32 c = in.contig_idx ? in.contig_idx[r] : 0u;
     const u64 start = in.start[r], end = in.end[r];
     u32 pre = 0;

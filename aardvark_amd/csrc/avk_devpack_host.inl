@@ -285,6 +285,18 @@ __global__ void __launch_bounds__(256) avk_dp_region_records_wave_kernel(dpk::Dp
     for (uint32_t item = blockIdx.x * 4u + (threadIdx.x >> 6); item < n_big; item += n_waves) dpk::dp_region_record_wave(a, item);
 }
 
+/* how many calls of the batch's range some region owns (DpIn::owned) */
+__global__ void __launch_bounds__(256) avk_dp_count_owned_kernel(const uint8_t *owned, uint64_t n, dpk::DpState *st) {
+    __shared__ uint32_t part;
+    if (threadIdx.x == 0) part = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint64_t i = ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 16u, e = i + 16u < n ? i + 16u : n; i < e; ++i) mine += owned[i] ? 1u : 0u;
+    if (mine) atomicAdd(&part, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && part) atomicAdd(&st->n_owned, part);
+}
+
 /* alt_ed of the calls dp_variant left to the host */
 __global__ void avk_dp_patch_ed_kernel(dpk::DpVarInfo *vinfo, const uint32_t *idx, const uint32_t *ed, uint32_t n) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
@@ -989,6 +1001,11 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         if (hi > nv) hi = nv;
         if (lo > hi) lo = hi;
         a.in.v_lo = lo, a.in.v_hi = hi;
+        if ((b || cb) && !pairs_mode && hi > lo) { /* explicit offsets: ownership is counted (DpIn::owned) */
+            a.in.owned = (uint8_t *)tmp(hi - lo + 16);
+            if (rc) return bail(rc);
+            if (hipMemsetAsync(a.in.owned, 0, hi - lo, s) != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(hipGetLastError())));
+        }
     }
     const bool lanes = ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b;
     a.opt.tier0_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), a.opt.tier0_ed_cap = (uint32_t)ctx->lds_ed_cap, a.opt.tier1_bytes = (uint64_t)ctx->lds2_bytes_per_wave,
@@ -1008,6 +1025,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         hipError_t x = hipSuccess;
         if (n) {
             hipLaunchKernelGGL(avk_dp_region_kernel, dim3(n_blocks), dim3(256), 0, s, a, d_block_sums);
+            if (a.in.owned && a.in.v_hi > a.in.v_lo)
+                hipLaunchKernelGGL(avk_dp_count_owned_kernel, dim3((unsigned)((a.in.v_hi - a.in.v_lo + 4095) / 4096)), dim3(256), 0, s, (const uint8_t *)a.in.owned, a.in.v_hi - a.in.v_lo, a.st);
             hipLaunchKernelGGL(avk_dp_scan_blocks_kernel, dim3(AVK_DP_BS), dim3(1024), 0, s, d_block_sums, n_blocks, a.st);
             hipLaunchKernelGGL(avk_dp_scan_apply_kernel, dim3(n_blocks), dim3(256), 0, s, a, (const uint64_t *)d_block_sums);
             hipLaunchKernelGGL(avk_dp_lane_switch_kernel, dim3(1), dim3(64), 0, s, a);
@@ -1069,7 +1088,9 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     if (hs->total_v > 0x7FFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "more than 2^31 variant records; split the batch"));
     db->v_lo = a.in.v_lo, db->v_hi = a.in.v_hi;
     if (hs->err & dpk::DP_NOTE_OUTSIDE) db->v_lo = 0, db->v_hi = nv;
-    db->var_dense = !(hs->err & dpk::DP_NOTE_OUTSIDE) && hs->total_v == db->v_hi - db->v_lo; /* every call of the range is owned (once): nothing to preserve */
+    /* every call of the range is owned, and once: nothing to preserve.  The packed forms' offsets are the running sums of the counts — dense when the sums are right;
+     * forms with explicit offsets are dense when as many calls are marked as the range has and the counts add up to the same number */
+    db->var_dense = !(hs->err & dpk::DP_NOTE_OUTSIDE) && hs->total_v == db->v_hi - db->v_lo && (!a.in.owned || hs->n_owned == db->v_hi - db->v_lo);
     if (hs->total_blob_words / 2 > 0xFFFFFFFFull) return bail(fail(ctx, AVK_E_ARG, "region blob arena exceeds its limits; split the batch"));
     db->n_variants_dev = hs->total_v;
     db->seq_total = hs->total_seq;

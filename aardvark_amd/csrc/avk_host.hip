@@ -621,10 +621,10 @@ void avk_ctx_destroy(avk_ctx *ctx) {
 int avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream) {
     if (!ctx) return AVK_E_ARG;
     (void)hipSetDevice(ctx->device);
-    if (ctx->own_stream && ctx->stream) {
-        (void)hipStreamSynchronize(ctx->stream);
-        (void)hipStreamDestroy(ctx->stream);
-    }
+    /* the buffer pool and the bounce buffer hand memory out again in the order of ONE stream: whatever the previous stream still has queued (the writers of an
+     * upload's temporaries, say) is finished before another stream may be given the same buffers — also when the previous stream was the caller's */
+    if (ctx->stream != (hipStream_t)hip_stream) AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;
     return 0;
@@ -2221,7 +2221,8 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         for (uint64_t slice = 1ull << 30; !cap.empty() && slice <= (16ull << 30); slice <<= 2) {
             if ((int64_t)slice <= ctx->big_ws_bytes) continue;
             CapacityFix fx;
-            const bool want_gm = out->group_metrics && ctx->emit_group_metrics && db->d_gm;
+            const bool dev_gm = ctx->emit_group_metrics && db->d_gm; /* the batch keeps per-region blocks on the device (avk_label_tallies reads them) */
+            const bool want_gm = (out->group_metrics && ctx->emit_group_metrics && db->d_gm) || dev_gm;
             const bool want_bp = out->bp_off && out->bp_groups && db->d_bp;
             const int rc = rerun_capacity_regions(ctx, db, cap, want_gm, want_seq, want_bp, slice, &fx);
             if (rc == AVK_E_OOM) break; /* the device cannot hold slices of this size: the regions keep their status */
@@ -2237,12 +2238,22 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
                     continue;
                 }
                 put_region(r, (uint32_t)fx.status[k], fx.ed1[k], fx.ed2[k], fx.nopt[k], fx.present[k]);
+                { /* the batch on the device learns of the repair as well: its region record, and its metric block when it keeps them — the per-label sums of
+                   * avk_label_tallies count every solved region, as the totals do */
+                    const uint32_t w4[4] = {(uint32_t)fx.status[k], fx.ed1[k], fx.ed2[k], fx.nopt[k] | ((uint32_t)fx.present[k] << 16)};
+                    hipError_t ew = hipMemcpyAsync(db->d_region_out + 4 * (size_t)r, w4, sizeof(w4), hipMemcpyHostToDevice, s);
+                    if (ew == hipSuccess && dev_gm)
+                        ew = hipMemcpyAsync(db->d_gm + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS,
+                                            sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS, hipMemcpyHostToDevice, s);
+                    if (ew == hipSuccess) ew = hipStreamSynchronize(s); /* (w4 and fx leave scope) */
+                    if (ew != hipSuccess && !retry_rc) retry_rc = fail(ctx, AVK_E_HIP, "capacity retry: %s", hipGetErrorString(ew));
+                }
                 const AvkDevRegion &dr = db->host.regions[r];
                 for (uint32_t i = 0; i < dr.t_cnt + dr.q_cnt; ++i) {
                     const uint64_t sv = fx.v_first[k] + i;
                     put_call(db->host.dev2host[dr.v_off + i], fx.ve[sv], fx.vo[sv], fx.vc[sv], fx.vz[sv]);
                 }
-                if (want_gm) memcpy(out->group_metrics + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
+                if (want_gm && out->group_metrics) memcpy(out->group_metrics + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
                 if (want_bp && out->bp_off[r + 1] - out->bp_off[r] == fx.bp_off[k + 1] - fx.bp_off[k]) /* the same calls, so the same groups */
                     memcpy(out->bp_groups + 4 * (size_t)out->bp_off[r], fx.bp.data() + 4 * (size_t)fx.bp_off[k], 16 * (size_t)(fx.bp_off[k + 1] - fx.bp_off[k]));
                 if (want_seq)

@@ -98,6 +98,10 @@ struct LCtx {
     u32 off_pool, pool; /* kept node states of the search (NodePool): first row, slots */
     /* the region */
     u32 L, T, Q, N, ord; /* ord: 3 bits per search depth = slot of the call handled there */
+    u32 takeq;           /* bit d: depth d handles a query call */
+    u64 syncs;           /* byte d: the sync point behind depth d's step (the next call's position, the window's length behind the last) */
+    u32 ends[2];         /* 10 bits per call of a side: where its REF allele ends in the window (position + REF length) */
+    u32 plain;           /* 1: no call's alleles are at distance 0 from each other, so a node of cost 0 has skipped no call (nodeA_restore_zero) */
     u32 vw0[NS], vw1[NS]; /* slots [0, MV) truth, [MV, 2 MV) query: rel_pos | a0_len << 8 | a1_len << 16 | type << 24 | zyg << 28 ; alt_ed | raw_space << 8 */
     u64 seq_len_lo, seq_len_hi;   /* 8 bits per sequence id (ids 0-7, 8-15) */
     u64 seq_fail_lo, seq_fail_hi; /* failed_ed per sequence id (generate_allele_sequence, :745-753) */
@@ -440,7 +444,7 @@ template <class C> AVK_DEV int hap_finalize(const C &c, Hap &h, u32 arr, u32 bud
 }
 /* the search order (order_variants, query_optimizer.rs:372-381): slot of the call at depth d, and the step's sync point */
 AVK_DEV u32 ord_slot(const LCtx &c, u32 d) { return (c.ord >> (3 * d)) & 7u; }
-AVK_DEV u32 sync_after(const LCtx &c, u32 d) { return d + 1 < c.N ? (sel4(c.vw0, ord_slot(c, d + 1)) & 0xFFu) : c.L; }
+AVK_DEV u32 sync_after(const LCtx &c, u32 d) { return (u32)(c.syncs >> (8 * d)) & 0xFFu; }
 
 /* ---- phase A: optimize_sequences ------------------------------------------------------------------------------------- */
 /* a node = two haplotypes; code: 2 bits per depth, bit 0 = ALT on haplotype 1, bit 1 = ALT on haplotype 2 */
@@ -499,7 +503,45 @@ AVK_DEV void nodeA_replay_steps(const LCtx &c, NodeA &n, u32 code, u32 depth) { 
         hap_step(c, n.h[1], slot < MV, true, slot, (choice & 2u) ? L_ALT : L_REF, sync);
     }
 }
+/* The same in closed form, for regions without calls whose alleles are at distance 0 (c.plain): a node of cost 0 has then skipped no call, so every ALT it chose
+ * was spliced in where it stands — a side's reference position is the later of the last sync point and the end of the REF span of the side's last ALT call, its
+ * length that position plus what the chosen ALTs add (the length of FULL(side, chosen) minus the window's).  A dozen operations per haplotype and side whatever
+ * the depth, against a haplotype step per depth. */
+AVK_DEV void nodeA_restore_zero(const LCtx &c, NodeA &n, u32 code, u32 depth) {
+    u32 alt[2][2] = {{0, 0}, {0, 0}}; /* [haplotype][side] */
+    u32 cnt[2] = {0, 0};
+    for (u32 d = 0; d < depth; ++d) {
+        const u32 ch = (code >> (2 * d)) & 3u, q = (c.takeq >> d) & 1u;
+        const u32 at = q ? cnt[1] : cnt[0];
+        const u32 b0 = (ch & 1u) << at, b1 = (ch >> 1) << at;
+        alt[0][0] |= q ? 0u : b0, alt[0][1] |= q ? b0 : 0u;
+        alt[1][0] |= q ? 0u : b1, alt[1][1] |= q ? b1 : 0u;
+        cnt[0] += 1u - q, cnt[1] += q;
+    }
+    const u32 sync = depth ? sync_after(c, depth - 1) : 0u;
+#pragma unroll
+    for (u32 k = 0; k < 2; ++k) {
+        Hap &h = n.h[k];
+        u32 pos[2], len[2];
+#pragma unroll
+        for (u32 side = 0; side < 2; ++side) {
+            const u32 m = alt[k][side];
+            const u32 last = m ? (c.ends[side] >> (10u * (31u - (u32)__builtin_clz(m)))) & 0x3FFu : 0u;
+            pos[side] = last > sync ? last : sync;
+            len[side] = pos[side] + c.seq_len(c.seq_id(side, m)) - c.L;
+        }
+        h.t_refpos = pos[0], h.q_refpos = pos[1], h.t_len = len[0], h.q_len = len[1];
+        h.t_skip = h.q_skip = h.nskip = 0;
+        h.t_alt = alt[k][0], h.q_alt = alt[k][1], h.t_nal = cnt[0], h.q_nal = cnt[1];
+        h.ed = 0;
+        h.d0 = len[0] < len[1] ? len[0] : len[1];
+    }
+}
 AVK_DEV void nodeA_replay_zero(const LCtx &c, NodeA &n, u32 code, u32 depth) {
+    if (c.plain) {
+        nodeA_restore_zero(c, n, code, depth);
+        return;
+    }
     nodeA_replay_steps(c, n, code, depth);
     n.h[0].d0 = n.h[0].t_len < n.h[0].q_len ? n.h[0].t_len : n.h[0].q_len;
     n.h[1].d0 = n.h[1].t_len < n.h[1].q_len ? n.h[1].t_len : n.h[1].q_len;
@@ -1007,6 +1049,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
             it += 1u - q;
         }
         c.ord = ord;
+        c.takeq = takeq & ((1u << c.N) - 1u);
     }
     c.max_branch = a.max_branch_factor;
     c.seq_len_lo = c.L;
@@ -1027,6 +1070,22 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
             a1hi[s] = v[3 * lane_stride];
             types |= 1u << ((c.vw0[s] >> 24) & 0xFu);
         }
+    }
+    { /* tables of the search: sync points per depth, ends of the REF spans per side, whether a cost of 0 means that nothing was skipped */
+        u64 syncs = 0;
+        for (u32 d = 0; d < c.N; ++d) syncs |= (u64)(d + 1 < c.N ? (sel4(c.vw0, ord_slot(c, d + 1)) & 0xFFu) : c.L) << (8 * d);
+        c.syncs = syncs;
+        c.ends[0] = c.ends[1] = 0;
+        u32 plain = 1;
+#pragma unroll
+        for (u32 s = 0; s < NS; ++s) {
+            const u32 side = s / MV, j = s % MV;
+            if (j < (side ? c.Q : c.T)) {
+                c.ends[side] |= ((c.vw0[s] & 0xFFu) + ((c.vw0[s] >> 8) & 0xFFu)) << (10u * j);
+                if ((c.vw1[s] & 0xFFu) == 0) plain = 0;
+            }
+        }
+        c.plain = plain;
     }
     /* reference window: 2 bits per base from the packed genome; a flagged word (anything but upper-case ACGT) is not for this kernel */
     {
@@ -1460,8 +1519,8 @@ AVK_DEV void lane_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #endif
     }
 #ifdef AVK_LANE_PHASE_TIMING
-    if (lane < width) {
-        u64 *pc = a.tally + (u64)(wave_id % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5 + (la.nm > 2 ? 8 : 0); /* one-call classes, two-call classes */
+    if (lane < width && (la.nm > 4 || (la.nm == 4 && la.lanes_log2 < 6))) { /* the launches that end a step: the three-call class, the head of the two-call class */
+        u64 *pc = a.tally + (u64)(wave_id % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5 + (la.nm > 4 ? 0 : 8);
         for (int k = 0; k < 7; ++k) avk_atomic_add_u64_global(pc + k, c.tph[k]);
         avk_atomic_add_u64_global(pc + 7, 1);
     }

@@ -87,9 +87,10 @@ enum {
                                    window, unsorted variants, empty allele): the reference panics or is undefined */
     AVK_ST_CAPACITY = 21        /* device workspace exhausted at the largest tier AND in the library's own retries with slices of
                                    1, 4 and 16 GB (avk_results_download, context option "capacity_retry", default 1).  The retries repair
-                                   what avk_results_download hands to the caller (per-region and per-call arrays, out->tally); the
-                                   DEVICE-side totals of the same step — tally_dev of avk_compare_resident, what avk_label_tallies reads —
-                                   still count a retried region as failed */
+                                   what avk_results_download hands to the caller (per-region and per-call arrays, out->tally) and the
+                                   batch's region records and metric blocks on the device, so that avk_label_tallies AFTER the download
+                                   counts the repaired regions as the totals do; tally_dev of avk_compare_resident was written before
+                                   the download and still counts a retried region as failed */
 };
 
 /* infrastructure errors (function return values) */

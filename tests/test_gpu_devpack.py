@@ -106,6 +106,16 @@ def test_capacity_retry_of_a_device_packed_batch(oracle):
         got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False))
         want = oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS)
         assert got.diff(want) == []
+        # the per-label sums of a resident batch, taken after the download that repaired the regions, count the repaired regions too (one label on every region:
+        # its sums are the batch's)
+        rb = ctx.upload(batch)
+        ctx.compare_resident(rb)
+        res = ctx.download(rb, group_metrics=True)
+        assert res.diff(want) == []
+        n = batch.n_regions
+        sums = ctx.label_tallies(rb, 1, np.arange(n + 1, dtype=np.uint64), np.zeros(n, np.uint32))
+        assert np.array_equal(sums[0][:13 * 22], want.tally[:13 * 22])
+        rb.free()
         ctx.set_option("capacity_retry", 0)
         starved = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False))
         assert (starved.status == 21).any()  # some regions do exhaust the last tier on the first try
@@ -180,6 +190,37 @@ def test_batches_that_share_the_call_arrays(ctx_pair, oracle):
                 whole.tally += res.tally
             assert whole.diff(want) == []
         c.set_option("emit_group_metrics", 1)
+
+
+def test_a_shared_call_and_an_unowned_call_in_one_range(ctx_pair, oracle):
+    """the counts of a batch's regions add up to the size of its call range, yet one call is owned by two regions and another by none: the unowned call keeps what
+    the caller's arrays hold (ownership is counted on the device, DpIn::owned, not inferred from the sum)"""
+    import ctypes as C
+    from aardvark_amd._abi import ResultBatch
+    contig, batch = synth.config_indel_mix_v2(n_truth=3_000, contig_len=1_200_000)
+    # regions with exactly one truth call and one query call each, far apart in the list
+    ones = np.nonzero((batch.t_cnt == 1) & (batch.q_cnt == 1))[0]
+    r0, r1 = int(ones[3]), int(ones[len(ones) // 2])
+    t_off = batch.t_off.copy()
+    orphan = int(t_off[r1])
+    t_off[r1] = t_off[r0]  # region r1's truth call is now region r0's: shared; its own is nobody's
+    odd = RegionBatch(batch.region_id, batch.contig_idx, batch.start, batch.end, t_off, batch.t_cnt, batch.q_off, batch.q_cnt, batch.var_pos, batch.var_type, batch.var_zyg,
+                      batch.var_raw_space, batch.a0_off, batch.a0_len, batch.a1_off, batch.a1_len, batch.allele_bytes)
+    cfg = CompareConfig(enable_sequences=False).c_struct()
+    for c in ctx_pair:
+        c.upload_reference([contig])
+        res = ResultBatch(odd, sequences=False, group_metrics=False)
+        for f in ("var_expected", "var_observed", "var_class", "var_zyg"):
+            getattr(res, f)[:] = 0x5A
+        cb, ro = odd.c_struct(), res.c_struct()
+        c._check(c.lib.avk_compare_batch(c.handle, C.byref(cb), C.byref(cfg), C.byref(ro)))
+        assert [int(getattr(res, f)[orphan]) for f in ("var_expected", "var_observed", "var_class", "var_zyg")] == [0x5A] * 4
+        owned = np.ones(batch.n_variants, bool)
+        owned[orphan] = False
+        assert not (res.var_class[:batch.n_variants][owned] == 0x5A).any()
+        # every region but r1 (whose window may not hold r0's call) solves as in the untouched batch
+        want = oracle_lib.compare_batch(oracle, odd, [contig], threads=CPUS, group_metrics=False)
+        assert np.array_equal(res.status, want.status) and np.array_equal(res.ed_h1, want.ed_h1)
 
 
 def test_compact_form(ctx_pair, oracle):

@@ -112,3 +112,23 @@ def test_head_launch_and_node_budget_do_not_change_results(oracle, head, cap):
     finally:
         lib.emu_set_lane_head_width(16)
         lib.emu_set_lane_node_cap(32)
+
+
+@pytest.mark.parametrize("pool", [0, 1, 3, 8])
+def test_kept_node_states_do_not_change_a_result(oracle, pool):
+    """option lane_pool: the fronts of queued nodes with a distance (and of nodes whose last step was stopped early) kept in `pool` slots per lane, taken up again
+    when the node is popped; without a free slot, or with 0 slots, the node's path is replayed.  Regions with many costly nodes, with the branch quota deciding
+    and without; 16 records per wave and 64"""
+    lib = emu_lib.load()
+    for seed, kw, quota in ((121, {"max_vars": 3, "related": 0.5}, 50), (122, {"max_vars": 2, "repeat_unit": b"CA", "max_len": 6}, 50), (123, {"max_vars": 3, "related": 0.9, "max_len": 12}, 2),
+                            (124, {"max_vars": 2, "span": (8, 60), "max_len": 4}, 1)):
+        contigs, batch = scenarios.fuzz_regions(seed, 300, **kw)
+        want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4, max_branch_factor=quota)
+        for width in (64, 16):
+            lib.emu_set_lane_width(width, width)
+            try:
+                got = emu_lib.compare_batch(batch, contigs, threads=THREADS, n_waves=8, max_branch_factor=quota, lane_pool=pool)
+            finally:
+                lib.emu_set_lane_width(64, 64)
+            assert got.diff(want) == [], (seed, width)
+            assert got.lane_solved > 0.2 * batch.n_regions

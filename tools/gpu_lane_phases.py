@@ -21,7 +21,7 @@ ctx.download(rb, group_metrics=False)
 ph = ctx.debug_phase_cycles()
 names = ["record + window + tables", "search A", "optimum replay + genotypes", "per-call outputs + ed to reference", "per-type alignments", "metric groups + tally",
          "whole tiles"]
-for base, what in ((0, "one-call classes"), (8, "two-call classes")):
+for base, what in ((0, "three-call class"), (8, "head of the two-call class")):
     lanes = max(int(ph[base + 7]), 1)
     tot = max(int(ph[base + 6]), 1)
     print("%s: %d lanes, %.0f ticks per lane in tiles" % (what, lanes, tot / lanes))

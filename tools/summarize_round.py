@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarises a tools/profile_r03.sh run (rocpd databases under gpurun_out/prof_<tag>/) into profiles/<tag>_kernel_stats.txt,
+"""Summarises a tools/profile_round.sh run (rocpd databases under gpurun_out/prof_<tag>/) into profiles/<tag>_kernel_stats.txt,
 profiles/<tag>_pmc.txt and profiles/<tag>_pmc_traffic.json.  Kernels are reported per launch geometry (name, grid, LDS bytes)."""
 import glob, json, os, sqlite3, sys
 tag = sys.argv[1]
@@ -40,8 +40,28 @@ for d in sorted(glob.glob(os.path.join(src, "pmc*", tag + "_results.db"))):
             vals.setdefault((kname.split("(")[0], grid, lds), {})[cname] = avg
     except Exception as e:
         pm.append("%s: %s" % (d, e))
-step_traffic = 0.0
-pack_traffic = 0.0
+# HBM traffic per STEP: a launch geometry's average per dispatch times its dispatches per step (two hand-back launches of the wide kernel share a geometry), by launch class.
+# avk_ps_* (the prefix sums of the packed form) and avk_dp_* are the packing of a boundary call, not the solver's.
+steps = {}
+for d in sorted(glob.glob(os.path.join(src, "pmc*", tag + "_results.db"))):
+    c = sqlite3.connect(d).cursor()
+    try:
+        for kname, grid, lds, cname, n in c.execute("select kernel_name, grid_size, lds_block_size, counter_name, count(*) from counters_collection where kernel_name like 'avk_%' "
+                                                    "group by kernel_name, grid_size, lds_block_size, counter_name"):
+            steps.setdefault(cname, {})[(kname.split("(")[0], grid, lds)] = n
+    except Exception:
+        pass
+def klass(name):
+    if name.startswith("avk_dp_unpack"):
+        return "results (dp_unpack)"
+    if name.startswith("avk_dp_") or name.startswith("avk_ps_") or name.startswith("avk_pack"):
+        return "packing"
+    for key, label in (("avk_lane", "lanes"), ("avk_pair", "looked-up pairs"), ("avk_wide", "wide"), ("avk_region_kernel_lds", "wave-per-region, LDS tiers"),
+                       ("avk_region_kernel_hbm", "wave-per-region, HBM tier"), ("avk_tally", "tally reduce")):
+        if name.startswith(key):
+            return label
+    return "other"
+per_class = {}
 have_traffic = False
 for k in sorted(vals, key=lambda k: -vals[k].get("SQ_WAVE_CYCLES", 0)):
     v = vals[k]
@@ -57,14 +77,20 @@ for k in sorted(vals, key=lambda k: -vals[k].get("SQ_WAVE_CYCLES", 0)):
         pm.append("    instruction cache hit rate = %.4f" % (v.get("SQC_ICACHE_HITS", 0) / v["SQC_ICACHE_REQ"]))
     if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
         t = (v["FETCH_SIZE"] + v["WRITE_SIZE"]) * 1024
-        pm.append("    HBM bytes per dispatch (FETCH_SIZE + WRITE_SIZE, KiB units) = %.0f" % t)
-        if k[0].startswith("avk_dp_"):
-            pack_traffic += t
-        elif not k[0].startswith("avk_pack"):
-            step_traffic += t
-            have_traffic = True
+        n_red = max(sum(n for kk, n in steps.get("FETCH_SIZE", {}).items() if kk[0].startswith("avk_tally_reduce")), 1)
+        per_step = steps.get("FETCH_SIZE", {}).get(k, n_red) / n_red
+        pm.append("    HBM bytes per dispatch (FETCH_SIZE + WRITE_SIZE, KiB units) = %.0f; dispatches per step %.2f" % (t, per_step))
+        per_class[klass(k[0])] = per_class.get(klass(k[0]), 0.0) + t * per_step
+        have_traffic = True
+solver = sum(v for c, v in per_class.items() if c not in ("packing", "results (dp_unpack)", "other"))
+pm.append("")
+pm.append("# HBM bytes per step by launch class (packing and results belong to the boundary call: per call, counted over the steps that ran them)")
+for c, v in sorted(per_class.items(), key=lambda kv: -kv[1]):
+    pm.append("    %-32s %.0f" % (c, v))
+pm.append("    %-32s %.0f" % ("solver launches of a step", solver))
 open(os.path.join(dst, tag + "_pmc.txt"), "w").write("\n".join(pm) + "\n")
 print("\n".join(pm))
-json.dump({"tag": tag, "hbm_bytes_per_launch": step_traffic if have_traffic else None, "packing_kernels_hbm_bytes_per_call": pack_traffic,
-           "note": "sum over the solver launches of one step (lane classes, bulk, solo, overflow, reduce): FETCH_SIZE + WRITE_SIZE in KiB x 1024",
+json.dump({"tag": tag, "hbm_bytes_per_launch": solver if have_traffic else None, "hbm_bytes_per_step_by_class": per_class,
+           "note": "sum over the SOLVER launches of one step (lanes, looked-up pairs, wide, wave-per-region tiers, tally reduce): (FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch x dispatches per "
+                   "step; the packing kernels (avk_dp_*, avk_ps_*) and the result unpacking are listed on their own",
            "per_kernel_avg_us": {"%s grid=%d lds=%d" % k: v for k, v in geo.items()}}, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
