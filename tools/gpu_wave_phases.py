@@ -9,6 +9,12 @@ from aardvark_amd import synth, CompareConfig
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 gap = int(os.environ.get("GAP", "50"))  # GAP=1000: the large-window workload of bench.py's secondary leg (use scale 0.05)
 contigs, batch = synth.config_genome(scale=scale, gap=gap) if gap != 50 else synth.config_genome(scale=scale)
+if os.environ.get("LARGEST"):  # LARGEST=0.001: only that share of the regions, the ones with the most calls
+    import numpy as np
+    from aardvark_amd.dist import take_regions, gather_calls
+    calls = batch.t_cnt.astype(np.int64) + batch.q_cnt
+    keep = np.sort(np.argsort(-calls, kind="stable")[:max(1, int(batch.n_regions * float(os.environ["LARGEST"])))])
+    batch = gather_calls(take_regions(batch, keep))
 ctx = aardvark_amd.Context(0)
 ctx.set_option("emit_group_metrics", 0)
 for kv in (sys.argv[2] if len(sys.argv) > 2 else "").split(","):
