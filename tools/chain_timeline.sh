@@ -1,10 +1,11 @@
 #!/bin/bash
-# Round 3, on the GPU box: for each option string (one argument each; "-" = defaults): wall time of 50 queued whole-genome resident steps in a fresh
+# On the GPU box: for each option string (one argument each; "-" = defaults): wall time of 50 queued whole-genome resident steps in a fresh
 # process, then the kernel timeline of one step (rocprofv3 --kernel-trace on the same probe, 3 steps): which launch ends when.
-# usage: tools/r03_chain.sh "-" "lane_stripe=0" ...
+# usage: tools/chain_timeline.sh "-" "lane_stripe=0" ...
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R
 mkdir -p gpurun_out
+[ -x .scratch/first_step_probe ] || { mkdir -p .scratch; g++ -O2 -std=c++17 -I include -I /opt/rocm/include -D__HIP_PLATFORM_AMD__ -o .scratch/first_step_probe tools/first_step_probe.cpp -L aardvark_amd -laardvark_amd -Wl,-rpath,$R/aardvark_amd -L/opt/rocm/lib -lamdhip64; }
 [ -f /tmp/w100.bin ] || python tools/dump_workload.py 1.0 /tmp/w100.bin > /dev/null
 k=0
 for o in "$@"; do
