@@ -1107,6 +1107,9 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         if (pick > 6) pick = 6;
         const int64_t want = 1ll << (20 + pick);
         db->ws_bytes_eff = want > ctx->ws_bytes_per_wave && ctx->ws_bytes_per_wave > 0 && ctx->adaptive_ws ? want : 0;
+        /* regions predicted beyond the last bucket (windows of tens of kilobases with dozens of calls): the shared slices start at the size of the library's first
+         * capacity retry, so that these regions are solved in the step and not again, one sub-batch at a time, by avk_results_download */
+        db->big_bytes_eff = hs->need_hist[dpk::DP_NEED_BUCKETS - 1] > 0 && ctx->adaptive_ws ? (1ll << 30) : 0;
     }
     db->plan.n_hbm = hs->n_hbm, db->plan.n_hard = hs->n_hard, db->plan.n_fast_total = hs->n_fast_total, db->plan.n_hbm_notwide = hs->n_hbm_notwide;
     uint32_t tiles_total = 0;

@@ -420,6 +420,7 @@ struct avk_dev_batch {
     uint32_t m_inputs = 0;
     uint64_t v_lo = 0, v_hi = 0;          /* the calls the batch's regions own: results are copied back for this range of the caller's arrays only */
     bool var_dense = false;               /* every call of the range is owned by a region of the batch */
+    int64_t big_bytes_eff = 0;            /* shared big slices of this batch's launches when the packer predicts regions beyond the largest bucket (0: the option big_ws_bytes) */
     int64_t ws_bytes_eff = 0;             /* per-wave HBM slice of this batch's launches when the packer's prediction asks for more than the option ws_bytes_per_wave (0: the option) */
     bool records_full = false; /* every region has its AvkDevRegion + blob (false: only the regions outside the lane classes, until a launch asks for more) */
 };
@@ -1312,7 +1313,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         ctx->ws_alloc = ws_need;
     }
     const uint32_t big_blocks = (uint32_t)((big_waves + waves_per_block - 1) / waves_per_block);
-    const size_t big_need = (size_t)big_blocks * waves_per_block * (size_t)ctx->big_ws_bytes;
+    const int64_t big_bytes = db->big_bytes_eff > ctx->big_ws_bytes && ctx->big_ws_bytes > 0 ? db->big_bytes_eff : ctx->big_ws_bytes;
+    const size_t big_need = (size_t)big_blocks * waves_per_block * (size_t)big_bytes;
     if (big_need > ctx->big_alloc) {
         if (ctx->d_big) {
             AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1358,7 +1360,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     a.tier[1].ed_cap = (uint32_t)ctx->lds2_ed_cap;
     a.tier[2].ws_bytes = (uint64_t)ws_bytes;
     a.tier[2].ed_cap = ctx->hbm_ed_cap > 0 ? ((uint32_t)ctx->hbm_ed_cap | AVK_CAP_BOUND_ONLY) : 0u;
-    a.tier[3].ws_bytes = (uint64_t)ctx->big_ws_bytes;
+    a.tier[3].ws_bytes = (uint64_t)big_bytes;
     a.tier[3].ed_cap = 0;
     a.region_out = db->d_region_out;
     a.group_metrics = ctx->emit_group_metrics ? db->d_gm : nullptr;
