@@ -2343,8 +2343,11 @@ int avk_ctx_reserve(avk_ctx *ctx, uint64_t n_regions, uint64_t n_variants) {
 static void warm_kernels(int device) {
     avk_ctx *t = nullptr;
     if (avk_ctx_create(device, &t) || !t) return;
-    const char *opts[] = {"lane_min_regions", "lane_min_batch", "emit_group_metrics"};
+    const char *opts[] = {"lane_min_regions", "lane_min_batch", "emit_group_metrics", "adaptive_ws"}; /* (adaptive_ws 0: with the class C threshold below the packer
+                                                                                                          would predict, and this context allocate, tens of GB of slices) */
     for (const char *o : opts) (void)avk_ctx_set_option(t, o, 0);
+    (void)avk_ctx_set_option(t, "big_ws_bytes", 8 << 20);
+    (void)avk_ctx_set_option(t, "big_waves", 4);
     (void)avk_ctx_set_option(t, "class_c_nodes_x2", 1000); /* every region the lanes do not take is planned as class C: the wide kernel, the HBM launches */
     (void)avk_ctx_set_option(t, "lane_node_cap", 4);       /* ... and the three-call class hands back */
     const uint32_t L = 120, n_contig = 1u << 16;
