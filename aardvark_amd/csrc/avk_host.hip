@@ -296,6 +296,8 @@ struct avk_ctx {
     int64_t lds_escalation = 1; /* in-workgroup escalation of the bulk launch (AvkKernelArgs::esc_bytes) */
     int64_t lds2_overflow_pass = 0; /* 1: a launch of its own with large LDS slices between the bulk and the HBM tier */
     int64_t bulk_full_grid = 0; /* 1: keep the bulk grid at full size (late workgroups only claim); measured unstable */
+    int64_t bulk_fit = 1;       /* 1: no more workgroups in the bulk launch than its list has regions for (a genome leaves it three dozen regions: 664 workgroups of 40 KB of
+                                   LDS queued for them beside the lane launches) */
     int64_t ws_bytes_per_wave = 1 << 20;
     int64_t big_ws_bytes = 256ll << 20;
     int64_t big_waves = 8;
@@ -657,6 +659,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->lds2_overflow_pass = value ? 1 : 0;
     } else if (n == "bulk_full_grid") {
         ctx->bulk_full_grid = value ? 1 : 0;
+    } else if (n == "bulk_fit") {
+        ctx->bulk_fit = value ? 1 : 0;
     } else if (n == "solo_regions_per_wave") {
         if (value < 1 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_regions_per_wave must be in [1, 1024]");
         ctx->solo_regions_per_wave = value;
@@ -1805,6 +1809,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (bulk < 1) bulk = 1;
             if (bulk > blocks) bulk = blocks;
             if (ctx->bulk_full_grid) bulk = blocks;
+            const uint32_t bulk_unfit = bulk; /* (the launch for the lanes' hand-backs below is sized by this) */
+            if (ctx->bulk_fit && !ctx->bulk_full_grid) {
+                const uint32_t fit = (a.n_work + waves_per_block - 1) / waves_per_block;
+                if (bulk > fit) bulk = fit < 1 ? 1 : fit;
+            }
             a.n_waves = bulk * waves_per_block;
             const uint64_t slice0 = a.tier[0].ws_bytes;
             if (ctx->lds_bytes_per_wave >= 1024) { /* slices shrink to make room for the workgroup's tail */
@@ -1838,7 +1847,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     d.work_list = db->d_overflow7;
                     d.n_work_dev = db->d_counters + 1264;
                 }
-                uint32_t dblocks = bulk < (uint32_t)ctx->n_cus ? bulk : (uint32_t)ctx->n_cus; /* one workgroup per CU: the list is short */
+                uint32_t dblocks = bulk_unfit < (uint32_t)ctx->n_cus ? bulk_unfit : (uint32_t)ctx->n_cus; /* one workgroup per CU: the list is short */
                 d.n_waves = dblocks * waves_per_block;
                 d.overflow_list = lists[1];
                 d.overflow_count = db->d_counters + 1024 + 16;

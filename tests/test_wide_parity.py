@@ -115,7 +115,7 @@ def test_windows_with_other_symbols_and_long_alleles_are_handed_over(oracle):
     wide, _ = through_wide(oracle, contigs, batch, n_waves=8)
     assert 0 < wide.wide_solved < batch.n_regions
     contigs, batch = scenarios.long_allele_regions()
-    wide, _ = through_wide(oracle, contigs, batch, n_waves=2)
+    wide, _ = through_wide(oracle, contigs, batch.slice(2, 4), n_waves=2)  # the 600 bp SV pair and the TR pair (the 3 kbp pair takes the emulator a minute; it runs on the GPU)
     assert wide.wide_solved == 0
 
 

@@ -30,9 +30,12 @@ def check(name, contigs, batch, sequences=True, mbf=50):
     want = oracle_lib.compare_batch(lib, batch, contigs, sequences=sequences, threads=min(16, os.cpu_count() or 1), max_branch_factor=mbf)
     t1 = time.time()
     ctx.upload_reference(contigs)
-    got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=sequences, max_branch_factor=mbf))
+    got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=sequences, max_branch_factor=mbf), packed=True)  # the wide arrays and the packed result form
     t2 = time.time()
     d = got.diff(want)
+    lanes_n, wide_n, tiers_n = ctx.last_lane_solved(), ctx.last_wide_solved(), ctx.last_tier_counts()
+    if not d:
+        d = ["packed:" + x for x in got.expanded(ctx.lib, batch).diff(want)]
     one_shot = " one-shot" if ctx.last_compare_was_one_shot() else ""
     if not d and os.environ.get("FORMS", "1") != "0":  # the same batch through the compact and the packed form (avk_compare_compact / avk_compare_packed), where it fits them
         from aardvark_amd import CompactBatch, PackedBatch
@@ -54,8 +57,8 @@ def check(name, contigs, batch, sequences=True, mbf=50):
             pass
     total += batch.n_regions
     cases += 1
-    print("%-70s %8d regions  oracle %.2fs gpu %.2fs  tiers %s lanes %d%s  status!=0: %d  %s" % (
-        name, batch.n_regions, t1 - t0, t2 - t1, ctx.last_tier_counts(), ctx.last_lane_solved(), one_shot,
+    print("%-70s %8d regions  oracle %.2fs gpu %.2fs  tiers %s lanes %d wide %d%s  status!=0: %d  %s" % (
+        name, batch.n_regions, t1 - t0, t2 - t1, tiers_n, lanes_n, wide_n, one_shot,
         int((want.status != 0).sum()), "OK" if not d else "DIFF " + str(d)), flush=True)
     if d:
         n = batch.n_regions
