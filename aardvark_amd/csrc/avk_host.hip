@@ -1479,11 +1479,19 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     w.overflow_list = db->d_overflow5;
                     w.overflow_count = db->d_counters + 1244;
                     uint32_t wg = n_c < (uint32_t)ctx->wide_blocks ? n_c : (uint32_t)ctx->wide_blocks;
+                    /* workgroups of the launch for the records that are not the wide kernel's: slices from the END of the solo launch's share, which keeps at least half of
+                     * it — a batch with large per-wave slices (adaptive_ws under its budget) may have a share of eight workgroups, and the two launches must never meet on
+                     * a slice (they did: xb == hbm_solo_max left the solo launch one workgroup ON the other's first slices — wrong results in a fuzz case where every
+                     * region was planned as class C, profiles/r04_gpu_fuzz_classc.txt) */
+                    uint32_t xb = (n_nw + 3u) / 4u;
+                    xb = xb < hbm_solo ? xb : hbm_solo;
+                    xb = xb < 64u ? xb : 64u;
+                    if (2u * xb > hbm_solo_max) xb = hbm_solo_max / 2u;
                     avk::wide::WideArgs wc = wa;
-                    wc.skip_static = n_nw ? 1u : 0u; /* (without the launch below such a record is handed over like any other) */
+                    wc.skip_static = n_nw && xb ? 1u : 0u; /* (without the launch below such a record is handed over like any other) */
                     hipLaunchKernelGGL(avk_wide_kernel, dim3(wg), dim3(64), (size_t)ctx->wide_lds_bytes, ctx->side_stream2, w, wc);
                     AVK_HIP(ctx, hipGetLastError());
-                    if (n_nw) { /* the records of class C that are not for the wide kernel by what they say themselves (avk_wide_static_ok: a long window, many calls on a
+                    if (n_nw && xb) { /* the records of class C that are not for the wide kernel by what they say themselves (avk_wide_static_ok: a long window, many calls on a
                        * side) start at the same time, on the HBM-tier kernel and a stream of their own: they are few and each of them is long */
                         AvkKernelArgs x = s;
                         x.pass_tier = 2;
@@ -1497,9 +1505,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.n_shards = 1;
                         x.claim = 4;
                         x.high_priority = 1;
-                        uint32_t xb = (n_nw + 3u) / 4u;
-                        xb = xb < hbm_solo ? xb : hbm_solo;
-                        xb = xb < 64u ? xb : 64u;
                         x.n_waves = xb * waves_per_block;
                         x.hbm_ws = ctx->d_ws + (size_t)(n_waves + (hbm_solo_max - xb) * waves_per_block) * (size_t)ws_bytes; /* the last slices of the solo launch's share (that launch gets the others) */
                         x.big_ws = ctx->d_big;
@@ -1512,7 +1517,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_wide, ctx->wide_stream));
                         wide_x = true;
-                        if (hbm_solo > hbm_solo_max - xb) hbm_solo = hbm_solo_max - xb > 0 ? hbm_solo_max - xb : 1;
+                        if (hbm_solo > hbm_solo_max - xb) hbm_solo = hbm_solo_max - xb; /* (at least half of the share: xb <= hbm_solo_max / 2) */
                     }
                     wide_c = true;
                     s.work_list = db->d_overflow5;

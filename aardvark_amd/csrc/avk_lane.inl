@@ -1134,6 +1134,13 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
     NodeA wn;
     for (u32 k = 0; k < (u32)nopt; ++k) {
         const u32 code = opt_get(c, k);
+        if (k) { /* the mirror image of an earlier optimum — the same two haplotypes the other way round, as every orientation of unphased hets has one — needs the
+                    same flips in total and comes later: it cannot win (:264-265 takes the first of the fewest), and it fails where the earlier one would have */
+            const u32 mirror = ((code & 0x555u) << 1) | ((code >> 1) & 0x555u);
+            bool seen = false;
+            for (u32 j = 0; j < k && mirror != code; ++j) seen = seen || opt_get(c, j) == mirror;
+            if (seen) continue;
+        }
         NodeA n;
         if (best_cost == 0) { /* nothing skipped, no edits: the finished haplotypes are equal sequences */
             nodeA_replay_zero(c, n, code, c.N);

@@ -96,3 +96,27 @@ def test_hand_backs_of_the_three_call_lane_class_and_class_c_of_a_genome_slice()
         assert ctx.last_wide_solved() > 100
     finally:
         ctx.close()
+
+
+def test_small_slice_shares_do_not_overlap(oracle):
+    """A workspace budget that leaves the class C launches eight workgroups' worth of HBM slices (as a batch with large adaptive slices does): the launch for the
+    records that are not the wide kernel's takes its slices from the end of the solo launch's share and must leave that launch slices of its own — the two once met on
+    a slice and a fuzz case came back wrong, now and then (profiles/r04_gpu_fuzz_classc.txt)"""
+    import aardvark_amd
+    from aardvark_amd import CompareConfig
+    contigs, batch = scenarios.fuzz_regions(411003, 20000, max_vars=9, span=(40, 200))
+    want = oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS, group_metrics=False)
+    ctx = aardvark_amd.Context(0)
+    try:
+        ctx.set_option("lane_min_regions", 0)
+        ctx.set_option("class_c_nodes_x2", 1000)
+        ctx.set_option("adaptive_ws", 0)
+        ctx.set_option("ws_bytes_per_wave", 4 << 20)
+        ctx.set_option("ws_budget_bytes", 1 << 30)  # 960 workgroups x 4 waves x 4 MB would be 15 GB: the shares shrink to eight workgroups
+        ctx.upload_reference(contigs)
+        for _ in range(4):
+            got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False)
+            assert got.diff(want) == []
+            assert ctx.last_wide_solved() > 5000 and ctx.last_tier_counts()[2] > 1000
+    finally:
+        ctx.close()
