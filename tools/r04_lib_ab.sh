@@ -4,5 +4,5 @@
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
 for rep in 1 2; do for lib in "$@"; do
   printf "%-34s " "$lib"
-  AVK_LIB=$lib timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-parity --steps 40 --resident-steps 300 2>&1 | grep -E "timed region|resident leg" | sed 's/.*(\([0-9.]* ms per call\).*/\1/; s/.*resident leg: /resident /' | tr '\n' ' '; echo
+  AVK_LIB=$lib timeout 600 python bench.py --no-secondary --no-cpu-baseline --no-parity --steps 40 --resident-steps 300 2>&1 | grep -E "timed region|resident leg" | grep -v '"metric"' | sed 's/.*(\([0-9.]* ms per call\).*/\1/; s/.*resident leg: /resident /' | tr '\n' ' '; echo
 done; done | tee gpurun_out/r04_lib_ab.txt
