@@ -305,8 +305,10 @@ struct avk_ctx {
     int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
     int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
     int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
-    int64_t lane_min_regions = 8192; /* a lane class is launched when it holds at least this many regions (x16 for the two-call
-                                        classes): a launch lasts at least as long as its slowest tile, which a small class cannot amortise */
+    int64_t lane_min_regions = 2048; /* a lane class is launched when it holds at least this many regions (x16 for the two-call classes, x2 for the three-call
+                                        class): a launch lasts at least as long as its slowest tile, which a small class cannot amortise.  8192 until the end of round 4;
+                                        since the lanes keep node states and skip mirror-image optima their classes pay at a quarter of the size: an eighth-of-a-genome
+                                        step 2.0 -> 1.5 ms, a quarter-genome step 3.6 -> 2.15 ms, the whole genome unchanged (profiles/r04_lane_min.txt) */
     int64_t lane_width_one = 64, lane_width_two = 64, lane_width_three = 16; /* records a wave takes at a time (64, 32, 16) in the one- / two- / three-call classes */
     int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
@@ -329,7 +331,7 @@ struct avk_ctx {
                                                          runs in lockstep, a claim of unequals takes turns */
     int64_t lane_head_stream = 0;                     /* 1: the heads of the two-call classes on a stream of their own (a synchronised step: 5.4 -> 5.1 ms;
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
-    int64_t lane_min_batch = 65536;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
+    int64_t lane_min_batch = 16384;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
     int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
     int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */

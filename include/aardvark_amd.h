@@ -284,11 +284,12 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
  *   lane kernel      "lane_kernel" (1, default: regions with at most three calls per side, a short window and a small edit-distance
  *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
- *                    are identical either way), "lane_min_regions" (8192: a class of the lane kernel gets a launch of its own only
+ *                    are identical either way), "lane_min_regions" (2048: a class of the lane kernel gets a launch of its own only
  *                    when the batch holds that many of its regions — x16 for the two-call classes, x2 for the three-call class —,
- *                    smaller classes stay with the wave-per-region kernels; 0 = always), "lane_min_batch" (65536: a resident batch with fewer
- *                    lane regions in all is solved by the wave-per-region kernels alone — a chr20-sized step is 0.37 ms that way, 0.41
- *                    with lane launches; the one-shot path of avk_compare_batch, whose packing is the cheaper one, keeps its lanes),
+ *                    smaller classes stay with the wave-per-region kernels; 0 = always), "lane_min_batch" (16384: a resident batch with fewer
+ *                    lane regions in all is solved by the wave-per-region kernels alone; it was 65536 until the end of round 4, when a chr20-sized
+ *                    step — 48 k regions — was 0.37 ms that way and 0.41 with lane launches: it is 0.26 ms with them now; the one-shot path of
+ *                    avk_compare_batch, whose packing is the cheaper one, keeps its lanes at any size),
  *                    "lane_max_calls" (3: classes with more
  *                    calls per side than this stay with the wave-per-region kernels), "lane_node_cap" (32: search nodes the
  *                    three-call class makes before it hands a region to a wave-per-region launch that runs right behind it),
