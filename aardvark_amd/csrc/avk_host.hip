@@ -312,6 +312,8 @@ struct avk_ctx {
     int64_t lane_width_one = 64, lane_width_two = 64, lane_width_three = 16; /* records a wave takes at a time (64, 32, 16) in the one- / two- / three-call classes */
     int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
+    int64_t lane_head_auto = 1;                       /* 1: a head of fewer regions than the machine has lane waves for takes fewer records per wave (lane_head_width is the most):
+                                                         under 24,576 regions 8, under 8,192 regions 4 — an eighth-of-a-genome step 1.5 -> 1.2 ms, a quarter genome 2.15 -> 1.95 */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
     int64_t hbm_ed_cap = 1024;                        /* the per-wave HBM slices size a region's wavefronts by the region's own bound (the sum of its calls' edit distances) when that is at most this;
@@ -745,6 +747,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_max_est") {
         if (value < 0 || value > 15) return fail(ctx, AVK_E_ARG, "lane_max_est must be 0..15");
         ctx->lane_max_est = value;
+    } else if (n == "lane_head_auto") {
+        ctx->lane_head_auto = value ? 1 : 0;
     } else if (n == "lane_head_width") {
         if (value != 0 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4) return fail(ctx, AVK_E_ARG, "lane_head_width must be 0, 64, 32, 16, 8 or 4");
         ctx->lane_head_width = value;
@@ -1158,8 +1162,12 @@ static uint32_t lane_width_log2(const avk_ctx *ctx, uint32_t maxv) {
 }
 /* LDS bytes of a one-wave workgroup of the lane kernel (0: does not fit) and the grid that fills the machine: the per-lane arrays of
  * `width` lanes plus a tally of its own; as many workgroups per CU as the LDS and the wave slots hold */
-static uint32_t head_width_log2(const avk_ctx *ctx) {
-    const int64_t w = ctx->lane_head_width;
+static uint32_t head_width_log2(const avk_ctx *ctx, uint32_t head_regions) {
+    int64_t w = ctx->lane_head_width;
+    if (ctx->lane_head_auto && w > 4) { /* lanes that diverge take turns: a head that cannot fill the machine's lane waves 16 wide is spread over more, narrower waves */
+        const int64_t fit = head_regions < 8192u ? 4 : (head_regions < 24576u ? 8 : 16);
+        if (fit < w) w = fit;
+    }
     return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
 }
 static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs &la, uint32_t *grid) {
@@ -1780,7 +1788,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         avk::lane::LaneArgs hd = la;
                         hd.n_tiles = head_tiles;
                         hd.tile_counter = db->d_counters + 1230 + fc;
-                        hd.lanes_log2 = head_width_log2(ctx);
+                        hd.lanes_log2 = head_width_log2(ctx, db->plan.n_fast_heavy[fc]);
                         hd.pool = pool_heavy;
                         uint32_t hgrid = 0;
                         const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
