@@ -2372,6 +2372,8 @@ static void warm_kernels(int device) {
     for (const char *o : opts) (void)avk_ctx_set_option(t, o, 0);
     (void)avk_ctx_set_option(t, "big_ws_bytes", 8 << 20);
     (void)avk_ctx_set_option(t, "big_waves", 4);
+    (void)avk_ctx_set_option(t, "ws_bytes_per_wave", 256 << 10); /* (the warm-up's regions are tiny: 0.4 GB of slices instead of 1.7 — what this context frees at its end is
+                                                                   memory the caller's first call may be handed next, and has to wait for while it is scrubbed) */
     (void)avk_ctx_set_option(t, "class_c_nodes_x2", 1000); /* every region the lanes do not take is planned as class C: the wide kernel, the HBM launches */
     (void)avk_ctx_set_option(t, "lane_node_cap", 4);       /* ... and the three-call class hands back */
     const uint32_t L = 120, n_contig = 1u << 16;
@@ -2442,6 +2444,20 @@ int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hi
             (void)hipFree(d_scratch);
             return rc;
         }
+    }
+    if (n_regions_hint >= 65536 && !getenv("AVK_WARM_POOL")) {
+        /* Device memory is scrubbed when it is handed out, at some 35-90 GB/s: the first whole-genome call of a process asks for 2.5 GB of buffers and 7 GB of workspaces and
+         * waited 0.1-0.2 s for them.  Memory that this process has been handed once and has given back comes back at once — so as much as that call will ask for is taken
+         * and released here, on the thread that runs beside the caller's parsing.  (Found by accident: the warm-up context above used to size 44 GB of workspaces for its 448
+         * regions, and the tool's solve stage was 0.02-0.04 s; with that fixed it became 0.15-0.2 s.) */
+        const size_t waves = ((size_t)ctx->n_cus * 3u + (size_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128) + (size_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64)) * 4u;
+        size_t ahead = waves * (size_t)ctx->ws_bytes_per_wave + (size_t)(ctx->big_waves < 64 ? ctx->big_waves : 64) * (size_t)ctx->big_ws_bytes + (size_t)n_regions_hint * 420u +
+                       (size_t)n_variants_hint * 130u + ((size_t)1 << 30);
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ahead > free_b / 2) ahead = free_b / 2;
+        void *blk = nullptr;
+        if (ahead && hipMalloc(&blk, ahead) == hipSuccess) (void)hipFree(blk);
+        else (void)hipGetLastError();
     }
     if (ctx->device_pack && n_regions_hint >= 65536 && getenv("AVK_WARM_POOL")) { /* (measured in the tool: the 2.5 GB of buffers and the 7 GB of workspaces below take longer
                                                                                         than the parsing they run beside — the solve stage waited for them; off unless asked for) */

@@ -300,8 +300,17 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    records of a class are sorted by a host-side cost estimate, avk_pack.h fast_cost_key; the tiles of regions with
  *                    estimated edits — the head of the class — get a launch of their own with this many records per wave, because
  *                    lanes that diverge take turns; 0 = no head launch), "lane_max_est" (15: regions whose estimated edits exceed
- *                    this stay with the wave-per-region kernels)
- *                    The launches of one call run on six HIP streams side by side; the HIP runtime gives a process 4 hardware queues
+ *                    this stay with the wave-per-region kernels), "lane_head_auto" (1: a head of fewer than 24,576 / 8,192 regions takes 8 / 4
+ *                    records per wave instead of lane_head_width), "lane_pool" (-1: by class — 2 / 4 / 6 kept node states per lane in the head
+ *                    launches and the three-call class, none in the 64-wide launches; 0 = every pop of a search replays its node's path; 1..8 =
+ *                    that many everywhere)
+ *   wide kernel      "wide_kernel" (1, default: large phasing searches on small windows — the class C regions of a batch with lane launches,
+ *                    and what the lanes hand back — are solved one per WAVE by avk_wide_kernel, csrc/avk_wide.inl; 0: by the wave-per-region
+ *                    kernels; results are identical either way), "wide_lds_bytes" (16384 per wave), "wide_retry_lds_bytes" (65536: a second
+ *                    launch with this much LDS for what the first could not hold; 0 = none), "wide_blocks" / "wide_lazy_blocks" (512: one-wave
+ *                    workgroups of the class C launch / of the launches for hand-backs), "wide_lane_handbacks" (1: the lanes' hand-backs go
+ *                    through it first), "bulk_fit" (1: the bulk launch has no more workgroups than its list has regions for)
+ *                    The launches of one call run on eight HIP streams side by side; the HIP runtime gives a process 4 hardware queues
  *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=24 unless the
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
  *                    earlier should export the variable itself (whole-genome step: 7.0 ms with 4 queues, 5.0 with 8 in round 2; with a
