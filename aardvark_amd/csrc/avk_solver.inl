@@ -255,6 +255,43 @@ AVK_DEV void dw_extend(u32 *wf, u32 ed, const u8 *B, u32 bl, const u8 *O, u32 ol
     const u32 G = 1u << gs, ngrp = 64u >> gs;
     const u32 grp = lane >> gs, li = lane & (G - 1);
     const u64 gmask = gs == 6 ? ~0ull : ((1ull << G) - 1);
+    if (gs <= 2) { /* wide fronts (more than 8 diagonals): few lanes per diagonal, so every lane compares EIGHT bases per step, its sixteen reads in flight together —
+                      a diagonal of a window of kilobases slides hundreds of bases between two edits, a memory round trip per step */
+        enum { K = 8 };
+        for (u32 base = 0; base < nd; base += ngrp) {
+            const u32 i = base + grp;
+            const bool active = i < nd;
+            u32 d = active ? wf[i] : 0;
+            bool done = !active;
+            for (;;) {
+                u32 run = 0;
+                if (!done) {
+                    const u32 oo = d + li * K, bo = d + ed - i + li * K;
+                    u8 xb[K], xo[K];
+#pragma unroll
+                    for (u32 k = 0; k < K; ++k) {
+                        const bool in = bo + k < bl && oo + k < ol;
+                        xb[k] = in ? B[bo + k] : (u8)0;
+                        xo[k] = in ? O[oo + k] : (u8)1; /* past an end: a difference */
+                    }
+#pragma unroll
+                    for (u32 k = 0; k < K; ++k) run += (run == k && xb[k] == xo[k]) ? 1u : 0u;
+                }
+                const u64 m = wv_ballot(done || run < K);
+                const u64 gm = (m >> (grp * G)) & gmask;
+                const u32 l0 = gm ? (u32)avk_ctz64(gm) : 0u;
+                const u32 r0 = G == 1 ? run : wv_shfl(run, (grp << gs) + l0); /* the run of the group's first lane that stops */
+                if (!done) {
+                    d += gm ? l0 * K + r0 : G * K;
+                    done = gm != 0;
+                }
+                if (wv_ballot(!done) == 0) break;
+            }
+            if (active && li == 0) wf[i] = d;
+        }
+        wv_sync();
+        return;
+    }
     for (u32 base = 0; base < nd; base += ngrp) {
         const u32 i = base + grp;
         const bool active = i < nd;
@@ -358,17 +395,25 @@ AVK_DEV u32 seq_match_run(const u8 *a, u32 al, u32 ia, const u8 *b, u32 bl, u32 
     const u32 ra = al > ia ? al - ia : 0, rb = bl > ib ? bl - ib : 0;
     const u32 lim = ra < rb ? ra : rb;
     u32 n = 0;
-    while (n < lim) {
-        const u32 i = n + lane;
-        const bool in = i < lim;
-        const u32 ii = in ? i : 0;
-        const bool match = in && a[ia + ii] == b[ib + ii];
-        const u64 m = wv_ballot(!match);
+    while (n < lim) { /* four bases per lane and step, the eight reads in flight together: 256 positions per memory round trip */
+        const u32 i0 = n + 4u * lane;
+        u8 xa[4], xb[4];
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) {
+            const bool in = i0 + k < lim;
+            xa[k] = in ? a[ia + i0 + k] : (u8)0;
+            xb[k] = in ? b[ib + i0 + k] : (u8)1; /* past the end: a difference */
+        }
+        u32 run = 0;
+#pragma unroll
+        for (u32 k = 0; k < 4; ++k) run += (run == k && xa[k] == xb[k]) ? 1u : 0u;
+        const u64 m = wv_ballot(run < 4u);
         if (m) {
-            n += (u32)avk_ctz64(m);
+            const u32 l0 = (u32)avk_ctz64(m);
+            n += 4u * l0 + wv_shfl(run, (int)l0);
             break;
         }
-        n += 64;
+        n += 256;
     }
     return n;
 }
@@ -537,24 +582,11 @@ AVK_DEV bool hap_extend_seq(const Ctx &c, const HapPtr &p, HapHdr &h, bool is_tr
 }
 
 /* DWFALite::update for a haplotype record (dynamic_wfa.rs:68-84).  While ed == 0 the wavefront is the single
- * offset h.d0: extend = slide it over the common part of the two sequences, 64 bases per step; only a real
+ * offset h.d0: extend = slide it over the common part of the two sequences, 256 bases per step; only a real
  * mismatch (both sequences continue and differ) enters the general wavefront code. */
 AVK_DEV bool hap_slide_d0(const HapPtr &p, HapHdr &h) { /* returns true when either end is touched */
-    const u32 lane = (u32)wv_lane();
     const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
-    u32 d = h.d0;
-    while (d < lim) {
-        const u32 i = d + lane;
-        const bool in = i < lim;
-        const u32 ii = in ? i : 0;
-        const bool match = in && p.tseq[ii] == p.qseq[ii];
-        const u64 m = wv_ballot(!match);
-        if (m) {
-            d += (u32)avk_ctz64(m);
-            break;
-        }
-        d += 64;
-    }
+    const u32 d = h.d0 < lim ? h.d0 + seq_match_run(p.tseq, lim, h.d0, p.qseq, lim, h.d0) : h.d0;
     h.d0 = d;
     return d >= lim;
 }
