@@ -473,7 +473,7 @@ def main():
                          "what": "the same boundary with the batch in the wide structure-of-arrays form (avk_region_batch through avk_compare_batch)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "all solver launches of a step (lane classes + bulk + solo + overflow; HIP events ev0..ev1 on the launch stream)",
+                         "kernel": "all solver launches of a step (lane classes + looked-up pairs + wide + bulk + solo + overflow; HIP events ev0..ev1 on the launch stream)",
                          "kernel_ms": s_ms, "first_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "bytes_per_region": alg_bytes / max(n_regions, 1),
                          "pcie": {"bytes_per_step": in_bytes + out_bytes, "achieved_GBs": (in_bytes + out_bytes) * (total_regions / max(n_regions, 1)) / world / (ms_per_step * 1e-3) / 1e9,
