@@ -1009,7 +1009,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     }
     const bool lanes = ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b;
     a.opt.tier0_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), a.opt.tier0_ed_cap = (uint32_t)ctx->lds_ed_cap, a.opt.tier1_bytes = (uint64_t)ctx->lds2_bytes_per_wave,
-    a.opt.tier1_ed_cap = (uint32_t)ctx->lds2_ed_cap, a.opt.solo_min_variants = pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, a.opt.max_branch = 50,
+    a.opt.tier1_ed_cap = (uint32_t)ctx->lds2_ed_cap, a.opt.solo_min_variants = pairs_mode && !ctx->pair_classes ? 0u : (uint32_t)ctx->solo_min_variants, a.opt.max_branch = 50,
     a.opt.class_c_nodes_x2 = (uint32_t)ctx->class_c_nodes_x2, a.opt.lane_min_regions = lanes ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull,
     a.opt.lane_max_calls = (uint32_t)ctx->lane_max_calls, a.opt.lane_min_batch = (uint64_t)ctx->lane_min_batch, a.opt.lane_max_est = (uint32_t)ctx->lane_max_est;
     a.opt.stripe_w = ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u;

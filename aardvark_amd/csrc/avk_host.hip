@@ -312,6 +312,10 @@ struct avk_ctx {
     int64_t lane_width_one = 64, lane_width_two = 64, lane_width_three = 16; /* records a wave takes at a time (64, 32, 16) in the one- / two- / three-call classes */
     int64_t lane_max_calls = AVK_FAST_MAXV;           /* classes with more calls per side stay with the wave-per-region kernels */
     int64_t lane_max_est = 15;                        /* regions whose estimated edits (fast_cost_key, avk_pack.h) exceed this stay with the wave-per-region kernels */
+    int64_t pair_classes = 1;                         /* 1: pair batches (merge) plan their large searches as classes C / B like compare batches do, so that the wide kernel
+                                                         and the solo launches take them at the start of the step; 0 (until the end of round 4): everything the lanes do not take
+                                                         goes through the bulk and what overflows there through an HBM launch at the very end — a 3-caller whole-genome merge
+                                                         call 22.5 -> 16 ms */
     int64_t lane_head_auto = 1;                       /* 1: a head of fewer regions than the machine has lane waves for takes fewer records per wave (lane_head_width is the most):
                                                          under 24,576 regions 8, under 8,192 regions 4 — an eighth-of-a-genome step 1.5 -> 1.2 ms, a quarter genome 2.15 -> 1.95 */
     int64_t lane_head_width = 16;                     /* records a wave takes at a time in the HEAD of a lane class: the tiles of regions with estimated edits (0 = no head launch) */
@@ -747,6 +751,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_max_est") {
         if (value < 0 || value > 15) return fail(ctx, AVK_E_ARG, "lane_max_est must be 0..15");
         ctx->lane_max_est = value;
+    } else if (n == "pair_classes") {
+        ctx->pair_classes = value ? 1 : 0;
     } else if (n == "lane_head_auto") {
         ctx->lane_head_auto = value ? 1 : 0;
     } else if (n == "lane_head_width") {
@@ -1097,7 +1103,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     const auto t_alloc = now();
     std::vector<uint32_t> order;
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
-                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
+                                    (uint32_t)ctx->lds2_ed_cap, pairs_mode && !ctx->pair_classes ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
                                     ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls,
                                     (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u, (uint32_t)ctx->lane_head_est, (uint32_t)ctx->het_search_min);
     const auto t_plan = now();

@@ -309,7 +309,8 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    kernels; results are identical either way), "wide_lds_bytes" (16384 per wave), "wide_retry_lds_bytes" (65536: a second
  *                    launch with this much LDS for what the first could not hold; 0 = none), "wide_blocks" / "wide_lazy_blocks" (512: one-wave
  *                    workgroups of the class C launch / of the launches for hand-backs), "wide_lane_handbacks" (1: the lanes' hand-backs go
- *                    through it first), "bulk_fit" (1: the bulk launch has no more workgroups than its list has regions for)
+ *                    through it first), "bulk_fit" (1: the bulk launch has no more workgroups than its list has regions for), "pair_classes" (1: pair batches — merge — plan their large searches
+ *                    as classes C and B like compare batches, so that the wide kernel and the solo launches take them at the start of a step)
  *                    The launches of one call run on eight HIP streams side by side; the HIP runtime gives a process 4 hardware queues
  *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=24 unless the
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP

@@ -165,6 +165,7 @@ uint64_t g_lane_solved = 0;
 uint32_t g_lane_width_log2[3] = {6, 6, 4};
 uint32_t g_lane_node_cap = 32;
 int g_lane_pool = -1; /* context option lane_pool */
+int g_pair_classes = 1; /* context option pair_classes */
 uint32_t g_lane_head_width = 16; /* run_internal's option lane_head_width */ /* emu_set_lane_width: records a wave takes at a time in the one-call / two-call classes */
 
 struct LaneTask {
@@ -335,7 +336,7 @@ dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_by
     dpk::DpOpts o;
     memset(&o, 0, sizeof(o));
     o.tier0_bytes = avk::bulk_slice_bytes(lds_bytes), o.tier0_ed_cap = lds_ed_cap, o.tier1_bytes = lds2_bytes, o.tier1_ed_cap = lds2_ed_cap;
-    o.solo_min_variants = pairs ? 0u : solo_min_variants, o.max_branch = 50;
+    o.solo_min_variants = pairs && !g_pair_classes ? 0u : solo_min_variants, o.max_branch = 50;
     o.class_c_nodes_x2 = getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u;
     o.lane_min_regions = lane_min_regions, o.lane_max_calls = AVK_FAST_MAXV, o.lane_min_batch = lane_min_batch, o.lane_max_est = lane_max_est;
     o.stripe_w = g_stripe_w;
@@ -565,7 +566,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         plan.n_hbm = dpr.st.n_hbm, plan.n_hard = dpr.st.n_hard, plan.n_fast_total = dpr.st.n_fast_total;
         for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) plan.n_fast[fc] = dpr.st.n_fast[fc], plan.n_fast_heavy[fc] = dpr.st.n_fast_heavy[fc], plan.fast_base[fc] = dpr.st.fast_base[fc];
     } else {
-        plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 ? 0u : solo_min_variants, 50, &order,
+        plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 && !g_pair_classes ? 0u : solo_min_variants, 50, &order,
                                     getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
                                     g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */, AVK_FAST_MAXV, 0, g_stripe_w);
         sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
@@ -1086,7 +1087,7 @@ int emu_devpack_compare(const avk_region_batch *batch, const uint64_t *ref_lens,
             else dr.pre_status = 0;
         }
     std::vector<uint32_t> order;
-    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), 48, lds2_bytes, 48, pairs_mode ? 0u : solo_min_variants, 50, &order, 12, lane_min_regions,
+    const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), 48, lds2_bytes, 48, pairs_mode && !g_pair_classes ? 0u : solo_min_variants, 50, &order, 12, lane_min_regions,
                                                     AVK_FAST_MAXV, lane_min_batch, g_stripe_w);
     if (pb.variants.size() != R.st.total_v) return say("per-call output words: host %zu, device %llu", pb.variants.size(), (unsigned long long)R.st.total_v);
     if (seq_total != R.st.total_seq) return say("sequence bytes: host %llu, device %llu", (unsigned long long)seq_total, (unsigned long long)R.st.total_seq);
@@ -1175,6 +1176,7 @@ void emu_wide_defer_stats(uint64_t *out, int reset) {
 void emu_set_wide_lds_bytes(uint32_t bytes) { g_wide_lds_bytes = bytes; }
 void emu_set_lane_node_cap(int cap) { g_lane_node_cap = (uint32_t)cap; }
 void emu_set_lane_pool(int slots) { g_lane_pool = slots; }
+void emu_set_pair_classes(int on) { g_pair_classes = on; }
 void emu_set_lane_head_width(int w) { g_lane_head_width = (uint32_t)w; }
 void emu_set_lane_width(int one, int two) {
     g_lane_width_log2[0] = one <= 16 ? 4 : (one <= 32 ? 5 : 6);
@@ -1201,7 +1203,8 @@ int emu_optimize_pairs_batch(const avk_region_batch *batch, const uint8_t *const
     memset(&out, 0, sizeof(out));
     out.status = status;
     out.ed_h1 = ed1.data();
-    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 10 * 1024, 48, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, 0, 0, 1);
+    int rc = emu_run(1, batch, refs, ref_lens, n_contigs, &cfg, &out, 10 * 1024, 48, 40 * 1024, 48, 1 << 20, 64ull << 20, 8, threads, nullptr, g_pair_classes ? 5u : 0u, 0, 1); /* (context option
+                                                                                                     pair_classes: pair batches plan their classes C and B with solo_min_variants 5) */
     if (rc) return rc;
     for (uint64_t r = 0; r < batch->n_regions; ++r) is_exact_match[r] = status[r] == 0 && ed1[r] ? 1 : 0;
     return 0;

@@ -176,3 +176,24 @@ def test_merge_pairs(oracle):
     assert np.array_equal(st_o, st_e) and np.array_equal(ex_o, ex_e)
     assert 20 < ex_o.sum() < batch.n_regions
 
+
+
+def test_merge_pairs_with_large_searches_are_planned_as_class_c(oracle):
+    """context option pair_classes (default on since the end of round 4): pair batches plan their large searches as classes C and B, as compare batches do, so that the
+    wide code takes them at the start of a step instead of the bulk launch's overflow at its end; merge_solver.rs:137-143 asks one bit per pair"""
+    lib = emu_lib.load()
+    contigs, batch = het_cluster_regions(72, 300, n_sites=(3, 7), drop=0.02, shift=0.05)
+    st_o, ex_o = oracle_lib.optimize_pairs(oracle, batch, contigs, threads=4)
+    lib.emu_set_pair_classes.argtypes = [__import__("ctypes").c_int]
+    seen = []
+    for on in (1, 0):
+        lib.emu_set_pair_classes(on)
+        try:
+            lib.emu_set_lane_kernel(1)
+            lib.emu_set_wide_kernel(1)
+            st_e, ex_e = emu_lib.optimize_pairs(batch, contigs, threads=THREADS)
+            seen.append(int(lib.emu_last_wide_solved()))
+        finally:
+            lib.emu_set_pair_classes(1)
+        assert np.array_equal(st_o, st_e) and np.array_equal(ex_o, ex_e)
+    assert seen[0] > seen[1] and seen[0] > 30, seen
