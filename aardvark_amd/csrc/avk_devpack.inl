@@ -119,6 +119,7 @@ struct DpState {
     u32 n_big, n_owned; /* regions left to the wave-per-region record writer; marked calls of DpIn::owned */
 };
 
+static_assert(DP_NB <= 65536, "DpArgs::bucket16 holds a bucket in two bytes");
 struct DpArgs {
     DpIn in;
     DpOpts opt;
@@ -133,6 +134,8 @@ struct DpArgs {
     u32 *order;         /* [n_regions] work order: record k holds region order[k] */
     u32 *big_list;      /* [n_regions] work-order indices of regions with more than DP_SMALL_N calls */
     DpSlot *slots;      /* [n_variants] */
+    uint16_t *bucket16; /* [n_regions] a region's bucket of the work order, from dp_hist to dp_scatter (two bytes a region instead of a word inside the 64-byte
+                           region info: the two passes moved 230 MB each for it) */
     /* outputs */
     AvkDevRegion *regions;
     u32 *blob;

@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(1024) avk_dp_hist_kernel(dpk::DpArgs a) {
     const uint64_t r = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
     if (r < a.in.n_regions) {
         const uint32_t b = dpk::dp_bucket_of(a, r);
-        a.rinfo[r].bucket = b;
+        a.bucket16[r] = (uint16_t)b;
         atomicAdd(&h[b], 1u);
     }
     __syncthreads();
@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(1024) avk_dp_scatter_kernel(dpk::DpArgs a) {
     const uint64_t r = (uint64_t)blockIdx.x * 1024u + threadIdx.x;
     uint32_t b = 0;
     if (r < a.in.n_regions) {
-        b = a.rinfo[r].bucket;
+        b = a.bucket16[r];
         atomicAdd(&h[b], 1u);
     }
     __syncthreads();
@@ -807,6 +807,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.st = (dpk::DpState *)kept(sizeof(dpk::DpState));
     a.pending = (uint32_t *)tmp((nv + 1) * 4);
     a.slots = (dpk::DpSlot *)tmp((nv + 1) * sizeof(dpk::DpSlot));
+    a.bucket16 = (uint16_t *)tmp((n + 16) * 2);
     db->d_voff = (uint32_t *)kept((n + 1) * 4);
     a.v_off = db->d_voff;
     a.blob_off8 = (uint32_t *)kept((n + 1) * 4);
@@ -818,7 +819,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.big_list = (uint32_t *)kept((n + 1) * 4);
     uint64_t *d_block_sums = (uint64_t *)tmp(((size_t)n_blocks + 1) * AVK_DP_BS * 8);
     if (!ctx->h_dpstate && !rc) {
-        hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState) + 16, hipHostMallocDefault);
         if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "pinned state block: %s", hipGetErrorString(e));
     }
     if (!ctx->d_contig_tab && !rc) rc = fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
@@ -1036,14 +1037,15 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             x = hipGetLastError();
         }
         if (x == hipSuccess) x = hipMemcpyAsync(hs, a.st, sizeof(dpk::DpState), hipMemcpyDeviceToHost, s);
+        if (x == hipSuccess && pk_totals) x = hipMemcpyAsync(hs + 1, pk_totals, 16, hipMemcpyDeviceToHost, s); /* (the packed forms' two sums ride along: 16 bytes behind the state block) */
         if (x == hipSuccess) x = hipStreamSynchronize(s);
         return x;
     };
     if (e == hipSuccess) e = region_passes();
     if (e == hipSuccess && (pk || pm)) { /* the two sums the packed form implies must be what the caller says they are */
         uint64_t tot[2] = {0, 0};
-        e = hipMemcpy(tot, pk_totals, sizeof(tot), hipMemcpyDeviceToHost);
-        if (e == hipSuccess && (((pm ? pm->n_regions : n) && tot[0] != nv) || (nv && tot[1] != alen)))
+        memcpy(tot, hs + 1, sizeof(tot));
+        if ((((pm ? pm->n_regions : n) && tot[0] != nv) || (nv && tot[1] != alen)))
             return bail(fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to %llu (n_variants %llu), the allele lengths to %llu (allele_bytes_len %llu)",
                              (unsigned long long)tot[0], (unsigned long long)nv, (unsigned long long)tot[1], (unsigned long long)alen));
     }
@@ -1225,7 +1227,7 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     uint8_t *d_exact = pair_exact ? (uint8_t *)tmp(n + 16) : nullptr;
     if (rc) return done(rc);
     if (!ctx->h_dpstate) {
-        hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState), hipHostMallocDefault);
+        hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState) + 16, hipHostMallocDefault);
         if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "pinned state block: %s", hipGetErrorString(e)));
     }
     static_assert(sizeof(dpk::DpState) >= AVK_TALLY_STRIDE * 8, "the pinned state block also receives the tally");
