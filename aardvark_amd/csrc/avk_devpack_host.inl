@@ -825,6 +825,16 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     if (!ctx->d_contig_tab && !rc) rc = fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
     if (rc) return bail(rc);
     const auto t_alloc = now();
+    auto mark = [&](int k) { /* AVK_TIMING: a mark of the call's device timeline on the context's stream */
+        if (!timing) return;
+        if (!ctx->ev_tl[k] && hipEventCreate(&ctx->ev_tl[k]) != hipSuccess) {
+            ctx->ev_tl[k] = nullptr;
+            (void)hipGetLastError();
+            return;
+        }
+        (void)hipEventRecord(ctx->ev_tl[k], s);
+    };
+    mark(0);
     if (pk) { /* the packed arrays as they are, two prefix sums for the offsets they leave out, one kernel that writes the wide arrays */
         uint16_t *p_contig = has_contig ? (uint16_t *)tmp((n + 1) * 2) : nullptr, *p_len = (uint16_t *)tmp((n + 1) * 2), *p_rel = (uint16_t *)tmp((nv + 1) * 2);
         uint32_t *p_start = (uint32_t *)tmp((n + 1) * 4);
@@ -844,6 +854,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         rc = copy_in(ctx, {{pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv, nullptr, ctx->ev_copy_fork}, {pk->start, p_start, n * 4},
                            {pk->len, p_len, n * 2}, {pk->contig_idx, p_contig, has_contig ? n * 2 : 0}, {pk->var_rel_pos, p_rel, nv * 2}, {pk->var_type_zyg, p_tz, nv, nullptr, ctx->ev_copy_mid},
                            {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {pk->allele_bytes, d_alleles, alen}});
+        mark(1);
         if (rc) return bail(rc);
         hipError_t ec = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0); /* (also orders the side stream behind everything queued on the context's stream before) */
         if (ec != hipSuccess) return bail(fail(ctx, AVK_E_HIP, "packed upload: %s", hipGetErrorString(ec)));
@@ -1036,6 +1047,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             hipLaunchKernelGGL(avk_dp_scatter_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(1024), 0, s, a);
             x = hipGetLastError();
         }
+        mark(2);
         if (x == hipSuccess) x = hipMemcpyAsync(hs, a.st, sizeof(dpk::DpState), hipMemcpyDeviceToHost, s);
         if (x == hipSuccess && pk_totals) x = hipMemcpyAsync(hs + 1, pk_totals, 16, hipMemcpyDeviceToHost, s); /* (the packed forms' two sums ride along: 16 bytes behind the state block) */
         if (x == hipSuccess) x = hipStreamSynchronize(s);
@@ -1179,6 +1191,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         (void)hipStreamSynchronize(ctx->lane_stream4);
         return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
     }
+    mark(3);
     for (void *p : temps) pool_release(ctx, p); /* in stream order: the writers above run before anything that is handed these buffers next */
     if (timing)
         fprintf(stderr, "avk upload (device-packed): %llu regions, %llu calls: buffers %.3f ms, copies queued %.3f ms, packing kernels + plan %.3f ms, writers queued %.3f ms; lanes %u regions in %u tiles, class C %u, class B %u\n",
@@ -1266,6 +1279,10 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     if (rc) return done(rc);
     e = hipMemcpyAsync(ctx->h_dpstate, db->d_tally, (size_t)AVK_TALLY_STRIDE * 8, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "tally download failed: %s", hipGetErrorString(e)));
+    if (getenv("AVK_TIMING")) { /* the last mark of the call's device timeline: behind the copies out */
+        if (!ctx->ev_tl[4] && hipEventCreate(&ctx->ev_tl[4]) != hipSuccess) ctx->ev_tl[4] = nullptr, (void)hipGetLastError();
+        if (ctx->ev_tl[4]) (void)hipEventRecord(ctx->ev_tl[4], s);
+    }
     rc = finish_copy_out(ctx, co);
     if (rc) return done(rc);
     memcpy(tally_words, ctx->h_dpstate, (size_t)AVK_TALLY_STRIDE * 8);

@@ -371,6 +371,7 @@ struct avk_ctx {
     hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
     hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr, ev_lane_head3 = nullptr;
+    hipEvent_t ev_tl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* AVK_TIMING only: marks of a boundary call on the context's stream (first copy, last copy, work order, writers, results) */
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     hipStream_t wide_stream = nullptr; /* the class C records that are not for the wide kernel (run_internal) */
@@ -589,6 +590,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->d_refexc) (void)hipFree(ctx->d_refexc);
     if (ctx->d_ws) (void)hipFree(ctx->d_ws);
     if (ctx->d_big) (void)hipFree(ctx->d_big);
+    for (hipEvent_t &t : ctx->ev_tl)
+        if (t) (void)hipEventDestroy(t);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
@@ -2534,6 +2537,16 @@ int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_co
         auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
         fprintf(stderr, "avk compare packed: upload %.3f ms, launches %.3f ms, download %.3f ms, free %.3f ms\n", ms(t0, t1), ms(t1, t2), ms(t2, t3),
                 ms(t3, std::chrono::steady_clock::now()));
+        if (!rc && ctx->ev_tl[4] && ctx->ev_valid) { /* the same call on the device's clock, free-running (no profiler): events on the context's stream */
+            float c1 = 0, c2 = 0, c3 = 0, c4 = 0, c5 = 0, c6 = 0;
+            if (hipEventElapsedTime(&c1, ctx->ev_tl[0], ctx->ev_tl[1]) == hipSuccess && hipEventElapsedTime(&c2, ctx->ev_tl[0], ctx->ev_tl[2]) == hipSuccess &&
+                hipEventElapsedTime(&c3, ctx->ev_tl[0], ctx->ev_tl[3]) == hipSuccess && hipEventElapsedTime(&c4, ctx->ev_tl[0], ctx->ev0) == hipSuccess &&
+                hipEventElapsedTime(&c5, ctx->ev_tl[0], ctx->ev1) == hipSuccess && hipEventElapsedTime(&c6, ctx->ev_tl[0], ctx->ev_tl[4]) == hipSuccess)
+                fprintf(stderr, "avk compare packed, device clock from the first copy: copies in done %.3f ms, work order done %.3f, record writers done %.3f, solver launches %.3f .. %.3f, results out %.3f\n",
+                        c1, c2, c3, c4, c5, c6);
+            else
+                (void)hipGetLastError();
+        }
     }
     return rc;
 }
