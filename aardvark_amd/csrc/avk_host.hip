@@ -538,36 +538,37 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         const char *pe = getenv("AVK_STREAM_PRIORITY");
         if (!pe || strcmp(pe, "high") != 0) prio_high = 0;
     }
+    const unsigned evf = getenv("AVK_TIMING") ? hipEventDefault : hipEventDisableTiming; /* the events that end the launch chains can be read when the stage timing is on */
     if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->wide_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, prio_tail) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->tail_stream2, hipStreamNonBlocking, prio_tail) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join2, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_ready2, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_wide, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_wide, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_join2, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join2, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream3, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_join3, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join3, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_join4, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_join4, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_join, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready4, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_early, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_lane_early, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_head3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_lane_join, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, evf) != hipSuccess) {
         avk_ctx_destroy(ctx);
         return fail(nullptr, AVK_E_HIP, "cannot create the side streams / events of the context");
     }
@@ -2546,6 +2547,17 @@ int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_co
                         c1, c2, c3, c4, c5, c6);
             else
                 (void)hipGetLastError();
+            /* where each chain of the launch graph ended, from the first solver launch (events of this call only when the batch used the chain) */
+            const struct { const char *what; hipEvent_t ev; } chains[] = {{"LDS solo", ctx->ev_join}, {"HBM solo", ctx->ev_join2}, {"wide", ctx->ev_wide}, {"lane stream 1", ctx->ev_lane_join},
+                {"lane stream 2", ctx->ev_lane_join2}, {"lane stream 3", ctx->ev_lane_join3}, {"lane stream 4", ctx->ev_lane_join4}, {"early hand-backs", ctx->ev_lane_early},
+                {"hand-back launches", ctx->ev_lane_done}};
+            fprintf(stderr, "avk compare packed, chains end (ms after the first solver launch):");
+            for (const auto &c : chains) {
+                float t = 0;
+                if (c.ev && hipEventElapsedTime(&t, ctx->ev0, c.ev) == hipSuccess) fprintf(stderr, " %s %.3f;", c.what, t);
+                else (void)hipGetLastError();
+            }
+            fprintf(stderr, " all %.3f\n", c5 - c4);
         }
     }
     return rc;
