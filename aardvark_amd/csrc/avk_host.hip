@@ -30,6 +30,7 @@
 #include "avk_pack.h"
 #include "avk_solver.inl"
 #include "avk_lane.inl"
+#include "avk_quad.inl"
 #include "avk_wide.inl"
 #include "avk_dwfa_script.inl"
 #include "avk_devpack.inl"
@@ -93,6 +94,41 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_LAN
     uint32_t n_ok = 0, n_err = 0;
     uint64_t *part = a.tally + (uint64_t)(blockIdx.x % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
     avk::lane::lane_worker(a, la, wave_id, smem + (size_t)wave_in_block * wave_words, wg_tally, n_ok, n_err, blockDim.x == 64 ? part : (uint64_t *)0);
+    n_ok = wv_sum_u32(n_ok);
+    n_err = wv_sum_u32(n_err);
+    if ((threadIdx.x & 63u) == 0) {
+        if (n_ok) {
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_SOLVED), (unsigned long long)n_ok);
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_LANE_SOLVED), (unsigned long long)n_ok);
+        }
+        if (n_err) {
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_ERRORS), (unsigned long long)n_err);
+            atomicAdd((unsigned long long *)(part + AVK_TALLY_LANE_SOLVED), (unsigned long long)n_err);
+        }
+    }
+    __syncthreads();
+    for (unsigned k = threadIdx.x; k < AVK_N_GROUPS * AVK_N_FIELDS; k += blockDim.x) {
+        const uint32_t v = wg_tally[k];
+        if (v) atomicAdd((unsigned long long *)(part + k), (unsigned long long)v);
+    }
+}
+
+/* The expensive small regions — the heads of the lane classes and the three-call class — one per QUAD (avk_quad.inl): the same records, rows and
+ * results as avk_lane_kernel at 16 (8, 4) records per wave, four lanes on every region instead of one */
+#ifndef AVK_QUAD_WPE
+#define AVK_QUAD_WPE 3
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_QUAD_WPE))) avk_quad_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
+    uint32_t *smem = (uint32_t *)avk_smem;
+    const uint32_t rows = avk::quad::quad_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool);
+    const uint32_t wave_words = rows << la.lanes_log2;
+    uint32_t *wg_tally = smem + wave_words;
+    for (unsigned k = threadIdx.x; k < 288; k += blockDim.x) wg_tally[k] = 0;
+    __syncthreads();
+    uint32_t n_ok = 0, n_err = 0;
+    uint64_t *part = a.tally + (uint64_t)(blockIdx.x % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE;
+    avk::quad::quad_worker(a, la, blockIdx.x, smem, wg_tally, n_ok, n_err, part);
     n_ok = wv_sum_u32(n_ok);
     n_err = wv_sum_u32(n_err);
     if ((threadIdx.x & 63u) == 0) {
@@ -341,6 +377,7 @@ struct avk_ctx {
     int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
     int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
+    int64_t lane_quad = 1;                            /* 1: lane launches of at most 16 records per wave (the heads, the three-call class) run four lanes per region: avk_quad_kernel, avk_quad.inl */
     int64_t lane_pool = -1;                           /* node states a lane keeps during its search (avk_lane.inl NodePool): -1 = by class (2 / 4 / 6 for one / two / three calls per side), 0 = none */
     int64_t lane_waves_three = 0;                     /* > 0: at most this many one-wave workgroups of the three-call class per CU (its waves take 17 KB of LDS each) */
     int64_t lane_waves_per_cu = 12;                   /* at most this many one-wave workgroups of a lane launch per CU */
@@ -799,6 +836,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
+    } else if (n == "lane_quad") {
+        ctx->lane_quad = value ? 1 : 0;
     } else if (n == "lane_pool") {
         if (value < -1 || value > 8) return fail(ctx, AVK_E_ARG, "lane_pool must be -1..8");
         ctx->lane_pool = value;
@@ -1180,8 +1219,10 @@ static uint32_t head_width_log2(const avk_ctx *ctx, uint32_t head_regions) {
     }
     return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
 }
+/* which of the two kernels a lane launch runs: four lanes per region when the launch is narrow (option lane_quad) */
+static bool lane_launch_is_quad(const avk_ctx *ctx, const avk::lane::LaneArgs &la) { return ctx->lane_quad && la.lanes_log2 <= 4; }
 static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs &la, uint32_t *grid) {
-    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + (3 + 2 * la.pool) * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + (la.nm == 2 ? 4 : 8); /* lane_rows */
+    const uint32_t rows = (1 + 2 * (la.nm - 1)) * (la.W + 1) + ((lane_launch_is_quad(ctx, la) ? 4 : 3) + 2 * la.pool) * ((2 * la.ed_max + 2 + 3) / 4) + la.qcap + (la.nm == 2 ? 4 : 8); /* lane_rows / quad_rows */
     const size_t lds = (size_t)rows * (4u << la.lanes_log2) + 288 * 4;
     uint32_t per_cu = (uint32_t)((160 * 1024) / lds);
     if (per_cu < 1) return 0;
@@ -1193,6 +1234,11 @@ static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs
     if (g > claims) g = claims;
     *grid = g;
     return lds;
+}
+/* a launch of a lane class: one lane per region, or four (lane_launch_is_quad) */
+static void launch_lane_class(const avk_ctx *ctx, uint32_t grid, size_t lds, hipStream_t s, const AvkKernelArgs &f, const avk::lane::LaneArgs &la) {
+    if (lane_launch_is_quad(ctx, la)) hipLaunchKernelGGL(avk_quad_kernel, dim3(grid), dim3(64), lds, s, f, la);
+    else hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, s, f, la);
 }
 
 /* The table of avk_pairs.inl for this max_branch_factor, on `s`: sixteen probe regions through the lane kernel, outputs redirected into the table.
@@ -1240,6 +1286,7 @@ static int ensure_pair_table(avk_ctx *ctx, uint32_t max_branch_factor, hipStream
     const size_t lds = lane_launch_geometry(ctx, la, &grid);
     if (!ctx->lane_attr_set) {
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->lane_attr_set = true;
     }
     hipLaunchKernelGGL(avk_lane_kernel, dim3(1), dim3(64), lds, s, f, la);
@@ -1633,6 +1680,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             if (use_fast) {
                 if (!ctx->lane_attr_set) {
                     AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     ctx->lane_attr_set = true;
                 }
                 AvkKernelArgs f = a;
@@ -1714,7 +1762,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             hd.tile_counter = db->d_counters + 1230 + fc;
                             uint32_t hgrid = 0;
                             const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
-                            hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, lstream[li], f3, hd);
+                            launch_lane_class(ctx, hgrid, hlds, lstream[li], f3, hd);
                             AVK_HIP(ctx, hipGetLastError());
                             AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_head3, lstream[li]));
                             es = lstream[3];
@@ -1723,9 +1771,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             la.n_tiles -= head3;
                             la.gen_base += head3 * 64u;
                             if (grid > la.n_tiles * (64u >> la.lanes_log2)) grid = la.n_tiles * (64u >> la.lanes_log2);
-                            hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f, la);
+                            launch_lane_class(ctx, grid, lds, lstream[li], f, la);
                         } else
-                            hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f3, la);
+                            launch_lane_class(ctx, grid, lds, lstream[li], f3, la);
                         AVK_HIP(ctx, hipGetLastError());
                         /* the launch for what ALL lanes hand back waits for the lane launches only, not for the launch behind this class */
                         AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
@@ -1808,14 +1856,14 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[hi], lstream[hi]));
                             lused[hi] = true;
                         }
-                        hipLaunchKernelGGL(avk_lane_kernel, dim3(hgrid), dim3(64), hlds, lstream[hi], f, hd);
+                        launch_lane_class(ctx, hgrid, hlds, lstream[hi], f, hd);
                         AVK_HIP(ctx, hipGetLastError());
                         la.recs += (size_t)head_tiles * la.rec_words * 64u;
                         la.n_tiles -= head_tiles;
                         la.gen_base += head_tiles * 64u;
                         if (grid > la.n_tiles) grid = la.n_tiles;
                     }
-                    hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, lstream[li], f, la);
+                    launch_lane_class(ctx, grid, lds, lstream[li], f, la);
                     AVK_HIP(ctx, hipGetLastError());
                 }
                 for (int li = 0; li < N_LS; ++li) {
@@ -2446,6 +2494,7 @@ int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hi
     AVK_HIP(ctx, hipGetLastError());
     if (!ctx->lane_attr_set) {
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->lane_attr_set = true;
     }
     if (ctx->lane_kernel && ctx->lane_pairs) {

@@ -97,6 +97,21 @@ AVK_DEV uint32_t wv_from_above_(uint32_t v, uint32_t site) {
 #define wv_from_above(v) wv_from_above_((v), AVK_SITE)
 #define wv_sync() wv_sync_(AVK_SITE)
 
+/* QUAD primitives (avk_quad.inl: four lanes on one region).  Lanes 4 g .. 4 g + 3 form quad g; control flow around these calls is
+ * quad-uniform but NOT wave-uniform (sixteen quads in sixteen places), so the emulator's rendezvous is of the quad's four fibers only. */
+namespace avk_emu {
+const uint64_t *quad_gather(uint64_t v, uint32_t site); /* the four deposited values of this lane's quad */
+}
+template <int SRC> AVK_DEV uint32_t qd_bcast_(uint32_t v, uint32_t site) { return (uint32_t)avk_emu::quad_gather(v, site)[SRC]; }
+template <int M> AVK_DEV uint32_t qd_xor_(uint32_t v, uint32_t site) {
+    const int l = avk_emu::lane() & 3;
+    return (uint32_t)avk_emu::quad_gather(v, site)[l ^ M];
+}
+AVK_DEV void qd_sync_(uint32_t site) { (void)avk_emu::quad_gather(0, site); }
+#define qd_bcast(SRC, v) qd_bcast_<SRC>((v), AVK_SITE)
+#define qd_xor(M, v) qd_xor_<M>((v), AVK_SITE)
+#define qd_sync() qd_sync_(AVK_SITE)
+
 AVK_DEV uint32_t avk_atomic_add_u32(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); } /* waves of a workgroup are OS threads */
 AVK_DEV uint32_t avk_atomic_add_u32_global(uint32_t *p, uint32_t v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 AVK_DEV void avk_atomic_add_u64_global(uint64_t *p, uint64_t v) { __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
@@ -204,6 +219,19 @@ AVK_DEV uint64_t wv_min_u64(uint64_t v) {
  * private HBM slice, the hardware keeps a wave's DS and VMEM operations in issue order, so only
  * the compiler has to be stopped from moving or caching accesses across this point */
 AVK_DEV void wv_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+/* QUAD primitives (avk_quad.inl: four lanes on one region): DPP quad permutes, one VALU move each.  They are used in code that is uniform
+ * over the quad but divergent over the wave; the four lanes of a quad are active together there, which is all a quad_perm reads. */
+template <int SRC> AVK_DEV uint32_t qd_bcast_(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, SRC * 0x55, 0xf, 0xf, false); }
+template <int M> AVK_DEV uint32_t qd_xor_(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, M == 1 ? 0xB1 : (M == 2 ? 0x4E : 0x1B), 0xf, 0xf, false);
+}
+#define qd_bcast(SRC, v) qd_bcast_<SRC>(v)
+#define qd_xor(M, v) qd_xor_<M>(v)
+/* lanes of a quad exchange through LDS rows as well: the hardware keeps a wave's DS operations in order, the compiler must */
+AVK_DEV void qd_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }

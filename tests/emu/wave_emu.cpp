@@ -59,6 +59,11 @@ struct Wave {
     bool done[64];
     uint64_t slots[2][64];
     uint32_t sites[2][64];
+    /* quad rendezvous (qd_bcast / qd_xor / qd_sync): generation, values and call sites per lane; the four lanes of a quad must agree */
+    uint32_t qgen[64];
+    uint64_t qslots[2][64];
+    uint32_t qsites[2][64];
+    uint64_t progress; /* deposits and finished fibers so far: a full round of the fibers without any is a deadlock */
     void (*fn)(void *, int);
     void *arg;
 };
@@ -71,6 +76,24 @@ static void switch_to(Wave *w, int from, int to) {
     w->cur = to;
     avk_emu_switch(&w->sp[from], w->sp[to]);
 }
+/* the fibers take turns in lane order; a fiber runs until its next rendezvous (of the wave or of its quad) and waits there, passing the turn on,
+ * until the others it meets there have arrived */
+static int next_runnable(const Wave *w, int me) {
+    for (int i = 1; i <= 64; ++i) {
+        const int t = (me + i) & 63;
+        if (!w->done[t] && t != me) return t;
+    }
+    return -1;
+}
+static void wait_turn(Wave *w, int me, const char *what, uint32_t site) {
+    const uint64_t p = w->progress;
+    const int nx = next_runnable(w, me);
+    if (nx >= 0) switch_to(w, me, nx);
+    if (w->progress == p) { /* every other fiber had its turn and none arrived anywhere */
+        fprintf(stderr, "avk_emu: DEADLOCK: lane %d waits at a %s rendezvous (site %u) that the others never reach\n", me, what, site & 0x7FFFFFFFu);
+        abort();
+    }
+}
 
 const uint64_t *gather(uint64_t v, uint32_t site) {
     Wave *w = t_wave;
@@ -78,11 +101,24 @@ const uint64_t *gather(uint64_t v, uint32_t site) {
     const uint32_t g = w->gen[me]++;
     w->slots[g & 1][me] = v;
     w->sites[g & 1][me] = site;
-    switch_to(w, me, (me + 1) & 63);
-    /* back: every lane has deposited generation g */
+    w->progress += 1;
+    for (;;) {
+        bool all = true;
+        for (int i = 0; i < 64; ++i)
+            if (w->gen[i] < g + 1) {
+                all = false;
+                if (w->done[i]) {
+                    fprintf(stderr, "avk_emu: DIVERGENT wave primitive: lane %d at site %u, lane %d has finished (gen %u/%u)\n", me, site & 0x7FFFFFFFu, i, g, w->gen[i]);
+                    abort();
+                }
+            }
+        if (all) break;
+        wait_turn(w, me, "wave", site);
+    }
+    /* every lane has deposited generation g */
     const uint32_t *s = w->sites[g & 1];
     for (int i = 0; i < 64; ++i) {
-        if (s[i] != site || w->gen[i] < g + 1) {
+        if (s[i] != site) {
             fprintf(stderr, "avk_emu: DIVERGENT wave primitive: lane %d at site %u, lane %d at site %u (gen %u/%u)\n", me, site & 0x7FFFFFFFu, i,
                     s[i] & 0x7FFFFFFFu, g, w->gen[i]);
             abort();
@@ -100,25 +136,53 @@ const uint64_t *gather(uint64_t v, uint32_t site) {
     return w->slots[g & 1];
 }
 
+const uint64_t *quad_gather(uint64_t v, uint32_t site) {
+    Wave *w = t_wave;
+    const int me = w->cur, q0 = me & ~3;
+    const uint32_t g = w->qgen[me]++;
+    w->qslots[g & 1][me] = v;
+    w->qsites[g & 1][me] = site;
+    w->progress += 1;
+    for (;;) {
+        bool all = true;
+        for (int i = q0; i < q0 + 4; ++i)
+            if (w->qgen[i] < g + 1) {
+                all = false;
+                if (w->done[i]) {
+                    fprintf(stderr, "avk_emu: DIVERGENT quad primitive: lane %d at site %u, lane %d has finished\n", me, site, i);
+                    abort();
+                }
+            }
+        if (all) break;
+        wait_turn(w, me, "quad", site);
+    }
+    for (int i = q0; i < q0 + 4; ++i)
+        if (w->qsites[g & 1][i] != site) {
+            fprintf(stderr, "avk_emu: DIVERGENT quad primitive: lane %d at site %u, lane %d at site %u\n", me, site, i, w->qsites[g & 1][i]);
+            abort();
+        }
+    return w->qslots[g & 1] + q0;
+}
+
 static void fiber_entry() {
     Wave *w = t_wave;
     const int me = w->cur;
     w->fn(w->arg, me);
     w->done[me] = true;
-    /* all lanes must have passed the same number of rendezvous */
-    for (int i = 0; i < 64; ++i)
-        if (w->gen[i] != w->gen[me]) {
-            fprintf(stderr, "avk_emu: lane %d finished after %u rendezvous but lane %d is at %u\n", me, w->gen[me], i, w->gen[i]);
-            abort();
-        }
-    if (me == 63) {
+    w->progress += 1;
+    const int nx = next_runnable(w, me);
+    void *dummy;
+    if (nx < 0) { /* the last fiber: all lanes must have passed the same number of wave rendezvous */
+        for (int i = 0; i < 64; ++i)
+            if (w->gen[i] != w->gen[me]) {
+                fprintf(stderr, "avk_emu: lane %d finished after %u rendezvous but lane %d after %u\n", me, w->gen[me], i, w->gen[i]);
+                abort();
+            }
         w->cur = -1;
-        void *dummy;
         avk_emu_switch(&dummy, w->main_sp);
     } else {
-        void *dummy;
-        w->cur = me + 1;
-        avk_emu_switch(&dummy, w->sp[me + 1]);
+        w->cur = nx;
+        avk_emu_switch(&dummy, w->sp[nx]);
     }
     abort(); /* unreachable */
 }
@@ -127,8 +191,10 @@ static void fiber_entry() {
 static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
     w->fn = fn;
     w->arg = arg;
+    w->progress = 0;
     for (int i = 0; i < 64; ++i) {
         w->gen[i] = 0;
+        w->qgen[i] = 0;
         w->done[i] = false;
         char *top = w->stacks + (size_t)(i + 1) * w->stack_bytes;
         uintptr_t t = ((uintptr_t)top & ~(uintptr_t)15) - 8; /* rsp % 16 == 8 at function entry */
@@ -151,6 +217,7 @@ static void run_wave(Wave *w, void (*fn)(void *, int), void *arg) {
 namespace avk { namespace lane { uint64_t g_lane_stats[32]; int g_lane_phase; uint32_t *g_lane_work; uint32_t *g_lane_comp; } }
 #endif
 #include "../../aardvark_amd/csrc/avk_lane.inl"
+#include "../../aardvark_amd/csrc/avk_quad.inl"
 #ifdef AVK_WIDE_STATS
 namespace avk { namespace wide { uint64_t g_wide_defer[64]; uint32_t g_wide_defer_region[64]; } }
 #endif
@@ -188,6 +255,15 @@ void lane_kernel_main(void *p, int lane) {
     LaneTask *t = (LaneTask *)p;
     uint32_t ok = 0, err = 0;
     avk::lane::lane_worker(*t->args, *t->la, t->wave_id, t->lds, t->tally, ok, err);
+    t->n_ok[lane] = ok;
+    t->n_err[lane] = err;
+}
+uint64_t g_quad_solved = 0; /* emu_last_quad_solved: regions the quad launches of the last call finished */
+int g_lane_quad = 1; /* context option lane_quad: launches of at most 16 records per wave (the heads, the three-call class) run four lanes per region (avk_quad.inl) */
+void quad_kernel_main(void *p, int lane) {
+    LaneTask *t = (LaneTask *)p;
+    uint32_t ok = 0, err = 0;
+    avk::quad::quad_worker(*t->args, *t->la, t->wave_id, t->lds, t->tally, ok, err);
     t->n_ok[lane] = ok;
     t->n_err[lane] = err;
 }
@@ -583,6 +659,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     (void)fast_list;
     const uint32_t n_fast = use_fast ? plan.n_fast_total : 0u;
     g_lane_solved = 0;
+    g_quad_solved = 0;
     g_last_pair_regions = 0;
     if (use_fast) {
         uint64_t word_base[AVK_FAST_CLASSES];
@@ -670,7 +747,8 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
             f3.overflow_list = lists[3].data();
             f3.overflow_count = counters + 1104;
             auto launch = [&](const avk::lane::LaneArgs &la) {
-                const uint32_t rows = avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool);
+                const bool quad = g_lane_quad && la.lanes_log2 <= 4; /* run_internal's rule */
+                const uint32_t rows = quad ? avk::quad::quad_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool) : avk::lane::lane_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool);
                 std::atomic<uint32_t> next(0);
                 const uint32_t waves = n_waves ? n_waves : 1;
                 const int nthr = threads < 1 ? 1 : threads;
@@ -691,11 +769,12 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
                         t.wave_id = wid;
                         t.lds = lds.data();
                         t.tally = tl.data();
-                        avk_emu::run_wave(&w, lane_kernel_main, &t);
+                        avk_emu::run_wave(&w, quad ? quad_kernel_main : lane_kernel_main, &t);
                         for (int l = 0; l < 64; ++l) {
                             sm[AVK_TALLY_SOLVED] += t.n_ok[l];
                             sm[AVK_TALLY_ERRORS] += t.n_err[l];
                             sm[AVK_TALLY_LANE_SOLVED] += t.n_ok[l] + t.n_err[l];
+                            if (quad) __atomic_fetch_add(&g_quad_solved, (uint64_t)(t.n_ok[l] + t.n_err[l]), __ATOMIC_RELAXED);
                         }
                     }
                     for (int i = 0; i < AVK_N_GROUPS * AVK_N_FIELDS; ++i) sm[i] += tl[i];
@@ -1176,12 +1255,16 @@ void emu_wide_defer_stats(uint64_t *out, int reset) {
 void emu_set_wide_lds_bytes(uint32_t bytes) { g_wide_lds_bytes = bytes; }
 void emu_set_lane_node_cap(int cap) { g_lane_node_cap = (uint32_t)cap; }
 void emu_set_lane_pool(int slots) { g_lane_pool = slots; }
+void emu_set_lane_quad(int on) { g_lane_quad = on; }
+uint64_t emu_last_quad_solved(void) { return g_quad_solved; }
 void emu_set_pair_classes(int on) { g_pair_classes = on; }
 void emu_set_lane_head_width(int w) { g_lane_head_width = (uint32_t)w; }
+static uint32_t width_log2(int w) { return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u))); }
 void emu_set_lane_width(int one, int two) {
-    g_lane_width_log2[0] = one <= 16 ? 4 : (one <= 32 ? 5 : 6);
-    g_lane_width_log2[1] = two <= 16 ? 4 : (two <= 32 ? 5 : 6);
+    g_lane_width_log2[0] = width_log2(one);
+    g_lane_width_log2[1] = width_log2(two);
 }
+void emu_set_lane_width_three(int three) { g_lane_width_log2[2] = width_log2(three); }
 
 int emu_compare_batch(const avk_region_batch *batch, const uint8_t *const *refs, const uint64_t *ref_lens, uint32_t n_contigs,
                       const avk_compare_config *cfg, avk_result_batch *out, uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_bytes,

@@ -27,6 +27,8 @@ def load():
         lib.emu_set_wide_kernel.argtypes = [C.c_int]
         lib.emu_set_wide_lds_bytes.argtypes = [C.c_uint32]
         lib.emu_set_lane_pool.argtypes = [C.c_int]
+        lib.emu_set_lane_quad.argtypes = [C.c_int]
+        lib.emu_last_quad_solved.restype = C.c_uint64
         _lib = lib
     return _lib
 
@@ -34,7 +36,7 @@ def load():
 def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_shortcut=False,
                   lds_bytes=10 * 1024, lds_ed_cap=48, lds2_bytes=40 * 1024, lds2_ed_cap=48, ws_bytes=1 << 20, big_ws_bytes=64 << 20,
                   n_waves=8, threads=8, solo_min_variants=5, lds2_overflow_pass=0, lds_escalation=1, group_metrics=True, lane_kernel=True, bp_groups=False,
-                  wide_kernel=True, wide_lds_bytes=16 * 1024, class_c_all=False, packed=False, lane_pool=-1):
+                  wide_kernel=True, wide_lds_bytes=16 * 1024, class_c_all=False, packed=False, lane_pool=-1, lane_quad=True):
     """lane_kernel: small regions go through the lane-per-region code (avk_lane.inl), the rest through the wave-per-region code, as
     avk_compare_resident does; False = everything through the wave-per-region code.  res.lane_solved = regions the lane code finished.
     wide_kernel: class C and what the three-call lane class hands back go through the wave-cooperative code of avk_wide.inl first
@@ -43,6 +45,7 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     lib.emu_set_lane_kernel(1 if lane_kernel else 0)
     lib.emu_set_wide_kernel(1 if wide_kernel else 0)
     lib.emu_set_wide_lds_bytes(wide_lds_bytes)
+    lib.emu_set_lane_quad(1 if lane_quad else 0)  # context option lane_quad: launches of at most 16 records per wave run four lanes per region (avk_quad.inl); res.quad_solved
     lib.emu_set_lane_pool(lane_pool)  # context option lane_pool: node states a lane keeps during its search (-1: by class, in the heads and the three-call class)
     before = os.environ.get("AVK_EMU_CLASS_C")
     if class_c_all:
@@ -58,6 +61,7 @@ def compare_batch(batch, contigs, max_branch_factor=50, sequences=False, exact_s
     res.tier_counts = [int(x) for x in tiers]
     res.lane_solved = int(lib.emu_last_lane_solved())
     res.wide_solved = int(lib.emu_last_wide_solved())
+    res.quad_solved = int(lib.emu_last_quad_solved())
     if class_c_all:
         if before is None:
             os.environ.pop("AVK_EMU_CLASS_C", None)
