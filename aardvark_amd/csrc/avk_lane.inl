@@ -84,7 +84,7 @@ struct LCtx {
     u32 wfr;     /* rows per wavefront array */
     u32 wfcap_c; /* bytes of the metrics phase's one array (wfa_ed) */
 #ifdef AVK_LANE_PHASE_TIMING
-    u64 tph[8], tlast;
+    mutable u64 tph[8], tlast;
 #endif
 #ifdef AVK_LANE_SLOW_TILES
     mutable u32 n_pops, n_diag, n_words; /* this lane's own loop turns in the current record (lanes share time, not turns) */
@@ -441,6 +441,28 @@ template <class C> AVK_DEV int hap_finalize(const C &c, Hap &h, u32 arr, u32 bud
         wf_set(c, arr, 0, h.d0);
     }
     return dw_finalize(c, arr, h.ed, st, h.t_len, sq, h.q_len, budget, c.wfcap);
+}
+/* hap_update (final = false) or hap_update + hap_finalize (final = true: the second carries on where the first stops, and a front with a full diagonal touches
+ * an end, so the two are ONE walk up the distances that ends at the later condition) — one copy of the aligner's loops where a kernel wants one call site */
+template <class C> AVK_DEV int hap_align(const C &c, Hap &h, u32 arr, u32 budget, bool final) {
+    const u32 st = c.seq_id(0, h.t_alt), sq = c.seq_id(1, h.q_alt);
+    if (h.ed == 0) {
+        h.d0 += match_run_same(c, st, h.t_len, sq, h.q_len, h.d0);
+        const u32 lim = h.t_len < h.q_len ? h.t_len : h.q_len;
+        if (final ? (h.d0 >= h.t_len && h.d0 >= h.q_len) : (h.d0 >= lim)) return 0;
+        if (budget == 0) return LS_PARTIAL;
+        if (c.wfcap < 3) return AVK_LDEFER(0);
+        wf_set(c, arr, 0, h.d0);
+    }
+    const u32 want = final ? (u32)DW_FULL : (u32)DW_TOUCH;
+    u32 fl = dw_extend(c, arr, h.ed, st, h.t_len, sq, h.q_len);
+    while (!(fl & want)) {
+        if (h.ed + 1 > budget) return LS_PARTIAL;
+        if (2 * h.ed + 3 > c.wfcap) return AVK_LDEFER(0);
+        fl = dw_bump_extend(c, arr, h.ed, st, h.t_len, sq, h.q_len);
+        h.ed += 1;
+    }
+    return 0;
 }
 /* the search order (order_variants, query_optimizer.rs:372-381): slot of the call at depth d, and the step's sync point */
 AVK_DEV u32 ord_slot(const LCtx &c, u32 d) { return (c.ord >> (3 * d)) & 7u; }
@@ -991,6 +1013,38 @@ template <u32 side> AVK_DEV void build_full(LCtx &c, u32 mask, const u32 (&a1lo)
     c.seq_fail_hi |= s < 8 ? 0ull : fail_s;
 }
 
+/* The reference window of a region into row 0 of its table: 2 bits per base from the packed genome, word k by lane q of NQ when k = q (mod NQ).
+ * Every global load is issued before the first one is used — a lane is otherwise a chain of memory round trips here: the flags of the packed words the
+ * window touches (at most 14 consecutive bits of the bitmap: two words) and the words themselves (static loop: at most 13 words of 16 bases).
+ * Returns false when a flagged word (anything but upper-case ACGT) is in the window: not for these kernels. */
+template <u32 NQ> AVK_DEV bool load_window(const AvkKernelArgs &a, const LCtx &c, u32 h0, u32 shift, u32 q) {
+    enum { KMAX = 13, NJ = (KMAX + NQ - 1) / NQ };
+    const u32 nw = (c.L + shift + 15u) >> 4; /* packed words the window touches */
+    const u64 w0 = h0;
+    const u32 e0 = a.ref_exc[w0 >> 5], e1 = a.ref_exc[(w0 + nw - 1) >> 5];
+    u32 lo[NJ + 1], hi[NJ];
+#pragma unroll
+    for (u32 j = 0; j < NJ; ++j) {
+        const u32 k = q + NQ * j;
+        const bool on = k < c.W1 && k * 16 < c.L;
+        /* (one lane for all words: the word behind word k is the next load, wanted whenever word k is) */
+        const bool need = NQ > 1 ? on : (k == 0 || (k - 1u < c.W1 && (k - 1u) * 16 < c.L));
+        lo[j] = a.ref_2bit[w0 + (need ? k : 0u)];
+        if (NQ > 1) hi[j] = a.ref_2bit[w0 + (on ? k + 1u : 0u)];
+    }
+    if (NQ == 1) lo[NJ] = a.ref_2bit[w0 + ((u32)KMAX - 1u < c.W1 && ((u32)KMAX - 1u) * 16 < c.L ? (u32)KMAX : 0u)];
+    const u64 flags = ((((u64)e1 << 32) | e0) >> (w0 & 31u)) & ((1ull << nw) - 1ull);
+    if (flags) return false;
+#pragma unroll
+    for (u32 j = 0; j < NJ; ++j) {
+        const u32 k = q + NQ * j;
+        if (k >= c.W1) continue;
+        const u32 h = NQ > 1 ? hi[j] : lo[j + 1];
+        c.p[k << c.ls] = k * 16 < c.L ? (u32)((((u64)h << 32) | lo[j]) >> (2 * shift)) : 0u;
+    }
+    return true;
+}
+
 /* ---- one region ------------------------------------------------------------------------------------------------------ */
 struct LaneOut {
     u32 ed1, ed2, n_opt, present;
@@ -1062,13 +1116,14 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
         const u32 side = s / MV, j = s % MV;
         const bool on = j < (side ? c.Q : c.T);
         c.vw0[s] = c.vw1[s] = a1lo[s] = a1hi[s] = 0;
-        if (on) {
+        if (j < maxv) { /* every slot the class's records have is loaded, whatever the header says: one round trip for the whole record */
             const u32 *v = rec + (AVK_FAST_HDR + 4 * (side * maxv + j)) * lane_stride;
-            c.vw0[s] = v[0];
-            c.vw1[s] = v[1 * lane_stride];
-            a1lo[s] = v[2 * lane_stride];
-            a1hi[s] = v[3 * lane_stride];
-            types |= 1u << ((c.vw0[s] >> 24) & 0xFu);
+            const u32 x0 = v[0], x1 = v[1 * lane_stride], x2 = v[2 * lane_stride], x3 = v[3 * lane_stride];
+            c.vw0[s] = on ? x0 : 0u;
+            c.vw1[s] = on ? x1 : 0u;
+            a1lo[s] = on ? x2 : 0u;
+            a1hi[s] = on ? x3 : 0u;
+            types |= on ? 1u << ((x0 >> 24) & 0xFu) : 0u;
         }
     }
     { /* tables of the search: sync points per depth, ends of the REF spans per side, whether a cost of 0 means that nothing was skipped */
@@ -1088,25 +1143,7 @@ AVK_DEV int solve_lane(const AvkKernelArgs &a, LCtx &c, const u32 *rec, u32 lane
         c.plain = plain;
     }
     /* reference window: 2 bits per base from the packed genome; a flagged word (anything but upper-case ACGT) is not for this kernel */
-    {
-        const u32 nw = (c.L + shift + 15u) >> 4; /* packed words the window touches */
-        bool exc = false;
-        for (u32 k = 0; k < nw; ++k) {
-            const u64 w = (u64)h0 + k;
-            exc = exc || ((a.ref_exc[w >> 5] >> (w & 31)) & 1u);
-        }
-        if (exc) return AVK_LDEFER(4);
-        u32 prev = a.ref_2bit[h0];
-        for (u32 k = 0; k < c.W1; ++k) {
-            u32 word = 0;
-            if (k * 16 < c.L) {
-                const u32 next = a.ref_2bit[(u64)h0 + k + 1];
-                word = (u32)((((u64)next << 32) | prev) >> (2 * shift));
-                prev = next;
-            }
-            c.p[k << c.ls] = word;
-        }
-    }
+    if (!load_window<1>(a, c, h0, shift, 0)) return AVK_LDEFER(4);
     for (u32 m = 1; m <= c.nm1; ++m) {
         if (m < (1u << c.T)) build_full<0>(c, m, a1lo, a1hi);
         if (m < (1u << c.Q)) build_full<1>(c, m, a1lo, a1hi);

@@ -33,6 +33,21 @@ namespace quad {
 
 using namespace avk::lane;
 
+/* profiling builds (-DAVK_LANE_PHASE_TIMING -DAVK_QUAD_FINE=1 or 2): the clock ticks of the staging (1) or of the phasing search (2) split further; the marks
+ * take the place of the phases' own, everything else lands in slot 0 (tools/gpu_lane_phases.py prints the slots under their fine names) */
+#if defined(AVK_LANE_PHASE_TIMING) && defined(AVK_QUAD_FINE)
+#define AVK_QF(which, c, k)                   \
+    if (AVK_QUAD_FINE == which) {             \
+        const u64 n_ = avk_clock();           \
+        (c).tph[k] += n_ - (c).tlast;         \
+        (c).tlast = n_;                       \
+    }
+#undef AVK_LT_MARK
+#define AVK_LT_MARK(c, k) AVK_QF(AVK_QUAD_FINE, c, 0)
+#else
+#define AVK_QF(which, c, k)
+#endif
+
 /* rows of a region (stride = regions per wave):
  *   sequence table | optima list | DYN = queue, kept node states (pool x 2 haplotypes x wfr), the four lanes' search fronts (4 x wfr)
  * after the search DYN is four private arrays of DYN / 4 rows: a lane's front while an optimum is replayed, its queue in the genotype search,
@@ -142,60 +157,74 @@ AVK_DEV int qq_pushA(const LCtx &c, u32 q, u32 &qn, u32 cost, u32 id, u32 code, 
     if (cost > 255u) return AVK_LDEFER(5);
     return qq_push(c, q, qn, keyA(cost, id, code, partial, depth));
 }
-/* the smallest queue word, removed; `second` = the smallest of what is left (only read for partial entries) */
+/* the smallest queue word, removed; `second` = the smallest of what is left (only made for partial entries).  The four lanes scan a quarter of the queue each. */
+AVK_DEV u32 qd_min(u32 v) {
+    const u32 a = qd_xor(1, v);
+    v = a < v ? a : v;
+    const u32 b = qd_xor(2, v);
+    return b < v ? b : v;
+}
 AVK_DEV u32 qq_pop_min(const LCtx &c, u32 q, u32 &qn, u32 &second) {
-    u32 best = 0xFFFFFFFFu, sec = 0xFFFFFFFFu;
-    if (q == 0) {
-        u32 bi = 0;
-        for (u32 i = 0; i < qn; ++i) {
-            const u32 e = c.p[(c.off_q + i) << c.ls];
-            if (e < best) {
-                sec = best;
-                best = e;
-                bi = i;
-            } else if (e < sec)
-                sec = e;
-        }
-        c.p[(c.off_q + bi) << c.ls] = c.p[(c.off_q + qn - 1) << c.ls];
+    qd_sync(); /* lane 0's pushes */
+    u32 best = 0xFFFFFFFFu, sec = 0xFFFFFFFFu, bi = 0;
+    for (u32 i = q; i < qn; i += 4) {
+        const u32 e = c.p[(c.off_q + i) << c.ls];
+        if (e < best) {
+            sec = best;
+            best = e;
+            bi = i;
+        } else if (e < sec)
+            sec = e;
     }
+    const u32 gbest = qd_min(best);
+    const u32 gi = qd_min(best == gbest ? bi : 0xFFFFFFFFu); /* (queue words are unique: one lane holds it) */
+    const u32 last = c.p[(c.off_q + qn - 1) << c.ls];
+    qd_sync(); /* every lane has read the queue */
+    if (q == 0) c.p[(c.off_q + gi) << c.ls] = last;
     qn -= 1;
-    best = qd_bcast(0, best);
-    second = sec;
-    if (best & 8u) second = qd_bcast(0, sec);
-    return best;
+    second = 0xFFFFFFFFu;
+    if (gbest & 8u) second = qd_min(best == gbest ? sec : best);
+    return gbest;
 }
 
-/* The alignments of a step whose haplotype steps are made (nodeA_settle), one haplotype per lane.  `cap` = the largest total node cost the
- * caller cares about.  The budget of a haplotype is what the cap leaves beside the skipped calls and the OTHER haplotype's distance before this
- * step — avk_lane.inl aligns the second haplotype with what the first one left, which only stops it earlier: either way a node comes back partial
- * with a lower bound that is not above its cost, or exact, and the sequence of real pops is the reference's.
- * Returns the node's summary, the same on its two lanes: cost or lower bound | eds << 16 | QS_PARTIAL | QS_DEFER. */
-template <bool FINAL> AVK_DEV u32 hapq_settle(const LCtx &c, Hap &h, u32 k, u32 cap, bool defer_in) {
+/* The alignments of a node's last step (nodeA_settle / finalize_dwfas), one haplotype per lane, in two halves around the ONE call of the aligner the search
+ * has (phaseA_quad).  `cap` = the largest total node cost the caller cares about.  The budget of a haplotype is what the cap leaves beside the skipped calls
+ * and the OTHER haplotype's distance before this step — avk_lane.inl aligns the second haplotype with what the first one left, which only stops it earlier:
+ * either way a node comes back partial with a lower bound that is not above its cost, or exact, and the sequence of real pops is the reference's. */
+struct Settle {
+    u32 base, oed, lb0;
+    bool defer0, over;
+};
+AVK_DEV void settle_before(const Hap &h, u32 cap, bool defer_in, Settle &t) {
     const u32 mine0 = (h.t_skip + h.q_skip) | (h.ed << 16) | (defer_in ? 1u << 24 : 0u);
     const u32 oth0 = qd_xor(1, mine0);
-    const u32 base = (mine0 & 0xFFFFu) + (oth0 & 0xFFFFu), oed = (oth0 >> 16) & 0xFFu;
-    const bool defer0 = ((mine0 | oth0) >> 24) & 1u;
-    const u32 lb0 = base + h.ed + oed; /* distances never decrease */
-    const bool over = lb0 > cap;
-    int r = 0;
-    if (!defer0 && !over) {
-        const u32 budget = cap - base - oed;
-        r = hap_update(c, h, 0, budget);
-        if (FINAL && r == 0) r = hap_finalize(c, h, 0, budget);
-    }
+    t.base = (mine0 & 0xFFFFu) + (oth0 & 0xFFFFu), t.oed = (oth0 >> 16) & 0xFFu;
+    t.defer0 = (((mine0 | oth0) >> 24) & 1u) != 0;
+    t.lb0 = t.base + h.ed + t.oed; /* distances never decrease */
+    t.over = t.lb0 > cap;
+}
+/* the node's summary, the same on its two lanes: cost or lower bound | eds << 16 | QS_PARTIAL | QS_DEFER */
+AVK_DEV u32 settle_after(const Hap &h, u32 k, u32 cap, int r, const Settle &t) {
     const u32 mine1 = h.ed | (r == LS_PARTIAL ? 1u << 8 : 0u) | (r == LS_DEFER ? 1u << 9 : 0u);
     const u32 oth1 = qd_xor(1, mine1);
-    const bool defer = defer0 || (((mine1 | oth1) >> 9) & 1u);
-    const bool partial = over || (((mine1 | oth1) >> 8) & 1u);
+    const bool defer = t.defer0 || (((mine1 | oth1) >> 9) & 1u);
+    const bool partial = t.over || (((mine1 | oth1) >> 8) & 1u);
     const u32 ed_me = h.ed, ed_ot = oth1 & 0xFFu;
     const u32 eds = k ? (ed_ot | (ed_me << 4)) : (ed_me | (ed_ot << 4));
-    u32 cst = partial ? (over ? lb0 : cap + 1u) : base + ed_me + ed_ot;
+    u32 cst = partial ? (t.over ? t.lb0 : cap + 1u) : t.base + ed_me + ed_ot;
     cst = cst < 0xFFFFu ? cst : 0xFFFFu;
     return cst | (eds << 16) | (partial ? (u32)QS_PARTIAL : 0u) | (defer ? (u32)QS_DEFER : 0u);
 }
 
 /* ---- phase A: optimize_sequences (avk_lane.inl phaseA, one haplotype per lane, two children side by side) ------------
- * q = lane of the quad: haplotype k = q & 1, child ch = q >> 1.  Returns the number of tied optima, LS_DEFER, or -100 - status. */
+ * q = lane of the quad: haplotype k = q & 1, child ch = q >> 1.  Returns the number of tied optima, LS_DEFER, or -100 - status.
+ *
+ * BRANCH-FLATTENED: the sixteen quads of a wave go round this loop together, whatever each of them popped — a partial entry to be taken further, a finished
+ * node, a node that splits in two or moves on — so the loop body has ONE haplotype step, ONE aligner and ONE push / keep sequence, and what differs between
+ * the cases is data: from which depth the node's path is walked again (`d`), from where its steps are aligned (`d_align`), which allele the last step takes,
+ * what the cap is and whether the last alignment is a finalisation.  (Sixteen quads in five copies of the aligner take five turns.)
+ * A partial entry that turns out to cost exactly what it was popped for goes back into the queue as an exact entry — the smallest word there, so it is the
+ * next pop, the real one, with its state kept — instead of being expanded in the same round. */
 AVK_DEV int phaseA_quad(const LCtx &c, u32 q, u32 &best_out) {
     const u32 k = q & 1u, ch = q >> 1;
     u32 qn = 0;
@@ -207,64 +236,107 @@ AVK_DEV int phaseA_quad(const LCtx &c, u32 q, u32 &best_out) {
     while (qn > 0) {
         u32 second;
         const u32 e = qq_pop_min(c, q, qn, second);
+        AVK_QF(2, c, 1)
         const u32 cost = e >> 24;
         if (cost > best) break; /* :204 */
         const u32 depth = e & 7u, code = (e >> 4) & 0xFFFu, id = (e >> 16) & 0xFFu;
-        Hap h;
-        bool have = false, dfr = false;
-        if (e & 8u) { /* partial: the last step is taken further, as far as it can matter for the order */
-            u32 cap = qn ? second >> 24 : 0xFFFFu;
+        const bool part = (e & 8u) != 0;
+        /* ---- the plan of this round */
+        u32 cap, d_to, choice = 0;
+        bool two = false;
+        if (part) { /* the last step is taken further: as far as it can matter for the order (the next entry's cost), at least doubling, never beyond the best finished cost */
+            cap = qn ? second >> 24 : 0xFFFFu;
             cap = cap > 2 * cost + 2 ? cap : 2 * cost + 2;
             cap = cap < best ? cap : best;
             cap = cap > cost ? cap : cost;
-            const u32 slot = pool_find(c, pl, id);
-            if (slot < c.pool) { /* where the step stopped was kept: on from there */
-                hapq_replay_steps(c, h, k, code, depth);
-                qpool_load(c, pl, slot, k, h);
-            } else {
-                dfr = hapq_replay_exact(c, h, k, code, depth - 1);
-                const u32 sl = ord_slot(c, depth - 1), choice = (code >> (2 * (depth - 1))) & 3u;
-                hap_step(c, h, sl < MV, true, sl, ((choice >> k) & 1u) ? L_ALT : L_REF, sync_after(c, depth - 1));
-            }
-            const u32 s = hapq_settle<false>(c, h, k, cap, dfr);
-            if (s & QS_DEFER) return LS_DEFER;
-            if (s & QS_PARTIAL) {
-                if (qq_pushA(c, q, qn, qs_cost(s), id, code, 1, depth)) return LS_DEFER;
-                qpool_keep(c, pl, id, h, k, qs_eds(s), true, ch == 0);
-                continue;
-            }
-            if (qs_cost(s) != cost) {
-                if (qq_pushA(c, q, qn, qs_cost(s), id, code, 0, depth)) return LS_DEFER;
-                qpool_keep(c, pl, id, h, k, qs_eds(s), false, ch == 0);
-                continue;
-            }
-            have = true;
-        }
-        const u32 cnt = (u32)(bucket >> (8 * depth)) & 0xFFu;
-        if (cnt >= c.max_branch) { /* :222 */
-            if (!have && cost) {
-                const u32 slot = pool_find(c, pl, id);
-                if (slot < c.pool) pool_free(pl, slot);
-            }
-            continue;
-        }
-        bucket += 1ull << (8 * depth);
-        if (!have) {
-            if (cost == 0) hapq_replay_zero(c, h, k, code, depth);
-            else {
-                hapq_replay_steps(c, h, k, code, depth);
-                const u32 sk = h.t_skip + h.q_skip;
-                if (sk + qd_xor(1, sk) == cost) h.d0 = h.t_len < h.q_len ? h.t_len : h.q_len; /* all skipped calls: the fronts are the ends of the shorter sequences */
-                else {
+            d_to = depth - 1;
+        } else {
+            const u32 cnt = (u32)(bucket >> (8 * depth)) & 0xFFu;
+            if (cnt >= c.max_branch) { /* :222 */
+                if (cost) {
                     const u32 slot = pool_find(c, pl, id);
-                    if (slot < c.pool) qpool_load(c, pl, slot, k, h);
-                    else dfr = hapq_replay_exact(c, h, k, code, depth);
+                    if (slot < c.pool) pool_free(pl, slot);
+                }
+                continue;
+            }
+            bucket += 1ull << (8 * depth);
+            d_to = depth;
+            cap = cost;
+            if (depth == c.N) cap = best; /* :227-247; finalize_dwfas (:457-462) */
+            else {
+                const u32 slot = ord_slot(c, depth);
+                const u32 zyg = (sel4(c.vw0, slot) >> 28) & 7u;
+                const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
+                two = het && (slot >= MV || zyg == AVK_ZYG_UNPHASED_HET); /* :269-293: two clones, (REF|ALT) then (ALT|REF): child 0 = choice 2, child 1 = choice 1 */
+                choice = two ? (ch ? 1u : 2u) : (het ? (zyg == AVK_ZYG_PHASED_HET01 ? 2u : 1u) : 3u); /* :294-327: the node is moved (the second pair of lanes does what the first does) */
+            }
+        }
+        const bool final = !part && depth == c.N;
+        /* ---- the node's state: in closed form, or its path walked again (lengths only up to the last step; with every step aligned when nothing else is left) */
+        Hap h;
+        bool dfr = false, need_front = false;
+        const u32 kept = (part || cost) ? pool_find(c, pl, id) : c.pool;
+        u32 d = 0, d_align = d_to;
+        if (!part && cost == 0 && c.plain) {
+            hapq_restore_zero(c, h, k, code, depth);
+            d = depth;
+        } else {
+            hap_init(h);
+            need_front = true;
+            if (part && kept >= c.pool) d_align = 0, need_front = false; /* where the step stopped was not kept */
+        }
+        Settle t;
+        t.base = t.oed = t.lb0 = 0, t.defer0 = t.over = false;
+        int r_last = 0;
+        for (;;) {
+            const bool last = d == d_to;
+            bool load_kept = false;
+            if (last && need_front) { /* the state in front of the last step is complete but for where its alignments stand */
+                need_front = false;
+                load_kept = part; /* (a partial entry's kept fronts are those of its last step) */
+                if (!part) {
+                    const u32 sk = h.t_skip + h.q_skip;
+                    if (sk + qd_xor(1, sk) == cost) h.d0 = h.t_len < h.q_len ? h.t_len : h.q_len; /* all skipped calls: the fronts are the ends of the shorter sequences */
+                    else if (kept < c.pool) load_kept = true;
+                    else { /* no kept state: the path again, every step aligned */
+                        hap_init(h);
+                        d = 0, d_align = 0;
+                        continue;
+                    }
                 }
             }
+            /* the step of depth d */
+            bool is_truth = true, has_var = false;
+            u32 slot = 0, allele = L_REF, sync = c.L;
+            if (d < c.N) {
+                slot = ord_slot(c, d);
+                is_truth = slot < MV;
+                has_var = true;
+                sync = sync_after(c, d);
+                const u32 chc = d == depth ? choice : (code >> (2 * d)) & 3u;
+                allele = ((chc >> k) & 1u) ? L_ALT : L_REF;
+            }
+            hap_step(c, h, is_truth, has_var, slot, allele, sync);
+            if (load_kept) qpool_load(c, pl, kept, k, h); /* (a step changes lengths and positions, not the fronts) */
+            if (d >= d_align) {
+                u32 budget = 0xFFFFu;
+                bool run = !dfr;
+                if (last) {
+                    settle_before(h, cap, dfr, t);
+                    run = !t.defer0 && !t.over;
+                    budget = cap - t.base - t.oed;
+                }
+                int r = 0;
+                if (run) r = hap_align(c, h, 0, budget, last && final);
+                if (last) r_last = r;
+                else dfr = dfr || r != 0;
+            }
+            if (last) break;
+            d += 1;
         }
-        if (depth == c.N) { /* :227-247; finalize_dwfas (:457-462) */
-            hap_step(c, h, true, false, 0, L_REF, c.L);
-            const u32 s = hapq_settle<true>(c, h, k, best, dfr);
+        const u32 s = settle_after(h, k, cap, r_last, t);
+        AVK_QF(2, c, 3)
+        if (final) {
             if (s & QS_DEFER) return LS_DEFER;
             if (s & QS_PARTIAL) continue; /* costs more than the best: neither kept nor tied */
             const u32 fc = qs_cost(s);
@@ -279,32 +351,21 @@ AVK_DEV int phaseA_quad(const LCtx &c, u32 q, u32 &best_out) {
             }
             continue;
         }
-        const u32 slot = ord_slot(c, depth);
-        const bool is_truth = slot < MV;
-        const u32 zyg = (sel4(c.vw0, slot) >> 28) & 7u;
-        const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
-        const u32 sync = sync_after(c, depth);
-        if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF): child 0 = choice 2, child 1 = choice 1 */
-            hap_step(c, h, is_truth, true, slot, k != ch ? L_ALT : L_REF, sync);
-            const u32 s = hapq_settle<false>(c, h, k, cost, dfr);
-            const u32 o = qd_xor(2, s);
-            const u32 s0 = ch ? o : s, s1 = ch ? s : o;
-            if ((s0 | s1) & QS_DEFER) return LS_DEFER;
-            if (qq_pushA(c, q, qn, qs_cost(s0), next_id, code | (2u << (2 * depth)), (s0 & QS_PARTIAL) ? 1u : 0u, depth + 1)) return LS_DEFER;
-            qpool_keep(c, pl, next_id, h, k, qs_eds(s0), (s0 & QS_PARTIAL) != 0, ch == 0);
-            next_id += 1;
-            if (qq_pushA(c, q, qn, qs_cost(s1), next_id, code | (1u << (2 * depth)), (s1 & QS_PARTIAL) ? 1u : 0u, depth + 1)) return LS_DEFER;
-            qpool_keep(c, pl, next_id, h, k, qs_eds(s1), (s1 & QS_PARTIAL) != 0, ch == 1);
-            next_id += 1;
-        } else { /* :294-327: the node is moved, its id kept (the second pair of lanes does what the first does) */
-            u32 choice = 3u;
-            if (het) choice = zyg == AVK_ZYG_PHASED_HET01 ? 2u : 1u;
-            hap_step(c, h, is_truth, true, slot, ((choice >> k) & 1u) ? L_ALT : L_REF, sync);
-            const u32 s = hapq_settle<false>(c, h, k, cost, dfr);
-            if (s & QS_DEFER) return LS_DEFER;
-            if (qq_pushA(c, q, qn, qs_cost(s), id, code | (choice << (2 * depth)), (s & QS_PARTIAL) ? 1u : 0u, depth + 1)) return LS_DEFER;
-            qpool_keep(c, pl, id, h, k, qs_eds(s), (s & QS_PARTIAL) != 0, ch == 0);
+        /* ---- what goes (back) into the queue: a partial entry as it is now, a moved node, or two children */
+        const u32 o = two ? qd_xor(2, s) : s;
+        const u32 s0 = (two && ch) ? o : s, s1 = ch ? s : o;
+        if ((s0 | (two ? s1 : 0u)) & QS_DEFER) return LS_DEFER;
+        const u32 n_push = two ? 2u : 1u;
+        for (u32 j = 0; j < n_push; ++j) {
+            const u32 sj = j ? s1 : s0;
+            const u32 pid = part ? id : (two ? next_id + j : id);
+            const u32 pdepth = part ? depth : depth + 1;
+            const u32 pcode = part ? code : code | ((two ? (j ? 1u : 2u) : choice) << (2 * depth));
+            if (qq_pushA(c, q, qn, qs_cost(sj), pid, pcode, (sj & QS_PARTIAL) ? 1u : 0u, pdepth)) return LS_DEFER;
+            qpool_keep(c, pl, pid, h, k, qs_eds(sj), (sj & QS_PARTIAL) != 0, ch == j);
         }
+        if (two) next_id += 2;
+        AVK_QF(2, c, 4)
         if (next_id > c.max_nodes) return AVK_LDEFER(3);
     }
     if (nbest == 0) return -100 - AVK_ST_NO_RESULTS; /* :331 */
@@ -364,17 +425,18 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
     u32 types = 0;
     const u32 maxv = c.nm1 == 1 ? 1u : (c.nm1 == 3 ? 2u : 3u);
 #pragma unroll
-    for (u32 s = 0; s < NS; ++s) {
+    for (u32 s = 0; s < NS; ++s) { /* every slot the class's records have is loaded, whatever the header says: one round trip for the whole record */
         const u32 side = s / MV, j = s % MV;
         const bool on = j < (side ? c.Q : c.T);
         c.vw0[s] = c.vw1[s] = a1lo[s] = a1hi[s] = 0;
-        if (on) {
+        if (j < maxv) {
             const u32 *v = rec + (AVK_FAST_HDR + 4 * (side * maxv + j)) * lane_stride;
-            c.vw0[s] = v[0];
-            c.vw1[s] = v[1 * lane_stride];
-            a1lo[s] = v[2 * lane_stride];
-            a1hi[s] = v[3 * lane_stride];
-            types |= 1u << ((c.vw0[s] >> 24) & 0xFu);
+            const u32 x0 = v[0], x1 = v[1 * lane_stride], x2 = v[2 * lane_stride], x3 = v[3 * lane_stride];
+            c.vw0[s] = on ? x0 : 0u;
+            c.vw1[s] = on ? x1 : 0u;
+            a1lo[s] = on ? x2 : 0u;
+            a1hi[s] = on ? x3 : 0u;
+            types |= on ? 1u << ((x0 >> 24) & 0xFu) : 0u;
         }
     }
     {
@@ -393,24 +455,10 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
         }
         c.plain = plain;
     }
+    AVK_QF(1, c, 1)
     /* reference window: lane q writes the words k = q (mod 4) */
-    {
-        const u32 nw = (c.L + shift + 15u) >> 4;
-        bool exc = false;
-        for (u32 k = 0; k < nw; ++k) {
-            const u64 w = (u64)h0 + k;
-            exc = exc || ((a.ref_exc[w >> 5] >> (w & 31)) & 1u);
-        }
-        if (exc) return AVK_LDEFER(4);
-        for (u32 k = q; k < c.W1; k += 4) {
-            u32 word = 0;
-            if (k * 16 < c.L) {
-                const u32 lo = a.ref_2bit[(u64)h0 + k], hi = a.ref_2bit[(u64)h0 + k + 1];
-                word = (u32)((((u64)hi << 32) | lo) >> (2 * shift));
-            }
-            c.p[k << c.ls] = word;
-        }
-    }
+    if (!load_window<4>(a, c, h0, shift, q)) return AVK_LDEFER(4);
+    AVK_QF(1, c, 2)
     qd_sync();
     /* FULL(side, mask): the 2 nm1 sequences dealt out over the four lanes, lengths and failed distances ORed together afterwards */
     {
@@ -431,12 +479,15 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
         c.seq_fail_hi = qd_or64(c.seq_fail_hi);
     }
     qd_sync();
+    AVK_QF(1, c, 3)
+    AVK_LT_MARK(c, 0)
 
     /* ---- phase A: the lane's front is one of the four behind the queue and the kept states */
     const u32 off_dyn = c.off_q;
     c.off_wf = off_dyn + c.qcap + 2 * c.pool * c.wfr + q * c.wfr;
     u32 best_cost = 0;
     const int nopt = phaseA_quad(c, q, best_cost);
+    AVK_LT_MARK(c, 1)
     if (nopt == LS_DEFER) return LS_DEFER;
     if (nopt < 0) return -nopt - 100;
     out.n_opt = (u32)nopt;
@@ -512,6 +563,7 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
     }
     out.ed1 = w0.ed;
     out.ed2 = w1.ed;
+    AVK_LT_MARK(c, 2)
 
     /* ---- phase C: compare_expected_observed (:296-327) + per-call outputs (lane 0 writes) */
     u32 exp_pack = 0, obs_pack = 0;
@@ -569,6 +621,7 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
             X1 = 2u * ert1, Y1 = 2u * erq1, tp1 = (X1 + Y1 - 2u * w1.ed) / 2u;
         }
     }
+    AVK_LT_MARK(c, 3)
     /* Alignments of the per-type groups (:383-445), BEFORE anything is added to the tally: entry (hh, side, first call of the type on the side) by lane
      * (hh, side); a second haplotype with the alleles of the first reads the first one's entries */
     {
@@ -614,6 +667,7 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
         }
         if (qd_any(dfr)) return LS_DEFER; /* (also: every lane's entries are written before any lane reads them) */
     }
+    AVK_LT_MARK(c, 4)
     /* the groups: the joint one on every lane (its RECORD_BP check is the only way the region can still fail), the i-th group of the region added by lane i mod 4 */
     u32 *gm_out = a.group_metrics ? a.group_metrics + (u64)orig * AVK_N_GROUPS * AVK_N_FIELDS : (u32 *)0;
     if (gm_out) /* groups the region has nothing in: zeros (the others are written whole by the lane that adds them) */
@@ -719,6 +773,7 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
         }
     }
     (void)qcap_search;
+    AVK_LT_MARK(c, 5)
     return AVK_ST_OK;
 }
 
@@ -744,9 +799,14 @@ AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     c.max_nodes = la.max_nodes < 250u ? la.max_nodes : 250u;
     u32 n_ok = 0, n_err = 0, n_claims_done = 0;
     const u32 n_claims = la.n_tiles * parts;
-    (void)wave_id;
+#ifdef AVK_LANE_PHASE_TIMING
+    for (int j = 0; j < 8; ++j) c.tph[j] = 0;
+#endif
     for (;;) {
         u32 t = 0;
+#ifdef AVK_LANE_PHASE_TIMING
+        const u64 t_tile0 = avk_clock();
+#endif
         if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
         t = wv_uni(wv_shfl(t, 0));
         if (t >= n_claims) break;
@@ -773,7 +833,13 @@ AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
         c.off_q = off_dyn;
         c.qcap = la.qcap;
         c.wfcap_c = 0;
+#ifdef AVK_LANE_PHASE_TIMING
+        c.tlast = avk_clock();
+#endif
         const int st = solve_quad(a, c, q, rec, 64u, dyn_rows, la.max_ed_c, out, wg_tally);
+#ifdef AVK_LANE_PHASE_TIMING
+        c.tph[6] += avk_clock() - t_tile0;
+#endif
         if (q != 0) continue; /* lane 0 of the quad reports */
         if (st == LS_DEFER) { /* hand over to the wave-per-region kernels */
             const u32 slot_o = avk_atomic_add_u32_global(a.overflow_count, 1u);
@@ -806,6 +872,15 @@ AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
             *dst = v;
         }
     }
+#ifdef AVK_LANE_PHASE_TIMING
+    if (q == 0 && rq < width && (la.nm > 4 || la.nm == 4)) { /* the launches that end a step: the three-call class, the head of the two-call class */
+        u64 *pc = a.tally + (u64)(wave_id % AVK_TALLY_COPIES) * AVK_TALLY_STRIDE + AVK_TALLY_LEN + 5 + (la.nm > 4 ? 0 : 8);
+        for (int j = 0; j < 7; ++j) avk_atomic_add_u64_global(pc + j, c.tph[j]);
+        avk_atomic_add_u64_global(pc + 7, 1);
+    }
+#else
+    (void)wave_id;
+#endif
     n_ok_out = n_ok;
     n_err_out = n_err;
 }

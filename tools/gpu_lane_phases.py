@@ -11,6 +11,10 @@ scale = float(sys.argv[1]) if len(sys.argv) > 1 else 1.0
 contigs, batch = synth.config_genome(scale=scale)
 ctx = aardvark_amd.Context(0)
 ctx.set_option("emit_group_metrics", 0)
+for kv in os.environ.get("AVK_OPTS", "").split(","):  # context options by name, e.g. AVK_OPTS=lane_quad=0
+    if "=" in kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+        print("option", kv)
 ctx.upload_reference(contigs)
 rb = ctx.upload(batch)
 cfg = CompareConfig(enable_sequences=False)
