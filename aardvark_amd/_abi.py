@@ -347,6 +347,27 @@ class PackedBatch:
     def nbytes(self):
         return sum(getattr(self, f).nbytes for f in self.FIELDS if getattr(self, f) is not None)
 
+    def split(self, n_parts):
+        """the batch as `n_parts` batches of consecutive regions (cut at contig boundaries where there are enough contigs): a job handed over piece by piece"""
+        n = self.n_regions
+        cuts = [n * i // n_parts for i in range(n_parts + 1)]
+        if self.contig_idx is not None and n:
+            starts = np.flatnonzero(np.diff(self.contig_idx.astype(np.int64)) != 0) + 1
+            if starts.size + 1 >= n_parts:
+                for i in range(1, n_parts):
+                    cuts[i] = int(starts[np.argmin(np.abs(starts - cuts[i]))])
+        cuts = sorted(set(cuts))
+        voff = np.concatenate([[0], np.cumsum(self.t_cnt.astype(np.int64) + self.q_cnt)])
+        aoff = np.concatenate([[0], np.cumsum(self.a0_len.astype(np.int64) + self.a1_len)])
+        parts = []
+        for r0, r1 in zip(cuts[:-1], cuts[1:]):
+            v0, v1 = int(voff[r0]), int(voff[r1])
+            a0, a1 = int(aoff[v0]), int(aoff[v1])
+            cut = {"contig_idx": (r0, r1), "start": (r0, r1), "len": (r0, r1), "t_cnt": (r0, r1), "q_cnt": (r0, r1), "var_rel_pos": (v0, v1), "var_type_zyg": (v0, v1),
+                   "a0_len": (v0, v1), "a1_len": (v0, v1), "var_raw_space": (v0, v1), "allele_bytes": (a0, a1)}
+            parts.append(PackedBatch(**{f: (None if getattr(self, f) is None else getattr(self, f)[cut[f][0]:cut[f][1]]) for f in self.FIELDS}))
+        return parts
+
     def c_struct(self):
         b = AvkPackedBatch()
         b.n_regions, b.n_variants = self.n_regions, self.n_variants

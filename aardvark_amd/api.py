@@ -59,6 +59,8 @@ def load_library():
     lib.avk_compare_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
     lib.avk_batch_upload_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(vp)]
     lib.avk_compare_packed.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
+    lib.avk_compare_packed_submit.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch), C.POINTER(vp)]
+    lib.avk_wait.argtypes = [vp, vp]
     lib.avk_batch_upload_packed.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(vp)]
     lib.avk_compare_resident.argtypes = [vp, vp, C.POINTER(AvkCompareConfig), vp]
     lib.avk_results_download.argtypes = [vp, vp, C.POINTER(AvkResultBatch)]
@@ -146,6 +148,21 @@ class _ContextCore:
             self.handle = C.c_void_p()
 
 
+class Ticket:
+    """a batch in flight (Context.submit_packed); wait() returns its ResultBatch, once"""
+
+    def __init__(self, ctx, handle, res, keep):
+        self.ctx, self.handle, self.res, self._keep = ctx, handle, res, keep
+
+    def wait(self):
+        if self.handle is None:
+            raise RuntimeError("the ticket has been waited for")
+        h, self.handle = self.handle, None
+        self.ctx._check(self.ctx.lib.avk_wait(self.ctx.handle, h))
+        self._keep = None
+        return self.res
+
+
 class Context:
     """One GPU context (avk_ctx): owns the uploaded reference genome and the workspaces."""
 
@@ -213,6 +230,16 @@ class Context:
         pb, cfg, ro = pbatch.c_struct(), config.c_struct(), res.c_struct()
         self._check(self.lib.avk_compare_packed(self.handle, C.byref(pb), C.byref(cfg), C.byref(ro)))
         return res
+
+    def submit_packed(self, pbatch, config=None, res=None):
+        """avk_compare_packed_submit: the batch is queued (its copies run beside the kernels of the batch submitted before) -> a Ticket; Ticket.wait() -> ResultBatch.
+        `pbatch` and `res` must live in pinned memory (pinned_packed / pinned_results) for the copies to overlap anything; at most four tickets are in flight."""
+        config = config or CompareConfig(enable_sequences=False)
+        res = res if res is not None else ResultBatch(pbatch, sequences=False, group_metrics=False)
+        pb, cfg, ro = pbatch.c_struct(), config.c_struct(), res.c_struct()
+        handle = C.c_void_p()
+        self._check(self.lib.avk_compare_packed_submit(self.handle, C.byref(pb), C.byref(cfg), C.byref(ro), C.byref(handle)))
+        return Ticket(self, handle, res, (pbatch, pb, ro))
 
     def solve_compact(self, cbatch, config=None, res=None):
         """avk_compare_compact: solve_compare_region for every region of a batch in the compact form -> ResultBatch (indexed like the compact arrays)"""

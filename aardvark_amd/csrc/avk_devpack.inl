@@ -788,7 +788,12 @@ AVK_DEV void dp_fast_record(const DpArgs &a, u32 fc, u32 tile_in_class, u32 lane
             V[0] = V[64] = V[128] = V[192] = 0;
             continue;
         }
-        const avk_u4 sl = *(const avk_u4 *)&a.slots[(u64)(side ? ri.q_first : ri.t_first) + j]; /* written by dp_region */
+        avk_u4 sl = *(const avk_u4 *)&a.slots[(u64)(side ? ri.q_first : ri.t_first) + j]; /* written by dp_region */
+        if (a.in.owned) { /* a form with explicit offsets: two regions with different starts may share this call, and the slot holds the position relative to whichever
+                             of them wrote last — this region's own comes from the caller's arrays (the packed forms own their calls by construction) */
+            const u64 v = (u64)(side ? ri.q_first : ri.t_first) + j;
+            sl.x = (sl.x & ~0xFFu) | ((u32)(a.in.var_pos[v] - a.in.start[r]) & 0xFFu);
+        }
         slot_pos[sidx] = sl.x & 0xFFu;
         V[0] = sl.x, V[64] = sl.y, V[128] = sl.z, V[192] = sl.w;
     }

@@ -732,11 +732,20 @@ static void release_pooled(avk_ctx *ctx, avk_dev_batch *db) {
     db->pooled.clear();
 }
 
+/* the arrays of an avk_packed_batch already in device memory (a staging slot of avk_compare_packed_submit, filled on the context's copy stream): nothing is copied,
+ * the context's stream waits for `ready`; the block stays with the caller (the allele bytes and raw spaces are read until the batch's solve is over) */
+struct PackedOnDevice {
+    uint8_t *t_cnt, *q_cnt, *a0_len, *a1_len, *var_type_zyg, *alleles;
+    uint32_t *start, *raw;
+    uint16_t *len, *contig, *rel_pos;
+    hipEvent_t ready;
+};
+
 /* b: the batch in the wide form, or NULL and cb: the batch in the compact form (avk_compact_batch: half the bytes over PCIe, widened on the device) */
 /* mb: a batch of MultiRegions (the merge path): one region per input pair is made on the device (dp_expand_pairs) */
 /* (pm: the packed form of a multi batch; `mb` then only carries n_regions, n_inputs, n_variants, allele_bytes and allele_bytes_len) */
 static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const avk_compact_batch *cb, bool pairs_mode, avk_dev_batch **out, const avk_multi_batch *mb = nullptr,
-                                const avk_packed_batch *pk = nullptr, const avk_packed_multi_batch *pm = nullptr) {
+                                const avk_packed_batch *pk = nullptr, const avk_packed_multi_batch *pm = nullptr, const PackedOnDevice *pre = nullptr) {
     const uint32_t mk = mb ? mb->n_inputs : 0, mppr = mk * (mk - (mk ? 1u : 0u)) / 2;
     const uint64_t n = pk ? pk->n_regions : (b ? b->n_regions : (cb ? cb->n_regions : mb->n_regions * mppr)), nv = pk ? pk->n_variants : (b ? b->n_variants : (cb ? cb->n_variants : mb->n_variants)),
                    alen = pk ? pk->allele_bytes_len : (b ? b->allele_bytes_len : (cb ? cb->allele_bytes_len : mb->allele_bytes_len));
@@ -759,7 +768,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](std::chrono::steady_clock::time_point x, std::chrono::steady_clock::time_point y) { return std::chrono::duration<double, std::milli>(y - x).count(); };
     const auto t_start = now();
-    hipStream_t s = ctx->stream;
+    hipStream_t s = ctx->up_stream ? ctx->up_stream : ctx->stream; /* (the asynchronous boundary packs on a stream of its own, beside the solve of the batch before) */
     uint64_t *pk_totals = nullptr; /* packed form: device words {sum of the call counts, sum of the allele lengths} */
     avk_dev_batch *db = new avk_dev_batch();
     db->dev_packed = true;
@@ -781,7 +790,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     };
     auto bail = [&](int code) {
         (void)hipStreamSynchronize(s);
-        (void)hipStreamSynchronize(ctx->lane_stream4); /* (the side stream of the upload: prefix sums, widening, the cleared scratch) */
+        (void)hipStreamSynchronize((ctx->up_side ? ctx->up_side : ctx->lane_stream4)); /* (the side stream of the upload: prefix sums, widening, the cleared scratch) */
         for (void *p : temps) pool_release(ctx, p);
         release_pooled(ctx, db);
         delete db;
@@ -798,8 +807,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     uint32_t *d_contig = has_contig ? (uint32_t *)tmp_or_kept((n + 1) * 4) : nullptr;
     uint64_t *d_pos = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a0o = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a1o = (uint64_t *)tmp_or_kept((nv + 1) * 8);
     uint32_t *d_a0l = (uint32_t *)tmp_or_kept((nv + 1) * 4), *d_a1l = (uint32_t *)tmp_or_kept((nv + 1) * 4);
-    uint32_t *d_raw = has_raw ? (uint32_t *)tmp_or_kept((nv + 1) * 4) : nullptr;
-    uint8_t *d_type = (uint8_t *)tmp_or_kept(nv + 16), *d_zyg = (uint8_t *)tmp_or_kept(nv + 16), *d_alleles = (uint8_t *)tmp_or_kept(alen + 16);
+    uint32_t *d_raw = has_raw ? (pre ? pre->raw : (uint32_t *)tmp_or_kept((nv + 1) * 4)) : nullptr;
+    uint8_t *d_type = (uint8_t *)tmp_or_kept(nv + 16), *d_zyg = (uint8_t *)tmp_or_kept(nv + 16), *d_alleles = pre ? pre->alleles : (uint8_t *)tmp_or_kept(alen + 16);
     /* intermediates */
     const uint32_t n_blocks = (uint32_t)((n + 255) / 256);
     a.vinfo = (dpk::DpVarInfo *)kept((nv + 1) * sizeof(dpk::DpVarInfo));
@@ -836,9 +845,11 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     };
     mark(0);
     if (pk) { /* the packed arrays as they are, two prefix sums for the offsets they leave out, one kernel that writes the wide arrays */
-        uint16_t *p_contig = has_contig ? (uint16_t *)tmp((n + 1) * 2) : nullptr, *p_len = (uint16_t *)tmp((n + 1) * 2), *p_rel = (uint16_t *)tmp((nv + 1) * 2);
-        uint32_t *p_start = (uint32_t *)tmp((n + 1) * 4);
-        uint8_t *p_tc = (uint8_t *)tmp(n + 16), *p_qc = (uint8_t *)tmp(n + 16), *p_tz = (uint8_t *)tmp(nv + 16), *p_a0 = (uint8_t *)tmp(nv + 16), *p_a1 = (uint8_t *)tmp(nv + 16);
+        uint16_t *p_contig = has_contig ? (pre ? pre->contig : (uint16_t *)tmp((n + 1) * 2)) : nullptr, *p_len = pre ? pre->len : (uint16_t *)tmp((n + 1) * 2),
+                 *p_rel = pre ? pre->rel_pos : (uint16_t *)tmp((nv + 1) * 2);
+        uint32_t *p_start = pre ? pre->start : (uint32_t *)tmp((n + 1) * 4);
+        uint8_t *p_tc = pre ? pre->t_cnt : (uint8_t *)tmp(n + 16), *p_qc = pre ? pre->q_cnt : (uint8_t *)tmp(n + 16), *p_tz = pre ? pre->var_type_zyg : (uint8_t *)tmp(nv + 16),
+                *p_a0 = pre ? pre->a0_len : (uint8_t *)tmp(nv + 16), *p_a1 = pre ? pre->a1_len : (uint8_t *)tmp(nv + 16);
         const uint32_t nb_r = (uint32_t)((n + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK), nb_v = (uint32_t)((nv + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK);
         uint64_t *p_voff = (uint64_t *)tmp((n + 1) * 8), *p_aoff = (uint64_t *)tmp((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
         if (rc) return bail(rc);
@@ -846,11 +857,17 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
          * allele bytes) run on a stream of their own beside the copies that follow: dp_variant, the first kernel that needs every byte, starts 0.24 ms earlier.
          * (The copies themselves stay on ONE stream: a large copy queued on a second stream now and then blocks the host for 7 to 9 ms inside hipMemcpyAsync —
          * the runtime bringing up another copy engine — which made one call in fifty 16 ms long.) */
-        hipStream_t side = ctx->lane_stream4;
+        hipStream_t side = (ctx->up_side ? ctx->up_side : ctx->lane_stream4);
         auto side_fail = [&](int code) { /* nothing of this call may still be in flight on the side stream when its buffers go back */
             (void)hipStreamSynchronize(side);
             return bail(code);
         };
+        if (pre) { /* the arrays are in a staging slot already (or on their way there on the copy stream) */
+            hipError_t ep = hipStreamWaitEvent(s, pre->ready, 0);
+            if (ep == hipSuccess) ep = hipEventRecord(ctx->ev_copy_fork, s);
+            if (ep == hipSuccess) ep = hipEventRecord(ctx->ev_copy_mid, s);
+            if (ep != hipSuccess) rc = fail(ctx, AVK_E_HIP, "packed upload: %s", hipGetErrorString(ep));
+        } else
         rc = copy_in(ctx, {{pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv, nullptr, ctx->ev_copy_fork}, {pk->start, p_start, n * 4},
                            {pk->len, p_len, n * 2}, {pk->contig_idx, p_contig, has_contig ? n * 2 : 0}, {pk->var_rel_pos, p_rel, nv * 2}, {pk->var_type_zyg, p_tz, nv, nullptr, ctx->ev_copy_mid},
                            {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {pk->allele_bytes, d_alleles, alen}});
@@ -910,7 +927,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             const uint32_t nb_r = (uint32_t)((ni + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK), nb_v = (uint32_t)((nv + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK);
             uint64_t *p_aoff = (uint64_t *)tmp((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
             if (rc) return bail(rc);
-            hipStream_t side = ctx->lane_stream4; /* as for avk_packed_batch: copies on the context's stream, counts first; prefix sums and widening beside them */
+            hipStream_t side = (ctx->up_side ? ctx->up_side : ctx->lane_stream4); /* as for avk_packed_batch: copies on the context's stream, counts first; prefix sums and widening beside them */
             auto side_fail = [&](int code) {
                 (void)hipStreamSynchronize(side);
                 return bail(code);
@@ -1158,7 +1175,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     db->dp_args = a;
     const bool clear_beside = n >= 262144; /* (a small batch: the two events between the streams cost more than the fills, 1.16 instead of 0.98 ms per 46,000-region call) */
     if (clear_beside) { /* the batch's partial tallies and counters are cleared beside the writers, on a side stream (in front of the solver launches the two fills took 55 us) */
-        hipStream_t side = ctx->lane_stream4;
+        hipStream_t side = (ctx->up_side ? ctx->up_side : ctx->lane_stream4);
         hipError_t ez = hipEventRecord(ctx->ev_copy_fork, s); /* the buffers may have been another batch's until here */
         if (ez == hipSuccess) ez = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0);
         if (ez == hipSuccess && db->d_dp_args) ez = hipMemcpyAsync(db->d_dp_args, &db->dp_args, sizeof(dpk::DpArgs), hipMemcpyHostToDevice, side); /* (behind the writers it was
@@ -1188,11 +1205,15 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     e = hipGetLastError();
     if (e == hipSuccess && clear_beside) e = hipStreamWaitEvent(s, ctx->ev_copy_join, 0); /* the cleared scratch, before anything that follows on this stream */
     if (e != hipSuccess) {
-        (void)hipStreamSynchronize(ctx->lane_stream4);
+        (void)hipStreamSynchronize((ctx->up_side ? ctx->up_side : ctx->lane_stream4));
         return bail(fail(ctx, AVK_E_HIP, "device packing failed: %s", hipGetErrorString(e)));
     }
     mark(3);
     for (void *p : temps) pool_release(ctx, p); /* in stream order: the writers above run before anything that is handed these buffers next */
+    if (!ctx->up_stream && ctx->ev_pool_fence) { /* ... which an upload on the packing stream of the asynchronous boundary is not, by itself: it waits for this point once */
+        if (hipEventRecord(ctx->ev_pool_fence, s) == hipSuccess) ctx->pool_fence_pending = true;
+        else (void)hipGetLastError();
+    }
     if (timing)
         fprintf(stderr, "avk upload (device-packed): %llu regions, %llu calls: buffers %.3f ms, copies queued %.3f ms, packing kernels + plan %.3f ms, writers queued %.3f ms; lanes %u regions in %u tiles, class C %u, class B %u\n",
                 (unsigned long long)n, (unsigned long long)nv, ms(t_start, t_alloc), ms(t_alloc, t_copy), ms(t_copy, t_plan), ms(t_plan, now()), hs->n_fast_total, tiles_total,
@@ -1202,7 +1223,15 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
 }
 
 /* ---- download of a device-packed batch: dp_unpack on the device, then plain copies into the caller's arrays ------------------------- */
-static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out, uint8_t *pair_exact, uint64_t *tally_words /* [AVK_TALLY_STRIDE] */) {
+/* `later` (avk_compare_packed_submit): the copies out go on the context's copy-out stream behind `later->ev_unpacked`, the tally into `later->h_tally`, nothing is
+ * waited for and the device buffers of the caller's layout stay in `later->temps` until avk_wait has seen `later->ev_done` (every destination must be pinned) */
+struct DownloadLater {
+    std::vector<void *> temps;
+    uint64_t *h_tally;
+    hipEvent_t ev_unpacked, ev_done;
+};
+static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out, uint8_t *pair_exact, uint64_t *tally_words /* [AVK_TALLY_STRIDE] */,
+                                  DownloadLater *later = nullptr) {
     const uint64_t n = db->n_regions, nv = db->n_variants_host;
     hipStream_t s = ctx->stream;
     std::vector<void *> temps;
@@ -1273,6 +1302,21 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {
         segs.push_back({out->bp_off, db->d_bp_off, (n + 1) * sizeof(uint32_t)});
         segs.push_back({out->bp_groups, db->d_bp, (size_t)db->n_bp_groups * 4 * sizeof(uint32_t)});
+    }
+    if (later) { /* queued on the copy-out stream, finished by avk_wait */
+        hipStream_t so = ctx->copy_out_stream;
+        hipError_t el = hipEventRecord(later->ev_unpacked, s);
+        if (el == hipSuccess) el = hipStreamWaitEvent(so, later->ev_unpacked, 0);
+        for (const CopySeg &sg : segs)
+            if (el == hipSuccess && sg.bytes && sg.host) el = hipMemcpyAsync((void *)sg.host, sg.dev, sg.bytes, hipMemcpyDeviceToHost, so);
+        if (el == hipSuccess) el = hipMemcpyAsync(later->h_tally, db->d_tally, (size_t)AVK_TALLY_STRIDE * 8, hipMemcpyDeviceToHost, so);
+        if (el == hipSuccess) el = hipEventRecord(later->ev_done, so);
+        if (el != hipSuccess) {
+            (void)hipStreamSynchronize(so);
+            return done(fail(ctx, AVK_E_HIP, "queueing the results' copies failed: %s", hipGetErrorString(el)));
+        }
+        later->temps.swap(temps);
+        return 0;
     }
     CopyOut co;
     rc = copy_out(ctx, segs, &co);

@@ -310,6 +310,21 @@ struct avk_ctx {
     uint8_t *h_bounce = nullptr; /* pinned staging for caller arrays that are not pinned (grow-only) */
     size_t bounce_bytes = 0;
     void *h_dpstate = nullptr;   /* pinned: the packer's state block / the tally of a download */
+    /* the asynchronous boundary (avk_compare_packed_submit / avk_wait): a copy stream each way and a ring of staging slots OUTSIDE the stream-ordered pool — the
+     * packed arrays of batch k + 1 cross the bus while batch k is being solved, the results of batch k while batch k + 1 is being packed */
+    hipStream_t copy_in_stream = nullptr, copy_out_stream = nullptr;
+    hipStream_t pack_stream = nullptr, pack_side_stream = nullptr; /* the packing kernels of a submitted batch, beside the solver launches of the batch before */
+    hipStream_t up_stream = nullptr, up_side = nullptr;            /* set while avk_compare_packed_submit runs upload_device_packed */
+    hipEvent_t ev_packed = nullptr, ev_pool_fence = nullptr;
+    bool pool_fence_pending = false; /* buffers went back to the pool in the order of the context's stream since the packing stream last waited for it */
+    int64_t async_pack_stream = 1;                                 /* option: 0 = a submitted batch is packed on the context's stream, behind the solve of the batch before */
+    struct StageSlot {
+        uint8_t *dev = nullptr; /* one device block for the eleven arrays of an avk_packed_batch */
+        size_t bytes = 0;
+        uint64_t *h_tally = nullptr; /* pinned: the batch's tally lands here */
+        hipEvent_t ev_in = nullptr, ev_unpacked = nullptr, ev_done = nullptr;
+        bool busy = false;
+    } stage[4];
     /* options */
     int64_t lds_bytes_per_wave = 10 * 1024;
     int64_t lds_ed_cap = 48;
@@ -621,6 +636,19 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto &sl : ctx->stage) { /* staging slots of the asynchronous boundary */
+        if (sl.dev) (void)hipFree(sl.dev);
+        if (sl.h_tally) (void)hipHostFree(sl.h_tally);
+        if (sl.ev_in) (void)hipEventDestroy(sl.ev_in);
+        if (sl.ev_unpacked) (void)hipEventDestroy(sl.ev_unpacked);
+        if (sl.ev_done) (void)hipEventDestroy(sl.ev_done);
+    }
+    if (ctx->pack_stream) (void)hipStreamDestroy(ctx->pack_stream);
+    if (ctx->pack_side_stream) (void)hipStreamDestroy(ctx->pack_side_stream);
+    if (ctx->ev_packed) (void)hipEventDestroy(ctx->ev_packed);
+    if (ctx->ev_pool_fence) (void)hipEventDestroy(ctx->ev_pool_fence);
+    if (ctx->copy_in_stream) (void)hipStreamDestroy(ctx->copy_in_stream);
+    if (ctx->copy_out_stream) (void)hipStreamDestroy(ctx->copy_out_stream);
     pool_destroy(ctx);
     if (ctx->d_contig_tab) (void)hipFree(ctx->d_contig_tab);
     if (ctx->d_ref) (void)hipFree(ctx->d_ref);
@@ -836,6 +864,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
+    } else if (n == "async_pack_stream") {
+        ctx->async_pack_stream = value ? 1 : 0;
     } else if (n == "lane_quad") {
         ctx->lane_quad = value ? 1 : 0;
     } else if (n == "lane_pool") {
@@ -2197,13 +2227,19 @@ static int rerun_capacity_regions(avk_ctx *ctx, avk_dev_batch *db, const std::ve
     return rc;
 }
 
-int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out) {
+} /* extern "C" */
+/* avk_results_download in one piece (later == NULL), or in the two pieces of the asynchronous boundary: everything up to the queued copies (later given, tally_ready
+ * NULL), and everything behind them — the tally, the statistics, the capacity retry — once the copies have arrived (tally_ready = the batch's tally words) */
+static int results_download_impl(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out, DownloadLater *later, const uint64_t *tally_ready) {
     if (!ctx || !db || !out || !(out->status || out->region_packed)) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
     const uint64_t n = db->n_regions, nv = db->n_variants_dev;
     const bool timing = getenv("AVK_TIMING") != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
     std::vector<uint64_t> tally((size_t)AVK_TALLY_STRIDE);
+    if (tally_ready) memcpy(tally.data(), tally_ready, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t));
+    if (later && !(db->dev_packed && db->var_dense && !(out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq)))
+        return fail(ctx, AVK_E_STATE, "results can only be queued for a device-packed batch that owns all its calls, without sequence outputs");
     hipStream_t s = ctx->stream;
     const bool want_seq = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && db->d_seq;
     std::vector<uint8_t> seq;
@@ -2234,9 +2270,11 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
         if (out->var_packed) out->var_packed[hv] = avk_vp_make(ea, oa, zyg);
     };
     auto status_of = [&](uint64_t r) -> int32_t { return out->status ? out->status[r] : avk_rp_status(out->region_packed[r]); };
-    if (db->dev_packed) { /* the caller's layout is made on the device (dp_unpack); the copies land in the caller's arrays */
-        const int rc = download_device_packed(ctx, db, out, nullptr, tally.data());
-        if (rc) return rc;
+    if (tally_ready) { /* the copies were queued earlier and have arrived */
+        t_copied = std::chrono::steady_clock::now();
+    } else if (db->dev_packed) { /* the caller's layout is made on the device (dp_unpack); the copies land in the caller's arrays */
+        const int rc = download_device_packed(ctx, db, out, nullptr, tally.data(), later);
+        if (rc || later) return rc;
         t_copied = std::chrono::steady_clock::now();
         if (want_seq) {
             const int rv = materialize_host_view(ctx, db);
@@ -2369,9 +2407,215 @@ int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out)
     return 0;
 }
 
-} /* extern "C" */
-
 extern "C" {
+
+int avk_results_download(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out) { return results_download_impl(ctx, db, out, nullptr, nullptr); }
+
+/* ---- the asynchronous boundary: one context, batches in flight -------------------------------------------------------------------------------
+ * The reference streams its regions through a rayon loop and collects at the end (src/main.rs:251-268); a caller with several batches gets the same here:
+ * avk_compare_packed_submit returns when batch k is QUEUED — its arrays crossed (or are crossing) the bus on the context's copy-in stream while batch k - 1 was
+ * being solved, its results will cross on the copy-out stream while batch k + 1 is packed — and avk_wait(ticket) returns when the results are in the caller's
+ * arrays.  The call blocks once in the middle (the packer's plan comes back to the host), which is where it waits for the batch before it. */
+struct avk_ticket {
+    int slot = -1;          /* staging slot, -1: the batch was solved synchronously at submit (pageable arrays) */
+    int rc = 0;
+    avk_dev_batch *db = nullptr;
+    avk_result_batch out;
+    DownloadLater later;
+    int64_t keep_gm = 0, keep_bp = 0;
+};
+
+static int stage_slot_prepare(avk_ctx *ctx, avk_ctx::StageSlot &sl, size_t bytes) {
+    if (!ctx->copy_in_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in_stream, hipStreamNonBlocking));
+    if (!ctx->copy_out_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out_stream, hipStreamNonBlocking));
+    if (!ctx->pack_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->pack_stream, hipStreamNonBlocking));
+    if (!ctx->pack_side_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->pack_side_stream, hipStreamNonBlocking));
+    if (!ctx->ev_packed) AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_packed, hipEventDisableTiming));
+    if (!ctx->ev_pool_fence) AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pool_fence, hipEventDisableTiming));
+    if (!sl.ev_in) {
+        AVK_HIP(ctx, hipEventCreateWithFlags(&sl.ev_in, hipEventDisableTiming));
+        AVK_HIP(ctx, hipEventCreateWithFlags(&sl.ev_unpacked, hipEventDisableTiming));
+        AVK_HIP(ctx, hipEventCreateWithFlags(&sl.ev_done, hipEventDisableTiming));
+        AVK_HIP(ctx, hipHostMalloc((void **)&sl.h_tally, (size_t)AVK_TALLY_STRIDE * sizeof(uint64_t), hipHostMallocDefault));
+    }
+    if (sl.bytes < bytes) {
+        if (sl.dev) AVK_HIP(ctx, hipFree(sl.dev)); /* (the slot is free: nothing of an earlier batch reads it) */
+        sl.dev = nullptr, sl.bytes = 0;
+        const size_t want = bytes + bytes / 8 + (1u << 20);
+        hipError_t e = hipMalloc((void **)&sl.dev, want);
+        if (e != hipSuccess) return fail(ctx, e == hipErrorOutOfMemory ? AVK_E_OOM : AVK_E_HIP, "staging slot of %zu bytes: %s", want, hipGetErrorString(e));
+        sl.bytes = want;
+    }
+    return 0;
+}
+
+/* the eleven arrays of `batch` into a staging slot: the slot is (re)sized and the copies are queued on the copy-in stream, counts and lengths first as in
+ * avk_compare_packed — nothing of this context reads or writes the slot */
+static int stage_layout(avk_ctx *ctx, avk_ctx::StageSlot &sl, const avk_packed_batch *batch, PackedOnDevice *pre) {
+    const uint64_t n = batch->n_regions, nv = batch->n_variants, alen = batch->allele_bytes_len;
+    const bool has_contig = batch->contig_idx != nullptr, has_raw = batch->var_raw_space != nullptr;
+    auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t need = 2 * up(n + 16) + 3 * up(nv + 16) + up(n * 4 + 16) + 2 * up(n * 2 + 16) + up(nv * 2 + 16) + up(nv * 4 + 16) + up(alen + 16);
+    {
+        const int rc = stage_slot_prepare(ctx, sl, need);
+        if (rc) return rc;
+    }
+    memset(pre, 0, sizeof(*pre));
+    uint8_t *q = sl.dev;
+    auto take = [&](size_t bytes) {
+        uint8_t *r = q;
+        q += up(bytes + 16);
+        return r;
+    };
+    pre->t_cnt = take(n), pre->q_cnt = take(n), pre->a0_len = take(nv), pre->a1_len = take(nv), pre->start = (uint32_t *)take(n * 4), pre->len = (uint16_t *)take(n * 2);
+    pre->contig = (uint16_t *)take(n * 2), pre->rel_pos = (uint16_t *)take(nv * 2), pre->var_type_zyg = take(nv), pre->raw = (uint32_t *)take(nv * 4), pre->alleles = take(alen);
+    pre->ready = sl.ev_in;
+    const struct { const void *src; void *dst; size_t bytes; } cp[] = {
+        {batch->t_cnt, pre->t_cnt, n}, {batch->q_cnt, pre->q_cnt, n}, {batch->a0_len, pre->a0_len, nv}, {batch->a1_len, pre->a1_len, nv}, {batch->start, pre->start, n * 4},
+        {batch->len, pre->len, n * 2}, {batch->contig_idx, pre->contig, has_contig ? n * 2 : 0}, {batch->var_rel_pos, pre->rel_pos, nv * 2}, {batch->var_type_zyg, pre->var_type_zyg, nv},
+        {batch->var_raw_space, pre->raw, has_raw ? nv * 4 : 0}, {batch->allele_bytes, pre->alleles, alen}};
+    hipError_t e = hipSuccess;
+    for (const auto &c : cp)
+        if (e == hipSuccess && c.bytes && c.src) e = hipMemcpyAsync(c.dst, c.src, c.bytes, hipMemcpyHostToDevice, ctx->copy_in_stream);
+    if (e == hipSuccess) e = hipEventRecord(sl.ev_in, ctx->copy_in_stream);
+    if (e != hipSuccess) {
+        (void)hipStreamSynchronize(ctx->copy_in_stream);
+        return fail(ctx, AVK_E_HIP, "queueing the batch's copies failed: %s", hipGetErrorString(e));
+    }
+    return 0;
+}
+static bool packed_inputs_pinned(const avk_packed_batch *batch) {
+    const uint64_t n = batch->n_regions, nv = batch->n_variants, alen = batch->allele_bytes_len;
+    return is_pinned(batch->t_cnt, n) && is_pinned(batch->q_cnt, n) && is_pinned(batch->a0_len, nv) && is_pinned(batch->a1_len, nv) && is_pinned(batch->start, n * 4) &&
+           is_pinned(batch->len, n * 2) && is_pinned(batch->contig_idx, n * 2) && is_pinned(batch->var_rel_pos, nv * 2) && is_pinned(batch->var_type_zyg, nv) &&
+           is_pinned(batch->var_raw_space, nv * 4) && is_pinned(batch->allele_bytes, alen);
+}
+
+int avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket) {
+    if (!ctx || !batch || !cfg || !out || !ticket || !(out->status || out->region_packed)) return AVK_E_ARG;
+    *ticket = nullptr;
+    if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    const uint64_t n = batch->n_regions, nv = batch->n_variants;
+    if (n && (!batch->start || !batch->len || !batch->t_cnt || !batch->q_cnt)) return fail(ctx, AVK_E_ARG, "region arrays missing");
+    if (nv && (!batch->var_rel_pos || !batch->var_type_zyg || !batch->a0_len || !batch->a1_len || !batch->allele_bytes)) return fail(ctx, AVK_E_ARG, "variant arrays missing");
+    const bool timing = getenv("AVK_TIMING") != nullptr;
+    static const auto t_epoch = std::chrono::steady_clock::now();
+    auto now_ms = [&] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_epoch).count(); };
+    const double ts0 = now_ms();
+    avk_ticket *t = new avk_ticket();
+    t->out = *out;
+    /* arrays that are not pinned cannot be copied behind the caller's back: such a batch is solved here and now, its ticket is complete */
+    bool pinned = packed_inputs_pinned(batch);
+    pinned = pinned && is_pinned(out->status, n * 4) && is_pinned(out->region_packed, n * 8) && is_pinned(out->ed_h1, n * 4) && is_pinned(out->ed_h2, n * 4) && is_pinned(out->n_optima, n * 4) &&
+             is_pinned(out->type_present, n * 2) && is_pinned(out->var_expected, nv) && is_pinned(out->var_observed, nv) && is_pinned(out->var_class, nv) && is_pinned(out->var_zyg, nv) &&
+             is_pinned(out->var_packed, nv) && is_pinned(out->group_metrics, n * AVK_N_GROUPS * AVK_N_FIELDS * 4);
+    const bool seq_out = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && cfg->enable_sequences;
+    int slot = -1;
+    const bool can_queue = pinned && !seq_out && !(out->bp_off && out->bp_groups);
+    for (int i = 0; i < 4 && slot < 0 && can_queue; ++i)
+        if (!ctx->stage[i].busy) {
+            slot = i;
+            break;
+        }
+    if (slot < 0) {
+        bool any_free = false;
+        for (int i = 0; i < 4; ++i) any_free = any_free || !ctx->stage[i].busy;
+        if (!any_free) {
+            delete t;
+            return fail(ctx, AVK_E_STATE, "four batches are in flight: avk_wait for one of them first");
+        }
+        t->rc = avk_compare_packed(ctx, batch, cfg, out);
+        *ticket = t;
+        return t->rc;
+    }
+    avk_ctx::StageSlot &sl = ctx->stage[slot];
+    PackedOnDevice pre;
+    int rc = stage_layout(ctx, sl, batch, &pre);
+    if (rc) {
+        delete t;
+        return rc;
+    }
+    const double ts1 = now_ms();
+    sl.busy = true;
+    t->slot = slot;
+    t->keep_gm = ctx->emit_group_metrics, t->keep_bp = ctx->emit_bp_groups;
+    if (!out->group_metrics) ctx->emit_group_metrics = 0;
+    t->later.h_tally = sl.h_tally, t->later.ev_unpacked = sl.ev_unpacked, t->later.ev_done = sl.ev_done;
+    /* Packing on a stream of its own: its kernels stream the batch's arrays through HBM while the solver launches of the batch before are busy with their searches,
+     * and the plan's round trip to the host no longer waits for that solve.  Pool buffers stay ordered: what this upload is handed was released either by an upload
+     * (on this same stream) or by a batch whose work is over (avk_wait). */
+    if (ctx->async_pack_stream) {
+        ctx->up_stream = ctx->pack_stream, ctx->up_side = ctx->pack_side_stream;
+        if (ctx->pool_fence_pending) { /* a synchronous upload released buffers behind kernels of the context's stream that may still be queued */
+            (void)hipStreamWaitEvent(ctx->pack_stream, ctx->ev_pool_fence, 0);
+            ctx->pool_fence_pending = false;
+        }
+    }
+    rc = upload_device_packed(ctx, nullptr, nullptr, false, &t->db, nullptr, batch, nullptr, &pre);
+    if (!rc && ctx->up_stream) {
+        hipError_t e = hipEventRecord(ctx->ev_packed, ctx->up_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->ev_packed, 0);
+        if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "packed upload: %s", hipGetErrorString(e));
+    }
+    ctx->up_stream = nullptr, ctx->up_side = nullptr;
+    const double ts2 = now_ms();
+    if (!rc) rc = avk_compare_resident(ctx, t->db, cfg, nullptr);
+    const double ts3 = now_ms();
+    if (!rc) rc = results_download_impl(ctx, t->db, out, &t->later, nullptr);
+    if (timing)
+        fprintf(stderr, "avk submit (slot %d): called at %.3f ms; copies queued +%.3f, packed and planned +%.3f, solver launches queued +%.3f, results queued +%.3f\n", slot, ts0, ts1 - ts0,
+                ts2 - ts0, ts3 - ts0, now_ms() - ts0);
+    ctx->emit_group_metrics = t->keep_gm, ctx->emit_bp_groups = t->keep_bp;
+    if (rc) { /* nothing of this batch stays in flight */
+        (void)hipStreamSynchronize(ctx->copy_in_stream);
+        (void)hipStreamSynchronize(ctx->pack_stream);
+        (void)hipStreamSynchronize(ctx->pack_side_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        (void)hipStreamSynchronize(ctx->copy_out_stream);
+        for (void *p : t->later.temps) pool_release(ctx, p);
+        if (t->db) avk_batch_free(ctx, t->db);
+        sl.busy = false;
+        delete t;
+        return rc;
+    }
+    ctx->last_one_shot = 1;
+    *ticket = t;
+    return 0;
+}
+
+int avk_wait(avk_ctx *ctx, avk_ticket *t) {
+    if (!ctx || !t) return AVK_E_ARG;
+    if (t->slot < 0) { /* solved at submit */
+        const int rc = t->rc;
+        delete t;
+        return rc;
+    }
+    (void)hipSetDevice(ctx->device);
+    avk_ctx::StageSlot &sl = ctx->stage[t->slot];
+    const auto tw0 = std::chrono::steady_clock::now();
+    hipError_t e = hipEventSynchronize(sl.ev_done);
+    const auto tw1 = std::chrono::steady_clock::now();
+    int rc = e == hipSuccess ? 0 : fail(ctx, AVK_E_HIP, "waiting for the batch's results failed: %s", hipGetErrorString(e));
+    if (!rc) { /* the tally, the statistics and — should a region have come back AVK_ST_CAPACITY — the retry, as in avk_results_download */
+        const int64_t gm = ctx->emit_group_metrics;
+        if (!t->out.group_metrics) ctx->emit_group_metrics = 0;
+        rc = results_download_impl(ctx, t->db, &t->out, nullptr, sl.h_tally);
+        ctx->emit_group_metrics = gm;
+    }
+    /* the batch's buffers go back to the pool: its work is over (the copies out ran behind its last kernel), so whoever is handed them next may use them at once */
+    for (void *p : t->later.temps) pool_release(ctx, p);
+    if (t->db) {
+        release_pooled(ctx, t->db);
+        delete t->db;
+    }
+    sl.busy = false;
+    if (getenv("AVK_TIMING"))
+        fprintf(stderr, "avk wait (slot %d): results arrived after %.3f ms, tally and buffers %.3f ms\n", t->slot, std::chrono::duration<double, std::milli>(tw1 - tw0).count(),
+                std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw1).count());
+    delete t;
+    return rc;
+}
 
 int avk_last_compare_was_one_shot(avk_ctx *ctx) { return ctx ? ctx->last_one_shot : 0; }
 

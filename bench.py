@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--form", choices=("packed", "compact"), default="packed", help="flat form of the region batch the timed calls hand over: packed (avk_packed_batch, 94 MB per genome) or compact (avk_compact_batch, 227 MB)")
     ap.add_argument("--pageable", action="store_true", help="caller arrays in ordinary memory (the library stages them through a pinned bounce buffer) instead of avk_host_alloc memory")
     ap.add_argument("--watchdog-seconds", type=int, default=900, help="a run that takes longer dumps every thread's stack to stderr and exits (0 = off)")
+    ap.add_argument("--torch", action="store_true",
+                    help="one GPU: load PyTorch as the N > 1 ranks do (the process then runs on the HIP runtime the wheel bundles instead of the system's)")
     ap.add_argument("--no-supervisor", action="store_true",
                     help="run in this process (default for N > 1 ranks and under a profiler): otherwise the single-GPU run is a child of a thin supervisor "
                          "that has not touched the GPU, ends a run that exceeds --watchdog-seconds and starts it once more")
@@ -133,6 +135,55 @@ def supervise(args):
     sys.exit(rc)
 
 
+class HipRuntime:
+    """The few runtime calls a one-GPU run needs besides the library's own, on the HIP runtime libaardvark_amd.so is linked with (no PyTorch in the process)."""
+
+    def __init__(self, device):
+        import ctypes as C
+        import aardvark_amd
+        aardvark_amd.load_library()
+        path = next((l.split()[-1] for l in open("/proc/self/maps") if "libamdhip64" in l), "libamdhip64.so")
+        self.C, self.lib = C, C.CDLL(path)
+        self.lib.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+        self.lib.hipMemset.argtypes = [C.c_void_p, C.c_int, C.c_size_t]
+        self.lib.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+        self.check(self.lib.hipSetDevice(device))
+
+    def check(self, rc):
+        if rc != 0:
+            raise RuntimeError("HIP runtime call failed: %d" % rc)
+
+    def synchronize(self):
+        self.check(self.lib.hipDeviceSynchronize())
+
+    def zeros_i64(self, n):
+        return _DevI64(self, n)
+
+
+class _DevI64:
+    """n int64 words of device memory (the running tally of the resident leg): the three things bench.py does with the torch tensor it stands in for"""
+
+    def __init__(self, hip, n):
+        self.hip, self.n, self.ptr = hip, n, hip.C.c_void_p()
+        hip.check(hip.lib.hipMalloc(hip.C.byref(self.ptr), 8 * n))
+        self.zero_()
+
+    def data_ptr(self):
+        return self.ptr.value
+
+    def zero_(self):
+        self.hip.check(self.hip.lib.hipMemset(self.ptr, 0, 8 * self.n))
+
+    def cpu(self):
+        return self
+
+    def numpy(self):
+        import numpy as np
+        out = np.zeros(self.n, np.int64)
+        self.hip.check(self.hip.lib.hipMemcpy(out.ctypes.data, self.ptr, 8 * self.n, 2))  # hipMemcpyDeviceToHost
+        return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -160,8 +211,16 @@ def main():
 
     import ctypes as C
     import numpy as np
-    import torch
-    import torch.distributed as dist
+
+    # One rank on one GPU runs WITHOUT PyTorch in the process (--torch forces it): the wheel brings a HIP runtime of its own (torch/lib/libamdhip64.so, ROCm 7.0)
+    # that the whole process would then run on instead of the system's (7.2) — on it the copies of the asynchronous boundary do not run beside the kernels
+    # (6.7-7.0 ms per genome against 4.3) and the queued resident step is 7 % slower (profiles/r05_runtime_ab.txt).  N > 1 ranks use torch.distributed (RCCL).
+    use_dist = world > 1 or os.environ.get("AVK_BENCH_FORCE_DIST") == "1"  # the second form exercises the collective path on one GPU
+    use_torch = use_dist or args.torch
+    torch = dist = None
+    if use_torch:
+        import torch
+        import torch.distributed as dist
 
     import aardvark_amd
     from aardvark_amd import CompareConfig, synth
@@ -173,9 +232,10 @@ def main():
             print("[bench %7.1fs] %s" % (time.perf_counter() - t_begin, msg), file=sys.stderr, flush=True)
 
     t_begin = time.perf_counter()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    use_dist = world > 1 or os.environ.get("AVK_BENCH_FORCE_DIST") == "1"  # the second form exercises the collective path on one GPU
+    dev = None
+    if use_torch:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     if use_dist:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -198,8 +258,15 @@ def main():
     log("workload: %d contigs, %d bases, %d regions on this rank, %d calls" % (len(contigs), sum(c.size for c in contigs), n_regions, batch.n_variants))
 
     ctx = aardvark_amd.Context(local_rank)
-    stream = torch.cuda.current_stream(dev)
-    ctx.set_stream(stream.cuda_stream)  # launches go on torch's current stream
+    hip = None
+    if use_torch:
+        # launches go on torch's current stream — a stream of the process's own, not the legacy null stream: with torch in the process the same queued steps take
+        # 2.96 ms on the null stream and 2.64 on any other (2.56-2.59 without torch; tools/gpu_resident_host.py, profiles/r05_runtime_ab.txt)
+        stream = torch.cuda.Stream(dev)
+        torch.cuda.set_stream(stream)
+        ctx.set_stream(stream.cuda_stream)
+    else:
+        hip = HipRuntime(local_rank)  # device memory for the running tally and the device-wide synchronisation, on the runtime the library is linked with
     ctx.set_option("emit_group_metrics", 0)  # per-region records + per-variant decisions + the tally; no 1144-byte block per region
     for kv in os.environ.get("AVK_OPTS", "").split(","):  # tuning experiments: context options by name
         if "=" in kv:
@@ -210,6 +277,9 @@ def main():
     log("reference resident")
 
     def fence():
+        if not use_torch:
+            hip.synchronize()  # hipDeviceSynchronize: every stream of the device, as torch.cuda.synchronize
+            return
         torch.cuda.synchronize(dev)
         if use_dist:
             dist.barrier()
@@ -245,7 +315,7 @@ def main():
         ctx._check(entry_point(ctx.handle, C.byref(cb), C.byref(ccfg), C.byref(ro)))
 
     job_tally_host = np.zeros(aardvark_amd.TALLY_LEN, np.uint64)
-    tally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
+    tally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev) if use_torch else None
     for _ in range(args.warmup):
         step()
     if use_dist:
@@ -257,7 +327,8 @@ def main():
         step()
         job_tally_host += res.tally  # SummaryWriter::add_comparison_benchmark over the job's batches (writers/summary.rs:146-163)
         call_end[k + 1] = time.perf_counter()
-    tally.copy_(torch.from_numpy(job_tally_host.astype(np.int64)))
+    if use_torch:
+        tally.copy_(torch.from_numpy(job_tally_host.astype(np.int64)))
     if use_dist:
         dist.all_reduce(tally, op=dist.ReduceOp.SUM)  # RCCL over xGMI: 288 x int64, the job's only collective
     fence()
@@ -275,7 +346,8 @@ def main():
     call_stats = {"min": round(float(call_ms.min()), 3), "median": round(float(np.median(call_ms)), 3), "p95": round(float(np.percentile(call_ms, 95)), 3),
                   "max": round(float(call_ms.max()), 3)} if args.steps else None
     log("timed region: %d %s calls in %.3f s (%.2f ms per call; single calls %s)" % (args.steps, entry_name, elapsed, elapsed / max(args.steps, 1) * 1e3, call_stats))
-    job_tally = tally.clone()
+    job_tally = tally.cpu().numpy().copy() if use_torch else job_tally_host.astype(np.int64)
+    res_ref_rp, res_ref_vp, res_ref_tally = (res.region_packed.copy(), res.var_packed.copy(), res.tally.copy()) if res_form else (None, None, None)
     got_boundary = res if args.wide_results else res.expanded(ctx.lib, batch)  # the outputs of the last timed call (the packed form: expanded on the host, outside the timed region)
     # the same call with the results in the wide arrays (18 B per region + 4 B per call over PCIe)
     wide_results_entry = None
@@ -300,6 +372,35 @@ def main():
                               "same_outputs_as_value_leg": r2.diff(got_boundary) == [],
                               "what": "the value leg's call with the results in the wide arrays of avk_result_batch instead of the packed form"}
         del r2
+    # the same job as batches IN FLIGHT inside the one context (avk_compare_packed_submit / avk_wait): genome k + 1 is copied and packed while genome k is solved, the
+    # results of k cross while k + 1 is packed.  The synchronous call stays `value`; this is what a caller with several batches gets.
+    pipelined_entry = None
+    if form == "packed" and not args.pageable and world == 1:
+        sets = [(hb, res), (ctx.pinned_packed(hb), ctx.pinned_results(hb, packed=res_form))]
+        n_p = max(4, min(args.steps, 20))
+        tk = ctx.submit_packed(sets[0][0], config=cfg, res=sets[0][1])
+        tk.wait()
+        fence()
+        tp0 = time.perf_counter()
+        tk = ctx.submit_packed(sets[0][0], config=cfg, res=sets[0][1])
+        for k in range(1, n_p):
+            nxt = ctx.submit_packed(sets[k & 1][0], config=cfg, res=sets[k & 1][1])
+            tk.wait()
+            tk = nxt
+        tk.wait()
+        fence()
+        p_elapsed = time.perf_counter() - tp0
+        same = all(np.array_equal(r.region_packed, res_ref_rp) and np.array_equal(r.var_packed, res_ref_vp) and np.array_equal(r.tally, res_ref_tally) for _, r in sets) if res_form else \
+            all(r.diff(got_boundary) == [] for _, r in sets)
+        pipelined_entry = {"value": total_regions * n_p / p_elapsed, "unit": "regions/s", "ms_per_step": p_elapsed / n_p * 1e3, "steps": n_p, "in_flight": 2,
+                           "same_outputs_as_value_leg": bool(same),
+                           "what": "the value leg's batch %d times back to back through avk_compare_packed_submit / avk_wait, two in flight in one context: copies in beside the solve of "
+                                   "the batch before, copies out beside the packing of the batch behind; host arrays to host arrays" % n_p}
+        log("pipelined boundary: %.3f ms per genome-sized batch (%s)" % (pipelined_entry["ms_per_step"], "outputs identical" if same else "OUTPUTS DIFFER"))
+        if not same:
+            print("PARITY FAILURE in the pipelined leg", file=sys.stderr)
+            sys.exit(3)
+        del sets
     # the same boundary with the batch in the compact form (avk_compact_batch: 20 B per region + 17 B per call, explicit offsets), when `value` is on the packed one
     compact_entry = None
     if form == "packed":
@@ -343,7 +444,7 @@ def main():
     kernel_ms, solver_ms = [], []
     if args.resident_steps > 0:
         ctx.set_option("accumulate_tally", 1)
-        rtally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev)
+        rtally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev) if use_torch else hip.zeros_i64(aardvark_amd.TALLY_LEN)
         for _ in range(args.warmup):
             ctx.compare_resident(rb, cfg, rtally.data_ptr())
         fence()
@@ -362,7 +463,7 @@ def main():
             r_elapsed = float(t.item())
         resident = {"value": total_regions * args.resident_steps / r_elapsed, "unit": "regions/s", "ms_per_step": r_elapsed / args.resident_steps * 1e3,
                     "steps": args.resident_steps, "what": "avk_compare_resident on the batch packed once in HBM, steps queued back to back, tally added on the device; no copies in the timed region"}
-        resident_tally = rtally.clone()
+        resident_tally = rtally.cpu().numpy().copy()
         ctx.set_option("accumulate_tally", 0)
         log("resident leg: %.3f ms per step" % resident["ms_per_step"])
     # kernel durations for the roofline: HIP events the library records on the launch stream, read on steps outside the timed regions
@@ -394,12 +495,14 @@ def main():
         byte_compares = oracle_lib.stats(lib).get("byte_compares")
         bad = ["boundary:" + x for x in got_boundary.diff(want)] + ["wide_boundary:" + x for x in wres.diff(want)] + ["resident:" + x for x in got.diff(want)]
         # the job total must be steps x this rank's tally, summed over the ranks
-        mine = torch.from_numpy(want.tally.astype(np.int64)).to(dev)
+        mine = want.tally.astype(np.int64)
         if use_dist:
-            dist.all_reduce(mine, op=dist.ReduceOp.SUM)
-        if not torch.equal(mine * args.steps, job_tally):
+            mine_d = torch.from_numpy(mine).to(dev)
+            dist.all_reduce(mine_d, op=dist.ReduceOp.SUM)
+            mine = mine_d.cpu().numpy()
+        if not np.array_equal(mine * args.steps, job_tally):
             bad.append("job_tally")
-        if resident is not None and not torch.equal(mine * args.resident_steps, resident_tally):
+        if resident is not None and not np.array_equal(mine * args.resident_steps, resident_tally):
             bad.append("resident_job_tally")
         if scaling == "strong" and world > 1:
             # the shards' per-variant decisions, gathered as ONE integer: the sum of the ranks' checksums must be the checksum of the
@@ -411,10 +514,12 @@ def main():
                 if int(chk.cpu().numpy().view(np.uint64)[0]) != avk_dist.result_checksum(job_batch, whole):
                     bad.append("job_checksum")
         parity = "bit-identical" if not bad else "MISMATCH:" + ",".join(bad)
-        ok = torch.tensor([0 if bad else 1], device=dev)
+        ok_all = 0 if bad else 1
         if world > 1:
+            ok = torch.tensor([ok_all], device=dev)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-        if int(ok.item()) != 1:
+            ok_all = int(ok.item())
+        if ok_all != 1:
             print("PARITY FAILURE on rank %d: %s" % (rank, parity), file=sys.stderr)
             sys.exit(3)
         log("parity vs oracle: %s (%d regions, oracle %.1f s on %d threads)" % (parity, n_regions, cpu_rate_parity[0], cpus))
@@ -468,6 +573,9 @@ def main():
             "resident_value": resident["value"] if resident else None,
             "resident": resident,
             "wide_results": wide_results_entry,
+            "pipelined": pipelined_entry,
+            "process": ("PyTorch loaded: the process runs on the HIP runtime the wheel bundles (torch/lib/libamdhip64.so)" if use_torch else
+                        "one rank, PyTorch not loaded: the process runs on the system's HIP runtime, the one libaardvark_amd.so is linked with (--torch loads it as N > 1 ranks do)"),
             "compact_soa": compact_entry,
             "wide_soa": {"value": total_regions * n_wide / wide_elapsed, "unit": "regions/s", "ms_per_step": wide_elapsed / n_wide * 1e3, "steps": n_wide, "host_bytes_in_per_step": wide_bytes,
                          "what": "the same boundary with the batch in the wide structure-of-arrays form (avk_region_batch through avk_compare_batch)"},

@@ -343,6 +343,18 @@ int  avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk
 int  avk_batch_upload_compact(avk_ctx *ctx, const avk_compact_batch *batch, avk_dev_batch **out);
 /* and in the packed form (replaces the same loop, src/main.rs:251-268; the batch crosses PCIe as 94 MB per whole genome) */
 int  avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out);
+
+/* The same call in two halves, for a caller with several batches (the reference streams its regions through one rayon loop and collects at the end,
+ * src/main.rs:251-268): batches in flight inside ONE context.  avk_compare_packed_submit copies the batch's arrays on the context's copy stream — beside the
+ * kernels of the batch submitted before — packs it, queues its solver launches and the copies of its results (on a second copy stream, beside whatever is
+ * submitted next) and returns a ticket; avk_wait returns when the results are in `out`'s arrays and frees the ticket.  Tickets may be waited for in any order;
+ * at most four are in flight.  The batch's arrays may be reused as soon as the submit has returned; `out`'s arrays belong to the library until the wait returns.
+ * Every array of `batch` and `out` must be pinned (avk_host_alloc) for the copies to run beside anything: a batch with a pageable array, with sequence outputs
+ * or compact BASEPAIR groups is solved inside the submit (its ticket is complete).  The submit blocks once, while the packer's plan comes back to the host —
+ * behind the batch submitted before.  Results are those of avk_compare_packed, bit for bit (tests/test_gpu_async.py). */
+typedef struct avk_ticket avk_ticket;
+int  avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket);
+int  avk_wait(avk_ctx *ctx, avk_ticket *ticket);
 int  avk_batch_upload_packed(avk_ctx *ctx, const avk_packed_batch *batch, avk_dev_batch **out);
 
 /* The same in three steps, for callers that keep batches resident in HBM. */

@@ -312,6 +312,7 @@ struct DpResult {
     std::vector<dpk::DpRegionInfo> rinfo;
     std::vector<dpk::DpSlot> slots;
     std::vector<uint32_t> pending, big_list;
+    std::vector<uint8_t> owned;
     dpk::DpState st;
     dpk::DpArgs args; /* for the writers that run later (records of the regions the lanes hand back) */
     bool lazy = false;
@@ -334,6 +335,8 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     a.in.a0_len = b->a0_len, a.in.a1_len = b->a1_len, a.in.alleles = b->allele_bytes, a.in.n_regions = n, a.in.n_variants = nv, a.in.alleles_len = b->allele_bytes_len,
     a.in.contig_base = base.data(), a.in.contig_len = lens.data(), a.in.n_contigs = (uint32_t)lens.size(), a.in.pairs_mode = pairs_mode ? 1u : 0u;
     a.in.v_lo = 0, a.in.v_hi = nv;
+    R->owned.assign(nv + 16, 0); /* upload_device_packed: forms with explicit offsets count the ownership of their calls (and re-derive a shared call's position per region) */
+    if (!pairs_mode) a.in.owned = R->owned.data();
     a.opt = opt;
     R->vinfo.assign(nv + 1, dpk::DpVarInfo());
     R->rinfo.assign(n + 1, dpk::DpRegionInfo());

@@ -384,3 +384,41 @@ def test_merge_of_three_call_sets_at_genome_density(oracle):
                 assert dec[m][1] == tuple(w) or dec[m][1] == w, (m, dec[m], w)
     finally:
         ctx.close()
+
+
+def test_two_lane_windows_with_different_starts_share_a_call(ctx_pair, oracle):
+    """two overlapping windows of the lane classes, 30 bases apart, name the same truth call through explicit offsets: each region's fast record holds the call's
+    position relative to ITS start (the packer's call slots are per call; the position is re-derived per region for forms with explicit offsets)"""
+    rng = np.random.default_rng(5)
+    contig = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=20_000)
+    n = 400
+    starts = 200 + 45 * np.arange(n, dtype=np.uint64)  # windows of 100 bases that overlap their neighbours
+    ends = starts + 100
+    var_pos, var_type, var_zyg, a0, a1, alle = [], [], [], [], [], []
+    t_off, q_off = np.zeros(n, np.uint64), np.zeros(n, np.uint64)
+    for r in range(n):
+        p = int(starts[r]) + 60  # inside window r at 60 and inside window r + 1 at 15
+        ref = contig[p]
+        alt = b"ACGT"[(b"ACGT".index(bytes([ref])) + 1) % 4]
+        for side in range(2):  # the call once as a truth call, once as a query call
+            (t_off if side == 0 else q_off)[r] = len(var_pos)
+            var_pos.append(p), var_type.append(0), var_zyg.append(int(rng.integers(2, 6))), a0.append(1), a1.append(1)
+            alle += [ref, alt]
+    nv = len(var_pos)
+    # odd regions take the truth call of their left neighbour (which their window holds at another offset) instead of their own
+    t_off_shared = t_off.copy()
+    t_off_shared[1::2] = t_off[0:-1:2]
+    a0_off = 2 * np.arange(nv, dtype=np.uint64)
+    batch = RegionBatch(np.arange(n, dtype=np.uint64), np.zeros(n, np.uint32), starts, ends, t_off_shared, np.ones(n, np.uint32), q_off, np.ones(n, np.uint32),
+                        np.array(var_pos, np.uint64), np.array(var_type, np.uint8), np.array(var_zyg, np.uint8), np.ones(nv, np.uint32), a0_off, np.array(a0, np.uint32),
+                        a0_off + 1, np.array(a1, np.uint32), np.array(alle, np.uint8))
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=False)
+    assert (want.status == 0).all() and (want.ed_h1[1::2] + want.ed_h2[1::2]).sum() > 0  # the shared calls are at other positions than the regions' own: edits
+    for c in ctx_pair:
+        c.upload_reference([contig])
+        c.set_option("lane_min_regions", 0)
+        c.set_option("lane_min_batch", 0)
+        got = c.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False)
+        assert np.array_equal(got.status, want.status) and np.array_equal(got.ed_h1, want.ed_h1) and np.array_equal(got.ed_h2, want.ed_h2)
+        assert np.array_equal(got.tally, want.tally)
+    assert ctx_pair[0].last_lane_solved() > n // 2
