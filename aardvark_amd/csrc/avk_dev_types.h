@@ -136,9 +136,6 @@ AVK_TYPES_HD uint32_t avk_head_slots(uint32_t maxv, uint32_t n_fast, uint32_t n_
  * hold.  Both packers put them into class C (solved from the start of the step on a wave and an HBM slice of their own) and keep them out of the lanes'
  * three-call class — they used to be tried there or in an LDS slice first and started over late in the step, on its critical path. */
 #define AVK_HET_SEARCH_MIN 6
-/* three-call lane class: regions with at least this many unphased heterozygous calls lead the class (cost key 0x10) — nearly every region the class hands
- * back for its node cap is one of them, and the launch for handed-back regions starts behind that head, beside the rest of the class */
-#define AVK_HET_HEAD_MIN 4
 
 #define AVK_WIDE_ED_MAX 62u /* largest distance a search node's wavefront holds there (one byte per offset, a state names at most 2 x 62 + 2 of them) */
 /* What a region record says about whether the wave-cooperative kernel of avk_wide.inl can take the region (it looks at the alleles and the reference window

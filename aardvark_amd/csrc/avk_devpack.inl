@@ -68,7 +68,7 @@ struct DpOpts {
     u32 solo_min_variants, max_branch, class_c_nodes_x2, lane_max_calls, lane_max_est;
     u32 head_est, het_min; /* het_min: regions with at least this many unphased heterozygous calls are big phasing searches (AVK_HET_SEARCH_MIN; 0 = no such rule) */
 /* regions with at least this many estimated edits form the head of their lane class (1..15) */
-    u32 lane_pairs, split_three; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
+    u32 lane_pairs; /* 1: regions with the same SNV on both sides get the class of their own (avk_pairs.inl) */
     u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
     u64 lane_min_batch;
@@ -618,7 +618,7 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                     fast_class = (u32)cl + 1u;
                     fast_key = dp_cost_key(calls, tc, qc);
                     if ((fast_key >> 4) > a.opt.lane_max_est) fast_class = 0;
-                    if (maxv > 2) fast_key = a.opt.split_three && nhet_u >= AVK_HET_HEAD_MIN ? 0x10u : 0u; /* the three-call class keeps the caller's order (avk_pack.h); option lane_split_three: likely hand-backs first */
+                    if (maxv > 2) fast_key = 0u; /* the three-call class keeps the caller's order (avk_pack.h) */
                     if (maxv > 2 && a.opt.het_min && nhet_u >= a.opt.het_min) fast_class = 0; /* a big phasing search (avk_dev_types.h): not for a lane */
                     break;
                 }

@@ -1042,7 +1042,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.opt.class_c_nodes_x2 = (uint32_t)ctx->class_c_nodes_x2, a.opt.lane_min_regions = lanes ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull,
     a.opt.lane_max_calls = (uint32_t)ctx->lane_max_calls, a.opt.lane_min_batch = (uint64_t)ctx->lane_min_batch, a.opt.lane_max_est = (uint32_t)ctx->lane_max_est;
     a.opt.stripe_w = ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u;
-    a.opt.lane_pairs = ctx->lane_pairs ? 1u : 0u, a.opt.split_three = ctx->lane_split_three ? 1u : 0u;
+    a.opt.lane_pairs = ctx->lane_pairs ? 1u : 0u;
     a.opt.head_est = (uint32_t)ctx->lane_head_est, a.opt.het_min = (uint32_t)ctx->het_search_min;
     hipError_t e = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
     if (e == hipSuccess && nv) {

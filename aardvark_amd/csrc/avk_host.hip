@@ -333,10 +333,6 @@ struct avk_ctx {
     int64_t waves_per_cu = 16;
     int64_t solo_min_variants = 5; /* regions with at least this many variants go to solo waves (0 = no solo waves) */
     int64_t solo_blocks_max = 128;
-    int64_t order_guard = 0; /* 1: the bulk launch waits until the side streams have reached their launches; 2: only for batches of 262,144 regions
-                                or more; 0 (default): never.  With the bulk of a genome on the lanes the wave-per-region bulk launch is short and
-                                better off early: 7.25 ms per whole-genome step without the guard, 7.5 with it (it paid off while the bulk launch
-                                held 52,000 regions: 10.5 -> 9.4 ms) */
     int64_t timing_events = 1; /* record the events avk_last_kernel_ms / avk_last_solver_ms read (three per call) */
     bool lds_attr_set = false;
     int64_t static_pct = AVK_STATIC_PCT; /* share of a launch's work list dealt statically; the rest is claimed */
@@ -373,11 +369,8 @@ struct avk_ctx {
     int64_t lane_metrics_ed_cap = 0;                  /* lanes hand a region over when an alignment of its metrics phase passes this distance (0 = as far as the LDS rows allow: 30 / 54) */
     int64_t hbm_ed_cap = 1024;                        /* the per-wave HBM slices size a region's wavefronts by the region's own bound (the sum of its calls' edit distances) when that is at most this;
                                                          0: two entries per base of the window for every region (rounds 1-2).  Large windows: 1.64 -> 1.21 s per 49 k-region step, whole genome -3 % */
-    int64_t early_lds = 0;                            /* 1: what the three-call lane class hands back goes through the LDS tier first (run_internal) */
     int64_t het_search_min = AVK_HET_SEARCH_MIN;      /* regions with at least this many unphased heterozygous calls go to class C and stay out of the three-call lane class (0 = no such rule) */
     int64_t lane_head_est = 1;                        /* regions with at least this many estimated edits (fast_cost_key) form the narrow-tiled head of their lane class */
-    int64_t lane_split_three = 0;                     /* 1: the three-call class as two launches: likely hand-backs (AVK_HET_HEAD_MIN) first, their launch beside the rest.  Measured WORSE (3.95 ->
-                                                         4.9 ms per whole-genome step): the class lasts as long as its slowest claims, and the head is all of them — 2.3 ms for a third of the class */
     int64_t lane_pairs = 1;                           /* regions with the same SNV on both sides are looked up in a table the solver fills (avk_pairs.inl); 0: they stay in the one-call classes */
     avk::pairs::PairTable *d_pair_tab = nullptr;      /* the table, made for max_branch_factor pair_tab_mbf */
     uint32_t *d_pair_aux = nullptr;                   /* probe records, probe reference and the scratch outputs of the probe launch */
@@ -418,21 +411,18 @@ struct avk_ctx {
     hipEvent_t ev_lane = nullptr; /* after the lane-kernel launches of a step */
     bool ev_lane_valid = false;
     hipStream_t lane_stream = nullptr, lane_stream2 = nullptr; /* the lane-kernel launches run beside the wave-per-region launches: two-call classes / one-call classes */
-    hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_lane_join2 = nullptr, ev_lane_ready = nullptr, ev_lane_ready2 = nullptr;
+    hipEvent_t ev_lane_fork = nullptr, ev_lane_join = nullptr, ev_lane_join2 = nullptr;
     hipStream_t lane_stream3 = nullptr; /* the three-call class: long tiles, few of them, beside everything else */
-    hipEvent_t ev_lane_join3 = nullptr, ev_lane_ready3 = nullptr, ev_lane_done = nullptr;
+    hipEvent_t ev_lane_join3 = nullptr, ev_lane_done = nullptr;
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
-    hipEvent_t ev_lane_join4 = nullptr, ev_lane_ready4 = nullptr, ev_lane_early = nullptr, ev_lane_head3 = nullptr;
+    hipEvent_t ev_lane_join4 = nullptr, ev_lane_early = nullptr;
     hipEvent_t ev_tl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* AVK_TIMING only: marks of a boundary call on the context's stream (first copy, last copy, work order, writers, results) */
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     hipStream_t wide_stream = nullptr; /* the class C records that are not for the wide kernel (run_internal) */
-    hipStream_t tail_stream = nullptr, tail_stream2 = nullptr; /* HIGH priority: the launches for what the lanes handed back start when the chip is full of the other lane classes' waiting
-                                                                  workgroups; at the default priority theirs wait their turn among thousands (a 0.2 ms launch took 0.9) */
-    int64_t tail_priority = 0;         /* 1: those launches on the high-priority streams.  Measured: no gain (their workgroups still wait for LDS), 0.5 % slower; off */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_ready = nullptr, ev_ready2 = nullptr, ev_wide = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_join2 = nullptr, ev_wide = nullptr;
     bool ev_valid = false;
     uint64_t last_tiers[5] = {0, 0, 0, 0, 0};
     uint64_t last_phase[16] = {0};
@@ -583,7 +573,6 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
      * of a process share queues, and a shared queue would serialise the solo launches with the bulk) */
     int prio_low = 0, prio_high = 0;
     (void)hipDeviceGetStreamPriorityRange(&prio_low, &prio_high);
-    const int prio_tail = prio_high; /* the streams of the launches that END a step (what the lanes handed back) */
     { /* the side and lane streams run at the default priority: with hardware queues of their own (GPU_MAX_HW_QUEUES >= 8) a high priority changes
        * nothing (4.94 / 4.98 ms per whole-genome step), with the runtime's default of 4 queues it costs 0.9 ms (7.0 / 7.9 ms);
        * AVK_STREAM_PRIORITY=high brings it back for experiments */
@@ -594,30 +583,21 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->wide_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->tail_stream, hipStreamNonBlocking, prio_tail) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->tail_stream2, hipStreamNonBlocking, prio_tail) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join2, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_wide, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join2, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream3, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join3, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_ready3, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_ready4, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_early, evf) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_head3, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_ready, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_lane_ready2, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, evf) != hipSuccess) {
@@ -663,8 +643,6 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->evk1) (void)hipEventDestroy(ctx->evk1);
     if (ctx->ev_lane) (void)hipEventDestroy(ctx->ev_lane);
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
-    if (ctx->ev_ready) (void)hipEventDestroy(ctx->ev_ready);
-    if (ctx->ev_ready2) (void)hipEventDestroy(ctx->ev_ready2);
     if (ctx->ev_wide) (void)hipEventDestroy(ctx->ev_wide);
     if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
     if (ctx->ev_join2) (void)hipEventDestroy(ctx->ev_join2);
@@ -673,27 +651,20 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_fork) (void)hipEventDestroy(ctx->ev_lane_fork);
     if (ctx->ev_lane_join) (void)hipEventDestroy(ctx->ev_lane_join);
     if (ctx->ev_lane_join2) (void)hipEventDestroy(ctx->ev_lane_join2);
-    if (ctx->ev_lane_ready) (void)hipEventDestroy(ctx->ev_lane_ready);
-    if (ctx->ev_lane_ready2) (void)hipEventDestroy(ctx->ev_lane_ready2);
     if (ctx->lane_stream) (void)hipStreamDestroy(ctx->lane_stream);
     if (ctx->lane_stream2) (void)hipStreamDestroy(ctx->lane_stream2);
     if (ctx->ev_lane_join3) (void)hipEventDestroy(ctx->ev_lane_join3);
-    if (ctx->ev_lane_ready3) (void)hipEventDestroy(ctx->ev_lane_ready3);
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
     if (ctx->ev_copy_fork) (void)hipEventDestroy(ctx->ev_copy_fork);
     if (ctx->ev_copy_mid) (void)hipEventDestroy(ctx->ev_copy_mid);
     if (ctx->ev_copy_join) (void)hipEventDestroy(ctx->ev_copy_join);
-    if (ctx->ev_lane_ready4) (void)hipEventDestroy(ctx->ev_lane_ready4);
     if (ctx->ev_lane_early) (void)hipEventDestroy(ctx->ev_lane_early);
-    if (ctx->ev_lane_head3) (void)hipEventDestroy(ctx->ev_lane_head3);
     if (ctx->lane_stream4) (void)hipStreamDestroy(ctx->lane_stream4);
     if (ctx->lane_stream3) (void)hipStreamDestroy(ctx->lane_stream3);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     if (ctx->wide_stream) (void)hipStreamDestroy(ctx->wide_stream);
-    if (ctx->tail_stream) (void)hipStreamDestroy(ctx->tail_stream);
-    if (ctx->tail_stream2) (void)hipStreamDestroy(ctx->tail_stream2);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -744,9 +715,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "class_c_nodes_x2") {
         if (value < 1 || value > 1000) return fail(ctx, AVK_E_ARG, "class_c_nodes_x2 must be in [1, 1000]");
         ctx->class_c_nodes_x2 = value;
-    } else if (n == "order_guard") {
-        if (value < 0 || value > 2) return fail(ctx, AVK_E_ARG, "order_guard must be 0, 1 or 2");
-        ctx->order_guard = value;
     } else if (n == "timing_events") {
         ctx->timing_events = value ? 1 : 0;
     } else if (n == "static_pct") {
@@ -763,8 +731,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "wide_blocks") {
         if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_blocks must be in [1, 4096]");
         ctx->wide_blocks = value;
-    } else if (n == "tail_priority") {
-        ctx->tail_priority = value ? 1 : 0;
     } else if (n == "wide_retry_lds_bytes") {
         if (value < 0 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_retry_lds_bytes must be in [0, 65536]");
         ctx->wide_retry_lds_bytes = value & ~15ll;
@@ -833,16 +799,12 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "hbm_ed_cap") {
         if (value < 0 || value > 1000000) return fail(ctx, AVK_E_ARG, "hbm_ed_cap must be 0..1000000");
         ctx->hbm_ed_cap = value;
-    } else if (n == "early_lds") {
-        ctx->early_lds = value ? 1 : 0;
     } else if (n == "het_search_min") {
         if (value < 0 || value > 255) return fail(ctx, AVK_E_ARG, "het_search_min must be 0..255");
         ctx->het_search_min = value;
     } else if (n == "lane_head_est") {
         if (value < 1 || value > 15) return fail(ctx, AVK_E_ARG, "lane_head_est must be 1..15");
         ctx->lane_head_est = value;
-    } else if (n == "lane_split_three") {
-        ctx->lane_split_three = value ? 1 : 0;
     } else if (n == "lane_pairs") {
         ctx->lane_pairs = value ? 1 : 0;
     } else if (n == "pair_blocks_per_cu") {
@@ -1111,7 +1073,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     }
     db->seq_total = seq_total;
     std::string err;
-    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0 && !pairs_mode, ctx->lane_split_three != 0, (uint32_t)ctx->het_search_min);
+    int rc = avk::pack_batch(batch, ctx->contig_base, ctx->contig_len, seq_off.data(), seq_stride.data(), &db->host, &err, 0, (uint32_t)ctx->lane_max_est, ctx->lane_pairs != 0 && !pairs_mode, (uint32_t)ctx->het_search_min);
     if (rc) {
         delete db;
         return fail(ctx, rc, "%s", err.c_str());
@@ -1486,7 +1448,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         ctx->lds_attr_set = true;
     }
     const bool timed = ctx->timing_events != 0;
-    const bool order_guard = ctx->order_guard == 1 || (ctx->order_guard == 2 && n >= 262144);
     if (timed) AVK_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     ctx->ev_lane_valid = false;
     const uint32_t big_slots = use[2] && use[3] ? (uint32_t)(big_waves < 128 ? big_waves : 128) : 0u;
@@ -1657,7 +1618,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     s.overflow_list = lists[launch[1] ? 2 : 1];
                     s.overflow_count = db->d_counters + 1024 + 16 * (launch[1] ? 2 : 1);
                 }
-                if (order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_ready2, ctx->side_stream2));
                 hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_solo), dim3(256), 0, ctx->side_stream2, s);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side_stream2));
@@ -1679,7 +1639,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 s.overflow_list = later ? lists[solo_list] : nullptr;
                 s.overflow_count = later ? db->d_counters + 1024 + 16 * solo_list : nullptr;
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->ev_fork, 0));
-                if (order_guard) AVK_HIP(ctx, hipEventRecord(ctx->ev_ready, ctx->side_stream));
                 hipLaunchKernelGGL(avk_region_kernel_lds, dim3(solo), dim3(64), (size_t)ctx->lds2_bytes_per_wave, ctx->side_stream, s);
                 AVK_HIP(ctx, hipGetLastError());
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join, ctx->side_stream));
@@ -1689,22 +1648,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 a.work_base = n_c + solo_regions;
                 a.n_work = (uint32_t)n - n_fast - n_c - solo_regions;
             }
-            /* With calls queued back to back (no host synchronisation in between) the bulk is dispatched the moment the previous call
-             * ends, ahead of the solo launches whose streams still have to see the fork event, and takes every LDS allocation before
-             * them: 0.395 ms per call instead of 0.365 with a synchronisation per call.  order_guard = 1 makes the bulk wait until both
-             * side streams are past their wait (0.376 ms queued; it costs 9 us when the caller synchronises every call anyway, so it
-             * is off by default). */
-            if (order_guard) {
-                if (hbm_solo) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ready2, 0));
-                if (solo) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_ready, 0));
-            }
             /* ---- the lane-per-region launches (avk_lane.inl): the classes with two calls per side (long, latency-bound tiles at low
              * occupancy) on a stream of their own, the one-call classes on the caller's stream ahead of the bulk.  What a lane cannot
              * finish goes to the DEFERRED list, solved after the bulk by an LDS launch of the wave-per-region kernel. */
             /* lane streams: 0 the two-call classes, 1 the one-call classes, 2 the three-call class, 3 the heads of the two-call classes */
             enum { N_LS = 4 };
             hipStream_t lstream[N_LS] = {ctx->lane_stream, ctx->lane_stream2, ctx->lane_stream3, ctx->lane_stream4};
-            hipEvent_t lready[N_LS] = {ctx->ev_lane_ready, ctx->ev_lane_ready2, ctx->ev_lane_ready3, ctx->ev_lane_ready4};
             hipEvent_t ljoin[N_LS] = {ctx->ev_lane_join, ctx->ev_lane_join2, ctx->ev_lane_join3, ctx->ev_lane_join4};
             bool lused[N_LS] = {false, false, false, false}, ljoined[N_LS] = {false, false, false, false}, early_used = false;
             if (use_fast) {
@@ -1726,7 +1675,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         const int li = 1;
                         if (!lused[li]) {
                             AVK_HIP(ctx, hipStreamWaitEvent(lstream[li], ctx->ev_lane_fork, 0));
-                            if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[li], lstream[li]));
                             lused[li] = true;
                         }
                         const int rt = ensure_pair_table(ctx, cfg->max_branch_factor, lstream[li]);
@@ -1769,7 +1717,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     const int li = cl.maxv == 2 ? 0 : (cl.maxv == 1 ? 1 : 2);
                     if (!lused[li]) {
                         AVK_HIP(ctx, hipStreamWaitEvent(lstream[li], ctx->ev_lane_fork, 0));
-                        if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[li], lstream[li]));
                         lused[li] = true;
                     }
                     if (cl.maxv > 2) {
@@ -1779,41 +1726,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         AvkKernelArgs f3 = f;
                         f3.overflow_list = lists[3];
                         f3.overflow_count = db->d_counters + 1104;
-                        /* The regions that are likely to come back (AVK_HET_HEAD_MIN: the packers put them first) are a launch of their own; the launch
-                         * for what they hand back starts behind it on another stream, BESIDE the rest of the class — it used to follow the whole class,
-                         * 1.1 ms at the very end of the step.  What the rest hands back (rare) joins the other classes' list. */
-                        const uint32_t head3 = (db->plan.n_fast_heavy[fc] + 63u) / 64u;
-                        const bool split3 = ctx->lane_split_three && head3 > 0 && head3 < la.n_tiles;
                         hipStream_t es = lstream[li]; /* where the launch for the handed-back regions goes */
-                        bool es_tail = false;
-                        if (split3) {
-                            avk::lane::LaneArgs hd = la;
-                            hd.n_tiles = head3;
-                            hd.tile_counter = db->d_counters + 1230 + fc;
-                            uint32_t hgrid = 0;
-                            const size_t hlds = lane_launch_geometry(ctx, hd, &hgrid);
-                            launch_lane_class(ctx, hgrid, hlds, lstream[li], f3, hd);
-                            AVK_HIP(ctx, hipGetLastError());
-                            AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_head3, lstream[li]));
-                            es = lstream[3];
-                            AVK_HIP(ctx, hipStreamWaitEvent(es, ctx->ev_lane_head3, 0));
-                            la.recs += (size_t)head3 * la.rec_words * 64u;
-                            la.n_tiles -= head3;
-                            la.gen_base += head3 * 64u;
-                            if (grid > la.n_tiles * (64u >> la.lanes_log2)) grid = la.n_tiles * (64u >> la.lanes_log2);
-                            launch_lane_class(ctx, grid, lds, lstream[li], f, la);
-                        } else
-                            launch_lane_class(ctx, grid, lds, lstream[li], f3, la);
+                        launch_lane_class(ctx, grid, lds, lstream[li], f3, la);
                         AVK_HIP(ctx, hipGetLastError());
                         /* the launch for what ALL lanes hand back waits for the lane launches only, not for the launch behind this class */
                         AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
                         ljoined[li] = true;
-                        if (ctx->tail_priority && !split3) { /* the hand-backs' launches on the high-priority stream, behind the class */
-                            es = ctx->tail_stream;
-                            es_tail = true;
-                            AVK_HIP(ctx, hipStreamWaitEvent(es, ljoin[li], 0));
-                        }
-                        (void)es_tail;
                         AvkKernelArgs e = a;
                         e.pass_tier = 2;
                         e.work_list = lists[3];
@@ -1846,23 +1764,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             e.work_list = db->d_overflow6;
                             e.n_work_dev = db->d_counters + 1252;
                         }
-                        if (ctx->early_lds && ctx->lds_bytes_per_wave >= 1024) {
-                            /* option early_lds: the regions the three-call class hands back are small windows with large searches — the LDS tier with its
-                             * in-workgroup escalation first (as the launch for the other classes' hand-backs), the HBM launch at the end for what overflows */
-                            e.pass_tier = 0;
-                            e.hbm_ws = nullptr;
-                            e.tier[0].ws_bytes = avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave);
-                            e.esc_bytes = (uint32_t)(waves_per_block * e.tier[0].ws_bytes);
-                            e.esc_enabled = ctx->lds_escalation ? 1u : 0u;
-                            e.overflow_list = lists[1];
-                            e.overflow_count = db->d_counters + 1024 + 16;
-                            if (eb > (uint32_t)ctx->n_cus * 2u) eb = (uint32_t)ctx->n_cus * 2u;
-                            e.n_waves = eb * waves_per_block;
-                            hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(eb), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, es, e);
-                        } else {
                         e.n_waves = eb * waves_per_block;
                         hipLaunchKernelGGL(avk_region_kernel_hbm_lazy, dim3(eb), dim3(256), 0, es, e);
-                        }
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_early, es)); /* the caller's stream waits for this one at the end */
                         early_used = true;
@@ -1883,7 +1786,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         const int hi = (cl.maxv == 2 && ctx->lane_head_stream) ? 3 : li; /* a long head runs beside the rest of its class */
                         if (!lused[hi]) {
                             AVK_HIP(ctx, hipStreamWaitEvent(lstream[hi], ctx->ev_lane_fork, 0));
-                            if (order_guard) AVK_HIP(ctx, hipEventRecord(lready[hi], lstream[hi]));
                             lused[hi] = true;
                         }
                         launch_lane_class(ctx, hgrid, hlds, lstream[hi], f, hd);
@@ -1898,7 +1800,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 }
                 for (int li = 0; li < N_LS; ++li) {
                     if (!lused[li]) continue;
-                    if (order_guard) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, lready[li], 0)); /* the bulk must not take the machine before the lane launches are in their queues */
                     if (!ljoined[li]) AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
                 }
                 if (lused[1] && timed) { /* end of the one-call classes' launches */
@@ -1930,8 +1831,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                  * stream, behind the lane launches, BESIDE the bulk and the HBM launch of this stream.  What overflows there (rare) goes to a
                  * list of its own, read by one more HBM launch at the very end (normally empty: 10 us). */
                 AVK_HIP(ctx, hipGetLastError());
-                const int di = ctx->tail_priority ? -1 : (lused[1] ? 1 : (lused[0] ? 0 : 2));
-                hipStream_t ds = di < 0 ? ctx->tail_stream2 : lstream[di];
+                const int di = lused[1] ? 1 : (lused[0] ? 0 : 2);
+                hipStream_t ds = lstream[di];
                 for (int li = 0; li < N_LS; ++li)
                     if (li != di && lused[li]) AVK_HIP(ctx, hipStreamWaitEvent(ds, ljoin[li], 0));
                 AvkKernelArgs d = a;

@@ -172,7 +172,7 @@ inline uint64_t host_edit_distance(const uint8_t *a, uint64_t n, const uint8_t *
  * independent once the offsets are known). */
 inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &contig_base, const std::vector<uint64_t> &contig_len,
                       const uint64_t *seq_off, const uint32_t *seq_stride, PackedBatch *out, std::string *err, int threads = 0, uint32_t lane_max_est = 15,
-                      bool lane_pairs = true, bool split_three = false, uint32_t het_min = AVK_HET_SEARCH_MIN) {
+                      bool lane_pairs = true, uint32_t het_min = AVK_HET_SEARCH_MIN) {
     const uint64_t n = b->n_regions;
     if (n > 0x7FFFFFFFull || b->n_variants > 0x7FFFFFFFull) {
         *err = "batch too large (more than 2^31 regions or variants); split it";
@@ -413,7 +413,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
                         /* The three-call class keeps the caller's order: its expensive regions are large searches, which the key does not
                          * see, and lanes that diverge do not run side by side — 16 expensive regions in one tile take 16 times as long as
                          * one, and the launch lasts as long as that tile (measured: 3.1 ms in caller order, 6.2 ms sorted). */
-                        if (fc.maxv > 2) out->fast_key[r] = split_three && out->nhet_u[r] >= AVK_HET_HEAD_MIN ? 0x10 : 0; /* (option lane_split_three: the likely hand-backs first, AVK_HET_HEAD_MIN) */
+                        if (fc.maxv > 2) out->fast_key[r] = 0;
                         if (fc.maxv > 2 && het_min && out->nhet_u[r] >= het_min) out->fast_class[r] = 0; /* a big phasing search (avk_dev_types.h): not for a lane */
                         break;
                     }

@@ -279,8 +279,7 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
  *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid",
  *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2),
- *                    "order_guard" (the bulk launch waits for the side streams to reach their launches: 1 always, 2 for batches of
- *                    262,144 regions or more, 0 = default: never), "timing_events" (0 = no event records for
+ *                    "timing_events" (0 = no event records for
  *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
  *   lane kernel      "lane_kernel" (1, default: regions with at most three calls per side, a short window and a small edit-distance
  *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
@@ -301,7 +300,10 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    estimated edits — the head of the class — get a launch of their own with this many records per wave, because
  *                    lanes that diverge take turns; 0 = no head launch), "lane_max_est" (15: regions whose estimated edits exceed
  *                    this stay with the wave-per-region kernels), "lane_head_auto" (1: a head of fewer than 24,576 / 8,192 regions takes 8 / 4
- *                    records per wave instead of lane_head_width), "lane_pool" (-1: by class — 2 / 4 / 6 kept node states per lane in the head
+ *                    records per wave instead of lane_head_width), "lane_quad" (1, default: lane launches of at most 16 records per wave — the heads of the classes and the three-call class, where the
+ *                    expensive searches are — run FOUR lanes on every region, avk_quad_kernel, csrc/avk_quad.inl: (child, haplotype) in the phasing search,
+ *                    a genotype search per haplotype, (side, haplotype) in the metrics; 0: one lane of sixteen per region; results are identical either way),
+ *                    "lane_pool" (-1: by class — 2 / 4 / 6 kept node states per lane in the head
  *                    launches and the three-call class, none in the 64-wide launches; 0 = every pop of a search replays its node's path; 1..8 =
  *                    that many everywhere)
  *   wide kernel      "wide_kernel" (1, default: large phasing searches on small windows — the class C regions of a batch with lane launches,
@@ -316,6 +318,8 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
  *                    earlier should export the variable itself (whole-genome step: 7.0 ms with 4 queues, 5.0 with 8 in round 2; with a
  *                    communicator library in the process 6.0 ms with 8 queues, 3.8 with 16 or 24 in round 3).
+ *   boundary         "async_pack_stream" (1, default: a batch submitted with avk_compare_packed_submit is packed on a stream of its own, beside the solver
+ *                    launches of the batch before, and the plan's round trip does not wait for them; 0: on the context's stream)
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
  *                    "emit_bp_groups" (1 = kernels write the compact per-region BASEPAIR groups, avk_result_batch::bp_groups; avk_compare_batch /
  *                    avk_compare_compact switch it on by themselves when the caller hands the two arrays in),

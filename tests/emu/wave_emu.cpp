@@ -419,7 +419,7 @@ dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_by
     o.class_c_nodes_x2 = getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u;
     o.lane_min_regions = lane_min_regions, o.lane_max_calls = AVK_FAST_MAXV, o.lane_min_batch = lane_min_batch, o.lane_max_est = lane_max_est;
     o.stripe_w = g_stripe_w;
-    o.lane_pairs = g_lane_pairs ? 1u : 0u, o.split_three = 0;
+    o.lane_pairs = g_lane_pairs ? 1u : 0u;
     o.head_est = 1, o.het_min = AVK_HET_SEARCH_MIN;
     return o;
 }

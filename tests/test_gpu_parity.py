@@ -136,7 +136,7 @@ def test_results_do_not_depend_on_the_workspace_tier(oracle):
                  {"lds_bytes_per_wave": 4096, "lds2_bytes_per_wave": 8192, "ws_bytes_per_wave": 12288, "big_waves": 4},
                  # launch-chain variants: work dealt only statically / only by claims of 1 and 7, the bulk held back for the side
                  # streams, no timing events, a class C list long enough to be shared with the main stream's HBM launch
-                 {"static_pct": 100}, {"static_pct": 0, "claim": 1}, {"static_pct": 10, "claim": 7}, {"order_guard": 1, "timing_events": 0},
+                 {"static_pct": 100}, {"static_pct": 0, "claim": 1}, {"static_pct": 10, "claim": 7}, {"timing_events": 0},
                  {"class_c_nodes_x2": 1000, "solo_min_variants": 2}):
         c = aardvark_amd.Context(0)
         for k, v in opts.items():
