@@ -139,6 +139,8 @@ class AvkResultBatch(C.Structure):
         ("bp_groups", _p(C.c_uint32)),
         ("region_packed", _p(C.c_uint64)),
         ("var_packed", _p(C.c_uint8)),
+        ("bp_packed", _p(C.c_uint32)),
+        ("bp_spilled", _p(C.c_uint32)),
     ]
 
 
@@ -391,8 +393,12 @@ class ResultBatch:
         alone — 8 bytes per region and 1 per call cross PCIe, the wide arrays are None until expand()"""
         n, v = batch.n_regions, batch.n_variants
         self.n_regions, self.n_variants = n, v
-        self.bp_off = np.zeros(n + 1, np.uint32) if bp_groups else None       # compact per-region BASEPAIR groups (avk_result_batch::bp_off / bp_groups)
+        # compact per-region BASEPAIR groups (avk_result_batch::bp_off / bp_groups); bp_groups="packed": one word per region, the groups of the regions that need
+        # more than a word spilled into bp_groups (avk_result_batch::bp_packed / bp_spilled)
+        self.bp_off = np.zeros(n + 1, np.uint32) if bp_groups and bp_groups != "packed" else None
         self.bp_groups = np.zeros((n + v + 1, 4), np.uint32) if bp_groups else None
+        self.bp_packed = np.zeros(max(n, 1), np.uint32) if bp_groups == "packed" else None
+        self.bp_spilled = np.zeros(1, np.uint32) if bp_groups == "packed" else None
         wide = packed != "only"
         self.status = np.full(n, -1, np.int32) if wide else None
         self.ed_h1 = np.zeros(n, np.uint32) if wide else None
@@ -436,6 +442,10 @@ class ResultBatch:
         o.tally = _ptr(self.tally, C.c_uint64)
         if self.bp_off is not None:
             o.bp_off = _ptr(self.bp_off, C.c_uint32)
+            o.bp_groups = _ptr(self.bp_groups, C.c_uint32)
+        if getattr(self, "bp_packed", None) is not None:
+            o.bp_packed = _ptr(self.bp_packed, C.c_uint32)
+            o.bp_spilled = _ptr(self.bp_spilled, C.c_uint32)
             o.bp_groups = _ptr(self.bp_groups, C.c_uint32)
         if self.sequences:
             o.seq_bytes = _ptr(self.seq_bytes, C.c_uint8)

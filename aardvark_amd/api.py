@@ -253,8 +253,8 @@ class Context:
         """a ResultBatch whose arrays live in pinned memory (packed: as ResultBatch)"""
         res = ResultBatch(batch, sequences=False, group_metrics=group_metrics, bp_groups=bp_groups, packed=packed)
         for f in ("status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", "var_observed", "var_class", "var_zyg", "region_packed", "var_packed",
-                  "group_metrics", "bp_off", "bp_groups"):
-            a = getattr(res, f)
+                  "group_metrics", "bp_off", "bp_groups", "bp_packed", "bp_spilled"):
+            a = getattr(res, f, None)
             if a is None:
                 continue
             b = self.host_array(a.shape, a.dtype)

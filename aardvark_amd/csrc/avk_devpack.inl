@@ -1007,10 +1007,33 @@ struct DpOut {
     u32 mode; /* 1: the pair form — no per-call outputs */
     u64 *region_packed; /* the packed form (avk_result_batch::region_packed / var_packed), or NULL; then status may be NULL too */
     u8 *var_packed;
+    /* the packed form of the BASEPAIR groups (avk_result_batch::bp_packed), or NULL: from the kernels' groups (bp_off_dev / bp_dev, 4 counters each) one word per
+     * region; the groups of a region that needs more are spilled behind an atomic counter */
+    const u32 *bp_off_dev, *bp_dev;
+    u32 *bp_packed, *bp_spill, *bp_spill_count;
 };
 AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
     if (r >= o.n_regions) return;
     const avk_u4 w = *(const avk_u4 *)(o.region_out + 4 * r);
+    if (o.bp_packed) {
+        const u32 lo = o.bp_off_dev[r], hi = o.bp_off_dev[r + 1];
+        u32 word = 0;
+        if (w.x == 0 && hi > lo) {
+            const avk_u4 j = *(const avk_u4 *)(o.bp_dev + 4 * (u64)lo);
+            bool simple = (j.x | j.y | j.z | j.w) < 128u;
+            for (u32 k = lo + 1; k < hi && simple; ++k) {
+                const avk_u4 g = *(const avk_u4 *)(o.bp_dev + 4 * (u64)k);
+                simple = g.x == j.x && g.y == j.y && g.z == j.z && g.w == j.w;
+            }
+            if (simple) word = j.x | (j.y << 7) | (j.z << 14) | (j.w << 21);
+            else {
+                const u32 at = avk_atomic_add_u32_global(o.bp_spill_count, hi - lo);
+                for (u32 k = lo; k < hi; ++k) *(avk_u4 *)(o.bp_spill + 4 * (u64)(at + k - lo)) = *(const avk_u4 *)(o.bp_dev + 4 * (u64)k);
+                word = 0x80000000u | at;
+            }
+        }
+        o.bp_packed[r] = word;
+    }
     if (o.status) o.status[r] = (int32_t)w.x;
     if (o.ed_h1) o.ed_h1[r] = w.y;
     if (o.ed_h2) o.ed_h2[r] = w.z;

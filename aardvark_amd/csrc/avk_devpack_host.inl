@@ -1267,6 +1267,15 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         if (out->var_packed) o.var_packed = (uint8_t *)tmp(nvr + 16);
     }
     uint8_t *d_exact = pair_exact ? (uint8_t *)tmp(n + 16) : nullptr;
+    const bool want_bp_packed = out->bp_packed && out->bp_spilled && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0;
+    if (want_bp_packed) {
+        if (later) return done(fail(ctx, AVK_E_STATE, "the packed BASEPAIR groups need a synchronous call"));
+        o.bp_off_dev = db->d_bp_off, o.bp_dev = db->d_bp;
+        o.bp_packed = (uint32_t *)tmp((n + 1) * 4);
+        o.bp_spill = (uint32_t *)tmp(((size_t)db->n_bp_groups + 1) * 16);
+        o.bp_spill_count = (uint32_t *)tmp(256);
+        if (!rc && hipMemsetAsync(o.bp_spill_count, 0, 4, s) != hipSuccess) rc = fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(hipGetLastError()));
+    }
     if (rc) return done(rc);
     if (!ctx->h_dpstate) {
         hipError_t e = hipHostMalloc((void **)&ctx->h_dpstate, sizeof(dpk::DpState) + 16, hipHostMallocDefault);
@@ -1299,7 +1308,15 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         segs.push_back({out->var_packed ? out->var_packed + db->v_lo : nullptr, o.var_packed, out->var_packed ? nvr : 0});
     }
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
-    if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {
+    if (want_bp_packed) { /* how many groups were spilled decides how much is copied: one word back first */
+        uint32_t spilled = 0;
+        hipError_t eb = hipMemcpyAsync(&spilled, o.bp_spill_count, 4, hipMemcpyDeviceToHost, s);
+        if (eb == hipSuccess) eb = hipStreamSynchronize(s);
+        if (eb != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(eb)));
+        out->bp_spilled[0] = spilled;
+        segs.push_back({out->bp_packed, o.bp_packed, n * sizeof(uint32_t)});
+        segs.push_back({out->bp_groups, o.bp_spill, (size_t)spilled * 4 * sizeof(uint32_t)});
+    } else if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {
         segs.push_back({out->bp_off, db->d_bp_off, (n + 1) * sizeof(uint32_t)});
         segs.push_back({out->bp_groups, db->d_bp, (size_t)db->n_bp_groups * 4 * sizeof(uint32_t)});
     }

@@ -979,7 +979,8 @@ int avk_results_expand(const avk_region_batch *b, const avk_result_batch *packed
 
 /* GroupTypeMetrics of one region from its compact BASEPAIR groups and the per-call outputs (include/aardvark_amd.h) */
 int avk_group_metrics_from_compact(const avk_region_batch *b, uint64_t r, const avk_result_batch *res, uint32_t *out) {
-    if (!b || !res || !out || r >= b->n_regions || !((res->var_expected && res->var_observed) || res->var_packed) || !res->bp_off || !res->bp_groups) return AVK_E_ARG;
+    const bool bp_packed = res && res->bp_packed && res->bp_spilled;
+    if (!b || !res || !out || r >= b->n_regions || !((res->var_expected && res->var_observed) || res->var_packed) || !(res->bp_off || bp_packed) || !res->bp_groups) return AVK_E_ARG;
     const bool wide_calls = res->var_expected && res->var_observed; /* otherwise the packed bytes */
     memset(out, 0, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
     uint32_t types = 0;
@@ -1021,13 +1022,26 @@ int avk_group_metrics_from_compact(const avk_region_batch *b, uint64_t r, const 
         }
     }
     /* BASEPAIR from the compact groups (joint, then the region's call types in type order); RECORD_BP from them and the totals (waffle_solver.rs:455-522) */
-    const uint32_t lo = res->bp_off[r], hi = res->bp_off[r + 1];
+    uint32_t simple[4] = {0, 0, 0, 0}; /* the packed form's word: every group of the region is this one */
+    uint32_t lo = 0, hi = 0;
+    bool one_for_all = false;
+    if (bp_packed) {
+        const uint32_t w = res->bp_packed[r], n_groups = 1u + (uint32_t)__builtin_popcount(types);
+        if (avk_bp_is_spilled(w)) {
+            lo = avk_bp_spill_index(w), hi = lo + n_groups;
+            if (hi > res->bp_spilled[0]) return AVK_E_ARG;
+        } else {
+            for (int i = 0; i < 4; ++i) simple[i] = avk_bp_counter(w, i);
+            one_for_all = true, hi = n_groups;
+        }
+    } else
+        lo = res->bp_off[r], hi = res->bp_off[r + 1];
     uint32_t k = lo;
     for (uint32_t left = 1u | (types << 1); left; left &= left - 1, ++k) {
         if (k >= hi) return AVK_E_ARG; /* the region owns no groups (it failed validation) or fewer than its call types */
         const uint32_t g = (uint32_t)__builtin_ctz(left);
         uint32_t *G = out + g * AVK_N_FIELDS;
-        const uint32_t *bp = res->bp_groups + 4 * (size_t)k;
+        const uint32_t *bp = one_for_all ? simple : res->bp_groups + 4 * (size_t)k;
         for (int i = 0; i < 4; ++i) G[AVK_F_BP_TRUTH_TP + i] = bp[i];
         G[AVK_F_RBP_TRUTH_TP] = (uint32_t)(2 * tot[0][g] - bp[1]);
         G[AVK_F_RBP_TRUTH_FN] = bp[1];
@@ -2246,7 +2260,8 @@ static int results_download_impl(avk_ctx *ctx, avk_dev_batch *db, avk_result_bat
             CapacityFix fx;
             const bool dev_gm = ctx->emit_group_metrics && db->d_gm; /* the batch keeps per-region blocks on the device (avk_label_tallies reads them) */
             const bool want_gm = (out->group_metrics && ctx->emit_group_metrics && db->d_gm) || dev_gm;
-            const bool want_bp = out->bp_off && out->bp_groups && db->d_bp;
+            const bool want_bp_words = out->bp_packed && out->bp_spilled && out->bp_groups && db->d_bp;
+            const bool want_bp = (out->bp_off && out->bp_groups && db->d_bp) || want_bp_words;
             const int rc = rerun_capacity_regions(ctx, db, cap, want_gm, want_seq, want_bp, slice, &fx);
             if (rc == AVK_E_OOM) break; /* the device cannot hold slices of this size: the regions keep their status */
             if (rc) { /* reported after the statistics and the shared slices are back as they were (below) */
@@ -2277,7 +2292,12 @@ static int results_download_impl(avk_ctx *ctx, avk_dev_batch *db, avk_result_bat
                     put_call(db->host.dev2host[dr.v_off + i], fx.ve[sv], fx.vo[sv], fx.vc[sv], fx.vz[sv]);
                 }
                 if (want_gm && out->group_metrics) memcpy(out->group_metrics + (size_t)r * AVK_N_GROUPS * AVK_N_FIELDS, fx.gm.data() + (size_t)k * AVK_N_GROUPS * AVK_N_FIELDS, sizeof(uint32_t) * AVK_N_GROUPS * AVK_N_FIELDS);
-                if (want_bp && out->bp_off[r + 1] - out->bp_off[r] == fx.bp_off[k + 1] - fx.bp_off[k]) /* the same calls, so the same groups */
+                if (want_bp_words) { /* the packed form: the repaired region's groups join the spilled ones */
+                    const uint32_t ng = fx.bp_off[k + 1] - fx.bp_off[k], at = out->bp_spilled[0];
+                    memcpy(out->bp_groups + 4 * (size_t)at, fx.bp.data() + 4 * (size_t)fx.bp_off[k], 16 * (size_t)ng);
+                    out->bp_packed[r] = AVK_BP_SPILL | at;
+                    out->bp_spilled[0] = at + ng;
+                } else if (want_bp && out->bp_off[r + 1] - out->bp_off[r] == fx.bp_off[k + 1] - fx.bp_off[k]) /* the same calls, so the same groups */
                     memcpy(out->bp_groups + 4 * (size_t)out->bp_off[r], fx.bp.data() + 4 * (size_t)fx.bp_off[k], 16 * (size_t)(fx.bp_off[k + 1] - fx.bp_off[k]));
                 if (want_seq)
                     for (int q = 0; q < 5; ++q) {
@@ -2413,7 +2433,7 @@ int avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const
              is_pinned(out->var_packed, nv) && is_pinned(out->group_metrics, n * AVK_N_GROUPS * AVK_N_FIELDS * 4);
     const bool seq_out = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && cfg->enable_sequences;
     int slot = -1;
-    const bool can_queue = pinned && !seq_out && !(out->bp_off && out->bp_groups);
+    const bool can_queue = pinned && !seq_out && !((out->bp_off || out->bp_packed) && out->bp_groups);
     for (int i = 0; i < 4 && slot < 0 && can_queue; ++i)
         if (!ctx->stage[i].busy) {
             slot = i;
@@ -2715,7 +2735,7 @@ int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_co
     avk_dev_batch *db = nullptr;
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
-    if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
+    if ((out->bp_off || (out->bp_packed && out->bp_spilled)) && out->bp_groups) ctx->emit_bp_groups = 1;
     const auto t0 = std::chrono::steady_clock::now();
     int rc = avk_batch_upload_packed(ctx, batch, &db);
     const auto t1 = std::chrono::steady_clock::now();
@@ -2763,7 +2783,7 @@ int avk_compare_compact(avk_ctx *ctx, const avk_compact_batch *batch, const avk_
     avk_dev_batch *db = nullptr;
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
-    if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
+    if ((out->bp_off || (out->bp_packed && out->bp_spilled)) && out->bp_groups) ctx->emit_bp_groups = 1;
     int rc = avk_batch_upload_compact(ctx, batch, &db);
     if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);
     if (!rc) rc = avk_results_download(ctx, db, out);
@@ -2784,7 +2804,7 @@ int avk_compare_batch(avk_ctx *ctx, const avk_region_batch *batch, const avk_com
     /* per-region metric blocks only when the caller has an array for them */
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
-    if (out->bp_off && out->bp_groups) ctx->emit_bp_groups = 1;
+    if ((out->bp_off || (out->bp_packed && out->bp_spilled)) && out->bp_groups) ctx->emit_bp_groups = 1;
     int rc = avk_batch_upload(ctx, batch, &db);
     const auto t1 = std::chrono::steady_clock::now();
     if (!rc) rc = avk_compare_resident(ctx, db, cfg, nullptr);

@@ -378,7 +378,11 @@ def main():
     if form == "packed" and not args.pageable and world == 1:
         sets = [(hb, res), (ctx.pinned_packed(hb), ctx.pinned_results(hb, packed=res_form))]
         n_p = max(4, min(args.steps, 20))
-        tk = ctx.submit_packed(sets[0][0], config=cfg, res=sets[0][1])
+        tk = ctx.submit_packed(sets[0][0], config=cfg, res=sets[0][1])  # warm-up in the timed pattern: the second batch in flight takes a second set of device buffers
+        for k in range(1, 5):
+            nxt = ctx.submit_packed(sets[k & 1][0], config=cfg, res=sets[k & 1][1])
+            tk.wait()
+            tk = nxt
         tk.wait()
         fence()
         tp0 = time.perf_counter()
@@ -401,6 +405,38 @@ def main():
             print("PARITY FAILURE in the pipelined leg", file=sys.stderr)
             sys.exit(3)
         del sets
+    # the value leg's call returning the FULL CompareBenchmark: with the per-region BASEPAIR groups (compare_benchmark.rs:9-33; the "all 8 types" loop of
+    # waffle_solver.rs:384-445) in their packed form — one word per region, the groups of multi-type regions spilled (avk_result_batch::bp_packed)
+    bp_entry = None
+    if form == "packed" and not args.pageable:
+        from aardvark_amd.api import group_metrics_from_compact
+        rbp = ctx.pinned_results(hb, packed=res_form, bp_groups="packed")
+        cbp = hb.c_struct()
+        rbo = rbp.c_struct()
+        ctx._check(entry_point(ctx.handle, C.byref(cbp), C.byref(ccfg), C.byref(rbo)))
+        n_b = max(3, min(args.steps, 20))
+        fence()
+        tb0 = time.perf_counter()
+        for _ in range(n_b):
+            ctx._check(entry_point(ctx.handle, C.byref(cbp), C.byref(ccfg), C.byref(rbo)))
+        fence()
+        b_elapsed = time.perf_counter() - tb0
+        b_solver_ms = ctx.last_solver_ms()
+        spilled = int(rbp.bp_spilled[0])
+        same = (np.array_equal(rbp.region_packed, res_ref_rp) and np.array_equal(rbp.var_packed, res_ref_vp)) if res_form else rbp.diff(got_boundary) == []
+        alg_g = ctx.algorithmic_bytes(batch, with_groups=True)
+        bp_entry = {"value": total_regions * n_b / b_elapsed, "unit": "regions/s", "ms_per_step": b_elapsed / n_b * 1e3, "steps": n_b,
+                    "extra_ms_over_value_leg": b_elapsed / n_b * 1e3 - elapsed / max(args.steps, 1) * 1e3,
+                    "host_bytes_out_per_step_extra": 4 * n_regions + 16 * spilled, "bytes_per_region_extra": (4 * n_regions + 16 * spilled) / max(n_regions, 1),
+                    "regions_in_one_word": int(n_regions - int(((rbp.bp_packed[:n_regions] & np.uint32(0x80000000)) != 0).sum())), "spilled_groups": spilled,
+                    "same_records_and_calls_as_value_leg": bool(same),
+                    "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg_g), "bytes_per_region": alg_g / max(n_regions, 1), "kernel_ms": b_solver_ms,
+                                 "achieved": alg_g / max(b_solver_ms, 1e-9) / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": alg_g / max(b_solver_ms, 1e-9) / 1e6 / 8000.0},
+                    "what": "the value leg's call returning per-region BASEPAIR groups as well (emit_bp_groups; avk_result_batch::bp_packed / bp_spilled / bp_groups): with the per-call "
+                            "decisions they are the region's whole GroupTypeMetrics (avk_group_metrics_from_compact)"}
+        bp_check = (rbp, group_metrics_from_compact)
+        log("with BASEPAIR groups: %.3f ms per call (+%.3f), %.2f extra bytes per region, %d groups spilled" % (bp_entry["ms_per_step"], bp_entry["extra_ms_over_value_leg"],
+                                                                                                              bp_entry["bytes_per_region_extra"], spilled))
     # the same boundary with the batch in the compact form (avk_compact_batch: 20 B per region + 17 B per call, explicit offsets), when `value` is on the packed one
     compact_entry = None
     if form == "packed":
@@ -494,6 +530,20 @@ def main():
         cpu_rate_parity = (time.perf_counter() - tp, n_regions)
         byte_compares = oracle_lib.stats(lib).get("byte_compares")
         bad = ["boundary:" + x for x in got_boundary.diff(want)] + ["wide_boundary:" + x for x in wres.diff(want)] + ["resident:" + x for x in got.diff(want)]
+        if bp_entry is not None:  # the full 13 x 22 block of every region of the first contig, rebuilt from the packed groups + the per-call decisions, against the oracle's
+            n0 = int((batch.contig_idx == batch.contig_idx[0]).sum()) if batch.contig_idx is not None else min(n_regions, 200_000)
+            n0 = min(n0, 300_000)
+            sub = batch.slice(0, n0)  # (shares the call arrays: the results' per-call arrays are indexed as the whole batch's)
+            if True:
+                want0 = oracle_lib.compare_batch(lib, sub, cs, threads=cpus, group_metrics=True)
+                rbp, from_compact = bp_check
+                exp = rbp.expanded(ctx.lib, batch) if res_form else rbp
+                exp.bp_packed, exp.bp_spilled, exp.bp_groups, exp.bp_off = rbp.bp_packed, rbp.bp_spilled, rbp.bp_groups, None
+                full = from_compact(sub, exp)
+                ok0 = want0.status == 0
+                if not np.array_equal(full[ok0], want0.group_metrics[ok0]):
+                    bad.append("bp_groups_full_blocks")
+                bp_entry["parity"] = "the 13 x 22 blocks of the first %d regions (one contig) rebuilt from the packed groups equal the oracle's" % n0 if "bp_groups_full_blocks" not in bad else "MISMATCH"
         # the job total must be steps x this rank's tally, summed over the ranks
         mine = want.tally.astype(np.int64)
         if use_dist:
@@ -574,6 +624,7 @@ def main():
             "resident": resident,
             "wide_results": wide_results_entry,
             "pipelined": pipelined_entry,
+            "with_bp_groups": bp_entry,
             "process": ("PyTorch loaded: the process runs on the HIP runtime the wheel bundles (torch/lib/libamdhip64.so)" if use_torch else
                         "one rank, PyTorch not loaded: the process runs on the system's HIP runtime, the one libaardvark_amd.so is linked with (--torch loads it as N > 1 ranks do)"),
             "compact_soa": compact_entry,

@@ -230,7 +230,23 @@ typedef struct avk_result_batch {
      *                      side the call is on (variant_metrics.rs:43-101): avk_vp_class */
     uint64_t *region_packed; /* [n_regions] */
     uint8_t  *var_packed;    /* [n_variants] */
+
+    /* The BASEPAIR groups in their packed form (optional; hand in bp_packed, bp_spilled AND bp_groups, leave bp_off NULL): one word per region instead of
+     * 4 + 16 x (1 + call types) bytes.  A region whose groups all equal its joint group — every region with calls of ONE type: a side filtered to the type it
+     * consists of is the side itself (waffle_solver.rs:383-445) — and whose four counters are below 128 is that word:
+     *   bp_packed[r] = truth_tp | truth_fn << 7 | query_tp << 14 | query_fp << 21                         (bit 31 clear)
+     * any other region's groups (the joint one, then one per call type, as above) are SPILLED into bp_groups, in no particular order:
+     *   bp_packed[r] = 0x80000000 | index of the region's first group in bp_groups
+     * bp_spilled[0] = number of groups in bp_groups.  A genome's regions need 4 + ~2.5 bytes each this way instead of 36 (profiles/r05_bp_packed.txt); regions with a
+     * non-zero status hold 0.  avk_group_metrics_from_compact reads either form.  Device-packed batches only (option device_pack, the default). */
+    uint32_t *bp_packed;     /* [n_regions] */
+    uint32_t *bp_spilled;    /* [1] */
 } avk_result_batch;
+
+#define AVK_BP_SPILL 0x80000000u
+static inline int      avk_bp_is_spilled(uint32_t w) { return (w & AVK_BP_SPILL) != 0; }
+static inline uint32_t avk_bp_spill_index(uint32_t w) { return w & 0x7FFFFFFFu; }
+static inline uint32_t avk_bp_counter(uint32_t w, int i) { return (w >> (7 * i)) & 0x7Fu; } /* i: 0 truth_tp, 1 truth_fn, 2 query_tp, 3 query_fp */
 
 #define AVK_RP_ED_MAX 0xFFFFFu
 /* the 8 variant types add_basepair_stats filters by (waffle_solver.rs:383-445): a solved region has map entries for them whether they occur or not */

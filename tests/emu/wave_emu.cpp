@@ -520,7 +520,13 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     a.seq_bytes = want_seq ? out->seq_bytes : nullptr;
     a.seq_len = want_seq ? out->seq_len : nullptr;
     a.tally = partials.data();
-    std::vector<uint32_t> bp_off_host; /* compact BASEPAIR groups (avk_result_batch::bp_groups): offsets as the packers count them, written straight to the caller's array */
+    std::vector<uint32_t> bp_off_host, bp_dev; /* compact BASEPAIR groups (avk_result_batch::bp_groups): offsets as the packers count them, written straight to the caller's array */
+    const bool bp_packed = out->bp_packed && out->bp_spilled && out->bp_groups && !out->bp_off && mode == 0 && devpack; /* the packed form: dp_unpack makes it from the kernels' groups */
+    if (bp_packed) {
+        bp_dev.assign(4 * ((size_t)dpr.bp_off[n] + 1), 0);
+        a.bp_off = dpr.bp_off.data();
+        a.bp_out = bp_dev.data();
+    }
     if (out->bp_off && out->bp_groups && mode == 0) {
         if (devpack) memcpy(out->bp_off, dpr.bp_off.data(), (n + 1) * sizeof(uint32_t));
         else {
@@ -1023,6 +1029,10 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         o.status = out->status, o.ed_h1 = out->ed_h1, o.ed_h2 = out->ed_h2, o.n_optima = out->n_optima, o.type_present = out->type_present;
         o.var_expected = out->var_expected, o.var_observed = out->var_observed, o.var_class = out->var_class, o.var_zyg = out->var_zyg;
         o.region_packed = out->region_packed, o.var_packed = out->var_packed;
+        if (bp_packed) {
+            out->bp_spilled[0] = 0;
+            o.bp_off_dev = dpr.bp_off.data(), o.bp_dev = bp_dev.data(), o.bp_packed = out->bp_packed, o.bp_spill = out->bp_groups, o.bp_spill_count = out->bp_spilled;
+        }
         for (uint64_t r = 0; r < n; ++r) dpk::dp_unpack(o, r);
     }
     /* copy back in caller order */

@@ -24,6 +24,24 @@ def check(batch, got, want):
             assert n_groups[r] == 1 + len(types)
 
 
+def check_packed(batch, got, want):
+    """the packed form of the groups (avk_result_batch::bp_packed): one word per region, the others' groups spilled; same full blocks"""
+    assert np.array_equal(got.status, want.status)
+    full = group_metrics_from_compact(batch, got)
+    ok = want.status == 0
+    assert np.array_equal(full[ok], want.group_metrics[ok])
+    spilled = (got.bp_packed[:batch.n_regions] & np.uint32(0x80000000)) != 0
+    assert not spilled[~ok].any() and (got.bp_packed[:batch.n_regions][~ok] == 0).all()
+    # a region with calls of one type and small counters is one word
+    for r in np.nonzero(ok)[0]:
+        types = set(int(batch.var_type[v]) for off, cnt in ((batch.t_off[r], batch.t_cnt[r]), (batch.q_off[r], batch.q_cnt[r])) for v in range(int(off), int(off) + int(cnt)))
+        bp = want.group_metrics[r][0][18:22] if False else None
+        if len(types) == 1 and int(want.group_metrics[r, 0].max()) < 128:
+            assert not spilled[r], r
+    assert int(got.bp_spilled[0]) == sum(1 + len(set(int(batch.var_type[v]) for off, cnt in ((batch.t_off[r], batch.t_cnt[r]), (batch.q_off[r], batch.q_cnt[r]))
+                                                         for v in range(int(off), int(off) + int(cnt)))) for r in np.nonzero(spilled)[0])
+
+
 def cases(light=False):
     """light: without the four long-allele regions and with fewer fuzz regions (the emulator needs seconds for each of the former)"""
     yield scenarios.golden()
@@ -48,6 +66,8 @@ def test_compact_groups_rebuild_the_full_block_kernel_logic(oracle, lane_kernel)
                 want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
                 got = emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel, group_metrics=False, bp_groups=True, threads=8)
                 check(batch, got, want)
+                if devpack == 2:  # the packed form is made by the device packer's result kernel
+                    check_packed(batch, emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel, group_metrics=False, bp_groups="packed", threads=8), want)
         finally:
             lib.emu_set_device_pack(0)
 
@@ -68,6 +88,8 @@ def test_compact_groups_on_the_gpu(oracle, device_pack):
                 ctx.upload_reference(contigs)
                 got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False, bp_groups=True)
                 check(batch, got, want)
+                if device_pack:
+                    check_packed(batch, ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False, bp_groups="packed"), want)
         # a contig at the benchmark's density: the compact groups cost 16 B x (1 + types) per region
         contig, batch = synth.config_indel_mix_v2(n_truth=60_000, contig_len=24_000_000)
         ctx.set_option("lane_kernel", 1)
@@ -76,5 +98,9 @@ def test_compact_groups_on_the_gpu(oracle, device_pack):
         got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False, bp_groups=True)
         check(batch, got, want)
         assert got.bp_off[-1] * 16 < 0.04 * want.group_metrics.nbytes
+        if device_pack:
+            got = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False), group_metrics=False, bp_groups="packed", packed=True)
+            check_packed(batch, got, want)
+            assert 4 * batch.n_regions + 16 * int(got.bp_spilled[0]) < 8 * batch.n_regions  # under 8 bytes per region
     finally:
         ctx.close()
