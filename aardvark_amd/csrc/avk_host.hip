@@ -2540,6 +2540,10 @@ int avk_wait(avk_ctx *ctx, avk_ticket *t) {
 
 int avk_last_compare_was_one_shot(avk_ctx *ctx) { return ctx ? ctx->last_one_shot : 0; }
 
+} /* extern "C" */
+#include "avk_shard_host.inl"
+extern "C" {
+
 /* pinned host memory for the caller's batch and result arrays: arrays that live there are copied by DMA, no host pass (pageable arrays go through
  * a pinned bounce buffer that the host threads fill) */
 void *avk_host_alloc(avk_ctx *ctx, size_t bytes) {

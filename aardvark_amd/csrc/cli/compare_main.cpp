@@ -5,6 +5,7 @@
  * (src/cli/compare.rs), --stratification included.  Outputs: summary.tsv, truth.vcf.gz, query.vcf.gz (+ .tbi).
  * --output-debug writes cli_settings.json, region_summary.tsv.gz and region_sequences.tsv.gz.
  */
+#include <dlfcn.h>
 #include <atomic>
 #include <mutex>
 #include <cerrno>
@@ -343,7 +344,94 @@ int main(int argc, char **argv) {
      * solves the batches it draws, the tallies are summed on the host (the sum the benchmark does with one RCCL all-reduce across
      * processes).  The debug tables are written in region order by one context. */
     const size_t n_workers = debug || devices.size() < 2 ? 1 : devices.size();
-    if (n_workers > 1) {
+    /* --devices with the packed feed and no stratification: the job is cut by the library's ONE rule, shard = hash(region_id) % ranks (avk_region_shard, the rule of
+     * aardvark_amd/dist.py), every context solves its shard, and the job tally is summed over the ranks — by one RCCL all-reduce (avk_tally_allreduce) when every
+     * context has a GPU of its own, on the host when entries repeat (RCCL does not take two ranks on one device). */
+    bool sharded = false;
+    if (n_workers > 1 && packed && !n_labels) {
+        sharded = true;
+        avk_packed_batch sel;
+        uint64_t sel_v = 0;
+        if (avf_packed_slice(feed, &packed_all, first, count, &sel, &sel_v)) die(70, "cannot select the regions", avf_last_error());
+        bool distinct = true;
+        for (size_t i = 0; i < n_workers; ++i)
+            for (size_t j = i + 1; j < n_workers; ++j) distinct = distinct && devices[i] != devices[j];
+        std::vector<void *> comms(n_workers, nullptr);
+        if (distinct) { /* one communicator per context, made here (ncclCommInitAll of RCCL, looked up at run time: the tool does not link it) */
+            typedef int (*init_all_fn)(void **, int, const int *);
+            void *h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            init_all_fn init_all = h ? (init_all_fn)dlsym(h, "ncclCommInitAll") : nullptr;
+            if (!init_all || init_all(comms.data(), (int)n_workers, devices.data()) != 0) {
+                if (verbosity) fprintf(stderr, "RCCL is not available (%s): the ranks' tallies are summed on the host.\n", h ? "ncclCommInitAll failed" : "librccl.so not found");
+                distinct = false;
+            }
+        }
+        std::vector<std::string> worker_err(n_workers);
+        std::vector<std::vector<uint64_t>> w_total(n_workers, std::vector<uint64_t>(AVK_TALLY_LEN, 0));
+        std::mutex log_mutex;
+        auto shard_worker = [&](size_t w) {
+            avk_ctx *my = ctx;
+            if (w > 0) {
+                my = nullptr;
+                if (avk_ctx_create(devices[w], &my)) {
+                    worker_err[w] = std::string("cannot create the GPU context: ") + avk_last_error(nullptr);
+                    return;
+                }
+                const uint32_t n_contigs = avf_genome_n_contigs(genome);
+                std::vector<const uint8_t *> seqs(n_contigs);
+                std::vector<uint64_t> lens(n_contigs);
+                for (uint32_t c = 0; c < n_contigs; ++c) seqs[c] = avf_genome_seq(genome, c), lens[c] = avf_genome_len(genome, c);
+                if (avk_ref_upload(my, n_contigs, seqs.data(), lens.data())) { /* the reference is replicated: 0.8 GB packed per rank */
+                    worker_err[w] = std::string("reference upload failed: ") + avk_last_error(my);
+                    avk_ctx_destroy(my);
+                    return;
+                }
+                (void)avk_ctx_set_option(my, "emit_group_metrics", 0);
+            }
+            avk_packed_shard *shard = nullptr;
+            if (avk_packed_shard_make(&sel, all->region_id + first, 0, (uint32_t)w, (uint32_t)n_workers, &shard)) worker_err[w] = "cannot cut the shard";
+            else {
+                const avk_packed_batch *sb = avk_packed_shard_batch(shard);
+                std::vector<int32_t> s_status(sb->n_regions + 1);
+                std::vector<uint8_t> s_e(sb->n_variants + 1), s_o(sb->n_variants + 1), s_c(sb->n_variants + 1);
+                avk_result_batch so;
+                memset(&so, 0, sizeof(so));
+                so.status = s_status.data(), so.var_expected = s_e.data(), so.var_observed = s_o.data(), so.var_class = s_c.data(), so.tally = w_total[w].data();
+                if (avk_compare_packed(my, sb, &cfg, &so)) worker_err[w] = std::string("compare failed: ") + avk_last_error(my);
+                else {
+                    avk_result_batch to; /* the selected regions' part of the job's arrays: regions from `first`, calls from the selection's first call */
+                    memset(&to, 0, sizeof(to));
+                    to.status = status.data() + first, to.var_expected = var_expected.data() + sel_v, to.var_observed = var_observed.data() + sel_v, to.var_class = var_class.data() + sel_v;
+                    (void)avk_packed_shard_scatter(shard, &so, &to);
+                    const uint64_t *idx = nullptr;
+                    const uint64_t m = avk_packed_shard_regions(shard, &idx);
+                    for (uint64_t k = 0; k < m; ++k)
+                        if (s_status[k] != 0) {
+                            std::lock_guard<std::mutex> lock(log_mutex);
+                            avk_region_batch b1 = *all;
+                            b1.region_id = all->region_id + first, b1.contig_idx = all->contig_idx + first, b1.start = all->start + first, b1.end = all->end + first;
+                            b1.t_off = all->t_off + first, b1.t_cnt = all->t_cnt + first, b1.q_off = all->q_off + first, b1.q_cnt = all->q_cnt + first;
+                            report_unsolved(b1, idx[k], s_status[k]);
+                        }
+                    if (distinct && avk_tally_allreduce(my, comms[w], w_total[w].data())) worker_err[w] = std::string("tally all-reduce failed: ") + avk_last_error(my);
+                }
+                avk_packed_shard_free(shard);
+            }
+            if (w > 0) avk_ctx_destroy(my);
+        };
+        std::vector<std::thread> pool;
+        for (size_t w = 1; w < n_workers; ++w) pool.emplace_back(shard_worker, w);
+        shard_worker(0);
+        for (std::thread &t : pool) t.join();
+        for (size_t w = 0; w < n_workers; ++w)
+            if (!worker_err[w].empty()) die(70, worker_err[w].c_str(), "");
+        if (distinct) total = w_total[0]; /* every rank holds the job's sums */
+        else
+            for (size_t w = 0; w < n_workers; ++w)
+                for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += w_total[w][k];
+        if (verbosity) fprintf(stderr, "%zu contexts, regions sharded by hash(region_id) %% %zu; the job tally summed %s.\n", n_workers, n_workers, distinct ? "by one RCCL all-reduce" : "on the host");
+    }
+    if (n_workers > 1 && !sharded) {
         if (!batch_given) { /* about two batches per context */
             batch_regions = (count + 2 * n_workers - 1) / (2 * n_workers);
             if (batch_regions < 100000) batch_regions = 100000;

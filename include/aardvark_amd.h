@@ -372,6 +372,31 @@ int  avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_c
  * Every array of `batch` and `out` must be pinned (avk_host_alloc) for the copies to run beside anything: a batch with a pageable array, with sequence outputs
  * or compact BASEPAIR groups is solved inside the submit (its ticket is complete).  The submit blocks once, while the packer's plan comes back to the host —
  * behind the batch submitted before.  Results are those of avk_compare_packed, bit for bit (tests/test_gpu_async.py). */
+/* ---- several GPUs: regions are independent, so a job is cut by ONE rule — shard = hash(region_id) % ranks (region ids are sequential in genome
+ * order, region_generation.rs:403-409, the hash spreads dense loci over the ranks) — every rank solves its shard, and the job tally is one all-reduce
+ * (SummaryWriter::add_comparison_benchmark over all regions, writers/summary.rs:146-163).  aardvark_amd/dist.py states the same hash for the Python side. */
+static inline uint64_t avk_region_hash(uint64_t x) { /* splitmix64's finaliser */
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+static inline uint32_t avk_region_shard(uint64_t region_id, uint32_t ranks) { return (uint32_t)(avk_region_hash(region_id) % ranks); }
+/* the regions of `whole` that rank `rank` of `world` owns (region_id[r], or first_id + r when region_id is NULL), gathered into a packed batch of their own in the
+ * whole batch's order; avk_packed_shard_scatter writes a result batch of the shard into the arrays of the whole batch (per-region arrays by region, per-call arrays
+ * by call; the tally is left to the caller: add the ranks' tallies, or avk_tally_allreduce) */
+typedef struct avk_packed_shard avk_packed_shard;
+int  avk_packed_shard_make(const avk_packed_batch *whole, const uint64_t *region_id, uint64_t first_id, uint32_t rank, uint32_t world, avk_packed_shard **out);
+const avk_packed_batch *avk_packed_shard_batch(const avk_packed_shard *s);
+uint64_t avk_packed_shard_regions(const avk_packed_shard *s, const uint64_t **index_in_whole);
+int  avk_packed_shard_scatter(const avk_packed_shard *s, const avk_result_batch *shard_results, avk_result_batch *whole_results);
+void avk_packed_shard_free(avk_packed_shard *s);
+/* tally[AVK_TALLY_LEN] (host) summed over the ranks of an RCCL communicator (ncclComm_t), on the context's stream: the job's one collective.  Every rank calls it
+ * with its own context and communicator; RCCL is looked up in the process (the caller that made the communicator loaded it), not linked. */
+int  avk_tally_allreduce(avk_ctx *ctx, void *nccl_comm, uint64_t *tally);
+
 typedef struct avk_ticket avk_ticket;
 int  avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket);
 int  avk_wait(avk_ctx *ctx, avk_ticket *ticket);
