@@ -346,7 +346,7 @@ struct avk_ctx {
     int64_t bulk_fit = 1;       /* 1: no more workgroups in the bulk launch than its list has regions for (a genome leaves it three dozen regions: 664 workgroups of 40 KB of
                                    LDS queued for them beside the lane launches) */
     int64_t ws_bytes_per_wave = 1 << 20;
-    int64_t big_ws_bytes = 256ll << 20;
+    int64_t big_ws_bytes = 64ll << 20; /* (256 MB until round 5: the shared slices were 2.1 GB of a fresh process's first hipMalloc; a batch whose packer predicts larger regions gets 1 GB slices, upload_device_packed) */
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
     int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
@@ -382,8 +382,8 @@ struct avk_ctx {
     int64_t lane_head_stream = 0;                     /* 1: the heads of the two-call classes on a stream of their own (a synchronised step: 5.4 -> 5.1 ms;
                                                          steps queued back to back: 6.0 -> 6.5 ms — more streams, worse starts; off) */
     int64_t lane_min_batch = 16384;                   /* a RESIDENT batch with fewer lane regions than this is solved by the wave-per-region kernels alone (not applied when lane_min_regions is 0, nor by the one-shot path of avk_compare_batch) */
-    int64_t hbm_early_blocks = 256;                   /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
-    int64_t hbm_solo_blocks = 128;                    /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
+    int64_t hbm_early_blocks = 64;                    /* workgroups (x 4 waves, 1 MB of HBM workspace each) of the launch behind the three-call lane class */
+    int64_t hbm_solo_blocks = 64;                     /* most workgroups (x 4 waves, 1 MB of HBM workspace each) of the HBM solo launch */
     int64_t lane_node_cap = 32;                       /* search nodes the three-call lane class makes before it hands a region over */
     int64_t lane_quad = 1;                            /* 1: lane launches of at most 16 records per wave (the heads, the three-call class) run four lanes per region: avk_quad_kernel, avk_quad.inl */
     int64_t lane_pool = -1;                           /* node states a lane keeps during its search (avk_lane.inl NodePool): -1 = by class (2 / 4 / 6 for one / two / three calls per side), 0 = none */
@@ -1301,6 +1301,10 @@ static int ensure_pair_table(avk_ctx *ctx, uint32_t max_branch_factor, hipStream
     return AVK_E_OK;
 }
 
+/* workgroups (x 4 waves x ws_bytes_per_wave of HBM) of the main HBM-tier launch of a batch that has lane launches.  Every wave of the grid needs a slice, and fresh device
+ * memory is scrubbed when it is handed out (75 ms per GB): n_cus x 3 workgroups were 3 of the 4.8 GB a process's first whole-genome call waited 0.39 s for
+ * (profiles/r05_first_solve.txt); the step does not notice the difference (profiles/r05_quad_sweeps.txt) */
+#define AVK_HBM_BLOCKS_BESIDE_LANES 192u
 static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_config *cfg, void *tally_dev, uint32_t mode) {
     if (!ctx || !db || !cfg) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));
@@ -1359,6 +1363,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
      * the work list empty anyway, and every wave of the grid needs a slice of HBM (fresh device memory is scrubbed when it is handed
      * out: 13 GB of workspaces cost 0.25 s at the first call of a process, 4 GB a third of that) */
     uint32_t hbm_blocks = (uint32_t)ctx->n_cus * 3u;
+    if (use_fast && n - n_fast <= 16384 && hbm_blocks > AVK_HBM_BLOCKS_BESIDE_LANES) hbm_blocks = AVK_HBM_BLOCKS_BESIDE_LANES; /* lane launches that leave the other kernels a few thousand regions leave this tier a few dozen (a genome: 27) */
     if (hbm_blocks > blocks) hbm_blocks = blocks;
     /* the HBM solo launch runs beside the main stream's HBM launch: its (at most 64) workgroups have slices of their own, after the others */
     uint32_t hbm_solo_max = (uint32_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128);
@@ -2602,7 +2607,7 @@ static void warm_kernels(int device) {
     (void)avk_ctx_set_option(t, "ws_bytes_per_wave", 256 << 10); /* (the warm-up's regions are tiny: 0.4 GB of slices instead of 1.7 — what this context frees at its end is
                                                                    memory the caller's first call may be handed next, and has to wait for while it is scrubbed) */
     (void)avk_ctx_set_option(t, "class_c_nodes_x2", 1000); /* every region the lanes do not take is planned as class C: the wide kernel, the HBM launches */
-    (void)avk_ctx_set_option(t, "lane_node_cap", 4);       /* ... and the three-call class hands back */
+    (void)avk_ctx_set_option(t, "lane_node_cap", 8);       /* ... and the three-call class hands back (8: the option's smallest value) */
     const uint32_t L = 120, n_contig = 1u << 16;
     std::vector<uint8_t> contig(n_contig);
     uint32_t x = 12345u;
@@ -2655,6 +2660,13 @@ int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hi
     if (rc) return rc;
     warm_kernels(ctx->device);
     unsigned *d_scratch = nullptr;
+    struct ScratchGuard { /* released on every way out, the AVK_HIP early returns included */
+        unsigned *&p;
+        ~ScratchGuard() {
+            if (p) (void)hipFree(p);
+            p = nullptr;
+        }
+    } scratch_guard{d_scratch};
     AVK_HIP(ctx, hipMalloc((void **)&d_scratch, (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1) * sizeof(uint64_t) + AVK_N_COUNTERS * sizeof(uint32_t)));
     AVK_HIP(ctx, hipMemsetAsync(d_scratch, 0, (size_t)AVK_TALLY_STRIDE * (AVK_TALLY_COPIES + 1) * sizeof(uint64_t) + AVK_N_COUNTERS * sizeof(uint32_t), ctx->stream));
     uint64_t *parts = (uint64_t *)d_scratch;
@@ -2668,52 +2680,50 @@ int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hi
     }
     if (ctx->lane_kernel && ctx->lane_pairs) {
         rc = ensure_pair_table(ctx, 50, ctx->stream);
-        if (rc) {
-            (void)hipFree(d_scratch);
-            return rc;
-        }
+        if (rc) return rc;
     }
-    if (n_regions_hint >= 65536 && !getenv("AVK_WARM_POOL")) {
-        /* Device memory is scrubbed when it is handed out, at some 35-90 GB/s: the first whole-genome call of a process asks for 2.5 GB of buffers and 7 GB of workspaces and
-         * waited 0.1-0.2 s for them.  Memory that this process has been handed once and has given back comes back at once — so as much as that call will ask for is taken
-         * and released here, on the thread that runs beside the caller's parsing.  (Found by accident: the warm-up context above used to size 44 GB of workspaces for its 448
-         * regions, and the tool's solve stage was 0.02-0.04 s; with that fixed it became 0.15-0.2 s.) */
-        const size_t waves = ((size_t)ctx->n_cus * 3u + (size_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128) + (size_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64)) * 4u;
-        size_t ahead = waves * (size_t)ctx->ws_bytes_per_wave + (size_t)(ctx->big_waves < 64 ? ctx->big_waves : 64) * (size_t)ctx->big_ws_bytes + (size_t)n_regions_hint * 420u +
-                       (size_t)n_variants_hint * 130u + ((size_t)1 << 30);
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && ahead > free_b / 2) ahead = free_b / 2;
-        void *blk = nullptr;
-        if (ahead && hipMalloc(&blk, ahead) == hipSuccess) (void)hipFree(blk);
-        else (void)hipGetLastError();
-    }
-    if (ctx->device_pack && n_regions_hint >= 65536 && getenv("AVK_WARM_POOL")) { /* (measured in the tool: the 2.5 GB of buffers and the 7 GB of workspaces below take longer
-                                                                                        than the parsing they run beside — the solve stage waited for them; off unless asked for) */
-        rc = pool_prewarm(ctx, n_regions_hint, n_variants_hint);
-        if (rc) {
-            (void)hipFree(d_scratch);
-            return rc;
-        }
-    }
-    if (n_regions_hint >= 65536 && ctx->ws_bytes_per_wave > 0 && getenv("AVK_WARM_POOL")) { /* the workspaces run_internal sizes for a batch of a genome's size (its lane classes leave a few thousand regions) */
-        const size_t waves = ((size_t)ctx->n_cus * 3u + (size_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128) + (size_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64)) * 4u;
+    if (n_regions_hint >= 65536 && ctx->ws_bytes_per_wave > 0) {
+        /* The workspaces run_internal sizes for a batch of a genome's size, allocated HERE, on the thread that runs beside the caller's parsing: hipMalloc of the
+         * 4.8 + 2.1 GB they were until round 5 took 0.39 s (device memory is scrubbed when it is handed out).  Round 4 took and released as many bytes instead, counting on memory the process has
+         * held once to come back at once: it does in two runs of three — in the third the first call's own hipMalloc paid the 0.39 s inside the tool's solve stage
+         * (profiles/r05_first_solve.txt: "avk run: workspaces (.. allocated now ..) 387 ms"). */
+        const size_t main_blocks = (size_t)ctx->n_cus * 3u < AVK_HBM_BLOCKS_BESIDE_LANES ? (size_t)ctx->n_cus * 3u : (size_t)AVK_HBM_BLOCKS_BESIDE_LANES; /* (a genome has lane launches) */
+        const size_t waves = (main_blocks + (size_t)(ctx->hbm_solo_blocks > 0 ? ctx->hbm_solo_blocks : 128) + (size_t)(ctx->hbm_early_blocks > 0 ? ctx->hbm_early_blocks : 64)) * 4u;
         const size_t ws_need = waves * (size_t)ctx->ws_bytes_per_wave;
         if (ws_need > ctx->ws_alloc && (double)ws_need <= (double)ctx->ws_budget_bytes) {
             if (ctx->d_ws) (void)hipFree(ctx->d_ws);
             ctx->d_ws = nullptr, ctx->ws_alloc = 0;
-            AVK_HIP(ctx, hipMalloc((void **)&ctx->d_ws, ws_need + 256));
-            ctx->ws_alloc = ws_need;
+            if (hipMalloc((void **)&ctx->d_ws, ws_need + 256) == hipSuccess) ctx->ws_alloc = ws_need;
+            else ctx->d_ws = nullptr, (void)hipGetLastError(); /* (the first call asks again, and reports) */
         }
         const size_t big_need = (size_t)((ctx->big_waves + 3) / 4) * 4u * (size_t)ctx->big_ws_bytes;
         if (ctx->big_ws_bytes > 0 && big_need > ctx->big_alloc) {
             if (ctx->d_big) (void)hipFree(ctx->d_big);
             ctx->d_big = nullptr, ctx->big_alloc = 0;
-            AVK_HIP(ctx, hipMalloc((void **)&ctx->d_big, big_need + 256));
-            ctx->big_alloc = big_need;
+            if (hipMalloc((void **)&ctx->d_big, big_need + 256) == hipSuccess) ctx->big_alloc = big_need;
+            else ctx->d_big = nullptr, (void)hipGetLastError();
+        }
+    }
+    if (n_regions_hint >= 65536 && ctx->device_pack) {
+        /* ... and the largest of the batch's own buffers, taken from the context's pool and put back: the first call finds them cached (a cached buffer serves requests
+         * of half its size and more, so the hints only have to be about right).  Without them a process's first whole-genome call waited 0.1 s inside one hipMalloc — the
+         * 675 MB arena of the region blobs (profiles/r05_first_solve.txt).  AVK_WARM_POOL=1 takes and clears every buffer of the batch instead. */
+        if (getenv("AVK_WARM_POOL")) {
+            rc = pool_prewarm(ctx, n_regions_hint, n_variants_hint);
+            if (rc) return rc;
+        } else {
+            const size_t n = (size_t)n_regions_hint, nv = (size_t)n_variants_hint;
+            const size_t sizes[] = {n * 190, n * 64, n * 64, n * 52, nv * 16, nv * 16, nv * 8, nv * 8, nv * 8}; /* blobs, region records, region info, fast records, call info and slots, positions and allele offsets */
+            std::vector<void *> got;
+            for (size_t b : sizes) {
+                void *p = nullptr;
+                if (pool_alloc(ctx, &p, b)) break;
+                got.push_back(p);
+            }
+            for (void *p : got) pool_release(ctx, p);
         }
     }
     AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_scratch);
     return 0;
 }
 

@@ -864,7 +864,7 @@ def e2e_leg(args, log):
     exe = os.path.join(ROOT, "aardvark_amd", "bin", "aardvark_amd_compare")
     if not os.path.exists(exe):
         return {"skipped": "aardvark_amd/bin/aardvark_amd_compare is not built (make -C aardvark_amd/csrc/cli)"}
-    env = dict(os.environ, SCALE=str(args.scale), RUNS="3", VERIFY="1")
+    env = dict(os.environ, SCALE=str(args.scale), RUNS="3", VERIFY="1", AVK_TIMING="1")  # AVK_TIMING: the library's own clocks of the tool's one solve, in the last run's lines
     env.pop("AVK_BENCH_CHILD", None)
     t0 = time.perf_counter()
     try:
@@ -888,6 +888,19 @@ def e2e_leg(args, log):
              "per_variant_identical_to_oracle": "per-variant verification PASSED" in text,
              "fixture_seconds": float(re.search(r"written to .* in ([0-9.]+) s", text).group(1)) if re.search(r"written to .* in ([0-9.]+) s", text) else None,
              "leg_seconds": time.perf_counter() - t0}
+    # where the first (only) solve of a fresh process spends its time, on the library's own clocks: the last run's AVK_TIMING lines for the whole-genome batch
+    up = re.findall(r"avk upload \(device-packed\): (\d+) regions, \d+ calls: buffers ([0-9.]+) ms, copies queued ([0-9.]+) ms, packing kernels \+ plan ([0-9.]+) ms, writers queued ([0-9.]+) ms", text)
+    ws = re.findall(r"avk run: workspaces \(([^)]*)\) ([0-9.]+) ms", text)
+    cp = re.findall(r"avk compare packed: upload ([0-9.]+) ms, launches ([0-9.]+) ms, download ([0-9.]+) ms", text)
+    slow = re.findall(r"avk pool: no cached buffer of (\d+) bytes, hipMalloc ([0-9.]+) ms", text)
+    if up and cp:
+        u = max(up, key=lambda x: int(x[0]))
+        entry["first_call_marks"] = {"regions": int(u[0]), "upload_ms": {"buffers": float(u[1]), "copies_queued": float(u[2]), "packing_kernels_and_plan": float(u[3]), "writers_queued": float(u[4])},
+                                     "workspaces": {"what": ws[-1][0], "ms": float(ws[-1][1])} if ws else None,
+                                     "call_ms": {"upload": float(cp[-1][0]), "launches": float(cp[-1][1]), "download": float(cp[-1][2])},
+                                     "pool_misses": len(slow), "slowest_hipMalloc_ms": max([float(x[1]) for x in slow], default=0.0),
+                                     "what": "AVK_TIMING lines of the last run's whole-genome call: a process's first call; avk_ctx_warmup (beside the parsing) has taken the code objects, "
+                                             "the workspaces and the largest pool buffers off it"}
     if not (entry["summary_identical_to_oracle"] and entry["per_variant_identical_to_oracle"]):
         print("PARITY FAILURE in the e2e_compare leg:\n" + text[-1500:], file=sys.stderr)
         sys.exit(3)

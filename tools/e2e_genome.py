@@ -222,4 +222,5 @@ if n_merge >= 2:  # the shape of BASELINE configs[4] on one GPU: majority vote o
         same = len(got) == n and all(got[int(r)] == w for r, w in zip(mb.region_id, want))
         print("merge reasons of %d regions identical to oracle pairs + majority rule: %s (%.1f s; identical %d, majority %d, different %d)" % (
             n, same, time.time() - t0, int(identical.sum()), int(((maj > 0) & ~identical).sum()), int((want == "different").sum())))
-subprocess.run(["rm", "-rf", d])
+if os.environ.get("KEEP", "0") != "1":
+    subprocess.run(["rm", "-rf", d])
