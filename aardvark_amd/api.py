@@ -59,8 +59,9 @@ def load_library():
     lib.avk_compare_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
     lib.avk_batch_upload_compact.argtypes = [vp, C.POINTER(AvkCompactBatch), C.POINTER(vp)]
     lib.avk_compare_packed.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch)]
-    lib.avk_compare_packed_submit.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch), C.POINTER(vp)]
-    lib.avk_wait.argtypes = [vp, vp]
+    if hasattr(lib, "avk_compare_packed_submit"):  # (AVK_LIB may name an older in-tree build: kernel A/B runs)
+        lib.avk_compare_packed_submit.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(AvkCompareConfig), C.POINTER(AvkResultBatch), C.POINTER(vp)]
+        lib.avk_wait.argtypes = [vp, vp]
     lib.avk_batch_upload_packed.argtypes = [vp, C.POINTER(AvkPackedBatch), C.POINTER(vp)]
     lib.avk_compare_resident.argtypes = [vp, vp, C.POINTER(AvkCompareConfig), vp]
     lib.avk_results_download.argtypes = [vp, vp, C.POINTER(AvkResultBatch)]

@@ -72,6 +72,7 @@ struct DpOpts {
     u32 stripe_w; /* claim width the heads of the lane classes are dealt out over (avk_stripe_slot; 0 = sorted order) */
     u64 lane_min_regions; /* 0xFFFFFFFF = no lane classes */
     u64 lane_min_batch;
+    u64 class_c_below; /* a batch with lane launches and at most this many regions outside them plans those regions as class C (0 = no such rule) */
 };
 
 /* per call, written by dp_variant */
@@ -103,6 +104,7 @@ struct DpState {
     u32 n_pending;  /* calls whose alt_ed is left to the host (both stripped alleles longer than 64 symbols) */
     u32 lane_on[AVK_FAST_CLASSES];
     u32 lanes_any; /* some lane class has launches */
+    u32 few_outside; /* ... and the regions outside them are few (class_c_below): those the wide kernel can take are class C */
     u64 have[AVK_FAST_CLASSES]; /* regions eligible per lane class */
     u64 total_v, total_blob_words, total_seq, total_groups; /* totals of the four scans */
     u64 need_hist[DP_NEED_BUCKETS];           /* class C regions by predicted HBM workspace: bucket b = at most 1 MB << b (the last one: more) */
@@ -680,6 +682,8 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
             cls = 1;
     }
     if (het_search) cls |= 0x80u;
+    /* (class_c_below: decided after this kernel as well) */
+    if (!failed && N != 0 && a.opt.solo_min_variants != 0 && a.opt.tier1_bytes && avk_wide_static_ok(ri.len, ri.grow, ri.ed_bound, tc, qc, 0u)) cls |= 0x40u;
     if (failed) fast_class = 0; /* `have` and the work order only count regions that will be solved */
     ri.keys = fast_class | (fast_key << 8) | (cls << 16) | ((u32)(N > 255 ? 255 : N) << 24);
     a.rinfo[r] = ri;
@@ -706,8 +710,10 @@ AVK_DEV void dp_lane_switch(const DpArgs &a) {
     if (a.opt.lane_min_regions != 0 && have_all < a.opt.lane_min_batch)
         for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) on[fc] = 0;
     u32 any = 0;
-    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) a.st->lane_on[fc] = on[fc], any |= on[fc];
+    u64 have_on = 0;
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) a.st->lane_on[fc] = on[fc], any |= on[fc], have_on += on[fc] ? a.st->have[fc] : 0;
     a.st->lanes_any = any;
+    a.st->few_outside = any && a.opt.class_c_below != 0 && a.in.n_regions - have_on <= a.opt.class_c_below;
 }
 
 /* the bucket of a region in the work order: [class C | class B | bulk | lane class 4 | .. | lane class 0], most expensive key first */
@@ -715,8 +721,9 @@ AVK_DEV u32 dp_bucket_of(const DpArgs &a, u64 r) {
     const u32 k = a.rinfo[r].keys;
     const u32 fc = k & 0xFFu;
     if (fc && a.st->lane_on[fc - 1]) return 256u * (3u + (AVK_FAST_CLASSES - fc)) + (255u - ((k >> 8) & 0xFFu));
-    u32 cls = (k >> 16) & 0x7Fu;
+    u32 cls = (k >> 16) & 0x3Fu;
     if (((k >> 16) & 0x80u) && a.st->lanes_any) cls = 0; /* a big phasing search, in a batch with lane launches: class C */
+    if (((k >> 16) & 0x40u) && a.st->few_outside) cls = 0; /* few regions outside the lanes: class C, the wide kernel */
     return 256u * cls + (255u - (k >> 24));
 }
 

@@ -1044,6 +1044,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.opt.stripe_w = ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u;
     a.opt.lane_pairs = ctx->lane_pairs ? 1u : 0u;
     a.opt.head_est = (uint32_t)ctx->lane_head_est, a.opt.het_min = (uint32_t)ctx->het_search_min;
+    a.opt.class_c_below = (uint64_t)ctx->class_c_below;
     hipError_t e = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
     if (e == hipSuccess && nv) {
         hipLaunchKernelGGL(avk_dp_variant_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, a);

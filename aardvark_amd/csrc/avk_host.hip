@@ -337,6 +337,7 @@ struct avk_ctx {
     bool lds_attr_set = false;
     int64_t static_pct = AVK_STATIC_PCT; /* share of a launch's work list dealt statically; the rest is claimed */
     int64_t claim = AVK_CLAIM;           /* regions per claim */
+    int64_t class_c_below = 16384; /* a batch with lane launches and at most this many regions outside them plans those regions as class C: the wide kernel (0: no such rule) */
     int64_t class_c_nodes_x2 = 12; /* a region is sent to the HBM solo launch when 0.5 x this x N nodes outgrow a tier-1 slice */
     int64_t solo_regions_per_wave = 4; /* predicted-hard regions beyond solo waves x this lead the bulk list */
     int64_t accumulate_tally = 0; /* avk_compare_resident adds to the caller's device tally instead of overwriting it */
@@ -419,6 +420,7 @@ struct avk_ctx {
     hipEvent_t ev_tl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* AVK_TIMING only: marks of a boundary call on the context's stream (first copy, last copy, work order, writers, results) */
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
+    hipStream_t spare_stream[16] = {nullptr}; /* never used: see avk_ctx_create */
     hipStream_t wide_stream = nullptr; /* the class C records that are not for the wide kernel (run_internal) */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -580,16 +582,32 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         if (!pe || strcmp(pe, "high") != 0) prio_high = 0;
     }
     const unsigned evf = getenv("AVK_TIMING") ? hipEventDefault : hipEventDisableTiming; /* the events that end the launch chains can be read when the stage timing is on */
-    if (hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+    /* The runtime hands streams their hardware queues in the order they are made, and which launches share a queue's pipe shows in the step: two streams that nothing
+     * is ever queued on, made behind the wide stream, are worth 0.3 ms of a 1.6 ms shard step and 0.04 of chr20's 0.33 (they were the streams of an option that was
+     * taken out in round 5; profiles/r05_stream_order.txt).  AVK_SPARE_STREAMS=a,b,c makes a / b / c of them in front of the side streams / behind the wide stream /
+     * behind the second lane stream instead (experiments). */
+    int spare_at[4] = {0, 2, 0, 0};
+    if (const char *se = getenv("AVK_SPARE_STREAMS")) (void)sscanf(se, "%d,%d,%d,%d", &spare_at[0], &spare_at[1], &spare_at[2], &spare_at[3]);
+    int n_spare = 0;
+    auto spare = [&](int k) {
+        bool ok = true;
+        for (int i = 0; i < k && n_spare < 16 && ok; ++i) ok = hipStreamCreateWithPriority(&ctx->spare_stream[n_spare++], hipStreamNonBlocking, prio_high) == hipSuccess;
+        return ok;
+    };
+    if (!spare(spare_at[0]) ||
+        hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->wide_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        !spare(spare_at[1]) ||
         hipEventCreateWithFlags(&ctx->ev_join2, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_wide, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        !spare(spare_at[2]) ||
         hipEventCreateWithFlags(&ctx->ev_lane_join2, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream3, hipStreamNonBlocking, prio_high) != hipSuccess ||
+        !spare(spare_at[3]) ||
         hipEventCreateWithFlags(&ctx->ev_lane_join3, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
@@ -665,6 +683,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->side_stream2) (void)hipStreamDestroy(ctx->side_stream2);
     if (ctx->wide_stream) (void)hipStreamDestroy(ctx->wide_stream);
+    for (hipStream_t sp : ctx->spare_stream)
+        if (sp) (void)hipStreamDestroy(sp);
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -712,6 +732,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "solo_regions_per_wave") {
         if (value < 1 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_regions_per_wave must be in [1, 1024]");
         ctx->solo_regions_per_wave = value;
+    } else if (n == "class_c_below") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "class_c_below must not be negative");
+        ctx->class_c_below = value;
     } else if (n == "class_c_nodes_x2") {
         if (value < 1 || value > 1000) return fail(ctx, AVK_E_ARG, "class_c_nodes_x2 must be in [1, 1000]");
         ctx->class_c_nodes_x2 = value;
@@ -778,7 +801,7 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_regions must not be negative");
         ctx->lane_min_regions = value;
     } else if (n == "lane_width_one" || n == "lane_width_two" || n == "lane_width_three") {
-        if (value != 64 && value != 32 && value != 16 && value != 8 && value != 4) return fail(ctx, AVK_E_ARG, "%s must be 64, 32, 16, 8 or 4", name);
+        if (value != 64 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2 && value != 1) return fail(ctx, AVK_E_ARG, "%s must be 64, 32, 16, 8, 4, 2 or 1", name);
         (n == "lane_width_one" ? ctx->lane_width_one : (n == "lane_width_two" ? ctx->lane_width_two : ctx->lane_width_three)) = value;
     } else if (n == "lane_max_calls") {
         if (value < 1 || value > AVK_FAST_MAXV) return fail(ctx, AVK_E_ARG, "lane_max_calls must be 1..%d", AVK_FAST_MAXV);
@@ -1154,7 +1177,8 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     db->plan = avk::plan_work_order(db->host, avk::bulk_slice_bytes((uint64_t)ctx->lds_bytes_per_wave), (uint32_t)ctx->lds_ed_cap, (uint64_t)ctx->lds2_bytes_per_wave,
                                     (uint32_t)ctx->lds2_ed_cap, pairs_mode && !ctx->pair_classes ? 0u : (uint32_t)ctx->solo_min_variants, 50, &order, (uint32_t)ctx->class_c_nodes_x2,
                                     ctx->lane_kernel && ctx->use_packed_reference && ctx->d_ref2b ? (uint64_t)ctx->lane_min_regions : 0xFFFFFFFFull, (uint32_t)ctx->lane_max_calls,
-                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u, (uint32_t)ctx->lane_head_est, (uint32_t)ctx->het_search_min);
+                                    (uint64_t)ctx->lane_min_batch, ctx->lane_stripe ? (uint32_t)ctx->lane_head_width : 0u, (uint32_t)ctx->lane_head_est, (uint32_t)ctx->het_search_min,
+                                    (uint64_t)ctx->class_c_below);
     const auto t_plan = now();
     hipError_t e = hipSuccess;
     /* the records go up in work order: a wave reads record k of its launch's range, no index list in between */
@@ -1213,7 +1237,7 @@ void avk_batch_free(avk_ctx *ctx, avk_dev_batch *db) {
 /* tile width of a lane launch (options lane_width_one / lane_width_two: 64, 32 or 16 records per wave at a time) */
 static uint32_t lane_width_log2(const avk_ctx *ctx, uint32_t maxv) {
     const int64_t w = maxv > 2 ? ctx->lane_width_three : (maxv > 1 ? ctx->lane_width_two : ctx->lane_width_one);
-    return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
+    return w <= 1 ? 0u : (w <= 2 ? 1u : (w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)))));
 }
 /* LDS bytes of a one-wave workgroup of the lane kernel (0: does not fit) and the grid that fills the machine: the per-lane arrays of
  * `width` lanes plus a tally of its own; as many workgroups per CU as the LDS and the wave slots hold */
@@ -1223,7 +1247,7 @@ static uint32_t head_width_log2(const avk_ctx *ctx, uint32_t head_regions) {
         const int64_t fit = head_regions < 8192u ? 4 : (head_regions < 24576u ? 8 : 16);
         if (fit < w) w = fit;
     }
-    return w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)));
+    return w <= 1 ? 0u : (w <= 2 ? 1u : (w <= 4 ? 2u : (w <= 8 ? 3u : (w <= 16 ? 4u : (w <= 32 ? 5u : 6u)))));
 }
 /* which of the two kernels a lane launch runs: four lanes per region when the launch is narrow (option lane_quad) */
 static bool lane_launch_is_quad(const avk_ctx *ctx, const avk::lane::LaneArgs &la) { return ctx->lane_quad && la.lanes_log2 <= 4; }
@@ -1560,7 +1584,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                      * it — a batch with large per-wave slices (adaptive_ws under its budget) may have a share of eight workgroups, and the two launches must never meet on
                      * a slice (they did: xb == hbm_solo_max left the solo launch one workgroup ON the other's first slices — wrong results in a fuzz case where every
                      * region was planned as class C, profiles/r04_gpu_fuzz_classc.txt) */
-                    uint32_t xb = (n_nw + 3u) / 4u;
+                    /* (a wave for each of these records and more: they lead the list, most calls first, and a wave that claimed four of them at a time solved four long
+                     * searches one after the other — 1.4 ms at the end of a rank's shard whose lanes were done after 0.8, profiles/r05_small_batches.txt) */
+                    uint32_t xb = n_nw;
                     xb = xb < hbm_solo ? xb : hbm_solo;
                     xb = xb < 64u ? xb : 64u;
                     if (2u * xb > hbm_solo_max) xb = hbm_solo_max / 2u;
@@ -1580,9 +1606,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.work_counter = db->d_counters + 1256;
                         x.static_pct = 0;
                         x.n_shards = 1;
-                        x.claim = 4;
-                        x.high_priority = 1;
                         x.n_waves = xb * waves_per_block;
+                        x.claim = n_c > 64u * x.n_waves ? 4u : 1u; /* (every wave walks its claims of the whole class for the records that are its launch's) */
+                        x.high_priority = 1;
                         x.hbm_ws = ctx->d_ws + (size_t)(n_waves + (hbm_solo_max - xb) * waves_per_block) * (size_t)ws_bytes; /* the last slices of the solo launch's share (that launch gets the others) */
                         x.big_ws = ctx->d_big;
                         x.big_busy = db->d_counters + 1088;

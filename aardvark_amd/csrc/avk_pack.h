@@ -491,7 +491,7 @@ struct WorkPlan {
 inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uint32_t tier0_ed_cap, uint64_t tier1_bytes, uint32_t tier1_ed_cap,
                                 uint32_t solo_min_variants, uint32_t max_branch, std::vector<uint32_t> *order, uint32_t class_c_nodes_x2 = 12,
                                 uint64_t lane_min_regions = 0, uint32_t lane_max_calls = AVK_FAST_MAXV, uint64_t lane_min_batch = 0, uint32_t stripe_w = 0,
-                                uint32_t head_est = 1, uint32_t het_min = AVK_HET_SEARCH_MIN) {
+                                uint32_t head_est = 1, uint32_t het_min = AVK_HET_SEARCH_MIN, uint64_t class_c_below = 0) {
     const uint64_t n = pb.regions.size();
     order->assign(n, 0);
     std::vector<uint8_t> cls(n, 2); /* 0 = C, 1 = B, 2 = bulk, 3 + k = fast class AVK_FAST_CLASSES - 1 - k */
@@ -515,6 +515,15 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
     }
     bool lanes_any = false;
     for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) lanes_any = lanes_any || lane_on[fc];
+    /* class_c_below: a batch with lane launches and few regions outside them (a contig, the shard of a rank) plans those the wide kernel can take as class C — what
+     * is left of such a step once the lanes are done is the latency of single regions, and the wave-cooperative kernel has the shortest (profiles/r05_small_batches.txt) */
+    bool few_outside = false;
+    if (lanes_any && class_c_below) {
+        uint64_t in_lanes = 0;
+        for (uint64_t r = 0; r < n; ++r)
+            in_lanes += !pb.fast_class.empty() && pb.fast_class[r] && !(pb.regions[r].pre_status & 0xFFFFu) && lane_on[pb.fast_class[r] - 1u];
+        few_outside = n - in_lanes <= class_c_below;
+    }
     auto need = [&](const AvkDevRegion &dr, uint64_t N, uint64_t alle, uint64_t grow, uint32_t tier_cap, uint64_t nodes) {
         const uint64_t seqcap = ((uint64_t)dr.len + grow + 7) & ~7ull;
         const uint64_t maxT = dr.t_cnt > dr.q_cnt ? dr.t_cnt : dr.q_cnt;
@@ -545,6 +554,9 @@ inline WorkPlan plan_work_order(const PackedBatch &pb, uint64_t tier0_bytes, uin
             plan.n_hbm += 1;
             if (need(dr, N, alle, grow, tier1_ed_cap, ((uint64_t)class_c_nodes_x2 * N + 1) / 2) > tier1_bytes && !avk_wide_static_ok(dr.len, dr.grow, dr.ed_bound, dr.t_cnt, dr.q_cnt, 0u))
                 plan.n_hbm_notwide += 1;
+        } else if (few_outside && tier1_bytes && avk_wide_static_ok(dr.len, dr.grow, dr.ed_bound, dr.t_cnt, dr.q_cnt, 0u)) {
+            cls[r] = 0;
+            plan.n_hbm += 1;
         } else if (N >= solo_min_variants || need(dr, N, alle, grow, tier0_ed_cap, 2 * N + 1) > tier0_bytes) {
             cls[r] = 1;
             plan.n_hard += 1;

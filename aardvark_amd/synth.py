@@ -562,11 +562,55 @@ def concat_batches(batches):
                        cat("a1_len"), cat("allele_bytes"))
 
 
-def contig_calls(ci, length, density, seed_ref=20250103, seed_query=20250104, keep_calls=False, **kw):
-    """one contig of the whole-genome workload: (contig bytes, bed, truth, query)"""
+def add_low_complexity(contig, seed, tract_every=700, n_gap_every=25_000_000):
+    """Writes a GRCh38-like low-complexity background into a uniform contig: homopolymer, di- and tri-nucleotide tracts of 8-60 bases, one per `tract_every` bases
+    on average (about 4 % of the bases: the reference's simple-repeat share), and blocks of N (assembly gaps, 10-50 kbp, one per `n_gap_every` bases).  Returns
+    (soft-mask, gap intervals): the mask marks about half of the bases in blocks of 0.3-3 kbp — what RepeatMasker lower-cases in GRCh38.  The benchmark uploads the
+    contig UPPER case, as the tool does after loading (--reference-case upper): the mask is reported, not applied."""
+    rng = np.random.default_rng(seed)
+    n = contig.size
+    k = max(1, n // tract_every)
+    start = np.sort(rng.integers(0, max(n - 64, 1), size=k))
+    unit = rng.choice([1, 1, 1, 2, 2, 3], size=k)
+    length = np.minimum(rng.geometric(1.0 / 14.0, size=k) + 7, 60)
+    ub = rng.integers(0, 4, size=(k, 3))
+    dst, within = _ragged(start, length)
+    row = np.repeat(np.arange(k), length)
+    contig[dst] = ACGT[ub[row, within % np.repeat(unit, length)]]
+    mask = np.zeros(n, bool)
+    m = max(1, n // 3300)
+    ms = rng.integers(0, n, size=m)
+    ml = rng.integers(300, 3000, size=m)
+    d, _ = _ragged(ms, np.minimum(ml, n - ms))
+    mask[d] = True
+    gaps = []
+    for _ in range(max(0, int(n // n_gap_every))):
+        a = int(rng.integers(0, max(n - 60_000, 1)))
+        b = min(n, a + int(rng.integers(10_000, 50_000)))
+        contig[a:b] = ord("N")
+        gaps.append((a, b))
+    return mask, gaps
+
+
+def contig_calls(ci, length, density, seed_ref=20250103, seed_query=20250104, keep_calls=False, low_complexity=False, **kw):
+    """one contig of the whole-genome workload: (contig bytes, bed, truth, query).  low_complexity: the contig gets add_low_complexity's background first, the
+    confident intervals avoid its N gaps (as GIAB's do), and the call generators run on it as on any contig — calls land in and beside tracts at the tracts' share."""
     contig = make_contig_fast(length, seed_ref + ci)
     rng = np.random.default_rng(seed_ref + 100 + ci)
     bed = make_bed(length, max(4, int(1000 * length / CHR20_LEN)), 0.9, rng)
+    if low_complexity:
+        _, gaps = add_low_complexity(contig, seed_ref + 300 + ci)
+        for a, b in gaps:  # intervals that touch a gap end in front of it or start behind it
+            keep = []
+            for s0, e0 in bed.tolist():
+                if e0 <= a - 200 or s0 >= b + 200:
+                    keep.append((s0, e0))
+                else:
+                    if s0 < a - 400:
+                        keep.append((s0, a - 200))
+                    if e0 > b + 400:
+                        keep.append((b + 200, e0))
+            bed = np.array(sorted(keep), dtype=bed.dtype).reshape(-1, 2)
     truth, info = genome_truth(contig, bed, max(1, int(length * density)), seed_ref + 200 + ci, **kw)
     query = genome_query(contig, bed, truth, info, seed_query + ci, max(1, len(truth) // 100))
     return contig, bed, truth, query

@@ -777,6 +777,31 @@ def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, 
     # robustness: a denser, messier mix and the reference's recommended SV / TR setting (docs/recommended_settings.md:16-37)
     contigs3, batch3 = synth.config_genome(scale=args.secondary_scale, threads=min(8, cpus), close_frac=0.10, str_frac=0.15, multi_frac=0.05)
     compare_leg("dense_mix", contigs3, batch3, "genome x %.3g, 10 %% of the sites within 30 bp of another, 15 %% of the indels in repeat runs, 5 %% multi-allelic, %d regions" % (args.secondary_scale, batch3.n_regions))
+    # a harder, more honest reference: the headline genome is i.i.d. uniform ACGT — the friendliest sequence an aligner can get.  This one has GRCh38's share of
+    # simple repeats (homopolymer, di- and tri-nucleotide tracts, one per 700 bases), assembly gaps of N, and half of its indels inside repeat runs (written at shifted
+    # positions on the query side).  Its soft mask is folded to upper case, as the tool folds it when it loads a FASTA (--reference-case upper).
+    contigs6, batch6 = synth.config_genome(scale=args.secondary_scale, threads=min(8, cpus), low_complexity=True, str_frac=0.5)
+    compare_leg("lowcomplexity_genome", contigs6, batch6, "genome x %.3g with a low-complexity background (4 %% of the bases in simple-repeat tracts, N gaps outside the confident intervals), "
+                "half of the indels in repeat runs, %d regions" % (args.secondary_scale, batch6.n_regions), packed=True)
+    n6 = max(batch6.n_regions, 1)
+    sec["lowcomplexity_genome"]["looked_up_share"] = None  # (the lanes' count includes the looked-up class; the hand-back share is what the wide and wave kernels finished)
+    sec["lowcomplexity_genome"]["handed_back_or_outside_lanes_share"] = 1.0 - sec["lowcomplexity_genome"]["lane_share"]
+    sec["lowcomplexity_genome"]["n_bases_share"] = float(sum(int((c == ord("N")).sum()) for c in contigs6) / max(sum(c.size for c in contigs6), 1))
+    del contigs6, batch6
+    # real call sets, when the host has them: AVK_REAL_REF / AVK_REAL_TRUTH / AVK_REAL_QUERY / AVK_REAL_BED (FASTA[.gz], two VCF.gz, confident BED — e.g. GRCh38, HG002 GIAB
+    # v4.2.1 and a DeepVariant call set, north_star's target).  This pool has no network: none can be fetched here.
+    real = {k: os.environ.get("AVK_REAL_" + k) for k in ("REF", "TRUTH", "QUERY", "BED")}
+    if all(real.values()):
+        from aardvark_amd import feeder
+        t_feed = time.perf_counter()
+        genome = feeder.Genome(real["REF"])
+        feed = feeder.feed_compare(real["TRUTH"], real["QUERY"], real["BED"], genome)
+        feed_s = time.perf_counter() - t_feed
+        compare_leg("real_data", genome.contigs(), feed.batch, "files named by AVK_REAL_REF/TRUTH/QUERY/BED through the feeder library: %d regions (%.1f s to load and walk)" % (feed.batch.n_regions, feed_s))
+        sec["real_data"]["files"] = real
+    else:
+        sec["real_data"] = {"skipped": "not supplied: set AVK_REAL_REF, AVK_REAL_TRUTH, AVK_REAL_QUERY and AVK_REAL_BED to run real call sets (GRCh38 + HG002 GIAB v4.2.1 vs a DeepVariant "
+                                       "query is north_star's target; no network on this pool)"}
     # (windows of kilobases: every region goes to the wave-per-region kernels and costs some fifty times a small one — on the CPU as well; a fifth of the other leg's scale)
     contigs4, batch4 = synth.config_genome(scale=args.secondary_scale / 5, threads=min(8, cpus), gap=1000)
     compare_leg("min_variant_gap_1000", contigs4, batch4, "genome x %.3g clustered with --min-variant-gap 1000, %d regions" % (args.secondary_scale / 5, batch4.n_regions), few=True)

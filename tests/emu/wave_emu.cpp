@@ -301,6 +301,7 @@ void lane_main(void *p, int /*lane*/) {
 uint64_t g_last_pair_regions = 0; /* emu_last_pair_regions: regions of the last emulated call that went through the lookup of avk_pairs.inl */
 uint32_t g_hbm_ed_cap = 1024; /* emu_set_hbm_ed_cap: context option hbm_ed_cap */
 int g_lane_pairs = 1; /* emu_set_lane_pairs: context option lane_pairs (regions with the same SNV on both sides are looked up, avk_pairs.inl) */
+uint64_t g_class_c_below = 0; /* emu_set_class_c_below: context option class_c_below (0 = no such rule, the emulator's default) */
 uint32_t g_stripe_w = 0; /* emu_set_stripe: claim width the heads of the lane classes are dealt out over (context option lane_stripe; 0 = sorted order) */
 int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
 namespace dpk = avk::dp;
@@ -421,6 +422,7 @@ dpk::DpOpts dp_opts_of(uint64_t lds_bytes, uint32_t lds_ed_cap, uint64_t lds2_by
     o.stripe_w = g_stripe_w;
     o.lane_pairs = g_lane_pairs ? 1u : 0u;
     o.head_est = 1, o.het_min = AVK_HET_SEARCH_MIN;
+    o.class_c_below = g_class_c_below;
     return o;
 }
 
@@ -653,7 +655,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
     } else {
         plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), lds_ed_cap, lds2_bytes, lds2_ed_cap, mode == 1 && !g_pair_classes ? 0u : solo_min_variants, 50, &order,
                                     getenv("AVK_EMU_CLASS_C") ? (uint32_t)atoi(getenv("AVK_EMU_CLASS_C")) : 12u,
-                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */, AVK_FAST_MAXV, 0, g_stripe_w);
+                                    g_lane_kernel ? 0ull : 0xFFFFFFFFull /* as upload_internal does with the option lane_kernel off */, AVK_FAST_MAXV, 0, g_stripe_w, 1, AVK_HET_SEARCH_MIN, g_class_c_below);
         sorted = avk::regions_in_work_order(pb, order); /* the records go in work order */
     }
     a.regions = devpack ? dpr.regions.data() : sorted.data();
@@ -1138,6 +1140,7 @@ int emu_merge_batch(const avk_multi_batch *mb, const uint8_t *const *refs, const
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_stripe(uint32_t w) { g_stripe_w = w; }
+void emu_set_class_c_below(uint64_t n) { g_class_c_below = n; }
 void emu_set_lane_pairs(int on) { g_lane_pairs = on; }
 void emu_set_hbm_ed_cap(uint32_t cap) { g_hbm_ed_cap = cap; }
 uint64_t emu_last_pair_regions() { return g_last_pair_regions; }
@@ -1180,7 +1183,7 @@ int emu_devpack_compare(const avk_region_batch *batch, const uint64_t *ref_lens,
         }
     std::vector<uint32_t> order;
     const avk::WorkPlan plan = avk::plan_work_order(pb, avk::bulk_slice_bytes(lds_bytes), 48, lds2_bytes, 48, pairs_mode && !g_pair_classes ? 0u : solo_min_variants, 50, &order, 12, lane_min_regions,
-                                                    AVK_FAST_MAXV, lane_min_batch, g_stripe_w);
+                                                    AVK_FAST_MAXV, lane_min_batch, g_stripe_w, 1, AVK_HET_SEARCH_MIN, g_class_c_below);
     if (pb.variants.size() != R.st.total_v) return say("per-call output words: host %zu, device %llu", pb.variants.size(), (unsigned long long)R.st.total_v);
     if (seq_total != R.st.total_seq) return say("sequence bytes: host %llu, device %llu", (unsigned long long)seq_total, (unsigned long long)R.st.total_seq);
     if (plan.n_hbm != R.st.n_hbm || plan.n_hard != R.st.n_hard || plan.n_fast_total != R.st.n_fast_total)

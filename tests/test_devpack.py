@@ -109,6 +109,34 @@ def test_benchmark_mix_packs_identically():
     same_as_host_packer(batch, [len(contig)], lane_min_regions=8192, lane_min_batch=65536)
 
 
+@pytest.mark.parametrize("below", [1 << 20, 10])
+def test_few_regions_outside_the_lanes_are_planned_for_the_wide_kernel(oracle, below):
+    """context option class_c_below: a batch with lane launches and at most that many regions outside them plans those the wide kernel can take as class C; both
+    packers make the same plan under it, more regions reach the wide kernel than without it, and the results do not change"""
+    lib = _lib()
+    lib.emu_set_class_c_below.argtypes = [C.c_uint64]
+    contig, batch = synth.config_indel_mix_v2(n_truth=6000, contig_len=2_400_000)
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=4)
+    off = emu_lib.compare_batch(batch, [contig], n_waves=16)
+    lib.emu_set_class_c_below(below)
+    try:
+        same_as_host_packer(batch, [len(contig)])
+        same_as_host_packer(batch, [len(contig)], lane_min_regions=256, lane_min_batch=1000)
+        same_as_host_packer(batch, [len(contig)], lane_min_regions=1 << 20)  # no lane launches: the rule does not apply
+        for mode in (0, 2):
+            lib.emu_set_device_pack(mode)
+            got = emu_lib.compare_batch(batch, [contig], n_waves=16)
+            assert got.diff(want) == []
+            outside = batch.n_regions - got.lane_solved
+            if below >= outside:
+                assert got.wide_solved > off.wide_solved and got.wide_solved > 0.5 * outside
+            else:
+                assert got.wide_solved == off.wide_solved
+    finally:
+        lib.emu_set_device_pack(0)
+        lib.emu_set_class_c_below(0)
+
+
 def test_invalid_long_and_odd_inputs_pack_identically():
     for sc in (scenarios.invalid_regions(), scenarios.long_allele_regions(), scenarios.non_acgt_regions(), scenarios.autofail_regions(), scenarios.quota_regions(3),
                scenarios.max_allele_regions(), scenarios.optimizer_golden_regions()):
