@@ -694,7 +694,16 @@ int avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream) {
     (void)hipSetDevice(ctx->device);
     /* the buffer pool and the bounce buffer hand memory out again in the order of ONE stream: whatever the previous stream still has queued (the writers of an
      * upload's temporaries, say) is finished before another stream may be given the same buffers — also when the previous stream was the caller's */
-    if (ctx->stream != (hipStream_t)hip_stream) AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream != (hipStream_t)hip_stream) {
+        const hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) {
+            /* a caller's stream that is gone already (the header asks for it to be alive; the handle must not stay installed either way): whatever was queued on the
+             * device is finished instead, and the switch goes through */
+            (void)hipGetLastError();
+            if (ctx->own_stream) return fail(ctx, AVK_E_HIP, "hipStreamSynchronize: %s", hipGetErrorString(e));
+            AVK_HIP(ctx, hipDeviceSynchronize());
+        }
+    }
     if (ctx->own_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     ctx->stream = (hipStream_t)hip_stream;
     ctx->own_stream = false;

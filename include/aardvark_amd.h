@@ -285,7 +285,9 @@ int  avk_ctx_create(int device_id, avk_ctx **out);
 void avk_ctx_destroy(avk_ctx *ctx);
 /* last error text of this context (or of the failed create when ctx == NULL) */
 const char *avk_last_error(const avk_ctx *ctx);
-/* run every launch of this context on an existing hipStream_t (e.g. torch's current stream) */
+/* run every launch of this context on an existing hipStream_t (e.g. torch's current stream).  The call BLOCKS until the stream the context used so far is idle
+ * (its buffer pool hands memory out in the order of one stream); when that one was the caller's too it should still be alive — if it has been destroyed the
+ * call waits for the whole device instead and still switches. */
 int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
 /* knobs (set them before avk_batch_upload: the work plan of a batch is made at upload):
  *   workspace tiers  "lds_bytes_per_wave", "lds_ed_cap" (small LDS slice), "lds2_bytes_per_wave", "lds2_ed_cap" (large LDS
@@ -293,6 +295,8 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    0 bytes disables a tier
  *   scheduling       "solo_min_variants" (regions with at least this many variants go to the solo launch, 0 = no solo
  *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
+ *                    "class_c_below" (16384: a batch with lane launches and at most this many regions outside them plans those regions for the
+ *                    wave-cooperative kernel, avk_wide.inl, instead of the bulk launch — a contig or a rank's shard: profiles/r05_small_batches.txt; 0 = never),
  *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid",
  *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2),
  *                    "timing_events" (0 = no event records for

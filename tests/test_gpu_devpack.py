@@ -119,6 +119,18 @@ def test_capacity_retry_of_a_device_packed_batch(oracle):
         ctx.set_option("capacity_retry", 0)
         starved = ctx.solve_compare_regions(batch, CompareConfig(enable_sequences=False))
         assert (starved.status == 21).any()  # some regions do exhaust the last tier on the first try
+        # the retry is gated on the kernels' own count of the regions they gave up on (last_tier_counts()[4]), not on a scan of the statuses: the two agree,
+        # for the one-shot call, for a resident batch of either packer, and for either result form
+        assert ctx.last_tier_counts()[4] == int((starved.status == 21).sum())
+        for dev_pack in (1, 0):
+            ctx.set_option("device_pack", dev_pack)
+            rb = ctx.upload(batch)
+            ctx.compare_resident(rb)
+            for packed in (False, True):
+                res = ctx.download(rb, group_metrics=False, packed=packed)
+                st = res.status if not packed else res.expanded(ctx.lib, batch).status
+                assert ctx.last_tier_counts()[4] == int((st == 21).sum()) > 0, (dev_pack, packed)
+            rb.free()
     finally:
         ctx.close()
 
