@@ -402,7 +402,7 @@ template <class F> void avk_parallel_for(uint64_t n, unsigned nt, F f) { /* f(th
 }
 
 unsigned avk_host_threads() {
-    unsigned nt = std::thread::hardware_concurrency();
+    unsigned nt = avk_usable_cpus();
     if (nt > 16) nt = 16;
     if (nt < 1) nt = 1;
     if (const char *e = getenv("AVK_HOST_THREADS")) {

@@ -1102,7 +1102,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     uint64_t seq_total = 0;
     {
         const uint64_t nr = batch->n_regions;
-        size_t nt = std::thread::hardware_concurrency();
+        size_t nt = avk_usable_cpus();
         if (nt > 16) nt = 16;
         if (nt > nr / 65536 + 1) nt = (size_t)(nr / 65536 + 1);
         auto part = [&](size_t t) {

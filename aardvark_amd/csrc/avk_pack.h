@@ -11,6 +11,8 @@
 #ifndef AVK_PACK_H
 #define AVK_PACK_H
 
+#include "avk_cpus.h"
+
 #include <cstring>
 #include <string>
 #include <functional>
@@ -186,7 +188,7 @@ inline int pack_batch(const avk_region_batch *b, const std::vector<uint64_t> &co
     out->fast_class.assign(n, 0);
     out->fast_key.assign(n, 0);
     /* the same cut of the regions into ranges for both passes */
-    int nt = threads > 0 ? threads : (int)std::thread::hardware_concurrency();
+    int nt = threads > 0 ? threads : (int)avk_usable_cpus();
     if (nt > 16) nt = 16;
     if ((uint64_t)nt > n / 4096 + 1) nt = (int)(n / 4096 + 1);
     if (nt < 1) nt = 1;
@@ -456,7 +458,7 @@ inline PodVec<AvkDevRegion> regions_in_work_order(const PackedBatch &pb, const s
     PodVec<AvkDevRegion> out;
     out.resize(order.size());
     const size_t n = order.size();
-    size_t nt = std::thread::hardware_concurrency();
+    size_t nt = avk_usable_cpus();
     if (nt > 16) nt = 16;
     if (nt > n / 65536 + 1) nt = n / 65536 + 1;
     if (nt < 1) nt = 1;
@@ -617,7 +619,7 @@ inline PodVec<uint32_t> build_fast_records(const PackedBatch &pb, const std::vec
     }
     PodVec<uint32_t> recs;
     recs.resize((size_t)words + 1);
-    size_t nt = std::thread::hardware_concurrency();
+    size_t nt = avk_usable_cpus();
     if (nt > 16) nt = 16;
     if (nt > tiles / 256 + 1) nt = tiles / 256 + 1;
     if (nt < 1) nt = 1;

@@ -5,6 +5,9 @@
  */
 #include "../../../include/aardvark_feeder.h"
 
+#include "../avk_cpus.h"
+#include "avf_bgzf.h"
+
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -511,6 +514,14 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, Ca
         if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0) return false;
         return (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)&out[at], b.isize) == b.crc;
     };
+    auto crc_of = [](const void *p, size_t n) { /* (libdeflate's CRC-32 is several times zlib 1.2.11's) */
+        return avf_bgzf::libdeflate().ok ? avf_bgzf::libdeflate().crc32(0, p, n) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)p, (uInt)n);
+    };
+    auto inflate_block_w = [&](const Blk &b, avf_bgzf::Inflater &inf, std::string &out) -> bool { /* the workers': libdeflate when the system has it */
+        const size_t at = out.size();
+        out.resize(at + b.isize);
+        return inf.run(d + b.data, b.len, &out[at], b.isize) && crc_of(&out[at], b.isize) == b.crc;
+    };
     /* the header: inflate from the start until the #CHROM line is complete */
     long sample_col = -1;
     {
@@ -581,9 +592,8 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, Ca
         out.lists[last].push_back(std::move(c));
     };
     auto worker = [&] {
-        z_stream zs;
-        memset(&zs, 0, sizeof(zs));
-        if (inflateInit2(&zs, -15) != Z_OK) {
+        avf_bgzf::Inflater zs;
+        if (!zs.ok()) {
             irregular.store(true);
             return;
         }
@@ -593,7 +603,7 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, Ca
             GroupOut &out = outs[g];
             text.clear();
             bool ok = true;
-            for (size_t k = g * group_blocks; k < std::min(blks.size(), (g + 1) * group_blocks) && ok; ++k) ok = inflate_block(blks[k], zs, text);
+            for (size_t k = g * group_blocks; k < std::min(blks.size(), (g + 1) * group_blocks) && ok; ++k) ok = inflate_block_w(blks[k], zs, text);
             if (!ok) {
                 irregular.store(true);
                 break;
@@ -633,7 +643,6 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, Ca
                 p = nl + 1;
             }
         }
-        inflateEnd(&zs);
     };
     {
         std::vector<std::thread> pool;
@@ -701,7 +710,7 @@ int load_vcf_bgzf(const char *path, const char *sample, bool enable_trimming, Ca
  * are put together in file order.  Anything irregular (an error, a #CHROM line after the first data line) is left to the sequential
  * reader above, which then reports it the usual way. */
 int load_vcf(const char *path, const char *sample, bool enable_trimming, CallMap &calls) {
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = avk_usable_cpus();
     const size_t n_workers = std::min<size_t>(hw > 1 ? hw - 1 : 0, 8);
     if (n_workers < 2 || getenv("AVF_SEQUENTIAL_VCF")) return load_vcf_sequential(path, sample, enable_trimming, calls);
     if (!getenv("AVF_NO_BGZF_GROUPS")) {
@@ -941,7 +950,7 @@ const char *avf_last_error(void) { return t_error.c_str(); }
  * every sequence body is cut into pieces whose kept bytes (everything but line terminators) are counted and copied side by side.
  * Same result as the line-by-line reader below, which still serves gzip / BGZF files. */
 static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n, avf_genome *g, bool upper) {
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = avk_usable_cpus();
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>(hw ? hw : 1, 32));
     auto parallel = [&](size_t items, const std::function<void(size_t)> &fn) {
         std::atomic<size_t> next{0};
@@ -1024,6 +1033,10 @@ static int genome_load_mapped(const char *fasta_path, const uint8_t *d, size_t n
     }
     for (size_t i = 0; i < headers.size(); ++i) {
         g->seqs[i].resize(total[i]);
+        /* 3 GB written once by many threads: with 4 KB pages that is 760,000 first-touch faults; huge pages where the system grants them on request
+         * (transparent_hugepage = madvise) */
+        const uintptr_t huge = (uintptr_t)2 << 20, lo = ((uintptr_t)g->seqs[i].data() + huge - 1) & ~(huge - 1), hi = ((uintptr_t)g->seqs[i].data() + total[i]) & ~(huge - 1);
+        if (hi > lo) (void)madvise((void *)lo, hi - lo, MADV_HUGEPAGE);
     }
     lap("allocate");
     parallel(pieces.size(), [&](size_t k) {
@@ -1075,30 +1088,24 @@ int avf_genome_load_case(const char *fasta_path, int upper_case, avf_genome **ou
                     std::vector<size_t> at(blks.size() + 1, 0);
                     for (size_t k = 0; k < blks.size(); ++k) at[k + 1] = at[k] + blks[k].isize;
                     raw.resize(at.back());
-                    const unsigned hw = std::thread::hardware_concurrency();
+                    const unsigned hw = avk_usable_cpus();
                     const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, blks.size()}));
                     std::atomic<size_t> next{0};
                     std::atomic<bool> bad{false};
                     auto work = [&] {
-                        z_stream zs;
-                        memset(&zs, 0, sizeof(zs));
-                        if (inflateInit2(&zs, -15) != Z_OK) {
+                        avf_bgzf::Inflater zs; /* libdeflate when the system has it */
+                        if (!zs.ok()) {
                             bad.store(true);
                             return;
                         }
+                        const bool ld = avf_bgzf::libdeflate().ok;
                         for (size_t k0 = next.fetch_add(64); k0 < blks.size() && !bad.load(std::memory_order_relaxed); k0 = next.fetch_add(64))
                             for (size_t k = k0; k < std::min(blks.size(), k0 + 64); ++k) {
                                 const BgzfBlk &b = blks[k];
-                                if (inflateReset(&zs) != Z_OK) bad.store(true);
-                                zs.next_in = (Bytef *)(d + b.data);
-                                zs.avail_in = (uInt)b.len;
-                                zs.next_out = (Bytef *)(raw.data() + at[k]);
-                                zs.avail_out = b.isize;
-                                if (inflate(&zs, Z_FINISH) != Z_STREAM_END || zs.avail_out != 0 ||
-                                    (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(raw.data() + at[k]), b.isize) != b.crc)
+                                if (!zs.run(d + b.data, b.len, raw.data() + at[k], b.isize) ||
+                                    (ld ? avf_bgzf::libdeflate().crc32(0, raw.data() + at[k], b.isize) : (uint32_t)crc32(crc32(0L, Z_NULL, 0), (const Bytef *)(raw.data() + at[k]), b.isize)) != b.crc)
                                     bad.store(true);
                             }
-                        inflateEnd(&zs);
                     };
                     std::vector<std::thread> pool;
                     for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
@@ -1187,7 +1194,7 @@ static int load_call_sets(uint32_t k, const char *const *vcfs, const char *const
     std::vector<int> rcs(k, 0);
     std::vector<std::string> errs(k);
     {
-        const uint32_t n_threads = std::min<uint32_t>(k, std::max(1u, std::min(8u, std::thread::hardware_concurrency())));
+        const uint32_t n_threads = std::min<uint32_t>(k, std::max(1u, std::min(8u, avk_usable_cpus())));
         std::atomic<uint32_t> next{0};
         auto work = [&] {
             for (uint32_t i = next.fetch_add(1); i < k; i = next.fetch_add(1)) {
@@ -1314,7 +1321,7 @@ static int build_regions(uint32_t k, const CallMap *const *calls, const char *re
             if (have_window && have_end) flush(window_start, window_end);
         }
     };
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = avk_usable_cpus();
     const size_t n_threads = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)16, n_chroms}));
     auto parallel = [&](const std::function<void(size_t)> &fn) {
         std::atomic<size_t> next{0};
@@ -1564,7 +1571,7 @@ int avf_feed_pack(const avf_feed *f, void *(*alloc)(void *, size_t), void *user,
     /* the form's constraints (aardvark_amd.h); the layout ones hold by construction (flush() above) and are checked all the same */
     if (nv >= (1ull << 32) || na >= (1ull << 32)) return 1;
     std::atomic<int> bad{0}, raw_differs{0};
-    const unsigned hw = std::thread::hardware_concurrency();
+    const unsigned hw = avk_usable_cpus();
     const unsigned n_threads = std::max(1u, std::min(hw ? hw : 1u, 16u));
     auto parallel = [&](uint64_t count, const std::function<void(uint64_t, uint64_t)> &fn) {
         std::vector<std::thread> pool;

@@ -7,6 +7,8 @@
  */
 #include "../../../include/aardvark_feeder.h"
 
+#include "../avk_cpus.h"
+
 #include <zlib.h>
 
 #include <algorithm>
@@ -171,7 +173,7 @@ int avf_strat_batch_labels(const avf_strat *s, const avf_genome *g, const avk_re
                            uint32_t *label_idx) {
     if (!s || !g || !b || !label_off || first > b->n_regions || n > b->n_regions - first) return AVK_E_ARG;
     const uint32_t n_labels = avf_strat_n_labels(s);
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = avk_usable_cpus();
     size_t nt = hw < 1 ? 1 : (hw > 16 ? 16 : hw);
     if (nt > n / 4096 + 1) nt = (size_t)(n / 4096 + 1);
     auto run = [&](const std::function<void(uint64_t, uint64_t)> &fn) {

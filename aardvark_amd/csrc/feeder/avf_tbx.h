@@ -1,6 +1,7 @@
 /* avf_tbx.h — a BGZF text file with a tabix index next to it (VCF or BED records), for the writers of libaardvark_feeder.so */
 #ifndef AVF_TBX_H
 #define AVF_TBX_H
+#include "../avk_cpus.h"
 #include "avf_bgzf.h"
 
 #include <algorithm>
@@ -157,7 +158,7 @@ class IndexedText {
         const auto t0 = std::chrono::steady_clock::now();
         FILE *fp = fopen(path.c_str(), "wb");
         if (!fp) return false;
-        int threads = (int)std::thread::hardware_concurrency();
+        int threads = (int)avk_usable_cpus();
         if (threads > 64) threads = 64;
         bool ok = w_.finish(fp, threads);
         ok = (fclose(fp) == 0) && ok;
@@ -399,7 +400,7 @@ struct LineMeta {
     int64_t beg, end;
 };
 template <class Fn, class NameOf> bool format_parallel(uint64_t n_items, Fn &&fn, NameOf &&name_of, IndexedText &out) {
-    unsigned hw = std::thread::hardware_concurrency();
+    unsigned hw = avk_usable_cpus();
     const size_t n_threads = hw < 1 ? 1 : (hw > 32 ? 32 : hw);
     const size_t n_pieces = n_items < 512 ? 1 : std::min<size_t>(4 * n_threads, (size_t)(n_items / 128));
     std::vector<std::string> texts(n_pieces);

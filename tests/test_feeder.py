@@ -659,6 +659,29 @@ def test_bgzf_writer_splits_large_outputs(tmp_path, oracle):
         assert tabix_fetch(out, "chr20", beg, end) == sorted(set(hit), key=lambda l: (int(l.split("\t")[1]), l))
 
 
+def test_zlib_and_libdeflate_write_and_read_the_same_text(tmp_path):
+    """the feeder compresses and inflates BGZF blocks with libdeflate when the system has it (looked up at run time) and with zlib otherwise (or under AVF_ZLIB=1):
+    either writer's file holds the same text, and either reader gets the same calls from either file (a fresh process per setting: the choice is made once)"""
+    import subprocess, sys
+    p, contig, want_batch = write_case_files(tmp_path, 1500, 800_000)
+    script = ("import sys, os; sys.path[:0] = [%r, %r]\n"
+              "import numpy as np, oracle_lib\nfrom aardvark_amd import feeder\n"
+              "g = feeder.Genome(sys.argv[1]); feed = feeder.feed_compare(sys.argv[2], sys.argv[3], sys.argv[4], g, enable_trimming=False)\n"
+              "res = oracle_lib.compare_batch(oracle_lib.load(), feed.batch, g.contigs(), threads=4)\n"
+              "feeder.write_annotated_vcf(sys.argv[5], sys.argv[2], g, feed.batch, res, 0)\n"
+              "print(feed.batch.n_regions, int(feed.batch.t_cnt.sum()), int(feed.batch.var_pos.astype(np.uint64).sum()))\n") % (os.path.dirname(os.path.abspath(__file__)), ROOT)
+    seen = {}
+    for name, env, truth in (("ld", {}, p["t"]), ("z", {"AVF_ZLIB": "1"}, p["t"]), ("z_reads_ld", {"AVF_ZLIB": "1"}, str(tmp_path / "ld.vcf.gz")),
+                             ("ld_reads_z", {}, str(tmp_path / "z.vcf.gz"))):
+        out = str(tmp_path / (name + ".vcf.gz"))
+        r = subprocess.run([sys.executable, "-c", script, p["fa"], truth, p["q"], p["bed"], out], capture_output=True, text=True, env={**os.environ, **env})
+        assert r.returncode == 0, r.stderr
+        seen[name] = (r.stdout.strip(), [raw for _, raw in bgzf_blocks(out)])
+    records = lambda blocks: [l for l in b"".join(blocks).decode().splitlines() if not l.startswith("##")]
+    assert records(seen["ld"][1]) == records(seen["z"][1]) and len(records(seen["ld"][1])) > 1000
+    assert seen["ld"][0] == seen["z"][0] == seen["z_reads_ld"][0] == seen["ld_reads_z"][0]
+
+
 def write_case_files(tmp_path, n_truth=3000, length=1_500_000):
     """a small chr20-shaped SNV+indel call set as FASTA(.gz) + BED + two VCFs; returns (paths, contig, batch the generator clusters)"""
     contig = synth.make_contig(length, 15)
