@@ -1998,6 +1998,15 @@ int avk_compare_resident(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_conf
     return run_internal(ctx, db, cfg, tally_dev, 0);
 }
 
+#ifdef AVK_QUAD_WAVE_LOG
+/* profiling build only (make quad-wave-log): the wave log of the quad launches, 6 x 4096 x 4 words; cleared by the call */
+extern "C" int avk_debug_wave_log(unsigned long long *dst) {
+    if (hipMemcpyFromSymbol(dst, HIP_SYMBOL(avk_wave_log_buf), sizeof(avk_wave_log_buf)) != hipSuccess) return AVK_E_HIP;
+    std::vector<unsigned long long> z(sizeof(avk_wave_log_buf) / 8, 0);
+    return hipMemcpyToSymbol(HIP_SYMBOL(avk_wave_log_buf), z.data(), sizeof(avk_wave_log_buf)) == hipSuccess ? 0 : AVK_E_HIP;
+}
+#endif
+
 int avk_synchronize(avk_ctx *ctx) {
     if (!ctx) return AVK_E_ARG;
     AVK_HIP(ctx, hipSetDevice(ctx->device));

@@ -779,6 +779,13 @@ AVK_DEV int solve_quad(const AvkKernelArgs &a, LCtx &c, u32 q, const u32 *rec, u
 
 /* One persistent wave: claims 2^lanes_log2 (at most 16) fast records of a tile, every quad solves one.  wave_lds = this wave's rows,
  * wg_tally = the workgroup's 288 tally words in LDS (zeroed and flushed by the caller). */
+#ifdef AVK_QUAD_WAVE_LOG
+} // namespace quad
+} // namespace avk
+__device__ unsigned long long avk_wave_log_buf[6 * 4096 * 4]; /* [launch slot][wave][t0, t1, claims, longest claim] (s_memrealtime ticks) of the last step */
+namespace avk {
+namespace quad {
+#endif
 AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id, u32 *wave_lds, u32 *wg_tally, u32 &n_ok_out, u32 &n_err_out, u64 *part = (u64 *)0) {
     const u32 lane = (u32)wv_lane();
     const u32 q = lane & 3u, rq = lane >> 2; /* lane of the quad, quad of the wave */
@@ -802,13 +809,24 @@ AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #ifdef AVK_LANE_PHASE_TIMING
     for (int j = 0; j < 8; ++j) c.tph[j] = 0;
 #endif
+#ifdef AVK_QUAD_WAVE_LOG /* profiling build (make quad-wave-log, tools/gpu_quad_waves.py): when every wave of a quad launch started and ended, its claims, its longest claim */
+    const u64 wl_t0 = __builtin_amdgcn_s_memrealtime();
+    u64 wl_longest = 0, wl_prev = 0;
+#endif
     for (;;) {
         u32 t = 0;
 #ifdef AVK_LANE_PHASE_TIMING
         const u64 t_tile0 = avk_clock();
 #endif
+#ifdef AVK_QUAD_WAVE_LOG
+        const u64 wl_c0 = __builtin_amdgcn_s_memrealtime();
+#endif
         if (lane == 0) t = avk_atomic_add_u32_global(la.tile_counter, 1u);
         t = wv_uni(wv_shfl(t, 0));
+#ifdef AVK_QUAD_WAVE_LOG
+        if (n_claims_done && wl_c0 - wl_prev > wl_longest) wl_longest = wl_c0 - wl_prev;
+        wl_prev = wl_c0;
+#endif
         if (t >= n_claims) break;
         n_claims_done += 1;
         if (part && (n_claims_done & 15u) == 0) { /* the 32-bit LDS tally moves on to the 64-bit partial tally every 16 claims */
@@ -880,6 +898,12 @@ AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
     }
 #else
     (void)wave_id;
+#endif
+#ifdef AVK_QUAD_WAVE_LOG
+    if (lane == 0 && wave_id < 4096u) { /* launch slot: class (one, two, three calls per side) x width (16 or narrower) */
+        unsigned long long *e = avk_wave_log_buf + ((size_t)((la.nm == 2 ? 0u : (la.nm == 4 ? 1u : 2u)) * 2u + (la.lanes_log2 == 4 ? 0u : 1u)) * 4096u + wave_id) * 4u;
+        e[0] = wl_t0, e[1] = __builtin_amdgcn_s_memrealtime(), e[2] = n_claims_done, e[3] = wl_longest;
+    }
 #endif
     n_ok_out = n_ok;
     n_err_out = n_err;

@@ -84,7 +84,7 @@ def parse():
     ap.add_argument("--merge-scale", type=float, default=1.0)
     ap.add_argument("--secondary-scale", type=float, default=0.25, help="genome scale of the two robustness mixes of `secondary`")
     ap.add_argument("--no-parity", action="store_true", help="skip the bit-identity gate against the oracle")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r04_pmc_traffic.json"),
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"),
                     help="PMC-derived HBM bytes per step collected with rocprofv3 --pmc in a builder-side run (optional; reported with its source)")
     return ap.parse_args()
 

@@ -3,7 +3,7 @@
 # Usage on the GPU box from the repo root: tools/profile_round.sh <tag> [extra bench flags]; then tools/summarize_round.py <tag> (here or there) writes profiles/<tag>_*.
 # Every run is checked: a bench that exits non-zero or prints no JSON line under the profiler fails the script's summary line.
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG

@@ -56,7 +56,7 @@ def klass(name):
         return "results (dp_unpack)"
     if name.startswith("avk_dp_") or name.startswith("avk_ps_") or name.startswith("avk_pack"):
         return "packing"
-    for key, label in (("avk_lane", "lanes"), ("avk_pair", "looked-up pairs"), ("avk_wide", "wide"), ("avk_region_kernel_lds", "wave-per-region, LDS tiers"),
+    for key, label in (("avk_quad", "lanes (quads)"), ("avk_lane", "lanes"), ("avk_pair", "looked-up pairs"), ("avk_wide", "wide"), ("avk_region_kernel_lds", "wave-per-region, LDS tiers"),
                        ("avk_region_kernel_hbm", "wave-per-region, HBM tier"), ("avk_tally", "tally reduce")):
         if name.startswith(key):
             return label
