@@ -14,7 +14,10 @@ _lib = None
 def load():
     global _lib
     if _lib is None:
-        subprocess.check_call(["make", "-C", EMU_DIR, "libavk_emu.so"], stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(EMU_DIR, ".build.lock"), "w") as lock:  # pytest-xdist workers: one of them builds, the others wait (a half-written .so is an OSError)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", EMU_DIR, "libavk_emu.so"], stdout=subprocess.DEVNULL)
         lib = C.CDLL(os.path.join(EMU_DIR, "libavk_emu.so"))
         lib.emu_compare_batch.argtypes = [C.POINTER(AvkRegionBatch), C.POINTER(u8p), u64p, C.c_uint32, C.POINTER(AvkCompareConfig),
                                           C.POINTER(AvkResultBatch), C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64,

@@ -19,7 +19,10 @@ def build():
     so = os.path.join(ORACLE_DIR, "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in ("oracle.cpp", "oracle.h")] + [os.path.join(ROOT, "include", "aardvark_amd.h")]
     if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-        subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
+        import fcntl
+        with open(os.path.join(ORACLE_DIR, ".build.lock"), "w") as lock:  # (pytest-xdist workers: one builds, the others wait)
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(["make", "-C", ORACLE_DIR, "liboracle.so"], stdout=subprocess.DEVNULL)
     return so
 
 
