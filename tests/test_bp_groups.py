@@ -42,14 +42,18 @@ def check_packed(batch, got, want):
                                                          for v in range(int(off), int(off) + int(cnt)))) for r in np.nonzero(spilled)[0])
 
 
-def cases(light=False):
-    """light: without the four long-allele regions and with fewer fuzz regions (the emulator needs seconds for each of the former)"""
+def cases(light=False, emulator=False):
+    """light: without the long alleles (counters over 127: spilled groups) and with fewer fuzz regions; emulator: alleles of up to 400 bases stand in for the
+    10,000-base ones (a minute per run there)"""
     yield scenarios.golden()
     yield scenarios.fuzz_regions(71, 120 if light else 400, max_vars=6, max_len=10)
     yield scenarios.fuzz_regions(72, 300, max_vars=3, repeat_unit=b"CA")
     if not light:
-        c = scenarios.long_allele_regions()
-        yield c[0], c[1]
+        if emulator:
+            yield scenarios.fuzz_regions(73, 16, max_vars=2, max_len=400, span=(300, 900))  # joint counters up to 1,443
+        else:
+            c = scenarios.long_allele_regions()
+            yield c[0], c[1]
     yield scenarios.invalid_regions()
     contig, batch = synth.config_indel_mix_v2(n_truth=700, contig_len=400_000)
     yield [contig], batch
@@ -62,7 +66,7 @@ def test_compact_groups_rebuild_the_full_block_kernel_logic(oracle, lane_kernel)
     for devpack in (0, 2):
         lib.emu_set_device_pack(devpack)
         try:
-            for contigs, batch in cases(light=not (devpack == 2 and lane_kernel)):  # the full set once, through the device packer and the lane code
+            for contigs, batch in cases(light=not (devpack == 2 and lane_kernel), emulator=True):  # the full set once, through the device packer and the lane code
                 want = oracle_lib.compare_batch(oracle, batch, contigs, threads=4)
                 got = emu_lib.compare_batch(batch, contigs, lane_kernel=lane_kernel, group_metrics=False, bp_groups=True, threads=8)
                 check(batch, got, want)
