@@ -46,8 +46,8 @@ def cases(light=False, emulator=False):
     """light: without the long alleles (counters over 127: spilled groups) and with fewer fuzz regions; emulator: alleles of up to 400 bases stand in for the
     10,000-base ones (a minute per run there)"""
     yield scenarios.golden()
-    yield scenarios.fuzz_regions(71, 120 if light else 400, max_vars=6, max_len=10)
-    yield scenarios.fuzz_regions(72, 300, max_vars=3, repeat_unit=b"CA")
+    yield scenarios.fuzz_regions(71, 100 if light else 240, max_vars=6, max_len=10)
+    yield scenarios.fuzz_regions(72, 160, max_vars=3, repeat_unit=b"CA")
     if not light:
         if emulator:
             yield scenarios.fuzz_regions(73, 16, max_vars=2, max_len=400, span=(300, 900))  # joint counters up to 1,443

@@ -133,7 +133,7 @@ def test_device_merge_path_kernel_logic(oracle):
     contig = [GOLD["contig"].encode()]
     for r, want in zip(GOLD["regions"], expect()):
         assert device_merge([{"start": r["start"], "end": r["end"], "inputs": r["inputs"]}], contig, MergeConfig(**r["config"]))[0] == want, r
-    contigs, batch = scenarios.fuzz_regions(44, 120, related=0.9)
+    contigs, batch = scenarios.fuzz_regions(44, 70, related=0.9)
 
     def variants(b, off, cnt):
         return [(int(b.var_pos[v]), bytes(b.allele_bytes[int(b.a0_off[v]):int(b.a0_off[v]) + int(b.a0_len[v])]), bytes(b.allele_bytes[int(b.a1_off[v]):int(b.a1_off[v]) + int(b.a1_len[v])]),

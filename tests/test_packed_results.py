@@ -18,8 +18,8 @@ WIDE = ["status", "ed_h1", "ed_h2", "n_optima", "type_present", "var_expected", 
 
 def cases():
     yield scenarios.golden()
-    yield scenarios.fuzz_regions(91, 200, max_vars=6, max_len=10)
-    yield scenarios.fuzz_regions(92, 200, max_vars=3, repeat_unit=b"CA")
+    yield scenarios.fuzz_regions(91, 120, max_vars=6, max_len=10)
+    yield scenarios.fuzz_regions(92, 120, max_vars=3, repeat_unit=b"CA")
     yield scenarios.invalid_regions()
     c = scenarios.optimizer_golden_regions()
     yield c[0], c[1]

@@ -70,7 +70,7 @@ def het_cluster_regions(seed, n, n_sites=(3, 7), span=(90, 230), drop=0.1, shift
 
 @pytest.mark.parametrize("seed,kw", [(11, {}), (12, {"n_sites": (4, 8), "drop": 0.0, "shift": 0.0}), (13, {"indel": 0.4}), (14, {"n_sites": (2, 5), "indel": 0.7, "drop": 0.3})])
 def test_het_clusters(oracle, seed, kw):
-    contigs, batch = het_cluster_regions(seed, 160, **kw)
+    contigs, batch = het_cluster_regions(seed, 100, **kw)
     wide, want = through_wide(oracle, contigs, batch, min_share=0.6, n_waves=8)
     assert int(want.n_optima.max()) >= 4  # tied optima: the order the reference finds them in decides the winner
 
@@ -80,7 +80,7 @@ def test_het_clusters(oracle, seed, kw):
                                      (26, {"max_vars": 5, "span": (4, 40), "max_len": 3})])
 def test_region_fuzz(oracle, seed, kw):
     """SNVs, insertions, deletions, indels, overlapping and same-position calls, repeats, up to ten calls on a side (beyond eight: handed over)"""
-    contigs, batch = scenarios.fuzz_regions(seed, 300, **kw)
+    contigs, batch = scenarios.fuzz_regions(seed, 180, **kw)
     through_wide(oracle, contigs, batch, min_share=0.3, n_waves=8)
 
 
@@ -131,7 +131,7 @@ def test_large_edit_bounds_align_by_the_whole_wave(oracle, seed, kw):
 @pytest.mark.parametrize("lds", [8 * 1024, 24 * 1024, 64 * 1024])
 def test_lds_budget_is_a_class_limit(oracle, lds):
     """a region whose 2^T + 2^Q sequences do not fit the launch's LDS goes to the wave-per-region code"""
-    contigs, batch = scenarios.fuzz_regions(41, 250, max_vars=8, related=0.9, span=(60, 230))
+    contigs, batch = scenarios.fuzz_regions(41, 140, max_vars=8, related=0.9, span=(60, 230))
     through_wide(oracle, contigs, batch, min_share=0.1, n_waves=8, wide_lds_bytes=lds)
 
 
