@@ -79,3 +79,26 @@ def test_wide_results_and_a_second_round_through_the_same_slots(job):
             got = t.wait()
             want = ctx.solve_packed(p, res=ResultBatch(p, sequences=False, group_metrics=False))
             assert got.diff(want) == []
+
+
+def test_packed_basepair_groups_through_tickets(job):
+    """bp_packed / bp_spilled / bp_groups of batches in flight against the synchronous call (the spill count is read when the ticket is waited for).  Where a region's
+    groups land in the spill area is decided by an atomic counter, so the words of spilled regions differ from call to call: compared are the one-word regions, which
+    regions spill, and the spilled groups as a multiset; the first region's groups are followed through its index."""
+    ctx, contigs, batch, whole = job
+    parts = [ctx.pinned_packed(p) for p in whole.split(3)]
+    want = [ctx.solve_packed(p, res=ResultBatch(p, sequences=False, group_metrics=False, packed="only", bp_groups="packed")) for p in parts]
+    tickets = [ctx.submit_packed(p, res=ctx.pinned_results(p, packed="only", bp_groups="packed")) for p in parts]
+    for k in (2, 0, 1):
+        got = tickets[k].wait()
+        n = parts[k].n_regions
+        g, w = got.bp_packed[:n], want[k].bp_packed[:n]
+        spill_g, spill_w = (g >> np.uint32(31)) != 0, (w >> np.uint32(31)) != 0
+        assert same(got, want[k]) and np.array_equal(spill_g, spill_w) and np.array_equal(g[~spill_g], w[~spill_w])
+        m = int(got.bp_spilled[0])
+        assert m == int(want[k].bp_spilled[0]) > 0
+        rows_g, rows_w = got.bp_groups[:m], want[k].bp_groups[:m]
+        assert np.array_equal(rows_g[np.lexsort(rows_g.T)], rows_w[np.lexsort(rows_w.T)])
+        r = int(np.flatnonzero(spill_g)[0])  # (a region has at least two groups when it spills: the joint one and one per call type)
+        ig, iw = int(g[r] & np.uint32(0x7FFFFFFF)), int(w[r] & np.uint32(0x7FFFFFFF))
+        assert np.array_equal(rows_g[ig:ig + 2], rows_w[iw:iw + 2])
