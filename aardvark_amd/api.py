@@ -42,6 +42,7 @@ def load_library():
     lib = C.CDLL(path)
     vp = C.c_void_p
     lib.avk_version.restype = C.c_char_p
+    lib.avk_source_hash.restype = C.c_char_p
     lib.avk_merge_classify.argtypes = [C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint8), C.POINTER(C.c_int32), C.POINTER(C.c_uint8),
                                        vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint8), C.POINTER(C.c_uint64)]
     lib.avk_edit_distance.restype = C.c_uint64

@@ -527,6 +527,10 @@ void free_batch_buffers(avk_dev_batch *db) {
 extern "C" {
 
 const char *avk_version(void) { return "aardvark_amd 0.1 (gfx950)"; }
+#ifndef AVK_SOURCE_HASH
+#define AVK_SOURCE_HASH "unknown"
+#endif
+const char *avk_source_hash(void) { return AVK_SOURCE_HASH; }
 
 uint64_t avk_edit_distance(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len) { return avk::host_edit_distance(a, a_len, b, b_len); }
 
@@ -566,7 +570,10 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     }
     ctx->own_stream = true;
     if (hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess || hipEventCreate(&ctx->evk1) != hipSuccess ||
-        hipEventCreate(&ctx->ev_lane) != hipSuccess) {
+        hipEventCreate(&ctx->ev_lane) != hipSuccess ||
+        /* the buffer pool's fence exists from the start: a resident upload that releases its temporaries in stream order BEFORE the first asynchronous submit must be
+         * able to record it (upload_device_packed), or the first packing on pack_stream could be handed buffers that queued kernels still read */
+        hipEventCreateWithFlags(&ctx->ev_pool_fence, hipEventDisableTiming) != hipSuccess) {
         avk_ctx_destroy(ctx);
         return fail(nullptr, AVK_E_HIP, "hipEventCreate failed");
     }
@@ -2488,16 +2495,19 @@ int avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const
             slot = i;
             break;
         }
-    if (slot < 0) {
-        bool any_free = false;
-        for (int i = 0; i < 4; ++i) any_free = any_free || !ctx->stage[i].busy;
-        if (!any_free) {
+    if (slot < 0 && can_queue) {
+        delete t;
+        return fail(ctx, AVK_E_STATE, "four batches are in flight: avk_wait for one of them first");
+    }
+    if (slot < 0) { /* solved here and now (it uses no staging slot): a complete ticket on success, no ticket on failure — the caller owns what it is handed */
+        const int rc_now = avk_compare_packed(ctx, batch, cfg, out);
+        if (rc_now) {
             delete t;
-            return fail(ctx, AVK_E_STATE, "four batches are in flight: avk_wait for one of them first");
+            return rc_now;
         }
-        t->rc = avk_compare_packed(ctx, batch, cfg, out);
+        t->rc = 0;
         *ticket = t;
-        return t->rc;
+        return AVK_E_OK;
     }
     avk_ctx::StageSlot &sl = ctx->stage[slot];
     PackedOnDevice pre;

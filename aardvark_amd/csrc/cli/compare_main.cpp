@@ -6,6 +6,7 @@
  * --output-debug writes cli_settings.json, region_summary.tsv.gz and region_sequences.tsv.gz.
  */
 #include <dlfcn.h>
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <cerrno>
@@ -364,11 +365,14 @@ int main(int argc, char **argv) {
             if (!init_all || init_all(comms.data(), (int)n_workers, devices.data()) != 0) {
                 if (verbosity) fprintf(stderr, "RCCL is not available (%s): the ranks' tallies are summed on the host.\n", h ? "ncclCommInitAll failed" : "librccl.so not found");
                 distinct = false;
+                std::fill(comms.begin(), comms.end(), nullptr);
             }
         }
         std::vector<std::string> worker_err(n_workers);
         std::vector<std::vector<uint64_t>> w_total(n_workers, std::vector<uint64_t>(AVK_TALLY_LEN, 0));
         std::mutex log_mutex;
+        std::vector<avk_ctx *> w_ctx(n_workers, nullptr); /* the contexts outlive the workers: the collective runs after every rank is known to have solved its shard */
+        w_ctx[0] = ctx;
         auto shard_worker = [&](size_t w) {
             avk_ctx *my = ctx;
             if (w > 0) {
@@ -377,13 +381,13 @@ int main(int argc, char **argv) {
                     worker_err[w] = std::string("cannot create the GPU context: ") + avk_last_error(nullptr);
                     return;
                 }
+                w_ctx[w] = my;
                 const uint32_t n_contigs = avf_genome_n_contigs(genome);
                 std::vector<const uint8_t *> seqs(n_contigs);
                 std::vector<uint64_t> lens(n_contigs);
                 for (uint32_t c = 0; c < n_contigs; ++c) seqs[c] = avf_genome_seq(genome, c), lens[c] = avf_genome_len(genome, c);
                 if (avk_ref_upload(my, n_contigs, seqs.data(), lens.data())) { /* the reference is replicated: 0.8 GB packed per rank */
                     worker_err[w] = std::string("reference upload failed: ") + avk_last_error(my);
-                    avk_ctx_destroy(my);
                     return;
                 }
                 (void)avk_ctx_set_option(my, "emit_group_metrics", 0);
@@ -413,20 +417,47 @@ int main(int argc, char **argv) {
                             b1.t_off = all->t_off + first, b1.t_cnt = all->t_cnt + first, b1.q_off = all->q_off + first, b1.q_cnt = all->q_cnt + first;
                             report_unsolved(b1, idx[k], s_status[k]);
                         }
-                    if (distinct && avk_tally_allreduce(my, comms[w], w_total[w].data())) worker_err[w] = std::string("tally all-reduce failed: ") + avk_last_error(my);
                 }
                 avk_packed_shard_free(shard);
             }
-            if (w > 0) avk_ctx_destroy(my);
         };
         std::vector<std::thread> pool;
         for (size_t w = 1; w < n_workers; ++w) pool.emplace_back(shard_worker, w);
         shard_worker(0);
         for (std::thread &t : pool) t.join();
+        pool.clear();
+        bool all_solved = true;
+        for (size_t w = 0; w < n_workers; ++w) all_solved = all_solved && worker_err[w].empty();
+        /* the collective: entered only when EVERY rank has its sums — a rank that failed above never leaves the others waiting inside ncclAllReduce */
+        if (all_solved && distinct) {
+            std::vector<std::vector<uint64_t>> reduced = w_total;
+            std::vector<std::string> reduce_err(n_workers);
+            auto reduce_worker = [&](size_t w) {
+                if (avk_tally_allreduce(w_ctx[w], comms[w], reduced[w].data())) reduce_err[w] = avk_last_error(w_ctx[w]);
+            };
+            for (size_t w = 1; w < n_workers; ++w) pool.emplace_back(reduce_worker, w);
+            reduce_worker(0);
+            for (std::thread &t : pool) t.join();
+            for (size_t w = 0; w < n_workers; ++w)
+                if (!reduce_err[w].empty()) { /* the ranks' own tallies are still there: the host sum stands in */
+                    if (verbosity) fprintf(stderr, "tally all-reduce failed (%s): the ranks' tallies are summed on the host.\n", reduce_err[w].c_str());
+                    distinct = false;
+                    break;
+                }
+            if (distinct) total = reduced[0]; /* every rank holds the job's sums */
+        } else if (!all_solved) distinct = false;
+        for (size_t w = 0; w < n_workers; ++w) {
+            if (comms[w]) {
+                typedef int (*destroy_fn)(void *);
+                void *h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+                destroy_fn destroy = h ? (destroy_fn)dlsym(h, "ncclCommDestroy") : nullptr;
+                if (destroy) (void)destroy(comms[w]);
+            }
+            if (w > 0 && w_ctx[w]) avk_ctx_destroy(w_ctx[w]);
+        }
         for (size_t w = 0; w < n_workers; ++w)
             if (!worker_err[w].empty()) die(70, worker_err[w].c_str(), "");
-        if (distinct) total = w_total[0]; /* every rank holds the job's sums */
-        else
+        if (!distinct)
             for (size_t w = 0; w < n_workers; ++w)
                 for (size_t k = 0; k < (size_t)AVK_TALLY_LEN; ++k) total[k] += w_total[w][k];
         if (verbosity) fprintf(stderr, "%zu contexts, regions sharded by hash(region_id) %% %zu; the job tally summed %s.\n", n_workers, n_workers, distinct ? "by one RCCL all-reduce" : "on the host");

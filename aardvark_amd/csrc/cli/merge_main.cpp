@@ -5,6 +5,7 @@
  * (+ .tbi each) and the summary table.  Option names are the reference's (src/cli/merge.rs).
  */
 #include <cerrno>
+#include <algorithm>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -14,6 +15,7 @@
 #include <thread>
 #include <vector>
 
+#include <dlfcn.h>
 #include <sys/stat.h>
 
 #include "../../../include/aardvark_amd.h"
@@ -34,7 +36,7 @@ void usage() {
             "  [-s SAMPLE ...] [-t TAG ...] [--output-summary SUMMARY.tsv|.csv] [--output-debug DIR]\n"
             "  [--min-variant-gap 50] [--disable-variant-trimming] [--merge-strategy exact|no_conflict|majority|all]\n"
             "  [--enable-no-conflict] [--enable-voting] [--conflict-select INDEX] [--max-branch-factor 50]\n"
-            "  [--skip N] [--take N] [--device 0] [--batch-regions 1000000] [--contexts 2] [--batch-form packed|wide]\n");
+            "  [--skip N] [--take N] [--device 0 | --devices 0,1,..] [--batch-regions 1000000] [--contexts 2] [--batch-form packed|wide]\n");
 }
 
 std::string json_string(const std::string &s) {
@@ -74,6 +76,7 @@ int main(int argc, char **argv) {
     bool ref_upper = true; /* --reference-case upper|raw (include/aardvark_feeder.h, avf_genome_load_case) */
     long long conflict_select = -1;
     int device = 0;
+    std::vector<int> devices; /* --devices: one solver context per entry; the regions are sharded over them by avk_region_shard (the first entry is `device`) */
     for (int i = 1; i < argc; ++i) {
         const std::string a = argv[i];
         auto val = [&]() -> const char * {
@@ -103,6 +106,18 @@ int main(int argc, char **argv) {
         else if (a == "--skip") skip = strtoull(val(), nullptr, 10);
         else if (a == "--take") take = strtoull(val(), nullptr, 10);
         else if (a == "--device") device = atoi(val());
+        else if (a == "--devices") { /* e.g. 0,1,2,3 — or 0,0 for two contexts on one GPU */
+            const std::string list = val();
+            devices.clear();
+            for (size_t b = 0; b <= list.size();) {
+                const size_t e = list.find(',', b);
+                const std::string item = list.substr(b, e == std::string::npos ? std::string::npos : e - b);
+                if (item.empty()) die(64, "invalid value for --devices", list.c_str());
+                devices.push_back(atoi(item.c_str()));
+                if (e == std::string::npos) break;
+                b = e + 1;
+            }
+        }
         else if (a == "--batch-regions") batch_regions = strtoull(val(), nullptr, 10);
         else if (a == "--contexts") contexts = strtoull(val(), nullptr, 10);
         else if (a == "--batch-form") { /* packed (default; wide when the call sets do not fit the form) | wide */
@@ -147,6 +162,7 @@ int main(int argc, char **argv) {
     if (samples.size() > vcfs.size()) samples.resize(vcfs.size());
     if (batch_regions == 0) batch_regions = 1;
     if (threads == 0) threads = 1;
+    if (!devices.empty()) device = devices[0];
 
     /* the reference genome, the call sets and the GPU context come up side by side */
     auto t0 = std::chrono::steady_clock::now();
@@ -276,10 +292,119 @@ int main(int argc, char **argv) {
     std::vector<uint8_t> classification(all->n_regions + 1, 0);
     std::vector<uint64_t> members(all->n_regions + 1, 0);
     uint64_t solved = 0, errors = 0;
+    /* --devices a,b,..: the merge regions are mapped exactly like compare regions (src/main.rs:463-478), so the job is cut by the library's ONE rule, shard =
+     * hash(region_id) % ranks (avk_region_shard), every context solves its shard of the packed batch and scatters status / classification / members back for the
+     * writers; the only state across regions, MergeSummaryWriter's (reason, type, input) -> (pass, fail) map (src/writers/merge_summary.rs:12-18), is a dense block
+     * of sums per rank (avk_merge_counts) added up by one RCCL all-reduce (avk_counts_allreduce) when every context has a GPU of its own, on the host when entries
+     * repeat (RCCL does not take two ranks on one device) — and the summary table is written from those sums. */
+    const size_t n_ranks = devices.size() >= 2 && packed ? devices.size() : 1;
+    const uint64_t counts_len = avk_merge_counts_len(k);
+    std::vector<uint64_t> job_counts;
+    if (n_ranks > 1) {
+        avk_packed_multi_batch sel;
+        if (avf_packed_multi_slice(feed, &packed_all, first, count, &sel)) die(70, "cannot select the regions", avf_last_error());
+        bool distinct = counts_len != 0;
+        for (size_t i = 0; i < n_ranks; ++i)
+            for (size_t j = i + 1; j < n_ranks; ++j) distinct = distinct && devices[i] != devices[j];
+        std::vector<void *> comms(n_ranks, nullptr);
+        void *rccl = nullptr;
+        if (distinct) { /* one communicator per context (ncclCommInitAll of RCCL, looked up at run time: the tool does not link it) */
+            typedef int (*init_all_fn)(void **, int, const int *);
+            rccl = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+            init_all_fn init_all = rccl ? (init_all_fn)dlsym(rccl, "ncclCommInitAll") : nullptr;
+            if (!init_all || init_all(comms.data(), (int)n_ranks, devices.data()) != 0) {
+                if (verbosity) fprintf(stderr, "RCCL is not available (%s): the ranks' summary counters are summed on the host.\n", rccl ? "ncclCommInitAll failed" : "librccl.so not found");
+                distinct = false;
+                std::fill(comms.begin(), comms.end(), nullptr);
+            }
+        }
+        std::vector<std::string> rank_err(n_ranks);
+        std::vector<avk_ctx *> r_ctx(n_ranks, nullptr);
+        r_ctx[0] = ctx;
+        std::vector<std::vector<uint64_t>> r_counts(n_ranks, std::vector<uint64_t>(counts_len ? counts_len : 1, 0));
+        auto rank_worker = [&](size_t w) {
+            avk_ctx *my = ctx;
+            if (w > 0) {
+                my = nullptr;
+                if (avk_ctx_create(devices[w], &my)) {
+                    rank_err[w] = std::string("cannot create the GPU context: ") + avk_last_error(nullptr);
+                    return;
+                }
+                r_ctx[w] = my;
+                const uint32_t n_contigs = avf_genome_n_contigs(genome);
+                std::vector<const uint8_t *> seqs(n_contigs);
+                std::vector<uint64_t> lens(n_contigs);
+                for (uint32_t c = 0; c < n_contigs; ++c) seqs[c] = avf_genome_seq(genome, c), lens[c] = avf_genome_len(genome, c);
+                if (avk_ref_upload(my, n_contigs, seqs.data(), lens.data())) { /* the reference is replicated */
+                    rank_err[w] = std::string("reference upload failed: ") + avk_last_error(my);
+                    return;
+                }
+            }
+            avk_packed_multi_shard *shard = nullptr;
+            if (avk_packed_multi_shard_make(&sel, all->region_id + first, 0, (uint32_t)w, (uint32_t)n_ranks, &shard)) {
+                rank_err[w] = "cannot cut the shard";
+                return;
+            }
+            const avk_packed_multi_batch *sb = avk_packed_multi_shard_batch(shard);
+            std::vector<int32_t> s_status(sb->n_regions + 1);
+            std::vector<uint8_t> s_cls(sb->n_regions + 1);
+            std::vector<uint64_t> s_members(sb->n_regions + 1);
+            if (avk_merge_packed(my, sb, &cfg, s_status.data(), s_cls.data(), s_members.data())) rank_err[w] = std::string("merge failed: ") + avk_last_error(my);
+            else {
+                (void)avk_packed_multi_shard_scatter(shard, s_status.data(), s_cls.data(), s_members.data(), status.data() + first, classification.data() + first,
+                                                     members.data() + first);
+                if (counts_len && avk_merge_counts(sb, s_status.data(), s_cls.data(), s_members.data(), r_counts[w].data())) rank_err[w] = "cannot count the shard's variants";
+            }
+            avk_packed_multi_shard_free(shard);
+        };
+        std::vector<std::thread> rank_pool;
+        for (size_t w = 1; w < n_ranks; ++w) rank_pool.emplace_back(rank_worker, w);
+        rank_worker(0);
+        for (std::thread &t : rank_pool) t.join();
+        rank_pool.clear();
+        bool all_solved = true;
+        for (size_t w = 0; w < n_ranks; ++w) all_solved = all_solved && rank_err[w].empty();
+        /* the collective: entered only when every rank has its sums, so a rank that failed never leaves the others waiting inside ncclAllReduce */
+        if (all_solved && distinct) {
+            std::vector<std::vector<uint64_t>> reduced = r_counts;
+            std::vector<std::string> reduce_err(n_ranks);
+            auto reduce_worker = [&](size_t w) {
+                if (avk_counts_allreduce(r_ctx[w], comms[w], reduced[w].data(), counts_len)) reduce_err[w] = avk_last_error(r_ctx[w]);
+            };
+            for (size_t w = 1; w < n_ranks; ++w) rank_pool.emplace_back(reduce_worker, w);
+            reduce_worker(0);
+            for (std::thread &t : rank_pool) t.join();
+            for (size_t w = 0; w < n_ranks; ++w)
+                if (!reduce_err[w].empty()) {
+                    if (verbosity) fprintf(stderr, "all-reduce of the summary counters failed (%s): they are summed on the host.\n", reduce_err[w].c_str());
+                    distinct = false;
+                    break;
+                }
+            if (distinct) job_counts = reduced[0]; /* every rank holds the job's sums */
+        } else distinct = false;
+        for (size_t w = 0; w < n_ranks; ++w) {
+            if (comms[w] && rccl) {
+                typedef int (*destroy_fn)(void *);
+                destroy_fn destroy = (destroy_fn)dlsym(rccl, "ncclCommDestroy");
+                if (destroy) (void)destroy(comms[w]);
+            }
+            if (w > 0 && r_ctx[w]) avk_ctx_destroy(r_ctx[w]);
+        }
+        for (size_t w = 0; w < n_ranks; ++w)
+            if (!rank_err[w].empty()) die(70, rank_err[w].c_str(), "");
+        if (!distinct && counts_len) {
+            job_counts.assign(counts_len, 0);
+            for (size_t w = 0; w < n_ranks; ++w)
+                for (uint64_t i = 0; i < counts_len; ++i) job_counts[i] += r_counts[w][i];
+        }
+        if (verbosity)
+            fprintf(stderr, "%zu contexts, regions sharded by hash(region_id) %% %zu; the summary counters summed %s.\n", n_ranks, n_ranks,
+                    distinct ? "by one RCCL all-reduce" : counts_len ? "on the host" : "from the scattered per-region results (more inputs than the dense counters take)");
+    }
     /* Two contexts on the same GPU work through the batches: the host side of one batch (pair records, packing, upload, classification)
      * runs beside the kernels of the other.  The second context is made by its own thread, reference upload included. */
     const uint64_t n_batches = (count + batch_regions - 1) / batch_regions;
-    const int n_workers = n_batches >= 2 && contexts >= 2 ? 2 : 1;
+    const int n_workers = n_ranks > 1 ? 0 : n_batches >= 2 && contexts >= 2 ? 2 : 1;
     std::atomic<uint64_t> next_batch{0};
     std::string worker_err[2];
     auto solve_batches = [&](int w) {
@@ -331,7 +456,7 @@ int main(int argc, char **argv) {
     {
         std::thread other;
         if (n_workers == 2) other = std::thread(solve_batches, 1);
-        solve_batches(0);
+        if (n_workers >= 1) solve_batches(0);
         if (other.joinable()) other.join();
         for (int w = 0; w < 2; ++w)
             if (!worker_err[w].empty()) die(70, worker_err[w].c_str(), "");
@@ -355,7 +480,8 @@ int main(int argc, char **argv) {
         die(74, "Error while writing merged VCF results", avf_last_error());
     fprintf(stderr, "Solved:error blocks: %llu : %llu\n", (unsigned long long)solved, (unsigned long long)errors);
     if (!summary_path.empty() &&
-        avf_write_merge_summary(summary_path.c_str(), all, tag_ptrs.data(), status.data(), classification.data(), members.data()))
+        (job_counts.empty() ? avf_write_merge_summary(summary_path.c_str(), all, tag_ptrs.data(), status.data(), classification.data(), members.data())
+                            : avf_write_merge_summary_counts(summary_path.c_str(), k, tag_ptrs.data(), job_counts.data(), job_counts.size())))
         die(74, "Error while saving summary file", avf_last_error());
     const double s_write = seconds_since(t0);
 

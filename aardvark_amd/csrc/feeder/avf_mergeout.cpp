@@ -222,34 +222,16 @@ extern "C" int avf_write_merge_outputs(const char *out_folder, const char *prima
     return 0;
 }
 
-extern "C" int avf_write_merge_summary(const char *path, const avk_multi_batch *b, const char *const *tags, const int32_t *status,
-                                       const uint8_t *classification, const uint64_t *members) {
-    if (!path || !b || !tags || !status || !classification || !members) return avf_fail_(AVK_E_ARG, "null argument");
-    int rc = check_results(b, classification, members, status);
-    if (rc) return rc;
-    /* derive(Ord) of MergeClassification: Different < NoConflict{indices} < MajorityAgree{indices} < ConflictSelection{index} <
-     * BasepairIdentical, index lists compared lexicographically; then VariantType in declaration order; then the input */
-    static const int rank_of[5] = {0, 4, 1, 2, 3}; /* AVK_MERGE_* -> position in the enum */
+namespace {
+/* derive(Ord) of MergeClassification: Different < NoConflict{indices} < MajorityAgree{indices} < ConflictSelection{index} <
+ * BasepairIdentical, index lists compared lexicographically; then VariantType in declaration order; then the input */
+typedef std::tuple<int, std::vector<uint32_t>, uint8_t, uint32_t> SummaryKey;
+typedef std::map<SummaryKey, std::pair<uint64_t, uint64_t>> SummaryCounts;
+const int summary_rank_of[5] = {0, 4, 1, 2, 3}; /* AVK_MERGE_* -> position in the enum */
+
+int write_summary_rows(const char *path, const char *const *tags, const SummaryCounts &counts) {
     static const char *const type_names[AVK_N_VARIANT_TYPES] = {"Snv", "Insertion", "Deletion", "Indel", "SvInsertion", "SvDeletion", "SvDuplication",
                                                                  "SvInversion", "SvBreakend", "TrContraction", "TrExpansion", "Unknown"};
-    typedef std::tuple<int, std::vector<uint32_t>, uint8_t, uint32_t> Key;
-    std::map<Key, std::pair<uint64_t, uint64_t>> counts;
-    const uint32_t k = b->n_inputs;
-    for (uint64_t r = 0; r < b->n_regions; ++r) {
-        if (status[r] != 0) continue;
-        const uint8_t cls = classification[r];
-        const std::vector<uint32_t> idx = member_indices(cls, members[r]);
-        for (uint32_t i = 0; i < k; ++i) {
-            const bool passing = cls == AVK_MERGE_IDENTICAL || std::find(idx.begin(), idx.end(), i) != idx.end();
-            const uint64_t off = b->in_off[r * k + i];
-            for (uint32_t j = 0; j < b->in_cnt[r * k + i]; ++j) {
-                const uint8_t vt = b->var_type[off + j];
-                if (vt >= AVK_N_VARIANT_TYPES) return avf_fail_(AVK_E_ARG, "variant %llu has the unknown type %u", (unsigned long long)(off + j), vt);
-                std::pair<uint64_t, uint64_t> &e = counts[Key(rank_of[cls], idx, vt, i)];
-                (passing ? e.first : e.second) += 1;
-            }
-        }
-    }
     const std::string p = path;
     const char delim = p.size() >= 4 && p.compare(p.size() - 4, 4, ".csv") == 0 ? ',' : '\t';
     std::string text;
@@ -285,4 +267,58 @@ extern "C" int avf_write_merge_summary(const char *path, const avk_multi_batch *
     const bool ok = fwrite(text.data(), 1, text.size(), fp) == text.size();
     if (fclose(fp) != 0 || !ok) return avf_fail_(AVK_E_ARG, "write error on %s", path);
     return 0;
+}
+} // namespace
+
+extern "C" int avf_write_merge_summary(const char *path, const avk_multi_batch *b, const char *const *tags, const int32_t *status,
+                                       const uint8_t *classification, const uint64_t *members) {
+    if (!path || !b || !tags || !status || !classification || !members) return avf_fail_(AVK_E_ARG, "null argument");
+    int rc = check_results(b, classification, members, status);
+    if (rc) return rc;
+    SummaryCounts counts;
+    const uint32_t k = b->n_inputs;
+    for (uint64_t r = 0; r < b->n_regions; ++r) {
+        if (status[r] != 0) continue;
+        const uint8_t cls = classification[r];
+        const std::vector<uint32_t> idx = member_indices(cls, members[r]);
+        for (uint32_t i = 0; i < k; ++i) {
+            const bool passing = cls == AVK_MERGE_IDENTICAL || std::find(idx.begin(), idx.end(), i) != idx.end();
+            const uint64_t off = b->in_off[r * k + i];
+            for (uint32_t j = 0; j < b->in_cnt[r * k + i]; ++j) {
+                const uint8_t vt = b->var_type[off + j];
+                if (vt >= AVK_N_VARIANT_TYPES) return avf_fail_(AVK_E_ARG, "variant %llu has the unknown type %u", (unsigned long long)(off + j), vt);
+                std::pair<uint64_t, uint64_t> &e = counts[SummaryKey(summary_rank_of[cls], idx, vt, i)];
+                (passing ? e.first : e.second) += 1;
+            }
+        }
+    }
+    return write_summary_rows(path, tags, counts);
+}
+
+/* The same table from the dense block of sums a sharded merge all-reduces (include/aardvark_amd.h: avk_merge_counts / avk_merge_counts_reason): the keys
+ * with a count become the rows, in the reference's key order.  The layout is restated here (the feeder library does not link the solver library):
+ * reason 0 Different, 1 + mask NoConflict, 1 + 2^k + mask MajorityAgree, 1 + 2 * 2^k + index ConflictSelection, 1 + 2 * 2^k + k BasepairIdentical. */
+extern "C" int avf_write_merge_summary_counts(const char *path, uint32_t n_inputs, const char *const *tags, const uint64_t *counts, uint64_t counts_len) {
+    if (!path || !tags || !counts) return avf_fail_(AVK_E_ARG, "null argument");
+    const uint32_t k = n_inputs;
+    if (k < 2 || k > AVK_MERGE_COUNTS_MAX_INPUTS) return avf_fail_(AVK_E_ARG, "dense summary counters exist for 2..%d inputs, not %u", AVK_MERGE_COUNTS_MAX_INPUTS, k);
+    const uint64_t masks = 1ull << k, reasons = 2 + 2 * masks + k;
+    if (counts_len != reasons * AVK_N_VARIANT_TYPES * k * 2) return avf_fail_(AVK_E_ARG, "%llu counters given, %u inputs have %llu", (unsigned long long)counts_len, k,
+                                                                              (unsigned long long)(reasons * AVK_N_VARIANT_TYPES * k * 2));
+    SummaryCounts rows;
+    for (uint64_t reason = 0; reason < reasons; ++reason) {
+        uint8_t cls = AVK_MERGE_DIFFERENT;
+        uint64_t members = 0;
+        if (reason == reasons - 1) cls = AVK_MERGE_IDENTICAL;
+        else if (reason >= 1 + 2 * masks) cls = AVK_MERGE_CONFLICT_SELECTION, members = reason - 1 - 2 * masks;
+        else if (reason >= 1 + masks) cls = AVK_MERGE_MAJORITY_AGREE, members = reason - 1 - masks;
+        else if (reason >= 1) cls = AVK_MERGE_NO_CONFLICT, members = reason - 1;
+        const std::vector<uint32_t> idx = member_indices(cls, members);
+        for (uint32_t vt = 0; vt < AVK_N_VARIANT_TYPES; ++vt)
+            for (uint32_t i = 0; i < k; ++i) {
+                const uint64_t *e = counts + ((reason * AVK_N_VARIANT_TYPES + vt) * k + i) * 2;
+                if (e[0] || e[1]) rows[SummaryKey(summary_rank_of[cls], idx, (uint8_t)vt, i)] = std::make_pair(e[0], e[1]);
+            }
+    }
+    return write_summary_rows(path, tags, rows);
 }

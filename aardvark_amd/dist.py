@@ -94,3 +94,9 @@ def allreduce_tally(tally):
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
         dist.all_reduce(tally, op=dist.ReduceOp.SUM)
     return tally
+
+
+def allreduce_counts(counts):
+    """in-place SUM all-reduce of an int64 tensor of sums over the default process group: a sharded merge's summary counters (aardvark_amd.merge.merge_counts; the
+    reference's only state across merge regions, src/writers/merge_summary.rs:12-18)"""
+    return allreduce_tally(counts)

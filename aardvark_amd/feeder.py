@@ -84,6 +84,7 @@ def load_library():
     lib.avf_write_merge_outputs.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, C.c_char_p, vp, C.POINTER(AvkMultiBatch), cpp,
                                             C.POINTER(C.c_int32), u8p, C.POINTER(C.c_uint64)]
     lib.avf_write_merge_summary.argtypes = [C.c_char_p, C.POINTER(AvkMultiBatch), cpp, C.POINTER(C.c_int32), u8p, C.POINTER(C.c_uint64)]
+    lib.avf_write_merge_summary_counts.argtypes = [C.c_char_p, C.c_uint32, cpp, C.POINTER(C.c_uint64), C.c_uint64]
     lib.avf_calls_load.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.POINTER(vp)]
     lib.avf_calls_free.argtypes = [vp]
     lib.avf_feed_from_calls.argtypes = [C.c_uint32, C.POINTER(vp), C.c_char_p, vp, C.c_uint64, C.c_int, C.POINTER(vp)]
@@ -441,3 +442,11 @@ def write_merge_summary(path, mb, result, tags=None):
     cb = mb.c_struct()
     _check(lib, lib.avf_write_merge_summary(os.fsencode(path), C.byref(cb), _strs(tags), st.ctypes.data_as(C.POINTER(C.c_int32)),
                                             cls.ctypes.data_as(C.POINTER(C.c_uint8)), mem.ctypes.data_as(C.POINTER(C.c_uint64))))
+
+
+def write_merge_summary_counts(path, n_inputs, counts, tags=None):
+    """the merge summary table from the dense block of sums of a sharded merge (aardvark_amd.merge.merge_counts, summed over the ranks)"""
+    lib = load_library()
+    tags = list(tags) if tags else ["vcf_%d" % i for i in range(n_inputs)]
+    counts = np.ascontiguousarray(counts, np.uint64)
+    _check(lib, lib.avf_write_merge_summary_counts(os.fsencode(path), n_inputs, _strs(tags), counts.ctypes.data_as(C.POINTER(C.c_uint64)), counts.size))

@@ -295,3 +295,79 @@ def merge_batch(ctx, multi_regions, config=None):
     if not multi_regions:
         return []
     return merge_multi_batch(ctx, MultiBatch.from_regions(multi_regions), config).decoded()
+
+
+# ---- merge on several GPUs (include/aardvark_amd.h: avk_packed_multi_shard_*, avk_merge_counts*; reference src/main.rs:463-478, src/writers/merge_summary.rs:12-18) ----
+
+MERGE_COUNTS_MAX_INPUTS = 10
+
+
+def _shard_api(lib):
+    if getattr(lib, "_avk_multi_shard_api", False):
+        return lib
+    P = C.POINTER
+    lib.avk_packed_multi_shard_make.argtypes = [P(AvkPackedMultiBatch), P(C.c_uint64), C.c_uint64, C.c_uint32, C.c_uint32, P(C.c_void_p)]
+    lib.avk_packed_multi_shard_batch.restype = P(AvkPackedMultiBatch)
+    lib.avk_packed_multi_shard_batch.argtypes = [C.c_void_p]
+    lib.avk_packed_multi_shard_regions.restype = C.c_uint64
+    lib.avk_packed_multi_shard_regions.argtypes = [C.c_void_p, P(P(C.c_uint64))]
+    lib.avk_packed_multi_shard_scatter.argtypes = [C.c_void_p, P(C.c_int32), P(C.c_uint8), P(C.c_uint64), P(C.c_int32), P(C.c_uint8), P(C.c_uint64)]
+    lib.avk_packed_multi_shard_free.argtypes = [C.c_void_p]
+    lib.avk_merge_counts_len.restype = C.c_uint64
+    lib.avk_merge_counts_len.argtypes = [C.c_uint32]
+    lib.avk_merge_counts_reason.restype = C.c_uint32
+    lib.avk_merge_counts_reason.argtypes = [C.c_uint32, C.c_uint8, C.c_uint64]
+    lib.avk_merge_counts.argtypes = [P(AvkPackedMultiBatch), P(C.c_int32), P(C.c_uint8), P(C.c_uint64), P(C.c_uint64)]
+    lib.avk_counts_allreduce.argtypes = [C.c_void_p, C.c_void_p, P(C.c_uint64), C.c_uint64]
+    lib._avk_multi_shard_api = True
+    return lib
+
+
+def shard_packed_multi(lib, pmb, region_id, rank, world):
+    """the regions of the packed multi-region batch that rank `rank` of `world` owns (avk_packed_multi_shard_make: shard = avk_region_shard(region_id), the rule of
+    dist.region_hash) -> (PackedMultiBatch with copies of the shard's arrays, the regions' indices in the whole batch)"""
+    lib = _shard_api(lib)
+    ids = np.ascontiguousarray(region_id, np.uint64)
+    cb = pmb.c_struct()
+    h = C.c_void_p()
+    rc = lib.avk_packed_multi_shard_make(C.byref(cb), ids.ctypes.data_as(C.POINTER(C.c_uint64)), 0, rank, world, C.byref(h))
+    if rc:
+        raise ValueError("avk_packed_multi_shard_make failed (%d)" % rc)
+    try:
+        b = lib.avk_packed_multi_shard_batch(h).contents
+        n, nv, na, k = int(b.n_regions), int(b.n_variants), int(b.allele_bytes_len), int(b.n_inputs)
+        take = lambda ptr, m, dt: np.ctypeslib.as_array(ptr, shape=(max(m, 1),))[:m].astype(dt).copy() if ptr else None
+        shard = PackedMultiBatch(k, contig_idx=take(b.contig_idx, n, np.uint16), start=take(b.start, n, np.uint32), len=take(b.len, n, np.uint16),
+                                 in_cnt=take(b.in_cnt, n * k, np.uint8), var_rel_pos=take(b.var_rel_pos, nv, np.uint16), var_type_zyg=take(b.var_type_zyg, nv, np.uint8),
+                                 a0_len=take(b.a0_len, nv, np.uint8), a1_len=take(b.a1_len, nv, np.uint8), var_raw_space=take(b.var_raw_space, nv, np.uint32),
+                                 allele_bytes=take(b.allele_bytes, na, np.uint8) if nv else np.zeros(1, np.uint8))
+        idx = C.POINTER(C.c_uint64)()
+        m = int(lib.avk_packed_multi_shard_regions(h, C.byref(idx)))
+        index = np.ctypeslib.as_array(idx, shape=(max(m, 1),))[:m].copy()
+    finally:
+        lib.avk_packed_multi_shard_free(h)
+    return shard, index
+
+
+def merge_counts_len(lib, n_inputs):
+    return int(_shard_api(lib).avk_merge_counts_len(n_inputs))
+
+
+def merge_counts(lib, pmb, result, counts=None):
+    """MergeSummaryWriter::add_merge_benchmark over a solved packed batch as a dense block of sums (avk_merge_counts), ADDED to `counts`"""
+    lib = _shard_api(lib)
+    n = merge_counts_len(lib, pmb.n_inputs)
+    if n == 0:
+        raise ValueError("dense summary counters exist for 2..%d inputs" % MERGE_COUNTS_MAX_INPUTS)
+    if counts is None:
+        counts = np.zeros(n, np.uint64)
+    assert counts.dtype == np.uint64 and counts.size == n and counts.flags.c_contiguous
+    P = lambda a, t: np.ascontiguousarray(a).ctypes.data_as(C.POINTER(t))
+    st, cls, mem = (np.ascontiguousarray(result.status, np.int32), np.ascontiguousarray(result.classification, np.uint8), np.ascontiguousarray(result.members, np.uint64))
+    if pmb.n_regions == 0:
+        return counts
+    cb = pmb.c_struct()
+    rc = lib.avk_merge_counts(C.byref(cb), P(st, C.c_int32), P(cls, C.c_uint8), P(mem, C.c_uint64), counts.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc:
+        raise ValueError("avk_merge_counts failed (%d)" % rc)
+    return counts

@@ -26,6 +26,7 @@ single-process solution through an order-independent checksum.  `--scaling weak`
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import glob
 import json
 import os
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "24")  # before anything loads the HIP runtime: the solver's streams need queues of their own, also beside a communicator's (aardvark_amd/__init__.py)
@@ -68,6 +69,8 @@ def parse():
     ap.add_argument("--resident-steps", type=int, default=300, help="timed avk_compare_resident steps of the resident leg (0 = skip)")
     ap.add_argument("--scale", type=float, default=1.0, help="shrinks the contigs (and the call counts with them); 1.0 = the named workload")
     ap.add_argument("--scaling", choices=["auto", "weak", "strong"], default="auto", help="auto = strong for N > 1 (one call set sharded over the ranks)")
+    ap.add_argument("--records-only", action="store_true", help="the timed calls return per-region records, per-call decisions and the tally only — round 5's `value` — instead of "
+                                                                "the reference's whole return value (those plus the per-region BASEPAIR groups)")
     ap.add_argument("--wide-results", action="store_true", help="the timed calls fill the wide result arrays instead of the packed form")
     ap.add_argument("--form", choices=("packed", "compact"), default="packed", help="flat form of the region batch the timed calls hand over: packed (avk_packed_batch, 94 MB per genome) or compact (avk_compact_batch, 227 MB)")
     ap.add_argument("--pageable", action="store_true", help="caller arrays in ordinary memory (the library stages them through a pinned bounce buffer) instead of avk_host_alloc memory")
@@ -84,8 +87,9 @@ def parse():
     ap.add_argument("--merge-scale", type=float, default=1.0)
     ap.add_argument("--secondary-scale", type=float, default=0.25, help="genome scale of the two robustness mixes of `secondary`")
     ap.add_argument("--no-parity", action="store_true", help="skip the bit-identity gate against the oracle")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r05_pmc_traffic.json"),
-                    help="PMC-derived HBM bytes per step collected with rocprofv3 --pmc in a builder-side run (optional; reported with its source)")
+    ap.add_argument("--traffic-json", default=None,
+                    help="PMC-derived HBM bytes per step collected with rocprofv3 --pmc in a builder-side run (default: the newest profiles/rNN_pmc_traffic.json); it is "
+                         "reported only when the file names the build (avk_source_hash) of the library this process has loaded")
     return ap.parse_args()
 
 
@@ -184,6 +188,27 @@ class _DevI64:
         return out
 
 
+class HostCollectives:
+    """torch.distributed with device tensors carried through host memory (a backend without device support: gloo); everything else is torch.distributed's"""
+
+    def __init__(self, dist):
+        self._dist = dist
+
+    def __getattr__(self, name):
+        return getattr(self._dist, name)
+
+    def all_reduce(self, t, op=None):
+        h = t.cpu()
+        self._dist.all_reduce(h, op=op if op is not None else self._dist.ReduceOp.SUM)
+        t.copy_(h)
+
+    def all_gather(self, out, t):
+        hs = [o.cpu() for o in out]
+        self._dist.all_gather(hs, t.cpu())
+        for o, h in zip(out, hs):
+            o.copy_(h)
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,6 +258,8 @@ def main():
 
     t_begin = time.perf_counter()
     dev = None
+    if os.environ.get("AVK_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     if use_torch:
         torch.cuda.set_device(local_rank)
         dev = torch.device("cuda", local_rank)
@@ -242,7 +269,15 @@ def main():
             os.environ.setdefault("MASTER_PORT", "29533")
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") is the product's transport.  AVK_BENCH_BACKEND=gloo with AVK_BENCH_ONE_DEVICE=1 runs the SAME N-rank code — sharding, the timed region, the
+        # collectives' call sites, the parity gates — with every rank on GPU 0 and the sums carried by gloo through host memory: what a one-GPU box can check of --gpus N
+        # (RCCL refuses two ranks on one device); tests/test_bench_contract.py
+        backend = os.environ.get("AVK_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+            dist = HostCollectives(dist)
     scaling = args.scaling if args.scaling != "auto" else ("strong" if world > 1 else "weak")
 
     # ---- workload
@@ -306,7 +341,12 @@ def main():
         cmp_b = ctx.pinned_compact(cmp_b) if form == "packed" else hb
     # the results in the packed form (avk_result_batch::region_packed / var_packed: 8 B per region + 1 B per call, everything the wide arrays say) unless --wide-results
     res_form = False if args.wide_results else "only"
-    res = ResultBatch(hb, sequences=False, group_metrics=False, packed=res_form) if args.pageable else ctx.pinned_results(hb, packed=res_form)
+    # `value` is measured on the reference's WHOLE return value: solve_compare_region gives a CompareBenchmark with the region's GroupTypeMetrics
+    # (src/data_types/compare_benchmark.rs:9-33), and its BASEPAIR groups cannot be rebuilt from the per-call decisions (waffle_solver.rs:384-445) — so the timed calls
+    # return them too, in the packed form (avk_result_batch::bp_packed / bp_spilled / bp_groups); with the per-call decisions they give the region's whole 13 x 22 block
+    # (avk_group_metrics_from_compact; checked against the oracle below).  --records-only (and the forms that cannot carry them) measure round 5's lighter call.
+    full_result = form == "packed" and not args.pageable and not args.wide_results and not args.records_only
+    res = ResultBatch(hb, sequences=False, group_metrics=False, packed=res_form) if args.pageable else ctx.pinned_results(hb, packed=res_form, bp_groups="packed" if full_result else False)
     cb, ro = hb.c_struct(), res.c_struct()
     entry_point = ctx.lib.avk_compare_packed if form == "packed" else ctx.lib.avk_compare_compact
     entry_name = "avk_compare_packed" if form == "packed" else "avk_compare_compact"
@@ -376,7 +416,8 @@ def main():
     # results of k cross while k + 1 is packed.  The synchronous call stays `value`; this is what a caller with several batches gets.
     pipelined_entry = None
     if form == "packed" and not args.pageable and world == 1:
-        sets = [(hb, res), (ctx.pinned_packed(hb), ctx.pinned_results(hb, packed=res_form))]
+        # (records and calls: a call that returns the BASEPAIR groups reads their spill count back before its last copy and is solved inside the submit)
+        sets = [(hb, ctx.pinned_results(hb, packed=res_form) if full_result else res), (ctx.pinned_packed(hb), ctx.pinned_results(hb, packed=res_form))]
         n_p = max(4, min(args.steps, 20))
         tk = ctx.submit_packed(sets[0][0], config=cfg, res=sets[0][1])  # warm-up in the timed pattern: the second batch in flight takes a second set of device buffers
         for k in range(1, 5):
@@ -405,14 +446,14 @@ def main():
             print("PARITY FAILURE in the pipelined leg", file=sys.stderr)
             sys.exit(3)
         del sets
-    # the value leg's call returning the FULL CompareBenchmark: with the per-region BASEPAIR groups (compare_benchmark.rs:9-33; the "all 8 types" loop of
-    # waffle_solver.rs:384-445) in their packed form — one word per region, the groups of multi-type regions spilled (avk_result_batch::bp_packed)
-    bp_entry = None
-    if form == "packed" and not args.pageable:
+    # the same call with the OTHER set of outputs: `value` returns the full CompareBenchmark (records + per-call decisions + packed BASEPAIR groups: compare_benchmark.rs:9-33;
+    # the "all 8 types" loop of waffle_solver.rs:384-445), this leg leaves the groups out (round 5's `value`) — or the other way round under --records-only
+    bp_entry = records_entry = None
+    if form == "packed" and not args.pageable and not args.wide_results:
         from aardvark_amd.api import group_metrics_from_compact
-        rbp = ctx.pinned_results(hb, packed=res_form, bp_groups="packed")
+        other = ctx.pinned_results(hb, packed=res_form, bp_groups=False if full_result else "packed")
         cbp = hb.c_struct()
-        rbo = rbp.c_struct()
+        rbo = other.c_struct()
         ctx._check(entry_point(ctx.handle, C.byref(cbp), C.byref(ccfg), C.byref(rbo)))
         n_b = max(3, min(args.steps, 20))
         fence()
@@ -421,22 +462,36 @@ def main():
             ctx._check(entry_point(ctx.handle, C.byref(cbp), C.byref(ccfg), C.byref(rbo)))
         fence()
         b_elapsed = time.perf_counter() - tb0
+        if world > 1:
+            t = torch.tensor([b_elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            b_elapsed = float(t.item())
         b_solver_ms = ctx.last_solver_ms()
+        rbp = res if full_result else other
+        bp_ms, rec_ms = (elapsed / max(args.steps, 1) * 1e3, b_elapsed / n_b * 1e3) if full_result else (b_elapsed / n_b * 1e3, elapsed / max(args.steps, 1) * 1e3)
         spilled = int(rbp.bp_spilled[0])
-        same = (np.array_equal(rbp.region_packed, res_ref_rp) and np.array_equal(rbp.var_packed, res_ref_vp)) if res_form else rbp.diff(got_boundary) == []
+        same = (np.array_equal(other.region_packed, res_ref_rp) and np.array_equal(other.var_packed, res_ref_vp)) if res_form else other.diff(got_boundary) == []
         alg_g = ctx.algorithmic_bytes(batch, with_groups=True)
-        bp_entry = {"value": total_regions * n_b / b_elapsed, "unit": "regions/s", "ms_per_step": b_elapsed / n_b * 1e3, "steps": n_b,
-                    "extra_ms_over_value_leg": b_elapsed / n_b * 1e3 - elapsed / max(args.steps, 1) * 1e3,
+        bp_entry = {"value": total_regions / (bp_ms * 1e-3), "unit": "regions/s", "ms_per_step": bp_ms, "steps": args.steps if full_result else n_b,
+                    "is_the_value_leg": bool(full_result), "extra_ms_over_records_only": bp_ms - rec_ms,
                     "host_bytes_out_per_step_extra": 4 * n_regions + 16 * spilled, "bytes_per_region_extra": (4 * n_regions + 16 * spilled) / max(n_regions, 1),
                     "regions_in_one_word": int(n_regions - int(((rbp.bp_packed[:n_regions] & np.uint32(0x80000000)) != 0).sum())), "spilled_groups": spilled,
-                    "same_records_and_calls_as_value_leg": bool(same),
-                    "roofline": {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg_g), "bytes_per_region": alg_g / max(n_regions, 1), "kernel_ms": b_solver_ms,
-                                 "achieved": alg_g / max(b_solver_ms, 1e-9) / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": alg_g / max(b_solver_ms, 1e-9) / 1e6 / 8000.0},
-                    "what": "the value leg's call returning per-region BASEPAIR groups as well (emit_bp_groups; avk_result_batch::bp_packed / bp_spilled / bp_groups): with the per-call "
-                            "decisions they are the region's whole GroupTypeMetrics (avk_group_metrics_from_compact)"}
+                    "same_records_and_calls_in_both_legs": bool(same),
+                    "what": "the call returning per-region BASEPAIR groups as well (avk_result_batch::bp_packed / bp_spilled / bp_groups): with the per-call decisions they are the "
+                            "region's whole GroupTypeMetrics (avk_group_metrics_from_compact), i.e. the reference's full return value"}
+        if not full_result:
+            bp_entry["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_launch": int(alg_g), "bytes_per_region": alg_g / max(n_regions, 1), "kernel_ms": b_solver_ms,
+                                    "achieved": alg_g / max(b_solver_ms, 1e-9) / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": alg_g / max(b_solver_ms, 1e-9) / 1e6 / 8000.0}
+        records_entry = {"value": total_regions / (rec_ms * 1e-3), "unit": "regions/s", "ms_per_step": rec_ms, "steps": n_b if full_result else args.steps,
+                         "is_the_value_leg": not full_result,
+                         "what": "the call returning per-region records (8 B), per-call decisions (1 B) and the tally only — round 5's `value`; the BASEPAIR groups of a region are not "
+                                 "derivable from these"}
+        if not same:
+            print("PARITY FAILURE: the two result sets disagree on records / calls", file=sys.stderr)
+            sys.exit(3)
         bp_check = (rbp, group_metrics_from_compact)
-        log("with BASEPAIR groups: %.3f ms per call (+%.3f), %.2f extra bytes per region, %d groups spilled" % (bp_entry["ms_per_step"], bp_entry["extra_ms_over_value_leg"],
-                                                                                                              bp_entry["bytes_per_region_extra"], spilled))
+        log("full result (with BASEPAIR groups): %.3f ms per call; records and calls only: %.3f ms (%+.3f); %.2f extra bytes per region, %d groups spilled" % (
+            bp_ms, rec_ms, bp_ms - rec_ms, bp_entry["bytes_per_region_extra"], spilled))
     # the same boundary with the batch in the compact form (avk_compact_batch: 20 B per region + 17 B per call, explicit offsets), when `value` is on the packed one
     compact_entry = None
     if form == "packed":
@@ -478,6 +533,8 @@ def main():
     resident = None
     rb = ctx.upload(batch)
     kernel_ms, solver_ms = [], []
+    if full_result:
+        ctx.set_option("emit_bp_groups", 1)  # the resident steps (and the roofline's kernel durations) write what the value leg's steps write: the per-region groups too
     if args.resident_steps > 0:
         ctx.set_option("accumulate_tally", 1)
         rtally = torch.zeros(aardvark_amd.TALLY_LEN, dtype=torch.int64, device=dev) if use_torch else hip.zeros_i64(aardvark_amd.TALLY_LEN)
@@ -507,6 +564,7 @@ def main():
         ctx.compare_resident(rb, cfg, None)
         kernel_ms.append(ctx.last_kernel_ms())
         solver_ms.append(ctx.last_solver_ms())
+    ctx.set_option("emit_bp_groups", 0)
     tiers = lane_regions = wide_regions = None
     got = ctx.download(rb, group_metrics=False)
     try:
@@ -574,20 +632,39 @@ def main():
             sys.exit(3)
         log("parity vs oracle: %s (%d regions, oracle %.1f s on %d threads)" % (parity, n_regions, cpu_rate_parity[0], cpus))
 
+    # ---- BASELINE configs[4] on N > 1 GPUs: the merge job cut by the same rule (every rank takes part; rank 0 reports)
+    merge_sharded = None
+    if world > 1 and not args.no_merge and not args.no_secondary:
+        merge_sharded = merge_leg_sharded(ctx, args, rank, world, torch, dist, dev, cpus, log, fence)
+        ctx.upload_reference(contigs)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = total_regions * args.steps / elapsed
-        alg_bytes = ctx.algorithmic_bytes(batch, with_groups=False)  # this run writes per-region records, per-call decisions and the tally: no per-region groups
+        alg_bytes = ctx.algorithmic_bytes(batch, with_groups=bool(full_result))  # per-region records, per-call decisions, the tally — and the per-region groups when the steps write them
         s_ms = float(np.mean(solver_ms))
         k_ms = float(np.mean(kernel_ms))
         achieved = alg_bytes / (s_ms * 1e-3) / 1e9
-        traffic = traffic_src = None
-        if os.path.exists(args.traffic_json):
+        # counter traffic is a builder-side measurement (rocprofv3 --pmc needs its own runs): it is reported only for the build it was measured on
+        traffic = None
+        tj = args.traffic_json
+        if tj is None:
+            found = sorted(glob.glob(os.path.join(ROOT, "profiles", "r[0-9][0-9]_pmc_traffic.json")))
+            tj = found[-1] if found else None
+        loaded_hash = (ctx.lib.avk_source_hash() or b"").decode()
+        if tj is None or not os.path.exists(tj):
+            traffic_src = "null: no profiles/rNN_pmc_traffic.json"
+        else:
             try:
-                traffic = json.load(open(args.traffic_json)).get("hbm_bytes_per_launch")
-                traffic_src = "NOT measured in this process: FETCH_SIZE + WRITE_SIZE of a builder-side `rocprofv3 --pmc` run of the resident step, " + os.path.relpath(args.traffic_json, ROOT)
-            except Exception:
-                traffic = None
+                tjs = json.load(open(tj))
+                if tjs.get("source_hash") != loaded_hash or loaded_hash in ("", "unknown"):
+                    traffic_src = "null: %s was measured on build %s, the loaded library is build %s" % (os.path.relpath(tj, ROOT), tjs.get("source_hash", "(unnamed)"), loaded_hash)
+                else:
+                    traffic = tjs.get("hbm_bytes_per_launch")
+                    traffic_src = ("NOT measured in this process: FETCH_SIZE + WRITE_SIZE of a builder-side `rocprofv3 --pmc` run of the resident step on this same build (%s), %s"
+                                   % (loaded_hash, os.path.relpath(tj, ROOT)))
+            except Exception as e:
+                traffic_src = "null: %s unreadable (%s)" % (os.path.relpath(tj, ROOT), e)
         in_bytes = hb.nbytes()
         wide_bytes = sum(getattr(wide, f).nbytes for f in ("contig_idx", "start", "end", "t_off", "t_cnt", "q_off", "q_cnt", "var_pos", "var_type", "var_zyg", "var_raw_space",
                                                             "a0_off", "a0_len", "a1_off", "a1_len", "allele_bytes"))
@@ -613,7 +690,10 @@ def main():
                                       "pageable" if args.pageable else "pinned (avk_host_alloc)"),
                        "regions_per_gpu": n_regions, "max_branch_factor": cfg.max_branch_factor, "min_variant_gap": 50,
                        "host_bytes_in_per_step": in_bytes, "host_bytes_out_per_step": out_bytes,
-                       "outputs_per_step": "per-region record (status, ed_h1, ed_h2, optima, types), per-variant decision (EA, OA, class, resolved zygosity), 288-counter tally" +
+                       "outputs_per_step": ("the reference's full return value (CompareBenchmark, compare_benchmark.rs:9-33): " if full_result else "") +
+                                           "per-region record (status, ed_h1, ed_h2, optima, types), per-variant decision (EA, OA, class, resolved zygosity), 288-counter tally" +
+                                           ("; per-region BASEPAIR groups, packed: one word per region, the groups of multi-type regions spilled (with the per-call decisions: the "
+                                            "region's whole 13 x 22 GroupTypeMetrics block, avk_group_metrics_from_compact)" if full_result else "; NO per-region groups (--records-only)") +
                                            ("" if args.wide_results else "; regions and calls in the packed form of avk_result_batch (8 B + 1 B; avk_results_expand gives the wide arrays)"),
                        "parallelism": ("regions of ONE call set sharded by hash(region_id) over %d GPU(s)" % world if scaling == "strong" else
                                        "one call set per GPU on %d GPU(s)" % world) +
@@ -625,6 +705,7 @@ def main():
             "wide_results": wide_results_entry,
             "pipelined": pipelined_entry,
             "with_bp_groups": bp_entry,
+            "records_only": records_entry,
             "process": ("PyTorch loaded: the process runs on the HIP runtime the wheel bundles (torch/lib/libamdhip64.so)" if use_torch else
                         "one rank, PyTorch not loaded: the process runs on the system's HIP runtime, the one libaardvark_amd.so is linked with (--torch loads it as N > 1 ranks do)"),
             "compact_soa": compact_entry,
@@ -674,6 +755,8 @@ def main():
                                    "sample": "%d pass(es) over the same %d-region batch on %d threads, %.2f s wall, same outputs as the GPU step, host arrays in and out; "
                                              "1 thread: first %d regions" % (reps, n_regions, cpus, sec, n1)}
             log("cpu baseline: %.0f regions/s on %d threads (%.2f s), 1 thread %.0f" % (rate, cpus, sec, rate1))
+        if merge_sharded is not None:
+            out["secondary"] = {"merge_3_callers": merge_sharded}
         if world == 1 and not args.no_secondary:
             out["secondary"] = secondary_legs(ctx, cfg, args, cpus, log, contigs, job_batch, ms_per_step, resident["ms_per_step"] if resident else None)
         sys.stdout.flush()
@@ -879,6 +962,80 @@ def secondary_legs(ctx, cfg, args, cpus, log, job_contigs=None, job_batch=None, 
     if not args.no_e2e:
         sec["e2e_compare"] = e2e_leg(args, log)
     return sec
+
+
+def merge_leg_sharded(ctx, args, rank, world, torch, dist, dev, cpus, log, fence):
+    """BASELINE configs[4] on `world` GPUs (SURVEY.md 8e "merge (config 5): same sharding"): ONE merge job of three call sets; merge regions are mapped like compare
+    regions (src/main.rs:463-478), so every rank cuts its shard of the packed multi-region batch by avk_region_shard (avk_packed_multi_shard_make), solves it
+    with avk_merge_packed, and the job's only cross-region state — MergeSummaryWriter's (reason, type, input) -> (pass, fail) counters
+    (src/writers/merge_summary.rs:12-18), a dense block of sums per rank (avk_merge_counts) — is added up with one all-reduce (RCCL).  Timed like the headline:
+    barrier + synchronise on both sides, MAX over ranks; value = the job's regions / that time.  Parity: the ranks' results gathered as one checksum and the reduced
+    counters against the oracle's pairs + the restated classification on rank 0."""
+    import numpy as np
+    import oracle_lib
+    import merge_oracle as mo
+    from aardvark_amd import dist as avk_dist, synth
+    from aardvark_amd.merge import MergeConfig, MergeResult, PackedMultiBatch, merge_counts, merge_multi_batch, pinned_multi_batch, shard_packed_multi
+    contigs5, mb = synth.config_genome_merge(scale=args.merge_scale, k=3, threads=max(1, min(8, cpus // world)))
+    ctx.upload_reference(contigs5)
+    whole = PackedMultiBatch.from_multi(mb)
+    shard, idx = shard_packed_multi(ctx.lib, whole, mb.region_id, rank, world)
+    if not args.pageable:
+        shard = pinned_multi_batch(ctx, shard)
+    mcfg = MergeConfig(majority_voting_enabled=True)
+    mres = merge_multi_batch(ctx, shard, mcfg)
+    counts = torch.zeros(int(merge_counts(ctx.lib, shard, mres).size), dtype=torch.int64, device=dev)
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    nm = 6
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(nm):
+        mres = merge_multi_batch(ctx, shard, mcfg)
+    mine = merge_counts(ctx.lib, shard, mres)  # add_merge_benchmark over the rank's regions (the job's batches would add into the same block)
+    counts.copy_(torch.from_numpy(mine.view(np.int64).copy()))
+    dist.all_reduce(counts, op=dist.ReduceOp.SUM)  # the merge job's only collective
+    fence()
+    me = time.perf_counter() - t0
+    t = torch.tensor([me], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    me = float(t.item())
+    job_counts = counts.cpu().numpy().view(np.uint64)
+    # one integer for the shards' per-region results: sum over regions of hash(region_id, status, classification, members), summed over the ranks
+    def checksum(ids, r):
+        with np.errstate(over="ignore"):
+            w = (r.status.astype(np.int64).astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + r.classification.astype(np.uint64) * np.uint64(1000003) +
+                 r.members.astype(np.uint64) * np.uint64(998244353))
+            return avk_dist.region_hash(np.asarray(ids, np.uint64) * np.uint64(3) + np.uint64(1) + w * np.uint64(0xD6E8FEB86659FD93)).sum(dtype=np.uint64)
+    chk = torch.from_numpy(np.array([checksum(mb.region_id[idx], mres)], np.uint64).view(np.int64).copy()).to(dev)
+    dist.all_reduce(chk, op=dist.ReduceOp.SUM)
+    sizes = torch.tensor([shard.n_regions], dtype=torch.int64, device=dev)
+    gathered = [torch.zeros_like(sizes) for _ in range(world)]
+    dist.all_gather(gathered, sizes)
+    entry = None
+    bad = []
+    if rank == 0:
+        lib = oracle_lib.load()
+        st_o, ex_o = oracle_lib.optimize_pairs(lib, pair_batch_of(mb), oracle_lib.ContigSet(contigs5), 50, threads=cpus)
+        want = MergeResult(*mo.classify_k3_majority(st_o, ex_o), 3)
+        if int(chk.cpu().numpy().view(np.uint64)[0]) != int(checksum(mb.region_id, want)):
+            bad.append("job_checksum")
+        if not np.array_equal(job_counts, merge_counts(ctx.lib, whole, want)):
+            bad.append("summary_counters")
+        entry = {"workload": "BASELINE configs[4] stand-in: ONE merge job of 3 call sets (seeds 20250105-7) x %.3g genome, majority strategy, %d regions, sharded by hash(region_id) over %d GPUs"
+                             % (args.merge_scale, mb.n_regions, world),
+                 "value": mb.n_regions * nm / me, "unit": "merge regions/s", "ms_per_step": me / nm * 1e3, "steps": nm, "n_gpus": world, "scaling": "strong",
+                 "regions_per_rank": [int(g.item()) for g in gathered], "summary_counters": int(job_counts.size), "variants_counted": int(job_counts.sum()),
+                 "what": "every rank: avk_packed_multi_shard_make -> avk_merge_packed on its shard (host arrays -> host arrays) x %d, then avk_merge_counts and ONE all-reduce of the "
+                         "(reason, type, input) -> (pass, fail) sums (src/writers/merge_summary.rs:12-18); max over ranks" % nm,
+                 "parity": "bit-identical (checksum of every region's status / classification / members over the ranks, and the reduced summary counters, vs oracle pairs + the restated rule)"
+                           if not bad else "MISMATCH:" + ",".join(bad)}
+        log("merge sharded over %d ranks: %.2f ms per job" % (world, entry["ms_per_step"]))
+    ok = torch.tensor([0 if bad else 1], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        print("PARITY FAILURE in the sharded merge leg on rank %d: %s" % (rank, bad), file=sys.stderr)
+        sys.exit(3)
+    return entry
 
 
 def e2e_leg(args, log):

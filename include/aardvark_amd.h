@@ -400,6 +400,8 @@ void avk_packed_shard_free(avk_packed_shard *s);
 /* tally[AVK_TALLY_LEN] (host) summed over the ranks of an RCCL communicator (ncclComm_t), on the context's stream: the job's one collective.  Every rank calls it
  * with its own context and communicator; RCCL is looked up in the process (the caller that made the communicator loaded it), not linked. */
 int  avk_tally_allreduce(avk_ctx *ctx, void *nccl_comm, uint64_t *tally);
+/* the same collective for any block of `n` 64-bit sums (avk_tally_allreduce is this with n = AVK_TALLY_LEN; a sharded merge sums its summary counters with it) */
+int  avk_counts_allreduce(avk_ctx *ctx, void *nccl_comm, uint64_t *counts, uint64_t n);
 
 typedef struct avk_ticket avk_ticket;
 int  avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket);
@@ -557,12 +559,37 @@ int avk_merge_batch(avk_ctx *ctx, const avk_multi_batch *batch, const avk_merge_
 int avk_merge_packed(avk_ctx *ctx, const avk_packed_multi_batch *batch, const avk_merge_config *cfg,
                      int32_t *status, uint8_t *classification, uint64_t *members);
 
+/* ---- merge on several GPUs (BASELINE configs[4]): merge regions are mapped exactly like compare regions (src/main.rs:463-478), so the same rule cuts a packed
+ * multi-region batch: avk_packed_multi_shard_make gathers the regions rank `rank` of `world` owns (avk_region_shard of region_id[r], or of first_id + r), in the
+ * whole batch's order; _scatter writes the shard's status / classification / members at the regions' places in the whole batch's arrays.  The only state a merge
+ * keeps across regions is MergeSummaryWriter's map (merge reason with its indices, variant type, input) -> (pass, fail) variant counts
+ * (src/writers/merge_summary.rs:12-18, filled by add_merge_benchmark :57-81): avk_merge_counts ADDS a solved batch to a dense block of avk_merge_counts_len(k)
+ * sums — entry ((reason * AVK_N_VARIANT_TYPES + type) * k + input) * 2 + (0 pass | 1 fail), reason = avk_merge_counts_reason() — which the ranks sum with one
+ * avk_counts_allreduce (RCCL) or on the host, and avf_write_merge_summary_counts of the feeder library writes as the reference's table.  Dense blocks exist for
+ * k <= AVK_MERGE_COUNTS_MAX_INPUTS inputs (the reasons carry a subset of the inputs: 2 + 2 * 2^k + k of them); avk_merge_counts_len is 0 beyond, and a job with
+ * more inputs writes its summary from the scattered per-region arrays (avf_write_merge_summary). */
+typedef struct avk_packed_multi_shard avk_packed_multi_shard;
+int  avk_packed_multi_shard_make(const avk_packed_multi_batch *whole, const uint64_t *region_id, uint64_t first_id, uint32_t rank, uint32_t world,
+                                 avk_packed_multi_shard **out);
+const avk_packed_multi_batch *avk_packed_multi_shard_batch(const avk_packed_multi_shard *s);
+uint64_t avk_packed_multi_shard_regions(const avk_packed_multi_shard *s, const uint64_t **index_in_whole);
+int  avk_packed_multi_shard_scatter(const avk_packed_multi_shard *s, const int32_t *status, const uint8_t *classification, const uint64_t *members,
+                                    int32_t *whole_status, uint8_t *whole_classification, uint64_t *whole_members);
+void avk_packed_multi_shard_free(avk_packed_multi_shard *s);
+#define AVK_MERGE_COUNTS_MAX_INPUTS 10
+uint64_t avk_merge_counts_len(uint32_t n_inputs);
+uint32_t avk_merge_counts_reason(uint32_t n_inputs, uint8_t classification, uint64_t members);
+int  avk_merge_counts(const avk_packed_multi_batch *batch, const int32_t *status, const uint8_t *classification, const uint64_t *members, uint64_t *counts);
+
 /* Host utility (no GPU involved): unit-cost edit distance of two byte strings, the value of the reference's
  * wfa_ed (src/util/sequence_alignment.rs:9-13).  The batch packer uses it for Variant::alt_ed
  * (src/data_types/variants.rs:413-415), which travels to the device with the region records. */
 uint64_t avk_edit_distance(const uint8_t *a, uint64_t a_len, const uint8_t *b, uint64_t b_len);
 
 const char *avk_version(void);
+/* the build's identity: the first 16 hex digits of the SHA-256 of the kernel and host sources the library was compiled from (csrc/Makefile), "unknown" for a
+ * build made another way.  Measurement files (profiles/rNN_pmc_traffic.json) carry it; bench.py reports counter traffic only when it matches the loaded library. */
+const char *avk_source_hash(void);
 
 #ifdef __cplusplus
 }

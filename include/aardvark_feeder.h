@@ -167,6 +167,9 @@ int avf_write_merge_outputs(const char *out_folder, const char *primary_vcf, con
  * variant_type, vcf_index, vcf_label, pass_variants, fail_variants.  A path ending in .csv is comma separated. */
 int avf_write_merge_summary(const char *path, const avk_multi_batch *batch, const char *const *tags, const int32_t *status,
                             const uint8_t *classification, const uint64_t *members);
+/* the same table from the dense block of sums a merge sharded over several GPUs adds up with one all-reduce (avk_merge_counts / avk_counts_allreduce of
+ * aardvark_amd.h; counts_len = avk_merge_counts_len(n_inputs)): byte for byte the table avf_write_merge_summary writes for the whole job */
+int avf_write_merge_summary_counts(const char *path, uint32_t n_inputs, const char *const *tags, const uint64_t *counts, uint64_t counts_len);
 
 /* ---- the debug tables of --output-debug, both BGZF-compressed tab-separated text, rows appended batch by batch ----------------
  * region_summary.tsv.gz   (RegionSummaryWriter, src/writers/region_summary.rs): one row per metric kind of metrics_mask and solved

@@ -40,3 +40,23 @@ def test_one_json_line_on_stdout(force_dist):
     assert all(sec[k]["cpu_baseline"]["value"] > 0 and sec[k]["cpu_baseline"]["cores"] >= 1 for k in ("shard_1_of_8", "dense_mix", "min_variant_gap_1000", "merge_3_callers", "chr20_snv"))
     assert sec["shard_1_of_8"]["strong_scaling_bound"]["boundary"] > 0
     assert out["cpu_baseline"]["all_core_extrapolation"]["value"] >= out["cpu_baseline"]["value"]
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_run_the_sharded_job():
+    """bench.py --gpus 2 as the driver launches it (torch.distributed.run, one process per rank), on a box with ONE GPU: both ranks on GPU 0 and the sums carried by gloo
+    (AVK_BENCH_ONE_DEVICE / AVK_BENCH_BACKEND; RCCL does not take two ranks on one device).  Everything else is the N-rank path: the compare job cut by hash(region_id),
+    the tally all-reduce inside the timed region, the job checksum, and the merge job (configs[4]) cut the same way with its summary counters all-reduced."""
+    env = dict(os.environ, AVK_BENCH_BACKEND="gloo", AVK_BENCH_ONE_DEVICE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29579")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29579",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--scale", "0.01", "--resident-steps", "4", "--merge-scale", "0.01"]
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[:500]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["parity"] == "bit-identical" and out["value"] > 0
+    m = out["secondary"]["merge_3_callers"]
+    assert m["n_gpus"] == 2 and m["parity"].startswith("bit-identical") and m["value"] > 0 and len(m["regions_per_rank"]) == 2
+    assert sum(m["regions_per_rank"]) > 0 and abs(m["regions_per_rank"][0] - m["regions_per_rank"][1]) < 0.1 * sum(m["regions_per_rank"])
+    assert m["variants_counted"] > 0

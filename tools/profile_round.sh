@@ -8,6 +8,7 @@ shift
 ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
+python3 -c "import ctypes; l = ctypes.CDLL('$ROOT/aardvark_amd/libaardvark_amd.so'); l.avk_source_hash.restype = ctypes.c_char_p; print(l.avk_source_hash().decode())" > "$OUT/source_hash.txt"
 cd /tmp && export TMPDIR=/tmp
 SHORT="python3 $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-parity --no-secondary --resident-steps 5 --no-supervisor $*"
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/stats" -o "$TAG" -- $SHORT > "$OUT/stats.log" 2>&1

@@ -90,7 +90,11 @@ for c, v in sorted(per_class.items(), key=lambda kv: -kv[1]):
 pm.append("    %-32s %.0f" % ("solver launches of a step", solver))
 open(os.path.join(dst, tag + "_pmc.txt"), "w").write("\n".join(pm) + "\n")
 print("\n".join(pm))
-json.dump({"tag": tag, "hbm_bytes_per_launch": solver if have_traffic else None, "hbm_bytes_per_step_by_class": per_class,
+try:  # the build the counters were collected on (tools/profile_round.sh asks the library on the GPU box)
+    source_hash = open(os.path.join(src, "source_hash.txt")).read().strip()
+except OSError:
+    source_hash = None
+json.dump({"tag": tag, "source_hash": source_hash, "hbm_bytes_per_launch": solver if have_traffic else None, "hbm_bytes_per_step_by_class": per_class,
            "note": "sum over the SOLVER launches of one step (lanes, looked-up pairs, wide, wave-per-region tiers, tally reduce): (FETCH_SIZE + WRITE_SIZE) x 1024 per dispatch x dispatches per "
                    "step; the packing kernels (avk_dp_*, avk_ps_*) and the result unpacking are listed on their own",
            "per_kernel_avg_us": {"%s grid=%d lds=%d" % k: v for k, v in geo.items()}}, open(os.path.join(dst, tag + "_pmc_traffic.json"), "w"), indent=1)
