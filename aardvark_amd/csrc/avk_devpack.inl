@@ -59,6 +59,29 @@ struct DpIn {
     u64 v_lo, v_hi; /* the calls the batch's regions are expected to own (results are copied back for this range only: batches may share call arrays) */
     u8 *owned;      /* [v_hi - v_lo] or NULL: forms with explicit call offsets — dp_region marks the calls its region owns, so that "every call of the range is owned
                        exactly once" is counted, not assumed from the sum of the counts (two regions may share a call while another call belongs to nobody) */
+    /* The PACKED source (round 6): a batch that came as avk_packed_batch is read AS IT CAME — pk_start != NULL, the wide arrays above are then NULL and never made
+     * (the widening pass wrote 44 B per region and 38 B per call that three later passes read back: 0.6 GB of a whole-genome call's 2 GB of packing traffic).
+     * Every offset is implied by order: pk_voff / pk_aoff are the two exclusive prefix sums (calls before region r, allele bytes before call v); a call's position
+     * is relative to its region's start, so whoever asks for it names the region's start. */
+    const u32 *pk_start;
+    const uint16_t *pk_len, *pk_contig, *pk_rel;
+    const u8 *pk_tc, *pk_qc, *pk_tz, *pk_a0, *pk_a1;
+    const u64 *pk_voff, *pk_aoff;
+    AVK_DEV_MEMBER u32 contig_of(u64 r) const { return pk_start ? (pk_contig ? (u32)pk_contig[r] : 0u) : (contig_idx ? contig_idx[r] : 0u); }
+    AVK_DEV_MEMBER u64 start_of(u64 r) const { return pk_start ? (u64)pk_start[r] : start[r]; }
+    AVK_DEV_MEMBER u64 end_of(u64 r) const { return pk_start ? (u64)pk_start[r] + pk_len[r] : end[r]; }
+    AVK_DEV_MEMBER u32 t_cnt_of(u64 r) const { return pk_start ? (u32)pk_tc[r] : t_cnt[r]; }
+    AVK_DEV_MEMBER u32 q_cnt_of(u64 r) const { return pk_start ? (u32)pk_qc[r] : q_cnt[r]; }
+    AVK_DEV_MEMBER u64 t_off_of(u64 r) const { return pk_start ? pk_voff[r] : t_off[r]; }
+    AVK_DEV_MEMBER u64 q_off_of(u64 r) const { return pk_start ? pk_voff[r] + pk_tc[r] : q_off[r]; }
+    AVK_DEV_MEMBER u64 pos_of(u64 v, u64 region_start) const { return pk_start ? region_start + pk_rel[v] : var_pos[v]; }
+    AVK_DEV_MEMBER u32 a0_len_of(u64 v) const { return pk_start ? (u32)pk_a0[v] : a0_len[v]; }
+    AVK_DEV_MEMBER u32 a1_len_of(u64 v) const { return pk_start ? (u32)pk_a1[v] : a1_len[v]; }
+    AVK_DEV_MEMBER u64 a0_off_of(u64 v) const { return pk_start ? pk_aoff[v] : a0_off[v]; }
+    AVK_DEV_MEMBER u64 a1_off_of(u64 v) const { return pk_start ? pk_aoff[v] + pk_a0[v] : a1_off[v]; }
+    AVK_DEV_MEMBER u32 type_of(u64 v) const { return pk_start ? (u32)(pk_tz[v] & 15u) : (u32)var_type[v]; }
+    AVK_DEV_MEMBER u32 zyg_of(u64 v) const { return pk_start ? (u32)(pk_tz[v] >> 4) : (u32)var_zyg[v]; }
+    AVK_DEV_MEMBER u32 raw_of(u64 v, u32 l0, u32 l1) const { return var_raw ? var_raw[v] : (l0 > l1 ? l0 : l1); }
 };
 
 /* context options the plan depends on (plan_work_order's arguments) */
@@ -403,8 +426,8 @@ AVK_DEV void dp_variant(const DpArgs &a, u64 v) {
     if (v >= a.in.n_variants) return;
     DpVarInfo o;
     o.alt_ed = 0, o.flags = 0, o.a1lo = 0, o.a1hi = 0;
-    const u64 o0 = a.in.a0_off[v], o1 = a.in.a1_off[v];
-    const u32 l0 = a.in.a0_len[v], l1 = a.in.a1_len[v];
+    const u64 o0 = a.in.a0_off_of(v), o1 = a.in.a1_off_of(v);
+    const u32 l0 = a.in.a0_len_of(v), l1 = a.in.a1_len_of(v);
     if (o0 + l0 > a.in.alleles_len || o1 + l1 > a.in.alleles_len || o0 + l0 < o0 || o1 + l1 < o1) {
         o.flags = DP_VF_BAD_RANGE;
         a.vinfo[v] = o;
@@ -515,8 +538,8 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
     const DpIn &in = a.in;
     DpRegionInfo ri;
     ri.pre_status = 0, ri.len = 0, ri.alle_bytes = 0, ri.blob_bytes = 0, ri.grow = 0, ri.ed_bound = 0, ri.seq_stride = 1, ri.keys = 2u << 16, ri.ref_off = 0, ri.bucket = 0, ri.counts = 0, ri.t_first = 0, ri.q_first = 0, ri.pad_[0] = ri.pad_[1] = 0;
-    const u32 tc = in.t_cnt[r], qc = in.q_cnt[r];
-    const u64 toff = in.t_off[r], qoff = in.q_off[r], nv = in.n_variants;
+    const u32 tc = in.t_cnt_of(r), qc = in.q_cnt_of(r);
+    const u64 toff = in.t_off_of(r), qoff = in.q_off_of(r), nv = in.n_variants;
     if (toff > nv || (u64)tc > nv - toff || qoff > nv || (u64)qc > nv - qoff) { /* pass 1 of pack_batch: the batch is rejected */
         avk_atomic_or_u32_global(&a.st->err, DP_ERR_RANGE);
         a.rinfo[r] = ri;
@@ -530,8 +553,8 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
         for (u32 i = 0; i < qc; ++i)
             if (qoff + i >= in.v_lo && qoff + i < in.v_hi) in.owned[qoff + i - in.v_lo] = 1;
     }
-    const u32 c = in.contig_idx ? in.contig_idx[r] : 0u;
-    const u64 start = in.start[r], end = in.end[r];
+    const u32 c = in.contig_of(r);
+    const u64 start = in.start_of(r), end = in.end_of(r);
     u32 pre = 0;
     if (c >= in.n_contigs || start > end || end > in.contig_len[c] || end - start > 0x7FFFFFFFull) pre = AVK_ST_INVALID_INPUT;
     if (N > 60000) pre = AVK_ST_INVALID_INPUT;
@@ -546,11 +569,11 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
         const u32 cnt = side == 0 ? tc : qc;
         u64 last = 0;
         for (u32 i = 0; i < cnt; ++i) {
-            const u64 v = off + i, pos = in.var_pos[v];
-            const u32 l0 = in.a0_len[v], l1 = in.a1_len[v];
+            const u64 v = off + i, pos = in.pos_of(v, start);
+            const u32 l0 = in.a0_len_of(v), l1 = in.a1_len_of(v);
             const u32 big = l0 > l1 ? l0 : l1;
-            const u32 raw = in.var_raw ? in.var_raw[v] : big;
-            const u32 vt = in.var_type[v], zy = in.var_zyg[v];
+            const u32 raw = in.raw_of(v, l0, l1);
+            const u32 vt = in.type_of(v), zy = in.zyg_of(v);
             const DpVarInfo vi = a.vinfo[v];
             alle += (u64)l0 + l1;
             bad_allele = bad_allele || (vi.flags & DP_VF_BAD_RANGE);
@@ -607,12 +630,12 @@ AVK_DEV void dp_region(const DpArgs &a, u64 r, u32 &n_calls, u32 &blob_words, u6
                 k.pos = k.a0 = k.a1 = k.alt_ed = k.type = k.zyg = k.lo = k.hi = k.raw = 0;
                 if (j >= (side ? qc : tc)) continue;
                 const u64 v = (side ? qoff : toff) + j;
-                const u32 l0 = in.a0_len[v], l1 = in.a1_len[v];
-                const u32 raw = in.var_raw ? in.var_raw[v] : (l0 > l1 ? l0 : l1);
+                const u32 l0 = in.a0_len_of(v), l1 = in.a1_len_of(v);
+                const u32 raw = in.raw_of(v, l0, l1);
                 const DpVarInfo vi = a.vinfo[v];
-                const u64 rel = in.var_pos[v] - start;
+                const u64 rel = in.pos_of(v, start) - start;
                 lane_ok = lane_ok && rel <= 255 && l0 <= 255 && l1 <= 32 && vi.alt_ed <= 255 && raw <= 0xFFFF && (vi.flags & DP_VF_ACGT32);
-                k.pos = (u32)rel, k.a0 = l0, k.a1 = l1, k.alt_ed = vi.alt_ed, k.type = in.var_type[v], k.zyg = in.var_zyg[v], k.lo = vi.a1lo, k.hi = vi.a1hi, k.raw = raw;
+                k.pos = (u32)rel, k.a0 = l0, k.a1 = l1, k.alt_ed = vi.alt_ed, k.type = in.type_of(v), k.zyg = in.zyg_of(v), k.lo = vi.a1lo, k.hi = vi.a1hi, k.raw = raw;
             }
             for (int cl = 0; cl < AVK_FAST_GENERIC && lane_ok; ++cl) {
                 const u32 W = AVK_FAST_CLASS[cl].W, maxv = AVK_FAST_CLASS[cl].maxv;
@@ -799,7 +822,7 @@ AVK_DEV void dp_fast_record(const DpArgs &a, u32 fc, u32 tile_in_class, u32 lane
         if (a.in.owned) { /* a form with explicit offsets: two regions with different starts may share this call, and the slot holds the position relative to whichever
                              of them wrote last — this region's own comes from the caller's arrays (the packed forms own their calls by construction) */
             const u64 v = (u64)(side ? ri.q_first : ri.t_first) + j;
-            sl.x = (sl.x & ~0xFFu) | ((u32)(a.in.var_pos[v] - a.in.start[r]) & 0xFFu);
+            sl.x = (sl.x & ~0xFFu) | ((u32)(a.in.pos_of(v, a.in.start_of(r)) - a.in.start_of(r)) & 0xFFu);
         }
         slot_pos[sidx] = sl.x & 0xFFu;
         V[0] = sl.x, V[64] = sl.y, V[128] = sl.z, V[192] = sl.w;
@@ -828,8 +851,8 @@ AVK_DEV AvkDevRegion dp_record_of(const DpArgs &a, u32 r, const DpRegionInfo &ri
     dr.ref_off = ri.ref_off;
     dr.len = ri.len;
     dr.v_off = a.v_off[r];
-    dr.t_cnt = a.in.t_cnt[r];
-    dr.q_cnt = a.in.q_cnt[r];
+    dr.t_cnt = a.in.t_cnt_of(r);
+    dr.q_cnt = a.in.q_cnt_of(r);
     dr.pre_status = ri.pre_status;
     dr.seq_stride = ri.seq_stride;
     dr.seq_off = a.seq_off[r];
@@ -866,22 +889,22 @@ AVK_DEV void dp_region_record(const DpArgs &a, u64 k) {
         for (u64 x = (u64)N * sizeof(AvkBlobVar); x < vb; ++x) base[x] = 0;
         for (u64 x = ri.alle_bytes; x < ab; ++x) ba[x] = 0;
     }
-    const u64 start = in.start[r];
+    const u64 start = in.start_of(r), toff_r = in.t_off_of(r), qoff_r = in.q_off_of(r);
     u32 run = 0, counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     for (u32 i = 0; i < N; ++i) {
-        const u64 v = i < tc ? in.t_off[r] + i : in.q_off[r] + (i - tc);
-        const u32 l0 = in.a0_len[v], l1 = in.a1_len[v];
-        const u32 vt = in.var_type[v], zy = in.var_zyg[v];
+        const u64 v = i < tc ? toff_r + i : qoff_r + (i - tc);
+        const u32 l0 = in.a0_len_of(v), l1 = in.a1_len_of(v);
+        const u32 vt = in.type_of(v), zy = in.zyg_of(v);
         AvkBlobVar b;
-        b.rel_pos = (u32)(in.var_pos[v] - start);
+        b.rel_pos = (u32)(in.pos_of(v, start) - start);
         b.a0_len = l0;
         b.a1_len = l1;
         b.a_off = run;
-        b.raw_space = in.var_raw ? in.var_raw[v] : (l0 > l1 ? l0 : l1);
+        b.raw_space = in.raw_of(v, l0, l1);
         b.alt_ed = a.vinfo[v].alt_ed;
         b.type_zyg = vt | (zy << 8);
         bv[i] = b;
-        const u8 *s0 = in.alleles + in.a0_off[v], *s1 = in.alleles + in.a1_off[v];
+        const u8 *s0 = in.alleles + in.a0_off_of(v), *s1 = in.alleles + in.a1_off_of(v);
         for (u32 x = 0; x < l0; ++x) ba[run + x] = s0[x];
         for (u32 x = 0; x < l1; ++x) ba[run + l0 + x] = s1[x];
         run += l0 + l1;
@@ -911,8 +934,8 @@ AVK_DEV void dp_region_record_wave(const DpArgs &a, u32 item) {
     const u32 k = a.big_list[item];
     const u32 r = a.order[k];
     const DpRegionInfo ri = a.rinfo[r];
-    const u32 tc = in.t_cnt[r], qc = in.q_cnt[r], N = tc + qc;
-    const u64 toff = in.t_off[r], qoff = in.q_off[r], start = in.start[r];
+    const u32 tc = in.t_cnt_of(r), qc = in.q_cnt_of(r), N = tc + qc;
+    const u64 toff = in.t_off_of(r), qoff = in.q_off_of(r), start = in.start_of(r);
     const u32 blob_off = a.blob_off8[r];
     const u64 vb = ((u64)N * sizeof(AvkBlobVar) + 15) & ~15ull, ab = ((u64)ri.alle_bytes + 15) & ~15ull, ob = (u64)N * sizeof(AvkOrdVar);
     u8 *base = (u8 *)(a.blob + 2ull * blob_off);
@@ -930,7 +953,7 @@ AVK_DEV void dp_region_record_wave(const DpArgs &a, u32 item) {
         const u32 i = i0 + lane;
         const bool on = i < N;
         const u64 v = on ? (i < tc ? toff + i : qoff + (i - tc)) : 0;
-        const u32 l0 = on ? in.a0_len[v] : 0u, l1 = on ? in.a1_len[v] : 0u;
+        const u32 l0 = on ? in.a0_len_of(v) : 0u, l1 = on ? in.a1_len_of(v) : 0u;
         /* exclusive prefix sum of l0 + l1 over the 64 lanes */
         u32 x = l0 + l1, incl = x;
         for (u32 d = 1; d < 64; d <<= 1) {
@@ -940,17 +963,17 @@ AVK_DEV void dp_region_record_wave(const DpArgs &a, u32 item) {
         const u32 a_off = carry + incl - x;
         carry += wv_shfl(incl, 63);
         if (on) {
-            const u32 vt = in.var_type[v], zy = in.var_zyg[v];
+            const u32 vt = in.type_of(v), zy = in.zyg_of(v);
             AvkBlobVar b;
-            b.rel_pos = (u32)(in.var_pos[v] - start);
+            b.rel_pos = (u32)(in.pos_of(v, start) - start);
             b.a0_len = l0;
             b.a1_len = l1;
             b.a_off = a_off;
-            b.raw_space = in.var_raw ? in.var_raw[v] : (l0 > l1 ? l0 : l1);
+            b.raw_space = in.raw_of(v, l0, l1);
             b.alt_ed = a.vinfo[v].alt_ed;
             b.type_zyg = vt | (zy << 8);
             bv[i] = b;
-            const u8 *s0 = in.alleles + in.a0_off[v], *s1 = in.alleles + in.a1_off[v];
+            const u8 *s0 = in.alleles + in.a0_off_of(v), *s1 = in.alleles + in.a1_off_of(v);
             for (u32 q = 0; q < l0; ++q) ba[a_off + q] = s0[q];
             for (u32 q = 0; q < l1; ++q) ba[a_off + l0 + q] = s1[q];
             const u32 si = dp_sup_index(vt);
@@ -1018,6 +1041,9 @@ struct DpOut {
      * region; the groups of a region that needs more are spilled behind an atomic counter */
     const u32 *bp_off_dev, *bp_dev;
     u32 *bp_packed, *bp_spill, *bp_spill_count;
+    /* a batch read from its packed source (DpIn::pk_*): t_off / q_off / t_cnt / q_cnt above are NULL, the counts and the running sum of the calls stand in */
+    const u64 *pk_voff;
+    const u8 *pk_tc, *pk_qc;
 };
 AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
     if (r >= o.n_regions) return;
@@ -1052,8 +1078,8 @@ AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
         o.region_packed[r] = (u64)(w.x & 0x7Fu) | filtered << 7 | (u64)(w.w & 0xFFFFu) << 8 | e1 << 24 | e2 << 44;
     }
     if (o.mode != 0 || !(o.var_expected || o.var_observed || o.var_class || o.var_zyg || o.var_packed)) return;
-    const u32 tc = o.t_cnt[r], qc = o.q_cnt[r];
-    const u64 toff = o.t_off[r], qoff = o.q_off[r];
+    const u32 tc = o.pk_voff ? (u32)o.pk_tc[r] : o.t_cnt[r], qc = o.pk_voff ? (u32)o.pk_qc[r] : o.q_cnt[r];
+    const u64 toff = o.pk_voff ? o.pk_voff[r] : o.t_off[r], qoff = o.pk_voff ? toff + tc : o.q_off[r];
     if (toff > o.n_variants || (u64)tc > o.n_variants - toff || qoff > o.n_variants || (u64)qc > o.n_variants - qoff) return;
     const u32 *vw = o.var_out + o.v_off[r];
     for (u32 k = 0; k < tc + qc; ++k) {

@@ -166,8 +166,8 @@ __global__ void __launch_bounds__(256) avk_dp_scan_apply_kernel(dpk::DpArgs a, c
     const uint64_t r = (uint64_t)blockIdx.x * 256u + t;
     unsigned long long v[AVK_DP_NS] = {0, 0, 0, 0};
     if (r < a.in.n_regions) {
-        const uint32_t tc = a.in.t_cnt[r], qc = a.in.q_cnt[r];
-        const uint64_t toff = a.in.t_off[r], qoff = a.in.q_off[r], nv = a.in.n_variants;
+        const uint32_t tc = a.in.t_cnt_of(r), qc = a.in.q_cnt_of(r);
+        const uint64_t toff = a.in.t_off_of(r), qoff = a.in.q_off_of(r), nv = a.in.n_variants;
         if (!(toff > nv || (uint64_t)tc > nv - toff || qoff > nv || (uint64_t)qc > nv - qoff)) { /* as dp_region counted it */
             v[0] = (unsigned long long)tc + qc;
             v[1] = a.rinfo[r].blob_bytes / 4u;
@@ -800,15 +800,18 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     dpk::DpArgs a;
     memset(&a, 0, sizeof(a));
     /* (the inputs and the packer's intermediates stay with the batch: region records of lane regions are written when a launch needs them) */
+    /* a compare batch in the packed form is read from the packed arrays themselves (DpIn::pk_*, round 6): no wide arrays, no widening pass */
+    const bool packed_src = pk != nullptr && ctx->packed_source;
     auto tmp_or_kept = [&](size_t bytes) -> void * { return kept(bytes); };
-    uint64_t *d_start = (uint64_t *)tmp_or_kept((n + 1) * 8), *d_end = (uint64_t *)tmp_or_kept((n + 1) * 8);
-    db->d_in_t_off = (uint64_t *)kept((n + 1) * 8), db->d_in_q_off = (uint64_t *)kept((n + 1) * 8);
-    db->d_in_t_cnt = (uint32_t *)kept((n + 1) * 4), db->d_in_q_cnt = (uint32_t *)kept((n + 1) * 4);
-    uint32_t *d_contig = has_contig ? (uint32_t *)tmp_or_kept((n + 1) * 4) : nullptr;
-    uint64_t *d_pos = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a0o = (uint64_t *)tmp_or_kept((nv + 1) * 8), *d_a1o = (uint64_t *)tmp_or_kept((nv + 1) * 8);
-    uint32_t *d_a0l = (uint32_t *)tmp_or_kept((nv + 1) * 4), *d_a1l = (uint32_t *)tmp_or_kept((nv + 1) * 4);
+    auto wide = [&](size_t bytes) -> void * { return packed_src ? nullptr : kept(bytes); };
+    uint64_t *d_start = (uint64_t *)wide((n + 1) * 8), *d_end = (uint64_t *)wide((n + 1) * 8);
+    db->d_in_t_off = (uint64_t *)wide((n + 1) * 8), db->d_in_q_off = (uint64_t *)wide((n + 1) * 8);
+    db->d_in_t_cnt = (uint32_t *)wide((n + 1) * 4), db->d_in_q_cnt = (uint32_t *)wide((n + 1) * 4);
+    uint32_t *d_contig = has_contig ? (uint32_t *)wide((n + 1) * 4) : nullptr;
+    uint64_t *d_pos = (uint64_t *)wide((nv + 1) * 8), *d_a0o = (uint64_t *)wide((nv + 1) * 8), *d_a1o = (uint64_t *)wide((nv + 1) * 8);
+    uint32_t *d_a0l = (uint32_t *)wide((nv + 1) * 4), *d_a1l = (uint32_t *)wide((nv + 1) * 4);
     uint32_t *d_raw = has_raw ? (pre ? pre->raw : (uint32_t *)tmp_or_kept((nv + 1) * 4)) : nullptr;
-    uint8_t *d_type = (uint8_t *)tmp_or_kept(nv + 16), *d_zyg = (uint8_t *)tmp_or_kept(nv + 16), *d_alleles = pre ? pre->alleles : (uint8_t *)tmp_or_kept(alen + 16);
+    uint8_t *d_type = (uint8_t *)wide(nv + 16), *d_zyg = (uint8_t *)wide(nv + 16), *d_alleles = pre ? pre->alleles : (uint8_t *)tmp_or_kept(alen + 16);
     /* intermediates */
     const uint32_t n_blocks = (uint32_t)((n + 255) / 256);
     a.vinfo = (dpk::DpVarInfo *)kept((nv + 1) * sizeof(dpk::DpVarInfo));
@@ -845,13 +848,15 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     };
     mark(0);
     if (pk) { /* the packed arrays as they are, two prefix sums for the offsets they leave out, one kernel that writes the wide arrays */
-        uint16_t *p_contig = has_contig ? (pre ? pre->contig : (uint16_t *)tmp((n + 1) * 2)) : nullptr, *p_len = pre ? pre->len : (uint16_t *)tmp((n + 1) * 2),
-                 *p_rel = pre ? pre->rel_pos : (uint16_t *)tmp((nv + 1) * 2);
-        uint32_t *p_start = pre ? pre->start : (uint32_t *)tmp((n + 1) * 4);
-        uint8_t *p_tc = pre ? pre->t_cnt : (uint8_t *)tmp(n + 16), *p_qc = pre ? pre->q_cnt : (uint8_t *)tmp(n + 16), *p_tz = pre ? pre->var_type_zyg : (uint8_t *)tmp(nv + 16),
-                *p_a0 = pre ? pre->a0_len : (uint8_t *)tmp(nv + 16), *p_a1 = pre ? pre->a1_len : (uint8_t *)tmp(nv + 16);
+        /* (the packed arrays stay with the batch when they are what the packer and the later record writers read; a staging slot's stay with its ticket) */
+        auto src = [&](size_t bytes) -> void * { return packed_src ? kept(bytes) : tmp(bytes); };
+        uint16_t *p_contig = has_contig ? (pre ? pre->contig : (uint16_t *)src((n + 1) * 2)) : nullptr, *p_len = pre ? pre->len : (uint16_t *)src((n + 1) * 2),
+                 *p_rel = pre ? pre->rel_pos : (uint16_t *)src((nv + 1) * 2);
+        uint32_t *p_start = pre ? pre->start : (uint32_t *)src((n + 1) * 4);
+        uint8_t *p_tc = pre ? pre->t_cnt : (uint8_t *)src(n + 16), *p_qc = pre ? pre->q_cnt : (uint8_t *)src(n + 16), *p_tz = pre ? pre->var_type_zyg : (uint8_t *)src(nv + 16),
+                *p_a0 = pre ? pre->a0_len : (uint8_t *)src(nv + 16), *p_a1 = pre ? pre->a1_len : (uint8_t *)src(nv + 16);
         const uint32_t nb_r = (uint32_t)((n + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK), nb_v = (uint32_t)((nv + AVK_PS_BLOCK - 1) / AVK_PS_BLOCK);
-        uint64_t *p_voff = (uint64_t *)tmp((n + 1) * 8), *p_aoff = (uint64_t *)tmp((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
+        uint64_t *p_voff = (uint64_t *)src((n + 1) * 8), *p_aoff = (uint64_t *)src((nv + 1) * 8), *p_sums = (uint64_t *)tmp(((size_t)nb_r + nb_v + 4) * 8);
         if (rc) return bail(rc);
         /* All copies on the context's stream, counts and lengths first; the two prefix sums (which need nothing else) and the widening kernel (everything but the
          * allele bytes) run on a stream of their own beside the copies that follow: dp_variant, the first kernel that needs every byte, starts 0.24 ms earlier.
@@ -895,7 +900,11 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         c.w_t_off = db->d_in_t_off, c.w_q_off = db->d_in_q_off, c.w_pos = d_pos, c.w_a0_off = d_a0o, c.w_a1_off = d_a1o, c.w_type = d_type, c.w_zyg = d_zyg;
         const uint64_t m = n > nv ? n : nv;
         hipError_t ew = hipStreamWaitEvent(side, ctx->ev_copy_mid, 0);
-        if (m && ew == hipSuccess) {
+        if (packed_src) { /* the packer reads these as they are */
+            a.in.pk_start = p_start, a.in.pk_len = p_len, a.in.pk_contig = p_contig, a.in.pk_rel = p_rel, a.in.pk_tc = p_tc, a.in.pk_qc = p_qc, a.in.pk_tz = p_tz, a.in.pk_a0 = p_a0,
+            a.in.pk_a1 = p_a1, a.in.pk_voff = p_voff, a.in.pk_aoff = p_aoff;
+            db->d_pk_voff = p_voff, db->d_pk_tc = p_tc, db->d_pk_qc = p_qc;
+        } else if (m && ew == hipSuccess) {
             hipLaunchKernelGGL(avk_dp_widen_packed_kernel, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, side, c);
             ew = hipGetLastError();
         }
@@ -1251,6 +1260,7 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     memset(&o, 0, sizeof(o));
     o.region_out = db->d_region_out, o.var_out = db->d_var_out, o.v_off = db->d_voff, o.t_off = db->d_in_t_off, o.q_off = db->d_in_q_off, o.t_cnt = db->d_in_t_cnt,
     o.q_cnt = db->d_in_q_cnt, o.n_regions = n, o.n_variants = nv, o.mode = db->last_mode;
+    o.pk_voff = db->d_pk_voff, o.pk_tc = db->d_pk_tc, o.pk_qc = db->d_pk_qc;
     if (out->status || !out->region_packed) o.status = (int32_t *)tmp((n + 1) * 4);
     if (out->region_packed) o.region_packed = (uint64_t *)tmp((n + 1) * 8);
     if (out->ed_h1) o.ed_h1 = (uint32_t *)tmp((n + 1) * 4);
@@ -1387,8 +1397,15 @@ static int materialize_host_view(avk_ctx *ctx, avk_dev_batch *db) {
     db->host.blob.resize(blob_words);
     AVK_HIP(ctx, hipMemcpy(db->host.blob.data(), db->d_blob, blob_words * 4, hipMemcpyDeviceToHost));
     std::vector<uint64_t> toff(n), qoff(n);
-    AVK_HIP(ctx, hipMemcpy(toff.data(), db->d_in_t_off, n * 8, hipMemcpyDeviceToHost));
-    AVK_HIP(ctx, hipMemcpy(qoff.data(), db->d_in_q_off, n * 8, hipMemcpyDeviceToHost));
+    if (db->d_pk_voff) { /* read from its packed source: the running sum of the calls, the query calls behind the truth calls */
+        std::vector<uint8_t> tcs(n);
+        AVK_HIP(ctx, hipMemcpy(toff.data(), db->d_pk_voff, n * 8, hipMemcpyDeviceToHost));
+        AVK_HIP(ctx, hipMemcpy(tcs.data(), db->d_pk_tc, n, hipMemcpyDeviceToHost));
+        for (uint64_t r = 0; r < n; ++r) qoff[r] = toff[r] + tcs[r];
+    } else {
+        AVK_HIP(ctx, hipMemcpy(toff.data(), db->d_in_t_off, n * 8, hipMemcpyDeviceToHost));
+        AVK_HIP(ctx, hipMemcpy(qoff.data(), db->d_in_q_off, n * 8, hipMemcpyDeviceToHost));
+    }
     db->host.dev2host.resize(db->n_variants_dev);
     for (uint64_t r = 0; r < n; ++r) {
         const AvkDevRegion &dr = db->host.regions[r];

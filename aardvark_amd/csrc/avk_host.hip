@@ -350,6 +350,7 @@ struct avk_ctx {
     int64_t big_ws_bytes = 64ll << 20; /* (256 MB until round 5: the shared slices were 2.1 GB of a fresh process's first hipMalloc; a batch whose packer predicts larger regions gets 1 GB slices, upload_device_packed) */
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
+    int64_t packed_source = 1;  /* 1: a batch in the packed form is packed from the packed arrays themselves (no wide copy of the caller's arrays in HBM); 0: round 5's widening pass */
     int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
     int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
     int64_t lane_kernel = 1; /* small regions go to the lane-per-region kernel (avk_lane.inl) */
@@ -463,6 +464,8 @@ struct avk_dev_batch {
     std::vector<void *> pooled;
     uint64_t *d_in_t_off = nullptr, *d_in_q_off = nullptr; /* the caller's t_off / q_off / t_cnt / q_cnt: dp_unpack scatters the per-call outputs with them */
     uint32_t *d_in_t_cnt = nullptr, *d_in_q_cnt = nullptr, *d_voff = nullptr;
+    const uint64_t *d_pk_voff = nullptr; /* a compare batch read from its packed source (DpIn::pk_*): these three stand in for the four arrays above */
+    const uint8_t *d_pk_tc = nullptr, *d_pk_qc = nullptr;
     avk::dp::DpArgs dp_args; /* the packer's arguments: the writers of region records run again for the regions a launch turns out to need */
     avk::dp::DpArgs *d_dp_args = nullptr; /* the same in device memory (AvkKernelArgs::lazy_dp) */
     uint32_t lazy_from = 0;               /* first work-order index without a record (the lane classes' segment) */
@@ -805,6 +808,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "pool_cache_bytes") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "pool_cache_bytes must not be negative");
         ctx->pool_cache_bytes = value;
+    } else if (n == "packed_source") {
+        ctx->packed_source = value ? 1 : 0;
     } else if (n == "emit_bp_groups") {
         ctx->emit_bp_groups = value ? 1 : 0;
     } else if (n == "emit_group_metrics") {

@@ -23,6 +23,7 @@
 #ifdef AVK_EMU
 /* ------------------------------------------------------------------------------ emulator */
 #define AVK_DEV static inline
+#define AVK_DEV_MEMBER inline /* member functions of device structs */
 #define AVK_DEV_M inline /* member functions */
 #define AVK_DEV_NOINLINE static
 #define AVK_HD static inline /* plain functions the host code calls as well */
@@ -150,6 +151,7 @@ AVK_DEV int avk_popc64(uint64_t x) { return __builtin_popcountll(x); }
 /* -------------------------------------------------------------------------------- gfx950 */
 #include <hip/hip_runtime.h>
 #define AVK_DEV __device__ __forceinline__
+#define AVK_DEV_MEMBER __host__ __device__ __forceinline__
 #define AVK_DEV_M __device__ __forceinline__ /* member functions */
 #define AVK_DEV_NOINLINE __device__ __noinline__
 #define AVK_HD __host__ __device__ inline /* plain functions the host code calls as well */

@@ -303,6 +303,8 @@ uint32_t g_hbm_ed_cap = 1024; /* emu_set_hbm_ed_cap: context option hbm_ed_cap *
 int g_lane_pairs = 1; /* emu_set_lane_pairs: context option lane_pairs (regions with the same SNV on both sides are looked up, avk_pairs.inl) */
 uint64_t g_class_c_below = 0; /* emu_set_class_c_below: context option class_c_below (0 = no such rule, the emulator's default) */
 uint32_t g_stripe_w = 0; /* emu_set_stripe: claim width the heads of the lane classes are dealt out over (context option lane_stripe; 0 = sorted order) */
+int g_last_packed_source = 0; /* emu_last_packed_source: the last packing run read its batch from the packed form */
+int g_dp_packed_source = 0; /* emu_set_packed_source: the device packer reads batches that fit the packed form from packed arrays (DpIn::pk_*), as the library does for avk_packed_batch */
 int g_device_pack = 0; /* emu_set_device_pack: emu_run packs its batch with the device functions instead of avk_pack.h */
 namespace dpk = avk::dp;
 struct DpResult {
@@ -317,6 +319,11 @@ struct DpResult {
     dpk::DpState st;
     dpk::DpArgs args; /* for the writers that run later (records of the regions the lanes hand back) */
     bool lazy = false;
+    bool packed_source = false; /* the packer read the batch from its packed form (g_dp_packed_source and the batch fits it) */
+    std::vector<uint32_t> pk_start;
+    std::vector<uint16_t> pk_len, pk_contig, pk_rel;
+    std::vector<uint8_t> pk_tc, pk_qc, pk_tz, pk_a0, pk_a1;
+    std::vector<uint64_t> pk_voff, pk_aoff;
     std::string err;
 };
 struct DpWaveTask {
@@ -338,6 +345,44 @@ int dp_run(const avk_region_batch *b, const std::vector<uint64_t> &base, const s
     a.in.v_lo = 0, a.in.v_hi = nv;
     R->owned.assign(nv + 16, 0); /* upload_device_packed: forms with explicit offsets count the ownership of their calls (and re-derive a shared call's position per region) */
     if (!pairs_mode) a.in.owned = R->owned.data();
+    if (g_dp_packed_source && !pairs_mode) {
+        /* upload_device_packed on an avk_packed_batch (round 6): the packer reads the packed arrays as they came (DpIn::pk_*), there are no wide arrays.  The batch is
+         * put into that form here when it fits it (calls and alleles back to back in region order, narrow fields wide enough); otherwise the wide path above stands. */
+        bool fits = n > 0;
+        uint64_t run_v = 0, run_a = 0;
+        for (uint64_t r = 0; r < n && fits; ++r) {
+            fits = b->t_off[r] == run_v && b->q_off[r] == run_v + b->t_cnt[r] && b->t_cnt[r] < 256 && b->q_cnt[r] < 256 && b->end[r] >= b->start[r] && b->end[r] - b->start[r] < 65536 &&
+                   b->start[r] < (1ull << 32) && (!b->contig_idx || b->contig_idx[r] < 65536);
+            for (uint64_t v = run_v; v < run_v + b->t_cnt[r] + b->q_cnt[r] && fits; ++v)
+                fits = v < nv && b->var_pos[v] >= b->start[r] && b->var_pos[v] - b->start[r] < 65536 && b->a0_len[v] < 256 && b->a1_len[v] < 256 && b->var_type[v] < 16 && b->var_zyg[v] < 16;
+            run_v += (uint64_t)b->t_cnt[r] + b->q_cnt[r];
+        }
+        fits = fits && run_v == nv;
+        for (uint64_t v = 0; v < nv && fits; ++v) {
+            fits = b->a0_off[v] == run_a && b->a1_off[v] == run_a + b->a0_len[v];
+            run_a += (uint64_t)b->a0_len[v] + b->a1_len[v];
+        }
+        fits = fits && run_a == b->allele_bytes_len;
+        R->packed_source = fits;
+        g_last_packed_source = fits ? 1 : 0;
+        if (fits) {
+            R->pk_start.assign(n + 1, 0), R->pk_len.assign(n + 1, 0), R->pk_contig.assign(n + 1, 0), R->pk_rel.assign(nv + 1, 0), R->pk_tc.assign(n + 1, 0), R->pk_qc.assign(n + 1, 0);
+            R->pk_tz.assign(nv + 1, 0), R->pk_a0.assign(nv + 1, 0), R->pk_a1.assign(nv + 1, 0), R->pk_voff.assign(n + 1, 0), R->pk_aoff.assign(nv + 1, 0);
+            for (uint64_t r = 0; r < n; ++r) {
+                R->pk_start[r] = (uint32_t)b->start[r], R->pk_len[r] = (uint16_t)(b->end[r] - b->start[r]), R->pk_contig[r] = (uint16_t)(b->contig_idx ? b->contig_idx[r] : 0);
+                R->pk_tc[r] = (uint8_t)b->t_cnt[r], R->pk_qc[r] = (uint8_t)b->q_cnt[r], R->pk_voff[r] = b->t_off[r];
+                for (uint64_t v = b->t_off[r]; v < b->t_off[r] + b->t_cnt[r] + b->q_cnt[r]; ++v) R->pk_rel[v] = (uint16_t)(b->var_pos[v] - b->start[r]);
+            }
+            for (uint64_t v = 0; v < nv; ++v)
+                R->pk_tz[v] = (uint8_t)(b->var_type[v] | (b->var_zyg[v] << 4)), R->pk_a0[v] = (uint8_t)b->a0_len[v], R->pk_a1[v] = (uint8_t)b->a1_len[v], R->pk_aoff[v] = b->a0_off[v];
+            a.in.contig_idx = nullptr, a.in.start = a.in.end = a.in.t_off = a.in.q_off = nullptr, a.in.t_cnt = a.in.q_cnt = nullptr, a.in.var_pos = nullptr, a.in.var_type = a.in.var_zyg = nullptr;
+            a.in.a0_off = a.in.a1_off = nullptr, a.in.a0_len = a.in.a1_len = nullptr;
+            a.in.owned = nullptr; /* (the packed form owns its calls by construction) */
+            a.in.pk_start = R->pk_start.data(), a.in.pk_len = R->pk_len.data(), a.in.pk_contig = b->contig_idx ? R->pk_contig.data() : nullptr, a.in.pk_rel = R->pk_rel.data();
+            a.in.pk_tc = R->pk_tc.data(), a.in.pk_qc = R->pk_qc.data(), a.in.pk_tz = R->pk_tz.data(), a.in.pk_a0 = R->pk_a0.data(), a.in.pk_a1 = R->pk_a1.data();
+            a.in.pk_voff = R->pk_voff.data(), a.in.pk_aoff = R->pk_aoff.data();
+        }
+    }
     a.opt = opt;
     R->vinfo.assign(nv + 1, dpk::DpVarInfo());
     R->rinfo.assign(n + 1, dpk::DpRegionInfo());
@@ -1028,6 +1073,7 @@ static int emu_run(uint32_t mode, const avk_region_batch *batch, const uint8_t *
         memset(&o, 0, sizeof(o));
         o.region_out = rout.data(), o.var_out = vout.data(), o.v_off = dpr.v_off.data(), o.t_off = batch->t_off, o.q_off = batch->q_off, o.t_cnt = batch->t_cnt, o.q_cnt = batch->q_cnt;
         o.n_regions = n, o.n_variants = batch->n_variants, o.mode = mode;
+        if (dpr.packed_source) o.t_off = o.q_off = nullptr, o.t_cnt = o.q_cnt = nullptr, o.pk_voff = dpr.pk_voff.data(), o.pk_tc = dpr.pk_tc.data(), o.pk_qc = dpr.pk_qc.data();
         o.status = out->status, o.ed_h1 = out->ed_h1, o.ed_h2 = out->ed_h2, o.n_optima = out->n_optima, o.type_present = out->type_present;
         o.var_expected = out->var_expected, o.var_observed = out->var_observed, o.var_class = out->var_class, o.var_zyg = out->var_zyg;
         o.region_packed = out->region_packed, o.var_packed = out->var_packed;
@@ -1139,6 +1185,8 @@ int emu_merge_batch(const avk_multi_batch *mb, const uint8_t *const *refs, const
 
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
+void emu_set_packed_source(int on) { g_dp_packed_source = on, g_last_packed_source = 0; }
+int emu_last_packed_source() { return g_last_packed_source; }
 void emu_set_stripe(uint32_t w) { g_stripe_w = w; }
 void emu_set_class_c_below(uint64_t n) { g_class_c_below = n; }
 void emu_set_lane_pairs(int on) { g_lane_pairs = on; }

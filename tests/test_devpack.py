@@ -145,8 +145,7 @@ def test_invalid_long_and_odd_inputs_pack_identically():
         same_as_host_packer(batch, lens_of(contigs), pairs=True)
 
 
-def test_large_regions_go_through_the_wave_writer():
-    """more than 48 calls in a region: the blob is written by a whole wave (prefix sums over lanes, ranks by binary search)"""
+def large_regions_batch():
     rng = np.random.default_rng(11)
     contig = bytes(rng.choice(list(b"ACGT"), size=60_000).astype(np.uint8))
     regions = []
@@ -167,7 +166,12 @@ def test_large_regions_go_through_the_wave_writer():
                     out.append((p, contig[p:p + d], contig[p:p + 1], "Deletion", scenarios.ZY[int(rng.integers(0, 4))]))
             return out
         regions.append({"start": start, "end": end, "truth": calls(int(rng.integers(49, 300))), "query": calls(int(rng.integers(1, 300)))})
-    batch = RegionBatch.from_regions(regions)
+    return contig, RegionBatch.from_regions(regions)
+
+
+def test_large_regions_go_through_the_wave_writer():
+    """more than 48 calls in a region: the blob is written by a whole wave (prefix sums over lanes, ranks by binary search)"""
+    contig, batch = large_regions_batch()
     same_as_host_packer(batch, [len(contig)])
 
 
@@ -309,3 +313,72 @@ def test_packed_multi_form_round_trip_and_constraints():
             m2.in_cnt[5] += 1
         with pytest.raises(ValueError):
             PackedMultiBatch.from_multi(m2)
+
+
+# ---- round 6: a batch that came in the packed form is packed FROM the packed arrays (DpIn::pk_*: every offset implied by order, positions relative to the region's
+# start): no wide copy of the caller's arrays is made in HBM.  Same records, same plan, same results.
+
+@pytest.fixture
+def packed_source():
+    lib = _lib()
+    lib.emu_set_packed_source.argtypes = [C.c_int]
+    lib.emu_set_packed_source(1)
+    yield lib
+    lib.emu_set_packed_source(0)
+
+
+def test_packed_source_packs_identically(packed_source):
+    lib = packed_source
+    contigs, batch = scenarios.golden()
+    same_as_host_packer(batch, lens_of(contigs))
+    assert lib.emu_last_packed_source() == 1
+    same_as_host_packer(batch, lens_of(contigs), lane_min_regions=0xFFFFFFFF)
+    for seed, kw in [(201, {}), (202, {"repeat_unit": b"CA", "max_vars": 3}), (203, {"max_vars": 9, "max_len": 12}), (204, {"max_len": 40, "span": (20, 250)}),
+                     (205, {"alphabet": b"ACGTN", "max_vars": 3})]:
+        contigs, batch = scenarios.fuzz_regions(seed, 800, **kw)
+        lib.emu_set_packed_source(1)
+        same_as_host_packer(batch, lens_of(contigs))
+        assert lib.emu_last_packed_source() == 1, seed
+        same_as_host_packer(batch, lens_of(contigs), lane_max_est=3, solo_min_variants=3)
+    contig, batch = synth.config_indel_mix_v2(n_truth=20_000, contig_len=8_000_000)
+    lib.emu_set_packed_source(1)
+    same_as_host_packer(batch, [len(contig)])
+    assert lib.emu_last_packed_source() == 1
+    same_as_host_packer(batch, [len(contig)], lane_min_regions=512, lane_min_batch=1000)
+    for sc in (scenarios.invalid_regions(), scenarios.long_allele_regions(), scenarios.non_acgt_regions(), scenarios.autofail_regions(), scenarios.quota_regions(3),
+               scenarios.max_allele_regions(), scenarios.optimizer_golden_regions()):
+        same_as_host_packer(sc[1], lens_of(sc[0]))  # (those that do not fit the form keep the wide path: same outcome either way)
+
+
+def test_packed_source_large_regions_go_through_the_wave_writer(packed_source):
+    contig, batch = large_regions_batch()
+    assert int((batch.t_cnt.astype(np.int64) + batch.q_cnt).max()) > 255  # ... which does not fit the form's one-byte counts: the wide path stands
+    same_as_host_packer(batch, [len(contig)])
+    assert packed_source.emu_last_packed_source() == 0
+    keep = np.nonzero((batch.t_cnt < 200) & (batch.q_cnt < 200) & (batch.t_cnt.astype(np.int64) + batch.q_cnt > 48))[0]
+    assert keep.size >= 1
+    from aardvark_amd import dist
+    sub = dist.gather_calls(dist.take_regions(batch, keep))
+    same_as_host_packer(sub, [len(contig)])
+    assert packed_source.emu_last_packed_source() == 1
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_packed_source_end_to_end_through_the_emulator_equals_oracle(oracle, packed_source, mode):
+    lib = packed_source
+    lib.emu_set_device_pack(mode)
+    try:
+        contigs, batch = scenarios.golden()
+        got = emu_lib.compare_batch(batch, contigs, n_waves=2)
+        assert lib.emu_last_packed_source() == 1
+        assert got.diff(oracle_lib.compare_batch(oracle, batch, contigs)) == []
+        contig, batch = synth.config_indel_mix_v2(n_truth=3000, contig_len=1_500_000)
+        got = emu_lib.compare_batch(batch, [contig], n_waves=16)
+        assert lib.emu_last_packed_source() == 1
+        assert got.diff(oracle_lib.compare_batch(oracle, batch, [contig], threads=4)) == []
+        assert got.lane_solved > 0.9 * batch.n_regions
+        for contigs, batch in (scenarios.fuzz_regions(41, 300, max_vars=6), scenarios.invalid_regions(), scenarios.non_acgt_regions()):
+            got = emu_lib.compare_batch(batch, contigs)
+            assert got.diff(oracle_lib.compare_batch(oracle, batch, contigs, threads=4)) == []
+    finally:
+        lib.emu_set_device_pack(0)

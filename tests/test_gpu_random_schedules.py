@@ -33,7 +33,7 @@ TABLE = {
     "lane_width_three": [16, 8, 4, 32, 64], "lane_max_calls": [3, 2, 1], "lane_max_est": [15, 3, 0], "lane_head_auto": [1, 0], "lane_head_width": [16, 0, 4, 8, 32, 64],
     "lane_metrics_ed_cap": [0, 4, 12], "hbm_ed_cap": [1024, 0, 8], "het_search_min": [6, 0, 3, 4], "lane_head_est": [1, 2, 6], "lane_pairs": [1, 0], "pair_blocks_per_cu": [1, 4],
     "lane_stripe": [0, 1], "lane_head_stream": [0, 1], "hbm_early_blocks": [256, 8, 768], "hbm_solo_blocks": [128, 4, 768], "lane_node_cap": [32, 8, 250], "lane_quad": [1, 1, 0],
-    "lane_pool": [-1, 0, 1, 8], "lane_waves_three": [0, 2, 16], "lane_waves_per_cu": [12, 2, 32],
+    "lane_pool": [-1, 0, 1, 8], "lane_waves_three": [0, 2, 16], "lane_waves_per_cu": [12, 2, 32], "packed_source": [1, 1, 0],
 }
 
 
@@ -49,7 +49,13 @@ def workloads(oracle):
     out.append(("genome slice", [contig], synth.cluster_regions_v(contig, bed, truth, query, 50)))
     contig, bed, truth, query = synth.contig_calls(5, 3_000_000, 3_800 / 3_000_000, seed_ref=905, seed_query=906, str_frac=0.15, multi_frac=0.05)  # the genome's density
     out.append(("large windows", [contig], synth.cluster_regions_v(contig, bed, truth, query, 1000)))
-    return [(name, contigs, batch, {gm: oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS, group_metrics=gm) for gm in (True, False)}) for name, contigs, batch in out]
+    def packed_form(batch):  # the batch as avk_packed_batch when it fits the form (a third of the draws hand it over that way: the packer then reads the packed arrays themselves)
+        from aardvark_amd import CompactBatch, PackedBatch
+        try:
+            return PackedBatch.from_compact(CompactBatch.from_region_batch(batch))
+        except ValueError:
+            return None
+    return [(name, contigs, batch, {gm: oracle_lib.compare_batch(oracle, batch, contigs, threads=CPUS, group_metrics=gm) for gm in (True, False)}, packed_form(batch)) for name, contigs, batch in out]
 
 
 def test_random_option_sets_do_not_change_a_result(workloads):
@@ -62,10 +68,11 @@ def test_random_option_sets_do_not_change_a_result(workloads):
         opts = {k: TABLE[k][int(rng.integers(0, len(TABLE[k])))] for k in names}
         if opts["lds_bytes_per_wave"] == 0 and opts["lds2_bytes_per_wave"] == 0:
             opts["lds2_bytes_per_wave"] = 40960  # (the bulk needs one LDS tier)
-        name, contigs, batch, want = workloads[draw % len(workloads)]
+        name, contigs, batch, want, pbatch = workloads[draw % len(workloads)]
         gm = bool(rng.integers(0, 2))
         resident = bool(rng.integers(0, 2))
         packed = bool(rng.integers(0, 2))
+        as_packed_batch = pbatch is not None and int(rng.integers(0, 3)) == 0
         ctx = aardvark_amd.Context(0)
         try:
             for k in names:
@@ -73,7 +80,10 @@ def test_random_option_sets_do_not_change_a_result(workloads):
             ctx.set_option("emit_group_metrics", 1 if gm else 0)
             ctx.upload_reference(contigs)
             cfg = CompareConfig(enable_sequences=False)
-            if resident:
+            if as_packed_batch:
+                from aardvark_amd import ResultBatch
+                got = ctx.solve_packed(pbatch, cfg, res=ResultBatch(pbatch, sequences=False, group_metrics=gm, packed=packed))
+            elif resident:
                 rb = ctx.upload(batch)
                 ctx.compare_resident(rb, cfg)
                 got = ctx.download(rb, group_metrics=gm, packed=packed)
@@ -86,6 +96,6 @@ def test_random_option_sets_do_not_change_a_result(workloads):
         finally:
             ctx.close()
         assert diff == [], "draw %d (seed %d, %s, %s path, group metrics %s, packed %s): %s\noptions: %s" % (
-            draw, SEED, name, "resident" if resident else "one-shot", gm, packed, diff[:5], ",".join("%s=%d" % (k, opts[k]) for k in names))
+            draw, SEED, name, "packed batch" if as_packed_batch else "resident" if resident else "one-shot", gm, packed, diff[:5], ",".join("%s=%d" % (k, opts[k]) for k in names))
     assert n_lane > 0 and n_wide > 0
     print("%d draws in %.0f s; regions through the lanes %d, through the wide kernel %d" % (N_DRAWS, time.time() - t0, n_lane, n_wide))

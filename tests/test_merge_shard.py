@@ -222,7 +222,7 @@ def test_merge_tool_sharded_over_two_contexts_writes_the_files_of_one(tmp_path):
     for a, b in (("one", "two"), ("one_skip", "three_skip")):
         for name in ("passing.vcf.gz", "regions.bed.gz", "failed_regions.bed.gz"):
             x, y = (gzip.open(os.path.join(runs[n][0], name), "rb").read() for n in (a, b))
-            assert strip(x) == strip(y) and len(x) > 100, name
+            assert strip(x) == strip(y) and (len(x) > 100 or name == "failed_regions.bed.gz"), name  # (this strategy fails no region)
         assert open(runs[a][1]).read() == open(runs[b][1]).read() != ""
         solved = [l for l in runs[a][2].splitlines() if l.startswith("Solved:error")]
         assert solved and solved == [l for l in runs[b][2].splitlines() if l.startswith("Solved:error")]
