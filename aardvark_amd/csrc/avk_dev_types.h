@@ -232,7 +232,8 @@ struct AvkKernelArgs {
     const uint32_t *bp_off;
     uint32_t *bp_out;
     uint32_t only_not_wide; /* this launch takes only the records avk_wide_static_ok() turns down (a launch of avk_wide.inl has the others) */
-    uint32_t pad4_;
+    uint32_t team;          /* 1: avk_region_kernel_team — a workgroup is ONE region's team: wave 0 runs the search, its siblings take the independent pieces it posts
+                               (the two haplotypes of up to two children of a popped node, the alignments of the metrics): the launch of the long windows */
 };
 
 #endif

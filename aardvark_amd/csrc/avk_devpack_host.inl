@@ -1239,6 +1239,9 @@ struct DownloadLater {
     std::vector<void *> temps;
     uint64_t *h_tally;
     hipEvent_t ev_unpacked, ev_done;
+    /* the parts of ONE split call (compare_packed_split) spill their BASEPAIR groups into one device buffer behind one counter: a part's dp_unpack appends where the
+     * part before it stopped, the words it writes index the call's one list, and the caller reads the count and copies the list once, after the last part */
+    uint32_t *shared_spill = nullptr, *shared_spill_count = nullptr;
 };
 static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_batch *out, uint8_t *pair_exact, uint64_t *tally_words /* [AVK_TALLY_STRIDE] */,
                                   DownloadLater *later = nullptr) {
@@ -1279,13 +1282,17 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     }
     uint8_t *d_exact = pair_exact ? (uint8_t *)tmp(n + 16) : nullptr;
     const bool want_bp_packed = out->bp_packed && out->bp_spilled && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0;
+    const bool bp_shared = later && later->shared_spill && later->shared_spill_count;
     if (want_bp_packed) {
-        if (later) return done(fail(ctx, AVK_E_STATE, "the packed BASEPAIR groups need a synchronous call"));
+        if (later && !bp_shared) return done(fail(ctx, AVK_E_STATE, "the packed BASEPAIR groups need a synchronous call"));
         o.bp_off_dev = db->d_bp_off, o.bp_dev = db->d_bp;
         o.bp_packed = (uint32_t *)tmp((n + 1) * 4);
-        o.bp_spill = (uint32_t *)tmp(((size_t)db->n_bp_groups + 1) * 16);
-        o.bp_spill_count = (uint32_t *)tmp(256);
-        if (!rc && hipMemsetAsync(o.bp_spill_count, 0, 4, s) != hipSuccess) rc = fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(hipGetLastError()));
+        if (bp_shared) o.bp_spill = later->shared_spill, o.bp_spill_count = later->shared_spill_count;
+        else {
+            o.bp_spill = (uint32_t *)tmp(((size_t)db->n_bp_groups + 1) * 16);
+            o.bp_spill_count = (uint32_t *)tmp(256);
+            if (!rc && hipMemsetAsync(o.bp_spill_count, 0, 4, s) != hipSuccess) rc = fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(hipGetLastError()));
+        }
     }
     if (rc) return done(rc);
     if (!ctx->h_dpstate) {
@@ -1319,7 +1326,8 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         segs.push_back({out->var_packed ? out->var_packed + db->v_lo : nullptr, o.var_packed, out->var_packed ? nvr : 0});
     }
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
-    if (want_bp_packed) { /* how many groups were spilled decides how much is copied: one word back first */
+    if (want_bp_packed && bp_shared) segs.push_back({out->bp_packed, o.bp_packed, n * sizeof(uint32_t)}); /* (the spilled groups and their count: the split call's, once) */
+    else if (want_bp_packed) { /* how many groups were spilled decides how much is copied: one word back first */
         uint32_t spilled = 0;
         hipError_t eb = hipMemcpyAsync(&spilled, o.bp_spill_count, 4, hipMemcpyDeviceToHost, s);
         if (eb == hipSuccess) eb = hipStreamSynchronize(s);

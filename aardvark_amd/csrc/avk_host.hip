@@ -59,6 +59,24 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_hbm(AvkKernelArgs a)
     avk::region_worker<false>(a, wave_id, (unsigned char *)0);
 }
 
+/* The long windows, a workgroup per region (avk_solver.inl "a region on a TEAM of wavefronts"): wave 0 claims regions and runs their searches, its three siblings
+ * take the independent pieces it posts — haplotype extensions of a popped node's children, the alignments of the metrics.  Every wave has an HBM slice: the
+ * owner's is the region's workspace, a sibling's is its scratch. */
+__global__ void __launch_bounds__(256, 2) avk_region_kernel_team(AvkKernelArgs a) {
+    __shared__ avk::TeamBox box;
+    for (unsigned k = threadIdx.x; k < sizeof(box) / 4; k += blockDim.x) ((uint32_t *)&box)[k] = 0;
+    __syncthreads();
+    const unsigned w = threadIdx.x >> 6;
+    if (a.high_priority) __builtin_amdgcn_s_setprio(3);
+    if (w == 0) {
+        avk::region_worker<false, false, true>(a, blockIdx.x * 4u, (unsigned char *)0, &box);
+        wv_sync();
+        if ((threadIdx.x & 63u) == 0) avk_wg_store(&box.quit, 1u);
+    } else {
+        avk::team_helper(&box, a.hbm_ws + (uint64_t)(blockIdx.x * 4u + w) * a.tier[a.pass_tier].ws_bytes, a.tier[a.pass_tier].ws_bytes);
+    }
+}
+
 /* the same two for the regions the lanes handed back: device-packed batches (avk_devpack.inl) write the region record and blob of such a region
  * on demand, in the wave that is about to solve it (AvkKernelArgs::lazy_dp) */
 __global__ void __launch_bounds__(256, AVK_LDS_WAVES_PER_SIMD) avk_region_kernel_lds_lazy(AvkKernelArgs a) {
@@ -350,6 +368,10 @@ struct avk_ctx {
     int64_t big_ws_bytes = 64ll << 20; /* (256 MB until round 5: the shared slices were 2.1 GB of a fresh process's first hipMalloc; a batch whose packer predicts larger regions gets 1 GB slices, upload_device_packed) */
     int64_t big_waves = 8;
     int64_t emit_group_metrics = 1;
+    int64_t team_long_windows = 1;         /* 1: the launch of the long windows runs a workgroup per region (avk_region_kernel_team); 0: a wave per region (round 5) */
+    int64_t team_head_regions = 48;        /* a batch of large windows (no region of class C is the wide kernel's): this many regions at the head of the class go to a team launch */
+    int64_t split_parts = 1;               /* > 1: a large avk_compare_packed call runs as this many batches in flight (compare_packed_split; measured slower than the whole call while a half genome's step costs 2.0 of the whole's 2.4 ms: profiles/r06_split_call.txt) ... */
+    int64_t split_min_regions = 1 << 20;   /* ... when it has at least this many regions and every array of the caller's is pinned */
     int64_t packed_source = 1;  /* 1: a batch in the packed form is packed from the packed arrays themselves (no wide copy of the caller's arrays in HBM); 0: round 5's widening pass */
     int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
     int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
@@ -808,6 +830,17 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "pool_cache_bytes") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "pool_cache_bytes must not be negative");
         ctx->pool_cache_bytes = value;
+    } else if (n == "team_long_windows") {
+        ctx->team_long_windows = value ? 1 : 0;
+    } else if (n == "team_head_regions") {
+        if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "team_head_regions must be 0..1024");
+        ctx->team_head_regions = value;
+    } else if (n == "split_parts") {
+        if (value < 1 || value > 4) return fail(ctx, AVK_E_ARG, "split_parts must be 1..4");
+        ctx->split_parts = value;
+    } else if (n == "split_min_regions") {
+        if (value < 0) return fail(ctx, AVK_E_ARG, "split_min_regions must be >= 0");
+        ctx->split_min_regions = value;
     } else if (n == "packed_source") {
         ctx->packed_source = value ? 1 : 0;
     } else if (n == "emit_bp_groups") {
@@ -1519,6 +1552,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
     bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false, hbm_shared = false, wide_x_pending = false;
+    uint32_t hbm_shared_base = 0; /* records of class C ahead of the shared list (a team launch has them) */
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
         a.pass_tier = (uint32_t)t;
@@ -1637,7 +1671,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.overflow_list = nullptr;
                         x.overflow_count = nullptr;
                         AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
-                        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
+                        x.team = ctx->team_long_windows ? 1u : 0u;
+                        if (x.team) hipLaunchKernelGGL(avk_region_kernel_team, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
+                        else hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_wide, ctx->wide_stream));
                         wide_x = true;
@@ -1665,9 +1701,46 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         s.n_work_dev = db->d_counters + 1272;
                     }
                 }
+                uint32_t team_head = 0; /* records at the front of class C (most calls first) that a team launch takes */
+                if (!wide_c && ctx->team_long_windows && ctx->team_head_regions > 0 && n_c > 1) {
+                    /* a batch of large windows (--min-variant-gap 1000: every region is class C and none is the wide kernel's): its step is as long as its few longest
+                     * searches — 0.25 s on one wave for 92 calls on 20 kbp while the other 49,000 regions need 0.05 s of the whole chip — so the head of the class, which
+                     * is sorted most calls first, gets a workgroup per region; the other launches start behind it in the list */
+                    uint32_t xb = n_c / 2u < (uint32_t)ctx->team_head_regions ? n_c / 2u : (uint32_t)ctx->team_head_regions;
+                    if (xb > hbm_solo_max / 2u) xb = hbm_solo_max / 2u;
+                    if (xb) {
+                        AvkKernelArgs x = s;
+                        x.pass_tier = 2;
+                        x.only_not_wide = 0;
+                        x.team = 1;
+                        x.work_list = nullptr;
+                        x.n_work_dev = nullptr;
+                        x.work_base = 0;
+                        x.n_work = xb;
+                        x.work_counter = db->d_counters + 1256;
+                        x.static_pct = 0;
+                        x.n_shards = 1;
+                        x.n_waves = xb * waves_per_block;
+                        x.claim = 1;
+                        x.high_priority = 1;
+                        x.hbm_ws = ctx->d_ws + (size_t)(n_waves + (hbm_solo_max - xb) * waves_per_block) * (size_t)ws_bytes; /* the last slices of the solo launch's share */
+                        x.big_ws = ctx->d_big;
+                        x.big_busy = db->d_counters + 1088;
+                        x.big_slots = big_slots;
+                        x.overflow_list = nullptr;
+                        x.overflow_count = nullptr;
+                        AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
+                        hipLaunchKernelGGL(avk_region_kernel_team, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
+                        AVK_HIP(ctx, hipGetLastError());
+                        AVK_HIP(ctx, hipEventRecord(ctx->ev_wide, ctx->wide_stream));
+                        wide_x = true;
+                        team_head = xb;
+                        if (hbm_solo > hbm_solo_max - xb) hbm_solo = hbm_solo_max - xb;
+                    }
+                }
                 s.pass_tier = 2;
-                s.work_base = 0;
-                s.n_work = n_c;
+                s.work_base = team_head;
+                s.n_work = n_c - team_head;
                 s.work_counter = db->d_counters + 1076;
                 s.static_pct = 0;
                 s.n_shards = 1;
@@ -1689,6 +1762,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_join2, ctx->side_stream2));
                 hbm_solo_pending = true;
                 hbm_shared = !wide_c; /* (the records of class C are the wide launch's: the main stream's HBM launch has nothing to share) */
+                hbm_shared_base = team_head;
                 wide_x_pending = wide_x;
             }
             if (solo) {
@@ -1941,8 +2015,8 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             a.n_waves = hbm_blocks * waves_per_block;
             if (hbm_solo_pending && hbm_shared) { /* class C records the solo launch has not started yet: every wave of this launch helps (same ticket counter) */
                 a.extra_counter = db->d_counters + 1076;
-                a.extra_base = 0;
-                a.extra_n = db->plan.n_hbm;
+                a.extra_base = hbm_shared_base;
+                a.extra_n = db->plan.n_hbm - hbm_shared_base;
             }
             hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(hbm_blocks), dim3(256), 0, ctx->stream, a);
         } else {
@@ -2473,7 +2547,15 @@ static bool packed_inputs_pinned(const avk_packed_batch *batch) {
            is_pinned(batch->var_raw_space, nv * 4) && is_pinned(batch->allele_bytes, alen);
 }
 
+static int submit_impl(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket, uint32_t *shared_spill,
+                       uint32_t *shared_spill_count);
 int avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket) {
+    return submit_impl(ctx, batch, cfg, out, ticket, nullptr, nullptr);
+}
+/* shared_spill / shared_spill_count: the device list and counter the parts of one split call spill their BASEPAIR groups into (compare_packed_split); with them a
+ * batch that returns the packed groups can be queued like any other */
+static int submit_impl(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out, avk_ticket **ticket, uint32_t *shared_spill,
+                       uint32_t *shared_spill_count) {
     if (!ctx || !batch || !cfg || !out || !ticket || !(out->status || out->region_packed)) return AVK_E_ARG;
     *ticket = nullptr;
     if (!ctx->d_ref) return fail(ctx, AVK_E_STATE, "avk_ref_upload has not been called");
@@ -2494,7 +2576,9 @@ int avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const
              is_pinned(out->var_packed, nv) && is_pinned(out->group_metrics, n * AVK_N_GROUPS * AVK_N_FIELDS * 4);
     const bool seq_out = out->seq_bytes && out->seq_len && out->seq_off && out->seq_stride && cfg->enable_sequences;
     int slot = -1;
-    const bool can_queue = pinned && !seq_out && !((out->bp_off || out->bp_packed) && out->bp_groups);
+    const bool bp_words = out->bp_packed && out->bp_spilled && out->bp_groups && !out->bp_off;
+    const bool bp_queueable = bp_words && shared_spill && shared_spill_count && is_pinned(out->bp_packed, n * 4);
+    const bool can_queue = pinned && !seq_out && (bp_queueable || !((out->bp_off || out->bp_packed) && out->bp_groups));
     for (int i = 0; i < 4 && slot < 0 && can_queue; ++i)
         if (!ctx->stage[i].busy) {
             slot = i;
@@ -2526,7 +2610,9 @@ int avk_compare_packed_submit(avk_ctx *ctx, const avk_packed_batch *batch, const
     t->slot = slot;
     t->keep_gm = ctx->emit_group_metrics, t->keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;
+    if (bp_queueable) ctx->emit_bp_groups = 1;
     t->later.h_tally = sl.h_tally, t->later.ev_unpacked = sl.ev_unpacked, t->later.ev_done = sl.ev_done;
+    t->later.shared_spill = bp_queueable ? shared_spill : nullptr, t->later.shared_spill_count = bp_queueable ? shared_spill_count : nullptr;
     /* Packing on a stream of its own: its kernels stream the batch's arrays through HBM while the solver launches of the batch before are busy with their searches,
      * and the plan's round trip to the host no longer waits for that solve.  Pool buffers stay ordered: what this upload is handed was released either by an upload
      * (on this same stream) or by a batch whose work is over (avk_wait). */
@@ -2802,9 +2888,132 @@ int avk_batch_upload_packed(avk_ctx *ctx, const avk_packed_batch *batch, avk_dev
     return upload_device_packed(ctx, nullptr, nullptr, false, out, nullptr, batch);
 }
 
+/* One large call as `parts` batches in flight (context option split_parts; avk_compare_packed below): the regions are independent (src/main.rs:251-268 maps over
+ * them), so the batch is cut into ranges of regions — the packed form has no explicit offsets, a range of regions with its calls and allele bytes is a packed batch of
+ * its own — that go through the staging slots of the asynchronous boundary: the arrays of part k + 1 cross the bus and are packed while part k is solved, the results of
+ * part k cross while part k + 1 is solved.  Same outputs, byte for byte: per-region and per-call arrays land at the parts' places in the caller's arrays, the tallies are
+ * added, the parts' spilled BASEPAIR groups form one list (one device buffer, one counter).  Returns -1 when the call does not qualify (the caller then runs it whole). */
+static int compare_packed_split(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
+    const uint64_t n = batch->n_regions, nv = batch->n_variants;
+    int64_t parts = ctx->split_parts;
+    if (parts > 4) parts = 4;
+    if (parts < 2 || !ctx->async_pack_stream || n < (uint64_t)ctx->split_min_regions || n / (uint64_t)parts < 4096) return -1;
+    if (cfg->enable_sequences && out->seq_bytes) return -1;
+    if (out->bp_off || (out->bp_packed && !(out->bp_spilled && out->bp_groups)) || out->group_metrics) return -1;
+    for (int i = 0; i < 4; ++i)
+        if (ctx->stage[i].busy) return -1; /* batches of the caller's are in flight: the slots are theirs */
+    if (!packed_inputs_pinned(batch)) return -1;
+    if (!(is_pinned(out->status, n * 4) && is_pinned(out->region_packed, n * 8) && is_pinned(out->ed_h1, n * 4) && is_pinned(out->ed_h2, n * 4) && is_pinned(out->n_optima, n * 4) &&
+          is_pinned(out->type_present, n * 2) && is_pinned(out->var_expected, nv) && is_pinned(out->var_observed, nv) && is_pinned(out->var_class, nv) && is_pinned(out->var_zyg, nv) &&
+          is_pinned(out->var_packed, nv) && is_pinned(out->bp_packed, n * 4)))
+        return -1;
+    const bool want_bp = out->bp_packed != nullptr;
+    /* where the parts begin: regions in equal shares, their calls and allele bytes by the running sums the packed form implies (host threads: two byte arrays read once) */
+    uint64_t r0[5], v0[5], a0[5];
+    for (int k = 0; k <= parts; ++k) r0[k] = n * (uint64_t)k / (uint64_t)parts;
+    v0[0] = a0[0] = 0;
+    {
+        const unsigned threads = avk_host_threads();
+        for (int k = 0; k < parts; ++k) {
+            std::vector<uint64_t> partial(threads + 1, 0);
+            avk_parallel_for(r0[k + 1] - r0[k], threads, [&](unsigned t, uint64_t lo, uint64_t hi) {
+                uint64_t sum = 0;
+                for (uint64_t r = r0[k] + lo; r < r0[k] + hi; ++r) sum += (uint64_t)batch->t_cnt[r] + batch->q_cnt[r];
+                partial[t] += sum;
+            });
+            uint64_t calls = 0;
+            for (uint64_t x : partial) calls += x;
+            v0[k + 1] = v0[k] + calls;
+            if (v0[k + 1] > nv) return fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to more than n_variants %llu", (unsigned long long)nv);
+            std::fill(partial.begin(), partial.end(), 0);
+            avk_parallel_for(calls, threads, [&](unsigned t, uint64_t lo, uint64_t hi) {
+                uint64_t sum = 0;
+                for (uint64_t v = v0[k] + lo; v < v0[k] + hi; ++v) sum += (uint64_t)batch->a0_len[v] + batch->a1_len[v];
+                partial[t] += sum;
+            });
+            uint64_t bytes = 0;
+            for (uint64_t x : partial) bytes += x;
+            a0[k + 1] = a0[k] + bytes;
+        }
+        if (v0[parts] != nv || a0[parts] != batch->allele_bytes_len)
+            return fail(ctx, AVK_E_ARG, "packed batch: the call counts sum to %llu (n_variants %llu), the allele lengths to %llu (allele_bytes_len %llu)", (unsigned long long)v0[parts],
+                        (unsigned long long)nv, (unsigned long long)a0[parts], (unsigned long long)batch->allele_bytes_len);
+    }
+    uint32_t *d_spill = nullptr, *d_count = nullptr;
+    if (want_bp) { /* every region has at most 1 + its calls groups */
+        int rc = pool_alloc(ctx, (void **)&d_spill, (size_t)(n + nv + 1) * 16);
+        if (!rc) rc = pool_alloc(ctx, (void **)&d_count, 256);
+        if (!rc && hipMemsetAsync(d_count, 0, 4, ctx->stream) != hipSuccess) rc = fail(ctx, AVK_E_HIP, "split call: %s", hipGetErrorString(hipGetLastError()));
+        if (rc) {
+            if (d_spill) pool_release(ctx, d_spill);
+            if (d_count) pool_release(ctx, d_count);
+            return rc;
+        }
+        out->bp_spilled[0] = 0;
+    }
+    avk_ticket *tickets[4] = {nullptr, nullptr, nullptr, nullptr};
+    std::vector<uint64_t> part_tally((size_t)parts * AVK_TALLY_LEN, 0);
+    int rc = 0;
+    int queued = 0;
+    for (int k = 0; k < parts && !rc; ++k) {
+        avk_packed_batch pb = *batch;
+        pb.n_regions = r0[k + 1] - r0[k], pb.n_variants = v0[k + 1] - v0[k], pb.allele_bytes_len = a0[k + 1] - a0[k];
+        pb.contig_idx = batch->contig_idx ? batch->contig_idx + r0[k] : nullptr;
+        pb.start = batch->start + r0[k], pb.len = batch->len + r0[k], pb.t_cnt = batch->t_cnt + r0[k], pb.q_cnt = batch->q_cnt + r0[k];
+        pb.var_rel_pos = batch->var_rel_pos + v0[k], pb.var_type_zyg = batch->var_type_zyg + v0[k], pb.a0_len = batch->a0_len + v0[k], pb.a1_len = batch->a1_len + v0[k];
+        pb.var_raw_space = batch->var_raw_space ? batch->var_raw_space + v0[k] : nullptr;
+        pb.allele_bytes = batch->allele_bytes + a0[k];
+        avk_result_batch po = *out;
+#define AVK_PART(field, at) po.field = out->field ? out->field + (at) : nullptr
+        AVK_PART(status, r0[k]), AVK_PART(region_packed, r0[k]), AVK_PART(ed_h1, r0[k]), AVK_PART(ed_h2, r0[k]), AVK_PART(n_optima, r0[k]), AVK_PART(type_present, r0[k]);
+        AVK_PART(var_expected, v0[k]), AVK_PART(var_observed, v0[k]), AVK_PART(var_class, v0[k]), AVK_PART(var_zyg, v0[k]), AVK_PART(var_packed, v0[k]);
+        AVK_PART(bp_packed, r0[k]);
+#undef AVK_PART
+        po.tally = part_tally.data() + (size_t)k * AVK_TALLY_LEN;
+        rc = submit_impl(ctx, &pb, cfg, &po, &tickets[k], d_spill, d_count);
+        if (!rc) queued = k + 1;
+    }
+    /* everything of every part is on the device's queues; the spilled groups' count and the list itself once the last part's results have crossed */
+    if (!rc && queued == parts && want_bp) {
+        hipError_t e = tickets[parts - 1]->slot >= 0 ? hipEventSynchronize(ctx->stage[tickets[parts - 1]->slot].ev_done) : hipSuccess;
+        for (int k = 0; k + 1 < parts && e == hipSuccess; ++k)
+            if (tickets[k]->slot >= 0) e = hipEventSynchronize(ctx->stage[tickets[k]->slot].ev_done);
+        uint32_t spilled = 0;
+        if (e == hipSuccess) e = hipMemcpyAsync(&spilled, d_count, 4, hipMemcpyDeviceToHost, ctx->copy_out_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_out_stream);
+        if (e == hipSuccess && spilled) e = hipMemcpyAsync(out->bp_groups, d_spill, (size_t)spilled * 16, hipMemcpyDeviceToHost, ctx->copy_out_stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->copy_out_stream);
+        if (e != hipSuccess) rc = fail(ctx, AVK_E_HIP, "split call: %s", hipGetErrorString(e));
+        out->bp_spilled[0] = spilled; /* (a part's capacity repair, should there be one, appends behind these: avk_wait below) */
+    }
+    uint64_t tiers[5] = {0, 0, 0, 0, 0}, lane_solved = 0, wide_solved = 0;
+    for (int k = 0; k < queued; ++k) {
+        const int rw = avk_wait(ctx, tickets[k]);
+        if (rw && !rc) rc = rw;
+        for (int i = 0; i < 5; ++i) tiers[i] += ctx->last_tiers[i];
+        lane_solved += ctx->last_lane_solved, wide_solved += ctx->last_wide_solved;
+    }
+    if (d_spill) pool_release(ctx, d_spill);
+    if (d_count) pool_release(ctx, d_count);
+    if (rc) return rc;
+    memcpy(ctx->last_tiers, tiers, sizeof(tiers));
+    ctx->last_lane_solved = lane_solved, ctx->last_wide_solved = wide_solved;
+    if (out->tally) {
+        memset(out->tally, 0, AVK_TALLY_LEN * sizeof(uint64_t));
+        for (int k = 0; k < parts; ++k)
+            for (int i = 0; i < AVK_TALLY_LEN; ++i) out->tally[i] += part_tally[(size_t)k * AVK_TALLY_LEN + i];
+    }
+    ctx->last_one_shot = 1;
+    return 0;
+}
+
 int avk_compare_packed(avk_ctx *ctx, const avk_packed_batch *batch, const avk_compare_config *cfg, avk_result_batch *out) {
     if (!ctx || !batch || !cfg || !out || !(out->status || out->region_packed)) return AVK_E_ARG;
     ctx->last_one_shot = 0;
+    if (ctx->split_parts > 1 && ctx->d_ref) {
+        const int rs = compare_packed_split(ctx, batch, cfg, out);
+        if (rs >= 0) return rs;
+    }
     avk_dev_batch *db = nullptr;
     const int64_t keep_gm = ctx->emit_group_metrics, keep_bp = ctx->emit_bp_groups;
     if (!out->group_metrics) ctx->emit_group_metrics = 0;

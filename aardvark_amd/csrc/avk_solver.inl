@@ -103,9 +103,13 @@ struct UVar {
     u32 rel_pos, a0_len, a1_len, a_off, raw_space, alt_ed, type, zyg;
 };
 
+struct TeamBox;
 struct Ctx {
     /* region */
     u32 L, T, Q, N;
+    TeamBox *team;          /* the workgroup's team (avk_region_kernel_team) or NULL: this wave alone */
+    u32 team_gen;           /* generation of the last batch of jobs posted */
+    u64 team_scratch_bytes; /* bytes of scratch every sibling has for the alignments of the metrics (its own workspace slice) */
     u8 *ws;        /* base of this wave's workspace */
     const u8 *ref; /* window bytes (workspace copy) */
     LVar *vars;    /* [N]: truth 0..T-1, query T..N-1 */
@@ -788,6 +792,192 @@ AVK_DEV void queue_reload(Ctx &c) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* a region on a TEAM of wavefronts (round 6: the launch of the long windows)                  */
+/* ------------------------------------------------------------------------------------------ */
+/* A search in a window of kilobases is one long chain on one wavefront — 0.25 s for 92 calls on 20 kbp — but its links are not one piece of work each:
+ *   - ComparisonNode::extend_variant (src/query_optimizer.rs:443-451) extends the node's two haplotypes independently (HaplotypeDWFA::extend_variant,
+ *     src/dwfa/haplotype_dwfa.rs:46-67), and a heterozygous call makes two children (:269-293): up to four copy + extend + DWFA-update jobs per pop;
+ *   - add_basepair_stats (src/waffle_solver.rs:335-449) is 4 alignments against the reference window and, per call type and haplotype, 2 x 2 more on
+ *     filtered sequences: a dozen and more independent wfa_ed calls.
+ * A workgroup of avk_region_kernel_team is ONE region's team: wave 0 (the owner) runs the search exactly as region_worker does — queue, quota, pop order, ids —
+ * and POSTS those pieces as jobs in the workgroup's LDS; its three siblings (and the owner itself) claim and run them, results come back through the job records.
+ * What a job reads and writes is the owner's workspace (global memory, the same CU's L1) and, for the metrics, the sibling's own scratch.  Children are made
+ * OUT OF PLACE — child record = copy of the parent's record, extended — so the jobs of a pop never touch each other's bytes; the popped node is freed instead
+ * of becoming the second clone.  Node contents, ids, costs and pop order are those of the one-wave search: the results are bit-identical. */
+enum { TJ_HAP = 1, TJ_ED = 2, TJ_FILT = 3 };
+enum { TJF_FINAL = 1 };
+enum { TEAM_JOBS = 36 };
+struct TeamJob {
+    u32 kind, flags;
+    u32 depth, allele; /* TJ_HAP: the call of this depth of the search order, AL_REF / AL_ALT */
+    u32 x0, x1;        /* TJ_ED: lengths; TJ_FILT: side, index into the filtered types */
+    u64 src, dst;      /* TJ_HAP: haplotype records (dst == src: in place); TJ_ED: the two sequences; TJ_FILT: src = the winner's haplotype record */
+    int res[3];
+    u32 pad_;
+};
+struct TeamBox {
+    u32 next;   /* generation << 8 | next job to claim: the word the siblings watch */
+    u32 n_jobs; /* generation << 8 | jobs of this generation */
+    u32 done, quit, ver, pad_[3];
+    /* what a sibling needs of the owner's Ctx (published once per region attempt, `ver` counts them) */
+    u64 ws, ref, vars, alle, ovars;
+    u32 L, T, Q, N, seqcap, wfcap, alw, hapA_bytes, wfs_cap, pad2_[3];
+    TeamJob job[TEAM_JOBS];
+};
+AVK_DEV u32 gen_filtered(const Ctx &c, u32 v0, u32 cnt, const u64 *alt, u32 ftype, u8 *out, u32 &failed_ed);
+AVK_DEV u32 team_sup_type(u32 s) {
+    return s == 0 ? (u32)AVK_VT_SNV : (s == 1 ? (u32)AVK_VT_INSERTION : (s == 2 ? (u32)AVK_VT_DELETION : (s == 3 ? (u32)AVK_VT_INDEL : (s == 4 ? (u32)AVK_VT_TR_CONTRACTION :
+           (s == 5 ? (u32)AVK_VT_TR_EXPANSION : (s == 6 ? (u32)AVK_VT_SV_DELETION : (u32)AVK_VT_SV_INSERTION))))));
+}
+AVK_DEV void team_publish(Ctx &c) { /* owner, after the workspace is carved */
+    TeamBox *b = c.team;
+    wv_sync();
+    if (wv_lane() == 0) {
+        b->ws = (u64)c.ws, b->ref = (u64)c.ref, b->vars = (u64)c.vars, b->alle = (u64)c.alle, b->ovars = (u64)c.ovars;
+        b->L = c.L, b->T = c.T, b->Q = c.Q, b->N = c.N, b->seqcap = c.seqcap, b->wfcap = c.wfcap, b->alw = c.alw, b->hapA_bytes = c.hapA_bytes, b->wfs_cap = c.wfs_cap;
+        avk_wg_store(&b->ver, avk_wg_load(&b->ver) + 1u);
+    }
+    wv_sync();
+}
+/* job j of the box, run by one wave with its own scratch (hc.wfs, hc.seq_a) on the owner's data */
+AVK_DEV void team_exec(const Ctx &hc, TeamBox *b, u32 j) {
+    TeamJob *jb = b->job + j;
+    const u32 kind = wv_uni(jb->kind);
+    int r0 = 0, r1 = 0, r2 = 0;
+    if (kind == TJ_HAP) {
+        const u8 *src = (const u8 *)wv_uni64(jb->src);
+        u8 *dst = (u8 *)wv_uni64(jb->dst);
+        const u32 flags = wv_uni(jb->flags), depth = wv_uni(jb->depth), allele = wv_uni(jb->allele);
+        if (dst != src) { /* the child's record: the parent's, copied (hap_record_copy) */
+            wv_sync();
+            if (hc.hapA_bytes < (u32)AVK_COPY_USED_MIN) copy_words((u32 *)dst, (const u32 *)src, hc.hapA_bytes >> 2);
+            else hap_copy_used(hc, dst, src, hc.wfcap);
+            wv_sync();
+        }
+        const HapPtr p = hap_ptr(dst, hc.alw, hc.wfcap, hc.seqcap);
+        HapHdr h = hap_load(p.w);
+        if (flags & TJF_FINAL) { /* nodeA_finalize */
+            UVar none;
+            none.rel_pos = none.a0_len = none.a1_len = none.a_off = none.raw_space = none.alt_ed = none.type = none.zyg = 0;
+            hap_extend_seq(hc, p, h, true, false, none, AL_REF, hc.L);
+            if (hap_update(p, hc.wfcap, h)) r0 = 1;
+            else if (hap_finalize(p, hc.wfcap, h)) r0 = 1;
+        } else { /* nodeA_extend, one haplotype */
+            u32 sync, vi;
+            const UVar v = load_ovar(hc.ovars, depth, sync, vi);
+            hap_extend_seq(hc, p, h, vi < hc.T, true, v, allele, sync);
+            if (hap_update(p, hc.wfcap, h)) r0 = 1;
+        }
+        wv_sync();
+        hap_store(p.w, h);
+        wv_sync();
+    } else if (kind == TJ_ED) {
+        r0 = wfa_ed(hc, (const u8 *)wv_uni64(jb->src), wv_uni(jb->x0), (const u8 *)wv_uni64(jb->dst), wv_uni(jb->x1));
+    } else { /* TJ_FILT: one side of one call type on one haplotype of the winner (waffle_solver.rs:383-445) */
+        const HapPtr wp = hap_ptr((u8 *)wv_uni64(jb->src), hc.alw, hc.wfcap, hc.seqcap);
+        const HapHdr hd = hap_load(wp.w);
+        const u32 side = wv_uni(jb->x0), ftype = team_sup_type(wv_uni(jb->x1));
+        u32 failed = 0;
+        if (side) { /* query */
+            const u32 fl = gen_filtered(hc, hc.T, hc.Q, wp.qalt, ftype, hc.seq_a, failed);
+            r0 = wfa_ed(hc, hc.ref, hc.L, hc.seq_a, fl);
+            r1 = r0 < 0 ? -1 : wfa_ed(hc, wp.tseq, hd.t_len, hc.seq_a, fl);
+        } else {
+            const u32 fl = gen_filtered(hc, 0, hc.T, wp.talt, ftype, hc.seq_a, failed);
+            r0 = wfa_ed(hc, hc.ref, hc.L, hc.seq_a, fl);
+            r1 = r0 < 0 ? -1 : wfa_ed(hc, hc.seq_a, fl, wp.qseq, hd.q_len);
+        }
+        r2 = (int)failed;
+    }
+    wv_sync();
+    if (wv_lane() == 0) jb->res[0] = r0, jb->res[1] = r1, jb->res[2] = r2;
+    wv_sync();
+}
+/* owner: the jobs 0 .. n - 1 of the box are written; every wave of the team (this one included) takes some; returns when all are done */
+AVK_DEV void team_run(Ctx &c, u32 n) {
+    TeamBox *b = c.team;
+    const u32 lane = (u32)wv_lane();
+    wv_sync();
+    avk_release_wg();
+    c.team_gen = (c.team_gen + 1u) & 0xFFFFFFu;
+    const u32 gen = c.team_gen;
+    if (lane == 0) { /* the generation opens with the LAST store: whoever sees it in `next` sees the jobs, their count and the cleared counter */
+        avk_wg_store(&b->n_jobs, (gen << 8) | n);
+        avk_wg_store(&b->done, 0u);
+        avk_wg_store(&b->next, gen << 8);
+    }
+    for (;;) {
+        u32 v = 0;
+        if (lane == 0) v = avk_wg_add(&b->next, 1u);
+        v = wv_uni(wv_shfl(v, 0));
+        const u32 j = v & 0xFFu;
+        if (j >= n) break;
+        team_exec(c, b, j);
+        avk_release_wg();
+        if (lane == 0) (void)avk_wg_add(&b->done, 1u);
+    }
+    for (;;) {
+        u32 d = 0;
+        if (lane == 0) d = avk_wg_load(&b->done);
+        d = wv_uni(wv_shfl(d, 0));
+        if (d >= n) break;
+        avk_sleep_short();
+    }
+    avk_acquire_wg();
+    wv_sync();
+}
+/* a sibling wave of the team: until the owner says quit.  `scratch` = this wave's own workspace slice. */
+AVK_DEV void team_helper(TeamBox *b, u8 *scratch, u64 scratch_bytes) {
+    const u32 lane = (u32)wv_lane();
+    u32 my_gen = 0, my_ver = 0;
+    Ctx hc;
+    hc.team = (TeamBox *)0, hc.team_gen = 0, hc.team_scratch_bytes = 0;
+    hc.L = hc.T = hc.Q = hc.N = hc.seqcap = hc.wfcap = hc.alw = hc.hapA_bytes = hc.wfs_cap = 0;
+    hc.ws = (u8 *)0, hc.ref = (const u8 *)0, hc.vars = (LVar *)0, hc.alle = (u8 *)0, hc.ovars = (const AvkOrdVar *)0, hc.wfs = (u32 *)0, hc.seq_a = (u8 *)0;
+    for (;;) {
+        u32 v = 0, q = 0;
+        for (;;) { /* a generation this wave has not seen, or the end */
+            if (lane == 0) v = avk_wg_load(&b->next), q = avk_wg_load(&b->quit);
+            v = wv_uni(wv_shfl(v, 0)), q = wv_uni(wv_shfl(q, 0));
+            if ((v >> 8) != my_gen || q) break;
+            avk_sleep_short();
+        }
+        if ((v >> 8) == my_gen && q) return;
+        for (;;) {
+            u32 w = 0, nj = 0;
+            if (lane == 0) {
+                w = avk_wg_add(&b->next, 1u);
+                nj = avk_wg_load(&b->n_jobs); /* read AFTER the claim: the count of the generation the claim belongs to, or of a later one */
+            }
+            w = wv_uni(wv_shfl(w, 0)), nj = wv_uni(wv_shfl(nj, 0));
+            my_gen = w >> 8;
+            if ((nj >> 8) != my_gen || (w & 0xFFu) >= (nj & 0xFFu)) break; /* (a claim made while the owner was opening the next generation is nobody's job) */
+            avk_acquire_wg();
+            u32 ver = 0;
+            if (lane == 0) ver = avk_wg_load(&b->ver);
+            ver = wv_uni(wv_shfl(ver, 0));
+            if (ver != my_ver) { /* another region (or another attempt at it): the owner's pointers and sizes, this wave's scratch */
+                my_ver = ver;
+                hc.ws = (u8 *)wv_uni64(b->ws), hc.ref = (const u8 *)wv_uni64(b->ref), hc.vars = (LVar *)wv_uni64(b->vars), hc.alle = (u8 *)wv_uni64(b->alle);
+                hc.ovars = (const AvkOrdVar *)wv_uni64(b->ovars);
+                hc.L = wv_uni(b->L), hc.T = wv_uni(b->T), hc.Q = wv_uni(b->Q), hc.N = wv_uni(b->N), hc.seqcap = wv_uni(b->seqcap), hc.wfcap = wv_uni(b->wfcap), hc.alw = wv_uni(b->alw);
+                hc.hapA_bytes = wv_uni(b->hapA_bytes), hc.wfs_cap = wv_uni(b->wfs_cap);
+                hc.wfs = (u32 *)scratch;
+                hc.seq_a = scratch + 4ull * hc.wfs_cap;
+                (void)scratch_bytes; /* (the owner posts metrics jobs only when 4 wfs_cap + seqcap fits: Ctx::team_scratch_bytes) */
+            }
+            team_exec(hc, b, w & 0xFFu);
+            avk_release_wg();
+            if (lane == 0) (void)avk_wg_add(&b->done, 1u);
+        }
+    }
+}
+AVK_DEV void team_job_hap(TeamBox *b, u32 j, const u8 *src, u8 *dst, u32 depth, u32 allele, u32 flags) { /* lane 0 of the owner */
+    TeamJob *jb = b->job + j;
+    jb->kind = TJ_HAP, jb->flags = flags, jb->depth = depth, jb->allele = allele, jb->x0 = jb->x1 = 0, jb->src = (u64)src, jb->dst = (u64)dst;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* phase A — optimize_sequences (src/query_optimizer.rs:166-365)                               */
 /* ------------------------------------------------------------------------------------------ */
 AVK_DEV u32 nodeA_cost(const Ctx &c, u32 idx) {
@@ -865,7 +1055,7 @@ AVK_DEV int nodeA_finalize(const Ctx &c, u32 idx) {
 }
 
 /* returns the number of tied optima (their node indices are in c.optlist), RS_OVERFLOW, or -status-100 */
-AVK_DEV int phaseA(Ctx &c) {
+template <bool TEAM = false> AVK_DEV int phaseA(Ctx &c) {
     AVK_TA_DECL
     c.node_bytes = c.nodeA_bytes;
     c.pool_base = c.pool;
@@ -921,7 +1111,16 @@ AVK_DEV int phaseA(Ctx &c) {
 
         AVK_TA_MARK(c, 9)
         if (depth == c.N) { /* :227-247 */
-            if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
+            if (TEAM && c.team) { /* the node's two haplotypes side by side (a twin's second record is computed like the first) */
+                u8 *n = node_at(c, ni);
+                wv_sync();
+                if (wv_lane() == 0) {
+                    team_job_hap(c.team, 0, n + NODE_HDR, n + NODE_HDR, 0, AL_REF, TJF_FINAL);
+                    team_job_hap(c.team, 1, n + NODE_HDR + c.hapA_bytes, n + NODE_HDR + c.hapA_bytes, 0, AL_REF, TJF_FINAL);
+                }
+                team_run(c, 2);
+                if (wv_uni((u32)c.team->job[0].res[0]) | wv_uni((u32)c.team->job[1].res[0])) return RS_OVERFLOW;
+            } else if (nodeA_finalize(c, ni)) return RS_OVERFLOW;
             const u32 fc = nodeA_cost(c, ni);
             if (fc < best_ed) {
                 for (u32 k = 0; k < nbest; ++k) node_free(c, ld32u(c.optlist + k));
@@ -947,7 +1146,51 @@ AVK_DEV int phaseA(Ctx &c) {
         const u32 zyg = v.zyg;
         const bool het = zyg == AVK_ZYG_UNPHASED_HET || zyg == AVK_ZYG_PHASED_HET01 || zyg == AVK_ZYG_PHASED_HET10;
 
-        if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
+        if (TEAM && c.team) {
+            const bool two = het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET);
+            u8 *pn = node_at(c, ni);
+            const bool sym = ld32u((const u32 *)pn + 1) != 0;
+            if (two) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) — both made out of place from the popped node, four records on four waves */
+                const int c1 = node_alloc(c);
+                if (c1 < 0) return RS_OVERFLOW;
+                const int c2 = node_alloc(c);
+                if (c2 < 0) return RS_OVERFLOW;
+                u8 *n1 = node_at(c, (u32)c1), *n2 = node_at(c, (u32)c2);
+                wv_sync();
+                if (wv_lane() == 0) {
+                    ((u32 *)n1)[0] = next_id, ((u32 *)n1)[1] = 0, ((u32 *)n1)[2] = ((const u32 *)pn)[2], ((u32 *)n1)[3] = ((const u32 *)pn)[3];
+                    ((u32 *)n2)[0] = next_id + 1, ((u32 *)n2)[1] = 0, ((u32 *)n2)[2] = ((const u32 *)pn)[2], ((u32 *)n2)[3] = ((const u32 *)pn)[3];
+                    team_job_hap(c.team, 0, pn + NODE_HDR, n1 + NODE_HDR, depth, AL_REF, 0);
+                    team_job_hap(c.team, 1, pn + NODE_HDR + c.hapA_bytes, n1 + NODE_HDR + c.hapA_bytes, depth, AL_ALT, 0);
+                    team_job_hap(c.team, 2, pn + NODE_HDR, n2 + NODE_HDR, depth, AL_ALT, 0);
+                    team_job_hap(c.team, 3, pn + NODE_HDR + c.hapA_bytes, n2 + NODE_HDR + c.hapA_bytes, depth, AL_REF, 0);
+                }
+                team_run(c, 4);
+                u32 bad = 0;
+                for (int j = 0; j < 4; ++j) bad |= wv_uni((u32)c.team->job[j].res[0]);
+                if (bad) return RS_OVERFLOW;
+                if (queue_push(c, ((u64)nodeA_cost(c, (u32)c1) << 32) | next_id, (u32)c1)) return RS_OVERFLOW;
+                if (queue_push(c, ((u64)nodeA_cost(c, (u32)c2) << 32) | (next_id + 1), (u32)c2)) return RS_OVERFLOW;
+                next_id += 2;
+                node_free(c, ni);
+            } else { /* :294-327: the node is moved, its id kept: its two haplotypes in place on two waves */
+                u32 a1 = AL_ALT, a2 = AL_ALT;
+                if (het) {
+                    a1 = zyg == AVK_ZYG_PHASED_HET01 ? AL_REF : AL_ALT;
+                    a2 = zyg == AVK_ZYG_PHASED_HET01 ? AL_ALT : AL_REF;
+                }
+                const u32 id = ld32u((const u32 *)pn);
+                wv_sync();
+                if (wv_lane() == 0) {
+                    team_job_hap(c.team, 0, pn + NODE_HDR, pn + NODE_HDR, depth, a1, 0);
+                    team_job_hap(c.team, 1, pn + NODE_HDR + c.hapA_bytes, pn + NODE_HDR + c.hapA_bytes, depth, a2, 0);
+                    if (sym && a1 != a2) ((u32 *)pn)[1] = 0; /* no longer two identical records (nodeA_extend) */
+                }
+                team_run(c, 2);
+                if (wv_uni((u32)c.team->job[0].res[0]) | wv_uni((u32)c.team->job[1].res[0])) return RS_OVERFLOW;
+                if (queue_push(c, ((u64)nodeA_cost(c, ni) << 32) | id, ni)) return RS_OVERFLOW;
+            }
+        } else if (het && (!is_truth || zyg == AVK_ZYG_UNPHASED_HET)) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) */
             const int c1 = node_alloc(c);
             if (c1 < 0) return RS_OVERFLOW;
             node_copy(c, (u32)c1, ni);
@@ -1311,7 +1554,7 @@ struct RegionOut {
 };
 
 /* returns AVK_ST_* (>= 0) or RS_OVERFLOW */
-AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_bytes, u32 ed_cap, Ctx &c, RegionOut &out, u32 &winner_node) {
+template <bool TEAM = false> AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_bytes, u32 ed_cap, Ctx &c, RegionOut &out, u32 &winner_node) {
     AVK_T_DECL
     const AvkDevRegion reg = a.regions[r];
     const u32 lane = (u32)wv_lane();
@@ -1448,9 +1691,10 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     }
     wv_sync();
 
+    if (TEAM && c.team) team_publish(c);
     AVK_T_MARK(c, 0)
     /* ---- phase A */
-    const int nopt = phaseA(c);
+    const int nopt = phaseA<TEAM>(c);
     AVK_T_MARK(c, 1)
     if (nopt == RS_OVERFLOW) return RS_OVERFLOW;
     if (nopt < 0) return -nopt - 100;
@@ -1663,7 +1907,126 @@ AVK_DEV int solve_region_tier(const AvkKernelArgs &a, u32 r, u8 *ws, u64 ws_byte
     AVK_T_MARK(c, 3)
     /* which of the 8 filtered types occur at all: one LDS read by 8 lanes instead of 8 dependent round trips per haplotype */
     const u32 type_mask = (u32)wv_ballot(lane < 8 && c.counts[lane < 8 ? lane : 0] != 0) & 0xFFu;
-    for (int hh = 0; hh < 2; ++hh) {
+    const bool team_metrics = TEAM && c.team && 4ull * c.wfs_cap + c.seqcap + 64 <= c.team_scratch_bytes;
+    if (team_metrics) {
+        /* the same sums, their alignments dealt out over the team: first the (at most four) distances to the reference window, then one job per
+         * (haplotype, call type, side) that needs a filtered sequence — each makes its sequence in its wave's own scratch and aligns it twice */
+        const HapPtr *wps[2] = {&w0, &w1};
+        const HapHdr *hds[2] = {&h0, &h1};
+        bool t_alt[2], q_alt[2];
+        int jt[2] = {-1, -1}, jq[2] = {-1, -1};
+        u32 nj = 0;
+        for (int hh = 0; hh < 2; ++hh) {
+            bool l_t = false, l_q = false;
+            for (u32 i = lane; i < c.alw; i += 64) {
+                l_t = l_t || wps[hh]->talt[i] != 0;
+                l_q = l_q || wps[hh]->qalt[i] != 0;
+            }
+            t_alt[hh] = wv_ballot(l_t) != 0, q_alt[hh] = wv_ballot(l_q) != 0;
+            if (t_alt[hh]) jt[hh] = (int)nj++;
+            if (q_alt[hh] && !(hds[hh]->ed == 0 && t_alt[hh])) jq[hh] = (int)nj++;
+        }
+        wv_sync();
+        if (lane == 0)
+            for (int hh = 0; hh < 2; ++hh) {
+                if (jt[hh] >= 0) {
+                    TeamJob *jb = c.team->job + jt[hh];
+                    jb->kind = TJ_ED, jb->flags = 0, jb->depth = jb->allele = 0, jb->src = (u64)c.ref, jb->x0 = c.L, jb->dst = (u64)wps[hh]->tseq, jb->x1 = hds[hh]->t_len;
+                }
+                if (jq[hh] >= 0) {
+                    TeamJob *jb = c.team->job + jq[hh];
+                    jb->kind = TJ_ED, jb->flags = 0, jb->depth = jb->allele = 0, jb->src = (u64)c.ref, jb->x0 = c.L, jb->dst = (u64)wps[hh]->qseq, jb->x1 = hds[hh]->q_len;
+                }
+            }
+        if (nj) team_run(c, nj);
+        u32 X[2], Y[2], TP[2];
+        for (int hh = 0; hh < 2; ++hh) {
+            int ert = 0, erq = 0;
+            if (jt[hh] >= 0) {
+                ert = (int)wv_uni((u32)c.team->job[jt[hh]].res[0]);
+                if (ert < 0) return RS_OVERFLOW;
+            }
+            if (q_alt[hh]) {
+                if (hds[hh]->ed == 0 && t_alt[hh]) erq = ert;
+                else {
+                    erq = (int)wv_uni((u32)c.team->job[jq[hh]].res[0]);
+                    if (erq < 0) return RS_OVERFLOW;
+                }
+            } else if (hds[hh]->ed == 0) erq = ert;
+            X[hh] = 2u * (u32)ert, Y[hh] = 2u * (u32)erq;
+            TP[hh] = (X[hh] + Y[hh] - 2u * hds[hh]->ed) / 2;
+            u32 add[4] = {TP[hh], X[hh] - TP[hh] + 2 * hds[hh]->t_skip, TP[hh], Y[hh] - TP[hh] + 2 * hds[hh]->q_skip}; /* + skip metrics :378-381 */
+            wv_sync();
+            if (lane < 4) c.gm[AVK_F_BP_TRUTH_TP + lane] += add[lane];
+            wv_sync();
+        }
+        /* the filtered alignments: job index of (hh, s, side) or -1 */
+        int fj[2][8][2];
+        nj = 0;
+        for (int hh = 0; hh < 2; ++hh)
+            for (int s = 0; s < 8; ++s) {
+                fj[hh][s][0] = fj[hh][s][1] = -1;
+                if (!((type_mask >> s) & 1u)) continue;
+                const u32 tq = ld32u(c.counts + s), tcount_s = tq & 0xFFFFu, qcount_s = tq >> 16;
+                if (qcount_s && qcount_s != c.Q) fj[hh][s][1] = (int)nj++;
+                if (tcount_s && tcount_s != c.T) fj[hh][s][0] = (int)nj++;
+            }
+        wv_sync();
+        if (lane == 0)
+            for (int hh = 0; hh < 2; ++hh)
+                for (int s = 0; s < 8; ++s)
+                    for (int side = 0; side < 2; ++side)
+                        if (fj[hh][s][side] >= 0) {
+                            TeamJob *jb = c.team->job + fj[hh][s][side];
+                            jb->kind = TJ_FILT, jb->flags = 0, jb->depth = jb->allele = 0, jb->x0 = (u32)side, jb->x1 = (u32)s, jb->src = (u64)wps[hh]->w, jb->dst = 0;
+                        }
+        if (nj) team_run(c, nj);
+        for (int hh = 0; hh < 2; ++hh)
+            for (u32 left = type_mask; left; left &= left - 1) {
+                const int s = avk_ctz64(left);
+                const u32 tq = ld32u(c.counts + s), tcount_s = tq & 0xFFFFu, qcount_s = tq >> 16;
+                const u32 tp = TP[hh];
+                u32 q_tp = 0, q_fp = 0, t_tp = 0, t_fn = 0;
+                if (qcount_s) {
+                    if (qcount_s == c.Q) {
+                        q_tp = tp;
+                        q_fp = Y[hh] - tp + 2 * hds[hh]->q_skip;
+                    } else {
+                        const TeamJob *jb = c.team->job + fj[hh][s][1];
+                        const int y2 = (int)wv_uni((u32)jb->res[0]), z2 = (int)wv_uni((u32)jb->res[1]);
+                        if (y2 < 0 || z2 < 0) return RS_OVERFLOW;
+                        const u32 Y2 = 2u * (u32)y2, Z2 = 2u * (u32)z2;
+                        const u32 tp2 = (X[hh] + Y2 - Z2) / 2;
+                        q_tp = tp2;
+                        q_fp = Y2 - tp2 + 2 * wv_uni((u32)jb->res[2]);
+                    }
+                }
+                if (tcount_s) {
+                    if (tcount_s == c.T) {
+                        t_tp = tp;
+                        t_fn = X[hh] - tp + 2 * hds[hh]->t_skip;
+                    } else {
+                        const TeamJob *jb = c.team->job + fj[hh][s][0];
+                        const int x2 = (int)wv_uni((u32)jb->res[0]), z2 = (int)wv_uni((u32)jb->res[1]);
+                        if (x2 < 0 || z2 < 0) return RS_OVERFLOW;
+                        const u32 X2 = 2u * (u32)x2, Z2 = 2u * (u32)z2;
+                        const u32 tp2 = (X2 + Y[hh] - Z2) / 2;
+                        t_tp = tp2;
+                        t_fn = X2 - tp2 + 2 * wv_uni((u32)jb->res[2]);
+                    }
+                }
+                wv_sync();
+                if (lane == 0) {
+                    u32 *g = c.gm + (1 + SUP[s]) * AVK_N_FIELDS;
+                    g[AVK_F_BP_TRUTH_TP] += t_tp;
+                    g[AVK_F_BP_TRUTH_FN] += t_fn;
+                    g[AVK_F_BP_QUERY_TP] += q_tp;
+                    g[AVK_F_BP_QUERY_FP] += q_fp;
+                }
+                wv_sync();
+            }
+    }
+    for (int hh = 0; hh < (team_metrics ? 0 : 2); ++hh) {
         const HapPtr &wp = hh == 0 ? w0 : w1;
         const HapHdr &hd = hh == 0 ? h0 : h1;
         /* a haplotype that carries no ALT allele IS the reference window: distance 0 without aligning */
@@ -1858,7 +2221,7 @@ AVK_DEV void wg_acquire(u32 *ctl, u32 w, u32 n_wg_waves) {
  * its slice starts w slices into the workgroup's LDS. */
 /* LAZY: a launch for regions the lanes handed back (device-packed batches write those regions' records on demand, below) — a separate instantiation, so that
  * the launches that solve a genome's bulk keep their register allocation */
-template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice) {
+template <bool PASS_LDS, bool LAZY = false, bool TEAM = false> AVK_DEV void region_worker(const AvkKernelArgs &a, u32 wave_id, u8 *lds_slice, TeamBox *team = (TeamBox *)0) {
     const bool wgt = PASS_LDS && a.esc_bytes != 0; /* this workgroup has a tail: shared tally, and the lock of the escalation */
     const bool esc = wgt && a.esc_enabled != 0;
     const u32 wave_in_wg = wave_id & 3u;
@@ -1958,6 +2321,9 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
             continue;
         }
         Ctx c;
+        c.team = TEAM ? team : (TeamBox *)0;
+        c.team_gen = TEAM && team ? (wv_uni(avk_wg_load(&team->next)) >> 8) : 0u; /* (generations go on from where the region before left them) */
+        c.team_scratch_bytes = TEAM ? ws_bytes : 0;
 #ifdef AVK_PHASE_TIMING
         for (int k = 0; k < 16; ++k) c.tphase[k] = 0;
         const u64 t_region0 = avk_clock();
@@ -1972,7 +2338,7 @@ template <bool PASS_LDS, bool LAZY = false> AVK_DEV void region_worker(const Avk
         u32 cur_cap = ed_cap, cur_tier = tier, slot = 0xFFFFFFFFu;
         int st;
         for (;;) {
-            st = solve_region_tier(a, r, cur_ws, cur_bytes, cur_cap, c, out, winner);
+            st = solve_region_tier<TEAM>(a, r, cur_ws, cur_bytes, cur_cap, c, out, winner);
             if (st != RS_OVERFLOW || slot != 0xFFFFFFFFu) break;
             if (PASS_LDS) {
                 if (!esc) break;

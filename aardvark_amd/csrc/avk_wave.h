@@ -80,6 +80,7 @@ AVK_DEV void wv_sync_(uint32_t site) { (void)avk_emu::gather(0, site); }
 #define wv_ballot(p) wv_ballot_((p), AVK_SITE)
 #define wv_shfl(v, src) wv_shfl_((v), (src), AVK_SITE)
 #define wv_uni(v) wv_uni_((v), AVK_SITE)
+#define wv_uni64(v) (((uint64_t)wv_uni((uint32_t)((uint64_t)(v) >> 32)) << 32) | (uint64_t)wv_uni((uint32_t)(uint64_t)(v)))
 #define wv_max_u32(v) wv_max_u32_((v), AVK_SITE)
 #define wv_min_u32(v) wv_min_u32_((v), AVK_SITE)
 #define wv_sum_u32(v) wv_sum_u32_((v), AVK_SITE)
@@ -135,6 +136,10 @@ AVK_DEV void avk_st_agent_u32(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, 
 AVK_DEV void avk_release_agent() { __atomic_thread_fence(__ATOMIC_RELEASE); }
 AVK_DEV void avk_acquire_agent() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 AVK_DEV void avk_sleep() { avk_emu::yield(); }
+AVK_DEV void avk_sleep_short() { avk_emu::yield(); }
+/* workgroup-scope fences around the LDS words below when they publish data in GLOBAL memory to the other waves of the workgroup (the team of avk_solver.inl) */
+AVK_DEV void avk_release_wg() { __atomic_thread_fence(__ATOMIC_RELEASE); }
+AVK_DEV void avk_acquire_wg() { __atomic_thread_fence(__ATOMIC_ACQUIRE); }
 /* words shared by the waves of one workgroup (LDS on the device) */
 AVK_DEV uint32_t avk_wg_load(const uint32_t *p) { return __atomic_load_n(p, __ATOMIC_ACQUIRE); }
 AVK_DEV void avk_wg_store(uint32_t *p, uint32_t v) { __atomic_store_n(p, v, __ATOMIC_RELEASE); }
@@ -179,6 +184,7 @@ AVK_DEV uint32_t wv_from_below(uint32_t v) { return (uint32_t)__builtin_amdgcn_u
 AVK_DEV uint32_t wv_from_above(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x130, 0xf, 0xf, false); }
 /* a value that is identical on every lane: move it to an SGPR so branches on it are scalar */
 AVK_DEV uint32_t wv_uni(uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+AVK_DEV uint64_t wv_uni64(uint64_t v) { return ((uint64_t)wv_uni((uint32_t)(v >> 32)) << 32) | (uint64_t)wv_uni((uint32_t)v); }
 /* cross-lane reductions on the DPP network (row shifts inside 16 lanes, then row broadcasts):
  * no LDS traffic, a handful of VALU cycles.  `ident` is the neutral element of the operation and
  * fills lanes that have no source.  The result lands in lane 63 and is read back as a scalar. */
@@ -275,6 +281,14 @@ AVK_DEV void avk_release_agent() {
 }
 AVK_DEV void avk_acquire_agent() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); }
 AVK_DEV void avk_sleep() { __builtin_amdgcn_s_sleep(32); }
+AVK_DEV void avk_sleep_short() { __builtin_amdgcn_s_sleep(2); }
+/* workgroup-scope fences around the LDS words below when they publish data in GLOBAL memory to the other waves of the workgroup (the team of avk_solver.inl): the
+ * waves of a workgroup share their CU's vector L1, so completing the stores (release) and ordering the later loads (acquire) is all there is to it */
+AVK_DEV void avk_release_wg() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+}
+AVK_DEV void avk_acquire_wg() { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
 /* words shared by the waves of one workgroup (they live in LDS) */
 AVK_DEV uint32_t avk_wg_load(const uint32_t *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 AVK_DEV void avk_wg_store(uint32_t *p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }

@@ -290,10 +290,16 @@ struct WaveTask {
     uint32_t wave_in_wg = 0, n_wg_waves = 0;
 };
 
+int g_team = 0; /* emu_set_team: the HBM-tier passes run their regions as avk_region_kernel_team's owner wave does — the search posts its independent pieces as jobs
+                   (children made out of place, the metrics' alignments one job each).  The emulator runs one wave at a time, so the owner takes every job itself:
+                   the decomposition is what is checked here, the hand-over between waves on the GPU (tests/test_gpu_team.py). */
 void lane_main(void *p, int /*lane*/) {
     WaveTask *t = (WaveTask *)p;
     if (t->lds) avk::region_worker<true, true>(*t->args, t->wave_id, t->lds); /* (the lazy instantiations: they differ from the others only when lazy_dp is set) */
-    else avk::region_worker<false, true>(*t->args, t->wave_id, nullptr);
+    else if (g_team) {
+        static thread_local avk::TeamBox box; /* (one wave = one thread of the emulator's pool at a time) */
+        avk::region_worker<false, true, true>(*t->args, t->wave_id, nullptr, &box);
+    } else avk::region_worker<false, true>(*t->args, t->wave_id, nullptr);
 }
 
 /* ---- the device-side packer (aardvark_amd/csrc/avk_devpack.inl) run the way upload_device_packed of avk_devpack_host.inl queues it: the same
@@ -1184,6 +1190,7 @@ int emu_merge_batch(const avk_multi_batch *mb, const uint8_t *const *refs, const
 }
 
 void emu_set_lane_kernel(int on) { g_lane_kernel = on; }
+void emu_set_team(int on) { g_team = on; }
 void emu_set_device_pack(int on) { g_device_pack = on; }
 void emu_set_packed_source(int on) { g_dp_packed_source = on, g_last_packed_source = 0; }
 int emu_last_packed_source() { return g_last_packed_source; }
