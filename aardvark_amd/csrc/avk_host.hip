@@ -72,8 +72,8 @@ __global__ void __launch_bounds__(256, 2) avk_region_kernel_team(AvkKernelArgs a
         avk::region_worker<false, false, true>(a, blockIdx.x * 4u, (unsigned char *)0, &box);
         wv_sync();
         if ((threadIdx.x & 63u) == 0) avk_wg_store(&box.quit, 1u);
-    } else {
-        avk::team_helper(&box, a.hbm_ws + (uint64_t)(blockIdx.x * 4u + w) * a.tier[a.pass_tier].ws_bytes, a.tier[a.pass_tier].ws_bytes);
+    } else if (a.team == 1) { /* (2 = the owner alone takes every job: a diagnostic) */
+        avk::team_helper(&box, a.hbm_ws + (uint64_t)(blockIdx.x * 4u + w) * a.tier[a.pass_tier].ws_bytes, a.tier[a.pass_tier].ws_bytes, w, 4u);
     }
 }
 
@@ -831,7 +831,8 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         if (value < 0) return fail(ctx, AVK_E_ARG, "pool_cache_bytes must not be negative");
         ctx->pool_cache_bytes = value;
     } else if (n == "team_long_windows") {
-        ctx->team_long_windows = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(ctx, AVK_E_ARG, "team_long_windows must be 0, 1 or 2 (2: the owner wave takes every job itself, a diagnostic)");
+        ctx->team_long_windows = value;
     } else if (n == "team_head_regions") {
         if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "team_head_regions must be 0..1024");
         ctx->team_head_regions = value;
@@ -1671,9 +1672,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.overflow_list = nullptr;
                         x.overflow_count = nullptr;
                         AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
-                        x.team = ctx->team_long_windows ? 1u : 0u;
-                        if (x.team) hipLaunchKernelGGL(avk_region_kernel_team, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
-                        else hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
+                        /* (a wave per region here: these long windows hold a handful of calls, their searches are short chains where a team's hand-overs cost more
+                         * than its parallel pieces give — shard 1.19 -> 1.31 ms, dense mix 2.29 -> 2.53 with teams, profiles/r06_team.txt) */
+                        hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
                         AVK_HIP(ctx, hipGetLastError());
                         AVK_HIP(ctx, hipEventRecord(ctx->ev_wide, ctx->wide_stream));
                         wide_x = true;
@@ -1712,7 +1713,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         AvkKernelArgs x = s;
                         x.pass_tier = 2;
                         x.only_not_wide = 0;
-                        x.team = 1;
+                        x.team = (uint32_t)ctx->team_long_windows;
                         x.work_list = nullptr;
                         x.n_work_dev = nullptr;
                         x.work_base = 0;

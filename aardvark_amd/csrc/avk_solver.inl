@@ -109,6 +109,9 @@ struct Ctx {
     u32 L, T, Q, N;
     TeamBox *team;          /* the workgroup's team (avk_region_kernel_team) or NULL: this wave alone */
     u32 team_gen;           /* generation of the last batch of jobs posted */
+    u32 team_waves;         /* waves of the team that take jobs (1: the owner alone) */
+    u32 *team_dbg;          /* seven words of device counters the team writes its progress to (tools/gpu_team_probe.py reads them while a launch is in flight) */
+    u32 team_mode;          /* AvkKernelArgs::team */
     u64 team_scratch_bytes; /* bytes of scratch every sibling has for the alignments of the metrics (its own workspace slice) */
     u8 *ws;        /* base of this wave's workspace */
     const u8 *ref; /* window bytes (workspace copy) */
@@ -839,8 +842,10 @@ AVK_DEV void team_publish(Ctx &c) { /* owner, after the workspace is carved */
     }
     wv_sync();
 }
-/* job j of the box, run by one wave with its own scratch (hc.wfs, hc.seq_a) on the owner's data */
-AVK_DEV void team_exec(const Ctx &hc, TeamBox *b, u32 j) {
+/* job j of the box, run by one wave with its own scratch (hc.wfs, hc.seq_a) on the owner's data.  A CALL, not inlined: inlined into the loops of team_run / team_helper
+ * the structurizer folded the job's loops and the `lane == 0` branches behind it into one divergent loop that sent lanes 1..63 round the job again (a step that never
+ * ended: tools/gpu_team_hang.py showed the wave stuck right behind its first job). */
+AVK_DEV_NOINLINE void team_exec(const Ctx &hc, TeamBox *b, u32 j) {
     TeamJob *jb = b->job + j;
     const u32 kind = wv_uni(jb->kind);
     int r0 = 0, r1 = 0, r2 = 0;
@@ -905,16 +910,21 @@ AVK_DEV void team_run(Ctx &c, u32 n) {
         avk_wg_store(&b->n_jobs, (gen << 8) | n);
         avk_wg_store(&b->done, 0u);
         avk_wg_store(&b->next, gen << 8);
+        if (c.team_dbg) avk_st_agent_u32(c.team_dbg + 0, gen), avk_st_agent_u32(c.team_dbg + 1, 10u), avk_st_agent_u32(c.team_dbg + 2, n);
     }
-    for (;;) {
-        u32 v = 0;
-        if (lane == 0) v = avk_wg_add(&b->next, 1u);
-        v = wv_uni(wv_shfl(v, 0));
-        const u32 j = v & 0xFFu;
-        if (j >= n) break;
+    /* the jobs are dealt: job j is wave j mod 4's (every sibling is idle when a generation opens: the owner waited for the one before); with the siblings away
+     * (diagnostic mode 2, the emulator) all of them are the owner's */
+    const u32 stride = c.team_waves ? c.team_waves : 1u;
+    u32 mine = 0;
+    for (u32 j = 0; j < n; j += stride) {
+        if (lane == 0 && c.team_dbg) avk_st_agent_u32(c.team_dbg + 1, 20u + j), avk_st_agent_u32(c.team_dbg + 4, b->job[j].kind);
         team_exec(c, b, j);
-        avk_release_wg();
-        if (lane == 0) (void)avk_wg_add(&b->done, 1u);
+        mine += 1;
+    }
+    avk_release_wg();
+    if (lane == 0) {
+        (void)avk_wg_add(&b->done, mine);
+        if (c.team_dbg) avk_st_agent_u32(c.team_dbg + 1, 30u);
     }
     for (;;) {
         u32 d = 0;
@@ -925,13 +935,14 @@ AVK_DEV void team_run(Ctx &c, u32 n) {
     }
     avk_acquire_wg();
     wv_sync();
+    if (lane == 0 && c.team_dbg) avk_st_agent_u32(c.team_dbg + 1, 40u);
 }
 /* a sibling wave of the team: until the owner says quit.  `scratch` = this wave's own workspace slice. */
-AVK_DEV void team_helper(TeamBox *b, u8 *scratch, u64 scratch_bytes) {
+AVK_DEV void team_helper(TeamBox *b, u8 *scratch, u64 scratch_bytes, u32 wave_in_team, u32 team_waves) {
     const u32 lane = (u32)wv_lane();
     u32 my_gen = 0, my_ver = 0;
     Ctx hc;
-    hc.team = (TeamBox *)0, hc.team_gen = 0, hc.team_scratch_bytes = 0;
+    hc.team = (TeamBox *)0, hc.team_gen = 0, hc.team_scratch_bytes = 0, hc.team_mode = 0, hc.team_dbg = (u32 *)0, hc.team_waves = 0;
     hc.L = hc.T = hc.Q = hc.N = hc.seqcap = hc.wfcap = hc.alw = hc.hapA_bytes = hc.wfs_cap = 0;
     hc.ws = (u8 *)0, hc.ref = (const u8 *)0, hc.vars = (LVar *)0, hc.alle = (u8 *)0, hc.ovars = (const AvkOrdVar *)0, hc.wfs = (u32 *)0, hc.seq_a = (u8 *)0;
     for (;;) {
@@ -942,34 +953,30 @@ AVK_DEV void team_helper(TeamBox *b, u8 *scratch, u64 scratch_bytes) {
             if ((v >> 8) != my_gen || q) break;
             avk_sleep_short();
         }
-        if ((v >> 8) == my_gen && q) return;
-        for (;;) {
-            u32 w = 0, nj = 0;
-            if (lane == 0) {
-                w = avk_wg_add(&b->next, 1u);
-                nj = avk_wg_load(&b->n_jobs); /* read AFTER the claim: the count of the generation the claim belongs to, or of a later one */
-            }
-            w = wv_uni(wv_shfl(w, 0)), nj = wv_uni(wv_shfl(nj, 0));
-            my_gen = w >> 8;
-            if ((nj >> 8) != my_gen || (w & 0xFFu) >= (nj & 0xFFu)) break; /* (a claim made while the owner was opening the next generation is nobody's job) */
-            avk_acquire_wg();
-            u32 ver = 0;
-            if (lane == 0) ver = avk_wg_load(&b->ver);
-            ver = wv_uni(wv_shfl(ver, 0));
-            if (ver != my_ver) { /* another region (or another attempt at it): the owner's pointers and sizes, this wave's scratch */
-                my_ver = ver;
-                hc.ws = (u8 *)wv_uni64(b->ws), hc.ref = (const u8 *)wv_uni64(b->ref), hc.vars = (LVar *)wv_uni64(b->vars), hc.alle = (u8 *)wv_uni64(b->alle);
-                hc.ovars = (const AvkOrdVar *)wv_uni64(b->ovars);
-                hc.L = wv_uni(b->L), hc.T = wv_uni(b->T), hc.Q = wv_uni(b->Q), hc.N = wv_uni(b->N), hc.seqcap = wv_uni(b->seqcap), hc.wfcap = wv_uni(b->wfcap), hc.alw = wv_uni(b->alw);
-                hc.hapA_bytes = wv_uni(b->hapA_bytes), hc.wfs_cap = wv_uni(b->wfs_cap);
-                hc.wfs = (u32 *)scratch;
-                hc.seq_a = scratch + 4ull * hc.wfs_cap;
-                (void)scratch_bytes; /* (the owner posts metrics jobs only when 4 wfs_cap + seqcap fits: Ctx::team_scratch_bytes) */
-            }
-            team_exec(hc, b, w & 0xFFu);
-            avk_release_wg();
-            if (lane == 0) (void)avk_wg_add(&b->done, 1u);
+        if ((v >> 8) == my_gen) return; /* quit, and no generation this wave has not served */
+        my_gen = v >> 8;
+        u32 nj = 0, ver = 0;
+        if (lane == 0) nj = avk_wg_load(&b->n_jobs), ver = avk_wg_load(&b->ver);
+        nj = wv_uni(wv_shfl(nj, 0)), ver = wv_uni(wv_shfl(ver, 0));
+        const u32 n = (nj >> 8) == my_gen ? (nj & 0xFFu) : 0u; /* (the count is stored before the generation opens) */
+        avk_acquire_wg();
+        if (ver != my_ver) { /* another region (or another attempt at it): the owner's pointers and sizes, this wave's scratch */
+            my_ver = ver;
+            hc.ws = (u8 *)wv_uni64(b->ws), hc.ref = (const u8 *)wv_uni64(b->ref), hc.vars = (LVar *)wv_uni64(b->vars), hc.alle = (u8 *)wv_uni64(b->alle);
+            hc.ovars = (const AvkOrdVar *)wv_uni64(b->ovars);
+            hc.L = wv_uni(b->L), hc.T = wv_uni(b->T), hc.Q = wv_uni(b->Q), hc.N = wv_uni(b->N), hc.seqcap = wv_uni(b->seqcap), hc.wfcap = wv_uni(b->wfcap), hc.alw = wv_uni(b->alw);
+            hc.hapA_bytes = wv_uni(b->hapA_bytes), hc.wfs_cap = wv_uni(b->wfs_cap);
+            hc.wfs = (u32 *)scratch;
+            hc.seq_a = scratch + 4ull * hc.wfs_cap;
+            (void)scratch_bytes; /* (the owner posts metrics jobs only when 4 wfs_cap + seqcap fits: Ctx::team_scratch_bytes) */
         }
+        u32 mine = 0;
+        for (u32 j = wave_in_team; j < n; j += team_waves) {
+            team_exec(hc, b, j);
+            mine += 1;
+        }
+        avk_release_wg();
+        if (lane == 0 && mine) (void)avk_wg_add(&b->done, mine);
     }
 }
 AVK_DEV void team_job_hap(TeamBox *b, u32 j, const u8 *src, u8 *dst, u32 depth, u32 allele, u32 flags) { /* lane 0 of the owner */
@@ -1153,26 +1160,38 @@ template <bool TEAM = false> AVK_DEV int phaseA(Ctx &c) {
             if (two) { /* :269-293: two clones, (REF|ALT) then (ALT|REF) — both made out of place from the popped node, four records on four waves */
                 const int c1 = node_alloc(c);
                 if (c1 < 0) return RS_OVERFLOW;
-                const int c2 = node_alloc(c);
-                if (c2 < 0) return RS_OVERFLOW;
-                u8 *n1 = node_at(c, (u32)c1), *n2 = node_at(c, (u32)c2);
+                const int c2 = node_alloc(c); /* (a full pool: the popped node becomes the second clone in place, behind the first one's jobs — what the one-wave search does) */
+                u8 *n1 = node_at(c, (u32)c1), *n2 = c2 >= 0 ? node_at(c, (u32)c2) : pn;
                 wv_sync();
                 if (wv_lane() == 0) {
                     ((u32 *)n1)[0] = next_id, ((u32 *)n1)[1] = 0, ((u32 *)n1)[2] = ((const u32 *)pn)[2], ((u32 *)n1)[3] = ((const u32 *)pn)[3];
-                    ((u32 *)n2)[0] = next_id + 1, ((u32 *)n2)[1] = 0, ((u32 *)n2)[2] = ((const u32 *)pn)[2], ((u32 *)n2)[3] = ((const u32 *)pn)[3];
+                    if (c2 >= 0) ((u32 *)n2)[0] = next_id + 1, ((u32 *)n2)[1] = 0, ((u32 *)n2)[2] = ((const u32 *)pn)[2], ((u32 *)n2)[3] = ((const u32 *)pn)[3];
                     team_job_hap(c.team, 0, pn + NODE_HDR, n1 + NODE_HDR, depth, AL_REF, 0);
                     team_job_hap(c.team, 1, pn + NODE_HDR + c.hapA_bytes, n1 + NODE_HDR + c.hapA_bytes, depth, AL_ALT, 0);
-                    team_job_hap(c.team, 2, pn + NODE_HDR, n2 + NODE_HDR, depth, AL_ALT, 0);
-                    team_job_hap(c.team, 3, pn + NODE_HDR + c.hapA_bytes, n2 + NODE_HDR + c.hapA_bytes, depth, AL_REF, 0);
+                    if (c2 >= 0) {
+                        team_job_hap(c.team, 2, pn + NODE_HDR, n2 + NODE_HDR, depth, AL_ALT, 0);
+                        team_job_hap(c.team, 3, pn + NODE_HDR + c.hapA_bytes, n2 + NODE_HDR + c.hapA_bytes, depth, AL_REF, 0);
+                    }
                 }
-                team_run(c, 4);
+                team_run(c, c2 >= 0 ? 4u : 2u);
                 u32 bad = 0;
-                for (int j = 0; j < 4; ++j) bad |= wv_uni((u32)c.team->job[j].res[0]);
+                for (int j = 0; j < (c2 >= 0 ? 4 : 2); ++j) bad |= wv_uni((u32)c.team->job[j].res[0]);
+                if (c2 < 0) {
+                    wv_sync();
+                    if (wv_lane() == 0) {
+                        ((u32 *)pn)[0] = next_id + 1, ((u32 *)pn)[1] = 0;
+                        team_job_hap(c.team, 0, pn + NODE_HDR, pn + NODE_HDR, depth, AL_ALT, 0);
+                        team_job_hap(c.team, 1, pn + NODE_HDR + c.hapA_bytes, pn + NODE_HDR + c.hapA_bytes, depth, AL_REF, 0);
+                    }
+                    team_run(c, 2);
+                    bad |= wv_uni((u32)c.team->job[0].res[0]) | wv_uni((u32)c.team->job[1].res[0]);
+                }
                 if (bad) return RS_OVERFLOW;
+                const u32 second = c2 >= 0 ? (u32)c2 : ni;
                 if (queue_push(c, ((u64)nodeA_cost(c, (u32)c1) << 32) | next_id, (u32)c1)) return RS_OVERFLOW;
-                if (queue_push(c, ((u64)nodeA_cost(c, (u32)c2) << 32) | (next_id + 1), (u32)c2)) return RS_OVERFLOW;
+                if (queue_push(c, ((u64)nodeA_cost(c, second) << 32) | (next_id + 1), second)) return RS_OVERFLOW;
                 next_id += 2;
-                node_free(c, ni);
+                if (c2 >= 0) node_free(c, ni);
             } else { /* :294-327: the node is moved, its id kept: its two haplotypes in place on two waves */
                 u32 a1 = AL_ALT, a2 = AL_ALT;
                 if (het) {
@@ -2324,6 +2343,9 @@ template <bool PASS_LDS, bool LAZY = false, bool TEAM = false> AVK_DEV void regi
         c.team = TEAM ? team : (TeamBox *)0;
         c.team_gen = TEAM && team ? (wv_uni(avk_wg_load(&team->next)) >> 8) : 0u; /* (generations go on from where the region before left them) */
         c.team_scratch_bytes = TEAM ? ws_bytes : 0;
+        c.team_mode = a.team;
+        c.team_waves = TEAM && team && a.team == 1 ? 4u : 1u;
+        c.team_dbg = a.work_counter ? a.work_counter + 17 : (u32 *)0; /* (the team launch's claim counter is word 1256 of the batch's counters: these are 1273..1279) */
 #ifdef AVK_PHASE_TIMING
         for (int k = 0; k < 16; ++k) c.tphase[k] = 0;
         const u64 t_region0 = avk_clock();
