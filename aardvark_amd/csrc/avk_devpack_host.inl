@@ -1326,16 +1326,8 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         segs.push_back({out->var_packed ? out->var_packed + db->v_lo : nullptr, o.var_packed, out->var_packed ? nvr : 0});
     }
     if (out->group_metrics && ctx->emit_group_metrics && db->d_gm) segs.push_back({out->group_metrics, db->d_gm, n * AVK_N_GROUPS * AVK_N_FIELDS * sizeof(uint32_t)});
-    if (want_bp_packed && bp_shared) segs.push_back({out->bp_packed, o.bp_packed, n * sizeof(uint32_t)}); /* (the spilled groups and their count: the split call's, once) */
-    else if (want_bp_packed) { /* how many groups were spilled decides how much is copied: one word back first */
-        uint32_t spilled = 0;
-        hipError_t eb = hipMemcpyAsync(&spilled, o.bp_spill_count, 4, hipMemcpyDeviceToHost, s);
-        if (eb == hipSuccess) eb = hipStreamSynchronize(s);
-        if (eb != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(eb)));
-        out->bp_spilled[0] = spilled;
-        segs.push_back({out->bp_packed, o.bp_packed, n * sizeof(uint32_t)});
-        segs.push_back({out->bp_groups, o.bp_spill, (size_t)spilled * 4 * sizeof(uint32_t)});
-    } else if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {
+    if (want_bp_packed) segs.push_back({out->bp_packed, o.bp_packed, n * sizeof(uint32_t)}); /* (the spilled groups and their count: below, behind the other copies — or the split call's, once) */
+    else if (out->bp_off && out->bp_groups && db->d_bp && db->d_bp_off && db->last_mode == 0) {
         segs.push_back({out->bp_off, db->d_bp_off, (n + 1) * sizeof(uint32_t)});
         segs.push_back({out->bp_groups, db->d_bp, (size_t)db->n_bp_groups * 4 * sizeof(uint32_t)});
     }
@@ -1359,6 +1351,22 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
     if (rc) return done(rc);
     e = hipMemcpyAsync(ctx->h_dpstate, db->d_tally, (size_t)AVK_TALLY_STRIDE * 8, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "tally download failed: %s", hipGetErrorString(e)));
+    if (want_bp_packed) {
+        /* how many groups were spilled decides how much of the list is copied.  The count rides behind the copies above (they start right behind dp_unpack, without
+         * a word from the host), the list — a tenth of the results — behind the count: round 5 read the count first and every copy waited for that round trip */
+        uint32_t *h_count = (uint32_t *)((uint8_t *)ctx->h_dpstate + sizeof(dpk::DpState));
+        e = hipMemcpyAsync(h_count, o.bp_spill_count, 4, hipMemcpyDeviceToHost, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+        if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(e)));
+        const uint32_t spilled = *h_count;
+        out->bp_spilled[0] = spilled;
+        if (spilled) { /* (pinned: queued, finish_copy_out waits for it; pageable: a blocking copy — the bounce buffer holds the parts queued above) */
+            const size_t tail_bytes = (size_t)spilled * 4 * sizeof(uint32_t);
+            e = is_pinned(out->bp_groups, tail_bytes) ? hipMemcpyAsync(out->bp_groups, o.bp_spill, tail_bytes, hipMemcpyDeviceToHost, s)
+                                                      : hipMemcpy(out->bp_groups, o.bp_spill, tail_bytes, hipMemcpyDeviceToHost);
+            if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(e)));
+        }
+    }
     if (getenv("AVK_TIMING")) { /* the last mark of the call's device timeline: behind the copies out */
         if (!ctx->ev_tl[4] && hipEventCreate(&ctx->ev_tl[4]) != hipSuccess) ctx->ev_tl[4] = nullptr, (void)hipGetLastError();
         if (ctx->ev_tl[4]) (void)hipEventRecord(ctx->ev_tl[4], s);

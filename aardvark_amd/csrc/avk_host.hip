@@ -371,7 +371,7 @@ struct avk_ctx {
     int64_t team_long_windows = 1;         /* 1: the launch of the long windows runs a workgroup per region (avk_region_kernel_team); 0: a wave per region (round 5) */
     int64_t team_head_regions = 48;        /* a batch of large windows (no region of class C is the wide kernel's): this many regions at the head of the class go to a team launch */
     int64_t split_parts = 1;               /* > 1: a large avk_compare_packed call runs as this many batches in flight (compare_packed_split; measured slower than the whole call while a half genome's step costs 2.0 of the whole's 2.4 ms: profiles/r06_split_call.txt) ... */
-    int64_t split_min_regions = 1 << 20;   /* ... when it has at least this many regions and every array of the caller's is pinned */
+                                           /* ... when every part has at least 4096 regions and every array of the caller's is pinned */
     int64_t packed_source = 1;  /* 1: a batch in the packed form is packed from the packed arrays themselves (no wide copy of the caller's arrays in HBM); 0: round 5's widening pass */
     int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
     int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
@@ -764,23 +764,12 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->accumulate_tally = value ? 1 : 0;
     } else if (n == "lds_escalation") {
         ctx->lds_escalation = value ? 1 : 0;
-    } else if (n == "lds2_overflow_pass") {
-        ctx->lds2_overflow_pass = value ? 1 : 0;
-    } else if (n == "bulk_full_grid") {
-        ctx->bulk_full_grid = value ? 1 : 0;
-    } else if (n == "bulk_fit") {
-        ctx->bulk_fit = value ? 1 : 0;
-    } else if (n == "solo_regions_per_wave") {
-        if (value < 1 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_regions_per_wave must be in [1, 1024]");
-        ctx->solo_regions_per_wave = value;
     } else if (n == "class_c_below") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "class_c_below must not be negative");
         ctx->class_c_below = value;
     } else if (n == "class_c_nodes_x2") {
         if (value < 1 || value > 1000) return fail(ctx, AVK_E_ARG, "class_c_nodes_x2 must be in [1, 1000]");
         ctx->class_c_nodes_x2 = value;
-    } else if (n == "timing_events") {
-        ctx->timing_events = value ? 1 : 0;
     } else if (n == "static_pct") {
         if (value < 0 || value > 100) return fail(ctx, AVK_E_ARG, "static_pct must be in [0, 100]");
         ctx->static_pct = value;
@@ -792,20 +781,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "wide_lds_bytes") {
         if (value < 8 * 1024 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_lds_bytes must be in [8192, 65536]");
         ctx->wide_lds_bytes = value & ~15ll;
-    } else if (n == "wide_blocks") {
-        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_blocks must be in [1, 4096]");
-        ctx->wide_blocks = value;
     } else if (n == "wide_retry_lds_bytes") {
         if (value < 0 || value > 64 * 1024) return fail(ctx, AVK_E_ARG, "wide_retry_lds_bytes must be in [0, 65536]");
         ctx->wide_retry_lds_bytes = value & ~15ll;
-    } else if (n == "wide_lane_handbacks") {
-        ctx->wide_lane_handbacks = value ? 1 : 0;
-    } else if (n == "wide_lazy_blocks") {
-        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "wide_lazy_blocks must be in [1, 4096]");
-        ctx->wide_lazy_blocks = value;
-    } else if (n == "solo_blocks_max") {
-        if (value < 0 || value > 1024) return fail(ctx, AVK_E_ARG, "solo_blocks_max must be in [0, 1024]");
-        ctx->solo_blocks_max = value;
     } else if (n == "waves_per_cu") {
         if (value < 1 || value > 32) return fail(ctx, AVK_E_ARG, "waves_per_cu must be in [1, 32]");
         ctx->waves_per_cu = value;
@@ -815,9 +793,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "big_ws_bytes") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "big_ws_bytes must be >= 0");
         ctx->big_ws_bytes = (value + 255) & ~255ll;
-    } else if (n == "big_waves") {
-        if (value < 1 || value > 4096) return fail(ctx, AVK_E_ARG, "big_waves must be in [1, 4096]");
-        ctx->big_waves = value;
     } else if (n == "use_packed_reference") {
         ctx->use_packed_reference = value ? 1 : 0;
     } else if (n == "adaptive_ws") {
@@ -827,9 +802,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
         ctx->ws_budget_bytes = value;
     } else if (n == "device_pack") {
         ctx->device_pack = value ? 1 : 0;
-    } else if (n == "pool_cache_bytes") {
-        if (value < 0) return fail(ctx, AVK_E_ARG, "pool_cache_bytes must not be negative");
-        ctx->pool_cache_bytes = value;
     } else if (n == "team_long_windows") {
         if (value < 0 || value > 2) return fail(ctx, AVK_E_ARG, "team_long_windows must be 0, 1 or 2 (2: the owner wave takes every job itself, a diagnostic)");
         ctx->team_long_windows = value;
@@ -839,9 +811,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "split_parts") {
         if (value < 1 || value > 4) return fail(ctx, AVK_E_ARG, "split_parts must be 1..4");
         ctx->split_parts = value;
-    } else if (n == "split_min_regions") {
-        if (value < 0) return fail(ctx, AVK_E_ARG, "split_min_regions must be >= 0");
-        ctx->split_min_regions = value;
     } else if (n == "packed_source") {
         ctx->packed_source = value ? 1 : 0;
     } else if (n == "emit_bp_groups") {
@@ -858,65 +827,25 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "lane_width_one" || n == "lane_width_two" || n == "lane_width_three") {
         if (value != 64 && value != 32 && value != 16 && value != 8 && value != 4 && value != 2 && value != 1) return fail(ctx, AVK_E_ARG, "%s must be 64, 32, 16, 8, 4, 2 or 1", name);
         (n == "lane_width_one" ? ctx->lane_width_one : (n == "lane_width_two" ? ctx->lane_width_two : ctx->lane_width_three)) = value;
-    } else if (n == "lane_max_calls") {
-        if (value < 1 || value > AVK_FAST_MAXV) return fail(ctx, AVK_E_ARG, "lane_max_calls must be 1..%d", AVK_FAST_MAXV);
-        ctx->lane_max_calls = value;
-    } else if (n == "lane_max_est") {
-        if (value < 0 || value > 15) return fail(ctx, AVK_E_ARG, "lane_max_est must be 0..15");
-        ctx->lane_max_est = value;
-    } else if (n == "pair_classes") {
-        ctx->pair_classes = value ? 1 : 0;
-    } else if (n == "lane_head_auto") {
-        ctx->lane_head_auto = value ? 1 : 0;
     } else if (n == "lane_head_width") {
         if (value != 0 && value != 64 && value != 32 && value != 16 && value != 8 && value != 4) return fail(ctx, AVK_E_ARG, "lane_head_width must be 0, 64, 32, 16, 8 or 4");
         ctx->lane_head_width = value;
-    } else if (n == "lane_metrics_ed_cap") {
-        if (value < 0 || value > 250) return fail(ctx, AVK_E_ARG, "lane_metrics_ed_cap must be 0..250");
-        ctx->lane_metrics_ed_cap = value;
     } else if (n == "hbm_ed_cap") {
         if (value < 0 || value > 1000000) return fail(ctx, AVK_E_ARG, "hbm_ed_cap must be 0..1000000");
         ctx->hbm_ed_cap = value;
     } else if (n == "het_search_min") {
         if (value < 0 || value > 255) return fail(ctx, AVK_E_ARG, "het_search_min must be 0..255");
         ctx->het_search_min = value;
-    } else if (n == "lane_head_est") {
-        if (value < 1 || value > 15) return fail(ctx, AVK_E_ARG, "lane_head_est must be 1..15");
-        ctx->lane_head_est = value;
     } else if (n == "lane_pairs") {
         ctx->lane_pairs = value ? 1 : 0;
-    } else if (n == "pair_blocks_per_cu") {
-        if (value < 1 || value > 8) return fail(ctx, AVK_E_ARG, "pair_blocks_per_cu must be 1..8");
-        ctx->pair_blocks_per_cu = value;
-    } else if (n == "lane_stripe") {
-        ctx->lane_stripe = value ? 1 : 0;
-    } else if (n == "lane_head_stream") {
-        ctx->lane_head_stream = value ? 1 : 0;
     } else if (n == "lane_min_batch") {
         if (value < 0) return fail(ctx, AVK_E_ARG, "lane_min_batch must not be negative");
         ctx->lane_min_batch = value;
-    } else if (n == "hbm_early_blocks") {
-        if (value < 1 || value > 768) return fail(ctx, AVK_E_ARG, "hbm_early_blocks must be 1..768");
-        ctx->hbm_early_blocks = value;
-    } else if (n == "hbm_solo_blocks") {
-        if (value < 1 || value > 768) return fail(ctx, AVK_E_ARG, "hbm_solo_blocks must be 1..768");
-        ctx->hbm_solo_blocks = value;
     } else if (n == "lane_node_cap") {
         if (value < 8 || value > 250) return fail(ctx, AVK_E_ARG, "lane_node_cap must be 8..250");
         ctx->lane_node_cap = value;
-    } else if (n == "async_pack_stream") {
-        ctx->async_pack_stream = value ? 1 : 0;
     } else if (n == "lane_quad") {
         ctx->lane_quad = value ? 1 : 0;
-    } else if (n == "lane_pool") {
-        if (value < -1 || value > 8) return fail(ctx, AVK_E_ARG, "lane_pool must be -1..8");
-        ctx->lane_pool = value;
-    } else if (n == "lane_waves_three") {
-        if (value < 0 || value > 32) return fail(ctx, AVK_E_ARG, "lane_waves_three must be 0..32");
-        ctx->lane_waves_three = value;
-    } else if (n == "lane_waves_per_cu") {
-        if (value < 1 || value > 32) return fail(ctx, AVK_E_ARG, "lane_waves_per_cu must be 1..32");
-        ctx->lane_waves_per_cu = value;
     } else
         return fail(ctx, AVK_E_ARG, "unknown option '%s'", name);
     return 0;
@@ -2898,7 +2827,7 @@ static int compare_packed_split(avk_ctx *ctx, const avk_packed_batch *batch, con
     const uint64_t n = batch->n_regions, nv = batch->n_variants;
     int64_t parts = ctx->split_parts;
     if (parts > 4) parts = 4;
-    if (parts < 2 || !ctx->async_pack_stream || n < (uint64_t)ctx->split_min_regions || n / (uint64_t)parts < 4096) return -1;
+    if (parts < 2 || !ctx->async_pack_stream || n / (uint64_t)parts < 4096) return -1;
     if (cfg->enable_sequences && out->seq_bytes) return -1;
     if (out->bp_off || (out->bp_packed && !(out->bp_spilled && out->bp_groups)) || out->group_metrics) return -1;
     for (int i = 0; i < 4; ++i)

@@ -289,67 +289,37 @@ const char *avk_last_error(const avk_ctx *ctx);
  * (its buffer pool hands memory out in the order of one stream); when that one was the caller's too it should still be alive — if it has been destroyed the
  * call waits for the whole device instead and still switches. */
 int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
-/* knobs (set them before avk_batch_upload: the work plan of a batch is made at upload):
- *   workspace tiers  "lds_bytes_per_wave", "lds_ed_cap" (small LDS slice), "lds2_bytes_per_wave", "lds2_ed_cap" (large LDS
- *                    slice), "ws_bytes_per_wave" (HBM slice), "big_ws_bytes", "big_waves" (big HBM slices), "waves_per_cu";
- *                    0 bytes disables a tier
- *   scheduling       "solo_min_variants" (regions with at least this many variants go to the solo launch, 0 = no solo
- *                    launches), "solo_blocks_max", "solo_regions_per_wave", "class_c_nodes_x2" (HBM solo launch threshold),
- *                    "class_c_below" (16384: a batch with lane launches and at most this many regions outside them plans those regions for the
- *                    wave-cooperative kernel, avk_wide.inl, instead of the bulk launch — a contig or a rank's shard: profiles/r05_small_batches.txt; 0 = never),
- *                    "lds_escalation" (in-workgroup escalation of the bulk launch), "lds2_overflow_pass", "bulk_full_grid",
- *                    "static_pct" (share of a launch's work list dealt statically, default 75), "claim" (regions per dynamic claim, 2),
- *                    "timing_events" (0 = no event records for
- *                    avk_last_kernel_ms / avk_last_solver_ms: three records per call, 10 us of a 360 us call)
- *   lane kernel      "lane_kernel" (1, default: regions with at most three calls per side, a short window and a small edit-distance
- *                    bound are solved one per LANE by avk_lane_kernel; 0: every region by the wave-per-region kernels; results
- *                    are identical either way), "lane_min_regions" (2048: a class of the lane kernel gets a launch of its own only
- *                    when the batch holds that many of its regions — x16 for the two-call classes, x2 for the three-call class —,
- *                    smaller classes stay with the wave-per-region kernels; 0 = always), "lane_min_batch" (16384: a resident batch with fewer
- *                    lane regions in all is solved by the wave-per-region kernels alone; it was 65536 until the end of round 4, when a chr20-sized
- *                    step — 48 k regions — was 0.37 ms that way and 0.41 with lane launches: it is 0.26 ms with them now; the one-shot path of
- *                    avk_compare_batch, whose packing is the cheaper one, keeps its lanes at any size),
- *                    "lane_max_calls" (3: classes with more
- *                    calls per side than this stay with the wave-per-region kernels), "lane_node_cap" (32: search nodes the
- *                    three-call class makes before it hands a region to a wave-per-region launch that runs right behind it),
- *                    "lane_width_one" / "lane_width_two" / "lane_width_three" (64, 64, 16: records a wave takes at a time in the
- *                    one- / two- / three-call classes; fewer = smaller LDS slice per wave and less waiting for the slowest record),
- *                    "hbm_early_blocks" (256: workgroups of that launch), "hbm_solo_blocks" (128: most workgroups of the HBM solo launch),
- *                    "lane_waves_per_cu" (12: cap on the one-wave workgroups of a lane launch per CU), "lane_head_width" (16: the
- *                    records of a class are sorted by a host-side cost estimate, avk_pack.h fast_cost_key; the tiles of regions with
- *                    estimated edits — the head of the class — get a launch of their own with this many records per wave, because
- *                    lanes that diverge take turns; 0 = no head launch), "lane_max_est" (15: regions whose estimated edits exceed
- *                    this stay with the wave-per-region kernels), "lane_head_auto" (1: a head of fewer than 24,576 / 8,192 regions takes 8 / 4
- *                    records per wave instead of lane_head_width), "lane_quad" (1, default: lane launches of at most 16 records per wave — the heads of the classes and the three-call class, where the
- *                    expensive searches are — run FOUR lanes on every region, avk_quad_kernel, csrc/avk_quad.inl: (child, haplotype) in the phasing search,
- *                    a genotype search per haplotype, (side, haplotype) in the metrics; 0: one lane of sixteen per region; results are identical either way),
- *                    "lane_pool" (-1: by class — 2 / 4 / 6 kept node states per lane in the head
- *                    launches and the three-call class, none in the 64-wide launches; 0 = every pop of a search replays its node's path; 1..8 =
- *                    that many everywhere)
- *   wide kernel      "wide_kernel" (1, default: large phasing searches on small windows — the class C regions of a batch with lane launches,
- *                    and what the lanes hand back — are solved one per WAVE by avk_wide_kernel, csrc/avk_wide.inl; 0: by the wave-per-region
- *                    kernels; results are identical either way), "wide_lds_bytes" (16384 per wave), "wide_retry_lds_bytes" (65536: a second
- *                    launch with this much LDS for what the first could not hold; 0 = none), "wide_blocks" / "wide_lazy_blocks" (512: one-wave
- *                    workgroups of the class C launch / of the launches for hand-backs), "wide_lane_handbacks" (1: the lanes' hand-backs go
- *                    through it first), "bulk_fit" (1: the bulk launch has no more workgroups than its list has regions for), "pair_classes" (1: pair batches — merge — plan their large searches
- *                    as classes C and B like compare batches, so that the wide kernel and the solo launches take them at the start of a step)
- *                    The launches of one call run on eight HIP streams side by side; the HIP runtime gives a process 4 hardware queues
- *                    by default and streams that share one take turns.  avk_ctx_create sets GPU_MAX_HW_QUEUES=24 unless the
- *                    environment already has it — effective when it is the process's first HIP call; a host that initialises HIP
- *                    earlier should export the variable itself (whole-genome step: 7.0 ms with 4 queues, 5.0 with 8 in round 2; with a
- *                    communicator library in the process 6.0 ms with 8 queues, 3.8 with 16 or 24 in round 3).
- *   boundary         "async_pack_stream" (1, default: a batch submitted with avk_compare_packed_submit is packed on a stream of its own, beside the solver
- *                    launches of the batch before, and the plan's round trip does not wait for them; 0: on the context's stream)
- *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13x22 block; the batch tally is always produced),
- *                    "emit_bp_groups" (1 = kernels write the compact per-region BASEPAIR groups, avk_result_batch::bp_groups; avk_compare_batch /
- *                    avk_compare_compact switch it on by themselves when the caller hands the two arrays in),
- *                    "accumulate_tally" (1 = avk_compare_resident ADDS the batch tally to tally_dev: a job's running total
- *                    over its batches, reduced over the ranks once at the end), "use_packed_reference"
- *   packing          "device_pack" (1, default: a batch is validated, classified, ordered and written in the kernels' layout ON THE DEVICE, from
- *                    the caller's arrays copied to HBM as they are — csrc/avk_devpack.inl; 0: by the host threads, csrc/avk_pack.h; same
- *                    records either way, tests/test_devpack.py), "pool_cache_bytes" (12 GiB: released device buffers the context keeps for
- *                    the next batch)
- * None of them changes a result (tests/test_emu_parity.py, tests/test_gpu_parity.py). */
+/* Context options, forty of them (set them before avk_batch_upload: the work plan of a batch is made at upload).  None of them changes a result: the parity tests run under
+ * random sets of them (tests/test_gpu_random_schedules.py).  Round 6 removed 27 names whose A/B comparisons were settled (profiles/r06_options.txt lists them with
+ * the value each is now fixed at); what is left is what selects a code path, sizes a workspace, or is needed to reproduce a measurement.
+ *   workspace tiers  "lds_bytes_per_wave" (10240), "lds_ed_cap" (48): the small LDS slice of the wave-per-region kernels; "lds2_bytes_per_wave" (40960), "lds2_ed_cap" (48):
+ *                    the large one; "ws_bytes_per_wave" (1 MiB): the per-wave HBM slice, "adaptive_ws" (1: sized from the batch's predicted needs), "ws_budget_bytes";
+ *                    "big_ws_bytes" (64 MiB): the shared big slices; "hbm_ed_cap"; "waves_per_cu"; 0 bytes disables a tier; "capacity_retry" (1: a region no tier could hold is
+ *                    solved again by the library in larger slices)
+ *   scheduling       "solo_min_variants" (5: regions with at least this many calls go to the solo launches), "class_c_nodes_x2" (12: nodes per call a search is priced at
+ *                    when class C is decided), "class_c_below" (16384: a batch with lane launches and at most this many regions outside them plans those regions for the
+ *                    wave-cooperative kernel — a contig, a rank's shard), "het_search_min" (6: regions with that many unphased heterozygous calls are class C),
+ *                    "lds_escalation" (1: in-workgroup escalation of the bulk launch), "static_pct" (75: share of a launch's work list dealt statically), "claim" (2:
+ *                    regions per dynamic claim)
+ *   lane kernels     "lane_kernel" (1: regions with at most three calls per side on a short window are solved one per LANE, avk_lane.inl / four lanes per region,
+ *                    avk_quad.inl), "lane_quad" (1: launches of at most 16 records per wave run four lanes per region), "lane_pairs" (1: regions with the same SNV on
+ *                    both sides are looked up, avk_pairs.inl), "lane_min_regions" (2048) / "lane_min_batch" (16384): smaller classes / batches stay with the
+ *                    wave-per-region kernels, "lane_node_cap" (32: search nodes the three-call class makes before it hands a region over), "lane_width_one" / "_two" /
+ *                    "_three" (64, 64, 16: records a wave takes at a time), "lane_head_width" (16: records per wave in the heads of the classes, the tiles of regions
+ *                    with estimated edits; 0 = no head launch), "use_packed_reference" (1: the 2-bit reference; 0: bytes — every region then goes to the wave kernels)
+ *   wide kernel      "wide_kernel" (1: large searches on small windows are solved one per WAVE, avk_wide.inl), "wide_lds_bytes" (16384), "wide_retry_lds_bytes" (65536)
+ *   long windows     "team_long_windows" (1: a batch of large windows — no region of class C is the wide kernel's — runs the head of the class a WORKGROUP per region,
+ *                    avk_region_kernel_team; 0: a wave per region; 2: a workgroup per region whose owner wave takes every job itself, a diagnostic),
+ *                    "team_head_regions" (48: how many regions that head has)
+ *   boundary         "device_pack" (1: batches are validated, classified, ordered and written in the kernels' layout on the device, avk_devpack.inl; 0: by host threads,
+ *                    avk_pack.h — same records either way), "packed_source" (1: an avk_packed_batch is packed from the packed arrays themselves; 0: from a wide copy made
+ *                    on the device first, round 5), "split_parts" (1; 2..4: an avk_compare_packed call of pinned arrays runs as that many batches in flight,
+ *                    compare_packed_split — slower than the whole call today, profiles/r06_split_call.txt)
+ *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13 x 22 block; the batch tally is always produced), "emit_bp_groups" (1 = kernels write the
+ *                    compact per-region BASEPAIR groups; the one-call entry points switch it on when the caller hands the arrays in), "accumulate_tally" (1 =
+ *                    avk_compare_resident ADDS the batch tally to tally_dev)
+ * The launches of one call run on HIP streams side by side; the HIP runtime gives a process 4 hardware queues by default and streams that share one take turns:
+ * avk_ctx_create sets GPU_MAX_HW_QUEUES=24 unless the environment already has it (effective when it is the process's first HIP call). */
 int  avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value);
 
 /* Replaces ReferenceGenome::from_fasta + get_full_chromosome (src/main.rs:94,

@@ -124,12 +124,12 @@ def test_one_shot_path_equals_resident_path(ctxs, oracle):
 
 
 @pytest.mark.parametrize("opts", [
-    dict(lane_width_one=32, lane_width_two=16, lane_width_three=8, lane_head_width=4, lane_waves_per_cu=24),
-    dict(lane_head_width=0, lane_node_cap=8, lane_max_est=3, hbm_early_blocks=8),
-    dict(lane_max_calls=2, lane_metrics_ed_cap=8, lane_head_stream=1, lane_head_width=32),
-    dict(lane_max_calls=1, lane_node_cap=250, lane_max_est=0, hbm_solo_blocks=16),
-    dict(lane_pairs=0, lane_head_est=3, lane_stripe=1, lane_quad=0),
-    dict(lane_pairs=1, lane_head_est=6, pair_blocks_per_cu=1, hbm_solo_blocks=768, device_pack=0),
+    dict(lane_width_one=32, lane_width_two=16, lane_width_three=8, lane_head_width=4),
+    dict(lane_head_width=0, lane_node_cap=8),
+    dict(lane_head_width=32, lane_width_three=64),
+    dict(lane_node_cap=250, lane_width_two=8),
+    dict(lane_pairs=0, lane_quad=0),
+    dict(lane_pairs=1, device_pack=0),
 ])
 def test_scheduling_options_do_not_change_results(oracle, opts):
     """tile widths, head launches, node budget, edit estimates, stream layout: every combination gives the oracle's outputs, in the

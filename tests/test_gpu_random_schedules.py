@@ -22,18 +22,14 @@ SEED = int(os.environ.get("AVK_RANDOM_SEED", "20251003"))
 # option -> values a draw picks from (the first one is the default)
 TABLE = {
     "lds_bytes_per_wave": [10240, 4096, 20480, 0], "lds2_bytes_per_wave": [40960, 20480, 0], "lds_ed_cap": [48, 8, 200], "lds2_ed_cap": [48, 16],
-    "ws_bytes_per_wave": [1 << 20, 1 << 18, 4 << 20], "big_ws_bytes": [64 << 20, 8 << 20, 256 << 20], "big_waves": [64, 4, 8], "waves_per_cu": [12, 4, 32],
+    "ws_bytes_per_wave": [1 << 20, 1 << 18, 4 << 20], "big_ws_bytes": [64 << 20, 8 << 20, 256 << 20], "waves_per_cu": [12, 4, 32],
     "ws_budget_bytes": [96 << 30, 1 << 30, 2 << 30], "adaptive_ws": [1, 0],
-    "solo_min_variants": [5, 3, 0, 9], "solo_blocks_max": [128, 1, 1024], "solo_regions_per_wave": [4, 1, 64], "class_c_nodes_x2": [12, 1, 50, 1000],
-    "lds_escalation": [1, 0], "lds2_overflow_pass": [0, 1], "bulk_full_grid": [0, 1], "bulk_fit": [1, 0], "static_pct": [75, 0, 100, 33], "claim": [2, 1, 7, 64],
-    "wide_kernel": [1, 1, 0], "wide_lds_bytes": [16384, 8192, 65536, 24576], "wide_blocks": [512, 16, 2048], "wide_retry_lds_bytes": [65536, 0, 32768],
-    "wide_lane_handbacks": [1, 0], "wide_lazy_blocks": [512, 8], "pair_classes": [1, 0],
-    "device_pack": [1, 1, 0], "use_packed_reference": [1, 1, 1, 0], "timing_events": [1, 0],
+    "solo_min_variants": [5, 3, 0, 9], "class_c_nodes_x2": [12, 1, 50, 1000],
+    "lds_escalation": [1, 0], "static_pct": [75, 0, 100, 33], "claim": [2, 1, 7, 64],
+    "wide_kernel": [1, 1, 0], "wide_lds_bytes": [16384, 8192, 65536, 24576], "wide_retry_lds_bytes": [65536, 0, 32768],
+    "device_pack": [1, 1, 0], "use_packed_reference": [1, 1, 1, 0],
     "lane_kernel": [1, 1, 1, 0], "lane_min_regions": [0, 0, 2048], "lane_min_batch": [0, 0, 16384], "lane_width_one": [64, 32, 16, 8, 4], "lane_width_two": [64, 32, 16, 8, 4],
-    "lane_width_three": [16, 8, 4, 32, 64], "lane_max_calls": [3, 2, 1], "lane_max_est": [15, 3, 0], "lane_head_auto": [1, 0], "lane_head_width": [16, 0, 4, 8, 32, 64],
-    "lane_metrics_ed_cap": [0, 4, 12], "hbm_ed_cap": [1024, 0, 8], "het_search_min": [6, 0, 3, 4], "lane_head_est": [1, 2, 6], "lane_pairs": [1, 0], "pair_blocks_per_cu": [1, 4],
-    "lane_stripe": [0, 1], "lane_head_stream": [0, 1], "hbm_early_blocks": [256, 8, 768], "hbm_solo_blocks": [128, 4, 768], "lane_node_cap": [32, 8, 250], "lane_quad": [1, 1, 0],
-    "lane_pool": [-1, 0, 1, 8], "lane_waves_three": [0, 2, 16], "lane_waves_per_cu": [12, 2, 32], "packed_source": [1, 1, 0],
+    "lane_width_three": [16, 8, 4, 32, 64], "lane_head_width": [16, 0, 4, 8, 32, 64], "hbm_ed_cap": [1024, 0, 8], "het_search_min": [6, 0, 3, 4], "lane_pairs": [1, 0], "lane_node_cap": [32, 8, 250], "lane_quad": [1, 1, 0], "packed_source": [1, 1, 0], "team_long_windows": [1, 1, 0, 2], "team_head_regions": [48, 2, 400],
 }
 
 

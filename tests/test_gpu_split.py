@@ -29,7 +29,6 @@ def job(oracle):
 
 def solve(ctx, whole, parts, bp):
     ctx.set_option("split_parts", parts)
-    ctx.set_option("split_min_regions", 0)
     res = ctx.pinned_results(whole, packed="only", bp_groups="packed" if bp else False)
     return ctx.solve_packed(whole, res=res)
 
@@ -95,12 +94,11 @@ def group_metrics_tail(batch, exp, lo):
     return out
 
 
-def test_small_and_pageable_calls_are_not_split(job):
+def test_pageable_calls_are_not_split(job):
     ctx, contigs, batch, whole, ref = job
-    ctx.set_option("split_parts", 2)
-    ctx.set_option("split_min_regions", 1 << 20)  # the default: this batch is below it
+    ctx.set_option("split_parts", 1)  # the default: whole
     res = ctx.solve_packed(whole, res=ctx.pinned_results(whole, packed="only"))
-    ctx.set_option("split_min_regions", 0)
+    ctx.set_option("split_parts", 2)  # ... and pageable arrays are never split
     pageable = PackedBatch.from_compact(CompactBatch.from_region_batch(batch))
     res2 = ctx.solve_packed(pageable, res=ResultBatch(pageable, sequences=False, group_metrics=False, packed="only"))
     assert np.array_equal(res.region_packed, res2.region_packed) and np.array_equal(res.var_packed, res2.var_packed) and np.array_equal(res.tally, res2.tally)
