@@ -802,6 +802,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     /* (the inputs and the packer's intermediates stay with the batch: region records of lane regions are written when a launch needs them) */
     /* a compare batch in the packed form is read from the packed arrays themselves (DpIn::pk_*, round 6): no wide arrays, no widening pass */
     const bool packed_src = pk != nullptr && ctx->packed_source;
+    bool early_variant = false, variant_done = false; /* dp_variant queued on the side stream of a packed upload, under its copies */
     auto tmp_or_kept = [&](size_t bytes) -> void * { return kept(bytes); };
     auto wide = [&](size_t bytes) -> void * { return packed_src ? nullptr : kept(bytes); };
     uint64_t *d_start = (uint64_t *)wide((n + 1) * 8), *d_end = (uint64_t *)wide((n + 1) * 8);
@@ -871,11 +872,15 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
             hipError_t ep = hipStreamWaitEvent(s, pre->ready, 0);
             if (ep == hipSuccess) ep = hipEventRecord(ctx->ev_copy_fork, s);
             if (ep == hipSuccess) ep = hipEventRecord(ctx->ev_copy_mid, s);
+            if (ep == hipSuccess) ep = hipEventRecord(ctx->ev_copy_alleles, s);
             if (ep != hipSuccess) rc = fail(ctx, AVK_E_HIP, "packed upload: %s", hipGetErrorString(ep));
         } else
-        rc = copy_in(ctx, {{pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv, nullptr, ctx->ev_copy_fork}, {pk->start, p_start, n * 4},
+        /* (round 6: the allele bytes cross right behind the lengths — dp_variant needs nothing else, and runs on the side stream under the copies that follow) */
+        rc = copy_in(ctx, {{pk->t_cnt, p_tc, n}, {pk->q_cnt, p_qc, n}, {pk->a0_len, p_a0, nv}, {pk->a1_len, p_a1, nv, nullptr, ctx->ev_copy_fork},
+                           {pk->allele_bytes, d_alleles, alen, nullptr, ctx->ev_copy_alleles}, {pk->start, p_start, n * 4},
                            {pk->len, p_len, n * 2}, {pk->contig_idx, p_contig, has_contig ? n * 2 : 0}, {pk->var_rel_pos, p_rel, nv * 2}, {pk->var_type_zyg, p_tz, nv, nullptr, ctx->ev_copy_mid},
-                           {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0}, {pk->allele_bytes, d_alleles, alen}});
+                           {pk->var_raw_space, d_raw, has_raw ? nv * 4 : 0}});
+        early_variant = packed_src && nv != 0;
         mark(1);
         if (rc) return bail(rc);
         hipError_t ec = hipStreamWaitEvent(side, ctx->ev_copy_fork, 0); /* (also orders the side stream behind everything queued on the context's stream before) */
@@ -899,7 +904,21 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         c.w_contig = d_contig, c.w_t_cnt = db->d_in_t_cnt, c.w_q_cnt = db->d_in_q_cnt, c.w_a0_len = d_a0l, c.w_a1_len = d_a1l, c.w_raw = nullptr, c.w_start = d_start, c.w_end = d_end,
         c.w_t_off = db->d_in_t_off, c.w_q_off = db->d_in_q_off, c.w_pos = d_pos, c.w_a0_off = d_a0o, c.w_a1_off = d_a1o, c.w_type = d_type, c.w_zyg = d_zyg;
         const uint64_t m = n > nv ? n : nv;
-        hipError_t ew = hipStreamWaitEvent(side, ctx->ev_copy_mid, 0);
+        hipError_t ew = hipSuccess;
+        if (early_variant) {
+            /* Variant::alt_ed for every call, on the side stream behind the prefix sums and the allele bytes, while the region arrays still cross the bus: the state
+             * block is cleared here (dp_variant counts the calls it leaves to the host); the context's stream waits for ev_copy_join below as before */
+            a.in.pk_a0 = p_a0, a.in.pk_a1 = p_a1, a.in.pk_aoff = p_aoff, a.in.pk_start = p_start; /* (what dp_variant reads of the packed source; the rest follows below) */
+            a.in.alleles = d_alleles, a.in.n_variants = nv, a.in.alleles_len = alen, a.in.n_regions = n;
+            ew = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), side);
+            if (ew == hipSuccess) ew = hipStreamWaitEvent(side, ctx->ev_copy_alleles, 0);
+            if (ew == hipSuccess) {
+                hipLaunchKernelGGL(avk_dp_variant_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, side, a);
+                ew = hipGetLastError();
+            }
+            variant_done = ew == hipSuccess;
+        }
+        if (ew == hipSuccess) ew = hipStreamWaitEvent(side, ctx->ev_copy_mid, 0);
         if (packed_src) { /* the packer reads these as they are */
             a.in.pk_start = p_start, a.in.pk_len = p_len, a.in.pk_contig = p_contig, a.in.pk_rel = p_rel, a.in.pk_tc = p_tc, a.in.pk_qc = p_qc, a.in.pk_tz = p_tz, a.in.pk_a0 = p_a0,
             a.in.pk_a1 = p_a1, a.in.pk_voff = p_voff, a.in.pk_aoff = p_aoff;
@@ -1054,8 +1073,8 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     a.opt.lane_pairs = ctx->lane_pairs ? 1u : 0u;
     a.opt.head_est = (uint32_t)ctx->lane_head_est, a.opt.het_min = (uint32_t)ctx->het_search_min;
     a.opt.class_c_below = (uint64_t)ctx->class_c_below;
-    hipError_t e = hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
-    if (e == hipSuccess && nv) {
+    hipError_t e = variant_done ? hipSuccess : hipMemsetAsync(a.st, 0, sizeof(dpk::DpState), s);
+    if (e == hipSuccess && nv && !variant_done) {
         hipLaunchKernelGGL(avk_dp_variant_kernel, dim3((unsigned)((nv + 255) / 256)), dim3(256), 0, s, a);
         e = hipGetLastError();
     }

@@ -441,6 +441,7 @@ struct avk_ctx {
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
     hipEvent_t ev_lane_join4 = nullptr, ev_lane_early = nullptr;
     hipEvent_t ev_tl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* AVK_TIMING only: marks of a boundary call on the context's stream (first copy, last copy, work order, writers, results) */
+    hipEvent_t ev_copy_alleles = nullptr; /* packed upload: behind the allele bytes' copy (dp_variant starts there) */
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     hipStream_t spare_stream[16] = {nullptr}; /* never used: see avk_ctx_create */
@@ -644,6 +645,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_copy_alleles, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_mid, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_join, hipEventDisableTiming) != hipSuccess ||
@@ -706,6 +708,7 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_join3) (void)hipEventDestroy(ctx->ev_lane_join3);
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
+    if (ctx->ev_copy_alleles) (void)hipEventDestroy(ctx->ev_copy_alleles);
     if (ctx->ev_copy_fork) (void)hipEventDestroy(ctx->ev_copy_fork);
     if (ctx->ev_copy_mid) (void)hipEventDestroy(ctx->ev_copy_mid);
     if (ctx->ev_copy_join) (void)hipEventDestroy(ctx->ev_copy_join);

@@ -72,9 +72,9 @@ def test_one_contig_full_density_on_quads(ctxs, oracle):
 
 
 @pytest.mark.parametrize("opts", [
-    dict(lane_head_width=4, lane_width_three=4, lane_pool=0),
-    dict(lane_head_width=8, lane_width_three=8, lane_pool=8, lane_node_cap=8),
-    dict(lane_head_width=16, lane_head_auto=0, lane_pool=1, lane_node_cap=250, lane_head_est=3),
+    dict(lane_head_width=4, lane_width_three=4),
+    dict(lane_head_width=8, lane_width_three=8, lane_node_cap=8),
+    dict(lane_head_width=16, lane_node_cap=250),
 ])
 def test_default_launch_graph_with_quads_of_any_width(oracle, opts):
     """the heads and the three-call class on 4, 8 or 16 quads per wave, the rest 64 lanes wide: scheduling only"""

@@ -1,7 +1,7 @@
 #!/bin/bash
 # On the GPU box: for each option string (one argument each; "-" = defaults): wall time of 50 queued whole-genome resident steps in a fresh
 # process, then the kernel timeline of one step (rocprofv3 --kernel-trace on the same probe, 3 steps): which launch ends when.
-# usage: tools/chain_timeline.sh "-" "lane_stripe=0" ...
+# usage: tools/chain_timeline.sh "-" "lane_quad=0" ...
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R
 mkdir -p gpurun_out
