@@ -1045,25 +1045,35 @@ struct DpOut {
     const u64 *pk_voff;
     const u8 *pk_tc, *pk_qc;
 };
-AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
+/* the packed BASEPAIR word of region r, or — the region needs its groups spilled — how many groups that is (then `word` is not set) */
+AVK_DEV u32 dp_unpack_bp_need(const DpOut &o, u64 r, u32 &word) {
+    word = 0;
+    if (r >= o.n_regions || !o.bp_packed) return 0;
+    const u32 lo = o.bp_off_dev[r], hi = o.bp_off_dev[r + 1];
+    if (o.region_out[4 * r] != 0 || hi <= lo) return 0;
+    const avk_u4 j = *(const avk_u4 *)(o.bp_dev + 4 * (u64)lo);
+    bool simple = (j.x | j.y | j.z | j.w) < 128u;
+    for (u32 k = lo + 1; k < hi && simple; ++k) {
+        const avk_u4 g = *(const avk_u4 *)(o.bp_dev + 4 * (u64)k);
+        simple = g.x == j.x && g.y == j.y && g.z == j.z && g.w == j.w;
+    }
+    if (simple) {
+        word = j.x | (j.y << 7) | (j.z << 14) | (j.w << 21);
+        return 0;
+    }
+    return hi - lo;
+}
+/* `need` / `word` from dp_unpack_bp_need; `at` = where the region's spilled groups go (the kernel hands the places out a workgroup at a time: one atomic per 256
+ * regions instead of one per wave — 56,000 returning atomics on one word were 0.4 ms of a whole-genome call); at == 0xFFFFFFFF: taken here, with an atomic of its own */
+AVK_DEV void dp_unpack(const DpOut &o, u64 r, u32 need, u32 word, u32 at) {
     if (r >= o.n_regions) return;
     const avk_u4 w = *(const avk_u4 *)(o.region_out + 4 * r);
     if (o.bp_packed) {
-        const u32 lo = o.bp_off_dev[r], hi = o.bp_off_dev[r + 1];
-        u32 word = 0;
-        if (w.x == 0 && hi > lo) {
-            const avk_u4 j = *(const avk_u4 *)(o.bp_dev + 4 * (u64)lo);
-            bool simple = (j.x | j.y | j.z | j.w) < 128u;
-            for (u32 k = lo + 1; k < hi && simple; ++k) {
-                const avk_u4 g = *(const avk_u4 *)(o.bp_dev + 4 * (u64)k);
-                simple = g.x == j.x && g.y == j.y && g.z == j.z && g.w == j.w;
-            }
-            if (simple) word = j.x | (j.y << 7) | (j.z << 14) | (j.w << 21);
-            else {
-                const u32 at = avk_atomic_add_u32_global(o.bp_spill_count, hi - lo);
-                for (u32 k = lo; k < hi; ++k) *(avk_u4 *)(o.bp_spill + 4 * (u64)(at + k - lo)) = *(const avk_u4 *)(o.bp_dev + 4 * (u64)k);
-                word = 0x80000000u | at;
-            }
+        if (need) {
+            const u32 lo = o.bp_off_dev[r];
+            if (at == 0xFFFFFFFFu) at = avk_atomic_add_u32_global(o.bp_spill_count, need);
+            for (u32 k = 0; k < need; ++k) *(avk_u4 *)(o.bp_spill + 4 * (u64)(at + k)) = *(const avk_u4 *)(o.bp_dev + 4 * (u64)(lo + k));
+            word = 0x80000000u | at;
         }
         o.bp_packed[r] = word;
     }
@@ -1091,6 +1101,12 @@ AVK_DEV void dp_unpack(const DpOut &o, u64 r) {
         if (o.var_zyg) o.var_zyg[hv] = (u8)(x >> 24);
         if (o.var_packed) o.var_packed[hv] = (u8)((x & 3u) | ((x >> 8) & 3u) << 2 | ((x >> 24) & 7u) << 4);
     }
+}
+
+AVK_DEV void dp_unpack(const DpOut &o, u64 r) { /* one region by itself (the emulator, the tests) */
+    u32 word = 0;
+    const u32 need = dp_unpack_bp_need(o, r, word);
+    dp_unpack(o, r, need, word, 0xFFFFFFFFu);
 }
 
 } // namespace dp

@@ -308,7 +308,28 @@ __global__ void avk_dp_patch_ed_kernel(dpk::DpVarInfo *vinfo, const uint32_t *id
 
 __global__ void __launch_bounds__(256) avk_dp_unpack_kernel(dpk::DpOut o, uint8_t *pair_exact) {
     const uint64_t r = (uint64_t)blockIdx.x * 256u + threadIdx.x;
-    dpk::dp_unpack(o, r);
+    uint32_t word = 0, at = 0;
+    const uint32_t need = dpk::dp_unpack_bp_need(o, r, word);
+    if (o.bp_packed) { /* places in the spill list for the whole workgroup with one atomic: an exclusive scan of the lanes' needs */
+        __shared__ uint32_t wave_sum[4], base;
+        const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+        uint32_t incl = need;
+        for (uint32_t d = 1; d < 64; d <<= 1) {
+            const uint32_t y = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += y;
+        }
+        if (lane == 63) wave_sum[wv] = incl;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const uint32_t total = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+            base = total ? atomicAdd(o.bp_spill_count, total) : 0u;
+        }
+        __syncthreads();
+        uint32_t before = 0;
+        for (uint32_t k = 0; k < wv; ++k) before += wave_sum[k];
+        at = base + before + incl - need;
+    }
+    dpk::dp_unpack(o, r, need, word, at);
     if (pair_exact && r < o.n_regions) pair_exact[r] = (o.region_out[4 * r] == 0 && o.region_out[4 * r + 1] != 0) ? 1 : 0; /* all_opt_haps[0].is_exact_match() */
 }
 
