@@ -369,6 +369,19 @@ class Context:
         self._check(self.lib.avk_last_tier_counts(self.handle, out))
         return [int(x) for x in out]
 
+    def work_order(self, rb, want_order=True):
+        """avk_debug_work_order: (order[n] or None, plan) of a device-packed resident batch; plan = {"class_c", "class_c_not_wide", "class_b", "lanes",
+        "fast": [(first record, regions, head regions) per lane class]}"""
+        import numpy as np
+        n = rb.batch.n_regions
+        order = np.zeros(max(n, 1), np.uint32) if want_order else None
+        counts = (C.c_uint64 * 22)()
+        self.lib.avk_debug_work_order.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]
+        self._check(self.lib.avk_debug_work_order(self.handle, rb.handle, order.ctypes.data_as(C.POINTER(C.c_uint32)) if want_order else None, counts))
+        c = [int(x) for x in counts]
+        return (order[:n] if want_order else None), {"class_c": c[0], "class_c_not_wide": c[1], "class_b": c[2], "lanes": c[3],
+                                                      "fast": [(c[4 + 3 * k], c[5 + 3 * k], c[6 + 3 * k]) for k in range(6)]}
+
     def debug_phase_cycles(self):
         out = (C.c_uint64 * 16)()
         self._check(self.lib.avk_debug_phase_cycles(self.handle, out))

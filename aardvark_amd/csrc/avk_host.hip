@@ -136,7 +136,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_LAN
 #ifndef AVK_QUAD_WPE
 #define AVK_QUAD_WPE 3
 #endif
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_QUAD_WPE))) avk_quad_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) {
+static __device__ __forceinline__ void avk_quad_body(const AvkKernelArgs &a, const avk::lane::LaneArgs &la) {
     extern __shared__ __attribute__((aligned(16))) unsigned char avk_smem[];
     uint32_t *smem = (uint32_t *)avk_smem;
     const uint32_t rows = avk::quad::quad_rows(la.W, la.nm, la.ed_max, la.qcap, la.pool);
@@ -165,6 +165,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_QUA
         if (v) atomicAdd((unsigned long long *)(part + k), (unsigned long long)v);
     }
 }
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(AVK_QUAD_WPE))) avk_quad_kernel(AvkKernelArgs a, avk::lane::LaneArgs la) { avk_quad_body(a, la); }
+/* The same code for launches whose LDS slice holds a CU to two waves per SIMD anyway (the three-call class: 20 KB per one-wave workgroup, seven per CU): built for two
+ * waves per SIMD it has 256 registers and spills nothing (at three: 168 registers, 26 VGPR + 214 SGPR spills, 108 bytes of scratch per lane) */
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) avk_quad_kernel_wide_regs(AvkKernelArgs a, avk::lane::LaneArgs la) { avk_quad_body(a, la); }
 
 /* Regions with large searches on small windows, one per wave, every lane a piece of the search (avk_wide.inl): one-wave workgroups, the region's tables in
  * the workgroup's LDS */
@@ -1254,7 +1258,10 @@ static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs
 }
 /* a launch of a lane class: one lane per region, or four (lane_launch_is_quad) */
 static void launch_lane_class(const avk_ctx *ctx, uint32_t grid, size_t lds, hipStream_t s, const AvkKernelArgs &f, const avk::lane::LaneArgs &la) {
-    if (lane_launch_is_quad(ctx, la)) hipLaunchKernelGGL(avk_quad_kernel, dim3(grid), dim3(64), lds, s, f, la);
+    if (lane_launch_is_quad(ctx, la)) {
+        if (lds * 8 > 160 * 1024) hipLaunchKernelGGL(avk_quad_kernel_wide_regs, dim3(grid), dim3(64), lds, s, f, la); /* fewer than eight workgroups per CU by LDS: registers to spare */
+        else hipLaunchKernelGGL(avk_quad_kernel, dim3(grid), dim3(64), lds, s, f, la);
+    }
     else hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, s, f, la);
 }
 
@@ -1304,6 +1311,7 @@ static int ensure_pair_table(avk_ctx *ctx, uint32_t max_branch_factor, hipStream
     if (!ctx->lane_attr_set) {
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel_wide_regs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->lane_attr_set = true;
     }
     hipLaunchKernelGGL(avk_lane_kernel, dim3(1), dim3(64), lds, s, f, la);
@@ -1733,6 +1741,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 if (!ctx->lane_attr_set) {
                     AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel_wide_regs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
                     ctx->lane_attr_set = true;
                 }
                 AvkKernelArgs f = a;
@@ -2091,6 +2100,23 @@ int avk_debug_snapshot(avk_ctx *ctx, avk_dev_batch *db, uint32_t *counters, uint
     if (n_counters > AVK_N_COUNTERS) n_counters = AVK_N_COUNTERS;
     AVK_HIP(ctx, hipMemcpyAsync(counters, db->d_counters, (size_t)n_counters * sizeof(uint32_t), hipMemcpyDeviceToHost, probe));
     AVK_HIP(ctx, hipStreamSynchronize(probe));
+    return 0;
+}
+
+/* The work order of a device-packed batch and the plan behind it: region order[k] is record k; [0, n_hbm) class C, [n_hbm, n_hbm + n_hard) class B, then the bulk, then the
+ * lane classes from fast_base[fc] (n_fast[fc] regions each, the first n_fast_heavy[fc] its head); class AVK_FAST_PAIR is looked up.  A measurement aid: bench.py prices every
+ * launch class with the algorithmic bytes of ITS regions.  counts[0..3] = n_hbm, n_hbm_notwide, n_hard, n_fast_total; [4 + 3 fc ..] = fast_base, n_fast, n_fast_heavy of
+ * class fc (22 words).  order may be NULL.  Host-packed batches: AVK_E_STATE. */
+int avk_debug_work_order(avk_ctx *ctx, avk_dev_batch *db, uint32_t *order, uint64_t counts[22]) {
+    if (!ctx || !db || !counts) return AVK_E_ARG;
+    if (!db->dev_packed || !db->dp_args.order) return fail(ctx, AVK_E_STATE, "the batch was not packed on the device");
+    AVK_HIP(ctx, hipSetDevice(ctx->device));
+    counts[0] = db->plan.n_hbm, counts[1] = db->plan.n_hbm_notwide, counts[2] = db->plan.n_hard, counts[3] = db->plan.n_fast_total;
+    for (int fc = 0; fc < AVK_FAST_CLASSES; ++fc) counts[4 + 3 * fc] = db->plan.fast_base[fc], counts[5 + 3 * fc] = db->plan.n_fast[fc], counts[6 + 3 * fc] = db->plan.n_fast_heavy[fc];
+    if (order && db->n_regions) {
+        AVK_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        AVK_HIP(ctx, hipMemcpy(order, db->dp_args.order, (size_t)db->n_regions * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    }
     return 0;
 }
 
@@ -2754,6 +2780,7 @@ int avk_ctx_warmup(avk_ctx *ctx, uint64_t n_regions_hint, uint64_t n_variants_hi
     if (!ctx->lane_attr_set) {
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        AVK_HIP(ctx, hipFuncSetAttribute((const void *)avk_quad_kernel_wide_regs, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         ctx->lane_attr_set = true;
     }
     if (ctx->lane_kernel && ctx->lane_pairs) {

@@ -566,6 +566,29 @@ def main():
         solver_ms.append(ctx.last_solver_ms())
     ctx.set_option("emit_bp_groups", 0)
     tiers = lane_regions = wide_regions = None
+    # the algorithmic bytes of every LAUNCH CLASS (SURVEY 8d's per-region formula over the regions the class's launches take: the library's own work order), so that a
+    # per-kernel fraction can be recomputed from the rocprof durations of profiles/
+    by_class = None
+    try:
+        order, plan = ctx.work_order(rb)
+        n_c, n_b, n_l = plan["class_c"], plan["class_b"], plan["lanes"]
+        names = ["one call per side, <= 112 bases", "one call per side, <= 192 bases", "two calls per side, <= 160 bases", "two calls per side, <= 192 bases",
+                 "three calls per side", "looked-up pairs (the same SNV on both sides)"]
+        spans = [("class C (large searches: wide kernel, long windows)", 0, n_c), ("class B (solo launches)", n_c, n_b), ("bulk (wave-per-region, LDS tiers)", n_c + n_b, n_regions - n_l - n_c - n_b)]
+        for k, (first, cnt, heavy) in enumerate(plan["fast"]):
+            if cnt and k < 5:
+                spans.append(("lanes: %s — head (quads)" % names[k], first, heavy))
+                spans.append(("lanes: %s — rest" % names[k], first + heavy, cnt - heavy))
+            elif cnt:
+                spans.append(("lanes: %s" % names[k], first, cnt))
+        by_class = []
+        for name, first, cnt in spans:
+            if cnt <= 0:
+                continue
+            sub = avk_dist.take_regions(batch, np.sort(order[first:first + cnt].astype(np.int64)))
+            by_class.append({"launch_class": name, "regions": int(cnt), "algorithmic_bytes": int(ctx.algorithmic_bytes(sub, with_groups=bool(full_result)))})
+    except Exception as e:  # a measurement aid: its absence must not cost the run
+        by_class = "unavailable: %s" % e
     got = ctx.download(rb, group_metrics=False)
     try:
         tiers = ctx.last_tier_counts()  # regions finished per workspace tier of the wave-per-region kernels, then capacity failures
@@ -714,7 +737,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "all solver launches of a step (lane classes + looked-up pairs + wide + bulk + solo + overflow; HIP events ev0..ev1 on the launch stream)",
-                         "kernel_ms": s_ms, "first_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel_ms": s_ms, "first_launch_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes, "algorithmic_bytes_by_launch_class": by_class,
                          "bytes_per_region": alg_bytes / max(n_regions, 1),
                          "pcie": {"bytes_per_step": in_bytes + out_bytes, "achieved_GBs": (in_bytes + out_bytes) * (total_regions / max(n_regions, 1)) / world / (ms_per_step * 1e-3) / 1e9,
                                   "note": "the host boundary moves the caller's arrays over PCIe (57 GB/s each way measured on this pool, profiles/r03_pcie_probe.txt): its floor per step is bytes / 57 GB/s"}},

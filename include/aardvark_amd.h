@@ -452,6 +452,11 @@ int  avk_debug_phase_cycles(avk_ctx *ctx, uint64_t out[16]);
  * counters (work-list claims, list lengths, tile claims) as they are at the time of the call, while the launches may still be running */
 int  avk_debug_snapshot(avk_ctx *ctx, avk_dev_batch *db, uint32_t *counters, uint32_t n_counters, int32_t busy[5]);
 
+/* measurement aid (bench.py's roofline by launch class): the work order of a device-packed batch — region order[k] is record k of the order the launches take their regions
+ * in — and the plan's counts: counts[0..3] = regions of class C, of those not the wide kernel's, of class B, of all lane classes; counts[4 + 3 fc .. 6 + 3 fc] = first record,
+ * regions and head regions of lane class fc (0 .. 5; 5 = the looked-up pairs).  Between class B and the first lane class lies the bulk.  order may be NULL. */
+int  avk_debug_work_order(avk_ctx *ctx, avk_dev_batch *db, uint32_t *order, uint64_t counts[22]);
+
 /* Stratified tallies on the device (SummaryWriter::add_comparison_benchmark with the region's containment labels,
  * src/writers/summary.rs:146-163): after avk_compare_resident with the option emit_group_metrics set, label l's block of
  * AVK_TALLY_LEN words gets the sum of the metric blocks of the solved regions whose label list names l.  The labels of region r (caller
