@@ -612,6 +612,52 @@ struct CopySeg {
     hipEvent_t then_record = nullptr; /* uploads: recorded on that stream behind this array's copy */
 };
 
+/* Copies between PINNED host arrays and HBM by a kernel instead of a DMA engine (round 6).  hipMemcpyAsync hands such a copy to an SDMA engine, and which engine a
+ * process gets is the driver's round robin: of the processes started one after the other on one box, every second or third copied at HALF the rate the first one got —
+ * 23.5 instead of 47 GB/s in, 2.4 instead of 1.2 ms out, a whole-genome call 9.5 ms instead of 6.5, for the life of the process (profiles/r06_copy_engines.txt).  In a
+ * synchronous call nothing else runs while its arrays cross the bus, so the compute units do it: every lane moves 16 bytes at a time straight from / to the pinned
+ * pages (they are mapped into the device's address space), at the link's rate in every process.  The asynchronous boundary keeps the engines: its copies run beside
+ * kernels. */
+__global__ void __launch_bounds__(256) avk_copy_kernel(const uint8_t *src, uint8_t *dst, size_t bytes) {
+    const size_t tid = (size_t)blockIdx.x * 256u + threadIdx.x, nthreads = (size_t)gridDim.x * 256u;
+    if ((((uintptr_t)src | (uintptr_t)dst) & 15u) == 0) {
+        typedef unsigned int avk_v4u __attribute__((ext_vector_type(4)));
+        const size_t n16 = bytes >> 4;
+        const avk_v4u *s16 = (const avk_v4u *)src;
+        avk_v4u *d16 = (avk_v4u *)dst;
+        size_t i = tid;
+        for (; i + 3 * nthreads < n16; i += 4 * nthreads) { /* four loads in flight per lane: the link's latency is microseconds */
+            const avk_v4u a0 = __builtin_nontemporal_load(s16 + i), a1 = __builtin_nontemporal_load(s16 + i + nthreads), a2 = __builtin_nontemporal_load(s16 + i + 2 * nthreads),
+                          a3 = __builtin_nontemporal_load(s16 + i + 3 * nthreads);
+            __builtin_nontemporal_store(a0, d16 + i), __builtin_nontemporal_store(a1, d16 + i + nthreads), __builtin_nontemporal_store(a2, d16 + i + 2 * nthreads),
+                __builtin_nontemporal_store(a3, d16 + i + 3 * nthreads);
+        }
+        for (; i < n16; i += nthreads) d16[i] = __builtin_nontemporal_load(s16 + i);
+        for (size_t i = (n16 << 4) + tid; i < bytes; i += nthreads) dst[i] = src[i];
+    } else if ((((uintptr_t)src | (uintptr_t)dst) & 3u) == 0) {
+        const size_t n4 = bytes >> 2;
+        const uint32_t *s4 = (const uint32_t *)src;
+        uint32_t *d4 = (uint32_t *)dst;
+        for (size_t i = tid; i < n4; i += nthreads) d4[i] = s4[i];
+        for (size_t i = (n4 << 2) + tid; i < bytes; i += nthreads) dst[i] = src[i];
+    } else
+        for (size_t i = tid; i < bytes; i += nthreads) dst[i] = src[i];
+}
+/* Which of the two this context's synchronous copies use (option kernel_copies: 1 = decided by measurement, 0 = the engines, 2 = the kernel).  A probe copy of a
+ * fresh buffer says nothing — it ran at 43-55 GB/s in processes whose calls then crawled — so the calls time THEMSELVES: two event records around the copies in of every
+ * call that uses the engine (upload_device_packed); the first call whose arrays cross below 36 GB/s switches the context to the kernel for good.  A process that
+ * drew a full-rate engine keeps it: it is 0.4 ms per whole-genome call faster than the kernel and leaves the CUs to dp_variant. */
+static bool copies_by_kernel(const avk_ctx *ctx) { return ctx->kernel_copies == 2 || (ctx->kernel_copies == 1 && !ctx->engines_fast); }
+static hipError_t kernel_copy(avk_ctx *ctx, void *dst, const void *src, size_t bytes, hipStream_t stream) {
+    if (!bytes) return hipSuccess;
+    size_t blocks = (bytes / 16 + 255) / 256;
+    const size_t cap = (size_t)ctx->n_cus * (size_t)(ctx->copy_blocks_per_cu > 0 ? ctx->copy_blocks_per_cu : 8);
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(avk_copy_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint8_t *)src, (uint8_t *)dst, bytes);
+    return hipGetLastError();
+}
+
 /* host -> device on the context's stream (or the segment's): straight from pinned arrays; pageable ones through the bounce buffer, piece by piece — the host threads
  * fill pieces while this thread queues the copy of every piece that is ready */
 static int copy_in(avk_ctx *ctx, const std::vector<CopySeg> &segs) {
@@ -648,9 +694,17 @@ static int copy_in(avk_ctx *ctx, const std::vector<CopySeg> &segs) {
         if (rc) return rc;
     }
     const bool timing = getenv("AVK_TIMING") != nullptr;
+    size_t direct_bytes = 0;
+    for (const Piece &p : pieces) direct_bytes += p.direct ? p.bytes : 0;
+    const bool by_kernel = !ctx->up_stream && direct_bytes >= (8u << 20) && copies_by_kernel(ctx); /* (small batches: the engines' latency is what counts) */
+    const bool timed_engine = !ctx->up_stream && !by_kernel && ctx->kernel_copies == 1 && direct_bytes >= (32u << 20) && staged == 0 && ctx->ev_cp0 && ctx->ev_cp1;
+    if (timed_engine) (void)hipEventRecord(ctx->ev_cp0, ctx->stream);
+    ctx->cp_timed_bytes = 0;
     auto issue = [&](const Piece &p) -> hipError_t { /* pieces are queued in segment order, whatever their source */
         const auto t0 = std::chrono::steady_clock::now();
-        hipError_t e = p.bytes ? hipMemcpyAsync(p.dev, p.direct ? p.src : ctx->h_bounce + p.off, p.bytes, hipMemcpyHostToDevice, p.stream) : hipSuccess;
+        hipError_t e = hipSuccess;
+        if (p.bytes && p.direct && by_kernel) e = kernel_copy(ctx, p.dev, p.src, p.bytes, p.stream); /* (a queued upload's copies run beside kernels: the engines) */
+        else if (p.bytes) e = hipMemcpyAsync(p.dev, p.direct ? p.src : ctx->h_bounce + p.off, p.bytes, hipMemcpyHostToDevice, p.stream);
         const auto t1 = std::chrono::steady_clock::now();
         if (e == hipSuccess && p.then_record) e = hipEventRecord(p.then_record, p.stream);
         if (timing) {
@@ -690,7 +744,22 @@ static int copy_in(avk_ctx *ctx, const std::vector<CopySeg> &segs) {
         });
     }
     if (herr != hipSuccess) return fail(ctx, AVK_E_HIP, "host to device copy failed: %s", hipGetErrorString(herr));
+    if (timed_engine && hipEventRecord(ctx->ev_cp1, ctx->stream) == hipSuccess) ctx->cp_timed_bytes = direct_bytes; /* (read by engine_rate_check once the stream has been waited for) */
     return 0;
+}
+/* behind a host synchronisation with the context's stream: how fast the engine moved the arrays of the copy_in before it */
+static void engine_rate_check(avk_ctx *ctx) {
+    if (!ctx->cp_timed_bytes) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, ctx->ev_cp0, ctx->ev_cp1) == hipSuccess && ms > 0) {
+        ctx->engine_in_gbs = ctx->cp_timed_bytes / (ms * 1e-3) / 1e9;
+        if (ctx->engine_in_gbs < 36.0) {
+            ctx->engines_fast = false;
+            if (getenv("AVK_TIMING")) fprintf(stderr, "avk copies: the DMA engine moved this call's arrays at %.1f GB/s: synchronous calls copy by kernel from now on\n", ctx->engine_in_gbs);
+        }
+    } else
+        (void)hipGetLastError();
+    ctx->cp_timed_bytes = 0;
 }
 
 /* device -> host: queues the copies (pinned destinations directly, the others into the bounce buffer); finish_copy_out waits for the stream and
@@ -710,11 +779,14 @@ static int copy_out(avk_ctx *ctx, const std::vector<CopySeg> &segs, CopyOut *co)
         const int rc = bounce_reserve(ctx, staged);
         if (rc) return rc;
     }
-    size_t off = 0;
+    size_t off = 0, pinned_bytes = 0;
+    for (const CopySeg &s : segs) pinned_bytes += s.bytes && s.host && is_pinned(s.host, s.bytes) ? s.bytes : 0;
+    const bool by_kernel = pinned_bytes >= (8u << 20) && copies_by_kernel(ctx);
     for (const CopySeg &s : segs) {
         if (!s.bytes || !s.host) continue;
         if (is_pinned(s.host, s.bytes)) {
-            AVK_HIP(ctx, hipMemcpyAsync((void *)s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
+            if (by_kernel) AVK_HIP(ctx, kernel_copy(ctx, (void *)s.host, s.dev, s.bytes, ctx->stream));
+            else AVK_HIP(ctx, hipMemcpyAsync((void *)s.host, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
             continue;
         }
         AVK_HIP(ctx, hipMemcpyAsync(ctx->h_bounce + off, s.dev, s.bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -1118,6 +1190,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
         if (x == hipSuccess) x = hipMemcpyAsync(hs, a.st, sizeof(dpk::DpState), hipMemcpyDeviceToHost, s);
         if (x == hipSuccess && pk_totals) x = hipMemcpyAsync(hs + 1, pk_totals, 16, hipMemcpyDeviceToHost, s); /* (the packed forms' two sums ride along: 16 bytes behind the state block) */
         if (x == hipSuccess) x = hipStreamSynchronize(s);
+        if (x == hipSuccess) engine_rate_check(ctx);
         return x;
     };
     if (e == hipSuccess) e = region_passes();
@@ -1402,7 +1475,8 @@ static int download_device_packed(avk_ctx *ctx, avk_dev_batch *db, avk_result_ba
         out->bp_spilled[0] = spilled;
         if (spilled) { /* (pinned: queued, finish_copy_out waits for it; pageable: a blocking copy — the bounce buffer holds the parts queued above) */
             const size_t tail_bytes = (size_t)spilled * 4 * sizeof(uint32_t);
-            e = is_pinned(out->bp_groups, tail_bytes) ? hipMemcpyAsync(out->bp_groups, o.bp_spill, tail_bytes, hipMemcpyDeviceToHost, s)
+            e = is_pinned(out->bp_groups, tail_bytes) ? (copies_by_kernel(ctx) ? kernel_copy(ctx, out->bp_groups, o.bp_spill, tail_bytes, s)
+                                                                            : hipMemcpyAsync(out->bp_groups, o.bp_spill, tail_bytes, hipMemcpyDeviceToHost, s))
                                                       : hipMemcpy(out->bp_groups, o.bp_spill, tail_bytes, hipMemcpyDeviceToHost);
             if (e != hipSuccess) return done(fail(ctx, AVK_E_HIP, "result unpacking failed: %s", hipGetErrorString(e)));
         }

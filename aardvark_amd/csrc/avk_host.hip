@@ -376,6 +376,13 @@ struct avk_ctx {
     int64_t team_head_regions = 48;        /* a batch of large windows (no region of class C is the wide kernel's): this many regions at the head of the class go to a team launch */
     int64_t split_parts = 1;               /* > 1: a large avk_compare_packed call runs as this many batches in flight (compare_packed_split; measured slower than the whole call while a half genome's step costs 2.0 of the whole's 2.4 ms: profiles/r06_split_call.txt) ... */
                                            /* ... when every part has at least 4096 regions and every array of the caller's is pinned */
+    int64_t copy_blocks_per_cu = 8; /* workgroups of avk_copy_kernel per CU (AVK_COPY_BLOCKS in the environment overrides: a tuning aid) */
+    int64_t kernel_copies = 1;  /* the pinned arrays of a synchronous call cross the bus 0: by the DMA engine the process drew, 2: by a copy kernel, 1: by whichever a measurement of
+                                   the engine says (avk_devpack_host.inl: copies_by_kernel) */
+    bool engines_fast = true;   /* no call of this context has seen its arrays cross below 36 GB/s on the engine */
+    double engine_in_gbs = 0;
+    size_t cp_timed_bytes = 0;  /* bytes between ev_cp0 and ev_cp1 of the last engine-timed copy_in (0: none pending) */
+    hipEvent_t ev_cp0 = nullptr, ev_cp1 = nullptr;
     int64_t packed_source = 1;  /* 1: a batch in the packed form is packed from the packed arrays themselves (no wide copy of the caller's arrays in HBM); 0: round 5's widening pass */
     int64_t emit_bp_groups = 0; /* kernels write the compact per-region BASEPAIR groups (avk_result_batch::bp_groups) */
     int64_t capacity_retry = 1; /* avk_results_download solves regions that exhausted the last workspace tier again with larger slices */
@@ -594,6 +601,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         return fail(nullptr, AVK_E_HIP, "hipGetDeviceProperties failed: %s", hipGetErrorString(e));
     }
     ctx->n_cus = prop.multiProcessorCount;
+    if (const char *e = getenv("AVK_COPY_BLOCKS")) ctx->copy_blocks_per_cu = atoi(e) > 0 ? atoi(e) : ctx->copy_blocks_per_cu;
     if (hipStreamCreate(&ctx->stream) != hipSuccess) {
         delete ctx;
         return fail(nullptr, AVK_E_HIP, "hipStreamCreate failed");
@@ -649,6 +657,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, evf) != hipSuccess ||
+        hipEventCreate(&ctx->ev_cp0) != hipSuccess || hipEventCreate(&ctx->ev_cp1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_alleles, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_mid, hipEventDisableTiming) != hipSuccess ||
@@ -712,6 +721,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_join3) (void)hipEventDestroy(ctx->ev_lane_join3);
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
+    if (ctx->ev_cp0) (void)hipEventDestroy(ctx->ev_cp0);
+    if (ctx->ev_cp1) (void)hipEventDestroy(ctx->ev_cp1);
     if (ctx->ev_copy_alleles) (void)hipEventDestroy(ctx->ev_copy_alleles);
     if (ctx->ev_copy_fork) (void)hipEventDestroy(ctx->ev_copy_fork);
     if (ctx->ev_copy_mid) (void)hipEventDestroy(ctx->ev_copy_mid);
@@ -818,6 +829,9 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "split_parts") {
         if (value < 1 || value > 4) return fail(ctx, AVK_E_ARG, "split_parts must be 1..4");
         ctx->split_parts = value;
+    } else if (n == "kernel_copies") {
+        if (value < 0 || value > 2) return fail(ctx, AVK_E_ARG, "kernel_copies must be 0 (engines), 1 (by measurement) or 2 (kernel)");
+        ctx->kernel_copies = value;
     } else if (n == "packed_source") {
         ctx->packed_source = value ? 1 : 0;
     } else if (n == "emit_bp_groups") {
@@ -840,9 +854,6 @@ int avk_ctx_set_option(avk_ctx *ctx, const char *name, int64_t value) {
     } else if (n == "hbm_ed_cap") {
         if (value < 0 || value > 1000000) return fail(ctx, AVK_E_ARG, "hbm_ed_cap must be 0..1000000");
         ctx->hbm_ed_cap = value;
-    } else if (n == "het_search_min") {
-        if (value < 0 || value > 255) return fail(ctx, AVK_E_ARG, "het_search_min must be 0..255");
-        ctx->het_search_min = value;
     } else if (n == "lane_pairs") {
         ctx->lane_pairs = value ? 1 : 0;
     } else if (n == "lane_min_batch") {

@@ -298,7 +298,7 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    solved again by the library in larger slices)
  *   scheduling       "solo_min_variants" (5: regions with at least this many calls go to the solo launches), "class_c_nodes_x2" (12: nodes per call a search is priced at
  *                    when class C is decided), "class_c_below" (16384: a batch with lane launches and at most this many regions outside them plans those regions for the
- *                    wave-cooperative kernel — a contig, a rank's shard), "het_search_min" (6: regions with that many unphased heterozygous calls are class C),
+ *                    wave-cooperative kernel — a contig, a rank's shard),
  *                    "lds_escalation" (1: in-workgroup escalation of the bulk launch), "static_pct" (75: share of a launch's work list dealt statically), "claim" (2:
  *                    regions per dynamic claim)
  *   lane kernels     "lane_kernel" (1: regions with at most three calls per side on a short window are solved one per LANE, avk_lane.inl / four lanes per region,
@@ -313,7 +313,10 @@ int  avk_ctx_set_stream(avk_ctx *ctx, void *hip_stream);
  *                    "team_head_regions" (48: how many regions that head has)
  *   boundary         "device_pack" (1: batches are validated, classified, ordered and written in the kernels' layout on the device, avk_devpack.inl; 0: by host threads,
  *                    avk_pack.h — same records either way), "packed_source" (1: an avk_packed_batch is packed from the packed arrays themselves; 0: from a wide copy made
- *                    on the device first, round 5), "split_parts" (1; 2..4: an avk_compare_packed call of pinned arrays runs as that many batches in flight,
+ *                    on the device first, round 5), "kernel_copies" (1: every synchronous call that copies by DMA engine times its own copies in; in every second process of a box they crawl at half the
+ *                    link's rate, and from the first such call on the pinned arrays of the context's synchronous calls cross the bus by a copy kernel, every lane 16
+ *                    bytes at a time from / to the pinned pages: profiles/r06_copy_engines.txt; 0: always hipMemcpyAsync; 2: always the kernel),
+ *                    "split_parts" (1; 2..4: an avk_compare_packed call of pinned arrays runs as that many batches in flight,
  *                    compare_packed_split — slower than the whole call today, profiles/r06_split_call.txt)
  *   outputs          "emit_group_metrics" (0 = kernels skip the per-region 13 x 22 block; the batch tally is always produced), "emit_bp_groups" (1 = kernels write the
  *                    compact per-region BASEPAIR groups; the one-call entry points switch it on when the caller hands the arrays in), "accumulate_tally" (1 =

@@ -29,7 +29,7 @@ TABLE = {
     "wide_kernel": [1, 1, 0], "wide_lds_bytes": [16384, 8192, 65536, 24576], "wide_retry_lds_bytes": [65536, 0, 32768],
     "device_pack": [1, 1, 0], "use_packed_reference": [1, 1, 1, 0],
     "lane_kernel": [1, 1, 1, 0], "lane_min_regions": [0, 0, 2048], "lane_min_batch": [0, 0, 16384], "lane_width_one": [64, 32, 16, 8, 4], "lane_width_two": [64, 32, 16, 8, 4],
-    "lane_width_three": [16, 8, 4, 32, 64], "lane_head_width": [16, 0, 4, 8, 32, 64], "hbm_ed_cap": [1024, 0, 8], "het_search_min": [6, 0, 3, 4], "lane_pairs": [1, 0], "lane_node_cap": [32, 8, 250], "lane_quad": [1, 1, 0], "packed_source": [1, 1, 0], "team_long_windows": [1, 1, 0, 2], "team_head_regions": [48, 2, 400],
+    "lane_width_three": [16, 8, 4, 32, 64], "lane_head_width": [16, 0, 4, 8, 32, 64], "hbm_ed_cap": [1024, 0, 8], "lane_pairs": [1, 0], "lane_node_cap": [32, 8, 250], "lane_quad": [1, 1, 0], "packed_source": [1, 1, 0], "kernel_copies": [1, 0, 2], "team_long_windows": [1, 1, 0, 2], "team_head_regions": [48, 2, 400],
 }
 
 
