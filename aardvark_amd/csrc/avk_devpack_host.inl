@@ -697,7 +697,7 @@ static int copy_in(avk_ctx *ctx, const std::vector<CopySeg> &segs) {
     size_t direct_bytes = 0;
     for (const Piece &p : pieces) direct_bytes += p.direct ? p.bytes : 0;
     const bool by_kernel = !ctx->up_stream && direct_bytes >= (8u << 20) && copies_by_kernel(ctx); /* (small batches: the engines' latency is what counts) */
-    const bool timed_engine = !ctx->up_stream && !by_kernel && ctx->kernel_copies == 1 && direct_bytes >= (32u << 20) && staged == 0 && ctx->ev_cp0 && ctx->ev_cp1;
+    const bool timed_engine = !ctx->up_stream && !by_kernel && ctx->kernel_copies == 1 && direct_bytes >= (8u << 20) && staged == 0 && ctx->ev_cp0 && ctx->ev_cp1;
     if (timed_engine) (void)hipEventRecord(ctx->ev_cp0, ctx->stream);
     ctx->cp_timed_bytes = 0;
     auto issue = [&](const Piece &p) -> hipError_t { /* pieces are queued in segment order, whatever their source */
@@ -753,7 +753,7 @@ static void engine_rate_check(avk_ctx *ctx) {
     float ms = 0;
     if (hipEventElapsedTime(&ms, ctx->ev_cp0, ctx->ev_cp1) == hipSuccess && ms > 0) {
         ctx->engine_in_gbs = ctx->cp_timed_bytes / (ms * 1e-3) / 1e9;
-        if (ctx->engine_in_gbs < 36.0) {
+        if (ms > ctx->cp_timed_bytes / 36e9 * 1e3 + 0.15) { /* below 36 GB/s, with 0.15 ms for the dozen copies' own latencies (a rank's shard is 10 MB) */
             ctx->engines_fast = false;
             if (getenv("AVK_TIMING")) fprintf(stderr, "avk copies: the DMA engine moved this call's arrays at %.1f GB/s: synchronous calls copy by kernel from now on\n", ctx->engine_in_gbs);
         }
