@@ -576,9 +576,11 @@ def main():
                  "three calls per side", "looked-up pairs (the same SNV on both sides)"]
         spans = [("class C (large searches: wide kernel, long windows)", 0, n_c), ("class B (solo launches)", n_c, n_b), ("bulk (wave-per-region, LDS tiers)", n_c + n_b, n_regions - n_l - n_c - n_b)]
         for k, (first, cnt, heavy) in enumerate(plan["fast"]):
-            if cnt and k < 5:
+            if cnt and k == 4:  # the whole three-call class runs four lanes per region (16 records per wave)
+                spans.append(("lanes: %s (quads)" % names[k], first, cnt))
+            elif cnt and k < 5:
                 spans.append(("lanes: %s — head (quads)" % names[k], first, heavy))
-                spans.append(("lanes: %s — rest" % names[k], first + heavy, cnt - heavy))
+                spans.append(("lanes: %s — rest (64 per wave)" % names[k], first + heavy, cnt - heavy))
             elif cnt:
                 spans.append(("lanes: %s" % names[k], first, cnt))
         by_class = []
