@@ -1284,12 +1284,13 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     db->d_counters = (uint32_t *)kept((size_t)AVK_N_COUNTERS * 4);
     db->d_overflow = (uint32_t *)kept((n + 1024) * 4);
     db->d_overflow2 = (uint32_t *)kept((n + 1) * 4);
-    db->d_overflow3 = (uint32_t *)kept((n + 1) * 4);
+    db->d_overflow3 = (uint32_t *)kept((2 * (n + 1) + 1024) * 4);
     db->d_overflow4 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow5 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow6 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow7 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow8 = (uint32_t *)kept((n + 1) * 4);
+    db->d_notwide = (uint32_t *)kept((n + 2) * 4);
     if (hs->n_fast_total) db->d_fast = (uint32_t *)kept(((size_t)hs->fast_words + 64) * 4);
     /* the packer's arguments in device memory: the waves that solve handed-back regions write their records themselves */
     if (hs->n_fast_total) db->d_dp_args = (dpk::DpArgs *)kept(sizeof(dpk::DpArgs));

@@ -276,6 +276,17 @@ __global__ void avk_pack_reference(const uint8_t *bytes, uint64_t n_bases, uint3
 
 /* sums the partial tallies into out[0 .. AVK_TALLY_STRIDE) (and the caller's device tally, if any), then clears
  * the partial tallies and the work / overflow counters for the next call on this batch */
+/* The records of class C (work order 0 .. n_c - 1) that are not for avk_wide.inl by what they say themselves (avk_wide_static_ok), as a list: a few dozen among
+ * thousands, each a long search on a wave of the HBM tier.  Their launch used to walk the whole class in claims of four and solved the not-wide records of a claim one
+ * after the other. */
+__global__ void __launch_bounds__(256) avk_notwide_list_kernel(const AvkDevRegion *regions, uint32_t n_c, uint32_t *list, uint32_t *count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_c) return;
+    const AvkDevRegion *g = regions + i;
+    if (avk_wide_static_ok(g->len, g->grow, g->ed_bound, g->t_cnt, g->q_cnt, g->pre_status)) return;
+    list[atomicAdd(count, 1u)] = i;
+}
+
 __global__ void avk_tally_reduce(uint64_t *partials, uint64_t *out, uint64_t *out_user, uint32_t *counters, unsigned n_counters, unsigned accumulate) {
     const unsigned i = blockIdx.x * blockDim.x + threadIdx.x;
     for (unsigned k = i; k < n_counters; k += gridDim.x * blockDim.x) counters[k] = 0;
@@ -308,7 +319,7 @@ struct PoolBlk { /* a device buffer of the context's pool (avk_devpack_host.inl)
 
 } // namespace
 
-#define AVK_N_COUNTERS 1280 /* words of avk_dev_batch::d_counters */
+#define AVK_N_COUNTERS 1408 /* words of avk_dev_batch::d_counters */
 
 struct avk_ctx {
     int device = 0;
@@ -451,6 +462,7 @@ struct avk_ctx {
     hipEvent_t ev_lane_join3 = nullptr, ev_lane_done = nullptr;
     hipStream_t lane_stream4 = nullptr; /* the head launches of the two-call classes (long: beside the rest of their class, not ahead of it) */
     hipEvent_t ev_lane_join4 = nullptr, ev_lane_early = nullptr;
+    hipEvent_t ev_hb[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr}; /* ends of the lane classes' head launches (handback_chains) */
     hipEvent_t ev_tl[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* AVK_TIMING only: marks of a boundary call on the context's stream (first copy, last copy, work order, writers, results) */
     hipEvent_t ev_copy_alleles = nullptr; /* packed upload: behind the allele bytes' copy (dp_variant starts there) */
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
@@ -481,6 +493,8 @@ struct avk_dev_batch {
     uint64_t *d_partials = nullptr; /* [AVK_TALLY_COPIES][AVK_TALLY_STRIDE] */
     uint32_t *d_counters = nullptr; /* [256*t + 32*s] claim counter of shard s in pass t, [1024 + 16*k] overflow counts, [1072] claim counter of the solo waves */
     uint32_t *d_overflow = nullptr, *d_overflow2 = nullptr, *d_overflow3 = nullptr, *d_overflow4 = nullptr;
+    uint32_t *d_notwide = nullptr;   /* [n + 1] class C records that are not avk_wide.inl's, then their number (avk_notwide_list_kernel, once per batch) */
+    bool notwide_ready = false;
     uint32_t *d_overflow8 = nullptr; /* what the second, large-LDS launch of avk_wide.inl over class C's leftovers could not take either */
     uint32_t *d_overflow5 = nullptr, *d_overflow6 = nullptr, *d_overflow7 = nullptr; /* what the launches of avk_wide.inl could not take: of class C, of the three-call lane class's hand-backs, of the other lane classes' */
     avk::WorkPlan plan;
@@ -551,7 +565,7 @@ template <typename T> int dev_alloc(avk_ctx *ctx, T **p, size_t count) {
 void free_batch_buffers(avk_dev_batch *db) {
     if (db->dev_packed) return; /* pooled buffers: release_pooled */
     void *ptrs[] = {db->d_regions, db->d_blob, db->d_region_out, db->d_gm, db->d_var_out,
-                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_overflow7, db->d_overflow8, db->d_fast,
+                    db->d_seq, db->d_seqlen, db->d_tally, db->d_partials, db->d_counters, db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4, db->d_overflow5, db->d_overflow6, db->d_overflow7, db->d_overflow8, db->d_notwide, db->d_fast,
                     db->d_bp_off, db->d_bp};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -657,6 +671,10 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
         hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, evf) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_hb[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_hb[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_hb[2], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_hb[3], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_hb[4], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_hb[5], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_hb[6], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_hb[7], hipEventDisableTiming) != hipSuccess ||
         hipEventCreate(&ctx->ev_cp0) != hipSuccess || hipEventCreate(&ctx->ev_cp1) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_alleles, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_copy_fork, hipEventDisableTiming) != hipSuccess ||
@@ -721,6 +739,8 @@ void avk_ctx_destroy(avk_ctx *ctx) {
     if (ctx->ev_lane_join3) (void)hipEventDestroy(ctx->ev_lane_join3);
     if (ctx->ev_lane_done) (void)hipEventDestroy(ctx->ev_lane_done);
     if (ctx->ev_lane_join4) (void)hipEventDestroy(ctx->ev_lane_join4);
+    for (hipEvent_t e : ctx->ev_hb)
+        if (e) (void)hipEventDestroy(e);
     if (ctx->ev_cp0) (void)hipEventDestroy(ctx->ev_cp0);
     if (ctx->ev_cp1) (void)hipEventDestroy(ctx->ev_cp1);
     if (ctx->ev_copy_alleles) (void)hipEventDestroy(ctx->ev_copy_alleles);
@@ -1149,12 +1169,13 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)AVK_N_COUNTERS));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1024));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
-    AVK_TRY(dev_alloc(ctx, &db->d_overflow3, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow3, 2 * (n + 1) + 1024)); /* (the lanes' hand-backs: a segment per chain and per head launch) */
     AVK_TRY(dev_alloc(ctx, &db->d_overflow4, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow5, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow6, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow7, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow8, n + 1));
+    AVK_TRY(dev_alloc(ctx, &db->d_notwide, n + 2));
 #undef AVK_TRY
     { /* compact BASEPAIR groups: 1 + the region's call types each (none for regions that fail validation), as the device packer counts them */
         std::vector<uint32_t> bp_off(n + 1, 0);
@@ -1503,7 +1524,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     const uint32_t *list = nullptr, *count = nullptr; /* first launch: the records themselves are in work order */
     uint32_t *lists[4] = {db->d_overflow, db->d_overflow2, db->d_overflow3, db->d_overflow4};
     int nlist = 0;
-    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false, hbm_shared = false, wide_x_pending = false;
+    bool solo_pending = false, hbm_solo_pending = false, deferred_pending = false, early_pending = false, hbm_shared = false, wide_x_pending = false, chains = false;
+    hipEvent_t chain_join[4] = {nullptr, nullptr, nullptr, nullptr}; /* handback_chains: the ends of the lane streams' chains, and the launch that follows them at the end of the step */
+    int n_chain_join = 0;
+    AvkKernelArgs chain_d;
+    uint32_t chain_dblocks = 0;
+    memset(&chain_d, 0, sizeof(chain_d));
     uint32_t hbm_shared_base = 0; /* records of class C ahead of the shared list (a team launch has them) */
     for (int t = 0; t < 4 && n; ++t) {
         if (!launch[t]) continue;
@@ -1521,7 +1547,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
         }
         const bool first_launch = list == nullptr; /* ev0 sits right before it */
         if (t >= 2) { /* the HBM launches read the list the LDS solo launch appends to; the tier-1 launch does not */
-            if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+            if (deferred_pending && chains) { /* what the chains' launches of avk_wide.inl left: ahead of the waits for the long solo launches, which it does not depend on */
+        for (int k = 0; k < n_chain_join; ++k) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, chain_join[k], 0));
+        hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(chain_dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ctx->stream, chain_d);
+        AVK_HIP(ctx, hipGetLastError());
+    }
+    if (solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
             solo_pending = false;
             /* the tier-3 launch of its own (big_slots == 0) reads the list the HBM solo launch appends to */
             if (t == 3 && hbm_solo_pending) {
@@ -1569,6 +1600,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             }
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
+            if (hbm_solo && use_wide && !db->notwide_ready) { /* once per batch, ahead of its first step (a launch of 20 workgroups in front of the class's own launch in every
+                                                                 step waited up to 0.2 ms for a place among the persistent waves of the step) */
+                AVK_HIP(ctx, hipMemsetAsync(db->d_notwide + n + 1, 0, sizeof(uint32_t), ctx->stream));
+                hipLaunchKernelGGL(avk_notwide_list_kernel, dim3((n_c + 255u) / 256u), dim3(256), 0, ctx->stream, db->d_regions, n_c, db->d_notwide, db->d_notwide + n + 1);
+                AVK_HIP(ctx, hipGetLastError());
+                db->notwide_ready = true;
+            }
             if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
             bool wide_c = false, wide_x = false;
             if (hbm_solo) {
@@ -1614,7 +1652,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.static_pct = 0;
                         x.n_shards = 1;
                         x.n_waves = xb * waves_per_block;
-                        x.claim = n_c > 64u * x.n_waves ? 4u : 1u; /* (every wave walks its claims of the whole class for the records that are its launch's) */
+                        /* a wave per record, one claim each, from a list made just ahead of the launch (walking the whole class in claims of four, a wave solved the
+                         * records of a claim one after the other: 2.06 -> 1.91 ms for the genome's 27, 0.96 -> 0.90 for a shard's 7) */
+                        x.only_not_wide = 0;
+                        x.work_list = db->d_notwide;
+                        x.n_work_dev = db->d_notwide + n + 1;
+                        x.n_work = 0;
+                        x.claim = 1;
                         x.high_priority = 1;
                         x.hbm_ws = ctx->d_ws + (size_t)(n_waves + (hbm_solo_max - xb) * waves_per_block) * (size_t)ws_bytes; /* the last slices of the solo launch's share (that launch gets the others) */
                         x.big_ws = ctx->d_big;
@@ -1759,6 +1803,44 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 f.overflow_list = lists[2];
                 f.overflow_count = db->d_counters + 1024 + 32;
                 AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_fork, ctx->stream));
+                /* hand-backs per chain: the launches of a lane stream append to a list of the stream's own, a head launch to one of its own; a list is read by a launch
+                 * of avk_wide.inl that follows its writers in stream order (the chain's list: on the chain's stream, no event; a head's: on the fourth lane stream,
+                 * behind the head's event, while the rest of the class runs).  One launch for one list behind ALL lane streams started 60-130 us after the last lane
+                 * launch (three event waits) and lasted as long as its longest region — a head's hand-back, 160-340 us — at the very end of the step. */
+                chains = use_wide && ctx->wide_lane_handbacks && !ctx->lane_head_stream;
+                struct HbSeg {
+                    uint32_t *list, *count, *cursor;
+                };
+                uint32_t hb_off = 0;
+                int hb_n = 0, hb_heads = 0;
+                auto hb_new = [&](uint32_t cap) {
+                    HbSeg g = {lists[2] + hb_off, db->d_counters + 1296 + hb_n, db->d_counters + 1328 + hb_n};
+                    hb_off += cap;
+                    hb_n += 1;
+                    return g;
+                };
+                auto hb_consume = [&](hipStream_t st, const HbSeg &g) {
+                    AvkKernelArgs w = a;
+                    w.work_list = g.list;
+                    w.n_work_dev = g.count;
+                    w.work_base = 0;
+                    w.n_work = 0;
+                    w.work_counter = g.cursor;
+                    w.overflow_list = db->d_overflow7;
+                    w.overflow_count = db->d_counters + 1264;
+                    hipLaunchKernelGGL(avk_wide_kernel_lazy, dim3((uint32_t)ctx->wide_lazy_blocks), dim3(64), (size_t)ctx->wide_lds_bytes, st, w, wa);
+                    return hipGetLastError();
+                };
+                HbSeg chain_seg[2] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+                if (chains) {
+                    uint32_t cap[2] = {0, 0};
+                    for (int fc = 0; fc < lane_k; ++fc) {
+                        const uint32_t mv = fc == AVK_FAST_PAIR ? 1u : AVK_FAST_CLASS[fc].maxv;
+                        if (db->fast_tiles[fc] && mv <= 2) cap[mv == 2 ? 0 : 1] += db->fast_tiles[fc] * 64u;
+                    }
+                    chain_seg[0] = hb_new(cap[0]);
+                    chain_seg[1] = hb_new(cap[1]);
+                }
                 for (int fc = lane_k - 1; fc >= 0; --fc) {
                     if (!db->fast_tiles[fc]) continue;
                     if (fc == AVK_FAST_PAIR && mode == 0 && ctx->lane_pairs) {
@@ -1781,7 +1863,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         uint32_t pg = (uint32_t)ctx->n_cus * (uint32_t)(ctx->pair_blocks_per_cu > 0 ? ctx->pair_blocks_per_cu : 1);
                         const uint32_t claims = (pa.n_tiles + avk::pairs::PAIR_CLAIM - 1) / avk::pairs::PAIR_CLAIM;
                         if (pg > (claims + 3u) / 4u) pg = (claims + 3u) / 4u;
-                        hipLaunchKernelGGL(avk_pair_kernel, dim3(pg), dim3(256), 0, lstream[li], f, pa);
+                        AvkKernelArgs fp = f;
+                        if (chains) fp.overflow_list = chain_seg[1].list, fp.overflow_count = chain_seg[1].count;
+                        hipLaunchKernelGGL(avk_pair_kernel, dim3(pg), dim3(256), 0, lstream[li], fp, pa);
                         AVK_HIP(ctx, hipGetLastError());
                         continue;
                     }
@@ -1881,16 +1965,37 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                             AVK_HIP(ctx, hipStreamWaitEvent(lstream[hi], ctx->ev_lane_fork, 0));
                             lused[hi] = true;
                         }
-                        launch_lane_class(ctx, hgrid, hlds, lstream[hi], f, hd);
+                        AvkKernelArgs fh = f;
+                        HbSeg hseg = {nullptr, nullptr, nullptr};
+                        const bool staged = chains && hb_heads < 8;
+                        if (staged) {
+                            hseg = hb_new(head_tiles * 64u);
+                            fh.overflow_list = hseg.list, fh.overflow_count = hseg.count;
+                        } else if (chains) {
+                            fh.overflow_list = chain_seg[li].list, fh.overflow_count = chain_seg[li].count;
+                        }
+                        launch_lane_class(ctx, hgrid, hlds, lstream[hi], fh, hd);
                         AVK_HIP(ctx, hipGetLastError());
+                        if (staged) { /* its hand-backs: solved beside the rest of the class */
+                            AVK_HIP(ctx, hipEventRecord(ctx->ev_hb[hb_heads], lstream[hi]));
+                            AVK_HIP(ctx, hipStreamWaitEvent(lstream[3], ctx->ev_hb[hb_heads], 0));
+                            lused[3] = true; /* (its first command waits for an event behind ev_lane_fork) */
+                            AVK_HIP(ctx, hb_consume(lstream[3], hseg));
+                            hb_heads += 1;
+                        }
                         la.recs += (size_t)head_tiles * la.rec_words * 64u;
                         la.n_tiles -= head_tiles;
                         la.gen_base += head_tiles * 64u;
                         if (grid > la.n_tiles) grid = la.n_tiles;
                     }
-                    launch_lane_class(ctx, grid, lds, lstream[li], f, la);
+                    AvkKernelArgs fr = f;
+                    if (chains) fr.overflow_list = chain_seg[li].list, fr.overflow_count = chain_seg[li].count;
+                    launch_lane_class(ctx, grid, lds, lstream[li], fr, la);
                     AVK_HIP(ctx, hipGetLastError());
                 }
+                if (chains)
+                    for (int li = 0; li < 2; ++li)
+                        if (lused[li]) AVK_HIP(ctx, hb_consume(lstream[li], chain_seg[li]));
                 for (int li = 0; li < N_LS; ++li) {
                     if (!lused[li]) continue;
                     if (!ljoined[li]) AVK_HIP(ctx, hipEventRecord(ljoin[li], lstream[li]));
@@ -1926,15 +2031,20 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 AVK_HIP(ctx, hipGetLastError());
                 const int di = lused[1] ? 1 : (lused[0] ? 0 : 2);
                 hipStream_t ds = lstream[di];
-                for (int li = 0; li < N_LS; ++li)
-                    if (li != di && lused[li]) AVK_HIP(ctx, hipStreamWaitEvent(ds, ljoin[li], 0));
+                if (chains) { /* every list has been through avk_wide.inl on its own stream; what that left is for the caller's stream at the end of the step (below) */
+                    for (int li = 0; li < N_LS; ++li)
+                        if (lused[li]) chain_join[n_chain_join++] = ljoin[li];
+                } else {
+                    for (int li = 0; li < N_LS; ++li)
+                        if (li != di && lused[li]) AVK_HIP(ctx, hipStreamWaitEvent(ds, ljoin[li], 0));
+                }
                 AvkKernelArgs d = a;
-                d.work_list = lists[2];
-                d.n_work_dev = db->d_counters + 1024 + 32;
+                d.work_list = chains ? db->d_overflow7 : lists[2];
+                d.n_work_dev = chains ? db->d_counters + 1264 : db->d_counters + 1024 + 32;
                 d.work_base = 0;
                 d.n_work = 0;
                 d.work_counter = db->d_counters + 768;
-                if (use_wide && ctx->wide_lane_handbacks) { /* small windows, whatever made the lanes give up: avk_wide.inl first, the LDS launch takes what is left */
+                if (!chains && use_wide && ctx->wide_lane_handbacks) { /* small windows, whatever made the lanes give up: avk_wide.inl first, the LDS launch takes what is left */
                     AvkKernelArgs w = d;
                     w.work_counter = db->d_counters + 1260;
                     w.overflow_list = db->d_overflow7;
@@ -1948,9 +2058,14 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                 d.n_waves = dblocks * waves_per_block;
                 d.overflow_list = lists[1];
                 d.overflow_count = db->d_counters + 1024 + 16;
-                hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ds, d);
-                AVK_HIP(ctx, hipGetLastError());
-                AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_done, ds)); /* everything of the lane streams is behind this record */
+                if (chains) {
+                    chain_d = d;
+                    chain_dblocks = dblocks;
+                } else {
+                    hipLaunchKernelGGL(avk_region_kernel_lds_lazy, dim3(dblocks), dim3(256), (size_t)waves_per_block * (size_t)ctx->lds_bytes_per_wave, ds, d);
+                    AVK_HIP(ctx, hipGetLastError());
+                    AVK_HIP(ctx, hipEventRecord(ctx->ev_lane_done, ds)); /* everything of the lane streams is behind this record */
+                }
                 deferred_pending = true;
                 early_pending = early_used;
             }
@@ -1993,7 +2108,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
     if (hbm_solo_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_join2, 0));
     if (wide_x_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_wide, 0));
     if (deferred_pending) { /* the lane streams (lane launches, then the handed-back regions) join here; what even the escalation could not hold */
-        AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_done, 0));
+        if (!chains) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_done, 0));
         if (early_pending) AVK_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->ev_lane_early, 0));
         AvkKernelArgs h = a;
         h.pass_tier = 2;

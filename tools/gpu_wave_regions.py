@@ -10,6 +10,9 @@ from aardvark_amd import synth, CompareConfig
 scale = float(sys.argv[1]) if len(sys.argv) > 1 else 0.25
 gap = int(os.environ.get("GAP", "50"))  # GAP=1000 with scale 0.05: the large-window leg of bench.py
 contigs, batch = synth.config_genome(scale=scale, gap=gap) if gap != 50 else synth.config_genome(scale=scale)
+if os.environ.get("SHARD"):  # SHARD=8: rank 0's hash shard of an 8-rank job
+    from aardvark_amd import dist
+    batch = dist.gather_calls(dist.shard_batch(batch, 0, int(os.environ["SHARD"])))
 ctx = aardvark_amd.Context(0)
 ctx.set_option("emit_group_metrics", 1)
 for kv in (sys.argv[2] if len(sys.argv) > 2 else "").split(","):
