@@ -319,7 +319,8 @@ struct PoolBlk { /* a device buffer of the context's pool (avk_devpack_host.inl)
 
 } // namespace
 
-#define AVK_N_COUNTERS 1408 /* words of avk_dev_batch::d_counters */
+#define AVK_N_COUNTERS 1408
+#define AVK_STREAM_ORDER_DEFAULT "stwxxabxxcd" /* profiles/r06_stream_order.txt */ /* words of avk_dev_batch::d_counters */
 
 struct avk_ctx {
     int device = 0;
@@ -641,35 +642,28 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
         if (!pe || strcmp(pe, "high") != 0) prio_high = 0;
     }
     const unsigned evf = getenv("AVK_TIMING") ? hipEventDefault : hipEventDisableTiming; /* the events that end the launch chains can be read when the stage timing is on */
-    /* The runtime hands streams their hardware queues in the order they are made, and which launches share a queue's pipe shows in the step: two streams that nothing
-     * is ever queued on, made behind the wide stream, are worth 0.3 ms of a 1.6 ms shard step and 0.04 of chr20's 0.33 (they were the streams of an option that was
-     * taken out in round 5; profiles/r05_stream_order.txt).  AVK_SPARE_STREAMS=a,b,c makes a / b / c of them in front of the side streams / behind the wide stream /
-     * behind the second lane stream instead (experiments). */
-    int spare_at[4] = {0, 2, 0, 0};
-    if (const char *se = getenv("AVK_SPARE_STREAMS")) (void)sscanf(se, "%d,%d,%d,%d", &spare_at[0], &spare_at[1], &spare_at[2], &spare_at[3]);
+    /* The runtime hands streams their hardware queues in the order they are made, and which launches share a queue's pipe shows in the step: streams that nothing is
+     * ever queued on, made between the others, move a shard's resident step between 1.05 and 1.64 ms and a genome's between 2.38 and 2.95 (profiles/r05_stream_order.txt,
+     * profiles/r06_stream_order.txt: a local search over the order, every candidate in fresh processes).  AVK_STREAM_ORDER: the order the seven side streams are made in,
+     * a letter each — s side, t side2, w wide, a b c d the four lane streams, x a stream nothing is ever queued on. */
+    const char *order = getenv("AVK_STREAM_ORDER") ? getenv("AVK_STREAM_ORDER") : AVK_STREAM_ORDER_DEFAULT;
     int n_spare = 0;
-    auto spare = [&](int k) {
-        bool ok = true;
-        for (int i = 0; i < k && n_spare < 16 && ok; ++i) ok = hipStreamCreateWithPriority(&ctx->spare_stream[n_spare++], hipStreamNonBlocking, prio_high) == hipSuccess;
-        return ok;
-    };
-    if (!spare(spare_at[0]) ||
-        hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->side_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->wide_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        !spare(spare_at[1]) ||
+    bool ok = true;
+    for (const char *o = order; *o && ok; ++o) {
+        hipStream_t *st = *o == 's' ? &ctx->side_stream : *o == 't' ? &ctx->side_stream2 : *o == 'w' ? &ctx->wide_stream : *o == 'a' ? &ctx->lane_stream : *o == 'b' ? &ctx->lane_stream2 :
+                          *o == 'c' ? &ctx->lane_stream3 : *o == 'd' ? &ctx->lane_stream4 : (*o == 'x' && n_spare < 16) ? &ctx->spare_stream[n_spare++] : nullptr;
+        if (st && !*st) ok = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_high) == hipSuccess;
+    }
+    hipStream_t *all[7] = {&ctx->side_stream, &ctx->side_stream2, &ctx->wide_stream, &ctx->lane_stream, &ctx->lane_stream2, &ctx->lane_stream3, &ctx->lane_stream4};
+    for (hipStream_t *st : all) /* (a letter the order left out) */
+        if (ok && !*st) ok = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_high) == hipSuccess;
+    if (!ok ||
         hipEventCreateWithFlags(&ctx->ev_join2, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_wide, evf) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->lane_stream, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->lane_stream2, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        !spare(spare_at[2]) ||
         hipEventCreateWithFlags(&ctx->ev_lane_join2, evf) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->lane_stream3, hipStreamNonBlocking, prio_high) != hipSuccess ||
-        !spare(spare_at[3]) ||
         hipEventCreateWithFlags(&ctx->ev_lane_join3, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_done, evf) != hipSuccess ||
-        hipStreamCreateWithPriority(&ctx->lane_stream4, hipStreamNonBlocking, prio_high) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_lane_join4, evf) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_hb[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_hb[1], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_hb[2], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ctx->ev_hb[3], hipEventDisableTiming) != hipSuccess ||
