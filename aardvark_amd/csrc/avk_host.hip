@@ -617,6 +617,7 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     }
     ctx->n_cus = prop.multiProcessorCount;
     if (const char *e = getenv("AVK_COPY_BLOCKS")) ctx->copy_blocks_per_cu = atoi(e) > 0 ? atoi(e) : ctx->copy_blocks_per_cu;
+    if (const char *e = getenv("AVK_WIDE_BLOCKS")) ctx->wide_blocks = atoi(e) > 0 ? atoi(e) : ctx->wide_blocks;
     if (hipStreamCreate(&ctx->stream) != hipSuccess) {
         delete ctx;
         return fail(nullptr, AVK_E_HIP, "hipStreamCreate failed");
