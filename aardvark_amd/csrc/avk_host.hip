@@ -12,6 +12,7 @@
  * also clears the counters for the next step.
  */
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1284,12 +1285,14 @@ static size_t lane_launch_geometry(const avk_ctx *ctx, const avk::lane::LaneArgs
     return lds;
 }
 /* a launch of a lane class: one lane per region, or four (lane_launch_is_quad) */
-static void launch_lane_class(const avk_ctx *ctx, uint32_t grid, size_t lds, hipStream_t s, const AvkKernelArgs &f, const avk::lane::LaneArgs &la) {
+/* done: an event that fires when THIS launch ends (bound to the launch's own completion signal: an event recorded behind the launch is a packet of its own in the
+ * stream, and the next launch of the chain started 55-60 us later for it) */
+static void launch_lane_class(const avk_ctx *ctx, uint32_t grid, size_t lds, hipStream_t s, const AvkKernelArgs &f, const avk::lane::LaneArgs &la, hipEvent_t done = nullptr) {
     if (lane_launch_is_quad(ctx, la)) {
-        if (lds * 8 > 160 * 1024) hipLaunchKernelGGL(avk_quad_kernel_wide_regs, dim3(grid), dim3(64), lds, s, f, la); /* fewer than eight workgroups per CU by LDS: registers to spare */
-        else hipLaunchKernelGGL(avk_quad_kernel, dim3(grid), dim3(64), lds, s, f, la);
+        if (lds * 8 > 160 * 1024) hipExtLaunchKernelGGL(avk_quad_kernel_wide_regs, dim3(grid), dim3(64), lds, s, nullptr, done, 0, f, la); /* fewer than eight workgroups per CU by LDS: registers to spare */
+        else hipExtLaunchKernelGGL(avk_quad_kernel, dim3(grid), dim3(64), lds, s, nullptr, done, 0, f, la);
     }
-    else hipLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, s, f, la);
+    else hipExtLaunchKernelGGL(avk_lane_kernel, dim3(grid), dim3(64), lds, s, nullptr, done, 0, f, la);
 }
 
 /* The table of avk_pairs.inl for this max_branch_factor, on `s`: sixteen probe regions through the lane kernel, outputs redirected into the table.
@@ -1595,13 +1598,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             }
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
-            if (hbm_solo && use_wide && !db->notwide_ready) { /* once per batch, ahead of its first step (a launch of 20 workgroups in front of the class's own launch in every
-                                                                 step waited up to 0.2 ms for a place among the persistent waves of the step) */
-                AVK_HIP(ctx, hipMemsetAsync(db->d_notwide + n + 1, 0, sizeof(uint32_t), ctx->stream));
-                hipLaunchKernelGGL(avk_notwide_list_kernel, dim3((n_c + 255u) / 256u), dim3(256), 0, ctx->stream, db->d_regions, n_c, db->d_notwide, db->d_notwide + n + 1);
-                AVK_HIP(ctx, hipGetLastError());
-                db->notwide_ready = true;
-            }
             if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
             bool wide_c = false, wide_x = false;
             if (hbm_solo) {
@@ -1662,6 +1658,13 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.overflow_list = nullptr;
                         x.overflow_count = nullptr;
                         AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
+                        if (!db->notwide_ready) { /* once per batch, at the head of its first step (made in every step, the list's 20 workgroups once waited 0.2 ms for
+                                                     a place among the persistent waves of the steps queued before) */
+                            AVK_HIP(ctx, hipMemsetAsync(db->d_notwide + n + 1, 0, sizeof(uint32_t), ctx->wide_stream));
+                            hipLaunchKernelGGL(avk_notwide_list_kernel, dim3((n_c + 255u) / 256u), dim3(256), 0, ctx->wide_stream, db->d_regions, n_c, db->d_notwide, db->d_notwide + n + 1);
+                            AVK_HIP(ctx, hipGetLastError());
+                            db->notwide_ready = true;
+                        }
                         /* (a wave per region here: these long windows hold a handful of calls, their searches are short chains where a team's hand-overs cost more
                          * than its parallel pieces give — shard 1.19 -> 1.31 ms, dense mix 2.29 -> 2.53 with teams, profiles/r06_team.txt) */
                         hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
@@ -1962,17 +1965,16 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         }
                         AvkKernelArgs fh = f;
                         HbSeg hseg = {nullptr, nullptr, nullptr};
-                        const bool staged = chains && hb_heads < 8;
+                        const bool staged = chains && hb_heads < 8 && (cl.maxv == 2 || getenv("AVK_STAGE_ALL_HEADS")); /* (the one-call heads are short: their hand-backs wait for the chain's end) */
                         if (staged) {
                             hseg = hb_new(head_tiles * 64u);
                             fh.overflow_list = hseg.list, fh.overflow_count = hseg.count;
                         } else if (chains) {
                             fh.overflow_list = chain_seg[li].list, fh.overflow_count = chain_seg[li].count;
                         }
-                        launch_lane_class(ctx, hgrid, hlds, lstream[hi], fh, hd);
+                        launch_lane_class(ctx, hgrid, hlds, lstream[hi], fh, hd, staged ? ctx->ev_hb[hb_heads] : nullptr);
                         AVK_HIP(ctx, hipGetLastError());
                         if (staged) { /* its hand-backs: solved beside the rest of the class */
-                            AVK_HIP(ctx, hipEventRecord(ctx->ev_hb[hb_heads], lstream[hi]));
                             AVK_HIP(ctx, hipStreamWaitEvent(lstream[3], ctx->ev_hb[hb_heads], 0));
                             lused[3] = true; /* (its first command waits for an event behind ev_lane_fork) */
                             AVK_HIP(ctx, hb_consume(lstream[3], hseg));
