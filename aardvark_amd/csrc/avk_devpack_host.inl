@@ -1284,7 +1284,7 @@ static int upload_device_packed(avk_ctx *ctx, const avk_region_batch *b, const a
     db->d_counters = (uint32_t *)kept((size_t)AVK_N_COUNTERS * 4);
     db->d_overflow = (uint32_t *)kept((n + 1024) * 4);
     db->d_overflow2 = (uint32_t *)kept((n + 1) * 4);
-    db->d_overflow3 = (uint32_t *)kept((2 * (n + 1) + 1024) * 4);
+    db->d_overflow3 = (uint32_t *)kept((3 * (n + 1) + 1024) * 4);
     db->d_overflow4 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow5 = (uint32_t *)kept((n + 1) * 4);
     db->d_overflow6 = (uint32_t *)kept((n + 1) * 4);

@@ -1165,7 +1165,7 @@ static int upload_internal(avk_ctx *ctx, const avk_region_batch *batch, bool pai
     AVK_TRY(dev_alloc(ctx, &db->d_counters, (size_t)AVK_N_COUNTERS));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow, n + 1024));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow2, n + 1));
-    AVK_TRY(dev_alloc(ctx, &db->d_overflow3, 2 * (n + 1) + 1024)); /* (the lanes' hand-backs: a segment per chain and per head launch) */
+    AVK_TRY(dev_alloc(ctx, &db->d_overflow3, 3 * (n + 1) + 1024)); /* (the lanes' hand-backs: a segment per chain, per head launch and for the looked-up pairs) */
     AVK_TRY(dev_alloc(ctx, &db->d_overflow4, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow5, n + 1));
     AVK_TRY(dev_alloc(ctx, &db->d_overflow6, n + 1));
@@ -1845,7 +1845,9 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         /* looked up, not searched (avk_pairs.inl): first on the stream of the one-call classes, BESIDE everything else.  (Alone it needs 0.18 ms;
                          * beside the persistent waves of the other launches its workgroups wait for wave slots and it lasts 1.1 ms — in their shadow, which
                          * measured better than 0.18 ms ahead of them: 3.95 against 4.2 ms per whole-genome step.) */
-                        const int li = 1;
+                        /* (AVK_PAIRS_OWN_STREAM=1: on the fourth lane stream with a hand-back list of its own, the one-call chain not waiting for it — a shard's step
+                         * 1.04 -> 1.00 ms, a genome's 2.33 -> 2.39: profiles/r06_handback_chains.txt) */
+                        const int li = chains && getenv("AVK_PAIRS_OWN_STREAM") ? 3 : 1;
                         if (!lused[li]) {
                             AVK_HIP(ctx, hipStreamWaitEvent(lstream[li], ctx->ev_lane_fork, 0));
                             lused[li] = true;
@@ -1862,9 +1864,12 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         const uint32_t claims = (pa.n_tiles + avk::pairs::PAIR_CLAIM - 1) / avk::pairs::PAIR_CLAIM;
                         if (pg > (claims + 3u) / 4u) pg = (claims + 3u) / 4u;
                         AvkKernelArgs fp = f;
-                        if (chains) fp.overflow_list = chain_seg[1].list, fp.overflow_count = chain_seg[1].count;
+                        HbSeg pseg = chain_seg[1];
+                        if (chains && li == 3) pseg = hb_new(pa.n_tiles * 64u);
+                        if (chains) fp.overflow_list = pseg.list, fp.overflow_count = pseg.count;
                         hipLaunchKernelGGL(avk_pair_kernel, dim3(pg), dim3(256), 0, lstream[li], fp, pa);
                         AVK_HIP(ctx, hipGetLastError());
+                        if (chains && li == 3) AVK_HIP(ctx, hb_consume(lstream[li], pseg));
                         continue;
                     }
                     /* (the looked-up class in merge mode or with the option off: its records are those of a one-call class) */
