@@ -656,6 +656,14 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
                           *o == 'c' ? &ctx->lane_stream3 : *o == 'd' ? &ctx->lane_stream4 : (*o == 'x' && n_spare < 16) ? &ctx->spare_stream[n_spare++] : nullptr;
         if (st && !*st) ok = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_high) == hipSuccess;
     }
+    /* the placeholders have done their work once the others exist: the streams made behind them keep their place, and a process that held on to four idle streams
+     * pushed a second process on the same GPU over the number of hardware queues the scheduler maps at a time — the tool's solve stage 0.02 -> 0.10-0.21 s beside
+     * bench.py's own context (profiles/r06_stream_order.txt).  AVK_KEEP_SPARES=1 keeps them (to reproduce that). */
+    if (!getenv("AVK_KEEP_SPARES"))
+        for (int k = 0; k < n_spare; ++k) {
+            if (ctx->spare_stream[k]) (void)hipStreamDestroy(ctx->spare_stream[k]);
+            ctx->spare_stream[k] = nullptr;
+        }
     hipStream_t *all[7] = {&ctx->side_stream, &ctx->side_stream2, &ctx->wide_stream, &ctx->lane_stream, &ctx->lane_stream2, &ctx->lane_stream3, &ctx->lane_stream4};
     for (hipStream_t *st : all) /* (a letter the order left out) */
         if (ok && !*st) ok = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_high) == hipSuccess;
