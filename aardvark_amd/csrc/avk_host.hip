@@ -470,6 +470,7 @@ struct avk_ctx {
     hipEvent_t ev_copy_fork = nullptr, ev_copy_mid = nullptr, ev_copy_join = nullptr; /* packed upload: all but the counts cross on lane_stream4 beside the offset kernels */
     hipStream_t side_stream = nullptr, side_stream2 = nullptr; /* solo launches (LDS, HBM): one stream each, they run side by side */
     hipStream_t spare_stream[16] = {nullptr}; /* never used: see avk_ctx_create */
+    int n_placeholders = 0;                   /* how many of them avk_ctx_create made (and destroyed again) */
     hipStream_t wide_stream = nullptr; /* the class C records that are not for the wide kernel (run_internal) */
     std::thread reaper; /* releases the buffers of the last large batch behind the caller (avk_batch_free) */
     std::mutex reaper_mutex;
@@ -647,18 +648,21 @@ int avk_ctx_create(int device_id, avk_ctx **out) {
     /* The runtime hands streams their hardware queues in the order they are made, and which launches share a queue's pipe shows in the step: streams that nothing is
      * ever queued on, made between the others, move a shard's resident step between 1.05 and 1.64 ms and a genome's between 2.38 and 2.95 (profiles/r05_stream_order.txt,
      * profiles/r06_stream_order.txt: a local search over the order, every candidate in fresh processes).  AVK_STREAM_ORDER: the order the seven side streams are made in,
-     * a letter each — s side, t side2, w wide, a b c d the four lane streams, x a stream nothing is ever queued on. */
+     * a letter each — s side, t side2, w wide, a b c d the four lane streams, x a stream nothing is ever queued on; i o p q: the copy-in, copy-out, packing and
+     * packing-side streams of the asynchronous calls (made at the first submit when the order does not name them). */
     const char *order = getenv("AVK_STREAM_ORDER") ? getenv("AVK_STREAM_ORDER") : AVK_STREAM_ORDER_DEFAULT;
     int n_spare = 0;
     bool ok = true;
     for (const char *o = order; *o && ok; ++o) {
         hipStream_t *st = *o == 's' ? &ctx->side_stream : *o == 't' ? &ctx->side_stream2 : *o == 'w' ? &ctx->wide_stream : *o == 'a' ? &ctx->lane_stream : *o == 'b' ? &ctx->lane_stream2 :
-                          *o == 'c' ? &ctx->lane_stream3 : *o == 'd' ? &ctx->lane_stream4 : (*o == 'x' && n_spare < 16) ? &ctx->spare_stream[n_spare++] : nullptr;
+                          *o == 'c' ? &ctx->lane_stream3 : *o == 'd' ? &ctx->lane_stream4 : *o == 'i' ? &ctx->copy_in_stream : *o == 'o' ? &ctx->copy_out_stream :
+                          *o == 'p' ? &ctx->pack_stream : *o == 'q' ? &ctx->pack_side_stream : (*o == 'x' && n_spare < 16) ? &ctx->spare_stream[n_spare++] : nullptr;
         if (st && !*st) ok = hipStreamCreateWithPriority(st, hipStreamNonBlocking, prio_high) == hipSuccess;
     }
     /* the placeholders have done their work once the others exist: the streams made behind them keep their place, and a process that held on to four idle streams
      * pushed a second process on the same GPU over the number of hardware queues the scheduler maps at a time — the tool's solve stage 0.02 -> 0.10-0.21 s beside
      * bench.py's own context (profiles/r06_stream_order.txt).  AVK_KEEP_SPARES=1 keeps them (to reproduce that). */
+    ctx->n_placeholders = n_spare;
     if (!getenv("AVK_KEEP_SPARES"))
         for (int k = 0; k < n_spare; ++k) {
             if (ctx->spare_stream[k]) (void)hipStreamDestroy(ctx->spare_stream[k]);
@@ -2577,10 +2581,24 @@ struct avk_ticket {
 };
 
 static int stage_slot_prepare(avk_ctx *ctx, avk_ctx::StageSlot &sl, size_t bytes) {
-    if (!ctx->copy_in_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_in_stream, hipStreamNonBlocking));
-    if (!ctx->copy_out_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->copy_out_stream, hipStreamNonBlocking));
-    if (!ctx->pack_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->pack_stream, hipStreamNonBlocking));
-    if (!ctx->pack_side_stream) AVK_HIP(ctx, hipStreamCreateWithFlags(&ctx->pack_side_stream, hipStreamNonBlocking));
+    if (!ctx->copy_in_stream || !ctx->copy_out_stream || !ctx->pack_stream || !ctx->pack_side_stream) {
+        /* the four streams of the asynchronous calls, made at the first submit (a context that never submits does not hold their hardware queues: two processes on a
+         * GPU with twelve streams each are more than the scheduler maps at a time).  The placeholders of avk_ctx_create are gone by now and their queues would be the
+         * first to be handed out again — to these four, which then sit exactly where nothing was meant to (two genomes in flight: 4.8 ms per genome instead of 4.4):
+         * the placeholders are made again for the moment, as they were when the order was searched. */
+        hipStream_t ph[16];
+        int n_ph = 0;
+        if (!getenv("AVK_KEEP_SPARES"))
+            for (; n_ph < ctx->n_placeholders && n_ph < 16; ++n_ph)
+                if (hipStreamCreateWithFlags(&ph[n_ph], hipStreamNonBlocking) != hipSuccess) break;
+        hipError_t e = hipSuccess;
+        if (!ctx->copy_in_stream) e = hipStreamCreateWithFlags(&ctx->copy_in_stream, hipStreamNonBlocking);
+        if (e == hipSuccess && !ctx->copy_out_stream) e = hipStreamCreateWithFlags(&ctx->copy_out_stream, hipStreamNonBlocking);
+        if (e == hipSuccess && !ctx->pack_stream) e = hipStreamCreateWithFlags(&ctx->pack_stream, hipStreamNonBlocking);
+        if (e == hipSuccess && !ctx->pack_side_stream) e = hipStreamCreateWithFlags(&ctx->pack_side_stream, hipStreamNonBlocking);
+        for (int k = 0; k < n_ph; ++k) (void)hipStreamDestroy(ph[k]);
+        AVK_HIP(ctx, e);
+    }
     if (!ctx->ev_packed) AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_packed, hipEventDisableTiming));
     if (!ctx->ev_pool_fence) AVK_HIP(ctx, hipEventCreateWithFlags(&ctx->ev_pool_fence, hipEventDisableTiming));
     if (!sl.ev_in) {
