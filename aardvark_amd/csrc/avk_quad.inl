@@ -854,7 +854,18 @@ AVK_DEV void quad_worker(const AvkKernelArgs &a, const LaneArgs &la, u32 wave_id
 #ifdef AVK_LANE_PHASE_TIMING
         c.tlast = avk_clock();
 #endif
+#ifdef AVK_QUAD_REGION_TICKS /* profiling build (tools/gpu_quad_regions.py): what every region costs its quad, by phase, in the unused last group of its metric block */
+        u64 qr_ph0[6];
+        for (int j = 0; j < 6; ++j) qr_ph0[j] = c.tph[j];
+        const u64 qr_t0 = avk_clock();
+#endif
         const int st = solve_quad(a, c, q, rec, 64u, dyn_rows, la.max_ed_c, out, wg_tally);
+#ifdef AVK_QUAD_REGION_TICKS /* (the two distances of the region's record carry the tile's ticks / 16 and those of its phasing search instead: results of this build are not results) */
+        if (st == AVK_ST_OK) {
+            out.ed1 = (u32)((avk_clock() - qr_t0) >> 4) | 0x40000000u;
+            out.ed2 = (u32)((c.tph[1] - qr_ph0[1]) >> 4) | (la.nm << 28);
+        }
+#endif
 #ifdef AVK_LANE_PHASE_TIMING
         c.tph[6] += avk_clock() - t_tile0;
 #endif
