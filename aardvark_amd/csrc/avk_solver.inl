@@ -566,16 +566,17 @@ template <bool is_truth> AVK_DEV bool hap_extend_seq_t(const Ctx &c, const HapPt
     const u32 s3 = rp;
     const u32 n3 = rp < sync ? sync - rp : 0;
     if (rp < sync) rp = sync;
-    /* everything lives in the wave's workspace: sources and destinations are 32-bit offsets from its base */
-    const u32 ref_o = (u32)(c.ref - c.ws), alle_o = (u32)(c.alle - c.ws) + v.a_off + v.a0_len;
-    const u32 ts_o = (u32)(ts - c.ws) + tl, os_o = (u32)(os - c.ws) + ol;
+    /* (sources — the window and the allele bytes — are the region's, destinations the record's: a genotype search dealt to a sibling wave keeps its records in
+     * that wave's own slice, which may be any distance from the region's workspace: pointers, not 32-bit offsets from one base) */
+    const u8 *const ref_p = c.ref, *const alle_p = c.alle + v.a_off + v.a0_len;
+    u8 *const ts_p = ts + tl, *const os_p = os + ol;
     const u32 total = n_o + n1 + n2 + n3;
     for (u32 j = lane; j < total; j += 64) {
         const bool other = j < n_o;
         const u32 k = j - n_o; /* index on this side (meaningless when `other`) */
-        const u32 so = other ? ref_o + s_o + j : (k < n1 ? ref_o + s1 + k : (k < n1 + n2 ? alle_o + (k - n1) : ref_o + s3 + (k - n1 - n2)));
-        const u32 dof = other ? os_o + j : ts_o + k;
-        c.ws[dof] = c.ws[so];
+        const u8 *sp = other ? ref_p + s_o + j : (k < n1 ? ref_p + s1 + k : (k < n1 + n2 ? alle_p + (k - n1) : ref_p + s3 + (k - n1 - n2)));
+        u8 *dp = other ? os_p + j : ts_p + k;
+        *dp = *sp;
     }
     ol += n_o;
     if (n_o) orp = sync;
@@ -807,7 +808,7 @@ AVK_DEV void queue_reload(Ctx &c) {
  * What a job reads and writes is the owner's workspace (global memory, the same CU's L1) and, for the metrics, the sibling's own scratch.  Children are made
  * OUT OF PLACE — child record = copy of the parent's record, extended — so the jobs of a pop never touch each other's bytes; the popped node is freed instead
  * of becoming the second clone.  Node contents, ids, costs and pop order are those of the one-wave search: the results are bit-identical. */
-enum { TJ_HAP = 1, TJ_ED = 2, TJ_FILT = 3 };
+enum { TJ_HAP = 1, TJ_ED = 2, TJ_FILT = 3, TJ_GT = 4 };
 enum { TJF_FINAL = 1 };
 enum { TEAM_JOBS = 36 };
 struct TeamJob {
@@ -824,10 +825,13 @@ struct TeamBox {
     u32 done, quit, ver, pad_[3];
     /* what a sibling needs of the owner's Ctx (published once per region attempt, `ver` counts them) */
     u64 ws, ref, vars, alle, ovars;
-    u32 L, T, Q, N, seqcap, wfcap, alw, hapA_bytes, wfs_cap, pad2_[3];
+    u32 L, T, Q, N, seqcap, wfcap, alw, hapA_bytes, wfs_cap, hapB_bytes, nodeB_bytes, qcap;
+    u64 own_poolB; /* TJ_GT on the owner: the first node of its phase-B pool */
+    u64 pad3_;
     TeamJob job[TEAM_JOBS];
 };
 AVK_DEV u32 gen_filtered(const Ctx &c, u32 v0, u32 cnt, const u64 *alt, u32 ftype, u8 *out, u32 &failed_ed);
+AVK_DEV int phaseB(Ctx &c, const u64 *in_talt, const u64 *in_qalt, u64 *res, u32 cutoff);
 AVK_DEV u32 team_sup_type(u32 s) {
     return s == 0 ? (u32)AVK_VT_SNV : (s == 1 ? (u32)AVK_VT_INSERTION : (s == 2 ? (u32)AVK_VT_DELETION : (s == 3 ? (u32)AVK_VT_INDEL : (s == 4 ? (u32)AVK_VT_TR_CONTRACTION :
            (s == 5 ? (u32)AVK_VT_TR_EXPANSION : (s == 6 ? (u32)AVK_VT_SV_DELETION : (u32)AVK_VT_SV_INSERTION))))));
@@ -838,6 +842,7 @@ AVK_DEV void team_publish(Ctx &c) { /* owner, after the workspace is carved */
     if (wv_lane() == 0) {
         b->ws = (u64)c.ws, b->ref = (u64)c.ref, b->vars = (u64)c.vars, b->alle = (u64)c.alle, b->ovars = (u64)c.ovars;
         b->L = c.L, b->T = c.T, b->Q = c.Q, b->N = c.N, b->seqcap = c.seqcap, b->wfcap = c.wfcap, b->alw = c.alw, b->hapA_bytes = c.hapA_bytes, b->wfs_cap = c.wfs_cap;
+        b->hapB_bytes = c.hapB_bytes, b->nodeB_bytes = c.nodeB_bytes, b->qcap = c.qcap;
         avk_wg_store(&b->ver, avk_wg_load(&b->ver) + 1u);
     }
     wv_sync();
@@ -878,6 +883,26 @@ AVK_DEV_NOINLINE void team_exec(const Ctx &hc, TeamBox *b, u32 j) {
         wv_sync();
     } else if (kind == TJ_ED) {
         r0 = wfa_ed(hc, (const u8 *)wv_uni64(jb->src), wv_uni(jb->x0), (const u8 *)wv_uni64(jb->dst), wv_uni(jb->x1));
+    } else if (kind == TJ_GT) { /* optimize_gt_alleles for one haplotype of an optimum (exact_gt_optimizer.rs:108-357): a search of its own, in a pool of its own */
+        Ctx lc = hc;
+        u64 *me = (u64 *)wv_uni64(jb->src); /* a memo entry: [talt | qalt | result truth | result query] */
+        lc.node_bytes = hc.nodeB_bytes;
+        if (wv_uni(jb->x1)) { /* the owner: its own phase-B pool and queue arrays */
+            lc.pool_base = (u8 *)wv_uni64(b->own_poolB);
+            lc.pool_cap = wv_uni(jb->x0);
+        } else { /* a sibling: queue, free list and nodes in its scratch slice */
+            u8 *sc = (u8 *)hc.wfs;
+            const u32 qc = hc.qcap;
+            lc.qkeys = (u64 *)sc;
+            lc.qslots = (u32 *)(sc + 8ull * qc);
+            lc.freelist = lc.qslots + qc;
+            const u64 off = AVK_ALIGN16(16ull * qc);
+            lc.pool_base = sc + off;
+            u64 cap = hc.team_scratch_bytes > off && hc.nodeB_bytes ? (hc.team_scratch_bytes - off) / hc.nodeB_bytes : 0;
+            if (cap > qc) cap = qc;
+            lc.pool_cap = (u32)cap;
+        }
+        r0 = phaseB(lc, me, me + hc.alw, me + 2ull * hc.alw, 0xFFFFFFFFu);
     } else { /* TJ_FILT: one side of one call type on one haplotype of the winner (waffle_solver.rs:383-445) */
         const HapPtr wp = hap_ptr((u8 *)wv_uni64(jb->src), hc.alw, hc.wfcap, hc.seqcap);
         const HapHdr hd = hap_load(wp.w);
@@ -943,7 +968,7 @@ AVK_DEV void team_helper(TeamBox *b, u8 *scratch, u64 scratch_bytes, u32 wave_in
     u32 my_gen = 0, my_ver = 0;
     Ctx hc;
     hc.team = (TeamBox *)0, hc.team_gen = 0, hc.team_scratch_bytes = 0, hc.team_mode = 0, hc.team_dbg = (u32 *)0, hc.team_waves = 0;
-    hc.L = hc.T = hc.Q = hc.N = hc.seqcap = hc.wfcap = hc.alw = hc.hapA_bytes = hc.wfs_cap = 0;
+    hc.L = hc.T = hc.Q = hc.N = hc.seqcap = hc.wfcap = hc.alw = hc.hapA_bytes = hc.wfs_cap = hc.hapB_bytes = hc.nodeB_bytes = hc.qcap = 0;
     hc.ws = (u8 *)0, hc.ref = (const u8 *)0, hc.vars = (LVar *)0, hc.alle = (u8 *)0, hc.ovars = (const AvkOrdVar *)0, hc.wfs = (u32 *)0, hc.seq_a = (u8 *)0;
     for (;;) {
         u32 v = 0, q = 0;
@@ -966,9 +991,11 @@ AVK_DEV void team_helper(TeamBox *b, u8 *scratch, u64 scratch_bytes, u32 wave_in
             hc.ovars = (const AvkOrdVar *)wv_uni64(b->ovars);
             hc.L = wv_uni(b->L), hc.T = wv_uni(b->T), hc.Q = wv_uni(b->Q), hc.N = wv_uni(b->N), hc.seqcap = wv_uni(b->seqcap), hc.wfcap = wv_uni(b->wfcap), hc.alw = wv_uni(b->alw);
             hc.hapA_bytes = wv_uni(b->hapA_bytes), hc.wfs_cap = wv_uni(b->wfs_cap);
+            hc.hapB_bytes = wv_uni(b->hapB_bytes), hc.nodeB_bytes = wv_uni(b->nodeB_bytes), hc.qcap = wv_uni(b->qcap);
+            hc.team_scratch_bytes = scratch_bytes;
             hc.wfs = (u32 *)scratch;
             hc.seq_a = scratch + 4ull * hc.wfs_cap;
-            (void)scratch_bytes; /* (the owner posts metrics jobs only when 4 wfs_cap + seqcap fits: Ctx::team_scratch_bytes) */
+            /* (the owner posts metrics jobs only when 4 wfs_cap + seqcap fits: Ctx::team_scratch_bytes) */
         }
         u32 mine = 0;
         for (u32 j = wave_in_team; j < n; j += team_waves) {
@@ -1789,6 +1816,50 @@ template <bool TEAM = false> AVK_DEV int solve_region_tier(const AvkKernelArgs &
         const u32 *w = (const u32 *)(poolA + NODE_HDR);
         const u32 ns0 = ld32u(w + H_NSKIP), ns1 = ld32u((const u32 *)((const u8 *)w + c.hapA_bytes) + H_NSKIP);
         obs_same = ns0 == 0 && ns1 == 0;
+    }
+    if (TEAM && c.team && !obs_same && nopt > 0 && c.memo_cap >= 2) {
+        /* The two genotype searches of the FIRST optimum are independent (one per haplotype, neither has a cutoff yet: best_total is still unset) — 27 of the 89 M
+         * ticks of a 92-call window: two jobs, the owner's in its own phase-B pool, a sibling's in its scratch slice.  Their results go into the memo; the loop below
+         * then finds them there and goes on exactly as if it had run them (a job that failed or outgrew its pool leaves no entry: the loop runs that search itself). */
+        const HapPtr g0 = hap_ptr(poolA + NODE_HDR, c.alw, c.wfcap, c.seqcap), g1 = hap_ptr(poolA + NODE_HDR + c.hapA_bytes, c.alw, c.wfcap, c.seqcap);
+        const HapHdr gh0 = hap_load(g0.w), gh1 = hap_load(g1.w);
+        const bool need0 = !(gh0.ed == 0 && gh0.nskip == 0 && small_n), need1 = !(gh1.ed == 0 && gh1.nskip == 0 && small_n);
+        bool l_diff = false;
+        for (u32 i = lane; i < c.alw; i += 64) l_diff = l_diff || g0.talt[i] != g1.talt[i] || g0.qalt[i] != g1.qalt[i];
+        const bool differ = wv_ballot(l_diff) != 0;
+        const u64 bbytes0 = c.pool_bytes > AVK_ALIGN16(a_bytes) ? c.pool_bytes - AVK_ALIGN16(a_bytes) : 0;
+        u64 cap0 = bbytes0 / c.nodeB_bytes;
+        if (cap0 > c.qcap) cap0 = c.qcap;
+        if (need0 && need1 && differ && cap0 >= 3) {
+            wv_sync();
+            for (u32 i = lane; i < c.alw; i += 64) {
+                c.memo[i] = g0.talt[i], c.memo[c.alw + i] = g0.qalt[i];
+                c.memo[4ull * c.alw + i] = g1.talt[i], c.memo[5ull * c.alw + i] = g1.qalt[i];
+            }
+            wv_sync();
+            if (lane == 0) {
+                TeamBox *tb = c.team;
+                tb->own_poolB = (u64)(poolA + AVK_ALIGN16(a_bytes));
+                for (u32 j = 0; j < 2; ++j) {
+                    TeamJob *jb = tb->job + j;
+                    jb->kind = TJ_GT, jb->flags = 0, jb->depth = jb->allele = 0;
+                    jb->x0 = (u32)cap0;
+                    jb->x1 = (j == 0 || c.team_waves <= 1) ? 1u : 0u; /* (the owner alone: both in its own pool, one after the other) */
+                    jb->src = (u64)(c.memo + (u64)j * 4 * c.alw), jb->dst = 0;
+                }
+            }
+            team_run(c, 2);
+            const int e0 = (int)ld32u((const u32 *)&c.team->job[0].res[0]), e1 = (int)ld32u((const u32 *)&c.team->job[1].res[0]);
+            if (e0 >= 0) {
+                st32(c.memo_err + 0, (u32)e0);
+                n_memo = 1;
+                if (e1 >= 0) {
+                    st32(c.memo_err + 1, (u32)e1);
+                    n_memo = 2;
+                }
+                wv_sync();
+            }
+        }
     }
     for (u32 k = 0; k < (obs_same ? 0u : (u32)nopt); ++k) {
         u32 errs[2] = {0, 0};

@@ -52,3 +52,14 @@ def test_genome_slice_with_its_long_windows_on_teams(oracle):
     for opts in ({}, {"lane_min_regions": 0, "lane_min_batch": 0}):
         got, _ = solve(contigs, batch, opts, gm=False)
         assert got.diff(want) == []
+
+
+def test_team_regions_in_the_shared_big_slices(oracle):
+    """per-wave slices too small for the head of the class: its regions are solved again in the shared big slices — another allocation, any distance from the sibling
+    waves' own slices, where the genotype search dealt to a sibling keeps its nodes (hap_extend_seq once addressed everything by 32-bit offsets from the region's workspace)"""
+    contig, bed, truth, query = synth.contig_calls(5, 3_000_000, 3_800 / 3_000_000, seed_ref=905, seed_query=906, str_frac=0.15, multi_frac=0.05)
+    batch = synth.cluster_regions_v(contig, bed, truth, query, 1000)
+    want = oracle_lib.compare_batch(oracle, batch, [contig], threads=CPUS, group_metrics=True)
+    got, tiers = solve([contig], batch, {"adaptive_ws": 0, "ws_bytes_per_wave": 1 << 18, "big_ws_bytes": 64 << 20, "team_head_regions": 64})
+    assert got.diff(want) == []
+    assert tiers[3] > 0, tiers  # (some regions did outgrow their slices)
