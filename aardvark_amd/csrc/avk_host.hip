@@ -1611,6 +1611,15 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
             if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
+            if (hbm_solo && use_wide && db->plan.n_hbm_notwide && !db->notwide_ready) {
+                /* the list of the class C records that are not avk_wide.inl's: once per batch, and the FIRST thing queued behind the fork — made behind the class's
+                 * wide launch its 20-170 workgroups waited for a place among the step's persistent waves (0.2 ms in a queued shard step, 1.2 ms in a merge call) */
+                AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
+                AVK_HIP(ctx, hipMemsetAsync(db->d_notwide + n + 1, 0, sizeof(uint32_t), ctx->wide_stream));
+                hipLaunchKernelGGL(avk_notwide_list_kernel, dim3((n_c + 255u) / 256u), dim3(256), 0, ctx->wide_stream, db->d_regions, n_c, db->d_notwide, db->d_notwide + n + 1);
+                AVK_HIP(ctx, hipGetLastError());
+                db->notwide_ready = true;
+            }
             bool wide_c = false, wide_x = false;
             if (hbm_solo) {
                 AvkKernelArgs s = a;
@@ -1627,7 +1636,11 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                     w.work_counter = db->d_counters + 1240;
                     w.overflow_list = db->d_overflow5;
                     w.overflow_count = db->d_counters + 1244;
-                    uint32_t wg = n_c < (uint32_t)ctx->wide_blocks ? n_c : (uint32_t)ctx->wide_blocks;
+                    /* (512 one-wave workgroups for a genome's 6,000-15,000 records; a merge job's 42,000 lasted 7.2 ms on them, the longest launch of its step: one
+                     * workgroup per 32 records up to four times as many — profiles/r06_merge_step.txt) */
+                    uint32_t wb = (uint32_t)ctx->wide_blocks;
+                    if (!getenv("AVK_WIDE_BLOCKS") && n_c / 32u > wb) wb = n_c / 32u < 4u * wb ? n_c / 32u : 4u * wb;
+                    uint32_t wg = n_c < wb ? n_c : wb;
                     /* workgroups of the launch for the records that are not the wide kernel's: slices from the END of the solo launch's share, which keeps at least half of
                      * it — a batch with large per-wave slices (adaptive_ws under its budget) may have a share of eight workgroups, and the two launches must never meet on
                      * a slice (they did: xb == hbm_solo_max left the solo launch one workgroup ON the other's first slices — wrong results in a fuzz case where every
@@ -1670,13 +1683,6 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
                         x.overflow_list = nullptr;
                         x.overflow_count = nullptr;
                         AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
-                        if (!db->notwide_ready) { /* once per batch, at the head of its first step (made in every step, the list's 20 workgroups once waited 0.2 ms for
-                                                     a place among the persistent waves of the steps queued before) */
-                            AVK_HIP(ctx, hipMemsetAsync(db->d_notwide + n + 1, 0, sizeof(uint32_t), ctx->wide_stream));
-                            hipLaunchKernelGGL(avk_notwide_list_kernel, dim3((n_c + 255u) / 256u), dim3(256), 0, ctx->wide_stream, db->d_regions, n_c, db->d_notwide, db->d_notwide + n + 1);
-                            AVK_HIP(ctx, hipGetLastError());
-                            db->notwide_ready = true;
-                        }
                         /* (a wave per region here: these long windows hold a handful of calls, their searches are short chains where a team's hand-overs cost more
                          * than its parallel pieces give — shard 1.19 -> 1.31 ms, dense mix 2.29 -> 2.53 with teams, profiles/r06_team.txt) */
                         hipLaunchKernelGGL(avk_region_kernel_hbm, dim3(xb), dim3(256), 0, ctx->wide_stream, x);
