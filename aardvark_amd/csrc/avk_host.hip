@@ -1611,7 +1611,7 @@ static int run_internal(avk_ctx *ctx, avk_dev_batch *db, const avk_compare_confi
             const int solo_list = launch[1] ? 1 : 0; /* the list the first HBM launch reads */
             const bool later = last > solo_list;
             if (solo || hbm_solo) AVK_HIP(ctx, hipEventRecord(ctx->ev_fork, ctx->stream)); /* after the memsets */
-            if (hbm_solo && use_wide && db->plan.n_hbm_notwide && !db->notwide_ready) {
+            if (hbm_solo && use_wide && db->plan.n_hbm_notwide && 2u * (db->plan.n_hbm_notwide < n_c ? db->plan.n_hbm_notwide : n_c) <= n_c && !db->notwide_ready) { /* (only the class's wide launch with its companion reads the list) */
                 /* the list of the class C records that are not avk_wide.inl's: once per batch, and the FIRST thing queued behind the fork — made behind the class's
                  * wide launch its 20-170 workgroups waited for a place among the step's persistent waves (0.2 ms in a queued shard step, 1.2 ms in a merge call) */
                 AVK_HIP(ctx, hipStreamWaitEvent(ctx->wide_stream, ctx->ev_fork, 0));
